@@ -1,0 +1,164 @@
+/*
+ * aslp_kernels.h -- kernel-level C ABI of libaslp_hip.so (boundary B1 + B2 of SURVEY.md §8b).
+ *
+ * Every entry point keeps the name and argument order of the reference wrapper it
+ * replaces in src/aslp-cudamatrix/cu-kernels-ansi.h (line cited per function), so a
+ * maintainer can relink the reference's CuMatrix against this library for the hot-path
+ * subset.  Differences, all deliberate:
+ *   - `Gr`/`Bl` (CUDA launch geometry) are accepted and ignored: the library chooses its
+ *     own CDNA4 geometry (64-wide wavefronts, 16-byte lanes).  Exception:
+ *     cudaF_add_conv_mat_mat_elements reads Bl.y because the reference encodes the
+ *     filter length there (cu-matrix.cc:3052-3056).
+ *   - kernels are enqueued on the stream set with aslp_set_stream() (default: the null
+ *     stream, like the reference); they are asynchronous.  Errors are sticky and read
+ *     with aslp_get_last_error() (the reference wraps cudaGetLastError in CU_SAFE_CALL).
+ *   - all pointers are DEVICE pointers unless the parameter is named *_host.
+ * Matrices are row-major fp32, `MatrixDim{rows, cols, stride}`; "rows = frames".
+ */
+#ifndef ASLP_KERNELS_H_
+#define ASLP_KERNELS_H_
+#include "aslp_matrixdim.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- runtime plumbing (replaces CuDevice, cu-device.h:43-151) --------------------- */
+void aslp_set_stream(void *hip_stream);          /* per host thread */
+void *aslp_get_stream(void);
+int aslp_get_last_error(char *buf, int buflen);  /* 0 = no error; clears it */
+int aslp_device_sync(void);
+const char *aslp_version(void);
+
+/* ---- elementwise (cu-kernels-ansi.h line in brackets) ------------------------------ */
+void cudaF_set_const(aslp_dim3 Gr, aslp_dim3 Bl, float *mat, float value, MatrixDim d);              /* [76]  */
+void cudaF_add(aslp_dim3 Gr, aslp_dim3 Bl, float *mat, float value, MatrixDim d);                    /* [78]  */
+void cudaF_scale(aslp_dim3 Gr, aslp_dim3 Bl, float *mat, float value, MatrixDim d);                  /* [81]  */
+void cudaF_apply_log(aslp_dim3 Gr, aslp_dim3 Bl, float *mat, MatrixDim d);                           /* [82]  */
+void cudaF_apply_exp(aslp_dim3 Gr, aslp_dim3 Bl, float *mat, MatrixDim d);                           /* [59]  */
+void cudaF_apply_pow(aslp_dim3 Gr, aslp_dim3 Bl, float *mat, float power, MatrixDim d);              /* [60]  */
+void cudaF_apply_heaviside(aslp_dim3 Gr, aslp_dim3 Bl, float *mat, MatrixDim d);                     /* [62]  */
+void cudaF_apply_floor(aslp_dim3 Gr, aslp_dim3 Bl, float *mat, float floor_val, MatrixDim d);        /* [63]  */
+void cudaF_apply_ceiling(aslp_dim3 Gr, aslp_dim3 Bl, float *mat, float ceiling_val, MatrixDim d);    /* [72]  */
+void cudaF_invert_elements(aslp_dim3 Gr, aslp_dim3 Bl, float *data, MatrixDim d);                    /* [130] */
+void cudaF_mul_elements(aslp_dim3 Gr, aslp_dim3 Bl, float *mat, const float *A, MatrixDim dst_d, int src_stride);  /* [83] */
+void cudaF_mul_cols_vec(aslp_dim3 Gr, aslp_dim3 Bl, float *mat, const float *scale, MatrixDim d);    /* [86] mat[r][c] *= scale[c] */
+void cudaF_mul_rows_vec(aslp_dim3 Gr, aslp_dim3 Bl, float *mat, const float *scale, MatrixDim d);    /* [87] mat[r][c] *= scale[r] */
+void cudaF_add_mat(aslp_dim3 Gr, aslp_dim3 Bl, float alpha, const float *src, float *dst, MatrixDim d, int src_stride, int A_trans); /* [92] dst += alpha*src */
+void cudaF_add_vec_to_cols(aslp_dim3 Gr, aslp_dim3 Bl, float alpha, const float *col, float beta, float *dst, MatrixDim d);          /* [95] */
+void cudaF_add_vec_to_rows(aslp_dim3 Gr, aslp_dim3 Bl, float alpha, const float *row, float beta, float *dst, MatrixDim d);          /* [96] */
+void cudaF_add_mat_diag_vec(aslp_dim3 Gr, aslp_dim3 Bl, float alpha, float *mat, MatrixDim mat_dim, const float *mat2,
+                            int mat2_row_stride, int mat2_col_stride, const float *vec, float beta);                                 /* [97] */
+void cudaF_add_mat_mat_elements(aslp_dim3 Gr, aslp_dim3 Bl, float *data, const float *srcA_data, const float *srcB_data,
+                                MatrixDim dim, int srcA_stride, int srcB_stride, float alpha, float beta);                           /* [98] */
+void cudaF_add_row_sum_mat(aslp_dim3 Gr, aslp_dim3 Bl, float *data, const float *src_data, MatrixDim dim, int src_stride,
+                           int patch_nrows, float alpha, float beta);                                                                /* [99]  ASLP */
+void cudaF_add_conv_mat_mat_elements(aslp_dim3 Gr, aslp_dim3 Bl, float *data, const float *srcA_data, const float *srcB_data,
+                                     MatrixDim dim, int srcA_stride, int srcB_stride, float alpha, float beta);                      /* [100] ASLP */
+void cudaF_sigmoid(aslp_dim3 Gr, aslp_dim3 Bl, float *y, const float *x, MatrixDim d, int src_stride);                               /* [148] */
+void cudaF_diff_sigmoid(aslp_dim3 Gr, aslp_dim3 Bl, float *eout, const float *e, const float *y, MatrixDim d, int e_stride, int y_stride); /* [149] */
+void cudaF_tanh(aslp_dim3 Gr, aslp_dim3 Bl, float *y, const float *x, MatrixDim d, int src_stride);                                  /* [150] */
+void cudaF_diff_tanh(aslp_dim3 Gr, aslp_dim3 Bl, float *eout, const float *e, const float *y, MatrixDim d, int e_stride, int y_stride);    /* [151] */
+void cudaF_regularize_l1(aslp_dim3 Gr, aslp_dim3 Bl, float *wei, float *grad, float l1, float lr, MatrixDim d, int stride_grad);     /* [153] */
+
+/* ---- index / gather ops (bit-exact) ------------------------------------------------ */
+void cudaF_copy_cols(aslp_dim3 Gr, aslp_dim3 Bl, float *dst, const float *src, const MatrixIndexT_cuda *reorder, MatrixDim dst_dim, int src_stride); /* [64] */
+void cudaF_add_cols(aslp_dim3 Gr, aslp_dim3 Bl, float *dst, const float *src, const MatrixIndexT_cuda *reorder, MatrixDim dst_dim, int src_stride);  /* [65] */
+void cudaF_copy_rows(aslp_dim3 Gr, aslp_dim3 Bl, float *dst, const float *src, const MatrixIndexT_cuda *reorder, MatrixDim dst_dim, int src_stride); /* [66] */
+void cudaF_add_rows(aslp_dim3 Gr, aslp_dim3 Bl, float alpha, float *dst, const float *src, const MatrixIndexT_cuda *reorder, MatrixDim dst_dim, int src_stride); /* [69] */
+void cudaF_randomize(aslp_dim3 Gr, aslp_dim3 Bl, float *y, const float *x, const int32_cuda *copy_from, MatrixDim d_out, MatrixDim d_in); /* [158] */
+void cudaF_splice(aslp_dim3 Gr, aslp_dim3 Bl, float *y, const float *x, const int32_cuda *off, MatrixDim d_out, MatrixDim d_in);          /* [159] */
+void cudaF_copy(aslp_dim3 Gr, aslp_dim3 Bl, float *y, const float *x, const int32_cuda *copy_from, MatrixDim d_out, MatrixDim d_in);      /* [161] */
+void cudaI32_set_const(aslp_dim3 Gr, aslp_dim3 Bl, int32_cuda *mat, int32_cuda value, MatrixDim d);                                       /* [37]  */
+
+/* ---- reductions ---------------------------------------------------------------------- */
+void cudaF_softmax_reduce(size_t Gr, size_t Bl, float *y, const float *x, MatrixDim d, int src_stride);        /* [143] */
+void cudaF_log_softmax_reduce(size_t Gr, size_t Bl, float *y, const float *x, MatrixDim d, int src_stride);    /* [144] */
+/* [154] processes the Bl.x columns starting at `mat` (column offset `voff`), keeping the running
+ * row maximum in vec_val / vec_id exactly like the reference's per-256-column calls. */
+void cudaF_find_row_max_id(aslp_dim3 Gr, aslp_dim3 Bl, const float *mat, float *vec_val, int32_cuda *vec_id, int32_cuda voff, MatrixDim d);
+void cudaF_diff_xent(aslp_dim3 Gr, aslp_dim3 Bl, const int32_cuda *vec_tgt, float *mat_net_out, float *vec_log_post, MatrixDim d);       /* [155] */
+/* [115] v = alpha * diag(op(M) * op(N)) + beta * v  (peephole gradients) */
+void cudaF_add_diag_mat_mat(int Gr, int Bl, float alpha, float *v, int v_dim, const float *M, int M_cols, int M_row_stride,
+                            int M_col_stride, const float *N, int N_row_stride, int N_col_stride, int threads_per_element, float beta);
+void cudaF_add_vec_vec(int Gr, int Bl, float alpha, float *v, const float *x, const float *y, float beta, int dim);                     /* [118] ASLP */
+void cudaF_vec_sum(int Gr, int Bl, float *v, float *value, int dim, int inc);                                                           /* [122] */
+
+/* Library-native whole-op forms used by the host engine (no reference twin: the reference
+ * builds these from cuBLAS gemv with a ones-vector, cu-vector.cc:1145-1166). */
+/* v[c] = alpha * sum_r M[r][c] + beta * v[c]      (CuVectorBase::AddRowSumMat) */
+void aslp_add_row_sum_mat_vec(float alpha, const float *M, MatrixDim d, float beta, float *v);
+/* v[r] = alpha * sum_c M[r][c] + beta * v[r]      (CuVectorBase::AddColSumMat) */
+void aslp_add_col_sum_mat_vec(float alpha, const float *M, MatrixDim d, float beta, float *v);
+/* whole-row argmax, first strict maximum (CuMatrixBase::FindRowMaxId, cu-matrix.cc:1466) */
+void aslp_find_row_max_id(const float *M, MatrixDim d, int32_cuda *id);
+/* sum of all elements -> *out_dev (double, one value)  (CuMatrixBase::Sum) */
+void aslp_matrix_sum(const float *M, MatrixDim d, double *out_dev);
+void aslp_copy_mat(float *dst, MatrixDim d, const float *src, int src_stride);
+void aslp_vec_axpy(float alpha, const float *x, float *y, int dim);           /* y += alpha x */
+void aslp_f2d(double *dst, const float *src, int n);
+void aslp_d2f(float *dst, const double *src, int n);
+
+/* ---- B2: BLAS seam (cublas-wrappers.h:28-47, call site cu-matrix.cc:1027-1061) ------ */
+/* Row-major C[M x N] = alpha * op(A) * op(B) + beta * C with fp32 MFMA; transX: 0 = kNoTrans,
+ * 1 = kTrans (MatrixTransposeType).  A is [M x K] (or [K x M] if transA), B is [K x N] (or
+ * [N x K] if transB).  Returns 0 or a negative argument-error code. */
+int aslp_sgemm(int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda,
+               const float *B, int ldb, float beta, float *C, int ldc);
+/* Fused epilogue form.  Applied in this order on the fp32 accumulator `acc`:
+ *   v = alpha*acc + beta*C;  if (bias) v += bias[col];  if (clip > 0) v = clamp(v, -clip, clip);
+ *   C = v;  if (W) W[row][col] += w_alpha * v  (SGD: w_alpha = -lr);
+ *   if (act_out) act_out[row][col] = act(v)  with act: 1 sigmoid, 2 tanh, 3 relu. */
+typedef struct aslp_gemm_epilogue_ {
+  const float *bias;   /* [N] or NULL */
+  float clip;          /* <= 0: off */
+  float *W;            /* same shape as C, or NULL */
+  int ldw;
+  float w_alpha;
+  float *act_out;      /* or NULL */
+  int ld_act;
+  int act;
+} aslp_gemm_epilogue;
+int aslp_sgemm_ex(int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda,
+                  const float *B, int ldb, float beta, float *C, int ldc, const aslp_gemm_epilogue *ep);
+/* GEMM launch statistics for bench.py's roofline: per variant launches / flops / (if
+ * profiling was enabled with aslp_gemm_profile(1)) event-timed milliseconds. */
+void aslp_gemm_profile(int enable);
+void aslp_gemm_profile_reset(void);
+/* variant: 0 = NT, 1 = NN, 2 = TN, 3 = TT.  Returns number of launches. */
+long aslp_gemm_profile_get(int variant, double *flops, double *ms);
+
+/* ---- fused hot-path ops (one pass each; see DESIGN.md for bytes/unit) ----------------- */
+/* BatchNormalization training forward (nnet-batch-normalization.h:177-220): writes out,
+ * xhat (XsharpO_), mean[D], inv_std[D] ("var_vec_"), and adds the batch sums to the double
+ * running statistics acc_means/acc_vars (may be NULL). */
+void aslp_bn_forward(const float *in, MatrixDim d, float *out, int out_stride, float *xhat, int xhat_stride,
+                     const float *scale, const float *shift, float *mean, float *inv_std,
+                     double *acc_means, double *acc_vars, float var_floor);
+/* BatchNormalization backward (same file :222-277): dscale = sum(xhat*dy) + mmt*dscale,
+ * dshift = sum(dy) + mmt*dshift, in_diff as the reference's 4 steps; xhat is overwritten
+ * with dy*scale like the reference (XsharpO_). in_diff may be NULL. */
+void aslp_bn_backward(const float *in, MatrixDim d, const float *out_diff, int od_stride, float *xhat, int xhat_stride,
+                      const float *scale, const float *mean, const float *inv_std, float *dscale, float *dshift,
+                      float momentum, float *in_diff, int id_stride);
+/* inference with given mean / inv_std (same file :166-173) */
+void aslp_bn_apply(const float *in, MatrixDim d, float *out, int out_stride, const float *mean, const float *inv_std,
+                   const float *scale, const float *shift);
+/* Xent::Eval (nnet-loss.cc:63-122) in one pass over [rows x cols]:
+ * diff = (y - t) * w_row with w_row = frame_weight * sum_c t;  stats_dev[0..4] (double) +=
+ * {frames, correct, -sum w t log(y+1e-20), -sum w t log(t+1e-20), sum w t y}.
+ * Dense targets (tgt != NULL) or one label per row (labels != NULL: one-hot posterior). */
+void aslp_xent_eval(const float *net_out, MatrixDim d, const float *tgt, int tgt_stride, const int32_cuda *labels,
+                    const float *frame_weights, float *diff, int diff_stride, double *stats_dev);
+/* PosteriorToMatrix scatter: mat[row[i]][col[i]] += val[i]  (hmm/posterior.cc, used nnet-loss.cc:168) */
+void aslp_scatter_add(float *mat, MatrixDim d, const int32_cuda *rows, const int32_cuda *cols, const float *vals, int n);
+/* Splice backward (nnet-various.h:143-175): in_diff[t] = sum_k out_diff[clamp(t+off[k])][k-th block] */
+void aslp_splice_backward(float *in_diff, MatrixDim d_in, const float *out_diff, int od_stride, const int32_cuda *off, int n_off);
+/* ReLU backward: in_diff = heaviside(in) * out_diff (nnet-activation.h:292-297) */
+void aslp_diff_relu(float *in_diff, const float *in, const float *out_diff, MatrixDim d, int in_stride, int od_stride);
+/* max-norm row shrink (nnet-affine-transform.h:231-243) */
+void aslp_max_norm_rows(float *W, MatrixDim d, float max_norm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,413 @@
+// ew_kernels.hip -- elementwise + gather kernels of the CuMatrix substrate for gfx950.
+//
+// All of these are HBM-bound: one read + one write per
+// element.  Layout rule: a lane moves 16 bytes (float4) whenever pointers and strides are
+// 16-byte aligned, a wave therefore covers 1 KiB of one row per instruction; otherwise a
+// scalar path with the same indexing.  Grids are capped at 256 CUs x 8 blocks and
+// grid-strided.  Reference twins are cited by cu-kernels.cu line.
+#include "aslp_kernels.h"
+#include "common.h"
+
+namespace aslp {
+namespace {
+
+// dst[r][c] = f(dst[r][c], a[r][c], b[r][c], r, c)
+template <class F>
+__global__ void __launch_bounds__(kBlock) map_scalar(float *dst, int ldd, const float *a, int lda, const float *b,
+                                                     int ldb, int rows, int cols, F f) {
+  long n = (long)rows * cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int r = (int)(i / cols), c = (int)(i - (long)r * cols);
+    float d = dst[(long)r * ldd + c];
+    float av = a ? a[(long)r * lda + c] : 0.0f;
+    float bv = b ? b[(long)r * ldb + c] : 0.0f;
+    dst[(long)r * ldd + c] = f(d, av, bv, r, c);
+  }
+}
+
+template <class F, bool READ_DST>
+__global__ void __launch_bounds__(kBlock) map_vec4(float *dst, int ldd, const float *a, int lda, const float *b,
+                                                   int ldb, int rows, int cols4, F f) {
+  long n = (long)rows * cols4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int r = (int)(i / cols4), c = (int)(i - (long)r * cols4) * 4;
+    float4 d = READ_DST ? *reinterpret_cast<const float4 *>(dst + (long)r * ldd + c) : make_float4(0, 0, 0, 0);
+    float4 av = a ? *reinterpret_cast<const float4 *>(a + (long)r * lda + c) : make_float4(0, 0, 0, 0);
+    float4 bv = b ? *reinterpret_cast<const float4 *>(b + (long)r * ldb + c) : make_float4(0, 0, 0, 0);
+    float4 o;
+    o.x = f(d.x, av.x, bv.x, r, c);
+    o.y = f(d.y, av.y, bv.y, r, c + 1);
+    o.z = f(d.z, av.z, bv.z, r, c + 2);
+    o.w = f(d.w, av.w, bv.w, r, c + 3);
+    *reinterpret_cast<float4 *>(dst + (long)r * ldd + c) = o;
+  }
+}
+
+template <bool READ_DST, class F>
+void launch_map(const char *name, float *dst, MatrixDim d, const float *a, int lda, const float *b, int ldb, F f) {
+  if (d.rows <= 0 || d.cols <= 0) return;
+  bool vec = (d.cols % 4 == 0) && (d.stride % 4 == 0) && aligned16(dst) && (!a || (lda % 4 == 0 && aligned16(a))) &&
+             (!b || (ldb % 4 == 0 && aligned16(b)));
+  if (vec) {
+    long n = (long)d.rows * (d.cols / 4);
+    hipLaunchKernelGGL((map_vec4<F, READ_DST>), dim3(grid_for(n)), dim3(kBlock), 0, cur_stream(), dst, d.stride, a,
+                       lda, b, ldb, d.rows, d.cols / 4, f);
+  } else {
+    long n = (long)d.rows * d.cols;
+    hipLaunchKernelGGL((map_scalar<F>), dim3(grid_for(n)), dim3(kBlock), 0, cur_stream(), dst, d.stride, a, lda, b,
+                       ldb, d.rows, d.cols, f);
+  }
+  check_launch(name);
+}
+
+// ---- functors ------------------------------------------------------------------------
+struct SetConst { float v; __device__ float operator()(float, float, float, int, int) const { return v; } };
+struct AddConst { float v; __device__ float operator()(float d, float, float, int, int) const { return d + v; } };
+struct Scale { float v; __device__ float operator()(float d, float, float, int, int) const { return d * v; } };
+struct Log { __device__ float operator()(float d, float, float, int, int) const { return logf(d); } };
+struct Exp { __device__ float operator()(float d, float, float, int, int) const { return expf(d); } };
+struct Pow {  // cu-kernels.cu:1287 _apply_pow: 2 -> square, 0.5 -> sqrt (neg checked by caller), else pow
+  float p;
+  __device__ float operator()(float d, float, float, int, int) const {
+    if (p == 1.0f) return d;
+    if (p == 2.0f) return d * d;
+    if (p == 0.5f) return sqrtf(d);
+    return powf(d, p);
+  }
+};
+struct Heaviside { __device__ float operator()(float d, float, float, int, int) const { return d > 0.0f ? 1.0f : 0.0f; } };
+struct Floor { float v; __device__ float operator()(float d, float, float, int, int) const { return d < v ? v : d; } };
+struct Ceil { float v; __device__ float operator()(float d, float, float, int, int) const { return d > v ? v : d; } };
+struct Invert { __device__ float operator()(float d, float, float, int, int) const { return 1.0f / d; } };
+struct MulElem { __device__ float operator()(float d, float a, float, int, int) const { return d * a; } };
+struct MulColsVec { const float *s; __device__ float operator()(float d, float, float, int, int c) const { return d * s[c]; } };
+struct MulRowsVec { const float *s; __device__ float operator()(float d, float, float, int r, int) const { return d * s[r]; } };
+struct AddMat { float alpha; __device__ float operator()(float d, float a, float, int, int) const { return alpha * a + d; } };
+struct AddVecToCols { float alpha, beta; const float *v; __device__ float operator()(float d, float, float, int r, int) const { return alpha * v[r] + beta * d; } };
+struct AddVecToRows { float alpha, beta; const float *v; __device__ float operator()(float d, float, float, int, int c) const { return alpha * v[c] + beta * d; } };
+struct AddVecToRows0 { float alpha; const float *v; __device__ float operator()(float, float, float, int, int c) const { return alpha * v[c]; } };
+struct AddMatDiagVec { float alpha, beta; const float *v; __device__ float operator()(float d, float a, float, int, int c) const { return alpha * a * v[c] + beta * d; } };
+struct AddMatMatElem { float alpha, beta; __device__ float operator()(float d, float a, float b, int, int) const { return alpha * a * b + beta * d; } };
+struct AddMatMatElem0 { float alpha; __device__ float operator()(float, float a, float b, int, int) const { return alpha * a * b; } };
+struct Sigmoid { __device__ float operator()(float, float a, float, int, int) const { return sigmoid_ref(a); } };
+struct Tanh { __device__ float operator()(float, float a, float, int, int) const { return tanh_ref(a); } };
+// matrix/kaldi-matrix.cc:2713-2744
+struct DiffSigmoid { __device__ float operator()(float, float e, float y, int, int) const { return e * y * (1.0f - y); } };
+struct DiffTanh { __device__ float operator()(float, float e, float y, int, int) const { return e * (1.0f - y * y); } };
+struct DiffRelu { __device__ float operator()(float, float in, float od, int, int) const { return in > 0.0f ? od : 0.0f; } };
+struct CopyMat { __device__ float operator()(float, float a, float, int, int) const { return a; } };
+
+// transposed AddMat (rare; cu-kernels.cu:584 A_trans branch)
+__global__ void add_mat_trans_kernel(float alpha, const float *src, float *dst, MatrixDim d, int src_stride) {
+  long n = (long)d.rows * d.cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int r = (int)(i / d.cols), c = (int)(i % d.cols);
+    dst[(long)r * d.stride + c] += alpha * src[(long)c * src_stride + r];
+  }
+}
+
+// _add_mat_diag_vec with a transposed mat2 (generic strides)
+__global__ void add_mat_diag_vec_strided(float alpha, float *mat, MatrixDim d, const float *mat2, int rs, int cs,
+                                         const float *vec, float beta) {
+  long n = (long)d.rows * d.cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int r = (int)(i / d.cols), c = (int)(i % d.cols);
+    mat[(long)r * d.stride + c] = alpha * mat2[(long)r * rs + (long)c * cs] * vec[c] + beta * mat[(long)r * d.stride + c];
+  }
+}
+
+// cu-math.cc:37-75 / cu-kernels.cu:2113 _regularize_l1
+__global__ void regularize_l1_kernel(float *wei, float *grad, float l1, float lr, MatrixDim d, int stride_grad) {
+  long n = (long)d.rows * d.cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int r = (int)(i / d.cols), c = (int)(i % d.cols);
+    long wi = (long)r * d.stride + c, gi = (long)r * stride_grad + c;
+    float w = wei[wi];
+    if (w == 0.0f) continue;
+    float l1_signed = w < 0.0f ? -l1 : l1;
+    float after = w - lr * grad[gi] - l1_signed;
+    if ((after > 0.0f) ^ (w > 0.0f)) {
+      wei[wi] = 0.0f;
+      grad[gi] = 0.0f;
+    } else {
+      wei[wi] = w - l1_signed;
+    }
+  }
+}
+
+// ---- gathers (bit-exact copies) -------------------------------------------------------
+// Row gather: dst[r][:] = src[idx[r]][:] (idx < 0 -> zeros, cu-kernels.cu:1413 _copy_rows), optionally
+// accumulate (cu-kernels.cu:1462 _add_rows).  One float4 per lane when aligned.
+template <bool ADD, bool VEC>
+__global__ void __launch_bounds__(kBlock) row_gather(float alpha, float *dst, const float *src, const int32_t *idx, int rows,
+                                                     int cols, int ldd, int lds) {
+  constexpr int W = VEC ? 4 : 1;
+  int cw = cols / W;
+  long n = (long)rows * cw;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int r = (int)(i / cw), c = (int)(i - (long)r * cw) * W;
+    int sr = idx[r];
+    if (VEC) {
+      float4 v = sr < 0 ? make_float4(0, 0, 0, 0) : *reinterpret_cast<const float4 *>(src + (long)sr * lds + c);
+      float4 *dp = reinterpret_cast<float4 *>(dst + (long)r * ldd + c);
+      if (ADD) {
+        float4 o = *dp;
+        o.x += alpha * v.x; o.y += alpha * v.y; o.z += alpha * v.z; o.w += alpha * v.w;
+        *dp = o;
+      } else {
+        *dp = v;
+      }
+    } else {
+      float v = sr < 0 ? 0.0f : src[(long)sr * lds + c];
+      if (ADD) dst[(long)r * ldd + c] += alpha * v; else dst[(long)r * ldd + c] = v;
+    }
+  }
+}
+
+template <bool ADD>
+void launch_row_gather(const char *name, float alpha, float *dst, const float *src, const int32_t *idx, int rows, int cols,
+                       int ldd, int lds) {
+  if (rows <= 0 || cols <= 0) return;
+  bool vec = cols % 4 == 0 && ldd % 4 == 0 && lds % 4 == 0 && aligned16(dst) && aligned16(src);
+  long n = (long)rows * (vec ? cols / 4 : cols);
+  if (vec)
+    hipLaunchKernelGGL((row_gather<ADD, true>), dim3(grid_for(n)), dim3(kBlock), 0, cur_stream(), alpha, dst, src, idx,
+                       rows, cols, ldd, lds);
+  else
+    hipLaunchKernelGGL((row_gather<ADD, false>), dim3(grid_for(n)), dim3(kBlock), 0, cur_stream(), alpha, dst, src, idx,
+                       rows, cols, ldd, lds);
+  check_launch(name);
+}
+
+// Column gather: dst[r][c] = src[r][reorder[c]] (reorder < 0 -> 0; cu-kernels.cu:1373/1394, 2075 _copy)
+template <bool ADD>
+__global__ void __launch_bounds__(kBlock) col_gather(float *dst, const float *src, const int32_t *reorder, int rows, int cols,
+                                                     int ldd, int lds) {
+  long n = (long)rows * cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int r = (int)(i / cols), c = (int)(i - (long)r * cols);
+    int sc = reorder[c];
+    float v = sc < 0 ? 0.0f : src[(long)r * lds + sc];
+    if (ADD) dst[(long)r * ldd + c] += v; else dst[(long)r * ldd + c] = v;
+  }
+}
+
+// Splice (cu-kernels.cu:1998 _splice): y[r][k*D + c] = x[clamp(r + off[k], 0, R-1)][c].
+// One work item = one float4 (or one float) of the OUTPUT row, so writes are fully coalesced
+// and each input row segment is re-read from L2 by the n_off consumers.
+template <bool VEC>
+__global__ void __launch_bounds__(kBlock) splice_kernel(float *y, const float *x, const int32_t *off, int rows, int out_cols,
+                                                        int in_cols, int ldy, int ldx) {
+  constexpr int W = VEC ? 4 : 1;
+  int cw = out_cols / W;
+  long n = (long)rows * cw;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int r = (int)(i / cw), oc = (int)(i - (long)r * cw) * W;
+    int k = oc / in_cols, c = oc - k * in_cols;
+    int sr = r + off[k];
+    sr = sr < 0 ? 0 : (sr >= rows ? rows - 1 : sr);
+    if (VEC)
+      *reinterpret_cast<float4 *>(y + (long)r * ldy + oc) = *reinterpret_cast<const float4 *>(x + (long)sr * ldx + c);
+    else
+      y[(long)r * ldy + oc] = x[(long)sr * ldx + c];
+  }
+}
+
+// Splice backward as the reference computes it (nnet-various.h:143-175).
+template <bool VEC>
+__global__ void __launch_bounds__(kBlock) splice_bwd_kernel(float *in_diff, const float *od, const int32_t *off, int n_off,
+                                                            int rows, int in_cols, int ldi, int ldo) {
+  constexpr int W = VEC ? 4 : 1;
+  int cw = in_cols / W;
+  long n = (long)rows * cw;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int t = (int)(i / cw), c = (int)(i - (long)t * cw) * W;
+    float4 acc = make_float4(0, 0, 0, 0);
+    for (int k = 0; k < n_off; k++) {
+      int sr = t + off[k];
+      sr = sr < 0 ? 0 : (sr >= rows ? rows - 1 : sr);
+      const float *p = od + (long)sr * ldo + (long)k * in_cols + c;
+      if (VEC) {
+        float4 v = *reinterpret_cast<const float4 *>(p);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      } else {
+        acc.x += *p;
+      }
+    }
+    if (VEC) *reinterpret_cast<float4 *>(in_diff + (long)t * ldi + c) = acc;
+    else in_diff[(long)t * ldi + c] = acc.x;
+  }
+}
+
+__global__ void set_const_i32(int32_t *mat, int32_t value, MatrixDim d) {
+  long n = (long)d.rows * d.cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    mat[(i / d.cols) * d.stride + i % d.cols] = value;
+}
+
+__global__ void scatter_add_kernel(float *mat, MatrixDim d, const int32_t *rows, const int32_t *cols, const float *vals, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    int r = rows[i], c = cols[i];
+    if (r >= 0 && r < d.rows && c >= 0 && c < d.cols) atomicAdd(mat + (long)r * d.stride + c, vals[i]);
+  }
+}
+
+__global__ void f2d_kernel(double *dst, const float *src, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = (double)src[i];
+}
+__global__ void d2f_kernel(float *dst, const double *src, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = (float)src[i];
+}
+__global__ void add_vec_vec_kernel(float alpha, float *v, const float *x, const float *y, float beta, int dim) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < dim; i += gridDim.x * blockDim.x)
+    v[i] = alpha * x[i] * y[i] + beta * v[i];
+}
+__global__ void axpy_kernel(float alpha, const float *x, float *y, int dim) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < dim; i += gridDim.x * blockDim.x) y[i] += alpha * x[i];
+}
+
+}  // namespace
+}  // namespace aslp
+
+using namespace aslp;
+
+extern "C" {
+
+void cudaF_set_const(aslp_dim3, aslp_dim3, float *mat, float value, MatrixDim d) { launch_map<false>("set_const", mat, d, nullptr, 0, nullptr, 0, SetConst{value}); }
+void cudaF_add(aslp_dim3, aslp_dim3, float *mat, float value, MatrixDim d) { launch_map<true>("add", mat, d, nullptr, 0, nullptr, 0, AddConst{value}); }
+void cudaF_scale(aslp_dim3, aslp_dim3, float *mat, float value, MatrixDim d) { launch_map<true>("scale", mat, d, nullptr, 0, nullptr, 0, Scale{value}); }
+void cudaF_apply_log(aslp_dim3, aslp_dim3, float *mat, MatrixDim d) { launch_map<true>("apply_log", mat, d, nullptr, 0, nullptr, 0, Log{}); }
+void cudaF_apply_exp(aslp_dim3, aslp_dim3, float *mat, MatrixDim d) { launch_map<true>("apply_exp", mat, d, nullptr, 0, nullptr, 0, Exp{}); }
+void cudaF_apply_pow(aslp_dim3, aslp_dim3, float *mat, float power, MatrixDim d) { launch_map<true>("apply_pow", mat, d, nullptr, 0, nullptr, 0, Pow{power}); }
+void cudaF_apply_heaviside(aslp_dim3, aslp_dim3, float *mat, MatrixDim d) { launch_map<true>("apply_heaviside", mat, d, nullptr, 0, nullptr, 0, Heaviside{}); }
+void cudaF_apply_floor(aslp_dim3, aslp_dim3, float *mat, float v, MatrixDim d) { launch_map<true>("apply_floor", mat, d, nullptr, 0, nullptr, 0, Floor{v}); }
+void cudaF_apply_ceiling(aslp_dim3, aslp_dim3, float *mat, float v, MatrixDim d) { launch_map<true>("apply_ceiling", mat, d, nullptr, 0, nullptr, 0, Ceil{v}); }
+void cudaF_invert_elements(aslp_dim3, aslp_dim3, float *data, MatrixDim d) { launch_map<true>("invert_elements", data, d, nullptr, 0, nullptr, 0, Invert{}); }
+void cudaF_mul_elements(aslp_dim3, aslp_dim3, float *mat, const float *A, MatrixDim d, int src_stride) { launch_map<true>("mul_elements", mat, d, A, src_stride, nullptr, 0, MulElem{}); }
+void cudaF_mul_cols_vec(aslp_dim3, aslp_dim3, float *mat, const float *scale, MatrixDim d) { launch_map<true>("mul_cols_vec", mat, d, nullptr, 0, nullptr, 0, MulColsVec{scale}); }
+void cudaF_mul_rows_vec(aslp_dim3, aslp_dim3, float *mat, const float *scale, MatrixDim d) { launch_map<true>("mul_rows_vec", mat, d, nullptr, 0, nullptr, 0, MulRowsVec{scale}); }
+
+void cudaF_add_mat(aslp_dim3, aslp_dim3, float alpha, const float *src, float *dst, MatrixDim d, int src_stride, int A_trans) {
+  if (!A_trans) {
+    launch_map<true>("add_mat", dst, d, src, src_stride, nullptr, 0, AddMat{alpha});
+  } else {
+    if (d.rows <= 0 || d.cols <= 0) return;
+    hipLaunchKernelGGL(add_mat_trans_kernel, dim3(grid_for((long)d.rows * d.cols)), dim3(kBlock), 0, cur_stream(), alpha, src, dst, d, src_stride);
+    check_launch("add_mat_trans");
+  }
+}
+void cudaF_add_vec_to_cols(aslp_dim3, aslp_dim3, float alpha, const float *col, float beta, float *dst, MatrixDim d) {
+  launch_map<true>("add_vec_to_cols", dst, d, nullptr, 0, nullptr, 0, AddVecToCols{alpha, beta, col});
+}
+void cudaF_add_vec_to_rows(aslp_dim3, aslp_dim3, float alpha, const float *row, float beta, float *dst, MatrixDim d) {
+  // beta == 0 must not read dst (the reference pre-zeroes; NaN garbage would otherwise leak through 0*NaN)
+  if (beta == 0.0f) launch_map<false>("add_vec_to_rows", dst, d, nullptr, 0, nullptr, 0, AddVecToRows0{alpha, row});
+  else launch_map<true>("add_vec_to_rows", dst, d, nullptr, 0, nullptr, 0, AddVecToRows{alpha, beta, row});
+}
+void cudaF_add_mat_diag_vec(aslp_dim3, aslp_dim3, float alpha, float *mat, MatrixDim mat_dim, const float *mat2, int mat2_row_stride,
+                            int mat2_col_stride, const float *vec, float beta) {
+  if (mat2_col_stride == 1) {
+    launch_map<true>("add_mat_diag_vec", mat, mat_dim, mat2, mat2_row_stride, nullptr, 0, AddMatDiagVec{alpha, beta, vec});
+  } else {
+    if (mat_dim.rows <= 0 || mat_dim.cols <= 0) return;
+    hipLaunchKernelGGL(add_mat_diag_vec_strided, dim3(grid_for((long)mat_dim.rows * mat_dim.cols)), dim3(kBlock), 0, cur_stream(),
+                       alpha, mat, mat_dim, mat2, mat2_row_stride, mat2_col_stride, vec, beta);
+    check_launch("add_mat_diag_vec_strided");
+  }
+}
+void cudaF_add_mat_mat_elements(aslp_dim3, aslp_dim3, float *data, const float *A, const float *B, MatrixDim dim, int sa, int sb, float alpha, float beta) {
+  if (beta == 0.0f) launch_map<false>("add_mat_mat_elements", data, dim, A, sa, B, sb, AddMatMatElem0{alpha});
+  else launch_map<true>("add_mat_mat_elements", data, dim, A, sa, B, sb, AddMatMatElem{alpha, beta});
+}
+void cudaF_sigmoid(aslp_dim3, aslp_dim3, float *y, const float *x, MatrixDim d, int src_stride) { launch_map<false>("sigmoid", y, d, x, src_stride, nullptr, 0, Sigmoid{}); }
+void cudaF_tanh(aslp_dim3, aslp_dim3, float *y, const float *x, MatrixDim d, int src_stride) { launch_map<false>("tanh", y, d, x, src_stride, nullptr, 0, Tanh{}); }
+void cudaF_diff_sigmoid(aslp_dim3, aslp_dim3, float *eout, const float *e, const float *y, MatrixDim d, int e_stride, int y_stride) {
+  launch_map<false>("diff_sigmoid", eout, d, e, e_stride, y, y_stride, DiffSigmoid{});
+}
+void cudaF_diff_tanh(aslp_dim3, aslp_dim3, float *eout, const float *e, const float *y, MatrixDim d, int e_stride, int y_stride) {
+  launch_map<false>("diff_tanh", eout, d, e, e_stride, y, y_stride, DiffTanh{});
+}
+void aslp_diff_relu(float *in_diff, const float *in, const float *out_diff, MatrixDim d, int in_stride, int od_stride) {
+  launch_map<false>("diff_relu", in_diff, d, in, in_stride, out_diff, od_stride, DiffRelu{});
+}
+void aslp_copy_mat(float *dst, MatrixDim d, const float *src, int src_stride) { launch_map<false>("copy_mat", dst, d, src, src_stride, nullptr, 0, CopyMat{}); }
+
+void cudaF_regularize_l1(aslp_dim3, aslp_dim3, float *wei, float *grad, float l1, float lr, MatrixDim d, int stride_grad) {
+  if (d.rows <= 0 || d.cols <= 0) return;
+  hipLaunchKernelGGL(regularize_l1_kernel, dim3(grid_for((long)d.rows * d.cols)), dim3(kBlock), 0, cur_stream(), wei, grad, l1, lr, d, stride_grad);
+  check_launch("regularize_l1");
+}
+
+void cudaF_copy_rows(aslp_dim3, aslp_dim3, float *dst, const float *src, const MatrixIndexT_cuda *reorder, MatrixDim dd, int src_stride) {
+  launch_row_gather<false>("copy_rows", 0.0f, dst, src, reorder, dd.rows, dd.cols, dd.stride, src_stride);
+}
+void cudaF_add_rows(aslp_dim3, aslp_dim3, float alpha, float *dst, const float *src, const MatrixIndexT_cuda *reorder, MatrixDim dd, int src_stride) {
+  launch_row_gather<true>("add_rows", alpha, dst, src, reorder, dd.rows, dd.cols, dd.stride, src_stride);
+}
+void cudaF_randomize(aslp_dim3, aslp_dim3, float *y, const float *x, const int32_cuda *copy_from, MatrixDim d_out, MatrixDim d_in) {
+  // cu-math.cc:105-110: d_out.rows = number of indices
+  launch_row_gather<false>("randomize", 0.0f, y, x, copy_from, d_out.rows, d_out.cols, d_out.stride, d_in.stride);
+}
+void cudaF_copy_cols(aslp_dim3, aslp_dim3, float *dst, const float *src, const MatrixIndexT_cuda *reorder, MatrixDim dd, int src_stride) {
+  if (dd.rows <= 0 || dd.cols <= 0) return;
+  hipLaunchKernelGGL((col_gather<false>), dim3(grid_for((long)dd.rows * dd.cols)), dim3(kBlock), 0, cur_stream(), dst, src, reorder, dd.rows, dd.cols, dd.stride, src_stride);
+  check_launch("copy_cols");
+}
+void cudaF_add_cols(aslp_dim3, aslp_dim3, float *dst, const float *src, const MatrixIndexT_cuda *reorder, MatrixDim dd, int src_stride) {
+  if (dd.rows <= 0 || dd.cols <= 0) return;
+  hipLaunchKernelGGL((col_gather<true>), dim3(grid_for((long)dd.rows * dd.cols)), dim3(kBlock), 0, cur_stream(), dst, src, reorder, dd.rows, dd.cols, dd.stride, src_stride);
+  check_launch("add_cols");
+}
+void cudaF_copy(aslp_dim3, aslp_dim3, float *y, const float *x, const int32_cuda *copy_from, MatrixDim d_out, MatrixDim d_in) {
+  if (d_out.rows <= 0 || d_out.cols <= 0) return;
+  hipLaunchKernelGGL((col_gather<false>), dim3(grid_for((long)d_out.rows * d_out.cols)), dim3(kBlock), 0, cur_stream(), y, x, copy_from, d_out.rows, d_out.cols, d_out.stride, d_in.stride);
+  check_launch("copy");
+}
+void cudaF_splice(aslp_dim3, aslp_dim3, float *y, const float *x, const int32_cuda *off, MatrixDim d_out, MatrixDim d_in) {
+  if (d_out.rows <= 0 || d_out.cols <= 0) return;
+  bool vec = d_in.cols % 4 == 0 && d_in.stride % 4 == 0 && d_out.stride % 4 == 0 && aligned16(y) && aligned16(x);
+  long n = (long)d_out.rows * (vec ? d_out.cols / 4 : d_out.cols);
+  if (vec) hipLaunchKernelGGL((splice_kernel<true>), dim3(grid_for(n)), dim3(kBlock), 0, cur_stream(), y, x, off, d_out.rows, d_out.cols, d_in.cols, d_out.stride, d_in.stride);
+  else hipLaunchKernelGGL((splice_kernel<false>), dim3(grid_for(n)), dim3(kBlock), 0, cur_stream(), y, x, off, d_out.rows, d_out.cols, d_in.cols, d_out.stride, d_in.stride);
+  check_launch("splice");
+}
+void aslp_splice_backward(float *in_diff, MatrixDim d_in, const float *out_diff, int od_stride, const int32_cuda *off, int n_off) {
+  if (d_in.rows <= 0 || d_in.cols <= 0) return;
+  bool vec = d_in.cols % 4 == 0 && d_in.stride % 4 == 0 && od_stride % 4 == 0 && aligned16(in_diff) && aligned16(out_diff);
+  long n = (long)d_in.rows * (vec ? d_in.cols / 4 : d_in.cols);
+  if (vec) hipLaunchKernelGGL((splice_bwd_kernel<true>), dim3(grid_for(n)), dim3(kBlock), 0, cur_stream(), in_diff, out_diff, off, n_off, d_in.rows, d_in.cols, d_in.stride, od_stride);
+  else hipLaunchKernelGGL((splice_bwd_kernel<false>), dim3(grid_for(n)), dim3(kBlock), 0, cur_stream(), in_diff, out_diff, off, n_off, d_in.rows, d_in.cols, d_in.stride, od_stride);
+  check_launch("splice_backward");
+}
+void cudaI32_set_const(aslp_dim3, aslp_dim3, int32_cuda *mat, int32_cuda value, MatrixDim d) {
+  if (d.rows <= 0 || d.cols <= 0) return;
+  hipLaunchKernelGGL(set_const_i32, dim3(grid_for((long)d.rows * d.cols)), dim3(kBlock), 0, cur_stream(), mat, value, d);
+  check_launch("set_const_i32");
+}
+void aslp_scatter_add(float *mat, MatrixDim d, const int32_cuda *rows, const int32_cuda *cols, const float *vals, int n) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(scatter_add_kernel, dim3(grid_for(n)), dim3(kBlock), 0, cur_stream(), mat, d, rows, cols, vals, n);
+  check_launch("scatter_add");
+}
+void aslp_f2d(double *dst, const float *src, int n) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(f2d_kernel, dim3(grid_for(n)), dim3(kBlock), 0, cur_stream(), dst, src, n);
+  check_launch("f2d");
+}
+void aslp_d2f(float *dst, const double *src, int n) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(d2f_kernel, dim3(grid_for(n)), dim3(kBlock), 0, cur_stream(), dst, src, n);
+  check_launch("d2f");
+}
+void cudaF_add_vec_vec(int, int, float alpha, float *v, const float *x, const float *y, float beta, int dim) {
+  if (dim <= 0) return;
+  hipLaunchKernelGGL(add_vec_vec_kernel, dim3(grid_for(dim)), dim3(kBlock), 0, cur_stream(), alpha, v, x, y, beta, dim);
+  check_launch("add_vec_vec");
+}
+void aslp_vec_axpy(float alpha, const float *x, float *y, int dim) {
+  if (dim <= 0) return;
+  hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(dim)), dim3(kBlock), 0, cur_stream(), alpha, x, y, dim);
+  check_launch("axpy");
+}
+
+}  // extern "C"

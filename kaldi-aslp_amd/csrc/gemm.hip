@@ -1,0 +1,373 @@
+// gemm.hip -- fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32) for gfx950.
+//
+// Replaces the cuBLAS sgemm seam (src/aslp-cudamatrix/cublas-wrappers.h:28-47, call site
+// CuMatrixBase::AddMatMat cu-matrix.cc:1027-1061): row-major
+//     C[M x N] = alpha * op(A) * op(B) + beta * C   (+ fused epilogue, see aslp_kernels.h)
+// gfx950 has no xf32/TF32 path: the f32-input MFMA is exact fp32 (bitwise an fmaf chain) at
+// 157.3 TFLOP/s peak, which is what keeps Propagate/Backpropagate inside the 1e-4 parity bar.
+//
+// Tiling (256 threads = 4 waves, one per SIMD; each wave owns a (BM/WGM) x (BN/WGN) patch
+// made of 32x32 MFMA tiles; accumulators stay in registers for the whole K loop):
+//   * operands whose K index is contiguous in memory ("KC": A of NT/NN, B of NT) are staged
+//     as [rows][BK+4] and read back with ONE ds_read_b128 per 4 MFMA k-steps: lane l takes
+//     k = 8*h + 4*(l>>5) + {0..3} of row (l&31).  The +4 pad makes the 16-lane b128 groups
+//     conflict-free (stride 20 dwords = 5 slots, odd).
+//   * operands whose row index is contiguous ("RC": A of TN, B of NN/TN) are staged as
+//     [BK][rows+4] and read with ds_read_b32 using the SAME k permutation, so both operands
+//     of one MFMA agree on which two k's a step consumes.
+//   * global->LDS goes through registers (float4 per lane, coalesced along the contiguous
+//     dimension), double-buffered in LDS: the loads of tile t+1 are issued before the MFMAs
+//     of tile t and written to the other buffer after them -- one barrier per K tile.
+// The K order inside a tile is a permutation of 0..BK-1; fp32 sums are therefore not
+// bitwise those of a k-ascending loop (parity is tolerance-based for GEMM rows).
+#include <mutex>
+#include <vector>
+
+#include "aslp_kernels.h"
+#include "common.h"
+
+namespace aslp {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmArgs {
+  const float *A, *B;
+  float *C;
+  int M, N, K, lda, ldb, ldc;
+  float alpha, beta;
+  aslp_gemm_epilogue ep;
+  int a_vec, b_vec;  // 16-byte vector loads allowed
+  int tiles_m, tiles_n;
+};
+
+constexpr int BK = 16;
+constexpr int KC_LD = BK + 4;
+
+template <int BR>
+struct Stage {
+  static constexpr int TOTAL = BR * BK / 4;             // float4 per tile
+  static constexpr int NV = (TOTAL + 255) / 256;         // float4 per thread per tile
+  static constexpr bool FULL = TOTAL % 256 == 0;         // otherwise the tail threads idle
+};
+
+// ---- global -> registers ------------------------------------------------------------------
+// KC operand: src is [R x K] row-major (ld), tile rows r0.., k0..
+template <int BR>
+__device__ __forceinline__ void gload_kc(const float *__restrict__ src, int ld, int R, int K, int r0, int k0, bool vec,
+                                         float4 (&v)[Stage<BR>::NV]) {
+  constexpr int C4 = BK / 4;
+#pragma unroll
+  for (int i = 0; i < Stage<BR>::NV; i++) {
+    int idx = threadIdx.x + i * 256;
+    int row = idx / C4, c4 = idx % C4;
+    int gr = r0 + row, gk = k0 + c4 * 4;
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((Stage<BR>::FULL || idx < Stage<BR>::TOTAL) && gr < R) {
+      const float *p = src + (long)gr * ld + gk;
+      if (vec && gk + 3 < K) {
+        x = *reinterpret_cast<const float4 *>(p);
+      } else {
+        if (gk < K) x.x = p[0];
+        if (gk + 1 < K) x.y = p[1];
+        if (gk + 2 < K) x.z = p[2];
+        if (gk + 3 < K) x.w = p[3];
+      }
+    }
+    v[i] = x;
+  }
+}
+template <int BR>
+__device__ __forceinline__ void sstore_kc(float *lds, const float4 (&v)[Stage<BR>::NV]) {
+  constexpr int C4 = BK / 4;
+#pragma unroll
+  for (int i = 0; i < Stage<BR>::NV; i++) {
+    int idx = threadIdx.x + i * 256;
+    int row = idx / C4, c4 = idx % C4;
+    if (Stage<BR>::FULL || idx < Stage<BR>::TOTAL) *reinterpret_cast<float4 *>(lds + row * KC_LD + c4 * 4) = v[i];
+  }
+}
+// RC operand: src is [K x R] row-major (ld), tile k0.., rows r0..
+template <int BR>
+__device__ __forceinline__ void gload_rc(const float *__restrict__ src, int ld, int R, int K, int r0, int k0, bool vec,
+                                         float4 (&v)[Stage<BR>::NV]) {
+  constexpr int C4 = BR / 4;
+#pragma unroll
+  for (int i = 0; i < Stage<BR>::NV; i++) {
+    int idx = threadIdx.x + i * 256;
+    int k = idx / C4, c4 = idx % C4;
+    int gk = k0 + k, gr = r0 + c4 * 4;
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((Stage<BR>::FULL || idx < Stage<BR>::TOTAL) && gk < K) {
+      const float *p = src + (long)gk * ld + gr;
+      if (vec && gr + 3 < R) {
+        x = *reinterpret_cast<const float4 *>(p);
+      } else {
+        if (gr < R) x.x = p[0];
+        if (gr + 1 < R) x.y = p[1];
+        if (gr + 2 < R) x.z = p[2];
+        if (gr + 3 < R) x.w = p[3];
+      }
+    }
+    v[i] = x;
+  }
+}
+template <int BR>
+__device__ __forceinline__ void sstore_rc(float *lds, const float4 (&v)[Stage<BR>::NV]) {
+  constexpr int C4 = BR / 4;
+#pragma unroll
+  for (int i = 0; i < Stage<BR>::NV; i++) {
+    int idx = threadIdx.x + i * 256;
+    int k = idx / C4, c4 = idx % C4;
+    if (Stage<BR>::FULL || idx < Stage<BR>::TOTAL) *reinterpret_cast<float4 *>(lds + k * (BR + 4) + c4 * 4) = v[i];
+  }
+}
+
+template <int BR, bool KC>
+struct OperandTile {
+  static constexpr int kFloats = KC ? BR * KC_LD : BK * (BR + 4);
+};
+
+// A_KC: op(A) rows are contiguous in k (transA == 0).  B_KC: op(B) columns are contiguous in k (transB == 1).
+template <int BM, int BN, int WGM, int WGN, bool A_KC, bool B_KC>
+__global__ void __launch_bounds__(256) gemm_f32_mfma(GemmArgs g) {
+  constexpr int WM = BM / WGM, WN = BN / WGN;  // wave patch
+  constexpr int TM = WM / 32, TN = WN / 32;    // 32x32 MFMA tiles per wave
+  static_assert(WGM * WGN == 4 && TM >= 1 && TN >= 1, "bad wave grid");
+  constexpr int A_FLOATS = OperandTile<BM, A_KC>::kFloats, B_FLOATS = OperandTile<BN, B_KC>::kFloats;
+  __shared__ __attribute__((aligned(16))) float lds[2 * (A_FLOATS + B_FLOATS)];
+  // layout [A0 | B0 | A1 | B1]
+  auto a_buf = [&](int b) { return lds + b * (A_FLOATS + B_FLOATS); };
+  auto b_buf = [&](int b) { return lds + b * (A_FLOATS + B_FLOATS) + A_FLOATS; };
+
+  // XCD-aware tile order: consecutive blocks go to different XCDs (block b -> XCD b%8), so give
+  // each XCD a contiguous run of tiles that share A row-panels in its private L2.
+  const int nt = g.tiles_m * g.tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nt / 8, r = nt % 8, xcd = bid % 8, j = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int tm = bid / g.tiles_n, tn = bid % g.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+
+  float4 ra[Stage<BM>::NV], rb[Stage<BN>::NV];
+  const int ktiles = (g.K + BK - 1) / BK;
+
+  auto gload = [&](int kt) {
+    if (A_KC) gload_kc<BM>(g.A, g.lda, g.M, g.K, m0, kt * BK, g.a_vec, ra);
+    else gload_rc<BM>(g.A, g.lda, g.M, g.K, m0, kt * BK, g.a_vec, ra);
+    if (B_KC) gload_kc<BN>(g.B, g.ldb, g.N, g.K, n0, kt * BK, g.b_vec, rb);
+    else gload_rc<BN>(g.B, g.ldb, g.N, g.K, n0, kt * BK, g.b_vec, rb);
+  };
+  auto sstore = [&](int buf) {
+    if (A_KC) sstore_kc<BM>(a_buf(buf), ra); else sstore_rc<BM>(a_buf(buf), ra);
+    if (B_KC) sstore_kc<BN>(b_buf(buf), rb); else sstore_rc<BN>(b_buf(buf), rb);
+  };
+
+  if (ktiles > 0) {
+    gload(0);
+    sstore(0);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < ktiles; kt++) {
+    const int cur = kt & 1;
+    if (kt + 1 < ktiles) gload(kt + 1);  // in flight during the MFMAs below
+    const float *a_s = a_buf(cur), *b_s = b_buf(cur);
+#pragma unroll
+    for (int h = 0; h < BK / 8; h++) {
+      float af[TM][4], bf[TN][4];
+#pragma unroll
+      for (int i = 0; i < TM; i++) {
+        const int row = wm * WM + i * 32 + l31;
+        if (A_KC) {
+          float4 t = *reinterpret_cast<const float4 *>(a_s + row * KC_LD + h * 8 + lh * 4);
+          af[i][0] = t.x; af[i][1] = t.y; af[i][2] = t.z; af[i][3] = t.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; j++) af[i][j] = a_s[(h * 8 + lh * 4 + j) * (BM + 4) + row];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TN; i++) {
+        const int col = wn * WN + i * 32 + l31;
+        if (B_KC) {
+          float4 t = *reinterpret_cast<const float4 *>(b_s + col * KC_LD + h * 8 + lh * 4);
+          bf[i][0] = t.x; bf[i][1] = t.y; bf[i][2] = t.z; bf[i][3] = t.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; j++) bf[i][j] = b_s[(h * 8 + lh * 4 + j) * (BN + 4) + col];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+          for (int n = 0; n < TN; n++)
+            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][j], bf[n][j], acc[i][n], 0, 0, 0);
+    }
+    if (kt + 1 < ktiles) sstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
+  const aslp_gemm_epilogue &ep = g.ep;
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int n = 0; n < TN; n++) {
+      const int col = n0 + wn * WN + n * 32 + l31;
+      if (col >= g.N) continue;
+      const float bias = ep.bias ? ep.bias[col] : 0.0f;
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const int row = m0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (row >= g.M) continue;
+        float *cp = g.C + (long)row * g.ldc + col;
+        float v = g.alpha * acc[i][n][e];
+        if (g.beta != 0.0f) v += g.beta * *cp;
+        v += bias;
+        if (ep.clip > 0.0f) v = fminf(fmaxf(v, -ep.clip), ep.clip);
+        *cp = v;
+        if (ep.W) ep.W[(long)row * ep.ldw + col] += ep.w_alpha * v;
+        if (ep.act_out) {
+          float a = ep.act == 1 ? sigmoid_ref(v) : ep.act == 2 ? tanh_ref(v) : ep.act == 3 ? fmaxf(v, 0.0f) : v;
+          ep.act_out[(long)row * ep.ld_act + col] = a;
+        }
+      }
+    }
+}
+
+// ---- profile counters (bench.py roofline) -------------------------------------------------
+struct GemmProf {
+  long launches = 0;
+  double flops = 0.0, ms = 0.0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+GemmProf g_prof[4];
+bool g_prof_on = false;
+std::mutex g_prof_mu;
+
+void drain(GemmProf &p) {
+  for (auto &ev : p.pending) {
+    float ms = 0.f;
+    if (hipEventSynchronize(ev.second) == hipSuccess && hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) p.ms += ms;
+    (void)hipEventDestroy(ev.first);
+    (void)hipEventDestroy(ev.second);
+  }
+  p.pending.clear();
+}
+
+template <int BM, int BN, int WGM, int WGN, bool A_KC, bool B_KC>
+void launch_cfg(GemmArgs &g) {
+  g.tiles_m = (g.M + BM - 1) / BM;
+  g.tiles_n = (g.N + BN - 1) / BN;
+  hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, WGM, WGN, A_KC, B_KC>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, cur_stream(), g);
+}
+
+template <bool A_KC, bool B_KC>
+void launch_variant(GemmArgs &g) {
+  // Tile choice: the largest tile that still gives >= ~256 blocks (one per CU); skinny M
+  // (the S-row recurrent GEMMs of the LSTM family) gets the 32-row tile.
+  auto blocks = [&](int bm, int bn) { return (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn); };
+  if (g.M <= 32) {
+    launch_cfg<32, 128, 1, 4, A_KC, B_KC>(g);
+  } else if (g.M <= 64 && blocks(64, 64) < 256) {
+    launch_cfg<64, 64, 2, 2, A_KC, B_KC>(g);
+  } else if (blocks(128, 128) >= 224) {
+    launch_cfg<128, 128, 2, 2, A_KC, B_KC>(g);
+  } else if (blocks(128, 64) >= 224) {
+    launch_cfg<128, 64, 2, 2, A_KC, B_KC>(g);
+  } else {
+    launch_cfg<64, 64, 2, 2, A_KC, B_KC>(g);
+  }
+}
+
+}  // namespace
+}  // namespace aslp
+
+using namespace aslp;
+
+extern "C" {
+
+int aslp_sgemm_ex(int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda, const float *B, int ldb, float beta,
+                  float *C, int ldc, const aslp_gemm_epilogue *ep) {
+  if (M < 0 || N < 0 || K < 0) return -1;
+  if (M == 0 || N == 0) return 0;
+  if (!C || ldc < N) return -2;
+  if (K > 0 && (!A || !B)) return -3;
+  if (K > 0 && (lda < (transA ? M : K) || ldb < (transB ? K : N))) return -4;
+  GemmArgs g;
+  g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.alpha = alpha; g.beta = beta;
+  if (ep) g.ep = *ep; else { g.ep = aslp_gemm_epilogue(); g.ep.bias = nullptr; g.ep.clip = 0.f; g.ep.W = nullptr; g.ep.act_out = nullptr; g.ep.act = 0; g.ep.ldw = 0; g.ep.ld_act = 0; g.ep.w_alpha = 0.f; }
+  g.a_vec = aligned16(A) && lda % 4 == 0;
+  g.b_vec = aligned16(B) && ldb % 4 == 0;
+  // report order: 0 = NT, 1 = NN, 2 = TN, 3 = TT
+  int slot = (!transA && transB) ? 0 : (!transA && !transB) ? 1 : (transA && !transB) ? 2 : 3;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  bool prof = g_prof_on;
+  if (prof) {
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, cur_stream());
+  }
+  if (!transA && transB) launch_variant<true, true>(g);
+  else if (!transA && !transB) launch_variant<true, false>(g);
+  else if (transA && !transB) launch_variant<false, false>(g);
+  else launch_variant<false, true>(g);
+  check_launch("aslp_sgemm");
+  {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof[slot].launches++;
+    g_prof[slot].flops += 2.0 * (double)M * (double)N * (double)K;
+    if (prof) {
+      (void)hipEventRecord(e1, cur_stream());
+      g_prof[slot].pending.emplace_back(e0, e1);
+    }
+  }
+  return 0;
+}
+
+int aslp_sgemm(int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda, const float *B, int ldb, float beta,
+               float *C, int ldc) {
+  return aslp_sgemm_ex(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, nullptr);
+}
+
+void aslp_gemm_profile(int enable) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_on = enable != 0;
+}
+void aslp_gemm_profile_reset(void) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (auto &p : g_prof) {
+    drain(p);
+    p.launches = 0;
+    p.flops = 0.0;
+    p.ms = 0.0;
+  }
+}
+long aslp_gemm_profile_get(int variant, double *flops, double *ms) {
+  if (variant < 0 || variant > 3) return -1;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  drain(g_prof[variant]);
+  if (flops) *flops = g_prof[variant].flops;
+  if (ms) *ms = g_prof[variant].ms;
+  return g_prof[variant].launches;
+}
+
+}  // extern "C"

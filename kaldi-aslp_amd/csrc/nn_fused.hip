@@ -1,0 +1,303 @@
+// nn_fused.hip -- fused hot-path ops: BatchNormalization forward/backward and Xent::Eval.
+//
+// Both are HBM-bound.  The reference issues ~25 elementwise /
+// gemv launches per BatchNormalization step and ~15 + 5 blocking reductions per Xent::Eval;
+// here BN forward is 2 column-statistics passes + 1 write pass, BN backward 1 statistics
+// pass + 1 write pass, and Xent one pass with the row held in registers.
+#include "aslp_kernels.h"
+#include "colreduce.h"
+#include "common.h"
+
+namespace aslp {
+namespace {
+
+// ---- BatchNormalization ---------------------------------------------------------------
+// pass 1: sum x (float, for the mean like the reference's fp32 gemv) and, for the running
+// statistics, sum x and sum fl(x*x) in double (nnet-batch-normalization.h:216-220).
+struct BnSum1F {
+  const float *in; int ld;
+  __device__ void operator()(int r, int c, double (&acc)[2]) const {
+    float x = in[(long)r * ld + c];
+    acc[0] += (double)x;
+    acc[1] += (double)(x * x);
+  }
+};
+struct BnSum1G {
+  float inv_rows; float *mean; double *acc_means, *acc_vars;
+  __device__ void operator()(int c, const double (&s)[2]) const {
+    // the reference's mean is an fp32 gemv result scaled by 1/B; a double sum rounded once to
+    // fp32 differs from it by < 1 ulp-of-sum, far inside the 1e-4 parity tolerance.
+    mean[c] = (float)s[0] * inv_rows;
+    if (acc_means) acc_means[c] += s[0];
+    if (acc_vars) acc_vars[c] += s[1];
+  }
+};
+// pass 2: sum (x - mean)^2 -> inv_std = 1/sqrt(var + floor)  (:193-204)
+struct BnSum2F {
+  const float *in; int ld; const float *mean;
+  __device__ void operator()(int r, int c, float (&acc)[1]) const {
+    float d = in[(long)r * ld + c] - mean[c];
+    acc[0] += d * d;
+  }
+};
+struct BnSum2G {
+  float inv_rows, floor_; float *inv_std;
+  __device__ void operator()(int c, const float (&s)[1]) const {
+    float v = s[0] * inv_rows + floor_;
+    inv_std[c] = 1.0f / sqrtf(v);
+  }
+};
+// pass 3: xhat = (x - mean) * inv_std ; out = xhat * gamma + beta
+template <bool VEC>
+__global__ void __launch_bounds__(kBlock) bn_normalize_kernel(const float *in, int ldi, float *out, int ldo, float *xhat, int ldx,
+                                                              const float *mean, const float *inv_std, const float *scale,
+                                                              const float *shift, int rows, int cols) {
+  constexpr int W = VEC ? 4 : 1;
+  int cw = cols / W;
+  long n = (long)rows * cw;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int r = (int)(i / cw), c = (int)(i - (long)r * cw) * W;
+    if (VEC) {
+      float4 x = *reinterpret_cast<const float4 *>(in + (long)r * ldi + c);
+      float4 m = *reinterpret_cast<const float4 *>(mean + c), s = *reinterpret_cast<const float4 *>(inv_std + c);
+      float4 g = *reinterpret_cast<const float4 *>(scale + c), b = *reinterpret_cast<const float4 *>(shift + c);
+      float4 h, o;
+      h.x = (x.x - m.x) * s.x; h.y = (x.y - m.y) * s.y; h.z = (x.z - m.z) * s.z; h.w = (x.w - m.w) * s.w;
+      o.x = h.x * g.x + b.x; o.y = h.y * g.y + b.y; o.z = h.z * g.z + b.z; o.w = h.w * g.w + b.w;
+      if (xhat) *reinterpret_cast<float4 *>(xhat + (long)r * ldx + c) = h;
+      *reinterpret_cast<float4 *>(out + (long)r * ldo + c) = o;
+    } else {
+      float h = (in[(long)r * ldi + c] - mean[c]) * inv_std[c];
+      if (xhat) xhat[(long)r * ldx + c] = h;
+      out[(long)r * ldo + c] = h * scale[c] + shift[c];
+    }
+  }
+}
+
+// backward statistics: S1 = sum dy, S2 = sum xhat*dy
+struct BnBwdF {
+  const float *dy; int ldd; const float *xhat; int ldx;
+  __device__ void operator()(int r, int c, float (&acc)[2]) const {
+    float d = dy[(long)r * ldd + c];
+    acc[0] += d;
+    acc[1] += xhat[(long)r * ldx + c] * d;
+  }
+};
+struct BnBwdG {
+  float mmt; float *dscale, *dshift; float *s1, *s2;
+  __device__ void operator()(int c, const float (&s)[2]) const {
+    dshift[c] = s[0] + mmt * dshift[c];
+    dscale[c] = s[1] + mmt * dscale[c];
+    s1[c] = s[0];
+    s2[c] = s[1];
+  }
+};
+// in_diff: with D = dy*gamma, the reference's 4 steps (:238-276) reduce to
+//   dvar  = -0.5 * inv^3 * sum (x-mean) * D      = -0.5 * inv^2 * gamma * S2
+//   dmean = -inv * gamma * S1  ( - (2/B) dvar * sum(x-mean), which is 0 up to rounding )
+//   in_diff = D*inv + (x-mean) * (2/B) * dvar + dmean/B,   (x-mean) = xhat/inv
+template <bool VEC>
+__global__ void __launch_bounds__(kBlock) bn_backward_kernel(const float *dy, int ldd, float *xhat, int ldx, const float *scale,
+                                                             const float *inv_std, const float *s1, const float *s2, float *in_diff,
+                                                             int ldi, int rows, int cols) {
+  constexpr int W = VEC ? 4 : 1;
+  int cw = cols / W;
+  long n = (long)rows * cw;
+  const float invB = 1.0f / (float)rows;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int r = (int)(i / cw), c = (int)(i - (long)r * cw) * W;
+    float dyv[W], hv[W], gv[W], iv[W], s1v[W], s2v[W], Dv[W], ov[W];
+    if (VEC) {
+      *reinterpret_cast<float4 *>(dyv) = *reinterpret_cast<const float4 *>(dy + (long)r * ldd + c);
+      *reinterpret_cast<float4 *>(hv) = *reinterpret_cast<const float4 *>(xhat + (long)r * ldx + c);
+      *reinterpret_cast<float4 *>(gv) = *reinterpret_cast<const float4 *>(scale + c);
+      *reinterpret_cast<float4 *>(iv) = *reinterpret_cast<const float4 *>(inv_std + c);
+      *reinterpret_cast<float4 *>(s1v) = *reinterpret_cast<const float4 *>(s1 + c);
+      *reinterpret_cast<float4 *>(s2v) = *reinterpret_cast<const float4 *>(s2 + c);
+    } else {
+      dyv[0] = dy[(long)r * ldd + c]; hv[0] = xhat[(long)r * ldx + c]; gv[0] = scale[c]; iv[0] = inv_std[c];
+      s1v[0] = s1[c]; s2v[0] = s2[c];
+    }
+#pragma unroll
+    for (int k = 0; k < W; k++) {
+      float g = gv[k], inv = iv[k];
+      float D = dyv[k] * g;
+      float dvar = -0.5f * inv * inv * g * s2v[k];         // = sum (x-mean) D * (-0.5 inv^3)
+      float dmean = -inv * g * s1v[k];
+      float xm = hv[k] / inv;
+      Dv[k] = D;  // XsharpO_ <- dy*gamma, like the reference (:241-242)
+      ov[k] = D * inv + xm * (2.0f * invB) * dvar + invB * dmean;
+    }
+    if (VEC) {
+      *reinterpret_cast<float4 *>(xhat + (long)r * ldx + c) = *reinterpret_cast<float4 *>(Dv);
+      *reinterpret_cast<float4 *>(in_diff + (long)r * ldi + c) = *reinterpret_cast<float4 *>(ov);
+    } else {
+      xhat[(long)r * ldx + c] = Dv[0];
+      in_diff[(long)r * ldi + c] = ov[0];
+    }
+  }
+}
+
+// ---- Xent ------------------------------------------------------------------------------
+constexpr int kXentPerThread = 32;  // cols <= 8192 cached in registers
+
+// One block (256 threads) per row.  rowstats[r][0..4] = {w, correct*w, w*sum t log(y+1e-20),
+// w*sum t log(t+1e-20), w*sum t y} as double; summed in fixed order by xent_finalize.
+template <bool DENSE>
+__global__ void __launch_bounds__(256) xent_rows_kernel(const float *y, int ldy, const float *t, int ldt, const int32_t *labels,
+                                                        const float *fw, float *diff, int ldd, int rows, int cols, double *rowstats) {
+  __shared__ float shf[4][4];
+  __shared__ int shi[4][2];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    const float *yr = y + (long)r * ldy;
+    const float *tr = DENSE ? t + (long)r * ldt : nullptr;
+    const int label = DENSE ? -1 : labels[r];
+    float yv[kXentPerThread], tv[kXentPerThread];
+    float tsum = 0.0f, ybest = -1e21f, tbest = -1e21f;
+    int yi = -1, ti = -1;
+#pragma unroll
+    for (int k = 0; k < kXentPerThread; k++) {
+      int c = tid + k * 256;
+      if (c < cols) {
+        yv[k] = yr[c];
+        tv[k] = DENSE ? tr[c] : (c == label ? 1.0f : 0.0f);
+        tsum += tv[k];
+        if (ybest < yv[k]) { ybest = yv[k]; yi = c; }
+        if (tbest < tv[k]) { tbest = tv[k]; ti = c; }
+      }
+    }
+    // block reductions: tsum, argmax(y), argmax(t)
+    tsum = wave_sum(tsum);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      float ov = __shfl_xor(ybest, o, 64); int oi = __shfl_xor(yi, o, 64);
+      if (ov > ybest || (ov == ybest && oi >= 0 && (yi < 0 || oi < yi))) { ybest = ov; yi = oi; }
+      ov = __shfl_xor(tbest, o, 64); oi = __shfl_xor(ti, o, 64);
+      if (ov > tbest || (ov == tbest && oi >= 0 && (ti < 0 || oi < ti))) { tbest = ov; ti = oi; }
+    }
+    if (lane == 0) { shf[w][0] = tsum; shf[w][1] = ybest; shf[w][2] = tbest; shi[w][0] = yi; shi[w][1] = ti; }
+    __syncthreads();
+    tsum = shf[0][0] + shf[1][0] + shf[2][0] + shf[3][0];
+    ybest = shf[0][1]; yi = shi[0][0]; tbest = shf[0][2]; ti = shi[0][1];
+#pragma unroll
+    for (int j = 1; j < 4; j++) {
+      if (shf[j][1] > ybest || (shf[j][1] == ybest && shi[j][0] >= 0 && (yi < 0 || shi[j][0] < yi))) { ybest = shf[j][1]; yi = shi[j][0]; }
+      if (shf[j][2] > tbest || (shf[j][2] == tbest && shi[j][1] >= 0 && (ti < 0 || shi[j][1] < ti))) { tbest = shf[j][2]; ti = shi[j][1]; }
+    }
+    __syncthreads();
+    const float wr = fw[r] * tsum;  // frames with sum(t) == 0 are switched off (nnet-loss.cc:80-85)
+    double xe = 0.0, en = 0.0, lk = 0.0;
+#pragma unroll
+    for (int k = 0; k < kXentPerThread; k++) {
+      int c = tid + k * 256;
+      if (c < cols) {
+        float yy = yv[k], tt = tv[k];
+        diff[(long)r * ldd + c] = (yy - tt) * wr;
+        if (tt != 0.0f) {  // t == 0 terms are exactly 0 (t*log(...) with finite log)
+          xe += (double)(logf(yy + 1e-20f) * tt * wr);
+          en += (double)(logf(tt + 1e-20f) * tt * wr);
+          lk += (double)(yy * tt * wr);
+        }
+      }
+    }
+    xe = wave_sum_d(xe); en = wave_sum_d(en); lk = wave_sum_d(lk);
+    __shared__ double shd[4][3];
+    if (lane == 0) { shd[w][0] = xe; shd[w][1] = en; shd[w][2] = lk; }
+    __syncthreads();
+    if (tid == 0) {
+      double *rs = rowstats + (long)r * 5;
+      rs[0] = (double)wr;
+      rs[1] = (double)wr * (yi == ti ? 1.0 : 0.0);
+      rs[2] = shd[0][0] + shd[1][0] + shd[2][0] + shd[3][0];
+      rs[3] = shd[0][1] + shd[1][1] + shd[2][1] + shd[3][1];
+      rs[4] = shd[0][2] + shd[1][2] + shd[2][2] + shd[3][2];
+    }
+    __syncthreads();
+  }
+}
+
+// stats[0..4] += {frames, correct, xent, entropy, likelihood}; fixed-order sum over rows
+__global__ void __launch_bounds__(256) xent_finalize_kernel(const double *rowstats, int rows, double *stats) {
+  __shared__ double sh[4][5];
+  double a[5] = {0, 0, 0, 0, 0};
+  for (int r = threadIdx.x; r < rows; r += 256)
+#pragma unroll
+    for (int k = 0; k < 5; k++) a[k] += rowstats[(long)r * 5 + k];
+#pragma unroll
+  for (int k = 0; k < 5; k++) a[k] = wave_sum_d(a[k]);
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int k = 0; k < 5; k++) sh[threadIdx.x >> 6][k] = a[k];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s[5];
+    for (int k = 0; k < 5; k++) s[k] = sh[0][k] + sh[1][k] + sh[2][k] + sh[3][k];
+    stats[0] += s[0];
+    stats[1] += s[1];
+    stats[2] += -s[2];
+    stats[3] += -s[3];
+    stats[4] += s[4];
+  }
+}
+
+}  // namespace
+}  // namespace aslp
+
+using namespace aslp;
+
+extern "C" {
+
+void aslp_bn_forward(const float *in, MatrixDim d, float *out, int out_stride, float *xhat, int xhat_stride, const float *scale,
+                     const float *shift, float *mean, float *inv_std, double *acc_means, double *acc_vars, float var_floor) {
+  if (d.rows <= 0 || d.cols <= 0) return;
+  const float invB = 1.0f / (float)d.rows;
+  colreduce<2, double>("bn_forward.sum", d.rows, d.cols, BnSum1F{in, d.stride}, BnSum1G{invB, mean, acc_means, acc_vars});
+  colreduce<1, float>("bn_forward.var", d.rows, d.cols, BnSum2F{in, d.stride, mean}, BnSum2G{invB, var_floor, inv_std}, kScratchReduce2);
+  bool vec = d.cols % 4 == 0 && d.stride % 4 == 0 && out_stride % 4 == 0 && (!xhat || xhat_stride % 4 == 0) && aligned16(in) &&
+             aligned16(out) && (!xhat || aligned16(xhat)) && aligned16(mean) && aligned16(inv_std) && aligned16(scale) && aligned16(shift);
+  long n = (long)d.rows * (vec ? d.cols / 4 : d.cols);
+  if (vec) hipLaunchKernelGGL((bn_normalize_kernel<true>), dim3(grid_for(n)), dim3(kBlock), 0, cur_stream(), in, d.stride, out, out_stride, xhat, xhat_stride, mean, inv_std, scale, shift, d.rows, d.cols);
+  else hipLaunchKernelGGL((bn_normalize_kernel<false>), dim3(grid_for(n)), dim3(kBlock), 0, cur_stream(), in, d.stride, out, out_stride, xhat, xhat_stride, mean, inv_std, scale, shift, d.rows, d.cols);
+  check_launch("bn_forward");
+}
+
+void aslp_bn_apply(const float *in, MatrixDim d, float *out, int out_stride, const float *mean, const float *inv_std, const float *scale, const float *shift) {
+  if (d.rows <= 0 || d.cols <= 0) return;
+  long n = (long)d.rows * d.cols;
+  hipLaunchKernelGGL((bn_normalize_kernel<false>), dim3(grid_for(n)), dim3(kBlock), 0, cur_stream(), in, d.stride, out, out_stride, (float *)nullptr, 0, mean, inv_std, scale, shift, d.rows, d.cols);
+  check_launch("bn_apply");
+}
+
+void aslp_bn_backward(const float *in, MatrixDim d, const float *out_diff, int od_stride, float *xhat, int xhat_stride, const float *scale,
+                      const float *mean, const float *inv_std, float *dscale, float *dshift, float momentum, float *in_diff, int id_stride) {
+  (void)in; (void)mean;  // (x - mean) is recovered as xhat / inv_std: saves one pass over `in`
+  if (d.rows <= 0 || d.cols <= 0) return;
+  float *s12 = static_cast<float *>(scratch(kScratchReduce2, sizeof(float) * 2 * (size_t)d.cols));
+  if (!s12) return;
+  colreduce<2, float>("bn_backward.stats", d.rows, d.cols, BnBwdF{out_diff, od_stride, xhat, xhat_stride},
+                      BnBwdG{momentum, dscale, dshift, s12, s12 + d.cols});
+  if (!in_diff) return;
+  long n = (long)d.rows * d.cols;
+  bool vec = d.cols % 4 == 0 && od_stride % 4 == 0 && xhat_stride % 4 == 0 && id_stride % 4 == 0 && aligned16(out_diff) &&
+             aligned16(xhat) && aligned16(in_diff) && aligned16(scale) && aligned16(inv_std) && aligned16(s12);
+  if (vec) hipLaunchKernelGGL((bn_backward_kernel<true>), dim3(grid_for(n / 4)), dim3(kBlock), 0, cur_stream(), out_diff, od_stride, xhat, xhat_stride, scale, inv_std, s12, s12 + d.cols, in_diff, id_stride, d.rows, d.cols);
+  else hipLaunchKernelGGL((bn_backward_kernel<false>), dim3(grid_for(n)), dim3(kBlock), 0, cur_stream(), out_diff, od_stride, xhat, xhat_stride, scale, inv_std, s12, s12 + d.cols, in_diff, id_stride, d.rows, d.cols);
+  check_launch("bn_backward");
+}
+
+void aslp_xent_eval(const float *net_out, MatrixDim d, const float *tgt, int tgt_stride, const int32_cuda *labels, const float *frame_weights,
+                    float *diff, int diff_stride, double *stats_dev) {
+  if (d.rows <= 0 || d.cols <= 0) return;
+  if (d.cols > 256 * kXentPerThread) { set_error("aslp_xent_eval: more than 8192 output classes not supported"); return; }
+  if (!tgt && !labels) { set_error("aslp_xent_eval: need dense targets or labels"); return; }
+  double *rowstats = static_cast<double *>(scratch(kScratchReduce, sizeof(double) * 5 * (size_t)d.rows));
+  if (!rowstats) return;
+  int g = d.rows > kMaxGrid * 2 ? kMaxGrid * 2 : d.rows;
+  if (tgt) hipLaunchKernelGGL((xent_rows_kernel<true>), dim3(g), dim3(256), 0, cur_stream(), net_out, d.stride, tgt, tgt_stride, labels, frame_weights, diff, diff_stride, d.rows, d.cols, rowstats);
+  else hipLaunchKernelGGL((xent_rows_kernel<false>), dim3(g), dim3(256), 0, cur_stream(), net_out, d.stride, tgt, tgt_stride, labels, frame_weights, diff, diff_stride, d.rows, d.cols, rowstats);
+  hipLaunchKernelGGL(xent_finalize_kernel, dim3(1), dim3(256), 0, cur_stream(), rowstats, d.rows, stats_dev);
+  check_launch("xent_eval");
+}
+
+}  // extern "C"

@@ -1,0 +1,112 @@
+"""torch.Tensor wrappers over the kernel C ABI (B1/B2).  Tensors must live on the GPU; the
+wrappers only extract (pointer, rows, cols, stride) -- all arithmetic happens in
+libaslp_hip.so.  Used by tests/, bench.py and the Python mirror of the sync workers."""
+import ctypes as C
+
+import torch
+
+from ._lib import lib, MatrixDim, Dim3, GemmEpilogue, D3, check_error
+
+
+def _chk(t, dtype=torch.float32):
+    if not t.is_cuda:
+        raise RuntimeError("aslp ops need device tensors (no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError("expected %s, got %s" % (dtype, t.dtype))
+    if t.dim() == 2 and t.stride(1) != 1:
+        raise ValueError("matrix must be row-major with unit column stride")
+    return t
+
+
+def dim(t):
+    """MatrixDim of a 2-D row-major tensor (or view with stride >= cols)."""
+    if t.dim() == 1:
+        return MatrixDim(1, t.shape[0], t.shape[0])
+    return MatrixDim(t.shape[0], t.shape[1], t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1]))
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def use_torch_stream():
+    """Enqueue library kernels on torch's current stream (so torch.cuda.Event sees them)."""
+    lib.aslp_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream))
+
+
+def sgemm(transA, transB, alpha, A, B, beta, Cm, epilogue=None):
+    """C = alpha*op(A)*op(B) + beta*C (cu-matrix.cc:1027-1061 semantics)."""
+    _chk(A), _chk(B), _chk(Cm)
+    M, N = Cm.shape
+    K = A.shape[0] if transA else A.shape[1]
+    ep = C.byref(epilogue) if epilogue is not None else None
+    rc = lib.aslp_sgemm_ex(int(transA), int(transB), M, N, K, alpha, ptr(A), dim(A).stride, ptr(B), dim(B).stride,
+                           beta, ptr(Cm), dim(Cm).stride, ep)
+    if rc != 0:
+        raise ValueError("aslp_sgemm argument error %d" % rc)
+    check_error()
+
+
+def sigmoid(y, x):
+    lib.cudaF_sigmoid(D3, D3, ptr(_chk(y)), ptr(_chk(x)), dim(y), dim(x).stride); check_error()
+
+
+def tanh(y, x):
+    lib.cudaF_tanh(D3, D3, ptr(_chk(y)), ptr(_chk(x)), dim(y), dim(x).stride); check_error()
+
+
+def diff_sigmoid(eout, y, e):
+    lib.cudaF_diff_sigmoid(D3, D3, ptr(_chk(eout)), ptr(_chk(e)), ptr(_chk(y)), dim(eout), dim(e).stride, dim(y).stride); check_error()
+
+
+def diff_tanh(eout, y, e):
+    lib.cudaF_diff_tanh(D3, D3, ptr(_chk(eout)), ptr(_chk(e)), ptr(_chk(y)), dim(eout), dim(e).stride, dim(y).stride); check_error()
+
+
+def softmax(y, x):
+    lib.cudaF_softmax_reduce(0, 0, ptr(_chk(y)), ptr(_chk(x)), dim(y), dim(x).stride); check_error()
+
+
+def splice(y, x, offsets):
+    lib.cudaF_splice(D3, D3, ptr(_chk(y)), ptr(_chk(x)), ptr(_chk(offsets, torch.int32)), dim(y), dim(x)); check_error()
+
+
+def splice_backward(in_diff, out_diff, offsets):
+    lib.aslp_splice_backward(ptr(_chk(in_diff)), dim(in_diff), ptr(_chk(out_diff)), dim(out_diff).stride,
+                             ptr(_chk(offsets, torch.int32)), offsets.numel()); check_error()
+
+
+def randomize(y, x, copy_from):
+    d_out = dim(y); d_out.rows = copy_from.numel()
+    d_in = dim(x); d_in.rows = copy_from.numel()
+    lib.cudaF_randomize(D3, D3, ptr(_chk(y)), ptr(_chk(x)), ptr(_chk(copy_from, torch.int32)), d_out, d_in); check_error()
+
+
+def find_row_max_id(m):
+    out = torch.empty(m.shape[0], dtype=torch.int32, device=m.device)
+    lib.aslp_find_row_max_id(ptr(_chk(m)), dim(m), ptr(out)); check_error()
+    return out
+
+
+def add_row_sum_mat_vec(alpha, M, beta, v):
+    lib.aslp_add_row_sum_mat_vec(alpha, ptr(_chk(M)), dim(M), beta, ptr(_chk(v))); check_error()
+
+
+def bn_forward(x, out, xhat, scale, shift, mean, inv_std, acc_means=None, acc_vars=None, var_floor=1e-7):
+    lib.aslp_bn_forward(ptr(_chk(x)), dim(x), ptr(_chk(out)), dim(out).stride, ptr(_chk(xhat)), dim(xhat).stride,
+                        ptr(scale), ptr(shift), ptr(mean), ptr(inv_std), ptr(acc_means), ptr(acc_vars), var_floor)
+    check_error()
+
+
+def bn_backward(x, dy, xhat, scale, mean, inv_std, dscale, dshift, momentum, in_diff):
+    lib.aslp_bn_backward(ptr(_chk(x)), dim(x), ptr(_chk(dy)), dim(dy).stride, ptr(_chk(xhat)), dim(xhat).stride,
+                         ptr(scale), ptr(mean), ptr(inv_std), ptr(dscale), ptr(dshift), momentum,
+                         ptr(in_diff), dim(in_diff).stride if in_diff is not None else 0)
+    check_error()
+
+
+def xent_eval(net_out, frame_weights, diff, stats, targets=None, labels=None):
+    lib.aslp_xent_eval(ptr(_chk(net_out)), dim(net_out), ptr(targets), dim(targets).stride if targets is not None else 0,
+                       ptr(labels), ptr(_chk(frame_weights)), ptr(_chk(diff)), dim(diff).stride,
+                       ptr(_chk(stats, torch.float64)))
+    check_error()

@@ -1,0 +1,136 @@
+/*
+ * aslp_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * A plain-C CPU restatement of the reference's (robin1001/kaldi-aslp) CPU
+ * ("matrix/ + BLAS") path for the aslp-nnet training step.  It exists so the
+ * HIP product path can be checked against it.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may link / load this library; the product
+ * (kaldi-aslp_amd/) never does.
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - CTC (orc_ctc_*): pinned against the reference's own Warp-CTC CPU code built
+ *     from /root/reference into oracle/_ref/ and against the known-answer vectors of
+ *     src/warp-ctc/tests/test_cpu.cpp.
+ *   - substrate ops: pinned against the closed-form expectations the reference's
+ *     unit tests hold (aslp-cudamatrix/cu-matrix-test.cc, cu-math-test.cc).
+ *   - Component / Nnet level (Affine, BN, LSTM family, FSMN, ...): the reference has
+ *     no tests and its Kaldi core cannot be built here without stand-ins for BLAS /
+ *     OpenFst, so for those rows: PARITY UNPINNED (restated from source, cited per fn).
+ *
+ * All matrices are row-major float with an explicit leading dimension (stride) in
+ * elements; "rows = frames".  Each function cites the reference file:line it follows
+ * (paths relative to /root/reference/src).
+ */
+#ifndef ASLP_ORACLE_H_
+#define ASLP_ORACLE_H_
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- substrate (aslp-cudamatrix CPU branches -> matrix/) ------------------------- */
+
+/* C = alpha*op(A)*op(B) + beta*C.  cu-matrix.cc:1027-1061 -> cblas_sgemm.
+ * M,N = dims of C; K = inner dim; transX != 0 means op(X) = X^T. */
+void orc_add_mat_mat(float *C, int M, int N, int ldc, float alpha,
+                     const float *A, int lda, int transA,
+                     const float *B, int ldb, int transB, int K, float beta);
+void orc_set_num_threads(int n);   /* OpenMP threads used by orc_add_mat_mat */
+int  orc_get_num_threads(void);
+
+void orc_sigmoid(float *y, int ldy, const float *x, int ldx, int rows, int cols);      /* matrix/kaldi-vector.cc:923-936 */
+void orc_tanh(float *y, int ldy, const float *x, int ldx, int rows, int cols);         /* matrix/kaldi-vector.cc:885-898 */
+void orc_diff_sigmoid(float *eout, int ldo, const float *y, int ldy, const float *e, int lde, int rows, int cols); /* cu-matrix.cc:1399 -> eout = y(1-y)e */
+void orc_diff_tanh(float *eout, int ldo, const float *y, int ldy, const float *e, int lde, int rows, int cols);    /* cu-matrix.cc:1445 -> eout = (1-y^2)e */
+void orc_softmax_rows(float *y, int ldy, const float *x, int ldx, int rows, int cols); /* cu-matrix.cc:1351-1371, kaldi-vector.cc:852-859 */
+void orc_find_row_max_id(const float *m, int ld, int rows, int cols, int32_t *id);     /* cu-matrix.cc:1466-1510 */
+void orc_splice(float *y, int ldy, const float *x, int ldx, int rows, int in_cols,
+                const int32_t *offsets, int n_off);                                    /* cu-math.cc:132-168 */
+void orc_copy_cols(float *y, int ldy, const float *x, int ldx, int rows,
+                   const int32_t *copy_from, int out_cols);                            /* cu-math.cc:173-210 (cu::Copy) */
+void orc_randomize(float *y, int ldy, const float *x, int ldx, int cols,
+                   const int32_t *copy_from, int n_idx);                               /* cu-math.cc:80-127 */
+void orc_add_row_sum_mat(float *dst, int ldd, int dst_rows, int cols, const float *src,
+                         int lds, int src_rows, float alpha, float beta);              /* cu-matrix.cc:3010-3034 (ASLP) */
+void orc_add_conv_mat_mat_elements(float *dst, int ldd, int cols, const float *A, int lda,
+                                   int a_rows, const float *B, int ldb, int b_rows,
+                                   float alpha, float beta);                           /* cu-matrix.cc:3037-3073 (ASLP) */
+void orc_regularize_l1(float *w, int ldw, float *g, int ldg, int rows, int cols, float l1, float lr); /* cu-math.cc:37-75 */
+
+/* ---- components (aslp-nnet) ------------------------------------------------------- */
+
+/* AffineTransform, nnet-affine-transform.h:186-245 */
+void orc_affine_propagate(float *out, int ldo, const float *in, int ldi, int rows,
+                          const float *W, int ldw, const float *bias, int in_dim, int out_dim);
+void orc_affine_backpropagate(float *in_diff, int ldid, const float *out_diff, int ldod, int rows,
+                              const float *W, int ldw, int in_dim, int out_dim);
+typedef struct {
+  float learn_rate, momentum, l2_penalty, l1_penalty;       /* nnet-trnopts.h:29-47 */
+  float learn_rate_coef, bias_learn_rate_coef, max_norm;    /* nnet-affine-transform.h:37-40 */
+} orc_affine_opts;
+void orc_affine_update(float *W, int ldw, float *bias, float *W_corr, int ldc, float *bias_corr,
+                       const float *input, int ldi, const float *diff, int ldd, int rows,
+                       int in_dim, int out_dim, const orc_affine_opts *o);
+
+/* ReLU, nnet-activation.h:281-298 */
+void orc_relu(float *y, int ldy, const float *x, int ldx, int rows, int cols);
+void orc_diff_relu(float *in_diff, int ldo, const float *in, int ldi, const float *out_diff, int lde, int rows, int cols);
+
+/* Splice backward quirk (gather with +offset, not the adjoint), nnet-various.h:143-175 */
+void orc_splice_backpropagate(float *in_diff, int ldid, const float *out_diff, int ldod, int rows,
+                              int in_cols, const int32_t *offsets, int n_off);
+
+/* BatchNormalization, nnet-batch-normalization.h:139-284.
+ * State that the component keeps between calls is passed explicitly. */
+typedef struct {
+  int dim;
+  float *scale, *shift;          /* gamma, beta                                   */
+  float *dscale, *dshift;        /* momentum-carrying gradient buffers             */
+  float *mean_vec, *var_vec;     /* batch mean; 1/sqrt(var+1e-7) ("var_vec_")      */
+  double *acc_means, *acc_vars;  /* running sums (double), :218-220                */
+  double num_acc_frames;
+  int acc_cleaned;               /* :178-181 first Propagate of the process clears */
+} orc_bn_state;
+void orc_bn_propagate(orc_bn_state *s, float *out, int ldo, const float *in, int ldi, int rows,
+                      float *xsharp /* rows x dim, ld = dim: XsharpO_ */);
+void orc_bn_backpropagate(orc_bn_state *s, float *in_diff, int ldid, const float *in, int ldi,
+                          const float *out_diff, int ldod, int rows, float momentum,
+                          float *xsharp /* in: xhat from propagate; out: dy*gamma (:241-242) */);
+void orc_bn_update(orc_bn_state *s, float learn_rate);                      /* :280-284 */
+/* inference path with global stats, :139-175 + ReadData :56-94 */
+void orc_bn_feedforward(orc_bn_state *s, float *out, int ldo, const float *in, int ldi, int rows);
+void orc_bn_global_stats_from_acc(orc_bn_state *s);                         /* ReadData :73-93 */
+
+/* Xent::Eval, nnet-loss.cc:63-156.  targets dense [rows x cols]. */
+typedef struct {
+  double frames, correct, loss, entropy, likelyhood;   /* per-call increments */
+} orc_xent_stats;
+void orc_xent_eval(const float *frame_weights, const float *net_out, int ldn, const float *targets,
+                   int ldt, int rows, int cols, float *diff, int ldd, orc_xent_stats *st);
+/* Mse::Eval, nnet-loss.cc:205-258 */
+void orc_mse_eval(const float *frame_weights, const float *net_out, int ldn, const float *targets,
+                  int ldt, int rows, int cols, float *diff, int ldd, double *loss, double *frames);
+
+/* ---- whole DNN train step for bench.py's cpu_baseline ("port") -------------------- */
+/* Chain: [Affine (+BN) + Sigmoid] x n_hidden, Affine, Softmax, Xent, backward with
+ * immediate Update in reference order (nnet-nnet.cc:70-154).  Buffers are owned by
+ * the caller through an opaque handle. */
+typedef struct orc_dnn orc_dnn;
+orc_dnn *orc_dnn_create(int in_dim, int hidden_dim, int n_hidden, int out_dim, int with_bn,
+                        int minibatch, unsigned seed);
+void orc_dnn_destroy(orc_dnn *d);
+/* one step on a resident minibatch; returns cross-entropy of the batch */
+double orc_dnn_train_step(orc_dnn *d, const float *in, const int32_t *labels, float learn_rate,
+                          float momentum);
+/* accessors so tests can compare the C chain with the HIP engine on shared weights */
+int  orc_dnn_num_layers(const orc_dnn *d);                 /* affine layers */
+float *orc_dnn_weight(orc_dnn *d, int layer, int *rows, int *cols);
+float *orc_dnn_bias(orc_dnn *d, int layer);
+float *orc_dnn_bn_scale(orc_dnn *d, int layer);
+float *orc_dnn_bn_shift(orc_dnn *d, int layer);
+const float *orc_dnn_output(const orc_dnn *d);             /* softmax output [mb x out] */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,36 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle_lib
+    return oracle_lib
+
+
+@pytest.fixture(scope="session")
+def aslp():
+    """The product package (libaslp_hip.so via ctypes). Fails loudly if not built."""
+    import aslp_import
+    return aslp_import.load()
+
+
+@pytest.fixture(scope="session")
+def dev():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import aslp_import
+    aslp_import.load().ops.use_torch_stream()
+    return torch.device("cuda:0")

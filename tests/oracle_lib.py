@@ -1,0 +1,182 @@
+"""ctypes/numpy binding of oracle/_build/libaslp_oracle.so (the CPU restatement of the
+reference) and oracle/_ref/libwarpctc_ref.so (the reference's own Warp-CTC CPU code).
+TEST INFRASTRUCTURE: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline use it."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ODIR = os.path.join(ROOT, "oracle")
+SO = os.path.join(ODIR, "_build", "libaslp_oracle.so")
+REF_CTC_SO = os.path.join(ODIR, "_ref", "libwarpctc_ref.so")
+
+
+def build(force=False):
+    srcs = [os.path.join(ODIR, f) for f in os.listdir(ODIR) if f.endswith((".c", ".h"))]
+    stale = (not os.path.exists(SO)) or any(os.path.getmtime(s) > os.path.getmtime(SO) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", ODIR], stdout=subprocess.DEVNULL)
+    if os.path.isdir("/root/reference/src/warp-ctc") and not os.path.exists(REF_CTC_SO):
+        subprocess.check_call(["make", "-C", ODIR, "ref"], stdout=subprocess.DEVNULL)
+
+
+build()
+lib = C.CDLL(SO)
+f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+_i, _f = C.c_int, C.c_float
+
+
+def _sig(name, restype, *args):
+    fn = getattr(lib, name)
+    fn.restype = restype
+    fn.argtypes = list(args)
+    return fn
+
+
+_sig("orc_add_mat_mat", None, f32p, _i, _i, _i, _f, f32p, _i, _i, f32p, _i, _i, _i, _f)
+_sig("orc_set_num_threads", None, _i)
+_sig("orc_get_num_threads", _i)
+for n in ("orc_sigmoid", "orc_tanh", "orc_softmax_rows", "orc_relu"):
+    _sig(n, None, f32p, _i, f32p, _i, _i, _i)
+for n in ("orc_diff_sigmoid", "orc_diff_tanh", "orc_diff_relu"):
+    _sig(n, None, f32p, _i, f32p, _i, f32p, _i, _i, _i)
+_sig("orc_find_row_max_id", None, f32p, _i, _i, _i, i32p)
+_sig("orc_splice", None, f32p, _i, f32p, _i, _i, _i, i32p, _i)
+_sig("orc_splice_backpropagate", None, f32p, _i, f32p, _i, _i, _i, i32p, _i)
+_sig("orc_copy_cols", None, f32p, _i, f32p, _i, _i, i32p, _i)
+_sig("orc_randomize", None, f32p, _i, f32p, _i, _i, i32p, _i)
+_sig("orc_add_row_sum_mat", None, f32p, _i, _i, _i, f32p, _i, _i, _f, _f)
+_sig("orc_add_conv_mat_mat_elements", None, f32p, _i, _i, f32p, _i, _i, f32p, _i, _i, _f, _f)
+_sig("orc_regularize_l1", None, f32p, _i, f32p, _i, _i, _i, _f, _f)
+_sig("orc_affine_propagate", None, f32p, _i, f32p, _i, _i, f32p, _i, f32p, _i, _i)
+_sig("orc_affine_backpropagate", None, f32p, _i, f32p, _i, _i, f32p, _i, _i, _i)
+
+
+class AffineOpts(C.Structure):
+    _fields_ = [(n, _f) for n in ("learn_rate", "momentum", "l2_penalty", "l1_penalty", "learn_rate_coef",
+                                  "bias_learn_rate_coef", "max_norm")]
+
+
+_sig("orc_affine_update", None, f32p, _i, f32p, f32p, _i, f32p, f32p, _i, f32p, _i, _i, _i, _i, C.POINTER(AffineOpts))
+
+
+class BnState(C.Structure):
+    _fields_ = [("dim", _i), ("scale", C.c_void_p), ("shift", C.c_void_p), ("dscale", C.c_void_p),
+                ("dshift", C.c_void_p), ("mean_vec", C.c_void_p), ("var_vec", C.c_void_p),
+                ("acc_means", C.c_void_p), ("acc_vars", C.c_void_p), ("num_acc_frames", C.c_double),
+                ("acc_cleaned", _i)]
+
+
+_sig("orc_bn_propagate", None, C.POINTER(BnState), f32p, _i, f32p, _i, _i, f32p)
+_sig("orc_bn_backpropagate", None, C.POINTER(BnState), f32p, _i, f32p, _i, f32p, _i, _i, _f, f32p)
+_sig("orc_bn_update", None, C.POINTER(BnState), _f)
+_sig("orc_bn_feedforward", None, C.POINTER(BnState), f32p, _i, f32p, _i, _i)
+_sig("orc_bn_global_stats_from_acc", None, C.POINTER(BnState))
+
+
+class XentStats(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("frames", "correct", "loss", "entropy", "likelyhood")]
+
+
+_sig("orc_xent_eval", None, f32p, f32p, _i, f32p, _i, _i, _i, f32p, _i, C.POINTER(XentStats))
+_sig("orc_mse_eval", None, f32p, f32p, _i, f32p, _i, _i, _i, f32p, _i, C.POINTER(C.c_double), C.POINTER(C.c_double))
+_sig("orc_dnn_create", C.c_void_p, _i, _i, _i, _i, _i, _i, C.c_uint)
+_sig("orc_dnn_destroy", None, C.c_void_p)
+_sig("orc_dnn_train_step", C.c_double, C.c_void_p, f32p, i32p, _f, _f)
+_sig("orc_dnn_num_layers", _i, C.c_void_p)
+_sig("orc_dnn_weight", C.POINTER(_f), C.c_void_p, _i, C.POINTER(_i), C.POINTER(_i))
+_sig("orc_dnn_bias", C.POINTER(_f), C.c_void_p, _i)
+_sig("orc_dnn_bn_scale", C.POINTER(_f), C.c_void_p, _i)
+_sig("orc_dnn_bn_shift", C.POINTER(_f), C.c_void_p, _i)
+_sig("orc_dnn_output", C.POINTER(_f), C.c_void_p)
+
+
+def c32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+# ---- numpy-level helpers (always contiguous, stride = cols) -------------------------------
+def add_mat_mat(Cm, alpha, A, transA, B, transB, beta):
+    Cm = c32(Cm).copy(); A = c32(A); B = c32(B)
+    M, N = Cm.shape
+    K = A.shape[0] if transA else A.shape[1]
+    lib.orc_add_mat_mat(Cm, M, N, N, alpha, A, A.shape[1], int(transA), B, B.shape[1], int(transB), K, beta)
+    return Cm
+
+
+def unary(name, x):
+    x = c32(x); y = np.empty_like(x)
+    getattr(lib, name)(y, x.shape[1], x, x.shape[1], x.shape[0], x.shape[1])
+    return y
+
+
+def binary(name, a, b):
+    """orc_diff_*(eout, y|in, e|out_diff)"""
+    a = c32(a); b = c32(b); o = np.empty_like(a)
+    getattr(lib, name)(o, a.shape[1], a, a.shape[1], b, b.shape[1], a.shape[0], a.shape[1])
+    return o
+
+
+def splice(x, offsets):
+    x = c32(x); off = np.ascontiguousarray(offsets, dtype=np.int32)
+    y = np.empty((x.shape[0], x.shape[1] * len(off)), np.float32)
+    lib.orc_splice(y, y.shape[1], x, x.shape[1], x.shape[0], x.shape[1], off, len(off))
+    return y
+
+
+def splice_backprop(out_diff, in_cols, offsets):
+    od = c32(out_diff); off = np.ascontiguousarray(offsets, dtype=np.int32)
+    idf = np.empty((od.shape[0], in_cols), np.float32)
+    lib.orc_splice_backpropagate(idf, in_cols, od, od.shape[1], od.shape[0], in_cols, off, len(off))
+    return idf
+
+
+def find_row_max_id(m):
+    m = c32(m); out = np.empty(m.shape[0], np.int32)
+    lib.orc_find_row_max_id(m, m.shape[1], m.shape[0], m.shape[1], out)
+    return out
+
+
+class Bn:
+    """Holds the state arrays of one BatchNormalization component for the oracle."""
+
+    def __init__(self, dim):
+        self.dim = dim
+        self.scale = np.ones(dim, np.float32); self.shift = np.zeros(dim, np.float32)
+        self.dscale = np.zeros(dim, np.float32); self.dshift = np.zeros(dim, np.float32)
+        self.mean = np.zeros(dim, np.float32); self.var = np.zeros(dim, np.float32)
+        self.acc_means = np.zeros(dim, np.float64); self.acc_vars = np.zeros(dim, np.float64)
+        self.st = BnState(dim, self.scale.ctypes.data, self.shift.ctypes.data, self.dscale.ctypes.data,
+                          self.dshift.ctypes.data, self.mean.ctypes.data, self.var.ctypes.data,
+                          self.acc_means.ctypes.data, self.acc_vars.ctypes.data, 0.0, 0)
+        self.xs = None
+
+    def propagate(self, x):
+        x = c32(x); out = np.empty_like(x); self.xs = np.empty_like(x)
+        lib.orc_bn_propagate(C.byref(self.st), out, x.shape[1], x, x.shape[1], x.shape[0], self.xs)
+        return out
+
+    def backpropagate(self, x, dy, momentum):
+        x = c32(x); dy = c32(dy); idf = np.empty_like(x)
+        lib.orc_bn_backpropagate(C.byref(self.st), idf, x.shape[1], x, x.shape[1], dy, dy.shape[1], x.shape[0], momentum, self.xs)
+        return idf
+
+    def update(self, lr):
+        lib.orc_bn_update(C.byref(self.st), lr)
+
+
+def xent_eval(fw, net_out, tgt):
+    fw = c32(fw); y = c32(net_out); t = c32(tgt); diff = np.empty_like(y); st = XentStats()
+    lib.orc_xent_eval(fw, y, y.shape[1], t, t.shape[1], y.shape[0], y.shape[1], diff, y.shape[1], C.byref(st))
+    return diff, dict(frames=st.frames, correct=st.correct, loss=st.loss, entropy=st.entropy, likelyhood=st.likelyhood)
+
+
+def rel_err(a, b):
+    """relative Frobenius error, the reference's AssertEqual metric (cu-matrix.h:803-811)"""
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    den = np.linalg.norm(b)
+    return float(np.linalg.norm(a - b) / den) if den > 0 else float(np.linalg.norm(a - b))

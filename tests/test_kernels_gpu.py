@@ -1,0 +1,308 @@
+"""GPU parity: every substrate kernel of libaslp_hip.so (called through the C ABI) against the
+CPU oracle on the same seeded inputs.  Mirrors the reference's CPU-vs-device differential
+tests (aslp-cudamatrix/cu-matrix-test.cc:2605-2636, cu-math-test.cc).  Tolerances: bit-exact
+for index/copy ops; 1e-4 relative (BASELINE.json north_star) for fp32 math -- most ops are
+far tighter and assert 1e-5/1e-6."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4  # north_star: fp32 within 1e-4 relative
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def strided(rows, cols, stride, dev, fill=None):
+    """A [rows x cols] view into a wider buffer, like the reference's pitched CuMatrix."""
+    buf = torch.full((rows, stride), float("nan"), device=dev)
+    v = buf[:, :cols]
+    if fill is not None:
+        v.copy_(T(fill, dev))
+    return v
+
+
+@pytest.mark.parametrize("rows,cols,stride", [(100, 111, 111), (100, 112, 128), (1, 1, 1), (257, 2048, 2048)])
+def test_sigmoid_tanh_and_diffs(aslp, oracle, dev, rows, cols, stride):
+    rng = np.random.default_rng(1)
+    x = (rng.standard_normal((rows, cols)) * 4).astype(np.float32)
+    e = rng.standard_normal((rows, cols)).astype(np.float32)
+    xd = strided(rows, cols, stride, dev, x)
+    for name, dname in (("sigmoid", "diff_sigmoid"), ("tanh", "diff_tanh")):
+        y = strided(rows, cols, stride, dev)
+        getattr(aslp.ops, name)(y, xd)
+        ref = oracle.unary("orc_" + name, x)
+        assert oracle.rel_err(y.cpu().numpy(), ref) < 1e-6
+        # the reference's UnitTestCuSigmoid closed form (cu-matrix-test.cc:1925-1948)
+        if name == "sigmoid":
+            assert oracle.rel_err(y.cpu().numpy(), 1.0 / (1.0 + np.exp(-x.astype(np.float64)))) < 1e-6
+        eo = strided(rows, cols, stride, dev)
+        getattr(aslp.ops, dname)(eo, y, T(e, dev))
+        dref = oracle.binary("orc_" + dname, y.cpu().numpy(), e)
+        assert oracle.rel_err(eo.cpu().numpy(), dref) < 1e-6
+
+
+def test_sigmoid_extremes_no_nan(aslp, dev):
+    x = torch.tensor([[-1e4, -100.0, -88.0, 0.0, 88.0, 100.0, 1e4, float("inf")]], device=dev)
+    y = torch.empty_like(x)
+    aslp.ops.sigmoid(y, x)
+    assert torch.isfinite(y).all() and y[0, 0] == 0 and y[0, -2] == 1
+    aslp.ops.tanh(y, x)
+    assert torch.isfinite(y).all() and y[0, 0] == -1 and y[0, -2] == 1
+
+
+@pytest.mark.parametrize("rows,cols", [(37, 10), (49, 59), (64, 128), (33, 513), (1024, 3000), (3, 9000)])
+def test_softmax(aslp, oracle, dev, rows, cols):
+    rng = np.random.default_rng(2)
+    x = (rng.standard_normal((rows, cols)) * 5).astype(np.float32)  # UnitTestCuSoftmax scales by 5
+    y = torch.empty(rows, cols, device=dev)
+    aslp.ops.softmax(y, T(x, dev))
+    ref = oracle.unary("orc_softmax_rows", x)
+    assert oracle.rel_err(y.cpu().numpy(), ref) < 1e-5  # the reference's own bar (cu-matrix-test.cc:2009)
+    assert np.allclose(y.sum(1).cpu().numpy(), 1.0, atol=1e-5)
+
+
+@pytest.mark.parametrize("rows,in_cols,offs", [(7, 5, [-2, 0, 3]), (300, 40, list(range(-5, 6))), (1, 8, [-1, 1]),
+                                                 (129, 24, [0]), (200, 13, [-199, 250, 0, 0])])
+def test_splice_bit_exact(aslp, oracle, dev, rows, in_cols, offs):
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((rows, in_cols)).astype(np.float32)
+    off = np.asarray(offs, np.int32)
+    y = torch.empty(rows, in_cols * len(offs), device=dev)
+    aslp.ops.splice(y, T(x, dev), T(off, dev))
+    assert np.array_equal(y.cpu().numpy(), oracle.splice(x, off))  # bit-exact
+    # reference unit test's expectation (cu-math-test.cc:123-138): clamped row copy
+    for k, o in enumerate(offs):
+        src = np.clip(np.arange(rows) + o, 0, rows - 1)
+        assert np.array_equal(y.cpu().numpy()[:, k * in_cols:(k + 1) * in_cols], x[src])
+    od = rng.standard_normal((rows, in_cols * len(offs))).astype(np.float32)
+    idf = torch.empty(rows, in_cols, device=dev)
+    aslp.ops.splice_backward(idf, T(od, dev), T(off, dev))
+    ref = oracle.splice_backprop(od, in_cols, off)
+    assert oracle.rel_err(idf.cpu().numpy(), ref) < 1e-6
+
+
+def test_randomize_bit_exact(aslp, oracle, dev):
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((500, 440)).astype(np.float32)
+    idx = rng.permutation(500).astype(np.int32)[:300]
+    y = torch.zeros(500, 440, device=dev)
+    aslp.ops.randomize(y, T(x, dev), T(idx, dev))
+    assert np.array_equal(y.cpu().numpy()[:300], x[idx])
+    assert (y[300:] == 0).all()
+
+
+@pytest.mark.parametrize("rows,cols", [(150, 233), (4, 3), (1024, 3000), (5, 600)])
+def test_find_row_max_id(aslp, oracle, dev, rows, cols):
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((rows, cols)).astype(np.float32)
+    x[0, :] = 0.5  # all ties: first index wins (cu-matrix.cc:1500-1505 strict '<')
+    if cols > 300:
+        x[1, 7] = x[1, 299] = 9.0
+    ids = aslp.ops.find_row_max_id(T(x, dev)).cpu().numpy()
+    assert np.array_equal(ids, oracle.find_row_max_id(x))
+    assert ids[0] == 0
+    # running per-256-column form with the reference's call pattern (cu-matrix.cc:1480-1499)
+    xd = T(x, dev)
+    val = torch.full((rows,), -1e21, device=dev)
+    idt = torch.full((rows,), -1, dtype=torch.int32, device=dev)
+    d = aslp.ops.dim(xd)
+    for blk in range(cols // 256):
+        aslp.lib.cudaF_find_row_max_id(aslp.Dim3(1, rows, 1), aslp.Dim3(256, 1, 1), C.c_void_p(xd.data_ptr() + 4 * 256 * blk),
+                                       aslp.ops.ptr(val), aslp.ops.ptr(idt), 256 * blk, d)
+    if cols % 256:
+        off = (cols // 256) * 256
+        aslp.lib.cudaF_find_row_max_id(aslp.Dim3(1, rows, 1), aslp.Dim3(cols % 256, 1, 1), C.c_void_p(xd.data_ptr() + 4 * off),
+                                       aslp.ops.ptr(val), aslp.ops.ptr(idt), off, d)
+    aslp.check_error()
+    assert np.array_equal(idt.cpu().numpy(), ids)
+
+
+GEMM_SHAPES = [
+    # (M, N, K)
+    (37, 41, 29), (1, 1, 1), (128, 128, 16), (130, 70, 33), (256, 2048, 440), (64, 3000, 512),
+    (32, 2048, 256), (8, 64, 40), (200, 96, 1000), (1024, 512, 2048),
+]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("tA,tB", [(0, 1), (0, 0), (1, 0), (1, 1)])
+def test_sgemm_vs_oracle(aslp, oracle, dev, M, N, K, tA, tB):
+    rng = np.random.default_rng(M * 7 + N * 3 + K + tA * 2 + tB)
+    A = rng.standard_normal((K, M) if tA else (M, K)).astype(np.float32)
+    B = rng.standard_normal((N, K) if tB else (K, N)).astype(np.float32)
+    C0 = rng.standard_normal((M, N)).astype(np.float32)
+    for alpha, beta in ((1.0, 0.0), (0.7, 1.3)):
+        Cd = T(C0, dev)
+        if beta == 0.0:
+            Cd.fill_(float("nan"))  # beta == 0 must not read C
+        aslp.ops.sgemm(tA, tB, alpha, T(A, dev), T(B, dev), beta, Cd)
+        ref = oracle.add_mat_mat(C0, alpha, A, tA, B, tB, beta)
+        assert oracle.rel_err(Cd.cpu().numpy(), ref) < 2e-6, (M, N, K, tA, tB, alpha, beta)
+
+
+def test_sgemm_asymmetric_identity(aslp, dev):
+    """A = I with an asymmetric B catches a transposed C write (cdna guide G9)."""
+    n = 96
+    B = torch.arange(n * n, dtype=torch.float32, device=dev).reshape(n, n) / 100.0
+    I = torch.eye(n, device=dev)
+    Cm = torch.empty(n, n, device=dev)
+    aslp.ops.sgemm(0, 0, 1.0, I, B, 0.0, Cm)
+    assert torch.equal(Cm, B)
+    aslp.ops.sgemm(0, 1, 1.0, I, B, 0.0, Cm)
+    assert torch.equal(Cm, B.t())
+    aslp.ops.sgemm(1, 0, 1.0, B, I, 0.0, Cm)
+    assert torch.equal(Cm, B.t())
+
+
+def test_sgemm_strided_views_unaligned(aslp, oracle, dev):
+    """Sub-matrix views (ColRange/RowRange of LSTM buffers): odd column offsets force the scalar path."""
+    rng = np.random.default_rng(11)
+    big = rng.standard_normal((70, 131)).astype(np.float32)
+    W = rng.standard_normal((50, 37)).astype(np.float32)
+    bd = T(big, dev)
+    A = bd[3:3 + 60, 5:5 + 37]  # unaligned pointer, stride 131
+    out = torch.zeros(64, 77, device=dev)
+    Cv = out[2:62, 9:59]
+    aslp.ops.sgemm(0, 1, 1.0, A, T(W, dev), 0.0, Cv)
+    ref = big[3:63, 5:42] @ W.T
+    assert oracle.rel_err(Cv.cpu().numpy(), ref) < 2e-6
+    mask = torch.ones_like(out, dtype=torch.bool)
+    mask[2:62, 9:59] = False
+    assert (out[mask] == 0).all()  # nothing outside the view was touched
+
+
+def test_sgemm_epilogue(aslp, oracle, dev):
+    rng = np.random.default_rng(12)
+    M, N, K = 100, 72, 64
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = rng.standard_normal((N, K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    out = torch.empty(M, N, device=dev)
+    act = torch.empty(M, N, device=dev)
+    bd = T(b, dev)
+    ep = aslp._lib.GemmEpilogue(bd.data_ptr(), 0.0, None, 0, 0.0, act.data_ptr(), N, 1)
+    aslp.ops.sgemm(0, 1, 1.0, T(A, dev), T(W, dev), 0.0, out, ep)
+    ref = A @ W.T + b
+    assert oracle.rel_err(out.cpu().numpy(), ref) < 2e-6
+    assert oracle.rel_err(act.cpu().numpy(), oracle.unary("orc_sigmoid", out.cpu().numpy())) < 1e-6
+    # SGD epilogue: G = diff^T in + mmt*G, clipped; W += -lr*G
+    diff = rng.standard_normal((M, N)).astype(np.float32)
+    G0 = rng.standard_normal((N, K)).astype(np.float32)
+    Gd, Wd = T(G0, dev), T(W, dev)
+    ep = aslp._lib.GemmEpilogue(None, 5.0, Wd.data_ptr(), K, -0.01, None, 0, 0)
+    aslp.ops.sgemm(1, 0, 1.0, T(diff, dev), T(A, dev), 0.9, Gd, ep)
+    Gref = np.clip(diff.T @ A + 0.9 * G0, -5, 5)
+    assert oracle.rel_err(Gd.cpu().numpy(), Gref) < 2e-6
+    assert oracle.rel_err(Wd.cpu().numpy(), W - 0.01 * Gref) < 2e-6
+
+
+@pytest.mark.parametrize("rows,cols", [(8, 6), (64, 32), (1024, 2048), (100, 37), (129, 260)])
+def test_batchnorm_forward_backward(aslp, oracle, dev, rows, cols):
+    rng = np.random.default_rng(6)
+    x = (rng.standard_normal((rows, cols)) * 2 + 0.5).astype(np.float32)
+    dy = rng.standard_normal((rows, cols)).astype(np.float32)
+    bn = oracle.Bn(cols)
+    bn.scale[:] = rng.uniform(0.5, 1.5, cols)
+    bn.shift[:] = rng.standard_normal(cols)
+    bn.dscale[:] = rng.standard_normal(cols)
+    bn.dshift[:] = rng.standard_normal(cols)
+    dsc0, dsh0 = bn.dscale.copy(), bn.dshift.copy()
+    ref_out = bn.propagate(x)
+    ref_xhat = bn.xs.copy()
+    xd = T(x, dev)
+    out, xhat = torch.empty_like(xd), torch.empty_like(xd)
+    scale, shift = T(bn.scale, dev), T(bn.shift, dev)
+    mean, inv = torch.empty(cols, device=dev), torch.empty(cols, device=dev)
+    accm = torch.zeros(cols, dtype=torch.float64, device=dev)
+    accv = torch.zeros(cols, dtype=torch.float64, device=dev)
+    aslp.ops.bn_forward(xd, out, xhat, scale, shift, mean, inv, accm, accv)
+    assert oracle.rel_err(out.cpu().numpy(), ref_out) < 1e-5
+    assert oracle.rel_err(xhat.cpu().numpy(), ref_xhat) < 1e-5
+    assert oracle.rel_err(mean.cpu().numpy(), bn.mean) < 1e-5
+    assert oracle.rel_err(inv.cpu().numpy(), bn.var) < 1e-5
+    assert oracle.rel_err(accm.cpu().numpy(), bn.acc_means) < 1e-12 * rows + 1e-9
+    assert oracle.rel_err(accv.cpu().numpy(), bn.acc_vars) < 1e-12 * rows + 1e-9
+    ref_idf = bn.backpropagate(x, dy, 0.9)
+    dsc, dsh = T(dsc0, dev), T(dsh0, dev)
+    idf = torch.empty_like(xd)
+    aslp.ops.bn_backward(xd, T(dy, dev), xhat, scale, mean, inv, dsc, dsh, 0.9, idf)
+    assert oracle.rel_err(idf.cpu().numpy(), ref_idf) < TOL
+    assert oracle.rel_err(dsc.cpu().numpy(), bn.dscale) < 1e-5
+    assert oracle.rel_err(dsh.cpu().numpy(), bn.dshift) < 1e-5
+
+
+@pytest.mark.parametrize("rows,cols", [(16, 10), (256, 3000), (100, 128), (5, 8192)])
+def test_xent_eval(aslp, oracle, dev, rows, cols):
+    rng = np.random.default_rng(7)
+    logits = rng.standard_normal((rows, cols)).astype(np.float32) * 3
+    y = oracle.unary("orc_softmax_rows", logits)
+    labels = rng.integers(0, cols, rows).astype(np.int32)
+    tgt = np.zeros((rows, cols), np.float32)
+    tgt[np.arange(rows), labels] = 1.0
+    fw = rng.uniform(0.0, 1.0, rows).astype(np.float32)
+    fw[0] = 0.0
+    # soft posteriors + a frame with an all-zero target row (masked, nnet-loss.cc:80-85)
+    tgt_soft = tgt.copy()
+    tgt_soft[1] *= 0
+    if rows > 2:
+        tgt_soft[2] = 0
+        tgt_soft[2, :2] = [0.25, 0.75]
+    for t_np, use_labels in ((tgt, True), (tgt, False), (tgt_soft, False)):
+        ref_diff, st = oracle.xent_eval(fw, y, t_np)
+        yd = T(y, dev)
+        diff = torch.empty_like(yd)
+        stats = torch.zeros(5, dtype=torch.float64, device=dev)
+        if use_labels:
+            aslp.ops.xent_eval(yd, T(fw, dev), diff, stats, labels=T(labels, dev))
+        else:
+            aslp.ops.xent_eval(yd, T(fw, dev), diff, stats, targets=T(t_np, dev))
+        assert oracle.rel_err(diff.cpu().numpy(), ref_diff) < 1e-6
+        s = stats.cpu().numpy()
+        ref = np.array([st["frames"], st["correct"], st["loss"], st["entropy"], st["likelyhood"]])
+        assert np.allclose(s, ref, rtol=1e-5, atol=1e-6), (s, ref)
+
+
+@pytest.mark.parametrize("rows,cols", [(20, 5), (1024, 2048), (129, 70), (0, 8)])
+def test_add_row_sum_mat_vec(aslp, oracle, dev, rows, cols):
+    rng = np.random.default_rng(8)
+    M = rng.standard_normal((rows, cols)).astype(np.float32)
+    v0 = rng.standard_normal(cols).astype(np.float32)
+    v = T(v0, dev)
+    aslp.ops.add_row_sum_mat_vec(0.43243, T(M, dev) if rows else torch.empty(0, cols, device=dev), 1.423, v)
+    ref = 0.43243 * M.astype(np.float64).sum(0) + 1.423 * v0
+    assert oracle.rel_err(v.cpu().numpy(), ref) < 1e-5
+
+
+def test_aslp_group_ops(aslp, oracle, dev):
+    """ASLP-added kernels, with the reference unit tests' shapes and expectations
+    (cu-matrix-test.cc:1056-1123)."""
+    rng = np.random.default_rng(9)
+    rowsM, cols, P = 21, 6, 7
+    M0 = rng.standard_normal((rowsM, cols)).astype(np.float32)
+    A = rng.standard_normal((rowsM * P, cols)).astype(np.float32)
+    Md, Ad = T(M0, dev), T(A, dev)
+    aslp.lib.cudaF_add_row_sum_mat(aslp.Dim3(1, 1, 1), aslp.Dim3(1, 1, 1), aslp.ops.ptr(Md), aslp.ops.ptr(Ad), aslp.ops.dim(Md), cols, P, 0.43243, 1.423)
+    aslp.check_error()
+    ref = M0.copy()
+    oracle.lib.orc_add_row_sum_mat(ref, cols, rowsM, cols, A, cols, rowsM * P, 0.43243, 1.423)
+    assert oracle.rel_err(Md.cpu().numpy(), ref) < 1e-6
+    check = 1.423 * M0 + 0.43243 * A.reshape(rowsM, P, cols).sum(1)  # "slow version" of the reference test
+    assert oracle.rel_err(Md.cpu().numpy(), check) < 1e-5
+    # AddConvMatMatElements: rowsA = 1000, rowsB = 8, alpha 1 beta 0
+    rowsA, rowsB, cols = 1000, 8, 5
+    A = rng.standard_normal((rowsA, cols)).astype(np.float32)
+    B = rng.standard_normal((rowsB, cols)).astype(np.float32)
+    rowsM = (rowsA - rowsB + 1) * rowsB
+    Md = torch.full((rowsM, cols), float("nan"), device=dev)
+    aslp.lib.cudaF_add_conv_mat_mat_elements(aslp.Dim3(1, 1, 1), aslp.Dim3(2, rowsB, 1), aslp.ops.ptr(Md), aslp.ops.ptr(T(A, dev)), aslp.ops.ptr(T(B, dev)),
+                                             aslp.ops.dim(Md), cols, cols, 1.0, 0.0)
+    aslp.check_error()
+    ref = np.zeros((rowsM, cols), np.float32)
+    oracle.lib.orc_add_conv_mat_mat_elements(ref, cols, cols, A, cols, rowsA, B, cols, rowsB, 1.0, 0.0)
+    assert np.array_equal(Md.cpu().numpy(), ref)

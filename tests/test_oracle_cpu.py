@@ -1,0 +1,179 @@
+"""CPU-only: pins the oracle (oracle/aslp_oracle.c) against the closed-form expectations the
+reference's own unit tests hold for this path, and checks that the C-ABI
+library loads and exports every symbol include/*.h declares (no compute without a GPU)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_exports_every_declared_symbol(aslp):
+    names = set()
+    for h in os.listdir(os.path.join(ROOT, "include")):
+        txt = open(os.path.join(ROOT, "include", h)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        names |= set(re.findall(r"\b((?:cudaF_|cudaI32_|aslp_|compute_ctc_loss|get_workspace_size|ctcGetStatusString|get_warpctc_version)\w*)\s*\(", txt))
+    names -= {"aslp_dim3"}
+    assert len(names) > 60
+    missing = [n for n in sorted(names) if not hasattr(aslp.lib, n)]
+    assert not missing, "declared in include/*.h but not exported: %s" % missing
+
+
+def test_product_does_not_touch_oracle():
+    """The product path must not import / link anything under oracle/ (it is the checker)."""
+    pkg = os.path.join(ROOT, "kaldi-aslp_amd")
+    for dp, _, fs in os.walk(pkg):
+        if "build" in dp.split(os.sep):
+            continue
+        for f in fs:
+            if f.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                assert "aslp_oracle" not in txt and "oracle_lib" not in txt and "orc_" not in txt, os.path.join(dp, f)
+
+
+def test_sigmoid_tanh_closed_forms(oracle):
+    # UnitTestCuSigmoid / UnitTestCuDiffSigmoid / tanh twins (cu-matrix-test.cc:1925-1978)
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((100, 111)).astype(np.float32)
+    y = oracle.unary("orc_sigmoid", x)
+    assert oracle.rel_err(y, 1.0 / (1.0 + np.exp(-x.astype(np.float64)))) < 1e-6
+    t = oracle.unary("orc_tanh", x)
+    assert oracle.rel_err(t, np.tanh(x.astype(np.float64))) < 1e-6
+    hy = rng.uniform(0, 1, (100, 111)).astype(np.float32)
+    assert oracle.rel_err(oracle.binary("orc_diff_sigmoid", hy, x), hy * (1.0 - hy) * x) < 1e-6
+    assert oracle.rel_err(oracle.binary("orc_diff_tanh", hy, x), (1.0 - hy * hy) * x) < 1e-6
+    big = np.array([[-1e4, -100, 100, 1e4]], np.float32)
+    assert np.isfinite(oracle.unary("orc_sigmoid", big)).all() and np.isfinite(oracle.unary("orc_tanh", big)).all()
+
+
+def test_softmax_matches_reference_test_form(oracle):
+    # UnitTestCuSoftmax (cu-matrix-test.cc:1983-2012): rows 10..49, cols 10..59, scale 5
+    rng = np.random.default_rng(1)
+    for _ in range(2):
+        x = (rng.standard_normal((10 + rng.integers(40), 10 + rng.integers(50))) * 5).astype(np.float32)
+        y = oracle.unary("orc_softmax_rows", x)
+        e = np.exp(x.astype(np.float64) - x.max(1, keepdims=True))
+        assert oracle.rel_err(y, e / e.sum(1, keepdims=True)) < 1e-5
+
+
+def test_find_row_max_id_reference_form(oracle):
+    # UnitTestCuFindRowMaxId (cu-matrix-test.cc:2045-2075)
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((100 + rng.integers(200), 100 + rng.integers(200))).astype(np.float32)
+    assert np.array_equal(oracle.find_row_max_id(x), x.argmax(1))
+    x[3, :] = 1.0
+    assert oracle.find_row_max_id(x)[3] == 0  # first of equal maxima
+    x[4, :] = np.nan
+    assert oracle.find_row_max_id(x)[4] == -1  # NaN never beats -1e21 (strict '<')
+
+
+def test_splice_reference_form(oracle):
+    # UnitTestCuMathSplice (cu-math-test.cc:101-140): offsets are -n_columns or 0
+    rng = np.random.default_rng(3)
+    M, N = 100 + rng.integers(200), 100 + rng.integers(200)
+    src = rng.standard_normal((M, N)).astype(np.float32)
+    offs = [int(rng.integers(2)) * N - N for _ in range(int(rng.integers(7)) + 2)]
+    tgt = oracle.splice(src, offs)
+    for i in range(M):
+        for k, o in enumerate(offs):
+            r = M - 1 if i + o >= M else (0 if i + o <= 0 else i + o)
+            assert np.array_equal(tgt[i, k * N:(k + 1) * N], src[r])
+
+
+def test_splice_backward_is_the_reference_gather_not_the_adjoint(oracle):
+    # nnet-various.h:143-175 gathers out_diff rows at t+off (forward used t+off as SOURCE row)
+    od = np.arange(4 * 6, dtype=np.float32).reshape(4, 6)
+    idf = oracle.splice_backprop(od, 2, [-1, 0, 1])
+    exp = np.zeros((4, 2), np.float32)
+    for t in range(4):
+        for c, o in enumerate([-1, 0, 1]):
+            exp[t] += od[min(max(t + o, 0), 3), 2 * c:2 * c + 2]
+    assert np.array_equal(idf, exp)
+
+
+def test_add_row_sum_mat_and_conv_reference_forms(oracle):
+    # UnitTestCuMatrixAddRowSumMat / AddConvMatMatElements (cu-matrix-test.cc:1056-1123)
+    rng = np.random.default_rng(4)
+    rowsM, cols, P = 21, 6, 7
+    M0 = rng.standard_normal((rowsM, cols)).astype(np.float32)
+    A = rng.standard_normal((rowsM * P, cols)).astype(np.float32)
+    M = M0.copy()
+    oracle.lib.orc_add_row_sum_mat(M, cols, rowsM, cols, A, cols, rowsM * P, 0.43243, 1.423)
+    assert oracle.rel_err(M, 1.423 * M0 + 0.43243 * A.reshape(rowsM, P, cols).sum(1)) < 1e-6
+    rowsA, rowsB, cols = 1000, 8, 5
+    A = rng.standard_normal((rowsA, cols)).astype(np.float32)
+    B = np.ones((rowsB, cols), np.float32)
+    out = np.zeros(((rowsA - rowsB + 1) * rowsB, cols), np.float32)
+    oracle.lib.orc_add_conv_mat_mat_elements(out, cols, cols, A, cols, rowsA, B, cols, rowsB, 1.0, 0.0)
+    for k in (0, 1, 500, rowsA - rowsB):
+        assert np.array_equal(out[k * rowsB:(k + 1) * rowsB], A[k:k + rowsB] * B)
+
+
+def test_add_mat_mat_all_transposes(oracle):
+    rng = np.random.default_rng(5)
+    for (M, N, K) in ((7, 5, 9), (33, 65, 17)):
+        for tA in (0, 1):
+            for tB in (0, 1):
+                A = rng.standard_normal((K, M) if tA else (M, K)).astype(np.float32)
+                B = rng.standard_normal((N, K) if tB else (K, N)).astype(np.float32)
+                C0 = rng.standard_normal((M, N)).astype(np.float32)
+                got = oracle.add_mat_mat(C0, 0.5, A, tA, B, tB, 2.0)
+                ref = 0.5 * (A.T if tA else A).astype(np.float64) @ (B.T if tB else B) + 2.0 * C0
+                assert oracle.rel_err(got, ref) < 1e-6
+
+
+def test_batchnorm_oracle_is_a_consistent_gradient(oracle):
+    """No reference test pins BN; check the restated backward against central
+    differences of the restated forward so at least fwd/bwd agree with each other."""
+    rng = np.random.default_rng(6)
+    B, D = 12, 5
+    x = rng.standard_normal((B, D)).astype(np.float32)
+    dy = rng.standard_normal((B, D)).astype(np.float32)
+    bn = oracle.Bn(D)
+    bn.scale[:] = rng.uniform(0.5, 1.5, D)
+    out = bn.propagate(x)
+    assert abs(out.astype(np.float64).mean(0) - bn.shift).max() < 1e-5
+    idf = bn.backpropagate(x, dy, 0.0)
+    assert oracle.rel_err(bn.dshift, dy.sum(0)) < 1e-6
+    eps = 1e-2
+    num = np.zeros_like(x, dtype=np.float64)
+    for i in range(B):
+        for j in range(D):
+            xp, xm = x.copy(), x.copy()
+            xp[i, j] += eps
+            xm[i, j] -= eps
+            b2 = oracle.Bn(D); b2.scale[:] = bn.scale
+            fp = (b2.propagate(xp).astype(np.float64) * dy).sum()
+            b3 = oracle.Bn(D); b3.scale[:] = bn.scale
+            fm = (b3.propagate(xm).astype(np.float64) * dy).sum()
+            num[i, j] = (fp - fm) / (2 * eps)
+    assert oracle.rel_err(idf, num) < 2e-3
+    # running statistics are plain sums in double
+    assert np.allclose(bn.acc_means, x.astype(np.float64).sum(0))
+    assert np.allclose(bn.acc_vars, (x * x).astype(np.float64).sum(0))
+    assert bn.st.num_acc_frames == B
+
+
+def test_xent_oracle_values(oracle):
+    y = np.array([[0.7, 0.2, 0.1], [0.1, 0.8, 0.1], [0.3, 0.3, 0.4]], np.float32)
+    t = np.array([[1, 0, 0], [0, 0, 1], [0, 0, 0]], np.float32)
+    fw = np.array([1.0, 0.5, 1.0], np.float32)
+    diff, st = oracle.xent_eval(fw, y, t)
+    assert st["frames"] == 1.5 and st["correct"] == 1.0
+    assert abs(st["loss"] - (-(np.log(0.7) + 0.5 * np.log(0.1)))) < 1e-6
+    assert abs(st["entropy"]) < 1e-12
+    assert np.allclose(diff[2], 0) and np.allclose(diff[1], (y[1] - t[1]) * 0.5)
+
+
+def test_dnn_chain_loss_decreases(oracle):
+    """cpu_baseline chain sanity: a few SGD steps on one minibatch reduce the loss."""
+    rng = np.random.default_rng(7)
+    d = oracle.lib.orc_dnn_create(20, 32, 2, 10, 1, 64, 1)
+    x = rng.standard_normal((64, 20)).astype(np.float32)
+    lab = rng.integers(0, 10, 64).astype(np.int32)
+    losses = [oracle.lib.orc_dnn_train_step(d, x, lab, 0.002, 0.0) for _ in range(30)]
+    oracle.lib.orc_dnn_destroy(d)
+    assert losses[-1] < 0.9 * losses[0]
