@@ -324,7 +324,7 @@ static void colsum_scaled(float *v, const float *m, int ld, int rows, int cols, 
   for (int c = 0; c < cols; c++) {
     float s = 0.0f;
     for (int r = 0; r < rows; r++) s += m[(size_t)r * ld + c];
-    v[c] = alpha * s + beta * v[c];
+    v[c] = beta == 0.0f ? alpha * s : alpha * s + beta * v[c]; /* gemv: beta 0 does not read v */
   }
 }
 
@@ -344,7 +344,7 @@ void orc_bn_propagate(orc_bn_state *s, float *out, int ldo, const float *in, int
   for (int r = 0; r < B; r++) /* out = xs .* xs */
     for (int c = 0; c < D; c++) {
       float x = xs[(size_t)r * D + c];
-      out[(size_t)r * ldo + c] = 0.0f * out[(size_t)r * ldo + c] + 1.0f * x * x;
+      out[(size_t)r * ldo + c] = 1.0f * x * x; /* beta = 0 on a zeroed buffer (nnet-component.h:311) */
     }
   colsum_scaled(s->var_vec, out, ldo, B, D, 1.0 / (B), 0.0f);
   for (int c = 0; c < D; c++) { /* :202-204  +1e-7, pow 0.5, invert */

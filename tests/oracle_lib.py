@@ -156,7 +156,8 @@ class Bn:
         self.xs = None
 
     def propagate(self, x):
-        x = c32(x); out = np.empty_like(x); self.xs = np.empty_like(x)
+        x = c32(x); out = np.zeros_like(x)  # Component::Propagate zeroes `out` first (nnet-component.h:311)
+        self.xs = np.empty_like(x)
         lib.orc_bn_propagate(C.byref(self.st), out, x.shape[1], x, x.shape[1], x.shape[0], self.xs)
         return out
 
