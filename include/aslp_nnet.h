@@ -1,0 +1,79 @@
+/*
+ * aslp_nnet.h -- C handle API over the host engine's Nnet / loss objects (boundary B4 of
+ * SURVEY.md §8b), so that non-C++ hosts (tests, bench.py, other runtimes) can drive the same
+ * objects a C++ caller links directly (kaldi-aslp_amd/nnet/nnet-nnet.h).
+ *
+ * Each function mirrors one method of the reference's kaldi::aslp_nnet::Nnet
+ * (src/aslp-nnet/nnet-nnet.h:38-193) or loss class (nnet-loss.h:35-218); the reference line is
+ * cited per function.  Reference methods throw (KALDI_ERR); here every function returns 0 on
+ * success and non-zero on error, with the message available from aslp_nnet_last_error().
+ * Matrices are DEVICE pointers, row-major fp32, with an explicit stride in elements.
+ */
+#ifndef ASLP_NNET_H_
+#define ASLP_NNET_H_
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct aslp_nnet_s *aslp_nnet_t;
+typedef struct aslp_xent_s *aslp_xent_t;
+
+const char *aslp_nnet_last_error(void);
+void aslp_set_verbose(int level);
+
+/* Nnet::Init (nnet-nnet.cc:570-612) from <NnetProto> text; srand(seed) first like aslp-nnet-init. */
+int aslp_nnet_init_from_proto(const char *proto_text, unsigned seed, aslp_nnet_t *out);
+int aslp_nnet_read(const char *path, aslp_nnet_t *out);                 /* Nnet::Read  :615 */
+int aslp_nnet_write(aslp_nnet_t n, const char *path, int binary);       /* Nnet::Write :648 */
+int aslp_nnet_copy(aslp_nnet_t n, aslp_nnet_t *out);                    /* copy ctor   :41  */
+void aslp_nnet_free(aslp_nnet_t n);
+
+int aslp_nnet_set_train_options(aslp_nnet_t n, float learn_rate, float momentum, float l2_penalty, float l1_penalty); /* :834 */
+int aslp_nnet_input_dim(aslp_nnet_t n);
+int aslp_nnet_output_dim(aslp_nnet_t n);
+int aslp_nnet_num_components(aslp_nnet_t n);
+int aslp_nnet_num_params(aslp_nnet_t n);
+int aslp_nnet_component_marker(aslp_nnet_t n, int c, char *buf, int buflen);
+int aslp_nnet_info(aslp_nnet_t n, char *buf, int buflen);               /* Nnet::Info :714 */
+int aslp_nnet_set_link_aliasing(aslp_nnet_t n, int on);                 /* engine switch, see nnet-nnet.h */
+
+/* out: [rows x OutputDim].  Nnet::Propagate :191 / Feedforward :218 */
+int aslp_nnet_propagate(aslp_nnet_t n, const float *in, int rows, int cols, int stride, float *out, int out_stride);
+int aslp_nnet_feedforward(aslp_nnet_t n, const float *in, int rows, int cols, int stride, float *out, int out_stride);
+/* in_diff may be NULL.  Nnet::Backpropagate :206 (Update of every updatable component included) */
+int aslp_nnet_backpropagate(aslp_nnet_t n, const float *out_diff, int rows, int cols, int stride, float *in_diff, int in_diff_stride);
+
+int aslp_nnet_reset_lstm_streams(aslp_nnet_t n, const int32_t *flags_host, int num_streams);   /* :473 */
+int aslp_nnet_set_seq_lengths(aslp_nnet_t n, const int32_t *lengths_host, int num_streams);    /* :498 */
+int aslp_nnet_set_chunk_size(aslp_nnet_t n, int chunk_size);                                   /* :532 */
+
+/* Nnet::GetParams (:296) -> host buffer of NumParams floats */
+int aslp_nnet_get_params(aslp_nnet_t n, float *host_buf, int buf_len);
+/* Nnet::GetGpuParams (:314): device pointers + float counts (rows*stride) of every tensor, in the
+ * reference's order.  Returns the number of tensors (also when max_n is too small). */
+int aslp_nnet_get_gpu_params(aslp_nnet_t n, float **ptrs, int *sizes, int max_n);
+/* Nnet::GetAccStats (:327): BatchNorm running statistics. counts_host[i] = num_acc_frames of BN i. */
+int aslp_nnet_get_acc_stats(aslp_nnet_t n, double **dev_ptrs, int *sizes, int max_n, double **counts_host, int max_bn, int *num_bn);
+/* copy component c's forward output / output-diff buffer to the host (reference: PropagateBuffer()) */
+int aslp_nnet_component_output(aslp_nnet_t n, int c, float *host_dst, int rows, int cols);
+int aslp_nnet_component_out_diff(aslp_nnet_t n, int c, float *host_dst, int rows, int cols);
+
+/* ---- Xent (nnet-loss.h:66-117) ------------------------------------------------------------ */
+int aslp_xent_create(aslp_xent_t *out);
+void aslp_xent_free(aslp_xent_t x);
+/* dense targets [rows x cols] or (targets == NULL) one int32 label per row; frame_weights [rows]; all device */
+int aslp_xent_eval_batch(aslp_xent_t x, const float *net_out, int rows, int cols, int stride, const float *targets, int tgt_stride,
+                   const int32_t *labels, const float *frame_weights, float *diff, int diff_stride);
+int aslp_xent_report(aslp_xent_t x, char *buf, int buflen);   /* Xent::Report nnet-loss.cc:175 */
+int aslp_xent_get_stats(aslp_xent_t x, double stats[5]);      /* frames, correct, loss, entropy, likelyhood */
+
+/* One whole training step with nothing on the host: Propagate -> Xent::Eval (labels) -> Backpropagate
+ * (nnet-nnet.cc:70-154 + nnet-loss.cc:63; the loop body of aslp-nnet-train-frame.cc:109-131). */
+int aslp_nnet_train_step_xent(aslp_nnet_t n, aslp_xent_t x, const float *in, int rows, int cols, int stride,
+                              const int32_t *labels, const float *frame_weights);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,680 @@
+// cu-matrix.cpp -- see cu-matrix.h.  Every method maps to one kernel of csrc/ (no CPU branch).
+#include "cu-matrix.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+
+#include "common.h"
+
+namespace aslp {
+
+int g_verbose_level = 0;
+
+static const aslp_dim3 kD3 = {1, 1, 1};
+
+// ---- caching device allocator ----------------------------------------------------------------
+namespace {
+std::mutex g_alloc_mu;
+std::multimap<size_t, void *> g_free;   // size -> block
+std::map<void *, size_t> g_live;        // block -> size
+size_t RoundSize(size_t b) { return (b + 255) & ~(size_t)255; }
+void CheckHip(hipError_t e, const char *what) {
+  if (e != hipSuccess) ASLP_ERR << what << ": " << hipGetErrorString(e);
+}
+void CheckKernels() {
+  char buf[512];
+  if (aslp_get_last_error(buf, sizeof(buf))) ASLP_ERR << buf;
+}
+}  // namespace
+
+void *DeviceAlloc(size_t bytes) {
+  if (bytes == 0) return nullptr;
+  size_t sz = RoundSize(bytes);
+  std::lock_guard<std::mutex> lk(g_alloc_mu);
+  auto it = g_free.find(sz);
+  void *p = nullptr;
+  if (it != g_free.end()) {
+    p = it->second;
+    g_free.erase(it);
+  } else {
+    hipError_t e = hipMalloc(&p, sz);
+    if (e != hipSuccess) {
+      // release the cache and retry once
+      for (auto &kv : g_free) (void)hipFree(kv.second);
+      g_free.clear();
+      CheckHip(hipMalloc(&p, sz), "hipMalloc");
+    }
+  }
+  g_live[p] = sz;
+  return p;
+}
+void DeviceFree(void *p) {
+  if (!p) return;
+  std::lock_guard<std::mutex> lk(g_alloc_mu);
+  auto it = g_live.find(p);
+  if (it == g_live.end()) return;
+  // Kernels are stream-ordered: a block handed out again is only touched by later launches.
+  g_free.insert({it->second, p});
+  g_live.erase(it);
+}
+void DeviceToHost(void *dst, const void *src, size_t bytes) {
+  if (!bytes) return;
+  CheckHip(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, cur_stream()), "hipMemcpy D2H");
+  CheckHip(hipStreamSynchronize(cur_stream()), "hipStreamSynchronize");
+}
+void HostToDevice(void *dst, const void *src, size_t bytes) {
+  if (!bytes) return;
+  CheckHip(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, cur_stream()), "hipMemcpy H2D");
+  CheckHip(hipStreamSynchronize(cur_stream()), "hipStreamSynchronize");  // src may be a temporary
+}
+void DeviceToDevice(void *dst, const void *src, size_t bytes) {
+  if (!bytes) return;
+  CheckHip(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, cur_stream()), "hipMemcpy D2D");
+}
+void DeviceMemset(void *dst, int v, size_t bytes) {
+  if (!bytes) return;
+  CheckHip(hipMemsetAsync(dst, v, bytes, cur_stream()), "hipMemset");
+}
+void StreamSync() {
+  CheckHip(hipStreamSynchronize(cur_stream()), "hipStreamSynchronize");
+  CheckKernels();
+}
+
+// ---- host matrix / vector I/O (matrix/kaldi-matrix.cc:1201-1430, kaldi-vector.cc:1094-1228) ------
+void HostMatrix::Write(std::ostream &os, bool binary) const {
+  if (!os.good()) ASLP_ERR << "Failed to write matrix to stream: stream not good";
+  if (binary) {
+    WriteToken(os, binary, "FM");
+    WriteBasicType(os, binary, (int32)rows);
+    WriteBasicType(os, binary, (int32)cols);
+    os.write(reinterpret_cast<const char *>(data.data()), sizeof(float) * data.size());
+  } else {
+    if (cols == 0) {
+      os << " [ ]\n";
+    } else {
+      os << " [";
+      for (int i = 0; i < rows; i++) {
+        os << "\n  ";
+        for (int j = 0; j < cols; j++) os << (*this)(i, j) << " ";
+      }
+      os << "]\n";
+    }
+  }
+  if (!os.good()) ASLP_ERR << "Failed to write matrix to stream";
+}
+
+static bool ParseSpecialFloat(const std::string &s, float *out) {
+  std::string l;
+  for (char c : s) l.push_back(::tolower(c));
+  if (l == "inf" || l == "infinity") { *out = std::numeric_limits<float>::infinity(); return true; }
+  if (l == "-inf" || l == "-infinity") { *out = -std::numeric_limits<float>::infinity(); return true; }
+  if (l == "nan" || l == "-nan") { *out = std::numeric_limits<float>::quiet_NaN(); return true; }
+  return false;
+}
+
+void HostMatrix::Read(std::istream &is, bool binary) {
+  if (binary) {
+    int peekval = Peek(is, binary);
+    std::string token;
+    ReadToken(is, binary, &token);
+    if (peekval == 'D') {
+      if (token != "DM") ASLP_ERR << "Failed to read matrix from stream: expected token DM, got " << token;
+      int32 r, c;
+      ReadBasicType(is, binary, &r);
+      ReadBasicType(is, binary, &c);
+      std::vector<double> tmp((size_t)r * c);
+      is.read(reinterpret_cast<char *>(tmp.data()), sizeof(double) * tmp.size());
+      Resize(r, c);
+      for (size_t i = 0; i < tmp.size(); i++) data[i] = (float)tmp[i];
+    } else {
+      if (token != "FM") ASLP_ERR << "Failed to read matrix from stream: Expected token FM, got " << token;
+      int32 r, c;
+      ReadBasicType(is, binary, &r);
+      ReadBasicType(is, binary, &c);
+      Resize(r, c);
+      is.read(reinterpret_cast<char *>(data.data()), sizeof(float) * data.size());
+    }
+    if (is.fail()) ASLP_ERR << "Failed to read matrix from stream (binary, truncated?)";
+    return;
+  }
+  std::string str;
+  is >> str;
+  if (is.fail()) ASLP_ERR << "Failed to read matrix from stream: Expected \"[\", got EOF";
+  if (str == "[]") { Resize(0, 0); return; }
+  if (str != "[") ASLP_ERR << "Failed to read matrix from stream: Expected \"[\", got \"" << str << '"';
+  std::vector<std::vector<float>> rows_v;
+  std::vector<float> cur;
+  while (true) {
+    int i = is.peek();
+    if (i == -1) ASLP_ERR << "Failed to read matrix from stream: got EOF while reading matrix data";
+    char ch = static_cast<char>(i);
+    if (ch == ']') {
+      is.get();
+      i = is.peek();
+      if (static_cast<char>(i) == '\r') { is.get(); is.get(); }
+      else if (static_cast<char>(i) == '\n') { is.get(); }
+      if (!cur.empty()) rows_v.push_back(cur);
+      if (rows_v.empty()) { Resize(0, 0); return; }
+      int nr = rows_v.size(), nc = rows_v[0].size();
+      Resize(nr, nc);
+      for (int r = 0; r < nr; r++) {
+        if ((int)rows_v[r].size() != nc)
+          ASLP_ERR << "Failed to read matrix from stream: Matrix has inconsistent #cols: " << nc << " vs." << rows_v[r].size()
+                   << " (processing row" << r << ")";
+        for (int c = 0; c < nc; c++) (*this)(r, c) = rows_v[r][c];
+      }
+      return;
+    } else if (ch == '\n' || ch == ';') {
+      is.get();
+      if (!cur.empty()) { rows_v.push_back(cur); cur.clear(); }
+    } else if ((i >= '0' && i <= '9') || i == '-') {
+      float r;
+      is >> r;
+      if (is.fail()) {
+        // libstdc++ refuses "-inf"/"-nan": re-read as a word
+        is.clear();
+        std::string w;
+        is >> w;
+        if (!ParseSpecialFloat(w, &r)) ASLP_ERR << "Failed to read matrix from stream: stream failure/EOF while reading matrix data.";
+      }
+      cur.push_back(r);
+    } else if (isspace(i)) {
+      is.get();
+    } else {
+      std::string w;
+      is >> w;
+      float r;
+      if (!ParseSpecialFloat(w, &r)) ASLP_ERR << "Failed to read matrix from stream: Expecting numeric matrix data, got " << w;
+      cur.push_back(r);
+    }
+  }
+}
+
+void HostVector::Write(std::ostream &os, bool binary) const {
+  if (!os.good()) ASLP_ERR << "Failed to write vector to stream: stream not good";
+  if (binary) {
+    WriteToken(os, binary, "FV");
+    WriteBasicType(os, binary, (int32)data.size());
+    os.write(reinterpret_cast<const char *>(data.data()), sizeof(float) * data.size());
+  } else {
+    os << " [ ";
+    for (float v : data) os << v << " ";
+    os << "]\n";
+  }
+  if (!os.good()) ASLP_ERR << "Failed to write vector to stream";
+}
+
+template <class Real>
+static void ReadVectorImpl(std::istream &is, bool binary, std::vector<Real> *out) {
+  if (binary) {
+    int peekval = Peek(is, binary);
+    std::string token;
+    ReadToken(is, binary, &token);
+    int32 size;
+    if (peekval == 'D') {
+      if (token != "DV") ASLP_ERR << "Failed to read vector from stream: expected token DV, got " << token;
+      ReadBasicType(is, binary, &size);
+      std::vector<double> tmp(size);
+      if (size > 0) is.read(reinterpret_cast<char *>(tmp.data()), sizeof(double) * size);
+      out->resize(size);
+      for (int i = 0; i < size; i++) (*out)[i] = (Real)tmp[i];
+    } else {
+      if (token != "FV") ASLP_ERR << "Failed to read vector from stream: Expected token FV, got " << token;
+      ReadBasicType(is, binary, &size);
+      std::vector<float> tmp(size);
+      if (size > 0) is.read(reinterpret_cast<char *>(tmp.data()), sizeof(float) * size);
+      out->resize(size);
+      for (int i = 0; i < size; i++) (*out)[i] = (Real)tmp[i];
+    }
+    if (is.fail()) ASLP_ERR << "Failed to read vector from stream: error reading vector data (binary mode); truncated stream?";
+    return;
+  }
+  std::string s;
+  is >> s;
+  if (is.fail()) ASLP_ERR << "Failed to read vector from stream: EOF while trying to read vector.";
+  if (s == "[]") { out->clear(); return; }
+  if (s != "[") ASLP_ERR << "Failed to read vector from stream: Expected \"[\" but got " << s;
+  std::vector<Real> data;
+  while (true) {
+    int i = is.peek();
+    if (i == '-' || (i >= '0' && i <= '9')) {
+      Real r;
+      is >> r;
+      if (is.fail()) {
+        is.clear();
+        std::string w;
+        is >> w;
+        float f;
+        if (!ParseSpecialFloat(w, &f)) ASLP_ERR << "Failed to read vector from stream: failed to read number.";
+        r = f;
+      }
+      data.push_back(r);
+    } else if (i == ' ' || i == '\t') {
+      is.get();
+    } else if (i == ']') {
+      is.get();
+      *out = data;
+      i = is.peek();
+      if (static_cast<char>(i) == '\r') { is.get(); is.get(); }
+      else if (static_cast<char>(i) == '\n') { is.get(); }
+      return;
+    } else if (i == -1) {
+      ASLP_ERR << "Failed to read vector from stream: EOF while reading vector data.";
+    } else if (i == '\n' || i == '\r') {
+      ASLP_ERR << "Failed to read vector from stream: newline found while reading vector (maybe it's a matrix?)";
+    } else {
+      is >> s;
+      float f;
+      if (!ParseSpecialFloat(s, &f)) ASLP_ERR << "Failed to read vector from stream: Expecting numeric vector data, got " << s;
+      data.push_back(f);
+    }
+  }
+}
+void HostVector::Read(std::istream &is, bool binary) { ReadVectorImpl(is, binary, &data); }
+void HostVectorD::Read(std::istream &is, bool binary) { ReadVectorImpl(is, binary, &data); }
+void HostVectorD::Write(std::ostream &os, bool binary) const {
+  if (binary) {
+    WriteToken(os, binary, "DV");
+    WriteBasicType(os, binary, (int32)data.size());
+    os.write(reinterpret_cast<const char *>(data.data()), sizeof(double) * data.size());
+  } else {
+    os << " [ ";
+    for (double v : data) os << v << " ";
+    os << "]\n";
+  }
+  if (!os.good()) ASLP_ERR << "Failed to write vector to stream";
+}
+
+// ---- text utils ---------------------------------------------------------------------------------
+void SplitStringToVector(const std::string &full, const char *delim, bool omit_empty_strings, std::vector<std::string> *out) {
+  size_t start = 0, found = 0, end = full.size();
+  out->clear();
+  while (found != std::string::npos) {
+    found = full.find_first_of(delim, start);
+    if (!omit_empty_strings || (found != start && start != end)) out->push_back(full.substr(start, found - start));
+    start = found + 1;
+  }
+}
+bool ConvertStringToInteger(const std::string &str, int32 *out) {
+  const char *this_str = str.c_str();
+  char *end = nullptr;
+  errno = 0;
+  long long i = strtoll(this_str, &end, 10);
+  if (end != this_str) while (isspace(*end)) end++;
+  if (end == this_str || *end != '\0' || errno != 0) return false;
+  if (i > std::numeric_limits<int32>::max() || i < std::numeric_limits<int32>::min()) return false;
+  *out = (int32)i;
+  return true;
+}
+bool ConvertStringToReal(const std::string &str, float *out) {
+  const char *this_str = str.c_str();
+  char *end = nullptr;
+  errno = 0;
+  double d = strtod(this_str, &end);
+  if (end != this_str) while (isspace(*end)) end++;
+  if (end == this_str || *end != '\0' || errno != 0) return false;
+  *out = (float)d;
+  return true;
+}
+bool SplitStringToIntegers(const std::string &full, const char *delim, bool omit_empty_strings, std::vector<int32> *out) {
+  if (*(full.c_str()) == '\0') { out->clear(); return true; }
+  std::vector<std::string> split;
+  SplitStringToVector(full, delim, omit_empty_strings, &split);
+  out->resize(split.size());
+  for (size_t i = 0; i < split.size(); i++)
+    if (!ConvertStringToInteger(split[i], &(*out)[i])) return false;
+  return true;
+}
+float RandUniform() { return (float)((rand() + 1.0) / (RAND_MAX + 2.0)); }
+float RandGauss() { return (float)(sqrtf(-2 * logf(RandUniform())) * cosf(2 * M_PI * RandUniform())); }
+
+// ---- CuVector ---------------------------------------------------------------------------------------
+void CuVector::Resize(int dim, MatrixResizeType t) {
+  if (dim != dim_) {
+    DeviceFree(data_);
+    data_ = dim ? static_cast<float *>(DeviceAlloc(sizeof(float) * dim)) : nullptr;
+    dim_ = dim;
+  }
+  if (t == kSetZero) SetZero();
+}
+void CuVectorBase::SetZero() { DeviceMemset(data_, 0, sizeof(float) * dim_); }
+void CuVectorBase::Set(float v) { if (dim_) { cudaF_set_const(kD3, kD3, data_, v, AsRow()); CheckKernels(); } }
+void CuVectorBase::Add(float v) { if (dim_) { cudaF_add(kD3, kD3, data_, v, AsRow()); CheckKernels(); } }
+void CuVectorBase::Scale(float v) { if (dim_) { cudaF_scale(kD3, kD3, data_, v, AsRow()); CheckKernels(); } }
+void CuVectorBase::CopyFromVec(const CuVectorBase &v) {
+  ASLP_ASSERT(v.Dim() == dim_);
+  DeviceToDevice(data_, v.Data(), sizeof(float) * dim_);
+}
+void CuVectorBase::CopyFromHost(const float *src, int n) { ASLP_ASSERT(n == dim_); HostToDevice(data_, src, sizeof(float) * n); }
+void CuVectorBase::CopyToHost(float *dst) const { DeviceToHost(dst, data_, sizeof(float) * dim_); }
+void CuVectorBase::AddVec(float alpha, const CuVectorBase &v, float beta) {
+  ASLP_ASSERT(v.Dim() == dim_);
+  if (!dim_) return;
+  if (beta != 1.0f) cudaF_scale(kD3, kD3, data_, beta, AsRow());
+  aslp_vec_axpy(alpha, v.Data(), data_, dim_);
+  CheckKernels();
+}
+void CuVectorBase::AddRowSumMat(float alpha, const CuMatrixBase &M, float beta) {
+  ASLP_ASSERT(M.NumCols() == dim_);
+  if (!dim_) return;
+  aslp_add_row_sum_mat_vec(alpha, M.Data(), M.Dim(), beta, data_);
+  CheckKernels();
+}
+void CuVectorBase::AddColSumMat(float alpha, const CuMatrixBase &M, float beta) {
+  ASLP_ASSERT(M.NumRows() == dim_);
+  if (!dim_) return;
+  aslp_add_col_sum_mat_vec(alpha, M.Data(), M.Dim(), beta, data_);
+  CheckKernels();
+}
+void CuVectorBase::AddDiagMatMat(float alpha, const CuMatrixBase &M, MatrixTransposeType tM, const CuMatrixBase &N,
+                                 MatrixTransposeType tN, float beta) {
+  // cu-vector.cc:540-590
+  int M_col_dim = (tM == kTrans ? M.NumRows() : M.NumCols()), N_row_dim = (tN == kTrans ? N.NumCols() : N.NumRows());
+  ASLP_ASSERT(M_col_dim == N_row_dim);
+  int M_row_stride = M.Stride(), M_col_stride = 1;
+  if (tM == kTrans) std::swap(M_row_stride, M_col_stride);
+  int N_row_stride = N.Stride(), N_col_stride = 1;
+  if (tN == kTrans) std::swap(N_row_stride, N_col_stride);
+  if (!dim_) return;
+  cudaF_add_diag_mat_mat(0, 0, alpha, data_, dim_, M.Data(), M_col_dim, M_row_stride, M_col_stride, N.Data(), N_row_stride,
+                         N_col_stride, 1, beta);
+  CheckKernels();
+}
+void CuVectorBase::AddVecVec(float alpha, const CuVectorBase &x, const CuVectorBase &y, float beta) {
+  ASLP_ASSERT(x.Dim() == dim_ && y.Dim() == dim_);
+  cudaF_add_vec_vec(0, 0, alpha, data_, x.Data(), y.Data(), beta, dim_);
+  CheckKernels();
+}
+void CuVectorBase::MulElements(const CuVectorBase &v) {
+  ASLP_ASSERT(v.Dim() == dim_);
+  if (dim_) { cudaF_mul_elements(kD3, kD3, data_, v.Data(), AsRow(), dim_); CheckKernels(); }
+}
+void CuVectorBase::ApplyFloor(float v) { if (dim_) { cudaF_apply_floor(kD3, kD3, data_, v, AsRow()); CheckKernels(); } }
+void CuVectorBase::ApplyCeiling(float v) { if (dim_) { cudaF_apply_ceiling(kD3, kD3, data_, v, AsRow()); CheckKernels(); } }
+void CuVectorBase::ApplyPow(float p) { if (dim_) { cudaF_apply_pow(kD3, kD3, data_, p, AsRow()); CheckKernels(); } }
+void CuVectorBase::InvertElements() { if (dim_) { cudaF_invert_elements(kD3, kD3, data_, AsRow()); CheckKernels(); } }
+float CuVectorBase::Sum() const {
+  if (!dim_) return 0.0f;
+  std::vector<float> h(dim_);
+  CopyToHost(h.data());
+  double s = 0.0;
+  for (float x : h) s += x;
+  return (float)s;
+}
+CuSubVector CuVectorBase::Range(int o, int n) {
+  ASLP_ASSERT(o >= 0 && n >= 0 && o + n <= dim_);
+  return CuSubVector(data_ + o, n);
+}
+
+// ---- CuVectorD ---------------------------------------------------------------------------------------
+CuVectorD &CuVectorD::operator=(const CuVectorD &o) {
+  if (this != &o) {
+    Resize(o.dim_, kUndefined);
+    DeviceToDevice(data_, o.data_, sizeof(double) * dim_);
+  }
+  return *this;
+}
+void CuVectorD::Resize(int dim, MatrixResizeType t) {
+  if (dim != dim_) {
+    DeviceFree(data_);
+    data_ = dim ? static_cast<double *>(DeviceAlloc(sizeof(double) * dim)) : nullptr;
+    dim_ = dim;
+  }
+  if (t == kSetZero) SetZero();
+}
+void CuVectorD::SetZero() { DeviceMemset(data_, 0, sizeof(double) * dim_); }
+void CuVectorD::CopyFromHost(const double *src, int n) { ASLP_ASSERT(n == dim_); HostToDevice(data_, src, sizeof(double) * n); }
+void CuVectorD::CopyToHost(double *dst) const { DeviceToHost(dst, data_, sizeof(double) * dim_); }
+void CuVectorD::Read(std::istream &is, bool binary) {
+  HostVectorD v;
+  v.Read(is, binary);
+  Resize(v.Dim(), kUndefined);
+  CopyFromHost(v.data.data(), v.Dim());
+}
+void CuVectorD::Write(std::ostream &os, bool binary) const {
+  HostVectorD v;
+  v.data.resize(dim_);
+  CopyToHost(v.data.data());
+  v.Write(os, binary);
+}
+
+// ---- CuMatrix ------------------------------------------------------------------------------------------
+void CuMatrix::Resize(int rows, int cols, MatrixResizeType t) {
+  ASLP_ASSERT(rows >= 0 && cols >= 0);
+  if (rows * cols == 0) rows = cols = 0;
+  if (rows != rows_ || cols != cols_) {
+    DeviceFree(data_);
+    data_ = nullptr;
+    stride_ = PaddedStride(cols);
+    if (rows) data_ = static_cast<float *>(DeviceAlloc(sizeof(float) * (size_t)rows * stride_));
+    rows_ = rows;
+    cols_ = cols;
+  }
+  if (t == kSetZero) SetZero();
+}
+CuSubMatrix CuMatrixBase::Range(int r0, int nr, int c0, int nc) const { return CuSubMatrix(*this, r0, nr, c0, nc); }
+CuSubMatrix CuMatrixBase::RowRange(int r0, int nr) const { return CuSubMatrix(*this, r0, nr, 0, cols_); }
+CuSubMatrix CuMatrixBase::ColRange(int c0, int nc) const { return CuSubMatrix(*this, 0, rows_, c0, nc); }
+CuSubVector CuMatrixBase::Row(int r) { ASLP_ASSERT(r >= 0 && r < rows_); return CuSubVector(RowData(r), cols_); }
+
+void CuMatrixBase::SetZero() {
+  if (!rows_) return;
+  // contiguous (owning) matrices: one memset incl. padding; views: strided kernel
+  if (stride_ == PaddedStride(cols_) || rows_ == 1) DeviceMemset(data_, 0, sizeof(float) * ((size_t)(rows_ - 1) * stride_ + cols_));
+  else { cudaF_set_const(kD3, kD3, data_, 0.0f, Dim()); CheckKernels(); }
+}
+#define ASLP_EW(call) do { if (rows_ && cols_) { call; CheckKernels(); } } while (0)
+void CuMatrixBase::Set(float v) { ASLP_EW(cudaF_set_const(kD3, kD3, data_, v, Dim())); }
+void CuMatrixBase::Add(float v) { ASLP_EW(cudaF_add(kD3, kD3, data_, v, Dim())); }
+void CuMatrixBase::Scale(float v) { ASLP_EW(cudaF_scale(kD3, kD3, data_, v, Dim())); }
+void CuMatrixBase::ApplyFloor(float v) { ASLP_EW(cudaF_apply_floor(kD3, kD3, data_, v, Dim())); }
+void CuMatrixBase::ApplyCeiling(float v) { ASLP_EW(cudaF_apply_ceiling(kD3, kD3, data_, v, Dim())); }
+void CuMatrixBase::ApplyPow(float p) { ASLP_EW(cudaF_apply_pow(kD3, kD3, data_, p, Dim())); }
+void CuMatrixBase::ApplyLog() { ASLP_EW(cudaF_apply_log(kD3, kD3, data_, Dim())); }
+void CuMatrixBase::ApplyExp() { ASLP_EW(cudaF_apply_exp(kD3, kD3, data_, Dim())); }
+void CuMatrixBase::ApplyHeaviside() { ASLP_EW(cudaF_apply_heaviside(kD3, kD3, data_, Dim())); }
+void CuMatrixBase::InvertElements() { ASLP_EW(cudaF_invert_elements(kD3, kD3, data_, Dim())); }
+
+void CuMatrixBase::CopyFromMat(const CuMatrixBase &src) {
+  ASLP_ASSERT(SameDim(*this, src));
+  if (!rows_) return;
+  if (src.Data() == data_ && src.Stride() == stride_) return;
+  aslp_copy_mat(data_, Dim(), src.Data(), src.Stride());
+  CheckKernels();
+}
+void CuMatrixBase::CopyFromHost(const float *src, int ld) {
+  if (!rows_) return;
+  CheckHip(hipMemcpy2DAsync(data_, sizeof(float) * stride_, src, sizeof(float) * ld, sizeof(float) * cols_, rows_,
+                            hipMemcpyHostToDevice, cur_stream()), "hipMemcpy2D H2D");
+  CheckHip(hipStreamSynchronize(cur_stream()), "hipStreamSynchronize");
+}
+void CuMatrixBase::CopyToHost(float *dst, int ld) const {
+  if (!rows_) return;
+  CheckHip(hipMemcpy2DAsync(dst, sizeof(float) * ld, data_, sizeof(float) * stride_, sizeof(float) * cols_, rows_,
+                            hipMemcpyDeviceToHost, cur_stream()), "hipMemcpy2D D2H");
+  CheckHip(hipStreamSynchronize(cur_stream()), "hipStreamSynchronize");
+}
+void CuMatrixBase::CopyFromMat(const HostMatrix &m) {
+  ASLP_ASSERT(m.rows == rows_ && m.cols == cols_);
+  CopyFromHost(m.data.data(), m.cols);
+}
+void CuMatrixBase::CopyToMat(HostMatrix *m) const {
+  m->Resize(rows_, cols_);
+  CopyToHost(m->data.data(), cols_);
+}
+void CuMatrixBase::AddMat(float alpha, const CuMatrixBase &A, MatrixTransposeType tA) {
+  if (tA == kNoTrans) ASLP_ASSERT(SameDim(*this, A));
+  else ASLP_ASSERT(A.NumRows() == cols_ && A.NumCols() == rows_);
+  ASLP_EW(cudaF_add_mat(kD3, kD3, alpha, A.Data(), data_, Dim(), A.Stride(), tA == kTrans ? 1 : 0));
+}
+void CuMatrixBase::AddMatMat(float alpha, const CuMatrixBase &A, MatrixTransposeType tA, const CuMatrixBase &B, MatrixTransposeType tB,
+                             float beta, const aslp_gemm_epilogue *ep) {
+  // cu-matrix.cc:1027-1046 dimension checks
+  int m = (tB == kTrans ? B.NumRows() : B.NumCols());
+  int n = (tA == kTrans ? A.NumCols() : A.NumRows());
+  int k = (tB == kTrans ? B.NumCols() : B.NumRows());
+  int k1 = (tA == kTrans ? A.NumRows() : A.NumCols());
+  ASLP_ASSERT(m == NumCols());
+  ASLP_ASSERT(n == NumRows());
+  ASLP_ASSERT(k == k1);
+  if (m == 0) return;
+  int rc = aslp_sgemm_ex(tA == kTrans, tB == kTrans, rows_, cols_, k, alpha, A.Data(), A.Stride(), B.Data(), B.Stride(), beta, data_,
+                         stride_, ep);
+  if (rc != 0) ASLP_ERR << "aslp_sgemm argument error " << rc;
+  CheckKernels();
+}
+void CuMatrixBase::AddVecToRows(float alpha, const CuVectorBase &row, float beta) {
+  if (row.Dim() != NumCols()) ASLP_ERR << "Non matching dimensions: Cols:" << NumCols() << " VectorDim:" << row.Dim();
+  ASLP_EW(cudaF_add_vec_to_rows(kD3, kD3, alpha, row.Data(), beta, data_, Dim()));
+}
+void CuMatrixBase::AddVecToCols(float alpha, const CuVectorBase &col, float beta) {
+  if (col.Dim() != NumRows()) ASLP_ERR << "Non matching dimensions: Rows:" << NumRows() << " VectorDim:" << col.Dim();
+  ASLP_EW(cudaF_add_vec_to_cols(kD3, kD3, alpha, col.Data(), beta, data_, Dim()));
+}
+void CuMatrixBase::AddMatMatElements(float alpha, const CuMatrixBase &A, const CuMatrixBase &B, float beta) {
+  ASLP_ASSERT(SameDim(*this, A) && SameDim(A, B));
+  ASLP_EW(cudaF_add_mat_mat_elements(kD3, kD3, data_, A.Data(), B.Data(), Dim(), A.Stride(), B.Stride(), alpha, beta));
+}
+void CuMatrixBase::AddMatDiagVec(float alpha, const CuMatrixBase &M, MatrixTransposeType tM, const CuVectorBase &v, float beta) {
+  if (tM == kNoTrans) ASLP_ASSERT(SameDim(*this, M));
+  else ASLP_ASSERT(M.NumRows() == NumCols() && M.NumCols() == NumRows());
+  ASLP_ASSERT(v.Dim() == NumCols());
+  int rs = M.Stride(), cs = 1;
+  if (tM == kTrans) std::swap(rs, cs);
+  ASLP_EW(cudaF_add_mat_diag_vec(kD3, kD3, alpha, data_, Dim(), M.Data(), rs, cs, v.Data(), beta));
+}
+void CuMatrixBase::AddRowSumMat(float alpha, const CuMatrixBase &A, float beta) {
+  ASLP_ASSERT(NumRows() != 0 && A.NumRows() % NumRows() == 0);
+  ASLP_ASSERT(A.NumCols() == NumCols());
+  ASLP_EW(cudaF_add_row_sum_mat(kD3, kD3, data_, A.Data(), Dim(), A.Stride(), A.NumRows() / NumRows(), alpha, beta));
+}
+void CuMatrixBase::AddConvMatMatElements(float alpha, const CuMatrixBase &A, const CuMatrixBase &B, float beta) {
+  if (NumRows() == 0) return;
+  int a = A.NumRows(), b = B.NumRows();
+  ASLP_ASSERT(a >= b && NumRows() == ((a - b + 1) * b));
+  ASLP_ASSERT(NumCols() == A.NumCols() && A.NumCols() == B.NumCols());
+  aslp_dim3 bl = {2, (uint32_t)b, 1};
+  ASLP_EW(cudaF_add_conv_mat_mat_elements(kD3, bl, data_, A.Data(), B.Data(), Dim(), A.Stride(), B.Stride(), alpha, beta));
+}
+void CuMatrixBase::MulElements(const CuMatrixBase &A) {
+  ASLP_ASSERT(SameDim(*this, A));
+  ASLP_EW(cudaF_mul_elements(kD3, kD3, data_, A.Data(), Dim(), A.Stride()));
+}
+void CuMatrixBase::MulColsVec(const CuVectorBase &scale) {
+  ASLP_ASSERT(scale.Dim() == NumCols());
+  ASLP_EW(cudaF_mul_cols_vec(kD3, kD3, data_, scale.Data(), Dim()));
+}
+void CuMatrixBase::MulRowsVec(const CuVectorBase &scale) {
+  ASLP_ASSERT(scale.Dim() == NumRows());
+  ASLP_EW(cudaF_mul_rows_vec(kD3, kD3, data_, scale.Data(), Dim()));
+}
+void CuMatrixBase::Sigmoid(const CuMatrixBase &src) { ASLP_ASSERT(SameDim(*this, src)); ASLP_EW(cudaF_sigmoid(kD3, kD3, data_, src.Data(), Dim(), src.Stride())); }
+void CuMatrixBase::Tanh(const CuMatrixBase &src) { ASLP_ASSERT(SameDim(*this, src)); ASLP_EW(cudaF_tanh(kD3, kD3, data_, src.Data(), Dim(), src.Stride())); }
+void CuMatrixBase::DiffSigmoid(const CuMatrixBase &value, const CuMatrixBase &diff) {
+  ASLP_ASSERT(SameDim(*this, value) && SameDim(*this, diff));
+  ASLP_EW(cudaF_diff_sigmoid(kD3, kD3, data_, diff.Data(), value.Data(), Dim(), diff.Stride(), value.Stride()));
+}
+void CuMatrixBase::DiffTanh(const CuMatrixBase &value, const CuMatrixBase &diff) {
+  ASLP_ASSERT(SameDim(*this, value) && SameDim(*this, diff));
+  ASLP_EW(cudaF_diff_tanh(kD3, kD3, data_, diff.Data(), value.Data(), Dim(), diff.Stride(), value.Stride()));
+}
+void CuMatrixBase::ApplySoftMaxPerRow(const CuMatrixBase &src) {
+  ASLP_ASSERT(SameDim(*this, src));
+  ASLP_EW(cudaF_softmax_reduce(0, 0, data_, src.Data(), Dim(), src.Stride()));
+}
+void CuMatrixBase::ApplyLogSoftMaxPerRow(const CuMatrixBase &src) {
+  ASLP_ASSERT(SameDim(*this, src));
+  ASLP_EW(cudaF_log_softmax_reduce(0, 0, data_, src.Data(), Dim(), src.Stride()));
+}
+void CuMatrixBase::FindRowMaxId(CuArray<int32> *id) const {
+  id->Resize(rows_);
+  if (!rows_) return;
+  aslp_find_row_max_id(data_, Dim(), id->Data());
+  CheckKernels();
+}
+void CuMatrixBase::CopyRows(const CuMatrixBase &src, const CuArray<int32> &indices) {
+  ASLP_ASSERT(indices.Dim() == NumRows() && NumCols() == src.NumCols());
+  ASLP_EW(cudaF_copy_rows(kD3, kD3, data_, src.Data(), indices.Data(), Dim(), src.Stride()));
+}
+void CuMatrixBase::AddRows(float alpha, const CuMatrixBase &src, const CuArray<int32> &indices) {
+  ASLP_ASSERT(indices.Dim() == NumRows() && NumCols() == src.NumCols());
+  ASLP_EW(cudaF_add_rows(kD3, kD3, alpha, data_, src.Data(), indices.Data(), Dim(), src.Stride()));
+}
+void CuMatrixBase::CopyCols(const CuMatrixBase &src, const CuArray<int32> &indices) {
+  ASLP_ASSERT(indices.Dim() == NumCols() && NumRows() == src.NumRows());
+  ASLP_EW(cudaF_copy_cols(kD3, kD3, data_, src.Data(), indices.Data(), Dim(), src.Stride()));
+}
+double CuMatrixBase::Sum() const {
+  if (!rows_) return 0.0;
+  double *d = static_cast<double *>(DeviceAlloc(sizeof(double)));
+  aslp_matrix_sum(data_, Dim(), d);
+  double h = 0.0;
+  DeviceToHost(&h, d, sizeof(double));
+  DeviceFree(d);
+  CheckKernels();
+  return h;
+}
+
+namespace cu {
+void Splice(const CuMatrixBase &src, const CuArray<int32> &frame_offsets, CuMatrixBase *tgt) {
+  ASLP_ASSERT(src.NumCols() * frame_offsets.Dim() == tgt->NumCols());
+  ASLP_ASSERT(src.NumRows() == tgt->NumRows());
+  cudaF_splice(kD3, kD3, tgt->Data(), src.Data(), frame_offsets.Data(), tgt->Dim(), src.Dim());
+  CheckKernels();
+}
+void Copy(const CuMatrixBase &src, const CuArray<int32> &copy_from_indices, CuMatrixBase *tgt) {
+  ASLP_ASSERT(copy_from_indices.Dim() == tgt->NumCols());
+  ASLP_ASSERT(src.NumRows() == tgt->NumRows());
+  cudaF_copy(kD3, kD3, tgt->Data(), src.Data(), copy_from_indices.Data(), tgt->Dim(), src.Dim());
+  CheckKernels();
+}
+void Randomize(const CuMatrixBase &src, const CuArray<int32> &copy_from_idx, CuMatrixBase *tgt) {
+  ASLP_ASSERT(src.NumCols() == tgt->NumCols());
+  ASLP_ASSERT(src.NumRows() == tgt->NumRows());
+  ASLP_ASSERT(copy_from_idx.Dim() <= tgt->NumRows());
+  MatrixDim dimsrc = src.Dim(), dimtgt = tgt->Dim();
+  dimsrc.rows = copy_from_idx.Dim();
+  dimtgt.rows = copy_from_idx.Dim();
+  cudaF_randomize(kD3, kD3, tgt->Data(), src.Data(), copy_from_idx.Data(), dimtgt, dimsrc);
+  CheckKernels();
+}
+void RegularizeL1(CuMatrixBase *weight, CuMatrixBase *grad, float l1, float lr) {
+  ASLP_ASSERT(SameDim(*weight, *grad));
+  cudaF_regularize_l1(kD3, kD3, weight->Data(), grad->Data(), l1, lr, weight->Dim(), grad->Stride());
+  CheckKernels();
+}
+}  // namespace cu
+
+// nnet-utils.h:61-124
+static std::string MomentStatisticsHost(const std::vector<float> &v) {
+  double n = (double)v.size();
+  if (v.empty()) return " ( empty ) ";
+  double sum = 0, mn = v[0], mx = v[0];
+  for (float x : v) { sum += x; if (x < mn) mn = x; if (x > mx) mx = x; }
+  float mean = sum / n;
+  double m2 = 0, m3 = 0, m4 = 0;
+  for (float x : v) { double d = x - mean; m2 += d * d; m3 += d * d * d; m4 += d * d * d * d; }
+  float variance = m2 / n;
+  float skewness = m3 / pow(variance, 3.0 / 2.0) / n;
+  float kurtosis = m4 / (variance * variance) / n - 3.0;
+  std::ostringstream ostr;
+  ostr << " ( min " << (float)mn << ", max " << (float)mx << ", mean " << mean << ", variance " << variance << ", stddev "
+       << sqrt(variance) << ", skewness " << skewness << ", kurtosis " << kurtosis << " ) ";
+  return ostr.str();
+}
+std::string MomentStatistics(const CuMatrixBase &m) {
+  HostMatrix h;
+  m.CopyToMat(&h);
+  return MomentStatisticsHost(h.data);
+}
+std::string MomentStatistics(const CuVectorBase &v) {
+  std::vector<float> h(v.Dim());
+  v.CopyToHost(h.data());
+  return MomentStatisticsHost(h);
+}
+
+}  // namespace aslp

@@ -1,0 +1,294 @@
+// cu-matrix.h -- device matrix / vector / array substrate of the host engine.
+//
+// Mirrors the method vocabulary of the reference's CuMatrixBase / CuVectorBase / CuArray
+// (src/aslp-cudamatrix/cu-matrix.h, cu-vector.h, cu-array.h) for the subset the hot path
+// uses, on top of the gfx950 kernels of csrc/.  There is no CPU branch: every method launches
+// a HIP kernel on the library stream.  Memory comes from a caching device allocator (the
+// reference has one for the same reason, cu-allocator.h:67-70); rows are padded to a multiple
+// of 16 floats so every row starts on a 64-byte boundary and float4 lanes never straddle rows.
+#pragma once
+#include <vector>
+
+#include "aslp_kernels.h"
+#include "base.h"
+
+namespace aslp {
+
+enum MatrixResizeType { kSetZero, kUndefined, kCopyData };
+enum MatrixTransposeType { kNoTrans = 0, kTrans = 1 };
+
+void *DeviceAlloc(size_t bytes);
+void DeviceFree(void *p);
+void DeviceToHost(void *dst, const void *src, size_t bytes);
+void HostToDevice(void *dst, const void *src, size_t bytes);
+void DeviceToDevice(void *dst, const void *src, size_t bytes);
+void DeviceMemset(void *dst, int v, size_t bytes);
+void StreamSync();
+inline int PaddedStride(int cols) { return (cols + 15) & ~15; }
+
+// Host-side matrix / vector used for I/O and parameter exchange (replaces kaldi::Matrix/Vector there).
+struct HostMatrix {
+  int rows = 0, cols = 0;
+  std::vector<float> data;
+  HostMatrix() {}
+  HostMatrix(int r, int c) : rows(r), cols(c), data((size_t)r * c, 0.0f) {}
+  float &operator()(int r, int c) { return data[(size_t)r * cols + c]; }
+  float operator()(int r, int c) const { return data[(size_t)r * cols + c]; }
+  void Resize(int r, int c) { rows = r; cols = c; data.assign((size_t)r * c, 0.0f); }
+  void Read(std::istream &is, bool binary);
+  void Write(std::ostream &os, bool binary) const;
+};
+struct HostVector {
+  std::vector<float> data;
+  HostVector() {}
+  explicit HostVector(int n) : data(n, 0.0f) {}
+  int Dim() const { return (int)data.size(); }
+  void Read(std::istream &is, bool binary);
+  void Write(std::ostream &os, bool binary) const;
+};
+struct HostVectorD {
+  std::vector<double> data;
+  int Dim() const { return (int)data.size(); }
+  void Read(std::istream &is, bool binary);
+  void Write(std::ostream &os, bool binary) const;
+};
+
+template <typename T>
+class CuArray {
+ public:
+  CuArray() : data_(nullptr), dim_(0) {}
+  explicit CuArray(const std::vector<T> &v) : data_(nullptr), dim_(0) { CopyFromVec(v); }
+  CuArray(const CuArray &o) : data_(nullptr), dim_(0) { *this = o; }
+  CuArray &operator=(const CuArray &o) {
+    if (this != &o) {
+      Resize(o.dim_);
+      if (dim_) DeviceToDevice(data_, o.data_, sizeof(T) * dim_);
+    }
+    return *this;
+  }
+  CuArray &operator=(const std::vector<T> &v) { CopyFromVec(v); return *this; }
+  ~CuArray() { DeviceFree(data_); }
+  void Resize(int n) {
+    if (n == dim_) return;
+    DeviceFree(data_);
+    data_ = n ? static_cast<T *>(DeviceAlloc(sizeof(T) * n)) : nullptr;
+    dim_ = n;
+  }
+  void CopyFromVec(const std::vector<T> &v) {
+    Resize((int)v.size());
+    if (dim_) HostToDevice(data_, v.data(), sizeof(T) * dim_);
+  }
+  void CopyToVec(std::vector<T> *v) const {
+    v->resize(dim_);
+    if (dim_) DeviceToHost(v->data(), data_, sizeof(T) * dim_);
+  }
+  int Dim() const { return dim_; }
+  T *Data() { return data_; }
+  const T *Data() const { return data_; }
+
+ private:
+  T *data_;
+  int dim_;
+};
+
+class CuMatrixBase;
+class CuSubVector;
+
+class CuVectorBase {
+ public:
+  int Dim() const { return dim_; }
+  float *Data() { return data_; }
+  const float *Data() const { return data_; }
+  void SetZero();
+  void Set(float v);
+  void Add(float v);
+  void Scale(float v);
+  void CopyFromVec(const CuVectorBase &v);
+  void CopyFromHost(const float *src, int n);
+  void CopyToHost(float *dst) const;
+  void CopyToVec(HostVector *v) const { v->data.resize(dim_); CopyToHost(v->data.data()); }
+  void AddVec(float alpha, const CuVectorBase &v, float beta = 1.0f);               // this = alpha*v + beta*this
+  void AddRowSumMat(float alpha, const CuMatrixBase &M, float beta = 1.0f);         // column sums
+  void AddColSumMat(float alpha, const CuMatrixBase &M, float beta = 1.0f);         // row sums
+  void AddDiagMatMat(float alpha, const CuMatrixBase &M, MatrixTransposeType tM, const CuMatrixBase &N,
+                     MatrixTransposeType tN, float beta = 1.0f);
+  void AddVecVec(float alpha, const CuVectorBase &x, const CuVectorBase &y, float beta);
+  void MulElements(const CuVectorBase &v);
+  void ApplyFloor(float v);
+  void ApplyCeiling(float v);
+  void ApplyPow(float p);
+  void InvertElements();
+  float Sum() const;  // blocking
+  CuSubVector Range(int o, int n);
+
+ protected:
+  CuVectorBase() : data_(nullptr), dim_(0) {}
+  MatrixDim AsRow() const { MatrixDim d = {1, dim_, dim_}; return d; }
+  float *data_;
+  int dim_;
+};
+
+class CuVector : public CuVectorBase {
+ public:
+  CuVector() {}
+  explicit CuVector(int dim, MatrixResizeType t = kSetZero) { Resize(dim, t); }
+  CuVector(const CuVectorBase &o) { *this = o; }
+  CuVector(const CuVector &o) : CuVectorBase() { *this = static_cast<const CuVectorBase &>(o); }
+  CuVector &operator=(const CuVectorBase &o) {
+    Resize(o.Dim(), kUndefined);
+    CopyFromVec(o);
+    return *this;
+  }
+  CuVector &operator=(const CuVector &o) { return *this = static_cast<const CuVectorBase &>(o); }
+  CuVector &operator=(const HostVector &v) {
+    Resize(v.Dim(), kUndefined);
+    CopyFromHost(v.data.data(), v.Dim());
+    return *this;
+  }
+  ~CuVector() { DeviceFree(data_); }
+  void Resize(int dim, MatrixResizeType t = kSetZero);
+  void Read(std::istream &is, bool binary) { HostVector v; v.Read(is, binary); *this = v; }
+  void Write(std::ostream &os, bool binary) const { HostVector v; CopyToVec(&v); v.Write(os, binary); }
+};
+
+class CuSubVector : public CuVectorBase {
+ public:
+  CuSubVector(float *data, int dim) { data_ = data; dim_ = dim; }
+};
+
+// double vector: only what BatchNormalization's running statistics need
+class CuVectorD {
+ public:
+  CuVectorD() : data_(nullptr), dim_(0) {}
+  CuVectorD(const CuVectorD &o) : data_(nullptr), dim_(0) { *this = o; }
+  CuVectorD &operator=(const CuVectorD &o);
+  ~CuVectorD() { DeviceFree(data_); }
+  void Resize(int dim, MatrixResizeType t = kSetZero);
+  void SetZero();
+  int Dim() const { return dim_; }
+  double *Data() { return data_; }
+  const double *Data() const { return data_; }
+  void CopyFromHost(const double *src, int n);
+  void CopyToHost(double *dst) const;
+  void Read(std::istream &is, bool binary);
+  void Write(std::ostream &os, bool binary) const;
+
+ private:
+  double *data_;
+  int dim_;
+};
+
+class CuSubMatrix;
+
+class CuMatrixBase {
+ public:
+  int NumRows() const { return rows_; }
+  int NumCols() const { return cols_; }
+  int Stride() const { return stride_; }
+  float *Data() { return data_; }
+  const float *Data() const { return data_; }
+  float *RowData(int r) { return data_ + (size_t)r * stride_; }
+  const float *RowData(int r) const { return data_ + (size_t)r * stride_; }
+  MatrixDim Dim() const { MatrixDim d = {rows_, cols_, stride_}; return d; }
+
+  CuSubMatrix Range(int r0, int nr, int c0, int nc) const;
+  CuSubMatrix RowRange(int r0, int nr) const;
+  CuSubMatrix ColRange(int c0, int nc) const;
+  CuSubVector Row(int r);
+
+  void SetZero();
+  void Set(float v);
+  void Add(float v);
+  void Scale(float v);
+  void ApplyFloor(float v);
+  void ApplyCeiling(float v);
+  void ApplyPow(float p);
+  void ApplyLog();
+  void ApplyExp();
+  void ApplyHeaviside();
+  void InvertElements();
+  void CopyFromMat(const CuMatrixBase &src);
+  void CopyFromHost(const float *src, int ld);
+  void CopyToHost(float *dst, int ld) const;
+  void CopyFromMat(const HostMatrix &m);
+  void CopyToMat(HostMatrix *m) const;
+  void AddMat(float alpha, const CuMatrixBase &A, MatrixTransposeType tA = kNoTrans);  // this += alpha*A
+  void AddMatMat(float alpha, const CuMatrixBase &A, MatrixTransposeType tA, const CuMatrixBase &B, MatrixTransposeType tB,
+                 float beta, const aslp_gemm_epilogue *ep = nullptr);
+  void AddVecToRows(float alpha, const CuVectorBase &row, float beta = 1.0f);
+  void AddVecToCols(float alpha, const CuVectorBase &col, float beta = 1.0f);
+  void AddMatMatElements(float alpha, const CuMatrixBase &A, const CuMatrixBase &B, float beta);
+  void AddMatDiagVec(float alpha, const CuMatrixBase &M, MatrixTransposeType tM, const CuVectorBase &v, float beta = 1.0f);
+  void AddRowSumMat(float alpha, const CuMatrixBase &A, float beta);           // ASLP group-row sum (cu-matrix.cc:3010)
+  void AddConvMatMatElements(float alpha, const CuMatrixBase &A, const CuMatrixBase &B, float beta);  // cu-matrix.cc:3037
+  void MulElements(const CuMatrixBase &A);
+  void MulColsVec(const CuVectorBase &scale);
+  void MulRowsVec(const CuVectorBase &scale);
+  void Sigmoid(const CuMatrixBase &src);
+  void Tanh(const CuMatrixBase &src);
+  void DiffSigmoid(const CuMatrixBase &value, const CuMatrixBase &diff);
+  void DiffTanh(const CuMatrixBase &value, const CuMatrixBase &diff);
+  void ApplySoftMaxPerRow(const CuMatrixBase &src);
+  void ApplyLogSoftMaxPerRow(const CuMatrixBase &src);
+  void FindRowMaxId(CuArray<int32> *id) const;
+  void CopyRows(const CuMatrixBase &src, const CuArray<int32> &indices);
+  void AddRows(float alpha, const CuMatrixBase &src, const CuArray<int32> &indices);
+  void CopyCols(const CuMatrixBase &src, const CuArray<int32> &indices);
+  double Sum() const;  // blocking (CuMatrixBase::Sum)
+
+ protected:
+  CuMatrixBase() : data_(nullptr), rows_(0), cols_(0), stride_(0) {}
+  CuMatrixBase(float *d, int r, int c, int s) : data_(d), rows_(r), cols_(c), stride_(s) {}
+  float *data_;
+  int rows_, cols_, stride_;
+};
+
+class CuMatrix : public CuMatrixBase {
+ public:
+  CuMatrix() {}
+  CuMatrix(int rows, int cols, MatrixResizeType t = kSetZero) { Resize(rows, cols, t); }
+  CuMatrix(const CuMatrixBase &o) { *this = o; }
+  CuMatrix(const CuMatrix &o) : CuMatrixBase() { *this = static_cast<const CuMatrixBase &>(o); }
+  CuMatrix &operator=(const CuMatrixBase &o) {
+    Resize(o.NumRows(), o.NumCols(), kUndefined);
+    CopyFromMat(o);
+    return *this;
+  }
+  CuMatrix &operator=(const CuMatrix &o) { return *this = static_cast<const CuMatrixBase &>(o); }
+  CuMatrix &operator=(const HostMatrix &m) {
+    Resize(m.rows, m.cols, kUndefined);
+    CopyFromMat(m);
+    return *this;
+  }
+  ~CuMatrix() { DeviceFree(data_); }
+  void Resize(int rows, int cols, MatrixResizeType t = kSetZero);
+  void Swap(CuMatrix *o) {
+    std::swap(data_, o->data_); std::swap(rows_, o->rows_); std::swap(cols_, o->cols_); std::swap(stride_, o->stride_);
+  }
+  void Read(std::istream &is, bool binary) { HostMatrix m; m.Read(is, binary); *this = m; }
+  void Write(std::ostream &os, bool binary) const { HostMatrix m; CopyToMat(&m); m.Write(os, binary); }
+};
+
+class CuSubMatrix : public CuMatrixBase {
+ public:
+  CuSubMatrix(const CuMatrixBase &m, int r0, int nr, int c0, int nc)
+      : CuMatrixBase(const_cast<float *>(m.Data()) + (size_t)r0 * m.Stride() + c0, nr, nc, m.Stride()) {
+    ASLP_ASSERT(r0 >= 0 && nr >= 0 && r0 + nr <= m.NumRows() && c0 >= 0 && nc >= 0 && c0 + nc <= m.NumCols());
+  }
+  CuSubMatrix(float *data, int rows, int cols, int stride) : CuMatrixBase(data, rows, cols, stride) {}
+};
+
+inline bool SameDim(const CuMatrixBase &a, const CuMatrixBase &b) { return a.NumRows() == b.NumRows() && a.NumCols() == b.NumCols(); }
+
+namespace cu {
+// cu-math.h
+void Splice(const CuMatrixBase &src, const CuArray<int32> &frame_offsets, CuMatrixBase *tgt);
+void Copy(const CuMatrixBase &src, const CuArray<int32> &copy_from_indices, CuMatrixBase *tgt);
+void Randomize(const CuMatrixBase &src, const CuArray<int32> &copy_from_idx, CuMatrixBase *tgt);
+void RegularizeL1(CuMatrixBase *weight, CuMatrixBase *grad, float l1, float lr);
+}  // namespace cu
+
+std::string MomentStatistics(const CuMatrixBase &m);
+std::string MomentStatistics(const CuVectorBase &v);
+
+}  // namespace aslp

@@ -1,0 +1,567 @@
+// nnet-basic.h -- feed-forward components of the hot path on the gfx950 kernels:
+// InputLayer / OutputLayer / ScaleLayer (nnet-io.h), AffineTransform (nnet-affine-transform.h),
+// Sigmoid / Tanh / ReLU / Softmax / BlockSoftmax (nnet-activation.h), Splice / Copy / AddShift /
+// Rescale (nnet-various.h), BatchNormalization (nnet-batch-normalization.h).
+// Reference file:line for each method is cited in place.
+#pragma once
+#include <algorithm>
+#include <cmath>
+
+#include "nnet-component.h"
+
+namespace aslp {
+
+// ---- graph endpoints (nnet-io.h:19-102) -------------------------------------------------------
+class InputLayer : public Component {
+ public:
+  InputLayer(int32 di, int32 dout) : Component(di, dout) { ASLP_ASSERT(di == dout); }
+  Component *Copy() const { return new InputLayer(*this); }
+  ComponentType GetType() const { return kInputLayer; }
+  void PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) { out->CopyFromMat(in); }
+  void BackpropagateFnc(const CuMatrixBase &, const CuMatrixBase &, const CuMatrixBase &od, CuMatrixBase *id) { id->CopyFromMat(od); }
+};
+class OutputLayer : public Component {
+ public:
+  OutputLayer(int32 di, int32 dout) : Component(di, dout) { ASLP_ASSERT(di == dout); }
+  Component *Copy() const { return new OutputLayer(*this); }
+  ComponentType GetType() const { return kOutputLayer; }
+  void PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) { out->CopyFromMat(in); }
+  void BackpropagateFnc(const CuMatrixBase &, const CuMatrixBase &, const CuMatrixBase &od, CuMatrixBase *id) { id->CopyFromMat(od); }
+};
+class ScaleLayer : public Component {
+ public:
+  ScaleLayer(int32 di, int32 dout) : Component(di, dout), scale_(1.0) { ASLP_ASSERT(di == dout); }
+  Component *Copy() const { return new ScaleLayer(*this); }
+  ComponentType GetType() const { return kScaleLayer; }
+  void InitData(std::istream &is) { ExpectToken(is, false, "<Scale>"); ReadBasicType(is, false, &scale_); }
+  void ReadData(std::istream &is, bool binary) { ExpectToken(is, binary, "<Scale>"); ReadBasicType(is, binary, &scale_); }
+  void WriteData(std::ostream &os, bool binary) const { WriteToken(os, binary, "<Scale>"); WriteBasicType(os, binary, scale_); }
+  void PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) { out->CopyFromMat(in); out->Scale(scale_); }
+  void BackpropagateFnc(const CuMatrixBase &, const CuMatrixBase &, const CuMatrixBase &od, CuMatrixBase *id) { id->CopyFromMat(od); id->Scale(scale_); }
+  BaseFloat Scale() const { return scale_; }
+ private:
+  BaseFloat scale_;
+};
+
+// ---- AffineTransform (nnet-affine-transform.h:34-286) --------------------------------------------
+class AffineTransform : public UpdatableComponent {
+ public:
+  AffineTransform(int32 dim_in, int32 dim_out)
+      : UpdatableComponent(dim_in, dim_out), linearity_(dim_out, dim_in), bias_(dim_out), linearity_corr_(dim_out, dim_in),
+        bias_corr_(dim_out), learn_rate_coef_(1.0), bias_learn_rate_coef_(1.0), max_norm_(0.0) {}
+  Component *Copy() const { return new AffineTransform(*this); }
+  ComponentType GetType() const { return kAffineTransform; }
+
+  void InitData(std::istream &is) {  // :61-127
+    float bias_mean = -2.0, bias_range = 2.0, param_stddev = 0.1;
+    float learn_rate_coef = 1.0, bias_learn_rate_coef = 1.0, max_norm = 0.0, norm_init_scale = 1.0;
+    bool gauss_init = true;
+    std::string token;
+    while (!is.eof()) {
+      ReadToken(is, false, &token);
+      if (token == "<NormInit>") { ReadBasicType(is, false, &norm_init_scale); gauss_init = false; }
+      else if (token == "<ParamStddev>") ReadBasicType(is, false, &param_stddev);
+      else if (token == "<BiasMean>") ReadBasicType(is, false, &bias_mean);
+      else if (token == "<BiasRange>") ReadBasicType(is, false, &bias_range);
+      else if (token == "<LearnRateCoef>") ReadBasicType(is, false, &learn_rate_coef);
+      else if (token == "<BiasLearnRateCoef>") ReadBasicType(is, false, &bias_learn_rate_coef);
+      else if (token == "<MaxNorm>") ReadBasicType(is, false, &max_norm);
+      else ASLP_ERR << "Unknown token " << token << ", a typo in config?"
+                    << " (ParamStddev|BiasMean|BiasRange|LearnRateCoef|BiasLearnRateCoef)";
+      is >> std::ws;
+    }
+    if (!gauss_init) {  // Glorot-Bengio
+      float scale = norm_init_scale * sqrt(6.0 / (linearity_.NumRows() + linearity_.NumCols()));
+      InitMatParamUniform(linearity_, scale);
+      InitVecParamUniform(bias_, scale);
+    } else {
+      HostMatrix mat(output_dim_, input_dim_);
+      for (int32 r = 0; r < output_dim_; r++)
+        for (int32 c = 0; c < input_dim_; c++) mat(r, c) = param_stddev * RandGauss();
+      linearity_ = mat;
+      HostVector vec(output_dim_);
+      for (int32 i = 0; i < output_dim_; i++) vec.data[i] = bias_mean + (RandUniform() - 0.5) * bias_range;
+      bias_ = vec;
+    }
+    learn_rate_coef_ = learn_rate_coef;
+    bias_learn_rate_coef_ = bias_learn_rate_coef;
+    max_norm_ = max_norm;
+  }
+  void ReadData(std::istream &is, bool binary) {  // :129-155
+    if ('<' == Peek(is, binary)) {
+      ExpectToken(is, binary, "<LearnRateCoef>");
+      ReadBasicType(is, binary, &learn_rate_coef_);
+      ExpectToken(is, binary, "<BiasLearnRateCoef>");
+      ReadBasicType(is, binary, &bias_learn_rate_coef_);
+    }
+    if ('<' == Peek(is, binary)) { ExpectToken(is, binary, "<MaxNorm>"); ReadBasicType(is, binary, &max_norm_); }
+    if ('<' == Peek(is, binary)) { float tmp; ExpectToken(is, binary, "<ClipGradient>"); ReadBasicType(is, binary, &tmp); }
+    linearity_.Read(is, binary);
+    bias_.Read(is, binary);
+    ASLP_ASSERT(linearity_.NumRows() == output_dim_);
+    ASLP_ASSERT(linearity_.NumCols() == input_dim_);
+    ASLP_ASSERT(bias_.Dim() == output_dim_);
+    linearity_corr_.Resize(output_dim_, input_dim_);
+    bias_corr_.Resize(output_dim_);
+  }
+  void WriteData(std::ostream &os, bool binary) const {  // :157-167
+    WriteToken(os, binary, "<LearnRateCoef>"); WriteBasicType(os, binary, learn_rate_coef_);
+    WriteToken(os, binary, "<BiasLearnRateCoef>"); WriteBasicType(os, binary, bias_learn_rate_coef_);
+    WriteToken(os, binary, "<MaxNorm>"); WriteBasicType(os, binary, max_norm_);
+    linearity_.Write(os, binary);
+    bias_.Write(os, binary);
+  }
+  int32 NumParams() const { return linearity_.NumRows() * linearity_.NumCols() + bias_.Dim(); }
+  void GetParams(std::vector<BaseFloat> *w) const { w->clear(); AppendRowMajor(linearity_, w); AppendVector(bias_, w); }
+  void GetGpuParams(std::vector<std::pair<BaseFloat *, int>> *params) {  // :166-170
+    params->clear();
+    params->push_back(std::make_pair(linearity_.Data(), linearity_.NumRows() * linearity_.Stride()));
+    params->push_back(std::make_pair(bias_.Data(), bias_.Dim()));
+  }
+  std::string Info() const { return std::string("\n  linearity") + MomentStatistics(linearity_) + "\n  bias" + MomentStatistics(bias_); }
+  std::string InfoGradient() const {
+    std::ostringstream o;
+    o << "\n  linearity_grad" << MomentStatistics(linearity_corr_) << ", lr-coef " << learn_rate_coef_ << ", max-norm " << max_norm_
+      << "\n  bias_grad" << MomentStatistics(bias_corr_) << ", lr-coef " << bias_learn_rate_coef_;
+    return o.str();
+  }
+
+  void PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) {
+    // :186-191  out = bias (beta 0); out += in * W^T.  One GEMM with the bias in the epilogue.
+    aslp_gemm_epilogue ep = aslp_gemm_epilogue();
+    ep.bias = bias_.Data();
+    out->AddMatMat(1.0, in, kNoTrans, linearity_, kTrans, 0.0, &ep);
+  }
+  void BackpropagateFnc(const CuMatrixBase &, const CuMatrixBase &, const CuMatrixBase &out_diff, CuMatrixBase *in_diff) {
+    in_diff->AddMatMat(1.0, out_diff, kNoTrans, linearity_, kNoTrans, 0.0);  // :193-197
+  }
+  void Update(const CuMatrixBase &input, const CuMatrixBase &diff) {  // :200-245
+    const BaseFloat lr = opts_.learn_rate * learn_rate_coef_;
+    const BaseFloat lr_bias = opts_.learn_rate * bias_learn_rate_coef_;
+    const BaseFloat mmt = opts_.momentum, l2 = opts_.l2_penalty, l1 = opts_.l1_penalty;
+    const int32 num_frames = input.NumRows();
+    const bool plain = (l2 == 0.0 && l1 == 0.0);
+    // gradient (sums over frames, incl. momentum); when no regulariser sits between the
+    // gradient and the step, the SGD step W += -lr * W_corr rides in the GEMM epilogue.
+    aslp_gemm_epilogue ep = aslp_gemm_epilogue();
+    if (plain) { ep.W = linearity_.Data(); ep.ldw = linearity_.Stride(); ep.w_alpha = -lr; }
+    linearity_corr_.AddMatMat(1.0, diff, kTrans, input, kNoTrans, mmt, &ep);
+    bias_corr_.AddRowSumMat(1.0, diff, mmt);
+    if (!plain) {
+      if (l2 != 0.0) linearity_.AddMat(-lr * l2 * num_frames, linearity_);
+      if (l1 != 0.0) cu::RegularizeL1(&linearity_, &linearity_corr_, lr * l1 * num_frames, lr);
+      linearity_.AddMat(-lr, linearity_corr_);
+    }
+    bias_.AddVec(-lr_bias, bias_corr_);
+    if (max_norm_ > 0.0) { aslp_max_norm_rows(linearity_.Data(), linearity_.Dim(), max_norm_); }  // :231-243
+  }
+  const CuVectorBase &GetBias() const { return bias_; }
+  void SetBias(const CuVectorBase &bias) { ASLP_ASSERT(bias.Dim() == bias_.Dim()); bias_.CopyFromVec(bias); }
+  const CuMatrixBase &GetLinearity() const { return linearity_; }
+  void SetLinearity(const CuMatrixBase &l) { ASLP_ASSERT(SameDim(l, linearity_)); linearity_.CopyFromMat(l); }
+  const CuVectorBase &GetBiasCorr() const { return bias_corr_; }
+  const CuMatrixBase &GetLinearityCorr() const { return linearity_corr_; }
+
+ private:
+  CuMatrix linearity_;
+  CuVector bias_;
+  CuMatrix linearity_corr_;
+  CuVector bias_corr_;
+  BaseFloat learn_rate_coef_, bias_learn_rate_coef_, max_norm_;
+};
+
+// ---- activations (nnet-activation.h) -----------------------------------------------------------------
+class Softmax : public Component {
+ public:
+  Softmax(int32 di, int32 dout) : Component(di, dout) {}
+  Component *Copy() const { return new Softmax(*this); }
+  ComponentType GetType() const { return kSoftmax; }
+  void PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) { out->ApplySoftMaxPerRow(in); }
+  // :51-59 backward is a plain copy: out_diff already is (y - t)
+  void BackpropagateFnc(const CuMatrixBase &, const CuMatrixBase &, const CuMatrixBase &od, CuMatrixBase *id) { id->CopyFromMat(od); }
+};
+
+class BlockSoftmax : public Component {  // :64-143
+ public:
+  BlockSoftmax(int32 di, int32 dout) : Component(di, dout) {}
+  Component *Copy() const { return new BlockSoftmax(*this); }
+  ComponentType GetType() const { return kBlockSoftmax; }
+  void InitData(std::istream &is) {
+    std::string token, dims_str;
+    while (!is.eof()) {
+      ReadToken(is, false, &token);
+      if (token == "<BlockDims>") is >> dims_str;
+      else ASLP_ERR << "Unknown token " << token << ", a typo in config? (BlockDims)";
+      is >> std::ws;
+    }
+    if (!SplitStringToIntegers(dims_str, ",:", false, &block_dims)) ASLP_ERR << "Invalid block-dims " << dims_str;
+    SetOffsets();
+  }
+  void ReadData(std::istream &is, bool binary) { ReadIntegerVector(is, binary, &block_dims); SetOffsets(); }
+  void WriteData(std::ostream &os, bool binary) const { WriteIntegerVector(os, binary, block_dims); }
+  void PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) {
+    for (size_t bl = 0; bl < block_dims.size(); bl++) {
+      CuSubMatrix in_bl = in.ColRange(block_offset[bl], block_dims[bl]);
+      CuSubMatrix out_bl = out->ColRange(block_offset[bl], block_dims[bl]);
+      out_bl.ApplySoftMaxPerRow(in_bl);
+    }
+  }
+  void BackpropagateFnc(const CuMatrixBase &, const CuMatrixBase &, const CuMatrixBase &od, CuMatrixBase *id) {
+    id->CopyFromMat(od);
+    for (size_t bl = 0; bl < block_dims.size(); bl++) {  // :118-131 zero rows whose block-sum is non-zero
+      CuSubMatrix diff_bl = id->ColRange(block_offset[bl], block_dims[bl]);
+      CuVector row_sum(diff_bl.NumRows());
+      row_sum.AddColSumMat(1.0, diff_bl, 0.0);
+      CuVector mask(row_sum);
+      mask.Scale(-1.0);
+      mask.Add(1.0);
+      diff_bl.MulRowsVec(mask);
+    }
+  }
+  std::vector<int32> block_dims, block_offset;
+ private:
+  void SetOffsets() {
+    block_offset.assign(block_dims.size() + 1, 0);
+    for (size_t i = 0; i < block_dims.size(); i++) block_offset[i + 1] = block_offset[i] + block_dims[i];
+    ASLP_ASSERT(OutputDim() == block_offset.back());
+  }
+};
+
+class Sigmoid : public Component {
+ public:
+  Sigmoid(int32 di, int32 dout) : Component(di, dout) {}
+  Component *Copy() const { return new Sigmoid(*this); }
+  ComponentType GetType() const { return kSigmoid; }
+  void PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) { out->Sigmoid(in); }
+  void BackpropagateFnc(const CuMatrixBase &, const CuMatrixBase &out, const CuMatrixBase &od, CuMatrixBase *id) { id->DiffSigmoid(out, od); }
+};
+class Tanh : public Component {
+ public:
+  Tanh(int32 di, int32 dout) : Component(di, dout) {}
+  Component *Copy() const { return new Tanh(*this); }
+  ComponentType GetType() const { return kTanh; }
+  void PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) { out->Tanh(in); }
+  void BackpropagateFnc(const CuMatrixBase &, const CuMatrixBase &out, const CuMatrixBase &od, CuMatrixBase *id) { id->DiffTanh(out, od); }
+};
+class ReLU : public Component {  // :281-298
+ public:
+  ReLU(int32 di, int32 dout) : Component(di, dout) {}
+  Component *Copy() const { return new ReLU(*this); }
+  ComponentType GetType() const { return kReLU; }
+  void PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) { out->CopyFromMat(in); out->ApplyFloor(0.0); }
+  void BackpropagateFnc(const CuMatrixBase &in, const CuMatrixBase &, const CuMatrixBase &od, CuMatrixBase *id) {
+    aslp_diff_relu(id->Data(), in.Data(), od.Data(), id->Dim(), in.Stride(), od.Stride());
+  }
+};
+
+// ---- Splice / Copy (nnet-various.h:43-330) ----------------------------------------------------------------
+inline void ParseBuildVector(std::istream &is, std::vector<int32> *out, const char *what) {
+  // nnet-various.h:54-107: <ReadVector> [ ... ] | <BuildVector> a:b a:s:b c </BuildVector>
+  std::vector<std::vector<int32>> build_vector;
+  std::string token;
+  while (!is.eof()) {
+    ReadToken(is, false, &token);
+    if (token == "<ReadVector>") {
+      ReadIntegerVector(is, false, out);
+    } else if (token == "<BuildVector>") {
+      while (!is.eof()) {
+        std::string s;
+        ReadToken(is, false, &s);
+        if (s == "</BuildVector>") break;
+        std::vector<int32> v;
+        SplitStringToIntegers(s, ":", false, &v);
+        build_vector.push_back(v);
+      }
+    } else {
+      ASLP_ERR << "Unknown token " << token << ", a typo in config? (ReadVector|BuildVector)";
+    }
+    is >> std::ws;
+  }
+  for (auto &b : build_vector) {
+    switch (b.size()) {
+      case 1: out->push_back(b[0]); break;
+      case 2: {
+        ASLP_ASSERT(b[0] <= b[1]);
+        for (int32 j = b[0]; j <= b[1]; j++) out->push_back(j);
+      } break;
+      case 3: {
+        int32 mn = b[0], step = b[1], mx = b[2];
+        ASLP_ASSERT((mn <= mx && step > 0) || (mn >= mx && step < 0));
+        for (int32 j = mn; j <= mx; j += step) out->push_back(j);
+      } break;
+      default: ASLP_ERR << "Error parsing <BuildVector> of " << what;
+    }
+  }
+}
+
+class Splice : public Component {
+ public:
+  Splice(int32 di, int32 dout) : Component(di, dout) {}
+  Component *Copy() const { return new Splice(*this); }
+  ComponentType GetType() const { return kSplice; }
+  void InitData(std::istream &is) {
+    std::vector<int32> fo;
+    ParseBuildVector(is, &fo, "Splice");
+    frame_offsets_ = fo;
+    ASLP_ASSERT(frame_offsets_.Dim() * InputDim() == OutputDim());
+  }
+  void ReadData(std::istream &is, bool binary) {
+    std::vector<int32> fo;
+    ReadIntegerVector(is, binary, &fo);
+    frame_offsets_ = fo;
+    ASLP_ASSERT(frame_offsets_.Dim() * InputDim() == OutputDim());
+  }
+  void WriteData(std::ostream &os, bool binary) const {
+    std::vector<int32> fo;
+    frame_offsets_.CopyToVec(&fo);
+    WriteIntegerVector(os, binary, fo);
+  }
+  void PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) { cu::Splice(in, frame_offsets_, out); }
+  void BackpropagateFnc(const CuMatrixBase &, const CuMatrixBase &, const CuMatrixBase &od, CuMatrixBase *id) {
+    // :143-175: one gather-sum kernel instead of n_splice CopyRows + AddMat passes
+    aslp_splice_backward(id->Data(), id->Dim(), od.Data(), od.Stride(), frame_offsets_.Data(), frame_offsets_.Dim());
+  }
+ protected:
+  CuArray<int32> frame_offsets_;
+};
+
+class CopyComponent : public Component {
+ public:
+  CopyComponent(int32 di, int32 dout) : Component(di, dout) {}
+  Component *Copy() const { return new CopyComponent(*this); }
+  ComponentType GetType() const { return kCopy; }
+  void InitData(std::istream &is) {
+    std::vector<int32> idx;
+    ParseBuildVector(is, &idx, "Copy");
+    for (auto &v : idx) --v;  // matlab indexing in the config (:253-255)
+    for (int32 v : idx) ASLP_ASSERT(v >= 0 && v < InputDim());
+    copy_from_indices_ = idx;
+    ASLP_ASSERT(copy_from_indices_.Dim() == OutputDim());
+  }
+  void ReadData(std::istream &is, bool binary) {
+    std::vector<int32> idx;
+    ReadIntegerVector(is, binary, &idx);
+    for (auto &v : idx) --v;
+    copy_from_indices_ = idx;
+    ASLP_ASSERT(copy_from_indices_.Dim() == OutputDim());
+  }
+  void WriteData(std::ostream &os, bool binary) const {
+    std::vector<int32> idx;
+    copy_from_indices_.CopyToVec(&idx);
+    for (auto &v : idx) ++v;
+    WriteIntegerVector(os, binary, idx);
+  }
+  void PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) { cu::Copy(in, copy_from_indices_, out); }
+  void BackpropagateFnc(const CuMatrixBase &, const CuMatrixBase &, const CuMatrixBase &, CuMatrixBase *id) {
+    static bool warned = false;  // :300-308 "Not implemented!": zero diff
+    if (!warned) { ASLP_WARN << __func__ << "Not implemented!"; warned = true; }
+    id->SetZero();
+  }
+ protected:
+  CuArray<int32> copy_from_indices_;
+};
+
+// ---- AddShift / Rescale (nnet-various.h:365-590) ----------------------------------------------------------
+class AddShift : public UpdatableComponent {
+ public:
+  AddShift(int32 di, int32 dout) : UpdatableComponent(di, dout), shift_data_(di), learn_rate_coef_(1.0) {}
+  Component *Copy() const { return new AddShift(*this); }
+  ComponentType GetType() const { return kAddShift; }
+  void InitData(std::istream &is) {
+    float init_param = 0.0;
+    std::string token;
+    while (!is.eof()) {
+      ReadToken(is, false, &token);
+      if (token == "<InitParam>") ReadBasicType(is, false, &init_param);
+      else if (token == "<LearnRateCoef>") ReadBasicType(is, false, &learn_rate_coef_);
+      else ASLP_ERR << "Unknown token " << token << ", a typo in config? (InitParam)";
+      is >> std::ws;
+    }
+    shift_data_.Resize(InputDim(), kSetZero);
+    shift_data_.Set(init_param);
+  }
+  void ReadData(std::istream &is, bool binary) {
+    if ('<' == Peek(is, binary)) { ExpectToken(is, binary, "<LearnRateCoef>"); ReadBasicType(is, binary, &learn_rate_coef_); }
+    shift_data_.Read(is, binary);
+  }
+  void WriteData(std::ostream &os, bool binary) const {
+    WriteToken(os, binary, "<LearnRateCoef>"); WriteBasicType(os, binary, learn_rate_coef_);
+    shift_data_.Write(os, binary);
+  }
+  int32 NumParams() const { return shift_data_.Dim(); }
+  void GetParams(std::vector<BaseFloat> *w) const { w->clear(); AppendVector(shift_data_, w); }
+  void GetGpuParams(std::vector<std::pair<BaseFloat *, int>> *p) { p->clear(); p->push_back(std::make_pair(shift_data_.Data(), shift_data_.Dim())); }
+  std::string Info() const { return std::string("\n  shift_data") + MomentStatistics(shift_data_); }
+  void PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) { out->CopyFromMat(in); out->AddVecToRows(1.0, shift_data_, 1.0); }
+  void BackpropagateFnc(const CuMatrixBase &, const CuMatrixBase &, const CuMatrixBase &od, CuMatrixBase *id) { id->CopyFromMat(od); }
+  void Update(const CuMatrixBase &, const CuMatrixBase &diff) {
+    const BaseFloat lr = opts_.learn_rate;
+    shift_data_grad_.Resize(InputDim(), kSetZero);
+    shift_data_grad_.AddRowSumMat(1.0, diff, 0.0);
+    shift_data_.AddVec(-lr * learn_rate_coef_, shift_data_grad_);
+  }
+ protected:
+  CuVector shift_data_, shift_data_grad_;
+  BaseFloat learn_rate_coef_;
+};
+
+class Rescale : public UpdatableComponent {
+ public:
+  Rescale(int32 di, int32 dout) : UpdatableComponent(di, dout), scale_data_(di), learn_rate_coef_(1.0) {}
+  Component *Copy() const { return new Rescale(*this); }
+  ComponentType GetType() const { return kRescale; }
+  void InitData(std::istream &is) {
+    float init_param = 0.0;
+    std::string token;
+    while (!is.eof()) {
+      ReadToken(is, false, &token);
+      if (token == "<InitParam>") ReadBasicType(is, false, &init_param);
+      else if (token == "<LearnRateCoef>") ReadBasicType(is, false, &learn_rate_coef_);
+      else ASLP_ERR << "Unknown token " << token << ", a typo in config? (InitParam)";
+      is >> std::ws;
+    }
+    scale_data_.Resize(InputDim(), kSetZero);
+    scale_data_.Set(init_param);
+  }
+  void ReadData(std::istream &is, bool binary) {
+    if ('<' == Peek(is, binary)) { ExpectToken(is, binary, "<LearnRateCoef>"); ReadBasicType(is, binary, &learn_rate_coef_); }
+    scale_data_.Read(is, binary);
+  }
+  void WriteData(std::ostream &os, bool binary) const {
+    WriteToken(os, binary, "<LearnRateCoef>"); WriteBasicType(os, binary, learn_rate_coef_);
+    scale_data_.Write(os, binary);
+  }
+  int32 NumParams() const { return scale_data_.Dim(); }
+  void GetParams(std::vector<BaseFloat> *w) const { w->clear(); AppendVector(scale_data_, w); }
+  void GetGpuParams(std::vector<std::pair<BaseFloat *, int>> *p) { p->clear(); p->push_back(std::make_pair(scale_data_.Data(), scale_data_.Dim())); }
+  std::string Info() const { return std::string("\n  scale_data") + MomentStatistics(scale_data_); }
+  void PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) { out->CopyFromMat(in); out->MulColsVec(scale_data_); }
+  void BackpropagateFnc(const CuMatrixBase &, const CuMatrixBase &, const CuMatrixBase &od, CuMatrixBase *id) { id->CopyFromMat(od); id->MulColsVec(scale_data_); }
+  void Update(const CuMatrixBase &input, const CuMatrixBase &diff) {
+    const BaseFloat lr = opts_.learn_rate;
+    scale_data_grad_.Resize(InputDim(), kSetZero);
+    CuMatrix gradient_aux(diff);
+    gradient_aux.MulElements(input);
+    scale_data_grad_.AddRowSumMat(1.0, gradient_aux, 0.0);
+    scale_data_.AddVec(-lr * learn_rate_coef_, scale_data_grad_);
+  }
+ protected:
+  CuVector scale_data_, scale_data_grad_;
+  BaseFloat learn_rate_coef_;
+};
+
+// ---- BatchNormalization (nnet-batch-normalization.h:32-298) ----------------------------------------------------
+class BatchNormalization : public UpdatableComponent {
+ public:
+  BatchNormalization(int32 di, int32 dout)
+      : UpdatableComponent(di, dout), var_floor_(0.0000001), num_acc_frames_(0), acc_cleaned_(false) {}
+  Component *Copy() const { return new BatchNormalization(*this); }
+  ComponentType GetType() const { return kBatchNormalization; }
+  void InitData(std::istream &) {  // :45-54
+    num_acc_frames_ = 0;
+    scale_.Resize(output_dim_); scale_.Set(1.0);
+    shift_.Resize(output_dim_); shift_.SetZero();
+    ASLP_ASSERT(output_dim_ > 0 && input_dim_ > 0);
+    acc_means_.Resize(output_dim_, kSetZero);
+    acc_vars_.Resize(output_dim_, kSetZero);
+    AllocAux();
+  }
+  void ReadData(std::istream &is, bool binary) {  // :56-94
+    ExpectToken(is, binary, "<NumAccFrames>");
+    ReadBasicType(is, binary, &num_acc_frames_);
+    acc_means_.Read(is, binary);
+    acc_vars_.Read(is, binary);
+    shift_.Read(is, binary);
+    scale_.Read(is, binary);
+    ASLP_ASSERT(acc_means_.Dim() == acc_vars_.Dim());
+    ASLP_ASSERT(acc_means_.Dim() == shift_.Dim());
+    ASLP_ASSERT(acc_means_.Dim() == scale_.Dim());
+    AllocAux();
+    mean_vec_.SetZero();
+    var_vec_.Set(1.0);
+    if (num_acc_frames_ <= 0.0) return;
+    float var_floor = 1e-10;
+    int D = acc_means_.Dim();
+    std::vector<double> am(D), av(D);
+    acc_means_.CopyToHost(am.data());
+    acc_vars_.CopyToHost(av.data());
+    std::vector<float> mh(D), vh(D);
+    for (int32 d = 0; d < D; d++) {
+      BaseFloat mean = am[d] / num_acc_frames_;
+      BaseFloat var = av[d] / num_acc_frames_ - mean * mean;
+      if (var <= var_floor) { ASLP_WARN << "Very small variance " << var << " flooring to " << var_floor; var = var_floor; }
+      mh[d] = mean;
+      vh[d] = 1.0 / sqrt(var + var_floor_);
+    }
+    mean_vec_.CopyFromHost(mh.data(), D);
+    var_vec_.CopyFromHost(vh.data(), D);
+  }
+  void WriteData(std::ostream &os, bool binary) const {  // :96-103
+    WriteToken(os, binary, "<NumAccFrames>");
+    WriteBasicType(os, binary, num_acc_frames_);
+    acc_means_.Write(os, binary);
+    acc_vars_.Write(os, binary);
+    shift_.Write(os, binary);
+    scale_.Write(os, binary);
+  }
+  int32 NumParams() const { return shift_.Dim() + scale_.Dim(); }
+  void GetParams(std::vector<BaseFloat> *w) const { w->clear(); AppendVector(shift_, w); AppendVector(scale_, w); }
+  void GetGpuParams(std::vector<std::pair<BaseFloat *, int>> *params) {  // :115-119
+    params->clear();
+    params->push_back(std::make_pair(shift_.Data(), shift_.Dim()));
+    params->push_back(std::make_pair(scale_.Data(), scale_.Dim()));
+  }
+  double *GetAccStats(std::vector<std::pair<double *, int>> *params) {  // :122-127
+    params->clear();
+    params->push_back(std::make_pair(acc_means_.Data(), acc_means_.Dim()));
+    params->push_back(std::make_pair(acc_vars_.Data(), acc_vars_.Dim()));
+    return &num_acc_frames_;
+  }
+  std::string Info() const { return std::string("\n  batch_normaliztion"); }
+  void CleanAccs() { acc_means_.SetZero(); acc_vars_.SetZero(); num_acc_frames_ = 0; }
+
+  void FeedforwardFnc(const CuMatrixBase &in, CuMatrixBase *out) {  // :139-175
+    if (num_acc_frames_ <= 0) {  // local statistics
+      aslp_bn_forward(in.Data(), in.Dim(), out->Data(), out->Stride(), nullptr, 0, scale_.Data(), shift_.Data(), mean_vec_.Data(),
+                      var_vec_.Data(), nullptr, nullptr, var_floor_);
+    } else {  // global statistics prepared by ReadData
+      aslp_bn_apply(in.Data(), in.Dim(), out->Data(), out->Stride(), mean_vec_.Data(), var_vec_.Data(), scale_.Data(), shift_.Data());
+    }
+  }
+  void PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) {  // :177-220
+    if (!acc_cleaned_) { acc_cleaned_ = true; CleanAccs(); }
+    if (XsharpO_.NumRows() != in.NumRows() || XsharpO_.NumCols() != output_dim_) XsharpO_.Resize(in.NumRows(), output_dim_, kUndefined);
+    aslp_bn_forward(in.Data(), in.Dim(), out->Data(), out->Stride(), XsharpO_.Data(), XsharpO_.Stride(), scale_.Data(), shift_.Data(),
+                    mean_vec_.Data(), var_vec_.Data(), acc_means_.Data(), acc_vars_.Data(), var_floor_);
+    num_acc_frames_ += in.NumRows();
+  }
+  void BackpropagateFnc(const CuMatrixBase &in, const CuMatrixBase &, const CuMatrixBase &out_diff, CuMatrixBase *in_diff) {  // :222-277
+    aslp_bn_backward(in.Data(), in.Dim(), out_diff.Data(), out_diff.Stride(), XsharpO_.Data(), XsharpO_.Stride(), scale_.Data(),
+                     mean_vec_.Data(), var_vec_.Data(), dscale_.Data(), dshift_.Data(), opts_.momentum,
+                     in_diff ? in_diff->Data() : nullptr, in_diff ? in_diff->Stride() : 0);
+  }
+  void Update(const CuMatrixBase &, const CuMatrixBase &) {  // :280-284
+    const BaseFloat lr = opts_.learn_rate;
+    scale_.AddVec(-lr, dscale_, 1.0);
+    shift_.AddVec(-lr, dshift_, 1.0);
+  }
+  CuVector &Scale() { return scale_; }
+  CuVector &Shift() { return shift_; }
+  double NumAccFrames() const { return num_acc_frames_; }
+  CuVectorD &AccMeans() { return acc_means_; }
+  CuVectorD &AccVars() { return acc_vars_; }
+
+ private:
+  void AllocAux() {
+    mean_vec_.Resize(output_dim_); var_vec_.Resize(output_dim_);
+    dscale_.Resize(output_dim_); dshift_.Resize(output_dim_);
+  }
+  CuMatrix XsharpO_;
+  CuVector mean_vec_, var_vec_, scale_, dscale_, shift_, dshift_;
+  BaseFloat var_floor_;
+  CuVectorD acc_means_, acc_vars_;
+  double num_acc_frames_;
+  bool acc_cleaned_;
+};
+
+}  // namespace aslp

@@ -1,0 +1,594 @@
+// nnet-nnet.cpp -- graph executor.  Follows src/aslp-nnet/nnet-nnet.cc (cited per function).
+#include "nnet-nnet.h"
+
+#include <chrono>
+#include <fstream>
+
+#include "nnet-basic.h"
+#if __has_include("nnet-recurrent.h")
+#include "nnet-recurrent.h"
+#define ASLP_HAVE_RECURRENT 1
+#endif
+#if __has_include("nnet-temporal.h")
+#include "nnet-temporal.h"
+#define ASLP_HAVE_TEMPORAL 1
+#endif
+
+namespace aslp {
+
+namespace {
+struct Timer {
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  double Elapsed() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+}  // namespace
+
+Nnet::Nnet(const Nnet &other) { *this = other; }
+Nnet &Nnet::operator=(const Nnet &other) {  // nnet-nnet.cc:41-65
+  if (this == &other) return *this;
+  Destroy();
+  for (int32 i = 0; i < other.NumComponents(); i++) components_.push_back(other.GetComponent(i).Copy());
+  SetTrainOptions(other.opts_);
+  alias_links_ = other.alias_links_;
+  InitInputOutput();
+  Check();
+  return *this;
+}
+Nnet::~Nnet() { Destroy(); }
+
+bool Nnet::IsDirectLink(int32 i) const {
+  const std::vector<int32> &in = components_[i]->GetInput(), &off = components_[i]->GetOffset();
+  return in.size() == 1 && in[0] >= 0 && off[0] == 0 && components_[in[0]]->OutputDim() == components_[i]->InputDim();
+}
+
+void Nnet::Propagate(const std::vector<const CuMatrixBase *> &in, std::vector<CuMatrix *> *out) {  // nnet-nnet.cc:70-106
+  ASLP_ASSERT(NULL != out);
+  ASLP_ASSERT(in.size() == input_.size());
+  int num_frame = in[0]->NumRows();
+  for (size_t i = 0; i < input_.size(); i++) in_view_[input_[i]] = in[i];  // InputLayer reads the caller's matrix
+  for (int32 i = 0; i < (int32)components_.size(); i++) {
+    if (components_[i]->GetType() != Component::kInputLayer) {
+      const std::vector<int32> &input_idx = components_[i]->GetInput();
+      const std::vector<int32> &offset = components_[i]->GetOffset();
+      ASLP_ASSERT(input_idx.size() == offset.size());
+      if (alias_links_ && IsDirectLink(i)) {
+        in_view_[i] = &output_buf_[input_idx[0]];
+      } else {  // :86-95 zeroed buffer, links added in (this is how branch splice / sum works)
+        input_buf_[i].Resize(num_frame, components_[i]->InputDim(), kSetZero);
+        for (size_t j = 0; j < input_idx.size(); j++) {
+          int out_len = components_[input_idx[j]]->OutputDim();
+          input_buf_[i].ColRange(offset[j], out_len).AddMat(1.0, output_buf_[input_idx[j]]);
+        }
+        in_view_[i] = &input_buf_[i];
+      }
+    }
+    Timer tim1;
+    components_[i]->Propagate(*in_view_[i], &output_buf_[i]);
+    propagate_time_[i].first = Component::TypeToMarker(components_[i]->GetType());
+    propagate_time_[i].second += tim1.Elapsed();
+  }
+  for (size_t i = 0; i < output_.size(); i++) *((*out)[i]) = output_buf_[output_[i]];
+  // the caller's input may go away: Update() of the consumers reads InputLayer's OUTPUT copy
+  for (size_t i = 0; i < input_.size(); i++) in_view_[input_[i]] = &output_buf_[input_[i]];
+}
+
+void Nnet::Backpropagate(const std::vector<const CuMatrixBase *> &out_diff, std::vector<CuMatrix *> *in_diff) {  // :108-154
+  ASLP_ASSERT(out_diff.size() == output_.size());
+  int num_frame = out_diff[0]->NumRows();
+  const int32 N = NumComponents();
+  // which producers receive their out-diff by accumulation (need a zeroed buffer, :112-114)
+  std::vector<char> direct(N, 0);
+  for (int32 i = 0; i < N; i++) {
+    if (components_[i]->GetType() == Component::kInputLayer) continue;
+    if (alias_links_ && IsDirectLink(i) && num_consumers_[components_[i]->GetInput()[0]] == 1) direct[i] = 1;
+  }
+  for (int32 i = 0; i < N; i++) {
+    bool fed_direct = false;
+    for (int32 c = i + 1; c < N && !fed_direct; c++)
+      if (direct[c] && components_[c]->GetInput()[0] == i) fed_direct = true;
+    if (!fed_direct) output_diff_buf_[i].Resize(num_frame, components_[i]->OutputDim(), kSetZero);
+  }
+  for (size_t i = 0; i < output_.size(); i++) output_diff_buf_[output_[i]].CopyFromMat(*(out_diff[i]));
+  const bool want_in_diff = (in_diff != NULL);
+  for (int32 i = N - 1; i >= 0; i--) {
+    Timer tim2;
+    const bool is_input = components_[i]->GetType() == Component::kInputLayer;
+    // The reference also back-propagates into the network input (:124-125); that in-diff is
+    // observable only through `in_diff`, so it is skipped when the caller passes NULL.
+    bool feeds_only_input = !is_input;
+    if (!is_input)
+      for (int32 p : components_[i]->GetInput())
+        if (components_[p]->GetType() != Component::kInputLayer) feeds_only_input = false;
+    const bool skip_backprop = !want_in_diff && (is_input || feeds_only_input);
+    CuMatrix *target = &input_diff_buf_[i];
+    if (!is_input && direct[i]) target = &output_diff_buf_[components_[i]->GetInput()[0]];
+    if (!skip_backprop) {
+      components_[i]->Backpropagate(*in_view_[i], output_buf_[i], output_diff_buf_[i], target);
+      in_diff_view_[i] = target;
+    }
+    if (components_[i]->IsUpdatable()) {
+      UpdatableComponent *uc = dynamic_cast<UpdatableComponent *>(components_[i]);
+      uc->Update(*in_view_[i], output_diff_buf_[i]);
+    }
+    back_propagate_time_[i].first = Component::TypeToMarker(components_[i]->GetType());
+    back_propagate_time_[i].second += tim2.Elapsed();
+    if (!is_input && !direct[i] && !skip_backprop) {  // :133-144 scatter-add to the producers
+      const std::vector<int32> &input_idx = components_[i]->GetInput();
+      const std::vector<int32> &offset = components_[i]->GetOffset();
+      for (size_t j = 0; j < input_idx.size(); j++) {
+        ASLP_ASSERT(input_idx[j] >= 0 && input_idx[j] <= NumComponents());
+        int out_len = components_[input_idx[j]]->OutputDim();
+        output_diff_buf_[input_idx[j]].AddMat(1.0, input_diff_buf_[i].ColRange(offset[j], out_len));
+      }
+    }
+  }
+  if (NULL == in_diff) return;
+  for (size_t i = 0; i < input_.size(); i++)
+    if ((*in_diff)[i] != NULL) *((*in_diff)[i]) = input_diff_buf_[input_[i]];
+}
+
+void Nnet::Feedforward(const std::vector<const CuMatrixBase *> &in, std::vector<CuMatrix *> *out) {  // :156-189
+  ASLP_ASSERT(NULL != out);
+  ASLP_ASSERT(in.size() == input_.size());
+  int num_frame = in[0]->NumRows();
+  for (size_t i = 0; i < input_.size(); i++) in_view_[input_[i]] = in[i];
+  for (int32 i = 0; i < (int32)components_.size(); i++) {
+    if (components_[i]->GetType() != Component::kInputLayer) {
+      const std::vector<int32> &input_idx = components_[i]->GetInput();
+      const std::vector<int32> &offset = components_[i]->GetOffset();
+      if (alias_links_ && IsDirectLink(i)) {
+        in_view_[i] = &output_buf_[input_idx[0]];
+      } else {
+        input_buf_[i].Resize(num_frame, components_[i]->InputDim(), kSetZero);
+        for (size_t j = 0; j < input_idx.size(); j++) {
+          int out_len = components_[input_idx[j]]->OutputDim();
+          input_buf_[i].ColRange(offset[j], out_len).AddMat(1.0, output_buf_[input_idx[j]]);
+        }
+        in_view_[i] = &input_buf_[i];
+      }
+    }
+    components_[i]->Feedforward(*in_view_[i], &output_buf_[i]);
+  }
+  for (size_t i = 0; i < output_.size(); i++) *((*out)[i]) = output_buf_[output_[i]];
+  for (size_t i = 0; i < input_.size(); i++) in_view_[input_[i]] = &output_buf_[input_[i]];
+}
+
+void Nnet::Propagate(const CuMatrixBase &in, CuMatrix *out) {  // :191-204
+  ASLP_ASSERT(NULL != out);
+  if (NumComponents() == 0) { (*out) = in; return; }
+  ASLP_ASSERT(input_.size() == 1);
+  ASLP_ASSERT(output_.size() == 1);
+  std::vector<const CuMatrixBase *> in_vec(1, &in);
+  std::vector<CuMatrix *> out_vec(1, out);
+  Propagate(in_vec, &out_vec);
+}
+void Nnet::Backpropagate(const CuMatrixBase &out_diff, CuMatrix *in_diff) {  // :206-216
+  if (NumComponents() == 0) { (*in_diff) = out_diff; return; }
+  ASLP_ASSERT(input_.size() == 1);
+  ASLP_ASSERT(output_.size() == 1);
+  std::vector<const CuMatrixBase *> od(1, &out_diff);
+  if (in_diff == NULL) { Backpropagate(od, NULL); return; }
+  std::vector<CuMatrix *> id(1, in_diff);
+  Backpropagate(od, &id);
+}
+void Nnet::Feedforward(const CuMatrixBase &in, CuMatrix *out) {  // :218-232
+  ASLP_ASSERT(NULL != out);
+  if (NumComponents() == 0) { out->Resize(in.NumRows(), in.NumCols()); out->CopyFromMat(in); return; }
+  ASLP_ASSERT(input_.size() == 1);
+  ASLP_ASSERT(output_.size() == 1);
+  std::vector<const CuMatrixBase *> in_vec(1, &in);
+  std::vector<CuMatrix *> out_vec(1, out);
+  Feedforward(in_vec, &out_vec);
+}
+
+const CuMatrixBase &Nnet::InputDiffBuffer(int32 c) const {
+  ASLP_ASSERT(in_diff_view_[c] != NULL);
+  return *in_diff_view_[c];
+}
+
+int32 Nnet::OutputDim() const { ASLP_ASSERT(!components_.empty()); return components_.back()->OutputDim(); }
+int32 Nnet::InputDim() const { ASLP_ASSERT(!components_.empty()); return components_.front()->InputDim(); }
+const Component &Nnet::GetComponent(int32 c) const { ASLP_ASSERT(static_cast<size_t>(c) < components_.size()); return *(components_[c]); }
+Component &Nnet::GetComponent(int32 c) { ASLP_ASSERT(static_cast<size_t>(c) < components_.size()); return *(components_[c]); }
+
+void Nnet::SetComponent(int32 c, Component *component) {
+  ASLP_ASSERT(static_cast<size_t>(c) < components_.size());
+  delete components_[c];
+  components_[c] = component;
+  InitInputOutput();
+  Check();
+}
+void Nnet::AppendComponent(Component *comp) {  // :262-272
+  components_.push_back(comp);
+  for (int32 i = 0; i < (int32)components_.size(); i++) {
+    components_[i]->SetId(i);
+    components_[i]->SetMonoInput(i - 1);
+  }
+  InitInputOutput();
+}
+void Nnet::AppendNnet(const Nnet &other) {
+  for (int32 i = 0; i < other.NumComponents(); i++) AppendComponent(other.GetComponent(i).Copy());
+  InitInputOutput();
+  Check();
+}
+void Nnet::RemoveComponent(int32 c) {
+  ASLP_ASSERT(c < NumComponents());
+  Component *ptr = components_[c];
+  components_.erase(components_.begin() + c);
+  delete ptr;
+  InitInputOutput();
+  Check();
+}
+
+void Nnet::GetParams(std::vector<BaseFloat> *wei_copy) const {  // :296-311
+  wei_copy->clear();
+  for (size_t i = 0; i < components_.size(); i++)
+    if (components_[i]->IsUpdatable()) {
+      std::vector<BaseFloat> c_params;
+      dynamic_cast<UpdatableComponent &>(*components_[i]).GetParams(&c_params);
+      wei_copy->insert(wei_copy->end(), c_params.begin(), c_params.end());
+    }
+  ASLP_ASSERT((int32)wei_copy->size() == NumParams());
+}
+void Nnet::GetGpuParams(std::vector<std::pair<BaseFloat *, int>> *params) {  // :314-325
+  ASLP_ASSERT(params != NULL);
+  params->clear();
+  for (size_t i = 0; i < components_.size(); i++)
+    if (components_[i]->IsUpdatable()) {
+      std::vector<std::pair<BaseFloat *, int>> c_params;
+      dynamic_cast<UpdatableComponent &>(*components_[i]).GetGpuParams(&c_params);
+      params->insert(params->end(), c_params.begin(), c_params.end());
+    }
+}
+void Nnet::GetAccStats(std::vector<double *> *acc_params, std::vector<std::pair<double *, int>> *data_params) {  // :327-342
+  ASLP_ASSERT(acc_params != NULL && data_params != NULL);
+  acc_params->clear();
+  data_params->clear();
+  for (size_t i = 0; i < components_.size(); i++)
+    if (GetComponent(i).GetType() == Component::kBatchNormalization) {
+      BatchNormalization &bn = dynamic_cast<BatchNormalization &>(GetComponent(i));
+      std::vector<std::pair<double *, int>> c_params;
+      double *acc_ptr = bn.GetAccStats(&c_params);
+      acc_params->push_back(acc_ptr);
+      data_params->insert(data_params->end(), c_params.begin(), c_params.end());
+    }
+}
+int32 Nnet::NumParams() const {
+  int32 n = 0;
+  for (size_t i = 0; i < components_.size(); i++)
+    if (components_[i]->IsUpdatable()) n += dynamic_cast<UpdatableComponent *>(components_[i])->NumParams();
+  return n;
+}
+
+void Nnet::ResetLstmStreams(const std::vector<int32> &flags) {  // :473-496
+#ifdef ASLP_HAVE_RECURRENT
+  for (int32 c = 0; c < NumComponents(); c++) {
+    RecurrentBase *r = dynamic_cast<RecurrentBase *>(components_[c]);
+    if (r && r->HasStreamReset()) r->ResetLstmStreams(flags);
+  }
+#else
+  (void)flags;
+#endif
+}
+void Nnet::SetSeqLengths(const std::vector<int32> &lens) {  // :498-530
+  for (int32 c = 0; c < NumComponents(); c++) {
+#ifdef ASLP_HAVE_RECURRENT
+    if (RecurrentBase *r = dynamic_cast<RecurrentBase *>(components_[c])) { if (r->HasSeqLengths()) r->SetSeqLengths(lens); continue; }
+#endif
+#ifdef ASLP_HAVE_TEMPORAL
+    if (RowConvolution *rc = dynamic_cast<RowConvolution *>(components_[c])) rc->SetSeqLengths(lens);
+#endif
+  }
+  (void)lens;
+}
+void Nnet::SetChunkSize(int chunk_size) {  // :532-539
+#ifdef ASLP_HAVE_RECURRENT
+  for (int32 c = 0; c < NumComponents(); c++)
+    if (BLstmProjectedStreamsLC *l = dynamic_cast<BLstmProjectedStreamsLC *>(components_[c])) l->SetChunkSize(chunk_size);
+#else
+  (void)chunk_size;
+#endif
+}
+
+void Nnet::AutoComplete() {  // :541-568
+  int input_dim = components_[0]->InputDim();
+  Component *in_comp = new InputLayer(input_dim, input_dim);
+  in_comp->SetId(0);
+  in_comp->SetMonoInput(-1);
+  components_.insert(components_.begin(), in_comp);
+  for (size_t i = 1; i < components_.size(); i++) {
+    ASLP_ASSERT(components_[i]->Id() < 0);
+    components_[i]->SetId(i);
+    components_[i]->SetMonoInput(i - 1);
+  }
+  int num_layers = components_.size();
+  int output_dim = components_[num_layers - 1]->OutputDim();
+  Component *out_comp = new OutputLayer(output_dim, output_dim);
+  out_comp->SetId(num_layers);
+  out_comp->SetMonoInput(num_layers - 1);
+  components_.push_back(out_comp);
+}
+
+void Nnet::InitStream(std::istream &is) {  // :570-612
+  std::string conf_line, token;
+  bool simple_net = true;
+  while (!is.eof()) {
+    ASLP_ASSERT(is.good());
+    std::getline(is, conf_line);
+    if (conf_line == "") continue;
+    ASLP_VLOG(1) << conf_line;
+    std::istringstream ls(conf_line);
+    ls >> std::ws >> token;
+    if (ls.fail()) continue;  // whitespace-only line
+    if (token == "<NnetProto>" || token == "</NnetProto>") continue;
+    if (token[0] == '#') continue;  // comment line (extension; the reference would raise "Unknown marker")
+    if (token == "<StructureType>") {
+      ls >> std::ws >> token;
+      if (token == "graph") simple_net = false;
+      else if (token == "simple") simple_net = true;
+      else ASLP_ERR << "The net's structure must be simple or graphi!";
+      continue;
+    }
+    components_.push_back(Component::Init(conf_line + "\n"));
+  }
+  if (!simple_net) {
+    AssignComponentId(components_);
+    SortComponent(components_);
+  }
+  if (simple_net) AutoComplete();
+  InitInputOutput();
+  Check();
+}
+void Nnet::Init(const std::string &file) {
+  std::ifstream in(file.c_str());
+  if (!in.is_open()) ASLP_ERR << "Error opening input stream " << file;
+  InitStream(in);
+}
+void Nnet::InitFromString(const std::string &proto) {
+  std::istringstream in(proto);
+  InitStream(in);
+}
+
+void Nnet::Read(const std::string &file) {  // :615-625
+  std::ifstream in(file.c_str(), std::ios_base::in | std::ios_base::binary);
+  if (!in.is_open()) ASLP_ERR << "Error opening input stream " << file;
+  bool binary;
+  if (!InitKaldiInputStream(in, &binary)) ASLP_ERR << "Error reading header of " << file;
+  Read(in, binary);
+  if (NumComponents() == 0) ASLP_WARN << "The network '" << file << "' is empty.";
+}
+void Nnet::Read(std::istream &is, bool binary) {  // :628-646
+  Component *comp;
+  while (NULL != (comp = Component::Read(is, binary))) {
+    int id = comp->Id();
+    if (id >= (int)components_.size()) components_.resize(id + 1, NULL);
+    if (components_[id] != NULL) ASLP_ERR << "Component id " << id << " already be taken" << "the id must be unique";
+    components_[id] = comp;
+  }
+  opts_.learn_rate = 0.0;  // :643 reset learn rate
+  InitInputOutput();
+  Check();
+}
+void Nnet::Write(const std::string &file, bool binary) const {
+  std::ofstream out(file.c_str(), std::ios_base::out | std::ios_base::binary);
+  if (!out.is_open()) ASLP_ERR << "Error opening output stream " << file;
+  InitKaldiOutputStream(out, binary);
+  Write(out, binary);
+}
+void Nnet::Write(std::ostream &os, bool binary) const {  // :654-663
+  Check();
+  WriteToken(os, binary, "<Nnet>");
+  if (binary == false) os << std::endl;
+  for (int32 i = 0; i < NumComponents(); i++) components_[i]->Write(os, binary);
+  WriteToken(os, binary, "</Nnet>");
+  if (binary == false) os << std::endl;
+}
+void Nnet::WriteStandard(const std::string &file, bool binary) const {  // :695-699 (sic: the reference calls Write here)
+  std::ofstream out(file.c_str(), std::ios_base::out | std::ios_base::binary);
+  if (!out.is_open()) ASLP_ERR << "Error opening output stream " << file;
+  InitKaldiOutputStream(out, binary);
+  Write(out, binary);
+}
+void Nnet::WriteStandard(std::ostream &os, bool binary) const {  // :701-712
+  Check();
+  WriteToken(os, binary, "<Nnet>");
+  if (binary == false) os << std::endl;
+  for (int32 i = 0; i < NumComponents(); i++) {
+    if (components_[i]->GetType() == Component::kInputLayer || components_[i]->GetType() == Component::kOutputLayer) continue;
+    components_[i]->WriteStandard(os, binary);
+  }
+  WriteToken(os, binary, "</Nnet>");
+  if (binary == false) os << std::endl;
+}
+void Nnet::WriteDotFile(std::ostream &os) const {  // :665-693
+  os << "digraph net{" << std::endl;
+  os << "rankdir=BT" << std::endl;
+  os << "node[shape = box; height = 1; width = 3; fontsize = 40];" << std::endl;
+  os << "edge[minlen = 1 ]" << std::endl;
+  for (int32 i = 0; i < NumComponents(); i++) {
+    std::string name = components_[i]->GetName();
+    int id = components_[i]->Id();
+    const std::vector<int32> &input = components_[i]->GetInput(), &offset = components_[i]->GetOffset();
+    if (name != "") os << id << " [label = " << "\"" << name << "\"]" << std::endl;
+    else os << id << " [label = " << "\"" << Component::TypeToMarker(components_[i]->GetType()) << "\"]" << std::endl;
+    if (input.size() == 1 && input[0] == -1) continue;
+    for (size_t j = 0; j < input.size(); j++)
+      os << "\t" << input[j] << " -> " << id << " [label = " << offset[j] << "; fontsize = 40]" << std::endl;
+  }
+  os << "}" << std::endl;
+}
+
+std::string Nnet::Info() const {  // :714-737
+  std::ostringstream ostr;
+  ostr << "num-components " << NumComponents() << std::endl;
+  ostr << "input-dim " << InputDim() << std::endl;
+  ostr << "output-dim " << OutputDim() << std::endl;
+  ostr << "number-of-parameters " << static_cast<float>(NumParams()) / 1e6 << " millions" << std::endl;
+  for (int32 i = 0; i < NumComponents(); i++) {
+    ostr << "component " << i + 1 << " : " << Component::TypeToMarker(components_[i]->GetType()) << ", input-dim "
+         << components_[i]->InputDim() << ", output-dim " << components_[i]->OutputDim() << ", id " << components_[i]->Id();
+    const std::vector<int32> &input_idx = components_[i]->GetInput(), &offset = components_[i]->GetOffset();
+    ostr << ", input ";
+    for (size_t j = 0; j < input_idx.size(); j++) ostr << input_idx[j] << ":" << offset[j] << ",";
+    ostr << "  " << components_[i]->Info() << std::endl;
+  }
+  return ostr.str();
+}
+std::string Nnet::InfoGradient() const {
+  std::ostringstream ostr;
+  ostr << "### Gradient stats :\n";
+  for (int32 i = 0; i < NumComponents(); i++)
+    ostr << "Component " << i + 1 << " : " << Component::TypeToMarker(components_[i]->GetType()) << ", "
+         << components_[i]->InfoGradient() << std::endl;
+  return ostr.str();
+}
+std::string Nnet::InfoPropagate() const {
+  std::ostringstream ostr;
+  ostr << "### Forward propagation buffer content :\n";
+  ostr << "[0] output of <Input> " << MomentStatistics(*in_view_[0]) << std::endl;
+  for (int32 i = 0; i < NumComponents(); i++)
+    ostr << "[" << 1 + i << "] output of " << Component::TypeToMarker(components_[i]->GetType()) << MomentStatistics(output_buf_[i]) << std::endl;
+  return ostr.str();
+}
+std::string Nnet::InfoBackPropagate() const {
+  std::ostringstream ostr;
+  ostr << "### Backward propagation buffer content :\n";
+  ostr << "[0] diff of <Input> " << MomentStatistics(output_diff_buf_[0]) << std::endl;
+  for (int32 i = 0; i < NumComponents(); i++)
+    ostr << "[" << 1 + i << "] diff-output of " << Component::TypeToMarker(components_[i]->GetType()) << MomentStatistics(output_diff_buf_[i]) << std::endl;
+  return ostr.str();
+}
+
+void Nnet::Check() const {  // :776-819
+  if (input_.size() < 1) ASLP_ERR << "Must have at least one InputLayer";
+  if (output_.size() < 1) ASLP_ERR << "Must have at least one OutputLayer";
+  for (int i = 0; i < NumComponents(); i++) {
+    if (components_[i] == NULL) ASLP_ERR << "Component id must be consistant, but have no id " << i;
+    if (components_[i]->Id() != i) ASLP_ERR << "Component id not equal index id, May be error in Read";
+  }
+  for (int i = 0; i < NumComponents(); i++) {
+    if (components_[i]->GetType() == Component::kInputLayer) continue;
+    const std::vector<int32> &input_idx = components_[i]->GetInput(), &offset = components_[i]->GetOffset();
+    ASLP_ASSERT(input_idx.size() == offset.size());
+    for (size_t j = 0; j < input_idx.size(); j++) {
+      int idx = input_idx[j];
+      if (idx < 0 || idx >= NumComponents()) ASLP_ERR << "Component " << i << " has an invalid input id " << idx;
+      if (components_[idx]->Id() >= components_[i]->Id())
+        ASLP_ERR << "Input id must be less than Component id, case " << " <Id> " << i << " <Input> " << idx;
+      int32 out_dim = components_[idx]->OutputDim();
+      if (offset[j] + out_dim > components_[i]->InputDim())
+        ASLP_ERR << "Component " << idx << " outputdim + offset must be less than " << "offset " << offset[j] << " " << "outdim "
+                 << out_dim << " " << "Component " << i << " inputdim";
+    }
+  }
+  std::vector<BaseFloat> weights;
+  GetParams(&weights);
+  double sum = 0.0;
+  for (BaseFloat w : weights) sum += w;
+  if (std::isinf(sum)) ASLP_ERR << "'inf' in network parameters (weight explosion, try lower learning rate?)";
+  if (std::isnan(sum)) ASLP_ERR << "'nan' in network parameters (try lower learning rate?)";
+}
+
+void Nnet::Destroy() {  // :822-832
+  for (int32 i = 0; i < NumComponents(); i++) delete components_[i];
+  components_.resize(0);
+  input_buf_.resize(0);
+  input_diff_buf_.resize(0);
+  output_buf_.resize(0);
+  output_diff_buf_.resize(0);
+  in_view_.resize(0);
+  in_diff_view_.resize(0);
+}
+
+void Nnet::SetTrainOptions(const NnetTrainOptions &opts) {
+  opts_ = opts;
+  for (int32 l = 0; l < NumComponents(); l++)
+    if (GetComponent(l).IsUpdatable()) dynamic_cast<UpdatableComponent &>(GetComponent(l)).SetTrainOptions(opts_);
+}
+
+void Nnet::InitInputOutput() {  // :845-870
+  input_.clear();
+  output_.clear();
+  for (int i = 0; i < NumComponents(); i++) {
+    if (components_[i] == NULL) continue;
+    if (components_[i]->GetType() == Component::kInputLayer) input_.push_back(components_[i]->Id());
+    else if (components_[i]->GetType() == Component::kOutputLayer) output_.push_back(components_[i]->Id());
+  }
+  input_buf_.resize(NumComponents());
+  output_buf_.resize(NumComponents());
+  input_diff_buf_.resize(NumComponents());
+  output_diff_buf_.resize(NumComponents());
+  in_view_.assign(NumComponents(), NULL);
+  in_diff_view_.assign(NumComponents(), NULL);
+  num_consumers_.assign(NumComponents(), 0);
+  for (int i = 0; i < NumComponents(); i++) {
+    if (components_[i] == NULL || components_[i]->GetType() == Component::kInputLayer) continue;
+    for (int32 p : components_[i]->GetInput())
+      if (p >= 0 && p < NumComponents()) num_consumers_[p]++;
+  }
+  propagate_time_.assign(NumComponents(), std::make_pair(std::string(), 0.0));
+  back_propagate_time_.assign(NumComponents(), std::make_pair(std::string(), 0.0));
+}
+
+void Nnet::GetComponentTime() {  // :872-884
+  for (size_t i = 0; i < propagate_time_.size(); i++) {
+    ASLP_LOG << propagate_time_[i].first << ": Propagate time " << propagate_time_[i].second << "s, " << "Back-Propagate time "
+             << back_propagate_time_[i].second << "s, " << "total time " << propagate_time_[i].second + back_propagate_time_[i].second << "s";
+    propagate_time_[i].second = 0.0;
+    back_propagate_time_[i].second = 0.0;
+  }
+}
+
+void Nnet::AssignComponentId(std::vector<Component *> &comp) {  // :886-949 (Kahn topological order, LIFO queue)
+  int32 num_comp = comp.size();
+  std::vector<int32> indegree;
+  std::vector<std::string> input_name;
+  for (int i = 0; i < num_comp; i++) {
+    input_name = comp[i]->GetInputName();
+    if (input_name.size() == 1 && input_name[0] == "-1") indegree.push_back(0);
+    else indegree.push_back(input_name.size());
+  }
+  std::vector<std::string> comp_queue;
+  for (int i = 0; i < num_comp; i++)
+    if (indegree[i] == 0) comp_queue.push_back(comp[i]->GetName());
+  int32 id = 0;
+  while (!comp_queue.empty()) {
+    std::string name = comp_queue.back();
+    comp_queue.pop_back();
+    for (int i = 0; i < num_comp; i++) {
+      input_name = comp[i]->GetInputName();
+      if (comp[i]->GetName() == name) {
+        comp[i]->SetId(id);
+        ++id;
+      }
+      for (size_t j = 0; j < input_name.size(); j++) {
+        if (input_name[j] == comp[i]->GetName())
+          ASLP_ERR << "The input of component " << comp[i]->GetName() << "include itself, Please check it!";
+        else if (input_name[j] == name)
+          if (--indegree[i] == 0) comp_queue.push_back(comp[i]->GetName());
+      }
+    }
+  }
+  if (id != num_comp) ASLP_ERR << "The graph has a cycle";
+  std::map<std::string, int32> name_to_id;
+  for (int i = 0; i < num_comp; i++) name_to_id.insert(std::make_pair(comp[i]->GetName(), comp[i]->GetId()));
+  for (int i = 0; i < num_comp; i++) {
+    input_name = comp[i]->GetInputName();
+    std::vector<int32> input(input_name.size(), 0);
+    for (size_t j = 0; j < input_name.size(); j++) {
+      if (input_name[j] == "-1") input[j] = -1;
+      else {
+        auto it = name_to_id.find(input_name[j]);
+        if (it != name_to_id.end()) input[j] = it->second;
+      }
+    }
+    comp[i]->SetInput(input);
+  }
+}
+void Nnet::SortComponent(std::vector<Component *> &comp) {  // :951-958
+  std::vector<Component *> tmp(comp.size());
+  for (size_t i = 0; i < comp.size(); i++) tmp[comp[i]->GetId()] = comp[i];
+  comp.swap(tmp);
+}
+
+}  // namespace aslp

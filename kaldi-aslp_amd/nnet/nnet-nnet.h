@@ -1,0 +1,100 @@
+// nnet-nnet.h -- the Nnet graph executor of the host engine.
+// Same public API as the reference's kaldi::aslp_nnet::Nnet (src/aslp-nnet/nnet-nnet.h:38-193).
+#pragma once
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "nnet-component.h"
+
+namespace aslp {
+
+class Nnet {
+ public:
+  Nnet() {}
+  Nnet(const Nnet &other);
+  Nnet &operator=(const Nnet &other);
+  ~Nnet();
+
+  void Propagate(const CuMatrixBase &in, CuMatrix *out);
+  void Propagate(const std::vector<const CuMatrixBase *> &in, std::vector<CuMatrix *> *out);
+  void Backpropagate(const CuMatrixBase &out_diff, CuMatrix *in_diff);
+  void Backpropagate(const std::vector<const CuMatrixBase *> &out_diff, std::vector<CuMatrix *> *in_diff);
+  void Feedforward(const CuMatrixBase &in, CuMatrix *out);
+  void Feedforward(const std::vector<const CuMatrixBase *> &in, std::vector<CuMatrix *> *out);
+  void GetComponentTime();
+
+  int32 InputDim() const;
+  int32 OutputDim() const;
+  int32 NumInput() const { return input_.size(); }
+  int32 NumOutput() const { return output_.size(); }
+  int32 NumComponents() const { return components_.size(); }
+  const Component &GetComponent(int32 c) const;
+  Component &GetComponent(int32 c);
+  void SetComponent(int32 c, Component *component);
+  void AppendComponent(Component *dynamically_allocated_comp);
+  void AppendNnet(const Nnet &nnet_to_append);
+  void RemoveComponent(int32 c);
+  void RemoveLastComponent() { RemoveComponent(NumComponents() - 1); }
+
+  // per-component forward outputs / backward output-diffs (reference: PropagateBuffer())
+  const CuMatrixBase &OutputBuffer(int32 c) const { return output_buf_[c]; }
+  const CuMatrixBase &OutputDiffBuffer(int32 c) const { return output_diff_buf_[c]; }
+  const CuMatrixBase &InputDiffBuffer(int32 c) const;
+
+  int32 NumParams() const;
+  void GetParams(std::vector<BaseFloat> *wei_copy) const;
+  void GetGpuParams(std::vector<std::pair<BaseFloat *, int>> *params);
+  void GetAccStats(std::vector<double *> *acc_params, std::vector<std::pair<double *, int>> *data_params);
+
+  void ResetLstmStreams(const std::vector<int32> &stream_reset_flag);
+  void SetSeqLengths(const std::vector<int32> &sequence_lengths);
+  void SetChunkSize(int chunk_size);
+
+  void Init(const std::string &config_file);
+  void InitFromString(const std::string &proto_text);  // same grammar, from memory
+  void Read(const std::string &file);
+  void Read(std::istream &in, bool binary);
+  void Write(const std::string &file, bool binary) const;
+  void Write(std::ostream &out, bool binary) const;
+  void WriteStandard(const std::string &file, bool binary) const;
+  void WriteStandard(std::ostream &out, bool binary) const;
+  void WriteDotFile(std::ostream &out) const;
+
+  std::string Info() const;
+  std::string InfoGradient() const;
+  std::string InfoPropagate() const;
+  std::string InfoBackPropagate() const;
+  void Check() const;
+  void Destroy();
+
+  void SetTrainOptions(const NnetTrainOptions &opts);
+  const NnetTrainOptions &GetTrainOptions() const { return opts_; }
+  void AutoComplete();
+  void AssignComponentId(std::vector<Component *> &components);
+  void SortComponent(std::vector<Component *> &components);
+
+  // Engine switch (not in the reference): when true (default) a component whose only input is the
+  // full output of its producer reads that buffer in place instead of "zero + AddMat" copying it
+  // (nnet-nnet.cc:86-95), and its in-diff is written straight into the producer's out-diff
+  // buffer when it is the producer's only consumer (nnet-nnet.cc:133-144).  Values are identical.
+  void SetLinkAliasing(bool on) { alias_links_ = on; }
+
+ private:
+  void InitStream(std::istream &is);
+  void InitInputOutput();
+  bool IsDirectLink(int32 i) const;  // single input, offset 0, full width
+
+  std::vector<Component *> components_;
+  std::vector<int32> input_, output_;
+  std::vector<int32> num_consumers_;
+  std::vector<std::pair<std::string, double>> propagate_time_, back_propagate_time_;
+  std::vector<CuMatrix> input_buf_, output_buf_, input_diff_buf_, output_diff_buf_;
+  std::vector<const CuMatrixBase *> in_view_;       // what component i actually reads as input
+  std::vector<const CuMatrixBase *> in_diff_view_;  // where component i's in-diff went
+  NnetTrainOptions opts_;
+  bool alias_links_ = true;
+};
+
+}  // namespace aslp

@@ -1,0 +1,198 @@
+"""GPU parity of the host engine (Nnet / Component / Xent driven through the C ABI of
+include/aslp_nnet.h) against the CPU oracle, for the DNN path of BASELINE.json configs 1-2:
+Propagate outputs, per-layer buffers, loss statistics, updated weights after 1 and 2 SGD steps
+(the second step exposes the momentum path), at small sizes; plus size-independent properties."""
+import numpy as np
+import pytest
+import torch
+
+import nnet_io
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def make_dnn(oracle, tmp_path, in_dim, hid, nh, out_dim, bn, mb, seed):
+    d = oracle.lib.orc_dnn_create(in_dim, hid, nh, out_dim, bn, mb, seed)
+    L = oracle.lib.orc_dnn_num_layers(d)
+    layers = []
+    import ctypes as C
+    for l in range(L):
+        r, c = C.c_int(), C.c_int()
+        wp = oracle.lib.orc_dnn_weight(d, l, C.byref(r), C.byref(c))
+        W = np.ctypeslib.as_array(wp, shape=(r.value, c.value)).copy()
+        b = np.ctypeslib.as_array(oracle.lib.orc_dnn_bias(d, l), shape=(r.value,)).copy()
+        layers.append(("<AffineTransform>", c.value, r.value, nnet_io.affine(W, b)))
+        if l < L - 1:
+            if bn:
+                layers.append(("<BatchNormalization>", r.value, r.value, nnet_io.batchnorm(np.zeros(r.value), np.ones(r.value))))
+            layers.append(("<Sigmoid>", r.value, r.value, b""))
+    layers.append(("<Softmax>", out_dim, out_dim, b""))
+    path = tmp_path / "dnn.nnet"
+    nnet_io.write_simple_nnet(path, layers)
+    return d, path
+
+
+def oracle_params(oracle, d, bn):
+    import ctypes as C
+    L = oracle.lib.orc_dnn_num_layers(d)
+    out = []
+    for l in range(L):
+        r, c = C.c_int(), C.c_int()
+        wp = oracle.lib.orc_dnn_weight(d, l, C.byref(r), C.byref(c))
+        out.append(np.ctypeslib.as_array(wp, shape=(r.value * c.value,)).copy())
+        out.append(np.ctypeslib.as_array(oracle.lib.orc_dnn_bias(d, l), shape=(r.value,)).copy())
+        if bn and l < L - 1:  # GetParams order of BatchNormalization: shift then scale
+            out.append(np.ctypeslib.as_array(oracle.lib.orc_dnn_bn_shift(d, l), shape=(r.value,)).copy())
+            out.append(np.ctypeslib.as_array(oracle.lib.orc_dnn_bn_scale(d, l), shape=(r.value,)).copy())
+    return np.concatenate(out)
+
+
+@pytest.mark.parametrize("bn", [0, 1])
+@pytest.mark.parametrize("dims", [(24, 32, 2, 10, 16), (44, 64, 3, 50, 128), (40, 96, 5, 300, 256)])
+@pytest.mark.parametrize("momentum", [0.0, 0.9])
+def test_dnn_train_steps_match_oracle(aslp, oracle, dev, tmp_path, dims, bn, momentum):
+    in_dim, hid, nh, out_dim, mb = dims
+    d, path = make_dnn(oracle, tmp_path, in_dim, hid, nh, out_dim, bn, mb, seed=5)
+    net = aslp.Nnet.Read(path)
+    lr = 0.002
+    net.SetTrainOptions(learn_rate=lr, momentum=momentum)
+    assert net.NumParams() == oracle_params(oracle, d, bn).size
+    assert oracle.rel_err(net.GetParams(), oracle_params(oracle, d, bn)) == 0.0  # file round trip is exact
+    rng = np.random.default_rng(3)
+    xent = aslp.Xent()
+    tot_loss = 0.0
+    for step in range(2):
+        x = rng.standard_normal((mb, in_dim)).astype(np.float32)
+        lab = rng.integers(0, out_dim, mb).astype(np.int32)
+        ref_loss = oracle.lib.orc_dnn_train_step(d, x, lab, lr, momentum)
+        tot_loss += ref_loss
+        xd, ld = torch.from_numpy(x).to(dev), torch.from_numpy(lab).to(dev)
+        net.TrainStepXent(xent, xd, ld)
+        # softmax output of this step (OutputLayer buffer) vs oracle
+        out_ref = np.ctypeslib.as_array(oracle.lib.orc_dnn_output(d), shape=(mb, out_dim))
+        out = net.ComponentOutput(net.NumComponents() - 1, mb, out_dim)
+        assert oracle.rel_err(out, out_ref) < TOL, ("output", step)
+        assert oracle.rel_err(net.GetParams(), oracle_params(oracle, d, bn)) < TOL, ("params", step)
+    st = xent.GetStats()
+    assert st["frames"] == 2 * mb
+    assert abs(st["loss"] - tot_loss) / tot_loss < 1e-5
+    assert "AvgLoss:" in xent.Report() and "FRAME_ACCURACY >>" in xent.Report()
+    oracle.lib.orc_dnn_destroy(d)
+
+
+def test_link_aliasing_is_value_neutral(aslp, oracle, dev, tmp_path):
+    """The engine's in-place links must give bit-identical results to the reference's zero+AddMat copies."""
+    d, path = make_dnn(oracle, tmp_path, 24, 32, 2, 10, 1, 16, seed=9)
+    rng = np.random.default_rng(1)
+    x = torch.from_numpy(rng.standard_normal((16, 24)).astype(np.float32)).to(dev)
+    lab = torch.from_numpy(rng.integers(0, 10, 16).astype(np.int32)).to(dev)
+    res = []
+    for alias in (1, 0):
+        net = aslp.Nnet.Read(path)
+        net.SetLinkAliasing(alias)
+        net.SetTrainOptions(learn_rate=0.01, momentum=0.5)
+        xe = aslp.Xent()
+        for _ in range(3):
+            net.TrainStepXent(xe, x, lab)
+        res.append(net.GetParams())
+    assert np.array_equal(res[0], res[1])
+    oracle.lib.orc_dnn_destroy(d)
+
+
+def test_propagate_backpropagate_api(aslp, oracle, dev, tmp_path):
+    """Separate Propagate / Xent / Backpropagate calls (the reference's loop, aslp-nnet-train-frame.cc:109-131)
+    including the in-diff w.r.t. the network input."""
+    in_dim, hid, out_dim, mb = 20, 16, 7, 12
+    rng = np.random.default_rng(2)
+    W1 = rng.standard_normal((hid, in_dim)).astype(np.float32) * 0.3
+    b1 = rng.standard_normal(hid).astype(np.float32)
+    W2 = rng.standard_normal((out_dim, hid)).astype(np.float32) * 0.3
+    b2 = rng.standard_normal(out_dim).astype(np.float32)
+    path = tmp_path / "n.nnet"
+    nnet_io.write_simple_nnet(path, [("<AffineTransform>", in_dim, hid, nnet_io.affine(W1, b1)), ("<Tanh>", hid, hid, b""),
+                                     ("<AffineTransform>", hid, out_dim, nnet_io.affine(W2, b2)), ("<Softmax>", out_dim, out_dim, b"")])
+    net = aslp.Nnet.Read(path)
+    net.SetTrainOptions(learn_rate=0.0)  # gradients only
+    x = rng.standard_normal((mb, in_dim)).astype(np.float32)
+    lab = rng.integers(0, out_dim, mb).astype(np.int32)
+    out = net.Propagate(torch.from_numpy(x).to(dev))
+    a1 = x @ W1.T + b1
+    h = oracle.unary("orc_tanh", a1)
+    y = oracle.unary("orc_softmax_rows", h @ W2.T + b2)
+    assert oracle.rel_err(out.cpu().numpy(), y) < 1e-5
+    tgt = np.zeros((mb, out_dim), np.float32)
+    tgt[np.arange(mb), lab] = 1
+    diff_ref, _ = oracle.xent_eval(np.ones(mb, np.float32), y, tgt)
+    xe = aslp.Xent()
+    diff = torch.empty_like(out)
+    xe.Eval(torch.ones(mb, device=dev), out, diff, labels=torch.from_numpy(lab).to(dev))
+    assert oracle.rel_err(diff.cpu().numpy(), diff_ref) < 1e-5
+    in_diff = net.Backpropagate(diff, want_in_diff=True)
+    dh = oracle.binary("orc_diff_tanh", h, diff_ref @ W2)
+    assert oracle.rel_err(in_diff.cpu().numpy(), dh @ W1) < 1e-5
+    # wrong dims raise like the reference's KALDI_ERR "Non-matching dims!"
+    with pytest.raises(RuntimeError, match="Non-matching dims"):
+        net.Propagate(torch.zeros(4, in_dim + 1, device=dev))
+
+
+def test_graph_net_multi_input_links(aslp, oracle, dev, tmp_path):
+    """Graph nets: a component's input is the zeroed buffer with each producer added at its column offset
+    (nnet-nnet.cc:86-95); out-diffs are scatter-added back (:133-144)."""
+    rng = np.random.default_rng(4)
+    D, mb = 6, 9
+    Wa = rng.standard_normal((D, D)).astype(np.float32); ba = rng.standard_normal(D).astype(np.float32)
+    Wb = rng.standard_normal((D, D)).astype(np.float32); bb = rng.standard_normal(D).astype(np.float32)
+    Wc = rng.standard_normal((4, 2 * D)).astype(np.float32); bc = rng.standard_normal(4).astype(np.float32)
+    comps = [
+        dict(marker="<InputLayer>", dim_in=D, dim_out=D, id=0, inputs=[-1], offsets=[0]),
+        dict(marker="<AffineTransform>", dim_in=D, dim_out=D, id=1, inputs=[0], offsets=[0], data=nnet_io.affine(Wa, ba)),
+        dict(marker="<AffineTransform>", dim_in=D, dim_out=D, id=2, inputs=[0], offsets=[0], data=nnet_io.affine(Wb, bb)),
+        dict(marker="<Sigmoid>", dim_in=D, dim_out=D, id=3, inputs=[1, 2], offsets=[0, 0]),            # sum of two branches
+        dict(marker="<AffineTransform>", dim_in=2 * D, dim_out=4, id=4, inputs=[3, 1], offsets=[0, D], data=nnet_io.affine(Wc, bc)),  # concat
+        dict(marker="<OutputLayer>", dim_in=4, dim_out=4, id=5, inputs=[4], offsets=[0]),
+    ]
+    path = tmp_path / "g.nnet"
+    nnet_io.write_graph_nnet(path, comps)
+    net = aslp.Nnet.Read(path)
+    net.SetTrainOptions(learn_rate=0.0)
+    x = rng.standard_normal((mb, D)).astype(np.float32)
+    out = net.Propagate(torch.from_numpy(x).to(dev)).cpu().numpy()
+    a, b = x @ Wa.T + ba, x @ Wb.T + bb
+    s = oracle.unary("orc_sigmoid", a + b)
+    ref = np.concatenate([s, a], 1) @ Wc.T + bc
+    assert oracle.rel_err(out, ref) < 1e-5
+    od = rng.standard_normal((mb, 4)).astype(np.float32)
+    in_diff = net.Backpropagate(torch.from_numpy(od).to(dev), want_in_diff=True).cpu().numpy()
+    dcat = od @ Wc
+    ds = oracle.binary("orc_diff_sigmoid", s, dcat[:, :D])
+    da = ds + dcat[:, D:]
+    ref_in = da @ Wa + ds @ Wb
+    assert oracle.rel_err(in_diff, ref_in) < 1e-5
+
+
+def test_model_file_round_trip_text_and_binary(aslp, oracle, dev, tmp_path):
+    proto = """<NnetProto>
+<Splice> <InputDim> 8 <OutputDim> 24 <BuildVector> -1:1 </BuildVector>
+<AffineTransform> <InputDim> 24 <OutputDim> 16 <BiasMean> -2.0 <BiasRange> 4.0 <ParamStddev> 0.04
+<BatchNormalization> <InputDim> 16 <OutputDim> 16
+<Sigmoid> <InputDim> 16 <OutputDim> 16
+<AffineTransform> <InputDim> 16 <OutputDim> 5 <BiasMean> 0.0 <BiasRange> 0.0 <ParamStddev> 0.04
+<Softmax> <InputDim> 5 <OutputDim> 5
+</NnetProto>
+"""
+    net = aslp.Nnet.Init(proto, seed=777)
+    assert net.NumComponents() == 8  # + InputLayer / OutputLayer (AutoComplete)
+    assert [net.Marker(i) for i in (0, 1, 7)] == ["<InputLayer>", "<Splice>", "<OutputLayer>"]
+    p0 = net.GetParams()
+    net.Write(tmp_path / "b.nnet", binary=True)
+    net.Write(tmp_path / "t.nnet", binary=False)
+    nb = aslp.Nnet.Read(tmp_path / "b.nnet")
+    nt = aslp.Nnet.Read(tmp_path / "t.nnet")
+    assert np.array_equal(nb.GetParams(), p0)
+    assert oracle.rel_err(nt.GetParams(), p0) < 1e-6  # text keeps 7 significant digits
+    x = torch.randn(10, 8, device=dev)
+    assert torch.equal(nb.Propagate(x), net.Propagate(x))
+    txt = open(tmp_path / "t.nnet").read()
+    assert txt.startswith("<Nnet> \n<InputLayer> 8 8 0 [ -1 ]\n[ 0 ]\n\n")  # header, then the "\n" of nnet-component.cc:340
+    assert "<Splice> 24 8 1 [ 0 ]\n[ 0 ]\n\n[ -1 0 1 ]\n" in txt and txt.rstrip().endswith("</Nnet>")
