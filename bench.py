@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/sec of the aslp-nnet training step on MI355X (BASELINE.json metric).
+
+Workload (config 2 of BASELINE.json): 5 x 2048 sigmoid DNN with BatchNormalization after every
+hidden AffineTransform, 440-dim input (40-dim fbank x 11 splice), 3000 pdf targets, minibatch
+1024 per GPU; one step = Nnet::Propagate -> Xent::Eval -> Nnet::Backpropagate (+ Update of every
+layer) on a synthetic minibatch already resident in HBM.  With N > 1 every rank trains its own
+replica on its own shard and the replicas are averaged BSP-style (aslp-parallel/bsp-worker.cc)
+with one RCCL all-reduce every `sync_period` frames (default 25600, as the reference).
+
+Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement" for the roofline / cpu_baseline fields.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+IN_DIM, HID, NH, OUT_DIM, MB = 440, 2048, 5, 3000, 1024
+FLOP_PER_FRAME = 141131776.0   # 2W fwd + 2(W-W1) bwd-data + 2W wgrad
+F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+
+
+def proto():
+    lines = ["<NnetProto>"]
+    d = IN_DIM
+    for _ in range(NH):
+        lines.append("<AffineTransform> <InputDim> %d <OutputDim> %d <BiasMean> -2.0 <BiasRange> 4.0 <ParamStddev> 0.04" % (d, HID))
+        lines.append("<BatchNormalization> <InputDim> %d <OutputDim> %d" % (HID, HID))
+        lines.append("<Sigmoid> <InputDim> %d <OutputDim> %d" % (HID, HID))
+        d = HID
+    lines.append("<AffineTransform> <InputDim> %d <OutputDim> %d <BiasMean> 0.0 <BiasRange> 0.0 <ParamStddev> 0.04" % (d, OUT_DIM))
+    lines.append("<Softmax> <InputDim> %d <OutputDim> %d" % (OUT_DIM, OUT_DIM))
+    lines.append("</NnetProto>")
+    return "\n".join(lines) + "\n"
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """The oracle's C chain (a port of the reference CPU path) timed on this host: same net, same
+    minibatch size, a bounded number of steps."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib as oracle
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    oracle.lib.orc_set_num_threads(cores)
+    d = oracle.lib.orc_dnn_create(IN_DIM, HID, NH, OUT_DIM, 1, MB, 777)
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((MB, IN_DIM)).astype(np.float32)
+    lab = rng.integers(0, OUT_DIM, MB).astype(np.int32)
+    oracle.lib.orc_dnn_train_step(d, x, lab, 1e-5, 0.0)  # warm-up (page-in)
+    t0 = time.time()
+    steps = 0
+    while True:
+        oracle.lib.orc_dnn_train_step(d, x, lab, 1e-5, 0.0)
+        steps += 1
+        el = time.time() - t0
+        if el > seconds_budget or steps >= 8:
+            break
+    oracle.lib.orc_dnn_destroy(d)
+    return {"value": steps * MB / el, "unit": "frames/sec", "cores": cores, "kind": "port",
+            "sample": "%d steps of minibatch %d of the same 5x2048+BN DNN (oracle/aslp_oracle.c, OpenMP blocked sgemm)" % (steps, MB)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--sync-period", type=int, default=25600, help="frames between BSP model syncs (N > 1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gemm-profile", action="store_true", help="do not bracket GEMM launches with HIP events")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+
+    import aslp_import
+    aslp = aslp_import.load()   # raises if libaslp_hip.so is missing (no fallback)
+    aslp.ops.use_torch_stream()
+    from kaldi_aslp_amd.parallel import BspWorker
+
+    net = aslp.Nnet.Init(proto(), seed=777)            # same init on every rank (like one aslp-nnet-init model)
+    net.SetTrainOptions(learn_rate=1e-5, momentum=0.0)  # small lr: synthetic labels, keep the run finite
+    xent = aslp.Xent()
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)                          # every rank its own shard
+    x = torch.randn(MB, IN_DIM, device=dev, generator=g)
+    labels = torch.randint(0, OUT_DIM, (MB,), device=dev, generator=g, dtype=torch.int32)
+    worker = BspWorker(net) if world > 1 else None
+
+    frames_since_sync = 0
+
+    def step():
+        nonlocal frames_since_sync
+        net.TrainStepXent(xent, x, labels)
+        frames_since_sync += MB
+        if worker is not None and frames_since_sync >= args.sync_period:
+            worker.Synchronize(frames_since_sync)
+            frames_since_sync = 0
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if not args.no_gemm_profile:
+        aslp.lib.aslp_gemm_profile(1)
+    aslp.lib.aslp_gemm_profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    aslp.lib.aslp_gemm_profile(0)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-variant GEMM statistics of the timed region (HIP events on the launch stream)
+    gemm = {}
+    for vi, name in enumerate(("NT", "NN", "TN", "TT")):
+        fl, ms = C.c_double(), C.c_double()
+        n = aslp.lib.aslp_gemm_profile_get(vi, C.byref(fl), C.byref(ms))
+        if n > 0:
+            gemm[name] = {"launches": int(n), "flop_per_launch": fl.value / n, "avg_us": ms.value * 1e3 / n if ms.value > 0 else None,
+                          "tflops": fl.value / ms.value / 1e9 if ms.value > 0 else None}
+    st = xent.GetStats()  # also proves the loss stayed finite
+
+    if rank == 0:
+        total_frames = world * args.steps * MB
+        value = total_frames / elapsed
+        out = {
+            "metric": "frames/sec (aslp-nnet-train)", "value": value, "unit": "frames/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cfg2: 5x2048 sigmoid DNN + BatchNorm, 440 in (40 fbank x 11 splice), 3000 pdfs, minibatch 1024/GPU, "
+                                   "Propagate + Xent + Backpropagate + SGD update",
+                       "global_batch": world * MB, "parallelism": "bsp-dp%d" % world, "sync_period_frames": args.sync_period,
+                       "learn_rate": 1e-5, "avg_xent_per_frame": (st["loss"] - st["entropy"]) / max(st["frames"], 1.0)},
+        }
+        timed = {k: v for k, v in gemm.items() if v["tflops"]}
+        if timed:
+            dom = max(timed, key=lambda k: timed[k]["avg_us"] * timed[k]["launches"])
+            d = timed[dom]
+            out["roofline"] = {"bound": "mfma", "kernel": "gemm_f32_mfma<%s>" % dom, "achieved": d["tflops"], "peak": F32_MFMA_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": d["tflops"] / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                               "flop_per_launch": d["flop_per_launch"], "avg_launch_us": d["avg_us"], "launches": d["launches"]}
+            tot_fl = sum(v["flop_per_launch"] * v["launches"] for v in timed.values())
+            tot_ms = sum(v["avg_us"] * v["launches"] for v in timed.values()) / 1e3
+            out["gemm_all"] = {"variants": gemm, "tflops": tot_fl / tot_ms / 1e9, "frac_of_step_time": tot_ms / (elapsed * 1e3),
+                               "algorithmic_tflops_whole_step": FLOP_PER_FRAME * args.steps * MB / elapsed / 1e12}
+        else:
+            out["roofline"] = {"bound": "mfma", "achieved": FLOP_PER_FRAME * args.steps * MB / elapsed / 1e12, "peak": F32_MFMA_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": FLOP_PER_FRAME * args.steps * MB / elapsed / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                               "traffic": None, "note": "whole-step algorithmic flops (per-kernel events disabled)"}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
