@@ -124,6 +124,8 @@ int aslp_sgemm_ex(int transA, int transB, int M, int N, int K, float alpha, cons
  * profiling was enabled with aslp_gemm_profile(1)) event-timed milliseconds. */
 void aslp_gemm_profile(int enable);
 void aslp_gemm_profile_reset(void);
+/* tuning aid: force tile config 1..5 (0 = heuristic).  1: 32x128x16  2: 64x64x16  3: 128x64x32  4: 128x128x32  5: 128x128x16 */
+void aslp_gemm_force_tile(int cfg);
 /* variant: 0 = NT, 1 = NN, 2 = TN, 3 = TT.  Returns number of launches. */
 long aslp_gemm_profile_get(int variant, double *flops, double *ms);
 

@@ -106,6 +106,7 @@ _sig("aslp_sgemm", _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _f, _vp, _i)
 _sig("aslp_sgemm_ex", _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _f, _vp, _i, C.POINTER(GemmEpilogue))
 _sig("aslp_gemm_profile", None, _i)
 _sig("aslp_gemm_profile_reset", None)
+_sig("aslp_gemm_force_tile", None, _i)
 _sig("aslp_gemm_profile_get", C.c_long, _i, C.POINTER(C.c_double), C.POINTER(C.c_double))
 # fused
 _sig("aslp_bn_forward", None, _vp, _md, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f)

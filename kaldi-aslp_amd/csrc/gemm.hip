@@ -41,33 +41,46 @@ struct GemmArgs {
   int tiles_m, tiles_n;
 };
 
-constexpr int BK = 16;
-constexpr int KC_LD = BK + 4;
+template <int BK>
+struct TileK {
+  static constexpr int KC_LD = BK + 4;  // row stride of a KC tile: odd number of 16-byte slots
+};
 
-template <int BR>
+template <int BR, int BK, int NT>
 struct Stage {
-  static constexpr int TOTAL = BR * BK / 4;             // float4 per tile
-  static constexpr int NV = (TOTAL + 255) / 256;         // float4 per thread per tile
-  static constexpr bool FULL = TOTAL % 256 == 0;         // otherwise the tail threads idle
+  static constexpr int TOTAL = BR * BK / 4;          // float4 per tile
+  static constexpr int NV = (TOTAL + NT - 1) / NT;   // float4 per thread per tile
+  static constexpr bool FULL = TOTAL % NT == 0;      // otherwise the tail threads idle
 };
 
 // ---- global -> registers ------------------------------------------------------------------
+// VEC variants are branch-free: addresses are clamped into the matrix and out-of-range k is
+// zeroed with a select, so the loads of one tile issue back to back with no s_waitcnt between
+// them (hipcc serialises "branch around each load" forms, cdna guide §5 trap (c)).  They need
+// 16-byte aligned pointers/strides and the contiguous extent to be a multiple of 4.
+// Rows beyond the matrix are clamped (they only feed accumulator rows that are never stored).
+//
 // KC operand: src is [R x K] row-major (ld), tile rows r0.., k0..
-template <int BR>
-__device__ __forceinline__ void gload_kc(const float *__restrict__ src, int ld, int R, int K, int r0, int k0, bool vec,
-                                         float4 (&v)[Stage<BR>::NV]) {
+template <int BR, int BK, int NT, bool VEC>
+__device__ __forceinline__ void gload_kc(const float *__restrict__ src, int ld, int R, int K, int r0, int k0,
+                                         float4 (&v)[Stage<BR, BK, NT>::NV]) {
   constexpr int C4 = BK / 4;
+  typedef Stage<BR, BK, NT> S;
 #pragma unroll
-  for (int i = 0; i < Stage<BR>::NV; i++) {
-    int idx = threadIdx.x + i * 256;
+  for (int i = 0; i < S::NV; i++) {
+    int idx = threadIdx.x + i * NT;
     int row = idx / C4, c4 = idx % C4;
     int gr = r0 + row, gk = k0 + c4 * 4;
     float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-    if ((Stage<BR>::FULL || idx < Stage<BR>::TOTAL) && gr < R) {
-      const float *p = src + (long)gr * ld + gk;
-      if (vec && gk + 3 < K) {
-        x = *reinterpret_cast<const float4 *>(p);
-      } else {
+    if (VEC) {
+      if (S::FULL || idx < S::TOTAL) {
+        const bool kv = gk < K;  // K % 4 == 0: the whole float4 is in or out
+        gr = gr < R ? gr : R - 1;
+        x = *reinterpret_cast<const float4 *>(src + (long)gr * ld + (kv ? gk : 0));  // masked at store time
+      }
+    } else {
+      if ((S::FULL || idx < S::TOTAL) && gr < R) {
+        const float *p = src + (long)gr * ld + gk;
         if (gk < K) x.x = p[0];
         if (gk + 1 < K) x.y = p[1];
         if (gk + 2 < K) x.z = p[2];
@@ -77,32 +90,46 @@ __device__ __forceinline__ void gload_kc(const float *__restrict__ src, int ld, 
     v[i] = x;
   }
 }
-template <int BR>
-__device__ __forceinline__ void sstore_kc(float *lds, const float4 (&v)[Stage<BR>::NV]) {
+// The k-tail zeroing of the VEC loads happens here, at LDS-store time: touching the loaded
+// registers right after the load would make the compiler wait for them (vmcnt) immediately and
+// kill the prefetch distance.
+template <int BR, int BK, int NT, bool VEC>
+__device__ __forceinline__ void sstore_kc(float *lds, const float4 (&v)[Stage<BR, BK, NT>::NV], int k0, int K) {
   constexpr int C4 = BK / 4;
+  typedef Stage<BR, BK, NT> S;
 #pragma unroll
-  for (int i = 0; i < Stage<BR>::NV; i++) {
-    int idx = threadIdx.x + i * 256;
+  for (int i = 0; i < S::NV; i++) {
+    int idx = threadIdx.x + i * NT;
     int row = idx / C4, c4 = idx % C4;
-    if (Stage<BR>::FULL || idx < Stage<BR>::TOTAL) *reinterpret_cast<float4 *>(lds + row * KC_LD + c4 * 4) = v[i];
+    float4 x = v[i];
+    if (VEC) {
+      const bool kv = k0 + c4 * 4 < K;
+      x.x = kv ? x.x : 0.f; x.y = kv ? x.y : 0.f; x.z = kv ? x.z : 0.f; x.w = kv ? x.w : 0.f;
+    }
+    if (S::FULL || idx < S::TOTAL) *reinterpret_cast<float4 *>(lds + row * TileK<BK>::KC_LD + c4 * 4) = x;
   }
 }
 // RC operand: src is [K x R] row-major (ld), tile k0.., rows r0..
-template <int BR>
-__device__ __forceinline__ void gload_rc(const float *__restrict__ src, int ld, int R, int K, int r0, int k0, bool vec,
-                                         float4 (&v)[Stage<BR>::NV]) {
+template <int BR, int BK, int NT, bool VEC>
+__device__ __forceinline__ void gload_rc(const float *__restrict__ src, int ld, int R, int K, int r0, int k0,
+                                         float4 (&v)[Stage<BR, BK, NT>::NV]) {
   constexpr int C4 = BR / 4;
+  typedef Stage<BR, BK, NT> S;
 #pragma unroll
-  for (int i = 0; i < Stage<BR>::NV; i++) {
-    int idx = threadIdx.x + i * 256;
+  for (int i = 0; i < S::NV; i++) {
+    int idx = threadIdx.x + i * NT;
     int k = idx / C4, c4 = idx % C4;
     int gk = k0 + k, gr = r0 + c4 * 4;
     float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-    if ((Stage<BR>::FULL || idx < Stage<BR>::TOTAL) && gk < K) {
-      const float *p = src + (long)gk * ld + gr;
-      if (vec && gr + 3 < R) {
-        x = *reinterpret_cast<const float4 *>(p);
-      } else {
+    if (VEC) {
+      if (S::FULL || idx < S::TOTAL) {
+        const bool kv = gk < K;
+        gr = gr + 3 < R ? gr : R - 4;  // R % 4 == 0
+        x = *reinterpret_cast<const float4 *>(src + (long)(kv ? gk : 0) * ld + gr);  // masked at store time
+      }
+    } else {
+      if ((S::FULL || idx < S::TOTAL) && gk < K) {
+        const float *p = src + (long)gk * ld + gr;
         if (gr < R) x.x = p[0];
         if (gr + 1 < R) x.y = p[1];
         if (gr + 2 < R) x.z = p[2];
@@ -112,30 +139,43 @@ __device__ __forceinline__ void gload_rc(const float *__restrict__ src, int ld, 
     v[i] = x;
   }
 }
-template <int BR>
-__device__ __forceinline__ void sstore_rc(float *lds, const float4 (&v)[Stage<BR>::NV]) {
+template <int BR, int BK, int NT, bool VEC>
+__device__ __forceinline__ void sstore_rc(float *lds, const float4 (&v)[Stage<BR, BK, NT>::NV], int k0, int K) {
   constexpr int C4 = BR / 4;
+  typedef Stage<BR, BK, NT> S;
 #pragma unroll
-  for (int i = 0; i < Stage<BR>::NV; i++) {
-    int idx = threadIdx.x + i * 256;
+  for (int i = 0; i < S::NV; i++) {
+    int idx = threadIdx.x + i * NT;
     int k = idx / C4, c4 = idx % C4;
-    if (Stage<BR>::FULL || idx < Stage<BR>::TOTAL) *reinterpret_cast<float4 *>(lds + k * (BR + 4) + c4 * 4) = v[i];
+    float4 x = v[i];
+    if (VEC) {
+      const bool kv = k0 + k < K;
+      x.x = kv ? x.x : 0.f; x.y = kv ? x.y : 0.f; x.z = kv ? x.z : 0.f; x.w = kv ? x.w : 0.f;
+    }
+    if (S::FULL || idx < S::TOTAL) *reinterpret_cast<float4 *>(lds + k * (BR + 4) + c4 * 4) = x;
   }
 }
 
-template <int BR, bool KC>
+template <int BR, int BK, bool KC>
 struct OperandTile {
-  static constexpr int kFloats = KC ? BR * KC_LD : BK * (BR + 4);
+  static constexpr int kFloats = KC ? BR * TileK<BK>::KC_LD : BK * (BR + 4);
 };
 
+template <int BM, int BN, int BK, bool A_KC, bool B_KC>
+constexpr int gemm_lds_bytes() {
+  return 2 * (OperandTile<BM, BK, A_KC>::kFloats + OperandTile<BN, BK, B_KC>::kFloats) * (int)sizeof(float);
+}
+
 // A_KC: op(A) rows are contiguous in k (transA == 0).  B_KC: op(B) columns are contiguous in k (transB == 1).
-template <int BM, int BN, int WGM, int WGN, bool A_KC, bool B_KC>
-__global__ void __launch_bounds__(256) gemm_f32_mfma(GemmArgs g) {
+template <int BM, int BN, int BK, int WGM, int WGN, bool A_KC, bool B_KC, bool VEC>
+__global__ void __launch_bounds__(64 * WGM * WGN) gemm_f32_mfma(GemmArgs g) {
+  constexpr int NT = 64 * WGM * WGN;
   constexpr int WM = BM / WGM, WN = BN / WGN;  // wave patch
   constexpr int TM = WM / 32, TN = WN / 32;    // 32x32 MFMA tiles per wave
-  static_assert(WGM * WGN == 4 && TM >= 1 && TN >= 1, "bad wave grid");
-  constexpr int A_FLOATS = OperandTile<BM, A_KC>::kFloats, B_FLOATS = OperandTile<BN, B_KC>::kFloats;
-  __shared__ __attribute__((aligned(16))) float lds[2 * (A_FLOATS + B_FLOATS)];
+  static_assert((WGM * WGN == 4 || WGM * WGN == 8) && TM >= 1 && TN >= 1, "bad wave grid");
+  constexpr int KC_LD = TileK<BK>::KC_LD;
+  constexpr int A_FLOATS = OperandTile<BM, BK, A_KC>::kFloats, B_FLOATS = OperandTile<BN, BK, B_KC>::kFloats;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
   // layout [A0 | B0 | A1 | B1]
   auto a_buf = [&](int b) { return lds + b * (A_FLOATS + B_FLOATS); };
   auto b_buf = [&](int b) { return lds + b * (A_FLOATS + B_FLOATS) + A_FLOATS; };
@@ -163,29 +203,28 @@ __global__ void __launch_bounds__(256) gemm_f32_mfma(GemmArgs g) {
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
 
-  float4 ra[Stage<BM>::NV], rb[Stage<BN>::NV];
+  // two register stages: while tile t is multiplied out of LDS, tile t+1 sits in one stage
+  // (already landed) and tile t+2 is in flight into the other -- >= one full MFMA phase of
+  // latency slack for every global load.
+  float4 ra0[Stage<BM, BK, NT>::NV], rb0[Stage<BN, BK, NT>::NV], ra1[Stage<BM, BK, NT>::NV], rb1[Stage<BN, BK, NT>::NV];
   const int ktiles = (g.K + BK - 1) / BK;
 
-  auto gload = [&](int kt) {
-    if (A_KC) gload_kc<BM>(g.A, g.lda, g.M, g.K, m0, kt * BK, g.a_vec, ra);
-    else gload_rc<BM>(g.A, g.lda, g.M, g.K, m0, kt * BK, g.a_vec, ra);
-    if (B_KC) gload_kc<BN>(g.B, g.ldb, g.N, g.K, n0, kt * BK, g.b_vec, rb);
-    else gload_rc<BN>(g.B, g.ldb, g.N, g.K, n0, kt * BK, g.b_vec, rb);
-  };
-  auto sstore = [&](int buf) {
-    if (A_KC) sstore_kc<BM>(a_buf(buf), ra); else sstore_rc<BM>(a_buf(buf), ra);
-    if (B_KC) sstore_kc<BN>(b_buf(buf), rb); else sstore_rc<BN>(b_buf(buf), rb);
-  };
+#define ASLP_GLOAD(kt, RA, RB)                                                                   \
+  do {                                                                                           \
+    if (A_KC) gload_kc<BM, BK, NT, VEC>(g.A, g.lda, g.M, g.K, m0, (kt)*BK, RA);                      \
+    else gload_rc<BM, BK, NT, VEC>(g.A, g.lda, g.M, g.K, m0, (kt)*BK, RA);                           \
+    if (B_KC) gload_kc<BN, BK, NT, VEC>(g.B, g.ldb, g.N, g.K, n0, (kt)*BK, RB);                      \
+    else gload_rc<BN, BK, NT, VEC>(g.B, g.ldb, g.N, g.K, n0, (kt)*BK, RB);                           \
+  } while (0)
+#define ASLP_SSTORE(buf, kt, RA, RB)                                                             \
+  do {                                                                                           \
+    if (A_KC) sstore_kc<BM, BK, NT, VEC>(a_buf(buf), RA, (kt)*BK, g.K);                              \
+    else sstore_rc<BM, BK, NT, VEC>(a_buf(buf), RA, (kt)*BK, g.K);                                   \
+    if (B_KC) sstore_kc<BN, BK, NT, VEC>(b_buf(buf), RB, (kt)*BK, g.K);                              \
+    else sstore_rc<BN, BK, NT, VEC>(b_buf(buf), RB, (kt)*BK, g.K);                                   \
+  } while (0)
 
-  if (ktiles > 0) {
-    gload(0);
-    sstore(0);
-  }
-  __syncthreads();
-
-  for (int kt = 0; kt < ktiles; kt++) {
-    const int cur = kt & 1;
-    if (kt + 1 < ktiles) gload(kt + 1);  // in flight during the MFMAs below
+  auto compute = [&](int cur) {
     const float *a_s = a_buf(cur), *b_s = b_buf(cur);
 #pragma unroll
     for (int h = 0; h < BK / 8; h++) {
@@ -220,9 +259,39 @@ __global__ void __launch_bounds__(256) gemm_f32_mfma(GemmArgs g) {
           for (int n = 0; n < TN; n++)
             acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][j], bf[n][j], acc[i][n], 0, 0, 0);
     }
-    if (kt + 1 < ktiles) sstore(cur ^ 1);
+  };
+
+  // Branch-free steady state: the k-tile count is rounded up to even (a tile beyond K loads from
+  // clamped addresses and is zeroed at store time, so it adds 0), and loads/stores for tiles past
+  // the end are issued unconditionally into buffers nobody reads.  With no conditional code
+  // between the loads and their use the compiler keeps exact vmcnt counts: a store of stage X
+  // waits only for stage X, the other stage's loads stay in flight across the barrier.
+  const int kt_end = (ktiles + 1) & ~1;
+  if (ktiles > 0) {
+    ASLP_GLOAD(0, ra0, rb0);
+    ASLP_SSTORE(0, 0, ra0, rb0);
+    ASLP_GLOAD(1, ra1, rb1);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < kt_end; kt += 2) {
+    // even step: tile kt in LDS[0], tile kt+1 in stage 1 (landed), load kt+2 into stage 0
+    ASLP_GLOAD(kt + 2, ra0, rb0);
+    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch issue ABOVE the MFMA phase
+    compute(0);
+    __builtin_amdgcn_sched_barrier(0);
+    ASLP_SSTORE(1, kt + 1, ra1, rb1);
+    __syncthreads();
+    // odd step: tile kt+1 in LDS[1], tile kt+2 in stage 0, load kt+3 into stage 1
+    ASLP_GLOAD(kt + 3, ra1, rb1);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(1);
+    __builtin_amdgcn_sched_barrier(0);
+    ASLP_SSTORE(0, kt + 2, ra0, rb0);
     __syncthreads();
   }
+#undef ASLP_GLOAD
+#undef ASLP_SSTORE
 
   // epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
   const aslp_gemm_epilogue &ep = g.ep;
@@ -272,29 +341,59 @@ void drain(GemmProf &p) {
   p.pending.clear();
 }
 
-template <int BM, int BN, int WGM, int WGN, bool A_KC, bool B_KC>
+int g_force_tile = 0;  // devtools: 0 = heuristic, else 1..5 picks a config
+
+template <int BM, int BN, int BK, int WGM, int WGN, bool A_KC, bool B_KC, bool VEC>
 void launch_cfg(GemmArgs &g) {
   g.tiles_m = (g.M + BM - 1) / BM;
   g.tiles_n = (g.N + BN - 1) / BN;
-  hipLaunchKernelGGL((gemm_f32_mfma<BM, BN, WGM, WGN, A_KC, B_KC>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, cur_stream(), g);
+  constexpr int lds_bytes = gemm_lds_bytes<BM, BN, BK, A_KC, B_KC>();
+  auto kern = gemm_f32_mfma<BM, BN, BK, WGM, WGN, A_KC, B_KC, VEC>;
+  static bool attr_set = false;  // one per template instantiation
+  if (!attr_set) {
+    if (lds_bytes > 48 * 1024)
+      ASLP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(64 * WGM * WGN), lds_bytes, cur_stream(), g);
 }
 
-template <bool A_KC, bool B_KC>
+template <bool A_KC, bool B_KC, bool VEC>
 void launch_variant(GemmArgs &g) {
   // Tile choice: the largest tile that still gives >= ~256 blocks (one per CU); skinny M
   // (the S-row recurrent GEMMs of the LSTM family) gets the 32-row tile.
   auto blocks = [&](int bm, int bn) { return (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn); };
-  if (g.M <= 32) {
-    launch_cfg<32, 128, 1, 4, A_KC, B_KC>(g);
-  } else if (g.M <= 64 && blocks(64, 64) < 256) {
-    launch_cfg<64, 64, 2, 2, A_KC, B_KC>(g);
-  } else if (blocks(128, 128) >= 224) {
-    launch_cfg<128, 128, 2, 2, A_KC, B_KC>(g);
-  } else if (blocks(128, 64) >= 224) {
-    launch_cfg<128, 64, 2, 2, A_KC, B_KC>(g);
-  } else {
-    launch_cfg<64, 64, 2, 2, A_KC, B_KC>(g);
+  int cfg;
+  // Measured on MI355X (devtools/bench_gemm.py, profiles/gemm_tiles_r01.txt): the 8-wave 64x128x32
+  // tile is best whenever it tiles the problem into >= ~200 full blocks; otherwise the 4-wave
+  // 64x64x32 tile (2+ blocks co-resident per CU) copes best with ragged edges / small grids.
+  if (g_force_tile) cfg = g_force_tile;
+  else if (g.M <= 32) cfg = 1;
+  else if (g.N % 128 == 0 && g.M % 64 == 0 && blocks(64, 128) >= 200) cfg = 12;
+  else cfg = 7;
+  switch (cfg) {
+    case 1: launch_cfg<32, 128, 16, 1, 4, A_KC, B_KC, VEC>(g); break;
+    case 2: launch_cfg<64, 64, 16, 2, 2, A_KC, B_KC, VEC>(g); break;
+    case 3: launch_cfg<128, 64, 32, 2, 2, A_KC, B_KC, VEC>(g); break;
+    case 4: launch_cfg<128, 128, 32, 2, 2, A_KC, B_KC, VEC>(g); break;
+    case 6: launch_cfg<128, 64, 64, 2, 2, A_KC, B_KC, VEC>(g); break;
+    case 7: launch_cfg<64, 64, 32, 2, 2, A_KC, B_KC, VEC>(g); break;
+    case 8: launch_cfg<64, 128, 32, 2, 2, A_KC, B_KC, VEC>(g); break;
+    case 9: launch_cfg<64, 64, 64, 2, 2, A_KC, B_KC, VEC>(g); break;
+    case 10: launch_cfg<128, 64, 32, 4, 2, A_KC, B_KC, VEC>(g); break;   // 8 waves
+    case 11: launch_cfg<128, 128, 32, 2, 4, A_KC, B_KC, VEC>(g); break;  // 8 waves
+    case 12: launch_cfg<64, 128, 32, 2, 4, A_KC, B_KC, VEC>(g); break;   // 8 waves
+    default: launch_cfg<128, 128, 16, 2, 2, A_KC, B_KC, VEC>(g); break;
   }
+}
+
+template <bool A_KC, bool B_KC>
+void launch_aligned(GemmArgs &g) {
+  // vector path: 16-byte aligned operands whose contiguous extent is a multiple of 4 floats
+  const int a_ext = A_KC ? g.K : g.M, b_ext = B_KC ? g.K : g.N;
+  const bool vec = g.a_vec && g.b_vec && a_ext % 4 == 0 && b_ext % 4 == 0 && a_ext >= 4 && b_ext >= 4;
+  if (vec) launch_variant<A_KC, B_KC, true>(g);
+  else launch_variant<A_KC, B_KC, false>(g);
 }
 
 }  // namespace
@@ -326,10 +425,10 @@ int aslp_sgemm_ex(int transA, int transB, int M, int N, int K, float alpha, cons
     (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, cur_stream());
   }
-  if (!transA && transB) launch_variant<true, true>(g);
-  else if (!transA && !transB) launch_variant<true, false>(g);
-  else if (transA && !transB) launch_variant<false, false>(g);
-  else launch_variant<false, true>(g);
+  if (!transA && transB) launch_aligned<true, true>(g);
+  else if (!transA && !transB) launch_aligned<true, false>(g);
+  else if (transA && !transB) launch_aligned<false, false>(g);
+  else launch_aligned<false, true>(g);
   check_launch("aslp_sgemm");
   {
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -348,6 +447,7 @@ int aslp_sgemm(int transA, int transB, int M, int N, int K, float alpha, const f
   return aslp_sgemm_ex(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, nullptr);
 }
 
+void aslp_gemm_force_tile(int cfg) { g_force_tile = cfg; }
 void aslp_gemm_profile(int enable) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   g_prof_on = enable != 0;
