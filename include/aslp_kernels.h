@@ -87,6 +87,9 @@ void cudaF_vec_sum(int Gr, int Bl, float *v, float *value, int dim, int inc);   
  * builds these from cuBLAS gemv with a ones-vector, cu-vector.cc:1145-1166). */
 /* v[c] = alpha * sum_r M[r][c] + beta * v[c]      (CuVectorBase::AddRowSumMat) */
 void aslp_add_row_sum_mat_vec(float alpha, const float *M, MatrixDim d, float beta, float *v);
+/* the same with the SGD step fused into the finalize pass: v = alpha*colsum + beta*v; w += w_alpha * v
+ * (bias_corr_ / bias_ of AffineTransform::Update, nnet-affine-transform.h:211,229) */
+void aslp_add_row_sum_mat_vec_sgd(float alpha, const float *M, MatrixDim d, float beta, float *v, float *w, float w_alpha);
 /* v[r] = alpha * sum_c M[r][c] + beta * v[r]      (CuVectorBase::AddColSumMat) */
 void aslp_add_col_sum_mat_vec(float alpha, const float *M, MatrixDim d, float beta, float *v);
 /* whole-row argmax, first strict maximum (CuMatrixBase::FindRowMaxId, cu-matrix.cc:1466) */
@@ -95,6 +98,7 @@ void aslp_find_row_max_id(const float *M, MatrixDim d, int32_cuda *id);
 void aslp_matrix_sum(const float *M, MatrixDim d, double *out_dev);
 void aslp_copy_mat(float *dst, MatrixDim d, const float *src, int src_stride);
 void aslp_vec_axpy(float alpha, const float *x, float *y, int dim);           /* y += alpha x */
+void aslp_vec_axpy2(float alpha, const float *x1, float *y1, const float *x2, float *y2, int dim); /* two at once */
 void aslp_f2d(double *dst, const float *src, int n);
 void aslp_d2f(float *dst, const double *src, int n);
 

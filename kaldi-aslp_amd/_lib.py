@@ -95,6 +95,8 @@ _sig("cudaF_add_vec_vec", None, _i, _i, _f, _vp, _vp, _vp, _f, _i)
 _sig("cudaF_vec_sum", None, _i, _i, _vp, _vp, _i, _i)
 _sig("aslp_add_row_sum_mat_vec", None, _f, _vp, _md, _f, _vp)
 _sig("aslp_add_col_sum_mat_vec", None, _f, _vp, _md, _f, _vp)
+_sig("aslp_add_row_sum_mat_vec_sgd", None, _f, _vp, _md, _f, _vp, _vp, _f)
+_sig("aslp_vec_axpy2", None, _f, _vp, _vp, _vp, _vp, _i)
 _sig("aslp_find_row_max_id", None, _vp, _md, _vp)
 _sig("aslp_matrix_sum", None, _vp, _md, _vp)
 _sig("aslp_copy_mat", None, _vp, _md, _vp, _i)

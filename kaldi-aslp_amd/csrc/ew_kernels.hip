@@ -262,6 +262,12 @@ __global__ void add_vec_vec_kernel(float alpha, float *v, const float *x, const 
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < dim; i += gridDim.x * blockDim.x)
     v[i] = alpha * x[i] * y[i] + beta * v[i];
 }
+__global__ void axpy2_kernel(float alpha, const float *x1, float *y1, const float *x2, float *y2, int dim) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < dim; i += gridDim.x * blockDim.x) {
+    y1[i] += alpha * x1[i];
+    y2[i] += alpha * x2[i];
+  }
+}
 __global__ void axpy_kernel(float alpha, const float *x, float *y, int dim) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < dim; i += gridDim.x * blockDim.x) y[i] += alpha * x[i];
 }
@@ -403,6 +409,11 @@ void cudaF_add_vec_vec(int, int, float alpha, float *v, const float *x, const fl
   if (dim <= 0) return;
   hipLaunchKernelGGL(add_vec_vec_kernel, dim3(grid_for(dim)), dim3(kBlock), 0, cur_stream(), alpha, v, x, y, beta, dim);
   check_launch("add_vec_vec");
+}
+void aslp_vec_axpy2(float alpha, const float *x1, float *y1, const float *x2, float *y2, int dim) {
+  if (dim <= 0) return;
+  hipLaunchKernelGGL(axpy2_kernel, dim3(grid_for(dim)), dim3(kBlock), 0, cur_stream(), alpha, x1, y1, x2, y2, dim);
+  check_launch("axpy2");
 }
 void aslp_vec_axpy(float alpha, const float *x, float *y, int dim) {
   if (dim <= 0) return;

@@ -15,11 +15,17 @@ namespace {
 // pass 1: sum x (float, for the mean like the reference's fp32 gemv) and, for the running
 // statistics, sum x and sum fl(x*x) in double (nnet-batch-normalization.h:216-220).
 struct BnSum1F {
+  static constexpr bool kVec = true;
   const float *in; int ld;
-  __device__ void operator()(int r, int c, double (&acc)[2]) const {
-    float x = in[(long)r * ld + c];
-    acc[0] += (double)x;
-    acc[1] += (double)(x * x);
+  template <int VW>
+  __device__ void operator()(int r, int c, double (&acc)[2][VW]) const {
+    float x[VW];
+    loadv<VW>(in + (long)r * ld + c, x);
+#pragma unroll
+    for (int i = 0; i < VW; i++) {
+      acc[0][i] += (double)x[i];
+      acc[1][i] += (double)(x[i] * x[i]);
+    }
   }
 };
 struct BnSum1G {
@@ -34,10 +40,18 @@ struct BnSum1G {
 };
 // pass 2: sum (x - mean)^2 -> inv_std = 1/sqrt(var + floor)  (:193-204)
 struct BnSum2F {
+  static constexpr bool kVec = true;
   const float *in; int ld; const float *mean;
-  __device__ void operator()(int r, int c, float (&acc)[1]) const {
-    float d = in[(long)r * ld + c] - mean[c];
-    acc[0] += d * d;
+  template <int VW>
+  __device__ void operator()(int r, int c, float (&acc)[1][VW]) const {
+    float x[VW], m[VW];
+    loadv<VW>(in + (long)r * ld + c, x);
+    loadv<VW>(mean + c, m);
+#pragma unroll
+    for (int i = 0; i < VW; i++) {
+      float d = x[i] - m[i];
+      acc[0][i] += d * d;
+    }
   }
 };
 struct BnSum2G {
@@ -76,11 +90,18 @@ __global__ void __launch_bounds__(kBlock) bn_normalize_kernel(const float *in, i
 
 // backward statistics: S1 = sum dy, S2 = sum xhat*dy
 struct BnBwdF {
+  static constexpr bool kVec = true;
   const float *dy; int ldd; const float *xhat; int ldx;
-  __device__ void operator()(int r, int c, float (&acc)[2]) const {
-    float d = dy[(long)r * ldd + c];
-    acc[0] += d;
-    acc[1] += xhat[(long)r * ldx + c] * d;
+  template <int VW>
+  __device__ void operator()(int r, int c, float (&acc)[2][VW]) const {
+    float d[VW], h[VW];
+    loadv<VW>(dy + (long)r * ldd + c, d);
+    loadv<VW>(xhat + (long)r * ldx + c, h);
+#pragma unroll
+    for (int i = 0; i < VW; i++) {
+      acc[0][i] += d[i];
+      acc[1][i] += h[i] * d[i];
+    }
   }
 };
 struct BnBwdG {
@@ -252,8 +273,10 @@ void aslp_bn_forward(const float *in, MatrixDim d, float *out, int out_stride, f
                      const float *shift, float *mean, float *inv_std, double *acc_means, double *acc_vars, float var_floor) {
   if (d.rows <= 0 || d.cols <= 0) return;
   const float invB = 1.0f / (float)d.rows;
-  colreduce<2, double>("bn_forward.sum", d.rows, d.cols, BnSum1F{in, d.stride}, BnSum1G{invB, mean, acc_means, acc_vars});
-  colreduce<1, float>("bn_forward.var", d.rows, d.cols, BnSum2F{in, d.stride, mean}, BnSum2G{invB, var_floor, inv_std}, kScratchReduce2);
+  const bool in_vec = aligned16(in) && d.stride % 4 == 0;
+  colreduce<2, double>("bn_forward.sum", d.rows, d.cols, BnSum1F{in, d.stride}, BnSum1G{invB, mean, acc_means, acc_vars}, in_vec);
+  colreduce<1, float>("bn_forward.var", d.rows, d.cols, BnSum2F{in, d.stride, mean}, BnSum2G{invB, var_floor, inv_std},
+                      in_vec && aligned16(mean), kScratchReduce2);
   bool vec = d.cols % 4 == 0 && d.stride % 4 == 0 && out_stride % 4 == 0 && (!xhat || xhat_stride % 4 == 0) && aligned16(in) &&
              aligned16(out) && (!xhat || aligned16(xhat)) && aligned16(mean) && aligned16(inv_std) && aligned16(scale) && aligned16(shift);
   long n = (long)d.rows * (vec ? d.cols / 4 : d.cols);
@@ -276,7 +299,8 @@ void aslp_bn_backward(const float *in, MatrixDim d, const float *out_diff, int o
   float *s12 = static_cast<float *>(scratch(kScratchReduce2, sizeof(float) * 2 * (size_t)d.cols));
   if (!s12) return;
   colreduce<2, float>("bn_backward.stats", d.rows, d.cols, BnBwdF{out_diff, od_stride, xhat, xhat_stride},
-                      BnBwdG{momentum, dscale, dshift, s12, s12 + d.cols});
+                      BnBwdG{momentum, dscale, dshift, s12, s12 + d.cols},
+                      aligned16(out_diff) && od_stride % 4 == 0 && aligned16(xhat) && xhat_stride % 4 == 0);
   if (!in_diff) return;
   long n = (long)d.rows * d.cols;
   bool vec = d.cols % 4 == 0 && od_stride % 4 == 0 && xhat_stride % 4 == 0 && id_stride % 4 == 0 && aligned16(out_diff) &&

@@ -218,18 +218,32 @@ __global__ void __launch_bounds__(256) vec_sum_kernel(const float *v, float *val
 
 // ---- column reductions -----------------------------------------------------------------
 struct ColSumF {
+  static constexpr bool kVec = true;
   const float *M; int ld;
-  __device__ void operator()(int r, int c, float (&acc)[1]) const { acc[0] += M[(long)r * ld + c]; }
+  template <int VW>
+  __device__ void operator()(int r, int c, float (&acc)[1][VW]) const {
+    float v[VW];
+    loadv<VW>(M + (long)r * ld + c, v);
+#pragma unroll
+    for (int i = 0; i < VW; i++) acc[0][i] += v[i];
+  }
 };
 struct ColSumG {
   float alpha, beta; float *v;
-  __device__ void operator()(int c, const float (&s)[1]) const { v[c] = beta == 0.0f ? alpha * s[0] : alpha * s[0] + beta * v[c]; }
+  float *w; float w_alpha;   // optional fused SGD step on a parameter vector: w += w_alpha * v_new
+  __device__ void operator()(int c, const float (&s)[1]) const {
+    float nv = beta == 0.0f ? alpha * s[0] : alpha * s[0] + beta * v[c];
+    v[c] = nv;
+    if (w) w[c] += w_alpha * nv;
+  }
 };
-// v[c] = alpha * sum_r M'[c][r] * N'[r][c] + beta v[c] with generic strides
+// v[c] = alpha * sum_j M'[c][j] * N'[j][c] + beta v[c] with generic strides
 struct DiagMMF {
+  static constexpr bool kVec = false;
   const float *M; long m_rs, m_cs; const float *N; long n_rs, n_cs;
   // here "r" runs over the summed dimension j, "c" over v's index
-  __device__ void operator()(int j, int c, float (&acc)[1]) const { acc[0] += M[c * m_rs + j * m_cs] * N[j * n_rs + c * n_cs]; }
+  template <int VW>
+  __device__ void operator()(int j, int c, float (&acc)[1][VW]) const { acc[0][0] += M[c * m_rs + j * m_cs] * N[j * n_rs + c * n_cs]; }
 };
 
 // ASLP _add_row_sum_mat (cu-kernels.cu:754-770): dst[j][c] = alpha * sum_{k<P} src[j*P+k][c] + beta*dst[j][c]
@@ -322,7 +336,12 @@ void cudaF_diff_xent(aslp_dim3, aslp_dim3, const int32_cuda *vec_tgt, float *mat
 }
 
 void aslp_add_row_sum_mat_vec(float alpha, const float *M, MatrixDim d, float beta, float *v) {
-  colreduce<1, float>("add_row_sum_mat_vec", d.rows, d.cols, ColSumF{M, d.stride}, ColSumG{alpha, beta, v});
+  colreduce<1, float>("add_row_sum_mat_vec", d.rows, d.cols, ColSumF{M, d.stride}, ColSumG{alpha, beta, v, nullptr, 0.0f},
+                      aligned16(M) && d.stride % 4 == 0);
+}
+void aslp_add_row_sum_mat_vec_sgd(float alpha, const float *M, MatrixDim d, float beta, float *v, float *w, float w_alpha) {
+  colreduce<1, float>("add_row_sum_mat_vec_sgd", d.rows, d.cols, ColSumF{M, d.stride}, ColSumG{alpha, beta, v, w, w_alpha},
+                      aligned16(M) && d.stride % 4 == 0);
 }
 void aslp_add_col_sum_mat_vec(float alpha, const float *M, MatrixDim d, float beta, float *v) {
   if (d.rows <= 0) return;
@@ -351,7 +370,7 @@ void cudaF_add_diag_mat_mat(int, int, float alpha, float *v, int v_dim, const fl
                             const float *N, int N_row_stride, int N_col_stride, int, float beta) {
   // v[i] = alpha * sum_j M[i*rs + j*cs] * N[j*rs' + i*cs'] + beta*v[i]; the summed index j plays "rows"
   colreduce<1, float>("add_diag_mat_mat", M_cols, v_dim, DiagMMF{M, M_row_stride, M_col_stride, N, N_row_stride, N_col_stride},
-                      ColSumG{alpha, beta, v});
+                      ColSumG{alpha, beta, v, nullptr, 0.0f});
 }
 void cudaF_add_row_sum_mat(aslp_dim3, aslp_dim3, float *data, const float *src, MatrixDim dim, int src_stride, int patch_nrows, float alpha, float beta) {
   if (dim.rows <= 0 || dim.cols <= 0) return;

@@ -17,6 +17,7 @@ class InputLayer : public Component {
   InputLayer(int32 di, int32 dout) : Component(di, dout) { ASLP_ASSERT(di == dout); }
   Component *Copy() const { return new InputLayer(*this); }
   ComponentType GetType() const { return kInputLayer; }
+  bool BackpropIsCopy() const { return true; }
   void PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) { out->CopyFromMat(in); }
   void BackpropagateFnc(const CuMatrixBase &, const CuMatrixBase &, const CuMatrixBase &od, CuMatrixBase *id) { id->CopyFromMat(od); }
 };
@@ -25,6 +26,8 @@ class OutputLayer : public Component {
   OutputLayer(int32 di, int32 dout) : Component(di, dout) { ASLP_ASSERT(di == dout); }
   Component *Copy() const { return new OutputLayer(*this); }
   ComponentType GetType() const { return kOutputLayer; }
+  bool PropagateIsCopy() const { return true; }
+  bool BackpropIsCopy() const { return true; }
   void PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) { out->CopyFromMat(in); }
   void BackpropagateFnc(const CuMatrixBase &, const CuMatrixBase &, const CuMatrixBase &od, CuMatrixBase *id) { id->CopyFromMat(od); }
 };
@@ -146,13 +149,13 @@ class AffineTransform : public UpdatableComponent {
     aslp_gemm_epilogue ep = aslp_gemm_epilogue();
     if (plain) { ep.W = linearity_.Data(); ep.ldw = linearity_.Stride(); ep.w_alpha = -lr; }
     linearity_corr_.AddMatMat(1.0, diff, kTrans, input, kNoTrans, mmt, &ep);
-    bias_corr_.AddRowSumMat(1.0, diff, mmt);
+    // bias_corr_ = colsum(diff) + mmt * bias_corr_ with the step bias_ += -lr_bias * bias_corr_ fused
+    aslp_add_row_sum_mat_vec_sgd(1.0f, diff.Data(), diff.Dim(), mmt, bias_corr_.Data(), bias_.Data(), -lr_bias);
     if (!plain) {
       if (l2 != 0.0) linearity_.AddMat(-lr * l2 * num_frames, linearity_);
       if (l1 != 0.0) cu::RegularizeL1(&linearity_, &linearity_corr_, lr * l1 * num_frames, lr);
       linearity_.AddMat(-lr, linearity_corr_);
     }
-    bias_.AddVec(-lr_bias, bias_corr_);
     if (max_norm_ > 0.0) { aslp_max_norm_rows(linearity_.Data(), linearity_.Dim(), max_norm_); }  // :231-243
   }
   const CuVectorBase &GetBias() const { return bias_; }
@@ -176,6 +179,7 @@ class Softmax : public Component {
   Softmax(int32 di, int32 dout) : Component(di, dout) {}
   Component *Copy() const { return new Softmax(*this); }
   ComponentType GetType() const { return kSoftmax; }
+  bool BackpropIsCopy() const { return true; }  // :51-59
   void PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) { out->ApplySoftMaxPerRow(in); }
   // :51-59 backward is a plain copy: out_diff already is (y - t)
   void BackpropagateFnc(const CuMatrixBase &, const CuMatrixBase &, const CuMatrixBase &od, CuMatrixBase *id) { id->CopyFromMat(od); }
@@ -542,8 +546,7 @@ class BatchNormalization : public UpdatableComponent {
   }
   void Update(const CuMatrixBase &, const CuMatrixBase &) {  // :280-284
     const BaseFloat lr = opts_.learn_rate;
-    scale_.AddVec(-lr, dscale_, 1.0);
-    shift_.AddVec(-lr, dshift_, 1.0);
+    aslp_vec_axpy2(-lr, dscale_.Data(), scale_.Data(), dshift_.Data(), shift_.Data(), scale_.Dim());
   }
   CuVector &Scale() { return scale_; }
   CuVector &Shift() { return shift_; }

@@ -116,6 +116,9 @@ class Component {
   // True if BackpropagateFnc writes every element of in_diff (so the wrapper need not zero it
   // first; the reference always zeroes, nnet-component.h:335).  All components here do.
   virtual bool BackpropOverwritesInDiff() const { return true; }
+  // Pure-copy layers: the executor may pass the buffer through instead of copying it.
+  virtual bool PropagateIsCopy() const { return false; }
+  virtual bool BackpropIsCopy() const { return false; }
 
  protected:
   virtual void FeedforwardFnc(const CuMatrixBase &in, CuMatrixBase *out) { PropagateFnc(in, out); }

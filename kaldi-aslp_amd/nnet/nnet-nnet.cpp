@@ -52,22 +52,27 @@ void Nnet::Propagate(const std::vector<const CuMatrixBase *> &in, std::vector<Cu
       const std::vector<int32> &offset = components_[i]->GetOffset();
       ASLP_ASSERT(input_idx.size() == offset.size());
       if (alias_links_ && IsDirectLink(i)) {
-        in_view_[i] = &output_buf_[input_idx[0]];
+        in_view_[i] = out_view_[input_idx[0]];
       } else {  // :86-95 zeroed buffer, links added in (this is how branch splice / sum works)
         input_buf_[i].Resize(num_frame, components_[i]->InputDim(), kSetZero);
         for (size_t j = 0; j < input_idx.size(); j++) {
           int out_len = components_[input_idx[j]]->OutputDim();
-          input_buf_[i].ColRange(offset[j], out_len).AddMat(1.0, output_buf_[input_idx[j]]);
+          input_buf_[i].ColRange(offset[j], out_len).AddMat(1.0, *out_view_[input_idx[j]]);
         }
         in_view_[i] = &input_buf_[i];
       }
     }
     Timer tim1;
-    components_[i]->Propagate(*in_view_[i], &output_buf_[i]);
+    if (alias_links_ && components_[i]->PropagateIsCopy() && components_[i]->GetType() != Component::kInputLayer) {
+      out_view_[i] = in_view_[i];  // pure copy layer: pass the buffer through
+    } else {
+      components_[i]->Propagate(*in_view_[i], &output_buf_[i]);
+      out_view_[i] = &output_buf_[i];
+    }
     propagate_time_[i].first = Component::TypeToMarker(components_[i]->GetType());
     propagate_time_[i].second += tim1.Elapsed();
   }
-  for (size_t i = 0; i < output_.size(); i++) *((*out)[i]) = output_buf_[output_[i]];
+  for (size_t i = 0; i < output_.size(); i++) *((*out)[i]) = *out_view_[output_[i]];
   // the caller's input may go away: Update() of the consumers reads InputLayer's OUTPUT copy
   for (size_t i = 0; i < input_.size(); i++) in_view_[input_[i]] = &output_buf_[input_[i]];
 }
@@ -89,6 +94,7 @@ void Nnet::Backpropagate(const std::vector<const CuMatrixBase *> &out_diff, std:
     if (!fed_direct) output_diff_buf_[i].Resize(num_frame, components_[i]->OutputDim(), kSetZero);
   }
   for (size_t i = 0; i < output_.size(); i++) output_diff_buf_[output_[i]].CopyFromMat(*(out_diff[i]));
+  for (int32 i = 0; i < N; i++) out_diff_view_[i] = &output_diff_buf_[i];
   const bool want_in_diff = (in_diff != NULL);
   for (int32 i = N - 1; i >= 0; i--) {
     Timer tim2;
@@ -103,7 +109,13 @@ void Nnet::Backpropagate(const std::vector<const CuMatrixBase *> &out_diff, std:
     CuMatrix *target = &input_diff_buf_[i];
     if (!is_input && direct[i]) target = &output_diff_buf_[components_[i]->GetInput()[0]];
     if (!skip_backprop) {
-      components_[i]->Backpropagate(*in_view_[i], output_buf_[i], output_diff_buf_[i], target);
+      if (!is_input && direct[i] && components_[i]->BackpropIsCopy()) {
+        // identity backward into the only consumer slot: hand the buffer over instead of copying
+        target->Swap(&output_diff_buf_[i]);
+        out_diff_view_[i] = target;
+      } else {
+        components_[i]->Backpropagate(*in_view_[i], *out_view_[i], output_diff_buf_[i], target);
+      }
       in_diff_view_[i] = target;
     }
     if (components_[i]->IsUpdatable()) {
@@ -137,19 +149,24 @@ void Nnet::Feedforward(const std::vector<const CuMatrixBase *> &in, std::vector<
       const std::vector<int32> &input_idx = components_[i]->GetInput();
       const std::vector<int32> &offset = components_[i]->GetOffset();
       if (alias_links_ && IsDirectLink(i)) {
-        in_view_[i] = &output_buf_[input_idx[0]];
+        in_view_[i] = out_view_[input_idx[0]];
       } else {
         input_buf_[i].Resize(num_frame, components_[i]->InputDim(), kSetZero);
         for (size_t j = 0; j < input_idx.size(); j++) {
           int out_len = components_[input_idx[j]]->OutputDim();
-          input_buf_[i].ColRange(offset[j], out_len).AddMat(1.0, output_buf_[input_idx[j]]);
+          input_buf_[i].ColRange(offset[j], out_len).AddMat(1.0, *out_view_[input_idx[j]]);
         }
         in_view_[i] = &input_buf_[i];
       }
     }
-    components_[i]->Feedforward(*in_view_[i], &output_buf_[i]);
+    if (alias_links_ && components_[i]->PropagateIsCopy() && components_[i]->GetType() != Component::kInputLayer) {
+      out_view_[i] = in_view_[i];
+    } else {
+      components_[i]->Feedforward(*in_view_[i], &output_buf_[i]);
+      out_view_[i] = &output_buf_[i];
+    }
   }
-  for (size_t i = 0; i < output_.size(); i++) *((*out)[i]) = output_buf_[output_[i]];
+  for (size_t i = 0; i < output_.size(); i++) *((*out)[i]) = *out_view_[output_[i]];
   for (size_t i = 0; i < input_.size(); i++) in_view_[input_[i]] = &output_buf_[input_[i]];
 }
 
@@ -447,7 +464,7 @@ std::string Nnet::InfoPropagate() const {
   ostr << "### Forward propagation buffer content :\n";
   ostr << "[0] output of <Input> " << MomentStatistics(*in_view_[0]) << std::endl;
   for (int32 i = 0; i < NumComponents(); i++)
-    ostr << "[" << 1 + i << "] output of " << Component::TypeToMarker(components_[i]->GetType()) << MomentStatistics(output_buf_[i]) << std::endl;
+    ostr << "[" << 1 + i << "] output of " << Component::TypeToMarker(components_[i]->GetType()) << MomentStatistics(*out_view_[i]) << std::endl;
   return ostr.str();
 }
 std::string Nnet::InfoBackPropagate() const {
@@ -455,7 +472,7 @@ std::string Nnet::InfoBackPropagate() const {
   ostr << "### Backward propagation buffer content :\n";
   ostr << "[0] diff of <Input> " << MomentStatistics(output_diff_buf_[0]) << std::endl;
   for (int32 i = 0; i < NumComponents(); i++)
-    ostr << "[" << 1 + i << "] diff-output of " << Component::TypeToMarker(components_[i]->GetType()) << MomentStatistics(output_diff_buf_[i]) << std::endl;
+    ostr << "[" << 1 + i << "] diff-output of " << Component::TypeToMarker(components_[i]->GetType()) << MomentStatistics(*out_diff_view_[i]) << std::endl;
   return ostr.str();
 }
 
@@ -498,6 +515,8 @@ void Nnet::Destroy() {  // :822-832
   output_diff_buf_.resize(0);
   in_view_.resize(0);
   in_diff_view_.resize(0);
+  out_view_.resize(0);
+  out_diff_view_.resize(0);
 }
 
 void Nnet::SetTrainOptions(const NnetTrainOptions &opts) {
@@ -520,6 +539,9 @@ void Nnet::InitInputOutput() {  // :845-870
   output_diff_buf_.resize(NumComponents());
   in_view_.assign(NumComponents(), NULL);
   in_diff_view_.assign(NumComponents(), NULL);
+  out_view_.assign(NumComponents(), NULL);
+  out_diff_view_.assign(NumComponents(), NULL);
+  for (int i = 0; i < NumComponents(); i++) { out_view_[i] = &output_buf_[i]; out_diff_view_[i] = &output_diff_buf_[i]; }
   num_consumers_.assign(NumComponents(), 0);
   for (int i = 0; i < NumComponents(); i++) {
     if (components_[i] == NULL || components_[i]->GetType() == Component::kInputLayer) continue;

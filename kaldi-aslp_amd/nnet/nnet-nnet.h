@@ -39,8 +39,8 @@ class Nnet {
   void RemoveLastComponent() { RemoveComponent(NumComponents() - 1); }
 
   // per-component forward outputs / backward output-diffs (reference: PropagateBuffer())
-  const CuMatrixBase &OutputBuffer(int32 c) const { return output_buf_[c]; }
-  const CuMatrixBase &OutputDiffBuffer(int32 c) const { return output_diff_buf_[c]; }
+  const CuMatrixBase &OutputBuffer(int32 c) const { return *out_view_[c]; }
+  const CuMatrixBase &OutputDiffBuffer(int32 c) const { return *out_diff_view_[c]; }
   const CuMatrixBase &InputDiffBuffer(int32 c) const;
 
   int32 NumParams() const;
@@ -93,6 +93,8 @@ class Nnet {
   std::vector<CuMatrix> input_buf_, output_buf_, input_diff_buf_, output_diff_buf_;
   std::vector<const CuMatrixBase *> in_view_;       // what component i actually reads as input
   std::vector<const CuMatrixBase *> in_diff_view_;  // where component i's in-diff went
+  std::vector<const CuMatrixBase *> out_view_;      // component i's forward output (own buffer, or its input for copy layers)
+  std::vector<const CuMatrixBase *> out_diff_view_; // component i's out-diff (may have been handed on to the producer)
   NnetTrainOptions opts_;
   bool alias_links_ = true;
 };
