@@ -121,6 +121,13 @@ _sig("aslp_diff_relu", None, _vp, _vp, _vp, _md, _i, _i)
 _sig("aslp_max_norm_rows", None, _vp, _md, _f)
 
 
+# CTC (B5, include/aslp_ctc.h)
+_sig("compute_ctc_loss", _i, _vp, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), _i, _i, C.POINTER(C.c_float), _vp, CtcComputeInfo)
+_sig("get_workspace_size", _i, C.POINTER(C.c_int), C.POINTER(C.c_int), _i, _i, CtcComputeInfo, C.POINTER(C.c_size_t))
+_sig("ctcGetStatusString", C.c_char_p, _i)
+_sig("get_warpctc_version", _i)
+
+
 def check_error():
     """Raise if any launch since the last call failed (the reference throws via KALDI_ERR)."""
     buf = C.create_string_buffer(1024)

@@ -5,7 +5,7 @@ import ctypes as C
 
 import torch
 
-from ._lib import lib, MatrixDim, Dim3, GemmEpilogue, D3, check_error
+from ._lib import lib, MatrixDim, Dim3, GemmEpilogue, CtcComputeInfo, D3, check_error
 
 
 def _chk(t, dtype=torch.float32):
@@ -110,3 +110,29 @@ def xent_eval(net_out, frame_weights, diff, stats, targets=None, labels=None):
                        ptr(labels), ptr(_chk(frame_weights)), ptr(_chk(diff)), dim(diff).stride,
                        ptr(_chk(stats, torch.float64)))
     check_error()
+
+
+def ctc_loss(acts, labels, input_lengths, want_grad=True):
+    """compute_ctc_loss (warp-ctc/include/ctc.h:88-97) on device activations [(maxT*mb) x A] laid out (t, n, p).
+    labels: list of int lists; returns (costs numpy[mb], grads tensor or None)."""
+    import numpy as np
+    _chk(acts)
+    mb = len(labels)
+    A = acts.shape[-1]
+    flat = [int(v) for l in labels for v in l] or [0]
+    flat_c = (C.c_int * len(flat))(*flat)
+    lab_len = (C.c_int * mb)(*[len(l) for l in labels])
+    in_len = (C.c_int * mb)(*[int(t) for t in input_lengths])
+    info = CtcComputeInfo(1, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    sz = C.c_size_t()
+    st = lib.get_workspace_size(lab_len, in_len, A, mb, info, C.byref(sz))
+    if st != 0:
+        raise RuntimeError("get_workspace_size: " + lib.ctcGetStatusString(st).decode())
+    ws = torch.empty(sz.value, dtype=torch.uint8, device=acts.device)
+    grads = torch.zeros_like(acts) if want_grad else None
+    costs = (C.c_float * mb)()
+    st = lib.compute_ctc_loss(ptr(acts), ptr(grads), flat_c, lab_len, in_len, A, mb, costs, ptr(ws), info)
+    if st != 0:
+        raise RuntimeError("compute_ctc_loss: " + lib.ctcGetStatusString(st).decode())
+    check_error()
+    return np.array(list(costs), np.float32), grads

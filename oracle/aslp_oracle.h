@@ -130,6 +130,16 @@ float *orc_dnn_bn_scale(orc_dnn *d, int layer);
 float *orc_dnn_bn_shift(orc_dnn *d, int layer);
 const float *orc_dnn_output(const orc_dnn *d);             /* softmax output [mb x out] */
 
+/* ---- Warp-CTC (src/warp-ctc/include/detail/cpu_ctc.h) + the WarpCtc wrapper (aslp-nnet/warp-ctc.cc) */
+int orc_ctc_cost_and_grad(const float *acts, float *grads, const int *flat_labels, const int *label_lengths,
+                          const int *input_lengths, int alphabet_size, int minibatch, float *costs);
+typedef struct {   /* members of WarpCtc, warp-ctc.h:96-113 */
+  double loss_sum, loss_square_sum, loss_sum_bak, loss_square_sum_bak, obj;
+  int normal_num, stat_period /* 500 */, frames, sequences;
+} orc_ctc_filter_state;
+void orc_ctc_loss_filter(const float *costs, const int *frame_num, int mb, orc_ctc_filter_state *st, int *keep);
+int orc_ctc_token_errors(const float *net_out, int ld, int T, int A, const int *ref, int ref_len, int *hyp_len);
+
 #ifdef __cplusplus
 }
 #endif
