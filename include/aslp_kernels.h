@@ -161,6 +161,23 @@ void aslp_scatter_add(float *mat, MatrixDim d, const int32_cuda *rows, const int
 void aslp_splice_backward(float *in_diff, MatrixDim d_in, const float *out_diff, int od_stride, const int32_cuda *off, int n_off);
 /* ReLU backward: in_diff = heaviside(in) * out_diff (nnet-activation.h:292-297) */
 void aslp_diff_relu(float *in_diff, const float *in, const float *out_diff, MatrixDim d, int in_stride, int od_stride);
+/* ---- recurrent gate blocks, one launch per timestep (csrc/rnn_cells.hip) -------------------------
+ * Pointers are to the row block of the (T+2)*S x width activation / diff buffers (row = t*S + s),
+ * column 0; column layout [g|i|f|o|c|h|m|r] (cifg: [g|f|o|c|h|m|r]).
+ * forward (nnet-blstm-projected-streams-lc.h:571-609): y_cur's gate columns hold the pre-activations
+ *   (x-part + bias + recurrent part); writes g,i,f,o,c,h,m.  seq_lengths != NULL: rows with
+ *   t > seq_lengths[s] are zeroed (nnet-blstm-projected-streams.h:654-657).
+ * backward (:783-835): d_cur's m column holds dL/dm; writes d_g,d_i,d_f,d_o,d_c,d_h.  d_next / y_next:
+ *   the step processed just before in BPTT order; y_prev: the step the forward recursion read. */
+void aslp_lstm_cell_forward(float *y_cur, const float *y_prev, int ld, int S, int C, int cifg, const float *peep_i, const float *peep_f,
+                            const float *peep_o, const int32_cuda *seq_lengths, int t);
+void aslp_lstm_cell_backward(float *d_cur, const float *d_next, const float *y_cur, const float *y_next, const float *y_prev, int ld, int S,
+                             int C, int cifg, const float *peep_i, const float *peep_f, const float *peep_o);
+/* GruStreams (nnet-gru-streams.h:275-303, 344-383), columns [z|r|m|g|h] */
+void aslp_gru_forward1(float *y_cur, const float *y_prev, int ld, int S, int H);
+void aslp_gru_forward2(float *y_cur, const float *y_prev, int ld, int S, int H);
+void aslp_gru_backward1(float *d_cur, const float *d_next, const float *y_cur, const float *y_next, int ld, int S, int H);
+void aslp_gru_backward2(float *d_cur, const float *y_cur, const float *y_prev, int ld, int S, int H);
 /* max-norm row shrink (nnet-affine-transform.h:231-243) */
 void aslp_max_norm_rows(float *W, MatrixDim d, float max_norm);
 

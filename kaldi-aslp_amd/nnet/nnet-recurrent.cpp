@@ -1,0 +1,508 @@
+// nnet-recurrent.cpp -- LSTM family + GruStreams host logic (see nnet-recurrent.h).
+#include "nnet-recurrent.h"
+
+#include <sstream>
+
+namespace aslp {
+
+namespace {
+void CheckK() {
+  char buf[512];
+  if (aslp_get_last_error(buf, sizeof(buf))) ASLP_ERR << buf;
+}
+void ClipVec(CuVector *v, float clip) {
+  if (clip > 0.0 && v->Dim()) { v->ApplyFloor(-clip); v->ApplyCeiling(clip); }
+}
+std::pair<BaseFloat *, int> MatParam(CuMatrix &m) { return std::make_pair(m.Data(), m.NumRows() * m.Stride()); }
+std::pair<BaseFloat *, int> VecParam(CuVector &v) { return std::make_pair(v.Data(), v.Dim()); }
+}  // namespace
+
+// ---- one LSTM direction ---------------------------------------------------------------------------
+void LstmDir::AllocCorr() {
+  w_x_corr.Resize(GC(), D, kSetZero);
+  w_r_corr.Resize(GC(), Rec(), kSetZero);
+  bias_corr.Resize(GC(), kSetZero);
+  if (!cifg) peep_i_corr.Resize(C, kSetZero);
+  peep_f_corr.Resize(C, kSetZero);
+  peep_o_corr.Resize(C, kSetZero);
+  if (R > 0) w_rm_corr.Resize(R, C, kSetZero);
+}
+
+void LstmDir::InitRandom(float scale) {
+  // matrices first, then vectors (e.g. nnet-blstm-projected-streams-lc.h:117-150)
+  w_x.Resize(GC(), D, kUndefined);
+  w_r.Resize(GC(), Rec(), kUndefined);
+  InitMatParamUniform(w_x, scale);
+  InitMatParamUniform(w_r, scale);
+  if (R > 0) { w_rm.Resize(R, C, kUndefined); InitMatParamUniform(w_rm, scale); }
+  bias.Resize(GC(), kUndefined);
+  InitVecParamUniform(bias, scale);
+  if (!cifg) { peep_i.Resize(C, kUndefined); InitVecParamUniform(peep_i, scale); }
+  peep_f.Resize(C, kUndefined);
+  peep_o.Resize(C, kUndefined);
+  InitVecParamUniform(peep_f, scale);
+  InitVecParamUniform(peep_o, scale);
+  AllocCorr();
+}
+
+void LstmDir::Read(std::istream &is, bool binary) {
+  w_x.Read(is, binary);
+  w_r.Read(is, binary);
+  bias.Read(is, binary);
+  if (!cifg) peep_i.Read(is, binary);
+  peep_f.Read(is, binary);
+  peep_o.Read(is, binary);
+  if (R > 0) w_rm.Read(is, binary);
+  ASLP_ASSERT(w_x.NumRows() == GC() && w_x.NumCols() == D);
+  ASLP_ASSERT(w_r.NumRows() == GC() && w_r.NumCols() == Rec());
+  ASLP_ASSERT(bias.Dim() == GC());
+  ASLP_ASSERT(cifg || peep_i.Dim() == C);
+  ASLP_ASSERT(peep_f.Dim() == C && peep_o.Dim() == C);
+  if (R > 0) ASLP_ASSERT(w_rm.NumRows() == R && w_rm.NumCols() == C);
+  AllocCorr();
+}
+
+void LstmDir::Write(std::ostream &os, bool binary) const {
+  w_x.Write(os, binary);
+  w_r.Write(os, binary);
+  bias.Write(os, binary);
+  if (!cifg) peep_i.Write(os, binary);
+  peep_f.Write(os, binary);
+  peep_o.Write(os, binary);
+  if (R > 0) w_rm.Write(os, binary);
+}
+
+int LstmDir::NumParams() const { return GC() * D + GC() * Rec() + GC() + (cifg ? 2 : 3) * C + R * C; }
+
+void LstmDir::AppendParams(std::vector<BaseFloat> *w) const {
+  AppendRowMajor(w_x, w);
+  AppendRowMajor(w_r, w);
+  AppendVector(bias, w);
+  if (!cifg) AppendVector(peep_i, w);
+  AppendVector(peep_f, w);
+  AppendVector(peep_o, w);
+  if (R > 0) AppendRowMajor(w_rm, w);
+}
+
+void LstmDir::AppendGpuParams(std::vector<std::pair<BaseFloat *, int>> *p) {
+  p->push_back(MatParam(w_x));
+  p->push_back(MatParam(w_r));
+  p->push_back(VecParam(bias));
+  if (!cifg) p->push_back(VecParam(peep_i));
+  p->push_back(VecParam(peep_f));
+  p->push_back(VecParam(peep_o));
+  if (R > 0) p->push_back(MatParam(w_rm));
+}
+
+std::string LstmDir::Info(const char *pre) const {
+  std::string s;
+  s += std::string("\n  ") + pre + "w_x  " + MomentStatistics(w_x);
+  s += std::string("\n  ") + pre + "w_r  " + MomentStatistics(w_r);
+  s += std::string("\n  ") + pre + "bias  " + MomentStatistics(bias);
+  if (!cifg) s += std::string("\n  ") + pre + "peephole_i_c  " + MomentStatistics(peep_i);
+  s += std::string("\n  ") + pre + "peephole_f_c  " + MomentStatistics(peep_f);
+  s += std::string("\n  ") + pre + "peephole_o_c  " + MomentStatistics(peep_o);
+  if (R > 0) s += std::string("\n  ") + pre + "w_r_m  " + MomentStatistics(w_rm);
+  return s;
+}
+
+void LstmDir::Forward(const CuMatrixBase &in, int T, int S, bool reverse, const CuMatrixBase *init_state, const CuArray<int32> *seq_len,
+                      CuMatrix *buf) const {
+  ASLP_ASSERT(in.NumRows() == T * S && in.NumCols() == D);
+  buf->Resize((T + 2) * S, Width(), kSetZero);
+  if (init_state) buf->RowRange(reverse ? (T + 1) * S : 0, S).CopyFromMat(*init_state);
+  {  // x -> gates for every t in one GEMM, bias in its epilogue (lc.h:553-556)
+    aslp_gemm_epilogue ep = aslp_gemm_epilogue();
+    ep.bias = bias.Data();
+    CuSubMatrix gates(*buf, S, T * S, 0, GC());
+    gates.AddMatMat(1.0, in, kNoTrans, w_x, kTrans, 0.0, &ep);
+  }
+  const int ld = buf->Stride();
+  for (int step = 0; step < T; step++) {
+    const int t = reverse ? T - step : 1 + step, tp = reverse ? t + 1 : t - 1;
+    CuSubMatrix y_gates(*buf, t * S, S, 0, GC());
+    CuSubMatrix rec_prev(*buf, tp * S, S, OffRec(), Rec());
+    y_gates.AddMatMat(1.0, rec_prev, kNoTrans, w_r, kTrans, 1.0);  // r(t-1) -> gates (lc.h:575)
+    aslp_lstm_cell_forward(buf->RowData(t * S), buf->RowData(tp * S), ld, S, C, cifg ? 1 : 0, cifg ? nullptr : peep_i.Data(), peep_f.Data(),
+                           peep_o.Data(), seq_len ? seq_len->Data() : nullptr, t);
+    if (R > 0) {  // m -> r (lc.h:608); masked rows have m = 0, hence r = 0
+      CuSubMatrix y_r(*buf, t * S, S, OffRec(), R), y_m(*buf, t * S, S, OffM(), C);
+      y_r.AddMatMat(1.0, y_m, kNoTrans, w_rm, kTrans, 0.0);
+    }
+  }
+  CheckK();
+}
+
+void LstmDir::Backward(const CuMatrixBase &out_diff, int T, int S, bool reverse, const CuMatrix &buf, CuMatrix *dbuf, CuMatrixBase *in_diff,
+                       float beta) const {
+  ASLP_ASSERT(out_diff.NumRows() == T * S && out_diff.NumCols() == Rec());
+  dbuf->Resize((T + 2) * S, Width(), kSetZero);
+  CuSubMatrix(*dbuf, S, T * S, OffRec(), Rec()).CopyFromMat(out_diff);
+  const int ld = dbuf->Stride();
+  ASLP_ASSERT(ld == buf.Stride());
+  for (int step = 0; step < T; step++) {
+    const int t = reverse ? 1 + step : T - step;
+    const int tn = reverse ? t - 1 : t + 1, tp = reverse ? t + 1 : t - 1;
+    if (step > 0) {  // d_rec(t) += dGATES(next) * w_r (lc.h:791); at the first step the next block is all zero
+      CuSubMatrix d_rec(*dbuf, t * S, S, OffRec(), Rec()), dn_gates(*dbuf, tn * S, S, 0, GC());
+      d_rec.AddMatMat(1.0, dn_gates, kNoTrans, w_r, kNoTrans, 1.0);
+    }
+    if (R > 0) {  // d_m = d_r * w_r_m (lc.h:793)
+      CuSubMatrix d_m(*dbuf, t * S, S, OffM(), C), d_r(*dbuf, t * S, S, OffRec(), R);
+      d_m.AddMatMat(1.0, d_r, kNoTrans, w_rm, kNoTrans, 0.0);
+    }
+    aslp_lstm_cell_backward(dbuf->RowData(t * S), dbuf->RowData(tn * S), buf.RowData(t * S), buf.RowData(tn * S), buf.RowData(tp * S), ld, S, C,
+                            cifg ? 1 : 0, cifg ? nullptr : peep_i.Data(), peep_f.Data(), peep_o.Data());
+  }
+  CheckK();
+  if (in_diff) {
+    CuSubMatrix d_gates(*dbuf, S, T * S, 0, GC());
+    in_diff->AddMatMat(1.0, d_gates, kNoTrans, w_x, kNoTrans, beta);
+  }
+}
+
+void LstmDir::Grads(const CuMatrixBase &in, int T, int S, bool reverse, const CuMatrix &buf, const CuMatrix &dbuf, float mmt, float clip) {
+  // lc.h:976-1058: corr = grad + mmt * corr, then clip element-wise (the clip rides in the GEMM epilogue)
+  aslp_gemm_epilogue ep = aslp_gemm_epilogue();
+  ep.clip = clip;
+  const int prev0 = (reverse ? 2 : 0) * S;  // recursion-previous row block of t = 1
+  CuSubMatrix d_gates(dbuf, S, T * S, 0, GC());
+  w_x_corr.AddMatMat(1.0, d_gates, kTrans, in, kNoTrans, mmt, &ep);
+  w_r_corr.AddMatMat(1.0, d_gates, kTrans, CuSubMatrix(buf, prev0, T * S, OffRec(), Rec()), kNoTrans, mmt, &ep);
+  bias_corr.AddRowSumMat(1.0, d_gates, mmt);
+  CuSubMatrix c_prev(buf, prev0, T * S, OffC(), C), c_cur(buf, S, T * S, OffC(), C);
+  if (!cifg) peep_i_corr.AddDiagMatMat(1.0, CuSubMatrix(dbuf, S, T * S, OffI(), C), kTrans, c_prev, kNoTrans, mmt);
+  peep_f_corr.AddDiagMatMat(1.0, CuSubMatrix(dbuf, S, T * S, OffF(), C), kTrans, c_prev, kNoTrans, mmt);
+  peep_o_corr.AddDiagMatMat(1.0, CuSubMatrix(dbuf, S, T * S, OffO(), C), kTrans, c_cur, kNoTrans, mmt);
+  if (R > 0)
+    w_rm_corr.AddMatMat(1.0, CuSubMatrix(dbuf, S, T * S, OffRec(), R), kTrans, CuSubMatrix(buf, S, T * S, OffM(), C), kNoTrans, mmt, &ep);
+  ClipVec(&bias_corr, clip);
+  if (!cifg) ClipVec(&peep_i_corr, clip);
+  ClipVec(&peep_f_corr, clip);
+  ClipVec(&peep_o_corr, clip);
+}
+
+void LstmDir::Update(float lr) {  // lc.h:1085-1110
+  w_x.AddMat(-lr, w_x_corr);
+  w_r.AddMat(-lr, w_r_corr);
+  bias.AddVec(-lr, bias_corr, 1.0);
+  if (!cifg) peep_i.AddVec(-lr, peep_i_corr, 1.0);
+  peep_f.AddVec(-lr, peep_f_corr, 1.0);
+  peep_o.AddVec(-lr, peep_o_corr, 1.0);
+  if (R > 0) w_rm.AddMat(-lr, w_rm_corr);
+}
+
+// ---- the component family ---------------------------------------------------------------------------
+LstmFamily::LstmFamily(int32 di, int32 dout, const Config &cfg)
+    : RecurrentBase(di, dout), cfg_(cfg), ncell_(0), nrecur_(0), nstream_(0), chunk_size_(0), clip_gradient_(0.0), do_stream_reset_(false) {
+  const int per_dir = cfg.bidir ? dout / 2 : dout;
+  if (cfg.proj) nrecur_ = per_dir;       // e.g. lc.h:61-62: ncell_(0), nrecur_(output_dim/2)
+  else ncell_ = per_dir;                 // nnet-recurrent-component.h:32,110
+}
+
+void LstmFamily::InitData(std::istream &is) {
+  float param_scale = 0.02;
+  std::string token;
+  while (!is.eof()) {
+    ReadToken(is, false, &token);
+    if (cfg_.cell_dim_token && token == "<CellDim>") ReadBasicType(is, false, &ncell_);
+    else if (token == "<ClipGradient>") ReadBasicType(is, false, &clip_gradient_);
+    else if (token == "<ParamScale>") ReadBasicType(is, false, &param_scale);
+    else ASLP_ERR << "Unknown token " << token << ", a typo in config?"
+                  << (cfg_.cell_dim_token ? " (CellDim|ClipGradient|ParamScale)" : " (ClipGradient|ParamScale)");
+    is >> std::ws;
+  }
+  ASLP_ASSERT(ncell_ > 0);
+  f_.Configure(input_dim_, ncell_, cfg_.proj ? nrecur_ : 0, cfg_.cifg);
+  f_.InitRandom(param_scale);
+  if (cfg_.bidir) {
+    b_.Configure(input_dim_, ncell_, cfg_.proj ? nrecur_ : 0, cfg_.cifg);
+    b_.InitRandom(param_scale);
+  }
+  ASLP_ASSERT(clip_gradient_ >= 0.0);
+}
+
+void LstmFamily::ReadData(std::istream &is, bool binary) {
+  if (cfg_.cell_dim_token) { ExpectToken(is, binary, "<CellDim>"); ReadBasicType(is, binary, &ncell_); }
+  ExpectToken(is, binary, "<ClipGradient>");
+  ReadBasicType(is, binary, &clip_gradient_);
+  f_.Configure(input_dim_, ncell_, cfg_.proj ? nrecur_ : 0, cfg_.cifg);
+  f_.Read(is, binary);
+  if (cfg_.bidir) {
+    b_.Configure(input_dim_, ncell_, cfg_.proj ? nrecur_ : 0, cfg_.cifg);
+    b_.Read(is, binary);
+  }
+}
+
+void LstmFamily::WriteData(std::ostream &os, bool binary) const {
+  if (cfg_.cell_dim_token) { WriteToken(os, binary, "<CellDim>"); WriteBasicType(os, binary, ncell_); }
+  WriteToken(os, binary, "<ClipGradient>");
+  WriteBasicType(os, binary, clip_gradient_);
+  f_.Write(os, binary);
+  if (cfg_.bidir) b_.Write(os, binary);
+}
+
+int32 LstmFamily::NumParams() const { return f_.NumParams() * (cfg_.bidir ? 2 : 1); }
+
+void LstmFamily::GetParams(std::vector<BaseFloat> *w) const {
+  w->clear();
+  f_.AppendParams(w);
+  if (cfg_.bidir) b_.AppendParams(w);
+}
+
+void LstmFamily::GetGpuParams(std::vector<std::pair<BaseFloat *, int>> *params) {
+  params->clear();
+  f_.AppendGpuParams(params);
+  if (cfg_.bidir) b_.AppendGpuParams(params);
+}
+
+std::string LstmFamily::Info() const {
+  std::string s = f_.Info(cfg_.bidir ? "f_" : "");
+  if (cfg_.bidir) s += b_.Info("b_");
+  return s;
+}
+
+void LstmFamily::ResetLstmStreams(const std::vector<int32> &stream_reset_flag) {
+  if (!cfg_.stream_reset) return;
+  if (nstream_ == 0) {  // first call tells the number of streams (lc.h:477-483)
+    nstream_ = stream_reset_flag.size();
+    prev_state_.Resize(nstream_, f_.Width(), kSetZero);
+    ASLP_LOG << "Running training with " << nstream_ << " streams.";
+  }
+  ASLP_ASSERT(prev_state_.NumRows() == (int)stream_reset_flag.size());
+  for (size_t s = 0; s < stream_reset_flag.size(); s++)
+    if (stream_reset_flag[s] == 1) prev_state_.RowRange(s, 1).SetZero();
+}
+
+void LstmFamily::SetSeqLengths(const std::vector<int32> &sequence_lengths) {
+  if (cfg_.bidir && !cfg_.lc) {  // nnet-blstm-projected-streams.h:81-83
+    sequence_lengths_ = sequence_lengths;
+    seq_len_dev_.CopyFromVec(sequence_lengths);
+  } else {  // whole-sentence training of the carried-state variants (nnet-lstm-projected-streams.h:308-311)
+    nstream_ = sequence_lengths.size();
+    prev_state_.Resize(nstream_, f_.Width(), kSetZero);
+  }
+}
+
+void LstmFamily::PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) {
+  const bool carried = !cfg_.bidir || cfg_.lc;
+  int32 S;
+  if (carried) {
+    if (nstream_ == 0) {  // nnet-forward: one stream, state reset per utterance (lc.h:505-512)
+      do_stream_reset_ = true;
+      nstream_ = 1;
+      prev_state_.Resize(nstream_, f_.Width(), kSetZero);
+      ASLP_LOG << "Running nnet-forward with per-utterance LSTM-state reset";
+    }
+    if (do_stream_reset_) prev_state_.SetZero();
+    S = nstream_;
+  } else {
+    S = sequence_lengths_.size();  // nnet-blstm-projected-streams.h:469
+  }
+  ASLP_ASSERT(S > 0);
+  ASLP_ASSERT(in.NumRows() % S == 0);
+  const int32 T = in.NumRows() / S;
+  const int rec = f_.Rec();
+  f_.Forward(in, T, S, false, carried ? &prev_state_ : nullptr, nullptr, &f_buf_);
+  if (carried) {
+    // next batch starts from the last frame (nnet-lstm-projected-streams.h:432); the latency-controlled
+    // BLSTM from the last frame of the chunk proper, not of its right context (lc.h:629)
+    const int row_block = cfg_.lc ? chunk_size_ : T;
+    ASLP_ASSERT(row_block <= T + 1);
+    prev_state_.CopyFromMat(f_buf_.RowRange(row_block * S, S));
+  }
+  if (cfg_.bidir) {
+    b_.Forward(in, T, S, true, nullptr, cfg_.lc ? nullptr : &seq_len_dev_, &b_buf_);
+    CuSubMatrix(*out, 0, T * S, 0, rec).CopyFromMat(CuSubMatrix(f_buf_, S, T * S, f_.OffRec(), rec));
+    CuSubMatrix(*out, 0, T * S, rec, rec).CopyFromMat(CuSubMatrix(b_buf_, S, T * S, b_.OffRec(), rec));
+  } else {
+    out->CopyFromMat(CuSubMatrix(f_buf_, S, T * S, f_.OffRec(), rec));
+  }
+}
+
+void LstmFamily::BackpropagateFnc(const CuMatrixBase &in, const CuMatrixBase &, const CuMatrixBase &out_diff, CuMatrixBase *in_diff) {
+  const bool carried = !cfg_.bidir || cfg_.lc;
+  const int32 S = carried ? nstream_ : (int32)sequence_lengths_.size();
+  ASLP_ASSERT(S > 0 && in.NumRows() % S == 0);
+  const int32 T = in.NumRows() / S;
+  const int rec = f_.Rec();
+  const BaseFloat mmt = opts_.momentum;
+  f_.Backward(CuSubMatrix(out_diff, 0, T * S, 0, rec), T, S, false, f_buf_, &f_dbuf_, in_diff, 0.0);
+  if (cfg_.bidir) b_.Backward(CuSubMatrix(out_diff, 0, T * S, rec, rec), T, S, true, b_buf_, &b_dbuf_, in_diff, 1.0);
+  f_.Grads(in, T, S, false, f_buf_, f_dbuf_, mmt, clip_gradient_);
+  if (cfg_.bidir) b_.Grads(in, T, S, true, b_buf_, b_dbuf_, mmt, clip_gradient_);
+}
+
+void LstmFamily::Update(const CuMatrixBase &, const CuMatrixBase &) {
+  const BaseFloat lr = opts_.learn_rate;
+  f_.Update(lr);
+  if (cfg_.bidir) b_.Update(lr);
+}
+
+// ---- GruStreams ---------------------------------------------------------------------------------------
+void GruStreams::AllocCorr() {
+  const int H = output_dim_;
+  w_zrm_x_corr_.Resize(3 * H, input_dim_, kSetZero);
+  w_zr_h_corr_.Resize(2 * H, H, kSetZero);
+  w_m_g_corr_.Resize(H, H, kSetZero);
+  bias_corr_.Resize(3 * H, kSetZero);
+}
+
+void GruStreams::InitData(std::istream &is) {  // nnet-gru-streams.h:68-109
+  float param_scale = 0.02;
+  std::string token;
+  while (!is.eof()) {
+    ReadToken(is, false, &token);
+    if (token == "<ClipGradient>") ReadBasicType(is, false, &clip_gradient_);
+    else if (token == "<ParamScale>") ReadBasicType(is, false, &param_scale);
+    else ASLP_ERR << "Unknown token " << token << ", a typo in config?"
+                  << " (ClipGradient|ParamScale)";
+    is >> std::ws;
+  }
+  const int H = output_dim_;
+  w_zrm_x_.Resize(3 * H, input_dim_, kUndefined);
+  w_zr_h_.Resize(2 * H, H, kUndefined);
+  w_m_g_.Resize(H, H, kUndefined);
+  InitMatParamUniform(w_zrm_x_, param_scale);
+  InitMatParamUniform(w_zr_h_, param_scale);
+  InitMatParamUniform(w_m_g_, param_scale);
+  bias_.Resize(3 * H, kUndefined);
+  InitVecParamUniform(bias_, param_scale);
+  AllocCorr();
+  ASLP_ASSERT(clip_gradient_ >= 0.0);
+}
+
+void GruStreams::ReadData(std::istream &is, bool binary) {  // :111-125
+  ExpectToken(is, binary, "<ClipGradient>");
+  ReadBasicType(is, binary, &clip_gradient_);
+  w_zrm_x_.Read(is, binary);
+  w_zr_h_.Read(is, binary);
+  w_m_g_.Read(is, binary);
+  bias_.Read(is, binary);
+  const int H = output_dim_;
+  ASLP_ASSERT(w_zrm_x_.NumRows() == 3 * H && w_zrm_x_.NumCols() == input_dim_);
+  ASLP_ASSERT(w_zr_h_.NumRows() == 2 * H && w_zr_h_.NumCols() == H);
+  ASLP_ASSERT(w_m_g_.NumRows() == H && w_m_g_.NumCols() == H);
+  ASLP_ASSERT(bias_.Dim() == 3 * H);
+  AllocCorr();
+}
+
+void GruStreams::WriteData(std::ostream &os, bool binary) const {  // :127-136
+  WriteToken(os, binary, "<ClipGradient>");
+  WriteBasicType(os, binary, clip_gradient_);
+  w_zrm_x_.Write(os, binary);
+  w_zr_h_.Write(os, binary);
+  w_m_g_.Write(os, binary);
+  bias_.Write(os, binary);
+}
+
+int32 GruStreams::NumParams() const {
+  const int H = output_dim_;
+  return 3 * H * input_dim_ + 2 * H * H + H * H + 3 * H;
+}
+
+void GruStreams::GetParams(std::vector<BaseFloat> *w) const {
+  w->clear();
+  AppendRowMajor(w_zrm_x_, w);
+  AppendRowMajor(w_zr_h_, w);
+  AppendRowMajor(w_m_g_, w);
+  AppendVector(bias_, w);
+}
+
+void GruStreams::GetGpuParams(std::vector<std::pair<BaseFloat *, int>> *params) {
+  params->clear();
+  params->push_back(MatParam(w_zrm_x_));
+  params->push_back(MatParam(w_zr_h_));
+  params->push_back(MatParam(w_m_g_));
+  params->push_back(VecParam(bias_));
+}
+
+void GruStreams::SetSeqLengths(const std::vector<int32> &sequence_lengths) {  // :216-219
+  nstream_ = sequence_lengths.size();
+  prev_state_.Resize(nstream_, 5 * output_dim_, kSetZero);
+}
+
+void GruStreams::ResetLstmStreams(const std::vector<int32> &stream_reset_flag) {  // :221-236
+  if (nstream_ == 0) {
+    nstream_ = stream_reset_flag.size();
+    prev_state_.Resize(nstream_, 5 * output_dim_, kSetZero);
+    ASLP_LOG << "Running training with " << nstream_ << " streams.";
+  }
+  ASLP_ASSERT(prev_state_.NumRows() == (int)stream_reset_flag.size());
+  for (size_t s = 0; s < stream_reset_flag.size(); s++)
+    if (stream_reset_flag[s] == 1) prev_state_.RowRange(s, 1).SetZero();
+}
+
+void GruStreams::PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) {  // :238-321
+  const int H = output_dim_;
+  if (nstream_ == 0) {
+    do_stream_reset_ = true;
+    nstream_ = 1;
+    prev_state_.Resize(nstream_, 5 * H, kSetZero);
+    ASLP_LOG << "Runing nnet-forward with per-utterance GRU-state reset";
+  }
+  if (do_stream_reset_) prev_state_.SetZero();
+  ASLP_ASSERT(in.NumRows() % nstream_ == 0);
+  const int32 T = in.NumRows() / nstream_, S = nstream_;
+  buf_.Resize((T + 2) * S, 5 * H, kSetZero);
+  buf_.RowRange(0, S).CopyFromMat(prev_state_);
+  {
+    aslp_gemm_epilogue ep = aslp_gemm_epilogue();
+    ep.bias = bias_.Data();
+    CuSubMatrix zrm(buf_, S, T * S, 0, 3 * H);
+    zrm.AddMatMat(1.0, in, kNoTrans, w_zrm_x_, kTrans, 0.0, &ep);
+  }
+  const int ld = buf_.Stride();
+  for (int t = 1; t <= T; t++) {
+    CuSubMatrix y_zr(buf_, t * S, S, 0, 2 * H), h_prev(buf_, (t - 1) * S, S, 4 * H, H);
+    y_zr.AddMatMat(1.0, h_prev, kNoTrans, w_zr_h_, kTrans, 1.0);
+    aslp_gru_forward1(buf_.RowData(t * S), buf_.RowData((t - 1) * S), ld, S, H);
+    CuSubMatrix y_m(buf_, t * S, S, 2 * H, H), y_g(buf_, t * S, S, 3 * H, H);
+    y_m.AddMatMat(1.0, y_g, kNoTrans, w_m_g_, kTrans, 1.0);
+    aslp_gru_forward2(buf_.RowData(t * S), buf_.RowData((t - 1) * S), ld, S, H);
+  }
+  CheckK();
+  prev_state_.CopyFromMat(buf_.RowRange(T * S, S));
+  out->CopyFromMat(CuSubMatrix(buf_, S, T * S, 4 * H, H));
+}
+
+void GruStreams::BackpropagateFnc(const CuMatrixBase &in, const CuMatrixBase &, const CuMatrixBase &out_diff, CuMatrixBase *in_diff) {  // :323-430
+  const int H = output_dim_;
+  ASLP_ASSERT(nstream_ > 0 && in.NumRows() % nstream_ == 0);
+  const int32 T = in.NumRows() / nstream_, S = nstream_;
+  dbuf_.Resize((T + 2) * S, 5 * H, kSetZero);
+  CuSubMatrix(dbuf_, S, T * S, 4 * H, H).CopyFromMat(out_diff);
+  const int ld = dbuf_.Stride();
+  for (int t = T; t >= 1; t--) {
+    if (t < T) {
+      CuSubMatrix d_h(dbuf_, t * S, S, 4 * H, H), dn_zr(dbuf_, (t + 1) * S, S, 0, 2 * H);
+      d_h.AddMatMat(1.0, dn_zr, kNoTrans, w_zr_h_, kNoTrans, 1.0);
+    }
+    aslp_gru_backward1(dbuf_.RowData(t * S), dbuf_.RowData((t + 1) * S), buf_.RowData(t * S), buf_.RowData((t + 1) * S), ld, S, H);
+    CuSubMatrix d_g(dbuf_, t * S, S, 3 * H, H), d_m(dbuf_, t * S, S, 2 * H, H);
+    d_g.AddMatMat(1.0, d_m, kNoTrans, w_m_g_, kNoTrans, 0.0);
+    aslp_gru_backward2(dbuf_.RowData(t * S), buf_.RowData(t * S), buf_.RowData((t - 1) * S), ld, S, H);
+  }
+  CheckK();
+  CuSubMatrix d_zrm(dbuf_, S, T * S, 0, 3 * H);
+  in_diff->AddMatMat(1.0, d_zrm, kNoTrans, w_zrm_x_, kNoTrans, 0.0);
+  // gradients with momentum, clipped element-wise (:432-455)
+  const BaseFloat mmt = opts_.momentum;
+  aslp_gemm_epilogue ep = aslp_gemm_epilogue();
+  ep.clip = clip_gradient_;
+  w_zrm_x_corr_.AddMatMat(1.0, d_zrm, kTrans, in, kNoTrans, mmt, &ep);
+  bias_corr_.AddRowSumMat(1.0, d_zrm, mmt);
+  w_zr_h_corr_.AddMatMat(1.0, CuSubMatrix(dbuf_, S, T * S, 0, 2 * H), kTrans, CuSubMatrix(buf_, 0, T * S, 4 * H, H), kNoTrans, mmt, &ep);
+  w_m_g_corr_.AddMatMat(1.0, CuSubMatrix(dbuf_, S, T * S, 2 * H, H), kTrans, CuSubMatrix(buf_, S, T * S, 3 * H, H), kNoTrans, mmt, &ep);
+  ClipVec(&bias_corr_, clip_gradient_);
+}
+
+void GruStreams::Update(const CuMatrixBase &, const CuMatrixBase &) {  // :457-466
+  const BaseFloat lr = opts_.learn_rate;
+  w_zrm_x_.AddMat(-lr, w_zrm_x_corr_);
+  w_zr_h_.AddMat(-lr, w_zr_h_corr_);
+  w_m_g_.AddMat(-lr, w_m_g_corr_);
+  bias_.AddVec(-lr, bias_corr_, 1.0);
+}
+
+}  // namespace aslp

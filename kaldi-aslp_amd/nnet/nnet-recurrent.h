@@ -1,0 +1,159 @@
+// nnet-recurrent.h -- the LSTM family and GruStreams on the gfx950 gate-block kernels.
+//
+// One parameterised engine (LstmDir = one direction) serves the six reference components:
+//   Lstm / BLstm                  nnet-recurrent-component.{h,cc}:28-215 / 26-1450   (no projection)
+//   LstmProjectedStreams          nnet-lstm-projected-streams.h
+//   BLstmProjectedStreams         nnet-blstm-projected-streams.h      (length masking, backward dir only)
+//   BLstmProjectedStreamsLC       nnet-blstm-projected-streams-lc.h   (carried state saved at chunk_size)
+//   LstmCifgProjectedStreams      nnet-lstm-couple-if-projected-streams.h  (i = 1 - f)
+// Same buffers ([(T+2)S x width], row = t*S + s, columns g|i|f|o|c|h|m|r), same file formats,
+// same GetParams / GetGpuParams tensor order, same quirks (cell clip +-50, per-element gradient
+// clipping after momentum, masking only in the backward direction, LC state taken from row chunk_size).
+// Per timestep: one skinny GEMM (recurrent), ONE fused gate-block kernel (the reference: ~18-22
+// elementwise launches), one projection GEMM.
+#pragma once
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "nnet-component.h"
+
+namespace aslp {
+
+class RecurrentBase : public UpdatableComponent {
+ public:
+  RecurrentBase(int32 di, int32 dout) : UpdatableComponent(di, dout) {}
+  virtual bool HasStreamReset() const { return false; }   // answers Nnet::ResetLstmStreams (nnet-nnet.cc:473-496)
+  virtual bool HasSeqLengths() const { return false; }    // answers Nnet::SetSeqLengths   (nnet-nnet.cc:498-530)
+  virtual void ResetLstmStreams(const std::vector<int32> &) {}
+  virtual void SetSeqLengths(const std::vector<int32> &) {}
+};
+
+struct LstmDir {
+  int D = 0, C = 0, R = 0;  // input dim, cells, projection dim (0: none)
+  bool cifg = false;
+  CuMatrix w_x, w_r, w_rm, w_x_corr, w_r_corr, w_rm_corr;
+  CuVector bias, peep_i, peep_f, peep_o, bias_corr, peep_i_corr, peep_f_corr, peep_o_corr;
+
+  int G() const { return cifg ? 3 : 4; }
+  int GC() const { return G() * C; }
+  int Rec() const { return R > 0 ? R : C; }
+  int Width() const { return (G() + 3) * C + R; }
+  int OffC() const { return GC(); }
+  int OffM() const { return GC() + 2 * C; }
+  int OffRec() const { return R > 0 ? GC() + 3 * C : OffM(); }
+  int OffI() const { return C; }
+  int OffF() const { return cifg ? C : 2 * C; }
+  int OffO() const { return cifg ? 2 * C : 3 * C; }
+
+  void Configure(int d, int c, int r, bool is_cifg) { D = d; C = c; R = r; cifg = is_cifg; }
+  void AllocCorr();
+  void InitRandom(float scale);
+  void Read(std::istream &is, bool binary);
+  void Write(std::ostream &os, bool binary) const;
+  int NumParams() const;
+  void AppendParams(std::vector<BaseFloat> *w) const;
+  void AppendGpuParams(std::vector<std::pair<BaseFloat *, int>> *p);
+  std::string Info(const char *prefix) const;
+
+  // buf: activations [(T+2)S x Width]; init_state (S x Width, may be NULL) seeds the history row block
+  void Forward(const CuMatrixBase &in, int T, int S, bool reverse, const CuMatrixBase *init_state, const CuArray<int32> *seq_len,
+               CuMatrix *buf) const;
+  // out_diff: [T*S x Rec] diff w.r.t. this direction's output; in_diff = dGATES*w_x + beta*in_diff
+  void Backward(const CuMatrixBase &out_diff, int T, int S, bool reverse, const CuMatrix &buf, CuMatrix *dbuf, CuMatrixBase *in_diff,
+                float beta) const;
+  void Grads(const CuMatrixBase &in, int T, int S, bool reverse, const CuMatrix &buf, const CuMatrix &dbuf, float mmt, float clip);
+  void Update(float lr);
+};
+
+// Shared implementation; the concrete classes below only fix the configuration.
+class LstmFamily : public RecurrentBase {
+ public:
+  struct Config {
+    bool bidir, proj, cifg, lc;
+    bool cell_dim_token;   // file / config carries <CellDim>
+    bool stream_reset;     // listed in Nnet::ResetLstmStreams
+    bool seq_lengths;      // listed in Nnet::SetSeqLengths
+  };
+  LstmFamily(int32 di, int32 dout, const Config &cfg);
+
+  void InitData(std::istream &is);
+  void ReadData(std::istream &is, bool binary);
+  void WriteData(std::ostream &os, bool binary) const;
+  int32 NumParams() const;
+  void GetParams(std::vector<BaseFloat> *w) const;
+  void GetGpuParams(std::vector<std::pair<BaseFloat *, int>> *params);
+  std::string Info() const;
+
+  bool HasStreamReset() const { return cfg_.stream_reset; }
+  bool HasSeqLengths() const { return cfg_.seq_lengths; }
+  void ResetLstmStreams(const std::vector<int32> &stream_reset_flag);
+  void SetSeqLengths(const std::vector<int32> &sequence_lengths);
+  void SetChunkSize(int chunk_size) { chunk_size_ = chunk_size; }
+
+  void PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out);
+  void BackpropagateFnc(const CuMatrixBase &in, const CuMatrixBase &out, const CuMatrixBase &out_diff, CuMatrixBase *in_diff);
+  void Update(const CuMatrixBase &input, const CuMatrixBase &diff);
+
+  // test access: activation buffers of the last Propagate
+  const CuMatrix &ForwardBuffer(int dir) const { return dir == 0 ? f_buf_ : b_buf_; }
+
+ protected:
+  Config cfg_;
+  int32 ncell_, nrecur_, nstream_, chunk_size_;
+  BaseFloat clip_gradient_;
+  bool do_stream_reset_;
+  LstmDir f_, b_;
+  CuMatrix prev_state_;                 // carried state of the forward-in-time direction
+  std::vector<int32> sequence_lengths_; // BLstm* masking
+  CuArray<int32> seq_len_dev_;
+  CuMatrix f_buf_, b_buf_, f_dbuf_, b_dbuf_;
+};
+
+#define ASLP_LSTM_CLASS(Name, Type, ...)                                                   \
+  class Name : public LstmFamily {                                                         \
+   public:                                                                                 \
+    Name(int32 di, int32 dout) : LstmFamily(di, dout, Config{__VA_ARGS__}) {}              \
+    Component *Copy() const { return new Name(*this); }                                    \
+    ComponentType GetType() const { return Type; }                                         \
+  }
+//                                                      bidir  proj   cifg   lc     celltok reset  seqlen
+ASLP_LSTM_CLASS(Lstm, kLstm,                             false, false, false, false, false, true,  true);
+ASLP_LSTM_CLASS(BLstm, kBLstm,                           true,  false, false, false, false, false, true);
+ASLP_LSTM_CLASS(LstmProjectedStreams, kLstmProjectedStreams, false, true, false, false, true, true, true);
+ASLP_LSTM_CLASS(BLstmProjectedStreams, kBLstmProjectedStreams, true, true, false, false, true, false, true);
+ASLP_LSTM_CLASS(BLstmProjectedStreamsLC, kBLstmProjectedStreamsLC, true, true, false, true, true, true, false);
+ASLP_LSTM_CLASS(LstmCifgProjectedStreams, kLstmCifgProjectedStreams, false, true, true, false, true, true, true);
+#undef ASLP_LSTM_CLASS
+
+// GruStreams (nnet-gru-streams.h:39-482)
+class GruStreams : public RecurrentBase {
+ public:
+  GruStreams(int32 di, int32 dout) : RecurrentBase(di, dout), nstream_(0), clip_gradient_(0.0), do_stream_reset_(false) {}
+  Component *Copy() const { return new GruStreams(*this); }
+  ComponentType GetType() const { return kGruStreams; }
+  void InitData(std::istream &is);
+  void ReadData(std::istream &is, bool binary);
+  void WriteData(std::ostream &os, bool binary) const;
+  int32 NumParams() const;
+  void GetParams(std::vector<BaseFloat> *w) const;
+  void GetGpuParams(std::vector<std::pair<BaseFloat *, int>> *params);
+  bool HasStreamReset() const { return true; }
+  bool HasSeqLengths() const { return true; }
+  void ResetLstmStreams(const std::vector<int32> &stream_reset_flag);
+  void SetSeqLengths(const std::vector<int32> &sequence_lengths);
+  void PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out);
+  void BackpropagateFnc(const CuMatrixBase &in, const CuMatrixBase &out, const CuMatrixBase &out_diff, CuMatrixBase *in_diff);
+  void Update(const CuMatrixBase &input, const CuMatrixBase &diff);
+
+ private:
+  void AllocCorr();
+  int32 nstream_;
+  BaseFloat clip_gradient_;
+  bool do_stream_reset_;
+  CuMatrix prev_state_, w_zrm_x_, w_zr_h_, w_m_g_, w_zrm_x_corr_, w_zr_h_corr_, w_m_g_corr_;
+  CuVector bias_, bias_corr_;
+  CuMatrix buf_, dbuf_;
+};
+
+}  // namespace aslp

@@ -130,6 +130,36 @@ float *orc_dnn_bn_scale(orc_dnn *d, int layer);
 float *orc_dnn_bn_shift(orc_dnn *d, int layer);
 const float *orc_dnn_output(const orc_dnn *d);             /* softmax output [mb x out] */
 
+/* ---- recurrent components (aslp_oracle_rnn.c) ---------------------------------------------- */
+typedef struct {   /* one direction of an LSTM-family component; all matrices dense row-major */
+  int D, C, R;     /* input dim, cells, projection dim (0 = no projection: Lstm / BLstm) */
+  int cifg;        /* LstmCifgProjectedStreams: gates g,f,o only */
+  float *w_x;      /* [G*C x D]   w_gifo_x_ */
+  float *w_r;      /* [G*C x rec] w_gifo_r_, rec = R or C */
+  float *bias;     /* [G*C] */
+  float *peep_i, *peep_f, *peep_o; /* [C] each (peep_i unused for cifg) */
+  float *w_rm;     /* [R x C] w_r_m_ (NULL without projection) */
+} orc_lstm_dir;
+int orc_lstm_width(const orc_lstm_dir *p);
+void orc_lstm_forward(const orc_lstm_dir *p, const float *in, int ldi, int T, int S, int reverse, const float *init_state,
+                      const int32_t *seq_len, float *buf);
+void orc_lstm_backward(const orc_lstm_dir *p, const float *out_diff, int ldo, int T, int S, int reverse, const float *buf,
+                       float *dbuf, float *in_diff, int ldid, float in_diff_beta);
+void orc_lstm_grads(const orc_lstm_dir *p, orc_lstm_dir *g, const float *in, int ldi, int T, int S, int reverse, const float *buf,
+                    const float *dbuf, float mmt, float clip);
+void orc_lstm_update(orc_lstm_dir *p, const orc_lstm_dir *g, float lr);
+typedef struct {
+  int D, H;
+  float *w_zrm_x; /* [3H x D] */
+  float *w_zr_h;  /* [2H x H] */
+  float *w_m_g;   /* [H x H]  */
+  float *bias;    /* [3H]     */
+} orc_gru;
+void orc_gru_forward(const orc_gru *p, const float *in, int ldi, int T, int S, const float *init_state, float *buf);
+void orc_gru_backward(const orc_gru *p, const float *out_diff, int ldo, int T, int S, const float *buf, float *dbuf, float *in_diff, int ldid);
+void orc_gru_grads(const orc_gru *p, orc_gru *g, const float *in, int ldi, int T, int S, const float *buf, const float *dbuf, float mmt, float clip);
+void orc_gru_update(orc_gru *p, const orc_gru *g, float lr);
+
 /* ---- Warp-CTC (src/warp-ctc/include/detail/cpu_ctc.h) + the WarpCtc wrapper (aslp-nnet/warp-ctc.cc) */
 int orc_ctc_cost_and_grad(const float *acts, float *grads, const int *flat_labels, const int *label_lengths,
                           const int *input_lengths, int alphabet_size, int minibatch, float *costs);

@@ -60,3 +60,24 @@ def write_graph_nnet(path, comps):
     out += tok("</Nnet>")
     with open(path, "wb") as f:
         f.write(out)
+
+
+def tensors(ts):
+    """matrices as FM, vectors as FV, in the given order"""
+    return b"".join(fmat(t) if t.ndim == 2 else fvec(t) for t in ts)
+
+
+def lstm(dirs, clip, cell_dim=None):
+    """LSTM-family payload: [<CellDim> n] <ClipGradient> f, then each direction's tensors
+    (e.g. nnet-blstm-projected-streams-lc.h:242-271)"""
+    b = b""
+    if cell_dim is not None:
+        b += tok("<CellDim>") + i32(cell_dim)
+    b += tok("<ClipGradient>") + f32(clip)
+    for d in dirs:
+        b += tensors(d.tensors())
+    return b
+
+
+def gru(g, clip):
+    return tok("<ClipGradient>") + f32(clip) + tensors(g.tensors())

@@ -181,3 +181,127 @@ def rel_err(a, b):
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
     den = np.linalg.norm(b)
     return float(np.linalg.norm(a - b) / den) if den > 0 else float(np.linalg.norm(a - b))
+
+
+# ---- recurrent oracle (oracle/aslp_oracle_rnn.c) -------------------------------------------------
+class LstmDirC(C.Structure):
+    _fields_ = [("D", _i), ("C", _i), ("R", _i), ("cifg", _i)] + [(n, C.c_void_p) for n in
+                ("w_x", "w_r", "bias", "peep_i", "peep_f", "peep_o", "w_rm")]
+
+
+class GruC(C.Structure):
+    _fields_ = [("D", _i), ("H", _i)] + [(n, C.c_void_p) for n in ("w_zrm_x", "w_zr_h", "w_m_g", "bias")]
+
+
+_LP, _GP = C.POINTER(LstmDirC), C.POINTER(GruC)
+_sig("orc_lstm_width", _i, _LP)
+_sig("orc_lstm_forward", None, _LP, f32p, _i, _i, _i, _i, C.c_void_p, C.c_void_p, f32p)
+_sig("orc_lstm_backward", None, _LP, f32p, _i, _i, _i, _i, f32p, f32p, f32p, _i, _f)
+_sig("orc_lstm_grads", None, _LP, _LP, f32p, _i, _i, _i, _i, f32p, f32p, _f, _f)
+_sig("orc_lstm_update", None, _LP, _LP, _f)
+_sig("orc_gru_forward", None, _GP, f32p, _i, _i, _i, C.c_void_p, f32p)
+_sig("orc_gru_backward", None, _GP, f32p, _i, _i, _i, f32p, f32p, f32p, _i)
+_sig("orc_gru_grads", None, _GP, _GP, f32p, _i, _i, _i, f32p, f32p, _f, _f)
+_sig("orc_gru_update", None, _GP, _GP, _f)
+
+
+class LstmDir:
+    """One direction of an LSTM-family component as numpy arrays + the C view of them."""
+    NAMES = ("w_x", "w_r", "bias", "peep_i", "peep_f", "peep_o", "w_rm")
+
+    def __init__(self, D, Cc, R, cifg, rng=None, scale=0.1, zero=False):
+        self.D, self.C, self.R, self.cifg = D, Cc, R, int(cifg)
+        G = 3 if cifg else 4
+        rec = R if R > 0 else Cc
+        shapes = dict(w_x=(G * Cc, D), w_r=(G * Cc, rec), bias=(G * Cc,), peep_i=(Cc,), peep_f=(Cc,), peep_o=(Cc,),
+                      w_rm=(max(R, 1), Cc))
+        for n in self.NAMES:
+            a = np.zeros(shapes[n], np.float32) if zero else ((rng.random(shapes[n]) - 0.5) * 2 * scale).astype(np.float32)
+            setattr(self, n, a)
+        self.c = LstmDirC(D, Cc, R, int(cifg), *[getattr(self, n).ctypes.data for n in self.NAMES])
+        if R == 0:
+            self.c.w_rm = None
+        self.width = lib.orc_lstm_width(C.byref(self.c))
+        self.rec = rec
+        self.off_rec = (G + 3) * Cc if R > 0 else (G + 2) * Cc
+
+    def tensors(self):
+        """file / GetParams order"""
+        out = [self.w_x, self.w_r, self.bias]
+        if not self.cifg:
+            out.append(self.peep_i)
+        out += [self.peep_f, self.peep_o]
+        if self.R > 0:
+            out.append(self.w_rm)
+        return out
+
+    def flat(self):
+        return np.concatenate([t.ravel() for t in self.tensors()])
+
+    def forward(self, x, T, S, reverse=False, init_state=None, seq_len=None):
+        x = c32(x)
+        buf = np.zeros(((T + 2) * S, self.width), np.float32)
+        ist = c32(init_state) if init_state is not None else None
+        sl = np.ascontiguousarray(seq_len, np.int32) if seq_len is not None else None
+        lib.orc_lstm_forward(C.byref(self.c), x, x.shape[1], T, S, int(reverse), ist.ctypes.data if ist is not None else None,
+                             sl.ctypes.data if sl is not None else None, buf)
+        return buf
+
+    def out_of(self, buf, T, S):
+        return buf[S:(T + 1) * S, self.off_rec:self.off_rec + self.rec].copy()
+
+    def backward(self, out_diff, T, S, buf, reverse=False, in_diff=None, beta=0.0):
+        od = c32(out_diff)
+        dbuf = np.zeros_like(buf)
+        idf = np.zeros((T * S, self.D), np.float32) if in_diff is None else in_diff
+        lib.orc_lstm_backward(C.byref(self.c), od, od.shape[1], T, S, int(reverse), buf, dbuf, idf, self.D, beta)
+        return dbuf, idf
+
+    def grads(self, g, x, T, S, buf, dbuf, mmt, clip, reverse=False):
+        x = c32(x)
+        lib.orc_lstm_grads(C.byref(self.c), C.byref(g.c), x, x.shape[1], T, S, int(reverse), buf, dbuf, mmt, clip)
+
+    def update(self, g, lr):
+        lib.orc_lstm_update(C.byref(self.c), C.byref(g.c), lr)
+
+
+class Gru:
+    NAMES = ("w_zrm_x", "w_zr_h", "w_m_g", "bias")
+
+    def __init__(self, D, H, rng=None, scale=0.1, zero=False):
+        self.D, self.H = D, H
+        shapes = dict(w_zrm_x=(3 * H, D), w_zr_h=(2 * H, H), w_m_g=(H, H), bias=(3 * H,))
+        for n in self.NAMES:
+            a = np.zeros(shapes[n], np.float32) if zero else ((rng.random(shapes[n]) - 0.5) * 2 * scale).astype(np.float32)
+            setattr(self, n, a)
+        self.c = GruC(D, H, *[getattr(self, n).ctypes.data for n in self.NAMES])
+
+    def tensors(self):
+        return [self.w_zrm_x, self.w_zr_h, self.w_m_g, self.bias]
+
+    def flat(self):
+        return np.concatenate([t.ravel() for t in self.tensors()])
+
+    def forward(self, x, T, S, init_state=None):
+        x = c32(x)
+        buf = np.zeros(((T + 2) * S, 5 * self.H), np.float32)
+        ist = c32(init_state) if init_state is not None else None
+        lib.orc_gru_forward(C.byref(self.c), x, x.shape[1], T, S, ist.ctypes.data if ist is not None else None, buf)
+        return buf
+
+    def out_of(self, buf, T, S):
+        return buf[S:(T + 1) * S, 4 * self.H:].copy()
+
+    def backward(self, out_diff, T, S, buf):
+        od = c32(out_diff)
+        dbuf = np.zeros_like(buf)
+        idf = np.zeros((T * S, self.D), np.float32)
+        lib.orc_gru_backward(C.byref(self.c), od, od.shape[1], T, S, buf, dbuf, idf, self.D)
+        return dbuf, idf
+
+    def grads(self, g, x, T, S, buf, dbuf, mmt, clip):
+        x = c32(x)
+        lib.orc_gru_grads(C.byref(self.c), C.byref(g.c), x, x.shape[1], T, S, buf, dbuf, mmt, clip)
+
+    def update(self, g, lr):
+        lib.orc_gru_update(C.byref(self.c), C.byref(g.c), lr)

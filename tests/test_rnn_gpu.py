@@ -1,0 +1,229 @@
+"""GPU parity of the LSTM family and GruStreams (kaldi-aslp_amd/nnet/nnet-recurrent.*, fused gate
+kernels in csrc/rnn_cells.hip) against oracle/aslp_oracle_rnn.c: Propagate output, input diff and
+updated parameters over several consecutive batches (carried state, momentum, gradient clipping),
+driven through the C ABI of include/aslp_nnet.h on model files in the reference's binary format."""
+import numpy as np
+import pytest
+import torch
+
+import nnet_io
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+# marker: (bidir, proj, cifg, lc, cell_dim_token)
+FAMILY = {
+    "<Lstm>": (False, False, False, False, False),
+    "<BLstm>": (True, False, False, False, False),
+    "<LstmProjectedStreams>": (False, True, False, False, True),
+    "<BLstmProjectedStreams>": (True, True, False, False, True),
+    "<BLstmProjectedStreamsLC>": (True, True, False, True, True),
+    "<LstmCifgProjectedStreams>": (False, True, True, False, True),
+}
+
+
+def build(oracle, tmp_path, marker, D, Cc, R, clip, seed, scale=0.3):
+    bidir, proj, cifg, lc, celltok = FAMILY[marker]
+    rng = np.random.default_rng(seed)
+    Rr = R if proj else 0
+    dirs = [oracle.LstmDir(D, Cc, Rr, cifg, rng, scale=scale) for _ in range(2 if bidir else 1)]
+    grads = [oracle.LstmDir(D, Cc, Rr, cifg, zero=True) for _ in dirs]
+    out_dim = dirs[0].rec * len(dirs)
+    path = tmp_path / "rnn.nnet"
+    nnet_io.write_simple_nnet(path, [(marker, D, out_dim, nnet_io.lstm(dirs, clip, Cc if celltok else None))])
+    return dirs, grads, out_dim, path
+
+
+def oracle_step(oracle, marker, dirs, grads, x, od, T, S, state, lens, chunk, lr, mmt, clip):
+    """One Propagate + Backpropagate(+Update) of the component in the oracle; returns out, in_diff, new state."""
+    bidir, proj, cifg, lc, _ = FAMILY[marker]
+    carried = (not bidir) or lc
+    f = dirs[0]
+    fbuf = f.forward(x, T, S, reverse=False, init_state=state if carried else None)
+    outs = [f.out_of(fbuf, T, S)]
+    new_state = None
+    if carried:
+        rb = chunk if lc else T
+        new_state = fbuf[rb * S:(rb + 1) * S].copy()
+    if bidir:
+        b = dirs[1]
+        bbuf = b.forward(x, T, S, reverse=True, seq_len=None if lc else lens)
+        outs.append(b.out_of(bbuf, T, S))
+    out = np.concatenate(outs, axis=1)
+    rec = f.rec
+    fd, in_diff = f.backward(od[:, :rec], T, S, fbuf, reverse=False)
+    if bidir:
+        bd, in_diff = b.backward(od[:, rec:], T, S, bbuf, reverse=True, in_diff=in_diff, beta=1.0)
+    f.grads(grads[0], x, T, S, fbuf, fd, mmt, clip, reverse=False)
+    if bidir:
+        b.grads(grads[1], x, T, S, bbuf, bd, mmt, clip, reverse=True)
+    for p, g in zip(dirs, grads):
+        p.update(g, lr)
+    return out, in_diff, new_state
+
+
+@pytest.mark.parametrize("marker", list(FAMILY))
+@pytest.mark.parametrize("dims", [(5, 8, 4, 6, 3), (40, 64, 32, 12, 4), (33, 48, 17, 9, 5)])
+def test_lstm_family_train_steps_match_oracle(aslp, oracle, dev, tmp_path, marker, dims):
+    D, Cc, R, T, S = dims
+    bidir, proj, cifg, lc, _ = FAMILY[marker]
+    clip, lr, mmt = 0.5, 0.01, 0.9
+    dirs, grads, out_dim, path = build(oracle, tmp_path, marker, D, Cc, R, clip, seed=1)
+    net = aslp.Nnet.Read(path)
+    net.SetTrainOptions(learn_rate=lr, momentum=mmt)
+    flat = lambda: np.concatenate([d.flat() for d in dirs])
+    assert net.NumParams() == flat().size
+    assert oracle.rel_err(net.GetParams(), flat()) == 0.0
+    rng = np.random.default_rng(7)
+    carried = (not bidir) or lc
+    chunk = T - 2 if lc else 0
+    if lc:
+        net.SetChunkSize(chunk)
+    state = np.zeros((S, dirs[0].width), np.float32) if carried else None
+    for step in range(3):
+        x = rng.standard_normal((T * S, D)).astype(np.float32)
+        od = rng.standard_normal((T * S, out_dim)).astype(np.float32)
+        lens = None
+        if carried:
+            flags = [1] * S if step == 0 else [int(v) for v in rng.integers(0, 2, S)]
+            net.ResetLstmStreams(flags)
+            for s, fl in enumerate(flags):
+                if fl:
+                    state[s] = 0
+        else:
+            lens = rng.integers(1, T + 1, S).astype(np.int32)
+            lens[0] = T
+            net.SetSeqLengths(lens)
+        out_ref, idf_ref, state = oracle_step(oracle, marker, dirs, grads, x, od, T, S, state, lens, chunk, lr, mmt, clip)
+        out = net.Propagate(torch.from_numpy(x).to(dev)).cpu().numpy()
+        assert oracle.rel_err(out, out_ref) < TOL, ("out", step)
+        idf = net.Backpropagate(torch.from_numpy(od).to(dev), want_in_diff=True).cpu().numpy()
+        assert oracle.rel_err(idf, idf_ref) < TOL, ("in_diff", step)
+        assert oracle.rel_err(net.GetParams(), flat()) < TOL, ("params", step)
+
+
+def test_lstm_forward_without_reset_is_per_utterance(aslp, oracle, dev, tmp_path):
+    """nnet-forward mode: no ResetLstmStreams call -> one stream, state zeroed every Propagate
+    (nnet-lstm-projected-streams.h:316-323)."""
+    D, Cc, R, T = 6, 8, 4, 7
+    dirs, _, out_dim, path = build(oracle, tmp_path, "<LstmProjectedStreams>", D, Cc, R, 0.0, seed=3)
+    net = aslp.Nnet.Read(path)
+    rng = np.random.default_rng(1)
+    for _ in range(2):
+        x = rng.standard_normal((T, D)).astype(np.float32)
+        ref = dirs[0].out_of(dirs[0].forward(x, T, 1), T, 1)
+        out = net.Propagate(torch.from_numpy(x).to(dev)).cpu().numpy()
+        assert oracle.rel_err(out, ref) < TOL
+
+
+def test_lc_blstm_baseline_shape(aslp, oracle, dev, tmp_path):
+    """BASELINE.json config 3 geometry: C=512, R=256 per direction, chunk 40 + 20 right context,
+    8 streams; two consecutive chunks with the forward state carried from row `chunk`."""
+    D, Cc, R, S, chunk, right = 120, 512, 256, 8, 40, 20
+    T = chunk + right
+    marker = "<BLstmProjectedStreamsLC>"
+    clip, lr, mmt = 5.0, 1e-4, 0.9
+    dirs, grads, out_dim, path = build(oracle, tmp_path, marker, D, Cc, R, clip, seed=9, scale=0.05)
+    net = aslp.Nnet.Read(path)
+    net.SetTrainOptions(learn_rate=lr, momentum=mmt)
+    net.SetChunkSize(chunk)
+    rng = np.random.default_rng(3)
+    state = np.zeros((S, dirs[0].width), np.float32)
+    for step in range(2):
+        x = rng.standard_normal((T * S, D)).astype(np.float32)
+        od = (rng.standard_normal((T * S, out_dim)) * 0.1).astype(np.float32)
+        net.ResetLstmStreams([1] * S if step == 0 else [0] * S)
+        out_ref, idf_ref, state = oracle_step(oracle, marker, dirs, grads, x, od, T, S, state, None, chunk, lr, mmt, clip)
+        out = net.Propagate(torch.from_numpy(x).to(dev)).cpu().numpy()
+        assert oracle.rel_err(out, out_ref) < TOL, ("out", step)
+        idf = net.Backpropagate(torch.from_numpy(od).to(dev), want_in_diff=True).cpu().numpy()
+        assert oracle.rel_err(idf, idf_ref) < TOL, ("in_diff", step)
+        assert oracle.rel_err(net.GetParams(), np.concatenate([d.flat() for d in dirs])) < TOL, ("params", step)
+
+
+@pytest.mark.parametrize("dims", [(5, 6, 6, 3), (40, 64, 10, 4), (33, 50, 7, 5)])
+def test_gru_train_steps_match_oracle(aslp, oracle, dev, tmp_path, dims):
+    D, H, T, S = dims
+    clip, lr, mmt = 0.5, 0.01, 0.9
+    rng = np.random.default_rng(2)
+    p = oracle.Gru(D, H, rng, scale=0.3)
+    g = oracle.Gru(D, H, zero=True)
+    path = tmp_path / "gru.nnet"
+    nnet_io.write_simple_nnet(path, [("<GruStreams>", D, H, nnet_io.gru(p, clip))])
+    net = aslp.Nnet.Read(path)
+    net.SetTrainOptions(learn_rate=lr, momentum=mmt)
+    assert oracle.rel_err(net.GetParams(), p.flat()) == 0.0
+    state = np.zeros((S, 5 * H), np.float32)
+    for step in range(3):
+        x = rng.standard_normal((T * S, D)).astype(np.float32)
+        od = rng.standard_normal((T * S, H)).astype(np.float32)
+        flags = [1] * S if step == 0 else [int(v) for v in rng.integers(0, 2, S)]
+        net.ResetLstmStreams(flags)
+        for s, fl in enumerate(flags):
+            if fl:
+                state[s] = 0
+        buf = p.forward(x, T, S, init_state=state)
+        out_ref = p.out_of(buf, T, S)
+        state = buf[T * S:(T + 1) * S].copy()
+        dbuf, idf_ref = p.backward(od, T, S, buf)
+        p.grads(g, x, T, S, buf, dbuf, mmt, clip)
+        p.update(g, lr)
+        out = net.Propagate(torch.from_numpy(x).to(dev)).cpu().numpy()
+        assert oracle.rel_err(out, out_ref) < TOL, ("out", step)
+        idf = net.Backpropagate(torch.from_numpy(od).to(dev), want_in_diff=True).cpu().numpy()
+        assert oracle.rel_err(idf, idf_ref) < TOL, ("in_diff", step)
+        assert oracle.rel_err(net.GetParams(), p.flat()) < TOL, ("params", step)
+
+
+def test_recurrent_write_read_roundtrip(aslp, oracle, dev, tmp_path):
+    for marker in FAMILY:
+        dirs, _, out_dim, path = build(oracle, tmp_path, marker, 7, 6, 4, 1.5, seed=4)
+        net = aslp.Nnet.Read(path)
+        p2 = tmp_path / "copy.nnet"
+        net.Write(p2, binary=True)
+        assert open(path, "rb").read() == open(p2, "rb").read(), marker
+        p3 = tmp_path / "copy.txt"
+        net.Write(p3, binary=False)
+        net3 = aslp.Nnet.Read(p3)
+        assert oracle.rel_err(net3.GetParams(), net.GetParams()) < 1e-6
+
+
+def test_recurrent_init_from_proto(aslp, dev):
+    """<NnetProto> lines as aslp_scripts/aslp_nnet/make_*_proto.py emit them; checks dims, parameter
+    counts and the uniform [-scale, scale] initialisation (e.g. lc.h:75-88, 96-150)."""
+    proto = """<NnetProto>
+<BLstmProjectedStreamsLC> <InputDim> 20 <OutputDim> 16 <CellDim> 12 <ParamScale> 0.05 <ClipGradient> 5.0
+<LstmProjectedStreams> <InputDim> 16 <OutputDim> 8 <CellDim> 10 <ParamScale> 0.05 <ClipGradient> 5.0
+<LstmCifgProjectedStreams> <InputDim> 8 <OutputDim> 8 <CellDim> 10 <ClipGradient> 5.0
+<BLstmProjectedStreams> <InputDim> 8 <OutputDim> 12 <CellDim> 9
+<Lstm> <InputDim> 12 <OutputDim> 7 <ParamScale> 0.05
+<BLstm> <InputDim> 7 <OutputDim> 10 <ClipGradient> 1.0
+<GruStreams> <InputDim> 10 <OutputDim> 6 <ParamScale> 0.05
+<AffineTransform> <InputDim> 6 <OutputDim> 4 <BiasMean> 0.0 <BiasRange> 0.0 <ParamStddev> 0.04
+<Softmax> <InputDim> 4 <OutputDim> 4
+</NnetProto>
+"""
+    net = aslp.Nnet.Init(proto, seed=777)
+
+    def n_lstm(D, Cc, R, G=4, ndir=1):
+        rec = R if R else Cc
+        return ndir * (G * Cc * D + G * Cc * rec + G * Cc + (G - 1) * Cc + R * Cc)
+
+    want = (n_lstm(20, 12, 8, ndir=2) + n_lstm(16, 10, 8) + n_lstm(8, 10, 8, G=3) + n_lstm(8, 9, 6, ndir=2) +
+            n_lstm(12, 7, 0) + n_lstm(7, 5, 0, ndir=2) + (3 * 6 * 10 + 2 * 6 * 6 + 6 * 6 + 3 * 6) + 6 * 4 + 4)
+    assert net.NumParams() == want
+    p = net.GetParams()
+    first = p[:n_lstm(20, 12, 8, ndir=2)]
+    assert np.abs(first).max() <= 0.05 and np.abs(first).max() > 0.04
+    # one training pass runs end to end
+    net.SetTrainOptions(learn_rate=0.01, momentum=0.5)
+    S, T = 2, 5
+    net.ResetLstmStreams([1] * S)
+    net.SetSeqLengths([T] * S)
+    net.SetChunkSize(3)
+    x = torch.randn(T * S, 20, device=dev)
+    out = net.Propagate(x)
+    assert out.shape == (T * S, 4) and torch.isfinite(out).all()
+    assert torch.allclose(out.sum(1), torch.ones(T * S, device=dev), atol=1e-5)
+    net.Backpropagate(torch.randn(T * S, 4, device=dev) * 0.1)
+    assert np.isfinite(net.GetParams()).all() and not np.array_equal(net.GetParams(), p)
