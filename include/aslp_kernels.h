@@ -178,6 +178,25 @@ void aslp_gru_forward1(float *y_cur, const float *y_prev, int ld, int S, int H);
 void aslp_gru_forward2(float *y_cur, const float *y_prev, int ld, int S, int H);
 void aslp_gru_backward1(float *d_cur, const float *d_next, const float *y_cur, const float *y_next, int ld, int S, int H);
 void aslp_gru_backward2(float *d_cur, const float *y_cur, const float *y_prev, int ld, int S, int H);
+/* ---- depthwise temporal filters (csrc/temporal.hip) ------------------------------------------------
+ * CompactFsmn (nnet-cfsmn-component.h:170-262), one sequence of T rows, coef [(past+future+1) x D]:
+ *   reverse = 0 (Propagate):       out[t] = src[t] + sum_j coef[j]     .* src[t + j - past]
+ *   reverse = 1 (in-diff, :232-249) out[t] = src[t] + sum_j coef[C-1-j] .* src[t + j - future]
+ *   coef_grad (:213-219, 251-254): coef_corr[i] = clip(sum_t in[t + i - past] .* out_diff[t])  (overwrites) */
+void aslp_fsmn_filter(float *out, int ldo, const float *src, int lds, const float *coef, int ldc, int D, int past, int future, int T,
+                      int reverse);
+void aslp_fsmn_coef_grad(float *coef_corr, int ldc, const float *in, int ldi, const float *out_diff, int ldod, int D, int past, int future,
+                         int T, float clip);
+/* RowConvolution (nnet-row-convolution.cc:105-176): rows t*S + s, w dense [D x (K+1)], seq_len [S] on the device.
+ *   forward : out[t] = sum_k w[:,k] .* in[min(t + k, L_s - 1)]   for t < L_s, 0 beyond
+ *   backward: in_diff[t] = sum_{k <= t} w[:,k] .* out_diff[t - k] for t < L_s, 0 beyond
+ *   wgrad   : w_diff[d][k] = sum_{s, t < L_s} in[min(t + k, L_s - 1)][d] * out_diff[t][d]  (overwrites) */
+void aslp_rowconv_forward(float *out, int ldo, const float *in, int ldi, const float *w, int D, int K, int T, int S,
+                          const int32_cuda *seq_len);
+void aslp_rowconv_backward(float *in_diff, int ldid, const float *out_diff, int ldod, const float *w, int D, int K, int T, int S,
+                           const int32_cuda *seq_len);
+void aslp_rowconv_wgrad(float *w_diff, const float *in, int ldi, const float *out_diff, int ldod, int D, int K, int T, int S,
+                        const int32_cuda *seq_len);
 /* max-norm row shrink (nnet-affine-transform.h:231-243) */
 void aslp_max_norm_rows(float *W, MatrixDim d, float max_norm);
 

@@ -160,6 +160,17 @@ void orc_gru_backward(const orc_gru *p, const float *out_diff, int ldo, int T, i
 void orc_gru_grads(const orc_gru *p, orc_gru *g, const float *in, int ldi, int T, int S, const float *buf, const float *dbuf, float mmt, float clip);
 void orc_gru_update(orc_gru *p, const orc_gru *g, float lr);
 
+/* ---- depthwise temporal components (aslp_oracle_temporal.c) ------------------------------------- */
+void orc_rowconv_propagate(const float *w, int D, int K, const float *in, int ldi, int T, int S, const int32_t *seq_len,
+                           float *in_buf, float *out, int ldo);
+void orc_rowconv_backpropagate(const float *w, int D, int K, const float *out_diff, int ldod, int T, int S, const int32_t *seq_len,
+                               const float *in_buf, float *in_diff_buf, float *w_diff, float *in_diff, int ldid);
+void orc_rowconv_update(float *w, float *w_corr, const float *w_diff, int D, int K, float lr, float mmt);
+void orc_fsmn_propagate(const float *coef, int D, int P, int F, const float *in, int ldi, int T, float *out, int ldo);
+void orc_fsmn_backpropagate(const float *coef, int D, int P, int F, const float *in, int ldi, const float *out_diff, int ldod, int T,
+                            float clip, float *coef_corr, float *in_diff, int ldid);
+void orc_fsmn_update(float *coef, const float *coef_corr, int D, int P, int F, float lr);
+
 /* ---- Warp-CTC (src/warp-ctc/include/detail/cpu_ctc.h) + the WarpCtc wrapper (aslp-nnet/warp-ctc.cc) */
 int orc_ctc_cost_and_grad(const float *acts, float *grads, const int *flat_labels, const int *label_lengths,
                           const int *input_lengths, int alphabet_size, int minibatch, float *costs);

@@ -81,3 +81,11 @@ def lstm(dirs, clip, cell_dim=None):
 
 def gru(g, clip):
     return tok("<ClipGradient>") + f32(clip) + tensors(g.tensors())
+
+
+def rowconv(w):
+    return tok("<FutureContext>") + i32(w.shape[1] - 1) + fmat(w)
+
+
+def fsmn(coef, past, future, lr_coef=1.0):
+    return tok("<PastContext>") + i32(past) + tok("<FutureContext>") + i32(future) + tok("<LearnRateCoef>") + f32(lr_coef) + fmat(coef)

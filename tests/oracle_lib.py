@@ -305,3 +305,56 @@ class Gru:
 
     def update(self, g, lr):
         lib.orc_gru_update(C.byref(self.c), C.byref(g.c), lr)
+
+
+# ---- depthwise temporal oracle (oracle/aslp_oracle_temporal.c) ------------------------------------
+_sig("orc_rowconv_propagate", None, f32p, _i, _i, f32p, _i, _i, _i, i32p, f32p, f32p, _i)
+_sig("orc_rowconv_backpropagate", None, f32p, _i, _i, f32p, _i, _i, _i, i32p, f32p, f32p, f32p, f32p, _i)
+_sig("orc_rowconv_update", None, f32p, f32p, f32p, _i, _i, _f, _f)
+_sig("orc_fsmn_propagate", None, f32p, _i, _i, _i, f32p, _i, _i, f32p, _i)
+_sig("orc_fsmn_backpropagate", None, f32p, _i, _i, _i, f32p, _i, f32p, _i, _i, _f, f32p, f32p, _i)
+_sig("orc_fsmn_update", None, f32p, f32p, _i, _i, _i, _f)
+
+
+class RowConv:
+    def __init__(self, D, K, rng):
+        self.D, self.K = D, K
+        self.w = rng.standard_normal((D, K + 1)).astype(np.float32)
+        self.w_diff = np.zeros_like(self.w); self.w_corr = np.zeros_like(self.w)
+
+    def propagate(self, x, T, S, lens):
+        x = c32(x); lens = np.ascontiguousarray(lens, np.int32)
+        self.in_buf = np.zeros((S * (T + self.K), self.D), np.float32)
+        out = np.zeros((T * S, self.D), np.float32)   # Component::Propagate zeroes out first
+        lib.orc_rowconv_propagate(self.w, self.D, self.K, x, x.shape[1], T, S, lens, self.in_buf, out, self.D)
+        return out
+
+    def backpropagate(self, od, T, S, lens):
+        od = c32(od); lens = np.ascontiguousarray(lens, np.int32)
+        idb = np.zeros_like(self.in_buf)
+        in_diff = np.zeros((T * S, self.D), np.float32)  # Component::Backpropagate zeroes in_diff first
+        lib.orc_rowconv_backpropagate(self.w, self.D, self.K, od, od.shape[1], T, S, lens, self.in_buf, idb, self.w_diff, in_diff, self.D)
+        return in_diff
+
+    def update(self, lr, mmt):
+        lib.orc_rowconv_update(self.w, self.w_corr, self.w_diff, self.D, self.K, lr, mmt)
+
+
+class Fsmn:
+    def __init__(self, D, P, F, rng, scale=0.3):
+        self.D, self.P, self.F = D, P, F
+        self.coef = ((rng.random((P + F + 1, D)) - 0.5) * 2 * scale).astype(np.float32)
+        self.corr = np.zeros_like(self.coef)
+
+    def propagate(self, x):
+        x = c32(x); out = np.zeros_like(x)
+        lib.orc_fsmn_propagate(self.coef, self.D, self.P, self.F, x, x.shape[1], x.shape[0], out, self.D)
+        return out
+
+    def backpropagate(self, x, od, clip):
+        x = c32(x); od = c32(od); in_diff = np.zeros_like(x)
+        lib.orc_fsmn_backpropagate(self.coef, self.D, self.P, self.F, x, x.shape[1], od, od.shape[1], x.shape[0], clip, self.corr, in_diff, self.D)
+        return in_diff
+
+    def update(self, lr):
+        lib.orc_fsmn_update(self.coef, self.corr, self.D, self.P, self.F, lr)
