@@ -56,6 +56,13 @@ ctcStatus_t get_workspace_size(const int *const label_lengths, const int *const 
 
 int get_warpctc_version(void);
 
+/* Extension used by the host engine's WarpCtc loss (replaces the de-stride / malloc / row copy-back
+ * sequence of aslp-nnet/warp-ctc.cc:85-147): same computation on row-padded device matrices, row
+ * (t*minibatch + n) at acts + (t*minibatch + n)*ld_acts; gradient rows of frames t < input_lengths[n]
+ * are written, all others left untouched; workspace is library-owned; runs on the aslp_set_stream() stream. */
+ctcStatus_t aslp_ctc_loss_strided(const float *acts, int ld_acts, float *grads, int ld_grads, const int *flat_labels,
+                                  const int *label_lengths, const int *input_lengths, int alphabet_size, int minibatch, float *costs);
+
 #ifdef __cplusplus
 }
 #endif

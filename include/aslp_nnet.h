@@ -73,6 +73,25 @@ int aslp_xent_get_stats(aslp_xent_t x, double stats[5]);      /* frames, correct
 int aslp_nnet_train_step_xent(aslp_nnet_t n, aslp_xent_t x, const float *in, int rows, int cols, int stride,
                               const int32_t *labels, const float *frame_weights);
 
+/* ---- WarpCtc (aslp-nnet/warp-ctc.h:29-113) -------------------------------------------------- */
+typedef struct aslp_warpctc_s *aslp_warpctc_t;
+int aslp_warpctc_create(aslp_warpctc_t *out);
+void aslp_warpctc_free(aslp_warpctc_t w);
+/* WarpCtc::Eval (warp-ctc.cc:33): net_out = pre-softmax activations [max_T*num_utt x alphabet] on the device,
+ * row = t*num_utt + s; labels flat on the host with label_lengths[num_utt]; diff (device, same shape) receives the
+ * filtered, +-1-clipped gradient; costs_host[num_utt] (may be NULL) the per-utterance -log p(l|x). */
+int aslp_warpctc_eval(aslp_warpctc_t w, const int32_t *frame_num_utt, int num_utt, const float *net_out, int rows, int cols, int stride,
+                      const int32_t *flat_labels, const int32_t *label_lengths, float *diff, int diff_stride, float *costs_host);
+/* WarpCtc::ErrorRate (warp-ctc.cc:487): best-path token errors vs the labels, accumulated into the report */
+int aslp_warpctc_error_rate(aslp_warpctc_t w, const int32_t *frame_num_utt, int num_utt, const float *net_out, int rows, int cols, int stride,
+                            const int32_t *flat_labels, const int32_t *label_lengths);
+int aslp_warpctc_report(aslp_warpctc_t w, char *buf, int buflen);   /* WarpCtc::Report warp-ctc.cc:531 */
+/* stats = {obj, frames, sequences, error_tokens, ref_tokens} */
+int aslp_warpctc_get_stats(aslp_warpctc_t w, double stats[5]);
+/* Propagate -> WarpCtc::Eval -> Backpropagate (the loop body of aslp-nnet-train-warp-ctc-streams.cc) */
+int aslp_nnet_train_step_warpctc(aslp_nnet_t n, aslp_warpctc_t w, const float *in, int rows, int cols, int stride,
+                                 const int32_t *frame_num_utt, int num_utt, const int32_t *flat_labels, const int32_t *label_lengths);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,6 +19,7 @@
 #include "aslp_ctc.h"
 #include "aslp_kernels.h"
 #include "common.h"
+#include "scratch.h"
 
 namespace aslp {
 namespace {
@@ -89,7 +90,7 @@ __global__ void __launch_bounds__(256) ctc_alpha_kernel(const float *__restrict_
 __global__ void __launch_bounds__(256) ctc_beta_grad_kernel(const float *__restrict__ probs, const float *__restrict__ alphas, float *__restrict__ grads,
                                                             const UttInfo *info, const int *__restrict__ lwb_all, const int *__restrict__ next_all,
                                                             const int *__restrict__ first_all, int A, int mb, int maxS, int maxT,
-                                                            const float *loglike) {
+                                                            const float *loglike, int ldg) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n = blockIdx.x;
   const UttInfo u = info[n];
@@ -110,7 +111,8 @@ __global__ void __launch_bounds__(256) ctc_beta_grad_kernel(const float *__restr
   const float logZ = loglike[n];
   const long tstride = (long)A * mb;
   const float *p = probs + (long)n * A;
-  float *g = grads + (long)n * A;
+  float *g = grads + (long)n * ldg;
+  const long gstride = (long)ldg * mb;
   const float *al = alphas + (long)n * maxS * maxT;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float *nextb = b0, *curb = b1;  // nextb = beta_{t+1}, curb = beta_t
@@ -157,7 +159,7 @@ __global__ void __launch_bounds__(256) ctc_beta_grad_kernel(const float *__restr
       float gv;
       if (o == 0.0f || o == kNegInf || pr == 0.0f) gv = pr;
       else gv = pr - expf(o - logf(pr) - logZ);
-      g[t * tstride + a] = gv;
+      g[t * gstride + a] = gv;
     }
     __syncthreads();
     float *tmp = nextb; nextb = curb; curb = tmp;
@@ -221,8 +223,9 @@ ctcStatus_t get_workspace_size(const int *const label_lengths, const int *const 
   return CTC_STATUS_SUCCESS;
 }
 
-ctcStatus_t compute_ctc_loss(const float *const activations, float *gradients, const int *const flat_labels, const int *const label_lengths,
-                             const int *const input_lengths, int A, int mb, float *costs, void *workspace, struct ctcComputeInfo cinfo) {
+static ctcStatus_t ctc_loss_impl(const float *const activations, int ld_acts, float *gradients, int ld_grads, const int *const flat_labels,
+                                 const int *const label_lengths, const int *const input_lengths, int A, int mb, float *costs, void *workspace,
+                                 struct ctcComputeInfo cinfo) {
   if (activations == nullptr || flat_labels == nullptr || label_lengths == nullptr || input_lengths == nullptr || costs == nullptr ||
       workspace == nullptr || A <= 0 || mb <= 0)
     return CTC_STATUS_INVALID_VALUE;  // ctc_entrypoint.cpp:46-54
@@ -280,7 +283,7 @@ ctcStatus_t compute_ctc_loss(const float *const activations, float *gradients, c
   hipStream_t saved = cur_stream();
   set_cur_stream(stream);
   MatrixDim d = {maxT * mb, A, A};
-  if (maxT > 0) cudaF_softmax_reduce(0, 0, probs, activations, d, A);
+  if (maxT > 0) cudaF_softmax_reduce(0, 0, probs, activations, d, ld_acts);
   set_cur_stream(saved);
 
   const size_t lds_alpha = sizeof(float) * 2 * maxS + sizeof(int) * maxS;
@@ -295,12 +298,35 @@ ctcStatus_t compute_ctc_loss(const float *const activations, float *gradients, c
   hipLaunchKernelGGL(ctc_alpha_kernel, dim3(mb), dim3(256), lds_alpha, stream, probs, alphas, d_info, d_lwb, A, mb, maxS, maxT > 0 ? maxT : 1, d_ll);
   if (gradients != nullptr)
     hipLaunchKernelGGL(ctc_beta_grad_kernel, dim3(mb), dim3(256), lds_beta, stream, probs, alphas, gradients, d_info, d_lwb, d_nxt, d_fst, A, mb,
-                       maxS, maxT > 0 ? maxT : 1, d_ll);
+                       maxS, maxT > 0 ? maxT : 1, d_ll, ld_grads);
   hipLaunchKernelGGL(neg_costs_kernel, dim3((mb + 255) / 256), dim3(256), 0, stream, d_ll, d_info, d_costs, mb);
   if (hipGetLastError() != hipSuccess) return CTC_STATUS_EXECUTION_FAILED;
   if (hipMemcpyAsync(costs, d_costs, sizeof(float) * mb, hipMemcpyDeviceToHost, stream) != hipSuccess) return CTC_STATUS_MEMOPS_FAILED;
   if (hipStreamSynchronize(stream) != hipSuccess) return CTC_STATUS_EXECUTION_FAILED;
   return CTC_STATUS_SUCCESS;
+}
+
+ctcStatus_t compute_ctc_loss(const float *const activations, float *gradients, const int *const flat_labels, const int *const label_lengths,
+                             const int *const input_lengths, int A, int mb, float *costs, void *workspace, struct ctcComputeInfo cinfo) {
+  return ctc_loss_impl(activations, A, gradients, A, flat_labels, label_lengths, input_lengths, A, mb, costs, workspace, cinfo);
+}
+
+// Same computation on row-padded matrices (what the host engine holds): activation row (t*mb + n) starts
+// at acts + (t*mb + n)*ld_acts, gradient rows likewise; the workspace comes from the library's grow-only
+// scratch slot, so a training loop does no allocation, no de-striding copy and no row-wise copy-back
+// (the reference's wrapper does all three per call, aslp-nnet/warp-ctc.cc:85-95,105-113,139-147).
+ctcStatus_t aslp_ctc_loss_strided(const float *acts, int ld_acts, float *grads, int ld_grads, const int *flat_labels, const int *label_lengths,
+                                  const int *input_lengths, int A, int mb, float *costs) {
+  if (ld_acts < A || (grads != nullptr && ld_grads < A)) return CTC_STATUS_INVALID_VALUE;
+  struct ctcComputeInfo info;
+  info.loc = CTC_GPU;
+  info.stream = reinterpret_cast<CUstream>(cur_stream());
+  size_t bytes = 0;
+  ctcStatus_t st = get_workspace_size(label_lengths, input_lengths, A, mb, info, &bytes);
+  if (st != CTC_STATUS_SUCCESS) return st;
+  void *ws = scratch(kScratchCtc, bytes);
+  if (!ws) return CTC_STATUS_MEMOPS_FAILED;
+  return ctc_loss_impl(acts, ld_acts, grads, ld_grads, flat_labels, label_lengths, input_lengths, A, mb, costs, ws, info);
 }
 
 }  // extern "C"

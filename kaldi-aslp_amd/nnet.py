@@ -48,6 +48,14 @@ _sig("aslp_xent_eval_batch", _i, _H, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i
 _sig("aslp_xent_report", _i, _H, C.c_char_p, _i)
 _sig("aslp_xent_get_stats", _i, _H, C.POINTER(C.c_double))
 _sig("aslp_nnet_train_step_xent", _i, _H, _H, _vp, _i, _i, _i, _vp, _vp)
+_i32p = C.POINTER(C.c_int32)
+_sig("aslp_warpctc_create", _i, C.POINTER(_H))
+_sig("aslp_warpctc_free", None, _H)
+_sig("aslp_warpctc_eval", _i, _H, _i32p, _i, _vp, _i, _i, _i, _i32p, _i32p, _vp, _i, C.POINTER(_f))
+_sig("aslp_warpctc_error_rate", _i, _H, _i32p, _i, _vp, _i, _i, _i, _i32p, _i32p)
+_sig("aslp_warpctc_report", _i, _H, C.c_char_p, _i)
+_sig("aslp_warpctc_get_stats", _i, _H, C.POINTER(C.c_double))
+_sig("aslp_nnet_train_step_warpctc", _i, _H, _H, _vp, _i, _i, _i, _i32p, _i, _i32p, _i32p)
 
 
 def _ok(rc):
@@ -81,6 +89,58 @@ class Xent:
         st = (C.c_double * 5)()
         _ok(lib.aslp_xent_get_stats(self.h, st))
         return dict(zip(("frames", "correct", "loss", "entropy", "likelyhood"), list(st)))
+
+
+def _i32arr(v):
+    return (C.c_int32 * max(1, len(v)))(*[int(x) for x in v])
+
+
+def _flat(labels):
+    flat = [int(x) for l in labels for x in l]
+    return _i32arr(flat), _i32arr([len(l) for l in labels])
+
+
+class WarpCtc:
+    """aslp-nnet/warp-ctc.h:29: Eval / ErrorRate / Report on device-resident activations."""
+
+    def __init__(self):
+        self.h = _H()
+        _ok(lib.aslp_warpctc_create(C.byref(self.h)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib.aslp_warpctc_free(self.h)
+            self.h = None
+
+    def Eval(self, frame_num_utt, net_out, labels, diff=None):
+        """returns (diff, costs); net_out rows are t*num_utt + s, pre-softmax activations"""
+        import numpy as np
+        _chk(net_out)
+        if diff is None:
+            diff = torch.empty_like(net_out)
+        n = len(frame_num_utt)
+        fl, ll = _flat(labels[:n])
+        costs = np.zeros(n, np.float32)
+        _ok(lib.aslp_warpctc_eval(self.h, _i32arr(frame_num_utt), n, ptr(net_out), net_out.shape[0], net_out.shape[1],
+                                  dim(net_out).stride, fl, ll, ptr(diff), dim(diff).stride, costs.ctypes.data_as(C.POINTER(_f))))
+        return diff, costs
+
+    def ErrorRate(self, frame_num_utt, net_out, labels):
+        _chk(net_out)
+        n = len(frame_num_utt)
+        fl, ll = _flat(labels[:n])
+        _ok(lib.aslp_warpctc_error_rate(self.h, _i32arr(frame_num_utt), n, ptr(net_out), net_out.shape[0], net_out.shape[1],
+                                        dim(net_out).stride, fl, ll))
+
+    def Report(self):
+        buf = C.create_string_buffer(4096)
+        _ok(lib.aslp_warpctc_report(self.h, buf, 4096))
+        return buf.value.decode()
+
+    def GetStats(self):
+        st = (C.c_double * 5)()
+        _ok(lib.aslp_warpctc_get_stats(self.h, st))
+        return dict(zip(("obj", "frames", "sequences", "error_tokens", "ref_tokens"), list(st)))
 
 
 class Nnet:
@@ -191,6 +251,13 @@ class Nnet:
         buf = np.empty((rows, cols), np.float32)
         _ok(lib.aslp_nnet_component_out_diff(self.h, c, buf.ctypes.data_as(C.POINTER(_f)), rows, cols))
         return buf
+
+    def TrainStepWarpCtc(self, ctc, x, frame_num_utt, labels):
+        """SetSeqLengths -> Propagate -> WarpCtc::Eval + ErrorRate -> Backpropagate(+Update)."""
+        _chk(x)
+        n = len(frame_num_utt)
+        fl, ll = _flat(labels[:n])
+        _ok(lib.aslp_nnet_train_step_warpctc(self.h, ctc.h, ptr(x), x.shape[0], x.shape[1], dim(x).stride, _i32arr(frame_num_utt), n, fl, ll))
 
     def TrainStepXent(self, xent, x, labels, frame_weights=None):
         """Propagate -> Xent::Eval -> Backpropagate(+Update), all on the device."""

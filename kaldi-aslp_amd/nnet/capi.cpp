@@ -5,6 +5,7 @@
 #include "aslp_nnet.h"
 #include "nnet-loss.h"
 #include "nnet-nnet.h"
+#include "warp-ctc.h"
 
 using namespace aslp;
 
@@ -16,6 +17,18 @@ struct aslp_nnet_s {
 struct aslp_xent_s {
   Xent xent;
 };
+struct aslp_warpctc_s {
+  WarpCtc ctc;
+  CuMatrix diff;
+};
+static void SplitLabels(const int32_t *flat, const int32_t *lens, int n, std::vector<std::vector<int32>> *out) {
+  out->resize(n);
+  int off = 0;
+  for (int i = 0; i < n; i++) {
+    (*out)[i].assign(flat + off, flat + off + lens[i]);
+    off += lens[i];
+  }
+}
 
 static thread_local std::string t_err;
 #define API_BEGIN try {
@@ -204,6 +217,57 @@ int aslp_nnet_train_step_xent(aslp_nnet_t n, aslp_xent_t x, const float *in, int
   lab.Resize(rows);
   DeviceToDevice(lab.Data(), labels, sizeof(int32) * rows);
   x->xent.EvalLabels(fwv, n->out, lab, &n->diff);
+  n->nnet.Backpropagate(n->diff, NULL);
+  API_END
+}
+
+int aslp_warpctc_create(aslp_warpctc_t *out) { API_BEGIN *out = new aslp_warpctc_s(); API_END }
+void aslp_warpctc_free(aslp_warpctc_t w) { delete w; }
+int aslp_warpctc_eval(aslp_warpctc_t w, const int32_t *frame_num_utt, int num_utt, const float *net_out, int rows, int cols, int stride,
+                      const int32_t *flat_labels, const int32_t *label_lengths, float *diff, int diff_stride, float *costs_host) {
+  API_BEGIN
+  CuSubMatrix y(const_cast<float *>(net_out), rows, cols, stride);
+  std::vector<int32> frames(frame_num_utt, frame_num_utt + num_utt);
+  std::vector<std::vector<int32>> labels;
+  SplitLabels(flat_labels, label_lengths, num_utt, &labels);
+  std::vector<std::string> utt(num_utt);
+  for (int i = 0; i < num_utt; i++) utt[i] = "utt" + std::to_string(i);
+  w->ctc.Eval(utt, frames, y, labels, &w->diff);
+  CuSubMatrix o(diff, rows, cols, diff_stride);
+  o.CopyFromMat(w->diff);
+  if (costs_host) std::memcpy(costs_host, w->ctc.LastCosts().data(), sizeof(float) * num_utt);
+  API_END
+}
+int aslp_warpctc_error_rate(aslp_warpctc_t w, const int32_t *frame_num_utt, int num_utt, const float *net_out, int rows, int cols, int stride,
+                            const int32_t *flat_labels, const int32_t *label_lengths) {
+  API_BEGIN
+  CuSubMatrix y(const_cast<float *>(net_out), rows, cols, stride);
+  std::vector<int32> frames(frame_num_utt, frame_num_utt + num_utt);
+  std::vector<std::vector<int32>> labels;
+  SplitLabels(flat_labels, label_lengths, num_utt, &labels);
+  w->ctc.ErrorRate(frames, y, labels);
+  API_END
+}
+int aslp_warpctc_report(aslp_warpctc_t w, char *buf, int buflen) { API_BEGIN CopyStr(w->ctc.Report(), buf, buflen); API_END }
+int aslp_warpctc_get_stats(aslp_warpctc_t w, double stats[5]) {
+  API_BEGIN
+  stats[0] = w->ctc.Obj(); stats[1] = w->ctc.Frames(); stats[2] = w->ctc.Sequences();
+  stats[3] = w->ctc.NumErrorTokens(); stats[4] = w->ctc.NumRefTokens();
+  API_END
+}
+int aslp_nnet_train_step_warpctc(aslp_nnet_t n, aslp_warpctc_t w, const float *in, int rows, int cols, int stride,
+                                 const int32_t *frame_num_utt, int num_utt, const int32_t *flat_labels, const int32_t *label_lengths) {
+  API_BEGIN
+  CuSubMatrix inm(const_cast<float *>(in), rows, cols, stride);
+  std::vector<int32> frames(frame_num_utt, frame_num_utt + num_utt);
+  std::vector<std::vector<int32>> labels;
+  SplitLabels(flat_labels, label_lengths, num_utt, &labels);
+  std::vector<std::string> utt(num_utt);
+  for (int i = 0; i < num_utt; i++) utt[i] = "utt" + std::to_string(i);
+  n->nnet.SetSeqLengths(frames);  // aslp-nnet-train-warp-ctc-streams.cc: whole-utterance batches
+  n->nnet.Propagate(inm, &n->out);
+  w->ctc.Eval(utt, frames, n->out, labels, &n->diff);
+  w->ctc.ErrorRate(frames, n->out, labels);
   n->nnet.Backpropagate(n->diff, NULL);
   API_END
 }

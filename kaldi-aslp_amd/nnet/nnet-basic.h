@@ -461,6 +461,7 @@ class BatchNormalization : public UpdatableComponent {
       : UpdatableComponent(di, dout), var_floor_(0.0000001), num_acc_frames_(0), acc_cleaned_(false) {}
   Component *Copy() const { return new BatchNormalization(*this); }
   ComponentType GetType() const { return kBatchNormalization; }
+  bool GradientInBackprop() const { return true; }
   void InitData(std::istream &) {  // :45-54
     num_acc_frames_ = 0;
     scale_.Resize(output_dim_); scale_.Set(1.0);

@@ -119,6 +119,9 @@ class Component {
   // Pure-copy layers: the executor may pass the buffer through instead of copying it.
   virtual bool PropagateIsCopy() const { return false; }
   virtual bool BackpropIsCopy() const { return false; }
+  // True if the parameter gradients are formed inside BackpropagateFnc (the recurrent and temporal
+  // components, e.g. lc.h:976-1058) rather than in Update: the executor must then never skip the call.
+  virtual bool GradientInBackprop() const { return false; }
 
  protected:
   virtual void FeedforwardFnc(const CuMatrixBase &in, CuMatrixBase *out) { PropagateFnc(in, out); }

@@ -105,7 +105,7 @@ void Nnet::Backpropagate(const std::vector<const CuMatrixBase *> &out_diff, std:
     if (!is_input)
       for (int32 p : components_[i]->GetInput())
         if (components_[p]->GetType() != Component::kInputLayer) feeds_only_input = false;
-    const bool skip_backprop = !want_in_diff && (is_input || feeds_only_input);
+    const bool skip_backprop = !want_in_diff && (is_input || feeds_only_input) && !components_[i]->GradientInBackprop();
     CuMatrix *target = &input_diff_buf_[i];
     if (!is_input && direct[i]) target = &output_diff_buf_[components_[i]->GetInput()[0]];
     if (!skip_backprop) {

@@ -18,6 +18,7 @@ class RowConvolution : public UpdatableComponent {
   }
   Component *Copy() const { return new RowConvolution(*this); }
   ComponentType GetType() const { return kRowConvolution; }
+  bool GradientInBackprop() const { return true; }
   void SetSeqLengths(const std::vector<int32> &sequence_lengths) {  // row-convolution.h:39-41
     sequence_lengths_ = sequence_lengths;
     seq_len_dev_.CopyFromVec(sequence_lengths);
@@ -102,6 +103,7 @@ class CompactFsmn : public UpdatableComponent {
       : UpdatableComponent(di, dout), max_frames_(3000), learn_rate_coef_(1.0), past_context_(0), future_context_(0), clip_gradient_(0.0) {}
   Component *Copy() const { return new CompactFsmn(*this); }
   ComponentType GetType() const { return kCompactFsmn; }
+  bool GradientInBackprop() const { return true; }
   void InitData(std::istream &is) {  // cfsmn.h:53-89
     int past_context = 30, future_context = 30;
     float learn_rate_coef = 1.0, vec_coef_mean = 0.0, vec_coef_range = 1.0;
