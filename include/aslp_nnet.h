@@ -92,6 +92,21 @@ int aslp_warpctc_get_stats(aslp_warpctc_t w, double stats[5]);
 int aslp_nnet_train_step_warpctc(aslp_nnet_t n, aslp_warpctc_t w, const float *in, int rows, int cols, int stride,
                                  const int32_t *frame_num_utt, int num_utt, const int32_t *flat_labels, const int32_t *label_lengths);
 
+/* ---- frame shuffling cache (aslp-nnet/nnet-randomizer.h:53-102) --------------------------------- */
+typedef struct aslp_matrix_randomizer_s *aslp_matrix_randomizer_t;
+/* RandomizerMask::Init + Generate: srand(seed) when seed >= 0, then a permutation of [0, size) in the order
+ * std::random_shuffle produces with the C library generator (nnet-randomizer.cc:33-44) */
+int aslp_randomizer_mask_generate(int seed, int size, int32_t *mask_host);
+int aslp_matrix_randomizer_create(int randomizer_size, int minibatch_size, aslp_matrix_randomizer_t *out);
+void aslp_matrix_randomizer_free(aslp_matrix_randomizer_t r);
+int aslp_matrix_randomizer_add_data(aslp_matrix_randomizer_t r, const float *dev, int rows, int cols, int stride);
+int aslp_matrix_randomizer_randomize(aslp_matrix_randomizer_t r, const int32_t *mask_host, int n);
+int aslp_matrix_randomizer_next(aslp_matrix_randomizer_t r);
+/* state[0..2] = IsFull, Done, NumFrames */
+int aslp_matrix_randomizer_state(aslp_matrix_randomizer_t r, int state[3]);
+/* Value(): a view of the current minibatch rows inside the cache (valid until the next AddData / Randomize) */
+int aslp_matrix_randomizer_value(aslp_matrix_randomizer_t r, const float **dev, int *rows, int *cols, int *stride);
+
 #ifdef __cplusplus
 }
 #endif

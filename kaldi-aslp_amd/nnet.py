@@ -91,6 +91,65 @@ class Xent:
         return dict(zip(("frames", "correct", "loss", "entropy", "likelyhood"), list(st)))
 
 
+_sig("aslp_randomizer_mask_generate", _i, _i, _i, _i32p)
+_sig("aslp_matrix_randomizer_create", _i, _i, _i, C.POINTER(_H))
+_sig("aslp_matrix_randomizer_free", None, _H)
+_sig("aslp_matrix_randomizer_add_data", _i, _H, _vp, _i, _i, _i)
+_sig("aslp_matrix_randomizer_randomize", _i, _H, _i32p, _i)
+_sig("aslp_matrix_randomizer_next", _i, _H)
+_sig("aslp_matrix_randomizer_state", _i, _H, C.POINTER(_i))
+_sig("aslp_matrix_randomizer_value", _i, _H, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i))
+
+
+def randomizer_mask(size, seed=777):
+    """RandomizerMask::Generate (nnet-randomizer.cc:38-44); seed < 0 keeps the current rand() state"""
+    import numpy as np
+    out = np.empty(size, np.int32)
+    _ok(lib.aslp_randomizer_mask_generate(int(seed), int(size), out.ctypes.data_as(_i32p)))
+    return out
+
+
+class MatrixRandomizer:
+    """aslp-nnet/nnet-randomizer.h:67-102 on device memory"""
+
+    def __init__(self, randomizer_size=32768, minibatch_size=256):
+        self.h = _H()
+        _ok(lib.aslp_matrix_randomizer_create(randomizer_size, minibatch_size, C.byref(self.h)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib.aslp_matrix_randomizer_free(self.h)
+            self.h = None
+
+    def AddData(self, m):
+        _chk(m)
+        _ok(lib.aslp_matrix_randomizer_add_data(self.h, ptr(m), m.shape[0], m.shape[1], dim(m).stride))
+
+    def _state(self):
+        st = (_i * 3)()
+        _ok(lib.aslp_matrix_randomizer_state(self.h, st))
+        return st
+
+    def IsFull(self): return bool(self._state()[0])
+    def Done(self): return bool(self._state()[1])
+    def NumFrames(self): return int(self._state()[2])
+    def Next(self): _ok(lib.aslp_matrix_randomizer_next(self.h))
+
+    def Randomize(self, mask):
+        a = _i32arr(mask)
+        _ok(lib.aslp_matrix_randomizer_randomize(self.h, a, len(mask)))
+
+    def Value(self):
+        """copy of the current minibatch as a torch tensor (the C++ API returns a view)"""
+        p, r, c, s = _vp(), _i(), _i(), _i()
+        _ok(lib.aslp_matrix_randomizer_value(self.h, C.byref(p), C.byref(r), C.byref(c), C.byref(s)))
+        out = torch.empty(r.value, c.value, device="cuda")
+        from ._lib import MatrixDim
+        lib.aslp_copy_mat(ptr(out), MatrixDim(r.value, c.value, c.value), p, s.value)
+        check_error()
+        return out
+
+
 def _i32arr(v):
     return (C.c_int32 * max(1, len(v)))(*[int(x) for x in v])
 

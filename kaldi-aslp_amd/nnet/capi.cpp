@@ -5,6 +5,7 @@
 #include "aslp_nnet.h"
 #include "nnet-loss.h"
 #include "nnet-nnet.h"
+#include "nnet-randomizer.h"
 #include "warp-ctc.h"
 
 using namespace aslp;
@@ -16,6 +17,9 @@ struct aslp_nnet_s {
 };
 struct aslp_xent_s {
   Xent xent;
+};
+struct aslp_matrix_randomizer_s {
+  MatrixRandomizer r;
 };
 struct aslp_warpctc_s {
   WarpCtc ctc;
@@ -269,6 +273,48 @@ int aslp_nnet_train_step_warpctc(aslp_nnet_t n, aslp_warpctc_t w, const float *i
   w->ctc.Eval(utt, frames, n->out, labels, &n->diff);
   w->ctc.ErrorRate(frames, n->out, labels);
   n->nnet.Backpropagate(n->diff, NULL);
+  API_END
+}
+
+int aslp_randomizer_mask_generate(int seed, int size, int32_t *mask_host) {
+  API_BEGIN
+  RandomizerMask m;
+  if (seed >= 0) srand(seed);
+  const std::vector<int32> &v = m.Generate(size);
+  std::memcpy(mask_host, v.data(), sizeof(int32) * size);
+  API_END
+}
+int aslp_matrix_randomizer_create(int randomizer_size, int minibatch_size, aslp_matrix_randomizer_t *out) {
+  API_BEGIN
+  NnetDataRandomizerOptions c;
+  c.randomizer_size = randomizer_size;
+  c.minibatch_size = minibatch_size;
+  aslp_matrix_randomizer_s *h = new aslp_matrix_randomizer_s();
+  h->r.Init(c);
+  *out = h;
+  API_END
+}
+void aslp_matrix_randomizer_free(aslp_matrix_randomizer_t r) { delete r; }
+int aslp_matrix_randomizer_add_data(aslp_matrix_randomizer_t r, const float *dev, int rows, int cols, int stride) {
+  API_BEGIN
+  r->r.AddData(CuSubMatrix(const_cast<float *>(dev), rows, cols, stride));
+  API_END
+}
+int aslp_matrix_randomizer_randomize(aslp_matrix_randomizer_t r, const int32_t *mask_host, int n) {
+  API_BEGIN
+  r->r.Randomize(std::vector<int32>(mask_host, mask_host + n));
+  API_END
+}
+int aslp_matrix_randomizer_next(aslp_matrix_randomizer_t r) { API_BEGIN r->r.Next(); API_END }
+int aslp_matrix_randomizer_state(aslp_matrix_randomizer_t r, int state[3]) {
+  API_BEGIN
+  state[0] = r->r.IsFull(); state[1] = r->r.Done(); state[2] = r->r.NumFrames();
+  API_END
+}
+int aslp_matrix_randomizer_value(aslp_matrix_randomizer_t r, const float **dev, int *rows, int *cols, int *stride) {
+  API_BEGIN
+  const CuMatrixBase &m = r->r.Value();
+  *dev = m.Data(); *rows = m.NumRows(); *cols = m.NumCols(); *stride = m.Stride();
   API_END
 }
 

@@ -1,0 +1,156 @@
+// nnet-randomizer.h -- frame-level shuffling caches of the training tools
+// (src/aslp-nnet/nnet-randomizer.{h,cc}): RandomizerMask, MatrixRandomizer, VectorRandomizer,
+// StdVectorRandomizer<T>.  Same interface and cache semantics (left-over rows move to the front,
+// +1000-row growth, IsFull / Done / NumFrames) as the reference, whose unit test
+// (nnet-randomizer-test.cc) is mirrored in tests/test_randomizer_gpu.py.
+// Mechanism differences on the device side: Randomize() gathers into a second buffer and swaps
+// (the reference first copies the whole cache, nnet-randomizer.cc:78), and Value() returns a view
+// of the cache rows instead of copying the minibatch out (:93-98).
+#pragma once
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
+
+#include "cu-matrix.h"
+
+namespace aslp {
+
+struct NnetDataRandomizerOptions {  // nnet-randomizer.h:34-50
+  int32 randomizer_size, randomizer_seed, minibatch_size;
+  NnetDataRandomizerOptions() : randomizer_size(32768), randomizer_seed(777), minibatch_size(256) {}
+};
+
+class RandomizerMask {  // :53-64
+ public:
+  RandomizerMask() {}
+  explicit RandomizerMask(const NnetDataRandomizerOptions &conf) { Init(conf); }
+  void Init(const NnetDataRandomizerOptions &conf) {
+    ASLP_LOG << "Seeding by srand with : " << conf.randomizer_seed;
+    srand(conf.randomizer_seed);
+  }
+  // std::random_shuffle(begin, end) with the C library generator, written out (libstdc++
+  // stl_algo.h: for i in [1, n): swap(v[i], v[rand() % (i + 1)])) because the algorithm left the
+  // standard in C++17; the order is part of the reference's reproducibility contract.
+  const std::vector<int32> &Generate(int32 mask_size) {
+    mask_.resize(mask_size);
+    for (int32 i = 0; i < mask_size; i++) mask_[i] = i;
+    for (int32 i = 1; i < mask_size; i++) {
+      int32 j = std::rand() % (i + 1);
+      if (i != j) std::swap(mask_[i], mask_[j]);
+    }
+    return mask_;
+  }
+
+ private:
+  std::vector<int32> mask_;
+};
+
+// shared cache bookkeeping (data_begin_/data_end_ arithmetic of nnet-randomizer.cc:47-71)
+class RandomizerBase {
+ public:
+  RandomizerBase() : data_begin_(0), data_end_(0) {}
+  void Init(const NnetDataRandomizerOptions &conf) { conf_ = conf; }
+  bool IsFull() { return ((data_begin_ == 0) && (data_end_ > conf_.randomizer_size)); }
+  int32 NumFrames() { return data_end_; }
+  bool Done() { return (data_end_ - data_begin_ < conf_.minibatch_size); }
+  void Next() { data_begin_ += conf_.minibatch_size; }
+
+ protected:
+  // returns the number of left-over rows that have to move to the front (0: nothing to move)
+  int32 BeginRefill() {
+    if (data_begin_ == 0) return 0;
+    ASLP_ASSERT(data_begin_ <= data_end_);
+    const int32 leftover = data_end_ - data_begin_;
+    ASLP_ASSERT(leftover < data_begin_);  // no overlap
+    return leftover;
+  }
+  void CheckRandomize(size_t mask_size) const {
+    ASLP_ASSERT(data_begin_ == 0);
+    ASLP_ASSERT(data_end_ > 0);
+    ASLP_ASSERT(data_end_ == (int32)mask_size);
+  }
+  void CheckValue() const { ASLP_ASSERT(data_end_ - data_begin_ >= conf_.minibatch_size); }
+  NnetDataRandomizerOptions conf_;
+  int32 data_begin_, data_end_;
+};
+
+class MatrixRandomizer : public RandomizerBase {  // :67-102
+ public:
+  MatrixRandomizer() : minibatch_(nullptr, 0, 0, 0) {}
+  explicit MatrixRandomizer(const NnetDataRandomizerOptions &conf) : minibatch_(nullptr, 0, 0, 0) { Init(conf); }
+  void AddData(const CuMatrixBase &m) {  // nnet-randomizer.cc:47-71
+    if (data_.NumCols() == 0) data_.Resize(conf_.randomizer_size, m.NumCols());
+    if (data_begin_ > 0) {
+      const int32 leftover = BeginRefill();
+      if (leftover > 0) data_.RowRange(0, leftover).CopyFromMat(data_.RowRange(data_begin_, leftover));
+      data_begin_ = 0;
+      data_end_ = leftover;
+      data_.RowRange(leftover, data_.NumRows() - leftover).SetZero();
+    }
+    if (data_.NumRows() < data_end_ + m.NumRows()) {
+      CuMatrix data_aux(data_);
+      data_.Resize(data_end_ + m.NumRows() + 1000, data_.NumCols());
+      data_.RowRange(0, data_aux.NumRows()).CopyFromMat(data_aux);
+    }
+    data_.RowRange(data_end_, m.NumRows()).CopyFromMat(m);
+    data_end_ += m.NumRows();
+  }
+  void Randomize(const std::vector<int32> &mask) {  // :73-88
+    CheckRandomize(mask.size());
+    mask_dev_.CopyFromVec(mask);
+    if (data_aux_.NumRows() != data_.NumRows() || data_aux_.NumCols() != data_.NumCols())
+      data_aux_.Resize(data_.NumRows(), data_.NumCols(), kUndefined);
+    cu::Randomize(data_, mask_dev_, &data_aux_);  // rows [0, mask.size()); rows beyond hold no frames
+    data_.Swap(&data_aux_);
+  }
+  const CuMatrixBase &Value() {  // :93-98
+    CheckValue();
+    minibatch_ = CuSubMatrix(data_, data_begin_, conf_.minibatch_size, 0, data_.NumCols());
+    return minibatch_;
+  }
+
+ private:
+  CuMatrix data_, data_aux_;
+  CuArray<int32> mask_dev_;
+  CuSubMatrix minibatch_;
+};
+
+// host-side caches share one implementation (VectorRandomizer :105-140 is the float instance,
+// Int32VectorRandomizer / PosteriorRandomizer :143-180 the std::vector<T> ones)
+template <typename T>
+class StdVectorRandomizer : public RandomizerBase {
+ public:
+  StdVectorRandomizer() {}
+  explicit StdVectorRandomizer(const NnetDataRandomizerOptions &conf) { Init(conf); }
+  void AddData(const std::vector<T> &v) {  // nnet-randomizer.cc:150-173
+    if (data_.size() == 0) data_.resize(conf_.randomizer_size);
+    if (data_begin_ > 0) {
+      const int32 leftover = BeginRefill();
+      if (leftover > 0) std::copy(data_.begin() + data_begin_, data_.begin() + data_begin_ + leftover, data_.begin());
+      data_begin_ = 0;
+      data_end_ = leftover;
+    }
+    if (data_.size() < data_end_ + v.size()) data_.resize(data_end_ + v.size() + 1000);
+    std::copy(v.begin(), v.end(), data_.begin() + data_end_);
+    data_end_ += v.size();
+  }
+  void Randomize(const std::vector<int32> &mask) {  // :175-187
+    CheckRandomize(mask.size());
+    std::vector<T> data_aux(data_);
+    for (size_t i = 0; i < mask.size(); i++) data_.at(i) = data_aux.at(mask.at(i));
+  }
+  const std::vector<T> &Value() {  // :194-201
+    CheckValue();
+    minibatch_.resize(conf_.minibatch_size);
+    std::copy(data_.begin() + data_begin_, data_.begin() + data_begin_ + conf_.minibatch_size, minibatch_.begin());
+    return minibatch_;
+  }
+
+ private:
+  std::vector<T> data_, minibatch_;
+};
+
+typedef StdVectorRandomizer<BaseFloat> VectorRandomizer;
+typedef StdVectorRandomizer<int32> Int32VectorRandomizer;
+
+}  // namespace aslp

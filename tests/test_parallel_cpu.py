@@ -1,0 +1,180 @@
+"""World-size-2 (and 3) protocol tests of the model-sync workers (kaldi-aslp_amd/parallel.py) on the
+gloo backend with CPU tensors: same code path as the RCCL one (backend "nccl"), only the tensors'
+device differs.  Expected values are the closed forms of the reference's update rules
+(src/aslp-parallel/bsp-worker.cc:33-65, bmuf-worker.cc:37-68, easgd-worker.cc:37-67,
+easgd-server.cc:63-86, mpi-node.h:77-93), evaluated with numpy in the parent process."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _load_parallel():
+    """parallel.py has no dependency on the HIP library: load it on its own for CPU-only runs"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("aslp_parallel", os.path.join(ROOT, "kaldi-aslp_amd", "parallel.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _init(rank, world, port):
+    torch.set_num_threads(1)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+def _make_params(rank, shapes, seed=0):
+    g = torch.Generator().manual_seed(seed * 100 + rank)
+    return [torch.randn(*s, generator=g) for s in shapes]
+
+
+SHAPES = [(7, 5), (5,), (3, 4), (1,)]
+
+
+def _bsp_proc(rank, world, port, out):
+    _init(rank, world, port)
+    P = _load_parallel()
+    params = _make_params(rank, SHAPES)
+    w = P.BspWorker(params)
+    res = []
+    # round 1: unequal counts; round 2: rank 1 has run out of data (n = 0) but keeps participating
+    counts = [(300, 100), (256, 0)]
+    for r, c in enumerate(counts):
+        ok = w.Synchronize(c[rank])
+        res.append((ok, [p.clone().numpy() for p in params]))
+        for p in params:  # local "training" between syncs
+            p.add_(0.1 * (rank + 1) * (r + 1))
+    # everybody out of data: the drain loop ends on a global count of 0
+    w.Stop()
+    res.append((w.Synchronize(0), None))
+    out[rank] = res
+    dist.destroy_process_group()
+
+
+def test_bsp_world2():
+    world, port = 2, _free_port()
+    with mp.Manager() as man:
+        out = man.dict()
+        mp.spawn(_bsp_proc, args=(world, port, out), nprocs=world, join=True)
+        out = dict(out)
+    p0, p1 = [[t.numpy() for t in _make_params(r, SHAPES)] for r in range(2)]
+    # round 1: theta = (300 th0 + 100 th1) / 400 on both ranks
+    want1 = [(np.float32(300 / 400) * a + np.float32(100 / 400) * b) for a, b in zip(p0, p1)]
+    for r in range(2):
+        ok, got = out[r][0]
+        assert ok
+        for g, w in zip(got, want1):
+            np.testing.assert_allclose(g, w, rtol=1e-6, atol=1e-6)
+    # round 2: rank 1 contributes a zero-scaled model, everyone gets rank 0's
+    w0 = [w + np.float32(0.1) for w in want1]
+    for r in range(2):
+        ok, got = out[r][1]
+        assert ok
+        for g, w in zip(got, w0):
+            np.testing.assert_allclose(g, w, rtol=1e-6, atol=1e-6)
+    assert out[0][2][0] is False and out[1][2][0] is False
+
+
+def _bmuf_proc(rank, world, port, out):
+    _init(rank, world, port)
+    P = _load_parallel()
+    params = _make_params(0, SHAPES)  # all ranks start from the same model, like the reference
+    w = P.BmufWorker(params, learn_rate=1.0, momentum=0.75)
+    res = []
+    for r in range(2):
+        for p in params:
+            p.add_(0.01 * (rank + 1) * (r + 1))  # local progress
+        w.Synchronize(10)
+        res.append([p.clone().numpy() for p in params])
+    out[rank] = res
+    dist.destroy_process_group()
+
+
+def test_bmuf_world2():
+    world, port = 2, _free_port()
+    with mp.Manager() as man:
+        out = man.dict()
+        mp.spawn(_bmuf_proc, args=(world, port, out), nprocs=world, join=True)
+        out = dict(out)
+    m, lr = 0.75, 1.0
+    base = [t.numpy() for t in _make_params(0, SHAPES)]
+    # step 1: g = sum_k (w_k - w_g) = 0.01 + 0.02; d = (1-m) lr g; w = w_g + d   (sum, not mean: bmuf-worker.cc:49)
+    d1 = (1 - m) * lr * 0.03
+    # step 2: local progress 0.02 / 0.04 on top of w_g(1) -> g = 0.06; d = m d1 + (1-m) lr g
+    d2 = m * d1 + (1 - m) * lr * 0.06
+    for r in range(2):
+        for g, b in zip(out[r][0], base):
+            np.testing.assert_allclose(g, b + d1, rtol=1e-5, atol=1e-6)
+        for g, b in zip(out[r][1], base):
+            np.testing.assert_allclose(g, b + d1 + d2, rtol=1e-5, atol=1e-6)
+
+
+def _easgd_proc(rank, world, port, out):
+    _init(rank, world, port)
+    P = _load_parallel()
+    params = _make_params(rank, SHAPES, seed=3)
+    if rank == 0:
+        s = P.EasgdServer(params, alpha=0.5)
+        s.Run()
+        out[rank] = [p.clone().numpy() for p in params]
+    else:
+        w = P.EasgdWorker(params, alpha=0.5)
+        w.Synchronize()
+        w.Stop()
+        out[rank] = [p.clone().numpy() for p in params]
+    dist.destroy_process_group()
+
+
+def test_easgd_server_and_one_worker():
+    world, port = 2, _free_port()
+    with mp.Manager() as man:
+        out = man.dict()
+        mp.spawn(_easgd_proc, args=(world, port, out), nprocs=world, join=True)
+        out = dict(out)
+    s0, w0 = [[t.numpy() for t in _make_params(r, SHAPES, seed=3)] for r in range(2)]
+    # both sides move half-way toward the other's PRE-exchange value (easgd-worker.cc:52-60, easgd-server.cc:75-83)
+    for g, a, b in zip(out[0], s0, w0):
+        np.testing.assert_allclose(g, 0.5 * a + 0.5 * b, rtol=1e-6, atol=1e-6)
+    for g, a, b in zip(out[1], s0, w0):
+        np.testing.assert_allclose(g, 0.5 * b + 0.5 * a, rtol=1e-6, atol=1e-6)
+
+
+def _accstat_proc(rank, world, port, out):
+    _init(rank, world, port)
+    P = _load_parallel()
+    node = P.MpiNodeLike()
+    data = [torch.full((4,), float(rank + 1), dtype=torch.float64), torch.arange(3, dtype=torch.float64) * (rank + 1)]
+    counts = node.ReduceAccStat([100.0 * (rank + 1), 7.0], data)
+    out[rank] = (counts, [d.numpy() for d in data], node.Rank(), node.NumNodes(), node.IsMainNode())
+    dist.destroy_process_group()
+
+
+def test_reduce_acc_stat_world2():
+    world, port = 2, _free_port()
+    with mp.Manager() as man:
+        out = man.dict()
+        mp.spawn(_accstat_proc, args=(world, port, out), nprocs=world, join=True)
+        out = dict(out)
+    for r in range(2):
+        counts, data, rank, n, main = out[r]
+        assert counts == [300.0, 14.0]
+        np.testing.assert_array_equal(data[0], np.full(4, 3.0))
+        np.testing.assert_array_equal(data[1], np.arange(3) * 3.0)
+        assert rank == r and n == 2 and main == (r == 0)
