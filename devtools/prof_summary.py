@@ -39,8 +39,9 @@ if pm:
         d[short(kn)][cn] += v
     for kn, in set((short(k),) for k, _, _ in pm):
         cnt[kn] = len(set(r[0] for r in c.execute("select dispatch_id from counters_collection where kernel_name like ?", (kn[:40] + "%",))))
-    print("\nPMC counters (summed over dispatches):")
-    for kn, cs in d.items():
-        print(kn)
+    print("\nPMC counters (sum over dispatches; per-dispatch average uses the dispatch count of the kernel trace):")
+    for kn, cs in sorted(d.items(), key=lambda kv: -agg[kv[0]][1] if kv[0] in agg else 0):
+        n = agg[kn][0] if kn in agg else 0
+        print("%s   [%d dispatches, avg %.2f us]" % (kn, n, agg[kn][1] / 1e3 / n if n else 0.0))
         for cn, v in sorted(cs.items()):
-            print("    %-32s %18.0f" % (cn, v))
+            print("    %-32s %18.0f   per-dispatch %14.1f" % (cn, v, v / n if n else 0.0))
