@@ -63,6 +63,14 @@ int get_warpctc_version(void);
 ctcStatus_t aslp_ctc_loss_strided(const float *acts, int ld_acts, float *grads, int ld_grads, const int *flat_labels,
                                   const int *label_lengths, const int *input_lengths, int alphabet_size, int minibatch, float *costs);
 
+
+/* Eesen CTC on POST-softmax outputs (Ctc::EvalParallel, aslp-nnet/ctc-loss.cc:115-227; kernels
+ * aslp-cudamatrix/cu-kernels.cu:3276-3534): diff rows of frames t < frame_num[n] receive y - posterior (the
+ * unclipped value the reference forms before its loss check), others are left untouched;
+ * pzx_host[n] = log p(z|x) (-1e30 = the reference's log_zero_ when there is no alignment). */
+ctcStatus_t aslp_eesen_ctc_mseq(const float *net_out, int ld, float *diff, int ld_diff, const int *flat_labels, const int *label_lengths,
+                                const int *frame_num, int alphabet_size, int minibatch, float *pzx_host);
+
 #ifdef __cplusplus
 }
 #endif

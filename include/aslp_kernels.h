@@ -197,6 +197,24 @@ void aslp_rowconv_backward(float *in_diff, int ldid, const float *out_diff, int 
                            const int32_cuda *seq_len);
 void aslp_rowconv_wgrad(float *w_diff, const float *in, int ldi, const float *out_diff, int ldod, int D, int K, int T, int S,
                         const int32_cuda *seq_len);
+/* ---- Eesen CTC rows (cu-kernels-ansi.h:366-394; device code cu-kernels.cu:3276-3534) -----------------------
+ * One lattice row per launch, log domain with log_zero = -1e30 (ctc-utils.h:28-95); `prob` holds LOG
+ * probabilities for alpha/beta and probabilities for error; labels are blank-augmented, -1 padded. */
+void cudaF_compute_ctc_alpha(aslp_dim3 Gr, aslp_dim3 Bl, float *alpha, int row_idx, MatrixDim dim_alpha, const float *prob, MatrixDim dim_prob,
+                             const int *labels);
+void cudaF_compute_ctc_beta(aslp_dim3 Gr, aslp_dim3 Bl, float *beta, int row_idx, MatrixDim dim_beta, const float *prob, MatrixDim dim_prob,
+                            const int *labels);
+void cudaF_compute_ctc_error(aslp_dim3 Gr, aslp_dim3 Bl, float *error, MatrixDim dim_error, const float *alpha, const float *beta,
+                             MatrixDim dim_alpha, const float *prob, const int *labels, float pzx);
+void cudaF_compute_ctc_alpha_multiple_sequence(aslp_dim3 Gr, aslp_dim3 Bl, float *alpha, int seq_num, int row_idx, MatrixDim dim_alpha,
+                                               const float *prob, MatrixDim dim_prob, const int *labels, int dim_label_stride,
+                                               const int *seq_lengths);
+void cudaF_compute_ctc_beta_multiple_sequence(aslp_dim3 Gr, aslp_dim3 Bl, float *beta, int seq_num, int row_idx, MatrixDim dim_beta,
+                                              const float *prob, MatrixDim dim_prob, const int *labels, int dim_label_stride,
+                                              const int *seq_lengths, const int *label_lengths);
+void cudaF_compute_ctc_error_multiple_sequence(aslp_dim3 Gr, aslp_dim3 Bl, float *error, int seq_num, MatrixDim dim_error, const float *alpha,
+                                               const float *beta, MatrixDim dim_alpha, const float *prob, const int *labels,
+                                               int dim_label_stride, const int *seq_lengths, const float *pzx);
 /* max-norm row shrink (nnet-affine-transform.h:231-243) */
 void aslp_max_norm_rows(float *W, MatrixDim d, float max_norm);
 

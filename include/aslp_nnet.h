@@ -92,6 +92,18 @@ int aslp_warpctc_get_stats(aslp_warpctc_t w, double stats[5]);
 int aslp_nnet_train_step_warpctc(aslp_nnet_t n, aslp_warpctc_t w, const float *in, int rows, int cols, int stride,
                                  const int32_t *frame_num_utt, int num_utt, const int32_t *flat_labels, const int32_t *label_lengths);
 
+/* ---- Ctc (Eesen-style, aslp-nnet/ctc-loss.h:39-124): input is the Softmax output ------------------------ */
+typedef struct aslp_eesenctc_s *aslp_eesenctc_t;
+int aslp_eesenctc_create(aslp_eesenctc_t *out);
+void aslp_eesenctc_free(aslp_eesenctc_t c);
+/* Ctc::EvalParallel (ctc-loss.cc:115); num_utt == 1 with frame_num_utt == NULL selects Ctc::Eval (:31) */
+int aslp_eesenctc_eval(aslp_eesenctc_t c, const int32_t *frame_num_utt, int num_utt, const float *net_out, int rows, int cols, int stride,
+                       const int32_t *flat_labels, const int32_t *label_lengths, float *diff, int diff_stride, float *costs_host);
+int aslp_eesenctc_error_rate(aslp_eesenctc_t c, const int32_t *frame_num_utt, int num_utt, const float *net_out, int rows, int cols, int stride,
+                             const int32_t *flat_labels, const int32_t *label_lengths);
+int aslp_eesenctc_report(aslp_eesenctc_t c, char *buf, int buflen);
+int aslp_eesenctc_get_stats(aslp_eesenctc_t c, double stats[5]);   /* obj, frames, sequences, error_tokens, ref_tokens */
+
 /* ---- frame shuffling cache (aslp-nnet/nnet-randomizer.h:53-102) --------------------------------- */
 typedef struct aslp_matrix_randomizer_s *aslp_matrix_randomizer_t;
 /* RandomizerMask::Init + Generate: srand(seed) when seed >= 0, then a permutation of [0, size) in the order

@@ -13,4 +13,4 @@ from . import _lib  # noqa: F401  (raises if libaslp_hip.so is absent)
 from ._lib import lib, MatrixDim, Dim3, check_error  # noqa: F401
 from . import ops  # noqa: F401
 from . import nnet  # noqa: F401
-from .nnet import Nnet, Xent, WarpCtc, MatrixRandomizer, randomizer_mask  # noqa: F401
+from .nnet import Nnet, Xent, WarpCtc, Ctc, MatrixRandomizer, randomizer_mask  # noqa: F401

@@ -40,7 +40,7 @@ struct UttInfo {
 // ---- alpha --------------------------------------------------------------------------------------------
 // LDS: two alpha columns + the blank-augmented label sequence.
 __global__ void __launch_bounds__(256) ctc_alpha_kernel(const float *__restrict__ probs, float *__restrict__ alphas, const UttInfo *info,
-                                                        const int *__restrict__ lwb_all, int A, int mb, int maxS, int maxT, float *loglike) {
+                                                        const int *__restrict__ lwb_all, int A, int mb, int maxS, int maxT, float *loglike, int ldp) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n = blockIdx.x;
   const UttInfo u = info[n];
@@ -53,8 +53,8 @@ __global__ void __launch_bounds__(256) ctc_alpha_kernel(const float *__restrict_
   int *lab = reinterpret_cast<int *>(smem + 2 * maxS);
   for (int s = threadIdx.x; s < S; s += blockDim.x) lab[s] = lwb_all[u.lab_off + s];
   __syncthreads();
-  const float *p = probs + (long)n * A;  // time stride A*mb
-  const long tstride = (long)A * mb;
+  const float *p = probs + (long)n * ldp;  // time stride ldp*mb
+  const long tstride = (long)ldp * mb;
   float *al = alphas + (long)n * maxS * maxT;
   for (int s = threadIdx.x; s < S; s += blockDim.x) {
     float v = s < 2 ? logf(p[lab[s]]) : kNegInf;
@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(256) ctc_alpha_kernel(const float *__restrict_
 __global__ void __launch_bounds__(256) ctc_beta_grad_kernel(const float *__restrict__ probs, const float *__restrict__ alphas, float *__restrict__ grads,
                                                             const UttInfo *info, const int *__restrict__ lwb_all, const int *__restrict__ next_all,
                                                             const int *__restrict__ first_all, int A, int mb, int maxS, int maxT,
-                                                            const float *loglike, int ldg) {
+                                                            const float *loglike, int ldg, int ldp) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n = blockIdx.x;
   const UttInfo u = info[n];
@@ -109,8 +109,8 @@ __global__ void __launch_bounds__(256) ctc_beta_grad_kernel(const float *__restr
   }
   __syncthreads();
   const float logZ = loglike[n];
-  const long tstride = (long)A * mb;
-  const float *p = probs + (long)n * A;
+  const long tstride = (long)ldp * mb;
+  const float *p = probs + (long)n * ldp;
   float *g = grads + (long)n * ldg;
   const long gstride = (long)ldg * mb;
   const float *al = alphas + (long)n * maxS * maxT;
@@ -225,7 +225,7 @@ ctcStatus_t get_workspace_size(const int *const label_lengths, const int *const 
 
 static ctcStatus_t ctc_loss_impl(const float *const activations, int ld_acts, float *gradients, int ld_grads, const int *const flat_labels,
                                  const int *const label_lengths, const int *const input_lengths, int A, int mb, float *costs, void *workspace,
-                                 struct ctcComputeInfo cinfo) {
+                                 struct ctcComputeInfo cinfo, bool acts_are_probs = false) {
   if (activations == nullptr || flat_labels == nullptr || label_lengths == nullptr || input_lengths == nullptr || costs == nullptr ||
       workspace == nullptr || A <= 0 || mb <= 0)
     return CTC_STATUS_INVALID_VALUE;  // ctc_entrypoint.cpp:46-54
@@ -283,7 +283,13 @@ static ctcStatus_t ctc_loss_impl(const float *const activations, int ld_acts, fl
   hipStream_t saved = cur_stream();
   set_cur_stream(stream);
   MatrixDim d = {maxT * mb, A, A};
-  if (maxT > 0) cudaF_softmax_reduce(0, 0, probs, activations, d, ld_acts);
+  int ldp = A;
+  if (acts_are_probs) {  // Eesen convention: the caller already ran the Softmax component
+    probs = const_cast<float *>(activations);
+    ldp = ld_acts;
+  } else if (maxT > 0) {
+    cudaF_softmax_reduce(0, 0, probs, activations, d, ld_acts);
+  }
   set_cur_stream(saved);
 
   const size_t lds_alpha = sizeof(float) * 2 * maxS + sizeof(int) * maxS;
@@ -295,10 +301,10 @@ static ctcStatus_t ctc_loss_impl(const float *const activations, int ld_acts, fl
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ctc_beta_grad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  hipLaunchKernelGGL(ctc_alpha_kernel, dim3(mb), dim3(256), lds_alpha, stream, probs, alphas, d_info, d_lwb, A, mb, maxS, maxT > 0 ? maxT : 1, d_ll);
+  hipLaunchKernelGGL(ctc_alpha_kernel, dim3(mb), dim3(256), lds_alpha, stream, probs, alphas, d_info, d_lwb, A, mb, maxS, maxT > 0 ? maxT : 1, d_ll, ldp);
   if (gradients != nullptr)
     hipLaunchKernelGGL(ctc_beta_grad_kernel, dim3(mb), dim3(256), lds_beta, stream, probs, alphas, gradients, d_info, d_lwb, d_nxt, d_fst, A, mb,
-                       maxS, maxT > 0 ? maxT : 1, d_ll, ld_grads);
+                       maxS, maxT > 0 ? maxT : 1, d_ll, ld_grads, ldp);
   hipLaunchKernelGGL(neg_costs_kernel, dim3((mb + 255) / 256), dim3(256), 0, stream, d_ll, d_info, d_costs, mb);
   if (hipGetLastError() != hipSuccess) return CTC_STATUS_EXECUTION_FAILED;
   if (hipMemcpyAsync(costs, d_costs, sizeof(float) * mb, hipMemcpyDeviceToHost, stream) != hipSuccess) return CTC_STATUS_MEMOPS_FAILED;
@@ -327,6 +333,37 @@ ctcStatus_t aslp_ctc_loss_strided(const float *acts, int ld_acts, float *grads, 
   void *ws = scratch(kScratchCtc, bytes);
   if (!ws) return CTC_STATUS_MEMOPS_FAILED;
   return ctc_loss_impl(acts, ld_acts, grads, ld_grads, flat_labels, label_lengths, input_lengths, A, mb, costs, ws, info);
+}
+
+// Eesen-style objective (Ctc::EvalParallel, aslp-nnet/ctc-loss.cc:115-227): `net_out` are POST-softmax
+// probabilities; diff = y - posterior for frames t < frame_num[n] (the reference forms it as
+// err.*y - y*rowsum(err.*y) from 2T per-row kernel launches plus an O(T*A*(2L+1)) error kernel,
+// cu-kernels.cu:3276-3534), untouched elsewhere; pzx_host[n] = log p(z|x), -1e30 (the reference's
+// log_zero_) when no alignment exists.  Same lattice kernels as compute_ctc_loss.
+ctcStatus_t aslp_eesen_ctc_mseq(const float *net_out, int ld, float *diff, int ld_diff, const int *flat_labels, const int *label_lengths,
+                                const int *frame_num, int A, int mb, float *pzx_host) {
+  if (ld < A || ld_diff < A || diff == nullptr) return CTC_STATUS_INVALID_VALUE;
+  struct ctcComputeInfo info;
+  info.loc = CTC_GPU;
+  info.stream = reinterpret_cast<CUstream>(cur_stream());
+  size_t bytes = 0;
+  ctcStatus_t st = get_workspace_size(label_lengths, frame_num, A, mb, info, &bytes);
+  if (st != CTC_STATUS_SUCCESS) return st;
+  void *ws = scratch(kScratchCtc, bytes);
+  if (!ws) return CTC_STATUS_MEMOPS_FAILED;
+  st = ctc_loss_impl(net_out, ld, diff, ld_diff, flat_labels, label_lengths, frame_num, A, mb, pzx_host, ws, info, true);
+  if (st != CTC_STATUS_SUCCESS) return st;
+  int off = 0;
+  for (int n = 0; n < mb; n++) {  // costs -> log-likelihoods; infeasible alignments are log_zero_
+    const int L = label_lengths[n];
+    int repeats = 0;
+    for (int i = 1; i < L; i++) repeats += flat_labels[off + i - 1] == flat_labels[off + i];
+    off += L;
+    const bool feasible = frame_num[n] > 0 && L + repeats <= frame_num[n];
+    pzx_host[n] = feasible ? -pzx_host[n] : -1e30f;
+    if (pzx_host[n] < -1e30f) pzx_host[n] = -1e30f;  // -inf (zero-probability path) is log_zero_ there
+  }
+  return CTC_STATUS_SUCCESS;
 }
 
 }  // extern "C"

@@ -91,6 +91,12 @@ class Xent:
         return dict(zip(("frames", "correct", "loss", "entropy", "likelyhood"), list(st)))
 
 
+_sig("aslp_eesenctc_create", _i, C.POINTER(_H))
+_sig("aslp_eesenctc_free", None, _H)
+_sig("aslp_eesenctc_eval", _i, _H, _i32p, _i, _vp, _i, _i, _i, _i32p, _i32p, _vp, _i, C.POINTER(_f))
+_sig("aslp_eesenctc_error_rate", _i, _H, _i32p, _i, _vp, _i, _i, _i, _i32p, _i32p)
+_sig("aslp_eesenctc_report", _i, _H, C.c_char_p, _i)
+_sig("aslp_eesenctc_get_stats", _i, _H, C.POINTER(C.c_double))
 _sig("aslp_randomizer_mask_generate", _i, _i, _i, _i32p)
 _sig("aslp_matrix_randomizer_create", _i, _i, _i, C.POINTER(_H))
 _sig("aslp_matrix_randomizer_free", None, _H)
@@ -199,6 +205,58 @@ class WarpCtc:
     def GetStats(self):
         st = (C.c_double * 5)()
         _ok(lib.aslp_warpctc_get_stats(self.h, st))
+        return dict(zip(("obj", "frames", "sequences", "error_tokens", "ref_tokens"), list(st)))
+
+
+class Ctc:
+    """aslp-nnet/ctc-loss.h:39 (Eesen-style): Eval / EvalParallel / ErrorRate[MSeq] / Report on Softmax outputs."""
+
+    def __init__(self):
+        self.h = _H()
+        _ok(lib.aslp_eesenctc_create(C.byref(self.h)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib.aslp_eesenctc_free(self.h)
+            self.h = None
+
+    def _eval(self, frame_num_utt, net_out, labels, diff):
+        import numpy as np
+        _chk(net_out)
+        if diff is None:
+            diff = torch.empty_like(net_out)
+        n = len(labels) if frame_num_utt is None else len(frame_num_utt)
+        fl, ll = _flat(labels[:n])
+        costs = np.zeros(n, np.float32)
+        _ok(lib.aslp_eesenctc_eval(self.h, None if frame_num_utt is None else _i32arr(frame_num_utt), n, ptr(net_out), net_out.shape[0],
+                                   net_out.shape[1], dim(net_out).stride, fl, ll, ptr(diff), dim(diff).stride,
+                                   costs.ctypes.data_as(C.POINTER(_f))))
+        return diff, costs
+
+    def Eval(self, net_out, label, diff=None):
+        return self._eval(None, net_out, [label], diff)
+
+    def EvalParallel(self, frame_num_utt, net_out, labels, diff=None):
+        return self._eval(frame_num_utt, net_out, labels, diff)
+
+    def ErrorRate(self, net_out, label):
+        fl, ll = _flat([label])
+        _ok(lib.aslp_eesenctc_error_rate(self.h, None, 1, ptr(net_out), net_out.shape[0], net_out.shape[1], dim(net_out).stride, fl, ll))
+
+    def ErrorRateMSeq(self, frame_num_utt, net_out, labels):
+        n = len(frame_num_utt)
+        fl, ll = _flat(labels[:n])
+        _ok(lib.aslp_eesenctc_error_rate(self.h, _i32arr(frame_num_utt), n, ptr(net_out), net_out.shape[0], net_out.shape[1],
+                                         dim(net_out).stride, fl, ll))
+
+    def Report(self):
+        buf = C.create_string_buffer(4096)
+        _ok(lib.aslp_eesenctc_report(self.h, buf, 4096))
+        return buf.value.decode()
+
+    def GetStats(self):
+        st = (C.c_double * 5)()
+        _ok(lib.aslp_eesenctc_get_stats(self.h, st))
         return dict(zip(("obj", "frames", "sequences", "error_tokens", "ref_tokens"), list(st)))
 
 

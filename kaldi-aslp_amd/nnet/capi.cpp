@@ -3,6 +3,7 @@
 #include <cstring>
 
 #include "aslp_nnet.h"
+#include "ctc-loss.h"
 #include "nnet-loss.h"
 #include "nnet-nnet.h"
 #include "nnet-randomizer.h"
@@ -20,6 +21,10 @@ struct aslp_xent_s {
 };
 struct aslp_matrix_randomizer_s {
   MatrixRandomizer r;
+};
+struct aslp_eesenctc_s {
+  Ctc ctc;
+  CuMatrix diff;
 };
 struct aslp_warpctc_s {
   WarpCtc ctc;
@@ -273,6 +278,52 @@ int aslp_nnet_train_step_warpctc(aslp_nnet_t n, aslp_warpctc_t w, const float *i
   w->ctc.Eval(utt, frames, n->out, labels, &n->diff);
   w->ctc.ErrorRate(frames, n->out, labels);
   n->nnet.Backpropagate(n->diff, NULL);
+  API_END
+}
+
+int aslp_eesenctc_create(aslp_eesenctc_t *out) { API_BEGIN *out = new aslp_eesenctc_s(); API_END }
+void aslp_eesenctc_free(aslp_eesenctc_t c) { delete c; }
+int aslp_eesenctc_eval(aslp_eesenctc_t c, const int32_t *frame_num_utt, int num_utt, const float *net_out, int rows, int cols, int stride,
+                       const int32_t *flat_labels, const int32_t *label_lengths, float *diff, int diff_stride, float *costs_host) {
+  API_BEGIN
+  CuSubMatrix y(const_cast<float *>(net_out), rows, cols, stride);
+  std::vector<std::vector<int32>> labels;
+  SplitLabels(flat_labels, label_lengths, num_utt, &labels);
+  if (frame_num_utt == NULL) {
+    ASLP_ASSERT(num_utt == 1);
+    c->ctc.Eval(y, labels[0], &c->diff);
+  } else {
+    std::vector<int32> frames(frame_num_utt, frame_num_utt + num_utt);
+    std::vector<std::string> utt(num_utt);
+    for (int i = 0; i < num_utt; i++) utt[i] = "utt" + std::to_string(i);
+    c->ctc.EvalParallel(utt, frames, y, labels, &c->diff);
+  }
+  CuSubMatrix o(diff, rows, cols, diff_stride);
+  o.CopyFromMat(c->diff);
+  if (costs_host) std::memcpy(costs_host, c->ctc.LastCosts().data(), sizeof(float) * num_utt);
+  API_END
+}
+int aslp_eesenctc_error_rate(aslp_eesenctc_t c, const int32_t *frame_num_utt, int num_utt, const float *net_out, int rows, int cols, int stride,
+                             const int32_t *flat_labels, const int32_t *label_lengths) {
+  API_BEGIN
+  CuSubMatrix y(const_cast<float *>(net_out), rows, cols, stride);
+  std::vector<std::vector<int32>> labels;
+  SplitLabels(flat_labels, label_lengths, num_utt, &labels);
+  if (frame_num_utt == NULL) {
+    float er;
+    std::vector<int32> hyp;
+    c->ctc.ErrorRate(y, labels[0], &er, &hyp);
+  } else {
+    std::vector<int32> frames(frame_num_utt, frame_num_utt + num_utt);
+    c->ctc.ErrorRateMSeq(frames, y, labels);
+  }
+  API_END
+}
+int aslp_eesenctc_report(aslp_eesenctc_t c, char *buf, int buflen) { API_BEGIN CopyStr(c->ctc.Report(), buf, buflen); API_END }
+int aslp_eesenctc_get_stats(aslp_eesenctc_t c, double stats[5]) {
+  API_BEGIN
+  stats[0] = c->ctc.Obj(); stats[1] = c->ctc.Frames(); stats[2] = c->ctc.Sequences();
+  stats[3] = c->ctc.NumErrorTokens(); stats[4] = c->ctc.NumRefTokens();
   API_END
 }
 

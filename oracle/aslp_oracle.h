@@ -179,6 +179,9 @@ typedef struct {   /* members of WarpCtc, warp-ctc.h:96-113 */
   int normal_num, stat_period /* 500 */, frames, sequences;
 } orc_ctc_filter_state;
 void orc_ctc_loss_filter(const float *costs, const int *frame_num, int mb, orc_ctc_filter_state *st, int *keep);
+void orc_eesen_ctc_mseq(const float *net_out, int ld, int T, int S, int A, const int *flat_labels, const int *label_lens,
+                        const int *frame_num, float *diff, int ldd, float *pzx);
+void orc_eesen_ctc_loss_filter(const float *costs, const int *frame_num, int mb, orc_ctc_filter_state *st, int *keep);
 int orc_ctc_token_errors(const float *net_out, int ld, int T, int A, const int *ref, int ref_len, int *hyp_len);
 
 #ifdef __cplusplus

@@ -244,3 +244,160 @@ int orc_ctc_token_errors(const float *net_out, int ld, int T, int A, const int *
   free(d);
   return res;
 }
+
+/* ---- Eesen CTC (Ctc::EvalParallel, aslp-nnet/ctc-loss.cc:115-227) --------------------------------------
+ * GPU-only in the reference: restated from the device kernels aslp-cudamatrix/cu-kernels.cu:3276-3534 and
+ * the log-domain helpers of ctc-utils.h:52-95 (float: log_zero = -1e30, exp_limit = 88.722839).
+ * PARITY UNPINNED on its own (no CPU path, no tests in the reference); cross-checked in
+ * tests/test_oracle_ctc_cpu.py against the pinned Warp-CTC restatement: the unclipped diff equals the
+ * Warp-CTC gradient on the pre-softmax activations and -pzx equals its cost. */
+#define E_LOG_ZERO (-1e30f)
+#define E_LOG_INF (1e30f)
+#define E_EXP_LIMIT (88.722839f)
+#define E_MAX (3.4028235e+038f)
+static float e_add(float a, float b) { return (a == E_LOG_ZERO || b == E_LOG_ZERO) ? E_LOG_ZERO : a + b; }
+static float e_sub(float a, float b) { return a == E_LOG_ZERO ? E_LOG_ZERO : (b == E_LOG_ZERO ? E_LOG_INF : a - b); }
+static float e_exp(float a) { return a <= E_LOG_ZERO ? 0.0f : (a >= E_EXP_LIMIT ? E_MAX : expf(a)); }
+static float e_logaddexp(float a, float b) {
+  if (b < a) return e_add(a, logf(1 + e_exp(e_sub(b, a))));
+  return e_add(b, logf(1 + e_exp(e_sub(a, b))));
+}
+static double e_logaddexp_d(double a, double b) { /* host call in double, ctc-loss.cc:176 (double limits -1e100 / 709.78) */
+  const double LZ = -1e100, LI = 1e100, EL = 709.78271289338397, MX = 1.7976931348623157e+308;
+#define DSUB(x, y) ((x) == LZ ? LZ : ((y) == LZ ? LI : (x) - (y)))
+#define DEXP(x) ((x) <= LZ ? 0.0 : ((x) >= EL ? MX : exp(x)))
+#define DADD(x, y) (((x) == LZ || (y) == LZ) ? LZ : (x) + (y))
+  if (b < a) return DADD(a, log(1 + DEXP(DSUB(b, a))));
+  return DADD(b, log(1 + DEXP(DSUB(a, b))));
+#undef DSUB
+#undef DEXP
+#undef DADD
+}
+
+/* net_out: softmax outputs [T*S x A] (row = t*S + s, leading dim ld); labels flat with label_lens[S];
+ * frame_num[S].  diff [T*S x A] (leading dim ldd) receives ctc_err .* y - y * rowsum(ctc_err .* y), UNclipped,
+ * zero rows past each utterance's end; pzx[S] receives log p(z|x). */
+void orc_eesen_ctc_mseq(const float *net_out, int ld, int T, int S, int A, const int *flat_labels, const int *label_lens,
+                        const int *frame_num, float *diff, int ldd, float *pzx) {
+  int maxL = 0;
+  for (int s = 0; s < S; s++)
+    if (label_lens[s] > maxL) maxL = label_lens[s];
+  const int E = 2 * maxL + 1;
+  int *lab = (int *)malloc(sizeof(int) * (size_t)S * E);
+  int *explen = (int *)malloc(sizeof(int) * S);
+  for (int i = 0; i < S * E; i++) lab[i] = -1;
+  int off = 0;
+  for (int s = 0; s < S; s++) {
+    explen[s] = 2 * label_lens[s] + 1;
+    for (int l = 0; l < label_lens[s]; l++) {
+      lab[s * E + 2 * l] = 0;
+      lab[s * E + 2 * l + 1] = flat_labels[off + l];
+    }
+    lab[s * E + 2 * label_lens[s]] = 0;
+    off += label_lens[s];
+  }
+  float *logp = (float *)malloc(sizeof(float) * (size_t)T * S * A);
+  for (int r = 0; r < T * S; r++)
+    for (int a = 0; a < A; a++) logp[(size_t)r * A + a] = logf(net_out[(size_t)r * ld + a]);
+  float *alpha = (float *)malloc(sizeof(float) * (size_t)T * S * E), *beta = (float *)malloc(sizeof(float) * (size_t)T * S * E);
+  for (size_t i = 0; i < (size_t)T * S * E; i++) alpha[i] = beta[i] = E_LOG_ZERO;
+  for (int t = 0; t < T; t++) /* _compute_ctc_alpha_multiple_sequence */
+    for (int s = 0; s < S; s++)
+      for (int j = 0; j < E; j++) {
+        float *a = alpha + ((size_t)t * S + s) * E + j;
+        const int cls = lab[s * E + j];
+        if (cls == -1 || t >= frame_num[s]) { *a = E_LOG_ZERO; continue; }
+        const float p = logp[((size_t)t * S + s) * A + cls];
+        const float *pa = alpha + ((size_t)(t - 1) * S + s) * E + j;
+        if (t == 0) *a = j < 2 ? p : E_LOG_ZERO;
+        else if (j > 1) {
+          if (j % 2 == 0 || lab[s * E + j - 2] == cls) *a = e_add(p, e_logaddexp(pa[-1], pa[0]));
+          else { float tmp = e_logaddexp(pa[-1], pa[0]); *a = e_add(p, e_logaddexp(pa[-2], tmp)); }
+        } else if (j == 1) *a = e_add(p, e_logaddexp(pa[-1], pa[0]));
+        else *a = e_add(p, pa[0]);
+      }
+  for (int t = T - 1; t >= 0; t--) /* _compute_ctc_beta_multiple_sequence */
+    for (int s = 0; s < S; s++)
+      for (int j = 0; j < E; j++) {
+        float *b = beta + ((size_t)t * S + s) * E + j;
+        const int cls = lab[s * E + j];
+        if (cls == -1 || t >= frame_num[s]) { *b = E_LOG_ZERO; continue; }
+        const float p = logp[((size_t)t * S + s) * A + cls];
+        const float *nb = beta + ((size_t)(t + 1) * S + s) * E + j;
+        const int LL = explen[s];
+        if (t == frame_num[s] - 1) *b = j > LL - 3 ? p : E_LOG_ZERO;
+        else if (j < LL - 2) {
+          if (j % 2 == 0 || lab[s * E + j + 2] == cls) *b = e_add(p, e_logaddexp(nb[1], nb[0]));
+          else { float tmp = e_logaddexp(nb[1], nb[0]); *b = e_add(p, e_logaddexp(nb[2], tmp)); }
+        } else if (j == LL - 2) *b = e_add(p, e_logaddexp(nb[1], nb[0]));
+        else *b = e_add(p, nb[0]);
+      }
+  for (int s = 0; s < S; s++) { /* ctc-loss.cc:169-177 */
+    const int LL = explen[s], fn = frame_num[s];
+    float tmp1 = alpha[((size_t)(fn - 1) * S + s) * E + LL - 1];
+    float tmp2 = LL >= 2 ? alpha[((size_t)(fn - 1) * S + s) * E + LL - 2] : E_LOG_ZERO;
+    pzx[s] = (float)e_logaddexp_d((double)tmp1, (double)tmp2);
+  }
+  for (int r = 0; r < T * S; r++) { /* _compute_ctc_error_multiple_sequence, then ctc-loss.cc:183-191 */
+    const int s = r % S, t = r / S;
+    float *d = diff + (size_t)r * ldd;
+    for (int a = 0; a < A; a++) d[a] = 0.0f;
+    if (t >= frame_num[s]) continue;
+    float rowsum = 0.0f;
+    for (int k = 0; k < A; k++) {
+      float err = E_LOG_ZERO;
+      for (int j = 0; j < E; j++) {
+        if (lab[s * E + j] == -1) continue;
+        if (lab[s * E + j] == k) err = e_logaddexp(err, e_add(alpha[(size_t)r * E + j], beta[(size_t)r * E + j]));
+      }
+      const float y = net_out[(size_t)r * ld + k];
+      float val = e_exp(e_sub(err, e_add(pzx[s], y == 0 ? E_LOG_ZERO : 2 * logf(y))));
+      float ce = -1.0f * val;
+      ce *= y; /* ctc_err_.MulElements(net_out) */
+      d[k] = ce;
+      rowsum += ce;
+    }
+    for (int k = 0; k < A; k++) d[k] += -1.0f * (net_out[(size_t)r * ld + k] * rowsum);
+  }
+  free(lab); free(explen); free(logp); free(alpha); free(beta);
+}
+
+/* Ctc::StatAndAverageLossCheck (ctc-loss.cc:229-302): like the WarpCtc one, but the warm-up phase also
+ * requires a finite cost in (0, 3000) -- and silently skips (without dropping the diff) when it is not. */
+void orc_eesen_ctc_loss_filter(const float *costs, const int *frame_num, int mb, orc_ctc_filter_state *st, int *keep) {
+  for (int s = 0; s < mb; s++) {
+    keep[s] = 1;
+    double loss_per_frame = costs[s] / frame_num[s];
+    if (st->normal_num < st->stat_period / 2) {
+      if (isfinite(costs[s]) && costs[s] > 0 && costs[s] < 3000) {
+        st->normal_num++;
+        st->loss_sum += loss_per_frame;
+        st->loss_sum_bak += loss_per_frame;
+        st->loss_square_sum += loss_per_frame * loss_per_frame;
+        st->loss_square_sum_bak += loss_per_frame * loss_per_frame;
+        st->obj += costs[s];
+      }
+    } else {
+      double mean = st->loss_sum / st->normal_num;
+      double sigma = sqrt(st->loss_square_sum / st->normal_num);
+      if (isfinite(costs[s]) && (loss_per_frame >= (mean - 6 * sigma) && loss_per_frame <= (mean + 6 * sigma)) &&
+          (costs[s] > 0 && costs[s] < 3000)) {
+        st->normal_num++;
+        st->loss_sum += loss_per_frame;
+        st->loss_square_sum += loss_per_frame * loss_per_frame;
+        st->obj += costs[s];
+        if (st->normal_num == st->stat_period) {
+          st->loss_sum -= st->loss_sum_bak;
+          st->loss_square_sum -= st->loss_square_sum_bak;
+          st->loss_sum_bak = st->loss_sum;
+          st->loss_square_sum_bak = st->loss_square_sum;
+          st->normal_num = st->stat_period / 2;
+        }
+      } else {
+        keep[s] = 0;
+      }
+    }
+    st->frames += frame_num[s];
+  }
+  st->sequences += mb;
+}

@@ -115,3 +115,47 @@ def test_token_error_and_loss_filter(oracle):
     assert fn(out, 4, 10, 4, np.array([1, 2, 3], np.int32), 3, C.byref(hl)) == 0 and hl.value == 3
     assert fn(out, 4, 10, 4, np.array([1, 3], np.int32), 2, C.byref(hl)) == 1
     assert fn(out, 4, 10, 4, np.array([2, 2, 2, 2], np.int32), 4, C.byref(hl)) == 3
+
+
+def orc_eesen(oracle, probs, labels, in_len, T, S, A):
+    fn = oracle.lib.orc_eesen_ctc_mseq
+    fn.restype = None
+    fn.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_int, i32p, i32p, i32p, f32p, C.c_int, f32p]
+    flat = np.array([v for l in labels for v in l] or [0], np.int32)
+    ll = np.array([len(l) for l in labels], np.int32)
+    diff = np.zeros((T * S, A), np.float32)
+    pzx = np.zeros(S, np.float32)
+    fn(np.ascontiguousarray(probs, np.float32), A, T, S, A, flat, ll, np.ascontiguousarray(in_len, np.int32), diff, A, pzx)
+    return diff, pzx
+
+
+@pytest.mark.parametrize("A,S,T,seed", [(5, 1, 6, 0), (12, 4, 15, 1), (40, 6, 30, 2)])
+def test_eesen_restatement_agrees_with_pinned_warpctc(oracle, A, S, T, seed):
+    """Ctc::EvalParallel (GPU-only in the reference) is the same objective as Warp-CTC on post-softmax
+    outputs: its unclipped diff is Warp-CTC's gradient w.r.t. the activations and -pzx its cost
+    (SURVEY.md 8c).  The Warp-CTC restatement is pinned to the reference's own code above."""
+    rng = np.random.default_rng(seed)
+    in_len = rng.integers(max(2, T // 2), T + 1, S).astype(np.int32)
+    in_len[0] = T
+    labels = []
+    for t in in_len:
+        L = int(rng.integers(1, max(2, t // 2)))
+        lab = rng.integers(1, A, L)
+        if L >= 3:
+            lab[1] = lab[2]  # a repeat
+        labels.append([int(v) for v in lab])
+    acts = (rng.standard_normal((T * S, A)) * 1.5).astype(np.float32)
+    e = np.exp(acts.astype(np.float64) - acts.max(1, keepdims=True))
+    probs = (e / e.sum(1, keepdims=True)).astype(np.float32)
+    flat = np.array([v for l in labels for v in l], np.int32)
+    ll = np.array([len(l) for l in labels], np.int32)
+    wcost, wgrad = orc_ctc(oracle, acts.reshape(-1).copy(), flat, ll, in_len, A, S)
+    diff, pzx = orc_eesen(oracle, probs, labels, in_len, T, S, A)
+    feas = np.array([len(l) + sum(a == b for a, b in zip(l, l[1:])) <= t for l, t in zip(labels, in_len)])
+    assert np.allclose(-pzx[feas], wcost[feas], rtol=1e-4, atol=1e-4)
+    wg = wgrad.reshape(T, S, A)
+    dg = diff.reshape(T, S, A)
+    for s in range(S):
+        if feas[s]:
+            assert np.abs(dg[:in_len[s], s] - wg[:in_len[s], s]).max() < 2e-4
+        assert np.all(dg[in_len[s]:, s] == 0)
