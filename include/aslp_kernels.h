@@ -173,6 +173,26 @@ void aslp_lstm_cell_forward(float *y_cur, const float *y_prev, int ld, int S, in
                             const float *peep_o, const int32_cuda *seq_lengths, int t);
 void aslp_lstm_cell_backward(float *d_cur, const float *d_next, const float *y_cur, const float *y_next, const float *y_prev, int ld, int S,
                              int C, int cifg, const float *peep_i, const float *peep_f, const float *peep_o);
+/* Fused recurrence step (csrc/rnn_fused.hip): ONE launch per timestep covers every direction.
+ * forward : gates(t) += m(t-1) * w^T with w = W_eff = W_r W_rm [G*C x C] (W_r itself without projection), then the
+ *           whole gate block of aslp_lstm_cell_forward; the projection r = m W_rm^T is NOT on the sequential path.
+ * backward: d_m(t) += dGATES(next) * W_eff (w = W_eff^T [C x G*C]), then the gate block of aslp_lstm_cell_backward.
+ * Requirements: C, ld, ldw multiples of 4 (16-byte operand loads). */
+typedef struct aslp_lstm_step_dir_ {
+  float *y_cur; const float *y_prev;                 /* activation row blocks: step t / recursion-previous */
+  float *d_cur; const float *d_next; const float *y_next; /* backward: diff blocks t / recursion-next, activations of recursion-next */
+  const float *w;                                    /* forward: W_eff; backward: W_eff^T */
+  const float *peep_i, *peep_f, *peep_o;
+  const int32_cuda *seq_lengths; int t;              /* forward length masking (may be NULL) */
+  int has_next;                                      /* backward: 0 on the first BPTT step (next block is all zero) */
+  int no_product;                                    /* forward: skip the m(t-1) W_eff^T term (the caller already added it) */
+} aslp_lstm_step_dir;
+typedef struct aslp_lstm_step_ {
+  aslp_lstm_step_dir dir[2];
+  int ndir, ld, ldw, S, C, cifg;
+} aslp_lstm_step;
+void aslp_lstm_step_forward(const aslp_lstm_step *a);
+void aslp_lstm_step_backward(const aslp_lstm_step *a);
 /* GruStreams (nnet-gru-streams.h:275-303, 344-383), columns [z|r|m|g|h] */
 void aslp_gru_forward1(float *y_cur, const float *y_prev, int ld, int S, int H);
 void aslp_gru_forward2(float *y_cur, const float *y_prev, int ld, int S, int H);

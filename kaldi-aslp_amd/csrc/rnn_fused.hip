@@ -1,0 +1,234 @@
+// rnn_fused.hip -- one launch per timestep for the LSTM recurrence (both directions at once).
+//
+// The reference runs, per timestep and direction, a skinny cuBLAS GEMM (S x 4C x R), ~18 elementwise
+// launches and a second skinny GEMM (S x R x C) (nnet-blstm-projected-streams-lc.h:571-609); with
+// M = S = 32 streams those GEMMs use a handful of CUs and are pure latency.  Here the recurrence is
+// re-associated so that only ONE product sits on the sequential path:
+//     gates(t) = [x(t) W_x^T + b]  +  m(t-1) W_eff^T,      W_eff = W_r W_rm   (4C x C;  = W_r without projection)
+// and the projection r = m W_rm^T is taken out of the loop (one batched GEMM over all t).  The step
+// kernel fuses that product with the whole gate block: a workgroup owns 8 cells x 32 streams, i.e. a
+// 32 x 32 MFMA tile whose columns are the (g,i,f,o) pre-activations of its 8 cells; its 4 waves split
+// K = C, operands go global -> VGPR as 16-B loads (both are K-contiguous, no LDS staging), partial
+// tiles are summed through LDS in wave order (deterministic) and the 256 threads then each finish one
+// (stream, cell): peepholes, sigmoid/tanh, cell clip, c/h/m -- one launch, C/8 x S/32 x ndir workgroups.
+// W_eff's row slices are pinned to a workgroup index, hence to one XCD's L2, across the T launches.
+// Backward mirrors it:  d_m(t) = dm_ext(t) + dGATES(t+1) W_eff  (K = 4C, split over 4 workgroups x 4 waves,
+// partials to scratch) followed by the fused gate-block backward, which adds the partials in a fixed order.
+#include "aslp_kernels.h"
+#include "common.h"
+#include "scratch.h"
+
+namespace aslp {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kCB = 8;    // cells per forward workgroup (x 4 gates = 32 MFMA columns)
+constexpr int kKQ = 4;    // K-split of the backward product across workgroups
+constexpr int kPad = 33;  // LDS row pitch of a 32 x 32 partial tile
+
+__device__ __forceinline__ float dsigm(float y, float d) { return d * y * (1.0f - y); }
+__device__ __forceinline__ float dtanh(float y, float d) { return d * (1.0f - y * y); }
+
+// acc += A[32 x K-slice] * B[32 x K-slice]^T over the 8-wide K-chunks [qbegin, qend): a CONTIGUOUS slice per wave,
+// so every 128-B line of an operand row is pulled by exactly one wave.
+// arow / brow: this lane's operand rows (lane & 31), K-contiguous, 16-B aligned; K % 4 == 0.
+__device__ __forceinline__ void mfma_k_slices(f32x16 &acc, const float *__restrict__ arow, const float *__restrict__ brow, int K, int qbegin,
+                                              int qend, int h) {
+  constexpr int U = 8;  // chunks in flight
+  for (int q0 = qbegin; q0 < qend; q0 += U) {
+    float4 a[U], b[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int k = 8 * (q0 + u) + 4 * h;
+      const bool ok = (q0 + u) < qend && k < K;
+      const int kk = ok ? k : 0;
+      a[u] = *reinterpret_cast<const float4 *>(arow + kk);
+      b[u] = *reinterpret_cast<const float4 *>(brow + kk);
+      if (!ok) { a[u] = make_float4(0.f, 0.f, 0.f, 0.f); b[u] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b[u].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, b[u].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].z, b[u].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].w, b[u].w, acc, 0, 0, 0);
+    }
+  }
+}
+
+// C/D layout of v_mfma_f32_32x32x2f32: element e of lane l is row (e&3) + 8*(e>>2) + 4*(l>>5), column l&31
+__device__ __forceinline__ void store_tile(float *tile, const f32x16 &acc, int lane) {
+  const int n = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int e = 0; e < 16; e++) tile[((e & 3) + 8 * (e >> 2) + 4 * h) * kPad + n] = acc[e];
+}
+
+template <bool CIFG>
+__global__ void __launch_bounds__(256) lstm_step_fwd(aslp_lstm_step a) {
+  __shared__ float red[4][32 * kPad];
+  constexpr int G = CIFG ? 3 : 4;
+  const aslp_lstm_step_dir D = a.dir[blockIdx.z];
+  const int C = a.C, S = a.S, ld = a.ld;
+  const int GC = G * C, oc = GC, oh = GC + C, om = GC + 2 * C;
+  const int c0 = blockIdx.x * kCB, s0 = blockIdx.y * 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
+  // epilogue operands of this thread's (stream, cell), requested before the product so their latency hides under it
+  const int sl = threadIdx.x / kCB, cc = threadIdx.x % kCB;
+  const int s = s0 + sl, c = c0 + cc;
+  const bool live = s < S && c < C;
+  constexpr int gi = 1, gf = CIFG ? 1 : 2, go = CIFG ? 2 : 3;
+  float *ys = D.y_cur + (long)(live ? s : 0) * ld;
+  const int cq = live ? c : 0;
+  const float xg = ys[cq], xf = ys[gf * C + cq], xo = ys[go * C + cq], xi = CIFG ? 0.f : ys[gi * C + cq];
+  const float cprev = D.y_prev[(long)(live ? s : 0) * ld + oc + cq];
+  const float pf = D.peep_f[cq], po = D.peep_o[cq], pi = CIFG ? 0.f : D.peep_i[cq];
+  const bool masked = D.seq_lengths && D.t > D.seq_lengths[live ? s : 0];
+  {
+    const int srow = min(s0 + l31, S - 1);
+    const int gate = l31 / kCB, cell = c0 + (l31 % kCB);
+    const bool nvalid = gate < G && cell < C;
+    const float *arow = D.y_prev + (long)srow * ld + om;                       // m(t-1) of stream srow
+    const float *brow = D.w + (long)(nvalid ? gate * C + cell : 0) * a.ldw;    // W_eff row of (gate, cell)
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int nch = (C + 7) / 8, per = (nch + 3) / 4;
+    if (!D.no_product) mfma_k_slices(acc, arow, brow, C, wave * per, min(nch, (wave + 1) * per), h);
+    store_tile(red[wave], acc, lane);
+  }
+  __syncthreads();
+  if (!live) return;
+  float pre[G];
+#pragma unroll
+  for (int g = 0; g < G; g++) {
+    const int n = g * kCB + cc;
+    pre[g] = red[0][sl * kPad + n] + red[1][sl * kPad + n] + red[2][sl * kPad + n] + red[3][sl * kPad + n];
+  }
+  if (masked) {  // nnet-blstm-projected-streams.h:654-657
+    ys[c] = 0.f; ys[gf * C + c] = 0.f; ys[go * C + c] = 0.f; ys[oc + c] = 0.f; ys[oh + c] = 0.f; ys[om + c] = 0.f;
+    if (!CIFG) ys[gi * C + c] = 0.f;
+    return;
+  }
+  const float g = tanh_ref(xg + pre[0]);
+  const float f = sigmoid_ref(xf + pre[gf] + cprev * pf);
+  float cell;
+  if (!CIFG) {
+    const float i = sigmoid_ref(xi + pre[gi] + cprev * pi);
+    ys[gi * C + c] = i;
+    cell = g * i + cprev * f;
+  } else {
+    cell = -g * f + g + cprev * f;
+  }
+  cell = fminf(fmaxf(cell, -50.0f), 50.0f);
+  const float hh = tanh_ref(cell);
+  const float o = sigmoid_ref(xo + pre[go] + cell * po);
+  ys[c] = g; ys[gf * C + c] = f; ys[go * C + c] = o; ys[oc + c] = cell; ys[oh + c] = hh; ys[om + c] = hh * o;
+}
+
+// partial[dir][kq][s][c] = sum over this workgroup's K-quarter of dGATES(next)[s][k] * W_eff^T[c][k]
+template <int G>
+__global__ void __launch_bounds__(256) lstm_step_bwd_gemm(aslp_lstm_step a, float *__restrict__ partial) {
+  __shared__ float red[4][32 * kPad];
+  const aslp_lstm_step_dir D = a.dir[blockIdx.z];
+  const int C = a.C, S = a.S, ld = a.ld, GC = G * C;
+  const int c0 = blockIdx.x * 32, kq = blockIdx.y % kKQ, s0 = (blockIdx.y / kKQ) * 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
+  {
+    const float *arow = D.d_next + (long)min(s0 + l31, S - 1) * ld;          // dGATES(next), columns [0, GC)
+    const float *brow = D.w + (long)min(c0 + l31, C - 1) * a.ldw;            // W_eff^T row of cell c0 + l31
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int nch = (GC + 7) / 8, per = (nch + 4 * kKQ - 1) / (4 * kKQ), part = kq * 4 + wave;
+    mfma_k_slices(acc, arow, brow, GC, part * per, min(nch, (part + 1) * per), h);
+    store_tile(red[wave], acc, lane);
+  }
+  __syncthreads();
+  float *out = partial + ((long)(blockIdx.z * kKQ + kq) * S) * C;
+  for (int e = threadIdx.x; e < 32 * 32; e += 256) {
+    const int sl = e >> 5, n = e & 31;
+    if (s0 + sl < S && c0 + n < C)
+      out[(long)(s0 + sl) * C + c0 + n] = red[0][sl * kPad + n] + red[1][sl * kPad + n] + red[2][sl * kPad + n] + red[3][sl * kPad + n];
+  }
+}
+
+// gate-block backward of step t for every direction; d_m = dm_ext (already in the m column) + the K-split partials
+template <bool CIFG>
+__global__ void __launch_bounds__(kBlock) lstm_step_bwd_cell(aslp_lstm_step a, const float *__restrict__ partial, int with_partial) {
+  constexpr int G = CIFG ? 3 : 4;
+  const aslp_lstm_step_dir D = a.dir[blockIdx.y];
+  const int C = a.C, S = a.S, ld = a.ld;
+  const int GC = G * C, oc = GC, oh = GC + C, om = GC + 2 * C;
+  const int og = 0, oi = C, of = CIFG ? C : 2 * C, oo = CIFG ? 2 * C : 3 * C;
+  const int n = S * C;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+    const int s = idx / C, c = idx - s * C;
+    const long o_ = (long)s * ld;
+    float dm = D.d_cur[o_ + om + c];
+    if (with_partial) {
+      const float *p = partial + ((long)blockIdx.y * kKQ * S + s) * C + c;
+#pragma unroll
+      for (int q = 0; q < kKQ; q++) dm += p[(long)q * S * C];
+      D.d_cur[o_ + om + c] = dm;  // the reference's d_m (lc.h:793) -- kept for InfoGradient-style dumps
+    }
+    const float yo = D.y_cur[o_ + oo + c], yh = D.y_cur[o_ + oh + c], yg = D.y_cur[o_ + og + c], yf = D.y_cur[o_ + of + c];
+    const float dh = dtanh(yh, dm * yo);
+    const float dov = dsigm(yo, dm * yh);
+    float dc = dh + D.d_next[o_ + oc + c] * D.y_next[o_ + of + c];
+    if (!CIFG) dc += D.d_next[o_ + oi + c] * D.peep_i[c];
+    dc += D.d_next[o_ + of + c] * D.peep_f[c];
+    dc += dov * D.peep_o[c];
+    const float cprev = D.y_prev[o_ + oc + c];
+    D.d_cur[o_ + oh + c] = dh;
+    D.d_cur[o_ + oo + c] = dov;
+    D.d_cur[o_ + oc + c] = dc;
+    if (!CIFG) {
+      const float yi = D.y_cur[o_ + oi + c];
+      D.d_cur[o_ + of + c] = dsigm(yf, dc * cprev);
+      D.d_cur[o_ + oi + c] = dsigm(yi, dc * yg);
+      D.d_cur[o_ + og + c] = dtanh(yg, dc * yi);
+    } else {
+      D.d_cur[o_ + of + c] = dsigm(yf, dc * cprev - dc * yg);
+      D.d_cur[o_ + og + c] = dtanh(yg, dc - dc * yf);
+    }
+  }
+}
+
+bool step_args_ok(const aslp_lstm_step *a, const char *who) {
+  if (!a || a->ndir < 1 || a->ndir > 2 || a->S <= 0 || a->C <= 0 || (a->C & 3) || (a->ld & 3) || (a->ldw & 3)) {
+    set_error(std::string(who) + ": bad arguments (needs 1..2 directions, C, ld, ldw multiples of 4)");
+    return false;
+  }
+  return true;
+}
+
+}  // namespace
+}  // namespace aslp
+
+using namespace aslp;
+
+extern "C" {
+
+void aslp_lstm_step_forward(const aslp_lstm_step *a) {
+  if (!step_args_ok(a, "aslp_lstm_step_forward")) return;
+  dim3 grid((a->C + kCB - 1) / kCB, (a->S + 31) / 32, a->ndir);
+  if (a->cifg) hipLaunchKernelGGL((lstm_step_fwd<true>), grid, dim3(256), 0, cur_stream(), *a);
+  else hipLaunchKernelGGL((lstm_step_fwd<false>), grid, dim3(256), 0, cur_stream(), *a);
+  check_launch("aslp_lstm_step_forward");
+}
+
+void aslp_lstm_step_backward(const aslp_lstm_step *a) {
+  if (!step_args_ok(a, "aslp_lstm_step_backward")) return;
+  int with_partial = 0;
+  for (int d = 0; d < a->ndir; d++) with_partial |= a->dir[d].has_next;
+  float *partial = nullptr;
+  if (with_partial) {
+    partial = static_cast<float *>(scratch(kScratchMisc, sizeof(float) * (size_t)a->ndir * kKQ * a->S * a->C));
+    if (!partial) return;
+    dim3 grid((a->C + 31) / 32, kKQ * ((a->S + 31) / 32), a->ndir);
+    if (a->cifg) hipLaunchKernelGGL((lstm_step_bwd_gemm<3>), grid, dim3(256), 0, cur_stream(), *a, partial);
+    else hipLaunchKernelGGL((lstm_step_bwd_gemm<4>), grid, dim3(256), 0, cur_stream(), *a, partial);
+  }
+  dim3 grid(grid_for((long)a->S * a->C), a->ndir);
+  if (a->cifg) hipLaunchKernelGGL((lstm_step_bwd_cell<true>), grid, dim3(kBlock), 0, cur_stream(), *a, partial, with_partial);
+  else hipLaunchKernelGGL((lstm_step_bwd_cell<false>), grid, dim3(kBlock), 0, cur_stream(), *a, partial, with_partial);
+  check_launch("aslp_lstm_step_backward");
+}
+
+}  // extern "C"

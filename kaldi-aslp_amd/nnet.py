@@ -70,7 +70,7 @@ class Xent:
         _ok(lib.aslp_xent_create(C.byref(self.h)))
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:
             lib.aslp_xent_free(self.h)
             self.h = None
 
@@ -123,7 +123,7 @@ class MatrixRandomizer:
         _ok(lib.aslp_matrix_randomizer_create(randomizer_size, minibatch_size, C.byref(self.h)))
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:
             lib.aslp_matrix_randomizer_free(self.h)
             self.h = None
 
@@ -173,7 +173,7 @@ class WarpCtc:
         _ok(lib.aslp_warpctc_create(C.byref(self.h)))
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:
             lib.aslp_warpctc_free(self.h)
             self.h = None
 
@@ -216,7 +216,7 @@ class Ctc:
         _ok(lib.aslp_eesenctc_create(C.byref(self.h)))
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:
             lib.aslp_eesenctc_free(self.h)
             self.h = None
 
@@ -282,7 +282,7 @@ class Nnet:
         return Nnet(h)
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:
             lib.aslp_nnet_free(self.h)
             self.h = None
 

@@ -1,6 +1,7 @@
 // nnet-recurrent.cpp -- LSTM family + GruStreams host logic (see nnet-recurrent.h).
 #include "nnet-recurrent.h"
 
+#include <cstdlib>
 #include <sstream>
 
 namespace aslp {
@@ -43,6 +44,7 @@ void LstmDir::InitRandom(float scale) {
   InitVecParamUniform(peep_f, scale);
   InitVecParamUniform(peep_o, scale);
   AllocCorr();
+  eff_dirty = true;
 }
 
 void LstmDir::Read(std::istream &is, bool binary) {
@@ -60,6 +62,7 @@ void LstmDir::Read(std::istream &is, bool binary) {
   ASLP_ASSERT(peep_f.Dim() == C && peep_o.Dim() == C);
   if (R > 0) ASLP_ASSERT(w_rm.NumRows() == R && w_rm.NumCols() == C);
   AllocCorr();
+  eff_dirty = true;
 }
 
 void LstmDir::Write(std::ostream &os, bool binary) const {
@@ -85,6 +88,7 @@ void LstmDir::AppendParams(std::vector<BaseFloat> *w) const {
 }
 
 void LstmDir::AppendGpuParams(std::vector<std::pair<BaseFloat *, int>> *p) {
+  aliased = true;
   p->push_back(MatParam(w_x));
   p->push_back(MatParam(w_r));
   p->push_back(VecParam(bias));
@@ -190,6 +194,64 @@ void LstmDir::Update(float lr) {  // lc.h:1085-1110
   peep_f.AddVec(-lr, peep_f_corr, 1.0);
   peep_o.AddVec(-lr, peep_o_corr, 1.0);
   if (R > 0) w_rm.AddMat(-lr, w_rm_corr);
+  eff_dirty = true;
+}
+
+// ---- fused-step path ------------------------------------------------------------------------------------
+bool LstmDir::FusedOk() const {
+  static const bool disabled = getenv("ASLP_LSTM_UNFUSED") != nullptr && getenv("ASLP_LSTM_UNFUSED")[0] == '1';
+  return !disabled && C % 4 == 0;
+}
+void LstmDir::RefreshEff() const {
+  if (!eff_dirty && !aliased) return;
+  if (R > 0) {
+    if (w_eff.NumRows() != GC() || w_eff.NumCols() != C) { w_eff.Resize(GC(), C, kUndefined); w_eff_t.Resize(C, GC(), kUndefined); }
+    w_eff.AddMatMat(1.0, w_r, kNoTrans, w_rm, kNoTrans, 0.0);
+    w_eff_t.AddMatMat(1.0, w_rm, kTrans, w_r, kTrans, 0.0);
+  } else {
+    if (w_eff_t.NumRows() != C || w_eff_t.NumCols() != GC()) w_eff_t.Resize(C, GC(), kUndefined);
+    w_eff_t.SetZero();
+    w_eff_t.AddMat(1.0, w_r, kTrans);
+  }
+  eff_dirty = false;
+}
+
+void LstmDir::ForwardPrepare(const CuMatrixBase &in, int T, int S, bool reverse, const CuMatrixBase *init_state, CuMatrix *buf) const {
+  ASLP_ASSERT(in.NumRows() == T * S && in.NumCols() == D);
+  RefreshEff();
+  buf->Resize((T + 2) * S, Width(), kSetZero);
+  if (init_state) buf->RowRange(reverse ? (T + 1) * S : 0, S).CopyFromMat(*init_state);
+  aslp_gemm_epilogue ep = aslp_gemm_epilogue();
+  ep.bias = bias.Data();
+  CuSubMatrix gates(*buf, S, T * S, 0, GC());
+  gates.AddMatMat(1.0, in, kNoTrans, w_x, kTrans, 0.0, &ep);
+}
+
+void LstmDir::ForwardFinish(int T, int S, CuMatrix *buf) const {
+  if (R <= 0) return;
+  CuSubMatrix y_r(*buf, S, T * S, OffRec(), R), y_m(*buf, S, T * S, OffM(), C);
+  y_r.AddMatMat(1.0, y_m, kNoTrans, w_rm, kTrans, 0.0);  // m -> r for every t at once (lc.h:608)
+}
+
+void LstmDir::BackwardPrepare(const CuMatrixBase &out_diff, int T, int S, CuMatrix *dbuf) const {
+  ASLP_ASSERT(out_diff.NumRows() == T * S && out_diff.NumCols() == Rec());
+  dbuf->Resize((T + 2) * S, Width(), kSetZero);
+  CuSubMatrix d_m(*dbuf, S, T * S, OffM(), C);
+  if (R > 0) d_m.AddMatMat(1.0, out_diff, kNoTrans, w_rm, kNoTrans, 0.0);  // the loss's share of d_m, all t at once
+  else d_m.CopyFromMat(out_diff);
+}
+
+void LstmDir::BackwardFinish(const CuMatrixBase &out_diff, int T, int S, bool reverse, CuMatrix *dbuf, CuMatrixBase *in_diff, float beta) const {
+  if (R > 0) {  // d_r(t) = out_diff(t) + dGATES(next) W_r (lc.h:791), needed by the W_rm gradient
+    CuSubMatrix d_r(*dbuf, S, T * S, OffRec(), R);
+    d_r.CopyFromMat(out_diff);
+    CuSubMatrix d_gates_next(*dbuf, (reverse ? 0 : 2) * S, T * S, 0, GC());  // row block of step t's recursion-next
+    d_r.AddMatMat(1.0, d_gates_next, kNoTrans, w_r, kNoTrans, 1.0);
+  }
+  if (in_diff) {
+    CuSubMatrix d_gates(*dbuf, S, T * S, 0, GC());
+    in_diff->AddMatMat(1.0, d_gates, kNoTrans, w_x, kNoTrans, beta);
+  }
 }
 
 // ---- the component family ---------------------------------------------------------------------------
@@ -303,7 +365,41 @@ void LstmFamily::PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) {
   ASLP_ASSERT(in.NumRows() % S == 0);
   const int32 T = in.NumRows() / S;
   const int rec = f_.Rec();
-  f_.Forward(in, T, S, false, carried ? &prev_state_ : nullptr, nullptr, &f_buf_);
+  if (f_.FusedOk()) {
+    // fused recurrence: batched x-part, ONE launch per timestep for all directions, batched projection
+    f_.ForwardPrepare(in, T, S, false, carried ? &prev_state_ : nullptr, &f_buf_);
+    if (cfg_.bidir) b_.ForwardPrepare(in, T, S, true, nullptr, &b_buf_);
+    aslp_lstm_step a = aslp_lstm_step();
+    a.ndir = cfg_.bidir ? 2 : 1; a.ld = f_buf_.Stride(); a.S = S; a.C = ncell_; a.cifg = cfg_.cifg ? 1 : 0;
+    a.ldw = f_.Weff().Stride();
+    for (int d = 0; d < a.ndir; d++) {
+      const LstmDir &p = d == 0 ? f_ : b_;
+      a.dir[d].w = p.Weff().Data();
+      a.dir[d].peep_i = cfg_.cifg ? nullptr : p.peep_i.Data();
+      a.dir[d].peep_f = p.peep_f.Data();
+      a.dir[d].peep_o = p.peep_o.Data();
+      a.dir[d].seq_lengths = (d == 1 && !cfg_.lc) ? seq_len_dev_.Data() : nullptr;
+    }
+    if (carried && cfg_.proj) {
+      // The carried history holds r(0) = m(0) W_rm^T formed with the weights of the PREVIOUS batch (the reference
+      // recurs on the stored r, lc.h:575); m(0) W_eff^T would silently re-project it with the updated W_rm.
+      CuSubMatrix y_gates(f_buf_, S, S, 0, f_.GC()), r0(f_buf_, 0, S, f_.OffRec(), f_.R);
+      y_gates.AddMatMat(1.0, r0, kNoTrans, f_.w_r, kTrans, 1.0);
+    }
+    for (int step = 0; step < T; step++) {
+      const int tf = 1 + step, tb = T - step;
+      a.dir[0].no_product = (step == 0 && carried && cfg_.proj) ? 1 : 0;
+      a.dir[0].y_cur = f_buf_.RowData(tf * S); a.dir[0].y_prev = f_buf_.RowData((tf - 1) * S); a.dir[0].t = tf;
+      if (cfg_.bidir) { a.dir[1].y_cur = b_buf_.RowData(tb * S); a.dir[1].y_prev = b_buf_.RowData((tb + 1) * S); a.dir[1].t = tb; }
+      aslp_lstm_step_forward(&a);
+    }
+    CheckK();
+    f_.ForwardFinish(T, S, &f_buf_);
+    if (cfg_.bidir) b_.ForwardFinish(T, S, &b_buf_);
+  } else {
+    f_.Forward(in, T, S, false, carried ? &prev_state_ : nullptr, nullptr, &f_buf_);
+    if (cfg_.bidir) b_.Forward(in, T, S, true, nullptr, cfg_.lc ? nullptr : &seq_len_dev_, &b_buf_);
+  }
   if (carried) {
     // next batch starts from the last frame (nnet-lstm-projected-streams.h:432); the latency-controlled
     // BLSTM from the last frame of the chunk proper, not of its right context (lc.h:629)
@@ -312,7 +408,6 @@ void LstmFamily::PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) {
     prev_state_.CopyFromMat(f_buf_.RowRange(row_block * S, S));
   }
   if (cfg_.bidir) {
-    b_.Forward(in, T, S, true, nullptr, cfg_.lc ? nullptr : &seq_len_dev_, &b_buf_);
     CuSubMatrix(*out, 0, T * S, 0, rec).CopyFromMat(CuSubMatrix(f_buf_, S, T * S, f_.OffRec(), rec));
     CuSubMatrix(*out, 0, T * S, rec, rec).CopyFromMat(CuSubMatrix(b_buf_, S, T * S, b_.OffRec(), rec));
   } else {
@@ -327,8 +422,40 @@ void LstmFamily::BackpropagateFnc(const CuMatrixBase &in, const CuMatrixBase &, 
   const int32 T = in.NumRows() / S;
   const int rec = f_.Rec();
   const BaseFloat mmt = opts_.momentum;
-  f_.Backward(CuSubMatrix(out_diff, 0, T * S, 0, rec), T, S, false, f_buf_, &f_dbuf_, in_diff, 0.0);
-  if (cfg_.bidir) b_.Backward(CuSubMatrix(out_diff, 0, T * S, rec, rec), T, S, true, b_buf_, &b_dbuf_, in_diff, 1.0);
+  if (f_.FusedOk()) {
+    CuSubMatrix od_f(out_diff, 0, T * S, 0, rec), od_b(out_diff, 0, T * S, cfg_.bidir ? rec : 0, rec);
+    f_.BackwardPrepare(od_f, T, S, &f_dbuf_);
+    if (cfg_.bidir) b_.BackwardPrepare(od_b, T, S, &b_dbuf_);
+    aslp_lstm_step a = aslp_lstm_step();
+    a.ndir = cfg_.bidir ? 2 : 1; a.ld = f_dbuf_.Stride(); a.S = S; a.C = ncell_; a.cifg = cfg_.cifg ? 1 : 0;
+    a.ldw = f_.w_eff_t.Stride();
+    ASLP_ASSERT(f_dbuf_.Stride() == f_buf_.Stride());
+    for (int d = 0; d < a.ndir; d++) {
+      const LstmDir &p = d == 0 ? f_ : b_;
+      a.dir[d].w = p.w_eff_t.Data();
+      a.dir[d].peep_i = cfg_.cifg ? nullptr : p.peep_i.Data();
+      a.dir[d].peep_f = p.peep_f.Data();
+      a.dir[d].peep_o = p.peep_o.Data();
+    }
+    for (int step = 0; step < T; step++) {
+      const int tf = T - step, tb = 1 + step;  // BPTT runs against each direction's recursion
+      a.dir[0].d_cur = f_dbuf_.RowData(tf * S); a.dir[0].d_next = f_dbuf_.RowData((tf + 1) * S);
+      a.dir[0].y_cur = f_buf_.RowData(tf * S); a.dir[0].y_next = f_buf_.RowData((tf + 1) * S); a.dir[0].y_prev = f_buf_.RowData((tf - 1) * S);
+      a.dir[0].has_next = step > 0;
+      if (cfg_.bidir) {
+        a.dir[1].d_cur = b_dbuf_.RowData(tb * S); a.dir[1].d_next = b_dbuf_.RowData((tb - 1) * S);
+        a.dir[1].y_cur = b_buf_.RowData(tb * S); a.dir[1].y_next = b_buf_.RowData((tb - 1) * S); a.dir[1].y_prev = b_buf_.RowData((tb + 1) * S);
+        a.dir[1].has_next = step > 0;
+      }
+      aslp_lstm_step_backward(&a);
+    }
+    CheckK();
+    f_.BackwardFinish(od_f, T, S, false, &f_dbuf_, in_diff, 0.0);
+    if (cfg_.bidir) b_.BackwardFinish(od_b, T, S, true, &b_dbuf_, in_diff, 1.0);
+  } else {
+    f_.Backward(CuSubMatrix(out_diff, 0, T * S, 0, rec), T, S, false, f_buf_, &f_dbuf_, in_diff, 0.0);
+    if (cfg_.bidir) b_.Backward(CuSubMatrix(out_diff, 0, T * S, rec, rec), T, S, true, b_buf_, &b_dbuf_, in_diff, 1.0);
+  }
   f_.Grads(in, T, S, false, f_buf_, f_dbuf_, mmt, clip_gradient_);
   if (cfg_.bidir) b_.Grads(in, T, S, true, b_buf_, b_dbuf_, mmt, clip_gradient_);
 }

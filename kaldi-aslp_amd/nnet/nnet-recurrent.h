@@ -34,6 +34,11 @@ struct LstmDir {
   int D = 0, C = 0, R = 0;  // input dim, cells, projection dim (0: none)
   bool cifg = false;
   CuMatrix w_x, w_r, w_rm, w_x_corr, w_r_corr, w_rm_corr;
+  // W_eff = W_r W_rm [GC x C] (with projection) and W_eff^T [C x GC]: the only products on the sequential path
+  // of the fused recurrence (csrc/rnn_fused.hip); refreshed lazily after every parameter change
+  mutable CuMatrix w_eff, w_eff_t;
+  mutable bool eff_dirty = true;
+  bool aliased = false;  // GetGpuParams handed the tensors out (model sync may rewrite them at any time)
   CuVector bias, peep_i, peep_f, peep_o, bias_corr, peep_i_corr, peep_f_corr, peep_o_corr;
 
   int G() const { return cifg ? 3 : 4; }
@@ -65,6 +70,15 @@ struct LstmDir {
                 float beta) const;
   void Grads(const CuMatrixBase &in, int T, int S, bool reverse, const CuMatrix &buf, const CuMatrix &dbuf, float mmt, float clip);
   void Update(float lr);
+
+  // ---- fused-step path: the per-timestep loop lives in LstmFamily (all directions share a launch) ----
+  bool FusedOk() const;  // C % 4 == 0 (16-byte operand loads) and not disabled by ASLP_LSTM_UNFUSED=1 (A/B switch for tests)
+  void RefreshEff() const;
+  const CuMatrixBase &Weff() const { return R > 0 ? static_cast<const CuMatrixBase &>(w_eff) : w_r; }
+  void ForwardPrepare(const CuMatrixBase &in, int T, int S, bool reverse, const CuMatrixBase *init_state, CuMatrix *buf) const;
+  void ForwardFinish(int T, int S, CuMatrix *buf) const;                                   // batched projection
+  void BackwardPrepare(const CuMatrixBase &out_diff, int T, int S, CuMatrix *dbuf) const;  // dm_ext
+  void BackwardFinish(const CuMatrixBase &out_diff, int T, int S, bool reverse, CuMatrix *dbuf, CuMatrixBase *in_diff, float beta) const;
 };
 
 // Shared implementation; the concrete classes below only fix the configuration.
