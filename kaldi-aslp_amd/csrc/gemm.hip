@@ -21,25 +21,13 @@
 // The K order inside a tile is a permutation of 0..BK-1; fp32 sums are therefore not
 // bitwise those of a k-ascending loop (parity is tolerance-based for GEMM rows).
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
-#include "aslp_kernels.h"
-#include "common.h"
+#include "gemm_common.h"
 
 namespace aslp {
 namespace {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-struct GemmArgs {
-  const float *A, *B;
-  float *C;
-  int M, N, K, lda, ldb, ldc;
-  float alpha, beta;
-  aslp_gemm_epilogue ep;
-  int a_vec, b_vec;  // 16-byte vector loads allowed
-  int tiles_m, tiles_n;
-};
 
 template <int BK>
 struct TileK {
@@ -156,6 +144,44 @@ __device__ __forceinline__ void sstore_rc(float *lds, const float4 (&v)[Stage<BR
   }
 }
 
+// ---- per-element forms (vector path only) used by the interleaved main loop ----------------------------
+template <int BR, int BK, int NT, bool KC>
+__device__ __forceinline__ float4 gload_one(const float *__restrict__ src, int ld, int R, int K, int r0, int k0, int i) {
+  const int idx = threadIdx.x + i * NT;
+  if (KC) {
+    constexpr int C4 = BK / 4;
+    const int row = idx / C4, c4 = idx % C4;
+    int gr = r0 + row;
+    const int gk = k0 + c4 * 4;
+    gr = gr < R ? gr : R - 1;
+    return *reinterpret_cast<const float4 *>(src + (long)gr * ld + (gk < K ? gk : 0));
+  } else {
+    constexpr int C4 = BR / 4;
+    const int k = idx / C4, c4 = idx % C4;
+    const int gk = k0 + k;
+    int gr = r0 + c4 * 4;
+    gr = gr + 3 < R ? gr : R - 4;
+    return *reinterpret_cast<const float4 *>(src + (long)(gk < K ? gk : 0) * ld + gr);
+  }
+}
+template <int BR, int BK, int NT, bool KC>
+__device__ __forceinline__ void sstore_one(float *lds, float4 x, int k0, int K, int i) {
+  const int idx = threadIdx.x + i * NT;
+  if (KC) {
+    constexpr int C4 = BK / 4;
+    const int row = idx / C4, c4 = idx % C4;
+    const bool kv = k0 + c4 * 4 < K;
+    x.x = kv ? x.x : 0.f; x.y = kv ? x.y : 0.f; x.z = kv ? x.z : 0.f; x.w = kv ? x.w : 0.f;
+    *reinterpret_cast<float4 *>(lds + row * TileK<BK>::KC_LD + c4 * 4) = x;
+  } else {
+    constexpr int C4 = BR / 4;
+    const int k = idx / C4, c4 = idx % C4;
+    const bool kv = k0 + k < K;
+    x.x = kv ? x.x : 0.f; x.y = kv ? x.y : 0.f; x.z = kv ? x.z : 0.f; x.w = kv ? x.w : 0.f;
+    *reinterpret_cast<float4 *>(lds + k * (BR + 4) + c4 * 4) = x;
+  }
+}
+
 template <int BR, int BK, bool KC>
 struct OperandTile {
   static constexpr int kFloats = KC ? BR * TileK<BK>::KC_LD : BK * (BR + 4);
@@ -167,7 +193,7 @@ constexpr int gemm_lds_bytes() {
 }
 
 // A_KC: op(A) rows are contiguous in k (transA == 0).  B_KC: op(B) columns are contiguous in k (transB == 1).
-template <int BM, int BN, int BK, int WGM, int WGN, bool A_KC, bool B_KC, bool VEC>
+template <int BM, int BN, int BK, int WGM, int WGN, bool A_KC, bool B_KC, bool VEC, int LOOP>
 __global__ void __launch_bounds__(64 * WGM * WGN) gemm_f32_mfma(GemmArgs g) {
   constexpr int NT = 64 * WGM * WGN;
   constexpr int WM = BM / WGM, WN = BN / WGN;  // wave patch
@@ -180,15 +206,35 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_f32_mfma(GemmArgs g) {
   auto a_buf = [&](int b) { return lds + b * (A_FLOATS + B_FLOATS); };
   auto b_buf = [&](int b) { return lds + b * (A_FLOATS + B_FLOATS) + A_FLOATS; };
 
-  // XCD-aware tile order: consecutive blocks go to different XCDs (block b -> XCD b%8), so give
-  // each XCD a contiguous run of tiles that share A row-panels in its private L2.
+  // XCD-aware tile order.  Consecutive workgroup ids land on different XCDs (id % 8), each with a private
+  // 4 MB L2; every operand panel an XCD touches is pulled through the fabric once per XCD, so give each
+  // XCD a compact 2-D sub-grid of tiles (px x py = 8) instead of a strip: for 16 x 16 tiles a 2 x 4 split
+  // needs 8 + 4 panels per XCD where a strip of 32 consecutive tiles needs 2 + 16.
   const int nt = g.tiles_m * g.tiles_n;
-  int bid = blockIdx.x;
+  int tm, tn;
   {
-    const int q = nt / 8, r = nt % 8, xcd = bid % 8, j = bid / 8;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    const int bid0 = blockIdx.x, xcd = bid0 % 8, j = bid0 / 8;
+    int px = 0;
+    // prefer the split whose sub-grid is closest to square in elements (BM*sm vs BN*sn)
+    long best = -1;
+    for (int cand = 1; cand <= 8; cand *= 2) {
+      const int py = 8 / cand;
+      if (g.tiles_m % cand || g.tiles_n % py) continue;
+      const long cost = (long)(g.tiles_m / cand) * BM + (long)(g.tiles_n / py) * BN;
+      if (best < 0 || cost < best) { best = cost; px = cand; }
+    }
+    if (px > 0) {
+      const int py = 8 / px, sn = g.tiles_n / py, sm = g.tiles_m / px;
+      (void)sm;
+      tm = (xcd / py) * (g.tiles_m / px) + j / sn;
+      tn = (xcd % py) * sn + j % sn;
+    } else {  // ragged grid: contiguous run of tiles per XCD
+      const int q = nt / 8, r = nt % 8;
+      const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+      tm = bid / g.tiles_n;
+      tn = bid % g.tiles_n;
+    }
   }
-  const int tm = bid / g.tiles_n, tn = bid % g.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -224,6 +270,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_f32_mfma(GemmArgs g) {
     else sstore_rc<BN, BK, NT, VEC>(b_buf(buf), RB, (kt)*BK, g.K);                                   \
   } while (0)
 
+  if constexpr (LOOP == 0) {
+  // ---- loop style 0: LDS reads interleaved with the MFMAs of the same K tile ----
   auto compute = [&](int cur) {
     const float *a_s = a_buf(cur), *b_s = b_buf(cur);
 #pragma unroll
@@ -290,6 +338,183 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_f32_mfma(GemmArgs g) {
     ASLP_SSTORE(0, kt + 2, ra0, rb0);
     __syncthreads();
   }
+  } else if constexpr (LOOP == 5) {
+  // ---- loop style 5: fragment double buffering with everything else issued in the shadow of the MFMAs ----
+  // A wave issues in program order, so whatever precedes the first MFMA of a K tile (address VALU, the LDS
+  // stores of the next tile, the global loads of the one after, the barrier, the fragment reads) leaves the
+  // matrix pipe idle -- for BOTH waves of a SIMD, which the barrier keeps in lockstep.  Here each of those
+  // units is slotted between two MFMAs of the current tile (sched_barrier pins the order): stores and
+  // global loads in the first half, the barrier in the middle, the next tile's fragment reads in the
+  // second half.  Only the barrier skew itself remains exposed.
+  static_assert(VEC, "interleaved loop needs the vector load path");
+  constexpr int KH = BK / 8;
+  constexpr int NVA = Stage<BM, BK, NT>::NV, NVB = Stage<BN, BK, NT>::NV;
+  static_assert(Stage<BM, BK, NT>::FULL && Stage<BN, BK, NT>::FULL, "tile loads must divide evenly over the threads");
+  constexpr int NM = KH * 4 * TM * TN;    // MFMAs per K tile per wave
+  constexpr int NPRE = 2 * (NVA + NVB);   // store units then load units
+  constexpr int NRD = KH * (TM + TN);     // fragment read units
+  constexpr int SB = NM / 2 - 1;          // the barrier follows this MFMA slot
+  static_assert(NM >= 4, "tile too small to interleave");
+  struct Frag {
+    float a[KH][TM][4], b[KH][TN][4];
+  };
+  auto read_unit = [&](int cur, Frag &f, auto R_) {
+    constexpr int r = decltype(R_)::value;
+    const float *a_s = a_buf(cur), *b_s = b_buf(cur);
+    constexpr int h = r / (TM + TN), t = r % (TM + TN);
+    if constexpr (t < TM) {
+      const int row = wm * WM + t * 32 + l31;
+      if (A_KC) {
+        float4 v = *reinterpret_cast<const float4 *>(a_s + row * KC_LD + h * 8 + lh * 4);
+        f.a[h][t][0] = v.x; f.a[h][t][1] = v.y; f.a[h][t][2] = v.z; f.a[h][t][3] = v.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) f.a[h][t][j] = a_s[(h * 8 + lh * 4 + j) * (BM + 4) + row];
+      }
+    } else {
+      constexpr int tb = t - TM;
+      const int col = wn * WN + tb * 32 + l31;
+      if (B_KC) {
+        float4 v = *reinterpret_cast<const float4 *>(b_s + col * KC_LD + h * 8 + lh * 4);
+        f.b[h][tb][0] = v.x; f.b[h][tb][1] = v.y; f.b[h][tb][2] = v.z; f.b[h][tb][3] = v.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) f.b[h][tb][j] = b_s[(h * 8 + lh * 4 + j) * (BN + 4) + col];
+      }
+    }
+  };
+  auto mma_unit = [&](const Frag &f, auto M_) {
+    constexpr int m = decltype(M_)::value;
+    constexpr int n = m % TN, i = (m / TN) % TM, j = (m / (TN * TM)) % 4, h = m / (TN * TM * 4);
+    acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[h][i][j], f.b[h][n][j], acc[i][n], 0, 0, 0);
+  };
+  // unit u of the pre-barrier work: [store A | store B | load A | load B]
+  auto pre_unit = [&](auto U_, int buf, int kt_store, int kt_load, float4 (&RA)[NVA], float4 (&RB)[NVB]) {
+    constexpr int u = decltype(U_)::value;
+    if constexpr (u < NVA) sstore_one<BM, BK, NT, A_KC>(a_buf(buf), RA[u], kt_store * BK, g.K, u);
+    else if constexpr (u < NVA + NVB) sstore_one<BN, BK, NT, B_KC>(b_buf(buf), RB[u - NVA], kt_store * BK, g.K, u - NVA);
+    else if constexpr (u < 2 * NVA + NVB) RA[u - NVA - NVB] = gload_one<BM, BK, NT, A_KC>(g.A, g.lda, g.M, g.K, m0, kt_load * BK, u - NVA - NVB);
+    else RB[u - 2 * NVA - NVB] = gload_one<BN, BK, NT, B_KC>(g.B, g.ldb, g.N, g.K, n0, kt_load * BK, u - 2 * NVA - NVB);
+  };
+  // one K tile: MFMAs from fcur; tile kt_store goes registers -> LDS[buf]; tile kt_load global -> the same registers;
+  // after the barrier the fragments of LDS[buf] are read into fnxt
+  auto half_step = [&](const Frag &fcur, Frag &fnxt, int buf, int kt_store, int kt_load, float4 (&RA)[NVA], float4 (&RB)[NVB]) {
+    static_for<0, NM>([&](auto S_) {
+      constexpr int sidx = decltype(S_)::value;
+      mma_unit(fcur, S_);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (sidx <= SB) {
+        static_for<sidx * NPRE / (SB + 1), (sidx + 1) * NPRE / (SB + 1)>([&](auto U_) { pre_unit(U_, buf, kt_store, kt_load, RA, RB); });
+        if constexpr (sidx == SB) __syncthreads();
+      } else {
+        constexpr int NS = NM - SB - 1;
+        static_for<(sidx - SB - 1) * NRD / NS, (sidx - SB) * NRD / NS>([&](auto R_) { read_unit(buf, fnxt, R_); });
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+
+  const int kt_end = (ktiles + 1) & ~1;
+  Frag f0, f1;
+  if (ktiles > 0) {
+    ASLP_GLOAD(0, ra0, rb0);
+    ASLP_SSTORE(0, 0, ra0, rb0);
+    ASLP_GLOAD(1, ra1, rb1);
+    ASLP_GLOAD(2, ra0, rb0);
+  }
+  __syncthreads();
+  if (ktiles > 0) static_for<0, NRD>([&](auto R_) { read_unit(0, f0, R_); });
+  for (int kt = 0; kt < kt_end; kt += 2) {
+    half_step(f0, f1, 1, kt + 1, kt + 3, ra1, rb1);
+    half_step(f1, f0, 0, kt + 2, kt + 4, ra0, rb0);
+  }
+  } else {
+  // ---- loop style 1: fragment double buffering ----
+  // Operand fragments of one whole K tile live in registers (BK/8 b128 reads per 32-row sub-tile), double
+  // buffered: the ds_reads of tile t+1 are issued right after the barrier that publishes it and complete
+  // under the MFMAs of tile t, so LDS latency is off the critical path and each K tile costs ONE barrier.
+  constexpr int KH = BK / 8;
+  struct Frag {
+    float a[KH][TM][4], b[KH][TN][4];
+  };
+  auto read_frags = [&](int cur, Frag &f) {
+    const float *a_s = a_buf(cur), *b_s = b_buf(cur);
+#pragma unroll
+    for (int h = 0; h < KH; h++) {
+#pragma unroll
+      for (int i = 0; i < TM; i++) {
+        const int row = wm * WM + i * 32 + l31;
+        if (A_KC) {
+          float4 t = *reinterpret_cast<const float4 *>(a_s + row * KC_LD + h * 8 + lh * 4);
+          f.a[h][i][0] = t.x; f.a[h][i][1] = t.y; f.a[h][i][2] = t.z; f.a[h][i][3] = t.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; j++) f.a[h][i][j] = a_s[(h * 8 + lh * 4 + j) * (BM + 4) + row];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TN; i++) {
+        const int col = wn * WN + i * 32 + l31;
+        if (B_KC) {
+          float4 t = *reinterpret_cast<const float4 *>(b_s + col * KC_LD + h * 8 + lh * 4);
+          f.b[h][i][0] = t.x; f.b[h][i][1] = t.y; f.b[h][i][2] = t.z; f.b[h][i][3] = t.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; j++) f.b[h][i][j] = b_s[(h * 8 + lh * 4 + j) * (BN + 4) + col];
+        }
+      }
+    }
+  };
+  auto mma = [&](const Frag &f) {
+#pragma unroll
+    for (int h = 0; h < KH; h++)
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+          for (int n = 0; n < TN; n++)
+            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[h][i][j], f.b[h][n][j], acc[i][n], 0, 0, 0);
+  };
+
+  // Branch-free steady state: the k-tile count is rounded up to even (a tile beyond K loads from
+  // clamped addresses and is zeroed at store time, so it adds 0), and loads/stores for tiles past
+  // the end are issued unconditionally into buffers nobody reads.  With no conditional code
+  // between the loads and their use the compiler keeps exact vmcnt counts.
+  // Invariant at the top of an even step kt: LDS[0] holds tile kt and its fragments are already in f0;
+  // register stage 1 holds tile kt+1 (landed), stage 0 holds tile kt+2 (in flight since the previous step):
+  // every global load has two MFMA phases to land before its registers are stored to LDS.
+  const int kt_end = (ktiles + 1) & ~1;
+  Frag f0, f1;
+  if (ktiles > 0) {
+    ASLP_GLOAD(0, ra0, rb0);
+    ASLP_SSTORE(0, 0, ra0, rb0);
+    ASLP_GLOAD(1, ra1, rb1);
+    ASLP_GLOAD(2, ra0, rb0);
+  }
+  __syncthreads();
+  if (ktiles > 0) read_frags(0, f0);
+
+  // ablation switches (styles 2,3,4,6,7 give wrong results; they exist to time the pieces, devtools/bench_gemm.py)
+  constexpr bool DO_GLOAD = LOOP == 1, DO_SSTORE = LOOP == 1 || LOOP == 2 || LOOP == 6, DO_BARRIER = LOOP == 1 || LOOP == 2 || LOOP == 7,
+                 DO_READS = LOOP != 4;
+  for (int kt = 0; kt < kt_end; kt += 2) {
+    if (DO_SSTORE) ASLP_SSTORE(1, kt + 1, ra1, rb1);      // tile kt+1 -> LDS[1] (its last readers passed the previous barrier)
+    if (DO_GLOAD) ASLP_GLOAD(kt + 3, ra1, rb1);
+    if (DO_BARRIER) __syncthreads();
+    if (DO_READS) read_frags(1, f1);                     // issue; lands under the MFMAs below
+    __builtin_amdgcn_sched_barrier(0);
+    mma(f0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (DO_SSTORE) ASLP_SSTORE(0, kt + 2, ra0, rb0);
+    if (DO_GLOAD) ASLP_GLOAD(kt + 4, ra0, rb0);
+    if (DO_BARRIER) __syncthreads();
+    if (DO_READS) read_frags(0, f0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(f1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  }
 #undef ASLP_GLOAD
 #undef ASLP_SSTORE
 
@@ -343,12 +568,12 @@ void drain(GemmProf &p) {
 
 int g_force_tile = 0;  // devtools: 0 = heuristic, else 1..5 picks a config
 
-template <int BM, int BN, int BK, int WGM, int WGN, bool A_KC, bool B_KC, bool VEC>
+template <int BM, int BN, int BK, int WGM, int WGN, bool A_KC, bool B_KC, bool VEC, int LOOP = 0>
 void launch_cfg(GemmArgs &g) {
   g.tiles_m = (g.M + BM - 1) / BM;
   g.tiles_n = (g.N + BN - 1) / BN;
   constexpr int lds_bytes = gemm_lds_bytes<BM, BN, BK, A_KC, B_KC>();
-  auto kern = gemm_f32_mfma<BM, BN, BK, WGM, WGN, A_KC, B_KC, VEC>;
+  auto kern = gemm_f32_mfma<BM, BN, BK, WGM, WGN, A_KC, B_KC, VEC, LOOP>;
   static bool attr_set = false;  // one per template instantiation
   if (!attr_set) {
     if (lds_bytes > 48 * 1024)
@@ -367,10 +592,16 @@ void launch_variant(GemmArgs &g) {
   // Measured on MI355X (devtools/bench_gemm.py, profiles/gemm_tiles_r01.txt): the 8-wave 64x128x32
   // tile is best whenever it tiles the problem into >= ~200 full blocks; otherwise the 4-wave
   // 64x64x32 tile (2+ blocks co-resident per CU) copes best with ragged edges / small grids.
+  // Measured on MI355X (devtools/bench_gemm.py, profiles/): the LDS-DMA kernels (cfg >= 200, gemm_glds.hip) win
+  // wherever they are eligible; 64x128 / 8 waves when it tiles the problem into >= ~200 full blocks, else 64x64 /
+  // 4 waves (2+ workgroups per CU copes best with ragged edges and small grids).  Skinny M keeps the 32-row tile.
   if (g_force_tile) cfg = g_force_tile;
-  else if (g.M <= 32) cfg = 1;
-  else if (g.N % 128 == 0 && g.M % 64 == 0 && blocks(64, 128) >= 200) cfg = 12;
-  else cfg = 7;
+  else if (g.N % 128 == 0 && g.M % 64 == 0 && blocks(64, 128) >= 200) cfg = 212;
+  else cfg = 207;
+  if (cfg >= 200) {
+    if (gemm_glds_launch(g, A_KC, B_KC, cfg)) return;
+    cfg = g.M <= 32 ? 1 : (cfg == 207 ? 7 : 12);  // not eligible: register-staged kernel of the same tile
+  }
   switch (cfg) {
     case 1: launch_cfg<32, 128, 16, 1, 4, A_KC, B_KC, VEC>(g); break;
     case 2: launch_cfg<64, 64, 16, 2, 2, A_KC, B_KC, VEC>(g); break;
@@ -383,6 +614,27 @@ void launch_variant(GemmArgs &g) {
     case 10: launch_cfg<128, 64, 32, 4, 2, A_KC, B_KC, VEC>(g); break;   // 8 waves
     case 11: launch_cfg<128, 128, 32, 2, 4, A_KC, B_KC, VEC>(g); break;  // 8 waves
     case 12: launch_cfg<64, 128, 32, 2, 4, A_KC, B_KC, VEC>(g); break;   // 8 waves
+    case 107: launch_cfg<64, 64, 32, 2, 2, A_KC, B_KC, VEC, 1>(g); break;   // loop style 1 variants
+    case 112: launch_cfg<64, 128, 32, 2, 4, A_KC, B_KC, VEC, 1>(g); break;
+    case 101: launch_cfg<32, 128, 16, 1, 4, A_KC, B_KC, VEC, 1>(g); break;
+    case 108: launch_cfg<64, 128, 32, 2, 2, A_KC, B_KC, VEC, 1>(g); break;
+    case 104: launch_cfg<128, 128, 32, 2, 2, A_KC, B_KC, VEC, 1>(g); break;
+    case 111: launch_cfg<128, 128, 32, 2, 4, A_KC, B_KC, VEC, 1>(g); break;
+    case 116: launch_cfg<64, 128, 16, 2, 2, A_KC, B_KC, VEC, 1>(g); break;
+    case 120: launch_cfg<64, 128, 64, 2, 4, A_KC, B_KC, VEC, 1>(g); break;
+    case 152: launch_cfg<64, 128, 32, 2, 4, A_KC, B_KC, VEC, VEC ? 5 : 0>(g); break;   // interleaved loop
+    case 157: launch_cfg<64, 64, 32, 2, 2, A_KC, B_KC, VEC, VEC ? 5 : 0>(g); break;
+    case 158: launch_cfg<64, 128, 32, 2, 2, A_KC, B_KC, VEC, VEC ? 5 : 0>(g); break;
+    case 154: launch_cfg<128, 128, 32, 2, 2, A_KC, B_KC, VEC, VEC ? 5 : 0>(g); break;
+    case 151: launch_cfg<128, 128, 32, 2, 4, A_KC, B_KC, VEC, VEC ? 5 : 0>(g); break;
+    case 132: launch_cfg<64, 128, 32, 2, 4, A_KC, B_KC, VEC, 2>(g); break;   // ablations (wrong results): no global loads
+    case 133: launch_cfg<64, 128, 32, 2, 4, A_KC, B_KC, VEC, 3>(g); break;   //   + no LDS stores / barriers
+    case 134: launch_cfg<64, 128, 32, 2, 4, A_KC, B_KC, VEC, 4>(g); break;   //   + no LDS reads (MFMA only)
+    case 136: launch_cfg<64, 128, 32, 2, 4, A_KC, B_KC, VEC, 6>(g); break;   //   reads + stores, no barrier, no global loads
+    case 137: launch_cfg<64, 128, 32, 2, 4, A_KC, B_KC, VEC, 7>(g); break;   //   reads + barrier, no stores, no global loads
+    case 121: launch_cfg<64, 128, 64, 2, 2, A_KC, B_KC, VEC, 1>(g); break;
+    case 122: launch_cfg<64, 128, 64, 2, 4, A_KC, B_KC, VEC, 0>(g); break;
+    case 117: launch_cfg<128, 64, 32, 2, 2, A_KC, B_KC, VEC, 1>(g); break;
     default: launch_cfg<128, 128, 16, 2, 2, A_KC, B_KC, VEC>(g); break;
   }
 }

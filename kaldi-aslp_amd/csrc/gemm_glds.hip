@@ -1,0 +1,270 @@
+// gemm_glds.hip -- fp32 MFMA GEMM whose operand tiles travel global -> LDS directly (LDS-DMA,
+// global_load_lds_dwordx4), gfx950 only.
+//
+// Measured on MI355X (devtools/bench_gemm.py ablations): in the register-staged kernel of
+// gemm.hip the ds_write_b128 pass that moves a K tile from VGPRs into LDS costs ~13 us of a 92 us layer GEMM
+// (more than the barrier and the global loads together) -- LDS write bandwidth, not latency.  LDS-DMA removes
+// that pass, the staging VGPRs and the k-tail select VALU: a wave instruction moves 64 x 16 B = 1 KiB from
+// per-lane global addresses to a lane-linear LDS block, asynchronously, counted by vmcnt.
+//   * K-contiguous operands ("KC"): LDS image [rows][32] floats, 128-B rows, unpadded (the DMA destination is
+//     lane-linear).  Bank conflicts of the ds_read_b128 fragment reads (32 lanes x same 16-B column) are
+//     removed by an XOR swizzle of the 16-B chunk index with (row & 7), applied to the SOURCE address of the
+//     DMA and to the read address (both sides or neither).
+//   * row-contiguous operands ("RC"): LDS image [32][rows], read with ds_read_b32, conflict-free as is.
+//   * NS LDS stages; tile t+NS-1 is requested while tile t is multiplied from registers (fragments are double
+//     buffered in VGPRs, read one tile ahead); each wave waits with a COUNTED s_waitcnt vmcnt for its own part
+//     of tile t+1, then one raw s_barrier publishes it.  All non-MFMA work of a K tile is slotted between its
+//     MFMAs (sched_barrier pins the order).
+// A partial last K tile is handled by pointing the out-of-range DMA lanes at a zero buffer.
+// Eligibility: K % 4 == 0, 16-byte aligned operands, leading dimensions % 4 == 0 (else gemm.hip's kernel).
+#include "gemm_common.h"
+
+namespace aslp {
+namespace {
+
+constexpr int BK = 32, KH = BK / 8;
+
+// source of the DMA lanes whose k index lies beyond K in the last, partial K tile: LDS receives zeros there, so the
+// tail needs no masking anywhere else
+__device__ float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// LDS-DMA through inline asm: hipcc does not see a VMEM op writing LDS, so it neither drains vmcnt(0) before the
+// next ds_read (it does for the builtin: every LDS read "may alias" the DMA target) nor counts these in its own
+// vmcnt bookkeeping -- the kernel waits with explicit counted s_waitcnt vmcnt(N) instead.
+__device__ __forceinline__ void glds16(const float *gsrc, unsigned lds_byte_addr) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_byte_addr) : "memory", "m0");
+}
+
+template <int BM, int BN, int WGM, int WGN, bool A_KC, bool B_KC, int NS, bool TAIL>
+__global__ void __launch_bounds__(64 * WGM * WGN) gemm_f32_glds(GemmArgs g) {
+  constexpr int NW = WGM * WGN;
+  constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
+  constexpr int A_FLOATS = BM * BK, B_FLOATS = BN * BK, STAGE = A_FLOATS + B_FLOATS;
+  constexpr int SLOTS_A = BM / 8, SLOTS_B = BN / 8;                 // 1-KiB DMA units per tile
+  static_assert((SLOTS_A + SLOTS_B) % NW == 0, "DMA units must divide over the waves");
+  constexpr int G = (SLOTS_A + SLOTS_B) / NW;                        // DMA instructions per wave per tile
+  constexpr int D = NS - 1;                                           // tiles requested ahead
+  constexpr int NM = KH * 4 * TM * TN, NRD = KH * (TM + TN), SB = NM / 2 - 1;
+  constexpr int UNROLL = (NS % 2 == 0) ? NS : 2 * NS;                 // stage and fragment-buffer indices both static
+  static_assert(G <= SB + 1, "not enough MFMA slots before the barrier");
+  extern __shared__ __attribute__((aligned(1024))) float lds[];
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lds;
+
+  int tm, tn;
+  xcd_tile<BM, BN>(g, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave / WGN, wn = wave % WGN, l31 = lane & 31, lh = lane >> 5;
+  const int kfull = g.K / BK, ktail = TAIL ? g.K % BK : 0, ktiles = kfull + (ktail ? 1 : 0);
+
+  // ---- DMA descriptors of this wave's G units: per-lane source pointer of tile 0, per-tile pointer step, LDS offset
+  const float *src[G];  // tile 0, then advanced tile by tile up to the last full tile
+  long kstep[G], tail_off[G];  // per-tile pointer step; (source of the partial last tile) - (source of the last full tile), in floats
+  unsigned dst_off[G];  // bytes within a stage
+  static_for<0, G>([&](auto U_) {
+    constexpr int u = decltype(U_)::value;
+    const int slot = wave + u * NW;  // wave-uniform
+    if (slot < SLOTS_A) {
+      dst_off[u] = slot * 1024;
+      if (A_KC) {  // rows 8*slot .. +7, 128 B each; source chunk = dest chunk ^ (row & 7)
+        const int r = lane >> 3, c = (lane & 7) ^ r;
+        int row = m0 + slot * 8 + r;
+        row = row < g.M ? row : g.M - 1;
+        src[u] = g.A + (long)row * g.lda + 4 * c;
+        tail_off[u] = (4 * c < ktail ? src[u] + (long)kfull * BK : g_zero16) - (src[u] + (long)max(kfull - 1, 0) * BK);
+        kstep[u] = BK;
+      } else {     // [32][BM]: 256 floats = 256 / BM k-rows
+        const int f = slot * 256 + 4 * lane, k = f / BM;
+        int r4 = m0 + f % BM;
+        r4 = r4 + 3 < g.M ? r4 : g.M - 4;
+        src[u] = g.A + (long)k * g.lda + r4;
+        tail_off[u] = (k < ktail ? src[u] + (long)kfull * BK * g.lda : g_zero16) - (src[u] + (long)max(kfull - 1, 0) * BK * g.lda);
+        kstep[u] = (long)BK * g.lda;
+      }
+    } else {
+      const int sb = slot - SLOTS_A;
+      dst_off[u] = (A_FLOATS + sb * 256) * 4;
+      if (B_KC) {
+        const int r = lane >> 3, c = (lane & 7) ^ r;
+        int row = n0 + sb * 8 + r;
+        row = row < g.N ? row : g.N - 1;
+        src[u] = g.B + (long)row * g.ldb + 4 * c;
+        tail_off[u] = (4 * c < ktail ? src[u] + (long)kfull * BK : g_zero16) - (src[u] + (long)max(kfull - 1, 0) * BK);
+        kstep[u] = BK;
+      } else {
+        const int f = sb * 256 + 4 * lane, k = f / BN;
+        int r4 = n0 + f % BN;
+        r4 = r4 + 3 < g.N ? r4 : g.N - 4;
+        src[u] = g.B + (long)k * g.ldb + r4;
+        tail_off[u] = (k < ktail ? src[u] + (long)kfull * BK * g.ldb : g_zero16) - (src[u] + (long)max(kfull - 1, 0) * BK * g.ldb);
+        kstep[u] = (long)BK * g.ldb;
+      }
+    }
+  });
+  // request tile r of unit u into stage ST.  src[u] points at tile min(r, kfull-1); requests past the last tile
+  // (pipeline tail) fetch that tile again into a stage nobody reads.
+  auto dma_unit = [&](auto U_, auto ST_, int r) {
+    constexpr int u = decltype(U_)::value, st = decltype(ST_)::value;
+    const float *p = src[u];
+    if constexpr (TAIL) p += (ktail && r >= kfull) ? tail_off[u] : 0;  // wave-uniform condition
+    glds16(p, __builtin_amdgcn_readfirstlane(lds_base + st * STAGE * 4 + dst_off[u]));
+    src[u] += (r + 1 < kfull) ? kstep[u] : 0;
+  };
+
+  // ---- fragments: per-lane LDS float offsets inside a stage, one per (sub-tile, k-octet) ----------------------------
+  int a_off[TM][KH], b_off[TN][KH];
+#pragma unroll
+  for (int t = 0; t < TM; t++)
+#pragma unroll
+    for (int h = 0; h < KH; h++) {
+      const int row = wm * WM + t * 32 + l31;
+      a_off[t][h] = A_KC ? row * BK + (((2 * h + lh) ^ (row & 7)) << 2) : (h * 8 + lh * 4) * BM + row;
+    }
+#pragma unroll
+  for (int t = 0; t < TN; t++)
+#pragma unroll
+    for (int h = 0; h < KH; h++) {
+      const int col = wn * WN + t * 32 + l31;
+      b_off[t][h] = A_FLOATS + (B_KC ? col * BK + (((2 * h + lh) ^ (col & 7)) << 2) : (h * 8 + lh * 4) * BN + col);
+    }
+  struct Frag {
+    float a[KH][TM][4], b[KH][TN][4];
+  };
+  auto read_unit = [&](auto ST_, Frag &f, auto R_) {
+    constexpr int r = decltype(R_)::value, st = decltype(ST_)::value;
+    constexpr int h = r / (TM + TN), t = r % (TM + TN);
+    const float *stage = lds + st * STAGE;
+    if constexpr (t < TM) {
+      if (A_KC) {
+        float4 v = *reinterpret_cast<const float4 *>(stage + a_off[t][h]);
+        f.a[h][t][0] = v.x; f.a[h][t][1] = v.y; f.a[h][t][2] = v.z; f.a[h][t][3] = v.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) f.a[h][t][j] = stage[a_off[t][h] + j * BM];
+      }
+    } else {
+      constexpr int tb = t - TM;
+      if (B_KC) {
+        float4 v = *reinterpret_cast<const float4 *>(stage + b_off[tb][h]);
+        f.b[h][tb][0] = v.x; f.b[h][tb][1] = v.y; f.b[h][tb][2] = v.z; f.b[h][tb][3] = v.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) f.b[h][tb][j] = stage[b_off[tb][h] + j * BN];
+      }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+  auto mma_unit = [&](const Frag &f, auto M_) {
+    constexpr int m = decltype(M_)::value;
+    constexpr int n = m % TN, i = (m / TN) % TM, j = (m / (TN * TM)) % 4, h = m / (TN * TM * 4);
+    acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[h][i][j], f.b[h][n][j], acc[i][n], 0, 0, 0);
+  };
+
+  // K tile t (stage index I % NS) from fcur; request tile t+D into stage (I+D) % NS; after the barrier read the
+  // fragments of tile t+1 (stage (I+1) % NS) into fnxt.  I = t mod UNROLL is a compile-time constant.
+  auto step = [&](auto I_, const Frag &fcur, Frag &fnxt, int t) {
+    constexpr int I = decltype(I_)::value;
+    using StReq = std::integral_constant<int, (I + D) % NS>;
+    using StNxt = std::integral_constant<int, (I + 1) % NS>;
+    static_for<0, NM>([&](auto S_) {
+      constexpr int sidx = decltype(S_)::value;
+      mma_unit(fcur, S_);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (sidx <= SB) {
+        static_for<sidx * G / (SB + 1), (sidx + 1) * G / (SB + 1)>([&](auto U_) { dma_unit(U_, StReq(), t + D); });
+        if constexpr (sidx == SB) {
+          wait_vmcnt<(D - 1) * G>();  // this wave's share of tile t+1 has landed; tiles t+2.. stay in flight
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+        }
+      } else {
+        constexpr int NSL = NM - SB - 1;
+        static_for<(sidx - SB - 1) * NRD / NSL, (sidx - SB) * NRD / NSL>([&](auto R_) { read_unit(StNxt(), fnxt, R_); });
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+
+  Frag f0, f1;
+  // prologue: request tiles 0 .. D-1 (stages 0 .. D-1), wait for tile 0, read its fragments
+  static_for<0, D>([&](auto T_) {
+    constexpr int t = decltype(T_)::value;
+    static_for<0, G>([&](auto U_) { dma_unit(U_, T_, t); });
+  });
+  wait_vmcnt<(D - 1) * G>();
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  static_for<0, NRD>([&](auto R_) { read_unit(std::integral_constant<int, 0>(), f0, R_); });
+
+  for (int t0 = 0; t0 < ktiles; t0 += UNROLL) {
+    static_for<0, UNROLL>([&](auto I_) {
+      constexpr int I = decltype(I_)::value;
+      if (t0 + I < ktiles) {  // wave-uniform
+        if constexpr (I % 2 == 0) step(I_, f0, f1, t0 + I);
+        else step(I_, f1, f0, t0 + I);
+      }
+    });
+  }
+  wait_vmcnt<0>();  // drain the clamped tail requests before the LDS block is released
+
+  gemm_epilogue<TM, TN>(g, acc, m0 + wm * WM, n0 + wn * WN, l31, lh);
+}
+
+template <int BM, int BN, int WGM, int WGN, bool A_KC, bool B_KC, int NS, bool TAIL>
+void launch_t(GemmArgs &g) {
+  g.tiles_m = (g.M + BM - 1) / BM;
+  g.tiles_n = (g.N + BN - 1) / BN;
+  constexpr int lds_bytes = NS * (BM + BN) * BK * (int)sizeof(float);
+  auto kern = gemm_f32_glds<BM, BN, WGM, WGN, A_KC, B_KC, NS, TAIL>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (lds_bytes > 48 * 1024)
+      ASLP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(64 * WGM * WGN), lds_bytes, cur_stream(), g);
+}
+
+template <int BM, int BN, int WGM, int WGN, bool A_KC, bool B_KC, int NS>
+void launch(GemmArgs &g) {
+  if (g.K % BK == 0) launch_t<BM, BN, WGM, WGN, A_KC, B_KC, NS, false>(g);
+  else launch_t<BM, BN, WGM, WGN, A_KC, B_KC, NS, true>(g);
+}
+
+template <bool A_KC, bool B_KC>
+bool launch_cfg(GemmArgs &g, int cfg) {
+  switch (cfg) {
+    case 212: launch<64, 128, 2, 4, A_KC, B_KC, 3>(g); return true;   // 8 waves, 3 stages (72 KiB)
+    case 213: launch<64, 128, 2, 4, A_KC, B_KC, 4>(g); return true;   // 4 stages (96 KiB)
+    case 208: launch<64, 128, 2, 2, A_KC, B_KC, 3>(g); return true;   // 4 waves, 32 x 64 per wave
+    case 207: launch<64, 64, 2, 2, A_KC, B_KC, 4>(g); return true;    // 4 waves, 2 workgroups per CU
+    case 211: launch<128, 128, 2, 4, A_KC, B_KC, 3>(g); return true;  // 8 waves, 64 x 32 per wave
+    default: return false;
+  }
+}
+
+}  // namespace
+
+bool gemm_glds_launch(GemmArgs &g, bool a_kc, bool b_kc, int cfg) {
+  if (g.K < 4 || g.K % 4 != 0 || !g.a_vec || !g.b_vec) return false;
+  if (!a_kc && (g.M % 4 != 0 || g.M < 4)) return false;
+  if (!b_kc && (g.N % 4 != 0 || g.N < 4)) return false;
+  if (a_kc && b_kc) return launch_cfg<true, true>(g, cfg);
+  if (a_kc && !b_kc) return launch_cfg<true, false>(g, cfg);
+  if (!a_kc && !b_kc) return launch_cfg<false, false>(g, cfg);
+  return launch_cfg<false, true>(g, cfg);
+}
+
+}  // namespace aslp
