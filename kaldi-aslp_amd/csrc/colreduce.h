@@ -72,10 +72,24 @@ __global__ void __launch_bounds__(kColLanes *kRowLanes) colreduce_stage2(G g, in
   T sum[NOUT];
 #pragma unroll
   for (int k = 0; k < NOUT; k++) sum[k] = T(0);
-  if (c < cols)
-    for (int j = y; j < chunks; j += kRowLanes)
+  if (c < cols) {
+    // the chunk loads are independent: keep 8 in flight per lane (latency-bound otherwise), add in index order
+    int j = y;
+    for (; j + 7 * kRowLanes < chunks; j += 8 * kRowLanes) {
+      T v[8][NOUT];
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+#pragma unroll
+        for (int k = 0; k < NOUT; k++) v[u][k] = partial[((long)(j + u * kRowLanes) * NOUT + k) * cols + c];
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+#pragma unroll
+        for (int k = 0; k < NOUT; k++) sum[k] += v[u][k];
+    }
+    for (; j < chunks; j += kRowLanes)
 #pragma unroll
       for (int k = 0; k < NOUT; k++) sum[k] += partial[((long)j * NOUT + k) * cols + c];
+  }
 #pragma unroll
   for (int k = 0; k < NOUT; k++) red[y][k][x] = sum[k];
   __syncthreads();

@@ -19,6 +19,8 @@
 // Eligibility: K % 4 == 0, 16-byte aligned operands, leading dimensions % 4 == 0 (else gemm.hip's kernel).
 #include "gemm_common.h"
 
+#pragma clang diagnostic ignored "-Winline-asm"  // the DMA asm clobbers m0 on purpose
+
 namespace aslp {
 namespace {
 

@@ -56,6 +56,29 @@ void *scratch(int slot, size_t bytes) {
   return g_scratch[slot];
 }
 
+static unsigned *g_tickets = nullptr;
+static int g_ticket_count = 0;
+unsigned *tickets(int count) {
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  if (count > g_ticket_count) {
+    if (g_tickets) {
+      (void)hipStreamSynchronize(cur_stream());
+      (void)hipFree(g_tickets);
+    }
+    const int want = count < 4096 ? 4096 : count * 2;
+    void *p = nullptr;
+    if (hipMalloc(&p, sizeof(unsigned) * want) != hipSuccess || hipMemset(p, 0, sizeof(unsigned) * want) != hipSuccess) {
+      set_error("hipMalloc(tickets) failed");
+      g_tickets = nullptr;
+      g_ticket_count = 0;
+      return nullptr;
+    }
+    g_tickets = static_cast<unsigned *>(p);
+    g_ticket_count = want;
+  }
+  return g_tickets;
+}
+
 }  // namespace aslp
 
 extern "C" {
