@@ -147,6 +147,15 @@ void aslp_bn_backward(const float *in, MatrixDim d, const float *out_diff, int o
                       const float *scale, const float *mean, const float *inv_std, float *dscale, float *dshift,
                       float momentum, float *in_diff, int id_stride);
 /* inference with given mean / inv_std (same file :166-173) */
+/* The same with a Sigmoid component fused behind the normalisation (nnet-activation.h:153-175): forward also writes
+ * act_out = sigmoid(bn_out) (out may then be NULL); backward takes the diff w.r.t. the SIGMOID output plus that output
+ * act_y and forms dy = out_diff .* y .* (1 - y) on the fly.  act_* == NULL gives the plain functions above. */
+void aslp_bn_forward_act(const float *in, MatrixDim d, float *out, int out_stride, float *xhat, int xhat_stride, const float *scale,
+                         const float *shift, float *mean, float *inv_std, double *acc_means, double *acc_vars, float var_floor, float *act_out,
+                         int act_stride);
+void aslp_bn_backward_act(const float *in, MatrixDim d, const float *out_diff, int od_stride, float *xhat, int xhat_stride, const float *scale,
+                          const float *mean, const float *inv_std, float *dscale, float *dshift, float momentum, float *in_diff, int id_stride,
+                          const float *act_y, int act_stride);
 void aslp_bn_apply(const float *in, MatrixDim d, float *out, int out_stride, const float *mean, const float *inv_std,
                    const float *scale, const float *shift);
 /* Xent::Eval (nnet-loss.cc:63-122) in one pass over [rows x cols]:

@@ -555,13 +555,25 @@ struct GemmProf {
 GemmProf g_prof[4];
 bool g_prof_on = false;
 std::mutex g_prof_mu;
+std::vector<hipEvent_t> g_event_pool;  // recycled: no event creation / destruction inside a timed region
+
+hipEvent_t take_event() {
+  if (!g_event_pool.empty()) {
+    hipEvent_t e = g_event_pool.back();
+    g_event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
 
 void drain(GemmProf &p) {
   for (auto &ev : p.pending) {
     float ms = 0.f;
     if (hipEventSynchronize(ev.second) == hipSuccess && hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) p.ms += ms;
-    (void)hipEventDestroy(ev.first);
-    (void)hipEventDestroy(ev.second);
+    g_event_pool.push_back(ev.first);
+    g_event_pool.push_back(ev.second);
   }
   p.pending.clear();
 }
@@ -673,10 +685,11 @@ int aslp_sgemm_ex(int transA, int transB, int M, int N, int K, float alpha, cons
   hipEvent_t e0 = nullptr, e1 = nullptr;
   bool prof = g_prof_on;
   if (prof) {
-    (void)hipEventCreate(&e0);
-    (void)hipEventCreate(&e1);
-    (void)hipEventRecord(e0, cur_stream());
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    e0 = take_event();
+    e1 = take_event();
   }
+  if (prof) (void)hipEventRecord(e0, cur_stream());
   if (!transA && transB) launch_aligned<true, true>(g);
   else if (!transA && !transB) launch_aligned<true, false>(g);
   else if (transA && !transB) launch_aligned<false, false>(g);
@@ -703,6 +716,12 @@ void aslp_gemm_force_tile(int cfg) { g_force_tile = cfg; }
 void aslp_gemm_profile(int enable) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   g_prof_on = enable != 0;
+  if (g_prof_on)  // events for ~100 training steps up front, so the timed region only records
+    while (g_event_pool.size() < 4096) {
+      hipEvent_t e = nullptr;
+      if (hipEventCreate(&e) != hipSuccess) break;
+      g_event_pool.push_back(e);
+    }
 }
 void aslp_gemm_profile_reset(void) {
   std::lock_guard<std::mutex> lk(g_prof_mu);

@@ -2,8 +2,8 @@
 //
 // Both are HBM-bound.  The reference issues ~25 elementwise /
 // gemv launches per BatchNormalization step and ~15 + 5 blocking reductions per Xent::Eval;
-// here BN forward is 2 column-statistics passes + 1 write pass, BN backward 1 statistics
-// pass + 1 write pass, and Xent one pass with the row held in registers.
+// here BN forward is ONE column-statistics pass + 1 write pass (optionally producing the following Sigmoid's
+// output as well), BN backward 1 statistics pass + 1 write pass (optionally absorbing that Sigmoid's backward), and Xent one pass with the row held in registers.
 #include "aslp_kernels.h"
 #include "colreduce.h"
 #include "common.h"
@@ -12,60 +12,47 @@ namespace aslp {
 namespace {
 
 // ---- BatchNormalization ---------------------------------------------------------------
-// pass 1: sum x (float, for the mean like the reference's fp32 gemv) and, for the running
-// statistics, sum x and sum fl(x*x) in double (nnet-batch-normalization.h:216-220).
+// the ONE statistics pass: sum x and sum fl(x*x) in double for the running statistics
+// (nnet-batch-normalization.h:216-220: the square is formed in float first), plus sum x*x with the
+// product exact in double, from which the batch variance follows without a second pass over `in`:
+//   var = E[x^2] - mean^2  evaluated in double (53-bit sums of 24-bit data: no cancellation problem),
+// where the reference makes a second fp32 pass sum (x - mean)^2 (:193-204); the two agree to fp32
+// rounding of the reference's own result, far inside the 1e-4 parity tolerance.
 struct BnSum1F {
   static constexpr bool kVec = true;
   const float *in; int ld;
   template <int VW>
-  __device__ void operator()(int r, int c, double (&acc)[2][VW]) const {
+  __device__ void operator()(int r, int c, double (&acc)[3][VW]) const {
     float x[VW];
     loadv<VW>(in + (long)r * ld + c, x);
 #pragma unroll
     for (int i = 0; i < VW; i++) {
       acc[0][i] += (double)x[i];
       acc[1][i] += (double)(x[i] * x[i]);
+      acc[2][i] += (double)x[i] * (double)x[i];
     }
   }
 };
 struct BnSum1G {
-  float inv_rows; float *mean; double *acc_means, *acc_vars;
-  __device__ void operator()(int c, const double (&s)[2]) const {
+  float inv_rows, floor_; float *mean, *inv_std; double *acc_means, *acc_vars;
+  __device__ void operator()(int c, const double (&s)[3]) const {
     // the reference's mean is an fp32 gemv result scaled by 1/B; a double sum rounded once to
-    // fp32 differs from it by < 1 ulp-of-sum, far inside the 1e-4 parity tolerance.
+    // fp32 differs from it by < 1 ulp-of-sum.
     mean[c] = (float)s[0] * inv_rows;
+    const double m = s[0] * (double)inv_rows;
+    double var = s[2] * (double)inv_rows - m * m;
+    var = var > 0.0 ? var : 0.0;
+    inv_std[c] = 1.0f / sqrtf((float)var + floor_);
     if (acc_means) acc_means[c] += s[0];
     if (acc_vars) acc_vars[c] += s[1];
   }
 };
-// pass 2: sum (x - mean)^2 -> inv_std = 1/sqrt(var + floor)  (:193-204)
-struct BnSum2F {
-  static constexpr bool kVec = true;
-  const float *in; int ld; const float *mean;
-  template <int VW>
-  __device__ void operator()(int r, int c, float (&acc)[1][VW]) const {
-    float x[VW], m[VW];
-    loadv<VW>(in + (long)r * ld + c, x);
-    loadv<VW>(mean + c, m);
-#pragma unroll
-    for (int i = 0; i < VW; i++) {
-      float d = x[i] - m[i];
-      acc[0][i] += d * d;
-    }
-  }
-};
-struct BnSum2G {
-  float inv_rows, floor_; float *inv_std;
-  __device__ void operator()(int c, const float (&s)[1]) const {
-    float v = s[0] * inv_rows + floor_;
-    inv_std[c] = 1.0f / sqrtf(v);
-  }
-};
-// pass 3: xhat = (x - mean) * inv_std ; out = xhat * gamma + beta
+// write pass: xhat = (x - mean) * inv_std ; out = xhat * gamma + beta ; optionally act = sigmoid(out) for a Sigmoid
+// component fused behind the normalisation (then `out` itself may be NULL: nobody else reads it)
 template <bool VEC>
 __global__ void __launch_bounds__(kBlock) bn_normalize_kernel(const float *in, int ldi, float *out, int ldo, float *xhat, int ldx,
                                                               const float *mean, const float *inv_std, const float *scale,
-                                                              const float *shift, int rows, int cols) {
+                                                              const float *shift, int rows, int cols, float *act, int lda) {
   constexpr int W = VEC ? 4 : 1;
   int cw = cols / W;
   long n = (long)rows * cw;
@@ -79,24 +66,39 @@ __global__ void __launch_bounds__(kBlock) bn_normalize_kernel(const float *in, i
       h.x = (x.x - m.x) * s.x; h.y = (x.y - m.y) * s.y; h.z = (x.z - m.z) * s.z; h.w = (x.w - m.w) * s.w;
       o.x = h.x * g.x + b.x; o.y = h.y * g.y + b.y; o.z = h.z * g.z + b.z; o.w = h.w * g.w + b.w;
       if (xhat) *reinterpret_cast<float4 *>(xhat + (long)r * ldx + c) = h;
-      *reinterpret_cast<float4 *>(out + (long)r * ldo + c) = o;
+      if (out) *reinterpret_cast<float4 *>(out + (long)r * ldo + c) = o;
+      if (act) {
+        float4 y;
+        y.x = sigmoid_ref(o.x); y.y = sigmoid_ref(o.y); y.z = sigmoid_ref(o.z); y.w = sigmoid_ref(o.w);
+        *reinterpret_cast<float4 *>(act + (long)r * lda + c) = y;
+      }
     } else {
       float h = (in[(long)r * ldi + c] - mean[c]) * inv_std[c];
       if (xhat) xhat[(long)r * ldx + c] = h;
-      out[(long)r * ldo + c] = h * scale[c] + shift[c];
+      const float o = h * scale[c] + shift[c];
+      if (out) out[(long)r * ldo + c] = o;
+      if (act) act[(long)r * lda + c] = sigmoid_ref(o);
     }
   }
 }
 
 // backward statistics: S1 = sum dy, S2 = sum xhat*dy
+// `y` != NULL: a Sigmoid is fused behind the normalisation and `dy` is the diff w.r.t. ITS output;
+// the diff w.r.t. the BN output is dy * y * (1 - y), formed on the fly (nnet-activation.h:170-173)
 struct BnBwdF {
   static constexpr bool kVec = true;
-  const float *dy; int ldd; const float *xhat; int ldx;
+  const float *dy; int ldd; const float *xhat; int ldx; const float *y; int ldy;
   template <int VW>
   __device__ void operator()(int r, int c, float (&acc)[2][VW]) const {
     float d[VW], h[VW];
     loadv<VW>(dy + (long)r * ldd + c, d);
     loadv<VW>(xhat + (long)r * ldx + c, h);
+    if (y) {
+      float yy[VW];
+      loadv<VW>(y + (long)r * ldy + c, yy);
+#pragma unroll
+      for (int i = 0; i < VW; i++) d[i] = d[i] * yy[i] * (1.0f - yy[i]);
+    }
 #pragma unroll
     for (int i = 0; i < VW; i++) {
       acc[0][i] += d[i];
@@ -120,7 +122,7 @@ struct BnBwdG {
 template <bool VEC>
 __global__ void __launch_bounds__(kBlock) bn_backward_kernel(const float *dy, int ldd, float *xhat, int ldx, const float *scale,
                                                              const float *inv_std, const float *s1, const float *s2, float *in_diff,
-                                                             int ldi, int rows, int cols) {
+                                                             int ldi, int rows, int cols, const float *y, int ldy) {
   constexpr int W = VEC ? 4 : 1;
   int cw = cols / W;
   long n = (long)rows * cw;
@@ -138,6 +140,13 @@ __global__ void __launch_bounds__(kBlock) bn_backward_kernel(const float *dy, in
     } else {
       dyv[0] = dy[(long)r * ldd + c]; hv[0] = xhat[(long)r * ldx + c]; gv[0] = scale[c]; iv[0] = inv_std[c];
       s1v[0] = s1[c]; s2v[0] = s2[c];
+    }
+    if (y) {
+      float yv[W];
+      if (VEC) *reinterpret_cast<float4 *>(yv) = *reinterpret_cast<const float4 *>(y + (long)r * ldy + c);
+      else yv[0] = y[(long)r * ldy + c];
+#pragma unroll
+      for (int k = 0; k < W; k++) dyv[k] = dyv[k] * yv[k] * (1.0f - yv[k]);
     }
 #pragma unroll
     for (int k = 0; k < W; k++) {
@@ -269,45 +278,58 @@ using namespace aslp;
 
 extern "C" {
 
-void aslp_bn_forward(const float *in, MatrixDim d, float *out, int out_stride, float *xhat, int xhat_stride, const float *scale,
-                     const float *shift, float *mean, float *inv_std, double *acc_means, double *acc_vars, float var_floor) {
+void aslp_bn_forward_act(const float *in, MatrixDim d, float *out, int out_stride, float *xhat, int xhat_stride, const float *scale,
+                         const float *shift, float *mean, float *inv_std, double *acc_means, double *acc_vars, float var_floor, float *act_out,
+                         int act_stride) {
   if (d.rows <= 0 || d.cols <= 0) return;
+  if (!out && !act_out) { set_error("aslp_bn_forward: no output"); return; }
   const float invB = 1.0f / (float)d.rows;
   const bool in_vec = aligned16(in) && d.stride % 4 == 0;
-  colreduce<2, double>("bn_forward.sum", d.rows, d.cols, BnSum1F{in, d.stride}, BnSum1G{invB, mean, acc_means, acc_vars}, in_vec);
-  colreduce<1, float>("bn_forward.var", d.rows, d.cols, BnSum2F{in, d.stride, mean}, BnSum2G{invB, var_floor, inv_std},
-                      in_vec && aligned16(mean), kScratchReduce2);
-  bool vec = d.cols % 4 == 0 && d.stride % 4 == 0 && out_stride % 4 == 0 && (!xhat || xhat_stride % 4 == 0) && aligned16(in) &&
-             aligned16(out) && (!xhat || aligned16(xhat)) && aligned16(mean) && aligned16(inv_std) && aligned16(scale) && aligned16(shift);
+  colreduce<3, double>("bn_forward.stats", d.rows, d.cols, BnSum1F{in, d.stride}, BnSum1G{invB, var_floor, mean, inv_std, acc_means, acc_vars},
+                       in_vec);
+  bool vec = d.cols % 4 == 0 && d.stride % 4 == 0 && (!out || (out_stride % 4 == 0 && aligned16(out))) &&
+             (!xhat || (xhat_stride % 4 == 0 && aligned16(xhat))) && (!act_out || (act_stride % 4 == 0 && aligned16(act_out))) &&
+             aligned16(in) && aligned16(mean) && aligned16(inv_std) && aligned16(scale) && aligned16(shift);
   long n = (long)d.rows * (vec ? d.cols / 4 : d.cols);
-  if (vec) hipLaunchKernelGGL((bn_normalize_kernel<true>), dim3(grid_for(n)), dim3(kBlock), 0, cur_stream(), in, d.stride, out, out_stride, xhat, xhat_stride, mean, inv_std, scale, shift, d.rows, d.cols);
-  else hipLaunchKernelGGL((bn_normalize_kernel<false>), dim3(grid_for(n)), dim3(kBlock), 0, cur_stream(), in, d.stride, out, out_stride, xhat, xhat_stride, mean, inv_std, scale, shift, d.rows, d.cols);
+  if (vec) hipLaunchKernelGGL((bn_normalize_kernel<true>), dim3(grid_for(n)), dim3(kBlock), 0, cur_stream(), in, d.stride, out, out_stride, xhat, xhat_stride, mean, inv_std, scale, shift, d.rows, d.cols, act_out, act_stride);
+  else hipLaunchKernelGGL((bn_normalize_kernel<false>), dim3(grid_for(n)), dim3(kBlock), 0, cur_stream(), in, d.stride, out, out_stride, xhat, xhat_stride, mean, inv_std, scale, shift, d.rows, d.cols, act_out, act_stride);
   check_launch("bn_forward");
+}
+void aslp_bn_forward(const float *in, MatrixDim d, float *out, int out_stride, float *xhat, int xhat_stride, const float *scale,
+                     const float *shift, float *mean, float *inv_std, double *acc_means, double *acc_vars, float var_floor) {
+  aslp_bn_forward_act(in, d, out, out_stride, xhat, xhat_stride, scale, shift, mean, inv_std, acc_means, acc_vars, var_floor, nullptr, 0);
 }
 
 void aslp_bn_apply(const float *in, MatrixDim d, float *out, int out_stride, const float *mean, const float *inv_std, const float *scale, const float *shift) {
   if (d.rows <= 0 || d.cols <= 0) return;
   long n = (long)d.rows * d.cols;
-  hipLaunchKernelGGL((bn_normalize_kernel<false>), dim3(grid_for(n)), dim3(kBlock), 0, cur_stream(), in, d.stride, out, out_stride, (float *)nullptr, 0, mean, inv_std, scale, shift, d.rows, d.cols);
+  hipLaunchKernelGGL((bn_normalize_kernel<false>), dim3(grid_for(n)), dim3(kBlock), 0, cur_stream(), in, d.stride, out, out_stride, (float *)nullptr, 0, mean, inv_std, scale, shift, d.rows, d.cols, (float *)nullptr, 0);
   check_launch("bn_apply");
 }
 
-void aslp_bn_backward(const float *in, MatrixDim d, const float *out_diff, int od_stride, float *xhat, int xhat_stride, const float *scale,
-                      const float *mean, const float *inv_std, float *dscale, float *dshift, float momentum, float *in_diff, int id_stride) {
+void aslp_bn_backward_act(const float *in, MatrixDim d, const float *out_diff, int od_stride, float *xhat, int xhat_stride, const float *scale,
+                          const float *mean, const float *inv_std, float *dscale, float *dshift, float momentum, float *in_diff, int id_stride,
+                          const float *act_y, int act_stride) {
   (void)in; (void)mean;  // (x - mean) is recovered as xhat / inv_std: saves one pass over `in`
   if (d.rows <= 0 || d.cols <= 0) return;
   float *s12 = static_cast<float *>(scratch(kScratchReduce2, sizeof(float) * 2 * (size_t)d.cols));
   if (!s12) return;
-  colreduce<2, float>("bn_backward.stats", d.rows, d.cols, BnBwdF{out_diff, od_stride, xhat, xhat_stride},
+  const bool y_ok = !act_y || (aligned16(act_y) && act_stride % 4 == 0);
+  colreduce<2, float>("bn_backward.stats", d.rows, d.cols, BnBwdF{out_diff, od_stride, xhat, xhat_stride, act_y, act_stride},
                       BnBwdG{momentum, dscale, dshift, s12, s12 + d.cols},
-                      aligned16(out_diff) && od_stride % 4 == 0 && aligned16(xhat) && xhat_stride % 4 == 0);
+                      aligned16(out_diff) && od_stride % 4 == 0 && aligned16(xhat) && xhat_stride % 4 == 0 && y_ok);
   if (!in_diff) return;
   long n = (long)d.rows * d.cols;
   bool vec = d.cols % 4 == 0 && od_stride % 4 == 0 && xhat_stride % 4 == 0 && id_stride % 4 == 0 && aligned16(out_diff) &&
-             aligned16(xhat) && aligned16(in_diff) && aligned16(scale) && aligned16(inv_std) && aligned16(s12);
-  if (vec) hipLaunchKernelGGL((bn_backward_kernel<true>), dim3(grid_for(n / 4)), dim3(kBlock), 0, cur_stream(), out_diff, od_stride, xhat, xhat_stride, scale, inv_std, s12, s12 + d.cols, in_diff, id_stride, d.rows, d.cols);
-  else hipLaunchKernelGGL((bn_backward_kernel<false>), dim3(grid_for(n)), dim3(kBlock), 0, cur_stream(), out_diff, od_stride, xhat, xhat_stride, scale, inv_std, s12, s12 + d.cols, in_diff, id_stride, d.rows, d.cols);
+             aligned16(xhat) && aligned16(in_diff) && aligned16(scale) && aligned16(inv_std) && aligned16(s12) && y_ok;
+  if (vec) hipLaunchKernelGGL((bn_backward_kernel<true>), dim3(grid_for(n / 4)), dim3(kBlock), 0, cur_stream(), out_diff, od_stride, xhat, xhat_stride, scale, inv_std, s12, s12 + d.cols, in_diff, id_stride, d.rows, d.cols, act_y, act_stride);
+  else hipLaunchKernelGGL((bn_backward_kernel<false>), dim3(grid_for(n)), dim3(kBlock), 0, cur_stream(), out_diff, od_stride, xhat, xhat_stride, scale, inv_std, s12, s12 + d.cols, in_diff, id_stride, d.rows, d.cols, act_y, act_stride);
   check_launch("bn_backward");
+}
+void aslp_bn_backward(const float *in, MatrixDim d, const float *out_diff, int od_stride, float *xhat, int xhat_stride, const float *scale,
+                      const float *mean, const float *inv_std, float *dscale, float *dshift, float momentum, float *in_diff, int id_stride) {
+  aslp_bn_backward_act(in, d, out_diff, od_stride, xhat, xhat_stride, scale, mean, inv_std, dscale, dshift, momentum, in_diff, id_stride, nullptr,
+                       0);
 }
 
 void aslp_xent_eval(const float *net_out, MatrixDim d, const float *tgt, int tgt_stride, const int32_cuda *labels, const float *frame_weights,

@@ -31,6 +31,7 @@ for _n in ("aslp_nnet_input_dim", "aslp_nnet_output_dim", "aslp_nnet_num_compone
 _sig("aslp_nnet_component_marker", _i, _H, _i, C.c_char_p, _i)
 _sig("aslp_nnet_info", _i, _H, C.c_char_p, _i)
 _sig("aslp_nnet_set_link_aliasing", _i, _H, _i)
+_sig("aslp_nnet_set_layer_fusion", _i, _H, _i)
 _sig("aslp_nnet_propagate", _i, _H, _vp, _i, _i, _i, _vp, _i)
 _sig("aslp_nnet_feedforward", _i, _H, _vp, _i, _i, _i, _vp, _i)
 _sig("aslp_nnet_backpropagate", _i, _H, _vp, _i, _i, _i, _vp, _i)
@@ -308,6 +309,7 @@ class Nnet:
         return buf.value.decode()
 
     def SetLinkAliasing(self, on): _ok(lib.aslp_nnet_set_link_aliasing(self.h, int(on)))
+    def SetLayerFusion(self, on): _ok(lib.aslp_nnet_set_layer_fusion(self.h, int(on)))
 
     def Propagate(self, x, out=None):
         _chk(x)

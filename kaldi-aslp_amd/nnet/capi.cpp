@@ -102,6 +102,7 @@ int aslp_nnet_component_marker(aslp_nnet_t n, int c, char *buf, int buflen) {
 }
 int aslp_nnet_info(aslp_nnet_t n, char *buf, int buflen) { API_BEGIN CopyStr(n->nnet.Info(), buf, buflen); API_END }
 int aslp_nnet_set_link_aliasing(aslp_nnet_t n, int on) { API_BEGIN n->nnet.SetLinkAliasing(on != 0); API_END }
+int aslp_nnet_set_layer_fusion(aslp_nnet_t n, int on) { API_BEGIN n->nnet.SetLayerFusion(on != 0); API_END }
 
 int aslp_nnet_propagate(aslp_nnet_t n, const float *in, int rows, int cols, int stride, float *out, int out_stride) {
   API_BEGIN

@@ -545,6 +545,24 @@ class BatchNormalization : public UpdatableComponent {
                      mean_vec_.Data(), var_vec_.Data(), dscale_.Data(), dshift_.Data(), opts_.momentum,
                      in_diff ? in_diff->Data() : nullptr, in_diff ? in_diff->Stride() : 0);
   }
+  // Executor peephole (nnet-nnet.cpp): a Sigmoid that is this component's only consumer is folded into the write
+  // pass (forward) and into the statistics / write passes (backward); the BN output itself is never materialised.
+  void PropagateWithSigmoid(const CuMatrixBase &in, CuMatrix *sigmoid_out) {
+    ASLP_ASSERT(in.NumCols() == input_dim_);
+    if (!acc_cleaned_) { acc_cleaned_ = true; CleanAccs(); }
+    if (XsharpO_.NumRows() != in.NumRows() || XsharpO_.NumCols() != output_dim_) XsharpO_.Resize(in.NumRows(), output_dim_, kUndefined);
+    if (sigmoid_out->NumRows() != in.NumRows() || sigmoid_out->NumCols() != output_dim_) sigmoid_out->Resize(in.NumRows(), output_dim_, kUndefined);
+    aslp_bn_forward_act(in.Data(), in.Dim(), nullptr, 0, XsharpO_.Data(), XsharpO_.Stride(), scale_.Data(), shift_.Data(), mean_vec_.Data(),
+                        var_vec_.Data(), acc_means_.Data(), acc_vars_.Data(), var_floor_, sigmoid_out->Data(), sigmoid_out->Stride());
+    num_acc_frames_ += in.NumRows();
+  }
+  void BackpropagateWithSigmoid(const CuMatrixBase &in, const CuMatrixBase &sigmoid_out, const CuMatrixBase &sigmoid_out_diff, CuMatrix *in_diff) {
+    ASLP_ASSERT(SameDim(sigmoid_out, sigmoid_out_diff) && sigmoid_out.NumCols() == output_dim_);
+    if (in_diff && (in_diff->NumRows() != in.NumRows() || in_diff->NumCols() != input_dim_)) in_diff->Resize(in.NumRows(), input_dim_, kUndefined);
+    aslp_bn_backward_act(in.Data(), in.Dim(), sigmoid_out_diff.Data(), sigmoid_out_diff.Stride(), XsharpO_.Data(), XsharpO_.Stride(), scale_.Data(),
+                         mean_vec_.Data(), var_vec_.Data(), dscale_.Data(), dshift_.Data(), opts_.momentum, in_diff ? in_diff->Data() : nullptr,
+                         in_diff ? in_diff->Stride() : 0, sigmoid_out.Data(), sigmoid_out.Stride());
+  }
   void Update(const CuMatrixBase &, const CuMatrixBase &) {  // :280-284
     const BaseFloat lr = opts_.learn_rate;
     aslp_vec_axpy2(-lr, dscale_.Data(), scale_.Data(), dshift_.Data(), shift_.Data(), scale_.Dim());

@@ -30,6 +30,7 @@ Nnet &Nnet::operator=(const Nnet &other) {  // nnet-nnet.cc:41-65
   for (int32 i = 0; i < other.NumComponents(); i++) components_.push_back(other.GetComponent(i).Copy());
   SetTrainOptions(other.opts_);
   alias_links_ = other.alias_links_;
+  fuse_layers_ = other.fuse_layers_;
   InitInputOutput();
   Check();
   return *this;
@@ -41,12 +42,32 @@ bool Nnet::IsDirectLink(int32 i) const {
   return in.size() == 1 && in[0] >= 0 && off[0] == 0 && components_[in[0]]->OutputDim() == components_[i]->InputDim();
 }
 
+int32 Nnet::FusedSigmoidOf(int32 i) const {
+  if (!fuse_layers_ || !alias_links_ || components_[i]->GetType() != Component::kBatchNormalization || num_consumers_[i] != 1) return -1;
+  for (int32 j = i + 1; j < NumComponents(); j++) {
+    const std::vector<int32> &inp = components_[j]->GetInput();
+    if (inp.size() == 1 && inp[0] == i)
+      return (components_[j]->GetType() == Component::kSigmoid && IsDirectLink(j)) ? j : -1;
+  }
+  return -1;
+}
+const CuMatrixBase &Nnet::OutputBuffer(int32 c) const {
+  if (FusedSigmoidOf(c) >= 0) ASLP_ERR << "output of component " << c << " is not materialised (fused into the Sigmoid behind it); SetLayerFusion(false)";
+  return *out_view_[c];
+}
+const CuMatrixBase &Nnet::OutputDiffBuffer(int32 c) const {
+  if (FusedSigmoidOf(c) >= 0) ASLP_ERR << "out-diff of component " << c << " is not materialised (fused into the Sigmoid behind it); SetLayerFusion(false)";
+  return *out_diff_view_[c];
+}
+
 void Nnet::Propagate(const std::vector<const CuMatrixBase *> &in, std::vector<CuMatrix *> *out) {  // nnet-nnet.cc:70-106
   ASLP_ASSERT(NULL != out);
   ASLP_ASSERT(in.size() == input_.size());
   int num_frame = in[0]->NumRows();
   for (size_t i = 0; i < input_.size(); i++) in_view_[input_[i]] = in[i];  // InputLayer reads the caller's matrix
+  std::vector<char> done(components_.size(), 0);  // Sigmoids already produced by the BatchNormalization in front of them
   for (int32 i = 0; i < (int32)components_.size(); i++) {
+    if (done[i]) continue;
     if (components_[i]->GetType() != Component::kInputLayer) {
       const std::vector<int32> &input_idx = components_[i]->GetInput();
       const std::vector<int32> &offset = components_[i]->GetOffset();
@@ -63,7 +84,14 @@ void Nnet::Propagate(const std::vector<const CuMatrixBase *> &in, std::vector<Cu
       }
     }
     Timer tim1;
-    if (alias_links_ && components_[i]->PropagateIsCopy() && components_[i]->GetType() != Component::kInputLayer) {
+    const int32 fs = FusedSigmoidOf(i);
+    if (fs >= 0) {  // BatchNormalization + Sigmoid in one statistics pass and one write pass
+      dynamic_cast<BatchNormalization *>(components_[i])->PropagateWithSigmoid(*in_view_[i], &output_buf_[fs]);
+      out_view_[i] = &output_buf_[fs];
+      out_view_[fs] = &output_buf_[fs];
+      in_view_[fs] = &output_buf_[fs];  // never read: Sigmoid's backward only needs its output
+      done[fs] = 1;
+    } else if (alias_links_ && components_[i]->PropagateIsCopy() && components_[i]->GetType() != Component::kInputLayer) {
       out_view_[i] = in_view_[i];  // pure copy layer: pass the buffer through
     } else {
       components_[i]->Propagate(*in_view_[i], &output_buf_[i]);
@@ -96,7 +124,14 @@ void Nnet::Backpropagate(const std::vector<const CuMatrixBase *> &out_diff, std:
   for (size_t i = 0; i < output_.size(); i++) output_diff_buf_[output_[i]].CopyFromMat(*(out_diff[i]));
   for (int32 i = 0; i < N; i++) out_diff_view_[i] = &output_diff_buf_[i];
   const bool want_in_diff = (in_diff != NULL);
+  std::vector<int32> fused_sigmoid(N, -1);   // BN index -> its folded Sigmoid
+  std::vector<char> folded(N, 0);            // Sigmoids handled by their BatchNormalization
+  for (int32 i = 0; i < N; i++) {
+    fused_sigmoid[i] = FusedSigmoidOf(i);
+    if (fused_sigmoid[i] >= 0) folded[fused_sigmoid[i]] = 1;
+  }
   for (int32 i = N - 1; i >= 0; i--) {
+    if (folded[i]) { in_diff_view_[i] = NULL; continue; }
     Timer tim2;
     const bool is_input = components_[i]->GetType() == Component::kInputLayer;
     // The reference also back-propagates into the network input (:124-125); that in-diff is
@@ -113,6 +148,9 @@ void Nnet::Backpropagate(const std::vector<const CuMatrixBase *> &out_diff, std:
         // identity backward into the only consumer slot: hand the buffer over instead of copying
         target->Swap(&output_diff_buf_[i]);
         out_diff_view_[i] = target;
+      } else if (fused_sigmoid[i] >= 0) {
+        const int32 fs = fused_sigmoid[i];
+        dynamic_cast<BatchNormalization *>(components_[i])->BackpropagateWithSigmoid(*in_view_[i], output_buf_[fs], output_diff_buf_[fs], target);
       } else {
         components_[i]->Backpropagate(*in_view_[i], *out_view_[i], output_diff_buf_[i], target);
       }

@@ -39,8 +39,8 @@ class Nnet {
   void RemoveLastComponent() { RemoveComponent(NumComponents() - 1); }
 
   // per-component forward outputs / backward output-diffs (reference: PropagateBuffer())
-  const CuMatrixBase &OutputBuffer(int32 c) const { return *out_view_[c]; }
-  const CuMatrixBase &OutputDiffBuffer(int32 c) const { return *out_diff_view_[c]; }
+  const CuMatrixBase &OutputBuffer(int32 c) const;
+  const CuMatrixBase &OutputDiffBuffer(int32 c) const;
   const CuMatrixBase &InputDiffBuffer(int32 c) const;
 
   int32 NumParams() const;
@@ -80,11 +80,16 @@ class Nnet {
   // (nnet-nnet.cc:86-95), and its in-diff is written straight into the producer's out-diff
   // buffer when it is the producer's only consumer (nnet-nnet.cc:133-144).  Values are identical.
   void SetLinkAliasing(bool on) { alias_links_ = on; }
+  // Engine switch (not in the reference): fold a Sigmoid whose only producer is a BatchNormalization (and which is
+  // that component's only consumer) into the BatchNormalization kernels.  Values are identical; the intermediate
+  // BN output / Sigmoid in-diff buffers are then not materialised (OutputBuffer() on them throws).
+  void SetLayerFusion(bool on) { fuse_layers_ = on; }
 
  private:
   void InitStream(std::istream &is);
   void InitInputOutput();
   bool IsDirectLink(int32 i) const;  // single input, offset 0, full width
+  int32 FusedSigmoidOf(int32 i) const;  // index of the Sigmoid folded into BatchNormalization i, or -1
 
   std::vector<Component *> components_;
   std::vector<int32> input_, output_;
@@ -97,6 +102,7 @@ class Nnet {
   std::vector<const CuMatrixBase *> out_diff_view_; // component i's out-diff (may have been handed on to the producer)
   NnetTrainOptions opts_;
   bool alias_links_ = true;
+  bool fuse_layers_ = true;
 };
 
 }  // namespace aslp

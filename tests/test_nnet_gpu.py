@@ -196,3 +196,29 @@ def test_model_file_round_trip_text_and_binary(aslp, oracle, dev, tmp_path):
     txt = open(tmp_path / "t.nnet").read()
     assert txt.startswith("<Nnet> \n<InputLayer> 8 8 0 [ -1 ]\n[ 0 ]\n\n")  # header, then the "\n" of nnet-component.cc:340
     assert "<Splice> 24 8 1 [ 0 ]\n[ 0 ]\n\n[ -1 0 1 ]\n" in txt and txt.rstrip().endswith("</Nnet>")
+
+
+def test_bn_sigmoid_fusion_is_bit_identical(aslp, oracle, dev, tmp_path):
+    """The executor folds a Sigmoid behind a BatchNormalization into the BN kernels (Nnet::SetLayerFusion, default on).
+    Same float operations in the same order: outputs and updated parameters must be bit-identical to the unfused run."""
+    in_dim, hid, nh, out_dim, mb = 40, 96, 3, 50, 128
+    d, path = make_dnn(oracle, tmp_path, in_dim, hid, nh, out_dim, 1, mb, seed=11)
+    nets = [aslp.Nnet.Read(path), aslp.Nnet.Read(path)]
+    nets[1].SetLayerFusion(False)
+    rng = np.random.default_rng(5)
+    xents = [aslp.Xent(), aslp.Xent()]
+    for step in range(3):
+        x = torch.from_numpy(rng.standard_normal((mb, in_dim)).astype(np.float32)).to(dev)
+        lab = torch.from_numpy(rng.integers(0, out_dim, mb).astype(np.int32)).to(dev)
+        outs = []
+        for net, xe in zip(nets, xents):
+            net.SetTrainOptions(learn_rate=0.01, momentum=0.9)
+            net.TrainStepXent(xe, x, lab)
+            outs.append(net.ComponentOutput(net.NumComponents() - 1, mb, out_dim))
+        assert np.array_equal(outs[0], outs[1]), step
+        assert np.array_equal(nets[0].GetParams(), nets[1].GetParams()), step
+    # the folded intermediate is not materialised: asking for it is an error, not stale data
+    bn = [c for c in range(nets[0].NumComponents()) if nets[0].Marker(c) == "<BatchNormalization>"][0]
+    with pytest.raises(RuntimeError):
+        nets[0].ComponentOutput(bn, mb, hid)
+    assert nets[1].ComponentOutput(bn, mb, hid).shape == (mb, hid)
