@@ -62,31 +62,32 @@ __global__ void __launch_bounds__(kColLanes *kRowLanes) colreduce_stage1(F f, in
 }
 
 // G: struct with  __device__ void operator()(int c, const T (&sum)[NOUT]) const
-// One lane per column, kRowLanes waves split the chunk list; the per-wave sums are combined
-// through LDS in wave order, so the result does not depend on scheduling.
+// Finalize: 16 column lanes x 16 chunk lanes per workgroup (cols/16 workgroups: the pass is pure latency, so it
+// wants many short dependent chains rather than few long ones); the per-lane sums are combined through LDS in
+// chunk-lane order, so the result does not depend on scheduling.
+constexpr int kFinCols = 16, kFinLanes = 16;
 template <int NOUT, class T, class G>
-__global__ void __launch_bounds__(kColLanes *kRowLanes) colreduce_stage2(G g, int chunks, int cols, const T *partial) {
-  __shared__ T red[kRowLanes][NOUT][kColLanes];
+__global__ void __launch_bounds__(kFinCols *kFinLanes) colreduce_stage2(G g, int chunks, int cols, const T *partial) {
+  __shared__ T red[kFinLanes][NOUT][kFinCols];
   const int x = threadIdx.x, y = threadIdx.y;
-  const int c = blockIdx.x * kColLanes + x;
+  const int c = blockIdx.x * kFinCols + x;
   T sum[NOUT];
 #pragma unroll
   for (int k = 0; k < NOUT; k++) sum[k] = T(0);
   if (c < cols) {
-    // the chunk loads are independent: keep 8 in flight per lane (latency-bound otherwise), add in index order
     int j = y;
-    for (; j + 7 * kRowLanes < chunks; j += 8 * kRowLanes) {
-      T v[8][NOUT];
+    for (; j + 3 * kFinLanes < chunks; j += 4 * kFinLanes) {  // 4 independent loads in flight per output
+      T v[4][NOUT];
 #pragma unroll
-      for (int u = 0; u < 8; u++)
+      for (int u = 0; u < 4; u++)
 #pragma unroll
-        for (int k = 0; k < NOUT; k++) v[u][k] = partial[((long)(j + u * kRowLanes) * NOUT + k) * cols + c];
+        for (int k = 0; k < NOUT; k++) v[u][k] = partial[((long)(j + u * kFinLanes) * NOUT + k) * cols + c];
 #pragma unroll
-      for (int u = 0; u < 8; u++)
+      for (int u = 0; u < 4; u++)
 #pragma unroll
         for (int k = 0; k < NOUT; k++) sum[k] += v[u][k];
     }
-    for (; j < chunks; j += kRowLanes)
+    for (; j < chunks; j += kFinLanes)
 #pragma unroll
       for (int k = 0; k < NOUT; k++) sum[k] += partial[((long)j * NOUT + k) * cols + c];
   }
@@ -98,7 +99,7 @@ __global__ void __launch_bounds__(kColLanes *kRowLanes) colreduce_stage2(G g, in
     for (int k = 0; k < NOUT; k++) {
       T s = red[0][k][x];
 #pragma unroll
-      for (int j = 1; j < kRowLanes; j++) s += red[j][k][x];
+      for (int j = 1; j < kFinLanes; j++) s += red[j][k][x];
       sum[k] = s;
     }
     g(c, sum);
@@ -123,7 +124,7 @@ void colreduce(const char *name, int rows, int cols, F f, G g, bool vec_ok = fal
   dim3 grid(ctiles, chunks), block(kColLanes, kRowLanes);
   if (vec) hipLaunchKernelGGL((colreduce_stage1<NOUT, 4, T, F>), grid, block, 0, cur_stream(), f, rows, cols, rpc, partial);
   else hipLaunchKernelGGL((colreduce_stage1<NOUT, 1, T, F>), grid, block, 0, cur_stream(), f, rows, cols, rpc, partial);
-  hipLaunchKernelGGL((colreduce_stage2<NOUT, T, G>), dim3((cols + kColLanes - 1) / kColLanes), block, 0, cur_stream(), g,
+  hipLaunchKernelGGL((colreduce_stage2<NOUT, T, G>), dim3((cols + kFinCols - 1) / kFinCols), dim3(kFinCols, kFinLanes), 0, cur_stream(), g,
                      chunks, cols, partial);
   check_launch(name);
 }
