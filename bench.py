@@ -114,7 +114,13 @@ def main():
     g.manual_seed(1234 + rank)                          # every rank its own shard
     x = torch.randn(MB, IN_DIM, device=dev, generator=g)
     labels = torch.randint(0, OUT_DIM, (MB,), device=dev, generator=g, dtype=torch.int32)
-    worker = BspWorker(net) if world > 1 else None
+    # ASLP_BENCH_FORCE_SYNC=1 exercises the sync path on a single GPU as well (all-reduce over one rank)
+    force_sync = os.environ.get("ASLP_BENCH_FORCE_SYNC") == "1"
+    if force_sync and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    worker = BspWorker(net) if (world > 1 or force_sync) else None
 
     frames_since_sync = 0
 
@@ -207,7 +213,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or dist.is_initialized():
         dist.destroy_process_group()
 
 

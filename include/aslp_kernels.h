@@ -121,6 +121,13 @@ typedef struct aslp_gemm_epilogue_ {
   float *act_out;      /* or NULL */
   int ld_act;
   int act;
+  /* transA products only (A is [K x M]): colsum[m] = sum_k A[k][m] + colsum_beta * colsum[m]; if colsum_w,
+   * colsum_w[m] += colsum_w_alpha * colsum[m].  This is the bias gradient + bias SGD step of AffineTransform::Update
+   * (nnet-affine-transform.h:214-216, 227) riding on the weight-gradient GEMM, whose A operand is the same `diff`. */
+  float *colsum;       /* [M] or NULL */
+  float colsum_beta;
+  float *colsum_w;     /* [M] or NULL */
+  float colsum_w_alpha;
 } aslp_gemm_epilogue;
 int aslp_sgemm_ex(int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda,
                   const float *B, int ldb, float beta, float *C, int ldc, const aslp_gemm_epilogue *ep);

@@ -611,7 +611,7 @@ void launch_variant(GemmArgs &g) {
   else if (g.N % 128 == 0 && g.M % 64 == 0 && blocks(64, 128) >= 200) cfg = 212;
   else cfg = 207;
   if (cfg >= 200) {
-    if (gemm_glds_launch(g, A_KC, B_KC, cfg)) return;
+    if (gemm_glds_launch(g, A_KC, B_KC, cfg)) { if (!A_KC) g.ep.colsum = nullptr; return; }  // column sums done in-kernel
     cfg = g.M <= 32 ? 1 : (cfg == 207 ? 7 : 12);  // not eligible: register-staged kernel of the same tile
   }
   switch (cfg) {
@@ -677,7 +677,8 @@ int aslp_sgemm_ex(int transA, int transB, int M, int N, int K, float alpha, cons
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.alpha = alpha; g.beta = beta;
-  if (ep) g.ep = *ep; else { g.ep = aslp_gemm_epilogue(); g.ep.bias = nullptr; g.ep.clip = 0.f; g.ep.W = nullptr; g.ep.act_out = nullptr; g.ep.act = 0; g.ep.ldw = 0; g.ep.ld_act = 0; g.ep.w_alpha = 0.f; }
+  if (ep) g.ep = *ep; else g.ep = aslp_gemm_epilogue();  // zero-initialised: every optional piece off
+  if (g.ep.colsum && !transA) return -5;  // column sums are defined for transposed A only
   g.a_vec = aligned16(A) && lda % 4 == 0;
   g.b_vec = aligned16(B) && ldb % 4 == 0;
   // report order: 0 = NT, 1 = NN, 2 = TN, 3 = TT
@@ -694,6 +695,11 @@ int aslp_sgemm_ex(int transA, int transB, int M, int N, int K, float alpha, cons
   else if (!transA && !transB) launch_aligned<true, false>(g);
   else if (transA && !transB) launch_aligned<false, false>(g);
   else launch_aligned<false, true>(g);
+  if (g.ep.colsum) {  // the chosen kernel could not fold the column sums in: one extra pass over A (same values)
+    MatrixDim da = {K, M, lda};
+    if (g.ep.colsum_w) aslp_add_row_sum_mat_vec_sgd(1.0f, A, da, g.ep.colsum_beta, g.ep.colsum, g.ep.colsum_w, g.ep.colsum_w_alpha);
+    else aslp_add_row_sum_mat_vec(1.0f, A, da, g.ep.colsum_beta, g.ep.colsum);
+  }
   check_launch("aslp_sgemm");
   {
     std::lock_guard<std::mutex> lk(g_prof_mu);

@@ -168,6 +168,12 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_f32_glds(GemmArgs g) {
     for (int j = 0; j < TN; j++)
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+  // optional column sums of a transposed A operand (bias gradient on the weight-gradient GEMM): the first column
+  // of tiles' wn == 0 waves add up the A fragments they multiply anyway
+  const bool do_colsum = !A_KC && g.ep.colsum != nullptr && tn == 0 && wn == 0;  // wave-uniform
+  float asum[TM];
+#pragma unroll
+  for (int i = 0; i < TM; i++) asum[i] = 0.0f;
   auto mma_unit = [&](const Frag &f, auto M_) {
     constexpr int m = decltype(M_)::value;
     constexpr int n = m % TN, i = (m / TN) % TM, j = (m / (TN * TM)) % 4, h = m / (TN * TM * 4);
@@ -184,6 +190,14 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_f32_glds(GemmArgs g) {
       constexpr int sidx = decltype(S_)::value;
       mma_unit(fcur, S_);
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!A_KC && sidx == 0) {
+        if (do_colsum) {
+#pragma unroll
+          for (int h = 0; h < KH; h++)
+#pragma unroll
+            for (int i = 0; i < TM; i++) asum[i] += (fcur.a[h][i][0] + fcur.a[h][i][1]) + (fcur.a[h][i][2] + fcur.a[h][i][3]);
+        }
+      }
       if constexpr (sidx <= SB) {
         static_for<sidx * G / (SB + 1), (sidx + 1) * G / (SB + 1)>([&](auto U_) { dma_unit(U_, StReq(), t + D); });
         if constexpr (sidx == SB) {
@@ -222,6 +236,21 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_f32_glds(GemmArgs g) {
   wait_vmcnt<0>();  // drain the clamped tail requests before the LDS block is released
 
   gemm_epilogue<TM, TN>(g, acc, m0 + wm * WM, n0 + wn * WN, l31, lh);
+  if constexpr (!A_KC) {
+    if (do_colsum) {
+#pragma unroll
+      for (int i = 0; i < TM; i++) {
+        const float s_all = asum[i] + __shfl_xor(asum[i], 32, 64);  // the two lane halves hold disjoint k subsets
+        const int row = m0 + wm * WM + i * 32 + l31;
+        if (lh == 0 && row < g.M) {
+          float v = s_all;
+          if (g.ep.colsum_beta != 0.0f) v += g.ep.colsum_beta * g.ep.colsum[row];
+          g.ep.colsum[row] = v;
+          if (g.ep.colsum_w) g.ep.colsum_w[row] += g.ep.colsum_w_alpha * v;
+        }
+      }
+    }
+  }
 }
 
 template <int BM, int BN, int WGM, int WGN, bool A_KC, bool B_KC, int NS, bool TAIL>
@@ -260,6 +289,7 @@ bool launch_cfg(GemmArgs &g, int cfg) {
 }  // namespace
 
 bool gemm_glds_launch(GemmArgs &g, bool a_kc, bool b_kc, int cfg) {
+  // (a column-sum request on a non-transposed A is the caller's job: see aslp_sgemm_ex)
   if (g.K < 4 || g.K % 4 != 0 || !g.a_vec || !g.b_vec) return false;
   if (!a_kc && (g.M % 4 != 0 || g.M < 4)) return false;
   if (!b_kc && (g.N % 4 != 0 || g.N < 4)) return false;

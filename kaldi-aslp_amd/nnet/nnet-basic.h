@@ -148,9 +148,10 @@ class AffineTransform : public UpdatableComponent {
     // gradient and the step, the SGD step W += -lr * W_corr rides in the GEMM epilogue.
     aslp_gemm_epilogue ep = aslp_gemm_epilogue();
     if (plain) { ep.W = linearity_.Data(); ep.ldw = linearity_.Stride(); ep.w_alpha = -lr; }
+    // bias_corr_ = colsum(diff) + mmt * bias_corr_ and the step bias_ += -lr_bias * bias_corr_ ride on the same GEMM:
+    // its transposed A operand IS `diff`, so the first column of tiles sums the fragments it multiplies anyway
+    ep.colsum = bias_corr_.Data(); ep.colsum_beta = mmt; ep.colsum_w = bias_.Data(); ep.colsum_w_alpha = -lr_bias;
     linearity_corr_.AddMatMat(1.0, diff, kTrans, input, kNoTrans, mmt, &ep);
-    // bias_corr_ = colsum(diff) + mmt * bias_corr_ with the step bias_ += -lr_bias * bias_corr_ fused
-    aslp_add_row_sum_mat_vec_sgd(1.0f, diff.Data(), diff.Dim(), mmt, bias_corr_.Data(), bias_.Data(), -lr_bias);
     if (!plain) {
       if (l2 != 0.0) linearity_.AddMat(-lr * l2 * num_frames, linearity_);
       if (l1 != 0.0) cu::RegularizeL1(&linearity_, &linearity_corr_, lr * l1 * num_frames, lr);

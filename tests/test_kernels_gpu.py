@@ -202,6 +202,28 @@ def test_sgemm_epilogue(aslp, oracle, dev):
     assert oracle.rel_err(Wd.cpu().numpy(), W - 0.01 * Gref) < 2e-6
 
 
+@pytest.mark.parametrize("mb,n_out,n_in", [(100, 72, 64), (1024, 2048, 440), (256, 3000, 128), (60, 130, 36), (33, 40, 20)])
+def test_sgemm_colsum_epilogue(aslp, oracle, dev, mb, n_out, n_in):
+    """Bias gradient + bias SGD step folded into the weight-gradient GEMM (AffineTransform::Update,
+    nnet-affine-transform.h:214-227): colsum = sum_k diff[k][:] + mmt*colsum ; bias += -lr*colsum."""
+    rng = np.random.default_rng(mb + n_out)
+    diff = rng.standard_normal((mb, n_out)).astype(np.float32)
+    x = rng.standard_normal((mb, n_in)).astype(np.float32)
+    G0 = rng.standard_normal((n_out, n_in)).astype(np.float32)
+    bc0 = rng.standard_normal(n_out).astype(np.float32)
+    b0 = rng.standard_normal(n_out).astype(np.float32)
+    Gd, bcd, bd = T(G0, dev), T(bc0, dev), T(b0, dev)
+    ep = aslp._lib.GemmEpilogue(None, 0.0, None, 0, 0.0, None, 0, 0, bcd.data_ptr(), 0.9, bd.data_ptr(), -0.02)
+    aslp.ops.sgemm(1, 0, 1.0, T(diff, dev), T(x, dev), 0.5, Gd, ep)
+    assert oracle.rel_err(Gd.cpu().numpy(), diff.T.astype(np.float64) @ x + 0.5 * G0) < 2e-6
+    bc_ref = diff.astype(np.float64).sum(0) + 0.9 * bc0
+    assert oracle.rel_err(bcd.cpu().numpy(), bc_ref) < 2e-6
+    assert oracle.rel_err(bd.cpu().numpy(), b0 - 0.02 * bc_ref) < 2e-6
+    # column sums of a non-transposed A are not defined
+    with pytest.raises(ValueError):
+        aslp.ops.sgemm(0, 0, 1.0, T(x, dev), T(rng.standard_normal((n_in, 8)).astype(np.float32), dev), 0.0, torch.empty(mb, 8, device=dev), ep)
+
+
 @pytest.mark.parametrize("rows,cols", [(8, 6), (64, 32), (1024, 2048), (100, 37), (129, 260)])
 def test_batchnorm_forward_backward(aslp, oracle, dev, rows, cols):
     rng = np.random.default_rng(6)
