@@ -79,6 +79,28 @@ def cpu_baseline(seconds_budget=20.0):
                       "%d of %d hardware threads)" % (steps, MB, cores, avail)}
 
 
+def ctc_rel_err(aslp, dev):
+    """Second half of BASELINE.json's metric ("CTC-loss fp32 rel-err"): the HIP forward-backward against the outputs
+    the REFERENCE's own CPU code produced for tests/golden/ctc_a128_t200.bin (data file, generator oracle/gen_ctc_golden.cpp)."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctc_golden
+    g = ctc_golden.load("a128_t200")
+    acts = torch.from_numpy(g["acts"].reshape(g["maxT"] * g["mb"], g["A"])).to(dev)
+    labels, o = [], 0
+    for l in g["label_lengths"]:
+        labels.append([int(v) for v in g["flat_labels"][o:o + l]])
+        o += l
+    costs, grads = aslp.ops.ctc_loss(acts, labels, g["input_lengths"])
+    fin = np.isfinite(g["costs"])
+    rel_cost = float(np.max(np.abs(costs[fin] - g["costs"][fin]) / np.maximum(np.abs(g["costs"][fin]), 1e-6)))
+    gr = grads.cpu().numpy().reshape(-1).astype(np.float64)
+    rel_grad = float(np.linalg.norm(gr - g["grads"]) / np.linalg.norm(g["grads"]))
+    return {"max_rel_err_cost": rel_cost, "rel_frobenius_err_grad": rel_grad, "tolerance": 1e-4,
+            "fixture": "tests/golden/ctc_a128_t200.bin (alphabet 128, %d utterances, T <= %d; reference CPU output)" % (g["mb"], g["maxT"])}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -210,6 +232,8 @@ def main():
             out["roofline"] = {"bound": "mfma", "achieved": FLOP_PER_FRAME * args.steps * MB / elapsed / 1e12, "peak": F32_MFMA_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": FLOP_PER_FRAME * args.steps * MB / elapsed / 1e12 / F32_MFMA_PEAK_TFLOPS,
                                "traffic": None, "note": "whole-step algorithmic flops (per-kernel events disabled)"}
+        if world == 1:
+            out["ctc_loss_fp32_rel_err"] = ctc_rel_err(aslp, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

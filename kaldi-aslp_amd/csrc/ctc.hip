@@ -26,10 +26,39 @@ namespace {
 
 constexpr float kNegInf = -INFINITY;
 
-__device__ __forceinline__ float log_plus(float p1, float p2) {  // ctc_helper.h:49-60
+// ctc_helper.h:49-60.  The reference's log_plus evaluates log1p(exp(-|a-b|)) + max(a,b) in DOUBLE (the unqualified
+// libm calls promote) and rounds once to float; at |alpha| ~ 1e3 (long utterances) a float evaluation is off by up to
+// an ulp of the SUM (6e-5), which shows as ~6e-5 relative gradient error.  The lattice is latency-bound, so the double
+// transcendental is affordable and buys parity at the 1e-7 level.
+__device__ __forceinline__ float log_plus(float p1, float p2) {
   if (p1 == kNegInf) return p2;
   if (p2 == kNegInf) return p1;
-  return log1pf(expf(-fabsf(p1 - p2))) + fmaxf(p1, p2);
+  return (float)(log1p(exp(-fabs((double)p1 - (double)p2))) + (double)fmaxf(p1, p2));
+}
+
+// The reference's host code calls std::log / std::exp on floats (glibc logf / expf: computed in double, rounded once,
+// correctly rounded in all but ~1e-9 of the cases).  alpha / beta reach magnitudes of several 1e3 on long utterances, where
+// one float ulp is 2-5e-4: unless the per-frame log-probabilities are BIT-identical to the reference's, the two lattices
+// drift apart by a few ulps and the posteriors by ~1e-4 relative.  So the CTC path evaluates them the same way.
+__device__ __forceinline__ float logf_cr(float x) { return (float)log((double)x); }
+__device__ __forceinline__ float expf_cr(float x) { return (float)exp((double)x); }
+
+// softmax of cpu_ctc.h:158-179 with the reference's exact arithmetic: max, exp(x - max) rounded to float, denominator
+// summed in float in index order, float division.  One lane per row (the sum order is sequential by definition).
+__global__ void __launch_bounds__(256) ctc_softmax_kernel(const float *__restrict__ acts, int ld, float *__restrict__ probs, int rows, int A) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const float *x = acts + (long)r * ld;
+  float *p = probs + (long)r * A;
+  float mx = -INFINITY;
+  for (int a = 0; a < A; a++) mx = fmaxf(mx, x[a]);
+  float denom = 0.0f;
+  for (int a = 0; a < A; a++) {
+    const float e = expf_cr(x[a] - mx);
+    p[a] = e;
+    denom += e;
+  }
+  for (int a = 0; a < A; a++) p[a] = p[a] / denom;
 }
 
 struct UttInfo {
@@ -39,11 +68,20 @@ struct UttInfo {
 
 // ---- alpha --------------------------------------------------------------------------------------------
 // LDS: two alpha columns + the blank-augmented label sequence.
-__global__ void __launch_bounds__(256) ctc_alpha_kernel(const float *__restrict__ probs, float *__restrict__ alphas, const UttInfo *info,
-                                                        const int *__restrict__ lwb_all, int A, int mb, int maxS, int maxT, float *loglike, int ldp) {
+__device__ void ctc_beta_pass(const float *__restrict__ probs, float *__restrict__ betas, const UttInfo &u, const int *__restrict__ lwb_all, int n,
+                              int mb, int maxS, int maxT, int ldp, float *smem);
+
+// blockIdx.y == 0: alpha pass; blockIdx.y == 1: beta pass of utterance blockIdx.x (both at once: 2 x mb workgroups)
+__global__ void __launch_bounds__(256) ctc_lattice_kernel(const float *__restrict__ probs, float *__restrict__ alphas, float *__restrict__ betas,
+                                                          const UttInfo *info, const int *__restrict__ lwb_all, int A, int mb, int maxS, int maxT,
+                                                          float *loglike, int ldp) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n = blockIdx.x;
   const UttInfo u = info[n];
+  if (blockIdx.y == 1) {
+    if (u.feasible) ctc_beta_pass(probs, betas, u, lwb_all, n, mb, maxS, maxT, ldp, smem);
+    return;
+  }
   if (!u.feasible) {
     if (threadIdx.x == 0) loglike[n] = 0.0f;
     return;
@@ -57,7 +95,7 @@ __global__ void __launch_bounds__(256) ctc_alpha_kernel(const float *__restrict_
   const long tstride = (long)ldp * mb;
   float *al = alphas + (long)n * maxS * maxT;
   for (int s = threadIdx.x; s < S; s += blockDim.x) {
-    float v = s < 2 ? logf(p[lab[s]]) : kNegInf;
+    float v = s < 2 ? logf_cr(p[lab[s]]) : kNegInf;
     a0[s] = v;
     al[s] = v;
   }
@@ -70,7 +108,7 @@ __global__ void __launch_bounds__(256) ctc_alpha_kernel(const float *__restrict_
       float sum = prev[s];
       if (s >= 1) sum = log_plus(sum, prev[s - 1]);
       if (s >= 2 && l != 0 && l != lab[s - 2]) sum = log_plus(sum, prev[s - 2]);
-      float v = sum + logf(pt[l]);
+      float v = sum + logf_cr(pt[l]);
       cur[s] = v;
       al[(long)t * S + s] = v;
     }
@@ -85,23 +123,65 @@ __global__ void __launch_bounds__(256) ctc_alpha_kernel(const float *__restrict_
   }
 }
 
-// ---- beta + gradient ------------------------------------------------------------------------------------
-// LDS: beta ping-pong [2*maxS], alpha*beta [maxS], labels [maxS], next_same [maxS], out[A], red[4]
-__global__ void __launch_bounds__(256) ctc_beta_grad_kernel(const float *__restrict__ probs, const float *__restrict__ alphas, float *__restrict__ grads,
-                                                            const UttInfo *info, const int *__restrict__ lwb_all, const int *__restrict__ next_all,
-                                                            const int *__restrict__ first_all, int A, int mb, int maxS, int maxT,
-                                                            const float *loglike, int ldg, int ldp) {
+// ---- beta -------------------------------------------------------------------------------------------------
+// Mirror of the alpha pass (cpu_ctc.h:300-350 without the per-frame reductions): beta rows ping-pong in LDS and
+// are written to the workspace.  Runs concurrently with the alpha pass (blockIdx.y selects the pass).
+__device__ void ctc_beta_pass(const float *__restrict__ probs, float *__restrict__ betas, const UttInfo &u, const int *__restrict__ lwb_all, int n,
+                              int mb, int maxS, int maxT, int ldp, float *smem) {
+  const int S = u.S, T = u.T;
+  float *b0 = smem, *b1 = smem + maxS;
+  int *lab = reinterpret_cast<int *>(smem + 2 * maxS);
+  for (int s = threadIdx.x; s < S; s += blockDim.x) lab[s] = lwb_all[u.lab_off + s];
+  __syncthreads();
+  const float *p = probs + (long)n * ldp;
+  const long tstride = (long)ldp * mb;
+  float *be = betas + (long)n * maxS * maxT;
+  float *nextb = b0, *curb = b1;
+  for (int t = T - 1; t >= 0; t--) {
+    const float *pt = p + t * tstride;
+    for (int s = threadIdx.x; s < S; s += blockDim.x) {
+      const int l = lab[s];
+      float v;
+      if (t == T - 1) {
+        v = (s >= S - 2) ? logf_cr(pt[l]) : kNegInf;
+      } else {
+        float sum = nextb[s];
+        if (s + 1 < S) sum = log_plus(sum, nextb[s + 1]);
+        if (s + 2 < S && l != 0 && l != lab[s + 2]) sum = log_plus(sum, nextb[s + 2]);
+        v = sum + logf_cr(pt[l]);
+      }
+      curb[s] = v;
+      be[(long)t * S + s] = v;
+    }
+    __syncthreads();
+    float *tmp = nextb; nextb = curb; curb = tmp;
+  }
+}
+
+// ---- gradient ---------------------------------------------------------------------------------------------
+// With both lattices in the workspace the per-frame work -- alpha*beta, the reduce-by-label and the gradient row
+// (cpu_ctc.h:318-362) -- is independent across frames: one wave per (frame, utterance), all CUs busy.  The
+// reduce-by-label keeps the reference's SEQUENTIAL order (ascending state index, every step a double log_plus
+// rounded to float): at |alpha + beta| of several 1e3 a float ulp is 2-5e-4, so any other summation order moves
+// the posteriors by ~1e-4 relative.  Lane 0 walks the blank states, the other lanes the chains of the non-blank
+// labels (first occurrence -> next occurrence of the same label).
+constexpr int kGradWaves = 4;
+__global__ void __launch_bounds__(64 * kGradWaves) ctc_grad_kernel(const float *__restrict__ probs, const float *__restrict__ alphas,
+                                                                    const float *__restrict__ betas, float *__restrict__ grads, const UttInfo *info,
+                                                                    const int *__restrict__ lwb_all, const int *__restrict__ next_all,
+                                                                    const int *__restrict__ first_all, int A, int mb, int maxS, int maxT,
+                                                                    const float *loglike, int ldg, int ldp) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int n = blockIdx.x;
+  const int n = blockIdx.y;
   const UttInfo u = info[n];
   if (!u.feasible) return;
   const int S = u.S, T = u.T;
-  float *b0 = smem, *b1 = smem + maxS, *ab = smem + 2 * maxS;
-  int *lab = reinterpret_cast<int *>(smem + 3 * maxS);
+  int *lab = reinterpret_cast<int *>(smem);
   int *nxt = lab + maxS;
   int *fst = nxt + maxS;
-  float *out = reinterpret_cast<float *>(fst + maxS);
-  float *red = out + A;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float *ab = reinterpret_cast<float *>(fst + maxS) + wave * (maxS + A);
+  float *out = ab + maxS;
   for (int s = threadIdx.x; s < S; s += blockDim.x) {
     lab[s] = lwb_all[u.lab_off + s];
     nxt[s] = next_all[u.lab_off + s];
@@ -109,60 +189,47 @@ __global__ void __launch_bounds__(256) ctc_beta_grad_kernel(const float *__restr
   }
   __syncthreads();
   const float logZ = loglike[n];
-  const long tstride = (long)ldp * mb;
+  const long tstride = (long)ldp * mb, gstride = (long)ldg * mb;
   const float *p = probs + (long)n * ldp;
   float *g = grads + (long)n * ldg;
-  const long gstride = (long)ldg * mb;
-  const float *al = alphas + (long)n * maxS * maxT;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float *nextb = b0, *curb = b1;  // nextb = beta_{t+1}, curb = beta_t
-  for (int t = T - 1; t >= 0; t--) {
-    const float *pt = p + t * tstride;
-    for (int a = threadIdx.x; a < A; a += blockDim.x) out[a] = kNegInf;
-    // beta_t and alpha*beta
-    for (int s = threadIdx.x; s < S; s += blockDim.x) {
-      const int l = lab[s];
-      float v;
-      if (t == T - 1) {
-        v = (s >= S - 2) ? logf(pt[l]) : kNegInf;
+  const float *al = alphas + (long)n * maxS * maxT, *be = betas + (long)n * maxS * maxT;
+  const int wstride = gridDim.x * kGradWaves;
+  const int iters = (T + wstride - 1) / wstride;  // same trip count for every wave of the grid: block barriers are legal
+  for (int it = 0; it < iters; it++) {
+    const int t = it * wstride + blockIdx.x * kGradWaves + wave;
+    const bool live = t < T;
+    if (live) {
+      for (int s = lane; s < S; s += 64) ab[s] = al[(long)t * S + s] + be[(long)t * S + s];
+      for (int a = lane; a < A; a += 64) out[a] = kNegInf;
+    }
+    __syncthreads();
+    if (live) {
+      if (lane == 0) {
+        float acc = kNegInf;
+        for (int s = 0; s < S; s += 2) acc = log_plus(ab[s], acc);
+        out[0] = acc;
       } else {
-        float sum = nextb[s];
-        if (s + 1 < S) sum = log_plus(sum, nextb[s + 1]);
-        if (s + 2 < S && l != 0 && l != lab[s + 2]) sum = log_plus(sum, nextb[s + 2]);
-        v = sum + logf(pt[l]);
-      }
-      curb[s] = v;
-      ab[s] = al[(long)t * S + s] + v;
-    }
-    __syncthreads();
-    // reduce by label: blanks (even s) by a block-wide log-sum-exp, every other label by the
-    // thread owning its first occurrence walking the chain of later occurrences (ascending s,
-    // the same order as the reference's sequential reduce-by-key, cpu_ctc.h:337-339)
-    float bl = kNegInf;
-    for (int s = 2 * threadIdx.x; s < S; s += 2 * blockDim.x) bl = log_plus(bl, ab[s]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) bl = log_plus(bl, __shfl_xor(bl, o, 64));
-    if (lane == 0) red[wave] = bl;
-    for (int s = 2 * threadIdx.x + 1; s < S; s += 2 * blockDim.x) {
-      if (fst[s]) {
-        float acc = ab[s];
-        for (int q = nxt[s]; q >= 0; q = nxt[q]) acc = log_plus(ab[q], acc);
-        out[lab[s]] = acc;
+        for (int s = 2 * (lane - 1) + 1; s < S; s += 2 * 63) {
+          if (fst[s]) {
+            float acc = ab[s];
+            for (int q = nxt[s]; q >= 0; q = nxt[q]) acc = log_plus(ab[q], acc);
+            out[lab[s]] = acc;
+          }
+        }
       }
     }
     __syncthreads();
-    if (threadIdx.x == 0) out[0] = log_plus(log_plus(red[0], red[1]), log_plus(red[2], red[3]));
-    __syncthreads();
-    // gradient row (cpu_ctc.h:352-362)
-    for (int a = threadIdx.x; a < A; a += blockDim.x) {
-      const float pr = pt[a], o = out[a];
-      float gv;
-      if (o == 0.0f || o == kNegInf || pr == 0.0f) gv = pr;
-      else gv = pr - expf(o - logf(pr) - logZ);
-      g[t * gstride + a] = gv;
+    if (live) {
+      const float *pt = p + t * tstride;
+      for (int a = lane; a < A; a += 64) {
+        const float pr = pt[a], o = out[a];
+        float gv;
+        if (o == 0.0f || o == kNegInf || pr == 0.0f) gv = pr;
+        else gv = pr - expf_cr(o - logf_cr(pr) - logZ);
+        g[t * gstride + a] = gv;
+      }
     }
     __syncthreads();
-    float *tmp = nextb; nextb = curb; curb = tmp;
   }
 }
 
@@ -172,7 +239,7 @@ __global__ void neg_costs_kernel(const float *loglike, const UttInfo *info, floa
 }
 
 struct Layout {
-  size_t probs, alphas, info, lwb, nxt, fst, loglike, costs, total;
+  size_t probs, alphas, betas, info, lwb, nxt, fst, loglike, costs, total;
 };
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 Layout make_layout(int A, int mb, int maxT, int maxS, size_t total_S) {
@@ -180,6 +247,7 @@ Layout make_layout(int A, int mb, int maxT, int maxS, size_t total_S) {
   size_t o = 0;
   l.probs = o; o += align256(sizeof(float) * (size_t)maxT * mb * A);
   l.alphas = o; o += align256(sizeof(float) * (size_t)mb * maxS * maxT);
+  l.betas = o; o += align256(sizeof(float) * (size_t)mb * maxS * maxT);
   l.info = o; o += align256(sizeof(UttInfo) * mb);
   l.lwb = o; o += align256(sizeof(int) * total_S);
   l.nxt = o; o += align256(sizeof(int) * total_S);
@@ -288,23 +356,31 @@ static ctcStatus_t ctc_loss_impl(const float *const activations, int ld_acts, fl
     probs = const_cast<float *>(activations);
     ldp = ld_acts;
   } else if (maxT > 0) {
-    cudaF_softmax_reduce(0, 0, probs, activations, d, ld_acts);
+    hipLaunchKernelGGL(ctc_softmax_kernel, dim3((d.rows + 255) / 256), dim3(256), 0, stream, activations, ld_acts, probs, d.rows, A);
   }
   set_cur_stream(saved);
 
-  const size_t lds_alpha = sizeof(float) * 2 * maxS + sizeof(int) * maxS;
-  const size_t lds_beta = sizeof(float) * 3 * maxS + sizeof(int) * 3 * maxS + sizeof(float) * (A + 4);
-  if (lds_beta > 160 * 1024) return CTC_STATUS_INVALID_VALUE;  // alphabet + label length beyond one CU's LDS
+  const int Tl = maxT > 0 ? maxT : 1;
+  const size_t lds_lattice = sizeof(float) * 2 * maxS + sizeof(int) * maxS;
+  const size_t lds_grad = sizeof(int) * 3 * maxS + sizeof(float) * kGradWaves * ((size_t)maxS + A);
+  if (lds_lattice > 160 * 1024 || lds_grad > 160 * 1024) return CTC_STATUS_INVALID_VALUE;  // alphabet + label length beyond one CU's LDS
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ctc_alpha_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ctc_beta_grad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ctc_lattice_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ctc_grad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  hipLaunchKernelGGL(ctc_alpha_kernel, dim3(mb), dim3(256), lds_alpha, stream, probs, alphas, d_info, d_lwb, A, mb, maxS, maxT > 0 ? maxT : 1, d_ll, ldp);
-  if (gradients != nullptr)
-    hipLaunchKernelGGL(ctc_beta_grad_kernel, dim3(mb), dim3(256), lds_beta, stream, probs, alphas, gradients, d_info, d_lwb, d_nxt, d_fst, A, mb,
-                       maxS, maxT > 0 ? maxT : 1, d_ll, ld_grads, ldp);
+  float *betas = reinterpret_cast<float *>(ws + lay.betas);
+  // alpha and (when gradients are wanted) beta lattices side by side: 2 x mb workgroups
+  hipLaunchKernelGGL(ctc_lattice_kernel, dim3(mb, gradients != nullptr ? 2 : 1), dim3(256), lds_lattice, stream, probs, alphas, betas, d_info, d_lwb,
+                     A, mb, maxS, Tl, d_ll, ldp);
+  if (gradients != nullptr) {
+    // one wave per (frame, utterance); a few frames per wave so the label tables are staged once per workgroup
+    int tchunks = (Tl + kGradWaves * 4 - 1) / (kGradWaves * 4);
+    if (tchunks < 1) tchunks = 1;
+    hipLaunchKernelGGL(ctc_grad_kernel, dim3(tchunks, mb), dim3(64 * kGradWaves), lds_grad, stream, probs, alphas, betas, gradients, d_info, d_lwb,
+                       d_nxt, d_fst, A, mb, maxS, Tl, d_ll, ld_grads, ldp);
+  }
   hipLaunchKernelGGL(neg_costs_kernel, dim3((mb + 255) / 256), dim3(256), 0, stream, d_ll, d_info, d_costs, mb);
   if (hipGetLastError() != hipSuccess) return CTC_STATUS_EXECUTION_FAILED;
   if (hipMemcpyAsync(costs, d_costs, sizeof(float) * mb, hipMemcpyDeviceToHost, stream) != hipSuccess) return CTC_STATUS_MEMOPS_FAILED;

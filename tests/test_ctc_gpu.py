@@ -47,7 +47,7 @@ def test_reference_small_test_known_answer(aslp, dev):
     assert abs(np.exp(-costs[0]) - (p[0, 1] * p[1, 2]).item()) < 1e-6
 
 
-@pytest.mark.parametrize("A,mb,maxT,seed", [(4, 1, 3, 0), (30, 7, 45, 1), (128, 32, 200, 2), (3000, 4, 60, 3), (50, 300, 20, 4)])
+@pytest.mark.parametrize("A,mb,maxT,seed", [(4, 1, 3, 0), (30, 7, 45, 1), (128, 32, 200, 2), (3000, 4, 60, 3), (50, 300, 20, 4), (128, 8, 800, 5)])
 def test_ctc_random_ragged_vs_oracle(aslp, oracle, dev, A, mb, maxT, seed):
     rng = np.random.default_rng(seed)
     in_len = rng.integers(1, maxT + 1, mb).astype(np.int32)
