@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--sync-period", type=int, default=25600, help="frames between BSP model syncs (N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-profile", action="store_true", help="do not bracket GEMM launches with HIP events")
+    ap.add_argument("--no-update-overlap", action="store_true",
+                    help="keep the weight-gradient GEMMs on the main stream (per-kernel profiles: every kernel alone on the chip)")
     args = ap.parse_args()
 
     import torch
@@ -131,6 +133,8 @@ def main():
 
     net = aslp.Nnet.Init(proto(), seed=777)            # same init on every rank (like one aslp-nnet-init model)
     net.SetTrainOptions(learn_rate=1e-5, momentum=0.0)  # small lr: synthetic labels, keep the run finite
+    if args.no_update_overlap:
+        net.SetUpdateOverlap(False)
     xent = aslp.Xent()
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)                          # every rank its own shard
@@ -175,13 +179,17 @@ def main():
     # Per-kernel durations for the roofline: HIP events around every GEMM launch on the launch stream, over the SAME
     # K steps run once more -- two event records per GEMM inside the timed region cost ~7 % of `value` (measured),
     # so `value` above is timed without them and the kernel timings come from this second, identical pass.
+    # The weight-gradient GEMMs normally run on a side stream beside the rest of the backward pass; for the per-kernel
+    # figure they are put back in line (SetUpdateOverlap(False)), so each duration is that kernel alone on the chip.
     if not args.no_gemm_profile:
+        net.SetUpdateOverlap(False)
         aslp.lib.aslp_gemm_profile(1)
         aslp.lib.aslp_gemm_profile_reset()
         for _ in range(args.steps):
             step()
         torch.cuda.synchronize()
         aslp.lib.aslp_gemm_profile(0)
+        net.SetUpdateOverlap(not args.no_update_overlap)
     else:
         aslp.lib.aslp_gemm_profile_reset()
 

@@ -163,6 +163,12 @@ void aslp_bn_forward_act(const float *in, MatrixDim d, float *out, int out_strid
 void aslp_bn_backward_act(const float *in, MatrixDim d, const float *out_diff, int od_stride, float *xhat, int xhat_stride, const float *scale,
                           const float *mean, const float *inv_std, float *dscale, float *dshift, float momentum, float *in_diff, int id_stride,
                           const float *act_y, int act_stride);
+/* aslp_bn_backward_act + BatchNormalization::Update (nnet-batch-normalization.h:280-284) taken in the statistics
+ * finalize: scale -= learn_rate * dscale, shift -= learn_rate * dshift; in_diff is formed with the scale the
+ * forward pass used. */
+void aslp_bn_backward_step(MatrixDim d, const float *out_diff, int od_stride, float *xhat, int xhat_stride, float *scale, float *shift,
+                           const float *inv_std, float *dscale, float *dshift, float momentum, float learn_rate, float *in_diff, int id_stride,
+                           const float *act_y, int act_stride);
 void aslp_bn_apply(const float *in, MatrixDim d, float *out, int out_stride, const float *mean, const float *inv_std,
                    const float *scale, const float *shift);
 /* Xent::Eval (nnet-loss.cc:63-122) in one pass over [rows x cols]:
@@ -171,6 +177,12 @@ void aslp_bn_apply(const float *in, MatrixDim d, float *out, int out_stride, con
  * Dense targets (tgt != NULL) or one label per row (labels != NULL: one-hot posterior). */
 void aslp_xent_eval(const float *net_out, MatrixDim d, const float *tgt, int tgt_stride, const int32_cuda *labels,
                     const float *frame_weights, float *diff, int diff_stride, double *stats_dev);
+/* Softmax::PropagateFnc (nnet-activation.h:46-49) + Xent::Eval over the activations IN FRONT of the softmax, one
+ * pass; post_out (nullable) receives the posteriors, bit-identical to cudaF_softmax_reduce. Only for
+ * aslp_softmax_xent_supported(cols) (513..8192 classes). */
+int aslp_softmax_xent_supported(int cols);
+void aslp_softmax_xent_eval(const float *acts, MatrixDim d, const float *tgt, int tgt_stride, const int32_cuda *labels,
+                            const float *frame_weights, float *diff, int diff_stride, double *stats_dev, float *post_out, int post_stride);
 /* PosteriorToMatrix scatter: mat[row[i]][col[i]] += val[i]  (hmm/posterior.cc, used nnet-loss.cc:168) */
 void aslp_scatter_add(float *mat, MatrixDim d, const int32_cuda *rows, const int32_cuda *cols, const float *vals, int n);
 /* Splice backward (nnet-various.h:143-175): in_diff[t] = sum_k out_diff[clamp(t+off[k])][k-th block] */

@@ -38,6 +38,7 @@ int aslp_nnet_component_marker(aslp_nnet_t n, int c, char *buf, int buflen);
 int aslp_nnet_info(aslp_nnet_t n, char *buf, int buflen);               /* Nnet::Info :714 */
 int aslp_nnet_set_link_aliasing(aslp_nnet_t n, int on);                 /* engine switch, see nnet-nnet.h */
 int aslp_nnet_set_layer_fusion(aslp_nnet_t n, int on);                  /* engine switch: BatchNormalization + Sigmoid in one kernel pair */
+int aslp_nnet_set_update_overlap(aslp_nnet_t n, int on);                /* engine switch: AffineTransform::Update on a side stream */
 
 /* out: [rows x OutputDim].  Nnet::Propagate :191 / Feedforward :218 */
 int aslp_nnet_propagate(aslp_nnet_t n, const float *in, int rows, int cols, int stride, float *out, int out_stride);

@@ -106,13 +106,23 @@ struct BnBwdF {
     }
   }
 };
+// `step`: the component's SGD step (nnet-batch-normalization.h:280-284) is taken right here instead of in a launch of
+// its own; the write pass that follows still needs the scale the forward pass used, so it is kept in `scale_used`.
 struct BnBwdG {
   float mmt; float *dscale, *dshift; float *s1, *s2;
+  float *scale, *shift, *scale_used; float neg_lr; bool step;
   __device__ void operator()(int c, const float (&s)[2]) const {
-    dshift[c] = s[0] + mmt * dshift[c];
-    dscale[c] = s[1] + mmt * dscale[c];
+    const float dsh = s[0] + mmt * dshift[c], dsc = s[1] + mmt * dscale[c];
+    dshift[c] = dsh;
+    dscale[c] = dsc;
     s1[c] = s[0];
     s2[c] = s[1];
+    const float g = scale[c];
+    scale_used[c] = g;
+    if (step) {
+      scale[c] = g + neg_lr * dsc;
+      shift[c] += neg_lr * dsh;
+    }
   }
 };
 // in_diff: with D = dy*gamma, the reference's 4 steps (:238-276) reduce to
@@ -173,11 +183,16 @@ constexpr int kXentPerThread = 32;  // cols <= 8192 cached in registers
 
 // One block (256 threads) per row.  rowstats[r][0..4] = {w, correct*w, w*sum t log(y+1e-20),
 // w*sum t log(t+1e-20), w*sum t y} as double; summed in fixed order by xent_finalize.
-template <bool DENSE>
+// SOFTMAX: `y` holds the activations in front of the network's final Softmax and the row softmax is formed here,
+// with exactly the arithmetic of softmax_rows_kernel<256> (same lane -> column mapping, same reduction order), so
+// folding the Softmax component into the loss changes no bit; `y_out` (nullable) receives the posteriors.
+template <bool DENSE, bool SOFTMAX>
 __global__ void __launch_bounds__(256) xent_rows_kernel(const float *y, int ldy, const float *t, int ldt, const int32_t *labels,
-                                                        const float *fw, float *diff, int ldd, int rows, int cols, double *rowstats) {
+                                                        const float *fw, float *diff, int ldd, int rows, int cols, double *rowstats,
+                                                        float *y_out, int ldyo) {
   __shared__ float shf[4][4];
   __shared__ int shi[4][2];
+  __shared__ float shs[4];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   for (int r = blockIdx.x; r < rows; r += gridDim.x) {
     const float *yr = y + (long)r * ldy;
@@ -186,11 +201,51 @@ __global__ void __launch_bounds__(256) xent_rows_kernel(const float *y, int ldy,
     float yv[kXentPerThread], tv[kXentPerThread];
     float tsum = 0.0f, ybest = -1e21f, tbest = -1e21f;
     int yi = -1, ti = -1;
+    if (SOFTMAX) {
+      float m = -INFINITY;
+#pragma unroll
+      for (int k = 0; k < kXentPerThread; k++) {
+        int c = tid + k * 256;
+        if (c < cols) {
+          yv[k] = yr[c];
+          m = fmaxf(m, yv[k]);
+        }
+      }
+      m = wave_max(m);
+      if (lane == 0) shs[w] = m;
+      __syncthreads();
+      m = fmaxf(fmaxf(fmaxf(shs[0], shs[1]), shs[2]), shs[3]);
+      __syncthreads();
+      float sum = 0.0f;
+#pragma unroll
+      for (int k = 0; k < kXentPerThread; k++) {
+        int c = tid + k * 256;
+        if (c < cols) {
+          yv[k] = expf(yv[k] - m);
+          sum += yv[k];
+        }
+      }
+      sum = wave_sum(sum);
+      if (lane == 0) shs[w] = sum;
+      __syncthreads();
+      sum = shs[0];
+      sum += shs[1]; sum += shs[2]; sum += shs[3];
+      __syncthreads();
+      const float inv = 1.0f / sum;
+#pragma unroll
+      for (int k = 0; k < kXentPerThread; k++) {
+        int c = tid + k * 256;
+        if (c < cols) {
+          yv[k] *= inv;
+          if (y_out) y_out[(long)r * ldyo + c] = yv[k];
+        }
+      }
+    }
 #pragma unroll
     for (int k = 0; k < kXentPerThread; k++) {
       int c = tid + k * 256;
       if (c < cols) {
-        yv[k] = yr[c];
+        if (!SOFTMAX) yv[k] = yr[c];
         tv[k] = DENSE ? tr[c] : (c == label ? 1.0f : 0.0f);
         tsum += tv[k];
         if (ybest < yv[k]) { ybest = yv[k]; yi = c; }
@@ -307,24 +362,38 @@ void aslp_bn_apply(const float *in, MatrixDim d, float *out, int out_stride, con
   check_launch("bn_apply");
 }
 
-void aslp_bn_backward_act(const float *in, MatrixDim d, const float *out_diff, int od_stride, float *xhat, int xhat_stride, const float *scale,
-                          const float *mean, const float *inv_std, float *dscale, float *dshift, float momentum, float *in_diff, int id_stride,
-                          const float *act_y, int act_stride) {
-  (void)in; (void)mean;  // (x - mean) is recovered as xhat / inv_std: saves one pass over `in`
+static void bn_backward_impl(MatrixDim d, const float *out_diff, int od_stride, float *xhat, int xhat_stride, float *scale, float *shift,
+                             const float *inv_std, float *dscale, float *dshift, float momentum, float *in_diff, int id_stride,
+                             const float *act_y, int act_stride, bool step, float learn_rate) {
   if (d.rows <= 0 || d.cols <= 0) return;
-  float *s12 = static_cast<float *>(scratch(kScratchReduce2, sizeof(float) * 2 * (size_t)d.cols));
+  float *s12 = static_cast<float *>(scratch(kScratchReduce2, sizeof(float) * 3 * (size_t)d.cols));
   if (!s12) return;
+  float *scale_used = s12 + 2 * (size_t)d.cols;
   const bool y_ok = !act_y || (aligned16(act_y) && act_stride % 4 == 0);
   colreduce<2, float>("bn_backward.stats", d.rows, d.cols, BnBwdF{out_diff, od_stride, xhat, xhat_stride, act_y, act_stride},
-                      BnBwdG{momentum, dscale, dshift, s12, s12 + d.cols},
+                      BnBwdG{momentum, dscale, dshift, s12, s12 + d.cols, scale, shift, scale_used, -learn_rate, step},
                       aligned16(out_diff) && od_stride % 4 == 0 && aligned16(xhat) && xhat_stride % 4 == 0 && y_ok);
   if (!in_diff) return;
   long n = (long)d.rows * d.cols;
   bool vec = d.cols % 4 == 0 && od_stride % 4 == 0 && xhat_stride % 4 == 0 && id_stride % 4 == 0 && aligned16(out_diff) &&
-             aligned16(xhat) && aligned16(in_diff) && aligned16(scale) && aligned16(inv_std) && aligned16(s12) && y_ok;
-  if (vec) hipLaunchKernelGGL((bn_backward_kernel<true>), dim3(grid_for(n / 4)), dim3(kBlock), 0, cur_stream(), out_diff, od_stride, xhat, xhat_stride, scale, inv_std, s12, s12 + d.cols, in_diff, id_stride, d.rows, d.cols, act_y, act_stride);
-  else hipLaunchKernelGGL((bn_backward_kernel<false>), dim3(grid_for(n)), dim3(kBlock), 0, cur_stream(), out_diff, od_stride, xhat, xhat_stride, scale, inv_std, s12, s12 + d.cols, in_diff, id_stride, d.rows, d.cols, act_y, act_stride);
+             aligned16(xhat) && aligned16(in_diff) && aligned16(inv_std) && aligned16(s12) && y_ok;
+  if (vec) hipLaunchKernelGGL((bn_backward_kernel<true>), dim3(grid_for(n / 4)), dim3(kBlock), 0, cur_stream(), out_diff, od_stride, xhat, xhat_stride, scale_used, inv_std, s12, s12 + d.cols, in_diff, id_stride, d.rows, d.cols, act_y, act_stride);
+  else hipLaunchKernelGGL((bn_backward_kernel<false>), dim3(grid_for(n)), dim3(kBlock), 0, cur_stream(), out_diff, od_stride, xhat, xhat_stride, scale_used, inv_std, s12, s12 + d.cols, in_diff, id_stride, d.rows, d.cols, act_y, act_stride);
   check_launch("bn_backward");
+}
+void aslp_bn_backward_act(const float *in, MatrixDim d, const float *out_diff, int od_stride, float *xhat, int xhat_stride, const float *scale,
+                          const float *mean, const float *inv_std, float *dscale, float *dshift, float momentum, float *in_diff, int id_stride,
+                          const float *act_y, int act_stride) {
+  (void)in; (void)mean;  // (x - mean) is recovered as xhat / inv_std: saves one pass over `in`
+  bn_backward_impl(d, out_diff, od_stride, xhat, xhat_stride, const_cast<float *>(scale), nullptr, inv_std, dscale, dshift, momentum, in_diff,
+                   id_stride, act_y, act_stride, false, 0.0f);
+}
+// backward + the component's own Update (scale -= lr*dscale, shift -= lr*dshift) in the statistics finalize
+void aslp_bn_backward_step(MatrixDim d, const float *out_diff, int od_stride, float *xhat, int xhat_stride, float *scale, float *shift,
+                           const float *inv_std, float *dscale, float *dshift, float momentum, float learn_rate, float *in_diff, int id_stride,
+                           const float *act_y, int act_stride) {
+  bn_backward_impl(d, out_diff, od_stride, xhat, xhat_stride, scale, shift, inv_std, dscale, dshift, momentum, in_diff, id_stride, act_y,
+                   act_stride, true, learn_rate);
 }
 void aslp_bn_backward(const float *in, MatrixDim d, const float *out_diff, int od_stride, float *xhat, int xhat_stride, const float *scale,
                       const float *mean, const float *inv_std, float *dscale, float *dshift, float momentum, float *in_diff, int id_stride) {
@@ -332,18 +401,35 @@ void aslp_bn_backward(const float *in, MatrixDim d, const float *out_diff, int o
                        0);
 }
 
-void aslp_xent_eval(const float *net_out, MatrixDim d, const float *tgt, int tgt_stride, const int32_cuda *labels, const float *frame_weights,
-                    float *diff, int diff_stride, double *stats_dev) {
+static void xent_eval_impl(const float *net_out, MatrixDim d, const float *tgt, int tgt_stride, const int32_cuda *labels,
+                           const float *frame_weights, float *diff, int diff_stride, double *stats_dev, bool softmax, float *y_out, int y_stride) {
   if (d.rows <= 0 || d.cols <= 0) return;
   if (d.cols > 256 * kXentPerThread) { set_error("aslp_xent_eval: more than 8192 output classes not supported"); return; }
   if (!tgt && !labels) { set_error("aslp_xent_eval: need dense targets or labels"); return; }
   double *rowstats = static_cast<double *>(scratch(kScratchReduce, sizeof(double) * 5 * (size_t)d.rows));
   if (!rowstats) return;
   int g = d.rows > kMaxGrid * 2 ? kMaxGrid * 2 : d.rows;
-  if (tgt) hipLaunchKernelGGL((xent_rows_kernel<true>), dim3(g), dim3(256), 0, cur_stream(), net_out, d.stride, tgt, tgt_stride, labels, frame_weights, diff, diff_stride, d.rows, d.cols, rowstats);
-  else hipLaunchKernelGGL((xent_rows_kernel<false>), dim3(g), dim3(256), 0, cur_stream(), net_out, d.stride, tgt, tgt_stride, labels, frame_weights, diff, diff_stride, d.rows, d.cols, rowstats);
+#define XENT_LAUNCH(DENSE, SM)                                                                                                        \
+  hipLaunchKernelGGL((xent_rows_kernel<DENSE, SM>), dim3(g), dim3(256), 0, cur_stream(), net_out, d.stride, tgt, tgt_stride, labels, \
+                     frame_weights, diff, diff_stride, d.rows, d.cols, rowstats, y_out, y_stride)
+  if (tgt) { if (softmax) XENT_LAUNCH(true, true); else XENT_LAUNCH(true, false); }
+  else { if (softmax) XENT_LAUNCH(false, true); else XENT_LAUNCH(false, false); }
+#undef XENT_LAUNCH
   hipLaunchKernelGGL(xent_finalize_kernel, dim3(1), dim3(256), 0, cur_stream(), rowstats, d.rows, stats_dev);
   check_launch("xent_eval");
+}
+
+void aslp_xent_eval(const float *net_out, MatrixDim d, const float *tgt, int tgt_stride, const int32_cuda *labels, const float *frame_weights,
+                    float *diff, int diff_stride, double *stats_dev) {
+  xent_eval_impl(net_out, d, tgt, tgt_stride, labels, frame_weights, diff, diff_stride, stats_dev, false, nullptr, 0);
+}
+// Softmax + Xent::Eval in one pass over the activations in front of the Softmax; only rows of 513..8192 classes (the
+// range where cudaF_softmax_reduce uses the same 256-lane row layout, so the posteriors are bit-identical)
+int aslp_softmax_xent_supported(int cols) { return cols > 512 && cols <= 256 * kXentPerThread; }
+void aslp_softmax_xent_eval(const float *acts, MatrixDim d, const float *tgt, int tgt_stride, const int32_cuda *labels,
+                            const float *frame_weights, float *diff, int diff_stride, double *stats_dev, float *post_out, int post_stride) {
+  if (!aslp_softmax_xent_supported(d.cols)) { set_error("aslp_softmax_xent_eval: unsupported number of classes"); return; }
+  xent_eval_impl(acts, d, tgt, tgt_stride, labels, frame_weights, diff, diff_stride, stats_dev, true, post_out, post_stride);
 }
 
 }  // extern "C"

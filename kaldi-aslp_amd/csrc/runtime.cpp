@@ -26,57 +26,86 @@ bool has_error() {
   return !g_err.empty();
 }
 
-// One grow-only scratch arena per slot.  Kernels on one stream run in order, so a slot can
+// One grow-only scratch arena per (stream bank, slot).  Kernels on one stream run in order, so a slot can
 // be reused by the next op on the same stream without synchronisation (the reference's
 // caching allocator exists for the same reason: cu-allocator.h:67-70).
-static void *g_scratch[kNumScratch] = {nullptr};
-static size_t g_scratch_bytes[kNumScratch] = {0};
+static thread_local int t_bank = 0;  // 0 = main stream, 1 = side stream
+static void *g_scratch[2][kNumScratch] = {{nullptr}};
+static size_t g_scratch_bytes[2][kNumScratch] = {{0}};
 static std::mutex g_scratch_mu;
 
 void *scratch(int slot, size_t bytes) {
   std::lock_guard<std::mutex> lk(g_scratch_mu);
-  if (bytes > g_scratch_bytes[slot]) {
-    if (g_scratch[slot]) {
+  void *&blk = g_scratch[t_bank][slot];
+  size_t &cap = g_scratch_bytes[t_bank][slot];
+  if (bytes > cap) {
+    if (blk) {
       // outstanding kernels may still use the old block
       (void)hipStreamSynchronize(cur_stream());
-      (void)hipFree(g_scratch[slot]);
+      (void)hipFree(blk);
     }
     size_t want = bytes < (1u << 20) ? (1u << 20) : bytes + bytes / 2;
     void *p = nullptr;
     hipError_t e = hipMalloc(&p, want);
     if (e != hipSuccess) {
       set_error(std::string("hipMalloc(scratch): ") + hipGetErrorString(e));
-      g_scratch[slot] = nullptr;
-      g_scratch_bytes[slot] = 0;
+      blk = nullptr;
+      cap = 0;
       return nullptr;
     }
-    g_scratch[slot] = p;
-    g_scratch_bytes[slot] = want;
+    blk = p;
+    cap = want;
   }
-  return g_scratch[slot];
+  return blk;
 }
 
-static unsigned *g_tickets = nullptr;
-static int g_ticket_count = 0;
-unsigned *tickets(int count) {
-  std::lock_guard<std::mutex> lk(g_scratch_mu);
-  if (count > g_ticket_count) {
-    if (g_tickets) {
-      (void)hipStreamSynchronize(cur_stream());
-      (void)hipFree(g_tickets);
-    }
-    const int want = count < 4096 ? 4096 : count * 2;
-    void *p = nullptr;
-    if (hipMalloc(&p, sizeof(unsigned) * want) != hipSuccess || hipMemset(p, 0, sizeof(unsigned) * want) != hipSuccess) {
-      set_error("hipMalloc(tickets) failed");
-      g_tickets = nullptr;
-      g_ticket_count = 0;
-      return nullptr;
-    }
-    g_tickets = static_cast<unsigned *>(p);
-    g_ticket_count = want;
+// ---- side stream: fork / join by events, no host synchronisation --------------------------------------------
+static thread_local hipStream_t t_side = nullptr;
+static thread_local hipEvent_t t_fork_ev = nullptr, t_join_ev = nullptr;
+static thread_local hipStream_t t_side_parent = nullptr;  // main stream the pending side work has to rejoin
+static thread_local bool t_side_dirty = false;
+
+static bool side_ready() {
+  if (t_side) return true;
+  // lowest priority: when both streams have workgroups to place, the main stream's (the critical path) go first
+  int prio_low = 0, prio_high = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+  if (hipStreamCreateWithPriority(&t_side, hipStreamNonBlocking, prio_low) != hipSuccess ||
+      hipEventCreateWithFlags(&t_fork_ev, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&t_join_ev, hipEventDisableTiming) != hipSuccess) {
+    set_error("side stream: cannot create stream / events");
+    t_side = nullptr;
+    return false;
   }
-  return g_tickets;
+  return true;
+}
+
+SideStreamScope::SideStreamScope() : saved_(nullptr), active_(false) {
+  if (t_bank != 0 || !side_ready()) return;  // nested scope or no stream: stay where we are
+  hipStream_t main = cur_stream();
+  if (t_side_dirty && t_side_parent != main) join_side_stream();  // pending work belongs to another main stream
+  if (hipEventRecord(t_fork_ev, main) != hipSuccess || hipStreamWaitEvent(t_side, t_fork_ev, 0) != hipSuccess) {
+    set_error("side stream: fork failed");
+    return;
+  }
+  saved_ = main;
+  t_side_parent = main;
+  set_cur_stream(t_side);
+  t_bank = 1;
+  t_side_dirty = true;
+  active_ = true;
+}
+SideStreamScope::~SideStreamScope() {
+  if (!active_) return;
+  set_cur_stream(static_cast<hipStream_t>(saved_));
+  t_bank = 0;
+}
+bool on_side_stream() { return t_bank == 1; }
+void join_side_stream() {
+  if (!t_side_dirty) return;
+  t_side_dirty = false;
+  if (hipEventRecord(t_join_ev, t_side) != hipSuccess || hipStreamWaitEvent(t_side_parent, t_join_ev, 0) != hipSuccess)
+    set_error("side stream: join failed");
 }
 
 }  // namespace aslp

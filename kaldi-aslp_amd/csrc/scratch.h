@@ -1,9 +1,25 @@
-// scratch.h -- grow-only device scratch slots (see runtime.cpp).
+// scratch.h -- grow-only device scratch slots and the side stream (see runtime.cpp).
 #pragma once
 #include <stddef.h>
 namespace aslp {
 enum { kScratchReduce = 0, kScratchReduce2 = 1, kScratchGemm = 2, kScratchCtc = 3, kScratchMisc = 4, kNumScratch = 5 };
+// Scratch of the calling thread's current stream: the side stream has its own bank, so ops running there never
+// share a partial-sum buffer with ops on the main stream.
 void *scratch(int slot, size_t bytes);
-// zero-initialised, never-moving array of counters (column-reduce tickets); every user leaves its counters at 0
-unsigned *tickets(int count);
+
+// While alive, every launch of this thread goes to the library's side stream, ordered after everything issued on the
+// main stream so far (event wait, no host sync).  join_side_stream() makes the main stream wait for the side work
+// issued since the last join; it is a no-op when there is none.
+class SideStreamScope {
+ public:
+  SideStreamScope();
+  ~SideStreamScope();
+  SideStreamScope(const SideStreamScope &) = delete;
+  SideStreamScope &operator=(const SideStreamScope &) = delete;
+ private:
+  void *saved_;
+  bool active_;
+};
+void join_side_stream();
+bool on_side_stream();  // is the calling thread inside a SideStreamScope?
 }  // namespace aslp

@@ -32,6 +32,7 @@ _sig("aslp_nnet_component_marker", _i, _H, _i, C.c_char_p, _i)
 _sig("aslp_nnet_info", _i, _H, C.c_char_p, _i)
 _sig("aslp_nnet_set_link_aliasing", _i, _H, _i)
 _sig("aslp_nnet_set_layer_fusion", _i, _H, _i)
+_sig("aslp_nnet_set_update_overlap", _i, _H, _i)
 _sig("aslp_nnet_propagate", _i, _H, _vp, _i, _i, _i, _vp, _i)
 _sig("aslp_nnet_feedforward", _i, _H, _vp, _i, _i, _i, _vp, _i)
 _sig("aslp_nnet_backpropagate", _i, _H, _vp, _i, _i, _i, _vp, _i)
@@ -310,6 +311,7 @@ class Nnet:
 
     def SetLinkAliasing(self, on): _ok(lib.aslp_nnet_set_link_aliasing(self.h, int(on)))
     def SetLayerFusion(self, on): _ok(lib.aslp_nnet_set_layer_fusion(self.h, int(on)))
+    def SetUpdateOverlap(self, on): _ok(lib.aslp_nnet_set_update_overlap(self.h, int(on)))
 
     def Propagate(self, x, out=None):
         _chk(x)

@@ -103,6 +103,7 @@ int aslp_nnet_component_marker(aslp_nnet_t n, int c, char *buf, int buflen) {
 int aslp_nnet_info(aslp_nnet_t n, char *buf, int buflen) { API_BEGIN CopyStr(n->nnet.Info(), buf, buflen); API_END }
 int aslp_nnet_set_link_aliasing(aslp_nnet_t n, int on) { API_BEGIN n->nnet.SetLinkAliasing(on != 0); API_END }
 int aslp_nnet_set_layer_fusion(aslp_nnet_t n, int on) { API_BEGIN n->nnet.SetLayerFusion(on != 0); API_END }
+int aslp_nnet_set_update_overlap(aslp_nnet_t n, int on) { API_BEGIN n->nnet.SetUpdateOverlap(on != 0); API_END }
 
 int aslp_nnet_propagate(aslp_nnet_t n, const float *in, int rows, int cols, int stride, float *out, int out_stride) {
   API_BEGIN
@@ -217,17 +218,15 @@ int aslp_nnet_train_step_xent(aslp_nnet_t n, aslp_xent_t x, const float *in, int
                               const float *frame_weights) {
   API_BEGIN
   CuSubMatrix inm(const_cast<float *>(in), rows, cols, stride);
-  n->nnet.Propagate(inm, &n->out);
+  n->nnet.PropagateForLoss(inm, true);
   if (frame_weights == NULL) {
     if (n->fw.Dim() != rows) { n->fw.Resize(rows, kUndefined); n->fw.Set(1.0f); }
     frame_weights = n->fw.Data();
   }
   CuSubVector fwv(const_cast<float *>(frame_weights), rows);
-  CuArray<int32> lab;
-  lab.Resize(rows);
-  DeviceToDevice(lab.Data(), labels, sizeof(int32) * rows);
-  x->xent.EvalLabels(fwv, n->out, lab, &n->diff);
-  n->nnet.Backpropagate(n->diff, NULL);
+  if (n->nnet.LossInputIsPreSoftmax()) x->xent.EvalLabelsPreSoftmax(fwv, n->nnet.LossInput(), labels, n->nnet.LossDiff(rows));
+  else x->xent.EvalLabels(fwv, n->nnet.LossInput(), labels, n->nnet.LossDiff(rows));
+  n->nnet.BackpropagateFromLossDiff();
   API_END
 }
 

@@ -542,10 +542,12 @@ class BatchNormalization : public UpdatableComponent {
     num_acc_frames_ += in.NumRows();
   }
   void BackpropagateFnc(const CuMatrixBase &in, const CuMatrixBase &, const CuMatrixBase &out_diff, CuMatrixBase *in_diff) {  // :222-277
-    aslp_bn_backward(in.Data(), in.Dim(), out_diff.Data(), out_diff.Stride(), XsharpO_.Data(), XsharpO_.Stride(), scale_.Data(),
-                     mean_vec_.Data(), var_vec_.Data(), dscale_.Data(), dshift_.Data(), opts_.momentum,
-                     in_diff ? in_diff->Data() : nullptr, in_diff ? in_diff->Stride() : 0);
+    Backward(in, out_diff, in_diff ? in_diff->Data() : nullptr, in_diff ? in_diff->Stride() : 0, nullptr, 0);
   }
+  // The executor calls this right before a Backpropagate that it follows with Update (Nnet::Backpropagate always
+  // does): the SGD step of scale / shift is then taken inside the backward statistics finalize and the next Update
+  // call is a no-op.
+  void FoldNextUpdateIntoBackprop() { fold_update_ = true; }
   // Executor peephole (nnet-nnet.cpp): a Sigmoid that is this component's only consumer is folded into the write
   // pass (forward) and into the statistics / write passes (backward); the BN output itself is never materialised.
   void PropagateWithSigmoid(const CuMatrixBase &in, CuMatrix *sigmoid_out) {
@@ -560,11 +562,11 @@ class BatchNormalization : public UpdatableComponent {
   void BackpropagateWithSigmoid(const CuMatrixBase &in, const CuMatrixBase &sigmoid_out, const CuMatrixBase &sigmoid_out_diff, CuMatrix *in_diff) {
     ASLP_ASSERT(SameDim(sigmoid_out, sigmoid_out_diff) && sigmoid_out.NumCols() == output_dim_);
     if (in_diff && (in_diff->NumRows() != in.NumRows() || in_diff->NumCols() != input_dim_)) in_diff->Resize(in.NumRows(), input_dim_, kUndefined);
-    aslp_bn_backward_act(in.Data(), in.Dim(), sigmoid_out_diff.Data(), sigmoid_out_diff.Stride(), XsharpO_.Data(), XsharpO_.Stride(), scale_.Data(),
-                         mean_vec_.Data(), var_vec_.Data(), dscale_.Data(), dshift_.Data(), opts_.momentum, in_diff ? in_diff->Data() : nullptr,
-                         in_diff ? in_diff->Stride() : 0, sigmoid_out.Data(), sigmoid_out.Stride());
+    Backward(in, sigmoid_out_diff, in_diff ? in_diff->Data() : nullptr, in_diff ? in_diff->Stride() : 0, sigmoid_out.Data(),
+             sigmoid_out.Stride());
   }
   void Update(const CuMatrixBase &, const CuMatrixBase &) {  // :280-284
+    if (update_done_) { update_done_ = false; return; }
     const BaseFloat lr = opts_.learn_rate;
     aslp_vec_axpy2(-lr, dscale_.Data(), scale_.Data(), dshift_.Data(), shift_.Data(), scale_.Dim());
   }
@@ -575,6 +577,17 @@ class BatchNormalization : public UpdatableComponent {
   CuVectorD &AccVars() { return acc_vars_; }
 
  private:
+  void Backward(const CuMatrixBase &in, const CuMatrixBase &out_diff, BaseFloat *in_diff, int32 id_stride, const BaseFloat *act_y, int32 act_stride) {
+    if (fold_update_) {
+      fold_update_ = false;
+      update_done_ = true;
+      aslp_bn_backward_step(in.Dim(), out_diff.Data(), out_diff.Stride(), XsharpO_.Data(), XsharpO_.Stride(), scale_.Data(), shift_.Data(),
+                            var_vec_.Data(), dscale_.Data(), dshift_.Data(), opts_.momentum, opts_.learn_rate, in_diff, id_stride, act_y, act_stride);
+    } else {
+      aslp_bn_backward_act(in.Data(), in.Dim(), out_diff.Data(), out_diff.Stride(), XsharpO_.Data(), XsharpO_.Stride(), scale_.Data(),
+                           mean_vec_.Data(), var_vec_.Data(), dscale_.Data(), dshift_.Data(), opts_.momentum, in_diff, id_stride, act_y, act_stride);
+    }
+  }
   void AllocAux() {
     mean_vec_.Resize(output_dim_); var_vec_.Resize(output_dim_);
     dscale_.Resize(output_dim_); dshift_.Resize(output_dim_);
@@ -585,6 +598,7 @@ class BatchNormalization : public UpdatableComponent {
   CuVectorD acc_means_, acc_vars_;
   double num_acc_frames_;
   bool acc_cleaned_;
+  bool fold_update_ = false, update_done_ = false;
 };
 
 }  // namespace aslp

@@ -126,6 +126,21 @@ void Xent::EvalLabels(const CuVectorBase &fw, const CuMatrixBase &net_out, const
   AfterEval(net_out.NumRows());
 }
 
+void Xent::EvalLabels(const CuVectorBase &fw, const CuMatrixBase &net_out, const int32 *labels_dev, CuMatrix *diff) {
+  ASLP_ASSERT(fw.Dim() == net_out.NumRows());
+  diff->Resize(net_out.NumRows(), net_out.NumCols(), kUndefined);
+  aslp_xent_eval(net_out.Data(), net_out.Dim(), nullptr, 0, labels_dev, fw.Data(), diff->Data(), diff->Stride(), stats_.Data());
+  CheckK();
+  AfterEval(net_out.NumRows());
+}
+void Xent::EvalLabelsPreSoftmax(const CuVectorBase &fw, const CuMatrixBase &acts, const int32 *labels_dev, CuMatrix *diff) {
+  ASLP_ASSERT(fw.Dim() == acts.NumRows());
+  diff->Resize(acts.NumRows(), acts.NumCols(), kUndefined);
+  aslp_softmax_xent_eval(acts.Data(), acts.Dim(), nullptr, 0, labels_dev, fw.Data(), diff->Data(), diff->Stride(), stats_.Data(), nullptr, 0);
+  CheckK();
+  AfterEval(acts.NumRows());
+}
+
 std::string Xent::Report() {  // nnet-loss.cc:175-199
   Fetch();
   std::ostringstream oss;

@@ -38,6 +38,9 @@ class Xent : public LossItf {
   using LossItf::Eval;
   // device-resident variants (no host data on the step path): weights / labels already on the GPU
   void EvalLabels(const CuVectorBase &frame_weights, const CuMatrixBase &net_out, const CuArray<int32> &labels, CuMatrix *diff);
+  // `acts` are the activations in front of the network's final Softmax; the posteriors are formed inside the loss kernel
+  void EvalLabelsPreSoftmax(const CuVectorBase &frame_weights, const CuMatrixBase &acts, const int32 *labels_dev, CuMatrix *diff);
+  void EvalLabels(const CuVectorBase &frame_weights, const CuMatrixBase &net_out, const int32 *labels_dev, CuMatrix *diff);
   std::string Report();
   BaseFloat AvgLoss() { Fetch(); return (loss_ - entropy_) / frames_; }
   // raw accumulators {frames, correct, loss, entropy, likelyhood}

@@ -5,6 +5,7 @@
 #include <fstream>
 
 #include "nnet-basic.h"
+#include "scratch.h"
 #if __has_include("nnet-recurrent.h")
 #include "nnet-recurrent.h"
 #define ASLP_HAVE_RECURRENT 1
@@ -31,6 +32,7 @@ Nnet &Nnet::operator=(const Nnet &other) {  // nnet-nnet.cc:41-65
   SetTrainOptions(other.opts_);
   alias_links_ = other.alias_links_;
   fuse_layers_ = other.fuse_layers_;
+  overlap_updates_ = other.overlap_updates_;
   InitInputOutput();
   Check();
   return *this;
@@ -53,6 +55,8 @@ int32 Nnet::FusedSigmoidOf(int32 i) const {
 }
 const CuMatrixBase &Nnet::OutputBuffer(int32 c) const {
   if (FusedSigmoidOf(c) >= 0) ASLP_ERR << "output of component " << c << " is not materialised (fused into the Sigmoid behind it); SetLayerFusion(false)";
+  if (softmax_folded_ && (IsFinalSoftmax(c) || c == output_[0]))
+    ASLP_ERR << "output of component " << c << " is not materialised (the last step left the final Softmax to the loss kernel); SetLayerFusion(false)";
   return *out_view_[c];
 }
 const CuMatrixBase &Nnet::OutputDiffBuffer(int32 c) const {
@@ -61,10 +65,10 @@ const CuMatrixBase &Nnet::OutputDiffBuffer(int32 c) const {
 }
 
 void Nnet::Propagate(const std::vector<const CuMatrixBase *> &in, std::vector<CuMatrix *> *out) {  // nnet-nnet.cc:70-106
-  ASLP_ASSERT(NULL != out);
   ASLP_ASSERT(in.size() == input_.size());
   int num_frame = in[0]->NumRows();
   for (size_t i = 0; i < input_.size(); i++) in_view_[input_[i]] = in[i];  // InputLayer reads the caller's matrix
+  softmax_folded_ = false;
   std::vector<char> done(components_.size(), 0);  // Sigmoids already produced by the BatchNormalization in front of them
   for (int32 i = 0; i < (int32)components_.size(); i++) {
     if (done[i]) continue;
@@ -93,6 +97,9 @@ void Nnet::Propagate(const std::vector<const CuMatrixBase *> &in, std::vector<Cu
       done[fs] = 1;
     } else if (alias_links_ && components_[i]->PropagateIsCopy() && components_[i]->GetType() != Component::kInputLayer) {
       out_view_[i] = in_view_[i];  // pure copy layer: pass the buffer through
+    } else if (fold_softmax_request_ && IsFinalSoftmax(i)) {
+      out_view_[i] = in_view_[i];  // the loss kernel forms the posteriors itself
+      softmax_folded_ = true;
     } else {
       components_[i]->Propagate(*in_view_[i], &output_buf_[i]);
       out_view_[i] = &output_buf_[i];
@@ -100,9 +107,44 @@ void Nnet::Propagate(const std::vector<const CuMatrixBase *> &in, std::vector<Cu
     propagate_time_[i].first = Component::TypeToMarker(components_[i]->GetType());
     propagate_time_[i].second += tim1.Elapsed();
   }
-  for (size_t i = 0; i < output_.size(); i++) *((*out)[i]) = *out_view_[output_[i]];
+  if (out != NULL)
+    for (size_t i = 0; i < output_.size(); i++) *((*out)[i]) = *out_view_[output_[i]];
   // the caller's input may go away: Update() of the consumers reads InputLayer's OUTPUT copy
   for (size_t i = 0; i < input_.size(); i++) in_view_[input_[i]] = &output_buf_[input_[i]];
+}
+
+// Softmax whose posteriors are the single network output (directly, or through the auto-added OutputLayer)
+bool Nnet::IsFinalSoftmax(int32 i) const {
+  if (!fuse_layers_ || !alias_links_ || output_.size() != 1 || components_[i]->GetType() != Component::kSoftmax) return false;
+  if (!aslp_softmax_xent_supported(components_[i]->OutputDim())) return false;
+  const int32 o = output_[0];
+  if (o == i) return num_consumers_[i] == 0;
+  return num_consumers_[i] == 1 && num_consumers_[o] == 0 && components_[o]->GetType() == Component::kOutputLayer && IsDirectLink(o) &&
+         components_[o]->GetInput()[0] == i;
+}
+void Nnet::PropagateForLoss(const CuMatrixBase &in, bool fold_softmax) {
+  ASLP_ASSERT(input_.size() == 1 && output_.size() == 1);
+  std::vector<const CuMatrixBase *> in_vec(1, &in);
+  fold_softmax_request_ = fold_softmax;
+  try { Propagate(in_vec, NULL); } catch (...) { fold_softmax_request_ = false; throw; }
+  fold_softmax_request_ = false;
+}
+const CuMatrixBase &Nnet::LossInput() const {
+  ASLP_ASSERT(output_.size() == 1 && out_view_[output_[0]] != NULL);
+  return *out_view_[output_[0]];
+}
+CuMatrix *Nnet::LossDiff(int32 num_frames) {
+  ASLP_ASSERT(output_.size() == 1);
+  CuMatrix *d = &output_diff_buf_[output_[0]];
+  d->Resize(num_frames, components_[output_[0]]->OutputDim(), kUndefined);
+  return d;
+}
+void Nnet::BackpropagateFromLossDiff() {
+  ASLP_ASSERT(output_.size() == 1);
+  std::vector<const CuMatrixBase *> od(1, &output_diff_buf_[output_[0]]);
+  diff_in_place_ = true;
+  try { Backpropagate(od, NULL); } catch (...) { diff_in_place_ = false; throw; }
+  diff_in_place_ = false;
 }
 
 void Nnet::Backpropagate(const std::vector<const CuMatrixBase *> &out_diff, std::vector<CuMatrix *> *in_diff) {  // :108-154
@@ -119,9 +161,11 @@ void Nnet::Backpropagate(const std::vector<const CuMatrixBase *> &out_diff, std:
     bool fed_direct = false;
     for (int32 c = i + 1; c < N && !fed_direct; c++)
       if (direct[c] && components_[c]->GetInput()[0] == i) fed_direct = true;
+    if (diff_in_place_ && i == output_[0]) continue;  // already holds the loss's diff
     if (!fed_direct) output_diff_buf_[i].Resize(num_frame, components_[i]->OutputDim(), kSetZero);
   }
-  for (size_t i = 0; i < output_.size(); i++) output_diff_buf_[output_[i]].CopyFromMat(*(out_diff[i]));
+  if (!diff_in_place_)
+    for (size_t i = 0; i < output_.size(); i++) output_diff_buf_[output_[i]].CopyFromMat(*(out_diff[i]));
   for (int32 i = 0; i < N; i++) out_diff_view_[i] = &output_diff_buf_[i];
   const bool want_in_diff = (in_diff != NULL);
   std::vector<int32> fused_sigmoid(N, -1);   // BN index -> its folded Sigmoid
@@ -150,15 +194,23 @@ void Nnet::Backpropagate(const std::vector<const CuMatrixBase *> &out_diff, std:
         out_diff_view_[i] = target;
       } else if (fused_sigmoid[i] >= 0) {
         const int32 fs = fused_sigmoid[i];
+        dynamic_cast<BatchNormalization *>(components_[i])->FoldNextUpdateIntoBackprop();
         dynamic_cast<BatchNormalization *>(components_[i])->BackpropagateWithSigmoid(*in_view_[i], output_buf_[fs], output_diff_buf_[fs], target);
       } else {
+        if (fuse_layers_ && components_[i]->GetType() == Component::kBatchNormalization)
+          dynamic_cast<BatchNormalization *>(components_[i])->FoldNextUpdateIntoBackprop();
         components_[i]->Backpropagate(*in_view_[i], *out_view_[i], output_diff_buf_[i], target);
       }
       in_diff_view_[i] = target;
     }
     if (components_[i]->IsUpdatable()) {
       UpdatableComponent *uc = dynamic_cast<UpdatableComponent *>(components_[i]);
-      uc->Update(*in_view_[i], output_diff_buf_[i]);
+      if (overlap_updates_ && components_[i]->GetType() == Component::kAffineTransform) {
+        SideStreamScope side;  // after this component's Backpropagate (which reads the weights), beside everything below it
+        uc->Update(*in_view_[i], output_diff_buf_[i]);
+      } else {
+        uc->Update(*in_view_[i], output_diff_buf_[i]);
+      }
     }
     back_propagate_time_[i].first = Component::TypeToMarker(components_[i]->GetType());
     back_propagate_time_[i].second += tim2.Elapsed();
@@ -172,6 +224,7 @@ void Nnet::Backpropagate(const std::vector<const CuMatrixBase *> &out_diff, std:
       }
     }
   }
+  join_side_stream();
   if (NULL == in_diff) return;
   for (size_t i = 0; i < input_.size(); i++)
     if ((*in_diff)[i] != NULL) *((*in_diff)[i]) = input_diff_buf_[input_[i]];

@@ -84,11 +84,27 @@ class Nnet {
   // that component's only consumer) into the BatchNormalization kernels.  Values are identical; the intermediate
   // BN output / Sigmoid in-diff buffers are then not materialised (OutputBuffer() on them throws).
   void SetLayerFusion(bool on) { fuse_layers_ = on; }
+  // Engine switch (not in the reference): issue AffineTransform::Update (weight-gradient GEMM with the SGD step in its
+  // epilogue) on a side stream, ordered after the component's own Backpropagate, so that it shares the chip with the
+  // backward pass of the layers below instead of sitting in its critical path; Backpropagate() returns with the main
+  // stream waiting for all of them.  Values are identical (no kernel changes, no reduction order changes).
+  void SetUpdateOverlap(bool on) { overlap_updates_ = on; }
+
+  // Step-path entry points for callers that evaluate the loss on the device right away (the train-step C API): the
+  // network output is read, and the loss's diff is written, in the executor's own buffers, which saves the two
+  // full-matrix copies of Propagate(in, &out) / Backpropagate(diff, NULL).  With `fold_softmax` a final Softmax that
+  // is the single network output is left to the loss kernel (LossInputIsPreSoftmax() tells whether that happened).
+  void PropagateForLoss(const CuMatrixBase &in, bool fold_softmax);
+  const CuMatrixBase &LossInput() const;
+  bool LossInputIsPreSoftmax() const { return softmax_folded_; }
+  CuMatrix *LossDiff(int32 num_frames);
+  void BackpropagateFromLossDiff();
 
  private:
   void InitStream(std::istream &is);
   void InitInputOutput();
   bool IsDirectLink(int32 i) const;  // single input, offset 0, full width
+  bool IsFinalSoftmax(int32 i) const;
   int32 FusedSigmoidOf(int32 i) const;  // index of the Sigmoid folded into BatchNormalization i, or -1
 
   std::vector<Component *> components_;
@@ -103,6 +119,8 @@ class Nnet {
   NnetTrainOptions opts_;
   bool alias_links_ = true;
   bool fuse_layers_ = true;
+  bool overlap_updates_ = true;
+  bool fold_softmax_request_ = false, softmax_folded_ = false, diff_in_place_ = false;
 };
 
 }  // namespace aslp

@@ -222,3 +222,36 @@ def test_bn_sigmoid_fusion_is_bit_identical(aslp, oracle, dev, tmp_path):
     with pytest.raises(RuntimeError):
         nets[0].ComponentOutput(bn, mb, hid)
     assert nets[1].ComponentOutput(bn, mb, hid).shape == (mb, hid)
+
+
+def test_softmax_fold_and_update_overlap_are_bit_identical(aslp, oracle, dev, tmp_path):
+    """TrainStepXent leaves a final Softmax (513..8192 classes) to the loss kernel and issues AffineTransform::Update on a
+    side stream; both are pure scheduling changes: parameters and loss statistics must equal, bit for bit, those of a net
+    with SetLayerFusion(False) / SetUpdateOverlap(False) driven through Propagate / Xent / Backpropagate."""
+    in_dim, hid, nh, out_dim, mb = 40, 128, 2, 600, 256
+    d, path = make_dnn(oracle, tmp_path, in_dim, hid, nh, out_dim, 1, mb, seed=12)
+    nets = [aslp.Nnet.Read(path) for _ in range(3)]
+    nets[1].SetLayerFusion(False)
+    nets[1].SetUpdateOverlap(False)
+    nets[2].SetUpdateOverlap(False)
+    rng = np.random.default_rng(6)
+    xents = [aslp.Xent() for _ in range(3)]
+    for step in range(4):
+        x = torch.from_numpy(rng.standard_normal((mb, in_dim)).astype(np.float32)).to(dev)
+        lab = torch.from_numpy(rng.integers(0, out_dim, mb).astype(np.int32)).to(dev)
+        for net in nets:
+            net.SetTrainOptions(learn_rate=0.01, momentum=0.9)
+        nets[0].TrainStepXent(xents[0], x, lab)
+        nets[2].TrainStepXent(xents[2], x, lab)
+        # the unfused net goes through the three separate calls of the reference's training loop
+        y = nets[1].Propagate(x)
+        diff = torch.empty_like(y)
+        xents[1].Eval(torch.ones(mb, device=dev), y, diff, labels=lab)
+        nets[1].Backpropagate(diff)
+        p0, p1, p2 = (n.GetParams() for n in nets)
+        assert np.array_equal(p0, p1), step
+        assert np.array_equal(p0, p2), step
+    s0, s1 = xents[0].GetStats(), xents[1].GetStats()
+    assert s0 == s1
+    with pytest.raises(RuntimeError):
+        nets[0].ComponentOutput(nets[0].NumComponents() - 1, mb, out_dim)
