@@ -11,6 +11,7 @@
 
 #include "aslp_kernels.h"
 #include "base.h"
+#include "host-matrix.h"
 
 namespace aslp {
 
@@ -25,33 +26,6 @@ void DeviceToDevice(void *dst, const void *src, size_t bytes);
 void DeviceMemset(void *dst, int v, size_t bytes);
 void StreamSync();
 inline int PaddedStride(int cols) { return (cols + 15) & ~15; }
-
-// Host-side matrix / vector used for I/O and parameter exchange (replaces kaldi::Matrix/Vector there).
-struct HostMatrix {
-  int rows = 0, cols = 0;
-  std::vector<float> data;
-  HostMatrix() {}
-  HostMatrix(int r, int c) : rows(r), cols(c), data((size_t)r * c, 0.0f) {}
-  float &operator()(int r, int c) { return data[(size_t)r * cols + c]; }
-  float operator()(int r, int c) const { return data[(size_t)r * cols + c]; }
-  void Resize(int r, int c) { rows = r; cols = c; data.assign((size_t)r * c, 0.0f); }
-  void Read(std::istream &is, bool binary);
-  void Write(std::ostream &os, bool binary) const;
-};
-struct HostVector {
-  std::vector<float> data;
-  HostVector() {}
-  explicit HostVector(int n) : data(n, 0.0f) {}
-  int Dim() const { return (int)data.size(); }
-  void Read(std::istream &is, bool binary);
-  void Write(std::ostream &os, bool binary) const;
-};
-struct HostVectorD {
-  std::vector<double> data;
-  int Dim() const { return (int)data.size(); }
-  void Read(std::istream &is, bool binary);
-  void Write(std::ostream &os, bool binary) const;
-};
 
 template <typename T>
 class CuArray {

@@ -10,10 +10,10 @@
 #include <vector>
 
 #include "cu-matrix.h"
+#include "posterior.h"
 
 namespace aslp {
 
-typedef std::vector<std::vector<std::pair<int32, BaseFloat>>> Posterior;
 
 class LossItf {
  public:

@@ -6,6 +6,7 @@
 
 #include "nnet-basic.h"
 #include "scratch.h"
+#include "kaldi-io.h"
 #if __has_include("nnet-recurrent.h")
 #include "nnet-recurrent.h"
 #define ASLP_HAVE_RECURRENT 1
@@ -448,9 +449,8 @@ void Nnet::InitStream(std::istream &is) {  // :570-612
   Check();
 }
 void Nnet::Init(const std::string &file) {
-  std::ifstream in(file.c_str());
-  if (!in.is_open()) ASLP_ERR << "Error opening input stream " << file;
-  InitStream(in);
+  Input in(file);  // extended filename: file, "-", "cmd |"
+  InitStream(in.Stream());
 }
 void Nnet::InitFromString(const std::string &proto) {
   std::istringstream in(proto);
@@ -458,11 +458,9 @@ void Nnet::InitFromString(const std::string &proto) {
 }
 
 void Nnet::Read(const std::string &file) {  // :615-625
-  std::ifstream in(file.c_str(), std::ios_base::in | std::ios_base::binary);
-  if (!in.is_open()) ASLP_ERR << "Error opening input stream " << file;
   bool binary;
-  if (!InitKaldiInputStream(in, &binary)) ASLP_ERR << "Error reading header of " << file;
-  Read(in, binary);
+  Input in(file, &binary);
+  Read(in.Stream(), binary);
   if (NumComponents() == 0) ASLP_WARN << "The network '" << file << "' is empty.";
 }
 void Nnet::Read(std::istream &is, bool binary) {  // :628-646
@@ -478,10 +476,9 @@ void Nnet::Read(std::istream &is, bool binary) {  // :628-646
   Check();
 }
 void Nnet::Write(const std::string &file, bool binary) const {
-  std::ofstream out(file.c_str(), std::ios_base::out | std::ios_base::binary);
-  if (!out.is_open()) ASLP_ERR << "Error opening output stream " << file;
-  InitKaldiOutputStream(out, binary);
-  Write(out, binary);
+  Output out(file, binary, true);
+  Write(out.Stream(), binary);
+  if (!out.Close()) ASLP_ERR << "Error closing output stream " << PrintableWxfilename(file);
 }
 void Nnet::Write(std::ostream &os, bool binary) const {  // :654-663
   Check();
@@ -492,10 +489,9 @@ void Nnet::Write(std::ostream &os, bool binary) const {  // :654-663
   if (binary == false) os << std::endl;
 }
 void Nnet::WriteStandard(const std::string &file, bool binary) const {  // :695-699 (sic: the reference calls Write here)
-  std::ofstream out(file.c_str(), std::ios_base::out | std::ios_base::binary);
-  if (!out.is_open()) ASLP_ERR << "Error opening output stream " << file;
-  InitKaldiOutputStream(out, binary);
-  Write(out, binary);
+  Output out(file, binary, true);
+  Write(out.Stream(), binary);
+  if (!out.Close()) ASLP_ERR << "Error closing output stream " << PrintableWxfilename(file);
 }
 void Nnet::WriteStandard(std::ostream &os, bool binary) const {  // :701-712
   Check();
