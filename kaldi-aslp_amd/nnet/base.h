@@ -6,6 +6,7 @@
 // size-byte + int32 count + raw data in binary; binary streams start with "\0B".
 // Errors throw std::runtime_error like KALDI_ERR (base/kaldi-error.h).
 #pragma once
+#include <chrono>
 #include <cstdint>
 #include <cstring>
 #include <iostream>
@@ -48,6 +49,12 @@ extern int g_verbose_level;
   do {                                                                      \
     if (!(cond)) ASLP_ERR << "Assertion failed: (" << #cond << ")";         \
   } while (0)
+
+struct Timer {  // base/timer.h
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  void Reset() { t0 = std::chrono::steady_clock::now(); }
+  double Elapsed() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
 
 // ---- io-funcs ------------------------------------------------------------------------------
 inline void InitKaldiOutputStream(std::ostream &os, bool binary) {
@@ -259,6 +266,12 @@ bool ConvertStringToReal(const std::string &str, float *out);
 
 // libc-rand based helpers with Kaldi's formulas (base/kaldi-math.h: RandUniform = (Rand()+1)/(RAND_MAX+2),
 // RandGauss = sqrt(-2 log U1) cos(2 pi U2)).  The reference seeds with srand(seed) in aslp-nnet-init.
+// The engine's private copy of the C library generator: the reference draws parameters and shuffle masks from libc
+// rand() (seeded by srand(--seed) / srand(--randomizer-seed)), but inside a HIP process the global rand() state is not
+// ours alone (the runtime draws from it while it loads code objects, measured), so the same glibc generator -- random_r
+// on a 128-byte state, bit-identical sequence to srand(seed); rand() -- is kept in a state only the engine touches.
+void SRand(unsigned seed);
+int Rand();
 float RandUniform();
 float RandGauss();
 

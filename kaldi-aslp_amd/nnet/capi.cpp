@@ -63,7 +63,7 @@ void aslp_set_verbose(int level) { g_verbose_level = level; }
 
 int aslp_nnet_init_from_proto(const char *proto_text, unsigned seed, aslp_nnet_t *out) {
   API_BEGIN
-  srand(seed);
+  SRand(seed);
   aslp_nnet_s *h = new aslp_nnet_s();
   try { h->nnet.InitFromString(proto_text); } catch (...) { delete h; throw; }
   *out = h;
@@ -330,7 +330,7 @@ int aslp_eesenctc_get_stats(aslp_eesenctc_t c, double stats[5]) {
 int aslp_randomizer_mask_generate(int seed, int size, int32_t *mask_host) {
   API_BEGIN
   RandomizerMask m;
-  if (seed >= 0) srand(seed);
+  if (seed >= 0) SRand(seed);
   const std::vector<int32> &v = m.Generate(size);
   std::memcpy(mask_host, v.data(), sizeof(int32) * size);
   API_END

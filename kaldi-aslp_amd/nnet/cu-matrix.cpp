@@ -83,6 +83,15 @@ void StreamSync() {
   CheckKernels();
 }
 
+void WarmUpDevice() {
+  CuMatrix m(2, 2);
+  m.Set(1.0f);
+  CuVector v(2);
+  v.AddRowSumMat(1.0f, m, 0.0f);
+  (void)v.Sum();
+  StreamSync();
+}
+
 // ---- CuVector ---------------------------------------------------------------------------------------
 void CuVector::Resize(int dim, MatrixResizeType t) {
   if (dim != dim_) {

@@ -25,6 +25,9 @@ void HostToDevice(void *dst, const void *src, size_t bytes);
 void DeviceToDevice(void *dst, const void *src, size_t bytes);
 void DeviceMemset(void *dst, int v, size_t bytes);
 void StreamSync();
+// Brings the HIP runtime fully up (context, code object, first launch).  The runtime draws from libc rand() while it
+// initialises, so anything that seeds rand() for reproducible parameters (aslp-nnet-init) calls this BEFORE srand().
+void WarmUpDevice();
 inline int PaddedStride(int cols) { return (cols + 15) & ~15; }
 
 template <typename T>

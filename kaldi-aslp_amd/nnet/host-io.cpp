@@ -299,8 +299,27 @@ bool SplitStringToIntegers(const std::string &full, const char *delim, bool omit
     if (!ConvertStringToInteger(split[i], &(*out)[i])) return false;
   return true;
 }
-float RandUniform() { return (float)((rand() + 1.0) / (RAND_MAX + 2.0)); }
-float RandGauss() { return (float)(sqrtf(-2 * logf(RandUniform())) * cosf(2 * M_PI * RandUniform())); }
+static char g_rand_statebuf[128];
+static struct random_data g_rand_data;
+static bool g_rand_seeded = false;
+void SRand(unsigned seed) {
+  std::memset(&g_rand_data, 0, sizeof(g_rand_data));
+  std::memset(g_rand_statebuf, 0, sizeof(g_rand_statebuf));
+  initstate_r(seed, g_rand_statebuf, sizeof(g_rand_statebuf), &g_rand_data);
+  g_rand_seeded = true;
+}
+int Rand() {
+  if (!g_rand_seeded) SRand(1);  // an unseeded rand() behaves as srand(1)
+  int32_t r;
+  random_r(&g_rand_data, &r);
+  return r;
+}
+float RandUniform() { return (float)((Rand() + 1.0) / (RAND_MAX + 2.0)); }
+float RandGauss() {
+  // base/kaldi-math.h:104-107 writes both draws in one expression (order unspecified in C++); fixed here: radius first
+  const float u1 = RandUniform(), u2 = RandUniform();
+  return (float)(sqrtf(-2 * logf(u1)) * cosf(2 * M_PI * u2));
+}
 
 // ---- Posterior (hmm/posterior.cc:29-125) ---------------------------------------------------------------
 void WritePosterior(std::ostream &os, bool binary, const Posterior &post) {

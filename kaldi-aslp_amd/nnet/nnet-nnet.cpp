@@ -18,13 +18,6 @@
 
 namespace aslp {
 
-namespace {
-struct Timer {
-  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-  double Elapsed() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
-};
-}  // namespace
-
 Nnet::Nnet(const Nnet &other) { *this = other; }
 Nnet &Nnet::operator=(const Nnet &other) {  // nnet-nnet.cc:41-65
   if (this == &other) return *this;

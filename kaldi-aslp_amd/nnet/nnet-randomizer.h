@@ -26,7 +26,7 @@ class RandomizerMask {  // :53-64
   explicit RandomizerMask(const NnetDataRandomizerOptions &conf) { Init(conf); }
   void Init(const NnetDataRandomizerOptions &conf) {
     ASLP_LOG << "Seeding by srand with : " << conf.randomizer_seed;
-    srand(conf.randomizer_seed);
+    SRand(conf.randomizer_seed);
   }
   // std::random_shuffle(begin, end) with the C library generator, written out (libstdc++
   // stl_algo.h: for i in [1, n): swap(v[i], v[rand() % (i + 1)])) because the algorithm left the
@@ -35,7 +35,7 @@ class RandomizerMask {  // :53-64
     mask_.resize(mask_size);
     for (int32 i = 0; i < mask_size; i++) mask_[i] = i;
     for (int32 i = 1; i < mask_size; i++) {
-      int32 j = std::rand() % (i + 1);
+      int32 j = Rand() % (i + 1);
       if (i != j) std::swap(mask_[i], mask_[j]);
     }
     return mask_;

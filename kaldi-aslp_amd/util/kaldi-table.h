@@ -95,6 +95,32 @@ struct BasicVectorHolder {  // :191-288: binary = int32 count + every element as
   T t_;
 };
 
+template <class B>
+struct BasicHolder {  // kaldi-holder-inl.h:99-189: one basic type; text form is "<value>\n"
+  typedef B T;
+  static bool Write(std::ostream &os, bool binary, const T &t) {
+    InitKaldiOutputStream(os, binary);
+    try { WriteBasicType(os, binary, t); if (!binary) os << '\n'; return os.good(); } catch (const std::exception &e) { ASLP_WARN << "Exception caught writing Table object. " << e.what(); return false; }
+  }
+  bool Read(std::istream &is) {
+    bool binary;
+    if (!InitKaldiInputStream(is, &binary)) { ASLP_WARN << "Reading Table object [integer type], failed reading binary header"; return false; }
+    try {
+      int c;
+      while (isspace((c = is.peek())) && c != static_cast<int>('\n')) is.get();
+      if (is.peek() == '\n') { ASLP_WARN << "Found newline but expected basic type."; return false; }
+      ReadBasicType(is, binary, &t_);
+      while (isspace((c = is.peek())) && c != static_cast<int>('\n')) is.get();
+      if (is.peek() == '\n') is.get();
+      else if (!binary) { ASLP_WARN << "BasicHolder::Read, expected newline, got " << is.peek(); return false; }
+      return true;
+    } catch (const std::exception &e) { ASLP_WARN << "Exception caught reading Table object. " << e.what(); return false; }
+  }
+  T &Value() { return t_; }
+  void Clear() {}
+  T t_ = T();
+};
+
 // ---- specifiers -------------------------------------------------------------------------------------------
 enum RspecifierType { kNoRspecifier, kArchiveRspecifier, kScriptRspecifier };
 struct RspecifierOptions { bool once = false, sorted = false, called_sorted = false, permissive = false; };
@@ -369,6 +395,7 @@ typedef TableWriter<BaseFloatMatrixHolder> BaseFloatMatrixWriter;
 typedef SequentialTableReader<BaseFloatVectorHolder> SequentialBaseFloatVectorReader;
 typedef RandomAccessTableReader<BaseFloatVectorHolder> RandomAccessBaseFloatVectorReader;
 typedef TableWriter<BaseFloatVectorHolder> BaseFloatVectorWriter;
+typedef RandomAccessTableReader<BasicHolder<BaseFloat>> RandomAccessBaseFloatReader;
 typedef SequentialTableReader<PosteriorHolder> SequentialPosteriorReader;
 typedef RandomAccessTableReader<PosteriorHolder> RandomAccessPosteriorReader;
 typedef TableWriter<PosteriorHolder> PosteriorWriter;

@@ -1,0 +1,249 @@
+"""The command-line tools (kaldi-aslp_amd/bin/aslp-nnet-*) run as the recipes run them: files
+in Kaldi formats in, model / posterior tables out.  Every result is compared with (a) the same computation driven
+through the engine's API on the same data order (bit-identical: the tools add I/O, not arithmetic) and (b) the CPU oracle
+stepping through the same minibatches (1e-4)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+import kaldi_formats as kf
+import nnet_io
+from test_nnet_gpu import make_dnn, oracle_params
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "kaldi-aslp_amd", "bin")
+TOL = 1e-4
+
+
+def tool(name, *args, ok=True):
+    exe = os.path.join(BIN, name)
+    assert os.path.exists(exe), "%s not built (make -C kaldi-aslp_amd)" % exe
+    p = subprocess.run([exe] + list(args), capture_output=True, timeout=300)
+    if ok:
+        assert p.returncode == 0, p.stderr.decode()[-3000:]
+    return p
+
+
+PROTO = """<NnetProto>
+<AffineTransform> <InputDim> 20 <OutputDim> 48 <BiasMean> -2.0 <BiasRange> 4.0 <ParamStddev> 0.1
+<BatchNormalization> <InputDim> 48 <OutputDim> 48
+<Sigmoid> <InputDim> 48 <OutputDim> 48
+<AffineTransform> <InputDim> 48 <OutputDim> 30 <BiasMean> 0.0 <BiasRange> 0.0 <ParamStddev> 0.1
+<Softmax> <InputDim> 30 <OutputDim> 30
+</NnetProto>
+"""
+
+
+def test_init_copy_info(aslp, dev, tmp_path):
+    (tmp_path / "nnet.proto").write_text(PROTO)
+    p = tool("aslp-nnet-init", "--binary=false", "--seed=123", str(tmp_path / "nnet.proto"), str(tmp_path / "a.txt"))
+    assert b"Written initialized model to" in p.stderr and b"aslp-nnet-init --binary=false --seed=123" in p.stderr
+    ref = aslp.Nnet.Init(PROTO, seed=123)
+    a = aslp.Nnet.Read(tmp_path / "a.txt")
+    # text carries 7 significant digits; binary is exact
+    tool("aslp-nnet-init", "--seed=123", str(tmp_path / "nnet.proto"), str(tmp_path / "a.bin"))
+    b = aslp.Nnet.Read(tmp_path / "a.bin")
+    assert np.array_equal(b.GetParams(), ref.GetParams())
+    np.testing.assert_allclose(a.GetParams(), ref.GetParams(), rtol=2e-6, atol=1e-9)
+    # copy: binary -> text -> binary; the text form is stable under a second round trip; pipes work as model files
+    tool("aslp-nnet-copy", "--binary=false", str(tmp_path / "a.bin"), str(tmp_path / "c.txt"))
+    tool("aslp-nnet-copy", "--binary=false", "cat %s |" % (tmp_path / "c.txt"), str(tmp_path / "c2.txt"))
+    assert (tmp_path / "c.txt").read_bytes() == (tmp_path / "c2.txt").read_bytes()
+    txt = (tmp_path / "c.txt").read_text()
+    assert txt.startswith("<Nnet> \n<InputLayer>") and txt.rstrip().endswith("</Nnet>")
+    tool("aslp-nnet-copy", str(tmp_path / "c.txt"), "| cat > %s" % (tmp_path / "c.bin"))
+    assert np.array_equal(aslp.Nnet.Read(tmp_path / "c.bin").GetParams(), aslp.Nnet.Read(tmp_path / "c.txt").GetParams())
+    p = tool("aslp-nnet-info", str(tmp_path / "a.bin"))
+    info = p.stdout.decode()
+    assert "num-components 7" in info and "<AffineTransform>" in info and info == ref.Info()
+    # wrong usage: usage text on stderr, exit status 1
+    p = tool("aslp-nnet-info", ok=False)
+    assert p.returncode == 1 and b"Usage:  aslp-nnet-info [options] <nnet-in>" in p.stderr
+    p = tool("aslp-nnet-copy", str(tmp_path / "missing.nnet"), str(tmp_path / "x"), ok=False)
+    assert p.returncode != 0 and b"Error opening input stream" in p.stderr
+
+
+def write_corpus(tmp_path, rng, n_utt, in_dim, out_dim, soft=False):
+    feats, posts, keys = [], [], []
+    for i in range(n_utt):
+        T = int(rng.integers(20, 60))
+        feats.append(rng.standard_normal((T, in_dim)).astype(np.float32))
+        if soft and i % 2:
+            post = []
+            for t in range(T):
+                a, b = rng.choice(out_dim, 2, replace=False)
+                post.append([(int(a), 0.75), (int(b), 0.25)])
+        else:
+            post = [[(int(rng.integers(0, out_dim)), 1.0)] for _ in range(T)]
+        posts.append(post)
+        keys.append("spk%02d-utt%03d" % (i % 3, i))
+    (tmp_path / "feats.ark").write_bytes(kf.archive([(k, kf.matrix_bin(f)) for k, f in zip(keys, feats)]))
+    (tmp_path / "post.ark").write_bytes(kf.archive([(k, kf.posterior_bin(p)) for k, p in zip(keys, posts)]))
+    return keys, feats, posts
+
+
+def minibatches(aslp, feats, posts, mb, seed, randomizer_size, shuffle=True, weights=None):
+    """FrameDataReader / the train-simple loop restated: fill the cache until it is full (utterance granularity, 'full'
+    = more than randomizer_size frames), shuffle with one libc-rand mask, hand out whole minibatches, carry the rest."""
+    first = True
+    cache_x, cache_t, cache_w = np.zeros((0, feats[0].shape[1]), np.float32), [], np.zeros(0, np.float32)
+    i = 0
+    while i < len(feats) or len(cache_t) >= mb:
+        while i < len(feats) and not len(cache_t) > randomizer_size:
+            cache_x = np.concatenate([cache_x, feats[i]])
+            cache_t = cache_t + posts[i]
+            cache_w = np.concatenate([cache_w, weights[i] if weights is not None else np.ones(len(posts[i]), np.float32)])
+            i += 1
+        if shuffle:
+            mask = aslp.randomizer_mask(len(cache_t), seed if first else -1)
+            first = False
+            cache_x, cache_t, cache_w = cache_x[mask], [cache_t[j] for j in mask], cache_w[mask]
+        b = 0
+        while len(cache_t) - b >= mb:
+            yield cache_x[b:b + mb], cache_t[b:b + mb], cache_w[b:b + mb]
+            b += mb
+        cache_x, cache_t, cache_w = cache_x[b:], cache_t[b:], cache_w[b:]
+        if i >= len(feats):
+            break
+
+
+@pytest.mark.parametrize("bn", [0, 1])
+def test_train_frame_matches_api_and_oracle(aslp, oracle, dev, tmp_path, bn):
+    in_dim, hid, nh, out_dim, mb = 24, 64, 2, 40, 32
+    d, path = make_dnn(oracle, tmp_path, in_dim, hid, nh, out_dim, bn, mb, seed=21)
+    rng = np.random.default_rng(7)
+    keys, feats, posts = write_corpus(tmp_path, rng, 12, in_dim, out_dim)
+    # drop one utterance's targets: the tool must warn and skip it
+    (tmp_path / "post.ark").write_bytes(kf.archive([(k, kf.posterior_bin(p)) for k, p in zip(keys, posts) if k != keys[4]]))
+    lr, seed, rsize = 0.004, 99, 150
+    p = tool("aslp-nnet-train-frame", "--learn-rate=%g" % lr, "--momentum=0.5", "--minibatch-size=%d" % mb, "--randomizer-size=%d" % rsize,
+             "--randomizer-seed=%d" % seed, "--report-period=200", "ark:%s" % (tmp_path / "feats.ark"), "ark:%s" % (tmp_path / "post.ark"),
+             str(path), str(tmp_path / "out.nnet"))
+    err = p.stderr.decode()
+    assert "%s, missing targets" % keys[4] in err and "TRAINING STARTED" in err and "AvgLoss:" in err and "FRAME_ACCURACY >>" in err
+    assert "[TRAINING, RANDOMIZED," in err and "fps" in err
+    got = aslp.Nnet.Read(tmp_path / "out.nnet").GetParams()
+    net = aslp.Nnet.Read(path)
+    net.SetTrainOptions(learn_rate=lr, momentum=0.5)
+    xent = aslp.Xent()
+    f2 = [f for k, f in zip(keys, feats) if k != keys[4]]
+    p2 = [q for k, q in zip(keys, posts) if k != keys[4]]
+    n_mb = 0
+    for x, t, _ in minibatches(aslp, f2, p2, mb, seed, rsize):
+        lab = np.array([fr[0][0] for fr in t], np.int32)
+        y = net.Propagate(torch.from_numpy(x).to(dev))
+        diff = torch.empty_like(y)
+        xent.Eval(torch.ones(mb, device=dev), y, diff, labels=torch.from_numpy(lab).to(dev))
+        net.Backpropagate(diff)
+        oracle.lib.orc_dnn_train_step(d, np.ascontiguousarray(x), lab, lr, 0.5)
+        n_mb += 1
+    assert n_mb >= 8
+    assert np.array_equal(got, net.GetParams())                      # the tool adds I/O, not arithmetic
+    assert oracle.rel_err(got, oracle_params(oracle, d, bn)) < TOL   # and the arithmetic is the reference's
+    rep = xent.Report().splitlines()
+    assert rep[0] in err and rep[1] in err
+    # cross-validation: no model written, same log vocabulary, loss of the TRAINED model below the initial one's
+    p = tool("aslp-nnet-train-frame", "--cross-validate=true", "--minibatch-size=%d" % mb, "ark:%s" % (tmp_path / "feats.ark"),
+             "ark:%s" % (tmp_path / "post.ark"), str(tmp_path / "out.nnet"))
+    assert b"CROSS-VALIDATION STARTED" in p.stderr and b"[CROSS-VALIDATION, RANDOMIZED" in p.stderr
+    oracle.lib.orc_dnn_destroy(d)
+
+
+def test_train_simple_weights_tolerance_and_soft_targets(aslp, oracle, dev, tmp_path):
+    in_dim, hid, nh, out_dim, mb = 20, 48, 1, 30, 16
+    d, path = make_dnn(oracle, tmp_path, in_dim, hid, nh, out_dim, 0, mb, seed=4)
+    oracle.lib.orc_dnn_destroy(d)
+    rng = np.random.default_rng(8)
+    keys, feats, posts = write_corpus(tmp_path, rng, 8, in_dim, out_dim, soft=True)
+    w = [rng.uniform(0.0, 2.0, len(p)).astype(np.float32) for p in posts]
+    w[2] = w[2][:-3]                       # 3 frames short: inside --length-tolerance=5 -> everything is cut to the minimum
+    posts_disk = list(posts)
+    posts_disk[5] = posts[5] + posts[5][:9]  # 9 frames long: dropped with a warning
+    uw = {k: 1.0 for k in keys}
+    uw[keys[1]] = 0.0                      # weight 0: utterance removed
+    uw[keys[3]] = 0.5
+    (tmp_path / "post.ark").write_bytes(kf.archive([(k, kf.posterior_bin(p)) for k, p in zip(keys, posts_disk)]))
+    (tmp_path / "w.ark").write_bytes(kf.archive([(k, kf.vector_bin(x)) for k, x in zip(keys, w)]))
+    (tmp_path / "uw.txt").write_text("".join("%s %g\n" % (k, uw[k]) for k in keys))
+    lr, seed = 0.01, 5
+    args = ["--learn-rate=%g" % lr, "--minibatch-size=%d" % mb, "--randomizer-size=100", "--randomizer-seed=%d" % seed,
+            "--frame-weights=ark:%s" % (tmp_path / "w.ark"), "--utt-weights=ark,t:%s" % (tmp_path / "uw.txt"),
+            "scp:%s" % (tmp_path / "feats.scp"), "ark:%s" % (tmp_path / "post.ark"), str(path)]
+    # features through an scp with byte offsets, made by the host-only table tool
+    tool("aslp-table-copy", "ark:%s" % (tmp_path / "feats.ark"), "ark,scp:%s,%s" % (tmp_path / "f2.ark", tmp_path / "feats.scp"))
+    p = tool("aslp-nnet-train-simple", *args, str(tmp_path / "out.nnet"))
+    err = p.stderr.decode()
+    assert "%s, length mismatch of targets" % keys[5] in err
+    assert "Done 6 files, 0 with no tgt_mats, 1 with other errors. [TRAINING, RANDOMIZED" in err
+    got = aslp.Nnet.Read(tmp_path / "out.nnet").GetParams()
+    net = aslp.Nnet.Read(path)
+    net.SetTrainOptions(learn_rate=lr)
+    xent = aslp.Xent()
+    use = [i for i in range(8) if i not in (1, 5)]
+    f2, p2, w2 = [], [], []
+    for i in use:
+        n = min(len(feats[i]), len(posts[i]), len(w[i]))
+        f2.append(feats[i][:n]); p2.append(posts[i][:n]); w2.append(w[i][:n] * np.float32(uw[keys[i]]))
+    for x, t, fw in minibatches(aslp, f2, p2, mb, seed, 100, weights=w2):
+        tgt = np.zeros((mb, out_dim), np.float32)
+        for r, fr in enumerate(t):
+            for c, v in fr:
+                tgt[r, c] = v
+        y = net.Propagate(torch.from_numpy(x).to(dev))
+        diff = torch.empty_like(y)
+        xent.Eval(torch.from_numpy(fw).to(dev), y, diff, targets=torch.from_numpy(tgt).to(dev))
+        net.Backpropagate(diff)
+    assert oracle.rel_err(got, net.GetParams()) < 1e-6   # one-hot frames take the label path in the tool, dense here
+    assert xent.Report().splitlines()[1] in err
+    # --randomize=false keeps the frame order; cross-validation never shuffles
+    p = tool("aslp-nnet-train-simple", "--randomize=false", *args, str(tmp_path / "out2.nnet"))
+    assert b"NOT-RANDOMIZED" in p.stderr
+    net2 = aslp.Nnet.Read(path)
+    net2.SetTrainOptions(learn_rate=lr)
+    xe2 = aslp.Xent()
+    for x, t, fw in minibatches(aslp, f2, p2, mb, seed, 100, shuffle=False, weights=w2):
+        tgt = np.zeros((mb, out_dim), np.float32)
+        for r, fr in enumerate(t):
+            for c, v in fr:
+                tgt[r, c] = v
+        y = net2.Propagate(torch.from_numpy(x).to(dev))
+        diff = torch.empty_like(y)
+        xe2.Eval(torch.from_numpy(fw).to(dev), y, diff, targets=torch.from_numpy(tgt).to(dev))
+        net2.Backpropagate(diff)
+    assert oracle.rel_err(aslp.Nnet.Read(tmp_path / "out2.nnet").GetParams(), net2.GetParams()) < 1e-6
+
+
+def test_forward_tool(aslp, oracle, dev, tmp_path):
+    in_dim, hid, nh, out_dim, mb = 20, 48, 2, 30, 16
+    d, path = make_dnn(oracle, tmp_path, in_dim, hid, nh, out_dim, 0, mb, seed=6)
+    oracle.lib.orc_dnn_destroy(d)
+    rng = np.random.default_rng(9)
+    keys, feats, _ = write_corpus(tmp_path, rng, 4, in_dim, out_dim)
+    counts = rng.integers(1, 1000, out_dim)
+    counts[3] = 0                                    # floored prior: the class is switched off for the decoder
+    (tmp_path / "counts").write_text(" [ " + " ".join(str(c) for c in counts) + " ]\n")
+    tool("aslp-nnet-forward", "--class-frame-counts=%s" % (tmp_path / "counts"), "--prior-scale=0.8", str(path),
+         "ark:%s" % (tmp_path / "feats.ark"), "ark:%s" % (tmp_path / "out.ark"))
+    got = kf.parse_bin_archive((tmp_path / "out.ark").read_bytes(), "matrix")
+    assert [k for k, _ in got] == keys
+    net = aslp.Nnet.Read(path)
+    rel = counts / counts.sum()
+    logp = np.log(rel + 1e-20)
+    logp[rel < 1e-10] = np.sqrt(np.finfo(np.float32).max)
+    for (k, o), f in zip(got, feats):
+        y = net.Feedforward(torch.from_numpy(f).to(dev)).cpu().numpy()
+        ref = np.log(y + np.float32(1e-20)) - np.float32(0.8) * logp.astype(np.float32)
+        assert o.shape == ref.shape
+        np.testing.assert_allclose(o, ref, rtol=1e-5, atol=1e-5)
+        assert np.all(o[:, 3] < -1e18)
+    # raw posteriors, text table to stdout
+    p = tool("aslp-nnet-forward", "--apply-log=false", str(path), "ark:%s" % (tmp_path / "feats.ark"), "ark,t:-")
+    first = p.stdout.decode().split("]")[0].split("[")[1].split()
+    y0 = net.Feedforward(torch.from_numpy(feats[0]).to(dev)).cpu().numpy()
+    np.testing.assert_allclose(np.array(first, np.float32).reshape(y0.shape), y0, rtol=2e-6, atol=1e-9)
+    p = tool("aslp-nnet-forward", "--no-softmax=true", str(path), "ark:%s" % (tmp_path / "feats.ark"), "ark:/dev/null", ok=False)
+    assert p.returncode != 0 and b"Cannot use both --apply-log=true --no-softmax=true" in p.stderr
