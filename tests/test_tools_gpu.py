@@ -247,3 +247,141 @@ def test_forward_tool(aslp, oracle, dev, tmp_path):
     np.testing.assert_allclose(np.array(first, np.float32).reshape(y0.shape), y0, rtol=2e-6, atol=1e-9)
     p = tool("aslp-nnet-forward", "--no-softmax=true", str(path), "ark:%s" % (tmp_path / "feats.ark"), "ark:/dev/null", ok=False)
     assert p.returncode != 0 and b"Cannot use both --apply-log=true --no-softmax=true" in p.stderr
+
+
+LC_PROTO = """<NnetProto>
+<BLstmProjectedStreamsLC> <InputDim> 12 <OutputDim> 16 <CellDim> 12 <ParamScale> 0.1 <ClipGradient> 5.0
+<AffineTransform> <InputDim> 16 <OutputDim> 10 <BiasMean> 0.0 <BiasRange> 0.0 <ParamStddev> 0.1
+<Softmax> <InputDim> 10 <OutputDim> 10
+</NnetProto>
+"""
+
+
+def test_blstm_lc_tool_matches_api(aslp, dev, tmp_path):
+    """aslp-nnet-train-blstm-streams-lc: stream bookkeeping (chunk + right context, rewind, history reset, padding,
+    frame mask) restated here and driven through the API; the tool's model must come out bit-identical."""
+    (tmp_path / "lc.proto").write_text(LC_PROTO)
+    tool("aslp-nnet-init", "--seed=31", str(tmp_path / "lc.proto"), str(tmp_path / "lc.init"))
+    rng = np.random.default_rng(11)
+    n_utt, D, A, S, chunk, right = 9, 12, 10, 3, 6, 3
+    keys = ["u%02d" % i for i in range(n_utt)]
+    lens = [int(x) for x in rng.integers(4, 26, n_utt)]
+    feats = [rng.standard_normal((n, D)).astype(np.float32) for n in lens]
+    posts = [[[(int(rng.integers(0, A)), 1.0)] for _ in range(n)] for n in lens]
+    posts_disk = {k: p for k, p in zip(keys, posts)}
+    del posts_disk[keys[2]]                                 # missing targets: skipped
+    posts_disk[keys[6]] = posts[6][:-1]                     # length mismatch: skipped
+    (tmp_path / "feats.ark").write_bytes(kf.archive([(k, kf.matrix_bin(f)) for k, f in zip(keys, feats)]))
+    (tmp_path / "post.ark").write_bytes(kf.archive([(k, kf.posterior_bin(p)) for k, p in posts_disk.items()]))
+    lr, mom = 0.01, 0.9
+    p = tool("aslp-nnet-train-blstm-streams-lc", "--learn-rate=%g" % lr, "--momentum=%g" % mom, "--num-stream=%d" % S, "--chunk-size=%d" % chunk,
+             "--right-splice=%d" % right, "--report-period=3", "ark:%s" % (tmp_path / "feats.ark"), "ark:%s" % (tmp_path / "post.ark"),
+             str(tmp_path / "lc.init"), str(tmp_path / "lc.out"))
+    err = p.stderr.decode()
+    assert "u02, missing targets" in err and "u06, length miss-match between feats and targets, skip" in err
+    got = aslp.Nnet.Read(tmp_path / "lc.out").GetParams()
+
+    net = aslp.Nnet.Read(tmp_path / "lc.init")
+    net.SetTrainOptions(learn_rate=lr, momentum=mom)
+    net.SetChunkSize(chunk)
+    xent = aslp.Xent()
+    todo = [i for i in range(n_utt) if i not in (2, 6)]
+    cur, length, which = [0] * S, [0] * S, [None] * S
+    T = chunk + right
+    valid_frames = steps = num_done = 0
+    flags = [0] * S
+    while True:
+        for s in range(S):
+            if cur[s] < length[s]:
+                flags[s] = 0
+                continue
+            if todo:
+                which[s] = todo.pop(0)
+                cur[s], length[s], flags[s] = 0, lens[which[s]], 1
+        if all(cur[s] >= length[s] for s in range(S)):
+            break
+        x = np.zeros((T * S, D), np.float32)
+        lab = np.zeros(T * S, np.int32)
+        mask = np.zeros(T * S, np.float32)
+        for t in range(T):
+            for s in range(S):
+                r = t * S + s
+                if cur[s] < length[s]:
+                    mask[r] = 1.0 if t < chunk else 0.0
+                    lab[r] = posts[which[s]][cur[s]][0][0]
+                    x[r] = feats[which[s]][cur[s]]
+                else:
+                    lab[r] = posts[which[s]][length[s] - 1][0][0] if which[s] is not None else 0
+                cur[s] += 1
+        for s in range(S):
+            cur[s] -= right
+        net.ResetLstmStreams(flags)
+        y = net.Propagate(torch.from_numpy(x).to(dev))
+        diff = torch.empty_like(y)
+        xent.Eval(torch.from_numpy(mask).to(dev), y, diff, labels=torch.from_numpy(lab).to(dev))
+        net.Backpropagate(diff)
+        valid_frames += int(mask.sum())
+        steps += 1
+        num_done += sum(flags)  # like the reference, a drained stream keeps its last flag: the count can exceed the files
+    assert steps > 5
+    assert "Done %d files, 1 with no tgt_mats, 1 with other errors. [TRAINING, NOT-RANDOMIZED" % num_done in err
+    assert np.array_equal(got, net.GetParams())
+    assert xent.GetStats()["frames"] == valid_frames
+    rep = xent.Report().splitlines()
+    assert rep[0] in err and rep[1] in err
+
+
+CTC_PROTO = """<NnetProto>
+<BLstmProjectedStreams> <InputDim> 12 <OutputDim> 16 <CellDim> 12 <ParamScale> 0.1 <ClipGradient> 5.0
+<AffineTransform> <InputDim> 16 <OutputDim> 9 <BiasMean> 0.0 <BiasRange> 0.0 <ParamStddev> 0.1
+</NnetProto>
+"""
+
+
+def test_warp_ctc_streams_tool_matches_api(aslp, dev, tmp_path):
+    """aslp-nnet-train-warp-ctc-streams: utterance grouping (num-stream / frame-limit), padding to the longest, the
+    learning rate divided by the valid frames of the group -- restated here through the API, bit-identical model."""
+    (tmp_path / "ctc.proto").write_text(CTC_PROTO)
+    tool("aslp-nnet-init", "--seed=41", str(tmp_path / "ctc.proto"), str(tmp_path / "ctc.init"))
+    rng = np.random.default_rng(12)
+    n_utt, D, A, S = 8, 12, 9, 3
+    keys = ["c%02d" % i for i in range(n_utt)]
+    lens = [int(x) for x in rng.integers(12, 40, n_utt)]
+    feats = [rng.standard_normal((n, D)).astype(np.float32) for n in lens]
+    labels = [[int(x) for x in rng.integers(1, A, max(1, n // 5))] for n in lens]
+    lab_disk = {k: l for k, l in zip(keys, labels)}
+    del lab_disk[keys[1]]
+    (tmp_path / "feats.ark").write_bytes(kf.archive([(k, kf.matrix_bin(f)) for k, f in zip(keys, feats)]))
+    (tmp_path / "lab.ark").write_bytes(kf.archive([(k, kf.int32vec_txt(l)) for k, l in lab_disk.items()]))
+    lr, frame_limit = 0.5, 70
+    p = tool("aslp-nnet-train-warp-ctc-streams", "--learn-rate=%g" % lr, "--momentum=0.9", "--num-stream=%d" % S, "--frame-limit=%d" % frame_limit,
+             "--report-period=2", "ark:%s" % (tmp_path / "feats.ark"), "ark,t:%s" % (tmp_path / "lab.ark"), str(tmp_path / "ctc.init"),
+             str(tmp_path / "ctc.out"))
+    err = p.stderr.decode()
+    assert "c01, missing targets" in err and "Done 7 files, 1 with no targets, 0 with other errors. [TRAINING" in err
+    assert "TOKEN_ACCURACY" in err
+    got = aslp.Nnet.Read(tmp_path / "ctc.out").GetParams()
+
+    net = aslp.Nnet.Read(tmp_path / "ctc.init")
+    ctc = aslp.WarpCtc()
+    todo = [i for i in range(n_utt) if i != 1]
+    groups = 0
+    while todo:
+        grp, mx = [], 0
+        while todo:
+            i = todo.pop(0)
+            grp.append(i)
+            mx = max(mx, lens[i])
+            if len(grp) == S or len(grp) * mx > frame_limit:
+                break
+        n = len(grp)
+        x = np.zeros((n * mx, D), np.float32)
+        for s, i in enumerate(grp):
+            x[np.arange(lens[i]) * n + s] = feats[i]
+        fn = [lens[i] for i in grp]
+        net.SetTrainOptions(learn_rate=np.float32(lr) / np.float32(sum(fn)), momentum=0.9)
+        net.TrainStepWarpCtc(ctc, torch.from_numpy(x).to(dev), fn, [labels[i] for i in grp])
+        groups += 1
+    assert groups >= 3
+    assert np.array_equal(got, net.GetParams())
+    assert ctc.Report().strip().splitlines()[-1] in err
