@@ -67,6 +67,10 @@ void CuDevice::SetGpuId(int32 gpu_id) {  // cu-device.cc:203-224
   FinalizeActiveGpu();
 }
 
+void CuDevice::BindThread() const {
+  if (active_gpu_id_ >= 0 && hipSetDevice(active_gpu_id_) != hipSuccess) ASLP_ERR << "hipSetDevice(" << active_gpu_id_ << ") failed";
+}
+
 void CuDevice::PrintProfile() {  // cu-device.cc:440-470
   if (!Enabled() && profile_map_.empty()) return;
   std::ostringstream os;

@@ -21,6 +21,7 @@ class CuDevice {
   void PrintProfile();
   void ResetProfile() { profile_map_.clear(); }
   std::string GetFreeMemory(int64_t *free = NULL, int64_t *total = NULL) const;
+  void BindThread() const;  // a new host thread starts on device 0: make it use the active GPU
   void CheckGpuHealth();  // runs a small GEMM + copy on the device and checks the result (cu-device.cc:482-510)
 
  private:

@@ -65,10 +65,65 @@ void DeviceToHost(void *dst, const void *src, size_t bytes) {
   CheckHip(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, cur_stream()), "hipMemcpy D2H");
   CheckHip(hipStreamSynchronize(cur_stream()), "hipStreamSynchronize");
 }
+// Host -> device without draining the stream: the bytes are copied into a ring of pinned staging slots and sent with
+// hipMemcpyAsync; `src` is free again on return, and the only wait is for the copy that used the same slot a whole ring
+// ago (long finished).  A stream synchronise per upload -- labels, frame weights, every utterance of a cache fill -- would
+// empty the launch queue each time and leave the GPU idle while the host refills it (measured on the tool path: 546 k
+// -> see DESIGN.md frames/s end to end).
+namespace {
+constexpr size_t kStageBytes = 4u << 20;
+constexpr int kStageSlots = 8;
+struct StageSlot { void *pinned = nullptr; hipEvent_t ev = nullptr; bool pending = false; };
+StageSlot g_stage[kStageSlots];
+int g_stage_next = 0;
+std::mutex g_stage_mu;
+}  // namespace
+// next free staging slot (caller holds g_stage_mu)
+static StageSlot &TakeStageSlot() {
+  StageSlot &slot = g_stage[g_stage_next];
+  g_stage_next = (g_stage_next + 1) % kStageSlots;
+  if (!slot.pinned) {
+    CheckHip(hipHostMalloc(&slot.pinned, kStageBytes, hipHostMallocDefault), "hipHostMalloc(staging)");
+    CheckHip(hipEventCreateWithFlags(&slot.ev, hipEventDisableTiming), "hipEventCreate(staging)");
+  }
+  if (slot.pending) { CheckHip(hipEventSynchronize(slot.ev), "hipEventSynchronize(staging)"); slot.pending = false; }
+  return slot;
+}
 void HostToDevice(void *dst, const void *src, size_t bytes) {
   if (!bytes) return;
-  CheckHip(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, cur_stream()), "hipMemcpy H2D");
-  CheckHip(hipStreamSynchronize(cur_stream()), "hipStreamSynchronize");  // src may be a temporary
+  std::lock_guard<std::mutex> lk(g_stage_mu);
+  const char *s = static_cast<const char *>(src);
+  char *d = static_cast<char *>(dst);
+  while (bytes > 0) {
+    StageSlot &slot = TakeStageSlot();
+    const size_t n = bytes < kStageBytes ? bytes : kStageBytes;
+    std::memcpy(slot.pinned, s, n);
+    CheckHip(hipMemcpyAsync(d, slot.pinned, n, hipMemcpyHostToDevice, cur_stream()), "hipMemcpy H2D");
+    CheckHip(hipEventRecord(slot.ev, cur_stream()), "hipEventRecord(staging)");
+    slot.pending = true;
+    s += n; d += n; bytes -= n;
+  }
+}
+// rows of `cols` floats at host pitch `ld` -> device rows at pitch `stride`, through the staging ring
+static void HostToDevice2D(float *dst, int stride, const float *src, int ld, int rows, int cols) {
+  if (rows <= 0 || cols <= 0) return;
+  std::lock_guard<std::mutex> lk(g_stage_mu);
+  const size_t row_bytes = sizeof(float) * (size_t)cols;
+  int rows_per_slot = (int)(kStageBytes / row_bytes);
+  if (rows_per_slot < 1) ASLP_ERR << "matrix row of " << cols << " floats exceeds the staging slot";
+  for (int r0 = 0; r0 < rows; r0 += rows_per_slot) {
+    const int nr = rows - r0 < rows_per_slot ? rows - r0 : rows_per_slot;
+    StageSlot &slot = TakeStageSlot();
+    if (ld == cols) std::memcpy(slot.pinned, src + (size_t)r0 * ld, row_bytes * nr);
+    else for (int r = 0; r < nr; r++) std::memcpy(static_cast<char *>(slot.pinned) + row_bytes * r, src + (size_t)(r0 + r) * ld, row_bytes);
+    if (stride == cols)
+      CheckHip(hipMemcpyAsync(dst + (size_t)r0 * stride, slot.pinned, row_bytes * nr, hipMemcpyHostToDevice, cur_stream()), "hipMemcpy H2D");
+    else
+      CheckHip(hipMemcpy2DAsync(dst + (size_t)r0 * stride, sizeof(float) * stride, slot.pinned, row_bytes, row_bytes, nr, hipMemcpyHostToDevice,
+                                cur_stream()), "hipMemcpy2D H2D");
+    CheckHip(hipEventRecord(slot.ev, cur_stream()), "hipEventRecord(staging)");
+    slot.pending = true;
+  }
 }
 void DeviceToDevice(void *dst, const void *src, size_t bytes) {
   if (!bytes) return;
@@ -78,6 +133,21 @@ void DeviceMemset(void *dst, int v, size_t bytes) {
   if (!bytes) return;
   CheckHip(hipMemsetAsync(dst, v, bytes, cur_stream()), "hipMemset");
 }
+void *PinnedAlloc(size_t bytes) {
+  void *p = nullptr;
+  CheckHip(hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault), "hipHostMalloc");
+  return p;
+}
+void PinnedFree(void *p) { if (p) (void)hipHostFree(p); }
+StreamMarker::StreamMarker() : ev_(nullptr), recorded_(false) {
+  hipEvent_t e;
+  CheckHip(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+  ev_ = e;
+}
+StreamMarker::~StreamMarker() { if (ev_) (void)hipEventDestroy(static_cast<hipEvent_t>(ev_)); }
+void StreamMarker::Record() { CheckHip(hipEventRecord(static_cast<hipEvent_t>(ev_), cur_stream()), "hipEventRecord"); recorded_ = true; }
+bool StreamMarker::Done() const { return !recorded_ || hipEventQuery(static_cast<hipEvent_t>(ev_)) == hipSuccess; }
+void StreamMarker::Wait() const { if (recorded_) CheckHip(hipEventSynchronize(static_cast<hipEvent_t>(ev_)), "hipEventSynchronize"); }
 void StreamSync() {
   CheckHip(hipStreamSynchronize(cur_stream()), "hipStreamSynchronize");
   CheckKernels();
@@ -248,9 +318,15 @@ void CuMatrixBase::CopyFromMat(const CuMatrixBase &src) {
 }
 void CuMatrixBase::CopyFromHost(const float *src, int ld) {
   if (!rows_) return;
-  CheckHip(hipMemcpy2DAsync(data_, sizeof(float) * stride_, src, sizeof(float) * ld, sizeof(float) * cols_, rows_,
-                            hipMemcpyHostToDevice, cur_stream()), "hipMemcpy2D H2D");
-  CheckHip(hipStreamSynchronize(cur_stream()), "hipStreamSynchronize");
+  HostToDevice2D(data_, stride_, src, ld, rows_, cols_);
+}
+void CuMatrixBase::CopyFromPinnedHost(const float *src, int ld) {
+  if (!rows_) return;
+  if (stride_ == cols_ && ld == cols_)
+    CheckHip(hipMemcpyAsync(data_, src, sizeof(float) * (size_t)rows_ * cols_, hipMemcpyHostToDevice, cur_stream()), "hipMemcpy H2D");
+  else
+    CheckHip(hipMemcpy2DAsync(data_, sizeof(float) * stride_, src, sizeof(float) * ld, sizeof(float) * cols_, rows_, hipMemcpyHostToDevice,
+                              cur_stream()), "hipMemcpy2D H2D");
 }
 void CuMatrixBase::CopyToHost(float *dst, int ld) const {
   if (!rows_) return;

@@ -25,6 +25,24 @@ void HostToDevice(void *dst, const void *src, size_t bytes);
 void DeviceToDevice(void *dst, const void *src, size_t bytes);
 void DeviceMemset(void *dst, int v, size_t bytes);
 void StreamSync();
+// Page-locked host memory + a completion marker, for uploads that must not pass through a staging copy: the caller fills
+// a pinned block (possibly on another thread), CopyFromPinnedHost() sends it with one async copy, and the block may be
+// reused once a StreamMarker recorded after the copy reports Done().
+void *PinnedAlloc(size_t bytes);
+void PinnedFree(void *p);
+class StreamMarker {
+ public:
+  StreamMarker();
+  ~StreamMarker();
+  void Record();        // on the calling thread's current stream
+  bool Done() const;    // everything issued before Record() has finished
+  void Wait() const;
+ private:
+  void *ev_;
+  bool recorded_;
+  StreamMarker(const StreamMarker &) = delete;
+  StreamMarker &operator=(const StreamMarker &) = delete;
+};
 // Brings the HIP runtime fully up (context, code object, first launch).  The runtime draws from libc rand() while it
 // initialises, so anything that seeds rand() for reproducible parameters (aslp-nnet-init) calls this BEFORE srand().
 void WarmUpDevice();
@@ -186,6 +204,7 @@ class CuMatrixBase {
   void InvertElements();
   void CopyFromMat(const CuMatrixBase &src);
   void CopyFromHost(const float *src, int ld);
+  void CopyFromPinnedHost(const float *src, int ld);  // async, no staging copy: `src` must stay valid until the stream passes
   void CopyToHost(float *dst, int ld) const;
   void CopyFromMat(const HostMatrix &m);
   void CopyToMat(HostMatrix *m) const;

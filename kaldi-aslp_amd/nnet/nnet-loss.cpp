@@ -141,6 +141,37 @@ void Xent::EvalLabelsPreSoftmax(const CuVectorBase &fw, const CuMatrixBase &acts
   AfterEval(acts.NumRows());
 }
 
+void Xent::EvalOnLossInput(const std::vector<BaseFloat> &frame_weights, const CuMatrixBase &in, bool pre_softmax, const Posterior &post,
+                           CuMatrix *diff) {
+  if (!pre_softmax) { Eval(frame_weights, in, post, diff); return; }
+  const int32 num_frames = in.NumRows(), num_pdf = in.NumCols();
+  ASLP_ASSERT(num_frames == (int32)post.size() && num_frames == (int32)frame_weights.size());
+  for (BaseFloat w : frame_weights) ASLP_ASSERT(std::isfinite(w));
+  bool one_hot = true;
+  std::vector<int32> labels(num_frames);
+  for (int32 t = 0; t < num_frames && one_hot; t++) {
+    if (post[t].size() != 1 || post[t][0].second != 1.0f || post[t][0].first < 0) one_hot = false;
+    else {
+      labels[t] = post[t][0].first;
+      if (labels[t] >= num_pdf) ASLP_ERR << "Out-of-bound Posterior element with index " << labels[t] << ", higher than number of columns " << num_pdf;
+    }
+  }
+  HostVector hv;
+  hv.data = frame_weights;
+  frame_weights_ = hv;
+  diff->Resize(num_frames, num_pdf, kUndefined);
+  if (one_hot) {
+    labels_ = labels;
+    aslp_softmax_xent_eval(in.Data(), in.Dim(), nullptr, 0, labels_.Data(), frame_weights_.Data(), diff->Data(), diff->Stride(), stats_.Data(), nullptr, 0);
+  } else {
+    PosteriorToMatrix(post, num_pdf, &tgt_mat_);
+    aslp_softmax_xent_eval(in.Data(), in.Dim(), tgt_mat_.Data(), tgt_mat_.Stride(), nullptr, frame_weights_.Data(), diff->Data(), diff->Stride(),
+                           stats_.Data(), nullptr, 0);
+  }
+  CheckK();
+  AfterEval(num_frames);
+}
+
 std::string Xent::Report() {  // nnet-loss.cc:175-199
   Fetch();
   std::ostringstream oss;

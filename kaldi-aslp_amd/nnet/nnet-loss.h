@@ -41,6 +41,10 @@ class Xent : public LossItf {
   // `acts` are the activations in front of the network's final Softmax; the posteriors are formed inside the loss kernel
   void EvalLabelsPreSoftmax(const CuVectorBase &frame_weights, const CuMatrixBase &acts, const int32 *labels_dev, CuMatrix *diff);
   void EvalLabels(const CuVectorBase &frame_weights, const CuMatrixBase &net_out, const int32 *labels_dev, CuMatrix *diff);
+  // Eval(frame_weights, net_out, Posterior) for callers that hold the executor's buffers (Nnet::PropagateForLoss):
+  // `loss_input` is the network output, or the activations in front of its final Softmax when `pre_softmax`
+  void EvalOnLossInput(const std::vector<BaseFloat> &frame_weights, const CuMatrixBase &loss_input, bool pre_softmax, const Posterior &target,
+                       CuMatrix *diff);
   std::string Report();
   BaseFloat AvgLoss() { Fetch(); return (loss_ - entropy_) / frames_; }
   // raw accumulators {frames, correct, loss, entropy, likelyhood}

@@ -79,7 +79,19 @@ class MatrixRandomizer : public RandomizerBase {  // :67-102
   MatrixRandomizer() : minibatch_(nullptr, 0, 0, 0) {}
   explicit MatrixRandomizer(const NnetDataRandomizerOptions &conf) : minibatch_(nullptr, 0, 0, 0) { Init(conf); }
   void AddData(const CuMatrixBase &m) {  // nnet-randomizer.cc:47-71
-    if (data_.NumCols() == 0) data_.Resize(conf_.randomizer_size, m.NumCols());
+    CuSubMatrix dst = Append(m.NumRows(), m.NumCols());
+    dst.CopyFromMat(m);
+  }
+  // same bookkeeping, rows taken straight from page-locked host memory (one async copy, no intermediate device matrix);
+  // `src` must stay valid until the stream has passed this call
+  void AddDataPinned(const float *src, int32 rows, int32 cols) {
+    CuSubMatrix dst = Append(rows, cols);
+    dst.CopyFromPinnedHost(src, cols);
+  }
+
+ private:
+  CuSubMatrix Append(int32 m_rows, int32 m_cols) {
+    if (data_.NumCols() == 0) data_.Resize(conf_.randomizer_size, m_cols);
     if (data_begin_ > 0) {
       const int32 leftover = BeginRefill();
       if (leftover > 0) data_.RowRange(0, leftover).CopyFromMat(data_.RowRange(data_begin_, leftover));
@@ -87,14 +99,18 @@ class MatrixRandomizer : public RandomizerBase {  // :67-102
       data_end_ = leftover;
       data_.RowRange(leftover, data_.NumRows() - leftover).SetZero();
     }
-    if (data_.NumRows() < data_end_ + m.NumRows()) {
+    if (data_.NumRows() < data_end_ + m_rows) {
       CuMatrix data_aux(data_);
-      data_.Resize(data_end_ + m.NumRows() + 1000, data_.NumCols());
+      data_.Resize(data_end_ + m_rows + 1000, data_.NumCols());
       data_.RowRange(0, data_aux.NumRows()).CopyFromMat(data_aux);
     }
-    data_.RowRange(data_end_, m.NumRows()).CopyFromMat(m);
-    data_end_ += m.NumRows();
+    ASLP_ASSERT(m_cols == data_.NumCols());
+    CuSubMatrix dst = data_.RowRange(data_end_, m_rows);
+    data_end_ += m_rows;
+    return dst;
   }
+
+ public:
   void Randomize(const std::vector<int32> &mask) {  // :73-88
     CheckRandomize(mask.size());
     mask_dev_.CopyFromVec(mask);

@@ -54,6 +54,8 @@ int main(int argc, char *argv[]) {
     if (objective_function == "xent") loss = new Xent;
     else if (objective_function == "mse") loss = new Mse;
     else ASLP_ERR << "Unsupported objective function: " << objective_function;
+    Xent *xent = dynamic_cast<Xent *>(loss);
+    std::vector<BaseFloat> ones;
 
     Timer time;
     int64_t total_frames = 0, report_frames = 0;
@@ -65,11 +67,28 @@ int main(int argc, char *argv[]) {
       CuMatrix nnet_out, obj_diff;
       const Posterior *nnet_tgt;
       while (!reader.Done()) {
-        if (!reader.ReadData(&nnet_in, &nnet_tgt)) continue;
-        if (!crossvalidate) nnet.Propagate(*nnet_in, &nnet_out);
-        else nnet.Feedforward(*nnet_in, &nnet_out);
-        loss->Eval(nnet_out, *nnet_tgt, &obj_diff);
-        if (!crossvalidate) nnet.Backpropagate(obj_diff, NULL);
+        Timer tr;
+        const bool got = reader.ReadData(&nnet_in, &nnet_tgt);
+        CuDevice::Instantiate().AccuProfile("host: FrameDataReader::ReadData", tr.Elapsed());
+        if (!got) continue;
+        if (!crossvalidate && xent != NULL) {
+          // same three steps, in the executor's own buffers: no output / diff copies, final Softmax left to the loss kernel
+          Timer t1;
+          nnet.PropagateForLoss(*nnet_in, true);
+          CuDevice::Instantiate().AccuProfile("host: Propagate (launches)", t1.Elapsed());
+          t1.Reset();
+          ones.assign(nnet_in->NumRows(), 1.0f);
+          xent->EvalOnLossInput(ones, nnet.LossInput(), nnet.LossInputIsPreSoftmax(), *nnet_tgt, nnet.LossDiff(nnet_in->NumRows()));
+          CuDevice::Instantiate().AccuProfile("host: Xent::Eval (launches + label upload)", t1.Elapsed());
+          t1.Reset();
+          nnet.BackpropagateFromLossDiff();
+          CuDevice::Instantiate().AccuProfile("host: Backpropagate (launches)", t1.Elapsed());
+        } else {
+          if (!crossvalidate) nnet.Propagate(*nnet_in, &nnet_out);
+          else nnet.Feedforward(*nnet_in, &nnet_out);
+          loss->Eval(nnet_out, *nnet_tgt, &obj_diff);
+          if (!crossvalidate) nnet.Backpropagate(obj_diff, NULL);
+        }
         total_frames += nnet_in->NumRows();
         report_frames += nnet_in->NumRows();
         if (report_period > 0 && report_frames >= report_period) {
@@ -78,8 +97,14 @@ int main(int argc, char *argv[]) {
         }
       }
     }
-    if (!crossvalidate) nnet.Write(target_model_filename, binary);
-    StreamSync();
+    {
+      Timer tw;
+      StreamSync();
+      CuDevice::Instantiate().AccuProfile("wait for the GPU after the last minibatch", tw.Elapsed());
+      tw.Reset();
+      if (!crossvalidate) nnet.Write(target_model_filename, binary);
+      CuDevice::Instantiate().AccuProfile("Nnet::Write", tw.Elapsed());
+    }
     ASLP_LOG << "[" << (crossvalidate ? "CROSS-VALIDATION" : "TRAINING") << ", " << (randomize ? "RANDOMIZED" : "NOT-RANDOMIZED") << ", "
              << time.Elapsed() / 60 << " min, fps" << total_frames / time.Elapsed() << "]";
     ASLP_LOG << loss->Report();

@@ -138,13 +138,19 @@ int main(int argc, char *argv[]) {
         const CuMatrixBase &nnet_in = feature_randomizer.Value();
         const Posterior &nnet_tgt = targets_randomizer.Value();
         const std::vector<BaseFloat> &frm_weights = weights_randomizer.Value();
-        if (!crossvalidate) nnet.Propagate(nnet_in, &nnet_out);
+        const bool fused = !crossvalidate && objective_function == "xent";
+        if (fused) {  // same three steps in the executor's own buffers (no output / diff copies, Softmax left to the loss kernel)
+          nnet.PropagateForLoss(nnet_in, true);
+          xent.EvalOnLossInput(frm_weights, nnet.LossInput(), nnet.LossInputIsPreSoftmax(), nnet_tgt, nnet.LossDiff(nnet_in.NumRows()));
+          nnet.BackpropagateFromLossDiff();
+        } else if (!crossvalidate) nnet.Propagate(nnet_in, &nnet_out);
         else nnet.Feedforward(nnet_in, &nnet_out);
-        if (objective_function == "xent") xent.Eval(frm_weights, nnet_out, nnet_tgt, &obj_diff);
+        if (fused) {
+        } else if (objective_function == "xent") xent.Eval(frm_weights, nnet_out, nnet_tgt, &obj_diff);
         else if (objective_function == "mse") mse.Eval(frm_weights, nnet_out, nnet_tgt, &obj_diff);
         else if (0 == objective_function.compare(0, 9, "multitask")) multitask.Eval(frm_weights, nnet_out, nnet_tgt, &obj_diff);
         else ASLP_ERR << "Unknown objective function code : " << objective_function;
-        if (!crossvalidate) nnet.Backpropagate(obj_diff, NULL);
+        if (!crossvalidate && !fused) nnet.Backpropagate(obj_diff, NULL);
         if (g_verbose_level >= 1 && total_frames == 0) {  // 1st minibatch : show what happens in network
           ASLP_VLOG(1) << "### After " << total_frames << " frames,";
           ASLP_VLOG(1) << nnet.InfoPropagate();
