@@ -220,4 +220,109 @@ class FrameDataReader {
   std::vector<std::pair<Block, std::unique_ptr<StreamMarker>>> in_flight_;
 };
 
+// ---- SequenceDataReader (data-reader.h:48-100, data-reader.cc:178-340) -------------------------------------------
+// num-stream utterances advance in parallel, batch-size frames per call, rows t*S + s; features are shifted by
+// targets-delay frames against the targets (the last frame repeats), an exhausted stream is padded with its last frame /
+// target under a zero mask and takes the next utterance (flag in GetNewUttFlags) at the next call.
+struct SequenceDataReaderOptions {
+  int32 batch_size, num_stream, drop_len, skip_width, targets_delay, length_tolerance;
+  double frame_limit;
+  SequenceDataReaderOptions() : batch_size(20), num_stream(100), drop_len(0), skip_width(1), targets_delay(5), length_tolerance(5), frame_limit(100000) {}
+  void Register(OptionsItf *opts) {
+    opts->Register("batch-size", &batch_size, "--LSTM-- BPTT batch_size");
+    opts->Register("num-stream", &num_stream, "--LSTM-- BPTT multistream training");
+    opts->Register("drop-len", &drop_len, "if Sentence frame length greater than drop_len,then drop it, default(0, no drop)");
+    opts->Register("skip-width", &skip_width, "num of frame for one skip(default 1, no skip)");
+    opts->Register("targets-delay", &targets_delay, "--LSTM-- BPTT targets delay");
+    opts->Register("length-tolerance", &length_tolerance, "Allowed length difference of features/targets (frames),for the whole utterance training");
+    opts->Register("frame-limit", &frame_limit, "Max number of frames to be processed for whole utterance training");
+  }
+};
+
+class SequenceDataReader {
+ public:
+  SequenceDataReader(const std::string &feature_rspecifier, const std::string &targets_rspecifier, const SequenceDataReaderOptions &read_opts)
+      : feature_reader_(feature_rspecifier), target_reader_(targets_rspecifier), read_opts_(read_opts), read_done_(false),
+        keys_(read_opts.num_stream), feats_(read_opts.num_stream), targets_(read_opts.num_stream), curt_(read_opts.num_stream, 0),
+        lent_(read_opts.num_stream, 0), new_utt_flags_(read_opts.num_stream, 0) {}
+  bool Done() { return read_done_ && feature_reader_.Done(); }
+  const std::vector<int32> &GetNewUttFlags() const { return new_utt_flags_; }
+  // When every stream is exhausted the reference leaves `feat` as it was and hands out an all-zero mask (the caller still
+  // runs one more step on it, which matters with momentum): same here.
+  void ReadData(CuMatrix *feat, Posterior *target, std::vector<BaseFloat> *frame_mask) {
+    ASLP_ASSERT(feat != NULL && target != NULL && frame_mask != NULL);
+    if (Done()) ASLP_ERR << "Already read done!";
+    AddNewUtt();
+    FillBatchBuff(feat, target, frame_mask);
+  }
+
+ private:
+  void AddNewUtt() {  // data-reader.cc:200-270
+    for (int s = 0; s < read_opts_.num_stream; s++) {
+      if (curt_[s] < lent_[s]) { new_utt_flags_[s] = 0; continue; }
+      while (!feature_reader_.Done()) {
+        const std::string key = feature_reader_.Key();
+        const HostMatrix &mat = feature_reader_.Value();
+        if (read_opts_.drop_len > 0 && mat.rows > read_opts_.drop_len) { ASLP_WARN << key << ", too long, droped"; feature_reader_.Next(); continue; }
+        if (!target_reader_.HasKey(key)) { ASLP_WARN << key << ", missing targets"; feature_reader_.Next(); continue; }
+        const Posterior &target = target_reader_.Value(key);
+        if (mat.rows != (int32)target.size()) { ASLP_WARN << key << ", length miss-match between feats and targers, skip"; feature_reader_.Next(); continue; }
+        const int32 skip_width = read_opts_.skip_width;
+        if (skip_width > 1) {
+          const int32 skip_len = (mat.rows - 1) / skip_width + 1;
+          feats_[s].Resize(skip_len, mat.cols);
+          targets_[s].assign(skip_len, Posterior::value_type());
+          for (int32 i = 0; i < skip_len; i++) {
+            std::copy(mat.data.begin() + (size_t)i * skip_width * mat.cols, mat.data.begin() + (size_t)(i * skip_width + 1) * mat.cols,
+                      feats_[s].data.begin() + (size_t)i * mat.cols);
+            targets_[s][i] = target[i * skip_width];
+          }
+        } else {
+          feats_[s] = mat;
+          targets_[s] = target;
+        }
+        keys_[s] = key;
+        curt_[s] = 0;
+        lent_[s] = feats_[s].rows;
+        new_utt_flags_[s] = 1;
+        feature_reader_.Next();
+        break;
+      }
+    }
+  }
+  void FillBatchBuff(CuMatrix *feat, Posterior *target, std::vector<BaseFloat> *frame_mask) {  // :272-325
+    const int32 S = read_opts_.num_stream, B = read_opts_.batch_size, delay = read_opts_.targets_delay;
+    read_done_ = true;
+    for (int s = 0; s < S; s++)
+      if (curt_[s] < lent_[s]) { read_done_ = false; break; }
+    const int32 feat_dim = feats_[0].cols;
+    target->resize((size_t)B * S);
+    frame_mask->assign((size_t)B * S, 0.0f);
+    if (read_done_) return;
+    host_.Resize(B * S, feat_dim);
+    for (int t = 0; t < B; t++) {
+      for (int s = 0; s < S; s++) {
+        const size_t row = (size_t)t * S + s;
+        if (lent_[s] == 0) { curt_[s]++; continue; }  // a stream that never got an utterance (the reference would index [-1])
+        if (curt_[s] < lent_[s]) { (*frame_mask)[row] = 1.0f; (*target)[row] = targets_[s][curt_[s]]; }
+        else { (*target)[row] = targets_[s][lent_[s] - 1]; }
+        const int32 src = curt_[s] + delay < lent_[s] ? curt_[s] + delay : lent_[s] - 1;
+        std::copy(feats_[s].data.begin() + (size_t)src * feat_dim, feats_[s].data.begin() + (size_t)(src + 1) * feat_dim,
+                  host_.data.begin() + row * feat_dim);
+        curt_[s]++;
+      }
+    }
+    *feat = host_;
+  }
+  SequentialBaseFloatMatrixReader feature_reader_;
+  RandomAccessPosteriorReader target_reader_;
+  SequenceDataReaderOptions read_opts_;
+  bool read_done_;
+  std::vector<std::string> keys_;
+  std::vector<HostMatrix> feats_;
+  std::vector<Posterior> targets_;
+  std::vector<int32> curt_, lent_, new_utt_flags_;
+  HostMatrix host_;
+};
+
 }  // namespace aslp

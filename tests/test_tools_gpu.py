@@ -385,3 +385,76 @@ def test_warp_ctc_streams_tool_matches_api(aslp, dev, tmp_path):
     assert groups >= 3
     assert np.array_equal(got, net.GetParams())
     assert ctc.Report().strip().splitlines()[-1] in err
+
+
+LSTM_PROTO = """<NnetProto>
+<LstmProjectedStreams> <InputDim> 12 <OutputDim> 16 <CellDim> 12 <ParamScale> 0.1 <ClipGradient> 5.0
+<AffineTransform> <InputDim> 16 <OutputDim> 10 <BiasMean> 0.0 <BiasRange> 0.0 <ParamStddev> 0.1
+<Softmax> <InputDim> 10 <OutputDim> 10
+</NnetProto>
+"""
+
+
+def test_lstm_streams_tool_matches_api(aslp, dev, tmp_path):
+    """aslp-nnet-train-lstm-streams / SequenceDataReader: truncated BPTT batches with delayed targets, restated through the
+    API -- including the reference's last step on the stale batch under an all-zero mask (it moves the weights when momentum
+    is on) -- bit-identical model."""
+    (tmp_path / "l.proto").write_text(LSTM_PROTO)
+    tool("aslp-nnet-init", "--seed=51", str(tmp_path / "l.proto"), str(tmp_path / "l.init"))
+    rng = np.random.default_rng(13)
+    n_utt, D, A, S, B, delay = 7, 12, 10, 3, 5, 2
+    keys = ["s%02d" % i for i in range(n_utt)]
+    lens = [int(x) for x in rng.integers(3, 19, n_utt)]
+    feats = [rng.standard_normal((n, D)).astype(np.float32) for n in lens]
+    posts = [[[(int(rng.integers(0, A)), 1.0)] for _ in range(n)] for n in lens]
+    (tmp_path / "feats.ark").write_bytes(kf.archive([(k, kf.matrix_bin(f)) for k, f in zip(keys, feats)]))
+    (tmp_path / "post.ark").write_bytes(kf.archive([(k, kf.posterior_bin(p)) for k, p in zip(keys, posts)]))
+    lr, mom = 0.02, 0.9
+    p = tool("aslp-nnet-train-lstm-streams", "--learn-rate=%g" % lr, "--momentum=%g" % mom, "--num-stream=%d" % S, "--batch-size=%d" % B,
+             "--targets-delay=%d" % delay, "--report-period=2", "ark:%s" % (tmp_path / "feats.ark"), "ark:%s" % (tmp_path / "post.ark"),
+             str(tmp_path / "l.init"), str(tmp_path / "l.out"))
+    err = p.stderr.decode()
+    got = aslp.Nnet.Read(tmp_path / "l.out").GetParams()
+    net = aslp.Nnet.Read(tmp_path / "l.init")
+    net.SetTrainOptions(learn_rate=lr, momentum=mom)
+    xent = aslp.Xent()
+    todo = list(range(n_utt))
+    cur, length, which, flags = [0] * S, [0] * S, [None] * S, [0] * S
+    x = lab = None
+    steps = num_done = 0
+    while True:
+        for s in range(S):
+            if cur[s] < length[s]:
+                flags[s] = 0
+                continue
+            if todo:
+                which[s] = todo.pop(0)
+                cur[s], length[s], flags[s] = 0, lens[which[s]], 1
+        done = all(cur[s] >= length[s] for s in range(S))
+        mask = np.zeros(B * S, np.float32)
+        if not done:
+            x = np.zeros((B * S, D), np.float32)
+            lab = np.zeros(B * S, np.int32)
+            for t in range(B):
+                for s in range(S):
+                    r, u = t * S + s, which[s]
+                    if cur[s] < length[s]:
+                        mask[r] = 1.0
+                        lab[r] = posts[u][cur[s]][0][0]
+                    else:
+                        lab[r] = posts[u][length[s] - 1][0][0]
+                    x[r] = feats[u][min(cur[s] + delay, length[s] - 1)]
+                    cur[s] += 1
+        net.ResetLstmStreams(flags)
+        y = net.Propagate(torch.from_numpy(x).to(dev))
+        diff = torch.empty_like(y)
+        xent.Eval(torch.from_numpy(mask).to(dev), y, diff, labels=torch.from_numpy(lab).to(dev))
+        net.Backpropagate(diff)
+        steps += 1
+        num_done += sum(flags)
+        if done and not todo:
+            break
+    assert steps > 6
+    assert np.array_equal(got, net.GetParams())
+    assert "Done %d files, [TRAINING, NOT-RANDOMIZED" % num_done in err
+    assert xent.Report().splitlines()[1] in err
