@@ -458,3 +458,46 @@ def test_lstm_streams_tool_matches_api(aslp, dev, tmp_path):
     assert np.array_equal(got, net.GetParams())
     assert "Done %d files, [TRAINING, NOT-RANDOMIZED" % num_done in err
     assert xent.Report().splitlines()[1] in err
+
+
+FSMN_PROTO = """<NnetProto>
+<AffineTransform> <InputDim> 12 <OutputDim> 32 <BiasMean> 0.0 <BiasRange> 0.0 <ParamStddev> 0.1
+<CompactFsmn> <InputDim> 32 <OutputDim> 32 <PastContext> 3 <FutureContext> 2 <LearnRateCoef> 1.0
+<Sigmoid> <InputDim> 32 <OutputDim> 32
+<AffineTransform> <InputDim> 32 <OutputDim> 10 <BiasMean> 0.0 <BiasRange> 0.0 <ParamStddev> 0.1
+<Softmax> <InputDim> 10 <OutputDim> 10
+</NnetProto>
+"""
+
+
+def test_perutt_tool_matches_api(aslp, dev, tmp_path):
+    """aslp-nnet-train-perutt (the FSMN recipes): one update per utterance with learn-rate / 1024."""
+    (tmp_path / "f.proto").write_text(FSMN_PROTO)
+    tool("aslp-nnet-init", "--seed=61", str(tmp_path / "f.proto"), str(tmp_path / "f.init"))
+    rng = np.random.default_rng(14)
+    n_utt, D, A = 6, 12, 10
+    keys = ["p%02d" % i for i in range(n_utt)]
+    lens = [int(x) for x in rng.integers(8, 40, n_utt)]
+    feats = [rng.standard_normal((n, D)).astype(np.float32) for n in lens]
+    posts = [[[(int(rng.integers(0, A)), 1.0)] for _ in range(n)] for n in lens]
+    (tmp_path / "feats.ark").write_bytes(kf.archive([(k, kf.matrix_bin(f)) for k, f in zip(keys, feats)]))
+    (tmp_path / "post.ark").write_bytes(kf.archive([(k, kf.posterior_bin(p)) for k, p in zip(keys, posts) if k != keys[3]]))
+    lr = 20.0
+    p = tool("aslp-nnet-train-perutt", "--learn-rate=%g" % lr, "--momentum=0.5", "--drop-len=38", "ark:%s" % (tmp_path / "feats.ark"),
+             "ark:%s" % (tmp_path / "post.ark"), str(tmp_path / "f.init"), str(tmp_path / "f.out"))
+    err = p.stderr.decode()
+    net = aslp.Nnet.Read(tmp_path / "f.init")
+    net.SetTrainOptions(learn_rate=np.float32(lr) / 1024.0, momentum=0.5)
+    xent = aslp.Xent()
+    done = 0
+    for i in range(n_utt):
+        if i == 3 or lens[i] > 38:
+            continue
+        lab = np.array([fr[0][0] for fr in posts[i]], np.int32)
+        y = net.Propagate(torch.from_numpy(feats[i]).to(dev))
+        diff = torch.empty_like(y)
+        xent.Eval(torch.ones(lens[i], device=dev), y, diff, labels=torch.from_numpy(lab).to(dev))
+        net.Backpropagate(diff)
+        done += 1
+    assert "Done %d files, 1 with no tgt_mats, 0 with other errors. [TRAINING, NOT-RANDOMIZED" % done in err
+    assert np.array_equal(aslp.Nnet.Read(tmp_path / "f.out").GetParams(), net.GetParams())
