@@ -501,3 +501,40 @@ def test_perutt_tool_matches_api(aslp, dev, tmp_path):
         done += 1
     assert "Done %d files, 1 with no tgt_mats, 0 with other errors. [TRAINING, NOT-RANDOMIZED" % done in err
     assert np.array_equal(aslp.Nnet.Read(tmp_path / "f.out").GetParams(), net.GetParams())
+
+
+def test_eesen_ctc_streams_tool_matches_api(aslp, dev, tmp_path):
+    """aslp-nnet-train-ctc-streams (Eesen Ctc on posteriors; what run_ctc_*.sh call), same grouping as the Warp-CTC tool."""
+    (tmp_path / "e.proto").write_text(CTC_PROTO.replace("</NnetProto>", "<Softmax> <InputDim> 9 <OutputDim> 9\n</NnetProto>"))
+    tool("aslp-nnet-init", "--seed=71", str(tmp_path / "e.proto"), str(tmp_path / "e.init"))
+    rng = np.random.default_rng(15)
+    n_utt, D, A, S = 7, 12, 9, 3
+    keys = ["e%02d" % i for i in range(n_utt)]
+    lens = [int(x) for x in rng.integers(12, 40, n_utt)]
+    feats = [rng.standard_normal((n, D)).astype(np.float32) for n in lens]
+    labels = [[int(x) for x in rng.integers(1, A, max(1, n // 5))] for n in lens]
+    (tmp_path / "feats.ark").write_bytes(kf.archive([(k, kf.matrix_bin(f)) for k, f in zip(keys, feats)]))
+    (tmp_path / "lab.ark").write_bytes(kf.archive([(k, kf.int32vec_bin(l)) for k, l in zip(keys, labels)]))
+    lr = 0.5
+    p = tool("aslp-nnet-train-ctc-streams", "--learn-rate=%g" % lr, "--momentum=0.9", "--num-stream=%d" % S, "ark:%s" % (tmp_path / "feats.ark"),
+             "ark:%s" % (tmp_path / "lab.ark"), str(tmp_path / "e.init"), str(tmp_path / "e.out"))
+    err = p.stderr.decode()
+    assert "Done 7 files, 0 with no targets, 0 with other errors. [TRAINING" in err and "TOKEN_ACCURACY" in err
+    net = aslp.Nnet.Read(tmp_path / "e.init")
+    ctc = aslp.Ctc()
+    todo = list(range(n_utt))
+    while todo:
+        grp, todo = todo[:S], todo[S:]
+        n, mx = len(grp), max(lens[i] for i in grp)
+        x = np.zeros((n * mx, D), np.float32)
+        for s, i in enumerate(grp):
+            x[np.arange(lens[i]) * n + s] = feats[i]
+        fn = [lens[i] for i in grp]
+        net.SetTrainOptions(learn_rate=np.float32(lr) / np.float32(sum(fn)), momentum=0.9)
+        net.SetSeqLengths(fn)
+        y = net.Propagate(torch.from_numpy(x).to(dev))
+        diff, _ = ctc.EvalParallel(fn, y, [labels[i] for i in grp])
+        ctc.ErrorRateMSeq(fn, y, [labels[i] for i in grp])
+        net.Backpropagate(diff)
+    assert np.array_equal(aslp.Nnet.Read(tmp_path / "e.out").GetParams(), net.GetParams())
+    assert ctc.Report().strip().splitlines()[-1] in err
