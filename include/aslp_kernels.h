@@ -187,6 +187,11 @@ void aslp_softmax_xent_eval(const float *acts, MatrixDim d, const float *tgt, in
 void aslp_scatter_add(float *mat, MatrixDim d, const int32_cuda *rows, const int32_cuda *cols, const float *vals, int n);
 /* Splice backward (nnet-various.h:143-175): in_diff[t] = sum_k out_diff[clamp(t+off[k])][k-th block] */
 void aslp_splice_backward(float *in_diff, MatrixDim d_in, const float *out_diff, int od_stride, const int32_cuda *off, int n_off);
+/* Dropout (nnet-activation.h:240-258) in one launch per pass: mask = [u < retention] with u from a counter-based
+ * generator keyed by (seed, element index); out = in * mask / retention; in_diff = out_diff * mask / retention. */
+void aslp_dropout_forward(float *out, int out_stride, const float *in, MatrixDim d, float *mask, int mask_stride, float retention,
+                          unsigned long long seed);
+void aslp_dropout_backward(float *in_diff, int id_stride, const float *out_diff, MatrixDim d, const float *mask, int mask_stride, float retention);
 /* ReLU backward: in_diff = heaviside(in) * out_diff (nnet-activation.h:292-297) */
 void aslp_diff_relu(float *in_diff, const float *in, const float *out_diff, MatrixDim d, int in_stride, int od_stride);
 /* ---- recurrent gate blocks, one launch per timestep (csrc/rnn_cells.hip) -------------------------

@@ -272,6 +272,38 @@ __global__ void axpy_kernel(float alpha, const float *x, float *y, int dim) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < dim; i += gridDim.x * blockDim.x) y[i] += alpha * x[i];
 }
 
+// ---- Dropout (nnet-activation.h:240-258) ---------------------------------------------------------------------
+// mask(r, c) = [u(r, c) < retention], u from a counter-based generator (one 64-bit mix of (seed, element index): no state
+// to carry, any launch geometry gives the same mask); out = in * mask / retention.  The reference draws its mask from
+// CuRand (five launches); the masks are different random streams, the distribution is the same.
+__device__ __forceinline__ float dropout_uniform(unsigned long long seed, unsigned long long idx) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);  // splitmix64
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (float)(z >> 40) * (1.0f / 16777216.0f);  // 24 bits -> [0, 1)
+}
+__global__ void dropout_fwd_kernel(float *out, int ldo, const float *in, int ldi, float *mask, int ldm, int rows, int cols, float retention,
+                                   unsigned long long seed) {
+  const long n = (long)rows * cols;
+  const float inv = 1.0f / retention;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cols), c = (int)(i - (long)r * cols);
+    const float m = dropout_uniform(seed, (unsigned long long)i) < retention ? 1.0f : 0.0f;
+    mask[(long)r * ldm + c] = m;
+    out[(long)r * ldo + c] = in[(long)r * ldi + c] * m * inv;
+  }
+}
+__global__ void dropout_bwd_kernel(float *in_diff, int ldid, const float *od, int ldod, const float *mask, int ldm, int rows, int cols,
+                                   float retention) {
+  const long n = (long)rows * cols;
+  const float inv = 1.0f / retention;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cols), c = (int)(i - (long)r * cols);
+    in_diff[(long)r * ldid + c] = od[(long)r * ldod + c] * mask[(long)r * ldm + c] * inv;
+  }
+}
+
 }  // namespace
 }  // namespace aslp
 
@@ -414,6 +446,19 @@ void aslp_vec_axpy2(float alpha, const float *x1, float *y1, const float *x2, fl
   if (dim <= 0) return;
   hipLaunchKernelGGL(axpy2_kernel, dim3(grid_for(dim)), dim3(kBlock), 0, cur_stream(), alpha, x1, y1, x2, y2, dim);
   check_launch("axpy2");
+}
+void aslp_dropout_forward(float *out, int out_stride, const float *in, MatrixDim d, float *mask, int mask_stride, float retention,
+                          unsigned long long seed) {
+  if (d.rows <= 0 || d.cols <= 0) return;
+  hipLaunchKernelGGL(dropout_fwd_kernel, dim3(grid_for((long)d.rows * d.cols)), dim3(kBlock), 0, cur_stream(), out, out_stride, in, d.stride, mask,
+                     mask_stride, d.rows, d.cols, retention, seed);
+  check_launch("dropout_forward");
+}
+void aslp_dropout_backward(float *in_diff, int id_stride, const float *out_diff, MatrixDim d, const float *mask, int mask_stride, float retention) {
+  if (d.rows <= 0 || d.cols <= 0) return;
+  hipLaunchKernelGGL(dropout_bwd_kernel, dim3(grid_for((long)d.rows * d.cols)), dim3(kBlock), 0, cur_stream(), in_diff, id_stride, out_diff, d.stride,
+                     mask, mask_stride, d.rows, d.cols, retention);
+  check_launch("dropout_backward");
 }
 void aslp_vec_axpy(float alpha, const float *x, float *y, int dim) {
   if (dim <= 0) return;

@@ -248,6 +248,57 @@ class Tanh : public Component {
   void PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) { out->Tanh(in); }
   void BackpropagateFnc(const CuMatrixBase &, const CuMatrixBase &out, const CuMatrixBase &od, CuMatrixBase *id) { id->DiffTanh(out, od); }
 };
+class Dropout : public Component {  // nnet-activation.h:203-273
+ public:
+  Dropout(int32 di, int32 dout) : Component(di, dout), dropout_retention_(0.5), calls_(0) {}
+  Component *Copy() const { return new Dropout(*this); }
+  ComponentType GetType() const { return kDropout; }
+  void InitData(std::istream &is) {
+    is >> std::ws;
+    std::string token;
+    while (!is.eof()) {
+      ReadToken(is, false, &token);
+      if (token == "<DropoutRetention>") ReadBasicType(is, false, &dropout_retention_);
+      else ASLP_ERR << "Unknown token " << token << ", a typo in config?" << " (DropoutRetention)";
+      is >> std::ws;
+    }
+    ASLP_ASSERT(dropout_retention_ > 0.0 && dropout_retention_ <= 1.0);
+  }
+  void ReadData(std::istream &is, bool binary) {
+    if ('<' == Peek(is, binary)) {
+      ExpectToken(is, binary, "<DropoutRetention>");
+      ReadBasicType(is, binary, &dropout_retention_);
+    }
+    ASLP_ASSERT(dropout_retention_ > 0.0 && dropout_retention_ <= 1.0);
+  }
+  void WriteData(std::ostream &os, bool binary) const {
+    WriteToken(os, binary, "<DropoutRetention>");
+    WriteBasicType(os, binary, dropout_retention_);
+  }
+  void PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) {
+    if (dropout_mask_.NumRows() != in.NumRows() || dropout_mask_.NumCols() != in.NumCols()) dropout_mask_.Resize(in.NumRows(), in.NumCols(), kUndefined);
+    // a fresh mask per call: the key is drawn from the engine's seeded generator once, then advanced by the call count
+    if (calls_ == 0) seed_ = ((unsigned long long)(unsigned)Rand() << 32) ^ (unsigned)Rand();
+    aslp_dropout_forward(out->Data(), out->Stride(), in.Data(), in.Dim(), dropout_mask_.Data(), dropout_mask_.Stride(), dropout_retention_,
+                         seed_ + 0xD1B54A32D192ED03ull * calls_);
+    calls_++;
+  }
+  void BackpropagateFnc(const CuMatrixBase &, const CuMatrixBase &, const CuMatrixBase &od, CuMatrixBase *id) {
+    ASLP_ASSERT(SameDim(od, dropout_mask_));
+    aslp_dropout_backward(id->Data(), id->Stride(), od.Data(), od.Dim(), dropout_mask_.Data(), dropout_mask_.Stride(), dropout_retention_);
+  }
+  BaseFloat GetDropoutRetention() const { return dropout_retention_; }
+  void SetDropoutRetention(BaseFloat dr) {
+    dropout_retention_ = dr;
+    ASLP_ASSERT(dropout_retention_ > 0.0 && dropout_retention_ <= 1.0);
+  }
+  const CuMatrixBase &Mask() const { return dropout_mask_; }
+
+ private:
+  CuMatrix dropout_mask_;
+  BaseFloat dropout_retention_;
+  unsigned long long seed_ = 0, calls_;
+};
 class ReLU : public Component {  // :281-298
  public:
   ReLU(int32 di, int32 dout) : Component(di, dout) {}

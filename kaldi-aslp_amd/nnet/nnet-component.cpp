@@ -79,6 +79,7 @@ Component *Component::NewComponentOfType(ComponentType comp_type, int32 input_di
     case kSigmoid: ans = new Sigmoid(input_dim, output_dim); break;
     case kTanh: ans = new Tanh(input_dim, output_dim); break;
     case kReLU: ans = new ReLU(input_dim, output_dim); break;
+    case kDropout: ans = new Dropout(input_dim, output_dim); break;
     case kSplice: ans = new Splice(input_dim, output_dim); break;
     case kCopy: ans = new CopyComponent(input_dim, output_dim); break;
     case kAddShift: ans = new AddShift(input_dim, output_dim); break;

@@ -116,6 +116,16 @@ bool Nnet::IsFinalSoftmax(int32 i) const {
   return num_consumers_[i] == 1 && num_consumers_[o] == 0 && components_[o]->GetType() == Component::kOutputLayer && IsDirectLink(o) &&
          components_[o]->GetInput()[0] == i;
 }
+void Nnet::SetDropoutRetention(BaseFloat r) {  // nnet-nnet.cc:454-464
+  for (int32 c = 0; c < NumComponents(); c++) {
+    if (GetComponent(c).GetType() == Component::kDropout) {
+      Dropout &comp = dynamic_cast<Dropout &>(GetComponent(c));
+      BaseFloat r_old = comp.GetDropoutRetention();
+      comp.SetDropoutRetention(r);
+      ASLP_LOG << "Setting dropout-retention in component " << c << " from " << r_old << " to " << r;
+    }
+  }
+}
 void Nnet::PropagateForLoss(const CuMatrixBase &in, bool fold_softmax) {
   ASLP_ASSERT(input_.size() == 1 && output_.size() == 1);
   std::vector<const CuMatrixBase *> in_vec(1, &in);

@@ -51,9 +51,7 @@ class Nnet {
   void ResetLstmStreams(const std::vector<int32> &stream_reset_flag);
   void SetSeqLengths(const std::vector<int32> &sequence_lengths);
   void SetChunkSize(int chunk_size);
-  // nnet-nnet.cc:454-464.  This engine has no <Dropout> component (Read rejects the marker), so there is nothing to set;
-  // kept so that the tools' --dropout-retention plumbing reads like the reference's.
-  void SetDropoutRetention(BaseFloat) {}
+  void SetDropoutRetention(BaseFloat r);  // nnet-nnet.cc:454-464
 
   void Init(const std::string &config_file);
   void InitFromString(const std::string &proto_text);  // same grammar, from memory

@@ -255,3 +255,33 @@ def test_softmax_fold_and_update_overlap_are_bit_identical(aslp, oracle, dev, tm
     assert s0 == s1
     with pytest.raises(RuntimeError):
         nets[0].ComponentOutput(nets[0].NumComponents() - 1, mb, out_dim)
+
+
+def test_dropout_component(aslp, dev, tmp_path):
+    """<Dropout> (nnet-activation.h:203-273): out = in * mask / retention with mask ~ Bernoulli(retention), the same mask in
+    the backward pass, a fresh one per Propagate; retention 1 is the identity; the retention survives a write / read."""
+    D, N, r = 64, 4096, 0.6
+    proto = "<NnetProto>\n<Dropout> <InputDim> %d <OutputDim> %d <DropoutRetention> %g\n</NnetProto>\n" % (D, D, r)
+    net = aslp.Nnet.Init(proto, seed=3)
+    x = torch.randn(N, D, device=dev) + 3.0          # keep away from 0 so that a zero output means "dropped"
+    y = net.Propagate(x)
+    kept = (y != 0)
+    frac = kept.float().mean().item()
+    assert abs(frac - r) < 4 * np.sqrt(r * (1 - r) / (N * D))
+    assert torch.equal(y[kept], (x * (1.0 / np.float32(r)))[kept]) or torch.allclose(y[kept], x[kept] / r, rtol=1e-6)
+    od = torch.randn(N, D, device=dev)
+    idiff = net.Backpropagate(od, want_in_diff=True)
+    assert torch.equal(idiff != 0, kept & (od != 0))
+    assert torch.allclose(idiff[kept], od[kept] / r, rtol=1e-6)
+    y2 = net.Propagate(x)
+    assert not torch.equal(y2 != 0, kept)             # a new mask every call
+    # columns and rows are all hit (no stripe pattern from the index hash)
+    assert kept.float().mean(0).min() > r - 0.1 and kept.float().mean(1).min() > r - 0.35
+    path = tmp_path / "d.nnet"
+    net.Write(path, binary=False)
+    assert "<DropoutRetention> 0.6" in open(path).read()
+    net2 = aslp.Nnet.Read(path)
+    assert net2.NumComponents() == net.NumComponents()
+    one = aslp.Nnet.Init(proto.replace("%g" % r, "1.0"), seed=3)
+    assert torch.equal(one.Propagate(x), x)
+    assert torch.equal(one.Backpropagate(od, want_in_diff=True), od)
