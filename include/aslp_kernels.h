@@ -227,6 +227,13 @@ typedef struct aslp_lstm_step_ {
 void aslp_lstm_step_forward(const aslp_lstm_step *a);
 void aslp_lstm_step_backward(const aslp_lstm_step *a);
 /* GruStreams (nnet-gru-streams.h:275-303, 344-383), columns [z|r|m|g|h] */
+/* GRU recurrence, one timestep, both dependent products fused with their gate arithmetic (csrc/gru_fused.hip):
+ * forward = aslp_gru_forward1/2 with the two skinny GEMMs folded in; backward likewise, reading TRANSPOSED copies of the
+ * recurrent matrices (w_zr_h_t [H x 2H], w_m_g_t [H x H]).  Needs H % 4 == 0 and 16-byte aligned, 4-float-pitched rows. */
+int aslp_gru_step_supported(int H);
+void aslp_gru_step_forward(float *y_cur, const float *y_prev, const float *w_zr_h, int ld_zr, const float *w_m_g, int ld_mg, int ld, int S, int H);
+void aslp_gru_step_backward(float *d_cur, const float *d_next, const float *y_cur, const float *y_next, const float *y_prev, const float *w_zr_h_t,
+                            int ld_zr_t, const float *w_m_g_t, int ld_mg_t, int ld, int S, int H, int has_next);
 void aslp_gru_forward1(float *y_cur, const float *y_prev, int ld, int S, int H);
 void aslp_gru_forward2(float *y_cur, const float *y_prev, int ld, int S, int H);
 void aslp_gru_backward1(float *d_cur, const float *d_next, const float *y_cur, const float *y_next, int ld, int S, int H);

@@ -580,7 +580,11 @@ void GruStreams::PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) {  // :
     zrm.AddMatMat(1.0, in, kNoTrans, w_zrm_x_, kTrans, 0.0, &ep);
   }
   const int ld = buf_.Stride();
-  for (int t = 1; t <= T; t++) {
+  static const bool unfused = getenv("ASLP_LSTM_UNFUSED") != nullptr && getenv("ASLP_LSTM_UNFUSED")[0] == '1';
+  const bool fused = !unfused && aslp_gru_step_supported(H);
+  for (int t = 1; t <= T && fused; t++)
+    aslp_gru_step_forward(buf_.RowData(t * S), buf_.RowData((t - 1) * S), w_zr_h_.Data(), w_zr_h_.Stride(), w_m_g_.Data(), w_m_g_.Stride(), ld, S, H);
+  for (int t = 1; t <= T && !fused; t++) {
     CuSubMatrix y_zr(buf_, t * S, S, 0, 2 * H), h_prev(buf_, (t - 1) * S, S, 4 * H, H);
     y_zr.AddMatMat(1.0, h_prev, kNoTrans, w_zr_h_, kTrans, 1.0);
     aslp_gru_forward1(buf_.RowData(t * S), buf_.RowData((t - 1) * S), ld, S, H);
@@ -600,7 +604,19 @@ void GruStreams::BackpropagateFnc(const CuMatrixBase &in, const CuMatrixBase &, 
   dbuf_.Resize((T + 2) * S, 5 * H, kSetZero);
   CuSubMatrix(dbuf_, S, T * S, 4 * H, H).CopyFromMat(out_diff);
   const int ld = dbuf_.Stride();
-  for (int t = T; t >= 1; t--) {
+  static const bool unfused = getenv("ASLP_LSTM_UNFUSED") != nullptr && getenv("ASLP_LSTM_UNFUSED")[0] == '1';
+  const bool fused = !unfused && aslp_gru_step_supported(H);
+  if (fused) {  // the backward products read W (not W^T): keep K-contiguous transposed copies, refreshed here once per call
+    if (w_zr_h_t_.NumRows() != H) { w_zr_h_t_.Resize(H, 2 * H, kUndefined); w_m_g_t_.Resize(H, H, kUndefined); }
+    w_zr_h_t_.SetZero();
+    w_zr_h_t_.AddMat(1.0, w_zr_h_, kTrans);
+    w_m_g_t_.SetZero();
+    w_m_g_t_.AddMat(1.0, w_m_g_, kTrans);
+    for (int t = T; t >= 1; t--)
+      aslp_gru_step_backward(dbuf_.RowData(t * S), dbuf_.RowData((t + 1) * S), buf_.RowData(t * S), buf_.RowData((t + 1) * S),
+                             buf_.RowData((t - 1) * S), w_zr_h_t_.Data(), w_zr_h_t_.Stride(), w_m_g_t_.Data(), w_m_g_t_.Stride(), ld, S, H, t < T);
+  }
+  for (int t = T; t >= 1 && !fused; t--) {
     if (t < T) {
       CuSubMatrix d_h(dbuf_, t * S, S, 4 * H, H), dn_zr(dbuf_, (t + 1) * S, S, 0, 2 * H);
       d_h.AddMatMat(1.0, dn_zr, kNoTrans, w_zr_h_, kNoTrans, 1.0);

@@ -169,6 +169,7 @@ class GruStreams : public RecurrentBase {
   CuMatrix prev_state_, w_zrm_x_, w_zr_h_, w_m_g_, w_zrm_x_corr_, w_zr_h_corr_, w_m_g_corr_;
   CuVector bias_, bias_corr_;
   CuMatrix buf_, dbuf_;
+  CuMatrix w_zr_h_t_, w_m_g_t_;  // transposed recurrent matrices for the fused backward step
 };
 
 }  // namespace aslp
