@@ -158,6 +158,7 @@ class FrameDataReader {
   void FillRandomizer() {  // data-reader.cc:66-128
     Timer fill_timer;
     double t_wait = 0.0;
+    int32 added = 0;
     RecycleBlocks();
     while (true) {
       if (feature_randomizer_.IsFull()) break;
@@ -187,13 +188,16 @@ class FrameDataReader {
       in_flight_.push_back(std::make_pair(item.block, std::move(marker)));
       targets_randomizer_.AddData(item.targets);
       num_done_++;
+      added++;
     }
     CuDevice::Instantiate().AccuProfile("FrameDataReader: waiting for the reader thread", t_wait);
     CuDevice::Instantiate().AccuProfile("FrameDataReader::FillRandomizer (host, total)", fill_timer.Elapsed());
     // the reference always shuffles here (its --randomize flag is only echoed in the log, aslp-nnet-train-frame.cc:41,136);
     // `randomize_ == false` keeps the frame order (identity mask) for the tools that expose a working switch
     const int32 n = feature_randomizer_.NumFrames();
-    if (n == 0) return;
+    // Nothing new arrived (the previous fill stopped on "cache full" exactly at the last utterance): what is left is less
+    // than a minibatch and is dropped.  The reference shuffles here regardless and dies on its own data_begin_ == 0 check.
+    if (n == 0 || added == 0) return;
     if (randomize_) {
       const std::vector<int32> &mask = randomizer_mask_.Generate(n);
       feature_randomizer_.Randomize(mask);

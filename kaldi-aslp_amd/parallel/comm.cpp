@@ -1,0 +1,198 @@
+// comm.cpp -- see comm.h.
+#include "comm.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <thread>
+
+#include "aslp_kernels.h"
+#include "common.h"
+
+namespace aslp {
+
+static void Hip(hipError_t e, const char *what) { if (e != hipSuccess) ASLP_ERR << what << ": " << hipGetErrorString(e); }
+static void Nccl(ncclResult_t r, const char *what) { if (r != ncclSuccess) ASLP_ERR << what << ": " << ncclGetErrorString(r); }
+
+void RankFromEnvironment(int *rank, int *num_nodes) {
+  const char *rk[] = {"OMPI_COMM_WORLD_RANK", "PMI_RANK", "RANK"}, *sz[] = {"OMPI_COMM_WORLD_SIZE", "PMI_SIZE", "WORLD_SIZE"};
+  if (*rank < 0)
+    for (const char *k : rk) if (getenv(k)) { *rank = atoi(getenv(k)); break; }
+  if (*num_nodes <= 0)
+    for (const char *k : sz) if (getenv(k)) { *num_nodes = atoi(getenv(k)); break; }
+  if (*rank < 0) *rank = 0;
+  if (*num_nodes <= 0) *num_nodes = 1;
+  if (*rank >= *num_nodes) ASLP_ERR << "rank " << *rank << " outside a group of " << *num_nodes;
+}
+
+// ---- RCCL ---------------------------------------------------------------------------------------------------
+namespace {
+class RcclComm : public Comm {
+ public:
+  RcclComm(int rank, int n, const std::string &id_file, int timeout_s) : rank_(rank), n_(n), comm_(nullptr), scratch_(nullptr), scratch_bytes_(0) {
+    ncclUniqueId id;
+    if (n > 1 && id_file.empty()) ASLP_ERR << "RcclComm: more than one rank needs a rendezvous file (--comm-file)";
+    if (rank == 0) {
+      Nccl(ncclGetUniqueId(&id), "ncclGetUniqueId");
+      if (n > 1) {
+        const std::string tmp = id_file + ".tmp." + std::to_string((long)getpid());
+        { std::ofstream f(tmp, std::ios::binary); f.write(reinterpret_cast<const char *>(&id), sizeof(id)); if (!f.good()) ASLP_ERR << "cannot write " << tmp; }
+        if (std::rename(tmp.c_str(), id_file.c_str()) != 0) ASLP_ERR << "cannot create " << id_file;
+      }
+    } else {
+      const auto t0 = std::chrono::steady_clock::now();
+      while (true) {
+        std::ifstream f(id_file, std::ios::binary);
+        if (f.good()) { f.read(reinterpret_cast<char *>(&id), sizeof(id)); if (f.gcount() == (std::streamsize)sizeof(id)) break; }
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
+          ASLP_ERR << "RcclComm: rank " << rank << " timed out waiting for " << id_file;
+        std::this_thread::sleep_for(std::chrono::milliseconds(50));
+      }
+    }
+    Nccl(ncclCommInitRank(&comm_, n, id, rank), "ncclCommInitRank");
+    Barrier();
+    if (rank == 0 && n > 1) std::remove(id_file.c_str());  // everybody has joined: the next run writes a fresh id
+  }
+  ~RcclComm() {
+    if (scratch_) (void)hipFree(scratch_);
+    if (comm_) (void)ncclCommDestroy(comm_);
+  }
+  int Rank() const { return rank_; }
+  int NumNodes() const { return n_; }
+  void Barrier() {
+    int32 one = 1;
+    AllReduceSumHost(&one, 1);
+  }
+  void AllReduceSum(float *dev, size_t n) {
+    if (n_ > 1 && n) Nccl(ncclAllReduce(dev, dev, n, ncclFloat, ncclSum, comm_, cur_stream()), "ncclAllReduce(float)");
+  }
+  void AllReduceSum(double *dev, size_t n) {
+    if (n_ > 1 && n) Nccl(ncclAllReduce(dev, dev, n, ncclDouble, ncclSum, comm_, cur_stream()), "ncclAllReduce(double)");
+  }
+  void AllReduceSumMany(const std::vector<std::pair<float *, int>> &bufs) {
+    if (n_ <= 1) return;
+    Nccl(ncclGroupStart(), "ncclGroupStart");
+    for (auto &b : bufs)
+      if (b.second > 0) Nccl(ncclAllReduce(b.first, b.first, (size_t)b.second, ncclFloat, ncclSum, comm_, cur_stream()), "ncclAllReduce(float)");
+    Nccl(ncclGroupEnd(), "ncclGroupEnd");
+  }
+  void AllReduceSumHost(int32 *host, size_t n) { HostReduce(host, n, ncclInt32); }
+  void AllReduceSumHost(double *host, size_t n) { HostReduce(host, n, ncclDouble); }
+
+ private:
+  template <class T>
+  void HostReduce(T *host, size_t n, ncclDataType_t type) {
+    if (n_ <= 1 || !n) return;
+    const size_t bytes = sizeof(T) * n;
+    if (bytes > scratch_bytes_) {
+      if (scratch_) Hip(hipFree(scratch_), "hipFree");
+      Hip(hipMalloc(&scratch_, bytes < 256 ? 256 : bytes), "hipMalloc");
+      scratch_bytes_ = bytes < 256 ? 256 : bytes;
+    }
+    Hip(hipMemcpyAsync(scratch_, host, bytes, hipMemcpyHostToDevice, cur_stream()), "hipMemcpy H2D");
+    Nccl(ncclAllReduce(scratch_, scratch_, n, type, ncclSum, comm_, cur_stream()), "ncclAllReduce(host value)");
+    Hip(hipMemcpyAsync(host, scratch_, bytes, hipMemcpyDeviceToHost, cur_stream()), "hipMemcpy D2H");
+    Hip(hipStreamSynchronize(cur_stream()), "hipStreamSynchronize");
+  }
+  int rank_, n_;
+  ncclComm_t comm_;
+  void *scratch_;
+  size_t scratch_bytes_;
+};
+}  // namespace
+
+Comm *NewRcclComm(int rank, int num_nodes, const std::string &id_file, int timeout_s) { return new RcclComm(rank, num_nodes, id_file, timeout_s); }
+
+// ---- threads of one process ---------------------------------------------------------------------------------------
+class ThreadCommGroup {
+ public:
+  explicit ThreadCommGroup(int n) : n(n), arrived(0), generation(0), ptrs(n, nullptr), hostsum_i(0), hostsum_d(0.0), tmp(nullptr), tmp_bytes(0) {}
+  ~ThreadCommGroup() { if (tmp) (void)hipFree(tmp); }
+  void Barrier() {
+    std::unique_lock<std::mutex> lk(mu);
+    const long gen = generation;
+    if (++arrived == n) { arrived = 0; generation++; cv.notify_all(); }
+    else cv.wait(lk, [&] { return generation != gen; });
+  }
+  int n, arrived;
+  long generation;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<void *> ptrs;
+  std::vector<int32> host_i;
+  std::vector<double> host_d;
+  long long hostsum_i;
+  double hostsum_d;
+  void *tmp;
+  size_t tmp_bytes;
+};
+std::shared_ptr<ThreadCommGroup> NewThreadCommGroup(int n) { return std::make_shared<ThreadCommGroup>(n); }
+
+namespace {
+__global__ void add_kernel_f(float *dst, const float *src, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] += src[i];
+}
+__global__ void add_kernel_d(double *dst, const double *src, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] += src[i];
+}
+class ThreadComm : public Comm {
+ public:
+  ThreadComm(std::shared_ptr<ThreadCommGroup> g, int rank) : g_(g), rank_(rank) {}
+  int Rank() const { return rank_; }
+  int NumNodes() const { return g_->n; }
+  void Barrier() { g_->Barrier(); }
+  void AllReduceSum(float *dev, size_t n) { Reduce(dev, n); }
+  void AllReduceSum(double *dev, size_t n) { Reduce(dev, n); }
+  void AllReduceSumHost(int32 *host, size_t n) { HostReduce(host, n, &g_->host_i); }
+  void AllReduceSumHost(double *host, size_t n) { HostReduce(host, n, &g_->host_d); }
+
+ private:
+  template <class T>
+  void HostReduce(T *host, size_t n, std::vector<T> *acc) {
+    {
+      std::lock_guard<std::mutex> lk(g_->mu);
+      if (acc->size() != n) acc->assign(n, T(0));
+    }
+    g_->Barrier();
+    {
+      std::lock_guard<std::mutex> lk(g_->mu);
+      for (size_t i = 0; i < n; i++) (*acc)[i] += host[i];
+    }
+    g_->Barrier();
+    for (size_t i = 0; i < n; i++) host[i] = (*acc)[i];
+    g_->Barrier();
+    if (rank_ == 0) { std::lock_guard<std::mutex> lk(g_->mu); acc->clear(); }
+    g_->Barrier();
+  }
+  static void Add(float *d, const float *s, size_t n) { hipLaunchKernelGGL(add_kernel_f, dim3(256), dim3(256), 0, cur_stream(), d, s, n); }
+  static void Add(double *d, const double *s, size_t n) { hipLaunchKernelGGL(add_kernel_d, dim3(256), dim3(256), 0, cur_stream(), d, s, n); }
+  template <class T>
+  void Reduce(T *dev, size_t n) {
+    if (!n) return;
+    Hip(hipStreamSynchronize(cur_stream()), "hipStreamSynchronize");  // this rank's buffer is final
+    g_->ptrs[rank_] = dev;
+    g_->Barrier();
+    if (rank_ == 0) {  // sum in rank order into a temporary
+      const size_t bytes = sizeof(T) * n;
+      if (bytes > g_->tmp_bytes) { if (g_->tmp) Hip(hipFree(g_->tmp), "hipFree"); Hip(hipMalloc(&g_->tmp, bytes), "hipMalloc"); g_->tmp_bytes = bytes; }
+      Hip(hipMemcpyAsync(g_->tmp, g_->ptrs[0], bytes, hipMemcpyDeviceToDevice, cur_stream()), "hipMemcpy D2D");
+      for (int r = 1; r < g_->n; r++) Add(static_cast<T *>(g_->tmp), static_cast<const T *>(g_->ptrs[r]), n);
+      Hip(hipStreamSynchronize(cur_stream()), "hipStreamSynchronize");
+    }
+    g_->Barrier();
+    Hip(hipMemcpyAsync(dev, g_->tmp, sizeof(T) * n, hipMemcpyDeviceToDevice, cur_stream()), "hipMemcpy D2D");
+    Hip(hipStreamSynchronize(cur_stream()), "hipStreamSynchronize");
+    g_->Barrier();
+  }
+  std::shared_ptr<ThreadCommGroup> g_;
+  int rank_;
+};
+}  // namespace
+Comm *NewThreadComm(std::shared_ptr<ThreadCommGroup> group, int rank) { return new ThreadComm(group, rank); }
+
+}  // namespace aslp

@@ -1,0 +1,46 @@
+// comm.h -- the communicator under the model-sync workers: what MpiNode (src/aslp-parallel/mpi-node.h:19-97) provides
+// to them -- rank, size, barrier, sum all-reduce -- with the parameter buffers staying in HBM.
+//   RcclComm    one process per GPU, RCCL over xGMI (ncclAllReduce on device pointers, no host staging).  No MPI in the
+//               launch path: ranks find each other through a file that rank 0 writes the ncclUniqueId into.
+//   ThreadComm  N ranks as threads of ONE process on one GPU -- the harness the worker arithmetic is tested with on a
+//               single-GPU box (RCCL refuses two ranks on one device).
+#pragma once
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "base.h"
+
+namespace aslp {
+
+class Comm {
+ public:
+  virtual ~Comm() {}
+  virtual int Rank() const = 0;
+  virtual int NumNodes() const = 0;
+  virtual void Barrier() = 0;
+  virtual void AllReduceSum(float *dev, size_t n) = 0;        // in place, device memory
+  virtual void AllReduceSum(double *dev, size_t n) = 0;       // in place, device memory
+  virtual void AllReduceSumHost(int32 *host, size_t n) = 0;   // small host-side counts
+  virtual void AllReduceSumHost(double *host, size_t n) = 0;
+  // several device buffers in one grouped operation
+  virtual void AllReduceSumMany(const std::vector<std::pair<float *, int>> &bufs) {
+    for (auto &b : bufs) AllReduceSum(b.first, (size_t)b.second);
+  }
+};
+
+// rank / world size of this process: --rank / --num-workers style explicit values win (>= 0), then the launcher's
+// environment (OMPI_COMM_WORLD_*, PMI_*, RANK / WORLD_SIZE), else a single rank
+void RankFromEnvironment(int *rank, int *num_nodes);
+
+// id_file: rendezvous file; rank 0 creates it (atomically), the others wait for it (up to timeout_s)
+Comm *NewRcclComm(int rank, int num_nodes, const std::string &id_file, int timeout_s = 300);
+
+class ThreadCommGroup;
+// one group, then one Comm per thread
+std::shared_ptr<ThreadCommGroup> NewThreadCommGroup(int num_nodes);
+Comm *NewThreadComm(std::shared_ptr<ThreadCommGroup> group, int rank);
+
+}  // namespace aslp

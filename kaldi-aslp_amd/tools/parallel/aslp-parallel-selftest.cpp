@@ -1,0 +1,84 @@
+// aslp-parallel-selftest -- runs BspWorker / BmufWorker with N ranks as threads of this process (ThreadComm) on raw device
+// buffers and prints every rank's parameters after each synchronisation, one line per (step, rank): the GPU test compares
+// them with the closed forms of bsp-worker.cc:33-65 / bmuf-worker.cc:37-68 computed in numpy.
+// Usage: aslp-parallel-selftest <bsp|bmuf> <num-ranks> <dim> <steps> [bmuf-lr bmuf-momentum]
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
+
+#include "common.h"
+#include "workers.h"
+
+using namespace aslp;
+
+int main(int argc, char **argv) {
+  if (argc < 5) { std::fprintf(stderr, "usage: %s <bsp|bmuf> <num-ranks> <dim> <steps> [lr momentum]\n", argv[0]); return 1; }
+  const std::string type = argv[1];
+  const int N = atoi(argv[2]), dim = atoi(argv[3]), steps = atoi(argv[4]);
+  const float lr = argc > 5 ? atof(argv[5]) : 1.0f, mom = argc > 6 ? atof(argv[6]) : 0.9f;
+  auto group = NewThreadCommGroup(N);
+  std::vector<std::vector<float>> out((size_t)N * (steps + 1));
+  std::vector<std::string> errors(N);
+  std::vector<std::thread> th;
+  for (int r = 0; r < N; r++) {
+    th.emplace_back([&, r] {
+      try {
+        hipStream_t st;
+        if (hipStreamCreate(&st) != hipSuccess) throw std::runtime_error("hipStreamCreate");
+        set_cur_stream(st);
+        std::unique_ptr<Comm> comm(NewThreadComm(group, r));
+        // two tensors (dim and dim / 2 + 1 floats): w[i] = rank + 1 + 0.01 i at the start
+        const int n1 = dim, n2 = dim / 2 + 1;
+        std::vector<float> h(n1 + n2);
+        for (int i = 0; i < n1 + n2; i++) h[i] = r + 1 + 0.01f * i;
+        float *d = nullptr;
+        if (hipMalloc(&d, sizeof(float) * (n1 + n2)) != hipSuccess) throw std::runtime_error("hipMalloc");
+        (void)hipMemcpyAsync(d, h.data(), sizeof(float) * h.size(), hipMemcpyHostToDevice, st);
+        std::vector<std::pair<float *, int>> params = {{d, n1}, {d + n1, n2}};
+        std::unique_ptr<IWorker> w;
+        if (type == "bsp") w.reset(new BspWorker(comm.get()));
+        else w.reset(new BmufWorker(comm.get(), lr, mom));
+        w->InitParam(params);
+        for (int s = 0; s <= steps; s++) {
+          // "training": every rank moves its model by a rank- and step-dependent amount, then synchronises with a
+          // rank-dependent sample count; rank r runs out of data after steps - r steps and calls Stop()
+          const bool has_data = s < steps - r;
+          if (has_data) {
+            (void)hipMemcpyAsync(h.data(), d, sizeof(float) * h.size(), hipMemcpyDeviceToHost, st);
+            (void)hipStreamSynchronize(st);
+            for (size_t i = 0; i < h.size(); i++) h[i] += 0.5f * (r + 1) + 0.25f * s;
+            (void)hipMemcpyAsync(d, h.data(), sizeof(float) * h.size(), hipMemcpyHostToDevice, st);
+            if (!w->Synchronize(100 * (r + 1) + s)) throw std::runtime_error("Synchronize returned false while data remains");
+          } else {
+            w->Stop();
+            break;
+          }
+          (void)hipMemcpyAsync(h.data(), d, sizeof(float) * h.size(), hipMemcpyDeviceToHost, st);
+          (void)hipStreamSynchronize(st);
+          out[(size_t)s * N + r] = h;
+        }
+        (void)hipMemcpyAsync(h.data(), d, sizeof(float) * h.size(), hipMemcpyDeviceToHost, st);
+        (void)hipStreamSynchronize(st);
+        out[(size_t)steps * N + r] = h;  // the final model of this rank
+        w.reset();
+        (void)hipFree(d);
+      } catch (const std::exception &e) {
+        errors[r] = e.what();
+      }
+    });
+  }
+  for (auto &t : th) t.join();
+  for (int r = 0; r < N; r++)
+    if (!errors[r].empty()) { std::fprintf(stderr, "rank %d: %s\n", r, errors[r].c_str()); return 2; }
+  for (int s = 0; s <= steps; s++)
+    for (int r = 0; r < N; r++) {
+      const auto &v = out[(size_t)s * N + r];
+      if (v.empty()) continue;
+      std::printf("%d %d", s, r);
+      for (float x : v) std::printf(" %.9g", x);
+      std::printf("\n");
+    }
+  return 0;
+}

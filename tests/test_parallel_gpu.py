@@ -1,0 +1,101 @@
+"""Native model-sync workers (kaldi-aslp_amd/parallel: BspWorker / BmufWorker on a Comm).  A one-GPU box cannot host two
+RCCL ranks, so the arithmetic and the protocol (sample-count all-reduce first, finished workers keep joining with 0
+samples, a global count of 0 ends the run) are exercised with N ranks as threads of one process (ThreadComm) against the
+closed forms of bsp-worker.cc:33-65 / bmuf-worker.cc:37-68; the RCCL path is exercised with a group of one."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import kaldi_formats as kf
+from test_tools_gpu import tool, write_corpus
+from test_nnet_gpu import make_dnn
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+def run_selftest(kind, n, dim, steps, *extra):
+    p = tool("aslp-parallel-selftest", kind, str(n), str(dim), str(steps), *[str(e) for e in extra])
+    out = {}
+    for line in p.stdout.decode().splitlines():
+        f = line.split()
+        out[(int(f[0]), int(f[1]))] = np.array(f[2:], f32)
+    return out
+
+
+def initial(n, dim):
+    size = dim + dim // 2 + 1
+    return [(f32(r + 1) + f32(0.01) * np.arange(size, dtype=f32)).astype(f32) for r in range(n)]
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_bsp_worker_threads(n):
+    dim, steps = 37, 5
+    got = run_selftest("bsp", n, dim, steps)
+    w = initial(n, dim)
+    for s in range(steps):
+        active = [r for r in range(n) if s < steps - r]
+        for r in active:
+            w[r] = (w[r] + f32(0.5 * (r + 1) + 0.25 * s)).astype(f32)
+        cnt = [100 * (r + 1) + s if r in active else 0 for r in range(n)]
+        tot = sum(cnt)
+        acc = np.zeros_like(w[0])
+        for r in range(n):  # rank order, like the harness' reduction
+            acc = (acc + w[r] * f32(f32(cnt[r]) / f32(tot))).astype(f32) if r else (w[0] * f32(f32(cnt[0]) / f32(tot))).astype(f32)
+        w = [acc.copy() for _ in range(n)]
+        for r in active:
+            np.testing.assert_allclose(got[(s, r)], acc, rtol=2e-6, atol=0)
+    for r in range(n):  # every rank ends with the same model, the last average
+        np.testing.assert_allclose(got[(steps, r)], w[r], rtol=2e-6, atol=0)
+
+
+def test_bmuf_worker_threads():
+    n, dim, steps, lr, mom = 3, 20, 4, 0.8, 0.6
+    got = run_selftest("bmuf", n, dim, steps, lr, mom)
+    w = initial(n, dim)
+    # every rank starts from its own model here, so w_g(t-1) differs per rank at the first round: follow each rank
+    prev = [x.copy() for x in w]
+    dprev = [np.zeros_like(x) for x in w]
+    for s in range(steps):
+        active = [r for r in range(n) if s < steps - r]
+        for r in active:
+            w[r] = (w[r] + f32(0.5 * (r + 1) + 0.25 * s)).astype(f32)
+        g = [(w[r] - prev[r]).astype(f32) for r in range(n)]
+        G = g[0].copy()
+        for r in range(1, n):
+            G = (G + g[r]).astype(f32)
+        coef = f32((1.0 - f32(mom)) * f32(lr))
+        for r in range(n):
+            d = (G * coef + f32(mom) * dprev[r]).astype(f32)
+            w[r] = (prev[r] + d).astype(f32)
+            prev[r], dprev[r] = w[r].copy(), d
+        for r in active:
+            np.testing.assert_allclose(got[(s, r)], w[r], rtol=3e-6, atol=1e-6)
+    for r in range(n):
+        np.testing.assert_allclose(got[(steps, r)], w[r], rtol=3e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("worker", ["bsp", "bmuf"])
+def test_frame_worker_tool_group_of_one(aslp, oracle, dev, tmp_path, worker):
+    """aslp-nnet-train-frame-worker through RCCL with one rank.  BSP with one worker is the identity (factor 1), so the
+    model equals aslp-nnet-train-frame's bit for bit; BMUF with lr 1 / momentum 0 likewise (w = w_g + (w - w_g))."""
+    in_dim, hid, nh, out_dim, mb = 24, 64, 2, 40, 32
+    d, path = make_dnn(oracle, tmp_path, in_dim, hid, nh, out_dim, 1, mb, seed=21)
+    oracle.lib.orc_dnn_destroy(d)
+    write_corpus(tmp_path, np.random.default_rng(7), 12, in_dim, out_dim)
+    common = ["--learn-rate=0.004", "--momentum=0.5", "--minibatch-size=%d" % mb, "--randomizer-size=150", "--randomizer-seed=9",
+              "ark:%s" % (tmp_path / "feats.ark"), "ark:%s" % (tmp_path / "post.ark"), str(path)]
+    tool("aslp-nnet-train-frame", *common, str(tmp_path / "ref.nnet"))
+    extra = ["--worker-type=%s" % worker, "--sync-period=64"]
+    if worker == "bmuf":
+        extra += ["--bmuf-learn-rate=1.0", "--bmuf-momentum=0.0"]
+    p = tool("aslp-nnet-train-frame-worker", *extra, *common, str(tmp_path / "w.nnet"))
+    err = p.stderr.decode()
+    assert "Mpi cluster info total 1 worker rank 0" in err and "All worker finished their data" in err and "AvgLoss:" in err
+    a, b = aslp.Nnet.Read(tmp_path / "ref.nnet").GetParams(), aslp.Nnet.Read(tmp_path / "w.nnet").GetParams()
+    if worker == "bsp":
+        assert np.array_equal(a, b)
+    else:
+        np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-7)
