@@ -30,6 +30,8 @@ lines.append("</NnetProto>")
 net = aslp.Nnet.Init("\n".join(lines) + "\n", seed=777)
 net.SetTrainOptions(learn_rate=1e-5, momentum=0.9)
 net.SetChunkSize(CHUNK)
+if os.environ.get('NO_OVERLAP') == '1': net.SetUpdateOverlap(False)
+if os.environ.get('NO_FUSION') == '1': net.SetLayerFusion(False)
 xent = aslp.Xent()
 dev = torch.device("cuda:0")
 x = torch.randn(T * S, 40, device=dev)

@@ -192,6 +192,8 @@ void aslp_splice_backward(float *in_diff, MatrixDim d_in, const float *out_diff,
 void aslp_dropout_forward(float *out, int out_stride, const float *in, MatrixDim d, float *mask, int mask_stride, float retention,
                           unsigned long long seed);
 void aslp_dropout_backward(float *in_diff, int id_stride, const float *out_diff, MatrixDim d, const float *mask, int mask_stride, float retention);
+/* ApplyFloor(lo) then ApplyCeiling(hi) in one pass (the gradient clipping of the recurrent components) */
+void aslp_apply_clamp(float *mat, MatrixDim d, float lo, float hi);
 /* ReLU backward: in_diff = heaviside(in) * out_diff (nnet-activation.h:292-297) */
 void aslp_diff_relu(float *in_diff, const float *in, const float *out_diff, MatrixDim d, int in_stride, int od_stride);
 /* ---- recurrent gate blocks, one launch per timestep (csrc/rnn_cells.hip) -------------------------

@@ -121,6 +121,7 @@ _sig("aslp_softmax_xent_supported", _i, _i)
 _sig("aslp_softmax_xent_eval", None, _vp, _md, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i)
 _sig("aslp_dropout_forward", None, _vp, _i, _vp, _md, _vp, _i, _f, C.c_ulonglong)
 _sig("aslp_dropout_backward", None, _vp, _i, _vp, _md, _vp, _i, _f)
+_sig("aslp_apply_clamp", None, _vp, _md, _f, _f)
 _sig("aslp_scatter_add", None, _vp, _md, _vp, _vp, _vp, _i)
 _sig("aslp_splice_backward", None, _vp, _md, _vp, _i, _vp, _i)
 _sig("aslp_diff_relu", None, _vp, _vp, _vp, _md, _i, _i)

@@ -78,6 +78,7 @@ struct Pow {  // cu-kernels.cu:1287 _apply_pow: 2 -> square, 0.5 -> sqrt (neg ch
 struct Heaviside { __device__ float operator()(float d, float, float, int, int) const { return d > 0.0f ? 1.0f : 0.0f; } };
 struct Floor { float v; __device__ float operator()(float d, float, float, int, int) const { return d < v ? v : d; } };
 struct Ceil { float v; __device__ float operator()(float d, float, float, int, int) const { return d > v ? v : d; } };
+struct Clamp { float lo, hi; __device__ float operator()(float d, float, float, int, int) const { return d < lo ? lo : (d > hi ? hi : d); } };
 struct Invert { __device__ float operator()(float d, float, float, int, int) const { return 1.0f / d; } };
 struct MulElem { __device__ float operator()(float d, float a, float, int, int) const { return d * a; } };
 struct MulColsVec { const float *s; __device__ float operator()(float d, float, float, int, int c) const { return d * s[c]; } };
@@ -318,6 +319,7 @@ void cudaF_apply_log(aslp_dim3, aslp_dim3, float *mat, MatrixDim d) { launch_map
 void cudaF_apply_exp(aslp_dim3, aslp_dim3, float *mat, MatrixDim d) { launch_map<true>("apply_exp", mat, d, nullptr, 0, nullptr, 0, Exp{}); }
 void cudaF_apply_pow(aslp_dim3, aslp_dim3, float *mat, float power, MatrixDim d) { launch_map<true>("apply_pow", mat, d, nullptr, 0, nullptr, 0, Pow{power}); }
 void cudaF_apply_heaviside(aslp_dim3, aslp_dim3, float *mat, MatrixDim d) { launch_map<true>("apply_heaviside", mat, d, nullptr, 0, nullptr, 0, Heaviside{}); }
+void aslp_apply_clamp(float *mat, MatrixDim d, float lo, float hi) { launch_map<true>("apply_clamp", mat, d, nullptr, 0, nullptr, 0, Clamp{lo, hi}); }
 void cudaF_apply_floor(aslp_dim3, aslp_dim3, float *mat, float v, MatrixDim d) { launch_map<true>("apply_floor", mat, d, nullptr, 0, nullptr, 0, Floor{v}); }
 void cudaF_apply_ceiling(aslp_dim3, aslp_dim3, float *mat, float v, MatrixDim d) { launch_map<true>("apply_ceiling", mat, d, nullptr, 0, nullptr, 0, Ceil{v}); }
 void cudaF_invert_elements(aslp_dim3, aslp_dim3, float *data, MatrixDim d) { launch_map<true>("invert_elements", data, d, nullptr, 0, nullptr, 0, Invert{}); }

@@ -122,6 +122,10 @@ class Component {
   // True if the parameter gradients are formed inside BackpropagateFnc (the recurrent and temporal
   // components, e.g. lc.h:976-1058) rather than in Update: the executor must then never skip the call.
   virtual bool GradientInBackprop() const { return false; }
+  // true for components whose passes are long chains of tiny dependent kernels (the recurrences): the executor then keeps
+  // everything on one stream -- a second active stream costs such a chain more than the overlap gives (measured on the
+  // LC-BLSTM net: 7.85 ms/step on one stream, 8.61 with the output layer's weight gradient on a side stream)
+  virtual bool LatencyBoundPasses() const { return false; }
 
  protected:
   virtual void FeedforwardFnc(const CuMatrixBase &in, CuMatrixBase *out) { PropagateFnc(in, out); }

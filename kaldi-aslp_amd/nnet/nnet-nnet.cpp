@@ -172,6 +172,9 @@ void Nnet::Backpropagate(const std::vector<const CuMatrixBase *> &out_diff, std:
     for (size_t i = 0; i < output_.size(); i++) output_diff_buf_[output_[i]].CopyFromMat(*(out_diff[i]));
   for (int32 i = 0; i < N; i++) out_diff_view_[i] = &output_diff_buf_[i];
   const bool want_in_diff = (in_diff != NULL);
+  bool overlap_updates = overlap_updates_;
+  for (int32 i = 0; i < N && overlap_updates; i++)
+    if (components_[i]->LatencyBoundPasses()) overlap_updates = false;
   std::vector<int32> fused_sigmoid(N, -1);   // BN index -> its folded Sigmoid
   std::vector<char> folded(N, 0);            // Sigmoids handled by their BatchNormalization
   for (int32 i = 0; i < N; i++) {
@@ -209,7 +212,7 @@ void Nnet::Backpropagate(const std::vector<const CuMatrixBase *> &out_diff, std:
     }
     if (components_[i]->IsUpdatable()) {
       UpdatableComponent *uc = dynamic_cast<UpdatableComponent *>(components_[i]);
-      if (overlap_updates_ && components_[i]->GetType() == Component::kAffineTransform) {
+      if (overlap_updates && components_[i]->GetType() == Component::kAffineTransform) {
         SideStreamScope side;  // after this component's Backpropagate (which reads the weights), beside everything below it
         uc->Update(*in_view_[i], output_diff_buf_[i]);
       } else {

@@ -88,7 +88,8 @@ class Nnet {
   // Engine switch (not in the reference): issue AffineTransform::Update (weight-gradient GEMM with the SGD step in its
   // epilogue) on a side stream, ordered after the component's own Backpropagate, so that it shares the chip with the
   // backward pass of the layers below instead of sitting in its critical path; Backpropagate() returns with the main
-  // stream waiting for all of them.  Values are identical (no kernel changes, no reduction order changes).
+  // stream waiting for all of them.  Values are identical (no kernel changes, no reduction order changes).  Not applied to
+  // nets with recurrent components (Component::LatencyBoundPasses).
   void SetUpdateOverlap(bool on) { overlap_updates_ = on; }
 
   // Step-path entry points for callers that evaluate the loss on the device right away (the train-step C API): the

@@ -12,7 +12,7 @@ void CheckK() {
   if (aslp_get_last_error(buf, sizeof(buf))) ASLP_ERR << buf;
 }
 void ClipVec(CuVector *v, float clip) {
-  if (clip > 0.0 && v->Dim()) { v->ApplyFloor(-clip); v->ApplyCeiling(clip); }
+  if (clip > 0.0 && v->Dim()) { MatrixDim d = {1, v->Dim(), v->Dim()}; aslp_apply_clamp(v->Data(), d, -clip, clip); }
 }
 std::pair<BaseFloat *, int> MatParam(CuMatrix &m) { return std::make_pair(m.Data(), m.NumRows() * m.Stride()); }
 std::pair<BaseFloat *, int> VecParam(CuVector &v) { return std::make_pair(v.Data(), v.Dim()); }

@@ -24,6 +24,7 @@ class RecurrentBase : public UpdatableComponent {
  public:
   RecurrentBase(int32 di, int32 dout) : UpdatableComponent(di, dout) {}
   bool GradientInBackprop() const { return true; }
+  bool LatencyBoundPasses() const { return true; }
   virtual bool HasStreamReset() const { return false; }   // answers Nnet::ResetLstmStreams (nnet-nnet.cc:473-496)
   virtual bool HasSeqLengths() const { return false; }    // answers Nnet::SetSeqLengths   (nnet-nnet.cc:498-530)
   virtual void ResetLstmStreams(const std::vector<int32> &) {}

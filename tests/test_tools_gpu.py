@@ -538,3 +538,36 @@ def test_eesen_ctc_streams_tool_matches_api(aslp, dev, tmp_path):
         net.Backpropagate(diff)
     assert np.array_equal(aslp.Nnet.Read(tmp_path / "e.out").GetParams(), net.GetParams())
     assert ctc.Report().strip().splitlines()[-1] in err
+
+
+def test_forward_blstm_lc_tool(aslp, dev, tmp_path):
+    """aslp-nnet-forward-blstm-lc: chunk + look-ahead blocks through a one-stream net, chunk part kept; the short last block
+    keeps the previous block's tail rows in the input buffer, as the reference's loop does."""
+    (tmp_path / "lc.proto").write_text(LC_PROTO)
+    tool("aslp-nnet-init", "--seed=31", str(tmp_path / "lc.proto"), str(tmp_path / "lc.init"))
+    rng = np.random.default_rng(16)
+    D, A, chunk, right = 12, 10, 6, 3
+    keys = ["f%d" % i for i in range(3)]
+    feats = [rng.standard_normal((n, D)).astype(np.float32) for n in (5, 20, 31)]
+    (tmp_path / "feats.ark").write_bytes(kf.archive([(k, kf.matrix_bin(f)) for k, f in zip(keys, feats)]))
+    p = tool("aslp-nnet-forward-blstm-lc", "--chunk-size=%d" % chunk, "--right-splice=%d" % right, "--apply-log=false", str(tmp_path / "lc.init"),
+             "ark:%s" % (tmp_path / "feats.ark"), "ark:%s" % (tmp_path / "out.ark"))
+    assert b"Done 3files in" in p.stderr
+    got = kf.parse_bin_archive((tmp_path / "out.ark").read_bytes(), "matrix")
+    net = aslp.Nnet.Read(tmp_path / "lc.init")
+    net.SetChunkSize(chunk)
+    B = chunk + right
+    for (k, o), f in zip(got, feats):
+        n = len(f)
+        net.ResetLstmStreams([1])
+        buf = np.zeros((B, D), np.float32)
+        ref = np.zeros((n, A), np.float32)
+        for i in range((n - 1) // chunk + 1):
+            off = i * chunk
+            ln = B if off + B < n else n - off
+            cp = chunk if off + chunk < n else n - off
+            buf[:ln] = f[off:off + ln]
+            y = net.Feedforward(torch.from_numpy(buf).to(dev)).cpu().numpy()
+            ref[off:off + cp] = y[:cp]
+        assert np.array_equal(o, ref), k
+        assert np.allclose(o.sum(1), 1.0, atol=1e-4)
