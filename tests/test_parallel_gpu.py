@@ -99,3 +99,23 @@ def test_frame_worker_tool_group_of_one(aslp, oracle, dev, tmp_path, worker):
         assert np.array_equal(a, b)
     else:
         np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-7)
+
+
+def test_lc_blstm_worker_tool_group_of_one(aslp, dev, tmp_path):
+    """aslp-nnet-train-lc-blstm-streams-worker with one BSP rank equals aslp-nnet-train-blstm-streams-lc bit for bit."""
+    from test_tools_gpu import LC_PROTO
+    (tmp_path / "lc.proto").write_text(LC_PROTO)
+    tool("aslp-nnet-init", "--seed=31", str(tmp_path / "lc.proto"), str(tmp_path / "lc.init"))
+    rng = np.random.default_rng(21)
+    keys = ["u%02d" % i for i in range(8)]
+    lens = [int(x) for x in rng.integers(6, 30, 8)]
+    feats = [rng.standard_normal((n, 12)).astype(np.float32) for n in lens]
+    posts = [[[(int(rng.integers(0, 10)), 1.0)] for _ in range(n)] for n in lens]
+    (tmp_path / "feats.ark").write_bytes(kf.archive([(k, kf.matrix_bin(f)) for k, f in zip(keys, feats)]))
+    (tmp_path / "post.ark").write_bytes(kf.archive([(k, kf.posterior_bin(p)) for k, p in zip(keys, posts)]))
+    common = ["--learn-rate=0.01", "--momentum=0.9", "--num-stream=3", "--chunk-size=6"]
+    io = ["ark:%s" % (tmp_path / "feats.ark"), "ark:%s" % (tmp_path / "post.ark"), str(tmp_path / "lc.init")]
+    tool("aslp-nnet-train-blstm-streams-lc", *common, "--right-splice=3", *io, str(tmp_path / "a.nnet"))
+    p = tool("aslp-nnet-train-lc-blstm-streams-worker", *common, "--right_splice=3", "--sync-period=20", *io, str(tmp_path / "b.nnet"))
+    assert b"synchronize once" in p.stderr and b"All worker finished their data" in p.stderr
+    assert np.array_equal(aslp.Nnet.Read(tmp_path / "a.nnet").GetParams(), aslp.Nnet.Read(tmp_path / "b.nnet").GetParams())
