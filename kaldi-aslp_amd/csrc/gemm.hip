@@ -607,8 +607,16 @@ void launch_variant(GemmArgs &g) {
   // Measured on MI355X (devtools/bench_gemm.py, profiles/): the LDS-DMA kernels (cfg >= 200, gemm_glds.hip) win
   // wherever they are eligible; 64x128 / 8 waves when it tiles the problem into >= ~200 full blocks, else 64x64 /
   // 4 waves (2+ workgroups per CU copes best with ragged edges and small grids).  Skinny M keeps the 32-row tile.
+  // experiment hook: ASLP_GEMM_TILE_{NT,NN,TN,TT}=<cfg> overrides the choice for one operand layout
+  static const int env_tile[4] = {getenv("ASLP_GEMM_TILE_NT") ? atoi(getenv("ASLP_GEMM_TILE_NT")) : 0, getenv("ASLP_GEMM_TILE_NN") ? atoi(getenv("ASLP_GEMM_TILE_NN")) : 0,
+                                  getenv("ASLP_GEMM_TILE_TN") ? atoi(getenv("ASLP_GEMM_TILE_TN")) : 0, getenv("ASLP_GEMM_TILE_TT") ? atoi(getenv("ASLP_GEMM_TILE_TT")) : 0};
+  const int env_cfg = env_tile[A_KC ? (B_KC ? 0 : 1) : (B_KC ? 3 : 2)];
+  const bool big_grid = g.N % 128 == 0 && g.M % 64 == 0 && blocks(64, 128) >= 200;
   if (g_force_tile) cfg = g_force_tile;
-  else if (g.N % 128 == 0 && g.M % 64 == 0 && blocks(64, 128) >= 200) cfg = 212;
+  else if (env_cfg && big_grid) cfg = env_cfg;
+  // both operands K-contiguous (the forward products): the 4-wave 64x64 tile, two workgroups per CU, measured 3 % ahead of
+  // the 8-wave tile inside the training step (devtools/sweep_tiles.sh: 70.0 vs 72.5 us average over the NT launches)
+  else if (big_grid && !(A_KC && B_KC)) cfg = 212;
   else cfg = 207;
   if (cfg >= 200) {
     if (gemm_glds_launch(g, A_KC, B_KC, cfg)) { if (!A_KC) g.ep.colsum = nullptr; return; }  // column sums done in-kernel
