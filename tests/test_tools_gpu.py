@@ -60,6 +60,12 @@ def test_init_copy_info(aslp, dev, tmp_path):
     p = tool("aslp-nnet-info", str(tmp_path / "a.bin"))
     info = p.stdout.decode()
     assert "num-components 7" in info and "<AffineTransform>" in info and info == ref.Info()
+    # standard nnet1 form: no Input / Output layers, no graph fields; dot file of the graph
+    tool("aslp-nnet-convert-to-standard", "--binary=false", str(tmp_path / "a.bin"), str(tmp_path / "std.txt"))
+    std = (tmp_path / "std.txt").read_text()
+    assert "<InputLayer>" not in std and "<OutputLayer>" not in std and std.count("<AffineTransform>") == 2
+    tool("aslp-nnet-dot", str(tmp_path / "a.bin"), str(tmp_path / "g.dot"))
+    assert (tmp_path / "g.dot").read_text().lstrip().startswith("digraph")
     # wrong usage: usage text on stderr, exit status 1
     p = tool("aslp-nnet-info", ok=False)
     assert p.returncode == 1 and b"Usage:  aslp-nnet-info [options] <nnet-in>" in p.stderr
