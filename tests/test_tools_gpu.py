@@ -21,6 +21,8 @@ TOL = 1e-4
 
 def tool(name, *args, ok=True):
     exe = os.path.join(BIN, name)
+    if not os.path.exists(exe):  # a tree without the built tools (they are not in git): build them, in-tree, once
+        subprocess.run(["make", "-C", os.path.join(ROOT, "kaldi-aslp_amd"), "-j8"], check=True, capture_output=True, timeout=1800)
     assert os.path.exists(exe), "%s not built (make -C kaldi-aslp_amd)" % exe
     p = subprocess.run([exe] + list(args), capture_output=True, timeout=300)
     if ok:
