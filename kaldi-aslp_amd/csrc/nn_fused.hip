@@ -186,7 +186,7 @@ constexpr int kXentPerThread = 32;  // cols <= 8192 cached in registers
 // SOFTMAX: `y` holds the activations in front of the network's final Softmax and the row softmax is formed here,
 // with exactly the arithmetic of softmax_rows_kernel<256> (same lane -> column mapping, same reduction order), so
 // folding the Softmax component into the loss changes no bit; `y_out` (nullable) receives the posteriors.
-template <bool DENSE, bool SOFTMAX>
+template <bool DENSE, bool SOFTMAX, int PER>
 __global__ void __launch_bounds__(256) xent_rows_kernel(const float *y, int ldy, const float *t, int ldt, const int32_t *labels,
                                                         const float *fw, float *diff, int ldd, int rows, int cols, double *rowstats,
                                                         float *y_out, int ldyo) {
@@ -198,13 +198,13 @@ __global__ void __launch_bounds__(256) xent_rows_kernel(const float *y, int ldy,
     const float *yr = y + (long)r * ldy;
     const float *tr = DENSE ? t + (long)r * ldt : nullptr;
     const int label = DENSE ? -1 : labels[r];
-    float yv[kXentPerThread], tv[kXentPerThread];
+    float yv[PER], tv[PER];
     float tsum = 0.0f, ybest = -1e21f, tbest = -1e21f;
     int yi = -1, ti = -1;
     if (SOFTMAX) {
       float m = -INFINITY;
 #pragma unroll
-      for (int k = 0; k < kXentPerThread; k++) {
+      for (int k = 0; k < PER; k++) {
         int c = tid + k * 256;
         if (c < cols) {
           yv[k] = yr[c];
@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(256) xent_rows_kernel(const float *y, int ldy,
       __syncthreads();
       float sum = 0.0f;
 #pragma unroll
-      for (int k = 0; k < kXentPerThread; k++) {
+      for (int k = 0; k < PER; k++) {
         int c = tid + k * 256;
         if (c < cols) {
           yv[k] = expf(yv[k] - m);
@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(256) xent_rows_kernel(const float *y, int ldy,
       __syncthreads();
       const float inv = 1.0f / sum;
 #pragma unroll
-      for (int k = 0; k < kXentPerThread; k++) {
+      for (int k = 0; k < PER; k++) {
         int c = tid + k * 256;
         if (c < cols) {
           yv[k] *= inv;
@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(256) xent_rows_kernel(const float *y, int ldy,
       }
     }
 #pragma unroll
-    for (int k = 0; k < kXentPerThread; k++) {
+    for (int k = 0; k < PER; k++) {
       int c = tid + k * 256;
       if (c < cols) {
         if (!SOFTMAX) yv[k] = yr[c];
@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(256) xent_rows_kernel(const float *y, int ldy,
     const float wr = fw[r] * tsum;  // frames with sum(t) == 0 are switched off (nnet-loss.cc:80-85)
     double xe = 0.0, en = 0.0, lk = 0.0;
 #pragma unroll
-    for (int k = 0; k < kXentPerThread; k++) {
+    for (int k = 0; k < PER; k++) {
       int c = tid + k * 256;
       if (c < cols) {
         float yy = yv[k], tt = tv[k];
@@ -409,12 +409,23 @@ static void xent_eval_impl(const float *net_out, MatrixDim d, const float *tgt, 
   double *rowstats = static_cast<double *>(scratch(kScratchReduce, sizeof(double) * 5 * (size_t)d.rows));
   if (!rowstats) return;
   int g = d.rows > kMaxGrid * 2 ? kMaxGrid * 2 : d.rows;
-#define XENT_LAUNCH(DENSE, SM)                                                                                                        \
-  hipLaunchKernelGGL((xent_rows_kernel<DENSE, SM>), dim3(g), dim3(256), 0, cur_stream(), net_out, d.stride, tgt, tgt_stride, labels, \
+  // elements cached per thread: the smallest of 4 / 8 / 16 / 32 that covers the row (the loops are fully unrolled: a row of
+  // 3000 classes runs 16 slots per thread instead of 32 predicated ones)
+  const int per = (d.cols + 255) / 256;
+#define XENT_LAUNCH_P(DENSE, SM, P)                                                                                                       \
+  hipLaunchKernelGGL((xent_rows_kernel<DENSE, SM, P>), dim3(g), dim3(256), 0, cur_stream(), net_out, d.stride, tgt, tgt_stride, labels, \
                      frame_weights, diff, diff_stride, d.rows, d.cols, rowstats, y_out, y_stride)
+#define XENT_LAUNCH(DENSE, SM)                                        \
+  do {                                                                \
+    if (per <= 4) XENT_LAUNCH_P(DENSE, SM, 4);                        \
+    else if (per <= 8) XENT_LAUNCH_P(DENSE, SM, 8);                   \
+    else if (per <= 16) XENT_LAUNCH_P(DENSE, SM, 16);                 \
+    else XENT_LAUNCH_P(DENSE, SM, 32);                                \
+  } while (0)
   if (tgt) { if (softmax) XENT_LAUNCH(true, true); else XENT_LAUNCH(true, false); }
   else { if (softmax) XENT_LAUNCH(false, true); else XENT_LAUNCH(false, false); }
 #undef XENT_LAUNCH
+#undef XENT_LAUNCH_P
   hipLaunchKernelGGL(xent_finalize_kernel, dim3(1), dim3(256), 0, cur_stream(), rowstats, d.rows, stats_dev);
   check_launch("xent_eval");
 }

@@ -41,17 +41,17 @@ __device__ __forceinline__ float block_reduce_sum(float v, float *sh) {
 }
 
 // T threads cooperate on one row; blockDim = (T, 256/T) so small rows still fill 4 waves.
-template <int T, bool LOG>
+template <int T, bool LOG, int PER = kMaxPerThread>
 __global__ void __launch_bounds__(256) softmax_rows_kernel(float *y, const float *x, int rows, int cols, int ldy, int ldx) {
   __shared__ float sh_all[4][4];
   float *sh = sh_all[threadIdx.y];
   for (int r = blockIdx.x * blockDim.y + threadIdx.y; r < rows; r += gridDim.x * blockDim.y) {
     const float *xr = x + (long)r * ldx;
     float *yr = y + (long)r * ldy;
-    float v[kMaxPerThread];
+    float v[PER];
     float m = -INFINITY;
 #pragma unroll
-    for (int k = 0; k < kMaxPerThread; k++) {
+    for (int k = 0; k < PER; k++) {
       int c = threadIdx.x + k * T;
       if (c < cols) {
         v[k] = xr[c];
@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(float *y, const float
     m = block_reduce_max<T>(m, sh);
     float s = 0.0f;
 #pragma unroll
-    for (int k = 0; k < kMaxPerThread; k++) {
+    for (int k = 0; k < PER; k++) {
       int c = threadIdx.x + k * T;
       if (c < cols) {
         if (LOG) {
@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(float *y, const float
     s = block_reduce_sum<T>(s, sh);
     float k2 = LOG ? logf(s) : 1.0f / s;
 #pragma unroll
-    for (int k = 0; k < kMaxPerThread; k++) {
+    for (int k = 0; k < PER; k++) {
       int c = threadIdx.x + k * T;
       if (c < cols) yr[c] = LOG ? v[k] - k2 : v[k] * k2;
     }
@@ -110,7 +110,13 @@ void launch_softmax(float *y, const float *x, MatrixDim d, int src_stride) {
     hipLaunchKernelGGL((softmax_rows_kernel<64, LOG>), dim3(g), dim3(64, 4), 0, cur_stream(), y, x, d.rows, d.cols, d.stride, src_stride);
   } else if (d.cols <= 256 * kMaxPerThread) {
     int g = d.rows > kMaxGrid * 4 ? kMaxGrid * 4 : d.rows;
-    hipLaunchKernelGGL((softmax_rows_kernel<256, LOG>), dim3(g), dim3(256, 1), 0, cur_stream(), y, x, d.rows, d.cols, d.stride, src_stride);
+    // per-thread slots: the smallest of 4 / 8 / 16 / 32 that covers the row (fully unrolled loops; same lane -> column map and
+    // summation order for every choice, so the result does not depend on it)
+    const int per = (d.cols + 255) / 256;
+    if (per <= 4) hipLaunchKernelGGL((softmax_rows_kernel<256, LOG, 4>), dim3(g), dim3(256, 1), 0, cur_stream(), y, x, d.rows, d.cols, d.stride, src_stride);
+    else if (per <= 8) hipLaunchKernelGGL((softmax_rows_kernel<256, LOG, 8>), dim3(g), dim3(256, 1), 0, cur_stream(), y, x, d.rows, d.cols, d.stride, src_stride);
+    else if (per <= 16) hipLaunchKernelGGL((softmax_rows_kernel<256, LOG, 16>), dim3(g), dim3(256, 1), 0, cur_stream(), y, x, d.rows, d.cols, d.stride, src_stride);
+    else hipLaunchKernelGGL((softmax_rows_kernel<256, LOG, 32>), dim3(g), dim3(256, 1), 0, cur_stream(), y, x, d.rows, d.cols, d.stride, src_stride);
   } else {
     int g = d.rows > kMaxGrid ? kMaxGrid : d.rows;
     hipLaunchKernelGGL((softmax_rows_wide<LOG>), dim3(g), dim3(256), 0, cur_stream(), y, x, d.rows, d.cols, d.stride, src_stride);
