@@ -123,8 +123,16 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # ASLP_BENCH_FORCE_SYNC=1 exercises the sync path on a single GPU as well (all-reduce over one rank)
+    force_sync = os.environ.get("ASLP_BENCH_FORCE_SYNC") == "1"
+    # The communicator comes up BEFORE the model is allocated and the first kernel runs: initialising RCCL afterwards
+    # leaves every later step ~1 ms slower on this stack (measured, devtools/dbg_sync2.py: 1.44 vs 2.39 ms/step).
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+    elif force_sync:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 
     import aslp_import
     aslp = aslp_import.load()   # raises if libaslp_hip.so is missing (no fallback)
@@ -140,12 +148,6 @@ def main():
     g.manual_seed(1234 + rank)                          # every rank its own shard
     x = torch.randn(MB, IN_DIM, device=dev, generator=g)
     labels = torch.randint(0, OUT_DIM, (MB,), device=dev, generator=g, dtype=torch.int32)
-    # ASLP_BENCH_FORCE_SYNC=1 exercises the sync path on a single GPU as well (all-reduce over one rank)
-    force_sync = os.environ.get("ASLP_BENCH_FORCE_SYNC") == "1"
-    if force_sync and world == 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     worker = BspWorker(net) if (world > 1 or force_sync) else None
 
     frames_since_sync = 0
@@ -160,6 +162,11 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if worker is not None:
+        # part of the warm-up: one model sync, so that the communicator's buffers and the pack / scale / unpack kernels are
+        # loaded before the clock starts (a first sync inside K = 50 steps costs more than the 50 steps)
+        worker.Synchronize(max(frames_since_sync, 1))
+        frames_since_sync = 0
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

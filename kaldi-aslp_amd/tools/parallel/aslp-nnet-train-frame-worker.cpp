@@ -61,6 +61,9 @@ int main(int argc, char *argv[]) {
     if (gpu_id >= 0) CuDevice::Instantiate().SetGpuId(gpu_id);
     else if (num_workers > 1) CuDevice::Instantiate().SetGpuId(rank);  // one process per GPU of the node
     else CuDevice::Instantiate().SelectGpuId(use_gpu);
+    // the communicator before the model: RCCL initialised after the first allocations / launches leaves every later step
+    // slower on this stack (measured: 1.44 vs 2.39 ms/step on the cfg2 DNN)
+    std::unique_ptr<Comm> comm(NewRcclComm(rank, num_workers, comm_file));
 
     Nnet nnet;
     nnet.Read(model_filename);
@@ -72,7 +75,6 @@ int main(int argc, char *argv[]) {
     else ASLP_ERR << "Unsupported objective function: " << objective_function;
     Xent *xent = dynamic_cast<Xent *>(loss);
 
-    std::unique_ptr<Comm> comm(NewRcclComm(rank, num_workers, comm_file));
     std::unique_ptr<IWorker> worker;
     if (worker_type == "bsp") worker.reset(new BspWorker(comm.get()));
     else if (worker_type == "bmuf") worker.reset(new BmufWorker(comm.get(), bmuf_learn_rate, bmuf_momentum));
