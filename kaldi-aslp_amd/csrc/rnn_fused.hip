@@ -23,11 +23,12 @@ namespace aslp {
 namespace {
 
 constexpr int kCB = 8;    // cells per forward workgroup (x 4 gates = 32 MFMA columns)
-constexpr int kKQ = 4;    // K-split of the backward product across workgroups
+constexpr int kKQ = 8;    // K-split of the backward product across workgroups (one round of 8 loads per wave at C = 512; 4: 7.85, 8: 7.42, 16: 8.17 ms per LC step)
+constexpr int kNW = 4;    // waves per step workgroup (K split 4 ways; 8 waves were measured slower: 8.15 vs 7.85 ms on the LC step)
 
 template <bool CIFG>
-__global__ void __launch_bounds__(256) lstm_step_fwd(aslp_lstm_step a) {
-  __shared__ float red[4][32 * kPad];
+__global__ void __launch_bounds__(64 * kNW) lstm_step_fwd(aslp_lstm_step a) {
+  __shared__ float red[kNW][32 * kPad];
   constexpr int G = CIFG ? 3 : 4;
   const aslp_lstm_step_dir D = a.dir[blockIdx.z];
   const int C = a.C, S = a.S, ld = a.ld;
@@ -37,7 +38,7 @@ __global__ void __launch_bounds__(256) lstm_step_fwd(aslp_lstm_step a) {
   // epilogue operands of this thread's (stream, cell), requested before the product so their latency hides under it
   const int sl = threadIdx.x / kCB, cc = threadIdx.x % kCB;
   const int s = s0 + sl, c = c0 + cc;
-  const bool live = s < S && c < C;
+  const bool live = threadIdx.x < 256 && s < S && c < C;  // the first 4 waves finish the 256 (stream, cell) pairs
   constexpr int gi = 1, gf = CIFG ? 1 : 2, go = CIFG ? 2 : 3;
   float *ys = D.y_cur + (long)(live ? s : 0) * ld;
   const int cq = live ? c : 0;
@@ -52,7 +53,7 @@ __global__ void __launch_bounds__(256) lstm_step_fwd(aslp_lstm_step a) {
     const float *arow = D.y_prev + (long)srow * ld + om;                       // m(t-1) of stream srow
     const float *brow = D.w + (long)(nvalid ? gate * C + cell : 0) * a.ldw;    // W_eff row of (gate, cell)
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const int nch = (C + 7) / 8, per = (nch + 3) / 4;
+    const int nch = (C + 7) / 8, per = (nch + kNW - 1) / kNW;
     if (!D.no_product) mfma_k_slices(acc, arow, brow, C, wave * per, min(nch, (wave + 1) * per), h);
     store_tile(red[wave], acc, lane);
   }
@@ -62,7 +63,10 @@ __global__ void __launch_bounds__(256) lstm_step_fwd(aslp_lstm_step a) {
 #pragma unroll
   for (int g = 0; g < G; g++) {
     const int n = g * kCB + cc;
-    pre[g] = red[0][sl * kPad + n] + red[1][sl * kPad + n] + red[2][sl * kPad + n] + red[3][sl * kPad + n];
+    float acc = red[0][sl * kPad + n];
+#pragma unroll
+    for (int w = 1; w < kNW; w++) acc += red[w][sl * kPad + n];
+    pre[g] = acc;
   }
   if (masked) {  // nnet-blstm-projected-streams.h:654-657
     ys[c] = 0.f; ys[gf * C + c] = 0.f; ys[go * C + c] = 0.f; ys[oc + c] = 0.f; ys[oh + c] = 0.f; ys[om + c] = 0.f;
@@ -87,8 +91,8 @@ __global__ void __launch_bounds__(256) lstm_step_fwd(aslp_lstm_step a) {
 
 // partial[dir][kq][s][c] = sum over this workgroup's K-quarter of dGATES(next)[s][k] * W_eff^T[c][k]
 template <int G>
-__global__ void __launch_bounds__(256) lstm_step_bwd_gemm(aslp_lstm_step a, float *__restrict__ partial) {
-  __shared__ float red[4][32 * kPad];
+__global__ void __launch_bounds__(64 * kNW) lstm_step_bwd_gemm(aslp_lstm_step a, float *__restrict__ partial) {
+  __shared__ float red[kNW][32 * kPad];
   const aslp_lstm_step_dir D = a.dir[blockIdx.z];
   const int C = a.C, S = a.S, ld = a.ld, GC = G * C;
   const int c0 = blockIdx.x * 32, kq = blockIdx.y % kKQ, s0 = (blockIdx.y / kKQ) * 32;
@@ -97,16 +101,20 @@ __global__ void __launch_bounds__(256) lstm_step_bwd_gemm(aslp_lstm_step a, floa
     const float *arow = D.d_next + (long)min(s0 + l31, S - 1) * ld;          // dGATES(next), columns [0, GC)
     const float *brow = D.w + (long)min(c0 + l31, C - 1) * a.ldw;            // W_eff^T row of cell c0 + l31
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const int nch = (GC + 7) / 8, per = (nch + 4 * kKQ - 1) / (4 * kKQ), part = kq * 4 + wave;
+    const int nch = (GC + 7) / 8, per = (nch + kNW * kKQ - 1) / (kNW * kKQ), part = kq * kNW + wave;
     mfma_k_slices(acc, arow, brow, GC, part * per, min(nch, (part + 1) * per), h);
     store_tile(red[wave], acc, lane);
   }
   __syncthreads();
   float *out = partial + ((long)(blockIdx.z * kKQ + kq) * S) * C;
-  for (int e = threadIdx.x; e < 32 * 32; e += 256) {
+  for (int e = threadIdx.x; e < 32 * 32; e += 64 * kNW) {
     const int sl = e >> 5, n = e & 31;
-    if (s0 + sl < S && c0 + n < C)
-      out[(long)(s0 + sl) * C + c0 + n] = red[0][sl * kPad + n] + red[1][sl * kPad + n] + red[2][sl * kPad + n] + red[3][sl * kPad + n];
+    if (s0 + sl < S && c0 + n < C) {
+      float acc = red[0][sl * kPad + n];
+#pragma unroll
+      for (int w = 1; w < kNW; w++) acc += red[w][sl * kPad + n];
+      out[(long)(s0 + sl) * C + c0 + n] = acc;
+    }
   }
 }
 
@@ -170,8 +178,8 @@ extern "C" {
 void aslp_lstm_step_forward(const aslp_lstm_step *a) {
   if (!step_args_ok(a, "aslp_lstm_step_forward")) return;
   dim3 grid((a->C + kCB - 1) / kCB, (a->S + 31) / 32, a->ndir);
-  if (a->cifg) hipLaunchKernelGGL((lstm_step_fwd<true>), grid, dim3(256), 0, cur_stream(), *a);
-  else hipLaunchKernelGGL((lstm_step_fwd<false>), grid, dim3(256), 0, cur_stream(), *a);
+  if (a->cifg) hipLaunchKernelGGL((lstm_step_fwd<true>), grid, dim3(64 * kNW), 0, cur_stream(), *a);
+  else hipLaunchKernelGGL((lstm_step_fwd<false>), grid, dim3(64 * kNW), 0, cur_stream(), *a);
   check_launch("aslp_lstm_step_forward");
 }
 
@@ -184,8 +192,8 @@ void aslp_lstm_step_backward(const aslp_lstm_step *a) {
     partial = static_cast<float *>(scratch(kScratchMisc, sizeof(float) * (size_t)a->ndir * kKQ * a->S * a->C));
     if (!partial) return;
     dim3 grid((a->C + 31) / 32, kKQ * ((a->S + 31) / 32), a->ndir);
-    if (a->cifg) hipLaunchKernelGGL((lstm_step_bwd_gemm<3>), grid, dim3(256), 0, cur_stream(), *a, partial);
-    else hipLaunchKernelGGL((lstm_step_bwd_gemm<4>), grid, dim3(256), 0, cur_stream(), *a, partial);
+    if (a->cifg) hipLaunchKernelGGL((lstm_step_bwd_gemm<3>), grid, dim3(64 * kNW), 0, cur_stream(), *a, partial);
+    else hipLaunchKernelGGL((lstm_step_bwd_gemm<4>), grid, dim3(64 * kNW), 0, cur_stream(), *a, partial);
   }
   dim3 grid(grid_for((long)a->S * a->C), a->ndir);
   if (a->cifg) hipLaunchKernelGGL((lstm_step_bwd_cell<true>), grid, dim3(kBlock), 0, cur_stream(), *a, partial, with_partial);
