@@ -24,6 +24,7 @@ namespace {
 
 constexpr int kCB = 8;    // cells per forward workgroup (x 4 gates = 32 MFMA columns)
 constexpr int kKQ = 8;    // K-split of the backward product across workgroups (one round of 8 loads per wave at C = 512; 4: 7.85, 8: 7.42, 16: 8.17 ms per LC step)
+constexpr int kFwdU = 8;   // K-chunks in flight in the forward product (16: 7.60 vs 7.45 ms per LC step)
 constexpr int kNW = 4;    // waves per step workgroup (K split 4 ways; 8 waves were measured slower: 8.15 vs 7.85 ms on the LC step)
 
 template <bool CIFG>
@@ -54,7 +55,7 @@ __global__ void __launch_bounds__(64 * kNW) lstm_step_fwd(aslp_lstm_step a) {
     const float *brow = D.w + (long)(nvalid ? gate * C + cell : 0) * a.ldw;    // W_eff row of (gate, cell)
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int nch = (C + 7) / 8, per = (nch + kNW - 1) / kNW;
-    if (!D.no_product) mfma_k_slices(acc, arow, brow, C, wave * per, min(nch, (wave + 1) * per), h);
+    if (!D.no_product) mfma_k_slices<kFwdU>(acc, arow, brow, C, wave * per, min(nch, (wave + 1) * per), h);
     store_tile(red[wave], acc, lane);
   }
   __syncthreads();

@@ -16,9 +16,10 @@ __device__ __forceinline__ float dtanh(float y, float d) { return d * (1.0f - y 
 // acc += A[32 x K-slice] * B[32 x K-slice]^T over the 8-wide K-chunks [qbegin, qend): a CONTIGUOUS slice per wave,
 // so every 128-B line of an operand row is pulled by exactly one wave.
 // arow / brow: this lane's operand rows (lane & 31), K-contiguous, 16-B aligned; K % 4 == 0.
+template <int U = 8>
 __device__ __forceinline__ void mfma_k_slices(f32x16 &acc, const float *__restrict__ arow, const float *__restrict__ brow, int K, int qbegin,
                                               int qend, int h) {
-  constexpr int U = 8;  // chunks in flight
+  // U: 8-wide K-chunks in flight
   for (int q0 = qbegin; q0 < qend; q0 += U) {
     float4 a[U], b[U];
 #pragma unroll
