@@ -224,6 +224,90 @@ class FrameDataReader {
   std::vector<std::pair<Block, std::unique_ptr<StreamMarker>>> in_flight_;
 };
 
+// ---- multi-input / multi-output FrameDataReader (data-reader.cc:12-150, the vector constructor) --------------------
+// N feature tables read in lock step (same keys in the same order, same number of frames), M target tables looked up by
+// key; every stream has its own randomizer, all shuffled with ONE mask per cache fill.  Single-threaded like the reference.
+class MimoFrameDataReader {
+ public:
+  MimoFrameDataReader(const std::vector<std::string> &feature_rspecifiers, const std::vector<std::string> &targets_rspecifiers,
+                      const NnetDataRandomizerOptions &rand_opts)
+      : num_input_(feature_rspecifiers.size()), num_output_(targets_rspecifiers.size()), rand_opts_(rand_opts), read_done_(false) {
+    ASLP_ASSERT(num_input_ > 0 && num_output_ > 0);
+    for (int i = 0; i < num_input_; i++) {
+      feature_readers_.emplace_back(new SequentialBaseFloatMatrixReader(feature_rspecifiers[i]));
+      feature_randomizers_.emplace_back(new MatrixRandomizer(rand_opts_));
+    }
+    for (int i = 0; i < num_output_; i++) {
+      targets_readers_.emplace_back(new RandomAccessPosteriorReader(targets_rspecifiers[i]));
+      targets_randomizers_.emplace_back(new PosteriorRandomizer(rand_opts_));
+    }
+    randomizer_mask_.Init(rand_opts_);
+  }
+  bool Done() { return read_done_ && feature_randomizers_[0]->Done(); }
+  // false when what is left does not fill a minibatch (the reference hands out a short read here and trips its own checks)
+  bool ReadData(std::vector<const CuMatrixBase *> *input, std::vector<const Posterior *> *output) {
+    ASLP_ASSERT(input != NULL && output != NULL);
+    input->resize(num_input_);
+    output->resize(num_output_);
+    if (Done()) ASLP_ERR << "Already read done";
+    if (feature_randomizers_[0]->Done()) FillRandomizer();
+    if (Done()) return false;
+    for (int i = 0; i < num_input_; i++) { (*input)[i] = &feature_randomizers_[i]->Value(); feature_randomizers_[i]->Next(); }
+    for (int i = 0; i < num_output_; i++) { (*output)[i] = &targets_randomizers_[i]->Value(); targets_randomizers_[i]->Next(); }
+    return true;
+  }
+
+ private:
+  void FillRandomizer() {
+    int32 added = 0;
+    while (true) {
+      if (feature_randomizers_[0]->IsFull()) break;
+      if (feature_readers_[0]->Done()) {
+        for (int i = 1; i < num_input_; i++) ASLP_ASSERT(feature_readers_[i]->Done());
+        read_done_ = true;
+        break;
+      }
+      const std::string utt = feature_readers_[0]->Key();
+      for (int i = 1; i < num_input_; i++)
+        if (utt != feature_readers_[i]->Key())
+          ASLP_ERR << "all feature not in the same order" << "[0] " << utt << "[" << i << "] " << feature_readers_[i]->Key();
+      bool all_have_target = true;
+      for (int i = 0; i < num_output_; i++)
+        if (!targets_readers_[i]->HasKey(utt)) { ASLP_WARN << utt << ", missing targets"; all_have_target = false; }
+      if (all_have_target) {
+        int32 num_frame = 0;
+        for (int i = 0; i < num_input_; i++) {
+          const HostMatrix &mat = feature_readers_[i]->Value();
+          if (i == 0) num_frame = mat.rows;
+          else if (mat.rows != num_frame) ASLP_ERR << "all feature dim not equal";
+          cu_mat_ = mat;
+          feature_randomizers_[i]->AddData(cu_mat_);
+        }
+        for (int i = 0; i < num_output_; i++) {
+          const Posterior &targets = targets_readers_[i]->Value(utt);
+          if ((int32)targets.size() != num_frame) ASLP_ERR << "feature and target dim must match";
+          targets_randomizers_[i]->AddData(targets);
+        }
+        added++;
+      }
+      for (int i = 0; i < num_input_; i++) feature_readers_[i]->Next();
+    }
+    if (feature_randomizers_[0]->NumFrames() == 0 || added == 0) return;
+    const std::vector<int32> &mask = randomizer_mask_.Generate(feature_randomizers_[0]->NumFrames());
+    for (auto &r : feature_randomizers_) r->Randomize(mask);
+    for (auto &r : targets_randomizers_) r->Randomize(mask);
+  }
+  int num_input_, num_output_;
+  NnetDataRandomizerOptions rand_opts_;
+  bool read_done_;
+  std::vector<std::unique_ptr<SequentialBaseFloatMatrixReader>> feature_readers_;
+  std::vector<std::unique_ptr<RandomAccessPosteriorReader>> targets_readers_;
+  std::vector<std::unique_ptr<MatrixRandomizer>> feature_randomizers_;
+  std::vector<std::unique_ptr<PosteriorRandomizer>> targets_randomizers_;
+  RandomizerMask randomizer_mask_;
+  CuMatrix cu_mat_;
+};
+
 // ---- SequenceDataReader (data-reader.h:48-100, data-reader.cc:178-340) -------------------------------------------
 // num-stream utterances advance in parallel, batch-size frames per call, rows t*S + s; features are shifted by
 // targets-delay frames against the targets (the last frame repeats), an exhausted stream is padded with its last frame /

@@ -579,3 +579,49 @@ def test_forward_blstm_lc_tool(aslp, dev, tmp_path):
             ref[off:off + cp] = y[:cp]
         assert np.array_equal(o, ref), k
         assert np.allclose(o.sum(1), 1.0, atol=1e-4)
+
+
+def test_train_frame_mimo_equals_two_independent_nets(aslp, dev, tmp_path):
+    """aslp-nnet-train-frame-mimo on a graph net made of two independent branches (two InputLayers, two OutputLayers) must
+    leave each branch exactly where aslp-nnet-train-frame leaves it when trained alone on its own tables (same seed: the
+    one shuffle mask per cache fill is shared by all streams)."""
+    rng = np.random.default_rng(17)
+    dims = [(10, 24, 7), (14, 16, 5)]  # (in, hidden, classes) of the two branches
+    W = []
+    for di, h, a in dims:
+        W.append((rng.standard_normal((h, di)).astype(np.float32) * 0.3, rng.standard_normal(h).astype(np.float32) * 0.1,
+                  rng.standard_normal((a, h)).astype(np.float32) * 0.3, np.zeros(a, np.float32)))
+    comps, cid = [], 2
+    comps.append(dict(marker="<InputLayer>", dim_in=dims[0][0], dim_out=dims[0][0], id=0, inputs=[-1], offsets=[0]))
+    comps.append(dict(marker="<InputLayer>", dim_in=dims[1][0], dim_out=dims[1][0], id=1, inputs=[-1], offsets=[0]))
+    for b, ((di, h, a), (W1, b1, W2, b2)) in enumerate(zip(dims, W)):
+        comps.append(dict(marker="<AffineTransform>", dim_in=di, dim_out=h, id=cid, inputs=[b], offsets=[0], data=nnet_io.affine(W1, b1)))
+        comps.append(dict(marker="<Sigmoid>", dim_in=h, dim_out=h, id=cid + 1, inputs=[cid], offsets=[0]))
+        comps.append(dict(marker="<AffineTransform>", dim_in=h, dim_out=a, id=cid + 2, inputs=[cid + 1], offsets=[0], data=nnet_io.affine(W2, b2)))
+        comps.append(dict(marker="<Softmax>", dim_in=a, dim_out=a, id=cid + 3, inputs=[cid + 2], offsets=[0]))
+        comps.append(dict(marker="<OutputLayer>", dim_in=a, dim_out=a, id=cid + 4, inputs=[cid + 3], offsets=[0]))
+        cid += 5
+        nnet_io.write_simple_nnet(tmp_path / ("b%d.nnet" % b), [("<AffineTransform>", di, h, nnet_io.affine(W1, b1)), ("<Sigmoid>", h, h, b""),
+                                                                 ("<AffineTransform>", h, a, nnet_io.affine(W2, b2)), ("<Softmax>", a, a, b"")])
+    nnet_io.write_graph_nnet(tmp_path / "mimo.nnet", comps)
+    keys = ["m%02d" % i for i in range(9)]
+    lens = [int(x) for x in rng.integers(15, 50, len(keys))]
+    for b, (di, h, a) in enumerate(dims):
+        feats = [rng.standard_normal((n, di)).astype(np.float32) for n in lens]
+        posts = [[[(int(rng.integers(0, a)), 1.0)] for _ in range(n)] for n in lens]
+        (tmp_path / ("f%d.ark" % b)).write_bytes(kf.archive([(k, kf.matrix_bin(f)) for k, f in zip(keys, feats)]))
+        (tmp_path / ("p%d.ark" % b)).write_bytes(kf.archive([(k, kf.posterior_bin(p)) for k, p in zip(keys, posts)]))
+    opts = ["--learn-rate=0.01", "--momentum=0.5", "--minibatch-size=16", "--randomizer-size=120", "--randomizer-seed=3"]
+    p = tool("aslp-nnet-train-frame-mimo", *opts, "--objective-function=xent:xent", "ark:%s" % (tmp_path / "f0.ark"), "ark:%s" % (tmp_path / "f1.ark"),
+             "ark:%s" % (tmp_path / "p0.ark"), "ark:%s" % (tmp_path / "p1.ark"), str(tmp_path / "mimo.nnet"), str(tmp_path / "mimo.out"))
+    assert b"Nnet num_input 2 num_output 2" in p.stderr and p.stderr.count(b"FRAME_ACCURACY") == 2
+    got = aslp.Nnet.Read(tmp_path / "mimo.out").GetParams()
+    parts = []
+    for b in range(2):
+        tool("aslp-nnet-train-frame", *opts, "ark:%s" % (tmp_path / ("f%d.ark" % b)), "ark:%s" % (tmp_path / ("p%d.ark" % b)),
+             str(tmp_path / ("b%d.nnet" % b)), str(tmp_path / ("b%d.out" % b)))
+        parts.append(aslp.Nnet.Read(tmp_path / ("b%d.out" % b)).GetParams())
+    assert np.array_equal(got, np.concatenate(parts))
+    # wrong number of tables for this net: usage, exit 1
+    p = tool("aslp-nnet-train-frame-mimo", "ark:%s" % (tmp_path / "f0.ark"), "ark:%s" % (tmp_path / "p0.ark"), str(tmp_path / "mimo.nnet"), "x", ok=False)
+    assert p.returncode == 1
