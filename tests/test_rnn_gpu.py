@@ -141,7 +141,7 @@ def test_lc_blstm_baseline_shape(aslp, oracle, dev, tmp_path):
         assert oracle.rel_err(net.GetParams(), np.concatenate([d.flat() for d in dirs])) < TOL, ("params", step)
 
 
-@pytest.mark.parametrize("dims", [(5, 6, 6, 3), (40, 64, 10, 4), (33, 50, 7, 5)])
+@pytest.mark.parametrize("dims", [(5, 6, 6, 3), (40, 64, 10, 4), (33, 50, 7, 5), (48, 128, 6, 40), (24, 36, 5, 33)])
 def test_gru_train_steps_match_oracle(aslp, oracle, dev, tmp_path, dims):
     D, H, T, S = dims
     clip, lr, mmt = 0.5, 0.01, 0.9
