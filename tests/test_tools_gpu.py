@@ -625,3 +625,34 @@ def test_train_frame_mimo_equals_two_independent_nets(aslp, dev, tmp_path):
     # wrong number of tables for this net: usage, exit 1
     p = tool("aslp-nnet-train-frame-mimo", "ark:%s" % (tmp_path / "f0.ark"), "ark:%s" % (tmp_path / "p0.ark"), str(tmp_path / "mimo.nnet"), "x", ok=False)
     assert p.returncode == 1
+
+
+def test_insert_tool(aslp, dev, tmp_path):
+    """aslp-nnet-insert (layer-wise pretraining): hidden components of a second net go in front of the last updatable
+    component, which is re-randomized with stddev-factor / sqrt(input dim) unless --randomize-next-component=false."""
+    base = "<NnetProto>\n<AffineTransform> <InputDim> 10 <OutputDim> 64 <BiasMean> -2.0 <BiasRange> 4.0 <ParamStddev> 0.1\n<Sigmoid> <InputDim> 64 <OutputDim> 64\n" \
+           "<AffineTransform> <InputDim> 64 <OutputDim> 5 <BiasMean> 0.0 <BiasRange> 0.0 <ParamStddev> 0.1\n<Softmax> <InputDim> 5 <OutputDim> 5\n</NnetProto>\n"
+    hid = "<NnetProto>\n<AffineTransform> <InputDim> 64 <OutputDim> 64 <BiasMean> -2.0 <BiasRange> 4.0 <ParamStddev> 0.1\n<Sigmoid> <InputDim> 64 <OutputDim> 64\n</NnetProto>\n"
+    (tmp_path / "base.proto").write_text(base)
+    (tmp_path / "hid.proto").write_text(hid)
+    tool("aslp-nnet-init", "--seed=1", str(tmp_path / "base.proto"), str(tmp_path / "base.nnet"))
+    tool("aslp-nnet-init", "--seed=2", str(tmp_path / "hid.proto"), str(tmp_path / "hid.nnet"))
+    b, h = aslp.Nnet.Read(tmp_path / "base.nnet"), aslp.Nnet.Read(tmp_path / "hid.nnet")
+    pb, ph = b.GetParams(), h.GetParams()
+    n1 = 64 * 10 + 64            # first affine of the base net
+    # the second model comes through a pipe, like the recipes' "aslp-nnet-init hidden.proto - |"
+    p = tool("aslp-nnet-insert", "--randomize-next-component=false", str(tmp_path / "base.nnet"), "cat %s |" % (tmp_path / "hid.nnet"), str(tmp_path / "o1.nnet"))
+    assert b"Inserted 2 components at position 3" in p.stderr
+    o1 = aslp.Nnet.Read(tmp_path / "o1.nnet")
+    assert o1.NumComponents() == b.NumComponents() + 2
+    assert [o1.Marker(i) for i in range(o1.NumComponents())] == ["<InputLayer>", "<AffineTransform>", "<Sigmoid>", "<AffineTransform>", "<Sigmoid>",
+                                                                   "<AffineTransform>", "<Softmax>", "<OutputLayer>"]
+    assert np.array_equal(o1.GetParams(), np.concatenate([pb[:n1], ph, pb[n1:]]))
+    p = tool("aslp-nnet-insert", "--stddev-factor=0.2", "--srand=5", str(tmp_path / "base.nnet"), str(tmp_path / "hid.nnet"), str(tmp_path / "o2.nnet"))
+    assert b"Randomized component index 5 with stddev 0.025" in p.stderr
+    po = aslp.Nnet.Read(tmp_path / "o2.nnet").GetParams()
+    assert np.array_equal(po[:n1 + ph.size], np.concatenate([pb[:n1], ph]))
+    last = po[n1 + ph.size:]
+    assert abs(last.std() - 0.025) < 0.004 and abs(last.mean()) < 0.004 and not np.array_equal(last, pb[n1:])
+    y = aslp.Nnet.Read(tmp_path / "o2.nnet").Propagate(torch.randn(7, 10, device=dev))
+    assert torch.allclose(y.sum(1), torch.ones(7, device=dev), atol=1e-5)
