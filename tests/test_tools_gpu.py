@@ -656,3 +656,27 @@ def test_insert_tool(aslp, dev, tmp_path):
     assert abs(last.std() - 0.025) < 0.004 and abs(last.mean()) < 0.004 and not np.array_equal(last, pb[n1:])
     y = aslp.Nnet.Read(tmp_path / "o2.nnet").Propagate(torch.randn(7, 10, device=dev))
     assert torch.allclose(y.sum(1), torch.ones(7, device=dev), atol=1e-5)
+
+
+def test_forward_skip_tool(aslp, dev, tmp_path):
+    """aslp-nnet-forward-skip: skip-width interleaved sub-sequences, each through the (recurrent) net on its own."""
+    (tmp_path / "l.proto").write_text(LSTM_PROTO)
+    tool("aslp-nnet-init", "--seed=51", str(tmp_path / "l.proto"), str(tmp_path / "l.init"))
+    rng = np.random.default_rng(19)
+    feats = [rng.standard_normal((n, 12)).astype(np.float32) for n in (17, 4, 9)]
+    keys = ["k%d" % i for i in range(3)]
+    (tmp_path / "feats.ark").write_bytes(kf.archive([(k, kf.matrix_bin(f)) for k, f in zip(keys, feats)]))
+    w = 3
+    tool("aslp-nnet-forward-skip", "--skip-width=%d" % w, "--apply-log=false", str(tmp_path / "l.init"), "ark:%s" % (tmp_path / "feats.ark"),
+         "ark:%s" % (tmp_path / "out.ark"))
+    got = kf.parse_bin_archive((tmp_path / "out.ark").read_bytes(), "matrix")
+    net = aslp.Nnet.Read(tmp_path / "l.init")
+    for (k, o), f in zip(got, feats):
+        ref = np.zeros((len(f), 10), np.float32)
+        for off in range(min(w, len(f))):
+            sub = np.ascontiguousarray(f[off::w])
+            net.SetSeqLengths([len(sub)])
+            ref[off::w] = net.Feedforward(torch.from_numpy(sub).to(dev)).cpu().numpy()
+        assert np.array_equal(o, ref), k
+    p = tool("aslp-nnet-forward-skip", str(tmp_path / "l.init"), "ark:%s" % (tmp_path / "feats.ark"), "ark:/dev/null", ok=False)
+    assert p.returncode != 0 and b"--skip-width must be at least 1" in p.stderr
