@@ -680,3 +680,52 @@ def test_forward_skip_tool(aslp, dev, tmp_path):
         assert np.array_equal(o, ref), k
     p = tool("aslp-nnet-forward-skip", str(tmp_path / "l.init"), "ark:%s" % (tmp_path / "feats.ark"), "ark:/dev/null", ok=False)
     assert p.returncode != 0 and b"--skip-width must be at least 1" in p.stderr
+
+
+BLSTM_PROTO = """<NnetProto>
+<BLstmProjectedStreams> <InputDim> 12 <OutputDim> 16 <CellDim> 12 <ParamScale> 0.1 <ClipGradient> 5.0
+<AffineTransform> <InputDim> 16 <OutputDim> 10 <BiasMean> 0.0 <BiasRange> 0.0 <ParamStddev> 0.1
+<Softmax> <InputDim> 10 <OutputDim> 10
+</NnetProto>
+"""
+
+
+def test_blstm_streams_tool_matches_api(aslp, dev, tmp_path):
+    """aslp-nnet-train-blstm-streams: whole utterances, groups of num-stream padded to the longest (zero features, empty
+    targets, weight 0), SetSeqLengths, learning rate / valid frames -- restated through the API, bit-identical model."""
+    (tmp_path / "b.proto").write_text(BLSTM_PROTO)
+    tool("aslp-nnet-init", "--seed=81", str(tmp_path / "b.proto"), str(tmp_path / "b.init"))
+    rng = np.random.default_rng(23)
+    n_utt, D, A, S = 7, 12, 10, 3
+    keys = ["w%02d" % i for i in range(n_utt)]
+    lens = [int(x) for x in rng.integers(5, 30, n_utt)]
+    feats = [rng.standard_normal((n, D)).astype(np.float32) for n in lens]
+    posts = [[[(int(rng.integers(0, A)), 1.0)] for _ in range(n)] for n in lens]
+    (tmp_path / "feats.ark").write_bytes(kf.archive([(k, kf.matrix_bin(f)) for k, f in zip(keys, feats)]))
+    (tmp_path / "post.ark").write_bytes(kf.archive([(k, kf.posterior_bin(p)) for k, p in zip(keys, posts)]))
+    lr = 0.4
+    p = tool("aslp-nnet-train-blstm-streams", "--learn-rate=%g" % lr, "--momentum=0.9", "--num-stream=%d" % S, "ark:%s" % (tmp_path / "feats.ark"),
+             "ark:%s" % (tmp_path / "post.ark"), str(tmp_path / "b.init"), str(tmp_path / "b.out"))
+    assert b"Done 7 files, 0 with no tgt_mats, 0 with other errors. [TRAINING, NOT-RANDOMIZED" in p.stderr
+    net = aslp.Nnet.Read(tmp_path / "b.init")
+    xent = aslp.Xent()
+    todo = list(range(n_utt))
+    while todo:
+        grp, todo = todo[:S], todo[S:]
+        n, mx = len(grp), max(lens[i] for i in grp)
+        x = np.zeros((n * mx, D), np.float32)
+        tgt = np.zeros((n * mx, A), np.float32)
+        wgt = np.zeros(n * mx, np.float32)
+        for s, i in enumerate(grp):
+            rows = np.arange(lens[i]) * n + s
+            x[rows] = feats[i]
+            tgt[rows, [fr[0][0] for fr in posts[i]]] = 1.0
+            wgt[rows] = 1.0
+        net.SetSeqLengths([lens[i] for i in grp])
+        net.SetTrainOptions(learn_rate=np.float32(lr) / np.float32(sum(lens[i] for i in grp)), momentum=0.9)
+        y = net.Propagate(torch.from_numpy(x).to(dev))
+        diff = torch.empty_like(y)
+        xent.Eval(torch.from_numpy(wgt).to(dev), y, diff, targets=torch.from_numpy(tgt).to(dev))
+        net.Backpropagate(diff)
+    assert np.array_equal(aslp.Nnet.Read(tmp_path / "b.out").GetParams(), net.GetParams())
+    assert xent.Report().splitlines()[1] in p.stderr.decode()
