@@ -119,3 +119,23 @@ def test_lc_blstm_worker_tool_group_of_one(aslp, dev, tmp_path):
     p = tool("aslp-nnet-train-lc-blstm-streams-worker", *common, "--right_splice=3", "--sync-period=20", *io, str(tmp_path / "b.nnet"))
     assert b"synchronize once" in p.stderr and b"All worker finished their data" in p.stderr
     assert np.array_equal(aslp.Nnet.Read(tmp_path / "a.nnet").GetParams(), aslp.Nnet.Read(tmp_path / "b.nnet").GetParams())
+
+
+def test_lstm_stream_worker_tool_group_of_one(aslp, dev, tmp_path):
+    """aslp-nnet-train-lstm-stream-worker with one BSP rank equals aslp-nnet-train-lstm-streams bit for bit."""
+    from test_tools_gpu import LSTM_PROTO
+    (tmp_path / "l.proto").write_text(LSTM_PROTO)
+    tool("aslp-nnet-init", "--seed=51", str(tmp_path / "l.proto"), str(tmp_path / "l.init"))
+    rng = np.random.default_rng(22)
+    keys = ["s%02d" % i for i in range(7)]
+    lens = [int(x) for x in rng.integers(4, 20, 7)]
+    feats = [rng.standard_normal((n, 12)).astype(np.float32) for n in lens]
+    posts = [[[(int(rng.integers(0, 10)), 1.0)] for _ in range(n)] for n in lens]
+    (tmp_path / "feats.ark").write_bytes(kf.archive([(k, kf.matrix_bin(f)) for k, f in zip(keys, feats)]))
+    (tmp_path / "post.ark").write_bytes(kf.archive([(k, kf.posterior_bin(p)) for k, p in zip(keys, posts)]))
+    common = ["--learn-rate=0.02", "--momentum=0.9", "--num-stream=3", "--batch-size=5", "--targets-delay=2"]
+    io = ["ark:%s" % (tmp_path / "feats.ark"), "ark:%s" % (tmp_path / "post.ark"), str(tmp_path / "l.init")]
+    tool("aslp-nnet-train-lstm-streams", *common, *io, str(tmp_path / "a.nnet"))
+    p = tool("aslp-nnet-train-lstm-stream-worker", *common, "--sync-period=12", "--verbose=2", *io, str(tmp_path / "b.nnet"))
+    assert b"synchronize once" in p.stderr and b"All worker finished their data" in p.stderr
+    assert np.array_equal(aslp.Nnet.Read(tmp_path / "a.nnet").GetParams(), aslp.Nnet.Read(tmp_path / "b.nnet").GetParams())
