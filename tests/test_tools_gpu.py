@@ -729,3 +729,32 @@ def test_blstm_streams_tool_matches_api(aslp, dev, tmp_path):
         net.Backpropagate(diff)
     assert np.array_equal(aslp.Nnet.Read(tmp_path / "b.out").GetParams(), net.GetParams())
     assert xent.Report().splitlines()[1] in p.stderr.decode()
+
+
+def test_feature_transform_option(aslp, oracle, dev, tmp_path):
+    """--feature-transform (a Splice net in front of the model, as the recipes build it): aslp-nnet-train-simple and
+    aslp-nnet-forward with the transform equal the same tools fed with features spliced beforehand."""
+    D, ctx = 8, 2
+    tr = "<NnetProto>\n<Splice> <InputDim> %d <OutputDim> %d <BuildVector> -%d:%d </BuildVector>\n</NnetProto>\n" % (D, D * (2 * ctx + 1), ctx, ctx)
+    (tmp_path / "tr.proto").write_text(tr)
+    tool("aslp-nnet-init", str(tmp_path / "tr.proto"), str(tmp_path / "tr.nnet"))
+    in_dim = D * (2 * ctx + 1)
+    d, path = make_dnn(oracle, tmp_path, in_dim, 32, 1, 12, 0, 16, seed=3)
+    oracle.lib.orc_dnn_destroy(d)
+    rng = np.random.default_rng(31)
+    keys = ["t%d" % i for i in range(5)]
+    lens = [int(x) for x in rng.integers(20, 40, 5)]
+    raw = [rng.standard_normal((n, D)).astype(np.float32) for n in lens]
+    posts = [[[(int(rng.integers(0, 12)), 1.0)] for _ in range(n)] for n in lens]
+    spliced = [np.concatenate([f[np.clip(np.arange(len(f)) + o, 0, len(f) - 1)] for o in range(-ctx, ctx + 1)], 1) for f in raw]
+    (tmp_path / "raw.ark").write_bytes(kf.archive([(k, kf.matrix_bin(f)) for k, f in zip(keys, raw)]))
+    (tmp_path / "spl.ark").write_bytes(kf.archive([(k, kf.matrix_bin(f)) for k, f in zip(keys, spliced)]))
+    (tmp_path / "post.ark").write_bytes(kf.archive([(k, kf.posterior_bin(p)) for k, p in zip(keys, posts)]))
+    opts = ["--learn-rate=0.01", "--minibatch-size=16", "--randomizer-size=60", "--randomizer-seed=4"]
+    tool("aslp-nnet-train-simple", *opts, "--feature-transform=%s" % (tmp_path / "tr.nnet"), "ark:%s" % (tmp_path / "raw.ark"),
+         "ark:%s" % (tmp_path / "post.ark"), str(path), str(tmp_path / "a.nnet"))
+    tool("aslp-nnet-train-simple", *opts, "ark:%s" % (tmp_path / "spl.ark"), "ark:%s" % (tmp_path / "post.ark"), str(path), str(tmp_path / "b.nnet"))
+    assert np.array_equal(aslp.Nnet.Read(tmp_path / "a.nnet").GetParams(), aslp.Nnet.Read(tmp_path / "b.nnet").GetParams())
+    tool("aslp-nnet-forward", "--feature-transform=%s" % (tmp_path / "tr.nnet"), str(tmp_path / "a.nnet"), "ark:%s" % (tmp_path / "raw.ark"), "ark:%s" % (tmp_path / "fa.ark"))
+    tool("aslp-nnet-forward", str(tmp_path / "a.nnet"), "ark:%s" % (tmp_path / "spl.ark"), "ark:%s" % (tmp_path / "fb.ark"))
+    assert (tmp_path / "fa.ark").read_bytes() == (tmp_path / "fb.ark").read_bytes()
