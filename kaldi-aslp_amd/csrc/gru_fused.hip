@@ -30,6 +30,16 @@ __global__ void __launch_bounds__(256) gru_step_fwd1(float *__restrict__ y, cons
   __shared__ float red[4][32 * kPad];
   const int c0 = blockIdx.x * 16, s0 = blockIdx.y * 32;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
+  // epilogue operands, requested before the product so their latency hides under it
+  // all loads of this thread's (stream, cell) pairs first, stores last: a store in between would fence the later loads behind
+  // it (possible aliasing), i.e. one more round of memory latency per pair
+  float xz[2], xr[2], hp[2];
+#pragma unroll
+  for (int p = 0; p < 2; p++) {
+    const int idx = threadIdx.x + 256 * p, sl = idx >> 4, cc = idx & 15;
+    const int s = min(s0 + sl, S - 1), c = min(c0 + cc, H - 1);
+    xz[p] = y[(long)s * ld + c]; xr[p] = y[(long)s * ld + H + c]; hp[p] = yp[(long)s * ld + 4 * H + c];
+  }
   {
     const int gate = l31 >> 4, cell = min(c0 + (l31 & 15), H - 1);
     const float *arow = yp + (long)min(s0 + l31, S - 1) * ld + 4 * H;  // h(t-1)
@@ -46,10 +56,10 @@ __global__ void __launch_bounds__(256) gru_step_fwd1(float *__restrict__ y, cons
     const int s = s0 + sl, c = c0 + cc;
     if (s >= S || c >= H) continue;
     float *ys = y + (long)s * ld;
-    const float z = sigmoid_ref(ys[c] + tile_sum(red, sl, cc)), r = sigmoid_ref(ys[H + c] + tile_sum(red, sl, 16 + cc));
+    const float z = sigmoid_ref(xz[p] + tile_sum(red, sl, cc)), r = sigmoid_ref(xr[p] + tile_sum(red, sl, 16 + cc));
     ys[c] = z;
     ys[H + c] = r;
-    ys[3 * H + c] = r * yp[(long)s * ld + 4 * H + c];
+    ys[3 * H + c] = r * hp[p];
   }
 }
 
@@ -58,6 +68,14 @@ __global__ void __launch_bounds__(256) gru_step_fwd2(float *__restrict__ y, cons
   __shared__ float red[4][32 * kPad];
   const int c0 = blockIdx.x * 32, s0 = blockIdx.y * 32;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
+  // epilogue operands, requested before the product so their latency hides under it
+  float hp[4], zz[4], xm[4];
+#pragma unroll
+  for (int p = 0; p < 4; p++) {  // loads first (see gru_step_fwd1)
+    const int idx = threadIdx.x + 256 * p, sl = idx >> 5, cc = idx & 31;
+    const int s = min(s0 + sl, S - 1), c = min(c0 + cc, H - 1);
+    hp[p] = yp[(long)s * ld + 4 * H + c]; zz[p] = y[(long)s * ld + c]; xm[p] = y[(long)s * ld + 2 * H + c];
+  }
   {
     const float *arow = y + (long)min(s0 + l31, S - 1) * ld + 3 * H;  // g(t)
     const float *brow = w_m_g + (long)min(c0 + l31, H - 1) * ldw;
@@ -73,10 +91,9 @@ __global__ void __launch_bounds__(256) gru_step_fwd2(float *__restrict__ y, cons
     const int s = s0 + sl, c = c0 + cc;
     if (s >= S || c >= H) continue;
     float *ys = y + (long)s * ld;
-    const float hp = yp[(long)s * ld + 4 * H + c], z = ys[c];
-    const float m = tanh_ref(ys[2 * H + c] + tile_sum(red, sl, cc));
+    const float m = tanh_ref(xm[p] + tile_sum(red, sl, cc));
     ys[2 * H + c] = m;
-    ys[4 * H + c] = hp - hp * z + z * m;
+    ys[4 * H + c] = hp[p] - hp[p] * zz[p] + zz[p] * m;
   }
 }
 
@@ -87,6 +104,17 @@ __global__ void __launch_bounds__(64 * kBwd1Waves) gru_step_bwd1(float *__restri
   __shared__ float red[kBwd1Waves][32 * kPad];
   const int c0 = blockIdx.x * 32, s0 = blockIdx.y * 32;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
+  // epilogue operands, requested before the product so their latency hides under it
+  constexpr int NP = 1024 / (64 * kBwd1Waves);
+  float v_dhn[NP], v_dh[NP], v_zn[NP], v_dgn[NP], v_rn[NP], v_m[NP], v_z[NP];
+#pragma unroll
+  for (int p = 0; p < NP; p++) {  // loads first (see gru_step_fwd1)
+    const int idx = threadIdx.x + 64 * kBwd1Waves * p, sl = idx >> 5, cc = idx & 31;
+    const long o = (long)min(s0 + sl, S - 1) * ld;
+    const int c = min(c0 + cc, H - 1);
+    v_dhn[p] = dn[o + 4 * H + c]; v_dh[p] = d[o + 4 * H + c]; v_zn[p] = yn[o + c]; v_dgn[p] = dn[o + 3 * H + c]; v_rn[p] = yn[o + H + c];
+    v_m[p] = y[o + 2 * H + c]; v_z[p] = y[o + c];
+  }
   {
     const float *arow = dn + (long)min(s0 + l31, S - 1) * ld;  // [d_z | d_r](t+1)
     const float *brow = w_t + (long)min(c0 + l31, H - 1) * ldwt;
@@ -97,15 +125,14 @@ __global__ void __launch_bounds__(64 * kBwd1Waves) gru_step_bwd1(float *__restri
   }
   __syncthreads();
 #pragma unroll
-  for (int p = 0; p < 1024 / (64 * kBwd1Waves); p++) {
+  for (int p = 0; p < NP; p++) {
     const int idx = threadIdx.x + 64 * kBwd1Waves * p, sl = idx >> 5, cc = idx & 31;
     const int s = s0 + sl, c = c0 + cc;
     if (s >= S || c >= H) continue;
     const long o = (long)s * ld;
-    const float dhn = dn[o + 4 * H + c];
-    const float dh = d[o + 4 * H + c] + tile_sum<kBwd1Waves>(red, sl, cc) + dhn - dhn * yn[o + c] + dn[o + 3 * H + c] * yn[o + H + c];
+    const float dh = v_dh[p] + tile_sum<kBwd1Waves>(red, sl, cc) + v_dhn[p] - v_dhn[p] * v_zn[p] + v_dgn[p] * v_rn[p];
     d[o + 4 * H + c] = dh;
-    d[o + 2 * H + c] = dtanh(y[o + 2 * H + c], dh * y[o + c]);
+    d[o + 2 * H + c] = dtanh(v_m[p], dh * v_z[p]);
   }
 }
 
@@ -115,6 +142,15 @@ __global__ void __launch_bounds__(256) gru_step_bwd2(float *__restrict__ d, cons
   __shared__ float red[4][32 * kPad];
   const int c0 = blockIdx.x * 32, s0 = blockIdx.y * 32;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
+  // epilogue operands, requested before the product so their latency hides under it
+  float v_hp[4], v_dh[4], v_r[4], v_z[4], v_m[4];
+#pragma unroll
+  for (int p = 0; p < 4; p++) {  // loads first (see gru_step_fwd1)
+    const int idx = threadIdx.x + 256 * p, sl = idx >> 5, cc = idx & 31;
+    const long o = (long)min(s0 + sl, S - 1) * ld;
+    const int c = min(c0 + cc, H - 1);
+    v_hp[p] = yp[o + 4 * H + c]; v_dh[p] = d[o + 4 * H + c]; v_r[p] = y[o + H + c]; v_z[p] = y[o + c]; v_m[p] = y[o + 2 * H + c];
+  }
   {
     const float *arow = d + (long)min(s0 + l31, S - 1) * ld + 2 * H;  // d_m(t)
     const float *brow = w_t + (long)min(c0 + l31, H - 1) * ldwt;
@@ -131,10 +167,9 @@ __global__ void __launch_bounds__(256) gru_step_bwd2(float *__restrict__ d, cons
     if (s >= S || c >= H) continue;
     const long o = (long)s * ld;
     const float dg = tile_sum(red, sl, cc);
-    const float hp = yp[o + 4 * H + c], dh = d[o + 4 * H + c];
     d[o + 3 * H + c] = dg;
-    d[o + H + c] = dsigm(y[o + H + c], dg * hp);
-    d[o + c] = dsigm(y[o + c], dh * y[o + 2 * H + c] - dh * hp);
+    d[o + H + c] = dsigm(v_r[p], dg * v_hp[p]);
+    d[o + c] = dsigm(v_z[p], v_dh[p] * v_m[p] - v_dh[p] * v_hp[p]);
   }
 }
 

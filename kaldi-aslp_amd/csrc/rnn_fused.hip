@@ -131,26 +131,36 @@ __global__ void __launch_bounds__(kBlock) lstm_step_bwd_cell(aslp_lstm_step a, c
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
     const int s = idx / C, c = idx - s * C;
     const long o_ = (long)s * ld;
+    // every load of this (stream, cell) first, stores last: the compiler cannot move a load above a store through a pointer
+    // that might alias it, and a store in the middle would split the loads into two dependent rounds of memory latency
     float dm = D.d_cur[o_ + om + c];
+    float psum[kKQ];
     if (with_partial) {
       const float *p = partial + ((long)blockIdx.y * kKQ * S + s) * C + c;
 #pragma unroll
-      for (int q = 0; q < kKQ; q++) dm += p[(long)q * S * C];
-      D.d_cur[o_ + om + c] = dm;  // the reference's d_m (lc.h:793) -- kept for InfoGradient-style dumps
+      for (int q = 0; q < kKQ; q++) psum[q] = p[(long)q * S * C];
     }
     const float yo = D.y_cur[o_ + oo + c], yh = D.y_cur[o_ + oh + c], yg = D.y_cur[o_ + og + c], yf = D.y_cur[o_ + of + c];
+    const float yi = CIFG ? 0.f : D.y_cur[o_ + oi + c];
+    const float dn_c = D.d_next[o_ + oc + c], yn_f = D.y_next[o_ + of + c], dn_f = D.d_next[o_ + of + c];
+    const float dn_i = CIFG ? 0.f : D.d_next[o_ + oi + c];
+    const float pi = CIFG ? 0.f : D.peep_i[c], pf = D.peep_f[c], po = D.peep_o[c];
+    const float cprev = D.y_prev[o_ + oc + c];
+    if (with_partial) {
+#pragma unroll
+      for (int q = 0; q < kKQ; q++) dm += psum[q];
+      D.d_cur[o_ + om + c] = dm;  // the reference's d_m (lc.h:793) -- kept for InfoGradient-style dumps
+    }
     const float dh = dtanh(yh, dm * yo);
     const float dov = dsigm(yo, dm * yh);
-    float dc = dh + D.d_next[o_ + oc + c] * D.y_next[o_ + of + c];
-    if (!CIFG) dc += D.d_next[o_ + oi + c] * D.peep_i[c];
-    dc += D.d_next[o_ + of + c] * D.peep_f[c];
-    dc += dov * D.peep_o[c];
-    const float cprev = D.y_prev[o_ + oc + c];
+    float dc = dh + dn_c * yn_f;
+    if (!CIFG) dc += dn_i * pi;
+    dc += dn_f * pf;
+    dc += dov * po;
     D.d_cur[o_ + oh + c] = dh;
     D.d_cur[o_ + oo + c] = dov;
     D.d_cur[o_ + oc + c] = dc;
     if (!CIFG) {
-      const float yi = D.y_cur[o_ + oi + c];
       D.d_cur[o_ + of + c] = dsigm(yf, dc * cprev);
       D.d_cur[o_ + oi + c] = dsigm(yi, dc * yg);
       D.d_cur[o_ + og + c] = dtanh(yg, dc * yi);
