@@ -24,7 +24,8 @@ def tool(name, *args, ok=True):
     if not os.path.exists(exe):  # a tree without the built tools (they are not in git): build them, in-tree, once
         subprocess.run(["make", "-C", os.path.join(ROOT, "kaldi-aslp_amd"), "-j8"], check=True, capture_output=True, timeout=1800)
     assert os.path.exists(exe), "%s not built (make -C kaldi-aslp_amd)" % exe
-    p = subprocess.run([exe] + list(args), capture_output=True, timeout=300)
+    # generous: on a freshly started box the first process that maps librccl / the HIP code objects can take minutes to page in
+    p = subprocess.run([exe] + list(args), capture_output=True, timeout=1800)
     if ok:
         assert p.returncode == 0, p.stderr.decode()[-3000:]
     return p
