@@ -21,11 +21,16 @@ namespace aslp {
 typedef float BaseFloat;
 typedef int32_t int32;
 
+// "name:" of the running tool (empty inside the library / Python); set by ParseOptions::Read like Kaldi's g_program_name
+const char *ProgramName();
+void SetProgramName(const char *argv0);
+
 class MessageLogger {
  public:
   MessageLogger(const char *sev, const char *func, const char *file, int line, bool fatal) : fatal_(fatal) {
     const char *b = std::strrchr(file, '/');
-    ss_ << sev << " (" << func << "():" << (b ? b + 1 : file) << ':' << line << ") ";
+    // "LOG (program:function():file:line) message", the program part once ParseOptions::Read has seen argv[0]
+    ss_ << sev << " (" << ProgramName() << func << "():" << (b ? b + 1 : file) << ':' << line << ") ";
   }
   ~MessageLogger() noexcept(false) {
     if (fatal_) throw std::runtime_error(ss_.str());

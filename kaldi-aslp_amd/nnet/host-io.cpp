@@ -10,6 +10,13 @@ namespace aslp {
 
 int g_verbose_level = 0;
 
+static std::string g_program_name;
+const char *ProgramName() { return g_program_name.c_str(); }
+void SetProgramName(const char *argv0) {
+  const char *c = std::strrchr(argv0, '/');
+  g_program_name = std::string(c ? c + 1 : argv0) + ":";
+}
+
 // ---- host matrix / vector I/O (matrix/kaldi-matrix.cc:1201-1430, kaldi-vector.cc:1094-1228) ------
 void HostMatrix::Write(std::ostream &os, bool binary) const {
   if (!os.good()) ASLP_ERR << "Failed to write matrix to stream: stream not good";

@@ -162,6 +162,7 @@ void ParseOptions::ReadConfigFile(const std::string &filename) {  // parse-optio
 int ParseOptions::Read(int argc, const char *const *argv) {
   argc_ = argc;
   argv_ = argv;
+  if (argc > 0) SetProgramName(argv[0]);
   std::string key, value;
   int i;
   for (i = 1; i < argc; i++) {  // first pass: config files and --help
