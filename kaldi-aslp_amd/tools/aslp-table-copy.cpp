@@ -20,10 +20,18 @@ static int Copy(const std::string &rspecifier, const std::string &wspecifier, bo
       for (; !reader.Done(); reader.Next()) keys.push_back(reader.Key());
     }
     RandomAccessTableReader<Holder> ra(rspecifier);
-    for (auto it = keys.rbegin(); it != keys.rend(); ++it)
-      if (!ra.HasKey(*it)) ASLP_ERR << "key " << *it << " not found by the random-access reader";
-    if (ra.HasKey("<no-such-key>")) ASLP_ERR << "random-access reader found a key that is not there";
-    for (const std::string &k : keys) { writer.Write(k, ra.Value(k)); n++; }
+    RspecifierOptions opts;
+    ClassifyRspecifier(rspecifier, NULL, &opts);
+    if (!opts.called_sorted) {  // any order is allowed: ask backwards first, and for a key that is not there
+      for (auto it = keys.rbegin(); it != keys.rend(); ++it)
+        if (!ra.HasKey(*it)) ASLP_ERR << "key " << *it << " not found by the random-access reader";
+      if (ra.HasKey("<no-such-key>")) ASLP_ERR << "random-access reader found a key that is not there";
+    }
+    for (const std::string &k : keys) {  // "cs": keys are asked for in sorted order, as promised
+      if (!ra.HasKey(k)) ASLP_ERR << "key " << k << " not found by the random-access reader";
+      writer.Write(k, ra.Value(k));
+      n++;
+    }
   }
   if (!writer.Close()) ASLP_ERR << "error closing " << wspecifier;
   return n;

@@ -279,7 +279,16 @@ class RandomAccessTableReader {
     return true;
   }
   bool FindInArchive(const std::string &key) {
+    // "s, cs" (archive sorted by key, keys asked for in sorted order: kaldi-table.h's sorted random-access mode): nothing
+    // before the key being asked for can be asked for again, so it is released instead of kept for the whole run
+    if (opts_.sorted && opts_.called_sorted && !map_.empty()) {
+      for (auto it = map_.begin(); it != map_.end();) {
+        if (it->first < key) it = map_.erase(it);
+        else ++it;
+      }
+    }
     if (map_.count(key)) return true;
+    if (opts_.sorted && !last_key_read_.empty() && key < last_key_read_) return false;  // sorted archive: already past it
     while (!eof_) {
       std::istream &is = input_.Stream();
       std::string k;
@@ -298,6 +307,7 @@ class RandomAccessTableReader {
       }
       if (map_.count(k)) ASLP_ERR << "Error in RandomAccessTableReader: duplicate key " << k << " in archive " << PrintableRxfilename(rxfilename_);
       map_[k].reset(new T(std::move(h.Value())));
+      last_key_read_ = k;
       if (k == key) return true;
     }
     return false;
@@ -309,7 +319,7 @@ class RandomAccessTableReader {
   std::unordered_map<std::string, std::string> script_map_;
   std::unordered_map<std::string, std::unique_ptr<T>> map_;
   Holder cur_;
-  std::string cur_key_;
+  std::string cur_key_, last_key_read_;
   bool cur_valid_ = false, open_ = false, eof_ = false, error_ = false;
 };
 
