@@ -208,6 +208,17 @@ void aslp_lstm_cell_forward(float *y_cur, const float *y_prev, int ld, int S, in
                             const float *peep_o, const int32_cuda *seq_lengths, int t);
 void aslp_lstm_cell_backward(float *d_cur, const float *d_next, const float *y_cur, const float *y_next, const float *y_prev, int ld, int S,
                              int C, int cifg, const float *peep_i, const float *peep_f, const float *peep_o);
+/* Vector gradients of a recurrent component, up to 4 in ONE launch (nnet-blstm-projected-streams-lc.h:1005-1058: the bias
+ * gradient AddRowSumMat, the peephole gradients AddDiagMatMat, each followed by ApplyFloor / ApplyCeiling; :1092-1104 the step):
+ *   corr[c] = clamp( sum_r d[r*ldd + c] * (x ? x[r*ldx + c] : 1) + mmt * corr[c], -clip, clip )     (clip <= 0: no clamp)
+ *   param[c] += neg_lr * corr[c]                                                                   (neg_lr == 0: no step) */
+typedef struct aslp_rnn_vec_grad_ {
+  const float *d;          /* first row / first column of the diff block */
+  const float *x; int ldx; /* element-wise weight block (NULL: plain column sum) */
+  int n;                   /* columns */
+  float *corr, *param;
+} aslp_rnn_vec_grad;
+void aslp_rnn_vec_grads(const aslp_rnn_vec_grad *jobs, int njobs, int ldd, int rows, float mmt, float clip, float neg_lr);
 /* Fused recurrence step (csrc/rnn_fused.hip): ONE launch per timestep covers every direction.
  * forward : gates(t) += m(t-1) * w^T with w = W_eff = W_r W_rm [G*C x C] (W_r itself without projection), then the
  *           whole gate block of aslp_lstm_cell_forward; the projection r = m W_rm^T is NOT on the sequential path.

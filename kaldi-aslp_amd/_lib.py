@@ -25,6 +25,11 @@ class GemmEpilogue(C.Structure):
                 ("colsum", C.c_void_p), ("colsum_beta", C.c_float), ("colsum_w", C.c_void_p), ("colsum_w_alpha", C.c_float)]
 
 
+class RnnVecGrad(C.Structure):
+    """aslp_rnn_vec_grad (include/aslp_kernels.h)"""
+    _fields_ = [("d", C.c_void_p), ("x", C.c_void_p), ("ldx", C.c_int), ("n", C.c_int), ("corr", C.c_void_p), ("param", C.c_void_p)]
+
+
 class CtcComputeInfo(C.Structure):
     """warp-ctc/include/ctc.h:45-60 (ctcComputeInfo: loc + union{num_threads, stream})"""
     _fields_ = [("loc", C.c_int), ("stream_or_threads", C.c_void_p)]
@@ -122,6 +127,7 @@ _sig("aslp_softmax_xent_eval", None, _vp, _md, _vp, _i, _vp, _vp, _vp, _i, _vp, 
 _sig("aslp_dropout_forward", None, _vp, _i, _vp, _md, _vp, _i, _f, C.c_ulonglong)
 _sig("aslp_dropout_backward", None, _vp, _i, _vp, _md, _vp, _i, _f)
 _sig("aslp_apply_clamp", None, _vp, _md, _f, _f)
+_sig("aslp_rnn_vec_grads", None, C.POINTER(RnnVecGrad), _i, _i, _i, _f, _f, _f)
 _sig("aslp_scatter_add", None, _vp, _md, _vp, _vp, _vp, _i)
 _sig("aslp_splice_backward", None, _vp, _md, _vp, _i, _vp, _i)
 _sig("aslp_diff_relu", None, _vp, _vp, _vp, _md, _i, _i)

@@ -138,6 +138,59 @@ __global__ void __launch_bounds__(kBlock) gru_bwd2(float *__restrict__ d, const 
   }
 }
 
+// Vector gradients of a recurrent component in one launch: every job is a column reduction over the T*S rows of the diff buffer,
+// optionally weighted element-wise by an activation block (the peephole gradients diag(d^T c)), followed by momentum, the
+// element-wise clip and -- when the caller folds the update in -- the SGD step.  16 columns x 64 row groups per block (a
+// 64-byte segment per row and wave quarter; 7C/16 blocks, enough to cover the chip at C = 512); the 64 partial sums of a
+// column meet in LDS in a fixed order, so results do not depend on the launch.
+constexpr int kVgCols = 16, kVgGroups = 64, kVgMaxJobs = 4;
+static_assert(kVgGroups == 64, "the LDS fold below is written for 64 row groups");
+struct VecGradJobs { aslp_rnn_vec_grad j[kVgMaxJobs]; int first_block[kVgMaxJobs + 1]; int njobs; };
+
+__global__ void __launch_bounds__(kVgCols * kVgGroups) rnn_vec_grads_kernel(VecGradJobs jobs, int ldd, int rows, float mmt, float clip, float neg_lr) {
+  __shared__ float part[kVgGroups][kVgCols];
+  int k = 0;
+  while (k + 1 < jobs.njobs && (int)blockIdx.x >= jobs.first_block[k + 1]) k++;
+  const aslp_rnn_vec_grad job = jobs.j[k];
+  const int cx = threadIdx.x & (kVgCols - 1), ry = threadIdx.x / kVgCols;
+  const int col = ((int)blockIdx.x - jobs.first_block[k]) * kVgCols + cx;
+  float acc = 0.0f;
+  if (col < job.n) {
+    const float *dp = job.d + col;
+    if (job.x != nullptr) {
+      const float *xp = job.x + col;
+      int r = ry;
+      for (; r + 3 * kVgGroups < rows; r += 4 * kVgGroups) {
+        const float d0 = dp[(long)r * ldd], d1 = dp[(long)(r + kVgGroups) * ldd], d2 = dp[(long)(r + 2 * kVgGroups) * ldd], d3 = dp[(long)(r + 3 * kVgGroups) * ldd];
+        const float x0 = xp[(long)r * job.ldx], x1 = xp[(long)(r + kVgGroups) * job.ldx], x2 = xp[(long)(r + 2 * kVgGroups) * job.ldx], x3 = xp[(long)(r + 3 * kVgGroups) * job.ldx];
+        acc += d0 * x0; acc += d1 * x1; acc += d2 * x2; acc += d3 * x3;
+      }
+      for (; r < rows; r += kVgGroups) acc += dp[(long)r * ldd] * xp[(long)r * job.ldx];
+    } else {
+      int r = ry;
+      for (; r + 3 * kVgGroups < rows; r += 4 * kVgGroups) {
+        const float d0 = dp[(long)r * ldd], d1 = dp[(long)(r + kVgGroups) * ldd], d2 = dp[(long)(r + 2 * kVgGroups) * ldd], d3 = dp[(long)(r + 3 * kVgGroups) * ldd];
+        acc += d0; acc += d1; acc += d2; acc += d3;
+      }
+      for (; r < rows; r += kVgGroups) acc += dp[(long)r * ldd];
+    }
+  }
+  part[ry][cx] = acc;
+  __syncthreads();
+  // fold 64 -> 4 partials per column with all threads, then one thread per column finishes
+  if (ry < 16) part[ry][cx] += part[ry + 16][cx] + part[ry + 32][cx] + part[ry + 48][cx];
+  __syncthreads();
+  if (ry < 4) part[ry][cx] += part[ry + 4][cx] + part[ry + 8][cx] + part[ry + 12][cx];
+  __syncthreads();
+  if (ry == 0 && col < job.n) {
+    float v = (part[0][cx] + part[1][cx]) + (part[2][cx] + part[3][cx]);
+    if (mmt != 0.0f) v += mmt * job.corr[col];
+    if (clip > 0.0f) v = v < -clip ? -clip : (v > clip ? clip : v);
+    job.corr[col] = v;
+    if (neg_lr != 0.0f) job.param[col] += neg_lr * v;
+  }
+}
+
 }  // namespace
 }  // namespace aslp
 
@@ -180,6 +233,25 @@ void aslp_gru_backward2(float *d_cur, const float *y_cur, const float *y_prev, i
   if (S <= 0 || H <= 0) return;
   hipLaunchKernelGGL(gru_bwd2, dim3(grid_for((long)S * H)), dim3(kBlock), 0, cur_stream(), d_cur, y_cur, y_prev, ld, S, H);
   check_launch("gru_backward2");
+}
+
+void aslp_rnn_vec_grads(const aslp_rnn_vec_grad *jobs, int njobs, int ldd, int rows, float mmt, float clip, float neg_lr) {
+  if (njobs <= 0) return;
+  if (njobs > kVgMaxJobs) { set_error("aslp_rnn_vec_grads: at most 4 jobs per launch"); return; }
+  VecGradJobs a;
+  int blocks = 0;
+  a.njobs = 0;
+  for (int k = 0; k < njobs; k++) {
+    if (jobs[k].n <= 0) continue;
+    a.j[a.njobs] = jobs[k];
+    a.first_block[a.njobs++] = blocks;
+    blocks += (jobs[k].n + kVgCols - 1) / kVgCols;
+  }
+  if (blocks == 0) return;
+  for (int k = a.njobs; k <= kVgMaxJobs; k++) a.first_block[k] = blocks;
+  for (int k = a.njobs; k < kVgMaxJobs; k++) a.j[k] = a.j[0];
+  hipLaunchKernelGGL(rnn_vec_grads_kernel, dim3(blocks), dim3(kVgCols * kVgGroups), 0, cur_stream(), a, ldd, rows, mmt, clip, neg_lr);
+  check_launch("rnn_vec_grads");
 }
 
 }  // extern "C"

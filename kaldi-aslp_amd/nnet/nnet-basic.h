@@ -595,9 +595,7 @@ class BatchNormalization : public UpdatableComponent {
   void BackpropagateFnc(const CuMatrixBase &in, const CuMatrixBase &, const CuMatrixBase &out_diff, CuMatrixBase *in_diff) {  // :222-277
     Backward(in, out_diff, in_diff ? in_diff->Data() : nullptr, in_diff ? in_diff->Stride() : 0, nullptr, 0);
   }
-  // The executor calls this right before a Backpropagate that it follows with Update (Nnet::Backpropagate always
-  // does): the SGD step of scale / shift is then taken inside the backward statistics finalize and the next Update
-  // call is a no-op.
+  // the SGD step of scale / shift is then taken inside the backward statistics finalize (see nnet-component.h)
   void FoldNextUpdateIntoBackprop() { fold_update_ = true; }
   // Executor peephole (nnet-nnet.cpp): a Sigmoid that is this component's only consumer is folded into the write
   // pass (forward) and into the statistics / write passes (backward); the BN output itself is never materialised.

@@ -126,6 +126,10 @@ class Component {
   // everything on one stream -- a second active stream costs such a chain more than the overlap gives (measured on the
   // LC-BLSTM net: 7.85 ms/step on one stream, 8.61 with the output layer's weight gradient on a side stream)
   virtual bool LatencyBoundPasses() const { return false; }
+  // The executor calls this right before a Backpropagate that it follows with Update (Nnet::Backpropagate always does).
+  // A component that forms its gradients inside Backpropagate may then take the SGD step there too (in the epilogue of
+  // the gradient kernels) and treat the next Update call as a no-op; the default ignores the hint.
+  virtual void FoldNextUpdateIntoBackprop() {}
 
  protected:
   virtual void FeedforwardFnc(const CuMatrixBase &in, CuMatrixBase *out) { PropagateFnc(in, out); }

@@ -204,8 +204,7 @@ void Nnet::Backpropagate(const std::vector<const CuMatrixBase *> &out_diff, std:
         dynamic_cast<BatchNormalization *>(components_[i])->FoldNextUpdateIntoBackprop();
         dynamic_cast<BatchNormalization *>(components_[i])->BackpropagateWithSigmoid(*in_view_[i], output_buf_[fs], output_diff_buf_[fs], target);
       } else {
-        if (fuse_layers_ && components_[i]->GetType() == Component::kBatchNormalization)
-          dynamic_cast<BatchNormalization *>(components_[i])->FoldNextUpdateIntoBackprop();
+        if (fuse_layers_) components_[i]->FoldNextUpdateIntoBackprop();
         components_[i]->Backpropagate(*in_view_[i], *out_view_[i], output_diff_buf_[i], target);
       }
       in_diff_view_[i] = target;

@@ -11,9 +11,6 @@ void CheckK() {
   char buf[512];
   if (aslp_get_last_error(buf, sizeof(buf))) ASLP_ERR << buf;
 }
-void ClipVec(CuVector *v, float clip) {
-  if (clip > 0.0 && v->Dim()) { MatrixDim d = {1, v->Dim(), v->Dim()}; aslp_apply_clamp(v->Data(), d, -clip, clip); }
-}
 std::pair<BaseFloat *, int> MatParam(CuMatrix &m) { return std::make_pair(m.Data(), m.NumRows() * m.Stride()); }
 std::pair<BaseFloat *, int> VecParam(CuVector &v) { return std::make_pair(v.Data(), v.Dim()); }
 }  // namespace
@@ -165,25 +162,31 @@ void LstmDir::Backward(const CuMatrixBase &out_diff, int T, int S, bool reverse,
   }
 }
 
-void LstmDir::Grads(const CuMatrixBase &in, int T, int S, bool reverse, const CuMatrix &buf, const CuMatrix &dbuf, float mmt, float clip) {
-  // lc.h:976-1058: corr = grad + mmt * corr, then clip element-wise (the clip rides in the GEMM epilogue)
-  aslp_gemm_epilogue ep = aslp_gemm_epilogue();
-  ep.clip = clip;
+void LstmDir::Grads(const CuMatrixBase &in, int T, int S, bool reverse, const CuMatrix &buf, const CuMatrix &dbuf, float mmt, float clip, float lr_fold) {
+  // lc.h:976-1058: corr = grad + mmt * corr, then clip element-wise (the clip rides in the GEMM epilogue, and with it --
+  // when the executor announced that Update follows -- the step W += -lr * corr of lc.h:1085-1110)
   const int prev0 = (reverse ? 2 : 0) * S;  // recursion-previous row block of t = 1
   CuSubMatrix d_gates(dbuf, S, T * S, 0, GC());
-  w_x_corr.AddMatMat(1.0, d_gates, kTrans, in, kNoTrans, mmt, &ep);
-  w_r_corr.AddMatMat(1.0, d_gates, kTrans, CuSubMatrix(buf, prev0, T * S, OffRec(), Rec()), kNoTrans, mmt, &ep);
-  bias_corr.AddRowSumMat(1.0, d_gates, mmt);
-  CuSubMatrix c_prev(buf, prev0, T * S, OffC(), C), c_cur(buf, S, T * S, OffC(), C);
-  if (!cifg) peep_i_corr.AddDiagMatMat(1.0, CuSubMatrix(dbuf, S, T * S, OffI(), C), kTrans, c_prev, kNoTrans, mmt);
-  peep_f_corr.AddDiagMatMat(1.0, CuSubMatrix(dbuf, S, T * S, OffF(), C), kTrans, c_prev, kNoTrans, mmt);
-  peep_o_corr.AddDiagMatMat(1.0, CuSubMatrix(dbuf, S, T * S, OffO(), C), kTrans, c_cur, kNoTrans, mmt);
-  if (R > 0)
-    w_rm_corr.AddMatMat(1.0, CuSubMatrix(dbuf, S, T * S, OffRec(), R), kTrans, CuSubMatrix(buf, S, T * S, OffM(), C), kNoTrans, mmt, &ep);
-  ClipVec(&bias_corr, clip);
-  if (!cifg) ClipVec(&peep_i_corr, clip);
-  ClipVec(&peep_f_corr, clip);
-  ClipVec(&peep_o_corr, clip);
+  auto wgrad = [&](CuMatrix &corr, CuMatrix &w, const CuMatrixBase &d, const CuMatrixBase &x) {
+    aslp_gemm_epilogue ep = aslp_gemm_epilogue();
+    ep.clip = clip;
+    if (lr_fold != 0.0f) { ep.W = w.Data(); ep.ldw = w.Stride(); ep.w_alpha = -lr_fold; }
+    corr.AddMatMat(1.0, d, kTrans, x, kNoTrans, mmt, &ep);
+  };
+  wgrad(w_x_corr, w_x, d_gates, in);
+  wgrad(w_r_corr, w_r, d_gates, CuSubMatrix(buf, prev0, T * S, OffRec(), Rec()));
+  if (R > 0) wgrad(w_rm_corr, w_rm, CuSubMatrix(dbuf, S, T * S, OffRec(), R), CuSubMatrix(buf, S, T * S, OffM(), C));
+  // bias and peephole gradients (:1005-1058), one launch: column sums of d_gates and of d_{i,f,o} .* c
+  const BaseFloat *d0 = dbuf.RowData(S), *c_prev = buf.RowData(prev0) + OffC(), *c_cur = buf.RowData(S) + OffC();
+  aslp_rnn_vec_grad jobs[4];
+  int n = 0;
+  jobs[n++] = {d0, nullptr, 0, GC(), bias_corr.Data(), bias.Data()};
+  if (!cifg) jobs[n++] = {d0 + OffI(), c_prev, buf.Stride(), C, peep_i_corr.Data(), peep_i.Data()};
+  jobs[n++] = {d0 + OffF(), c_prev, buf.Stride(), C, peep_f_corr.Data(), peep_f.Data()};
+  jobs[n++] = {d0 + OffO(), c_cur, buf.Stride(), C, peep_o_corr.Data(), peep_o.Data()};
+  aslp_rnn_vec_grads(jobs, n, dbuf.Stride(), T * S, mmt, clip, -lr_fold);
+  CheckK();
+  if (lr_fold != 0.0f) eff_dirty = true;
 }
 
 void LstmDir::Update(float lr) {  // lc.h:1085-1110
@@ -456,11 +459,13 @@ void LstmFamily::BackpropagateFnc(const CuMatrixBase &in, const CuMatrixBase &, 
     f_.Backward(CuSubMatrix(out_diff, 0, T * S, 0, rec), T, S, false, f_buf_, &f_dbuf_, in_diff, 0.0);
     if (cfg_.bidir) b_.Backward(CuSubMatrix(out_diff, 0, T * S, rec, rec), T, S, true, b_buf_, &b_dbuf_, in_diff, 1.0);
   }
-  f_.Grads(in, T, S, false, f_buf_, f_dbuf_, mmt, clip_gradient_);
-  if (cfg_.bidir) b_.Grads(in, T, S, true, b_buf_, b_dbuf_, mmt, clip_gradient_);
+  const BaseFloat lr_fold = TakeFoldHint() ? opts_.learn_rate : 0.0f;
+  f_.Grads(in, T, S, false, f_buf_, f_dbuf_, mmt, clip_gradient_, lr_fold);
+  if (cfg_.bidir) b_.Grads(in, T, S, true, b_buf_, b_dbuf_, mmt, clip_gradient_, lr_fold);
 }
 
 void LstmFamily::Update(const CuMatrixBase &, const CuMatrixBase &) {
+  if (SkipFoldedUpdate()) return;
   const BaseFloat lr = opts_.learn_rate;
   f_.Update(lr);
   if (cfg_.bidir) b_.Update(lr);
@@ -629,18 +634,25 @@ void GruStreams::BackpropagateFnc(const CuMatrixBase &in, const CuMatrixBase &, 
   CheckK();
   CuSubMatrix d_zrm(dbuf_, S, T * S, 0, 3 * H);
   in_diff->AddMatMat(1.0, d_zrm, kNoTrans, w_zrm_x_, kNoTrans, 0.0);
-  // gradients with momentum, clipped element-wise (:432-455)
+  // gradients with momentum, clipped element-wise (:432-455); with the executor's fold hint the step of :457-466 rides along
   const BaseFloat mmt = opts_.momentum;
-  aslp_gemm_epilogue ep = aslp_gemm_epilogue();
-  ep.clip = clip_gradient_;
-  w_zrm_x_corr_.AddMatMat(1.0, d_zrm, kTrans, in, kNoTrans, mmt, &ep);
-  bias_corr_.AddRowSumMat(1.0, d_zrm, mmt);
-  w_zr_h_corr_.AddMatMat(1.0, CuSubMatrix(dbuf_, S, T * S, 0, 2 * H), kTrans, CuSubMatrix(buf_, 0, T * S, 4 * H, H), kNoTrans, mmt, &ep);
-  w_m_g_corr_.AddMatMat(1.0, CuSubMatrix(dbuf_, S, T * S, 2 * H, H), kTrans, CuSubMatrix(buf_, S, T * S, 3 * H, H), kNoTrans, mmt, &ep);
-  ClipVec(&bias_corr_, clip_gradient_);
+  const BaseFloat lr_fold = TakeFoldHint() ? opts_.learn_rate : 0.0f;
+  auto wgrad = [&](CuMatrix &corr, CuMatrix &w, const CuMatrixBase &d, const CuMatrixBase &x) {
+    aslp_gemm_epilogue ep = aslp_gemm_epilogue();
+    ep.clip = clip_gradient_;
+    if (lr_fold != 0.0f) { ep.W = w.Data(); ep.ldw = w.Stride(); ep.w_alpha = -lr_fold; }
+    corr.AddMatMat(1.0, d, kTrans, x, kNoTrans, mmt, &ep);
+  };
+  wgrad(w_zrm_x_corr_, w_zrm_x_, d_zrm, in);
+  wgrad(w_zr_h_corr_, w_zr_h_, CuSubMatrix(dbuf_, S, T * S, 0, 2 * H), CuSubMatrix(buf_, 0, T * S, 4 * H, H));
+  wgrad(w_m_g_corr_, w_m_g_, CuSubMatrix(dbuf_, S, T * S, 2 * H, H), CuSubMatrix(buf_, S, T * S, 3 * H, H));
+  aslp_rnn_vec_grad job = {dbuf_.RowData(S), nullptr, 0, 3 * H, bias_corr_.Data(), bias_.Data()};
+  aslp_rnn_vec_grads(&job, 1, dbuf_.Stride(), T * S, mmt, clip_gradient_, -lr_fold);
+  CheckK();
 }
 
 void GruStreams::Update(const CuMatrixBase &, const CuMatrixBase &) {  // :457-466
+  if (SkipFoldedUpdate()) return;
   const BaseFloat lr = opts_.learn_rate;
   w_zrm_x_.AddMat(-lr, w_zrm_x_corr_);
   w_zr_h_.AddMat(-lr, w_zr_h_corr_);

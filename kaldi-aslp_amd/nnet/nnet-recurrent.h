@@ -25,10 +25,20 @@ class RecurrentBase : public UpdatableComponent {
   RecurrentBase(int32 di, int32 dout) : UpdatableComponent(di, dout) {}
   bool GradientInBackprop() const { return true; }
   bool LatencyBoundPasses() const { return true; }
+  void FoldNextUpdateIntoBackprop() { fold_update_ = CanFoldUpdate(); }
   virtual bool HasStreamReset() const { return false; }   // answers Nnet::ResetLstmStreams (nnet-nnet.cc:473-496)
   virtual bool HasSeqLengths() const { return false; }    // answers Nnet::SetSeqLengths   (nnet-nnet.cc:498-530)
   virtual void ResetLstmStreams(const std::vector<int32> &) {}
   virtual void SetSeqLengths(const std::vector<int32> &) {}
+
+ protected:
+  virtual bool CanFoldUpdate() const { return false; }
+  // BackpropagateFnc of a folding subclass: true once per hint, and the following Update() then returns at once
+  bool TakeFoldHint() { if (!fold_update_) return false; fold_update_ = false; update_done_ = true; return true; }
+  bool SkipFoldedUpdate() { if (!update_done_) return false; update_done_ = false; return true; }
+
+ private:
+  bool fold_update_ = false, update_done_ = false;
 };
 
 struct LstmDir {
@@ -69,7 +79,8 @@ struct LstmDir {
   // out_diff: [T*S x Rec] diff w.r.t. this direction's output; in_diff = dGATES*w_x + beta*in_diff
   void Backward(const CuMatrixBase &out_diff, int T, int S, bool reverse, const CuMatrix &buf, CuMatrix *dbuf, CuMatrixBase *in_diff,
                 float beta) const;
-  void Grads(const CuMatrixBase &in, int T, int S, bool reverse, const CuMatrix &buf, const CuMatrix &dbuf, float mmt, float clip);
+  // lr_fold != 0: the step param += -lr_fold * corr is taken in the epilogues of the gradient kernels
+  void Grads(const CuMatrixBase &in, int T, int S, bool reverse, const CuMatrix &buf, const CuMatrix &dbuf, float mmt, float clip, float lr_fold);
   void Update(float lr);
 
   // ---- fused-step path: the per-timestep loop lives in LstmFamily (all directions share a launch) ----
@@ -92,6 +103,7 @@ class LstmFamily : public RecurrentBase {
     bool seq_lengths;      // listed in Nnet::SetSeqLengths
   };
   LstmFamily(int32 di, int32 dout, const Config &cfg);
+  bool CanFoldUpdate() const { return true; }
 
   void InitData(std::istream &is);
   void ReadData(std::istream &is, bool binary);
@@ -148,6 +160,7 @@ class GruStreams : public RecurrentBase {
   GruStreams(int32 di, int32 dout) : RecurrentBase(di, dout), nstream_(0), clip_gradient_(0.0), do_stream_reset_(false) {}
   Component *Copy() const { return new GruStreams(*this); }
   ComponentType GetType() const { return kGruStreams; }
+  bool CanFoldUpdate() const { return true; }
   void InitData(std::istream &is);
   void ReadData(std::istream &is, bool binary);
   void WriteData(std::ostream &os, bool binary) const;

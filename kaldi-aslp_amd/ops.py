@@ -92,6 +92,17 @@ def add_row_sum_mat_vec(alpha, M, beta, v):
     lib.aslp_add_row_sum_mat_vec(alpha, ptr(_chk(M)), dim(M), beta, ptr(_chk(v))); check_error()
 
 
+def rnn_vec_grads(jobs, d_stride, rows, mmt, clip, neg_lr):
+    """jobs: list of (d_view, x_view or None, corr, param); d_view / x_view are [rows x n] column blocks of pitched buffers."""
+    from ._lib import RnnVecGrad
+    arr = (RnnVecGrad * len(jobs))()
+    for k, (d, x, corr, param) in enumerate(jobs):
+        arr[k].d = ptr(d); arr[k].x = ptr(x) if x is not None else None
+        arr[k].ldx = x.stride(0) if x is not None else 0
+        arr[k].n = d.shape[1]; arr[k].corr = ptr(_chk(corr)); arr[k].param = ptr(_chk(param))
+    lib.aslp_rnn_vec_grads(arr, len(jobs), d_stride, rows, mmt, clip, neg_lr); check_error()
+
+
 def bn_forward(x, out, xhat, scale, shift, mean, inv_std, acc_means=None, acc_vars=None, var_floor=1e-7):
     lib.aslp_bn_forward(ptr(_chk(x)), dim(x), ptr(_chk(out)), dim(out).stride, ptr(_chk(xhat)), dim(xhat).stride,
                         ptr(scale), ptr(shift), ptr(mean), ptr(inv_std), ptr(acc_means), ptr(acc_vars), var_floor)

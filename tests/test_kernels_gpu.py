@@ -328,3 +328,40 @@ def test_aslp_group_ops(aslp, oracle, dev):
     ref = np.zeros((rowsM, cols), np.float32)
     oracle.lib.orc_add_conv_mat_mat_elements(ref, cols, cols, A, cols, rowsA, B, cols, rowsB, 1.0, 0.0)
     assert np.array_equal(Md.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("rows,C,cifg", [(1536, 320, False), (37, 20, False), (100, 65, True), (1, 4, False), (3000, 1024, False)])
+@pytest.mark.parametrize("clip,lr", [(0.0, 0.0), (0.7, 0.01)])
+def test_rnn_vec_grads(aslp, oracle, dev, rows, C, cifg, clip, lr):
+    """bias / peephole gradients of one LSTM direction in one launch (lc.h:1005-1058, :1092-1104) vs float64 numpy"""
+    rng = np.random.default_rng(rows + C)
+    G = 3 if cifg else 4
+    width = (G + 3) * C + 8
+    d = T(rng.standard_normal((rows, width)).astype(np.float32), dev)
+    y = T(rng.standard_normal((rows + 2, width)).astype(np.float32), dev)
+    mmt = 0.9
+    names = ["bias"] + ([] if cifg else ["pi"]) + ["pf", "po"]
+    off = {"bias": 0, "pi": C, "pf": C if cifg else 2 * C, "po": 2 * C if cifg else 3 * C}
+    n = {"bias": G * C, "pi": C, "pf": C, "po": C}
+    xrow = {"bias": None, "pi": 0, "pf": 0, "po": 1}
+    corr0 = {k: rng.standard_normal(n[k]).astype(np.float32) for k in names}
+    par0 = {k: rng.standard_normal(n[k]).astype(np.float32) for k in names}
+    corr = {k: T(corr0[k], dev) for k in names}
+    par = {k: T(par0[k], dev) for k in names}
+    jobs = []
+    for k in names:
+        dv = d[:, off[k]:off[k] + n[k]]
+        xv = None if xrow[k] is None else y[xrow[k]:xrow[k] + rows, G * C:G * C + C]
+        jobs.append((dv, xv, corr[k], par[k]))
+    aslp.ops.rnn_vec_grads(jobs, d.stride(0), rows, mmt, clip, -lr)
+    torch.cuda.synchronize()
+    dn, yn = d.cpu().numpy().astype(np.float64), y.cpu().numpy().astype(np.float64)
+    for k in names:
+        g = dn[:, off[k]:off[k] + n[k]]
+        if xrow[k] is not None:
+            g = g * yn[xrow[k]:xrow[k] + rows, G * C:G * C + C]
+        ref = g.sum(0) + mmt * corr0[k]
+        if clip > 0:
+            ref = np.clip(ref, -clip, clip)
+        assert oracle.rel_err(corr[k].cpu().numpy(), ref) < 1e-5, k
+        assert oracle.rel_err(par[k].cpu().numpy(), par0[k] - lr * ref) < 1e-5, k
