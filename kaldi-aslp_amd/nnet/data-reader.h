@@ -14,6 +14,7 @@
 #include "cu-device.h"
 #include "kaldi-table.h"
 #include "nnet-component.h"
+#include "nnet-nnet.h"
 #include "nnet-randomizer.h"
 #include "parse-options.h"
 
@@ -335,6 +336,12 @@ class SequenceDataReader {
         lent_(read_opts.num_stream, 0), new_utt_flags_(read_opts.num_stream, 0) {}
   bool Done() { return read_done_ && feature_reader_.Done(); }
   const std::vector<int32> &GetNewUttFlags() const { return new_utt_flags_; }
+  // aslp-nnet-train-lstm-streams-skip.cc:160-225: that tool runs skip_width passes over the data, pass k keeping the frames
+  // k, k + skip_width, ...; it also sends every utterance through a feature transform and counts what it had to leave out
+  void SetSkipOffset(int32 offset) { skip_offset_ = offset; }
+  void SetFeatureTransform(Nnet *transform) { transform_ = transform; }
+  int32 NumNoTargets() const { return num_no_tgt_; }
+  int32 NumLengthMismatch() const { return num_len_mismatch_; }
   // When every stream is exhausted the reference leaves `feat` as it was and hands out an all-zero mask (the caller still
   // runs one more step on it, which matters with momentum): same here.
   void ReadData(CuMatrix *feat, Posterior *target, std::vector<BaseFloat> *frame_mask) {
@@ -350,20 +357,31 @@ class SequenceDataReader {
       if (curt_[s] < lent_[s]) { new_utt_flags_[s] = 0; continue; }
       while (!feature_reader_.Done()) {
         const std::string key = feature_reader_.Key();
-        const HostMatrix &mat = feature_reader_.Value();
-        if (read_opts_.drop_len > 0 && mat.rows > read_opts_.drop_len) { ASLP_WARN << key << ", too long, droped"; feature_reader_.Next(); continue; }
-        if (!target_reader_.HasKey(key)) { ASLP_WARN << key << ", missing targets"; feature_reader_.Next(); continue; }
+        const HostMatrix &raw = feature_reader_.Value();
+        if (read_opts_.drop_len > 0 && raw.rows > read_opts_.drop_len) { ASLP_WARN << key << ", too long, droped"; feature_reader_.Next(); continue; }
+        if (transform_ != NULL) {  // through the device and back: the batches are assembled on the host
+          dev_in_ = raw;
+          transform_->Feedforward(dev_in_, &dev_out_);
+          dev_out_.CopyToMat(&transformed_);
+        }
+        const HostMatrix &mat = transform_ != NULL ? transformed_ : raw;
+        if (!target_reader_.HasKey(key)) { ASLP_WARN << key << ", missing targets"; num_no_tgt_++; feature_reader_.Next(); continue; }
         const Posterior &target = target_reader_.Value(key);
-        if (mat.rows != (int32)target.size()) { ASLP_WARN << key << ", length miss-match between feats and targers, skip"; feature_reader_.Next(); continue; }
+        if (mat.rows != (int32)target.size()) {
+          ASLP_WARN << key << ", length miss-match between feats and targers, skip";
+          num_len_mismatch_++;
+          feature_reader_.Next();
+          continue;
+        }
         const int32 skip_width = read_opts_.skip_width;
         if (skip_width > 1) {
-          const int32 skip_len = (mat.rows - 1) / skip_width + 1;
+          const int32 skip_len = mat.rows > skip_offset_ ? (mat.rows - 1 - skip_offset_) / skip_width + 1 : 0;
           feats_[s].Resize(skip_len, mat.cols);
           targets_[s].assign(skip_len, Posterior::value_type());
           for (int32 i = 0; i < skip_len; i++) {
-            std::copy(mat.data.begin() + (size_t)i * skip_width * mat.cols, mat.data.begin() + (size_t)(i * skip_width + 1) * mat.cols,
-                      feats_[s].data.begin() + (size_t)i * mat.cols);
-            targets_[s][i] = target[i * skip_width];
+            const size_t src = (size_t)i * skip_width + skip_offset_;
+            std::copy(mat.data.begin() + src * mat.cols, mat.data.begin() + (src + 1) * mat.cols, feats_[s].data.begin() + (size_t)i * mat.cols);
+            targets_[s][i] = target[src];
           }
         } else {
           feats_[s] = mat;
@@ -411,6 +429,10 @@ class SequenceDataReader {
   std::vector<Posterior> targets_;
   std::vector<int32> curt_, lent_, new_utt_flags_;
   HostMatrix host_;
+  int32 skip_offset_ = 0, num_no_tgt_ = 0, num_len_mismatch_ = 0;
+  Nnet *transform_ = NULL;
+  CuMatrix dev_in_, dev_out_;
+  HostMatrix transformed_;
 };
 
 }  // namespace aslp

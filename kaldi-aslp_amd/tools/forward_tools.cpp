@@ -1,6 +1,7 @@
-// forward_tools.cpp -- the inference tools of src/aslp-nnetbin (forward, forward-blstm-lc, forward-skip): one entry function per tool
+// forward_tools.cpp -- the inference tools of src/aslp-nnetbin (forward, forward-mimo, forward-blstm-lc, forward-skip): one entry function per tool
 // (Main_<tool name with _ for ->), linked behind tools/main_stub.cpp into bin/<tool name>.
 #include <cmath>
+#include <memory>
 
 #include "cu-device.h"
 #include "kaldi-table.h"
@@ -149,6 +150,122 @@ int Main_aslp_nnet_forward(int argc, char *argv[]) {
       num_done++;
       tot_t += in_rows;
     }
+    ASLP_LOG << "Done " << num_done << " files in " << time.Elapsed() / 60 << "min, (fps " << tot_t / time.Elapsed() << ")";
+    if (g_verbose_level >= 1) CuDevice::Instantiate().PrintProfile();
+    if (num_done == 0) return -1;
+    return 0;
+  } catch (const std::exception &e) {
+    std::cerr << e.what();
+    return -1;
+  }
+}
+
+// ======================================================================================================================
+// aslp-nnet-forward-mimo -- src/aslp-nnetbin/aslp-nnet-forward-mimo.cc: forward pass through a graph net with several
+// <InputLayer>s: one feature table per input (same keys, same order), the LAST output is written (the main task of a
+// multi-task net).
+int Main_aslp_nnet_forward_mimo(int argc, char *argv[]) {
+  using namespace aslp;
+  try {
+    const char *usage =
+        "Perform forward pass through Neural Network.\n"
+        "\n"
+        "Usage:  aslp-nnet-forward-mimo [options] <model-in> <feature-rspecifier_1>...<feature_rspecifier_n> <feature-wspecifier>\n"
+        "e.g.: \n"
+        " aslp-nnet-forward-mimo nnet ark:features1.ark ark:features2.ark ark:mlpoutput.ark\n";
+    ParseOptions po(usage);
+    PdfPriorOptions prior_opts;
+    prior_opts.Register(&po);
+    std::string feature_transform;
+    po.Register("feature-transform", &feature_transform, "Feature transform in front of main network (in nnet format)");
+    bool no_softmax = false;
+    po.Register("no-softmax", &no_softmax, "No softmax on MLP output (or remove it if found), the pre-softmax activations will be used as log-likelihoods, log-priors will be subtracted");
+    bool apply_log = false;
+    po.Register("apply-log", &apply_log, "Transform MLP output to logscale");
+    std::string use_gpu = "no";
+    po.Register("use-gpu", &use_gpu, "yes|no|optional, only has effect if compiled with CUDA");
+    int32 time_shift = 0;
+    po.Register("time-shift", &time_shift, "LSTM : repeat last input frame N-times, discrad N initial output frames.");
+    po.Read(argc, argv);
+    if (po.NumArgs() < 3) { po.PrintUsage(); exit(1); }
+    if (apply_log && no_softmax) ASLP_ERR << "Cannot use both --apply-log=true --no-softmax=true, use only one of the two!";
+    CuDevice::Instantiate().SelectGpuId(use_gpu == "no" ? "yes" : use_gpu);  // no host engine here, see aslp-nnet-forward
+
+    const int num_args = po.NumArgs();
+    std::string model_filename = po.GetArg(1), feature_wspecifier = po.GetArg(num_args);
+    Nnet nnet;
+    nnet.Read(model_filename);
+    const int num_input = nnet.NumInput(), num_output = nnet.NumOutput();
+    ASLP_LOG << "Nnet num_input " << num_input << " num_output " << num_output;
+    if (num_args != 1 + num_input + 1) { po.PrintUsage(); exit(1); }
+    PdfPrior pdf_prior(prior_opts);
+    nnet.SetDropoutRetention(1.0);
+
+    std::vector<std::unique_ptr<SequentialBaseFloatMatrixReader>> readers;
+    for (int i = 0; i < num_input; i++) readers.emplace_back(new SequentialBaseFloatMatrixReader(po.GetArg(i + 2)));
+    BaseFloatMatrixWriter feature_writer(feature_wspecifier);
+    std::vector<CuMatrix> in_store(num_input), out_store(num_output);
+    std::vector<const CuMatrixBase *> nnet_in(num_input);
+    std::vector<CuMatrix *> nnet_outs(num_output);
+    for (int i = 0; i < num_input; i++) nnet_in[i] = &in_store[i];
+    for (int i = 0; i < num_output; i++) nnet_outs[i] = &out_store[i];
+    HostMatrix nnet_out_host;
+    int64_t tot_t = 0;
+    Timer time;
+    int32 num_done = 0;
+    while (!readers[0]->Done()) {
+      const std::string utt = readers[0]->Key();
+      ASLP_VLOG(2) << "Processing " << utt;
+      for (int i = 0; i < num_input; i++) {
+        if (readers[i]->Done() || readers[i]->Key() != utt)
+          ASLP_ERR << "Different key from the features " << utt << " " << (readers[i]->Done() ? std::string("<end of table>") : readers[i]->Key())
+                   << " please check the order of feat scp";
+        HostMatrix mat = readers[i]->Value();
+        for (float v : mat.data)
+          if (!std::isfinite(v)) ASLP_ERR << "NaN or inf found in features for " << utt;
+        if (time_shift > 0) {
+          const int32 last_row = mat.rows - 1, cols = mat.cols;
+          mat.data.resize((size_t)(mat.rows + time_shift) * cols);
+          for (int32 r = last_row + 1; r < last_row + 1 + time_shift; r++)
+            std::copy(mat.data.begin() + (size_t)last_row * cols, mat.data.begin() + (size_t)(last_row + 1) * cols, mat.data.begin() + (size_t)r * cols);
+          mat.rows += time_shift;
+        }
+        in_store[i] = mat;
+      }
+      nnet.Feedforward(nnet_in, &nnet_outs);
+      CuMatrix &nnet_out = out_store[num_output - 1];  // if multitask, only the last task is written
+      MinMax st = Stats(nnet_out);
+      if (apply_log) {
+        if (!(st.mn >= 0.0 && st.mx <= 1.0))
+          ASLP_WARN << utt << " Applying 'log' to data which don't seem to be probabilities (is there a softmax somwhere?)";
+        nnet_out.Add(1e-20);
+        nnet_out.ApplyLog();
+        st = Stats(nnet_out);
+      }
+      if (prior_opts.class_frame_counts != "") {
+        if (st.mn >= 0.0 && st.mx <= 1.0)
+          ASLP_WARN << utt << " Subtracting log-prior on 'probability-like' data in range [0..1] (Did you forget --no-softmax=true or --apply-log=true ?)";
+        pdf_prior.SubtractOnLogpost(&nnet_out);
+      }
+      nnet_out.CopyToMat(&nnet_out_host);
+      if (time_shift > 0) {
+        HostMatrix tmp(nnet_out_host.rows - time_shift, nnet_out_host.cols);
+        std::copy(nnet_out_host.data.begin() + (size_t)time_shift * nnet_out_host.cols, nnet_out_host.data.end(), tmp.data.begin());
+        nnet_out_host = tmp;
+      }
+      for (float v : nnet_out_host.data)
+        if (!std::isfinite(v)) ASLP_ERR << "NaN or inf found in final output nn-output for " << utt;
+      feature_writer.Write(utt, nnet_out_host);
+      if (num_done % 100 == 0) {
+        double time_now = time.Elapsed();
+        ASLP_VLOG(1) << "After " << num_done << " utterances: time elapsed = " << time_now / 60 << " min; processed " << tot_t / time_now
+                     << " frames per second.";
+      }
+      num_done++;
+      tot_t += in_store[0].NumRows();
+      for (int i = 0; i < num_input; i++) readers[i]->Next();
+    }
+    for (int i = 1; i < num_input; i++) ASLP_ASSERT(readers[i]->Done());
     ASLP_LOG << "Done " << num_done << " files in " << time.Elapsed() / 60 << "min, (fps " << tot_t / time.Elapsed() << ")";
     if (g_verbose_level >= 1) CuDevice::Instantiate().PrintProfile();
     if (num_done == 0) return -1;

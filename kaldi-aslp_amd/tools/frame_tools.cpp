@@ -1,4 +1,4 @@
-// frame_tools.cpp -- the frame-level training tools of src/aslp-nnetbin (train-frame, train-simple, train-frame-mimo, train-perutt):
+// frame_tools.cpp -- the frame-level training tools of src/aslp-nnetbin (train-frame, train-simple, train-mse, train-frame-mimo, train-perutt):
 // one entry function per tool (Main_<tool name with _ for ->), linked behind tools/main_stub.cpp into bin/<tool name>.
 #include <algorithm>
 
@@ -301,6 +301,158 @@ int Main_aslp_nnet_train_simple(int argc, char *argv[]) {
     else if (objective_function == "mse") ASLP_LOG << mse.Report();
     else if (0 == objective_function.compare(0, 9, "multitask")) ASLP_LOG << multitask.Report();
     else ASLP_ERR << "Unknown objective function code : " << objective_function;
+    CuDevice::Instantiate().PrintProfile();
+    return 0;
+  } catch (const std::exception &e) {
+    std::cerr << e.what();
+    return -1;
+  }
+}
+
+// ======================================================================================================================
+// aslp-nnet-train-mse -- src/aslp-nnetbin/aslp-nnet-train-mse.cc: the train-simple loop for regression nets.  The targets
+// are a second MATRIX table read in step with the features (same keys, same order -- anything else is an error), shuffled
+// by a MatrixRandomizer under the same mask, scored by Mse.  The usage text still says train-simple, as in the reference.
+int Main_aslp_nnet_train_mse(int argc, char *argv[]) {
+  using namespace aslp;
+  try {
+    const char *usage =
+        "Perform one iteration of Neural Network training by mini-batch Stochastic Gradient Descent.\n"
+        "This version use pdf-posterior as targets, prepared typically by ali-to-post.\n"
+        "Usage:  aslp-nnet-train-simple [options] <feature-rspecifier> <targets-rspecifier> <model-in> [<model-out>]\n"
+        "e.g.: \n"
+        " aslp-nnet-train-simple scp:feature.scp ark:posterior.ark nnet.init nnet.iter1\n";
+    ParseOptions po(usage);
+    NnetTrainOptions trn_opts;
+    RegisterTrainOptions(&trn_opts, &po);
+    NnetDataRandomizerOptions rnd_opts;
+    RegisterRandomizerOptions(&rnd_opts, &po);
+    bool binary = true, crossvalidate = false, randomize = true;
+    po.Register("binary", &binary, "Write output in binary mode");
+    po.Register("cross-validate", &crossvalidate, "Perform cross-validation (don't backpropagate)");
+    po.Register("randomize", &randomize, "Perform the frame-level shuffling within the Cache::");
+    std::string feature_transform;
+    po.Register("feature-transform", &feature_transform, "Feature transform in Nnet format");
+    std::string objective_function = "mse";
+    po.Register("objective-function", &objective_function, "Objective function : xent|mse");
+    int32 length_tolerance = 5;
+    po.Register("length-tolerance", &length_tolerance, "Allowed length difference of features/targets (frames)");
+    std::string frame_weights;
+    po.Register("frame-weights", &frame_weights, "Per-frame weights to scale gradients (frame selection/weighting).");
+    std::string utt_weights;
+    po.Register("utt-weights", &utt_weights, "Per-utterance weights (scalar applied to frame-weights).");
+    std::string use_gpu = "yes";
+    po.Register("use-gpu", &use_gpu, "yes|no|optional, only has effect if compiled with CUDA");
+    double dropout_retention = 0.0;
+    po.Register("dropout-retention", &dropout_retention, "number between 0..1, saying how many neurons to preserve (0.0 will keep original value");
+    int32 report_period = 60000;
+    po.Register("report-period", &report_period, "Number of frames for one report log, default(60000)");
+    po.Read(argc, argv);
+    if (po.NumArgs() != 4 - (crossvalidate ? 1 : 0)) { po.PrintUsage(); exit(1); }
+    std::string feature_rspecifier = po.GetArg(1), targets_rspecifier = po.GetArg(2), model_filename = po.GetArg(3);
+    std::string target_model_filename;
+    if (!crossvalidate) target_model_filename = po.GetArg(4);
+    CuDevice::Instantiate().SelectGpuId(use_gpu);
+
+    Nnet nnet_transf;
+    if (feature_transform != "") nnet_transf.Read(feature_transform);
+    Nnet nnet;
+    nnet.Read(model_filename);
+    nnet.SetTrainOptions(trn_opts);
+    if (dropout_retention > 0.0) { nnet_transf.SetDropoutRetention(dropout_retention); nnet.SetDropoutRetention(dropout_retention); }
+    if (crossvalidate) { nnet_transf.SetDropoutRetention(1.0); nnet.SetDropoutRetention(1.0); }
+
+    int64_t total_frames = 0, report_frames = 0;
+    SequentialBaseFloatMatrixReader feature_reader(feature_rspecifier), targets_reader(targets_rspecifier);
+    RandomAccessBaseFloatVectorReader weights_reader;
+    if (frame_weights != "" && !weights_reader.Open(frame_weights)) ASLP_ERR << "cannot open " << frame_weights;
+    RandomAccessBaseFloatReader utt_weights_reader;
+    if (utt_weights != "" && !utt_weights_reader.Open(utt_weights)) ASLP_ERR << "cannot open " << utt_weights;
+    RandomizerMask randomizer_mask(rnd_opts);
+    MatrixRandomizer feature_randomizer(rnd_opts), targets_randomizer(rnd_opts);
+    VectorRandomizer weights_randomizer(rnd_opts);
+    Mse mse;
+    if (objective_function != "mse") ASLP_ERR << "Only support mse training";
+
+    CuMatrix feats, feats_transf, tgt_dev, nnet_out, obj_diff;
+    Timer time;
+    ASLP_LOG << (crossvalidate ? "CROSS-VALIDATION" : "TRAINING") << " STARTED";
+    int32 num_done = 0, num_no_tgt_mat = 0, num_other_error = 0;
+    while (!feature_reader.Done()) {
+      CuDevice::Instantiate().CheckGpuHealth();
+      // both tables advance together, also past an utterance that is left out (:163)
+      for (; !feature_reader.Done(); feature_reader.Next(), targets_reader.Next()) {
+        if (feature_randomizer.IsFull()) break;
+        const std::string utt = feature_reader.Key();
+        if (targets_reader.Done() || utt != targets_reader.Key())
+          ASLP_ERR << "feat and target not in the same order or not exist in target"
+                   << "feat key " << utt << "target key " << (targets_reader.Done() ? std::string() : targets_reader.Key());
+        ASLP_VLOG(3) << "Reading " << utt;
+        if (frame_weights != "" && !weights_reader.HasKey(utt)) { ASLP_WARN << utt << ", missing per-frame weights"; num_other_error++; continue; }
+        if (utt_weights != "" && !utt_weights_reader.HasKey(utt)) { ASLP_WARN << utt << ", missing per-utterance weight"; num_other_error++; continue; }
+        const HostMatrix &mat = feature_reader.Value();
+        const HostMatrix &targets = targets_reader.Value();
+        if (mat.rows != targets.rows) {
+          ASLP_WARN << utt << " feat and target are not the same dim" << " feat " << mat.rows << " target " << targets.rows;
+          continue;
+        }
+        std::vector<BaseFloat> weights;
+        if (frame_weights != "") weights = weights_reader.Value(utt).data;
+        else weights.assign(mat.rows, 1.0f);
+        feats = mat;
+        nnet_transf.Feedforward(feats, &feats_transf);
+        ASLP_ASSERT(feats_transf.NumRows() == targets.rows);
+        tgt_dev = targets;
+        feature_randomizer.AddData(feats_transf);
+        targets_randomizer.AddData(tgt_dev);
+        weights_randomizer.AddData(weights);
+        num_done++;
+        if (num_done % 5000 == 0) {
+          double time_now = time.Elapsed();
+          ASLP_VLOG(1) << "After " << num_done << " utterances: time elapsed = " << time_now / 60 << " min; processed "
+                       << total_frames / time_now << " frames per second.";
+        }
+      }
+      if (!crossvalidate && randomize) {
+        const std::vector<int32> &mask = randomizer_mask.Generate(feature_randomizer.NumFrames());
+        feature_randomizer.Randomize(mask);
+        targets_randomizer.Randomize(mask);
+        weights_randomizer.Randomize(mask);
+      }
+      for (; !feature_randomizer.Done(); feature_randomizer.Next(), targets_randomizer.Next(), weights_randomizer.Next()) {
+        const CuMatrixBase &nnet_in = feature_randomizer.Value();
+        const CuMatrixBase &nnet_tgt = targets_randomizer.Value();
+        const std::vector<BaseFloat> &frm_weights = weights_randomizer.Value();
+        if (!crossvalidate) nnet.Propagate(nnet_in, &nnet_out);
+        else nnet.Feedforward(nnet_in, &nnet_out);
+        mse.Eval(frm_weights, nnet_out, nnet_tgt, &obj_diff);
+        if (!crossvalidate) nnet.Backpropagate(obj_diff, NULL);
+        if (g_verbose_level >= 1 && total_frames == 0) {
+          ASLP_VLOG(1) << "### After " << total_frames << " frames,";
+          ASLP_VLOG(1) << nnet.InfoPropagate();
+          if (!crossvalidate) { ASLP_VLOG(1) << nnet.InfoBackPropagate(); ASLP_VLOG(1) << nnet.InfoGradient(); }
+        }
+        if (g_verbose_level >= 2 && (total_frames / 25000) != ((total_frames + nnet_in.NumRows()) / 25000)) {
+          ASLP_VLOG(2) << "### After " << total_frames << " frames,";
+          ASLP_VLOG(2) << nnet.InfoPropagate();
+          if (!crossvalidate) ASLP_VLOG(2) << nnet.InfoGradient();
+        }
+        total_frames += nnet_in.NumRows();
+        report_frames += nnet_in.NumRows();
+        if (report_frames >= report_period) { ASLP_LOG << mse.Report(); report_frames -= report_period; }
+      }
+    }
+    if (g_verbose_level >= 1) {
+      ASLP_VLOG(1) << "### After " << total_frames << " frames,";
+      ASLP_VLOG(1) << nnet.InfoPropagate();
+      if (!crossvalidate) { ASLP_VLOG(1) << nnet.InfoBackPropagate(); ASLP_VLOG(1) << nnet.InfoGradient(); }
+    }
+    if (!crossvalidate) nnet.Write(target_model_filename, binary);
+    StreamSync();
+    ASLP_LOG << "Done " << num_done << " files, " << num_no_tgt_mat << " with no tgt_mats, " << num_other_error << " with other errors. "
+             << "[" << (crossvalidate ? "CROSS-VALIDATION" : "TRAINING") << ", " << (randomize ? "RANDOMIZED" : "NOT-RANDOMIZED") << ", "
+             << time.Elapsed() / 60 << " min, fps" << total_frames / time.Elapsed() << "]";
+    ASLP_LOG << mse.Report();
     CuDevice::Instantiate().PrintProfile();
     return 0;
   } catch (const std::exception &e) {

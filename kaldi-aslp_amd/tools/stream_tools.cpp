@@ -1,6 +1,8 @@
-// stream_tools.cpp -- the sequence training tools of src/aslp-nnetbin (lstm-streams, blstm-streams, blstm-streams-lc, warp-ctc-streams,
-// ctc-streams): one entry function per tool (Main_<tool name with _ for ->), linked behind tools/main_stub.cpp into bin/<tool name>.
+// stream_tools.cpp -- the sequence training tools of src/aslp-nnetbin (lstm-streams, lstm-streams-skip, blstm-streams, blstm-parallel,
+// blstm-streams-lc, warp-ctc-streams, ctc-streams, ctc): one entry function per tool (Main_<tool name with _ for ->), linked behind tools/main_stub.cpp into bin/<tool name>.
 #include <algorithm>
+#include <map>
+#include <memory>
 
 #include "ctc-loss.h"
 #include "cu-device.h"
@@ -111,6 +113,114 @@ int Main_aslp_nnet_train_lstm_streams(int argc, char *argv[]) {
              << (randomize ? "RANDOMIZED" : "NOT-RANDOMIZED") << ", " << time.Elapsed() / 60 << " min, fps" << total_frames / time.Elapsed() << "]";
     ASLP_LOG << loss->Report();  // the reference calls Report() and drops the string (:222); the schedulers need the line
     delete loss;
+    CuDevice::Instantiate().PrintProfile();
+    return 0;
+  } catch (const std::exception &e) {
+    std::cerr << e.what();
+    return -1;
+  }
+}
+
+// ======================================================================================================================
+// aslp-nnet-train-lstm-streams-skip -- src/aslp-nnetbin/aslp-nnet-train-lstm-streams-skip.cc: the multi-stream LSTM trainer
+// with frame skipping done as skip-width passes over the data, pass k training on frames k, k + skip-width, ... of every
+// utterance (so each utterance is used skip-width times, once per phase).  Own stream options instead of the reader's.
+int Main_aslp_nnet_train_lstm_streams_skip(int argc, char *argv[]) {
+  using namespace aslp;
+  try {
+    const char *usage =
+        "Perform one iteration of LSTM training by Stochastic Gradient Descent.\n"
+        "This version use pdf-posterior as targets, prepared typically by ali-to-post.\n"
+        "The updates are done per-utterance, shuffling options are dummy for compatibility reason.\n"
+        "Attention: one sentence will be devided into N part for skip training\n"
+        "\n"
+        "Usage: aslp-nnet-train-lstm-streams-skip [options] <feature-rspecifier> <targets-rspecifier> <model-in> [<model-out>]\n"
+        "e.g.: \n"
+        " aslp-nnet-train-lstm-streams-skip scp:feature.scp ark:posterior.ark nnet.init nnet.iter1\n";
+    ParseOptions po(usage);
+    NnetTrainOptions trn_opts;
+    RegisterTrainOptions(&trn_opts, &po);
+    bool binary = true, crossvalidate = false;
+    po.Register("binary", &binary, "Write output in binary mode");
+    po.Register("cross-validate", &crossvalidate, "Perform cross-validation (don't backpropagate)");
+    std::string feature_transform;
+    po.Register("feature-transform", &feature_transform, "Feature transform in Nnet format");
+    std::string objective_function = "xent";
+    po.Register("objective-function", &objective_function, "Objective function : xent|mse");
+    std::string use_gpu = "yes";
+    po.Register("use-gpu", &use_gpu, "yes|no|optional, only has effect if compiled with CUDA");
+    SequenceDataReaderOptions read_opts;
+    read_opts.num_stream = 4;
+    po.Register("targets-delay", &read_opts.targets_delay, "---LSTM--- BPTT targets delay");
+    po.Register("batch-size", &read_opts.batch_size, "---LSTM--- BPTT batch size");
+    po.Register("num-stream", &read_opts.num_stream, "---LSTM--- BPTT multi-stream training");
+    int32 dump_interval = 0;
+    po.Register("dump-interval", &dump_interval, "---LSTM--- num utts between model dumping [ 0 == disabled ]");
+    NnetDataRandomizerOptions rnd_opts;
+    RegisterRandomizerOptions(&rnd_opts, &po);
+    bool randomize = false;
+    po.Register("randomize", &randomize, "Dummy option, for compatibility...");
+    int32 report_period = 200;
+    po.Register("report-period", &report_period, "Number of sentence for one report log, default(200)");
+    po.Register("drop-len", &read_opts.drop_len, "if Sentence frame length greater than drop_len,then drop it, default(0, no drop)");
+    po.Register("skip-width", &read_opts.skip_width, "num of frame for one skip(default 0, no skip)");
+    po.Read(argc, argv);
+    if (po.NumArgs() != 4 - (crossvalidate ? 1 : 0)) { po.PrintUsage(); exit(1); }
+    std::string feature_rspecifier = po.GetArg(1), targets_rspecifier = po.GetArg(2), model_filename = po.GetArg(3);
+    std::string target_model_filename;
+    if (!crossvalidate) target_model_filename = po.GetArg(4);
+    CuDevice::Instantiate().SelectGpuId(use_gpu);
+
+    Nnet nnet_transf;
+    if (feature_transform != "") nnet_transf.Read(feature_transform);
+    Nnet nnet;
+    nnet.Read(model_filename);
+    nnet.SetTrainOptions(trn_opts);
+    Xent xent;
+    if (objective_function != "xent") ASLP_ERR << "Only Support xent objective function, but got" << objective_function;
+    Timer time;
+    ASLP_LOG << (crossvalidate ? "CROSS-VALIDATION" : "TRAINING") << " STARTED";
+    int64_t total_frames = 0;
+    int32 num_done = 0, num_no_tgt_mat = 0, num_other_error = 0, num_sentence = 0;
+    CuMatrix nnet_in, nnet_out, obj_diff;
+    std::vector<BaseFloat> frame_mask;
+    Posterior nnet_tgt;
+    const int32 passes = read_opts.skip_width > 1 ? read_opts.skip_width : 1;
+    for (int32 skip_offset = 0; skip_offset < passes; skip_offset++) {  // every pass reopens both tables (:163-164)
+      SequenceDataReader reader(feature_rspecifier, targets_rspecifier, read_opts);
+      reader.SetSkipOffset(skip_offset);
+      if (nnet_transf.NumComponents() > 0) reader.SetFeatureTransform(&nnet_transf);
+      while (!reader.Done()) {
+        reader.ReadData(&nnet_in, &nnet_tgt, &frame_mask);
+        if (reader.Done()) break;  // all streams exhausted: the reference leaves the loop before touching the net (:238)
+        std::vector<int32> new_utt_flags = reader.GetNewUttFlags();
+        nnet.ResetLstmStreams(new_utt_flags);
+        if (!crossvalidate) nnet.Propagate(nnet_in, &nnet_out);
+        else nnet.Feedforward(nnet_in, &nnet_out);
+        xent.Eval(frame_mask, nnet_out, nnet_tgt, &obj_diff);
+        if (!crossvalidate) nnet.Backpropagate(obj_diff, NULL);
+        int32 frame_progress = 0, num_done_progress = 0;
+        for (BaseFloat m : frame_mask) frame_progress += (int32)m;
+        for (int32 f : new_utt_flags) num_done_progress += f;
+        total_frames += frame_progress;
+        num_done += num_done_progress;
+        num_sentence += num_done_progress;
+        if (num_sentence >= report_period) { ASLP_LOG << xent.Report(); num_sentence -= report_period; }
+        if (dump_interval > 0 && (num_done - num_done_progress) / dump_interval != num_done / dump_interval && !crossvalidate) {
+          char nnet_name[512];
+          snprintf(nnet_name, sizeof(nnet_name), "%s_utt%d", target_model_filename.c_str(), num_done);
+          nnet.Write(nnet_name, binary);
+        }
+      }
+      num_no_tgt_mat += reader.NumNoTargets();
+      num_other_error += reader.NumLengthMismatch();
+    }
+    if (!crossvalidate) nnet.Write(target_model_filename, binary);
+    StreamSync();
+    ASLP_LOG << "Done " << num_done << " files, " << num_no_tgt_mat << " with no tgt_mats, " << num_other_error << " with other errors. "
+             << "[" << (crossvalidate ? "CROSS-VALIDATION" : "TRAINING") << ", " << (randomize ? "RANDOMIZED" : "NOT-RANDOMIZED") << ", "
+             << time.Elapsed() / 60 << " min, fps" << total_frames / time.Elapsed() << "]";
+    ASLP_LOG << xent.Report();
     CuDevice::Instantiate().PrintProfile();
     return 0;
   } catch (const std::exception &e) {
@@ -295,6 +405,133 @@ int Main_aslp_nnet_train_blstm_streams(int argc, char *argv[]) {
              << time.Elapsed() / 60 << " min, fps" << total_frames / time.Elapsed() << "]";
     if (objective_function == "xent") ASLP_LOG << xent.Report();
     else if (objective_function == "mse") ASLP_LOG << mse.Report();
+    CuDevice::Instantiate().PrintProfile();
+    return 0;
+  } catch (const std::exception &e) {
+    std::cerr << e.what();
+    return -1;
+  }
+}
+
+// ======================================================================================================================
+// aslp-nnet-train-blstm-parallel -- src/aslp-nnetbin/aslp-nnet-train-blstm-parallel.cc: whole-utterance BLSTM training on up to
+// num-stream utterances per step, the plain predecessor of aslp-nnet-train-blstm-streams: no feature transform (the flag is
+// accepted and ignored), no frame weights -- padded frames score like any other (LossItf::Eval without weights, :211) -- no
+// per-step learn-rate normalisation, utterances whose lengths differ from their targets' are left out.
+int Main_aslp_nnet_train_blstm_parallel(int argc, char *argv[]) {
+  using namespace aslp;
+  try {
+    const char *usage =
+        "Perform one iteration of Neural Network training by Stochastic Gradient Descent.\n"
+        "This version use pdf-posterior as targets, prepared typically by ali-to-post.\n"
+        "The updates are done per-utternace, shuffling options are dummy for compatibility reason.\n"
+        "\n"
+        "Usage: aslp-nnet-train-blstm-parallel [options] <feature-rspecifier> <labels-rspecifier> <model-in> [<model-out>]\n"
+        "e.g.: \n"
+        " aslp-nnet-train-blstm-parallel scp:feature.scp ark:labels.ark nnet.init nnet.iter1\n";
+    ParseOptions po(usage);
+    NnetTrainOptions trn_opts;
+    RegisterTrainOptions(&trn_opts, &po);
+    bool binary = true, crossvalidate = false;
+    po.Register("binary", &binary, "Write model  in binary mode");
+    po.Register("cross-validate", &crossvalidate, "Perform cross-validation (no backpropagation)");
+    std::string feature_transform;
+    po.Register("feature-transform", &feature_transform, "Feature transform in Nnet format");
+    int32 length_tolerance = 5;
+    po.Register("length-tolerance", &length_tolerance, "Allowed length difference of features/targets (frames)");
+    std::string frame_weights;
+    po.Register("frame-weights", &frame_weights, "Per-frame weights to scale gradients (frame selection/weighting).");
+    std::string objective_function = "xent";
+    po.Register("objective-function", &objective_function, "Objective function : xent|mse");
+    int32 num_stream = 4;
+    po.Register("num-stream", &num_stream, "Number of sequences processed in parallel");
+    double frame_limit = 100000;
+    po.Register("frame-limit", &frame_limit, "Max number of frames to be processed");
+    std::string use_gpu = "yes";
+    po.Register("use-gpu", &use_gpu, "yes|no|optional, only has effect if compiled with CUDA");
+    NnetDataRandomizerOptions rnd_opts;
+    RegisterRandomizerOptions(&rnd_opts, &po);
+    bool randomize = false;
+    po.Register("randomize", &randomize, "Dummy option, for compatibility...");
+    int32 report_period = 200;
+    po.Register("report-period", &report_period, "Number of sentence for one report log, default(200)");
+    int32 drop_len = 0;
+    po.Register("drop-len", &drop_len, "if Sentence frame length greater than drop_len,then drop it, default(0, no drop)");
+    po.Read(argc, argv);
+    if (po.NumArgs() != 4 - (crossvalidate ? 1 : 0)) { po.PrintUsage(); exit(1); }
+    std::string feature_rspecifier = po.GetArg(1), targets_rspecifier = po.GetArg(2), model_filename = po.GetArg(3);
+    std::string target_model_filename;
+    if (!crossvalidate) target_model_filename = po.GetArg(4);
+    CuDevice::Instantiate().SelectGpuId(use_gpu);
+
+    Nnet nnet;
+    nnet.Read(model_filename);
+    nnet.SetTrainOptions(trn_opts);
+    SequentialBaseFloatMatrixReader feature_reader(feature_rspecifier);
+    RandomAccessPosteriorReader targets_reader(targets_rspecifier);
+    std::unique_ptr<LossItf> loss;
+    if (objective_function == "xent") loss.reset(new Xent);
+    else if (objective_function == "mse") loss.reset(new Mse);
+    else ASLP_ERR << "Unsupported objective function: " << objective_function;
+    CuMatrix feats, nnet_out, obj_diff;
+    Timer time;
+    ASLP_LOG << (crossvalidate ? "CROSS-VALIDATION" : "TRAINING") << " STARTED";
+    std::vector<HostMatrix> feats_utt(num_stream);
+    std::vector<Posterior> labels_utt(num_stream);
+    const int32 feat_dim = nnet.InputDim();
+    int64_t total_frames = 0;
+    int32 num_done = 0, num_no_tgt_mat = 0, num_other_error = 0, num_sentence = 0;
+    while (1) {
+      std::vector<int32> frame_num_utt;
+      int32 max_frame_num = 0;
+      for (; !feature_reader.Done(); feature_reader.Next()) {
+        const std::string utt = feature_reader.Key();
+        if (!targets_reader.HasKey(utt)) { ASLP_WARN << utt << ", missing targets"; num_no_tgt_mat++; continue; }
+        const HostMatrix &mat = feature_reader.Value();
+        if (drop_len > 0 && mat.rows > drop_len) {
+          ASLP_WARN << utt << ", too long, droped";
+          feature_reader.Next();  // (sic) the loop header advances once more: the utterance after a dropped one goes too (:159)
+          if (feature_reader.Done()) break;
+          continue;
+        }
+        const Posterior &targets = targets_reader.Value(utt);
+        if (mat.rows != (int32)targets.size()) { ASLP_WARN << utt << "feat and the target are not the same length, droped"; continue; }
+        if (mat.cols != feat_dim) ASLP_ERR << "feature dim " << mat.cols << " vs network input " << feat_dim;
+        if (max_frame_num < mat.rows) max_frame_num = mat.rows;
+        feats_utt[frame_num_utt.size()] = mat;
+        labels_utt[frame_num_utt.size()] = targets;
+        frame_num_utt.push_back(mat.rows);
+        if ((int32)frame_num_utt.size() == num_stream || frame_num_utt.size() * (double)max_frame_num > frame_limit) { feature_reader.Next(); break; }
+      }
+      const int32 S = frame_num_utt.size();
+      if (S == 0) break;  // nothing usable left (the reference would run the net on an empty batch)
+      HostMatrix feat_mat_host(S * max_frame_num, feat_dim);
+      Posterior target_host((size_t)S * max_frame_num);
+      for (int s = 0; s < S; s++)
+        for (int r = 0; r < frame_num_utt[s]; r++) {
+          const size_t row = (size_t)r * S + s;
+          std::copy(feats_utt[s].data.begin() + (size_t)r * feat_dim, feats_utt[s].data.begin() + (size_t)(r + 1) * feat_dim,
+                    feat_mat_host.data.begin() + row * feat_dim);
+          target_host[row] = labels_utt[s][r];
+        }
+      feats = feat_mat_host;
+      nnet.SetSeqLengths(frame_num_utt);
+      if (!crossvalidate) nnet.Propagate(feats, &nnet_out);
+      else nnet.Feedforward(feats, &nnet_out);
+      loss->Eval(nnet_out, target_host, &obj_diff);
+      if (!crossvalidate) nnet.Backpropagate(obj_diff, NULL);
+      num_done += S;
+      total_frames += feat_mat_host.rows;
+      num_sentence += S;
+      if (num_sentence >= report_period) { ASLP_LOG << loss->Report(); num_sentence -= report_period; }
+      if (feature_reader.Done()) break;
+    }
+    if (!crossvalidate) nnet.Write(target_model_filename, binary);
+    StreamSync();
+    ASLP_LOG << "Done " << num_done << " files, " << num_no_tgt_mat << " with no tgt_mats, " << num_other_error << " with other errors. "
+             << "[" << (crossvalidate ? "CROSS-VALIDATION" : "TRAINING") << ", " << time.Elapsed() / 60 << " min, fps"
+             << total_frames / time.Elapsed() << "]";
+    ASLP_LOG << loss->Report();
     CuDevice::Instantiate().PrintProfile();
     return 0;
   } catch (const std::exception &e) {
@@ -727,6 +964,103 @@ int Main_aslp_nnet_train_ctc_streams(int argc, char *argv[]) {
       num_sentence += cur_sequence_num;
       if (num_sentence >= report_period) { ASLP_LOG << ctc.Report(); num_sentence -= report_period; }
       if (feature_reader.Done()) break;
+    }
+    if (!crossvalidate) ASLP_LOG << net.InfoGradient();
+    if (!crossvalidate) net.Write(target_model_filename, binary);
+    StreamSync();
+    ASLP_LOG << "Done " << num_done << " files, " << num_no_tgt_mat << " with no targets, " << num_other_error << " with other errors. "
+             << "[" << (crossvalidate ? "CROSS-VALIDATION" : "TRAINING") << ", " << time.Elapsed() / 60 << " min, fps"
+             << total_frames / time.Elapsed() << "]";
+    ASLP_LOG << ctc.Report();
+    CuDevice::Instantiate().PrintProfile();
+    return 0;
+  } catch (const std::exception &e) {
+    std::cerr << e.what();
+    return -1;
+  }
+}
+
+// ======================================================================================================================
+// aslp-nnet-train-ctc -- src/aslp-nnetbin/aslp-nnet-train-ctc.cc: CTC training (Eesen objective on the net's softmax output)
+// one utterance per update; --token-symbol-table prints the greedy hypothesis of every utterance in token names.
+int Main_aslp_nnet_train_ctc(int argc, char *argv[]) {
+  using namespace aslp;
+  try {
+    const char *usage =
+        "Perform one iteration of CTC training by SGD.\n"
+        "The updates are done per-utternace and by processing a single utterance at one time.\n"
+        "\n"
+        "Usage: aslp-nnet-train-ctc [options] <feature-rspecifier> <labels-rspecifier> <model-in> [<model-out>]\n"
+        "e.g.: \n"
+        "aslp-nnet-train-ctc scp:feature.scp ark:labels.ark nnet.init nnet.iter1\n";
+    ParseOptions po(usage);
+    NnetTrainOptions trn_opts;
+    RegisterTrainOptions(&trn_opts, &po);
+    bool binary = true, crossvalidate = false;
+    po.Register("binary", &binary, "Write output in binary mode");
+    po.Register("cross-validate", &crossvalidate, "Perform cross-validation (don't backpropagate)");
+    std::string token_syms_filename;
+    po.Register("token-symbol-table", &token_syms_filename, "Symbol table for tokens [for debug output]");
+    int32 report_step = 100;
+    po.Register("report-step", &report_step, "Step (number of sequences) for status reporting");
+    int32 drop_len = 0;
+    po.Register("drop-len", &drop_len, "if Sentence frame length greater than drop_len,then drop it, default(0, no drop)");
+    po.Read(argc, argv);
+    if (po.NumArgs() != 4 - (crossvalidate ? 1 : 0)) { po.PrintUsage(); exit(1); }
+    std::string feature_rspecifier = po.GetArg(1), targets_rspecifier = po.GetArg(2), model_filename = po.GetArg(3);
+    std::string target_model_filename;
+    if (!crossvalidate) target_model_filename = po.GetArg(4);
+
+    // token table in OpenFst's text form: "<symbol> <id>" per line
+    std::map<int32, std::string> token_syms;
+    if (token_syms_filename != "") {
+      bool binary_in;
+      Input ki;
+      if (!ki.Open(token_syms_filename, &binary_in)) ASLP_ERR << "Could not read symbol table from file " << token_syms_filename;
+      std::string sym;
+      int64_t id;
+      while (ki.Stream() >> sym >> id) token_syms[(int32)id] = sym;
+      if (token_syms.empty()) ASLP_ERR << "Could not read symbol table from file " << token_syms_filename;
+    }
+    CuDevice::Instantiate().SelectGpuId("yes");  // the reference has --use-gpu commented out and always asks for a GPU
+
+    Nnet net;
+    net.Read(model_filename);
+    net.SetTrainOptions(trn_opts);
+    int64_t total_frames = 0;
+    SequentialBaseFloatMatrixReader feature_reader(feature_rspecifier);
+    RandomAccessInt32VectorReader targets_reader(targets_rspecifier);
+    Ctc ctc;
+    ctc.SetReportStep(report_step);
+    CuMatrix feats, net_out, obj_diff;
+    Timer time;
+    ASLP_LOG << (crossvalidate ? "CROSS-VALIDATION" : "TRAINING") << " STARTED";
+    int32 num_done = 0, num_no_tgt_mat = 0, num_other_error = 0;
+    for (; !feature_reader.Done(); feature_reader.Next()) {
+      const std::string utt = feature_reader.Key();
+      if (!targets_reader.HasKey(utt)) { ASLP_WARN << utt << ", missing targets"; num_no_tgt_mat++; continue; }
+      const HostMatrix &mat = feature_reader.Value();
+      if (drop_len > 0 && mat.rows > drop_len) { ASLP_WARN << utt << ", too long, droped"; continue; }
+      const std::vector<int32> &targets = targets_reader.Value(utt);
+      feats = mat;
+      if (!crossvalidate) net.Propagate(feats, &net_out);
+      else net.Feedforward(feats, &net_out);
+      ctc.Eval(net_out, targets, &obj_diff);
+      float err = 0.0;
+      std::vector<int32> hyp;
+      ctc.ErrorRate(net_out, targets, &err, &hyp);
+      if (!crossvalidate) net.Backpropagate(obj_diff, NULL);
+      if (!token_syms.empty()) {
+        std::cerr << utt << ' ';
+        for (int32 h : hyp) {
+          auto it = token_syms.find(h);
+          if (it == token_syms.end()) ASLP_ERR << "Token-id " << h << " not in symbol table.";
+          std::cerr << it->second << " ";
+        }
+        std::cerr << '\n';
+      }
+      num_done++;
+      total_frames += mat.rows;
     }
     if (!crossvalidate) ASLP_LOG << net.InfoGradient();
     if (!crossvalidate) net.Write(target_model_filename, binary);

@@ -759,3 +759,236 @@ def test_feature_transform_option(aslp, oracle, dev, tmp_path):
     tool("aslp-nnet-forward", "--feature-transform=%s" % (tmp_path / "tr.nnet"), str(tmp_path / "a.nnet"), "ark:%s" % (tmp_path / "raw.ark"), "ark:%s" % (tmp_path / "fa.ark"))
     tool("aslp-nnet-forward", str(tmp_path / "a.nnet"), "ark:%s" % (tmp_path / "spl.ark"), "ark:%s" % (tmp_path / "fb.ark"))
     assert (tmp_path / "fa.ark").read_bytes() == (tmp_path / "fb.ark").read_bytes()
+
+
+def test_train_mse_tool_matches_float64_sgd(aslp, oracle, dev, tmp_path):
+    """aslp-nnet-train-mse: matrix targets read in step with the features, Mse diff = (y - t) * w, momentum SGD.  Checked
+    against float64 numpy stepping through the same (unshuffled) minibatches; an utterance whose target has another
+    number of rows is left out; tables in a different order are an error."""
+    rng = np.random.default_rng(31)
+    D, H, O, mb = 10, 24, 6, 16
+    W1, b1 = rng.standard_normal((H, D)).astype(np.float32) * 0.3, rng.standard_normal(H).astype(np.float32) * 0.1
+    W2, b2 = rng.standard_normal((O, H)).astype(np.float32) * 0.3, np.zeros(O, np.float32)
+    nnet_io.write_simple_nnet(tmp_path / "r.nnet", [("<AffineTransform>", D, H, nnet_io.affine(W1, b1)), ("<Sigmoid>", H, H, b""),
+                                                     ("<AffineTransform>", H, O, nnet_io.affine(W2, b2))])
+    keys = ["r%02d" % i for i in range(8)]
+    lens = [int(x) for x in rng.integers(10, 40, len(keys))]
+    feats = [rng.standard_normal((n, D)).astype(np.float32) for n in lens]
+    tgts = [rng.standard_normal((n, O)).astype(np.float32) for n in lens]
+    tgts[2] = tgts[2][:-1]  # row count differs: warned about and left out
+    (tmp_path / "f.ark").write_bytes(kf.archive([(k, kf.matrix_bin(f)) for k, f in zip(keys, feats)]))
+    (tmp_path / "t.ark").write_bytes(kf.archive([(k, kf.matrix_bin(t)) for k, t in zip(keys, tgts)]))
+    lr, mom = 0.002, 0.5
+    p = tool("aslp-nnet-train-mse", "--learn-rate=%g" % lr, "--momentum=%g" % mom, "--minibatch-size=%d" % mb, "--randomize=false",
+             "--report-period=64", "ark:%s" % (tmp_path / "f.ark"), "ark:%s" % (tmp_path / "t.ark"), str(tmp_path / "r.nnet"), str(tmp_path / "r.out"))
+    err = p.stderr.decode()
+    assert "%s feat and target are not the same dim feat %d target %d" % (keys[2], lens[2], lens[2] - 1) in err
+    assert "Done 7 files, 0 with no tgt_mats, 0 with other errors. [TRAINING, NOT-RANDOMIZED" in err and "AvgLoss:" in err
+    X = np.concatenate([f for i, f in enumerate(feats) if i != 2]).astype(np.float64)
+    Tg = np.concatenate([t for i, t in enumerate(tgts) if i != 2]).astype(np.float64)
+    P = [a.astype(np.float64) for a in (W1, b1, W2, b2)]
+    V = [np.zeros_like(a) for a in P]
+    for s in range(0, len(X) - mb + 1, mb):
+        x, t = X[s:s + mb], Tg[s:s + mb]
+        h = 1.0 / (1.0 + np.exp(-(x @ P[0].T + P[1])))
+        y = h @ P[2].T + P[3]
+        d2 = y - t
+        d1 = (d2 @ P[2]) * h * (1.0 - h)
+        G = [d1.T @ x, d1.sum(0), d2.T @ h, d2.sum(0)]
+        for k in range(4):
+            V[k] = G[k] + mom * V[k]
+            P[k] = P[k] - lr * V[k]
+    got = aslp.Nnet.Read(tmp_path / "r.out").GetParams()
+    assert oracle.rel_err(got, np.concatenate([a.ravel() for a in P])) < TOL
+    # cross-validation on the trained model: no update, loss reported
+    p = tool("aslp-nnet-train-mse", "--cross-validate=true", "--minibatch-size=%d" % mb, "ark:%s" % (tmp_path / "f.ark"), "ark:%s" % (tmp_path / "t.ark"),
+             str(tmp_path / "r.out"))
+    assert b"[CROSS-VALIDATION, RANDOMIZED" in p.stderr and b"AvgLoss:" in p.stderr
+    # the two tables must list the same keys in the same order
+    (tmp_path / "t2.ark").write_bytes(kf.archive([(k, kf.matrix_bin(t)) for k, t in list(zip(keys, tgts))[::-1]]))
+    p = tool("aslp-nnet-train-mse", "ark:%s" % (tmp_path / "f.ark"), "ark:%s" % (tmp_path / "t2.ark"), str(tmp_path / "r.nnet"), str(tmp_path / "x.out"), ok=False)
+    assert p.returncode != 0 and b"feat and target not in the same order" in p.stderr
+
+
+def test_train_ctc_tool_matches_api(aslp, dev, tmp_path):
+    """aslp-nnet-train-ctc: one utterance per update with the Eesen objective; missing targets and --drop-len leave utterances
+    out; --token-symbol-table prints every greedy hypothesis in token names."""
+    # a unidirectional net: with no SetSeqLengths / ResetLstmStreams call the LSTM runs as one stream, history carried over
+    (tmp_path / "e.proto").write_text(LSTM_PROTO.replace("<OutputDim> 10", "<OutputDim> 9").replace("<InputDim> 10", "<InputDim> 9"))
+    tool("aslp-nnet-init", "--seed=72", str(tmp_path / "e.proto"), str(tmp_path / "e.init"))
+    rng = np.random.default_rng(16)
+    n_utt, D, A = 6, 12, 9
+    keys = ["c%02d" % i for i in range(n_utt)]
+    lens = [int(x) for x in rng.integers(12, 40, n_utt)]
+    lens[4] = 55
+    feats = [rng.standard_normal((n, D)).astype(np.float32) for n in lens]
+    labels = [[int(x) for x in rng.integers(1, A, max(1, n // 5))] for n in lens]
+    (tmp_path / "feats.ark").write_bytes(kf.archive([(k, kf.matrix_bin(f)) for k, f in zip(keys, feats)]))
+    (tmp_path / "lab.ark").write_bytes(kf.archive([(k, kf.int32vec_bin(l)) for k, l in zip(keys, labels) if k != keys[1]]))
+    (tmp_path / "tokens.txt").write_text("".join("tok%d %d\n" % (i, i) for i in range(A)))
+    lr = 0.01
+    p = tool("aslp-nnet-train-ctc", "--learn-rate=%g" % lr, "--momentum=0.9", "--drop-len=50", "--token-symbol-table=%s" % (tmp_path / "tokens.txt"),
+             "ark:%s" % (tmp_path / "feats.ark"), "ark:%s" % (tmp_path / "lab.ark"), str(tmp_path / "e.init"), str(tmp_path / "e.out"))
+    err = p.stderr.decode()
+    assert "%s, missing targets" % keys[1] in err and "%s, too long, droped" % keys[4] in err
+    assert "Done 4 files, 1 with no targets, 0 with other errors. [TRAINING" in err and "TOKEN_ACCURACY" in err
+    net = aslp.Nnet.Read(tmp_path / "e.init")
+    net.SetTrainOptions(learn_rate=lr, momentum=0.9)
+    ctc = aslp.Ctc()
+    for i in range(n_utt):
+        if i in (1, 4):
+            continue
+        y = net.Propagate(torch.from_numpy(feats[i]).to(dev))
+        diff = ctc.Eval(y, labels[i])
+        diff = diff[0] if isinstance(diff, tuple) else diff
+        ctc.ErrorRate(y, labels[i])
+        best = y.argmax(1).cpu().numpy()  # greedy path: collapse repeats, drop blanks (ctc-loss.cc:229-262)
+        hyp = [int(a) for k, a in enumerate(best) if a != 0 and (k == 0 or a != best[k - 1])]
+        net.Backpropagate(diff)
+        line = [ln for ln in err.splitlines() if ln.startswith(keys[i] + " ")]
+        assert len(line) == 1 and line[0].split()[1:] == ["tok%d" % h for h in hyp]
+    assert np.array_equal(aslp.Nnet.Read(tmp_path / "e.out").GetParams(), net.GetParams())
+    assert ctc.Report().strip().splitlines()[-1] in err
+
+
+def test_lstm_streams_skip_tool_matches_api(aslp, dev, tmp_path):
+    """aslp-nnet-train-lstm-streams-skip: skip-width passes over the data, pass k on frames k, k + skip-width, ... of every
+    utterance; each pass ends as soon as all streams are exhausted (no extra step on a stale batch, unlike the -streams tool)."""
+    (tmp_path / "l.proto").write_text(LSTM_PROTO)
+    tool("aslp-nnet-init", "--seed=52", str(tmp_path / "l.proto"), str(tmp_path / "l.init"))
+    rng = np.random.default_rng(33)
+    n_utt, D, A, S, B, delay, W = 6, 12, 10, 2, 4, 1, 3
+    keys = ["k%02d" % i for i in range(n_utt)]
+    lens = [int(x) for x in rng.integers(4, 25, n_utt)]
+    feats = [rng.standard_normal((n, D)).astype(np.float32) for n in lens]
+    posts = [[[(int(rng.integers(0, A)), 1.0)] for _ in range(n)] for n in lens]
+    (tmp_path / "feats.ark").write_bytes(kf.archive([(k, kf.matrix_bin(f)) for k, f in zip(keys, feats)]))
+    (tmp_path / "post.ark").write_bytes(kf.archive([(k, kf.posterior_bin(p)) for k, p in zip(keys, posts)]))
+    lr, mom = 0.02, 0.9
+    p = tool("aslp-nnet-train-lstm-streams-skip", "--learn-rate=%g" % lr, "--momentum=%g" % mom, "--num-stream=%d" % S, "--batch-size=%d" % B,
+             "--targets-delay=%d" % delay, "--skip-width=%d" % W, "ark:%s" % (tmp_path / "feats.ark"), "ark:%s" % (tmp_path / "post.ark"),
+             str(tmp_path / "l.init"), str(tmp_path / "l.out"))
+    err = p.stderr.decode()
+    net = aslp.Nnet.Read(tmp_path / "l.init")
+    net.SetTrainOptions(learn_rate=lr, momentum=mom)
+    xent = aslp.Xent()
+    steps = num_done = 0
+    for off in range(W):
+        sub_f = [f[off::W] for f in feats]
+        sub_p = [q[off::W] for q in posts]
+        sub_n = [len(q) for q in sub_p]
+        todo = list(range(n_utt))
+        cur, length, which, flags = [0] * S, [0] * S, [None] * S, [0] * S
+        while True:
+            for s in range(S):
+                if cur[s] < length[s]:
+                    flags[s] = 0
+                    continue
+                if todo:
+                    which[s] = todo.pop(0)
+                    cur[s], length[s], flags[s] = 0, sub_n[which[s]], 1
+            if all(cur[s] >= length[s] for s in range(S)):
+                break
+            x = np.zeros((B * S, D), np.float32)
+            lab = np.zeros(B * S, np.int32)
+            mask = np.zeros(B * S, np.float32)
+            for t in range(B):
+                for s in range(S):
+                    r, u = t * S + s, which[s]
+                    if cur[s] < length[s]:
+                        mask[r] = 1.0
+                        lab[r] = sub_p[u][cur[s]][0][0]
+                    else:
+                        lab[r] = sub_p[u][length[s] - 1][0][0]
+                    x[r] = sub_f[u][min(cur[s] + delay, length[s] - 1)]
+                    cur[s] += 1
+            net.ResetLstmStreams(flags)
+            y = net.Propagate(torch.from_numpy(x).to(dev))
+            diff = torch.empty_like(y)
+            xent.Eval(torch.from_numpy(mask).to(dev), y, diff, labels=torch.from_numpy(lab).to(dev))
+            net.Backpropagate(diff)
+            steps += 1
+            num_done += sum(flags)
+    assert steps > 8 and num_done == W * n_utt
+    assert np.array_equal(aslp.Nnet.Read(tmp_path / "l.out").GetParams(), net.GetParams())
+    assert "Done %d files, 0 with no tgt_mats, 0 with other errors. [TRAINING, NOT-RANDOMIZED" % num_done in err
+    assert xent.Report().splitlines()[1] in err
+
+
+def test_blstm_parallel_tool_matches_api(aslp, dev, tmp_path):
+    """aslp-nnet-train-blstm-parallel: groups of num-stream whole utterances, NO frame weights (padded frames count, with an
+    empty target), fixed learning rate."""
+    (tmp_path / "b.proto").write_text(BLSTM_PROTO)
+    tool("aslp-nnet-init", "--seed=82", str(tmp_path / "b.proto"), str(tmp_path / "b.init"))
+    rng = np.random.default_rng(24)
+    n_utt, D, A, S = 7, 12, 10, 3
+    keys = ["q%02d" % i for i in range(n_utt)]
+    lens = [int(x) for x in rng.integers(5, 30, n_utt)]
+    feats = [rng.standard_normal((n, D)).astype(np.float32) for n in lens]
+    posts = [[[(int(rng.integers(0, A)), 1.0)] for _ in range(n)] for n in lens]
+    (tmp_path / "feats.ark").write_bytes(kf.archive([(k, kf.matrix_bin(f)) for k, f in zip(keys, feats)]))
+    (tmp_path / "post.ark").write_bytes(kf.archive([(k, kf.posterior_bin(p)) for k, p in zip(keys, posts)]))
+    lr = 0.001
+    p = tool("aslp-nnet-train-blstm-parallel", "--learn-rate=%g" % lr, "--momentum=0.9", "--num-stream=%d" % S, "ark:%s" % (tmp_path / "feats.ark"),
+             "ark:%s" % (tmp_path / "post.ark"), str(tmp_path / "b.init"), str(tmp_path / "b.out"))
+    assert b"Done 7 files, 0 with no tgt_mats, 0 with other errors. [TRAINING, " in p.stderr
+    net = aslp.Nnet.Read(tmp_path / "b.init")
+    net.SetTrainOptions(learn_rate=lr, momentum=0.9)
+    xent = aslp.Xent()
+    todo = list(range(n_utt))
+    while todo:
+        grp, todo = todo[:S], todo[S:]
+        n, mx = len(grp), max(lens[i] for i in grp)
+        x = np.zeros((n * mx, D), np.float32)
+        tgt = np.zeros((n * mx, A), np.float32)
+        for s, i in enumerate(grp):
+            rows = np.arange(lens[i]) * n + s
+            x[rows] = feats[i]
+            tgt[rows, [fr[0][0] for fr in posts[i]]] = 1.0
+        net.SetSeqLengths([lens[i] for i in grp])
+        y = net.Propagate(torch.from_numpy(x).to(dev))
+        diff = torch.empty_like(y)
+        xent.Eval(torch.ones(n * mx, device=dev), y, diff, targets=torch.from_numpy(tgt).to(dev))
+        net.Backpropagate(diff)
+    assert np.array_equal(aslp.Nnet.Read(tmp_path / "b.out").GetParams(), net.GetParams())
+    assert xent.Report().splitlines()[1] in p.stderr.decode()
+
+
+def test_forward_mimo_tool(aslp, dev, tmp_path):
+    """aslp-nnet-forward-mimo on a two-input / two-output graph net: the LAST output is written, equal to what aslp-nnet-forward
+    writes for that branch alone; tables whose keys disagree are an error."""
+    rng = np.random.default_rng(41)
+    dims = [(10, 24, 7), (14, 16, 5)]
+    comps, cid = [], 2
+    comps.append(dict(marker="<InputLayer>", dim_in=dims[0][0], dim_out=dims[0][0], id=0, inputs=[-1], offsets=[0]))
+    comps.append(dict(marker="<InputLayer>", dim_in=dims[1][0], dim_out=dims[1][0], id=1, inputs=[-1], offsets=[0]))
+    for b, (di, h, a) in enumerate(dims):
+        W1, b1 = rng.standard_normal((h, di)).astype(np.float32) * 0.3, rng.standard_normal(h).astype(np.float32) * 0.1
+        W2, b2 = rng.standard_normal((a, h)).astype(np.float32) * 0.3, rng.standard_normal(a).astype(np.float32) * 0.1
+        comps.append(dict(marker="<AffineTransform>", dim_in=di, dim_out=h, id=cid, inputs=[b], offsets=[0], data=nnet_io.affine(W1, b1)))
+        comps.append(dict(marker="<Sigmoid>", dim_in=h, dim_out=h, id=cid + 1, inputs=[cid], offsets=[0]))
+        comps.append(dict(marker="<AffineTransform>", dim_in=h, dim_out=a, id=cid + 2, inputs=[cid + 1], offsets=[0], data=nnet_io.affine(W2, b2)))
+        comps.append(dict(marker="<Softmax>", dim_in=a, dim_out=a, id=cid + 3, inputs=[cid + 2], offsets=[0]))
+        comps.append(dict(marker="<OutputLayer>", dim_in=a, dim_out=a, id=cid + 4, inputs=[cid + 3], offsets=[0]))
+        cid += 5
+        nnet_io.write_simple_nnet(tmp_path / ("b%d.nnet" % b), [("<AffineTransform>", di, h, nnet_io.affine(W1, b1)), ("<Sigmoid>", h, h, b""),
+                                                                 ("<AffineTransform>", h, a, nnet_io.affine(W2, b2)), ("<Softmax>", a, a, b"")])
+    nnet_io.write_graph_nnet(tmp_path / "mimo.nnet", comps)
+    keys = ["m%02d" % i for i in range(5)]
+    lens = [int(x) for x in rng.integers(5, 30, len(keys))]
+    for b, (di, h, a) in enumerate(dims):
+        feats = [rng.standard_normal((n, di)).astype(np.float32) for n in lens]
+        (tmp_path / ("f%d.ark" % b)).write_bytes(kf.archive([(k, kf.matrix_bin(f)) for k, f in zip(keys, feats)]))
+    p = tool("aslp-nnet-forward-mimo", "--apply-log=true", str(tmp_path / "mimo.nnet"), "ark:%s" % (tmp_path / "f0.ark"), "ark:%s" % (tmp_path / "f1.ark"),
+             "ark:%s" % (tmp_path / "out.ark"))
+    assert b"Nnet num_input 2 num_output 2" in p.stderr and b"Done 5 files" in p.stderr
+    tool("aslp-nnet-forward", "--apply-log=true", str(tmp_path / "b1.nnet"), "ark:%s" % (tmp_path / "f1.ark"), "ark:%s" % (tmp_path / "single.ark"))
+    assert (tmp_path / "out.ark").read_bytes() == (tmp_path / "single.ark").read_bytes()
+    # key order differs between the tables
+    ent = kf.parse_bin_archive((tmp_path / "f1.ark").read_bytes(), "matrix")
+    (tmp_path / "f1r.ark").write_bytes(kf.archive([(k, kf.matrix_bin(m)) for k, m in ent[::-1]]))
+    p = tool("aslp-nnet-forward-mimo", str(tmp_path / "mimo.nnet"), "ark:%s" % (tmp_path / "f0.ark"), "ark:%s" % (tmp_path / "f1r.ark"),
+             "ark:%s" % (tmp_path / "x.ark"), ok=False)
+    assert p.returncode != 0 and b"Different key from the features" in p.stderr
+    p = tool("aslp-nnet-forward-mimo", str(tmp_path / "mimo.nnet"), "ark:%s" % (tmp_path / "f0.ark"), "ark:%s" % (tmp_path / "x.ark"), ok=False)
+    assert p.returncode == 1
