@@ -99,6 +99,23 @@ void aslp_matrix_sum(const float *M, MatrixDim d, double *out_dev);
 void aslp_copy_mat(float *dst, MatrixDim d, const float *src, int src_stride);
 void aslp_vec_axpy(float alpha, const float *x, float *y, int dim);           /* y += alpha x */
 void aslp_vec_axpy2(float alpha, const float *x1, float *y1, const float *x2, float *y2, int dim); /* two at once */
+void aslp_vec_diff(float *out, const float *a, const float *b, int n);        /* out = a - b */
+/* ---- SOD model sync: one pass per tensor (csrc/optim_kernels.hip; aslp-parallel/optimizer.h:40-171, sod-worker.cc:46-58) ----
+ * Advances the solver state (state1 / state2: what the solver keeps per element, zero at the start; unused ones may be NULL),
+ * applies the step to param and copies the new param to prev:
+ *   sgd       p -= lr g
+ *   momentum  m = lr g + momentum m;  p -= m                                          (state1 = m)
+ *   adagrad   G = g g + G;             p -= lr g / sqrt(max(G, 1e-8))                  (state1 = G)
+ *   rmsprop   G = 0.1 g g + 0.9 G;     p -= lr g / sqrt(max(G, 1e-8))                  (state1 = G)
+ *   adadelta  G = (1-gamma) g g + gamma G;  d = g sqrt(max(D, 1e-8)) / sqrt(max(G, 1e-8));  p -= d;  D = (1-gamma) d d + gamma D
+ *   adam      m = (1-b1) g + b1 m;  v = (1-b2) g g + b2 v;  p -= lr corr1 m / sqrt(max(v corr2, 1e-8))
+ *             with corr1 = 1 / (1 - b1^t), corr2 = 1 / (1 - b2^t) computed by the caller for its step counter t = 1, 2, ... */
+enum { ASLP_SOD_SGD = 0, ASLP_SOD_MOMENTUM = 1, ASLP_SOD_ADAGRAD = 2, ASLP_SOD_RMSPROP = 3, ASLP_SOD_ADADELTA = 4, ASLP_SOD_ADAM = 5 };
+typedef struct aslp_sod_solver_ {
+  int solver;
+  float lr, momentum, gamma, beta1, beta2, corr1, corr2;
+} aslp_sod_solver;
+void aslp_sod_solve(const aslp_sod_solver *a, const float *grad, float *param, float *prev, float *state1, float *state2, int n);
 void aslp_f2d(double *dst, const float *src, int n);
 void aslp_d2f(float *dst, const double *src, int n);
 

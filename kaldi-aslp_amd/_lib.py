@@ -30,6 +30,12 @@ class RnnVecGrad(C.Structure):
     _fields_ = [("d", C.c_void_p), ("x", C.c_void_p), ("ldx", C.c_int), ("n", C.c_int), ("corr", C.c_void_p), ("param", C.c_void_p)]
 
 
+class SodSolver(C.Structure):
+    """aslp_sod_solver (include/aslp_kernels.h)"""
+    _fields_ = [("solver", C.c_int), ("lr", C.c_float), ("momentum", C.c_float), ("gamma", C.c_float), ("beta1", C.c_float),
+                ("beta2", C.c_float), ("corr1", C.c_float), ("corr2", C.c_float)]
+
+
 class CtcComputeInfo(C.Structure):
     """warp-ctc/include/ctc.h:45-60 (ctcComputeInfo: loc + union{num_threads, stream})"""
     _fields_ = [("loc", C.c_int), ("stream_or_threads", C.c_void_p)]
@@ -127,6 +133,8 @@ _sig("aslp_softmax_xent_eval", None, _vp, _md, _vp, _i, _vp, _vp, _vp, _i, _vp, 
 _sig("aslp_dropout_forward", None, _vp, _i, _vp, _md, _vp, _i, _f, C.c_ulonglong)
 _sig("aslp_dropout_backward", None, _vp, _i, _vp, _md, _vp, _i, _f)
 _sig("aslp_apply_clamp", None, _vp, _md, _f, _f)
+_sig("aslp_vec_diff", None, _vp, _vp, _vp, _i)
+_sig("aslp_sod_solve", None, C.POINTER(SodSolver), _vp, _vp, _vp, _vp, _vp, _i)
 _sig("aslp_rnn_vec_grads", None, C.POINTER(RnnVecGrad), _i, _i, _i, _f, _f, _f)
 _sig("aslp_scatter_add", None, _vp, _md, _vp, _vp, _vp, _i)
 _sig("aslp_splice_backward", None, _vp, _md, _vp, _i, _vp, _i)

@@ -170,6 +170,75 @@ class BmufWorker(MpiNodeLike):
             pass
 
 
+class SodWorker(MpiNodeLike):
+    """"Synchronous optimize the difference" (sod-worker.cc:36-68): the summed model deltas w(t-1) - w(t) are handed to one of
+    the solvers of optimizer.h:40-171 as a gradient, and the solver steps this worker's own current model."""
+
+    DEFAULTS = dict(solver="momentum", lr=0.01, momentum=0.9, adagrad_lr=0.01, rmsprop_lr=0.001, adam_lr=0.001, adadelta_gamma=0.95,
+                    adam_beta1=0.9, adam_beta2=0.999)   # optimizer.h:180-184
+
+    def __init__(self, model_or_params=None, group=None, **config):
+        super().__init__(group)
+        unknown = set(config) - set(self.DEFAULTS)
+        if unknown:
+            raise ValueError("unknown optimizer options: %s" % sorted(unknown))
+        self.cfg = dict(self.DEFAULTS, **config)
+        if self.cfg["solver"] not in ("sgd", "momentum", "adagrad", "rmsprop", "adadelta", "adam"):
+            raise ValueError("Unknown solver type %s" % self.cfg["solver"])
+        self.t = 1
+        if model_or_params is not None:
+            self.InitParam(model_or_params)
+
+    def InitParam(self, model_or_params):
+        self.fp = _FlatParams(_params_of(model_or_params))
+        self.prev = self.fp.pack().clone()
+        self.s1, self.s2 = torch.zeros_like(self.prev), torch.zeros_like(self.prev)
+
+    def _solve(self, g, w):
+        c, k = self.cfg, self.cfg["solver"]
+        floor_rsqrt = lambda v: v.clamp(min=1e-8).sqrt_().reciprocal_()
+        if k == "sgd":
+            w.add_(g, alpha=-c["lr"])
+        elif k == "momentum":
+            self.s1.mul_(c["momentum"]).add_(g, alpha=c["lr"])
+            w.sub_(self.s1)
+        elif k in ("adagrad", "rmsprop"):
+            if k == "adagrad":
+                self.s1.addcmul_(g, g)
+            else:
+                self.s1.mul_(0.9).addcmul_(g, g, value=0.1)
+            w.add_(floor_rsqrt(self.s1).mul_(g), alpha=-(c["adagrad_lr"] if k == "adagrad" else c["rmsprop_lr"]))
+        elif k == "adadelta":
+            gm = c["adadelta_gamma"]
+            self.s1.mul_(gm).addcmul_(g, g, value=1 - gm)
+            d = floor_rsqrt(self.s1).mul_(self.s2.clamp(min=1e-8).sqrt_()).mul_(g)
+            w.sub_(d)
+            self.s2.mul_(gm).addcmul_(d, d, value=1 - gm)
+        else:
+            b1, b2 = c["adam_beta1"], c["adam_beta2"]
+            self.s1.mul_(b1).add_(g, alpha=1 - b1)
+            self.s2.mul_(b2).addcmul_(g, g, value=1 - b2)
+            w.add_(floor_rsqrt(self.s2 * (1.0 / (1 - b2 ** self.t))).mul_(self.s1), alpha=-c["adam_lr"] / (1 - b1 ** self.t))
+
+    def Synchronize(self, num_worker_samples):
+        n = torch.tensor([int(num_worker_samples)], dtype=torch.int32, device=self.fp.device)
+        self.AllReduce(n)
+        if int(n.item()) <= 0:
+            return False
+        w = self.fp.pack()
+        grad = self.prev - w                 # 1. w(t-1) - w(t)
+        self.AllReduce(grad)                 # 2. summed over workers
+        self._solve(grad, w)                 # 4. on the LOCAL model: workers are not re-unified
+        self.t += 1
+        self.fp.unpack()
+        self.prev.copy_(w)                   # 5.
+        return True
+
+    def Stop(self):
+        while self.Synchronize(0):
+            pass
+
+
 K_MSG_SYNCHRONIZE, K_MSG_FINISHED = 0, 1   # itf.h:19-22
 
 

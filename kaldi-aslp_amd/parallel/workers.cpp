@@ -3,6 +3,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cmath>
+
 #include "aslp_kernels.h"
 #include "common.h"
 
@@ -86,6 +88,52 @@ bool BmufWorker::Synchronize(int num_worker_samples) {
   return true;
 }
 void BmufWorker::Stop() {
+  ASLP_LOG << "Worker " << Rank() << "finished, waitting for others";
+  while (Synchronize(0)) {}
+}
+
+// ---- SOD (sod-worker.cc:36-68) -----------------------------------------------------------------------------------
+SodWorker::SodWorker(Comm *comm, const OptimizerOption &config) : IWorker(comm), config_(config), solver_(-1), step_(1) {
+  const char *names[] = {"sgd", "momentum", "adagrad", "rmsprop", "adadelta", "adam"};
+  for (int k = 0; k < 6; k++)
+    if (config_.solver == names[k]) solver_ = k;
+  if (solver_ < 0) ASLP_ERR << "Unknown solver type " << config_.solver;
+}
+void SodWorker::InitParam(const std::vector<std::pair<BaseFloat *, int>> &params) {
+  params_ = params;
+  prev_ = AllocLike(params, true);  // w(t-1) = the initial model
+  grad_ = AllocLike(params, false);
+  if (solver_ != ASLP_SOD_SGD) state1_ = AllocLike(params, false);
+  if (solver_ == ASLP_SOD_ADADELTA || solver_ == ASLP_SOD_ADAM) state2_ = AllocLike(params, false);
+}
+SodWorker::~SodWorker() {
+  for (auto *v : {&prev_, &grad_, &state1_, &state2_})
+    for (auto &p : *v) (void)hipFree(p.first);
+}
+bool SodWorker::Synchronize(int num_worker_samples) {
+  int32 num_all_samples = num_worker_samples;
+  comm_->AllReduceSumHost(&num_all_samples, 1);
+  if (num_all_samples <= 0) { ASLP_LOG << "All worker finished their data"; return false; }
+  for (size_t i = 0; i < params_.size(); i++) aslp_vec_diff(grad_[i].first, prev_[i].first, params_[i].first, params_[i].second);  // 1. w(t-1) - w(t)
+  CheckK();
+  comm_->AllReduceSumMany(grad_);  // 2./3. summed over workers where they live
+  aslp_sod_solver a = {};
+  a.solver = solver_;
+  a.lr = solver_ == ASLP_SOD_ADAGRAD ? config_.adagrad_lr : solver_ == ASLP_SOD_RMSPROP ? config_.rmsprop_lr : solver_ == ASLP_SOD_ADAM ? config_.adam_lr : config_.lr;
+  a.momentum = config_.momentum;
+  a.gamma = config_.adadelta_gamma;
+  a.beta1 = config_.adam_beta1;
+  a.beta2 = config_.adam_beta2;
+  a.corr1 = 1.0 / (1 - pow(a.beta1, step_));  // optimizer.h:158-159
+  a.corr2 = 1.0 / (1 - pow(a.beta2, step_));
+  for (size_t i = 0; i < params_.size(); i++)  // 4. solver step on the local model, 5. which becomes the new reference point
+    aslp_sod_solve(&a, grad_[i].first, params_[i].first, prev_[i].first, state1_.empty() ? nullptr : state1_[i].first,
+                   state2_.empty() ? nullptr : state2_[i].first, params_[i].second);
+  CheckK();
+  step_++;
+  return true;
+}
+void SodWorker::Stop() {
   ASLP_LOG << "Worker " << Rank() << "finished, waitting for others";
   while (Synchronize(0)) {}
 }

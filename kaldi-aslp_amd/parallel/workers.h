@@ -1,9 +1,11 @@
-// workers.h -- seam B6: the model-sync interface of src/aslp-parallel/itf.h:26-42 and the two collective workers,
-// BspWorker (bsp-worker.cc:33-65) and BmufWorker (bmuf-worker.cc:37-68), on a Comm (comm.h).  The workers alias the
+// workers.h -- seam B6: the model-sync interface of src/aslp-parallel/itf.h:26-42 and the three collective workers,
+// BspWorker (bsp-worker.cc:33-65), BmufWorker (bmuf-worker.cc:37-68) and SodWorker (sod-worker.cc:36-68, with the six
+// solvers of optimizer.h), on a Comm (comm.h).  The workers alias the
 // model's device memory (GetGpuParams) and never own it; the reference copies every tensor to the host, calls
 // MPI_Allreduce per tensor and copies back -- here the tensors are reduced where they live, in one grouped collective.
 #pragma once
 #include <memory>
+#include <string>
 #include <vector>
 
 #include "comm.h"
@@ -53,6 +55,43 @@ class BmufWorker : public IWorker {
   float learn_rate_, momentum_;
   std::vector<std::pair<BaseFloat *, int>> params_;
   std::vector<std::pair<BaseFloat *, int>> prev_, prev_grad_, grad_;  // w_g(t-1), d(t-1), work buffers (owned)
+};
+
+// optimizer.h:173-230: which solver SOD runs on the summed model deltas, with the reference's flag names and defaults
+struct OptimizerOption {
+  std::string solver = "momentum";
+  float lr = 0.01f, momentum = 0.9f, adagrad_lr = 0.01f, rmsprop_lr = 0.001f, adam_lr = 0.001f, adadelta_gamma = 0.95f, adam_beta1 = 0.9f,
+        adam_beta2 = 0.999f;
+  template <class Opts>
+  void Register(Opts *opts) {
+    opts->Register("solver", &solver, "Optimizer solver(sgd | momentum | adagrad | adadelta | rmsprop | adam)");
+    opts->Register("lr", &lr, "learning rate for (sgd | momentum) optimizer");
+    opts->Register("sgd-momentum", &momentum, "momentum for (momentum) optimizer");
+    opts->Register("adagrad-lr", &adagrad_lr, "learning rate for (adagrad) optimizer");
+    opts->Register("rmsprop-lr", &rmsprop_lr, "learning rate for (rmsprop) optimizer");
+    opts->Register("adam-lr", &adam_lr, "learning rate for (adam) optimizer");
+    opts->Register("adadelta-gamma", &adadelta_gamma, "update factor for (adadelta) optimizer");
+    opts->Register("adam-beta1", &adam_beta1, "update mean factor for (adam) optimizer");
+    opts->Register("adam-beta2", &adam_beta2, "update variance factor for (adam) optimizer");
+  }
+};
+
+// "Synchronous Optimize the Difference between global and local model" (sod-worker.h:17): the workers' model deltas since the
+// last sync are summed and handed to a solver as if they were a gradient; the solver steps each worker's OWN current model
+// (the models are not re-unified -- they stay apart by whatever separated them at the start, as in the reference).
+class SodWorker : public IWorker {
+ public:
+  SodWorker(Comm *comm, const OptimizerOption &config);
+  ~SodWorker();
+  void InitParam(const std::vector<std::pair<BaseFloat *, int>> &params);
+  bool Synchronize(int num_worker_samples);
+  void Stop();
+
+ private:
+  OptimizerOption config_;
+  int solver_, step_;  // step_: Adam's t (optimizer.h:150), one counter serves every tensor since all advance together
+  std::vector<std::pair<BaseFloat *, int>> params_;
+  std::vector<std::pair<BaseFloat *, int>> prev_, grad_, state1_, state2_;  // owned
 };
 
 }  // namespace aslp

@@ -1,7 +1,8 @@
-// aslp-parallel-selftest -- runs BspWorker / BmufWorker with N ranks as threads of this process (ThreadComm) on raw device
+// aslp-parallel-selftest -- runs BspWorker / BmufWorker / SodWorker with N ranks as threads of this process (ThreadComm) on raw device
 // buffers and prints every rank's parameters after each synchronisation, one line per (step, rank): the GPU test compares
 // them with the closed forms of bsp-worker.cc:33-65 / bmuf-worker.cc:37-68 computed in numpy.
-// Usage: aslp-parallel-selftest <bsp|bmuf> <num-ranks> <dim> <steps> [bmuf-lr bmuf-momentum]
+// (sod: of optimizer.h:40-171 applied to the summed deltas, sod-worker.cc:46-58).
+// Usage: aslp-parallel-selftest <bsp|bmuf|sod:SOLVER> <num-ranks> <dim> <steps> [bmuf-lr bmuf-momentum]   (sod runs the solver's defaults)
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -39,6 +40,7 @@ int main(int argc, char **argv) {
         std::vector<std::pair<float *, int>> params = {{d, n1}, {d + n1, n2}};
         std::unique_ptr<IWorker> w;
         if (type == "bsp") w.reset(new BspWorker(comm.get()));
+        else if (type.compare(0, 4, "sod:") == 0) { OptimizerOption o; o.solver = type.substr(4); w.reset(new SodWorker(comm.get(), o)); }
         else w.reset(new BmufWorker(comm.get(), lr, mom));
         w->InitParam(params);
         for (int s = 0; s <= steps; s++) {

@@ -41,6 +41,8 @@ int Main_aslp_nnet_train_frame_worker(int argc, char *argv[]) {
     po.Register("report-period", &report_period, "Number of frames for one report log, default(-1, no report)");
     std::string worker_type = "bsp";
     po.Register("worker-type", &worker_type, "Worker type(bsp | bmuf | easgd | asgd | masgd | sod)");
+    OptimizerOption optimizer_opts;
+    optimizer_opts.Register(&po);
     float alpha = 0.5;
     po.Register("alpha", &alpha, "Moving rate alpha for easgd worker");
     float bmuf_momentum = 0.9;
@@ -82,7 +84,8 @@ int Main_aslp_nnet_train_frame_worker(int argc, char *argv[]) {
     std::unique_ptr<IWorker> worker;
     if (worker_type == "bsp") worker.reset(new BspWorker(comm.get()));
     else if (worker_type == "bmuf") worker.reset(new BmufWorker(comm.get(), bmuf_learn_rate, bmuf_momentum));
-    else ASLP_ERR << "Unsupported worker type: " << worker_type << " (this build has the collective workers bsp | bmuf)";
+    else if (worker_type == "sod") worker.reset(new SodWorker(comm.get(), optimizer_opts));
+    else ASLP_ERR << "Unsupported worker type: " << worker_type << " (this build has the collective workers bsp | bmuf | sod)";
     std::vector<std::pair<BaseFloat *, int>> params;
     nnet.GetGpuParams(&params);
     worker->InitParam(params);
@@ -182,6 +185,8 @@ int Main_aslp_nnet_train_lstm_stream_worker(int argc, char *argv[]) {
     po.Register("dump-interval", &dump_interval, "---LSTM--- num utts between model dumping [ 0 == disabled ]");
     std::string worker_type = "bsp";
     po.Register("worker-type", &worker_type, "Worker type(bsp | bmuf | easgd | asgd | masgd | sod)");
+    OptimizerOption optimizer_opts;
+    optimizer_opts.Register(&po);
     float alpha = 0.5;
     po.Register("alpha", &alpha, "Moving rate alpha for easgd worker");
     float bmuf_momentum = 0.9;
@@ -220,7 +225,8 @@ int Main_aslp_nnet_train_lstm_stream_worker(int argc, char *argv[]) {
     std::unique_ptr<IWorker> worker;
     if (worker_type == "bsp") worker.reset(new BspWorker(comm.get()));
     else if (worker_type == "bmuf") worker.reset(new BmufWorker(comm.get(), bmuf_learn_rate, bmuf_momentum));
-    else ASLP_ERR << "Unsupported worker type: " << worker_type << " (this build has the collective workers bsp | bmuf)";
+    else if (worker_type == "sod") worker.reset(new SodWorker(comm.get(), optimizer_opts));
+    else ASLP_ERR << "Unsupported worker type: " << worker_type << " (this build has the collective workers bsp | bmuf | sod)";
     std::vector<std::pair<BaseFloat *, int>> params;
     nnet.GetGpuParams(&params);
     worker->InitParam(params);

@@ -126,6 +126,65 @@ def test_bmuf_world2():
             np.testing.assert_allclose(g, b + d1 + d2, rtol=1e-5, atol=1e-6)
 
 
+def _sod_proc(rank, world, port, out, solver):
+    _init(rank, world, port)
+    P = _load_parallel()
+    params = _make_params(rank, SHAPES, seed=5)
+    w = P.SodWorker(params, solver=solver)
+    res = []
+    for step in range(3):
+        for p in params:
+            p.add_(0.01 * (rank + 1) * (step + 1))
+        ok = w.Synchronize(100 if (rank == 0 or step < 2) else 0)  # rank 1 reports no new frames at the last step, still takes part
+        res.append((ok, [p.clone().numpy() for p in params]))
+    w.Stop()
+    out[rank] = res
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("solver", ["sgd", "momentum", "adagrad", "rmsprop", "adadelta", "adam"])
+def test_sod_world2(solver):
+    """sod-worker.cc:36-68 + optimizer.h:40-171 over gloo, two ranks: every step the summed deltas -(0.01 + 0.02)(step + 1) go
+    through the solver (defaults of optimizer.h:180-184) on each rank's own model."""
+    world, port = 2, _free_port()
+    with mp.Manager() as man:
+        out = man.dict()
+        mp.spawn(_sod_proc, args=(world, port, out, solver), nprocs=world, join=True)
+        out = dict(out)
+    fl = lambda v: max(v, 1e-8)
+    for r in range(2):
+        w = [t.numpy().astype(np.float64) for t in _make_params(r, SHAPES, seed=5)]
+        s1 = s2 = 0.0
+        for step in range(3):
+            g = -(0.01 + 0.02) * (step + 1)
+            local = 0.01 * (r + 1) * (step + 1)
+            t = step + 1
+            if solver == "sgd":
+                d = 0.01 * g
+            elif solver == "momentum":
+                s1 = 0.01 * g + 0.9 * s1
+                d = s1
+            elif solver == "adagrad":
+                s1 = g * g + s1
+                d = 0.01 * g / np.sqrt(fl(s1))
+            elif solver == "rmsprop":
+                s1 = 0.1 * g * g + 0.9 * s1
+                d = 0.001 * g / np.sqrt(fl(s1))
+            elif solver == "adadelta":
+                s1 = 0.05 * g * g + 0.95 * s1
+                d = g * np.sqrt(fl(s2)) / np.sqrt(fl(s1))
+                s2 = 0.05 * d * d + 0.95 * s2
+            else:
+                s1 = 0.1 * g + 0.9 * s1
+                s2 = 0.001 * g * g + 0.999 * s2
+                d = 0.001 / (1 - 0.9 ** t) * s1 / np.sqrt(fl(s2 / (1 - 0.999 ** t)))
+            w = [x + local - d for x in w]
+            ok, got = out[r][step]
+            assert ok
+            for a, b in zip(got, w):
+                np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6)
+
+
 def _easgd_proc(rank, world, port, out):
     _init(rank, world, port)
     P = _load_parallel()

@@ -77,10 +77,56 @@ def test_bmuf_worker_threads():
         np.testing.assert_allclose(got[(steps, r)], w[r], rtol=3e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize("worker", ["bsp", "bmuf"])
+@pytest.mark.parametrize("solver", ["sgd", "momentum", "adagrad", "rmsprop", "adadelta", "adam"])
+def test_sod_worker_threads(solver):
+    """SodWorker (sod-worker.cc:36-68) with the six solvers of optimizer.h at their default settings, three ranks as threads:
+    summed deltas w(t-1) - w(t) drive the solver on every rank's own model -- float64 numpy restatement, 1e-5."""
+    n, dim, steps = 3, 20, 5
+    got = run_selftest("sod:" + solver, n, dim, steps)
+    w = [x.astype(np.float64) for x in initial(n, dim)]
+    prev = [x.copy() for x in w]
+    s1 = [np.zeros_like(x) for x in w]
+    s2 = [np.zeros_like(x) for x in w]
+    fl = lambda v: np.maximum(v, 1e-8)
+    for s in range(steps):
+        active = [r for r in range(n) if s < steps - r]
+        for r in active:
+            w[r] = w[r] + (0.5 * (r + 1) + 0.25 * s)
+        g = sum(prev[r] - w[r] for r in range(n))
+        t = s + 1
+        for r in range(n):
+            if solver == "sgd":
+                w[r] = w[r] - 0.01 * g
+            elif solver == "momentum":
+                s1[r] = 0.01 * g + 0.9 * s1[r]
+                w[r] = w[r] - s1[r]
+            elif solver in ("adagrad", "rmsprop"):
+                s1[r] = g * g + s1[r] if solver == "adagrad" else 0.1 * g * g + 0.9 * s1[r]
+                w[r] = w[r] - (0.01 if solver == "adagrad" else 0.001) * g / np.sqrt(fl(s1[r]))
+            elif solver == "adadelta":
+                s1[r] = 0.05 * g * g + 0.95 * s1[r]
+                d = g * np.sqrt(fl(s2[r])) / np.sqrt(fl(s1[r]))
+                w[r] = w[r] - d
+                s2[r] = 0.05 * d * d + 0.95 * s2[r]
+            else:
+                s1[r] = 0.1 * g + 0.9 * s1[r]
+                s2[r] = 0.001 * g * g + 0.999 * s2[r]
+                w[r] = w[r] - 0.001 / (1 - 0.9 ** t) * s1[r] / np.sqrt(fl(s2[r] / (1 - 0.999 ** t)))
+            prev[r] = w[r].copy()
+        for r in active:
+            np.testing.assert_allclose(got[(s, r)], w[r], rtol=1e-5, atol=1e-6)
+    for r in range(n):
+        np.testing.assert_allclose(got[(steps, r)], w[r], rtol=1e-5, atol=1e-6)
+        if r:  # the models are stepped, not re-unified: ranks keep their initial offsets plus what their own data added
+            assert not np.allclose(got[(steps, r)], got[(steps, 0)])
+
+
+@pytest.mark.parametrize("worker", ["bsp", "bmuf", "sod"])
 def test_frame_worker_tool_group_of_one(aslp, oracle, dev, tmp_path, worker):
     """aslp-nnet-train-frame-worker through RCCL with one rank.  BSP with one worker is the identity (factor 1), so the
-    model equals aslp-nnet-train-frame's bit for bit; BMUF with lr 1 / momentum 0 likewise (w = w_g + (w - w_g))."""
+    model equals aslp-nnet-train-frame's bit for bit; BMUF with lr 1 / momentum 0 likewise (w = w_g + (w - w_g)); SOD with the
+    sgd solver at --lr=0 steps by nothing (the flags, InitParam and the sync schedule are what this case covers; the solvers
+    themselves are checked in test_sod_worker_threads)."""
     in_dim, hid, nh, out_dim, mb = 24, 64, 2, 40, 32
     d, path = make_dnn(oracle, tmp_path, in_dim, hid, nh, out_dim, 1, mb, seed=21)
     oracle.lib.orc_dnn_destroy(d)
@@ -91,11 +137,13 @@ def test_frame_worker_tool_group_of_one(aslp, oracle, dev, tmp_path, worker):
     extra = ["--worker-type=%s" % worker, "--sync-period=64"]
     if worker == "bmuf":
         extra += ["--bmuf-learn-rate=1.0", "--bmuf-momentum=0.0"]
+    if worker == "sod":
+        extra += ["--solver=sgd", "--lr=0"]
     p = tool("aslp-nnet-train-frame-worker", *extra, *common, str(tmp_path / "w.nnet"))
     err = p.stderr.decode()
     assert "Mpi cluster info total 1 worker rank 0" in err and "All worker finished their data" in err and "AvgLoss:" in err
     a, b = aslp.Nnet.Read(tmp_path / "ref.nnet").GetParams(), aslp.Nnet.Read(tmp_path / "w.nnet").GetParams()
-    if worker == "bsp":
+    if worker in ("bsp", "sod"):
         assert np.array_equal(a, b)
     else:
         np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-7)
