@@ -307,3 +307,98 @@ class EasgdServer(MpiNodeLike):
             r.wait()
         s.mul_(1.0 - self.alpha_).add_(self.worker, alpha=self.alpha_)   # x_s = (1-a) x_s + a x_w
         self.fp.unpack()
+
+
+class AsgdWorker(MpiNodeLike):
+    """asgd-worker.cc:37-71: sends the model DELTA since the last exchange to the server (rank 0) and takes the server's
+    model in return.  The same worker talks to AsgdServer and MasgdServer."""
+
+    def __init__(self, model_or_params=None, group=None):
+        super().__init__(group)
+        if model_or_params is not None:
+            self.InitParam(model_or_params)
+
+    def InitParam(self, model_or_params):
+        self.fp = _FlatParams(_params_of(model_or_params))
+        self.prev = self.fp.pack().clone()
+
+    def Synchronize(self, num_worker_samples=0):
+        msg = torch.tensor([K_MSG_SYNCHRONIZE], dtype=torch.int32, device=self.fp.device)
+        dist.send(msg, dst=self.MainNode(), group=self.group)
+        w = self.fp.pack()
+        w.sub_(self.prev)                               # w(t) - w(t-1)
+        dist.send(w, dst=self.MainNode(), group=self.group)
+        dist.recv(w, src=self.MainNode(), group=self.group)   # blocks until the server answers (at once, or at its barrier)
+        self.fp.unpack()
+        self.prev.copy_(w)
+        return True
+
+    def Stop(self):
+        msg = torch.tensor([K_MSG_FINISHED], dtype=torch.int32, device=self.fp.device)
+        dist.send(msg, dst=self.MainNode(), group=self.group)
+
+
+class AsgdServer(MpiNodeLike):
+    """asgd-server.cc:39-102: x_s += alpha * delta in arrival order.  With sync_period > 0, once sync_period exchanges have
+    been counted the server stops answering: each worker that arrives waits, and when all running workers wait they all get
+    the same model (a barrier every sync_period exchanges), the count drops by sync_period."""
+
+    def __init__(self, model_or_params=None, alpha=1.0, sync_period=1000, group=None):
+        super().__init__(group)
+        assert 0.0 <= alpha <= 1.0
+        self.alpha_, self.sync_period_ = alpha, sync_period
+        if model_or_params is not None:
+            self.InitParam(model_or_params)
+
+    def InitParam(self, model_or_params):
+        self.fp = _FlatParams(_params_of(model_or_params))
+        self.delta = torch.empty_like(self.fp.flat)
+        self._init_state()
+
+    def _init_state(self):
+        pass
+
+    def _apply(self, server, delta, worker_rank):
+        server.add_(delta, alpha=self.alpha_)
+
+    def Run(self):
+        num_running = self.NumNodes() - 1
+        count, waited = 0, []
+        msg = torch.zeros(1, dtype=torch.int32, device=self.fp.device)
+        server = self.fp.pack()
+        while num_running > 0:
+            src = dist.recv(msg, group=self.group)
+            m = int(msg.item())
+            if m == K_MSG_FINISHED:
+                num_running -= 1
+            elif m == K_MSG_SYNCHRONIZE:
+                count += 1
+                if self.sync_period_ > 0 and count >= self.sync_period_:
+                    waited.append(src)
+                dist.recv(self.delta, src=src, group=self.group)
+                self._apply(server, self.delta, src)
+                if count < self.sync_period_ or self.sync_period_ <= 0:
+                    dist.send(server, dst=src, group=self.group)
+            if self.sync_period_ > 0 and count >= self.sync_period_ and len(waited) == num_running and num_running != 0:
+                for wr in waited:
+                    dist.send(server, dst=wr, group=self.group)
+                count -= self.sync_period_
+                waited = []
+        self.fp.unpack()
+
+
+class MasgdServer(AsgdServer):
+    """masgd-server.cc:93-118 as compiled (MASGD_TYPE == LMASGD, masgd-server.h:23): one momentum buffer PER WORKER,
+    d_k = delta + momentum * d_k;  x_s += d_k."""
+
+    def __init__(self, model_or_params=None, sync_period=1000, momentum=0.9, group=None):
+        self.momentum_ = momentum
+        super().__init__(model_or_params, alpha=1.0, sync_period=sync_period, group=group)
+
+    def _init_state(self):
+        self.diffs = [torch.zeros_like(self.fp.flat) for _ in range(self.NumNodes() - 1)]
+
+    def _apply(self, server, delta, worker_rank):
+        d = self.diffs[worker_rank - 1]
+        d.mul_(self.momentum_).add_(delta)
+        server.add_(d)

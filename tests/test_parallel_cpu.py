@@ -225,6 +225,81 @@ def _accstat_proc(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def _asgd_proc(rank, world, port, out, kind):
+    _init(rank, world, port)
+    P = _load_parallel()
+    params = _make_params(0, SHAPES, seed=9)  # everybody starts from the same model
+    if rank == 0:
+        s = P.AsgdServer(params, alpha=0.5, sync_period=0) if kind == "asgd" else P.MasgdServer(params, sync_period=0, momentum=0.5)
+        s.Run()
+        out[rank] = [p.clone().numpy() for p in params]
+    else:
+        w = P.AsgdWorker(params)
+        res = []
+        for step in range(2):
+            for p in params:
+                p.add_(0.25 * (step + 1))
+            w.Synchronize()
+            res.append([p.clone().numpy() for p in params])
+        w.Stop()
+        out[rank] = res
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["asgd", "masgd"])
+def test_asgd_server_and_one_worker(kind):
+    """asgd-worker.cc:37-71 against asgd-server.cc:96-102 (x_s += alpha delta) and masgd-server.cc:104-106 (per-worker
+    momentum on the deltas): the worker leaves each exchange holding the server's model."""
+    world, port = 2, _free_port()
+    with mp.Manager() as man:
+        out = man.dict()
+        mp.spawn(_asgd_proc, args=(world, port, out, kind), nprocs=world, join=True)
+        out = dict(out)
+    base = [t.numpy() for t in _make_params(0, SHAPES, seed=9)]
+    if kind == "asgd":   # server: +0.5 * 0.25, then the worker moves +0.5 from there and the server takes half of it
+        after = [0.125, 0.125 + 0.25]
+    else:                # d1 = 0.25; d2 = 0.5 + 0.5 * 0.25
+        after = [0.25, 0.25 + 0.625]
+    for step in range(2):
+        for g, b in zip(out[1][step], base):
+            np.testing.assert_allclose(g, b + after[step], rtol=1e-6, atol=1e-6)
+    for g, b in zip(out[0], base):
+        np.testing.assert_allclose(g, b + after[1], rtol=1e-6, atol=1e-6)
+
+
+def _asgd_barrier_proc(rank, world, port, out):
+    _init(rank, world, port)
+    P = _load_parallel()
+    params = _make_params(0, SHAPES, seed=9)
+    if rank == 0:
+        P.AsgdServer(params, alpha=1.0, sync_period=2).Run()
+        out[rank] = [p.clone().numpy() for p in params]
+    else:
+        w = P.AsgdWorker(params)
+        for p in params:
+            p.add_(0.1 * rank)
+        w.Synchronize()
+        out[rank] = [p.clone().numpy() for p in params]
+        w.Stop()
+    dist.destroy_process_group()
+
+
+def test_asgd_periodic_barrier_world3():
+    """sync_period = 2 with two workers: the first exchange is answered at once or held, the second completes the period --
+    whichever order they arrive in, a worker that was held gets the model that contains BOTH deltas (asgd-server.cc:62-88)."""
+    world, port = 3, _free_port()
+    with mp.Manager() as man:
+        out = man.dict()
+        mp.spawn(_asgd_barrier_proc, args=(world, port, out), nprocs=world, join=True)
+        out = dict(out)
+    base = [t.numpy() for t in _make_params(0, SHAPES, seed=9)]
+    for g, b in zip(out[0], base):
+        np.testing.assert_allclose(g, b + 0.3, rtol=1e-6, atol=1e-6)
+    got = sorted(float((out[r][0] - base[0]).ravel()[0]) for r in (1, 2))
+    # first arrival answered at once (its own delta only), second held until the barrier (both deltas)
+    assert abs(got[1] - 0.3) < 1e-5 and (abs(got[0] - 0.1) < 1e-5 or abs(got[0] - 0.2) < 1e-5)
+
+
 def test_reduce_acc_stat_world2():
     world, port = 2, _free_port()
     with mp.Manager() as man:
