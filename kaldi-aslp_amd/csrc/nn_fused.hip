@@ -178,6 +178,212 @@ __global__ void __launch_bounds__(kBlock) bn_backward_kernel(const float *dy, in
   }
 }
 
+// ---- BatchNormalization, panel-resident variants -----------------------------------------------------------------
+// For minibatch-sized inputs (rows <= SLOTS * row lanes) a workgroup owns a panel of 4*CG columns over ALL rows and
+// keeps it in registers: statistics, their finalize and the write pass are one launch that reads its operands once, instead
+// of statistics stage 1 + stage 2 + write pass (3 launches, operands read twice).  These passes are latency-bound at
+// [1024 x 2048] (8 MB, largely still in L2 / MALL behind the GEMM that produced it), so launches are what counts; each thread
+// holds SLOTS rows of one 4-column group.
+// Thread layout: column group fastest (CG adjacent threads read 16*CG contiguous bytes of a row), kPanelThreads / CG row
+// lanes; a column's partial sums meet by wave shuffles, then across the waves in LDS, always in the same order.
+constexpr int kPanelThreads = 256;
+constexpr int kPanelWaves = kPanelThreads / kWave;
+
+template <typename T, int N, int CG>
+__device__ __forceinline__ void panel_reduce(T (&acc)[N][4], T *red /* [4 waves][CG][N*4] */) {
+#pragma unroll
+  for (int off = CG; off < kWave; off <<= 1)
+#pragma unroll
+    for (int a = 0; a < N; a++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) acc[a][i] += __shfl_xor(acc[a][i], off);
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+  if (lane < CG)
+#pragma unroll
+    for (int a = 0; a < N; a++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) red[(wave * CG + lane) * (N * 4) + a * 4 + i] = acc[a][i];
+  __syncthreads();
+}
+// after panel_reduce: total of accumulator a for panel column pc (0 .. 4*CG-1)
+template <typename T, int N, int CG>
+__device__ __forceinline__ T panel_total(const T *red, int a, int pc) {
+  const int cg = pc / 4, i = pc % 4;
+  T s = red[(0 * CG + cg) * (N * 4) + a * 4 + i];
+#pragma unroll
+  for (int w = 1; w < kPanelWaves; w++) s += red[(w * CG + cg) * (N * 4) + a * 4 + i];
+  return s;
+}
+
+template <int CG, int SLOTS>
+__global__ void __launch_bounds__(kPanelThreads) bn_forward_panel(const float *__restrict__ in, int ldi, float *__restrict__ out, int ldo,
+                                                           float *__restrict__ xhat, int ldx, const float *__restrict__ scale,
+                                                           const float *__restrict__ shift, float *__restrict__ mean,
+                                                           float *__restrict__ inv_std, double *__restrict__ acc_means,
+                                                           double *__restrict__ acc_vars, float inv_rows, float floor_, int rows,
+                                                           float *__restrict__ act, int lda) {
+  constexpr int L = kPanelThreads / CG;
+  __shared__ double red[kPanelWaves * CG * 12];
+  __shared__ float stat[2][4 * CG];
+  const int cg = threadIdx.x % CG, lane = threadIdx.x / CG;
+  const int c = ((int)blockIdx.x * CG + cg) * 4;
+  float4 x[SLOTS];
+#pragma unroll
+  for (int k = 0; k < SLOTS; k++) {
+    const int r = lane + k * L;
+    x[k] = r < rows ? *reinterpret_cast<const float4 *>(in + (long)r * ldi + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  double acc[3][4] = {};
+#pragma unroll
+  for (int k = 0; k < SLOTS; k++) {
+    const float v[4] = {x[k].x, x[k].y, x[k].z, x[k].w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      acc[0][i] += (double)v[i];
+      acc[1][i] += (double)(v[i] * v[i]);
+      acc[2][i] += (double)v[i] * (double)v[i];
+    }
+  }
+  panel_reduce<double, 3, CG>(acc, red);
+  if (threadIdx.x < 4 * CG) {  // the finalize of BnSum1G for one column
+    const int pc = threadIdx.x, col = (int)blockIdx.x * CG * 4 + pc;
+    const double s0 = panel_total<double, 3, CG>(red, 0, pc), s1 = panel_total<double, 3, CG>(red, 1, pc), s2 = panel_total<double, 3, CG>(red, 2, pc);
+    const float mu = (float)s0 * inv_rows;
+    const double m = s0 * (double)inv_rows;
+    double var = s2 * (double)inv_rows - m * m;
+    var = var > 0.0 ? var : 0.0;
+    const float is = 1.0f / sqrtf((float)var + floor_);
+    mean[col] = mu;
+    inv_std[col] = is;
+    if (acc_means) acc_means[col] += s0;
+    if (acc_vars) acc_vars[col] += s1;
+    stat[0][pc] = mu;
+    stat[1][pc] = is;
+  }
+  __syncthreads();
+  const float4 g = *reinterpret_cast<const float4 *>(scale + c), b = *reinterpret_cast<const float4 *>(shift + c);
+  const float4 m = *reinterpret_cast<const float4 *>(&stat[0][cg * 4]), is = *reinterpret_cast<const float4 *>(&stat[1][cg * 4]);
+#pragma unroll
+  for (int k = 0; k < SLOTS; k++) {
+    const int r = lane + k * L;
+    if (r >= rows) break;
+    float4 h, o;
+    h.x = (x[k].x - m.x) * is.x; h.y = (x[k].y - m.y) * is.y; h.z = (x[k].z - m.z) * is.z; h.w = (x[k].w - m.w) * is.w;
+    o.x = h.x * g.x + b.x; o.y = h.y * g.y + b.y; o.z = h.z * g.z + b.z; o.w = h.w * g.w + b.w;
+    if (xhat) *reinterpret_cast<float4 *>(xhat + (long)r * ldx + c) = h;
+    if (out) *reinterpret_cast<float4 *>(out + (long)r * ldo + c) = o;
+    if (act) {
+      float4 y;
+      y.x = sigmoid_ref(o.x); y.y = sigmoid_ref(o.y); y.z = sigmoid_ref(o.z); y.w = sigmoid_ref(o.w);
+      *reinterpret_cast<float4 *>(act + (long)r * lda + c) = y;
+    }
+  }
+}
+
+template <int CG, int SLOTS, bool HAS_Y>
+__global__ void __launch_bounds__(kPanelThreads) bn_backward_panel(const float *__restrict__ dy, int ldd, float *__restrict__ xhat, int ldx,
+                                                            float *__restrict__ scale, float *__restrict__ shift,
+                                                            const float *__restrict__ inv_std, float *__restrict__ dscale,
+                                                            float *__restrict__ dshift, float mmt, float neg_lr, bool step,
+                                                            float *__restrict__ in_diff, int ldi, int rows, const float *__restrict__ y, int ldy) {
+  constexpr int L = kPanelThreads / CG;
+  __shared__ float red[kPanelWaves * CG * 8];
+  __shared__ float stat[3][4 * CG];  // S1, S2, the scale the forward pass used
+  const int cg = threadIdx.x % CG, lane = threadIdx.x / CG;
+  const int c = ((int)blockIdx.x * CG + cg) * 4;
+  float4 d[SLOTS], h[SLOTS];
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int k = 0; k < SLOTS; k++) {
+    const int r = lane + k * L;
+    d[k] = r < rows ? *reinterpret_cast<const float4 *>(dy + (long)r * ldd + c) : zero;
+    h[k] = r < rows ? *reinterpret_cast<const float4 *>(xhat + (long)r * ldx + c) : zero;
+  }
+  if (HAS_Y) {
+#pragma unroll
+    for (int k = 0; k < SLOTS; k++) {
+      const int r = lane + k * L;
+      const float4 yy = r < rows ? *reinterpret_cast<const float4 *>(y + (long)r * ldy + c) : zero;
+      {
+        // products rounded on their own, never contracted into the sums below: the values a separate Sigmoid backward would
+        // have stored, so the folded and the unfolded executor agree bit for bit (HIP's __fmul_rn is a plain multiply)
+#pragma clang fp contract(off)
+        d[k].x = d[k].x * yy.x * (1.0f - yy.x); d[k].y = d[k].y * yy.y * (1.0f - yy.y);
+        d[k].z = d[k].z * yy.z * (1.0f - yy.z); d[k].w = d[k].w * yy.w * (1.0f - yy.w);
+      }
+    }
+  }
+  float acc[2][4] = {};
+#pragma unroll
+  for (int k = 0; k < SLOTS; k++) {
+    acc[0][0] += d[k].x; acc[0][1] += d[k].y; acc[0][2] += d[k].z; acc[0][3] += d[k].w;
+    acc[1][0] += h[k].x * d[k].x; acc[1][1] += h[k].y * d[k].y; acc[1][2] += h[k].z * d[k].z; acc[1][3] += h[k].w * d[k].w;
+  }
+  panel_reduce<float, 2, CG>(acc, red);
+  if (threadIdx.x < 4 * CG) {  // BnBwdG for one column
+    const int pc = threadIdx.x, col = (int)blockIdx.x * CG * 4 + pc;
+    const float s1 = panel_total<float, 2, CG>(red, 0, pc), s2 = panel_total<float, 2, CG>(red, 1, pc);
+    const float dsh = s1 + mmt * dshift[col], dsc = s2 + mmt * dscale[col];
+    dshift[col] = dsh;
+    dscale[col] = dsc;
+    const float g = scale[col];
+    if (step) {
+      scale[col] = g + neg_lr * dsc;
+      shift[col] += neg_lr * dsh;
+    }
+    stat[0][pc] = s1;
+    stat[1][pc] = s2;
+    stat[2][pc] = g;
+  }
+  __syncthreads();
+  if (in_diff == nullptr) return;
+  const float invB = 1.0f / (float)rows;
+  const float4 iv4 = *reinterpret_cast<const float4 *>(inv_std + c);
+  const float iv[4] = {iv4.x, iv4.y, iv4.z, iv4.w};
+  float gv[4], ca[4], cb[4];  // per column: in_diff = D*inv + xm * ca + cb
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const float g = stat[2][cg * 4 + i], inv = iv[i];
+    const float dvar = -0.5f * inv * inv * g * stat[1][cg * 4 + i];
+    const float dmean = -inv * g * stat[0][cg * 4 + i];
+    gv[i] = g;
+    ca[i] = (2.0f * invB) * dvar;
+    cb[i] = invB * dmean;
+  }
+#pragma unroll
+  for (int k = 0; k < SLOTS; k++) {
+    const int r = lane + k * L;
+    if (r >= rows) break;
+    const float dv[4] = {d[k].x, d[k].y, d[k].z, d[k].w}, hv[4] = {h[k].x, h[k].y, h[k].z, h[k].w};
+    float Dv[4], ov[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const float D = dv[i] * gv[i];
+      const float xm = hv[i] / iv[i];
+      Dv[i] = D;
+      ov[i] = D * iv[i] + xm * ca[i] + cb[i];
+    }
+    *reinterpret_cast<float4 *>(xhat + (long)r * ldx + c) = make_float4(Dv[0], Dv[1], Dv[2], Dv[3]);
+    *reinterpret_cast<float4 *>(in_diff + (long)r * ldi + c) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+  }
+}
+
+// 0: the three-launch path; else column groups per workgroup and row slots per thread (4, 8 or 16).  Measured on the cfg2 step
+// (1024 x 2048): 4 groups x 256 threads 729 k frames/s, 2 groups (32-byte row segments) 698 k, 1024-thread workgroups with 4 / 8
+// groups 680 k / 713 k, the three-launch path 717-721 k.
+struct PanelShape { int cg, slots; };
+inline PanelShape bn_panel_shape(int rows, int cols) {
+  static const int forced = [] { const char *e = getenv("ASLP_BN_PANEL"); return e ? atoi(e) : -1; }();
+  PanelShape none = {0, 0};
+  if (forced == 0) return none;
+  const int cg = 4;
+  if (cols % (4 * cg) != 0) return none;
+  const int lanes = kPanelThreads / cg;
+  for (int slots : {4, 8, 16})
+    if (rows <= slots * lanes) return PanelShape{cg, slots};
+  return none;
+}
+
 // ---- Xent ------------------------------------------------------------------------------
 constexpr int kXentPerThread = 32;  // cols <= 8192 cached in registers
 
@@ -340,11 +546,26 @@ void aslp_bn_forward_act(const float *in, MatrixDim d, float *out, int out_strid
   if (!out && !act_out) { set_error("aslp_bn_forward: no output"); return; }
   const float invB = 1.0f / (float)d.rows;
   const bool in_vec = aligned16(in) && d.stride % 4 == 0;
-  colreduce<3, double>("bn_forward.stats", d.rows, d.cols, BnSum1F{in, d.stride}, BnSum1G{invB, var_floor, mean, inv_std, acc_means, acc_vars},
-                       in_vec);
   bool vec = d.cols % 4 == 0 && d.stride % 4 == 0 && (!out || (out_stride % 4 == 0 && aligned16(out))) &&
              (!xhat || (xhat_stride % 4 == 0 && aligned16(xhat))) && (!act_out || (act_stride % 4 == 0 && aligned16(act_out))) &&
              aligned16(in) && aligned16(mean) && aligned16(inv_std) && aligned16(scale) && aligned16(shift);
+  const PanelShape ps = vec ? bn_panel_shape(d.rows, d.cols) : PanelShape{0, 0};
+  if (ps.cg) {
+    const dim3 grid(d.cols / (4 * ps.cg)), block(kPanelThreads);
+#define ASLP_BN_FWD_PANEL(CG, SLOTS)                                                                                                       \
+    case CG * 100 + SLOTS:                                                                                                                \
+      hipLaunchKernelGGL((bn_forward_panel<CG, SLOTS>), grid, block, 0, cur_stream(), in, d.stride, out, out_stride, xhat, xhat_stride, scale, \
+                         shift, mean, inv_std, acc_means, acc_vars, invB, var_floor, d.rows, act_out, act_stride);                          \
+      break;
+    switch (ps.cg * 100 + ps.slots) {
+      ASLP_BN_FWD_PANEL(4, 4) ASLP_BN_FWD_PANEL(4, 8) ASLP_BN_FWD_PANEL(4, 16)
+    }
+#undef ASLP_BN_FWD_PANEL
+    check_launch("bn_forward_panel");
+    return;
+  }
+  colreduce<3, double>("bn_forward.stats", d.rows, d.cols, BnSum1F{in, d.stride}, BnSum1G{invB, var_floor, mean, inv_std, acc_means, acc_vars},
+                       in_vec);
   long n = (long)d.rows * (vec ? d.cols / 4 : d.cols);
   if (vec) hipLaunchKernelGGL((bn_normalize_kernel<true>), dim3(grid_for(n)), dim3(kBlock), 0, cur_stream(), in, d.stride, out, out_stride, xhat, xhat_stride, mean, inv_std, scale, shift, d.rows, d.cols, act_out, act_stride);
   else hipLaunchKernelGGL((bn_normalize_kernel<false>), dim3(grid_for(n)), dim3(kBlock), 0, cur_stream(), in, d.stride, out, out_stride, xhat, xhat_stride, mean, inv_std, scale, shift, d.rows, d.cols, act_out, act_stride);
@@ -366,10 +587,31 @@ static void bn_backward_impl(MatrixDim d, const float *out_diff, int od_stride, 
                              const float *inv_std, float *dscale, float *dshift, float momentum, float *in_diff, int id_stride,
                              const float *act_y, int act_stride, bool step, float learn_rate) {
   if (d.rows <= 0 || d.cols <= 0) return;
+  const bool y_ok = !act_y || (aligned16(act_y) && act_stride % 4 == 0);
+  const bool panel_ok = od_stride % 4 == 0 && xhat_stride % 4 == 0 && (!in_diff || (id_stride % 4 == 0 && aligned16(in_diff))) &&
+                        aligned16(out_diff) && aligned16(xhat) && aligned16(inv_std) && y_ok;
+  const PanelShape ps = panel_ok ? bn_panel_shape(d.rows, d.cols) : PanelShape{0, 0};
+  if (ps.cg) {
+    const dim3 grid(d.cols / (4 * ps.cg)), block(kPanelThreads);
+#define ASLP_BN_BWD_PANEL(CG, SLOTS)                                                                                                              \
+    case CG * 100 + SLOTS:                                                                                                                       \
+      if (act_y)                                                                                                                                 \
+        hipLaunchKernelGGL((bn_backward_panel<CG, SLOTS, true>), grid, block, 0, cur_stream(), out_diff, od_stride, xhat, xhat_stride, scale, shift, \
+                           inv_std, dscale, dshift, momentum, -learn_rate, step, in_diff, id_stride, d.rows, act_y, act_stride);                  \
+      else                                                                                                                                       \
+        hipLaunchKernelGGL((bn_backward_panel<CG, SLOTS, false>), grid, block, 0, cur_stream(), out_diff, od_stride, xhat, xhat_stride, scale, shift, \
+                           inv_std, dscale, dshift, momentum, -learn_rate, step, in_diff, id_stride, d.rows, act_y, act_stride);                  \
+      break;
+    switch (ps.cg * 100 + ps.slots) {
+      ASLP_BN_BWD_PANEL(4, 4) ASLP_BN_BWD_PANEL(4, 8) ASLP_BN_BWD_PANEL(4, 16)
+    }
+#undef ASLP_BN_BWD_PANEL
+    check_launch("bn_backward_panel");
+    return;
+  }
   float *s12 = static_cast<float *>(scratch(kScratchReduce2, sizeof(float) * 3 * (size_t)d.cols));
   if (!s12) return;
   float *scale_used = s12 + 2 * (size_t)d.cols;
-  const bool y_ok = !act_y || (aligned16(act_y) && act_stride % 4 == 0);
   colreduce<2, float>("bn_backward.stats", d.rows, d.cols, BnBwdF{out_diff, od_stride, xhat, xhat_stride, act_y, act_stride},
                       BnBwdG{momentum, dscale, dshift, s12, s12 + d.cols, scale, shift, scale_used, -learn_rate, step},
                       aligned16(out_diff) && od_stride % 4 == 0 && aligned16(xhat) && xhat_stride % 4 == 0 && y_ok);

@@ -224,7 +224,8 @@ def test_sgemm_colsum_epilogue(aslp, oracle, dev, mb, n_out, n_in):
         aslp.ops.sgemm(0, 0, 1.0, T(x, dev), T(rng.standard_normal((n_in, 8)).astype(np.float32), dev), 0.0, torch.empty(mb, 8, device=dev), ep)
 
 
-@pytest.mark.parametrize("rows,cols", [(8, 6), (64, 32), (1024, 2048), (100, 37), (129, 260)])
+# (64, 32) (300, 48) (1024, 2048) (5, 16) run the panel-resident kernels (4 / 8 / 16 / 4 row slots), the others the three-launch path
+@pytest.mark.parametrize("rows,cols", [(8, 6), (64, 32), (1024, 2048), (100, 37), (129, 260), (300, 48), (1025, 64), (5, 16)])
 def test_batchnorm_forward_backward(aslp, oracle, dev, rows, cols):
     rng = np.random.default_rng(6)
     x = (rng.standard_normal((rows, cols)) * 2 + 0.5).astype(np.float32)
