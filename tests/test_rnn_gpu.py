@@ -227,3 +227,39 @@ def test_recurrent_init_from_proto(aslp, dev):
     assert torch.allclose(out.sum(1), torch.ones(T * S, device=dev), atol=1e-5)
     net.Backpropagate(torch.randn(T * S, 4, device=dev) * 0.1)
     assert np.isfinite(net.GetParams()).all() and not np.array_equal(net.GetParams(), p)
+
+
+def test_folded_update_equals_separate_update(aslp, dev):
+    """With layer fusion on, the executor announces Update to the recurrent components and their SGD step rides in the gradient
+    kernels (GEMM epilogue, rnn_vec_grads); with it off, Update is a launch sequence of its own (lc.h:1085-1110,
+    nnet-gru-streams.h:457-466).  Same arithmetic either way: parameters agree to the last bit over several steps."""
+    proto = """<NnetProto>
+<BLstmProjectedStreamsLC> <InputDim> 20 <OutputDim> 16 <CellDim> 12 <ParamScale> 0.2 <ClipGradient> 0.05
+<LstmProjectedStreams> <InputDim> 16 <OutputDim> 8 <CellDim> 12 <ParamScale> 0.2 <ClipGradient> 0.05
+<LstmCifgProjectedStreams> <InputDim> 8 <OutputDim> 8 <CellDim> 8 <ParamScale> 0.2 <ClipGradient> 0.05
+<GruStreams> <InputDim> 8 <OutputDim> 8 <ParamScale> 0.2 <ClipGradient> 0.05
+<AffineTransform> <InputDim> 8 <OutputDim> 5 <BiasMean> 0.0 <BiasRange> 0.0 <ParamStddev> 0.3
+<Softmax> <InputDim> 5 <OutputDim> 5
+</NnetProto>
+"""
+    nets = [aslp.Nnet.Init(proto, seed=5), aslp.Nnet.Init(proto, seed=5)]
+    nets[1].SetLayerFusion(False)
+    assert np.array_equal(nets[0].GetParams(), nets[1].GetParams())
+    T, S, chunk = 9, 4, 6
+    rng = np.random.default_rng(3)
+    xents = [aslp.Xent(), aslp.Xent()]
+    for step in range(4):
+        x = torch.from_numpy(rng.standard_normal((T * S, 20)).astype(np.float32)).to(dev)
+        lab = torch.from_numpy(rng.integers(0, 5, T * S).astype(np.int32)).to(dev)
+        flags = [1] * S if step == 0 else [int(v) for v in rng.integers(0, 2, S)]
+        for net, xe in zip(nets, xents):
+            net.SetTrainOptions(learn_rate=0.05, momentum=0.9)
+            net.SetChunkSize(chunk)
+            net.ResetLstmStreams(flags)
+            y = net.Propagate(x)
+            diff = torch.empty_like(y)
+            xe.Eval(torch.ones(T * S, device=dev), y, diff, labels=lab)
+            net.Backpropagate(diff)
+        a, b = nets[0].GetParams(), nets[1].GetParams()
+        assert np.array_equal(a, b), (step, float(np.abs(a - b).max()))
+    assert np.abs(nets[0].GetParams() - aslp.Nnet.Init(proto, seed=5).GetParams()).max() > 1e-3  # and they did move
