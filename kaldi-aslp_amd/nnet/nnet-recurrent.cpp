@@ -230,10 +230,13 @@ void LstmDir::ForwardPrepare(const CuMatrixBase &in, int T, int S, bool reverse,
   gates.AddMatMat(1.0, in, kNoTrans, w_x, kTrans, 0.0, &ep);
 }
 
-void LstmDir::ForwardFinish(int T, int S, CuMatrix *buf) const {
-  if (R <= 0) return;
+bool LstmDir::ForwardFinish(int T, int S, CuMatrix *buf, CuMatrixBase *out, int out_col) const {
+  if (R <= 0) return false;
   CuSubMatrix y_r(*buf, S, T * S, OffRec(), R), y_m(*buf, S, T * S, OffM(), C);
-  y_r.AddMatMat(1.0, y_m, kNoTrans, w_rm, kTrans, 0.0);  // m -> r for every t at once (lc.h:608)
+  aslp_gemm_epilogue ep = aslp_gemm_epilogue();
+  if (out) { ep.act_out = out->Data() + out_col; ep.ld_act = out->Stride(); ep.act = 0; }  // second store: the component's output block
+  y_r.AddMatMat(1.0, y_m, kNoTrans, w_rm, kTrans, 0.0, &ep);  // m -> r for every t at once (lc.h:608)
+  return out != nullptr;
 }
 
 void LstmDir::BackwardPrepare(const CuMatrixBase &out_diff, int T, int S, CuMatrix *dbuf) const {
@@ -351,6 +354,7 @@ void LstmFamily::SetSeqLengths(const std::vector<int32> &sequence_lengths) {
 
 void LstmFamily::PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) {
   const bool carried = !cfg_.bidir || cfg_.lc;
+  bool out_written = false;
   int32 S;
   if (carried) {
     if (nstream_ == 0) {  // nnet-forward: one stream, state reset per utterance (lc.h:505-512)
@@ -397,8 +401,9 @@ void LstmFamily::PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) {
       aslp_lstm_step_forward(&a);
     }
     CheckK();
-    f_.ForwardFinish(T, S, &f_buf_);
-    if (cfg_.bidir) b_.ForwardFinish(T, S, &b_buf_);
+    // with a projection the GEMM that forms r(t) for all t also writes it into this component's output block
+    out_written = f_.ForwardFinish(T, S, &f_buf_, out, 0);
+    if (cfg_.bidir) out_written = b_.ForwardFinish(T, S, &b_buf_, out, rec) && out_written;
   } else {
     f_.Forward(in, T, S, false, carried ? &prev_state_ : nullptr, nullptr, &f_buf_);
     if (cfg_.bidir) b_.Forward(in, T, S, true, nullptr, cfg_.lc ? nullptr : &seq_len_dev_, &b_buf_);
@@ -410,7 +415,8 @@ void LstmFamily::PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) {
     ASLP_ASSERT(row_block <= T + 1);
     prev_state_.CopyFromMat(f_buf_.RowRange(row_block * S, S));
   }
-  if (cfg_.bidir) {
+  if (out_written) {
+  } else if (cfg_.bidir) {
     CuSubMatrix(*out, 0, T * S, 0, rec).CopyFromMat(CuSubMatrix(f_buf_, S, T * S, f_.OffRec(), rec));
     CuSubMatrix(*out, 0, T * S, rec, rec).CopyFromMat(CuSubMatrix(b_buf_, S, T * S, b_.OffRec(), rec));
   } else {
