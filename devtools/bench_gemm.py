@@ -11,6 +11,11 @@ for mb in [int(m) for m in os.environ.get('MBS', '1024,256').split(',')]:
                ('TN wgrad', 1, 0, 2048, 2048, mb), ('TN wgrdL', 1, 0, 3000, 2048, mb), ('TN wgrd1', 1, 0, 2048, 440, mb)]
 if os.environ.get('LSTM', '1') == '1':
     shapes += [('NT lstm x', 0, 1, 60 * 32, 2048, 512), ('NT lstm r', 0, 1, 32, 2048, 256), ('NT lstm p', 0, 1, 32, 256, 512)]
+if os.environ.get('LC', '0') == '1':  # the whole-sequence products of one LC-BLSTM direction (cfg3: T*S = 1920 rows, C = 512, R = 256)
+    shapes = [('NT x->gates ', 0, 1, 1920, 2048, 512), ('NT m->r     ', 0, 1, 1920, 256, 512), ('NN d_m      ', 0, 0, 1920, 512, 256),
+              ('NN d_r      ', 0, 0, 1920, 256, 2048), ('NN in_diff  ', 0, 0, 1920, 512, 2048), ('TN w_x grad ', 1, 0, 2048, 512, 1920),
+              ('TN w_r grad ', 1, 0, 2048, 256, 1920), ('TN w_rm grad', 1, 0, 256, 512, 1920), ('NN W_eff    ', 0, 0, 2048, 512, 256),
+              ('TT W_eff^T  ', 1, 1, 512, 2048, 256)]
 cfgs = [int(c) for c in os.environ.get('TILES', '0').split(',')]
 ref = os.environ.get('REF', '1') == '1'
 

@@ -27,6 +27,10 @@ struct GemmArgs {
   aslp_gemm_epilogue ep;
   int a_vec, b_vec;  // 16-byte vector loads allowed
   int tiles_m, tiles_n;
+  // split-K (gemm_glds.hip): blockIdx.y = chunk of k_chunk (a multiple of the K tile) reduction steps, whose plain product
+  // goes to C + chunk * split_stride (a scratch stack of packed M x N partials; the epilogue runs in the reduce kernel)
+  int split_k, k_chunk;
+  long split_stride;
 };
 
 // workgroup id -> (tile row, tile column): each XCD (id % 8, private 4 MB L2) gets a compact 2-D sub-grid of

@@ -18,6 +18,7 @@
 // A partial last K tile is handled by pointing the out-of-range DMA lanes at a zero buffer.
 // Eligibility: K % 4 == 0, 16-byte aligned operands, leading dimensions % 4 == 0 (else gemm.hip's kernel).
 #include "gemm_common.h"
+#include "scratch.h"
 
 #pragma clang diagnostic ignored "-Winline-asm"  // the DMA asm clobbers m0 on purpose
 
@@ -57,6 +58,13 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_f32_glds(GemmArgs g) {
   extern __shared__ __attribute__((aligned(1024))) float lds[];
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lds;
 
+  if (g.split_k > 1) {  // this workgroup reduces over K chunk blockIdx.y only and leaves a plain partial product
+    const int k0 = (int)blockIdx.y * g.k_chunk;
+    g.A += A_KC ? (long)k0 : (long)k0 * g.lda;
+    g.B += B_KC ? (long)k0 : (long)k0 * g.ldb;
+    g.K = min(g.k_chunk, g.K - k0);
+    g.C += (long)blockIdx.y * g.split_stride;
+  }
   int tm, tn;
   xcd_tile<BM, BN>(g, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
@@ -265,7 +273,7 @@ void launch_t(GemmArgs &g) {
       ASLP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(64 * WGM * WGN), lds_bytes, cur_stream(), g);
+  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n, g.split_k > 1 ? g.split_k : 1), dim3(64 * WGM * WGN), lds_bytes, cur_stream(), g);
 }
 
 template <int BM, int BN, int WGM, int WGN, bool A_KC, bool B_KC, int NS>
@@ -282,17 +290,83 @@ bool launch_cfg(GemmArgs &g, int cfg) {
     case 208: launch<64, 128, 2, 2, A_KC, B_KC, 3>(g); return true;   // 4 waves, 32 x 64 per wave
     case 207: launch<64, 64, 2, 2, A_KC, B_KC, 4>(g); return true;    // 4 waves, 2 workgroups per CU
     case 211: launch<128, 128, 2, 4, A_KC, B_KC, 3>(g); return true;  // 8 waves, 64 x 32 per wave
+    case 205: launch<32, 128, 1, 4, A_KC, B_KC, 4>(g); return true;   // 4 waves, 32-row tile: twice the workgroups of 64 x 128
+    case 206: launch<32, 64, 1, 2, A_KC, B_KC, 4>(g); return true;    // 2 waves, for grids the 64 x 64 tile cannot fill
     default: return false;
   }
 }
 
 }  // namespace
 
+// Second half of a split-K product: C = epilogue(alpha * sum_s partial[s] + beta * C), partials added in chunk order.
+// Covers what the split path accepts: alpha / beta, the element-wise clip and the fused SGD step on W.
+__global__ void __launch_bounds__(kBlock) splitk_reduce_kernel(const float *__restrict__ part, int split, long stride, GemmArgs g) {
+  const long n = (long)g.M * g.N;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int row = (int)(i / g.N), col = (int)(i - (long)row * g.N);
+    float acc = part[i];
+    for (int s = 1; s < split; s++) acc += part[i + s * stride];
+    float *cp = g.C + (long)row * g.ldc + col;
+    const float c_old = g.beta != 0.0f ? *cp : 0.0f;
+    const float w_old = g.ep.W ? g.ep.W[(long)row * g.ep.ldw + col] : 0.0f;
+    float v = g.alpha * acc + g.beta * c_old;
+    if (g.ep.clip > 0.0f) v = fminf(fmaxf(v, -g.ep.clip), g.ep.clip);
+    *cp = v;
+    if (g.ep.W) g.ep.W[(long)row * g.ep.ldw + col] = w_old + g.ep.w_alpha * v;
+  }
+}
+
+// Long reductions on a grid that cannot fill the chip (the recurrent weight gradients and d_r of the LSTM family: K = T*S
+// or 4C against 30-130 output tiles) are bound by the length of one workgroup's K loop, not by the MFMA rate: 36 us whether
+// the output is 256 x 512 or 2048 x 512.  Splitting K over blockIdx.y shortens that loop; the partial products are summed in
+// chunk order by a second launch, so results do not depend on scheduling.  Returns 0 when the product should not be split.
+int pick_split_k(const GemmArgs &g, int bm, int bn) {
+  static const int forced = [] { const char *e = getenv("ASLP_GEMM_SPLITK"); return e ? atoi(e) : -1; }();
+  if (forced == 0) return 0;
+  const aslp_gemm_epilogue &ep = g.ep;
+  if (ep.bias || ep.act_out || ep.colsum || g.K < 1024) return 0;
+  const long tiles = (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn);
+  static const int slots = [] { const char *e = getenv("ASLP_GEMM_SPLITK_SLOTS"); return e ? atoi(e) : 256; }();
+  int split = (int)(slots / tiles);
+  if (split > g.K / 256) split = g.K / 256;
+  if (split > 8) split = 8;
+  if (forced > 0 && split >= 2) split = forced;
+  return split >= 2 ? split : 0;
+}
+
+template <bool A_KC, bool B_KC>
+bool launch_split(GemmArgs &g, int cfg, int split) {
+  int chunk = ((g.K + split - 1) / split + BK - 1) / BK * BK;
+  split = (g.K + chunk - 1) / chunk;
+  if (split < 2) return false;
+  const long stride = (long)g.M * g.N;
+  float *part = static_cast<float *>(scratch(kScratchSplitK, sizeof(float) * (size_t)stride * split));
+  if (!part) return false;
+  GemmArgs p = g;
+  p.C = part; p.ldc = g.N; p.alpha = 1.0f; p.beta = 0.0f; p.ep = aslp_gemm_epilogue();
+  p.split_k = split; p.k_chunk = chunk; p.split_stride = stride;
+  if (!launch_cfg<A_KC, B_KC>(p, cfg)) return false;
+  GemmArgs r = g;
+  r.split_k = 0;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for(stride)), dim3(kBlock), 0, cur_stream(), part, split, stride, r);
+  return true;
+}
+
 bool gemm_glds_launch(GemmArgs &g, bool a_kc, bool b_kc, int cfg) {
   // (a column-sum request on a non-transposed A is the caller's job: see aslp_sgemm_ex)
   if (g.K < 4 || g.K % 4 != 0 || !g.a_vec || !g.b_vec) return false;
   if (!a_kc && (g.M % 4 != 0 || g.M < 4)) return false;
   if (!b_kc && (g.N % 4 != 0 || g.N < 4)) return false;
+  if (cfg == 207) {
+    if (const int split = pick_split_k(g, 64, 64)) {
+      bool ok = false;
+      if (a_kc && b_kc) ok = launch_split<true, true>(g, cfg, split);
+      else if (a_kc && !b_kc) ok = launch_split<true, false>(g, cfg, split);
+      else if (!a_kc && !b_kc) ok = launch_split<false, false>(g, cfg, split);
+      else ok = launch_split<false, true>(g, cfg, split);
+      if (ok) return true;
+    }
+  }
   if (a_kc && b_kc) return launch_cfg<true, true>(g, cfg);
   if (a_kc && !b_kc) return launch_cfg<true, false>(g, cfg);
   if (!a_kc && !b_kc) return launch_cfg<false, false>(g, cfg);

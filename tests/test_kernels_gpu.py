@@ -127,6 +127,7 @@ GEMM_SHAPES = [
     # (M, N, K)
     (37, 41, 29), (1, 1, 1), (128, 128, 16), (130, 70, 33), (256, 2048, 440), (64, 3000, 512),
     (32, 2048, 256), (8, 64, 40), (200, 96, 1000), (1024, 512, 2048),
+    (256, 512, 1920), (100, 72, 1100), (1920, 256, 2048),  # long K on a small grid: split-K + ordered reduce
 ]
 
 
@@ -200,6 +201,24 @@ def test_sgemm_epilogue(aslp, oracle, dev):
     Gref = np.clip(diff.T @ A + 0.9 * G0, -5, 5)
     assert oracle.rel_err(Gd.cpu().numpy(), Gref) < 2e-6
     assert oracle.rel_err(Wd.cpu().numpy(), W - 0.01 * Gref) < 2e-6
+    # the same epilogue behind a split-K product (recurrent weight gradient: 1920 frames, 256 x 512 output), run twice:
+    # the chunk-ordered reduction makes it reproducible to the bit
+    M, N, K = 1920, 256, 512
+    diff = rng.standard_normal((M, N)).astype(np.float32)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    G0 = rng.standard_normal((N, K)).astype(np.float32)
+    W = rng.standard_normal((N, K)).astype(np.float32)
+    res = []
+    for _ in range(2):
+        Gd, Wd = T(G0, dev), T(W, dev)
+        ep = aslp._lib.GemmEpilogue(None, 40.0, Wd.data_ptr(), K, -0.01, None, 0, 0)
+        aslp.ops.sgemm(1, 0, 1.0, T(diff, dev), T(A, dev), 0.9, Gd, ep)
+        res.append((Gd.cpu().numpy(), Wd.cpu().numpy()))
+    Gref = np.clip(diff.astype(np.float64).T @ A + 0.9 * G0, -40, 40)
+    assert (np.abs(Gref) == 40).any() and (np.abs(Gref) < 40).any()
+    assert oracle.rel_err(res[0][0], Gref) < 2e-6
+    assert oracle.rel_err(res[0][1], W - 0.01 * Gref) < 2e-6
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
 
 
 @pytest.mark.parametrize("mb,n_out,n_in", [(100, 72, 64), (1024, 2048, 440), (256, 3000, 128), (60, 130, 36), (33, 40, 20)])
