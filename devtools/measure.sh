@@ -11,7 +11,7 @@ O=$R/gpurun_out
 mkdir -p $O
 export TMPDIR=/tmp
 cd /tmp
-python3 $R/bench.py --steps 50 --warmup 5 > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
+python3 $R/bench.py --steps 500 --warmup 50 > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 tail -c 3000 $O/${TAG}_bench.json
 rocprofv3 --kernel-trace --stats -d $O/${TAG}_trace -o bench -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-update-overlap > $O/${TAG}_trace.log 2>&1
 python3 $R/devtools/prof_summary.py $O/${TAG}_trace/bench_results.db > $O/${TAG}_kernel_stats.txt 2>&1
