@@ -3,12 +3,18 @@
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <fcntl.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <chrono>
 #include <cstdio>
+#include <cerrno>
 #include <cstdlib>
+#include <cstring>
+#include <deque>
 #include <fstream>
+#include <map>
 #include <thread>
 
 #include "aslp_kernels.h"
@@ -34,12 +40,19 @@ void RankFromEnvironment(int *rank, int *num_nodes) {
 namespace {
 class RcclComm : public Comm {
  public:
-  RcclComm(int rank, int n, const std::string &id_file, int timeout_s) : rank_(rank), n_(n), comm_(nullptr), scratch_(nullptr), scratch_bytes_(0) {
+  RcclComm(int rank, int n, const std::string &id_file, int timeout_s)
+      : rank_(rank), n_(n), comm_(nullptr), scratch_(nullptr), scratch_bytes_(0), ctl_fd_(-1) {
     ncclUniqueId id;
     if (n > 1 && id_file.empty()) ASLP_ERR << "RcclComm: more than one rank needs a rendezvous file (--comm-file)";
+    ctl_path_ = id_file.empty() ? std::string() : id_file + ".ctl";
     if (rank == 0) {
       Nccl(ncclGetUniqueId(&id), "ncclGetUniqueId");
       if (n > 1) {
+        // the control pipe exists before the id does, so whoever found the id can open it; O_RDWR: never sees end-of-file
+        (void)unlink(ctl_path_.c_str());
+        if (mkfifo(ctl_path_.c_str(), 0600) != 0) ASLP_ERR << "cannot create " << ctl_path_ << ": " << strerror(errno);
+        ctl_fd_ = open(ctl_path_.c_str(), O_RDWR);
+        if (ctl_fd_ < 0) ASLP_ERR << "cannot open " << ctl_path_ << ": " << strerror(errno);
         const std::string tmp = id_file + ".tmp." + std::to_string((long)getpid());
         { std::ofstream f(tmp, std::ios::binary); f.write(reinterpret_cast<const char *>(&id), sizeof(id)); if (!f.good()) ASLP_ERR << "cannot write " << tmp; }
         if (std::rename(tmp.c_str(), id_file.c_str()) != 0) ASLP_ERR << "cannot create " << id_file;
@@ -54,6 +67,10 @@ class RcclComm : public Comm {
         std::this_thread::sleep_for(std::chrono::milliseconds(50));
       }
     }
+    if (rank != 0 && n > 1) {
+      ctl_fd_ = open(ctl_path_.c_str(), O_WRONLY);
+      if (ctl_fd_ < 0) ASLP_ERR << "cannot open " << ctl_path_ << ": " << strerror(errno);
+    }
     Nccl(ncclCommInitRank(&comm_, n, id, rank), "ncclCommInitRank");
     Barrier();
     if (rank == 0 && n > 1) std::remove(id_file.c_str());  // everybody has joined: the next run writes a fresh id
@@ -61,7 +78,28 @@ class RcclComm : public Comm {
   ~RcclComm() {
     if (scratch_) (void)hipFree(scratch_);
     if (comm_) (void)ncclCommDestroy(comm_);
+    if (ctl_fd_ >= 0) (void)close(ctl_fd_);
+    if (rank_ == 0 && n_ > 1 && !ctl_path_.empty()) (void)unlink(ctl_path_.c_str());
   }
+  void PostToServer(int32 msg) {
+    const int32 rec[2] = {rank_, msg};  // 8 bytes: one atomic write (< PIPE_BUF), so messages of different workers never mix
+    if (ctl_fd_ < 0 || write(ctl_fd_, rec, sizeof(rec)) != (ssize_t)sizeof(rec)) ASLP_ERR << "control pipe write failed: " << strerror(errno);
+  }
+  void WaitFromWorker(int *src, int32 *msg) {
+    int32 rec[2];
+    size_t got = 0;
+    while (got < sizeof(rec)) {
+      const ssize_t k = read(ctl_fd_, reinterpret_cast<char *>(rec) + got, sizeof(rec) - got);
+      if (k < 0 && errno == EINTR) continue;
+      if (k <= 0) ASLP_ERR << "control pipe read failed: " << strerror(errno);
+      got += (size_t)k;
+    }
+    *src = rec[0];
+    *msg = rec[1];
+  }
+  void Send(int peer, const Buffers &bufs) { P2P(peer, &bufs, nullptr); }
+  void Recv(int peer, const Buffers &bufs) { P2P(peer, nullptr, &bufs); }
+  void Exchange(int peer, const Buffers &send, const Buffers &recv) { P2P(peer, &send, &recv); }
   int Rank() const { return rank_; }
   int NumNodes() const { return n_; }
   void Barrier() {
@@ -85,6 +123,17 @@ class RcclComm : public Comm {
   void AllReduceSumHost(double *host, size_t n) { HostReduce(host, n, ncclDouble); }
 
  private:
+  void P2P(int peer, const Buffers *send, const Buffers *recv) {
+    Nccl(ncclGroupStart(), "ncclGroupStart");
+    if (send)
+      for (auto &b : *send)
+        if (b.second > 0) Nccl(ncclSend(b.first, (size_t)b.second, ncclFloat, peer, comm_, cur_stream()), "ncclSend");
+    if (recv)
+      for (auto &b : *recv)
+        if (b.second > 0) Nccl(ncclRecv(b.first, (size_t)b.second, ncclFloat, peer, comm_, cur_stream()), "ncclRecv");
+    Nccl(ncclGroupEnd(), "ncclGroupEnd");
+    Hip(hipStreamSynchronize(cur_stream()), "hipStreamSynchronize");
+  }
   template <class T>
   void HostReduce(T *host, size_t n, ncclDataType_t type) {
     if (n_ <= 1 || !n) return;
@@ -103,6 +152,8 @@ class RcclComm : public Comm {
   ncclComm_t comm_;
   void *scratch_;
   size_t scratch_bytes_;
+  std::string ctl_path_;
+  int ctl_fd_;
 };
 }  // namespace
 
@@ -130,6 +181,10 @@ class ThreadCommGroup {
   double hostsum_d;
   void *tmp;
   size_t tmp_bytes;
+  // server-based protocols: control queue (arrival order) and one rendezvous slot per ordered pair of ranks
+  std::deque<std::pair<int, int32>> ctl;
+  struct Slot { const Comm::Buffers *send = nullptr; bool taken = false; };
+  std::map<std::pair<int, int>, Slot> slots;
 };
 std::shared_ptr<ThreadCommGroup> NewThreadCommGroup(int n) { return std::make_shared<ThreadCommGroup>(n); }
 
@@ -150,6 +205,53 @@ class ThreadComm : public Comm {
   void AllReduceSum(double *dev, size_t n) { Reduce(dev, n); }
   void AllReduceSumHost(int32 *host, size_t n) { HostReduce(host, n, &g_->host_i); }
   void AllReduceSumHost(double *host, size_t n) { HostReduce(host, n, &g_->host_d); }
+  void PostToServer(int32 msg) {
+    std::lock_guard<std::mutex> lk(g_->mu);
+    g_->ctl.push_back(std::make_pair(rank_, msg));
+    g_->cv.notify_all();
+  }
+  void WaitFromWorker(int *src, int32 *msg) {
+    std::unique_lock<std::mutex> lk(g_->mu);
+    g_->cv.wait(lk, [&] { return !g_->ctl.empty(); });
+    *src = g_->ctl.front().first;
+    *msg = g_->ctl.front().second;
+    g_->ctl.pop_front();
+  }
+  // rendezvous: the sender offers its buffers and waits until the receiver has copied them (device to device)
+  void Send(int peer, const Buffers &bufs) {
+    Hip(hipStreamSynchronize(cur_stream()), "hipStreamSynchronize");  // what is sent is final
+    std::unique_lock<std::mutex> lk(g_->mu);
+    ThreadCommGroup::Slot &slot = g_->slots[std::make_pair(rank_, peer)];
+    slot.send = &bufs;
+    slot.taken = false;
+    g_->cv.notify_all();
+    g_->cv.wait(lk, [&] { return slot.taken; });
+    slot.send = nullptr;
+    slot.taken = false;
+  }
+  void Recv(int peer, const Buffers &bufs) {
+    const Buffers *src = nullptr;
+    {
+      std::unique_lock<std::mutex> lk(g_->mu);
+      ThreadCommGroup::Slot &slot = g_->slots[std::make_pair(peer, rank_)];
+      g_->cv.wait(lk, [&] { return slot.send != nullptr && !slot.taken; });
+      src = slot.send;
+    }
+    ASLP_ASSERT(src->size() == bufs.size());
+    for (size_t i = 0; i < bufs.size(); i++) {
+      ASLP_ASSERT((*src)[i].second == bufs[i].second);
+      if (bufs[i].second > 0)
+        Hip(hipMemcpyAsync(bufs[i].first, (*src)[i].first, sizeof(float) * (size_t)bufs[i].second, hipMemcpyDeviceToDevice, cur_stream()), "hipMemcpy D2D");
+    }
+    Hip(hipStreamSynchronize(cur_stream()), "hipStreamSynchronize");
+    std::lock_guard<std::mutex> lk(g_->mu);
+    g_->slots[std::make_pair(peer, rank_)].taken = true;
+    g_->cv.notify_all();
+  }
+  void Exchange(int peer, const Buffers &send, const Buffers &recv) {
+    if (rank_ < peer) { Send(peer, send); Recv(peer, recv); }
+    else { Recv(peer, recv); Send(peer, send); }
+  }
 
  private:
   template <class T>

@@ -29,6 +29,17 @@ class Comm {
   virtual void AllReduceSumMany(const std::vector<std::pair<float *, int>> &bufs) {
     for (auto &b : bufs) AllReduceSum(b.first, (size_t)b.second);
   }
+  // ---- what the server-based protocols need (EASGD / ASGD / MASGD: rank 0 serves the others in ARRIVAL order) ----
+  // Control channel, the MPI_Recv(MPI_ANY_SOURCE) of easgd-server.cc:44: a worker posts a small message to rank 0, rank 0
+  // takes messages in the order they arrived.  (RCCL has no any-source receive: the order is decided on the host -- a
+  // named pipe next to the rendezvous file for RcclComm, a queue for ThreadComm -- the tensors still move GPU to GPU.)
+  typedef std::vector<std::pair<float *, int>> Buffers;
+  virtual void PostToServer(int32 msg) = 0;
+  virtual void WaitFromWorker(int *src, int32 *msg) = 0;
+  // point-to-point transfers of whole parameter sets (device memory), each one grouped operation; Exchange = both ways at once
+  virtual void Send(int peer, const Buffers &bufs) = 0;
+  virtual void Recv(int peer, const Buffers &bufs) = 0;
+  virtual void Exchange(int peer, const Buffers &send, const Buffers &recv) = 0;
 };
 
 // rank / world size of this process: --rank / --num-workers style explicit values win (>= 0), then the launcher's

@@ -138,4 +138,118 @@ void SodWorker::Stop() {
   while (Synchronize(0)) {}
 }
 
+// ---- EASGD (easgd-worker.cc:37-80, easgd-server.cc:37-86) --------------------------------------------------------
+static void FreeAll(std::vector<std::pair<BaseFloat *, int>> *v) {
+  for (auto &p : *v) (void)hipFree(p.first);
+  v->clear();
+}
+// y = a * x + b * y per tensor (CuVectorBase::AddVec(a, x, b))
+static void AddVec(const std::vector<std::pair<BaseFloat *, int>> &y, float a, const std::vector<std::pair<BaseFloat *, int>> &x, float b) {
+  for (size_t i = 0; i < y.size(); i++) {
+    if (b != 1.0f) Scale(y[i].first, y[i].second, b);
+    aslp_vec_axpy(a, x[i].first, y[i].first, y[i].second);
+  }
+  CheckK();
+}
+void EasgdWorker::InitParam(const std::vector<std::pair<BaseFloat *, int>> &params) { params_ = params; server_ = AllocLike(params, false); }
+EasgdWorker::~EasgdWorker() { FreeAll(&server_); }
+bool EasgdWorker::Synchronize(int) {
+  comm_->PostToServer(kMsgSynchronize);
+  comm_->Exchange(MainNode(), params_, server_);          // both sides hand over their model as it is now
+  AddVec(params_, alpha_, server_, 1.0f - alpha_);         // x_w = (1 - alpha) x_w + alpha x_s
+  return true;
+}
+void EasgdWorker::Stop() {
+  comm_->PostToServer(kMsgFinished);
+  ASLP_LOG << "Worker " << Rank() << " finished";
+}
+void EasgdServer::InitParam(const std::vector<std::pair<BaseFloat *, int>> &params) { params_ = params; worker_ = AllocLike(params, false); }
+EasgdServer::~EasgdServer() { FreeAll(&worker_); }
+void EasgdServer::Run() {
+  int num_running_workers = NumNodes() - 1;
+  while (num_running_workers > 0) {
+    int worker_rank;
+    int32 msg;
+    comm_->WaitFromWorker(&worker_rank, &msg);
+    if (msg == kMsgFinished) {
+      num_running_workers--;
+      ASLP_LOG << "Worker " << worker_rank << " Finished ";
+    } else if (msg == kMsgSynchronize) {
+      comm_->Exchange(worker_rank, params_, worker_);
+      AddVec(params_, alpha_, worker_, 1.0f - alpha_);     // x_s = (1 - alpha) x_s + alpha x_w
+    } else {
+      ASLP_WARN << "Unknown mpi msg type " << msg;
+    }
+  }
+  Hip(hipStreamSynchronize(cur_stream()), "hipStreamSynchronize");
+  ASLP_LOG << "All worker finished";
+}
+
+// ---- ASGD / MASGD (asgd-worker.cc:37-71, asgd-server.cc:39-102, masgd-server.cc:39-118) -------------------------
+void AsgdWorker::InitParam(const std::vector<std::pair<BaseFloat *, int>> &params) {
+  params_ = params;
+  prev_ = AllocLike(params, true);
+  delta_ = AllocLike(params, false);
+}
+AsgdWorker::~AsgdWorker() { FreeAll(&prev_); FreeAll(&delta_); }
+bool AsgdWorker::Synchronize(int) {
+  comm_->PostToServer(kMsgSynchronize);
+  for (size_t i = 0; i < params_.size(); i++) aslp_vec_diff(delta_[i].first, params_[i].first, prev_[i].first, params_[i].second);
+  CheckK();
+  comm_->Send(MainNode(), delta_);
+  comm_->Recv(MainNode(), params_);  // returns when the server answers: at once, or at its periodic barrier
+  for (size_t i = 0; i < params_.size(); i++) Copy(prev_[i].first, params_[i].first, params_[i].second);
+  return true;
+}
+void AsgdWorker::Stop() {
+  comm_->PostToServer(kMsgFinished);
+  ASLP_LOG << "Worker " << Rank() << " finished";
+}
+void AsgdServer::InitParam(const std::vector<std::pair<BaseFloat *, int>> &params) {
+  params_ = params;
+  delta_ = AllocLike(params, false);
+  if (masgd_)
+    for (int w = 1; w < NumNodes(); w++) diffs_.push_back(AllocLike(params, false));
+}
+AsgdServer::~AsgdServer() {
+  FreeAll(&delta_);
+  for (auto &d : diffs_) FreeAll(&d);
+}
+void AsgdServer::Run() {
+  int num_running_workers = NumNodes() - 1, synchronized_count = 0;
+  std::vector<int> waited_worker;
+  while (num_running_workers > 0) {
+    int worker_rank;
+    int32 msg;
+    comm_->WaitFromWorker(&worker_rank, &msg);
+    if (msg == kMsgFinished) {
+      num_running_workers--;
+      ASLP_LOG << "Worker " << worker_rank << " Finished ";
+    } else if (msg == kMsgSynchronize) {
+      ++synchronized_count;
+      if (sync_period_ > 0 && synchronized_count >= sync_period_) waited_worker.push_back(worker_rank);
+      comm_->Recv(worker_rank, delta_);
+      if (masgd_) {
+        AddVec(diffs_[worker_rank - 1], 1.0f, delta_, momentum_);  // d_k = delta + momentum d_k
+        AddVec(params_, 1.0f, diffs_[worker_rank - 1], 1.0f);
+      } else {
+        AddVec(params_, alpha_, delta_, 1.0f);
+      }
+      if (synchronized_count < sync_period_ || sync_period_ <= 0) comm_->Send(worker_rank, params_);
+    } else {
+      ASLP_WARN << "Unknown mpi msg type " << msg;
+    }
+    if (sync_period_ > 0 && synchronized_count >= sync_period_ && (int)waited_worker.size() == num_running_workers && num_running_workers != 0) {
+      for (int w : waited_worker) {
+        ASLP_LOG << "Worker " << w << " synchronized!";
+        comm_->Send(w, params_);
+      }
+      synchronized_count -= sync_period_;
+      waited_worker.clear();
+    }
+  }
+  Hip(hipStreamSynchronize(cur_stream()), "hipStreamSynchronize");
+  ASLP_LOG << "All worker finished";
+}
+
 }  // namespace aslp

@@ -94,4 +94,74 @@ class SodWorker : public IWorker {
   std::vector<std::pair<BaseFloat *, int>> prev_, grad_, state1_, state2_;  // owned
 };
 
+// ---- server-based protocols: rank 0 is a parameter server (aslp-nnet-train-server), ranks 1.. are workers ----------------
+enum { kMsgSynchronize = 0, kMsgFinished = 1 };  // itf.h:19-22
+
+// easgd-worker.cc:37-80: the worker and the server swap models; x_w = (1 - alpha) x_w + alpha x_s
+class EasgdWorker : public IWorker {
+ public:
+  EasgdWorker(Comm *comm, float alpha) : IWorker(comm), alpha_(alpha) {}
+  ~EasgdWorker();
+  void InitParam(const std::vector<std::pair<BaseFloat *, int>> &params);
+  bool Synchronize(int num_worker_samples);
+  void Stop();
+
+ private:
+  float alpha_;
+  std::vector<std::pair<BaseFloat *, int>> params_, server_;  // server_: the server's model as received (owned)
+};
+
+// asgd-worker.cc:37-71 (also the worker of MasgdServer): sends its model DELTA since the last exchange, takes the server's model
+class AsgdWorker : public IWorker {
+ public:
+  explicit AsgdWorker(Comm *comm) : IWorker(comm) {}
+  ~AsgdWorker();
+  void InitParam(const std::vector<std::pair<BaseFloat *, int>> &params);
+  bool Synchronize(int num_worker_samples);
+  void Stop();
+
+ private:
+  std::vector<std::pair<BaseFloat *, int>> params_, prev_, delta_;
+};
+
+class IServer : public IWorker {  // itf.h:44-50
+ public:
+  explicit IServer(Comm *comm) : IWorker(comm) {}
+  bool Synchronize(int) { return false; }
+  void Stop() {}
+  virtual void Run() = 0;  // serves until every worker has sent kMsgFinished
+};
+
+// easgd-server.cc:37-86: x_s = (1 - alpha) x_s + alpha x_w, one worker at a time in arrival order
+class EasgdServer : public IServer {
+ public:
+  EasgdServer(Comm *comm, float alpha) : IServer(comm), alpha_(alpha) {}
+  ~EasgdServer();
+  void InitParam(const std::vector<std::pair<BaseFloat *, int>> &params);
+  void Run();
+
+ private:
+  float alpha_;
+  std::vector<std::pair<BaseFloat *, int>> params_, worker_;
+};
+
+// asgd-server.cc:39-102 / masgd-server.cc:39-118 (per-worker momentum buffers, the LMASGD variant the reference compiles):
+// x_s += alpha * delta  |  d_k = delta + momentum * d_k, x_s += d_k.  sync_period > 0: after that many exchanges the server
+// stops answering until every running worker waits, then answers them all with the same model.
+class AsgdServer : public IServer {
+ public:
+  AsgdServer(Comm *comm, float alpha, int sync_period, bool masgd = false, float momentum = 0.0f)
+      : IServer(comm), alpha_(alpha), momentum_(momentum), sync_period_(sync_period), masgd_(masgd) {}
+  ~AsgdServer();
+  void InitParam(const std::vector<std::pair<BaseFloat *, int>> &params);
+  void Run();
+
+ private:
+  float alpha_, momentum_;
+  int sync_period_;
+  bool masgd_;
+  std::vector<std::pair<BaseFloat *, int>> params_, delta_;
+  std::vector<std::vector<std::pair<BaseFloat *, int>>> diffs_;  // masgd: one per worker
+};
+
 }  // namespace aslp

@@ -2,9 +2,13 @@
 // buffers and prints every rank's parameters after each synchronisation, one line per (step, rank): the GPU test compares
 // them with the closed forms of bsp-worker.cc:33-65 / bmuf-worker.cc:37-68 computed in numpy.
 // (sod: of optimizer.h:40-171 applied to the summed deltas, sod-worker.cc:46-58).
-// Usage: aslp-parallel-selftest <bsp|bmuf|sod:SOLVER> <num-ranks> <dim> <steps> [bmuf-lr bmuf-momentum]   (sod runs the solver's defaults)
+// easgd | asgd | masgd: rank 0 is the parameter server, the other ranks are workers that take turns (worker 1, 2, ..., 1, 2, ...)
+// so that the arrival order at the server -- which decides the result -- is the same in every run; [lr momentum] are then
+// alpha (easgd, asgd) / the masgd momentum, and the asgd / masgd sync period.
+// Usage: aslp-parallel-selftest <bsp|bmuf|sod:SOLVER|easgd|asgd|masgd> <num-ranks> <dim> <steps> [bmuf-lr bmuf-momentum]   (sod runs the solver's defaults)
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <thread>
@@ -23,6 +27,8 @@ int main(int argc, char **argv) {
   std::vector<std::vector<float>> out((size_t)N * (steps + 1));
   std::vector<std::string> errors(N);
   std::vector<std::thread> th;
+  const bool served = type == "easgd" || type == "asgd" || type == "masgd";
+  std::atomic<int> turn(0);  // served protocols: which (step, worker) may synchronise next
   for (int r = 0; r < N; r++) {
     th.emplace_back([&, r] {
       try {
@@ -30,6 +36,49 @@ int main(int argc, char **argv) {
         if (hipStreamCreate(&st) != hipSuccess) throw std::runtime_error("hipStreamCreate");
         set_cur_stream(st);
         std::unique_ptr<Comm> comm(NewThreadComm(group, r));
+        if (served) {
+          // every rank starts from the same model w[i] = 1 + 0.01 i; worker r adds 0.5 r + 0.25 s before its s-th exchange
+          std::vector<float> h(dim);
+          for (int i = 0; i < dim; i++) h[i] = 1 + 0.01f * i;
+          float *d = nullptr;
+          if (hipMalloc(&d, sizeof(float) * dim) != hipSuccess) throw std::runtime_error("hipMalloc");
+          (void)hipMemcpyAsync(d, h.data(), sizeof(float) * dim, hipMemcpyHostToDevice, st);
+          (void)hipStreamSynchronize(st);
+          std::vector<std::pair<float *, int>> params = {{d, dim / 2}, {d + dim / 2, dim - dim / 2}};
+          if (r == 0) {
+            std::unique_ptr<IServer> srv;
+            if (type == "easgd") srv.reset(new EasgdServer(comm.get(), lr));
+            else if (type == "asgd") srv.reset(new AsgdServer(comm.get(), lr, (int)mom));
+            else srv.reset(new AsgdServer(comm.get(), 1.0f, (int)mom, true, lr));
+            srv->InitParam(params);
+            srv->Run();
+          } else {
+            std::unique_ptr<IWorker> w;
+            if (type == "easgd") w.reset(new EasgdWorker(comm.get(), lr));
+            else w.reset(new AsgdWorker(comm.get()));
+            w->InitParam(params);
+            for (int s = 0; s < steps; s++) {
+              (void)hipMemcpyAsync(h.data(), d, sizeof(float) * dim, hipMemcpyDeviceToHost, st);
+              (void)hipStreamSynchronize(st);
+              for (float &x : h) x += 0.5f * r + 0.25f * s;
+              (void)hipMemcpyAsync(d, h.data(), sizeof(float) * dim, hipMemcpyHostToDevice, st);
+              (void)hipStreamSynchronize(st);
+              const int my_turn = s * (N - 1) + (r - 1);
+              while (turn.load() != my_turn) std::this_thread::yield();
+              w->Synchronize(100);
+              (void)hipMemcpyAsync(h.data(), d, sizeof(float) * dim, hipMemcpyDeviceToHost, st);
+              (void)hipStreamSynchronize(st);
+              out[(size_t)s * N + r] = h;
+              turn.fetch_add(1);
+            }
+            w->Stop();
+          }
+          (void)hipMemcpyAsync(h.data(), d, sizeof(float) * dim, hipMemcpyDeviceToHost, st);
+          (void)hipStreamSynchronize(st);
+          if (r == 0) out[(size_t)steps * N + r] = h;  // the server's final model
+          (void)hipFree(d);
+          return;
+        }
         // two tensors (dim and dim / 2 + 1 floats): w[i] = rank + 1 + 0.01 i at the start
         const int n1 = dim, n2 = dim / 2 + 1;
         std::vector<float> h(n1 + n2);

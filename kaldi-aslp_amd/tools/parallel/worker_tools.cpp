@@ -7,6 +7,29 @@
 #include "nnet-nnet.h"
 #include "workers.h"
 
+namespace {
+// the --worker-type switch of the three worker tools (aslp-nnet-train-frame-worker.cc:114-126).  With easgd / asgd / masgd rank 0
+// of the group is aslp-nnet-train-server and these tools are ranks 1 .. N-1.
+std::unique_ptr<aslp::IWorker> MakeWorker(const std::string &type, aslp::Comm *comm, float alpha, float bmuf_learn_rate, float bmuf_momentum,
+                                          const aslp::OptimizerOption *optimizer_opts) {
+  using namespace aslp;
+  std::unique_ptr<IWorker> worker;
+  if (type == "bsp") worker.reset(new BspWorker(comm));
+  else if (type == "bmuf") worker.reset(new BmufWorker(comm, bmuf_learn_rate, bmuf_momentum));
+  else if (type == "sod" && optimizer_opts) worker.reset(new SodWorker(comm, *optimizer_opts));
+  else if (type == "easgd" || type == "asgd" || type == "masgd") {
+    if (comm->NumNodes() < 2 || comm->Rank() == 0)
+      ASLP_ERR << "worker type " << type << " needs aslp-nnet-train-server as rank 0 and the workers as ranks 1 .. N-1 (this is rank " << comm->Rank()
+               << " of " << comm->NumNodes() << ")";
+    if (type == "easgd") worker.reset(new EasgdWorker(comm, alpha));
+    else worker.reset(new AsgdWorker(comm));
+  } else {
+    ASLP_ERR << "Unsupported worker type: " << type;
+  }
+  return worker;
+}
+}  // namespace
+
 // ======================================================================================================================
 // aslp-nnet-train-frame-worker -- src/aslp-parallelbin/aslp-nnet-train-frame-worker.cc: the data-parallel twin of
 // aslp-nnet-train-frame.  One process per GPU, each on its own shard of the utterance list; every --sync-period frames
@@ -81,11 +104,7 @@ int Main_aslp_nnet_train_frame_worker(int argc, char *argv[]) {
     else ASLP_ERR << "Unsupported objective function: " << objective_function;
     Xent *xent = dynamic_cast<Xent *>(loss);
 
-    std::unique_ptr<IWorker> worker;
-    if (worker_type == "bsp") worker.reset(new BspWorker(comm.get()));
-    else if (worker_type == "bmuf") worker.reset(new BmufWorker(comm.get(), bmuf_learn_rate, bmuf_momentum));
-    else if (worker_type == "sod") worker.reset(new SodWorker(comm.get(), optimizer_opts));
-    else ASLP_ERR << "Unsupported worker type: " << worker_type << " (this build has the collective workers bsp | bmuf | sod)";
+    std::unique_ptr<IWorker> worker = MakeWorker(worker_type, comm.get(), alpha, bmuf_learn_rate, bmuf_momentum, &optimizer_opts);
     std::vector<std::pair<BaseFloat *, int>> params;
     nnet.GetGpuParams(&params);
     worker->InitParam(params);
@@ -222,11 +241,7 @@ int Main_aslp_nnet_train_lstm_stream_worker(int argc, char *argv[]) {
     if (objective_function == "xent") loss = new Xent;
     else if (objective_function == "mse") loss = new Mse;
     else ASLP_ERR << "Unsupported objective function: " << objective_function;
-    std::unique_ptr<IWorker> worker;
-    if (worker_type == "bsp") worker.reset(new BspWorker(comm.get()));
-    else if (worker_type == "bmuf") worker.reset(new BmufWorker(comm.get(), bmuf_learn_rate, bmuf_momentum));
-    else if (worker_type == "sod") worker.reset(new SodWorker(comm.get(), optimizer_opts));
-    else ASLP_ERR << "Unsupported worker type: " << worker_type << " (this build has the collective workers bsp | bmuf | sod)";
+    std::unique_ptr<IWorker> worker = MakeWorker(worker_type, comm.get(), alpha, bmuf_learn_rate, bmuf_momentum, &optimizer_opts);
     std::vector<std::pair<BaseFloat *, int>> params;
     nnet.GetGpuParams(&params);
     worker->InitParam(params);
@@ -393,10 +408,7 @@ int Main_aslp_nnet_train_lc_blstm_streams_worker(int argc, char *argv[]) {
     RandomAccessPosteriorReader target_reader(targets_rspecifier);
     Xent xent;
     Mse mse;
-    std::unique_ptr<IWorker> worker;
-    if (worker_type == "bsp") worker.reset(new BspWorker(comm.get()));
-    else if (worker_type == "bmuf") worker.reset(new BmufWorker(comm.get(), bmuf_learn_rate, bmuf_momentum));
-    else ASLP_ERR << "Unsupported worker type: " << worker_type << " (this build has the collective workers bsp | bmuf)";
+    std::unique_ptr<IWorker> worker = MakeWorker(worker_type, comm.get(), alpha, bmuf_learn_rate, bmuf_momentum, nullptr);
     std::vector<std::pair<BaseFloat *, int>> params;
     nnet.GetGpuParams(&params);
     worker->InitParam(params);
@@ -523,6 +535,75 @@ int Main_aslp_nnet_train_lc_blstm_streams_worker(int argc, char *argv[]) {
     else ASLP_ERR << "Unknown objective function code : " << objective_function;
     worker.reset();
     comm.reset();
+    CuDevice::Instantiate().PrintProfile();
+    return 0;
+  } catch (const std::exception &e) {
+    std::cerr << e.what();
+    return -1;
+  }
+}
+
+// ======================================================================================================================
+// aslp-nnet-train-server -- src/aslp-parallelbin/aslp-nnet-train-server.cc: the parameter server of the easgd / asgd / masgd
+// protocols, rank 0 of the group.  Holds the model on its own GPU, serves the workers in arrival order until each has
+// reported that it is finished, joins the final BatchNormalization statistics reduction and writes the model.
+int Main_aslp_nnet_train_server(int argc, char *argv[]) {
+  using namespace aslp;
+  try {
+    const char *usage =
+        "Parameter server for training, it can adapt all kinds of wokers,"
+        "eg framewise, sequential and stream training\n"
+        "Usage:  aslp-nnet-train-server [options] <model-in> <model-out>\n"
+        "e.g.: \n"
+        " aslp-nnet-train-server nnet.init nnet.out\n";
+    ParseOptions po(usage);
+    bool binary = true;
+    po.Register("binary", &binary, "Write output in binary mode");
+    std::string use_gpu = "yes";
+    po.Register("use-gpu", &use_gpu, "yes|no|optional, only has effect if compiled with CUDA");
+    std::string server_type = "easgd";
+    po.Register("server-type", &server_type, "Server type(easgd | asgd)");
+    float alpha = 0.5;
+    po.Register("alpha", &alpha, "Moving rate alpha for easgd server");
+    int32 sync_period = 1000;
+    po.Register("sync-period", &sync_period, "Synchronization period for ASGD");
+    int32 gpu_id = -1;
+    po.Register("gpu-id", &gpu_id, "selected gpu id, if negative then select automaticly");
+    float masgd_momentum = 0.9;
+    po.Register("masgd-momentum", &masgd_momentum, "momentum for masgd");
+    int32 rank = -1, num_workers = -1;
+    po.Register("rank", &rank, "Rank of the server (default: from the launcher's environment; must be 0)");
+    po.Register("num-workers", &num_workers, "Size of the group, server included (default: from the launcher's environment)");
+    std::string comm_file = "";
+    po.Register("comm-file", &comm_file, "Rendezvous file for the RCCL communicator");
+    po.Read(argc, argv);
+    if (po.NumArgs() != 2) { po.PrintUsage(); exit(1); }
+    std::string model_filename = po.GetArg(1), target_model_filename = po.GetArg(2);
+    RankFromEnvironment(&rank, &num_workers);
+    if (rank != 0) ASLP_ERR << "the parameter server is rank 0 of the group (got rank " << rank << ")";
+    if (gpu_id >= 0) CuDevice::Instantiate().SetGpuId(gpu_id);
+    else if (num_workers > 1) CuDevice::Instantiate().SetGpuId(rank);
+    else CuDevice::Instantiate().SelectGpuId(use_gpu);
+    std::unique_ptr<Comm> comm(NewRcclComm(rank, num_workers, comm_file));
+
+    Nnet nnet;
+    nnet.Read(model_filename);
+    std::unique_ptr<IServer> server;
+    if (server_type == "easgd") server.reset(new EasgdServer(comm.get(), alpha));
+    else if (server_type == "asgd") server.reset(new AsgdServer(comm.get(), alpha, sync_period));
+    else if (server_type == "masgd") server.reset(new AsgdServer(comm.get(), 1.0f, sync_period, true, masgd_momentum));
+    else ASLP_ERR << "Unsupported server type: " << server_type;
+    std::vector<std::pair<BaseFloat *, int>> params;
+    nnet.GetGpuParams(&params);
+    server->InitParam(params);
+    ASLP_LOG << "Mpi cluster info total " << server->NumNodes() << " server rank " << server->Rank();
+    server->Run();
+    std::vector<double *> acc_params;
+    std::vector<std::pair<double *, int>> data_params;
+    nnet.GetAccStats(&acc_params, &data_params);
+    server->ReduceAccStat(acc_params, data_params);
+    nnet.Write(target_model_filename, binary);
+    StreamSync();
     CuDevice::Instantiate().PrintProfile();
     return 0;
   } catch (const std::exception &e) {

@@ -121,6 +121,54 @@ def test_sod_worker_threads(solver):
             assert not np.allclose(got[(steps, r)], got[(steps, 0)])
 
 
+@pytest.mark.parametrize("kind,a,b", [("easgd", 0.5, 0), ("easgd", 0.25, 0), ("asgd", 0.5, 0), ("masgd", 0.5, 0)])
+def test_served_workers_threads(kind, a, b):
+    """EasgdWorker / AsgdWorker against EasgdServer / AsgdServer / the MASGD server (easgd-*.cc, asgd-*.cc, masgd-server.cc) with
+    rank 0 as the server and two workers taking turns, so the arrival order is fixed and the closed forms can be followed in
+    numpy.  (The periodic barrier of the asgd server is exercised with one worker below: with strict turns a held worker
+    would keep the next one from arriving.)"""
+    n, dim, steps = 3, 11, 3
+    got = run_selftest(kind, n, dim, steps, a, b)
+    base = (f32(1) + f32(0.01) * np.arange(dim, dtype=f32)).astype(np.float64)
+    server = base.copy()
+    w = {r: base.copy() for r in (1, 2)}
+    prev = {r: base.copy() for r in (1, 2)}
+    diffs = {r: np.zeros(dim) for r in (1, 2)}
+    for s in range(steps):
+        for r in (1, 2):
+            w[r] = w[r] + (0.5 * r + 0.25 * s)
+            if kind == "easgd":
+                ws, ss = w[r].copy(), server.copy()
+                w[r] = (1 - a) * ws + a * ss
+                server = (1 - a) * ss + a * ws
+            else:
+                delta = w[r] - prev[r]
+                if kind == "asgd":
+                    server = server + a * delta
+                else:
+                    diffs[r] = delta + a * diffs[r]
+                    server = server + diffs[r]
+                w[r] = server.copy()
+                prev[r] = server.copy()
+            np.testing.assert_allclose(got[(s, r)], w[r], rtol=2e-6, atol=1e-6)
+    np.testing.assert_allclose(got[(steps, 0)], server, rtol=2e-6, atol=1e-6)
+
+
+def test_asgd_periodic_barrier_single_worker_threads():
+    """asgd-server.cc:62-88 with sync_period 2 and one worker: exchanges 2, 4, ... are answered through the barrier branch
+    (every running worker -- the only one -- waits), the counter drops by the period; the arithmetic is unchanged."""
+    n, dim, steps = 2, 7, 5
+    got = run_selftest("asgd", n, dim, steps, 0.5, 2)
+    base = (f32(1) + f32(0.01) * np.arange(dim, dtype=f32)).astype(np.float64)
+    server, w, prev = base.copy(), base.copy(), base.copy()
+    for s in range(steps):
+        w = w + (0.5 + 0.25 * s)
+        server = server + 0.5 * (w - prev)
+        w, prev = server.copy(), server.copy()
+        np.testing.assert_allclose(got[(s, 1)], w, rtol=2e-6, atol=1e-6)
+    np.testing.assert_allclose(got[(steps, 0)], server, rtol=2e-6, atol=1e-6)
+
+
 @pytest.mark.parametrize("worker", ["bsp", "bmuf", "sod"])
 def test_frame_worker_tool_group_of_one(aslp, oracle, dev, tmp_path, worker):
     """aslp-nnet-train-frame-worker through RCCL with one rank.  BSP with one worker is the identity (factor 1), so the
@@ -147,6 +195,29 @@ def test_frame_worker_tool_group_of_one(aslp, oracle, dev, tmp_path, worker):
         assert np.array_equal(a, b)
     else:
         np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-7)
+
+
+def test_train_server_tool_and_served_worker_flags(aslp, oracle, dev, tmp_path):
+    """aslp-nnet-train-server alone in its group (no worker ever reports): it must come up on RCCL, read the model, find nothing
+    to serve, join the statistics reduction and write the model back unchanged; a worker tool asked for a served protocol
+    without a server says what it needs.  (Server + workers as separate processes need one GPU each; the protocols
+    themselves run in test_served_workers_threads.)"""
+    in_dim, hid, nh, out_dim, mb = 24, 64, 2, 40, 32
+    d, path = make_dnn(oracle, tmp_path, in_dim, hid, nh, out_dim, 1, mb, seed=21)
+    oracle.lib.orc_dnn_destroy(d)
+    for st in ("easgd", "asgd", "masgd"):
+        p = tool("aslp-nnet-train-server", "--server-type=%s" % st, "--alpha=0.5", "--sync-period=10", str(path), str(tmp_path / ("s_%s.nnet" % st)))
+        err = p.stderr.decode()
+        assert "Mpi cluster info total 1 server rank 0" in err and "All worker finished" in err
+        assert np.array_equal(aslp.Nnet.Read(tmp_path / ("s_%s.nnet" % st)).GetParams(), aslp.Nnet.Read(path).GetParams())
+    p = tool("aslp-nnet-train-server", "--server-type=nope", str(path), str(tmp_path / "x.nnet"), ok=False)
+    assert p.returncode != 0 and b"Unsupported server type: nope" in p.stderr
+    p = tool("aslp-nnet-train-server", ok=False)
+    assert p.returncode == 1 and b"Usage:  aslp-nnet-train-server [options] <model-in> <model-out>" in p.stderr
+    write_corpus(tmp_path, np.random.default_rng(7), 4, in_dim, out_dim)
+    p = tool("aslp-nnet-train-frame-worker", "--worker-type=easgd", "ark:%s" % (tmp_path / "feats.ark"), "ark:%s" % (tmp_path / "post.ark"), str(path),
+             str(tmp_path / "w.nnet"), ok=False)
+    assert p.returncode != 0 and b"needs aslp-nnet-train-server as rank 0" in p.stderr
 
 
 def test_lc_blstm_worker_tool_group_of_one(aslp, dev, tmp_path):
