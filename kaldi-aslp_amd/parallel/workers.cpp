@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <iostream>
 
 #include "aslp_kernels.h"
 #include "common.h"
@@ -183,6 +184,43 @@ void EasgdServer::Run() {
   }
   Hip(hipStreamSynchronize(cur_stream()), "hipStreamSynchronize");
   ASLP_LOG << "All worker finished";
+}
+
+// ---- pairwise averaging (nnet-mpi-sync.cc:17-135) ------------------------------------------------------------------
+PairSync::PairSync(Comm *comm) : comm_(comm), peer_(0), self_done_(0), peer_done_(0) {
+  if (comm_->NumNodes() != 2) ASLP_ERR << "num of jobs must be 2";
+  peer_ = (comm_->Rank() + 1) % 2;
+}
+PairSync::~PairSync() { FreeAll(&peer_params_); }
+void PairSync::Init(const std::vector<std::pair<BaseFloat *, int>> &params) {
+  params_ = params;
+  peer_params_ = AllocLike(params, false);
+  size_t total = 0;
+  for (auto &p : params) total += p.second;
+  ASLP_LOG << "num params " << params.size();
+  ASLP_LOG << "total params " << total;
+}
+void PairSync::Sync() {
+  int32 done[2] = {0, 0};
+  done[comm_->Rank()] = self_done_;
+  comm_->AllReduceSumHost(done, 2);  // both flags on both ranks
+  peer_done_ = done[peer_];
+  comm_->Exchange(peer_, params_, peer_params_);
+  if (PeerDone()) return;              // the peer only listens now: keep training on the own model
+  for (size_t i = 0; i < params_.size(); i++) {
+    const int n = params_[i].second;
+    if (SelfDone()) {
+      Copy(params_[i].first, peer_params_[i].first, n);   // out of data: follow the peer
+    } else {
+      aslp_vec_axpy(1.0f, peer_params_[i].first, params_[i].first, n);  // (mine + peer's) / 2
+      Scale(params_[i].first, n, 0.5f);
+    }
+  }
+  CheckK();
+  Hip(hipStreamSynchronize(cur_stream()), "hipStreamSynchronize");
+}
+void PairSync::SyncStatus() const {
+  std::cerr << "self\tpeer\tall\n" << SelfDone() << "\t" << PeerDone() << "\t" << AllDone() << "\n";
 }
 
 // ---- ASGD / MASGD (asgd-worker.cc:37-71, asgd-server.cc:39-102, masgd-server.cc:39-118) -------------------------

@@ -94,6 +94,28 @@ class SodWorker : public IWorker {
   std::vector<std::pair<BaseFloat *, int>> prev_, grad_, state1_, state2_;  // owned
 };
 
+// nnet-mpi-sync.cc:17-135 (NnetMpiSync, the synchroniser inside aslp-nnet-train-simple-mpi): exactly two ranks swap their whole
+// models and their "my data is finished" flags; while both still train each keeps the average, a finished rank adopts the
+// peer's model, and a rank whose peer has finished keeps its own.
+class PairSync {
+ public:
+  explicit PairSync(Comm *comm);
+  ~PairSync();
+  void Init(const std::vector<std::pair<BaseFloat *, int>> &params);
+  void Sync();
+  void SetSelfDone() { self_done_ = 1; }
+  bool SelfDone() const { return self_done_ > 0; }
+  bool PeerDone() const { return peer_done_ > 0; }
+  bool AllDone() const { return self_done_ > 0 && peer_done_ > 0; }
+  int Rank() const { return comm_->Rank(); }
+  void SyncStatus() const;  // the reference's three-column status line on stderr
+
+ private:
+  Comm *comm_;
+  int peer_, self_done_, peer_done_;
+  std::vector<std::pair<BaseFloat *, int>> params_, peer_params_;
+};
+
 // ---- server-based protocols: rank 0 is a parameter server (aslp-nnet-train-server), ranks 1.. are workers ----------------
 enum { kMsgSynchronize = 0, kMsgFinished = 1 };  // itf.h:19-22
 

@@ -6,6 +6,7 @@
 #include "data-reader.h"
 #include "nnet-loss.h"
 #include "nnet-nnet.h"
+#include "simple_sync.h"
 
 // ======================================================================================================================
 // aslp-nnet-train-frame -- src/aslp-nnetbin/aslp-nnet-train-frame.cc: one epoch of minibatch SGD (or cross-validation)
@@ -126,7 +127,9 @@ int Main_aslp_nnet_train_frame(int argc, char *argv[]) {
 // aslp-nnet-train-simple -- src/aslp-nnetbin/aslp-nnet-train-simple.cc: one epoch of minibatch SGD (or cross-validation)
 // with the tool's own cache-fill loop: optional feature transform, per-frame and per-utterance weights, length
 // tolerance, xent | mse | multitask objectives.  Same flags, usage text, positional arguments and log lines.
-int Main_aslp_nnet_train_simple(int argc, char *argv[]) {
+int Main_aslp_nnet_train_simple(int argc, char *argv[]) { return TrainSimpleWithSync(argc, argv, NULL); }
+
+int TrainSimpleWithSync(int argc, char *argv[], SimpleSync *sync) {
   using namespace aslp;
   try {
     const char *usage =
@@ -160,19 +163,22 @@ int Main_aslp_nnet_train_simple(int argc, char *argv[]) {
     po.Register("dropout-retention", &dropout_retention, "number between 0..1, saying how many neurons to preserve (0.0 will keep original value");
     int32 report_period = 60000;
     po.Register("report-period", &report_period, "Number of frames for one report log, default(60000)");
+    if (sync) sync->Register(&po);
     po.Read(argc, argv);
     if (po.NumArgs() != 4 - (crossvalidate ? 1 : 0)) { po.PrintUsage(); exit(1); }
     std::string feature_rspecifier = po.GetArg(1), targets_rspecifier = po.GetArg(2), model_filename = po.GetArg(3);
     std::string target_model_filename;
     if (!crossvalidate) target_model_filename = po.GetArg(4);
 
-    CuDevice::Instantiate().SelectGpuId(use_gpu);
+    if (sync) sync->Connect();  // picks the GPU of its rank and brings up the communicator before the model exists
+    else CuDevice::Instantiate().SelectGpuId(use_gpu);
 
     Nnet nnet_transf;
     if (feature_transform != "") nnet_transf.Read(feature_transform);
     Nnet nnet;
     nnet.Read(model_filename);
     nnet.SetTrainOptions(trn_opts);
+    if (sync) sync->Init(&nnet, &feature_rspecifier);
     if (dropout_retention > 0.0) { nnet_transf.SetDropoutRetention(dropout_retention); nnet.SetDropoutRetention(dropout_retention); }
     if (crossvalidate) { nnet_transf.SetDropoutRetention(1.0); nnet.SetDropoutRetention(1.0); }
 
@@ -285,14 +291,16 @@ int Main_aslp_nnet_train_simple(int argc, char *argv[]) {
           if (objective_function == "xent") ASLP_LOG << xent.Report();
           report_frames -= report_period;
         }
+        if (sync) sync->AfterMinibatch();
       }
     }
+    if (sync) sync->Finish();
     if (g_verbose_level >= 1) {
       ASLP_VLOG(1) << "### After " << total_frames << " frames,";
       ASLP_VLOG(1) << nnet.InfoPropagate();
       if (!crossvalidate) { ASLP_VLOG(1) << nnet.InfoBackPropagate(); ASLP_VLOG(1) << nnet.InfoGradient(); }
     }
-    if (!crossvalidate) nnet.Write(target_model_filename, binary);
+    if (!crossvalidate && (!sync || sync->WritesModel())) nnet.Write(target_model_filename, binary);
     StreamSync();
     ASLP_LOG << "Done " << num_done << " files, " << num_no_tgt_mat << " with no tgt_mats, " << num_other_error << " with other errors. "
              << "[" << (crossvalidate ? "CROSS-VALIDATION" : "TRAINING") << ", " << (randomize ? "RANDOMIZED" : "NOT-RANDOMIZED") << ", "

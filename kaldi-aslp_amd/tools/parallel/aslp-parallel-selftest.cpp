@@ -5,7 +5,8 @@
 // easgd | asgd | masgd: rank 0 is the parameter server, the other ranks are workers that take turns (worker 1, 2, ..., 1, 2, ...)
 // so that the arrival order at the server -- which decides the result -- is the same in every run; [lr momentum] are then
 // alpha (easgd, asgd) / the masgd momentum, and the asgd / masgd sync period.
-// Usage: aslp-parallel-selftest <bsp|bmuf|sod:SOLVER|easgd|asgd|masgd> <num-ranks> <dim> <steps> [bmuf-lr bmuf-momentum]   (sod runs the solver's defaults)
+// pair: PairSync with two ranks, one line per (exchange, rank).
+// Usage: aslp-parallel-selftest <bsp|bmuf|sod:SOLVER|easgd|asgd|masgd|pair> <num-ranks> <dim> <steps> [bmuf-lr bmuf-momentum]   (sod runs the solver's defaults)
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -36,6 +37,37 @@ int main(int argc, char **argv) {
         if (hipStreamCreate(&st) != hipSuccess) throw std::runtime_error("hipStreamCreate");
         set_cur_stream(st);
         std::unique_ptr<Comm> comm(NewThreadComm(group, r));
+        if (type == "pair") {  // PairSync (aslp-nnet-train-simple-mpi): rank 1 runs out of data two exchanges before rank 0
+          std::vector<float> h(dim);
+          for (int i = 0; i < dim; i++) h[i] = 1 + 0.01f * i;
+          float *d = nullptr;
+          if (hipMalloc(&d, sizeof(float) * dim) != hipSuccess) throw std::runtime_error("hipMalloc");
+          (void)hipMemcpyAsync(d, h.data(), sizeof(float) * dim, hipMemcpyHostToDevice, st);
+          (void)hipStreamSynchronize(st);
+          PairSync pair(comm.get());
+          pair.Init({{d, dim / 2}, {d + dim / 2, dim - dim / 2}});
+          const int mine = r == 0 ? steps : steps - 2;
+          int k = 0;
+          auto record = [&] {
+            (void)hipMemcpyAsync(h.data(), d, sizeof(float) * dim, hipMemcpyDeviceToHost, st);
+            (void)hipStreamSynchronize(st);
+            if (k <= steps) out[(size_t)k * N + r] = h;
+            k++;
+          };
+          for (int s = 0; s < mine; s++) {
+            (void)hipMemcpyAsync(h.data(), d, sizeof(float) * dim, hipMemcpyDeviceToHost, st);
+            (void)hipStreamSynchronize(st);
+            for (float &x : h) x += 0.5f * (r + 1) + 0.25f * s;
+            (void)hipMemcpyAsync(d, h.data(), sizeof(float) * dim, hipMemcpyHostToDevice, st);
+            (void)hipStreamSynchronize(st);
+            pair.Sync();
+            record();
+          }
+          pair.SetSelfDone();
+          do { pair.Sync(); record(); } while (!pair.AllDone());
+          (void)hipFree(d);
+          return;
+        }
         if (served) {
           // every rank starts from the same model w[i] = 1 + 0.01 i; worker r adds 0.5 r + 0.25 s before its s-th exchange
           std::vector<float> h(dim);

@@ -6,6 +6,7 @@
 #include "nnet-loss.h"
 #include "nnet-nnet.h"
 #include "workers.h"
+#include "../simple_sync.h"
 
 namespace {
 // the --worker-type switch of the three worker tools (aslp-nnet-train-frame-worker.cc:114-126).  With easgd / asgd / masgd rank 0
@@ -610,4 +611,64 @@ int Main_aslp_nnet_train_server(int argc, char *argv[]) {
     std::cerr << e.what();
     return -1;
   }
+}
+
+// ======================================================================================================================
+// aslp-nnet-train-simple-mpi -- src/aslp-parallelbin/aslp-nnet-train-simple-mpi.cc: aslp-nnet-train-simple run as exactly two
+// ranks that average their models every --sync-period minibatches (PairSync).  "JOB" in the feature rspecifier becomes the
+// rank; rank 0 writes the model.  Usage text and flags are train-simple's (as in the reference) plus --sync-period.
+namespace {
+class PairSimpleSync : public SimpleSync {
+ public:
+  PairSimpleSync() : sync_period_(1), rank_(-1), num_workers_(-1), num_minibatch_(0) {}
+  void Register(aslp::ParseOptions *po) {
+    po->Register("sync-period", &sync_period_, "every n minibatch(sync_period) sync once");
+    po->Register("rank", &rank_, "Rank of this process (default: from the launcher's environment)");
+    po->Register("num-workers", &num_workers_, "Number of processes, must be 2 (default: from the launcher's environment)");
+    po->Register("comm-file", &comm_file_, "Rendezvous file for the RCCL communicator");
+  }
+  void Connect() {
+    using namespace aslp;
+    RankFromEnvironment(&rank_, &num_workers_);
+    if (num_workers_ != 2) ASLP_ERR << "num of jobs must be 2";
+    CuDevice::Instantiate().SetGpuId(rank_);
+    comm_.reset(NewRcclComm(rank_, num_workers_, comm_file_));
+    pair_.reset(new PairSync(comm_.get()));
+  }
+  void Init(aslp::Nnet *nnet, std::string *feature_rspecifier) {
+    std::vector<std::pair<aslp::BaseFloat *, int>> params;
+    nnet->GetGpuParams(&params);
+    pair_->Init(params);
+    const std::string rank = std::to_string(pair_->Rank());
+    for (size_t pos = 0; (pos = feature_rspecifier->find("JOB", pos)) != std::string::npos; pos += rank.size()) feature_rspecifier->replace(pos, 3, rank);
+    ASLP_LOG << "MPI Rank " << pair_->Rank();
+    ASLP_LOG << "Train scp " << *feature_rspecifier;
+  }
+  void AfterMinibatch() {
+    if (++num_minibatch_ % sync_period_ == 0) {
+      ASLP_LOG << "MPI sync on " << num_minibatch_;
+      pair_->Sync();
+    }
+  }
+  void Finish() {  // keep answering the peer's exchanges until it is done as well (:362-368)
+    pair_->SyncStatus();
+    pair_->SetSelfDone();
+    pair_->SyncStatus();
+    do { pair_->Sync(); } while (!pair_->AllDone());
+    pair_->SyncStatus();
+  }
+  bool WritesModel() const { return pair_->Rank() == 0; }
+
+ private:
+  aslp::int32 sync_period_, rank_, num_workers_;
+  long num_minibatch_;
+  std::string comm_file_;
+  std::unique_ptr<aslp::Comm> comm_;
+  std::unique_ptr<aslp::PairSync> pair_;
+};
+}  // namespace
+
+int Main_aslp_nnet_train_simple_mpi(int argc, char *argv[]) {
+  PairSimpleSync sync;
+  return TrainSimpleWithSync(argc, argv, &sync);
 }

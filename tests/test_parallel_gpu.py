@@ -154,6 +154,35 @@ def test_served_workers_threads(kind, a, b):
     np.testing.assert_allclose(got[(steps, 0)], server, rtol=2e-6, atol=1e-6)
 
 
+def test_pair_sync_threads():
+    """PairSync (nnet-mpi-sync.cc:75-128, inside aslp-nnet-train-simple-mpi): while both ranks train each keeps the average; the
+    rank that runs out of data first follows its peer, which keeps its own model; the loop ends when both are done."""
+    dim, steps = 9, 5
+    got = run_selftest("pair", 2, dim, steps)
+    w = [(f32(1) + f32(0.01) * np.arange(dim, dtype=f32)).astype(np.float64) for _ in range(2)]
+    data = [steps, steps - 2]
+    done = [False, False]
+    k = 0
+    while not all(done):
+        for r in range(2):
+            if k < data[r]:
+                w[r] = w[r] + (0.5 * (r + 1) + 0.25 * k)
+            else:
+                done[r] = True
+        a, b = w[0].copy(), w[1].copy()
+        for r, (mine, peer) in enumerate(((a, b), (b, a))):
+            if done[1 - r]:
+                pass                       # the peer has finished: keep the own model
+            elif done[r]:
+                w[r] = peer.copy()         # finished: adopt the peer's
+            else:
+                w[r] = (mine + peer) / 2
+        for r in range(2):
+            np.testing.assert_allclose(got[(k, r)], w[r], rtol=2e-6, atol=1e-6)
+        k += 1
+    assert k == steps + 1 and (k, 0) not in got
+
+
 def test_asgd_periodic_barrier_single_worker_threads():
     """asgd-server.cc:62-88 with sync_period 2 and one worker: exchanges 2, 4, ... are answered through the barrier branch
     (every running worker -- the only one -- waits), the counter drops by the period; the arithmetic is unchanged."""
@@ -218,6 +247,10 @@ def test_train_server_tool_and_served_worker_flags(aslp, oracle, dev, tmp_path):
     p = tool("aslp-nnet-train-frame-worker", "--worker-type=easgd", "ark:%s" % (tmp_path / "feats.ark"), "ark:%s" % (tmp_path / "post.ark"), str(path),
              str(tmp_path / "w.nnet"), ok=False)
     assert p.returncode != 0 and b"needs aslp-nnet-train-server as rank 0" in p.stderr
+    # the two-rank averaging tool refuses any other group size, like the reference ("num of jobs must be 2")
+    p = tool("aslp-nnet-train-simple-mpi", "ark:%s" % (tmp_path / "feats.ark"), "ark:%s" % (tmp_path / "post.ark"), str(path), str(tmp_path / "m.nnet"),
+             ok=False)
+    assert p.returncode != 0 and b"num of jobs must be 2" in p.stderr
 
 
 def test_lc_blstm_worker_tool_group_of_one(aslp, dev, tmp_path):
