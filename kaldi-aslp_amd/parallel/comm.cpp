@@ -49,10 +49,10 @@ class RcclComm : public Comm {
       Nccl(ncclGetUniqueId(&id), "ncclGetUniqueId");
       if (n > 1) {
         // the control pipe exists before the id does, so whoever found the id can open it; O_RDWR: never sees end-of-file
+        // (only the served protocols need it: on a filesystem without FIFOs the collective workers still run)
         (void)unlink(ctl_path_.c_str());
-        if (mkfifo(ctl_path_.c_str(), 0600) != 0) ASLP_ERR << "cannot create " << ctl_path_ << ": " << strerror(errno);
-        ctl_fd_ = open(ctl_path_.c_str(), O_RDWR);
-        if (ctl_fd_ < 0) ASLP_ERR << "cannot open " << ctl_path_ << ": " << strerror(errno);
+        if (mkfifo(ctl_path_.c_str(), 0600) == 0) ctl_fd_ = open(ctl_path_.c_str(), O_RDWR);
+        if (ctl_fd_ < 0) ASLP_WARN << "no control pipe at " << ctl_path_ << " (" << strerror(errno) << "): easgd / asgd / masgd are unavailable in this group";
         const std::string tmp = id_file + ".tmp." + std::to_string((long)getpid());
         { std::ofstream f(tmp, std::ios::binary); f.write(reinterpret_cast<const char *>(&id), sizeof(id)); if (!f.good()) ASLP_ERR << "cannot write " << tmp; }
         if (std::rename(tmp.c_str(), id_file.c_str()) != 0) ASLP_ERR << "cannot create " << id_file;
@@ -67,10 +67,7 @@ class RcclComm : public Comm {
         std::this_thread::sleep_for(std::chrono::milliseconds(50));
       }
     }
-    if (rank != 0 && n > 1) {
-      ctl_fd_ = open(ctl_path_.c_str(), O_WRONLY);
-      if (ctl_fd_ < 0) ASLP_ERR << "cannot open " << ctl_path_ << ": " << strerror(errno);
-    }
+    if (rank != 0 && n > 1) ctl_fd_ = open(ctl_path_.c_str(), O_WRONLY | O_NONBLOCK);  // rank 0 holds the read end already; -1: see PostToServer
     Nccl(ncclCommInitRank(&comm_, n, id, rank), "ncclCommInitRank");
     Barrier();
     if (rank == 0 && n > 1) std::remove(id_file.c_str());  // everybody has joined: the next run writes a fresh id
@@ -83,9 +80,11 @@ class RcclComm : public Comm {
   }
   void PostToServer(int32 msg) {
     const int32 rec[2] = {rank_, msg};  // 8 bytes: one atomic write (< PIPE_BUF), so messages of different workers never mix
-    if (ctl_fd_ < 0 || write(ctl_fd_, rec, sizeof(rec)) != (ssize_t)sizeof(rec)) ASLP_ERR << "control pipe write failed: " << strerror(errno);
+    if (ctl_fd_ < 0) ASLP_ERR << "this group has no control pipe (" << ctl_path_ << "): the served protocols need one";
+    if (write(ctl_fd_, rec, sizeof(rec)) != (ssize_t)sizeof(rec)) ASLP_ERR << "control pipe write failed: " << strerror(errno);
   }
   void WaitFromWorker(int *src, int32 *msg) {
+    if (ctl_fd_ < 0) ASLP_ERR << "this group has no control pipe (" << ctl_path_ << "): the served protocols need one";
     int32 rec[2];
     size_t got = 0;
     while (got < sizeof(rec)) {
