@@ -135,6 +135,17 @@ class AffineTransform : public UpdatableComponent {
     ep.bias = bias_.Data();
     out->AddMatMat(1.0, in, kNoTrans, linearity_, kTrans, 0.0, &ep);
   }
+  // Executor peephole (nnet-nnet.cpp): a Sigmoid that is this component's only consumer gets its output from the same
+  // GEMM (second store of the epilogue, sigmoid of the value just written to `out`): same bits as the separate launch.
+  void PropagateWithSigmoid(const CuMatrixBase &in, CuMatrix *out, CuMatrix *sigmoid_out) {
+    ASLP_ASSERT(in.NumCols() == input_dim_);
+    if (out->NumRows() != in.NumRows() || out->NumCols() != output_dim_) out->Resize(in.NumRows(), output_dim_, kUndefined);
+    if (sigmoid_out->NumRows() != in.NumRows() || sigmoid_out->NumCols() != output_dim_) sigmoid_out->Resize(in.NumRows(), output_dim_, kUndefined);
+    aslp_gemm_epilogue ep = aslp_gemm_epilogue();
+    ep.bias = bias_.Data();
+    ep.act_out = sigmoid_out->Data(); ep.ld_act = sigmoid_out->Stride(); ep.act = 1;
+    out->AddMatMat(1.0, in, kNoTrans, linearity_, kTrans, 0.0, &ep);
+  }
   void BackpropagateFnc(const CuMatrixBase &, const CuMatrixBase &, const CuMatrixBase &out_diff, CuMatrixBase *in_diff) {
     in_diff->AddMatMat(1.0, out_diff, kNoTrans, linearity_, kNoTrans, 0.0);  // :193-197
   }

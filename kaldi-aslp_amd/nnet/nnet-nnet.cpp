@@ -47,6 +47,15 @@ int32 Nnet::FusedSigmoidOf(int32 i) const {
   }
   return -1;
 }
+int32 Nnet::AffineSigmoidOf(int32 i) const {
+  if (!fuse_layers_ || !alias_links_ || components_[i]->GetType() != Component::kAffineTransform || num_consumers_[i] != 1) return -1;
+  for (int32 j = i + 1; j < NumComponents(); j++) {
+    const std::vector<int32> &inp = components_[j]->GetInput();
+    if (inp.size() == 1 && inp[0] == i)
+      return (components_[j]->GetType() == Component::kSigmoid && IsDirectLink(j)) ? j : -1;
+  }
+  return -1;
+}
 const CuMatrixBase &Nnet::OutputBuffer(int32 c) const {
   if (FusedSigmoidOf(c) >= 0) ASLP_ERR << "output of component " << c << " is not materialised (fused into the Sigmoid behind it); SetLayerFusion(false)";
   if (softmax_folded_ && (IsFinalSoftmax(c) || c == output_[0]))
@@ -82,8 +91,14 @@ void Nnet::Propagate(const std::vector<const CuMatrixBase *> &in, std::vector<Cu
       }
     }
     Timer tim1;
-    const int32 fs = FusedSigmoidOf(i);
-    if (fs >= 0) {  // BatchNormalization + Sigmoid in one statistics pass and one write pass
+    const int32 fs = FusedSigmoidOf(i), as = AffineSigmoidOf(i);
+    if (as >= 0) {  // AffineTransform + Sigmoid forward in one GEMM; both outputs exist, the backward passes stay separate
+      dynamic_cast<AffineTransform *>(components_[i])->PropagateWithSigmoid(*in_view_[i], &output_buf_[i], &output_buf_[as]);
+      out_view_[i] = &output_buf_[i];
+      in_view_[as] = &output_buf_[i];
+      out_view_[as] = &output_buf_[as];
+      done[as] = 1;
+    } else if (fs >= 0) {  // BatchNormalization + Sigmoid in one statistics pass and one write pass
       dynamic_cast<BatchNormalization *>(components_[i])->PropagateWithSigmoid(*in_view_[i], &output_buf_[fs]);
       out_view_[i] = &output_buf_[fs];
       out_view_[fs] = &output_buf_[fs];

@@ -108,6 +108,7 @@ class Nnet {
   bool IsDirectLink(int32 i) const;  // single input, offset 0, full width
   bool IsFinalSoftmax(int32 i) const;
   int32 FusedSigmoidOf(int32 i) const;  // index of the Sigmoid folded into BatchNormalization i, or -1
+  int32 AffineSigmoidOf(int32 i) const;  // index of the Sigmoid whose forward pass rides in AffineTransform i's GEMM, or -1
 
   std::vector<Component *> components_;
   std::vector<int32> input_, output_;

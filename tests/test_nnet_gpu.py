@@ -198,11 +198,13 @@ def test_model_file_round_trip_text_and_binary(aslp, oracle, dev, tmp_path):
     assert "<Splice> 24 8 1 [ 0 ]\n[ 0 ]\n\n[ -1 0 1 ]\n" in txt and txt.rstrip().endswith("</Nnet>")
 
 
-def test_bn_sigmoid_fusion_is_bit_identical(aslp, oracle, dev, tmp_path):
-    """The executor folds a Sigmoid behind a BatchNormalization into the BN kernels (Nnet::SetLayerFusion, default on).
+@pytest.mark.parametrize("bn", [1, 0])
+def test_bn_sigmoid_fusion_is_bit_identical(aslp, oracle, dev, tmp_path, bn):
+    """The executor folds a Sigmoid behind a BatchNormalization into the BN kernels, and the forward pass of a Sigmoid behind
+    an AffineTransform (nets without BatchNormalization) into that layer's GEMM (Nnet::SetLayerFusion, default on).
     Same float operations in the same order: outputs and updated parameters must be bit-identical to the unfused run."""
     in_dim, hid, nh, out_dim, mb = 40, 96, 3, 50, 128
-    d, path = make_dnn(oracle, tmp_path, in_dim, hid, nh, out_dim, 1, mb, seed=11)
+    d, path = make_dnn(oracle, tmp_path, in_dim, hid, nh, out_dim, bn, mb, seed=11)
     nets = [aslp.Nnet.Read(path), aslp.Nnet.Read(path)]
     nets[1].SetLayerFusion(False)
     rng = np.random.default_rng(5)
@@ -217,11 +219,15 @@ def test_bn_sigmoid_fusion_is_bit_identical(aslp, oracle, dev, tmp_path):
             outs.append(net.ComponentOutput(net.NumComponents() - 1, mb, out_dim))
         assert np.array_equal(outs[0], outs[1]), step
         assert np.array_equal(nets[0].GetParams(), nets[1].GetParams()), step
+    if not bn:  # the AffineTransform fold keeps both outputs: the pre-activation is there and equal
+        aff = [c for c in range(nets[0].NumComponents()) if nets[0].Marker(c) == "<AffineTransform>"][0]
+        assert np.array_equal(nets[0].ComponentOutput(aff, mb, hid), nets[1].ComponentOutput(aff, mb, hid))
+        return
     # the folded intermediate is not materialised: asking for it is an error, not stale data
-    bn = [c for c in range(nets[0].NumComponents()) if nets[0].Marker(c) == "<BatchNormalization>"][0]
+    bnc = [c for c in range(nets[0].NumComponents()) if nets[0].Marker(c) == "<BatchNormalization>"][0]
     with pytest.raises(RuntimeError):
-        nets[0].ComponentOutput(bn, mb, hid)
-    assert nets[1].ComponentOutput(bn, mb, hid).shape == (mb, hid)
+        nets[0].ComponentOutput(bnc, mb, hid)
+    assert nets[1].ComponentOutput(bnc, mb, hid).shape == (mb, hid)
 
 
 def test_softmax_fold_and_update_overlap_are_bit_identical(aslp, oracle, dev, tmp_path):
