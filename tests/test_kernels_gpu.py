@@ -385,3 +385,34 @@ def test_rnn_vec_grads(aslp, oracle, dev, rows, C, cifg, clip, lr):
             ref = np.clip(ref, -clip, clip)
         assert oracle.rel_err(corr[k].cpu().numpy(), ref) < 1e-5, k
         assert oracle.rel_err(par[k].cpu().numpy(), par0[k] - lr * ref) < 1e-5, k
+
+
+@pytest.mark.parametrize("rows,cols", [(256, 128), (1024, 2048), (129, 260)])
+def test_bn_backward_with_folded_sigmoid_is_bit_identical(aslp, dev, rows, cols):
+    """aslp_bn_backward_act forming dy = od * y * (1 - y) on the fly must give, bit for bit, what Sigmoid's backward followed by
+    the plain BatchNormalization backward gives (the folded and unfolded executors rely on it): the products are rounded on
+    their own in both, never contracted into the column sums.  Panel-resident and three-launch paths."""
+    g = torch.Generator(device="cpu").manual_seed(1)
+    od = torch.randn(rows, cols, generator=g).to(dev)
+    xhat = torch.randn(rows, cols, generator=g).to(dev)
+    y = torch.sigmoid(torch.randn(rows, cols, generator=g)).to(dev)
+    scale = (torch.rand(cols, generator=g) + 0.5).to(dev)
+    inv = (torch.rand(cols, generator=g) + 0.5).to(dev)
+    ptr, dim, lib = aslp.ops.ptr, aslp.ops.dim, aslp.ops.lib
+    res = []
+    for folded in (True, False):
+        xh, ds, dsh = xhat.clone(), torch.zeros(cols, device=dev), torch.zeros(cols, device=dev)
+        ind = torch.empty(rows, cols, device=dev)
+        if folded:
+            lib.aslp_bn_backward_act(None, dim(od), ptr(od), dim(od).stride, ptr(xh), dim(xh).stride, ptr(scale), None, ptr(inv), ptr(ds), ptr(dsh), 0.0,
+                                     ptr(ind), dim(ind).stride, ptr(y), dim(y).stride)
+        else:
+            d = torch.empty_like(od)
+            aslp.ops.diff_sigmoid(d, y, od)
+            lib.aslp_bn_backward_act(None, dim(d), ptr(d), dim(d).stride, ptr(xh), dim(xh).stride, ptr(scale), None, ptr(inv), ptr(ds), ptr(dsh), 0.0,
+                                     ptr(ind), dim(ind).stride, None, 0)
+        aslp.ops.check_error()
+        torch.cuda.synchronize()
+        res.append([t.cpu().numpy() for t in (ds, dsh, ind, xh)])
+    for name, a, b in zip(("dscale", "dshift", "in_diff", "xhat <- dy * gamma"), res[0], res[1]):
+        assert np.array_equal(a, b), name
