@@ -35,4 +35,6 @@ p = subprocess.run([BIN + "/aslp-nnet-train-frame", "--print-args=false", "--lea
 wall = time.time() - t0
 err = p.stderr.decode()
 print([l for l in err.splitlines() if "fps" in l or "AvgLoss" in l or "ERROR" in l][-3:])
+if os.environ.get("PROFILE") == "1":
+    print("\n".join(l for l in err.splitlines() if "profile" in l.lower() or "\t" in l or "Time" in l)[-3000:])
 print("frames %d, process wall %.2f s -> %.0f frames/s incl. start-up, model read / write" % (n_utt * 500, wall, n_utt * 500 / wall))
