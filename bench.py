@@ -101,6 +101,50 @@ def ctc_rel_err(aslp, dev):
             "fixture": "tests/golden/ctc_a128_t200.bin (alphabet 128, %d utterances, T <= %d; reference CPU output)" % (g["mb"], g["maxT"])}
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` from a bare shell (no launcher environment): start N ranks, one process per GPU, and hand
+    back rank 0's JSON line.  This parent never touches the GPU (no torch.cuda call, no HIP call): the children are ordinary
+    child processes, nothing is exec'ed over a process that has initialised the device.  The ranks meet through a
+    rendezvous file carrying a per-launch token (kaldi-aslp_amd/parallel/comm.cpp) -- no MPI, no torch.distributed."""
+    import secrets
+    import subprocess
+    import tempfile
+    token = secrets.token_hex(8)
+    comm_file = os.path.join(tempfile.gettempdir(), "aslp_bench_comm_" + token)
+    argv = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), ASLP_COMM_FILE=comm_file, ASLP_COMM_TOKEN=token)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs between processes on this driver
+        procs.append(subprocess.Popen(argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = b""
+    rc = 0
+    try:
+        out0 = procs[0].communicate()[0]      # rank 0 prints the line; it ends after the last collective
+        deadline = time.time() + 120.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(1.0, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                pass
+    finally:
+        for p in procs:                        # exactly the processes started here, never a pattern
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+                rc = rc or 124
+        for p in procs:
+            rc = rc or (p.returncode or 0)
+        for f in (comm_file, comm_file + ".ctl"):
+            try:
+                os.unlink(f)
+            except OSError:
+                pass
+    sys.stdout.write(out0.decode(errors="replace"))
+    sys.stdout.flush()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,34 +155,49 @@ def main():
     ap.add_argument("--no-gemm-profile", action="store_true", help="do not bracket GEMM launches with HIP events")
     ap.add_argument("--no-update-overlap", action="store_true",
                     help="keep the weight-gradient GEMMs on the main stream (per-kernel profiles: every kernel alone on the chip)")
+    ap.add_argument("--no-cfg3", action="store_true", help="skip the LC-BLSTM (BASELINE cfg3) block of the JSON line")
+    ap.add_argument("--dry-run-ranks", action="store_true", help=argparse.SUPPRESS)   # launcher plumbing test (no GPU): tests/test_bench_cpu.py
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and args.gpus > 1:
+        sys.exit(launch_ranks(args))          # before anything touches the GPU
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks" % (args.gpus, world))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if args.dry_run_ranks:
+        if os.environ.get("ASLP_BENCH_DRYRUN_FAIL_RANK") == str(rank):
+            raise SystemExit(3)
+        if rank == 0:
+            print(json.dumps({"n_gpus": world, "dry_run": True, "comm_file": os.environ.get("ASLP_COMM_FILE"), "token": os.environ.get("ASLP_COMM_TOKEN")}))
+        return
+
+    import torch
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    # ASLP_BENCH_FORCE_SYNC=1 exercises the sync path on a single GPU as well (all-reduce over one rank)
+    # ASLP_BENCH_FORCE_SYNC=1 exercises the sync path on a single GPU as well (RCCL all-reduce over a group of one)
     force_sync = os.environ.get("ASLP_BENCH_FORCE_SYNC") == "1"
     # The communicator comes up BEFORE the model is allocated and the first kernel runs: initialising RCCL afterwards
     # leaves every later step ~1 ms slower on this stack (measured, devtools/dbg_sync2.py: 1.44 vs 2.39 ms/step).
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
-    elif force_sync:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    # It is the product's own RcclComm (kaldi-aslp_amd/parallel/comm.cpp through libaslp_parallel.so), not torch.distributed.
+    comm = None
+    if world > 1 or force_sync:
+        import aslp_import
+        from kaldi_aslp_amd import native_parallel
+        comm_file = os.environ.get("ASLP_COMM_FILE")
+        token = os.environ.get("ASLP_COMM_TOKEN")
+        if world > 1 and not comm_file:
+            # started by torch.distributed.run (the driver's N > 1 command): every rank sees the same MASTER_PORT and the
+            # same parent (the elastic agent), which together name this launch
+            import tempfile
+            token = "%s-%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid())
+            comm_file = os.path.join(tempfile.gettempdir(), "aslp_bench_comm_" + token)
+        comm = native_parallel.RcclComm(comm_file, rank=rank, num_nodes=world, token=token, timeout_s=300)
 
     import aslp_import
     aslp = aslp_import.load()   # raises if libaslp_hip.so is missing (no fallback)
     aslp.ops.use_torch_stream()
-    from kaldi_aslp_amd.parallel import BspWorker
-
     net = aslp.Nnet.Init(proto(), seed=777)            # same init on every rank (like one aslp-nnet-init model)
     net.SetTrainOptions(learn_rate=1e-5, momentum=0.0)  # small lr: synthetic labels, keep the run finite
     if args.no_update_overlap:
@@ -148,7 +207,10 @@ def main():
     g.manual_seed(1234 + rank)                          # every rank its own shard
     x = torch.randn(MB, IN_DIM, device=dev, generator=g)
     labels = torch.randint(0, OUT_DIM, (MB,), device=dev, generator=g, dtype=torch.int32)
-    worker = BspWorker(net) if (world > 1 or force_sync) else None
+    worker = None
+    if comm is not None:                                # bsp-worker.cc:33-65 as reimplemented (parallel/workers.cpp), RCCL all-reduce
+        worker = native_parallel.BspWorker(comm)
+        worker.InitParam(net)
 
     frames_since_sync = 0
 
@@ -167,21 +229,19 @@ def main():
         # loaded before the clock starts (a first sync inside K = 50 steps costs more than the 50 steps)
         worker.Synchronize(max(frames_since_sync, 1))
         frames_since_sync = 0
-    if world > 1:
-        dist.barrier()
+    if comm is not None:
+        comm.Barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    if comm is not None:
+        comm.Barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    if comm is not None:
+        elapsed = comm.MaxOverRanks(elapsed)
 
     # Per-kernel durations for the roofline: HIP events around every GEMM launch on the launch stream, over the SAME
     # K steps run once more -- two event records per GEMM inside the timed region cost ~7 % of `value` (measured),
@@ -219,7 +279,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "cfg2: 5x2048 sigmoid DNN + BatchNorm, 440 in (40 fbank x 11 splice), 3000 pdfs, minibatch 1024/GPU, "
                                    "Propagate + Xent + Backpropagate + SGD update",
-                       "global_batch": world * MB, "parallelism": "bsp-dp%d" % world, "sync_period_frames": args.sync_period,
+                       "global_batch": world * MB, "parallelism": "bsp-dp%d" % world,
+                       "sync": "native BspWorker on RcclComm (libaslp_parallel.so: ncclAllReduce over the parameter tensors in HBM)" if comm is not None else None, "sync_period_frames": args.sync_period,
                        "learn_rate": 1e-5, "avg_xent_per_frame": (st["loss"] - st["entropy"]) / max(st["frames"], 1.0)},
         }
         timed = {k: v for k, v in gemm.items() if v["tflops"]}
@@ -231,10 +292,15 @@ def main():
                 with open(os.path.join(ROOT, "profiles", "dnn_cfg2_pmc.json")) as f:
                     pmc = json.load(f)[dom]
                 traffic = (2.0 * pmc["fetch_kb"] + pmc["write_kb"]) * 1024.0
-                traffic_src = "profiles/dnn_cfg2_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction)"
+                traffic_src = "NOT measured in this run: committed PMC pass profiles/dnn_cfg2_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction)"
             except (OSError, KeyError, ValueError):
                 pass
-            out["roofline"] = {"bound": "mfma", "kernel": "aslp_sgemm<%s> (gemm_f32_glds 64x128x32, LDS-DMA)" % dom, "achieved": d["tflops"], "peak": F32_MFMA_PEAK_TFLOPS,
+            tile_buf = C.create_string_buffer(128)
+            tile_cfg = aslp.lib.aslp_gemm_profile_tile(("NT", "NN", "TN", "TT").index(dom), tile_buf, 128)
+            tile_name = tile_buf.value.decode()
+            if traffic is not None and pmc.get("cfg") not in (None, tile_cfg):
+                traffic, traffic_src = None, "committed PMC pass was taken with tile cfg %s, this run used %d: omitted" % (pmc.get("cfg"), tile_cfg)
+            out["roofline"] = {"bound": "mfma", "kernel": "aslp_sgemm<%s> (%s; cfg %d)" % (dom, tile_name, tile_cfg), "achieved": d["tflops"], "peak": F32_MFMA_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": d["tflops"] / F32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
                                "traffic_source": traffic_src,
                                "flop_per_launch": d["flop_per_launch"], "avg_launch_us": d["avg_us"], "launches": d["launches"],
@@ -252,8 +318,11 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
-    if world > 1 or dist.is_initialized():
-        dist.destroy_process_group()
+    if comm is not None:
+        comm.Barrier()
+        if worker is not None:
+            worker.close()
+        comm.close()
 
 
 if __name__ == "__main__":

@@ -156,6 +156,9 @@ void aslp_gemm_profile_reset(void);
 void aslp_gemm_force_tile(int cfg);
 /* variant: 0 = NT, 1 = NN, 2 = TN, 3 = TT.  Returns number of launches. */
 long aslp_gemm_profile_get(int variant, double *flops, double *ms);
+/* the tile configuration that carried most of that variant's flops since the last reset: returns its number, writes a
+ * description ("gemm_f32_glds 64x128x32, 8 waves, LDS-DMA, 3 stages") into buf */
+int aslp_gemm_profile_tile(int variant, char *buf, int buflen);
 
 /* ---- fused hot-path ops (one pass each; see DESIGN.md for bytes/unit) ----------------- */
 /* BatchNormalization training forward (nnet-batch-normalization.h:177-220): writes out,

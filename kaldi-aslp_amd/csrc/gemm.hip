@@ -20,6 +20,8 @@
 //     of tile t and written to the other buffer after them -- one barrier per K tile.
 // The K order inside a tile is a permutation of 0..BK-1; fp32 sums are therefore not
 // bitwise those of a k-ascending loop (parity is tolerance-based for GEMM rows).
+#include <cstring>
+#include <map>
 #include <mutex>
 #include <type_traits>
 #include <vector>
@@ -551,8 +553,10 @@ struct GemmProf {
   long launches = 0;
   double flops = 0.0, ms = 0.0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  std::map<int, double> cfg_flops;  // tile configuration actually launched -> flops it carried
 };
 GemmProf g_prof[4];
+thread_local int t_last_cfg = 0;    // what launch_variant chose for the calling thread's latest product
 bool g_prof_on = false;
 std::mutex g_prof_mu;
 std::vector<hipEvent_t> g_event_pool;  // recycled: no event creation / destruction inside a timed region
@@ -618,9 +622,15 @@ void launch_variant(GemmArgs &g) {
   // the 8-wave tile inside the training step (devtools/sweep_tiles.sh: 70.0 vs 72.5 us average over the NT launches)
   else if (big_grid && !(A_KC && B_KC)) cfg = 212;
   else cfg = 207;
+  t_last_cfg = cfg;
   if (cfg >= 200) {
     if (gemm_glds_launch(g, A_KC, B_KC, cfg)) { if (!A_KC) g.ep.colsum = nullptr; return; }  // column sums done in-kernel
+    if (cfg != 205 && cfg != 206 && cfg != 207 && cfg != 208 && cfg != 211 && cfg != 212 && cfg != 213) {
+      set_error("aslp_sgemm: unknown tile configuration " + std::to_string(cfg) + " (ASLP_GEMM_TILE_* / aslp_gemm_force_tile)");
+      return;
+    }
     cfg = g.M <= 32 ? 1 : (cfg == 207 ? 7 : 12);  // not eligible: register-staged kernel of the same tile
+    t_last_cfg = cfg;
   }
   switch (cfg) {
     case 1: launch_cfg<32, 128, 16, 1, 4, A_KC, B_KC, VEC>(g); break;
@@ -634,6 +644,8 @@ void launch_variant(GemmArgs &g) {
     case 10: launch_cfg<128, 64, 32, 4, 2, A_KC, B_KC, VEC>(g); break;   // 8 waves
     case 11: launch_cfg<128, 128, 32, 2, 4, A_KC, B_KC, VEC>(g); break;  // 8 waves
     case 12: launch_cfg<64, 128, 32, 2, 4, A_KC, B_KC, VEC>(g); break;   // 8 waves
+#ifdef ASLP_GEMM_EXPERIMENTS  // devtools builds only (make EXPERIMENTS=1): loop-style variants and the ablation kernels, which
+                              // knowingly return wrong results -- never compiled into the product library
     case 107: launch_cfg<64, 64, 32, 2, 2, A_KC, B_KC, VEC, 1>(g); break;   // loop style 1 variants
     case 112: launch_cfg<64, 128, 32, 2, 4, A_KC, B_KC, VEC, 1>(g); break;
     case 101: launch_cfg<32, 128, 16, 1, 4, A_KC, B_KC, VEC, 1>(g); break;
@@ -655,7 +667,9 @@ void launch_variant(GemmArgs &g) {
     case 121: launch_cfg<64, 128, 64, 2, 2, A_KC, B_KC, VEC, 1>(g); break;
     case 122: launch_cfg<64, 128, 64, 2, 4, A_KC, B_KC, VEC, 0>(g); break;
     case 117: launch_cfg<128, 64, 32, 2, 2, A_KC, B_KC, VEC, 1>(g); break;
-    default: launch_cfg<128, 128, 16, 2, 2, A_KC, B_KC, VEC>(g); break;
+#endif
+    case 13: launch_cfg<128, 128, 16, 2, 2, A_KC, B_KC, VEC>(g); break;
+    default: set_error("aslp_sgemm: unknown tile configuration " + std::to_string(cfg) + " (ASLP_GEMM_TILE_* / aslp_gemm_force_tile)"); break;
   }
 }
 
@@ -714,6 +728,7 @@ int aslp_sgemm_ex(int transA, int transB, int M, int N, int K, float alpha, cons
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof[slot].launches++;
     g_prof[slot].flops += 2.0 * (double)M * (double)N * (double)K;
+    g_prof[slot].cfg_flops[t_last_cfg] += 2.0 * (double)M * (double)N * (double)K;
     if (prof) {
       (void)hipEventRecord(e1, cur_stream());
       g_prof[slot].pending.emplace_back(e0, e1);
@@ -745,6 +760,7 @@ void aslp_gemm_profile_reset(void) {
     p.launches = 0;
     p.flops = 0.0;
     p.ms = 0.0;
+    p.cfg_flops.clear();
   }
 }
 long aslp_gemm_profile_get(int variant, double *flops, double *ms) {
@@ -754,6 +770,30 @@ long aslp_gemm_profile_get(int variant, double *flops, double *ms) {
   if (flops) *flops = g_prof[variant].flops;
   if (ms) *ms = g_prof[variant].ms;
   return g_prof[variant].launches;
+}
+int aslp_gemm_profile_tile(int variant, char *buf, int buflen) {
+  if (variant < 0 || variant > 3) return 0;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  int best = 0;
+  double fl = -1.0;
+  for (auto &kv : g_prof[variant].cfg_flops)
+    if (kv.second > fl) { fl = kv.second; best = kv.first; }
+  const char *d = "";
+  switch (best) {  // the tables of launch_variant (register-staged) and gemm_glds_launch (LDS-DMA)
+    case 1: d = "gemm_f32_mfma 32x128x16, 4 waves, register-staged"; break;
+    case 7: d = "gemm_f32_mfma 64x64x32, 4 waves, register-staged"; break;
+    case 12: d = "gemm_f32_mfma 64x128x32, 8 waves, register-staged"; break;
+    case 205: d = "gemm_f32_glds 32x128x32, 4 waves, LDS-DMA, 4 stages"; break;
+    case 206: d = "gemm_f32_glds 32x64x32, 2 waves, LDS-DMA, 4 stages"; break;
+    case 207: d = "gemm_f32_glds 64x64x32, 4 waves, LDS-DMA, 4 stages"; break;
+    case 208: d = "gemm_f32_glds 64x128x32, 4 waves, LDS-DMA, 3 stages"; break;
+    case 211: d = "gemm_f32_glds 128x128x32, 8 waves, LDS-DMA, 3 stages"; break;
+    case 212: d = "gemm_f32_glds 64x128x32, 8 waves, LDS-DMA, 3 stages"; break;
+    case 213: d = "gemm_f32_glds 64x128x32, 8 waves, LDS-DMA, 4 stages"; break;
+    default: d = "gemm_f32_mfma (devtools tile)"; break;
+  }
+  if (buf && buflen > 0) { std::strncpy(buf, d, buflen - 1); buf[buflen - 1] = 0; }
+  return best;
 }
 
 }  // extern "C"

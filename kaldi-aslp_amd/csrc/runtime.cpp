@@ -3,6 +3,8 @@
 #include <mutex>
 #include <string>
 #include <cstring>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include "aslp_kernels.h"
 #include "common.h"
@@ -26,21 +28,34 @@ bool has_error() {
   return !g_err.empty();
 }
 
-// One grow-only scratch arena per (stream bank, slot).  Kernels on one stream run in order, so a slot can
-// be reused by the next op on the same stream without synchronisation (the reference's
-// caching allocator exists for the same reason: cu-allocator.h:67-70).
+// One grow-only scratch arena per (host thread, stream bank, slot).  Kernels on one stream run in order, so a slot can
+// be reused by the next op on the same stream without synchronisation (the reference's caching allocator exists for
+// the same reason: cu-allocator.h:67-70).  The arenas are thread_local like the stream they serve: two host threads
+// (ThreadComm ranks, a multi-threaded API user) launch on different streams and must never hand the same partial-sum
+// buffer to their column reductions / split-K GEMMs / CTC lattices.
 static thread_local int t_bank = 0;  // 0 = main stream, 1 = side stream
-static void *g_scratch[2][kNumScratch] = {{nullptr}};
-static size_t g_scratch_bytes[2][kNumScratch] = {{0}};
-static std::mutex g_scratch_mu;
+namespace {
+struct ScratchArenas {
+  void *blk[2][kNumScratch] = {{nullptr}};
+  size_t cap[2][kNumScratch] = {{0}};
+  ~ScratchArenas() {
+    // worker threads give their blocks back; the process' main thread (tid == pid) leaves them to process teardown,
+    // which may already have unloaded the HIP runtime when thread_local destructors run
+    if ((long)syscall(SYS_gettid) == (long)getpid()) return;
+    for (auto &bank : blk)
+      for (void *&p : bank)
+        if (p) { (void)hipFree(p); p = nullptr; }
+  }
+};
+}  // namespace
+static thread_local ScratchArenas t_arenas;
 
 void *scratch(int slot, size_t bytes) {
-  std::lock_guard<std::mutex> lk(g_scratch_mu);
-  void *&blk = g_scratch[t_bank][slot];
-  size_t &cap = g_scratch_bytes[t_bank][slot];
+  void *&blk = t_arenas.blk[t_bank][slot];
+  size_t &cap = t_arenas.cap[t_bank][slot];
   if (bytes > cap) {
     if (blk) {
-      // outstanding kernels may still use the old block
+      // outstanding kernels of this thread's stream may still use the old block
       (void)hipStreamSynchronize(cur_stream());
       (void)hipFree(blk);
     }

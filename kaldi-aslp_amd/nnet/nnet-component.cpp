@@ -5,14 +5,8 @@
 #include <algorithm>
 
 #include "nnet-basic.h"
-#if __has_include("nnet-recurrent.h")
 #include "nnet-recurrent.h"
-#define ASLP_HAVE_RECURRENT 1
-#endif
-#if __has_include("nnet-temporal.h")
 #include "nnet-temporal.h"
-#define ASLP_HAVE_TEMPORAL 1
-#endif
 
 namespace aslp {
 
@@ -88,7 +82,6 @@ Component *Component::NewComponentOfType(ComponentType comp_type, int32 input_di
     case kInputLayer: ans = new InputLayer(input_dim, output_dim); break;
     case kOutputLayer: ans = new OutputLayer(input_dim, output_dim); break;
     case kScaleLayer: ans = new ScaleLayer(input_dim, output_dim); break;
-#ifdef ASLP_HAVE_RECURRENT
     case kBLstmProjectedStreamsLC: ans = new BLstmProjectedStreamsLC(input_dim, output_dim); break;
     case kLstmProjectedStreams: ans = new LstmProjectedStreams(input_dim, output_dim); break;
     case kBLstmProjectedStreams: ans = new BLstmProjectedStreams(input_dim, output_dim); break;
@@ -96,11 +89,8 @@ Component *Component::NewComponentOfType(ComponentType comp_type, int32 input_di
     case kLstm: ans = new Lstm(input_dim, output_dim); break;
     case kBLstm: ans = new BLstm(input_dim, output_dim); break;
     case kGruStreams: ans = new GruStreams(input_dim, output_dim); break;
-#endif
-#ifdef ASLP_HAVE_TEMPORAL
     case kRowConvolution: ans = new RowConvolution(input_dim, output_dim); break;
     case kCompactFsmn: ans = new CompactFsmn(input_dim, output_dim); break;
-#endif
     case kUnknown:
     default:
       // Out of the hot-path scope: LinearTransform, Convolutional, MaxPooling,

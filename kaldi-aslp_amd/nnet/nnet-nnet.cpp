@@ -7,14 +7,8 @@
 #include "nnet-basic.h"
 #include "scratch.h"
 #include "kaldi-io.h"
-#if __has_include("nnet-recurrent.h")
 #include "nnet-recurrent.h"
-#define ASLP_HAVE_RECURRENT 1
-#endif
-#if __has_include("nnet-temporal.h")
 #include "nnet-temporal.h"
-#define ASLP_HAVE_TEMPORAL 1
-#endif
 
 namespace aslp {
 
@@ -390,33 +384,21 @@ int32 Nnet::NumParams() const {
 }
 
 void Nnet::ResetLstmStreams(const std::vector<int32> &flags) {  // :473-496
-#ifdef ASLP_HAVE_RECURRENT
   for (int32 c = 0; c < NumComponents(); c++) {
     RecurrentBase *r = dynamic_cast<RecurrentBase *>(components_[c]);
     if (r && r->HasStreamReset()) r->ResetLstmStreams(flags);
   }
-#else
-  (void)flags;
-#endif
 }
 void Nnet::SetSeqLengths(const std::vector<int32> &lens) {  // :498-530
   for (int32 c = 0; c < NumComponents(); c++) {
-#ifdef ASLP_HAVE_RECURRENT
     if (RecurrentBase *r = dynamic_cast<RecurrentBase *>(components_[c])) { if (r->HasSeqLengths()) r->SetSeqLengths(lens); continue; }
-#endif
-#ifdef ASLP_HAVE_TEMPORAL
     if (RowConvolution *rc = dynamic_cast<RowConvolution *>(components_[c])) rc->SetSeqLengths(lens);
-#endif
   }
   (void)lens;
 }
 void Nnet::SetChunkSize(int chunk_size) {  // :532-539
-#ifdef ASLP_HAVE_RECURRENT
   for (int32 c = 0; c < NumComponents(); c++)
     if (BLstmProjectedStreamsLC *l = dynamic_cast<BLstmProjectedStreamsLC *>(components_[c])) l->SetChunkSize(chunk_size);
-#else
-  (void)chunk_size;
-#endif
 }
 
 void Nnet::AutoComplete() {  // :541-568

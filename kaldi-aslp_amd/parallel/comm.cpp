@@ -8,6 +8,9 @@
 #include <unistd.h>
 
 #include <chrono>
+#include <condition_variable>
+#include <ctime>
+#include <mutex>
 #include <cstdio>
 #include <cerrno>
 #include <cstdlib>
@@ -40,37 +43,95 @@ void RankFromEnvironment(int *rank, int *num_nodes) {
 namespace {
 class RcclComm : public Comm {
  public:
-  RcclComm(int rank, int n, const std::string &id_file, int timeout_s)
-      : rank_(rank), n_(n), comm_(nullptr), scratch_(nullptr), scratch_bytes_(0), ctl_fd_(-1) {
+  // The rendezvous file is bound to ONE launch: {magic, world size, token, ncclUniqueId}.  The token comes from the caller,
+  // else ASLP_COMM_TOKEN, else the launcher's job id (TORCHELASTIC_RUN_ID, SLURM_JOB_ID, PMI_ID): every rank of a launch
+  // sees the same value, a file left behind by a run that died between writing and removing it carries another one (or
+  // is older than ASLP_COMM_MAX_AGE_S, default 600 s, when there is no token at all) and is ignored.  Rank 0 removes whatever
+  // is there before it writes; ncclCommInitRank itself runs under the same timeout, so a rank that did pick up a wrong
+  // id fails with a message instead of blocking for ever.
+  struct IdRecord {
+    char magic[8];
+    int32 world, reserved;
+    char token[64];
     ncclUniqueId id;
+  };
+  static std::string LaunchToken(const std::string &given) {
+    if (!given.empty()) return given;
+    for (const char *k : {"ASLP_COMM_TOKEN", "TORCHELASTIC_RUN_ID", "SLURM_JOB_ID", "PMI_ID"})
+      if (getenv(k) && getenv(k)[0]) return getenv(k);
+    return std::string();
+  }
+  RcclComm(int rank, int n, const std::string &id_file, int timeout_s, const std::string &token_arg)
+      : rank_(rank), n_(n), comm_(nullptr), scratch_(nullptr), scratch_bytes_(0), ctl_fd_(-1) {
+    IdRecord rec;
+    std::memset(&rec, 0, sizeof(rec));
+    const std::string token = LaunchToken(token_arg);
+    if (token.size() >= sizeof(rec.token)) ASLP_ERR << "RcclComm: launch token longer than " << sizeof(rec.token) - 1 << " characters";
     if (n > 1 && id_file.empty()) ASLP_ERR << "RcclComm: more than one rank needs a rendezvous file (--comm-file)";
     ctl_path_ = id_file.empty() ? std::string() : id_file + ".ctl";
+    const double max_age = getenv("ASLP_COMM_MAX_AGE_S") ? atof(getenv("ASLP_COMM_MAX_AGE_S")) : 600.0;
+    const time_t started = time(nullptr);
     if (rank == 0) {
-      Nccl(ncclGetUniqueId(&id), "ncclGetUniqueId");
+      Nccl(ncclGetUniqueId(&rec.id), "ncclGetUniqueId");
       if (n > 1) {
+        (void)unlink(id_file.c_str());  // a leftover of a run that died: nobody may join it
         // the control pipe exists before the id does, so whoever found the id can open it; O_RDWR: never sees end-of-file
         // (only the served protocols need it: on a filesystem without FIFOs the collective workers still run)
         (void)unlink(ctl_path_.c_str());
         if (mkfifo(ctl_path_.c_str(), 0600) == 0) ctl_fd_ = open(ctl_path_.c_str(), O_RDWR);
         if (ctl_fd_ < 0) ASLP_WARN << "no control pipe at " << ctl_path_ << " (" << strerror(errno) << "): easgd / asgd / masgd are unavailable in this group";
+        std::memcpy(rec.magic, "ASLPRCCL", 8);
+        rec.world = n;
+        std::strncpy(rec.token, token.c_str(), sizeof(rec.token) - 1);
         const std::string tmp = id_file + ".tmp." + std::to_string((long)getpid());
-        { std::ofstream f(tmp, std::ios::binary); f.write(reinterpret_cast<const char *>(&id), sizeof(id)); if (!f.good()) ASLP_ERR << "cannot write " << tmp; }
+        { std::ofstream f(tmp, std::ios::binary); f.write(reinterpret_cast<const char *>(&rec), sizeof(rec)); if (!f.good()) ASLP_ERR << "cannot write " << tmp; }
         if (std::rename(tmp.c_str(), id_file.c_str()) != 0) ASLP_ERR << "cannot create " << id_file;
       }
     } else {
       const auto t0 = std::chrono::steady_clock::now();
+      std::string why = "no file yet";
       while (true) {
+        struct stat st;
         std::ifstream f(id_file, std::ios::binary);
-        if (f.good()) { f.read(reinterpret_cast<char *>(&id), sizeof(id)); if (f.gcount() == (std::streamsize)sizeof(id)) break; }
+        if (f.good() && stat(id_file.c_str(), &st) == 0) {
+          f.read(reinterpret_cast<char *>(&rec), sizeof(rec));
+          rec.token[sizeof(rec.token) - 1] = 0;
+          if (f.gcount() != (std::streamsize)sizeof(rec) || std::memcmp(rec.magic, "ASLPRCCL", 8) != 0) why = "not a rendezvous record";
+          else if (rec.world != n) why = "written for a group of " + std::to_string(rec.world);
+          else if (token != rec.token) why = "belongs to another launch (token '" + std::string(rec.token) + "')";
+          else if (difftime(started, st.st_mtime) > max_age) why = "older than " + std::to_string((int)max_age) + " s (a leftover; see ASLP_COMM_MAX_AGE_S)";
+          else break;
+        }
         if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
-          ASLP_ERR << "RcclComm: rank " << rank << " timed out waiting for " << id_file;
+          ASLP_ERR << "RcclComm: rank " << rank << " timed out waiting for " << id_file << " (" << why << ")";
         std::this_thread::sleep_for(std::chrono::milliseconds(50));
       }
     }
     if (rank != 0 && n > 1) ctl_fd_ = open(ctl_path_.c_str(), O_WRONLY | O_NONBLOCK);  // rank 0 holds the read end already; -1: see PostToServer
-    Nccl(ncclCommInitRank(&comm_, n, id, rank), "ncclCommInitRank");
+    InitWithTimeout(rec.id, timeout_s);
     Barrier();
     if (rank == 0 && n > 1) std::remove(id_file.c_str());  // everybody has joined: the next run writes a fresh id
+  }
+  void InitWithTimeout(const ncclUniqueId &id, int timeout_s) {
+    int device = 0;
+    Hip(hipGetDevice(&device), "hipGetDevice");
+    struct Shared { std::mutex mu; std::condition_variable cv; bool done = false; ncclResult_t res = ncclSuccess; ncclComm_t comm = nullptr; };
+    auto sh = std::make_shared<Shared>();
+    const int rank = rank_, n = n_;
+    std::thread([sh, id, device, rank, n] {  // detached: if it never returns, the caller has long thrown
+      (void)hipSetDevice(device);
+      ncclComm_t c = nullptr;
+      const ncclResult_t r = ncclCommInitRank(&c, n, id, rank);
+      std::lock_guard<std::mutex> lk(sh->mu);
+      sh->res = r; sh->comm = c; sh->done = true;
+      sh->cv.notify_all();
+    }).detach();
+    std::unique_lock<std::mutex> lk(sh->mu);
+    if (!sh->cv.wait_for(lk, std::chrono::seconds(timeout_s > 0 ? timeout_s : 300), [&] { return sh->done; }))
+      ASLP_ERR << "RcclComm: rank " << rank_ << " of " << n_ << ": ncclCommInitRank did not return within " << timeout_s
+               << " s (another rank missing, or a rendezvous id of another run)";
+    Nccl(sh->res, "ncclCommInitRank");
+    comm_ = sh->comm;
   }
   ~RcclComm() {
     if (scratch_) (void)hipFree(scratch_);
@@ -106,13 +167,12 @@ class RcclComm : public Comm {
     AllReduceSumHost(&one, 1);
   }
   void AllReduceSum(float *dev, size_t n) {
-    if (n_ > 1 && n) Nccl(ncclAllReduce(dev, dev, n, ncclFloat, ncclSum, comm_, cur_stream()), "ncclAllReduce(float)");
+    if (n) Nccl(ncclAllReduce(dev, dev, n, ncclFloat, ncclSum, comm_, cur_stream()), "ncclAllReduce(float)");
   }
   void AllReduceSum(double *dev, size_t n) {
-    if (n_ > 1 && n) Nccl(ncclAllReduce(dev, dev, n, ncclDouble, ncclSum, comm_, cur_stream()), "ncclAllReduce(double)");
+    if (n) Nccl(ncclAllReduce(dev, dev, n, ncclDouble, ncclSum, comm_, cur_stream()), "ncclAllReduce(double)");
   }
   void AllReduceSumMany(const std::vector<std::pair<float *, int>> &bufs) {
-    if (n_ <= 1) return;
     Nccl(ncclGroupStart(), "ncclGroupStart");
     for (auto &b : bufs)
       if (b.second > 0) Nccl(ncclAllReduce(b.first, b.first, (size_t)b.second, ncclFloat, ncclSum, comm_, cur_stream()), "ncclAllReduce(float)");
@@ -135,7 +195,7 @@ class RcclComm : public Comm {
   }
   template <class T>
   void HostReduce(T *host, size_t n, ncclDataType_t type) {
-    if (n_ <= 1 || !n) return;
+    if (!n) return;
     const size_t bytes = sizeof(T) * n;
     if (bytes > scratch_bytes_) {
       if (scratch_) Hip(hipFree(scratch_), "hipFree");
@@ -156,7 +216,9 @@ class RcclComm : public Comm {
 };
 }  // namespace
 
-Comm *NewRcclComm(int rank, int num_nodes, const std::string &id_file, int timeout_s) { return new RcclComm(rank, num_nodes, id_file, timeout_s); }
+Comm *NewRcclComm(int rank, int num_nodes, const std::string &id_file, int timeout_s, const std::string &token) {
+  return new RcclComm(rank, num_nodes, id_file, timeout_s, token);
+}
 
 // ---- threads of one process ---------------------------------------------------------------------------------------
 class ThreadCommGroup {
