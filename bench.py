@@ -184,6 +184,7 @@ def main():
     comm = None
     if world > 1 or force_sync:
         import aslp_import
+        aslp_import.load()
         from kaldi_aslp_amd import native_parallel
         comm_file = os.environ.get("ASLP_COMM_FILE")
         token = os.environ.get("ASLP_COMM_TOKEN")

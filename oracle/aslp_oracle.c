@@ -295,6 +295,51 @@ void orc_regularize_l1(float *w, int ldw, float *g, int ldg, int rows, int cols,
 }
 
 /* ------------------------------------------------------------------------------- */
+/* element-wise / broadcast arithmetic (reference CPU branches, plain loops) */
+void orc_add_mat_mat_elements(float *dst, int ldd, const float *A, int lda, const float *B, int ldb, int rows, int cols,
+                              float alpha, float beta) {
+  /* kaldi-matrix.cc:483-501: data[j] = beta*data[j] + alpha*dataA[j]*dataB[j] */
+  for (int r = 0; r < rows; r++)
+    for (int c = 0; c < cols; c++)
+      dst[(size_t)r * ldd + c] = beta * dst[(size_t)r * ldd + c] + alpha * A[(size_t)r * lda + c] * B[(size_t)r * ldb + c];
+}
+void orc_add_mat_diag_vec(float *dst, int ldd, const float *M, int m_row_stride, int m_col_stride, const float *v, int rows,
+                          int cols, float alpha) {
+  /* kaldi-matrix.cc:448-480 with beta == 1: data[i][j] += alpha * v[j] * M[i][j] (strides swapped for kTrans) */
+  for (int i = 0; i < rows; i++)
+    for (int j = 0; j < cols; j++) dst[(size_t)i * ldd + j] += alpha * v[j] * M[(size_t)i * m_row_stride + (size_t)j * m_col_stride];
+}
+void orc_add_vec_to_rows(float *dst, int ldd, const float *row, int rows, int cols, float alpha) {
+  /* kaldi-matrix.cc:2754-2759 (the <= 64 column branch; wider matrices take the same sums through BLAS ger) */
+  for (int i = 0; i < rows; i++)
+    for (int j = 0; j < cols; j++) dst[(size_t)i * ldd + j] += alpha * row[j];
+}
+void orc_add_vec_to_cols(float *dst, int ldd, const float *col, int rows, int cols, float alpha) {
+  /* kaldi-matrix.cc:2786-2792: to_add = alpha * v[i] first, then added */
+  for (int i = 0; i < rows; i++) {
+    const float to_add = alpha * col[i];
+    for (int j = 0; j < cols; j++) dst[(size_t)i * ldd + j] += to_add;
+  }
+}
+void orc_mul_cols_vec(float *dst, int ldd, const float *scale, int rows, int cols) {
+  for (int i = 0; i < rows; i++)
+    for (int j = 0; j < cols; j++) dst[(size_t)i * ldd + j] *= scale[j];
+}
+void orc_mul_rows_vec(float *dst, int ldd, const float *scale, int rows, int cols) {
+  for (int i = 0; i < rows; i++)
+    for (int j = 0; j < cols; j++) dst[(size_t)i * ldd + j] *= scale[i];
+}
+void orc_copy_cols_idx(float *dst, int ldd, const float *src, int lds, int rows, const int32_t *idx, int n_idx) {
+  for (int r = 0; r < rows; r++)
+    for (int c = 0; c < n_idx; c++) dst[(size_t)r * ldd + c] = idx[c] < 0 ? 0.0f : src[(size_t)r * lds + idx[c]];
+}
+void orc_add_cols_idx(float *dst, int ldd, const float *src, int lds, int rows, const int32_t *idx, int n_idx) {
+  for (int r = 0; r < rows; r++)
+    for (int c = 0; c < n_idx; c++)
+      if (idx[c] >= 0) dst[(size_t)r * ldd + c] += src[(size_t)r * lds + idx[c]];
+}
+
+/* ------------------------------------------------------------------------------- */
 /* AffineTransform */
 void orc_affine_propagate(float *out, int ldo, const float *in, int ldi, int rows, const float *W,
                           int ldw, const float *bias, int in_dim, int out_dim) {

@@ -56,6 +56,17 @@ void orc_add_conv_mat_mat_elements(float *dst, int ldd, int cols, const float *A
                                    int a_rows, const float *B, int ldb, int b_rows,
                                    float alpha, float beta);                           /* cu-matrix.cc:3037-3073 (ASLP) */
 void orc_regularize_l1(float *w, int ldw, float *g, int ldg, int rows, int cols, float l1, float lr); /* cu-math.cc:37-75 */
+/* element-wise / broadcast arithmetic the components are composed from (all pinned by tests/golden/cumatrix_ops.bin) */
+void orc_add_mat_mat_elements(float *dst, int ldd, const float *A, int lda, const float *B, int ldb, int rows, int cols,
+                              float alpha, float beta);                                /* kaldi-matrix.cc:483-501 */
+void orc_add_mat_diag_vec(float *dst, int ldd, const float *M, int m_row_stride, int m_col_stride, const float *v,
+                          int rows, int cols, float alpha);                            /* kaldi-matrix.cc:448-480 (beta = 1) */
+void orc_add_vec_to_rows(float *dst, int ldd, const float *row, int rows, int cols, float alpha);  /* kaldi-matrix.cc:2749-2766 */
+void orc_add_vec_to_cols(float *dst, int ldd, const float *col, int rows, int cols, float alpha);  /* kaldi-matrix.cc:2780-2799 */
+void orc_mul_cols_vec(float *dst, int ldd, const float *scale, int rows, int cols);    /* kaldi-matrix.cc:1141-1150 */
+void orc_mul_rows_vec(float *dst, int ldd, const float *scale, int rows, int cols);    /* kaldi-matrix.cc:1057-1068 */
+void orc_copy_cols_idx(float *dst, int ldd, const float *src, int lds, int rows, const int32_t *idx, int n_idx);  /* kaldi-matrix.cc:2561-2584 */
+void orc_add_cols_idx(float *dst, int ldd, const float *src, int lds, int rows, const int32_t *idx, int n_idx);   /* kaldi-matrix.cc:2587-2610 */
 
 /* ---- components (aslp-nnet) ------------------------------------------------------- */
 

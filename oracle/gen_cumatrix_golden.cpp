@@ -126,6 +126,76 @@ int main(int argc, char **argv) {
     CuMatrix<float> orr(T, D);
     cu::Randomize(f, cmask, &orr); PutMat("randomize_out", orr);
   }
+  // ---- round 2: the BLAS-free arithmetic under FSMN, the LSTM peepholes, the affine L1 step and the bias / scale broadcasts.
+  // Appended AFTER the records above so those stay byte-identical (the generator stream just continues).
+  {  // AddConvMatMatElements (cu-matrix.cc:3037-3073 -> kaldi-matrix.cc:483-501): CompactFsmn's product; and its building block
+    const int a_rows = 19, b_rows = 7, W = 23;
+    CuMatrix<float> A, B, dst;
+    Fill(&A, a_rows, W, -2.0f, 2.0f); PutMat("conv_A", A);
+    Fill(&B, b_rows, W, -1.0f, 1.0f); PutMat("conv_B", B);
+    Fill(&dst, (a_rows - b_rows + 1) * b_rows, W, -1.0f, 1.0f); PutMat("conv_dst_in", dst);
+    dst.AddConvMatMatElements(0.7f, A, B, 0.3f); PutMat("conv_dst_out", dst);
+    CuMatrix<float> z((a_rows - b_rows + 1) * b_rows, W);
+    z.AddConvMatMatElements(1.0f, A, B, 0.0f); PutMat("conv_dst_beta0", z);
+    CuMatrix<float> e, f, g;
+    Fill(&e, R, C, -2.0f, 2.0f); PutMat("mme_A", e);
+    Fill(&f, R, C, -2.0f, 2.0f); PutMat("mme_B", f);
+    Fill(&g, R, C, -2.0f, 2.0f); PutMat("mme_dst_in", g);
+    g.AddMatMatElements(-1.25f, e, f, 0.5f); PutMat("mme_dst_out", g);
+  }
+  {  // AddMatDiagVec with beta = 1 (the peephole term: YGIFO += YC * diag(peephole), lc.h:585-590), both orientations of M
+    CuMatrix<float> m, m2, dst;
+    CuVector<float> v(C);
+    { Vector<float> hv(C); for (int i = 0; i < C; i++) hv(i) = -1.0f + 2.0f * Uniform(); v.CopyFromVec(hv);
+      CuMatrix<float> vm(1, C); vm.Row(0).CopyFromVec(v); PutMat("mdv_vec", vm); }
+    Fill(&m, R, C, -2.0f, 2.0f); PutMat("mdv_M", m);
+    Fill(&dst, R, C, -2.0f, 2.0f); PutMat("mdv_dst_in", dst);
+    dst.AddMatDiagVec(0.75f, m, kNoTrans, v, 1.0f); PutMat("mdv_dst_out", dst);
+    Fill(&m2, C, R, -2.0f, 2.0f); PutMat("mdv_Mt", m2);
+    Fill(&dst, R, C, -2.0f, 2.0f); PutMat("mdv_dst_in_t", dst);
+    dst.AddMatDiagVec(-0.5f, m2, kTrans, v, 1.0f); PutMat("mdv_dst_out_t", dst);
+  }
+  {  // bias / scale broadcasts on <= 64 rows / columns (beyond that the CPU branch goes through BLAS): AddVecToRows, AddVecToCols
+     // with beta = 1, MulColsVec, MulRowsVec
+    const int r2 = 41, c2 = 59;
+    CuMatrix<float> m;
+    CuVector<float> row(c2), col(r2);
+    { Vector<float> h(c2); for (int i = 0; i < c2; i++) h(i) = -3.0f + 6.0f * Uniform(); row.CopyFromVec(h);
+      CuMatrix<float> t2(1, c2); t2.Row(0).CopyFromVec(row); PutMat("bc_row", t2); }
+    { Vector<float> h(r2); for (int i = 0; i < r2; i++) h(i) = -3.0f + 6.0f * Uniform(); col.CopyFromVec(h);
+      CuMatrix<float> t2(1, r2); t2.Row(0).CopyFromVec(col); PutMat("bc_col", t2); }
+    Fill(&m, r2, c2, -2.0f, 2.0f); PutMat("bc_in", m);
+    CuMatrix<float> t2(m);
+    t2.AddVecToRows(0.5f, row, 1.0f); PutMat("add_vec_to_rows", t2);
+    t2.CopyFromMat(m); t2.AddVecToCols(-1.5f, col, 1.0f); PutMat("add_vec_to_cols", t2);
+    t2.CopyFromMat(m); t2.MulColsVec(row); PutMat("mul_cols_vec", t2);
+    t2.CopyFromMat(m); t2.MulRowsVec(col); PutMat("mul_rows_vec", t2);
+  }
+  {  // cu::RegularizeL1 (cu-math.cc:37-75): zero weights are skipped, a sign change clamps weight AND gradient to zero
+    CuMatrix<float> w, gr;
+    Fill(&w, R, C, -0.01f, 0.01f);
+    Fill(&gr, R, C, -1.0f, 1.0f);
+    Matrix<float> h(R, C); w.CopyToMat(&h);
+    for (int i = 0; i < C; i += 5) h(1, i) = 0.0f;        // exact zeros
+    for (int i = 0; i < C; i += 3) h(2, i) *= 1e-3f;      // near zero: the step overshoots
+    w.CopyFromMat(h);
+    PutMat("l1_w_in", w); PutMat("l1_g_in", gr);
+    cu::RegularizeL1(&w, &gr, 0.002f, 0.01f);
+    PutMat("l1_w_out", w); PutMat("l1_g_out", gr);
+  }
+  {  // CopyCols / AddCols (kaldi-matrix.cc:2561-2610): -1 = zero / skip
+    const int T = 29, D = 11;
+    CuMatrix<float> f;
+    Fill(&f, T, D, -3.0f, 3.0f); PutMat("cols_in", f);
+    std::vector<int32> idx = {10, -1, 3, 3, 0, 7, -1, 1, 5};
+    PutInts("cols_idx", idx);
+    CuArray<int32> cidx(idx);
+    CuMatrix<float> o;
+    Fill(&o, T, (int)idx.size(), -1.0f, 1.0f); PutMat("cols_dst_in", o);
+    CuMatrix<float> o2(o);
+    o2.CopyCols(f, cidx); PutMat("copy_cols_out", o2);
+    o.AddCols(f, cidx); PutMat("add_cols_out", o);
+  }
   std::fclose(g_out);
   return 0;
 }

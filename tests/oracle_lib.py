@@ -52,6 +52,14 @@ _sig("orc_randomize", None, f32p, _i, f32p, _i, _i, i32p, _i)
 _sig("orc_add_row_sum_mat", None, f32p, _i, _i, _i, f32p, _i, _i, _f, _f)
 _sig("orc_add_conv_mat_mat_elements", None, f32p, _i, _i, f32p, _i, _i, f32p, _i, _i, _f, _f)
 _sig("orc_regularize_l1", None, f32p, _i, f32p, _i, _i, _i, _f, _f)
+_sig("orc_add_mat_mat_elements", None, f32p, _i, f32p, _i, f32p, _i, _i, _i, _f, _f)
+_sig("orc_add_mat_diag_vec", None, f32p, _i, f32p, _i, _i, f32p, _i, _i, _f)
+_sig("orc_add_vec_to_rows", None, f32p, _i, f32p, _i, _i, _f)
+_sig("orc_add_vec_to_cols", None, f32p, _i, f32p, _i, _i, _f)
+_sig("orc_mul_cols_vec", None, f32p, _i, f32p, _i, _i)
+_sig("orc_mul_rows_vec", None, f32p, _i, f32p, _i, _i)
+_sig("orc_copy_cols_idx", None, f32p, _i, f32p, _i, _i, i32p, _i)
+_sig("orc_add_cols_idx", None, f32p, _i, f32p, _i, _i, i32p, _i)
 _sig("orc_affine_propagate", None, f32p, _i, f32p, _i, _i, f32p, _i, f32p, _i, _i)
 _sig("orc_affine_backpropagate", None, f32p, _i, f32p, _i, _i, f32p, _i, _i, _i)
 

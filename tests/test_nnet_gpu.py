@@ -81,6 +81,51 @@ def test_dnn_train_steps_match_oracle(aslp, oracle, dev, tmp_path, dims, bn, mom
     oracle.lib.orc_dnn_destroy(d)
 
 
+@pytest.mark.parametrize("reg", [dict(l2=1e-3), dict(l1=2e-4), dict(max_norm=0.9), dict(l2=5e-4, l1=1e-4, max_norm=1.1),
+                                 dict(l1=2e-4, lr_coef=0.5, bias_lr_coef=2.0), dict(max_norm=0.9, momentum=0.0)])
+@pytest.mark.parametrize("dims", [(40, 24, 32), (130, 257, 128)])
+def test_affine_update_regularisers_match_oracle(aslp, oracle, dev, tmp_path, dims, reg):
+    """AffineTransform::Update beyond the plain SGD step (nnet-affine-transform.h:200-245): l2 weight decay scaled by the
+    frame count (:214-216), cu::RegularizeL1 on the weights AND the momentum buffer (:218-220, cu-math.cc:37-75), the
+    <MaxNorm> row shrink (:231-243), and the two learn-rate coefficients -- three steps with momentum so the L1 clamp of
+    the gradient buffer carries over."""
+    in_dim, out_dim, mb = dims
+    l2, l1, max_norm = reg.get("l2", 0.0), reg.get("l1", 0.0), reg.get("max_norm", 0.0)
+    lr_coef, bias_lr_coef, mmt, lr = reg.get("lr_coef", 1.0), reg.get("bias_lr_coef", 1.0), reg.get("momentum", 0.9), 0.01
+    rng = np.random.default_rng(11)
+    W = (rng.standard_normal((out_dim, in_dim)) * 0.1).astype(np.float32)
+    W[rng.random(W.shape) < 0.2] *= 1e-3          # weights near zero: the L1 step must clamp them to exactly 0
+    b = rng.standard_normal(out_dim).astype(np.float32)
+    path = tmp_path / "aff.nnet"
+    nnet_io.write_simple_nnet(path, [("<AffineTransform>", in_dim, out_dim, nnet_io.affine(W, b, lr_coef, bias_lr_coef, max_norm))])
+    net = aslp.Nnet.Read(path)
+    net.SetTrainOptions(learn_rate=lr, momentum=mmt, l2_penalty=l2, l1_penalty=l1)
+    Wc, bc = np.zeros_like(W), np.zeros_like(b)
+    o = oracle.AffineOpts(lr, mmt, l2, l1, lr_coef, bias_lr_coef, max_norm)
+    import ctypes as C
+    for step in range(3):
+        x = rng.standard_normal((mb, in_dim)).astype(np.float32)
+        od = (rng.standard_normal((mb, out_dim)) * 0.05).astype(np.float32)
+        out_ref = np.empty((mb, out_dim), np.float32)
+        oracle.lib.orc_affine_propagate(out_ref, out_dim, x, in_dim, mb, W, in_dim, b, in_dim, out_dim)
+        idf_ref = np.empty((mb, in_dim), np.float32)
+        oracle.lib.orc_affine_backpropagate(idf_ref, in_dim, od, out_dim, mb, W, in_dim, in_dim, out_dim)
+        oracle.lib.orc_affine_update(W, in_dim, b, Wc, in_dim, bc, x, in_dim, od, out_dim, mb, in_dim, out_dim, C.byref(o))
+        out = net.Propagate(torch.from_numpy(x).to(dev)).cpu().numpy()
+        assert oracle.rel_err(out, out_ref) < TOL, ("out", step)
+        idf = net.Backpropagate(torch.from_numpy(od).to(dev), want_in_diff=True).cpu().numpy()
+        assert oracle.rel_err(idf, idf_ref) < TOL, ("in_diff", step)
+        got = net.GetParams()
+        assert oracle.rel_err(got, np.concatenate([W.ravel(), b])) < TOL, ("params", step)
+        if l1:   # the exact zeros land on the same elements (an element whose sign test sits within rounding of 0 may go either way)
+            mism = (got[:W.size] == 0) != (W.ravel() == 0)
+            assert mism.sum() <= 3 and np.abs(got[:W.size][mism]).max(initial=0) < 1e-7 and np.abs(W.ravel()[mism]).max(initial=0) < 1e-7, step
+    if l1:
+        assert (W == 0).sum() > 0
+    if max_norm:
+        assert np.sqrt((got[:W.size].reshape(W.shape) ** 2).sum(1)).max() <= max_norm * (1 + 1e-5)
+
+
 def test_link_aliasing_is_value_neutral(aslp, oracle, dev, tmp_path):
     """The engine's in-place links must give bit-identical results to the reference's zero+AddMat copies."""
     d, path = make_dnn(oracle, tmp_path, 24, 32, 2, 10, 1, 16, seed=9)

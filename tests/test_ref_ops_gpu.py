@@ -62,3 +62,51 @@ def test_kernels_match_reference_cumatrix_cpu(aslp, dev):
     mask = t(g["rand_mask"], torch.int32)
     orr = torch.empty_like(f)
     ops.randomize(orr, f, mask); assert np.array_equal(orr.cpu().numpy(), g["randomize_out"])
+
+
+def test_composite_kernels_match_reference_cumatrix_cpu(aslp, dev):
+    """Round 2 pins (same records as tests/test_oracle_ref_ops_cpu.py): the HIP kernels behind CompactFsmn's product
+    (cudaF_add_conv_mat_mat_elements), cudaF_add_mat_mat_elements, the peephole term (cudaF_add_mat_diag_vec, both
+    orientations), the broadcasts (cudaF_add_vec_to_rows / _cols, cudaF_mul_cols_vec / _rows_vec), cudaF_regularize_l1 and
+    cudaF_copy_cols / cudaF_add_cols against what the reference's own CuMatrix CPU branch produced."""
+    g = cumatrix_golden.load()
+    from kaldi_aslp_amd._lib import D3, check_error
+    ops, lib = aslp.ops, aslp.lib
+    t = lambda a, dt=torch.float32: torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(dt)
+    A, B = t(g["conv_A"]), t(g["conv_B"])
+    d = t(g["conv_dst_in"])
+    lib.cudaF_add_conv_mat_mat_elements(D3, D3, ops.ptr(d), ops.ptr(A), ops.ptr(B), ops.dim(d), ops.dim(A).stride, ops.dim(B).stride, 0.7, 0.3)
+    check_error(); assert close(d.cpu().numpy(), g["conv_dst_out"])
+    d = torch.zeros_like(d)
+    lib.cudaF_add_conv_mat_mat_elements(D3, D3, ops.ptr(d), ops.ptr(A), ops.ptr(B), ops.dim(d), ops.dim(A).stride, ops.dim(B).stride, 1.0, 0.0)
+    check_error(); assert close(d.cpu().numpy(), g["conv_dst_beta0"])
+    d, a, b = t(g["mme_dst_in"]), t(g["mme_A"]), t(g["mme_B"])
+    lib.cudaF_add_mat_mat_elements(D3, D3, ops.ptr(d), ops.ptr(a), ops.ptr(b), ops.dim(d), ops.dim(a).stride, ops.dim(b).stride, -1.25, 0.5)
+    check_error(); assert close(d.cpu().numpy(), g["mme_dst_out"])
+    v = t(g["mdv_vec"][0])
+    d, m = t(g["mdv_dst_in"]), t(g["mdv_M"])
+    lib.cudaF_add_mat_diag_vec(D3, D3, 0.75, ops.ptr(d), ops.dim(d), ops.ptr(m), ops.dim(m).stride, 1, ops.ptr(v), 1.0)
+    check_error(); assert close(d.cpu().numpy(), g["mdv_dst_out"])
+    d, m = t(g["mdv_dst_in_t"]), t(g["mdv_Mt"])
+    lib.cudaF_add_mat_diag_vec(D3, D3, -0.5, ops.ptr(d), ops.dim(d), ops.ptr(m), 1, ops.dim(m).stride, ops.ptr(v), 1.0)   # kTrans (cu-matrix.cc:1166-1168)
+    check_error(); assert close(d.cpu().numpy(), g["mdv_dst_out_t"])
+    row, col = t(g["bc_row"][0]), t(g["bc_col"][0])
+    d = t(g["bc_in"]); lib.cudaF_add_vec_to_rows(D3, D3, 0.5, ops.ptr(row), 1.0, ops.ptr(d), ops.dim(d)); check_error()
+    assert close(d.cpu().numpy(), g["add_vec_to_rows"])
+    d = t(g["bc_in"]); lib.cudaF_add_vec_to_cols(D3, D3, -1.5, ops.ptr(col), 1.0, ops.ptr(d), ops.dim(d)); check_error()
+    assert close(d.cpu().numpy(), g["add_vec_to_cols"])
+    d = t(g["bc_in"]); lib.cudaF_mul_cols_vec(D3, D3, ops.ptr(d), ops.ptr(row), ops.dim(d)); check_error()
+    assert np.array_equal(d.cpu().numpy(), g["mul_cols_vec"])      # one rounding per element: exact
+    d = t(g["bc_in"]); lib.cudaF_mul_rows_vec(D3, D3, ops.ptr(d), ops.ptr(col), ops.dim(d)); check_error()
+    assert np.array_equal(d.cpu().numpy(), g["mul_rows_vec"])
+    w, gr = t(g["l1_w_in"]), t(g["l1_g_in"])
+    lib.cudaF_regularize_l1(D3, D3, ops.ptr(w), ops.ptr(gr), 0.002, 0.01, ops.dim(w), ops.dim(gr).stride); check_error()
+    wn, gn = w.cpu().numpy(), gr.cpu().numpy()
+    assert close(wn, g["l1_w_out"]) and close(gn, g["l1_g_out"])
+    # which elements were clamped to zero: identical unless the sign test sits within an fma rounding of zero
+    assert ((wn == 0) != (g["l1_w_out"] == 0)).sum() <= 1 and ((gn == 0) != (g["l1_g_out"] == 0)).sum() <= 1
+    src, idx = t(g["cols_in"]), t(g["cols_idx"], torch.int32)
+    d = t(g["cols_dst_in"]); lib.cudaF_copy_cols(D3, D3, ops.ptr(d), ops.ptr(src), ops.ptr(idx), ops.dim(d), ops.dim(src).stride); check_error()
+    assert np.array_equal(d.cpu().numpy(), g["copy_cols_out"])
+    d = t(g["cols_dst_in"]); lib.cudaF_add_cols(D3, D3, ops.ptr(d), ops.ptr(src), ops.ptr(idx), ops.dim(d), ops.dim(src).stride); check_error()
+    assert np.array_equal(d.cpu().numpy(), g["add_cols_out"])

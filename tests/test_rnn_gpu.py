@@ -102,6 +102,41 @@ def test_lstm_family_train_steps_match_oracle(aslp, oracle, dev, tmp_path, marke
         assert oracle.rel_err(net.GetParams(), flat()) < TOL, ("params", step)
 
 
+@pytest.mark.parametrize("marker", list(FAMILY))
+def test_lstm_family_at_cell_dim_512(aslp, oracle, dev, tmp_path, marker):
+    """Every member of the family at the BASELINE cell size (C = 512, R = 256, S = 32 streams): the fused step kernels' full
+    K-split / tile paths, not the ragged small shapes above.  Two batches, so the carried state and momentum are in play."""
+    D, Cc, R, T, S = 64, 512, 256, 12, 32
+    bidir, proj, cifg, lc, _ = FAMILY[marker]
+    clip, lr, mmt = 5.0, 1e-3, 0.9
+    dirs, grads, out_dim, path = build(oracle, tmp_path, marker, D, Cc, R, clip, seed=21, scale=0.05)
+    net = aslp.Nnet.Read(path)
+    net.SetTrainOptions(learn_rate=lr, momentum=mmt)
+    flat = lambda: np.concatenate([d.flat() for d in dirs])
+    rng = np.random.default_rng(17)
+    carried = (not bidir) or lc
+    chunk = T - 4 if lc else 0
+    if lc:
+        net.SetChunkSize(chunk)
+    state = np.zeros((S, dirs[0].width), np.float32) if carried else None
+    for step in range(2):
+        x = rng.standard_normal((T * S, D)).astype(np.float32)
+        od = (rng.standard_normal((T * S, out_dim)) * 0.1).astype(np.float32)
+        lens = None
+        if carried:
+            net.ResetLstmStreams([1] * S if step == 0 else [0] * S)
+        else:
+            lens = rng.integers(1, T + 1, S).astype(np.int32)
+            lens[0] = T
+            net.SetSeqLengths(lens)
+        out_ref, idf_ref, state = oracle_step(oracle, marker, dirs, grads, x, od, T, S, state, lens, chunk, lr, mmt, clip)
+        out = net.Propagate(torch.from_numpy(x).to(dev)).cpu().numpy()
+        assert oracle.rel_err(out, out_ref) < TOL, ("out", step)
+        idf = net.Backpropagate(torch.from_numpy(od).to(dev), want_in_diff=True).cpu().numpy()
+        assert oracle.rel_err(idf, idf_ref) < TOL, ("in_diff", step)
+        assert oracle.rel_err(net.GetParams(), flat()) < TOL, ("params", step)
+
+
 def test_lstm_forward_without_reset_is_per_utterance(aslp, oracle, dev, tmp_path):
     """nnet-forward mode: no ResetLstmStreams call -> one stream, state zeroed every Propagate
     (nnet-lstm-projected-streams.h:316-323)."""
@@ -141,12 +176,13 @@ def test_lc_blstm_baseline_shape(aslp, oracle, dev, tmp_path):
         assert oracle.rel_err(net.GetParams(), np.concatenate([d.flat() for d in dirs])) < TOL, ("params", step)
 
 
-@pytest.mark.parametrize("dims", [(5, 6, 6, 3), (40, 64, 10, 4), (33, 50, 7, 5), (48, 128, 6, 40), (24, 36, 5, 33)])
+# (512, 512, 60, 32): BASELINE cfg5's GruStreams swap at full size (H = 512, S = 32 streams, T = 60)
+@pytest.mark.parametrize("dims", [(5, 6, 6, 3), (40, 64, 10, 4), (33, 50, 7, 5), (48, 128, 6, 40), (24, 36, 5, 33), (512, 512, 60, 32)])
 def test_gru_train_steps_match_oracle(aslp, oracle, dev, tmp_path, dims):
     D, H, T, S = dims
     clip, lr, mmt = 0.5, 0.01, 0.9
     rng = np.random.default_rng(2)
-    p = oracle.Gru(D, H, rng, scale=0.3)
+    p = oracle.Gru(D, H, rng, scale=0.3 if H < 256 else 0.05)
     g = oracle.Gru(D, H, zero=True)
     path = tmp_path / "gru.nnet"
     nnet_io.write_simple_nnet(path, [("<GruStreams>", D, H, nnet_io.gru(p, clip))])

@@ -19,6 +19,20 @@ BIN = os.path.join(ROOT, "kaldi-aslp_amd", "bin")
 TOL = 1e-4
 
 
+def scheduler_reads(stderr_text, pipeline):
+    """What the reference's bash scheduler extracts from a tool's log: the scheduler's own pipeline (restated here as a one-line
+    shell string, nothing copied to disk), fed the tool's stderr.  Returns the stripped stdout."""
+    p = subprocess.run(["bash", "-c", pipeline], input=stderr_text.encode(), stdout=subprocess.PIPE, check=True)
+    return p.stdout.decode().strip()
+
+
+# aslp_scripts/aslp_nnet/train_scheduler.sh:87-88,120,129: loss = 4th token, loss type = 5th token of the LAST "AvgLoss:" line
+SCHED_LOSS = "grep \"AvgLoss:\" | tail -n 1 | awk '{ print $4; }'"
+SCHED_LOSS_TYPE = "grep \"AvgLoss:\" | tail -n 1 | awk '{ print $5; }'"
+# aslp_scripts/aslp_nnet/train_scheduler_ctc.sh:90,125,134: accuracy = 11th token of the LAST "TOKEN_ACCURACY" line
+SCHED_TOKEN_ACC = "grep \"TOKEN_ACCURACY\" | tail -n 1 | awk '{ print $11; }'"
+
+
 def tool(name, *args, ok=True):
     exe = os.path.join(BIN, name)
     if not os.path.exists(exe):  # a tree without the built tools (they are not in git): build them, in-tree, once
@@ -155,10 +169,17 @@ def test_train_frame_matches_api_and_oracle(aslp, oracle, dev, tmp_path, bn):
     assert oracle.rel_err(got, oracle_params(oracle, d, bn)) < TOL   # and the arithmetic is the reference's
     rep = xent.Report().splitlines()
     assert rep[0] in err and rep[1] in err
+    # the scheduler's view of that log (train_scheduler.sh:120): a float that IS the average loss, and the loss type
+    st = xent.GetStats()
+    sched = float(scheduler_reads(err, SCHED_LOSS))
+    assert abs(sched - (st["loss"] - st["entropy"]) / st["frames"]) <= 1e-4 * abs(sched)
+    assert scheduler_reads(err, SCHED_LOSS_TYPE) == "(Xent),"
     # cross-validation: no model written, same log vocabulary, loss of the TRAINED model below the initial one's
     p = tool("aslp-nnet-train-frame", "--cross-validate=true", "--minibatch-size=%d" % mb, "ark:%s" % (tmp_path / "feats.ark"),
              "ark:%s" % (tmp_path / "post.ark"), str(tmp_path / "out.nnet"))
     assert b"CROSS-VALIDATION STARTED" in p.stderr and b"[CROSS-VALIDATION, RANDOMIZED" in p.stderr
+    cv_loss = float(scheduler_reads(p.stderr.decode(), SCHED_LOSS))     # train_scheduler.sh:87,129 (accept / reject compares these)
+    assert 0.0 < cv_loss < 20.0 and "%.4f" % cv_loss                     # printf "%.4f" of the scheduler works on it
     oracle.lib.orc_dnn_destroy(d)
 
 
@@ -394,6 +415,10 @@ def test_warp_ctc_streams_tool_matches_api(aslp, dev, tmp_path):
     assert groups >= 3
     assert np.array_equal(got, net.GetParams())
     assert ctc.Report().strip().splitlines()[-1] in err
+    # train_scheduler_ctc.sh:125: the 11th token of the last TOKEN_ACCURACY line is the accuracy in percent
+    stt = ctc.GetStats()
+    acc = float(scheduler_reads(err, SCHED_TOKEN_ACC))
+    assert abs(acc - 100.0 * (1.0 - stt["error_tokens"] / stt["ref_tokens"])) < 1e-2
 
 
 LSTM_PROTO = """<NnetProto>
