@@ -75,10 +75,13 @@ def test_composite_kernels_match_reference_cumatrix_cpu(aslp, dev):
     t = lambda a, dt=torch.float32: torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(dt)
     A, B = t(g["conv_A"]), t(g["conv_B"])
     d = t(g["conv_dst_in"])
-    lib.cudaF_add_conv_mat_mat_elements(D3, D3, ops.ptr(d), ops.ptr(A), ops.ptr(B), ops.dim(d), ops.dim(A).stride, ops.dim(B).stride, 0.7, 0.3)
+    # the reference launches this kernel with blockDim.y = rows of B (cu-matrix.cc:3054-3058): the tap count travels in Bl.y
+    from kaldi_aslp_amd._lib import Dim3
+    BL = Dim3(2, B.shape[0], 1)
+    lib.cudaF_add_conv_mat_mat_elements(D3, BL, ops.ptr(d), ops.ptr(A), ops.ptr(B), ops.dim(d), ops.dim(A).stride, ops.dim(B).stride, 0.7, 0.3)
     check_error(); assert close(d.cpu().numpy(), g["conv_dst_out"])
     d = torch.zeros_like(d)
-    lib.cudaF_add_conv_mat_mat_elements(D3, D3, ops.ptr(d), ops.ptr(A), ops.ptr(B), ops.dim(d), ops.dim(A).stride, ops.dim(B).stride, 1.0, 0.0)
+    lib.cudaF_add_conv_mat_mat_elements(D3, BL, ops.ptr(d), ops.ptr(A), ops.ptr(B), ops.dim(d), ops.dim(A).stride, ops.dim(B).stride, 1.0, 0.0)
     check_error(); assert close(d.cpu().numpy(), g["conv_dst_beta0"])
     d, a, b = t(g["mme_dst_in"]), t(g["mme_A"]), t(g["mme_B"])
     lib.cudaF_add_mat_mat_elements(D3, D3, ops.ptr(d), ops.ptr(a), ops.ptr(b), ops.dim(d), ops.dim(a).stride, ops.dim(b).stride, -1.25, 0.5)
