@@ -318,12 +318,13 @@ def main():
             out["ctc_loss_fp32_rel_err"] = ctc_rel_err(aslp, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
     if comm is not None:
         comm.Barrier()
         if worker is not None:
             worker.close()
         comm.close()
+    if rank == 0:
+        print(json.dumps(out))   # the last thing on stdout
 
 
 if __name__ == "__main__":

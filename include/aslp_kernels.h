@@ -159,6 +159,12 @@ long aslp_gemm_profile_get(int variant, double *flops, double *ms);
 /* the tile configuration that carried most of that variant's flops since the last reset: returns its number, writes a
  * description ("gemm_f32_glds 64x128x32, 8 waves, LDS-DMA, 3 stages") into buf */
 int aslp_gemm_profile_tile(int variant, char *buf, int buflen);
+/* Named region timers (HIP events on the launch stream, off by default): the engine brackets "lstm_recurrence_fwd",
+ * "lstm_recurrence_bwd" (the timestep loops of the LSTM family), "gru_recurrence_fwd" / "_bwd" and "ctc_loss" (Warp-CTC / Eesen
+ * forward-backward).  aslp_region_get returns the number of regions recorded under `name` and their summed milliseconds. */
+void aslp_region_profile(int enable);
+void aslp_region_reset(void);
+long aslp_region_get(const char *name, double *ms);
 
 /* ---- fused hot-path ops (one pass each; see DESIGN.md for bytes/unit) ----------------- */
 /* BatchNormalization training forward (nnet-batch-normalization.h:177-220): writes out,
@@ -259,6 +265,32 @@ typedef struct aslp_lstm_step_ {
 } aslp_lstm_step;
 void aslp_lstm_step_forward(const aslp_lstm_step *a);
 void aslp_lstm_step_backward(const aslp_lstm_step *a);
+/* The same recurrence for a WHOLE sequence in one launch per pass (csrc/rnn_persistent.hip): the workgroups stay resident
+ * for all T timesteps, the weights they multiply with live in registers, and m(t) / dGATES(t) travel between workgroups
+ * through the buffers themselves (write-through stores, agent-scope loads, "not yet written" = the bit pattern 0xFFFFFFFF).
+ *   y : activation buffer [(T+2)*S x ld] (row = t*S + s), forward: gate columns of rows 1..T hold x-part + bias
+ *   d : diff buffer of the same shape (backward only), m columns of rows 1..T hold dL/dm from the layer above
+ * Contract: the caller prepared the buffer that is written (y forward, d backward) with aslp_lstm_seq_fill BEFORE it stored
+ * anything into it, and calls the kernel only when aslp_lstm_seq_supported says 1 (S <= 32 forward, C <= 1024 forward /
+ * G*C <= 2048 backward, the grid co-resident on the device); otherwise it keeps the per-timestep entry points above. */
+typedef struct aslp_lstm_seq_dir_ {
+  float *y;
+  float *d;
+  const float *w;                         /* forward: W_eff [G*C x C]; backward: W_eff^T [C x G*C] */
+  const float *peep_i, *peep_f, *peep_o;
+  const int32_cuda *seq_lengths;          /* forward length masking (may be NULL) */
+  int reverse;                            /* 0: the recursion runs t = 1..T, 1: t = T..1 (BPTT runs against it) */
+  int skip_first_product;                 /* forward: the caller already added the recurrent term of the first step */
+} aslp_lstm_seq_dir;
+typedef struct aslp_lstm_seq_ {
+  aslp_lstm_seq_dir dir[2];
+  int ndir, ld, ldw, T, S, C, cifg;
+} aslp_lstm_seq;
+int aslp_lstm_seq_supported(const aslp_lstm_seq *a, int backward);
+/* row blocks 0 and T+1 := 0, row blocks 1..T := bytes 0xFF */
+void aslp_lstm_seq_fill(float *buf, int ld, int T, int S);
+void aslp_lstm_seq_forward(const aslp_lstm_seq *a);
+void aslp_lstm_seq_backward(const aslp_lstm_seq *a);
 /* GruStreams (nnet-gru-streams.h:275-303, 344-383), columns [z|r|m|g|h] */
 /* GRU recurrence, one timestep, both dependent products fused with their gate arithmetic (csrc/gru_fused.hip):
  * forward = aslp_gru_forward1/2 with the two skinny GEMMs folded in; backward likewise, reading TRANSPOSED copies of the

@@ -123,6 +123,9 @@ _sig("aslp_gemm_profile_reset", None)
 _sig("aslp_gemm_force_tile", None, _i)
 _sig("aslp_gemm_profile_get", C.c_long, _i, C.POINTER(C.c_double), C.POINTER(C.c_double))
 _sig("aslp_gemm_profile_tile", _i, _i, C.c_char_p, _i)
+_sig("aslp_region_profile", None, _i)
+_sig("aslp_region_reset", None)
+_sig("aslp_region_get", C.c_long, C.c_char_p, C.POINTER(C.c_double))
 # fused
 _sig("aslp_bn_forward", None, _vp, _md, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f)
 _sig("aslp_bn_backward", None, _vp, _md, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i)

@@ -1,0 +1,472 @@
+// rnn_persistent.hip -- the LSTM recurrence of a whole sequence as ONE launch per layer and pass (both directions at once).
+//
+// rnn_fused.hip runs one launch per timestep: at S = 32 streams each of those sits on the launch floor (8 us forward,
+// 6 + 4 us backward at C = 512) with half the chip idle.  Here the workgroups stay resident for all T timesteps:
+//
+//   forward   workgroup (direction, 4 cells): keeps its 16 rows of W_eff (4 gates x 4 cells, K = C) in REGISTERS as MFMA
+//             B fragments for the whole launch; per timestep it reads m(t-1) of all streams (the only quantity that crosses
+//             workgroups), multiplies (v_mfma_f32_16x16x4_f32, K split over the 4 waves, partial tiles summed through LDS in
+//             wave order), finishes the gate block for its 32 x 4 (stream, cell) pairs and publishes m(t).  c(t-1) of a
+//             pair never leaves its thread's registers.
+//   backward  workgroup (direction, 16 cells, 16 streams): keeps its 16 rows of W_eff^T (K = G*C) in registers, per
+//             timestep reads dGATES(next) of its 16 streams, multiplies, finishes the gate-block backward for its 16 x 16
+//             pairs and publishes its 16 x G gate diffs.  The own-cell terms of the next step (d_c, d_i, d_f, y_f) are
+//             carried in registers.
+//
+// Hand-off between workgroups: the data is its own flag.  The host fills the row blocks 1..T of the activation / diff
+// buffer with the byte 0xFF before the launch (aslp_lstm_seq_fill), i.e. every float is the bit pattern 0xFFFFFFFF, a NaN no
+// arithmetic here produces.  Producers store their 16-byte pieces write-through at agent scope (buffer_store_dwordx4 sc1:
+// the line leaves the XCD's L2); consumers load the pieces they need with agent-scope loads (buffer_load_dwordx4 sc1: not
+// served from the CU's L1) and simply reload until no lane holds the sentinel.  No flag, no fence, no barrier across
+// workgroups, no dependence on which XCD a workgroup landed on; every row block is written exactly once per launch, so
+// there is no reuse hazard.  (MI355X_MICROARCH.md, inter-workgroup visibility: "R2 -- the data is the flag"; sc1 stores and
+// sc1 loads on both sides replace the release / acquire pair.)
+// Every spin is bounded (wall clock): on a timeout the workgroup raises a device-wide abort word, all workgroups leave, and
+// the host reports the failure through aslp_get_last_error -- a wrong result is never silent and the GPU never hangs.
+// The grid must be co-resident: aslp_lstm_seq_supported() checks it against the occupancy of the kernel with a margin
+// of one workgroup per CU, otherwise the caller keeps the one-launch-per-timestep path.
+#include <mutex>
+
+#include "aslp_kernels.h"
+#include "common.h"
+#include "scratch.h"
+
+namespace aslp {
+void register_async_error_word(const volatile unsigned *host_word, const char *what);  // runtime.cpp
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr unsigned kSentinel = 0xFFFFFFFFu;
+constexpr int kAuxSc1 = 16;          // buffer instruction cache policy: sc1 = agent scope
+constexpr long kSpinLimitTicks = 200000000L;  // wall_clock64 runs at 100 MHz: 2 s
+
+__device__ __forceinline__ float dsigm(float y, float d) { return d * y * (1.0f - y); }
+__device__ __forceinline__ float dtanh(float y, float d) { return d * (1.0f - y * y); }
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float *p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ bool has_sentinel(const u32x4 &v) {
+  return v.x == kSentinel || v.y == kSentinel || v.z == kSentinel || v.w == kSentinel;
+}
+__device__ __forceinline__ float as_f(unsigned u) { return __uint_as_float(u); }
+
+// device-side status: [0] abort flag (zeroed before every launch), host_err: mapped host word, counts timeouts
+struct SeqStatus {
+  unsigned *abort_flag;
+  unsigned *host_err;
+};
+
+// Loads NP 16-byte pieces per lane (off[i]: bytes from the resource base, always inside the buffer; bit i of `valid`: the
+// piece is an operand -- the others are replaced by zeros; `full`: wave-uniform, every piece of every lane is valid) with
+// agent-scope loads until none of them holds the sentinel.  Returns false on timeout / device-wide abort (wave-uniform).
+template <int NP>
+__device__ __forceinline__ bool load_published(u32x4 (&v)[NP], __amdgpu_buffer_rsrc_t rsrc, const int (&off)[NP], unsigned valid, bool full,
+                                               const SeqStatus &st) {
+  long t0 = 0;
+  for (unsigned spins = 0;; spins++) {
+#pragma unroll
+    for (int i = 0; i < NP; i++) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[i], 0, kAuxSc1);
+    if (!full) {
+#pragma unroll
+      for (int i = 0; i < NP; i++)
+        if (!((valid >> i) & 1u)) v[i] = u32x4{0u, 0u, 0u, 0u};
+    }
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < NP; i++) bad |= has_sentinel(v[i]);
+    if (!__any(bad)) return true;
+    asm volatile("" ::: "memory");  // the reloads stay inside the loop
+    if ((spins & 31u) == 31u) {
+      if (__hip_atomic_load(st.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+      const long now = (long)wall_clock64();
+      if (t0 == 0) t0 = now;
+      else if (now - t0 > kSpinLimitTicks) {
+        if ((threadIdx.x & 63) == 0) {
+          __hip_atomic_store(st.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_fetch_add(st.host_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return false;
+      }
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
+
+// C/D layout of v_mfma_f32_16x16x4_f32: element e of lane l is row 4 * (l >> 4) + e, column l & 15
+constexpr int kTP = 17;  // LDS pitch of a 16 x 16 partial tile
+__device__ __forceinline__ void store_tile16(float *tile, const f32x4 &acc, int lane) {
+  const int n = lane & 15, r0 = 4 * (lane >> 4);
+  tile[(r0 + 0) * kTP + n] = acc.x;
+  tile[(r0 + 1) * kTP + n] = acc.y;
+  tile[(r0 + 2) * kTP + n] = acc.z;
+  tile[(r0 + 3) * kTP + n] = acc.w;
+}
+
+// ---- forward -------------------------------------------------------------------------------------------------------
+// grid (ceil(C / 4), ndir), 256 threads.  NCH: 16-wide K chunks per wave (C <= 64 * NCH).
+template <bool CIFG, int NCH>
+__global__ void __launch_bounds__(256) lstm_seq_fwd(aslp_lstm_seq a, SeqStatus st) {
+  constexpr int G = CIFG ? 3 : 4;
+  __shared__ float red[2][4][2][16 * kTP];
+  __shared__ int fail[2][4];
+  const aslp_lstm_seq_dir D = a.dir[blockIdx.y];
+  const int C = a.C, S = a.S, T = a.T, ld = a.ld;
+  const int GC = G * C, oc = GC, oh = GC + C, om = GC + 2 * C;
+  constexpr int gi = 1, gf = CIFG ? 1 : 2, go = CIFG ? 2 : 3;
+  const int c0 = blockIdx.x * 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, kg = lane >> 4;
+  const int nq = (C + 15) / 16, per = (nq + 3) / 4, q0 = wave * per;
+  // B fragments, resident for the launch: tile column n = gate * 4 + cell
+  f32x4 b[NCH];
+  {
+    const int gate = l15 >> 2, cell = c0 + (l15 & 3);
+    const bool nvalid = gate < G && cell < C;
+    const float *brow = D.w + (long)(nvalid ? gate * C + cell : 0) * a.ldw;
+#pragma unroll
+    for (int i = 0; i < NCH; i++) {
+      const int k0 = 16 * (q0 + i) + 4 * kg;
+      const bool ok = nvalid && i < per && (q0 + i) < nq && k0 < C;
+      b[i] = ok ? *reinterpret_cast<const f32x4 *>(brow + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  // this lane's operand rows of the two stream tiles and its K offsets (bytes from the row block base)
+  int offA[2 * NCH];
+  unsigned validA = 0u;
+#pragma unroll
+  for (int mt = 0; mt < 2; mt++) {
+    const int row = min(16 * mt + l15, S - 1);
+#pragma unroll
+    for (int i = 0; i < NCH; i++) {
+      const int k0 = 16 * (q0 + i) + 4 * kg;
+      const bool ok = i < per && (q0 + i) < nq && k0 < C && 16 * mt < S;
+      offA[mt * NCH + i] = ok ? (row * ld + om + k0) * 4 : 0;
+      validA |= ok ? 1u << (mt * NCH + i) : 0u;
+    }
+  }
+  const bool fullA = per == NCH && nq == 4 * per && (C & 15) == 0 && S > 16;  // uniform: no piece of any lane is padding
+  // epilogue role: threads 0..127 own one (stream, cell) pair each
+  const int s = threadIdx.x >> 2, cc = threadIdx.x & 3, cell = c0 + cc;
+  const bool live = threadIdx.x < 128 && s < S && cell < C;
+  const int cq = live ? cell : 0, sq = live ? s : 0;
+  const float pf = D.peep_f[cq], po = D.peep_o[cq], pi = CIFG ? 0.f : D.peep_i[cq];
+  const int slen = (D.seq_lengths && live) ? D.seq_lengths[sq] : 0x7fffffff;
+  float cprev = 0.f;
+  {
+    const int tp0 = D.reverse ? T + 1 : 0;
+    if (live) cprev = D.y[((long)tp0 * S + sq) * ld + oc + cq];
+  }
+  for (int step = 0; step < T; step++) {
+    const int t = D.reverse ? T - step : 1 + step, tp = D.reverse ? t + 1 : t - 1;
+    const int par = step & 1;
+    float *ys = D.y + ((long)t * S + sq) * ld;
+    // the x-part (+ bias) of this pair's gates: written before the launch, requested before the hand-off wait
+    float xg = 0.f, xf = 0.f, xo = 0.f, xi = 0.f;
+    if (live) {
+      xg = ys[cq]; xf = ys[gf * C + cq]; xo = ys[go * C + cq];
+      if (!CIFG) xi = ys[gi * C + cq];
+    }
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    bool ok = true;
+    if (!(step == 0 && D.skip_first_product)) {
+      u32x4 av[2 * NCH];
+      ok = load_published<2 * NCH>(av, make_rsrc(D.y + (long)tp * S * ld), offA, validA, fullA, st);
+#pragma unroll
+      for (int i = 0; i < NCH; i++) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[i].x), b[i].x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[NCH + i].x), b[i].x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[i].y), b[i].y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[NCH + i].y), b[i].y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[i].z), b[i].z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[NCH + i].z), b[i].z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[i].w), b[i].w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[NCH + i].w), b[i].w, acc1, 0, 0, 0);
+      }
+    }
+    store_tile16(red[par][wave][0], acc0, lane);
+    store_tile16(red[par][wave][1], acc1, lane);
+    if (lane == 0) fail[par][wave] = ok ? 0 : 1;
+    __syncthreads();
+    if (fail[par][0] | fail[par][1] | fail[par][2] | fail[par][3]) return;  // uniform: every wave reads the same four words
+    if (!live) continue;
+    float pre[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      const int idx = (s & 15) * kTP + g * 4 + cc;
+      float v = red[par][0][s >> 4][idx];
+#pragma unroll
+      for (int w = 1; w < 4; w++) v += red[par][w][s >> 4][idx];
+      pre[g] = v;
+    }
+    float gg = 0.f, ii = 0.f, ff = 0.f, oo = 0.f, cellv = 0.f, hh = 0.f, mm = 0.f;
+    if (t <= slen) {  // nnet-blstm-projected-streams.h:654-657: rows past the utterance end are zeroed
+      gg = tanh_ref(xg + pre[0]);
+      ff = sigmoid_ref(xf + pre[gf] + cprev * pf);
+      if (!CIFG) {
+        ii = sigmoid_ref(xi + pre[gi] + cprev * pi);
+        cellv = gg * ii + cprev * ff;
+      } else {
+        cellv = -gg * ff + gg + cprev * ff;
+      }
+      cellv = fminf(fmaxf(cellv, -50.0f), 50.0f);
+      hh = tanh_ref(cellv);
+      oo = sigmoid_ref(xo + pre[go] + cellv * po);
+      mm = hh * oo;
+    }
+    // publish m(t) first: it is what the other workgroups wait for.  The quad's four cells are 16 contiguous bytes.
+    {
+      const float m1 = __shfl_down(mm, 1, 64), m2 = __shfl_down(mm, 2, 64), m3 = __shfl_down(mm, 3, 64);
+      if (cc == 0) {
+        u32x4 pk = {__float_as_uint(mm), __float_as_uint(m1), __float_as_uint(m2), __float_as_uint(m3)};
+        __builtin_amdgcn_raw_buffer_store_b128(pk, make_rsrc(D.y + (long)t * S * ld), (s * ld + om + c0) * 4, 0, kAuxSc1);
+      }
+    }
+    ys[cell] = gg; ys[gf * C + cell] = ff; ys[go * C + cell] = oo; ys[oc + cell] = cellv; ys[oh + cell] = hh;
+    if (!CIFG) ys[gi * C + cell] = ii;
+    cprev = cellv;
+  }
+}
+
+// ---- backward ------------------------------------------------------------------------------------------------------
+// grid (ceil(C / 16), ceil(S / 16), ndir), 512 threads: 8 waves split K = G*C.  NCH: 16-wide K chunks per wave (G*C <= 128 * NCH).
+template <bool CIFG, int NCH>
+__global__ void __launch_bounds__(512) lstm_seq_bwd(aslp_lstm_seq a, SeqStatus st) {
+  constexpr int G = CIFG ? 3 : 4;
+  __shared__ float red[2][8][16 * kTP];
+  __shared__ int fail[2][8];
+  const aslp_lstm_seq_dir D = a.dir[blockIdx.z];
+  const int C = a.C, S = a.S, T = a.T, ld = a.ld;
+  const int GC = G * C, oc = GC, oh = GC + C, om = GC + 2 * C;
+  const int og = 0, oi = C, of = CIFG ? C : 2 * C, oo = CIFG ? 2 * C : 3 * C;
+  const int c0 = blockIdx.x * 16, s0 = blockIdx.y * 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, kg = lane >> 4;
+  const int nq = (GC + 15) / 16, per = (nq + 7) / 8, q0 = wave * per;
+  f32x4 b[NCH];
+  {
+    const bool nvalid = c0 + l15 < C;
+    const float *brow = D.w + (long)(nvalid ? c0 + l15 : 0) * a.ldw;  // W_eff^T row of cell c0 + n
+#pragma unroll
+    for (int i = 0; i < NCH; i++) {
+      const int k0 = 16 * (q0 + i) + 4 * kg;
+      const bool ok = nvalid && i < per && (q0 + i) < nq && k0 < GC;
+      b[i] = ok ? *reinterpret_cast<const f32x4 *>(brow + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  int offA[NCH];
+  unsigned validA = 0u;
+  {
+    const int row = min(s0 + l15, S - 1);
+#pragma unroll
+    for (int i = 0; i < NCH; i++) {
+      const int k0 = 16 * (q0 + i) + 4 * kg;
+      const bool ok = i < per && (q0 + i) < nq && k0 < GC;
+      offA[i] = ok ? (row * ld + k0) * 4 : 0;
+      validA |= ok ? 1u << i : 0u;
+    }
+  }
+  const bool fullA = per == NCH && nq == 8 * per && (GC & 15) == 0;
+  // epilogue role: threads 0..255 own one (stream, cell) pair each
+  const int sl = threadIdx.x >> 4, cc = threadIdx.x & 15, s = s0 + sl, cell = c0 + cc;
+  const bool live = threadIdx.x < 256 && s < S && cell < C;
+  const int cq = live ? cell : 0, sq = live ? s : 0;
+  const float pf = D.peep_f[cq], po = D.peep_o[cq], pi = CIFG ? 0.f : D.peep_i[cq];
+  // own-cell quantities of the step processed just before (BPTT order): all zero ahead of the first step
+  float dn_c = 0.f, dn_f = 0.f, dn_i = 0.f;
+  for (int step = 0; step < T; step++) {
+    // BPTT runs against the direction's recursion: reverse = 0 (t = T..1), reverse = 1 (t = 1..T)
+    const int t = D.reverse ? 1 + step : T - step;
+    const int tn = D.reverse ? t - 1 : t + 1, tp = D.reverse ? t + 1 : t - 1;
+    const int par = step & 1;
+    const long o_ = ((long)t * S + sq) * ld;
+    float dm = 0.f, yo = 0.f, yh = 0.f, yg = 0.f, yf = 0.f, yi = 0.f, yn_f = 0.f, cprev = 0.f, ccur = 0.f;
+    if (live) {  // everything that does not depend on the other workgroups, requested before the hand-off wait
+      dm = D.d[o_ + om + cq];
+      yo = D.y[o_ + oo + cq]; yh = D.y[o_ + oh + cq]; yg = D.y[o_ + og + cq]; yf = D.y[o_ + of + cq];
+      if (!CIFG) yi = D.y[o_ + oi + cq];
+      yn_f = D.y[((long)tn * S + sq) * ld + of + cq];
+      cprev = D.y[((long)tp * S + sq) * ld + oc + cq];
+      (void)ccur;
+    }
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    bool ok = true;
+    if (step > 0) {
+      u32x4 av[NCH];
+      ok = load_published<NCH>(av, make_rsrc(D.d + (long)tn * S * ld), offA, validA, fullA, st);
+#pragma unroll
+      for (int i = 0; i < NCH; i++) {  // two accumulators: the dependent-issue latency of 16x16x4 (40 cycles) exceeds its issue time (32)
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[i].x), b[i].x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[i].y), b[i].y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[i].z), b[i].z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[i].w), b[i].w, acc1, 0, 0, 0);
+      }
+    }
+    store_tile16(red[par][wave], acc0 + acc1, lane);
+    if (lane == 0) fail[par][wave] = ok ? 0 : 1;
+    __syncthreads();
+    {
+      int f = 0;
+#pragma unroll
+      for (int w = 0; w < 8; w++) f |= fail[par][w];
+      if (f) return;
+    }
+    if (threadIdx.x >= 256) continue;  // whole waves: the quad exchange below needs every lane of waves 0..3
+    float psum = red[par][0][sl * kTP + cc];
+#pragma unroll
+    for (int w = 1; w < 8; w++) psum += red[par][w][sl * kTP + cc];
+    dm += psum;
+    const float dh = dtanh(yh, dm * yo);
+    const float dov = dsigm(yo, dm * yh);
+    float dc = dh + dn_c * yn_f;
+    if (!CIFG) dc += dn_i * pi;
+    dc += dn_f * pf;
+    dc += dov * po;
+    float dg, df, di = 0.f;
+    if (!CIFG) {
+      df = dsigm(yf, dc * cprev);
+      di = dsigm(yi, dc * yg);
+      dg = dtanh(yg, dc * yi);
+    } else {
+      df = dsigm(yf, dc * cprev - dc * yg);
+      dg = dtanh(yg, dc - dc * yf);
+    }
+    // publish the gate diffs first.  In the diff buffer gate x of the workgroup's 16 cells is 64 contiguous bytes; lane j of
+    // a quad collects gate j of the quad's four cells (three quad rotations) and stores them as one 16-byte piece.
+    {
+      const int j = lane & 3, qb = lane & ~3;
+      float gate[4];
+      gate[0] = dg;
+      if (!CIFG) { gate[1] = di; gate[2] = df; gate[3] = dov; }
+      else { gate[1] = df; gate[2] = dov; gate[3] = 0.f; }
+      float out[4];
+#pragma unroll
+      for (int p = 0; p < 4; p++) out[p] = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        // lane p sends gate[(p - r) & 3]; lane j receives from p = (j + r) & 3, i.e. gate j of quad cell p
+        const int gsel = (j - r) & 3;
+        const float send = gsel == 0 ? gate[0] : gsel == 1 ? gate[1] : gsel == 2 ? gate[2] : gate[3];
+        const float recv = __shfl(send, qb + ((j + r) & 3), 64);
+        const int p = (j + r) & 3;
+        if (p == 0) out[0] = recv; else if (p == 1) out[1] = recv; else if (p == 2) out[2] = recv; else out[3] = recv;
+      }
+      if (live && j < G) {
+        u32x4 pk = {__float_as_uint(out[0]), __float_as_uint(out[1]), __float_as_uint(out[2]), __float_as_uint(out[3])};
+        __builtin_amdgcn_raw_buffer_store_b128(pk, make_rsrc(D.d + (long)t * S * ld), (s * ld + j * C + c0 + (cc & ~3)) * 4, 0, kAuxSc1);
+      }
+    }
+    if (live) {
+      D.d[o_ + om + cell] = dm;  // the reference's d_m (lc.h:793) -- kept for InfoGradient-style dumps
+      D.d[o_ + oh + cell] = dh;
+      D.d[o_ + oc + cell] = dc;
+    }
+    dn_c = dc; dn_f = df; dn_i = di;
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------
+struct SeqRuntime {
+  unsigned *abort_flag = nullptr;  // device
+  unsigned *host_err = nullptr;    // mapped host memory (device-visible)
+  unsigned *host_err_dev = nullptr;
+  int num_cu = 0;
+  bool ok = false;
+};
+SeqRuntime &seq_runtime() {
+  static SeqRuntime rt;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return;
+    rt.num_cu = prop.multiProcessorCount;
+    if (hipMalloc(&rt.abort_flag, 64) != hipSuccess) return;
+    if (hipHostMalloc(&rt.host_err, 64, hipHostMallocMapped) != hipSuccess) return;
+    *rt.host_err = 0;
+    if (hipHostGetDevicePointer(reinterpret_cast<void **>(&rt.host_err_dev), rt.host_err, 0) != hipSuccess) return;
+    register_async_error_word(rt.host_err, "persistent LSTM recurrence: a workgroup timed out waiting for another workgroup's hand-off "
+                                           "(results of that call are invalid)");
+    rt.ok = true;
+  });
+  return rt;
+}
+
+typedef void (*SeqKernel)(aslp_lstm_seq, SeqStatus);
+SeqKernel pick_fwd(bool cifg, int C) {
+  if (C <= 128) return cifg ? lstm_seq_fwd<true, 2> : lstm_seq_fwd<false, 2>;
+  if (C <= 512) return cifg ? lstm_seq_fwd<true, 8> : lstm_seq_fwd<false, 8>;
+  if (C <= 1024) return cifg ? lstm_seq_fwd<true, 16> : lstm_seq_fwd<false, 16>;
+  return nullptr;
+}
+SeqKernel pick_bwd(bool cifg, int C) {
+  const int GC = (cifg ? 3 : 4) * C;
+  if (GC <= 512) return cifg ? lstm_seq_bwd<true, 4> : lstm_seq_bwd<false, 4>;
+  if (GC <= 2048) return cifg ? lstm_seq_bwd<true, 16> : lstm_seq_bwd<false, 16>;
+  return nullptr;
+}
+
+bool seq_args_ok(const aslp_lstm_seq *a) {
+  return a && a->ndir >= 1 && a->ndir <= 2 && a->T > 0 && a->S > 0 && a->C > 0 && (a->C & 3) == 0 && (a->ld & 3) == 0 && (a->ldw & 3) == 0;
+}
+
+// the whole grid has to be resident at once: leave one workgroup per CU of slack against the occupancy the runtime reports
+// (MI355X_MICROARCH.md: the API can be one block per CU high) -- unless a single workgroup per CU is all we need
+bool grid_fits(SeqKernel k, int threads, long blocks) {
+  SeqRuntime &rt = seq_runtime();
+  if (!rt.ok || !k) return false;
+  int occ = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(k), threads, 0) != hipSuccess || occ < 1) return false;
+  const long cap = (long)rt.num_cu * (occ >= 2 ? occ - 1 : (blocks <= rt.num_cu / 2 ? 1 : 0));
+  return blocks <= cap;
+}
+
+}  // namespace
+}  // namespace aslp
+
+using namespace aslp;
+
+extern "C" {
+
+int aslp_lstm_seq_supported(const aslp_lstm_seq *a, int backward) {
+  static const bool disabled = getenv("ASLP_LSTM_PERSISTENT") != nullptr && getenv("ASLP_LSTM_PERSISTENT")[0] == '0';
+  if (disabled || !seq_args_ok(a)) return 0;
+  if (!backward) {
+    if (a->S > 32) return 0;
+    SeqKernel k = pick_fwd(a->cifg != 0, a->C);
+    return grid_fits(k, 256, (long)((a->C + 3) / 4) * a->ndir) ? 1 : 0;
+  }
+  SeqKernel k = pick_bwd(a->cifg != 0, a->C);
+  return grid_fits(k, 512, (long)((a->C + 15) / 16) * ((a->S + 15) / 16) * a->ndir) ? 1 : 0;
+}
+
+void aslp_lstm_seq_fill(float *buf, int ld, int T, int S) {
+  if (!buf || T <= 0 || S <= 0 || ld <= 0) return;
+  const size_t block = sizeof(float) * (size_t)S * ld;
+  ASLP_CHECK_HIP(hipMemsetAsync(buf, 0, block, cur_stream()));                                   // history / boundary row block 0
+  ASLP_CHECK_HIP(hipMemsetAsync(buf + (size_t)S * ld, 0xFF, block * (size_t)T, cur_stream()));   // row blocks 1..T: "not yet published"
+  ASLP_CHECK_HIP(hipMemsetAsync(buf + (size_t)(T + 1) * S * ld, 0, block, cur_stream()));        // boundary row block T + 1
+}
+
+static void launch_seq(const aslp_lstm_seq *a, bool backward, const char *who) {
+  if (!seq_args_ok(a) || !aslp_lstm_seq_supported(a, backward ? 1 : 0)) {
+    set_error(std::string(who) + ": arguments outside what the persistent kernel supports (check aslp_lstm_seq_supported first)");
+    return;
+  }
+  SeqRuntime &rt = seq_runtime();
+  ASLP_CHECK_HIP(hipMemsetAsync(rt.abort_flag, 0, 64, cur_stream()));
+  SeqStatus st = {rt.abort_flag, rt.host_err_dev};
+  if (!backward) {
+    SeqKernel k = pick_fwd(a->cifg != 0, a->C);
+    hipLaunchKernelGGL(k, dim3((a->C + 3) / 4, a->ndir), dim3(256), 0, cur_stream(), *a, st);
+  } else {
+    SeqKernel k = pick_bwd(a->cifg != 0, a->C);
+    hipLaunchKernelGGL(k, dim3((a->C + 15) / 16, (a->S + 15) / 16, a->ndir), dim3(512), 0, cur_stream(), *a, st);
+  }
+  check_launch(who);
+}
+
+void aslp_lstm_seq_forward(const aslp_lstm_seq *a) { launch_seq(a, false, "aslp_lstm_seq_forward"); }
+void aslp_lstm_seq_backward(const aslp_lstm_seq *a) { launch_seq(a, true, "aslp_lstm_seq_backward"); }
+
+}  // extern "C"

@@ -1,6 +1,8 @@
 // runtime.cpp -- per-thread stream, sticky error slot and device scratch for libaslp_hip.so.
 // Replaces the slice of CuDevice (src/aslp-cudamatrix/cu-device.h:43-151) the hot path needs.
+#include <map>
 #include <mutex>
+#include <vector>
 #include <string>
 #include <cstring>
 #include <sys/syscall.h>
@@ -19,12 +21,29 @@ static std::string g_err;
 hipStream_t cur_stream() { return t_stream; }
 void set_cur_stream(hipStream_t s) { t_stream = s; }
 
+// Error words that a running kernel raises on its own (mapped host memory): looked at whenever the error slot is read.
+namespace {
+struct AsyncErr { const volatile unsigned *word; unsigned seen; std::string what; };
+std::vector<AsyncErr> g_async_errs;
+void poll_async_errors_locked() {
+  for (auto &a : g_async_errs) {
+    const unsigned v = *a.word;
+    if (v != a.seen) { a.seen = v; if (g_err.empty()) g_err = a.what; }
+  }
+}
+}  // namespace
+void register_async_error_word(const volatile unsigned *host_word, const char *what) {
+  std::lock_guard<std::mutex> lk(g_err_mu);
+  g_async_errs.push_back({host_word, *host_word, what});
+}
+
 void set_error(const std::string &msg) {
   std::lock_guard<std::mutex> lk(g_err_mu);
   if (g_err.empty()) g_err = msg;  // keep the first one: it is the cause
 }
 bool has_error() {
   std::lock_guard<std::mutex> lk(g_err_mu);
+  poll_async_errors_locked();
   return !g_err.empty();
 }
 
@@ -123,15 +142,79 @@ void join_side_stream() {
     set_error("side stream: join failed");
 }
 
+// ---- named region timers (bench.py's cfg3 block): HIP events on the launch stream around a host-side region ------------
+namespace {
+struct Region {
+  double ms = 0.0;
+  long count = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+std::mutex g_region_mu;
+std::map<std::string, Region> g_regions;
+std::vector<hipEvent_t> g_region_pool;
+bool g_region_on = false;
+hipEvent_t region_event() {
+  if (!g_region_pool.empty()) { hipEvent_t e = g_region_pool.back(); g_region_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+void region_drain(Region &r) {
+  for (auto &ev : r.pending) {
+    float ms = 0.f;
+    if (hipEventSynchronize(ev.second) == hipSuccess && hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) r.ms += ms;
+    g_region_pool.push_back(ev.first);
+    g_region_pool.push_back(ev.second);
+  }
+  r.pending.clear();
+}
+}  // namespace
+
+RegionScope::RegionScope(const char *name) : name_(nullptr), e0_(nullptr) {
+  if (!g_region_on) return;
+  std::lock_guard<std::mutex> lk(g_region_mu);
+  name_ = name;
+  e0_ = region_event();
+  (void)hipEventRecord(static_cast<hipEvent_t>(e0_), cur_stream());
+}
+RegionScope::~RegionScope() {
+  if (!name_) return;
+  std::lock_guard<std::mutex> lk(g_region_mu);
+  hipEvent_t e1 = region_event();
+  (void)hipEventRecord(e1, cur_stream());
+  Region &r = g_regions[name_];
+  r.count++;
+  r.pending.emplace_back(static_cast<hipEvent_t>(e0_), e1);
+}
+
 }  // namespace aslp
 
 extern "C" {
+
+void aslp_region_profile(int enable) {
+  std::lock_guard<std::mutex> lk(aslp::g_region_mu);
+  aslp::g_region_on = enable != 0;
+}
+void aslp_region_reset(void) {
+  std::lock_guard<std::mutex> lk(aslp::g_region_mu);
+  for (auto &kv : aslp::g_regions) aslp::region_drain(kv.second);
+  aslp::g_regions.clear();
+}
+long aslp_region_get(const char *name, double *ms) {
+  std::lock_guard<std::mutex> lk(aslp::g_region_mu);
+  auto it = aslp::g_regions.find(name ? name : "");
+  if (it == aslp::g_regions.end()) { if (ms) *ms = 0.0; return 0; }
+  aslp::region_drain(it->second);
+  if (ms) *ms = it->second.ms;
+  return it->second.count;
+}
 
 void aslp_set_stream(void *s) { aslp::set_cur_stream(reinterpret_cast<hipStream_t>(s)); }
 void *aslp_get_stream(void) { return reinterpret_cast<void *>(aslp::cur_stream()); }
 
 int aslp_get_last_error(char *buf, int buflen) {
   std::lock_guard<std::mutex> lk(aslp::g_err_mu);
+  aslp::poll_async_errors_locked();
   if (aslp::g_err.empty()) {
     if (buf && buflen > 0) buf[0] = 0;
     return 0;

@@ -20,6 +20,18 @@ class SideStreamScope {
   void *saved_;
   bool active_;
 };
+// Times the region between construction and destruction with HIP events on the calling thread's stream when region profiling
+// is on (aslp_region_profile(1)); free otherwise.  name must be a string literal.  Read with aslp_region_get(name, &ms).
+class RegionScope {
+ public:
+  explicit RegionScope(const char *name);
+  ~RegionScope();
+  RegionScope(const RegionScope &) = delete;
+  RegionScope &operator=(const RegionScope &) = delete;
+ private:
+  const char *name_;
+  void *e0_;
+};
 void join_side_stream();
 bool on_side_stream();  // is the calling thread inside a SideStreamScope?
 }  // namespace aslp

@@ -49,6 +49,22 @@ def lib():
     return _lib
 
 
+class _StdoutToStderr:
+    """RCCL prints a version banner on the C-level stdout when a communicator comes up or goes away; a host whose stdout
+    is a protocol (bench.py: one JSON line) gets it on stderr instead."""
+
+    def __enter__(self):
+        import sys
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def _ok(rc):
     if rc != 0:
         raise RuntimeError((lib().aslp_parallel_last_error() or b"").decode(errors="replace"))
@@ -59,12 +75,16 @@ class RcclComm:
 
     def __init__(self, id_file=None, rank=-1, num_nodes=-1, token=None, timeout_s=300):
         self.h = C.c_void_p()
-        _ok(lib().aslp_comm_create_rccl(rank, num_nodes, id_file.encode() if id_file else None, token.encode() if token else None,
-                                        timeout_s, C.byref(self.h)))
+        L = lib()
+        with _StdoutToStderr():
+            rc = L.aslp_comm_create_rccl(rank, num_nodes, id_file.encode() if id_file else None, token.encode() if token else None,
+                                         timeout_s, C.byref(self.h))
+        _ok(rc)
 
     def close(self):
         if getattr(self, "h", None):
-            lib().aslp_comm_free(self.h)
+            with _StdoutToStderr():
+                lib().aslp_comm_free(self.h)
             self.h = None
 
     def Rank(self): return lib().aslp_comm_rank(self.h)

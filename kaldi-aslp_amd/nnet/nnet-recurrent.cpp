@@ -1,6 +1,8 @@
 // nnet-recurrent.cpp -- LSTM family + GruStreams host logic (see nnet-recurrent.h).
 #include "nnet-recurrent.h"
 
+#include "scratch.h"
+
 #include <cstdlib>
 #include <sstream>
 
@@ -219,10 +221,16 @@ void LstmDir::RefreshEff() const {
   eff_dirty = false;
 }
 
-void LstmDir::ForwardPrepare(const CuMatrixBase &in, int T, int S, bool reverse, const CuMatrixBase *init_state, CuMatrix *buf) const {
+void LstmDir::ForwardPrepare(const CuMatrixBase &in, int T, int S, bool reverse, const CuMatrixBase *init_state, CuMatrix *buf,
+                             bool persistent) const {
   ASLP_ASSERT(in.NumRows() == T * S && in.NumCols() == D);
   RefreshEff();
-  buf->Resize((T + 2) * S, Width(), kSetZero);
+  if (persistent) {  // row blocks 1..T start as "not yet published" (csrc/rnn_persistent.hip), the two boundary blocks as zero
+    buf->Resize((T + 2) * S, Width(), kUndefined);
+    aslp_lstm_seq_fill(buf->Data(), buf->Stride(), T, S);
+  } else {
+    buf->Resize((T + 2) * S, Width(), kSetZero);
+  }
   if (init_state) buf->RowRange(reverse ? (T + 1) * S : 0, S).CopyFromMat(*init_state);
   aslp_gemm_epilogue ep = aslp_gemm_epilogue();
   ep.bias = bias.Data();
@@ -239,9 +247,14 @@ bool LstmDir::ForwardFinish(int T, int S, CuMatrix *buf, CuMatrixBase *out, int 
   return out != nullptr;
 }
 
-void LstmDir::BackwardPrepare(const CuMatrixBase &out_diff, int T, int S, CuMatrix *dbuf) const {
+void LstmDir::BackwardPrepare(const CuMatrixBase &out_diff, int T, int S, CuMatrix *dbuf, bool persistent) const {
   ASLP_ASSERT(out_diff.NumRows() == T * S && out_diff.NumCols() == Rec());
-  dbuf->Resize((T + 2) * S, Width(), kSetZero);
+  if (persistent) {
+    dbuf->Resize((T + 2) * S, Width(), kUndefined);
+    aslp_lstm_seq_fill(dbuf->Data(), dbuf->Stride(), T, S);
+  } else {
+    dbuf->Resize((T + 2) * S, Width(), kSetZero);
+  }
   CuSubMatrix d_m(*dbuf, S, T * S, OffM(), C);
   if (R > 0) d_m.AddMatMat(1.0, out_diff, kNoTrans, w_rm, kNoTrans, 0.0);  // the loss's share of d_m, all t at once
   else d_m.CopyFromMat(out_diff);
@@ -373,32 +386,55 @@ void LstmFamily::PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) {
   const int32 T = in.NumRows() / S;
   const int rec = f_.Rec();
   if (f_.FusedOk()) {
-    // fused recurrence: batched x-part, ONE launch per timestep for all directions, batched projection
-    f_.ForwardPrepare(in, T, S, false, carried ? &prev_state_ : nullptr, &f_buf_);
-    if (cfg_.bidir) b_.ForwardPrepare(in, T, S, true, nullptr, &b_buf_);
-    aslp_lstm_step a = aslp_lstm_step();
-    a.ndir = cfg_.bidir ? 2 : 1; a.ld = f_buf_.Stride(); a.S = S; a.C = ncell_; a.cifg = cfg_.cifg ? 1 : 0;
-    a.ldw = f_.Weff().Stride();
-    for (int d = 0; d < a.ndir; d++) {
-      const LstmDir &p = d == 0 ? f_ : b_;
-      a.dir[d].w = p.Weff().Data();
-      a.dir[d].peep_i = cfg_.cifg ? nullptr : p.peep_i.Data();
-      a.dir[d].peep_f = p.peep_f.Data();
-      a.dir[d].peep_o = p.peep_o.Data();
-      a.dir[d].seq_lengths = (d == 1 && !cfg_.lc) ? seq_len_dev_.Data() : nullptr;
-    }
+    // fused recurrence: batched x-part, the recurrence itself as ONE persistent launch for all timesteps and directions
+    // (csrc/rnn_persistent.hip) -- or, where that kernel does not apply, one launch per timestep --, batched projection
+    aslp_lstm_seq q = aslp_lstm_seq();
+    q.ndir = cfg_.bidir ? 2 : 1; q.ld = 4; q.ldw = 4; q.T = T; q.S = S; q.C = ncell_; q.cifg = cfg_.cifg ? 1 : 0;
+    const bool persistent = aslp_lstm_seq_supported(&q, 0) != 0;
+    f_.ForwardPrepare(in, T, S, false, carried ? &prev_state_ : nullptr, &f_buf_, persistent);
+    if (cfg_.bidir) b_.ForwardPrepare(in, T, S, true, nullptr, &b_buf_, persistent);
     if (carried && cfg_.proj) {
       // The carried history holds r(0) = m(0) W_rm^T formed with the weights of the PREVIOUS batch (the reference
       // recurs on the stored r, lc.h:575); m(0) W_eff^T would silently re-project it with the updated W_rm.
       CuSubMatrix y_gates(f_buf_, S, S, 0, f_.GC()), r0(f_buf_, 0, S, f_.OffRec(), f_.R);
       y_gates.AddMatMat(1.0, r0, kNoTrans, f_.w_r, kTrans, 1.0);
     }
-    for (int step = 0; step < T; step++) {
-      const int tf = 1 + step, tb = T - step;
-      a.dir[0].no_product = (step == 0 && carried && cfg_.proj) ? 1 : 0;
-      a.dir[0].y_cur = f_buf_.RowData(tf * S); a.dir[0].y_prev = f_buf_.RowData((tf - 1) * S); a.dir[0].t = tf;
-      if (cfg_.bidir) { a.dir[1].y_cur = b_buf_.RowData(tb * S); a.dir[1].y_prev = b_buf_.RowData((tb + 1) * S); a.dir[1].t = tb; }
-      aslp_lstm_step_forward(&a);
+    if (persistent) {
+      q.ld = f_buf_.Stride(); q.ldw = f_.Weff().Stride();
+      for (int d = 0; d < q.ndir; d++) {
+        const LstmDir &p = d == 0 ? f_ : b_;
+        q.dir[d].y = (d == 0 ? f_buf_ : b_buf_).Data();
+        q.dir[d].w = p.Weff().Data();
+        q.dir[d].peep_i = cfg_.cifg ? nullptr : p.peep_i.Data();
+        q.dir[d].peep_f = p.peep_f.Data();
+        q.dir[d].peep_o = p.peep_o.Data();
+        q.dir[d].seq_lengths = (d == 1 && !cfg_.lc) ? seq_len_dev_.Data() : nullptr;
+        q.dir[d].reverse = d;
+        q.dir[d].skip_first_product = (d == 0 && carried && cfg_.proj) ? 1 : 0;
+      }
+      ASLP_ASSERT(!cfg_.bidir || b_buf_.Stride() == f_buf_.Stride());
+      RegionScope timed("lstm_recurrence_fwd");
+      aslp_lstm_seq_forward(&q);
+    } else {
+      aslp_lstm_step a = aslp_lstm_step();
+      a.ndir = cfg_.bidir ? 2 : 1; a.ld = f_buf_.Stride(); a.S = S; a.C = ncell_; a.cifg = cfg_.cifg ? 1 : 0;
+      a.ldw = f_.Weff().Stride();
+      for (int d = 0; d < a.ndir; d++) {
+        const LstmDir &p = d == 0 ? f_ : b_;
+        a.dir[d].w = p.Weff().Data();
+        a.dir[d].peep_i = cfg_.cifg ? nullptr : p.peep_i.Data();
+        a.dir[d].peep_f = p.peep_f.Data();
+        a.dir[d].peep_o = p.peep_o.Data();
+        a.dir[d].seq_lengths = (d == 1 && !cfg_.lc) ? seq_len_dev_.Data() : nullptr;
+      }
+      RegionScope timed("lstm_recurrence_fwd");
+      for (int step = 0; step < T; step++) {
+        const int tf = 1 + step, tb = T - step;
+        a.dir[0].no_product = (step == 0 && carried && cfg_.proj) ? 1 : 0;
+        a.dir[0].y_cur = f_buf_.RowData(tf * S); a.dir[0].y_prev = f_buf_.RowData((tf - 1) * S); a.dir[0].t = tf;
+        if (cfg_.bidir) { a.dir[1].y_cur = b_buf_.RowData(tb * S); a.dir[1].y_prev = b_buf_.RowData((tb + 1) * S); a.dir[1].t = tb; }
+        aslp_lstm_step_forward(&a);
+      }
     }
     CheckK();
     // with a projection the GEMM that forms r(t) for all t also writes it into this component's output block
@@ -433,30 +469,50 @@ void LstmFamily::BackpropagateFnc(const CuMatrixBase &in, const CuMatrixBase &, 
   const BaseFloat mmt = opts_.momentum;
   if (f_.FusedOk()) {
     CuSubMatrix od_f(out_diff, 0, T * S, 0, rec), od_b(out_diff, 0, T * S, cfg_.bidir ? rec : 0, rec);
-    f_.BackwardPrepare(od_f, T, S, &f_dbuf_);
-    if (cfg_.bidir) b_.BackwardPrepare(od_b, T, S, &b_dbuf_);
-    aslp_lstm_step a = aslp_lstm_step();
-    a.ndir = cfg_.bidir ? 2 : 1; a.ld = f_dbuf_.Stride(); a.S = S; a.C = ncell_; a.cifg = cfg_.cifg ? 1 : 0;
-    a.ldw = f_.w_eff_t.Stride();
+    aslp_lstm_seq q = aslp_lstm_seq();
+    q.ndir = cfg_.bidir ? 2 : 1; q.ld = 4; q.ldw = 4; q.T = T; q.S = S; q.C = ncell_; q.cifg = cfg_.cifg ? 1 : 0;
+    const bool persistent = aslp_lstm_seq_supported(&q, 1) != 0;
+    f_.BackwardPrepare(od_f, T, S, &f_dbuf_, persistent);
+    if (cfg_.bidir) b_.BackwardPrepare(od_b, T, S, &b_dbuf_, persistent);
     ASLP_ASSERT(f_dbuf_.Stride() == f_buf_.Stride());
-    for (int d = 0; d < a.ndir; d++) {
-      const LstmDir &p = d == 0 ? f_ : b_;
-      a.dir[d].w = p.w_eff_t.Data();
-      a.dir[d].peep_i = cfg_.cifg ? nullptr : p.peep_i.Data();
-      a.dir[d].peep_f = p.peep_f.Data();
-      a.dir[d].peep_o = p.peep_o.Data();
-    }
-    for (int step = 0; step < T; step++) {
-      const int tf = T - step, tb = 1 + step;  // BPTT runs against each direction's recursion
-      a.dir[0].d_cur = f_dbuf_.RowData(tf * S); a.dir[0].d_next = f_dbuf_.RowData((tf + 1) * S);
-      a.dir[0].y_cur = f_buf_.RowData(tf * S); a.dir[0].y_next = f_buf_.RowData((tf + 1) * S); a.dir[0].y_prev = f_buf_.RowData((tf - 1) * S);
-      a.dir[0].has_next = step > 0;
-      if (cfg_.bidir) {
-        a.dir[1].d_cur = b_dbuf_.RowData(tb * S); a.dir[1].d_next = b_dbuf_.RowData((tb - 1) * S);
-        a.dir[1].y_cur = b_buf_.RowData(tb * S); a.dir[1].y_next = b_buf_.RowData((tb - 1) * S); a.dir[1].y_prev = b_buf_.RowData((tb + 1) * S);
-        a.dir[1].has_next = step > 0;
+    if (persistent) {
+      q.ld = f_dbuf_.Stride(); q.ldw = f_.w_eff_t.Stride();
+      for (int d = 0; d < q.ndir; d++) {
+        const LstmDir &p = d == 0 ? f_ : b_;
+        q.dir[d].y = (d == 0 ? f_buf_ : b_buf_).Data();
+        q.dir[d].d = (d == 0 ? f_dbuf_ : b_dbuf_).Data();
+        q.dir[d].w = p.w_eff_t.Data();
+        q.dir[d].peep_i = cfg_.cifg ? nullptr : p.peep_i.Data();
+        q.dir[d].peep_f = p.peep_f.Data();
+        q.dir[d].peep_o = p.peep_o.Data();
+        q.dir[d].reverse = d;
       }
-      aslp_lstm_step_backward(&a);
+      RegionScope timed("lstm_recurrence_bwd");
+      aslp_lstm_seq_backward(&q);
+    } else {
+      aslp_lstm_step a = aslp_lstm_step();
+      a.ndir = cfg_.bidir ? 2 : 1; a.ld = f_dbuf_.Stride(); a.S = S; a.C = ncell_; a.cifg = cfg_.cifg ? 1 : 0;
+      a.ldw = f_.w_eff_t.Stride();
+      for (int d = 0; d < a.ndir; d++) {
+        const LstmDir &p = d == 0 ? f_ : b_;
+        a.dir[d].w = p.w_eff_t.Data();
+        a.dir[d].peep_i = cfg_.cifg ? nullptr : p.peep_i.Data();
+        a.dir[d].peep_f = p.peep_f.Data();
+        a.dir[d].peep_o = p.peep_o.Data();
+      }
+      RegionScope timed("lstm_recurrence_bwd");
+      for (int step = 0; step < T; step++) {
+        const int tf = T - step, tb = 1 + step;  // BPTT runs against each direction's recursion
+        a.dir[0].d_cur = f_dbuf_.RowData(tf * S); a.dir[0].d_next = f_dbuf_.RowData((tf + 1) * S);
+        a.dir[0].y_cur = f_buf_.RowData(tf * S); a.dir[0].y_next = f_buf_.RowData((tf + 1) * S); a.dir[0].y_prev = f_buf_.RowData((tf - 1) * S);
+        a.dir[0].has_next = step > 0;
+        if (cfg_.bidir) {
+          a.dir[1].d_cur = b_dbuf_.RowData(tb * S); a.dir[1].d_next = b_dbuf_.RowData((tb - 1) * S);
+          a.dir[1].y_cur = b_buf_.RowData(tb * S); a.dir[1].y_next = b_buf_.RowData((tb - 1) * S); a.dir[1].y_prev = b_buf_.RowData((tb + 1) * S);
+          a.dir[1].has_next = step > 0;
+        }
+        aslp_lstm_step_backward(&a);
+      }
     }
     CheckK();
     f_.BackwardFinish(od_f, T, S, false, &f_dbuf_, in_diff, 0.0);

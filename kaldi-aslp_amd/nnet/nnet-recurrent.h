@@ -87,10 +87,10 @@ struct LstmDir {
   bool FusedOk() const;  // C % 4 == 0 (16-byte operand loads) and not disabled by ASLP_LSTM_UNFUSED=1 (A/B switch for tests)
   void RefreshEff() const;
   const CuMatrixBase &Weff() const { return R > 0 ? static_cast<const CuMatrixBase &>(w_eff) : w_r; }
-  void ForwardPrepare(const CuMatrixBase &in, int T, int S, bool reverse, const CuMatrixBase *init_state, CuMatrix *buf) const;
+  void ForwardPrepare(const CuMatrixBase &in, int T, int S, bool reverse, const CuMatrixBase *init_state, CuMatrix *buf, bool persistent) const;
   // returns true if the projected output r(1..T) was also stored at out[:, out_col ...] (only with a projection)
   bool ForwardFinish(int T, int S, CuMatrix *buf, CuMatrixBase *out, int out_col) const;                                   // batched projection
-  void BackwardPrepare(const CuMatrixBase &out_diff, int T, int S, CuMatrix *dbuf) const;  // dm_ext
+  void BackwardPrepare(const CuMatrixBase &out_diff, int T, int S, CuMatrix *dbuf, bool persistent) const;  // dm_ext
   void BackwardFinish(const CuMatrixBase &out_diff, int T, int S, bool reverse, CuMatrix *dbuf, CuMatrixBase *in_diff, float beta) const;
 };
 

@@ -1,5 +1,6 @@
 // warp-ctc.cpp -- WarpCtc loss wrapper (see warp-ctc.h; reference src/aslp-nnet/warp-ctc.cc).
 #include "warp-ctc.h"
+#include "scratch.h"
 
 #include <cmath>
 #include <sstream>
@@ -42,8 +43,12 @@ void WarpCtc::EvalGpu(const std::vector<std::string> &utt, const std::vector<int
   ASLP_ASSERT(max_frames * minibatch <= net_out.NumRows());
   if (flat_labels.empty()) flat_labels.push_back(0);  // keep the pointer valid for all-empty label sets
   last_costs_.assign(minibatch, 0.0f);
-  ctcStatus_t st = aslp_ctc_loss_strided(net_out.Data(), net_out.Stride(), diff->Data(), diff->Stride(), flat_labels.data(),
-                                         label_lengths.data(), frame_num_utt.data(), net_out.NumCols(), minibatch, last_costs_.data());
+  ctcStatus_t st;
+  {
+    RegionScope timed("ctc_loss");
+    st = aslp_ctc_loss_strided(net_out.Data(), net_out.Stride(), diff->Data(), diff->Stride(), flat_labels.data(),
+                               label_lengths.data(), frame_num_utt.data(), net_out.NumCols(), minibatch, last_costs_.data());
+  }
   if (st != CTC_STATUS_SUCCESS) ASLP_ERR << "Error: compute_ctc_loss: " << ctcGetStatusString(st);
 
   bool checked_finite = false;

@@ -1,8 +1,15 @@
 """BASELINE.json cfg3 at its full layer sizes: 4 x BLstmProjectedStreamsLC (C = 512, R = 256, in 40) + AffineTransform
-512 -> 128 + WarpCtc, S = 32 whole-utterance streams as aslp-nnet-train-warp-ctc-streams.cc:158-223 drives them
-(SetSeqLengths -> Propagate -> WarpCtc::Eval -> Backpropagate), two steps with momentum 0.9, against the oracle chain
+512 -> 128 + WarpCtc, S = 32 whole-utterance streams: the loop body of aslp-nnet-train-warp-ctc-streams.cc:158-223
+(SetSeqLengths -> Propagate -> WarpCtc::Eval -> Backpropagate) preceded by ResetLstmStreams(all 1), two steps with momentum
+0.9, against the oracle chain
 (LSTM oracle per layer and direction + affine oracle + the reference-pinned CTC restatement + wrapper logic).  T is kept at
-60 frames (ragged 30..60) so the CPU chain finishes in seconds; every kernel runs at the BASELINE widths."""
+60 frames (ragged 30..60) so the CPU chain finishes in seconds; every kernel runs at the BASELINE widths.
+
+Why the ResetLstmStreams call: Nnet::SetSeqLengths does not reach BLstmProjectedStreamsLC in the reference (nnet-nnet.cc:498-530
+lists seven component types, the LC one is not among them), so under the Warp-CTC tool alone the component never learns the
+number of streams and runs its "nnet-forward" branch -- ONE stream of T*S frames (lc.h:505-512).  The engine reproduces that
+(it is what the log line "Running nnet-forward with per-utterance LSTM-state reset" says); a meaningful multi-stream CTC
+step tells the component its streams the way aslp-nnet-train-blstm-streams-lc.cc does, by ResetLstmStreams."""
 import ctypes as C
 
 import numpy as np
@@ -76,6 +83,7 @@ def test_cfg3_lcblstm_warpctc_two_steps_match_oracle_chain(aslp, oracle, dev, tm
             bk.update(grads[l][1], lr)
             dh = idf
         # ---- engine
+        net.ResetLstmStreams([1] * S)
         net.TrainStepWarpCtc(ctc, torch.from_numpy(x).to(dev), in_len, labels)
         out = net.ComponentOutput(net.NumComponents() - 1, T * S, A)
         assert oracle.rel_err(out, y) < TOL, ("activations", step)
