@@ -48,11 +48,13 @@ def step(i):
 for i in range(3):
     step(i)
 torch.cuda.synchronize()
+aslp.lib.aslp_lstm_seq_polls(1)
 t0 = time.perf_counter()
 for i in range(STEPS):
     step(i + 3)
 torch.cuda.synchronize()
 el = time.perf_counter() - t0
+print("hand-off re-polls per step (all waves): %.0f" % (aslp.lib.aslp_lstm_seq_polls(1) / STEPS))
 print("S=%d  ms/step %.3f  valid frames/s %.0f  rows/s %.0f  xent/frame %.4f" % (
     S, el * 1e3 / STEPS, CHUNK * S * STEPS / el, T * S * STEPS / el,
     (xent.GetStats()["loss"] - xent.GetStats()["entropy"]) / max(1.0, xent.GetStats()["frames"])))

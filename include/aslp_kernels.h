@@ -271,8 +271,8 @@ void aslp_lstm_step_backward(const aslp_lstm_step *a);
  *   y : activation buffer [(T+2)*S x ld] (row = t*S + s), forward: gate columns of rows 1..T hold x-part + bias
  *   d : diff buffer of the same shape (backward only), m columns of rows 1..T hold dL/dm from the layer above
  * Contract: the caller prepared the buffer that is written (y forward, d backward) with aslp_lstm_seq_fill BEFORE it stored
- * anything into it, and calls the kernel only when aslp_lstm_seq_supported says 1 (S <= 32 forward, C <= 1024 forward /
- * G*C <= 2048 backward, the grid co-resident on the device); otherwise it keeps the per-timestep entry points above. */
+ * anything into it, and calls the kernel only when aslp_lstm_seq_supported says 1 (directions x ceil(S / 8) <= 8 chains, C <= 512,
+ * the grid co-resident on the device); otherwise it keeps the per-timestep entry points above. */
 typedef struct aslp_lstm_seq_dir_ {
   float *y;
   float *d;
@@ -290,6 +290,8 @@ int aslp_lstm_seq_supported(const aslp_lstm_seq *a, int backward);
 /* row blocks 0 and T+1 := 0, row blocks 1..T := bytes 0xFF */
 void aslp_lstm_seq_fill(float *buf, int ld, int T, int S);
 void aslp_lstm_seq_forward(const aslp_lstm_seq *a);
+/* diagnostics: hand-off re-polls (per wave) since the last reset, summed over all persistent launches; synchronises */
+unsigned aslp_lstm_seq_polls(int reset);
 void aslp_lstm_seq_backward(const aslp_lstm_seq *a);
 /* GruStreams (nnet-gru-streams.h:275-303, 344-383), columns [z|r|m|g|h] */
 /* GRU recurrence, one timestep, both dependent products fused with their gate arithmetic (csrc/gru_fused.hip):

@@ -1,25 +1,32 @@
 // rnn_persistent.hip -- the LSTM recurrence of a whole sequence as ONE launch per layer and pass (both directions at once).
 //
 // rnn_fused.hip runs one launch per timestep: at S = 32 streams each of those sits on the launch floor (8 us forward,
-// 6 + 4 us backward at C = 512) with half the chip idle.  Here the workgroups stay resident for all T timesteps:
+// 6 + 4 us backward at C = 512) with half the chip idle.  Here the workgroups stay resident for all T timesteps.
 //
-//   forward   workgroup (direction, 4 cells): keeps its 16 rows of W_eff (4 gates x 4 cells, K = C) in REGISTERS as MFMA
-//             B fragments for the whole launch; per timestep it reads m(t-1) of all streams (the only quantity that crosses
-//             workgroups), multiplies (v_mfma_f32_16x16x4_f32, K split over the 4 waves, partial tiles summed through LDS in
-//             wave order), finishes the gate block for its 32 x 4 (stream, cell) pairs and publishes m(t).  c(t-1) of a
-//             pair never leaves its thread's registers.
-//   backward  workgroup (direction, 16 cells, 16 streams): keeps its 16 rows of W_eff^T (K = G*C) in registers, per
-//             timestep reads dGATES(next) of its 16 streams, multiplies, finishes the gate-block backward for its 16 x 16
-//             pairs and publishes its 16 x G gate diffs.  The own-cell terms of the next step (d_c, d_i, d_f, y_f) are
-//             carried in registers.
+// The recurrence decomposes into independent CHAINS: one per (direction, group of 8 streams) -- streams never interact and
+// the two directions of a BLSTM never do either; at S = 32, bidirectional, that is 8 chains.  A chain is served by C / 16
+// workgroups, each owning 16 cells:
+//   forward   keeps its 4 x 16 rows of W_eff (gate x cell, K = C) in REGISTERS as MFMA B fragments for the whole launch; per
+//             timestep reads m(t-1) of the chain's 8 streams (the only quantity that crosses workgroups), multiplies
+//             (v_mfma_f32_16x16x4_f32, one 16 x 16 tile per gate, K split over the 4 waves, partial tiles summed through LDS in
+//             wave order), finishes the gate block for its 8 x 16 (stream, cell) pairs and publishes m(t).  c(t-1) of a pair
+//             never leaves its thread's registers.
+//   backward  keeps its 16 rows of W_eff^T (K = G*C, split over 8 waves) in registers, per timestep reads dGATES(next) of
+//             the chain's 8 streams, multiplies, finishes the gate-block backward for its 8 x 16 pairs and publishes its
+//             16 x G gate diffs.  The own-cell terms of the next step (d_c, d_i, d_f) are carried in registers.
+// Workgroup b serves chain b & 7.  On this chip consecutive workgroups go round-robin to the 8 XCDs, so a chain's C / 16 = 32
+// workgroups (at C = 512) are the 32 CUs of ONE XCD and the hand-off of m(t) stays inside that XCD's L2 (measured: a
+// hand-off through the fabric costs ~2 us each way under load, 6.7 us per timestep; inside one L2 a fraction of that).
+// Nothing depends on that placement for correctness: at kernel start every workgroup publishes the XCC id it runs on, the
+// chain's workgroups read all of them, and only if they agree does the chain use plain (L2-resident) stores; otherwise it
+// stores write-through at agent scope (sc1), which is correct for any placement, just slower.
 //
 // Hand-off between workgroups: the data is its own flag.  The host fills the row blocks 1..T of the activation / diff
 // buffer with the byte 0xFF before the launch (aslp_lstm_seq_fill), i.e. every float is the bit pattern 0xFFFFFFFF, a NaN no
-// arithmetic here produces.  Producers store their 16-byte pieces write-through at agent scope (buffer_store_dwordx4 sc1:
-// the line leaves the XCD's L2); consumers load the pieces they need with agent-scope loads (buffer_load_dwordx4 sc1: not
-// served from the CU's L1) and simply reload until no lane holds the sentinel.  No flag, no fence, no barrier across
-// workgroups, no dependence on which XCD a workgroup landed on; every row block is written exactly once per launch, so
-// there is no reuse hazard.  (MI355X_MICROARCH.md, inter-workgroup visibility: "R2 -- the data is the flag"; sc1 stores and
+// arithmetic here produces.  Producers store 16-byte pieces (plain when the chain shares an L2, else write-through at agent
+// scope: buffer_store_dwordx4 sc1, the line leaves the XCD's L2); consumers load the pieces they need with agent-scope loads
+// (buffer_load_dwordx4 sc1: never served from the CU's L1) and reload until no lane holds the sentinel.  No flag, no fence,
+// no barrier across workgroups; every row block is written exactly once per launch, so there is no reuse hazard.  (MI355X_MICROARCH.md, inter-workgroup visibility: "R2 -- the data is the flag"; sc1 stores and
 // sc1 loads on both sides replace the release / acquire pair.)
 // Every spin is bounded (wall clock): on a timeout the workgroup raises a device-wide abort word, all workgroups leave, and
 // the host reports the failure through aslp_get_last_error -- a wrong result is never silent and the GPU never hangs.
@@ -53,19 +60,47 @@ __device__ __forceinline__ bool has_sentinel(const u32x4 &v) {
 }
 __device__ __forceinline__ float as_f(unsigned u) { return __uint_as_float(u); }
 
-// device-side status: [0] abort flag (zeroed before every launch), host_err: mapped host word, counts timeouts
+// device-side status: abort_flag[0] abort flag (zeroed before every launch), abort_flag[2] running count of hand-off
+// re-polls (diagnostics, aslp_lstm_seq_polls); host_err: mapped host word, counts timeouts
 struct SeqStatus {
   unsigned *abort_flag;
   unsigned *host_err;
 };
 
-// Loads NP 16-byte pieces per lane (off[i]: bytes from the resource base, always inside the buffer; bit i of `valid`: the
-// piece is an operand -- the others are replaced by zeros; `full`: wave-uniform, every piece of every lane is valid) with
-// agent-scope loads until none of them holds the sentinel.  Returns false on timeout / device-wide abort (wave-uniform).
+// Bounded spin bookkeeping shared by the two phases below: false = give up (device-wide abort or 2 s without progress).
+__device__ __forceinline__ bool spin_ok(unsigned spins, long &t0, const SeqStatus &st) {
+  if ((spins & 31u) != 31u) return true;
+  if (__hip_atomic_load(st.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+  const long now = (long)wall_clock64();
+  if (t0 == 0) { t0 = now; return true; }
+  if (now - t0 <= kSpinLimitTicks) return true;
+  if ((threadIdx.x & 63) == 0) {
+    __hip_atomic_store(st.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(st.host_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  return false;
+}
+
+// Waits for and loads this lane's NP 16-byte operand pieces of another workgroup's row block.
+//   off[i]  bytes from the resource base, always inside the buffer; bit i of `valid`: the piece is an operand (the others are
+//           replaced by zeros); `full` (wave-uniform): every piece of every lane is valid
+//   offS    ONE piece of this lane chosen so that the wave's 64 samples touch every producing workgroup: phase 1 polls only
+//           those (1 KiB per wave and attempt -- a poll that re-reads all operands multiplies the fabric traffic of every
+//           waiting workgroup by the number of attempts, measured 9.4 us per timestep); phase 2 loads everything once the
+//           samples have landed and still checks every dword, repeating in the rare case a straggler piece is missing.
+// All loads are agent-scope (sc1).  Returns false on timeout / device-wide abort (wave-uniform).
 template <int NP>
 __device__ __forceinline__ bool load_published(u32x4 (&v)[NP], __amdgpu_buffer_rsrc_t rsrc, const int (&off)[NP], unsigned valid, bool full,
-                                               const SeqStatus &st) {
+                                               int offS, bool validS, const SeqStatus &st, unsigned &polls) {
   long t0 = 0;
+  for (unsigned spins = 0;; spins++) {
+    const u32x4 smp = __builtin_amdgcn_raw_buffer_load_b128(rsrc, offS, 0, kAuxSc1);
+    if (!__any(validS && has_sentinel(smp))) break;
+    asm volatile("" ::: "memory");  // the reload stays inside the loop
+    polls++;
+    if (!spin_ok(spins, t0, st)) return false;
+    __builtin_amdgcn_s_sleep(1);
+  }
   for (unsigned spins = 0;; spins++) {
 #pragma unroll
     for (int i = 0; i < NP; i++) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[i], 0, kAuxSc1);
@@ -78,20 +113,10 @@ __device__ __forceinline__ bool load_published(u32x4 (&v)[NP], __amdgpu_buffer_r
 #pragma unroll
     for (int i = 0; i < NP; i++) bad |= has_sentinel(v[i]);
     if (!__any(bad)) return true;
-    asm volatile("" ::: "memory");  // the reloads stay inside the loop
-    if ((spins & 31u) == 31u) {
-      if (__hip_atomic_load(st.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
-      const long now = (long)wall_clock64();
-      if (t0 == 0) t0 = now;
-      else if (now - t0 > kSpinLimitTicks) {
-        if ((threadIdx.x & 63) == 0) {
-          __hip_atomic_store(st.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_fetch_add(st.host_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-        return false;
-      }
-    }
-    __builtin_amdgcn_s_sleep(2);
+    asm volatile("" ::: "memory");
+    polls += 0x10000u;  // diagnostics: full reloads in the high half
+    if (!spin_ok(spins, t0, st)) return false;
+    __builtin_amdgcn_s_sleep(1);
   }
 }
 
@@ -105,50 +130,111 @@ __device__ __forceinline__ void store_tile16(float *tile, const f32x4 &acc, int 
   tile[(r0 + 3) * kTP + n] = acc.w;
 }
 
+// ---- chain geometry shared by both kernels ------------------------------------------------------------------------
+constexpr int kChainStreams = 8;   // streams per chain (rows 0..7 of the 16-row MFMA tile; rows 8..15 repeat them, outputs unused)
+constexpr int kCellsPerWg = 16;
+constexpr int kMaxChains = 8;      // = XCDs of the chip: workgroup b serves chain b & 7
+constexpr int kMaxWgPerChain = 32; // = CUs of one XCD (C <= 512)
+
+struct ChainRole {
+  int dir, s0, c0;   // direction, first stream, first cell
+  bool active;       // this workgroup has a chain to serve
+  bool local;        // the chain's workgroups share one XCD (one L2): plain stores suffice
+};
+
+// Who am I, and does my chain sit on one XCD?  place: [kMaxChains][kMaxWgPerChain] words, zeroed before the launch.
+__device__ __forceinline__ ChainRole chain_role(const aslp_lstm_seq &a, const SeqStatus &st, unsigned *place, int *lds_flag) {
+  ChainRole r;
+  const int chain = blockIdx.x & (kMaxChains - 1), cb = blockIdx.x >> 3;
+  const int nsg = (a.S + kChainStreams - 1) / kChainStreams, nchains = a.ndir * nsg, wpc = (a.C + kCellsPerWg - 1) / kCellsPerWg;
+  r.active = chain < nchains;
+  r.dir = r.active ? chain % a.ndir : 0;
+  r.s0 = (r.active ? chain / a.ndir : 0) * kChainStreams;
+  r.c0 = cb * kCellsPerWg;
+  r.local = false;
+  if (!r.active) return r;
+  if (threadIdx.x < 64) {  // wave 0
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc = (xcc & 15u) + 1u;  // 0 = "not yet written"
+    unsigned *row = place + chain * kMaxWgPerChain;
+    if (threadIdx.x == 0) __hip_atomic_store(row + cb, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int l = threadIdx.x;
+    unsigned v = xcc;
+    long t0 = 0;
+    bool ok = true;
+    for (unsigned spins = 0;; spins++) {
+      if (l < wpc) v = __hip_atomic_load(row + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!__any(l < wpc && v == 0u)) break;
+      if (!spin_ok(spins, t0, st)) { ok = false; break; }
+      __builtin_amdgcn_s_sleep(4);
+    }
+    const bool same = __all(l >= wpc || v == xcc);
+    if (threadIdx.x == 0) *lds_flag = !ok ? -1 : (same ? 1 : 0);
+  }
+  __syncthreads();
+  const int f = *lds_flag;
+  if (f < 0) r.active = false;  // timed out waiting for the chain to show up: abort word is set, leave
+  r.local = f == 1;
+  return r;
+}
+
 // ---- forward -------------------------------------------------------------------------------------------------------
-// grid (ceil(C / 4), ndir), 256 threads.  NCH: 16-wide K chunks per wave (C <= 64 * NCH).
+// grid 8 * ceil(C / 16) workgroups of 256 threads.  NCH: 16-wide K chunks per wave (C <= 64 * NCH).
 template <bool CIFG, int NCH>
-__global__ void __launch_bounds__(256) lstm_seq_fwd(aslp_lstm_seq a, SeqStatus st) {
+__global__ void __launch_bounds__(256) lstm_seq_fwd(aslp_lstm_seq a, SeqStatus st, unsigned *place) {
   constexpr int G = CIFG ? 3 : 4;
-  __shared__ float red[2][4][2][16 * kTP];
+  __shared__ float red[2][4][G][16 * kTP];
   __shared__ int fail[2][4];
-  const aslp_lstm_seq_dir D = a.dir[blockIdx.y];
+  __shared__ int place_flag;
+  const ChainRole R = chain_role(a, st, place, &place_flag);
+  if (!R.active) return;
+  const aslp_lstm_seq_dir D = a.dir[R.dir];
   const int C = a.C, S = a.S, T = a.T, ld = a.ld;
   const int GC = G * C, oc = GC, oh = GC + C, om = GC + 2 * C;
   constexpr int gi = 1, gf = CIFG ? 1 : 2, go = CIFG ? 2 : 3;
-  const int c0 = blockIdx.x * 4;
+  const int c0 = R.c0, s0 = R.s0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, kg = lane >> 4;
   const int nq = (C + 15) / 16, per = (nq + 3) / 4, q0 = wave * per;
-  // B fragments, resident for the launch: tile column n = gate * 4 + cell
-  f32x4 b[NCH];
+  const int aux_store = R.local ? 0 : kAuxSc1;
+  // B fragments, resident for the launch: tile g = gate g, column n = cell c0 + n
+  f32x4 b[G][NCH];
   {
-    const int gate = l15 >> 2, cell = c0 + (l15 & 3);
-    const bool nvalid = gate < G && cell < C;
-    const float *brow = D.w + (long)(nvalid ? gate * C + cell : 0) * a.ldw;
+    const bool nvalid = c0 + l15 < C;
 #pragma unroll
-    for (int i = 0; i < NCH; i++) {
-      const int k0 = 16 * (q0 + i) + 4 * kg;
-      const bool ok = nvalid && i < per && (q0 + i) < nq && k0 < C;
-      b[i] = ok ? *reinterpret_cast<const f32x4 *>(brow + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < G; g++) {
+      const float *brow = D.w + (long)(g * C + (nvalid ? c0 + l15 : 0)) * a.ldw;
+#pragma unroll
+      for (int i = 0; i < NCH; i++) {
+        const int k0 = 16 * (q0 + i) + 4 * kg;
+        const bool ok = nvalid && i < per && (q0 + i) < nq && k0 < C;
+        b[g][i] = ok ? *reinterpret_cast<const f32x4 *>(brow + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
     }
   }
-  // this lane's operand rows of the two stream tiles and its K offsets (bytes from the row block base)
-  int offA[2 * NCH];
+  // this lane's operand row (tile rows 8..15 repeat rows 0..7: never "unpublished", their products are not read) and K offsets
+  int offA[NCH];
   unsigned validA = 0u;
+  const int arow = min(s0 + (l15 & 7), S - 1);
 #pragma unroll
-  for (int mt = 0; mt < 2; mt++) {
-    const int row = min(16 * mt + l15, S - 1);
-#pragma unroll
-    for (int i = 0; i < NCH; i++) {
-      const int k0 = 16 * (q0 + i) + 4 * kg;
-      const bool ok = i < per && (q0 + i) < nq && k0 < C && 16 * mt < S;
-      offA[mt * NCH + i] = ok ? (row * ld + om + k0) * 4 : 0;
-      validA |= ok ? 1u << (mt * NCH + i) : 0u;
-    }
+  for (int i = 0; i < NCH; i++) {
+    const int k0 = 16 * (q0 + i) + 4 * kg;
+    const bool ok = i < per && (q0 + i) < nq && k0 < C;
+    offA[i] = ok ? (arow * ld + om + k0) * 4 : 0;
+    validA |= ok ? 1u << i : 0u;
   }
-  const bool fullA = per == NCH && nq == 4 * per && (C & 15) == 0 && S > 16;  // uniform: no piece of any lane is padding
+  const bool fullA = per == NCH && nq == 4 * per && (C & 15) == 0;  // uniform: no piece of any lane is padding
+  // readiness sample: chunk l15 % per of the lane's K group -- together the wave's lanes look at a piece of every workgroup
+  // whose cells fall into this wave's K range
+  int offS = 0;
+  bool validS = false;
+  {
+    const int is = l15 % per, k0 = 16 * (q0 + is) + 4 * kg;
+    validS = (q0 + is) < nq && k0 < C;
+    offS = validS ? (arow * ld + om + k0) * 4 : 0;
+  }
   // epilogue role: threads 0..127 own one (stream, cell) pair each
-  const int s = threadIdx.x >> 2, cc = threadIdx.x & 3, cell = c0 + cc;
+  const int sl = threadIdx.x >> 4, cc = threadIdx.x & 15, s = s0 + sl, cell = c0 + cc;
   const bool live = threadIdx.x < 128 && s < S && cell < C;
   const int cq = live ? cell : 0, sq = live ? s : 0;
   const float pf = D.peep_f[cq], po = D.peep_o[cq], pi = CIFG ? 0.f : D.peep_i[cq];
@@ -158,6 +244,7 @@ __global__ void __launch_bounds__(256) lstm_seq_fwd(aslp_lstm_seq a, SeqStatus s
     const int tp0 = D.reverse ? T + 1 : 0;
     if (live) cprev = D.y[((long)tp0 * S + sq) * ld + oc + cq];
   }
+  unsigned polls = 0u;
   for (int step = 0; step < T; step++) {
     const int t = D.reverse ? T - step : 1 + step, tp = D.reverse ? t + 1 : t - 1;
     const int par = step & 1;
@@ -168,36 +255,38 @@ __global__ void __launch_bounds__(256) lstm_seq_fwd(aslp_lstm_seq a, SeqStatus s
       xg = ys[cq]; xf = ys[gf * C + cq]; xo = ys[go * C + cq];
       if (!CIFG) xi = ys[gi * C + cq];
     }
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
     bool ok = true;
     if (!(step == 0 && D.skip_first_product)) {
-      u32x4 av[2 * NCH];
-      ok = load_published<2 * NCH>(av, make_rsrc(D.y + (long)tp * S * ld), offA, validA, fullA, st);
+      u32x4 av[NCH];
+      ok = load_published<NCH>(av, make_rsrc(D.y + (long)tp * S * ld), offA, validA, fullA, offS, validS, st, polls);
 #pragma unroll
       for (int i = 0; i < NCH; i++) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[i].x), b[i].x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[NCH + i].x), b[i].x, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[i].y), b[i].y, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[NCH + i].y), b[i].y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[i].z), b[i].z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[NCH + i].z), b[i].z, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[i].w), b[i].w, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[NCH + i].w), b[i].w, acc1, 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < G; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[i].x), b[g][i].x, acc[g], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < G; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[i].y), b[g][i].y, acc[g], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < G; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[i].z), b[g][i].z, acc[g], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < G; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[i].w), b[g][i].w, acc[g], 0, 0, 0);
       }
     }
-    store_tile16(red[par][wave][0], acc0, lane);
-    store_tile16(red[par][wave][1], acc1, lane);
+#pragma unroll
+    for (int g = 0; g < G; g++) store_tile16(red[par][wave][g], acc[g], lane);
     if (lane == 0) fail[par][wave] = ok ? 0 : 1;
     __syncthreads();
     if (fail[par][0] | fail[par][1] | fail[par][2] | fail[par][3]) return;  // uniform: every wave reads the same four words
-    if (!live) continue;
+    if (threadIdx.x >= 128) continue;  // whole waves: the quad gather below needs every lane of waves 0 and 1
     float pre[G];
 #pragma unroll
     for (int g = 0; g < G; g++) {
-      const int idx = (s & 15) * kTP + g * 4 + cc;
-      float v = red[par][0][s >> 4][idx];
+      const int idx = sl * kTP + cc;
+      float v = red[par][0][g][idx];
 #pragma unroll
-      for (int w = 1; w < 4; w++) v += red[par][w][s >> 4][idx];
+      for (int w = 1; w < 4; w++) v += red[par][w][g][idx];
       pre[g] = v;
     }
     float gg = 0.f, ii = 0.f, ff = 0.f, oo = 0.f, cellv = 0.f, hh = 0.f, mm = 0.f;
@@ -215,32 +304,42 @@ __global__ void __launch_bounds__(256) lstm_seq_fwd(aslp_lstm_seq a, SeqStatus s
       oo = sigmoid_ref(xo + pre[go] + cellv * po);
       mm = hh * oo;
     }
-    // publish m(t) first: it is what the other workgroups wait for.  The quad's four cells are 16 contiguous bytes.
+    // publish m(t) first: it is what the other workgroups wait for.  A quad's four cells are 16 contiguous bytes.
     {
       const float m1 = __shfl_down(mm, 1, 64), m2 = __shfl_down(mm, 2, 64), m3 = __shfl_down(mm, 3, 64);
-      if (cc == 0) {
+      if (live && (cc & 3) == 0) {
         u32x4 pk = {__float_as_uint(mm), __float_as_uint(m1), __float_as_uint(m2), __float_as_uint(m3)};
-        __builtin_amdgcn_raw_buffer_store_b128(pk, make_rsrc(D.y + (long)t * S * ld), (s * ld + om + c0) * 4, 0, kAuxSc1);
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(D.y + (long)t * S * ld);
+        const int off = (s * ld + om + cell) * 4;
+        if (R.local) __builtin_amdgcn_raw_buffer_store_b128(pk, rs, off, 0, 0);
+        else __builtin_amdgcn_raw_buffer_store_b128(pk, rs, off, 0, kAuxSc1);
       }
     }
-    ys[cell] = gg; ys[gf * C + cell] = ff; ys[go * C + cell] = oo; ys[oc + cell] = cellv; ys[oh + cell] = hh;
-    if (!CIFG) ys[gi * C + cell] = ii;
+    if (live) {
+      ys[cell] = gg; ys[gf * C + cell] = ff; ys[go * C + cell] = oo; ys[oc + cell] = cellv; ys[oh + cell] = hh;
+      if (!CIFG) ys[gi * C + cell] = ii;
+    }
     cprev = cellv;
   }
+  (void)aux_store;
+  if (polls && lane == 0) __hip_atomic_fetch_add(st.abort_flag + 2, polls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // diagnostics, once per wave
 }
 
 // ---- backward ------------------------------------------------------------------------------------------------------
-// grid (ceil(C / 16), ceil(S / 16), ndir), 512 threads: 8 waves split K = G*C.  NCH: 16-wide K chunks per wave (G*C <= 128 * NCH).
+// grid 8 * ceil(C / 16) workgroups of 512 threads: 8 waves split K = G*C.  NCH: 16-wide K chunks per wave (G*C <= 128 * NCH).
 template <bool CIFG, int NCH>
-__global__ void __launch_bounds__(512) lstm_seq_bwd(aslp_lstm_seq a, SeqStatus st) {
+__global__ void __launch_bounds__(512) lstm_seq_bwd(aslp_lstm_seq a, SeqStatus st, unsigned *place) {
   constexpr int G = CIFG ? 3 : 4;
   __shared__ float red[2][8][16 * kTP];
   __shared__ int fail[2][8];
-  const aslp_lstm_seq_dir D = a.dir[blockIdx.z];
+  __shared__ int place_flag;
+  const ChainRole R = chain_role(a, st, place, &place_flag);
+  if (!R.active) return;
+  const aslp_lstm_seq_dir D = a.dir[R.dir];
   const int C = a.C, S = a.S, T = a.T, ld = a.ld;
   const int GC = G * C, oc = GC, oh = GC + C, om = GC + 2 * C;
   const int og = 0, oi = C, of = CIFG ? C : 2 * C, oo = CIFG ? 2 * C : 3 * C;
-  const int c0 = blockIdx.x * 16, s0 = blockIdx.y * 16;
+  const int c0 = R.c0, s0 = R.s0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, kg = lane >> 4;
   const int nq = (GC + 15) / 16, per = (nq + 7) / 8, q0 = wave * per;
   f32x4 b[NCH];
@@ -256,44 +355,49 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd(aslp_lstm_seq a, SeqStatus s
   }
   int offA[NCH];
   unsigned validA = 0u;
-  {
-    const int row = min(s0 + l15, S - 1);
+  const int arow = min(s0 + (l15 & 7), S - 1);
 #pragma unroll
-    for (int i = 0; i < NCH; i++) {
-      const int k0 = 16 * (q0 + i) + 4 * kg;
-      const bool ok = i < per && (q0 + i) < nq && k0 < GC;
-      offA[i] = ok ? (row * ld + k0) * 4 : 0;
-      validA |= ok ? 1u << i : 0u;
-    }
+  for (int i = 0; i < NCH; i++) {
+    const int k0 = 16 * (q0 + i) + 4 * kg;
+    const bool ok = i < per && (q0 + i) < nq && k0 < GC;
+    offA[i] = ok ? (arow * ld + k0) * 4 : 0;
+    validA |= ok ? 1u << i : 0u;
   }
   const bool fullA = per == NCH && nq == 8 * per && (GC & 15) == 0;
-  // epilogue role: threads 0..255 own one (stream, cell) pair each
+  int offS = 0;
+  bool validS = false;
+  {
+    const int is = l15 % per, k0 = 16 * (q0 + is) + 4 * kg;
+    validS = (q0 + is) < nq && k0 < GC;
+    offS = validS ? (arow * ld + k0) * 4 : 0;
+  }
+  // epilogue role: threads 0..127 own one (stream, cell) pair each
   const int sl = threadIdx.x >> 4, cc = threadIdx.x & 15, s = s0 + sl, cell = c0 + cc;
-  const bool live = threadIdx.x < 256 && s < S && cell < C;
+  const bool live = threadIdx.x < 128 && s < S && cell < C;
   const int cq = live ? cell : 0, sq = live ? s : 0;
   const float pf = D.peep_f[cq], po = D.peep_o[cq], pi = CIFG ? 0.f : D.peep_i[cq];
   // own-cell quantities of the step processed just before (BPTT order): all zero ahead of the first step
   float dn_c = 0.f, dn_f = 0.f, dn_i = 0.f;
+  unsigned polls = 0u;
   for (int step = 0; step < T; step++) {
     // BPTT runs against the direction's recursion: reverse = 0 (t = T..1), reverse = 1 (t = 1..T)
     const int t = D.reverse ? 1 + step : T - step;
     const int tn = D.reverse ? t - 1 : t + 1, tp = D.reverse ? t + 1 : t - 1;
     const int par = step & 1;
     const long o_ = ((long)t * S + sq) * ld;
-    float dm = 0.f, yo = 0.f, yh = 0.f, yg = 0.f, yf = 0.f, yi = 0.f, yn_f = 0.f, cprev = 0.f, ccur = 0.f;
+    float dm = 0.f, yo = 0.f, yh = 0.f, yg = 0.f, yf = 0.f, yi = 0.f, yn_f = 0.f, cprev = 0.f;
     if (live) {  // everything that does not depend on the other workgroups, requested before the hand-off wait
       dm = D.d[o_ + om + cq];
       yo = D.y[o_ + oo + cq]; yh = D.y[o_ + oh + cq]; yg = D.y[o_ + og + cq]; yf = D.y[o_ + of + cq];
       if (!CIFG) yi = D.y[o_ + oi + cq];
       yn_f = D.y[((long)tn * S + sq) * ld + of + cq];
       cprev = D.y[((long)tp * S + sq) * ld + oc + cq];
-      (void)ccur;
     }
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     bool ok = true;
     if (step > 0) {
       u32x4 av[NCH];
-      ok = load_published<NCH>(av, make_rsrc(D.d + (long)tn * S * ld), offA, validA, fullA, st);
+      ok = load_published<NCH>(av, make_rsrc(D.d + (long)tn * S * ld), offA, validA, fullA, offS, validS, st, polls);
 #pragma unroll
       for (int i = 0; i < NCH; i++) {  // two accumulators: the dependent-issue latency of 16x16x4 (40 cycles) exceeds its issue time (32)
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[i].x), b[i].x, acc0, 0, 0, 0);
@@ -311,7 +415,7 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd(aslp_lstm_seq a, SeqStatus s
       for (int w = 0; w < 8; w++) f |= fail[par][w];
       if (f) return;
     }
-    if (threadIdx.x >= 256) continue;  // whole waves: the quad exchange below needs every lane of waves 0..3
+    if (threadIdx.x >= 128) continue;  // whole waves: the quad exchange below needs every lane of waves 0 and 1
     float psum = red[par][0][sl * kTP + cc];
 #pragma unroll
     for (int w = 1; w < 8; w++) psum += red[par][w][sl * kTP + cc];
@@ -332,7 +436,7 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd(aslp_lstm_seq a, SeqStatus s
       dg = dtanh(yg, dc - dc * yf);
     }
     // publish the gate diffs first.  In the diff buffer gate x of the workgroup's 16 cells is 64 contiguous bytes; lane j of
-    // a quad collects gate j of the quad's four cells (three quad rotations) and stores them as one 16-byte piece.
+    // a quad collects gate j of the quad's four cells (quad rotations) and stores them as one 16-byte piece.
     {
       const int j = lane & 3, qb = lane & ~3;
       float gate[4];
@@ -353,7 +457,10 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd(aslp_lstm_seq a, SeqStatus s
       }
       if (live && j < G) {
         u32x4 pk = {__float_as_uint(out[0]), __float_as_uint(out[1]), __float_as_uint(out[2]), __float_as_uint(out[3])};
-        __builtin_amdgcn_raw_buffer_store_b128(pk, make_rsrc(D.d + (long)t * S * ld), (s * ld + j * C + c0 + (cc & ~3)) * 4, 0, kAuxSc1);
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(D.d + (long)t * S * ld);
+        const int off = (s * ld + j * C + c0 + (cc & ~3)) * 4;
+        if (R.local) __builtin_amdgcn_raw_buffer_store_b128(pk, rs, off, 0, 0);
+        else __builtin_amdgcn_raw_buffer_store_b128(pk, rs, off, 0, kAuxSc1);
       }
     }
     if (live) {
@@ -363,11 +470,13 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd(aslp_lstm_seq a, SeqStatus s
     }
     dn_c = dc; dn_f = df; dn_i = di;
   }
+  if (polls && lane == 0) __hip_atomic_fetch_add(st.abort_flag + 2, polls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
 struct SeqRuntime {
-  unsigned *abort_flag = nullptr;  // device
+  unsigned *abort_flag = nullptr;  // device: [0] abort, [2] poll diagnostics, [16 ...] the placement table of chain_role
+  unsigned *place = nullptr;
   unsigned *host_err = nullptr;    // mapped host memory (device-visible)
   unsigned *host_err_dev = nullptr;
   int num_cu = 0;
@@ -381,7 +490,9 @@ SeqRuntime &seq_runtime() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return;
     rt.num_cu = prop.multiProcessorCount;
-    if (hipMalloc(&rt.abort_flag, 64) != hipSuccess) return;
+    const size_t bytes = 64 + sizeof(unsigned) * kMaxChains * kMaxWgPerChain;
+    if (hipMalloc(&rt.abort_flag, bytes) != hipSuccess || hipMemset(rt.abort_flag, 0, bytes) != hipSuccess) return;
+    rt.place = rt.abort_flag + 16;
     if (hipHostMalloc(&rt.host_err, 64, hipHostMallocMapped) != hipSuccess) return;
     *rt.host_err = 0;
     if (hipHostGetDevicePointer(reinterpret_cast<void **>(&rt.host_err_dev), rt.host_err, 0) != hipSuccess) return;
@@ -392,11 +503,10 @@ SeqRuntime &seq_runtime() {
   return rt;
 }
 
-typedef void (*SeqKernel)(aslp_lstm_seq, SeqStatus);
+typedef void (*SeqKernel)(aslp_lstm_seq, SeqStatus, unsigned *);
 SeqKernel pick_fwd(bool cifg, int C) {
   if (C <= 128) return cifg ? lstm_seq_fwd<true, 2> : lstm_seq_fwd<false, 2>;
   if (C <= 512) return cifg ? lstm_seq_fwd<true, 8> : lstm_seq_fwd<false, 8>;
-  if (C <= 1024) return cifg ? lstm_seq_fwd<true, 16> : lstm_seq_fwd<false, 16>;
   return nullptr;
 }
 SeqKernel pick_bwd(bool cifg, int C) {
@@ -410,15 +520,15 @@ bool seq_args_ok(const aslp_lstm_seq *a) {
   return a && a->ndir >= 1 && a->ndir <= 2 && a->T > 0 && a->S > 0 && a->C > 0 && (a->C & 3) == 0 && (a->ld & 3) == 0 && (a->ldw & 3) == 0;
 }
 
-// the whole grid has to be resident at once: leave one workgroup per CU of slack against the occupancy the runtime reports
-// (MI355X_MICROARCH.md: the API can be one block per CU high) -- unless a single workgroup per CU is all we need
+// the whole grid has to be resident at once.  Where the runtime reports room for two or more workgroups per CU one of them
+// is left as slack (MI355X_MICROARCH.md: the API can be one block per CU high); a kernel that fits exactly once per CU
+// cannot be over-reported -- it would not launch at all -- so one workgroup per CU is accepted as is.
 bool grid_fits(SeqKernel k, int threads, long blocks) {
   SeqRuntime &rt = seq_runtime();
   if (!rt.ok || !k) return false;
   int occ = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(k), threads, 0) != hipSuccess || occ < 1) return false;
-  const long cap = (long)rt.num_cu * (occ >= 2 ? occ - 1 : (blocks <= rt.num_cu / 2 ? 1 : 0));
-  return blocks <= cap;
+  return blocks <= (long)rt.num_cu * (occ >= 2 ? occ - 1 : 1);
 }
 
 }  // namespace
@@ -431,13 +541,10 @@ extern "C" {
 int aslp_lstm_seq_supported(const aslp_lstm_seq *a, int backward) {
   static const bool disabled = getenv("ASLP_LSTM_PERSISTENT") != nullptr && getenv("ASLP_LSTM_PERSISTENT")[0] == '0';
   if (disabled || !seq_args_ok(a)) return 0;
-  if (!backward) {
-    if (a->S > 32) return 0;
-    SeqKernel k = pick_fwd(a->cifg != 0, a->C);
-    return grid_fits(k, 256, (long)((a->C + 3) / 4) * a->ndir) ? 1 : 0;
-  }
-  SeqKernel k = pick_bwd(a->cifg != 0, a->C);
-  return grid_fits(k, 512, (long)((a->C + 15) / 16) * ((a->S + 15) / 16) * a->ndir) ? 1 : 0;
+  const int nsg = (a->S + kChainStreams - 1) / kChainStreams, wpc = (a->C + kCellsPerWg - 1) / kCellsPerWg;
+  if (a->ndir * nsg > kMaxChains || wpc > kMaxWgPerChain) return 0;   // S <= 32 (bidirectional) / 64, C <= 512
+  SeqKernel k = backward ? pick_bwd(a->cifg != 0, a->C) : pick_fwd(a->cifg != 0, a->C);
+  return grid_fits(k, backward ? 512 : 256, (long)kMaxChains * wpc) ? 1 : 0;
 }
 
 void aslp_lstm_seq_fill(float *buf, int ld, int T, int S) {
@@ -454,18 +561,24 @@ static void launch_seq(const aslp_lstm_seq *a, bool backward, const char *who) {
     return;
   }
   SeqRuntime &rt = seq_runtime();
-  ASLP_CHECK_HIP(hipMemsetAsync(rt.abort_flag, 0, 64, cur_stream()));
+  ASLP_CHECK_HIP(hipMemsetAsync(rt.abort_flag, 0, 4, cur_stream()));
+  ASLP_CHECK_HIP(hipMemsetAsync(rt.place, 0, sizeof(unsigned) * kMaxChains * kMaxWgPerChain, cur_stream()));
   SeqStatus st = {rt.abort_flag, rt.host_err_dev};
-  if (!backward) {
-    SeqKernel k = pick_fwd(a->cifg != 0, a->C);
-    hipLaunchKernelGGL(k, dim3((a->C + 3) / 4, a->ndir), dim3(256), 0, cur_stream(), *a, st);
-  } else {
-    SeqKernel k = pick_bwd(a->cifg != 0, a->C);
-    hipLaunchKernelGGL(k, dim3((a->C + 15) / 16, (a->S + 15) / 16, a->ndir), dim3(512), 0, cur_stream(), *a, st);
-  }
+  const int wpc = (a->C + kCellsPerWg - 1) / kCellsPerWg;
+  SeqKernel k = backward ? pick_bwd(a->cifg != 0, a->C) : pick_fwd(a->cifg != 0, a->C);
+  hipLaunchKernelGGL(k, dim3(kMaxChains * wpc), dim3(backward ? 512 : 256), 0, cur_stream(), *a, st, rt.place);
   check_launch(who);
 }
 
+unsigned aslp_lstm_seq_polls(int reset) {
+  SeqRuntime &rt = seq_runtime();
+  unsigned v = 0;
+  if (!rt.ok) return 0;
+  (void)hipStreamSynchronize(cur_stream());
+  (void)hipMemcpy(&v, rt.abort_flag + 2, 4, hipMemcpyDeviceToHost);
+  if (reset) (void)hipMemset(rt.abort_flag + 2, 0, 4);
+  return v;
+}
 void aslp_lstm_seq_forward(const aslp_lstm_seq *a) { launch_seq(a, false, "aslp_lstm_seq_forward"); }
 void aslp_lstm_seq_backward(const aslp_lstm_seq *a) { launch_seq(a, true, "aslp_lstm_seq_backward"); }
 
