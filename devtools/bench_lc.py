@@ -54,6 +54,17 @@ for i in range(STEPS):
     step(i + 3)
 torch.cuda.synchronize()
 el = time.perf_counter() - t0
+if os.environ.get("SEQ_TIMING") == "1":
+    import ctypes as C
+    for mode, name in ((1, "forward"), (2, "backward")):
+        aslp.lib.aslp_lstm_seq_timing(mode, None)
+        for i in range(5):
+            step(i + 100)
+        buf = (C.c_ulonglong * 8)()
+        aslp.lib.aslp_lstm_seq_timing(0, buf)
+        n = max(1, buf[0])
+        print("%s kernel, workgroup 0 wave 0, us per timestep: sample-wait %.2f  load+mfma-issue %.2f  mfma-drain+lds %.2f  barrier %.2f  epilogue %.2f   (L2-local launches %d of %d)"
+              % tuple([name] + [buf[k] * 0.01 / n for k in (1, 2, 3, 4, 5)] + [buf[6], n // T]))
 print("hand-off re-polls per step (all waves): %.0f" % (aslp.lib.aslp_lstm_seq_polls(1) / STEPS))
 print("S=%d  ms/step %.3f  valid frames/s %.0f  rows/s %.0f  xent/frame %.4f" % (
     S, el * 1e3 / STEPS, CHUNK * S * STEPS / el, T * S * STEPS / el,

@@ -292,6 +292,8 @@ void aslp_lstm_seq_fill(float *buf, int ld, int T, int S);
 void aslp_lstm_seq_forward(const aslp_lstm_seq *a);
 /* diagnostics: hand-off re-polls (per wave) since the last reset, summed over all persistent launches; synchronises */
 unsigned aslp_lstm_seq_polls(int reset);
+/* diagnostics (devtools/bench_lc.py): phase timing of the forward kernel, see csrc/rnn_persistent.hip */
+void aslp_lstm_seq_timing(int enable, unsigned long long *out);
 void aslp_lstm_seq_backward(const aslp_lstm_seq *a);
 /* GruStreams (nnet-gru-streams.h:275-303, 344-383), columns [z|r|m|g|h] */
 /* GRU recurrence, one timestep, both dependent products fused with their gate arithmetic (csrc/gru_fused.hip):

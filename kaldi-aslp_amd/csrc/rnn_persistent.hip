@@ -65,7 +65,15 @@ __device__ __forceinline__ float as_f(unsigned u) { return __uint_as_float(u); }
 struct SeqStatus {
   unsigned *abort_flag;
   unsigned *host_err;
+  unsigned long long *timing;  // diagnostics (devtools): NULL, or 8 accumulators of 10 ns ticks written by workgroup 0, wave 0
 };
+__device__ __forceinline__ long tick(const SeqStatus &st) { return st.timing ? (long)wall_clock64() : 0; }
+__device__ __forceinline__ void tock(const SeqStatus &st, int slot, long &t) {
+  if (!st.timing) return;
+  const long now = (long)wall_clock64();
+  if (blockIdx.x == 0 && threadIdx.x == 0) st.timing[slot] += (unsigned long long)(now - t);
+  t = now;
+}
 
 // Bounded spin bookkeeping shared by the two phases below: false = give up (device-wide abort or 2 s without progress).
 __device__ __forceinline__ bool spin_ok(unsigned spins, long &t0, const SeqStatus &st) {
@@ -81,40 +89,20 @@ __device__ __forceinline__ bool spin_ok(unsigned spins, long &t0, const SeqStatu
   return false;
 }
 
-// Waits for and loads this lane's NP 16-byte operand pieces of another workgroup's row block.
-//   off[i]  bytes from the resource base, always inside the buffer; bit i of `valid`: the piece is an operand (the others are
-//           replaced by zeros); `full` (wave-uniform): every piece of every lane is valid
-//   offS    ONE piece of this lane chosen so that the wave's 64 samples touch every producing workgroup: phase 1 polls only
-//           those (1 KiB per wave and attempt -- a poll that re-reads all operands multiplies the fabric traffic of every
-//           waiting workgroup by the number of attempts, measured 9.4 us per timestep); phase 2 loads everything once the
-//           samples have landed and still checks every dword, repeating in the rare case a straggler piece is missing.
-// All loads are agent-scope (sc1).  Returns false on timeout / device-wide abort (wave-uniform).
-template <int NP>
-__device__ __forceinline__ bool load_published(u32x4 (&v)[NP], __amdgpu_buffer_rsrc_t rsrc, const int (&off)[NP], unsigned valid, bool full,
-                                               int offS, bool validS, const SeqStatus &st, unsigned &polls) {
+// Hand-off wait, phase 1: polls ONE piece per lane (offS, chosen so that the wave's 64 samples touch every producing
+// workgroup) until none of them reads "not yet published" -- 1 KiB per wave and attempt; a poll that re-reads all operands
+// multiplies the traffic of every waiting workgroup by the number of attempts (measured: 9.4 us per timestep).  Phase 2 is in
+// the kernels: all operand pieces are requested at once and consumed piece by piece, so the products of the first pieces
+// run while the later ones are still in flight; every dword is still checked, and in the rare case a straggler piece is
+// missing the accumulators are dropped and the step's product repeated.  All loads are agent-scope (sc1).
+// Returns false on timeout / device-wide abort (wave-uniform).
+__device__ __forceinline__ bool wait_sample(__amdgpu_buffer_rsrc_t rsrc, int offS, bool validS, const SeqStatus &st, unsigned &polls) {
   long t0 = 0;
   for (unsigned spins = 0;; spins++) {
     const u32x4 smp = __builtin_amdgcn_raw_buffer_load_b128(rsrc, offS, 0, kAuxSc1);
-    if (!__any(validS && has_sentinel(smp))) break;
+    if (!__any(validS && has_sentinel(smp))) return true;
     asm volatile("" ::: "memory");  // the reload stays inside the loop
     polls++;
-    if (!spin_ok(spins, t0, st)) return false;
-    __builtin_amdgcn_s_sleep(1);
-  }
-  for (unsigned spins = 0;; spins++) {
-#pragma unroll
-    for (int i = 0; i < NP; i++) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[i], 0, kAuxSc1);
-    if (!full) {
-#pragma unroll
-      for (int i = 0; i < NP; i++)
-        if (!((valid >> i) & 1u)) v[i] = u32x4{0u, 0u, 0u, 0u};
-    }
-    bool bad = false;
-#pragma unroll
-    for (int i = 0; i < NP; i++) bad |= has_sentinel(v[i]);
-    if (!__any(bad)) return true;
-    asm volatile("" ::: "memory");
-    polls += 0x10000u;  // diagnostics: full reloads in the high half
     if (!spin_ok(spins, t0, st)) return false;
     __builtin_amdgcn_s_sleep(1);
   }
@@ -249,6 +237,7 @@ __global__ void __launch_bounds__(256) lstm_seq_fwd(aslp_lstm_seq a, SeqStatus s
     const int t = D.reverse ? T - step : 1 + step, tp = D.reverse ? t + 1 : t - 1;
     const int par = step & 1;
     float *ys = D.y + ((long)t * S + sq) * ld;
+    long tm = tick(st);
     // the x-part (+ bias) of this pair's gates: written before the launch, requested before the hand-off wait
     float xg = 0.f, xf = 0.f, xo = 0.f, xi = 0.f;
     if (live) {
@@ -260,24 +249,45 @@ __global__ void __launch_bounds__(256) lstm_seq_fwd(aslp_lstm_seq a, SeqStatus s
     for (int g = 0; g < G; g++) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
     bool ok = true;
     if (!(step == 0 && D.skip_first_product)) {
-      u32x4 av[NCH];
-      ok = load_published<NCH>(av, make_rsrc(D.y + (long)tp * S * ld), offA, validA, fullA, offS, validS, st, polls);
+      const __amdgpu_buffer_rsrc_t rs = make_rsrc(D.y + (long)tp * S * ld);
+      ok = wait_sample(rs, offS, validS, st, polls);
+      tock(st, 1, tm);
+      long t0 = 0;
+      for (unsigned att = 0; ok; att++) {
+        u32x4 av[NCH];
 #pragma unroll
-      for (int i = 0; i < NCH; i++) {
+        for (int i = 0; i < NCH; i++) av[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, offA[i], 0, kAuxSc1);
+        bool bad = false;
 #pragma unroll
-        for (int g = 0; g < G; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[i].x), b[g][i].x, acc[g], 0, 0, 0);
+        for (int i = 0; i < NCH; i++) {
+          if (!fullA && !((validA >> i) & 1u)) av[i] = u32x4{0u, 0u, 0u, 0u};
+          bad |= has_sentinel(av[i]);
 #pragma unroll
-        for (int g = 0; g < G; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[i].y), b[g][i].y, acc[g], 0, 0, 0);
+          for (int g = 0; g < G; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[i].x), b[g][i].x, acc[g], 0, 0, 0);
 #pragma unroll
-        for (int g = 0; g < G; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[i].z), b[g][i].z, acc[g], 0, 0, 0);
+          for (int g = 0; g < G; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[i].y), b[g][i].y, acc[g], 0, 0, 0);
 #pragma unroll
-        for (int g = 0; g < G; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[i].w), b[g][i].w, acc[g], 0, 0, 0);
+          for (int g = 0; g < G; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[i].z), b[g][i].z, acc[g], 0, 0, 0);
+#pragma unroll
+          for (int g = 0; g < G; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[i].w), b[g][i].w, acc[g], 0, 0, 0);
+        }
+        if (!__any(bad)) break;
+        // a piece the samples did not cover had not landed yet: drop the products and repeat (rare)
+#pragma unroll
+        for (int g = 0; g < G; g++) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        asm volatile("" ::: "memory");
+        polls += 0x10000u;  // diagnostics: repeated products in the high half
+        ok = spin_ok(att, t0, st);
+        __builtin_amdgcn_s_sleep(1);
       }
     }
+    tock(st, 2, tm);  // full load landed (the MFMAs below are only issued)
 #pragma unroll
     for (int g = 0; g < G; g++) store_tile16(red[par][wave][g], acc[g], lane);
     if (lane == 0) fail[par][wave] = ok ? 0 : 1;
+    tock(st, 3, tm);  // MFMA + LDS stores
     __syncthreads();
+    tock(st, 4, tm);  // barrier
     if (fail[par][0] | fail[par][1] | fail[par][2] | fail[par][3]) return;  // uniform: every wave reads the same four words
     if (threadIdx.x >= 128) continue;  // whole waves: the quad gather below needs every lane of waves 0 and 1
     float pre[G];
@@ -320,7 +330,9 @@ __global__ void __launch_bounds__(256) lstm_seq_fwd(aslp_lstm_seq a, SeqStatus s
       if (!CIFG) ys[gi * C + cell] = ii;
     }
     cprev = cellv;
+    tock(st, 5, tm);  // epilogue
   }
+  if (st.timing && blockIdx.x == 0 && threadIdx.x == 0) { st.timing[0] += (unsigned long long)T; st.timing[6] += R.local ? 1ull : 0ull; }
   (void)aux_store;
   if (polls && lane == 0) __hip_atomic_fetch_add(st.abort_flag + 2, polls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // diagnostics, once per wave
 }
@@ -385,6 +397,7 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd(aslp_lstm_seq a, SeqStatus s
     const int tn = D.reverse ? t - 1 : t + 1, tp = D.reverse ? t + 1 : t - 1;
     const int par = step & 1;
     const long o_ = ((long)t * S + sq) * ld;
+    long tm = tick(st);
     float dm = 0.f, yo = 0.f, yh = 0.f, yg = 0.f, yf = 0.f, yi = 0.f, yn_f = 0.f, cprev = 0.f;
     if (live) {  // everything that does not depend on the other workgroups, requested before the hand-off wait
       dm = D.d[o_ + om + cq];
@@ -396,19 +409,39 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd(aslp_lstm_seq a, SeqStatus s
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     bool ok = true;
     if (step > 0) {
-      u32x4 av[NCH];
-      ok = load_published<NCH>(av, make_rsrc(D.d + (long)tn * S * ld), offA, validA, fullA, offS, validS, st, polls);
+      const __amdgpu_buffer_rsrc_t rs = make_rsrc(D.d + (long)tn * S * ld);
+      ok = wait_sample(rs, offS, validS, st, polls);
+      tock(st, 1, tm);
+      long t0 = 0;
+      for (unsigned att = 0; ok; att++) {
+        u32x4 av[NCH];
 #pragma unroll
-      for (int i = 0; i < NCH; i++) {  // two accumulators: the dependent-issue latency of 16x16x4 (40 cycles) exceeds its issue time (32)
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[i].x), b[i].x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[i].y), b[i].y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[i].z), b[i].z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[i].w), b[i].w, acc1, 0, 0, 0);
+        for (int i = 0; i < NCH; i++) av[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, offA[i], 0, kAuxSc1);
+        bool bad = false;
+#pragma unroll
+        for (int i = 0; i < NCH; i++) {  // two accumulators: the dependent-issue latency of 16x16x4 (40 cycles) exceeds its issue time (32)
+          if (!fullA && !((validA >> i) & 1u)) av[i] = u32x4{0u, 0u, 0u, 0u};
+          bad |= has_sentinel(av[i]);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[i].x), b[i].x, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[i].y), b[i].y, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[i].z), b[i].z, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[i].w), b[i].w, acc1, 0, 0, 0);
+        }
+        if (!__any(bad)) break;
+        acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+        asm volatile("" ::: "memory");
+        polls += 0x10000u;
+        ok = spin_ok(att, t0, st);
+        __builtin_amdgcn_s_sleep(1);
       }
     }
+    tock(st, 2, tm);
     store_tile16(red[par][wave], acc0 + acc1, lane);
     if (lane == 0) fail[par][wave] = ok ? 0 : 1;
+    tock(st, 3, tm);
     __syncthreads();
+    tock(st, 4, tm);
     {
       int f = 0;
 #pragma unroll
@@ -469,7 +502,9 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd(aslp_lstm_seq a, SeqStatus s
       D.d[o_ + oc + cell] = dc;
     }
     dn_c = dc; dn_f = df; dn_i = di;
+    tock(st, 5, tm);
   }
+  if (st.timing && blockIdx.x == 0 && threadIdx.x == 0) { st.timing[0] += (unsigned long long)T; st.timing[6] += R.local ? 1ull : 0ull; }
   if (polls && lane == 0) __hip_atomic_fetch_add(st.abort_flag + 2, polls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -477,6 +512,8 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd(aslp_lstm_seq a, SeqStatus s
 struct SeqRuntime {
   unsigned *abort_flag = nullptr;  // device: [0] abort, [2] poll diagnostics, [16 ...] the placement table of chain_role
   unsigned *place = nullptr;
+  unsigned long long *timing = nullptr;  // device, 8 words; handed to the kernels only while aslp_lstm_seq_timing(1) is in effect
+  int timing_mode = 0;  // 0 off, 1 forward kernel, 2 backward kernel
   unsigned *host_err = nullptr;    // mapped host memory (device-visible)
   unsigned *host_err_dev = nullptr;
   int num_cu = 0;
@@ -493,6 +530,7 @@ SeqRuntime &seq_runtime() {
     const size_t bytes = 64 + sizeof(unsigned) * kMaxChains * kMaxWgPerChain;
     if (hipMalloc(&rt.abort_flag, bytes) != hipSuccess || hipMemset(rt.abort_flag, 0, bytes) != hipSuccess) return;
     rt.place = rt.abort_flag + 16;
+    if (hipMalloc(&rt.timing, 64) != hipSuccess || hipMemset(rt.timing, 0, 64) != hipSuccess) return;
     if (hipHostMalloc(&rt.host_err, 64, hipHostMallocMapped) != hipSuccess) return;
     *rt.host_err = 0;
     if (hipHostGetDevicePointer(reinterpret_cast<void **>(&rt.host_err_dev), rt.host_err, 0) != hipSuccess) return;
@@ -563,13 +601,26 @@ static void launch_seq(const aslp_lstm_seq *a, bool backward, const char *who) {
   SeqRuntime &rt = seq_runtime();
   ASLP_CHECK_HIP(hipMemsetAsync(rt.abort_flag, 0, 4, cur_stream()));
   ASLP_CHECK_HIP(hipMemsetAsync(rt.place, 0, sizeof(unsigned) * kMaxChains * kMaxWgPerChain, cur_stream()));
-  SeqStatus st = {rt.abort_flag, rt.host_err_dev};
+  SeqStatus st = {rt.abort_flag, rt.host_err_dev, ((rt.timing_mode == 1 && !backward) || (rt.timing_mode == 2 && backward)) ? rt.timing : nullptr};
   const int wpc = (a->C + kCellsPerWg - 1) / kCellsPerWg;
   SeqKernel k = backward ? pick_bwd(a->cifg != 0, a->C) : pick_fwd(a->cifg != 0, a->C);
   hipLaunchKernelGGL(k, dim3(kMaxChains * wpc), dim3(backward ? 512 : 256), 0, cur_stream(), *a, st, rt.place);
   check_launch(who);
 }
 
+// devtools: phase timing of the forward (enable = 1) or backward (2) kernel, workgroup 0, wave 0; 0 switches it off; out (8 words, may be NULL)
+// receives {timesteps, ticks waiting for the readiness sample, full load, MFMA + LDS stores, barrier, epilogue, launches that
+// ran L2-local, -} in 10 ns ticks and clears them.  Synchronises.
+void aslp_lstm_seq_timing(int enable, unsigned long long *out) {
+  SeqRuntime &rt = seq_runtime();
+  if (!rt.ok) return;
+  (void)hipStreamSynchronize(cur_stream());
+  if (out) {
+    (void)hipMemcpy(out, rt.timing, 64, hipMemcpyDeviceToHost);
+    (void)hipMemset(rt.timing, 0, 64);
+  }
+  rt.timing_mode = enable;
+}
 unsigned aslp_lstm_seq_polls(int reset) {
   SeqRuntime &rt = seq_runtime();
   unsigned v = 0;
