@@ -270,13 +270,13 @@ void aslp_lstm_step_backward(const aslp_lstm_step *a);
  * through the buffers themselves (write-through stores, agent-scope loads, "not yet written" = the bit pattern 0xFFFFFFFF).
  *   y : activation buffer [(T+2)*S x ld] (row = t*S + s), forward: gate columns of rows 1..T hold x-part + bias
  *   d : diff buffer of the same shape (backward only), m columns of rows 1..T hold dL/dm from the layer above
- * Contract: the caller prepared the buffer that is written (y forward, d backward) with aslp_lstm_seq_fill BEFORE it stored
- * anything into it, and calls the kernel only when aslp_lstm_seq_supported says 1 (directions x ceil(S / 8) <= 8 chains, C <= 512,
+ * Contract: the caller prepared y with aslp_lstm_seq_fill BEFORE it stored anything into it (forward; the backward pass
+ * exchanges through an internal ring and takes an ordinarily zero-initialised d), and calls the kernel only when aslp_lstm_seq_supported says 1 (directions x ceil(S / 8) <= 8 chains, C <= 512,
  * the grid co-resident on the device); otherwise it keeps the per-timestep entry points above. */
 typedef struct aslp_lstm_seq_dir_ {
   float *y;
   float *d;
-  const float *w;                         /* forward: W_eff [G*C x C]; backward: W_eff^T [C x G*C] */
+  const float *w;                         /* W_eff [G*C x C], both passes */
   const float *peep_i, *peep_f, *peep_o;
   const int32_cuda *seq_lengths;          /* forward length masking (may be NULL) */
   int reverse;                            /* 0: the recursion runs t = 1..T, 1: t = T..1 (BPTT runs against it) */
@@ -287,8 +287,9 @@ typedef struct aslp_lstm_seq_ {
   int ndir, ld, ldw, T, S, C, cifg;
 } aslp_lstm_seq;
 int aslp_lstm_seq_supported(const aslp_lstm_seq *a, int backward);
-/* row blocks 0 and T+1 := 0, row blocks 1..T := bytes 0xFF */
-void aslp_lstm_seq_fill(float *buf, int ld, int T, int S);
+/* row blocks 0 and T+1 := 0 (all ld columns); columns [col0, col0 + ncols) of row blocks 1..T := 0xFFFFFFFF words.
+ * For the forward kernel: col0 = the m column block (G + 2) * C, ncols = C. */
+void aslp_lstm_seq_fill(float *buf, int ld, int T, int S, int col0, int ncols);
 void aslp_lstm_seq_forward(const aslp_lstm_seq *a);
 /* diagnostics: hand-off re-polls (per wave) since the last reset, summed over all persistent launches; synchronises */
 unsigned aslp_lstm_seq_polls(int reset);

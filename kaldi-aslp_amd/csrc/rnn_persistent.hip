@@ -66,6 +66,7 @@ struct SeqStatus {
   unsigned *abort_flag;
   unsigned *host_err;
   unsigned long long *timing;  // diagnostics (devtools): NULL, or 8 accumulators of 10 ns ticks written by workgroup 0, wave 0
+  unsigned epoch;              // launch counter (28 bits, never 0): tags the placement table entries of this launch
 };
 __device__ __forceinline__ long tick(const SeqStatus &st) { return st.timing ? (long)wall_clock64() : 0; }
 __device__ __forceinline__ void tock(const SeqStatus &st, int slot, long &t) {
@@ -130,7 +131,8 @@ struct ChainRole {
   bool local;        // the chain's workgroups share one XCD (one L2): plain stores suffice
 };
 
-// Who am I, and does my chain sit on one XCD?  place: [kMaxChains][kMaxWgPerChain] words, zeroed before the launch.
+// Who am I, and does my chain sit on one XCD?  place: [kMaxChains][kMaxWgPerChain] words; an entry counts once it carries
+// this launch's epoch (a host-side launch counter, st.epoch) -- nothing to clear between launches.
 __device__ __forceinline__ ChainRole chain_role(const aslp_lstm_seq &a, const SeqStatus &st, unsigned *place, int *lds_flag) {
   ChainRole r;
   const int chain = blockIdx.x & (kMaxChains - 1), cb = blockIdx.x >> 3;
@@ -144,7 +146,7 @@ __device__ __forceinline__ ChainRole chain_role(const aslp_lstm_seq &a, const Se
   if (threadIdx.x < 64) {  // wave 0
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    xcc = (xcc & 15u) + 1u;  // 0 = "not yet written"
+    xcc = (xcc & 15u) | (st.epoch << 4);  // entries of earlier launches carry another epoch = "not yet written"
     unsigned *row = place + chain * kMaxWgPerChain;
     if (threadIdx.x == 0) __hip_atomic_store(row + cb, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int l = threadIdx.x;
@@ -153,7 +155,7 @@ __device__ __forceinline__ ChainRole chain_role(const aslp_lstm_seq &a, const Se
     bool ok = true;
     for (unsigned spins = 0;; spins++) {
       if (l < wpc) v = __hip_atomic_load(row + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (!__any(l < wpc && v == 0u)) break;
+      if (!__any(l < wpc && (v >> 4) != st.epoch)) break;
       if (!spin_ok(spins, t0, st)) { ok = false; break; }
       __builtin_amdgcn_s_sleep(4);
     }
@@ -256,7 +258,11 @@ __global__ void __launch_bounds__(256) lstm_seq_fwd(aslp_lstm_seq a, SeqStatus s
       for (unsigned att = 0; ok; att++) {
         u32x4 av[NCH];
 #pragma unroll
-        for (int i = 0; i < NCH; i++) av[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, offA[i], 0, kAuxSc1);
+        for (int i = 0; i < NCH; i++) av[i] = u32x4{0u, 0u, 0u, 0u};
+        if (l15 < kChainStreams) {  // tile rows 8..15 feed products nobody reads: their lanes request nothing
+#pragma unroll
+          for (int i = 0; i < NCH; i++) av[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, offA[i], 0, kAuxSc1);
+        }
         bool bad = false;
 #pragma unroll
         for (int i = 0; i < NCH; i++) {
@@ -338,11 +344,25 @@ __global__ void __launch_bounds__(256) lstm_seq_fwd(aslp_lstm_seq a, SeqStatus s
 }
 
 // ---- backward ------------------------------------------------------------------------------------------------------
-// grid 8 * ceil(C / 16) workgroups of 512 threads: 8 waves split K = G*C.  NCH: 16-wide K chunks per wave (G*C <= 128 * NCH).
-template <bool CIFG, int NCH>
-__global__ void __launch_bounds__(512) lstm_seq_bwd(aslp_lstm_seq a, SeqStatus st, unsigned *place) {
-  constexpr int G = CIFG ? 3 : 4;
-  __shared__ float red[2][8][16 * kTP];
+// d_m(t) = dm_ext(t) + dGATES(next) W_eff is a product over K = G*C gate columns.  Partitioned by OUTPUT cell (like the forward
+// pass) every workgroup would have to pull all of dGATES(next) of its chain -- 64 KiB per workgroup and timestep through the
+// CU's 64 B/clk path, measured 2.5 us of a 7 us timestep.  It is partitioned by INPUT instead: a workgroup multiplies the
+// 16 x G gate diffs it produced itself at the previous step (they never leave the CU: LDS) with its 16 x G ROWS of W_eff
+// (registers), which yields its share of d_m for ALL cells of the chain; the shares travel -- 512 B to each of the chain's
+// workgroups -- and every workgroup adds up the C / 16 shares of its own 16 cells in workgroup order (deterministic).
+// Traffic per workgroup and timestep: 16 KiB out, 16 KiB in.
+//   inbox[ring slot][chain][consumer block][producer block][tile row group 0..1][column 0..15] of f32x4 (4 tile rows):
+//   exactly the accumulator layout of v_mfma_f32_16x16x4_f32, so a producer's lanes store their accumulators as they are.
+// The inbox is a ring (kRing slots, slot = timestep % kRing): a consumer writes the sentinel back over what it has read and
+// drains those stores (vmcnt(0)) before it goes on -- its next publication, and through it every later write to that
+// slot by anybody, is therefore ordered after the reset.
+// grid 8 * ceil(C / 16) workgroups of 512 threads.  TPW: N tiles per wave (C <= 128 * TPW).
+constexpr int kRing = 4;
+template <bool CIFG, int TPW>
+__global__ void __launch_bounds__(512) lstm_seq_bwd(aslp_lstm_seq a, SeqStatus st, unsigned *place, float *inbox) {
+  constexpr int G = CIFG ? 3 : 4, KS = 4 * G;  // KS: MFMA k-steps over the workgroup's own 16 * G gate columns
+  __shared__ __attribute__((aligned(16))) float own_dg[2][kChainStreams][16 * G + 4];   // [parity][stream][gate * 16 + cell]
+  __shared__ __attribute__((aligned(16))) float shares[kMaxWgPerChain * 2 * 16 * 4];     // [producer][row group][column][row]
   __shared__ int fail[2][8];
   __shared__ int place_flag;
   const ChainRole R = chain_role(a, st, place, &place_flag);
@@ -352,37 +372,27 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd(aslp_lstm_seq a, SeqStatus s
   const int GC = G * C, oc = GC, oh = GC + C, om = GC + 2 * C;
   const int og = 0, oi = C, of = CIFG ? C : 2 * C, oo = CIFG ? 2 * C : 3 * C;
   const int c0 = R.c0, s0 = R.s0;
+  const int chain = blockIdx.x & (kMaxChains - 1), me = blockIdx.x >> 3, wpc = (C + kCellsPerWg - 1) / kCellsPerWg;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, kg = lane >> 4;
-  const int nq = (GC + 15) / 16, per = (nq + 7) / 8, q0 = wave * per;
-  f32x4 b[NCH];
-  {
-    const bool nvalid = c0 + l15 < C;
-    const float *brow = D.w + (long)(nvalid ? c0 + l15 : 0) * a.ldw;  // W_eff^T row of cell c0 + n
+  // B fragments, resident for the launch: tile j of this wave = the 16 cells of consumer block wave + 8 * j;
+  // k index 16 * q + 4 * kg + jj of the product = own gate column (gate q, cell 4 * kg + jj)
+  float bw[TPW][KS];
 #pragma unroll
-    for (int i = 0; i < NCH; i++) {
-      const int k0 = 16 * (q0 + i) + 4 * kg;
-      const bool ok = nvalid && i < per && (q0 + i) < nq && k0 < GC;
-      b[i] = ok ? *reinterpret_cast<const f32x4 *>(brow + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-  }
-  int offA[NCH];
-  unsigned validA = 0u;
-  const int arow = min(s0 + (l15 & 7), S - 1);
+  for (int j = 0; j < TPW; j++) {
+    const int col = (wave + 8 * j) * 16 + l15;
 #pragma unroll
-  for (int i = 0; i < NCH; i++) {
-    const int k0 = 16 * (q0 + i) + 4 * kg;
-    const bool ok = i < per && (q0 + i) < nq && k0 < GC;
-    offA[i] = ok ? (arow * ld + k0) * 4 : 0;
-    validA |= ok ? 1u << i : 0u;
+    for (int q = 0; q < G; q++)
+#pragma unroll
+      for (int jj = 0; jj < 4; jj++) {
+        const int cellk = c0 + 4 * kg + jj;
+        const bool ok = col < C && cellk < C && (wave + 8 * j) < wpc;
+        bw[j][q * 4 + jj] = ok ? D.w[(long)(q * C + cellk) * a.ldw + col] : 0.f;
+      }
   }
-  const bool fullA = per == NCH && nq == 8 * per && (GC & 15) == 0;
-  int offS = 0;
-  bool validS = false;
-  {
-    const int is = l15 % per, k0 = 16 * (q0 + is) + 4 * kg;
-    validS = (q0 + is) < nq && k0 < GC;
-    offS = validS ? (arow * ld + k0) * 4 : 0;
-  }
+  // inbox geometry
+  const size_t slot_words = (size_t)kMaxChains * kMaxWgPerChain * kMaxWgPerChain * 128;  // floats per ring slot
+  float *chain_box = inbox + (size_t)chain * kMaxWgPerChain * kMaxWgPerChain * 128;
+  const int npiece = wpc * 32;  // 16-byte pieces addressed to this workgroup per timestep: [producer][row group][column]
   // epilogue role: threads 0..127 own one (stream, cell) pair each
   const int sl = threadIdx.x >> 4, cc = threadIdx.x & 15, s = s0 + sl, cell = c0 + cc;
   const bool live = threadIdx.x < 128 && s < S && cell < C;
@@ -399,47 +409,83 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd(aslp_lstm_seq a, SeqStatus s
     const long o_ = ((long)t * S + sq) * ld;
     long tm = tick(st);
     float dm = 0.f, yo = 0.f, yh = 0.f, yg = 0.f, yf = 0.f, yi = 0.f, yn_f = 0.f, cprev = 0.f;
-    if (live) {  // everything that does not depend on the other workgroups, requested before the hand-off wait
+    if (live) {  // everything that does not depend on the other workgroups, requested first
       dm = D.d[o_ + om + cq];
       yo = D.y[o_ + oo + cq]; yh = D.y[o_ + oh + cq]; yg = D.y[o_ + og + cq]; yf = D.y[o_ + of + cq];
       if (!CIFG) yi = D.y[o_ + oi + cq];
       yn_f = D.y[((long)tn * S + sq) * ld + of + cq];
       cprev = D.y[((long)tp * S + sq) * ld + oc + cq];
     }
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     bool ok = true;
     if (step > 0) {
-      const __amdgpu_buffer_rsrc_t rs = make_rsrc(D.d + (long)tn * S * ld);
-      ok = wait_sample(rs, offS, validS, st, polls);
-      tock(st, 1, tm);
-      long t0 = 0;
-      for (unsigned att = 0; ok; att++) {
-        u32x4 av[NCH];
+      float *box = chain_box + (size_t)(step % kRing) * slot_words;
+      // 1. my share of d_m for every cell of the chain: own gate diffs of the previous step (LDS) x my rows of W_eff
+      {
+        f32x4 av[G];
 #pragma unroll
-        for (int i = 0; i < NCH; i++) av[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, offA[i], 0, kAuxSc1);
-        bool bad = false;
+        for (int q = 0; q < G; q++) av[q] = *reinterpret_cast<const f32x4 *>(&own_dg[par ^ 1][l15 & 7][q * 16 + 4 * kg]);
+        f32x4 acc[TPW];
 #pragma unroll
-        for (int i = 0; i < NCH; i++) {  // two accumulators: the dependent-issue latency of 16x16x4 (40 cycles) exceeds its issue time (32)
-          if (!fullA && !((validA >> i) & 1u)) av[i] = u32x4{0u, 0u, 0u, 0u};
-          bad |= has_sentinel(av[i]);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[i].x), b[i].x, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[i].y), b[i].y, acc1, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[i].z), b[i].z, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[i].w), b[i].w, acc1, 0, 0, 0);
+        for (int j = 0; j < TPW; j++) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < G; q++) {
+#pragma unroll
+          for (int j = 0; j < TPW; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q].x, bw[j][q * 4 + 0], acc[j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < TPW; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q].y, bw[j][q * 4 + 1], acc[j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < TPW; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q].z, bw[j][q * 4 + 2], acc[j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < TPW; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q].w, bw[j][q * 4 + 3], acc[j], 0, 0, 0);
         }
-        if (!__any(bad)) break;
-        acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
-        acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-        asm volatile("" ::: "memory");
-        polls += 0x10000u;
-        ok = spin_ok(att, t0, st);
-        __builtin_amdgcn_s_sleep(1);
+        // 2. hand the shares out: tile rows 0..7 are the chain's streams (lanes kg < 2), one 16-byte piece per lane and tile
+        if (kg < 2) {
+          const __amdgpu_buffer_rsrc_t rs = make_rsrc(box);
+#pragma unroll
+          for (int j = 0; j < TPW; j++) {
+            const int cb = wave + 8 * j;
+            if (cb < wpc) {
+              const int off = (((cb * kMaxWgPerChain + me) * 2 + kg) * 16 + l15) * 16;
+              const u32x4 pk = {__float_as_uint(acc[j].x), __float_as_uint(acc[j].y), __float_as_uint(acc[j].z), __float_as_uint(acc[j].w)};
+              if (R.local) __builtin_amdgcn_raw_buffer_store_b128(pk, rs, off, 0, 0);
+              else __builtin_amdgcn_raw_buffer_store_b128(pk, rs, off, 0, kAuxSc1);
+            }
+          }
+        }
       }
+      tock(st, 1, tm);  // product + publication
+      // 3. collect what the chain's workgroups sent me: pieces tid and tid + 512 of [producer][row group][column]
+      {
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(box + (size_t)me * kMaxWgPerChain * 128);
+        const int i0 = threadIdx.x, i1 = threadIdx.x + 512;
+        const bool h0 = i0 < npiece, h1 = i1 < npiece;
+        u32x4 v0 = {0u, 0u, 0u, 0u}, v1 = {0u, 0u, 0u, 0u};
+        long t0 = 0;
+        for (unsigned spins = 0;; spins++) {
+          if (h0) v0 = __builtin_amdgcn_raw_buffer_load_b128(rs, i0 * 16, 0, kAuxSc1);
+          if (h1) v1 = __builtin_amdgcn_raw_buffer_load_b128(rs, i1 * 16, 0, kAuxSc1);
+          if (!__any((h0 && has_sentinel(v0)) || (h1 && has_sentinel(v1)))) break;
+          asm volatile("" ::: "memory");
+          polls++;
+          if (!spin_ok(spins, t0, st)) { ok = false; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        // give the slot back (sentinel) and make sure that has happened before anything of mine is published again
+        const u32x4 sent = {kSentinel, kSentinel, kSentinel, kSentinel};
+        if (R.local) {
+          if (h0) __builtin_amdgcn_raw_buffer_store_b128(sent, rs, i0 * 16, 0, 0);
+          if (h1) __builtin_amdgcn_raw_buffer_store_b128(sent, rs, i1 * 16, 0, 0);
+        } else {
+          if (h0) __builtin_amdgcn_raw_buffer_store_b128(sent, rs, i0 * 16, 0, kAuxSc1);
+          if (h1) __builtin_amdgcn_raw_buffer_store_b128(sent, rs, i1 * 16, 0, kAuxSc1);
+        }
+        if (h0) *reinterpret_cast<u32x4 *>(&shares[i0 * 4]) = v0;
+        if (h1) *reinterpret_cast<u32x4 *>(&shares[i1 * 4]) = v1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      tock(st, 2, tm);  // collection
     }
-    tock(st, 2, tm);
-    store_tile16(red[par][wave], acc0 + acc1, lane);
     if (lane == 0) fail[par][wave] = ok ? 0 : 1;
-    tock(st, 3, tm);
     __syncthreads();
     tock(st, 4, tm);
     {
@@ -448,72 +494,70 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd(aslp_lstm_seq a, SeqStatus s
       for (int w = 0; w < 8; w++) f |= fail[par][w];
       if (f) return;
     }
-    if (threadIdx.x >= 128) continue;  // whole waves: the quad exchange below needs every lane of waves 0 and 1
-    float psum = red[par][0][sl * kTP + cc];
-#pragma unroll
-    for (int w = 1; w < 8; w++) psum += red[par][w][sl * kTP + cc];
-    dm += psum;
-    const float dh = dtanh(yh, dm * yo);
-    const float dov = dsigm(yo, dm * yh);
-    float dc = dh + dn_c * yn_f;
-    if (!CIFG) dc += dn_i * pi;
-    dc += dn_f * pf;
-    dc += dov * po;
-    float dg, df, di = 0.f;
-    if (!CIFG) {
-      df = dsigm(yf, dc * cprev);
-      di = dsigm(yi, dc * yg);
-      dg = dtanh(yg, dc * yi);
-    } else {
-      df = dsigm(yf, dc * cprev - dc * yg);
-      dg = dtanh(yg, dc - dc * yf);
-    }
-    // publish the gate diffs first.  In the diff buffer gate x of the workgroup's 16 cells is 64 contiguous bytes; lane j of
-    // a quad collects gate j of the quad's four cells (quad rotations) and stores them as one 16-byte piece.
-    {
-      const int j = lane & 3, qb = lane & ~3;
-      float gate[4];
-      gate[0] = dg;
-      if (!CIFG) { gate[1] = di; gate[2] = df; gate[3] = dov; }
-      else { gate[1] = df; gate[2] = dov; gate[3] = 0.f; }
-      float out[4];
-#pragma unroll
-      for (int p = 0; p < 4; p++) out[p] = 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        // lane p sends gate[(p - r) & 3]; lane j receives from p = (j + r) & 3, i.e. gate j of quad cell p
-        const int gsel = (j - r) & 3;
-        const float send = gsel == 0 ? gate[0] : gsel == 1 ? gate[1] : gsel == 2 ? gate[2] : gate[3];
-        const float recv = __shfl(send, qb + ((j + r) & 3), 64);
-        const int p = (j + r) & 3;
-        if (p == 0) out[0] = recv; else if (p == 1) out[1] = recv; else if (p == 2) out[2] = recv; else out[3] = recv;
+    if (threadIdx.x < 128) {
+      if (step > 0) {  // shares of my 16 cells, added in workgroup order
+        float psum = 0.f;
+        const int base = ((sl >> 2) * 16 + cc) * 4 + (sl & 3);
+        for (int p = 0; p < wpc; p++) psum += shares[p * 128 + base];
+        dm += psum;
       }
-      if (live && j < G) {
-        u32x4 pk = {__float_as_uint(out[0]), __float_as_uint(out[1]), __float_as_uint(out[2]), __float_as_uint(out[3])};
-        const __amdgpu_buffer_rsrc_t rs = make_rsrc(D.d + (long)t * S * ld);
-        const int off = (s * ld + j * C + c0 + (cc & ~3)) * 4;
-        if (R.local) __builtin_amdgcn_raw_buffer_store_b128(pk, rs, off, 0, 0);
-        else __builtin_amdgcn_raw_buffer_store_b128(pk, rs, off, 0, kAuxSc1);
+      const float dh = dtanh(yh, dm * yo);
+      const float dov = dsigm(yo, dm * yh);
+      float dc = dh + dn_c * yn_f;
+      if (!CIFG) dc += dn_i * pi;
+      dc += dn_f * pf;
+      dc += dov * po;
+      float dg, df, di = 0.f;
+      if (!CIFG) {
+        df = dsigm(yf, dc * cprev);
+        di = dsigm(yi, dc * yg);
+        dg = dtanh(yg, dc * yi);
+      } else {
+        df = dsigm(yf, dc * cprev - dc * yg);
+        dg = dtanh(yg, dc - dc * yf);
       }
+      // the next step's left operand stays here; the buffer copy is for the batched products after the launch
+      float *mine = &own_dg[par][sl][cc];
+      mine[0] = dg;
+      if (!CIFG) { mine[16] = di; mine[32] = df; mine[48] = dov; }
+      else { mine[16] = df; mine[32] = dov; }
+      if (live) {
+        D.d[o_ + og + cell] = dg; D.d[o_ + of + cell] = df; D.d[o_ + oo + cell] = dov;
+        if (!CIFG) D.d[o_ + oi + cell] = di;
+        D.d[o_ + om + cell] = dm;  // the reference's d_m (lc.h:793) -- kept for InfoGradient-style dumps
+        D.d[o_ + oh + cell] = dh;
+        D.d[o_ + oc + cell] = dc;
+      }
+      dn_c = dc; dn_f = df; dn_i = di;
     }
-    if (live) {
-      D.d[o_ + om + cell] = dm;  // the reference's d_m (lc.h:793) -- kept for InfoGradient-style dumps
-      D.d[o_ + oh + cell] = dh;
-      D.d[o_ + oc + cell] = dc;
-    }
-    dn_c = dc; dn_f = df; dn_i = di;
     tock(st, 5, tm);
+    __syncthreads();  // own_dg[par] complete before anybody multiplies with it; shares[] free for the next collection
   }
   if (st.timing && blockIdx.x == 0 && threadIdx.x == 0) { st.timing[0] += (unsigned long long)T; st.timing[6] += R.local ? 1ull : 0ull; }
   if (polls && lane == 0) __hip_atomic_fetch_add(st.abort_flag + 2, polls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Prepares an activation buffer for the forward kernel: boundary row blocks 0 and T + 1 := 0 (all columns), columns
+// [col0, col0 + ncols) of row blocks 1..T := "not yet published".  One launch instead of three memsets over the whole buffer.
+__global__ void __launch_bounds__(256) lstm_seq_fill_kernel(float *buf, int ld, int T, int S, int col0, int ncols) {
+  const int row = blockIdx.x;  // 0 .. (T + 2) * S - 1
+  const bool boundary = row < S || row >= (T + 1) * S;
+  u32x4 *p = reinterpret_cast<u32x4 *>(buf + (long)row * ld + (boundary ? 0 : col0));
+  const int n4 = (boundary ? ld : ncols) >> 2;
+  const unsigned w = boundary ? 0u : kSentinel;
+  const u32x4 v = {w, w, w, w};
+  for (int i = threadIdx.x; i < n4; i += 256) p[i] = v;
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
 struct SeqRuntime {
   unsigned *abort_flag = nullptr;  // device: [0] abort, [2] poll diagnostics, [16 ...] the placement table of chain_role
   unsigned *place = nullptr;
+  float *inbox = nullptr;  // backward: kRing slots of [chain][consumer][producer][128 floats]
   unsigned long long *timing = nullptr;  // device, 8 words; handed to the kernels only while aslp_lstm_seq_timing(1) is in effect
   int timing_mode = 0;  // 0 off, 1 forward kernel, 2 backward kernel
+  unsigned epoch = 0, err_seen = 0;
+  bool ring_ready = false;
   unsigned *host_err = nullptr;    // mapped host memory (device-visible)
   unsigned *host_err_dev = nullptr;
   int num_cu = 0;
@@ -531,6 +575,7 @@ SeqRuntime &seq_runtime() {
     if (hipMalloc(&rt.abort_flag, bytes) != hipSuccess || hipMemset(rt.abort_flag, 0, bytes) != hipSuccess) return;
     rt.place = rt.abort_flag + 16;
     if (hipMalloc(&rt.timing, 64) != hipSuccess || hipMemset(rt.timing, 0, 64) != hipSuccess) return;
+    if (hipMalloc(&rt.inbox, sizeof(float) * (size_t)kRing * kMaxChains * kMaxWgPerChain * kMaxWgPerChain * 128) != hipSuccess) return;
     if (hipHostMalloc(&rt.host_err, 64, hipHostMallocMapped) != hipSuccess) return;
     *rt.host_err = 0;
     if (hipHostGetDevicePointer(reinterpret_cast<void **>(&rt.host_err_dev), rt.host_err, 0) != hipSuccess) return;
@@ -542,15 +587,15 @@ SeqRuntime &seq_runtime() {
 }
 
 typedef void (*SeqKernel)(aslp_lstm_seq, SeqStatus, unsigned *);
+typedef void (*SeqKernelB)(aslp_lstm_seq, SeqStatus, unsigned *, float *);
 SeqKernel pick_fwd(bool cifg, int C) {
   if (C <= 128) return cifg ? lstm_seq_fwd<true, 2> : lstm_seq_fwd<false, 2>;
   if (C <= 512) return cifg ? lstm_seq_fwd<true, 8> : lstm_seq_fwd<false, 8>;
   return nullptr;
 }
-SeqKernel pick_bwd(bool cifg, int C) {
-  const int GC = (cifg ? 3 : 4) * C;
-  if (GC <= 512) return cifg ? lstm_seq_bwd<true, 4> : lstm_seq_bwd<false, 4>;
-  if (GC <= 2048) return cifg ? lstm_seq_bwd<true, 16> : lstm_seq_bwd<false, 16>;
+SeqKernelB pick_bwd(bool cifg, int C) {
+  if (C <= 128) return cifg ? lstm_seq_bwd<true, 1> : lstm_seq_bwd<false, 1>;
+  if (C <= 512) return cifg ? lstm_seq_bwd<true, 4> : lstm_seq_bwd<false, 4>;
   return nullptr;
 }
 
@@ -561,11 +606,11 @@ bool seq_args_ok(const aslp_lstm_seq *a) {
 // the whole grid has to be resident at once.  Where the runtime reports room for two or more workgroups per CU one of them
 // is left as slack (MI355X_MICROARCH.md: the API can be one block per CU high); a kernel that fits exactly once per CU
 // cannot be over-reported -- it would not launch at all -- so one workgroup per CU is accepted as is.
-bool grid_fits(SeqKernel k, int threads, long blocks) {
+bool grid_fits(const void *k, int threads, long blocks) {
   SeqRuntime &rt = seq_runtime();
   if (!rt.ok || !k) return false;
   int occ = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(k), threads, 0) != hipSuccess || occ < 1) return false;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, threads, 0) != hipSuccess || occ < 1) return false;
   return blocks <= (long)rt.num_cu * (occ >= 2 ? occ - 1 : 1);
 }
 
@@ -581,16 +626,15 @@ int aslp_lstm_seq_supported(const aslp_lstm_seq *a, int backward) {
   if (disabled || !seq_args_ok(a)) return 0;
   const int nsg = (a->S + kChainStreams - 1) / kChainStreams, wpc = (a->C + kCellsPerWg - 1) / kCellsPerWg;
   if (a->ndir * nsg > kMaxChains || wpc > kMaxWgPerChain) return 0;   // S <= 32 (bidirectional) / 64, C <= 512
-  SeqKernel k = backward ? pick_bwd(a->cifg != 0, a->C) : pick_fwd(a->cifg != 0, a->C);
+  const void *k = backward ? reinterpret_cast<const void *>(pick_bwd(a->cifg != 0, a->C)) : reinterpret_cast<const void *>(pick_fwd(a->cifg != 0, a->C));
   return grid_fits(k, backward ? 512 : 256, (long)kMaxChains * wpc) ? 1 : 0;
 }
 
-void aslp_lstm_seq_fill(float *buf, int ld, int T, int S) {
+void aslp_lstm_seq_fill(float *buf, int ld, int T, int S, int col0, int ncols) {
   if (!buf || T <= 0 || S <= 0 || ld <= 0) return;
-  const size_t block = sizeof(float) * (size_t)S * ld;
-  ASLP_CHECK_HIP(hipMemsetAsync(buf, 0, block, cur_stream()));                                   // history / boundary row block 0
-  ASLP_CHECK_HIP(hipMemsetAsync(buf + (size_t)S * ld, 0xFF, block * (size_t)T, cur_stream()));   // row blocks 1..T: "not yet published"
-  ASLP_CHECK_HIP(hipMemsetAsync(buf + (size_t)(T + 1) * S * ld, 0, block, cur_stream()));        // boundary row block T + 1
+  if ((ld & 3) || (col0 & 3) || (ncols & 3) || col0 < 0 || col0 + ncols > ld || !aligned16(buf)) { set_error("aslp_lstm_seq_fill: 16-byte alignment"); return; }
+  hipLaunchKernelGGL(lstm_seq_fill_kernel, dim3((T + 2) * S), dim3(256), 0, cur_stream(), buf, ld, T, S, col0, ncols);
+  check_launch("aslp_lstm_seq_fill");
 }
 
 static void launch_seq(const aslp_lstm_seq *a, bool backward, const char *who) {
@@ -599,12 +643,22 @@ static void launch_seq(const aslp_lstm_seq *a, bool backward, const char *who) {
     return;
   }
   SeqRuntime &rt = seq_runtime();
-  ASLP_CHECK_HIP(hipMemsetAsync(rt.abort_flag, 0, 4, cur_stream()));
-  ASLP_CHECK_HIP(hipMemsetAsync(rt.place, 0, sizeof(unsigned) * kMaxChains * kMaxWgPerChain, cur_stream()));
-  SeqStatus st = {rt.abort_flag, rt.host_err_dev, ((rt.timing_mode == 1 && !backward) || (rt.timing_mode == 2 && backward)) ? rt.timing : nullptr};
+  // Device-side state is self-cleaning: the placement table is epoch-tagged and every share a backward launch publishes is
+  // consumed and reset inside that launch.  Only after a launch that gave up (the mapped error word moved) are the abort
+  // word and the share ring put back by hand.
+  const size_t slot_bytes = sizeof(float) * (size_t)kMaxChains * kMaxWgPerChain * kMaxWgPerChain * 128;
+  if (*rt.host_err != rt.err_seen || !rt.ring_ready) {
+    rt.err_seen = *rt.host_err;
+    ASLP_CHECK_HIP(hipMemsetAsync(rt.abort_flag, 0, 4, cur_stream()));
+    ASLP_CHECK_HIP(hipMemsetAsync(rt.inbox, 0xFF, slot_bytes * kRing, cur_stream()));
+    rt.ring_ready = true;
+  }
+  rt.epoch = (rt.epoch + 1u) & 0x0FFFFFFFu;
+  if (rt.epoch == 0u) rt.epoch = 1u;
+  SeqStatus st = {rt.abort_flag, rt.host_err_dev, ((rt.timing_mode == 1 && !backward) || (rt.timing_mode == 2 && backward)) ? rt.timing : nullptr, rt.epoch};
   const int wpc = (a->C + kCellsPerWg - 1) / kCellsPerWg;
-  SeqKernel k = backward ? pick_bwd(a->cifg != 0, a->C) : pick_fwd(a->cifg != 0, a->C);
-  hipLaunchKernelGGL(k, dim3(kMaxChains * wpc), dim3(backward ? 512 : 256), 0, cur_stream(), *a, st, rt.place);
+  if (!backward) hipLaunchKernelGGL(pick_fwd(a->cifg != 0, a->C), dim3(kMaxChains * wpc), dim3(256), 0, cur_stream(), *a, st, rt.place);
+  else hipLaunchKernelGGL(pick_bwd(a->cifg != 0, a->C), dim3(kMaxChains * wpc), dim3(512), 0, cur_stream(), *a, st, rt.place, rt.inbox);
   check_launch(who);
 }
 

@@ -227,7 +227,7 @@ void LstmDir::ForwardPrepare(const CuMatrixBase &in, int T, int S, bool reverse,
   RefreshEff();
   if (persistent) {  // row blocks 1..T start as "not yet published" (csrc/rnn_persistent.hip), the two boundary blocks as zero
     buf->Resize((T + 2) * S, Width(), kUndefined);
-    aslp_lstm_seq_fill(buf->Data(), buf->Stride(), T, S);
+    aslp_lstm_seq_fill(buf->Data(), buf->Stride(), T, S, OffM(), C);
   } else {
     buf->Resize((T + 2) * S, Width(), kSetZero);
   }
@@ -251,7 +251,7 @@ void LstmDir::BackwardPrepare(const CuMatrixBase &out_diff, int T, int S, CuMatr
   ASLP_ASSERT(out_diff.NumRows() == T * S && out_diff.NumCols() == Rec());
   if (persistent) {
     dbuf->Resize((T + 2) * S, Width(), kUndefined);
-    aslp_lstm_seq_fill(dbuf->Data(), dbuf->Stride(), T, S);
+    aslp_lstm_seq_fill(dbuf->Data(), dbuf->Stride(), T, S, 0, GC());
   } else {
     dbuf->Resize((T + 2) * S, Width(), kSetZero);
   }
@@ -472,16 +472,16 @@ void LstmFamily::BackpropagateFnc(const CuMatrixBase &in, const CuMatrixBase &, 
     aslp_lstm_seq q = aslp_lstm_seq();
     q.ndir = cfg_.bidir ? 2 : 1; q.ld = 4; q.ldw = 4; q.T = T; q.S = S; q.C = ncell_; q.cifg = cfg_.cifg ? 1 : 0;
     const bool persistent = aslp_lstm_seq_supported(&q, 1) != 0;
-    f_.BackwardPrepare(od_f, T, S, &f_dbuf_, persistent);
-    if (cfg_.bidir) b_.BackwardPrepare(od_b, T, S, &b_dbuf_, persistent);
+    f_.BackwardPrepare(od_f, T, S, &f_dbuf_, false);
+    if (cfg_.bidir) b_.BackwardPrepare(od_b, T, S, &b_dbuf_, false);
     ASLP_ASSERT(f_dbuf_.Stride() == f_buf_.Stride());
     if (persistent) {
-      q.ld = f_dbuf_.Stride(); q.ldw = f_.w_eff_t.Stride();
+      q.ld = f_dbuf_.Stride(); q.ldw = f_.Weff().Stride();
       for (int d = 0; d < q.ndir; d++) {
         const LstmDir &p = d == 0 ? f_ : b_;
         q.dir[d].y = (d == 0 ? f_buf_ : b_buf_).Data();
         q.dir[d].d = (d == 0 ? f_dbuf_ : b_dbuf_).Data();
-        q.dir[d].w = p.w_eff_t.Data();
+        q.dir[d].w = p.Weff().Data();   // the persistent backward kernel multiplies with ROWS of W_eff (csrc/rnn_persistent.hip)
         q.dir[d].peep_i = cfg_.cifg ? nullptr : p.peep_i.Data();
         q.dir[d].peep_f = p.peep_f.Data();
         q.dir[d].peep_o = p.peep_o.Data();
