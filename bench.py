@@ -101,6 +101,115 @@ def ctc_rel_err(aslp, dev):
             "fixture": "tests/golden/ctc_a128_t200.bin (alphabet 128, %d utterances, T <= %d; reference CPU output)" % (g["mb"], g["maxT"])}
 
 
+LC_FLOP_PER_ROW = 70.25e6  # 4 x BLstmProjectedStreamsLC (C 512, R 256, in 40) + Affine 512 -> 128, fwd + bwd + wgrad
+
+
+def cfg3_block(aslp, dev):
+    """BASELINE.json configs[2] beside the headline (extra key `cfg3`): 4 x BLstmProjectedStreamsLC (C 512, R 256, in 40) +
+    AffineTransform 512 -> 128, S = 32 streams, lr 1e-5, momentum 0.9, synthetic data resident in HBM.
+      (i)  chunked: chunk 40 + 20 frames of right context (T = 60), Softmax + Xent on the chunk frames, the streams' state
+           carried from chunk to chunk -- the loop body of aslp-nnet-train-blstm-streams-lc.cc;
+      (ii) whole utterances of U(200, 800) frames padded to the longest, Warp-CTC on the pre-softmax activations (L = T / 4
+           labels) -- the loop body of aslp-nnet-train-warp-ctc-streams.cc:158-223, with ResetLstmStreams telling the LC
+           component its streams (Nnet::SetSeqLengths does not reach it in the reference, nnet-nnet.cc:498-530).
+    Times are wall clock around K steps (synchronised both sides); the recurrence / CTC shares come from a second pass with
+    HIP-event region timers on the launch stream (include/aslp_kernels.h aslp_region_*)."""
+    import numpy as np
+    import torch
+    S, CHUNK, RIGHT, A = 32, 40, 20, 128
+
+    def proto(softmax):
+        lines, d = ["<NnetProto>"], 40
+        for _ in range(4):
+            lines.append("<BLstmProjectedStreamsLC> <InputDim> %d <OutputDim> 512 <CellDim> 512 <ParamScale> 0.02 <ClipGradient> 5.0" % d)
+            d = 512
+        lines.append("<AffineTransform> <InputDim> 512 <OutputDim> %d <BiasMean> 0.0 <BiasRange> 0.0 <ParamStddev> 0.04" % A)
+        if softmax:
+            lines.append("<Softmax> <InputDim> %d <OutputDim> %d" % (A, A))
+        return "\n".join(lines + ["</NnetProto>"]) + "\n"
+
+    def regions(names):
+        out = {}
+        for n in names:
+            ms = C.c_double()
+            cnt = aslp.lib.aslp_region_get(n.encode(), C.byref(ms))
+            out[n] = (int(cnt), ms.value)
+        return out
+
+    def timed(step, warm, k, k_prof, names):
+        for i in range(warm):
+            step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(k):
+            step(warm + i)
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / k
+        aslp.lib.aslp_region_reset()
+        aslp.lib.aslp_region_profile(1)
+        for i in range(k_prof):
+            step(warm + k + i)
+        torch.cuda.synchronize()
+        aslp.lib.aslp_region_profile(0)
+        r = {n: v[1] / k_prof for n, v in regions(names).items()}
+        aslp.lib.aslp_region_reset()
+        return el, r
+
+    g = torch.Generator(device=dev)
+    g.manual_seed(4321)
+    out = {"model": "4 x BLstmProjectedStreamsLC (C 512, R 256, in 40) + AffineTransform 512->128", "streams": S, "dtype": "f32",
+           "flop_per_row": LC_FLOP_PER_ROW, "peak_tflops": F32_MFMA_PEAK_TFLOPS,
+           "recurrence": "persistent kernels, one launch per layer and pass (csrc/rnn_persistent.hip)"}
+    # (i) chunked + Xent
+    T = CHUNK + RIGHT
+    net = aslp.Nnet.Init(proto(True), seed=777)
+    net.SetTrainOptions(learn_rate=1e-5, momentum=0.9)
+    net.SetChunkSize(CHUNK)
+    xent = aslp.Xent()
+    x = torch.randn(T * S, 40, device=dev, generator=g)
+    labels = torch.randint(0, A, (T * S,), device=dev, generator=g, dtype=torch.int32)
+    fw = torch.ones(T * S, device=dev)
+    fw.view(T, S)[CHUNK:] = 0   # right-context frames carry no loss
+
+    def step_x(i):
+        net.ResetLstmStreams([1] * S if i == 0 else [0] * S)
+        net.TrainStepXent(xent, x, labels, fw)
+
+    el, r = timed(step_x, 5, 30, 10, ("lstm_recurrence_fwd", "lstm_recurrence_bwd"))
+    rec = r["lstm_recurrence_fwd"] + r["lstm_recurrence_bwd"]
+    tf = LC_FLOP_PER_ROW * T * S / el / 1e12
+    out["chunked_xent"] = {"chunk": CHUNK, "right_context": RIGHT, "rows_per_step": T * S, "ms_per_step": el * 1e3,
+                           "valid_frames_per_sec": CHUNK * S / el, "tflops": tf, "frac_of_mfma_peak": tf / F32_MFMA_PEAK_TFLOPS,
+                           "recurrence_ms_per_step": rec, "recurrence_share": rec / (el * 1e3),
+                           "recurrent_launches_per_layer_per_pass": 1}
+    del net
+    # (ii) whole utterances + Warp-CTC
+    rng = np.random.default_rng(99)
+    lens = rng.integers(200, 801, S).astype(np.int32)
+    lens[0] = 800
+    Tm = int(lens.max())
+    lab = [[int(v) for v in rng.integers(1, A, max(1, int(t) // 4))] for t in lens]
+    netc = aslp.Nnet.Init(proto(False), seed=777)
+    netc.SetTrainOptions(learn_rate=1e-5 / float(lens.sum()), momentum=0.9)   # the tool's per-frame normalisation of the step
+    ctc = aslp.WarpCtc()
+    xc = torch.randn(Tm * S, 40, device=dev, generator=g)
+
+    def step_c(i):
+        netc.ResetLstmStreams([1] * S)
+        netc.TrainStepWarpCtc(ctc, xc, lens, lab)
+
+    el, r = timed(step_c, 1, 3, 2, ("lstm_recurrence_fwd", "lstm_recurrence_bwd", "ctc_loss"))
+    rec = r["lstm_recurrence_fwd"] + r["lstm_recurrence_bwd"]
+    tf = LC_FLOP_PER_ROW * Tm * S / el / 1e12
+    st = ctc.GetStats()
+    out["whole_utterance_warpctc"] = {"max_frames": Tm, "valid_frames": int(lens.sum()), "rows_per_step": Tm * S, "labels_per_utt": "T/4",
+                                      "ms_per_step": el * 1e3, "valid_frames_per_sec": float(lens.sum()) / el, "rows_per_sec": Tm * S / el,
+                                      "tflops": tf, "frac_of_mfma_peak": tf / F32_MFMA_PEAK_TFLOPS, "recurrence_ms_per_step": rec,
+                                      "recurrence_share": rec / (el * 1e3), "ctc_ms_per_step": r["ctc_loss"],
+                                      "ctc_share": r["ctc_loss"] / (el * 1e3), "avg_ctc_obj_per_sequence": st["obj"] / max(st["sequences"], 1.0)}
+    return out
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` from a bare shell (no launcher environment): start N ranks, one process per GPU, and hand
     back rank 0's JSON line.  This parent never touches the GPU (no torch.cuda call, no HIP call): the children are ordinary
@@ -316,6 +425,10 @@ def main():
                                "traffic": None, "note": "whole-step algorithmic flops (per-kernel events disabled)"}
         if world == 1:
             out["ctc_loss_fp32_rel_err"] = ctc_rel_err(aslp, dev)
+        if world == 1 and not args.no_cfg3:
+            del net
+            torch.cuda.empty_cache()
+            out["cfg3"] = cfg3_block(aslp, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
     if comm is not None:

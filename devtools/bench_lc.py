@@ -66,6 +66,20 @@ if os.environ.get("SEQ_TIMING") == "1":
         print("%s kernel, workgroup 0 wave 0, us per timestep: sample-wait %.2f  load+mfma-issue %.2f  mfma-drain+lds %.2f  barrier %.2f  epilogue %.2f   (L2-local launches %d of %d)"
               % tuple([name] + [buf[k] * 0.01 / n for k in (1, 2, 3, 4, 5)] + [buf[6], n // T]))
 print("hand-off re-polls per step (all waves): %.0f" % (aslp.lib.aslp_lstm_seq_polls(1) / STEPS))
+if os.environ.get("GEMM_PROFILE") == "1":
+    import ctypes as C
+    aslp.lib.aslp_gemm_profile(1)
+    aslp.lib.aslp_gemm_profile_reset()
+    for i in range(5):
+        step(i + 200)
+    torch.cuda.synchronize()
+    aslp.lib.aslp_gemm_profile(0)
+    aslp.lib.aslp_gemm_profile_dump()
+    for vi, name in enumerate(("NT", "NN", "TN", "TT")):
+        fl, ms = C.c_double(), C.c_double()
+        n = aslp.lib.aslp_gemm_profile_get(vi, C.byref(fl), C.byref(ms))
+        if n:
+            print("GEMM %s: %d launches/step, %.1f GF/step, %.3f ms/step, %.1f TFLOP/s" % (name, n / 5, fl.value / 5e9, ms.value / 5, fl.value / ms.value / 1e9))
 print("S=%d  ms/step %.3f  valid frames/s %.0f  rows/s %.0f  xent/frame %.4f" % (
     S, el * 1e3 / STEPS, CHUNK * S * STEPS / el, T * S * STEPS / el,
     (xent.GetStats()["loss"] - xent.GetStats()["entropy"]) / max(1.0, xent.GetStats()["frames"])))

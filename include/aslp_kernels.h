@@ -159,6 +159,7 @@ long aslp_gemm_profile_get(int variant, double *flops, double *ms);
 /* the tile configuration that carried most of that variant's flops since the last reset: returns its number, writes a
  * description ("gemm_f32_glds 64x128x32, 8 waves, LDS-DMA, 3 stages") into buf */
 int aslp_gemm_profile_tile(int variant, char *buf, int buflen);
+void aslp_gemm_profile_dump(void);   /* devtools: per-shape table of the event-timed launches, to stderr */
 /* Named region timers (HIP events on the launch stream, off by default): the engine brackets "lstm_recurrence_fwd",
  * "lstm_recurrence_bwd" (the timestep loops of the LSTM family), "gru_recurrence_fwd" / "_bwd" and "ctc_loss" (Warp-CTC / Eesen
  * forward-backward).  aslp_region_get returns the number of regions recorded under `name` and their summed milliseconds. */

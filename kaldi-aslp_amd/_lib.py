@@ -123,6 +123,7 @@ _sig("aslp_gemm_profile_reset", None)
 _sig("aslp_gemm_force_tile", None, _i)
 _sig("aslp_gemm_profile_get", C.c_long, _i, C.POINTER(C.c_double), C.POINTER(C.c_double))
 _sig("aslp_gemm_profile_tile", _i, _i, C.c_char_p, _i)
+_sig("aslp_gemm_profile_dump", None)
 _sig("aslp_lstm_seq_polls", C.c_uint, _i)
 _sig("aslp_lstm_seq_timing", None, _i, C.POINTER(C.c_ulonglong))
 _sig("aslp_region_profile", None, _i)

@@ -20,6 +20,7 @@
 //     of tile t and written to the other buffer after them -- one barrier per K tile.
 // The K order inside a tile is a permutation of 0..BK-1; fp32 sums are therefore not
 // bitwise those of a k-ascending loop (parity is tolerance-based for GEMM rows).
+#include <cstdio>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -553,6 +554,8 @@ struct GemmProf {
   long launches = 0;
   double flops = 0.0, ms = 0.0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  std::vector<long> pending_shape;  // parallel to pending: (M << 40) | (N << 20) | K of the launch
+  std::map<long, std::pair<long, double>> shape_ms;  // shape -> launches, milliseconds (aslp_gemm_profile_dump)
   std::map<int, double> cfg_flops;  // tile configuration actually launched -> flops it carried
 };
 GemmProf g_prof[4];
@@ -573,13 +576,20 @@ hipEvent_t take_event() {
 }
 
 void drain(GemmProf &p) {
-  for (auto &ev : p.pending) {
+  for (size_t i = 0; i < p.pending.size(); i++) {
+    auto &ev = p.pending[i];
     float ms = 0.f;
-    if (hipEventSynchronize(ev.second) == hipSuccess && hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) p.ms += ms;
+    if (hipEventSynchronize(ev.second) == hipSuccess && hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
+      p.ms += ms;
+      auto &sh = p.shape_ms[p.pending_shape[i]];
+      sh.first++;
+      sh.second += ms;
+    }
     g_event_pool.push_back(ev.first);
     g_event_pool.push_back(ev.second);
   }
   p.pending.clear();
+  p.pending_shape.clear();
 }
 
 int g_force_tile = 0;  // devtools: 0 = heuristic, else 1..5 picks a config
@@ -732,6 +742,7 @@ int aslp_sgemm_ex(int transA, int transB, int M, int N, int K, float alpha, cons
     if (prof) {
       (void)hipEventRecord(e1, cur_stream());
       g_prof[slot].pending.emplace_back(e0, e1);
+      g_prof[slot].pending_shape.push_back(((long)M << 40) | ((long)N << 20) | (long)K);
     }
   }
   return 0;
@@ -761,6 +772,7 @@ void aslp_gemm_profile_reset(void) {
     p.flops = 0.0;
     p.ms = 0.0;
     p.cfg_flops.clear();
+    p.shape_ms.clear();
   }
 }
 long aslp_gemm_profile_get(int variant, double *flops, double *ms) {
@@ -770,6 +782,19 @@ long aslp_gemm_profile_get(int variant, double *flops, double *ms) {
   if (flops) *flops = g_prof[variant].flops;
   if (ms) *ms = g_prof[variant].ms;
   return g_prof[variant].launches;
+}
+void aslp_gemm_profile_dump(void) {  // devtools: per-shape table of the event-timed launches since the last reset, to stderr
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  const char *names[4] = {"NT", "NN", "TN", "TT"};
+  for (int v = 0; v < 4; v++) {
+    drain(g_prof[v]);
+    for (auto &kv : g_prof[v].shape_ms) {
+      const long M = kv.first >> 40, N = (kv.first >> 20) & 0xFFFFF, K = kv.first & 0xFFFFF;
+      const double us = kv.second.second * 1e3 / kv.second.first;
+      std::fprintf(stderr, "gemm %s %6ld x %6ld x %6ld  launches %5ld  avg %8.2f us  %7.1f TFLOP/s\n", names[v], M, N, K, kv.second.first, us,
+                   2.0 * M * N * K / us / 1e6);
+    }
+  }
 }
 int aslp_gemm_profile_tile(int variant, char *buf, int buflen) {
   if (variant < 0 || variant > 3) return 0;

@@ -48,7 +48,7 @@ struct LstmDir {
   // W_eff = W_r W_rm [GC x C] (with projection) and W_eff^T [C x GC]: the only products on the sequential path
   // of the fused recurrence (csrc/rnn_fused.hip); refreshed lazily after every parameter change
   mutable CuMatrix w_eff, w_eff_t;
-  mutable bool eff_dirty = true;
+  mutable bool eff_dirty = true, eff_t_dirty = true;
   bool aliased = false;  // GetGpuParams handed the tensors out (model sync may rewrite them at any time)
   CuVector bias, peep_i, peep_f, peep_o, bias_corr, peep_i_corr, peep_f_corr, peep_o_corr;
 
@@ -86,12 +86,14 @@ struct LstmDir {
   // ---- fused-step path: the per-timestep loop lives in LstmFamily (all directions share a launch) ----
   bool FusedOk() const;  // C % 4 == 0 (16-byte operand loads) and not disabled by ASLP_LSTM_UNFUSED=1 (A/B switch for tests)
   void RefreshEff() const;
+  void RefreshEffT() const;
   const CuMatrixBase &Weff() const { return R > 0 ? static_cast<const CuMatrixBase &>(w_eff) : w_r; }
   void ForwardPrepare(const CuMatrixBase &in, int T, int S, bool reverse, const CuMatrixBase *init_state, CuMatrix *buf, bool persistent) const;
   // returns true if the projected output r(1..T) was also stored at out[:, out_col ...] (only with a projection)
   bool ForwardFinish(int T, int S, CuMatrix *buf, CuMatrixBase *out, int out_col) const;                                   // batched projection
   void BackwardPrepare(const CuMatrixBase &out_diff, int T, int S, CuMatrix *dbuf, bool persistent) const;  // dm_ext
-  void BackwardFinish(const CuMatrixBase &out_diff, int T, int S, bool reverse, CuMatrix *dbuf, CuMatrixBase *in_diff, float beta) const;
+  // with_dr: also form d_r (needed by the W_rm gradient); in_diff == NULL: only that
+  void BackwardFinish(const CuMatrixBase &out_diff, int T, int S, bool reverse, CuMatrix *dbuf, CuMatrixBase *in_diff, float beta, bool with_dr) const;
 };
 
 // Shared implementation; the concrete classes below only fix the configuration.
