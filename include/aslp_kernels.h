@@ -195,7 +195,11 @@ void aslp_bn_backward_act(const float *in, MatrixDim d, const float *out_diff, i
  * forward pass used. */
 void aslp_bn_backward_step(MatrixDim d, const float *out_diff, int od_stride, float *xhat, int xhat_stride, float *scale, float *shift,
                            const float *inv_std, float *dscale, float *dshift, float momentum, float learn_rate, float *in_diff, int id_stride,
-                           const float *act_y, int act_stride);
+                           const float *act_y, int act_stride, const float *in, const float *mean);
+/* xhat == NULL in the forward / backward entry points above: no normalised copy of the input is kept; the backward pass forms
+ * x_hat again from `in` (d.stride) and `mean` with the forward pass' own operations.  Only where this returns 1 (the
+ * single-launch panel kernels: cols % 16 == 0, rows <= 1024) and all operands are 16-byte aligned. */
+int aslp_bn_panel_supported(int rows, int cols);
 void aslp_bn_apply(const float *in, MatrixDim d, float *out, int out_stride, const float *mean, const float *inv_std,
                    const float *scale, const float *shift);
 /* Xent::Eval (nnet-loss.cc:63-122) in one pass over [rows x cols]:

@@ -136,7 +136,8 @@ _sig("aslp_bn_apply", None, _vp, _md, _vp, _i, _vp, _vp, _vp, _vp)
 _sig("aslp_xent_eval", None, _vp, _md, _vp, _i, _vp, _vp, _vp, _i, _vp)
 _sig("aslp_bn_forward_act", None, _vp, _md, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i)
 _sig("aslp_bn_backward_act", None, _vp, _md, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _i)
-_sig("aslp_bn_backward_step", None, _md, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _i, _vp, _i)
+_sig("aslp_bn_backward_step", None, _md, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _i, _vp, _i, _vp, _vp)
+_sig("aslp_bn_panel_supported", _i, _i, _i)
 _sig("aslp_softmax_xent_supported", _i, _i)
 _sig("aslp_softmax_xent_eval", None, _vp, _md, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i)
 _sig("aslp_dropout_forward", None, _vp, _i, _vp, _md, _vp, _i, _f, C.c_ulonglong)

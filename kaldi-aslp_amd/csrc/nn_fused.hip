@@ -9,6 +9,7 @@
 #include "common.h"
 
 namespace aslp {
+unsigned *new_async_error_word(const char *what);  // runtime.cpp
 namespace {
 
 // ---- BatchNormalization ---------------------------------------------------------------
@@ -280,12 +281,16 @@ __global__ void __launch_bounds__(kPanelThreads) bn_forward_panel(const float *_
   }
 }
 
-template <int CG, int SLOTS, bool HAS_Y>
+// RECOMPUTE: no normalised copy of the input was kept by the forward pass; x_hat = (x - mean) * inv_std is formed again from
+// the layer input with the forward kernel's own two operations (same bits), and the in-place D = dy * scale the reference
+// leaves in that buffer is not written at all -- 8.4 MB less traffic each way at [1024 x 2048].
+template <int CG, int SLOTS, bool HAS_Y, bool RECOMPUTE>
 __global__ void __launch_bounds__(kPanelThreads) bn_backward_panel(const float *__restrict__ dy, int ldd, float *__restrict__ xhat, int ldx,
                                                             float *__restrict__ scale, float *__restrict__ shift,
                                                             const float *__restrict__ inv_std, float *__restrict__ dscale,
                                                             float *__restrict__ dshift, float mmt, float neg_lr, bool step,
-                                                            float *__restrict__ in_diff, int ldi, int rows, const float *__restrict__ y, int ldy) {
+                                                            float *__restrict__ in_diff, int ldi, int rows, const float *__restrict__ y, int ldy,
+                                                            const float *__restrict__ xin, int ldxin, const float *__restrict__ mean) {
   constexpr int L = kPanelThreads / CG;
   __shared__ float red[kPanelWaves * CG * 8];
   __shared__ float stat[3][4 * CG];  // S1, S2, the scale the forward pass used
@@ -297,7 +302,16 @@ __global__ void __launch_bounds__(kPanelThreads) bn_backward_panel(const float *
   for (int k = 0; k < SLOTS; k++) {
     const int r = lane + k * L;
     d[k] = r < rows ? *reinterpret_cast<const float4 *>(dy + (long)r * ldd + c) : zero;
-    h[k] = r < rows ? *reinterpret_cast<const float4 *>(xhat + (long)r * ldx + c) : zero;
+    if (RECOMPUTE) h[k] = r < rows ? *reinterpret_cast<const float4 *>(xin + (long)r * ldxin + c) : zero;
+    else h[k] = r < rows ? *reinterpret_cast<const float4 *>(xhat + (long)r * ldx + c) : zero;
+  }
+  if (RECOMPUTE) {
+    const float4 m = *reinterpret_cast<const float4 *>(mean + c), is = *reinterpret_cast<const float4 *>(inv_std + c);
+#pragma unroll
+    for (int k = 0; k < SLOTS; k++) {
+      const int r = lane + k * L;
+      if (r < rows) { h[k].x = (h[k].x - m.x) * is.x; h[k].y = (h[k].y - m.y) * is.y; h[k].z = (h[k].z - m.z) * is.z; h[k].w = (h[k].w - m.w) * is.w; }
+    }
   }
   if (HAS_Y) {
 #pragma unroll
@@ -363,9 +377,273 @@ __global__ void __launch_bounds__(kPanelThreads) bn_backward_panel(const float *
       Dv[i] = D;
       ov[i] = D * iv[i] + xm * ca[i] + cb[i];
     }
-    *reinterpret_cast<float4 *>(xhat + (long)r * ldx + c) = make_float4(Dv[0], Dv[1], Dv[2], Dv[3]);
+    if (!RECOMPUTE) *reinterpret_cast<float4 *>(xhat + (long)r * ldx + c) = make_float4(Dv[0], Dv[1], Dv[2], Dv[3]);
     *reinterpret_cast<float4 *>(in_diff + (long)r * ldi + c) = make_float4(ov[0], ov[1], ov[2], ov[3]);
   }
+}
+
+// ---- cooperative panels ---------------------------------------------------------------------------------------------
+// The panel kernels above give a workgroup 16 columns over ALL rows: 128 workgroups for [1024 x 2048], half the chip idle and
+// 64-byte row segments (measured 1.5-2.2 TB/s).  Here a column panel is 32 columns (one 128-byte line per row) and is shared
+// by Q workgroups, each holding rows/Q rows in registers: 64 x 4 = 256 workgroups.  The Q partial statistics of a panel meet
+// through a tiny inbox in global memory: every workgroup stores its partial into the inbox of each of the Q readers
+// (agent-scope stores), every reader polls its own inbox until all Q partials are there, adds them in workgroup order
+// (so all Q readers -- and every run -- get the same bits), and puts the "nothing here" pattern back before it leaves.
+// The launch is ordered behind the previous one on its stream, so a reader-owned reset needs no further protocol.
+// Workgroups p, p + P, p + 2P, ... share a panel: with P a multiple of 8 they sit on one XCD (speed only).
+constexpr int kCoopCG = 8, kCoopCols = 32, kCoopLanes = kPanelThreads / kCoopCG;
+constexpr unsigned long long kNothing = 0xFFFFFFFFFFFFFFFFull;
+constexpr int kCoopSpinLimit = 1 << 22;  // polls before a reader gives up (seconds): the error word is raised, the output is garbage
+
+template <int NW>  // 8-byte words per column
+__device__ __forceinline__ bool coop_exchange(unsigned long long *inbox, int P, int Q, int p, int q, int pc, const unsigned long long (&mine)[NW],
+                                              unsigned long long (*got)[NW] /* [Q][NW] */, unsigned *err) {
+  // writer: my partial for column pc into every reader's inbox
+  for (int qr = 0; qr < Q; qr++) {
+    unsigned long long *dst = inbox + ((((size_t)p * Q + qr) * Q + q) * kCoopCols + pc) * NW;
+#pragma unroll
+    for (int w = 0; w < NW; w++) __hip_atomic_store(dst + w, mine[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // reader: all Q partials of column pc
+  unsigned long long *src = inbox + (((size_t)p * Q + q) * Q * kCoopCols + pc) * NW;
+  bool ok = true;
+  for (int qw = 0; qw < Q; qw++) {
+    unsigned long long *w0 = src + (size_t)qw * kCoopCols * NW;
+    int spins = 0;
+    for (;;) {
+      bool all = true;
+#pragma unroll
+      for (int w = 0; w < NW; w++) { got[qw][w] = __hip_atomic_load(w0 + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); all &= got[qw][w] != kNothing; }
+      if (all) break;
+      if (++spins > kCoopSpinLimit) { ok = false; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int w = 0; w < NW; w++) __hip_atomic_store(w0 + w, kNothing, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // hand the slot back
+  }
+  if (!ok && pc == 0) __hip_atomic_fetch_add(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  return ok;
+}
+
+template <int SLOTS>
+__global__ void __launch_bounds__(kPanelThreads) bn_forward_coop(const float *__restrict__ in, int ldi, float *__restrict__ out, int ldo,
+                                                          float *__restrict__ xhat, int ldx, const float *__restrict__ scale,
+                                                          const float *__restrict__ shift, float *__restrict__ mean,
+                                                          float *__restrict__ inv_std, double *__restrict__ acc_means,
+                                                          double *__restrict__ acc_vars, float inv_rows, float floor_, int rows,
+                                                          float *__restrict__ act, int lda, int Q, unsigned long long *inbox, unsigned *err) {
+  constexpr int CG = kCoopCG, L = kCoopLanes;
+  __shared__ double red[kPanelWaves * CG * 12];
+  __shared__ float stat[2][4 * CG];
+  const int P = gridDim.x / Q, p = blockIdx.x % P, q = blockIdx.x / P;
+  const int rp = (rows + Q - 1) / Q, r0 = q * rp, r1 = min(rows, r0 + rp);
+  const int cg = threadIdx.x % CG, lane = threadIdx.x / CG;
+  const int c = (p * CG + cg) * 4;
+  float4 x[SLOTS];
+#pragma unroll
+  for (int k = 0; k < SLOTS; k++) {
+    const int r = r0 + lane + k * L;
+    x[k] = r < r1 ? *reinterpret_cast<const float4 *>(in + (long)r * ldi + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  double acc[3][4] = {};
+#pragma unroll
+  for (int k = 0; k < SLOTS; k++) {
+    const float v[4] = {x[k].x, x[k].y, x[k].z, x[k].w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      acc[0][i] += (double)v[i];
+      acc[1][i] += (double)(v[i] * v[i]);
+      acc[2][i] += (double)v[i] * (double)v[i];
+    }
+  }
+  panel_reduce<double, 3, CG>(acc, red);
+  if (threadIdx.x < 4 * CG) {
+    const int pc = threadIdx.x, col = p * CG * 4 + pc;
+    unsigned long long mine[3], got[8][3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) mine[a] = (unsigned long long)__double_as_longlong(panel_total<double, 3, CG>(red, a, pc));
+    coop_exchange<3>(inbox, P, Q, p, q, pc, mine, got, err);
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int qw = 0; qw < Q; qw++) {  // workgroup order: the same bits in all Q readers
+      s0 += __longlong_as_double((long long)got[qw][0]);
+      s1 += __longlong_as_double((long long)got[qw][1]);
+      s2 += __longlong_as_double((long long)got[qw][2]);
+    }
+    const float mu = (float)s0 * inv_rows;
+    const double m = s0 * (double)inv_rows;
+    double var = s2 * (double)inv_rows - m * m;
+    var = var > 0.0 ? var : 0.0;
+    const float is = 1.0f / sqrtf((float)var + floor_);
+    if (q == 0) {
+      mean[col] = mu;
+      inv_std[col] = is;
+      if (acc_means) acc_means[col] += s0;
+      if (acc_vars) acc_vars[col] += s1;
+    }
+    stat[0][pc] = mu;
+    stat[1][pc] = is;
+  }
+  __syncthreads();
+  const float4 g = *reinterpret_cast<const float4 *>(scale + c), b = *reinterpret_cast<const float4 *>(shift + c);
+  const float4 m = *reinterpret_cast<const float4 *>(&stat[0][cg * 4]), is = *reinterpret_cast<const float4 *>(&stat[1][cg * 4]);
+#pragma unroll
+  for (int k = 0; k < SLOTS; k++) {
+    const int r = r0 + lane + k * L;
+    if (r >= r1) break;
+    float4 h, o;
+    h.x = (x[k].x - m.x) * is.x; h.y = (x[k].y - m.y) * is.y; h.z = (x[k].z - m.z) * is.z; h.w = (x[k].w - m.w) * is.w;
+    o.x = h.x * g.x + b.x; o.y = h.y * g.y + b.y; o.z = h.z * g.z + b.z; o.w = h.w * g.w + b.w;
+    if (xhat) *reinterpret_cast<float4 *>(xhat + (long)r * ldx + c) = h;
+    if (out) *reinterpret_cast<float4 *>(out + (long)r * ldo + c) = o;
+    if (act) {
+      float4 y;
+      y.x = sigmoid_ref(o.x); y.y = sigmoid_ref(o.y); y.z = sigmoid_ref(o.z); y.w = sigmoid_ref(o.w);
+      *reinterpret_cast<float4 *>(act + (long)r * lda + c) = y;
+    }
+  }
+}
+
+template <int SLOTS, bool HAS_Y, bool RECOMPUTE>
+__global__ void __launch_bounds__(kPanelThreads) bn_backward_coop(const float *__restrict__ dy, int ldd, float *__restrict__ xhat, int ldx,
+                                                           float *__restrict__ scale, float *__restrict__ shift,
+                                                           const float *__restrict__ inv_std, float *__restrict__ dscale,
+                                                           float *__restrict__ dshift, float mmt, float neg_lr, bool step,
+                                                           float *__restrict__ in_diff, int ldi, int rows, const float *__restrict__ y, int ldy,
+                                                           const float *__restrict__ xin, int ldxin, const float *__restrict__ mean, int Q,
+                                                           unsigned long long *inbox, unsigned *err) {
+  constexpr int CG = kCoopCG, L = kCoopLanes;
+  __shared__ float red[kPanelWaves * CG * 8];
+  __shared__ float stat[3][4 * CG];  // S1, S2, the scale the forward pass used
+  const int P = gridDim.x / Q, p = blockIdx.x % P, q = blockIdx.x / P;
+  const int rp = (rows + Q - 1) / Q, r0 = q * rp, r1 = min(rows, r0 + rp);
+  const int cg = threadIdx.x % CG, lane = threadIdx.x / CG;
+  const int c = (p * CG + cg) * 4;
+  float4 d[SLOTS], h[SLOTS];
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int k = 0; k < SLOTS; k++) {
+    const int r = r0 + lane + k * L;
+    d[k] = r < r1 ? *reinterpret_cast<const float4 *>(dy + (long)r * ldd + c) : zero;
+    if (RECOMPUTE) h[k] = r < r1 ? *reinterpret_cast<const float4 *>(xin + (long)r * ldxin + c) : zero;
+    else h[k] = r < r1 ? *reinterpret_cast<const float4 *>(xhat + (long)r * ldx + c) : zero;
+  }
+  if (RECOMPUTE) {
+    const float4 m = *reinterpret_cast<const float4 *>(mean + c), is = *reinterpret_cast<const float4 *>(inv_std + c);
+#pragma unroll
+    for (int k = 0; k < SLOTS; k++) {
+      const int r = r0 + lane + k * L;
+      if (r < r1) { h[k].x = (h[k].x - m.x) * is.x; h[k].y = (h[k].y - m.y) * is.y; h[k].z = (h[k].z - m.z) * is.z; h[k].w = (h[k].w - m.w) * is.w; }
+    }
+  }
+  if (HAS_Y) {
+#pragma unroll
+    for (int k = 0; k < SLOTS; k++) {
+      const int r = r0 + lane + k * L;
+      const float4 yy = r < r1 ? *reinterpret_cast<const float4 *>(y + (long)r * ldy + c) : zero;
+      {
+#pragma clang fp contract(off)
+        d[k].x = d[k].x * yy.x * (1.0f - yy.x); d[k].y = d[k].y * yy.y * (1.0f - yy.y);
+        d[k].z = d[k].z * yy.z * (1.0f - yy.z); d[k].w = d[k].w * yy.w * (1.0f - yy.w);
+      }
+    }
+  }
+  float acc[2][4] = {};
+#pragma unroll
+  for (int k = 0; k < SLOTS; k++) {
+    acc[0][0] += d[k].x; acc[0][1] += d[k].y; acc[0][2] += d[k].z; acc[0][3] += d[k].w;
+    acc[1][0] += h[k].x * d[k].x; acc[1][1] += h[k].y * d[k].y; acc[1][2] += h[k].z * d[k].z; acc[1][3] += h[k].w * d[k].w;
+  }
+  panel_reduce<float, 2, CG>(acc, red);
+  if (threadIdx.x < 4 * CG) {
+    const int pc = threadIdx.x, col = p * CG * 4 + pc;
+    unsigned long long mine[1], got[8][1];
+    const float p1 = panel_total<float, 2, CG>(red, 0, pc), p2 = panel_total<float, 2, CG>(red, 1, pc);
+    mine[0] = ((unsigned long long)__float_as_uint(p2) << 32) | (unsigned long long)__float_as_uint(p1);   // one granule: {S2, S1}
+    // The scale the forward pass used is fetched BEFORE this workgroup publishes its partial: workgroup q == 0 rewrites it
+    // (the folded SGD step) only after it has seen every partial of the panel, i.e. after every workgroup holds its copy.
+    const float g = scale[col];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    coop_exchange<1>(inbox, P, Q, p, q, pc, mine, got, err);
+    float s1 = 0.f, s2 = 0.f;
+    for (int qw = 0; qw < Q; qw++) { s1 += __uint_as_float((unsigned)got[qw][0]); s2 += __uint_as_float((unsigned)(got[qw][0] >> 32)); }
+    stat[0][pc] = s1;
+    stat[1][pc] = s2;
+    stat[2][pc] = g;
+    if (q == 0) {
+      const float dsh = s1 + mmt * dshift[col], dsc = s2 + mmt * dscale[col];
+      dshift[col] = dsh;
+      dscale[col] = dsc;
+      if (step) {
+        scale[col] = g + neg_lr * dsc;
+        shift[col] += neg_lr * dsh;
+      }
+    }
+  }
+  __syncthreads();
+  const float invB = 1.0f / (float)rows;
+  if (in_diff != nullptr) {
+    const float4 iv4 = *reinterpret_cast<const float4 *>(inv_std + c);
+    const float iv[4] = {iv4.x, iv4.y, iv4.z, iv4.w};
+    float gv[4], ca[4], cb[4];  // per column: in_diff = D*inv + xm * ca + cb
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const float g = stat[2][cg * 4 + i], inv = iv[i];
+      const float dvar = -0.5f * inv * inv * g * stat[1][cg * 4 + i];
+      const float dmean = -inv * g * stat[0][cg * 4 + i];
+      gv[i] = g;
+      ca[i] = (2.0f * invB) * dvar;
+      cb[i] = invB * dmean;
+    }
+#pragma unroll
+    for (int k = 0; k < SLOTS; k++) {
+      const int r = r0 + lane + k * L;
+      if (r >= r1) break;
+      const float dv[4] = {d[k].x, d[k].y, d[k].z, d[k].w}, hv[4] = {h[k].x, h[k].y, h[k].z, h[k].w};
+      float Dv[4], ov[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const float D = dv[i] * gv[i];
+        const float xm = hv[i] / iv[i];
+        Dv[i] = D;
+        ov[i] = D * iv[i] + xm * ca[i] + cb[i];
+      }
+      if (!RECOMPUTE) *reinterpret_cast<float4 *>(xhat + (long)r * ldx + c) = make_float4(Dv[0], Dv[1], Dv[2], Dv[3]);
+      *reinterpret_cast<float4 *>(in_diff + (long)r * ldi + c) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+    }
+  }
+}
+struct CoopState { unsigned long long *inbox = nullptr; unsigned *err = nullptr; bool tried = false; };
+CoopState &coop_state() {
+  static CoopState st;
+  if (!st.tried) {
+    st.tried = true;
+    const size_t words = (size_t)256 * 8 * 8 * kCoopCols * 3;  // up to 256 panels x Q <= 8 readers x 8 writers
+    unsigned long long *p = nullptr;
+    if (hipMalloc(&p, words * 8) == hipSuccess && hipMemset(p, 0xFF, words * 8) == hipSuccess) {
+      st.err = new_async_error_word("BatchNormalization cooperative kernel: a workgroup timed out waiting for the partial statistics of its panel "
+                                    "(results of that call are invalid)");
+      if (st.err) st.inbox = p;
+    }
+  }
+  return st;
+}
+// rows x cols served by the cooperative kernels?  returns Q (row parts per panel) and the slots per thread, or Q = 0
+struct CoopShape { int q, slots; };
+inline CoopShape bn_coop_shape(int rows, int cols) {
+  static const int forced = [] { const char *e = getenv("ASLP_BN_COOP"); return e ? atoi(e) : -1; }();
+  CoopShape none = {0, 0};
+  if (forced == 0 || cols % kCoopCols != 0) return none;
+  static int num_cu = [] { hipDeviceProp_t pr; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 0; }();
+  const int P = cols / kCoopCols;
+  if (P > 256 || num_cu <= 0) return none;
+  int Q = num_cu / P;              // every workgroup resident at once, one per CU (they wait for each other)
+  Q = Q > 4 ? 4 : Q;
+  if (Q < 2) return none;
+  const int rp = (rows + Q - 1) / Q;
+  if (rp < 64) return none;        // small batches: the single-workgroup panels are already launch-latency bound
+  for (int slots : {4, 8, 16})
+    if (rp <= slots * kCoopLanes) return CoopShape{Q, slots};
+  return none;
 }
 
 // 0: the three-launch path; else column groups per workgroup and row slots per thread (4, 8 or 16).  Measured on the cfg2 step
@@ -550,6 +828,20 @@ void aslp_bn_forward_act(const float *in, MatrixDim d, float *out, int out_strid
              (!xhat || (xhat_stride % 4 == 0 && aligned16(xhat))) && (!act_out || (act_stride % 4 == 0 && aligned16(act_out))) &&
              aligned16(in) && aligned16(mean) && aligned16(inv_std) && aligned16(scale) && aligned16(shift);
   const PanelShape ps = vec ? bn_panel_shape(d.rows, d.cols) : PanelShape{0, 0};
+  const CoopShape cs = (vec && ps.cg) ? bn_coop_shape(d.rows, d.cols) : CoopShape{0, 0};
+  if (cs.q && coop_state().inbox) {
+    CoopState &st = coop_state();
+    const dim3 grid((d.cols / kCoopCols) * cs.q), block(kPanelThreads);
+#define ASLP_BN_FWD_COOP(SLOTS)                                                                                                             \
+    case SLOTS:                                                                                                                             \
+      hipLaunchKernelGGL((bn_forward_coop<SLOTS>), grid, block, 0, cur_stream(), in, d.stride, out, out_stride, xhat, xhat_stride, scale, shift, \
+                         mean, inv_std, acc_means, acc_vars, invB, var_floor, d.rows, act_out, act_stride, cs.q, st.inbox, st.err);           \
+      break;
+    switch (cs.slots) { ASLP_BN_FWD_COOP(4) ASLP_BN_FWD_COOP(8) ASLP_BN_FWD_COOP(16) }
+#undef ASLP_BN_FWD_COOP
+    check_launch("bn_forward_coop");
+    return;
+  }
   if (ps.cg) {
     const dim3 grid(d.cols / (4 * ps.cg)), block(kPanelThreads);
 #define ASLP_BN_FWD_PANEL(CG, SLOTS)                                                                                                       \
@@ -585,27 +877,48 @@ void aslp_bn_apply(const float *in, MatrixDim d, float *out, int out_stride, con
 
 static void bn_backward_impl(MatrixDim d, const float *out_diff, int od_stride, float *xhat, int xhat_stride, float *scale, float *shift,
                              const float *inv_std, float *dscale, float *dshift, float momentum, float *in_diff, int id_stride,
-                             const float *act_y, int act_stride, bool step, float learn_rate) {
+                             const float *act_y, int act_stride, bool step, float learn_rate, const float *in, const float *mean) {
   if (d.rows <= 0 || d.cols <= 0) return;
   const bool y_ok = !act_y || (aligned16(act_y) && act_stride % 4 == 0);
-  const bool panel_ok = od_stride % 4 == 0 && xhat_stride % 4 == 0 && (!in_diff || (id_stride % 4 == 0 && aligned16(in_diff))) &&
-                        aligned16(out_diff) && aligned16(xhat) && aligned16(inv_std) && y_ok;
+  const bool recompute = xhat == nullptr;
+  if (recompute && (!in || !mean)) { set_error("aslp_bn_backward: without a normalised copy (xhat == NULL) the layer input and the batch mean are needed"); return; }
+  const bool panel_ok = od_stride % 4 == 0 && (!in_diff || (id_stride % 4 == 0 && aligned16(in_diff))) && aligned16(out_diff) && aligned16(inv_std) && y_ok &&
+                        (recompute ? (d.stride % 4 == 0 && aligned16(in) && aligned16(mean)) : (xhat_stride % 4 == 0 && aligned16(xhat)));
   const PanelShape ps = panel_ok ? bn_panel_shape(d.rows, d.cols) : PanelShape{0, 0};
+  if (!ps.cg && recompute) { set_error("aslp_bn_backward: xhat == NULL is only served by the single-launch panel path (check aslp_bn_panel_supported)"); return; }
+  const CoopShape cs = ps.cg ? bn_coop_shape(d.rows, d.cols) : CoopShape{0, 0};
+  if (cs.q && coop_state().inbox) {
+    CoopState &st = coop_state();
+    const dim3 grid((d.cols / kCoopCols) * cs.q), block(kPanelThreads);
+#define ASLP_BN_BWD_CL(SLOTS, Y, RC)                                                                                                           \
+    hipLaunchKernelGGL((bn_backward_coop<SLOTS, Y, RC>), grid, block, 0, cur_stream(), out_diff, od_stride, xhat, xhat_stride, scale, shift, inv_std, \
+                       dscale, dshift, momentum, -learn_rate, step, in_diff, id_stride, d.rows, act_y, act_stride, in, d.stride, mean, cs.q, st.inbox, st.err)
+#define ASLP_BN_BWD_COOP(SLOTS)                                                                      \
+    case SLOTS:                                                                                      \
+      if (act_y) { if (recompute) ASLP_BN_BWD_CL(SLOTS, true, true); else ASLP_BN_BWD_CL(SLOTS, true, false); }     \
+      else { if (recompute) ASLP_BN_BWD_CL(SLOTS, false, true); else ASLP_BN_BWD_CL(SLOTS, false, false); }         \
+      break;
+    switch (cs.slots) { ASLP_BN_BWD_COOP(4) ASLP_BN_BWD_COOP(8) ASLP_BN_BWD_COOP(16) }
+#undef ASLP_BN_BWD_COOP
+#undef ASLP_BN_BWD_CL
+    check_launch("bn_backward_coop");
+    return;
+  }
   if (ps.cg) {
     const dim3 grid(d.cols / (4 * ps.cg)), block(kPanelThreads);
-#define ASLP_BN_BWD_PANEL(CG, SLOTS)                                                                                                              \
-    case CG * 100 + SLOTS:                                                                                                                       \
-      if (act_y)                                                                                                                                 \
-        hipLaunchKernelGGL((bn_backward_panel<CG, SLOTS, true>), grid, block, 0, cur_stream(), out_diff, od_stride, xhat, xhat_stride, scale, shift, \
-                           inv_std, dscale, dshift, momentum, -learn_rate, step, in_diff, id_stride, d.rows, act_y, act_stride);                  \
-      else                                                                                                                                       \
-        hipLaunchKernelGGL((bn_backward_panel<CG, SLOTS, false>), grid, block, 0, cur_stream(), out_diff, od_stride, xhat, xhat_stride, scale, shift, \
-                           inv_std, dscale, dshift, momentum, -learn_rate, step, in_diff, id_stride, d.rows, act_y, act_stride);                  \
+#define ASLP_BN_BWD_LAUNCH(CG, SLOTS, Y, RC)                                                                                                      \
+    hipLaunchKernelGGL((bn_backward_panel<CG, SLOTS, Y, RC>), grid, block, 0, cur_stream(), out_diff, od_stride, xhat, xhat_stride, scale, shift,    \
+                       inv_std, dscale, dshift, momentum, -learn_rate, step, in_diff, id_stride, d.rows, act_y, act_stride, in, d.stride, mean)
+#define ASLP_BN_BWD_PANEL(CG, SLOTS)                                                             \
+    case CG * 100 + SLOTS:                                                                      \
+      if (act_y) { if (recompute) ASLP_BN_BWD_LAUNCH(CG, SLOTS, true, true); else ASLP_BN_BWD_LAUNCH(CG, SLOTS, true, false); }   \
+      else { if (recompute) ASLP_BN_BWD_LAUNCH(CG, SLOTS, false, true); else ASLP_BN_BWD_LAUNCH(CG, SLOTS, false, false); }       \
       break;
     switch (ps.cg * 100 + ps.slots) {
       ASLP_BN_BWD_PANEL(4, 4) ASLP_BN_BWD_PANEL(4, 8) ASLP_BN_BWD_PANEL(4, 16)
     }
 #undef ASLP_BN_BWD_PANEL
+#undef ASLP_BN_BWD_LAUNCH
     check_launch("bn_backward_panel");
     return;
   }
@@ -626,17 +939,20 @@ static void bn_backward_impl(MatrixDim d, const float *out_diff, int od_stride, 
 void aslp_bn_backward_act(const float *in, MatrixDim d, const float *out_diff, int od_stride, float *xhat, int xhat_stride, const float *scale,
                           const float *mean, const float *inv_std, float *dscale, float *dshift, float momentum, float *in_diff, int id_stride,
                           const float *act_y, int act_stride) {
-  (void)in; (void)mean;  // (x - mean) is recovered as xhat / inv_std: saves one pass over `in`
+  // with xhat: (x - mean) is recovered as xhat / inv_std; without (panel path only): x_hat is formed again from `in` and `mean`
   bn_backward_impl(d, out_diff, od_stride, xhat, xhat_stride, const_cast<float *>(scale), nullptr, inv_std, dscale, dshift, momentum, in_diff,
-                   id_stride, act_y, act_stride, false, 0.0f);
+                   id_stride, act_y, act_stride, false, 0.0f, in, mean);
 }
 // backward + the component's own Update (scale -= lr*dscale, shift -= lr*dshift) in the statistics finalize
 void aslp_bn_backward_step(MatrixDim d, const float *out_diff, int od_stride, float *xhat, int xhat_stride, float *scale, float *shift,
                            const float *inv_std, float *dscale, float *dshift, float momentum, float learn_rate, float *in_diff, int id_stride,
-                           const float *act_y, int act_stride) {
+                           const float *act_y, int act_stride, const float *in, const float *mean) {
   bn_backward_impl(d, out_diff, od_stride, xhat, xhat_stride, scale, shift, inv_std, dscale, dshift, momentum, in_diff, id_stride, act_y,
-                   act_stride, true, learn_rate);
+                   act_stride, true, learn_rate, in, mean);
 }
+// 1: a [rows x cols] batch is served by the single-launch panel kernels (given 16-byte aligned operands), which need no
+// normalised copy of the input: pass xhat = NULL to the forward and backward entry points and save its 8.4 MB each way
+int aslp_bn_panel_supported(int rows, int cols) { return bn_panel_shape(rows, cols).cg != 0 ? 1 : 0; }
 void aslp_bn_backward(const float *in, MatrixDim d, const float *out_diff, int od_stride, float *xhat, int xhat_stride, const float *scale,
                       const float *mean, const float *inv_std, float *dscale, float *dshift, float momentum, float *in_diff, int id_stride) {
   aslp_bn_backward_act(in, d, out_diff, od_stride, xhat, xhat_stride, scale, mean, inv_std, dscale, dshift, momentum, in_diff, id_stride, nullptr,

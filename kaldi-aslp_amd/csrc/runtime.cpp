@@ -37,6 +37,16 @@ void register_async_error_word(const volatile unsigned *host_word, const char *w
   g_async_errs.push_back({host_word, *host_word, what});
 }
 
+// A fresh mapped host word a kernel can bump (system-scope atomic) to report a failure of its own; returns the device pointer.
+unsigned *new_async_error_word(const char *what) {
+  unsigned *host = nullptr, *dev = nullptr;
+  if (hipHostMalloc(&host, 64, hipHostMallocMapped) != hipSuccess) return nullptr;
+  *host = 0;
+  if (hipHostGetDevicePointer(reinterpret_cast<void **>(&dev), host, 0) != hipSuccess) return nullptr;
+  register_async_error_word(host, what);
+  return dev;
+}
+
 void set_error(const std::string &msg) {
   std::lock_guard<std::mutex> lk(g_err_mu);
   if (g_err.empty()) g_err = msg;  // keep the first one: it is the cause

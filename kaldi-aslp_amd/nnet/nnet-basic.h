@@ -598,8 +598,8 @@ class BatchNormalization : public UpdatableComponent {
   }
   void PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) {  // :177-220
     if (!acc_cleaned_) { acc_cleaned_ = true; CleanAccs(); }
-    if (XsharpO_.NumRows() != in.NumRows() || XsharpO_.NumCols() != output_dim_) XsharpO_.Resize(in.NumRows(), output_dim_, kUndefined);
-    aslp_bn_forward(in.Data(), in.Dim(), out->Data(), out->Stride(), XsharpO_.Data(), XsharpO_.Stride(), scale_.Data(), shift_.Data(),
+    BaseFloat *xhat = XhatFor(in);
+    aslp_bn_forward(in.Data(), in.Dim(), out->Data(), out->Stride(), xhat, XsharpO_.Stride(), scale_.Data(), shift_.Data(),
                     mean_vec_.Data(), var_vec_.Data(), acc_means_.Data(), acc_vars_.Data(), var_floor_);
     num_acc_frames_ += in.NumRows();
   }
@@ -613,9 +613,9 @@ class BatchNormalization : public UpdatableComponent {
   void PropagateWithSigmoid(const CuMatrixBase &in, CuMatrix *sigmoid_out) {
     ASLP_ASSERT(in.NumCols() == input_dim_);
     if (!acc_cleaned_) { acc_cleaned_ = true; CleanAccs(); }
-    if (XsharpO_.NumRows() != in.NumRows() || XsharpO_.NumCols() != output_dim_) XsharpO_.Resize(in.NumRows(), output_dim_, kUndefined);
+    BaseFloat *xhat = XhatFor(in);
     if (sigmoid_out->NumRows() != in.NumRows() || sigmoid_out->NumCols() != output_dim_) sigmoid_out->Resize(in.NumRows(), output_dim_, kUndefined);
-    aslp_bn_forward_act(in.Data(), in.Dim(), nullptr, 0, XsharpO_.Data(), XsharpO_.Stride(), scale_.Data(), shift_.Data(), mean_vec_.Data(),
+    aslp_bn_forward_act(in.Data(), in.Dim(), nullptr, 0, xhat, XsharpO_.Stride(), scale_.Data(), shift_.Data(), mean_vec_.Data(),
                         var_vec_.Data(), acc_means_.Data(), acc_vars_.Data(), var_floor_, sigmoid_out->Data(), sigmoid_out->Stride());
     num_acc_frames_ += in.NumRows();
   }
@@ -641,12 +641,21 @@ class BatchNormalization : public UpdatableComponent {
     if (fold_update_) {
       fold_update_ = false;
       update_done_ = true;
-      aslp_bn_backward_step(in.Dim(), out_diff.Data(), out_diff.Stride(), XsharpO_.Data(), XsharpO_.Stride(), scale_.Data(), shift_.Data(),
-                            var_vec_.Data(), dscale_.Data(), dshift_.Data(), opts_.momentum, opts_.learn_rate, in_diff, id_stride, act_y, act_stride);
+      aslp_bn_backward_step(in.Dim(), out_diff.Data(), out_diff.Stride(), xhat_kept_ ? XsharpO_.Data() : nullptr, XsharpO_.Stride(), scale_.Data(),
+                            shift_.Data(), var_vec_.Data(), dscale_.Data(), dshift_.Data(), opts_.momentum, opts_.learn_rate, in_diff, id_stride, act_y,
+                            act_stride, in.Data(), mean_vec_.Data());
     } else {
-      aslp_bn_backward_act(in.Data(), in.Dim(), out_diff.Data(), out_diff.Stride(), XsharpO_.Data(), XsharpO_.Stride(), scale_.Data(),
+      aslp_bn_backward_act(in.Data(), in.Dim(), out_diff.Data(), out_diff.Stride(), xhat_kept_ ? XsharpO_.Data() : nullptr, XsharpO_.Stride(), scale_.Data(),
                            mean_vec_.Data(), var_vec_.Data(), dscale_.Data(), dshift_.Data(), opts_.momentum, in_diff, id_stride, act_y, act_stride);
     }
+  }
+  // The normalised copy X# of the input (the reference's XsharpO_, nnet-batch-normalization.h:188) is only materialised where
+  // the kernels need it: the single-launch panel kernels form it again from the layer input in the backward pass.
+  BaseFloat *XhatFor(const CuMatrixBase &in) {
+    xhat_kept_ = !(aslp_bn_panel_supported(in.NumRows(), output_dim_) && in.Stride() % 4 == 0 && (reinterpret_cast<uintptr_t>(in.Data()) & 15u) == 0);
+    if (!xhat_kept_) return nullptr;
+    if (XsharpO_.NumRows() != in.NumRows() || XsharpO_.NumCols() != output_dim_) XsharpO_.Resize(in.NumRows(), output_dim_, kUndefined);
+    return XsharpO_.Data();
   }
   void AllocAux() {
     mean_vec_.Resize(output_dim_); var_vec_.Resize(output_dim_);
@@ -658,7 +667,7 @@ class BatchNormalization : public UpdatableComponent {
   CuVectorD acc_means_, acc_vars_;
   double num_acc_frames_;
   bool acc_cleaned_;
-  bool fold_update_ = false, update_done_ = false;
+  bool fold_update_ = false, update_done_ = false, xhat_kept_ = true;
 };
 
 }  // namespace aslp
