@@ -63,8 +63,10 @@ if os.environ.get("SEQ_TIMING") == "1":
         buf = (C.c_ulonglong * 8)()
         aslp.lib.aslp_lstm_seq_timing(0, buf)
         n = max(1, buf[0])
-        print("%s kernel, workgroup 0 wave 0, us per timestep: sample-wait %.2f  load+mfma-issue %.2f  mfma-drain+lds %.2f  barrier %.2f  epilogue %.2f   (L2-local launches %d of %d)"
-              % tuple([name] + [buf[k] * 0.01 / n for k in (1, 2, 3, 4, 5)] + [buf[6], n // T]))
+        names = ("collect m(t-1)", "barrier", "product", "barrier", "epilogue") if mode == 1 else ("product+publish", "-", "collect shares", "barrier", "epilogue")
+        vals = [buf[k] * 0.01 / n for k in (1, 3, 2, 4, 5)]
+        print("%s kernel, workgroup 0 wave 0, us per timestep: %s   (L2-local launches %d of %d)"
+              % (name, "  ".join("%s %.2f" % (nm, v) for nm, v in zip(names, vals)), buf[6], n // T))
 print("hand-off re-polls per step (all waves): %.0f" % (aslp.lib.aslp_lstm_seq_polls(1) / STEPS))
 if os.environ.get("GEMM_PROFILE") == "1":
     import ctypes as C

@@ -33,6 +33,21 @@ __global__ void __launch_bounds__(512) k16(float *out, int iters, float a, float
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+template <int NACC>
+__global__ void __launch_bounds__(512) k4(float *out, int iters, float a, float b) {
+  f32x4 acc[NACC];
+  for (int i = 0; i < NACC; i++) for (int e = 0; e < 4; e++) acc[i][e] = 0.f;
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+#pragma unroll
+      for (int i = 0; i < NACC; i++) acc[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, acc[i], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int i = 0; i < NACC; i++) for (int e = 0; e < 4; e++) s += acc[i][e];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 template <class K>
 void run(const char *name, K kern, int threads, int nacc, double flop_per_mfma) {
   float *out;
@@ -58,5 +73,7 @@ int main() {
   run("16x16x4  1 acc (dependent chain)", k16<1>, 256, 1, 2048); run("16x16x4  1 acc (dependent chain)", k16<1>, 512, 1, 2048);
   run("16x16x4  2 acc", k16<2>, 256, 2, 2048); run("16x16x4  4 acc", k16<4>, 256, 4, 2048);
   run("16x16x4  8 acc", k16<8>, 256, 8, 2048); run("16x16x4  8 acc", k16<8>, 512, 8, 2048);
+  run("4x4x1_16B 1 acc (dependent chain)", k4<1>, 256, 1, 512); run("4x4x1_16B 2 acc", k4<2>, 256, 2, 512);
+  run("4x4x1_16B 4 acc", k4<4>, 256, 4, 512); run("4x4x1_16B 8 acc", k4<8>, 256, 8, 512); run("4x4x1_16B 8 acc", k4<8>, 512, 8, 512);
   return 0;
 }

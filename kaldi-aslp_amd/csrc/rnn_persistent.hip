@@ -170,12 +170,18 @@ __device__ __forceinline__ ChainRole chain_role(const aslp_lstm_seq &a, const Se
 }
 
 // ---- forward -------------------------------------------------------------------------------------------------------
-// grid 8 * ceil(C / 16) workgroups of 256 threads.  NCH: 16-wide K chunks per wave (C <= 64 * NCH).
-template <bool CIFG, int NCH>
-__global__ void __launch_bounds__(256) lstm_seq_fwd(aslp_lstm_seq a, SeqStatus st, unsigned *place) {
-  constexpr int G = CIFG ? 3 : 4;
-  __shared__ float red[2][4][G][16 * kTP];
-  __shared__ int fail[2][4];
+// grid 8 * ceil(C / 16) workgroups of 512 threads.  KW: K values per wave (C <= 8 * KW).
+// The product runs on v_mfma_f32_4x4x1_16b_f32 (see the backward kernel for the block layout): one instruction covers the
+// chain's 8 streams x 32 of the workgroup's 64 gate columns with no padding rows, the 8 waves split K.  The left operand
+// m(t-1) [8 x C] is collected ONCE per workgroup into LDS (every thread two 16-byte pieces, agent-scope loads, repeated until
+// no piece reads "not yet published") and read from there by all lanes -- the 4 x 4 blocks would otherwise pull every
+// piece eight times through the L2.
+template <bool CIFG, int KW>
+__global__ void __launch_bounds__(512) lstm_seq_fwd(aslp_lstm_seq a, SeqStatus st, unsigned *place) {
+  constexpr int G = CIFG ? 3 : 4, KMAX = 8 * KW, MP = KMAX + 4, RP = 80;  // RP = 16 mod 32: the epilogue's reads hit 32 distinct banks
+  __shared__ __attribute__((aligned(16))) float m_lds[kChainStreams][MP];
+  __shared__ float red[2][8][kChainStreams][RP];
+  __shared__ int fail[2][8];
   __shared__ int place_flag;
   const ChainRole R = chain_role(a, st, place, &place_flag);
   if (!R.active) return;
@@ -184,45 +190,28 @@ __global__ void __launch_bounds__(256) lstm_seq_fwd(aslp_lstm_seq a, SeqStatus s
   const int GC = G * C, oc = GC, oh = GC + C, om = GC + 2 * C;
   constexpr int gi = 1, gf = CIFG ? 1 : 2, go = CIFG ? 2 : 3;
   const int c0 = R.c0, s0 = R.s0;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, kg = lane >> 4;
-  const int nq = (C + 15) / 16, per = (nq + 3) / 4, q0 = wave * per;
-  const int aux_store = R.local ? 0 : kAuxSc1;
-  // B fragments, resident for the launch: tile g = gate g, column n = cell c0 + n
-  f32x4 b[G][NCH];
-  {
-    const bool nvalid = c0 + l15 < C;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int qs = (lane >> 2) & 1, qc = lane >> 3, jl = lane & 3;
+  const int kw = ((C + 31) / 32) * 4, kb = wave * kw;  // this wave's K range [kb, kb + kw), a multiple of 4 long
+  // B fragments, resident for the launch: instruction h covers tile columns 32 h + 4 qc + jl; column n = gate n >> 4, cell c0 + (n & 15)
+  f32x4 bw[2][KW / 4];
 #pragma unroll
-    for (int g = 0; g < G; g++) {
-      const float *brow = D.w + (long)(g * C + (nvalid ? c0 + l15 : 0)) * a.ldw;
+  for (int h = 0; h < 2; h++) {
+    const int n = 32 * h + 4 * qc + jl, gate = n >> 4, cellb = c0 + (n & 15);
+    const bool nvalid = gate < G && cellb < C;
+    const float *brow = D.w + (long)(nvalid ? gate * C + cellb : 0) * a.ldw;
 #pragma unroll
-      for (int i = 0; i < NCH; i++) {
-        const int k0 = 16 * (q0 + i) + 4 * kg;
-        const bool ok = nvalid && i < per && (q0 + i) < nq && k0 < C;
-        b[g][i] = ok ? *reinterpret_cast<const f32x4 *>(brow + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
+    for (int i = 0; i < KW / 4; i++) {
+      const int k0 = kb + 4 * i;
+      bw[h][i] = (nvalid && 4 * i < kw && k0 < C) ? *reinterpret_cast<const f32x4 *>(brow + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
-  // this lane's operand row (tile rows 8..15 repeat rows 0..7: never "unpublished", their products are not read) and K offsets
-  int offA[NCH];
-  unsigned validA = 0u;
-  const int arow = min(s0 + (l15 & 7), S - 1);
-#pragma unroll
-  for (int i = 0; i < NCH; i++) {
-    const int k0 = 16 * (q0 + i) + 4 * kg;
-    const bool ok = i < per && (q0 + i) < nq && k0 < C;
-    offA[i] = ok ? (arow * ld + om + k0) * 4 : 0;
-    validA |= ok ? 1u << i : 0u;
-  }
-  const bool fullA = per == NCH && nq == 4 * per && (C & 15) == 0;  // uniform: no piece of any lane is padding
-  // readiness sample: chunk l15 % per of the lane's K group -- together the wave's lanes look at a piece of every workgroup
-  // whose cells fall into this wave's K range
-  int offS = 0;
-  bool validS = false;
-  {
-    const int is = l15 % per, k0 = 16 * (q0 + is) + 4 * kg;
-    validS = (q0 + is) < nq && k0 < C;
-    offS = validS ? (arow * ld + om + k0) * 4 : 0;
-  }
+  // collection role: pieces tid and tid + 512 of [stream][C / 4]
+  const int c4 = C >> 2, npiece = kChainStreams * c4;
+  const int p0 = threadIdx.x, p1 = threadIdx.x + 512;
+  const bool h0 = p0 < npiece, h1 = p1 < npiece;
+  const int st0 = h0 ? p0 / c4 : 0, kq0 = h0 ? p0 % c4 : 0, st1 = h1 ? p1 / c4 : 0, kq1 = h1 ? p1 % c4 : 0;
+  const int off0 = (min(s0 + st0, S - 1) * ld + om + 4 * kq0) * 4, off1 = (min(s0 + st1, S - 1) * ld + om + 4 * kq1) * 4;
   // epilogue role: threads 0..127 own one (stream, cell) pair each
   const int sl = threadIdx.x >> 4, cc = threadIdx.x & 15, s = s0 + sl, cell = c0 + cc;
   const bool live = threadIdx.x < 128 && s < S && cell < C;
@@ -246,63 +235,75 @@ __global__ void __launch_bounds__(256) lstm_seq_fwd(aslp_lstm_seq a, SeqStatus s
       xg = ys[cq]; xf = ys[gf * C + cq]; xo = ys[go * C + cq];
       if (!CIFG) xi = ys[gi * C + cq];
     }
-    f32x4 acc[G];
+    f32x4 acc[2][2];
 #pragma unroll
-    for (int g = 0; g < G; g++) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int h = 0; h < 2; h++) { acc[h][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[h][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     bool ok = true;
-    if (!(step == 0 && D.skip_first_product)) {
+    const bool product = !(step == 0 && D.skip_first_product);
+    if (product) {
+      // 1. m(t-1) of the chain's streams -> LDS
       const __amdgpu_buffer_rsrc_t rs = make_rsrc(D.y + (long)tp * S * ld);
-      ok = wait_sample(rs, offS, validS, st, polls);
-      tock(st, 1, tm);
+      u32x4 v0 = {0u, 0u, 0u, 0u}, v1 = {0u, 0u, 0u, 0u};
       long t0 = 0;
-      for (unsigned att = 0; ok; att++) {
-        u32x4 av[NCH];
-#pragma unroll
-        for (int i = 0; i < NCH; i++) av[i] = u32x4{0u, 0u, 0u, 0u};
-        if (l15 < kChainStreams) {  // tile rows 8..15 feed products nobody reads: their lanes request nothing
-#pragma unroll
-          for (int i = 0; i < NCH; i++) av[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, offA[i], 0, kAuxSc1);
-        }
-        bool bad = false;
-#pragma unroll
-        for (int i = 0; i < NCH; i++) {
-          if (!fullA && !((validA >> i) & 1u)) av[i] = u32x4{0u, 0u, 0u, 0u};
-          bad |= has_sentinel(av[i]);
-#pragma unroll
-          for (int g = 0; g < G; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[i].x), b[g][i].x, acc[g], 0, 0, 0);
-#pragma unroll
-          for (int g = 0; g < G; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[i].y), b[g][i].y, acc[g], 0, 0, 0);
-#pragma unroll
-          for (int g = 0; g < G; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[i].z), b[g][i].z, acc[g], 0, 0, 0);
-#pragma unroll
-          for (int g = 0; g < G; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(as_f(av[i].w), b[g][i].w, acc[g], 0, 0, 0);
-        }
-        if (!__any(bad)) break;
-        // a piece the samples did not cover had not landed yet: drop the products and repeat (rare)
-#pragma unroll
-        for (int g = 0; g < G; g++) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (unsigned spins = 0;; spins++) {
+        if (h0) v0 = __builtin_amdgcn_raw_buffer_load_b128(rs, off0, 0, kAuxSc1);
+        if (h1) v1 = __builtin_amdgcn_raw_buffer_load_b128(rs, off1, 0, kAuxSc1);
+        if (!__any((h0 && has_sentinel(v0)) || (h1 && has_sentinel(v1)))) break;
         asm volatile("" ::: "memory");
-        polls += 0x10000u;  // diagnostics: repeated products in the high half
-        ok = spin_ok(att, t0, st);
+        polls++;
+        if (!spin_ok(spins, t0, st)) { ok = false; break; }
         __builtin_amdgcn_s_sleep(1);
       }
+      if (h0) *reinterpret_cast<u32x4 *>(&m_lds[st0][4 * kq0]) = v0;
+      if (h1) *reinterpret_cast<u32x4 *>(&m_lds[st1][4 * kq1]) = v1;
     }
-    tock(st, 2, tm);  // full load landed (the MFMAs below are only issued)
-#pragma unroll
-    for (int g = 0; g < G; g++) store_tile16(red[par][wave][g], acc[g], lane);
+    tock(st, 1, tm);  // collection
     if (lane == 0) fail[par][wave] = ok ? 0 : 1;
-    tock(st, 3, tm);  // MFMA + LDS stores
     __syncthreads();
-    tock(st, 4, tm);  // barrier
-    if (fail[par][0] | fail[par][1] | fail[par][2] | fail[par][3]) return;  // uniform: every wave reads the same four words
+    tock(st, 3, tm);  // barrier behind the collection
+    if (product) {
+      // 2. this wave's K slice of the product
+      // all operand reads first, unconditionally (slices past C read element 0 of the row: finite, and their B fragments are 0),
+      // so that the LDS latency is paid once and not in front of every group of products
+      const float *arow = &m_lds[4 * qs + jl][0];
+      f32x4 av[KW / 4];
+#pragma unroll
+      for (int i = 0; i < KW / 4; i++) av[i] = *reinterpret_cast<const f32x4 *>(arow + ((4 * i < kw && kb + 4 * i < C) ? kb + 4 * i : 0));
+#pragma unroll
+      for (int i = 0; i < KW / 4; i++) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) acc[h][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i].x, bw[h][i].x, acc[h][0], 0, 0, 0);
+#pragma unroll
+        for (int h = 0; h < 2; h++) acc[h][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i].y, bw[h][i].y, acc[h][1], 0, 0, 0);
+#pragma unroll
+        for (int h = 0; h < 2; h++) acc[h][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i].z, bw[h][i].z, acc[h][0], 0, 0, 0);
+#pragma unroll
+        for (int h = 0; h < 2; h++) acc[h][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i].w, bw[h][i].w, acc[h][1], 0, 0, 0);
+      }
+    }
+    // result register r of a lane = stream 4 qs + r of tile column 32 h + 4 qc + jl
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const f32x4 sum = acc[h][0] + acc[h][1];
+      float *rp = &red[par][wave][4 * qs][32 * h + 4 * qc + jl];
+      rp[0 * RP] = sum.x; rp[1 * RP] = sum.y; rp[2 * RP] = sum.z; rp[3 * RP] = sum.w;
+    }
+    tock(st, 2, tm);  // product
+    __syncthreads();
+    tock(st, 4, tm);
+    {
+      int f = 0;
+#pragma unroll
+      for (int w = 0; w < 8; w++) f |= fail[par][w];
+      if (f) return;  // uniform: every wave reads the same eight words
+    }
     if (threadIdx.x >= 128) continue;  // whole waves: the quad gather below needs every lane of waves 0 and 1
     float pre[G];
 #pragma unroll
     for (int g = 0; g < G; g++) {
-      const int idx = sl * kTP + cc;
-      float v = red[par][0][g][idx];
+      float v = red[par][0][sl][g * 16 + cc];
 #pragma unroll
-      for (int w = 1; w < 4; w++) v += red[par][w][g][idx];
+      for (int w = 1; w < 8; w++) v += red[par][w][sl][g * 16 + cc];
       pre[g] = v;
     }
     float gg = 0.f, ii = 0.f, ff = 0.f, oo = 0.f, cellv = 0.f, hh = 0.f, mm = 0.f;
@@ -339,7 +340,6 @@ __global__ void __launch_bounds__(256) lstm_seq_fwd(aslp_lstm_seq a, SeqStatus s
     tock(st, 5, tm);  // epilogue
   }
   if (st.timing && blockIdx.x == 0 && threadIdx.x == 0) { st.timing[0] += (unsigned long long)T; st.timing[6] += R.local ? 1ull : 0ull; }
-  (void)aux_store;
   if (polls && lane == 0) __hip_atomic_fetch_add(st.abort_flag + 2, polls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // diagnostics, once per wave
 }
 
@@ -373,21 +373,25 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd(aslp_lstm_seq a, SeqStatus s
   const int og = 0, oi = C, of = CIFG ? C : 2 * C, oo = CIFG ? 2 * C : 3 * C;
   const int c0 = R.c0, s0 = R.s0;
   const int chain = blockIdx.x & (kMaxChains - 1), me = blockIdx.x >> 3, wpc = (C + kCellsPerWg - 1) / kCellsPerWg;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, kg = lane >> 4;
-  // B fragments, resident for the launch: tile j of this wave = the 16 cells of consumer block wave + 8 * j;
-  // k index 16 * q + 4 * kg + jj of the product = own gate column (gate q, cell 4 * kg + jj)
-  float bw[TPW][KS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // The product runs on v_mfma_f32_4x4x1_16b_f32: 16 independent 4 x 4 blocks per instruction, here 2 stream quads x 8 cell
+  // quads = the chain's 8 streams x 32 cells with NO padding rows (the 16 x 16 tile carries 8 idle rows: twice the MFMA time).
+  // Lane l: block l >> 2 = (stream quad sq = block & 1, cell quad cq = block >> 1); A operand = own gate diff of stream
+  // 4 sq + (l & 3), B operand = W_eff[own gate column k][cell], result register r = stream 4 sq + r of that cell.
+  // This wave's cells: consumer blocks wave + 8 j, two blocks (32 cells) per instruction h.
+  constexpr int NH = (TPW + 1) / 2;
+  const int qs = (lane >> 2) & 1, qc = lane >> 3, jl = lane & 3;
+  float bw[NH][KS * 4];
 #pragma unroll
-  for (int j = 0; j < TPW; j++) {
-    const int col = (wave + 8 * j) * 16 + l15;
+  for (int h = 0; h < NH; h++) {
+    const int cb = wave + 8 * (2 * h + (qc >> 2));
+    const int col = cb * 16 + 4 * (qc & 3) + jl;
+    const bool colok = (2 * h + (qc >> 2)) < TPW && cb < wpc && col < C;
 #pragma unroll
-    for (int q = 0; q < G; q++)
-#pragma unroll
-      for (int jj = 0; jj < 4; jj++) {
-        const int cellk = c0 + 4 * kg + jj;
-        const bool ok = col < C && cellk < C && (wave + 8 * j) < wpc;
-        bw[j][q * 4 + jj] = ok ? D.w[(long)(q * C + cellk) * a.ldw + col] : 0.f;
-      }
+    for (int kk = 0; kk < KS * 4; kk++) {
+      const int cellk = c0 + (kk & 15);
+      bw[h][kk] = (colok && cellk < C) ? D.w[(long)((kk >> 4) * C + cellk) * a.ldw + col] : 0.f;
+    }
   }
   // inbox geometry
   const size_t slot_words = (size_t)kMaxChains * kMaxWgPerChain * kMaxWgPerChain * 128;  // floats per ring slot
@@ -421,35 +425,35 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd(aslp_lstm_seq a, SeqStatus s
       float *box = chain_box + (size_t)(step % kRing) * slot_words;
       // 1. my share of d_m for every cell of the chain: own gate diffs of the previous step (LDS) x my rows of W_eff
       {
-        f32x4 av[G];
+        f32x4 av[KS];
+        const float *arow = &own_dg[par ^ 1][4 * qs + jl][0];
 #pragma unroll
-        for (int q = 0; q < G; q++) av[q] = *reinterpret_cast<const f32x4 *>(&own_dg[par ^ 1][l15 & 7][q * 16 + 4 * kg]);
-        f32x4 acc[TPW];
+        for (int q = 0; q < KS; q++) av[q] = *reinterpret_cast<const f32x4 *>(arow + 4 * q);
+        f32x4 acc[NH][2];  // two accumulators per instruction stream (even / odd k): four independent chains keep the pipe full
 #pragma unroll
-        for (int j = 0; j < TPW; j++) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int h = 0; h < NH; h++) { acc[h][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[h][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-        for (int q = 0; q < G; q++) {
+        for (int q = 0; q < KS; q++) {
 #pragma unroll
-          for (int j = 0; j < TPW; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q].x, bw[j][q * 4 + 0], acc[j], 0, 0, 0);
+          for (int h = 0; h < NH; h++) acc[h][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[q].x, bw[h][4 * q + 0], acc[h][0], 0, 0, 0);
 #pragma unroll
-          for (int j = 0; j < TPW; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q].y, bw[j][q * 4 + 1], acc[j], 0, 0, 0);
+          for (int h = 0; h < NH; h++) acc[h][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[q].y, bw[h][4 * q + 1], acc[h][1], 0, 0, 0);
 #pragma unroll
-          for (int j = 0; j < TPW; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q].z, bw[j][q * 4 + 2], acc[j], 0, 0, 0);
+          for (int h = 0; h < NH; h++) acc[h][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[q].z, bw[h][4 * q + 2], acc[h][0], 0, 0, 0);
 #pragma unroll
-          for (int j = 0; j < TPW; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q].w, bw[j][q * 4 + 3], acc[j], 0, 0, 0);
+          for (int h = 0; h < NH; h++) acc[h][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[q].w, bw[h][4 * q + 3], acc[h][1], 0, 0, 0);
         }
-        // 2. hand the shares out: tile rows 0..7 are the chain's streams (lanes kg < 2), one 16-byte piece per lane and tile
-        if (kg < 2) {
-          const __amdgpu_buffer_rsrc_t rs = make_rsrc(box);
+        // 2. hand the shares out: one 16-byte piece (4 streams of one cell) per lane and instruction
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(box);
 #pragma unroll
-          for (int j = 0; j < TPW; j++) {
-            const int cb = wave + 8 * j;
-            if (cb < wpc) {
-              const int off = (((cb * kMaxWgPerChain + me) * 2 + kg) * 16 + l15) * 16;
-              const u32x4 pk = {__float_as_uint(acc[j].x), __float_as_uint(acc[j].y), __float_as_uint(acc[j].z), __float_as_uint(acc[j].w)};
-              if (R.local) __builtin_amdgcn_raw_buffer_store_b128(pk, rs, off, 0, 0);
-              else __builtin_amdgcn_raw_buffer_store_b128(pk, rs, off, 0, kAuxSc1);
-            }
+        for (int h = 0; h < NH; h++) {
+          const int tj = 2 * h + (qc >> 2), cb = wave + 8 * tj;
+          if (tj < TPW && cb < wpc) {
+            const f32x4 sum = acc[h][0] + acc[h][1];
+            const int off = (((cb * kMaxWgPerChain + me) * 2 + qs) * 16 + 4 * (qc & 3) + jl) * 16;
+            const u32x4 pk = {__float_as_uint(sum.x), __float_as_uint(sum.y), __float_as_uint(sum.z), __float_as_uint(sum.w)};
+            if (R.local) __builtin_amdgcn_raw_buffer_store_b128(pk, rs, off, 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b128(pk, rs, off, 0, kAuxSc1);
           }
         }
       }
@@ -589,8 +593,8 @@ SeqRuntime &seq_runtime() {
 typedef void (*SeqKernel)(aslp_lstm_seq, SeqStatus, unsigned *);
 typedef void (*SeqKernelB)(aslp_lstm_seq, SeqStatus, unsigned *, float *);
 SeqKernel pick_fwd(bool cifg, int C) {
-  if (C <= 128) return cifg ? lstm_seq_fwd<true, 2> : lstm_seq_fwd<false, 2>;
-  if (C <= 512) return cifg ? lstm_seq_fwd<true, 8> : lstm_seq_fwd<false, 8>;
+  if (C <= 128) return cifg ? lstm_seq_fwd<true, 16> : lstm_seq_fwd<false, 16>;
+  if (C <= 512) return cifg ? lstm_seq_fwd<true, 64> : lstm_seq_fwd<false, 64>;
   return nullptr;
 }
 SeqKernelB pick_bwd(bool cifg, int C) {
@@ -627,7 +631,7 @@ int aslp_lstm_seq_supported(const aslp_lstm_seq *a, int backward) {
   const int nsg = (a->S + kChainStreams - 1) / kChainStreams, wpc = (a->C + kCellsPerWg - 1) / kCellsPerWg;
   if (a->ndir * nsg > kMaxChains || wpc > kMaxWgPerChain) return 0;   // S <= 32 (bidirectional) / 64, C <= 512
   const void *k = backward ? reinterpret_cast<const void *>(pick_bwd(a->cifg != 0, a->C)) : reinterpret_cast<const void *>(pick_fwd(a->cifg != 0, a->C));
-  return grid_fits(k, backward ? 512 : 256, (long)kMaxChains * wpc) ? 1 : 0;
+  return grid_fits(k, 512, (long)kMaxChains * wpc) ? 1 : 0;
 }
 
 void aslp_lstm_seq_fill(float *buf, int ld, int T, int S, int col0, int ncols) {
@@ -657,7 +661,7 @@ static void launch_seq(const aslp_lstm_seq *a, bool backward, const char *who) {
   if (rt.epoch == 0u) rt.epoch = 1u;
   SeqStatus st = {rt.abort_flag, rt.host_err_dev, ((rt.timing_mode == 1 && !backward) || (rt.timing_mode == 2 && backward)) ? rt.timing : nullptr, rt.epoch};
   const int wpc = (a->C + kCellsPerWg - 1) / kCellsPerWg;
-  if (!backward) hipLaunchKernelGGL(pick_fwd(a->cifg != 0, a->C), dim3(kMaxChains * wpc), dim3(256), 0, cur_stream(), *a, st, rt.place);
+  if (!backward) hipLaunchKernelGGL(pick_fwd(a->cifg != 0, a->C), dim3(kMaxChains * wpc), dim3(512), 0, cur_stream(), *a, st, rt.place);
   else hipLaunchKernelGGL(pick_bwd(a->cifg != 0, a->C), dim3(kMaxChains * wpc), dim3(512), 0, cur_stream(), *a, st, rt.place, rt.inbox);
   check_launch(who);
 }

@@ -148,10 +148,11 @@ def test_cu_device_c_view(aslp, dev):
     p = lib.aslp_device_malloc_pitch(440 * 4, 1024, C.byref(pitch))
     assert p and pitch.value >= 440 * 4 and pitch.value % 64 == 0
     t = torch.zeros(8, device=dev)
-    q = lib.aslp_device_malloc(1 << 20)
+    odd = (1 << 20) + 77 * 4096               # a size nothing else in this process has cached
+    q = lib.aslp_device_malloc(odd)
     assert q and q != p
     lib.aslp_device_free(q)
-    q2 = lib.aslp_device_malloc(1 << 20)      # the caching allocator hands the block back (cu-allocator.h:67-70)
+    q2 = lib.aslp_device_malloc(odd)           # the caching allocator hands the block back (cu-allocator.h:67-70)
     assert q2 == q
     lib.aslp_device_free(q2)
     lib.aslp_device_free(p)
