@@ -708,6 +708,8 @@ int aslp_sgemm_ex(int transA, int transB, int M, int N, int K, float alpha, cons
   if (K > 0 && (lda < (transA ? M : K) || ldb < (transB ? K : N))) return -4;
   GemmArgs g;
   g.split_k = 0; g.k_chunk = 0; g.split_stride = 0;
+  static const int wide = [] { const char *e = getenv("ASLP_GEMM_WIDE_EPI"); return e ? atoi(e) : 1; }();
+  g.wide_epilogue = wide;
   g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.alpha = alpha; g.beta = beta;
   if (ep) g.ep = *ep; else g.ep = aslp_gemm_epilogue();  // zero-initialised: every optional piece off

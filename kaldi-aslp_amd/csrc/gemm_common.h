@@ -26,6 +26,7 @@ struct GemmArgs {
   float alpha, beta;
   aslp_gemm_epilogue ep;
   int a_vec, b_vec;  // 16-byte vector loads allowed
+  int wide_epilogue;  // 16-byte epilogue accesses through the LDS transpose (A/B switch: ASLP_GEMM_WIDE_EPI=0)
   int tiles_m, tiles_n;
   // split-K (gemm_glds.hip): blockIdx.y = chunk of k_chunk (a multiple of the K tile) reduction steps, whose plain product
   // goes to C + chunk * split_stride (a scratch stack of packed M x N partials; the epilogue runs in the reduce kernel)
@@ -110,6 +111,76 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, const f32x16 (&
             float a = ep.act == 1 ? sigmoid_ref(v) : ep.act == 2 ? tanh_ref(v) : ep.act == 3 ? fmaxf(v, 0.0f) : v;
             ep.act_out[(long)row * ep.ld_act + col] = a;
           }
+        }
+      }
+    }
+}
+
+// The same epilogue with 16-byte global accesses.  A lane of the 32x32 MFMA holds 16 ROWS of one column, so the epilogue above
+// issues one 4-byte access per element: 16 stores (48 memory instructions with the fused SGD step) per wave and patch, and the
+// tail of the kernel is store-ISSUE bound (one workgroup per CU: nothing overlaps it).  Here the wave first passes its patch
+// through its own 32 x 36-float slice of the (now idle) operand LDS: written in the accumulator layout, read back as rows, so
+// that every lane holds 4 x 4 consecutive columns -- 4 instead of 16 accesses per array, each wave instruction 8 full 128-byte lines.
+// The arithmetic per element is the scalar epilogue's.  Eligibility (uniform, checked by the caller): N, ldc (ldw, ld_act) multiples
+// of 4, all pointers 16-byte aligned.  `tile`: this wave's LDS slice; the caller has passed a workgroup barrier since the last operand read.
+constexpr int kEpiPitch = 36;
+__device__ __forceinline__ bool gemm_epilogue_wide_ok(const GemmArgs &g) {
+  const aslp_gemm_epilogue &ep = g.ep;
+  auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+  return (g.N & 3) == 0 && (g.ldc & 3) == 0 && al(g.C) && (!ep.bias || al(ep.bias)) && (!ep.W || ((ep.ldw & 3) == 0 && al(ep.W))) &&
+         (!ep.act_out || ((ep.ld_act & 3) == 0 && al(ep.act_out)));
+}
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs &g, const f32x16 (&acc)[TM][TN], int row0, int col0, int lane, float *tile) {
+  const aslp_gemm_epilogue &ep = g.ep;
+  const int l31 = lane & 31, lh = lane >> 5, c4 = lane & 7, rr = lane >> 3;
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int n = 0; n < TN; n++) {
+#pragma unroll
+      for (int e = 0; e < 16; e++) tile[((e & 3) + 8 * (e >> 2) + 4 * lh) * kEpiPitch + l31] = acc[i][n][e];
+      const int col = col0 + n * 32 + 4 * c4;
+      const bool colok = col < g.N;
+      float4 v[4], c_old[4], w_old[4];
+      const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 bias = (ep.bias && colok) ? *reinterpret_cast<const float4 *>(ep.bias + col) : zero;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int r = rr + 8 * j, row = row0 + i * 32 + r;
+        const bool ok = colok && row < g.M;
+        v[j] = *reinterpret_cast<const float4 *>(tile + r * kEpiPitch + 4 * c4);
+        c_old[j] = (ok && g.beta != 0.0f) ? *reinterpret_cast<const float4 *>(g.C + (long)row * g.ldc + col) : zero;
+        w_old[j] = (ok && ep.W) ? *reinterpret_cast<const float4 *>(ep.W + (long)row * ep.ldw + col) : zero;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int row = row0 + i * 32 + rr + 8 * j;
+        if (!colok || row >= g.M) continue;
+        float o[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+        const float co[4] = {c_old[j].x, c_old[j].y, c_old[j].z, c_old[j].w}, bs[4] = {bias.x, bias.y, bias.z, bias.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          float t = (ep.W != nullptr || g.beta != 0.0f) ? g.alpha * o[q] + g.beta * co[q] + bs[q] : g.alpha * o[q] + bs[q];
+          if (ep.clip > 0.0f) t = fminf(fmaxf(t, -ep.clip), ep.clip);
+          o[q] = t;
+        }
+        typedef float f32x4v __attribute__((ext_vector_type(4)));
+        const f32x4v out = {o[0], o[1], o[2], o[3]};
+        f32x4v *cp = reinterpret_cast<f32x4v *>(g.C + (long)row * g.ldc + col);
+        if (ep.W && g.beta == 0.0f) __builtin_nontemporal_store(out, cp);  // gradient written once, not read again this step
+        else *cp = out;
+        if (ep.W) {
+          float4 wn;
+          wn.x = w_old[j].x + ep.w_alpha * o[0]; wn.y = w_old[j].y + ep.w_alpha * o[1];
+          wn.z = w_old[j].z + ep.w_alpha * o[2]; wn.w = w_old[j].w + ep.w_alpha * o[3];
+          *reinterpret_cast<float4 *>(ep.W + (long)row * ep.ldw + col) = wn;
+        }
+        if (ep.act_out) {
+          float a[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) a[q] = ep.act == 1 ? sigmoid_ref(o[q]) : ep.act == 2 ? tanh_ref(o[q]) : ep.act == 3 ? fmaxf(o[q], 0.0f) : o[q];
+          *reinterpret_cast<float4 *>(ep.act_out + (long)row * ep.ld_act + col) = make_float4(a[0], a[1], a[2], a[3]);
         }
       }
     }

@@ -243,7 +243,13 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_f32_glds(GemmArgs g) {
   }
   wait_vmcnt<0>();  // drain the clamped tail requests before the LDS block is released
 
-  gemm_epilogue<TM, TN>(g, acc, m0 + wm * WM, n0 + wn * WN, l31, lh);
+  static_assert(NW * 32 * kEpiPitch * (int)sizeof(float) <= NS * STAGE * (int)sizeof(float), "the waves' epilogue slices must fit into the operand LDS");
+  if (g.wide_epilogue && gemm_epilogue_wide_ok(g) && g.split_k <= 1) {  // uniform
+    __builtin_amdgcn_s_barrier();  // every wave is past its last operand read: the LDS is free
+    gemm_epilogue_wide<TM, TN>(g, acc, m0 + wm * WM, n0 + wn * WN, lane, lds + wave * 32 * kEpiPitch);
+  } else {
+    gemm_epilogue<TM, TN>(g, acc, m0 + wm * WM, n0 + wn * WN, l31, lh);
+  }
   if constexpr (!A_KC) {
     if (do_colsum) {
 #pragma unroll
