@@ -1,6 +1,6 @@
 """Times the HIP CTC loss: 32 utterances x <= 800 frames x alphabet 128 (SURVEY 8d CTC variant)."""
 import sys, time, numpy as np, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import aslp_import; aslp = aslp_import.load(); aslp.ops.use_torch_stream()
 dev = torch.device('cuda:0')
 A, mb, maxT = 128, 32, 800

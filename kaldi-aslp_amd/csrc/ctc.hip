@@ -66,95 +66,115 @@ struct UttInfo {
   int lab_off;   // offset of this utterance's S entries in labels_w_blanks / next_same / first_of_label
 };
 
-// ---- alpha --------------------------------------------------------------------------------------------
-// LDS: two alpha columns + the blank-augmented label sequence.
-__device__ void ctc_beta_pass(const float *__restrict__ probs, float *__restrict__ betas, const UttInfo &u, const int *__restrict__ lwb_all, int n,
-                              int mb, int maxS, int maxT, int ldp, float *smem);
+// ---- emission log-probabilities ------------------------------------------------------------------------
+// log p_t(label of state s) for every (utterance, frame, state), stored where alpha(t, s) and beta(t, s) will go.  The lattice
+// recursions below then find their only frame-dependent input already in the workspace -- coalesced, requested one frame ahead --
+// instead of a gather through the label table plus a double-precision logarithm on the sequential path of every timestep.
+__global__ void __launch_bounds__(256) ctc_emit_kernel(const float *__restrict__ probs, float *__restrict__ alphas, float *__restrict__ betas,
+                                                       const UttInfo *info, const int *__restrict__ lwb_all, int mb, int maxS, int maxT, int ldp,
+                                                       int want_beta) {
+  const int n = blockIdx.y, t = blockIdx.x;
+  const UttInfo u = info[n];
+  if (!u.feasible || t >= u.T) return;
+  const float *pt = probs + ((long)t * mb + n) * ldp;
+  const int *lab = lwb_all + u.lab_off;
+  float *al = alphas + (long)n * maxS * maxT + (long)t * u.S, *be = betas + (long)n * maxS * maxT + (long)t * u.S;
+  for (int s = threadIdx.x; s < u.S; s += blockDim.x) {
+    const float lp = logf_cr(pt[lab[s]]);
+    al[s] = lp;
+    if (want_beta) be[s] = lp;
+  }
+}
+
+// ---- alpha / beta ------------------------------------------------------------------------------------------
+// One workgroup per utterance and direction walks its lattice over T with the previous and current columns ping-ponging in
+// LDS (cpu_ctc.h:217-255 / :300-350 without the [start, end) window).  Every thread owns up to kLatSlots states
+// (tid + k * blockDim); a step's emission terms are requested at its top and consumed at its end, so the only things on the
+// sequential path are three LDS reads, two log_plus and the barrier.
+constexpr int kLatSlots = 8;
 
 // blockIdx.y == 0: alpha pass; blockIdx.y == 1: beta pass of utterance blockIdx.x (both at once: 2 x mb workgroups)
-__global__ void __launch_bounds__(256) ctc_lattice_kernel(const float *__restrict__ probs, float *__restrict__ alphas, float *__restrict__ betas,
-                                                          const UttInfo *info, const int *__restrict__ lwb_all, int A, int mb, int maxS, int maxT,
-                                                          float *loglike, int ldp) {
+__global__ void __launch_bounds__(512) ctc_lattice_kernel(float *__restrict__ alphas, float *__restrict__ betas, const UttInfo *info,
+                                                          const int *__restrict__ lwb_all, int mb, int maxS, int maxT, float *loglike) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n = blockIdx.x;
   const UttInfo u = info[n];
-  if (blockIdx.y == 1) {
-    if (u.feasible) ctc_beta_pass(probs, betas, u, lwb_all, n, mb, maxS, maxT, ldp, smem);
-    return;
-  }
+  const bool beta = blockIdx.y == 1;
   if (!u.feasible) {
-    if (threadIdx.x == 0) loglike[n] = 0.0f;
+    if (!beta && threadIdx.x == 0) loglike[n] = 0.0f;
     return;
   }
-  const int S = u.S, T = u.T;
-  float *a0 = smem, *a1 = smem + maxS;
+  const int S = u.S, T = u.T, nthr = blockDim.x, nslots = (S + nthr - 1) / nthr;  // nslots <= kLatSlots (host check), uniform
+  float *c0 = smem, *c1 = smem + maxS;
   int *lab = reinterpret_cast<int *>(smem + 2 * maxS);
-  for (int s = threadIdx.x; s < S; s += blockDim.x) lab[s] = lwb_all[u.lab_off + s];
+  for (int s = threadIdx.x; s < S; s += nthr) lab[s] = lwb_all[u.lab_off + s];
   __syncthreads();
-  const float *p = probs + (long)n * ldp;  // time stride ldp*mb
-  const long tstride = (long)ldp * mb;
-  float *al = alphas + (long)n * maxS * maxT;
-  for (int s = threadIdx.x; s < S; s += blockDim.x) {
-    float v = s < 2 ? logf_cr(p[lab[s]]) : kNegInf;
-    a0[s] = v;
-    al[s] = v;
+  float *lat = (beta ? betas : alphas) + (long)n * maxS * maxT;   // holds the emission terms, becomes the lattice
+  // per-slot constants: may this state take the skip transition (from s - 2 forward, from s + 2 backward)?
+  bool skip[kLatSlots];
+#pragma unroll
+  for (int k = 0; k < kLatSlots; k++) {
+    const int s = threadIdx.x + k * nthr;
+    skip[k] = false;
+    if (s < S) {
+      const int l = lab[s];
+      skip[k] = beta ? (s + 2 < S && l != 0 && l != lab[s + 2]) : (s >= 2 && l != 0 && l != lab[s - 2]);
+    }
+  }
+  // first column
+  const int tfirst = beta ? T - 1 : 0, dt = beta ? -1 : 1;
+  float lp[kLatSlots];
+#pragma unroll
+  for (int k = 0; k < kLatSlots; k++) {
+    const int s = threadIdx.x + k * nthr;
+    lp[k] = s < S ? lat[(long)tfirst * S + s] : 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < kLatSlots; k++) {
+    const int s = threadIdx.x + k * nthr;
+    if (s < S) {
+      const bool start = beta ? (s >= S - 2) : (s < 2);
+      const float v = start ? lp[k] : kNegInf;
+      c0[s] = v;
+      lat[(long)tfirst * S + s] = v;
+    }
   }
   __syncthreads();
-  float *prev = a0, *cur = a1;
-  for (int t = 1; t < T; t++) {
-    const float *pt = p + t * tstride;
-    for (int s = threadIdx.x; s < S; s += blockDim.x) {
-      const int l = lab[s];
-      float sum = prev[s];
-      if (s >= 1) sum = log_plus(sum, prev[s - 1]);
-      if (s >= 2 && l != 0 && l != lab[s - 2]) sum = log_plus(sum, prev[s - 2]);
-      float v = sum + logf_cr(pt[l]);
-      cur[s] = v;
-      al[(long)t * S + s] = v;
+  float *prev = c0, *cur = c1;
+  for (int step = 1; step < T; step++) {
+    const int t = tfirst + dt * step;
+#pragma unroll
+    for (int k = 0; k < kLatSlots; k++) {  // this frame's emission terms: in flight while the LDS reads and log_plus of the step run
+      if (k >= nslots) break;
+      const int s = threadIdx.x + k * nthr;
+      lp[k] = s < S ? lat[(long)t * S + s] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < kLatSlots; k++) {
+      if (k >= nslots) break;
+      const int s = threadIdx.x + k * nthr;
+      if (s < S) {
+        float sum = prev[s];
+        if (beta) {
+          if (s + 1 < S) sum = log_plus(sum, prev[s + 1]);
+          if (skip[k]) sum = log_plus(sum, prev[s + 2]);
+        } else {
+          if (s >= 1) sum = log_plus(sum, prev[s - 1]);
+          if (skip[k]) sum = log_plus(sum, prev[s - 2]);
+        }
+        const float v = sum + lp[k];
+        cur[s] = v;
+        lat[(long)t * S + s] = v;
+      }
     }
     __syncthreads();
     float *tmp = prev; prev = cur; cur = tmp;
   }
-  if (threadIdx.x == 0) {
+  if (!beta && threadIdx.x == 0) {
     float ll = kNegInf;
     if (S > 1) ll = log_plus(ll, prev[S - 2]);
     ll = log_plus(ll, prev[S - 1]);
     loglike[n] = ll;
-  }
-}
-
-// ---- beta -------------------------------------------------------------------------------------------------
-// Mirror of the alpha pass (cpu_ctc.h:300-350 without the per-frame reductions): beta rows ping-pong in LDS and
-// are written to the workspace.  Runs concurrently with the alpha pass (blockIdx.y selects the pass).
-__device__ void ctc_beta_pass(const float *__restrict__ probs, float *__restrict__ betas, const UttInfo &u, const int *__restrict__ lwb_all, int n,
-                              int mb, int maxS, int maxT, int ldp, float *smem) {
-  const int S = u.S, T = u.T;
-  float *b0 = smem, *b1 = smem + maxS;
-  int *lab = reinterpret_cast<int *>(smem + 2 * maxS);
-  for (int s = threadIdx.x; s < S; s += blockDim.x) lab[s] = lwb_all[u.lab_off + s];
-  __syncthreads();
-  const float *p = probs + (long)n * ldp;
-  const long tstride = (long)ldp * mb;
-  float *be = betas + (long)n * maxS * maxT;
-  float *nextb = b0, *curb = b1;
-  for (int t = T - 1; t >= 0; t--) {
-    const float *pt = p + t * tstride;
-    for (int s = threadIdx.x; s < S; s += blockDim.x) {
-      const int l = lab[s];
-      float v;
-      if (t == T - 1) {
-        v = (s >= S - 2) ? logf_cr(pt[l]) : kNegInf;
-      } else {
-        float sum = nextb[s];
-        if (s + 1 < S) sum = log_plus(sum, nextb[s + 1]);
-        if (s + 2 < S && l != 0 && l != lab[s + 2]) sum = log_plus(sum, nextb[s + 2]);
-        v = sum + logf_cr(pt[l]);
-      }
-      curb[s] = v;
-      be[(long)t * S + s] = v;
-    }
-    __syncthreads();
-    float *tmp = nextb; nextb = curb; curb = tmp;
   }
 }
 
@@ -165,12 +185,36 @@ __device__ void ctc_beta_pass(const float *__restrict__ probs, float *__restrict
 // rounded to float): at |alpha + beta| of several 1e3 a float ulp is 2-5e-4, so any other summation order moves
 // the posteriors by ~1e-4 relative.  Lane 0 walks the blank states, the other lanes the chains of the non-blank
 // labels (first occurrence -> next occurrence of the same label).
+// The blank label owns every other state: its reduce-by-label is ONE chain of L + 1 sequential log_plus per frame.  Walked by a
+// single lane of the frame's wave (as the other chains are) it made the gradient kernel FP64-issue bound at 1/64 lane
+// utilisation (1.44 of 3.07 ms for 32 x <= 800 x 128).  Here the chains of 64 FRAMES run side by side in the lanes of one wave;
+// the order inside every chain is unchanged (ascending state index, each step rounded to float).
+__global__ void __launch_bounds__(64) ctc_blank_kernel(const float *__restrict__ alphas, const float *__restrict__ betas, const UttInfo *info,
+                                                       int maxS, int maxT, float *__restrict__ blank_acc) {
+  const int n = blockIdx.y, t = blockIdx.x * 64 + threadIdx.x;
+  const UttInfo u = info[n];
+  if (!u.feasible || t >= u.T) return;
+  const int S = u.S;
+  const float *al = alphas + (long)n * maxS * maxT + (long)t * S, *be = betas + (long)n * maxS * maxT + (long)t * S;
+  float acc = kNegInf;
+  int s = 0;
+  for (; s + 14 < S; s += 16) {  // eight blank states per round: their loads are in flight together
+    float ab[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) ab[k] = al[s + 2 * k] + be[s + 2 * k];
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc = log_plus(ab[k], acc);
+  }
+  for (; s < S; s += 2) acc = log_plus(al[s] + be[s], acc);
+  blank_acc[(long)n * maxT + t] = acc;
+}
+
 constexpr int kGradWaves = 4;
 __global__ void __launch_bounds__(64 * kGradWaves) ctc_grad_kernel(const float *__restrict__ probs, const float *__restrict__ alphas,
                                                                     const float *__restrict__ betas, float *__restrict__ grads, const UttInfo *info,
                                                                     const int *__restrict__ lwb_all, const int *__restrict__ next_all,
                                                                     const int *__restrict__ first_all, int A, int mb, int maxS, int maxT,
-                                                                    const float *loglike, int ldg, int ldp) {
+                                                                    const float *loglike, int ldg, int ldp, const float *__restrict__ blank_acc) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n = blockIdx.y;
   const UttInfo u = info[n];
@@ -205,9 +249,7 @@ __global__ void __launch_bounds__(64 * kGradWaves) ctc_grad_kernel(const float *
     __syncthreads();
     if (live) {
       if (lane == 0) {
-        float acc = kNegInf;
-        for (int s = 0; s < S; s += 2) acc = log_plus(ab[s], acc);
-        out[0] = acc;
+        out[0] = blank_acc[(long)n * maxT + t];   // ctc_blank_kernel
       } else {
         for (int s = 2 * (lane - 1) + 1; s < S; s += 2 * 63) {
           if (fst[s]) {
@@ -239,7 +281,7 @@ __global__ void neg_costs_kernel(const float *loglike, const UttInfo *info, floa
 }
 
 struct Layout {
-  size_t probs, alphas, betas, info, lwb, nxt, fst, loglike, costs, total;
+  size_t probs, alphas, betas, info, lwb, nxt, fst, loglike, costs, blank, total;
 };
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 Layout make_layout(int A, int mb, int maxT, int maxS, size_t total_S) {
@@ -254,6 +296,7 @@ Layout make_layout(int A, int mb, int maxT, int maxS, size_t total_S) {
   l.fst = o; o += align256(sizeof(int) * total_S);
   l.loglike = o; o += align256(sizeof(float) * mb);
   l.costs = o; o += align256(sizeof(float) * mb);
+  l.blank = o; o += align256(sizeof(float) * (size_t)mb * maxT);
   l.total = o;
   return l;
 }
@@ -371,15 +414,23 @@ static ctcStatus_t ctc_loss_impl(const float *const activations, int ld_acts, fl
     attr_done = true;
   }
   float *betas = reinterpret_cast<float *>(ws + lay.betas);
-  // alpha and (when gradients are wanted) beta lattices side by side: 2 x mb workgroups
-  hipLaunchKernelGGL(ctc_lattice_kernel, dim3(mb, gradients != nullptr ? 2 : 1), dim3(256), lds_lattice, stream, probs, alphas, betas, d_info, d_lwb,
-                     A, mb, maxS, Tl, d_ll, ldp);
+  // emission terms for every (utterance, frame, state) in one parallel pass, then the alpha and (when gradients are wanted)
+  // beta lattices side by side: 2 x mb workgroups; as many threads as states (up to 512), kLatSlots states per thread beyond
+  hipLaunchKernelGGL(ctc_emit_kernel, dim3(Tl, mb), dim3(256), 0, stream, probs, alphas, betas, d_info, d_lwb, mb, maxS, Tl, ldp,
+                     gradients != nullptr ? 1 : 0);
+  int lat_threads = 64;
+  while (lat_threads < maxS && lat_threads < 512) lat_threads *= 2;
+  if (maxS > lat_threads * kLatSlots) return CTC_STATUS_INVALID_VALUE;  // label sequences beyond 2047 symbols
+  hipLaunchKernelGGL(ctc_lattice_kernel, dim3(mb, gradients != nullptr ? 2 : 1), dim3(lat_threads), lds_lattice, stream, alphas, betas, d_info, d_lwb,
+                     mb, maxS, Tl, d_ll);
   if (gradients != nullptr) {
     // one wave per (frame, utterance); a few frames per wave so the label tables are staged once per workgroup
     int tchunks = (Tl + kGradWaves * 4 - 1) / (kGradWaves * 4);
     if (tchunks < 1) tchunks = 1;
+    float *d_blank = reinterpret_cast<float *>(ws + lay.blank);
+    hipLaunchKernelGGL(ctc_blank_kernel, dim3((Tl + 63) / 64, mb), dim3(64), 0, stream, alphas, betas, d_info, maxS, Tl, d_blank);
     hipLaunchKernelGGL(ctc_grad_kernel, dim3(tchunks, mb), dim3(64 * kGradWaves), lds_grad, stream, probs, alphas, betas, gradients, d_info, d_lwb,
-                       d_nxt, d_fst, A, mb, maxS, Tl, d_ll, ld_grads, ldp);
+                       d_nxt, d_fst, A, mb, maxS, Tl, d_ll, ld_grads, ldp, d_blank);
   }
   hipLaunchKernelGGL(neg_costs_kernel, dim3((mb + 255) / 256), dim3(256), 0, stream, d_ll, d_info, d_costs, mb);
   if (hipGetLastError() != hipSuccess) return CTC_STATUS_EXECUTION_FAILED;
