@@ -632,6 +632,8 @@ void launch_variant(GemmArgs &g) {
   // the 8-wave tile inside the training step (devtools/sweep_tiles.sh: 70.0 vs 72.5 us average over the NT launches)
   else if (big_grid && !(A_KC && B_KC)) cfg = 212;
   else cfg = 207;
+  // (32 x 64 / 32 x 128 tiles for products whose 64 x 64 grid leaves a third of the chip idle were measured on the LC-BLSTM step:
+  //  1920 x 256 x 512 16.4 vs 17.1 us, but the long-K members lose their K split: 4.21 vs 3.75 ms per step.  Not taken.)
   t_last_cfg = cfg;
   if (cfg >= 200) {
     if (gemm_glds_launch(g, A_KC, B_KC, cfg)) { if (!A_KC) g.ep.colsum = nullptr; return; }  // column sums done in-kernel

@@ -258,8 +258,10 @@ bool LstmDir::ForwardFinish(int T, int S, CuMatrix *buf, CuMatrixBase *out, int 
 void LstmDir::BackwardPrepare(const CuMatrixBase &out_diff, int T, int S, CuMatrix *dbuf, bool persistent) const {
   ASLP_ASSERT(out_diff.NumRows() == T * S && out_diff.NumCols() == Rec());
   if (persistent) {
+    // the persistent backward kernel writes every gate / c / h / m entry of row blocks 1..T itself (d_r follows in BackwardFinish):
+    // only the two boundary row blocks have to be zero -- 1 MB instead of a 29 MB memset per direction and layer
     dbuf->Resize((T + 2) * S, Width(), kUndefined);
-    aslp_lstm_seq_fill(dbuf->Data(), dbuf->Stride(), T, S, 0, GC());
+    aslp_lstm_seq_fill(dbuf->Data(), dbuf->Stride(), T, S, 0, 0);
   } else {
     dbuf->Resize((T + 2) * S, Width(), kSetZero);
   }
@@ -481,8 +483,8 @@ void LstmFamily::BackpropagateFnc(const CuMatrixBase &in, const CuMatrixBase &, 
     aslp_lstm_seq q = aslp_lstm_seq();
     q.ndir = cfg_.bidir ? 2 : 1; q.ld = 4; q.ldw = 4; q.T = T; q.S = S; q.C = ncell_; q.cifg = cfg_.cifg ? 1 : 0;
     const bool persistent = aslp_lstm_seq_supported(&q, 1) != 0;
-    f_.BackwardPrepare(od_f, T, S, &f_dbuf_, false);
-    if (cfg_.bidir) b_.BackwardPrepare(od_b, T, S, &b_dbuf_, false);
+    f_.BackwardPrepare(od_f, T, S, &f_dbuf_, persistent);
+    if (cfg_.bidir) b_.BackwardPrepare(od_b, T, S, &b_dbuf_, persistent);
     ASLP_ASSERT(f_dbuf_.Stride() == f_buf_.Stride());
     if (persistent) {
       q.ld = f_dbuf_.Stride(); q.ldw = f_.Weff().Stride();
