@@ -52,13 +52,30 @@ constexpr long kSpinLimitTicks = 200000000L;  // wall_clock64 runs at 100 MHz: 2
 __device__ __forceinline__ float dsigm(float y, float d) { return d * y * (1.0f - y); }
 __device__ __forceinline__ float dtanh(float y, float d) { return d * (1.0f - y * y); }
 
+// Every base pointer handed to a buffer instruction here is wave-uniform by construction (kernel arguments, blockIdx, the loop
+// counter), but hipcc cannot always prove it (the direction's pointers are picked from the argument struct with an index that
+// went through shared memory) and then wraps EVERY buffer load / store in a waterfall loop over the lanes' descriptor values.
+// readfirstlane makes the uniformity explicit: the descriptor lives in SGPRs and the access is one instruction.
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float *p) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, 0x7fffffff, 0x00020000);
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  float *u = reinterpret_cast<float *>(((unsigned long long)hi << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(u, 0, 0x7fffffff, 0x00020000);
 }
 __device__ __forceinline__ bool has_sentinel(const u32x4 &v) {
   return v.x == kSentinel || v.y == kSentinel || v.z == kSentinel || v.w == kSentinel;
 }
 __device__ __forceinline__ float as_f(unsigned u) { return __uint_as_float(u); }
+// cross-lane moves on the DPP path of the VALU (no LDS crossbar round trip like ds_bpermute): lane K of the caller's quad, and the
+// lane N places up within the caller's row of 16 lanes
+template <int K>
+__device__ __forceinline__ float quad_bcast(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), K * 0x55, 0xF, 0xF, true));   // quad_perm:[K,K,K,K]
+}
+template <int N>
+__device__ __forceinline__ float row_up(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x100 + N, 0xF, 0xF, true));  // row_shl:N -> dst[i] = src[i + N]
+}
 
 // device-side status: abort_flag[0] abort flag (zeroed before every launch), abort_flag[2] running count of hand-off
 // re-polls (diagnostics, aslp_lstm_seq_polls); host_err: mapped host word, counts timeouts
@@ -188,7 +205,6 @@ __global__ void __launch_bounds__(512) lstm_seq_fwd(aslp_lstm_seq a, SeqStatus s
   const aslp_lstm_seq_dir D = a.dir[R.dir];
   const int C = a.C, S = a.S, T = a.T, ld = a.ld;
   const int GC = G * C, oc = GC, oh = GC + C, om = GC + 2 * C;
-  constexpr int gi = 1, gf = CIFG ? 1 : 2, go = CIFG ? 2 : 3;
   const int c0 = R.c0, s0 = R.s0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int qs = (lane >> 2) & 1, qc = lane >> 3, jl = lane & 3;
@@ -212,11 +228,17 @@ __global__ void __launch_bounds__(512) lstm_seq_fwd(aslp_lstm_seq a, SeqStatus s
   const bool h0 = p0 < npiece, h1 = p1 < npiece;
   const int st0 = h0 ? p0 / c4 : 0, kq0 = h0 ? p0 % c4 : 0, st1 = h1 ? p1 / c4 : 0, kq1 = h1 ? p1 % c4 : 0;
   const int off0 = (min(s0 + st0, S - 1) * ld + om + 4 * kq0) * 4, off1 = (min(s0 + st1, S - 1) * ld + om + 4 * kq1) * 4;
-  // epilogue role: threads 0..127 own one (stream, cell) pair each
-  const int sl = threadIdx.x >> 4, cc = threadIdx.x & 15, s = s0 + sl, cell = c0 + cc;
-  const bool live = threadIdx.x < 128 && s < S && cell < C;
+  // gate-block role: a quad of lanes owns one (stream, cell) pair, lane r of the quad its gate r (g, i, f, o; CIFG: g, f, o, -).
+  // The five transcendentals of a pair then take two rounds (gates side by side, then tanh(c) beside the output gate) instead of
+  // five in a row on one lane, and all 8 waves share the work.
+  const int pair = threadIdx.x >> 2, role = threadIdx.x & 3;
+  const int sl = pair >> 4, cc = pair & 15, s = s0 + sl, cell = c0 + cc;
+  const bool live = s < S && cell < C;
   const int cq = live ? cell : 0, sq = live ? s : 0;
-  const float pf = D.peep_f[cq], po = D.peep_o[cq], pi = CIFG ? 0.f : D.peep_i[cq];
+  // the peephole weight of this lane's gate (none for g): i <- c(t-1), f <- c(t-1), o <- c(t)
+  float pw = 0.f;
+  if (!CIFG) pw = role == 1 ? D.peep_i[cq] : role == 2 ? D.peep_f[cq] : role == 3 ? D.peep_o[cq] : 0.f;
+  else pw = role == 1 ? D.peep_f[cq] : role == 2 ? D.peep_o[cq] : 0.f;
   const int slen = (D.seq_lengths && live) ? D.seq_lengths[sq] : 0x7fffffff;
   float cprev = 0.f;
   {
@@ -230,11 +252,7 @@ __global__ void __launch_bounds__(512) lstm_seq_fwd(aslp_lstm_seq a, SeqStatus s
     float *ys = D.y + ((long)t * S + sq) * ld;
     long tm = tick(st);
     // the x-part (+ bias) of this pair's gates: written before the launch, requested before the hand-off wait
-    float xg = 0.f, xf = 0.f, xo = 0.f, xi = 0.f;
-    if (live) {
-      xg = ys[cq]; xf = ys[gf * C + cq]; xo = ys[go * C + cq];
-      if (!CIFG) xi = ys[gi * C + cq];
-    }
+    const float xr = (live && role < G) ? ys[role * C + cq] : 0.f;
     f32x4 acc[2][2];
 #pragma unroll
     for (int h = 0; h < 2; h++) { acc[h][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[h][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -297,34 +315,33 @@ __global__ void __launch_bounds__(512) lstm_seq_fwd(aslp_lstm_seq a, SeqStatus s
       for (int w = 0; w < 8; w++) f |= fail[par][w];
       if (f) return;  // uniform: every wave reads the same eight words
     }
-    if (threadIdx.x >= 128) continue;  // whole waves: the quad gather below needs every lane of waves 0 and 1
-    float pre[G];
+    float pre = 0.f;
+    if (role < G) {
+      pre = red[par][0][sl][role * 16 + cc];
 #pragma unroll
-    for (int g = 0; g < G; g++) {
-      float v = red[par][0][sl][g * 16 + cc];
-#pragma unroll
-      for (int w = 1; w < 8; w++) v += red[par][w][sl][g * 16 + cc];
-      pre[g] = v;
+      for (int w = 1; w < 8; w++) pre += red[par][w][sl][role * 16 + cc];
     }
-    float gg = 0.f, ii = 0.f, ff = 0.f, oo = 0.f, cellv = 0.f, hh = 0.f, mm = 0.f;
-    if (t <= slen) {  // nnet-blstm-projected-streams.h:654-657: rows past the utterance end are zeroed
-      gg = tanh_ref(xg + pre[0]);
-      ff = sigmoid_ref(xf + pre[gf] + cprev * pf);
-      if (!CIFG) {
-        ii = sigmoid_ref(xi + pre[gi] + cprev * pi);
-        cellv = gg * ii + cprev * ff;
-      } else {
-        cellv = -gg * ff + gg + cprev * ff;
-      }
-      cellv = fminf(fmaxf(cellv, -50.0f), 50.0f);
-      hh = tanh_ref(cellv);
-      oo = sigmoid_ref(xo + pre[go] + cellv * po);
-      mm = hh * oo;
-    }
-    // publish m(t) first: it is what the other workgroups wait for.  A quad's four cells are 16 contiguous bytes.
+    const bool masked = t > slen;  // nnet-blstm-projected-streams.h:654-657: rows past the utterance end are zeroed
+    // round 1: g = tanh(.), i / f = sigmoid(. + c(t-1) * peephole), each on its own lane
+    float gate = 0.f;
+    if (role == 0) gate = tanh_ref(xr + pre);
+    else if (role < G - 1) gate = sigmoid_ref(xr + pre + cprev * pw);
+    const float gg = quad_bcast<0>(gate), g1 = quad_bcast<1>(gate), g2 = quad_bcast<2>(gate);
+    float cellv;
+    if (!CIFG) cellv = gg * g1 + cprev * g2;        // g * i + c(t-1) * f
+    else cellv = -gg * g1 + gg + cprev * g1;        // coupled input gate: i = 1 - f
+    cellv = fminf(fmaxf(cellv, -50.0f), 50.0f);
+    // round 2: h = tanh(c) on lane 0, o = sigmoid(. + c * peephole) on lane G - 1
+    float hh = 0.f;
+    if (role == 0) hh = tanh_ref(cellv);
+    if (role == G - 1) gate = sigmoid_ref(xr + pre + cellv * pw);
+    const float oo = quad_bcast<G - 1>(gate);
+    float mm = hh * oo;   // meaningful on lane 0 of the quad
+    if (masked) { gate = 0.f; cellv = 0.f; hh = 0.f; mm = 0.f; }
+    // publish m(t) first: it is what the other workgroups wait for.  Four consecutive cells = lane 0 of four consecutive quads.
     {
-      const float m1 = __shfl_down(mm, 1, 64), m2 = __shfl_down(mm, 2, 64), m3 = __shfl_down(mm, 3, 64);
-      if (live && (cc & 3) == 0) {
+      const float m1 = row_up<4>(mm), m2 = row_up<8>(mm), m3 = row_up<12>(mm);
+      if (live && role == 0 && (cc & 3) == 0) {
         u32x4 pk = {__float_as_uint(mm), __float_as_uint(m1), __float_as_uint(m2), __float_as_uint(m3)};
         const __amdgpu_buffer_rsrc_t rs = make_rsrc(D.y + (long)t * S * ld);
         const int off = (s * ld + om + cell) * 4;
@@ -333,8 +350,9 @@ __global__ void __launch_bounds__(512) lstm_seq_fwd(aslp_lstm_seq a, SeqStatus s
       }
     }
     if (live) {
-      ys[cell] = gg; ys[gf * C + cell] = ff; ys[go * C + cell] = oo; ys[oc + cell] = cellv; ys[oh + cell] = hh;
-      if (!CIFG) ys[gi * C + cell] = ii;
+      if (role < G) ys[role * C + cell] = gate;
+      if (role == 0) ys[oh + cell] = hh;
+      if (role == 1) ys[oc + cell] = cellv;
     }
     cprev = cellv;
     tock(st, 5, tm);  // epilogue
