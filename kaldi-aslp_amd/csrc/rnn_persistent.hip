@@ -580,6 +580,8 @@ struct SeqRuntime {
   int timing_mode = 0;  // 0 off, 1 forward kernel, 2 backward kernel
   unsigned epoch = 0, err_seen = 0;
   bool ring_ready = false;
+  hipEvent_t last_done = nullptr;   // completion of the latest persistent launch, and the stream it went to
+  hipStream_t last_stream = nullptr;
   unsigned *host_err = nullptr;    // mapped host memory (device-visible)
   unsigned *host_err_dev = nullptr;
   int num_cu = 0;
@@ -665,6 +667,12 @@ static void launch_seq(const aslp_lstm_seq *a, bool backward, const char *who) {
     return;
   }
   SeqRuntime &rt = seq_runtime();
+  // One persistent launch at a time per process: the kernels share the placement table, the abort word and the share ring, and two
+  // grids that both need every CU must not be half resident beside each other.  Launches from different host threads / streams
+  // are therefore chained by an event (no host wait); the common single-stream case costs one event record per launch.
+  static std::mutex launch_mu;
+  std::lock_guard<std::mutex> launch_lock(launch_mu);
+  if (rt.last_done && rt.last_stream != cur_stream()) ASLP_CHECK_HIP(hipStreamWaitEvent(cur_stream(), rt.last_done, 0));
   // Device-side state is self-cleaning: the placement table is epoch-tagged and every share a backward launch publishes is
   // consumed and reset inside that launch.  Only after a launch that gave up (the mapped error word moved) are the abort
   // word and the share ring put back by hand.
@@ -681,6 +689,8 @@ static void launch_seq(const aslp_lstm_seq *a, bool backward, const char *who) {
   const int wpc = (a->C + kCellsPerWg - 1) / kCellsPerWg;
   if (!backward) hipLaunchKernelGGL(pick_fwd(a->cifg != 0, a->C), dim3(kMaxChains * wpc), dim3(512), 0, cur_stream(), *a, st, rt.place);
   else hipLaunchKernelGGL(pick_bwd(a->cifg != 0, a->C), dim3(kMaxChains * wpc), dim3(512), 0, cur_stream(), *a, st, rt.place, rt.inbox);
+  if (!rt.last_done) (void)hipEventCreateWithFlags(&rt.last_done, hipEventDisableTiming);
+  if (rt.last_done) { ASLP_CHECK_HIP(hipEventRecord(rt.last_done, cur_stream())); rt.last_stream = cur_stream(); }
   check_launch(who);
 }
 
