@@ -210,6 +210,61 @@ def cfg3_block(aslp, dev):
     return out
 
 
+def cfg3_bsp_block(aslp, dev, native_parallel, comm, rank, world, sync_period):
+    """N > 1 only (extra key `cfg3_bsp`): every rank trains its own replica of the cfg3 LC-BLSTM (chunked, Xent) on its own synthetic shard and
+    the replicas are averaged BSP-style by the native BspWorker every `sync_period` valid frames -- the configuration BASELINE.json's 8-GPU
+    target is quoted on.  Whole-job valid frames/s, barrier + synchronise on both sides, max over ranks."""
+    import torch
+    S, CHUNK, RIGHT, A = 32, 40, 20, 128
+    T = CHUNK + RIGHT
+    lines, d = ["<NnetProto>"], 40
+    for _ in range(4):
+        lines.append("<BLstmProjectedStreamsLC> <InputDim> %d <OutputDim> 512 <CellDim> 512 <ParamScale> 0.02 <ClipGradient> 5.0" % d)
+        d = 512
+    lines += ["<AffineTransform> <InputDim> 512 <OutputDim> %d <BiasMean> 0.0 <BiasRange> 0.0 <ParamStddev> 0.04" % A,
+              "<Softmax> <InputDim> %d <OutputDim> %d" % (A, A), "</NnetProto>"]
+    net = aslp.Nnet.Init("\n".join(lines) + "\n", seed=777)
+    net.SetTrainOptions(learn_rate=1e-5, momentum=0.9)
+    net.SetChunkSize(CHUNK)
+    xent = aslp.Xent()
+    g = torch.Generator(device=dev)
+    g.manual_seed(99 + rank)
+    x = torch.randn(T * S, 40, device=dev, generator=g)
+    labels = torch.randint(0, A, (T * S,), device=dev, generator=g, dtype=torch.int32)
+    fw = torch.ones(T * S, device=dev)
+    fw.view(T, S)[CHUNK:] = 0
+    worker = native_parallel.BspWorker(comm)
+    worker.InitParam(net)
+    since = 0
+    steps, warm = 100, 10
+
+    def step(i):
+        nonlocal since
+        net.ResetLstmStreams([1] * S if i == 0 else [0] * S)
+        net.TrainStepXent(xent, x, labels, fw)
+        since += CHUNK * S
+        if since >= sync_period:
+            worker.Synchronize(since)
+            since = 0
+
+    for i in range(warm):
+        step(i)
+    worker.Synchronize(max(since, 1))
+    since = 0
+    comm.Barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warm + i)
+    torch.cuda.synchronize()
+    comm.Barrier()
+    torch.cuda.synchronize()
+    el = comm.MaxOverRanks(time.perf_counter() - t0)
+    worker.close()
+    return {"workload": "cfg3 LC-BLSTM (4 x 512-cell, chunk 40 + 20, S = 32) + Xent, BSP every %d valid frames" % sync_period, "n_gpus": world,
+            "steps": steps, "ms_per_step": el * 1e3 / steps, "valid_frames_per_sec": world * steps * CHUNK * S / el, "scaling": "weak"}
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` from a bare shell (no launcher environment): start N ranks, one process per GPU, and hand
     back rank 0's JSON line.  This parent never touches the GPU (no torch.cuda call, no HIP call): the children are ordinary
@@ -426,11 +481,20 @@ def main():
         if world == 1:
             out["ctc_loss_fp32_rel_err"] = ctc_rel_err(aslp, dev)
         if world == 1 and not args.no_cfg3:
-            del net
+            net = None
             torch.cuda.empty_cache()
             out["cfg3"] = cfg3_block(aslp, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+    if comm is not None and not args.no_cfg3:   # N > 1 (or ASLP_BENCH_FORCE_SYNC=1): every rank takes part; rank 0 reports
+        if worker is not None:
+            worker.close()   # it aliases the cfg2 net's parameter tensors
+            worker = None
+        net = None
+        torch.cuda.empty_cache()
+        blk = cfg3_bsp_block(aslp, dev, native_parallel, comm, rank, world, args.sync_period)
+        if rank == 0:
+            out["cfg3_bsp"] = blk
     if comm is not None:
         comm.Barrier()
         if worker is not None:

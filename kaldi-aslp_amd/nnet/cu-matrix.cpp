@@ -148,6 +148,43 @@ StreamMarker::~StreamMarker() { if (ev_) (void)hipEventDestroy(static_cast<hipEv
 void StreamMarker::Record() { CheckHip(hipEventRecord(static_cast<hipEvent_t>(ev_), cur_stream()), "hipEventRecord"); recorded_ = true; }
 bool StreamMarker::Done() const { return !recorded_ || hipEventQuery(static_cast<hipEvent_t>(ev_)) == hipSuccess; }
 void StreamMarker::Wait() const { if (recorded_) CheckHip(hipEventSynchronize(static_cast<hipEvent_t>(ev_)), "hipEventSynchronize"); }
+CopyLane::CopyLane() : stream_(nullptr), ev_(nullptr) {
+  hipStream_t s;
+  hipEvent_t e;
+  CheckHip(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");  // non-blocking: no implicit ordering with the null stream
+  CheckHip(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+  stream_ = s;
+  ev_ = e;
+}
+CopyLane::~CopyLane() {
+  if (stream_) { (void)hipStreamSynchronize(static_cast<hipStream_t>(stream_)); (void)hipStreamDestroy(static_cast<hipStream_t>(stream_)); }
+  if (ev_) (void)hipEventDestroy(static_cast<hipEvent_t>(ev_));
+}
+void CopyLane::Upload(float *dst, int dst_stride, const float *src, int ld, int rows, int cols) {
+  if (!rows) return;
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  if (dst_stride == cols && ld == cols)
+    CheckHip(hipMemcpyAsync(dst, src, sizeof(float) * (size_t)rows * cols, hipMemcpyHostToDevice, s), "hipMemcpy H2D (lane)");
+  else
+    CheckHip(hipMemcpy2DAsync(dst, sizeof(float) * dst_stride, src, sizeof(float) * ld, sizeof(float) * cols, rows, hipMemcpyHostToDevice, s),
+             "hipMemcpy2D H2D (lane)");
+}
+void CopyLane::Zero(void *dst, size_t bytes) {
+  if (bytes) CheckHip(hipMemsetAsync(dst, 0, bytes, static_cast<hipStream_t>(stream_)), "hipMemset (lane)");
+}
+void CopyLane::Record(StreamMarker *m) {
+  CheckHip(hipEventRecord(static_cast<hipEvent_t>(m->ev_), static_cast<hipStream_t>(stream_)), "hipEventRecord (lane)");
+  m->recorded_ = true;
+}
+void CopyLane::LaneWaitsForStream() {
+  CheckHip(hipEventRecord(static_cast<hipEvent_t>(ev_), cur_stream()), "hipEventRecord");
+  CheckHip(hipStreamWaitEvent(static_cast<hipStream_t>(stream_), static_cast<hipEvent_t>(ev_), 0), "hipStreamWaitEvent");
+}
+void CopyLane::StreamWaitsForLane() {
+  CheckHip(hipEventRecord(static_cast<hipEvent_t>(ev_), static_cast<hipStream_t>(stream_)), "hipEventRecord (lane)");
+  CheckHip(hipStreamWaitEvent(cur_stream(), static_cast<hipEvent_t>(ev_), 0), "hipStreamWaitEvent");
+}
+void CopyLane::Sync() { CheckHip(hipStreamSynchronize(static_cast<hipStream_t>(stream_)), "hipStreamSynchronize (lane)"); }
 void StreamSync() {
   CheckHip(hipStreamSynchronize(cur_stream()), "hipStreamSynchronize");
   CheckKernels();

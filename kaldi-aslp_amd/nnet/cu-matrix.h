@@ -38,10 +38,30 @@ class StreamMarker {
   bool Done() const;    // everything issued before Record() has finished
   void Wait() const;
  private:
+  friend class CopyLane;
   void *ev_;
   bool recorded_;
   StreamMarker(const StreamMarker &) = delete;
   StreamMarker &operator=(const StreamMarker &) = delete;
+};
+// A second HIP stream for uploads that overlap the training stream (the calling thread's current stream): the frame tools
+// fill the NEXT randomizer cache on it while the minibatches of the current one train.  Ordering between the two streams is
+// explicit: LaneWaitsForStream() before the lane overwrites something the training stream may still read,
+// StreamWaitsForLane() before the training stream reads what the lane wrote.  Both are device-side waits (no host stall).
+class CopyLane {
+ public:
+  CopyLane();
+  ~CopyLane();
+  void Upload(float *dst, int dst_stride, const float *pinned_src, int ld, int rows, int cols);  // async H2D on the lane
+  void Zero(void *dst, size_t bytes);                                                            // async on the lane
+  void Record(StreamMarker *m);   // marker on the lane
+  void LaneWaitsForStream();
+  void StreamWaitsForLane();
+  void Sync();                    // host waits for the lane (buffer growth, teardown)
+ private:
+  void *stream_, *ev_;
+  CopyLane(const CopyLane &) = delete;
+  CopyLane &operator=(const CopyLane &) = delete;
 };
 // Brings the HIP runtime fully up (context, code object, first launch).  The runtime draws from libc rand() while it
 // initialises, so anything that seeds rand() for reproducible parameters (aslp-nnet-init) calls this BEFORE srand().
