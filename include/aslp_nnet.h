@@ -114,6 +114,15 @@ int aslp_randomizer_mask_generate(int seed, int size, int32_t *mask_host);
 int aslp_matrix_randomizer_create(int randomizer_size, int minibatch_size, aslp_matrix_randomizer_t *out);
 void aslp_matrix_randomizer_free(aslp_matrix_randomizer_t r);
 int aslp_matrix_randomizer_add_data(aslp_matrix_randomizer_t r, const float *dev, int rows, int cols, int stride);
+/* Staged refill (this library's addition, no reference counterpart): the rows of the NEXT cache go up on a copy stream while
+ * the minibatches of the current one are consumed.  stage_begin() any time after randomize(); stage_add() takes host rows
+ * (copied to page-locked memory, sent asynchronously); stage_commit() once the current cache is Done(): the state afterwards is
+ * the one add_data() calls with the same rows would have produced (left-over rows first, data_begin 0).
+ * stage_state: [0] the staged cache is full (IsFull of nnet-randomizer.h:83), [1] frames staged including the left-over rows */
+int aslp_matrix_randomizer_stage_begin(aslp_matrix_randomizer_t r);
+int aslp_matrix_randomizer_stage_add(aslp_matrix_randomizer_t r, const float *host, int rows, int cols);
+int aslp_matrix_randomizer_stage_commit(aslp_matrix_randomizer_t r);
+int aslp_matrix_randomizer_stage_state(aslp_matrix_randomizer_t r, int state[2]);
 int aslp_matrix_randomizer_randomize(aslp_matrix_randomizer_t r, const int32_t *mask_host, int n);
 int aslp_matrix_randomizer_next(aslp_matrix_randomizer_t r);
 /* state[0..2] = IsFull, Done, NumFrames */

@@ -105,6 +105,10 @@ _sig("aslp_matrix_randomizer_free", None, _H)
 _sig("aslp_matrix_randomizer_add_data", _i, _H, _vp, _i, _i, _i)
 _sig("aslp_matrix_randomizer_randomize", _i, _H, _i32p, _i)
 _sig("aslp_matrix_randomizer_next", _i, _H)
+_sig("aslp_matrix_randomizer_stage_begin", _i, _H)
+_sig("aslp_matrix_randomizer_stage_add", _i, _H, _vp, _i, _i)
+_sig("aslp_matrix_randomizer_stage_commit", _i, _H)
+_sig("aslp_matrix_randomizer_stage_state", _i, _H, C.POINTER(_i))
 _sig("aslp_matrix_randomizer_state", _i, _H, C.POINTER(_i))
 _sig("aslp_matrix_randomizer_value", _i, _H, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i))
 
@@ -146,6 +150,21 @@ class MatrixRandomizer:
     def Randomize(self, mask):
         a = _i32arr(mask)
         _ok(lib.aslp_matrix_randomizer_randomize(self.h, a, len(mask)))
+
+    # staged refill (include/aslp_nnet.h): host rows go up on a copy stream while the current cache is consumed
+    def StageBegin(self): _ok(lib.aslp_matrix_randomizer_stage_begin(self.h))
+
+    def StageAdd(self, host_rows):
+        import numpy as np
+        a = np.ascontiguousarray(host_rows, dtype=np.float32)
+        _ok(lib.aslp_matrix_randomizer_stage_add(self.h, a.ctypes.data_as(_vp), a.shape[0], a.shape[1]))
+
+    def StageCommit(self): _ok(lib.aslp_matrix_randomizer_stage_commit(self.h))
+
+    def StageFull(self):
+        st = (_i * 2)()
+        _ok(lib.aslp_matrix_randomizer_stage_state(self.h, st))
+        return bool(st[0])
 
     def Value(self):
         """copy of the current minibatch as a torch tensor (the C++ API returns a view)"""

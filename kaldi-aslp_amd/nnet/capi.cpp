@@ -1,6 +1,9 @@
 // capi.cpp -- C handle API (include/aslp_nnet.h) over Nnet / Xent.
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <utility>
+#include <vector>
 
 #include "aslp_nnet.h"
 #include "ctc-loss.h"
@@ -20,6 +23,12 @@ struct aslp_xent_s {
   Xent xent;
 };
 struct aslp_matrix_randomizer_s {
+  ~aslp_matrix_randomizer_s() { ReleaseStaged(); }
+  void ReleaseStaged() {
+    for (auto &b : staged) { b.second->Wait(); PinnedFree(b.first); }
+    staged.clear();
+  }
+  std::vector<std::pair<float *, std::unique_ptr<StreamMarker>>> staged;  // pinned copies of stage_add()'s rows, until the lane has sent them
   MatrixRandomizer r;
 };
 struct aslp_eesenctc_s {
@@ -349,6 +358,27 @@ void aslp_matrix_randomizer_free(aslp_matrix_randomizer_t r) { delete r; }
 int aslp_matrix_randomizer_add_data(aslp_matrix_randomizer_t r, const float *dev, int rows, int cols, int stride) {
   API_BEGIN
   r->r.AddData(CuSubMatrix(const_cast<float *>(dev), rows, cols, stride));
+  API_END
+}
+int aslp_matrix_randomizer_stage_begin(aslp_matrix_randomizer_t r) { API_BEGIN r->r.StageBegin(); API_END }
+int aslp_matrix_randomizer_stage_add(aslp_matrix_randomizer_t r, const float *host, int rows, int cols) {
+  API_BEGIN
+  float *blk = static_cast<float *>(PinnedAlloc(sizeof(float) * (size_t)rows * cols));
+  std::memcpy(blk, host, sizeof(float) * (size_t)rows * cols);
+  std::unique_ptr<StreamMarker> done(new StreamMarker);
+  r->r.StageAddPinned(blk, rows, cols, done.get());
+  r->staged.push_back(std::make_pair(blk, std::move(done)));
+  API_END
+}
+int aslp_matrix_randomizer_stage_commit(aslp_matrix_randomizer_t r) {
+  API_BEGIN
+  r->r.StageCommit();
+  r->ReleaseStaged();
+  API_END
+}
+int aslp_matrix_randomizer_stage_state(aslp_matrix_randomizer_t r, int state[2]) {
+  API_BEGIN
+  state[0] = r->r.StageFull(); state[1] = r->r.StageFrames();
   API_END
 }
 int aslp_matrix_randomizer_randomize(aslp_matrix_randomizer_t r, const int32_t *mask_host, int n) {

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <map>
@@ -133,12 +134,45 @@ void DeviceMemset(void *dst, int v, size_t bytes) {
   if (!bytes) return;
   CheckHip(hipMemsetAsync(dst, v, bytes, cur_stream()), "hipMemset");
 }
+// Page-locked blocks are cached for the life of the process: hipHostMalloc / hipHostFree cost a fraction of a millisecond
+// per call plus the (un)pinning of every page, and a cache fill of the frame tools cycles through a hundred blocks.  Sizes
+// are rounded to 1 MiB so the handful of distinct utterance lengths share blocks.  PinnedPoolRelease() gives them back.
+namespace {
+std::mutex g_pin_mu;
+std::multimap<size_t, void *> g_pin_free;
+std::map<void *, size_t> g_pin_live;
+}  // namespace
 void *PinnedAlloc(size_t bytes) {
+  const size_t sz = (std::max<size_t>(bytes, 1) + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
+  {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    auto it = g_pin_free.find(sz);
+    if (it != g_pin_free.end()) {
+      void *p = it->second;
+      g_pin_free.erase(it);
+      g_pin_live[p] = sz;
+      return p;
+    }
+  }
   void *p = nullptr;
-  CheckHip(hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault), "hipHostMalloc");
+  CheckHip(hipHostMalloc(&p, sz, hipHostMallocDefault), "hipHostMalloc");
+  std::lock_guard<std::mutex> lk(g_pin_mu);
+  g_pin_live[p] = sz;
   return p;
 }
-void PinnedFree(void *p) { if (p) (void)hipHostFree(p); }
+void PinnedFree(void *p) {
+  if (!p) return;
+  std::lock_guard<std::mutex> lk(g_pin_mu);
+  auto it = g_pin_live.find(p);
+  if (it == g_pin_live.end()) return;
+  g_pin_free.insert({it->second, p});
+  g_pin_live.erase(it);
+}
+void PinnedPoolRelease() {
+  std::lock_guard<std::mutex> lk(g_pin_mu);
+  for (auto &kv : g_pin_free) (void)hipHostFree(kv.second);
+  g_pin_free.clear();
+}
 StreamMarker::StreamMarker() : ev_(nullptr), recorded_(false) {
   hipEvent_t e;
   CheckHip(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
@@ -374,6 +408,37 @@ void CuMatrixBase::CopyToHost(float *dst, int ld) const {
 void CuMatrixBase::CopyFromMat(const HostMatrix &m) {
   ASLP_ASSERT(m.rows == rows_ && m.cols == cols_);
   CopyFromHost(m.data.data(), m.cols);
+}
+// Kaldi binary matrix ("FM", rows, cols, packed rows -- what HostMatrix::Write emits) straight from HBM: packed row blocks
+// come down into two page-locked buffers in turn, the next block is in flight while the previous one is written to the stream.
+// The pageable-memory detour of CopyToMat() (a zero-filled std::vector, a staged pageable copy) cost more than the file write.
+void CuMatrixBase::WriteBinary(std::ostream &os) const {
+  if (!os.good()) ASLP_ERR << "Failed to write matrix to stream: stream not good";
+  WriteToken(os, true, "FM");
+  WriteBasicType(os, true, (int32)rows_);
+  WriteBasicType(os, true, (int32)cols_);
+  if (rows_ == 0 || cols_ == 0) return;
+  const size_t row_bytes = sizeof(float) * (size_t)cols_;
+  const size_t kBuf = 8u << 20;
+  const int rows_per = (int)std::max<size_t>(1, kBuf / row_bytes);
+  void *buf[2] = {PinnedAlloc(std::max(kBuf, row_bytes)), PinnedAlloc(std::max(kBuf, row_bytes))};
+  StreamMarker done[2];
+  auto fetch = [&](int r0, int k) {
+    const int nr = std::min(rows_per, rows_ - r0);
+    CheckHip(hipMemcpy2DAsync(buf[k], row_bytes, data_ + (size_t)r0 * stride_, sizeof(float) * stride_, row_bytes, nr, hipMemcpyDeviceToHost,
+                              cur_stream()), "hipMemcpy2D D2H");
+    done[k].Record();
+  };
+  fetch(0, 0);
+  int k = 0;
+  for (int r0 = 0; r0 < rows_; r0 += rows_per, k ^= 1) {
+    if (r0 + rows_per < rows_) fetch(r0 + rows_per, k ^ 1);
+    done[k].Wait();
+    os.write(static_cast<const char *>(buf[k]), row_bytes * std::min(rows_per, rows_ - r0));
+  }
+  PinnedFree(buf[0]);
+  PinnedFree(buf[1]);
+  if (!os.good()) ASLP_ERR << "Failed to write matrix to stream";
 }
 void CuMatrixBase::CopyToMat(HostMatrix *m) const {
   m->Resize(rows_, cols_);

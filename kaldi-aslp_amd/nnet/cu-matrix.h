@@ -29,7 +29,8 @@ void StreamSync();
 // a pinned block (possibly on another thread), CopyFromPinnedHost() sends it with one async copy, and the block may be
 // reused once a StreamMarker recorded after the copy reports Done().
 void *PinnedAlloc(size_t bytes);
-void PinnedFree(void *p);
+void PinnedFree(void *p);      // back to the process-wide cache of page-locked blocks
+void PinnedPoolRelease();      // hipHostFree of everything cached
 class StreamMarker {
  public:
   StreamMarker();
@@ -228,6 +229,7 @@ class CuMatrixBase {
   void CopyToHost(float *dst, int ld) const;
   void CopyFromMat(const HostMatrix &m);
   void CopyToMat(HostMatrix *m) const;
+  void WriteBinary(std::ostream &os) const;  // the bytes HostMatrix::Write(os, true) would write
   void AddMat(float alpha, const CuMatrixBase &A, MatrixTransposeType tA = kNoTrans);  // this += alpha*A
   void AddMatMat(float alpha, const CuMatrixBase &A, MatrixTransposeType tA, const CuMatrixBase &B, MatrixTransposeType tB,
                  float beta, const aslp_gemm_epilogue *ep = nullptr);
@@ -282,7 +284,10 @@ class CuMatrix : public CuMatrixBase {
     std::swap(data_, o->data_); std::swap(rows_, o->rows_); std::swap(cols_, o->cols_); std::swap(stride_, o->stride_);
   }
   void Read(std::istream &is, bool binary) { HostMatrix m; m.Read(is, binary); *this = m; }
-  void Write(std::ostream &os, bool binary) const { HostMatrix m; CopyToMat(&m); m.Write(os, binary); }
+  void Write(std::ostream &os, bool binary) const {
+    if (binary) { WriteBinary(os); return; }
+    HostMatrix m; CopyToMat(&m); m.Write(os, binary);
+  }
 };
 
 class CuSubMatrix : public CuMatrixBase {

@@ -74,6 +74,7 @@ class FrameDataReader {
     feature_randomizer_.Next();
     *targets = &targets_randomizer_.Value();
     targets_randomizer_.Next();
+    if (!read_done_) Prefetch(false);
     return true;
   }
   int32 NumUtterances() const { return num_done_; }
@@ -156,54 +157,74 @@ class FrameDataReader {
       }
     }
   }
-  void FillRandomizer() {  // data-reader.cc:66-128
-    Timer fill_timer;
-    double t_wait = 0.0;
-    int32 added = 0;
+  // Moves parsed utterances from the reader thread's queue into the STAGED next cache (uploads on the randomizer's copy
+  // lane, nnet-randomizer.h) until that cache is full or the table ends.  Non-blocking calls (one per ReadData) take what
+  // has arrived, so by the time the current cache runs out the next one is already in HBM; the blocking call finishes it.
+  // The loop body is the reference's, data-reader.cc:72-118, with "add to the randomizer" replaced by "add to the stage".
+  void Prefetch(bool block) {
+    if (stage_closed_) return;
+    if (!feature_randomizer_.Staging()) {
+      feature_randomizer_.StageBegin();
+      stage_added_ = 0;
+      stage_end_seen_ = false;
+    }
     RecycleBlocks();
     while (true) {
-      if (feature_randomizer_.IsFull()) break;
+      if (feature_randomizer_.StageFull()) { stage_closed_ = true; break; }
       Item item;
       {
         Timer tw;
         std::unique_lock<std::mutex> lk(mu_);
+        if (!block && queue_.empty()) return;
         cv_.wait(lk, [&] { return !queue_.empty(); });
         item = std::move(queue_.front());
         queue_.pop_front();
         queued_frames_ -= item.rows;
         lk.unlock();
         cv_.notify_all();
-        t_wait += tw.Elapsed();
+        if (block) t_wait_ += tw.Elapsed();
       }
       if (!item.error.empty()) throw std::runtime_error(item.error);
-      if (item.end) { read_done_ = true; break; }
+      if (item.end) { stage_end_seen_ = true; stage_closed_ = true; break; }
       if (!item.has_targets) {
         ASLP_WARN << item.key << ", missing targets";
         num_no_tgt_++;
         continue;
       }
       if ((int32)item.targets.size() != item.rows) ASLP_ERR << "feature and target dim must match";
-      feature_randomizer_.AddDataPinned(item.block.ptr, item.rows, item.cols);
       std::unique_ptr<StreamMarker> marker(new StreamMarker);
-      marker->Record();
+      feature_randomizer_.StageAddPinned(item.block.ptr, item.rows, item.cols, marker.get());
       in_flight_.push_back(std::make_pair(item.block, std::move(marker)));
-      targets_randomizer_.AddData(item.targets);
+      stage_targets_.push_back(std::move(item.targets));
       num_done_++;
-      added++;
+      stage_added_++;
     }
-    CuDevice::Instantiate().AccuProfile("FrameDataReader: waiting for the reader thread", t_wait);
-    CuDevice::Instantiate().AccuProfile("FrameDataReader::FillRandomizer (host, total)", fill_timer.Elapsed());
+  }
+  void FillRandomizer() {  // data-reader.cc:66-128
+    Timer fill_timer;
+    t_wait_ = 0.0;
+    Prefetch(true);
+    feature_randomizer_.StageCommit();
+    for (auto &t : stage_targets_) targets_randomizer_.AddData(t);
+    stage_targets_.clear();
+    const int32 added = stage_added_;
+    read_done_ = stage_end_seen_;
+    stage_closed_ = false;
+    CuDevice::Instantiate().AccuProfile("FrameDataReader: waiting for the reader thread", t_wait_);
     // the reference always shuffles here (its --randomize flag is only echoed in the log, aslp-nnet-train-frame.cc:41,136);
     // `randomize_ == false` keeps the frame order (identity mask) for the tools that expose a working switch
     const int32 n = feature_randomizer_.NumFrames();
     // Nothing new arrived (the previous fill stopped on "cache full" exactly at the last utterance): what is left is less
     // than a minibatch and is dropped.  The reference shuffles here regardless and dies on its own data_begin_ == 0 check.
     if (n == 0 || added == 0) return;
+    ASLP_ASSERT(n == targets_randomizer_.NumFrames());
     if (randomize_) {
       const std::vector<int32> &mask = randomizer_mask_.Generate(n);
       feature_randomizer_.Randomize(mask);
       targets_randomizer_.Randomize(mask);
     }
+    CuDevice::Instantiate().AccuProfile("FrameDataReader::FillRandomizer (host, total)", fill_timer.Elapsed());
+    if (!read_done_) Prefetch(false);  // opens the next stage: whatever the reader thread already has goes up behind the shuffle
   }
 
   std::string feature_rspecifier_, targets_rspecifier_;
@@ -223,6 +244,11 @@ class FrameDataReader {
   std::deque<Item> queue_;
   std::vector<Block> free_blocks_;
   std::vector<std::pair<Block, std::unique_ptr<StreamMarker>>> in_flight_;
+  // the cache being staged
+  bool stage_closed_ = false, stage_end_seen_ = false;
+  int32 stage_added_ = 0;
+  double t_wait_ = 0.0;
+  std::vector<Posterior> stage_targets_;
 };
 
 // ---- multi-input / multi-output FrameDataReader (data-reader.cc:12-150, the vector constructor) --------------------

@@ -6,6 +6,11 @@
 // Mechanism differences on the device side: Randomize() gathers into a second buffer and swaps
 // (the reference first copies the whole cache, nnet-randomizer.cc:78), and Value() returns a view
 // of the cache rows instead of copying the minibatch out (:93-98).
+// MatrixRandomizer additionally has a STAGED refill (StageBegin / StageAddPinned / StageCommit): the
+// utterances of the next cache are uploaded into the second buffer on a CopyLane while the minibatches
+// of the current cache train; StageCommit() is the AddData() sequence of the reference collapsed into
+// "left-over rows to the front of the staged buffer, swap" -- same rows in the same order, same
+// data_begin_ / data_end_ afterwards.
 #pragma once
 #include <algorithm>
 #include <cstdlib>
@@ -125,8 +130,68 @@ class MatrixRandomizer : public RandomizerBase {  // :67-102
     return minibatch_;
   }
 
+  // ---- staged refill -------------------------------------------------------------------------------------------
+  // The rows AddData() would find left over once every minibatch of the current cache has been handed out are known as
+  // soon as the cache is shuffled: (data_end_ - data_begin_) % minibatch_size of them, the last rows of the cache.  The
+  // stage reserves that many rows at its front and appends utterances behind them.
+  void StageBegin() {
+    ASLP_ASSERT(!staging_);
+    staging_ = true;
+    stage_leftover_ = (data_end_ - data_begin_) % conf_.minibatch_size;
+    stage_end_ = stage_leftover_;
+    stage_zeroed_ = false;
+    // the stage buffer is the gather source of the last Randomize(): the lane must not overwrite it before that ran
+    lane_.LaneWaitsForStream();
+  }
+  bool Staging() const { return staging_; }
+  bool StageFull() const { return stage_end_ > conf_.randomizer_size; }  // IsFull() of the cache being staged
+  int32 StageFrames() const { return stage_end_; }
+  // rows from page-locked memory, appended to the stage on the copy lane; `done` (may be NULL) is recorded behind the copy
+  void StageAddPinned(const float *src, int32 rows, int32 cols, StreamMarker *done) {
+    ASLP_ASSERT(staging_);
+    if (data_aux_.NumCols() == 0) {
+      data_aux_.Resize(std::max(conf_.randomizer_size, data_.NumRows()), cols, kUndefined);
+      lane_.LaneWaitsForStream();  // the allocator may hand out a block the training stream has not finished with
+    }
+    ASLP_ASSERT(cols == data_aux_.NumCols());
+    if (data_aux_.NumRows() < stage_end_ + rows) {  // the +1000-row growth of :60-64, on the stage
+      lane_.Sync();
+      CuMatrix grown(stage_end_ + rows + 1000, cols, kUndefined);
+      if (stage_end_ > stage_leftover_)
+        grown.RowRange(stage_leftover_, stage_end_ - stage_leftover_).CopyFromMat(data_aux_.RowRange(stage_leftover_, stage_end_ - stage_leftover_));
+      data_aux_.Swap(&grown);
+      lane_.LaneWaitsForStream();
+      stage_zeroed_ = false;
+    }
+    if (!stage_zeroed_) {  // :57 zeroes everything behind the left-over rows; rows behind data_end_ are never read, kept for fidelity
+      CuSubMatrix rest = data_aux_.RowRange(stage_end_, data_aux_.NumRows() - stage_end_);
+      lane_.Zero(rest.Data(), sizeof(float) * (size_t)rest.NumRows() * rest.Stride());
+      stage_zeroed_ = true;
+    }
+    CuSubMatrix dst = data_aux_.RowRange(stage_end_, rows);
+    lane_.Upload(dst.Data(), dst.Stride(), src, cols, rows, cols);
+    if (done) lane_.Record(done);
+    stage_end_ += rows;
+  }
+  // The current cache must be Done() (or empty).  Afterwards the object is in the state the reference's AddData() calls
+  // would have left it in: data_begin_ == 0, data_end_ == left-over + staged rows.
+  void StageCommit() {
+    ASLP_ASSERT(staging_);
+    ASLP_ASSERT(data_end_ - data_begin_ == stage_leftover_);
+    staging_ = false;
+    if (stage_end_ == stage_leftover_) return;  // nothing was staged: the cache stays as it is, like a loop that added nothing
+    lane_.StreamWaitsForLane();
+    if (stage_leftover_ > 0) data_aux_.RowRange(0, stage_leftover_).CopyFromMat(data_.RowRange(data_begin_, stage_leftover_));
+    data_.Swap(&data_aux_);
+    data_begin_ = 0;
+    data_end_ = stage_end_;
+  }
+
  private:
   CuMatrix data_, data_aux_;
+  CopyLane lane_;
+  bool staging_ = false, stage_zeroed_ = false;
+  int32 stage_leftover_ = 0, stage_end_ = 0;
   CuArray<int32> mask_dev_;
   CuSubMatrix minibatch_;
 };

@@ -62,3 +62,50 @@ def test_shuffled_minibatches_are_exact_row_gathers(aslp, oracle, dev, rows, col
     # asking for a minibatch that is not there is an error (KALDI_ASSERT, nnet-randomizer.cc:94)
     with pytest.raises(RuntimeError):
         r.Value()
+
+
+@pytest.mark.parametrize("cap,mb,cols", [(1000, 100, 10), (3000, 256, 43), (500, 64, 440)])
+def test_staged_refill_equals_add_data_refill(aslp, dev, cap, mb, cols):
+    """The staged refill (StageBegin / StageAdd / StageCommit: uploads on a copy stream while the current cache is consumed,
+    what FrameDataReader does between cache fills) leaves the cache in the state the reference's AddData() sequence
+    (nnet-randomizer.cc:47-71) would: same frames in the same rows over several fills, with real shuffles, utterances of
+    ragged length, a buffer that has to grow (+1000 rows, :60-64) and left-over rows carried from fill to fill."""
+    rng = np.random.default_rng(11)
+    utts = [rng.standard_normal((int(n), cols)).astype(np.float32) for n in rng.integers(30, 700, 40)]
+    plain = aslp.MatrixRandomizer(randomizer_size=cap, minibatch_size=mb)
+    staged = aslp.MatrixRandomizer(randomizer_size=cap, minibatch_size=mb)
+    nxt, fills, batches = 0, 0, 0
+    staged.StageBegin()
+    while nxt < len(utts):
+        first = nxt
+        while nxt < len(utts) and not plain.IsFull():     # the reference's fill loop
+            plain.AddData(torch.from_numpy(utts[nxt]).to(dev))
+            nxt += 1
+        k = first
+        while k < len(utts) and not staged.StageFull():   # the same utterances, staged
+            staged.StageAdd(utts[k])
+            k += 1
+        assert k == nxt
+        staged.StageCommit()
+        assert staged.NumFrames() == plain.NumFrames() and staged.IsFull() == plain.IsFull()
+        mask = aslp.randomizer_mask(plain.NumFrames(), seed=fills)
+        plain.Randomize(mask)
+        staged.Randomize(mask)
+        staged.StageBegin()
+        half = False
+        while not plain.Done():
+            assert not staged.Done()
+            assert torch.equal(plain.Value(), staged.Value())
+            plain.Next()
+            staged.Next()
+            batches += 1
+            if not half and nxt < len(utts):   # part of the next cache goes up while this one is being read
+                staged.StageAdd(utts[nxt])
+                plain_pending = utts[nxt]
+                half = True
+        assert staged.Done()
+        if half:   # the plain cache takes that utterance first thing in its next fill
+            plain.AddData(torch.from_numpy(plain_pending).to(dev))
+            nxt += 1
+        fills += 1
+    assert fills >= 3 and batches > 10
