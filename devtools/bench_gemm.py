@@ -4,6 +4,9 @@ import os, sys, torch
 sys.path.insert(0, '.')
 import aslp_import; aslp = aslp_import.load(); aslp.ops.use_torch_stream()
 dev = torch.device('cuda:0')
+_w = torch.randn(4096, 4096, device=dev)
+for _ in range(60): torch.mm(_w, _w)  # warm the clocks: the first ~50 ms after idle run slow and would bias the first line
+torch.cuda.synchronize()
 shapes = []
 for mb in [int(m) for m in os.environ.get('MBS', '1024,256').split(',')]:
     shapes += [('NT fwd  ', 0, 1, mb, 2048, 2048), ('NT fwd1 ', 0, 1, mb, 2048, 440), ('NT fwdL ', 0, 1, mb, 3000, 2048),
