@@ -5,7 +5,7 @@ sys.path.insert(0, '.')
 import aslp_import; aslp = aslp_import.load(); aslp.ops.use_torch_stream()
 dev = torch.device('cuda:0')
 _w = torch.randn(4096, 4096, device=dev)
-for _ in range(60): torch.mm(_w, _w)  # warm the clocks: the first ~50 ms after idle run slow and would bias the first line
+for _ in range(800): torch.mm(_w, _w)  # ~1 s: the clocks take several hundred ms to settle after idle; shorter warm-ups bias whatever is timed first
 torch.cuda.synchronize()
 shapes = []
 for mb in [int(m) for m in os.environ.get('MBS', '1024,256').split(',')]:

@@ -154,6 +154,8 @@ void aslp_gemm_profile(int enable);
 void aslp_gemm_profile_reset(void);
 /* tuning aid: force tile config 1..5 (0 = heuristic).  1: 32x128x16  2: 64x64x16  3: 128x64x32  4: 128x128x32  5: 128x128x16 */
 void aslp_gemm_force_tile(int cfg);
+/* tile configuration of the calling thread's latest aslp_sgemm / aslp_sgemm_ex (the numbers aslp_gemm_profile_tile names) */
+int aslp_gemm_last_tile(void);
 /* variant: 0 = NT, 1 = NN, 2 = TN, 3 = TT.  Returns number of launches. */
 long aslp_gemm_profile_get(int variant, double *flops, double *ms);
 /* the tile configuration that carried most of that variant's flops since the last reset: returns its number, writes a

@@ -121,6 +121,7 @@ _sig("aslp_sgemm_ex", _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _f, _vp, _i,
 _sig("aslp_gemm_profile", None, _i)
 _sig("aslp_gemm_profile_reset", None)
 _sig("aslp_gemm_force_tile", None, _i)
+_sig("aslp_gemm_last_tile", _i)
 _sig("aslp_gemm_profile_get", C.c_long, _i, C.POINTER(C.c_double), C.POINTER(C.c_double))
 _sig("aslp_gemm_profile_tile", _i, _i, C.c_char_p, _i)
 _sig("aslp_gemm_profile_dump", None)

@@ -535,12 +535,11 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_f32_mfma(GemmArgs g) {
         const int row = m0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
         if (row >= g.M) continue;
         float *cp = g.C + (long)row * g.ldc + col;
-        float v = g.alpha * acc[i][n][e];
-        if (g.beta != 0.0f) v += g.beta * *cp;
-        v += bias;
+        // the arithmetic of gemm_epilogue_store4 (gemm_common.h), spelled the same way
+        float v = (ep.W != nullptr || g.beta != 0.0f) ? fmaf(g.alpha, acc[i][n][e], fmaf(g.beta, g.beta != 0.0f ? *cp : 0.0f, bias)) : fmaf(g.alpha, acc[i][n][e], bias);
         if (ep.clip > 0.0f) v = fminf(fmaxf(v, -ep.clip), ep.clip);
         *cp = v;
-        if (ep.W) ep.W[(long)row * ep.ldw + col] += ep.w_alpha * v;
+        if (ep.W) ep.W[(long)row * ep.ldw + col] = fmaf(ep.w_alpha, v, ep.W[(long)row * ep.ldw + col]);
         if (ep.act_out) {
           float a = ep.act == 1 ? sigmoid_ref(v) : ep.act == 2 ? tanh_ref(v) : ep.act == 3 ? fmaxf(v, 0.0f) : v;
           ep.act_out[(long)row * ep.ld_act + col] = a;
@@ -636,7 +635,8 @@ void launch_variant(GemmArgs &g) {
   //  1920 x 256 x 512 16.4 vs 17.1 us, but the long-K members lose their K split: 4.21 vs 3.75 ms per step.  Not taken.)
   t_last_cfg = cfg;
   if (cfg >= 200) {
-    if (gemm_glds_launch(g, A_KC, B_KC, cfg)) { if (!A_KC) g.ep.colsum = nullptr; return; }  // column sums done in-kernel
+    int used = cfg;
+    if (gemm_glds_launch(g, A_KC, B_KC, cfg, &used)) { t_last_cfg = used; if (!A_KC) g.ep.colsum = nullptr; return; }  // column sums done in-kernel
     if (cfg != 205 && cfg != 206 && cfg != 207 && cfg != 208 && cfg != 211 && cfg != 212 && cfg != 213) {
       set_error("aslp_sgemm: unknown tile configuration " + std::to_string(cfg) + " (ASLP_GEMM_TILE_* / aslp_gemm_force_tile)");
       return;
@@ -758,6 +758,7 @@ int aslp_sgemm(int transA, int transB, int M, int N, int K, float alpha, const f
 }
 
 void aslp_gemm_force_tile(int cfg) { g_force_tile = cfg; }
+int aslp_gemm_last_tile(void) { return t_last_cfg; }
 void aslp_gemm_profile(int enable) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   g_prof_on = enable != 0;

@@ -37,9 +37,9 @@ struct GemmArgs {
 // workgroup id -> (tile row, tile column): each XCD (id % 8, private 4 MB L2) gets a compact 2-D sub-grid of
 // tiles when the grid divides evenly, else a contiguous run (bijective in both cases)
 template <int BM, int BN>
-__device__ __forceinline__ void xcd_tile(const GemmArgs &g, int &tm, int &tn) {
+__device__ __forceinline__ void xcd_tile(const GemmArgs &g, int &tm, int &tn, int bid0 = blockIdx.x) {
   const int nt = g.tiles_m * g.tiles_n;
-  const int bid0 = blockIdx.x, xcd = bid0 % 8, j = bid0 / 8;
+  const int xcd = bid0 % 8, j = bid0 / 8;
   int px = 0;
   long best = -1;
   for (int cand = 1; cand <= 8; cand *= 2) {
@@ -89,11 +89,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, const f32x16 (&
           const int row = row0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
           if (row >= g.M) continue;
           float *cp = g.C + (long)row * g.ldc + col;
-          float v = g.alpha * acc[i][n][e] + g.beta * c_old[e] + bias;
+          float v = fmaf(g.alpha, acc[i][n][e], fmaf(g.beta, c_old[e], bias));
           if (ep.clip > 0.0f) v = fminf(fmaxf(v, -ep.clip), ep.clip);
           if (ep.W && g.beta == 0.0f) __builtin_nontemporal_store(v, cp);  // gradient written once, not read again this step
           else *cp = v;
-          if (ep.W) ep.W[(long)row * ep.ldw + col] = w_old[e] + ep.w_alpha * v;
+          if (ep.W) ep.W[(long)row * ep.ldw + col] = fmaf(ep.w_alpha, v, w_old[e]);
           if (ep.act_out) {
             float a = ep.act == 1 ? sigmoid_ref(v) : ep.act == 2 ? tanh_ref(v) : ep.act == 3 ? fmaxf(v, 0.0f) : v;
             ep.act_out[(long)row * ep.ld_act + col] = a;
@@ -104,7 +104,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, const f32x16 (&
         for (int e = 0; e < 16; e++) {
           const int row = row0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
           if (row >= g.M) continue;
-          float v = g.alpha * acc[i][n][e] + bias;
+          float v = fmaf(g.alpha, acc[i][n][e], bias);
           if (ep.clip > 0.0f) v = fminf(fmaxf(v, -ep.clip), ep.clip);
           g.C[(long)row * g.ldc + col] = v;
           if (ep.act_out) {
@@ -130,6 +130,38 @@ __device__ __forceinline__ bool gemm_epilogue_wide_ok(const GemmArgs &g) {
   return (g.N & 3) == 0 && (g.ldc & 3) == 0 && al(g.C) && (!ep.bias || al(ep.bias)) && (!ep.W || ((ep.ldw & 3) == 0 && al(ep.W))) &&
          (!ep.act_out || ((ep.ld_act & 3) == 0 && al(ep.act_out)));
 }
+// one lane's 4 consecutive outputs of row `row` (columns col .. col+3): the arithmetic and the stores of the epilogue
+__device__ __forceinline__ void gemm_epilogue_store4(const GemmArgs &g, float4 acc4, float4 c_old, float4 w_old, float4 bias, int row, int col) {
+  const aslp_gemm_epilogue &ep = g.ep;
+  float o[4] = {acc4.x, acc4.y, acc4.z, acc4.w};
+  const float co[4] = {c_old.x, c_old.y, c_old.z, c_old.w}, bs[4] = {bias.x, bias.y, bias.z, bias.w};
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    // explicit fused multiply-adds: the same rounding wherever this arithmetic is compiled (the narrow epilogue, the split-K
+    // reduction and the register-staged kernel spell it the same way), whatever contraction the optimiser would pick
+    float t = (ep.W != nullptr || g.beta != 0.0f) ? fmaf(g.alpha, o[q], fmaf(g.beta, co[q], bs[q])) : fmaf(g.alpha, o[q], bs[q]);
+    if (ep.clip > 0.0f) t = fminf(fmaxf(t, -ep.clip), ep.clip);
+    o[q] = t;
+  }
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  const f32x4v out = {o[0], o[1], o[2], o[3]};
+  f32x4v *cp = reinterpret_cast<f32x4v *>(g.C + (long)row * g.ldc + col);
+  if (ep.W && g.beta == 0.0f) __builtin_nontemporal_store(out, cp);  // gradient written once, not read again this step
+  else *cp = out;
+  if (ep.W) {
+    float4 wn;
+    wn.x = fmaf(ep.w_alpha, o[0], w_old.x); wn.y = fmaf(ep.w_alpha, o[1], w_old.y);
+    wn.z = fmaf(ep.w_alpha, o[2], w_old.z); wn.w = fmaf(ep.w_alpha, o[3], w_old.w);
+    *reinterpret_cast<float4 *>(ep.W + (long)row * ep.ldw + col) = wn;
+  }
+  if (ep.act_out) {
+    float a[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) a[q] = ep.act == 1 ? sigmoid_ref(o[q]) : ep.act == 2 ? tanh_ref(o[q]) : ep.act == 3 ? fmaxf(o[q], 0.0f) : o[q];
+    *reinterpret_cast<float4 *>(ep.act_out + (long)row * ep.ld_act + col) = make_float4(a[0], a[1], a[2], a[3]);
+  }
+}
+
 template <int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs &g, const f32x16 (&acc)[TM][TN], int row0, int col0, int lane, float *tile) {
   const aslp_gemm_epilogue &ep = g.ep;
@@ -157,36 +189,12 @@ __device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs &g, const f32x
       for (int j = 0; j < 4; j++) {
         const int row = row0 + i * 32 + rr + 8 * j;
         if (!colok || row >= g.M) continue;
-        float o[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
-        const float co[4] = {c_old[j].x, c_old[j].y, c_old[j].z, c_old[j].w}, bs[4] = {bias.x, bias.y, bias.z, bias.w};
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          float t = (ep.W != nullptr || g.beta != 0.0f) ? g.alpha * o[q] + g.beta * co[q] + bs[q] : g.alpha * o[q] + bs[q];
-          if (ep.clip > 0.0f) t = fminf(fmaxf(t, -ep.clip), ep.clip);
-          o[q] = t;
-        }
-        typedef float f32x4v __attribute__((ext_vector_type(4)));
-        const f32x4v out = {o[0], o[1], o[2], o[3]};
-        f32x4v *cp = reinterpret_cast<f32x4v *>(g.C + (long)row * g.ldc + col);
-        if (ep.W && g.beta == 0.0f) __builtin_nontemporal_store(out, cp);  // gradient written once, not read again this step
-        else *cp = out;
-        if (ep.W) {
-          float4 wn;
-          wn.x = w_old[j].x + ep.w_alpha * o[0]; wn.y = w_old[j].y + ep.w_alpha * o[1];
-          wn.z = w_old[j].z + ep.w_alpha * o[2]; wn.w = w_old[j].w + ep.w_alpha * o[3];
-          *reinterpret_cast<float4 *>(ep.W + (long)row * ep.ldw + col) = wn;
-        }
-        if (ep.act_out) {
-          float a[4];
-#pragma unroll
-          for (int q = 0; q < 4; q++) a[q] = ep.act == 1 ? sigmoid_ref(o[q]) : ep.act == 2 ? tanh_ref(o[q]) : ep.act == 3 ? fmaxf(o[q], 0.0f) : o[q];
-          *reinterpret_cast<float4 *>(ep.act_out + (long)row * ep.ld_act + col) = make_float4(a[0], a[1], a[2], a[3]);
-        }
+        gemm_epilogue_store4(g, v[j], c_old[j], w_old[j], bias, row, col);
       }
     }
 }
 
 // gemm_glds.hip: direct-to-LDS kernels.  Returns false if the problem is not eligible (caller falls back).
-bool gemm_glds_launch(GemmArgs &g, bool a_kc, bool b_kc, int cfg);
+bool gemm_glds_launch(GemmArgs &g, bool a_kc, bool b_kc, int cfg, int *cfg_used);  // *cfg_used: the tile configuration that ran
 
 }  // namespace aslp

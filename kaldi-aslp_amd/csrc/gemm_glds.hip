@@ -315,10 +315,10 @@ __global__ void __launch_bounds__(kBlock) splitk_reduce_kernel(const float *__re
     float *cp = g.C + (long)row * g.ldc + col;
     const float c_old = g.beta != 0.0f ? *cp : 0.0f;
     const float w_old = g.ep.W ? g.ep.W[(long)row * g.ep.ldw + col] : 0.0f;
-    float v = g.alpha * acc + g.beta * c_old;
+    float v = fmaf(g.alpha, acc, g.beta * c_old);  // = fmaf(alpha, acc, fmaf(beta, c_old, 0)): the epilogue's spelling (gemm_common.h)
     if (g.ep.clip > 0.0f) v = fminf(fmaxf(v, -g.ep.clip), g.ep.clip);
     *cp = v;
-    if (g.ep.W) g.ep.W[(long)row * g.ep.ldw + col] = w_old + g.ep.w_alpha * v;
+    if (g.ep.W) g.ep.W[(long)row * g.ep.ldw + col] = fmaf(g.ep.w_alpha, v, w_old);
   }
 }
 
@@ -358,7 +358,8 @@ bool launch_split(GemmArgs &g, int cfg, int split) {
   return true;
 }
 
-bool gemm_glds_launch(GemmArgs &g, bool a_kc, bool b_kc, int cfg) {
+bool gemm_glds_launch(GemmArgs &g, bool a_kc, bool b_kc, int cfg, int *cfg_used) {
+  *cfg_used = cfg;
   // (a column-sum request on a non-transposed A is the caller's job: see aslp_sgemm_ex)
   if (g.K < 4 || g.K % 4 != 0 || !g.a_vec || !g.b_vec) return false;
   if (!a_kc && (g.M % 4 != 0 || g.M < 4)) return false;

@@ -134,3 +134,49 @@ def test_ctc_fullsize_properties(aslp, dev):
     c5, g5 = aslp.ops.ctc_loss(a5, [labels[5]], [int(in_len[5])])
     assert abs(c5[0] - costs[5]) < 1e-4 * abs(costs[5])
     assert ((g5 - g3[:int(in_len[5]), 5]).norm() / g5.norm()).item() < 1e-4
+
+
+@pytest.mark.parametrize("tA,tB,M,N,K,mmt", [(1, 0, 2048, 2048, 1024, 0.9), (1, 0, 3000, 2048, 1024, 0.9), (1, 0, 2048, 2048, 1024, 0.0),
+                                             (0, 1, 2048, 2048, 1024, 0.5), (0, 0, 1984, 2176, 640, 0.9), (1, 1, 2048, 2048, 704, 0.9)])
+def test_weight_gradient_gemm_with_full_epilogue(aslp, dev, tA, tB, M, N, K, mmt):
+    """The weight-gradient product of cfg2 with everything AffineTransform::Update folds into it (momentum on the gradient
+    buffer, clip, W += -lr * G, bias gradient + bias step from the column sums) at full size: against float64, and bit for bit
+    across tile configurations (64x128 / 8 waves with 3 and 4 LDS stages, 64x64 / 4 waves): every kernel adds the K terms of an
+    output in the same order and spells the epilogue with the same explicit fused multiply-adds (gemm_common.h), so the tile
+    heuristic can change without changing a trained model.  Partial edge tiles (M = 3000), every operand layout."""
+    g = torch.Generator(device=dev).manual_seed(M + N + K)
+    A = torch.randn((K, M) if tA else (M, K), device=dev, generator=g)
+    B = torch.randn((N, K) if tB else (K, N), device=dev, generator=g)
+    G0 = torch.randn(M, N, device=dev, generator=g)
+    W0 = torch.randn(M, N, device=dev, generator=g)
+    bc0 = torch.randn(M, device=dev, generator=g)
+    b0 = torch.randn(M, device=dev, generator=g)
+    clip, lr = 60.0, -0.01
+    outs = []
+    for force in (0, 212, 213, 207):
+        Gd, Wd, bc, b = G0.clone(), W0.clone(), bc0.clone(), b0.clone()
+        if tA:
+            ep = aslp._lib.GemmEpilogue(None, clip, Wd.data_ptr(), N, lr, None, 0, 0, bc.data_ptr(), 0.9, b.data_ptr(), -0.02)
+        else:
+            ep = aslp._lib.GemmEpilogue(None, clip, Wd.data_ptr(), N, lr, None, 0, 0)
+        aslp.lib.aslp_gemm_force_tile(force)
+        try:
+            aslp.ops.sgemm(tA, tB, 1.0, A, B, mmt, Gd, ep)
+        finally:
+            aslp.lib.aslp_gemm_force_tile(0)
+        if force:
+            assert aslp.lib.aslp_gemm_last_tile() == force
+        outs.append((Gd, Wd, bc, b))
+    opA, opB = (A.t() if tA else A).double(), (B.t() if tB else B).double()
+    Gref = (opA @ opB + mmt * G0.double()).clamp(-clip, clip)
+    assert (Gref.abs() == clip).any() and (Gref.abs() < clip).any()
+    Gd, Wd, bc, b = outs[0]
+    rel = lambda x, r: ((x.double() - r).norm() / r.norm()).item()
+    assert rel(Gd, Gref) < 2e-6
+    assert rel(Wd, W0.double() + lr * Gref) < 2e-6
+    if tA:
+        bc_ref = A.double().sum(0) + 0.9 * bc0.double()
+        assert rel(bc, bc_ref) < 2e-6 and rel(b, b0.double() - 0.02 * bc_ref) < 2e-6
+    for other in outs[1:]:
+        for x, y in zip(outs[0][:2], other[:2]):
+            assert torch.equal(x, y)
