@@ -148,6 +148,15 @@ typedef struct aslp_gemm_epilogue_ {
 } aslp_gemm_epilogue;
 int aslp_sgemm_ex(int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda,
                   const float *B, int ldb, float beta, float *C, int ldc, const aslp_gemm_epilogue *ep);
+/* Two products of the same shape, leading dimensions, alpha and beta in ONE launch: C0 = alpha op(A0) op(B0) + beta C0 (+ ep0),
+ * C1 = alpha op(A1) op(B1) + beta C1 (+ ep1).  Each output is computed exactly as aslp_sgemm_ex computes it (two such calls are what
+ * runs wherever the paired kernel does not apply); only the K split chosen for a grid that cannot fill the chip may differ from
+ * the single product's, i.e. the order in which the K chunks' partial sums are added (still fixed: run-to-run reproducible).
+ * The outputs (and every array the epilogues write) must not overlap.
+ * The two directions of a bidirectional recurrent layer issue each of their batched products as such a pair. */
+int aslp_sgemm_pair_ex(int transA, int transB, int M, int N, int K, float alpha, const float *A0, const float *A1, int lda,
+                       const float *B0, const float *B1, int ldb, float beta, float *C0, float *C1, int ldc,
+                       const aslp_gemm_epilogue *ep0, const aslp_gemm_epilogue *ep1);
 /* GEMM launch statistics for bench.py's roofline: per variant launches / flops / (if
  * profiling was enabled with aslp_gemm_profile(1)) event-timed milliseconds. */
 void aslp_gemm_profile(int enable);

@@ -118,6 +118,7 @@ _sig("aslp_d2f", None, _vp, _vp, _i)
 # gemm (B2)
 _sig("aslp_sgemm", _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _f, _vp, _i)
 _sig("aslp_sgemm_ex", _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _f, _vp, _i, C.POINTER(GemmEpilogue))
+_sig("aslp_sgemm_pair_ex", _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _i, C.POINTER(GemmEpilogue), C.POINTER(GemmEpilogue))
 _sig("aslp_gemm_profile", None, _i)
 _sig("aslp_gemm_profile_reset", None)
 _sig("aslp_gemm_force_tile", None, _i)

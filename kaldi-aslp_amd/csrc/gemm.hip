@@ -612,7 +612,7 @@ template <bool A_KC, bool B_KC, bool VEC>
 void launch_variant(GemmArgs &g) {
   // Tile choice: the largest tile that still gives >= ~256 blocks (one per CU); skinny M
   // (the S-row recurrent GEMMs of the LSTM family) gets the 32-row tile.
-  auto blocks = [&](int bm, int bn) { return (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn); };
+  auto blocks = [&](int bm, int bn) { return (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * (g.pair ? 2 : 1); };
   int cfg;
   // Measured on MI355X (devtools/bench_gemm.py, profiles/gemm_tiles_r01.txt): the 8-wave 64x128x32
   // tile is best whenever it tiles the problem into >= ~200 full blocks; otherwise the 4-wave
@@ -636,7 +636,8 @@ void launch_variant(GemmArgs &g) {
   t_last_cfg = cfg;
   if (cfg >= 200) {
     int used = cfg;
-    if (gemm_glds_launch(g, A_KC, B_KC, cfg, &used)) { t_last_cfg = used; if (!A_KC) g.ep.colsum = nullptr; return; }  // column sums done in-kernel
+    if (gemm_glds_launch(g, A_KC, B_KC, cfg, &used)) { t_last_cfg = used; if (!A_KC) { g.ep.colsum = nullptr; g.ep1.colsum = nullptr; } return; }  // column sums done in-kernel
+    if (g.pair) { t_last_cfg = -1; return; }  // only the LDS-DMA kernels take pairs: the caller issues two single products
     if (cfg != 205 && cfg != 206 && cfg != 207 && cfg != 208 && cfg != 211 && cfg != 212 && cfg != 213) {
       set_error("aslp_sgemm: unknown tile configuration " + std::to_string(cfg) + " (ASLP_GEMM_TILE_* / aslp_gemm_force_tile)");
       return;
@@ -644,6 +645,7 @@ void launch_variant(GemmArgs &g) {
     cfg = g.M <= 32 ? 1 : (cfg == 207 ? 7 : 12);  // not eligible: register-staged kernel of the same tile
     t_last_cfg = cfg;
   }
+  if (g.pair) { t_last_cfg = -1; return; }
   switch (cfg) {
     case 1: launch_cfg<32, 128, 16, 1, 4, A_KC, B_KC, VEC>(g); break;
     case 2: launch_cfg<64, 64, 16, 2, 2, A_KC, B_KC, VEC>(g); break;
@@ -710,6 +712,7 @@ int aslp_sgemm_ex(int transA, int transB, int M, int N, int K, float alpha, cons
   if (K > 0 && (lda < (transA ? M : K) || ldb < (transB ? K : N))) return -4;
   GemmArgs g;
   g.split_k = 0; g.k_chunk = 0; g.split_stride = 0;
+  g.pair = 0; g.A1 = g.B1 = nullptr; g.C1 = nullptr; g.ep1 = aslp_gemm_epilogue();
   static const int wide = [] { const char *e = getenv("ASLP_GEMM_WIDE_EPI"); return e ? atoi(e) : 1; }();
   g.wide_epilogue = wide;
   g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
@@ -748,6 +751,48 @@ int aslp_sgemm_ex(int transA, int transB, int M, int N, int K, float alpha, cons
       g_prof[slot].pending.emplace_back(e0, e1);
       g_prof[slot].pending_shape.push_back(((long)M << 40) | ((long)N << 20) | (long)K);
     }
+  }
+  return 0;
+}
+
+// Two products of one shape in one launch (include/aslp_kernels.h).  Falls back to two launches wherever the paired kernel does
+// not apply (unaligned operands, K % 4, column sums on a kernel that cannot fold them, the register-staged tiles).
+int aslp_sgemm_pair_ex(int transA, int transB, int M, int N, int K, float alpha, const float *A0, const float *A1, int lda, const float *B0,
+                       const float *B1, int ldb, float beta, float *C0, float *C1, int ldc, const aslp_gemm_epilogue *ep0,
+                       const aslp_gemm_epilogue *ep1) {
+  static const int enabled = [] { const char *e = getenv("ASLP_GEMM_PAIR"); return e ? atoi(e) : 1; }();
+  auto two = [&]() {
+    const int rc = aslp_sgemm_ex(transA, transB, M, N, K, alpha, A0, lda, B0, ldb, beta, C0, ldc, ep0);
+    return rc ? rc : aslp_sgemm_ex(transA, transB, M, N, K, alpha, A1, lda, B1, ldb, beta, C1, ldc, ep1);
+  };
+  if (M <= 0 || N <= 0 || K <= 0 || !A0 || !A1 || !B0 || !B1 || !C0 || !C1 || ldc < N) return two();  // argument errors are reported there
+  if (lda < (transA ? M : K) || ldb < (transB ? K : N)) return two();
+  const bool colsum = (ep0 && ep0->colsum) || (ep1 && ep1->colsum);
+  if (!enabled || g_prof_on || colsum) return two();   // per-launch event timing and the column-sum fallback work on single products
+  GemmArgs g;
+  g.split_k = 0; g.k_chunk = 0; g.split_stride = 0;
+  static const int wide = [] { const char *e = getenv("ASLP_GEMM_WIDE_EPI"); return e ? atoi(e) : 1; }();
+  g.wide_epilogue = wide;
+  g.A = A0; g.B = B0; g.C = C0; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.alpha = alpha; g.beta = beta;
+  g.ep = ep0 ? *ep0 : aslp_gemm_epilogue();
+  g.pair = 1; g.A1 = A1; g.B1 = B1; g.C1 = C1;
+  g.ep1 = ep1 ? *ep1 : aslp_gemm_epilogue();
+  g.a_vec = aligned16(A0) && aligned16(A1) && lda % 4 == 0;
+  g.b_vec = aligned16(B0) && aligned16(B1) && ldb % 4 == 0;
+  if (!g.a_vec || !g.b_vec) return two();
+  if (!transA && transB) launch_aligned<true, true>(g);
+  else if (!transA && !transB) launch_aligned<true, false>(g);
+  else if (transA && !transB) launch_aligned<false, false>(g);
+  else launch_aligned<false, true>(g);
+  if (t_last_cfg < 0) return two();
+  check_launch("aslp_sgemm_pair");
+  {
+    const int slot = (!transA && transB) ? 0 : (!transA && !transB) ? 1 : (transA && !transB) ? 2 : 3;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof[slot].launches += 2;
+    g_prof[slot].flops += 4.0 * (double)M * (double)N * (double)K;
+    g_prof[slot].cfg_flops[t_last_cfg] += 4.0 * (double)M * (double)N * (double)K;
   }
   return 0;
 }

@@ -32,6 +32,13 @@ struct GemmArgs {
   // goes to C + chunk * split_stride (a scratch stack of packed M x N partials; the epilogue runs in the reduce kernel)
   int split_k, k_chunk;
   long split_stride;
+  // pair (gemm_glds.hip, aslp_sgemm_pair_ex): a second product of the same shape, leading dimensions, alpha and beta in the same
+  // launch -- blockIdx.z == 1 works on (A1, B1, C1, ep1).  The two directions of a bidirectional recurrent layer issue every
+  // one of their batched products twice with different operands; most of those grids cannot fill the chip alone.
+  int pair;
+  const float *A1, *B1;
+  float *C1;
+  aslp_gemm_epilogue ep1;
 };
 
 // workgroup id -> (tile row, tile column): each XCD (id % 8, private 4 MB L2) gets a compact 2-D sub-grid of

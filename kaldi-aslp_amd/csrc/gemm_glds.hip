@@ -58,6 +58,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_f32_glds(GemmArgs g) {
   extern __shared__ __attribute__((aligned(1024))) float lds[];
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lds;
 
+  if (g.pair && blockIdx.z == 1) {  // second product of a pair (uniform)
+    g.A = g.A1; g.B = g.B1; g.C = g.C1; g.ep = g.ep1;
+  }
   if (g.split_k > 1) {  // this workgroup reduces over K chunk blockIdx.y only and leaves a plain partial product
     const int k0 = (int)blockIdx.y * g.k_chunk;
     g.A += A_KC ? (long)k0 : (long)k0 * g.lda;
@@ -279,7 +282,7 @@ void launch_t(GemmArgs &g) {
       ASLP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n, g.split_k > 1 ? g.split_k : 1), dim3(64 * WGM * WGN), lds_bytes, cur_stream(), g);
+  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n, g.split_k > 1 ? g.split_k : 1, g.pair ? 2 : 1), dim3(64 * WGM * WGN), lds_bytes, cur_stream(), g);
 }
 
 template <int BM, int BN, int WGM, int WGN, bool A_KC, bool B_KC, int NS>
@@ -307,6 +310,10 @@ bool launch_cfg(GemmArgs &g, int cfg) {
 // Second half of a split-K product: C = epilogue(alpha * sum_s partial[s] + beta * C), partials added in chunk order.
 // Covers what the split path accepts: alpha / beta, the element-wise clip and the fused SGD step on W.
 __global__ void __launch_bounds__(kBlock) splitk_reduce_kernel(const float *__restrict__ part, int split, long stride, GemmArgs g) {
+  if (g.pair && blockIdx.y == 1) {  // the second product's partials follow the first's
+    part += (long)split * stride;
+    g.C = g.C1; g.ep = g.ep1;
+  }
   const long n = (long)g.M * g.N;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int row = (int)(i / g.N), col = (int)(i - (long)row * g.N);
@@ -331,7 +338,8 @@ int pick_split_k(const GemmArgs &g, int bm, int bn) {
   if (forced == 0) return 0;
   const aslp_gemm_epilogue &ep = g.ep;
   if (ep.bias || ep.act_out || ep.colsum || g.K < 1024) return 0;
-  const long tiles = (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn);
+  if (g.pair && (g.ep1.bias || g.ep1.act_out || g.ep1.colsum)) return 0;
+  const long tiles = (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * (g.pair ? 2 : 1);
   static const int slots = [] { const char *e = getenv("ASLP_GEMM_SPLITK_SLOTS"); return e ? atoi(e) : 256; }();
   int split = (int)(slots / tiles);
   if (split > g.K / 256) split = g.K / 256;
@@ -346,15 +354,17 @@ bool launch_split(GemmArgs &g, int cfg, int split) {
   split = (g.K + chunk - 1) / chunk;
   if (split < 2) return false;
   const long stride = (long)g.M * g.N;
-  float *part = static_cast<float *>(scratch(kScratchSplitK, sizeof(float) * (size_t)stride * split));
+  const int np = g.pair ? 2 : 1;
+  float *part = static_cast<float *>(scratch(kScratchSplitK, sizeof(float) * (size_t)stride * split * np));
   if (!part) return false;
   GemmArgs p = g;
   p.C = part; p.ldc = g.N; p.alpha = 1.0f; p.beta = 0.0f; p.ep = aslp_gemm_epilogue();
+  p.C1 = part + (size_t)stride * split; p.ep1 = aslp_gemm_epilogue();
   p.split_k = split; p.k_chunk = chunk; p.split_stride = stride;
   if (!launch_cfg<A_KC, B_KC>(p, cfg)) return false;
   GemmArgs r = g;
   r.split_k = 0;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for(stride)), dim3(kBlock), 0, cur_stream(), part, split, stride, r);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for(stride), np), dim3(kBlock), 0, cur_stream(), part, split, stride, r);
   return true;
 }
 

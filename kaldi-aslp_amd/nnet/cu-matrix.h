@@ -299,6 +299,13 @@ class CuSubMatrix : public CuMatrixBase {
   CuSubMatrix(float *data, int rows, int cols, int stride) : CuMatrixBase(data, rows, cols, stride) {}
 };
 
+// C0 = alpha op(A0) op(B0) + beta C0 (+ ep0) and C1 = alpha op(A1) op(B1) + beta C1 (+ ep1): one launch when the two products agree
+// in shape and strides (aslp_sgemm_pair_ex), two AddMatMat calls otherwise -- same results either way.  The forward and backward
+// direction of a bidirectional recurrent layer issue every batched product as such a pair.
+void AddMatMatPair(CuMatrixBase &C0, CuMatrixBase &C1, float alpha, const CuMatrixBase &A0, const CuMatrixBase &A1, MatrixTransposeType tA,
+                   const CuMatrixBase &B0, const CuMatrixBase &B1, MatrixTransposeType tB, float beta, const aslp_gemm_epilogue *ep0 = nullptr,
+                   const aslp_gemm_epilogue *ep1 = nullptr);
+
 inline bool SameDim(const CuMatrixBase &a, const CuMatrixBase &b) { return a.NumRows() == b.NumRows() && a.NumCols() == b.NumCols(); }
 
 namespace cu {

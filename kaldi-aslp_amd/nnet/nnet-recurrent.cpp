@@ -164,7 +164,8 @@ void LstmDir::Backward(const CuMatrixBase &out_diff, int T, int S, bool reverse,
   }
 }
 
-void LstmDir::Grads(const CuMatrixBase &in, int T, int S, bool reverse, const CuMatrix &buf, const CuMatrix &dbuf, float mmt, float clip, float lr_fold) {
+void LstmDir::Grads(const CuMatrixBase &in, int T, int S, bool reverse, const CuMatrix &buf, const CuMatrix &dbuf, float mmt, float clip, float lr_fold,
+                    bool with_gemm) {
   // lc.h:976-1058: corr = grad + mmt * corr, then clip element-wise (the clip rides in the GEMM epilogue, and with it --
   // when the executor announced that Update follows -- the step W += -lr * corr of lc.h:1085-1110)
   const int prev0 = (reverse ? 2 : 0) * S;  // recursion-previous row block of t = 1
@@ -175,9 +176,11 @@ void LstmDir::Grads(const CuMatrixBase &in, int T, int S, bool reverse, const Cu
     if (lr_fold != 0.0f) { ep.W = w.Data(); ep.ldw = w.Stride(); ep.w_alpha = -lr_fold; }
     corr.AddMatMat(1.0, d, kTrans, x, kNoTrans, mmt, &ep);
   };
-  wgrad(w_x_corr, w_x, d_gates, in);
-  wgrad(w_r_corr, w_r, d_gates, CuSubMatrix(buf, prev0, T * S, OffRec(), Rec()));
-  if (R > 0) wgrad(w_rm_corr, w_rm, CuSubMatrix(dbuf, S, T * S, OffRec(), R), CuSubMatrix(buf, S, T * S, OffM(), C));
+  if (with_gemm) {
+    wgrad(w_x_corr, w_x, d_gates, in);
+    wgrad(w_r_corr, w_r, d_gates, CuSubMatrix(buf, prev0, T * S, OffRec(), Rec()));
+    if (R > 0) wgrad(w_rm_corr, w_rm, CuSubMatrix(dbuf, S, T * S, OffRec(), R), CuSubMatrix(buf, S, T * S, OffM(), C));
+  }
   // bias and peephole gradients (:1005-1058), one launch: column sums of d_gates and of d_{i,f,o} .* c
   const BaseFloat *d0 = dbuf.RowData(S), *c_prev = buf.RowData(prev0) + OffC(), *c_cur = buf.RowData(S) + OffC();
   aslp_rnn_vec_grad jobs[4];
@@ -230,9 +233,9 @@ void LstmDir::RefreshEffT() const {
 }
 
 void LstmDir::ForwardPrepare(const CuMatrixBase &in, int T, int S, bool reverse, const CuMatrixBase *init_state, CuMatrix *buf,
-                             bool persistent) const {
+                             bool persistent, bool with_gemm) const {
   ASLP_ASSERT(in.NumRows() == T * S && in.NumCols() == D);
-  RefreshEff();
+  if (with_gemm) RefreshEff();
   if (persistent) {  // row blocks 1..T start as "not yet published" (csrc/rnn_persistent.hip), the two boundary blocks as zero
     buf->Resize((T + 2) * S, Width(), kUndefined);
     aslp_lstm_seq_fill(buf->Data(), buf->Stride(), T, S, OffM(), C);
@@ -240,6 +243,7 @@ void LstmDir::ForwardPrepare(const CuMatrixBase &in, int T, int S, bool reverse,
     buf->Resize((T + 2) * S, Width(), kSetZero);
   }
   if (init_state) buf->RowRange(reverse ? (T + 1) * S : 0, S).CopyFromMat(*init_state);
+  if (!with_gemm) return;
   aslp_gemm_epilogue ep = aslp_gemm_epilogue();
   ep.bias = bias.Data();
   CuSubMatrix gates(*buf, S, T * S, 0, GC());
@@ -255,7 +259,7 @@ bool LstmDir::ForwardFinish(int T, int S, CuMatrix *buf, CuMatrixBase *out, int 
   return out != nullptr;
 }
 
-void LstmDir::BackwardPrepare(const CuMatrixBase &out_diff, int T, int S, CuMatrix *dbuf, bool persistent) const {
+void LstmDir::BackwardPrepare(const CuMatrixBase &out_diff, int T, int S, CuMatrix *dbuf, bool persistent, bool with_gemm) const {
   ASLP_ASSERT(out_diff.NumRows() == T * S && out_diff.NumCols() == Rec());
   if (persistent) {
     // the persistent backward kernel writes every gate / c / h / m entry of row blocks 1..T itself (d_r follows in BackwardFinish):
@@ -265,6 +269,7 @@ void LstmDir::BackwardPrepare(const CuMatrixBase &out_diff, int T, int S, CuMatr
   } else {
     dbuf->Resize((T + 2) * S, Width(), kSetZero);
   }
+  if (!with_gemm) return;
   CuSubMatrix d_m(*dbuf, S, T * S, OffM(), C);
   if (R > 0) d_m.AddMatMat(1.0, out_diff, kNoTrans, w_rm, kNoTrans, 0.0);  // the loss's share of d_m, all t at once
   else d_m.CopyFromMat(out_diff);
@@ -282,6 +287,118 @@ void LstmDir::BackwardFinish(const CuMatrixBase &out_diff, int T, int S, bool re
     CuSubMatrix d_gates(*dbuf, S, T * S, 0, GC());
     in_diff->AddMatMat(1.0, d_gates, kNoTrans, w_x, kNoTrans, beta);
   }
+}
+
+// ---- both directions at once ------------------------------------------------------------------------
+namespace {
+bool PairsOn() {
+  static const bool off = getenv("ASLP_LSTM_PAIR") != nullptr && getenv("ASLP_LSTM_PAIR")[0] == '0';  // A/B switch
+  return !off;
+}
+bool SameShape(const LstmDir &f, const LstmDir &b) { return PairsOn() && f.D == b.D && f.C == b.C && f.R == b.R && f.cifg == b.cifg; }
+}  // namespace
+
+void LstmDir::RefreshEffPair(const LstmDir &f, const LstmDir &b) {
+  const bool stale_f = f.eff_dirty || f.aliased, stale_b = b.eff_dirty || b.aliased;
+  if (!(stale_f && stale_b && f.R > 0 && SameShape(f, b))) { f.RefreshEff(); b.RefreshEff(); return; }
+  for (const LstmDir *p : {&f, &b})
+    if (p->w_eff.NumRows() != p->GC() || p->w_eff.NumCols() != p->C) p->w_eff.Resize(p->GC(), p->C, kUndefined);
+  AddMatMatPair(f.w_eff, b.w_eff, 1.0, f.w_r, b.w_r, kNoTrans, f.w_rm, b.w_rm, kNoTrans, 0.0);
+  f.eff_dirty = b.eff_dirty = false;
+  f.eff_t_dirty = b.eff_t_dirty = true;
+}
+
+void LstmDir::ForwardPreparePair(const LstmDir &f, const LstmDir &b, const CuMatrixBase &in, int T, int S, const CuMatrixBase *init_f,
+                                 CuMatrix *fbuf, CuMatrix *bbuf, bool persistent) {
+  if (!SameShape(f, b)) {
+    f.ForwardPrepare(in, T, S, false, init_f, fbuf, persistent);
+    b.ForwardPrepare(in, T, S, true, nullptr, bbuf, persistent);
+    return;
+  }
+  RefreshEffPair(f, b);
+  f.ForwardPrepare(in, T, S, false, init_f, fbuf, persistent, false);
+  b.ForwardPrepare(in, T, S, true, nullptr, bbuf, persistent, false);
+  aslp_gemm_epilogue ep_f = aslp_gemm_epilogue(), ep_b = aslp_gemm_epilogue();
+  ep_f.bias = f.bias.Data();
+  ep_b.bias = b.bias.Data();
+  CuSubMatrix gates_f(*fbuf, S, T * S, 0, f.GC()), gates_b(*bbuf, S, T * S, 0, b.GC());
+  AddMatMatPair(gates_f, gates_b, 1.0, in, in, kNoTrans, f.w_x, b.w_x, kTrans, 0.0, &ep_f, &ep_b);
+}
+
+bool LstmDir::ForwardFinishPair(const LstmDir &f, const LstmDir &b, int T, int S, CuMatrix *fbuf, CuMatrix *bbuf, CuMatrixBase *out) {
+  if (f.R <= 0 || !SameShape(f, b)) {
+    bool w = f.ForwardFinish(T, S, fbuf, out, 0);
+    return b.ForwardFinish(T, S, bbuf, out, f.Rec()) && w;
+  }
+  CuSubMatrix r_f(*fbuf, S, T * S, f.OffRec(), f.R), m_f(*fbuf, S, T * S, f.OffM(), f.C);
+  CuSubMatrix r_b(*bbuf, S, T * S, b.OffRec(), b.R), m_b(*bbuf, S, T * S, b.OffM(), b.C);
+  aslp_gemm_epilogue ep_f = aslp_gemm_epilogue(), ep_b = aslp_gemm_epilogue();
+  if (out) {  // second store: the component's output block [r_f | r_b]
+    ep_f.act_out = out->Data(); ep_f.ld_act = out->Stride(); ep_f.act = 0;
+    ep_b.act_out = out->Data() + f.Rec(); ep_b.ld_act = out->Stride(); ep_b.act = 0;
+  }
+  AddMatMatPair(r_f, r_b, 1.0, m_f, m_b, kNoTrans, f.w_rm, b.w_rm, kTrans, 0.0, &ep_f, &ep_b);  // m -> r for every t at once (lc.h:608)
+  return out != nullptr;
+}
+
+void LstmDir::BackwardPreparePair(const LstmDir &f, const LstmDir &b, const CuMatrixBase &od_f, const CuMatrixBase &od_b, int T, int S,
+                                  CuMatrix *fdbuf, CuMatrix *bdbuf, bool persistent) {
+  if (f.R <= 0 || !SameShape(f, b)) {
+    f.BackwardPrepare(od_f, T, S, fdbuf, persistent);
+    b.BackwardPrepare(od_b, T, S, bdbuf, persistent);
+    return;
+  }
+  f.BackwardPrepare(od_f, T, S, fdbuf, persistent, false);
+  b.BackwardPrepare(od_b, T, S, bdbuf, persistent, false);
+  CuSubMatrix dm_f(*fdbuf, S, T * S, f.OffM(), f.C), dm_b(*bdbuf, S, T * S, b.OffM(), b.C);
+  AddMatMatPair(dm_f, dm_b, 1.0, od_f, od_b, kNoTrans, f.w_rm, b.w_rm, kNoTrans, 0.0);  // the loss's share of d_m, all t at once
+}
+
+void LstmDir::BackwardFinishPair(const LstmDir &f, const LstmDir &b, const CuMatrixBase &od_f, const CuMatrixBase &od_b, int T, int S,
+                                 CuMatrix *fdbuf, CuMatrix *bdbuf, CuMatrixBase *in_diff) {
+  if (f.R <= 0 || !SameShape(f, b)) {
+    f.BackwardFinish(od_f, T, S, false, fdbuf, in_diff, 0.0, true);
+    b.BackwardFinish(od_b, T, S, true, bdbuf, in_diff, 1.0, true);
+    return;
+  }
+  // d_r(t) = out_diff(t) + dGATES(next) W_r (lc.h:791), needed by the W_rm gradient
+  CuSubMatrix dr_f(*fdbuf, S, T * S, f.OffRec(), f.R), dr_b(*bdbuf, S, T * S, b.OffRec(), b.R);
+  dr_f.CopyFromMat(od_f);
+  dr_b.CopyFromMat(od_b);
+  CuSubMatrix next_f(*fdbuf, 2 * S, T * S, 0, f.GC()), next_b(*bdbuf, 0, T * S, 0, b.GC());  // row blocks of each step's recursion-next
+  AddMatMatPair(dr_f, dr_b, 1.0, next_f, next_b, kNoTrans, f.w_r, b.w_r, kNoTrans, 1.0);
+  // in_diff = dGATES_f W_x,f + dGATES_b W_x,b: two products into ONE output, in sequence
+  f.BackwardFinish(od_f, T, S, false, fdbuf, in_diff, 0.0, false);
+  b.BackwardFinish(od_b, T, S, true, bdbuf, in_diff, 1.0, false);
+}
+
+void LstmDir::GradsPair(LstmDir &f, LstmDir &b, const CuMatrixBase &in, int T, int S, const CuMatrix &fbuf, const CuMatrix &bbuf,
+                        const CuMatrix &fdbuf, const CuMatrix &bdbuf, float mmt, float clip, float lr_fold) {
+  if (!SameShape(f, b)) {
+    f.Grads(in, T, S, false, fbuf, fdbuf, mmt, clip, lr_fold);
+    b.Grads(in, T, S, true, bbuf, bdbuf, mmt, clip, lr_fold);
+    return;
+  }
+  // lc.h:976-1058, as in Grads(): corr = grad + mmt * corr, clipped, and (folded) W += -lr * corr
+  auto wgrad = [&](CuMatrix &corr_f, CuMatrix &corr_b, CuMatrix &w_f, CuMatrix &w_b, const CuMatrixBase &d_f, const CuMatrixBase &d_b,
+                   const CuMatrixBase &x_f, const CuMatrixBase &x_b) {
+    aslp_gemm_epilogue ep_f = aslp_gemm_epilogue(), ep_b = aslp_gemm_epilogue();
+    ep_f.clip = ep_b.clip = clip;
+    if (lr_fold != 0.0f) {
+      ep_f.W = w_f.Data(); ep_f.ldw = w_f.Stride(); ep_f.w_alpha = -lr_fold;
+      ep_b.W = w_b.Data(); ep_b.ldw = w_b.Stride(); ep_b.w_alpha = -lr_fold;
+    }
+    AddMatMatPair(corr_f, corr_b, 1.0, d_f, d_b, kTrans, x_f, x_b, kNoTrans, mmt, &ep_f, &ep_b);
+  };
+  CuSubMatrix dg_f(fdbuf, S, T * S, 0, f.GC()), dg_b(bdbuf, S, T * S, 0, b.GC());
+  wgrad(f.w_x_corr, b.w_x_corr, f.w_x, b.w_x, dg_f, dg_b, in, in);
+  wgrad(f.w_r_corr, b.w_r_corr, f.w_r, b.w_r, dg_f, dg_b, CuSubMatrix(fbuf, 0, T * S, f.OffRec(), f.Rec()),
+        CuSubMatrix(bbuf, 2 * S, T * S, b.OffRec(), b.Rec()));
+  if (f.R > 0)
+    wgrad(f.w_rm_corr, b.w_rm_corr, f.w_rm, b.w_rm, CuSubMatrix(fdbuf, S, T * S, f.OffRec(), f.R), CuSubMatrix(bdbuf, S, T * S, b.OffRec(), b.R),
+          CuSubMatrix(fbuf, S, T * S, f.OffM(), f.C), CuSubMatrix(bbuf, S, T * S, b.OffM(), b.C));
+  f.Grads(in, T, S, false, fbuf, fdbuf, mmt, clip, lr_fold, false);   // bias and peephole gradients
+  b.Grads(in, T, S, true, bbuf, bdbuf, mmt, clip, lr_fold, false);
 }
 
 // ---- the component family ---------------------------------------------------------------------------
@@ -402,8 +519,8 @@ void LstmFamily::PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) {
     aslp_lstm_seq q = aslp_lstm_seq();
     q.ndir = cfg_.bidir ? 2 : 1; q.ld = 4; q.ldw = 4; q.T = T; q.S = S; q.C = ncell_; q.cifg = cfg_.cifg ? 1 : 0;
     const bool persistent = aslp_lstm_seq_supported(&q, 0) != 0;
-    f_.ForwardPrepare(in, T, S, false, carried ? &prev_state_ : nullptr, &f_buf_, persistent);
-    if (cfg_.bidir) b_.ForwardPrepare(in, T, S, true, nullptr, &b_buf_, persistent);
+    if (cfg_.bidir) LstmDir::ForwardPreparePair(f_, b_, in, T, S, carried ? &prev_state_ : nullptr, &f_buf_, &b_buf_, persistent);
+    else f_.ForwardPrepare(in, T, S, false, carried ? &prev_state_ : nullptr, &f_buf_, persistent);
     if (carried && cfg_.proj) {
       // The carried history holds r(0) = m(0) W_rm^T formed with the weights of the PREVIOUS batch (the reference
       // recurs on the stored r, lc.h:575); m(0) W_eff^T would silently re-project it with the updated W_rm.
@@ -449,8 +566,8 @@ void LstmFamily::PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) {
     }
     CheckK();
     // with a projection the GEMM that forms r(t) for all t also writes it into this component's output block
-    out_written = f_.ForwardFinish(T, S, &f_buf_, out, 0);
-    if (cfg_.bidir) out_written = b_.ForwardFinish(T, S, &b_buf_, out, rec) && out_written;
+    if (cfg_.bidir) out_written = LstmDir::ForwardFinishPair(f_, b_, T, S, &f_buf_, &b_buf_, out);
+    else out_written = f_.ForwardFinish(T, S, &f_buf_, out, 0);
   } else {
     f_.Forward(in, T, S, false, carried ? &prev_state_ : nullptr, nullptr, &f_buf_);
     if (cfg_.bidir) b_.Forward(in, T, S, true, nullptr, cfg_.lc ? nullptr : &seq_len_dev_, &b_buf_);
@@ -483,8 +600,8 @@ void LstmFamily::BackpropagateFnc(const CuMatrixBase &in, const CuMatrixBase &, 
     aslp_lstm_seq q = aslp_lstm_seq();
     q.ndir = cfg_.bidir ? 2 : 1; q.ld = 4; q.ldw = 4; q.T = T; q.S = S; q.C = ncell_; q.cifg = cfg_.cifg ? 1 : 0;
     const bool persistent = aslp_lstm_seq_supported(&q, 1) != 0;
-    f_.BackwardPrepare(od_f, T, S, &f_dbuf_, persistent);
-    if (cfg_.bidir) b_.BackwardPrepare(od_b, T, S, &b_dbuf_, persistent);
+    if (cfg_.bidir) LstmDir::BackwardPreparePair(f_, b_, od_f, od_b, T, S, &f_dbuf_, &b_dbuf_, persistent);
+    else f_.BackwardPrepare(od_f, T, S, &f_dbuf_, persistent);
     ASLP_ASSERT(f_dbuf_.Stride() == f_buf_.Stride());
     if (persistent) {
       q.ld = f_dbuf_.Stride(); q.ldw = f_.Weff().Stride();
@@ -530,15 +647,18 @@ void LstmFamily::BackpropagateFnc(const CuMatrixBase &in, const CuMatrixBase &, 
     CheckK();
     // (Running the backward direction's batched products beside the forward direction's on the side stream was tried: no gain,
     // 4.289 vs 4.285 ms per LC step -- the small products do not overlap usefully -- so everything stays on one stream.)
-    f_.BackwardFinish(od_f, T, S, false, &f_dbuf_, in_diff, 0.0, true);
-    if (cfg_.bidir) b_.BackwardFinish(od_b, T, S, true, &b_dbuf_, in_diff, 1.0, true);
+    if (cfg_.bidir) LstmDir::BackwardFinishPair(f_, b_, od_f, od_b, T, S, &f_dbuf_, &b_dbuf_, in_diff);
+    else f_.BackwardFinish(od_f, T, S, false, &f_dbuf_, in_diff, 0.0, true);
   } else {
     f_.Backward(CuSubMatrix(out_diff, 0, T * S, 0, rec), T, S, false, f_buf_, &f_dbuf_, in_diff, 0.0);
     if (cfg_.bidir) b_.Backward(CuSubMatrix(out_diff, 0, T * S, rec, rec), T, S, true, b_buf_, &b_dbuf_, in_diff, 1.0);
   }
   const BaseFloat lr_fold = TakeFoldHint() ? opts_.learn_rate : 0.0f;
-  f_.Grads(in, T, S, false, f_buf_, f_dbuf_, mmt, clip_gradient_, lr_fold);
-  if (cfg_.bidir) b_.Grads(in, T, S, true, b_buf_, b_dbuf_, mmt, clip_gradient_, lr_fold);
+  if (cfg_.bidir && f_.FusedOk()) LstmDir::GradsPair(f_, b_, in, T, S, f_buf_, b_buf_, f_dbuf_, b_dbuf_, mmt, clip_gradient_, lr_fold);
+  else {
+    f_.Grads(in, T, S, false, f_buf_, f_dbuf_, mmt, clip_gradient_, lr_fold);
+    if (cfg_.bidir) b_.Grads(in, T, S, true, b_buf_, b_dbuf_, mmt, clip_gradient_, lr_fold);
+  }
 }
 
 void LstmFamily::Update(const CuMatrixBase &, const CuMatrixBase &) {

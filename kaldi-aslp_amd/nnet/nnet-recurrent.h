@@ -80,18 +80,33 @@ struct LstmDir {
   void Backward(const CuMatrixBase &out_diff, int T, int S, bool reverse, const CuMatrix &buf, CuMatrix *dbuf, CuMatrixBase *in_diff,
                 float beta) const;
   // lr_fold != 0: the step param += -lr_fold * corr is taken in the epilogues of the gradient kernels
-  void Grads(const CuMatrixBase &in, int T, int S, bool reverse, const CuMatrix &buf, const CuMatrix &dbuf, float mmt, float clip, float lr_fold);
+  void Grads(const CuMatrixBase &in, int T, int S, bool reverse, const CuMatrix &buf, const CuMatrix &dbuf, float mmt, float clip, float lr_fold,
+             bool with_gemm = true);
   void Update(float lr);
 
   // ---- fused-step path: the per-timestep loop lives in LstmFamily (all directions share a launch) ----
   bool FusedOk() const;  // C % 4 == 0 (16-byte operand loads) and not disabled by ASLP_LSTM_UNFUSED=1 (A/B switch for tests)
   void RefreshEff() const;
   void RefreshEffT() const;
+  // Both directions of a bidirectional layer: every batched product below exists twice with the same shape, and most of them
+  // (K or N = R, or a [R x C] output) cannot fill the chip alone -- they go out as pairs, one launch each (AddMatMatPair).
+  // `with_gemm = false` on the single-direction methods leaves out the product the *Pair function then issues for both.
+  static void RefreshEffPair(const LstmDir &f, const LstmDir &b);
+  static void ForwardPreparePair(const LstmDir &f, const LstmDir &b, const CuMatrixBase &in, int T, int S, const CuMatrixBase *init_f,
+                                 CuMatrix *fbuf, CuMatrix *bbuf, bool persistent);
+  static bool ForwardFinishPair(const LstmDir &f, const LstmDir &b, int T, int S, CuMatrix *fbuf, CuMatrix *bbuf, CuMatrixBase *out);
+  static void BackwardPreparePair(const LstmDir &f, const LstmDir &b, const CuMatrixBase &od_f, const CuMatrixBase &od_b, int T, int S,
+                                  CuMatrix *fdbuf, CuMatrix *bdbuf, bool persistent);
+  static void BackwardFinishPair(const LstmDir &f, const LstmDir &b, const CuMatrixBase &od_f, const CuMatrixBase &od_b, int T, int S,
+                                 CuMatrix *fdbuf, CuMatrix *bdbuf, CuMatrixBase *in_diff);
+  static void GradsPair(LstmDir &f, LstmDir &b, const CuMatrixBase &in, int T, int S, const CuMatrix &fbuf, const CuMatrix &bbuf,
+                        const CuMatrix &fdbuf, const CuMatrix &bdbuf, float mmt, float clip, float lr_fold);
   const CuMatrixBase &Weff() const { return R > 0 ? static_cast<const CuMatrixBase &>(w_eff) : w_r; }
-  void ForwardPrepare(const CuMatrixBase &in, int T, int S, bool reverse, const CuMatrixBase *init_state, CuMatrix *buf, bool persistent) const;
+  void ForwardPrepare(const CuMatrixBase &in, int T, int S, bool reverse, const CuMatrixBase *init_state, CuMatrix *buf, bool persistent,
+                      bool with_gemm = true) const;
   // returns true if the projected output r(1..T) was also stored at out[:, out_col ...] (only with a projection)
   bool ForwardFinish(int T, int S, CuMatrix *buf, CuMatrixBase *out, int out_col) const;                                   // batched projection
-  void BackwardPrepare(const CuMatrixBase &out_diff, int T, int S, CuMatrix *dbuf, bool persistent) const;  // dm_ext
+  void BackwardPrepare(const CuMatrixBase &out_diff, int T, int S, CuMatrix *dbuf, bool persistent, bool with_gemm = true) const;  // dm_ext
   // with_dr: also form d_r (needed by the W_rm gradient); in_diff == NULL: only that
   void BackwardFinish(const CuMatrixBase &out_diff, int T, int S, bool reverse, CuMatrix *dbuf, CuMatrixBase *in_diff, float beta, bool with_dr) const;
 };

@@ -47,6 +47,22 @@ def sgemm(transA, transB, alpha, A, B, beta, Cm, epilogue=None):
     check_error()
 
 
+def sgemm_pair(transA, transB, alpha, A0, A1, B0, B1, beta, C0, C1, ep0=None, ep1=None):
+    """two products of one shape in one launch (aslp_sgemm_pair_ex)"""
+    for t in (A0, A1, B0, B1, C0, C1):
+        _chk(t)
+    assert A0.shape == A1.shape and B0.shape == B1.shape and C0.shape == C1.shape
+    assert dim(A0).stride == dim(A1).stride and dim(B0).stride == dim(B1).stride and dim(C0).stride == dim(C1).stride
+    M, N = C0.shape
+    K = A0.shape[0] if transA else A0.shape[1]
+    rc = lib.aslp_sgemm_pair_ex(int(transA), int(transB), M, N, K, alpha, ptr(A0), ptr(A1), dim(A0).stride, ptr(B0), ptr(B1), dim(B0).stride,
+                                beta, ptr(C0), ptr(C1), dim(C0).stride, C.byref(ep0) if ep0 is not None else None,
+                                C.byref(ep1) if ep1 is not None else None)
+    if rc != 0:
+        raise ValueError("aslp_sgemm_pair argument error %d" % rc)
+    check_error()
+
+
 def sigmoid(y, x):
     lib.cudaF_sigmoid(D3, D3, ptr(_chk(y)), ptr(_chk(x)), dim(y), dim(x).stride); check_error()
 

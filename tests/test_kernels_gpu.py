@@ -416,3 +416,59 @@ def test_bn_backward_with_folded_sigmoid_is_bit_identical(aslp, dev, rows, cols)
         res.append([t.cpu().numpy() for t in (ds, dsh, ind, xh)])
     for name, a, b in zip(("dscale", "dshift", "in_diff", "xhat <- dy * gamma"), res[0], res[1]):
         assert np.array_equal(a, b), name
+
+
+@pytest.mark.parametrize("tA,tB,M,N,K,mode", [
+    (0, 1, 1920, 2048, 512, "bias"), (0, 1, 1920, 256, 512, "act_out"), (0, 0, 1920, 512, 256, "plain"), (0, 0, 1920, 256, 2048, "beta1"),
+    (0, 0, 2048, 512, 256, "plain"), (1, 0, 2048, 512, 1920, "sgd"), (1, 0, 2048, 256, 1920, "sgd"), (1, 0, 256, 512, 1920, "sgd"),
+    (1, 1, 96, 80, 64, "plain"), (0, 1, 33, 20, 18, "plain"), (0, 1, 64, 64, 30, "bias")])
+def test_sgemm_pair_matches_two_products(aslp, dev, tA, tB, M, N, K, mode):
+    """aslp_sgemm_pair_ex: the batched products of the two directions of a bidirectional recurrent layer (cfg3 shapes: x -> gates,
+    m -> r with the second store, d_m, d_r, W_eff, the three weight gradients with momentum + clip + SGD step), one launch for both.
+    Against float64 and against two single launches (equal up to the order of the K-split partial sums); the last shapes are not
+    eligible for the paired kernel (K % 4, unaligned rows) and must come out of the two-launch fallback unchanged."""
+    g = torch.Generator(device=dev).manual_seed(M * 7 + N * 3 + K)
+    mk = lambda *s: torch.randn(*s, device=dev, generator=g)
+    A = [mk(*((K, M) if tA else (M, K))) for _ in range(2)]
+    B = [mk(*((N, K) if tB else (K, N))) for _ in range(2)]
+    C0 = [mk(M, N) for _ in range(2)]
+    W0 = [mk(M, N) for _ in range(2)]
+    bias = [mk(N) for _ in range(2)]
+    beta = {"beta1": 1.0, "sgd": 0.9}.get(mode, 0.0)
+
+    def run(paired):
+        Cs, Ws, acts = [c.clone() for c in C0], [w.clone() for w in W0], [torch.zeros(M, 2 * N, device=dev) for _ in range(2)]
+        eps = []
+        for i in range(2):
+            if mode == "bias":
+                eps.append(aslp._lib.GemmEpilogue(bias[i].data_ptr(), 0.0, None, 0, 0.0, None, 0, 0))
+            elif mode == "act_out":   # second store into a column block of a wider matrix, like the LSTM's [r_f | r_b] output
+                eps.append(aslp._lib.GemmEpilogue(None, 0.0, None, 0, 0.0, acts[0].data_ptr() + 4 * N * i, 2 * N, 0))
+            elif mode == "sgd":
+                eps.append(aslp._lib.GemmEpilogue(None, 50.0, Ws[i].data_ptr(), N, -0.01, None, 0, 0))
+            else:
+                eps.append(None)
+        if paired:
+            aslp.ops.sgemm_pair(tA, tB, 1.0, A[0], A[1], B[0], B[1], beta, Cs[0], Cs[1], eps[0], eps[1])
+        else:
+            for i in range(2):
+                aslp.ops.sgemm(tA, tB, 1.0, A[i], B[i], beta, Cs[i], eps[i])
+        return Cs, Ws, acts
+
+    (Cp, Wp, actp), (Cs, Ws, acts) = run(True), run(False)
+    rel = lambda x, r: ((x.double() - r.double()).norm() / r.double().norm()).item()
+    for i in range(2):
+        ref = (A[i].t() if tA else A[i]).double() @ (B[i].t() if tB else B[i]).double() + beta * C0[i].double()
+        if mode == "bias":
+            ref = ref + bias[i].double()
+        if mode == "sgd":
+            ref = ref.clamp(-50.0, 50.0)
+            assert rel(Wp[i], W0[i].double() - 0.01 * ref) < 2e-6
+            assert rel(Wp[i], Ws[i]) < 1e-6
+        assert rel(Cp[i], ref) < 2e-6, (i, rel(Cp[i], ref))
+        assert rel(Cp[i], Cs[i]) < 1e-6
+    if mode == "act_out":
+        assert torch.equal(actp[0][:, :N], Cp[0]) and torch.equal(actp[0][:, N:], Cp[1])
+    # run-to-run reproducible
+    Cp2, Wp2, _ = run(True)
+    assert all(torch.equal(x, y) for x, y in zip(Cp + Wp, Cp2 + Wp2))
