@@ -250,7 +250,7 @@ void aslp_lstm_cell_forward(float *y_cur, const float *y_prev, int ld, int S, in
                             const float *peep_o, const int32_cuda *seq_lengths, int t);
 void aslp_lstm_cell_backward(float *d_cur, const float *d_next, const float *y_cur, const float *y_next, const float *y_prev, int ld, int S,
                              int C, int cifg, const float *peep_i, const float *peep_f, const float *peep_o);
-/* Vector gradients of a recurrent component, up to 4 in ONE launch (nnet-blstm-projected-streams-lc.h:1005-1058: the bias
+/* Vector gradients of a recurrent component, up to 8 (both directions of a bidirectional layer) in ONE launch (nnet-blstm-projected-streams-lc.h:1005-1058: the bias
  * gradient AddRowSumMat, the peephole gradients AddDiagMatMat, each followed by ApplyFloor / ApplyCeiling; :1092-1104 the step):
  *   corr[c] = clamp( sum_r d[r*ldd + c] * (x ? x[r*ldx + c] : 1) + mmt * corr[c], -clip, clip )     (clip <= 0: no clamp)
  *   param[c] += neg_lr * corr[c]                                                                   (neg_lr == 0: no step) */
@@ -306,6 +306,9 @@ int aslp_lstm_seq_supported(const aslp_lstm_seq *a, int backward);
 /* row blocks 0 and T+1 := 0 (all ld columns); columns [col0, col0 + ncols) of row blocks 1..T := 0xFFFFFFFF words.
  * For the forward kernel: col0 = the m column block (G + 2) * C, ncols = C. */
 void aslp_lstm_seq_fill(float *buf, int ld, int T, int S, int col0, int ncols);
+/* the same for the two directions' buffers of one layer (same ld, T, S) in one launch; init0 (S rows of ld_init floats, init_cols of them
+ * meaningful; may be NULL): copied into row block 0 of buf0 -- the carried history of the forward direction -- instead of zeros */
+void aslp_lstm_seq_fill_pair(float *buf0, float *buf1, int ld, int T, int S, int col0, int ncols, const float *init0, int ld_init, int init_cols);
 void aslp_lstm_seq_forward(const aslp_lstm_seq *a);
 /* diagnostics: hand-off re-polls (per wave) since the last reset, summed over all persistent launches; synchronises */
 unsigned aslp_lstm_seq_polls(int reset);

@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(kBlock) gru_bwd2(float *__restrict__ d, const 
 // element-wise clip and -- when the caller folds the update in -- the SGD step.  16 columns x 64 row groups per block (a
 // 64-byte segment per row and wave quarter; 7C/16 blocks, enough to cover the chip at C = 512); the 64 partial sums of a
 // column meet in LDS in a fixed order, so results do not depend on the launch.
-constexpr int kVgCols = 16, kVgGroups = 64, kVgMaxJobs = 4;
+constexpr int kVgCols = 16, kVgGroups = 64, kVgMaxJobs = 8;
 static_assert(kVgGroups == 64, "the LDS fold below is written for 64 row groups");
 struct VecGradJobs { aslp_rnn_vec_grad j[kVgMaxJobs]; int first_block[kVgMaxJobs + 1]; int njobs; };
 
@@ -237,7 +237,7 @@ void aslp_gru_backward2(float *d_cur, const float *y_cur, const float *y_prev, i
 
 void aslp_rnn_vec_grads(const aslp_rnn_vec_grad *jobs, int njobs, int ldd, int rows, float mmt, float clip, float neg_lr) {
   if (njobs <= 0) return;
-  if (njobs > kVgMaxJobs) { set_error("aslp_rnn_vec_grads: at most 4 jobs per launch"); return; }
+  if (njobs > kVgMaxJobs) { set_error("aslp_rnn_vec_grads: at most 8 jobs per launch"); return; }
   VecGradJobs a;
   int blocks = 0;
   a.njobs = 0;

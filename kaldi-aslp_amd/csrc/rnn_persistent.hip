@@ -561,10 +561,20 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd(aslp_lstm_seq a, SeqStatus s
 
 // Prepares an activation buffer for the forward kernel: boundary row blocks 0 and T + 1 := 0 (all columns), columns
 // [col0, col0 + ncols) of row blocks 1..T := "not yet published".  One launch instead of three memsets over the whole buffer.
-__global__ void __launch_bounds__(256) lstm_seq_fill_kernel(float *buf, int ld, int T, int S, int col0, int ncols) {
+// blockIdx.y picks the buffer (both directions of a layer in one launch); `init` (S rows of `ld_init` floats, may be NULL) is
+// copied into row block 0 of buffer 0 instead of zeros -- the history the forward direction of a stream-carrying layer starts from.
+__global__ void __launch_bounds__(256) lstm_seq_fill_kernel(float *buf0, float *buf1, int ld, int T, int S, int col0, int ncols,
+                                                            const float *init, int ld_init, int init_cols) {
   const int row = blockIdx.x;  // 0 .. (T + 2) * S - 1
+  float *buf = blockIdx.y == 0 ? buf0 : buf1;
   const bool boundary = row < S || row >= (T + 1) * S;
   u32x4 *p = reinterpret_cast<u32x4 *>(buf + (long)row * ld + (boundary ? 0 : col0));
+  if (init != nullptr && blockIdx.y == 0 && row < S) {
+    const u32x4 *q = reinterpret_cast<const u32x4 *>(init + (long)row * ld_init);
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    for (int i = threadIdx.x; i < (ld >> 2); i += 256) p[i] = i < (init_cols >> 2) ? q[i] : z;
+    return;
+  }
   const int n4 = (boundary ? ld : ncols) >> 2;
   const unsigned w = boundary ? 0u : kSentinel;
   const u32x4 v = {w, w, w, w};
@@ -657,8 +667,19 @@ int aslp_lstm_seq_supported(const aslp_lstm_seq *a, int backward) {
 void aslp_lstm_seq_fill(float *buf, int ld, int T, int S, int col0, int ncols) {
   if (!buf || T <= 0 || S <= 0 || ld <= 0) return;
   if ((ld & 3) || (col0 & 3) || (ncols & 3) || col0 < 0 || col0 + ncols > ld || !aligned16(buf)) { set_error("aslp_lstm_seq_fill: 16-byte alignment"); return; }
-  hipLaunchKernelGGL(lstm_seq_fill_kernel, dim3((T + 2) * S), dim3(256), 0, cur_stream(), buf, ld, T, S, col0, ncols);
+  hipLaunchKernelGGL(lstm_seq_fill_kernel, dim3((T + 2) * S), dim3(256), 0, cur_stream(), buf, buf, ld, T, S, col0, ncols, nullptr, 0, 0);
   check_launch("aslp_lstm_seq_fill");
+}
+
+void aslp_lstm_seq_fill_pair(float *buf0, float *buf1, int ld, int T, int S, int col0, int ncols, const float *init0, int ld_init, int init_cols) {
+  if (!buf0 || !buf1 || T <= 0 || S <= 0 || ld <= 0) return;
+  if ((ld & 3) || (col0 & 3) || (ncols & 3) || col0 < 0 || col0 + ncols > ld || !aligned16(buf0) || !aligned16(buf1) ||
+      (init0 && ((ld_init & 3) || (init_cols & 3) || init_cols > ld || init_cols > ld_init || !aligned16(init0)))) {
+    set_error("aslp_lstm_seq_fill_pair: 16-byte alignment");
+    return;
+  }
+  hipLaunchKernelGGL(lstm_seq_fill_kernel, dim3((T + 2) * S, 2), dim3(256), 0, cur_stream(), buf0, buf1, ld, T, S, col0, ncols, init0, ld_init, init_cols);
+  check_launch("aslp_lstm_seq_fill_pair");
 }
 
 static void launch_seq(const aslp_lstm_seq *a, bool backward, const char *who) {

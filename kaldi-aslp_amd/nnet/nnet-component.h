@@ -130,6 +130,10 @@ class Component {
   // A component that forms its gradients inside Backpropagate may then take the SGD step there too (in the epilogue of
   // the gradient kernels) and treat the next Update call as a no-op; the default ignores the hint.
   virtual void FoldNextUpdateIntoBackprop() {}
+  // The executor calls this right before a Backpropagate whose in-diff nobody will read (the component is fed by the network
+  // input only and the caller asked for no input diff): a component that forms its gradients inside Backpropagate is still
+  // called, but may leave the in-diff product out.  One-shot: taken back by the component once used; the default ignores it.
+  virtual void InDiffUnusedInNextBackprop() {}
 
  protected:
   virtual void FeedforwardFnc(const CuMatrixBase &in, CuMatrixBase *out) { PropagateFnc(in, out); }

@@ -214,6 +214,7 @@ void Nnet::Backpropagate(const std::vector<const CuMatrixBase *> &out_diff, std:
         dynamic_cast<BatchNormalization *>(components_[i])->BackpropagateWithSigmoid(*in_view_[i], output_buf_[fs], output_diff_buf_[fs], target);
       } else {
         if (fuse_layers_) components_[i]->FoldNextUpdateIntoBackprop();
+        if (!want_in_diff && (is_input || feeds_only_input)) components_[i]->InDiffUnusedInNextBackprop();  // here for its gradients only
         components_[i]->Backpropagate(*in_view_[i], *out_view_[i], output_diff_buf_[i], target);
       }
       in_diff_view_[i] = target;

@@ -164,8 +164,7 @@ void LstmDir::Backward(const CuMatrixBase &out_diff, int T, int S, bool reverse,
   }
 }
 
-void LstmDir::Grads(const CuMatrixBase &in, int T, int S, bool reverse, const CuMatrix &buf, const CuMatrix &dbuf, float mmt, float clip, float lr_fold,
-                    bool with_gemm) {
+void LstmDir::Grads(const CuMatrixBase &in, int T, int S, bool reverse, const CuMatrix &buf, const CuMatrix &dbuf, float mmt, float clip, float lr_fold) {
   // lc.h:976-1058: corr = grad + mmt * corr, then clip element-wise (the clip rides in the GEMM epilogue, and with it --
   // when the executor announced that Update follows -- the step W += -lr * corr of lc.h:1085-1110)
   const int prev0 = (reverse ? 2 : 0) * S;  // recursion-previous row block of t = 1
@@ -176,22 +175,26 @@ void LstmDir::Grads(const CuMatrixBase &in, int T, int S, bool reverse, const Cu
     if (lr_fold != 0.0f) { ep.W = w.Data(); ep.ldw = w.Stride(); ep.w_alpha = -lr_fold; }
     corr.AddMatMat(1.0, d, kTrans, x, kNoTrans, mmt, &ep);
   };
-  if (with_gemm) {
-    wgrad(w_x_corr, w_x, d_gates, in);
-    wgrad(w_r_corr, w_r, d_gates, CuSubMatrix(buf, prev0, T * S, OffRec(), Rec()));
-    if (R > 0) wgrad(w_rm_corr, w_rm, CuSubMatrix(dbuf, S, T * S, OffRec(), R), CuSubMatrix(buf, S, T * S, OffM(), C));
-  }
+  wgrad(w_x_corr, w_x, d_gates, in);
+  wgrad(w_r_corr, w_r, d_gates, CuSubMatrix(buf, prev0, T * S, OffRec(), Rec()));
+  if (R > 0) wgrad(w_rm_corr, w_rm, CuSubMatrix(dbuf, S, T * S, OffRec(), R), CuSubMatrix(buf, S, T * S, OffM(), C));
   // bias and peephole gradients (:1005-1058), one launch: column sums of d_gates and of d_{i,f,o} .* c
-  const BaseFloat *d0 = dbuf.RowData(S), *c_prev = buf.RowData(prev0) + OffC(), *c_cur = buf.RowData(S) + OffC();
   aslp_rnn_vec_grad jobs[4];
+  const int n = VecGradJobs(S, reverse, buf, dbuf, jobs);
+  aslp_rnn_vec_grads(jobs, n, dbuf.Stride(), T * S, mmt, clip, -lr_fold);
+  CheckK();
+  if (lr_fold != 0.0f) eff_dirty = true;
+}
+
+int LstmDir::VecGradJobs(int S, bool reverse, const CuMatrix &buf, const CuMatrix &dbuf, aslp_rnn_vec_grad *jobs) {
+  const int prev0 = (reverse ? 2 : 0) * S;
+  const BaseFloat *d0 = dbuf.RowData(S), *c_prev = buf.RowData(prev0) + OffC(), *c_cur = buf.RowData(S) + OffC();
   int n = 0;
   jobs[n++] = {d0, nullptr, 0, GC(), bias_corr.Data(), bias.Data()};
   if (!cifg) jobs[n++] = {d0 + OffI(), c_prev, buf.Stride(), C, peep_i_corr.Data(), peep_i.Data()};
   jobs[n++] = {d0 + OffF(), c_prev, buf.Stride(), C, peep_f_corr.Data(), peep_f.Data()};
   jobs[n++] = {d0 + OffO(), c_cur, buf.Stride(), C, peep_o_corr.Data(), peep_o.Data()};
-  aslp_rnn_vec_grads(jobs, n, dbuf.Stride(), T * S, mmt, clip, -lr_fold);
-  CheckK();
-  if (lr_fold != 0.0f) eff_dirty = true;
+  return n;
 }
 
 void LstmDir::Update(float lr) {  // lc.h:1085-1110
@@ -316,8 +319,20 @@ void LstmDir::ForwardPreparePair(const LstmDir &f, const LstmDir &b, const CuMat
     return;
   }
   RefreshEffPair(f, b);
-  f.ForwardPrepare(in, T, S, false, init_f, fbuf, persistent, false);
-  b.ForwardPrepare(in, T, S, true, nullptr, bbuf, persistent, false);
+  if (persistent && f.Width() % 4 == 0 && (!init_f || init_f->Stride() % 4 == 0)) {
+    // both buffers in one launch: boundary row blocks zero (the forward direction's history block takes the carried state),
+    // the m columns of row blocks 1..T "not yet published" (csrc/rnn_persistent.hip)
+    ASLP_ASSERT(in.NumRows() == T * S && in.NumCols() == f.D);
+    fbuf->Resize((T + 2) * S, f.Width(), kUndefined);
+    bbuf->Resize((T + 2) * S, b.Width(), kUndefined);
+    ASLP_ASSERT(fbuf->Stride() == bbuf->Stride());
+    if (init_f) ASLP_ASSERT(init_f->NumRows() == S && init_f->NumCols() == f.Width());
+    aslp_lstm_seq_fill_pair(fbuf->Data(), bbuf->Data(), fbuf->Stride(), T, S, f.OffM(), f.C, init_f ? init_f->Data() : nullptr,
+                            init_f ? init_f->Stride() : 0, f.Width());
+  } else {
+    f.ForwardPrepare(in, T, S, false, init_f, fbuf, persistent, false);
+    b.ForwardPrepare(in, T, S, true, nullptr, bbuf, persistent, false);
+  }
   aslp_gemm_epilogue ep_f = aslp_gemm_epilogue(), ep_b = aslp_gemm_epilogue();
   ep_f.bias = f.bias.Data();
   ep_b.bias = b.bias.Data();
@@ -348,8 +363,15 @@ void LstmDir::BackwardPreparePair(const LstmDir &f, const LstmDir &b, const CuMa
     b.BackwardPrepare(od_b, T, S, bdbuf, persistent);
     return;
   }
-  f.BackwardPrepare(od_f, T, S, fdbuf, persistent, false);
-  b.BackwardPrepare(od_b, T, S, bdbuf, persistent, false);
+  if (persistent) {   // only the two boundary row blocks of each buffer have to be zero (BackwardPrepare)
+    fdbuf->Resize((T + 2) * S, f.Width(), kUndefined);
+    bdbuf->Resize((T + 2) * S, b.Width(), kUndefined);
+    ASLP_ASSERT(fdbuf->Stride() == bdbuf->Stride());
+    aslp_lstm_seq_fill_pair(fdbuf->Data(), bdbuf->Data(), fdbuf->Stride(), T, S, 0, 0, nullptr, 0, 0);
+  } else {
+    f.BackwardPrepare(od_f, T, S, fdbuf, persistent, false);
+    b.BackwardPrepare(od_b, T, S, bdbuf, persistent, false);
+  }
   CuSubMatrix dm_f(*fdbuf, S, T * S, f.OffM(), f.C), dm_b(*bdbuf, S, T * S, b.OffM(), b.C);
   AddMatMatPair(dm_f, dm_b, 1.0, od_f, od_b, kNoTrans, f.w_rm, b.w_rm, kNoTrans, 0.0);  // the loss's share of d_m, all t at once
 }
@@ -367,9 +389,21 @@ void LstmDir::BackwardFinishPair(const LstmDir &f, const LstmDir &b, const CuMat
   dr_b.CopyFromMat(od_b);
   CuSubMatrix next_f(*fdbuf, 2 * S, T * S, 0, f.GC()), next_b(*bdbuf, 0, T * S, 0, b.GC());  // row blocks of each step's recursion-next
   AddMatMatPair(dr_f, dr_b, 1.0, next_f, next_b, kNoTrans, f.w_r, b.w_r, kNoTrans, 1.0);
-  // in_diff = dGATES_f W_x,f + dGATES_b W_x,b: two products into ONE output, in sequence
-  f.BackwardFinish(od_f, T, S, false, fdbuf, in_diff, 0.0, false);
-  b.BackwardFinish(od_b, T, S, true, bdbuf, in_diff, 1.0, false);
+  if (!in_diff) return;
+  // in_diff = dGATES_f W_x,f + dGATES_b W_x,b.  Two products into one output cannot share a launch; as a pair into (in_diff, scratch)
+  // followed by one addition they can, and the [T*S x D] output alone does not fill the chip (240 tiles for D = 512).  The sum is
+  // rounded once either way (the accumulating epilogue computes acc + C as one rounded addition, gemm_common.h).
+  CuSubMatrix dg_f(*fdbuf, S, T * S, 0, f.GC()), dg_b(*bdbuf, S, T * S, 0, b.GC());
+  static thread_local CuMatrix scratch;
+  if (scratch.NumRows() != in_diff->NumRows() || scratch.NumCols() != in_diff->NumCols() || scratch.Stride() != in_diff->Stride())
+    scratch.Resize(in_diff->NumRows(), in_diff->NumCols(), kUndefined);
+  if (scratch.Stride() != in_diff->Stride()) {   // (a view with a foreign stride: keep the two accumulating launches)
+    f.BackwardFinish(od_f, T, S, false, fdbuf, in_diff, 0.0, false);
+    b.BackwardFinish(od_b, T, S, true, bdbuf, in_diff, 1.0, false);
+    return;
+  }
+  AddMatMatPair(*in_diff, scratch, 1.0, dg_f, dg_b, kNoTrans, f.w_x, b.w_x, kNoTrans, 0.0);
+  in_diff->AddMat(1.0, scratch);
 }
 
 void LstmDir::GradsPair(LstmDir &f, LstmDir &b, const CuMatrixBase &in, int T, int S, const CuMatrix &fbuf, const CuMatrix &bbuf,
@@ -397,8 +431,14 @@ void LstmDir::GradsPair(LstmDir &f, LstmDir &b, const CuMatrixBase &in, int T, i
   if (f.R > 0)
     wgrad(f.w_rm_corr, b.w_rm_corr, f.w_rm, b.w_rm, CuSubMatrix(fdbuf, S, T * S, f.OffRec(), f.R), CuSubMatrix(bdbuf, S, T * S, b.OffRec(), b.R),
           CuSubMatrix(fbuf, S, T * S, f.OffM(), f.C), CuSubMatrix(bbuf, S, T * S, b.OffM(), b.C));
-  f.Grads(in, T, S, false, fbuf, fdbuf, mmt, clip, lr_fold, false);   // bias and peephole gradients
-  b.Grads(in, T, S, true, bbuf, bdbuf, mmt, clip, lr_fold, false);
+  // bias and peephole gradients of both directions: one launch
+  aslp_rnn_vec_grad jobs[8];
+  int n = f.VecGradJobs(S, false, fbuf, fdbuf, jobs);
+  n += b.VecGradJobs(S, true, bbuf, bdbuf, jobs + n);
+  ASLP_ASSERT(fdbuf.Stride() == bdbuf.Stride());
+  aslp_rnn_vec_grads(jobs, n, fdbuf.Stride(), T * S, mmt, clip, -lr_fold);
+  CheckK();
+  if (lr_fold != 0.0f) f.eff_dirty = b.eff_dirty = true;
 }
 
 // ---- the component family ---------------------------------------------------------------------------
@@ -589,6 +629,7 @@ void LstmFamily::PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) {
 }
 
 void LstmFamily::BackpropagateFnc(const CuMatrixBase &in, const CuMatrixBase &, const CuMatrixBase &out_diff, CuMatrixBase *in_diff) {
+  if (TakeInDiffUnused()) in_diff = nullptr;   // first layer of a training step: only the gradients are wanted
   const bool carried = !cfg_.bidir || cfg_.lc;
   const int32 S = carried ? nstream_ : (int32)sequence_lengths_.size();
   ASLP_ASSERT(S > 0 && in.NumRows() % S == 0);
@@ -801,6 +842,7 @@ void GruStreams::PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) {  // :
 
 void GruStreams::BackpropagateFnc(const CuMatrixBase &in, const CuMatrixBase &, const CuMatrixBase &out_diff, CuMatrixBase *in_diff) {  // :323-430
   const int H = output_dim_;
+  if (TakeInDiffUnused()) in_diff = nullptr;
   ASLP_ASSERT(nstream_ > 0 && in.NumRows() % nstream_ == 0);
   const int32 T = in.NumRows() / nstream_, S = nstream_;
   dbuf_.Resize((T + 2) * S, 5 * H, kSetZero);
@@ -830,7 +872,7 @@ void GruStreams::BackpropagateFnc(const CuMatrixBase &in, const CuMatrixBase &, 
   }
   CheckK();
   CuSubMatrix d_zrm(dbuf_, S, T * S, 0, 3 * H);
-  in_diff->AddMatMat(1.0, d_zrm, kNoTrans, w_zrm_x_, kNoTrans, 0.0);
+  if (in_diff) in_diff->AddMatMat(1.0, d_zrm, kNoTrans, w_zrm_x_, kNoTrans, 0.0);
   // gradients with momentum, clipped element-wise (:432-455); with the executor's fold hint the step of :457-466 rides along
   const BaseFloat mmt = opts_.momentum;
   const BaseFloat lr_fold = TakeFoldHint() ? opts_.learn_rate : 0.0f;

@@ -25,6 +25,7 @@ class RecurrentBase : public UpdatableComponent {
   RecurrentBase(int32 di, int32 dout) : UpdatableComponent(di, dout) {}
   bool GradientInBackprop() const { return true; }
   bool LatencyBoundPasses() const { return true; }
+  void InDiffUnusedInNextBackprop() { in_diff_unused_ = true; }
   void FoldNextUpdateIntoBackprop() { fold_update_ = CanFoldUpdate(); }
   virtual bool HasStreamReset() const { return false; }   // answers Nnet::ResetLstmStreams (nnet-nnet.cc:473-496)
   virtual bool HasSeqLengths() const { return false; }    // answers Nnet::SetSeqLengths   (nnet-nnet.cc:498-530)
@@ -39,6 +40,10 @@ class RecurrentBase : public UpdatableComponent {
 
  private:
   bool fold_update_ = false, update_done_ = false;
+ protected:
+  bool TakeInDiffUnused() { const bool v = in_diff_unused_; in_diff_unused_ = false; return v; }
+ private:
+  bool in_diff_unused_ = false;
 };
 
 struct LstmDir {
@@ -80,9 +85,9 @@ struct LstmDir {
   void Backward(const CuMatrixBase &out_diff, int T, int S, bool reverse, const CuMatrix &buf, CuMatrix *dbuf, CuMatrixBase *in_diff,
                 float beta) const;
   // lr_fold != 0: the step param += -lr_fold * corr is taken in the epilogues of the gradient kernels
-  void Grads(const CuMatrixBase &in, int T, int S, bool reverse, const CuMatrix &buf, const CuMatrix &dbuf, float mmt, float clip, float lr_fold,
-             bool with_gemm = true);
+  void Grads(const CuMatrixBase &in, int T, int S, bool reverse, const CuMatrix &buf, const CuMatrix &dbuf, float mmt, float clip, float lr_fold);
   void Update(float lr);
+  int VecGradJobs(int S, bool reverse, const CuMatrix &buf, const CuMatrix &dbuf, aslp_rnn_vec_grad *jobs);  // bias + peephole gradient jobs (<= 4)
 
   // ---- fused-step path: the per-timestep loop lives in LstmFamily (all directions share a launch) ----
   bool FusedOk() const;  // C % 4 == 0 (16-byte operand loads) and not disabled by ASLP_LSTM_UNFUSED=1 (A/B switch for tests)
