@@ -65,8 +65,25 @@ if os.environ.get("SEQ_TIMING") == "1":
         n = max(1, buf[0])
         names = ("collect m(t-1)", "barrier", "product", "barrier", "epilogue") if mode == 1 else ("product+publish", "-", "collect shares", "barrier", "epilogue")
         vals = [buf[k] * 0.01 / n for k in (1, 3, 2, 4, 5)]
-        print("%s kernel, workgroup 0 wave 0, us per timestep: %s   (L2-local launches %d of %d)"
-              % (name, "  ".join("%s %.2f" % (nm, v) for nm, v in zip(names, vals)), buf[6], n // T))
+        print("%s kernel, workgroup 0 wave 0, us per timestep: %s   (L2-local launches %d of %d; workgroup 0 resident %.1f us per launch)"
+              % (name, "  ".join("%s %.2f" % (nm, v) for nm, v in zip(names, vals)), buf[6], n // T, buf[7] * 0.01 / max(1, n // T)))
+if os.environ.get("SEQ_RESIDENCY") == "1":   # when do the workgroups of a persistent launch arrive and leave?
+    import ctypes as C
+    aslp.lib.aslp_lstm_seq_residency.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    for mode, name in ((3, "forward"), (4, "backward")):
+        aslp.lib.aslp_lstm_seq_timing(mode, None)
+        step(300)
+        aslp.lib.aslp_lstm_seq_timing(0, None)
+        # the step's 8 persistent launches: forward layers 0..3, then backward layers 3..0 -> the traced kind sits at these distances
+        for back, layer in (((7, 0), (6, 1), (5, 2), (4, 3)) if mode == 3 else ((3, 3), (2, 2), (1, 1), (0, 0))):
+            buf = (C.c_ulonglong * 512)()
+            aslp.lib.aslp_lstm_seq_residency(buf, 256, back)
+            ent = [buf[2 * i] for i in range(256)]
+            ext = [buf[2 * i + 1] for i in range(256)]
+            e0 = min(ent)
+            print("%s layer %d: last entry %.2f us; exit first %.1f / median %.1f / last %.1f us; last exit per chain: %s"
+                  % (name, layer, (max(ent) - e0) * 0.01, (min(ext) - e0) * 0.01, (sorted(ext)[128] - e0) * 0.01, (max(ext) - e0) * 0.01,
+                     " ".join("%.1f" % ((max(ext[c::8]) - e0) * 0.01) for c in range(8))))
 print("hand-off re-polls per step (all waves): %.0f" % (aslp.lib.aslp_lstm_seq_polls(1) / STEPS))
 if os.environ.get("GEMM_PROFILE") == "1":
     import ctypes as C

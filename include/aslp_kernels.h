@@ -311,6 +311,10 @@ void aslp_lstm_seq_fill(float *buf, int ld, int T, int S, int col0, int ncols);
 void aslp_lstm_seq_fill_pair(float *buf0, float *buf1, int ld, int T, int S, int col0, int ncols, const float *init0, int ld_init, int init_cols);
 void aslp_lstm_seq_forward(const aslp_lstm_seq *a);
 /* diagnostics: hand-off re-polls (per wave) since the last reset, summed over all persistent launches; synchronises */
+/* devtools: after aslp_lstm_seq_timing(3, NULL) (forward) or (4, NULL) (backward) every workgroup of such a launch records the
+ * 100 MHz clock at entry and exit (a ring of the 8 latest persistent launches of either kind); out receives the (entry, exit) pairs of
+ * workgroups 0 .. n-1 of the launch `launches_back` (0 = latest .. 7) persistent launches ago.  Synchronises. */
+void aslp_lstm_seq_residency(unsigned long long *out, int n, int launches_back);
 unsigned aslp_lstm_seq_polls(int reset);
 /* diagnostics (devtools/bench_lc.py): phase timing of the forward kernel, see csrc/rnn_persistent.hip */
 void aslp_lstm_seq_timing(int enable, unsigned long long *out);

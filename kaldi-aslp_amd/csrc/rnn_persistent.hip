@@ -83,6 +83,7 @@ struct SeqStatus {
   unsigned *abort_flag;
   unsigned *host_err;
   unsigned long long *timing;  // diagnostics (devtools): NULL, or 8 accumulators of 10 ns ticks written by workgroup 0, wave 0
+  unsigned long long *trace;   // diagnostics (devtools): NULL, or [workgroup][2] entry / exit clock of the latest launch
   unsigned epoch;              // launch counter (28 bits, never 0): tags the placement table entries of this launch
 };
 __device__ __forceinline__ long tick(const SeqStatus &st) { return st.timing ? (long)wall_clock64() : 0; }
@@ -200,6 +201,7 @@ __global__ void __launch_bounds__(512) lstm_seq_fwd(aslp_lstm_seq a, SeqStatus s
   __shared__ float red[2][8][kChainStreams][RP];
   __shared__ int fail[2][8];
   __shared__ int place_flag;
+  const long t_entry = (st.timing || st.trace) ? (long)wall_clock64() : 0;
   const ChainRole R = chain_role(a, st, place, &place_flag);
   if (!R.active) return;
   const aslp_lstm_seq_dir D = a.dir[R.dir];
@@ -357,7 +359,14 @@ __global__ void __launch_bounds__(512) lstm_seq_fwd(aslp_lstm_seq a, SeqStatus s
     cprev = cellv;
     tock(st, 5, tm);  // epilogue
   }
-  if (st.timing && blockIdx.x == 0 && threadIdx.x == 0) { st.timing[0] += (unsigned long long)T; st.timing[6] += R.local ? 1ull : 0ull; }
+  if (st.timing && blockIdx.x == 0 && threadIdx.x == 0) {
+    st.timing[0] += (unsigned long long)T; st.timing[6] += R.local ? 1ull : 0ull;
+    st.timing[7] += (unsigned long long)((long)wall_clock64() - t_entry);   // this workgroup's whole stay, entry to exit
+  }
+  if (st.trace && threadIdx.x == 0) {   // ring of the 8 latest launches
+    unsigned long long *tr = st.trace + (st.epoch & 7u) * 2048u;
+    tr[2 * blockIdx.x] = (unsigned long long)t_entry; tr[2 * blockIdx.x + 1] = wall_clock64();
+  }
   if (polls && lane == 0) __hip_atomic_fetch_add(st.abort_flag + 2, polls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // diagnostics, once per wave
 }
 
@@ -383,6 +392,7 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd(aslp_lstm_seq a, SeqStatus s
   __shared__ __attribute__((aligned(16))) float shares[kMaxWgPerChain * 2 * 16 * 4];     // [producer][row group][column][row]
   __shared__ int fail[2][8];
   __shared__ int place_flag;
+  const long t_entry = st.trace ? (long)wall_clock64() : 0;
   const ChainRole R = chain_role(a, st, place, &place_flag);
   if (!R.active) return;
   const aslp_lstm_seq_dir D = a.dir[R.dir];
@@ -556,6 +566,10 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd(aslp_lstm_seq a, SeqStatus s
     __syncthreads();  // own_dg[par] complete before anybody multiplies with it; shares[] free for the next collection
   }
   if (st.timing && blockIdx.x == 0 && threadIdx.x == 0) { st.timing[0] += (unsigned long long)T; st.timing[6] += R.local ? 1ull : 0ull; }
+  if (st.trace && threadIdx.x == 0) {   // ring of the 8 latest launches
+    unsigned long long *tr = st.trace + (st.epoch & 7u) * 2048u;
+    tr[2 * blockIdx.x] = (unsigned long long)t_entry; tr[2 * blockIdx.x + 1] = wall_clock64();
+  }
   if (polls && lane == 0) __hip_atomic_fetch_add(st.abort_flag + 2, polls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -608,7 +622,7 @@ SeqRuntime &seq_runtime() {
     const size_t bytes = 64 + sizeof(unsigned) * kMaxChains * kMaxWgPerChain;
     if (hipMalloc(&rt.abort_flag, bytes) != hipSuccess || hipMemset(rt.abort_flag, 0, bytes) != hipSuccess) return;
     rt.place = rt.abort_flag + 16;
-    if (hipMalloc(&rt.timing, 64) != hipSuccess || hipMemset(rt.timing, 0, 64) != hipSuccess) return;
+    if (hipMalloc(&rt.timing, 64 + 8 * 16 * 1024) != hipSuccess || hipMemset(rt.timing, 0, 64 + 8 * 16 * 1024) != hipSuccess) return;
     if (hipMalloc(&rt.inbox, sizeof(float) * (size_t)kRing * kMaxChains * kMaxWgPerChain * kMaxWgPerChain * 128) != hipSuccess) return;
     if (hipHostMalloc(&rt.host_err, 64, hipHostMallocMapped) != hipSuccess) return;
     *rt.host_err = 0;
@@ -706,7 +720,8 @@ static void launch_seq(const aslp_lstm_seq *a, bool backward, const char *who) {
   }
   rt.epoch = (rt.epoch + 1u) & 0x0FFFFFFFu;
   if (rt.epoch == 0u) rt.epoch = 1u;
-  SeqStatus st = {rt.abort_flag, rt.host_err_dev, ((rt.timing_mode == 1 && !backward) || (rt.timing_mode == 2 && backward)) ? rt.timing : nullptr, rt.epoch};
+  SeqStatus st = {rt.abort_flag, rt.host_err_dev, ((rt.timing_mode == 1 && !backward) || (rt.timing_mode == 2 && backward)) ? rt.timing : nullptr,
+                  ((rt.timing_mode == 3 && !backward) || (rt.timing_mode == 4 && backward)) ? rt.timing + 8 : nullptr, rt.epoch};
   const int wpc = (a->C + kCellsPerWg - 1) / kCellsPerWg;
   if (!backward) hipLaunchKernelGGL(pick_fwd(a->cifg != 0, a->C), dim3(kMaxChains * wpc), dim3(512), 0, cur_stream(), *a, st, rt.place);
   else hipLaunchKernelGGL(pick_bwd(a->cifg != 0, a->C), dim3(kMaxChains * wpc), dim3(512), 0, cur_stream(), *a, st, rt.place, rt.inbox);
@@ -727,6 +742,14 @@ void aslp_lstm_seq_timing(int enable, unsigned long long *out) {
     (void)hipMemset(rt.timing, 0, 64);
   }
   rt.timing_mode = enable;
+}
+// devtools: with aslp_lstm_seq_timing(3 | 4, NULL) in effect every workgroup of a forward | backward launch records the clock
+// (10 ns ticks) at entry and exit; this returns the latest launch's pairs for workgroups 0 .. n-1 (n <= 1024).  Synchronises.
+void aslp_lstm_seq_residency(unsigned long long *out, int n, int launches_back) {
+  SeqRuntime &rt = seq_runtime();
+  if (!rt.ok || !out || n <= 0 || n > 1024 || launches_back < 0 || launches_back > 7) return;
+  (void)hipStreamSynchronize(cur_stream());
+  (void)hipMemcpy(out, rt.timing + 8 + ((rt.epoch - (unsigned)launches_back) & 7u) * 2048u, sizeof(unsigned long long) * 2 * n, hipMemcpyDeviceToHost);
 }
 unsigned aslp_lstm_seq_polls(int reset) {
   SeqRuntime &rt = seq_runtime();
