@@ -145,6 +145,13 @@ typedef struct aslp_gemm_epilogue_ {
   float colsum_beta;
   float *colsum_w;     /* [M] or NULL */
   float colsum_w_alpha;
+  /* Column statistics of the OUTPUT, for a BatchNormalization that consumes it (the forward products: beta == 0, no W): for every
+   * group of 32 consecutive rows g = row / 32 and every column n, over the values v just stored (after alpha, bias, clip),
+   *   colstats[(a * groups + g) * colstats_ld + n],  groups = ceil(M / 32),  a = 0: sum v   1: sum (float)(v * v)   2: sum (double)v * v
+   * in double.  The statistics pass of aslp_bn_forward_stats then adds `groups` partials per column instead of reading the matrix.
+   * Always filled on return (by the GEMM kernel's epilogue where it can, by one extra pass over C otherwise). */
+  double *colstats;    /* [3 * groups * colstats_ld] or NULL */
+  int colstats_ld;     /* >= N */
 } aslp_gemm_epilogue;
 int aslp_sgemm_ex(int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda,
                   const float *B, int ldb, float beta, float *C, int ldc, const aslp_gemm_epilogue *ep);
@@ -201,6 +208,14 @@ void aslp_bn_forward_act(const float *in, MatrixDim d, float *out, int out_strid
 void aslp_bn_backward_act(const float *in, MatrixDim d, const float *out_diff, int od_stride, float *xhat, int xhat_stride, const float *scale,
                           const float *mean, const float *inv_std, float *dscale, float *dshift, float momentum, float *in_diff, int id_stride,
                           const float *act_y, int act_stride);
+/* aslp_bn_forward_act with the column statistics already formed by the producer of `in` (aslp_gemm_epilogue.colstats: `groups` partial
+ * sums per column and statistic, leading dimension stats_ld): no statistics pass and no exchange between workgroups, the launch only
+ * streams `in` once.  Same results up to the order in which the partial sums are added (all in double).  Returns 1 if it ran, 0 if
+ * this shape is not served (the caller then uses aslp_bn_forward_act; nothing was written). */
+int aslp_bn_forward_stats(const float *in, MatrixDim d, float *out, int out_stride, const float *scale, const float *shift, float *mean,
+                          float *inv_std, double *acc_means, double *acc_vars, float var_floor, float *act_out, int act_stride,
+                          const double *colstats, int groups, int stats_ld);
+
 /* aslp_bn_backward_act + BatchNormalization::Update (nnet-batch-normalization.h:280-284) taken in the statistics
  * finalize: scale -= learn_rate * dscale, shift -= learn_rate * dshift; in_diff is formed with the scale the
  * forward pass used. */

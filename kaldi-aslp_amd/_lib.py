@@ -22,7 +22,8 @@ class Dim3(C.Structure):
 class GemmEpilogue(C.Structure):
     _fields_ = [("bias", C.c_void_p), ("clip", C.c_float), ("W", C.c_void_p), ("ldw", C.c_int),
                 ("w_alpha", C.c_float), ("act_out", C.c_void_p), ("ld_act", C.c_int), ("act", C.c_int),
-                ("colsum", C.c_void_p), ("colsum_beta", C.c_float), ("colsum_w", C.c_void_p), ("colsum_w_alpha", C.c_float)]
+                ("colsum", C.c_void_p), ("colsum_beta", C.c_float), ("colsum_w", C.c_void_p), ("colsum_w_alpha", C.c_float),
+                ("colstats", C.c_void_p), ("colstats_ld", C.c_int)]
 
 
 class RnnVecGrad(C.Structure):
@@ -137,6 +138,7 @@ _sig("aslp_bn_backward", None, _vp, _md, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _
 _sig("aslp_bn_apply", None, _vp, _md, _vp, _i, _vp, _vp, _vp, _vp)
 _sig("aslp_xent_eval", None, _vp, _md, _vp, _i, _vp, _vp, _vp, _i, _vp)
 _sig("aslp_bn_forward_act", None, _vp, _md, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i)
+_sig("aslp_bn_forward_stats", _i, _vp, _md, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _i, _i)
 _sig("aslp_bn_backward_act", None, _vp, _md, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _i)
 _sig("aslp_bn_backward_step", None, _md, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _i, _vp, _i, _vp, _vp)
 _sig("aslp_bn_panel_supported", _i, _i, _i)

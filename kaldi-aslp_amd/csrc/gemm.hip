@@ -548,6 +548,22 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_f32_mfma(GemmArgs g) {
     }
 }
 
+// aslp_gemm_epilogue.colstats by one pass over the finished C, for the kernels that do not form them in their epilogue
+// (register-staged tiles): thread = column, blockIdx.y = 32-row group; the same three sums in the same per-group layout.
+__global__ void __launch_bounds__(64) colstats_kernel(const float *__restrict__ C, int ldc, int M, int N, double *__restrict__ stats, int ld, int groups) {
+  const int col = blockIdx.x * 64 + threadIdx.x, grp = blockIdx.y;
+  if (col >= N) return;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  const int r1 = min(M, 32 * grp + 32);
+  for (int r = 32 * grp; r < r1; r++) {
+    const float v = C[(long)r * ldc + col];
+    s0 += (double)v; s1 += (double)(v * v); s2 += (double)v * (double)v;
+  }
+  double *p = stats + (long)grp * ld + col;
+  const long plane = (long)groups * ld;
+  p[0] = s0; p[plane] = s1; p[2 * plane] = s2;
+}
+
 // ---- profile counters (bench.py roofline) -------------------------------------------------
 struct GemmProf {
   long launches = 0;
@@ -636,7 +652,12 @@ void launch_variant(GemmArgs &g) {
   t_last_cfg = cfg;
   if (cfg >= 200) {
     int used = cfg;
-    if (gemm_glds_launch(g, A_KC, B_KC, cfg, &used)) { t_last_cfg = used; if (!A_KC) { g.ep.colsum = nullptr; g.ep1.colsum = nullptr; } return; }  // column sums done in-kernel
+    if (gemm_glds_launch(g, A_KC, B_KC, cfg, &used)) {  // column sums / column statistics done in-kernel
+      t_last_cfg = used;
+      if (!A_KC) { g.ep.colsum = nullptr; g.ep1.colsum = nullptr; }
+      g.ep.colstats = nullptr;
+      return;
+    }
     if (g.pair) { t_last_cfg = -1; return; }  // only the LDS-DMA kernels take pairs: the caller issues two single products
     if (cfg != 205 && cfg != 206 && cfg != 207 && cfg != 208 && cfg != 211 && cfg != 212 && cfg != 213) {
       set_error("aslp_sgemm: unknown tile configuration " + std::to_string(cfg) + " (ASLP_GEMM_TILE_* / aslp_gemm_force_tile)");
@@ -719,6 +740,7 @@ int aslp_sgemm_ex(int transA, int transB, int M, int N, int K, float alpha, cons
   g.alpha = alpha; g.beta = beta;
   if (ep) g.ep = *ep; else g.ep = aslp_gemm_epilogue();  // zero-initialised: every optional piece off
   if (g.ep.colsum && !transA) return -5;  // column sums are defined for transposed A only
+  if (g.ep.colstats && (beta != 0.0f || g.ep.W || g.ep.colstats_ld < N)) return -6;  // statistics of a plain forward product only
   g.a_vec = aligned16(A) && lda % 4 == 0;
   g.b_vec = aligned16(B) && ldb % 4 == 0;
   // report order: 0 = NT, 1 = NN, 2 = TN, 3 = TT
@@ -735,6 +757,10 @@ int aslp_sgemm_ex(int transA, int transB, int M, int N, int K, float alpha, cons
   else if (!transA && !transB) launch_aligned<true, false>(g);
   else if (transA && !transB) launch_aligned<false, false>(g);
   else launch_aligned<false, true>(g);
+  if (g.ep.colstats) {  // the chosen kernel does not form them in its epilogue: one pass over the finished C
+    const int groups = (M + 31) / 32;
+    hipLaunchKernelGGL(colstats_kernel, dim3((N + 63) / 64, groups), dim3(64), 0, cur_stream(), C, ldc, M, N, g.ep.colstats, g.ep.colstats_ld, groups);
+  }
   if (g.ep.colsum) {  // the chosen kernel could not fold the column sums in: one extra pass over A (same values)
     MatrixDim da = {K, M, lda};
     if (g.ep.colsum_w) aslp_add_row_sum_mat_vec_sgd(1.0f, A, da, g.ep.colsum_beta, g.ep.colsum, g.ep.colsum_w, g.ep.colsum_w_alpha);
@@ -767,7 +793,7 @@ int aslp_sgemm_pair_ex(int transA, int transB, int M, int N, int K, float alpha,
   };
   if (M <= 0 || N <= 0 || K <= 0 || !A0 || !A1 || !B0 || !B1 || !C0 || !C1 || ldc < N) return two();  // argument errors are reported there
   if (lda < (transA ? M : K) || ldb < (transB ? K : N)) return two();
-  const bool colsum = (ep0 && ep0->colsum) || (ep1 && ep1->colsum);
+  const bool colsum = (ep0 && (ep0->colsum || ep0->colstats)) || (ep1 && (ep1->colsum || ep1->colstats));
   if (!enabled || g_prof_on || colsum) return two();   // per-launch event timing and the column-sum fallback work on single products
   GemmArgs g;
   g.split_k = 0; g.k_chunk = 0; g.split_stride = 0;

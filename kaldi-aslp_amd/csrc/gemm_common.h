@@ -123,6 +123,43 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, const f32x16 (&
     }
 }
 
+// Column statistics of a wave's output patch for aslp_gemm_epilogue.colstats (forward products only: beta == 0, no W -- the host
+// guarantees it): the values are the ones the epilogue stores, v = fma(alpha, acc, bias) clipped.  A lane holds 16 rows of one
+// column; the two lane halves hold the other 16 rows of the same 32-row group.
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_colstats(const GemmArgs &g, const f32x16 (&acc)[TM][TN], int row0, int col0, int l31, int lh) {
+  const aslp_gemm_epilogue &ep = g.ep;
+  const int groups = (g.M + 31) >> 5;
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int n = 0; n < TN; n++) {
+      const int col = col0 + n * 32 + l31;
+      const float bias = (ep.bias && col < g.N) ? ep.bias[col] : 0.0f;
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const int row = row0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        float v = fmaf(g.alpha, acc[i][n][e], bias);
+        if (ep.clip > 0.0f) v = fminf(fmaxf(v, -ep.clip), ep.clip);
+        if (row < g.M) {
+          s0 += (double)v;
+          s1 += (double)(v * v);
+          s2 += (double)v * (double)v;
+        }
+      }
+      s0 += __shfl_xor(s0, 32, 64);
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      const int grp = (row0 + i * 32) >> 5;
+      if (lh == 0 && col < g.N && grp < groups) {
+        double *p = ep.colstats + (long)grp * ep.colstats_ld + col;
+        const long plane = (long)groups * ep.colstats_ld;
+        p[0] = s0; p[plane] = s1; p[2 * plane] = s2;
+      }
+    }
+}
+
 // The same epilogue with 16-byte global accesses.  A lane of the 32x32 MFMA holds 16 ROWS of one column, so the epilogue above
 // issues one 4-byte access per element: 16 stores (48 memory instructions with the fused SGD step) per wave and patch, and the
 // tail of the kernel is store-ISSUE bound (one workgroup per CU: nothing overlaps it).  Here the wave first passes its patch

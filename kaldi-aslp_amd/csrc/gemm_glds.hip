@@ -246,6 +246,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_f32_glds(GemmArgs g) {
   }
   wait_vmcnt<0>();  // drain the clamped tail requests before the LDS block is released
 
+  if (g.ep.colstats != nullptr && g.split_k <= 1) gemm_colstats<TM, TN>(g, acc, m0 + wm * WM, n0 + wn * WN, l31, lh);  // uniform
   static_assert(NW * 32 * kEpiPitch * (int)sizeof(float) <= NS * STAGE * (int)sizeof(float), "the waves' epilogue slices must fit into the operand LDS");
   if (g.wide_epilogue && gemm_epilogue_wide_ok(g) && g.split_k <= 1) {  // uniform
     __builtin_amdgcn_s_barrier();  // every wave is past its last operand read: the LDS is free
@@ -337,7 +338,7 @@ int pick_split_k(const GemmArgs &g, int bm, int bn) {
   static const int forced = [] { const char *e = getenv("ASLP_GEMM_SPLITK"); return e ? atoi(e) : -1; }();
   if (forced == 0) return 0;
   const aslp_gemm_epilogue &ep = g.ep;
-  if (ep.bias || ep.act_out || ep.colsum || g.K < 1024) return 0;
+  if (ep.bias || ep.act_out || ep.colsum || ep.colstats || g.K < 1024) return 0;
   if (g.pair && (g.ep1.bias || g.ep1.act_out || g.ep1.colsum)) return 0;
   const long tiles = (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * (g.pair ? 2 : 1);
   static const int slots = [] { const char *e = getenv("ASLP_GEMM_SPLITK_SLOTS"); return e ? atoi(e) : 256; }();

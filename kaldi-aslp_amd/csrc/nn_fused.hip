@@ -503,6 +503,80 @@ __global__ void __launch_bounds__(kPanelThreads) bn_forward_coop(const float *__
   }
 }
 
+// BatchNormalization forward whose column statistics come from the producer of `in` (the forward GEMM's epilogue,
+// aslp_gemm_epilogue.colstats: `groups` partial sums per column and statistic).  No statistics pass over the matrix, no exchange
+// between workgroups: a workgroup adds the partials of its 32 columns (group order, double), then streams its rows once.
+// Grid: (cols / 32) x Q row chunks like bn_forward_coop; every row chunk derives the same statistics, chunk 0 publishes them.
+constexpr int kStatSlots = 4;
+__global__ void __launch_bounds__(kPanelThreads) bn_forward_stats_kernel(const float *__restrict__ in, int ldi, float *__restrict__ out, int ldo,
+                                                                        const float *__restrict__ scale, const float *__restrict__ shift,
+                                                                        float *__restrict__ mean, float *__restrict__ inv_std,
+                                                                        double *__restrict__ acc_means, double *__restrict__ acc_vars, float inv_rows,
+                                                                        float floor_, int rows, float *__restrict__ act, int lda, int Q,
+                                                                        const double *__restrict__ part, int groups, int ldp) {
+  constexpr int CG = kCoopCG, L = kCoopLanes, COLS = kCoopCols, SL = kPanelThreads / COLS;  // SL partial-sum slices per column
+  __shared__ double red[3][SL][COLS];
+  __shared__ float stat[2][COLS];
+  const int P = gridDim.x / Q, p = blockIdx.x % P, q = blockIdx.x / P;
+  const int rp = (rows + Q - 1) / Q, r0 = q * rp, r1 = min(rows, r0 + rp);
+  const int cg = threadIdx.x % CG, lane = threadIdx.x / CG;
+  const int c = (p * CG + cg) * 4;
+  // the rows first (<= kStatSlots per thread, the host sizes Q for that): their latency overlaps the statistics below
+  float4 x[kStatSlots];
+#pragma unroll
+  for (int k = 0; k < kStatSlots; k++) {
+    const int r = r0 + lane + k * L;
+    x[k] = r < r1 ? *reinterpret_cast<const float4 *>(in + (long)r * ldi + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  {
+    const int pc = threadIdx.x % COLS, sl = threadIdx.x / COLS, col = p * COLS + pc;
+    const long plane = (long)groups * ldp;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int gi = sl; gi < groups; gi += SL) {
+      const double *pp = part + (long)gi * ldp + col;
+      s0 += pp[0]; s1 += pp[plane]; s2 += pp[2 * plane];
+    }
+    red[0][sl][pc] = s0; red[1][sl][pc] = s1; red[2][sl][pc] = s2;
+  }
+  __syncthreads();
+  if (threadIdx.x < COLS) {
+    const int pc = threadIdx.x, col = p * COLS + pc;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int sl = 0; sl < SL; sl++) { s0 += red[0][sl][pc]; s1 += red[1][sl][pc]; s2 += red[2][sl][pc]; }
+    const float mu = (float)s0 * inv_rows;   // as bn_forward_coop
+    const double m = s0 * (double)inv_rows;
+    double var = s2 * (double)inv_rows - m * m;
+    var = var > 0.0 ? var : 0.0;
+    const float is = 1.0f / sqrtf((float)var + floor_);
+    if (q == 0) {
+      mean[col] = mu;
+      inv_std[col] = is;
+      if (acc_means) acc_means[col] += s0;
+      if (acc_vars) acc_vars[col] += s1;
+    }
+    stat[0][pc] = mu;
+    stat[1][pc] = is;
+  }
+  __syncthreads();
+  const float4 g = *reinterpret_cast<const float4 *>(scale + c), b = *reinterpret_cast<const float4 *>(shift + c);
+  const float4 m = *reinterpret_cast<const float4 *>(&stat[0][cg * 4]), is = *reinterpret_cast<const float4 *>(&stat[1][cg * 4]);
+#pragma unroll
+  for (int k = 0; k < kStatSlots; k++) {
+    const int r = r0 + lane + k * L;
+    if (r >= r1) break;
+    float4 h, o;
+    h.x = (x[k].x - m.x) * is.x; h.y = (x[k].y - m.y) * is.y; h.z = (x[k].z - m.z) * is.z; h.w = (x[k].w - m.w) * is.w;
+    o.x = h.x * g.x + b.x; o.y = h.y * g.y + b.y; o.z = h.z * g.z + b.z; o.w = h.w * g.w + b.w;
+    if (out) *reinterpret_cast<float4 *>(out + (long)r * ldo + c) = o;
+    if (act) {
+      float4 y;
+      y.x = sigmoid_ref(o.x); y.y = sigmoid_ref(o.y); y.z = sigmoid_ref(o.z); y.w = sigmoid_ref(o.w);
+      *reinterpret_cast<float4 *>(act + (long)r * lda + c) = y;
+    }
+  }
+}
+
 template <int SLOTS, bool HAS_Y, bool RECOMPUTE>
 __global__ void __launch_bounds__(kPanelThreads) bn_backward_coop(const float *__restrict__ dy, int ldd, float *__restrict__ xhat, int ldx,
                                                            float *__restrict__ scale, float *__restrict__ shift,
@@ -863,6 +937,28 @@ void aslp_bn_forward_act(const float *in, MatrixDim d, float *out, int out_strid
   else hipLaunchKernelGGL((bn_normalize_kernel<false>), dim3(grid_for(n)), dim3(kBlock), 0, cur_stream(), in, d.stride, out, out_stride, xhat, xhat_stride, mean, inv_std, scale, shift, d.rows, d.cols, act_out, act_stride);
   check_launch("bn_forward");
 }
+int aslp_bn_forward_stats(const float *in, MatrixDim d, float *out, int out_stride, const float *scale, const float *shift, float *mean,
+                          float *inv_std, double *acc_means, double *acc_vars, float var_floor, float *act_out, int act_stride,
+                          const double *colstats, int groups, int stats_ld) {
+  if (d.rows <= 0 || d.cols <= 0 || !colstats) return 0;
+  if (!out && !act_out) { set_error("aslp_bn_forward_stats: no output"); return 0; }
+  if (groups != (d.rows + 31) / 32 || stats_ld < d.cols) { set_error("aslp_bn_forward_stats: statistics layout does not match the matrix"); return 0; }
+  static const bool off = [] { const char *e = getenv("ASLP_BN_FROM_STATS"); return e && e[0] == '0'; }();   // A/B switch
+  const bool vec = d.cols % 4 == 0 && d.stride % 4 == 0 && (!out || (out_stride % 4 == 0 && aligned16(out))) &&
+                   (!act_out || (act_stride % 4 == 0 && aligned16(act_out))) && aligned16(in) && aligned16(mean) && aligned16(inv_std) &&
+                   aligned16(scale) && aligned16(shift);
+  // the shapes the backward pass serves without a stored normalised copy (it recomputes xhat from `in` and the batch mean)
+  if (off || !vec || d.cols % kCoopCols != 0 || !bn_panel_shape(d.rows, d.cols).cg) return 0;
+  const int P = d.cols / kCoopCols;
+  int Q = 1;
+  while (Q < 8 && P * Q * 2 <= 1024 && (d.rows + 2 * Q - 1) / (2 * Q) >= 64) Q *= 2;   // ~4 workgroups per CU at most, >= 64 rows each
+  while ((d.rows + Q - 1) / Q > kStatSlots * kCoopLanes) Q *= 2;                       // at most kStatSlots rows per thread
+  hipLaunchKernelGGL(bn_forward_stats_kernel, dim3(P * Q), dim3(kPanelThreads), 0, cur_stream(), in, d.stride, out, out_stride, scale, shift, mean,
+                     inv_std, acc_means, acc_vars, 1.0f / (float)d.rows, var_floor, d.rows, act_out, act_stride, Q, colstats, groups, stats_ld);
+  check_launch("bn_forward_stats");
+  return 1;
+}
+
 void aslp_bn_forward(const float *in, MatrixDim d, float *out, int out_stride, float *xhat, int xhat_stride, const float *scale,
                      const float *shift, float *mean, float *inv_std, double *acc_means, double *acc_vars, float var_floor) {
   aslp_bn_forward_act(in, d, out, out_stride, xhat, xhat_stride, scale, shift, mean, inv_std, acc_means, acc_vars, var_floor, nullptr, 0);

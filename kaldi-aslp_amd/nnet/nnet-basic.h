@@ -133,8 +133,18 @@ class AffineTransform : public UpdatableComponent {
     // :186-191  out = bias (beta 0); out += in * W^T.  One GEMM with the bias in the epilogue.
     aslp_gemm_epilogue ep = aslp_gemm_epilogue();
     ep.bias = bias_.Data();
+    if (stats_request_) {  // a BatchNormalization is the only consumer: the epilogue also leaves its column statistics (one-shot)
+      const int groups = (in.NumRows() + 31) / 32, ld = (output_dim_ + 3) & ~3;
+      if (stats_request_->Dim() != 3 * groups * ld) stats_request_->Resize(3 * groups * ld, kUndefined);
+      ep.colstats = stats_request_->Data();
+      ep.colstats_ld = ld;
+      stats_request_ = nullptr;
+    }
     out->AddMatMat(1.0, in, kNoTrans, linearity_, kTrans, 0.0, &ep);
   }
+  // Executor peephole (nnet-nnet.cpp): the next Propagate also forms the per-column statistics of its output for the
+  // BatchNormalization behind it, in `buf` as aslp_gemm_epilogue.colstats lays them out (groups = ceil(rows / 32), ld = dim rounded to 4)
+  void RequestOutputStats(CuVectorD *buf) { stats_request_ = buf; }
   // Executor peephole (nnet-nnet.cpp): a Sigmoid that is this component's only consumer gets its output from the same
   // GEMM (second store of the epilogue, sigmoid of the value just written to `out`): same bits as the separate launch.
   void PropagateWithSigmoid(const CuMatrixBase &in, CuMatrix *out, CuMatrix *sigmoid_out) {
@@ -178,6 +188,7 @@ class AffineTransform : public UpdatableComponent {
   const CuMatrixBase &GetLinearityCorr() const { return linearity_corr_; }
 
  private:
+  CuVectorD *stats_request_ = nullptr;
   CuMatrix linearity_;
   CuVector bias_;
   CuMatrix linearity_corr_;
@@ -599,6 +610,7 @@ class BatchNormalization : public UpdatableComponent {
   void PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) {  // :177-220
     if (!acc_cleaned_) { acc_cleaned_ = true; CleanAccs(); }
     BaseFloat *xhat = XhatFor(in);
+    if (ForwardFromStats(in, out->Data(), out->Stride(), nullptr, 0)) return;
     aslp_bn_forward(in.Data(), in.Dim(), out->Data(), out->Stride(), xhat, XsharpO_.Stride(), scale_.Data(), shift_.Data(),
                     mean_vec_.Data(), var_vec_.Data(), acc_means_.Data(), acc_vars_.Data(), var_floor_);
     num_acc_frames_ += in.NumRows();
@@ -610,11 +622,15 @@ class BatchNormalization : public UpdatableComponent {
   void FoldNextUpdateIntoBackprop() { fold_update_ = true; }
   // Executor peephole (nnet-nnet.cpp): a Sigmoid that is this component's only consumer is folded into the write
   // pass (forward) and into the statistics / write passes (backward); the BN output itself is never materialised.
+  // Executor peephole: the producer of the next Propagate's input (an AffineTransform) has left the column statistics of that
+  // input in `stats` (AffineTransform::RequestOutputStats); one-shot.
+  void UseInputStats(const CuVectorD *stats) { input_stats_ = stats; }
   void PropagateWithSigmoid(const CuMatrixBase &in, CuMatrix *sigmoid_out) {
     ASLP_ASSERT(in.NumCols() == input_dim_);
     if (!acc_cleaned_) { acc_cleaned_ = true; CleanAccs(); }
     BaseFloat *xhat = XhatFor(in);
     if (sigmoid_out->NumRows() != in.NumRows() || sigmoid_out->NumCols() != output_dim_) sigmoid_out->Resize(in.NumRows(), output_dim_, kUndefined);
+    if (ForwardFromStats(in, nullptr, 0, sigmoid_out->Data(), sigmoid_out->Stride())) return;
     aslp_bn_forward_act(in.Data(), in.Dim(), nullptr, 0, xhat, XsharpO_.Stride(), scale_.Data(), shift_.Data(), mean_vec_.Data(),
                         var_vec_.Data(), acc_means_.Data(), acc_vars_.Data(), var_floor_, sigmoid_out->Data(), sigmoid_out->Stride());
     num_acc_frames_ += in.NumRows();
@@ -637,6 +653,7 @@ class BatchNormalization : public UpdatableComponent {
   CuVectorD &AccVars() { return acc_vars_; }
 
  private:
+  const CuVectorD *input_stats_ = nullptr;
   void Backward(const CuMatrixBase &in, const CuMatrixBase &out_diff, BaseFloat *in_diff, int32 id_stride, const BaseFloat *act_y, int32 act_stride) {
     if (fold_update_) {
       fold_update_ = false;
@@ -648,6 +665,19 @@ class BatchNormalization : public UpdatableComponent {
       aslp_bn_backward_act(in.Data(), in.Dim(), out_diff.Data(), out_diff.Stride(), xhat_kept_ ? XsharpO_.Data() : nullptr, XsharpO_.Stride(), scale_.Data(),
                            mean_vec_.Data(), var_vec_.Data(), dscale_.Data(), dshift_.Data(), opts_.momentum, in_diff, id_stride, act_y, act_stride);
     }
+  }
+  // statistics handed over by the producer (UseInputStats): the launch that only streams the input once; false = not served
+  bool ForwardFromStats(const CuMatrixBase &in, BaseFloat *out, int32 out_stride, BaseFloat *act, int32 act_stride) {
+    const CuVectorD *st = input_stats_;
+    input_stats_ = nullptr;
+    if (st == nullptr || xhat_kept_) return false;
+    const int groups = (in.NumRows() + 31) / 32, ld = (input_dim_ + 3) & ~3;
+    if (st->Dim() != 3 * groups * ld) return false;
+    if (!aslp_bn_forward_stats(in.Data(), in.Dim(), out, out_stride, scale_.Data(), shift_.Data(), mean_vec_.Data(), var_vec_.Data(), acc_means_.Data(),
+                               acc_vars_.Data(), var_floor_, act, act_stride, st->Data(), groups, ld))
+      return false;
+    num_acc_frames_ += in.NumRows();
+    return true;
   }
   // The normalised copy X# of the input (the reference's XsharpO_, nnet-batch-normalization.h:188) is only materialised where
   // the kernels need it: the single-launch panel kernels form it again from the layer input in the backward pass.

@@ -1,6 +1,7 @@
 // nnet-nnet.cpp -- graph executor.  Follows src/aslp-nnet/nnet-nnet.cc (cited per function).
 #include "nnet-nnet.h"
 
+#include <cstdlib>
 #include <chrono>
 #include <fstream>
 
@@ -38,6 +39,15 @@ int32 Nnet::FusedSigmoidOf(int32 i) const {
     const std::vector<int32> &inp = components_[j]->GetInput();
     if (inp.size() == 1 && inp[0] == i)
       return (components_[j]->GetType() == Component::kSigmoid && IsDirectLink(j)) ? j : -1;
+  }
+  return -1;
+}
+int32 Nnet::BatchNormOf(int32 i) const {
+  if (!fuse_layers_ || !alias_links_ || components_[i]->GetType() != Component::kAffineTransform || num_consumers_[i] != 1) return -1;
+  for (int32 j = i + 1; j < NumComponents(); j++) {
+    const std::vector<int32> &inp = components_[j]->GetInput();
+    if (inp.size() == 1 && inp[0] == i)
+      return (components_[j]->GetType() == Component::kBatchNormalization && IsDirectLink(j)) ? j : -1;
   }
   return -1;
 }
@@ -86,6 +96,16 @@ void Nnet::Propagate(const std::vector<const CuMatrixBase *> &in, std::vector<Cu
     }
     Timer tim1;
     const int32 fs = FusedSigmoidOf(i), as = AffineSigmoidOf(i);
+    {
+      // AffineTransform whose only consumer is a BatchNormalization: the GEMM's epilogue leaves the column statistics of its output
+      // (32-row partial sums), and the normalisation then streams that output once instead of reading it for statistics first
+      static const bool stats_off = getenv("ASLP_BN_FROM_STATS") != nullptr && getenv("ASLP_BN_FROM_STATS")[0] == '0';  // A/B switch
+      const int32 bn = stats_off ? -1 : BatchNormOf(i);
+      if (bn >= 0) {
+        dynamic_cast<AffineTransform *>(components_[i])->RequestOutputStats(&bn_stats_buf_[i]);
+        dynamic_cast<BatchNormalization *>(components_[bn])->UseInputStats(&bn_stats_buf_[i]);
+      }
+    }
     if (as >= 0) {  // AffineTransform + Sigmoid forward in one GEMM; both outputs exist, the backward passes stay separate
       dynamic_cast<AffineTransform *>(components_[i])->PropagateWithSigmoid(*in_view_[i], &output_buf_[i], &output_buf_[as]);
       out_view_[i] = &output_buf_[i];
@@ -603,6 +623,7 @@ void Nnet::Destroy() {  // :822-832
   input_diff_buf_.resize(0);
   output_buf_.resize(0);
   output_diff_buf_.resize(0);
+  bn_stats_buf_.resize(0);
   in_view_.resize(0);
   in_diff_view_.resize(0);
   out_view_.resize(0);
@@ -627,6 +648,7 @@ void Nnet::InitInputOutput() {  // :845-870
   output_buf_.resize(NumComponents());
   input_diff_buf_.resize(NumComponents());
   output_diff_buf_.resize(NumComponents());
+  bn_stats_buf_.resize(NumComponents());
   in_view_.assign(NumComponents(), NULL);
   in_diff_view_.assign(NumComponents(), NULL);
   out_view_.assign(NumComponents(), NULL);

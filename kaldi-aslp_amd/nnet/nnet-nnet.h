@@ -108,6 +108,7 @@ class Nnet {
   bool IsDirectLink(int32 i) const;  // single input, offset 0, full width
   bool IsFinalSoftmax(int32 i) const;
   int32 FusedSigmoidOf(int32 i) const;  // index of the Sigmoid folded into BatchNormalization i, or -1
+  int32 BatchNormOf(int32 i) const;      // index of the BatchNormalization that is AffineTransform i's only consumer (direct link), or -1
   int32 AffineSigmoidOf(int32 i) const;  // index of the Sigmoid whose forward pass rides in AffineTransform i's GEMM, or -1
 
   std::vector<Component *> components_;
@@ -115,6 +116,7 @@ class Nnet {
   std::vector<int32> num_consumers_;
   std::vector<std::pair<std::string, double>> propagate_time_, back_propagate_time_;
   std::vector<CuMatrix> input_buf_, output_buf_, input_diff_buf_, output_diff_buf_;
+  std::vector<CuVectorD> bn_stats_buf_;  // per AffineTransform in front of a BatchNormalization: column statistics of its output
   std::vector<const CuMatrixBase *> in_view_;       // what component i actually reads as input
   std::vector<const CuMatrixBase *> in_diff_view_;  // where component i's in-diff went
   std::vector<const CuMatrixBase *> out_view_;      // component i's forward output (own buffer, or its input for copy layers)

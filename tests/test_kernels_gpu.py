@@ -472,3 +472,59 @@ def test_sgemm_pair_matches_two_products(aslp, dev, tA, tB, M, N, K, mode):
     # run-to-run reproducible
     Cp2, Wp2, _ = run(True)
     assert all(torch.equal(x, y) for x, y in zip(Cp + Wp, Cp2 + Wp2))
+
+
+@pytest.mark.parametrize("M,N,K,force", [(1024, 2048, 440, 0), (1024, 2048, 2048, 212), (1000, 96, 64, 0), (77, 40, 36, 0), (256, 128, 130, 0), (1024, 2048, 512, 7)])
+def test_gemm_column_statistics_feed_batchnorm(aslp, dev, M, N, K, force):
+    """aslp_gemm_epilogue.colstats: the forward product x = in W^T + b also leaves, per 32-row group and column, sum x, sum (float)(x*x)
+    and sum x*x in double -- from the LDS-DMA kernels' epilogue, from one extra pass for the other kernels (odd K, forced
+    register-staged tile) -- and aslp_bn_forward_stats normalises from those partials without a statistics pass of its own.
+    The partials against float64 sums of the stored output; the normalisation (+ folded Sigmoid, running accumulators) against
+    aslp_bn_forward_act on the same matrix."""
+    from kaldi_aslp_amd._lib import GemmEpilogue
+    import ctypes as C
+    g = torch.Generator(device=dev).manual_seed(M + N + K)
+    A = torch.randn(M, K, device=dev, generator=g)
+    W = torch.randn(N, K, device=dev, generator=g) * 0.1
+    b = torch.randn(N, device=dev, generator=g)
+    groups, ld = (M + 31) // 32, (N + 3) & ~3
+    stats = torch.full((3, groups, ld), float("nan"), dtype=torch.float64, device=dev)
+    x = torch.empty(M, N, device=dev)
+    ep = GemmEpilogue(b.data_ptr(), 0.0, None, 0, 0.0, None, 0, 0, None, 0.0, None, 0.0, stats.data_ptr(), ld)
+    aslp.lib.aslp_gemm_force_tile(force)
+    try:
+        aslp.ops.sgemm(0, 1, 1.0, A, W, 0.0, x, ep)
+    finally:
+        aslp.lib.aslp_gemm_force_tile(0)
+    xp = torch.zeros(groups * 32, N, dtype=torch.float64, device=dev)
+    xp[:M] = x.double()
+    xg = xp.view(groups, 32, N)
+    assert torch.allclose(stats[0, :, :N], xg.sum(1), rtol=1e-12, atol=1e-9)
+    assert torch.allclose(stats[2, :, :N], (xg * xg).sum(1), rtol=1e-12, atol=1e-9)
+    x32 = torch.zeros(groups * 32, N, device=dev)
+    x32[:M] = x
+    assert torch.allclose(stats[1, :, :N], (x32 * x32).double().view(groups, 32, N).sum(1), rtol=1e-12, atol=1e-9)
+    # the BatchNormalization that consumes them
+    scale, shift = torch.rand(N, device=dev, generator=g) + 0.5, torch.randn(N, device=dev, generator=g)
+    outs = []
+    for from_stats in (True, False):
+        out, act = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
+        mean, inv = torch.empty(N, device=dev), torch.empty(N, device=dev)
+        accm = torch.ones(N, dtype=torch.float64, device=dev)
+        accv = torch.ones(N, dtype=torch.float64, device=dev)
+        d = aslp.ops.dim(x)
+        if from_stats:
+            ran = aslp.lib.aslp_bn_forward_stats(x.data_ptr(), d, out.data_ptr(), N, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), inv.data_ptr(),
+                                                 accm.data_ptr(), accv.data_ptr(), 1e-7, act.data_ptr(), N, stats.data_ptr(), groups, ld)
+            aslp._lib.check_error()
+            served = N % 32 == 0 and M <= 1024
+            assert bool(ran) == served, (ran, served)
+            if not ran:
+                return
+        else:
+            aslp.lib.aslp_bn_forward_act(x.data_ptr(), d, out.data_ptr(), N, None, 0, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), inv.data_ptr(),
+                                         accm.data_ptr(), accv.data_ptr(), 1e-7, act.data_ptr(), N)
+            aslp._lib.check_error()
+        outs.append((out, act, mean, inv, accm, accv))
+    for a, r in zip(outs[0], outs[1]):
+        assert torch.allclose(a, r, rtol=2e-6, atol=1e-6), (a - r).abs().max()
