@@ -210,6 +210,11 @@ void Nnet::Backpropagate(const std::vector<const CuMatrixBase *> &out_diff, std:
     fused_sigmoid[i] = FusedSigmoidOf(i);
     if (fused_sigmoid[i] >= 0) folded[fused_sigmoid[i]] = 1;
   }
+  int32 lowest_updatable = -1;
+  for (int32 i = 0; i < N && lowest_updatable < 0; i++)
+    if (components_[i]->IsUpdatable()) lowest_updatable = i;
+  static const bool lowest_on_side = getenv("ASLP_LOWEST_UPDATE_ON_SIDE") != nullptr && getenv("ASLP_LOWEST_UPDATE_ON_SIDE")[0] == '1';  // A/B switch
+  if (lowest_on_side) lowest_updatable = -1;
   for (int32 i = N - 1; i >= 0; i--) {
     if (folded[i]) { in_diff_view_[i] = NULL; continue; }
     Timer tim2;
@@ -241,7 +246,9 @@ void Nnet::Backpropagate(const std::vector<const CuMatrixBase *> &out_diff, std:
     }
     if (components_[i]->IsUpdatable()) {
       UpdatableComponent *uc = dynamic_cast<UpdatableComponent *>(components_[i]);
-      if (overlap_updates && components_[i]->GetType() == Component::kAffineTransform) {
+      // (the lowest updatable component has nothing below it to run beside: on the main stream it spares the step boundary a
+      //  cross-stream event wait, ~10 us before the next forward pass can start)
+      if (overlap_updates && components_[i]->GetType() == Component::kAffineTransform && i != lowest_updatable) {
         SideStreamScope side;  // after this component's Backpropagate (which reads the weights), beside everything below it
         uc->Update(*in_view_[i], output_diff_buf_[i]);
       } else {
