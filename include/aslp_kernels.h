@@ -334,6 +334,24 @@ unsigned aslp_lstm_seq_polls(int reset);
 /* diagnostics (devtools/bench_lc.py): phase timing of the forward kernel, see csrc/rnn_persistent.hip */
 void aslp_lstm_seq_timing(int enable, unsigned long long *out);
 void aslp_lstm_seq_backward(const aslp_lstm_seq *a);
+/* GruStreams, the whole recurrence of T timesteps as ONE launch per pass (csrc/rnn_persistent.hip; the scheme of aslp_lstm_seq_*):
+ * y / d: [(T + 2) * S x ld] activations / diffs, row block 0 = the carried history h(0) (forward), row blocks 0 and T + 1 of d zero,
+ * columns [z|r|m|g|h], H each.  Before the launch the caller has stored
+ *   forward:  the x-parts (+ bias) of z, r, m in columns [0, 3H) of row blocks 1..T, and aslp_lstm_seq_fill(y, ld, T, S, 3H, 2H)
+ *             BEFORE that (g and h start as "not yet published");
+ *   backward: aslp_lstm_seq_fill(d, ld, T, S, 0, 3H), then the loss's share of d_h in column block 4 of row blocks 1..T.
+ * w_zr / w_m: forward W_zr_h [2H x H] and W_m_g [H x H]; backward their TRANSPOSES [H x 2H] and [H x H] (rows K-contiguous).
+ * aslp_gru_seq_supported: S <= 64, H <= 512, H % 4 == 0, the grid co-resident; otherwise use aslp_gru_step_*. */
+typedef struct aslp_gru_seq_ {
+  float *y;
+  float *d;            /* backward only */
+  const float *w_zr;
+  const float *w_m;
+  int ldw_zr, ldw_m, ld, T, S, H;
+} aslp_gru_seq;
+int aslp_gru_seq_supported(const aslp_gru_seq *a, int backward);
+void aslp_gru_seq_forward(const aslp_gru_seq *a);
+void aslp_gru_seq_backward(const aslp_gru_seq *a);
 /* GruStreams (nnet-gru-streams.h:275-303, 344-383), columns [z|r|m|g|h] */
 /* GRU recurrence, one timestep, both dependent products fused with their gate arithmetic (csrc/gru_fused.hip):
  * forward = aslp_gru_forward1/2 with the two skinny GEMMs folded in; backward likewise, reading TRANSPOSED copies of the

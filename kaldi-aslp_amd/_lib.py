@@ -26,6 +26,12 @@ class GemmEpilogue(C.Structure):
                 ("colstats", C.c_void_p), ("colstats_ld", C.c_int)]
 
 
+class GruSeq(C.Structure):
+    """aslp_gru_seq (include/aslp_kernels.h)"""
+    _fields_ = [("y", C.c_void_p), ("d", C.c_void_p), ("w_zr", C.c_void_p), ("w_m", C.c_void_p), ("ldw_zr", C.c_int), ("ldw_m", C.c_int),
+                ("ld", C.c_int), ("T", C.c_int), ("S", C.c_int), ("H", C.c_int)]
+
+
 class RnnVecGrad(C.Structure):
     """aslp_rnn_vec_grad (include/aslp_kernels.h)"""
     _fields_ = [("d", C.c_void_p), ("x", C.c_void_p), ("ldx", C.c_int), ("n", C.c_int), ("corr", C.c_void_p), ("param", C.c_void_p)]
@@ -122,6 +128,7 @@ _sig("aslp_sgemm_ex", _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _f, _vp, _i,
 _sig("aslp_sgemm_pair_ex", _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _i, C.POINTER(GemmEpilogue), C.POINTER(GemmEpilogue))
 _sig("aslp_gemm_profile", None, _i)
 _sig("aslp_gemm_profile_reset", None)
+_sig("aslp_gru_seq_supported", _i, C.POINTER(GruSeq), _i)
 _sig("aslp_gemm_force_tile", None, _i)
 _sig("aslp_gemm_last_tile", _i)
 _sig("aslp_gemm_profile_get", C.c_long, _i, C.POINTER(C.c_double), C.POINTER(C.c_double))

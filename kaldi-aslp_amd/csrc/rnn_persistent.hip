@@ -151,13 +151,13 @@ struct ChainRole {
 
 // Who am I, and does my chain sit on one XCD?  place: [kMaxChains][kMaxWgPerChain] words; an entry counts once it carries
 // this launch's epoch (a host-side launch counter, st.epoch) -- nothing to clear between launches.
-__device__ __forceinline__ ChainRole chain_role(const aslp_lstm_seq &a, const SeqStatus &st, unsigned *place, int *lds_flag) {
+__device__ __forceinline__ ChainRole chain_role(int S, int ndir, int C, const SeqStatus &st, unsigned *place, int *lds_flag) {
   ChainRole r;
   const int chain = blockIdx.x & (kMaxChains - 1), cb = blockIdx.x >> 3;
-  const int nsg = (a.S + kChainStreams - 1) / kChainStreams, nchains = a.ndir * nsg, wpc = (a.C + kCellsPerWg - 1) / kCellsPerWg;
+  const int nsg = (S + kChainStreams - 1) / kChainStreams, nchains = ndir * nsg, wpc = (C + kCellsPerWg - 1) / kCellsPerWg;
   r.active = chain < nchains;
-  r.dir = r.active ? chain % a.ndir : 0;
-  r.s0 = (r.active ? chain / a.ndir : 0) * kChainStreams;
+  r.dir = r.active ? chain % ndir : 0;
+  r.s0 = (r.active ? chain / ndir : 0) * kChainStreams;
   r.c0 = cb * kCellsPerWg;
   r.local = false;
   if (!r.active) return r;
@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(512) lstm_seq_fwd(aslp_lstm_seq a, SeqStatus s
   __shared__ int fail[2][8];
   __shared__ int place_flag;
   const long t_entry = (st.timing || st.trace) ? (long)wall_clock64() : 0;
-  const ChainRole R = chain_role(a, st, place, &place_flag);
+  const ChainRole R = chain_role(a.S, a.ndir, a.C, st, place, &place_flag);
   if (!R.active) return;
   const aslp_lstm_seq_dir D = a.dir[R.dir];
   const int C = a.C, S = a.S, T = a.T, ld = a.ld;
@@ -393,7 +393,7 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd(aslp_lstm_seq a, SeqStatus s
   __shared__ int fail[2][8];
   __shared__ int place_flag;
   const long t_entry = st.trace ? (long)wall_clock64() : 0;
-  const ChainRole R = chain_role(a, st, place, &place_flag);
+  const ChainRole R = chain_role(a.S, a.ndir, a.C, st, place, &place_flag);
   if (!R.active) return;
   const aslp_lstm_seq_dir D = a.dir[R.dir];
   const int C = a.C, S = a.S, T = a.T, ld = a.ld;
@@ -573,6 +573,299 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd(aslp_lstm_seq a, SeqStatus s
   if (polls && lane == 0) __hip_atomic_fetch_add(st.abort_flag + 2, polls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---- GruStreams (nnet-gru-streams.h:238-430): the same persistent scheme, two hand-offs per timestep ------------------------------
+// Buffer columns [z | r | m | g | h], H each.  In each direction of time a GRU step is two products that depend on each other:
+//   forward   zr(t) += h(t-1) W_zr_h^T -> z, r = sigmoid, g = r .* h(t-1)     then   m(t) += g(t) W_m_g^T -> m = tanh, h(t) = h(t-1) - h(t-1) z + z m
+//   backward  d_h(t) += [d_z | d_r](t+1) W_zr_h -> d_h, d_m                    then   d_g(t) = d_m(t) W_m_g -> d_r, d_z
+// so every timestep is two rounds of "collect the chain's left operand (8 streams x K, published by the chain's workgroups in the
+// previous round) into LDS -- multiply with this workgroup's columns of the recurrent matrix (registers, resident for the launch,
+// v_mfma_f32_4x4x1, 8 waves split K) -- finish the 8 x 16 (stream, cell) pairs -- publish 16-byte pieces".  Chains, placement check,
+// "the data is its own flag" hand-off and the bounded spins are those of the LSTM kernels above; GruStreams is unidirectional, so
+// S = 32 gives 4 chains of 32 workgroups (H = 512).  A lane pair owns a (stream, cell): lane 0 of the pair z (forward) / d_z, d_h,
+// d_m, d_g (backward), lane 1 r and g / d_r; h(t-1) and the terms the backward step carries from t+1 never leave the pair's registers.
+//
+// One MFMA instruction is 16 independent 4 x 4 blocks.  The first forward product has 32 columns per workgroup (z and r of its 16
+// cells): blocks = 2 stream quads x 8 column quads ("wide").  The other three products have 16 columns: blocks = 2 stream quads x 4
+// column quads x 2 HALVES OF THE WAVE'S K SLICE ("split") -- no idle blocks, half the instructions and half the weight registers;
+// the two halves' partial sums are two of the 16 terms the epilogue adds per output.
+struct GruGeom {
+  int lane, wave, qs, qc, jl, kh, col16, pair, role, sl, cc;
+};
+__device__ __forceinline__ GruGeom gru_geom() {
+  GruGeom g;
+  g.lane = threadIdx.x & 63; g.wave = threadIdx.x >> 6;
+  g.qs = (g.lane >> 2) & 1; g.qc = g.lane >> 3; g.jl = g.lane & 3;
+  g.kh = g.qc >> 2; g.col16 = 4 * (g.qc & 3) + g.jl;   // split products: K half and column of this lane's block
+  g.pair = threadIdx.x >> 1; g.role = threadIdx.x & 1;
+  g.sl = (g.pair >> 4) & 7; g.cc = g.pair & 15;
+  return g;
+}
+// Collects NP pieces per thread (piece p = threadIdx.x + 512 j of [stream][K / 4], 16 bytes each) of the chain's 8 streams from
+// row block `base` columns [col0, col0 + K) into a_lds[stream][MP]; reloads until no piece reads "not yet published".
+// Returns false on a timeout / device-wide abort (wave-uniform; the caller posts it in fail[] for the workgroup).
+template <int NP>
+__device__ __forceinline__ bool gru_collect(const float *base, int ld, int S, int s0, int col0, int K, float *a_lds, int MP, const SeqStatus &st,
+                                            unsigned &polls) {
+  const int k4 = K >> 2, npiece = kChainStreams * k4;
+  int off[NP], dst[NP];
+  bool have[NP];
+#pragma unroll
+  for (int j = 0; j < NP; j++) {
+    const int p = threadIdx.x + 512 * j;
+    have[j] = p < npiece;
+    const int sp = have[j] ? p / k4 : 0, kq = have[j] ? p % k4 : 0;
+    off[j] = (min(s0 + sp, S - 1) * ld + col0 + 4 * kq) * 4;
+    dst[j] = sp * MP + 4 * kq;
+  }
+  const __amdgpu_buffer_rsrc_t rs = make_rsrc(base);
+  u32x4 v[NP];
+#pragma unroll
+  for (int j = 0; j < NP; j++) v[j] = u32x4{0u, 0u, 0u, 0u};
+  long t0 = 0;
+  bool ok = true;
+  for (unsigned spins = 0;; spins++) {
+    bool missing = false;
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+      if (have[j]) v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[j], 0, kAuxSc1);
+    }
+#pragma unroll
+    for (int j = 0; j < NP; j++) missing = missing || (have[j] && has_sentinel(v[j]));
+    if (!__any(missing)) break;
+    asm volatile("" ::: "memory");
+    polls++;
+    if (!spin_ok(spins, t0, st)) { ok = false; break; }
+    __builtin_amdgcn_s_sleep(1);
+  }
+#pragma unroll
+  for (int j = 0; j < NP; j++)
+    if (have[j]) *reinterpret_cast<u32x4 *>(a_lds + dst[j]) = v[j];
+  return ok;
+}
+// This lane's K slice [k0, k0 + klen) of (8 streams x K) x (K x columns): NB fragments of 4 k values.  Result register r of a lane =
+// stream 4 qs + r of the lane's column.  Slices past K read element 0 of the row (finite; their B fragments are 0).
+template <int NB>
+__device__ __forceinline__ f32x4 gru_product(const float *a_lds, int MP, const f32x4 (&bw)[NB], int k0, int klen, int K, const GruGeom &g) {
+  const float *arow = a_lds + (4 * g.qs + g.jl) * MP;
+  f32x4 av[NB];
+#pragma unroll
+  for (int i = 0; i < NB; i++) av[i] = *reinterpret_cast<const f32x4 *>(arow + ((4 * i < klen && k0 + 4 * i < K) ? k0 + 4 * i : 0));
+  f32x4 acc[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < NB; i++) {   // four independent accumulators: the instruction's latency is hidden without padding
+    acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i].x, bw[i].x, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i].y, bw[i].y, acc[1], 0, 0, 0);
+    acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i].z, bw[i].z, acc[2], 0, 0, 0);
+    acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i].w, bw[i].w, acc[3], 0, 0, 0);
+  }
+  return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+// loads NB fragments of row `row` (K-contiguous, `ldw` floats apart) starting at k0; zero where !valid or beyond klen / K
+template <int NB>
+__device__ __forceinline__ void gru_load_b(f32x4 (&bw)[NB], const float *w, int ldw, int row, bool valid, int k0, int klen, int K) {
+  const float *b = w + (long)(valid ? row : 0) * ldw;
+#pragma unroll
+  for (int i = 0; i < NB; i++)
+    bw[i] = (valid && 4 * i < klen && k0 + 4 * i < K) ? *reinterpret_cast<const f32x4 *>(b + k0 + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+}
+// partial sums of a round meet in LDS: wide products [wave 8][stream 8][kGruRPW], split products [wave * 2 + K half 16][stream 8][kGruRPS]
+constexpr int kGruRPW = 48, kGruRPS = 24, kGruRed = 8 * kChainStreams * kGruRPW;   // = 16 * 8 * 24 floats
+__device__ __forceinline__ void gru_store_wide(float *red, const f32x4 &sum, const GruGeom &g) {
+  float *rp = red + (g.wave * kChainStreams + 4 * g.qs) * kGruRPW + 4 * g.qc + g.jl;
+  rp[0 * kGruRPW] = sum.x; rp[1 * kGruRPW] = sum.y; rp[2 * kGruRPW] = sum.z; rp[3 * kGruRPW] = sum.w;
+}
+__device__ __forceinline__ void gru_store_split(float *red, const f32x4 &sum, const GruGeom &g) {
+  float *rp = red + ((2 * g.wave + g.kh) * kChainStreams + 4 * g.qs) * kGruRPS + g.col16;
+  rp[0 * kGruRPS] = sum.x; rp[1 * kGruRPS] = sum.y; rp[2 * kGruRPS] = sum.z; rp[3 * kGruRPS] = sum.w;
+}
+__device__ __forceinline__ float gru_sum_wide(const float *red, int sl, int col) {
+  float v = red[sl * kGruRPW + col];
+#pragma unroll
+  for (int w = 1; w < 8; w++) v += red[(w * kChainStreams + sl) * kGruRPW + col];
+  return v;
+}
+__device__ __forceinline__ float gru_sum_split(const float *red, int sl, int col) {
+  float v = red[sl * kGruRPS + col];
+#pragma unroll
+  for (int w = 1; w < 16; w++) v += red[(w * kChainStreams + sl) * kGruRPS + col];
+  return v;
+}
+// 16-byte piece = this lane's value and those of the lanes 2, 4, 6 places up in its row of 16 (the same role of the next three cells)
+__device__ __forceinline__ u32x4 gru_piece(float v) {
+  const float v1 = row_up<2>(v), v2 = row_up<4>(v), v3 = row_up<6>(v);
+  return u32x4{__float_as_uint(v), __float_as_uint(v1), __float_as_uint(v2), __float_as_uint(v3)};
+}
+__device__ __forceinline__ void gru_publish(const u32x4 &pk, float *rowblock, int off_floats, bool local) {
+  const __amdgpu_buffer_rsrc_t rs = make_rsrc(rowblock);
+  if (local) __builtin_amdgcn_raw_buffer_store_b128(pk, rs, off_floats * 4, 0, 0);
+  else __builtin_amdgcn_raw_buffer_store_b128(pk, rs, off_floats * 4, 0, kAuxSc1);
+}
+// K values per wave for a reduction of length K: a multiple of 8 (so that the split products' halves are whole fragments), 8 waves cover K
+__device__ __forceinline__ int gru_kw(int K) { return ((K + 63) / 64) * 8; }
+__device__ __forceinline__ bool gru_failed(const int (*fail)[8], int round) {
+  int f = 0;
+#pragma unroll
+  for (int w = 0; w < 8; w++) f |= fail[round][w];
+  return f != 0;  // uniform: every wave reads the same eight words
+}
+
+// grid 8 * ceil(H / 16) workgroups of 512 threads (chains >= S / 8 leave at once).  KW: K values per wave, H <= 8 * KW.
+template <int KW>
+__global__ void __launch_bounds__(512) gru_seq_fwd(aslp_gru_seq a, SeqStatus st, unsigned *place) {
+  constexpr int NBW = KW / 4, NBS = KW / 8, MP = 8 * KW + 4;
+  __shared__ __attribute__((aligned(16))) float a_lds[kChainStreams * MP];
+  __shared__ float red[2][kGruRed];
+  __shared__ int fail[2][8];
+  __shared__ int place_flag;
+  const long t_entry = st.trace ? (long)wall_clock64() : 0;
+  const ChainRole R = chain_role(a.S, 1, a.H, st, place, &place_flag);
+  if (!R.active) return;
+  const int H = a.H, S = a.S, T = a.T, ld = a.ld;
+  const int omm = 2 * H, og = 3 * H, oh = 4 * H;
+  const int c0 = R.c0, s0 = R.s0;
+  const GruGeom g = gru_geom();
+  const int kw = gru_kw(H), kb = g.wave * kw, kbs = kb + g.kh * (kw / 2);
+  // B fragments, resident for the launch.  Round 1 (wide): column n = 4 qc + jl is gate n >> 4 (z, r) of cell c0 + (n & 15);
+  // round 2 (split): column col16 is m of cell c0 + col16, this lane's half of the wave's K slice
+  f32x4 bw1[NBW], bw2[NBS];
+  {
+    const int n = 4 * g.qc + g.jl;
+    gru_load_b<NBW>(bw1, a.w_zr, a.ldw_zr, (n >> 4) * H + c0 + (n & 15), c0 + (n & 15) < H, kb, kw, H);
+    gru_load_b<NBS>(bw2, a.w_m, a.ldw_m, c0 + g.col16, c0 + g.col16 < H, kbs, kw / 2, H);
+  }
+  const int s = s0 + g.sl, cell = c0 + g.cc;
+  const bool live = threadIdx.x < 256 && s < S && cell < H;
+  const int cq = live ? cell : 0, sq = live ? s : 0;
+  float hp = live ? a.y[(long)sq * ld + oh + cq] : 0.f;   // h(0): the carried history in row block 0
+  unsigned polls = 0u;
+  for (int step = 0; step < T; step++) {
+    const int t = 1 + step;
+    float *ys = a.y + ((long)t * S + sq) * ld;
+    // the x-parts (+ bias) of this pair: written before the launch, requested before the hand-off wait
+    const float xg = live ? ys[g.role * H + cq] : 0.f;
+    const float xm = (live && g.role == 0) ? ys[omm + cq] : 0.f;
+    // ---- round 1: h(t-1) -> z, r, g ------------------------------------------------------------------------------
+    bool ok = gru_collect<2>(a.y + (long)(t - 1) * S * ld, ld, S, s0, oh, H, a_lds, MP, st, polls);
+    if (g.lane == 0) fail[0][g.wave] = ok ? 0 : 1;
+    __syncthreads();
+    gru_store_wide(red[0], gru_product<NBW>(a_lds, MP, bw1, kb, kw, H, g), g);
+    __syncthreads();
+    if (gru_failed(fail, 0)) return;
+    float gate = 0.f;
+    if (threadIdx.x < 256) gate = sigmoid_ref(xg + gru_sum_wide(red[0], g.sl, g.role * 16 + g.cc));
+    const float zz = gate;                       // meaningful on lane 0 of the pair
+    const float gg = gate * hp;                  // g = r .* h(t-1), meaningful on lane 1
+    {
+      const u32x4 pk = gru_piece(gg);
+      if (live && g.role == 1 && (g.cc & 3) == 0) gru_publish(pk, a.y + (long)t * S * ld, s * ld + og + cell, R.local);
+      if (live) ys[g.role * H + cell] = gate;
+    }
+    // ---- round 2: g(t) -> m, h -----------------------------------------------------------------------------------
+    ok = gru_collect<2>(a.y + (long)t * S * ld, ld, S, s0, og, H, a_lds, MP, st, polls);
+    if (g.lane == 0) fail[1][g.wave] = ok ? 0 : 1;
+    __syncthreads();
+    gru_store_split(red[1], gru_product<NBS>(a_lds, MP, bw2, kbs, kw / 2, H, g), g);
+    __syncthreads();
+    if (gru_failed(fail, 1)) return;
+    float mm = 0.f, hh = 0.f;
+    if (threadIdx.x < 256 && g.role == 0) {
+      mm = tanh_ref(xm + gru_sum_split(red[1], g.sl, g.cc));
+      hh = hp - hp * zz + zz * mm;
+    }
+    {
+      const u32x4 pk = gru_piece(hh);
+      if (live && g.role == 0 && (g.cc & 3) == 0) gru_publish(pk, a.y + (long)t * S * ld, s * ld + oh + cell, R.local);
+      if (live && g.role == 0) ys[omm + cell] = mm;
+    }
+    // h(t) to both lanes of the pair
+    const float from_left = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(hh), 0x111, 0xF, 0xF, true));  // row_shr:1
+    hp = g.role == 0 ? hh : from_left;
+  }
+  if (st.trace && threadIdx.x == 0) {
+    unsigned long long *tr = st.trace + (st.epoch & 7u) * 2048u;
+    tr[2 * blockIdx.x] = (unsigned long long)t_entry; tr[2 * blockIdx.x + 1] = wall_clock64();
+  }
+  if (polls && g.lane == 0) __hip_atomic_fetch_add(st.abort_flag + 2, polls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// backward: a.w_zr = W_zr_h^T [H x 2H], a.w_m = W_m_g^T [H x H] (K-contiguous rows of this workgroup's 16 cells); both products split.
+// KW1 / KW2: K values per wave of the two products (2H <= 8 KW1, H <= 8 KW2).
+template <int KW1, int KW2>
+__global__ void __launch_bounds__(512) gru_seq_bwd(aslp_gru_seq a, SeqStatus st, unsigned *place) {
+  constexpr int NB1 = KW1 / 8, NB2 = KW2 / 8, MP = 8 * KW1 + 4;
+  __shared__ __attribute__((aligned(16))) float a_lds[kChainStreams * MP];
+  __shared__ float red[2][kGruRed];
+  __shared__ int fail[2][8];
+  __shared__ int place_flag;
+  const long t_entry = st.trace ? (long)wall_clock64() : 0;
+  const ChainRole R = chain_role(a.S, 1, a.H, st, place, &place_flag);
+  if (!R.active) return;
+  const int H = a.H, S = a.S, T = a.T, ld = a.ld;
+  const int orr = H, omm = 2 * H, og = 3 * H, oh = 4 * H;
+  const int c0 = R.c0, s0 = R.s0;
+  const GruGeom g = gru_geom();
+  const int kw1 = gru_kw(2 * H), k1 = g.wave * kw1 + g.kh * (kw1 / 2), kw2 = gru_kw(H), k2 = g.wave * kw2 + g.kh * (kw2 / 2);
+  f32x4 bwa[NB1], bwb[NB2];
+  gru_load_b<NB1>(bwa, a.w_zr, a.ldw_zr, c0 + g.col16, c0 + g.col16 < H, k1, kw1 / 2, 2 * H);
+  gru_load_b<NB2>(bwb, a.w_m, a.ldw_m, c0 + g.col16, c0 + g.col16 < H, k2, kw2 / 2, H);
+  const int s = s0 + g.sl, cell = c0 + g.cc;
+  const bool live = threadIdx.x < 256 && s < S && cell < H;
+  const int cq = live ? cell : 0, sq = live ? s : 0;
+  float dhn = 0.f, zn = 0.f, dgn = 0.f, rn = 0.f;   // d_h, z, d_g, r of this pair at t + 1 (row block T + 1 is zero)
+  unsigned polls = 0u;
+  for (int step = 0; step < T; step++) {
+    const int t = T - step;
+    const long o = ((long)t * S + sq) * ld;
+    const float yz = live ? a.y[o + cq] : 0.f, yr = live ? a.y[o + orr + cq] : 0.f, ym = live ? a.y[o + omm + cq] : 0.f;
+    const float hprev = live ? a.y[o - (long)S * ld + oh + cq] : 0.f;   // h(t-1)
+    const float dh_ext = live ? a.d[o + oh + cq] : 0.f;                  // the loss's share, stored before the launch
+    // ---- round 1: [d_z | d_r](t+1) W_zr_h -> d_h, d_m ----------------------------------------------------------------
+    bool ok = true;
+    if (step > 0) ok = gru_collect<4>(a.d + (long)(t + 1) * S * ld, ld, S, s0, 0, 2 * H, a_lds, MP, st, polls);
+    if (g.lane == 0) fail[0][g.wave] = ok ? 0 : 1;
+    __syncthreads();
+    if (step > 0) gru_store_split(red[0], gru_product<NB1>(a_lds, MP, bwa, k1, kw1 / 2, 2 * H, g), g);
+    __syncthreads();
+    if (gru_failed(fail, 0)) return;
+    float dh = 0.f, dm = 0.f;
+    if (threadIdx.x < 256) {   // both lanes of the pair form d_h (lane 1 needs it for nothing; the arithmetic is uniform)
+      const float prod = step > 0 ? gru_sum_split(red[0], g.sl, g.cc) : 0.f;
+      dh = dh_ext + prod + dhn - dhn * zn + dgn * rn;
+      dm = dtanh(ym, dh * yz);
+    }
+    {
+      const u32x4 pk = gru_piece(dm);
+      if (live && g.role == 0 && (g.cc & 3) == 0) gru_publish(pk, a.d + (long)t * S * ld, s * ld + omm + cell, R.local);
+      if (live && g.role == 0) a.d[o + oh + cell] = dh;
+    }
+    // ---- round 2: d_m(t) W_m_g -> d_g, d_r, d_z ----------------------------------------------------------------------
+    ok = gru_collect<2>(a.d + (long)t * S * ld, ld, S, s0, omm, H, a_lds, MP, st, polls);
+    if (g.lane == 0) fail[1][g.wave] = ok ? 0 : 1;
+    __syncthreads();
+    gru_store_split(red[1], gru_product<NB2>(a_lds, MP, bwb, k2, kw2 / 2, H, g), g);
+    __syncthreads();
+    if (gru_failed(fail, 1)) return;
+    float dg = 0.f, dzr = 0.f;
+    if (threadIdx.x < 256) {
+      dg = gru_sum_split(red[1], g.sl, g.cc);
+      dzr = g.role == 0 ? dsigm(yz, dh * ym - dh * hprev) : dsigm(yr, dg * hprev);
+    }
+    {
+      const u32x4 pk = gru_piece(dzr);   // lane 0 of the pairs: four d_z; lane 1: four d_r
+      if (live && (g.cc & 3) == 0) gru_publish(pk, a.d + (long)t * S * ld, s * ld + g.role * H + cell, R.local);
+      if (live && g.role == 0) a.d[o + og + cell] = dg;
+    }
+    dhn = dh; zn = yz; dgn = dg; rn = yr;
+  }
+  if (st.trace && threadIdx.x == 0) {
+    unsigned long long *tr = st.trace + (st.epoch & 7u) * 2048u;
+    tr[2 * blockIdx.x] = (unsigned long long)t_entry; tr[2 * blockIdx.x + 1] = wall_clock64();
+  }
+  if (polls && g.lane == 0) __hip_atomic_fetch_add(st.abort_flag + 2, polls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Prepares an activation buffer for the forward kernel: boundary row blocks 0 and T + 1 := 0 (all columns), columns
 // [col0, col0 + ncols) of row blocks 1..T := "not yet published".  One launch instead of three memsets over the whole buffer.
 // blockIdx.y picks the buffer (both directions of a layer in one launch); `init` (S rows of `ld_init` floats, may be NULL) is
@@ -645,6 +938,18 @@ SeqKernelB pick_bwd(bool cifg, int C) {
   if (C <= 128) return cifg ? lstm_seq_bwd<true, 1> : lstm_seq_bwd<false, 1>;
   if (C <= 512) return cifg ? lstm_seq_bwd<true, 4> : lstm_seq_bwd<false, 4>;
   return nullptr;
+}
+
+typedef void (*GruKernel)(aslp_gru_seq, SeqStatus, unsigned *);
+GruKernel pick_gru(bool backward, int H) {
+  if (H <= 128) return backward ? gru_seq_bwd<32, 16> : gru_seq_fwd<16>;
+  if (H <= 512) return backward ? gru_seq_bwd<128, 64> : gru_seq_fwd<64>;
+  return nullptr;
+}
+bool gru_args_ok(const aslp_gru_seq *a, bool backward) {
+  return a && a->y && a->w_zr && a->w_m && (!backward || a->d) && a->T > 0 && a->S > 0 && a->H > 0 && (a->H & 3) == 0 && (a->ld & 3) == 0 &&
+         (a->ldw_zr & 3) == 0 && (a->ldw_m & 3) == 0 && a->ld >= 5 * a->H && aligned16(a->y) && aligned16(a->w_zr) && aligned16(a->w_m) &&
+         (!backward || aligned16(a->d));
 }
 
 bool seq_args_ok(const aslp_lstm_seq *a) {
@@ -729,6 +1034,42 @@ static void launch_seq(const aslp_lstm_seq *a, bool backward, const char *who) {
   if (rt.last_done) { ASLP_CHECK_HIP(hipEventRecord(rt.last_done, cur_stream())); rt.last_stream = cur_stream(); }
   check_launch(who);
 }
+
+int aslp_gru_seq_supported(const aslp_gru_seq *a, int backward) {
+  static const bool disabled = (getenv("ASLP_LSTM_PERSISTENT") != nullptr && getenv("ASLP_LSTM_PERSISTENT")[0] == '0') ||
+                               (getenv("ASLP_GRU_PERSISTENT") != nullptr && getenv("ASLP_GRU_PERSISTENT")[0] == '0');
+  if (disabled || !a || a->T <= 0 || a->S <= 0 || a->H <= 0 || (a->H & 3) || (a->ld & 3)) return 0;
+  const int nsg = (a->S + kChainStreams - 1) / kChainStreams, wpc = (a->H + kCellsPerWg - 1) / kCellsPerWg;
+  if (nsg > kMaxChains || wpc > kMaxWgPerChain) return 0;   // S <= 64, H <= 512
+  return grid_fits(reinterpret_cast<const void *>(pick_gru(backward != 0, a->H)), 512, (long)kMaxChains * wpc) ? 1 : 0;
+}
+
+static void launch_gru(const aslp_gru_seq *a, bool backward, const char *who) {
+  if (!gru_args_ok(a, backward) || !aslp_gru_seq_supported(a, backward ? 1 : 0)) {
+    set_error(std::string(who) + ": arguments outside what the persistent kernel supports (check aslp_gru_seq_supported first)");
+    return;
+  }
+  SeqRuntime &rt = seq_runtime();
+  static std::mutex launch_mu;   // as launch_seq: one persistent launch at a time, chained by an event across streams
+  std::lock_guard<std::mutex> launch_lock(launch_mu);
+  if (rt.last_done && rt.last_stream != cur_stream()) ASLP_CHECK_HIP(hipStreamWaitEvent(cur_stream(), rt.last_done, 0));
+  if (*rt.host_err != rt.err_seen) {
+    rt.err_seen = *rt.host_err;
+    rt.ring_ready = false;   // the LSTM backward's share ring may be half consumed: launch_seq puts it back
+    ASLP_CHECK_HIP(hipMemsetAsync(rt.abort_flag, 0, 4, cur_stream()));
+  }
+  rt.epoch = (rt.epoch + 1u) & 0x0FFFFFFFu;
+  if (rt.epoch == 0u) rt.epoch = 1u;
+  SeqStatus st = {rt.abort_flag, rt.host_err_dev, nullptr, ((rt.timing_mode == 3 && !backward) || (rt.timing_mode == 4 && backward)) ? rt.timing + 8 : nullptr,
+                  rt.epoch};
+  const int wpc = (a->H + kCellsPerWg - 1) / kCellsPerWg;
+  hipLaunchKernelGGL(pick_gru(backward, a->H), dim3(kMaxChains * wpc), dim3(512), 0, cur_stream(), *a, st, rt.place);
+  if (!rt.last_done) (void)hipEventCreateWithFlags(&rt.last_done, hipEventDisableTiming);
+  if (rt.last_done) { ASLP_CHECK_HIP(hipEventRecord(rt.last_done, cur_stream())); rt.last_stream = cur_stream(); }
+  check_launch(who);
+}
+void aslp_gru_seq_forward(const aslp_gru_seq *a) { launch_gru(a, false, "aslp_gru_seq_forward"); }
+void aslp_gru_seq_backward(const aslp_gru_seq *a) { launch_gru(a, true, "aslp_gru_seq_backward"); }
 
 // devtools: phase timing of the forward (enable = 1) or backward (2) kernel, workgroup 0, wave 0; 0 switches it off; out (8 words, may be NULL)
 // receives {timesteps, ticks waiting for the readiness sample, full load, MFMA + LDS stores, barrier, epilogue, launches that

@@ -814,7 +814,17 @@ void GruStreams::PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) {  // :
   if (do_stream_reset_) prev_state_.SetZero();
   ASLP_ASSERT(in.NumRows() % nstream_ == 0);
   const int32 T = in.NumRows() / nstream_, S = nstream_;
-  buf_.Resize((T + 2) * S, 5 * H, kSetZero);
+  static const bool unfused = getenv("ASLP_LSTM_UNFUSED") != nullptr && getenv("ASLP_LSTM_UNFUSED")[0] == '1';
+  // the whole recurrence as one persistent launch (csrc/rnn_persistent.hip) where it applies, else four launches per timestep
+  aslp_gru_seq q = aslp_gru_seq();
+  q.T = T; q.S = S; q.H = H; q.ld = (5 * H + 15) & ~15;
+  const bool persistent = !unfused && aslp_gru_seq_supported(&q, 0) != 0;
+  if (persistent) {  // g and h of row blocks 1..T start as "not yet published", the two boundary blocks as zero
+    buf_.Resize((T + 2) * S, 5 * H, kUndefined);
+    aslp_lstm_seq_fill(buf_.Data(), buf_.Stride(), T, S, 3 * H, 2 * H);
+  } else {
+    buf_.Resize((T + 2) * S, 5 * H, kSetZero);
+  }
   buf_.RowRange(0, S).CopyFromMat(prev_state_);
   {
     aslp_gemm_epilogue ep = aslp_gemm_epilogue();
@@ -823,11 +833,17 @@ void GruStreams::PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) {  // :
     zrm.AddMatMat(1.0, in, kNoTrans, w_zrm_x_, kTrans, 0.0, &ep);
   }
   const int ld = buf_.Stride();
-  static const bool unfused = getenv("ASLP_LSTM_UNFUSED") != nullptr && getenv("ASLP_LSTM_UNFUSED")[0] == '1';
-  const bool fused = !unfused && aslp_gru_step_supported(H);
+  if (persistent) {
+    q.y = buf_.Data(); q.ld = ld;
+    q.w_zr = w_zr_h_.Data(); q.ldw_zr = w_zr_h_.Stride();
+    q.w_m = w_m_g_.Data(); q.ldw_m = w_m_g_.Stride();
+    RegionScope timed("gru_recurrence_fwd");
+    aslp_gru_seq_forward(&q);
+  }
+  const bool fused = !persistent && !unfused && aslp_gru_step_supported(H);
   for (int t = 1; t <= T && fused; t++)
     aslp_gru_step_forward(buf_.RowData(t * S), buf_.RowData((t - 1) * S), w_zr_h_.Data(), w_zr_h_.Stride(), w_m_g_.Data(), w_m_g_.Stride(), ld, S, H);
-  for (int t = 1; t <= T && !fused; t++) {
+  for (int t = 1; t <= T && !fused && !persistent; t++) {
     CuSubMatrix y_zr(buf_, t * S, S, 0, 2 * H), h_prev(buf_, (t - 1) * S, S, 4 * H, H);
     y_zr.AddMatMat(1.0, h_prev, kNoTrans, w_zr_h_, kTrans, 1.0);
     aslp_gru_forward1(buf_.RowData(t * S), buf_.RowData((t - 1) * S), ld, S, H);
@@ -845,22 +861,40 @@ void GruStreams::BackpropagateFnc(const CuMatrixBase &in, const CuMatrixBase &, 
   if (TakeInDiffUnused()) in_diff = nullptr;
   ASLP_ASSERT(nstream_ > 0 && in.NumRows() % nstream_ == 0);
   const int32 T = in.NumRows() / nstream_, S = nstream_;
-  dbuf_.Resize((T + 2) * S, 5 * H, kSetZero);
+  static const bool unfused = getenv("ASLP_LSTM_UNFUSED") != nullptr && getenv("ASLP_LSTM_UNFUSED")[0] == '1';
+  aslp_gru_seq q = aslp_gru_seq();
+  q.T = T; q.S = S; q.H = H; q.ld = buf_.Stride();
+  const bool persistent = !unfused && aslp_gru_seq_supported(&q, 1) != 0;
+  if (persistent) {  // d_z, d_r, d_m of row blocks 1..T start as "not yet published" (the kernel writes d_g, d_h's loss share follows), boundary blocks zero
+    dbuf_.Resize((T + 2) * S, 5 * H, kUndefined);
+    aslp_lstm_seq_fill(dbuf_.Data(), dbuf_.Stride(), T, S, 0, 3 * H);
+  } else {
+    dbuf_.Resize((T + 2) * S, 5 * H, kSetZero);
+  }
   CuSubMatrix(dbuf_, S, T * S, 4 * H, H).CopyFromMat(out_diff);
   const int ld = dbuf_.Stride();
-  static const bool unfused = getenv("ASLP_LSTM_UNFUSED") != nullptr && getenv("ASLP_LSTM_UNFUSED")[0] == '1';
-  const bool fused = !unfused && aslp_gru_step_supported(H);
-  if (fused) {  // the backward products read W (not W^T): keep K-contiguous transposed copies, refreshed here once per call
+  ASLP_ASSERT(ld == buf_.Stride());
+  const bool fused = !persistent && !unfused && aslp_gru_step_supported(H);
+  if (fused || persistent) {  // the backward products read W (not W^T): keep K-contiguous transposed copies, refreshed here once per call
     if (w_zr_h_t_.NumRows() != H) { w_zr_h_t_.Resize(H, 2 * H, kUndefined); w_m_g_t_.Resize(H, H, kUndefined); }
     w_zr_h_t_.SetZero();
     w_zr_h_t_.AddMat(1.0, w_zr_h_, kTrans);
     w_m_g_t_.SetZero();
     w_m_g_t_.AddMat(1.0, w_m_g_, kTrans);
+  }
+  if (persistent) {
+    q.y = buf_.Data(); q.d = dbuf_.Data();
+    q.w_zr = w_zr_h_t_.Data(); q.ldw_zr = w_zr_h_t_.Stride();
+    q.w_m = w_m_g_t_.Data(); q.ldw_m = w_m_g_t_.Stride();
+    RegionScope timed("gru_recurrence_bwd");
+    aslp_gru_seq_backward(&q);
+  }
+  if (fused) {
     for (int t = T; t >= 1; t--)
       aslp_gru_step_backward(dbuf_.RowData(t * S), dbuf_.RowData((t + 1) * S), buf_.RowData(t * S), buf_.RowData((t + 1) * S),
                              buf_.RowData((t - 1) * S), w_zr_h_t_.Data(), w_zr_h_t_.Stride(), w_m_g_t_.Data(), w_m_g_t_.Stride(), ld, S, H, t < T);
   }
-  for (int t = T; t >= 1 && !fused; t--) {
+  for (int t = T; t >= 1 && !fused && !persistent; t--) {
     if (t < T) {
       CuSubMatrix d_h(dbuf_, t * S, S, 4 * H, H), dn_zr(dbuf_, (t + 1) * S, S, 0, 2 * H);
       d_h.AddMatMat(1.0, dn_zr, kNoTrans, w_zr_h_, kNoTrans, 1.0);

@@ -2,6 +2,8 @@
 kernels in csrc/rnn_cells.hip) against oracle/aslp_oracle_rnn.c: Propagate output, input diff and
 updated parameters over several consecutive batches (carried state, momentum, gradient clipping),
 driven through the C ABI of include/aslp_nnet.h on model files in the reference's binary format."""
+import ctypes as C
+
 import numpy as np
 import pytest
 import torch
@@ -176,10 +178,17 @@ def test_lc_blstm_baseline_shape(aslp, oracle, dev, tmp_path):
         assert oracle.rel_err(net.GetParams(), np.concatenate([d.flat() for d in dirs])) < TOL, ("params", step)
 
 
-# (512, 512, 60, 32): BASELINE cfg5's GruStreams swap at full size (H = 512, S = 32 streams, T = 60)
-@pytest.mark.parametrize("dims", [(5, 6, 6, 3), (40, 64, 10, 4), (33, 50, 7, 5), (48, 128, 6, 40), (24, 36, 5, 33), (512, 512, 60, 32)])
+# (512, 512, 60, 32): BASELINE cfg5's GruStreams swap at full size (H = 512, S = 32 streams, T = 60).
+# Three execution paths: the persistent kernels (csrc/rnn_persistent.hip: H % 4 == 0, H <= 512, S <= 64 -- one launch per pass),
+# four fused launches per timestep (csrc/gru_fused.hip: H % 4 == 0 otherwise, here S = 70), GEMM + cell kernels per timestep (the rest).
+@pytest.mark.parametrize("dims", [(5, 6, 6, 3), (40, 64, 10, 4), (33, 50, 7, 5), (48, 128, 6, 40), (24, 36, 5, 33), (512, 512, 60, 32), (16, 64, 4, 70),
+                                  (20, 132, 9, 11)])
 def test_gru_train_steps_match_oracle(aslp, oracle, dev, tmp_path, dims):
     D, H, T, S = dims
+    from kaldi_aslp_amd._lib import GruSeq
+    q = GruSeq(None, None, None, None, 0, 0, (5 * H + 15) & ~15, T, S, H)
+    for backward in (0, 1):   # the shapes meant for the persistent kernels do run on them (not on a silent fallback)
+        assert bool(aslp.lib.aslp_gru_seq_supported(C.byref(q), backward)) == (H % 4 == 0 and H <= 512 and S <= 64), (dims, backward)
     clip, lr, mmt = 0.5, 0.01, 0.9
     rng = np.random.default_rng(2)
     p = oracle.Gru(D, H, rng, scale=0.3 if H < 256 else 0.05)
