@@ -210,6 +210,42 @@ def cfg3_block(aslp, dev):
     return out
 
 
+def recurrent_family_block(aslp, dev):
+    """One recurrent layer (512 in, H / C = 512, S = 32 streams, T = 60 frames) + Affine 512 -> 128 + Softmax + Xent per family member of
+    SURVEY 8(a) rows a8-a10: train-step time through the engine, reported as microseconds per timestep (forward + backward).
+    Extra key `recurrent_layers` (N = 1 only); a few hundredths of a second each."""
+    import torch
+    S, T, A = 32, 60, 128
+    cases = [("GruStreams", "<GruStreams> <InputDim> 512 <OutputDim> 512 <ParamScale> 0.02 <ClipGradient> 5.0", 512),
+             ("LstmProjectedStreams", "<LstmProjectedStreams> <InputDim> 512 <OutputDim> 256 <CellDim> 512 <ParamScale> 0.02 <ClipGradient> 5.0", 256),
+             ("BLstmProjectedStreams", "<BLstmProjectedStreams> <InputDim> 512 <OutputDim> 512 <CellDim> 512 <ParamScale> 0.02 <ClipGradient> 5.0", 512),
+             ("Lstm", "<Lstm> <InputDim> 512 <OutputDim> 512 <ParamScale> 0.01 <ClipGradient> 5.0", 512)]
+    out = {"streams": S, "frames": T, "unit": "us per timestep, forward + backward, one layer"}
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    x = torch.randn(T * S, 512, device=dev, generator=g)
+    lab = torch.randint(0, A, (T * S,), device=dev, generator=g, dtype=torch.int32)
+    for name, line, od in cases:
+        proto = ("<NnetProto>\n%s\n<AffineTransform> <InputDim> %d <OutputDim> %d <BiasMean> 0.0 <BiasRange> 0.0 <ParamStddev> 0.04\n"
+                 "<Softmax> <InputDim> %d <OutputDim> %d\n</NnetProto>\n" % (line, od, A, A, A))
+        net = aslp.Nnet.Init(proto, seed=1)
+        net.SetTrainOptions(learn_rate=1e-5, momentum=0.9)
+        xent = aslp.Xent()
+        net.SetSeqLengths([T] * S)
+        for i in range(5):
+            net.ResetLstmStreams([1] * S if i == 0 else [0] * S)
+            net.TrainStepXent(xent, x, lab)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 40
+        for i in range(n):
+            net.ResetLstmStreams([0] * S)
+            net.TrainStepXent(xent, x, lab)
+        torch.cuda.synchronize()
+        out[name] = (time.perf_counter() - t0) / n * 1e6 / T
+    return out
+
+
 def cfg3_bsp_block(aslp, dev, native_parallel, comm, rank, world, sync_period):
     """N > 1 only (extra key `cfg3_bsp`): every rank trains its own replica of the cfg3 LC-BLSTM (chunked, Xent) on its own synthetic shard and
     the replicas are averaged BSP-style by the native BspWorker every `sync_period` valid frames -- the configuration BASELINE.json's 8-GPU
@@ -484,6 +520,7 @@ def main():
             net = None
             torch.cuda.empty_cache()
             out["cfg3"] = cfg3_block(aslp, dev)
+            out["recurrent_layers"] = recurrent_family_block(aslp, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
     if comm is not None and not args.no_cfg3:   # N > 1 (or ASLP_BENCH_FORCE_SYNC=1): every rank takes part; rank 0 reports

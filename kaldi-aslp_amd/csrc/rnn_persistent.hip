@@ -108,25 +108,6 @@ __device__ __forceinline__ bool spin_ok(unsigned spins, long &t0, const SeqStatu
   return false;
 }
 
-// Hand-off wait, phase 1: polls ONE piece per lane (offS, chosen so that the wave's 64 samples touch every producing
-// workgroup) until none of them reads "not yet published" -- 1 KiB per wave and attempt; a poll that re-reads all operands
-// multiplies the traffic of every waiting workgroup by the number of attempts (measured: 9.4 us per timestep).  Phase 2 is in
-// the kernels: all operand pieces are requested at once and consumed piece by piece, so the products of the first pieces
-// run while the later ones are still in flight; every dword is still checked, and in the rare case a straggler piece is
-// missing the accumulators are dropped and the step's product repeated.  All loads are agent-scope (sc1).
-// Returns false on timeout / device-wide abort (wave-uniform).
-__device__ __forceinline__ bool wait_sample(__amdgpu_buffer_rsrc_t rsrc, int offS, bool validS, const SeqStatus &st, unsigned &polls) {
-  long t0 = 0;
-  for (unsigned spins = 0;; spins++) {
-    const u32x4 smp = __builtin_amdgcn_raw_buffer_load_b128(rsrc, offS, 0, kAuxSc1);
-    if (!__any(validS && has_sentinel(smp))) return true;
-    asm volatile("" ::: "memory");  // the reload stays inside the loop
-    polls++;
-    if (!spin_ok(spins, t0, st)) return false;
-    __builtin_amdgcn_s_sleep(1);
-  }
-}
-
 // C/D layout of v_mfma_f32_16x16x4_f32: element e of lane l is row 4 * (l >> 4) + e, column l & 15
 constexpr int kTP = 17;  // LDS pitch of a 16 x 16 partial tile
 __device__ __forceinline__ void store_tile16(float *tile, const f32x4 &acc, int lane) {

@@ -308,3 +308,36 @@ def test_folded_update_equals_separate_update(aslp, dev):
         a, b = nets[0].GetParams(), nets[1].GetParams()
         assert np.array_equal(a, b), (step, float(np.abs(a - b).max()))
     assert np.abs(nets[0].GetParams() - aslp.Nnet.Init(proto, seed=5).GetParams()).max() > 1e-3  # and they did move
+
+
+def test_gru_persistent_long_sequence_and_reset_pattern(aslp, oracle, dev, tmp_path):
+    """The persistent GRU kernels over a long sequence (T = 300: 600 hand-off rounds per pass, two per timestep) with H = 128,
+    S = 16 (two chains, one of them with idle stream slots none) and a carried state: a missed or stale hand-off piece anywhere
+    in the chain would show up in the last frames.  Also checks that a second call reuses the runtime state cleanly."""
+    D, H, T, S = 24, 128, 300, 16
+    clip, lr, mmt = 0.5, 0.005, 0.9
+    rng = np.random.default_rng(9)
+    p = oracle.Gru(D, H, rng, scale=0.08)
+    g = oracle.Gru(D, H, zero=True)
+    path = tmp_path / "gru.nnet"
+    nnet_io.write_simple_nnet(path, [("<GruStreams>", D, H, nnet_io.gru(p, clip))])
+    net = aslp.Nnet.Read(path)
+    net.SetTrainOptions(learn_rate=lr, momentum=mmt)
+    state = np.zeros((S, 5 * H), np.float32)
+    for step in range(2):
+        x = rng.standard_normal((T * S, D)).astype(np.float32)
+        od = rng.standard_normal((T * S, H)).astype(np.float32) * 0.1
+        net.ResetLstmStreams([1] * S if step == 0 else [0] * S)
+        buf = p.forward(x, T, S, init_state=state)
+        out_ref = p.out_of(buf, T, S)
+        state = buf[T * S:(T + 1) * S].copy()
+        dbuf, idf_ref = p.backward(od, T, S, buf)
+        p.grads(g, x, T, S, buf, dbuf, mmt, clip)
+        p.update(g, lr)
+        out = net.Propagate(torch.from_numpy(x).to(dev)).cpu().numpy()
+        assert oracle.rel_err(out, out_ref) < TOL, ("out", step)
+        assert oracle.rel_err(out[-S:], out_ref[-S:]) < TOL, ("last frame", step)
+        idf = net.Backpropagate(torch.from_numpy(od).to(dev), want_in_diff=True).cpu().numpy()
+        assert oracle.rel_err(idf, idf_ref) < TOL, ("in_diff", step)
+        assert oracle.rel_err(idf[:S], idf_ref[:S]) < 5 * TOL, ("first frame's in_diff", step)
+        assert oracle.rel_err(net.GetParams(), p.flat()) < TOL, ("params", step)
