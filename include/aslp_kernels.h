@@ -316,6 +316,12 @@ typedef struct aslp_lstm_seq_dir_ {
 typedef struct aslp_lstm_seq_ {
   aslp_lstm_seq_dir dir[2];
   int ndir, ld, ldw, T, S, C, cifg;
+  /* backward, optional: the kernel also leaves what the bias and peephole gradients (lc.h:1005-1058) are sums of -- per chain (direction
+   * x group of 8 streams; chain index = group * ndir + direction, at most 8) the sums over its streams and all T timesteps of
+   *   0..3: d_g, d_i, d_f, d_o      4: d_i * c(t-1)      5: d_f * c(t-1)      6: d_o * c(t)        (no d_i rows with cifg)
+   * at grad_partial[(chain * 7 + k) * grad_ld + cell].  aslp_lstm_seq_vec_grads finishes them; NULL: nothing is formed. */
+  float *grad_partial;
+  int grad_ld;
 } aslp_lstm_seq;
 int aslp_lstm_seq_supported(const aslp_lstm_seq *a, int backward);
 /* row blocks 0 and T+1 := 0 (all ld columns); columns [col0, col0 + ncols) of row blocks 1..T := 0xFFFFFFFF words.
@@ -334,6 +340,11 @@ unsigned aslp_lstm_seq_polls(int reset);
 /* diagnostics (devtools/bench_lc.py): phase timing of the forward kernel, see csrc/rnn_persistent.hip */
 void aslp_lstm_seq_timing(int enable, unsigned long long *out);
 void aslp_lstm_seq_backward(const aslp_lstm_seq *a);
+/* After aslp_lstm_seq_backward with grad_partial set: bias / peephole gradients of direction `dir` from the per-chain sums (added in chain
+ * order), then what aslp_rnn_vec_grads does with them: corr = grad + mmt * corr, clipped element-wise to [-clip, clip] if clip > 0, and
+ * param += neg_lr * corr if neg_lr != 0.  bias_corr / bias: [G*C] in the buffer's gate order; peephole vectors [C] (peep_i_* NULL with cifg). */
+void aslp_lstm_seq_vec_grads(const aslp_lstm_seq *a, int dir, float *bias_corr, float *bias, float *peep_i_corr, float *peep_i, float *peep_f_corr,
+                             float *peep_f, float *peep_o_corr, float *peep_o, float mmt, float clip, float neg_lr);
 /* GruStreams, the whole recurrence of T timesteps as ONE launch per pass (csrc/rnn_persistent.hip; the scheme of aslp_lstm_seq_*):
  * y / d: [(T + 2) * S x ld] activations / diffs, row block 0 = the carried history h(0) (forward), row blocks 0 and T + 1 of d zero,
  * columns [z|r|m|g|h], H each.  Before the launch the caller has stored

@@ -413,6 +413,7 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd(aslp_lstm_seq a, SeqStatus s
   const float pf = D.peep_f[cq], po = D.peep_o[cq], pi = CIFG ? 0.f : D.peep_i[cq];
   // own-cell quantities of the step processed just before (BPTT order): all zero ahead of the first step
   float dn_c = 0.f, dn_f = 0.f, dn_i = 0.f;
+  float gsum[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   unsigned polls = 0u;
   for (int step = 0; step < T; step++) {
     // BPTT runs against the direction's recursion: reverse = 0 (t = T..1), reverse = 1 (t = 1..T)
@@ -421,13 +422,14 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd(aslp_lstm_seq a, SeqStatus s
     const int par = step & 1;
     const long o_ = ((long)t * S + sq) * ld;
     long tm = tick(st);
-    float dm = 0.f, yo = 0.f, yh = 0.f, yg = 0.f, yf = 0.f, yi = 0.f, yn_f = 0.f, cprev = 0.f;
+    float dm = 0.f, yo = 0.f, yh = 0.f, yg = 0.f, yf = 0.f, yi = 0.f, yn_f = 0.f, cprev = 0.f, ccur = 0.f;
     if (live) {  // everything that does not depend on the other workgroups, requested first
       dm = D.d[o_ + om + cq];
       yo = D.y[o_ + oo + cq]; yh = D.y[o_ + oh + cq]; yg = D.y[o_ + og + cq]; yf = D.y[o_ + of + cq];
       if (!CIFG) yi = D.y[o_ + oi + cq];
       yn_f = D.y[((long)tn * S + sq) * ld + of + cq];
       cprev = D.y[((long)tp * S + sq) * ld + oc + cq];
+      if (a.grad_partial) ccur = D.y[o_ + oc + cq];
     }
     bool ok = true;
     if (step > 0) {
@@ -542,9 +544,29 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd(aslp_lstm_seq a, SeqStatus s
         D.d[o_ + oc + cell] = dc;
       }
       dn_c = dc; dn_f = df; dn_i = di;
+      if (a.grad_partial && live) {   // what the bias and peephole gradients are sums of (lc.h:1005-1058), this pair's share
+        gsum[0] += dg; gsum[2] += df; gsum[3] += dov;
+        gsum[5] += df * cprev; gsum[6] += dov * ccur;
+        if (!CIFG) { gsum[1] += di; gsum[4] += di * cprev; }
+      }
     }
     tock(st, 5, tm);
     __syncthreads();  // own_dg[par] complete before anybody multiplies with it; shares[] free for the next collection
+  }
+  if (a.grad_partial) {   // the chain's 8 streams meet in LDS (stream order), one row of 16 cells per quantity goes out per workgroup
+    float *gl = shares;   // [stream 8][quantity 7][cell 16]: free after the loop's last barrier
+    if (threadIdx.x < 128) {
+#pragma unroll
+      for (int k = 0; k < 7; k++) gl[(sl * 7 + k) * 16 + cc] = gsum[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 7 * 16) {
+      const int k = threadIdx.x >> 4, c = threadIdx.x & 15;
+      float v = gl[k * 16 + c];
+#pragma unroll
+      for (int q = 1; q < kChainStreams; q++) v += gl[(q * 7 + k) * 16 + c];
+      if (c0 + c < C) a.grad_partial[((long)chain * 7 + k) * a.grad_ld + c0 + c] = v;
+    }
   }
   if (st.timing && blockIdx.x == 0 && threadIdx.x == 0) { st.timing[0] += (unsigned long long)T; st.timing[6] += R.local ? 1ull : 0ull; }
   if (st.trace && threadIdx.x == 0) {   // ring of the 8 latest launches
@@ -847,6 +869,26 @@ __global__ void __launch_bounds__(512) gru_seq_bwd(aslp_gru_seq a, SeqStatus st,
   if (polls && g.lane == 0) __hip_atomic_fetch_add(st.abort_flag + 2, polls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Finishes the bias / peephole gradients of one direction from the per-chain sums lstm_seq_bwd left (grad_partial): thread = (quantity k,
+// cell c); chains of the direction added in order; then momentum, clip and the folded SGD step as rnn_vec_grads_kernel does them.
+struct SeqVecGradArgs {
+  const float *partial; int ld, ndir, dir, nsg, C, cifg;
+  float *corr[7], *param[7];   // per quantity: where its [C] slice lives (bias rows are slices of bias_corr / bias)
+  float mmt, clip, neg_lr;
+};
+__global__ void __launch_bounds__(256) lstm_seq_vec_grads_kernel(SeqVecGradArgs g) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= 7 * g.C) return;
+  const int k = idx / g.C, c = idx - k * g.C;
+  if (g.corr[k] == nullptr) return;
+  float v = 0.f;
+  for (int sg = 0; sg < g.nsg; sg++) v += g.partial[((long)(sg * g.ndir + g.dir) * 7 + k) * g.ld + c];
+  if (g.mmt != 0.0f) v += g.mmt * g.corr[k][c];
+  if (g.clip > 0.0f) v = v < -g.clip ? -g.clip : (v > g.clip ? g.clip : v);
+  g.corr[k][c] = v;
+  if (g.neg_lr != 0.0f) g.param[k][c] += g.neg_lr * v;
+}
+
 // Prepares an activation buffer for the forward kernel: boundary row blocks 0 and T + 1 := 0 (all columns), columns
 // [col0, col0 + ncols) of row blocks 1..T := "not yet published".  One launch instead of three memsets over the whole buffer.
 // blockIdx.y picks the buffer (both directions of a layer in one launch); `init` (S rows of `ld_init` floats, may be NULL) is
@@ -1081,6 +1123,29 @@ unsigned aslp_lstm_seq_polls(int reset) {
   (void)hipMemcpy(&v, rt.abort_flag + 2, 4, hipMemcpyDeviceToHost);
   if (reset) (void)hipMemset(rt.abort_flag + 2, 0, 4);
   return v;
+}
+void aslp_lstm_seq_vec_grads(const aslp_lstm_seq *a, int dir, float *bias_corr, float *bias, float *peep_i_corr, float *peep_i, float *peep_f_corr,
+                             float *peep_f, float *peep_o_corr, float *peep_o, float mmt, float clip, float neg_lr) {
+  if (!seq_args_ok(a) || !a->grad_partial || a->grad_ld < a->C || dir < 0 || dir >= a->ndir || !bias_corr || !bias || !peep_f_corr || !peep_f ||
+      !peep_o_corr || !peep_o || (!a->cifg && (!peep_i_corr || !peep_i))) {
+    set_error("aslp_lstm_seq_vec_grads: bad arguments");
+    return;
+  }
+  SeqVecGradArgs g;
+  g.partial = a->grad_partial; g.ld = a->grad_ld; g.ndir = a->ndir; g.dir = dir; g.nsg = (a->S + kChainStreams - 1) / kChainStreams;
+  g.C = a->C; g.cifg = a->cifg; g.mmt = mmt; g.clip = clip; g.neg_lr = neg_lr;
+  const int C = a->C;
+  // gate order of the buffer: g, i, f, o (cifg: g, f, o)
+  const int off_g = 0, off_i = C, off_f = a->cifg ? C : 2 * C, off_o = a->cifg ? 2 * C : 3 * C;
+  g.corr[0] = bias_corr + off_g; g.param[0] = bias + off_g;
+  g.corr[1] = a->cifg ? nullptr : bias_corr + off_i; g.param[1] = a->cifg ? nullptr : bias + off_i;
+  g.corr[2] = bias_corr + off_f; g.param[2] = bias + off_f;
+  g.corr[3] = bias_corr + off_o; g.param[3] = bias + off_o;
+  g.corr[4] = a->cifg ? nullptr : peep_i_corr; g.param[4] = a->cifg ? nullptr : peep_i;
+  g.corr[5] = peep_f_corr; g.param[5] = peep_f;
+  g.corr[6] = peep_o_corr; g.param[6] = peep_o;
+  hipLaunchKernelGGL(lstm_seq_vec_grads_kernel, dim3((7 * C + 255) / 256), dim3(256), 0, cur_stream(), g);
+  check_launch("aslp_lstm_seq_vec_grads");
 }
 void aslp_lstm_seq_forward(const aslp_lstm_seq *a) { launch_seq(a, false, "aslp_lstm_seq_forward"); }
 void aslp_lstm_seq_backward(const aslp_lstm_seq *a) { launch_seq(a, true, "aslp_lstm_seq_backward"); }

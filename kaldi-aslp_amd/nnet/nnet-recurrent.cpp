@@ -164,7 +164,22 @@ void LstmDir::Backward(const CuMatrixBase &out_diff, int T, int S, bool reverse,
   }
 }
 
-void LstmDir::Grads(const CuMatrixBase &in, int T, int S, bool reverse, const CuMatrix &buf, const CuMatrix &dbuf, float mmt, float clip, float lr_fold) {
+void LstmDir::VecGrads(int T, int S, bool reverse, const CuMatrix &buf, const CuMatrix &dbuf, float mmt, float clip, float lr_fold,
+                       const aslp_lstm_seq *seq, int dir) {
+  // bias and peephole gradients (:1005-1058): column sums of d_gates and of d_{i,f,o} .* c.  The persistent backward kernel has the
+  // addends in registers and leaves per-chain sums (one small launch finishes them); otherwise one pass over the diff buffer.
+  if (seq != nullptr && seq->grad_partial != nullptr) {
+    aslp_lstm_seq_vec_grads(seq, dir, bias_corr.Data(), bias.Data(), cifg ? nullptr : peep_i_corr.Data(), cifg ? nullptr : peep_i.Data(),
+                            peep_f_corr.Data(), peep_f.Data(), peep_o_corr.Data(), peep_o.Data(), mmt, clip, -lr_fold);
+  } else {
+    aslp_rnn_vec_grad jobs[4];
+    const int n = VecGradJobs(S, reverse, buf, dbuf, jobs);
+    aslp_rnn_vec_grads(jobs, n, dbuf.Stride(), T * S, mmt, clip, -lr_fold);
+  }
+}
+
+void LstmDir::Grads(const CuMatrixBase &in, int T, int S, bool reverse, const CuMatrix &buf, const CuMatrix &dbuf, float mmt, float clip, float lr_fold,
+                    const aslp_lstm_seq *seq, int dir) {
   // lc.h:976-1058: corr = grad + mmt * corr, then clip element-wise (the clip rides in the GEMM epilogue, and with it --
   // when the executor announced that Update follows -- the step W += -lr * corr of lc.h:1085-1110)
   const int prev0 = (reverse ? 2 : 0) * S;  // recursion-previous row block of t = 1
@@ -178,10 +193,7 @@ void LstmDir::Grads(const CuMatrixBase &in, int T, int S, bool reverse, const Cu
   wgrad(w_x_corr, w_x, d_gates, in);
   wgrad(w_r_corr, w_r, d_gates, CuSubMatrix(buf, prev0, T * S, OffRec(), Rec()));
   if (R > 0) wgrad(w_rm_corr, w_rm, CuSubMatrix(dbuf, S, T * S, OffRec(), R), CuSubMatrix(buf, S, T * S, OffM(), C));
-  // bias and peephole gradients (:1005-1058), one launch: column sums of d_gates and of d_{i,f,o} .* c
-  aslp_rnn_vec_grad jobs[4];
-  const int n = VecGradJobs(S, reverse, buf, dbuf, jobs);
-  aslp_rnn_vec_grads(jobs, n, dbuf.Stride(), T * S, mmt, clip, -lr_fold);
+  VecGrads(T, S, reverse, buf, dbuf, mmt, clip, lr_fold, seq, dir);
   CheckK();
   if (lr_fold != 0.0f) eff_dirty = true;
 }
@@ -407,10 +419,10 @@ void LstmDir::BackwardFinishPair(const LstmDir &f, const LstmDir &b, const CuMat
 }
 
 void LstmDir::GradsPair(LstmDir &f, LstmDir &b, const CuMatrixBase &in, int T, int S, const CuMatrix &fbuf, const CuMatrix &bbuf,
-                        const CuMatrix &fdbuf, const CuMatrix &bdbuf, float mmt, float clip, float lr_fold) {
+                        const CuMatrix &fdbuf, const CuMatrix &bdbuf, float mmt, float clip, float lr_fold, const aslp_lstm_seq *seq) {
   if (!SameShape(f, b)) {
-    f.Grads(in, T, S, false, fbuf, fdbuf, mmt, clip, lr_fold);
-    b.Grads(in, T, S, true, bbuf, bdbuf, mmt, clip, lr_fold);
+    f.Grads(in, T, S, false, fbuf, fdbuf, mmt, clip, lr_fold, seq, 0);
+    b.Grads(in, T, S, true, bbuf, bdbuf, mmt, clip, lr_fold, seq, 1);
     return;
   }
   // lc.h:976-1058, as in Grads(): corr = grad + mmt * corr, clipped, and (folded) W += -lr * corr
@@ -431,12 +443,16 @@ void LstmDir::GradsPair(LstmDir &f, LstmDir &b, const CuMatrixBase &in, int T, i
   if (f.R > 0)
     wgrad(f.w_rm_corr, b.w_rm_corr, f.w_rm, b.w_rm, CuSubMatrix(fdbuf, S, T * S, f.OffRec(), f.R), CuSubMatrix(bdbuf, S, T * S, b.OffRec(), b.R),
           CuSubMatrix(fbuf, S, T * S, f.OffM(), f.C), CuSubMatrix(bbuf, S, T * S, b.OffM(), b.C));
-  // bias and peephole gradients of both directions: one launch
-  aslp_rnn_vec_grad jobs[8];
-  int n = f.VecGradJobs(S, false, fbuf, fdbuf, jobs);
-  n += b.VecGradJobs(S, true, bbuf, bdbuf, jobs + n);
-  ASLP_ASSERT(fdbuf.Stride() == bdbuf.Stride());
-  aslp_rnn_vec_grads(jobs, n, fdbuf.Stride(), T * S, mmt, clip, -lr_fold);
+  if (seq != nullptr && seq->grad_partial != nullptr) {   // the persistent backward launch left the sums: two small finishing launches
+    f.VecGrads(T, S, false, fbuf, fdbuf, mmt, clip, lr_fold, seq, 0);
+    b.VecGrads(T, S, true, bbuf, bdbuf, mmt, clip, lr_fold, seq, 1);
+  } else {   // bias and peephole gradients of both directions: one launch over the two diff buffers
+    aslp_rnn_vec_grad jobs[8];
+    int n = f.VecGradJobs(S, false, fbuf, fdbuf, jobs);
+    n += b.VecGradJobs(S, true, bbuf, bdbuf, jobs + n);
+    ASLP_ASSERT(fdbuf.Stride() == bdbuf.Stride());
+    aslp_rnn_vec_grads(jobs, n, fdbuf.Stride(), T * S, mmt, clip, -lr_fold);
+  }
   CheckK();
   if (lr_fold != 0.0f) f.eff_dirty = b.eff_dirty = true;
 }
@@ -646,6 +662,12 @@ void LstmFamily::BackpropagateFnc(const CuMatrixBase &in, const CuMatrixBase &, 
     ASLP_ASSERT(f_dbuf_.Stride() == f_buf_.Stride());
     if (persistent) {
       q.ld = f_dbuf_.Stride(); q.ldw = f_.Weff().Stride();
+      static const bool vec_fused_off = getenv("ASLP_LSTM_VEC_FUSED") != nullptr && getenv("ASLP_LSTM_VEC_FUSED")[0] == '0';   // A/B switch
+      if (!vec_fused_off) {   // the kernel also leaves the sums the bias / peephole gradients are made of (8 chains x 7 quantities x C)
+        if (grad_partial_.NumRows() != 8 * 7 || grad_partial_.NumCols() != ncell_) grad_partial_.Resize(8 * 7, ncell_, kUndefined);
+        q.grad_partial = grad_partial_.Data();
+        q.grad_ld = grad_partial_.Stride();
+      }
       for (int d = 0; d < q.ndir; d++) {
         const LstmDir &p = d == 0 ? f_ : b_;
         q.dir[d].y = (d == 0 ? f_buf_ : b_buf_).Data();
@@ -658,6 +680,7 @@ void LstmFamily::BackpropagateFnc(const CuMatrixBase &in, const CuMatrixBase &, 
       }
       RegionScope timed("lstm_recurrence_bwd");
       aslp_lstm_seq_backward(&q);
+      if (q.grad_partial) { vec_seq_ = q; vec_seq_valid_ = true; }
     } else {
       aslp_lstm_step a = aslp_lstm_step();
       a.ndir = cfg_.bidir ? 2 : 1; a.ld = f_dbuf_.Stride(); a.S = S; a.C = ncell_; a.cifg = cfg_.cifg ? 1 : 0;
@@ -695,10 +718,12 @@ void LstmFamily::BackpropagateFnc(const CuMatrixBase &in, const CuMatrixBase &, 
     if (cfg_.bidir) b_.Backward(CuSubMatrix(out_diff, 0, T * S, rec, rec), T, S, true, b_buf_, &b_dbuf_, in_diff, 1.0);
   }
   const BaseFloat lr_fold = TakeFoldHint() ? opts_.learn_rate : 0.0f;
-  if (cfg_.bidir && f_.FusedOk()) LstmDir::GradsPair(f_, b_, in, T, S, f_buf_, b_buf_, f_dbuf_, b_dbuf_, mmt, clip_gradient_, lr_fold);
+  const aslp_lstm_seq *seq = vec_seq_valid_ ? &vec_seq_ : nullptr;
+  vec_seq_valid_ = false;
+  if (cfg_.bidir && f_.FusedOk()) LstmDir::GradsPair(f_, b_, in, T, S, f_buf_, b_buf_, f_dbuf_, b_dbuf_, mmt, clip_gradient_, lr_fold, seq);
   else {
-    f_.Grads(in, T, S, false, f_buf_, f_dbuf_, mmt, clip_gradient_, lr_fold);
-    if (cfg_.bidir) b_.Grads(in, T, S, true, b_buf_, b_dbuf_, mmt, clip_gradient_, lr_fold);
+    f_.Grads(in, T, S, false, f_buf_, f_dbuf_, mmt, clip_gradient_, lr_fold, seq, 0);
+    if (cfg_.bidir) b_.Grads(in, T, S, true, b_buf_, b_dbuf_, mmt, clip_gradient_, lr_fold, seq, 1);
   }
 }
 

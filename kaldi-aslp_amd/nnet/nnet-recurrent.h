@@ -85,7 +85,10 @@ struct LstmDir {
   void Backward(const CuMatrixBase &out_diff, int T, int S, bool reverse, const CuMatrix &buf, CuMatrix *dbuf, CuMatrixBase *in_diff,
                 float beta) const;
   // lr_fold != 0: the step param += -lr_fold * corr is taken in the epilogues of the gradient kernels
-  void Grads(const CuMatrixBase &in, int T, int S, bool reverse, const CuMatrix &buf, const CuMatrix &dbuf, float mmt, float clip, float lr_fold);
+  // seq (may be NULL): the persistent backward launch that already left this direction's (index dir) bias / peephole sums
+  void Grads(const CuMatrixBase &in, int T, int S, bool reverse, const CuMatrix &buf, const CuMatrix &dbuf, float mmt, float clip, float lr_fold,
+             const aslp_lstm_seq *seq = nullptr, int dir = 0);
+  void VecGrads(int T, int S, bool reverse, const CuMatrix &buf, const CuMatrix &dbuf, float mmt, float clip, float lr_fold, const aslp_lstm_seq *seq, int dir);
   void Update(float lr);
   int VecGradJobs(int S, bool reverse, const CuMatrix &buf, const CuMatrix &dbuf, aslp_rnn_vec_grad *jobs);  // bias + peephole gradient jobs (<= 4)
 
@@ -105,7 +108,7 @@ struct LstmDir {
   static void BackwardFinishPair(const LstmDir &f, const LstmDir &b, const CuMatrixBase &od_f, const CuMatrixBase &od_b, int T, int S,
                                  CuMatrix *fdbuf, CuMatrix *bdbuf, CuMatrixBase *in_diff);
   static void GradsPair(LstmDir &f, LstmDir &b, const CuMatrixBase &in, int T, int S, const CuMatrix &fbuf, const CuMatrix &bbuf,
-                        const CuMatrix &fdbuf, const CuMatrix &bdbuf, float mmt, float clip, float lr_fold);
+                        const CuMatrix &fdbuf, const CuMatrix &bdbuf, float mmt, float clip, float lr_fold, const aslp_lstm_seq *seq = nullptr);
   const CuMatrixBase &Weff() const { return R > 0 ? static_cast<const CuMatrixBase &>(w_eff) : w_r; }
   void ForwardPrepare(const CuMatrixBase &in, int T, int S, bool reverse, const CuMatrixBase *init_state, CuMatrix *buf, bool persistent,
                       bool with_gemm = true) const;
@@ -159,6 +162,9 @@ class LstmFamily : public RecurrentBase {
   std::vector<int32> sequence_lengths_; // BLstm* masking
   CuArray<int32> seq_len_dev_;
   CuMatrix f_buf_, b_buf_, f_dbuf_, b_dbuf_;
+  CuMatrix grad_partial_;          // per-chain bias / peephole gradient sums of the persistent backward launch (aslp_lstm_seq.grad_partial)
+  aslp_lstm_seq vec_seq_ = aslp_lstm_seq();   // that launch's arguments, for aslp_lstm_seq_vec_grads
+  bool vec_seq_valid_ = false;
 };
 
 #define ASLP_LSTM_CLASS(Name, Type, ...)                                                   \
