@@ -152,6 +152,10 @@ typedef struct aslp_gemm_epilogue_ {
    * Always filled on return (by the GEMM kernel's epilogue where it can, by one extra pass over C otherwise). */
   double *colstats;    /* [3 * groups * colstats_ld] or NULL */
   int colstats_ld;     /* >= N */
+  /* the beta term read from another matrix: C = alpha op(A) op(B) + beta * c_src (+ ...) instead of + beta * C.  E.g. the LSTM's
+   * d_r = out_diff + dGATES(next) W_r (lc.h:791) without first copying out_diff into d_r.  NULL: the classic form. */
+  const float *c_src;  /* [M x N], leading dimension ld_c_src, or NULL */
+  int ld_c_src;
 } aslp_gemm_epilogue;
 int aslp_sgemm_ex(int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda,
                   const float *B, int ldb, float beta, float *C, int ldc, const aslp_gemm_epilogue *ep);

@@ -23,7 +23,7 @@ class GemmEpilogue(C.Structure):
     _fields_ = [("bias", C.c_void_p), ("clip", C.c_float), ("W", C.c_void_p), ("ldw", C.c_int),
                 ("w_alpha", C.c_float), ("act_out", C.c_void_p), ("ld_act", C.c_int), ("act", C.c_int),
                 ("colsum", C.c_void_p), ("colsum_beta", C.c_float), ("colsum_w", C.c_void_p), ("colsum_w_alpha", C.c_float),
-                ("colstats", C.c_void_p), ("colstats_ld", C.c_int)]
+                ("colstats", C.c_void_p), ("colstats_ld", C.c_int), ("c_src", C.c_void_p), ("ld_c_src", C.c_int)]
 
 
 class GruSeq(C.Structure):

@@ -536,7 +536,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_f32_mfma(GemmArgs g) {
         if (row >= g.M) continue;
         float *cp = g.C + (long)row * g.ldc + col;
         // the arithmetic of gemm_epilogue_store4 (gemm_common.h), spelled the same way
-        float v = (ep.W != nullptr || g.beta != 0.0f) ? fmaf(g.alpha, acc[i][n][e], fmaf(g.beta, g.beta != 0.0f ? *cp : 0.0f, bias)) : fmaf(g.alpha, acc[i][n][e], bias);
+        float v = (ep.W != nullptr || g.beta != 0.0f) ? fmaf(g.alpha, acc[i][n][e], fmaf(g.beta, g.beta != 0.0f ? (ep.c_src ? ep.c_src[(long)row * ep.ld_c_src + col] : *cp) : 0.0f, bias)) : fmaf(g.alpha, acc[i][n][e], bias);
         if (ep.clip > 0.0f) v = fminf(fmaxf(v, -ep.clip), ep.clip);
         *cp = v;
         if (ep.W) ep.W[(long)row * ep.ldw + col] = fmaf(ep.w_alpha, v, ep.W[(long)row * ep.ldw + col]);
@@ -741,6 +741,7 @@ int aslp_sgemm_ex(int transA, int transB, int M, int N, int K, float alpha, cons
   if (ep) g.ep = *ep; else g.ep = aslp_gemm_epilogue();  // zero-initialised: every optional piece off
   if (g.ep.colsum && !transA) return -5;  // column sums are defined for transposed A only
   if (g.ep.colstats && (beta != 0.0f || g.ep.W || g.ep.colstats_ld < N)) return -6;  // statistics of a plain forward product only
+  if (g.ep.c_src && g.ep.ld_c_src < N) return -7;
   g.a_vec = aligned16(A) && lda % 4 == 0;
   g.b_vec = aligned16(B) && ldb % 4 == 0;
   // report order: 0 = NT, 1 = NN, 2 = TN, 3 = TT

@@ -88,7 +88,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, const f32x16 (&
         for (int e = 0; e < 16; e++) {
           const int row = row0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
           const bool ok = row < g.M;
-          c_old[e] = (ok && g.beta != 0.0f) ? g.C[(long)row * g.ldc + col] : 0.0f;
+          c_old[e] = (ok && g.beta != 0.0f) ? (ep.c_src ? ep.c_src[(long)row * ep.ld_c_src + col] : g.C[(long)row * g.ldc + col]) : 0.0f;
           w_old[e] = (ok && ep.W) ? ep.W[(long)row * ep.ldw + col] : 0.0f;
         }
 #pragma unroll
@@ -172,6 +172,7 @@ __device__ __forceinline__ bool gemm_epilogue_wide_ok(const GemmArgs &g) {
   const aslp_gemm_epilogue &ep = g.ep;
   auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
   return (g.N & 3) == 0 && (g.ldc & 3) == 0 && al(g.C) && (!ep.bias || al(ep.bias)) && (!ep.W || ((ep.ldw & 3) == 0 && al(ep.W))) &&
+         (!ep.c_src || ((ep.ld_c_src & 3) == 0 && al(ep.c_src))) &&
          (!ep.act_out || ((ep.ld_act & 3) == 0 && al(ep.act_out)));
 }
 // one lane's 4 consecutive outputs of row `row` (columns col .. col+3): the arithmetic and the stores of the epilogue
@@ -226,7 +227,8 @@ __device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs &g, const f32x
         const int r = rr + 8 * j, row = row0 + i * 32 + r;
         const bool ok = colok && row < g.M;
         v[j] = *reinterpret_cast<const float4 *>(tile + r * kEpiPitch + 4 * c4);
-        c_old[j] = (ok && g.beta != 0.0f) ? *reinterpret_cast<const float4 *>(g.C + (long)row * g.ldc + col) : zero;
+        c_old[j] = (ok && g.beta != 0.0f) ? (ep.c_src ? *reinterpret_cast<const float4 *>(ep.c_src + (long)row * ep.ld_c_src + col)
+                                                       : *reinterpret_cast<const float4 *>(g.C + (long)row * g.ldc + col)) : zero;
         w_old[j] = (ok && ep.W) ? *reinterpret_cast<const float4 *>(ep.W + (long)row * ep.ldw + col) : zero;
       }
 #pragma unroll

@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(kBlock) splitk_reduce_kernel(const float *__re
     float acc = part[i];
     for (int s = 1; s < split; s++) acc += part[i + s * stride];
     float *cp = g.C + (long)row * g.ldc + col;
-    const float c_old = g.beta != 0.0f ? *cp : 0.0f;
+    const float c_old = g.beta != 0.0f ? (g.ep.c_src ? g.ep.c_src[(long)row * g.ep.ld_c_src + col] : *cp) : 0.0f;
     const float w_old = g.ep.W ? g.ep.W[(long)row * g.ep.ldw + col] : 0.0f;
     float v = fmaf(g.alpha, acc, g.beta * c_old);  // = fmaf(alpha, acc, fmaf(beta, c_old, 0)): the epilogue's spelling (gemm_common.h)
     if (g.ep.clip > 0.0f) v = fminf(fmaxf(v, -g.ep.clip), g.ep.clip);

@@ -396,11 +396,13 @@ void LstmDir::BackwardFinishPair(const LstmDir &f, const LstmDir &b, const CuMat
     return;
   }
   // d_r(t) = out_diff(t) + dGATES(next) W_r (lc.h:791), needed by the W_rm gradient
+  // (out_diff enters as the epilogue's beta term read from its own matrix: no copy into d_r first)
   CuSubMatrix dr_f(*fdbuf, S, T * S, f.OffRec(), f.R), dr_b(*bdbuf, S, T * S, b.OffRec(), b.R);
-  dr_f.CopyFromMat(od_f);
-  dr_b.CopyFromMat(od_b);
   CuSubMatrix next_f(*fdbuf, 2 * S, T * S, 0, f.GC()), next_b(*bdbuf, 0, T * S, 0, b.GC());  // row blocks of each step's recursion-next
-  AddMatMatPair(dr_f, dr_b, 1.0, next_f, next_b, kNoTrans, f.w_r, b.w_r, kNoTrans, 1.0);
+  aslp_gemm_epilogue ep_f = aslp_gemm_epilogue(), ep_b = aslp_gemm_epilogue();
+  ep_f.c_src = od_f.Data(); ep_f.ld_c_src = od_f.Stride();
+  ep_b.c_src = od_b.Data(); ep_b.ld_c_src = od_b.Stride();
+  AddMatMatPair(dr_f, dr_b, 1.0, next_f, next_b, kNoTrans, f.w_r, b.w_r, kNoTrans, 1.0, &ep_f, &ep_b);
   if (!in_diff) return;
   // in_diff = dGATES_f W_x,f + dGATES_b W_x,b.  Two products into one output cannot share a launch; as a pair into (in_diff, scratch)
   // followed by one addition they can, and the [T*S x D] output alone does not fill the chip (240 tiles for D = 512).  The sum is

@@ -528,3 +528,28 @@ def test_gemm_column_statistics_feed_batchnorm(aslp, dev, M, N, K, force):
         outs.append((out, act, mean, inv, accm, accv))
     for a, r in zip(outs[0], outs[1]):
         assert torch.allclose(a, r, rtol=2e-6, atol=1e-6), (a - r).abs().max()
+
+
+@pytest.mark.parametrize("tA,tB,M,N,K,force", [(0, 0, 1920, 256, 2048, 0), (0, 1, 100, 72, 64, 0), (1, 0, 256, 512, 1920, 0), (0, 0, 130, 44, 36, 0), (0, 1, 512, 256, 128, 7)])
+def test_sgemm_beta_term_from_another_matrix(aslp, dev, tA, tB, M, N, K, force):
+    """aslp_gemm_epilogue.c_src: C = alpha op(A) op(B) + beta * c_src (the LSTM's d_r = out_diff + dGATES(next) W_r without the copy of
+    out_diff into d_r first).  Same bits as copying c_src into C and running the classic form; LDS-DMA kernels (with and without a K
+    split), the unaligned fallback and a forced register-staged tile."""
+    from kaldi_aslp_amd._lib import GemmEpilogue
+    g = torch.Generator(device=dev).manual_seed(M + N * 3 + K)
+    A = torch.randn((K, M) if tA else (M, K), device=dev, generator=g)
+    B = torch.randn((N, K) if tB else (K, N), device=dev, generator=g)
+    wide = torch.randn(M, 2 * N + 4, device=dev, generator=g)
+    src = wide[:, N + 4:]            # a column block of a wider matrix, like out_diff's backward-direction half
+    want = src.clone()
+    got = torch.full((M, N), float("nan"), device=dev)
+    ep = GemmEpilogue(None, 0.0, None, 0, 0.0, None, 0, 0, None, 0.0, None, 0.0, None, 0, src.data_ptr(), wide.stride(0))
+    aslp.lib.aslp_gemm_force_tile(force)
+    try:
+        aslp.ops.sgemm(tA, tB, 0.5, A, B, 0.75, got, ep)
+        aslp.ops.sgemm(tA, tB, 0.5, A, B, 0.75, want)
+    finally:
+        aslp.lib.aslp_gemm_force_tile(0)
+    assert torch.equal(got, want)
+    ref = 0.5 * ((A.t() if tA else A).double() @ (B.t() if tB else B).double()) + 0.75 * src.double()
+    assert ((got.double() - ref).norm() / ref.norm()).item() < 2e-6
