@@ -97,3 +97,17 @@ def test_dnn_with_batchnorm_gradients_match_finite_differences(aslp, dev, rows, 
     x = torch.randn(rows, 12, device=dev, generator=g)
     R = torch.randn(rows, 9, device=dev, generator=g).double()
     check(aslp, dev, net, x, R, lambda: None, eps=5e-3)
+
+
+def test_compact_fsmn_gradients_match_finite_differences(aslp, dev):
+    proto = """<NnetProto>
+<AffineTransform> <InputDim> 6 <OutputDim> 12 <BiasMean> 0.0 <BiasRange> 0.5 <ParamStddev> 0.4
+<CompactFsmn> <InputDim> 12 <OutputDim> 12 <PastContext> 3 <FutureContext> 2
+<AffineTransform> <InputDim> 12 <OutputDim> 5 <BiasMean> 0.0 <BiasRange> 0.5 <ParamStddev> 0.4
+</NnetProto>
+"""
+    net = aslp.Nnet.Init(proto, seed=7)
+    g = torch.Generator(device=dev).manual_seed(3)
+    x = torch.randn(40, 6, device=dev, generator=g)
+    R = torch.randn(40, 5, device=dev, generator=g).double()
+    check(aslp, dev, net, x, R, lambda: None, eps=5e-3)
