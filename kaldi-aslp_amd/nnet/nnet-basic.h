@@ -129,6 +129,7 @@ class AffineTransform : public UpdatableComponent {
     return o.str();
   }
 
+  double ParamSum() const { return linearity_.Sum() + (double)bias_.Sum(); }   // on the device
   void PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) {
     // :186-191  out = bias (beta 0); out += in * W^T.  One GEMM with the bias in the epilogue.
     aslp_gemm_epilogue ep = aslp_gemm_epilogue();

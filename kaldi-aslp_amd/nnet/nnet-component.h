@@ -159,6 +159,15 @@ class UpdatableComponent : public Component {
   bool IsUpdatable() const { return true; }
   virtual int32 NumParams() const = 0;
   virtual void GetParams(std::vector<BaseFloat> *params) const = 0;
+  // Sum of all parameters, for Nnet::Check()'s inf / nan test (nnet-nnet.cc:812-818 sums a host copy of every weight: 108 MB through
+  // pageable memory for cfg2, 0.1 s inside the training tool's timer).  Components whose tensors are large add them up on the device.
+  virtual double ParamSum() const {
+    std::vector<BaseFloat> w;
+    GetParams(&w);
+    double s = 0.0;
+    for (BaseFloat v : w) s += v;
+    return s;
+  }
   // (device pointer, number of floats incl. row padding) per tensor, in the reference's order
   virtual void GetGpuParams(std::vector<std::pair<BaseFloat *, int>> *params) = 0;
   virtual void Update(const CuMatrixBase &input, const CuMatrixBase &diff) = 0;

@@ -615,10 +615,9 @@ void Nnet::Check() const {  // :776-819
                  << out_dim << " " << "Component " << i << " inputdim";
     }
   }
-  std::vector<BaseFloat> weights;
-  GetParams(&weights);
   double sum = 0.0;
-  for (BaseFloat w : weights) sum += w;
+  for (int i = 0; i < NumComponents(); i++)
+    if (components_[i]->IsUpdatable()) sum += dynamic_cast<const UpdatableComponent *>(components_[i])->ParamSum();
   if (std::isinf(sum)) ASLP_ERR << "'inf' in network parameters (weight explosion, try lower learning rate?)";
   if (std::isnan(sum)) ASLP_ERR << "'nan' in network parameters (try lower learning rate?)";
 }

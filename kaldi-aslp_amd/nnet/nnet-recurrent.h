@@ -90,7 +90,13 @@ struct LstmDir {
              const aslp_lstm_seq *seq = nullptr, int dir = 0);
   void VecGrads(int T, int S, bool reverse, const CuMatrix &buf, const CuMatrix &dbuf, float mmt, float clip, float lr_fold, const aslp_lstm_seq *seq, int dir);
   void Update(float lr);
-  int VecGradJobs(int S, bool reverse, const CuMatrix &buf, const CuMatrix &dbuf, aslp_rnn_vec_grad *jobs);  // bias + peephole gradient jobs (<= 4)
+  int VecGradJobs(int S, bool reverse, const CuMatrix &buf, const CuMatrix &dbuf, aslp_rnn_vec_grad *jobs);
+  double ParamSum() const {   // on the device (Nnet::Check)
+    double s = w_x.Sum() + w_r.Sum() + (double)bias.Sum() + (double)peep_f.Sum() + (double)peep_o.Sum();
+    if (!cifg) s += (double)peep_i.Sum();
+    if (R > 0) s += w_rm.Sum();
+    return s;
+  }  // bias + peephole gradient jobs (<= 4)
 
   // ---- fused-step path: the per-timestep loop lives in LstmFamily (all directions share a launch) ----
   bool FusedOk() const;  // C % 4 == 0 (16-byte operand loads) and not disabled by ASLP_LSTM_UNFUSED=1 (A/B switch for tests)
@@ -135,6 +141,7 @@ class LstmFamily : public RecurrentBase {
   void ReadData(std::istream &is, bool binary);
   void WriteData(std::ostream &os, bool binary) const;
   int32 NumParams() const;
+  double ParamSum() const { return f_.ParamSum() + (cfg_.bidir ? b_.ParamSum() : 0.0); }
   void GetParams(std::vector<BaseFloat> *w) const;
   void GetGpuParams(std::vector<std::pair<BaseFloat *, int>> *params);
   std::string Info() const;
