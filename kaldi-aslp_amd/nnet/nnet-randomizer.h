@@ -14,6 +14,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdlib>
+#include <memory>
 #include <vector>
 
 #include "cu-matrix.h"
@@ -136,12 +137,13 @@ class MatrixRandomizer : public RandomizerBase {  // :67-102
   // stage reserves that many rows at its front and appends utterances behind them.
   void StageBegin() {
     ASLP_ASSERT(!staging_);
+    if (!lane_) lane_.reset(new CopyLane);   // the copy stream exists only for randomizers that stage
     staging_ = true;
     stage_leftover_ = (data_end_ - data_begin_) % conf_.minibatch_size;
     stage_end_ = stage_leftover_;
     stage_zeroed_ = false;
     // the stage buffer is the gather source of the last Randomize(): the lane must not overwrite it before that ran
-    lane_.LaneWaitsForStream();
+    lane_->LaneWaitsForStream();
   }
   bool Staging() const { return staging_; }
   bool StageFull() const { return stage_end_ > conf_.randomizer_size; }  // IsFull() of the cache being staged
@@ -151,26 +153,26 @@ class MatrixRandomizer : public RandomizerBase {  // :67-102
     ASLP_ASSERT(staging_);
     if (data_aux_.NumCols() == 0) {
       data_aux_.Resize(std::max(conf_.randomizer_size, data_.NumRows()), cols, kUndefined);
-      lane_.LaneWaitsForStream();  // the allocator may hand out a block the training stream has not finished with
+      lane_->LaneWaitsForStream();  // the allocator may hand out a block the training stream has not finished with
     }
     ASLP_ASSERT(cols == data_aux_.NumCols());
     if (data_aux_.NumRows() < stage_end_ + rows) {  // the +1000-row growth of :60-64, on the stage
-      lane_.Sync();
+      lane_->Sync();
       CuMatrix grown(stage_end_ + rows + 1000, cols, kUndefined);
       if (stage_end_ > stage_leftover_)
         grown.RowRange(stage_leftover_, stage_end_ - stage_leftover_).CopyFromMat(data_aux_.RowRange(stage_leftover_, stage_end_ - stage_leftover_));
       data_aux_.Swap(&grown);
-      lane_.LaneWaitsForStream();
+      lane_->LaneWaitsForStream();
       stage_zeroed_ = false;
     }
     if (!stage_zeroed_) {  // :57 zeroes everything behind the left-over rows; rows behind data_end_ are never read, kept for fidelity
       CuSubMatrix rest = data_aux_.RowRange(stage_end_, data_aux_.NumRows() - stage_end_);
-      lane_.Zero(rest.Data(), sizeof(float) * (size_t)rest.NumRows() * rest.Stride());
+      lane_->Zero(rest.Data(), sizeof(float) * (size_t)rest.NumRows() * rest.Stride());
       stage_zeroed_ = true;
     }
     CuSubMatrix dst = data_aux_.RowRange(stage_end_, rows);
-    lane_.Upload(dst.Data(), dst.Stride(), src, cols, rows, cols);
-    if (done) lane_.Record(done);
+    lane_->Upload(dst.Data(), dst.Stride(), src, cols, rows, cols);
+    if (done) lane_->Record(done);
     stage_end_ += rows;
   }
   // The current cache must be Done() (or empty).  Afterwards the object is in the state the reference's AddData() calls
@@ -180,7 +182,7 @@ class MatrixRandomizer : public RandomizerBase {  // :67-102
     ASLP_ASSERT(data_end_ - data_begin_ == stage_leftover_);
     staging_ = false;
     if (stage_end_ == stage_leftover_) return;  // nothing was staged: the cache stays as it is, like a loop that added nothing
-    lane_.StreamWaitsForLane();
+    lane_->StreamWaitsForLane();
     if (stage_leftover_ > 0) data_aux_.RowRange(0, stage_leftover_).CopyFromMat(data_.RowRange(data_begin_, stage_leftover_));
     data_.Swap(&data_aux_);
     data_begin_ = 0;
@@ -189,7 +191,7 @@ class MatrixRandomizer : public RandomizerBase {  // :67-102
 
  private:
   CuMatrix data_, data_aux_;
-  CopyLane lane_;
+  std::unique_ptr<CopyLane> lane_;
   bool staging_ = false, stage_zeroed_ = false;
   int32 stage_leftover_ = 0, stage_end_ = 0;
   CuArray<int32> mask_dev_;
