@@ -326,6 +326,9 @@ typedef struct aslp_lstm_seq_ {
    * at grad_partial[(chain * 7 + k) * grad_ld + cell].  aslp_lstm_seq_vec_grads finishes them; NULL: nothing is formed. */
   float *grad_partial;
   int grad_ld;
+  /* stream window: this launch serves streams [s_begin, s_begin + s_count) of the S streams the buffers hold (s_count == 0: all of them).
+   * More streams than one launch has chains for (8 chains of 8 streams: 32 bidirectional, 64 unidirectional) go in several launches. */
+  int s_begin, s_count;
 } aslp_lstm_seq;
 int aslp_lstm_seq_supported(const aslp_lstm_seq *a, int backward);
 /* row blocks 0 and T+1 := 0 (all ld columns); columns [col0, col0 + ncols) of row blocks 1..T := 0xFFFFFFFF words.
@@ -363,6 +366,7 @@ typedef struct aslp_gru_seq_ {
   const float *w_zr;
   const float *w_m;
   int ldw_zr, ldw_m, ld, T, S, H;
+  int s_begin, s_count;   /* stream window as in aslp_lstm_seq (s_count == 0: all S streams) */
 } aslp_gru_seq;
 int aslp_gru_seq_supported(const aslp_gru_seq *a, int backward);
 void aslp_gru_seq_forward(const aslp_gru_seq *a);

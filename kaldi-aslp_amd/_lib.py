@@ -29,7 +29,7 @@ class GemmEpilogue(C.Structure):
 class GruSeq(C.Structure):
     """aslp_gru_seq (include/aslp_kernels.h)"""
     _fields_ = [("y", C.c_void_p), ("d", C.c_void_p), ("w_zr", C.c_void_p), ("w_m", C.c_void_p), ("ldw_zr", C.c_int), ("ldw_m", C.c_int),
-                ("ld", C.c_int), ("T", C.c_int), ("S", C.c_int), ("H", C.c_int)]
+                ("ld", C.c_int), ("T", C.c_int), ("S", C.c_int), ("H", C.c_int), ("s_begin", C.c_int), ("s_count", C.c_int)]
 
 
 class RnnVecGrad(C.Structure):

@@ -183,12 +183,13 @@ __global__ void __launch_bounds__(512) lstm_seq_fwd(aslp_lstm_seq a, SeqStatus s
   __shared__ int fail[2][8];
   __shared__ int place_flag;
   const long t_entry = (st.timing || st.trace) ? (long)wall_clock64() : 0;
-  const ChainRole R = chain_role(a.S, a.ndir, a.C, st, place, &place_flag);
+  const int SE = a.s_count > 0 ? a.s_begin + a.s_count : a.S;   // this launch's streams: [a.s_begin, SE)
+  const ChainRole R = chain_role(SE - a.s_begin, a.ndir, a.C, st, place, &place_flag);
   if (!R.active) return;
   const aslp_lstm_seq_dir D = a.dir[R.dir];
   const int C = a.C, S = a.S, T = a.T, ld = a.ld;
   const int GC = G * C, oc = GC, oh = GC + C, om = GC + 2 * C;
-  const int c0 = R.c0, s0 = R.s0;
+  const int c0 = R.c0, s0 = a.s_begin + R.s0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int qs = (lane >> 2) & 1, qc = lane >> 3, jl = lane & 3;
   const int kw = ((C + 31) / 32) * 4, kb = wave * kw;  // this wave's K range [kb, kb + kw), a multiple of 4 long
@@ -210,13 +211,13 @@ __global__ void __launch_bounds__(512) lstm_seq_fwd(aslp_lstm_seq a, SeqStatus s
   const int p0 = threadIdx.x, p1 = threadIdx.x + 512;
   const bool h0 = p0 < npiece, h1 = p1 < npiece;
   const int st0 = h0 ? p0 / c4 : 0, kq0 = h0 ? p0 % c4 : 0, st1 = h1 ? p1 / c4 : 0, kq1 = h1 ? p1 % c4 : 0;
-  const int off0 = (min(s0 + st0, S - 1) * ld + om + 4 * kq0) * 4, off1 = (min(s0 + st1, S - 1) * ld + om + 4 * kq1) * 4;
+  const int off0 = (min(s0 + st0, SE - 1) * ld + om + 4 * kq0) * 4, off1 = (min(s0 + st1, SE - 1) * ld + om + 4 * kq1) * 4;
   // gate-block role: a quad of lanes owns one (stream, cell) pair, lane r of the quad its gate r (g, i, f, o; CIFG: g, f, o, -).
   // The five transcendentals of a pair then take two rounds (gates side by side, then tanh(c) beside the output gate) instead of
   // five in a row on one lane, and all 8 waves share the work.
   const int pair = threadIdx.x >> 2, role = threadIdx.x & 3;
   const int sl = pair >> 4, cc = pair & 15, s = s0 + sl, cell = c0 + cc;
-  const bool live = s < S && cell < C;
+  const bool live = s < SE && cell < C;
   const int cq = live ? cell : 0, sq = live ? s : 0;
   // the peephole weight of this lane's gate (none for g): i <- c(t-1), f <- c(t-1), o <- c(t)
   float pw = 0.f;
@@ -374,13 +375,14 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd(aslp_lstm_seq a, SeqStatus s
   __shared__ int fail[2][8];
   __shared__ int place_flag;
   const long t_entry = st.trace ? (long)wall_clock64() : 0;
-  const ChainRole R = chain_role(a.S, a.ndir, a.C, st, place, &place_flag);
+  const int SE = a.s_count > 0 ? a.s_begin + a.s_count : a.S;
+  const ChainRole R = chain_role(SE - a.s_begin, a.ndir, a.C, st, place, &place_flag);
   if (!R.active) return;
   const aslp_lstm_seq_dir D = a.dir[R.dir];
   const int C = a.C, S = a.S, T = a.T, ld = a.ld;
   const int GC = G * C, oc = GC, oh = GC + C, om = GC + 2 * C;
   const int og = 0, oi = C, of = CIFG ? C : 2 * C, oo = CIFG ? 2 * C : 3 * C;
-  const int c0 = R.c0, s0 = R.s0;
+  const int c0 = R.c0, s0 = a.s_begin + R.s0;
   const int chain = blockIdx.x & (kMaxChains - 1), me = blockIdx.x >> 3, wpc = (C + kCellsPerWg - 1) / kCellsPerWg;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // The product runs on v_mfma_f32_4x4x1_16b_f32: 16 independent 4 x 4 blocks per instruction, here 2 stream quads x 8 cell
@@ -408,7 +410,7 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd(aslp_lstm_seq a, SeqStatus s
   const int npiece = wpc * 32;  // 16-byte pieces addressed to this workgroup per timestep: [producer][row group][column]
   // epilogue role: threads 0..127 own one (stream, cell) pair each
   const int sl = threadIdx.x >> 4, cc = threadIdx.x & 15, s = s0 + sl, cell = c0 + cc;
-  const bool live = threadIdx.x < 128 && s < S && cell < C;
+  const bool live = threadIdx.x < 128 && s < SE && cell < C;
   const int cq = live ? cell : 0, sq = live ? s : 0;
   const float pf = D.peep_f[cq], po = D.peep_o[cq], pi = CIFG ? 0.f : D.peep_i[cq];
   // own-cell quantities of the step processed just before (BPTT order): all zero ahead of the first step
@@ -723,11 +725,12 @@ __global__ void __launch_bounds__(512) gru_seq_fwd(aslp_gru_seq a, SeqStatus st,
   __shared__ int fail[2][8];
   __shared__ int place_flag;
   const long t_entry = st.trace ? (long)wall_clock64() : 0;
-  const ChainRole R = chain_role(a.S, 1, a.H, st, place, &place_flag);
+  const int SE = a.s_count > 0 ? a.s_begin + a.s_count : a.S;
+  const ChainRole R = chain_role(SE - a.s_begin, 1, a.H, st, place, &place_flag);
   if (!R.active) return;
   const int H = a.H, S = a.S, T = a.T, ld = a.ld;
   const int omm = 2 * H, og = 3 * H, oh = 4 * H;
-  const int c0 = R.c0, s0 = R.s0;
+  const int c0 = R.c0, s0 = a.s_begin + R.s0;
   const GruGeom g = gru_geom();
   const int kw = gru_kw(H), kb = g.wave * kw, kbs = kb + g.kh * (kw / 2);
   // B fragments, resident for the launch.  Round 1 (wide): column n = 4 qc + jl is gate n >> 4 (z, r) of cell c0 + (n & 15);
@@ -739,7 +742,7 @@ __global__ void __launch_bounds__(512) gru_seq_fwd(aslp_gru_seq a, SeqStatus st,
     gru_load_b<NBS>(bw2, a.w_m, a.ldw_m, c0 + g.col16, c0 + g.col16 < H, kbs, kw / 2, H);
   }
   const int s = s0 + g.sl, cell = c0 + g.cc;
-  const bool live = threadIdx.x < 256 && s < S && cell < H;
+  const bool live = threadIdx.x < 256 && s < SE && cell < H;
   const int cq = live ? cell : 0, sq = live ? s : 0;
   float hp = live ? a.y[(long)sq * ld + oh + cq] : 0.f;   // h(0): the carried history in row block 0
   unsigned polls = 0u;
@@ -750,7 +753,7 @@ __global__ void __launch_bounds__(512) gru_seq_fwd(aslp_gru_seq a, SeqStatus st,
     const float xg = live ? ys[g.role * H + cq] : 0.f;
     const float xm = (live && g.role == 0) ? ys[omm + cq] : 0.f;
     // ---- round 1: h(t-1) -> z, r, g ------------------------------------------------------------------------------
-    bool ok = gru_collect<2>(a.y + (long)(t - 1) * S * ld, ld, S, s0, oh, H, a_lds, MP, st, polls);
+    bool ok = gru_collect<2>(a.y + (long)(t - 1) * S * ld, ld, SE, s0, oh, H, a_lds, MP, st, polls);
     if (g.lane == 0) fail[0][g.wave] = ok ? 0 : 1;
     __syncthreads();
     gru_store_wide(red[0], gru_product<NBW>(a_lds, MP, bw1, kb, kw, H, g), g);
@@ -766,7 +769,7 @@ __global__ void __launch_bounds__(512) gru_seq_fwd(aslp_gru_seq a, SeqStatus st,
       if (live) ys[g.role * H + cell] = gate;
     }
     // ---- round 2: g(t) -> m, h -----------------------------------------------------------------------------------
-    ok = gru_collect<2>(a.y + (long)t * S * ld, ld, S, s0, og, H, a_lds, MP, st, polls);
+    ok = gru_collect<2>(a.y + (long)t * S * ld, ld, SE, s0, og, H, a_lds, MP, st, polls);
     if (g.lane == 0) fail[1][g.wave] = ok ? 0 : 1;
     __syncthreads();
     gru_store_split(red[1], gru_product<NBS>(a_lds, MP, bw2, kbs, kw / 2, H, g), g);
@@ -803,18 +806,19 @@ __global__ void __launch_bounds__(512) gru_seq_bwd(aslp_gru_seq a, SeqStatus st,
   __shared__ int fail[2][8];
   __shared__ int place_flag;
   const long t_entry = st.trace ? (long)wall_clock64() : 0;
-  const ChainRole R = chain_role(a.S, 1, a.H, st, place, &place_flag);
+  const int SE = a.s_count > 0 ? a.s_begin + a.s_count : a.S;
+  const ChainRole R = chain_role(SE - a.s_begin, 1, a.H, st, place, &place_flag);
   if (!R.active) return;
   const int H = a.H, S = a.S, T = a.T, ld = a.ld;
   const int orr = H, omm = 2 * H, og = 3 * H, oh = 4 * H;
-  const int c0 = R.c0, s0 = R.s0;
+  const int c0 = R.c0, s0 = a.s_begin + R.s0;
   const GruGeom g = gru_geom();
   const int kw1 = gru_kw(2 * H), k1 = g.wave * kw1 + g.kh * (kw1 / 2), kw2 = gru_kw(H), k2 = g.wave * kw2 + g.kh * (kw2 / 2);
   f32x4 bwa[NB1], bwb[NB2];
   gru_load_b<NB1>(bwa, a.w_zr, a.ldw_zr, c0 + g.col16, c0 + g.col16 < H, k1, kw1 / 2, 2 * H);
   gru_load_b<NB2>(bwb, a.w_m, a.ldw_m, c0 + g.col16, c0 + g.col16 < H, k2, kw2 / 2, H);
   const int s = s0 + g.sl, cell = c0 + g.cc;
-  const bool live = threadIdx.x < 256 && s < S && cell < H;
+  const bool live = threadIdx.x < 256 && s < SE && cell < H;
   const int cq = live ? cell : 0, sq = live ? s : 0;
   float dhn = 0.f, zn = 0.f, dgn = 0.f, rn = 0.f;   // d_h, z, d_g, r of this pair at t + 1 (row block T + 1 is zero)
   unsigned polls = 0u;
@@ -826,7 +830,7 @@ __global__ void __launch_bounds__(512) gru_seq_bwd(aslp_gru_seq a, SeqStatus st,
     const float dh_ext = live ? a.d[o + oh + cq] : 0.f;                  // the loss's share, stored before the launch
     // ---- round 1: [d_z | d_r](t+1) W_zr_h -> d_h, d_m ----------------------------------------------------------------
     bool ok = true;
-    if (step > 0) ok = gru_collect<4>(a.d + (long)(t + 1) * S * ld, ld, S, s0, 0, 2 * H, a_lds, MP, st, polls);
+    if (step > 0) ok = gru_collect<4>(a.d + (long)(t + 1) * S * ld, ld, SE, s0, 0, 2 * H, a_lds, MP, st, polls);
     if (g.lane == 0) fail[0][g.wave] = ok ? 0 : 1;
     __syncthreads();
     if (step > 0) gru_store_split(red[0], gru_product<NB1>(a_lds, MP, bwa, k1, kw1 / 2, 2 * H, g), g);
@@ -844,7 +848,7 @@ __global__ void __launch_bounds__(512) gru_seq_bwd(aslp_gru_seq a, SeqStatus st,
       if (live && g.role == 0) a.d[o + oh + cell] = dh;
     }
     // ---- round 2: d_m(t) W_m_g -> d_g, d_r, d_z ----------------------------------------------------------------------
-    ok = gru_collect<2>(a.d + (long)t * S * ld, ld, S, s0, omm, H, a_lds, MP, st, polls);
+    ok = gru_collect<2>(a.d + (long)t * S * ld, ld, SE, s0, omm, H, a_lds, MP, st, polls);
     if (g.lane == 0) fail[1][g.wave] = ok ? 0 : 1;
     __syncthreads();
     gru_store_split(red[1], gru_product<NB2>(a_lds, MP, bwb, k2, kw2 / 2, H, g), g);
@@ -1000,8 +1004,10 @@ extern "C" {
 int aslp_lstm_seq_supported(const aslp_lstm_seq *a, int backward) {
   static const bool disabled = getenv("ASLP_LSTM_PERSISTENT") != nullptr && getenv("ASLP_LSTM_PERSISTENT")[0] == '0';
   if (disabled || !seq_args_ok(a)) return 0;
-  const int nsg = (a->S + kChainStreams - 1) / kChainStreams, wpc = (a->C + kCellsPerWg - 1) / kCellsPerWg;
-  if (a->ndir * nsg > kMaxChains || wpc > kMaxWgPerChain) return 0;   // S <= 32 (bidirectional) / 64, C <= 512
+  if (a->s_begin < 0 || a->s_count < 0 || a->s_begin + a->s_count > a->S) return 0;
+  const int ns = a->s_count > 0 ? a->s_count : a->S;   // streams of this launch
+  const int nsg = (ns + kChainStreams - 1) / kChainStreams, wpc = (a->C + kCellsPerWg - 1) / kCellsPerWg;
+  if (a->ndir * nsg > kMaxChains || wpc > kMaxWgPerChain) return 0;   // <= 32 streams per launch (bidirectional) / 64, C <= 512
   const void *k = backward ? reinterpret_cast<const void *>(pick_bwd(a->cifg != 0, a->C)) : reinterpret_cast<const void *>(pick_fwd(a->cifg != 0, a->C));
   return grid_fits(k, 512, (long)kMaxChains * wpc) ? 1 : 0;
 }
@@ -1062,8 +1068,10 @@ int aslp_gru_seq_supported(const aslp_gru_seq *a, int backward) {
   static const bool disabled = (getenv("ASLP_LSTM_PERSISTENT") != nullptr && getenv("ASLP_LSTM_PERSISTENT")[0] == '0') ||
                                (getenv("ASLP_GRU_PERSISTENT") != nullptr && getenv("ASLP_GRU_PERSISTENT")[0] == '0');
   if (disabled || !a || a->T <= 0 || a->S <= 0 || a->H <= 0 || (a->H & 3) || (a->ld & 3)) return 0;
-  const int nsg = (a->S + kChainStreams - 1) / kChainStreams, wpc = (a->H + kCellsPerWg - 1) / kCellsPerWg;
-  if (nsg > kMaxChains || wpc > kMaxWgPerChain) return 0;   // S <= 64, H <= 512
+  if (a->s_begin < 0 || a->s_count < 0 || a->s_begin + a->s_count > a->S) return 0;
+  const int ns = a->s_count > 0 ? a->s_count : a->S;
+  const int nsg = (ns + kChainStreams - 1) / kChainStreams, wpc = (a->H + kCellsPerWg - 1) / kCellsPerWg;
+  if (nsg > kMaxChains || wpc > kMaxWgPerChain) return 0;   // <= 64 streams per launch, H <= 512
   return grid_fits(reinterpret_cast<const void *>(pick_gru(backward != 0, a->H)), 512, (long)kMaxChains * wpc) ? 1 : 0;
 }
 
@@ -1132,7 +1140,7 @@ void aslp_lstm_seq_vec_grads(const aslp_lstm_seq *a, int dir, float *bias_corr, 
     return;
   }
   SeqVecGradArgs g;
-  g.partial = a->grad_partial; g.ld = a->grad_ld; g.ndir = a->ndir; g.dir = dir; g.nsg = (a->S + kChainStreams - 1) / kChainStreams;
+  g.partial = a->grad_partial; g.ld = a->grad_ld; g.ndir = a->ndir; g.dir = dir; g.nsg = ((a->s_count > 0 ? a->s_count : a->S) + kChainStreams - 1) / kChainStreams;
   g.C = a->C; g.cifg = a->cifg; g.mmt = mmt; g.clip = clip; g.neg_lr = neg_lr;
   const int C = a->C;
   // gate order of the buffer: g, i, f, o (cifg: g, f, o)

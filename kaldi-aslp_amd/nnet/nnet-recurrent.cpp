@@ -1,6 +1,8 @@
 // nnet-recurrent.cpp -- LSTM family + GruStreams host logic (see nnet-recurrent.h).
 #include "nnet-recurrent.h"
 
+#include <algorithm>
+
 #include "scratch.h"
 
 #include <cstdlib>
@@ -576,6 +578,9 @@ void LstmFamily::PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) {
     // (csrc/rnn_persistent.hip) -- or, where that kernel does not apply, one launch per timestep --, batched projection
     aslp_lstm_seq q = aslp_lstm_seq();
     q.ndir = cfg_.bidir ? 2 : 1; q.ld = 4; q.ldw = 4; q.T = T; q.S = S; q.C = ncell_; q.cifg = cfg_.cifg ? 1 : 0;
+    // one launch serves 8 chains of 8 streams (32 streams of a bidirectional layer, 64 of a unidirectional one); more streams go in windows
+    const int per_launch = 64 / q.ndir, nwin = (S + per_launch - 1) / per_launch;
+    if (nwin > 1) q.s_count = per_launch;
     const bool persistent = aslp_lstm_seq_supported(&q, 0) != 0;
     if (cfg_.bidir) LstmDir::ForwardPreparePair(f_, b_, in, T, S, carried ? &prev_state_ : nullptr, &f_buf_, &b_buf_, persistent);
     else f_.ForwardPrepare(in, T, S, false, carried ? &prev_state_ : nullptr, &f_buf_, persistent);
@@ -600,7 +605,10 @@ void LstmFamily::PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) {
       }
       ASLP_ASSERT(!cfg_.bidir || b_buf_.Stride() == f_buf_.Stride());
       RegionScope timed("lstm_recurrence_fwd");
-      aslp_lstm_seq_forward(&q);
+      for (int w = 0; w < nwin; w++) {
+        if (nwin > 1) { q.s_begin = w * per_launch; q.s_count = std::min(per_launch, S - q.s_begin); }
+        aslp_lstm_seq_forward(&q);
+      }
     } else {
       aslp_lstm_step a = aslp_lstm_step();
       a.ndir = cfg_.bidir ? 2 : 1; a.ld = f_buf_.Stride(); a.S = S; a.C = ncell_; a.cifg = cfg_.cifg ? 1 : 0;
@@ -658,6 +666,8 @@ void LstmFamily::BackpropagateFnc(const CuMatrixBase &in, const CuMatrixBase &, 
     CuSubMatrix od_f(out_diff, 0, T * S, 0, rec), od_b(out_diff, 0, T * S, cfg_.bidir ? rec : 0, rec);
     aslp_lstm_seq q = aslp_lstm_seq();
     q.ndir = cfg_.bidir ? 2 : 1; q.ld = 4; q.ldw = 4; q.T = T; q.S = S; q.C = ncell_; q.cifg = cfg_.cifg ? 1 : 0;
+    const int per_launch = 64 / q.ndir, nwin = (S + per_launch - 1) / per_launch;   // stream windows as in PropagateFnc
+    if (nwin > 1) q.s_count = per_launch;
     const bool persistent = aslp_lstm_seq_supported(&q, 1) != 0;
     if (cfg_.bidir) LstmDir::BackwardPreparePair(f_, b_, od_f, od_b, T, S, &f_dbuf_, &b_dbuf_, persistent);
     else f_.BackwardPrepare(od_f, T, S, &f_dbuf_, persistent);
@@ -665,7 +675,7 @@ void LstmFamily::BackpropagateFnc(const CuMatrixBase &in, const CuMatrixBase &, 
     if (persistent) {
       q.ld = f_dbuf_.Stride(); q.ldw = f_.Weff().Stride();
       static const bool vec_fused_off = getenv("ASLP_LSTM_VEC_FUSED") != nullptr && getenv("ASLP_LSTM_VEC_FUSED")[0] == '0';   // A/B switch
-      if (!vec_fused_off) {   // the kernel also leaves the sums the bias / peephole gradients are made of (8 chains x 7 quantities x C)
+      if (!vec_fused_off && nwin == 1) {   // the kernel also leaves the sums the bias / peephole gradients are made of (8 chains x 7 quantities x C)
         if (grad_partial_.NumRows() != 8 * 7 || grad_partial_.NumCols() != ncell_) grad_partial_.Resize(8 * 7, ncell_, kUndefined);
         q.grad_partial = grad_partial_.Data();
         q.grad_ld = grad_partial_.Stride();
@@ -681,7 +691,10 @@ void LstmFamily::BackpropagateFnc(const CuMatrixBase &in, const CuMatrixBase &, 
         q.dir[d].reverse = d;
       }
       RegionScope timed("lstm_recurrence_bwd");
-      aslp_lstm_seq_backward(&q);
+      for (int w = 0; w < nwin; w++) {
+        if (nwin > 1) { q.s_begin = w * per_launch; q.s_count = std::min(per_launch, S - q.s_begin); }
+        aslp_lstm_seq_backward(&q);
+      }
       if (q.grad_partial) { vec_seq_ = q; vec_seq_valid_ = true; }
     } else {
       aslp_lstm_step a = aslp_lstm_step();
@@ -845,6 +858,8 @@ void GruStreams::PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) {  // :
   // the whole recurrence as one persistent launch (csrc/rnn_persistent.hip) where it applies, else four launches per timestep
   aslp_gru_seq q = aslp_gru_seq();
   q.T = T; q.S = S; q.H = H; q.ld = (5 * H + 15) & ~15;
+  const int per_launch = 64, nwin = (S + per_launch - 1) / per_launch;   // 8 chains of 8 streams per launch; more streams go in windows
+  if (nwin > 1) q.s_count = per_launch;
   const bool persistent = !unfused && aslp_gru_seq_supported(&q, 0) != 0;
   if (persistent) {  // g and h of row blocks 1..T start as "not yet published", the two boundary blocks as zero
     buf_.Resize((T + 2) * S, 5 * H, kUndefined);
@@ -865,7 +880,10 @@ void GruStreams::PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) {  // :
     q.w_zr = w_zr_h_.Data(); q.ldw_zr = w_zr_h_.Stride();
     q.w_m = w_m_g_.Data(); q.ldw_m = w_m_g_.Stride();
     RegionScope timed("gru_recurrence_fwd");
-    aslp_gru_seq_forward(&q);
+    for (int w = 0; w < nwin; w++) {
+      if (nwin > 1) { q.s_begin = w * per_launch; q.s_count = std::min(per_launch, S - q.s_begin); }
+      aslp_gru_seq_forward(&q);
+    }
   }
   const bool fused = !persistent && !unfused && aslp_gru_step_supported(H);
   for (int t = 1; t <= T && fused; t++)
@@ -891,6 +909,8 @@ void GruStreams::BackpropagateFnc(const CuMatrixBase &in, const CuMatrixBase &, 
   static const bool unfused = getenv("ASLP_LSTM_UNFUSED") != nullptr && getenv("ASLP_LSTM_UNFUSED")[0] == '1';
   aslp_gru_seq q = aslp_gru_seq();
   q.T = T; q.S = S; q.H = H; q.ld = buf_.Stride();
+  const int per_launch = 64, nwin = (S + per_launch - 1) / per_launch;
+  if (nwin > 1) q.s_count = per_launch;
   const bool persistent = !unfused && aslp_gru_seq_supported(&q, 1) != 0;
   if (persistent) {  // d_z, d_r, d_m of row blocks 1..T start as "not yet published" (the kernel writes d_g, d_h's loss share follows), boundary blocks zero
     dbuf_.Resize((T + 2) * S, 5 * H, kUndefined);
@@ -914,7 +934,10 @@ void GruStreams::BackpropagateFnc(const CuMatrixBase &in, const CuMatrixBase &, 
     q.w_zr = w_zr_h_t_.Data(); q.ldw_zr = w_zr_h_t_.Stride();
     q.w_m = w_m_g_t_.Data(); q.ldw_m = w_m_g_t_.Stride();
     RegionScope timed("gru_recurrence_bwd");
-    aslp_gru_seq_backward(&q);
+    for (int w = 0; w < nwin; w++) {
+      if (nwin > 1) { q.s_begin = w * per_launch; q.s_count = std::min(per_launch, S - q.s_begin); }
+      aslp_gru_seq_backward(&q);
+    }
   }
   if (fused) {
     for (int t = T; t >= 1; t--)

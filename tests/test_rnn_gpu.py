@@ -64,8 +64,10 @@ def oracle_step(oracle, marker, dirs, grads, x, od, T, S, state, lens, chunk, lr
     return out, in_diff, new_state
 
 
+# (12, 16, 8, 5, 70): 70 streams are more than one persistent launch has chains for (32 bidirectional / 64 unidirectional): the engine
+# runs the recurrence in stream windows (aslp_lstm_seq.s_begin / s_count), 3 resp. 2 launches per pass
 @pytest.mark.parametrize("marker", list(FAMILY))
-@pytest.mark.parametrize("dims", [(5, 8, 4, 6, 3), (40, 64, 32, 12, 4), (33, 48, 17, 9, 5)])
+@pytest.mark.parametrize("dims", [(5, 8, 4, 6, 3), (40, 64, 32, 12, 4), (33, 48, 17, 9, 5), (12, 16, 8, 5, 70)])
 def test_lstm_family_train_steps_match_oracle(aslp, oracle, dev, tmp_path, marker, dims):
     D, Cc, R, T, S = dims
     bidir, proj, cifg, lc, _ = FAMILY[marker]
@@ -180,15 +182,16 @@ def test_lc_blstm_baseline_shape(aslp, oracle, dev, tmp_path):
 
 # (512, 512, 60, 32): BASELINE cfg5's GruStreams swap at full size (H = 512, S = 32 streams, T = 60).
 # Three execution paths: the persistent kernels (csrc/rnn_persistent.hip: H % 4 == 0, H <= 512, S <= 64 -- one launch per pass),
-# four fused launches per timestep (csrc/gru_fused.hip: H % 4 == 0 otherwise, here S = 70), GEMM + cell kernels per timestep (the rest).
+# in stream windows of 64 where there are more streams (here S = 70: two launches per pass), four fused launches per timestep
+# (csrc/gru_fused.hip: H % 4 == 0 and H > 512, here 516), GEMM + cell kernels per timestep (the rest).
 @pytest.mark.parametrize("dims", [(5, 6, 6, 3), (40, 64, 10, 4), (33, 50, 7, 5), (48, 128, 6, 40), (24, 36, 5, 33), (512, 512, 60, 32), (16, 64, 4, 70),
-                                  (20, 132, 9, 11)])
+                                  (20, 132, 9, 11), (8, 516, 3, 4)])
 def test_gru_train_steps_match_oracle(aslp, oracle, dev, tmp_path, dims):
     D, H, T, S = dims
     from kaldi_aslp_amd._lib import GruSeq
-    q = GruSeq(None, None, None, None, 0, 0, (5 * H + 15) & ~15, T, S, H)
+    q = GruSeq(None, None, None, None, 0, 0, (5 * H + 15) & ~15, T, S, H, 0, min(S, 64) if S > 64 else 0)
     for backward in (0, 1):   # the shapes meant for the persistent kernels do run on them (not on a silent fallback)
-        assert bool(aslp.lib.aslp_gru_seq_supported(C.byref(q), backward)) == (H % 4 == 0 and H <= 512 and S <= 64), (dims, backward)
+        assert bool(aslp.lib.aslp_gru_seq_supported(C.byref(q), backward)) == (H % 4 == 0 and H <= 512), (dims, backward)
     clip, lr, mmt = 0.5, 0.01, 0.9
     rng = np.random.default_rng(2)
     p = oracle.Gru(D, H, rng, scale=0.3 if H < 256 else 0.05)
