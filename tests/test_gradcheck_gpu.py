@@ -17,6 +17,9 @@ NETS = {
     "Lstm": ("<Lstm> <InputDim> 10 <OutputDim> 16 <ParamScale> 0.3", 16, 16),
     "BLstmProjectedStreams": ("<BLstmProjectedStreams> <InputDim> 10 <OutputDim> 16 <CellDim> 16 <ParamScale> 0.3", 16, 16),
     "BLstm": ("<BLstm> <InputDim> 10 <OutputDim> 32 <ParamScale> 0.3", 32, 16),
+    # latency-controlled: with the streams reset and the whole batch as the chunk (no right context) the carried history is zero and
+    # every frame counts -- the arithmetic of cfg3's component, where the gradient is exact
+    "BLstmProjectedStreamsLC": ("<BLstmProjectedStreamsLC> <InputDim> 10 <OutputDim> 16 <CellDim> 16 <ParamScale> 0.3", 16, 16),
 }
 
 
@@ -72,10 +75,13 @@ def test_recurrent_gradients_match_finite_differences(aslp, dev, name):
     R = torch.randn(T * S, out_dim, device=dev, generator=g).double()
     lens = [T, T - 2, T, 3, T, T - 1, 1, T]
 
+    if name.endswith("LC"):
+        net.SetChunkSize(T)
+
     def before():
         net.ResetLstmStreams([1] * S)
         net.SetSeqLengths(lens)
-    if name.startswith("BLstm"):   # frames past an utterance's end carry no gradient (nnet-blstm-projected-streams.h:654-657)
+    if name.startswith("BLstm") and not name.endswith("LC"):   # frames past an utterance's end carry no gradient (nnet-blstm-projected-streams.h:654-657)
         m = torch.zeros(T, S, 1, device=dev, dtype=torch.float64)
         for s, n in enumerate(lens):
             m[:n, s] = 1
@@ -111,3 +117,20 @@ def test_compact_fsmn_gradients_match_finite_differences(aslp, dev):
     x = torch.randn(40, 6, device=dev, generator=g)
     R = torch.randn(40, 5, device=dev, generator=g).double()
     check(aslp, dev, net, x, R, lambda: None, eps=5e-3)
+
+
+def test_row_convolution_gradients_match_finite_differences(aslp, dev):
+    """RowConvolution (nnet-row-convolution.cc): the reference drops the diff that lands on the replicated tail frames of a stream, so
+    its tap gradient is exact only for functionals that ignore the last K frames -- R is zero there."""
+    D, K, T, S = 8, 3, 12, 4
+    proto = """<NnetProto>
+<AffineTransform> <InputDim> 5 <OutputDim> %d <BiasMean> 0.0 <BiasRange> 0.5 <ParamStddev> 0.4
+<RowConvolution> <InputDim> %d <OutputDim> %d <FutureContext> %d
+</NnetProto>
+""" % (D, D, D, K)
+    net = aslp.Nnet.Init(proto, seed=11)
+    g = torch.Generator(device=dev).manual_seed(4)
+    x = torch.randn(T * S, 5, device=dev, generator=g)
+    R = torch.randn(T, S, D, device=dev, generator=g).double()
+    R[T - K:] = 0
+    check(aslp, dev, net, x, R.view(T * S, D), lambda: net.SetSeqLengths([T] * S), eps=5e-3)
