@@ -316,6 +316,12 @@ typedef struct aslp_lstm_seq_dir_ {
   const int32_cuda *seq_lengths;          /* forward length masking (may be NULL) */
   int reverse;                            /* 0: the recursion runs t = 1..T, 1: t = T..1 (BPTT runs against it) */
   int skip_first_product;                 /* forward: the caller already added the recurrent term of the first step */
+  /* forward, optional: the first step's recurrent term is r(0) W_first^T instead of m(0) W_eff^T -- the carried history of a layer with
+   * a projection holds r(0) formed with the weights of the previous batch (lc.h:575) --, r(0) = columns [col_first, col_first + k_first)
+   * of the history row block, w_first = W_r [G*C x k_first] (leading dimension ldw_first).  Served inside the launch for k_first <= 256
+   * (aslp_lstm_seq_first_product_supported); otherwise the caller adds the term itself and sets skip_first_product. */
+  const float *w_first;
+  int ldw_first, k_first, col_first;
 } aslp_lstm_seq_dir;
 typedef struct aslp_lstm_seq_ {
   aslp_lstm_seq_dir dir[2];
@@ -331,6 +337,7 @@ typedef struct aslp_lstm_seq_ {
   int s_begin, s_count;
 } aslp_lstm_seq;
 int aslp_lstm_seq_supported(const aslp_lstm_seq *a, int backward);
+int aslp_lstm_seq_first_product_supported(int k_first);
 /* row blocks 0 and T+1 := 0 (all ld columns); columns [col0, col0 + ncols) of row blocks 1..T := 0xFFFFFFFF words.
  * For the forward kernel: col0 = the m column block (G + 2) * C, ncols = C. */
 void aslp_lstm_seq_fill(float *buf, int ld, int T, int S, int col0, int ncols);

@@ -119,6 +119,7 @@ __device__ __forceinline__ void store_tile16(float *tile, const f32x4 &acc, int 
 }
 
 // ---- chain geometry shared by both kernels ------------------------------------------------------------------------
+constexpr int kFirstK = 256;       // largest K of a first-step product served inside the forward launch (aslp_lstm_seq_dir.w_first)
 constexpr int kChainStreams = 8;   // streams per chain (rows 0..7 of the 16-row MFMA tile; rows 8..15 repeat them, outputs unused)
 constexpr int kCellsPerWg = 16;
 constexpr int kMaxChains = 8;      // = XCDs of the chip: workgroup b serves chain b & 7
@@ -179,6 +180,7 @@ template <bool CIFG, int KW>
 __global__ void __launch_bounds__(512) lstm_seq_fwd(aslp_lstm_seq a, SeqStatus st, unsigned *place) {
   constexpr int G = CIFG ? 3 : 4, KMAX = 8 * KW, MP = KMAX + 4, RP = 80;  // RP = 16 mod 32: the epilogue's reads hit 32 distinct banks
   __shared__ __attribute__((aligned(16))) float m_lds[kChainStreams][MP];
+  __shared__ __attribute__((aligned(16))) float wf_lds[64][kFirstK + 4];   // this workgroup's 64 rows of W_first (first step only, see w_first)
   __shared__ float red[2][8][kChainStreams][RP];
   __shared__ int fail[2][8];
   __shared__ int place_flag;
@@ -204,6 +206,17 @@ __global__ void __launch_bounds__(512) lstm_seq_fwd(aslp_lstm_seq a, SeqStatus s
     for (int i = 0; i < KW / 4; i++) {
       const int k0 = kb + 4 * i;
       bw[h][i] = (nvalid && 4 * i < kw && k0 < C) ? *reinterpret_cast<const f32x4 *>(brow + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  // W_first rows of this workgroup's 64 gate columns -> LDS (zero where the column or k does not exist); read at step 0 only
+  const bool first_in_kernel = D.w_first != nullptr && D.k_first > 0 && D.k_first <= kFirstK;
+  if (first_in_kernel) {
+    const int kq = (D.k_first + 3) >> 2;   // 16-byte pieces per row
+    for (int p = threadIdx.x; p < 64 * kq; p += 512) {
+      const int n = p / kq, k0 = 4 * (p % kq), gate = n >> 4, cellb = c0 + (n & 15);
+      const bool ok = gate < G && cellb < C;
+      *reinterpret_cast<f32x4 *>(&wf_lds[n][k0]) = ok ? *reinterpret_cast<const f32x4 *>(D.w_first + (long)(gate * C + cellb) * D.ldw_first + k0)
+                                                      : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
   // collection role: pieces tid and tid + 512 of [stream][C / 4]
@@ -241,7 +254,16 @@ __global__ void __launch_bounds__(512) lstm_seq_fwd(aslp_lstm_seq a, SeqStatus s
 #pragma unroll
     for (int h = 0; h < 2; h++) { acc[h][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[h][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     bool ok = true;
-    const bool product = !(step == 0 && D.skip_first_product);
+    const bool first_special = step == 0 && first_in_kernel;
+    const bool product = !first_special && !(step == 0 && D.skip_first_product);
+    if (first_special) {   // r(0) of the chain's streams -> LDS (the history row block: stored before the launch, no hand-off)
+      const int kq = D.k_first >> 2;
+      for (int p = threadIdx.x; p < kChainStreams * kq; p += 512) {
+        const int sp = p / kq, k0 = 4 * (p % kq);
+        *reinterpret_cast<f32x4 *>(&m_lds[sp][k0]) =
+            *reinterpret_cast<const f32x4 *>(D.y + ((long)tp * S + min(s0 + sp, SE - 1)) * ld + D.col_first + k0);
+      }
+    }
     if (product) {
       // 1. m(t-1) of the chain's streams -> LDS
       const __amdgpu_buffer_rsrc_t rs = make_rsrc(D.y + (long)tp * S * ld);
@@ -281,6 +303,21 @@ __global__ void __launch_bounds__(512) lstm_seq_fwd(aslp_lstm_seq a, SeqStatus s
         for (int h = 0; h < 2; h++) acc[h][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i].z, bw[h][i].z, acc[h][0], 0, 0, 0);
 #pragma unroll
         for (int h = 0; h < 2; h++) acc[h][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i].w, bw[h][i].w, acc[h][1], 0, 0, 0);
+      }
+    }
+    if (first_special) {   // r(0) W_first^T, both operands from LDS; this wave's slice of K = k_first
+      const int kwf = ((D.k_first + 31) / 32) * 4, kbf = wave * kwf;
+      const float *arow = &m_lds[4 * qs + jl][0];
+      for (int k0 = kbf; k0 < min(kbf + kwf, D.k_first); k0 += 4) {
+        const f32x4 av = *reinterpret_cast<const f32x4 *>(arow + k0);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const f32x4 b = *reinterpret_cast<const f32x4 *>(&wf_lds[32 * h + 4 * qc + jl][k0]);
+          acc[h][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.x, b.x, acc[h][0], 0, 0, 0);
+          acc[h][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.y, b.y, acc[h][1], 0, 0, 0);
+          acc[h][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.z, b.z, acc[h][0], 0, 0, 0);
+          acc[h][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.w, b.w, acc[h][1], 0, 0, 0);
+        }
       }
     }
     // result register r of a lane = stream 4 qs + r of tile column 32 h + 4 qc + jl
@@ -1011,6 +1048,8 @@ int aslp_lstm_seq_supported(const aslp_lstm_seq *a, int backward) {
   const void *k = backward ? reinterpret_cast<const void *>(pick_bwd(a->cifg != 0, a->C)) : reinterpret_cast<const void *>(pick_fwd(a->cifg != 0, a->C));
   return grid_fits(k, 512, (long)kMaxChains * wpc) ? 1 : 0;
 }
+
+int aslp_lstm_seq_first_product_supported(int k_first) { return k_first > 0 && k_first <= kFirstK && (k_first & 3) == 0; }
 
 void aslp_lstm_seq_fill(float *buf, int ld, int T, int S, int col0, int ncols) {
   if (!buf || T <= 0 || S <= 0 || ld <= 0) return;

@@ -584,9 +584,12 @@ void LstmFamily::PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) {
     const bool persistent = aslp_lstm_seq_supported(&q, 0) != 0;
     if (cfg_.bidir) LstmDir::ForwardPreparePair(f_, b_, in, T, S, carried ? &prev_state_ : nullptr, &f_buf_, &b_buf_, persistent);
     else f_.ForwardPrepare(in, T, S, false, carried ? &prev_state_ : nullptr, &f_buf_, persistent);
-    if (carried && cfg_.proj) {
-      // The carried history holds r(0) = m(0) W_rm^T formed with the weights of the PREVIOUS batch (the reference
-      // recurs on the stored r, lc.h:575); m(0) W_eff^T would silently re-project it with the updated W_rm.
+    // The carried history holds r(0) = m(0) W_rm^T formed with the weights of the PREVIOUS batch (the reference
+    // recurs on the stored r, lc.h:575); m(0) W_eff^T would silently re-project it with the updated W_rm.  The persistent
+    // kernel forms r(0) W_r^T itself at its first step where it can; otherwise a 32-row product adds it here.
+    const bool first_in_kernel = carried && cfg_.proj && persistent && aslp_lstm_seq_first_product_supported(f_.R) != 0 &&
+                                 f_.w_r.Stride() % 4 == 0 && f_.OffRec() % 4 == 0;
+    if (carried && cfg_.proj && !first_in_kernel) {
       CuSubMatrix y_gates(f_buf_, S, S, 0, f_.GC()), r0(f_buf_, 0, S, f_.OffRec(), f_.R);
       y_gates.AddMatMat(1.0, r0, kNoTrans, f_.w_r, kTrans, 1.0);
     }
@@ -601,7 +604,11 @@ void LstmFamily::PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) {
         q.dir[d].peep_o = p.peep_o.Data();
         q.dir[d].seq_lengths = (d == 1 && !cfg_.lc) ? seq_len_dev_.Data() : nullptr;
         q.dir[d].reverse = d;
-        q.dir[d].skip_first_product = (d == 0 && carried && cfg_.proj) ? 1 : 0;
+        q.dir[d].skip_first_product = (d == 0 && carried && cfg_.proj && !first_in_kernel) ? 1 : 0;
+        if (d == 0 && first_in_kernel) {
+          q.dir[d].w_first = f_.w_r.Data(); q.dir[d].ldw_first = f_.w_r.Stride();
+          q.dir[d].k_first = f_.R; q.dir[d].col_first = f_.OffRec();
+        }
       }
       ASLP_ASSERT(!cfg_.bidir || b_buf_.Stride() == f_buf_.Stride());
       RegionScope timed("lstm_recurrence_fwd");
