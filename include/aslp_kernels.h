@@ -359,6 +359,8 @@ void aslp_lstm_seq_backward(const aslp_lstm_seq *a);
  * param += neg_lr * corr if neg_lr != 0.  bias_corr / bias: [G*C] in the buffer's gate order; peephole vectors [C] (peep_i_* NULL with cifg). */
 void aslp_lstm_seq_vec_grads(const aslp_lstm_seq *a, int dir, float *bias_corr, float *bias, float *peep_i_corr, float *peep_i, float *peep_f_corr,
                              float *peep_f, float *peep_o_corr, float *peep_o, float mmt, float clip, float neg_lr);
+/* both directions of a bidirectional layer in one launch: vec8_dirN = the eight pointers above in that order, for direction N */
+void aslp_lstm_seq_vec_grads2(const aslp_lstm_seq *a, float *const *vec8_dir0, float *const *vec8_dir1, float mmt, float clip, float neg_lr);
 /* GruStreams, the whole recurrence of T timesteps as ONE launch per pass (csrc/rnn_persistent.hip; the scheme of aslp_lstm_seq_*):
  * y / d: [(T + 2) * S x ld] activations / diffs, row block 0 = the carried history h(0) (forward), row blocks 0 and T + 1 of d zero,
  * columns [z|r|m|g|h], H each.  Before the launch the caller has stored

@@ -917,7 +917,9 @@ struct SeqVecGradArgs {
   float *corr[7], *param[7];   // per quantity: where its [C] slice lives (bias rows are slices of bias_corr / bias)
   float mmt, clip, neg_lr;
 };
-__global__ void __launch_bounds__(256) lstm_seq_vec_grads_kernel(SeqVecGradArgs g) {
+struct SeqVecGradPair { SeqVecGradArgs d[2]; };   // blockIdx.y picks the direction
+__global__ void __launch_bounds__(256) lstm_seq_vec_grads_kernel(SeqVecGradPair gp) {
+  const SeqVecGradArgs &g = gp.d[blockIdx.y];
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= 7 * g.C) return;
   const int k = idx / g.C, c = idx - k * g.C;
@@ -1171,15 +1173,13 @@ unsigned aslp_lstm_seq_polls(int reset) {
   if (reset) (void)hipMemset(rt.abort_flag + 2, 0, 4);
   return v;
 }
-void aslp_lstm_seq_vec_grads(const aslp_lstm_seq *a, int dir, float *bias_corr, float *bias, float *peep_i_corr, float *peep_i, float *peep_f_corr,
-                             float *peep_f, float *peep_o_corr, float *peep_o, float mmt, float clip, float neg_lr) {
+static bool fill_vec_grad_args(SeqVecGradArgs &g, const aslp_lstm_seq *a, int dir, float *bias_corr, float *bias, float *peep_i_corr, float *peep_i,
+                               float *peep_f_corr, float *peep_f, float *peep_o_corr, float *peep_o, float mmt, float clip, float neg_lr) {
   if (!seq_args_ok(a) || !a->grad_partial || a->grad_ld < a->C || dir < 0 || dir >= a->ndir || !bias_corr || !bias || !peep_f_corr || !peep_f ||
-      !peep_o_corr || !peep_o || (!a->cifg && (!peep_i_corr || !peep_i))) {
-    set_error("aslp_lstm_seq_vec_grads: bad arguments");
-    return;
-  }
-  SeqVecGradArgs g;
-  g.partial = a->grad_partial; g.ld = a->grad_ld; g.ndir = a->ndir; g.dir = dir; g.nsg = ((a->s_count > 0 ? a->s_count : a->S) + kChainStreams - 1) / kChainStreams;
+      !peep_o_corr || !peep_o || (!a->cifg && (!peep_i_corr || !peep_i)))
+    return false;
+  g.partial = a->grad_partial; g.ld = a->grad_ld; g.ndir = a->ndir; g.dir = dir;
+  g.nsg = ((a->s_count > 0 ? a->s_count : a->S) + kChainStreams - 1) / kChainStreams;
   g.C = a->C; g.cifg = a->cifg; g.mmt = mmt; g.clip = clip; g.neg_lr = neg_lr;
   const int C = a->C;
   // gate order of the buffer: g, i, f, o (cifg: g, f, o)
@@ -1191,8 +1191,29 @@ void aslp_lstm_seq_vec_grads(const aslp_lstm_seq *a, int dir, float *bias_corr, 
   g.corr[4] = a->cifg ? nullptr : peep_i_corr; g.param[4] = a->cifg ? nullptr : peep_i;
   g.corr[5] = peep_f_corr; g.param[5] = peep_f;
   g.corr[6] = peep_o_corr; g.param[6] = peep_o;
-  hipLaunchKernelGGL(lstm_seq_vec_grads_kernel, dim3((7 * C + 255) / 256), dim3(256), 0, cur_stream(), g);
+  return true;
+}
+void aslp_lstm_seq_vec_grads(const aslp_lstm_seq *a, int dir, float *bias_corr, float *bias, float *peep_i_corr, float *peep_i, float *peep_f_corr,
+                             float *peep_f, float *peep_o_corr, float *peep_o, float mmt, float clip, float neg_lr) {
+  SeqVecGradPair gp;
+  if (!fill_vec_grad_args(gp.d[0], a, dir, bias_corr, bias, peep_i_corr, peep_i, peep_f_corr, peep_f, peep_o_corr, peep_o, mmt, clip, neg_lr)) {
+    set_error("aslp_lstm_seq_vec_grads: bad arguments");
+    return;
+  }
+  gp.d[1] = gp.d[0];
+  hipLaunchKernelGGL(lstm_seq_vec_grads_kernel, dim3((7 * a->C + 255) / 256, 1), dim3(256), 0, cur_stream(), gp);
   check_launch("aslp_lstm_seq_vec_grads");
+}
+void aslp_lstm_seq_vec_grads2(const aslp_lstm_seq *a, float *const *vec8_dir0, float *const *vec8_dir1, float mmt, float clip, float neg_lr) {
+  SeqVecGradPair gp;
+  bool ok = a && a->ndir == 2 && vec8_dir0 && vec8_dir1;
+  for (int d = 0; d < 2 && ok; d++) {
+    float *const *v = d == 0 ? vec8_dir0 : vec8_dir1;
+    ok = fill_vec_grad_args(gp.d[d], a, d, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], mmt, clip, neg_lr);
+  }
+  if (!ok) { set_error("aslp_lstm_seq_vec_grads2: bad arguments"); return; }
+  hipLaunchKernelGGL(lstm_seq_vec_grads_kernel, dim3((7 * a->C + 255) / 256, 2), dim3(256), 0, cur_stream(), gp);
+  check_launch("aslp_lstm_seq_vec_grads2");
 }
 void aslp_lstm_seq_forward(const aslp_lstm_seq *a) { launch_seq(a, false, "aslp_lstm_seq_forward"); }
 void aslp_lstm_seq_backward(const aslp_lstm_seq *a) { launch_seq(a, true, "aslp_lstm_seq_backward"); }

@@ -447,9 +447,16 @@ void LstmDir::GradsPair(LstmDir &f, LstmDir &b, const CuMatrixBase &in, int T, i
   if (f.R > 0)
     wgrad(f.w_rm_corr, b.w_rm_corr, f.w_rm, b.w_rm, CuSubMatrix(fdbuf, S, T * S, f.OffRec(), f.R), CuSubMatrix(bdbuf, S, T * S, b.OffRec(), b.R),
           CuSubMatrix(fbuf, S, T * S, f.OffM(), f.C), CuSubMatrix(bbuf, S, T * S, b.OffM(), b.C));
-  if (seq != nullptr && seq->grad_partial != nullptr) {   // the persistent backward launch left the sums: two small finishing launches
-    f.VecGrads(T, S, false, fbuf, fdbuf, mmt, clip, lr_fold, seq, 0);
-    b.VecGrads(T, S, true, bbuf, bdbuf, mmt, clip, lr_fold, seq, 1);
+  if (seq != nullptr && seq->grad_partial != nullptr) {   // the persistent backward launch left the sums: one small finishing launch
+    auto vec8 = [](LstmDir &p, float **v) {
+      v[0] = p.bias_corr.Data(); v[1] = p.bias.Data();
+      v[2] = p.cifg ? nullptr : p.peep_i_corr.Data(); v[3] = p.cifg ? nullptr : p.peep_i.Data();
+      v[4] = p.peep_f_corr.Data(); v[5] = p.peep_f.Data(); v[6] = p.peep_o_corr.Data(); v[7] = p.peep_o.Data();
+    };
+    float *vf[8], *vb[8];
+    vec8(f, vf);
+    vec8(b, vb);
+    aslp_lstm_seq_vec_grads2(seq, vf, vb, mmt, clip, -lr_fold);
   } else {   // bias and peephole gradients of both directions: one launch over the two diff buffers
     aslp_rnn_vec_grad jobs[8];
     int n = f.VecGradJobs(S, false, fbuf, fdbuf, jobs);
