@@ -11,11 +11,15 @@
  *   - CTC (orc_ctc_*): pinned against the reference's own Warp-CTC CPU code built
  *     from /root/reference into oracle/_ref/ and against the known-answer vectors of
  *     src/warp-ctc/tests/test_cpu.cpp.
- *   - substrate ops: pinned against the closed-form expectations the reference's
- *     unit tests hold (aslp-cudamatrix/cu-matrix-test.cc, cu-math-test.cc).
- *   - Component / Nnet level (Affine, BN, LSTM family, FSMN, ...): the reference has
- *     no tests and its Kaldi core cannot be built here without stand-ins for BLAS /
- *     OpenFst, so for those rows: PARITY UNPINNED (restated from source, cited per fn).
+ *   - substrate ops: pinned against outputs of the reference's own CuMatrix CPU branch, built where it lies:
+ *     tests/golden/cumatrix_ops.bin (BLAS-free operations) and tests/golden/cumatrix_blas_ops.bin (the BLAS-backed ones, linked
+ *     against the OpenBLAS inside the image's scipy wheel: product, softmax, column / row sums, wide broadcasts).
+ *   - Component level: AffineTransform, BatchNormalization, the projected-LSTM gate block (LstmProjectedStreams and both directions
+ *     of BLstmProjectedStreamsLC) and GruStreams are pinned against their op sequences issued on the reference's library
+ *     (oracle/gen_cumatrix_blas_golden.cpp, tests/test_oracle_ref_blas_cpu.py).  The component headers themselves need OpenFst
+ *     and cannot be compiled here, so control flow that lives only there (CIFG, Lstm / BLstm of nnet-recurrent-component.cc,
+ *     masking, chunk bookkeeping, RowConvolution, Xent's bookkeeping) stays restated from source, cited per fn: PARITY UNPINNED
+ *     for those parts.
  *
  * All matrices are row-major float with an explicit leading dimension (stride) in
  * elements; "rows = frames".  Each function cites the reference file:line it follows

@@ -1,0 +1,424 @@
+// gen_cumatrix_blas_golden.cpp -- TEST INFRASTRUCTURE.  Runs the REFERENCE's own CuMatrix / CuVector CPU branch (src/aslp-cudamatrix
+// with HAVE_CUDA undefined, on top of src/matrix) INCLUDING its BLAS-backed operations and writes inputs + outputs to
+// tests/golden/cumatrix_blas_ops.bin (same record format as gen_cumatrix_golden.cpp).
+//
+// The BLAS is a real one: the OpenBLAS build that ships inside this image's scipy wheel (scipy.libs/libscipy_openblas-*.so, LP64,
+// CBLAS + LAPACK).  That build exports every routine under a vendor prefix (scipy_cblas_sgemm, scipy_sgesvd_, ...); the Makefile
+// derives one -Dname=scipy_name per exported routine from `nm -D` of the library, so that the reference's sources (compiled where they
+// lie, with the CLAPACK headers of the reference tree) bind to it.  Nothing is written in place of a library or a header.
+//
+// Part 1 -- operations: AddMatMat in the four operand layouts (cu-matrix.cc:1027-1061 -> cblas_sgemm), ApplySoftMaxPerRow
+// (cu-matrix.cc:1351-1371 -> kaldi-vector.cc:852-859), CuVector::AddRowSumMat / AddColSumMat in float and double, the bias broadcasts
+// beyond 64 columns / rows (the cblas_sger branch of kaldi-matrix.cc:2749-2799), CuMatrix::AddRowSumMat (cu-matrix.cc:3010-3034).
+// Part 2 -- the op sequences of five components, issued by this driver against the reference's library in the order the component
+// headers issue them (those headers themselves need OpenFst's fst/fst-decl.h through nnet-utils.h and cannot be compiled here):
+// AffineTransform (nnet-affine-transform.h:186-245), BatchNormalization (nnet-batch-normalization.h:177-284), LstmProjectedStreams
+// (nnet-lstm-projected-streams.h:313-617), GruStreams (nnet-gru-streams.h:238-450), the two directions of BLstmProjectedStreamsLC
+// (nnet-blstm-projected-streams-lc.h:503-1040).  The sequences are this file's reading of those lines; the arithmetic of every step is
+// the reference's own.
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "aslp-cudamatrix/cu-math.h"
+#include "aslp-cudamatrix/cu-matrix.h"
+#include "aslp-cudamatrix/cu-vector.h"
+
+using namespace kaldi;
+typedef CuMatrix<float> Mat;
+typedef CuSubMatrix<float> Sub;
+typedef CuVector<float> Vec;
+
+static FILE *g_out;
+static void Put(const char *name, int rows, int cols, int kind, const void *data, int elem = 4) {
+  char nm[32];
+  std::memset(nm, 0, sizeof(nm));
+  std::strncpy(nm, name, 31);
+  std::fwrite(nm, 1, 32, g_out);
+  int32 hdr[3] = {rows, cols, kind};
+  std::fwrite(hdr, sizeof(int32), 3, g_out);
+  std::fwrite(data, elem, (size_t)rows * cols, g_out);
+}
+static void PutMat(const char *name, const CuMatrixBase<float> &m) {
+  Matrix<float> h(m.NumRows(), m.NumCols());
+  m.CopyToMat(&h);
+  std::vector<float> flat((size_t)h.NumRows() * h.NumCols());
+  for (int r = 0; r < h.NumRows(); r++) std::memcpy(&flat[(size_t)r * h.NumCols()], h.RowData(r), sizeof(float) * h.NumCols());
+  Put(name, h.NumRows(), h.NumCols(), 0, flat.data());
+}
+static void PutVec(const char *name, const CuVectorBase<float> &v) {
+  Vector<float> h(v.Dim());
+  v.CopyToVec(&h);
+  Put(name, 1, v.Dim(), 0, h.Data());
+}
+static void PutVecD(const char *name, const CuVectorBase<double> &v) {  // kind 2 = float64
+  Vector<double> h(v.Dim());
+  v.CopyToVec(&h);
+  Put(name, 1, v.Dim(), 2, h.Data(), 8);
+}
+
+static unsigned long long g_state = 0x9E3779B97F4A7C15ull;
+static float Uniform() {
+  g_state ^= g_state << 13; g_state ^= g_state >> 7; g_state ^= g_state << 17;
+  return (float)((g_state >> 40) * (1.0 / 16777216.0));
+}
+static void Fill(Mat *m, int rows, int cols, float lo, float hi) {
+  Matrix<float> h(rows, cols);
+  for (int r = 0; r < rows; r++)
+    for (int c = 0; c < cols; c++) h(r, c) = lo + (hi - lo) * Uniform();
+  m->Resize(rows, cols);
+  m->CopyFromMat(h);
+}
+static void FillVec(Vec *v, int n, float lo, float hi) {
+  Vector<float> h(n);
+  for (int i = 0; i < n; i++) h(i) = lo + (hi - lo) * Uniform();
+  v->Resize(n);
+  v->CopyFromVec(h);
+}
+
+static void Operations() {
+  {  // AddMatMat: C = alpha op(A) op(B) + beta C, all four layouts, two shapes (ragged; long reduction)
+    const int shapes[2][3] = {{67, 45, 83}, {33, 20, 1000}};
+    const char *lay[4] = {"nn", "nt", "tn", "tt"};
+    for (int s = 0; s < 2; s++) {
+      const int M = shapes[s][0], N = shapes[s][1], K = shapes[s][2];
+      for (int l = 0; l < 4; l++) {
+        const bool ta = l >= 2, tb = l & 1;
+        Mat A, B, Cm;
+        Fill(&A, ta ? K : M, ta ? M : K, -2.0f, 2.0f);
+        Fill(&B, tb ? N : K, tb ? K : N, -2.0f, 2.0f);
+        Fill(&Cm, M, N, -1.0f, 1.0f);
+        char nm[32];
+        std::snprintf(nm, 32, "gemm%d_%s_A", s, lay[l]); PutMat(nm, A);
+        std::snprintf(nm, 32, "gemm%d_%s_B", s, lay[l]); PutMat(nm, B);
+        std::snprintf(nm, 32, "gemm%d_%s_Cin", s, lay[l]); PutMat(nm, Cm);
+        Cm.AddMatMat(0.7f, A, ta ? kTrans : kNoTrans, B, tb ? kTrans : kNoTrans, 0.3f);
+        std::snprintf(nm, 32, "gemm%d_%s_Cout", s, lay[l]); PutMat(nm, Cm);
+      }
+    }
+  }
+  {  // softmax over rows, 300 classes, logits in [-9, 9] and one row with a dominating class
+    Mat x, y;
+    Fill(&x, 37, 300, -9.0f, 9.0f);
+    Matrix<float> h(37, 300); x.CopyToMat(&h);
+    h(5, 17) = 60.0f;
+    for (int c = 0; c < 300; c++) h(6, c) = 0.25f;   // uniform row
+    x.CopyFromMat(h);
+    PutMat("softmax_in", x);
+    y.Resize(37, 300);
+    y.ApplySoftMaxPerRow(x);
+    PutMat("softmax_out", y);
+  }
+  {  // column sums / row sums into vectors, float and double (the BatchNormalization statistics take the double ones)
+    Mat m;
+    Fill(&m, 200, 150, -3.0f, 5.0f); PutMat("sum_in", m);
+    Vec v; FillVec(&v, 150, -1.0f, 1.0f); PutVec("colsum_v_in", v);
+    v.AddRowSumMat(0.43f, m, 1.4f); PutVec("colsum_v_out", v);
+    Vec w; FillVec(&w, 200, -1.0f, 1.0f); PutVec("rowsum_v_in", w);
+    w.AddColSumMat(-0.6f, m, 0.5f); PutVec("rowsum_v_out", w);
+    CuVector<double> vd(150);
+    vd.AddRowSumMat(1.0, CuMatrix<double>(m), 1.0);
+    Mat sq(200, 150);
+    sq.AddMatMatElements(1.0, m, m, 0.0);
+    CuVector<double> vq(150);
+    vq.AddRowSumMat(1.0, CuMatrix<double>(sq), 1.0);
+    PutVecD("colsum_d", vd); PutVecD("colsumsq_d", vq);
+  }
+  {  // bias broadcasts beyond 64 columns / rows
+    Mat m, t;
+    Fill(&m, 90, 130, -2.0f, 2.0f); PutMat("bc_in", m);
+    Vec row, col;
+    FillVec(&row, 130, -3.0f, 3.0f); PutVec("bc_row", row);
+    FillVec(&col, 90, -3.0f, 3.0f); PutVec("bc_col", col);
+    t = m; t.AddVecToRows(0.5f, row, 1.0f); PutMat("add_vec_to_rows", t);
+    t = m; t.AddVecToRows(1.0f, row, 0.0f); PutMat("add_vec_to_rows_beta0", t);
+    t = m; t.AddVecToCols(-1.5f, col, 1.0f); PutMat("add_vec_to_cols", t);
+  }
+  {  // CuMatrix::AddRowSumMat (ASLP): dst row r = beta dst_r + alpha * sum of the r-th group of src rows
+    Mat src, dst;
+    Fill(&src, 21 * 7, 6, -2.0f, 2.0f); PutMat("grp_src", src);
+    Fill(&dst, 21, 6, -1.0f, 1.0f); PutMat("grp_dst_in", dst);
+    dst.AddRowSumMat(0.8f, src, 0.25f); PutMat("grp_dst_out", dst);
+  }
+}
+
+// AffineTransform: nnet-affine-transform.h:186-245 (Propagate, Backpropagate, Update with momentum, l2, max-norm), two minibatches
+static void Affine() {
+  const int rows = 70, din = 45, dout = 83;
+  const float lr = 0.02f, lr_bias = 0.02f * 0.5f, mmt = 0.9f, l2 = 1e-3f, max_norm = 0.9f;
+  Mat W, Wc(dout, din), in, out(rows, dout), od, id(rows, din);
+  Vec b, bc(dout);
+  Fill(&W, dout, din, -0.3f, 0.3f); FillVec(&b, dout, -1.0f, 1.0f);
+  PutMat("aff_W0", W); PutVec("aff_b0", b);
+  for (int step = 0; step < 2; step++) {
+    char nm[32];
+    Fill(&in, rows, din, -2.0f, 2.0f); Fill(&od, rows, dout, -1.0f, 1.0f);
+    std::snprintf(nm, 32, "aff_in%d", step); PutMat(nm, in);
+    std::snprintf(nm, 32, "aff_od%d", step); PutMat(nm, od);
+    out.SetZero();                                            // Component::Propagate clears the output first
+    out.AddVecToRows(1.0, b, 0.0);
+    out.AddMatMat(1.0, in, kNoTrans, W, kTrans, 1.0);
+    std::snprintf(nm, 32, "aff_out%d", step); PutMat(nm, out);
+    id.AddMatMat(1.0, od, kNoTrans, W, kNoTrans, 0.0);
+    std::snprintf(nm, 32, "aff_id%d", step); PutMat(nm, id);
+    Wc.AddMatMat(1.0, od, kTrans, in, kNoTrans, mmt);
+    bc.AddRowSumMat(1.0, od, mmt);
+    W.AddMat(-lr * l2 * rows, W);
+    W.AddMat(-lr, Wc);
+    b.AddVec(-lr_bias, bc);
+    {
+      Mat sq(W);
+      sq.MulElements(W);
+      Vec nrm(dout);
+      nrm.AddColSumMat(1.0, sq, 0.0);
+      nrm.ApplyPow(0.5);
+      Vec scl(nrm);
+      scl.Scale(1.0 / max_norm);
+      scl.ApplyFloor(1.0);
+      scl.InvertElements();
+      W.MulRowsVec(scl);
+    }
+    std::snprintf(nm, 32, "aff_W%d", step + 1); PutMat(nm, W);
+    std::snprintf(nm, 32, "aff_b%d", step + 1); PutVec(nm, b);
+    std::snprintf(nm, 32, "aff_Wc%d", step + 1); PutMat(nm, Wc);
+    std::snprintf(nm, 32, "aff_bc%d", step + 1); PutVec(nm, bc);
+  }
+}
+
+// BatchNormalization: nnet-batch-normalization.h:177-284, two minibatches (the running sums carry over, momentum on the second)
+static void BatchNorm() {
+  const int rows = 96, dim = 70;
+  const float var_floor = 1e-7f, mmt = 0.9f, lr = 0.05f;   // var_floor_: nnet-batch-normalization.h (member initialiser)
+  Vec scale, shift, mean(dim), var(dim), dmean(dim), dvar(dim), dshift(dim), dscale(dim);
+  CuVector<double> acc_m(dim), acc_v(dim);
+  FillVec(&scale, dim, 0.5f, 1.5f); FillVec(&shift, dim, -1.0f, 1.0f);
+  PutVec("bn_scale0", scale); PutVec("bn_shift0", shift);
+  Mat in, od, out(rows, dim), xs(rows, dim), e(rows, dim), id(rows, dim);
+  for (int step = 0; step < 2; step++) {
+    char nm[32];
+    Fill(&in, rows, dim, -1.5f, 2.5f); Fill(&od, rows, dim, -1.0f, 1.0f);
+    std::snprintf(nm, 32, "bn_in%d", step); PutMat(nm, in);
+    std::snprintf(nm, 32, "bn_od%d", step); PutMat(nm, od);
+    // forward :193-220
+    mean.AddRowSumMat(1.0 / rows, in, 0.0);
+    xs.CopyFromMat(in);
+    xs.AddVecToRows(-1.0, mean, 1.0);
+    out.AddMatMatElements(1.0, xs, xs, 0.0);
+    var.AddRowSumMat(1.0 / rows, out, 0.0);
+    var.Add(var_floor);
+    var.ApplyPow(0.5);
+    var.InvertElements();
+    xs.MulColsVec(var);
+    out.CopyFromMat(xs);
+    out.MulColsVec(scale);
+    out.AddVecToRows(1.0, shift, 1.0);
+    acc_m.AddRowSumMat(1.0, CuMatrix<double>(in), 1.0);
+    e.AddMatMatElements(1.0, in, in, 0.0);
+    acc_v.AddRowSumMat(1.0, CuMatrix<double>(e), 1.0);
+    std::snprintf(nm, 32, "bn_out%d", step); PutMat(nm, out);
+    std::snprintf(nm, 32, "bn_xhat%d", step); PutMat(nm, xs);
+    std::snprintf(nm, 32, "bn_mean%d", step); PutVec(nm, mean);
+    std::snprintf(nm, 32, "bn_invstd%d", step); PutVec(nm, var);
+    std::snprintf(nm, 32, "bn_accm%d", step); PutVecD(nm, acc_m);
+    std::snprintf(nm, 32, "bn_accv%d", step); PutVecD(nm, acc_v);
+    // backward :233-274
+    const float m_step = step == 0 ? 0.0f : mmt;
+    e.AddMatMatElements(1.0, xs, od, 0.0);
+    dscale.AddRowSumMat(1.0, e, m_step);
+    dshift.AddRowSumMat(1.0, od, m_step);
+    xs.CopyFromMat(od);
+    xs.MulColsVec(scale);
+    dvar.CopyFromVec(var);
+    dvar.ApplyPow(3);
+    dvar.Scale(-0.5);
+    e.CopyFromMat(in);
+    e.AddVecToRows(-1.0, mean, 1.0);
+    e.MulElements(xs);
+    e.MulColsVec(dvar);
+    dvar.AddRowSumMat(1.0, e, 0.0);
+    e.CopyFromMat(xs);
+    e.MulColsVec(var);
+    e.Scale(-1.0);
+    dmean.AddRowSumMat(1.0, e, 0.0);
+    e.CopyFromMat(in);
+    e.AddVecToRows(-1.0, mean);
+    e.Scale(2.0 / rows);
+    e.MulColsVec(dvar);
+    dmean.AddRowSumMat(-1.0, e, 1.0);
+    id.CopyFromMat(xs);
+    id.MulColsVec(var);
+    id.AddMat(1.0, e);
+    id.AddVecToRows(1.0 / rows, dmean, 1.0);
+    std::snprintf(nm, 32, "bn_id%d", step); PutMat(nm, id);
+    std::snprintf(nm, 32, "bn_dscale%d", step); PutVec(nm, dscale);
+    std::snprintf(nm, 32, "bn_dshift%d", step); PutVec(nm, dshift);
+    // update :280-284
+    scale.AddVec(-lr, dscale, 1.0);
+    shift.AddVec(-lr, dshift, 1.0);
+    std::snprintf(nm, 32, "bn_scale%d", step + 1); PutVec(nm, scale);
+    std::snprintf(nm, 32, "bn_shift%d", step + 1); PutVec(nm, shift);
+  }
+}
+
+// The projected-LSTM gate block: LstmProjectedStreams (nnet-lstm-projected-streams.h:313-617) = forward in time from a zero state;
+// BLstmProjectedStreamsLC (nnet-blstm-projected-streams-lc.h:503-1040) = one direction forward in time from the state carried out of the
+// previous chunk + one direction backward in time from zero.  Buffer columns g|i|f|o|c|h|m|r; row block t holds the S streams of
+// frame t; block 0 / T+1 are the boundaries (carried state or zero).  `tag` prefixes the record names.
+static void LstmProjected(const char *tag, bool reverse, bool carried) {
+  const int T = 5, S = 3, D = 6, C = 8, R = 5;
+  Mat Wx, Wr, Wrm, in, od;
+  Vec bias, pi, pf, po;
+  Fill(&Wx, 4 * C, D, -0.4f, 0.4f); Fill(&Wr, 4 * C, R, -0.4f, 0.4f); Fill(&Wrm, R, C, -0.4f, 0.4f);
+  FillVec(&bias, 4 * C, -0.3f, 0.3f); FillVec(&pi, C, -0.3f, 0.3f); FillVec(&pf, C, -0.3f, 0.3f); FillVec(&po, C, -0.3f, 0.3f);
+  Fill(&in, T * S, D, -1.5f, 1.5f); Fill(&od, T * S, R, -1.0f, 1.0f);
+  char nm[32];
+#define NAME(x) (std::snprintf(nm, 32, "%s_%s", tag, x), nm)
+  PutMat(NAME("Wx"), Wx); PutMat(NAME("Wr"), Wr); PutMat(NAME("Wrm"), Wrm); PutVec(NAME("bias"), bias);
+  PutVec(NAME("pi"), pi); PutVec(NAME("pf"), pf); PutVec(NAME("po"), po); PutMat(NAME("in"), in); PutMat(NAME("od"), od);
+  Mat Y((T + 2) * S, 7 * C + R), Dd((T + 2) * S, 7 * C + R);
+  if (carried) {   // f_propagate_buf_.RowRange(0, S).CopyFromMat(f_prev_nnet_state_): a whole row block of an earlier chunk
+    Mat st;
+    Fill(&st, S, 7 * C + R, -0.8f, 0.8f);
+    PutMat(NAME("state"), st);
+    Sub(Y, 0, S, 0, 7 * C + R).CopyFromMat(st);
+  }
+  enum { G, I, F, O, Cc, H, Mm };
+  struct View {
+    Mat &b; int C, R, S;
+    Sub gate(int k, int t) { return Sub(b, t * S, S, k * C, C); }
+    Sub rec(int t) { return Sub(b, t * S, S, 7 * C, R); }
+    Sub gifo(int t0, int n) { return Sub(b, t0 * S, n * S, 0, 4 * C); }
+    Sub cols(int k, int t0, int n) { return Sub(b, t0 * S, n * S, k * C, C); }
+    Sub recs(int t0, int n) { return Sub(b, t0 * S, n * S, 7 * C, R); }
+  } y = {Y, C, R, S}, d = {Dd, C, R, S};
+  const int step = reverse ? -1 : 1;      // the frame a step depends on is t - step, the one that depends on it t + step
+  y.gifo(1, T).AddMatMat(1.0, in, kNoTrans, Wx, kTrans, 0.0);
+  y.gifo(1, T).AddVecToRows(1.0, bias);
+  for (int n = 0, t = reverse ? T : 1; n < T; n++, t += step) {
+    const int p = t - step;
+    y.gifo(t, 1).AddMatMat(1.0, y.rec(p), kNoTrans, Wr, kTrans, 1.0);
+    y.gate(I, t).AddMatDiagVec(1.0, y.gate(Cc, p), kNoTrans, pi, 1.0);
+    y.gate(F, t).AddMatDiagVec(1.0, y.gate(Cc, p), kNoTrans, pf, 1.0);
+    y.gate(I, t).Sigmoid(y.gate(I, t));
+    y.gate(F, t).Sigmoid(y.gate(F, t));
+    y.gate(G, t).Tanh(y.gate(G, t));
+    y.gate(Cc, t).AddMatMatElements(1.0, y.gate(G, t), y.gate(I, t), 0.0);
+    y.gate(Cc, t).AddMatMatElements(1.0, y.gate(Cc, p), y.gate(F, t), 1.0);
+    y.gate(Cc, t).ApplyFloor(-50);
+    y.gate(Cc, t).ApplyCeiling(50);
+    y.gate(H, t).Tanh(y.gate(Cc, t));
+    y.gate(O, t).AddMatDiagVec(1.0, y.gate(Cc, t), kNoTrans, po, 1.0);
+    y.gate(O, t).Sigmoid(y.gate(O, t));
+    y.gate(Mm, t).AddMatMatElements(1.0, y.gate(H, t), y.gate(O, t), 0.0);
+    y.rec(t).AddMatMat(1.0, y.gate(Mm, t), kNoTrans, Wrm, kTrans, 0.0);
+  }
+  PutMat(NAME("fwd_buf"), Y);
+  d.recs(1, T).CopyFromMat(od);
+  for (int n = 0, t = reverse ? 1 : T; n < T; n++, t -= step) {
+    const int p = t - step, q = t + step;
+    d.rec(t).AddMatMat(1.0, d.gifo(q, 1), kNoTrans, Wr, kNoTrans, 1.0);
+    d.gate(Mm, t).AddMatMat(1.0, d.rec(t), kNoTrans, Wrm, kNoTrans, 0.0);
+    d.gate(H, t).AddMatMatElements(1.0, d.gate(Mm, t), y.gate(O, t), 0.0);
+    d.gate(H, t).DiffTanh(y.gate(H, t), d.gate(H, t));
+    d.gate(O, t).AddMatMatElements(1.0, d.gate(Mm, t), y.gate(H, t), 0.0);
+    d.gate(O, t).DiffSigmoid(y.gate(O, t), d.gate(O, t));
+    d.gate(Cc, t).AddMat(1.0, d.gate(H, t));
+    d.gate(Cc, t).AddMatMatElements(1.0, d.gate(Cc, q), y.gate(F, q), 1.0);
+    d.gate(Cc, t).AddMatDiagVec(1.0, d.gate(I, q), kNoTrans, pi, 1.0);
+    d.gate(Cc, t).AddMatDiagVec(1.0, d.gate(F, q), kNoTrans, pf, 1.0);
+    d.gate(Cc, t).AddMatDiagVec(1.0, d.gate(O, t), kNoTrans, po, 1.0);
+    d.gate(F, t).AddMatMatElements(1.0, d.gate(Cc, t), y.gate(Cc, p), 0.0);
+    d.gate(F, t).DiffSigmoid(y.gate(F, t), d.gate(F, t));
+    d.gate(I, t).AddMatMatElements(1.0, d.gate(Cc, t), y.gate(G, t), 0.0);
+    d.gate(I, t).DiffSigmoid(y.gate(I, t), d.gate(I, t));
+    d.gate(G, t).AddMatMatElements(1.0, d.gate(Cc, t), y.gate(I, t), 0.0);
+    d.gate(G, t).DiffTanh(y.gate(G, t), d.gate(G, t));
+  }
+  PutMat(NAME("bwd_buf"), Dd);
+  Mat id(T * S, D);
+  id.AddMatMat(1.0, d.gifo(1, T), kNoTrans, Wx, kNoTrans, 0.0);
+  PutMat(NAME("in_diff"), id);
+  // gradients (momentum 0, no clipping: clipping is ApplyFloor / ApplyCeiling, pinned in cumatrix_ops.bin); the frames a step
+  // depended on are the row blocks 0..T-1 (forward in time) or 2..T+1 (backward in time)
+  const int pb = reverse ? 2 : 0;
+  Mat gWx(4 * C, D), gWr(4 * C, R), gWrm(R, C);
+  Vec gb(4 * C), gpi(C), gpf(C), gpo(C);
+  gWx.AddMatMat(1.0, d.gifo(1, T), kTrans, in, kNoTrans, 0.0);
+  gWr.AddMatMat(1.0, d.gifo(1, T), kTrans, y.recs(pb, T), kNoTrans, 0.0);
+  gb.AddRowSumMat(1.0, d.gifo(1, T), 0.0);
+  gpi.AddDiagMatMat(1.0, d.cols(I, 1, T), kTrans, y.cols(Cc, pb, T), kNoTrans, 0.0);
+  gpf.AddDiagMatMat(1.0, d.cols(F, 1, T), kTrans, y.cols(Cc, pb, T), kNoTrans, 0.0);
+  gpo.AddDiagMatMat(1.0, d.cols(O, 1, T), kTrans, y.cols(Cc, 1, T), kNoTrans, 0.0);
+  gWrm.AddMatMat(1.0, d.recs(1, T), kTrans, y.cols(Mm, 1, T), kNoTrans, 0.0);
+  PutMat(NAME("gWx"), gWx); PutMat(NAME("gWr"), gWr); PutMat(NAME("gWrm"), gWrm); PutVec(NAME("gb"), gb);
+  PutVec(NAME("gpi"), gpi); PutVec(NAME("gpf"), gpf); PutVec(NAME("gpo"), gpo);
+#undef NAME
+}
+
+// GruStreams: nnet-gru-streams.h:238-450.  Buffer columns z|r|m|g|h; row blocks as above.
+static void Gru() {
+  const int T = 5, S = 3, D = 6, H = 7;
+  Mat Wx, Wh, Wg, in, od;
+  Vec bias;
+  Fill(&Wx, 3 * H, D, -0.4f, 0.4f); Fill(&Wh, 2 * H, H, -0.4f, 0.4f); Fill(&Wg, H, H, -0.4f, 0.4f); FillVec(&bias, 3 * H, -0.3f, 0.3f);
+  Fill(&in, T * S, D, -1.5f, 1.5f); Fill(&od, T * S, H, -1.0f, 1.0f);
+  PutMat("gru_Wx", Wx); PutMat("gru_Wh", Wh); PutMat("gru_Wg", Wg); PutVec("gru_bias", bias); PutMat("gru_in", in); PutMat("gru_od", od);
+  Mat Y((T + 2) * S, 5 * H), Dd((T + 2) * S, 5 * H);
+  enum { Z, Rr, Mm, G, Hh };
+  struct View {
+    Mat &b; int H, S;
+    Sub col(int k, int t, int n = 1, int w = 1) { return Sub(b, t * S, n * S, k * H, w * H); }
+  } y = {Y, H, S}, d = {Dd, H, S};
+  y.col(Z, 1, T, 3).AddMatMat(1.0, in, kNoTrans, Wx, kTrans, 0.0);
+  y.col(Z, 1, T, 3).AddVecToRows(1.0, bias);
+  for (int t = 1; t <= T; t++) {
+    y.col(Z, t, 1, 2).AddMatMat(1.0, y.col(Hh, t - 1), kNoTrans, Wh, kTrans, 1.0);
+    y.col(Z, t, 1, 2).Sigmoid(y.col(Z, t, 1, 2));
+    y.col(G, t).AddMatMatElements(1.0, y.col(Rr, t), y.col(Hh, t - 1), 0.0);
+    y.col(Mm, t).AddMatMat(1.0, y.col(G, t), kNoTrans, Wg, kTrans, 1.0);
+    y.col(Mm, t).Tanh(y.col(Mm, t));
+    y.col(Hh, t).AddMat(1.0, y.col(Hh, t - 1));
+    y.col(Hh, t).AddMatMatElements(-1.0, y.col(Hh, t - 1), y.col(Z, t), 1.0);
+    y.col(Hh, t).AddMatMatElements(1.0, y.col(Z, t), y.col(Mm, t), 1.0);
+  }
+  PutMat("gru_fwd_buf", Y);
+  d.col(Hh, 1, T).CopyFromMat(od);
+  for (int t = T; t >= 1; t--) {
+    d.col(Hh, t).AddMatMat(1.0, d.col(Z, t + 1, 1, 2), kNoTrans, Wh, kNoTrans, 1.0);
+    d.col(Hh, t).AddMat(1.0, d.col(Hh, t + 1));
+    d.col(Hh, t).AddMatMatElements(-1.0, d.col(Hh, t + 1), y.col(Z, t + 1), 1.0);
+    d.col(Hh, t).AddMatMatElements(1.0, d.col(G, t + 1), y.col(Rr, t + 1), 1.0);
+    d.col(Mm, t).AddMatMatElements(1.0, d.col(Hh, t), y.col(Z, t), 0.0);
+    d.col(Mm, t).DiffTanh(y.col(Mm, t), d.col(Mm, t));
+    d.col(G, t).AddMatMat(1.0, d.col(Mm, t), kNoTrans, Wg, kNoTrans, 0.0);
+    d.col(Rr, t).AddMatMatElements(1.0, d.col(G, t), y.col(Hh, t - 1), 0.0);
+    d.col(Rr, t).DiffSigmoid(y.col(Rr, t), d.col(Rr, t));
+    d.col(Z, t).AddMatMatElements(1.0, d.col(Hh, t), y.col(Mm, t), 0.0);
+    d.col(Z, t).AddMatMatElements(-1.0, d.col(Hh, t), y.col(Hh, t - 1), 1.0);
+    d.col(Z, t).DiffSigmoid(y.col(Z, t), d.col(Z, t));
+  }
+  PutMat("gru_bwd_buf", Dd);
+  Mat id(T * S, D), gWx(3 * H, D), gWh(2 * H, H), gWg(H, H);
+  Vec gb(3 * H);
+  id.AddMatMat(1.0, d.col(Z, 1, T, 3), kNoTrans, Wx, kNoTrans, 0.0);
+  gWx.AddMatMat(1.0, d.col(Z, 1, T, 3), kTrans, in, kNoTrans, 0.0);
+  gb.AddRowSumMat(1.0, d.col(Z, 1, T, 3), 0.0);
+  gWh.AddMatMat(1.0, d.col(Z, 1, T, 2), kTrans, y.col(Hh, 0, T), kNoTrans, 0.0);
+  gWg.AddMatMat(1.0, d.col(Mm, 1, T), kTrans, y.col(G, 1, T), kNoTrans, 0.0);
+  PutMat("gru_in_diff", id); PutMat("gru_gWx", gWx); PutMat("gru_gWh", gWh); PutMat("gru_gWg", gWg); PutVec("gru_gb", gb);
+}
+
+int main(int argc, char **argv) {
+  if (argc != 2) { std::fprintf(stderr, "usage: %s <out.bin>\n", argv[0]); return 1; }
+  g_out = std::fopen(argv[1], "wb");
+  if (!g_out) return 1;
+  Operations();
+  Affine();
+  BatchNorm();
+  LstmProjected("lstm", false, false);
+  Gru();
+  LstmProjected("lcf", false, true);    // appended after the records above: those stay byte-identical
+  LstmProjected("lcb", true, false);
+  std::fclose(g_out);
+  return 0;
+}

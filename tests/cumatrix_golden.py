@@ -8,14 +8,25 @@ import numpy as np
 PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cumatrix_ops.bin")
 
 
-def load():
-    b = open(PATH, "rb").read()
+BLAS_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cumatrix_blas_ops.bin")
+
+
+def load_blas():
+    """tests/golden/cumatrix_blas_ops.bin: the same CPU branch linked against the OpenBLAS inside the image's scipy wheel (generator
+    oracle/gen_cumatrix_blas_golden.cpp): BLAS-backed operations and the op sequences of AffineTransform, BatchNormalization and
+    LstmProjectedStreams issued against the reference's library.  kind 2 = float64; one-row records are vectors."""
+    return {k: (v[0] if v.ndim == 2 and v.shape[0] == 1 else v) for k, v in load(BLAS_PATH).items()}
+
+
+def load(path=PATH):
+    b = open(path, "rb").read()
     out, p = {}, 0
     while p < len(b):
         name = b[p:p + 32].split(b"\0")[0].decode()
         r, c, kind = struct.unpack("<iii", b[p + 32:p + 44])
         p += 44
-        a = np.frombuffer(b[p:p + 4 * r * c], np.int32 if kind else np.float32).reshape(r, c).copy()
-        p += 4 * r * c
+        esz = 8 if kind == 2 else 4
+        a = np.frombuffer(b[p:p + esz * r * c], (np.float32, np.int32, np.float64)[kind]).reshape(r, c).copy()
+        p += esz * r * c
         out[name] = a[0] if kind else a
     return out

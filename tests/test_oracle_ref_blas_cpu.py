@@ -1,0 +1,142 @@
+"""The C oracle against the REFERENCE's own CuMatrix / CuVector CPU branch linked to a real BLAS (tests/golden/cumatrix_blas_ops.bin,
+generator oracle/gen_cumatrix_blas_golden.cpp; the BLAS is the OpenBLAS inside the image's scipy wheel).  Pins what
+tests/golden/cumatrix_ops.bin could not reach: the product (row a1), softmax (a4), the column / row sums incl. the double ones of
+BatchNormalization, the wide bias broadcasts -- and the oracle's AffineTransform (a2), BatchNormalization (a7) and projected-LSTM
+(a8 / a9: the gate block all family members share) chains against the same op sequences issued on the reference's library.
+Tolerance: where a BLAS reduction is involved the summation order differs, so those records are compared with the reference's own
+AssertEqual metric (relative Frobenius error, cu-matrix.h:803-811) at 2e-6 for the bare products and element-wise at 2e-5 of
+max(1, |ref|) for the short chains; 1e-6 element-wise otherwise; the bar is 1e-4."""
+import ctypes as C
+
+import numpy as np
+
+import cumatrix_golden
+
+
+def close(a, b, tol):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))) <= tol
+
+
+def test_blas_backed_operations(oracle):
+    g = cumatrix_golden.load_blas()
+    for s in (0, 1):
+        for lay, ta, tb in (("nn", 0, 0), ("nt", 0, 1), ("tn", 1, 0), ("tt", 1, 1)):
+            k = "gemm%d_%s_" % (s, lay)
+            out = oracle.add_mat_mat(g[k + "Cin"], 0.7, g[k + "A"], ta, g[k + "B"], tb, 0.3)
+            assert oracle.rel_err(out, g[k + "Cout"]) < 2e-6, k
+    y = oracle.unary("orc_softmax_rows", g["softmax_in"])
+    assert close(y, g["softmax_out"], 1e-6)
+    assert abs(g["softmax_out"][5, 17] - 1.0) < 1e-6 and np.allclose(g["softmax_out"][6], 1.0 / 300, rtol=1e-6)
+    m = g["sum_in"]
+    # CuVector::AddRowSumMat / AddColSumMat: v = beta v + alpha * column (row) sums
+    assert close(1.4 * g["colsum_v_in"] + 0.43 * m.astype(np.float64).sum(0), g["colsum_v_out"], 2e-5)
+    assert close(0.5 * g["rowsum_v_in"] - 0.6 * m.astype(np.float64).sum(1), g["rowsum_v_out"], 2e-5)
+    assert np.allclose(m.astype(np.float64).sum(0), g["colsum_d"], rtol=1e-13)
+    assert np.allclose((m * m).astype(np.float64).sum(0), g["colsumsq_d"], rtol=1e-13)   # squares rounded to float first
+    L, c32 = oracle.lib, oracle.c32
+    cp = lambda a: np.array(a, dtype=np.float32, order="C", copy=True)
+    r, c = g["bc_in"].shape
+    d = cp(g["bc_in"]); L.orc_add_vec_to_rows(d, c, c32(g["bc_row"]), r, c, 0.5); assert close(d, g["add_vec_to_rows"], 1e-6)
+    d = cp(g["bc_in"]); L.orc_add_vec_to_cols(d, c, c32(g["bc_col"]), r, c, -1.5); assert close(d, g["add_vec_to_cols"], 1e-6)
+    assert np.array_equal(g["add_vec_to_rows_beta0"], np.broadcast_to(g["bc_row"], (r, c)))
+    d = cp(g["grp_dst_in"])
+    L.orc_add_row_sum_mat(d, d.shape[1], d.shape[0], d.shape[1], c32(g["grp_src"]), d.shape[1], g["grp_src"].shape[0], 0.8, 0.25)
+    assert close(d, g["grp_dst_out"], 2e-6)
+
+
+def test_affine_chain_matches_reference_library(oracle):
+    """nnet-affine-transform.h:186-245 with momentum 0.9, l2 1e-3, bias-learn-rate-coef 0.5, max-norm 0.9, two minibatches."""
+    g = cumatrix_golden.load_blas()
+    L, c32 = oracle.lib, oracle.c32
+    W = np.array(g["aff_W0"], np.float32, copy=True); b = np.array(g["aff_b0"], np.float32, copy=True)
+    dout, din = W.shape
+    Wc = np.zeros_like(W); bc = np.zeros_like(b)
+    o = oracle.AffineOpts(0.02, 0.9, 1e-3, 0.0, 1.0, 0.5, 0.9)
+    for step in (0, 1):
+        x, od = g["aff_in%d" % step], g["aff_od%d" % step]
+        rows = x.shape[0]
+        out = np.zeros((rows, dout), np.float32)
+        L.orc_affine_propagate(out, dout, c32(x), din, rows, W, din, b, din, dout)
+        assert close(out, g["aff_out%d" % step], 2e-5)
+        idf = np.zeros((rows, din), np.float32)
+        L.orc_affine_backpropagate(idf, din, c32(od), dout, rows, W, din, din, dout)
+        assert close(idf, g["aff_id%d" % step], 2e-5)
+        L.orc_affine_update(W, din, b, Wc, din, bc, c32(x), din, c32(od), dout, rows, din, dout, C.byref(o))
+        assert close(Wc, g["aff_Wc%d" % (step + 1)], 2e-5) and close(bc, g["aff_bc%d" % (step + 1)], 2e-5)
+        assert close(W, g["aff_W%d" % (step + 1)], 2e-5) and close(b, g["aff_b%d" % (step + 1)], 2e-5)
+    nrm = np.sqrt((g["aff_W2"].astype(np.float64) ** 2).sum(1))
+    assert nrm.max() <= 0.9 * (1 + 1e-5) and (nrm > 0.9 * (1 - 1e-5)).sum() > 0   # the max-norm branch did shrink some rows
+
+
+def test_batchnorm_chain_matches_reference_library(oracle):
+    """nnet-batch-normalization.h:177-284, two minibatches: running sums in double, momentum on the second gradient."""
+    g = cumatrix_golden.load_blas()
+    dim = g["bn_scale0"].shape[0]
+    bn = oracle.Bn(dim)
+    bn.scale[:] = g["bn_scale0"]; bn.shift[:] = g["bn_shift0"]
+    for step in (0, 1):
+        x, od = g["bn_in%d" % step], g["bn_od%d" % step]
+        out = bn.propagate(x)
+        assert close(out, g["bn_out%d" % step], 1e-5)
+        assert close(bn.xs, g["bn_xhat%d" % step], 1e-5)
+        assert close(bn.mean, g["bn_mean%d" % step], 2e-6) and close(bn.var, g["bn_invstd%d" % step], 1e-5)
+        assert np.allclose(bn.acc_means, g["bn_accm%d" % step], rtol=1e-12) and np.allclose(bn.acc_vars, g["bn_accv%d" % step], rtol=1e-12)
+        idf = bn.backpropagate(x, od, 0.0 if step == 0 else 0.9)
+        assert close(idf, g["bn_id%d" % step], 2e-5)
+        assert close(bn.dscale, g["bn_dscale%d" % step], 2e-5) and close(bn.dshift, g["bn_dshift%d" % step], 2e-5)
+        bn.update(0.05)
+        assert close(bn.scale, g["bn_scale%d" % (step + 1)], 2e-5) and close(bn.shift, g["bn_shift%d" % (step + 1)], 2e-5)
+
+
+import pytest
+
+
+@pytest.mark.parametrize("tag,reverse,carried", [("lstm", False, False), ("lcf", False, True), ("lcb", True, False)])
+def test_projected_lstm_chain_matches_reference_library(oracle, tag, reverse, carried):
+    """The projected-LSTM gate block: forward buffer (g|i|f|o|c|h|m|r of every frame), backward buffer, input diff and the seven
+    gradients (momentum 0, no clipping) of T = 5 frames x S = 3 streams.  `lstm` = LstmProjectedStreams (nnet-lstm-projected-streams.h:
+    313-617); `lcf` / `lcb` = the two directions of BLstmProjectedStreamsLC (nnet-blstm-projected-streams-lc.h:503-1040): forward in time
+    from a carried state, backward in time from zero."""
+    g = {k[len(tag) + 1:]: v for k, v in cumatrix_golden.load_blas().items() if k.startswith(tag + "_")}
+    Wx, Wr = g["Wx"], g["Wr"]
+    Cc, D, R = Wx.shape[0] // 4, Wx.shape[1], Wr.shape[1]
+    x, od = g["in"], g["od"]
+    S = 3
+    T = x.shape[0] // S
+    d = oracle.LstmDir(D, Cc, R, False, zero=True)
+    names = (("w_x", "Wx"), ("w_r", "Wr"), ("w_rm", "Wrm"), ("bias", "bias"), ("peep_i", "pi"), ("peep_f", "pf"), ("peep_o", "po"))
+    for n, k in names:
+        getattr(d, n)[...] = g[k]
+    buf = d.forward(x, T, S, reverse=reverse, init_state=g["state"] if carried else None)
+    assert buf.shape == g["fwd_buf"].shape
+    assert close(buf[S:(T + 1) * S], g["fwd_buf"][S:(T + 1) * S], 2e-6)
+    dbuf, idf = d.backward(od, T, S, buf, reverse=reverse)
+    assert close(dbuf[S:(T + 1) * S], g["bwd_buf"][S:(T + 1) * S], 5e-6)
+    assert close(idf, g["in_diff"], 5e-6)
+    gr = oracle.LstmDir(D, Cc, R, False, zero=True)
+    d.grads(gr, x, T, S, buf, dbuf, 0.0, 0.0, reverse=reverse)
+    for n, k in names:
+        assert close(getattr(gr, n), g["g" + ("b" if k == "bias" else k)], 5e-6), n
+
+
+def test_gru_chain_matches_reference_library(oracle):
+    """nnet-gru-streams.h:238-450: forward buffer (z|r|m|g|h), backward buffer, input diff and the four gradients."""
+    g = cumatrix_golden.load_blas()
+    H, D = g["gru_Wg"].shape[0], g["gru_Wx"].shape[1]
+    x, od = g["gru_in"], g["gru_od"]
+    S = 3
+    T = x.shape[0] // S
+    u = oracle.Gru(D, H, zero=True)
+    for n, k in (("w_zrm_x", "gru_Wx"), ("w_zr_h", "gru_Wh"), ("w_m_g", "gru_Wg"), ("bias", "gru_bias")):
+        getattr(u, n)[...] = g[k]
+    buf = u.forward(x, T, S)
+    assert close(buf[S:(T + 1) * S], g["gru_fwd_buf"][S:(T + 1) * S], 2e-6)
+    dbuf, idf = u.backward(od, T, S, buf)
+    assert close(dbuf[S:(T + 1) * S], g["gru_bwd_buf"][S:(T + 1) * S], 5e-6)
+    assert close(idf, g["gru_in_diff"], 5e-6)
+    gr = oracle.Gru(D, H, zero=True)
+    u.grads(gr, x, T, S, buf, dbuf, 0.0, 0.0)
+    for n, k in (("w_zrm_x", "gru_gWx"), ("w_zr_h", "gru_gWh"), ("w_m_g", "gru_gWg"), ("bias", "gru_gb")):
+        assert close(getattr(gr, n), g[k], 5e-6), n

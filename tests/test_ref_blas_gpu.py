@@ -1,0 +1,134 @@
+"""The HIP engine against outputs of the REFERENCE's own CuMatrix / CuVector CPU branch linked to a real BLAS
+(tests/golden/cumatrix_blas_ops.bin, generator oracle/gen_cumatrix_blas_golden.cpp): the product in four layouts, softmax, the column
+sums, BatchNormalization forward / backward over two minibatches, and the AffineTransform / LstmProjectedStreams / GruStreams
+components driven through the C ABI on the fixture's weights -- no oracle in between.  Tolerances as in
+tests/test_oracle_ref_blas_cpu.py (the bar is 1e-4)."""
+import numpy as np
+import pytest
+import torch
+
+import cumatrix_golden
+import nnet_io
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, tol):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))) <= tol
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.linalg.norm(a - b) / np.linalg.norm(b)
+
+
+def T(a, dev, dt=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(dt)
+
+
+def test_kernels_match_reference_blas_branch(aslp, dev):
+    g = cumatrix_golden.load_blas()
+    ops = aslp.ops
+    for s in (0, 1):
+        for lay, ta, tb in (("nn", 0, 0), ("nt", 0, 1), ("tn", 1, 0), ("tt", 1, 1)):
+            k = "gemm%d_%s_" % (s, lay)
+            c = T(g[k + "Cin"], dev)
+            ops.sgemm(ta, tb, 0.7, T(g[k + "A"], dev), T(g[k + "B"], dev), 0.3, c)
+            assert rel(c.cpu().numpy(), g[k + "Cout"]) < 2e-6, k
+    x = T(g["softmax_in"], dev)
+    y = torch.empty_like(x)
+    ops.softmax(y, x)
+    assert close(y.cpu().numpy(), g["softmax_out"], 1e-6)
+    v = T(g["colsum_v_in"], dev)
+    ops.add_row_sum_mat_vec(0.43, T(g["sum_in"], dev), 1.4, v)
+    assert close(v.cpu().numpy(), g["colsum_v_out"], 2e-5)
+
+
+def test_batchnorm_kernels_match_reference_library(aslp, dev):
+    """nnet-batch-normalization.h:177-284 as the reference's library computes it, two minibatches."""
+    g = cumatrix_golden.load_blas()
+    ops = aslp.ops
+    dim = g["bn_scale0"].shape[0]
+    accm = torch.zeros(dim, dtype=torch.float64, device=dev)
+    accv = torch.zeros(dim, dtype=torch.float64, device=dev)
+    dsc, dsh = torch.zeros(dim, device=dev), torch.zeros(dim, device=dev)
+    for step in (0, 1):
+        x, od = T(g["bn_in%d" % step], dev), T(g["bn_od%d" % step], dev)
+        scale, shift = T(g["bn_scale%d" % step], dev), T(g["bn_shift%d" % step], dev)
+        out, xhat = torch.empty_like(x), torch.empty_like(x)
+        mean, inv = torch.empty(dim, device=dev), torch.empty(dim, device=dev)
+        ops.bn_forward(x, out, xhat, scale, shift, mean, inv, accm, accv)
+        assert close(out.cpu().numpy(), g["bn_out%d" % step], 1e-5)
+        assert close(mean.cpu().numpy(), g["bn_mean%d" % step], 2e-6) and close(inv.cpu().numpy(), g["bn_invstd%d" % step], 1e-5)
+        assert np.allclose(accm.cpu().numpy(), g["bn_accm%d" % step], rtol=1e-12) and np.allclose(accv.cpu().numpy(), g["bn_accv%d" % step], rtol=1e-12)
+        idf = torch.empty_like(x)
+        ops.bn_backward(x, od, xhat, scale, mean, inv, dsc, dsh, 0.0 if step == 0 else 0.9, idf)
+        assert close(idf.cpu().numpy(), g["bn_id%d" % step], 2e-5)
+        assert close(dsc.cpu().numpy(), g["bn_dscale%d" % step], 2e-5) and close(dsh.cpu().numpy(), g["bn_dshift%d" % step], 2e-5)
+
+
+def test_affine_component_matches_reference_library(aslp, dev, tmp_path):
+    """nnet-affine-transform.h:186-245 with momentum 0.9, l2 1e-3, bias-learn-rate-coef 0.5, <MaxNorm> 0.9, two minibatches."""
+    g = cumatrix_golden.load_blas()
+    W, b = g["aff_W0"], g["aff_b0"]
+    dout, din = W.shape
+    path = tmp_path / "aff.nnet"
+    nnet_io.write_simple_nnet(path, [("<AffineTransform>", din, dout, nnet_io.affine(W, b, 1.0, 0.5, 0.9))])
+    net = aslp.Nnet.Read(path)
+    net.SetTrainOptions(learn_rate=0.02, momentum=0.9, l2_penalty=1e-3, l1_penalty=0.0)
+    for step in (0, 1):
+        out = net.Propagate(T(g["aff_in%d" % step], dev)).cpu().numpy()
+        assert close(out, g["aff_out%d" % step], 2e-5)
+        idf = net.Backpropagate(T(g["aff_od%d" % step], dev), want_in_diff=True).cpu().numpy()
+        assert close(idf, g["aff_id%d" % step], 2e-5)
+        ref = np.concatenate([g["aff_W%d" % (step + 1)].ravel(), g["aff_b%d" % (step + 1)]])
+        assert close(net.GetParams(), ref, 2e-5), step
+
+
+def test_projected_lstm_component_matches_reference_library(aslp, oracle, dev, tmp_path):
+    """nnet-lstm-projected-streams.h:313-617: output r(1..T), input diff, and parameters after one step (learn rate 0.1, momentum 0, no
+    clipping) = W - 0.1 * the reference library's gradients."""
+    g = {k[5:]: v for k, v in cumatrix_golden.load_blas().items() if k.startswith("lstm_")}
+    Cc, D, R = g["Wx"].shape[0] // 4, g["Wx"].shape[1], g["Wr"].shape[1]
+    S = 3
+    Tn = g["in"].shape[0] // S
+    d = oracle.LstmDir(D, Cc, R, False, zero=True)   # container of the fixture's tensors for the model writer (no oracle arithmetic runs)
+    names = (("w_x", "Wx"), ("w_r", "Wr"), ("bias", "bias"), ("peep_i", "pi"), ("peep_f", "pf"), ("peep_o", "po"), ("w_rm", "Wrm"))
+    for n, k in names:
+        getattr(d, n)[...] = g[k]
+    path = tmp_path / "lstm.nnet"
+    nnet_io.write_simple_nnet(path, [("<LstmProjectedStreams>", D, R, nnet_io.lstm([d], 0.0, Cc))])
+    net = aslp.Nnet.Read(path)
+    net.SetTrainOptions(learn_rate=0.1, momentum=0.0)
+    net.ResetLstmStreams([1] * S)
+    out = net.Propagate(T(g["in"], dev)).cpu().numpy()
+    assert close(out, g["fwd_buf"][S:(Tn + 1) * S, 7 * Cc:], 2e-6)
+    idf = net.Backpropagate(T(g["od"], dev), want_in_diff=True).cpu().numpy()
+    assert close(idf, g["in_diff"], 5e-6)
+    ref = np.concatenate([(g[k] - 0.1 * g["g" + ("b" if k == "bias" else k)]).ravel() for _, k in names])
+    assert close(net.GetParams(), ref, 5e-6)
+
+
+def test_gru_component_matches_reference_library(aslp, oracle, dev, tmp_path):
+    """nnet-gru-streams.h:238-450: output h(1..T), input diff, parameters after one step."""
+    g = {k[4:]: v for k, v in cumatrix_golden.load_blas().items() if k.startswith("gru_")}
+    H, D = g["Wg"].shape[0], g["Wx"].shape[1]
+    S = 3
+    Tn = g["in"].shape[0] // S
+    u = oracle.Gru(D, H, zero=True)
+    names = (("w_zrm_x", "Wx"), ("w_zr_h", "Wh"), ("w_m_g", "Wg"), ("bias", "bias"))
+    for n, k in names:
+        getattr(u, n)[...] = g[k]
+    path = tmp_path / "gru.nnet"
+    nnet_io.write_simple_nnet(path, [("<GruStreams>", D, H, nnet_io.gru(u, 0.0))])
+    net = aslp.Nnet.Read(path)
+    net.SetTrainOptions(learn_rate=0.1, momentum=0.0)
+    net.ResetLstmStreams([1] * S)
+    out = net.Propagate(T(g["in"], dev)).cpu().numpy()
+    assert close(out, g["fwd_buf"][S:(Tn + 1) * S, 4 * H:], 2e-6)
+    idf = net.Backpropagate(T(g["od"], dev), want_in_diff=True).cpu().numpy()
+    assert close(idf, g["in_diff"], 5e-6)
+    ref = np.concatenate([(g[k] - 0.1 * g["g" + ("b" if k == "bias" else k)]).ravel() for _, k in names])
+    assert close(net.GetParams(), ref, 5e-6)
