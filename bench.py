@@ -356,6 +356,7 @@ def main():
     ap.add_argument("--no-update-overlap", action="store_true",
                     help="keep the weight-gradient GEMMs on the main stream (per-kernel profiles: every kernel alone on the chip)")
     ap.add_argument("--no-cfg3", action="store_true", help="skip the LC-BLSTM (BASELINE cfg3) block of the JSON line")
+    ap.add_argument("--cfg3-bsp-timeout", type=int, default=240, help="N > 1: seconds the extra cfg3_bsp block may take before it is dropped")
     ap.add_argument("--dry-run-ranks", action="store_true", help=argparse.SUPPRESS)   # launcher plumbing test (no GPU): tests/test_bench_cpu.py
     args = ap.parse_args()
 
@@ -529,9 +530,32 @@ def main():
             worker = None
         net = None
         torch.cuda.empty_cache()
-        blk = cfg3_bsp_block(aslp, dev, native_parallel, comm, rank, world, args.sync_period)
+        # The headline above is already measured: this extra block must not be able to take it down.  A watchdog ends the
+        # process with the line printed if the block has not come back (a rank that died inside it leaves the others in a
+        # collective); an exception on this rank is recorded instead of raised.
+        import threading
+
+        def bail():
+            if rank == 0:
+                out["cfg3_bsp"] = {"error": "did not finish within %d s; dropped" % args.cfg3_bsp_timeout}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(args.cfg3_bsp_timeout, bail)
+        dog.daemon = True
+        dog.start()
+        try:
+            blk = cfg3_bsp_block(aslp, dev, native_parallel, comm, rank, world, args.sync_period)
+        except Exception as e:   # noqa: BLE001 -- reported in the line, never silent
+            blk = {"error": "%s: %s" % (type(e).__name__, e)}
+        if "error" not in blk:
+            dog.cancel()         # (after an error the other ranks may be stuck: let the watchdog end this rank too)
         if rank == 0:
             out["cfg3_bsp"] = blk
+        if "error" in blk:
+            if rank == 0:
+                print(json.dumps(out), flush=True)
+            os._exit(0)
     if comm is not None:
         comm.Barrier()
         if worker is not None:

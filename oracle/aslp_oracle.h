@@ -14,12 +14,12 @@
  *   - substrate ops: pinned against outputs of the reference's own CuMatrix CPU branch, built where it lies:
  *     tests/golden/cumatrix_ops.bin (BLAS-free operations) and tests/golden/cumatrix_blas_ops.bin (the BLAS-backed ones, linked
  *     against the OpenBLAS inside the image's scipy wheel: product, softmax, column / row sums, wide broadcasts).
- *   - Component level: AffineTransform, BatchNormalization, the projected-LSTM gate block (LstmProjectedStreams and both directions
- *     of BLstmProjectedStreamsLC) and GruStreams are pinned against their op sequences issued on the reference's library
- *     (oracle/gen_cumatrix_blas_golden.cpp, tests/test_oracle_ref_blas_cpu.py).  The component headers themselves need OpenFst
- *     and cannot be compiled here, so control flow that lives only there (CIFG, Lstm / BLstm of nnet-recurrent-component.cc,
- *     masking, chunk bookkeeping, RowConvolution, Xent's bookkeeping) stays restated from source, cited per fn: PARITY UNPINNED
- *     for those parts.
+ *   - Component level: AffineTransform, BatchNormalization, every LSTM gate block (LstmProjectedStreams, both directions of
+ *     BLstmProjectedStreamsLC, LstmCifgProjectedStreams, Lstm / BLstm), GruStreams, RowConvolution and CompactFsmn are pinned
+ *     against their op sequences issued on the reference's library (oracle/gen_cumatrix_blas_golden.cpp,
+ *     tests/test_oracle_ref_blas_cpu.py).  The component headers themselves need OpenFst and cannot be compiled here, so
+ *     control flow that lives only there (sequence-length masking, chunk / stream-reset bookkeeping, Xent's bookkeeping) stays
+ *     restated from source, cited per fn: PARITY UNPINNED for those parts.
  *
  * All matrices are row-major float with an explicit leading dimension (stride) in
  * elements; "rows = frames".  Each function cites the reference file:line it follows

@@ -10,11 +10,12 @@
 // Part 1 -- operations: AddMatMat in the four operand layouts (cu-matrix.cc:1027-1061 -> cblas_sgemm), ApplySoftMaxPerRow
 // (cu-matrix.cc:1351-1371 -> kaldi-vector.cc:852-859), CuVector::AddRowSumMat / AddColSumMat in float and double, the bias broadcasts
 // beyond 64 columns / rows (the cblas_sger branch of kaldi-matrix.cc:2749-2799), CuMatrix::AddRowSumMat (cu-matrix.cc:3010-3034).
-// Part 2 -- the op sequences of five components, issued by this driver against the reference's library in the order the component
+// Part 2 -- the op sequences of the components, issued by this driver against the reference's library in the order the component
 // headers issue them (those headers themselves need OpenFst's fst/fst-decl.h through nnet-utils.h and cannot be compiled here):
 // AffineTransform (nnet-affine-transform.h:186-245), BatchNormalization (nnet-batch-normalization.h:177-284), LstmProjectedStreams
 // (nnet-lstm-projected-streams.h:313-617), GruStreams (nnet-gru-streams.h:238-450), the two directions of BLstmProjectedStreamsLC
-// (nnet-blstm-projected-streams-lc.h:503-1040).  The sequences are this file's reading of those lines; the arithmetic of every step is
+// (nnet-blstm-projected-streams-lc.h:503-1040), LstmCifgProjectedStreams (nnet-lstm-couple-if-projected-streams.h), Lstm / BLstm (nnet-recurrent-component.cc),
+// RowConvolution (nnet-row-convolution.cc:90-169), CompactFsmn (nnet-cfsmn-component.h:169-264).  The sequences are this file's reading of those lines; the arithmetic of every step is
 // the reference's own.
 #include <cstdio>
 #include <cstring>
@@ -264,45 +265,59 @@ static void BatchNorm() {
 // BLstmProjectedStreamsLC (nnet-blstm-projected-streams-lc.h:503-1040) = one direction forward in time from the state carried out of the
 // previous chunk + one direction backward in time from zero.  Buffer columns g|i|f|o|c|h|m|r; row block t holds the S streams of
 // frame t; block 0 / T+1 are the boundaries (carried state or zero).  `tag` prefixes the record names.
-static void LstmProjected(const char *tag, bool reverse, bool carried) {
-  const int T = 5, S = 3, D = 6, C = 8, R = 5;
+static void LstmProjected(const char *tag, bool reverse, bool carried, bool cifg = false, int R = 5) {
+  // cifg: LstmCifgProjectedStreams (nnet-lstm-couple-if-projected-streams.h): no input gate, i = 1 - f, columns g|f|o|c|h|m|r.
+  // R = 0: Lstm of nnet-recurrent-component.cc:235-420: no projection, the recurrence runs on m, columns g|i|f|o|c|h|m.
+  const int T = 5, S = 3, D = 6, C = 8;
+  const int NG = cifg ? 3 : 4, rec_w = R > 0 ? R : C, W = (NG + 3) * C + R;
   Mat Wx, Wr, Wrm, in, od;
   Vec bias, pi, pf, po;
-  Fill(&Wx, 4 * C, D, -0.4f, 0.4f); Fill(&Wr, 4 * C, R, -0.4f, 0.4f); Fill(&Wrm, R, C, -0.4f, 0.4f);
-  FillVec(&bias, 4 * C, -0.3f, 0.3f); FillVec(&pi, C, -0.3f, 0.3f); FillVec(&pf, C, -0.3f, 0.3f); FillVec(&po, C, -0.3f, 0.3f);
-  Fill(&in, T * S, D, -1.5f, 1.5f); Fill(&od, T * S, R, -1.0f, 1.0f);
+  Fill(&Wx, NG * C, D, -0.4f, 0.4f); Fill(&Wr, NG * C, rec_w, -0.4f, 0.4f);
+  if (R > 0) Fill(&Wrm, R, C, -0.4f, 0.4f);
+  FillVec(&bias, NG * C, -0.3f, 0.3f);
+  if (!cifg) FillVec(&pi, C, -0.3f, 0.3f);
+  FillVec(&pf, C, -0.3f, 0.3f); FillVec(&po, C, -0.3f, 0.3f);
+  Fill(&in, T * S, D, -1.5f, 1.5f); Fill(&od, T * S, rec_w, -1.0f, 1.0f);
   char nm[32];
 #define NAME(x) (std::snprintf(nm, 32, "%s_%s", tag, x), nm)
-  PutMat(NAME("Wx"), Wx); PutMat(NAME("Wr"), Wr); PutMat(NAME("Wrm"), Wrm); PutVec(NAME("bias"), bias);
-  PutVec(NAME("pi"), pi); PutVec(NAME("pf"), pf); PutVec(NAME("po"), po); PutMat(NAME("in"), in); PutMat(NAME("od"), od);
-  Mat Y((T + 2) * S, 7 * C + R), Dd((T + 2) * S, 7 * C + R);
+  PutMat(NAME("Wx"), Wx); PutMat(NAME("Wr"), Wr);
+  if (R > 0) PutMat(NAME("Wrm"), Wrm);
+  PutVec(NAME("bias"), bias);
+  if (!cifg) PutVec(NAME("pi"), pi);
+  PutVec(NAME("pf"), pf); PutVec(NAME("po"), po); PutMat(NAME("in"), in); PutMat(NAME("od"), od);
+  Mat Y((T + 2) * S, W), Dd((T + 2) * S, W);
   if (carried) {   // f_propagate_buf_.RowRange(0, S).CopyFromMat(f_prev_nnet_state_): a whole row block of an earlier chunk
     Mat st;
-    Fill(&st, S, 7 * C + R, -0.8f, 0.8f);
+    Fill(&st, S, W, -0.8f, 0.8f);
     PutMat(NAME("state"), st);
-    Sub(Y, 0, S, 0, 7 * C + R).CopyFromMat(st);
+    Sub(Y, 0, S, 0, W).CopyFromMat(st);
   }
-  enum { G, I, F, O, Cc, H, Mm };
+  const int G = 0, I = cifg ? -1 : 1, F = cifg ? 1 : 2, O = NG - 1, Cc = NG, H = NG + 1, Mm = NG + 2;
   struct View {
-    Mat &b; int C, R, S;
+    Mat &b; int C, R, S, NG;
     Sub gate(int k, int t) { return Sub(b, t * S, S, k * C, C); }
-    Sub rec(int t) { return Sub(b, t * S, S, 7 * C, R); }
-    Sub gifo(int t0, int n) { return Sub(b, t0 * S, n * S, 0, 4 * C); }
+    Sub rec(int t) { return R > 0 ? Sub(b, t * S, S, (NG + 3) * C, R) : gate(NG + 2, t); }   // what the next frame recurs on: r, or m
+    Sub gates(int t0, int n) { return Sub(b, t0 * S, n * S, 0, NG * C); }
     Sub cols(int k, int t0, int n) { return Sub(b, t0 * S, n * S, k * C, C); }
-    Sub recs(int t0, int n) { return Sub(b, t0 * S, n * S, 7 * C, R); }
-  } y = {Y, C, R, S}, d = {Dd, C, R, S};
+    Sub recs(int t0, int n) { return R > 0 ? Sub(b, t0 * S, n * S, (NG + 3) * C, R) : cols(NG + 2, t0, n); }
+  } y = {Y, C, R, S, NG}, d = {Dd, C, R, S, NG};
   const int step = reverse ? -1 : 1;      // the frame a step depends on is t - step, the one that depends on it t + step
-  y.gifo(1, T).AddMatMat(1.0, in, kNoTrans, Wx, kTrans, 0.0);
-  y.gifo(1, T).AddVecToRows(1.0, bias);
+  y.gates(1, T).AddMatMat(1.0, in, kNoTrans, Wx, kTrans, 0.0);
+  y.gates(1, T).AddVecToRows(1.0, bias);
   for (int n = 0, t = reverse ? T : 1; n < T; n++, t += step) {
     const int p = t - step;
-    y.gifo(t, 1).AddMatMat(1.0, y.rec(p), kNoTrans, Wr, kTrans, 1.0);
-    y.gate(I, t).AddMatDiagVec(1.0, y.gate(Cc, p), kNoTrans, pi, 1.0);
+    y.gates(t, 1).AddMatMat(1.0, y.rec(p), kNoTrans, Wr, kTrans, 1.0);
+    if (!cifg) y.gate(I, t).AddMatDiagVec(1.0, y.gate(Cc, p), kNoTrans, pi, 1.0);
     y.gate(F, t).AddMatDiagVec(1.0, y.gate(Cc, p), kNoTrans, pf, 1.0);
-    y.gate(I, t).Sigmoid(y.gate(I, t));
+    if (!cifg) y.gate(I, t).Sigmoid(y.gate(I, t));
     y.gate(F, t).Sigmoid(y.gate(F, t));
     y.gate(G, t).Tanh(y.gate(G, t));
-    y.gate(Cc, t).AddMatMatElements(1.0, y.gate(G, t), y.gate(I, t), 0.0);
+    if (cifg) {   // c = g (1 - f) + c_prev f, spelled g - g f
+      y.gate(Cc, t).AddMatMatElements(-1.0, y.gate(G, t), y.gate(F, t), 0.0);
+      y.gate(Cc, t).AddMat(1.0, y.gate(G, t));
+    } else {
+      y.gate(Cc, t).AddMatMatElements(1.0, y.gate(G, t), y.gate(I, t), 0.0);
+    }
     y.gate(Cc, t).AddMatMatElements(1.0, y.gate(Cc, p), y.gate(F, t), 1.0);
     y.gate(Cc, t).ApplyFloor(-50);
     y.gate(Cc, t).ApplyCeiling(50);
@@ -310,48 +325,57 @@ static void LstmProjected(const char *tag, bool reverse, bool carried) {
     y.gate(O, t).AddMatDiagVec(1.0, y.gate(Cc, t), kNoTrans, po, 1.0);
     y.gate(O, t).Sigmoid(y.gate(O, t));
     y.gate(Mm, t).AddMatMatElements(1.0, y.gate(H, t), y.gate(O, t), 0.0);
-    y.rec(t).AddMatMat(1.0, y.gate(Mm, t), kNoTrans, Wrm, kTrans, 0.0);
+    if (R > 0) y.rec(t).AddMatMat(1.0, y.gate(Mm, t), kNoTrans, Wrm, kTrans, 0.0);
   }
   PutMat(NAME("fwd_buf"), Y);
   d.recs(1, T).CopyFromMat(od);
   for (int n = 0, t = reverse ? 1 : T; n < T; n++, t -= step) {
     const int p = t - step, q = t + step;
-    d.rec(t).AddMatMat(1.0, d.gifo(q, 1), kNoTrans, Wr, kNoTrans, 1.0);
-    d.gate(Mm, t).AddMatMat(1.0, d.rec(t), kNoTrans, Wrm, kNoTrans, 0.0);
+    d.rec(t).AddMatMat(1.0, d.gates(q, 1), kNoTrans, Wr, kNoTrans, 1.0);
+    if (R > 0) d.gate(Mm, t).AddMatMat(1.0, d.rec(t), kNoTrans, Wrm, kNoTrans, 0.0);
     d.gate(H, t).AddMatMatElements(1.0, d.gate(Mm, t), y.gate(O, t), 0.0);
     d.gate(H, t).DiffTanh(y.gate(H, t), d.gate(H, t));
     d.gate(O, t).AddMatMatElements(1.0, d.gate(Mm, t), y.gate(H, t), 0.0);
     d.gate(O, t).DiffSigmoid(y.gate(O, t), d.gate(O, t));
     d.gate(Cc, t).AddMat(1.0, d.gate(H, t));
     d.gate(Cc, t).AddMatMatElements(1.0, d.gate(Cc, q), y.gate(F, q), 1.0);
-    d.gate(Cc, t).AddMatDiagVec(1.0, d.gate(I, q), kNoTrans, pi, 1.0);
+    if (!cifg) d.gate(Cc, t).AddMatDiagVec(1.0, d.gate(I, q), kNoTrans, pi, 1.0);
     d.gate(Cc, t).AddMatDiagVec(1.0, d.gate(F, q), kNoTrans, pf, 1.0);
     d.gate(Cc, t).AddMatDiagVec(1.0, d.gate(O, t), kNoTrans, po, 1.0);
     d.gate(F, t).AddMatMatElements(1.0, d.gate(Cc, t), y.gate(Cc, p), 0.0);
+    if (cifg) d.gate(F, t).AddMatMatElements(-1.0, d.gate(Cc, t), y.gate(G, t), 1.0);
     d.gate(F, t).DiffSigmoid(y.gate(F, t), d.gate(F, t));
-    d.gate(I, t).AddMatMatElements(1.0, d.gate(Cc, t), y.gate(G, t), 0.0);
-    d.gate(I, t).DiffSigmoid(y.gate(I, t), d.gate(I, t));
-    d.gate(G, t).AddMatMatElements(1.0, d.gate(Cc, t), y.gate(I, t), 0.0);
+    if (cifg) {
+      d.gate(G, t).AddMatMatElements(-1.0, d.gate(Cc, t), y.gate(F, t), 0.0);
+      d.gate(G, t).AddMat(1.0, d.gate(Cc, t));
+    } else {
+      d.gate(I, t).AddMatMatElements(1.0, d.gate(Cc, t), y.gate(G, t), 0.0);
+      d.gate(I, t).DiffSigmoid(y.gate(I, t), d.gate(I, t));
+      d.gate(G, t).AddMatMatElements(1.0, d.gate(Cc, t), y.gate(I, t), 0.0);
+    }
     d.gate(G, t).DiffTanh(y.gate(G, t), d.gate(G, t));
   }
   PutMat(NAME("bwd_buf"), Dd);
   Mat id(T * S, D);
-  id.AddMatMat(1.0, d.gifo(1, T), kNoTrans, Wx, kNoTrans, 0.0);
+  id.AddMatMat(1.0, d.gates(1, T), kNoTrans, Wx, kNoTrans, 0.0);
   PutMat(NAME("in_diff"), id);
   // gradients (momentum 0, no clipping: clipping is ApplyFloor / ApplyCeiling, pinned in cumatrix_ops.bin); the frames a step
   // depended on are the row blocks 0..T-1 (forward in time) or 2..T+1 (backward in time)
   const int pb = reverse ? 2 : 0;
-  Mat gWx(4 * C, D), gWr(4 * C, R), gWrm(R, C);
-  Vec gb(4 * C), gpi(C), gpf(C), gpo(C);
-  gWx.AddMatMat(1.0, d.gifo(1, T), kTrans, in, kNoTrans, 0.0);
-  gWr.AddMatMat(1.0, d.gifo(1, T), kTrans, y.recs(pb, T), kNoTrans, 0.0);
-  gb.AddRowSumMat(1.0, d.gifo(1, T), 0.0);
-  gpi.AddDiagMatMat(1.0, d.cols(I, 1, T), kTrans, y.cols(Cc, pb, T), kNoTrans, 0.0);
+  Mat gWx(NG * C, D), gWr(NG * C, rec_w), gWrm(R > 0 ? R : 1, C);
+  Vec gb(NG * C), gpi(C), gpf(C), gpo(C);
+  gWx.AddMatMat(1.0, d.gates(1, T), kTrans, in, kNoTrans, 0.0);
+  gWr.AddMatMat(1.0, d.gates(1, T), kTrans, y.recs(pb, T), kNoTrans, 0.0);
+  gb.AddRowSumMat(1.0, d.gates(1, T), 0.0);
+  if (!cifg) gpi.AddDiagMatMat(1.0, d.cols(I, 1, T), kTrans, y.cols(Cc, pb, T), kNoTrans, 0.0);
   gpf.AddDiagMatMat(1.0, d.cols(F, 1, T), kTrans, y.cols(Cc, pb, T), kNoTrans, 0.0);
   gpo.AddDiagMatMat(1.0, d.cols(O, 1, T), kTrans, y.cols(Cc, 1, T), kNoTrans, 0.0);
-  gWrm.AddMatMat(1.0, d.recs(1, T), kTrans, y.cols(Mm, 1, T), kNoTrans, 0.0);
-  PutMat(NAME("gWx"), gWx); PutMat(NAME("gWr"), gWr); PutMat(NAME("gWrm"), gWrm); PutVec(NAME("gb"), gb);
-  PutVec(NAME("gpi"), gpi); PutVec(NAME("gpf"), gpf); PutVec(NAME("gpo"), gpo);
+  if (R > 0) gWrm.AddMatMat(1.0, d.recs(1, T), kTrans, y.cols(Mm, 1, T), kNoTrans, 0.0);
+  PutMat(NAME("gWx"), gWx); PutMat(NAME("gWr"), gWr);
+  if (R > 0) PutMat(NAME("gWrm"), gWrm);
+  PutVec(NAME("gb"), gb);
+  if (!cifg) PutVec(NAME("gpi"), gpi);
+  PutVec(NAME("gpf"), gpf); PutVec(NAME("gpo"), gpo);
 #undef NAME
 }
 
@@ -408,6 +432,56 @@ static void Gru() {
   PutMat("gru_in_diff", id); PutMat("gru_gWx", gWx); PutMat("gru_gWh", gWh); PutMat("gru_gWg", gWg); PutVec("gru_gb", gb);
 }
 
+// RowConvolution: nnet-row-convolution.cc:90-169 (a D x D product per frame whose diagonal is the output), ragged lengths
+static void RowConv() {
+  const int T = 6, S = 2, D = 7, K = 3, Ts = T + K;
+  const int len[2] = {6, 4};
+  Mat w, in, od, out(T * S, D), in_buf(Ts * S, D), conv(D, D), idb(Ts * S, D), cd(D, K + 1), wdiff(D, K + 1), idf(T * S, D);
+  Fill(&w, D, K + 1, -0.8f, 0.8f); Fill(&in, T * S, D, -1.5f, 1.5f); Fill(&od, T * S, D, -1.0f, 1.0f);
+  PutMat("rc_w", w); PutMat("rc_in", in); PutMat("rc_od", od);
+  std::vector<int32> lens(len, len + 2);
+  Put("rc_lens", 1, 2, 1, lens.data());
+  for (int s = 0; s < S; s++) {
+    for (int t = 0; t < len[s] + K; t++) in_buf.Row(s * Ts + t).CopyFromVec(in.Row((t < len[s] ? t : len[s] - 1) * S + s));
+    for (int t = 0; t < len[s]; t++) {
+      conv.AddMatMat(1.0, w, kNoTrans, in_buf.RowRange(s * Ts + t, K + 1), kNoTrans, 0.0);
+      out.Row(t * S + s).CopyDiagFromMat(conv);
+    }
+  }
+  PutMat("rc_out", out);
+  for (int s = 0; s < S; s++)
+    for (int t = 0; t < len[s]; t++) {
+      Sub yh(in_buf.RowRange(s * Ts + t, K + 1)), yd(idb.RowRange(s * Ts + t, K + 1));
+      cd.SetZero(); cd.AddMat(1.0, w); cd.MulRowsVec(od.Row(t * S + s)); yd.AddMat(1.0, cd, kTrans);
+      cd.SetZero(); cd.AddMat(1.0, yh, kTrans); cd.MulRowsVec(od.Row(t * S + s)); wdiff.AddMat(1.0, cd);
+    }
+  for (int s = 0; s < S; s++)
+    for (int t = 0; t < len[s]; t++) idf.Row(t * S + s).CopyFromVec(idb.Row(s * Ts + t));
+  PutMat("rc_in_diff", idf); PutMat("rc_w_diff", wdiff);
+}
+
+// CompactFsmn: nnet-cfsmn-component.h:169-264 (past 3, future 2 taps)
+static void Fsmn() {
+  const int T = 11, D = 9, P = 3, F = 2, C = P + F + 1;
+  Mat coef, in, od, pad(T + C - 1, D), tmp(T * C, D), out(T, D), corr(C, D), rev(C, D), idf(T, D);
+  Fill(&coef, C, D, -0.5f, 0.5f); Fill(&in, T, D, -1.5f, 1.5f); Fill(&od, T, D, -1.0f, 1.0f);
+  PutMat("fsmn_coef", coef); PutMat("fsmn_in", in); PutMat("fsmn_od", od);
+  pad.RowRange(P, T).CopyFromMat(in);
+  tmp.AddConvMatMatElements(1.0, pad, coef, 0.0);
+  out.CopyFromMat(in);
+  out.AddRowSumMat(1.0, tmp, 1.0);
+  PutMat("fsmn_out", out);
+  for (int i = 0; i < C; i++) tmp.RowRange(i * T, T).AddMatMatElements(1.0, pad.RowRange(i, T), od, 0.0);
+  corr.AddRowSumMat(1.0, tmp, 0.0);
+  pad.SetZero();
+  pad.RowRange(F, T).CopyFromMat(od);
+  for (int i = 0, j = C - 1; i < C; i++, j--) rev.Row(j).CopyFromVec(coef.Row(i));
+  tmp.AddConvMatMatElements(1.0, pad, rev, 0.0);
+  idf.CopyFromMat(od);
+  idf.AddRowSumMat(1.0, tmp, 1.0);
+  PutMat("fsmn_in_diff", idf); PutMat("fsmn_corr", corr);
+}
+
 int main(int argc, char **argv) {
   if (argc != 2) { std::fprintf(stderr, "usage: %s <out.bin>\n", argv[0]); return 1; }
   g_out = std::fopen(argv[1], "wb");
@@ -419,6 +493,11 @@ int main(int argc, char **argv) {
   Gru();
   LstmProjected("lcf", false, true);    // appended after the records above: those stay byte-identical
   LstmProjected("lcb", true, false);
+  LstmProjected("cifg", false, false, true);
+  LstmProjected("lstmnp", false, false, false, 0);
+  LstmProjected("blstmnp", true, false, false, 0);   // the backward-in-time direction of BLstm (nnet-recurrent-component.cc:912-1450)
+  RowConv();
+  Fsmn();
   std::fclose(g_out);
   return 0;
 }

@@ -93,20 +93,28 @@ def test_batchnorm_chain_matches_reference_library(oracle):
 import pytest
 
 
-@pytest.mark.parametrize("tag,reverse,carried", [("lstm", False, False), ("lcf", False, True), ("lcb", True, False)])
-def test_projected_lstm_chain_matches_reference_library(oracle, tag, reverse, carried):
-    """The projected-LSTM gate block: forward buffer (g|i|f|o|c|h|m|r of every frame), backward buffer, input diff and the seven
-    gradients (momentum 0, no clipping) of T = 5 frames x S = 3 streams.  `lstm` = LstmProjectedStreams (nnet-lstm-projected-streams.h:
-    313-617); `lcf` / `lcb` = the two directions of BLstmProjectedStreamsLC (nnet-blstm-projected-streams-lc.h:503-1040): forward in time
-    from a carried state, backward in time from zero."""
+@pytest.mark.parametrize("tag,reverse,carried,cifg", [("lstm", False, False, False), ("lcf", False, True, False), ("lcb", True, False, False),
+                                                      ("cifg", False, False, True), ("lstmnp", False, False, False), ("blstmnp", True, False, False)])
+def test_lstm_family_chains_match_reference_library(oracle, tag, reverse, carried, cifg):
+    """The LSTM gate blocks: forward buffer (every gate of every frame), backward buffer, input diff and all gradients (momentum 0, no
+    clipping) of T = 5 frames x S = 3 streams.  `lstm` = LstmProjectedStreams (nnet-lstm-projected-streams.h:313-617); `lcf` / `lcb` = the
+    two directions of BLstmProjectedStreamsLC (nnet-blstm-projected-streams-lc.h:503-1040): forward in time from a carried state,
+    backward in time from zero; `cifg` = LstmCifgProjectedStreams (nnet-lstm-couple-if-projected-streams.h); `lstmnp` / `blstmnp` = Lstm
+    and the backward-in-time direction of BLstm (nnet-recurrent-component.cc:235-554, 912-1450; no projection)."""
     g = {k[len(tag) + 1:]: v for k, v in cumatrix_golden.load_blas().items() if k.startswith(tag + "_")}
     Wx, Wr = g["Wx"], g["Wr"]
-    Cc, D, R = Wx.shape[0] // 4, Wx.shape[1], Wr.shape[1]
+    ng = 3 if cifg else 4
+    Cc, D = Wx.shape[0] // ng, Wx.shape[1]
+    R = g["Wrm"].shape[0] if "Wrm" in g else 0
     x, od = g["in"], g["od"]
     S = 3
     T = x.shape[0] // S
-    d = oracle.LstmDir(D, Cc, R, False, zero=True)
-    names = (("w_x", "Wx"), ("w_r", "Wr"), ("w_rm", "Wrm"), ("bias", "bias"), ("peep_i", "pi"), ("peep_f", "pf"), ("peep_o", "po"))
+    d = oracle.LstmDir(D, Cc, R, cifg, zero=True)
+    names = [("w_x", "Wx"), ("w_r", "Wr"), ("bias", "bias"), ("peep_f", "pf"), ("peep_o", "po")]
+    if R:
+        names.append(("w_rm", "Wrm"))
+    if not cifg:
+        names.append(("peep_i", "pi"))
     for n, k in names:
         getattr(d, n)[...] = g[k]
     buf = d.forward(x, T, S, reverse=reverse, init_state=g["state"] if carried else None)
@@ -115,7 +123,7 @@ def test_projected_lstm_chain_matches_reference_library(oracle, tag, reverse, ca
     dbuf, idf = d.backward(od, T, S, buf, reverse=reverse)
     assert close(dbuf[S:(T + 1) * S], g["bwd_buf"][S:(T + 1) * S], 5e-6)
     assert close(idf, g["in_diff"], 5e-6)
-    gr = oracle.LstmDir(D, Cc, R, False, zero=True)
+    gr = oracle.LstmDir(D, Cc, R, cifg, zero=True)
     d.grads(gr, x, T, S, buf, dbuf, 0.0, 0.0, reverse=reverse)
     for n, k in names:
         assert close(getattr(gr, n), g["g" + ("b" if k == "bias" else k)], 5e-6), n
@@ -140,3 +148,30 @@ def test_gru_chain_matches_reference_library(oracle):
     u.grads(gr, x, T, S, buf, dbuf, 0.0, 0.0)
     for n, k in (("w_zrm_x", "gru_gWx"), ("w_zr_h", "gru_gWh"), ("w_m_g", "gru_gWg"), ("bias", "gru_gb")):
         assert close(getattr(gr, n), g[k], 5e-6), n
+
+
+def test_rowconvolution_chain_matches_reference_library(oracle):
+    """nnet-row-convolution.cc:90-169 (the reference's D x D product per frame, diagonal taken), ragged sequence lengths."""
+    g = cumatrix_golden.load_blas()
+    w = g["rc_w"]
+    D, K = w.shape[0], w.shape[1] - 1
+    lens = g["rc_lens"]
+    S = len(lens)
+    T = g["rc_in"].shape[0] // S
+    rc = oracle.RowConv(D, K, np.random.default_rng(0))
+    rc.w[...] = w
+    out = rc.propagate(g["rc_in"], T, S, lens)
+    assert close(out, g["rc_out"], 2e-6)
+    idf = rc.backpropagate(g["rc_od"], T, S, lens)
+    assert close(idf, g["rc_in_diff"], 2e-6) and close(rc.w_diff, g["rc_w_diff"], 5e-6)
+
+
+def test_compact_fsmn_chain_matches_reference_library(oracle):
+    """nnet-cfsmn-component.h:169-264: output, input diff and the tap gradients (no clipping)."""
+    g = cumatrix_golden.load_blas()
+    coef = g["fsmn_coef"]
+    f = oracle.Fsmn(coef.shape[1], 3, 2, np.random.default_rng(0))
+    f.coef[...] = coef
+    assert close(f.propagate(g["fsmn_in"]), g["fsmn_out"], 2e-6)
+    idf = f.backpropagate(g["fsmn_in"], g["fsmn_od"], 0.0)
+    assert close(idf, g["fsmn_in_diff"], 2e-6) and close(f.corr, g["fsmn_corr"], 5e-6)

@@ -132,3 +132,67 @@ def test_gru_component_matches_reference_library(aslp, oracle, dev, tmp_path):
     assert close(idf, g["in_diff"], 5e-6)
     ref = np.concatenate([(g[k] - 0.1 * g["g" + ("b" if k == "bias" else k)]).ravel() for _, k in names])
     assert close(net.GetParams(), ref, 5e-6)
+
+
+def test_rowconvolution_component_matches_reference_library(aslp, dev, tmp_path):
+    """nnet-row-convolution.cc:90-169, ragged lengths: output, input diff, taps after one step (learn rate 0.1, momentum 0)."""
+    g = cumatrix_golden.load_blas()
+    w = g["rc_w"]
+    D = w.shape[0]
+    path = tmp_path / "rc.nnet"
+    nnet_io.write_simple_nnet(path, [("<RowConvolution>", D, D, nnet_io.rowconv(w))])
+    net = aslp.Nnet.Read(path)
+    net.SetTrainOptions(learn_rate=0.1, momentum=0.0)
+    net.SetSeqLengths(g["rc_lens"].astype(np.int32))
+    lens, S = g["rc_lens"], len(g["rc_lens"])
+    valid = np.array([(r // S) < lens[r % S] for r in range(g["rc_in"].shape[0])])   # rows past a stream's length are not defined
+    out = net.Propagate(T(g["rc_in"], dev)).cpu().numpy()
+    assert close(out[valid], g["rc_out"][valid], 2e-6)
+    idf = net.Backpropagate(T(g["rc_od"], dev), want_in_diff=True).cpu().numpy()
+    assert close(idf[valid], g["rc_in_diff"][valid], 2e-6)
+    assert close(net.GetParams(), (w - 0.1 * g["rc_w_diff"]).ravel(), 5e-6)
+
+
+def test_compact_fsmn_component_matches_reference_library(aslp, dev, tmp_path):
+    """nnet-cfsmn-component.h:169-264: output, input diff, taps after one step."""
+    g = cumatrix_golden.load_blas()
+    coef = g["fsmn_coef"]
+    D = coef.shape[1]
+    path = tmp_path / "fsmn.nnet"
+    nnet_io.write_simple_nnet(path, [("<CompactFsmn>", D, D, nnet_io.fsmn(coef, 3, 2))])
+    net = aslp.Nnet.Read(path)
+    net.SetTrainOptions(learn_rate=0.1, momentum=0.0)
+    out = net.Propagate(T(g["fsmn_in"], dev)).cpu().numpy()
+    assert close(out, g["fsmn_out"], 2e-6)
+    idf = net.Backpropagate(T(g["fsmn_od"], dev), want_in_diff=True).cpu().numpy()
+    assert close(idf, g["fsmn_in_diff"], 2e-6)
+    assert close(net.GetParams(), (coef - 0.1 * g["fsmn_corr"]).ravel(), 5e-6)
+
+
+@pytest.mark.parametrize("tag,marker,cifg", [("cifg", "<LstmCifgProjectedStreams>", True), ("lstmnp", "<Lstm>", False)])
+def test_other_lstm_components_match_reference_library(aslp, oracle, dev, tmp_path, tag, marker, cifg):
+    """LstmCifgProjectedStreams (nnet-lstm-couple-if-projected-streams.h) and Lstm (nnet-recurrent-component.cc:235-420): output,
+    input diff, parameters after one step (learn rate 0.1, momentum 0, no clipping)."""
+    g = {k[len(tag) + 1:]: v for k, v in cumatrix_golden.load_blas().items() if k.startswith(tag + "_")}
+    ng = 3 if cifg else 4
+    Cc, D = g["Wx"].shape[0] // ng, g["Wx"].shape[1]
+    R = g["Wrm"].shape[0] if "Wrm" in g else 0
+    S = 3
+    Tn = g["in"].shape[0] // S
+    d = oracle.LstmDir(D, Cc, R, cifg, zero=True)   # container of the fixture's tensors for the model writer (no oracle arithmetic runs)
+    key = {"w_x": "Wx", "w_r": "Wr", "bias": "bias", "peep_i": "pi", "peep_f": "pf", "peep_o": "po", "w_rm": "Wrm"}
+    order = ["w_x", "w_r", "bias"] + ([] if cifg else ["peep_i"]) + ["peep_f", "peep_o"] + (["w_rm"] if R else [])   # file / GetParams order
+    for n in order:
+        getattr(d, n)[...] = g[key[n]]
+    path = tmp_path / "l.nnet"
+    nnet_io.write_simple_nnet(path, [(marker, D, R if R else Cc, nnet_io.lstm([d], 0.0, Cc if R else None))])
+    net = aslp.Nnet.Read(path)
+    net.SetTrainOptions(learn_rate=0.1, momentum=0.0)
+    net.ResetLstmStreams([1] * S)
+    out = net.Propagate(T(g["in"], dev)).cpu().numpy()
+    off = (ng + 3) * Cc if R else (ng + 2) * Cc
+    assert close(out, g["fwd_buf"][S:(Tn + 1) * S, off:off + (R if R else Cc)], 2e-6)
+    idf = net.Backpropagate(T(g["od"], dev), want_in_diff=True).cpu().numpy()
+    assert close(idf, g["in_diff"], 5e-6)
+    ref = np.concatenate([(g[key[n]] - 0.1 * g["g" + ("b" if n == "bias" else key[n])]).ravel() for n in order])
+    assert close(net.GetParams(), ref, 5e-6)
