@@ -79,6 +79,37 @@ def cpu_baseline(seconds_budget=20.0):
                       "%d of %d hardware threads)" % (steps, MB, cores, avail)}
 
 
+def cpu_baseline_reference(seconds_budget=15.0):
+    """The same training step on the REFERENCE's own CuMatrix / CuVector CPU code over OpenBLAS (oracle/_ref/ref_dnn_bench, built by
+    `make -C oracle ref` in the development container from the reference sources where they lie; it travels with the snapshot and binds
+    to the OpenBLAS of the image's scipy wheel, which the GPU box has too).  Thread count: best of a short probe.  Returns None when the
+    binary is absent or does not run here (the caller then reports the port alone)."""
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_dnn_bench")
+    if not os.path.exists(exe):
+        return None
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+
+    def run(threads, seconds, steps):
+        env = dict(os.environ, OPENBLAS_NUM_THREADS=str(threads), OMP_NUM_THREADS=str(threads))
+        out = subprocess.run([exe, str(seconds), str(steps)], env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=240)
+        return json.loads(out.stdout.decode().strip().splitlines()[-1])
+
+    try:
+        best = None
+        for th in sorted({min(avail, 128), min(avail, 64), min(avail, 32), min(avail, 16)}, reverse=True):
+            r = run(th, 1.0, 2)
+            if best is None or r["frames_per_sec"] > best[1]:
+                best = (th, r["frames_per_sec"])
+        r = run(best[0], seconds_budget, 20)
+    except Exception:   # noqa: BLE001 -- a baseline that cannot run is reported as absent, the port below still is
+        return None
+    return {"value": r["frames_per_sec"], "unit": "frames/sec", "cores": r["threads"], "kind": "reference",
+            "sample": "%d steps of minibatch %d of the same 5x2048+BN DNN on the reference's own CuMatrix CPU code + OpenBLAS (oracle/_ref/ref_dnn_bench: "
+                      "aslp-cudamatrix / matrix sources compiled where they lie, operations issued in Nnet::Propagate / Backpropagate order by "
+                      "oracle/ref_dnn_bench.cpp), %d OpenBLAS threads of %d hardware threads" % (r["steps"], r["minibatch"], r["threads"], avail)}
+
+
 def ctc_rel_err(aslp, dev):
     """Second half of BASELINE.json's metric ("CTC-loss fp32 rel-err"): the HIP forward-backward against the outputs
     the REFERENCE's own CPU code produced for tests/golden/ctc_a128_t200.bin (data file, generator oracle/gen_ctc_golden.cpp)."""
@@ -523,7 +554,11 @@ def main():
             out["cfg3"] = cfg3_block(aslp, dev)
             out["recurrent_layers"] = recurrent_family_block(aslp, dev)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            port = cpu_baseline()
+            ref = cpu_baseline_reference()
+            out["cpu_baseline"] = ref if ref is not None else port
+            if ref is not None:
+                out["cpu_baseline_port"] = port   # the oracle's own C chain beside it (round 1's figure)
     if comm is not None and not args.no_cfg3:   # N > 1 (or ASLP_BENCH_FORCE_SYNC=1): every rank takes part; rank 0 reports
         if worker is not None:
             worker.close()   # it aliases the cfg2 net's parameter tensors

@@ -15,12 +15,14 @@
 // AffineTransform (nnet-affine-transform.h:186-245), BatchNormalization (nnet-batch-normalization.h:177-284), LstmProjectedStreams
 // (nnet-lstm-projected-streams.h:313-617), GruStreams (nnet-gru-streams.h:238-450), the two directions of BLstmProjectedStreamsLC
 // (nnet-blstm-projected-streams-lc.h:503-1040), LstmCifgProjectedStreams (nnet-lstm-couple-if-projected-streams.h), Lstm / BLstm (nnet-recurrent-component.cc),
-// RowConvolution (nnet-row-convolution.cc:90-169), CompactFsmn (nnet-cfsmn-component.h:169-264).  The sequences are this file's reading of those lines; the arithmetic of every step is
+// RowConvolution (nnet-row-convolution.cc:90-169), CompactFsmn (nnet-cfsmn-component.h:169-264), Xent::Eval
+// (nnet-loss.cc:63-156).  The sequences are this file's reading of those lines; the arithmetic of every step is
 // the reference's own.
 #include <cstdio>
 #include <cstring>
 #include <vector>
 
+#include "aslp-cudamatrix/cu-array.h"
 #include "aslp-cudamatrix/cu-math.h"
 #include "aslp-cudamatrix/cu-matrix.h"
 #include "aslp-cudamatrix/cu-vector.h"
@@ -482,6 +484,55 @@ static void Fsmn() {
   PutMat("fsmn_in_diff", idf); PutMat("fsmn_corr", corr);
 }
 
+// Xent::Eval: nnet-loss.cc:63-156 -- frames whose target row sums to zero are masked through the frame weights; diff = (y - t) w;
+// frame accuracy; cross entropy, entropy and likelihood sums.  stats = {frames, correct, loss, entropy, likelihood} (double).
+static void XentChain() {
+  const int R = 40, Cn = 50;
+  Mat logits, y, tgt;
+  Fill(&logits, R, Cn, -3.0f, 3.0f);
+  y.Resize(R, Cn);
+  y.ApplySoftMaxPerRow(logits);
+  Matrix<float> ht(R, Cn);
+  for (int r = 0; r < R; r++) ht(r, (int)(Uniform() * Cn) % Cn) = 1.0f;
+  for (int c = 0; c < Cn; c++) ht(1, c) = 0.0f;                       // a frame without a target: masked
+  for (int c = 0; c < Cn; c++) ht(2, c) = 0.0f;
+  ht(2, 0) = 0.25f; ht(2, 1) = 0.75f;                                 // a soft posterior
+  tgt.Resize(R, Cn); tgt.CopyFromMat(ht);
+  Vector<float> fw(R);
+  for (int r = 0; r < R; r++) fw(r) = Uniform();
+  fw(0) = 0.0f;
+  PutMat("xe_y", y); PutMat("xe_tgt", tgt);
+  { Vec t(R); t.CopyFromVec(fw); PutVec("xe_fw", t); }
+  Vec w(R), tsum(R);
+  w.CopyFromVec(fw);
+  tsum.AddColSumMat(1.0, tgt, 0.0);
+  w.MulElements(tsum);
+  double st[5];
+  st[0] = w.Sum();
+  Mat diff(y);
+  diff.AddMat(-1.0, tgt);
+  diff.MulRowsVec(w);
+  PutMat("xe_diff", diff);
+  CuArray<int32> io, it;
+  y.FindRowMaxId(&io);
+  tgt.FindRowMaxId(&it);
+  std::vector<int32> ho, htg;
+  io.CopyToVec(&ho); it.CopyToVec(&htg);
+  Vector<float> hw(R); w.CopyToVec(&hw);
+  st[1] = 0.0;
+  for (int r = 0; r < R; r++) if (ho[r] == htg[r]) st[1] += hw(r);     // CountCorrectFramesWeighted (nnet-loss.cc:40-60): weights of the hits
+  Mat a(y);
+  a.Add(1e-20); a.ApplyLog(); a.MulElements(tgt); a.MulRowsVec(w);
+  st[2] = -a.Sum();
+  a.CopyFromMat(tgt);
+  a.Add(1e-20); a.ApplyLog(); a.MulElements(tgt); a.MulRowsVec(w);
+  st[3] = -a.Sum();
+  a.CopyFromMat(y);
+  a.MulElements(tgt); a.MulRowsVec(w);
+  st[4] = a.Sum();
+  Put("xe_stats", 1, 5, 2, st, 8);
+}
+
 int main(int argc, char **argv) {
   if (argc != 2) { std::fprintf(stderr, "usage: %s <out.bin>\n", argv[0]); return 1; }
   g_out = std::fopen(argv[1], "wb");
@@ -498,6 +549,7 @@ int main(int argc, char **argv) {
   LstmProjected("blstmnp", true, false, false, 0);   // the backward-in-time direction of BLstm (nnet-recurrent-component.cc:912-1450)
   RowConv();
   Fsmn();
+  XentChain();
   std::fclose(g_out);
   return 0;
 }

@@ -1,0 +1,208 @@
+// ref_dnn_bench.cpp -- TEST / MEASUREMENT INFRASTRUCTURE (bench.py's cpu_baseline leg, kind "reference").  One training step of
+// BASELINE cfg2 (5 x 2048 sigmoid DNN + BatchNormalization, 440 -> 3000, minibatch 1024) executed on the REFERENCE's own CuMatrix /
+// CuVector CPU branch (src/aslp-cudamatrix with HAVE_CUDA undefined on src/matrix, compiled where they lie) over a real BLAS, the
+// OpenBLAS inside the image's scipy wheel -- the arrangement of oracle/gen_cumatrix_blas_golden.cpp (see oracle/Makefile), and
+// the one BASELINE.md's CPU numbers were taken with.  The component headers cannot be compiled here (OpenFst), so this driver
+// issues the operations of AffineTransform (nnet-affine-transform.h:186-245), BatchNormalization (nnet-batch-normalization.h:
+// 177-284), Sigmoid (nnet-activation.h:153-165), Softmax, Xent::Eval (nnet-loss.cc:63-156) in the order of Nnet::Propagate /
+// Backpropagate (nnet-nnet.cc:70-154: Update right after each component's Backpropagate; the unused in-diff of the first layer
+// is computed like the reference computes it); every operation is the reference's own code.  The same sequences are what
+// tests/golden/cumatrix_blas_ops.bin pins the oracle and the HIP engine against.
+// usage: ref_dnn_bench <seconds> [max_steps]    ->  one JSON line on stdout
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "aslp-cudamatrix/cu-array.h"
+#include "aslp-cudamatrix/cu-math.h"
+#include "aslp-cudamatrix/cu-matrix.h"
+#include "aslp-cudamatrix/cu-vector.h"
+
+extern "C" int scipy_openblas_get_num_threads(void);
+
+using namespace kaldi;
+typedef CuMatrix<float> Mat;
+typedef CuVector<float> Vec;
+
+static unsigned long long g_state = 777;
+static float Uniform() {
+  g_state ^= g_state << 13; g_state ^= g_state >> 7; g_state ^= g_state << 17;
+  return (float)((g_state >> 40) * (1.0 / 16777216.0));
+}
+static void Fill(Mat *m, int rows, int cols, float lo, float hi) {
+  Matrix<float> h(rows, cols);
+  for (int r = 0; r < rows; r++)
+    for (int c = 0; c < cols; c++) h(r, c) = lo + (hi - lo) * Uniform();
+  m->Resize(rows, cols);
+  m->CopyFromMat(h);
+}
+
+struct Affine {
+  Mat W, Wc;
+  Vec b, bc;
+  void Init(int out, int in) {
+    Fill(&W, out, in, -0.07f, 0.07f);
+    Wc.Resize(out, in);
+    b.Resize(out); bc.Resize(out);
+  }
+  void Propagate(const Mat &in, Mat *out) {
+    out->Resize(in.NumRows(), W.NumRows());
+    out->AddVecToRows(1.0, b, 0.0);
+    out->AddMatMat(1.0, in, kNoTrans, W, kTrans, 1.0);
+  }
+  void Backpropagate(const Mat &od, Mat *id) {
+    id->Resize(od.NumRows(), W.NumCols(), kUndefined);
+    id->AddMatMat(1.0, od, kNoTrans, W, kNoTrans, 0.0);
+  }
+  void Update(const Mat &in, const Mat &od, float lr, float mmt) {
+    Wc.AddMatMat(1.0, od, kTrans, in, kNoTrans, mmt);
+    bc.AddRowSumMat(1.0, od, mmt);
+    W.AddMat(-lr, Wc);
+    b.AddVec(-lr, bc);
+  }
+};
+
+struct BatchNorm {
+  Vec scale, shift, mean, var, dmean, dvar, dshift, dscale;
+  CuVector<double> acc_m, acc_v;
+  Mat xs, e;
+  void Init(int dim) {
+    scale.Resize(dim); scale.Set(1.0); shift.Resize(dim);
+    mean.Resize(dim); var.Resize(dim); dmean.Resize(dim); dvar.Resize(dim); dshift.Resize(dim); dscale.Resize(dim);
+    acc_m.Resize(dim); acc_v.Resize(dim);
+  }
+  void Propagate(const Mat &in, Mat *out) {
+    const int rows = in.NumRows();
+    out->Resize(rows, in.NumCols());
+    xs.Resize(rows, in.NumCols(), kUndefined); e.Resize(rows, in.NumCols(), kUndefined);
+    mean.AddRowSumMat(1.0 / rows, in, 0.0);
+    xs.CopyFromMat(in);
+    xs.AddVecToRows(-1.0, mean, 1.0);
+    out->AddMatMatElements(1.0, xs, xs, 0.0);
+    var.AddRowSumMat(1.0 / rows, *out, 0.0);
+    var.Add(1e-7);
+    var.ApplyPow(0.5);
+    var.InvertElements();
+    xs.MulColsVec(var);
+    out->CopyFromMat(xs);
+    out->MulColsVec(scale);
+    out->AddVecToRows(1.0, shift, 1.0);
+    acc_m.AddRowSumMat(1.0, CuMatrix<double>(in), 1.0);
+    e.AddMatMatElements(1.0, in, in, 0.0);
+    acc_v.AddRowSumMat(1.0, CuMatrix<double>(e), 1.0);
+  }
+  void Backpropagate(const Mat &in, const Mat &od, Mat *id, float mmt) {
+    const int rows = in.NumRows();
+    e.AddMatMatElements(1.0, xs, od, 0.0);
+    dscale.AddRowSumMat(1.0, e, mmt);
+    dshift.AddRowSumMat(1.0, od, mmt);
+    xs.CopyFromMat(od);
+    xs.MulColsVec(scale);
+    dvar.CopyFromVec(var);
+    dvar.ApplyPow(3);
+    dvar.Scale(-0.5);
+    e.CopyFromMat(in);
+    e.AddVecToRows(-1.0, mean, 1.0);
+    e.MulElements(xs);
+    e.MulColsVec(dvar);
+    dvar.AddRowSumMat(1.0, e, 0.0);
+    e.CopyFromMat(xs);
+    e.MulColsVec(var);
+    e.Scale(-1.0);
+    dmean.AddRowSumMat(1.0, e, 0.0);
+    e.CopyFromMat(in);
+    e.AddVecToRows(-1.0, mean);
+    e.Scale(2.0 / rows);
+    e.MulColsVec(dvar);
+    dmean.AddRowSumMat(-1.0, e, 1.0);
+    id->Resize(rows, in.NumCols(), kUndefined);
+    id->CopyFromMat(xs);
+    id->MulColsVec(var);
+    id->AddMat(1.0, e);
+    id->AddVecToRows(1.0 / rows, dmean, 1.0);
+  }
+  void Update(float lr) {
+    scale.AddVec(-lr, dscale, 1.0);
+    shift.AddVec(-lr, dshift, 1.0);
+  }
+};
+
+int main(int argc, char **argv) {
+  const double budget = argc > 1 ? atof(argv[1]) : 10.0;
+  const int max_steps = argc > 2 ? atoi(argv[2]) : 20;
+  const int IN = 440, HID = 2048, NH = 5, OUT = 3000, MB = 1024;
+  const float lr = 1e-5f, mmt = 0.0f;
+  std::vector<Affine> aff(NH + 1);
+  std::vector<BatchNorm> bn(NH);
+  for (int l = 0; l <= NH; l++) aff[l].Init(l == NH ? OUT : HID, l == 0 ? IN : HID);
+  for (int l = 0; l < NH; l++) bn[l].Init(HID);
+  Mat x, tgt;
+  Fill(&x, MB, IN, -1.7f, 1.7f);
+  {
+    Matrix<float> ht(MB, OUT);
+    for (int r = 0; r < MB; r++) ht(r, (int)(Uniform() * OUT) % OUT) = 1.0f;
+    tgt.Resize(MB, OUT); tgt.CopyFromMat(ht);
+  }
+  Vector<float> fw_host(MB);
+  fw_host.Set(1.0);
+  std::vector<Mat> a(NH + 1), z(NH), y(NH), da(NH + 1), dz(NH), dy(NH);   // affine out, BN out, sigmoid out and their diffs
+  Mat post, diff, aux, in_diff0;
+  Vec w(MB), tsum(MB);
+  CuArray<int32> io, it;
+  double loss = 0.0;
+  auto step = [&]() {
+    const Mat *cur = &x;
+    for (int l = 0; l < NH; l++) {
+      aff[l].Propagate(*cur, &a[l]);
+      bn[l].Propagate(a[l], &z[l]);
+      y[l].Resize(MB, HID, kUndefined);
+      y[l].Sigmoid(z[l]);
+      cur = &y[l];
+    }
+    aff[NH].Propagate(*cur, &a[NH]);
+    post.Resize(MB, OUT, kUndefined);
+    post.ApplySoftMaxPerRow(a[NH]);
+    // Xent::Eval
+    w.CopyFromVec(fw_host);
+    tsum.AddColSumMat(1.0, tgt, 0.0);
+    w.MulElements(tsum);
+    diff = post;
+    diff.AddMat(-1.0, tgt);
+    diff.MulRowsVec(w);
+    post.FindRowMaxId(&io);
+    tgt.FindRowMaxId(&it);
+    aux = post; aux.Add(1e-20); aux.ApplyLog(); aux.MulElements(tgt); aux.MulRowsVec(w);
+    loss = -aux.Sum();
+    aux = tgt; aux.Add(1e-20); aux.ApplyLog(); aux.MulElements(tgt); aux.MulRowsVec(w);
+    loss += aux.Sum();
+    aux = post; aux.MulElements(tgt); aux.MulRowsVec(w);
+    (void)aux.Sum();
+    // Backpropagate: Softmax passes the diff through (nnet-activation.h:51-55), then top affine, then [Sigmoid, BN, Affine] x 5
+    const Mat *d = &diff;
+    aff[NH].Backpropagate(*d, &da[NH]);
+    aff[NH].Update(y[NH - 1], *d, lr, mmt);
+    d = &da[NH];
+    for (int l = NH - 1; l >= 0; l--) {
+      dy[l].Resize(MB, HID, kUndefined);
+      dy[l].DiffSigmoid(y[l], *d);
+      bn[l].Backpropagate(a[l], dy[l], &dz[l], mmt);
+      bn[l].Update(lr);
+      aff[l].Backpropagate(dz[l], &da[l]);
+      aff[l].Update(l == 0 ? x : y[l - 1], dz[l], lr, mmt);
+      d = &da[l];
+    }
+  };
+  step();  // warm-up (page-in, OpenBLAS thread start)
+  const auto t0 = std::chrono::steady_clock::now();
+  int steps = 0;
+  double el = 0.0;
+  do {
+    step();
+    steps++;
+    el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  } while (el < budget && steps < max_steps);
+  std::printf("{\"frames_per_sec\": %.3f, \"steps\": %d, \"seconds\": %.3f, \"minibatch\": %d, \"threads\": %d, \"xent_per_frame\": %.5f}\n",
+              steps * MB / el, steps, el, MB, scipy_openblas_get_num_threads(), loss / MB);
+  return 0;
+}

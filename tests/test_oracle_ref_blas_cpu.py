@@ -175,3 +175,13 @@ def test_compact_fsmn_chain_matches_reference_library(oracle):
     assert close(f.propagate(g["fsmn_in"]), g["fsmn_out"], 2e-6)
     idf = f.backpropagate(g["fsmn_in"], g["fsmn_od"], 0.0)
     assert close(idf, g["fsmn_in_diff"], 2e-6) and close(f.corr, g["fsmn_corr"], 5e-6)
+
+
+def test_xent_eval_chain_matches_reference_library(oracle):
+    """Xent::Eval, nnet-loss.cc:63-156: a zero-weight frame, a frame without a target (masked), a soft posterior; the diff and the five
+    sums {frames, correct, loss, entropy, likelihood}."""
+    g = cumatrix_golden.load_blas()
+    diff, st = oracle.xent_eval(g["xe_fw"], g["xe_y"], g["xe_tgt"])
+    assert close(diff, g["xe_diff"], 1e-6)
+    got = np.array([st["frames"], st["correct"], st["loss"], st["entropy"], st["likelyhood"]])
+    assert np.allclose(got, g["xe_stats"], rtol=2e-6, atol=1e-6), (got, g["xe_stats"])

@@ -196,3 +196,14 @@ def test_other_lstm_components_match_reference_library(aslp, oracle, dev, tmp_pa
     assert close(idf, g["in_diff"], 5e-6)
     ref = np.concatenate([(g[key[n]] - 0.1 * g["g" + ("b" if n == "bias" else key[n])]).ravel() for n in order])
     assert close(net.GetParams(), ref, 5e-6)
+
+
+def test_xent_eval_matches_reference_library(aslp, dev):
+    """Xent::Eval, nnet-loss.cc:63-156 as the reference's library computes it: diff and {frames, correct, loss, entropy, likelihood}."""
+    g = cumatrix_golden.load_blas()
+    y = T(g["xe_y"], dev)
+    diff = torch.empty_like(y)
+    stats = torch.zeros(5, dtype=torch.float64, device=dev)
+    aslp.ops.xent_eval(y, T(g["xe_fw"], dev), diff, stats, targets=T(g["xe_tgt"], dev))
+    assert close(diff.cpu().numpy(), g["xe_diff"], 1e-6)
+    assert np.allclose(stats.cpu().numpy(), g["xe_stats"], rtol=2e-6, atol=1e-6), (stats.cpu().numpy(), g["xe_stats"])
