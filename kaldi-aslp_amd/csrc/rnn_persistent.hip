@@ -85,6 +85,8 @@ struct SeqStatus {
   unsigned long long *timing;  // diagnostics (devtools): NULL, or 8 accumulators of 10 ns ticks written by workgroup 0, wave 0
   unsigned long long *trace;   // diagnostics (devtools): NULL, or [workgroup][2] entry / exit clock of the latest launch
   unsigned epoch;              // launch counter (28 bits, never 0): tags the placement table entries of this launch
+  unsigned wave_collect;       // LSTM forward.  bit 0: every wave collects the K slice of m(t-1) it multiplies itself (no workgroup barrier behind the
+                               // collection); bit 1: operand reads pinned four fragments ahead of the products
 };
 __device__ __forceinline__ long tick(const SeqStatus &st) { return st.timing ? (long)wall_clock64() : 0; }
 __device__ __forceinline__ void tock(const SeqStatus &st, int slot, long &t) {
@@ -184,8 +186,10 @@ __global__ void __launch_bounds__(512) lstm_seq_fwd(aslp_lstm_seq a, SeqStatus s
   __shared__ float red[2][8][kChainStreams][RP];
   __shared__ int fail[2][8];
   __shared__ int place_flag;
+  __shared__ __attribute__((aligned(16))) float zero_lds[4];
   const long t_entry = (st.timing || st.trace) ? (long)wall_clock64() : 0;
   const int SE = a.s_count > 0 ? a.s_begin + a.s_count : a.S;   // this launch's streams: [a.s_begin, SE)
+  if (threadIdx.x < 4) zero_lds[threadIdx.x] = 0.f;   // (chain_role's barrier publishes it)
   const ChainRole R = chain_role(SE - a.s_begin, a.ndir, a.C, st, place, &place_flag);
   if (!R.active) return;
   const aslp_lstm_seq_dir D = a.dir[R.dir];
@@ -219,11 +223,24 @@ __global__ void __launch_bounds__(512) lstm_seq_fwd(aslp_lstm_seq a, SeqStatus s
                                                       : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
-  // collection role: pieces tid and tid + 512 of [stream][C / 4]
-  const int c4 = C >> 2, npiece = kChainStreams * c4;
-  const int p0 = threadIdx.x, p1 = threadIdx.x + 512;
-  const bool h0 = p0 < npiece, h1 = p1 < npiece;
-  const int st0 = h0 ? p0 / c4 : 0, kq0 = h0 ? p0 % c4 : 0, st1 = h1 ? p1 / c4 : 0, kq1 = h1 ? p1 % c4 : 0;
+  // collection role.  Workgroup-wide: pieces tid and tid + 512 of [stream][C / 4], a barrier, then every wave reads its K slice.
+  // Wave-local (st.wave_collect): a wave fetches exactly what it multiplies -- the 8 streams' pieces of its own K slice [kb, kb + kw),
+  // 2 kw <= 128 pieces, lanes 0..63 take pieces lane and lane + 64 of [stream][kw / 4] -- so no other wave's data is involved, the
+  // workgroup barrier behind the collection goes, and a wave waits for the 4 producers of its slice instead of all 32.
+  const bool wave_collect = (st.wave_collect & 1u) != 0u;
+  const int c4 = C >> 2, npiece = kChainStreams * c4, kq_w = kw >> 2, npw = kChainStreams * kq_w;
+  const int p0 = wave_collect ? lane : threadIdx.x, p1 = wave_collect ? lane + 64 : threadIdx.x + 512;
+  int st0, kq0, st1, kq1;
+  bool h0, h1;
+  if (wave_collect) {
+    st0 = p0 / kq_w; kq0 = (kb >> 2) + p0 % kq_w; st1 = p1 / kq_w; kq1 = (kb >> 2) + p1 % kq_w;
+    h0 = p0 < npw && kq0 < c4; h1 = p1 < npw && kq1 < c4;
+    if (!h0) { st0 = 0; kq0 = 0; }
+    if (!h1) { st1 = 0; kq1 = 0; }
+  } else {
+    h0 = p0 < npiece; h1 = p1 < npiece;
+    st0 = h0 ? p0 / c4 : 0; kq0 = h0 ? p0 % c4 : 0; st1 = h1 ? p1 / c4 : 0; kq1 = h1 ? p1 % c4 : 0;
+  }
   const int off0 = (min(s0 + st0, SE - 1) * ld + om + 4 * kq0) * 4, off1 = (min(s0 + st1, SE - 1) * ld + om + 4 * kq1) * 4;
   // gate-block role: a quad of lanes owns one (stream, cell) pair, lane r of the quad its gate r (g, i, f, o; CIFG: g, f, o, -).
   // The five transcendentals of a pair then take two rounds (gates side by side, then tanh(c) beside the output gate) instead of
@@ -283,18 +300,45 @@ __global__ void __launch_bounds__(512) lstm_seq_fwd(aslp_lstm_seq a, SeqStatus s
     }
     tock(st, 1, tm);  // collection
     if (lane == 0) fail[par][wave] = ok ? 0 : 1;
-    __syncthreads();
+    if (!wave_collect || first_special) __syncthreads();   // (uniform) wave-local collection: this wave reads back only what it stored itself
+    else __builtin_amdgcn_wave_barrier();
     tock(st, 3, tm);  // barrier behind the collection
     if (product) {
       // 2. this wave's K slice of the product
       // all operand reads first, unconditionally (slices past C read element 0 of the row: finite, and their B fragments are 0),
       // so that the LDS latency is paid once and not in front of every group of products
+      // The operand reads run PD fragments ahead of the products that use them (sched_barrier pins the order: left alone, the
+      // scheduler re-uses one register quad for every read and waits for each of the 16 reads two products after issuing it --
+      // the LDS latency 16 times per timestep, with all eight waves of the workgroup in step).
       const float *arow = &m_lds[4 * qs + jl][0];
-      f32x4 av[KW / 4];
+      constexpr int NF = KW / 4, PD = NF < 4 ? NF : 4;
+      auto load_a = [&](int i) -> f32x4 {   // fragments past the wave's slice / past C read four zeros kept in LDS (nobody else's data, no select on the loaded value)
+        const bool in_slice = 4 * i < kw && kb + 4 * i < C;
+        return *reinterpret_cast<const f32x4 *>(in_slice ? arow + kb + 4 * i : zero_lds);
+      };
+      f32x4 av[NF];
+      if ((st.wave_collect & 2u) == 0u) {   // A/B: the scheduler's own order (ASLP_LSTM_READ_AHEAD=0)
 #pragma unroll
-      for (int i = 0; i < KW / 4; i++) av[i] = *reinterpret_cast<const f32x4 *>(arow + ((4 * i < kw && kb + 4 * i < C) ? kb + 4 * i : 0));
+        for (int i = 0; i < NF; i++) av[i] = load_a(i);
 #pragma unroll
-      for (int i = 0; i < KW / 4; i++) {
+        for (int i = 0; i < NF; i++) {
+#pragma unroll
+          for (int h = 0; h < 2; h++) acc[h][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i].x, bw[h][i].x, acc[h][0], 0, 0, 0);
+#pragma unroll
+          for (int h = 0; h < 2; h++) acc[h][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i].y, bw[h][i].y, acc[h][1], 0, 0, 0);
+#pragma unroll
+          for (int h = 0; h < 2; h++) acc[h][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i].z, bw[h][i].z, acc[h][0], 0, 0, 0);
+#pragma unroll
+          for (int h = 0; h < 2; h++) acc[h][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i].w, bw[h][i].w, acc[h][1], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+      for (int i = 0; i < PD; i++) av[i] = load_a(i);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < NF; i++) {
+        if (i + PD < NF) av[i + PD] = load_a(i + PD);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int h = 0; h < 2; h++) acc[h][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i].x, bw[h][i].x, acc[h][0], 0, 0, 0);
 #pragma unroll
@@ -303,6 +347,8 @@ __global__ void __launch_bounds__(512) lstm_seq_fwd(aslp_lstm_seq a, SeqStatus s
         for (int h = 0; h < 2; h++) acc[h][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i].z, bw[h][i].z, acc[h][0], 0, 0, 0);
 #pragma unroll
         for (int h = 0; h < 2; h++) acc[h][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i].w, bw[h][i].w, acc[h][1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       }
     }
     if (first_special) {   // r(0) W_first^T, both operands from LDS; this wave's slice of K = k_first
@@ -477,13 +523,17 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd(aslp_lstm_seq a, SeqStatus s
       {
         f32x4 av[KS];
         const float *arow = &own_dg[par ^ 1][4 * qs + jl][0];
+        constexpr int PD = KS < 4 ? KS : 4;   // operand reads pinned PD fragments ahead of their products (see lstm_seq_fwd)
 #pragma unroll
-        for (int q = 0; q < KS; q++) av[q] = *reinterpret_cast<const f32x4 *>(arow + 4 * q);
+        for (int q = 0; q < PD; q++) av[q] = *reinterpret_cast<const f32x4 *>(arow + 4 * q);
         f32x4 acc[NH][2];  // two accumulators per instruction stream (even / odd k): four independent chains keep the pipe full
 #pragma unroll
         for (int h = 0; h < NH; h++) { acc[h][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[h][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < KS; q++) {
+          if (q + PD < KS) av[q + PD] = *reinterpret_cast<const f32x4 *>(arow + 4 * (q + PD));
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int h = 0; h < NH; h++) acc[h][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[q].x, bw[h][4 * q + 0], acc[h][0], 0, 0, 0);
 #pragma unroll
@@ -492,6 +542,7 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd(aslp_lstm_seq a, SeqStatus s
           for (int h = 0; h < NH; h++) acc[h][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[q].z, bw[h][4 * q + 2], acc[h][0], 0, 0, 0);
 #pragma unroll
           for (int h = 0; h < NH; h++) acc[h][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[q].w, bw[h][4 * q + 3], acc[h][1], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
         }
         // 2. hand the shares out: one 16-byte piece (4 streams of one cell) per lane and instruction
         const __amdgpu_buffer_rsrc_t rs = make_rsrc(box);
@@ -689,18 +740,26 @@ __device__ __forceinline__ bool gru_collect(const float *base, int ld, int S, in
 template <int NB>
 __device__ __forceinline__ f32x4 gru_product(const float *a_lds, int MP, const f32x4 (&bw)[NB], int k0, int klen, int K, const GruGeom &g) {
   const float *arow = a_lds + (4 * g.qs + g.jl) * MP;
+  // operand reads pinned PD fragments ahead of their products (see lstm_seq_fwd: left alone, the scheduler waits for each read right
+  // behind the previous fragment's four products)
+  constexpr int PD = NB < 6 ? NB : 6;
+  auto load_a = [&](int i) -> f32x4 { return *reinterpret_cast<const f32x4 *>(arow + ((4 * i < klen && k0 + 4 * i < K) ? k0 + 4 * i : 0)); };
   f32x4 av[NB];
 #pragma unroll
-  for (int i = 0; i < NB; i++) av[i] = *reinterpret_cast<const f32x4 *>(arow + ((4 * i < klen && k0 + 4 * i < K) ? k0 + 4 * i : 0));
+  for (int i = 0; i < PD; i++) av[i] = load_a(i);
   f32x4 acc[4];
 #pragma unroll
   for (int q = 0; q < 4; q++) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int i = 0; i < NB; i++) {   // four independent accumulators: the instruction's latency is hidden without padding
+    if (i + PD < NB) av[i + PD] = load_a(i + PD);
+    __builtin_amdgcn_sched_barrier(0);
     acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i].x, bw[i].x, acc[0], 0, 0, 0);
     acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i].y, bw[i].y, acc[1], 0, 0, 0);
     acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i].z, bw[i].z, acc[2], 0, 0, 0);
     acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i].w, bw[i].w, acc[3], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
   return (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
@@ -1095,8 +1154,10 @@ static void launch_seq(const aslp_lstm_seq *a, bool backward, const char *who) {
   }
   rt.epoch = (rt.epoch + 1u) & 0x0FFFFFFFu;
   if (rt.epoch == 0u) rt.epoch = 1u;
+  static const unsigned wave_collect = ((getenv("ASLP_LSTM_WAVE_COLLECT") != nullptr && getenv("ASLP_LSTM_WAVE_COLLECT")[0] == '0') ? 0u : 1u) |   // A/B switches
+                                       ((getenv("ASLP_LSTM_READ_AHEAD") != nullptr && getenv("ASLP_LSTM_READ_AHEAD")[0] == '0') ? 0u : 2u);
   SeqStatus st = {rt.abort_flag, rt.host_err_dev, ((rt.timing_mode == 1 && !backward) || (rt.timing_mode == 2 && backward)) ? rt.timing : nullptr,
-                  ((rt.timing_mode == 3 && !backward) || (rt.timing_mode == 4 && backward)) ? rt.timing + 8 : nullptr, rt.epoch};
+                  ((rt.timing_mode == 3 && !backward) || (rt.timing_mode == 4 && backward)) ? rt.timing + 8 : nullptr, rt.epoch, wave_collect};
   const int wpc = (a->C + kCellsPerWg - 1) / kCellsPerWg;
   if (!backward) hipLaunchKernelGGL(pick_fwd(a->cifg != 0, a->C), dim3(kMaxChains * wpc), dim3(512), 0, cur_stream(), *a, st, rt.place);
   else hipLaunchKernelGGL(pick_bwd(a->cifg != 0, a->C), dim3(kMaxChains * wpc), dim3(512), 0, cur_stream(), *a, st, rt.place, rt.inbox);
@@ -1133,7 +1194,7 @@ static void launch_gru(const aslp_gru_seq *a, bool backward, const char *who) {
   rt.epoch = (rt.epoch + 1u) & 0x0FFFFFFFu;
   if (rt.epoch == 0u) rt.epoch = 1u;
   SeqStatus st = {rt.abort_flag, rt.host_err_dev, nullptr, ((rt.timing_mode == 3 && !backward) || (rt.timing_mode == 4 && backward)) ? rt.timing + 8 : nullptr,
-                  rt.epoch};
+                  rt.epoch, 0u};
   const int wpc = (a->H + kCellsPerWg - 1) / kCellsPerWg;
   hipLaunchKernelGGL(pick_gru(backward, a->H), dim3(kMaxChains * wpc), dim3(512), 0, cur_stream(), *a, st, rt.place);
   if (!rt.last_done) (void)hipEventCreateWithFlags(&rt.last_done, hipEventDisableTiming);
