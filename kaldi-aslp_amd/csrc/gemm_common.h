@@ -221,15 +221,24 @@ __device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs &g, const f32x
       const bool colok = col < g.N;
       float4 v[4], c_old[4], w_old[4];
       const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-      const float4 bias = (ep.bias && colok) ? *reinterpret_cast<const float4 *>(ep.bias + col) : zero;
+      // Every read below is unconditional per lane: lanes past the matrix edge read a clamped, valid position and never store.  Only the
+      // wave-uniform "is this piece asked for at all" conditions branch.  (A per-lane `ok ? *p : zero` became a pointer select between
+      // the operand and a zero in scratch memory: flat loads split into three, behind exec-mask branches -- in the one place where the
+      // weight-gradient kernel is bound by how fast it gets its reads out.)
+      const int colc = colok ? col : 0;
+      float4 bias = zero;
+      if (ep.bias) bias = *reinterpret_cast<const float4 *>(ep.bias + colc);
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        const int r = rr + 8 * j, row = row0 + i * 32 + r;
-        const bool ok = colok && row < g.M;
+        const int r = rr + 8 * j, row = row0 + i * 32 + r, rowc = row < g.M ? row : g.M - 1;
         v[j] = *reinterpret_cast<const float4 *>(tile + r * kEpiPitch + 4 * c4);
-        c_old[j] = (ok && g.beta != 0.0f) ? (ep.c_src ? *reinterpret_cast<const float4 *>(ep.c_src + (long)row * ep.ld_c_src + col)
-                                                       : *reinterpret_cast<const float4 *>(g.C + (long)row * g.ldc + col)) : zero;
-        w_old[j] = (ok && ep.W) ? *reinterpret_cast<const float4 *>(ep.W + (long)row * ep.ldw + col) : zero;
+        c_old[j] = zero;
+        if (g.beta != 0.0f) {
+          if (ep.c_src) c_old[j] = *reinterpret_cast<const float4 *>(ep.c_src + (long)rowc * ep.ld_c_src + colc);
+          else c_old[j] = *reinterpret_cast<const float4 *>(g.C + (long)rowc * g.ldc + colc);
+        }
+        w_old[j] = zero;
+        if (ep.W) w_old[j] = *reinterpret_cast<const float4 *>(ep.W + (long)rowc * ep.ldw + colc);
       }
 #pragma unroll
       for (int j = 0; j < 4; j++) {
