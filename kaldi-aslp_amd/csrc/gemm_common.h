@@ -175,8 +175,9 @@ __device__ __forceinline__ bool gemm_epilogue_wide_ok(const GemmArgs &g) {
          (!ep.c_src || ((ep.ld_c_src & 3) == 0 && al(ep.c_src))) &&
          (!ep.act_out || ((ep.ld_act & 3) == 0 && al(ep.act_out)));
 }
-// one lane's 4 consecutive outputs of row `row` (columns col .. col+3): the arithmetic and the stores of the epilogue
-__device__ __forceinline__ void gemm_epilogue_store4(const GemmArgs &g, float4 acc4, float4 c_old, float4 w_old, float4 bias, int row, int col) {
+// one lane's 4 consecutive outputs of a row (columns col .. col+3): the arithmetic of the epilogue ...
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void gemm_epilogue_value4(const GemmArgs &g, float4 acc4, float4 c_old, float4 w_old, float4 bias, f32x4v *out, float4 *wn) {
   const aslp_gemm_epilogue &ep = g.ep;
   float o[4] = {acc4.x, acc4.y, acc4.z, acc4.w};
   const float co[4] = {c_old.x, c_old.y, c_old.z, c_old.w}, bs[4] = {bias.x, bias.y, bias.z, bias.w};
@@ -188,21 +189,21 @@ __device__ __forceinline__ void gemm_epilogue_store4(const GemmArgs &g, float4 a
     if (ep.clip > 0.0f) t = fminf(fmaxf(t, -ep.clip), ep.clip);
     o[q] = t;
   }
-  typedef float f32x4v __attribute__((ext_vector_type(4)));
-  const f32x4v out = {o[0], o[1], o[2], o[3]};
+  *out = f32x4v{o[0], o[1], o[2], o[3]};
+  wn->x = fmaf(ep.w_alpha, o[0], w_old.x); wn->y = fmaf(ep.w_alpha, o[1], w_old.y);   // (only stored when ep.W is set)
+  wn->z = fmaf(ep.w_alpha, o[2], w_old.z); wn->w = fmaf(ep.w_alpha, o[3], w_old.w);
+}
+// ... and its stores
+__device__ __forceinline__ void gemm_epilogue_store4(const GemmArgs &g, const f32x4v &out, const float4 &wn, int row, int col) {
+  const aslp_gemm_epilogue &ep = g.ep;
   f32x4v *cp = reinterpret_cast<f32x4v *>(g.C + (long)row * g.ldc + col);
   if (ep.W && g.beta == 0.0f) __builtin_nontemporal_store(out, cp);  // gradient written once, not read again this step
   else *cp = out;
-  if (ep.W) {
-    float4 wn;
-    wn.x = fmaf(ep.w_alpha, o[0], w_old.x); wn.y = fmaf(ep.w_alpha, o[1], w_old.y);
-    wn.z = fmaf(ep.w_alpha, o[2], w_old.z); wn.w = fmaf(ep.w_alpha, o[3], w_old.w);
-    *reinterpret_cast<float4 *>(ep.W + (long)row * ep.ldw + col) = wn;
-  }
+  if (ep.W) *reinterpret_cast<float4 *>(ep.W + (long)row * ep.ldw + col) = wn;
   if (ep.act_out) {
     float a[4];
 #pragma unroll
-    for (int q = 0; q < 4; q++) a[q] = ep.act == 1 ? sigmoid_ref(o[q]) : ep.act == 2 ? tanh_ref(o[q]) : ep.act == 3 ? fmaxf(o[q], 0.0f) : o[q];
+    for (int q = 0; q < 4; q++) a[q] = ep.act == 1 ? sigmoid_ref(out[q]) : ep.act == 2 ? tanh_ref(out[q]) : ep.act == 3 ? fmaxf(out[q], 0.0f) : out[q];
     *reinterpret_cast<float4 *>(ep.act_out + (long)row * ep.ld_act + col) = make_float4(a[0], a[1], a[2], a[3]);
   }
 }
@@ -240,11 +241,34 @@ __device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs &g, const f32x
         w_old[j] = zero;
         if (ep.W) w_old[j] = *reinterpret_cast<const float4 *>(ep.W + (long)rowc * ep.ldw + colc);
       }
+      f32x4v out[4];
+      float4 wn[4];
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int row = row0 + i * 32 + rr + 8 * j;
-        if (!colok || row >= g.M) continue;
-        gemm_epilogue_store4(g, v[j], c_old[j], w_old[j], bias, row, col);
+      for (int j = 0; j < 4; j++) gemm_epilogue_value4(g, v[j], c_old[j], w_old[j], bias, &out[j], &wn[j]);
+      // A patch that lies inside the matrix (wave-uniform; every patch of the layer products) stores in a straight line: with the
+      // per-lane edge test around each row's stores the compiler put an s_waitcnt vmcnt(0) behind every row group -- the wave sat
+      // out the acknowledgement of its stores four times per patch, at the tail of the kernel where nothing else is left to run.
+      const bool interior = row0 + i * 32 + 32 <= g.M && col0 + n * 32 + 32 <= g.N;
+      if (interior && !ep.act_out) {
+        const long r0 = row0 + i * 32 + rr;
+        if (ep.W && g.beta == 0.0f) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) __builtin_nontemporal_store(out[j], reinterpret_cast<f32x4v *>(g.C + (r0 + 8 * j) * g.ldc + col));
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; j++) *reinterpret_cast<f32x4v *>(g.C + (r0 + 8 * j) * g.ldc + col) = out[j];
+        }
+        if (ep.W) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) *reinterpret_cast<float4 *>(ep.W + (r0 + 8 * j) * ep.ldw + col) = wn[j];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int row = row0 + i * 32 + rr + 8 * j;
+          if (!colok || row >= g.M) continue;
+          gemm_epilogue_store4(g, out[j], wn[j], row, col);
+        }
       }
     }
 }
