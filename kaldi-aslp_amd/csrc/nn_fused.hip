@@ -12,6 +12,16 @@ namespace aslp {
 unsigned *new_async_error_word(const char *what);  // runtime.cpp
 namespace {
 
+// Row r of a matrix as a float4 at column c, zero for rows at / past `end`.  The read itself is unconditional (clamped to the last valid
+// row) and the zero a select on the VALUE: `r < end ? *p : zero` compiles to a pointer select against a zero kept in scratch memory and a
+// flat load -- every kernel that spelled it that way carried a private segment.
+__device__ __forceinline__ float4 load4_rows(const float *base, long ld, int r, int end, int c) {
+  const int rc = r < end ? r : (end > 0 ? end - 1 : 0);
+  float4 v = *reinterpret_cast<const float4 *>(base + (long)rc * ld + c);
+  if (r >= end) v = make_float4(0.f, 0.f, 0.f, 0.f);
+  return v;
+}
+
 // ---- BatchNormalization ---------------------------------------------------------------
 // the ONE statistics pass: sum x and sum fl(x*x) in double for the running statistics
 // (nnet-batch-normalization.h:216-220: the square is formed in float first), plus sum x*x with the
@@ -232,7 +242,7 @@ __global__ void __launch_bounds__(kPanelThreads) bn_forward_panel(const float *_
 #pragma unroll
   for (int k = 0; k < SLOTS; k++) {
     const int r = lane + k * L;
-    x[k] = r < rows ? *reinterpret_cast<const float4 *>(in + (long)r * ldi + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    x[k] = load4_rows(in, ldi, r, rows, c);
   }
   double acc[3][4] = {};
 #pragma unroll
@@ -301,9 +311,9 @@ __global__ void __launch_bounds__(kPanelThreads) bn_backward_panel(const float *
 #pragma unroll
   for (int k = 0; k < SLOTS; k++) {
     const int r = lane + k * L;
-    d[k] = r < rows ? *reinterpret_cast<const float4 *>(dy + (long)r * ldd + c) : zero;
-    if (RECOMPUTE) h[k] = r < rows ? *reinterpret_cast<const float4 *>(xin + (long)r * ldxin + c) : zero;
-    else h[k] = r < rows ? *reinterpret_cast<const float4 *>(xhat + (long)r * ldx + c) : zero;
+    d[k] = load4_rows(dy, ldd, r, rows, c);
+    if (RECOMPUTE) h[k] = load4_rows(xin, ldxin, r, rows, c);
+    else h[k] = load4_rows(xhat, ldx, r, rows, c);
   }
   if (RECOMPUTE) {
     const float4 m = *reinterpret_cast<const float4 *>(mean + c), is = *reinterpret_cast<const float4 *>(inv_std + c);
@@ -317,7 +327,7 @@ __global__ void __launch_bounds__(kPanelThreads) bn_backward_panel(const float *
 #pragma unroll
     for (int k = 0; k < SLOTS; k++) {
       const int r = lane + k * L;
-      const float4 yy = r < rows ? *reinterpret_cast<const float4 *>(y + (long)r * ldy + c) : zero;
+      const float4 yy = load4_rows(y, ldy, r, rows, c);
       {
         // products rounded on their own, never contracted into the sums below: the values a separate Sigmoid backward would
         // have stored, so the folded and the unfolded executor agree bit for bit (HIP's __fmul_rn is a plain multiply)
@@ -443,7 +453,7 @@ __global__ void __launch_bounds__(kPanelThreads) bn_forward_coop(const float *__
 #pragma unroll
   for (int k = 0; k < SLOTS; k++) {
     const int r = r0 + lane + k * L;
-    x[k] = r < r1 ? *reinterpret_cast<const float4 *>(in + (long)r * ldi + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    x[k] = load4_rows(in, ldi, r, r1, c);
   }
   double acc[3][4] = {};
 #pragma unroll
@@ -526,7 +536,7 @@ __global__ void __launch_bounds__(kPanelThreads) bn_forward_stats_kernel(const f
 #pragma unroll
   for (int k = 0; k < kStatSlots; k++) {
     const int r = r0 + lane + k * L;
-    x[k] = r < r1 ? *reinterpret_cast<const float4 *>(in + (long)r * ldi + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    x[k] = load4_rows(in, ldi, r, r1, c);
   }
   {
     const int pc = threadIdx.x % COLS, sl = threadIdx.x / COLS, col = p * COLS + pc;
@@ -597,9 +607,9 @@ __global__ void __launch_bounds__(kPanelThreads) bn_backward_coop(const float *_
 #pragma unroll
   for (int k = 0; k < SLOTS; k++) {
     const int r = r0 + lane + k * L;
-    d[k] = r < r1 ? *reinterpret_cast<const float4 *>(dy + (long)r * ldd + c) : zero;
-    if (RECOMPUTE) h[k] = r < r1 ? *reinterpret_cast<const float4 *>(xin + (long)r * ldxin + c) : zero;
-    else h[k] = r < r1 ? *reinterpret_cast<const float4 *>(xhat + (long)r * ldx + c) : zero;
+    d[k] = load4_rows(dy, ldd, r, r1, c);
+    if (RECOMPUTE) h[k] = load4_rows(xin, ldxin, r, r1, c);
+    else h[k] = load4_rows(xhat, ldx, r, r1, c);
   }
   if (RECOMPUTE) {
     const float4 m = *reinterpret_cast<const float4 *>(mean + c), is = *reinterpret_cast<const float4 *>(inv_std + c);
@@ -613,7 +623,7 @@ __global__ void __launch_bounds__(kPanelThreads) bn_backward_coop(const float *_
 #pragma unroll
     for (int k = 0; k < SLOTS; k++) {
       const int r = r0 + lane + k * L;
-      const float4 yy = r < r1 ? *reinterpret_cast<const float4 *>(y + (long)r * ldy + c) : zero;
+      const float4 yy = load4_rows(y, ldy, r, r1, c);
       {
 #pragma clang fp contract(off)
         d[k].x = d[k].x * yy.x * (1.0f - yy.x); d[k].y = d[k].y * yy.y * (1.0f - yy.y);
