@@ -645,6 +645,10 @@ void launch_variant(GemmArgs &g) {
   else if (env_cfg && big_grid) cfg = env_cfg;
   // both operands K-contiguous (the forward products): the 4-wave 64x64 tile, two workgroups per CU, measured 3 % ahead of
   // the 8-wave tile inside the training step (devtools/sweep_tiles.sh: 70.0 vs 72.5 us average over the NT launches)
+  // neither operand K-contiguous (the weight-gradient products): the same 64 x 128 tile on 4 waves (32 x 64 per wave, half the
+  // fragment reads per MFMA); after the epilogue rewrite measured 1 % ahead on cfg2 inside the training step (devtools/sweep_env.sh:
+  // 773.3 vs 781.7 k frames/s over three alternations, TN 74.5 vs 73.7 us) and neutral on the LC-BLSTM step
+  else if (big_grid && !A_KC && !B_KC) cfg = 208;
   else if (big_grid && !(A_KC && B_KC)) cfg = 212;
   else cfg = 207;
   // (32 x 64 / 32 x 128 tiles for products whose 64 x 64 grid leaves a third of the chip idle were measured on the LC-BLSTM step:
