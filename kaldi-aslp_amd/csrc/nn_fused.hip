@@ -307,7 +307,6 @@ __global__ void __launch_bounds__(kPanelThreads) bn_backward_panel(const float *
   const int cg = threadIdx.x % CG, lane = threadIdx.x / CG;
   const int c = ((int)blockIdx.x * CG + cg) * 4;
   float4 d[SLOTS], h[SLOTS];
-  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int k = 0; k < SLOTS; k++) {
     const int r = lane + k * L;
@@ -603,7 +602,6 @@ __global__ void __launch_bounds__(kPanelThreads) bn_backward_coop(const float *_
   const int cg = threadIdx.x % CG, lane = threadIdx.x / CG;
   const int c = (p * CG + cg) * 4;
   float4 d[SLOTS], h[SLOTS];
-  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int k = 0; k < SLOTS; k++) {
     const int r = r0 + lane + k * L;
