@@ -1,0 +1,59 @@
+"""The A/B switches of the recurrent kernels (DESIGN "A/B switches") select between code paths that must agree: a child process
+per setting (the switches are read once per process) trains the same small latency-controlled BLSTM for two chunks and reports a
+digest of output, input diff and parameters.  The wave-local collection and the pinned read-ahead change WHEN operands are fetched,
+not what is multiplied: bit-identical to the workgroup-wide / scheduler-ordered path.  The per-timestep kernels sum the recurrent
+product in another order: equal within the fp32 bar."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r'''
+import sys, json, hashlib
+import numpy as np, torch
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
+import aslp_import
+aslp = aslp_import.load(); aslp.ops.use_torch_stream()
+dev = torch.device("cuda:0")
+S, chunk, T, D, C = 16, 6, 9, 24, 128
+proto = ("<NnetProto>\n<BLstmProjectedStreamsLC> <InputDim> %%d <OutputDim> 128 <CellDim> %%d <ParamScale> 0.05 <ClipGradient> 5.0\n</NnetProto>\n" %% (D, C))
+net = aslp.Nnet.Init(proto, seed=5)
+net.SetTrainOptions(learn_rate=1e-3, momentum=0.9)
+net.SetChunkSize(chunk)
+g = torch.Generator(device="cpu"); g.manual_seed(3)
+outs = []
+for step in range(2):
+    x = torch.randn(T * S, D, generator=g).to(dev)
+    od = (torch.randn(T * S, 128, generator=g) * 0.1).to(dev)
+    net.ResetLstmStreams([1] * S if step == 0 else [0] * S)
+    out = net.Propagate(x).cpu().numpy()
+    idf = net.Backpropagate(od, want_in_diff=True).cpu().numpy()
+    outs += [out, idf]
+outs.append(np.asarray(net.GetParams(), np.float32))
+np.save(sys.argv[1], np.concatenate([o.ravel() for o in outs]))
+'''
+
+
+def run(tmp_path, name, **env):
+    out = str(tmp_path / (name + ".npy"))
+    e = dict(os.environ, **env)
+    p = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}, out], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    return np.load(out)
+
+
+def test_recurrent_ab_switches_agree(tmp_path):
+    base = run(tmp_path, "default")
+    assert np.isfinite(base).all()
+    for name, env in (("wg_collect", {"ASLP_LSTM_WAVE_COLLECT": "0"}), ("own_order", {"ASLP_LSTM_READ_AHEAD": "0"}),
+                      ("both_off", {"ASLP_LSTM_WAVE_COLLECT": "0", "ASLP_LSTM_READ_AHEAD": "0"})):
+        other = run(tmp_path, name, **env)
+        assert np.array_equal(base, other), name            # same operands, same order of products: same bits
+    step = run(tmp_path, "per_timestep", ASLP_LSTM_PERSISTENT="0")
+    assert np.linalg.norm(step - base) / np.linalg.norm(base) < 1e-5
