@@ -1,0 +1,11 @@
+#!/bin/bash
+# Where do the waves of one product wait -- this repo's kernel and the vendor library's on the same shape?
+# devtools/pmc_one_gemm.sh "tA,tB,M,N,K" [tile cfg]  -> per-dispatch SQ wait / LDS / MFMA counters (three passes)
+R=${GRAFT_REPO_ROOT:-/root/repo}
+export TMPDIR=/tmp
+cd $R
+for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_BUSY_CYCLES" "SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_MISC GRBM_GUI_ACTIVE"; do
+  rm -rf /tmp/og
+  SHAPE=$1 TILE=${2:-0} REF=1 REPS=10 rocprofv3 --kernel-trace --pmc $set -d /tmp/og -o og -- python3 devtools/one_gemm.py > /tmp/og.log 2>&1
+  python3 devtools/prof_summary.py $(find /tmp/og -name "*.db" | head -1) 2>&1 | grep -A5 "^\(gemm_f32_glds\|Cijk\).*dispatches" | cut -c1-60,200-260 | grep -v '^--'
+done
