@@ -267,7 +267,9 @@ static void BatchNorm() {
 // BLstmProjectedStreamsLC (nnet-blstm-projected-streams-lc.h:503-1040) = one direction forward in time from the state carried out of the
 // previous chunk + one direction backward in time from zero.  Buffer columns g|i|f|o|c|h|m|r; row block t holds the S streams of
 // frame t; block 0 / T+1 are the boundaries (carried state or zero).  `tag` prefixes the record names.
-static void LstmProjected(const char *tag, bool reverse, bool carried, bool cifg = false, int R = 5) {
+static void LstmProjected(const char *tag, bool reverse, bool carried, bool cifg = false, int R = 5, const int *lens = nullptr) {
+  // lens (backward-in-time direction of the whole-utterance BLSTMs only): after a frame is computed, the buffer rows of the streams that
+  // have already ended are cleared (nnet-blstm-projected-streams.h:654-657, nnet-recurrent-component.cc:1077-1080)
   // cifg: LstmCifgProjectedStreams (nnet-lstm-couple-if-projected-streams.h): no input gate, i = 1 - f, columns g|f|o|c|h|m|r.
   // R = 0: Lstm of nnet-recurrent-component.cc:235-420: no projection, the recurrence runs on m, columns g|i|f|o|c|h|m.
   const int T = 5, S = 3, D = 6, C = 8;
@@ -328,7 +330,11 @@ static void LstmProjected(const char *tag, bool reverse, bool carried, bool cifg
     y.gate(O, t).Sigmoid(y.gate(O, t));
     y.gate(Mm, t).AddMatMatElements(1.0, y.gate(H, t), y.gate(O, t), 0.0);
     if (R > 0) y.rec(t).AddMatMat(1.0, y.gate(Mm, t), kNoTrans, Wrm, kTrans, 0.0);
+    if (lens)
+      for (int sidx = 0; sidx < S; sidx++)
+        if (t > lens[sidx]) Sub(Y, t * S + sidx, 1, 0, W).SetZero();
   }
+  if (lens) { std::vector<int32> lv(lens, lens + S); Put(NAME("lens"), 1, S, 1, lv.data()); }
   PutMat(NAME("fwd_buf"), Y);
   d.recs(1, T).CopyFromMat(od);
   for (int n = 0, t = reverse ? 1 : T; n < T; n++, t -= step) {
@@ -550,6 +556,7 @@ int main(int argc, char **argv) {
   RowConv();
   Fsmn();
   XentChain();
+  { const int lens[3] = {5, 3, 4}; LstmProjected("bmask", true, false, false, 5, lens); }   // appended last: earlier records unchanged
   std::fclose(g_out);
   return 0;
 }

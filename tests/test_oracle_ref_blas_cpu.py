@@ -94,7 +94,8 @@ import pytest
 
 
 @pytest.mark.parametrize("tag,reverse,carried,cifg", [("lstm", False, False, False), ("lcf", False, True, False), ("lcb", True, False, False),
-                                                      ("cifg", False, False, True), ("lstmnp", False, False, False), ("blstmnp", True, False, False)])
+                                                      ("cifg", False, False, True), ("lstmnp", False, False, False), ("blstmnp", True, False, False),
+                                                      ("bmask", True, False, False)])
 def test_lstm_family_chains_match_reference_library(oracle, tag, reverse, carried, cifg):
     """The LSTM gate blocks: forward buffer (every gate of every frame), backward buffer, input diff and all gradients (momentum 0, no
     clipping) of T = 5 frames x S = 3 streams.  `lstm` = LstmProjectedStreams (nnet-lstm-projected-streams.h:313-617); `lcf` / `lcb` = the
@@ -117,7 +118,9 @@ def test_lstm_family_chains_match_reference_library(oracle, tag, reverse, carrie
         names.append(("peep_i", "pi"))
     for n, k in names:
         getattr(d, n)[...] = g[k]
-    buf = d.forward(x, T, S, reverse=reverse, init_state=g["state"] if carried else None)
+    # `bmask`: ragged utterance lengths -- the backward-in-time direction of BLstmProjectedStreams clears the rows of streams that have ended
+    lens = g.get("lens")
+    buf = d.forward(x, T, S, reverse=reverse, init_state=g["state"] if carried else None, seq_len=lens)
     assert buf.shape == g["fwd_buf"].shape
     assert close(buf[S:(T + 1) * S], g["fwd_buf"][S:(T + 1) * S], 2e-6)
     dbuf, idf = d.backward(od, T, S, buf, reverse=reverse)
