@@ -427,7 +427,7 @@ def main():
             import tempfile
             token = "%s-%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid())
             comm_file = os.path.join(tempfile.gettempdir(), "aslp_bench_comm_" + token)
-        comm = native_parallel.RcclComm(comm_file, rank=rank, num_nodes=world, token=token, timeout_s=300)
+        comm = native_parallel.RcclComm(comm_file, rank=rank, num_nodes=world, token=token, timeout_s=900)
 
     import aslp_import
     aslp = aslp_import.load()   # raises if libaslp_hip.so is missing (no fallback)

@@ -73,7 +73,7 @@ def _ok(rc):
 class RcclComm:
     """mpi-node.h:19-97 on RCCL.  rank / num_nodes default to the launcher's environment (RANK / WORLD_SIZE, PMI_*, OMPI_*)."""
 
-    def __init__(self, id_file=None, rank=-1, num_nodes=-1, token=None, timeout_s=300):
+    def __init__(self, id_file=None, rank=-1, num_nodes=-1, token=None, timeout_s=900):
         self.h = C.c_void_p()
         L = lib()
         with _StdoutToStderr():

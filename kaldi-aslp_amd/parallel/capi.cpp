@@ -39,7 +39,7 @@ int aslp_comm_create_rccl(int rank, int num_nodes, const char *id_file, const ch
   RankFromEnvironment(&rank, &num_nodes);
   aslp_comm_s *h = new aslp_comm_s();
   try {
-    h->comm.reset(NewRcclComm(rank, num_nodes, id_file ? id_file : "", timeout_s > 0 ? timeout_s : 300, token ? token : ""));
+    h->comm.reset(NewRcclComm(rank, num_nodes, id_file ? id_file : "", timeout_s > 0 ? timeout_s : 900, token ? token : ""));
   } catch (...) { delete h; throw; }
   *out = h;
   API_END

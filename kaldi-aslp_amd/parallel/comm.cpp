@@ -127,7 +127,7 @@ class RcclComm : public Comm {
       sh->cv.notify_all();
     }).detach();
     std::unique_lock<std::mutex> lk(sh->mu);
-    if (!sh->cv.wait_for(lk, std::chrono::seconds(timeout_s > 0 ? timeout_s : 300), [&] { return sh->done; }))
+    if (!sh->cv.wait_for(lk, std::chrono::seconds(timeout_s > 0 ? timeout_s : 900), [&] { return sh->done; }))
       ASLP_ERR << "RcclComm: rank " << rank_ << " of " << n_ << ": ncclCommInitRank did not return within " << timeout_s
                << " s (another rank missing, or a rendezvous id of another run)";
     Nccl(sh->res, "ncclCommInitRank");

@@ -49,7 +49,7 @@ void RankFromEnvironment(int *rank, int *num_nodes);
 // id_file: rendezvous file; rank 0 creates it (atomically), the others wait for it (up to timeout_s, which also bounds
 // ncclCommInitRank).  token: ties the file to one launch (default: ASLP_COMM_TOKEN / the launcher's job id); a file with
 // another token, another world size or an age beyond ASLP_COMM_MAX_AGE_S is a leftover and is not joined.
-Comm *NewRcclComm(int rank, int num_nodes, const std::string &id_file, int timeout_s = 300, const std::string &token = std::string());
+Comm *NewRcclComm(int rank, int num_nodes, const std::string &id_file, int timeout_s = 900, const std::string &token = std::string());
 
 class ThreadCommGroup;
 // one group, then one Comm per thread

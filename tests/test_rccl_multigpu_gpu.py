@@ -25,7 +25,7 @@ def ngpus():
     return torch.cuda.device_count()   # counting does not initialise the device
 
 
-def run_ranks(tmp_path, n, *args, timeout=300):
+def run_ranks(tmp_path, n, *args, timeout=1200):
     token = secrets.token_hex(6)
     comm_file = str(tmp_path / ("comm_" + token))
     procs = []
