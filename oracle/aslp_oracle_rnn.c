@@ -9,8 +9,12 @@
  *   LstmCifgProjectedStreams  nnet-lstm-couple-if-projected-streams.h:300-600
  *   Lstm / BLstm              nnet-recurrent-component.cc:235-554, 912-1450
  *   GruStreams                nnet-gru-streams.h:238-450
- * PARITY UNPINNED: the reference has no tests for these and cannot be built here;
- * tests/test_oracle_rnn_cpu.py checks backward against central differences of forward.
+ * Pinning: the reference ships no tests for these and its component headers cannot be compiled here (OpenFst),
+ * but its CuMatrix library can (linked to the image's OpenBLAS): every gate block below -- forward buffer, backward buffer, input
+ * diff, gradients, incl. the carried state, the backward-in-time direction and the length masking -- is checked against the same
+ * op sequence issued on that library (oracle/gen_cumatrix_blas_golden.cpp -> tests/golden/cumatrix_blas_ops.bin,
+ * tests/test_oracle_ref_blas_cpu.py).  The chunk / stream-reset bookkeeping stays restated from source (PARITY UNPINNED for that
+ * part); tests/test_oracle_rnn_cpu.py checks backward against central differences of forward besides.
  *
  * Buffer layout as in the reference: rows (T+2)*S, row = t*S + s; columns
  *   LSTM: [g | i | f | o | c | h | m | r]  (CIFG: [g | f | o | c | h | m | r]; no r without projection)

@@ -4,9 +4,10 @@
  * Plain-C restatement of the two depthwise temporal components, op by op in the reference's order:
  *   RowConvolution  src/aslp-nnet/nnet-row-convolution.cc:105-176
  *   CompactFsmn     src/aslp-nnet/nnet-cfsmn-component.h:170-262
- * PARITY UNPINNED: the reference holds no tests / golden vectors for them and its Kaldi core cannot be
- * built here; tests/test_oracle_temporal_cpu.py checks the backward passes against central
- * differences and documents where the reference deliberately is not the exact gradient.
+ * Pinning: both are checked against their op sequences issued on the reference's own CuMatrix library
+ * (oracle/gen_cumatrix_blas_golden.cpp -> tests/golden/cumatrix_blas_ops.bin, tests/test_oracle_ref_blas_cpu.py: output, input diff,
+ * tap gradients, ragged lengths for RowConvolution); tests/test_oracle_temporal_cpu.py checks the backward passes against central
+ * differences besides and documents where the reference deliberately is not the exact gradient.
  */
 #include <stdlib.h>
 #include <string.h>

@@ -1,6 +1,6 @@
 """Self-consistency of the recurrent oracle (oracle/aslp_oracle_rnn.c).  The reference ships no
-tests or golden vectors for its LSTM/GRU components and its Kaldi core cannot be built here, so
-this part of the oracle is PARITY UNPINNED; what can be checked on CPU is that its hand-written
+tests or golden vectors for its LSTM/GRU components; the gate blocks are pinned against the reference's
+own CuMatrix library in tests/test_oracle_ref_blas_cpu.py, and what is checked here is that the hand-written
 BPTT is the gradient of its forward pass (directional central differences), that the direction /
 state / masking plumbing does what the reference's comments say, and the update rule."""
 import numpy as np

@@ -1,5 +1,5 @@
-"""Self-consistency of oracle/aslp_oracle_temporal.c (RowConvolution, CompactFsmn): PARITY UNPINNED
-(no reference tests / golden vectors exist for these components), so the CPU suite checks the
+"""Self-consistency of oracle/aslp_oracle_temporal.c (RowConvolution, CompactFsmn; pinned against the reference's own
+CuMatrix library in tests/test_oracle_ref_blas_cpu.py -- no reference tests / golden vectors exist for these components): the CPU suite checks the
 hand-written backward passes against central differences of the forward pass and pins down the
 one place where the reference is knowingly not the exact gradient."""
 import numpy as np
