@@ -1,0 +1,17 @@
+#!/bin/bash
+# round 3, GPU run 3: 8 accumulator chains in the half-chain kernels; phase offset sweep; fast activations; parity
+mkdir -p gpurun_out/r3
+L=gpurun_out/r3/run3_bench.log; : > $L
+for d in 0 700 1200 1700; do
+  echo "=== HALF delay $d ns" >> $L
+  ASLP_LSTM_HALF_DELAY_NS=$d SEQ_TIMING=1 timeout 300 python devtools/bench_lc.py 32 100 2>&1 | grep -v "^LOG\|amdgpu.ids" >> $L
+done
+echo "=== HALF delay 1200 FAST_ACT=1" >> $L
+ASLP_LSTM_FAST_ACT=1 SEQ_TIMING=1 timeout 300 python devtools/bench_lc.py 32 100 2>&1 | grep -v "^LOG\|amdgpu.ids" >> $L
+echo "=== HALF delay 0 FAST_ACT=1" >> $L
+ASLP_LSTM_HALF_DELAY_NS=0 ASLP_LSTM_FAST_ACT=1 timeout 300 python devtools/bench_lc.py 32 100 2>&1 | grep -v "^LOG\|amdgpu.ids" >> $L
+echo "=== chains of 8" >> $L
+ASLP_LSTM_HALF_CHAINS=0 timeout 300 python devtools/bench_lc.py 32 100 2>&1 | grep -v "^LOG\|amdgpu.ids" >> $L
+echo "=== parity" >> $L
+timeout 900 python -m pytest tests/test_rnn_gpu.py tests/test_cfg3_step_gpu.py tests/test_gradcheck_gpu.py tests/test_ab_switches_gpu.py tests/test_ref_blas_gpu.py -x -q -m gpu 2>&1 | tail -5 >> $L
+cat $L

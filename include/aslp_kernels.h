@@ -83,6 +83,39 @@ void cudaF_add_diag_mat_mat(int Gr, int Bl, float alpha, float *v, int v_dim, co
 void cudaF_add_vec_vec(int Gr, int Bl, float alpha, float *v, const float *x, const float *y, float beta, int dim);                     /* [118] ASLP */
 void cudaF_vec_sum(int Gr, int Bl, float *v, float *value, int dim, int inc);                                                           /* [122] */
 
+/* ---- element-wise / group ops of MaxPooling, Pnorm, Maxout (csrc/conv_pool.hip) ---- */
+void cudaF_max(aslp_dim3 Gr, aslp_dim3 Bl, float *mat, const float *A, MatrixDim dst_d, int src_stride);                                  /* [85] mat = max(mat, A) */
+void cudaF_mul_rows_group_mat(aslp_dim3 Gr, aslp_dim3 Bl, float *y, const float *x, MatrixDim d, int src_stride, int group_size);        /* [88] */
+void cudaF_calc_pnorm_deriv(aslp_dim3 Gr, aslp_dim3 Bl, float *y, const float *x1, const float *x2, MatrixDim d, int src_stride, int group_size, float power); /* [89] */
+void cudaF_calc_group_max_deriv(aslp_dim3 Gr, aslp_dim3 Bl, float *y, const float *x1, const float *x2, MatrixDim d, int src_stride, int group_size);          /* [90] */
+void cudaF_group_pnorm(aslp_dim3 Gr, aslp_dim3 Bl, float *y, const float *x, MatrixDim d, int src_stride, int group_size, float power);  /* [146] */
+void cudaF_group_max(aslp_dim3 Gr, aslp_dim3 Bl, float *y, const float *x, MatrixDim d, int src_stride, int group_size);                 /* [147] */
+void cudaF_equal_element_mask(aslp_dim3 Gr, aslp_dim3 Bl, const float *mat1, const float *mat2, float *mask, MatrixDim mat1_dim, int mat2_stride,
+                              int mask_stride);                                                                                          /* [182] */
+
+/* ---- ConvolutionalComponent / MaxPoolingComponent / LengthNormComponent / Pnorm as whole ops (csrc/conv_pool.hip) ----
+ * ConvolutionalComponent (nnet-convolutional-component.h:301-481): the reference gathers the P patches of a frame into P column blocks
+ * (CopyCols) and runs P products; here the patches of frame n are the P consecutive ROWS n * P .. n * P + P - 1 of `patches`
+ * ([rows * P x num_splice * patch_dim], leading dimension ldp), so that forward, in-diff and filter gradient are ONE product each. */
+void aslp_conv_gather_patches(float *patches, int ldp, const float *in, MatrixDim d_in, int num_patches, int num_splice, int patch_dim, int patch_step,
+                              int patch_stride);
+/* in_diff[n][s * patch_stride + q] = sum over patches p containing q (ascending p) of patch_diff[n * P + p][s * patch_dim + q - p * step]
+ * (the AddCols passes over the reversed column map, :413-421, in their order) */
+void aslp_conv_in_diff(float *in_diff, MatrixDim d_id, const float *patch_diff, int ldp, int num_patches, int num_splice, int patch_dim, int patch_step,
+                       int patch_stride);
+/* nnet-max-pooling-component.h:101-162: out [rows x num_pools * pool_stride]; the backward pass routes out_diff to the inputs that equal their
+ * pool's maximum, summed over overlapping pools (ascending) and divided by the number of pools a patch belongs to */
+void aslp_max_pool_forward(float *out, int ld_out, const float *in, MatrixDim d_in, int pool_size, int pool_step, int pool_stride);
+void aslp_max_pool_backward(float *in_diff, int ld_id, const float *in, MatrixDim d_in, const float *out, int ld_out, const float *out_diff, int ld_od,
+                            int pool_size, int pool_step, int pool_stride);
+/* nnet-various.h:338-352: out = in * row_scales, row_scales[r] = 1 / sqrt(sum_c in[r][c]^2) (kept for the backward MulRowsVec) */
+void aslp_length_norm_forward(float *out, int ld_out, const float *in, MatrixDim d_in, float *row_scales);
+/* GroupPnormDeriv / GroupMaxDeriv followed by MulRowsGroupMat(out_diff) in one pass (nnet-activation.h:346-349, 370-373) */
+void aslp_group_pnorm_backward(float *in_diff, int ld_id, const float *in, MatrixDim d_in, const float *out, int ld_out, const float *out_diff, int ld_od,
+                               int group_size, float power);
+void aslp_group_max_backward(float *in_diff, int ld_id, const float *in, MatrixDim d_in, const float *out, int ld_out, const float *out_diff, int ld_od,
+                             int group_size);
+
 /* Library-native whole-op forms used by the host engine (no reference twin: the reference
  * builds these from cuBLAS gemv with a ones-vector, cu-vector.cc:1145-1166). */
 /* v[c] = alpha * sum_r M[r][c] + beta * v[c]      (CuVectorBase::AddRowSumMat) */
@@ -338,6 +371,11 @@ typedef struct aslp_lstm_seq_ {
 } aslp_lstm_seq;
 int aslp_lstm_seq_supported(const aslp_lstm_seq *a, int backward);
 int aslp_lstm_seq_first_product_supported(int k_first);
+int aslp_lstm_seq_first_product_supported_for(int k_first, int C);   /* ... in a layer of C cells (the staging row is 128 floats for C <= 128) */
+/* Streams per chain the launch for these arguments uses: 8 (one 512-thread workgroup per CU) or 4 (half chains: two 256-thread workgroups
+ * of two independent chains per CU, so that one chain's product runs under the other's hand-off and gate block; ASLP_LSTM_HALF_CHAINS=0
+ * keeps 8).  grad_partial then has ndir * ceil(streams / that) chains of 7 rows. */
+int aslp_lstm_seq_chain_streams(const aslp_lstm_seq *a, int backward);
 /* row blocks 0 and T+1 := 0 (all ld columns); columns [col0, col0 + ncols) of row blocks 1..T := 0xFFFFFFFF words.
  * For the forward kernel: col0 = the m column block (G + 2) * C, ncols = C. */
 void aslp_lstm_seq_fill(float *buf, int ld, int T, int S, int col0, int ncols);
@@ -351,6 +389,10 @@ void aslp_lstm_seq_forward(const aslp_lstm_seq *a);
  * workgroups 0 .. n-1 of the launch `launches_back` (0 = latest .. 7) persistent launches ago.  Synchronises. */
 void aslp_lstm_seq_residency(unsigned long long *out, int n, int launches_back);
 unsigned aslp_lstm_seq_polls(int reset);
+/* devtools: placement census of the latest traced half-chain forward launch: out[b] = XCC id << 48 | HW_ID[15:0] << 32 | chain << 8 | block */
+void aslp_lstm_seq_census(unsigned long long *out, int n);
+/* devtools: phase log of the latest traced half-chain forward launch: out[slot * 256 + 4 * step + k] (512 words), see csrc/rnn_persistent.hip */
+void aslp_lstm_seq_phase_log(unsigned long long *out);
 /* diagnostics (devtools/bench_lc.py): phase timing of the forward kernel, see csrc/rnn_persistent.hip */
 void aslp_lstm_seq_timing(int enable, unsigned long long *out);
 void aslp_lstm_seq_backward(const aslp_lstm_seq *a);

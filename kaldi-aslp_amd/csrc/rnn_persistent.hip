@@ -33,6 +33,8 @@
 // The grid must be co-resident: aslp_lstm_seq_supported() checks it against the occupancy of the kernel with a margin
 // of one workgroup per CU, otherwise the caller keeps the one-launch-per-timestep path.
 #include <mutex>
+#include <utility>
+#include <vector>
 
 #include "aslp_kernels.h"
 #include "common.h"
@@ -87,6 +89,8 @@ struct SeqStatus {
   unsigned epoch;              // launch counter (28 bits, never 0): tags the placement table entries of this launch
   unsigned wave_collect;       // LSTM forward.  bit 0: every wave collects the K slice of m(t-1) it multiplies itself (no workgroup barrier behind the
                                // collection); bit 1: operand reads pinned four fragments ahead of the products
+  unsigned half_map;           // half-chain kernels: which workgroup indices are taken to share a CU (see chain_role4)
+  unsigned half_delay;         // half-chain kernels: the second chain of a CU starts this many 10 ns ticks late (see chain_role4)
 };
 __device__ __forceinline__ long tick(const SeqStatus &st) { return st.timing ? (long)wall_clock64() : 0; }
 __device__ __forceinline__ void tock(const SeqStatus &st, int slot, long &t) {
@@ -171,6 +175,23 @@ __device__ __forceinline__ ChainRole chain_role(int S, int ndir, int C, const Se
   return r;
 }
 
+// The gate non-linearities on the hardware's exp2 and reciprocal (v_exp_f32, v_rcp_f32: 1 ulp each) instead of the correctly rounded
+// expf and division of sigmoid_ref / tanh_ref: ~6 instructions on the sequential path of a timestep instead of ~60, results within a
+// few ulp (1e-6 relative after T = 60 steps; the parity bar is 1e-4).  Default; ASLP_LSTM_FAST_ACT=0 keeps the exact forms (A/B).
+template <bool FAST>
+__device__ __forceinline__ float act_sigmoid(float x) {
+  if (!FAST) return sigmoid_ref(x);
+  const float e = __builtin_amdgcn_exp2f(-1.44269504088896340736f * fabsf(x));
+  return (x > 0.0f ? 1.0f : e) * __builtin_amdgcn_rcpf(1.0f + e);
+}
+template <bool FAST>
+__device__ __forceinline__ float act_tanh(float x) {
+  if (!FAST) return tanh_ref(x);
+  const float e2 = __builtin_amdgcn_exp2f(-2.88539008177792681472f * fabsf(x));   // exp(-2 |x|)
+  const float q = 2.0f * __builtin_amdgcn_rcpf(1.0f + e2);
+  return x > 0.0f ? -1.0f + q : 1.0f - q;
+}
+
 // ---- forward -------------------------------------------------------------------------------------------------------
 // grid 8 * ceil(C / 16) workgroups of 512 threads.  KW: K values per wave (C <= 8 * KW).
 // The product runs on v_mfma_f32_4x4x1_16b_f32 (see the backward kernel for the block layout): one instruction covers the
@@ -178,7 +199,7 @@ __device__ __forceinline__ ChainRole chain_role(int S, int ndir, int C, const Se
 // m(t-1) [8 x C] is collected ONCE per workgroup into LDS (every thread two 16-byte pieces, agent-scope loads, repeated until
 // no piece reads "not yet published") and read from there by all lanes -- the 4 x 4 blocks would otherwise pull every
 // piece eight times through the L2.
-template <bool CIFG, int KW>
+template <bool CIFG, int KW, bool FAST>
 __global__ void __launch_bounds__(512) lstm_seq_fwd(aslp_lstm_seq a, SeqStatus st, unsigned *place) {
   constexpr int G = CIFG ? 3 : 4, KMAX = 8 * KW, MP = KMAX + 4, RP = 80;  // RP = 16 mod 32: the epilogue's reads hit 32 distinct banks
   __shared__ __attribute__((aligned(16))) float m_lds[kChainStreams][MP];
@@ -213,7 +234,7 @@ __global__ void __launch_bounds__(512) lstm_seq_fwd(aslp_lstm_seq a, SeqStatus s
     }
   }
   // W_first rows of this workgroup's 64 gate columns -> LDS (zero where the column or k does not exist); read at step 0 only
-  const bool first_in_kernel = D.w_first != nullptr && D.k_first > 0 && D.k_first <= kFirstK;
+  const bool first_in_kernel = D.w_first != nullptr && D.k_first > 0 && D.k_first <= kFirstK && D.k_first <= KMAX;   // r(0) is staged in m_lds rows of KMAX floats
   if (first_in_kernel) {
     const int kq = (D.k_first + 3) >> 2;   // 16-byte pieces per row
     for (int p = threadIdx.x; p < 64 * kq; p += 512) {
@@ -391,8 +412,8 @@ __global__ void __launch_bounds__(512) lstm_seq_fwd(aslp_lstm_seq a, SeqStatus s
     const bool masked = t > slen;  // nnet-blstm-projected-streams.h:654-657: rows past the utterance end are zeroed
     // round 1: g = tanh(.), i / f = sigmoid(. + c(t-1) * peephole), each on its own lane
     float gate = 0.f;
-    if (role == 0) gate = tanh_ref(xr + pre);
-    else if (role < G - 1) gate = sigmoid_ref(xr + pre + cprev * pw);
+    if (role == 0) gate = act_tanh<FAST>(xr + pre);
+    else if (role < G - 1) gate = act_sigmoid<FAST>(xr + pre + cprev * pw);
     const float gg = quad_bcast<0>(gate), g1 = quad_bcast<1>(gate), g2 = quad_bcast<2>(gate);
     float cellv;
     if (!CIFG) cellv = gg * g1 + cprev * g2;        // g * i + c(t-1) * f
@@ -400,8 +421,8 @@ __global__ void __launch_bounds__(512) lstm_seq_fwd(aslp_lstm_seq a, SeqStatus s
     cellv = fminf(fmaxf(cellv, -50.0f), 50.0f);
     // round 2: h = tanh(c) on lane 0, o = sigmoid(. + c * peephole) on lane G - 1
     float hh = 0.f;
-    if (role == 0) hh = tanh_ref(cellv);
-    if (role == G - 1) gate = sigmoid_ref(xr + pre + cellv * pw);
+    if (role == 0) hh = act_tanh<FAST>(cellv);
+    if (role == G - 1) gate = act_sigmoid<FAST>(xr + pre + cellv * pw);
     const float oo = quad_bcast<G - 1>(gate);
     float mm = hh * oo;   // meaningful on lane 0 of the quad
     if (masked) { gate = 0.f; cellv = 0.f; hh = 0.f; mm = 0.f; }
@@ -660,6 +681,477 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd(aslp_lstm_seq a, SeqStatus s
   }
   if (st.timing && blockIdx.x == 0 && threadIdx.x == 0) { st.timing[0] += (unsigned long long)T; st.timing[6] += R.local ? 1ull : 0ull; }
   if (st.trace && threadIdx.x == 0) {   // ring of the 8 latest launches
+    unsigned long long *tr = st.trace + (st.epoch & 7u) * 2048u;
+    tr[2 * blockIdx.x] = (unsigned long long)t_entry; tr[2 * blockIdx.x + 1] = wall_clock64();
+  }
+  if (polls && lane == 0) __hip_atomic_fetch_add(st.abort_flag + 2, polls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- half chains: 4 streams per chain, 256-thread workgroups, TWO per CU --------------------------------------------------------
+// A timestep of the kernels above is a serial chain on every CU: collect (L2 round trip) -> product -> barrier -> gate block -> publish;
+// the MFMA pipe works for a third of it.  Here a chain has 4 streams instead of 8 and a workgroup 4 waves instead of 8, so TWO
+// workgroups -- of two different, independent chains -- live on every CU (one wave of each per SIMD, 2 x ~200 VGPRs): while one
+// chain's workgroup waits for its hand-off or finishes its gate block, the other one's product has the matrix pipe.  The hardware's
+// own wave scheduling does the overlap; there is no new synchronisation.  A wave's K slice doubles (4 waves split K), the weights
+// are again resident in registers (the two workgroups of a CU hold the same 64 gate columns, of the same direction, twice).
+//   v_mfma_f32_4x4x1_16b_f32: all 16 blocks share the A operand (lane l & 3 = stream), block l >> 2 = 4 gate columns -> one
+//   instruction = the chain's 4 streams x all 64 gate columns of the workgroup (column = lane).
+// Workgroup b: XCD x = b & 7 (observed dispatch: round-robin), index i = b >> 3 in [0, 2 wpc): chains x and x + 8 share the XCD.
+// Which i land on the same CU is the dispatcher's business: st.half_map = 0 pairs (chain x, block i >> 1) with (chain x + 8, block
+// i >> 1) as neighbours i, i ^ 1; half_map = 1 as i, i + wpc.  Either way the results are the same; only the overlap differs.
+constexpr int kHalfStreams = 4;
+constexpr int kMaxChains4 = 16;
+
+__device__ __forceinline__ ChainRole chain_role4(int S, int ndir, int C, const SeqStatus &st, unsigned *place, int *lds_flag, int *chain_out, int *cb_out) {
+  ChainRole r;
+  const int wpc = (C + kCellsPerWg - 1) / kCellsPerWg;
+  const int x = blockIdx.x & 7, i = blockIdx.x >> 3;
+  const bool two = (int)gridDim.x > 8 * wpc;   // 16 chains' worth of workgroups launched
+  const int hi = !two ? 0 : (st.half_map ? i / wpc : (i & 1)), cb = !two ? i : (st.half_map ? i % wpc : (i >> 1));
+  const int chain = x + 8 * hi;
+  const int nsg = (S + kHalfStreams - 1) / kHalfStreams, nchains = ndir * nsg;
+  *chain_out = chain; *cb_out = cb;
+  r.active = chain < nchains;
+  r.dir = r.active ? chain % ndir : 0;
+  r.s0 = (r.active ? chain / ndir : 0) * kHalfStreams;
+  r.c0 = cb * kCellsPerWg;
+  r.local = false;
+  if (!r.active) return r;
+  if (threadIdx.x < 64) {  // wave 0
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc = (xcc & 15u) | (st.epoch << 4);
+    unsigned *row = place + chain * kMaxWgPerChain;
+    if (threadIdx.x == 0) __hip_atomic_store(row + cb, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int l = threadIdx.x;
+    unsigned v = xcc;
+    long t0 = 0;
+    bool ok = true;
+    for (unsigned spins = 0;; spins++) {
+      if (l < wpc) v = __hip_atomic_load(row + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!__any(l < wpc && (v >> 4) != st.epoch)) break;
+      if (!spin_ok(spins, t0, st)) { ok = false; break; }
+      __builtin_amdgcn_s_sleep(4);
+    }
+    const bool same = __all(l >= wpc || v == xcc);
+    if (threadIdx.x == 0) *lds_flag = !ok ? -1 : (same ? 1 : 0);
+  }
+  __syncthreads();
+  const int f = *lds_flag;
+  if (f < 0) r.active = false;
+  r.local = f == 1;
+  // Two chains that start together stay in lock-step: both collect, both multiply (sharing the matrix pipe), both finish their gate
+  // blocks at the same time, and nothing overlaps.  The second chain of every CU therefore starts a fraction of a timestep late;
+  // the two chains have the same period, so the offset persists and one's product falls into the other's hand-off / gate block.
+  if (two && hi == 1 && st.half_delay != 0u && r.active) {
+    const long t0 = (long)wall_clock64();
+    while ((long)wall_clock64() - t0 < (long)st.half_delay) __builtin_amdgcn_s_sleep(2);
+  }
+  return r;
+}
+
+// forward.  grid (8 or 16) * ceil(C / 16) workgroups of 256 threads.  KW: K values per wave (C <= 4 * KW).
+template <bool CIFG, int KW, bool FAST>
+__global__ void __launch_bounds__(256, 2) lstm_seq_fwd4(aslp_lstm_seq a, SeqStatus st, unsigned *place) {
+  constexpr int G = CIFG ? 3 : 4, NS = kHalfStreams, KMAX = 4 * KW, MP = KMAX + 4, RP = 80;
+  __shared__ __attribute__((aligned(16))) float m_lds[NS][MP];
+  __shared__ float red[2][4][NS][RP];
+  __shared__ int fail[2][4];
+  __shared__ int place_flag;
+  const long t_entry = (st.timing || st.trace) ? (long)wall_clock64() : 0;
+  const int SE = a.s_count > 0 ? a.s_begin + a.s_count : a.S;
+  // m_lds starts as zeros and is only ever written where k < C (or k < k_first): the product reads whole rows with immediate offsets,
+  // positions past C (whose B fragments are zero) included          (chain_role4's barrier publishes the zeros)
+  for (int i = threadIdx.x; i < NS * MP; i += 256) (&m_lds[0][0])[i] = 0.f;
+  int chain, me;
+  const ChainRole R = chain_role4(SE - a.s_begin, a.ndir, a.C, st, place, &place_flag, &chain, &me);
+  if (st.trace && threadIdx.x == 0) {   // diagnostics: where this workgroup runs (XCC id, HW_ID) and whom it serves
+    unsigned xcc, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    st.trace[8 * 2048u + blockIdx.x] = ((unsigned long long)(xcc & 15u) << 48) | ((unsigned long long)(hw & 0xFFFFu) << 32) | ((unsigned)chain << 8) | (unsigned)me;
+  }
+  if (!R.active) return;
+  const aslp_lstm_seq_dir D = a.dir[R.dir];
+  const int C = a.C, S = a.S, T = a.T, ld = a.ld;
+  const int GC = G * C, oc = GC, oh = GC + C, om = GC + 2 * C;
+  const int c0 = R.c0, s0 = a.s_begin + R.s0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int jl = lane & 3;
+  const int kw = ((C + 15) / 16) * 4, kb = wave * kw;   // this wave's K range [kb, kb + kw), a multiple of 4 long
+  // B fragments, resident for the launch: this lane's tile column n = lane: gate n >> 4, cell c0 + (n & 15)
+  const int gate_n = lane >> 4, cell_n = c0 + (lane & 15);
+  const bool nvalid = gate_n < G && cell_n < C;
+  f32x4 bw[KW / 4];
+  {
+    const float *brow = D.w + (long)(nvalid ? gate_n * C + cell_n : 0) * a.ldw;
+#pragma unroll
+    for (int i = 0; i < KW / 4; i++) {
+      const int k0 = kb + 4 * i;
+      bw[i] = (nvalid && 4 * i < kw && k0 < C) ? *reinterpret_cast<const f32x4 *>(brow + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  const bool first_in_kernel = D.w_first != nullptr && D.k_first > 0 && D.k_first <= kFirstK && D.k_first <= KMAX;
+  // collection role (wave-local): the 4 streams' pieces of this wave's own K slice, lanes take pieces lane and lane + 64 of [stream][kw / 4]
+  const int c4 = C >> 2, kq_w = kw >> 2, npw = NS * kq_w;
+  const int p0 = lane, p1 = lane + 64;
+  int st0 = p0 / kq_w, kq0 = (kb >> 2) + p0 % kq_w, st1 = p1 / kq_w, kq1 = (kb >> 2) + p1 % kq_w;
+  const bool h0 = p0 < npw && kq0 < c4, h1 = p1 < npw && kq1 < c4;
+  if (!h0) { st0 = 0; kq0 = 0; }
+  if (!h1) { st1 = 0; kq1 = 0; }
+  const int off0 = (min(s0 + st0, SE - 1) * ld + om + 4 * kq0) * 4, off1 = (min(s0 + st1, SE - 1) * ld + om + 4 * kq1) * 4;
+  // gate-block role: a quad of lanes owns one (stream, cell) pair, lane r of the quad its gate r (as lstm_seq_fwd)
+  const int pair = threadIdx.x >> 2, role = threadIdx.x & 3;
+  const int sl = pair >> 4, cc = pair & 15, s = s0 + sl, cell = c0 + cc;
+  const bool live = s < SE && cell < C;
+  const int cq = live ? cell : 0, sq = live ? s : 0;
+  float pw = 0.f;
+  if (!CIFG) pw = role == 1 ? D.peep_i[cq] : role == 2 ? D.peep_f[cq] : role == 3 ? D.peep_o[cq] : 0.f;
+  else pw = role == 1 ? D.peep_f[cq] : role == 2 ? D.peep_o[cq] : 0.f;
+  const int slen = (D.seq_lengths && live) ? D.seq_lengths[sq] : 0x7fffffff;
+  float cprev = 0.f;
+  {
+    const int tp0 = D.reverse ? T + 1 : 0;
+    if (live) cprev = D.y[((long)tp0 * S + sq) * ld + oc + cq];
+  }
+  unsigned polls = 0u;
+  // diagnostics (timing mode 3): workgroup 0 and the workgroup taken to share its CU log four absolute clocks per timestep
+  const int wpc_ = (C + kCellsPerWg - 1) / kCellsPerWg;
+  const int log_slot = !st.trace ? -1 : (blockIdx.x == 0 ? 0 : ((int)blockIdx.x == (st.half_map ? 8 * wpc_ : 8) ? 1 : -1));
+  unsigned long long *plog = log_slot >= 0 ? st.trace + 8 * 2048u + 1024u + log_slot * 256 : nullptr;
+  for (int step = 0; step < T; step++) {
+    const int t = D.reverse ? T - step : 1 + step, tp = D.reverse ? t + 1 : t - 1;
+    const int par = step & 1;
+    float *ys = D.y + ((long)t * S + sq) * ld;
+    long tm = tick(st);
+    const float xr = (live && role < G) ? ys[role * C + cq] : 0.f;
+    // EIGHT independent accumulators: one wave per SIMD multiplies at a time (the other workgroup's wave is in another phase), and a
+    // 4x4x1 product returns its accumulator after ~64 cycles -- four chains ran at 18 cycles per instruction, half the pipe's rate
+    f32x4 acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bool ok = true;
+    const bool first_special = step == 0 && first_in_kernel;
+    const bool product = !first_special && !(step == 0 && D.skip_first_product);
+    if (first_special) {   // r(0) of the chain's streams -> LDS (the history row block: stored before the launch, no hand-off)
+      const int kq = D.k_first >> 2;
+      for (int p = threadIdx.x; p < NS * kq; p += 256) {
+        const int sp = p / kq, k0 = 4 * (p % kq);
+        *reinterpret_cast<f32x4 *>(&m_lds[sp][k0]) =
+            *reinterpret_cast<const f32x4 *>(D.y + ((long)tp * S + min(s0 + sp, SE - 1)) * ld + D.col_first + k0);
+      }
+    }
+    if (product) {
+      const __amdgpu_buffer_rsrc_t rs = make_rsrc(D.y + (long)tp * S * ld);
+      u32x4 v0 = {0u, 0u, 0u, 0u}, v1 = {0u, 0u, 0u, 0u};
+      long t0 = 0;
+      for (unsigned spins = 0;; spins++) {
+        if (h0) v0 = __builtin_amdgcn_raw_buffer_load_b128(rs, off0, 0, kAuxSc1);
+        if (h1) v1 = __builtin_amdgcn_raw_buffer_load_b128(rs, off1, 0, kAuxSc1);
+        if (!__any((h0 && has_sentinel(v0)) || (h1 && has_sentinel(v1)))) break;
+        asm volatile("" ::: "memory");
+        polls++;
+        if (!spin_ok(spins, t0, st)) { ok = false; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (h0) *reinterpret_cast<u32x4 *>(&m_lds[st0][4 * kq0]) = v0;
+      if (h1) *reinterpret_cast<u32x4 *>(&m_lds[st1][4 * kq1]) = v1;
+    }
+    tock(st, 1, tm);  // collection
+    if (plog && threadIdx.x == 0 && step < 64) plog[4 * step + 0] = wall_clock64();
+    if (lane == 0) fail[par][wave] = ok ? 0 : 1;
+    if (first_special) __syncthreads();   // (uniform) every wave reads what all waves staged
+    else __builtin_amdgcn_wave_barrier();  // a wave reads back only what it stored itself
+    tock(st, 3, tm);
+    if (product) {
+      const float *arow = &m_lds[jl][kb];   // fragment i at a compile-time offset from here (past the wave's slice / past C: zeros or finite values x a zero B fragment)
+      constexpr int NF = KW / 4, PD = NF < 4 ? NF : 4;
+      f32x4 av[NF];
+#pragma unroll
+      for (int i = 0; i < PD; i++) av[i] = *reinterpret_cast<const f32x4 *>(arow + 4 * i);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < NF; i++) {
+        if (i + PD < NF) av[i + PD] = *reinterpret_cast<const f32x4 *>(arow + 4 * (i + PD));
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int b = 0;
+        acc[4 * (i & 1) + 0 + b] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i].x, bw[i].x, acc[4 * (i & 1) + 0 + b], 0, 0, 0);
+        acc[4 * (i & 1) + 1 + b] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i].y, bw[i].y, acc[4 * (i & 1) + 1 + b], 0, 0, 0);
+        acc[4 * (i & 1) + 2 + b] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i].z, bw[i].z, acc[4 * (i & 1) + 2 + b], 0, 0, 0);
+        acc[4 * (i & 1) + 3 + b] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i].w, bw[i].w, acc[4 * (i & 1) + 3 + b], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (first_special) {   // r(0) W_first^T: left operand from LDS, this lane's row of W_first straight from memory (one step per launch)
+      const int kwf = ((D.k_first + 15) / 16) * 4, kbf = wave * kwf;
+      const float *arow = &m_lds[jl][0];
+      const float *brow = D.w_first + (long)(nvalid ? gate_n * C + cell_n : 0) * D.ldw_first;
+      for (int k0 = kbf; k0 < min(kbf + kwf, D.k_first); k0 += 4) {
+        const f32x4 av = *reinterpret_cast<const f32x4 *>(arow + k0);
+        const f32x4 b = nvalid ? *reinterpret_cast<const f32x4 *>(brow + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+        acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.x, b.x, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.y, b.y, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.z, b.z, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.w, b.w, acc[3], 0, 0, 0);
+      }
+    }
+    {   // result register r of a lane = stream r of tile column `lane`
+      const f32x4 sum = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+      float *rp = &red[par][wave][0][lane];
+      rp[0 * RP] = sum.x; rp[1 * RP] = sum.y; rp[2 * RP] = sum.z; rp[3 * RP] = sum.w;
+    }
+    tock(st, 2, tm);  // product
+    if (plog && threadIdx.x == 0 && step < 64) plog[4 * step + 1] = wall_clock64();
+    __syncthreads();
+    tock(st, 4, tm);
+    if (plog && threadIdx.x == 0 && step < 64) plog[4 * step + 2] = wall_clock64();
+    if (fail[par][0] | fail[par][1] | fail[par][2] | fail[par][3]) return;  // uniform
+    float pre = 0.f;
+    if (role < G) {
+      pre = red[par][0][sl][role * 16 + cc];
+#pragma unroll
+      for (int w = 1; w < 4; w++) pre += red[par][w][sl][role * 16 + cc];
+    }
+    const bool masked = t > slen;
+    float gate = 0.f;
+    if (role == 0) gate = act_tanh<FAST>(xr + pre);
+    else if (role < G - 1) gate = act_sigmoid<FAST>(xr + pre + cprev * pw);
+    const float gg = quad_bcast<0>(gate), g1 = quad_bcast<1>(gate), g2 = quad_bcast<2>(gate);
+    float cellv;
+    if (!CIFG) cellv = gg * g1 + cprev * g2;
+    else cellv = -gg * g1 + gg + cprev * g1;
+    cellv = fminf(fmaxf(cellv, -50.0f), 50.0f);
+    float hh = 0.f;
+    if (role == 0) hh = act_tanh<FAST>(cellv);
+    if (role == G - 1) gate = act_sigmoid<FAST>(xr + pre + cellv * pw);
+    const float oo = quad_bcast<G - 1>(gate);
+    float mm = hh * oo;
+    if (masked) { gate = 0.f; cellv = 0.f; hh = 0.f; mm = 0.f; }
+    {
+      const float m1 = row_up<4>(mm), m2 = row_up<8>(mm), m3 = row_up<12>(mm);
+      if (live && role == 0 && (cc & 3) == 0) {
+        u32x4 pk = {__float_as_uint(mm), __float_as_uint(m1), __float_as_uint(m2), __float_as_uint(m3)};
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(D.y + (long)t * S * ld);
+        const int off = (s * ld + om + cell) * 4;
+        if (R.local) __builtin_amdgcn_raw_buffer_store_b128(pk, rs, off, 0, 0);
+        else __builtin_amdgcn_raw_buffer_store_b128(pk, rs, off, 0, kAuxSc1);
+      }
+    }
+    if (live) {
+      if (role < G) ys[role * C + cell] = gate;
+      if (role == 0) ys[oh + cell] = hh;
+      if (role == 1) ys[oc + cell] = cellv;
+    }
+    cprev = cellv;
+    tock(st, 5, tm);  // epilogue
+    if (plog && threadIdx.x == 0 && step < 64) plog[4 * step + 3] = wall_clock64();
+  }
+  if (st.timing && blockIdx.x == 0 && threadIdx.x == 0) {
+    st.timing[0] += (unsigned long long)T; st.timing[6] += R.local ? 1ull : 0ull;
+    st.timing[7] += (unsigned long long)((long)wall_clock64() - t_entry);
+  }
+  if (st.trace && threadIdx.x == 0) {
+    unsigned long long *tr = st.trace + (st.epoch & 7u) * 2048u;
+    tr[2 * blockIdx.x] = (unsigned long long)t_entry; tr[2 * blockIdx.x + 1] = wall_clock64();
+  }
+  if (polls && lane == 0) __hip_atomic_fetch_add(st.abort_flag + 2, polls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// backward, partitioned by input like lstm_seq_bwd.  One instruction = the chain's 4 streams x 64 cells (column = lane); wave w covers
+// the cell spans w * NH + h, h < NH (C <= 256 * NH).
+//   inbox[ring slot][chain 16][consumer block][producer block][column 0..15] of f32x4 (the 4 streams)
+template <bool CIFG, int NH>
+__global__ void __launch_bounds__(256, 2) lstm_seq_bwd4(aslp_lstm_seq a, SeqStatus st, unsigned *place, float *inbox) {
+  constexpr int G = CIFG ? 3 : 4, KS = 4 * G, NS = kHalfStreams;
+  __shared__ __attribute__((aligned(16))) float own_dg[2][NS][16 * G + 4];
+  __shared__ __attribute__((aligned(16))) float shares[kMaxWgPerChain * 16 * 4];   // [producer][column][stream]
+  __shared__ int fail[2][4];
+  __shared__ int place_flag;
+  const long t_entry = st.trace ? (long)wall_clock64() : 0;
+  const int SE = a.s_count > 0 ? a.s_begin + a.s_count : a.S;
+  int chain, me;
+  const ChainRole R = chain_role4(SE - a.s_begin, a.ndir, a.C, st, place, &place_flag, &chain, &me);
+  if (!R.active) return;
+  const aslp_lstm_seq_dir D = a.dir[R.dir];
+  const int C = a.C, S = a.S, T = a.T, ld = a.ld;
+  const int GC = G * C, oc = GC, oh = GC + C, om = GC + 2 * C;
+  const int og = 0, oi = C, of = CIFG ? C : 2 * C, oo = CIFG ? 2 * C : 3 * C;
+  const int c0 = R.c0, s0 = a.s_begin + R.s0;
+  const int wpc = (C + kCellsPerWg - 1) / kCellsPerWg;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int jl = lane & 3;
+  float bw[NH][KS * 4];
+#pragma unroll
+  for (int h = 0; h < NH; h++) {
+    const int col = 64 * (wave * NH + h) + lane;
+    const bool colok = col < C;
+#pragma unroll
+    for (int kk = 0; kk < KS * 4; kk++) {
+      const int cellk = c0 + (kk & 15);
+      bw[h][kk] = (colok && cellk < C) ? D.w[(long)((kk >> 4) * C + cellk) * a.ldw + col] : 0.f;
+    }
+  }
+  const size_t slot_words = (size_t)kMaxChains4 * kMaxWgPerChain * kMaxWgPerChain * 64;  // floats per ring slot
+  float *chain_box = inbox + (size_t)chain * kMaxWgPerChain * kMaxWgPerChain * 64;
+  const int npiece = wpc * 16;  // 16-byte pieces addressed to this workgroup per timestep: [producer][column]
+  const int sl = threadIdx.x >> 4, cc = threadIdx.x & 15, s = s0 + sl, cell = c0 + cc;
+  const bool live = threadIdx.x < 64 && s < SE && cell < C;
+  const int cq = live ? cell : 0, sq = live ? s : 0;
+  const float pf = D.peep_f[cq], po = D.peep_o[cq], pi = CIFG ? 0.f : D.peep_i[cq];
+  float dn_c = 0.f, dn_f = 0.f, dn_i = 0.f;
+  float gsum[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  unsigned polls = 0u;
+  for (int step = 0; step < T; step++) {
+    const int t = D.reverse ? 1 + step : T - step;
+    const int tn = D.reverse ? t - 1 : t + 1, tp = D.reverse ? t + 1 : t - 1;
+    const int par = step & 1;
+    const long o_ = ((long)t * S + sq) * ld;
+    long tm = tick(st);
+    float dm = 0.f, yo = 0.f, yh = 0.f, yg = 0.f, yf = 0.f, yi = 0.f, yn_f = 0.f, cprev = 0.f, ccur = 0.f;
+    if (live) {
+      dm = D.d[o_ + om + cq];
+      yo = D.y[o_ + oo + cq]; yh = D.y[o_ + oh + cq]; yg = D.y[o_ + og + cq]; yf = D.y[o_ + of + cq];
+      if (!CIFG) yi = D.y[o_ + oi + cq];
+      yn_f = D.y[((long)tn * S + sq) * ld + of + cq];
+      cprev = D.y[((long)tp * S + sq) * ld + oc + cq];
+      if (a.grad_partial) ccur = D.y[o_ + oc + cq];
+    }
+    bool ok = true;
+    if (step > 0) {
+      float *box = chain_box + (size_t)(step % kRing) * slot_words;
+      {
+        f32x4 av[KS];
+        const float *arow = &own_dg[par ^ 1][jl][0];
+        constexpr int PD = KS < 4 ? KS : 4;
+#pragma unroll
+        for (int q = 0; q < PD; q++) av[q] = *reinterpret_cast<const f32x4 *>(arow + 4 * q);
+        f32x4 acc[NH][4];   // 4 NH independent chains per wave (one wave per SIMD multiplies at a time: see lstm_seq_fwd4)
+#pragma unroll
+        for (int h = 0; h < NH; h++)
+#pragma unroll
+          for (int c = 0; c < 4; c++) acc[h][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < KS; q++) {
+          if (q + PD < KS) av[q + PD] = *reinterpret_cast<const f32x4 *>(arow + 4 * (q + PD));
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int h = 0; h < NH; h++) acc[h][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[q].x, bw[h][4 * q + 0], acc[h][0], 0, 0, 0);
+#pragma unroll
+          for (int h = 0; h < NH; h++) acc[h][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[q].y, bw[h][4 * q + 1], acc[h][1], 0, 0, 0);
+#pragma unroll
+          for (int h = 0; h < NH; h++) acc[h][2] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[q].z, bw[h][4 * q + 2], acc[h][2], 0, 0, 0);
+#pragma unroll
+          for (int h = 0; h < NH; h++) acc[h][3] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[q].w, bw[h][4 * q + 3], acc[h][3], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(box);
+#pragma unroll
+        for (int h = 0; h < NH; h++) {
+          const int col = 64 * (wave * NH + h) + lane, cb = col >> 4;
+          if (cb < wpc) {
+            const f32x4 sum = (acc[h][0] + acc[h][1]) + (acc[h][2] + acc[h][3]);
+            const int off = ((cb * kMaxWgPerChain + me) * 16 + (lane & 15)) * 16;
+            const u32x4 pk = {__float_as_uint(sum.x), __float_as_uint(sum.y), __float_as_uint(sum.z), __float_as_uint(sum.w)};
+            if (R.local) __builtin_amdgcn_raw_buffer_store_b128(pk, rs, off, 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b128(pk, rs, off, 0, kAuxSc1);
+          }
+        }
+      }
+      tock(st, 1, tm);
+      {
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(box + (size_t)me * kMaxWgPerChain * 64);
+        const int i0 = threadIdx.x, i1 = threadIdx.x + 256;
+        const bool h0 = i0 < npiece, h1 = i1 < npiece;
+        u32x4 v0 = {0u, 0u, 0u, 0u}, v1 = {0u, 0u, 0u, 0u};
+        long t0 = 0;
+        for (unsigned spins = 0;; spins++) {
+          if (h0) v0 = __builtin_amdgcn_raw_buffer_load_b128(rs, i0 * 16, 0, kAuxSc1);
+          if (h1) v1 = __builtin_amdgcn_raw_buffer_load_b128(rs, i1 * 16, 0, kAuxSc1);
+          if (!__any((h0 && has_sentinel(v0)) || (h1 && has_sentinel(v1)))) break;
+          asm volatile("" ::: "memory");
+          polls++;
+          if (!spin_ok(spins, t0, st)) { ok = false; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        const u32x4 sent = {kSentinel, kSentinel, kSentinel, kSentinel};
+        if (R.local) {
+          if (h0) __builtin_amdgcn_raw_buffer_store_b128(sent, rs, i0 * 16, 0, 0);
+          if (h1) __builtin_amdgcn_raw_buffer_store_b128(sent, rs, i1 * 16, 0, 0);
+        } else {
+          if (h0) __builtin_amdgcn_raw_buffer_store_b128(sent, rs, i0 * 16, 0, kAuxSc1);
+          if (h1) __builtin_amdgcn_raw_buffer_store_b128(sent, rs, i1 * 16, 0, kAuxSc1);
+        }
+        if (h0) *reinterpret_cast<u32x4 *>(&shares[i0 * 4]) = v0;
+        if (h1) *reinterpret_cast<u32x4 *>(&shares[i1 * 4]) = v1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      tock(st, 2, tm);
+    }
+    if (lane == 0) fail[par][wave] = ok ? 0 : 1;
+    __syncthreads();
+    tock(st, 4, tm);
+    if (fail[par][0] | fail[par][1] | fail[par][2] | fail[par][3]) return;
+    if (threadIdx.x < 64) {
+      if (step > 0) {  // shares of my 16 cells, added in workgroup order
+        float psum = 0.f;
+        const int base = cc * 4 + sl;
+        for (int p = 0; p < wpc; p++) psum += shares[p * 64 + base];
+        dm += psum;
+      }
+      const float dh = dtanh(yh, dm * yo);
+      const float dov = dsigm(yo, dm * yh);
+      float dc = dh + dn_c * yn_f;
+      if (!CIFG) dc += dn_i * pi;
+      dc += dn_f * pf;
+      dc += dov * po;
+      float dg, df, di = 0.f;
+      if (!CIFG) {
+        df = dsigm(yf, dc * cprev);
+        di = dsigm(yi, dc * yg);
+        dg = dtanh(yg, dc * yi);
+      } else {
+        df = dsigm(yf, dc * cprev - dc * yg);
+        dg = dtanh(yg, dc - dc * yf);
+      }
+      float *mine = &own_dg[par][sl][cc];
+      mine[0] = dg;
+      if (!CIFG) { mine[16] = di; mine[32] = df; mine[48] = dov; }
+      else { mine[16] = df; mine[32] = dov; }
+      if (live) {
+        D.d[o_ + og + cell] = dg; D.d[o_ + of + cell] = df; D.d[o_ + oo + cell] = dov;
+        if (!CIFG) D.d[o_ + oi + cell] = di;
+        D.d[o_ + om + cell] = dm;
+        D.d[o_ + oh + cell] = dh;
+        D.d[o_ + oc + cell] = dc;
+      }
+      dn_c = dc; dn_f = df; dn_i = di;
+      if (a.grad_partial && live) {
+        gsum[0] += dg; gsum[2] += df; gsum[3] += dov;
+        gsum[5] += df * cprev; gsum[6] += dov * ccur;
+        if (!CIFG) { gsum[1] += di; gsum[4] += di * cprev; }
+      }
+    }
+    tock(st, 5, tm);
+    __syncthreads();
+  }
+  if (a.grad_partial) {   // the chain's 4 streams meet in LDS (stream order), one row of 16 cells per quantity goes out per workgroup
+    float *gl = shares;   // [stream 4][quantity 7][cell 16]
+    if (threadIdx.x < 64) {
+#pragma unroll
+      for (int k = 0; k < 7; k++) gl[(sl * 7 + k) * 16 + cc] = gsum[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 7 * 16) {
+      const int k = threadIdx.x >> 4, c = threadIdx.x & 15;
+      float v = gl[k * 16 + c];
+#pragma unroll
+      for (int q = 1; q < NS; q++) v += gl[(q * 7 + k) * 16 + c];
+      if (c0 + c < C) a.grad_partial[((long)chain * 7 + k) * a.grad_ld + c0 + c] = v;
+    }
+  }
+  if (st.timing && blockIdx.x == 0 && threadIdx.x == 0) { st.timing[0] += (unsigned long long)T; st.timing[6] += R.local ? 1ull : 0ull; }
+  if (st.trace && threadIdx.x == 0) {
     unsigned long long *tr = st.trace + (st.epoch & 7u) * 2048u;
     tr[2 * blockIdx.x] = (unsigned long long)t_entry; tr[2 * blockIdx.x + 1] = wall_clock64();
   }
@@ -1028,6 +1520,7 @@ struct SeqRuntime {
   unsigned *host_err_dev = nullptr;
   int num_cu = 0;
   bool ok = false;
+  std::mutex launch_mu;   // one persistent launch (LSTM or GRU) is issued at a time: epoch, event chaining, abort word, placement table, ring
 };
 SeqRuntime &seq_runtime() {
   static SeqRuntime rt;
@@ -1037,10 +1530,11 @@ SeqRuntime &seq_runtime() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return;
     rt.num_cu = prop.multiProcessorCount;
-    const size_t bytes = 64 + sizeof(unsigned) * kMaxChains * kMaxWgPerChain;
+    const size_t bytes = 64 + sizeof(unsigned) * kMaxChains4 * kMaxWgPerChain;
     if (hipMalloc(&rt.abort_flag, bytes) != hipSuccess || hipMemset(rt.abort_flag, 0, bytes) != hipSuccess) return;
     rt.place = rt.abort_flag + 16;
-    if (hipMalloc(&rt.timing, 64 + 8 * 16 * 1024) != hipSuccess || hipMemset(rt.timing, 0, 64 + 8 * 16 * 1024) != hipSuccess) return;
+    // 8 timing words, a ring of 8 launches x 2048 residency words, 1024 placement-census words (lstm_seq_fwd4)
+    if (hipMalloc(&rt.timing, 64 + 8 * 18 * 1024) != hipSuccess || hipMemset(rt.timing, 0, 64 + 8 * 18 * 1024) != hipSuccess) return;   // + 1024 phase-log words
     if (hipMalloc(&rt.inbox, sizeof(float) * (size_t)kRing * kMaxChains * kMaxWgPerChain * kMaxWgPerChain * 128) != hipSuccess) return;
     if (hipHostMalloc(&rt.host_err, 64, hipHostMallocMapped) != hipSuccess) return;
     *rt.host_err = 0;
@@ -1054,14 +1548,39 @@ SeqRuntime &seq_runtime() {
 
 typedef void (*SeqKernel)(aslp_lstm_seq, SeqStatus, unsigned *);
 typedef void (*SeqKernelB)(aslp_lstm_seq, SeqStatus, unsigned *, float *);
+bool fast_act() {   // A/B switch: ASLP_LSTM_FAST_ACT=0 keeps the correctly rounded expf / division of the reference's CPU code
+  static const bool off = getenv("ASLP_LSTM_FAST_ACT") != nullptr && getenv("ASLP_LSTM_FAST_ACT")[0] == '0';
+  return !off;
+}
 SeqKernel pick_fwd(bool cifg, int C) {
-  if (C <= 128) return cifg ? lstm_seq_fwd<true, 16> : lstm_seq_fwd<false, 16>;
-  if (C <= 512) return cifg ? lstm_seq_fwd<true, 64> : lstm_seq_fwd<false, 64>;
+  if (fast_act()) {
+    if (C <= 128) return cifg ? lstm_seq_fwd<true, 16, true> : lstm_seq_fwd<false, 16, true>;
+    if (C <= 512) return cifg ? lstm_seq_fwd<true, 64, true> : lstm_seq_fwd<false, 64, true>;
+    return nullptr;
+  }
+  if (C <= 128) return cifg ? lstm_seq_fwd<true, 16, false> : lstm_seq_fwd<false, 16, false>;
+  if (C <= 512) return cifg ? lstm_seq_fwd<true, 64, false> : lstm_seq_fwd<false, 64, false>;
   return nullptr;
 }
 SeqKernelB pick_bwd(bool cifg, int C) {
   if (C <= 128) return cifg ? lstm_seq_bwd<true, 1> : lstm_seq_bwd<false, 1>;
   if (C <= 512) return cifg ? lstm_seq_bwd<true, 4> : lstm_seq_bwd<false, 4>;
+  return nullptr;
+}
+
+SeqKernel pick_fwd4(bool cifg, int C) {
+  if (fast_act()) {
+    if (C <= 128) return cifg ? lstm_seq_fwd4<true, 32, true> : lstm_seq_fwd4<false, 32, true>;
+    if (C <= 512) return cifg ? lstm_seq_fwd4<true, 128, true> : lstm_seq_fwd4<false, 128, true>;
+    return nullptr;
+  }
+  if (C <= 128) return cifg ? lstm_seq_fwd4<true, 32, false> : lstm_seq_fwd4<false, 32, false>;
+  if (C <= 512) return cifg ? lstm_seq_fwd4<true, 128, false> : lstm_seq_fwd4<false, 128, false>;
+  return nullptr;
+}
+SeqKernelB pick_bwd4(bool cifg, int C) {
+  if (C <= 256) return cifg ? lstm_seq_bwd4<true, 1> : lstm_seq_bwd4<false, 1>;
+  if (C <= 512) return cifg ? lstm_seq_bwd4<true, 2> : lstm_seq_bwd4<false, 2>;
   return nullptr;
 }
 
@@ -1091,6 +1610,36 @@ bool grid_fits(const void *k, int threads, long blocks) {
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, threads, 0) != hipSuccess || occ < 1) return false;
   return blocks <= (long)rt.num_cu * (occ >= 2 ? occ - 1 : 1);
 }
+// The half-chain kernels want exactly two 256-thread workgroups per CU; at ~200 VGPRs the register file admits two and no third, which
+// is a limit the occupancy API reports exactly (its known over-report comes from the SGPR budget at many blocks per CU).
+bool grid_fits_half(const void *k, long blocks) {
+  SeqRuntime &rt = seq_runtime();
+  if (!rt.ok || !k) return false;
+  static std::mutex mu;
+  static std::vector<std::pair<const void *, int>> cache;   // occupancy per kernel, asked once
+  int occ = 0;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto &e : cache) if (e.first == k) occ = e.second;
+    if (occ == 0) {
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, 256, 0) != hipSuccess || occ < 1) occ = -1;
+      cache.emplace_back(k, occ);
+    }
+  }
+  return occ >= 2 && blocks <= (long)rt.num_cu * 2;
+}
+// Streams per chain a launch with these arguments uses: 4 (half chains, two workgroups per CU) where that scheme applies, else 8.
+int chain_streams_for(const aslp_lstm_seq *a, bool backward) {
+  // A/B switch, default off: measured on cfg3 the half chains are level with the chains of 8 (3.19 vs 3.16 ms per step) -- each chain's
+  // timestep is the same serial hand-off -> product -> gate-block path, and two of them on a CU take each other's LDS / VALU slots
+  static const bool half_on = getenv("ASLP_LSTM_HALF_CHAINS") != nullptr && getenv("ASLP_LSTM_HALF_CHAINS")[0] == '1';
+  if (!half_on || !a) return kChainStreams;
+  const int ns = a->s_count > 0 ? a->s_count : a->S;
+  const int nsg = (ns + kHalfStreams - 1) / kHalfStreams, wpc = (a->C + kCellsPerWg - 1) / kCellsPerWg, nchains = a->ndir * nsg;
+  if (nchains > kMaxChains4 || wpc > kMaxWgPerChain) return kChainStreams;
+  const void *k = backward ? reinterpret_cast<const void *>(pick_bwd4(a->cifg != 0, a->C)) : reinterpret_cast<const void *>(pick_fwd4(a->cifg != 0, a->C));
+  return grid_fits_half(k, (long)(nchains > 8 ? 16 : 8) * wpc) ? kHalfStreams : kChainStreams;
+}
 
 }  // namespace
 }  // namespace aslp
@@ -1103,6 +1652,7 @@ int aslp_lstm_seq_supported(const aslp_lstm_seq *a, int backward) {
   static const bool disabled = getenv("ASLP_LSTM_PERSISTENT") != nullptr && getenv("ASLP_LSTM_PERSISTENT")[0] == '0';
   if (disabled || !seq_args_ok(a)) return 0;
   if (a->s_begin < 0 || a->s_count < 0 || a->s_begin + a->s_count > a->S) return 0;
+  if (chain_streams_for(a, backward != 0) == kHalfStreams) return 1;
   const int ns = a->s_count > 0 ? a->s_count : a->S;   // streams of this launch
   const int nsg = (ns + kChainStreams - 1) / kChainStreams, wpc = (a->C + kCellsPerWg - 1) / kCellsPerWg;
   if (a->ndir * nsg > kMaxChains || wpc > kMaxWgPerChain) return 0;   // <= 32 streams per launch (bidirectional) / 64, C <= 512
@@ -1111,6 +1661,11 @@ int aslp_lstm_seq_supported(const aslp_lstm_seq *a, int backward) {
 }
 
 int aslp_lstm_seq_first_product_supported(int k_first) { return k_first > 0 && k_first <= kFirstK && (k_first & 3) == 0; }
+// ... for a layer of C cells: the kernels stage r(0) in LDS rows as long as the K range of their instantiation (128 floats for C <= 128, else 512)
+int aslp_lstm_seq_first_product_supported_for(int k_first, int C) {
+  return aslp_lstm_seq_first_product_supported(k_first) && k_first <= (C <= 128 ? 128 : 512);
+}
+int aslp_lstm_seq_chain_streams(const aslp_lstm_seq *a, int backward) { return seq_args_ok(a) ? chain_streams_for(a, backward != 0) : kChainStreams; }
 
 void aslp_lstm_seq_fill(float *buf, int ld, int T, int S, int col0, int ncols) {
   if (!buf || T <= 0 || S <= 0 || ld <= 0) return;
@@ -1139,13 +1694,12 @@ static void launch_seq(const aslp_lstm_seq *a, bool backward, const char *who) {
   // One persistent launch at a time per process: the kernels share the placement table, the abort word and the share ring, and two
   // grids that both need every CU must not be half resident beside each other.  Launches from different host threads / streams
   // are therefore chained by an event (no host wait); the common single-stream case costs one event record per launch.
-  static std::mutex launch_mu;
-  std::lock_guard<std::mutex> launch_lock(launch_mu);
+  std::lock_guard<std::mutex> launch_lock(rt.launch_mu);
   if (rt.last_done && rt.last_stream != cur_stream()) ASLP_CHECK_HIP(hipStreamWaitEvent(cur_stream(), rt.last_done, 0));
   // Device-side state is self-cleaning: the placement table is epoch-tagged and every share a backward launch publishes is
   // consumed and reset inside that launch.  Only after a launch that gave up (the mapped error word moved) are the abort
   // word and the share ring put back by hand.
-  const size_t slot_bytes = sizeof(float) * (size_t)kMaxChains * kMaxWgPerChain * kMaxWgPerChain * 128;
+  const size_t slot_bytes = sizeof(float) * (size_t)kMaxChains * kMaxWgPerChain * kMaxWgPerChain * 128;   // = 16 chains x 64 floats (half chains)
   if (*rt.host_err != rt.err_seen || !rt.ring_ready) {
     rt.err_seen = *rt.host_err;
     ASLP_CHECK_HIP(hipMemsetAsync(rt.abort_flag, 0, 4, cur_stream()));
@@ -1156,10 +1710,17 @@ static void launch_seq(const aslp_lstm_seq *a, bool backward, const char *who) {
   if (rt.epoch == 0u) rt.epoch = 1u;
   static const unsigned wave_collect = ((getenv("ASLP_LSTM_WAVE_COLLECT") != nullptr && getenv("ASLP_LSTM_WAVE_COLLECT")[0] == '0') ? 0u : 1u) |   // A/B switches
                                        ((getenv("ASLP_LSTM_READ_AHEAD") != nullptr && getenv("ASLP_LSTM_READ_AHEAD")[0] == '0') ? 0u : 2u);
+  static const unsigned half_map = (getenv("ASLP_LSTM_HALF_MAP") != nullptr && getenv("ASLP_LSTM_HALF_MAP")[0] == '0') ? 0u : 1u;
+  static const unsigned half_delay_ns = getenv("ASLP_LSTM_HALF_DELAY_NS") != nullptr ? (unsigned)atoi(getenv("ASLP_LSTM_HALF_DELAY_NS")) : 1200u;
   SeqStatus st = {rt.abort_flag, rt.host_err_dev, ((rt.timing_mode == 1 && !backward) || (rt.timing_mode == 2 && backward)) ? rt.timing : nullptr,
-                  ((rt.timing_mode == 3 && !backward) || (rt.timing_mode == 4 && backward)) ? rt.timing + 8 : nullptr, rt.epoch, wave_collect};
+                  ((rt.timing_mode == 3 && !backward) || (rt.timing_mode == 4 && backward)) ? rt.timing + 8 : nullptr, rt.epoch, wave_collect, half_map, half_delay_ns / 10u};
   const int wpc = (a->C + kCellsPerWg - 1) / kCellsPerWg;
-  if (!backward) hipLaunchKernelGGL(pick_fwd(a->cifg != 0, a->C), dim3(kMaxChains * wpc), dim3(512), 0, cur_stream(), *a, st, rt.place);
+  if (chain_streams_for(a, backward) == kHalfStreams) {
+    const int ns = a->s_count > 0 ? a->s_count : a->S, nchains = a->ndir * ((ns + kHalfStreams - 1) / kHalfStreams);
+    const int grid = (nchains > 8 ? 16 : 8) * wpc;
+    if (!backward) hipLaunchKernelGGL(pick_fwd4(a->cifg != 0, a->C), dim3(grid), dim3(256), 0, cur_stream(), *a, st, rt.place);
+    else hipLaunchKernelGGL(pick_bwd4(a->cifg != 0, a->C), dim3(grid), dim3(256), 0, cur_stream(), *a, st, rt.place, rt.inbox);
+  } else if (!backward) hipLaunchKernelGGL(pick_fwd(a->cifg != 0, a->C), dim3(kMaxChains * wpc), dim3(512), 0, cur_stream(), *a, st, rt.place);
   else hipLaunchKernelGGL(pick_bwd(a->cifg != 0, a->C), dim3(kMaxChains * wpc), dim3(512), 0, cur_stream(), *a, st, rt.place, rt.inbox);
   if (!rt.last_done) (void)hipEventCreateWithFlags(&rt.last_done, hipEventDisableTiming);
   if (rt.last_done) { ASLP_CHECK_HIP(hipEventRecord(rt.last_done, cur_stream())); rt.last_stream = cur_stream(); }
@@ -1183,8 +1744,7 @@ static void launch_gru(const aslp_gru_seq *a, bool backward, const char *who) {
     return;
   }
   SeqRuntime &rt = seq_runtime();
-  static std::mutex launch_mu;   // as launch_seq: one persistent launch at a time, chained by an event across streams
-  std::lock_guard<std::mutex> launch_lock(launch_mu);
+  std::lock_guard<std::mutex> launch_lock(rt.launch_mu);   // as launch_seq (the same lock: LSTM and GRU launches share the runtime state)
   if (rt.last_done && rt.last_stream != cur_stream()) ASLP_CHECK_HIP(hipStreamWaitEvent(cur_stream(), rt.last_done, 0));
   if (*rt.host_err != rt.err_seen) {
     rt.err_seen = *rt.host_err;
@@ -1194,7 +1754,7 @@ static void launch_gru(const aslp_gru_seq *a, bool backward, const char *who) {
   rt.epoch = (rt.epoch + 1u) & 0x0FFFFFFFu;
   if (rt.epoch == 0u) rt.epoch = 1u;
   SeqStatus st = {rt.abort_flag, rt.host_err_dev, nullptr, ((rt.timing_mode == 3 && !backward) || (rt.timing_mode == 4 && backward)) ? rt.timing + 8 : nullptr,
-                  rt.epoch, 0u};
+                  rt.epoch, 0u, 0u, 0u};
   const int wpc = (a->H + kCellsPerWg - 1) / kCellsPerWg;
   hipLaunchKernelGGL(pick_gru(backward, a->H), dim3(kMaxChains * wpc), dim3(512), 0, cur_stream(), *a, st, rt.place);
   if (!rt.last_done) (void)hipEventCreateWithFlags(&rt.last_done, hipEventDisableTiming);
@@ -1225,6 +1785,22 @@ void aslp_lstm_seq_residency(unsigned long long *out, int n, int launches_back) 
   (void)hipStreamSynchronize(cur_stream());
   (void)hipMemcpy(out, rt.timing + 8 + ((rt.epoch - (unsigned)launches_back) & 7u) * 2048u, sizeof(unsigned long long) * 2 * n, hipMemcpyDeviceToHost);
 }
+// devtools: with aslp_lstm_seq_timing(3, NULL) in effect the half-chain forward kernel (lstm_seq_fwd4) also records where every workgroup
+// ran and whom it served: out[b] = XCC id << 48 | HW_ID[15:0] << 32 | chain << 8 | block within the chain, b < n <= 1024.  Synchronises.
+void aslp_lstm_seq_census(unsigned long long *out, int n) {
+  SeqRuntime &rt = seq_runtime();
+  if (!rt.ok || !out || n <= 0 || n > 1024) return;
+  (void)hipStreamSynchronize(cur_stream());
+  (void)hipMemcpy(out, rt.timing + 8 + 8 * 2048u, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost);
+}
+// devtools: after a traced half-chain forward launch (timing mode 3): out[slot * 256 + 4 * step + k], slot 0 = workgroup 0, slot 1 = the workgroup
+// taken to share its CU; k = clock (10 ns ticks) after collection / product / barrier / gate block of that timestep (step < 64)
+void aslp_lstm_seq_phase_log(unsigned long long *out) {
+  SeqRuntime &rt = seq_runtime();
+  if (!rt.ok || !out) return;
+  (void)hipStreamSynchronize(cur_stream());
+  (void)hipMemcpy(out, rt.timing + 8 + 8 * 2048u + 1024u, sizeof(unsigned long long) * 512, hipMemcpyDeviceToHost);
+}
 unsigned aslp_lstm_seq_polls(int reset) {
   SeqRuntime &rt = seq_runtime();
   unsigned v = 0;
@@ -1240,7 +1816,8 @@ static bool fill_vec_grad_args(SeqVecGradArgs &g, const aslp_lstm_seq *a, int di
       !peep_o_corr || !peep_o || (!a->cifg && (!peep_i_corr || !peep_i)))
     return false;
   g.partial = a->grad_partial; g.ld = a->grad_ld; g.ndir = a->ndir; g.dir = dir;
-  g.nsg = ((a->s_count > 0 ? a->s_count : a->S) + kChainStreams - 1) / kChainStreams;
+  const int cs = chain_streams_for(a, true);
+  g.nsg = ((a->s_count > 0 ? a->s_count : a->S) + cs - 1) / cs;
   g.C = a->C; g.cifg = a->cifg; g.mmt = mmt; g.clip = clip; g.neg_lr = neg_lr;
   const int C = a->C;
   // gate order of the buffer: g, i, f, o (cifg: g, f, o)

@@ -5,6 +5,7 @@
 #include <algorithm>
 
 #include "nnet-basic.h"
+#include "nnet-conv.h"
 #include "nnet-recurrent.h"
 #include "nnet-temporal.h"
 
@@ -91,12 +92,15 @@ Component *Component::NewComponentOfType(ComponentType comp_type, int32 input_di
     case kGruStreams: ans = new GruStreams(input_dim, output_dim); break;
     case kRowConvolution: ans = new RowConvolution(input_dim, output_dim); break;
     case kCompactFsmn: ans = new CompactFsmn(input_dim, output_dim); break;
+    case kLinearTransform: ans = new LinearTransform(input_dim, output_dim); break;
+    case kConvolutionalComponent: ans = new ConvolutionalComponent(input_dim, output_dim); break;
+    case kMaxPoolingComponent: ans = new MaxPoolingComponent(input_dim, output_dim); break;
+    case kLengthNormComponent: ans = new LengthNormComponent(input_dim, output_dim); break;
+    case kPnormComponent: ans = new PnormComponent(input_dim, output_dim); break;
+    case kMaxoutComponent: ans = new MaxoutComponent(input_dim, output_dim); break;
     case kUnknown:
     default:
-      // Out of the hot-path scope: LinearTransform, Convolutional, MaxPooling,
-      // Dropout, LengthNorm, Pnorm/Maxout.  Fail loudly rather than silently mis-train.
-      ASLP_ERR << "Component type " << TypeToMarker(comp_type) << " is not built in this library "
-               << "(outside the aslp-nnet training hot path)";
+      ASLP_ERR << "Missing type: " << TypeToMarker(comp_type);   // nnet-component.cc:203-205
   }
   return ans;
 }

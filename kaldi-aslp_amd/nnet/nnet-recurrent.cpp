@@ -594,7 +594,7 @@ void LstmFamily::PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) {
     // The carried history holds r(0) = m(0) W_rm^T formed with the weights of the PREVIOUS batch (the reference
     // recurs on the stored r, lc.h:575); m(0) W_eff^T would silently re-project it with the updated W_rm.  The persistent
     // kernel forms r(0) W_r^T itself at its first step where it can; otherwise a 32-row product adds it here.
-    const bool first_in_kernel = carried && cfg_.proj && persistent && aslp_lstm_seq_first_product_supported(f_.R) != 0 &&
+    const bool first_in_kernel = carried && cfg_.proj && persistent && aslp_lstm_seq_first_product_supported_for(f_.R, ncell_) != 0 &&
                                  f_.w_r.Stride() % 4 == 0 && f_.OffRec() % 4 == 0;
     if (carried && cfg_.proj && !first_in_kernel) {
       CuSubMatrix y_gates(f_buf_, S, S, 0, f_.GC()), r0(f_buf_, 0, S, f_.OffRec(), f_.R);
@@ -690,7 +690,7 @@ void LstmFamily::BackpropagateFnc(const CuMatrixBase &in, const CuMatrixBase &, 
       q.ld = f_dbuf_.Stride(); q.ldw = f_.Weff().Stride();
       static const bool vec_fused_off = getenv("ASLP_LSTM_VEC_FUSED") != nullptr && getenv("ASLP_LSTM_VEC_FUSED")[0] == '0';   // A/B switch
       if (!vec_fused_off && nwin == 1) {   // the kernel also leaves the sums the bias / peephole gradients are made of (8 chains x 7 quantities x C)
-        if (grad_partial_.NumRows() != 8 * 7 || grad_partial_.NumCols() != ncell_) grad_partial_.Resize(8 * 7, ncell_, kUndefined);
+        if (grad_partial_.NumRows() != 16 * 7 || grad_partial_.NumCols() != ncell_) grad_partial_.Resize(16 * 7, ncell_, kUndefined);   // <= 16 chains
         q.grad_partial = grad_partial_.Data();
         q.grad_ld = grad_partial_.Stride();
       }

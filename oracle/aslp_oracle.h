@@ -126,6 +126,35 @@ void orc_xent_eval(const float *frame_weights, const float *net_out, int ldn, co
 void orc_mse_eval(const float *frame_weights, const float *net_out, int ldn, const float *targets,
                   int ldt, int rows, int cols, float *diff, int ldd, double *loss, double *frames);
 
+/* ---- front-end components of the CNN / cFSMN recipes (aslp_oracle_conv.c) ------------------------------------------- */
+/* LinearTransform, nnet-linear-transform.h:127-160 (orc_affine_opts: learn_rate, momentum, l2, l1, learn_rate_coef are used) */
+void orc_linear_propagate(float *out, int ldo, const float *in, int ldi, int rows, const float *W, int ldw, int in_dim, int out_dim);
+void orc_linear_backpropagate(float *in_diff, int ldid, const float *out_diff, int ldod, int rows, const float *W, int ldw, int in_dim, int out_dim);
+void orc_linear_update(float *W, int ldw, float *W_corr, int ldc, const float *input, int ldi, const float *diff, int ldd, int rows, int in_dim,
+                       int out_dim, const orc_affine_opts *o);
+/* ConvolutionalComponent, nnet-convolutional-component.h:268-470.  patches / patch_diffs: [rows x filter_dim * num_patches], ld = that width
+ * (vectorized_feature_patches_, feature_patch_diffs_); filters [num_filters x filter_dim]; filters_grad dense (ld = filter_dim) */
+void orc_conv_propagate(float *out, int ldo, float *patches, const float *in, int ldi, int rows, int in_dim, const float *filters, int ldf,
+                        const float *bias, int num_filters, int patch_dim, int patch_step, int patch_stride);
+void orc_conv_backpropagate(float *in_diff, int ldid, float *patch_diffs, const float *out_diff, int ldod, int rows, int in_dim, const float *filters,
+                            int ldf, int num_filters, int patch_dim, int patch_step, int patch_stride);
+void orc_conv_update(float *filters, int ldf, float *bias, float *filters_grad, float *bias_grad, const float *patches, const float *diff, int ldd,
+                     int rows, int in_dim, int num_filters, int patch_dim, int patch_step, int patch_stride, float learn_rate, float learn_rate_coef,
+                     float bias_learn_rate_coef, float max_norm);
+/* MaxPoolingComponent, nnet-max-pooling-component.h:101-162 */
+void orc_max_pool_propagate(float *out, int ldo, const float *in, int ldi, int rows, int in_dim, int pool_size, int pool_step, int pool_stride);
+void orc_max_pool_backpropagate(float *in_diff, int ldid, const float *in, int ldi, const float *out, int ldo, const float *out_diff, int ldod, int rows,
+                                int in_dim, int pool_size, int pool_step, int pool_stride);
+/* LengthNormComponent, nnet-various.h:338-358 */
+void orc_length_norm_propagate(float *out, int ldo, float *row_scales, const float *in, int ldi, int rows, int cols);
+void orc_length_norm_backpropagate(float *in_diff, int ldid, const float *out_diff, int ldod, const float *row_scales, int rows, int cols);
+/* GroupPnorm / GroupPnormDeriv / GroupMax / GroupMaxDeriv / MulRowsGroupMat, kaldi-matrix.cc:1071-1138, 2530-2558 */
+void orc_group_pnorm(float *y, int ldy, const float *x, int ldx, int rows, int out_cols, int group, float power);
+void orc_group_pnorm_deriv(float *d, int ldd, const float *in, int ldi, const float *out, int ldo, int rows, int in_cols, int group, float power);
+void orc_group_max(float *y, int ldy, const float *x, int ldx, int rows, int out_cols, int group);
+void orc_group_max_deriv(float *d, int ldd, const float *in, int ldi, const float *out, int ldo, int rows, int in_cols, int group);
+void orc_mul_rows_group_mat(float *y, int ldy, const float *src, int lds, int rows, int cols, int group);
+
 /* ---- whole DNN train step for bench.py's cpu_baseline ("port") -------------------- */
 /* Chain: [Affine (+BN) + Sigmoid] x n_hidden, Affine, Softmax, Xent, backward with
  * immediate Update in reference order (nnet-nnet.cc:70-154).  Buffers are owned by

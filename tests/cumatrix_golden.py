@@ -18,6 +18,26 @@ def load_blas():
     return {k: (v[0] if v.ndim == 2 and v.shape[0] == 1 else v) for k, v in load(BLAS_PATH).items()}
 
 
+COMPONENT_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "component_ops.bin")
+
+
+def load_components():
+    """tests/golden/component_ops.bin: the op sequences of LinearTransform, ConvolutionalComponent, MaxPoolingComponent, LengthNormComponent,
+    Pnorm / Maxout issued on the reference's CuMatrix library (generator oracle/gen_component_golden.cpp)."""
+    return {k: (v[0] if v.ndim == 2 and v.shape[0] == 1 else v) for k, v in load(COMPONENT_PATH).items()}
+
+
+def load_known_answers():
+    """tests/golden/component_known_answers.json: the vectors of the reference's own nnet-component-test.cc (oracle/gen_component_known_answers.py)"""
+    import json
+    doc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "component_known_answers.json")))
+    out = {}
+    for name, rec in doc["tests"].items():
+        out[name] = {"component": rec.get("component"), "format": rec.get("component_format"),
+                     "matrices": {k: np.asarray(v, np.float32) for k, v in rec["matrices"].items()}}
+    return out
+
+
 def load(path=PATH):
     b = open(path, "rb").read()
     out, p = {}, 0

@@ -103,6 +103,24 @@ _sig("orc_dnn_bn_shift", C.POINTER(_f), C.c_void_p, _i)
 _sig("orc_dnn_output", C.POINTER(_f), C.c_void_p)
 
 
+# front-end components of the CNN / cFSMN recipes (oracle/aslp_oracle_conv.c)
+_sig("orc_linear_propagate", None, f32p, _i, f32p, _i, _i, f32p, _i, _i, _i)
+_sig("orc_linear_backpropagate", None, f32p, _i, f32p, _i, _i, f32p, _i, _i, _i)
+_sig("orc_linear_update", None, f32p, _i, f32p, _i, f32p, _i, f32p, _i, _i, _i, _i, C.POINTER(AffineOpts))
+_sig("orc_conv_propagate", None, f32p, _i, f32p, f32p, _i, _i, _i, f32p, _i, f32p, _i, _i, _i, _i)
+_sig("orc_conv_backpropagate", None, f32p, _i, f32p, f32p, _i, _i, _i, f32p, _i, _i, _i, _i, _i)
+_sig("orc_conv_update", None, f32p, _i, f32p, f32p, f32p, f32p, f32p, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f)
+_sig("orc_max_pool_propagate", None, f32p, _i, f32p, _i, _i, _i, _i, _i, _i)
+_sig("orc_max_pool_backpropagate", None, f32p, _i, f32p, _i, f32p, _i, f32p, _i, _i, _i, _i, _i, _i)
+_sig("orc_length_norm_propagate", None, f32p, _i, f32p, f32p, _i, _i, _i)
+_sig("orc_length_norm_backpropagate", None, f32p, _i, f32p, _i, f32p, _i, _i)
+_sig("orc_group_pnorm", None, f32p, _i, f32p, _i, _i, _i, _i, _f)
+_sig("orc_group_pnorm_deriv", None, f32p, _i, f32p, _i, f32p, _i, _i, _i, _i, _f)
+_sig("orc_group_max", None, f32p, _i, f32p, _i, _i, _i, _i)
+_sig("orc_group_max_deriv", None, f32p, _i, f32p, _i, f32p, _i, _i, _i, _i)
+_sig("orc_mul_rows_group_mat", None, f32p, _i, f32p, _i, _i, _i, _i)
+
+
 def c32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
@@ -366,3 +384,113 @@ class Fsmn:
 
     def update(self, lr):
         lib.orc_fsmn_update(self.coef, self.corr, self.D, self.P, self.F, lr)
+
+
+# ---- front-end components (oracle/aslp_oracle_conv.c) ------------------------------------------------------------------
+class Linear:
+    """LinearTransform (nnet-linear-transform.h): W [out x in] + momentum buffer"""
+    def __init__(self, W):
+        self.W = c32(W).copy(); self.corr = np.zeros_like(self.W)
+
+    def propagate(self, x):
+        x = c32(x); out = np.empty((x.shape[0], self.W.shape[0]), np.float32)
+        lib.orc_linear_propagate(out, out.shape[1], x, x.shape[1], x.shape[0], self.W, self.W.shape[1], self.W.shape[1], self.W.shape[0])
+        return out
+
+    def backpropagate(self, od):
+        od = c32(od); idf = np.empty((od.shape[0], self.W.shape[1]), np.float32)
+        lib.orc_linear_backpropagate(idf, idf.shape[1], od, od.shape[1], od.shape[0], self.W, self.W.shape[1], self.W.shape[1], self.W.shape[0])
+        return idf
+
+    def update(self, x, od, lr, mmt=0.0, l2=0.0, l1=0.0, coef=1.0):
+        x, od = c32(x), c32(od)
+        o = AffineOpts(lr, mmt, l2, l1, coef, 1.0, 0.0)
+        lib.orc_linear_update(self.W, self.W.shape[1], self.corr, self.corr.shape[1], x, x.shape[1], od, od.shape[1], x.shape[0], self.W.shape[1],
+                              self.W.shape[0], C.byref(o))
+
+
+class Conv:
+    """ConvolutionalComponent (nnet-convolutional-component.h) in the reference's per-patch structure"""
+    def __init__(self, filters, bias, in_dim, patch_dim, patch_step, patch_stride):
+        self.filters = c32(filters).copy(); self.bias = c32(bias).copy()
+        self.in_dim, self.pd, self.ps, self.pst = in_dim, patch_dim, patch_step, patch_stride
+        self.F, self.K = self.filters.shape
+        self.P = 1 + (patch_stride - patch_dim) // patch_step
+        assert self.K == (in_dim // patch_stride) * patch_dim
+        self.fgrad = np.zeros_like(self.filters); self.bgrad = np.zeros_like(self.bias)
+
+    def propagate(self, x):
+        x = c32(x); N = x.shape[0]
+        out = np.empty((N, self.F * self.P), np.float32)
+        self.patches = np.empty((N, self.K * self.P), np.float32)
+        lib.orc_conv_propagate(out, out.shape[1], self.patches, x, x.shape[1], N, self.in_dim, self.filters, self.K, self.bias, self.F, self.pd, self.ps,
+                               self.pst)
+        return out
+
+    def backpropagate(self, od):
+        od = c32(od); N = od.shape[0]
+        idf = np.empty((N, self.in_dim), np.float32)
+        pd = np.empty((N, self.K * self.P), np.float32)
+        lib.orc_conv_backpropagate(idf, self.in_dim, pd, od, od.shape[1], N, self.in_dim, self.filters, self.K, self.F, self.pd, self.ps, self.pst)
+        return idf
+
+    def update(self, od, lr, coef=1.0, bias_coef=1.0, max_norm=0.0):
+        od = c32(od)
+        lib.orc_conv_update(self.filters, self.K, self.bias, self.fgrad, self.bgrad, self.patches, od, od.shape[1], od.shape[0], self.in_dim, self.F,
+                            self.pd, self.ps, self.pst, lr, coef, bias_coef, max_norm)
+
+
+def max_pool(x, size, step, stride):
+    x = c32(x); n_p = x.shape[1] // stride
+    out = np.empty((x.shape[0], (1 + (n_p - size) // step) * stride), np.float32)
+    lib.orc_max_pool_propagate(out, out.shape[1], x, x.shape[1], x.shape[0], x.shape[1], size, step, stride)
+    return out
+
+
+def max_pool_backprop(x, out, od, size, step, stride):
+    x, out, od = c32(x), c32(out), c32(od)
+    idf = np.empty_like(x)
+    lib.orc_max_pool_backpropagate(idf, idf.shape[1], x, x.shape[1], out, out.shape[1], od, od.shape[1], x.shape[0], x.shape[1], size, step, stride)
+    return idf
+
+
+def length_norm(x):
+    x = c32(x); out = np.empty_like(x); sc = np.empty(x.shape[0], np.float32)
+    lib.orc_length_norm_propagate(out, out.shape[1], sc, x, x.shape[1], x.shape[0], x.shape[1])
+    return out, sc
+
+
+def length_norm_backprop(od, sc):
+    od = c32(od); idf = np.empty_like(od)
+    lib.orc_length_norm_backpropagate(idf, idf.shape[1], od, od.shape[1], c32(sc), od.shape[0], od.shape[1])
+    return idf
+
+
+def group_pnorm(x, out_cols, power):
+    x = c32(x); y = np.empty((x.shape[0], out_cols), np.float32)
+    lib.orc_group_pnorm(y, out_cols, x, x.shape[1], x.shape[0], out_cols, x.shape[1] // out_cols, power)
+    return y
+
+
+def group_pnorm_deriv(x, y, power):
+    x, y = c32(x), c32(y); d = np.empty_like(x)
+    lib.orc_group_pnorm_deriv(d, d.shape[1], x, x.shape[1], y, y.shape[1], x.shape[0], x.shape[1], x.shape[1] // y.shape[1], power)
+    return d
+
+
+def group_max(x, out_cols):
+    x = c32(x); y = np.empty((x.shape[0], out_cols), np.float32)
+    lib.orc_group_max(y, out_cols, x, x.shape[1], x.shape[0], out_cols, x.shape[1] // out_cols)
+    return y
+
+
+def group_max_deriv(x, y):
+    x, y = c32(x), c32(y); d = np.empty_like(x)
+    lib.orc_group_max_deriv(d, d.shape[1], x, x.shape[1], y, y.shape[1], x.shape[0], x.shape[1], x.shape[1] // y.shape[1])
+    return d
+
+
+def mul_rows_group_mat(y, src):
+    y = c32(y).copy(); src = c32(src)
+    lib.orc_mul_rows_group_mat(y, y.shape[1], src, src.shape[1], y.shape[0], y.shape[1], y.shape[1] // src.shape[1])
+    return y

@@ -49,11 +49,21 @@ def run(tmp_path, name, **env):
 
 
 def test_recurrent_ab_switches_agree(tmp_path):
-    base = run(tmp_path, "default")
+    base = run(tmp_path, "default")                       # chains of 8 streams, gate non-linearities on v_exp_f32 / v_rcp_f32
     assert np.isfinite(base).all()
     for name, env in (("wg_collect", {"ASLP_LSTM_WAVE_COLLECT": "0"}), ("own_order", {"ASLP_LSTM_READ_AHEAD": "0"}),
                       ("both_off", {"ASLP_LSTM_WAVE_COLLECT": "0", "ASLP_LSTM_READ_AHEAD": "0"})):
         other = run(tmp_path, name, **env)
         assert np.array_equal(base, other), name            # same operands, same order of products: same bits
+
+    def close(a, b, tol=1e-5):
+        return np.linalg.norm(a - b) / np.linalg.norm(b) < tol and np.abs(a - b).max() / max(1.0, np.abs(b).max()) < 10 * tol
+
+    exact = run(tmp_path, "exact_act", ASLP_LSTM_FAST_ACT="0")      # correctly rounded expf / division (the reference's CPU bits)
+    assert close(exact, base)
+    half = run(tmp_path, "half_chains", ASLP_LSTM_HALF_CHAINS="1")  # 4 streams per chain, two workgroups per CU: K split over 4 waves
+    assert close(half, base)
+    assert np.array_equal(half, run(tmp_path, "half_map0", ASLP_LSTM_HALF_CHAINS="1", ASLP_LSTM_HALF_MAP="0"))   # who shares a CU changes nothing
+    assert np.array_equal(half, run(tmp_path, "half_delay0", ASLP_LSTM_HALF_CHAINS="1", ASLP_LSTM_HALF_DELAY_NS="0"))
     step = run(tmp_path, "per_timestep", ASLP_LSTM_PERSISTENT="0")
-    assert np.linalg.norm(step - base) / np.linalg.norm(base) < 1e-5
+    assert close(step, base)
