@@ -299,3 +299,64 @@ def test_run_cfsmn_proto_initialises_and_its_linear_transform_trains_like_the_or
         e, r = ((before - after) / lr).astype(np.float64), ((Wb - lin.W) / lr).ravel().astype(np.float64)
         assert np.linalg.norm(e - r) / np.linalg.norm(r) < 1e-4 and np.max(np.abs(e - r)) / max(1.0, np.max(np.abs(r))) < 1e-2, step
         assert close(after, lin.W.ravel(), 2e-6), step
+
+
+def _aff(i, o, extra=""):
+    return "<AffineTransform> <InputDim> %d <OutputDim> %d <BiasMean> -2.000000 <BiasRange> 4.000000 <ParamStddev> 0.1%s" % (i, o, extra)
+
+
+def _act(kind, d):
+    return "<%s> <InputDim> %d <OutputDim> %d" % (kind, d, d)
+
+
+def _cnn_front(num_feat):
+    return ["<ConvolutionalComponent> <InputDim> %d <OutputDim> 4096 <PatchDim> 9 <PatchStep> 1 <PatchStride> 40 <BiasMean> -2.000000 <BiasRange> 4.000000 "
+            "<ParamStddev> 0.1 <MaxNorm> 30" % num_feat,
+            "<MaxPoolingComponent> <InputDim> 4096 <OutputDim> 1024 <PoolSize> 4 <PoolStep> 4 <PoolStride> 128"]
+
+
+def recipe_protos(num_feat=440, num_tgt=120):
+    """The network descriptions of the recipes in aslp_scripts/aslp_nnet that round 2's aslp-nnet-init refused, rebuilt from their layer lists
+    (run_cnn.sh:69-77 + its hidden.conf :79-84, run_cnn_1dnn_2lstm.sh, run_ctc_cnn_1dnn_2blstm.sh:64-82, run_cfsmn.sh:68-93, run_cfsmn_pre.sh)."""
+    out_layer = ["<AffineTransform> <InputDim> 512 <OutputDim> %d <BiasMean> 0.0 <BiasRange> 0.0 <ParamStddev> 0.040000" % num_tgt, _act("Softmax", num_tgt)]
+    lstm = "<%s> <InputDim> 512 <OutputDim> 512 <CellDim> 1024 <ParamScale> 0.010000 <ClipGradient> 5.000000"
+    p = {}
+    p["run_cnn"] = _cnn_front(num_feat) + [_act("Sigmoid", 1024), _aff(1024, num_tgt), _act("Softmax", num_tgt)]
+    p["run_cnn.hidden"] = [_aff(1024, 1024), _act("Sigmoid", 1024)]
+    p["run_cnn_1dnn_2lstm"] = ([_cnn_front(num_feat)[0], _act("BatchNormalization", 4096), _cnn_front(num_feat)[1], _act("Sigmoid", 1024), _aff(1024, 512),
+                                _act("BatchNormalization", 512), _act("Sigmoid", 512)] +
+                               [lstm % "LstmProjectedStreams", _act("BatchNormalization", 512)] * 2 + out_layer)
+    p["run_ctc_cnn_1dnn_2blstm"] = (_cnn_front(num_feat) + [_act("BatchNormalization", 1024), _act("Sigmoid", 1024), _aff(1024, 1024),
+                                    _act("BatchNormalization", 1024), _act("Sigmoid", 1024), _aff(1024, 512), _act("BatchNormalization", 512), _act("Sigmoid", 512)] +
+                                    [lstm % "BLstmProjectedStreams", _act("BatchNormalization", 512)] * 2 + out_layer)
+    fsmn = "<CompactFsmn> <InputDim> 512 <OutputDim> 512 <PastContext> 30 <FutureContext> 30 <LearnRateCoef> 1.0 "
+    p["run_cfsmn_pre.block"] = [_aff(1024, 512, " <MaxNorm> 20"), fsmn + " <ClipGradient> 10", _aff(512, 1024, " <MaxNorm> 20"), _act("ReLU", 1024)]
+    p["run_cfsmn_pre.init"] = [_aff(num_feat, 1024, " <MaxNorm> 20"), _act("ReLU", 1024), "<LinearTransform> <InputDim> 1024 <OutputDim> 512 <ParamStddev> 0.1",
+                               "<AffineTransform> <InputDim> 512 <OutputDim> %d <BiasMean> 0.0 <BiasRange> 0.0 <ParamStddev> 0.040000 <MaxNorm> 20" % num_tgt,
+                               _act("Softmax", num_tgt)]
+    return {k: "<NnetProto>\n" + "\n".join(v) + "\n</NnetProto>\n" for k, v in p.items()}
+
+
+def test_aslp_nnet_init_accepts_the_cnn_and_cfsmn_recipes(aslp, dev, tmp_path):
+    """The tool itself (bin/aslp-nnet-init, then aslp-nnet-info and a forward pass through the written model): the B7 row's "recipes drop in
+    unchanged" for the recipes whose first stage died in round 2."""
+    from test_tools_gpu import tool
+    protos = dict(recipe_protos(), run_cfsmn=CFSMN_PROTO)
+    for name, proto in protos.items():
+        (tmp_path / (name + ".proto")).write_text(proto)
+        out = tmp_path / (name + ".nnet")
+        tool("aslp-nnet-init", "--binary=true", "--seed=777", str(tmp_path / (name + ".proto")), str(out))
+        info = tool("aslp-nnet-info", str(out)).stdout.decode()
+        for marker in set(re.findall(r"^<(\w+)>", proto, re.M)) - {"NnetProto"}:
+            assert "<%s>" % marker in info, (name, marker)
+        net = aslp.Nnet.Read(out)
+        rows = 64
+        if "Lstm" in proto:
+            net.SetSeqLengths([16] * 4) if "BLstm" in proto else net.ResetLstmStreams([1] * 4)
+        y = net.Propagate(torch.randn(rows, net.InputDim(), device=dev))
+        assert y.shape == (rows, net.OutputDim()) and bool(torch.isfinite(y).all()), name
+    # the reference's own refusal stays a refusal: <ClipGradient> is no AffineTransform option (nnet-affine-transform.h:70-83), so
+    # run_eesen_ctc_cnn_1dnn_2blstm.sh:71 fails in the reference's aslp-nnet-init as well
+    (tmp_path / "bad.proto").write_text("<NnetProto>\n" + _aff(64, 64, " <ClipGradient> 5.000000") + "\n</NnetProto>\n")
+    p = tool("aslp-nnet-init", str(tmp_path / "bad.proto"), str(tmp_path / "bad.nnet"), ok=False)
+    assert p.returncode != 0 and b"Unknown token <ClipGradient>" in p.stderr
