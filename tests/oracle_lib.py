@@ -209,6 +209,40 @@ def rel_err(a, b):
     return float(np.linalg.norm(a - b) / den) if den > 0 else float(np.linalg.norm(a - b))
 
 
+def max_err(a, b):
+    """largest element-wise deviation, relative to max(1, largest |reference|): a whole-tensor norm lets a few wrong elements through"""
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b)) / max(1.0, float(np.max(np.abs(b))))) if a.size else 0.0
+
+
+def applied_gradient_errors(before, after, lr, grad_ref):
+    """What the engine APPLIED in one step, read back from the parameters -- g = (W_before - W_after) / lr -- against the gradient the
+    oracle applied (its momentum-carrying, clipped `*_corr` tensor).  Comparing updated parameters instead hides a wrong gradient:
+    with |lr g| << |W| a 10 % error in g moves rel_err(W) by 1e-5.  Returns (relative Frobenius error, max-element error, and the
+    read-back floor of both): W_after is an fp32 number, so every element of g carries up to 2^-24 |W| / lr of rounding."""
+    before = np.asarray(before, np.float64).ravel(); after = np.asarray(after, np.float64).ravel()
+    ref = np.asarray(grad_ref, np.float64).ravel()
+    g = (before - after) / lr
+    nref = np.linalg.norm(ref)
+    floor_el = 2.0 ** -24 * np.maximum(np.abs(before), np.abs(after)) / abs(lr)
+    rel = np.linalg.norm(g - ref) / nref if nref > 0 else np.linalg.norm(g - ref)
+    rel_floor = np.linalg.norm(floor_el) / nref if nref > 0 else 0.0
+    den = max(1.0, float(np.max(np.abs(ref)))) if ref.size else 1.0
+    return float(rel), float(np.max(np.abs(g - ref)) / den) if ref.size else 0.0, float(rel_floor), float(np.max(floor_el) / den) if ref.size else 0.0
+
+
+def assert_applied_gradients(before, after, lr, tensors_ref, tol=1e-4, what=""):
+    """tensors_ref: list of (name, reference gradient) in GetParams order; every tensor on its own (W_x, W_r, bias, each peephole, W_rm ...)"""
+    off = 0
+    for name, ref in tensors_ref:
+        n = int(np.asarray(ref).size)
+        rel, mx, rel_floor, mx_floor = applied_gradient_errors(before[off:off + n], after[off:off + n], lr, ref)
+        assert rel <= tol + 2.0 * rel_floor, (what, name, "rel", rel, "read-back floor", rel_floor)
+        assert mx <= 10.0 * tol + 2.0 * mx_floor, (what, name, "max element", mx, "read-back floor", mx_floor)
+        off += n
+    assert off == len(before), (off, len(before))
+
+
 # ---- recurrent oracle (oracle/aslp_oracle_rnn.c) -------------------------------------------------
 class LstmDirC(C.Structure):
     _fields_ = [("D", _i), ("C", _i), ("R", _i), ("cifg", _i)] + [(n, C.c_void_p) for n in
@@ -250,6 +284,11 @@ class LstmDir:
         self.width = lib.orc_lstm_width(C.byref(self.c))
         self.rec = rec
         self.off_rec = (G + 3) * Cc if R > 0 else (G + 2) * Cc
+
+    def named_tensors(self, prefix=""):
+        """(name, tensor) in file / GetParams order"""
+        names = ["w_x", "w_r", "bias"] + ([] if self.cifg else ["peep_i"]) + ["peep_f", "peep_o"] + (["w_rm"] if self.R > 0 else [])
+        return [(prefix + n, getattr(self, n)) for n in names]
 
     def tensors(self):
         """file / GetParams order"""

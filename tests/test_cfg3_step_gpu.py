@@ -25,7 +25,7 @@ TOL = 1e-4
 
 def test_cfg3_lcblstm_warpctc_two_steps_match_oracle_chain(aslp, oracle, dev, tmp_path):
     D, Cc, R, A, T, S, NL = 40, 512, 256, 128, 60, 32, 4
-    clip, lr, mmt = 5.0, 1e-4, 0.9
+    clip, lr, mmt = 5.0, 1e-3, 0.9   # (at 1e-4 the applied gradient, read back as (W_before - W_after) / lr, drowns in the weights' fp32 rounding)
     rng = np.random.default_rng(33)
     layers, params, grads = [], [], []
     d = D
@@ -84,11 +84,16 @@ def test_cfg3_lcblstm_warpctc_two_steps_match_oracle_chain(aslp, oracle, dev, tm
             dh = idf
         # ---- engine
         net.ResetLstmStreams([1] * S)
+        before = net.GetParams()
         net.TrainStepWarpCtc(ctc, torch.from_numpy(x).to(dev), in_len, labels)
         out = net.ComponentOutput(net.NumComponents() - 1, T * S, A)
-        assert oracle.rel_err(out, y) < TOL, ("activations", step)
+        assert oracle.rel_err(out, y) < TOL and oracle.max_err(out, y) < 10 * TOL, ("activations", step)
         got, want = net.GetParams(), flat()
-        assert oracle.rel_err(got, want) < TOL, ("params", step)
+        assert oracle.rel_err(got, want) < TOL and oracle.max_err(got, want) < 10 * TOL, ("params", step)
+        # the gradients the engine applied, tensor by tensor (4 layers x 2 directions x {W_x, W_r, bias, 3 peepholes, W_rm}, W and b of the
+        # output layer), against the oracle's momentum-carrying clipped *_corr tensors
+        ref = [t for li in range(NL) for di in range(2) for t in grads[li][di].named_tensors("layer%d.dir%d." % (li, di))] + [("W", Wc), ("b", bc)]
+        oracle.assert_applied_gradients(before, got, lr, ref, TOL, step)
         # per tensor group too: a whole-vector norm would hide a small tensor (peepholes, biases) that is wrong
         off = 0
         for li, dirs in enumerate(params):
@@ -99,3 +104,84 @@ def test_cfg3_lcblstm_warpctc_two_steps_match_oracle_chain(aslp, oracle, dev, tm
         stt = ctc.GetStats()
         assert abs(stt["obj"] - st.obj) <= 1e-4 * abs(st.obj), step
     assert ctc.GetStats()["sequences"] == 2 * S
+
+
+def test_cfg3_chunked_three_chunks_with_mixed_stream_resets(aslp, oracle, dev, tmp_path):
+    """The chunked (latency-controlled) use of the same 4-layer net as aslp-nnet-train-blstm-streams-lc.cc drives it: chunk 40 + 20 frames
+    of right context, S = 32 streams, THREE consecutive chunks with mixed ResetLstmStreams flags -- streams that end are restarted from
+    zero while their neighbours carry the forward direction's state from row chunk * S of the previous chunk (lc.h:477-483, 629); the
+    backward direction always starts from zero at the end of the right context.  Output, parameters and the applied gradients of every
+    tensor against the oracle chain."""
+    D, Cc, R, A, S, NL, chunk, right = 40, 512, 256, 128, 32, 4, 40, 20
+    T = chunk + right
+    clip, lr, mmt = 5.0, 1e-3, 0.9
+    rng = np.random.default_rng(71)
+    layers, params, grads = [], [], []
+    d = D
+    for l in range(NL):
+        dirs = [oracle.LstmDir(d, Cc, R, False, rng, scale=0.05) for _ in range(2)]
+        params.append(dirs)
+        grads.append([oracle.LstmDir(d, Cc, R, False, zero=True) for _ in range(2)])
+        layers.append(("<BLstmProjectedStreamsLC>", d, 2 * R, nnet_io.lstm(dirs, clip, Cc)))
+        d = 2 * R
+    W = (rng.standard_normal((A, d)) * 0.04).astype(np.float32)
+    b = np.zeros(A, np.float32)
+    Wc, bc = np.zeros_like(W), np.zeros_like(b)
+    layers.append(("<AffineTransform>", d, A, nnet_io.affine(W, b)))
+    path = tmp_path / "cfg3_chunked.nnet"
+    nnet_io.write_simple_nnet(path, layers)
+    net = aslp.Nnet.Read(path)
+    net.SetTrainOptions(learn_rate=lr, momentum=mmt)
+    net.SetChunkSize(chunk)
+    o = oracle.AffineOpts(lr, mmt, 0.0, 0.0, 1.0, 1.0, 0.0)
+    state = [np.zeros((S, params[l][0].width), np.float32) for l in range(NL)]
+
+    def flat():
+        return np.concatenate([p.flat() for dirs in params for p in dirs] + [W.ravel(), b])
+
+    for step in range(3):
+        flags = [1] * S if step == 0 else [int(v) for v in rng.integers(0, 2, S)]
+        if step > 0:
+            flags[0], flags[1] = 0, 1   # both kinds present whatever the draw
+        x = rng.standard_normal((T * S, D)).astype(np.float32)
+        od = (rng.standard_normal((T * S, A)) * 0.05).astype(np.float32)
+        od[chunk * S:] = 0.0            # right-context frames carry no loss (the tool's frame mask)
+        # ---- oracle chain
+        h, bufs, ins = x, [], []
+        for l, dirs in enumerate(params):
+            f, bk = dirs
+            for s_, fl in enumerate(flags):
+                if fl:
+                    state[l][s_] = 0
+            fbuf = f.forward(h, T, S, reverse=False, init_state=state[l])
+            state[l] = fbuf[chunk * S:(chunk + 1) * S].copy()
+            bbuf = bk.forward(h, T, S, reverse=True, seq_len=None)
+            ins.append(h)
+            bufs.append((fbuf, bbuf))
+            h = np.concatenate([f.out_of(fbuf, T, S), bk.out_of(bbuf, T, S)], axis=1)
+        y = np.empty((T * S, A), np.float32)
+        oracle.lib.orc_affine_propagate(y, A, h, d, T * S, W, d, b, d, A)
+        dh = np.empty((T * S, d), np.float32)
+        oracle.lib.orc_affine_backpropagate(dh, d, od, A, T * S, W, d, d, A)
+        oracle.lib.orc_affine_update(W, d, b, Wc, d, bc, h, d, od, A, T * S, d, A, C.byref(o))
+        for l in range(NL - 1, -1, -1):
+            f, bk = params[l]
+            fbuf, bbuf = bufs[l]
+            fd, idf = f.backward(np.ascontiguousarray(dh[:, :R]), T, S, fbuf, reverse=False)
+            bd, idf = bk.backward(np.ascontiguousarray(dh[:, R:]), T, S, bbuf, reverse=True, in_diff=idf, beta=1.0)
+            f.grads(grads[l][0], ins[l], T, S, fbuf, fd, mmt, clip, reverse=False)
+            bk.grads(grads[l][1], ins[l], T, S, bbuf, bd, mmt, clip, reverse=True)
+            f.update(grads[l][0], lr)
+            bk.update(grads[l][1], lr)
+            dh = idf
+        # ---- engine
+        net.ResetLstmStreams(flags)
+        out = net.Propagate(torch.from_numpy(x).to(dev)).cpu().numpy()
+        assert oracle.rel_err(out, y) < TOL and oracle.max_err(out, y) < 10 * TOL, ("output", step)
+        before = net.GetParams()
+        idf_e = net.Backpropagate(torch.from_numpy(od).to(dev), want_in_diff=True).cpu().numpy()
+        assert oracle.rel_err(idf_e, dh) < TOL and oracle.max_err(idf_e, dh) < 10 * TOL, ("in_diff", step)
+        got = net.GetParams()
+        assert oracle.rel_err(got, flat()) < TOL and oracle.max_err(got, flat()) < 10 * TOL, ("params", step)
+        ref = [t for li in range(NL) for di in range(2) for t in grads[li][di].named_tensors("layer%d.dir%d." % (li, di))] + [("W", Wc), ("b", bc)]
+        oracle.assert_applied_gradients(before, got, lr, ref, TOL, step)

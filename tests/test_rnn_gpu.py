@@ -100,10 +100,14 @@ def test_lstm_family_train_steps_match_oracle(aslp, oracle, dev, tmp_path, marke
             net.SetSeqLengths(lens)
         out_ref, idf_ref, state = oracle_step(oracle, marker, dirs, grads, x, od, T, S, state, lens, chunk, lr, mmt, clip)
         out = net.Propagate(torch.from_numpy(x).to(dev)).cpu().numpy()
-        assert oracle.rel_err(out, out_ref) < TOL, ("out", step)
+        assert oracle.rel_err(out, out_ref) < TOL and oracle.max_err(out, out_ref) < 10 * TOL, ("out", step)
+        before = net.GetParams()
         idf = net.Backpropagate(torch.from_numpy(od).to(dev), want_in_diff=True).cpu().numpy()
-        assert oracle.rel_err(idf, idf_ref) < TOL, ("in_diff", step)
-        assert oracle.rel_err(net.GetParams(), flat()) < TOL, ("params", step)
+        assert oracle.rel_err(idf, idf_ref) < TOL and oracle.max_err(idf, idf_ref) < 10 * TOL, ("in_diff", step)
+        after = net.GetParams()
+        assert oracle.rel_err(after, flat()) < TOL and oracle.max_err(after, flat()) < 10 * TOL, ("params", step)
+        # the gradient the engine applied, tensor by tensor (W_x, W_r, bias, the peepholes, W_rm per direction), against the oracle's *_corr
+        oracle.assert_applied_gradients(before, after, lr, [t for di, g in enumerate(grads) for t in g.named_tensors("dir%d." % di)], TOL, (marker, step))
 
 
 @pytest.mark.parametrize("marker", list(FAMILY))
@@ -135,10 +139,14 @@ def test_lstm_family_at_cell_dim_512(aslp, oracle, dev, tmp_path, marker):
             net.SetSeqLengths(lens)
         out_ref, idf_ref, state = oracle_step(oracle, marker, dirs, grads, x, od, T, S, state, lens, chunk, lr, mmt, clip)
         out = net.Propagate(torch.from_numpy(x).to(dev)).cpu().numpy()
-        assert oracle.rel_err(out, out_ref) < TOL, ("out", step)
+        assert oracle.rel_err(out, out_ref) < TOL and oracle.max_err(out, out_ref) < 10 * TOL, ("out", step)
+        before = net.GetParams()
         idf = net.Backpropagate(torch.from_numpy(od).to(dev), want_in_diff=True).cpu().numpy()
-        assert oracle.rel_err(idf, idf_ref) < TOL, ("in_diff", step)
-        assert oracle.rel_err(net.GetParams(), flat()) < TOL, ("params", step)
+        assert oracle.rel_err(idf, idf_ref) < TOL and oracle.max_err(idf, idf_ref) < 10 * TOL, ("in_diff", step)
+        after = net.GetParams()
+        assert oracle.rel_err(after, flat()) < TOL and oracle.max_err(after, flat()) < 10 * TOL, ("params", step)
+        # the gradient the engine applied, tensor by tensor (W_x, W_r, bias, the peepholes, W_rm per direction), against the oracle's *_corr
+        oracle.assert_applied_gradients(before, after, lr, [t for di, g in enumerate(grads) for t in g.named_tensors("dir%d." % di)], TOL, (marker, step))
 
 
 def test_lstm_forward_without_reset_is_per_utterance(aslp, oracle, dev, tmp_path):
@@ -161,7 +169,7 @@ def test_lc_blstm_baseline_shape(aslp, oracle, dev, tmp_path):
     D, Cc, R, S, chunk, right = 120, 512, 256, 8, 40, 20
     T = chunk + right
     marker = "<BLstmProjectedStreamsLC>"
-    clip, lr, mmt = 5.0, 1e-4, 0.9
+    clip, lr, mmt = 5.0, 1e-3, 0.9   # (1e-4 would leave the applied gradient, read back as (W_before - W_after) / lr, under the weights' fp32 rounding)
     dirs, grads, out_dim, path = build(oracle, tmp_path, marker, D, Cc, R, clip, seed=9, scale=0.05)
     net = aslp.Nnet.Read(path)
     net.SetTrainOptions(learn_rate=lr, momentum=mmt)
@@ -174,10 +182,13 @@ def test_lc_blstm_baseline_shape(aslp, oracle, dev, tmp_path):
         net.ResetLstmStreams([1] * S if step == 0 else [0] * S)
         out_ref, idf_ref, state = oracle_step(oracle, marker, dirs, grads, x, od, T, S, state, None, chunk, lr, mmt, clip)
         out = net.Propagate(torch.from_numpy(x).to(dev)).cpu().numpy()
-        assert oracle.rel_err(out, out_ref) < TOL, ("out", step)
+        assert oracle.rel_err(out, out_ref) < TOL and oracle.max_err(out, out_ref) < 10 * TOL, ("out", step)
+        before = net.GetParams()
         idf = net.Backpropagate(torch.from_numpy(od).to(dev), want_in_diff=True).cpu().numpy()
-        assert oracle.rel_err(idf, idf_ref) < TOL, ("in_diff", step)
-        assert oracle.rel_err(net.GetParams(), np.concatenate([d.flat() for d in dirs])) < TOL, ("params", step)
+        assert oracle.rel_err(idf, idf_ref) < TOL and oracle.max_err(idf, idf_ref) < 10 * TOL, ("in_diff", step)
+        after = net.GetParams()
+        assert oracle.rel_err(after, np.concatenate([d.flat() for d in dirs])) < TOL, ("params", step)
+        oracle.assert_applied_gradients(before, after, lr, [t for di, g in enumerate(grads) for t in g.named_tensors("dir%d." % di)], TOL, step)
 
 
 # (512, 512, 60, 32): BASELINE cfg5's GruStreams swap at full size (H = 512, S = 32 streams, T = 60).
