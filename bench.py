@@ -277,6 +277,89 @@ def recurrent_family_block(aslp, dev):
     return out
 
 
+def cfg1_gpu_block(aslp, dev):
+    """BASELINE.json configs[0] / the per-GPU leg of configs[3] on the GPU (extra key `cfg1_gpu`, N = 1): the 5 x 2048 sigmoid DNN WITHOUT
+    BatchNormalization, minibatch 256, learn rate 0.008, no momentum (run_dnn.sh:60-101; the frame tool's loop body,
+    aslp-nnet-train-frame.cc:109-131).  256 rows are a quarter of cfg2's minibatch: a 2048 x 2048 layer product has 128 tiles of 64 x 64 for
+    256 CUs, so this is the small-batch regime of the same kernels."""
+    import torch
+    mb = 256
+    lines, d = ["<NnetProto>"], IN_DIM
+    for _ in range(NH):
+        lines.append("<AffineTransform> <InputDim> %d <OutputDim> %d <BiasMean> -2.0 <BiasRange> 4.0 <ParamStddev> 0.04" % (d, HID))
+        lines.append("<Sigmoid> <InputDim> %d <OutputDim> %d" % (HID, HID))
+        d = HID
+    lines += ["<AffineTransform> <InputDim> %d <OutputDim> %d <BiasMean> 0.0 <BiasRange> 0.0 <ParamStddev> 0.04" % (d, OUT_DIM),
+              "<Softmax> <InputDim> %d <OutputDim> %d" % (OUT_DIM, OUT_DIM), "</NnetProto>"]
+    net = aslp.Nnet.Init("\n".join(lines) + "\n", seed=777)
+    net.SetTrainOptions(learn_rate=0.008, momentum=0.0)
+    xent = aslp.Xent()
+    g = torch.Generator(device=dev)
+    g.manual_seed(2468)
+    x = torch.randn(mb, IN_DIM, device=dev, generator=g)
+    labels = torch.randint(0, OUT_DIM, (mb,), device=dev, generator=g, dtype=torch.int32)
+    warm, k = 100, 400
+    for _ in range(warm):
+        net.TrainStepXent(xent, x, labels)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(k):
+        net.TrainStepXent(xent, x, labels)
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / k
+    st = xent.GetStats()
+    tf = FLOP_PER_FRAME * mb / el / 1e12
+    return {"workload": "cfg1 net on the GPU: 5x2048 sigmoid DNN, no BatchNorm, minibatch 256, lr 0.008, Propagate + Xent + Backpropagate + SGD update",
+            "steps": k, "warmup": warm, "ms_per_step": el * 1e3, "frames_per_sec": mb / el, "tflops": tf, "frac_of_mfma_peak": tf / F32_MFMA_PEAK_TFLOPS,
+            "avg_xent_per_frame": (st["loss"] - st["entropy"]) / max(st["frames"], 1.0)}
+
+
+def e2e_tool_block(frames=1024000):
+    """SURVEY 8(d) asks for the end-to-end figure beside the compute-only one (extra key `e2e_tool`, N = 1): the cfg2 net trained by the
+    command-line tool itself -- aslp-nnet-init, then aslp-nnet-train-frame reading a feature archive and a posterior archive (page
+    cache), randomizer 32768, minibatch 1024 -- and the tool's OWN `fps` figure, whose timer spans archive parsing, the randomizer,
+    uploads, every step and the model write like the reference's (aslp-nnet-train-frame.cc:99-139).  A child process: this one's GPU
+    state is untouched.  Returns an {"error": ...} record instead of raising."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import kaldi_formats as kf
+    bindir = os.path.join(ROOT, "kaldi-aslp_amd", "bin")
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 6 * frames * IN_DIM else None
+    tmp = tempfile.mkdtemp(prefix="aslp_e2e_", dir=base)
+    try:
+        with open(os.path.join(tmp, "nnet.proto"), "w") as f:
+            f.write(proto())
+        rng = np.random.default_rng(0)
+        utt = 1000
+        n_utt = frames // utt
+        with open(os.path.join(tmp, "feats.ark"), "wb") as ff, open(os.path.join(tmp, "post.ark"), "wb") as pf:
+            for i in range(n_utt):
+                ff.write(("utt%05d " % i).encode() + kf.matrix_bin(rng.standard_normal((utt, IN_DIM), dtype=np.float32)))
+                pf.write(("utt%05d " % i).encode() + kf.posterior_bin([[(int(l), 1.0)] for l in rng.integers(0, OUT_DIM, utt)]))
+        subprocess.run([os.path.join(bindir, "aslp-nnet-init"), "--print-args=false", os.path.join(tmp, "nnet.proto"), os.path.join(tmp, "nnet.init")],
+                       check=True, capture_output=True, timeout=600)
+        t0 = time.time()
+        p = subprocess.run([os.path.join(bindir, "aslp-nnet-train-frame"), "--print-args=false", "--learn-rate=0.00001", "--minibatch-size=%d" % MB,
+                            "--randomizer-size=32768", "ark:%s/feats.ark" % tmp, "ark:%s/post.ark" % tmp, os.path.join(tmp, "nnet.init"),
+                            os.path.join(tmp, "nnet.out")], capture_output=True, timeout=900)
+        wall = time.time() - t0
+        err = p.stderr.decode(errors="replace")
+        m = re.findall(r"fps\s*([0-9.eE+]+)", err)
+        if p.returncode != 0 or not m:
+            return {"error": "aslp-nnet-train-frame rc %d: %s" % (p.returncode, err[-300:])}
+        return {"tool": "aslp-nnet-init + aslp-nnet-train-frame (randomizer 32768, minibatch %d) on binary archives in the page cache" % MB,
+                "frames": n_utt * utt, "frames_per_sec": float(m[-1]), "process_wall_s": wall,
+                "timer": "the tool's own fps line: archive parsing, randomizer, uploads, every step and the model write are inside it"}
+    except Exception as e:   # noqa: BLE001 -- an extra block never takes the headline down
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def cfg3_bsp_block(aslp, dev, native_parallel, comm, rank, world, sync_period):
     """N > 1 only (extra key `cfg3_bsp`): every rank trains its own replica of the cfg3 LC-BLSTM (chunked, Xent) on its own synthetic shard and
     the replicas are averaged BSP-style by the native BspWorker every `sync_period` valid frames -- the configuration BASELINE.json's 8-GPU
@@ -351,7 +434,12 @@ def launch_ranks(args):
     out0 = b""
     rc = 0
     try:
-        out0 = procs[0].communicate()[0]      # rank 0 prints the line; it ends after the last collective
+        try:
+            out0 = procs[0].communicate(timeout=args.launch_timeout)[0]      # rank 0 prints the line; it ends after the last collective
+        except subprocess.TimeoutExpired:
+            procs[0].kill()
+            out0 = procs[0].communicate()[0]
+            rc = 124
         deadline = time.time() + 120.0
         for p in procs:
             try:
@@ -389,6 +477,9 @@ def main():
                     help="keep the weight-gradient GEMMs on the main stream (per-kernel profiles: every kernel alone on the chip)")
     ap.add_argument("--no-cfg3", action="store_true", help="skip the LC-BLSTM (BASELINE cfg3) block of the JSON line")
     ap.add_argument("--cfg3-bsp-timeout", type=int, default=240, help="N > 1: seconds the extra cfg3_bsp block may take before it is dropped")
+    ap.add_argument("--launch-timeout", type=int, default=3000, help="N > 1 from a bare shell: seconds the parent waits for rank 0")
+    ap.add_argument("--no-e2e-tool", action="store_true", help="skip the end-to-end command-line block of the JSON line (extra key e2e_tool)")
+    ap.add_argument("--e2e-frames", type=int, default=1024000)
     ap.add_argument("--dry-run-ranks", action="store_true", help=argparse.SUPPRESS)   # launcher plumbing test (no GPU): tests/test_bench_cpu.py
     args = ap.parse_args()
 
@@ -460,7 +551,22 @@ def main():
     # chip measures 5 % less than the same 20 steps half a second later: devtools/bench_gemm.py).  A fixed number of untimed
     # steps -- the same on every rank, so the sync schedule stays aligned -- precedes the W warm-up steps when the run itself is short.
     prewarm = max(0, args.prewarm_steps - args.warmup) if args.steps < 400 else 0
-    for _ in range(prewarm):
+    cold_value = None
+    if prewarm > 0 and worker is None:
+        # the same W warm-up + K timed steps WITHOUT the pre-warm, first thing on the cold chip (extra key `cold_value`): how much of the
+        # headline depends on the pre-warm is then visible in the line itself.  Its steps count towards the pre-warm.
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        cold_value = world * args.steps * MB / (time.perf_counter() - tc)
+        prewarm_left = max(0, prewarm - args.warmup - args.steps)
+    else:
+        prewarm_left = prewarm
+    for _ in range(prewarm_left):
         step()
     for _ in range(args.warmup):
         step()
@@ -515,7 +621,7 @@ def main():
         value = total_frames / elapsed
         out = {
             "metric": "frames/sec (aslp-nnet-train)", "value": value, "unit": "frames/sec", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "prewarm_steps": prewarm, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "prewarm_steps": prewarm, "cold_value": cold_value, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "cfg2: 5x2048 sigmoid DNN + BatchNorm, 440 in (40 fbank x 11 splice), 3000 pdfs, minibatch 1024/GPU, "
                                    "Propagate + Xent + Backpropagate + SGD update",
@@ -560,6 +666,11 @@ def main():
             torch.cuda.empty_cache()
             out["cfg3"] = cfg3_block(aslp, dev)
             out["recurrent_layers"] = recurrent_family_block(aslp, dev)
+            out["cfg1_gpu"] = cfg1_gpu_block(aslp, dev)
+        if world == 1 and not args.no_e2e_tool:
+            out["e2e_tool"] = e2e_tool_block(args.e2e_frames)
+            if "frames_per_sec" in out["e2e_tool"]:
+                out["e2e_tool"]["of_compute_only"] = out["e2e_tool"]["frames_per_sec"] / value
         if world == 1 and not args.no_cpu_baseline:
             port = cpu_baseline()
             ref = cpu_baseline_reference()
@@ -576,12 +687,15 @@ def main():
         # process with the line printed if the block has not come back (a rank that died inside it leaves the others in a
         # collective); an exception on this rank is recorded instead of raised.
         import threading
+        printed = threading.Lock()   # the line goes out once, whoever gets there first (watchdog thread or main thread)
 
         def bail():
+            if not printed.acquire(blocking=False):
+                return
             if rank == 0:
                 out["cfg3_bsp"] = {"error": "did not finish within %d s; dropped" % args.cfg3_bsp_timeout}
                 print(json.dumps(out), flush=True)
-            os._exit(0)
+            os._exit(3)   # the headline is on stdout, but the run did not complete: non-zero
 
         dog = threading.Timer(args.cfg3_bsp_timeout, bail)
         dog.daemon = True
@@ -595,15 +709,21 @@ def main():
         if rank == 0:
             out["cfg3_bsp"] = blk
         if "error" in blk:
-            if rank == 0:
-                print(json.dumps(out), flush=True)
-            os._exit(0)
+            if printed.acquire(blocking=False):
+                if rank == 0:
+                    print(json.dumps(out), flush=True)
+                os._exit(3)
+            time.sleep(3600)   # the watchdog is printing: it ends the process
     if comm is not None:
         comm.Barrier()
         if worker is not None:
             worker.close()
         comm.close()
     if rank == 0:
+        if comm is not None and not args.no_cfg3:
+            dog.cancel()
+            if not printed.acquire(blocking=False):
+                time.sleep(3600)   # the watchdog fired at the very end and is printing
         print(json.dumps(out))   # the last thing on stdout
 
 

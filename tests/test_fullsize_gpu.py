@@ -10,7 +10,11 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("tA,tB,M,N,K", [(0, 1, 1024, 2048, 2048), (0, 1, 1024, 2048, 440), (0, 1, 1024, 3000, 2048), (0, 0, 1024, 2048, 3000),
                                            (0, 0, 1024, 2048, 2048), (1, 0, 2048, 2048, 1024), (1, 0, 3000, 2048, 1024), (1, 0, 2048, 440, 1024),
-                                           (0, 1, 1920, 2048, 512), (0, 0, 1920, 256, 2048)])
+                                           (0, 1, 1920, 2048, 512), (0, 0, 1920, 256, 2048),
+                                           # cfg1 / cfg4's per-GPU minibatch of 256: the small-grid regime (a 256 x 2048 output is 128 tiles of
+                                           # 64 x 64 for 256 CUs), all three layouts of a layer + the input and output layers
+                                           (0, 1, 256, 2048, 2048), (0, 0, 256, 2048, 2048), (1, 0, 2048, 2048, 256), (0, 1, 256, 2048, 440),
+                                           (0, 1, 256, 3000, 2048), (0, 0, 256, 2048, 3000), (1, 0, 3000, 2048, 256), (1, 0, 2048, 440, 256)])
 def test_sgemm_fullsize_vs_float64(aslp, dev, tA, tB, M, N, K):
     g = torch.Generator(device=dev).manual_seed(M + N + K)
     A = torch.randn((K, M) if tA else (M, K), device=dev, generator=g)
