@@ -868,6 +868,72 @@ __global__ void __launch_bounds__(256) xent_rows_kernel(const float *y, int ldy,
   }
 }
 
+// The same for rows of any width (more than 256 * kXentPerThread classes): nothing is cached in registers, the row is streamed twice
+// (targets: sum and both arg-maxes; then diff and the three sums).  Every thread visits the columns tid, tid + 256, ... in the same
+// order and the reductions are those of the kernel above, so the result does not depend on which of the two kernels served a row.
+template <bool DENSE>
+__global__ void __launch_bounds__(256) xent_rows_wide_kernel(const float *y, int ldy, const float *t, int ldt, const int32_t *labels, const float *fw,
+                                                             float *diff, int ldd, int rows, int cols, double *rowstats) {
+  __shared__ float shf[4][4];
+  __shared__ int shi[4][2];
+  __shared__ double shd[4][3];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    const float *yr = y + (long)r * ldy;
+    const float *tr = DENSE ? t + (long)r * ldt : nullptr;
+    const int label = DENSE ? -1 : labels[r];
+    float tsum = 0.0f, ybest = -1e21f, tbest = -1e21f;
+    int yi = -1, ti = -1;
+    for (int c = tid; c < cols; c += 256) {
+      const float yy = yr[c], tt = DENSE ? tr[c] : (c == label ? 1.0f : 0.0f);
+      tsum += tt;
+      if (ybest < yy) { ybest = yy; yi = c; }
+      if (tbest < tt) { tbest = tt; ti = c; }
+    }
+    tsum = wave_sum(tsum);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      float ov = __shfl_xor(ybest, o, 64); int oi = __shfl_xor(yi, o, 64);
+      if (ov > ybest || (ov == ybest && oi >= 0 && (yi < 0 || oi < yi))) { ybest = ov; yi = oi; }
+      ov = __shfl_xor(tbest, o, 64); oi = __shfl_xor(ti, o, 64);
+      if (ov > tbest || (ov == tbest && oi >= 0 && (ti < 0 || oi < ti))) { tbest = ov; ti = oi; }
+    }
+    if (lane == 0) { shf[w][0] = tsum; shf[w][1] = ybest; shf[w][2] = tbest; shi[w][0] = yi; shi[w][1] = ti; }
+    __syncthreads();
+    tsum = shf[0][0] + shf[1][0] + shf[2][0] + shf[3][0];
+    ybest = shf[0][1]; yi = shi[0][0]; tbest = shf[0][2]; ti = shi[0][1];
+#pragma unroll
+    for (int j = 1; j < 4; j++) {
+      if (shf[j][1] > ybest || (shf[j][1] == ybest && shi[j][0] >= 0 && (yi < 0 || shi[j][0] < yi))) { ybest = shf[j][1]; yi = shi[j][0]; }
+      if (shf[j][2] > tbest || (shf[j][2] == tbest && shi[j][1] >= 0 && (ti < 0 || shi[j][1] < ti))) { tbest = shf[j][2]; ti = shi[j][1]; }
+    }
+    __syncthreads();
+    const float wr = fw[r] * tsum;
+    double xe = 0.0, en = 0.0, lk = 0.0;
+    for (int c = tid; c < cols; c += 256) {
+      const float yy = yr[c], tt = DENSE ? tr[c] : (c == label ? 1.0f : 0.0f);
+      diff[(long)r * ldd + c] = (yy - tt) * wr;
+      if (tt != 0.0f) {
+        xe += (double)(logf(yy + 1e-20f) * tt * wr);
+        en += (double)(logf(tt + 1e-20f) * tt * wr);
+        lk += (double)(yy * tt * wr);
+      }
+    }
+    xe = wave_sum_d(xe); en = wave_sum_d(en); lk = wave_sum_d(lk);
+    if (lane == 0) { shd[w][0] = xe; shd[w][1] = en; shd[w][2] = lk; }
+    __syncthreads();
+    if (tid == 0) {
+      double *rs = rowstats + (long)r * 5;
+      rs[0] = (double)wr;
+      rs[1] = (double)wr * (yi == ti ? 1.0 : 0.0);
+      rs[2] = shd[0][0] + shd[1][0] + shd[2][0] + shd[3][0];
+      rs[3] = shd[0][1] + shd[1][1] + shd[2][1] + shd[3][1];
+      rs[4] = shd[0][2] + shd[1][2] + shd[2][2] + shd[3][2];
+    }
+    __syncthreads();
+  }
+}
+
 // stats[0..4] += {frames, correct, xent, entropy, likelihood}; fixed-order sum over rows
 __global__ void __launch_bounds__(256) xent_finalize_kernel(const double *rowstats, int rows, double *stats) {
   __shared__ double sh[4][5];
@@ -1066,11 +1132,20 @@ void aslp_bn_backward(const float *in, MatrixDim d, const float *out_diff, int o
 static void xent_eval_impl(const float *net_out, MatrixDim d, const float *tgt, int tgt_stride, const int32_cuda *labels,
                            const float *frame_weights, float *diff, int diff_stride, double *stats_dev, bool softmax, float *y_out, int y_stride) {
   if (d.rows <= 0 || d.cols <= 0) return;
-  if (d.cols > 256 * kXentPerThread) { set_error("aslp_xent_eval: more than 8192 output classes not supported"); return; }
   if (!tgt && !labels) { set_error("aslp_xent_eval: need dense targets or labels"); return; }
   double *rowstats = static_cast<double *>(scratch(kScratchReduce, sizeof(double) * 5 * (size_t)d.rows));
   if (!rowstats) return;
   int g = d.rows > kMaxGrid * 2 ? kMaxGrid * 2 : d.rows;
+  if (d.cols > 256 * kXentPerThread) {   // wider than the register-cached kernels hold: the streaming kernel (the reference has no limit)
+    if (softmax) { set_error("aslp_softmax_xent_eval: unsupported number of classes"); return; }
+    if (tgt) hipLaunchKernelGGL((xent_rows_wide_kernel<true>), dim3(g), dim3(256), 0, cur_stream(), net_out, d.stride, tgt, tgt_stride, labels, frame_weights,
+                                diff, diff_stride, d.rows, d.cols, rowstats);
+    else hipLaunchKernelGGL((xent_rows_wide_kernel<false>), dim3(g), dim3(256), 0, cur_stream(), net_out, d.stride, tgt, tgt_stride, labels, frame_weights,
+                            diff, diff_stride, d.rows, d.cols, rowstats);
+    hipLaunchKernelGGL(xent_finalize_kernel, dim3(1), dim3(256), 0, cur_stream(), rowstats, d.rows, stats_dev);
+    check_launch("xent_eval");
+    return;
+  }
   // elements cached per thread: the smallest of 4 / 8 / 16 / 32 that covers the row (the loops are fully unrolled: a row of
   // 3000 classes runs 16 slots per thread instead of 32 predicated ones)
   const int per = (d.cols + 255) / 256;

@@ -237,7 +237,10 @@ void aslp_gru_backward2(float *d_cur, const float *y_cur, const float *y_prev, i
 
 void aslp_rnn_vec_grads(const aslp_rnn_vec_grad *jobs, int njobs, int ldd, int rows, float mmt, float clip, float neg_lr) {
   if (njobs <= 0) return;
-  if (njobs > kVgMaxJobs) { set_error("aslp_rnn_vec_grads: at most 8 jobs per launch"); return; }
+  if (njobs > kVgMaxJobs) {   // a launch carries kVgMaxJobs jobs in its arguments: longer lists go out in pieces (independent jobs)
+    for (int k = 0; k < njobs; k += kVgMaxJobs) aslp_rnn_vec_grads(jobs + k, njobs - k < kVgMaxJobs ? njobs - k : kVgMaxJobs, ldd, rows, mmt, clip, neg_lr);
+    return;
+  }
   VecGradJobs a;
   int blocks = 0;
   a.njobs = 0;

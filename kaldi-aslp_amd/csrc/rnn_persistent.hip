@@ -1603,11 +1603,22 @@ bool seq_args_ok(const aslp_lstm_seq *a) {
 // the whole grid has to be resident at once.  Where the runtime reports room for two or more workgroups per CU one of them
 // is left as slack (MI355X_MICROARCH.md: the API can be one block per CU high); a kernel that fits exactly once per CU
 // cannot be over-reported -- it would not launch at all -- so one workgroup per CU is accepted as is.
+// occupancy of a kernel at `threads` per workgroup, asked once per kernel (the engine probes *_supported on every Propagate / Backpropagate)
+int cached_occupancy(const void *k, int threads) {
+  static std::mutex mu;
+  static std::vector<std::pair<const void *, int>> cache;
+  std::lock_guard<std::mutex> lock(mu);
+  for (auto &e : cache) if (e.first == k) return e.second;
+  int occ = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, threads, 0) != hipSuccess || occ < 1) occ = -1;
+  cache.emplace_back(k, occ);
+  return occ;
+}
 bool grid_fits(const void *k, int threads, long blocks) {
   SeqRuntime &rt = seq_runtime();
   if (!rt.ok || !k) return false;
-  int occ = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, threads, 0) != hipSuccess || occ < 1) return false;
+  const int occ = cached_occupancy(k, threads);
+  if (occ < 1) return false;
   return blocks <= (long)rt.num_cu * (occ >= 2 ? occ - 1 : 1);
 }
 // The half-chain kernels want exactly two 256-thread workgroups per CU; at ~200 VGPRs the register file admits two and no third, which
@@ -1615,18 +1626,7 @@ bool grid_fits(const void *k, int threads, long blocks) {
 bool grid_fits_half(const void *k, long blocks) {
   SeqRuntime &rt = seq_runtime();
   if (!rt.ok || !k) return false;
-  static std::mutex mu;
-  static std::vector<std::pair<const void *, int>> cache;   // occupancy per kernel, asked once
-  int occ = 0;
-  {
-    std::lock_guard<std::mutex> lock(mu);
-    for (auto &e : cache) if (e.first == k) occ = e.second;
-    if (occ == 0) {
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, 256, 0) != hipSuccess || occ < 1) occ = -1;
-      cache.emplace_back(k, occ);
-    }
-  }
-  return occ >= 2 && blocks <= (long)rt.num_cu * 2;
+  return cached_occupancy(k, 256) >= 2 && blocks <= (long)rt.num_cu * 2;
 }
 // Streams per chain a launch with these arguments uses: 4 (half chains, two workgroups per CU) where that scheme applies, else 8.
 int chain_streams_for(const aslp_lstm_seq *a, bool backward) {
@@ -1689,6 +1689,14 @@ static void launch_seq(const aslp_lstm_seq *a, bool backward, const char *who) {
   if (!seq_args_ok(a) || !aslp_lstm_seq_supported(a, backward ? 1 : 0)) {
     set_error(std::string(who) + ": arguments outside what the persistent kernel supports (check aslp_lstm_seq_supported first)");
     return;
+  }
+  for (int d = 0; d < a->ndir; d++) {   // the kernels move 16-byte pieces: the real pointers of this launch (seq_args_ok saw the strides)
+    const aslp_lstm_seq_dir &q = a->dir[d];
+    if (!q.y || !q.w || !aligned16(q.y) || !aligned16(q.w) || (backward && (!q.d || !aligned16(q.d))) ||
+        (q.w_first && (!aligned16(q.w_first) || (q.ldw_first & 3) || (q.col_first & 3) || (q.k_first & 3)))) {
+      set_error(std::string(who) + ": buffers of direction " + std::to_string(d) + " missing or not 16-byte aligned");
+      return;
+    }
   }
   SeqRuntime &rt = seq_runtime();
   // One persistent launch at a time per process: the kernels share the placement table, the abort word and the share ring, and two

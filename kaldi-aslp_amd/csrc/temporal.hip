@@ -144,7 +144,8 @@ __global__ void __launch_bounds__(kBlock) rowconv_bwd(float *__restrict__ in_dif
 template <int KP>
 __global__ void __launch_bounds__(kBlock) rowconv_wgrad1(float *__restrict__ partial, const float *__restrict__ in, int ldi,
                                                          const float *__restrict__ od, int ldod, int D, int K, int T, int S,
-                                                         const int32_t *__restrict__ seq_len, int tc, int spg) {
+                                                         const int32_t *__restrict__ seq_len, int tc, int spg, int k0) {
+  // k0: first tap of this launch (taps k0 .. k0 + KP - 1; more than 64 taps go in groups of 64, one launch each)
   __shared__ float red[kBlock / kWave][KP][kWave];
   const int x = threadIdx.x, y = threadIdx.y;
   const int d = blockIdx.x * kWave + x;
@@ -159,14 +160,14 @@ __global__ void __launch_bounds__(kBlock) rowconv_wgrad1(float *__restrict__ par
       if (ta >= tb) continue;
       float w[KP];
 #pragma unroll
-      for (int k = 0; k < KP; k++) w[k] = in[((long)min(ta + k, L - 1) * S + s) * ldi + d];
+      for (int k = 0; k < KP; k++) w[k] = in[((long)min(ta + k0 + k, L - 1) * S + s) * ldi + d];
       for (int t = ta; t < tb; t++) {
         const float g = od[((long)t * S + s) * ldod + d];
 #pragma unroll
         for (int k = 0; k < KP; k++) acc[k] += w[k] * g;
 #pragma unroll
         for (int k = 0; k < KP - 1; k++) w[k] = w[k + 1];
-        w[KP - 1] = in[((long)min(t + KP, L - 1) * S + s) * ldi + d];
+        w[KP - 1] = in[((long)min(t + k0 + KP, L - 1) * S + s) * ldi + d];
       }
     }
   }
@@ -174,11 +175,11 @@ __global__ void __launch_bounds__(kBlock) rowconv_wgrad1(float *__restrict__ par
   for (int k = 0; k < KP; k++) red[y][k][x] = acc[k];
   __syncthreads();
   if (d < D)
-    for (int k = y; k <= K; k += kBlock / kWave) {
+    for (int k = y; k < KP && k0 + k <= K; k += kBlock / kWave) {
       float sum = red[0][k][x];
 #pragma unroll
       for (int j = 1; j < kBlock / kWave; j++) sum += red[j][k][x];
-      partial[(((long)blockIdx.z * gridDim.y + blockIdx.y) * (K + 1) + k) * D + d] = sum;
+      partial[(((long)blockIdx.z * gridDim.y + blockIdx.y) * (K + 1) + k0 + k) * D + d] = sum;
     }
 }
 __global__ void __launch_bounds__(kBlock) rowconv_wgrad2(float *__restrict__ w_diff, const float *__restrict__ partial, int D, int K,
@@ -249,7 +250,6 @@ void aslp_rowconv_backward(float *in_diff, int ldid, const float *out_diff, int 
 void aslp_rowconv_wgrad(float *w_diff, const float *in, int ldi, const float *out_diff, int ldod, int D, int K, int T, int S,
                         const int32_cuda *seq_len) {
   if (T <= 0 || D <= 0 || S <= 0) return;
-  if (K + 1 > 64) { set_error("aslp_rowconv_wgrad: FutureContext > 63 not supported"); return; }
   const int ctiles = (D + kWave - 1) / kWave;
   // one partial per (frame chunk, stream group): chunks of two window lengths keep the window fill at a third of the
   // loads; stream groups supply the rest of the ~1000 workgroups the chip wants
@@ -262,10 +262,12 @@ void aslp_rowconv_wgrad(float *w_diff, const float *in, int ldi, const float *ou
   float *partial = static_cast<float *>(scratch(kScratchMisc, sizeof(float) * (size_t)chunks * sg * (K + 1) * D));
   if (!partial) return;
   dim3 grid(ctiles, chunks, sg), block(kWave, waves);
-  if (K + 1 <= 8) hipLaunchKernelGGL((rowconv_wgrad1<8>), grid, block, 0, cur_stream(), partial, in, ldi, out_diff, ldod, D, K, T, S, seq_len, tc, spg);
-  else if (K + 1 <= 16) hipLaunchKernelGGL((rowconv_wgrad1<16>), grid, block, 0, cur_stream(), partial, in, ldi, out_diff, ldod, D, K, T, S, seq_len, tc, spg);
-  else if (K + 1 <= 32) hipLaunchKernelGGL((rowconv_wgrad1<32>), grid, block, 0, cur_stream(), partial, in, ldi, out_diff, ldod, D, K, T, S, seq_len, tc, spg);
-  else hipLaunchKernelGGL((rowconv_wgrad1<64>), grid, block, 0, cur_stream(), partial, in, ldi, out_diff, ldod, D, K, T, S, seq_len, tc, spg);
+  if (K + 1 <= 8) hipLaunchKernelGGL((rowconv_wgrad1<8>), grid, block, 0, cur_stream(), partial, in, ldi, out_diff, ldod, D, K, T, S, seq_len, tc, spg, 0);
+  else if (K + 1 <= 16) hipLaunchKernelGGL((rowconv_wgrad1<16>), grid, block, 0, cur_stream(), partial, in, ldi, out_diff, ldod, D, K, T, S, seq_len, tc, spg, 0);
+  else if (K + 1 <= 32) hipLaunchKernelGGL((rowconv_wgrad1<32>), grid, block, 0, cur_stream(), partial, in, ldi, out_diff, ldod, D, K, T, S, seq_len, tc, spg, 0);
+  else   // 64 taps per launch: a register window longer than that spills; the reference has no limit on FutureContext
+    for (int k0 = 0; k0 <= K; k0 += 64)
+      hipLaunchKernelGGL((rowconv_wgrad1<64>), grid, block, 0, cur_stream(), partial, in, ldi, out_diff, ldod, D, K, T, S, seq_len, tc, spg, k0);
   hipLaunchKernelGGL(rowconv_wgrad2, dim3(grid_for((long)D * (K + 1))), dim3(kBlock), 0, cur_stream(), w_diff, partial, D, K, chunks * sg);
   check_launch("aslp_rowconv_wgrad");
 }

@@ -44,11 +44,14 @@ namespace {
 class RcclComm : public Comm {
  public:
   // The rendezvous file is bound to ONE launch: {magic, world size, token, ncclUniqueId}.  The token comes from the caller,
-  // else ASLP_COMM_TOKEN, else the launcher's job id (TORCHELASTIC_RUN_ID, SLURM_JOB_ID, PMI_ID): every rank of a launch
-  // sees the same value, a file left behind by a run that died between writing and removing it carries another one (or
-  // is older than ASLP_COMM_MAX_AGE_S, default 600 s, when there is no token at all) and is ignored.  Rank 0 removes whatever
-  // is there before it writes; ncclCommInitRank itself runs under the same timeout, so a rank that did pick up a wrong
-  // id fails with a message instead of blocking for ever.
+  // else ASLP_COMM_TOKEN, else the launcher's job id (torchrun, Slurm, PMI, and the PMIx / Open MPI ids mpirun exports -- the
+  // reference's recipes start the workers with mpirun): every rank of a launch sees the same value, a file left behind by a run
+  // that died between writing and removing it carries another one and is ignored.  With no token at all a leftover is told
+  // apart by its age (ASLP_COMM_MAX_AGE_S, default 600 s) and by a second look: a record is only taken once it has stayed
+  // unchanged for a grace period, within which a rank 0 that is starting up has replaced it.  Rank 0 removes whatever is there
+  // FIRST THING (before ncclGetUniqueId, which can take minutes on a cold box), so the window in which the others can see a
+  // leftover closes as soon as rank 0 runs; ncclCommInitRank itself runs under the same timeout, so a rank that did pick up a
+  // wrong id fails with a message instead of blocking for ever.
   struct IdRecord {
     char magic[8];
     int32 world, reserved;
@@ -57,7 +60,8 @@ class RcclComm : public Comm {
   };
   static std::string LaunchToken(const std::string &given) {
     if (!given.empty()) return given;
-    for (const char *k : {"ASLP_COMM_TOKEN", "TORCHELASTIC_RUN_ID", "SLURM_JOB_ID", "PMI_ID"})
+    for (const char *k : {"ASLP_COMM_TOKEN", "TORCHELASTIC_RUN_ID", "SLURM_JOB_ID", "PMI_ID", "PMIX_NAMESPACE", "OMPI_MCA_ess_base_jobid",
+                          "OMPI_MCA_orte_ess_jobid", "PMI_JOBID"})
       if (getenv(k) && getenv(k)[0]) return getenv(k);
     return std::string();
   }
@@ -72,12 +76,14 @@ class RcclComm : public Comm {
     const double max_age = getenv("ASLP_COMM_MAX_AGE_S") ? atof(getenv("ASLP_COMM_MAX_AGE_S")) : 600.0;
     const time_t started = time(nullptr);
     if (rank == 0) {
+      if (n > 1) {   // leftovers of a run that died go before anything slow happens: nobody may join them
+        (void)unlink(id_file.c_str());
+        (void)unlink(ctl_path_.c_str());
+      }
       Nccl(ncclGetUniqueId(&rec.id), "ncclGetUniqueId");
       if (n > 1) {
-        (void)unlink(id_file.c_str());  // a leftover of a run that died: nobody may join it
         // the control pipe exists before the id does, so whoever found the id can open it; O_RDWR: never sees end-of-file
         // (only the served protocols need it: on a filesystem without FIFOs the collective workers still run)
-        (void)unlink(ctl_path_.c_str());
         if (mkfifo(ctl_path_.c_str(), 0600) == 0) ctl_fd_ = open(ctl_path_.c_str(), O_RDWR);
         if (ctl_fd_ < 0) ASLP_WARN << "no control pipe at " << ctl_path_ << " (" << strerror(errno) << "): easgd / asgd / masgd are unavailable in this group";
         std::memcpy(rec.magic, "ASLPRCCL", 8);
@@ -100,7 +106,20 @@ class RcclComm : public Comm {
           else if (rec.world != n) why = "written for a group of " + std::to_string(rec.world);
           else if (token != rec.token) why = "belongs to another launch (token '" + std::string(rec.token) + "')";
           else if (difftime(started, st.st_mtime) > max_age) why = "older than " + std::to_string((int)max_age) + " s (a leftover; see ASLP_COMM_MAX_AGE_S)";
-          else break;
+          else if (!token.empty()) break;   // this launch's own record
+          else {
+            // no token: take the record only if it is still the same after a grace period (a rank 0 that is just starting has
+            // removed or replaced a leftover by then)
+            static const double grace = getenv("ASLP_COMM_GRACE_S") ? atof(getenv("ASLP_COMM_GRACE_S")) : 2.0;
+            std::this_thread::sleep_for(std::chrono::milliseconds((long)(grace * 1000)));
+            IdRecord again;
+            std::memset(&again, 0, sizeof(again));
+            std::ifstream f2(id_file, std::ios::binary);
+            f2.read(reinterpret_cast<char *>(&again), sizeof(again));
+            if (f2.gcount() == (std::streamsize)sizeof(again) && std::memcmp(&again, &rec, sizeof(rec)) == 0) break;
+            why = "changed while it was being read (a leftover replaced by this launch's rank 0)";
+            continue;   // look again at once: the fresh record may already be there
+          }
         }
         if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
           ASLP_ERR << "RcclComm: rank " << rank << " timed out waiting for " << id_file << " (" << why << ")";

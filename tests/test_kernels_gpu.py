@@ -279,7 +279,8 @@ def test_batchnorm_forward_backward(aslp, oracle, dev, rows, cols):
     assert oracle.rel_err(dsh.cpu().numpy(), bn.dshift) < 1e-5
 
 
-@pytest.mark.parametrize("rows,cols", [(16, 10), (256, 3000), (100, 128), (5, 8192)])
+# (5, 8192): the widest row the register-cached kernels hold; (6, 8193) and (4, 20000): the streaming kernel beyond (the reference has no limit)
+@pytest.mark.parametrize("rows,cols", [(16, 10), (256, 3000), (100, 128), (5, 8192), (6, 8193), (4, 20000)])
 def test_xent_eval(aslp, oracle, dev, rows, cols):
     rng = np.random.default_rng(7)
     logits = rng.standard_normal((rows, cols)).astype(np.float32) * 3
@@ -373,8 +374,12 @@ def test_rnn_vec_grads(aslp, oracle, dev, rows, C, cifg, clip, lr):
         dv = d[:, off[k]:off[k] + n[k]]
         xv = None if xrow[k] is None else y[xrow[k]:xrow[k] + rows, G * C:G * C + C]
         jobs.append((dv, xv, corr[k], par[k]))
-    aslp.ops.rnn_vec_grads(jobs, d.stride(0), rows, mmt, clip, -lr)
+    # a job list longer than one launch carries (8): the same jobs three times over, on copies of their buffers
+    extra = [(dv, xv, c.clone(), q.clone()) for _ in range(2) for (dv, xv, c, q) in jobs]
+    aslp.ops.rnn_vec_grads(jobs + extra, d.stride(0), rows, mmt, clip, -lr)
     torch.cuda.synchronize()
+    for i, (dv, xv, c, q) in enumerate(extra):
+        assert torch.equal(c, jobs[i % len(jobs)][2]) and torch.equal(q, jobs[i % len(jobs)][3]), i
     dn, yn = d.cpu().numpy().astype(np.float64), y.cpu().numpy().astype(np.float64)
     for k in names:
         g = dn[:, off[k]:off[k] + n[k]]

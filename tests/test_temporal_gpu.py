@@ -12,9 +12,11 @@ TOL = 1e-4
 
 
 # K + 1 taps select the tap-gradient instantiation (temporal.hip rowconv_wgrad1<8|16|32|64>): K = 2..5 -> <8>, 12 -> <16>,
-# 20 (cfg5's FutureContext, at its full size D=512 / T=800 / S=32) and 31 -> <32>, 40 and 63 (the largest supported) -> <64>
+# 20 (cfg5's FutureContext, at its full size D=512 / T=800 / S=32) and 31 -> <32>, 40 and 63 -> <64>; 64, 100 and 130 taps and more go in groups
+# of 64 taps, one launch each (the reference has no limit on FutureContext)
 @pytest.mark.parametrize("dims", [(4, 2, 6, 3), (70, 3, 21, 4), (256, 2, 50, 8), (33, 5, 9, 2), (64, 12, 40, 4), (96, 15, 33, 5),
-                                  (512, 20, 800, 32), (40, 31, 64, 3), (48, 40, 90, 3), (130, 63, 70, 2)])
+                                  (512, 20, 800, 32), (40, 31, 64, 3), (48, 40, 90, 3), (130, 63, 70, 2), (72, 64, 150, 3), (40, 100, 120, 2),
+                                  (36, 130, 90, 2)])
 def test_rowconv_train_steps_match_oracle(aslp, oracle, dev, tmp_path, dims):
     D, K, T, S = dims
     rng = np.random.default_rng(5)
