@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 mode = sys.argv[1]
 import aslp_import; aslp = aslp_import.load(); aslp.ops.use_torch_stream()
-from kaldi_aslp_amd.parallel import BspWorker
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from parallel_model import BspWorker
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 def init_pg():

@@ -35,6 +35,10 @@ const char *aslp_parallel_last_error(void);
  * the file to this launch; default ASLP_COMM_TOKEN / TORCHELASTIC_RUN_ID / SLURM_JOB_ID.  timeout_s bounds both the wait
  * for the file and ncclCommInitRank.  Create the communicator BEFORE the model is allocated. */
 int aslp_comm_create_rccl(int rank, int num_nodes, const char *id_file, const char *token, int timeout_s, aslp_comm_t *out);
+/* The same communicator for ranks that are separate processes on ANY devices -- all on one GPU included, which RCCL refuses: the same
+ * rendezvous file and control pipe, tensors staged through a POSIX shared-memory segment (kaldi-aslp_amd/parallel/comm.cpp ShmComm).
+ * A functional transport for single-GPU boxes; the worker tools take it with --comm-transport=shm / ASLP_COMM_TRANSPORT=shm. */
+int aslp_comm_create_shm(int rank, int num_nodes, const char *id_file, const char *token, int timeout_s, aslp_comm_t *out);
 void aslp_comm_free(aslp_comm_t c);
 int aslp_comm_rank(aslp_comm_t c);        /* MpiNode::Rank      mpi-node.h:40 */
 int aslp_comm_num_nodes(aslp_comm_t c);   /* MpiNode::NumNodes  mpi-node.h:43 */

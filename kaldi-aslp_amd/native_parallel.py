@@ -26,6 +26,7 @@ def lib():
         L.aslp_parallel_last_error.restype = C.c_char_p
         for name, args in [
             ("aslp_comm_create_rccl", [i, i, C.c_char_p, C.c_char_p, i, C.POINTER(vp)]),
+            ("aslp_comm_create_shm", [i, i, C.c_char_p, C.c_char_p, i, C.POINTER(vp)]),
             ("aslp_comm_rank", [vp]), ("aslp_comm_num_nodes", [vp]), ("aslp_comm_barrier", [vp]),
             ("aslp_comm_allreduce_sum_f32", [vp, vp, sz]), ("aslp_comm_allreduce_sum_f64", [vp, vp, sz]),
             ("aslp_comm_allreduce_sum_host_i32", [vp, C.POINTER(C.c_int32), sz]),
@@ -73,12 +74,14 @@ def _ok(rc):
 class RcclComm:
     """mpi-node.h:19-97 on RCCL.  rank / num_nodes default to the launcher's environment (RANK / WORLD_SIZE, PMI_*, OMPI_*)."""
 
+    _create = "aslp_comm_create_rccl"
+
     def __init__(self, id_file=None, rank=-1, num_nodes=-1, token=None, timeout_s=900):
         self.h = C.c_void_p()
         L = lib()
         with _StdoutToStderr():
-            rc = L.aslp_comm_create_rccl(rank, num_nodes, id_file.encode() if id_file else None, token.encode() if token else None,
-                                         timeout_s, C.byref(self.h))
+            rc = getattr(L, self._create)(rank, num_nodes, id_file.encode() if id_file else None, token.encode() if token else None,
+                                          timeout_s, C.byref(self.h))
         _ok(rc)
 
     def close(self):
@@ -124,6 +127,18 @@ class RcclComm:
     def Send(self, peer, t): _ok(lib().aslp_comm_send_f32(self.h, peer, t.data_ptr(), t.numel()))
     def Recv(self, peer, t): _ok(lib().aslp_comm_recv_f32(self.h, peer, t.data_ptr(), t.numel()))
     def Exchange(self, peer, send, recv): _ok(lib().aslp_comm_exchange_f32(self.h, peer, send.data_ptr(), recv.data_ptr(), send.numel()))
+
+
+class ShmComm(RcclComm):
+    """The same communicator for ranks that are separate processes sharing GPUs (all on one device included): rendezvous file and
+    control pipe as RcclComm, tensors staged through a shared-memory segment (parallel/comm.cpp ShmComm)."""
+    _create = "aslp_comm_create_shm"
+
+
+def ProcessComm(id_file=None, rank=-1, num_nodes=-1, token=None, timeout_s=900, transport=None):
+    """RcclComm unless transport / ASLP_COMM_TRANSPORT says "shm" (what the worker tools do)"""
+    t = transport or os.environ.get("ASLP_COMM_TRANSPORT") or "rccl"
+    return (ShmComm if t == "shm" else RcclComm)(id_file, rank=rank, num_nodes=num_nodes, token=token, timeout_s=timeout_s)
 
 
 class Worker:

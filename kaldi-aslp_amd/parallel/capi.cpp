@@ -44,6 +44,16 @@ int aslp_comm_create_rccl(int rank, int num_nodes, const char *id_file, const ch
   *out = h;
   API_END
 }
+int aslp_comm_create_shm(int rank, int num_nodes, const char *id_file, const char *token, int timeout_s, aslp_comm_t *out) {
+  API_BEGIN
+  RankFromEnvironment(&rank, &num_nodes);
+  aslp_comm_s *h = new aslp_comm_s();
+  try {
+    h->comm.reset(NewShmComm(rank, num_nodes, id_file ? id_file : "", timeout_s > 0 ? timeout_s : 900, token ? token : ""));
+  } catch (...) { delete h; throw; }
+  *out = h;
+  API_END
+}
 void aslp_comm_free(aslp_comm_t c) { delete c; }
 int aslp_comm_rank(aslp_comm_t c) { return c->comm->Rank(); }
 int aslp_comm_num_nodes(aslp_comm_t c) { return c->comm->NumNodes(); }

@@ -2,8 +2,10 @@
 // to them -- rank, size, barrier, sum all-reduce -- with the parameter buffers staying in HBM.
 //   RcclComm    one process per GPU, RCCL over xGMI (ncclAllReduce on device pointers, no host staging).  No MPI in the
 //               launch path: ranks find each other through a file that rank 0 writes the ncclUniqueId into.
-//   ThreadComm  N ranks as threads of ONE process on one GPU -- the harness the worker arithmetic is tested with on a
-//               single-GPU box (RCCL refuses two ranks on one device).
+//   ShmComm     one process per rank on ANY devices, all on one GPU included: the same rendezvous file and control pipe, tensors
+//               staged through a POSIX shared-memory segment.  What runs the process-per-rank machinery (server + workers as separate
+//               OS processes) on a one-GPU box, where RCCL refuses two ranks on one device.
+//   ThreadComm  N ranks as threads of ONE process on one GPU -- the harness the worker arithmetic is tested with.
 #pragma once
 #include <condition_variable>
 #include <memory>
@@ -50,6 +52,12 @@ void RankFromEnvironment(int *rank, int *num_nodes);
 // ncclCommInitRank).  token: ties the file to one launch (default: ASLP_COMM_TOKEN / the launcher's job id); a file with
 // another token, another world size or an age beyond ASLP_COMM_MAX_AGE_S is a leftover and is not joined.
 Comm *NewRcclComm(int rank, int num_nodes, const std::string &id_file, int timeout_s = 900, const std::string &token = std::string());
+
+// the same contract on a shared-memory segment (ranks may share a GPU); slot size per rank: ASLP_SHM_SLOT_MB (default 16)
+Comm *NewShmComm(int rank, int num_nodes, const std::string &id_file, int timeout_s = 900, const std::string &token = std::string());
+// the process-per-rank communicator the tools create: transport "rccl" (default) | "shm"; empty = ASLP_COMM_TRANSPORT, else rccl
+Comm *NewProcessComm(const std::string &transport, int rank, int num_nodes, const std::string &id_file, int timeout_s = 900,
+                     const std::string &token = std::string());
 
 class ThreadCommGroup;
 // one group, then one Comm per thread

@@ -1,6 +1,7 @@
 // worker_tools.cpp -- the data-parallel worker tools of src/aslp-parallelbin (train-frame-worker, train-lstm-stream-worker,
 // train-lc-blstm-streams-worker) on the native sync workers (parallel/workers.h): one entry function per tool, linked behind
 // tools/main_stub.cpp into bin/<tool name>.
+#include <hip/hip_runtime.h>
 #include "cu-device.h"
 #include "data-reader.h"
 #include "nnet-loss.h"
@@ -82,6 +83,8 @@ int Main_aslp_nnet_train_frame_worker(int argc, char *argv[]) {
     po.Register("num-workers", &num_workers, "Number of workers (default: from the launcher's environment)");
     std::string comm_file = "";
     po.Register("comm-file", &comm_file, "Rendezvous file for the RCCL communicator (required with more than one worker)");
+    std::string comm_transport = "";
+    po.Register("comm-transport", &comm_transport, "rccl (one GPU per worker, default) | shm (workers may share a GPU: tensors staged through shared memory); default from ASLP_COMM_TRANSPORT");
     po.Read(argc, argv);
     if (po.NumArgs() != 4) { po.PrintUsage(); exit(1); }
     std::string feature_rspecifier = po.GetArg(1), targets_rspecifier = po.GetArg(2), model_filename = po.GetArg(3),
@@ -93,7 +96,7 @@ int Main_aslp_nnet_train_frame_worker(int argc, char *argv[]) {
     else CuDevice::Instantiate().SelectGpuId(use_gpu);
     // the communicator before the model: RCCL initialised after the first allocations / launches leaves every later step
     // slower on this stack (measured: 1.44 vs 2.39 ms/step on the cfg2 DNN)
-    std::unique_ptr<Comm> comm(NewRcclComm(rank, num_workers, comm_file));
+    std::unique_ptr<Comm> comm(NewProcessComm(comm_transport, rank, num_workers, comm_file));
 
     Nnet nnet;
     nnet.Read(model_filename);
@@ -220,6 +223,8 @@ int Main_aslp_nnet_train_lstm_stream_worker(int argc, char *argv[]) {
     po.Register("num-workers", &num_workers, "Number of workers (default: from the launcher's environment)");
     std::string comm_file = "";
     po.Register("comm-file", &comm_file, "Rendezvous file for the RCCL communicator (required with more than one worker)");
+    std::string comm_transport = "";
+    po.Register("comm-transport", &comm_transport, "rccl (one GPU per worker, default) | shm (workers may share a GPU: tensors staged through shared memory); default from ASLP_COMM_TRANSPORT");
     po.Read(argc, argv);
     if (crossvalidate) ASLP_ERR << "the worker tools train only (use aslp-nnet-train-lstm-streams --cross-validate=true)";
     if (po.NumArgs() != 4) { po.PrintUsage(); exit(1); }
@@ -231,7 +236,7 @@ int Main_aslp_nnet_train_lstm_stream_worker(int argc, char *argv[]) {
     else if (num_workers > 1) CuDevice::Instantiate().SetGpuId(rank);
     else CuDevice::Instantiate().SelectGpuId(use_gpu);
     // the communicator before the model (see aslp-nnet-train-frame-worker)
-    std::unique_ptr<Comm> comm(NewRcclComm(rank, num_workers, comm_file));
+    std::unique_ptr<Comm> comm(NewProcessComm(comm_transport, rank, num_workers, comm_file));
 
     Nnet nnet;
     nnet.Read(model_filename);
@@ -370,6 +375,8 @@ int Main_aslp_nnet_train_lc_blstm_streams_worker(int argc, char *argv[]) {
     po.Register("num-workers", &num_workers, "Number of workers (default: from the launcher's environment)");
     std::string comm_file = "";
     po.Register("comm-file", &comm_file, "Rendezvous file for the RCCL communicator (required with more than one worker)");
+    std::string comm_transport = "";
+    po.Register("comm-transport", &comm_transport, "rccl (one GPU per worker, default) | shm (workers may share a GPU: tensors staged through shared memory); default from ASLP_COMM_TRANSPORT");
     int32 num_stream = 4;
     po.Register("num-stream", &num_stream, "---LSTM--- BPTT multi-stream training");
     int32 dump_interval = 0;
@@ -396,7 +403,7 @@ int Main_aslp_nnet_train_lc_blstm_streams_worker(int argc, char *argv[]) {
     else CuDevice::Instantiate().SelectGpuId(use_gpu);
     // the communicator before the model: RCCL initialised after the first allocations / launches leaves every later step
     // slower on this stack (measured: 1.44 vs 2.39 ms/step on the cfg2 DNN)
-    std::unique_ptr<Comm> comm(NewRcclComm(rank, num_workers, comm_file));
+    std::unique_ptr<Comm> comm(NewProcessComm(comm_transport, rank, num_workers, comm_file));
     Nnet nnet_transf;
     if (feature_transform != "") nnet_transf.Read(feature_transform);
     Nnet nnet;
@@ -577,6 +584,8 @@ int Main_aslp_nnet_train_server(int argc, char *argv[]) {
     po.Register("num-workers", &num_workers, "Size of the group, server included (default: from the launcher's environment)");
     std::string comm_file = "";
     po.Register("comm-file", &comm_file, "Rendezvous file for the RCCL communicator");
+    std::string comm_transport = "";
+    po.Register("comm-transport", &comm_transport, "rccl (one GPU per worker, default) | shm (workers may share a GPU: tensors staged through shared memory); default from ASLP_COMM_TRANSPORT");
     po.Read(argc, argv);
     if (po.NumArgs() != 2) { po.PrintUsage(); exit(1); }
     std::string model_filename = po.GetArg(1), target_model_filename = po.GetArg(2);
@@ -585,7 +594,7 @@ int Main_aslp_nnet_train_server(int argc, char *argv[]) {
     if (gpu_id >= 0) CuDevice::Instantiate().SetGpuId(gpu_id);
     else if (num_workers > 1) CuDevice::Instantiate().SetGpuId(rank);
     else CuDevice::Instantiate().SelectGpuId(use_gpu);
-    std::unique_ptr<Comm> comm(NewRcclComm(rank, num_workers, comm_file));
+    std::unique_ptr<Comm> comm(NewProcessComm(comm_transport, rank, num_workers, comm_file));
 
     Nnet nnet;
     nnet.Read(model_filename);
@@ -631,8 +640,11 @@ class PairSimpleSync : public SimpleSync {
     using namespace aslp;
     RankFromEnvironment(&rank_, &num_workers_);
     if (num_workers_ != 2) ASLP_ERR << "num of jobs must be 2";
-    CuDevice::Instantiate().SetGpuId(rank_);
-    comm_.reset(NewRcclComm(rank_, num_workers_, comm_file_));
+    const bool shm = getenv("ASLP_COMM_TRANSPORT") != nullptr && std::string(getenv("ASLP_COMM_TRANSPORT")) == "shm";
+    int ndev = 1;
+    if (shm && (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)) ndev = 1;
+    CuDevice::Instantiate().SetGpuId(shm ? rank_ % ndev : rank_);   // one GPU per rank; over shared memory the two ranks may share one
+    comm_.reset(NewProcessComm("", rank_, num_workers_, comm_file_));
     pair_.reset(new PairSync(comm_.get()));
   }
   void Init(aslp::Nnet *nnet, std::string *feature_rspecifier) {

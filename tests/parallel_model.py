@@ -1,4 +1,5 @@
-"""Data-parallel model-sync workers: BSP, BMUF, EASGD (worker + server).
+"""TEST INFRASTRUCTURE: a torch.distributed model of the data-parallel model-sync workers -- BSP, BMUF, EASGD (worker + server) -- for
+the world-size-2 gloo tests on CPU (tests/test_parallel_cpu.py).  The product's workers are kaldi-aslp_amd/parallel/*.cpp.
 
 Mirror of the reference's aslp-parallel interface (src/aslp-parallel/itf.h:26-42):
 `InitParam(params)`, `Synchronize(num_worker_samples) -> bool`, `Stop()`, `ReduceAccStat(...)`,

@@ -29,7 +29,8 @@ def main():
     aslp = aslp_import.load()
     aslp.ops.use_torch_stream()
     from kaldi_aslp_amd import native_parallel as npar
-    comm = npar.RcclComm(os.environ.get("ASLP_COMM_FILE"), rank=rank, num_nodes=world, token=os.environ.get("ASLP_COMM_TOKEN"))   # the library default (900 s: a cold box can take minutes to page RCCL in)
+    # RcclComm, or ShmComm when ASLP_COMM_TRANSPORT=shm (ranks as separate processes on ONE device)
+    comm = npar.ProcessComm(os.environ.get("ASLP_COMM_FILE"), rank=rank, num_nodes=world, token=os.environ.get("ASLP_COMM_TOKEN"))   # the library default (900 s: a cold box can take minutes to page RCCL in)
     out = {"rank": comm.Rank(), "world": comm.NumNodes()}
     f32 = np.float32
 

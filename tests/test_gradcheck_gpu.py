@@ -24,7 +24,7 @@ NETS = {
 
 
 def check(aslp, dev, net, x, R, before_forward, n_probe=14, eps=1e-2, seed=0):
-    from kaldi_aslp_amd.parallel import alias_device_params
+    from parallel_model import alias_device_params   # (tests/parallel_model.py: aliases device memory as torch tensors)
     params = alias_device_params(net.GetGpuParams())
     flat = lambda: torch.cat([p.reshape(-1) for p in params]).clone()
 

