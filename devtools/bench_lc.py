@@ -63,6 +63,9 @@ if os.environ.get("SEQ_TIMING") == "1":
         buf = (C.c_ulonglong * 8)()
         aslp.lib.aslp_lstm_seq_timing(0, buf)
         n = max(1, buf[0])
+        if mode == 1 and os.environ.get("ASLP_LSTM_DUAL", "0") == "1":
+            print("(wave-specialised forward: per timestep = two half-steps; 'barrier' (2nd) = product waves waiting for the gate waves; the 1st 'barrier' column = "
+                  "gate role: reduce + gate block up to the publication; 'epilogue' = gate role: stores behind the publication)")
         names = ("collect m(t-1)", "barrier", "product", "barrier", "epilogue") if mode == 1 else ("product+publish", "-", "collect shares", "barrier", "epilogue")
         vals = [buf[k] * 0.01 / n for k in (1, 3, 2, 4, 5)]
         print("%s kernel, workgroup 0 wave 0, us per timestep: %s   (L2-local launches %d of %d; workgroup 0 resident %.1f us per launch)"

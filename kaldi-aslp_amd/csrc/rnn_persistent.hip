@@ -100,6 +100,14 @@ __device__ __forceinline__ void tock(const SeqStatus &st, int slot, long &t) {
   t = now;
 }
 
+// the same for the first thread of the gate role (thread 256) of the wave-specialised kernel
+__device__ __forceinline__ void tock_gate(const SeqStatus &st, int slot, long &t) {
+  if (!st.timing) return;
+  const long now = (long)wall_clock64();
+  if (blockIdx.x == 0 && threadIdx.x == 256) st.timing[slot] += (unsigned long long)(now - t);
+  t = now;
+}
+
 // Bounded spin bookkeeping shared by the two phases below: false = give up (device-wide abort or 2 s without progress).
 __device__ __forceinline__ bool spin_ok(unsigned spins, long &t0, const SeqStatus &st) {
   if ((spins & 31u) != 31u) return true;
@@ -957,6 +965,276 @@ __global__ void __launch_bounds__(256, 2) lstm_seq_fwd4(aslp_lstm_seq a, SeqStat
   if (polls && lane == 0) __hip_atomic_fetch_add(st.abort_flag + 2, polls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---- wave-specialised forward: two half-chains alternating inside ONE workgroup -----------------------------------------------
+// The timestep of lstm_seq_fwd is a serial path -- hand-off (L2 round trip) -> product -> barrier -> gate block -> publish -- of which the
+// matrix pipe works a third.  Here the chain's 8 streams are two halves A and B of 4 streams, and the workgroup's 8 waves have two ROLES:
+//   waves 0-3 ("product"): own the weights (the workgroup's 64 gate columns x K / 4 each, resident in registers as in lstm_seq_fwd4),
+//                          collect m(t-1) of the half whose turn it is and multiply -- A, B, A, B, ... one half per half-step;
+//   waves 4-7 ("gates"):   own c(t-1) of both halves; finish the gate block of the half multiplied in the PREVIOUS half-step and publish
+//                          its m(t) while the product waves are busy with the other half.
+// One workgroup barrier per half-step hands the partial sums (LDS) from the product waves to the gate waves.  For one half the path
+// product -> gates -> publish -> (L2) -> collect closes after two half-steps, during which the matrix pipe serves both halves and the
+// gate waves both gate blocks: a half-step is (path length) / 2 instead of the whole path per 8 streams.
+//   half-step h:   product waves  P_X(h >> 1), X = h & 1        gate waves  G_X'((h - 1) >> 1), X' = (h - 1) & 1        [2 T + 1 half-steps]
+// Chains, placement, hand-off through the buffers ("the data is its own flag") and the bounded spins are lstm_seq_fwd's.
+template <bool CIFG, int KW, bool FAST>
+__global__ void __launch_bounds__(512) lstm_seq_fwd_dual(aslp_lstm_seq a, SeqStatus st, unsigned *place) {
+  constexpr int G = CIFG ? 3 : 4, NS = 4, KMAX = 4 * KW, MP = KMAX + 4, RP = 80;
+  __shared__ __attribute__((aligned(16))) float m_lds[2][NS][MP];   // [half][stream][k]: the left operand of that half's product
+  __shared__ float red[2][4][NS][RP];                                // [half][product wave][stream][tile column]
+  __shared__ int fail[2][8];
+  __shared__ int place_flag;
+  const long t_entry = (st.timing || st.trace) ? (long)wall_clock64() : 0;
+  const int SE = a.s_count > 0 ? a.s_begin + a.s_count : a.S;
+  for (int i = threadIdx.x; i < 2 * NS * MP; i += 512) (&m_lds[0][0][0])[i] = 0.f;   // read past C with zero B fragments: must be finite
+  const ChainRole R = chain_role(SE - a.s_begin, a.ndir, a.C, st, place, &place_flag);   // (its barrier publishes the zeros)
+  if (!R.active) return;
+  const aslp_lstm_seq_dir D = a.dir[R.dir];
+  const int C = a.C, S = a.S, T = a.T, ld = a.ld;
+  const int GC = G * C, oc = GC, oh = GC + C, om = GC + 2 * C;
+  const int c0 = R.c0, s0 = a.s_begin + R.s0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool product_role = wave < 4;
+  const int pw_ = wave & 3;   // index within the role
+  const int jl = lane & 3;
+  // ---- product role state
+  const int kw = ((C + 15) / 16) * 4, kb = pw_ * kw;
+  const int gate_n = lane >> 4, cell_n = c0 + (lane & 15);
+  const bool nvalid = gate_n < G && cell_n < C;
+  f32x4 bw[KW / 4];
+  if (product_role) {
+    const float *brow = D.w + (long)(nvalid ? gate_n * C + cell_n : 0) * a.ldw;
+#pragma unroll
+    for (int i = 0; i < KW / 4; i++) {
+      const int k0 = kb + 4 * i;
+      bw[i] = (nvalid && 4 * i < kw && k0 < C) ? *reinterpret_cast<const f32x4 *>(brow + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < KW / 4; i++) bw[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const bool first_in_kernel = D.w_first != nullptr && D.k_first > 0 && D.k_first <= kFirstK && D.k_first <= KMAX;
+  // collection (gate role): the 4 streams' rows of a half, [stream][C / 4] pieces of 16 bytes, threads take pieces g, g + 256, ...
+  const int c4 = C >> 2, npiece = NS * c4;
+  // ---- gate role state: thread g = threadIdx.x - 256; a quad of lanes owns one (stream, cell) pair of EACH half, lane r of the quad its gate r
+  const int g_ = threadIdx.x & 255;
+  const int pair = g_ >> 2, role = g_ & 3;
+  const int sl = pair >> 4, cc = pair & 15, cell = c0 + cc;
+  float pw = 0.f, cprev[2] = {0.f, 0.f};
+  int slen[2] = {0x7fffffff, 0x7fffffff};
+  bool live[2] = {false, false};
+  if (!product_role) {
+    const int cq = cell < C ? cell : 0;
+    if (!CIFG) pw = role == 1 ? D.peep_i[cq] : role == 2 ? D.peep_f[cq] : role == 3 ? D.peep_o[cq] : 0.f;
+    else pw = role == 1 ? D.peep_f[cq] : role == 2 ? D.peep_o[cq] : 0.f;
+    const int tp0 = D.reverse ? T + 1 : 0;
+#pragma unroll
+    for (int X = 0; X < 2; X++) {
+      const int s = s0 + 4 * X + sl;
+      live[X] = s < SE && cell < C;
+      if (live[X]) {
+        cprev[X] = D.y[((long)tp0 * S + s) * ld + oc + cell];
+        if (D.seq_lengths) slen[X] = D.seq_lengths[s];
+      }
+    }
+  }
+  unsigned polls = 0u;
+  if (!first_in_kernel && !D.skip_first_product) {   // the first product multiplies the history row block: stored before the launch, no hand-off
+    const int tp0 = D.reverse ? T + 1 : 0;
+    for (int p = threadIdx.x; p < 2 * npiece; p += 512) {
+      const int X = p / npiece, q = p - X * npiece, sp = q / c4, kq = q - sp * c4;
+      *reinterpret_cast<f32x4 *>(&m_lds[X][sp][4 * kq]) =
+          *reinterpret_cast<const f32x4 *>(D.y + ((long)tp0 * S + min(s0 + 4 * X + sp, SE - 1)) * ld + om + 4 * kq);
+    }
+  }
+  __syncthreads();
+  for (int h = 0; h <= 2 * T; h++) {
+    const int par = h & 1;
+    bool ok = true;
+    long tm = tick(st);
+    if (product_role) {
+      const int X = h & 1, step = h >> 1;
+      if (step < T) {
+        const int t = D.reverse ? T - step : 1 + step, tp = D.reverse ? t + 1 : t - 1;
+        const int sh = s0 + 4 * X;   // first stream of this half
+        f32x4 acc[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const bool first_special = step == 0 && first_in_kernel;
+        const bool product = !first_special && !(step == 0 && D.skip_first_product);
+        if (first_special) {   // r(0) W_first^T: this wave's K slice of r(0) -> its rows of m_lds (nobody else reads them), B straight from memory
+          const int kwf = ((D.k_first + 15) / 16) * 4, kbf = pw_ * kwf, kqf = kwf >> 2;
+          for (int p = lane; p < NS * kqf; p += 64) {
+            const int sp = p / kqf, k0 = kbf + 4 * (p % kqf);
+            if (k0 < D.k_first)
+              *reinterpret_cast<f32x4 *>(&m_lds[X][sp][k0]) =
+                  *reinterpret_cast<const f32x4 *>(D.y + ((long)tp * S + min(sh + sp, SE - 1)) * ld + D.col_first + k0);
+          }
+          __builtin_amdgcn_wave_barrier();
+          const float *arow = &m_lds[X][jl][0];
+          const float *brow = D.w_first + (long)(nvalid ? gate_n * C + cell_n : 0) * D.ldw_first;
+          // the B fragments of this wave's slice come in groups of four requested together (one round trip per group, not one per fragment;
+          // all sixteen at once would not fit beside the resident weights)
+          constexpr int NFF = kFirstK / 16;
+          for (int i0 = 0; i0 < NFF; i0 += 4) {   // (not unrolled: one step per launch)
+            f32x4 bf[4], af[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              const int k0 = kbf + 4 * (i0 + j);
+              const bool in = 4 * (i0 + j) < kwf && k0 < D.k_first;
+              bf[j] = (nvalid && in) ? *reinterpret_cast<const f32x4 *>(brow + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+              af[j] = in ? *reinterpret_cast<const f32x4 *>(arow + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(af[j].x, bf[j].x, acc[0], 0, 0, 0);
+              acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(af[j].y, bf[j].y, acc[1], 0, 0, 0);
+              acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(af[j].z, bf[j].z, acc[2], 0, 0, 0);
+              acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(af[j].w, bf[j].w, acc[3], 0, 0, 0);
+            }
+          }
+          // r(0) sits where m(t) of the later steps goes: positions of this wave's rows past C (k_first > C) would otherwise keep it
+          __builtin_amdgcn_wave_barrier();
+          for (int p = lane; p < NS * kqf; p += 64) {
+            const int sp = p / kqf, k0 = kbf + 4 * (p % kqf);
+            if (k0 < D.k_first) *reinterpret_cast<f32x4 *>(&m_lds[X][sp][k0]) = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+        }
+        if (product) {   // m(t-1) of this half is in LDS: the gate waves collected it behind their previous publication (or the prologue did)
+          const float *arow = &m_lds[X][jl][kb];
+          __builtin_amdgcn_s_setprio(2);   // the gate wave on this SIMD yields issue slots to the product
+          constexpr int NF = KW / 4, PD = NF < 4 ? NF : 4;
+          f32x4 av[NF];
+#pragma unroll
+          for (int i = 0; i < PD; i++) av[i] = *reinterpret_cast<const f32x4 *>(arow + 4 * i);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < NF; i++) {
+            if (i + PD < NF) av[i + PD] = *reinterpret_cast<const f32x4 *>(arow + 4 * (i + PD));
+            __builtin_amdgcn_sched_barrier(0);
+            acc[4 * (i & 1) + 0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i].x, bw[i].x, acc[4 * (i & 1) + 0], 0, 0, 0);
+            acc[4 * (i & 1) + 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i].y, bw[i].y, acc[4 * (i & 1) + 1], 0, 0, 0);
+            acc[4 * (i & 1) + 2] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i].z, bw[i].z, acc[4 * (i & 1) + 2], 0, 0, 0);
+            acc[4 * (i & 1) + 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i].w, bw[i].w, acc[4 * (i & 1) + 3], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          __builtin_amdgcn_s_setprio(0);
+        }
+        {   // result register r of a lane = stream r of tile column `lane`
+          const f32x4 sum = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+          float *rp = &red[X][pw_][0][lane];
+          rp[0 * RP] = sum.x; rp[1 * RP] = sum.y; rp[2 * RP] = sum.z; rp[3 * RP] = sum.w;
+        }
+        tock(st, 2, tm);  // product
+      }
+    } else if (h >= 1) {
+      const int X = (h - 1) & 1, step = (h - 1) >> 1;   // the half multiplied in the previous half-step (step < T always: h - 1 <= 2 T - 1)
+      const int t = D.reverse ? T - step : 1 + step;
+      const int s = s0 + 4 * X + sl;
+      const bool lv = live[X];
+      const int cq = lv ? cell : 0, sq = lv ? s : 0;
+      float *ys = D.y + ((long)t * S + sq) * ld;
+      const float xr = (lv && role < G) ? ys[role * C + cq] : 0.f;
+      float pre = 0.f;
+      if (role < G) {
+        pre = red[X][0][sl][role * 16 + cc];
+#pragma unroll
+        for (int w = 1; w < 4; w++) pre += red[X][w][sl][role * 16 + cc];
+      }
+      const float cp = cprev[X];
+      const bool masked = t > slen[X];
+      float gate = 0.f;
+      if (role == 0) gate = act_tanh<FAST>(xr + pre);
+      else if (role < G - 1) gate = act_sigmoid<FAST>(xr + pre + cp * pw);
+      const float gg = quad_bcast<0>(gate), g1 = quad_bcast<1>(gate), g2 = quad_bcast<2>(gate);
+      float cellv;
+      if (!CIFG) cellv = gg * g1 + cp * g2;
+      else cellv = -gg * g1 + gg + cp * g1;
+      cellv = fminf(fmaxf(cellv, -50.0f), 50.0f);
+      float hh = 0.f;
+      if (role == 0) hh = act_tanh<FAST>(cellv);
+      if (role == G - 1) gate = act_sigmoid<FAST>(xr + pre + cellv * pw);
+      const float oo = quad_bcast<G - 1>(gate);
+      float mm = hh * oo;
+      if (masked) { gate = 0.f; cellv = 0.f; hh = 0.f; mm = 0.f; }
+      {
+        const float m1 = row_up<4>(mm), m2 = row_up<8>(mm), m3 = row_up<12>(mm);
+        if (lv && role == 0 && (cc & 3) == 0) {
+          u32x4 pk = {__float_as_uint(mm), __float_as_uint(m1), __float_as_uint(m2), __float_as_uint(m3)};
+          const __amdgpu_buffer_rsrc_t rs = make_rsrc(D.y + (long)t * S * ld);
+          const int off = (s * ld + om + cell) * 4;
+          if (R.local) __builtin_amdgcn_raw_buffer_store_b128(pk, rs, off, 0, 0);
+          else __builtin_amdgcn_raw_buffer_store_b128(pk, rs, off, 0, kAuxSc1);
+        }
+      }
+      tock_gate(st, 3, tm);   // gate role: reduce + gate block up to the publication of m(t)
+      if (lv) {
+        if (role < G) ys[role * C + cell] = gate;
+        if (role == 0) ys[oh + cell] = hh;
+        if (role == 1) ys[oc + cell] = cellv;
+      }
+      cprev[X] = cellv;
+      tock_gate(st, 5, tm);   // gate role: the stores behind the publication
+      // m(t) of this half from the chain's other workgroups -> LDS, for the product waves' next turn at this half (half-step h + 1).  They
+      // published it about when this workgroup did; the product waves are busy with the other half meanwhile.
+      if (step + 1 < T) {
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(D.y + (long)t * S * ld);
+        const int sh = s0 + 4 * X;
+        constexpr int NP = (NS * KMAX / 4 + 255) / 256;   // pieces per thread
+        int off[NP], dst[NP];
+        bool have[NP];
+#pragma unroll
+        for (int j = 0; j < NP; j++) {
+          const int p = g_ + 256 * j;
+          have[j] = p < npiece;
+          const int sp = have[j] ? p / c4 : 0, kq = have[j] ? p % c4 : 0;
+          off[j] = (min(sh + sp, SE - 1) * ld + om + 4 * kq) * 4;
+          dst[j] = sp * MP + 4 * kq;
+        }
+        u32x4 v[NP];
+#pragma unroll
+        for (int j = 0; j < NP; j++) v[j] = u32x4{0u, 0u, 0u, 0u};
+        long t0 = 0;
+        for (unsigned spins = 0;; spins++) {
+          bool missing = false;
+#pragma unroll
+          for (int j = 0; j < NP; j++)
+            if (have[j]) v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[j], 0, kAuxSc1);
+#pragma unroll
+          for (int j = 0; j < NP; j++) missing = missing || (have[j] && has_sentinel(v[j]));
+          if (!__any(missing)) break;
+          asm volatile("" ::: "memory");
+          polls++;
+          if (!spin_ok(spins, t0, st)) { ok = false; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int j = 0; j < NP; j++)
+          if (have[j]) *reinterpret_cast<u32x4 *>(&m_lds[X][0][0] + dst[j]) = v[j];
+        tock_gate(st, 1, tm);   // gate role: collection of the next left operand
+      }
+    }
+    if (lane == 0) fail[par][wave] = ok ? 0 : 1;
+    __syncthreads();
+    if (product_role) tock(st, 4, tm);   // product waves: what is left of the half-step after their product (waiting for the gate waves, or nothing)
+    {
+      int f = 0;
+#pragma unroll
+      for (int w = 0; w < 8; w++) f |= fail[par][w];
+      if (f) return;  // uniform
+    }
+  }
+  if (st.timing && blockIdx.x == 0 && threadIdx.x == 0) {
+    st.timing[0] += (unsigned long long)T; st.timing[6] += R.local ? 1ull : 0ull;
+    st.timing[7] += (unsigned long long)((long)wall_clock64() - t_entry);
+  }
+  if (st.trace && threadIdx.x == 0) {
+    unsigned long long *tr = st.trace + (st.epoch & 7u) * 2048u;
+    tr[2 * blockIdx.x] = (unsigned long long)t_entry; tr[2 * blockIdx.x + 1] = wall_clock64();
+  }
+  if (polls && lane == 0) __hip_atomic_fetch_add(st.abort_flag + 2, polls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // backward, partitioned by input like lstm_seq_bwd.  One instruction = the chain's 4 streams x 64 cells (column = lane); wave w covers
 // the cell spans w * NH + h, h < NH (C <= 256 * NH).
 //   inbox[ring slot][chain 16][consumer block][producer block][column 0..15] of f32x4 (the 4 streams)
@@ -1568,6 +1846,24 @@ SeqKernelB pick_bwd(bool cifg, int C) {
   return nullptr;
 }
 
+// wave-specialised forward (two half-chains alternating inside the workgroup): ASLP_LSTM_DUAL=1 (A/B switch, default off).  Measured on
+// cfg3 it is SLOWER than lstm_seq_fwd (3.21 / 3.40 ms per step against 3.10): a v_mfma_f32_4x4x1 is two passes, so a product wave takes
+// the SIMD's vector issue port every other slot and the gate wave beside it runs at half speed and vice versa -- product 0.8 us instead
+// of 0.5, gate block 0.97 instead of 0.5 -- and a half's path product -> gates -> publish -> L2 -> collect stays as long as before.
+bool dual_on() {
+  static const bool on = getenv("ASLP_LSTM_DUAL") != nullptr && getenv("ASLP_LSTM_DUAL")[0] == '1';
+  return on;
+}
+SeqKernel pick_fwd_dual(bool cifg, int C) {
+  if (fast_act()) {
+    if (C <= 128) return cifg ? lstm_seq_fwd_dual<true, 32, true> : lstm_seq_fwd_dual<false, 32, true>;
+    if (C <= 512) return cifg ? lstm_seq_fwd_dual<true, 128, true> : lstm_seq_fwd_dual<false, 128, true>;
+    return nullptr;
+  }
+  if (C <= 128) return cifg ? lstm_seq_fwd_dual<true, 32, false> : lstm_seq_fwd_dual<false, 32, false>;
+  if (C <= 512) return cifg ? lstm_seq_fwd_dual<true, 128, false> : lstm_seq_fwd_dual<false, 128, false>;
+  return nullptr;
+}
 SeqKernel pick_fwd4(bool cifg, int C) {
   if (fast_act()) {
     if (C <= 128) return cifg ? lstm_seq_fwd4<true, 32, true> : lstm_seq_fwd4<false, 32, true>;
@@ -1656,7 +1952,8 @@ int aslp_lstm_seq_supported(const aslp_lstm_seq *a, int backward) {
   const int ns = a->s_count > 0 ? a->s_count : a->S;   // streams of this launch
   const int nsg = (ns + kChainStreams - 1) / kChainStreams, wpc = (a->C + kCellsPerWg - 1) / kCellsPerWg;
   if (a->ndir * nsg > kMaxChains || wpc > kMaxWgPerChain) return 0;   // <= 32 streams per launch (bidirectional) / 64, C <= 512
-  const void *k = backward ? reinterpret_cast<const void *>(pick_bwd(a->cifg != 0, a->C)) : reinterpret_cast<const void *>(pick_fwd(a->cifg != 0, a->C));
+  const void *k = backward ? reinterpret_cast<const void *>(pick_bwd(a->cifg != 0, a->C))
+                           : reinterpret_cast<const void *>(dual_on() ? pick_fwd_dual(a->cifg != 0, a->C) : pick_fwd(a->cifg != 0, a->C));
   return grid_fits(k, 512, (long)kMaxChains * wpc) ? 1 : 0;
 }
 
@@ -1728,7 +2025,8 @@ static void launch_seq(const aslp_lstm_seq *a, bool backward, const char *who) {
     const int grid = (nchains > 8 ? 16 : 8) * wpc;
     if (!backward) hipLaunchKernelGGL(pick_fwd4(a->cifg != 0, a->C), dim3(grid), dim3(256), 0, cur_stream(), *a, st, rt.place);
     else hipLaunchKernelGGL(pick_bwd4(a->cifg != 0, a->C), dim3(grid), dim3(256), 0, cur_stream(), *a, st, rt.place, rt.inbox);
-  } else if (!backward) hipLaunchKernelGGL(pick_fwd(a->cifg != 0, a->C), dim3(kMaxChains * wpc), dim3(512), 0, cur_stream(), *a, st, rt.place);
+  } else if (!backward) hipLaunchKernelGGL(dual_on() ? pick_fwd_dual(a->cifg != 0, a->C) : pick_fwd(a->cifg != 0, a->C), dim3(kMaxChains * wpc), dim3(512), 0,
+                                           cur_stream(), *a, st, rt.place);
   else hipLaunchKernelGGL(pick_bwd(a->cifg != 0, a->C), dim3(kMaxChains * wpc), dim3(512), 0, cur_stream(), *a, st, rt.place, rt.inbox);
   if (!rt.last_done) (void)hipEventCreateWithFlags(&rt.last_done, hipEventDisableTiming);
   if (rt.last_done) { ASLP_CHECK_HIP(hipEventRecord(rt.last_done, cur_stream())); rt.last_stream = cur_stream(); }

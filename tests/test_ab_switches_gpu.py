@@ -65,5 +65,7 @@ def test_recurrent_ab_switches_agree(tmp_path):
     assert close(half, base)
     assert np.array_equal(half, run(tmp_path, "half_map0", ASLP_LSTM_HALF_CHAINS="1", ASLP_LSTM_HALF_MAP="0"))   # who shares a CU changes nothing
     assert np.array_equal(half, run(tmp_path, "half_delay0", ASLP_LSTM_HALF_CHAINS="1", ASLP_LSTM_HALF_DELAY_NS="0"))
+    dual = run(tmp_path, "dual", ASLP_LSTM_DUAL="1")               # wave-specialised forward: product waves / gate waves, two half-chains
+    assert close(dual, base)
     step = run(tmp_path, "per_timestep", ASLP_LSTM_PERSISTENT="0")
     assert close(step, base)
