@@ -37,3 +37,18 @@ for _ in range(STEPS):
 torch.cuda.synchronize()
 dt = (time.time() - t0) / STEPS
 print("cfg1 minibatch %d: %.3f ms/step, %.0f frames/s, %.1f TFLOP/s algorithmic" % (MB, dt * 1e3, MB / dt, MB / dt * 141131776 / 1e12))
+if os.environ.get("GEMM_PROFILE") == "1":
+    import ctypes as C
+    net.SetUpdateOverlap(False)
+    aslp.lib.aslp_gemm_profile(1)
+    aslp.lib.aslp_gemm_profile_reset()
+    for _ in range(20):
+        net.TrainStepXent(xent, x, lab)
+    torch.cuda.synchronize()
+    aslp.lib.aslp_gemm_profile(0)
+    aslp.lib.aslp_gemm_profile_dump()
+    for vi, name in enumerate(("NT", "NN", "TN", "TT")):
+        fl, ms = C.c_double(), C.c_double()
+        n = aslp.lib.aslp_gemm_profile_get(vi, C.byref(fl), C.byref(ms))
+        if n:
+            print("GEMM %s: %d launches/step, %.1f GF/step, %.3f ms/step, %.1f TFLOP/s" % (name, n / 20, fl.value / 20e9, ms.value / 20, fl.value / ms.value / 1e9))

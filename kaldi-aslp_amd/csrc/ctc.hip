@@ -61,6 +61,49 @@ __global__ void __launch_bounds__(256) ctc_softmax_kernel(const float *__restric
   for (int a = 0; a < A; a++) p[a] = p[a] / denom;
 }
 
+// The same arithmetic with coalesced memory traffic: a workgroup stages TR rows in LDS (pitch odd: a lane walking its row hits a bank
+// of its own), all threads take the element-wise parts (row maximum -- exact in any order --, exp(x - max), the division), and only
+// the denominator, whose float sum is sequential BY DEFINITION (cpu_ctc.h:171-174), is walked by one lane per row, 64 rows side by side
+// in a wave.  The lane-per-row kernel above read its row with a stride of A floats per lane: 0.33 TB/s on 25,600 x 128.
+__global__ void __launch_bounds__(256) ctc_softmax_tile_kernel(const float *__restrict__ acts, int ld, float *__restrict__ probs, int rows, int A,
+                                                               int TR, int pitch) {
+  extern __shared__ float tile[];          // [TR][pitch] values, then [TR] row maxima / denominators
+  float *rowv = tile + TR * pitch;
+  const int r0 = blockIdx.x * TR, nr = min(TR, rows - r0), n = nr * A;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int r = i / A, a = i - r * A;
+    tile[r * pitch + a] = acts[(long)(r0 + r) * ld + a];
+  }
+  __syncthreads();
+  // row maxima: 4 threads per row (any order gives the same maximum)
+  {
+    const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
+    float mx = -INFINITY;
+    if (r < nr)
+      for (int a = q; a < A; a += 4) mx = fmaxf(mx, tile[r * pitch + a]);
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+    if (r < nr && q == 0) rowv[r] = mx;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int r = i / A, a = i - r * A;
+    tile[r * pitch + a] = expf_cr(tile[r * pitch + a] - rowv[r]);
+  }
+  __syncthreads();
+  if (threadIdx.x < nr) {   // the denominator: float additions in index order
+    const float *e = tile + threadIdx.x * pitch;
+    float denom = 0.0f;
+    for (int a = 0; a < A; a++) denom += e[a];
+    rowv[threadIdx.x] = denom;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int r = i / A, a = i - r * A;
+    probs[(long)(r0 + r) * A + a] = tile[r * pitch + a] / rowv[r];
+  }
+}
+
 struct UttInfo {
   int T, L, S, repeats, feasible;
   int lab_off;   // offset of this utterance's S entries in labels_w_blanks / next_same / first_of_label
@@ -399,7 +442,17 @@ static ctcStatus_t ctc_loss_impl(const float *const activations, int ld_acts, fl
     probs = const_cast<float *>(activations);
     ldp = ld_acts;
   } else if (maxT > 0) {
-    hipLaunchKernelGGL(ctc_softmax_kernel, dim3((d.rows + 255) / 256), dim3(256), 0, stream, activations, ld_acts, probs, d.rows, A);
+    {
+      const int pitch = A | 1;
+      int TR = (40 * 1024 / 4 - 64) / pitch;   // rows of a 40 KB tile
+      TR = TR > 64 ? 64 : TR;
+      static const bool old_kernel = getenv("ASLP_CTC_SOFTMAX_TILED") != nullptr && getenv("ASLP_CTC_SOFTMAX_TILED")[0] == '0';   // A/B switch
+      if (TR >= 1 && !old_kernel)
+        hipLaunchKernelGGL(ctc_softmax_tile_kernel, dim3((d.rows + TR - 1) / TR), dim3(256), sizeof(float) * (size_t)(TR * pitch + TR), stream, activations, ld_acts,
+                           probs, d.rows, A, TR, pitch);
+      else
+        hipLaunchKernelGGL(ctc_softmax_kernel, dim3((d.rows + 255) / 256), dim3(256), 0, stream, activations, ld_acts, probs, d.rows, A);
+    }
   }
   set_cur_stream(saved);
 

@@ -317,7 +317,8 @@ bool launch_cfg(GemmArgs &g, int cfg) {
 }  // namespace
 
 // Second half of a split-K product: C = epilogue(alpha * sum_s partial[s] + beta * C), partials added in chunk order.
-// Covers what the split path accepts: alpha / beta, the element-wise clip and the fused SGD step on W.
+// Covers what the split path accepts: alpha / beta, bias, the element-wise clip, the fused SGD step on W and the second (activation)
+// output -- per element the scalar epilogue's arithmetic (gemm_common.h), on the chunk-ordered sum instead of one accumulator.
 __global__ void __launch_bounds__(kBlock) splitk_reduce_kernel(const float *__restrict__ part, int split, long stride, GemmArgs g) {
   if (g.pair && blockIdx.y == 1) {  // the second product's partials follow the first's
     part += (long)split * stride;
@@ -331,10 +332,13 @@ __global__ void __launch_bounds__(kBlock) splitk_reduce_kernel(const float *__re
     float *cp = g.C + (long)row * g.ldc + col;
     const float c_old = g.beta != 0.0f ? (g.ep.c_src ? g.ep.c_src[(long)row * g.ep.ld_c_src + col] : *cp) : 0.0f;
     const float w_old = g.ep.W ? g.ep.W[(long)row * g.ep.ldw + col] : 0.0f;
-    float v = fmaf(g.alpha, acc, g.beta * c_old);  // = fmaf(alpha, acc, fmaf(beta, c_old, 0)): the epilogue's spelling (gemm_common.h)
+    const float bias = g.ep.bias ? g.ep.bias[col] : 0.0f;
+    float v = fmaf(g.alpha, acc, fmaf(g.beta, c_old, bias));  // the epilogue's spelling (gemm_common.h)
     if (g.ep.clip > 0.0f) v = fminf(fmaxf(v, -g.ep.clip), g.ep.clip);
     *cp = v;
     if (g.ep.W) g.ep.W[(long)row * g.ep.ldw + col] = fmaf(g.ep.w_alpha, v, w_old);
+    if (g.ep.act_out)
+      g.ep.act_out[(long)row * g.ep.ld_act + col] = g.ep.act == 1 ? sigmoid_ref(v) : g.ep.act == 2 ? tanh_ref(v) : g.ep.act == 3 ? fmaxf(v, 0.0f) : v;
   }
 }
 
@@ -346,8 +350,8 @@ int pick_split_k(const GemmArgs &g, int bm, int bn) {
   static const int forced = [] { const char *e = getenv("ASLP_GEMM_SPLITK"); return e ? atoi(e) : -1; }();
   if (forced == 0) return 0;
   const aslp_gemm_epilogue &ep = g.ep;
-  if (ep.bias || ep.act_out || ep.colsum || ep.colstats || g.K < 1024) return 0;
-  if (g.pair && (g.ep1.bias || g.ep1.act_out || g.ep1.colsum)) return 0;
+  if (ep.colsum || ep.colstats || g.K < 1024) return 0;
+  if (g.pair && (g.ep1.colsum || g.ep1.colstats)) return 0;
   const long tiles = (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * (g.pair ? 2 : 1);
   static const int slots = [] { const char *e = getenv("ASLP_GEMM_SPLITK_SLOTS"); return e ? atoi(e) : 256; }();
   int split = (int)(slots / tiles);
