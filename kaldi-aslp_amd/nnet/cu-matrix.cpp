@@ -50,6 +50,10 @@ void *DeviceAlloc(size_t bytes) {
     }
   }
   g_live[p] = sz;
+  // debugging aid: ASLP_ALLOC_POISON=1 hands every block out filled with 0xFF bytes (a NaN in every float), so that a kernel which reads
+  // memory nobody wrote shows in a fresh process and not only when the allocator happens to recycle a dirty block
+  static const bool poison = getenv("ASLP_ALLOC_POISON") != nullptr && getenv("ASLP_ALLOC_POISON")[0] == '1';
+  if (poison) CheckHip(hipMemsetAsync(p, 0xFF, sz, cur_stream()), "hipMemset (poison)");
   return p;
 }
 void DeviceFree(void *p) {
