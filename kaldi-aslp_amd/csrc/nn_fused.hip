@@ -868,6 +868,128 @@ __global__ void __launch_bounds__(256) xent_rows_kernel(const float *y, int ldy,
   }
 }
 
+// The same arithmetic with ONE WAVE per row and no workgroup barrier: lane l plays the four threads l, l + 64, l + 128, l + 192 of the
+// kernel above (the same columns tid + 256 k each, the same per-thread partial results), reduces each of the four "waves" with the same
+// butterfly and combines the four results in the same order -- bit for bit the kernel above, but a row no longer pays six barriers and
+// four waves' worth of latency for 12 KB of data.  Four rows per workgroup.  (Measured: not faster, see the launch code; ASLP_XENT_WAVE=1.)
+template <bool DENSE, bool SOFTMAX, int PER>
+__global__ void __launch_bounds__(256) xent_rows_wave_kernel(const float *y, int ldy, const float *t, int ldt, const int32_t *labels, const float *fw,
+                                                             float *diff, int ldd, int rows, int cols, double *rowstats, float *y_out, int ldyo) {
+  const int lane = threadIdx.x & 63;
+  for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += gridDim.x * 4) {
+    const float *yr = y + (long)r * ldy;
+    const float *tr = DENSE ? t + (long)r * ldt : nullptr;
+    const int label = DENSE ? -1 : labels[r];
+    float yv[4][PER];
+#pragma unroll
+    for (int w = 0; w < 4; w++)
+#pragma unroll
+      for (int k = 0; k < PER; k++) {
+        const int c = 64 * w + lane + k * 256;
+        yv[w][k] = c < cols ? yr[c] : 0.0f;
+      }
+    if (SOFTMAX) {
+      float m = -INFINITY;
+#pragma unroll
+      for (int w = 0; w < 4; w++)
+#pragma unroll
+        for (int k = 0; k < PER; k++)
+          if (64 * w + lane + k * 256 < cols) m = fmaxf(m, yv[w][k]);
+      m = wave_max(m);   // (a maximum does not depend on the order)
+      float sw[4];
+#pragma unroll
+      for (int w = 0; w < 4; w++) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < PER; k++)
+          if (64 * w + lane + k * 256 < cols) {
+            yv[w][k] = expf(yv[w][k] - m);
+            sum += yv[w][k];
+          }
+        sw[w] = wave_sum(sum);
+      }
+      float sum = sw[0];
+      sum += sw[1]; sum += sw[2]; sum += sw[3];
+      const float inv = 1.0f / sum;
+#pragma unroll
+      for (int w = 0; w < 4; w++)
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+          const int c = 64 * w + lane + k * 256;
+          if (c < cols) {
+            yv[w][k] *= inv;
+            if (y_out) y_out[(long)r * ldyo + c] = yv[w][k];
+          }
+        }
+    }
+    float tsw[4], ybw[4], tbw[4];
+    int yiw[4], tiw[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      float tsum = 0.0f, ybest = -1e21f, tbest = -1e21f;
+      int yi = -1, ti = -1;
+#pragma unroll
+      for (int k = 0; k < PER; k++) {
+        const int c = 64 * w + lane + k * 256;
+        if (c < cols) {
+          const float tt = DENSE ? tr[c] : (c == label ? 1.0f : 0.0f);
+          tsum += tt;
+          if (ybest < yv[w][k]) { ybest = yv[w][k]; yi = c; }
+          if (tbest < tt) { tbest = tt; ti = c; }
+        }
+      }
+      tsum = wave_sum(tsum);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        float ov = __shfl_xor(ybest, o, 64); int oi = __shfl_xor(yi, o, 64);
+        if (ov > ybest || (ov == ybest && oi >= 0 && (yi < 0 || oi < yi))) { ybest = ov; yi = oi; }
+        ov = __shfl_xor(tbest, o, 64); oi = __shfl_xor(ti, o, 64);
+        if (ov > tbest || (ov == tbest && oi >= 0 && (ti < 0 || oi < ti))) { tbest = ov; ti = oi; }
+      }
+      // (what lane 0 of that wave held: the butterfly leaves the same value in every lane for the sum; for the arg-max the workgroup kernel
+      //  takes lane 0's)
+      tsw[w] = tsum;
+      ybw[w] = __shfl(ybest, 0, 64); yiw[w] = __shfl(yi, 0, 64); tbw[w] = __shfl(tbest, 0, 64); tiw[w] = __shfl(ti, 0, 64);
+    }
+    const float tsum = tsw[0] + tsw[1] + tsw[2] + tsw[3];
+    float ybest = ybw[0], tbest = tbw[0];
+    int yi = yiw[0], ti = tiw[0];
+#pragma unroll
+    for (int j = 1; j < 4; j++) {
+      if (ybw[j] > ybest || (ybw[j] == ybest && yiw[j] >= 0 && (yi < 0 || yiw[j] < yi))) { ybest = ybw[j]; yi = yiw[j]; }
+      if (tbw[j] > tbest || (tbw[j] == tbest && tiw[j] >= 0 && (ti < 0 || tiw[j] < ti))) { tbest = tbw[j]; ti = tiw[j]; }
+    }
+    const float wr = fw[r] * tsum;
+    double xw[4], ew[4], lw[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      double xe = 0.0, en = 0.0, lk = 0.0;
+#pragma unroll
+      for (int k = 0; k < PER; k++) {
+        const int c = 64 * w + lane + k * 256;
+        if (c < cols) {
+          const float yy = yv[w][k], tt = DENSE ? tr[c] : (c == label ? 1.0f : 0.0f);
+          diff[(long)r * ldd + c] = (yy - tt) * wr;
+          if (tt != 0.0f) {
+            xe += (double)(logf(yy + 1e-20f) * tt * wr);
+            en += (double)(logf(tt + 1e-20f) * tt * wr);
+            lk += (double)(yy * tt * wr);
+          }
+        }
+      }
+      xw[w] = wave_sum_d(xe); ew[w] = wave_sum_d(en); lw[w] = wave_sum_d(lk);
+    }
+    if (lane == 0) {
+      double *rs = rowstats + (long)r * 5;
+      rs[0] = (double)wr;
+      rs[1] = (double)wr * (yi == ti ? 1.0 : 0.0);
+      rs[2] = xw[0] + xw[1] + xw[2] + xw[3];
+      rs[3] = ew[0] + ew[1] + ew[2] + ew[3];
+      rs[4] = lw[0] + lw[1] + lw[2] + lw[3];
+    }
+  }
+}
+
 // The same for rows of any width (more than 256 * kXentPerThread classes): nothing is cached in registers, the row is streamed twice
 // (targets: sum and both arg-maxes; then diff and the three sums).  Every thread visits the columns tid, tid + 256, ... in the same
 // order and the reductions are those of the kernel above, so the result does not depend on which of the two kernels served a row.
@@ -1149,12 +1271,24 @@ static void xent_eval_impl(const float *net_out, MatrixDim d, const float *tgt, 
   // elements cached per thread: the smallest of 4 / 8 / 16 / 32 that covers the row (the loops are fully unrolled: a row of
   // 3000 classes runs 16 slots per thread instead of 32 predicated ones)
   const int per = (d.cols + 255) / 256;
+  // enough rows for a wave each to fill the chip: the barrier-free kernel (4 rows per workgroup; same bits, see above)
+  // A/B switch, default off: measured on cfg2 (1024 x 3000, Softmax folded in) the barrier-free kernel is 1 % SLOWER on the step (776 / 777 k
+  // against 782 / 785 k frames/s, two alternations): a lane now walks 47 exponentials in a row where the workgroup kernel's thread walks 12
+  static const bool wave_on = getenv("ASLP_XENT_WAVE") != nullptr && getenv("ASLP_XENT_WAVE")[0] == '1';
+  const bool wave_rows = wave_on && d.rows >= 512 && per <= 16;
+  const int gw = (d.rows + 3) / 4;
+#define XENT_LAUNCH_W(DENSE, SM, P)                                                                                                         \
+  hipLaunchKernelGGL((xent_rows_wave_kernel<DENSE, SM, P>), dim3(gw), dim3(256), 0, cur_stream(), net_out, d.stride, tgt, tgt_stride, labels, \
+                     frame_weights, diff, diff_stride, d.rows, d.cols, rowstats, y_out, y_stride)
 #define XENT_LAUNCH_P(DENSE, SM, P)                                                                                                       \
   hipLaunchKernelGGL((xent_rows_kernel<DENSE, SM, P>), dim3(g), dim3(256), 0, cur_stream(), net_out, d.stride, tgt, tgt_stride, labels, \
                      frame_weights, diff, diff_stride, d.rows, d.cols, rowstats, y_out, y_stride)
 #define XENT_LAUNCH(DENSE, SM)                                        \
   do {                                                                \
-    if (per <= 4) XENT_LAUNCH_P(DENSE, SM, 4);                        \
+    if (wave_rows && per <= 4) XENT_LAUNCH_W(DENSE, SM, 4);           \
+    else if (wave_rows && per <= 8) XENT_LAUNCH_W(DENSE, SM, 8);      \
+    else if (wave_rows) XENT_LAUNCH_W(DENSE, SM, 16);                 \
+    else if (per <= 4) XENT_LAUNCH_P(DENSE, SM, 4);                   \
     else if (per <= 8) XENT_LAUNCH_P(DENSE, SM, 8);                   \
     else if (per <= 16) XENT_LAUNCH_P(DENSE, SM, 16);                 \
     else XENT_LAUNCH_P(DENSE, SM, 32);                                \
@@ -1163,6 +1297,7 @@ static void xent_eval_impl(const float *net_out, MatrixDim d, const float *tgt, 
   else { if (softmax) XENT_LAUNCH(false, true); else XENT_LAUNCH(false, false); }
 #undef XENT_LAUNCH
 #undef XENT_LAUNCH_P
+#undef XENT_LAUNCH_W
   hipLaunchKernelGGL(xent_finalize_kernel, dim3(1), dim3(256), 0, cur_stream(), rowstats, d.rows, stats_dev);
   check_launch("xent_eval");
 }
