@@ -498,6 +498,10 @@ def main():
         return
 
     import torch
+    if os.environ.get("ASLP_COMM_TRANSPORT") == "shm":
+        # ranks as separate processes that may SHARE GPUs (parallel/comm.cpp ShmComm): lets `bench.py --gpus N` exercise the whole N > 1 flow --
+        # launcher, rendezvous, BSP sync, max-over-ranks timing, the cfg3_bsp block -- on a one-GPU box.  Not a scaling measurement.
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # ASLP_BENCH_FORCE_SYNC=1 exercises the sync path on a single GPU as well (RCCL all-reduce over a group of one)
@@ -518,7 +522,7 @@ def main():
             import tempfile
             token = "%s-%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid())
             comm_file = os.path.join(tempfile.gettempdir(), "aslp_bench_comm_" + token)
-        comm = native_parallel.RcclComm(comm_file, rank=rank, num_nodes=world, token=token, timeout_s=900)
+        comm = native_parallel.ProcessComm(comm_file, rank=rank, num_nodes=world, token=token, timeout_s=900)   # RcclComm unless ASLP_COMM_TRANSPORT=shm
 
     import aslp_import
     aslp = aslp_import.load()   # raises if libaslp_hip.so is missing (no fallback)
@@ -626,7 +630,10 @@ def main():
             "config": {"workload": "cfg2: 5x2048 sigmoid DNN + BatchNorm, 440 in (40 fbank x 11 splice), 3000 pdfs, minibatch 1024/GPU, "
                                    "Propagate + Xent + Backpropagate + SGD update",
                        "global_batch": world * MB, "parallelism": "bsp-dp%d" % world,
-                       "sync": "native BspWorker on RcclComm (libaslp_parallel.so: ncclAllReduce over the parameter tensors in HBM)" if comm is not None else None, "sync_period_frames": args.sync_period,
+                       "sync": ("native BspWorker on ShmComm (ranks sharing GPUs, tensors staged through shared memory: a functional run, not a scaling measurement)"
+                                if os.environ.get("ASLP_COMM_TRANSPORT") == "shm" else
+                                "native BspWorker on RcclComm (libaslp_parallel.so: ncclAllReduce over the parameter tensors in HBM)") if comm is not None else None,
+                       "sync_period_frames": args.sync_period,
                        "learn_rate": 1e-5, "avg_xent_per_frame": (st["loss"] - st["entropy"]) / max(st["frames"], 1.0)},
         }
         timed = {k: v for k, v in gemm.items() if v["tflops"]}

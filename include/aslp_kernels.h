@@ -370,6 +370,11 @@ typedef struct aslp_lstm_seq_ {
   int s_begin, s_count;
 } aslp_lstm_seq;
 int aslp_lstm_seq_supported(const aslp_lstm_seq *a, int backward);
+/* Several processes on ONE GPU (ShmComm ranks, or two jobs given the same device): on != 0 makes every persistent LSTM / GRU launch hold a
+ * per-device cross-process lock until its kernel has completed, so that two grids which each need the whole device are never half resident
+ * beside each other (they would wait for each other's unscheduled workgroups until the spin limit).  Same as ASLP_DEVICE_SHARED=1.  Default off.
+ * No reference counterpart: the reference's per-timestep kernels need no co-residency. */
+void aslp_device_shared(int on);
 int aslp_lstm_seq_first_product_supported(int k_first);
 int aslp_lstm_seq_first_product_supported_for(int k_first, int C);   /* ... in a layer of C cells (the staging row is 128 floats for C <= 128) */
 /* Streams per chain the launch for these arguments uses: 8 (one 512-thread workgroup per CU) or 4 (half chains: two 256-thread workgroups

@@ -32,7 +32,13 @@
 // the host reports the failure through aslp_get_last_error -- a wrong result is never silent and the GPU never hangs.
 // The grid must be co-resident: aslp_lstm_seq_supported() checks it against the occupancy of the kernel with a margin
 // of one workgroup per CU, otherwise the caller keeps the one-launch-per-timestep path.
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
+
+#include <cerrno>
 #include <mutex>
+#include <string>
 #include <utility>
 #include <vector>
 
@@ -1800,6 +1806,50 @@ struct SeqRuntime {
   bool ok = false;
   std::mutex launch_mu;   // one persistent launch (LSTM or GRU) is issued at a time: epoch, event chaining, abort word, placement table, ring
 };
+// Several PROCESSES on one GPU (ranks of parallel/comm.cpp's ShmComm, or two training jobs given the same device): each one's persistent
+// grid is sized to be resident at once on an otherwise free device, and two of them half resident beside each other wait for workgroups
+// that cannot be scheduled until the 2 s spin limit ends both.  With ASLP_DEVICE_SHARED=1 (or aslp_device_shared(1)) a persistent launch
+// therefore holds a per-device file lock (flock on /dev/shm/aslp_seq_gate.<uid>.<pci bus id>) from before the launch until the kernel
+// has completed -- one host-side stream synchronise per launch, the price of sharing.  Off by default: one process per GPU needs none of it.
+struct DeviceGate {
+  int fd = -1;
+  bool on = false;
+  std::once_flag once;
+  void open_once() {
+    std::call_once(once, [this] {
+      int dev = 0;
+      char bus[64] = "dev";
+      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetPCIBusId(bus, sizeof(bus), dev);
+      for (char *c = bus; *c; c++) if (*c == ':' || *c == '/' || *c == '.') *c = '_';
+      const std::string path = "/dev/shm/aslp_seq_gate." + std::to_string((long)getuid()) + "." + bus;
+      fd = ::open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0600);
+    });
+  }
+};
+DeviceGate &device_gate() {
+  static DeviceGate g;
+  static std::once_flag env_once;
+  std::call_once(env_once, [] { const char *e = getenv("ASLP_DEVICE_SHARED"); g.on = e != nullptr && e[0] == '1'; });
+  return g;
+}
+// RAII around one persistent launch: lock -> (launch) -> wait for the kernel -> unlock.  A no-op unless the device is declared shared.
+struct SharedDeviceLaunch {
+  bool held = false;
+  SharedDeviceLaunch() {
+    DeviceGate &g = device_gate();
+    if (!g.on) return;
+    g.open_once();
+    if (g.fd < 0) return;
+    while (flock(g.fd, LOCK_EX) != 0 && errno == EINTR) {}
+    held = true;
+  }
+  ~SharedDeviceLaunch() {
+    if (!held) return;
+    (void)hipStreamSynchronize(cur_stream());
+    (void)flock(device_gate().fd, LOCK_UN);
+  }
+};
+
 SeqRuntime &seq_runtime() {
   static SeqRuntime rt;
   static std::once_flag once;
@@ -1818,7 +1868,7 @@ SeqRuntime &seq_runtime() {
     *rt.host_err = 0;
     if (hipHostGetDevicePointer(reinterpret_cast<void **>(&rt.host_err_dev), rt.host_err, 0) != hipSuccess) return;
     register_async_error_word(rt.host_err, "persistent LSTM recurrence: a workgroup timed out waiting for another workgroup's hand-off "
-                                           "(results of that call are invalid)");
+                                           "(results of that call are invalid; if several processes share this GPU set ASLP_DEVICE_SHARED=1)");
     rt.ok = true;
   });
   return rt;
@@ -1957,6 +2007,8 @@ int aslp_lstm_seq_supported(const aslp_lstm_seq *a, int backward) {
   return grid_fits(k, 512, (long)kMaxChains * wpc) ? 1 : 0;
 }
 
+void aslp_device_shared(int on) { device_gate().on = on != 0; }
+
 int aslp_lstm_seq_first_product_supported(int k_first) { return k_first > 0 && k_first <= kFirstK && (k_first & 3) == 0; }
 // ... for a layer of C cells: the kernels stage r(0) in LDS rows as long as the K range of their instantiation (128 floats for C <= 128, else 512)
 int aslp_lstm_seq_first_product_supported_for(int k_first, int C) {
@@ -2000,6 +2052,7 @@ static void launch_seq(const aslp_lstm_seq *a, bool backward, const char *who) {
   // grids that both need every CU must not be half resident beside each other.  Launches from different host threads / streams
   // are therefore chained by an event (no host wait); the common single-stream case costs one event record per launch.
   std::lock_guard<std::mutex> launch_lock(rt.launch_mu);
+  SharedDeviceLaunch shared_device;   // ASLP_DEVICE_SHARED=1 only: cross-process lock held until this kernel has completed
   if (rt.last_done && rt.last_stream != cur_stream()) ASLP_CHECK_HIP(hipStreamWaitEvent(cur_stream(), rt.last_done, 0));
   // Device-side state is self-cleaning: the placement table is epoch-tagged and every share a backward launch publishes is
   // consumed and reset inside that launch.  Only after a launch that gave up (the mapped error word moved) are the abort
@@ -2051,6 +2104,7 @@ static void launch_gru(const aslp_gru_seq *a, bool backward, const char *who) {
   }
   SeqRuntime &rt = seq_runtime();
   std::lock_guard<std::mutex> launch_lock(rt.launch_mu);   // as launch_seq (the same lock: LSTM and GRU launches share the runtime state)
+  SharedDeviceLaunch shared_device;
   if (rt.last_done && rt.last_stream != cur_stream()) ASLP_CHECK_HIP(hipStreamWaitEvent(cur_stream(), rt.last_done, 0));
   if (*rt.host_err != rt.err_seen) {
     rt.err_seen = *rt.host_err;

@@ -290,6 +290,9 @@ class ShmComm : public FileRendezvousComm {
   ShmComm(int rank, int n, const std::string &id_file, int timeout_s, const std::string &token_arg)
       : FileRendezvousComm(rank, n), base_(nullptr), bytes_(0), hdr_(nullptr), timeout_s_(timeout_s > 0 ? timeout_s : 900) {
     if (n > kMaxRanks) ASLP_ERR << "ShmComm: at most " << kMaxRanks << " ranks";
+    // ranks of this transport may share a GPU: the persistent LSTM / GRU launches of libaslp_hip then take a cross-process device lock
+    // (include/aslp_kernels.h aslp_device_shared; read from the environment at the first such launch).  An explicit setting wins.
+    if (n > 1) (void)setenv("ASLP_DEVICE_SHARED", "1", 0);
     static_assert(std::atomic<int>::is_always_lock_free && std::atomic<long>::is_always_lock_free, "address-free atomics needed in shared memory");
     const size_t slot_mb = getenv("ASLP_SHM_SLOT_MB") ? (size_t)atol(getenv("ASLP_SHM_SLOT_MB")) : 16;
     slot_bytes_ = (slot_mb < 1 ? 1 : slot_mb) << 20;

@@ -1,0 +1,46 @@
+"""bench.py's N > 1 flow end to end on ONE GPU: with ASLP_COMM_TRANSPORT=shm the ranks are separate processes sharing the device
+(parallel/comm.cpp ShmComm), so the launcher / rendezvous / BSP sync / max-over-ranks timing / cfg3_bsp block / exit status that the
+driver's 2-, 4-, 8-GPU runs go through are exercised where only one GPU exists.  Both launch forms: bench.py's own launcher and
+`python -m torch.distributed.run` (the driver's command line)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLEAN = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "ASLP_COMM_FILE", "ASLP_COMM_TOKEN", "MASTER_ADDR", "MASTER_PORT")
+
+
+def check_line(out, n):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == n and d["steps"] == 6 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["metric"] == "frames/sec (aslp-nnet-train)" and d["unit"] == "frames/sec"
+    assert "ShmComm" in d["config"]["sync"] and d["config"]["parallelism"] == "bsp-dp%d" % n
+    assert d["value"] == pytest.approx(d["config"]["global_batch"] * 1000.0 / d["ms_per_step"], rel=1e-3)   # whole-job frames over the max-over-ranks time
+    bsp = d.get("cfg3_bsp")
+    assert bsp and bsp["n_gpus"] == n and bsp["valid_frames_per_sec"] > 0
+    return d
+
+
+def test_bench_two_ranks_own_launcher():
+    env = {k: v for k, v in os.environ.items() if k not in CLEAN}
+    env["ASLP_COMM_TRANSPORT"] = "shm"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, "\n".join(l for l in p.stderr.decode().splitlines() if "ResetLstmStreams" not in l)[-4000:]
+    check_line(p.stdout.decode(), 2)
+
+
+def test_bench_two_ranks_under_torch_distributed_run():
+    env = {k: v for k, v in os.environ.items() if k not in CLEAN}
+    env["ASLP_COMM_TRANSPORT"] = "shm"
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29731", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, "\n".join(l for l in p.stderr.decode().splitlines() if "ResetLstmStreams" not in l)[-4000:]
+    check_line(p.stdout.decode(), 2)
