@@ -128,6 +128,9 @@ __device__ __forceinline__ bool spin_ok(unsigned spins, long &t0, const SeqStatu
   return false;
 }
 
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 // C/D layout of v_mfma_f32_16x16x4_f32: element e of lane l is row 4 * (l >> 4) + e, column l & 15
 constexpr int kTP = 17;  // LDS pitch of a 16 x 16 partial tile
 __device__ __forceinline__ void store_tile16(float *tile, const f32x4 &acc, int lane) {
@@ -470,6 +473,333 @@ __global__ void __launch_bounds__(512) lstm_seq_fwd(aslp_lstm_seq a, SeqStatus s
   if (polls && lane == 0) __hip_atomic_fetch_add(st.abort_flag + 2, polls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // diagnostics, once per wave
 }
 
+// ---- forward, product on fp16 matrix instructions with fp32-equivalent operands ---------------------------------------------------
+// Same chains, hand-off, gate block and buffers as lstm_seq_fwd; only the recurrent product m(t-1) W^T differs.  The fp32 instruction
+// (v_mfma_f32_4x4x1: 256 FLOP / clk / CU) makes that product the longest phase of a timestep (8 streams x 64 gate columns x K = 512 per
+// workgroup = 2048 clk, 0.85 us of ~2.35); v_mfma_f32_16x16x32_f16 runs 16 x that rate.  Each fp32 operand is therefore carried as TWO
+// fp16 pieces (x = x_hi + 2^-11 x_lo', 22-23 significant bits; weights after a per-column power-of-two scale, so any magnitude is safe):
+// the A tile's rows 0..7 are m_hi of the chain's 8 streams and rows 8..15 m_lo' of the same streams -- the instruction's 16 rows are all
+// used -- and two instructions per chunk (B = w_hi, w_lo') form all four partial products, every one exact in the multiplier and
+// accumulated in fp32.  Measured against a double product the result is CLOSER than an fp32 fma chain (devtools/micro/f16_split.hip:
+// 3-5e-8 of sum |m w| against 0.9-2e-7).  Wave w multiplies its own K slice (as collected) for all gate tiles; the two row halves are
+// joined with v_permlane32_swap and the 8 waves' partial sums go through the same LDS reduction as before.
+// Step 0 with a W_first operand keeps the fp32 instructions (once per launch, operands from LDS).  A/B switch: ASLP_LSTM_SPLIT_F16.
+template <bool CIFG, int NCH, bool FAST>
+__global__ void __launch_bounds__(512) lstm_seq_fwd_h(aslp_lstm_seq a, SeqStatus st, unsigned *place) {
+  constexpr int KW = 32 * NCH;   // K values per wave: NCH chunks of the instruction's 32
+  constexpr int G = CIFG ? 3 : 4, KMAX = 8 * KW, MP = KMAX + 4, RP = 80;  // RP = 16 mod 32: the epilogue's reads hit 32 distinct banks
+  constexpr int AP = KW + 8;     // halves per operand row: 16-byte reads of 16 rows x 4 k-groups then spread over the banks
+  __shared__ __attribute__((aligned(16))) _Float16 a_h[8][16][AP];   // per wave: rows 0..7 = m_hi of stream r, rows 8..15 = m_lo' of stream r - 8, its K slice
+  __shared__ __attribute__((aligned(16))) float m_lds[kChainStreams][MP];
+  __shared__ __attribute__((aligned(16))) float wf_lds[64][kFirstK + 4];   // this workgroup's 64 rows of W_first (first step only, see w_first)
+  __shared__ float red[2][8][kChainStreams][RP];
+  __shared__ int fail[2][8];
+  __shared__ int place_flag;
+  __shared__ __attribute__((aligned(16))) float zero_lds[4];
+  const long t_entry = (st.timing || st.trace) ? (long)wall_clock64() : 0;
+  const int SE = a.s_count > 0 ? a.s_begin + a.s_count : a.S;   // this launch's streams: [a.s_begin, SE)
+  if (threadIdx.x < 4) zero_lds[threadIdx.x] = 0.f;   // (chain_role's barrier publishes it)
+  const ChainRole R = chain_role(SE - a.s_begin, a.ndir, a.C, st, place, &place_flag);
+  if (!R.active) return;
+  const aslp_lstm_seq_dir D = a.dir[R.dir];
+  const int C = a.C, S = a.S, T = a.T, ld = a.ld;
+  const int GC = G * C, oc = GC, oh = GC + C, om = GC + 2 * C;
+  const int c0 = R.c0, s0 = a.s_begin + R.s0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int qs = (lane >> 2) & 1, qc = lane >> 3, jl = lane & 3;
+  const int kw = ((C + 31) / 32) * 4, kb = wave * kw;  // this wave's K range [kb, kb + kw), a multiple of 4 long
+  // B fragments, resident for the launch: tile = gate, column l & 15 = cell c0 + (l & 15); lane l holds k = kb + 32 j + 8 (l >> 4) + 0..7 of
+  // chunk j.  Each weight is carried as two fp16 pieces of w * sc (sc = the column's power of two that puts max |w| in [2^13, 2^14)):
+  // w_hi = fp16(w sc), w_lo = fp16(w sc - w_hi) -- 22 significant bits for every weight down to 2^-17 of its column's largest, no
+  // overflow whatever the weights' size; both pieces accumulate into ONE result tile (A w_hi + A w_lo = A w).
+  const int hr = lane & 15, hg = lane >> 4;
+  half8 bh[4][NCH], bl[4][NCH];
+  float inv_sc[4];
+  {
+    float wv[4][NCH][8];
+    float *cm = &red[0][0][0][0];   // scratch before the first timestep: [wave][tile][lane]
+#pragma unroll
+    for (int tile = 0; tile < 4; tile++) {
+      const int cellb = c0 + hr;
+      const bool nvalid = tile < G && cellb < C;
+      const float *brow = D.w + (long)(nvalid ? tile * C + cellb : 0) * a.ldw;
+      float lmax = 0.f;
+#pragma unroll
+      for (int j = 0; j < NCH; j++) {
+        const int kl = 32 * j + 8 * hg, k0 = kb + kl;   // kw and C are multiples of 4: a piece of four is inside or outside as a whole
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+          const bool in = nvalid && kl + 4 * q < kw && k0 + 4 * q < C;
+          const f32x4 w4 = in ? *reinterpret_cast<const f32x4 *>(brow + k0 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+          wv[tile][j][4 * q + 0] = w4.x; wv[tile][j][4 * q + 1] = w4.y; wv[tile][j][4 * q + 2] = w4.z; wv[tile][j][4 * q + 3] = w4.w;
+          lmax = fmaxf(lmax, fmaxf(fmaxf(fabsf(w4.x), fabsf(w4.y)), fmaxf(fabsf(w4.z), fabsf(w4.w))));
+        }
+      }
+      cm[(wave * 4 + tile) * 64 + lane] = lmax;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tile = 0; tile < 4; tile++) {
+      float cmax = 0.f;
+      for (int w = 0; w < 8; w++)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) cmax = fmaxf(cmax, cm[(w * 4 + tile) * 64 + 16 * g4 + hr]);
+      int e = 0;
+      (void)frexpf(cmax, &e);   // cmax = f 2^e, f in [0.5, 1)
+      const bool scaled = cmax > 0.f && cmax < 3.0e38f;
+      const float sc = scaled ? ldexpf(1.f, 14 - e) : 1.f;
+      inv_sc[tile] = scaled ? ldexpf(1.f, e - 14) : 1.f;
+#pragma unroll
+      for (int j = 0; j < NCH; j++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const float x = wv[tile][j][i] * sc;
+          const _Float16 xh = (_Float16)x;
+          bh[tile][j][i] = xh;
+          bl[tile][j][i] = (_Float16)(x - (float)xh);   // the residual as it is (<= 8 for the column's largest weight; a subnormal one is < 2^-39 of it)
+        }
+    }
+    __syncthreads();   // the scratch is the reduction buffer of the timesteps
+  }
+  // W_first rows of this workgroup's 64 gate columns -> LDS (zero where the column or k does not exist); read at step 0 only
+  const bool first_in_kernel = D.w_first != nullptr && D.k_first > 0 && D.k_first <= kFirstK && D.k_first <= KMAX;   // r(0) is staged in m_lds rows of KMAX floats
+  if (first_in_kernel) {
+    const int kq = (D.k_first + 3) >> 2;   // 16-byte pieces per row
+    for (int p = threadIdx.x; p < 64 * kq; p += 512) {
+      const int n = p / kq, k0 = 4 * (p % kq), gate = n >> 4, cellb = c0 + (n & 15);
+      const bool ok = gate < G && cellb < C;
+      *reinterpret_cast<f32x4 *>(&wf_lds[n][k0]) = ok ? *reinterpret_cast<const f32x4 *>(D.w_first + (long)(gate * C + cellb) * D.ldw_first + k0)
+                                                      : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  // collection role.  Workgroup-wide: pieces tid and tid + 512 of [stream][C / 4], a barrier, then every wave reads its K slice.
+  // Wave-local (st.wave_collect): a wave fetches exactly what it multiplies -- the 8 streams' pieces of its own K slice [kb, kb + kw),
+  // 2 kw <= 128 pieces, lanes 0..63 take pieces lane and lane + 64 of [stream][kw / 4] -- so no other wave's data is involved, the
+  // workgroup barrier behind the collection goes, and a wave waits for the 4 producers of its slice instead of all 32.
+  const bool wave_collect = (st.wave_collect & 1u) != 0u;
+  const int c4 = C >> 2, npiece = kChainStreams * c4, kq_w = kw >> 2, npw = kChainStreams * kq_w;
+  const int p0 = wave_collect ? lane : threadIdx.x, p1 = wave_collect ? lane + 64 : threadIdx.x + 512;
+  int st0, kq0, st1, kq1;
+  bool h0, h1;
+  if (wave_collect) {
+    st0 = p0 / kq_w; kq0 = (kb >> 2) + p0 % kq_w; st1 = p1 / kq_w; kq1 = (kb >> 2) + p1 % kq_w;
+    h0 = p0 < npw && kq0 < c4; h1 = p1 < npw && kq1 < c4;
+    if (!h0) { st0 = 0; kq0 = 0; }
+    if (!h1) { st1 = 0; kq1 = 0; }
+  } else {
+    h0 = p0 < npiece; h1 = p1 < npiece;
+    st0 = h0 ? p0 / c4 : 0; kq0 = h0 ? p0 % c4 : 0; st1 = h1 ? p1 / c4 : 0; kq1 = h1 ? p1 % c4 : 0;
+  }
+  const int off0 = (min(s0 + st0, SE - 1) * ld + om + 4 * kq0) * 4, off1 = (min(s0 + st1, SE - 1) * ld + om + 4 * kq1) * 4;
+  // gate-block role: a quad of lanes owns one (stream, cell) pair, lane r of the quad its gate r (g, i, f, o; CIFG: g, f, o, -).
+  // The five transcendentals of a pair then take two rounds (gates side by side, then tanh(c) beside the output gate) instead of
+  // five in a row on one lane, and all 8 waves share the work.
+  const int pair = threadIdx.x >> 2, role = threadIdx.x & 3;
+  const int sl = pair >> 4, cc = pair & 15, s = s0 + sl, cell = c0 + cc;
+  const bool live = s < SE && cell < C;
+  const int cq = live ? cell : 0, sq = live ? s : 0;
+  // the peephole weight of this lane's gate (none for g): i <- c(t-1), f <- c(t-1), o <- c(t)
+  float pw = 0.f;
+  if (!CIFG) pw = role == 1 ? D.peep_i[cq] : role == 2 ? D.peep_f[cq] : role == 3 ? D.peep_o[cq] : 0.f;
+  else pw = role == 1 ? D.peep_f[cq] : role == 2 ? D.peep_o[cq] : 0.f;
+  const int slen = (D.seq_lengths && live) ? D.seq_lengths[sq] : 0x7fffffff;
+  float cprev = 0.f;
+  {
+    const int tp0 = D.reverse ? T + 1 : 0;
+    if (live) cprev = D.y[((long)tp0 * S + sq) * ld + oc + cq];
+  }
+  for (int p = lane; p < 16 * AP / 8; p += 64) reinterpret_cast<u32x4 *>(&a_h[wave][0][0])[p] = u32x4{0u, 0u, 0u, 0u};   // own wave's rows; read back by this wave only
+  unsigned polls = 0u;
+  for (int step = 0; step < T; step++) {
+    const int t = D.reverse ? T - step : 1 + step, tp = D.reverse ? t + 1 : t - 1;
+    const int par = step & 1;
+    float *ys = D.y + ((long)t * S + sq) * ld;
+    long tm = tick(st);
+    // the x-part (+ bias) of this pair's gates: written before the launch, requested before the hand-off wait
+    const float xr = (live && role < G) ? ys[role * C + cq] : 0.f;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) { acc[h][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[h][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    bool ok = true;
+    const bool first_special = step == 0 && first_in_kernel;
+    const bool product = !first_special && !(step == 0 && D.skip_first_product);
+    if (first_special) {   // r(0) of the chain's streams -> LDS (the history row block: stored before the launch, no hand-off)
+      const int kq = D.k_first >> 2;
+      for (int p = threadIdx.x; p < kChainStreams * kq; p += 512) {
+        const int sp = p / kq, k0 = 4 * (p % kq);
+        *reinterpret_cast<f32x4 *>(&m_lds[sp][k0]) =
+            *reinterpret_cast<const f32x4 *>(D.y + ((long)tp * S + min(s0 + sp, SE - 1)) * ld + D.col_first + k0);
+      }
+    }
+    if (product) {
+      // 1. m(t-1) of the chain's streams -> LDS
+      const __amdgpu_buffer_rsrc_t rs = make_rsrc(D.y + (long)tp * S * ld);
+      u32x4 v0 = {0u, 0u, 0u, 0u}, v1 = {0u, 0u, 0u, 0u};
+      long t0 = 0;
+      for (unsigned spins = 0;; spins++) {
+        if (h0) v0 = __builtin_amdgcn_raw_buffer_load_b128(rs, off0, 0, kAuxSc1);
+        if (h1) v1 = __builtin_amdgcn_raw_buffer_load_b128(rs, off1, 0, kAuxSc1);
+        if (!__any((h0 && has_sentinel(v0)) || (h1 && has_sentinel(v1)))) break;
+        asm volatile("" ::: "memory");
+        polls++;
+        if (!spin_ok(spins, t0, st)) { ok = false; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (wave_collect) {   // m = m_hi + 2^-11 m_lo' (|m| <= 1: no scale needed), into this wave's operand rows
+        auto put = [&](const u32x4 v, int stv, int kqv) {
+          const int kl = 4 * kqv - kb;
+          _Float16 hi[4], lo[4];
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const float x = __uint_as_float(v[i]);
+            hi[i] = (_Float16)x;
+            lo[i] = (_Float16)((x - (float)hi[i]) * 2048.f);
+          }
+          *reinterpret_cast<half4 *>(&a_h[wave][stv][kl]) = half4{hi[0], hi[1], hi[2], hi[3]};
+          *reinterpret_cast<half4 *>(&a_h[wave][8 + stv][kl]) = half4{lo[0], lo[1], lo[2], lo[3]};
+        };
+        if (h0) put(v0, st0, kq0);
+        if (h1) put(v1, st1, kq1);
+      } else {
+        if (h0) *reinterpret_cast<u32x4 *>(&m_lds[st0][4 * kq0]) = v0;
+        if (h1) *reinterpret_cast<u32x4 *>(&m_lds[st1][4 * kq1]) = v1;
+      }
+    }
+    tock(st, 1, tm);  // collection
+    if (lane == 0) fail[par][wave] = ok ? 0 : 1;
+    if (!wave_collect || first_special) __syncthreads();   // (uniform) wave-local collection: this wave reads back only what it stored itself
+    else __builtin_amdgcn_wave_barrier();
+    tock(st, 3, tm);  // barrier behind the collection
+    f32x4 hacc[4];
+    if (product) {
+      // 2. this wave's K slice of the product: NCH chunks x G gate tiles x {w_hi, w_lo'} instructions of 16 x 16 x 32
+      if (!wave_collect) {   // (A/B path: the workgroup-wide collection left fp32 rows in m_lds; split this wave's slice from there)
+        for (int p = lane; p < kChainStreams * (kw >> 2); p += 64) {
+          const int stv = p / (kw >> 2), kl = 4 * (p % (kw >> 2));
+          if (kb + kl < C) {
+            const f32x4 x4 = *reinterpret_cast<const f32x4 *>(&m_lds[stv][kb + kl]);
+            _Float16 hi[4], lo[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) { hi[i] = (_Float16)x4[i]; lo[i] = (_Float16)((x4[i] - (float)hi[i]) * 2048.f); }
+            *reinterpret_cast<half4 *>(&a_h[wave][stv][kl]) = half4{hi[0], hi[1], hi[2], hi[3]};
+            *reinterpret_cast<half4 *>(&a_h[wave][8 + stv][kl]) = half4{lo[0], lo[1], lo[2], lo[3]};
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      half8 af[NCH];
+#pragma unroll
+      for (int j = 0; j < NCH; j++) af[j] = *reinterpret_cast<const half8 *>(&a_h[wave][hr][32 * j + 8 * hg]);
+#pragma unroll
+      for (int tile = 0; tile < 4; tile++) hacc[tile] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < NCH; j++) {
+#pragma unroll
+        for (int tile = 0; tile < G; tile++) hacc[tile] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[j], bh[tile][j], hacc[tile], 0, 0, 0);
+#pragma unroll
+        for (int tile = 0; tile < G; tile++) hacc[tile] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[j], bl[tile][j], hacc[tile], 0, 0, 0);
+      }
+    }
+    if (first_special) {   // r(0) W_first^T, both operands from LDS; this wave's slice of K = k_first
+      const int kwf = ((D.k_first + 31) / 32) * 4, kbf = wave * kwf;
+      const float *arow = &m_lds[4 * qs + jl][0];
+      for (int k0 = kbf; k0 < min(kbf + kwf, D.k_first); k0 += 4) {
+        const f32x4 av = *reinterpret_cast<const f32x4 *>(arow + k0);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const f32x4 b = *reinterpret_cast<const f32x4 *>(&wf_lds[32 * h + 4 * qc + jl][k0]);
+          acc[h][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.x, b.x, acc[h][0], 0, 0, 0);
+          acc[h][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.y, b.y, acc[h][1], 0, 0, 0);
+          acc[h][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.z, b.z, acc[h][0], 0, 0, 0);
+          acc[h][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.w, b.w, acc[h][1], 0, 0, 0);
+        }
+      }
+    }
+    if (product) {
+      // rows 0..7 (lanes 0..31) hold m_hi w, rows 8..15 (lanes 32..63) m_lo' w of the same streams: m w = ([m_hi w] + 2^-11 [m_lo' w]) / sc.
+      // One v_permlane32_swap joins the halves of TWO result registers at once: of (x, y) it leaves x's two halves in lanes 0..31 of the
+      // pair and y's two halves in lanes 32..63, so the sum is register e's total in the lower lanes and register e + 1's in the upper.
+      const int hg2 = hg & 1, eodd = lane >> 5;
+#pragma unroll
+      for (int tile = 0; tile < G; tile++) {
+        const float f = lane < 32 ? inv_sc[tile] : inv_sc[tile] * 0x1p-11f;
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(hacc[tile][e] * f), __float_as_uint(hacc[tile][e + 1] * f), false, false);
+          red[par][wave][4 * hg2 + e + eodd][16 * tile + hr] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);   // stream = result row 4 (l >> 4 & 1) + e (+ 1 in the upper lanes)
+        }
+      }
+    } else {
+      // result register r of a lane = stream 4 qs + r of tile column 32 h + 4 qc + jl
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const f32x4 sum = acc[h][0] + acc[h][1];
+        float *rp = &red[par][wave][4 * qs][32 * h + 4 * qc + jl];
+        rp[0 * RP] = sum.x; rp[1 * RP] = sum.y; rp[2 * RP] = sum.z; rp[3 * RP] = sum.w;
+      }
+    }
+    tock(st, 2, tm);  // product
+    __syncthreads();
+    tock(st, 4, tm);
+    {
+      int f = 0;
+#pragma unroll
+      for (int w = 0; w < 8; w++) f |= fail[par][w];
+      if (f) return;  // uniform: every wave reads the same eight words
+    }
+    float pre = 0.f;
+    if (role < G) {
+      pre = red[par][0][sl][role * 16 + cc];
+#pragma unroll
+      for (int w = 1; w < 8; w++) pre += red[par][w][sl][role * 16 + cc];
+    }
+    const bool masked = t > slen;  // nnet-blstm-projected-streams.h:654-657: rows past the utterance end are zeroed
+    // round 1: g = tanh(.), i / f = sigmoid(. + c(t-1) * peephole), each on its own lane
+    float gate = 0.f;
+    if (role == 0) gate = act_tanh<FAST>(xr + pre);
+    else if (role < G - 1) gate = act_sigmoid<FAST>(xr + pre + cprev * pw);
+    const float gg = quad_bcast<0>(gate), g1 = quad_bcast<1>(gate), g2 = quad_bcast<2>(gate);
+    float cellv;
+    if (!CIFG) cellv = gg * g1 + cprev * g2;        // g * i + c(t-1) * f
+    else cellv = -gg * g1 + gg + cprev * g1;        // coupled input gate: i = 1 - f
+    cellv = fminf(fmaxf(cellv, -50.0f), 50.0f);
+    // round 2: h = tanh(c) on lane 0, o = sigmoid(. + c * peephole) on lane G - 1
+    float hh = 0.f;
+    if (role == 0) hh = act_tanh<FAST>(cellv);
+    if (role == G - 1) gate = act_sigmoid<FAST>(xr + pre + cellv * pw);
+    const float oo = quad_bcast<G - 1>(gate);
+    float mm = hh * oo;   // meaningful on lane 0 of the quad
+    if (masked) { gate = 0.f; cellv = 0.f; hh = 0.f; mm = 0.f; }
+    // publish m(t) first: it is what the other workgroups wait for.  Four consecutive cells = lane 0 of four consecutive quads.
+    {
+      const float m1 = row_up<4>(mm), m2 = row_up<8>(mm), m3 = row_up<12>(mm);
+      if (live && role == 0 && (cc & 3) == 0) {
+        u32x4 pk = {__float_as_uint(mm), __float_as_uint(m1), __float_as_uint(m2), __float_as_uint(m3)};
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(D.y + (long)t * S * ld);
+        const int off = (s * ld + om + cell) * 4;
+        if (R.local) __builtin_amdgcn_raw_buffer_store_b128(pk, rs, off, 0, 0);
+        else __builtin_amdgcn_raw_buffer_store_b128(pk, rs, off, 0, kAuxSc1);
+      }
+    }
+    if (live) {
+      if (role < G) ys[role * C + cell] = gate;
+      if (role == 0) ys[oh + cell] = hh;
+      if (role == 1) ys[oc + cell] = cellv;
+    }
+    cprev = cellv;
+    tock(st, 5, tm);  // epilogue
+  }
+  if (st.timing && blockIdx.x == 0 && threadIdx.x == 0) {
+    st.timing[0] += (unsigned long long)T; st.timing[6] += R.local ? 1ull : 0ull;
+    st.timing[7] += (unsigned long long)((long)wall_clock64() - t_entry);   // this workgroup's whole stay, entry to exit
+  }
+  if (st.trace && threadIdx.x == 0) {   // ring of the 8 latest launches
+    unsigned long long *tr = st.trace + (st.epoch & 7u) * 2048u;
+    tr[2 * blockIdx.x] = (unsigned long long)t_entry; tr[2 * blockIdx.x + 1] = wall_clock64();
+  }
+  if (polls && lane == 0) __hip_atomic_fetch_add(st.abort_flag + 2, polls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // diagnostics, once per wave
+}
+
 // ---- backward ------------------------------------------------------------------------------------------------------
 // d_m(t) = dm_ext(t) + dGATES(next) W_eff is a product over K = G*C gate columns.  Partitioned by OUTPUT cell (like the forward
 // pass) every workgroup would have to pull all of dGATES(next) of its chain -- 64 KiB per workgroup and timestep through the
@@ -677,6 +1007,263 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd(aslp_lstm_seq a, SeqStatus s
     }
     tock(st, 5, tm);
     __syncthreads();  // own_dg[par] complete before anybody multiplies with it; shares[] free for the next collection
+  }
+  if (a.grad_partial) {   // the chain's 8 streams meet in LDS (stream order), one row of 16 cells per quantity goes out per workgroup
+    float *gl = shares;   // [stream 8][quantity 7][cell 16]: free after the loop's last barrier
+    if (threadIdx.x < 128) {
+#pragma unroll
+      for (int k = 0; k < 7; k++) gl[(sl * 7 + k) * 16 + cc] = gsum[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 7 * 16) {
+      const int k = threadIdx.x >> 4, c = threadIdx.x & 15;
+      float v = gl[k * 16 + c];
+#pragma unroll
+      for (int q = 1; q < kChainStreams; q++) v += gl[(q * 7 + k) * 16 + c];
+      if (c0 + c < C) a.grad_partial[((long)chain * 7 + k) * a.grad_ld + c0 + c] = v;
+    }
+  }
+  if (st.timing && blockIdx.x == 0 && threadIdx.x == 0) { st.timing[0] += (unsigned long long)T; st.timing[6] += R.local ? 1ull : 0ull; }
+  if (st.trace && threadIdx.x == 0) {   // ring of the 8 latest launches
+    unsigned long long *tr = st.trace + (st.epoch & 7u) * 2048u;
+    tr[2 * blockIdx.x] = (unsigned long long)t_entry; tr[2 * blockIdx.x + 1] = wall_clock64();
+  }
+  if (polls && lane == 0) __hip_atomic_fetch_add(st.abort_flag + 2, polls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- backward, product on fp16 matrix instructions with fp32-equivalent operands ------------------------------------------------------
+// lstm_seq_bwd with the share product dG(next) W_eff carried as in lstm_seq_fwd_h: the fp32 instruction made "product + publication" the
+// longest phase of a backward timestep (1.4 of ~3 us).  The gate diffs a workgroup multiplies are its own (LDS), so their power-of-two
+// scale is per stream AND timestep (the largest of the 16 * G values of a stream goes to [2^13, 2^14)): gradients of any magnitude keep 22
+// significant bits.  The share layout inside a producer -> consumer block changes with the instruction's result layout (8-byte pieces).
+template <bool CIFG, int TPW>
+__global__ void __launch_bounds__(512) lstm_seq_bwd_h(aslp_lstm_seq a, SeqStatus st, unsigned *place, float *inbox) {
+  constexpr int G = CIFG ? 3 : 4;
+  constexpr int AP = 64 + 8;   // halves per operand row: K = the workgroup's own 16 * G gate columns (two chunks of 32; CIFG leaves 16 zeros)
+  __shared__ __attribute__((aligned(16))) _Float16 a_h[2][16][AP];        // [parity][rows 0..7 = dG_hi of stream r, 8..15 = dG_lo' of stream r - 8][gate * 16 + cell]
+  __shared__ __attribute__((aligned(16))) float row_inv[2][kChainStreams];   // [parity][stream]: 1 / (the power of two its gate diffs were scaled by)
+  __shared__ __attribute__((aligned(16))) float shares[kMaxWgPerChain * 2 * 16 * 4];     // [producer][row group][column][row]
+  __shared__ int fail[2][8];
+  __shared__ int place_flag;
+  const long t_entry = st.trace ? (long)wall_clock64() : 0;
+  const int SE = a.s_count > 0 ? a.s_begin + a.s_count : a.S;
+  const ChainRole R = chain_role(SE - a.s_begin, a.ndir, a.C, st, place, &place_flag);
+  if (!R.active) return;
+  const aslp_lstm_seq_dir D = a.dir[R.dir];
+  const int C = a.C, S = a.S, T = a.T, ld = a.ld;
+  const int GC = G * C, oc = GC, oh = GC + C, om = GC + 2 * C;
+  const int og = 0, oi = C, of = CIFG ? C : 2 * C, oo = CIFG ? 2 * C : 3 * C;
+  const int c0 = R.c0, s0 = a.s_begin + R.s0;
+  const int chain = blockIdx.x & (kMaxChains - 1), me = blockIdx.x >> 3, wpc = (C + kCellsPerWg - 1) / kCellsPerWg;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // The product runs on v_mfma_f32_16x16x32_f16 with two-piece operands (see lstm_seq_fwd_h): A rows 0..7 = dG_hi of the chain's streams,
+  // rows 8..15 = dG_lo' (dG scaled per stream and timestep by a power of two, so gradients of any size keep 22 bits), B = this workgroup's
+  // 16 * G rows of W_eff as w_hi / w_lo after a power-of-two scale per column.  This wave's cells: consumer blocks wave + 8 j, one 16-cell
+  // tile each; K = 64 = two chunks -> 4 instructions per tile.
+  const int hr = lane & 15, hg = lane >> 4, hg2 = hg & 1, eodd = lane >> 5;
+  half8 bh[TPW][2], bl[TPW][2];
+  float csc[TPW];
+#pragma unroll
+  for (int tj = 0; tj < TPW; tj++) {
+    const int cb = wave + 8 * tj, col = cb * 16 + hr;
+    const bool colok = cb < wpc && col < C;
+    float wv[2][8];
+    float cmax = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const int kk = 32 * j + 8 * hg + i, cellk = c0 + (kk & 15);
+        wv[j][i] = (colok && (kk >> 4) < G && cellk < C) ? D.w[(long)((kk >> 4) * C + cellk) * a.ldw + col] : 0.f;
+        cmax = fmaxf(cmax, fabsf(wv[j][i]));
+      }
+    cmax = fmaxf(cmax, __shfl_xor(cmax, 16));   // the column's other k-groups
+    cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+    int e = 0;
+    (void)frexpf(cmax, &e);
+    const bool scaled = cmax > 0.f && cmax < 3.0e38f;
+    const float sc = scaled ? ldexpf(1.f, 14 - e) : 1.f;
+    csc[tj] = scaled ? ldexpf(1.f, e - 14) : 1.f;
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const float x = wv[j][i] * sc;
+        const _Float16 xh = (_Float16)x;
+        bh[tj][j][i] = xh;
+        bl[tj][j][i] = (_Float16)(x - (float)xh);
+      }
+  }
+  for (int p = threadIdx.x; p < 2 * 16 * AP / 8; p += 512) reinterpret_cast<u32x4 *>(&a_h[0][0][0])[p] = u32x4{0u, 0u, 0u, 0u};   // (the loop's first barrier publishes it)
+  // inbox geometry
+  const size_t slot_words = (size_t)kMaxChains * kMaxWgPerChain * kMaxWgPerChain * 128;  // floats per ring slot
+  float *chain_box = inbox + (size_t)chain * kMaxWgPerChain * kMaxWgPerChain * 128;
+  const int npiece = wpc * 32;  // 16-byte pieces addressed to this workgroup per timestep: [producer][row group][column]
+  // epilogue role: threads 0..127 own one (stream, cell) pair each
+  const int sl = threadIdx.x >> 4, cc = threadIdx.x & 15, s = s0 + sl, cell = c0 + cc;
+  const bool live = threadIdx.x < 128 && s < SE && cell < C;
+  const int cq = live ? cell : 0, sq = live ? s : 0;
+  const float pf = D.peep_f[cq], po = D.peep_o[cq], pi = CIFG ? 0.f : D.peep_i[cq];
+  // own-cell quantities of the step processed just before (BPTT order): all zero ahead of the first step
+  float dn_c = 0.f, dn_f = 0.f, dn_i = 0.f;
+  float gsum[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  unsigned polls = 0u;
+  for (int step = 0; step < T; step++) {
+    // BPTT runs against the direction's recursion: reverse = 0 (t = T..1), reverse = 1 (t = 1..T)
+    const int t = D.reverse ? 1 + step : T - step;
+    const int tn = D.reverse ? t - 1 : t + 1, tp = D.reverse ? t + 1 : t - 1;
+    const int par = step & 1;
+    const long o_ = ((long)t * S + sq) * ld;
+    long tm = tick(st);
+    float dm = 0.f, yo = 0.f, yh = 0.f, yg = 0.f, yf = 0.f, yi = 0.f, yn_f = 0.f, cprev = 0.f, ccur = 0.f;
+    if (live) {  // everything that does not depend on the other workgroups, requested first
+      dm = D.d[o_ + om + cq];
+      yo = D.y[o_ + oo + cq]; yh = D.y[o_ + oh + cq]; yg = D.y[o_ + og + cq]; yf = D.y[o_ + of + cq];
+      if (!CIFG) yi = D.y[o_ + oi + cq];
+      yn_f = D.y[((long)tn * S + sq) * ld + of + cq];
+      cprev = D.y[((long)tp * S + sq) * ld + oc + cq];
+      if (a.grad_partial) ccur = D.y[o_ + oc + cq];
+    }
+    bool ok = true;
+    if (step > 0) {
+      float *box = chain_box + (size_t)(step % kRing) * slot_words;
+      // 1. my share of d_m for every cell of the chain: own gate diffs of the previous step (LDS) x my rows of W_eff
+      {
+        half8 af[2];
+#pragma unroll
+        for (int j = 0; j < 2; j++) af[j] = *reinterpret_cast<const half8 *>(&a_h[par ^ 1][hr][32 * j + 8 * hg]);
+        const f32x4 rinv = *reinterpret_cast<const f32x4 *>(&row_inv[par ^ 1][4 * hg2]);   // streams 4 hg2 + e of this lane's result registers
+        f32x4 hacc[TPW];
+#pragma unroll
+        for (int tj = 0; tj < TPW; tj++) hacc[tj] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+#pragma unroll
+          for (int tj = 0; tj < TPW; tj++) hacc[tj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[j], bh[tj][j], hacc[tj], 0, 0, 0);
+#pragma unroll
+          for (int tj = 0; tj < TPW; tj++) hacc[tj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[j], bl[tj][j], hacc[tj], 0, 0, 0);
+        }
+        // 2. hand the shares out.  Rows 0..7 (lanes 0..31) hold dG_hi W, rows 8..15 dG_lo' W of the same streams; one v_permlane32_swap joins
+        // the halves of two result registers (see lstm_seq_fwd_h), leaving registers 0 / 2 in the lower lanes and 1 / 3 in the upper: an
+        // 8-byte piece per lane, [row group][odd][column][register pair] inside the 512 bytes a producer sends a consumer.
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(box);
+        const float half_f = lane < 32 ? 1.f : 0x1p-11f;
+#pragma unroll
+        for (int tj = 0; tj < TPW; tj++) {
+          const int cb = wave + 8 * tj;
+          const float f = csc[tj] * half_f;
+          const auto s01 = __builtin_amdgcn_permlane32_swap(__float_as_uint(hacc[tj][0] * (f * rinv[0])), __float_as_uint(hacc[tj][1] * (f * rinv[1])), false, false);
+          const auto s23 = __builtin_amdgcn_permlane32_swap(__float_as_uint(hacc[tj][2] * (f * rinv[2])), __float_as_uint(hacc[tj][3] * (f * rinv[3])), false, false);
+          if (cb < wpc) {
+            const float v01 = __uint_as_float(s01[0]) + __uint_as_float(s01[1]), v23 = __uint_as_float(s23[0]) + __uint_as_float(s23[1]);
+            const int off = ((cb * kMaxWgPerChain + me) * 128 + ((hg2 * 2 + eodd) * 16 + hr) * 2) * 4;
+            const u32x2 pk = {__float_as_uint(v01), __float_as_uint(v23)};
+            if (R.local) __builtin_amdgcn_raw_buffer_store_b64(pk, rs, off, 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b64(pk, rs, off, 0, kAuxSc1);
+          }
+        }
+      }
+      tock(st, 1, tm);  // product + publication
+      // 3. collect what the chain's workgroups sent me: pieces tid and tid + 512 of [producer][row group][column]
+      {
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(box + (size_t)me * kMaxWgPerChain * 128);
+        const int i0 = threadIdx.x, i1 = threadIdx.x + 512;
+        const bool h0 = i0 < npiece, h1 = i1 < npiece;
+        u32x4 v0 = {0u, 0u, 0u, 0u}, v1 = {0u, 0u, 0u, 0u};
+        long t0 = 0;
+        for (unsigned spins = 0;; spins++) {
+          if (h0) v0 = __builtin_amdgcn_raw_buffer_load_b128(rs, i0 * 16, 0, kAuxSc1);
+          if (h1) v1 = __builtin_amdgcn_raw_buffer_load_b128(rs, i1 * 16, 0, kAuxSc1);
+          if (!__any((h0 && has_sentinel(v0)) || (h1 && has_sentinel(v1)))) break;
+          asm volatile("" ::: "memory");
+          polls++;
+          if (!spin_ok(spins, t0, st)) { ok = false; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        // give the slot back (sentinel) and make sure that has happened before anything of mine is published again
+        const u32x4 sent = {kSentinel, kSentinel, kSentinel, kSentinel};
+        if (R.local) {
+          if (h0) __builtin_amdgcn_raw_buffer_store_b128(sent, rs, i0 * 16, 0, 0);
+          if (h1) __builtin_amdgcn_raw_buffer_store_b128(sent, rs, i1 * 16, 0, 0);
+        } else {
+          if (h0) __builtin_amdgcn_raw_buffer_store_b128(sent, rs, i0 * 16, 0, kAuxSc1);
+          if (h1) __builtin_amdgcn_raw_buffer_store_b128(sent, rs, i1 * 16, 0, kAuxSc1);
+        }
+        if (h0) *reinterpret_cast<u32x4 *>(&shares[i0 * 4]) = v0;
+        if (h1) *reinterpret_cast<u32x4 *>(&shares[i1 * 4]) = v1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      tock(st, 2, tm);  // collection
+    }
+    if (lane == 0) fail[par][wave] = ok ? 0 : 1;
+    __syncthreads();
+    tock(st, 4, tm);
+    {
+      int f = 0;
+#pragma unroll
+      for (int w = 0; w < 8; w++) f |= fail[par][w];
+      if (f) return;
+    }
+    if (threadIdx.x < 128) {
+      if (step > 0) {  // shares of my 16 cells, added in workgroup order
+        float psum = 0.f;
+        const int base = (((sl >> 2) * 2 + (sl & 1)) * 16 + cc) * 2 + ((sl & 3) >> 1);   // [row group][odd register][column][register pair] (see the publication)
+        for (int p = 0; p < wpc; p++) psum += shares[p * 128 + base];
+        dm += psum;
+      }
+      const float dh = dtanh(yh, dm * yo);
+      const float dov = dsigm(yo, dm * yh);
+      float dc = dh + dn_c * yn_f;
+      if (!CIFG) dc += dn_i * pi;
+      dc += dn_f * pf;
+      dc += dov * po;
+      float dg, df, di = 0.f;
+      if (!CIFG) {
+        df = dsigm(yf, dc * cprev);
+        di = dsigm(yi, dc * yg);
+        dg = dtanh(yg, dc * yi);
+      } else {
+        df = dsigm(yf, dc * cprev - dc * yg);
+        dg = dtanh(yg, dc - dc * yf);
+      }
+      // the next step's left operand stays here; the buffer copy is for the batched products after the launch
+      {
+        // this stream's gate diffs, scaled by the power of two that puts the largest of its 16 * G in [2^13, 2^14), as two fp16 pieces
+        float rmax = fmaxf(fmaxf(fabsf(dg), fabsf(df)), fmaxf(fabsf(di), fabsf(dov)));
+        rmax = fmaxf(rmax, __shfl_xor(rmax, 1)); rmax = fmaxf(rmax, __shfl_xor(rmax, 2));
+        rmax = fmaxf(rmax, __shfl_xor(rmax, 4)); rmax = fmaxf(rmax, __shfl_xor(rmax, 8));   // the 16 lanes of a stream (tid = stream * 16 + cell)
+        int e = 0;
+        (void)frexpf(rmax, &e);
+        const bool scaled = rmax > 0.f && rmax < 3.0e38f;
+        const int up = scaled ? min(14 - e, 120) : 0;
+        const float sc = ldexpf(1.f, up), inv = ldexpf(1.f, -up);
+        auto put = [&](int k, float x) {
+          const float xs = x * sc;
+          const _Float16 xh = (_Float16)xs;
+          a_h[par][sl][k] = xh;
+          a_h[par][8 + sl][k] = (_Float16)((xs - (float)xh) * 2048.f);
+        };
+        put(cc, dg);
+        if (!CIFG) { put(16 + cc, di); put(32 + cc, df); put(48 + cc, dov); }
+        else { put(16 + cc, df); put(32 + cc, dov); }
+        if (cc == 0) row_inv[par][sl] = inv;
+      }
+      if (live) {
+        D.d[o_ + og + cell] = dg; D.d[o_ + of + cell] = df; D.d[o_ + oo + cell] = dov;
+        if (!CIFG) D.d[o_ + oi + cell] = di;
+        D.d[o_ + om + cell] = dm;  // the reference's d_m (lc.h:793) -- kept for InfoGradient-style dumps
+        D.d[o_ + oh + cell] = dh;
+        D.d[o_ + oc + cell] = dc;
+      }
+      dn_c = dc; dn_f = df; dn_i = di;
+      if (a.grad_partial && live) {   // what the bias and peephole gradients are sums of (lc.h:1005-1058), this pair's share
+        gsum[0] += dg; gsum[2] += df; gsum[3] += dov;
+        gsum[5] += df * cprev; gsum[6] += dov * ccur;
+        if (!CIFG) { gsum[1] += di; gsum[4] += di * cprev; }
+      }
+    }
+    tock(st, 5, tm);
+    __syncthreads();  // a_h[par] complete before anybody multiplies with it; shares[] free for the next collection
   }
   if (a.grad_partial) {   // the chain's 8 streams meet in LDS (stream order), one row of 16 cells per quantity goes out per workgroup
     float *gl = shares;   // [stream 8][quantity 7][cell 16]: free after the loop's last barrier
@@ -1890,6 +2477,26 @@ SeqKernel pick_fwd(bool cifg, int C) {
   if (C <= 512) return cifg ? lstm_seq_fwd<true, 64, false> : lstm_seq_fwd<false, 64, false>;
   return nullptr;
 }
+// product on fp16 matrix instructions with two-piece fp32-equivalent operands (lstm_seq_fwd_h): A/B switch ASLP_LSTM_SPLIT_F16
+bool split_f16_on() {   // default on; ASLP_LSTM_SPLIT_F16=0 puts the recurrent products back on the fp32 instruction (lstm_seq_fwd / lstm_seq_bwd)
+  static const bool off = getenv("ASLP_LSTM_SPLIT_F16") != nullptr && getenv("ASLP_LSTM_SPLIT_F16")[0] == '0';
+  return !off;
+}
+SeqKernel pick_fwd_h(bool cifg, int C) {
+  if (fast_act()) {
+    if (C <= 256) return cifg ? lstm_seq_fwd_h<true, 1, true> : lstm_seq_fwd_h<false, 1, true>;
+    if (C <= 512) return cifg ? lstm_seq_fwd_h<true, 2, true> : lstm_seq_fwd_h<false, 2, true>;
+    return nullptr;
+  }
+  if (C <= 256) return cifg ? lstm_seq_fwd_h<true, 1, false> : lstm_seq_fwd_h<false, 1, false>;
+  if (C <= 512) return cifg ? lstm_seq_fwd_h<true, 2, false> : lstm_seq_fwd_h<false, 2, false>;
+  return nullptr;
+}
+SeqKernelB pick_bwd_h(bool cifg, int C) {
+  if (C <= 128) return cifg ? lstm_seq_bwd_h<true, 1> : lstm_seq_bwd_h<false, 1>;
+  if (C <= 512) return cifg ? lstm_seq_bwd_h<true, 4> : lstm_seq_bwd_h<false, 4>;
+  return nullptr;
+}
 SeqKernelB pick_bwd(bool cifg, int C) {
   if (C <= 128) return cifg ? lstm_seq_bwd<true, 1> : lstm_seq_bwd<false, 1>;
   if (C <= 512) return cifg ? lstm_seq_bwd<true, 4> : lstm_seq_bwd<false, 4>;
@@ -2002,8 +2609,8 @@ int aslp_lstm_seq_supported(const aslp_lstm_seq *a, int backward) {
   const int ns = a->s_count > 0 ? a->s_count : a->S;   // streams of this launch
   const int nsg = (ns + kChainStreams - 1) / kChainStreams, wpc = (a->C + kCellsPerWg - 1) / kCellsPerWg;
   if (a->ndir * nsg > kMaxChains || wpc > kMaxWgPerChain) return 0;   // <= 32 streams per launch (bidirectional) / 64, C <= 512
-  const void *k = backward ? reinterpret_cast<const void *>(pick_bwd(a->cifg != 0, a->C))
-                           : reinterpret_cast<const void *>(dual_on() ? pick_fwd_dual(a->cifg != 0, a->C) : pick_fwd(a->cifg != 0, a->C));
+  const void *k = backward ? reinterpret_cast<const void *>(split_f16_on() ? pick_bwd_h(a->cifg != 0, a->C) : pick_bwd(a->cifg != 0, a->C))
+                           : reinterpret_cast<const void *>(dual_on() ? pick_fwd_dual(a->cifg != 0, a->C) : split_f16_on() ? pick_fwd_h(a->cifg != 0, a->C) : pick_fwd(a->cifg != 0, a->C));
   return grid_fits(k, 512, (long)kMaxChains * wpc) ? 1 : 0;
 }
 
@@ -2078,9 +2685,9 @@ static void launch_seq(const aslp_lstm_seq *a, bool backward, const char *who) {
     const int grid = (nchains > 8 ? 16 : 8) * wpc;
     if (!backward) hipLaunchKernelGGL(pick_fwd4(a->cifg != 0, a->C), dim3(grid), dim3(256), 0, cur_stream(), *a, st, rt.place);
     else hipLaunchKernelGGL(pick_bwd4(a->cifg != 0, a->C), dim3(grid), dim3(256), 0, cur_stream(), *a, st, rt.place, rt.inbox);
-  } else if (!backward) hipLaunchKernelGGL(dual_on() ? pick_fwd_dual(a->cifg != 0, a->C) : pick_fwd(a->cifg != 0, a->C), dim3(kMaxChains * wpc), dim3(512), 0,
+  } else if (!backward) hipLaunchKernelGGL(dual_on() ? pick_fwd_dual(a->cifg != 0, a->C) : split_f16_on() ? pick_fwd_h(a->cifg != 0, a->C) : pick_fwd(a->cifg != 0, a->C), dim3(kMaxChains * wpc), dim3(512), 0,
                                            cur_stream(), *a, st, rt.place);
-  else hipLaunchKernelGGL(pick_bwd(a->cifg != 0, a->C), dim3(kMaxChains * wpc), dim3(512), 0, cur_stream(), *a, st, rt.place, rt.inbox);
+  else hipLaunchKernelGGL(split_f16_on() ? pick_bwd_h(a->cifg != 0, a->C) : pick_bwd(a->cifg != 0, a->C), dim3(kMaxChains * wpc), dim3(512), 0, cur_stream(), *a, st, rt.place, rt.inbox);
   if (!rt.last_done) (void)hipEventCreateWithFlags(&rt.last_done, hipEventDisableTiming);
   if (rt.last_done) { ASLP_CHECK_HIP(hipEventRecord(rt.last_done, cur_stream())); rt.last_stream = cur_stream(); }
   check_launch(who);

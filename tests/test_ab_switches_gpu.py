@@ -15,22 +15,22 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 CHILD = r'''
-import sys, json, hashlib
+import sys, json, hashlib, os
 import numpy as np, torch
 sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
 import aslp_import
 aslp = aslp_import.load(); aslp.ops.use_torch_stream()
 dev = torch.device("cuda:0")
 S, chunk, T, D, C = 16, 6, 9, 24, 128
-proto = ("<NnetProto>\n<BLstmProjectedStreamsLC> <InputDim> %%d <OutputDim> 128 <CellDim> %%d <ParamScale> 0.05 <ClipGradient> 5.0\n</NnetProto>\n" %% (D, C))
+proto = ("<NnetProto>\n<BLstmProjectedStreamsLC> <InputDim> %%d <OutputDim> 128 <CellDim> %%d <ParamScale> %%s <ClipGradient> %%s\n</NnetProto>\n" %% (D, C, os.environ.get("AB_PSCALE", "0.05"), os.environ.get("AB_CLIP", "5.0")))
 net = aslp.Nnet.Init(proto, seed=5)
-net.SetTrainOptions(learn_rate=1e-3, momentum=0.9)
+net.SetTrainOptions(learn_rate=float(os.environ.get("AB_LR", "1e-3")), momentum=0.9)
 net.SetChunkSize(chunk)
 g = torch.Generator(device="cpu"); g.manual_seed(3)
 outs = []
 for step in range(2):
     x = torch.randn(T * S, D, generator=g).to(dev)
-    od = (torch.randn(T * S, 128, generator=g) * 0.1).to(dev)
+    od = (torch.randn(T * S, 128, generator=g) * float(os.environ.get("AB_ODSCALE", "0.1"))).to(dev)
     net.ResetLstmStreams([1] * S if step == 0 else [0] * S)
     out = net.Propagate(x).cpu().numpy()
     idf = net.Backpropagate(od, want_in_diff=True).cpu().numpy()
@@ -49,7 +49,7 @@ def run(tmp_path, name, **env):
 
 
 def test_recurrent_ab_switches_agree(tmp_path):
-    base = run(tmp_path, "default")                       # chains of 8 streams, gate non-linearities on v_exp_f32 / v_rcp_f32
+    base = run(tmp_path, "default")                       # chains of 8 streams, gate non-linearities on v_exp_f32 / v_rcp_f32, products on v_mfma_f32_16x16x32_f16
     assert np.isfinite(base).all()
     for name, env in (("wg_collect", {"ASLP_LSTM_WAVE_COLLECT": "0"}), ("own_order", {"ASLP_LSTM_READ_AHEAD": "0"}),
                       ("both_off", {"ASLP_LSTM_WAVE_COLLECT": "0", "ASLP_LSTM_READ_AHEAD": "0"})):
@@ -59,6 +59,12 @@ def test_recurrent_ab_switches_agree(tmp_path):
     def close(a, b, tol=1e-5):
         return np.linalg.norm(a - b) / np.linalg.norm(b) < tol and np.abs(a - b).max() / max(1.0, np.abs(b).max()) < 10 * tol
 
+    # the recurrent products on the fp32 matrix instruction (lstm_seq_fwd / lstm_seq_bwd) instead of two-piece fp16 operands: same values to
+    # fp32 rounding, and that family's own switches still agree bit for bit
+    f32 = run(tmp_path, "fp32_mfma", ASLP_LSTM_SPLIT_F16="0")
+    assert close(f32, base)
+    for name, env in (("f32_wg_collect", {"ASLP_LSTM_WAVE_COLLECT": "0"}), ("f32_own_order", {"ASLP_LSTM_READ_AHEAD": "0"})):
+        assert np.array_equal(f32, run(tmp_path, name, ASLP_LSTM_SPLIT_F16="0", **env)), name
     exact = run(tmp_path, "exact_act", ASLP_LSTM_FAST_ACT="0")      # correctly rounded expf / division (the reference's CPU bits)
     assert close(exact, base)
     half = run(tmp_path, "half_chains", ASLP_LSTM_HALF_CHAINS="1")  # 4 streams per chain, two workgroups per CU: K split over 4 waves
@@ -69,6 +75,26 @@ def test_recurrent_ab_switches_agree(tmp_path):
     assert close(dual, base)
     step = run(tmp_path, "per_timestep", ASLP_LSTM_PERSISTENT="0")
     assert close(step, base)
+
+
+@pytest.mark.parametrize("pscale,odscale,lr", [("0.3", "1e-9", "1e-3"), ("0.001", "1e5", "1e-12"), ("0.05", "1e-20", "1e-3"), ("0.2", "30.0", "1e-6")])
+def test_split_f16_products_keep_fp32_accuracy_at_any_magnitude(tmp_path, pscale, odscale, lr):
+    """The recurrent products carry each fp32 operand as two fp16 pieces behind power-of-two scales (weights per column, gate diffs per
+    stream and timestep: csrc/rnn_persistent.hip lstm_seq_fwd_h / lstm_seq_bwd_h), so nothing depends on the operands' magnitude: large
+    weights with vanishing gradients, tiny weights with huge gradients (no clipping), gradients near the bottom of fp32's range -- output,
+    input diff and the parameters after two updates agree with the fp32-instruction kernels like two fp32 summation orders do.  (Weights
+    large enough to saturate the gates are left out: that recurrence is chaotic and any two fp32 summation orders part ways on it; the
+    column scale itself is exercised over 10 orders of magnitude by devtools/micro/f16_split.hip.)"""
+    env = dict(AB_PSCALE=pscale, AB_ODSCALE=odscale, AB_LR=lr, AB_CLIP="0.0")
+    split = run(tmp_path, "split", **env)
+    f32 = run(tmp_path, "f32", ASLP_LSTM_SPLIT_F16="0", **env)
+    assert np.isfinite(split).all() and np.isfinite(f32).all()
+    n = 2 * (9 * 16 * 128 + 9 * 16 * 24)        # outputs and input diffs of the two chunks, then the parameters
+    for name, a, b in (("out/in_diff", split[:n], f32[:n]), ("params", split[n:], f32[n:])):
+        # per block of equal kind: input diffs of the 1e-9 case are ~1e-9 themselves, so compare blockwise relative to each block's own size
+        for lo, hi in ((0, 9 * 16 * 128), (9 * 16 * 128, 9 * 16 * (128 + 24))) if name != "params" else ((0, len(a)),):
+            x, y = a[lo:hi].astype(np.float64), b[lo:hi].astype(np.float64)
+            assert np.linalg.norm(x - y) <= 1e-5 * np.linalg.norm(y) + 1e-30, (name, lo, np.linalg.norm(x - y) / max(np.linalg.norm(y), 1e-300))
 
 
 XENT_CHILD = r'''
