@@ -66,7 +66,7 @@ if os.environ.get("SEQ_TIMING") == "1":
         if mode == 1 and os.environ.get("ASLP_LSTM_DUAL", "0") == "1":
             print("(wave-specialised forward: per timestep = two half-steps; 'barrier' (2nd) = product waves waiting for the gate waves; the 1st 'barrier' column = "
                   "gate role: reduce + gate block up to the publication; 'epilogue' = gate role: stores behind the publication)")
-        names = ("collect m(t-1)", "barrier", "product", "barrier", "epilogue") if mode == 1 else ("product+publish", "-", "collect shares", "barrier", "epilogue")
+        names = ("collect m(t-1)", "barrier", "product", "barrier", "epilogue") if mode == 1 else ("product+publish", "sum shares", "collect shares", "barrier", "gate diffs")
         vals = [buf[k] * 0.01 / n for k in (1, 3, 2, 4, 5)]
         print("%s kernel, workgroup 0 wave 0, us per timestep: %s   (L2-local launches %d of %d; workgroup 0 resident %.1f us per launch)"
               % (name, "  ".join("%s %.2f" % (nm, v) for nm, v in zip(names, vals)), buf[6], n // T, buf[7] * 0.01 / max(1, n // T)))

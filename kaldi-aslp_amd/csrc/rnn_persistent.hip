@@ -85,6 +85,11 @@ __device__ __forceinline__ float row_up(float v) {
   return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x100 + N, 0xF, 0xF, true));  // row_shl:N -> dst[i] = src[i + N]
 }
 
+template <int N>
+__device__ __forceinline__ float row_ror(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x120 + N, 0xF, 0xF, true));  // row_ror:N -> rotation within the row of 16 lanes
+}
+
 // device-side status: abort_flag[0] abort flag (zeroed before every launch), abort_flag[2] running count of hand-off
 // re-polls (diagnostics, aslp_lstm_seq_polls); host_err: mapped host word, counts timeouts
 struct SeqStatus {
@@ -99,10 +104,20 @@ struct SeqStatus {
   unsigned half_delay;         // half-chain kernels: the second chain of a CU starts this many 10 ns ticks late (see chain_role4)
 };
 __device__ __forceinline__ long tick(const SeqStatus &st) { return st.timing ? (long)wall_clock64() : 0; }
+// The phase accumulators live in LDS while the kernel runs (a fire-and-forget ds_add per mark): accumulating in global memory put an L2
+// round trip and a wait behind every mark -- 0.1-0.2 us charged to the NEXT phase, five times per timestep, and workgroup 0 (hence the
+// whole lock-stepped chain) ran that much slower under the timer.  timing_flush adds them to st.timing once, at the end.
+__shared__ unsigned long long g_tacc[8];
+__device__ __forceinline__ void timing_begin(const SeqStatus &st) {
+  if (st.timing && threadIdx.x < 8) g_tacc[threadIdx.x] = 0ull;   // (chain_role's barrier publishes it)
+}
+__device__ __forceinline__ void timing_flush(const SeqStatus &st) {   // caller: st.timing != NULL, workgroup 0, thread 0, behind the loop's last barrier
+  for (int k = 1; k <= 5; k++) st.timing[k] += g_tacc[k];
+}
 __device__ __forceinline__ void tock(const SeqStatus &st, int slot, long &t) {
   if (!st.timing) return;
   const long now = (long)wall_clock64();
-  if (blockIdx.x == 0 && threadIdx.x == 0) st.timing[slot] += (unsigned long long)(now - t);
+  if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_fetch_add(&g_tacc[slot], (unsigned long long)(now - t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   t = now;
 }
 
@@ -110,7 +125,7 @@ __device__ __forceinline__ void tock(const SeqStatus &st, int slot, long &t) {
 __device__ __forceinline__ void tock_gate(const SeqStatus &st, int slot, long &t) {
   if (!st.timing) return;
   const long now = (long)wall_clock64();
-  if (blockIdx.x == 0 && threadIdx.x == 256) st.timing[slot] += (unsigned long long)(now - t);
+  if (blockIdx.x == 0 && threadIdx.x == 256) __hip_atomic_fetch_add(&g_tacc[slot], (unsigned long long)(now - t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   t = now;
 }
 
@@ -226,6 +241,7 @@ __global__ void __launch_bounds__(512) lstm_seq_fwd(aslp_lstm_seq a, SeqStatus s
   __shared__ int place_flag;
   __shared__ __attribute__((aligned(16))) float zero_lds[4];
   const long t_entry = (st.timing || st.trace) ? (long)wall_clock64() : 0;
+  timing_begin(st);
   const int SE = a.s_count > 0 ? a.s_begin + a.s_count : a.S;   // this launch's streams: [a.s_begin, SE)
   if (threadIdx.x < 4) zero_lds[threadIdx.x] = 0.f;   // (chain_role's barrier publishes it)
   const ChainRole R = chain_role(SE - a.s_begin, a.ndir, a.C, st, place, &place_flag);
@@ -463,7 +479,7 @@ __global__ void __launch_bounds__(512) lstm_seq_fwd(aslp_lstm_seq a, SeqStatus s
     tock(st, 5, tm);  // epilogue
   }
   if (st.timing && blockIdx.x == 0 && threadIdx.x == 0) {
-    st.timing[0] += (unsigned long long)T; st.timing[6] += R.local ? 1ull : 0ull;
+    timing_flush(st); st.timing[0] += (unsigned long long)T; st.timing[6] += R.local ? 1ull : 0ull;
     st.timing[7] += (unsigned long long)((long)wall_clock64() - t_entry);   // this workgroup's whole stay, entry to exit
   }
   if (st.trace && threadIdx.x == 0) {   // ring of the 8 latest launches
@@ -497,6 +513,8 @@ __global__ void __launch_bounds__(512) lstm_seq_fwd_h(aslp_lstm_seq a, SeqStatus
   __shared__ int place_flag;
   __shared__ __attribute__((aligned(16))) float zero_lds[4];
   const long t_entry = (st.timing || st.trace) ? (long)wall_clock64() : 0;
+  __builtin_amdgcn_s_setprio(3);   // a latency chain: when weight-gradient workgroups share the CU (side stream), this kernel's waves issue first
+  timing_begin(st);
   const int SE = a.s_count > 0 ? a.s_begin + a.s_count : a.S;   // this launch's streams: [a.s_begin, SE)
   if (threadIdx.x < 4) zero_lds[threadIdx.x] = 0.f;   // (chain_role's barrier publishes it)
   const ChainRole R = chain_role(SE - a.s_begin, a.ndir, a.C, st, place, &place_flag);
@@ -790,7 +808,7 @@ __global__ void __launch_bounds__(512) lstm_seq_fwd_h(aslp_lstm_seq a, SeqStatus
     tock(st, 5, tm);  // epilogue
   }
   if (st.timing && blockIdx.x == 0 && threadIdx.x == 0) {
-    st.timing[0] += (unsigned long long)T; st.timing[6] += R.local ? 1ull : 0ull;
+    timing_flush(st); st.timing[0] += (unsigned long long)T; st.timing[6] += R.local ? 1ull : 0ull;
     st.timing[7] += (unsigned long long)((long)wall_clock64() - t_entry);   // this workgroup's whole stay, entry to exit
   }
   if (st.trace && threadIdx.x == 0) {   // ring of the 8 latest launches
@@ -823,6 +841,7 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd(aslp_lstm_seq a, SeqStatus s
   __shared__ int fail[2][8];
   __shared__ int place_flag;
   const long t_entry = st.trace ? (long)wall_clock64() : 0;
+  timing_begin(st);
   const int SE = a.s_count > 0 ? a.s_begin + a.s_count : a.S;
   const ChainRole R = chain_role(SE - a.s_begin, a.ndir, a.C, st, place, &place_flag);
   if (!R.active) return;
@@ -1023,7 +1042,7 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd(aslp_lstm_seq a, SeqStatus s
       if (c0 + c < C) a.grad_partial[((long)chain * 7 + k) * a.grad_ld + c0 + c] = v;
     }
   }
-  if (st.timing && blockIdx.x == 0 && threadIdx.x == 0) { st.timing[0] += (unsigned long long)T; st.timing[6] += R.local ? 1ull : 0ull; }
+  if (st.timing && blockIdx.x == 0 && threadIdx.x == 0) { timing_flush(st); st.timing[0] += (unsigned long long)T; st.timing[6] += R.local ? 1ull : 0ull; }
   if (st.trace && threadIdx.x == 0) {   // ring of the 8 latest launches
     unsigned long long *tr = st.trace + (st.epoch & 7u) * 2048u;
     tr[2 * blockIdx.x] = (unsigned long long)t_entry; tr[2 * blockIdx.x + 1] = wall_clock64();
@@ -1046,6 +1065,8 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd_h(aslp_lstm_seq a, SeqStatus
   __shared__ int fail[2][8];
   __shared__ int place_flag;
   const long t_entry = st.trace ? (long)wall_clock64() : 0;
+  __builtin_amdgcn_s_setprio(3);   // a latency chain: when weight-gradient workgroups share the CU (side stream), this kernel's waves issue first
+  timing_begin(st);
   const int SE = a.s_count > 0 ? a.s_begin + a.s_count : a.S;
   const ChainRole R = chain_role(SE - a.s_begin, a.ndir, a.C, st, place, &place_flag);
   if (!R.active) return;
@@ -1208,9 +1229,16 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd_h(aslp_lstm_seq a, SeqStatus
       if (step > 0) {  // shares of my 16 cells, added in workgroup order
         float psum = 0.f;
         const int base = (((sl >> 2) * 2 + (sl & 1)) * 16 + cc) * 2 + ((sl & 3) >> 1);   // [row group][odd register][column][register pair] (see the publication)
-        for (int p = 0; p < wpc; p++) psum += shares[p * 128 + base];
+        // all reads first (left as a loop of read -> wait -> add the 32 LDS latencies of a pair were 0.6 us of the timestep), then the
+        // additions in workgroup order
+        float sv[8 * TPW];
+#pragma unroll
+        for (int p = 0; p < 8 * TPW; p++) sv[p] = shares[p * 128 + base];   // unconditional (a guarded read becomes a branch each): rows past wpc hold stale words, dropped below
+#pragma unroll
+        for (int p = 0; p < 8 * TPW; p++) psum += p < wpc ? sv[p] : 0.f;
         dm += psum;
       }
+      tock(st, 3, tm);  // (devtools) shares summed
       const float dh = dtanh(yh, dm * yo);
       const float dov = dsigm(yo, dm * yh);
       float dc = dh + dn_c * yn_f;
@@ -1230,8 +1258,8 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd_h(aslp_lstm_seq a, SeqStatus
       {
         // this stream's gate diffs, scaled by the power of two that puts the largest of its 16 * G in [2^13, 2^14), as two fp16 pieces
         float rmax = fmaxf(fmaxf(fabsf(dg), fabsf(df)), fmaxf(fabsf(di), fabsf(dov)));
-        rmax = fmaxf(rmax, __shfl_xor(rmax, 1)); rmax = fmaxf(rmax, __shfl_xor(rmax, 2));
-        rmax = fmaxf(rmax, __shfl_xor(rmax, 4)); rmax = fmaxf(rmax, __shfl_xor(rmax, 8));   // the 16 lanes of a stream (tid = stream * 16 + cell)
+        rmax = fmaxf(rmax, row_ror<8>(rmax)); rmax = fmaxf(rmax, row_ror<4>(rmax));
+        rmax = fmaxf(rmax, row_ror<2>(rmax)); rmax = fmaxf(rmax, row_ror<1>(rmax));   // the 16 lanes of a stream (tid = stream * 16 + cell) = one DPP row
         int e = 0;
         (void)frexpf(rmax, &e);
         const bool scaled = rmax > 0.f && rmax < 3.0e38f;
@@ -1280,7 +1308,7 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd_h(aslp_lstm_seq a, SeqStatus
       if (c0 + c < C) a.grad_partial[((long)chain * 7 + k) * a.grad_ld + c0 + c] = v;
     }
   }
-  if (st.timing && blockIdx.x == 0 && threadIdx.x == 0) { st.timing[0] += (unsigned long long)T; st.timing[6] += R.local ? 1ull : 0ull; }
+  if (st.timing && blockIdx.x == 0 && threadIdx.x == 0) { timing_flush(st); st.timing[0] += (unsigned long long)T; st.timing[6] += R.local ? 1ull : 0ull; }
   if (st.trace && threadIdx.x == 0) {   // ring of the 8 latest launches
     unsigned long long *tr = st.trace + (st.epoch & 7u) * 2048u;
     tr[2 * blockIdx.x] = (unsigned long long)t_entry; tr[2 * blockIdx.x + 1] = wall_clock64();
@@ -1360,6 +1388,7 @@ __global__ void __launch_bounds__(256, 2) lstm_seq_fwd4(aslp_lstm_seq a, SeqStat
   __shared__ int fail[2][4];
   __shared__ int place_flag;
   const long t_entry = (st.timing || st.trace) ? (long)wall_clock64() : 0;
+  timing_begin(st);
   const int SE = a.s_count > 0 ? a.s_begin + a.s_count : a.S;
   // m_lds starts as zeros and is only ever written where k < C (or k < k_first): the product reads whole rows with immediate offsets,
   // positions past C (whose B fragments are zero) included          (chain_role4's barrier publishes the zeros)
@@ -1548,7 +1577,7 @@ __global__ void __launch_bounds__(256, 2) lstm_seq_fwd4(aslp_lstm_seq a, SeqStat
     if (plog && threadIdx.x == 0 && step < 64) plog[4 * step + 3] = wall_clock64();
   }
   if (st.timing && blockIdx.x == 0 && threadIdx.x == 0) {
-    st.timing[0] += (unsigned long long)T; st.timing[6] += R.local ? 1ull : 0ull;
+    timing_flush(st); st.timing[0] += (unsigned long long)T; st.timing[6] += R.local ? 1ull : 0ull;
     st.timing[7] += (unsigned long long)((long)wall_clock64() - t_entry);
   }
   if (st.trace && threadIdx.x == 0) {
@@ -1578,6 +1607,7 @@ __global__ void __launch_bounds__(512) lstm_seq_fwd_dual(aslp_lstm_seq a, SeqSta
   __shared__ int fail[2][8];
   __shared__ int place_flag;
   const long t_entry = (st.timing || st.trace) ? (long)wall_clock64() : 0;
+  timing_begin(st);
   const int SE = a.s_count > 0 ? a.s_begin + a.s_count : a.S;
   for (int i = threadIdx.x; i < 2 * NS * MP; i += 512) (&m_lds[0][0][0])[i] = 0.f;   // read past C with zero B fragments: must be finite
   const ChainRole R = chain_role(SE - a.s_begin, a.ndir, a.C, st, place, &place_flag);   // (its barrier publishes the zeros)
@@ -1818,7 +1848,7 @@ __global__ void __launch_bounds__(512) lstm_seq_fwd_dual(aslp_lstm_seq a, SeqSta
     }
   }
   if (st.timing && blockIdx.x == 0 && threadIdx.x == 0) {
-    st.timing[0] += (unsigned long long)T; st.timing[6] += R.local ? 1ull : 0ull;
+    timing_flush(st); st.timing[0] += (unsigned long long)T; st.timing[6] += R.local ? 1ull : 0ull;
     st.timing[7] += (unsigned long long)((long)wall_clock64() - t_entry);
   }
   if (st.trace && threadIdx.x == 0) {
@@ -1839,6 +1869,7 @@ __global__ void __launch_bounds__(256, 2) lstm_seq_bwd4(aslp_lstm_seq a, SeqStat
   __shared__ int fail[2][4];
   __shared__ int place_flag;
   const long t_entry = st.trace ? (long)wall_clock64() : 0;
+  timing_begin(st);
   const int SE = a.s_count > 0 ? a.s_begin + a.s_count : a.S;
   int chain, me;
   const ChainRole R = chain_role4(SE - a.s_begin, a.ndir, a.C, st, place, &place_flag, &chain, &me);
@@ -2021,7 +2052,7 @@ __global__ void __launch_bounds__(256, 2) lstm_seq_bwd4(aslp_lstm_seq a, SeqStat
       if (c0 + c < C) a.grad_partial[((long)chain * 7 + k) * a.grad_ld + c0 + c] = v;
     }
   }
-  if (st.timing && blockIdx.x == 0 && threadIdx.x == 0) { st.timing[0] += (unsigned long long)T; st.timing[6] += R.local ? 1ull : 0ull; }
+  if (st.timing && blockIdx.x == 0 && threadIdx.x == 0) { timing_flush(st); st.timing[0] += (unsigned long long)T; st.timing[6] += R.local ? 1ull : 0ull; }
   if (st.trace && threadIdx.x == 0) {
     unsigned long long *tr = st.trace + (st.epoch & 7u) * 2048u;
     tr[2 * blockIdx.x] = (unsigned long long)t_entry; tr[2 * blockIdx.x + 1] = wall_clock64();

@@ -126,10 +126,16 @@ class Component {
   // everything on one stream -- a second active stream costs such a chain more than the overlap gives (measured on the
   // LC-BLSTM net: 7.85 ms/step on one stream, 8.61 with the output layer's weight gradient on a side stream)
   virtual bool LatencyBoundPasses() const { return false; }
+  // true for a recurrent component whose last Propagate ran its recurrence as one persistent launch (csrc/rnn_persistent.hip)
+  virtual bool PersistentRecurrence() const { return false; }
   // The executor calls this right before a Backpropagate that it follows with Update (Nnet::Backpropagate always does).
   // A component that forms its gradients inside Backpropagate may then take the SGD step there too (in the epilogue of
   // the gradient kernels) and treat the next Update call as a no-op; the default ignores the hint.
   virtual void FoldNextUpdateIntoBackprop() {}
+  // Hint in front of a Backpropagate of a component that forms its gradients there (GradientInBackprop): the executor has work below this
+  // component that does not depend on them, so they may be issued on the library's side stream (csrc/scratch.h SideStreamScope; the
+  // executor joins it at the end of the pass).  One-shot, like the fold hint; the default ignores it.
+  virtual void GradientsBesideLowerLayers() {}
   // The executor calls this right before a Backpropagate whose in-diff nobody will read (the component is fed by the network
   // input only and the caller asked for no input diff): a component that forms its gradients inside Backpropagate is still
   // called, but may leave the in-diff product out.  One-shot: taken back by the component once used; the default ignores it.

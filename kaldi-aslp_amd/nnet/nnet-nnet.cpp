@@ -202,8 +202,17 @@ void Nnet::Backpropagate(const std::vector<const CuMatrixBase *> &out_diff, std:
   for (int32 i = 0; i < N; i++) out_diff_view_[i] = &output_diff_buf_[i];
   const bool want_in_diff = (in_diff != NULL);
   bool overlap_updates = overlap_updates_;
-  for (int32 i = 0; i < N && overlap_updates; i++)
+  // Recurrent layers whose passes are launches per timestep keep everything on one stream (Component::LatencyBoundPasses).  Persistent
+  // recurrences (one launch per pass) do not: the weight gradients of the layer above then run on the side stream BESIDE the recurrence
+  // below, whose workgroups leave most of every CU idle (measured on cfg3: 3.00 -> 2.88 ms per step; the recurrence itself stretches
+  // from 190 to ~300 us while 165 us of GEMMs share its CUs, so a third of the gradient time is hidden).  A/B: ASLP_LSTM_SIDE_GRADS=0.
+  static const bool lstm_side_off = getenv("ASLP_LSTM_SIDE_GRADS") != nullptr && getenv("ASLP_LSTM_SIDE_GRADS")[0] == '0';
+  bool recurrent_net = false;
+  for (int32 i = 0; i < N; i++) {
     if (components_[i]->LatencyBoundPasses()) overlap_updates = false;
+    if (components_[i]->PersistentRecurrence()) recurrent_net = true;
+  }
+  if (recurrent_net && lstm_side_off) overlap_updates = false;
   std::vector<int32> fused_sigmoid(N, -1);   // BN index -> its folded Sigmoid
   std::vector<char> folded(N, 0);            // Sigmoids handled by their BatchNormalization
   for (int32 i = 0; i < N; i++) {
@@ -239,6 +248,7 @@ void Nnet::Backpropagate(const std::vector<const CuMatrixBase *> &out_diff, std:
         dynamic_cast<BatchNormalization *>(components_[i])->BackpropagateWithSigmoid(*in_view_[i], output_buf_[fs], output_diff_buf_[fs], target);
       } else {
         if (fuse_layers_) components_[i]->FoldNextUpdateIntoBackprop();
+        if (overlap_updates && components_[i]->PersistentRecurrence() && i != lowest_updatable) components_[i]->GradientsBesideLowerLayers();
         if (!want_in_diff && (is_input || feeds_only_input)) components_[i]->InDiffUnusedInNextBackprop();  // here for its gradients only
         components_[i]->Backpropagate(*in_view_[i], *out_view_[i], output_diff_buf_[i], target);
       }

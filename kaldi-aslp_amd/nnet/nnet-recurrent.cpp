@@ -589,6 +589,7 @@ void LstmFamily::PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) {
     const int per_launch = 64 / q.ndir, nwin = (S + per_launch - 1) / per_launch;
     if (nwin > 1) q.s_count = per_launch;
     const bool persistent = aslp_lstm_seq_supported(&q, 0) != 0;
+    last_persistent_ = persistent;
     if (cfg_.bidir) LstmDir::ForwardPreparePair(f_, b_, in, T, S, carried ? &prev_state_ : nullptr, &f_buf_, &b_buf_, persistent);
     else f_.ForwardPrepare(in, T, S, false, carried ? &prev_state_ : nullptr, &f_buf_, persistent);
     // The carried history holds r(0) = m(0) W_rm^T formed with the weights of the PREVIOUS batch (the reference
@@ -746,13 +747,26 @@ void LstmFamily::BackpropagateFnc(const CuMatrixBase &in, const CuMatrixBase &, 
     f_.Backward(CuSubMatrix(out_diff, 0, T * S, 0, rec), T, S, false, f_buf_, &f_dbuf_, in_diff, 0.0);
     if (cfg_.bidir) b_.Backward(CuSubMatrix(out_diff, 0, T * S, rec, rec), T, S, true, b_buf_, &b_dbuf_, in_diff, 1.0);
   }
-  const BaseFloat lr_fold = TakeFoldHint() ? opts_.learn_rate : 0.0f;
+  const bool folded = TakeFoldHint();
+  const BaseFloat lr_fold = folded ? opts_.learn_rate : 0.0f;
   const aslp_lstm_seq *seq = vec_seq_valid_ ? &vec_seq_ : nullptr;
   vec_seq_valid_ = false;
-  if (cfg_.bidir && f_.FusedOk()) LstmDir::GradsPair(f_, b_, in, T, S, f_buf_, b_buf_, f_dbuf_, b_dbuf_, mmt, clip_gradient_, lr_fold, seq);
-  else {
-    f_.Grads(in, T, S, false, f_buf_, f_dbuf_, mmt, clip_gradient_, lr_fold, seq, 0);
-    if (cfg_.bidir) b_.Grads(in, T, S, true, b_buf_, b_dbuf_, mmt, clip_gradient_, lr_fold, seq, 1);
+  auto grads = [&]() {
+    if (cfg_.bidir && f_.FusedOk()) LstmDir::GradsPair(f_, b_, in, T, S, f_buf_, b_buf_, f_dbuf_, b_dbuf_, mmt, clip_gradient_, lr_fold, seq);
+    else {
+      f_.Grads(in, T, S, false, f_buf_, f_dbuf_, mmt, clip_gradient_, lr_fold, seq, 0);
+      if (cfg_.bidir) b_.Grads(in, T, S, true, b_buf_, b_dbuf_, mmt, clip_gradient_, lr_fold, seq, 1);
+    }
+  };
+  // The weight gradients (and their folded SGD steps) read this layer's activations and diffs only: with layers below, the executor lets them
+  // run on the side stream, where their workgroups share the CUs with the NEXT layer's persistent recurrence -- a latency chain that leaves
+  // the CU's issue slots, LDS and registers mostly idle.  Everything they write (corr, W) is next read after the executor's join.
+  // (Only with the SGD step folded into them: a separate Update() would follow on the main stream and read corr too early.)
+  if (TakeGradsAside() && folded) {
+    SideStreamScope aside;
+    grads();
+  } else {
+    grads();
   }
 }
 

@@ -27,6 +27,7 @@ class RecurrentBase : public UpdatableComponent {
   bool LatencyBoundPasses() const { return true; }
   void InDiffUnusedInNextBackprop() { in_diff_unused_ = true; }
   void FoldNextUpdateIntoBackprop() { fold_update_ = CanFoldUpdate(); }
+  void GradientsBesideLowerLayers() { grads_aside_ = true; }
   virtual bool HasStreamReset() const { return false; }   // answers Nnet::ResetLstmStreams (nnet-nnet.cc:473-496)
   virtual bool HasSeqLengths() const { return false; }    // answers Nnet::SetSeqLengths   (nnet-nnet.cc:498-530)
   virtual void ResetLstmStreams(const std::vector<int32> &) {}
@@ -42,8 +43,9 @@ class RecurrentBase : public UpdatableComponent {
   bool fold_update_ = false, update_done_ = false;
  protected:
   bool TakeInDiffUnused() { const bool v = in_diff_unused_; in_diff_unused_ = false; return v; }
+  bool TakeGradsAside() { const bool v = grads_aside_; grads_aside_ = false; return v; }
  private:
-  bool in_diff_unused_ = false;
+  bool in_diff_unused_ = false, grads_aside_ = false;
 };
 
 struct LstmDir {
@@ -146,6 +148,9 @@ class LstmFamily : public RecurrentBase {
   void GetGpuParams(std::vector<std::pair<BaseFloat *, int>> *params);
   std::string Info() const;
 
+  // a pass of launches per timestep is a chain of tiny dependent kernels (see Component::LatencyBoundPasses); one persistent launch is not
+  bool LatencyBoundPasses() const { return !last_persistent_; }
+  bool PersistentRecurrence() const { return last_persistent_; }
   bool HasStreamReset() const { return cfg_.stream_reset; }
   bool HasSeqLengths() const { return cfg_.seq_lengths; }
   void ResetLstmStreams(const std::vector<int32> &stream_reset_flag);
@@ -169,6 +174,7 @@ class LstmFamily : public RecurrentBase {
   std::vector<int32> sequence_lengths_; // BLstm* masking
   CuArray<int32> seq_len_dev_;
   CuMatrix f_buf_, b_buf_, f_dbuf_, b_dbuf_;
+  bool last_persistent_ = false;   // the last Propagate ran the recurrence as ONE persistent launch (else: launches per timestep)
   CuMatrix grad_partial_;          // per-chain bias / peephole gradient sums of the persistent backward launch (aslp_lstm_seq.grad_partial)
   aslp_lstm_seq vec_seq_ = aslp_lstm_seq();   // that launch's arguments, for aslp_lstm_seq_vec_grads
   bool vec_seq_valid_ = false;
