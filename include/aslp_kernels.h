@@ -190,6 +190,11 @@ typedef struct aslp_gemm_epilogue_ {
   const float *c_src;  /* [M x N], leading dimension ld_c_src, or NULL */
   int ld_c_src;
 } aslp_gemm_epilogue;
+/* Large products of aslp_sgemm_ex on the fp16 matrix instruction with each fp32 operand carried as two fp16 pieces behind a power-of-two
+ * scale of its matrix (csrc/gemm_split16.hip: 22 significant bits, fp32 accumulation; results agree with the fp32 instruction's to fp32
+ * rounding).  on = 1 / 0 switches it for this process, -1 hands the choice back to ASLP_GEMM_SPLIT_F16 (default off).  No reference
+ * counterpart (cuBLAS sgemm on fp32 CUDA cores). */
+void aslp_gemm_split16(int on);
 int aslp_sgemm_ex(int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda,
                   const float *B, int ldb, float beta, float *C, int ldc, const aslp_gemm_epilogue *ep);
 /* Two products of the same shape, leading dimensions, alpha and beta in ONE launch: C0 = alpha op(A0) op(B0) + beta C0 (+ ep0),

@@ -758,7 +758,11 @@ int aslp_sgemm_ex(int transA, int transB, int M, int N, int K, float alpha, cons
     e1 = take_event();
   }
   if (prof) (void)hipEventRecord(e0, cur_stream());
-  if (!transA && transB) launch_aligned<true, true>(g);
+  static const int s16_cfg = [] { const char *e = getenv("ASLP_GEMM_SPLIT_F16_TILE"); return e ? atoi(e) : 0; }();
+  if (gemm_split16_enabled() && !g_force_tile && gemm_split16_launch(g, !transA, transB != 0, s16_cfg)) {   // (a forced tile asks for an fp32 kernel by name)
+    g.ep.colstats = nullptr;   // formed in its epilogue; column sums (if asked for) by the pass over A below
+    t_last_cfg = 311;
+  } else if (!transA && transB) launch_aligned<true, true>(g);
   else if (!transA && !transB) launch_aligned<true, false>(g);
   else if (transA && !transB) launch_aligned<false, false>(g);
   else launch_aligned<false, true>(g);

@@ -1061,7 +1061,8 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd_h(aslp_lstm_seq a, SeqStatus
   constexpr int AP = 64 + 8;   // halves per operand row: K = the workgroup's own 16 * G gate columns (two chunks of 32; CIFG leaves 16 zeros)
   __shared__ __attribute__((aligned(16))) _Float16 a_h[2][16][AP];        // [parity][rows 0..7 = dG_hi of stream r, 8..15 = dG_lo' of stream r - 8][gate * 16 + cell]
   __shared__ __attribute__((aligned(16))) float row_inv[2][kChainStreams];   // [parity][stream]: 1 / (the power of two its gate diffs were scaled by)
-  __shared__ __attribute__((aligned(16))) float shares[kMaxWgPerChain * 2 * 16 * 4];     // [producer][row group][column][row]
+  __shared__ __attribute__((aligned(16))) float dmsum[128];   // the chain's shares of this workgroup's 8 x 16 d_m values, summed (layout of one producer block)
+  __shared__ float shares[kChainStreams * 7 * 16];              // scratch of the final bias / peephole reduction
   __shared__ int fail[2][8];
   __shared__ int place_flag;
   const long t_entry = st.trace ? (long)wall_clock64() : 0;
@@ -1185,11 +1186,15 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd_h(aslp_lstm_seq a, SeqStatus
         }
       }
       tock(st, 1, tm);  // product + publication
-      // 3. collect what the chain's workgroups sent me: pieces tid and tid + 512 of [producer][row group][column]
+      // 3. collect what the chain's workgroups sent me AND add it up on the way: a producer block is 32 pieces of 16 bytes; wave w takes
+      // pieces 4 w .. 4 w + 3, one per row of 16 lanes, lane j of the row producers j and j + 16.  The row's 16 partial sums meet in lane 0
+      // over four DPP row shifts (a fixed tree: deterministic), which writes the piece's total to LDS -- the gate-diff threads then read ONE
+      // value each instead of adding 32 (that loop was 0.55 us of the timestep, on two waves while six waited).
       {
         const __amdgpu_buffer_rsrc_t rs = make_rsrc(box + (size_t)me * kMaxWgPerChain * 128);
-        const int i0 = threadIdx.x, i1 = threadIdx.x + 512;
-        const bool h0 = i0 < npiece, h1 = i1 < npiece;
+        const int q = 4 * wave + (lane >> 4), pa = lane & 15, pb = pa + 16;
+        const int i0 = pa * 32 + q, i1 = pb * 32 + q;
+        const bool h0 = pa < wpc, h1 = pb < wpc;
         u32x4 v0 = {0u, 0u, 0u, 0u}, v1 = {0u, 0u, 0u, 0u};
         long t0 = 0;
         for (unsigned spins = 0;; spins++) {
@@ -1210,8 +1215,14 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd_h(aslp_lstm_seq a, SeqStatus
           if (h0) __builtin_amdgcn_raw_buffer_store_b128(sent, rs, i0 * 16, 0, kAuxSc1);
           if (h1) __builtin_amdgcn_raw_buffer_store_b128(sent, rs, i1 * 16, 0, kAuxSc1);
         }
-        if (h0) *reinterpret_cast<u32x4 *>(&shares[i0 * 4]) = v0;
-        if (h1) *reinterpret_cast<u32x4 *>(&shares[i1 * 4]) = v1;
+        f32x4 sum;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          float x = (h0 ? as_f(v0[c]) : 0.f) + (h1 ? as_f(v1[c]) : 0.f);
+          x += row_up<8>(x); x += row_up<4>(x); x += row_up<2>(x); x += row_up<1>(x);   // lane 0 of the row: all 16 lanes' values
+          sum[c] = x;
+        }
+        if ((lane & 15) == 0) *reinterpret_cast<f32x4 *>(&dmsum[4 * q]) = sum;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       tock(st, 2, tm);  // collection
@@ -1226,18 +1237,8 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd_h(aslp_lstm_seq a, SeqStatus
       if (f) return;
     }
     if (threadIdx.x < 128) {
-      if (step > 0) {  // shares of my 16 cells, added in workgroup order
-        float psum = 0.f;
-        const int base = (((sl >> 2) * 2 + (sl & 1)) * 16 + cc) * 2 + ((sl & 3) >> 1);   // [row group][odd register][column][register pair] (see the publication)
-        // all reads first (left as a loop of read -> wait -> add the 32 LDS latencies of a pair were 0.6 us of the timestep), then the
-        // additions in workgroup order
-        float sv[8 * TPW];
-#pragma unroll
-        for (int p = 0; p < 8 * TPW; p++) sv[p] = shares[p * 128 + base];   // unconditional (a guarded read becomes a branch each): rows past wpc hold stale words, dropped below
-#pragma unroll
-        for (int p = 0; p < 8 * TPW; p++) psum += p < wpc ? sv[p] : 0.f;
-        dm += psum;
-      }
+      if (step > 0)   // the chain's shares of this pair, already added up: [row group][odd register][column][register pair] (see the publication)
+        dm += dmsum[(((sl >> 2) * 2 + (sl & 1)) * 16 + cc) * 2 + ((sl & 3) >> 1)];
       tock(st, 3, tm);  // (devtools) shares summed
       const float dh = dtanh(yh, dm * yo);
       const float dov = dsigm(yo, dm * yh);

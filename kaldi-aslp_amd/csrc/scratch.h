@@ -2,7 +2,7 @@
 #pragma once
 #include <stddef.h>
 namespace aslp {
-enum { kScratchReduce = 0, kScratchReduce2 = 1, kScratchGemm = 2, kScratchCtc = 3, kScratchMisc = 4, kScratchSplitK = 5, kNumScratch = 6 };
+enum { kScratchReduce = 0, kScratchReduce2 = 1, kScratchGemm = 2, kScratchCtc = 3, kScratchMisc = 4, kScratchSplitK = 5, kScratchSplit16 = 6, kNumScratch = 7 };
 // Scratch of the calling thread's current stream: the side stream has its own bank, so ops running there never
 // share a partial-sum buffer with ops on the main stream.
 void *scratch(int slot, size_t bytes);

@@ -1,0 +1,143 @@
+"""csrc/gemm_split16.hip: aslp_sgemm_ex on the fp16 matrix instruction with every fp32 operand carried as two fp16 pieces behind a
+power-of-two scale of its matrix (aslp_gemm_split16(1) / ASLP_GEMM_SPLIT_F16=1; default off).  The claim is fp32 accuracy, so the bar is
+the fp32-instruction kernels' own: against a float64 product the error relative to sum |a||b| must not exceed theirs by more than
+rounding noise, at any magnitude of the operands, in every operand layout, with every epilogue feature, on ragged sizes."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def split_off_afterwards(aslp):
+    yield
+    aslp.lib.aslp_gemm_split16(-1)
+
+
+def products(aslp, tA, tB, A, B, alpha=1.0, beta=0.0, C0=None, ep=None):
+    out = []
+    for on in (0, 1):
+        aslp.lib.aslp_gemm_split16(on)
+        C = C0.clone() if C0 is not None else torch.zeros((A.shape[1] if tA else A.shape[0]), (B.shape[0] if tB else B.shape[1]), device=A.device)
+        aslp.ops.sgemm(tA, tB, alpha, A, B, beta, C, ep(on) if ep else None)
+        if on:
+            assert aslp.lib.aslp_gemm_last_tile() == 311      # the split kernel really ran
+        out.append(C)
+    aslp.lib.aslp_gemm_split16(-1)
+    return out
+
+
+def err_vs_double(C, A, B, tA, tB):
+    opA, opB = (A.t() if tA else A).double(), (B.t() if tB else B).double()
+    return (((C.double() - opA @ opB).abs()) / (opA.abs() @ opB.abs())).max().item()
+
+
+@pytest.mark.parametrize("tA,tB,M,N,K", [(0, 1, 1024, 2048, 2048), (0, 0, 1024, 2048, 2048), (1, 0, 2048, 2048, 1024), (1, 1, 512, 640, 768),
+                                         (0, 1, 1000, 3000, 440), (1, 0, 3000, 2048, 1024), (0, 0, 132, 260, 68), (1, 0, 436, 128, 2052)])
+def test_as_accurate_as_the_fp32_instruction(aslp, dev, tA, tB, M, N, K):
+    g = torch.Generator(device=dev).manual_seed(M + 3 * N + 7 * K)
+    A = torch.randn((K, M) if tA else (M, K), device=dev, generator=g)
+    B = torch.randn((N, K) if tB else (K, N), device=dev, generator=g)
+    c32, c16 = products(aslp, tA, tB, A, B)
+    e32, e16 = err_vs_double(c32, A, B, tA, tB), err_vs_double(c16, A, B, tA, tB)
+    assert e16 <= max(e32, 2.5e-7), (e16, e32)          # measured: 1.0-1.4e-7 against 3-4e-7 of the fp32 instruction
+    assert ((c16 - c32).norm() / c32.norm()).item() < 1e-6
+    # bit-reproducible run to run (no atomics anywhere: two-level maximum, fixed summation order)
+    aslp.lib.aslp_gemm_split16(1)
+    again = torch.zeros_like(c16)
+    aslp.ops.sgemm(tA, tB, 1.0, A, B, 0.0, again)
+    assert torch.equal(again, c16)
+
+
+@pytest.mark.parametrize("sa,sb", [(1e-12, 1.0), (1e-30, 1e8), (3e4, 2e-20), (1e15, 1e-15), (1.0, 1e-38)])
+def test_any_magnitude(aslp, dev, sa, sb):
+    """gradients of 1e-12, weights of 1e8, operands near the ends of fp32's range: the per-matrix power-of-two scale takes the magnitude out;
+    rows a million times smaller than the matrix's largest keep their own 22 bits (fp16 is normal over 29 binades)"""
+    g = torch.Generator(device=dev).manual_seed(11)
+    A = torch.randn(512, 1024, device=dev, generator=g) * sa
+    B = torch.randn(768, 1024, device=dev, generator=g) * sb
+    A[5] *= 1e-6
+    A[7, ::2] *= 3e-5
+    B[9] *= 1e-7
+    c32, c16 = products(aslp, 0, 1, A, B)
+    assert torch.isfinite(c16).all()
+    e32, e16 = err_vs_double(c32, A, B, 0, 1), err_vs_double(c16, A, B, 0, 1)
+    assert e16 <= max(e32, 2.5e-7), (e16, e32)
+
+
+def test_zero_and_nonfinite_operands(aslp, dev):
+    A = torch.zeros(256, 512, device=dev)
+    B = torch.randn(384, 512, device=dev)
+    _, c16 = products(aslp, 0, 1, A, B)
+    assert (c16 == 0).all()
+    A[3, 4] = float("inf")
+    A[9, 1] = float("nan")
+    A[20:] = torch.randn(236, 512, device=dev)
+    c32, c16 = products(aslp, 0, 1, A, B)
+    assert torch.isnan(c16[9]).all() and not torch.isfinite(c16[3]).any()        # what the fp32 kernel gives for those rows
+    ok = torch.ones(256, dtype=torch.bool, device=dev)
+    ok[3] = ok[9] = False
+    assert torch.isfinite(c16[ok]).all() and ((c16[ok] - c32[ok]).norm() / c32[ok].norm()).item() < 1e-6
+
+
+@pytest.mark.parametrize("tA,tB,M,N,K,mmt", [(1, 0, 2048, 2048, 1024, 0.9), (1, 0, 3000, 2048, 1024, 0.0), (0, 1, 2048, 2048, 1024, 0.5), (0, 0, 1984, 2176, 640, 0.9)])
+def test_full_epilogue(aslp, dev, tA, tB, M, N, K, mmt):
+    """momentum on the gradient buffer, clip, W += -lr G, bias gradient + bias step from the column sums (tests/test_fullsize_gpu.py's case)"""
+    g = torch.Generator(device=dev).manual_seed(M + N + K)
+    A = torch.randn((K, M) if tA else (M, K), device=dev, generator=g)
+    B = torch.randn((N, K) if tB else (K, N), device=dev, generator=g)
+    G0 = torch.randn(M, N, device=dev, generator=g)
+    W0 = torch.randn(M, N, device=dev, generator=g)
+    bc0, b0 = torch.randn(M, device=dev, generator=g), torch.randn(M, device=dev, generator=g)
+    clip, lr = 60.0, -0.01
+    res = []
+    for on in (0, 1):
+        Gd, Wd, bc, b = G0.clone(), W0.clone(), bc0.clone(), b0.clone()
+        ep = (aslp._lib.GemmEpilogue(None, clip, Wd.data_ptr(), N, lr, None, 0, 0, bc.data_ptr(), 0.9, b.data_ptr(), -0.02) if tA else
+              aslp._lib.GemmEpilogue(None, clip, Wd.data_ptr(), N, lr, None, 0, 0))
+        aslp.lib.aslp_gemm_split16(on)
+        aslp.ops.sgemm(tA, tB, 1.0, A, B, mmt, Gd, ep)
+        res.append((Gd, Wd, bc, b))
+    aslp.lib.aslp_gemm_split16(-1)
+    opA, opB = (A.t() if tA else A).double(), (B.t() if tB else B).double()
+    Gref = (opA @ opB + mmt * G0.double()).clamp(-clip, clip)
+    rel = lambda x, r: ((x.double() - r).norm() / r.norm()).item()
+    Gd, Wd, bc, b = res[1]
+    assert rel(Gd, Gref) < 2e-6 and rel(Wd, W0.double() + lr * Gref) < 2e-6
+    if tA:
+        bc_ref = A.double().sum(0) + 0.9 * bc0.double()
+        assert rel(bc, bc_ref) < 2e-6 and rel(b, b0.double() - 0.02 * bc_ref) < 2e-6
+        assert rel(bc, res[0][2].double()) < 1e-6      # (column sums: a plain fp32 pass over A here, folded into the fp32 kernel's K loop there)
+    assert rel(Gd, res[0][0].double()) < 1e-6
+
+
+def test_cfg2_training_steps_agree(aslp, dev):
+    """five training steps of a 3 x 1024 sigmoid DNN + BatchNorm at minibatch 1024 with the products on either instruction: the losses agree like
+    two fp32 summation orders do"""
+    proto = "<NnetProto>\n"
+    d = 440
+    for _ in range(3):
+        proto += "<AffineTransform> <InputDim> %d <OutputDim> 1024 <BiasMean> -2.0 <BiasRange> 4.0 <ParamStddev> 0.05\n" % d
+        proto += "<BatchNormalization> <InputDim> 1024 <OutputDim> 1024\n<Sigmoid> <InputDim> 1024 <OutputDim> 1024\n"
+        d = 1024
+    proto += "<AffineTransform> <InputDim> 1024 <OutputDim> 3000 <BiasMean> 0.0 <BiasRange> 0.0 <ParamStddev> 0.05\n<Softmax> <InputDim> 3000 <OutputDim> 3000\n</NnetProto>\n"
+    losses = []
+    for on in (0, 1):
+        aslp.lib.aslp_gemm_split16(on)
+        net = aslp.Nnet.Init(proto, seed=3)
+        net.SetTrainOptions(learn_rate=1e-3, momentum=0.9)
+        xe = aslp.Xent()
+        g = torch.Generator(device="cpu").manual_seed(5)
+        for step in range(5):
+            x = torch.randn(1024, 440, generator=g).to(dev)
+            lab = torch.randint(0, 3000, (1024,), generator=g, dtype=torch.int32).to(dev)
+            net.TrainStepXent(xe, x, lab, torch.ones(1024, device=dev))
+        st = xe.GetStats()
+        losses.append((st["loss"] - st["entropy"]) / st["frames"])
+        params = np.asarray(net.GetParams(), np.float32)
+        losses.append(params)
+    aslp.lib.aslp_gemm_split16(-1)
+    l32, p32, l16, p16 = losses
+    assert abs(l16 - l32) < 2e-6 * abs(l32), (l16, l32)
+    assert np.linalg.norm(p16 - p32) < 2e-6 * np.linalg.norm(p32)
