@@ -314,6 +314,50 @@ def cfg1_gpu_block(aslp, dev):
             "avg_xent_per_frame": (st["loss"] - st["entropy"]) / max(st["frames"], 1.0)}
 
 
+def cfg2_split_f16_block(aslp, dev, value_fp32):
+    """Extra key `cfg2_split_f16` (N = 1), NOT the headline: the same cfg2 step with the large products on the fp16 matrix instruction and every
+    fp32 operand carried as two fp16 pieces behind a power-of-two scale of its matrix (csrc/gemm_split16.hip, switched with aslp_gemm_split16;
+    default off).  Reported with its accuracy beside it -- error of one layer product against float64 for both instructions -- so that the
+    reader can judge whether it may become the default: operands and results are fp32, the 22-bit pieces multiply exactly, accumulation is
+    fp32, and the product is CLOSER to the float64 one than the fp32 instruction's."""
+    import torch
+    net = aslp.Nnet.Init(proto(), seed=777)
+    net.SetTrainOptions(learn_rate=1e-5, momentum=0.9)
+    xent = aslp.Xent()
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234)
+    x = torch.randn(MB, IN_DIM, device=dev, generator=g)
+    labels = torch.randint(0, OUT_DIM, (MB,), device=dev, generator=g, dtype=torch.int32)
+    out = {"workload": "cfg2 step as in `config`, products through aslp_gemm_split16(1)", "steps": 300, "warmup": 100}
+    try:
+        aslp.lib.aslp_gemm_split16(1)
+        for _ in range(100):
+            net.TrainStepXent(xent, x, labels)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(300):
+            net.TrainStepXent(xent, x, labels)
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / 300
+        st = xent.GetStats()
+        out.update(ms_per_step=el * 1e3, frames_per_sec=MB / el, vs_fp32_instruction=MB / el / value_fp32,
+                   algorithmic_tflops=FLOP_PER_FRAME * MB / el / 1e12, avg_xent_per_frame=(st["loss"] - st["entropy"]) / max(st["frames"], 1.0))
+        # accuracy of one hidden-layer product (1024 x 2048 x 2048, NT) on either instruction against float64: max |error| / sum |a||b|
+        A = torch.randn(MB, HID, device=dev, generator=g)
+        B = torch.randn(HID, HID, device=dev, generator=g)
+        ref = A.double() @ B.double().t()
+        mag = A.double().abs() @ B.double().abs().t()
+        for name, on in (("fp32_instruction", 0), ("split_f16", 1)):
+            aslp.lib.aslp_gemm_split16(on)
+            C = torch.zeros(MB, HID, device=dev)
+            aslp.ops.sgemm(0, 1, 1.0, A, B, 0.0, C)
+            out["layer_product_max_err_over_sum_abs_" + name] = ((C.double() - ref).abs() / mag).max().item()
+    finally:
+        aslp.lib.aslp_gemm_split16(-1)
+    out["instruction"] = "v_mfma_f32_32x32x16_f16, 3 per 16-wide k step (hi hi, hi lo', lo' hi), fp32 accumulate; dense fp16 peak 2516 TFLOP/s"
+    return out
+
+
 def e2e_tool_block(frames=1024000):
     """SURVEY 8(d) asks for the end-to-end figure beside the compute-only one (extra key `e2e_tool`, N = 1): the cfg2 net trained by the
     command-line tool itself -- aslp-nnet-init, then aslp-nnet-train-frame reading a feature archive and a posterior archive (page
@@ -674,6 +718,7 @@ def main():
             out["cfg3"] = cfg3_block(aslp, dev)
             out["recurrent_layers"] = recurrent_family_block(aslp, dev)
             out["cfg1_gpu"] = cfg1_gpu_block(aslp, dev)
+            out["cfg2_split_f16"] = cfg2_split_f16_block(aslp, dev, value)
         if world == 1 and not args.no_e2e_tool:
             out["e2e_tool"] = e2e_tool_block(args.e2e_frames)
             if "frames_per_sec" in out["e2e_tool"]:

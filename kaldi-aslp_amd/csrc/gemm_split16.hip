@@ -354,8 +354,9 @@ bool gemm_split16_launch(GemmArgs &g, bool a_kc, bool b_kc, int cfg) {
   ConvJob ca = {g.A, ma.rows, ma.cols, g.lda, ah, al, kp, a_kc ? 0 : 1}, cb = {g.B, mb.rows, mb.cols, g.ldb, bh, bl, kp, b_kc ? 0 : 1};
   hipLaunchKernelGGL(split16_convert_kernel, dim3(256, 4, 2), dim3(256), 0, cur_stream(), ca, cb, part, kMaxParts, slots);
   S16Planes pl = {ah, al, bh, bl, kp, slots};
+  if (cfg == 0)   // 128 x 128 where that still gives every CU a workgroup, else 64 x 128 (measured: 1024 x 2048 x 2048 52 against 70 us per call)
+    cfg = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) >= 224 ? 311 : 308;
   switch (cfg) {
-    case 0:
     case 311: launch_s16<128, 128, 2, 2, 2>(g, pl); break;
     case 312: launch_s16<128, 128, 2, 4, 2>(g, pl); break;
     case 308: launch_s16<64, 128, 2, 2, 3>(g, pl); break;
