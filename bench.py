@@ -190,7 +190,10 @@ def cfg3_block(aslp, dev):
     g.manual_seed(4321)
     out = {"model": "4 x BLstmProjectedStreamsLC (C 512, R 256, in 40) + AffineTransform 512->128", "streams": S, "dtype": "f32",
            "flop_per_row": LC_FLOP_PER_ROW, "peak_tflops": F32_MFMA_PEAK_TFLOPS,
-           "recurrence": "persistent kernels, one launch per layer and pass (csrc/rnn_persistent.hip)"}
+           "recurrence": "persistent kernels, one launch per layer and pass (csrc/rnn_persistent.hip); their products on v_mfma_f32_16x16x32_f16 "
+                         "with every fp32 operand as two fp16 pieces behind power-of-two scales, fp32 accumulation (error below an fp32 fma chain's: "
+                         "devtools/micro/f16_split.hip; ASLP_LSTM_SPLIT_F16=0 = the fp32 instruction); weight gradients on the side stream beside the "
+                         "recurrence below (ASLP_LSTM_SIDE_GRADS=0 = one stream)"}
     # (i) chunked + Xent
     T = CHUNK + RIGHT
     net = aslp.Nnet.Init(proto(True), seed=777)

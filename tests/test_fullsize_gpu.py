@@ -157,6 +157,7 @@ def test_weight_gradient_gemm_with_full_epilogue(aslp, dev, tA, tB, M, N, K, mmt
     b0 = torch.randn(M, device=dev, generator=g)
     clip, lr = 60.0, -0.01
     outs = []
+    aslp.lib.aslp_gemm_split16(0)   # this test is about the fp32-instruction kernels (ASLP_GEMM_SPLIT_F16=1 in the environment would take the unforced call)
     for force in (0, 212, 213, 207):
         Gd, Wd, bc, b = G0.clone(), W0.clone(), bc0.clone(), b0.clone()
         if tA:
@@ -171,6 +172,7 @@ def test_weight_gradient_gemm_with_full_epilogue(aslp, dev, tA, tB, M, N, K, mmt
         if force:
             assert aslp.lib.aslp_gemm_last_tile() == force
         outs.append((Gd, Wd, bc, b))
+    aslp.lib.aslp_gemm_split16(-1)
     opA, opB = (A.t() if tA else A).double(), (B.t() if tB else B).double()
     Gref = (opA @ opB + mmt * G0.double()).clamp(-clip, clip)
     assert (Gref.abs() == clip).any() and (Gref.abs() < clip).any()
