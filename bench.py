@@ -216,6 +216,15 @@ def cfg3_block(aslp, dev):
                            "valid_frames_per_sec": CHUNK * S / el, "tflops": tf, "frac_of_mfma_peak": tf / F32_MFMA_PEAK_TFLOPS,
                            "recurrence_ms_per_step": rec, "recurrence_share": rec / (el * 1e3),
                            "recurrent_launches_per_layer_per_pass": 1}
+    # the same step with the recurrent products on the fp32 matrix instruction (aslp_lstm_split16(0)): beside the default, for the reader who
+    # wants the figure without fp16 multiplies anywhere
+    try:
+        aslp.lib.aslp_lstm_split16(0)
+        el32, _ = timed(step_x, 5, 30, 0, ())
+        out["chunked_xent"]["fp32_instruction_recurrence"] = {"ms_per_step": el32 * 1e3, "valid_frames_per_sec": CHUNK * S / el32,
+                                                              "frac_of_mfma_peak": LC_FLOP_PER_ROW * T * S / el32 / 1e12 / F32_MFMA_PEAK_TFLOPS}
+    finally:
+        aslp.lib.aslp_lstm_split16(-1)
     del net
     # (ii) whole utterances + Warp-CTC
     rng = np.random.default_rng(99)

@@ -380,6 +380,10 @@ int aslp_lstm_seq_supported(const aslp_lstm_seq *a, int backward);
  * beside each other (they would wait for each other's unscheduled workgroups until the spin limit).  Same as ASLP_DEVICE_SHARED=1.  Default off.
  * No reference counterpart: the reference's per-timestep kernels need no co-residency. */
 void aslp_device_shared(int on);
+/* The persistent LSTM recurrences multiply on v_mfma_f32_16x16x32_f16 with every fp32 operand carried as two fp16 pieces behind power-of-two
+ * scales (the default: closer to a float64 product than an fp32 fma chain, csrc/rnn_persistent.hip lstm_seq_fwd_h / lstm_seq_bwd_h).  on = 0
+ * puts them on the fp32 instruction v_mfma_f32_4x4x1 (lstm_seq_fwd / lstm_seq_bwd), 1 back, -1 hands the choice to ASLP_LSTM_SPLIT_F16. */
+void aslp_lstm_split16(int on);
 int aslp_lstm_seq_first_product_supported(int k_first);
 int aslp_lstm_seq_first_product_supported_for(int k_first, int C);   /* ... in a layer of C cells (the staging row is 128 floats for C <= 128) */
 /* Streams per chain the launch for these arguments uses: 8 (one 512-thread workgroup per CU) or 4 (half chains: two 256-thread workgroups

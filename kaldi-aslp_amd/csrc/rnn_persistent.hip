@@ -2510,9 +2510,10 @@ SeqKernel pick_fwd(bool cifg, int C) {
   return nullptr;
 }
 // product on fp16 matrix instructions with two-piece fp32-equivalent operands (lstm_seq_fwd_h): A/B switch ASLP_LSTM_SPLIT_F16
+int g_lstm_split_override = -1;   // aslp_lstm_split16(): -1 = the environment decides
 bool split_f16_on() {   // default on; ASLP_LSTM_SPLIT_F16=0 puts the recurrent products back on the fp32 instruction (lstm_seq_fwd / lstm_seq_bwd)
   static const bool off = getenv("ASLP_LSTM_SPLIT_F16") != nullptr && getenv("ASLP_LSTM_SPLIT_F16")[0] == '0';
-  return !off;
+  return g_lstm_split_override >= 0 ? g_lstm_split_override != 0 : !off;
 }
 SeqKernel pick_fwd_h(bool cifg, int C) {
   if (fast_act()) {
@@ -2647,6 +2648,7 @@ int aslp_lstm_seq_supported(const aslp_lstm_seq *a, int backward) {
 }
 
 void aslp_device_shared(int on) { device_gate().on = on != 0; }
+void aslp_lstm_split16(int on) { g_lstm_split_override = on < 0 ? -1 : (on != 0); }
 
 int aslp_lstm_seq_first_product_supported(int k_first) { return k_first > 0 && k_first <= kFirstK && (k_first & 3) == 0; }
 // ... for a layer of C cells: the kernels stage r(0) in LDS rows as long as the K range of their instantiation (128 floats for C <= 128, else 512)
