@@ -355,3 +355,44 @@ def test_gru_persistent_long_sequence_and_reset_pattern(aslp, oracle, dev, tmp_p
         assert oracle.rel_err(idf, idf_ref) < TOL, ("in_diff", step)
         assert oracle.rel_err(idf[:S], idf_ref[:S]) < 5 * TOL, ("first frame's in_diff", step)
         assert oracle.rel_err(net.GetParams(), p.flat()) < TOL, ("params", step)
+
+
+def test_recurrent_products_against_float64(aslp, oracle, dev, tmp_path):
+    """How far is each way of multiplying in the persistent recurrence from the truth?  One LstmProjectedStreams layer at cfg3's size (C = 512,
+    R = 256, T = 60, S = 32) against the same recurrence in float64 (numpy; nnet-lstm-projected-streams.h:286-352 written out): the default kernels
+    (v_mfma_f32_16x16x32_f16, every fp32 operand as two fp16 pieces), the fp32-instruction kernels (aslp_lstm_split16(0)) and the oracle's fp32 C
+    code.  All three sit at fp32 rounding level; the two-piece products must not be further from float64 than the fp32 instruction's."""
+    D, Cc, R, T, S = 40, 512, 256, 60, 32
+    marker = "<LstmProjectedStreams>"
+    dirs, _, out_dim, path = build(oracle, tmp_path, marker, D, Cc, R, 5.0, seed=21, scale=0.05)
+    d = dirs[0]
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((T * S, D)).astype(np.float32)
+    f8 = np.float64
+    wx, wr, b, wrm = d.w_x.astype(f8), d.w_r.astype(f8), d.bias.astype(f8), d.w_rm.astype(f8)
+    pi, pf, po = d.peep_i.astype(f8), d.peep_f.astype(f8), d.peep_o.astype(f8)
+    sig = lambda v: 1.0 / (1.0 + np.exp(-v))
+    r, c, ref = np.zeros((S, R)), np.zeros((S, Cc)), []
+    for t in range(T):
+        pre = x[t * S:(t + 1) * S].astype(f8) @ wx.T + b + r @ wr.T
+        g, i, f = np.tanh(pre[:, :Cc]), sig(pre[:, Cc:2 * Cc] + c * pi), sig(pre[:, 2 * Cc:3 * Cc] + c * pf)
+        c = np.clip(g * i + c * f, -50.0, 50.0)
+        o = sig(pre[:, 3 * Cc:] + c * po)
+        r = (o * np.tanh(c)) @ wrm.T
+        ref.append(r)
+    ref = np.concatenate(ref, axis=0)
+    errs = {}
+    try:
+        for name, on in (("fp32_instruction", 0), ("two_piece_fp16", 1)):
+            aslp.lib.aslp_lstm_split16(on)
+            net = aslp.Nnet.Read(path)
+            net.ResetLstmStreams([1] * S)
+            out = net.Propagate(torch.from_numpy(x).to(dev)).cpu().numpy().astype(f8)
+            errs[name] = float(np.linalg.norm(out - ref) / np.linalg.norm(ref))
+    finally:
+        aslp.lib.aslp_lstm_split16(-1)
+    obuf = d.forward(x, T, S, reverse=False, init_state=np.zeros((S, d.width), np.float32))
+    errs["oracle_fp32_c"] = float(np.linalg.norm(d.out_of(obuf, T, S).astype(f8) - ref) / np.linalg.norm(ref))
+    print("relative error against float64:", errs)
+    assert max(errs.values()) < 5e-6, errs
+    assert errs["two_piece_fp16"] <= 1.5 * errs["fp32_instruction"] + 2e-7, errs
