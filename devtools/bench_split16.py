@@ -40,8 +40,20 @@ def run(tA, tB, M, N, K, scale_a=1.0, scale_b=1.0):
         torch.cuda.synchronize()
         us = (time.perf_counter() - t0) / REPS * 1e6
         out[name] = (err, us)
+    # the product alone, from planes made once (what a training step pays per product)
+    aslp.lib.aslp_gemm_split16(1)
+    pa, pb = aslp.ops.Planes(A), aslp.ops.Planes(B)
+    C = torch.zeros(M, N, device=dev)
+    aslp.ops.sgemm_planes(tA, tB, 1.0, A, pa, B, pb, 0.0, C)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(REPS):
+        aslp.ops.sgemm_planes(tA, tB, 1.0, A, pa, B, pb, 0.0, C)
+    torch.cuda.synchronize()
+    us_planes = (time.perf_counter() - t0) / REPS * 1e6
     aslp.lib.aslp_gemm_split16(-1)
     f = 2.0 * M * N * K
+    print("   product alone from prepared planes: %7.1f us  %6.1f TF-equivalent (%.2f of 839)" % (us_planes, f / us_planes / 1e6, f / us_planes / 1e6 / 839))
     print("%s%s %5d x %5d x %5d  scale %g/%g:  fp32 err %.2e %7.1f us %6.1f TF | split err %.2e %7.1f us %6.1f TF-equivalent"
           % ("T" if tA else "N", "T" if tB else "N", M, N, K, scale_a, scale_b, out["fp32"][0], out["fp32"][1], f / out["fp32"][1] / 1e6,
              out["split"][0], out["split"][1], f / out["split"][1] / 1e6))

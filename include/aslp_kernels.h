@@ -192,9 +192,22 @@ typedef struct aslp_gemm_epilogue_ {
 } aslp_gemm_epilogue;
 /* Large products of aslp_sgemm_ex on the fp16 matrix instruction with each fp32 operand carried as two fp16 pieces behind a power-of-two
  * scale of its matrix (csrc/gemm_split16.hip: 22 significant bits, fp32 accumulation; results agree with the fp32 instruction's to fp32
- * rounding).  on = 1 / 0 switches it for this process, -1 hands the choice back to ASLP_GEMM_SPLIT_F16 (default off).  No reference
+ * rounding).  on = 1 / 0 switches it for this process, -1 hands the choice back to ASLP_GEMM_SPLIT_F16 (default on).  No reference
  * counterpart (cuBLAS sgemm on fp32 CUDA cores). */
 void aslp_gemm_split16(int on);
+/* Prepared operands of such products: the two fp16 planes of an fp32 matrix, in the matrix' own layout (csrc/split16.h), made once and
+ * read by every product the matrix takes part in (as op(A) or op(B), transposed or not).  aslp_planes_convert: one maximum pass and one
+ * conversion pass over src [d.rows x d.cols] (cols and stride multiples of 4, 16-byte aligned).  The engine's components keep such
+ * planes per tensor and step and let the kernels that write a tensor write its planes (nnet/nnet-basic.h). */
+typedef struct aslp_planes_ aslp_planes;
+aslp_planes *aslp_planes_new(void);
+void aslp_planes_free(aslp_planes *p);
+int aslp_planes_convert(aslp_planes *p, const float *src, MatrixDim d);
+/* aslp_sgemm_ex with the planes of A and / or B (NULL: that operand is converted inside the call); the planes must be those of the
+ * matrix the fp32 pointer names.  Runs on the fp32 instruction like aslp_sgemm_ex when aslp_gemm_split16 is off or the shape is not
+ * served. */
+int aslp_sgemm_planes_ex(int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda, const aslp_planes *pa,
+                         const float *B, int ldb, const aslp_planes *pb, float beta, float *C, int ldc, const aslp_gemm_epilogue *ep);
 int aslp_sgemm_ex(int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda,
                   const float *B, int ldb, float beta, float *C, int ldc, const aslp_gemm_epilogue *ep);
 /* Two products of the same shape, leading dimensions, alpha and beta in ONE launch: C0 = alpha op(A0) op(B0) + beta C0 (+ ep0),

@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "gemm_common.h"
+#include "split16.h"
 
 namespace aslp {
 namespace {
@@ -728,8 +729,9 @@ using namespace aslp;
 
 extern "C" {
 
-int aslp_sgemm_ex(int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda, const float *B, int ldb, float beta,
-                  float *C, int ldc, const aslp_gemm_epilogue *ep) {
+// aslp_sgemm_ex with optional prepared planes of either operand (split16.h); an operand without planes is converted in scratch
+static int sgemm_impl(int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda, const float *B, int ldb, float beta,
+                      float *C, int ldc, const aslp_gemm_epilogue *ep, const S16View *pa, const S16View *pb) {
   if (M < 0 || N < 0 || K < 0) return -1;
   if (M == 0 || N == 0) return 0;
   if (!C || ldc < N) return -2;
@@ -759,7 +761,7 @@ int aslp_sgemm_ex(int transA, int transB, int M, int N, int K, float alpha, cons
   }
   if (prof) (void)hipEventRecord(e0, cur_stream());
   static const int s16_cfg = [] { const char *e = getenv("ASLP_GEMM_SPLIT_F16_TILE"); return e ? atoi(e) : 0; }();
-  if (gemm_split16_enabled() && !g_force_tile && gemm_split16_launch(g, !transA, transB != 0, s16_cfg)) {   // (a forced tile asks for an fp32 kernel by name)
+  if (gemm_split16_enabled() && !g_force_tile && gemm_split16_launch(g, !transA, transB != 0, s16_cfg, pa, pb)) {   // (a forced tile asks for an fp32 kernel by name)
     g.ep.colstats = nullptr;   // formed in its epilogue; column sums (if asked for) by the pass over A below
     t_last_cfg = 311;
   } else if (!transA && transB) launch_aligned<true, true>(g);
@@ -788,6 +790,28 @@ int aslp_sgemm_ex(int transA, int transB, int M, int N, int K, float alpha, cons
     }
   }
   return 0;
+}
+
+int aslp_sgemm_ex(int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda, const float *B, int ldb, float beta,
+                  float *C, int ldc, const aslp_gemm_epilogue *ep) {
+  return sgemm_impl(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, ep, nullptr, nullptr);
+}
+
+// ---- prepared operand planes (include/aslp_kernels.h) ---------------------------------------------------------------------------
+aslp_planes *aslp_planes_new(void) { return reinterpret_cast<aslp_planes *>(new PlaneSet()); }
+void aslp_planes_free(aslp_planes *p) { delete reinterpret_cast<PlaneSet *>(p); }
+int aslp_planes_convert(aslp_planes *p, const float *src, MatrixDim d) {
+  if (!p || !src) return -1;
+  const bool ok = reinterpret_cast<PlaneSet *>(p)->ConvertFrom(src, d.rows, d.cols, d.stride);
+  check_launch("aslp_planes_convert");
+  return ok ? 0 : -2;
+}
+int aslp_sgemm_planes_ex(int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda, const aslp_planes *pa, const float *B,
+                         int ldb, const aslp_planes *pb, float beta, float *C, int ldc, const aslp_gemm_epilogue *ep) {
+  S16View va, vb;
+  if (pa) va = reinterpret_cast<const PlaneSet *>(pa)->View();
+  if (pb) vb = reinterpret_cast<const PlaneSet *>(pb)->View();
+  return sgemm_impl(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, ep, pa ? &va : nullptr, pb ? &vb : nullptr);
 }
 
 // Two products of one shape in one launch (include/aslp_kernels.h).  Falls back to two launches wherever the paired kernel does

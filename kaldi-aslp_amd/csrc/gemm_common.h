@@ -278,6 +278,10 @@ bool gemm_glds_launch(GemmArgs &g, bool a_kc, bool b_kc, int cfg, int *cfg_used)
 // gemm_split16.hip: the same product on the fp16 matrix instruction with two-piece fp32-equivalent operands (A/B: ASLP_GEMM_SPLIT_F16=1).
 // cfg 0 = default tile.  false: not eligible.  Forms ep.colstats itself; ep.colsum stays the caller's.
 bool gemm_split16_enabled();
-bool gemm_split16_launch(GemmArgs &g, bool a_kc, bool b_kc, int cfg);
+struct S16View;
+// pa / pb: prepared planes of the operands (split16.h) or NULL = convert g.A / g.B in scratch
+bool gemm_split16_launch(GemmArgs &g, bool a_kc, bool b_kc, int cfg, const S16View *pa = nullptr, const S16View *pb = nullptr);
+// ... both from prepared planes; a1 / b1: the second product's operands when g.pair
+bool gemm_split16_planes_launch(GemmArgs &g, bool a_kc, bool b_kc, const S16View &a, const S16View &b, const S16View *a1, const S16View *b1, int cfg);
 
 }  // namespace aslp

@@ -1,37 +1,47 @@
 // gemm_split16.hip -- fp32 GEMM carried on the fp16 matrix instruction (v_mfma_f32_32x32x16_f16) with fp32-equivalent operands.
 //
 // The fp32 MFMA rate of gfx950 is 256 FLOP/clk/CU (157 TFLOP/s) whatever the instruction shape; the fp16 instruction runs 16 x that.
-// An fp32 value x is carried as TWO fp16 pieces behind a power-of-two scale s of its matrix (s puts the matrix's largest |x| in
-// [2^13, 2^14)):  x s = hi + 2^-11 lo',  hi = fp16(x s),  lo' = fp16((x s - hi) 2^11)  -- 22 significant bits for every element down to
-// 2^-28 of the matrix's largest (fp16 is normal over 29 binades), and an element below that contributes < 2^-39 of the largest either way.
+// An fp32 value x is carried as TWO fp16 pieces behind a power-of-two scale s of its matrix (split16.h):  x s = hi + 2^-11 lo'.
 // A product a b then is  hi_a hi_b + 2^-11 (hi_a lo'_b + lo'_a hi_b)  (+ 2^-22 lo'_a lo'_b, dropped: below the pieces' own rounding):
 // three instructions per 16-wide k step, every partial product exact in the multiplier, accumulated in fp32 in two accumulators (main and
-// cross terms) that are joined once in front of the epilogue.  Measured against double (tests/test_gemm_split16_gpu.py) the result is as
-// close as the fp32 instruction's.
+// cross terms) that are joined once in front of the epilogue.  Measured against double (tests/test_gemm_split16_gpu.py) the result is
+// closer than the fp32 instruction's.
 //
-// Operands reach the kernel as PLANES: hi[rows][Kp] and lo'[rows][Kp] fp16, Kp = K rounded up to 64 (zeros behind K), always with the
-// reduction index contiguous ("NT" form) -- split16_convert writes them from the fp32 operand in one pass, transposing through LDS
-// where the operand is stored reduction-major.  Each (operand, orientation) of a training step is used by exactly one product, so the
-// planes are scratch of the call.  The kernel itself is gemm_glds.hip's pipeline with both operands K-contiguous: LDS-DMA into
-// 128-byte-row tiles (same swizzle), fragments double-buffered in registers, the epilogues of gemm_common.h unchanged (the 32 x 32 fp16
-// instruction has the fp32 one's result layout).
+// Operands reach the kernel as PLANES in the layout of their matrix (split16.h): made once per tensor and step -- by the kernel that
+// writes the tensor where that kernel knows a bound of it, else by split16_convert_kernel -- and read by every product the tensor
+// takes part in, whichever index that product reduces over:
+//   * reduction index contiguous ("KC": x in the forward product, dy in the in-diff, W in the forward product): LDS image
+//     [rows][64 halves], 128-byte rows with gemm_glds.hip's chunk swizzle, fragments by ds_read_b128;
+//   * reduction index = row index ("KS": dy and x in the weight gradient, W in the in-diff): LDS image [64 k][BR halves] exactly as the
+//     rows lie in memory, fragments by TWO ds_read_b64_tr_b16 -- each 16-lane group reads a [4 k][16 columns] block and receives it
+//     transposed, lane (column) p holding k .. k+3 (checked lane by lane on the device: devtools/micro/tr_read.hip).  The 64-byte
+//     column groups of a k row are XOR-swizzled with the row's low bits so that the four rows a 32-lane group touches fall on four
+//     different quarters of the 64 banks.
+// Everything else is gemm_glds.hip's pipeline: LDS-DMA (global_load_lds_dwordx4) into NS stages, counted vmcnt, fragments double
+// buffered in registers, the epilogues of gemm_common.h unchanged (the 32 x 32 fp16 instruction has the fp32 one's result layout).
 //
-// A/B: ASLP_GEMM_SPLIT_F16=1 routes eligible aslp_sgemm_ex products here (default off: the fp32 instruction stays the shipped path).
+// A/B: ASLP_GEMM_SPLIT_F16=0 keeps every product on the fp32 instruction (default: on).
+#include <algorithm>
+
 #include "gemm_common.h"
 #include "scratch.h"
+#include "split16.h"
 
 #pragma clang diagnostic ignored "-Winline-asm"  // the DMA asm clobbers m0 on purpose
 
 namespace aslp {
 namespace {
 
-typedef _Float16 h16;
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-constexpr int BKH = 64;      // halves per K tile: 128-byte rows, the LDS geometry of gemm_glds.hip's K-contiguous tiles
+constexpr int BKH = 64;       // halves per K tile
 constexpr int KH = BKH / 16;  // instruction k steps per tile
+typedef __attribute__((address_space(3))) char lds_char;
+typedef short short4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) short4v lds_short4;
 
 __device__ __forceinline__ int kc_swizzle(int row) { return (row >> 1) & 7; }   // as gemm_glds.hip
+// KS image: XOR of the 64-byte column-group index of k row `krow` (BR halves per row)
+template <int BR>
+__device__ __forceinline__ int ks_swizzle(int krow) { return BR == 64 ? ((krow >> 1) & 1) : BR == 128 ? (krow & 3) : 0; }
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -40,192 +50,186 @@ __device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_byte_addr)
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_byte_addr) : "memory", "m0");
 }
 
-// the scale of a matrix from the bits of its largest |x| (0, inf and NaN leave it at 1): *up = the exponent added
-__device__ __forceinline__ float scale_from_max_bits(unsigned bits, float *inv) {
-  const float mx = __uint_as_float(bits);
-  int e = 0;
-  (void)frexpf(mx, &e);   // mx = f 2^e, f in [0.5, 1)
-  const bool scaled = mx > 0.f && mx < 3.0e38f;
-  int up = scaled ? 14 - e : 0;
-  up = up > 120 ? 120 : (up < -120 ? -120 : up);
-  *inv = ldexpf(1.f, -up);
-  return ldexpf(1.f, up);
-}
-
-// ---- largest |x| of two operands (blockIdx.y): every workgroup leaves its own maximum in part[operand][workgroup] (kMaxParts each) --
-// no atomics and nothing to zero first; the conversion kernel reduces the partials (and leaves the result in slots[] for the product)
-constexpr int kMaxParts = 256;
-struct MaxJob { const float *p; int rows, cols, ld; };
-__global__ void __launch_bounds__(256) absmax2_kernel(MaxJob a, MaxJob b, float *part) {
+// ---- largest finite |x| of up to two matrices (blockIdx.y): every workgroup leaves its own maximum in part[workgroup] -- no atomics,
+// nothing to zero first; the conversion reduces the partials
+struct MaxJob { const float *p; int rows, cols, ld; float *part; };
+__global__ void __launch_bounds__(256) s16_absmax_kernel(MaxJob a, MaxJob b) {
   const MaxJob j = blockIdx.y ? b : a;
   const int c4 = j.cols >> 2;
   const long n = (long)j.rows * c4;
   float m = 0.f;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const int r = (int)(i / c4), c = (int)(i - (long)r * c4);
-    const float4 v = *reinterpret_cast<const float4 *>(j.p + (long)r * j.ld + 4 * c);
-    m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    m = s16_absmax4(m, *reinterpret_cast<const float4 *>(j.p + (long)r * j.ld + 4 * c));
   }
-  // NaN anywhere: fmaxf drops it; the product then carries it through the pieces (fp16(NaN) = NaN) like the fp32 kernel would
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  m = wave_max(m);
   __shared__ float wm[4];
   if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x == 0) part[blockIdx.y * kMaxParts + blockIdx.x] = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+  if (threadIdx.x == 0) j.part[blockIdx.x] = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
 }
 // the matrix maximum from the partials (every thread of a 256-thread workgroup gets it)
 __device__ __forceinline__ float reduce_parts(const float *part, int nparts) {
   __shared__ float wm2[4];
   float m = (int)threadIdx.x < nparts ? part[threadIdx.x] : 0.f;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  m = wave_max(m);
   if ((threadIdx.x & 63) == 0) wm2[threadIdx.x >> 6] = m;
   __syncthreads();
   return fmaxf(fmaxf(wm2[0], wm2[1]), fmaxf(wm2[2], wm2[3]));
 }
 
-__device__ __forceinline__ void split4(const float4 v, float s, half4 *hi, half4 *lo) {
-  const float x[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const h16 h = (h16)x[i];
-    (*hi)[i] = h;
-    (*lo)[i] = (h16)((x[i] - (float)h) * 2048.f);
-  }
-}
-
-// ---- fp32 operand -> planes, reduction index already contiguous: out row r = src row r --------------------------------------------
-struct ConvJob { const float *src; int rows, cols, ld; h16 *hi, *lo; int kp; int transpose; };
-__global__ void __launch_bounds__(256) split16_convert_kernel(ConvJob a, ConvJob b, const float *part, int nparts, unsigned *slots) {
-  const ConvJob j = blockIdx.z ? b : a;
-  float inv;
-  const unsigned mbits = __float_as_uint(reduce_parts(part + blockIdx.z * kMaxParts, nparts));
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) slots[blockIdx.z] = mbits;   // for the product kernel (launched behind this one)
-  const float s = scale_from_max_bits(mbits, &inv);
-  if (!j.transpose) {
-    const int k4 = j.kp >> 2, c4 = j.cols >> 2;
-    const long n = (long)j.rows * k4;
-    for (long i = (long)(blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < n; i += (long)gridDim.x * gridDim.y * 256) {
-      const int r = (int)(i / k4), c = (int)(i - (long)r * k4);
-      half4 hi = {0, 0, 0, 0}, lo = {0, 0, 0, 0};
-      if (c < c4) split4(*reinterpret_cast<const float4 *>(j.src + (long)r * j.ld + 4 * c), s, &hi, &lo);
-      *reinterpret_cast<half4 *>(j.hi + (long)r * j.kp + 4 * c) = hi;
-      *reinterpret_cast<half4 *>(j.lo + (long)r * j.kp + 4 * c) = lo;
-    }
-    return;
-  }
-  // transpose: out row = src column, out k = src row.  64 x 64 tiles through LDS: read along the source rows, write along k.
-  __shared__ float tile[64][65];
-  const int tiles_c = (j.cols + 63) >> 6, tiles_k = j.kp >> 6;
-  for (int t = blockIdx.y * gridDim.x + blockIdx.x; t < tiles_c * tiles_k; t += gridDim.x * gridDim.y) {
-    const int tk = t / tiles_c, tc = t - tk * tiles_c;
-    const int k0 = tk * 64, c0 = tc * 64;
-#pragma unroll
-    for (int p = 0; p < 4; p++) {   // 64 source rows (k) x 16 float4
-      const int kr = (threadIdx.x >> 4) + 16 * p, c = 4 * (threadIdx.x & 15);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (k0 + kr < j.rows && c0 + c < j.cols) v = *reinterpret_cast<const float4 *>(j.src + (long)(k0 + kr) * j.ld + c0 + c);   // cols % 4 == 0
-      tile[kr][c] = v.x; tile[kr][c + 1] = v.y; tile[kr][c + 2] = v.z; tile[kr][c + 3] = v.w;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int p = 0; p < 4; p++) {   // 64 out rows (source columns) x 16 groups of 4 k
-      const int orow = (threadIdx.x >> 4) + 16 * p, k = 4 * (threadIdx.x & 15);
-      if (c0 + orow < j.cols) {
-        const float4 v = make_float4(tile[k][orow], tile[k + 1][orow], tile[k + 2][orow], tile[k + 3][orow]);
-        half4 hi, lo;
-        split4(v, s, &hi, &lo);
-        *reinterpret_cast<half4 *>(j.hi + (long)(c0 + orow) * j.kp + k0 + k) = hi;
-        *reinterpret_cast<half4 *>(j.lo + (long)(c0 + orow) * j.kp + k0 + k) = lo;
-      }
-    }
-    __syncthreads();
+// ---- fp32 matrix -> planes in the matrix' own layout (padding written as zeros), up to two matrices per launch (blockIdx.y) --------
+struct ConvJob { const float *src; int ld_src; S16View pl; const float *part; int nparts; };
+__global__ void __launch_bounds__(256) split16_convert_kernel(ConvJob a, ConvJob b) {
+  const ConvJob j = blockIdx.y ? b : a;
+  const unsigned mbits = __float_as_uint(reduce_parts(j.part, j.nparts));
+  if (blockIdx.x == 0 && threadIdx.x == 0) *j.pl.slot = mbits;   // for the products (launched behind this kernel)
+  const float s = ldexpf(1.f, s16_exponent(mbits));
+  const int k4 = j.pl.ld >> 2, c4 = j.pl.cols >> 2;   // cols % 4 == 0 (eligibility)
+  const int rows_p = (j.pl.rows + kS16Pad - 1) / kS16Pad * kS16Pad;
+  const long n = (long)rows_p * k4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int r = (int)(i / k4), c = (int)(i - (long)r * k4);
+    half4 hi = {0, 0, 0, 0}, lo = {0, 0, 0, 0};
+    if (c < c4 && r < j.pl.rows) s16_split4(*reinterpret_cast<const float4 *>(j.src + (long)r * j.ld_src + 4 * c), s, &hi, &lo);
+    *reinterpret_cast<half4 *>(j.pl.hi + (long)r * j.pl.ld + 4 * c) = hi;
+    *reinterpret_cast<half4 *>(j.pl.lo + (long)r * j.pl.ld + 4 * c) = lo;
   }
 }
 
 // ---- the product ---------------------------------------------------------------------------------------------------------------
-struct S16Planes { const h16 *ah, *al, *bh, *bl; int kp; const unsigned *slots; };
+struct S16Operands { S16View a, b, a1, b1; int kp; };   // a1 / b1: second product of a pair (blockIdx.z == 1)
 
-template <int BM, int BN, int WGM, int WGN, int NS>
-__global__ void __launch_bounds__(64 * WGM * WGN) gemm_s16_glds(GemmArgs g, S16Planes pl) {
+template <int BM, int BN, int WGM, int WGN, int NS, bool A_KC, bool B_KC>
+__global__ void __launch_bounds__(64 * WGM * WGN) gemm_s16_glds(GemmArgs g, S16Operands ops) {
   constexpr int NW = WGM * WGN;
   constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
-  // a stage, in floats (128-byte rows = 32 floats): A_hi | A_lo | B_hi | B_lo
-  constexpr int A_FLOATS = BM * 32, B_FLOATS = BN * 32, STAGE = 2 * (A_FLOATS + B_FLOATS);
+  // a stage, in bytes (every plane tile is 64 halves x BR rows whichever way it lies): A_hi | A_lo | B_hi | B_lo
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = 2 * (A_BYTES + B_BYTES);
   constexpr int SLOTS_A = BM / 8, SLOTS_B = BN / 8, SLOTS = 2 * (SLOTS_A + SLOTS_B);   // 1-KiB DMA units per tile
   static_assert(SLOTS % NW == 0, "DMA units must divide over the waves");
   constexpr int G = SLOTS / NW;
   constexpr int D = NS - 1;
-  constexpr int NM = KH * 3 * TM * TN, NRD = KH * 2 * (TM + TN), SB = NM / 2 - 1;
+  constexpr int RA = A_KC ? 1 : 2, RB = B_KC ? 1 : 2;            // LDS reads per fragment and plane
+  constexpr int NRH = 2 * (TM * RA + TN * RB);                    // reads per instruction k step
+  constexpr int NM = KH * 3 * TM * TN, NRD = KH * NRH, SB = NM / 2 - 1;
   constexpr int UNROLL = (NS % 2 == 0) ? NS : 2 * NS;
   static_assert(G <= SB + 1, "not enough MFMA slots before the barrier");
+  static_assert(A_KC || BM == 32 || BM == 64 || BM == 128, "KS image: 32, 64 or 128 columns");
+  static_assert(B_KC || BN == 32 || BN == 64 || BN == 128, "KS image: 32, 64 or 128 columns");
   extern __shared__ __attribute__((aligned(1024))) float lds[];
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lds;
+  lds_char *lds3 = (lds_char *)(__attribute__((address_space(3))) void *)lds;
+  const char *ldsb = reinterpret_cast<const char *>(lds);
 
+  S16View va = ops.a, vb = ops.b;
+  if (g.pair && blockIdx.z == 1) {  // second product of a pair (uniform)
+    g.C = g.C1; g.ep = g.ep1;
+    va = ops.a1; vb = ops.b1;
+  }
   int tm, tn;
   xcd_tile<BM, BN>(g, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave / WGN, wn = wave % WGN, l31 = lane & 31, lh = lane >> 5;
-  const int ktiles = pl.kp / BKH;
+  const int ktiles = ops.kp / BKH;
 
-  // ---- DMA descriptors: unit = 8 rows x 128 B of one plane
+  // ---- DMA descriptors: unit = 1 KiB of one plane tile.  KC: 8 rows x 128 B.  KS: 64 / (BR / 8) k rows x 2 BR bytes.
   const h16 *src[G];
+  int adv[G];          // halves per K tile
   unsigned dst_off[G];
   static_for<0, G>([&](auto U_) {
     constexpr int u = decltype(U_)::value;
     const int slot = wave + u * NW;  // wave-uniform
-    const int r = lane >> 3;
     // plane order inside a stage: A_hi [0, SLOTS_A), A_lo, B_hi [2 SLOTS_A, ...), B_lo
     const bool is_a = slot < 2 * SLOTS_A;
     const int s2 = is_a ? slot : slot - 2 * SLOTS_A, per = is_a ? SLOTS_A : SLOTS_B;
     const bool lo_plane = s2 >= per;
-    const int sr = lo_plane ? s2 - per : s2;   // 8-row group within the tile
-    const int c = (lane & 7) ^ kc_swizzle(sr * 8 + r);
-    int row = (is_a ? m0 : n0) + sr * 8 + r;
-    const int lim = is_a ? g.M : g.N;
-    row = row < lim ? row : lim - 1;
-    const h16 *base = is_a ? (lo_plane ? pl.al : pl.ah) : (lo_plane ? pl.bl : pl.bh);
-    src[u] = base + (long)row * pl.kp + 8 * c;
+    const int sr = lo_plane ? s2 - per : s2;   // unit within the plane tile
+    const S16View &v = is_a ? va : vb;
+    const h16 *base = lo_plane ? v.lo : v.hi;
+    const int rows_p = (v.rows + kS16Pad - 1) / kS16Pad * kS16Pad;
+    auto kc_src = [&](int first_row) {
+      const int r = lane >> 3;
+      const int c = (lane & 7) ^ kc_swizzle(sr * 8 + r);
+      int row = first_row + sr * 8 + r;
+      row = row < rows_p ? row : rows_p - 1;   // (a row of the padding or of another tile: feeds outputs that are not stored)
+      adv[u] = BKH;
+      return base + (long)row * v.ld + 8 * c;
+    };
+    auto ks_src = [&](int first_col, auto BR_) {
+      constexpr int BR = decltype(BR_)::value, CPR = BR / 8;   // 16-byte chunks per k row
+      const int krow = sr * (64 / CPR) + lane / CPR;
+      const int c = (lane % CPR) ^ (4 * ks_swizzle<BR>(krow));
+      int col = first_col + 8 * c;
+      col = col + 8 <= v.ld ? col : v.ld - 8;   // (columns past the planes: outputs that are not stored)
+      adv[u] = BKH * v.ld;
+      return base + (long)krow * v.ld + col;
+    };
+    if (is_a) {
+      if constexpr (A_KC) src[u] = kc_src(m0); else src[u] = ks_src(m0, std::integral_constant<int, BM>());
+    } else {
+      if constexpr (B_KC) src[u] = kc_src(n0); else src[u] = ks_src(n0, std::integral_constant<int, BN>());
+    }
     dst_off[u] = slot * 1024;
   });
   auto dma_unit = [&](auto U_, auto ST_, int r) {
     constexpr int u = decltype(U_)::value, st = decltype(ST_)::value;
-    glds16(src[u], __builtin_amdgcn_readfirstlane(lds_base + st * STAGE * 4 + dst_off[u]));
-    src[u] += (r + 1 < ktiles) ? BKH : 0;   // requests past the last tile fetch it again into a stage nobody reads
+    glds16(src[u], __builtin_amdgcn_readfirstlane(lds_base + st * STAGE + dst_off[u]));
+    src[u] += (r + 1 < ktiles) ? adv[u] : 0;   // requests past the last tile fetch it again into a stage nobody reads
   };
 
-  // ---- fragments: per-lane float offsets inside a plane tile (row * 32 + swizzled 16-byte chunk * 4)
-  int a_off[TM][KH], b_off[TN][KH];
+  // ---- fragments: per-lane byte offsets inside a plane tile
+  //  KC: row * 128 + swizzled 16-byte chunk (2 h + lh);  KS: lane (p = lane & 15, column half g = (lane >> 4) & 1) of a 16-lane group
+  //  addresses k row 8 lh + p / 4, columns 16 g + 4 (p & 3) .. + 3 of its 32-column fragment and receives column 16 g + p, k .. k + 3
+  //  (KC keeps one offset per k step: the swizzle is an XOR; KS steps are plain additions that fold into the instruction's offset field)
+  constexpr int AH = A_KC ? KH : 1, BH = B_KC ? KH : 1;
+  int a_off[TM][AH], b_off[TN][BH];
+  const int p16 = lane & 15, g16 = (lane >> 4) & 1;
 #pragma unroll
-  for (int t = 0; t < TM; t++)
-#pragma unroll
-    for (int h = 0; h < KH; h++) {
+  for (int t = 0; t < TM; t++) {
+    if constexpr (A_KC) {
       const int row = wm * WM + t * 32 + l31;
-      a_off[t][h] = row * 32 + (((2 * h + lh) ^ kc_swizzle(row)) << 2);
+#pragma unroll
+      for (int h = 0; h < KH; h++) a_off[t][h] = row * 128 + (((2 * h + lh) ^ kc_swizzle(row)) << 4);
+    } else {
+      const int T = wm * TM + t, krow = 8 * lh + (p16 >> 2);
+      a_off[t][0] = krow * (2 * BM) + 64 * (T ^ ks_swizzle<BM>(krow)) + 32 * g16 + 8 * (p16 & 3);
     }
+  }
 #pragma unroll
-  for (int t = 0; t < TN; t++)
-#pragma unroll
-    for (int h = 0; h < KH; h++) {
+  for (int t = 0; t < TN; t++) {
+    if constexpr (B_KC) {
       const int col = wn * WN + t * 32 + l31;
-      b_off[t][h] = 2 * A_FLOATS + col * 32 + (((2 * h + lh) ^ kc_swizzle(col)) << 2);
+#pragma unroll
+      for (int h = 0; h < KH; h++) b_off[t][h] = 2 * A_BYTES + col * 128 + (((2 * h + lh) ^ kc_swizzle(col)) << 4);
+    } else {
+      const int T = wn * TN + t, krow = 8 * lh + (p16 >> 2);
+      b_off[t][0] = 2 * A_BYTES + krow * (2 * BN) + 64 * (T ^ ks_swizzle<BN>(krow)) + 32 * g16 + 8 * (p16 & 3);
     }
+  }
   struct Frag {
     half8 ah[KH][TM], al[KH][TM], bh[KH][TN], bl[KH][TN];
   };
+  // one LDS read: flat index r -> (k step h, operand, fragment t, plane, half of the fragment)
   auto read_unit = [&](auto ST_, Frag &f, auto R_) {
     constexpr int r = decltype(R_)::value, st = decltype(ST_)::value;
-    constexpr int h = r / (2 * (TM + TN)), q = r % (2 * (TM + TN)), t = q >> 1, lo = q & 1;
-    const float *stage = lds + st * STAGE;
-    if constexpr (t < TM) {
-      const half8 v = *reinterpret_cast<const half8 *>(stage + a_off[t][h] + (lo ? A_FLOATS : 0));
-      if constexpr (lo) f.al[h][t] = v; else f.ah[h][t] = v;
+    constexpr int h = r / NRH, q = r % NRH;
+    constexpr bool is_a = q < 2 * TM * RA;
+    constexpr int q2 = is_a ? q : q - 2 * TM * RA, RR = is_a ? RA : RB;
+    constexpr int t = q2 / (2 * RR), w = q2 % (2 * RR), lo = w / RR, half = w % RR;
+    constexpr bool kc = is_a ? A_KC : B_KC;
+    constexpr int plane_bytes = is_a ? A_BYTES : B_BYTES, BR = is_a ? BM : BN;
+    int base = st * STAGE + (lo ? plane_bytes : 0);
+    if constexpr (is_a) base += a_off[t][kc ? h : 0]; else base += b_off[t][kc ? h : 0];
+    if constexpr (kc) {
+      const half8 v = *reinterpret_cast<const half8 *>(ldsb + base);
+      if constexpr (is_a) { if constexpr (lo) f.al[h][t] = v; else f.ah[h][t] = v; }
+      else { if constexpr (lo) f.bl[h][t] = v; else f.bh[h][t] = v; }
     } else {
-      constexpr int tb = t - TM;
-      const half8 v = *reinterpret_cast<const half8 *>(stage + b_off[tb][h] + (lo ? B_FLOATS : 0));
-      if constexpr (lo) f.bl[h][tb] = v; else f.bh[h][tb] = v;
+      const half4 v = __builtin_bit_cast(half4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4 *)(lds3 + base + (16 * h + 4 * half) * (2 * BR))));
+      half8 *dst = is_a ? (lo ? &f.al[h][t] : &f.ah[h][t]) : (lo ? &f.bl[h][t] : &f.bh[h][t]);
+      if constexpr (half == 0) dst->lo = v; else dst->hi = v;
     }
   };
 
@@ -288,21 +292,20 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_s16_glds(GemmArgs g, S16P
   }
   wait_vmcnt<0>();
 
-  // join the two accumulators and undo the operand scales (exact powers of two) through alpha
-#pragma unroll
-  for (int i = 0; i < TM; i++)
-#pragma unroll
-    for (int j = 0; j < TN; j++)
-#pragma unroll
-      for (int e = 0; e < 16; e++) acc[i][j][e] = fmaf(accx[i][j][e], 0x1p-11f, acc[i][j][e]);
+  // join the two accumulators and undo the operand scales: 2^-(up_a + up_b), in two exact factors (either alone may leave fp32's range
+  // where their product with the accumulator does not)
   {
-    float inv_a, inv_b;
-    (void)scale_from_max_bits(pl.slots[0], &inv_a);
-    (void)scale_from_max_bits(pl.slots[1], &inv_b);
-    g.alpha *= inv_a * inv_b;
+    const int e = -(s16_exponent(*va.slot) + s16_exponent(*vb.slot));
+    const float s1 = ldexpf(1.f, e / 2), s2 = ldexpf(1.f, e - e / 2);
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+      for (int j = 0; j < TN; j++)
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc[i][j][q] = (fmaf(accx[i][j][q], 0x1p-11f, acc[i][j][q]) * s1) * s2;
   }
   if (g.ep.colstats != nullptr) gemm_colstats<TM, TN>(g, acc, m0 + wm * WM, n0 + wn * WN, l31, lh);  // uniform
-  static_assert(NW * 32 * kEpiPitch * (int)sizeof(float) <= NS * STAGE * (int)sizeof(float), "the waves' epilogue slices must fit into the operand LDS");
+  static_assert(NW * 32 * kEpiPitch * (int)sizeof(float) <= NS * STAGE, "the waves' epilogue slices must fit into the operand LDS");
   if (g.wide_epilogue && gemm_epilogue_wide_ok(g)) {  // uniform
     __builtin_amdgcn_s_barrier();
     gemm_epilogue_wide<TM, TN>(g, acc, m0 + wm * WM, n0 + wn * WN, lane, lds + wave * 32 * kEpiPitch);
@@ -311,58 +314,163 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_s16_glds(GemmArgs g, S16P
   }
 }
 
-template <int BM, int BN, int WGM, int WGN, int NS>
-void launch_s16(GemmArgs &g, const S16Planes &pl) {
+template <int BM, int BN, int WGM, int WGN, int NS, bool A_KC, bool B_KC>
+void launch_s16(GemmArgs &g, const S16Operands &ops) {
   g.tiles_m = (g.M + BM - 1) / BM;
   g.tiles_n = (g.N + BN - 1) / BN;
   constexpr int lds_bytes = NS * 2 * (BM + BN) * 128;
-  auto kern = gemm_s16_glds<BM, BN, WGM, WGN, NS>;
+  auto kern = gemm_s16_glds<BM, BN, WGM, WGN, NS, A_KC, B_KC>;
   static bool attr_set = false;
   if (!attr_set) {
     if (lds_bytes > 48 * 1024)
       ASLP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n), dim3(64 * WGM * WGN), lds_bytes, cur_stream(), g, pl);
+  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n, 1, g.pair ? 2 : 1), dim3(64 * WGM * WGN), lds_bytes, cur_stream(), g, ops);
 }
+template <bool A_KC, bool B_KC>
+bool launch_s16_layout(GemmArgs &g, const S16Operands &ops, int cfg) {
+  // 128 x 128 where that still gives every CU a workgroup, else 64 x 128 (measured: 1024 x 2048 x 2048 52 against 70 us per call).  Only with
+  // both operands reduction-contiguous: the transposing reads' address registers push the 128 x 128 tile past 512 registers (27-31 spilled),
+  // and a kernel with a private segment pays ~1 ms per launch for it on this runtime.
+  if (cfg == 0 || !(A_KC && B_KC))
+    cfg = (A_KC && B_KC && (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * (g.pair ? 2 : 1) >= 224) ? 311 : 308;
+  switch (cfg) {
+    case 311: if constexpr (A_KC && B_KC) launch_s16<128, 128, 2, 2, 2, true, true>(g, ops); break;
+    case 308: launch_s16<64, 128, 2, 2, 3, A_KC, B_KC>(g, ops); break;
+    default: return false;
+  }
+  return true;
+}
+
+int g_split16_override = -1;   // aslp_gemm_split16(): -1 = the environment decides
 
 }  // namespace
 
-int g_split16_override = -1;   // aslp_gemm_split16(): -1 = the environment decides
 bool gemm_split16_enabled() {
-  static const bool on = getenv("ASLP_GEMM_SPLIT_F16") != nullptr && getenv("ASLP_GEMM_SPLIT_F16")[0] == '1';
+  static const bool on = !(getenv("ASLP_GEMM_SPLIT_F16") != nullptr && getenv("ASLP_GEMM_SPLIT_F16")[0] == '0');
   return g_split16_override >= 0 ? g_split16_override != 0 : on;
 }
 
-// C = epilogue(alpha op(A) op(B) + beta C) through fp16 planes.  a_kc: A is stored [M x K] (else [K x M]); b_kc: B is stored [N x K]
-// (else [K x N]).  false: not eligible (the caller runs the fp32 kernels).  Column sums (ep.colsum) stay the caller's job.
-bool gemm_split16_launch(GemmArgs &g, bool a_kc, bool b_kc, int cfg) {
+// ---- PlaneSet ----------------------------------------------------------------------------------------------------------------------
+PlaneSet::~PlaneSet() {
+  // (process teardown may already have unloaded the HIP runtime: errors are ignored)
+  if (hi_) (void)hipFree(hi_);
+  if (slot_) (void)hipFree(slot_);
+}
+bool PlaneSet::Reserve(int rows, int cols) {
+  if (rows <= 0 || cols <= 0) return false;
+  const int ld = (cols + kS16Pad - 1) / kS16Pad * kS16Pad, rows_p = (rows + kS16Pad - 1) / kS16Pad * kS16Pad;
+  const size_t need = (size_t)rows_p * ld;
+  if (!slot_) {
+    void *p = nullptr;
+    if (hipMalloc(&p, 256 + sizeof(float) * kS16MaxParts) != hipSuccess) { set_error("PlaneSet: hipMalloc failed"); return false; }
+    slot_ = static_cast<unsigned *>(p);
+    parts_ = reinterpret_cast<float *>(static_cast<char *>(p) + 256);
+    (void)hipMemsetAsync(p, 0, 256 + sizeof(float) * kS16MaxParts, cur_stream());
+    host_bound_ = -1.f;
+  }
+  const bool reshape = rows != rows_ || cols != cols_;
+  if (need > cap_) {
+    if (hi_) {
+      (void)hipStreamSynchronize(cur_stream());   // outstanding products may still read the old planes
+      (void)hipFree(hi_);
+      hi_ = lo_ = nullptr;
+      cap_ = 0;
+    }
+    void *p = nullptr;
+    if (hipMalloc(&p, 2 * need * sizeof(h16)) != hipSuccess) { set_error("PlaneSet: hipMalloc failed"); return false; }
+    hi_ = static_cast<h16 *>(p);
+    cap_ = need;
+  }
+  if (reshape) {
+    lo_ = hi_ + need;
+    rows_ = rows; cols_ = cols; ld_ = ld; rows_p_ = rows_p;
+    (void)hipMemsetAsync(hi_, 0, 2 * need * sizeof(h16), cur_stream());   // the padding stays zero from here on
+    Invalidate();
+  }
+  return true;
+}
+bool PlaneSet::SetBound(float bound) {
+  if (!slot_) return false;
+  if (bound != host_bound_) {
+    (void)hipMemcpyAsync(slot_, &bound, sizeof(float), hipMemcpyHostToDevice, cur_stream());   // (pageable source: copied before the call returns)
+    host_bound_ = bound;
+  }
+  return true;
+}
+bool PlaneSet::ConvertWithParts(const float *src, int rows, int cols, int stride, int nparts) {
+  if ((cols & 3) || (stride & 3) || !aligned16(src) || nparts > kS16MaxParts) return false;
+  if (!Reserve(rows, cols)) return false;
+  host_bound_ = -1.f;
+  ConvJob j = {src, stride, View(), parts_, nparts};
+  const long quads = (long)rows_p_ * (ld_ >> 2);
+  hipLaunchKernelGGL(split16_convert_kernel, dim3((unsigned)std::min<long>(1024, (quads + 255) / 256), 1), dim3(256), 0, cur_stream(), j, j);
+  return true;
+}
+bool PlaneSet::ConvertFrom(const float *src, int rows, int cols, int stride) {
+  if ((cols & 3) || (stride & 3) || !aligned16(src)) return false;
+  if (!Reserve(rows, cols)) return false;
+  MaxJob m = {src, rows, cols, stride, parts_};
+  hipLaunchKernelGGL(s16_absmax_kernel, dim3(kS16MaxParts, 1), dim3(256), 0, cur_stream(), m, m);
+  return ConvertWithParts(src, rows, cols, stride, kS16MaxParts);
+}
+
+// C = epilogue(alpha op(A) op(B) + beta C) from planes.  a_kc: A is stored [M x K] (else [K x M]); b_kc: B is stored [N x K]
+// (else [K x N]).  For a pair (g.pair) a1 / b1 are the second product's operands.  false: not eligible (nothing was launched).
+// Column sums (ep.colsum) stay the caller's job.
+bool gemm_split16_planes_launch(GemmArgs &g, bool a_kc, bool b_kc, const S16View &a, const S16View &b, const S16View *a1, const S16View *b1,
+                                int cfg) {
+  if (g.split_k > 1) return false;
+  if (g.M < 64 || g.N < 64 || g.K < 32) return false;
+  if (g.pair && (!a1 || !b1)) return false;
+  S16Operands ops;
+  ops.a = a; ops.b = b;
+  ops.a1 = a1 ? *a1 : a; ops.b1 = b1 ? *b1 : b;
+  ops.kp = (g.K + BKH - 1) / BKH * BKH;
+  // the planes must describe the operands of this product
+  auto fits = [&](const S16View &v, bool kc, int outer) { return v.hi && (kc ? (v.rows == outer && v.cols == g.K) : (v.rows == g.K && v.cols == outer)); };
+  if (!fits(ops.a, a_kc, g.M) || !fits(ops.b, b_kc, g.N) || !fits(ops.a1, a_kc, g.M) || !fits(ops.b1, b_kc, g.N)) return false;
+  bool ok;
+  if (a_kc && b_kc) ok = launch_s16_layout<true, true>(g, ops, cfg);
+  else if (a_kc && !b_kc) ok = launch_s16_layout<true, false>(g, ops, cfg);
+  else if (!a_kc && !b_kc) ok = launch_s16_layout<false, false>(g, ops, cfg);
+  else ok = launch_s16_layout<false, true>(g, ops, cfg);
+  return ok;
+}
+
+// The same with either operand given as fp32 only (pa / pb NULL): its planes are made in the call's scratch, by a maximum pass and a
+// conversion in front of the product.
+bool gemm_split16_launch(GemmArgs &g, bool a_kc, bool b_kc, int cfg, const S16View *pa, const S16View *pb) {
   if (g.pair || g.split_k > 1) return false;
-  if (g.M < 128 || g.N < 128 || g.K < 64 || !g.a_vec || !g.b_vec) return false;
+  if (g.M < 128 || g.N < 128 || g.K < 64) return false;
   if ((g.M & 3) || (g.N & 3) || (g.K & 3)) return false;
-  const int kp = (g.K + BKH - 1) / BKH * BKH;
-  const size_t plane_a = (size_t)g.M * kp, plane_b = (size_t)g.N * kp;
-  const size_t head = 256 + sizeof(float) * 2 * kMaxParts;
+  if ((!pa && !(g.A && g.a_vec)) || (!pb && !(g.B && g.b_vec))) return false;
+  if (pa && pb) return gemm_split16_planes_launch(g, a_kc, b_kc, *pa, *pb, nullptr, nullptr, cfg);
+  auto pad = [](int x) { return (x + kS16Pad - 1) / kS16Pad * kS16Pad; };
+  const int a_rows = a_kc ? g.M : g.K, a_cols = a_kc ? g.K : g.M, b_rows = b_kc ? g.N : g.K, b_cols = b_kc ? g.K : g.N;
+  const size_t plane_a = pa ? 0 : (size_t)pad(a_rows) * pad(a_cols), plane_b = pb ? 0 : (size_t)pad(b_rows) * pad(b_cols);
+  const size_t head = 256 + sizeof(float) * 2 * kS16MaxParts;
   const size_t bytes = head + sizeof(h16) * 2 * (plane_a + plane_b);
   unsigned char *buf = static_cast<unsigned char *>(scratch(kScratchSplit16, bytes));
   if (!buf) return false;
   unsigned *slots = reinterpret_cast<unsigned *>(buf);
   float *part = reinterpret_cast<float *>(buf + 256);
   h16 *ah = reinterpret_cast<h16 *>(buf + head), *al = ah + plane_a, *bh = al + plane_a, *bl = bh + plane_b;
-  MaxJob ma = {g.A, a_kc ? g.M : g.K, a_kc ? g.K : g.M, g.lda}, mb = {g.B, b_kc ? g.N : g.K, b_kc ? g.K : g.N, g.ldb};
-  hipLaunchKernelGGL(absmax2_kernel, dim3(kMaxParts, 2), dim3(256), 0, cur_stream(), ma, mb, part);
-  ConvJob ca = {g.A, ma.rows, ma.cols, g.lda, ah, al, kp, a_kc ? 0 : 1}, cb = {g.B, mb.rows, mb.cols, g.ldb, bh, bl, kp, b_kc ? 0 : 1};
-  hipLaunchKernelGGL(split16_convert_kernel, dim3(256, 4, 2), dim3(256), 0, cur_stream(), ca, cb, part, kMaxParts, slots);
-  S16Planes pl = {ah, al, bh, bl, kp, slots};
-  if (cfg == 0)   // 128 x 128 where that still gives every CU a workgroup, else 64 x 128 (measured: 1024 x 2048 x 2048 52 against 70 us per call)
-    cfg = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) >= 224 ? 311 : 308;
-  switch (cfg) {
-    case 311: launch_s16<128, 128, 2, 2, 2>(g, pl); break;
-    case 312: launch_s16<128, 128, 2, 4, 2>(g, pl); break;
-    case 308: launch_s16<64, 128, 2, 2, 3>(g, pl); break;
-    default: return false;
+  const S16View va = pa ? *pa : S16View{ah, al, pad(a_cols), a_rows, a_cols, slots};
+  const S16View vb = pb ? *pb : S16View{bh, bl, pad(b_cols), b_rows, b_cols, slots + 1};
+  const MaxJob ma = {g.A, a_rows, a_cols, g.lda, part}, mb = {g.B, b_rows, b_cols, g.ldb, part + kS16MaxParts};
+  const ConvJob ca = {g.A, g.lda, va, part, kS16MaxParts}, cb = {g.B, g.ldb, vb, part + kS16MaxParts, kS16MaxParts};
+  if (!pa && !pb) {
+    hipLaunchKernelGGL(s16_absmax_kernel, dim3(kS16MaxParts, 2), dim3(256), 0, cur_stream(), ma, mb);
+    hipLaunchKernelGGL(split16_convert_kernel, dim3(1024, 2), dim3(256), 0, cur_stream(), ca, cb);
+  } else {
+    const MaxJob &m = pa ? mb : ma;
+    const ConvJob &c = pa ? cb : ca;
+    hipLaunchKernelGGL(s16_absmax_kernel, dim3(kS16MaxParts, 1), dim3(256), 0, cur_stream(), m, m);
+    hipLaunchKernelGGL(split16_convert_kernel, dim3(1024, 1), dim3(256), 0, cur_stream(), c, c);
   }
-  return true;
+  return gemm_split16_planes_launch(g, a_kc, b_kc, va, vb, nullptr, nullptr, cfg);
 }
 
 }  // namespace aslp

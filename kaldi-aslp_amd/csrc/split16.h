@@ -1,0 +1,115 @@
+// split16.h -- fp32 matrices carried as two fp16 planes behind a power-of-two scale (the operand format of gemm_split16.hip).
+//
+// An fp32 value x of a matrix with scale s = 2^up is held as  x s = hi + 2^-11 lo',  hi = fp16(x s),  lo' = fp16((x s - hi) 2^11):
+// 22 significant bits for every element whose |x s| lies in fp16's normal range.  The scale comes from a BOUND of the matrix: any
+// finite b >= max |x| (its bits live in a device word, the "slot"); s puts b into [2^13, 2^14), so every |x s| < 2^14 (fp16 overflows
+// at 2^16) and elements down to 2^-28 b keep their 22 bits (an element below that adds < 2^-39 b to a sum either way).  The bound need not
+// be tight: a producer that knows one before it has written its last element (a sigmoid's 1, |y - t| <= 1, |W| + lr |dW|) writes
+// the planes in the same pass as the fp32 values; everything else leaves per-workgroup maxima and is converted by one pass.
+//
+// Planes have the LAYOUT OF THE MATRIX (row r, column c at [r * ld + c]), ld = cols rounded up to 64, rows rounded up to 64, zeros in
+// the padding: the product kernels read an operand whose reduction index is contiguous with ds_read_b128 and one whose reduction
+// index is the row index with the transposing LDS read (ds_read_b64_tr_b16), so ONE pair of planes serves every product that reads
+// the matrix (x: forward and weight gradient; dy: in-diff and weight gradient; W: forward and in-diff).
+#pragma once
+#include "common.h"
+
+namespace aslp {
+
+typedef _Float16 h16;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+constexpr int kS16Pad = 64;         // both extents of the planes are multiples of this
+constexpr int kS16MaxParts = 256;   // per-workgroup maxima a producer leaves for one matrix
+
+// what a kernel needs of a pair of planes (by value in kernel arguments)
+struct S16View {
+  h16 *hi, *lo;
+  int ld;            // halves per plane row
+  int rows, cols;    // of the fp32 matrix
+  unsigned *slot;    // bits of the bound the planes are (to be) scaled by
+};
+
+// exponent `up` of the scale 2^up for a bound (0, inf and NaN: no scaling)
+__host__ __device__ inline int s16_exponent(unsigned bound_bits) {
+  union { unsigned u; float f; } v;
+  v.u = bound_bits;
+  const float b = v.f;
+  if (!(b > 0.f && b < 3.0e38f)) return 0;
+  int e = 0;
+  (void)frexpf(b, &e);   // b = f 2^e, f in [0.5, 1)
+  int up = 14 - e;
+  return up > 120 ? 120 : (up < -120 ? -120 : up);
+}
+
+#if defined(__HIPCC__)
+__device__ __forceinline__ void s16_split(float x, float s, h16 *hi, h16 *lo) {
+  const float y = x * s;
+  const h16 h = (h16)y;
+  *hi = h;
+  *lo = (h16)((y - (float)h) * 2048.f);
+}
+__device__ __forceinline__ void s16_split4(const float4 v, float s, half4 *hi, half4 *lo) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    h16 h, l;
+    s16_split(x[i], s, &h, &l);
+    (*hi)[i] = h;
+    (*lo)[i] = l;
+  }
+}
+// largest finite |x| of four values (non-finite elements do not set the scale: they stay inf / NaN in the planes and make their rows
+// and columns of a product non-finite, like they do in the fp32 kernels, while every other element keeps its precision)
+__device__ __forceinline__ float s16_absmax4(float m, const float4 v) {
+  const float a[4] = {fabsf(v.x), fabsf(v.y), fabsf(v.z), fabsf(v.w)};
+#pragma unroll
+  for (int i = 0; i < 4; i++) m = fmaxf(m, a[i] < 3.0e38f ? a[i] : 0.f);
+  return m;
+}
+#endif
+
+// ---- host side: device planes of one fp32 matrix, reused from step to step --------------------------------------------------------
+// valid_for(...): the planes hold the values of that matrix as of the tag's epoch (the executor bumps the epochs: nnet-nnet.cpp).
+class PlaneSet {
+ public:
+  PlaneSet() = default;
+  ~PlaneSet();
+  PlaneSet(const PlaneSet &) = delete;
+  PlaneSet &operator=(const PlaneSet &) = delete;
+  // planes for a [rows x cols] matrix (zeroed when the buffers are new or the shape changed: producers only write the matrix region)
+  bool Reserve(int rows, int cols);
+  S16View View() const { return S16View{hi_, lo_, ld_, rows_, cols_, slot_}; }
+  float *Parts() const { return parts_; }        // kS16MaxParts per-workgroup maxima (producers) -> Convert / bound kernels
+  unsigned *Slot() const { return slot_; }
+  int Rows() const { return rows_; }
+  int Cols() const { return cols_; }
+  // max pass + conversion of src (two launches on the current stream)
+  bool ConvertFrom(const float *src, int rows, int cols, int stride);
+  // conversion with the bound already in Parts() (nparts per-workgroup maxima left by the kernel that wrote src)
+  bool ConvertWithParts(const float *src, int rows, int cols, int stride, int nparts);
+  // the planes were / will be written by a producer under a bound known on the host (e.g. 1 for sigmoid outputs)
+  bool SetBound(float bound);
+  // validity tag
+  void Tag(const void *src, int stride, long epoch) { src_ = src; stride_ = stride; epoch_ = epoch; }
+  bool ValidFor(const void *src, int rows, int cols, int stride, long epoch) const {
+    return hi_ && src_ == src && rows_ == rows && cols_ == cols && stride_ == stride && epoch_ == epoch;
+  }
+  void Invalidate() { src_ = nullptr; epoch_ = -1; }
+
+ private:
+  h16 *hi_ = nullptr, *lo_ = nullptr;
+  unsigned *slot_ = nullptr;
+  float *parts_ = nullptr;
+  float host_bound_ = -1.f;
+  size_t cap_ = 0;   // halves per plane allocated
+  int rows_ = 0, cols_ = 0, ld_ = 0, rows_p_ = 0;
+  const void *src_ = nullptr;
+  int stride_ = 0;
+  long epoch_ = -1;
+};
+
+bool gemm_split16_enabled();
+
+}  // namespace aslp

@@ -47,6 +47,36 @@ def sgemm(transA, transB, alpha, A, B, beta, Cm, epilogue=None):
     check_error()
 
 
+class Planes:
+    """the two fp16 planes of an fp32 matrix (aslp_planes_*): made once, read by every product the matrix takes part in"""
+
+    def __init__(self, t):
+        self.h = C.c_void_p(lib.aslp_planes_new())
+        self.t = _chk(t)
+        rc = lib.aslp_planes_convert(self.h, ptr(t), dim(t))
+        if rc != 0:
+            raise ValueError("aslp_planes_convert error %d" % rc)
+        check_error()
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib.aslp_planes_free(self.h)
+            self.h = None
+
+
+def sgemm_planes(transA, transB, alpha, A, pa, B, pb, beta, Cm, epilogue=None):
+    """sgemm with prepared planes of A and / or B (Planes or None)"""
+    _chk(A), _chk(B), _chk(Cm)
+    M, N = Cm.shape
+    K = A.shape[0] if transA else A.shape[1]
+    ep = C.byref(epilogue) if epilogue is not None else None
+    rc = lib.aslp_sgemm_planes_ex(int(transA), int(transB), M, N, K, alpha, ptr(A), dim(A).stride, pa.h if pa else None, ptr(B), dim(B).stride,
+                                  pb.h if pb else None, beta, ptr(Cm), dim(Cm).stride, ep)
+    if rc != 0:
+        raise ValueError("aslp_sgemm_planes argument error %d" % rc)
+    check_error()
+
+
 def sgemm_pair(transA, transB, alpha, A0, A1, B0, B1, beta, C0, C1, ep0=None, ep1=None):
     """two products of one shape in one launch (aslp_sgemm_pair_ex)"""
     for t in (A0, A1, B0, B1, C0, C1):

@@ -1,5 +1,5 @@
 """csrc/gemm_split16.hip: aslp_sgemm_ex on the fp16 matrix instruction with every fp32 operand carried as two fp16 pieces behind a
-power-of-two scale of its matrix (aslp_gemm_split16(1) / ASLP_GEMM_SPLIT_F16=1; default off).  The claim is fp32 accuracy, so the bar is
+power-of-two scale of its matrix (the default; aslp_gemm_split16(0) / ASLP_GEMM_SPLIT_F16=0 keep the fp32 instruction).  The claim is fp32 accuracy, so the bar is
 the fp32-instruction kernels' own: against a float64 product the error relative to sum |a||b| must not exceed theirs by more than
 rounding noise, at any magnitude of the operands, in every operand layout, with every epilogue feature, on ragged sizes."""
 import numpy as np
@@ -48,6 +48,31 @@ def test_as_accurate_as_the_fp32_instruction(aslp, dev, tA, tB, M, N, K):
     again = torch.zeros_like(c16)
     aslp.ops.sgemm(tA, tB, 1.0, A, B, 0.0, again)
     assert torch.equal(again, c16)
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 2048, 2048), (1000, 3000, 440), (256, 2048, 2048), (1920, 512, 2048), (132, 260, 68), (1088, 1984, 1028)])
+def test_one_pair_of_planes_serves_every_product(aslp, dev, M, N, K):
+    """x [M x K], W [N x K], dy [M x N] as planes in their own layout: the forward product x W^T (both reduction-contiguous), the in-diff
+    dy W (W read with the transposing LDS load) and the weight gradient dy^T x (both operands read that way) from the same three pairs
+    of planes -- each bit-identical to the call that converts its operands itself, and as close to float64 as that one"""
+    g = torch.Generator(device=dev).manual_seed(M + 5 * N + 11 * K)
+    x = torch.randn(M, K, device=dev, generator=g)
+    W = torch.randn(N, K, device=dev, generator=g) * 0.05
+    dy = torch.randn(M, N, device=dev, generator=g) * 1e-3
+    aslp.lib.aslp_gemm_split16(1)
+    px, pW, pdy = aslp.ops.Planes(x), aslp.ops.Planes(W), aslp.ops.Planes(dy)
+    for tA, tB, A, pa, B, pb, shape in ((0, 1, x, px, W, pW, (M, N)), (0, 0, dy, pdy, W, pW, (M, K)), (1, 0, dy, pdy, x, px, (N, K)),
+                                        (1, 1, W, pW, dy, pdy, (K, M))):
+        C1 = torch.zeros(shape, device=dev)
+        aslp.ops.sgemm_planes(tA, tB, 1.0, A, pa, B, pb, 0.0, C1)
+        assert aslp.lib.aslp_gemm_last_tile() == 311 or min(shape) < 128
+        C2 = torch.zeros(shape, device=dev)
+        aslp.ops.sgemm(tA, tB, 1.0, A, B, 0.0, C2)
+        assert torch.equal(C1, C2), (tA, tB)
+        C3 = torch.zeros(shape, device=dev)     # one operand prepared, the other converted inside the call
+        aslp.ops.sgemm_planes(tA, tB, 1.0, A, pa, B, None, 0.0, C3)
+        assert torch.equal(C1, C3), (tA, tB)
+        assert err_vs_double(C1, A, B, tA, tB) <= 2.5e-7, (tA, tB, err_vs_double(C1, A, B, tA, tB))
 
 
 @pytest.mark.parametrize("sa,sb", [(1e-12, 1.0), (1e-30, 1e8), (3e4, 2e-20), (1e15, 1e-15), (1.0, 1e-38)])
