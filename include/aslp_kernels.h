@@ -158,6 +158,17 @@ void aslp_d2f(float *dst, const double *src, int n);
  * [N x K] if transB).  Returns 0 or a negative argument-error code. */
 int aslp_sgemm(int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda,
                const float *B, int ldb, float beta, float *C, int ldc);
+typedef struct aslp_planes_ aslp_planes;   /* prepared operand planes: below, behind aslp_gemm_split16 */
+/* What a kernel that WRITES a matrix may leave for the products that will read it (csrc/split16.h): the matrix' planes, scaled by a bound
+ * of |value| that is known before the launch (`slot`: its bits, in device memory), and / or one maximum of |value| per workgroup
+ * (`parts`, at most 256) from which the conversion pass takes its scale without reading the matrix for it.  All members optional. */
+typedef struct aslp_planes_out_ {
+  void *hi, *lo;          /* fp16 planes [rows rounded to 64][ld], or NULL */
+  int ld;                 /* halves per plane row */
+  const unsigned *slot;   /* device word: bits of the bound (float) the planes are scaled by */
+  float *parts;           /* device, 256 floats: per-workgroup maxima, or NULL */
+  int nparts;             /* out: how many the launch wrote (0: none, the kernel that ran does not leave them) */
+} aslp_planes_out;
 /* Fused epilogue form.  Applied in this order on the fp32 accumulator `acc`:
  *   v = alpha*acc + beta*C;  if (bias) v += bias[col];  if (clip > 0) v = clamp(v, -clip, clip);
  *   C = v;  if (W) W[row][col] += w_alpha * v  (SGD: w_alpha = -lr);
@@ -189,7 +200,30 @@ typedef struct aslp_gemm_epilogue_ {
    * d_r = out_diff + dGATES(next) W_r (lc.h:791) without first copying out_diff into d_r.  NULL: the classic form. */
   const float *c_src;  /* [M x N], leading dimension ld_c_src, or NULL */
   int ld_c_src;
+  /* What the epilogue leaves for the split-fp16 products that will read its output (honoured by the split-fp16 kernel only:
+   * aslp_gemm_last_parts() tells whether the launch did).  planes_of = 1: the planes of W after the fused step (`planes.slot` must hold
+   * a bound of |W + w_alpha C| before the launch: aslp_weight_bound); 2: the planes of act_out (bound: 1 for sigmoid / tanh).
+   * wmax_parts / cmax_parts (each NULL or aslp_gemm_last_parts() floats): one maximum per wave of |W| after the step / of |C|. */
+  aslp_planes_out planes;
+  int planes_of;
+  float *wmax_parts, *cmax_parts;
 } aslp_gemm_epilogue;
+/* number of per-wave maxima (and proof that the planes were written) of the calling thread's latest aslp_sgemm* call; 0 = the kernel that
+ * ran does not leave them */
+int aslp_gemm_last_parts(void);
+/* Bound of |W + w_alpha C| for the next fused weight step, C = clip(alpha A^T B + beta C_old): from the per-wave maxima of |W| (n_w) and
+ * |C_old| (n_c, may be 0) the previous step left, the bounds of the two operands' planes and K; written to *slot_out (device).  One
+ * small launch on the current stream. */
+void aslp_weight_bound(const float *w_parts, int n_w, const float *c_parts, int n_c, const aslp_planes *a, const aslp_planes *b, int K,
+                       float alpha, float beta, float w_alpha, float clip, aslp_planes *w_planes);
+/* Parameters were written through the raw pointers of GetGpuParams (model averaging, a test perturbing weights): planes of weights the
+ * components keep from step to step are stale from here on.  The native sync workers call it after every exchange. */
+void aslp_params_changed(void);
+/* A/B switch (ASLP_KEEP_WEIGHT_PLANES): 0 = the components convert their weights in every step instead of keeping the planes the
+ * weight-gradient epilogue wrote; -1 = back to the environment's choice (default on) */
+void aslp_keep_weight_planes(int on);
+/* per-workgroup maxima of |src| into parts (256 floats): the start of the chain above */
+void aslp_absmax_parts(const float *src, MatrixDim d, float *parts);
 /* Large products of aslp_sgemm_ex on the fp16 matrix instruction with each fp32 operand carried as two fp16 pieces behind a power-of-two
  * scale of its matrix (csrc/gemm_split16.hip: 22 significant bits, fp32 accumulation; results agree with the fp32 instruction's to fp32
  * rounding).  on = 1 / 0 switches it for this process, -1 hands the choice back to ASLP_GEMM_SPLIT_F16 (default on).  No reference
@@ -199,13 +233,16 @@ void aslp_gemm_split16(int on);
  * read by every product the matrix takes part in (as op(A) or op(B), transposed or not).  aslp_planes_convert: one maximum pass and one
  * conversion pass over src [d.rows x d.cols] (cols and stride multiples of 4, 16-byte aligned).  The engine's components keep such
  * planes per tensor and step and let the kernels that write a tensor write its planes (nnet/nnet-basic.h). */
-typedef struct aslp_planes_ aslp_planes;
 aslp_planes *aslp_planes_new(void);
 void aslp_planes_free(aslp_planes *p);
 int aslp_planes_convert(aslp_planes *p, const float *src, MatrixDim d);
 /* aslp_sgemm_ex with the planes of A and / or B (NULL: that operand is converted inside the call); the planes must be those of the
  * matrix the fp32 pointer names.  Runs on the fp32 instruction like aslp_sgemm_ex when aslp_gemm_split16 is off or the shape is not
  * served. */
+/* the members a producer needs, from an aslp_planes whose bound has been set / whose parts are to be filled */
+void aslp_planes_reserve(aslp_planes *p, int rows, int cols);
+void aslp_planes_set_bound(aslp_planes *p, float bound);
+void aslp_planes_as_output(const aslp_planes *p, aslp_planes_out *out);
 int aslp_sgemm_planes_ex(int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda, const aslp_planes *pa,
                          const float *B, int ldb, const aslp_planes *pb, float beta, float *C, int ldc, const aslp_gemm_epilogue *ep);
 int aslp_sgemm_ex(int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda,
@@ -270,6 +307,10 @@ void aslp_bn_backward_act(const float *in, MatrixDim d, const float *out_diff, i
 int aslp_bn_forward_stats(const float *in, MatrixDim d, float *out, int out_stride, const float *scale, const float *shift, float *mean,
                           float *inv_std, double *acc_means, double *acc_vars, float var_floor, float *act_out, int act_stride,
                           const double *colstats, int groups, int stats_ld);
+/* ... which also leaves the planes of act_out (sigmoid outputs: bound 1; `act_planes->slot` must hold a bound >= 1) */
+int aslp_bn_forward_stats_p(const float *in, MatrixDim d, float *out, int out_stride, const float *scale, const float *shift, float *mean,
+                            float *inv_std, double *acc_means, double *acc_vars, float var_floor, float *act_out, int act_stride,
+                            const double *colstats, int groups, int stats_ld, const aslp_planes_out *act_planes);
 
 /* aslp_bn_backward_act + BatchNormalization::Update (nnet-batch-normalization.h:280-284) taken in the statistics
  * finalize: scale -= learn_rate * dscale, shift -= learn_rate * dshift; in_diff is formed with the scale the
@@ -277,6 +318,11 @@ int aslp_bn_forward_stats(const float *in, MatrixDim d, float *out, int out_stri
 void aslp_bn_backward_step(MatrixDim d, const float *out_diff, int od_stride, float *xhat, int xhat_stride, float *scale, float *shift,
                            const float *inv_std, float *dscale, float *dshift, float momentum, float learn_rate, float *in_diff, int id_stride,
                            const float *act_y, int act_stride, const float *in, const float *mean);
+/* ... which also leaves the per-workgroup maxima of |in_diff| (diff_out->parts / nparts; nparts stays 0 where the kernel that served the
+ * shape does not form them) */
+void aslp_bn_backward_step_p(MatrixDim d, const float *out_diff, int od_stride, float *xhat, int xhat_stride, float *scale, float *shift,
+                             const float *inv_std, float *dscale, float *dshift, float momentum, float learn_rate, float *in_diff, int id_stride,
+                             const float *act_y, int act_stride, const float *in, const float *mean, aslp_planes_out *diff_out);
 /* xhat == NULL in the forward / backward entry points above: no normalised copy of the input is kept; the backward pass forms
  * x_hat again from `in` (d.stride) and `mean` with the forward pass' own operations.  Only where this returns 1 (the
  * single-launch panel kernels: cols % 16 == 0, rows <= 1024) and all operands are 16-byte aligned. */

@@ -55,6 +55,10 @@ int aslp_nnet_get_params(aslp_nnet_t n, float *host_buf, int buf_len);
 /* Nnet::GetGpuParams (:314): device pointers + float counts (rows*stride) of every tensor, in the
  * reference's order.  Returns the number of tensors (also when max_n is too small). */
 int aslp_nnet_get_gpu_params(aslp_nnet_t n, float **ptrs, int *sizes, int max_n);
+/* Whoever writes through those pointers promises to call aslp_params_changed() (include/aslp_kernels.h) after every write; without this
+ * promise a net whose pointers were handed out re-derives everything it keeps of its weights in every step (correct, slower).  The native
+ * sync workers make the promise themselves (aslp_worker_init_param_nnet). */
+int aslp_nnet_param_writers_announce(aslp_nnet_t n);
 /* Nnet::GetAccStats (:327): BatchNorm running statistics. counts_host[i] = num_acc_frames of BN i. */
 int aslp_nnet_get_acc_stats(aslp_nnet_t n, double **dev_ptrs, int *sizes, int max_n, double **counts_host, int max_bn, int *num_bn);
 /* copy component c's forward output / output-diff buffer to the host (reference: PropagateBuffer()) */

@@ -19,11 +19,17 @@ class Dim3(C.Structure):
     _fields_ = [("x", C.c_uint32), ("y", C.c_uint32), ("z", C.c_uint32)]
 
 
+class PlanesOut(C.Structure):
+    """aslp_planes_out (include/aslp_kernels.h)"""
+    _fields_ = [("hi", C.c_void_p), ("lo", C.c_void_p), ("ld", C.c_int), ("slot", C.c_void_p), ("parts", C.c_void_p), ("nparts", C.c_int)]
+
+
 class GemmEpilogue(C.Structure):
     _fields_ = [("bias", C.c_void_p), ("clip", C.c_float), ("W", C.c_void_p), ("ldw", C.c_int),
                 ("w_alpha", C.c_float), ("act_out", C.c_void_p), ("ld_act", C.c_int), ("act", C.c_int),
                 ("colsum", C.c_void_p), ("colsum_beta", C.c_float), ("colsum_w", C.c_void_p), ("colsum_w_alpha", C.c_float),
-                ("colstats", C.c_void_p), ("colstats_ld", C.c_int), ("c_src", C.c_void_p), ("ld_c_src", C.c_int)]
+                ("colstats", C.c_void_p), ("colstats_ld", C.c_int), ("c_src", C.c_void_p), ("ld_c_src", C.c_int),
+                ("planes", PlanesOut), ("planes_of", C.c_int), ("wmax_parts", C.c_void_p), ("cmax_parts", C.c_void_p)]
 
 
 class GruSeq(C.Structure):
@@ -131,6 +137,11 @@ _sig("aslp_planes_new", _vp)
 _sig("aslp_planes_free", None, _vp)
 _sig("aslp_planes_convert", _i, _vp, _vp, _md)
 _sig("aslp_sgemm_planes_ex", _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _vp, _i, _vp, _f, _vp, _i, C.POINTER(GemmEpilogue))
+_sig("aslp_gemm_last_parts", _i)
+_sig("aslp_params_changed", None)
+_sig("aslp_keep_weight_planes", None, _i)
+_sig("aslp_absmax_parts", None, _vp, _md, _vp)
+_sig("aslp_weight_bound", None, _vp, _i, _vp, _i, _vp, _vp, _i, _f, _f, _f, _f, _vp)
 _sig("aslp_gemm_profile", None, _i)
 _sig("aslp_gemm_profile_reset", None)
 _sig("aslp_gru_seq_supported", _i, C.POINTER(GruSeq), _i)

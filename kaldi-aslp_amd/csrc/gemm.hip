@@ -732,6 +732,7 @@ extern "C" {
 // aslp_sgemm_ex with optional prepared planes of either operand (split16.h); an operand without planes is converted in scratch
 static int sgemm_impl(int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda, const float *B, int ldb, float beta,
                       float *C, int ldc, const aslp_gemm_epilogue *ep, const S16View *pa, const S16View *pb) {
+  gemm_split16_reset_last_parts();
   if (M < 0 || N < 0 || K < 0) return -1;
   if (M == 0 || N == 0) return 0;
   if (!C || ldc < N) return -2;
@@ -762,7 +763,8 @@ static int sgemm_impl(int transA, int transB, int M, int N, int K, float alpha, 
   if (prof) (void)hipEventRecord(e0, cur_stream());
   static const int s16_cfg = [] { const char *e = getenv("ASLP_GEMM_SPLIT_F16_TILE"); return e ? atoi(e) : 0; }();
   if (gemm_split16_enabled() && !g_force_tile && gemm_split16_launch(g, !transA, transB != 0, s16_cfg, pa, pb)) {   // (a forced tile asks for an fp32 kernel by name)
-    g.ep.colstats = nullptr;   // formed in its epilogue; column sums (if asked for) by the pass over A below
+    g.ep.colstats = nullptr;   // formed in its epilogue, like the column sums of a transposed A
+    g.ep.colsum = nullptr;
     t_last_cfg = 311;
   } else if (!transA && transB) launch_aligned<true, true>(g);
   else if (!transA && !transB) launch_aligned<true, false>(g);
@@ -805,6 +807,16 @@ int aslp_planes_convert(aslp_planes *p, const float *src, MatrixDim d) {
   const bool ok = reinterpret_cast<PlaneSet *>(p)->ConvertFrom(src, d.rows, d.cols, d.stride);
   check_launch("aslp_planes_convert");
   return ok ? 0 : -2;
+}
+void aslp_planes_reserve(aslp_planes *p, int rows, int cols) { if (p) reinterpret_cast<PlaneSet *>(p)->Reserve(rows, cols); }
+void aslp_planes_set_bound(aslp_planes *p, float bound) { if (p) reinterpret_cast<PlaneSet *>(p)->SetBound(bound); }
+void aslp_planes_as_output(const aslp_planes *p, aslp_planes_out *out) {
+  if (!out) return;
+  *out = aslp_planes_out();
+  if (!p) return;
+  const PlaneSet *ps = reinterpret_cast<const PlaneSet *>(p);
+  const S16View v = ps->View();
+  out->hi = v.hi; out->lo = v.lo; out->ld = v.ld; out->slot = v.slot; out->parts = ps->Parts(); out->nparts = 0;
 }
 int aslp_sgemm_planes_ex(int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda, const aslp_planes *pa, const float *B,
                          int ldb, const aslp_planes *pb, float beta, float *C, int ldc, const aslp_gemm_epilogue *ep) {

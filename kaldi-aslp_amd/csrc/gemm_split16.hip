@@ -22,6 +22,7 @@
 //
 // A/B: ASLP_GEMM_SPLIT_F16=0 keeps every product on the fp32 instruction (default: on).
 #include <algorithm>
+#include <atomic>
 
 #include "gemm_common.h"
 #include "scratch.h"
@@ -32,6 +33,7 @@
 namespace aslp {
 namespace {
 
+thread_local int t_last_parts = 0;   // per-wave maxima the calling thread's latest product left (aslp_gemm_last_parts)
 constexpr int BKH = 64;       // halves per K tile
 constexpr int KH = BKH / 16;  // instruction k steps per tile
 typedef __attribute__((address_space(3))) char lds_char;
@@ -51,16 +53,19 @@ __device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_byte_addr)
 }
 
 // ---- largest finite |x| of up to two matrices (blockIdx.y): every workgroup leaves its own maximum in part[workgroup] -- no atomics,
-// nothing to zero first; the conversion reduces the partials
+// nothing to zero first; the conversion reduces the partials.  Rows are dealt to the workgroups in contiguous chunks; a row is
+// covered by tw = 2^tw_log2 threads with 16 bytes each per pass (no division anywhere, every load of a thread independent).
 struct MaxJob { const float *p; int rows, cols, ld; float *part; };
-__global__ void __launch_bounds__(256) s16_absmax_kernel(MaxJob a, MaxJob b) {
+__global__ void __launch_bounds__(256) s16_absmax_kernel(MaxJob a, MaxJob b, int tw_log2) {
   const MaxJob j = blockIdx.y ? b : a;
-  const int c4 = j.cols >> 2;
-  const long n = (long)j.rows * c4;
+  const int c4 = j.cols >> 2, tw = 1 << tw_log2, rpw = 256 >> tw_log2;
+  const int tr = threadIdx.x >> tw_log2, tc = threadIdx.x & (tw - 1);
+  const int per = (j.rows + gridDim.x - 1) / gridDim.x, r0 = blockIdx.x * per, r1 = min(j.rows, r0 + per);
   float m = 0.f;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    const int r = (int)(i / c4), c = (int)(i - (long)r * c4);
-    m = s16_absmax4(m, *reinterpret_cast<const float4 *>(j.p + (long)r * j.ld + 4 * c));
+  for (int r = r0 + tr; r < r1; r += rpw) {
+    const float *row = j.p + (long)r * j.ld;
+#pragma unroll 4
+    for (int c = tc; c < c4; c += tw) m = s16_absmax4(m, *reinterpret_cast<const float4 *>(row + 4 * c));
   }
   m = wave_max(m);
   __shared__ float wm[4];
@@ -71,36 +76,66 @@ __global__ void __launch_bounds__(256) s16_absmax_kernel(MaxJob a, MaxJob b) {
 // the matrix maximum from the partials (every thread of a 256-thread workgroup gets it)
 __device__ __forceinline__ float reduce_parts(const float *part, int nparts) {
   __shared__ float wm2[4];
-  float m = (int)threadIdx.x < nparts ? part[threadIdx.x] : 0.f;
+  float m = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) m = fmaxf(m, part[i]);
   m = wave_max(m);
   if ((threadIdx.x & 63) == 0) wm2[threadIdx.x >> 6] = m;
   __syncthreads();
-  return fmaxf(fmaxf(wm2[0], wm2[1]), fmaxf(wm2[2], wm2[3]));
+  const float r = fmaxf(fmaxf(wm2[0], wm2[1]), fmaxf(wm2[2], wm2[3]));
+  __syncthreads();   // (wm2 may be reused by a second reduction)
+  return r;
+}
+
+// ---- bound of the weights after the next fused step (include/aslp_kernels.h aslp_weight_bound): one workgroup
+struct BoundJob { const float *w_parts; int n_w; const float *c_parts; int n_c; const unsigned *slot_a, *slot_b; float k, alpha, beta, w_alpha, clip; unsigned *slot_out; };
+__global__ void __launch_bounds__(256) s16_weight_bound_kernel(BoundJob j) {
+  const float mw = reduce_parts(j.w_parts, j.n_w);
+  const float mc = j.n_c > 0 ? reduce_parts(j.c_parts, j.n_c) : 0.f;
+  if (threadIdx.x == 0) {
+    const float ba = __uint_as_float(*j.slot_a), bb = __uint_as_float(*j.slot_b);
+    float v = fabsf(j.alpha) * j.k * ba * bb + fabsf(j.beta) * mc;    // |alpha A^T B + beta C_old| <= alpha K max|a| max|b| + beta max|C_old|
+    if (j.clip > 0.f) v = fminf(v, j.clip);
+    *j.slot_out = __float_as_uint(mw + fabsf(j.w_alpha) * v);
+  }
 }
 
 // ---- fp32 matrix -> planes in the matrix' own layout (padding written as zeros), up to two matrices per launch (blockIdx.y) --------
+// Same dealing of rows; a thread converts 8 consecutive columns per pass (two 16-byte loads, one 16-byte store per plane).
 struct ConvJob { const float *src; int ld_src; S16View pl; const float *part; int nparts; };
-__global__ void __launch_bounds__(256) split16_convert_kernel(ConvJob a, ConvJob b) {
+__global__ void __launch_bounds__(256) split16_convert_kernel(ConvJob a, ConvJob b, int tw_log2) {
   const ConvJob j = blockIdx.y ? b : a;
   const unsigned mbits = __float_as_uint(reduce_parts(j.part, j.nparts));
   if (blockIdx.x == 0 && threadIdx.x == 0) *j.pl.slot = mbits;   // for the products (launched behind this kernel)
   const float s = ldexpf(1.f, s16_exponent(mbits));
-  const int k4 = j.pl.ld >> 2, c4 = j.pl.cols >> 2;   // cols % 4 == 0 (eligibility)
+  const int k8 = j.pl.ld >> 3, tw = 1 << tw_log2, rpw = 256 >> tw_log2;   // ld is a multiple of 64
+  const int tr = threadIdx.x >> tw_log2, tc = threadIdx.x & (tw - 1);
   const int rows_p = (j.pl.rows + kS16Pad - 1) / kS16Pad * kS16Pad;
-  const long n = (long)rows_p * k4;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    const int r = (int)(i / k4), c = (int)(i - (long)r * k4);
-    half4 hi = {0, 0, 0, 0}, lo = {0, 0, 0, 0};
-    if (c < c4 && r < j.pl.rows) s16_split4(*reinterpret_cast<const float4 *>(j.src + (long)r * j.ld_src + 4 * c), s, &hi, &lo);
-    *reinterpret_cast<half4 *>(j.pl.hi + (long)r * j.pl.ld + 4 * c) = hi;
-    *reinterpret_cast<half4 *>(j.pl.lo + (long)r * j.pl.ld + 4 * c) = lo;
+  const int per = (rows_p + gridDim.x - 1) / gridDim.x, r0 = blockIdx.x * per, r1 = min(rows_p, r0 + per);
+  for (int r = r0 + tr; r < r1; r += rpw) {
+    const float *row = j.src + (long)r * j.ld_src;
+    const bool row_ok = r < j.pl.rows;
+#pragma unroll 2
+    for (int c = tc; c < k8; c += tw) {
+      half4 h0 = {0, 0, 0, 0}, l0 = {0, 0, 0, 0}, h1 = {0, 0, 0, 0}, l1 = {0, 0, 0, 0};
+      if (row_ok && 8 * c < j.pl.cols) s16_split4(*reinterpret_cast<const float4 *>(row + 8 * c), s, &h0, &l0);          // cols % 4 == 0
+      if (row_ok && 8 * c + 4 < j.pl.cols) s16_split4(*reinterpret_cast<const float4 *>(row + 8 * c + 4), s, &h1, &l1);
+      *reinterpret_cast<half8 *>(j.pl.hi + (long)r * j.pl.ld + 8 * c) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+      *reinterpret_cast<half8 *>(j.pl.lo + (long)r * j.pl.ld + 8 * c) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
   }
+}
+// threads per row for `units` 16-byte (absmax) / 32-byte (convert) pieces per row
+inline int tw_log2_for(int units) {
+  int l = 0;
+  while (l < 8 && (1 << l) < units) l++;
+  return l;
 }
 
 // ---- the product ---------------------------------------------------------------------------------------------------------------
 struct S16Operands { S16View a, b, a1, b1; int kp; };   // a1 / b1: second product of a pair (blockIdx.z == 1)
 
-template <int BM, int BN, int WGM, int WGN, int NS, bool A_KC, bool B_KC>
+// ABL (devtools/micro/s16_ablate.hip only; 0 in the library): 1 = no MFMA, 2 = no DMA, 4 = no LDS reads -- wrong results, for timing
+template <int BM, int BN, int WGM, int WGN, int NS, bool A_KC, bool B_KC, int ABL = 0>
 __global__ void __launch_bounds__(64 * WGM * WGN) gemm_s16_glds(GemmArgs g, S16Operands ops) {
   constexpr int NW = WGM * WGN;
   constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
@@ -175,7 +210,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_s16_glds(GemmArgs g, S16O
   });
   auto dma_unit = [&](auto U_, auto ST_, int r) {
     constexpr int u = decltype(U_)::value, st = decltype(ST_)::value;
-    glds16(src[u], __builtin_amdgcn_readfirstlane(lds_base + st * STAGE + dst_off[u]));
+    if constexpr (!(ABL & 2)) glds16(src[u], __builtin_amdgcn_readfirstlane(lds_base + st * STAGE + dst_off[u]));
     src[u] += (r + 1 < ktiles) ? adv[u] : 0;   // requests past the last tile fetch it again into a stage nobody reads
   };
 
@@ -214,6 +249,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_s16_glds(GemmArgs g, S16O
   // one LDS read: flat index r -> (k step h, operand, fragment t, plane, half of the fragment)
   auto read_unit = [&](auto ST_, Frag &f, auto R_) {
     constexpr int r = decltype(R_)::value, st = decltype(ST_)::value;
+    if constexpr (ABL & 4) return;
     constexpr int h = r / NRH, q = r % NRH;
     constexpr bool is_a = q < 2 * TM * RA;
     constexpr int q2 = is_a ? q : q - 2 * TM * RA, RR = is_a ? RA : RB;
@@ -224,10 +260,12 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_s16_glds(GemmArgs g, S16O
     if constexpr (is_a) base += a_off[t][kc ? h : 0]; else base += b_off[t][kc ? h : 0];
     if constexpr (kc) {
       const half8 v = *reinterpret_cast<const half8 *>(ldsb + base);
+      if constexpr (ABL & 1) asm volatile("" ::"v"(v));
       if constexpr (is_a) { if constexpr (lo) f.al[h][t] = v; else f.ah[h][t] = v; }
       else { if constexpr (lo) f.bl[h][t] = v; else f.bh[h][t] = v; }
     } else {
       const half4 v = __builtin_bit_cast(half4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4 *)(lds3 + base + (16 * h + 4 * half) * (2 * BR))));
+      if constexpr (ABL & 1) asm volatile("" ::"v"(v));
       half8 *dst = is_a ? (lo ? &f.al[h][t] : &f.ah[h][t]) : (lo ? &f.bl[h][t] : &f.bh[h][t]);
       if constexpr (half == 0) dst->lo = v; else dst->hi = v;
     }
@@ -240,8 +278,29 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_s16_glds(GemmArgs g, S16O
     for (int j = 0; j < TN; j++)
 #pragma unroll
       for (int e = 0; e < 16; e++) { acc[i][j][e] = 0.0f; accx[i][j][e] = 0.0f; }
+  // optional column sums of a reduction-major A operand (the bias gradient on the weight-gradient product, as gemm_glds.hip): the
+  // first column of tiles' wn == 0 waves add up the A pieces they multiply anyway -- sum_k (hi + 2^-11 lo'), unscaled at the end
+  const bool do_colsum = !A_KC && g.ep.colsum != nullptr && tn == 0 && wn == 0;  // wave-uniform
+  float asum[TM];
+#pragma unroll
+  for (int i = 0; i < TM; i++) asum[i] = 0.0f;
+  auto colsum_unit = [&](const Frag &f) {
+    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    const half2v one = {(h16)1.0f, (h16)1.0f}, eps = {(h16)0x1p-11f, (h16)0x1p-11f};
+#pragma unroll
+    for (int h = 0; h < KH; h++)
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const half2v hv = {f.ah[h][i][2 * q], f.ah[h][i][2 * q + 1]}, lv = {f.al[h][i][2 * q], f.al[h][i][2 * q + 1]};
+          asum[i] = __builtin_amdgcn_fdot2(hv, one, asum[i], false);     // fp32 accumulation of exact fp16 values
+          asum[i] = __builtin_amdgcn_fdot2(lv, eps, asum[i], false);
+        }
+  };
   auto mma_unit = [&](const Frag &f, auto M_) {
     constexpr int m = decltype(M_)::value;
+    if constexpr (ABL & 1) return;
     constexpr int n = m % TN, i = (m / TN) % TM, j = (m / (TN * TM)) % 3, h = m / (TN * TM * 3);
     if constexpr (j == 0) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[h][i], f.bh[h][n], acc[i][n], 0, 0, 0);
     else if constexpr (j == 1) accx[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[h][i], f.bl[h][n], accx[i][n], 0, 0, 0);
@@ -256,6 +315,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_s16_glds(GemmArgs g, S16O
       constexpr int sidx = decltype(S_)::value;
       mma_unit(fcur, S_);
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!A_KC && sidx == 0) {
+        if (do_colsum) colsum_unit(fcur);
+      }
       if constexpr (sidx <= SB) {
         static_for<sidx * G / (SB + 1), (sidx + 1) * G / (SB + 1)>([&](auto U_) { dma_unit(U_, StReq(), t + D); });
         if constexpr (sidx == SB) {
@@ -272,6 +334,18 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_s16_glds(GemmArgs g, S16O
   };
 
   Frag f0, f1;
+  if constexpr (ABL & 4) {   // fragments never read: give them defined (non-constant) contents
+    half8 z;
+#pragma unroll
+    for (int e = 0; e < 8; e++) z[e] = (h16)(float)(lane + e);
+    static_for<0, KH>([&](auto H_) {
+      constexpr int h = decltype(H_)::value;
+#pragma unroll
+      for (int t = 0; t < TM; t++) { f0.ah[h][t] = z; f0.al[h][t] = z; f1.ah[h][t] = z; f1.al[h][t] = z; }
+#pragma unroll
+      for (int t = 0; t < TN; t++) { f0.bh[h][t] = z; f0.bl[h][t] = z; f1.bh[h][t] = z; f1.bl[h][t] = z; }
+    });
+  }
   static_for<0, D>([&](auto T_) {
     constexpr int t = decltype(T_)::value;
     static_for<0, G>([&](auto U_) { dma_unit(U_, T_, t); });
@@ -304,22 +378,50 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_s16_glds(GemmArgs g, S16O
 #pragma unroll
         for (int q = 0; q < 16; q++) acc[i][j][q] = (fmaf(accx[i][j][q], 0x1p-11f, acc[i][j][q]) * s1) * s2;
   }
+  if constexpr (!A_KC) {
+    if (do_colsum) {
+      const float inv_a = ldexpf(1.f, -s16_exponent(*va.slot));
+#pragma unroll
+      for (int i = 0; i < TM; i++) {
+        const float s_all = (asum[i] + __shfl_xor(asum[i], 32, 64)) * inv_a;  // the two lane halves hold disjoint k subsets
+        const int row = m0 + wm * WM + i * 32 + l31;
+        if (lh == 0 && row < g.M) {
+          float v = s_all;
+          if (g.ep.colsum_beta != 0.0f) v += g.ep.colsum_beta * g.ep.colsum[row];
+          g.ep.colsum[row] = v;
+          if (g.ep.colsum_w) g.ep.colsum_w[row] += g.ep.colsum_w_alpha * v;
+        }
+      }
+    }
+  }
   if (g.ep.colstats != nullptr) gemm_colstats<TM, TN>(g, acc, m0 + wm * WM, n0 + wn * WN, l31, lh);  // uniform
   static_assert(NW * 32 * kEpiPitch * (int)sizeof(float) <= NS * STAGE, "the waves' epilogue slices must fit into the operand LDS");
+  // planes of an output and per-wave maxima for the products that will read it (aslp_gemm_epilogue.planes / *_parts)
+  EpiExtra xtra;
+  const bool want_extra = g.ep.planes_of != 0 || g.ep.wmax_parts != nullptr || g.ep.cmax_parts != nullptr;   // uniform
+  if (g.ep.planes_of != 0 && g.ep.planes.hi != nullptr) xtra.pscale = ldexpf(1.f, s16_exponent(*g.ep.planes.slot));
   if (g.wide_epilogue && gemm_epilogue_wide_ok(g)) {  // uniform
     __builtin_amdgcn_s_barrier();
-    gemm_epilogue_wide<TM, TN>(g, acc, m0 + wm * WM, n0 + wn * WN, lane, lds + wave * 32 * kEpiPitch);
+    gemm_epilogue_wide<TM, TN>(g, acc, m0 + wm * WM, n0 + wn * WN, lane, lds + wave * 32 * kEpiPitch, want_extra ? &xtra : nullptr);
   } else {
-    gemm_epilogue<TM, TN>(g, acc, m0 + wm * WM, n0 + wn * WN, l31, lh);
+    gemm_epilogue<TM, TN>(g, acc, m0 + wm * WM, n0 + wn * WN, l31, lh, want_extra ? &xtra : nullptr);
+  }
+  if (g.ep.wmax_parts != nullptr || g.ep.cmax_parts != nullptr) {
+    const float wmx = wave_max(xtra.wmax), cmx = wave_max(xtra.cmax);
+    const int idx = ((int)blockIdx.z * (int)gridDim.x + (int)blockIdx.x) * NW + wave;
+    if (lane == 0) {
+      if (g.ep.wmax_parts) g.ep.wmax_parts[idx] = wmx;
+      if (g.ep.cmax_parts) g.ep.cmax_parts[idx] = cmx;
+    }
   }
 }
 
-template <int BM, int BN, int WGM, int WGN, int NS, bool A_KC, bool B_KC>
+template <int BM, int BN, int WGM, int WGN, int NS, bool A_KC, bool B_KC, int ABL = 0>
 void launch_s16(GemmArgs &g, const S16Operands &ops) {
   g.tiles_m = (g.M + BM - 1) / BM;
   g.tiles_n = (g.N + BN - 1) / BN;
   constexpr int lds_bytes = NS * 2 * (BM + BN) * 128;
-  auto kern = gemm_s16_glds<BM, BN, WGM, WGN, NS, A_KC, B_KC>;
+  auto kern = gemm_s16_glds<BM, BN, WGM, WGN, NS, A_KC, B_KC, ABL>;
   static bool attr_set = false;
   if (!attr_set) {
     if (lds_bytes > 48 * 1024)
@@ -327,6 +429,7 @@ void launch_s16(GemmArgs &g, const S16Operands &ops) {
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n, 1, g.pair ? 2 : 1), dim3(64 * WGM * WGN), lds_bytes, cur_stream(), g, ops);
+  t_last_parts = g.tiles_m * g.tiles_n * (g.pair ? 2 : 1) * WGM * WGN;
 }
 template <bool A_KC, bool B_KC>
 bool launch_s16_layout(GemmArgs &g, const S16Operands &ops, int cfg) {
@@ -350,6 +453,25 @@ int g_split16_override = -1;   // aslp_gemm_split16(): -1 = the environment deci
 bool gemm_split16_enabled() {
   static const bool on = !(getenv("ASLP_GEMM_SPLIT_F16") != nullptr && getenv("ASLP_GEMM_SPLIT_F16")[0] == '0');
   return g_split16_override >= 0 ? g_split16_override != 0 : on;
+}
+
+bool gemm_split16_serves(int M, int N, int K) {
+  return gemm_split16_enabled() && M >= 128 && N >= 128 && K >= 64 && !((M | N | K) & 3);
+}
+static int g_keep_override = -1;
+bool s16_keep_weight_planes() {
+  static const bool on = !(getenv("ASLP_KEEP_WEIGHT_PLANES") != nullptr && getenv("ASLP_KEEP_WEIGHT_PLANES")[0] == '0');
+  return g_keep_override >= 0 ? g_keep_override != 0 : on;
+}
+static std::atomic<long> g_param_epoch{1};
+long s16_param_epoch() { return g_param_epoch.load(std::memory_order_relaxed); }
+long s16_new_epoch() {
+  static std::atomic<long> counter{0};
+  return ++counter;
+}
+S16Epochs &s16_epochs() {
+  static thread_local S16Epochs e;
+  return e;
 }
 
 // ---- PlaneSet ----------------------------------------------------------------------------------------------------------------------
@@ -404,21 +526,20 @@ bool PlaneSet::ConvertWithParts(const float *src, int rows, int cols, int stride
   if (!Reserve(rows, cols)) return false;
   host_bound_ = -1.f;
   ConvJob j = {src, stride, View(), parts_, nparts};
-  const long quads = (long)rows_p_ * (ld_ >> 2);
-  hipLaunchKernelGGL(split16_convert_kernel, dim3((unsigned)std::min<long>(1024, (quads + 255) / 256), 1), dim3(256), 0, cur_stream(), j, j);
+  hipLaunchKernelGGL(split16_convert_kernel, dim3(std::min(rows_p_, 512), 1), dim3(256), 0, cur_stream(), j, j, tw_log2_for(ld_ >> 3));
   return true;
 }
 bool PlaneSet::ConvertFrom(const float *src, int rows, int cols, int stride) {
   if ((cols & 3) || (stride & 3) || !aligned16(src)) return false;
   if (!Reserve(rows, cols)) return false;
   MaxJob m = {src, rows, cols, stride, parts_};
-  hipLaunchKernelGGL(s16_absmax_kernel, dim3(kS16MaxParts, 1), dim3(256), 0, cur_stream(), m, m);
-  return ConvertWithParts(src, rows, cols, stride, kS16MaxParts);
+  hipLaunchKernelGGL(s16_absmax_kernel, dim3(kS16ConvParts, 1), dim3(256), 0, cur_stream(), m, m, tw_log2_for(cols >> 2));
+  return ConvertWithParts(src, rows, cols, stride, kS16ConvParts);
 }
 
 // C = epilogue(alpha op(A) op(B) + beta C) from planes.  a_kc: A is stored [M x K] (else [K x M]); b_kc: B is stored [N x K]
 // (else [K x N]).  For a pair (g.pair) a1 / b1 are the second product's operands.  false: not eligible (nothing was launched).
-// Column sums (ep.colsum) stay the caller's job.
+// Column statistics and (transposed A) column sums are formed in the kernel.
 bool gemm_split16_planes_launch(GemmArgs &g, bool a_kc, bool b_kc, const S16View &a, const S16View &b, const S16View *a1, const S16View *b1,
                                 int cfg) {
   if (g.split_k > 1) return false;
@@ -431,6 +552,7 @@ bool gemm_split16_planes_launch(GemmArgs &g, bool a_kc, bool b_kc, const S16View
   // the planes must describe the operands of this product
   auto fits = [&](const S16View &v, bool kc, int outer) { return v.hi && (kc ? (v.rows == outer && v.cols == g.K) : (v.rows == g.K && v.cols == outer)); };
   if (!fits(ops.a, a_kc, g.M) || !fits(ops.b, b_kc, g.N) || !fits(ops.a1, a_kc, g.M) || !fits(ops.b1, b_kc, g.N)) return false;
+  t_last_parts = 0;
   bool ok;
   if (a_kc && b_kc) ok = launch_s16_layout<true, true>(g, ops, cfg);
   else if (a_kc && !b_kc) ok = launch_s16_layout<true, false>(g, ops, cfg);
@@ -443,14 +565,13 @@ bool gemm_split16_planes_launch(GemmArgs &g, bool a_kc, bool b_kc, const S16View
 // conversion in front of the product.
 bool gemm_split16_launch(GemmArgs &g, bool a_kc, bool b_kc, int cfg, const S16View *pa, const S16View *pb) {
   if (g.pair || g.split_k > 1) return false;
-  if (g.M < 128 || g.N < 128 || g.K < 64) return false;
-  if ((g.M & 3) || (g.N & 3) || (g.K & 3)) return false;
+  if (!gemm_split16_serves(g.M, g.N, g.K)) return false;
   if ((!pa && !(g.A && g.a_vec)) || (!pb && !(g.B && g.b_vec))) return false;
   if (pa && pb) return gemm_split16_planes_launch(g, a_kc, b_kc, *pa, *pb, nullptr, nullptr, cfg);
   auto pad = [](int x) { return (x + kS16Pad - 1) / kS16Pad * kS16Pad; };
   const int a_rows = a_kc ? g.M : g.K, a_cols = a_kc ? g.K : g.M, b_rows = b_kc ? g.N : g.K, b_cols = b_kc ? g.K : g.N;
   const size_t plane_a = pa ? 0 : (size_t)pad(a_rows) * pad(a_cols), plane_b = pb ? 0 : (size_t)pad(b_rows) * pad(b_cols);
-  const size_t head = 256 + sizeof(float) * 2 * kS16MaxParts;
+  const size_t head = 256 + sizeof(float) * 2 * kS16ConvParts;
   const size_t bytes = head + sizeof(h16) * 2 * (plane_a + plane_b);
   unsigned char *buf = static_cast<unsigned char *>(scratch(kScratchSplit16, bytes));
   if (!buf) return false;
@@ -459,20 +580,48 @@ bool gemm_split16_launch(GemmArgs &g, bool a_kc, bool b_kc, int cfg, const S16Vi
   h16 *ah = reinterpret_cast<h16 *>(buf + head), *al = ah + plane_a, *bh = al + plane_a, *bl = bh + plane_b;
   const S16View va = pa ? *pa : S16View{ah, al, pad(a_cols), a_rows, a_cols, slots};
   const S16View vb = pb ? *pb : S16View{bh, bl, pad(b_cols), b_rows, b_cols, slots + 1};
-  const MaxJob ma = {g.A, a_rows, a_cols, g.lda, part}, mb = {g.B, b_rows, b_cols, g.ldb, part + kS16MaxParts};
-  const ConvJob ca = {g.A, g.lda, va, part, kS16MaxParts}, cb = {g.B, g.ldb, vb, part + kS16MaxParts, kS16MaxParts};
+  const MaxJob ma = {g.A, a_rows, a_cols, g.lda, part}, mb = {g.B, b_rows, b_cols, g.ldb, part + kS16ConvParts};
+  const ConvJob ca = {g.A, g.lda, va, part, kS16ConvParts}, cb = {g.B, g.ldb, vb, part + kS16ConvParts, kS16ConvParts};
+  // (two matrices in one launch share the threads-per-row choice: the wider of the two)
   if (!pa && !pb) {
-    hipLaunchKernelGGL(s16_absmax_kernel, dim3(kS16MaxParts, 2), dim3(256), 0, cur_stream(), ma, mb);
-    hipLaunchKernelGGL(split16_convert_kernel, dim3(1024, 2), dim3(256), 0, cur_stream(), ca, cb);
+    hipLaunchKernelGGL(s16_absmax_kernel, dim3(kS16ConvParts, 2), dim3(256), 0, cur_stream(), ma, mb, tw_log2_for(std::max(a_cols, b_cols) >> 2));
+    hipLaunchKernelGGL(split16_convert_kernel, dim3(512, 2), dim3(256), 0, cur_stream(), ca, cb, tw_log2_for(std::max(va.ld, vb.ld) >> 3));
   } else {
     const MaxJob &m = pa ? mb : ma;
     const ConvJob &c = pa ? cb : ca;
-    hipLaunchKernelGGL(s16_absmax_kernel, dim3(kS16MaxParts, 1), dim3(256), 0, cur_stream(), m, m);
-    hipLaunchKernelGGL(split16_convert_kernel, dim3(1024, 1), dim3(256), 0, cur_stream(), c, c);
+    hipLaunchKernelGGL(s16_absmax_kernel, dim3(kS16ConvParts, 1), dim3(256), 0, cur_stream(), m, m, tw_log2_for(m.cols >> 2));
+    hipLaunchKernelGGL(split16_convert_kernel, dim3(512, 1), dim3(256), 0, cur_stream(), c, c, tw_log2_for(c.pl.ld >> 3));
   }
   return gemm_split16_planes_launch(g, a_kc, b_kc, va, vb, nullptr, nullptr, cfg);
 }
 
+int gemm_split16_last_parts() { return t_last_parts; }
+void gemm_split16_reset_last_parts() { t_last_parts = 0; }
+// most per-wave maxima a split-fp16 product of this output shape leaves (the caller's arrays must hold them)
+int gemm_split16_max_parts(int M, int N) { return ((M + 63) / 64) * ((N + 127) / 128) * 4; }
+
 }  // namespace aslp
 
-extern "C" void aslp_gemm_split16(int on) { aslp::g_split16_override = on < 0 ? -1 : (on != 0); }
+extern "C" {
+void aslp_keep_weight_planes(int on) { aslp::g_keep_override = on < 0 ? -1 : (on != 0); }
+void aslp_params_changed(void) { aslp::g_param_epoch.fetch_add(1, std::memory_order_relaxed); }
+void aslp_gemm_split16(int on) { aslp::g_split16_override = on < 0 ? -1 : (on != 0); }
+int aslp_gemm_last_parts(void) { return aslp::gemm_split16_last_parts(); }
+void aslp_weight_bound(const float *w_parts, int n_w, const float *c_parts, int n_c, const aslp_planes *a, const aslp_planes *b, int K, float alpha,
+                       float beta, float w_alpha, float clip, aslp_planes *w_planes) {
+  using namespace aslp;
+  if (!w_parts || n_w <= 0 || !a || !b || !w_planes) { set_error("aslp_weight_bound: missing argument"); return; }
+  BoundJob j = {w_parts, n_w, c_parts, c_parts ? n_c : 0, reinterpret_cast<const PlaneSet *>(a)->Slot(), reinterpret_cast<const PlaneSet *>(b)->Slot(),
+                (float)K, alpha, beta, w_alpha, clip, reinterpret_cast<PlaneSet *>(w_planes)->Slot()};
+  hipLaunchKernelGGL(s16_weight_bound_kernel, dim3(1), dim3(256), 0, cur_stream(), j);
+  reinterpret_cast<PlaneSet *>(w_planes)->ForgetHostBound();
+  check_launch("aslp_weight_bound");
+}
+void aslp_absmax_parts(const float *src, MatrixDim d, float *parts) {
+  using namespace aslp;
+  if (!src || !parts || (d.cols & 3) || (d.stride & 3) || !aligned16(src)) { set_error("aslp_absmax_parts: unsupported matrix"); return; }
+  MaxJob m = {src, d.rows, d.cols, d.stride, parts};
+  hipLaunchKernelGGL(s16_absmax_kernel, dim3(kS16ConvParts, 1), dim3(256), 0, cur_stream(), m, m, tw_log2_for(d.cols >> 2));
+  check_launch("aslp_absmax_parts");
+}
+}

@@ -7,6 +7,7 @@
 #include "aslp_kernels.h"
 #include "colreduce.h"
 #include "common.h"
+#include "split16.h"
 
 namespace aslp {
 unsigned *new_async_error_word(const char *what);  // runtime.cpp
@@ -522,7 +523,7 @@ __global__ void __launch_bounds__(kPanelThreads) bn_forward_stats_kernel(const f
                                                                         float *__restrict__ mean, float *__restrict__ inv_std,
                                                                         double *__restrict__ acc_means, double *__restrict__ acc_vars, float inv_rows,
                                                                         float floor_, int rows, float *__restrict__ act, int lda, int Q,
-                                                                        const double *__restrict__ part, int groups, int ldp) {
+                                                                        const double *__restrict__ part, int groups, int ldp, S16Out po) {
   constexpr int CG = kCoopCG, L = kCoopLanes, COLS = kCoopCols, SL = kPanelThreads / COLS;  // SL partial-sum slices per column
   __shared__ double red[3][SL][COLS];
   __shared__ float stat[2][COLS];
@@ -582,6 +583,12 @@ __global__ void __launch_bounds__(kPanelThreads) bn_forward_stats_kernel(const f
       float4 y;
       y.x = sigmoid_ref(o.x); y.y = sigmoid_ref(o.y); y.z = sigmoid_ref(o.z); y.w = sigmoid_ref(o.w);
       *reinterpret_cast<float4 *>(act + (long)r * lda + c) = y;
+      if (po.hi) {   // the planes of the activations for the products that read them (bound: a sigmoid's 1)
+        half4 hi, lo;
+        s16_split4(y, ldexpf(1.f, s16_exponent(*po.slot)), &hi, &lo);
+        *reinterpret_cast<half4 *>(po.hi + (long)r * po.ld + c) = hi;
+        *reinterpret_cast<half4 *>(po.lo + (long)r * po.ld + c) = lo;
+      }
     }
   }
 }
@@ -593,7 +600,7 @@ __global__ void __launch_bounds__(kPanelThreads) bn_backward_coop(const float *_
                                                            float *__restrict__ dshift, float mmt, float neg_lr, bool step,
                                                            float *__restrict__ in_diff, int ldi, int rows, const float *__restrict__ y, int ldy,
                                                            const float *__restrict__ xin, int ldxin, const float *__restrict__ mean, int Q,
-                                                           unsigned long long *inbox, unsigned *err) {
+                                                           unsigned long long *inbox, unsigned *err, float *__restrict__ max_parts) {
   constexpr int CG = kCoopCG, L = kCoopLanes;
   __shared__ float red[kPanelWaves * CG * 8];
   __shared__ float stat[3][4 * CG];  // S1, S2, the scale the forward pass used
@@ -676,6 +683,7 @@ __global__ void __launch_bounds__(kPanelThreads) bn_backward_coop(const float *_
       ca[i] = (2.0f * invB) * dvar;
       cb[i] = invB * dmean;
     }
+    float omax = 0.f;
 #pragma unroll
     for (int k = 0; k < SLOTS; k++) {
       const int r = r0 + lane + k * L;
@@ -691,6 +699,18 @@ __global__ void __launch_bounds__(kPanelThreads) bn_backward_coop(const float *_
       }
       if (!RECOMPUTE) *reinterpret_cast<float4 *>(xhat + (long)r * ldx + c) = make_float4(Dv[0], Dv[1], Dv[2], Dv[3]);
       *reinterpret_cast<float4 *>(in_diff + (long)r * ldi + c) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+      omax = s16_absmax4(omax, make_float4(ov[0], ov[1], ov[2], ov[3]));
+    }
+    if (max_parts != nullptr) {   // this workgroup's largest |in_diff|: the conversion of in_diff takes its scale from these (split16.h)
+      omax = wave_max(omax);
+      __syncthreads();            // (red[] is free: every thread is past the statistics)
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = omax;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        float m = red[0];
+        for (int w = 1; w < kPanelWaves; w++) m = fmaxf(m, red[w]);
+        max_parts[blockIdx.x] = m;
+      }
     }
   }
 }
@@ -1136,6 +1156,12 @@ void aslp_bn_forward_act(const float *in, MatrixDim d, float *out, int out_strid
 int aslp_bn_forward_stats(const float *in, MatrixDim d, float *out, int out_stride, const float *scale, const float *shift, float *mean,
                           float *inv_std, double *acc_means, double *acc_vars, float var_floor, float *act_out, int act_stride,
                           const double *colstats, int groups, int stats_ld) {
+  return aslp_bn_forward_stats_p(in, d, out, out_stride, scale, shift, mean, inv_std, acc_means, acc_vars, var_floor, act_out, act_stride, colstats,
+                                 groups, stats_ld, nullptr);
+}
+int aslp_bn_forward_stats_p(const float *in, MatrixDim d, float *out, int out_stride, const float *scale, const float *shift, float *mean,
+                            float *inv_std, double *acc_means, double *acc_vars, float var_floor, float *act_out, int act_stride,
+                            const double *colstats, int groups, int stats_ld, const aslp_planes_out *act_planes) {
   if (d.rows <= 0 || d.cols <= 0 || !colstats) return 0;
   if (!out && !act_out) { set_error("aslp_bn_forward_stats: no output"); return 0; }
   if (groups != (d.rows + 31) / 32 || stats_ld < d.cols) { set_error("aslp_bn_forward_stats: statistics layout does not match the matrix"); return 0; }
@@ -1149,8 +1175,11 @@ int aslp_bn_forward_stats(const float *in, MatrixDim d, float *out, int out_stri
   int Q = 1;
   while (Q < 8 && P * Q * 2 <= 1024 && (d.rows + 2 * Q - 1) / (2 * Q) >= 64) Q *= 2;   // ~4 workgroups per CU at most, >= 64 rows each
   while ((d.rows + Q - 1) / Q > kStatSlots * kCoopLanes) Q *= 2;                       // at most kStatSlots rows per thread
+  S16Out po = {nullptr, nullptr, 0, nullptr, nullptr};
+  if (act_planes && act_planes->hi && act_out && act_planes->slot && act_planes->ld >= d.cols)
+    po = S16Out{static_cast<h16 *>(act_planes->hi), static_cast<h16 *>(act_planes->lo), act_planes->ld, act_planes->slot, nullptr};
   hipLaunchKernelGGL(bn_forward_stats_kernel, dim3(P * Q), dim3(kPanelThreads), 0, cur_stream(), in, d.stride, out, out_stride, scale, shift, mean,
-                     inv_std, acc_means, acc_vars, 1.0f / (float)d.rows, var_floor, d.rows, act_out, act_stride, Q, colstats, groups, stats_ld);
+                     inv_std, acc_means, acc_vars, 1.0f / (float)d.rows, var_floor, d.rows, act_out, act_stride, Q, colstats, groups, stats_ld, po);
   check_launch("bn_forward_stats");
   return 1;
 }
@@ -1169,7 +1198,9 @@ void aslp_bn_apply(const float *in, MatrixDim d, float *out, int out_stride, con
 
 static void bn_backward_impl(MatrixDim d, const float *out_diff, int od_stride, float *xhat, int xhat_stride, float *scale, float *shift,
                              const float *inv_std, float *dscale, float *dshift, float momentum, float *in_diff, int id_stride,
-                             const float *act_y, int act_stride, bool step, float learn_rate, const float *in, const float *mean) {
+                             const float *act_y, int act_stride, bool step, float learn_rate, const float *in, const float *mean,
+                             aslp_planes_out *diff_out = nullptr) {
+  if (diff_out) diff_out->nparts = 0;
   if (d.rows <= 0 || d.cols <= 0) return;
   const bool y_ok = !act_y || (aligned16(act_y) && act_stride % 4 == 0);
   const bool recompute = xhat == nullptr;
@@ -1182,9 +1213,12 @@ static void bn_backward_impl(MatrixDim d, const float *out_diff, int od_stride, 
   if (cs.q && coop_state().inbox) {
     CoopState &st = coop_state();
     const dim3 grid((d.cols / kCoopCols) * cs.q), block(kPanelThreads);
+    float *max_parts = (diff_out && diff_out->parts && in_diff && (int)grid.x <= kS16MaxParts) ? diff_out->parts : nullptr;
+    if (max_parts) diff_out->nparts = (int)grid.x;
 #define ASLP_BN_BWD_CL(SLOTS, Y, RC)                                                                                                           \
     hipLaunchKernelGGL((bn_backward_coop<SLOTS, Y, RC>), grid, block, 0, cur_stream(), out_diff, od_stride, xhat, xhat_stride, scale, shift, inv_std, \
-                       dscale, dshift, momentum, -learn_rate, step, in_diff, id_stride, d.rows, act_y, act_stride, in, d.stride, mean, cs.q, st.inbox, st.err)
+                       dscale, dshift, momentum, -learn_rate, step, in_diff, id_stride, d.rows, act_y, act_stride, in, d.stride, mean, cs.q, st.inbox, st.err, \
+                       max_parts)
 #define ASLP_BN_BWD_COOP(SLOTS)                                                                      \
     case SLOTS:                                                                                      \
       if (act_y) { if (recompute) ASLP_BN_BWD_CL(SLOTS, true, true); else ASLP_BN_BWD_CL(SLOTS, true, false); }     \
@@ -1241,6 +1275,12 @@ void aslp_bn_backward_step(MatrixDim d, const float *out_diff, int od_stride, fl
                            const float *act_y, int act_stride, const float *in, const float *mean) {
   bn_backward_impl(d, out_diff, od_stride, xhat, xhat_stride, scale, shift, inv_std, dscale, dshift, momentum, in_diff, id_stride, act_y,
                    act_stride, true, learn_rate, in, mean);
+}
+void aslp_bn_backward_step_p(MatrixDim d, const float *out_diff, int od_stride, float *xhat, int xhat_stride, float *scale, float *shift,
+                             const float *inv_std, float *dscale, float *dshift, float momentum, float learn_rate, float *in_diff, int id_stride,
+                             const float *act_y, int act_stride, const float *in, const float *mean, aslp_planes_out *diff_out) {
+  bn_backward_impl(d, out_diff, od_stride, xhat, xhat_stride, scale, shift, inv_std, dscale, dshift, momentum, in_diff, id_stride, act_y,
+                   act_stride, true, learn_rate, in, mean, diff_out);
 }
 // 1: a [rows x cols] batch is served by the single-launch panel kernels (given 16-byte aligned operands), which need no
 // normalised copy of the input: pass xhat = NULL to the forward and backward entry points and save its 8.4 MB each way

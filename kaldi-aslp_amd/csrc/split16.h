@@ -21,7 +21,8 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
 constexpr int kS16Pad = 64;         // both extents of the planes are multiples of this
-constexpr int kS16MaxParts = 256;   // per-workgroup maxima a producer leaves for one matrix
+constexpr int kS16MaxParts = 4096;  // maxima (one per workgroup or wave) a producer may leave for one matrix
+constexpr int kS16ConvParts = 256;  // what the library's own maximum pass leaves
 
 // what a kernel needs of a pair of planes (by value in kernel arguments)
 struct S16View {
@@ -42,6 +43,14 @@ __host__ __device__ inline int s16_exponent(unsigned bound_bits) {
   int up = 14 - e;
   return up > 120 ? 120 : (up < -120 ? -120 : up);
 }
+
+// where a producer kernel leaves planes / maxima (include/aslp_kernels.h aslp_planes_out, as the kernels take it)
+struct S16Out {
+  h16 *hi, *lo;
+  int ld;
+  const unsigned *slot;
+  float *parts;
+};
 
 #if defined(__HIPCC__)
 __device__ __forceinline__ void s16_split(float x, float s, h16 *hi, h16 *lo) {
@@ -91,12 +100,16 @@ class PlaneSet {
   bool ConvertWithParts(const float *src, int rows, int cols, int stride, int nparts);
   // the planes were / will be written by a producer under a bound known on the host (e.g. 1 for sigmoid outputs)
   bool SetBound(float bound);
+  void ForgetHostBound() { host_bound_ = -1.f; }   // a kernel has written the slot
   // validity tag
   void Tag(const void *src, int stride, long epoch) { src_ = src; stride_ = stride; epoch_ = epoch; }
   bool ValidFor(const void *src, int rows, int cols, int stride, long epoch) const {
     return hi_ && src_ == src && rows_ == rows && cols_ == cols && stride_ == stride && epoch_ == epoch;
   }
   void Invalidate() { src_ = nullptr; epoch_ = -1; }
+  // the kernel that wrote `src` left nparts per-workgroup maxima in Parts(): the next conversion of that matrix skips its maximum pass
+  void TagParts(const void *src, int nparts, long epoch) { parts_src_ = src; nparts_ = nparts; parts_epoch_ = epoch; }
+  int PartsFor(const void *src, long epoch) const { return (epoch != 0 && parts_src_ == src && parts_epoch_ == epoch) ? nparts_ : 0; }
 
  private:
   h16 *hi_ = nullptr, *lo_ = nullptr;
@@ -108,8 +121,37 @@ class PlaneSet {
   const void *src_ = nullptr;
   int stride_ = 0;
   long epoch_ = -1;
+  const void *parts_src_ = nullptr;
+  int nparts_ = 0;
+  long parts_epoch_ = -1;
 };
 
 bool gemm_split16_enabled();
+// would aslp_sgemm_ex carry an M x N x K product on the fp16 instruction (switch on, shape served)?
+bool gemm_split16_serves(int M, int N, int K);
+int gemm_split16_last_parts();
+void gemm_split16_reset_last_parts();
+int gemm_split16_max_parts(int M, int N);
+
+// ---- when may planes be reused?  Only inside the graph executor (nnet-nnet.cpp), which knows when its buffers are written: it draws a
+// fresh epoch for every forward pass and for every backward pass and publishes both to the calling thread while a pass runs; planes are
+// tagged with the epoch they were made under.  Outside a pass the epochs are 0 = "nothing may be reused": a component called on its own
+// converts its operands in every call.
+long s16_new_epoch();                        // process-wide unique, > 0
+struct S16Epochs { long fwd = 0, bwd = 0; };
+S16Epochs &s16_epochs();                     // the calling thread's
+struct S16EpochScope {                       // publishes (fwd, bwd) for the duration of a pass
+  S16EpochScope(long fwd, long bwd) : saved_(s16_epochs()) { s16_epochs().fwd = fwd; s16_epochs().bwd = bwd; }
+  ~S16EpochScope() { s16_epochs() = saved_; }
+  S16EpochScope(const S16EpochScope &) = delete;
+  S16EpochScope &operator=(const S16EpochScope &) = delete;
+ private:
+  S16Epochs saved_;
+};
+
+// ---- parameters written behind the components' backs (model averaging through the GetGpuParams pointers): whoever writes them calls
+// aslp_params_changed(), which moves this epoch; planes of weights kept from step to step are tagged with it
+long s16_param_epoch();
+bool s16_keep_weight_planes();   // A/B switch ASLP_KEEP_WEIGHT_PLANES=0 / aslp_keep_weight_planes(0): weights' planes made anew in every step
 
 }  // namespace aslp

@@ -41,6 +41,7 @@ _sig("aslp_nnet_set_seq_lengths", _i, _H, C.POINTER(C.c_int32), _i)
 _sig("aslp_nnet_set_chunk_size", _i, _H, _i)
 _sig("aslp_nnet_get_params", _i, _H, C.POINTER(_f), _i)
 _sig("aslp_nnet_get_gpu_params", _i, _H, C.POINTER(_vp), C.POINTER(_i), _i)
+_sig("aslp_nnet_param_writers_announce", _i, _H)
 _sig("aslp_nnet_get_acc_stats", _i, _H, C.POINTER(_vp), C.POINTER(_i), _i, C.POINTER(C.POINTER(C.c_double)), _i, C.POINTER(_i))
 _sig("aslp_nnet_component_output", _i, _H, _i, C.POINTER(_f), _i, _i)
 _sig("aslp_nnet_component_out_diff", _i, _H, _i, C.POINTER(_f), _i, _i)
@@ -370,14 +371,18 @@ class Nnet:
         _ok(lib.aslp_nnet_get_params(self.h, buf.ctypes.data_as(C.POINTER(_f)), n))
         return buf
 
-    def GetGpuParams(self):
-        """[(device_ptr, n_floats)] in the reference's tensor order (nnet-nnet.cc:314-325)."""
+    def GetGpuParams(self, writers_announce=False):
+        """[(device_ptr, n_floats)] in the reference's tensor order (nnet-nnet.cc:314-325).  writers_announce: the caller promises
+        lib.aslp_params_changed() after every write through these pointers (include/aslp_nnet.h); without it the net stops keeping
+        anything derived from its weights from step to step (always correct, a little slower)."""
         n = lib.aslp_nnet_get_gpu_params(self.h, None, None, 0)
         if n < 0:
             _ok(1)
         ptrs = (_vp * n)()
         sizes = (_i * n)()
         lib.aslp_nnet_get_gpu_params(self.h, ptrs, sizes, n)
+        if writers_announce:
+            _ok(lib.aslp_nnet_param_writers_announce(self.h))
         return [(ptrs[i], sizes[i]) for i in range(n)]
 
     def ComponentOutput(self, c, rows, cols):

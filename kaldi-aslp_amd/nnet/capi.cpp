@@ -170,6 +170,7 @@ int aslp_nnet_get_gpu_params(aslp_nnet_t n, float **ptrs, int *sizes, int max_n)
     return (int)p.size();
   } catch (const std::exception &e) { t_err = e.what(); return -1; }
 }
+int aslp_nnet_param_writers_announce(aslp_nnet_t n) { API_BEGIN n->nnet.ParamWritersAnnounce(); API_END }
 int aslp_nnet_get_acc_stats(aslp_nnet_t n, double **dev_ptrs, int *sizes, int max_n, double **counts_host, int max_bn, int *num_bn) {
   try {
     std::vector<double *> acc;

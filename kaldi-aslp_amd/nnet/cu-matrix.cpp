@@ -455,6 +455,10 @@ void CuMatrixBase::AddMat(float alpha, const CuMatrixBase &A, MatrixTransposeTyp
 }
 void CuMatrixBase::AddMatMat(float alpha, const CuMatrixBase &A, MatrixTransposeType tA, const CuMatrixBase &B, MatrixTransposeType tB,
                              float beta, const aslp_gemm_epilogue *ep) {
+  AddMatMat(alpha, A, tA, B, tB, beta, ep, nullptr, nullptr);
+}
+void CuMatrixBase::AddMatMat(float alpha, const CuMatrixBase &A, MatrixTransposeType tA, const CuMatrixBase &B, MatrixTransposeType tB,
+                             float beta, const aslp_gemm_epilogue *ep, const PlaneSet *pa, const PlaneSet *pb) {
   // cu-matrix.cc:1027-1046 dimension checks
   int m = (tB == kTrans ? B.NumRows() : B.NumCols());
   int n = (tA == kTrans ? A.NumCols() : A.NumRows());
@@ -464,8 +468,8 @@ void CuMatrixBase::AddMatMat(float alpha, const CuMatrixBase &A, MatrixTranspose
   ASLP_ASSERT(n == NumRows());
   ASLP_ASSERT(k == k1);
   if (m == 0) return;
-  int rc = aslp_sgemm_ex(tA == kTrans, tB == kTrans, rows_, cols_, k, alpha, A.Data(), A.Stride(), B.Data(), B.Stride(), beta, data_,
-                         stride_, ep);
+  int rc = aslp_sgemm_planes_ex(tA == kTrans, tB == kTrans, rows_, cols_, k, alpha, A.Data(), A.Stride(), reinterpret_cast<const aslp_planes *>(pa),
+                                B.Data(), B.Stride(), reinterpret_cast<const aslp_planes *>(pb), beta, data_, stride_, ep);
   if (rc != 0) ASLP_ERR << "aslp_sgemm argument error " << rc;
   CheckKernels();
 }

@@ -109,6 +109,7 @@ class CuArray {
 
 class CuMatrixBase;
 class CuSubVector;
+class PlaneSet;
 
 class CuVectorBase {
  public:
@@ -233,6 +234,9 @@ class CuMatrixBase {
   void AddMat(float alpha, const CuMatrixBase &A, MatrixTransposeType tA = kNoTrans);  // this += alpha*A
   void AddMatMat(float alpha, const CuMatrixBase &A, MatrixTransposeType tA, const CuMatrixBase &B, MatrixTransposeType tB,
                  float beta, const aslp_gemm_epilogue *ep = nullptr);
+  // the same with the prepared fp16 planes of A and / or B (csrc/split16.h; NULL: none)
+  void AddMatMat(float alpha, const CuMatrixBase &A, MatrixTransposeType tA, const CuMatrixBase &B, MatrixTransposeType tB,
+                 float beta, const aslp_gemm_epilogue *ep, const PlaneSet *pa, const PlaneSet *pb);
   void AddVecToRows(float alpha, const CuVectorBase &row, float beta = 1.0f);
   void AddVecToCols(float alpha, const CuVectorBase &col, float beta = 1.0f);
   void AddMatMatElements(float alpha, const CuMatrixBase &A, const CuMatrixBase &B, float beta);

@@ -7,9 +7,33 @@
 #include <algorithm>
 #include <cmath>
 
+#include <memory>
+
 #include "nnet-component.h"
+#include "split16.h"
 
 namespace aslp {
+
+// fp16 planes of one operand of a component's products (csrc/split16.h), made on first use; a copied component starts without any
+struct PlaneHolder {
+  PlaneHolder() = default;
+  PlaneHolder(const PlaneHolder &) {}
+  PlaneHolder &operator=(const PlaneHolder &) { return *this; }
+  PlaneSet &get() { if (!p) p.reset(new PlaneSet()); return *p; }
+  // the planes of m for a product about to be issued: reused when the executor's epoch says m is unchanged since they were made, else
+  // converted now (maximum pass + conversion pass).  NULL: the product converts for itself / runs on the fp32 instruction.
+  const PlaneSet *Of(const CuMatrixBase &m, long epoch) {
+    PlaneSet &ps = get();
+    if (epoch != 0 && ps.ValidFor(m.Data(), m.NumRows(), m.NumCols(), m.Stride(), epoch)) return &ps;
+    const int np = ps.PartsFor(m.Data(), epoch);   // maxima left by the kernel that wrote m: no maximum pass
+    const bool ok = np > 0 ? ps.ConvertWithParts(m.Data(), m.NumRows(), m.NumCols(), m.Stride(), np)
+                           : ps.ConvertFrom(m.Data(), m.NumRows(), m.NumCols(), m.Stride());
+    if (!ok) return nullptr;
+    ps.Tag(m.Data(), m.Stride(), epoch);
+    return &ps;
+  }
+  std::unique_ptr<PlaneSet> p;
+};
 
 // ---- graph endpoints (nnet-io.h:19-102) -------------------------------------------------------
 class InputLayer : public Component {
@@ -52,7 +76,12 @@ class AffineTransform : public UpdatableComponent {
   AffineTransform(int32 dim_in, int32 dim_out)
       : UpdatableComponent(dim_in, dim_out), linearity_(dim_out, dim_in), bias_(dim_out), linearity_corr_(dim_out, dim_in),
         bias_corr_(dim_out), learn_rate_coef_(1.0), bias_learn_rate_coef_(1.0), max_norm_(0.0) {}
-  Component *Copy() const { return new AffineTransform(*this); }
+  Component *Copy() const {
+    AffineTransform *c = new AffineTransform(*this);
+    c->WeightsWritten();   // (planes are not copied)
+    c->stats_request_ = nullptr;
+    return c;
+  }
   ComponentType GetType() const { return kAffineTransform; }
 
   void InitData(std::istream &is) {  // :61-127
@@ -89,6 +118,7 @@ class AffineTransform : public UpdatableComponent {
     learn_rate_coef_ = learn_rate_coef;
     bias_learn_rate_coef_ = bias_learn_rate_coef;
     max_norm_ = max_norm;
+    WeightsWritten();
   }
   void ReadData(std::istream &is, bool binary) {  // :129-155
     if ('<' == Peek(is, binary)) {
@@ -106,6 +136,7 @@ class AffineTransform : public UpdatableComponent {
     ASLP_ASSERT(bias_.Dim() == output_dim_);
     linearity_corr_.Resize(output_dim_, input_dim_);
     bias_corr_.Resize(output_dim_);
+    WeightsWritten();
   }
   void WriteData(std::ostream &os, bool binary) const {  // :157-167
     WriteToken(os, binary, "<LearnRateCoef>"); WriteBasicType(os, binary, learn_rate_coef_);
@@ -141,8 +172,31 @@ class AffineTransform : public UpdatableComponent {
       ep.colstats_ld = ld;
       stats_request_ = nullptr;
     }
-    out->AddMatMat(1.0, in, kNoTrans, linearity_, kTrans, 0.0, &ep);
+    const PlaneSet *pa = nullptr, *pb = nullptr;
+    ForwardPlanes(in, &pa, &pb);
+    out->AddMatMat(1.0, in, kNoTrans, linearity_, kTrans, 0.0, &ep, pa, pb);
   }
+  // Every tensor of this layer takes part in two products -- the input in the forward product and the weight gradient, the out-diff in
+  // the in-diff and the weight gradient, the weights in the forward product and the in-diff -- so its fp16 planes (csrc/split16.h) are
+  // made once per step and kept by the component; the executor's epochs (nnet-nnet.cpp) say when a buffer is still what it was.
+  void ForwardPlanes(const CuMatrixBase &in, const PlaneSet **pa, const PlaneSet **pb) {
+    if (!gemm_split16_serves(in.NumRows(), output_dim_, input_dim_)) return;
+    *pa = in_planes_.Of(in, s16_epochs().fwd);
+    *pb = WeightPlanes();
+  }
+  // The planes of the weights: the ones the last weight-gradient product's epilogue wrote beside the updated weights (Update below), as
+  // long as nothing else has touched the weights since; else made now and good for this step.
+  const PlaneSet *WeightPlanes() {
+    if (w_kept_ && !aliased_silently_ && w_kept_param_epoch_ == s16_param_epoch()) return &w_planes_.get();
+    w_kept_ = false;
+    return w_planes_.Of(linearity_, s16_epochs().fwd);
+  }
+  void WeightsWritten() { w_kept_ = false; maxima_valid_ = false; w_planes_.get().Invalidate(); }
+  void ParamsAliased(bool announces) { aliased_silently_ = !announces; }
+  // Executor peepholes (nnet-nnet.cpp): the component that writes this layer's input / out-diff leaves their planes (or the maxima the
+  // conversion needs) here
+  PlaneHolder &InputPlanes() { return in_planes_; }
+  PlaneHolder &DiffPlanes() { return diff_planes_; }
   // Executor peephole (nnet-nnet.cpp): the next Propagate also forms the per-column statistics of its output for the
   // BatchNormalization behind it, in `buf` as aslp_gemm_epilogue.colstats lays them out (groups = ceil(rows / 32), ld = dim rounded to 4)
   void RequestOutputStats(CuVectorD *buf) { stats_request_ = buf; }
@@ -155,10 +209,17 @@ class AffineTransform : public UpdatableComponent {
     aslp_gemm_epilogue ep = aslp_gemm_epilogue();
     ep.bias = bias_.Data();
     ep.act_out = sigmoid_out->Data(); ep.ld_act = sigmoid_out->Stride(); ep.act = 1;
-    out->AddMatMat(1.0, in, kNoTrans, linearity_, kTrans, 0.0, &ep);
+    const PlaneSet *pa = nullptr, *pb = nullptr;
+    ForwardPlanes(in, &pa, &pb);
+    out->AddMatMat(1.0, in, kNoTrans, linearity_, kTrans, 0.0, &ep, pa, pb);
   }
   void BackpropagateFnc(const CuMatrixBase &, const CuMatrixBase &, const CuMatrixBase &out_diff, CuMatrixBase *in_diff) {
-    in_diff->AddMatMat(1.0, out_diff, kNoTrans, linearity_, kNoTrans, 0.0);  // :193-197
+    const PlaneSet *pa = nullptr, *pb = nullptr;
+    if (gemm_split16_serves(out_diff.NumRows(), input_dim_, output_dim_)) {
+      pa = diff_planes_.Of(out_diff, s16_epochs().bwd);
+      pb = WeightPlanes();   // (the weights have not moved since the forward pass: Update comes after this)
+    }
+    in_diff->AddMatMat(1.0, out_diff, kNoTrans, linearity_, kNoTrans, 0.0, nullptr, pa, pb);  // :193-197
   }
   void Update(const CuMatrixBase &input, const CuMatrixBase &diff) {  // :200-245
     const BaseFloat lr = opts_.learn_rate * learn_rate_coef_;
@@ -173,23 +234,68 @@ class AffineTransform : public UpdatableComponent {
     // bias_corr_ = colsum(diff) + mmt * bias_corr_ and the step bias_ += -lr_bias * bias_corr_ ride on the same GEMM:
     // its transposed A operand IS `diff`, so the first column of tiles sums the fragments it multiplies anyway
     ep.colsum = bias_corr_.Data(); ep.colsum_beta = mmt; ep.colsum_w = bias_.Data(); ep.colsum_w_alpha = -lr_bias;
-    linearity_corr_.AddMatMat(1.0, diff, kTrans, input, kNoTrans, mmt, &ep);
+    const PlaneSet *pa = nullptr, *pb = nullptr;
+    if (gemm_split16_serves(output_dim_, input_dim_, num_frames)) {
+      pa = diff_planes_.Of(diff, s16_epochs().bwd);
+      pb = in_planes_.Of(input, s16_epochs().fwd);
+    }
+    // The epilogue that writes the updated weights also writes their fp16 planes for the next step's forward and in-diff products
+    // (csrc/split16.h).  Their scale must be known before the first tile is written: a bound of max |W - lr W_corr| from the
+    // maxima of |W| and |W_corr| the previous step's epilogue left (the first time: one pass over each), the operands' bounds and K.
+    const bool keep = s16_keep_weight_planes() && plain && max_norm_ <= 0.0 && !aliased_silently_ && pa && pb && gemm_split16_serves(num_frames, output_dim_, input_dim_) &&
+                      gemm_split16_max_parts(output_dim_, input_dim_) <= kS16MaxParts && w_planes_.get().Reserve(output_dim_, input_dim_);
+    if (keep) {
+      for (int i = 0; i < 2; i++) {
+        if (w_maxima_[i].Dim() != kS16MaxParts) { w_maxima_[i].Resize(kS16MaxParts); maxima_valid_ = false; }
+        if (c_maxima_[i].Dim() != kS16MaxParts) { c_maxima_[i].Resize(kS16MaxParts); maxima_valid_ = false; }
+      }
+      if (!maxima_valid_ || maxima_param_epoch_ != s16_param_epoch()) {
+        aslp_absmax_parts(linearity_.Data(), linearity_.Dim(), w_maxima_[cur_].Data());
+        aslp_absmax_parts(linearity_corr_.Data(), linearity_corr_.Dim(), c_maxima_[cur_].Data());
+        n_maxima_ = 256;
+      }
+      aslp_planes *wp = reinterpret_cast<aslp_planes *>(&w_planes_.get());
+      aslp_weight_bound(w_maxima_[cur_].Data(), n_maxima_, c_maxima_[cur_].Data(), n_maxima_, reinterpret_cast<const aslp_planes *>(pa),
+                        reinterpret_cast<const aslp_planes *>(pb), num_frames, 1.0f, mmt, -lr, 0.0f, wp);
+      aslp_planes_as_output(wp, &ep.planes);
+      ep.planes_of = 1;
+      ep.wmax_parts = w_maxima_[1 - cur_].Data();
+      ep.cmax_parts = c_maxima_[1 - cur_].Data();
+    }
+    linearity_corr_.AddMatMat(1.0, diff, kTrans, input, kNoTrans, mmt, &ep, pa, pb);
+    const int left = keep ? aslp_gemm_last_parts() : 0;
+    if (left > 0) {   // the split-fp16 kernel ran: planes and maxima are those of the weights as they are now
+      cur_ = 1 - cur_;
+      n_maxima_ = left;
+      maxima_valid_ = true;
+      maxima_param_epoch_ = w_kept_param_epoch_ = s16_param_epoch();
+      w_kept_ = true;
+    } else {
+      WeightsWritten();
+    }
     if (!plain) {
       if (l2 != 0.0) linearity_.AddMat(-lr * l2 * num_frames, linearity_);
       if (l1 != 0.0) cu::RegularizeL1(&linearity_, &linearity_corr_, lr * l1 * num_frames, lr);
       linearity_.AddMat(-lr, linearity_corr_);
     }
-    if (max_norm_ > 0.0) { aslp_max_norm_rows(linearity_.Data(), linearity_.Dim(), max_norm_); }  // :231-243
+    if (max_norm_ > 0.0) { aslp_max_norm_rows(linearity_.Data(), linearity_.Dim(), max_norm_); WeightsWritten(); }  // :231-243
   }
   const CuVectorBase &GetBias() const { return bias_; }
   void SetBias(const CuVectorBase &bias) { ASLP_ASSERT(bias.Dim() == bias_.Dim()); bias_.CopyFromVec(bias); }
   const CuMatrixBase &GetLinearity() const { return linearity_; }
-  void SetLinearity(const CuMatrixBase &l) { ASLP_ASSERT(SameDim(l, linearity_)); linearity_.CopyFromMat(l); }
+  void SetLinearity(const CuMatrixBase &l) { ASLP_ASSERT(SameDim(l, linearity_)); linearity_.CopyFromMat(l); WeightsWritten(); }
   const CuVectorBase &GetBiasCorr() const { return bias_corr_; }
   const CuMatrixBase &GetLinearityCorr() const { return linearity_corr_; }
 
  private:
   CuVectorD *stats_request_ = nullptr;
+  PlaneHolder in_planes_, diff_planes_, w_planes_;
+  // weights' planes kept from step to step (Update): valid flag, the parameter epoch they belong to, per-wave maxima of |W| and
+  // |W_corr| in two alternating arrays (one is read by the bound kernel while the epilogue fills the other)
+  bool w_kept_ = false, maxima_valid_ = false, aliased_silently_ = false;
+  long w_kept_param_epoch_ = -1, maxima_param_epoch_ = -1;
+  CuVector w_maxima_[2], c_maxima_[2];
+  int n_maxima_ = 0, cur_ = 0;
   CuMatrix linearity_;
   CuVector bias_;
   CuMatrix linearity_corr_;
@@ -626,6 +732,11 @@ class BatchNormalization : public UpdatableComponent {
   // Executor peephole: the producer of the next Propagate's input (an AffineTransform) has left the column statistics of that
   // input in `stats` (AffineTransform::RequestOutputStats); one-shot.
   void UseInputStats(const CuVectorD *stats) { input_stats_ = stats; }
+  // Executor peepholes (one-shot): the AffineTransform that alone reads the next PropagateWithSigmoid's output wants its fp16 planes
+  // (csrc/split16.h; sigmoid outputs: bound 1, written by the same launch); the AffineTransform whose out-diff the next
+  // BackpropagateWithSigmoid writes wants the maxima its conversion needs.
+  void ProduceOutputPlanes(PlaneHolder *h) { out_planes_ = h; }
+  void LeaveDiffMaxima(PlaneHolder *h) { diff_maxima_ = h; }
   void PropagateWithSigmoid(const CuMatrixBase &in, CuMatrix *sigmoid_out) {
     ASLP_ASSERT(in.NumCols() == input_dim_);
     if (!acc_cleaned_) { acc_cleaned_ = true; CleanAccs(); }
@@ -655,13 +766,19 @@ class BatchNormalization : public UpdatableComponent {
 
  private:
   const CuVectorD *input_stats_ = nullptr;
+  PlaneHolder *out_planes_ = nullptr, *diff_maxima_ = nullptr;
   void Backward(const CuMatrixBase &in, const CuMatrixBase &out_diff, BaseFloat *in_diff, int32 id_stride, const BaseFloat *act_y, int32 act_stride) {
+    PlaneHolder *dm = diff_maxima_;
+    diff_maxima_ = nullptr;
     if (fold_update_) {
       fold_update_ = false;
       update_done_ = true;
-      aslp_bn_backward_step(in.Dim(), out_diff.Data(), out_diff.Stride(), xhat_kept_ ? XsharpO_.Data() : nullptr, XsharpO_.Stride(), scale_.Data(),
-                            shift_.Data(), var_vec_.Data(), dscale_.Data(), dshift_.Data(), opts_.momentum, opts_.learn_rate, in_diff, id_stride, act_y,
-                            act_stride, in.Data(), mean_vec_.Data());
+      aslp_planes_out po = aslp_planes_out();
+      if (dm && in_diff && dm->get().Reserve(in.NumRows(), input_dim_)) aslp_planes_as_output(reinterpret_cast<const aslp_planes *>(&dm->get()), &po);
+      aslp_bn_backward_step_p(in.Dim(), out_diff.Data(), out_diff.Stride(), xhat_kept_ ? XsharpO_.Data() : nullptr, XsharpO_.Stride(), scale_.Data(),
+                              shift_.Data(), var_vec_.Data(), dscale_.Data(), dshift_.Data(), opts_.momentum, opts_.learn_rate, in_diff, id_stride, act_y,
+                              act_stride, in.Data(), mean_vec_.Data(), &po);
+      if (po.nparts > 0) dm->get().TagParts(in_diff, po.nparts, s16_epochs().bwd);
     } else {
       aslp_bn_backward_act(in.Data(), in.Dim(), out_diff.Data(), out_diff.Stride(), xhat_kept_ ? XsharpO_.Data() : nullptr, XsharpO_.Stride(), scale_.Data(),
                            mean_vec_.Data(), var_vec_.Data(), dscale_.Data(), dshift_.Data(), opts_.momentum, in_diff, id_stride, act_y, act_stride);
@@ -671,12 +788,19 @@ class BatchNormalization : public UpdatableComponent {
   bool ForwardFromStats(const CuMatrixBase &in, BaseFloat *out, int32 out_stride, BaseFloat *act, int32 act_stride) {
     const CuVectorD *st = input_stats_;
     input_stats_ = nullptr;
+    PlaneHolder *oh = out_planes_;
+    out_planes_ = nullptr;
     if (st == nullptr || xhat_kept_) return false;
     const int groups = (in.NumRows() + 31) / 32, ld = (input_dim_ + 3) & ~3;
     if (st->Dim() != 3 * groups * ld) return false;
-    if (!aslp_bn_forward_stats(in.Data(), in.Dim(), out, out_stride, scale_.Data(), shift_.Data(), mean_vec_.Data(), var_vec_.Data(), acc_means_.Data(),
-                               acc_vars_.Data(), var_floor_, act, act_stride, st->Data(), groups, ld))
+    aslp_planes_out po = aslp_planes_out();
+    PlaneSet *ps = (oh && act) ? &oh->get() : nullptr;
+    if (ps && ps->Reserve(in.NumRows(), output_dim_) && ps->SetBound(1.0f)) aslp_planes_as_output(reinterpret_cast<const aslp_planes *>(ps), &po);
+    else ps = nullptr;
+    if (!aslp_bn_forward_stats_p(in.Data(), in.Dim(), out, out_stride, scale_.Data(), shift_.Data(), mean_vec_.Data(), var_vec_.Data(), acc_means_.Data(),
+                                 acc_vars_.Data(), var_floor_, act, act_stride, st->Data(), groups, ld, ps ? &po : nullptr))
       return false;
+    if (ps) ps->Tag(act, act_stride, s16_epochs().fwd);
     num_acc_frames_ += in.NumRows();
     return true;
   }

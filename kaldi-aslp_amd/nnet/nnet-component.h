@@ -176,6 +176,9 @@ class UpdatableComponent : public Component {
   }
   // (device pointer, number of floats incl. row padding) per tensor, in the reference's order
   virtual void GetGpuParams(std::vector<std::pair<BaseFloat *, int>> *params) = 0;
+  // The GetGpuParams pointers went to a writer outside the component.  announces: that writer calls aslp_params_changed() after every write
+  // (the native sync workers do); otherwise nothing derived from the parameters may be kept from step to step any more.
+  virtual void ParamsAliased(bool announces) {}
   virtual void Update(const CuMatrixBase &input, const CuMatrixBase &diff) = 0;
   virtual void SetTrainOptions(const NnetTrainOptions &opts) { opts_ = opts; }
   const NnetTrainOptions &GetTrainOptions() const { return opts_; }

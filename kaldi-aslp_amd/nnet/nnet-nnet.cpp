@@ -1,5 +1,6 @@
 // nnet-nnet.cpp -- graph executor.  Follows src/aslp-nnet/nnet-nnet.cc (cited per function).
 #include "nnet-nnet.h"
+#include "split16.h"
 
 #include <cstdlib>
 #include <chrono>
@@ -60,6 +61,14 @@ int32 Nnet::AffineSigmoidOf(int32 i) const {
   }
   return -1;
 }
+int32 Nnet::AffineConsumerOf(int32 c) const {
+  if (!fuse_layers_ || !alias_links_ || num_consumers_[c] != 1) return -1;
+  for (int32 j = c + 1; j < NumComponents(); j++) {
+    const std::vector<int32> &inp = components_[j]->GetInput();
+    if (inp.size() == 1 && inp[0] == c) return (components_[j]->GetType() == Component::kAffineTransform && IsDirectLink(j)) ? j : -1;
+  }
+  return -1;
+}
 const CuMatrixBase &Nnet::OutputBuffer(int32 c) const {
   if (FusedSigmoidOf(c) >= 0) ASLP_ERR << "output of component " << c << " is not materialised (fused into the Sigmoid behind it); SetLayerFusion(false)";
   if (softmax_folded_ && (IsFinalSoftmax(c) || c == output_[0]))
@@ -74,6 +83,10 @@ const CuMatrixBase &Nnet::OutputDiffBuffer(int32 c) const {
 void Nnet::Propagate(const std::vector<const CuMatrixBase *> &in, std::vector<CuMatrix *> *out) {  // nnet-nnet.cc:70-106
   ASLP_ASSERT(in.size() == input_.size());
   int num_frame = in[0]->NumRows();
+  // every buffer of the forward pass is rewritten from here on: operand planes of the previous pass are stale; the ones made
+  // during this pass stay usable until the next forward pass (the backward pass reads the same buffers)
+  fwd_epoch_ = s16_new_epoch();
+  S16EpochScope plane_scope(fwd_epoch_, 0);
   for (size_t i = 0; i < input_.size(); i++) in_view_[input_[i]] = in[i];  // InputLayer reads the caller's matrix
   softmax_folded_ = false;
   std::vector<char> done(components_.size(), 0);  // Sigmoids already produced by the BatchNormalization in front of them
@@ -113,6 +126,9 @@ void Nnet::Propagate(const std::vector<const CuMatrixBase *> &in, std::vector<Cu
       out_view_[as] = &output_buf_[as];
       done[as] = 1;
     } else if (fs >= 0) {  // BatchNormalization + Sigmoid in one statistics pass and one write pass
+      const int32 ac = AffineConsumerOf(fs);   // ... which also leaves the activations' fp16 planes for the layer product that reads them
+      if (ac >= 0 && gemm_split16_serves(num_frame, components_[ac]->OutputDim(), components_[ac]->InputDim()))
+        dynamic_cast<BatchNormalization *>(components_[i])->ProduceOutputPlanes(&dynamic_cast<AffineTransform *>(components_[ac])->InputPlanes());
       dynamic_cast<BatchNormalization *>(components_[i])->PropagateWithSigmoid(*in_view_[i], &output_buf_[fs]);
       out_view_[i] = &output_buf_[fs];
       out_view_[fs] = &output_buf_[fs];
@@ -184,6 +200,7 @@ void Nnet::Backpropagate(const std::vector<const CuMatrixBase *> &out_diff, std:
   ASLP_ASSERT(out_diff.size() == output_.size());
   int num_frame = out_diff[0]->NumRows();
   const int32 N = NumComponents();
+  S16EpochScope plane_scope(fwd_epoch_, s16_new_epoch());   // the forward buffers as Propagate left them; every diff buffer new
   // which producers receive their out-diff by accumulation (need a zeroed buffer, :112-114)
   std::vector<char> direct(N, 0);
   for (int32 i = 0; i < N; i++) {
@@ -244,6 +261,12 @@ void Nnet::Backpropagate(const std::vector<const CuMatrixBase *> &out_diff, std:
         out_diff_view_[i] = target;
       } else if (fused_sigmoid[i] >= 0) {
         const int32 fs = fused_sigmoid[i];
+        if (direct[i] && components_[components_[i]->GetInput()[0]]->GetType() == Component::kAffineTransform) {
+          // the in-diff is the out-diff of the AffineTransform in front: its conversion takes the scale from maxima this launch leaves
+          AffineTransform *at = dynamic_cast<AffineTransform *>(components_[components_[i]->GetInput()[0]]);
+          if (gemm_split16_serves(at->OutputDim(), at->InputDim(), num_frame))
+            dynamic_cast<BatchNormalization *>(components_[i])->LeaveDiffMaxima(&at->DiffPlanes());
+        }
         dynamic_cast<BatchNormalization *>(components_[i])->FoldNextUpdateIntoBackprop();
         dynamic_cast<BatchNormalization *>(components_[i])->BackpropagateWithSigmoid(*in_view_[i], output_buf_[fs], output_diff_buf_[fs], target);
       } else {
@@ -287,6 +310,8 @@ void Nnet::Feedforward(const std::vector<const CuMatrixBase *> &in, std::vector<
   ASLP_ASSERT(NULL != out);
   ASLP_ASSERT(in.size() == input_.size());
   int num_frame = in[0]->NumRows();
+  fwd_epoch_ = s16_new_epoch();   // (the forward buffers are rewritten: see Propagate)
+  S16EpochScope plane_scope(fwd_epoch_, 0);
   for (size_t i = 0; i < input_.size(); i++) in_view_[input_[i]] = in[i];
   for (int32 i = 0; i < (int32)components_.size(); i++) {
     if (components_[i]->GetType() != Component::kInputLayer) {
@@ -398,8 +423,14 @@ void Nnet::GetGpuParams(std::vector<std::pair<BaseFloat *, int>> *params) {  // 
     if (components_[i]->IsUpdatable()) {
       std::vector<std::pair<BaseFloat *, int>> c_params;
       dynamic_cast<UpdatableComponent &>(*components_[i]).GetGpuParams(&c_params);
+      dynamic_cast<UpdatableComponent &>(*components_[i]).ParamsAliased(false);
       params->insert(params->end(), c_params.begin(), c_params.end());
     }
+  aslp_params_changed();   // (the caller may already hold pointers from an earlier call)
+}
+void Nnet::ParamWritersAnnounce() {
+  for (size_t i = 0; i < components_.size(); i++)
+    if (components_[i]->IsUpdatable()) dynamic_cast<UpdatableComponent &>(*components_[i]).ParamsAliased(true);
 }
 void Nnet::GetAccStats(std::vector<double *> *acc_params, std::vector<std::pair<double *, int>> *data_params) {  // :327-342
   ASLP_ASSERT(acc_params != NULL && data_params != NULL);

@@ -46,6 +46,8 @@ class Nnet {
   int32 NumParams() const;
   void GetParams(std::vector<BaseFloat> *wei_copy) const;
   void GetGpuParams(std::vector<std::pair<BaseFloat *, int>> *params);
+  // whoever holds the GetGpuParams pointers calls aslp_params_changed() after writing through them (the native sync workers)
+  void ParamWritersAnnounce();
   void GetAccStats(std::vector<double *> *acc_params, std::vector<std::pair<double *, int>> *data_params);
 
   void ResetLstmStreams(const std::vector<int32> &stream_reset_flag);
@@ -109,7 +111,8 @@ class Nnet {
   bool IsFinalSoftmax(int32 i) const;
   int32 FusedSigmoidOf(int32 i) const;  // index of the Sigmoid folded into BatchNormalization i, or -1
   int32 BatchNormOf(int32 i) const;      // index of the BatchNormalization that is AffineTransform i's only consumer (direct link), or -1
-  int32 AffineSigmoidOf(int32 i) const;  // index of the Sigmoid whose forward pass rides in AffineTransform i's GEMM, or -1
+  int32 AffineSigmoidOf(int32 i) const;
+  int32 AffineConsumerOf(int32 c) const;  // index of the AffineTransform that alone reads component c's output (direct link), or -1  // index of the Sigmoid whose forward pass rides in AffineTransform i's GEMM, or -1
 
   std::vector<Component *> components_;
   std::vector<int32> input_, output_;
@@ -126,6 +129,7 @@ class Nnet {
   bool fuse_layers_ = true;
   bool overlap_updates_ = true;
   bool fold_softmax_request_ = false, softmax_folded_ = false, diff_in_place_ = false;
+  long fwd_epoch_ = 0;  // csrc/split16.h: the forward pass whose buffers are still in place (operand planes made from them may be reused)
 };
 
 }  // namespace aslp

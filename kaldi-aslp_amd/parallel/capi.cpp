@@ -98,6 +98,7 @@ int aslp_worker_init_param_nnet(aslp_worker_t w, aslp_nnet_t net) {
   std::vector<int> sizes(n > 0 ? n : 1);
   if (aslp_nnet_get_gpu_params(net, ptrs.data(), sizes.data(), n) != n) ASLP_ERR << "aslp_worker_init_param_nnet: " << aslp_nnet_last_error();
   w->worker->InitParam(Params(ptrs.data(), sizes.data(), n));
+  if (aslp_nnet_param_writers_announce(net) != 0) ASLP_ERR << "aslp_worker_init_param_nnet: " << aslp_nnet_last_error();   // the workers call aslp_params_changed()
   API_END
 }
 int aslp_worker_synchronize(aslp_worker_t w, int num_worker_samples, int *more) {

@@ -28,6 +28,7 @@ void IWorker::ReduceAccStat(const std::vector<double *> &acc_params, const std::
 
 // ---- BSP (bsp-worker.cc:33-65) ------------------------------------------------------------------------------------
 bool BspWorker::Synchronize(int num_worker_samples) {
+  aslp_params_changed();   // the model is (about to be) written through the GetGpuParams pointers: planes kept of it are stale
   int32 num_all_samples = num_worker_samples;
   comm_->AllReduceSumHost(&num_all_samples, 1);
   if (num_all_samples <= 0) { ASLP_LOG << "All worker finished their data"; return false; }
@@ -39,6 +40,7 @@ bool BspWorker::Synchronize(int num_worker_samples) {
   return true;
 }
 void BspWorker::Stop() {
+  aslp_params_changed();   // the model is (about to be) written through the GetGpuParams pointers: planes kept of it are stale
   ASLP_LOG << "Worker " << Rank() << "finished, waitting for others";
   while (Synchronize(0)) {}
 }
@@ -66,6 +68,7 @@ BmufWorker::~BmufWorker() {
     for (auto &p : *v) (void)hipFree(p.first);
 }
 bool BmufWorker::Synchronize(int num_worker_samples) {
+  aslp_params_changed();   // the model is (about to be) written through the GetGpuParams pointers: planes kept of it are stale
   int32 num_all_samples = num_worker_samples;
   comm_->AllReduceSumHost(&num_all_samples, 1);
   if (num_all_samples <= 0) { ASLP_LOG << "All worker finished their data"; return false; }
@@ -89,6 +92,7 @@ bool BmufWorker::Synchronize(int num_worker_samples) {
   return true;
 }
 void BmufWorker::Stop() {
+  aslp_params_changed();   // the model is (about to be) written through the GetGpuParams pointers: planes kept of it are stale
   ASLP_LOG << "Worker " << Rank() << "finished, waitting for others";
   while (Synchronize(0)) {}
 }
@@ -112,6 +116,7 @@ SodWorker::~SodWorker() {
     for (auto &p : *v) (void)hipFree(p.first);
 }
 bool SodWorker::Synchronize(int num_worker_samples) {
+  aslp_params_changed();   // the model is (about to be) written through the GetGpuParams pointers: planes kept of it are stale
   int32 num_all_samples = num_worker_samples;
   comm_->AllReduceSumHost(&num_all_samples, 1);
   if (num_all_samples <= 0) { ASLP_LOG << "All worker finished their data"; return false; }
@@ -135,6 +140,7 @@ bool SodWorker::Synchronize(int num_worker_samples) {
   return true;
 }
 void SodWorker::Stop() {
+  aslp_params_changed();   // the model is (about to be) written through the GetGpuParams pointers: planes kept of it are stale
   ASLP_LOG << "Worker " << Rank() << "finished, waitting for others";
   while (Synchronize(0)) {}
 }
@@ -155,12 +161,14 @@ static void AddVec(const std::vector<std::pair<BaseFloat *, int>> &y, float a, c
 void EasgdWorker::InitParam(const std::vector<std::pair<BaseFloat *, int>> &params) { params_ = params; server_ = AllocLike(params, false); }
 EasgdWorker::~EasgdWorker() { FreeAll(&server_); }
 bool EasgdWorker::Synchronize(int) {
+  aslp_params_changed();   // the model is (about to be) written through the GetGpuParams pointers: planes kept of it are stale
   comm_->PostToServer(kMsgSynchronize);
   comm_->Exchange(MainNode(), params_, server_);          // both sides hand over their model as it is now
   AddVec(params_, alpha_, server_, 1.0f - alpha_);         // x_w = (1 - alpha) x_w + alpha x_s
   return true;
 }
 void EasgdWorker::Stop() {
+  aslp_params_changed();   // the model is (about to be) written through the GetGpuParams pointers: planes kept of it are stale
   comm_->PostToServer(kMsgFinished);
   ASLP_LOG << "Worker " << Rank() << " finished";
 }
@@ -201,6 +209,7 @@ void PairSync::Init(const std::vector<std::pair<BaseFloat *, int>> &params) {
   ASLP_LOG << "total params " << total;
 }
 void PairSync::Sync() {
+  aslp_params_changed();   // the model is (about to be) written through the GetGpuParams pointers: planes kept of it are stale
   int32 done[2] = {0, 0};
   done[comm_->Rank()] = self_done_;
   comm_->AllReduceSumHost(done, 2);  // both flags on both ranks
@@ -231,6 +240,7 @@ void AsgdWorker::InitParam(const std::vector<std::pair<BaseFloat *, int>> &param
 }
 AsgdWorker::~AsgdWorker() { FreeAll(&prev_); FreeAll(&delta_); }
 bool AsgdWorker::Synchronize(int) {
+  aslp_params_changed();   // the model is (about to be) written through the GetGpuParams pointers: planes kept of it are stale
   comm_->PostToServer(kMsgSynchronize);
   for (size_t i = 0; i < params_.size(); i++) aslp_vec_diff(delta_[i].first, params_[i].first, prev_[i].first, params_[i].second);
   CheckK();
@@ -240,6 +250,7 @@ bool AsgdWorker::Synchronize(int) {
   return true;
 }
 void AsgdWorker::Stop() {
+  aslp_params_changed();   // the model is (about to be) written through the GetGpuParams pointers: planes kept of it are stale
   comm_->PostToServer(kMsgFinished);
   ASLP_LOG << "Worker " << Rank() << " finished";
 }

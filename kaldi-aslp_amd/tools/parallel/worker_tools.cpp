@@ -111,6 +111,7 @@ int Main_aslp_nnet_train_frame_worker(int argc, char *argv[]) {
     std::unique_ptr<IWorker> worker = MakeWorker(worker_type, comm.get(), alpha, bmuf_learn_rate, bmuf_momentum, &optimizer_opts);
     std::vector<std::pair<BaseFloat *, int>> params;
     nnet.GetGpuParams(&params);
+    nnet.ParamWritersAnnounce();   // the sync workers call aslp_params_changed() after every exchange
     worker->InitParam(params);
     ASLP_LOG << "Mpi cluster info total " << worker->NumNodes() << " worker rank " << worker->Rank();
 
@@ -250,6 +251,7 @@ int Main_aslp_nnet_train_lstm_stream_worker(int argc, char *argv[]) {
     std::unique_ptr<IWorker> worker = MakeWorker(worker_type, comm.get(), alpha, bmuf_learn_rate, bmuf_momentum, &optimizer_opts);
     std::vector<std::pair<BaseFloat *, int>> params;
     nnet.GetGpuParams(&params);
+    nnet.ParamWritersAnnounce();   // the sync workers call aslp_params_changed() after every exchange
     worker->InitParam(params);
     ASLP_LOG << "Mpi cluster info total " << worker->NumNodes() << " worker rank " << worker->Rank();
     int32 num_frames_since_last_sync = 0;
@@ -419,6 +421,7 @@ int Main_aslp_nnet_train_lc_blstm_streams_worker(int argc, char *argv[]) {
     std::unique_ptr<IWorker> worker = MakeWorker(worker_type, comm.get(), alpha, bmuf_learn_rate, bmuf_momentum, nullptr);
     std::vector<std::pair<BaseFloat *, int>> params;
     nnet.GetGpuParams(&params);
+    nnet.ParamWritersAnnounce();   // the sync workers call aslp_params_changed() after every exchange
     worker->InitParam(params);
     ASLP_LOG << "Mpi cluster info total " << worker->NumNodes() << " worker rank " << worker->Rank();
     int32 num_frames_since_last_sync = 0;
@@ -605,6 +608,7 @@ int Main_aslp_nnet_train_server(int argc, char *argv[]) {
     else ASLP_ERR << "Unsupported server type: " << server_type;
     std::vector<std::pair<BaseFloat *, int>> params;
     nnet.GetGpuParams(&params);
+    nnet.ParamWritersAnnounce();   // the sync workers call aslp_params_changed() after every exchange
     server->InitParam(params);
     ASLP_LOG << "Mpi cluster info total " << server->NumNodes() << " server rank " << server->Rank();
     server->Run();
@@ -650,6 +654,7 @@ class PairSimpleSync : public SimpleSync {
   void Init(aslp::Nnet *nnet, std::string *feature_rspecifier) {
     std::vector<std::pair<aslp::BaseFloat *, int>> params;
     nnet->GetGpuParams(&params);
+    nnet->ParamWritersAnnounce();
     pair_->Init(params);
     const std::string rank = std::to_string(pair_->Rank());
     for (size_t pos = 0; (pos = feature_rspecifier->find("JOB", pos)) != std::string::npos; pos += rank.size()) feature_rspecifier->replace(pos, 3, rank);

@@ -166,3 +166,77 @@ def test_cfg2_training_steps_agree(aslp, dev):
     l32, p32, l16, p16 = losses
     assert abs(l16 - l32) < 2e-6 * abs(l32), (l16, l32)
     assert np.linalg.norm(p16 - p32) < 2e-6 * np.linalg.norm(p32)
+
+
+def _bn_dnn_proto(hidden=1024, layers=3, out=3000, bn=True):
+    proto, d = "<NnetProto>\n", 440
+    for _ in range(layers):
+        proto += "<AffineTransform> <InputDim> %d <OutputDim> %d <BiasMean> -2.0 <BiasRange> 4.0 <ParamStddev> 0.05\n" % (d, hidden)
+        if bn:
+            proto += "<BatchNormalization> <InputDim> %d <OutputDim> %d\n" % (hidden, hidden)
+        proto += "<Sigmoid> <InputDim> %d <OutputDim> %d\n" % (hidden, hidden)
+        d = hidden
+    return proto + ("<AffineTransform> <InputDim> %d <OutputDim> %d <BiasMean> 0.0 <BiasRange> 0.0 <ParamStddev> 0.05\n"
+                    "<Softmax> <InputDim> %d <OutputDim> %d\n</NnetProto>\n" % (d, out, out, out))
+
+
+@pytest.mark.parametrize("mmt,bn", [(0.0, True), (0.9, True), (0.9, False)])
+def test_weight_planes_kept_from_step_to_step(aslp, dev, mmt, bn):
+    """The weight-gradient product's epilogue writes the updated weights' planes (under a bound of |W - lr dW| known before the launch) and
+    the next step's forward and in-diff products read them: six steps agree with six steps that convert the weights anew every time, and
+    with the fp32 instruction, like two fp32 summation orders do"""
+    runs = {}
+    try:
+        for name, split, keep in (("fp32", 0, 0), ("convert", 1, 0), ("kept", 1, 1)):
+            aslp.lib.aslp_gemm_split16(split)
+            aslp.lib.aslp_keep_weight_planes(keep)
+            net = aslp.Nnet.Init(_bn_dnn_proto(bn=bn), seed=3)
+            net.SetTrainOptions(learn_rate=2e-3, momentum=mmt)
+            xe = aslp.Xent()
+            g = torch.Generator(device="cpu").manual_seed(5)
+            for step in range(6):
+                x = torch.randn(1024, 440, generator=g).to(dev)
+                lab = torch.randint(0, 3000, (1024,), generator=g, dtype=torch.int32).to(dev)
+                net.TrainStepXent(xe, x, lab)
+            st = xe.GetStats()
+            runs[name] = ((st["loss"] - st["entropy"]) / st["frames"], np.asarray(net.GetParams(), np.float32))
+    finally:
+        aslp.lib.aslp_gemm_split16(-1)
+        aslp.lib.aslp_keep_weight_planes(-1)
+    for a, b in (("kept", "convert"), ("kept", "fp32")):
+        assert abs(runs[a][0] - runs[b][0]) < 2e-6 * abs(runs[b][0]), (a, b, runs[a][0], runs[b][0])
+        assert np.linalg.norm(runs[a][1] - runs[b][1]) < 2e-6 * np.linalg.norm(runs[b][1]), (a, b)
+
+
+@pytest.mark.parametrize("announce", [False, True])
+def test_weights_written_through_the_raw_pointers(aslp, dev, announce):
+    """GetGpuParams hands the weights to outside writers (model averaging).  Silent writers: the net stops keeping planes of its weights.
+    Announcing writers (aslp_params_changed after every write, what the native sync workers do): the kept planes are dropped at the
+    announcement.  Either way the next forward pass sees the written weights: with every weight matrix zeroed the posteriors no longer
+    depend on the input."""
+    aslp.lib.aslp_gemm_split16(1)
+    aslp.lib.aslp_keep_weight_planes(1)
+    try:
+        net = aslp.Nnet.Init(_bn_dnn_proto(layers=2), seed=9)
+        net.SetTrainOptions(learn_rate=1e-3, momentum=0.0)
+        xe = aslp.Xent()
+        g = torch.Generator(device="cpu").manual_seed(6)
+        x = torch.randn(1024, 440, generator=g).to(dev)
+        lab = torch.randint(0, 3000, (1024,), generator=g, dtype=torch.int32).to(dev)
+        params = net.GetGpuParams(writers_announce=announce)
+        for _ in range(3):
+            net.TrainStepXent(xe, x, lab)     # (with announcing writers the planes of the weights are kept across these steps)
+        torch.cuda.synchronize()
+        from parallel_model import alias_device_params
+        for t in alias_device_params(params):
+            if t.numel() > 4096:    # the weight matrices (biases and BatchNormalization vectors are shorter)
+                t.zero_()
+        torch.cuda.synchronize()
+        if announce:
+            aslp.lib.aslp_params_changed()
+        net.TrainStepXent(xe, x, lab)
+        out = torch.from_numpy(net.ComponentOutput(net.NumComponents() - 2, 1024, 3000))   # activations in front of the Softmax
+        assert (out - out[0]).abs().max().item() == 0.0      # W = 0 in the forward pass: every row is the bias
+    finally:
+        aslp.lib.aslp_gemm_split16(-1)
+        aslp.lib.aslp_keep_weight_planes(-1)
