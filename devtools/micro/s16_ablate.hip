@@ -54,6 +54,11 @@ int main() {
   for (size_t off = 0; off < halves; off += h.size()) (void)hipMemcpy(pool + off, h.data(), h.size() * 2, hipMemcpyHostToDevice);
   float one = 1.f;
   (void)hipMemcpy(slots, &one, 4, hipMemcpyHostToDevice); (void)hipMemcpy(slots + 1, &one, 4, hipMemcpyHostToDevice);
+  run<64, 128, 2, 4, 3, true, true>("64x128 8w NS3 NT", 1024, 2048, 2048, pool, slots, C);
+  run<64, 128, 2, 4, 3, true, false>("64x128 8w NS3 NN", 1024, 2048, 2048, pool, slots, C);
+  run<64, 128, 2, 4, 3, false, false>("64x128 8w NS3 TN", 2048, 2048, 1024, pool, slots, C);
+  run<128, 128, 2, 4, 2, true, true>("128x128 8w NS2 NT", 4096, 4096, 4096, pool, slots, C);
+  run<128, 128, 4, 2, 2, true, true>("128x128 8w(4x2) NS2 NT", 4096, 4096, 4096, pool, slots, C);
   run<64, 128, 2, 2, 3, true, true>("64x128 4w NS3 NT", 1024, 2048, 2048, pool, slots, C);
   run<64, 128, 2, 2, 3, true, false>("64x128 4w NS3 NN", 1024, 2048, 2048, pool, slots, C);
   run<64, 128, 2, 2, 3, false, false>("64x128 4w NS3 TN", 2048, 2048, 1024, pool, slots, C);

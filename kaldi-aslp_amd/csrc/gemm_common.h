@@ -91,9 +91,9 @@ __device__ __forceinline__ void epi_plane_store4(const aslp_gemm_epilogue &ep, f
 // Fused epilogue on one wave's accumulators.  C/D layout of the 32x32 MFMA: col = lane&31,
 // row = (e&3) + 8*(e>>2) + 4*(lane>>5).  (row0, col0): global position of the wave patch.
 template <int TM, int TN>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, const f32x16 (&acc)[TM][TN], int row0, int col0, int l31, int lh, EpiExtra *x = nullptr) {
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, const f32x16 (&acc)[TM][TN], int row0, int col0, int l31, int lh, EpiExtra &x, bool track) {
   const aslp_gemm_epilogue &ep = g.ep;
-  const bool w_planes = x && x->pscale != 0.f && ep.planes_of == 1 && ep.W, a_planes = x && x->pscale != 0.f && ep.planes_of == 2 && ep.act_out;
+  const bool w_planes = track && x.pscale != 0.f && ep.planes_of == 1 && ep.W, a_planes = track && x.pscale != 0.f && ep.planes_of == 2 && ep.act_out;
 #pragma unroll
   for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -125,14 +125,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, const f32x16 (&
           if (ep.W) {
             const float wn = fmaf(ep.w_alpha, v, w_old[e]);
             ep.W[(long)row * ep.ldw + col] = wn;
-            if (w_planes) epi_plane_store(ep, x->pscale, wn, row, col);
-            if (x) x->wmax = fmaxf(x->wmax, epi_finite_abs(wn));
+            if (w_planes) epi_plane_store(ep, x.pscale, wn, row, col);
+            if (track) x.wmax = fmaxf(x.wmax, epi_finite_abs(wn));
           }
-          if (x) x->cmax = fmaxf(x->cmax, epi_finite_abs(v));
+          if (track) x.cmax = fmaxf(x.cmax, epi_finite_abs(v));
           if (ep.act_out) {
             float a = ep.act == 1 ? sigmoid_ref(v) : ep.act == 2 ? tanh_ref(v) : ep.act == 3 ? fmaxf(v, 0.0f) : v;
             ep.act_out[(long)row * ep.ld_act + col] = a;
-            if (a_planes) epi_plane_store(ep, x->pscale, a, row, col);
+            if (a_planes) epi_plane_store(ep, x.pscale, a, row, col);
           }
         }
       } else {
@@ -143,11 +143,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, const f32x16 (&
           float v = fmaf(g.alpha, acc[i][n][e], bias);
           if (ep.clip > 0.0f) v = fminf(fmaxf(v, -ep.clip), ep.clip);
           g.C[(long)row * g.ldc + col] = v;
-          if (x) x->cmax = fmaxf(x->cmax, epi_finite_abs(v));
+          if (track) x.cmax = fmaxf(x.cmax, epi_finite_abs(v));
           if (ep.act_out) {
             float a = ep.act == 1 ? sigmoid_ref(v) : ep.act == 2 ? tanh_ref(v) : ep.act == 3 ? fmaxf(v, 0.0f) : v;
             ep.act_out[(long)row * ep.ld_act + col] = a;
-            if (a_planes) epi_plane_store(ep, x->pscale, a, row, col);
+            if (a_planes) epi_plane_store(ep, x.pscale, a, row, col);
           }
         }
       }
@@ -225,9 +225,9 @@ __device__ __forceinline__ void gemm_epilogue_value4(const GemmArgs &g, float4 a
   wn->z = fmaf(ep.w_alpha, o[2], w_old.z); wn->w = fmaf(ep.w_alpha, o[3], w_old.w);
 }
 // ... and its stores
-__device__ __forceinline__ void gemm_epilogue_store4(const GemmArgs &g, const f32x4v &out, const float4 &wn, int row, int col, EpiExtra *x = nullptr) {
+__device__ __forceinline__ void gemm_epilogue_store4(const GemmArgs &g, const f32x4v &out, const float4 &wn, int row, int col, float pscale = 0.f) {
   const aslp_gemm_epilogue &ep = g.ep;
-  if (x && x->pscale != 0.f && ep.planes_of == 1 && ep.W) epi_plane_store4(ep, x->pscale, wn, row, col);
+  if (pscale != 0.f && ep.planes_of == 1 && ep.W) epi_plane_store4(ep, pscale, wn, row, col);
   f32x4v *cp = reinterpret_cast<f32x4v *>(g.C + (long)row * g.ldc + col);
   if (ep.W && g.beta == 0.0f) __builtin_nontemporal_store(out, cp);  // gradient written once, not read again this step
   else *cp = out;
@@ -237,13 +237,13 @@ __device__ __forceinline__ void gemm_epilogue_store4(const GemmArgs &g, const f3
 #pragma unroll
     for (int q = 0; q < 4; q++) a[q] = ep.act == 1 ? sigmoid_ref(out[q]) : ep.act == 2 ? tanh_ref(out[q]) : ep.act == 3 ? fmaxf(out[q], 0.0f) : out[q];
     *reinterpret_cast<float4 *>(ep.act_out + (long)row * ep.ld_act + col) = make_float4(a[0], a[1], a[2], a[3]);
-    if (x && x->pscale != 0.f && ep.planes_of == 2) epi_plane_store4(ep, x->pscale, make_float4(a[0], a[1], a[2], a[3]), row, col);
+    if (pscale != 0.f && ep.planes_of == 2) epi_plane_store4(ep, pscale, make_float4(a[0], a[1], a[2], a[3]), row, col);
   }
 }
 
 template <int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs &g, const f32x16 (&acc)[TM][TN], int row0, int col0, int lane, float *tile,
-                                                   EpiExtra *x = nullptr) {
+                                                   EpiExtra &x, bool track) {
   const aslp_gemm_epilogue &ep = g.ep;
   const int l31 = lane & 31, lh = lane >> 5, c4 = lane & 7, rr = lane >> 3;
 #pragma unroll
@@ -295,16 +295,16 @@ __device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs &g, const f32x
         if (ep.W) {
 #pragma unroll
           for (int j = 0; j < 4; j++) *reinterpret_cast<float4 *>(ep.W + (r0 + 8 * j) * ep.ldw + col) = wn[j];
-          if (x && x->pscale != 0.f && ep.planes_of == 1) {
+          if (track && x.pscale != 0.f && ep.planes_of == 1) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) epi_plane_store4(ep, x->pscale, wn[j], r0 + 8 * j, col);
+            for (int j = 0; j < 4; j++) epi_plane_store4(ep, x.pscale, wn[j], r0 + 8 * j, col);
           }
         }
-        if (x) {
+        if (track) {
 #pragma unroll
           for (int j = 0; j < 4; j++) {
-            x->cmax = fmaxf(x->cmax, fmaxf(fmaxf(epi_finite_abs(out[j][0]), epi_finite_abs(out[j][1])), fmaxf(epi_finite_abs(out[j][2]), epi_finite_abs(out[j][3]))));
-            if (ep.W) x->wmax = s16_absmax4(x->wmax, wn[j]);
+            x.cmax = fmaxf(x.cmax, fmaxf(fmaxf(epi_finite_abs(out[j][0]), epi_finite_abs(out[j][1])), fmaxf(epi_finite_abs(out[j][2]), epi_finite_abs(out[j][3]))));
+            if (ep.W) x.wmax = s16_absmax4(x.wmax, wn[j]);
           }
         }
       } else {
@@ -312,14 +312,25 @@ __device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs &g, const f32x
         for (int j = 0; j < 4; j++) {
           const int row = row0 + i * 32 + rr + 8 * j;
           if (!colok || row >= g.M) continue;
-          gemm_epilogue_store4(g, out[j], wn[j], row, col, x);
-          if (x) {
-            x->cmax = fmaxf(x->cmax, fmaxf(fmaxf(epi_finite_abs(out[j][0]), epi_finite_abs(out[j][1])), fmaxf(epi_finite_abs(out[j][2]), epi_finite_abs(out[j][3]))));
-            if (ep.W) x->wmax = s16_absmax4(x->wmax, wn[j]);
+          gemm_epilogue_store4(g, out[j], wn[j], row, col, track ? x.pscale : 0.f);
+          if (track) {
+            x.cmax = fmaxf(x.cmax, fmaxf(fmaxf(epi_finite_abs(out[j][0]), epi_finite_abs(out[j][1])), fmaxf(epi_finite_abs(out[j][2]), epi_finite_abs(out[j][3]))));
+            if (ep.W) x.wmax = s16_absmax4(x.wmax, wn[j]);
           }
         }
       }
     }
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, const f32x16 (&acc)[TM][TN], int row0, int col0, int l31, int lh) {
+  EpiExtra none;
+  gemm_epilogue<TM, TN>(g, acc, row0, col0, l31, lh, none, false);
+}
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs &g, const f32x16 (&acc)[TM][TN], int row0, int col0, int lane, float *tile) {
+  EpiExtra none;
+  gemm_epilogue_wide<TM, TN>(g, acc, row0, col0, lane, tile, none, false);
 }
 
 // gemm_glds.hip: direct-to-LDS kernels.  Returns false if the problem is not eligible (caller falls back).

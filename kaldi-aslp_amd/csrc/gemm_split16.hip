@@ -135,7 +135,9 @@ inline int tw_log2_for(int units) {
 struct S16Operands { S16View a, b, a1, b1; int kp; };   // a1 / b1: second product of a pair (blockIdx.z == 1)
 
 // ABL (devtools/micro/s16_ablate.hip only; 0 in the library): 1 = no MFMA, 2 = no DMA, 4 = no LDS reads -- wrong results, for timing
-template <int BM, int BN, int WGM, int WGN, int NS, bool A_KC, bool B_KC, int ABL = 0>
+// EXTRA: the epilogue also leaves planes / maxima of its output (aslp_gemm_epilogue.planes, *_parts); a variant of its own because the
+// extra epilogue state costs the 128 x 128 tile its last registers.
+template <int BM, int BN, int WGM, int WGN, int NS, bool A_KC, bool B_KC, int ABL = 0, bool EXTRA = false>
 __global__ void __launch_bounds__(64 * WGM * WGN) gemm_s16_glds(GemmArgs g, S16Operands ops) {
   constexpr int NW = WGM * WGN;
   constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
@@ -181,25 +183,26 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_s16_glds(GemmArgs g, S16O
     const int s2 = is_a ? slot : slot - 2 * SLOTS_A, per = is_a ? SLOTS_A : SLOTS_B;
     const bool lo_plane = s2 >= per;
     const int sr = lo_plane ? s2 - per : s2;   // unit within the plane tile
-    const S16View &v = is_a ? va : vb;
-    const h16 *base = lo_plane ? v.lo : v.hi;
-    const int rows_p = (v.rows + kS16Pad - 1) / kS16Pad * kS16Pad;
+    // (field by field: a reference to "va or vb" would put both structs into scratch memory)
+    const h16 *base = is_a ? (lo_plane ? va.lo : va.hi) : (lo_plane ? vb.lo : vb.hi);
+    const int v_ld = is_a ? va.ld : vb.ld, v_rows = is_a ? va.rows : vb.rows;
+    const int rows_p = (v_rows + kS16Pad - 1) / kS16Pad * kS16Pad;
     auto kc_src = [&](int first_row) {
       const int r = lane >> 3;
       const int c = (lane & 7) ^ kc_swizzle(sr * 8 + r);
       int row = first_row + sr * 8 + r;
       row = row < rows_p ? row : rows_p - 1;   // (a row of the padding or of another tile: feeds outputs that are not stored)
       adv[u] = BKH;
-      return base + (long)row * v.ld + 8 * c;
+      return base + (long)row * v_ld + 8 * c;
     };
     auto ks_src = [&](int first_col, auto BR_) {
       constexpr int BR = decltype(BR_)::value, CPR = BR / 8;   // 16-byte chunks per k row
       const int krow = sr * (64 / CPR) + lane / CPR;
       const int c = (lane % CPR) ^ (4 * ks_swizzle<BR>(krow));
       int col = first_col + 8 * c;
-      col = col + 8 <= v.ld ? col : v.ld - 8;   // (columns past the planes: outputs that are not stored)
-      adv[u] = BKH * v.ld;
-      return base + (long)krow * v.ld + col;
+      col = col + 8 <= v_ld ? col : v_ld - 8;   // (columns past the planes: outputs that are not stored)
+      adv[u] = BKH * v_ld;
+      return base + (long)krow * v_ld + col;
     };
     if (is_a) {
       if constexpr (A_KC) src[u] = kc_src(m0); else src[u] = ks_src(m0, std::integral_constant<int, BM>());
@@ -398,15 +401,17 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_s16_glds(GemmArgs g, S16O
   static_assert(NW * 32 * kEpiPitch * (int)sizeof(float) <= NS * STAGE, "the waves' epilogue slices must fit into the operand LDS");
   // planes of an output and per-wave maxima for the products that will read it (aslp_gemm_epilogue.planes / *_parts)
   EpiExtra xtra;
-  const bool want_extra = g.ep.planes_of != 0 || g.ep.wmax_parts != nullptr || g.ep.cmax_parts != nullptr;   // uniform
-  if (g.ep.planes_of != 0 && g.ep.planes.hi != nullptr) xtra.pscale = ldexpf(1.f, s16_exponent(*g.ep.planes.slot));
+  constexpr bool want_extra = EXTRA;
+  if constexpr (EXTRA) {
+    if (g.ep.planes_of != 0 && g.ep.planes.hi != nullptr) xtra.pscale = ldexpf(1.f, s16_exponent(*g.ep.planes.slot));
+  }
   if (g.wide_epilogue && gemm_epilogue_wide_ok(g)) {  // uniform
     __builtin_amdgcn_s_barrier();
-    gemm_epilogue_wide<TM, TN>(g, acc, m0 + wm * WM, n0 + wn * WN, lane, lds + wave * 32 * kEpiPitch, want_extra ? &xtra : nullptr);
+    gemm_epilogue_wide<TM, TN>(g, acc, m0 + wm * WM, n0 + wn * WN, lane, lds + wave * 32 * kEpiPitch, xtra, want_extra);
   } else {
-    gemm_epilogue<TM, TN>(g, acc, m0 + wm * WM, n0 + wn * WN, l31, lh, want_extra ? &xtra : nullptr);
+    gemm_epilogue<TM, TN>(g, acc, m0 + wm * WM, n0 + wn * WN, l31, lh, xtra, want_extra);
   }
-  if (g.ep.wmax_parts != nullptr || g.ep.cmax_parts != nullptr) {
+  if (EXTRA && (g.ep.wmax_parts != nullptr || g.ep.cmax_parts != nullptr)) {
     const float wmx = wave_max(xtra.wmax), cmx = wave_max(xtra.cmax);
     const int idx = ((int)blockIdx.z * (int)gridDim.x + (int)blockIdx.x) * NW + wave;
     if (lane == 0) {
@@ -416,12 +421,12 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_s16_glds(GemmArgs g, S16O
   }
 }
 
-template <int BM, int BN, int WGM, int WGN, int NS, bool A_KC, bool B_KC, int ABL = 0>
+template <int BM, int BN, int WGM, int WGN, int NS, bool A_KC, bool B_KC, int ABL = 0, bool EXTRA = false>
 void launch_s16(GemmArgs &g, const S16Operands &ops) {
   g.tiles_m = (g.M + BM - 1) / BM;
   g.tiles_n = (g.N + BN - 1) / BN;
   constexpr int lds_bytes = NS * 2 * (BM + BN) * 128;
-  auto kern = gemm_s16_glds<BM, BN, WGM, WGN, NS, A_KC, B_KC, ABL>;
+  auto kern = gemm_s16_glds<BM, BN, WGM, WGN, NS, A_KC, B_KC, ABL, EXTRA>;
   static bool attr_set = false;
   if (!attr_set) {
     if (lds_bytes > 48 * 1024)
@@ -429,18 +434,22 @@ void launch_s16(GemmArgs &g, const S16Operands &ops) {
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n, 1, g.pair ? 2 : 1), dim3(64 * WGM * WGN), lds_bytes, cur_stream(), g, ops);
-  t_last_parts = g.tiles_m * g.tiles_n * (g.pair ? 2 : 1) * WGM * WGN;
+  t_last_parts = EXTRA ? g.tiles_m * g.tiles_n * (g.pair ? 2 : 1) * WGM * WGN : 0;
 }
 template <bool A_KC, bool B_KC>
 bool launch_s16_layout(GemmArgs &g, const S16Operands &ops, int cfg) {
   // 128 x 128 where that still gives every CU a workgroup, else 64 x 128 (measured: 1024 x 2048 x 2048 52 against 70 us per call).  Only with
   // both operands reduction-contiguous: the transposing reads' address registers push the 128 x 128 tile past 512 registers (27-31 spilled),
   // and a kernel with a private segment pays ~1 ms per launch for it on this runtime.
-  if (cfg == 0 || !(A_KC && B_KC))
-    cfg = (A_KC && B_KC && (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * (g.pair ? 2 : 1) >= 224) ? 311 : 308;
+  const bool extra = g.ep.planes_of != 0 || g.ep.wmax_parts != nullptr || g.ep.cmax_parts != nullptr || (g.pair && (g.ep1.planes_of != 0 || g.ep1.wmax_parts || g.ep1.cmax_parts));
+  if (cfg == 0 || !(A_KC && B_KC) || extra)
+    cfg = (!extra && A_KC && B_KC && (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * (g.pair ? 2 : 1) >= 224) ? 311 : 308;
   switch (cfg) {
     case 311: if constexpr (A_KC && B_KC) launch_s16<128, 128, 2, 2, 2, true, true>(g, ops); break;
-    case 308: launch_s16<64, 128, 2, 2, 3, A_KC, B_KC>(g, ops); break;
+    case 308:
+      if (extra) launch_s16<64, 128, 2, 2, 3, A_KC, B_KC, 0, true>(g, ops);
+      else launch_s16<64, 128, 2, 2, 3, A_KC, B_KC>(g, ops);
+      break;
     default: return false;
   }
   return true;
