@@ -207,6 +207,11 @@ typedef struct aslp_gemm_epilogue_ {
   aslp_planes_out planes;
   int planes_of;
   float *wmax_parts, *cmax_parts;
+  /* planes_of = 1 without a separate aslp_weight_bound launch: the kernel forms the bound itself before its first tile (every workgroup
+   * the same value, workgroup 0 stores it to planes.slot) from the bound_n per-wave maxima of |W| and |C_old| (bound_c_parts may be
+   * NULL when beta == 0) the previous step left, the bounds of its two operands' planes and K. */
+  const float *bound_w_parts, *bound_c_parts;
+  int bound_n;
 } aslp_gemm_epilogue;
 /* number of per-wave maxima (and proof that the planes were written) of the calling thread's latest aslp_sgemm* call; 0 = the kernel that
  * ran does not leave them */
@@ -341,6 +346,11 @@ void aslp_xent_eval(const float *net_out, MatrixDim d, const float *tgt, int tgt
 int aslp_softmax_xent_supported(int cols);
 void aslp_softmax_xent_eval(const float *acts, MatrixDim d, const float *tgt, int tgt_stride, const int32_cuda *labels,
                             const float *frame_weights, float *diff, int diff_stride, double *stats_dev, float *post_out, int post_stride);
+/* aslp_xent_eval / aslp_softmax_xent_eval (softmax != 0) which also leave the planes of `diff` (diff_planes->slot must hold a bound of
+ * |diff| = |y - t| w: max w for posteriors against a distribution).  Returns 1 if the planes were written (label targets on the
+ * register-cached row kernel), 0 if only diff was. */
+int aslp_xent_eval_p(const float *net_out, MatrixDim d, const int32_cuda *labels, const float *frame_weights, float *diff, int diff_stride,
+                     double *stats_dev, int softmax, const aslp_planes_out *diff_planes);
 /* PosteriorToMatrix scatter: mat[row[i]][col[i]] += val[i]  (hmm/posterior.cc, used nnet-loss.cc:168) */
 void aslp_scatter_add(float *mat, MatrixDim d, const int32_cuda *rows, const int32_cuda *cols, const float *vals, int n);
 /* Splice backward (nnet-various.h:143-175): in_diff[t] = sum_k out_diff[clamp(t+off[k])][k-th block] */

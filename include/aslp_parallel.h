@@ -41,6 +41,10 @@ int aslp_comm_create_rccl(int rank, int num_nodes, const char *id_file, const ch
 int aslp_comm_create_shm(int rank, int num_nodes, const char *id_file, const char *token, int timeout_s, aslp_comm_t *out);
 void aslp_comm_free(aslp_comm_t c);
 int aslp_comm_rank(aslp_comm_t c);        /* MpiNode::Rank      mpi-node.h:40 */
+/* what the transport itself reports: the size of the live group (RCCL: ncclCommCount) and "rccl" | "shm" | "threads" -- so that a bench
+ * line can prove which transport carried a run and that every rank joined it (no reference counterpart) */
+int aslp_comm_ranks_seen(aslp_comm_t c);
+const char *aslp_comm_transport(aslp_comm_t c);
 int aslp_comm_num_nodes(aslp_comm_t c);   /* MpiNode::NumNodes  mpi-node.h:43 */
 int aslp_comm_barrier(aslp_comm_t c);     /* MpiNode::Barrier   mpi-node.h:46 */
 /* MpiNode::AllReduce (mpi-node.h:52-75) without the host round trip: in place on device memory */

@@ -29,7 +29,8 @@ class GemmEpilogue(C.Structure):
                 ("w_alpha", C.c_float), ("act_out", C.c_void_p), ("ld_act", C.c_int), ("act", C.c_int),
                 ("colsum", C.c_void_p), ("colsum_beta", C.c_float), ("colsum_w", C.c_void_p), ("colsum_w_alpha", C.c_float),
                 ("colstats", C.c_void_p), ("colstats_ld", C.c_int), ("c_src", C.c_void_p), ("ld_c_src", C.c_int),
-                ("planes", PlanesOut), ("planes_of", C.c_int), ("wmax_parts", C.c_void_p), ("cmax_parts", C.c_void_p)]
+                ("planes", PlanesOut), ("planes_of", C.c_int), ("wmax_parts", C.c_void_p), ("cmax_parts", C.c_void_p),
+                ("bound_w_parts", C.c_void_p), ("bound_c_parts", C.c_void_p), ("bound_n", C.c_int)]
 
 
 class GruSeq(C.Structure):

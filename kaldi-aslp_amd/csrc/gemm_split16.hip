@@ -353,6 +353,24 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_s16_glds(GemmArgs g, S16O
     constexpr int t = decltype(T_)::value;
     static_for<0, G>([&](auto U_) { dma_unit(U_, T_, t); });
   });
+  // (EXTRA) the bound of the weights after the fused step, while the first tiles are on their way: |W + w_alpha C| <= max |W| +
+  // |w_alpha| (|alpha| K max|a| max|b| + |beta| max |C_old|), the maxima from the previous step's per-wave partials
+  float w_bound = 0.f;
+  if constexpr (EXTRA) {
+    if (g.ep.bound_w_parts != nullptr) {   // uniform
+      float mw = 0.f, mc = 0.f;
+      for (int i = lane; i < g.ep.bound_n; i += 64) {
+        mw = fmaxf(mw, g.ep.bound_w_parts[i]);
+        if (g.ep.bound_c_parts != nullptr) mc = fmaxf(mc, g.ep.bound_c_parts[i]);
+      }
+      mw = wave_max(mw);
+      mc = wave_max(mc);
+      float v = fabsf(g.alpha) * (float)g.K * __uint_as_float(*va.slot) * __uint_as_float(*vb.slot) + fabsf(g.beta) * mc;
+      if (g.ep.clip > 0.f) v = fminf(v, g.ep.clip);
+      w_bound = mw + fabsf(g.ep.w_alpha) * v;
+      if (blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0) *const_cast<unsigned *>(g.ep.planes.slot) = __float_as_uint(w_bound);
+    }
+  }
   wait_vmcnt<(D - 1) * G>();
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -403,7 +421,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_s16_glds(GemmArgs g, S16O
   EpiExtra xtra;
   constexpr bool want_extra = EXTRA;
   if constexpr (EXTRA) {
-    if (g.ep.planes_of != 0 && g.ep.planes.hi != nullptr) xtra.pscale = ldexpf(1.f, s16_exponent(*g.ep.planes.slot));
+    if (g.ep.planes_of != 0 && g.ep.planes.hi != nullptr)
+      xtra.pscale = ldexpf(1.f, s16_exponent(g.ep.bound_w_parts != nullptr ? __float_as_uint(w_bound) : *g.ep.planes.slot));
   }
   if (g.wide_epilogue && gemm_epilogue_wide_ok(g)) {  // uniform
     __builtin_amdgcn_s_barrier();
@@ -477,6 +496,10 @@ long s16_param_epoch() { return g_param_epoch.load(std::memory_order_relaxed); }
 long s16_new_epoch() {
   static std::atomic<long> counter{0};
   return ++counter;
+}
+S16DiffTarget &s16_loss_diff_target() {
+  static thread_local S16DiffTarget t;
+  return t;
 }
 S16Epochs &s16_epochs() {
   static thread_local S16Epochs e;

@@ -775,10 +775,11 @@ constexpr int kXentPerThread = 32;  // cols <= 8192 cached in registers
 template <bool DENSE, bool SOFTMAX, int PER>
 __global__ void __launch_bounds__(256) xent_rows_kernel(const float *y, int ldy, const float *t, int ldt, const int32_t *labels,
                                                         const float *fw, float *diff, int ldd, int rows, int cols, double *rowstats,
-                                                        float *y_out, int ldyo) {
+                                                        float *y_out, int ldyo, S16Out po) {
   __shared__ float shf[4][4];
   __shared__ int shi[4][2];
   __shared__ float shs[4];
+  const float pscale = po.hi ? ldexpf(1.f, s16_exponent(*po.slot)) : 0.f;   // planes of diff for the product that reads it (split16.h)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   for (int r = blockIdx.x; r < rows; r += gridDim.x) {
     const float *yr = y + (long)r * ldy;
@@ -864,7 +865,14 @@ __global__ void __launch_bounds__(256) xent_rows_kernel(const float *y, int ldy,
       int c = tid + k * 256;
       if (c < cols) {
         float yy = yv[k], tt = tv[k];
-        diff[(long)r * ldd + c] = (yy - tt) * wr;
+        const float dv = (yy - tt) * wr;
+        diff[(long)r * ldd + c] = dv;
+        if (po.hi) {
+          h16 h, l;
+          s16_split(dv, pscale, &h, &l);
+          po.hi[(long)r * po.ld + c] = h;
+          po.lo[(long)r * po.ld + c] = l;
+        }
         if (tt != 0.0f) {  // t == 0 terms are exactly 0 (t*log(...) with finite log)
           xe += (double)(logf(yy + 1e-20f) * tt * wr);
           en += (double)(logf(tt + 1e-20f) * tt * wr);
@@ -1291,22 +1299,25 @@ void aslp_bn_backward(const float *in, MatrixDim d, const float *out_diff, int o
                        0);
 }
 
-static void xent_eval_impl(const float *net_out, MatrixDim d, const float *tgt, int tgt_stride, const int32_cuda *labels,
-                           const float *frame_weights, float *diff, int diff_stride, double *stats_dev, bool softmax, float *y_out, int y_stride) {
-  if (d.rows <= 0 || d.cols <= 0) return;
-  if (!tgt && !labels) { set_error("aslp_xent_eval: need dense targets or labels"); return; }
+static bool xent_eval_impl(const float *net_out, MatrixDim d, const float *tgt, int tgt_stride, const int32_cuda *labels,
+                           const float *frame_weights, float *diff, int diff_stride, double *stats_dev, bool softmax, float *y_out, int y_stride,
+                           const aslp_planes_out *diff_planes = nullptr) {
+  if (d.rows <= 0 || d.cols <= 0) return false;
+  if (!tgt && !labels) { set_error("aslp_xent_eval: need dense targets or labels"); return false; }
+  S16Out po = {nullptr, nullptr, 0, nullptr, nullptr};
+  bool planes_written = false;
   double *rowstats = static_cast<double *>(scratch(kScratchReduce, sizeof(double) * 5 * (size_t)d.rows));
-  if (!rowstats) return;
+  if (!rowstats) return false;
   int g = d.rows > kMaxGrid * 2 ? kMaxGrid * 2 : d.rows;
   if (d.cols > 256 * kXentPerThread) {   // wider than the register-cached kernels hold: the streaming kernel (the reference has no limit)
-    if (softmax) { set_error("aslp_softmax_xent_eval: unsupported number of classes"); return; }
+    if (softmax) { set_error("aslp_softmax_xent_eval: unsupported number of classes"); return false; }
     if (tgt) hipLaunchKernelGGL((xent_rows_wide_kernel<true>), dim3(g), dim3(256), 0, cur_stream(), net_out, d.stride, tgt, tgt_stride, labels, frame_weights,
                                 diff, diff_stride, d.rows, d.cols, rowstats);
     else hipLaunchKernelGGL((xent_rows_wide_kernel<false>), dim3(g), dim3(256), 0, cur_stream(), net_out, d.stride, tgt, tgt_stride, labels, frame_weights,
                             diff, diff_stride, d.rows, d.cols, rowstats);
     hipLaunchKernelGGL(xent_finalize_kernel, dim3(1), dim3(256), 0, cur_stream(), rowstats, d.rows, stats_dev);
     check_launch("xent_eval");
-    return;
+    return false;
   }
   // elements cached per thread: the smallest of 4 / 8 / 16 / 32 that covers the row (the loops are fully unrolled: a row of
   // 3000 classes runs 16 slots per thread instead of 32 predicated ones)
@@ -1316,13 +1327,17 @@ static void xent_eval_impl(const float *net_out, MatrixDim d, const float *tgt, 
   // against 782 / 785 k frames/s, two alternations): a lane now walks 47 exponentials in a row where the workgroup kernel's thread walks 12
   static const bool wave_on = getenv("ASLP_XENT_WAVE") != nullptr && getenv("ASLP_XENT_WAVE")[0] == '1';
   const bool wave_rows = wave_on && d.rows >= 512 && per <= 16;
+  if (diff_planes && diff_planes->hi && diff_planes->slot && !tgt && !wave_rows && diff_planes->ld >= d.cols) {   // the row kernel, label targets
+    po = S16Out{static_cast<h16 *>(diff_planes->hi), static_cast<h16 *>(diff_planes->lo), diff_planes->ld, diff_planes->slot, nullptr};
+    planes_written = true;
+  }
   const int gw = (d.rows + 3) / 4;
 #define XENT_LAUNCH_W(DENSE, SM, P)                                                                                                         \
   hipLaunchKernelGGL((xent_rows_wave_kernel<DENSE, SM, P>), dim3(gw), dim3(256), 0, cur_stream(), net_out, d.stride, tgt, tgt_stride, labels, \
                      frame_weights, diff, diff_stride, d.rows, d.cols, rowstats, y_out, y_stride)
 #define XENT_LAUNCH_P(DENSE, SM, P)                                                                                                       \
   hipLaunchKernelGGL((xent_rows_kernel<DENSE, SM, P>), dim3(g), dim3(256), 0, cur_stream(), net_out, d.stride, tgt, tgt_stride, labels, \
-                     frame_weights, diff, diff_stride, d.rows, d.cols, rowstats, y_out, y_stride)
+                     frame_weights, diff, diff_stride, d.rows, d.cols, rowstats, y_out, y_stride, po)
 #define XENT_LAUNCH(DENSE, SM)                                        \
   do {                                                                \
     if (wave_rows && per <= 4) XENT_LAUNCH_W(DENSE, SM, 4);           \
@@ -1340,11 +1355,17 @@ static void xent_eval_impl(const float *net_out, MatrixDim d, const float *tgt, 
 #undef XENT_LAUNCH_W
   hipLaunchKernelGGL(xent_finalize_kernel, dim3(1), dim3(256), 0, cur_stream(), rowstats, d.rows, stats_dev);
   check_launch("xent_eval");
+  return planes_written;
 }
 
 void aslp_xent_eval(const float *net_out, MatrixDim d, const float *tgt, int tgt_stride, const int32_cuda *labels, const float *frame_weights,
                     float *diff, int diff_stride, double *stats_dev) {
   xent_eval_impl(net_out, d, tgt, tgt_stride, labels, frame_weights, diff, diff_stride, stats_dev, false, nullptr, 0);
+}
+int aslp_xent_eval_p(const float *net_out, MatrixDim d, const int32_cuda *labels, const float *frame_weights, float *diff, int diff_stride,
+                     double *stats_dev, int softmax, const aslp_planes_out *diff_planes) {
+  if (softmax && !aslp_softmax_xent_supported(d.cols)) { set_error("aslp_softmax_xent_eval: unsupported number of classes"); return 0; }
+  return xent_eval_impl(net_out, d, nullptr, 0, labels, frame_weights, diff, diff_stride, stats_dev, softmax != 0, nullptr, 0, diff_planes) ? 1 : 0;
 }
 // Softmax + Xent::Eval in one pass over the activations in front of the Softmax; only rows of 513..8192 classes (the
 // range where cudaF_softmax_reduce uses the same 256-lane row layout, so the posteriors are bit-identical)

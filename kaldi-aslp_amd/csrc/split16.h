@@ -149,6 +149,12 @@ struct S16EpochScope {                       // publishes (fwd, bwd) for the dur
   S16Epochs saved_;
 };
 
+// ---- the loss writes the out-diff of the network's last layer product: Nnet::LossDiff() says (to the calling thread) where that
+// layer wants the diff's planes and under which epoch the backward pass (BackpropagateFromLossDiff) will look for them; a loss whose
+// kernel knows a bound of |diff| before it runs (Xent on posteriors: |y - t| w <= max w) writes them, tags them and clears this.
+struct S16DiffTarget { PlaneSet *planes = nullptr; long epoch = 0; const void *diff = nullptr; };
+S16DiffTarget &s16_loss_diff_target();
+
 // ---- parameters written behind the components' backs (model averaging through the GetGpuParams pointers): whoever writes them calls
 // aslp_params_changed(), which moves this epoch; planes of weights kept from step to step are tagged with it
 long s16_param_epoch();

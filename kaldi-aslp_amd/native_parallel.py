@@ -27,7 +27,7 @@ def lib():
         for name, args in [
             ("aslp_comm_create_rccl", [i, i, C.c_char_p, C.c_char_p, i, C.POINTER(vp)]),
             ("aslp_comm_create_shm", [i, i, C.c_char_p, C.c_char_p, i, C.POINTER(vp)]),
-            ("aslp_comm_rank", [vp]), ("aslp_comm_num_nodes", [vp]), ("aslp_comm_barrier", [vp]),
+            ("aslp_comm_rank", [vp]), ("aslp_comm_num_nodes", [vp]), ("aslp_comm_barrier", [vp]), ("aslp_comm_ranks_seen", [vp]),
             ("aslp_comm_allreduce_sum_f32", [vp, vp, sz]), ("aslp_comm_allreduce_sum_f64", [vp, vp, sz]),
             ("aslp_comm_allreduce_sum_host_i32", [vp, C.POINTER(C.c_int32), sz]),
             ("aslp_comm_allreduce_sum_host_f64", [vp, C.POINTER(C.c_double), sz]),
@@ -42,6 +42,8 @@ def lib():
             fn = getattr(L, name)
             fn.restype = i
             fn.argtypes = args
+        L.aslp_comm_transport.restype = C.c_char_p
+        L.aslp_comm_transport.argtypes = [vp]
         L.aslp_comm_free.restype = None
         L.aslp_comm_free.argtypes = [vp]
         L.aslp_worker_free.restype = None
@@ -92,6 +94,8 @@ class RcclComm:
 
     def Rank(self): return lib().aslp_comm_rank(self.h)
     def NumNodes(self): return lib().aslp_comm_num_nodes(self.h)
+    def RanksSeen(self): return lib().aslp_comm_ranks_seen(self.h)          # RcclComm: ncclCommCount of the live communicator
+    def Transport(self): return lib().aslp_comm_transport(self.h).decode()  # "rccl" | "shm"
     def MainNode(self): return 0
     def IsMainNode(self): return self.Rank() == 0
     def Barrier(self): _ok(lib().aslp_comm_barrier(self.h))

@@ -229,13 +229,15 @@ int aslp_nnet_train_step_xent(aslp_nnet_t n, aslp_xent_t x, const float *in, int
   API_BEGIN
   CuSubMatrix inm(const_cast<float *>(in), rows, cols, stride);
   n->nnet.PropagateForLoss(inm, true);
+  float fw_max = -1.0f;   // unknown for weights given in device memory
   if (frame_weights == NULL) {
     if (n->fw.Dim() != rows) { n->fw.Resize(rows, kUndefined); n->fw.Set(1.0f); }
     frame_weights = n->fw.Data();
+    fw_max = 1.0f;
   }
   CuSubVector fwv(const_cast<float *>(frame_weights), rows);
-  if (n->nnet.LossInputIsPreSoftmax()) x->xent.EvalLabelsPreSoftmax(fwv, n->nnet.LossInput(), labels, n->nnet.LossDiff(rows));
-  else x->xent.EvalLabels(fwv, n->nnet.LossInput(), labels, n->nnet.LossDiff(rows));
+  if (n->nnet.LossInputIsPreSoftmax()) x->xent.EvalLabelsPreSoftmax(fwv, n->nnet.LossInput(), labels, n->nnet.LossDiff(rows), fw_max);
+  else x->xent.EvalLabels(fwv, n->nnet.LossInput(), labels, n->nnet.LossDiff(rows), fw_max);
   n->nnet.BackpropagateFromLossDiff();
   API_END
 }

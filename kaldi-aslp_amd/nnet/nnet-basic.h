@@ -202,7 +202,8 @@ class AffineTransform : public UpdatableComponent {
   void RequestOutputStats(CuVectorD *buf) { stats_request_ = buf; }
   // Executor peephole (nnet-nnet.cpp): a Sigmoid that is this component's only consumer gets its output from the same
   // GEMM (second store of the epilogue, sigmoid of the value just written to `out`): same bits as the separate launch.
-  void PropagateWithSigmoid(const CuMatrixBase &in, CuMatrix *out, CuMatrix *sigmoid_out) {
+  // act_planes: the AffineTransform that alone reads sigmoid_out wants its fp16 planes (bound 1): the same epilogue writes them
+  void PropagateWithSigmoid(const CuMatrixBase &in, CuMatrix *out, CuMatrix *sigmoid_out, PlaneHolder *act_planes = nullptr) {
     ASLP_ASSERT(in.NumCols() == input_dim_);
     if (out->NumRows() != in.NumRows() || out->NumCols() != output_dim_) out->Resize(in.NumRows(), output_dim_, kUndefined);
     if (sigmoid_out->NumRows() != in.NumRows() || sigmoid_out->NumCols() != output_dim_) sigmoid_out->Resize(in.NumRows(), output_dim_, kUndefined);
@@ -211,7 +212,15 @@ class AffineTransform : public UpdatableComponent {
     ep.act_out = sigmoid_out->Data(); ep.ld_act = sigmoid_out->Stride(); ep.act = 1;
     const PlaneSet *pa = nullptr, *pb = nullptr;
     ForwardPlanes(in, &pa, &pb);
+    PlaneSet *ap = (act_planes && pa && pb) ? &act_planes->get() : nullptr;
+    if (ap && ap->Reserve(in.NumRows(), output_dim_) && ap->SetBound(1.0f)) {
+      aslp_planes_as_output(reinterpret_cast<const aslp_planes *>(ap), &ep.planes);
+      ep.planes_of = 2;
+    } else {
+      ap = nullptr;
+    }
     out->AddMatMat(1.0, in, kNoTrans, linearity_, kTrans, 0.0, &ep, pa, pb);
+    if (ap && aslp_gemm_last_parts() > 0) ap->Tag(sigmoid_out->Data(), sigmoid_out->Stride(), s16_epochs().fwd);   // (the split-fp16 kernel ran)
   }
   void BackpropagateFnc(const CuMatrixBase &, const CuMatrixBase &, const CuMatrixBase &out_diff, CuMatrixBase *in_diff) {
     const PlaneSet *pa = nullptr, *pb = nullptr;
@@ -240,8 +249,9 @@ class AffineTransform : public UpdatableComponent {
       pb = in_planes_.Of(input, s16_epochs().fwd);
     }
     // The epilogue that writes the updated weights also writes their fp16 planes for the next step's forward and in-diff products
-    // (csrc/split16.h).  Their scale must be known before the first tile is written: a bound of max |W - lr W_corr| from the
-    // maxima of |W| and |W_corr| the previous step's epilogue left (the first time: one pass over each), the operands' bounds and K.
+    // (csrc/split16.h).  Their scale must be known before the first tile is written: a bound of max |W - lr W_corr| that every
+    // workgroup forms from the maxima of |W| and |W_corr| the previous step's epilogue left (the first time: one pass over each),
+    // the operands' bounds and K.
     const bool keep = s16_keep_weight_planes() && plain && max_norm_ <= 0.0 && !aliased_silently_ && pa && pb && gemm_split16_serves(num_frames, output_dim_, input_dim_) &&
                       gemm_split16_max_parts(output_dim_, input_dim_) <= kS16MaxParts && w_planes_.get().Reserve(output_dim_, input_dim_);
     if (keep) {
@@ -254,11 +264,12 @@ class AffineTransform : public UpdatableComponent {
         aslp_absmax_parts(linearity_corr_.Data(), linearity_corr_.Dim(), c_maxima_[cur_].Data());
         n_maxima_ = 256;
       }
-      aslp_planes *wp = reinterpret_cast<aslp_planes *>(&w_planes_.get());
-      aslp_weight_bound(w_maxima_[cur_].Data(), n_maxima_, c_maxima_[cur_].Data(), n_maxima_, reinterpret_cast<const aslp_planes *>(pa),
-                        reinterpret_cast<const aslp_planes *>(pb), num_frames, 1.0f, mmt, -lr, 0.0f, wp);
-      aslp_planes_as_output(wp, &ep.planes);
+      aslp_planes_as_output(reinterpret_cast<const aslp_planes *>(&w_planes_.get()), &ep.planes);
+      w_planes_.get().ForgetHostBound();   // (the kernel writes the slot)
       ep.planes_of = 1;
+      ep.bound_w_parts = w_maxima_[cur_].Data();   // the kernel forms the bound itself before its first tile
+      ep.bound_c_parts = c_maxima_[cur_].Data();
+      ep.bound_n = n_maxima_;
       ep.wmax_parts = w_maxima_[1 - cur_].Data();
       ep.cmax_parts = c_maxima_[1 - cur_].Data();
     }

@@ -1,5 +1,6 @@
 // nnet-loss.cpp -- follows src/aslp-nnet/nnet-loss.cc (line cited per function).
 #include "nnet-loss.h"
+#include "split16.h"
 
 #include <cmath>
 #include <map>
@@ -118,6 +119,21 @@ void Xent::Eval(const std::vector<BaseFloat> &frame_weights, const CuMatrixBase 
   EvalLabels(frame_weights_, net_out, labels_, diff);
 }
 
+// Xent on posteriors with one label per frame: |diff| = |y - t| w <= max w, known before the launch when the caller knows its frame
+// weights' maximum (fw_max > 0).  If the network asked for the diff's planes (Nnet::LossDiff -> s16_loss_diff_target) the kernel
+// writes them beside the diff.
+static void XentLabels(const CuMatrixBase &in, bool softmax, const int32 *labels_dev, const CuVectorBase &fw, float fw_max, CuMatrix *diff,
+                       double *stats) {
+  S16DiffTarget t = s16_loss_diff_target();
+  s16_loss_diff_target() = S16DiffTarget();
+  aslp_planes_out po = aslp_planes_out();
+  PlaneSet *ps = (t.planes && t.diff == diff->Data() && fw_max > 0.0f && std::isfinite(fw_max)) ? t.planes : nullptr;
+  if (ps && ps->Reserve(in.NumRows(), in.NumCols()) && ps->SetBound(fw_max)) aslp_planes_as_output(reinterpret_cast<const aslp_planes *>(ps), &po);
+  else ps = nullptr;
+  if (aslp_xent_eval_p(in.Data(), in.Dim(), labels_dev, fw.Data(), diff->Data(), diff->Stride(), stats, softmax ? 1 : 0, ps ? &po : nullptr) && ps)
+    ps->Tag(diff->Data(), diff->Stride(), t.epoch);
+}
+
 void Xent::EvalLabels(const CuVectorBase &fw, const CuMatrixBase &net_out, const CuArray<int32> &labels, CuMatrix *diff) {
   ASLP_ASSERT(fw.Dim() == net_out.NumRows() && labels.Dim() == net_out.NumRows());
   diff->Resize(net_out.NumRows(), net_out.NumCols(), kUndefined);
@@ -126,17 +142,18 @@ void Xent::EvalLabels(const CuVectorBase &fw, const CuMatrixBase &net_out, const
   AfterEval(net_out.NumRows());
 }
 
-void Xent::EvalLabels(const CuVectorBase &fw, const CuMatrixBase &net_out, const int32 *labels_dev, CuMatrix *diff) {
+void Xent::EvalLabels(const CuVectorBase &fw, const CuMatrixBase &net_out, const int32 *labels_dev, CuMatrix *diff, float fw_max) {
   ASLP_ASSERT(fw.Dim() == net_out.NumRows());
   diff->Resize(net_out.NumRows(), net_out.NumCols(), kUndefined);
-  aslp_xent_eval(net_out.Data(), net_out.Dim(), nullptr, 0, labels_dev, fw.Data(), diff->Data(), diff->Stride(), stats_.Data());
+  XentLabels(net_out, false, labels_dev, fw, fw_max, diff, stats_.Data());
   CheckK();
   AfterEval(net_out.NumRows());
 }
-void Xent::EvalLabelsPreSoftmax(const CuVectorBase &fw, const CuMatrixBase &acts, const int32 *labels_dev, CuMatrix *diff) {
+void Xent::EvalLabelsPreSoftmax(const CuVectorBase &fw, const CuMatrixBase &acts, const int32 *labels_dev, CuMatrix *diff, float fw_max) {
   ASLP_ASSERT(fw.Dim() == acts.NumRows());
   diff->Resize(acts.NumRows(), acts.NumCols(), kUndefined);
-  aslp_softmax_xent_eval(acts.Data(), acts.Dim(), nullptr, 0, labels_dev, fw.Data(), diff->Data(), diff->Stride(), stats_.Data(), nullptr, 0);
+  if (!aslp_softmax_xent_supported(acts.NumCols())) ASLP_ERR << "Softmax + Xent in one pass: unsupported number of classes " << acts.NumCols();
+  XentLabels(acts, true, labels_dev, fw, fw_max, diff, stats_.Data());
   CheckK();
   AfterEval(acts.NumRows());
 }
@@ -162,7 +179,9 @@ void Xent::EvalOnLossInput(const std::vector<BaseFloat> &frame_weights, const Cu
   diff->Resize(num_frames, num_pdf, kUndefined);
   if (one_hot) {
     labels_ = labels;
-    aslp_softmax_xent_eval(in.Data(), in.Dim(), nullptr, 0, labels_.Data(), frame_weights_.Data(), diff->Data(), diff->Stride(), stats_.Data(), nullptr, 0);
+    float fw_max = 0.0f;
+    for (BaseFloat w : frame_weights) fw_max = std::max(fw_max, std::fabs(w));
+    XentLabels(in, true, labels_.Data(), frame_weights_, fw_max, diff, stats_.Data());
   } else {
     PosteriorToMatrix(post, num_pdf, &tgt_mat_);
     aslp_softmax_xent_eval(in.Data(), in.Dim(), tgt_mat_.Data(), tgt_mat_.Stride(), nullptr, frame_weights_.Data(), diff->Data(), diff->Stride(),

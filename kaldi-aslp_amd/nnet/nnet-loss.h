@@ -39,8 +39,10 @@ class Xent : public LossItf {
   // device-resident variants (no host data on the step path): weights / labels already on the GPU
   void EvalLabels(const CuVectorBase &frame_weights, const CuMatrixBase &net_out, const CuArray<int32> &labels, CuMatrix *diff);
   // `acts` are the activations in front of the network's final Softmax; the posteriors are formed inside the loss kernel
-  void EvalLabelsPreSoftmax(const CuVectorBase &frame_weights, const CuMatrixBase &acts, const int32 *labels_dev, CuMatrix *diff);
-  void EvalLabels(const CuVectorBase &frame_weights, const CuMatrixBase &net_out, const int32 *labels_dev, CuMatrix *diff);
+  // fw_max: the largest |frame weight| if the caller knows it (> 0): the diff's bound, which lets the kernel leave the diff's fp16 planes
+  // for the layer product that reads it (csrc/split16.h)
+  void EvalLabelsPreSoftmax(const CuVectorBase &frame_weights, const CuMatrixBase &acts, const int32 *labels_dev, CuMatrix *diff, float fw_max = -1.0f);
+  void EvalLabels(const CuVectorBase &frame_weights, const CuMatrixBase &net_out, const int32 *labels_dev, CuMatrix *diff, float fw_max = -1.0f);
   // Eval(frame_weights, net_out, Posterior) for callers that hold the executor's buffers (Nnet::PropagateForLoss):
   // `loss_input` is the network output, or the activations in front of its final Softmax when `pre_softmax`
   void EvalOnLossInput(const std::vector<BaseFloat> &frame_weights, const CuMatrixBase &loss_input, bool pre_softmax, const Posterior &target,

@@ -120,7 +120,10 @@ void Nnet::Propagate(const std::vector<const CuMatrixBase *> &in, std::vector<Cu
       }
     }
     if (as >= 0) {  // AffineTransform + Sigmoid forward in one GEMM; both outputs exist, the backward passes stay separate
-      dynamic_cast<AffineTransform *>(components_[i])->PropagateWithSigmoid(*in_view_[i], &output_buf_[i], &output_buf_[as]);
+      const int32 ac = AffineConsumerOf(as);   // the layer product that reads the activations gets their fp16 planes from the same epilogue
+      PlaneHolder *ap = (ac >= 0 && gemm_split16_serves(num_frame, components_[ac]->OutputDim(), components_[ac]->InputDim()))
+                            ? &dynamic_cast<AffineTransform *>(components_[ac])->InputPlanes() : nullptr;
+      dynamic_cast<AffineTransform *>(components_[i])->PropagateWithSigmoid(*in_view_[i], &output_buf_[i], &output_buf_[as], ap);
       out_view_[i] = &output_buf_[i];
       in_view_[as] = &output_buf_[i];
       out_view_[as] = &output_buf_[as];
@@ -186,6 +189,28 @@ CuMatrix *Nnet::LossDiff(int32 num_frames) {
   ASLP_ASSERT(output_.size() == 1);
   CuMatrix *d = &output_diff_buf_[output_[0]];
   d->Resize(num_frames, components_[output_[0]]->OutputDim(), kUndefined);
+  // Does this very buffer reach an AffineTransform as its out-diff (through identity backward passes that hand the buffer on:
+  // OutputLayer, the final Softmax)?  Then the loss may leave the diff's fp16 planes with that layer (csrc/split16.h).
+  S16DiffTarget &t = s16_loss_diff_target();
+  t = S16DiffTarget();
+  next_bwd_epoch_ = 0;
+  if (fuse_layers_ && alias_links_) {
+    int32 c = output_[0];
+    while (c >= 0 && components_[c]->GetType() != Component::kAffineTransform) {
+      const bool hands_on = components_[c]->BackpropIsCopy() && components_[c]->GetType() != Component::kInputLayer && IsDirectLink(c) &&
+                            num_consumers_[components_[c]->GetInput()[0]] == 1;
+      c = hands_on ? components_[c]->GetInput()[0] : -1;
+    }
+    if (c >= 0 && (c == output_[0] || num_consumers_[c] == 1)) {
+      AffineTransform *at = dynamic_cast<AffineTransform *>(components_[c]);
+      if (gemm_split16_serves(at->OutputDim(), at->InputDim(), num_frames) && d->NumCols() == at->OutputDim()) {
+        next_bwd_epoch_ = s16_new_epoch();
+        t.planes = &at->DiffPlanes().get();
+        t.epoch = next_bwd_epoch_;
+        t.diff = d->Data();
+      }
+    }
+  }
   return d;
 }
 void Nnet::BackpropagateFromLossDiff() {
@@ -200,7 +225,12 @@ void Nnet::Backpropagate(const std::vector<const CuMatrixBase *> &out_diff, std:
   ASLP_ASSERT(out_diff.size() == output_.size());
   int num_frame = out_diff[0]->NumRows();
   const int32 N = NumComponents();
-  S16EpochScope plane_scope(fwd_epoch_, s16_new_epoch());   // the forward buffers as Propagate left them; every diff buffer new
+  // the forward buffers as Propagate left them; every diff buffer new (the loss's diff may already carry planes under the epoch
+  // LossDiff drew for this pass)
+  const long bwd_epoch = (diff_in_place_ && next_bwd_epoch_ != 0) ? next_bwd_epoch_ : s16_new_epoch();
+  next_bwd_epoch_ = 0;
+  s16_loss_diff_target() = S16DiffTarget();
+  S16EpochScope plane_scope(fwd_epoch_, bwd_epoch);
   // which producers receive their out-diff by accumulation (need a zeroed buffer, :112-114)
   std::vector<char> direct(N, 0);
   for (int32 i = 0; i < N; i++) {

@@ -129,6 +129,7 @@ class Nnet {
   bool fuse_layers_ = true;
   bool overlap_updates_ = true;
   bool fold_softmax_request_ = false, softmax_folded_ = false, diff_in_place_ = false;
+  long next_bwd_epoch_ = 0;  // drawn by LossDiff() for the backward pass that will read the diff the loss is about to write
   long fwd_epoch_ = 0;  // csrc/split16.h: the forward pass whose buffers are still in place (operand planes made from them may be reused)
 };
 

@@ -90,6 +90,8 @@ void aslp_worker_free(aslp_worker_t w) { delete w; }
 int aslp_worker_init_param(aslp_worker_t w, float *const *dev_ptrs, const int *sizes, int n) {
   API_BEGIN w->worker->InitParam(Params(dev_ptrs, sizes, n)); API_END
 }
+int aslp_comm_ranks_seen(aslp_comm_t c) { try { return c->comm->RanksSeen(); } catch (const std::exception &e) { t_err = e.what(); return -1; } }
+const char *aslp_comm_transport(aslp_comm_t c) { return c->comm->Transport(); }
 int aslp_worker_init_param_nnet(aslp_worker_t w, aslp_nnet_t net) {
   API_BEGIN
   const int n = aslp_nnet_get_gpu_params(net, nullptr, nullptr, 0);

@@ -216,6 +216,12 @@ class RcclComm : public FileRendezvousComm {
     if (scratch_) (void)hipFree(scratch_);
     if (comm_) (void)ncclCommDestroy(comm_);
   }
+  int RanksSeen() const {
+    int n = 0;
+    Nccl(ncclCommCount(comm_, &n), "ncclCommCount");
+    return n;
+  }
+  const char *Transport() const { return "rccl"; }
   void Send(int peer, const Buffers &bufs) { P2P(peer, &bufs, nullptr); }
   void Recv(int peer, const Buffers &bufs) { P2P(peer, nullptr, &bufs); }
   void Exchange(int peer, const Buffers &send, const Buffers &recv) { P2P(peer, &send, &recv); }
@@ -230,10 +236,17 @@ class RcclComm : public FileRendezvousComm {
     if (n) Nccl(ncclAllReduce(dev, dev, n, ncclDouble, ncclSum, comm_, cur_stream()), "ncclAllReduce(double)");
   }
   void AllReduceSumMany(const std::vector<std::pair<float *, int>> &bufs) {
-    Nccl(ncclGroupStart(), "ncclGroupStart");
-    for (auto &b : bufs)
-      if (b.second > 0) Nccl(ncclAllReduce(b.first, b.first, (size_t)b.second, ncclFloat, ncclSum, comm_, cur_stream()), "ncclAllReduce(float)");
-    Nccl(ncclGroupEnd(), "ncclGroupEnd");
+    // tensors that lie back to back in memory (a parameter arena, the pitched rows of one matrix followed by its bias) travel as ONE
+    // collective; whatever is left goes into one group
+    std::vector<std::pair<float *, size_t>> spans;
+    for (auto &b : bufs) {
+      if (b.second <= 0) continue;
+      if (!spans.empty() && spans.back().first + spans.back().second == b.first) spans.back().second += (size_t)b.second;
+      else spans.emplace_back(b.first, (size_t)b.second);
+    }
+    if (spans.size() > 1) Nccl(ncclGroupStart(), "ncclGroupStart");
+    for (auto &sp : spans) Nccl(ncclAllReduce(sp.first, sp.first, sp.second, ncclFloat, ncclSum, comm_, cur_stream()), "ncclAllReduce(float)");
+    if (spans.size() > 1) Nccl(ncclGroupEnd(), "ncclGroupEnd");
   }
   void AllReduceSumHost(int32 *host, size_t n) { HostReduce(host, n, ncclInt32); }
   void AllReduceSumHost(double *host, size_t n) { HostReduce(host, n, ncclDouble); }
@@ -292,7 +305,10 @@ class ShmComm : public FileRendezvousComm {
     if (n > kMaxRanks) ASLP_ERR << "ShmComm: at most " << kMaxRanks << " ranks";
     // ranks of this transport may share a GPU: the persistent LSTM / GRU launches of libaslp_hip then take a cross-process device lock
     // (include/aslp_kernels.h aslp_device_shared; read from the environment at the first such launch).  An explicit setting wins.
-    if (n > 1) (void)setenv("ASLP_DEVICE_SHARED", "1", 0);
+    if (n > 1) {
+      (void)setenv("ASLP_DEVICE_SHARED", "1", 0);
+      if (getenv("ASLP_DEVICE_SHARED")[0] == '1') aslp_device_shared(1);   // also when libaslp_hip has already read the environment
+    }
     static_assert(std::atomic<int>::is_always_lock_free && std::atomic<long>::is_always_lock_free, "address-free atomics needed in shared memory");
     const size_t slot_mb = getenv("ASLP_SHM_SLOT_MB") ? (size_t)atol(getenv("ASLP_SHM_SLOT_MB")) : 16;
     slot_bytes_ = (slot_mb < 1 ? 1 : slot_mb) << 20;
@@ -324,10 +340,18 @@ class ShmComm : public FileRendezvousComm {
       Map(fd);
       (void)close(fd);
     }
-    Barrier();
+    try {
+      Barrier();
+    } catch (...) {   // a peer never came: no destructor will run for this object, so name and mapping go here
+      if (rank == 0) (void)shm_unlink(name_.c_str());
+      if (base_) (void)munmap(base_, bytes_);
+      base_ = nullptr;
+      throw;
+    }
     if (rank == 0) (void)shm_unlink(name_.c_str());   // everybody has it mapped: the name can go, the memory lives until the last unmap
     Joined();
   }
+  const char *Transport() const { return "shm"; }
   ~ShmComm() {
     if (base_) (void)munmap(base_, bytes_);
   }
@@ -512,6 +536,7 @@ class ThreadComm : public Comm {
   ThreadComm(std::shared_ptr<ThreadCommGroup> g, int rank) : g_(g), rank_(rank) {}
   int Rank() const { return rank_; }
   int NumNodes() const { return g_->n; }
+  const char *Transport() const { return "threads"; }
   void Barrier() { g_->Barrier(); }
   void AllReduceSum(float *dev, size_t n) { Reduce(dev, n); }
   void AllReduceSum(double *dev, size_t n) { Reduce(dev, n); }

@@ -22,6 +22,10 @@ class Comm {
   virtual ~Comm() {}
   virtual int Rank() const = 0;
   virtual int NumNodes() const = 0;
+  // how many ranks the transport itself reports in the group (RcclComm: ncclCommCount of the live communicator) and its name: a bench
+  // line or a log can then prove which transport carried a run and that every rank really joined it
+  virtual int RanksSeen() const { return NumNodes(); }
+  virtual const char *Transport() const = 0;
   virtual void Barrier() = 0;
   virtual void AllReduceSum(float *dev, size_t n) = 0;        // in place, device memory
   virtual void AllReduceSum(double *dev, size_t n) = 0;       // in place, device memory
