@@ -203,20 +203,20 @@ typedef struct aslp_gemm_epilogue_ {
   /* What the epilogue leaves for the split-fp16 products that will read its output (honoured by the split-fp16 kernel only:
    * aslp_gemm_last_parts() tells whether the launch did).  planes_of = 1: the planes of W after the fused step (`planes.slot` must hold
    * a bound of |W + w_alpha C| before the launch: aslp_weight_bound); 2: the planes of act_out (bound: 1 for sigmoid / tanh).
-   * wmax_parts / cmax_parts (each NULL or aslp_gemm_last_parts() floats): one maximum per wave of |W| after the step / of |C|. */
+   * wmax_parts / cmax_parts (each NULL or aslp_gemm_last_parts() floats): one maximum per workgroup of |W| after the step / of |C|. */
   aslp_planes_out planes;
   int planes_of;
   float *wmax_parts, *cmax_parts;
   /* planes_of = 1 without a separate aslp_weight_bound launch: the kernel forms the bound itself before its first tile (every workgroup
-   * the same value, workgroup 0 stores it to planes.slot) from the bound_n per-wave maxima of |W| and |C_old| (bound_c_parts may be
+   * the same value, workgroup 0 stores it to planes.slot) from the bound_n per-workgroup maxima of |W| and |C_old| (bound_c_parts may be
    * NULL when beta == 0) the previous step left, the bounds of its two operands' planes and K. */
   const float *bound_w_parts, *bound_c_parts;
   int bound_n;
 } aslp_gemm_epilogue;
-/* number of per-wave maxima (and proof that the planes were written) of the calling thread's latest aslp_sgemm* call; 0 = the kernel that
+/* number of per-workgroup maxima (and proof that the planes were written) of the calling thread's latest aslp_sgemm* call; 0 = the kernel that
  * ran does not leave them */
 int aslp_gemm_last_parts(void);
-/* Bound of |W + w_alpha C| for the next fused weight step, C = clip(alpha A^T B + beta C_old): from the per-wave maxima of |W| (n_w) and
+/* Bound of |W + w_alpha C| for the next fused weight step, C = clip(alpha A^T B + beta C_old): from the per-workgroup maxima of |W| (n_w) and
  * |C_old| (n_c, may be 0) the previous step left, the bounds of the two operands' planes and K; written to *slot_out (device).  One
  * small launch on the current stream. */
 void aslp_weight_bound(const float *w_parts, int n_w, const float *c_parts, int n_c, const aslp_planes *a, const aslp_planes *b, int K,

@@ -199,7 +199,7 @@ __device__ __forceinline__ void gemm_colstats(const GemmArgs &g, const f32x16 (&
 // The arithmetic per element is the scalar epilogue's.  Eligibility (uniform, checked by the caller): N, ldc (ldw, ld_act) multiples
 // of 4, all pointers 16-byte aligned.  `tile`: this wave's LDS slice; the caller has passed a workgroup barrier since the last operand read.
 constexpr int kEpiPitch = 36;
-__device__ __forceinline__ bool gemm_epilogue_wide_ok(const GemmArgs &g) {
+__host__ __device__ __forceinline__ bool gemm_epilogue_wide_ok(const GemmArgs &g) {
   const aslp_gemm_epilogue &ep = g.ep;
   auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
   return (g.N & 3) == 0 && (g.ldc & 3) == 0 && al(g.C) && (!ep.bias || al(ep.bias)) && (!ep.W || ((ep.ldw & 3) == 0 && al(ep.W))) &&

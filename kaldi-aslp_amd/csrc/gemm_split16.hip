@@ -131,6 +131,107 @@ inline int tw_log2_for(int units) {
   return l;
 }
 
+// ---- shared by the product kernels ------------------------------------------------------------------------------------------------
+// (EXTRA) the bound of the weights after the fused step: |W + w_alpha C| <= max |W| + |w_alpha| (|alpha| K max|a| max|b| + |beta| max |C_old|),
+// the maxima from the previous step's per-workgroup partials.  Every wave forms it; workgroup 0 stores it for the planes' readers.
+__device__ __forceinline__ float s16_weight_bound(const GemmArgs &g, const S16View &va, const S16View &vb, int lane) {
+  if (g.ep.bound_w_parts == nullptr) return 0.f;   // uniform
+  // (four independent loads per array and pass: a dependent load per element here once cost every weight-gradient launch 50 us)
+  float mw = 0.f, mc = 0.f;
+  const int n = g.ep.bound_n;
+  const float *wp = g.ep.bound_w_parts, *cp = g.ep.bound_c_parts;
+  for (int i = lane; i < n; i += 256) {
+    const int i1 = i + 64, i2 = i + 128, i3 = i + 192;
+    const float a0 = wp[i], a1 = i1 < n ? wp[i1] : 0.f, a2 = i2 < n ? wp[i2] : 0.f, a3 = i3 < n ? wp[i3] : 0.f;
+    mw = fmaxf(fmaxf(mw, fmaxf(a0, a1)), fmaxf(a2, a3));
+    if (cp != nullptr) {
+      const float c0 = cp[i], c1 = i1 < n ? cp[i1] : 0.f, c2 = i2 < n ? cp[i2] : 0.f, c3 = i3 < n ? cp[i3] : 0.f;
+      mc = fmaxf(fmaxf(mc, fmaxf(c0, c1)), fmaxf(c2, c3));
+    }
+  }
+  mw = wave_max(mw);
+  mc = wave_max(mc);
+  float v = fabsf(g.alpha) * (float)g.K * __uint_as_float(*va.slot) * __uint_as_float(*vb.slot) + fabsf(g.beta) * mc;
+  if (g.ep.clip > 0.f) v = fminf(v, g.ep.clip);
+  const float w_bound = mw + fabsf(g.ep.w_alpha) * v;
+  if (blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0) *const_cast<unsigned *>(g.ep.planes.slot) = __float_as_uint(w_bound);
+  return w_bound;
+}
+
+// Everything behind the K loop: join the two accumulators and undo the operand scales, the column sums of a reduction-major A
+// (COLSUM), the column statistics, the epilogue (with the planes / maxima of its output when EXTRA).  (row0, col0): this wave's patch.
+template <int TM, int TN, int NW, bool EXTRA, bool COLSUM>
+__device__ __forceinline__ void s16_finish(const GemmArgs &g, const S16View &va, const S16View &vb, f32x16 (&acc)[TM][TN], const f32x16 (&accx)[TM][TN],
+                                           const float (&asum)[TM], bool do_colsum, float w_bound, int row0, int col0, int lane, int wave, float *lds) {
+  const int l31 = lane & 31, lh = lane >> 5;
+  // 2^-(up_a + up_b) in two exact factors (either alone may leave fp32's range where their product with the accumulator does not)
+  {
+    const int e = -(s16_exponent(*va.slot) + s16_exponent(*vb.slot));
+    const float s1 = ldexpf(1.f, e / 2), s2 = ldexpf(1.f, e - e / 2);
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+      for (int j = 0; j < TN; j++)
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc[i][j][q] = (fmaf(accx[i][j][q], 0x1p-11f, acc[i][j][q]) * s1) * s2;
+  }
+  if constexpr (COLSUM) {
+    if (do_colsum) {
+      const float inv_a = ldexpf(1.f, -s16_exponent(*va.slot));
+#pragma unroll
+      for (int i = 0; i < TM; i++) {
+        const float s_all = (asum[i] + __shfl_xor(asum[i], 32, 64)) * inv_a;  // the two lane halves hold disjoint k subsets
+        const int row = row0 + i * 32 + l31;
+        if (lh == 0 && row < g.M) {
+          float v = s_all;
+          if (g.ep.colsum_beta != 0.0f) v += g.ep.colsum_beta * g.ep.colsum[row];
+          g.ep.colsum[row] = v;
+          if (g.ep.colsum_w) g.ep.colsum_w[row] += g.ep.colsum_w_alpha * v;
+        }
+      }
+    }
+  }
+  if (g.ep.colstats != nullptr) gemm_colstats<TM, TN>(g, acc, row0, col0, l31, lh);  // uniform
+  // planes of an output and per-workgroup maxima for the products that will read it (aslp_gemm_epilogue.planes / *_parts)
+  EpiExtra xtra;
+  if constexpr (EXTRA) {
+    if (g.ep.planes_of != 0 && g.ep.planes.hi != nullptr)
+      xtra.pscale = ldexpf(1.f, s16_exponent(g.ep.bound_w_parts != nullptr ? __float_as_uint(w_bound) : *g.ep.planes.slot));
+  }
+  if (g.wide_epilogue && gemm_epilogue_wide_ok(g)) {  // uniform
+    __builtin_amdgcn_s_barrier();
+    gemm_epilogue_wide<TM, TN>(g, acc, row0, col0, lane, lds + wave * 32 * kEpiPitch, xtra, EXTRA);
+  } else {
+    gemm_epilogue<TM, TN>(g, acc, row0, col0, l31, lh, xtra, false);   // (the host asks for planes / maxima only where the wide epilogue applies)
+  }
+  if (EXTRA && (g.ep.wmax_parts != nullptr || g.ep.cmax_parts != nullptr)) {   // one maximum per workgroup: the waves meet in LDS
+    const float wmx = wave_max(xtra.wmax), cmx = wave_max(xtra.cmax);
+    __builtin_amdgcn_s_barrier();   // every wave is done with its epilogue slice of the LDS
+    if (lane == 0) { lds[2 * wave] = wmx; lds[2 * wave + 1] = cmx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float w = lds[0], c = lds[1];
+#pragma unroll
+      for (int q = 1; q < NW; q++) { w = fmaxf(w, lds[2 * q]); c = fmaxf(c, lds[2 * q + 1]); }
+      const int idx = (int)blockIdx.z * (int)gridDim.x + (int)blockIdx.x;
+      if (g.ep.wmax_parts) g.ep.wmax_parts[idx] = w;
+      if (g.ep.cmax_parts) g.ep.cmax_parts[idx] = c;
+    }
+  }
+}
+// column sums of a reduction-major A from the fragments a wave multiplies anyway: sum over the 8 k of a fragment of hi + 2^-11 lo'
+__device__ __forceinline__ float s16_frag_sum(float sum, const half8 hi, const half8 lo) {
+  typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+  const half2v one = {(h16)1.0f, (h16)1.0f}, eps = {(h16)0x1p-11f, (h16)0x1p-11f};
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const half2v hv = {hi[2 * q], hi[2 * q + 1]}, lv = {lo[2 * q], lo[2 * q + 1]};
+    sum = __builtin_amdgcn_fdot2(hv, one, sum, false);     // fp32 accumulation of exact fp16 values
+    sum = __builtin_amdgcn_fdot2(lv, eps, sum, false);
+  }
+  return sum;
+}
+
 // ---- the product ---------------------------------------------------------------------------------------------------------------
 struct S16Operands { S16View a, b, a1, b1; int kp; };   // a1 / b1: second product of a pair (blockIdx.z == 1)
 
@@ -353,24 +454,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_s16_glds(GemmArgs g, S16O
     constexpr int t = decltype(T_)::value;
     static_for<0, G>([&](auto U_) { dma_unit(U_, T_, t); });
   });
-  // (EXTRA) the bound of the weights after the fused step, while the first tiles are on their way: |W + w_alpha C| <= max |W| +
-  // |w_alpha| (|alpha| K max|a| max|b| + |beta| max |C_old|), the maxima from the previous step's per-wave partials
   float w_bound = 0.f;
-  if constexpr (EXTRA) {
-    if (g.ep.bound_w_parts != nullptr) {   // uniform
-      float mw = 0.f, mc = 0.f;
-      for (int i = lane; i < g.ep.bound_n; i += 64) {
-        mw = fmaxf(mw, g.ep.bound_w_parts[i]);
-        if (g.ep.bound_c_parts != nullptr) mc = fmaxf(mc, g.ep.bound_c_parts[i]);
-      }
-      mw = wave_max(mw);
-      mc = wave_max(mc);
-      float v = fabsf(g.alpha) * (float)g.K * __uint_as_float(*va.slot) * __uint_as_float(*vb.slot) + fabsf(g.beta) * mc;
-      if (g.ep.clip > 0.f) v = fminf(v, g.ep.clip);
-      w_bound = mw + fabsf(g.ep.w_alpha) * v;
-      if (blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0) *const_cast<unsigned *>(g.ep.planes.slot) = __float_as_uint(w_bound);
-    }
-  }
+  if constexpr (EXTRA) w_bound = s16_weight_bound(g, va, vb, lane);   // while the first tiles are on their way
   wait_vmcnt<(D - 1) * G>();
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -387,57 +472,180 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_s16_glds(GemmArgs g, S16O
   }
   wait_vmcnt<0>();
 
-  // join the two accumulators and undo the operand scales: 2^-(up_a + up_b), in two exact factors (either alone may leave fp32's range
-  // where their product with the accumulator does not)
-  {
-    const int e = -(s16_exponent(*va.slot) + s16_exponent(*vb.slot));
-    const float s1 = ldexpf(1.f, e / 2), s2 = ldexpf(1.f, e - e / 2);
-#pragma unroll
-    for (int i = 0; i < TM; i++)
-#pragma unroll
-      for (int j = 0; j < TN; j++)
-#pragma unroll
-        for (int q = 0; q < 16; q++) acc[i][j][q] = (fmaf(accx[i][j][q], 0x1p-11f, acc[i][j][q]) * s1) * s2;
+  static_assert(NW * 32 * kEpiPitch * (int)sizeof(float) <= NS * STAGE, "the waves' epilogue slices must fit into the operand LDS");
+  s16_finish<TM, TN, NW, EXTRA, !A_KC>(g, va, vb, acc, accx, asum, do_colsum, w_bound, m0 + wm * WM, n0 + wn * WN, lane, wave, lds);
+}
+
+// ---- both operands reduction-major (the weight gradient dW = dy^T x), 128 x 128 tile ---------------------------------------------
+// The generic kernel above keeps the fragments of a whole 64-deep K tile in registers, twice: with a 128 x 128 tile on four waves that is
+// 256 registers of fragments beside 128 of accumulators, and the transposing reads' addresses push it into scratch memory.  Here the
+// tile's depth is 32 (two instruction steps), the fragments are double buffered per instruction step (64 registers), and the LDS holds a
+// ring of FOUR such half tiles (128 KB): the DMA runs three half tiles (~2300 matrix-pipe cycles) ahead of the reads.  Against the
+// 64 x 128 tile the 128 x 128 one moves a third less through L2 -> LDS per flop and issues a third fewer LDS reads per MFMA (wave tile
+// 64 x 64) -- the two things gemm_s16_glds waits for (devtools/micro/s16_ablate.hip).
+//   half tile h, slot h % 4:  A_hi | A_lo | B_hi | B_lo, each [32 k][128 columns] halves = 8 KB, rows as they lie in memory
+//   per half tile and wave: 8 DMA units (4 k rows x 256 B each), 2 x 12 MFMAs, 2 x 16 transposing reads, one barrier
+template <bool EXTRA>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) gemm_s16_ks128(GemmArgs g, S16Operands ops) {   // (128 KB of LDS: one workgroup per CU whatever the register count)
+  constexpr int BM = 128, BN = 128, NW = 4, TM = 2, TN = 2, KT = 32, RING = 4;
+  constexpr int PLANE = KT * BM * 2, SLOT = 4 * PLANE;      // bytes: 8 KB per plane, 32 KB per half tile
+  constexpr int G = (4 * PLANE / 1024) / NW;                  // 8 DMA units per wave and half tile
+  extern __shared__ __attribute__((aligned(1024))) float lds[];
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lds;
+  lds_char *lds3 = (lds_char *)(__attribute__((address_space(3))) void *)lds;
+
+  S16View va = ops.a, vb = ops.b;
+  if (g.pair && blockIdx.z == 1) {  // second product of a pair (uniform)
+    g.C = g.C1; g.ep = g.ep1;
+    va = ops.a1; vb = ops.b1;
   }
-  if constexpr (!A_KC) {
-    if (do_colsum) {
-      const float inv_a = ldexpf(1.f, -s16_exponent(*va.slot));
+  int tm, tn;
+  xcd_tile<BM, BN>(g, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1, lh = lane >> 5;
+  const int htiles = ops.kp / KT;
+
+  // ---- DMA descriptors: unit = 4 k rows x 256 B of one plane; plane p = unit / 8 (A_hi, A_lo, B_hi, B_lo), 8 units per plane
+  const h16 *src[G];
+  int adv[G];
+  static_for<0, G>([&](auto U_) {
+    constexpr int u = decltype(U_)::value;
+    const int unit = wave + u * NW;   // wave-uniform, 0 .. 31
+    const int plane = unit >> 3, sub = unit & 7;
+    const bool is_a = plane < 2, lo_plane = plane & 1;
+    const h16 *base = is_a ? (lo_plane ? va.lo : va.hi) : (lo_plane ? vb.lo : vb.hi);
+    const int v_ld = is_a ? va.ld : vb.ld;
+    const int krow = sub * 4 + (lane >> 4);
+    const int c = (lane & 15) ^ (4 * (krow & 3));   // the 64-byte column groups of a k row, XOR-swizzled with the row's low bits
+    int col = (is_a ? m0 : n0) + 8 * c;
+    col = col + 8 <= v_ld ? col : v_ld - 8;         // (columns past the planes: outputs that are not stored)
+    src[u] = base + (long)krow * v_ld + col;
+    adv[u] = KT * v_ld;
+  });
+  auto dma_half_tile = [&](int slot, int h) {   // slot: wave-uniform ring index
+    static_for<0, G>([&](auto U_) {
+      constexpr int u = decltype(U_)::value;
+      glds16(src[u], __builtin_amdgcn_readfirstlane(lds_base + slot * SLOT + (wave + u * NW) * 1024));
+      src[u] += (h + 1 < htiles) ? adv[u] : 0;   // requests past the last half tile fetch it again into a slot nobody reads
+    });
+  };
+  auto dma_unit = [&](auto U_, int slot, int h) {
+    constexpr int u = decltype(U_)::value;
+    glds16(src[u], __builtin_amdgcn_readfirstlane(lds_base + slot * SLOT + (wave + u * NW) * 1024));
+    src[u] += (h + 1 < htiles) ? adv[u] : 0;
+  };
+
+  // ---- fragment addresses (bytes inside a slot): lane (p = lane & 15, column half gg) addresses k row 8 lh + p / 4 of its 16-lane group's
+  // [4 k][16 columns] block and receives column 16 gg + p, k .. k + 3 (ds_read_b64_tr_b16)
+  const int p16 = lane & 15, gg = (lane >> 4) & 1, krow_l = 8 * lh + (p16 >> 2);
+  int a_off[TM], b_off[TN];
 #pragma unroll
-      for (int i = 0; i < TM; i++) {
-        const float s_all = (asum[i] + __shfl_xor(asum[i], 32, 64)) * inv_a;  // the two lane halves hold disjoint k subsets
-        const int row = m0 + wm * WM + i * 32 + l31;
-        if (lh == 0 && row < g.M) {
-          float v = s_all;
-          if (g.ep.colsum_beta != 0.0f) v += g.ep.colsum_beta * g.ep.colsum[row];
-          g.ep.colsum[row] = v;
-          if (g.ep.colsum_w) g.ep.colsum_w[row] += g.ep.colsum_w_alpha * v;
+  for (int t = 0; t < TM; t++) a_off[t] = krow_l * 256 + 64 * ((wm * TM + t) ^ (krow_l & 3)) + 32 * gg + 8 * (p16 & 3);
+#pragma unroll
+  for (int t = 0; t < TN; t++) b_off[t] = 2 * PLANE + krow_l * 256 + 64 * ((wn * TN + t) ^ (krow_l & 3)) + 32 * gg + 8 * (p16 & 3);
+  struct Frag { half8 ah[TM], al[TM], bh[TN], bl[TN]; };   // one instruction step
+  // read r of the 16 of an instruction step: operand, fragment, plane, half of the fragment
+  auto read_unit = [&](int slot_base, auto KS_, Frag &f, auto R_) {
+    constexpr int r = decltype(R_)::value, ks = decltype(KS_)::value;
+    constexpr bool is_a = r < 8;
+    constexpr int q = r & 7, t = q >> 2, lo = (q >> 1) & 1, half = q & 1;
+    const int off = slot_base + (is_a ? a_off[t] : b_off[t]) + (lo ? PLANE : 0) + (16 * ks + 4 * half) * 256;
+    const half4 v = __builtin_bit_cast(half4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4 *)(lds3 + off)));
+    half8 *dst = is_a ? (lo ? &f.al[t] : &f.ah[t]) : (lo ? &f.bl[t] : &f.bh[t]);
+    if constexpr (half == 0) dst->lo = v; else dst->hi = v;
+  };
+
+  f32x16 acc[TM][TN], accx[TM][TN];   // hi hi; hi lo' + lo' hi
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) { acc[i][j][e] = 0.0f; accx[i][j][e] = 0.0f; }
+  const bool do_colsum = g.ep.colsum != nullptr && tn == 0 && wn == 0;  // wave-uniform
+  float asum[TM] = {0.f, 0.f};
+  // MFMA m of the 12 of an instruction step: the four main products, then the four hi lo', then the four lo' hi (a cross accumulator is
+  // met again four instructions later)
+  auto mma_unit = [&](const Frag &f, auto M_) {
+    constexpr int m = decltype(M_)::value, j = m >> 2, i = (m >> 1) & 1, n = m & 1;
+    if constexpr (j == 0) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[n], acc[i][n], 0, 0, 0);
+    else if constexpr (j == 1) accx[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[n], accx[i][n], 0, 0, 0);
+    else accx[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[n], accx[i][n], 0, 0, 0);
+  };
+
+  // prologue: three half tiles on their way, the first one landed, its first step's fragments read
+  Frag f0, f1;
+  dma_half_tile(0, 0);
+  dma_half_tile(1, 1);
+  dma_half_tile(2, 2);
+  float w_bound = 0.f;
+  if constexpr (EXTRA) w_bound = s16_weight_bound(g, va, vb, lane);
+  wait_vmcnt<2 * G>();
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  static_for<0, 16>([&](auto R_) { read_unit(0, std::integral_constant<int, 0>(), f0, R_); });
+
+  for (int h = 0; h < htiles; h++) {
+    const int slot = h & (RING - 1), slot_base = slot * SLOT;
+    const int slot_req = (h + 3) & (RING - 1), slot_nxt = ((h + 1) & (RING - 1)) * SLOT;
+    // step 0 of half tile h from f0: request half tile h + 3 (the slot of h - 1: every wave has passed the barrier behind its last
+    // read of it), read step 1's fragments into f1
+    static_for<0, 12>([&](auto S_) {
+      constexpr int sidx = decltype(S_)::value;
+      mma_unit(f0, S_);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (sidx == 0) {
+        if (do_colsum) {
+#pragma unroll
+          for (int i = 0; i < TM; i++) asum[i] = s16_frag_sum(asum[i], f0.ah[i], f0.al[i]);
         }
       }
-    }
+      if constexpr (sidx < G) dma_unit(S_, slot_req, h + 3);
+      static_for<sidx * 16 / 12, (sidx + 1) * 16 / 12>([&](auto R_) { read_unit(slot_base, std::integral_constant<int, 1>(), f1, R_); });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    // step 1 from f1: this wave's share of half tile h + 1 has landed (h + 2, h + 3 stay in flight), one barrier publishes it, then
+    // its first step's fragments go into f0
+    static_for<0, 12>([&](auto S_) {
+      constexpr int sidx = decltype(S_)::value;
+      mma_unit(f1, S_);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (sidx == 0) {
+        if (do_colsum) {
+#pragma unroll
+          for (int i = 0; i < TM; i++) asum[i] = s16_frag_sum(asum[i], f1.ah[i], f1.al[i]);
+        }
+      }
+      if constexpr (sidx == 3) {
+        wait_vmcnt<2 * G>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+      if constexpr (sidx >= 4) {
+        static_for<(sidx - 4) * 16 / 8, (sidx - 3) * 16 / 8>([&](auto R_) { read_unit(slot_nxt, std::integral_constant<int, 0>(), f0, R_); });
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
   }
-  if (g.ep.colstats != nullptr) gemm_colstats<TM, TN>(g, acc, m0 + wm * WM, n0 + wn * WN, l31, lh);  // uniform
-  static_assert(NW * 32 * kEpiPitch * (int)sizeof(float) <= NS * STAGE, "the waves' epilogue slices must fit into the operand LDS");
-  // planes of an output and per-wave maxima for the products that will read it (aslp_gemm_epilogue.planes / *_parts)
-  EpiExtra xtra;
-  constexpr bool want_extra = EXTRA;
-  if constexpr (EXTRA) {
-    if (g.ep.planes_of != 0 && g.ep.planes.hi != nullptr)
-      xtra.pscale = ldexpf(1.f, s16_exponent(g.ep.bound_w_parts != nullptr ? __float_as_uint(w_bound) : *g.ep.planes.slot));
+  wait_vmcnt<0>();
+  static_assert(NW * 32 * kEpiPitch * (int)sizeof(float) <= RING * SLOT, "the waves' epilogue slices must fit into the operand LDS");
+  s16_finish<TM, TN, NW, EXTRA, true>(g, va, vb, acc, accx, asum, do_colsum, w_bound, m0 + wm * 64, n0 + wn * 64, lane, wave, lds);
+}
+
+template <bool EXTRA>
+void launch_s16_ks128(GemmArgs &g, const S16Operands &ops) {
+  g.tiles_m = (g.M + 127) / 128;
+  g.tiles_n = (g.N + 127) / 128;
+  constexpr int lds_bytes = 4 * 4 * 32 * 128 * 2;   // 128 KB
+  auto kern = gemm_s16_ks128<EXTRA>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    ASLP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    attr_set = true;
   }
-  if (g.wide_epilogue && gemm_epilogue_wide_ok(g)) {  // uniform
-    __builtin_amdgcn_s_barrier();
-    gemm_epilogue_wide<TM, TN>(g, acc, m0 + wm * WM, n0 + wn * WN, lane, lds + wave * 32 * kEpiPitch, xtra, want_extra);
-  } else {
-    gemm_epilogue<TM, TN>(g, acc, m0 + wm * WM, n0 + wn * WN, l31, lh, xtra, want_extra);
-  }
-  if (EXTRA && (g.ep.wmax_parts != nullptr || g.ep.cmax_parts != nullptr)) {
-    const float wmx = wave_max(xtra.wmax), cmx = wave_max(xtra.cmax);
-    const int idx = ((int)blockIdx.z * (int)gridDim.x + (int)blockIdx.x) * NW + wave;
-    if (lane == 0) {
-      if (g.ep.wmax_parts) g.ep.wmax_parts[idx] = wmx;
-      if (g.ep.cmax_parts) g.ep.cmax_parts[idx] = cmx;
-    }
-  }
+  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n, 1, g.pair ? 2 : 1), dim3(256), lds_bytes, cur_stream(), g, ops);
+  t_last_parts = EXTRA ? g.tiles_m * g.tiles_n * (g.pair ? 2 : 1) : 0;
 }
 
 template <int BM, int BN, int WGM, int WGN, int NS, bool A_KC, bool B_KC, int ABL = 0, bool EXTRA = false>
@@ -453,7 +661,7 @@ void launch_s16(GemmArgs &g, const S16Operands &ops) {
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n, 1, g.pair ? 2 : 1), dim3(64 * WGM * WGN), lds_bytes, cur_stream(), g, ops);
-  t_last_parts = EXTRA ? g.tiles_m * g.tiles_n * (g.pair ? 2 : 1) * WGM * WGN : 0;
+  t_last_parts = EXTRA ? g.tiles_m * g.tiles_n * (g.pair ? 2 : 1) : 0;
 }
 template <bool A_KC, bool B_KC>
 bool launch_s16_layout(GemmArgs &g, const S16Operands &ops, int cfg) {
@@ -461,6 +669,17 @@ bool launch_s16_layout(GemmArgs &g, const S16Operands &ops, int cfg) {
   // both operands reduction-contiguous: the transposing reads' address registers push the 128 x 128 tile past 512 registers (27-31 spilled),
   // and a kernel with a private segment pays ~1 ms per launch for it on this runtime.
   const bool extra = g.ep.planes_of != 0 || g.ep.wmax_parts != nullptr || g.ep.cmax_parts != nullptr || (g.pair && (g.ep1.planes_of != 0 || g.ep1.wmax_parts || g.ep1.cmax_parts));
+  if constexpr (!A_KC && !B_KC) {
+    // both operands reduction-major: the 128 x 128 kernel wherever its grid fills the chip about as well as the 64 x 128 one's --
+    // rounds of 256 workgroups, a 128 x 128 round costing ~1.6 of a 64 x 128 one (measured on 2048 x 2048 x 1024)
+    static const int ks128 = [] { const char *e = getenv("ASLP_GEMM_KS128"); return e ? atoi(e) : 1; }();   // A/B switch
+    const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * (g.pair ? 2 : 1), t64 = (long)((g.M + 63) / 64) * ((g.N + 127) / 128) * (g.pair ? 2 : 1);
+    const double cost128 = 1.6 * (double)((t128 + 255) / 256), cost64 = (double)((t64 + 255) / 256);
+    if (ks128 && (cfg == 0 || cfg == 328) && (cfg == 328 || (t128 >= 200 && cost128 <= cost64)) && (g.N % 8) == 0 && (g.M % 8) == 0) {
+      if (extra) launch_s16_ks128<true>(g, ops); else launch_s16_ks128<false>(g, ops);
+      return true;
+    }
+  }
   if (cfg == 0 || !(A_KC && B_KC) || extra)
     cfg = (!extra && A_KC && B_KC && (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * (g.pair ? 2 : 1) >= 224) ? 311 : 308;
   switch (cfg) {
@@ -483,6 +702,12 @@ bool gemm_split16_enabled() {
   return g_split16_override >= 0 ? g_split16_override != 0 : on;
 }
 
+int s16_plane_ld(int cols) {
+  // (measured: no effect on the layer products -- 31.5 / 31.6 / 31.8 us with 64 / 0 / 128 halves -- so off; ASLP_S16_LD_PAD=<halves> switches it on)
+  static const int pad = [] { const char *e = getenv("ASLP_S16_LD_PAD"); return e ? atoi(e) : 0; }();
+  const int ld = (cols + kS16Pad - 1) / kS16Pad * kS16Pad;
+  return (pad > 0 && (ld * 2) % 2048 == 0) ? ld + pad : ld;
+}
 bool gemm_split16_serves(int M, int N, int K) {
   return gemm_split16_enabled() && M >= 128 && N >= 128 && K >= 64 && !((M | N | K) & 3);
 }
@@ -514,7 +739,7 @@ PlaneSet::~PlaneSet() {
 }
 bool PlaneSet::Reserve(int rows, int cols) {
   if (rows <= 0 || cols <= 0) return false;
-  const int ld = (cols + kS16Pad - 1) / kS16Pad * kS16Pad, rows_p = (rows + kS16Pad - 1) / kS16Pad * kS16Pad;
+  const int ld = s16_plane_ld(cols), rows_p = (rows + kS16Pad - 1) / kS16Pad * kS16Pad;
   const size_t need = (size_t)rows_p * ld;
   if (!slot_) {
     void *p = nullptr;
@@ -585,6 +810,15 @@ bool gemm_split16_planes_launch(GemmArgs &g, bool a_kc, bool b_kc, const S16View
   auto fits = [&](const S16View &v, bool kc, int outer) { return v.hi && (kc ? (v.rows == outer && v.cols == g.K) : (v.rows == g.K && v.cols == outer)); };
   if (!fits(ops.a, a_kc, g.M) || !fits(ops.b, b_kc, g.N) || !fits(ops.a1, a_kc, g.M) || !fits(ops.b1, b_kc, g.N)) return false;
   t_last_parts = 0;
+  // planes / maxima of the output are written by the 16-byte epilogue only: where that does not apply the request is dropped (the
+  // caller sees aslp_gemm_last_parts() == 0 and converts for itself)
+  auto drop_extras = [](aslp_gemm_epilogue &ep) { ep.planes_of = 0; ep.wmax_parts = ep.cmax_parts = nullptr; ep.bound_w_parts = ep.bound_c_parts = nullptr; };
+  if (!(g.wide_epilogue && gemm_epilogue_wide_ok(g))) drop_extras(g.ep);
+  if (g.pair) {
+    GemmArgs g1 = g;
+    g1.C = g.C1; g1.ep = g.ep1;
+    if (!(g.wide_epilogue && gemm_epilogue_wide_ok(g1))) drop_extras(g.ep1);
+  }
   bool ok;
   if (a_kc && b_kc) ok = launch_s16_layout<true, true>(g, ops, cfg);
   else if (a_kc && !b_kc) ok = launch_s16_layout<true, false>(g, ops, cfg);
@@ -602,7 +836,7 @@ bool gemm_split16_launch(GemmArgs &g, bool a_kc, bool b_kc, int cfg, const S16Vi
   if (pa && pb) return gemm_split16_planes_launch(g, a_kc, b_kc, *pa, *pb, nullptr, nullptr, cfg);
   auto pad = [](int x) { return (x + kS16Pad - 1) / kS16Pad * kS16Pad; };
   const int a_rows = a_kc ? g.M : g.K, a_cols = a_kc ? g.K : g.M, b_rows = b_kc ? g.N : g.K, b_cols = b_kc ? g.K : g.N;
-  const size_t plane_a = pa ? 0 : (size_t)pad(a_rows) * pad(a_cols), plane_b = pb ? 0 : (size_t)pad(b_rows) * pad(b_cols);
+  const size_t plane_a = pa ? 0 : (size_t)pad(a_rows) * s16_plane_ld(a_cols), plane_b = pb ? 0 : (size_t)pad(b_rows) * s16_plane_ld(b_cols);
   const size_t head = 256 + sizeof(float) * 2 * kS16ConvParts;
   const size_t bytes = head + sizeof(h16) * 2 * (plane_a + plane_b);
   unsigned char *buf = static_cast<unsigned char *>(scratch(kScratchSplit16, bytes));
@@ -610,8 +844,8 @@ bool gemm_split16_launch(GemmArgs &g, bool a_kc, bool b_kc, int cfg, const S16Vi
   unsigned *slots = reinterpret_cast<unsigned *>(buf);
   float *part = reinterpret_cast<float *>(buf + 256);
   h16 *ah = reinterpret_cast<h16 *>(buf + head), *al = ah + plane_a, *bh = al + plane_a, *bl = bh + plane_b;
-  const S16View va = pa ? *pa : S16View{ah, al, pad(a_cols), a_rows, a_cols, slots};
-  const S16View vb = pb ? *pb : S16View{bh, bl, pad(b_cols), b_rows, b_cols, slots + 1};
+  const S16View va = pa ? *pa : S16View{ah, al, s16_plane_ld(a_cols), a_rows, a_cols, slots};
+  const S16View vb = pb ? *pb : S16View{bh, bl, s16_plane_ld(b_cols), b_rows, b_cols, slots + 1};
   const MaxJob ma = {g.A, a_rows, a_cols, g.lda, part}, mb = {g.B, b_rows, b_cols, g.ldb, part + kS16ConvParts};
   const ConvJob ca = {g.A, g.lda, va, part, kS16ConvParts}, cb = {g.B, g.ldb, vb, part + kS16ConvParts, kS16ConvParts};
   // (two matrices in one launch share the threads-per-row choice: the wider of the two)
@@ -629,8 +863,8 @@ bool gemm_split16_launch(GemmArgs &g, bool a_kc, bool b_kc, int cfg, const S16Vi
 
 int gemm_split16_last_parts() { return t_last_parts; }
 void gemm_split16_reset_last_parts() { t_last_parts = 0; }
-// most per-wave maxima a split-fp16 product of this output shape leaves (the caller's arrays must hold them)
-int gemm_split16_max_parts(int M, int N) { return ((M + 63) / 64) * ((N + 127) / 128) * 4; }
+// most per-workgroup maxima a split-fp16 product of this output shape leaves (the caller's arrays must hold them)
+int gemm_split16_max_parts(int M, int N) { return ((M + 63) / 64) * ((N + 127) / 128); }
 
 }  // namespace aslp
 

@@ -301,7 +301,7 @@ class AffineTransform : public UpdatableComponent {
  private:
   CuVectorD *stats_request_ = nullptr;
   PlaneHolder in_planes_, diff_planes_, w_planes_;
-  // weights' planes kept from step to step (Update): valid flag, the parameter epoch they belong to, per-wave maxima of |W| and
+  // weights' planes kept from step to step (Update): valid flag, the parameter epoch they belong to, per-workgroup maxima of |W| and
   // |W_corr| in two alternating arrays (one is read by the bound kernel while the epilogue fills the other)
   bool w_kept_ = false, maxima_valid_ = false, aliased_silently_ = false;
   long w_kept_param_epoch_ = -1, maxima_param_epoch_ = -1;
