@@ -8,6 +8,9 @@ layer) on a synthetic minibatch already resident in HBM.  With N > 1 every rank 
 replica on its own shard and the replicas are averaged BSP-style (aslp-parallel/bsp-worker.cc)
 with one RCCL all-reduce every `sync_period` frames (default 25600, as the reference).
 
+The layer products run on the fp16 matrix instruction with every fp32 operand carried as two fp16 pieces (csrc/gemm_split16.hip; results
+at least as close to float64 as the fp32 instruction's, `product_accuracy`); `fp32_instruction` is the same step with ASLP_GEMM_SPLIT_F16=0.
+
 Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement" for the roofline / cpu_baseline fields.
 """
 import argparse
@@ -23,6 +26,10 @@ sys.path.insert(0, ROOT)
 IN_DIM, HID, NH, OUT_DIM, MB = 440, 2048, 5, 3000, 1024
 FLOP_PER_FRAME = 141131776.0   # 2W fwd + 2(W-W1) bwd-data + 2W wgrad
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+F16_MFMA_PEAK_TFLOPS = 2516.0  # MI355X_MICROARCH.md: dense fp16 MFMA (v_mfma_f32_32x32x16_f16)
+SPLIT_PEAK_TF_EQUIV = F16_MFMA_PEAK_TFLOPS / 3.0   # three fp16 instructions per fp32-equivalent product: 839 TF-equivalent
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+ARITHMETIC = "fp32 operands as 2xfp16 pieces behind power-of-two scales, fp32 accumulate"
 
 
 def proto():
@@ -326,48 +333,157 @@ def cfg1_gpu_block(aslp, dev):
             "avg_xent_per_frame": (st["loss"] - st["entropy"]) / max(st["frames"], 1.0)}
 
 
-def cfg2_split_f16_block(aslp, dev, value_fp32):
-    """Extra key `cfg2_split_f16` (N = 1), NOT the headline: the same cfg2 step with the large products on the fp16 matrix instruction and every
-    fp32 operand carried as two fp16 pieces behind a power-of-two scale of its matrix (csrc/gemm_split16.hip, switched with aslp_gemm_split16;
-    default off).  Reported with its accuracy beside it -- error of one layer product against float64 for both instructions -- so that the
-    reader can judge whether it may become the default: operands and results are fp32, the 22-bit pieces multiply exactly, accumulation is
-    fp32, and the product is CLOSER to the float64 one than the fp32 instruction's."""
+def fp32_instruction_block(aslp, dev, steps, warmup):
+    """Extra key `fp32_instruction` (N = 1): the SAME cfg2 step (same net, options, data, step counts) with every product on the fp32 matrix
+    instruction v_mfma_f32_32x32x2_f32 (aslp_gemm_split16(0) = ASLP_GEMM_SPLIT_F16=0) -- the figure without an fp16 multiply anywhere."""
     import torch
-    net = aslp.Nnet.Init(proto(), seed=777)
-    net.SetTrainOptions(learn_rate=1e-5, momentum=0.9)
-    xent = aslp.Xent()
-    g = torch.Generator(device=dev)
-    g.manual_seed(1234)
-    x = torch.randn(MB, IN_DIM, device=dev, generator=g)
-    labels = torch.randint(0, OUT_DIM, (MB,), device=dev, generator=g, dtype=torch.int32)
-    out = {"workload": "cfg2 step as in `config`, products through aslp_gemm_split16(1)", "steps": 300, "warmup": 100}
+    aslp.lib.aslp_gemm_split16(0)
     try:
-        aslp.lib.aslp_gemm_split16(1)
-        for _ in range(100):
+        net = aslp.Nnet.Init(proto(), seed=777)
+        net.SetTrainOptions(learn_rate=1e-5, momentum=0.0)
+        xent = aslp.Xent()
+        g = torch.Generator(device=dev)
+        g.manual_seed(1234)
+        x = torch.randn(MB, IN_DIM, device=dev, generator=g)
+        labels = torch.randint(0, OUT_DIM, (MB,), device=dev, generator=g, dtype=torch.int32)
+        for _ in range(warmup):
             net.TrainStepXent(xent, x, labels)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(300):
+        for _ in range(steps):
             net.TrainStepXent(xent, x, labels)
         torch.cuda.synchronize()
-        el = (time.perf_counter() - t0) / 300
+        el = (time.perf_counter() - t0) / steps
         st = xent.GetStats()
-        out.update(ms_per_step=el * 1e3, frames_per_sec=MB / el, vs_fp32_instruction=MB / el / value_fp32,
-                   algorithmic_tflops=FLOP_PER_FRAME * MB / el / 1e12, avg_xent_per_frame=(st["loss"] - st["entropy"]) / max(st["frames"], 1.0))
-        # accuracy of one hidden-layer product (1024 x 2048 x 2048, NT) on either instruction against float64: max |error| / sum |a||b|
-        A = torch.randn(MB, HID, device=dev, generator=g)
-        B = torch.randn(HID, HID, device=dev, generator=g)
-        ref = A.double() @ B.double().t()
-        mag = A.double().abs() @ B.double().abs().t()
-        for name, on in (("fp32_instruction", 0), ("split_f16", 1)):
-            aslp.lib.aslp_gemm_split16(on)
-            C = torch.zeros(MB, HID, device=dev)
-            aslp.ops.sgemm(0, 1, 1.0, A, B, 0.0, C)
-            out["layer_product_max_err_over_sum_abs_" + name] = ((C.double() - ref).abs() / mag).max().item()
     finally:
         aslp.lib.aslp_gemm_split16(-1)
-    out["instruction"] = "v_mfma_f32_32x32x16_f16, 3 per 16-wide k step (hi hi, hi lo', lo' hi), fp32 accumulate; dense fp16 peak 2516 TFLOP/s"
-    return out
+    tf = FLOP_PER_FRAME * MB / el / 1e12
+    return {"value": MB / el, "unit": "frames/sec", "ms_per_step": el * 1e3, "steps": steps, "warmup": warmup, "algorithmic_tflops": tf,
+            "frac": tf / F32_MFMA_PEAK_TFLOPS, "peak": F32_MFMA_PEAK_TFLOPS,
+            "avg_xent_per_frame": (st["loss"] - st["entropy"]) / max(st["frames"], 1.0),
+            "instruction": "v_mfma_f32_32x32x2_f32 (aslp_gemm_split16(0) / ASLP_GEMM_SPLIT_F16=0)"}
+
+
+def product_accuracy_block(aslp, dev):
+    """Extra key `product_accuracy` (N = 1): for every product shape of BASELINE's configs -- K = 40, 256, 440, 512, 2048 (and the minibatch-long
+    reductions of the weight gradients), all three operand layouts -- max |C - C_float64| / sum |a||b| on either instruction.  The split path is the
+    default because it is at least as close to float64 as the fp32 instruction on every one of them (`split_le_fp32`)."""
+    import torch
+    g = torch.Generator(device=dev)
+    g.manual_seed(4242)
+    shapes = []
+    for K in (40, 256, 440, 512, 2048):
+        rows = 1920 if K in (40, 256, 512) else 1024      # cfg3 (T S = 1920) / cfg2 (minibatch 1024)
+        shapes += [("NT", 0, 1, rows, 2048, K), ("NN", 0, 0, rows, 2048, K), ("TN", 1, 0, 2048, 2048 if K == 2048 else 512, K)]
+    shapes += [("TN", 1, 0, 2048, 2048, 1024), ("TN", 1, 0, 3000, 2048, 1024), ("TN", 1, 0, 2048, 512, 1920), ("NT", 0, 1, 1024, 3000, 2048),
+               ("NN", 0, 0, 1024, 2048, 3000), ("NT", 0, 1, 256, 2048, 2048), ("TN", 1, 0, 2048, 2048, 256)]
+    rows_out, all_le = [], True
+    try:
+        for name, tA, tB, M, N, K in shapes:
+            A = torch.randn((K, M) if tA else (M, K), device=dev, generator=g)
+            B = torch.randn((N, K) if tB else (K, N), device=dev, generator=g) * 0.05
+            opA, opB = (A.t() if tA else A).double(), (B.t() if tB else B).double()
+            ref, mag = opA @ opB, opA.abs() @ opB.abs()
+            err = {}
+            served = False
+            for key, on in (("fp32", 0), ("split", 1)):
+                aslp.lib.aslp_gemm_split16(on)
+                C_ = torch.zeros(M, N, device=dev)
+                aslp.ops.sgemm(tA, tB, 1.0, A, B, 0.0, C_)
+                if on:
+                    served = aslp.lib.aslp_gemm_last_tile() in (308, 311, 328)
+                err[key] = ((C_.double() - ref).abs() / mag).max().item()
+            le = err["split"] <= err["fp32"] * 1.0000001
+            all_le = all_le and le
+            rows_out.append({"layout": name, "M": M, "N": N, "K": K, "split": err["split"], "fp32_instruction": err["fp32"],
+                             "on_fp16_instruction": bool(served), "split_le_fp32": bool(le)})
+    finally:
+        aslp.lib.aslp_gemm_split16(-1)
+    return {"metric": "max |C - C_f64| / sum |a||b|", "split_le_fp32": bool(all_le), "shapes": rows_out,
+            "note": "on_fp16_instruction false: the shape is below the split kernels' floor (K < 64 or an extent < 128) and runs the fp32 instruction either way"}
+
+
+def hbm_kernels_block(aslp, dev):
+    """Extra key `hbm_kernels` (N = 1): the bandwidth-bound kernels of the path, each timed alone with HIP events on the launch stream:
+    algorithmic bytes (every tensor read once and written once per pass, as the reference's own launches would move them) / time
+    = GB/s and the fraction of the 8 TB/s HBM peak.  cfg2 shapes (1024 x 2048, 1024 x 3000), the randomizer cache (32768 x 440), cfg5's
+    CompactFsmn / RowConvolution swaps."""
+    import numpy as np
+    import torch
+
+    def timed_us(fn, n=50, warm=5):
+        for _ in range(warm):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / n
+
+    out = {}
+
+    def rec(name, us, nbytes, what):
+        out[name] = {"us": us, "algorithmic_bytes": nbytes, "gb_per_s": nbytes / us / 1e3, "frac_of_hbm_peak": nbytes / us / 1e3 / HBM_PEAK_GBS, "what": what}
+
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    R, D = MB, HID
+    x = torch.randn(R, D, device=dev, generator=g)
+    dy = torch.randn(R, D, device=dev, generator=g) * 1e-2
+    o, xh, idf = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    scale, shift = torch.ones(D, device=dev), torch.zeros(D, device=dev)
+    mean, istd, dsc, dsh = (torch.zeros(D, device=dev) for _ in range(4))
+    rec("bn_forward", timed_us(lambda: aslp.ops.bn_forward(x, o, xh, scale, shift, mean, istd)), 12 * R * D,
+        "BatchNormalization forward 1024 x 2048 (statistics + normalise, two reads + one write per element in the reference's passes)")
+    rec("bn_backward", timed_us(lambda: aslp.ops.bn_backward(x, dy, xh, scale, mean, istd, dsc, dsh, 0.0, idf)), 20 * R * D,
+        "BatchNormalization backward 1024 x 2048")
+    acts = torch.randn(R, OUT_DIM, device=dev, generator=g)
+    post = torch.softmax(acts, 1).contiguous()
+    lab = torch.randint(0, OUT_DIM, (R,), device=dev, generator=g, dtype=torch.int32)
+    diff, fw, stats = torch.empty_like(acts), torch.ones(R, device=dev), torch.zeros(5, device=dev, dtype=torch.float64)
+    rec("xent", timed_us(lambda: aslp.ops.xent_eval(post, fw, diff, stats, labels=lab)), 8 * R * OUT_DIM, "Xent::Eval 1024 x 3000 (read posteriors, write diff)")
+    sm = torch.empty_like(acts)
+    rec("softmax", timed_us(lambda: aslp.ops.softmax(sm, acts)), 8 * R * OUT_DIM, "Softmax 1024 x 3000")
+    rows = 32768
+    feats = torch.randn(rows, 40, device=dev, generator=g)
+    spl = torch.empty(rows, 440, device=dev)
+    offs = torch.arange(-5, 6, device=dev, dtype=torch.int32)
+    rec("splice", timed_us(lambda: aslp.ops.splice(spl, feats, offs), 20), 4 * rows * (40 + 440), "Splice -5..5, 32768 x 40 -> 32768 x 440")
+    cache = torch.randn(rows, 440, device=dev, generator=g)
+    shuf = torch.empty_like(cache)
+    mask = torch.randperm(rows, device=dev, generator=g).to(torch.int32)
+    rec("randomize", timed_us(lambda: aslp.ops.randomize(shuf, cache, mask), 20), 8 * rows * 440, "MatrixRandomizer row gather, 32768 x 440")
+    sg, sy = torch.empty_like(x), torch.empty_like(x)
+    rec("sigmoid", timed_us(lambda: aslp.ops.sigmoid(sy, x)), 8 * R * D, "Sigmoid forward 1024 x 2048")
+    rec("diff_sigmoid", timed_us(lambda: aslp.ops.diff_sigmoid(sg, sy, dy)), 12 * R * D, "Sigmoid backward 1024 x 2048")
+    # cfg5 swaps through the engine (Propagate + Backpropagate + Update of one component)
+    T, Dm = 800, 512
+    net = aslp.Nnet.Init("<NnetProto>\n<CompactFsmn> <InputDim> 512 <OutputDim> 512 <PastContext> 30 <FutureContext> 30 <LearnRateCoef> 1.0\n</NnetProto>\n")
+    net.SetTrainOptions(learn_rate=1e-5)
+    xf = torch.randn(T, Dm, device=dev, generator=g)
+    odf = torch.randn(T, Dm, device=dev, generator=g) * 0.01
+
+    def fsmn():
+        net.Propagate(xf)
+        net.Backpropagate(odf, want_in_diff=True)
+    rec("compact_fsmn", timed_us(fsmn, 30), 4 * Dm * T * 7, "CompactFsmn 512, 30 + 30 taps, T = 800: forward + backward + update (2 + 5 tensor passes)")
+    S = 32
+    net2 = aslp.Nnet.Init("<NnetProto>\n<RowConvolution> <InputDim> 512 <OutputDim> 512 <FutureContext> 20\n</NnetProto>\n")
+    net2.SetTrainOptions(learn_rate=1e-5, momentum=0.9)
+    lens = np.random.default_rng(0).integers(T // 2, T + 1, S)
+    lens[0] = T
+    net2.SetSeqLengths(lens)
+    x2 = torch.randn(T * S, Dm, device=dev, generator=g)
+    od2 = torch.randn(T * S, Dm, device=dev, generator=g) * 0.01
+
+    def rowconv():
+        net2.Propagate(x2)
+        net2.Backpropagate(od2, want_in_diff=True)
+    rec("row_convolution", timed_us(rowconv, 10), 4 * Dm * T * S * 7, "RowConvolution 512, FutureContext 20, T = 800, S = 32: forward + backward + update (7 tensor passes)")
+    return {"peak_gb_per_s": HBM_PEAK_GBS, "timing": "HIP events (torch.cuda.Event on the launch stream), mean over the repetitions", "kernels": out}
 
 
 def e2e_tool_block(frames=1024000):
@@ -467,8 +583,155 @@ def cfg3_bsp_block(aslp, dev, native_parallel, comm, rank, world, sync_period):
     torch.cuda.synchronize()
     el = comm.MaxOverRanks(time.perf_counter() - t0)
     worker.close()
-    return {"workload": "cfg3 LC-BLSTM (4 x 512-cell, chunk 40 + 20, S = 32) + Xent, BSP every %d valid frames" % sync_period, "n_gpus": world,
-            "steps": steps, "ms_per_step": el * 1e3 / steps, "valid_frames_per_sec": world * steps * CHUNK * S / el, "scaling": "weak"}
+    out = {"workload": "cfg3 LC-BLSTM (4 x 512-cell, chunk 40 + 20, S = 32) + Xent, BSP every %d valid frames" % sync_period, "n_gpus": world,
+           "steps": steps, "ms_per_step": el * 1e3 / steps, "valid_frames_per_sec": world * steps * CHUNK * S / el, "scaling": "weak"}
+    out.update(_comm_facts(comm))
+    return out
+
+
+def _comm_facts(comm):
+    """what the transport itself says about the group: proves which transport carried the run and that every rank joined it"""
+    t = comm.Transport()
+    return {"transport": t, "ranks_seen": comm.RanksSeen(), "ranks_seen_source": "ncclCommCount" if t == "rccl" else "ranks that joined the shared-memory segment",
+            "scaling_measured": t == "rccl",
+            "note": None if t == "rccl" else "ranks share GPUs and stage tensors through host shared memory: a functional run of the N > 1 flow, NOT a scaling measurement"}
+
+
+def cfg4_bsp_block(aslp, dev, native_parallel, comm, rank, world, sync_period):
+    """N > 1 only (extra key `cfg4_bsp`), BASELINE.json configs[3]: the cfg1 net (5 x 2048 sigmoid DNN, no BatchNormalization), minibatch 256 per
+    GPU, learn rate 0.008, every rank on its own shard, BSP model averaging every `sync_period` frames (run_parallel.sh;
+    aslp-nnet-train-frame-worker.cc:109-188; bsp-worker.cc:33-65).  Whole-job frames/s (barrier + synchronise on both sides, max over ranks) and
+    the time the ranks spend inside Synchronize."""
+    import torch
+    mb = 256
+    lines, d = ["<NnetProto>"], IN_DIM
+    for _ in range(NH):
+        lines.append("<AffineTransform> <InputDim> %d <OutputDim> %d <BiasMean> -2.0 <BiasRange> 4.0 <ParamStddev> 0.04" % (d, HID))
+        lines.append("<Sigmoid> <InputDim> %d <OutputDim> %d" % (HID, HID))
+        d = HID
+    lines += ["<AffineTransform> <InputDim> %d <OutputDim> %d <BiasMean> 0.0 <BiasRange> 0.0 <ParamStddev> 0.04" % (d, OUT_DIM),
+              "<Softmax> <InputDim> %d <OutputDim> %d" % (OUT_DIM, OUT_DIM), "</NnetProto>"]
+    net = aslp.Nnet.Init("\n".join(lines) + "\n", seed=777)
+    net.SetTrainOptions(learn_rate=0.008, momentum=0.0)
+    xent = aslp.Xent()
+    g = torch.Generator(device=dev)
+    g.manual_seed(4321 + rank)
+    x = torch.randn(mb, IN_DIM, device=dev, generator=g)
+    labels = torch.randint(0, OUT_DIM, (mb,), device=dev, generator=g, dtype=torch.int32)
+    worker = native_parallel.BspWorker(comm)
+    worker.InitParam(net)
+    steps, warm = 400, 100
+    since, sync_s, syncs = 0, 0.0, 0
+
+    def step(timed):
+        nonlocal since, sync_s, syncs
+        net.TrainStepXent(xent, x, labels)
+        since += mb
+        if since >= sync_period:
+            if timed:
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+            worker.Synchronize(since)
+            if timed:
+                torch.cuda.synchronize()
+                sync_s += time.perf_counter() - t
+                syncs += 1
+            since = 0
+
+    for _ in range(warm):
+        step(False)
+    worker.Synchronize(max(since, 1))
+    since = 0
+    comm.Barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(True)
+    torch.cuda.synchronize()
+    comm.Barrier()
+    torch.cuda.synchronize()
+    el = comm.MaxOverRanks(time.perf_counter() - t0)
+    sync_ms = comm.MaxOverRanks(sync_s * 1e3 / max(syncs, 1))
+    worker.close()
+    out = {"workload": "cfg4: 5x2048 sigmoid DNN (no BatchNorm), minibatch 256/GPU, lr 0.008, BSP every %d frames, distinct shards" % sync_period,
+           "n_gpus": world, "steps": steps, "ms_per_step": el * 1e3 / steps, "frames_per_sec": world * steps * mb / el, "syncs_timed": syncs,
+           "sync_ms": sync_ms, "scaling": "weak"}
+    out.update(_comm_facts(comm))
+    return out
+
+
+def cfg5_easgd_block(aslp, dev, native_parallel, comm, rank, world, sync_period):
+    """N > 1 only (extra key `cfg5_easgd`), BASELINE.json configs[4]: the cfg3 LC-BLSTM on whole utterances with Warp-CTC, rank 0 the EASGD
+    parameter server (alpha = 0.5: easgd-server.cc:37-86), ranks 1 .. N-1 the workers that exchange their model with it every `sync_period`
+    valid frames (easgd-worker.cc:37-67).  Whole-job valid frames/s of the N - 1 workers; the server's time is the workers' (it serves until
+    the last one has stopped)."""
+    import numpy as np
+    import torch
+    S, A = 32, 128
+    lines, d = ["<NnetProto>"], 40
+    for _ in range(4):
+        lines.append("<BLstmProjectedStreamsLC> <InputDim> %d <OutputDim> 512 <CellDim> 512 <ParamScale> 0.02 <ClipGradient> 5.0" % d)
+        d = 512
+    lines += ["<AffineTransform> <InputDim> 512 <OutputDim> %d <BiasMean> 0.0 <BiasRange> 0.0 <ParamStddev> 0.04" % A, "</NnetProto>"]
+    net = aslp.Nnet.Init("\n".join(lines) + "\n", seed=777)
+    rng = np.random.default_rng(99 + rank)
+    lens = rng.integers(200, 801, S).astype(np.int32)
+    lens[0] = 800
+    Tm = int(lens.max())
+    lab = [[int(v) for v in rng.integers(1, A, max(1, int(t) // 4))] for t in lens]
+    net.SetTrainOptions(learn_rate=1e-5 / float(lens.sum()), momentum=0.9)
+    steps, warm = 6, 1
+    comm.Barrier()
+    if rank == 0:
+        class _Ptr:   # a raw device pointer as a torch tensor (the server works on the model's own tensors)
+            def __init__(self, ptr, n):
+                self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (int(ptr), False), "version": 2, "strides": None}
+        params = [torch.as_tensor(_Ptr(p_, n_), device=dev) for p_, n_ in net.GetGpuParams(writers_announce=True) if n_ > 0]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        native_parallel.ServerRun(comm, "easgd", params, p0=0.5)
+        torch.cuda.synchronize()
+        el_local, frames_local, sync_ms_local = time.perf_counter() - t0, 0.0, 0.0
+    else:
+        ctc = aslp.WarpCtc()
+        g = torch.Generator(device=dev)
+        g.manual_seed(99 + rank)
+        xc = torch.randn(Tm * S, 40, device=dev, generator=g)
+        worker = native_parallel.EasgdWorker(comm, 0.5)
+        worker.InitParam(net)
+        since, sync_s, syncs = 0, 0.0, 0
+        for _ in range(warm):
+            net.ResetLstmStreams([1] * S)
+            net.TrainStepWarpCtc(ctc, xc, lens, lab)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            net.ResetLstmStreams([1] * S)
+            net.TrainStepWarpCtc(ctc, xc, lens, lab)
+            since += int(lens.sum())
+            if since >= sync_period:
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                worker.Synchronize(since)
+                torch.cuda.synchronize()
+                sync_s += time.perf_counter() - t
+                syncs += 1
+                since = 0
+        torch.cuda.synchronize()
+        el_local = time.perf_counter() - t0
+        worker.Stop()
+        worker.close()
+        frames_local, sync_ms_local = float(steps * int(lens.sum())), sync_s * 1e3 / max(syncs, 1)
+    comm.Barrier()
+    el = comm.MaxOverRanks(el_local if rank != 0 else 0.0)
+    frames = sum(comm.AllReduceHostDouble([frames_local]))
+    sync_ms = comm.MaxOverRanks(sync_ms_local)
+    out = {"workload": "cfg5: 4 x BLstmProjectedStreamsLC (C 512) + Warp-CTC on whole utterances (S = 32, T <= 800), EASGD alpha 0.5, server on rank 0, "
+                       "%d worker(s), exchange every %d valid frames" % (world - 1, sync_period),
+           "n_gpus": world, "workers": world - 1, "steps_per_worker": steps, "valid_frames_per_sec": frames / el if el > 0 else 0.0,
+           "ms_per_step": el * 1e3 / steps, "sync_ms": sync_ms, "scaling": "weak"}
+    out.update(_comm_facts(comm))
+    return out
 
 
 def launch_ranks(args):
@@ -532,7 +795,7 @@ def main():
     ap.add_argument("--no-update-overlap", action="store_true",
                     help="keep the weight-gradient GEMMs on the main stream (per-kernel profiles: every kernel alone on the chip)")
     ap.add_argument("--no-cfg3", action="store_true", help="skip the LC-BLSTM (BASELINE cfg3) block of the JSON line")
-    ap.add_argument("--cfg3-bsp-timeout", type=int, default=240, help="N > 1: seconds the extra cfg3_bsp block may take before it is dropped")
+    ap.add_argument("--cfg3-bsp-timeout", type=int, default=420, help="N > 1: seconds the extra cfg4_bsp / cfg3_bsp / cfg5_easgd blocks may take before they are dropped")
     ap.add_argument("--launch-timeout", type=int, default=3000, help="N > 1 from a bare shell: seconds the parent waits for rank 0")
     ap.add_argument("--no-e2e-tool", action="store_true", help="skip the end-to-end command-line block of the JSON line (extra key e2e_tool)")
     ap.add_argument("--e2e-frames", type=int, default=1024000)
@@ -682,14 +945,14 @@ def main():
         out = {
             "metric": "frames/sec (aslp-nnet-train)", "value": value, "unit": "frames/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "prewarm_steps": prewarm, "cold_value": cold_value, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "arithmetic": ARITHMETIC, "data": "synthetic",
             "config": {"workload": "cfg2: 5x2048 sigmoid DNN + BatchNorm, 440 in (40 fbank x 11 splice), 3000 pdfs, minibatch 1024/GPU, "
                                    "Propagate + Xent + Backpropagate + SGD update",
                        "global_batch": world * MB, "parallelism": "bsp-dp%d" % world,
                        "sync": ("native BspWorker on ShmComm (ranks sharing GPUs, tensors staged through shared memory: a functional run, not a scaling measurement)"
                                 if os.environ.get("ASLP_COMM_TRANSPORT") == "shm" else
                                 "native BspWorker on RcclComm (libaslp_parallel.so: ncclAllReduce over the parameter tensors in HBM)") if comm is not None else None,
-                       "sync_period_frames": args.sync_period,
+                       "sync_period_frames": args.sync_period, "comm": _comm_facts(comm) if comm is not None else None,
                        "learn_rate": 1e-5, "avg_xent_per_frame": (st["loss"] - st["entropy"]) / max(st["frames"], 1.0)},
         }
         timed = {k: v for k, v in gemm.items() if v["tflops"]}
@@ -698,7 +961,7 @@ def main():
             d = timed[dom]
             traffic, traffic_src = None, None
             try:  # per-launch L2<->fabric bytes of this kernel from the committed PMC passes of the same command
-                with open(os.path.join(ROOT, "profiles", "dnn_cfg2_pmc.json")) as f:
+                with open(os.path.join(ROOT, "profiles", "dnn_cfg2_pmc.json")) as f:   # (refreshed per round; the entry names the tile it was taken with)
                     pmc = json.load(f)[dom]
                 traffic = (2.0 * pmc["fetch_kb"] + pmc["write_kb"]) * 1024.0
                 traffic_src = "NOT measured in this run: committed PMC pass profiles/dnn_cfg2_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction)"
@@ -709,15 +972,22 @@ def main():
             tile_name = tile_buf.value.decode()
             if traffic is not None and pmc.get("cfg") not in (None, tile_cfg):
                 traffic, traffic_src = None, "committed PMC pass was taken with tile cfg %s, this run used %d: omitted" % (pmc.get("cfg"), tile_cfg)
-            out["roofline"] = {"bound": "mfma", "kernel": "aslp_sgemm<%s> (%s; cfg %d)" % (dom, tile_name, tile_cfg), "achieved": d["tflops"], "peak": F32_MFMA_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": d["tflops"] / F32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
-                               "traffic_source": traffic_src,
+            split = tile_cfg in (308, 311, 328)   # the product ran on the fp16 instruction (three per fp32-equivalent multiply)
+            peak = SPLIT_PEAK_TF_EQUIV if split else F32_MFMA_PEAK_TFLOPS
+            out["roofline"] = {"bound": "mfma", "kernel": "aslp_sgemm<%s> (%s; cfg %d)" % (dom, tile_name, tile_cfg), "achieved": d["tflops"], "peak": peak,
+                               "unit": "TFLOP/s (fp32-equivalent)" if split else "TFLOP/s", "frac": d["tflops"] / peak,
+                               "peak_note": ("dense fp16 MFMA peak %.0f TFLOP/s / 3 instructions per fp32-equivalent product" % F16_MFMA_PEAK_TFLOPS) if split
+                                            else "fp32 MFMA peak",
+                               "frac_of_fp32_mfma_peak": d["tflops"] / F32_MFMA_PEAK_TFLOPS,
+                               "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                                "flop_per_launch": d["flop_per_launch"], "avg_launch_us": d["avg_us"], "launches": d["launches"],
                                "timing": "HIP events on the launch stream, second pass over the same K steps"}
             tot_fl = sum(v["flop_per_launch"] * v["launches"] for v in timed.values())
             tot_ms = sum(v["avg_us"] * v["launches"] for v in timed.values()) / 1e3
+            step_tf = FLOP_PER_FRAME * args.steps * MB / elapsed / 1e12
             out["gemm_all"] = {"variants": gemm, "tflops": tot_fl / tot_ms / 1e9, "frac_of_step_time": tot_ms / (elapsed * 1e3),
-                               "algorithmic_tflops_whole_step": FLOP_PER_FRAME * args.steps * MB / elapsed / 1e12}
+                               "algorithmic_tflops_whole_step": step_tf, "whole_step_frac_of_split_peak": step_tf / SPLIT_PEAK_TF_EQUIV,
+                               "whole_step_frac_of_fp32_mfma_peak": step_tf / F32_MFMA_PEAK_TFLOPS}
         else:
             out["roofline"] = {"bound": "mfma", "achieved": FLOP_PER_FRAME * args.steps * MB / elapsed / 1e12, "peak": F32_MFMA_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": FLOP_PER_FRAME * args.steps * MB / elapsed / 1e12 / F32_MFMA_PEAK_TFLOPS,
@@ -730,7 +1000,14 @@ def main():
             out["cfg3"] = cfg3_block(aslp, dev)
             out["recurrent_layers"] = recurrent_family_block(aslp, dev)
             out["cfg1_gpu"] = cfg1_gpu_block(aslp, dev)
-            out["cfg2_split_f16"] = cfg2_split_f16_block(aslp, dev, value)
+        if world == 1:
+            net = None
+            torch.cuda.empty_cache()
+            # the same step on the fp32 matrix instruction, the accuracy of every product shape on both instructions, the bandwidth-bound kernels
+            out["fp32_instruction"] = fp32_instruction_block(aslp, dev, min(args.steps, 200), min(args.warmup, 50))
+            out["fp32_instruction"]["vs_default"] = out["fp32_instruction"]["value"] / value
+            out["product_accuracy"] = product_accuracy_block(aslp, dev)
+            out["hbm_kernels"] = hbm_kernels_block(aslp, dev)
         if world == 1 and not args.no_e2e_tool:
             out["e2e_tool"] = e2e_tool_block(args.e2e_frames)
             if "frames_per_sec" in out["e2e_tool"]:
@@ -757,21 +1034,29 @@ def main():
             if not printed.acquire(blocking=False):
                 return
             if rank == 0:
-                out["cfg3_bsp"] = {"error": "did not finish within %d s; dropped" % args.cfg3_bsp_timeout}
+                out["multi_gpu_blocks"] = {"error": "cfg4_bsp / cfg3_bsp / cfg5_easgd did not finish within %d s; dropped" % args.cfg3_bsp_timeout}
                 print(json.dumps(out), flush=True)
             os._exit(3)   # the headline is on stdout, but the run did not complete: non-zero
 
         dog = threading.Timer(args.cfg3_bsp_timeout, bail)
         dog.daemon = True
         dog.start()
-        try:
-            blk = cfg3_bsp_block(aslp, dev, native_parallel, comm, rank, world, args.sync_period)
-        except Exception as e:   # noqa: BLE001 -- reported in the line, never silent
-            blk = {"error": "%s: %s" % (type(e).__name__, e)}
+        blk = {}
+        extra = {}
+        for key, fn in (("cfg4_bsp", cfg4_bsp_block), ("cfg3_bsp", cfg3_bsp_block), ("cfg5_easgd", cfg5_easgd_block)):
+            try:
+                b_ = fn(aslp, dev, native_parallel, comm, rank, world, args.sync_period)
+            except Exception as e:   # noqa: BLE001 -- reported in the line, never silent
+                b_ = {"error": "%s: %s" % (type(e).__name__, e)}
+            extra[key] = b_
+            if "error" in b_:
+                blk = b_         # (the other ranks may be stuck in a collective: stop here, the watchdog ends this rank too)
+                break
+            torch.cuda.empty_cache()
         if "error" not in blk:
-            dog.cancel()         # (after an error the other ranks may be stuck: let the watchdog end this rank too)
+            dog.cancel()
         if rank == 0:
-            out["cfg3_bsp"] = blk
+            out.update(extra)
         if "error" in blk:
             if printed.acquire(blocking=False):
                 if rank == 0:

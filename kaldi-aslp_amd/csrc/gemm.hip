@@ -765,7 +765,7 @@ static int sgemm_impl(int transA, int transB, int M, int N, int K, float alpha, 
   if (gemm_split16_enabled() && !g_force_tile && gemm_split16_launch(g, !transA, transB != 0, s16_cfg, pa, pb)) {   // (a forced tile asks for an fp32 kernel by name)
     g.ep.colstats = nullptr;   // formed in its epilogue, like the column sums of a transposed A
     g.ep.colsum = nullptr;
-    t_last_cfg = 311;
+    t_last_cfg = gemm_split16_last_tile();
   } else if (!transA && transB) launch_aligned<true, true>(g);
   else if (!transA && !transB) launch_aligned<true, false>(g);
   else if (transA && !transB) launch_aligned<false, false>(g);
@@ -936,6 +936,9 @@ int aslp_gemm_profile_tile(int variant, char *buf, int buflen) {
     case 211: d = "gemm_f32_glds 128x128x32, 8 waves, LDS-DMA, 3 stages"; break;
     case 212: d = "gemm_f32_glds 64x128x32, 8 waves, LDS-DMA, 3 stages"; break;
     case 213: d = "gemm_f32_glds 64x128x32, 8 waves, LDS-DMA, 4 stages"; break;
+    case 308: d = "gemm_s16_glds 64x128x64 halves, 4 waves, v_mfma_f32_32x32x16_f16 x3 on two-piece fp32 operands, LDS-DMA, 3 stages"; break;
+    case 311: d = "gemm_s16_glds 128x128x64 halves, 4 waves, v_mfma_f32_32x32x16_f16 x3 on two-piece fp32 operands, LDS-DMA, 2 stages"; break;
+    case 328: d = "gemm_s16_ks128 128x128x32 halves, 4 waves, v_mfma_f32_32x32x16_f16 x3 on two-piece fp32 operands, transposing LDS reads, ring of 4"; break;
     default: d = "gemm_f32_mfma (devtools tile)"; break;
   }
   if (buf && buflen > 0) { std::strncpy(buf, d, buflen - 1); buf[buflen - 1] = 0; }

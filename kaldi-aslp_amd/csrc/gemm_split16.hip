@@ -33,6 +33,7 @@
 namespace aslp {
 namespace {
 
+thread_local int t_last_cfg_s16 = 0;   // tile the calling thread's latest split-fp16 product ran on: 311 = 128x128, 308 = 64x128, 328 = 128x128 both operands reduction-major
 thread_local int t_last_parts = 0;   // per-wave maxima the calling thread's latest product left (aslp_gemm_last_parts)
 constexpr int BKH = 64;       // halves per K tile
 constexpr int KH = BKH / 16;  // instruction k steps per tile
@@ -677,6 +678,7 @@ bool launch_s16_layout(GemmArgs &g, const S16Operands &ops, int cfg) {
     const double cost128 = 1.6 * (double)((t128 + 255) / 256), cost64 = (double)((t64 + 255) / 256);
     if (ks128 && (cfg == 0 || cfg == 328) && (cfg == 328 || (t128 >= 200 && cost128 <= cost64)) && (g.N % 8) == 0 && (g.M % 8) == 0) {
       if (extra) launch_s16_ks128<true>(g, ops); else launch_s16_ks128<false>(g, ops);
+      t_last_cfg_s16 = 328;
       return true;
     }
   }
@@ -690,6 +692,7 @@ bool launch_s16_layout(GemmArgs &g, const S16Operands &ops, int cfg) {
       break;
     default: return false;
   }
+  t_last_cfg_s16 = cfg;
   return true;
 }
 
@@ -862,6 +865,7 @@ bool gemm_split16_launch(GemmArgs &g, bool a_kc, bool b_kc, int cfg, const S16Vi
 }
 
 int gemm_split16_last_parts() { return t_last_parts; }
+int gemm_split16_last_tile() { return t_last_cfg_s16; }
 void gemm_split16_reset_last_parts() { t_last_parts = 0; }
 // most per-workgroup maxima a split-fp16 product of this output shape leaves (the caller's arrays must hold them)
 int gemm_split16_max_parts(int M, int N) { return ((M + 63) / 64) * ((N + 127) / 128); }

@@ -134,6 +134,7 @@ bool gemm_split16_enabled();
 // would aslp_sgemm_ex carry an M x N x K product on the fp16 instruction (switch on, shape served)?
 bool gemm_split16_serves(int M, int N, int K);
 int gemm_split16_last_parts();
+int gemm_split16_last_tile();   // 311 / 308 / 328 (gemm_split16.hip)
 void gemm_split16_reset_last_parts();
 int gemm_split16_max_parts(int M, int N);
 

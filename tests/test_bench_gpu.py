@@ -24,6 +24,12 @@ def check_line(out, n):
     assert d["value"] == pytest.approx(d["config"]["global_batch"] * 1000.0 / d["ms_per_step"], rel=1e-3)   # whole-job frames over the max-over-ranks time
     bsp = d.get("cfg3_bsp")
     assert bsp and bsp["n_gpus"] == n and bsp["valid_frames_per_sec"] > 0
+    # BASELINE's own multi-GPU configurations: cfg4 (cfg1 net, minibatch 256/GPU, BSP) and cfg5 (LC-BLSTM + Warp-CTC, EASGD server + workers)
+    c4, c5 = d.get("cfg4_bsp"), d.get("cfg5_easgd")
+    assert c4 and "error" not in c4 and c4["n_gpus"] == n and c4["frames_per_sec"] > 0 and c4["sync_ms"] > 0, c4
+    assert c5 and "error" not in c5 and c5["workers"] == n - 1 and c5["valid_frames_per_sec"] > 0, c5
+    for blk in (bsp, c4, c5, d["config"]["comm"]):
+        assert blk["transport"] == "shm" and blk["ranks_seen"] == n and blk["scaling_measured"] is False   # says so when nothing was scaled
     return d
 
 

@@ -7,6 +7,7 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+SPLIT_TILES = (308, 311, 328)   # gemm_s16_glds 64x128 / 128x128, gemm_s16_ks128 (csrc/gemm_split16.hip)
 
 
 @pytest.fixture(autouse=True)
@@ -22,7 +23,7 @@ def products(aslp, tA, tB, A, B, alpha=1.0, beta=0.0, C0=None, ep=None):
         C = C0.clone() if C0 is not None else torch.zeros((A.shape[1] if tA else A.shape[0]), (B.shape[0] if tB else B.shape[1]), device=A.device)
         aslp.ops.sgemm(tA, tB, alpha, A, B, beta, C, ep(on) if ep else None)
         if on:
-            assert aslp.lib.aslp_gemm_last_tile() == 311      # the split kernel really ran
+            assert aslp.lib.aslp_gemm_last_tile() in SPLIT_TILES      # a split kernel really ran
         out.append(C)
     aslp.lib.aslp_gemm_split16(-1)
     return out
@@ -65,7 +66,7 @@ def test_one_pair_of_planes_serves_every_product(aslp, dev, M, N, K):
                                         (1, 1, W, pW, dy, pdy, (K, M))):
         C1 = torch.zeros(shape, device=dev)
         aslp.ops.sgemm_planes(tA, tB, 1.0, A, pa, B, pb, 0.0, C1)
-        assert aslp.lib.aslp_gemm_last_tile() == 311 or min(shape) < 128
+        assert aslp.lib.aslp_gemm_last_tile() in SPLIT_TILES or min(shape) < 128
         C2 = torch.zeros(shape, device=dev)
         aslp.ops.sgemm(tA, tB, 1.0, A, B, 0.0, C2)
         assert torch.equal(C1, C2), (tA, tB)
