@@ -831,10 +831,19 @@ int aslp_sgemm_planes_ex(int transA, int transB, int M, int N, int K, float alph
 int aslp_sgemm_pair_ex(int transA, int transB, int M, int N, int K, float alpha, const float *A0, const float *A1, int lda, const float *B0,
                        const float *B1, int ldb, float beta, float *C0, float *C1, int ldc, const aslp_gemm_epilogue *ep0,
                        const aslp_gemm_epilogue *ep1) {
+  return aslp::sgemm_pair_views(transA, transB, M, N, K, alpha, A0, A1, lda, B0, B1, ldb, beta, C0, C1, ldc, ep0, ep1, nullptr, nullptr, nullptr, nullptr);
+}
+}  // extern "C"
+
+// the pair with prepared planes (windows) of all four operands, or of none (csrc/split16.h)
+int aslp::sgemm_pair_views(int transA, int transB, int M, int N, int K, float alpha, const float *A0, const float *A1, int lda, const float *B0,
+                           const float *B1, int ldb, float beta, float *C0, float *C1, int ldc, const aslp_gemm_epilogue *ep0,
+                           const aslp_gemm_epilogue *ep1, const S16View *va0, const S16View *va1, const S16View *vb0, const S16View *vb1) {
   static const int enabled = [] { const char *e = getenv("ASLP_GEMM_PAIR"); return e ? atoi(e) : 1; }();
+  const bool views = va0 && va1 && vb0 && vb1;
   auto two = [&]() {
-    const int rc = aslp_sgemm_ex(transA, transB, M, N, K, alpha, A0, lda, B0, ldb, beta, C0, ldc, ep0);
-    return rc ? rc : aslp_sgemm_ex(transA, transB, M, N, K, alpha, A1, lda, B1, ldb, beta, C1, ldc, ep1);
+    const int rc = sgemm_impl(transA, transB, M, N, K, alpha, A0, lda, B0, ldb, beta, C0, ldc, ep0, views ? va0 : nullptr, views ? vb0 : nullptr);
+    return rc ? rc : sgemm_impl(transA, transB, M, N, K, alpha, A1, lda, B1, ldb, beta, C1, ldc, ep1, views ? va1 : nullptr, views ? vb1 : nullptr);
   };
   if (M <= 0 || N <= 0 || K <= 0 || !A0 || !A1 || !B0 || !B1 || !C0 || !C1 || ldc < N) return two();  // argument errors are reported there
   if (lda < (transA ? M : K) || ldb < (transB ? K : N)) return two();
@@ -852,6 +861,18 @@ int aslp_sgemm_pair_ex(int transA, int transB, int M, int N, int K, float alpha,
   g.a_vec = aligned16(A0) && aligned16(A1) && lda % 4 == 0;
   g.b_vec = aligned16(B0) && aligned16(B1) && ldb % 4 == 0;
   if (!g.a_vec || !g.b_vec) return two();
+  gemm_split16_reset_last_parts();
+  if (views && gemm_split16_serves(M, N, K) && !g_force_tile && K % 64 == 0 &&
+      gemm_split16_planes_launch(g, !transA, transB != 0, *va0, *vb0, va1, vb1, 0)) {
+    t_last_cfg = gemm_split16_last_tile();
+    check_launch("aslp_sgemm_pair (split-fp16)");
+    const int slot = (!transA && transB) ? 0 : (!transA && !transB) ? 1 : (transA && !transB) ? 2 : 3;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof[slot].launches += 2;
+    g_prof[slot].flops += 4.0 * (double)M * (double)N * (double)K;
+    g_prof[slot].cfg_flops[t_last_cfg] += 4.0 * (double)M * (double)N * (double)K;
+    return 0;
+  }
   if (!transA && transB) launch_aligned<true, true>(g);
   else if (!transA && !transB) launch_aligned<true, false>(g);
   else if (transA && !transB) launch_aligned<false, false>(g);
@@ -868,6 +889,7 @@ int aslp_sgemm_pair_ex(int transA, int transB, int M, int N, int K, float alpha,
   return 0;
 }
 
+extern "C" {
 int aslp_sgemm(int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda, const float *B, int ldb, float beta,
                float *C, int ldc) {
   return aslp_sgemm_ex(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, nullptr);

@@ -381,6 +381,10 @@ bool launch_split(GemmArgs &g, int cfg, int split) {
   return true;
 }
 
+void gemm_splitk_reduce(const float *part, int split, long stride, const GemmArgs &r) {
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for(stride), r.pair ? 2 : 1), dim3(kBlock), 0, cur_stream(), part, split, stride, r);
+}
+
 bool gemm_glds_launch(GemmArgs &g, bool a_kc, bool b_kc, int cfg, int *cfg_used) {
   *cfg_used = cfg;
   // (a column-sum request on a non-transposed A is the caller's job: see aslp_sgemm_ex)

@@ -57,8 +57,10 @@ __device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_byte_addr)
 // nothing to zero first; the conversion reduces the partials.  Rows are dealt to the workgroups in contiguous chunks; a row is
 // covered by tw = 2^tw_log2 threads with 16 bytes each per pass (no division anywhere, every load of a thread independent).
 struct MaxJob { const float *p; int rows, cols, ld; float *part; };
-__global__ void __launch_bounds__(256) s16_absmax_kernel(MaxJob a, MaxJob b, int tw_log2) {
-  const MaxJob j = blockIdx.y ? b : a;
+constexpr int kS16MaxJobs = 8;     // matrices per maximum / conversion launch (blockIdx.y)
+struct MaxJobs { MaxJob j[kS16MaxJobs]; };
+__global__ void __launch_bounds__(256) s16_absmax_kernel(MaxJobs jobs, int tw_log2) {
+  const MaxJob j = jobs.j[blockIdx.y];
   const int c4 = j.cols >> 2, tw = 1 << tw_log2, rpw = 256 >> tw_log2;
   const int tr = threadIdx.x >> tw_log2, tc = threadIdx.x & (tw - 1);
   const int per = (j.rows + gridDim.x - 1) / gridDim.x, r0 = blockIdx.x * per, r1 = min(j.rows, r0 + per);
@@ -103,8 +105,9 @@ __global__ void __launch_bounds__(256) s16_weight_bound_kernel(BoundJob j) {
 // ---- fp32 matrix -> planes in the matrix' own layout (padding written as zeros), up to two matrices per launch (blockIdx.y) --------
 // Same dealing of rows; a thread converts 8 consecutive columns per pass (two 16-byte loads, one 16-byte store per plane).
 struct ConvJob { const float *src; int ld_src; S16View pl; const float *part; int nparts; };
-__global__ void __launch_bounds__(256) split16_convert_kernel(ConvJob a, ConvJob b, int tw_log2) {
-  const ConvJob j = blockIdx.y ? b : a;
+struct ConvJobs { ConvJob j[kS16MaxJobs]; };
+__global__ void __launch_bounds__(256) split16_convert_kernel(ConvJobs jobs, int tw_log2) {
+  const ConvJob j = jobs.j[blockIdx.y];
   const unsigned mbits = __float_as_uint(reduce_parts(j.part, j.nparts));
   if (blockIdx.x == 0 && threadIdx.x == 0) *j.pl.slot = mbits;   // for the products (launched behind this kernel)
   const float s = ldexpf(1.f, s16_exponent(mbits));
@@ -271,7 +274,14 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_s16_glds(GemmArgs g, S16O
   const int m0 = tm * BM, n0 = tn * BN;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave / WGN, wn = wave % WGN, l31 = lane & 31, lh = lane >> 5;
-  const int ktiles = ops.kp / BKH;
+  // split-K (as gemm_glds.hip): this workgroup reduces over K chunk blockIdx.y only and leaves a plain, unscaled-back partial product
+  // in C + chunk * split_stride (the host has emptied the epilogue; splitk_reduce_kernel adds the chunks in order and applies it)
+  int k_first = 0, ktiles = ops.kp / BKH;
+  if (g.split_k > 1) {
+    k_first = (int)blockIdx.y * g.k_chunk;                       // a multiple of the K tile
+    ktiles = min(g.k_chunk, ops.kp - k_first) / BKH;
+    g.C += (long)blockIdx.y * g.split_stride;
+  }
 
   // ---- DMA descriptors: unit = 1 KiB of one plane tile.  KC: 8 rows x 128 B.  KS: 64 / (BR / 8) k rows x 2 BR bytes.
   const h16 *src[G];
@@ -295,7 +305,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_s16_glds(GemmArgs g, S16O
       int row = first_row + sr * 8 + r;
       row = row < rows_p ? row : rows_p - 1;   // (a row of the padding or of another tile: feeds outputs that are not stored)
       adv[u] = BKH;
-      return base + (long)row * v_ld + 8 * c;
+      return base + (long)row * v_ld + 8 * c + k_first;
     };
     auto ks_src = [&](int first_col, auto BR_) {
       constexpr int BR = decltype(BR_)::value, CPR = BR / 8;   // 16-byte chunks per k row
@@ -304,7 +314,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_s16_glds(GemmArgs g, S16O
       int col = first_col + 8 * c;
       col = col + 8 <= v_ld ? col : v_ld - 8;   // (columns past the planes: outputs that are not stored)
       adv[u] = BKH * v_ld;
-      return base + (long)krow * v_ld + col;
+      return base + (long)(k_first + krow) * v_ld + col;
     };
     if (is_a) {
       if constexpr (A_KC) src[u] = kc_src(m0); else src[u] = ks_src(m0, std::integral_constant<int, BM>());
@@ -661,7 +671,7 @@ void launch_s16(GemmArgs &g, const S16Operands &ops) {
       ASLP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n, 1, g.pair ? 2 : 1), dim3(64 * WGM * WGN), lds_bytes, cur_stream(), g, ops);
+  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n, g.split_k > 1 ? g.split_k : 1, g.pair ? 2 : 1), dim3(64 * WGM * WGN), lds_bytes, cur_stream(), g, ops);
   t_last_parts = EXTRA ? g.tiles_m * g.tiles_n * (g.pair ? 2 : 1) : 0;
 }
 template <bool A_KC, bool B_KC>
@@ -785,16 +795,39 @@ bool PlaneSet::ConvertWithParts(const float *src, int rows, int cols, int stride
   if ((cols & 3) || (stride & 3) || !aligned16(src) || nparts > kS16MaxParts) return false;
   if (!Reserve(rows, cols)) return false;
   host_bound_ = -1.f;
-  ConvJob j = {src, stride, View(), parts_, nparts};
-  hipLaunchKernelGGL(split16_convert_kernel, dim3(std::min(rows_p_, 512), 1), dim3(256), 0, cur_stream(), j, j, tw_log2_for(ld_ >> 3));
+  ConvJobs js;
+  js.j[0] = ConvJob{src, stride, View(), parts_, nparts};
+  hipLaunchKernelGGL(split16_convert_kernel, dim3(std::min(rows_p_, 512), 1), dim3(256), 0, cur_stream(), js, tw_log2_for(ld_ >> 3));
   return true;
 }
 bool PlaneSet::ConvertFrom(const float *src, int rows, int cols, int stride) {
   if ((cols & 3) || (stride & 3) || !aligned16(src)) return false;
   if (!Reserve(rows, cols)) return false;
-  MaxJob m = {src, rows, cols, stride, parts_};
-  hipLaunchKernelGGL(s16_absmax_kernel, dim3(kS16ConvParts, 1), dim3(256), 0, cur_stream(), m, m, tw_log2_for(cols >> 2));
+  MaxJobs ms;
+  ms.j[0] = MaxJob{src, rows, cols, stride, parts_};
+  hipLaunchKernelGGL(s16_absmax_kernel, dim3(kS16ConvParts, 1), dim3(256), 0, cur_stream(), ms, tw_log2_for(cols >> 2));
   return ConvertWithParts(src, rows, cols, stride, kS16ConvParts);
+}
+// several matrices in one maximum launch and one conversion launch (the recurrent layers convert up to seven small tensors at a time)
+bool PlaneSet::ConvertMany(const ConvertSpec *specs, int n) {
+  if (n <= 0 || n > kS16MaxJobs) return false;
+  MaxJobs ms;
+  ConvJobs js;
+  int max_c4 = 0, max_k8 = 0, max_rows = 0;
+  for (int i = 0; i < n; i++) {
+    const ConvertSpec &c = specs[i];
+    if (!c.planes || !c.src || (c.cols & 3) || (c.stride & 3) || !aligned16(c.src)) return false;
+    if (!c.planes->Reserve(c.rows, c.cols)) return false;
+    c.planes->host_bound_ = -1.f;
+    ms.j[i] = MaxJob{c.src, c.rows, c.cols, c.stride, c.planes->parts_};
+    js.j[i] = ConvJob{c.src, c.stride, c.planes->View(), c.planes->parts_, kS16ConvParts};
+    max_c4 = std::max(max_c4, c.cols >> 2);
+    max_k8 = std::max(max_k8, c.planes->ld_ >> 3);
+    max_rows = std::max(max_rows, c.planes->rows_p_);
+  }
+  hipLaunchKernelGGL(s16_absmax_kernel, dim3(kS16ConvParts, n), dim3(256), 0, cur_stream(), ms, tw_log2_for(max_c4));
+  hipLaunchKernelGGL(split16_convert_kernel, dim3(std::min(max_rows, 512), n), dim3(256), 0, cur_stream(), js, tw_log2_for(max_k8));
+  return true;
 }
 
 // C = epilogue(alpha op(A) op(B) + beta C) from planes.  a_kc: A is stored [M x K] (else [K x M]); b_kc: B is stored [N x K]
@@ -802,7 +835,7 @@ bool PlaneSet::ConvertFrom(const float *src, int rows, int cols, int stride) {
 // Column statistics and (transposed A) column sums are formed in the kernel.
 bool gemm_split16_planes_launch(GemmArgs &g, bool a_kc, bool b_kc, const S16View &a, const S16View &b, const S16View *a1, const S16View *b1,
                                 int cfg) {
-  if (g.split_k > 1) return false;
+  if (g.split_k > 1) return false;   // (the split is chosen here, not by the caller)
   if (g.M < 64 || g.N < 64 || g.K < 32) return false;
   if (g.pair && (!a1 || !b1)) return false;
   S16Operands ops;
@@ -822,12 +855,48 @@ bool gemm_split16_planes_launch(GemmArgs &g, bool a_kc, bool b_kc, const S16View
     g1.C = g.C1; g1.ep = g.ep1;
     if (!(g.wide_epilogue && gemm_epilogue_wide_ok(g1))) drop_extras(g.ep1);
   }
-  bool ok;
-  if (a_kc && b_kc) ok = launch_s16_layout<true, true>(g, ops, cfg);
-  else if (a_kc && !b_kc) ok = launch_s16_layout<true, false>(g, ops, cfg);
-  else if (!a_kc && !b_kc) ok = launch_s16_layout<false, false>(g, ops, cfg);
-  else ok = launch_s16_layout<false, true>(g, ops, cfg);
-  return ok;
+  auto launch = [&](GemmArgs &ga, int c) {
+    if (a_kc && b_kc) return launch_s16_layout<true, true>(ga, ops, c);
+    if (a_kc && !b_kc) return launch_s16_layout<true, false>(ga, ops, c);
+    if (!a_kc && !b_kc) return launch_s16_layout<false, false>(ga, ops, c);
+    return launch_s16_layout<false, true>(ga, ops, c);
+  };
+  // A long reduction on a grid that cannot fill the chip (the minibatch-256 layer products: 64 tiles of 64 x 128 for 256 CUs): K is split
+  // over blockIdx.y, the chunks' partial products are added in chunk order by gemm_glds.hip's second launch, which also runs the epilogue
+  // (bias, clip, SGD step, activation output -- not planes / maxima / column statistics: such requests keep the single launch).
+  const bool extras = g.ep.planes_of != 0 || g.ep.wmax_parts || g.ep.cmax_parts || g.ep.colstats || g.ep.colsum ||
+                      (g.pair && (g.ep1.planes_of != 0 || g.ep1.wmax_parts || g.ep1.cmax_parts || g.ep1.colstats || g.ep1.colsum));
+  const long tiles = (long)((g.M + 63) / 64) * ((g.N + 127) / 128) * (g.pair ? 2 : 1);
+  static const int splitk_off = [] { const char *e = getenv("ASLP_GEMM_SPLITK"); return e && atoi(e) == 0; }();
+  // (act_out planes asked for by a forward product are given up for the split: the consumer converts the small activation matrix itself)
+  const bool only_act_planes = !g.ep.wmax_parts && !g.ep.cmax_parts && !g.ep.colstats && !g.ep.colsum && g.ep.planes_of == 2 && !g.pair;
+  if (!splitk_off && (!extras || only_act_planes) && (cfg == 0 || cfg == 308) && tiles <= 128 && g.K >= 1024) {
+    int split = (int)(256 / tiles);
+    if (split > g.K / 256) split = g.K / 256;
+    if (split > 8) split = 8;
+    int chunk = ((ops.kp / BKH + split - 1) / split) * BKH;
+    split = (ops.kp + chunk - 1) / chunk;
+    if (split >= 2) {
+      const long stride = (long)g.M * g.N;
+      const int np = g.pair ? 2 : 1;
+      float *part = static_cast<float *>(scratch(kScratchSplitK, sizeof(float) * (size_t)stride * split * np));
+      if (part) {
+        GemmArgs pg = g;
+        pg.C = part; pg.ldc = g.N; pg.alpha = 1.0f; pg.beta = 0.0f; pg.ep = aslp_gemm_epilogue();
+        pg.C1 = part + (size_t)stride * split; pg.ep1 = aslp_gemm_epilogue();
+        pg.split_k = split; pg.k_chunk = chunk; pg.split_stride = stride;
+        if (launch(pg, 308)) {
+          GemmArgs r = g;
+          r.split_k = 0;
+          r.ep.planes_of = 0;
+          gemm_splitk_reduce(part, split, stride, r);
+          t_last_parts = 0;
+          return true;
+        }
+      }
+    }
+  }
+  return launch(g, cfg);
 }
 
 // The same with either operand given as fp32 only (pa / pb NULL): its planes are made in the call's scratch, by a maximum pass and a
@@ -851,15 +920,18 @@ bool gemm_split16_launch(GemmArgs &g, bool a_kc, bool b_kc, int cfg, const S16Vi
   const S16View vb = pb ? *pb : S16View{bh, bl, s16_plane_ld(b_cols), b_rows, b_cols, slots + 1};
   const MaxJob ma = {g.A, a_rows, a_cols, g.lda, part}, mb = {g.B, b_rows, b_cols, g.ldb, part + kS16ConvParts};
   const ConvJob ca = {g.A, g.lda, va, part, kS16ConvParts}, cb = {g.B, g.ldb, vb, part + kS16ConvParts, kS16ConvParts};
-  // (two matrices in one launch share the threads-per-row choice: the wider of the two)
+  // (matrices in one launch share the threads-per-row choice: the widest one's)
+  MaxJobs ms;
+  ConvJobs js;
   if (!pa && !pb) {
-    hipLaunchKernelGGL(s16_absmax_kernel, dim3(kS16ConvParts, 2), dim3(256), 0, cur_stream(), ma, mb, tw_log2_for(std::max(a_cols, b_cols) >> 2));
-    hipLaunchKernelGGL(split16_convert_kernel, dim3(512, 2), dim3(256), 0, cur_stream(), ca, cb, tw_log2_for(std::max(va.ld, vb.ld) >> 3));
+    ms.j[0] = ma; ms.j[1] = mb; js.j[0] = ca; js.j[1] = cb;
+    hipLaunchKernelGGL(s16_absmax_kernel, dim3(kS16ConvParts, 2), dim3(256), 0, cur_stream(), ms, tw_log2_for(std::max(a_cols, b_cols) >> 2));
+    hipLaunchKernelGGL(split16_convert_kernel, dim3(512, 2), dim3(256), 0, cur_stream(), js, tw_log2_for(std::max(va.ld, vb.ld) >> 3));
   } else {
-    const MaxJob &m = pa ? mb : ma;
-    const ConvJob &c = pa ? cb : ca;
-    hipLaunchKernelGGL(s16_absmax_kernel, dim3(kS16ConvParts, 1), dim3(256), 0, cur_stream(), m, m, tw_log2_for(m.cols >> 2));
-    hipLaunchKernelGGL(split16_convert_kernel, dim3(512, 1), dim3(256), 0, cur_stream(), c, c, tw_log2_for(c.pl.ld >> 3));
+    ms.j[0] = pa ? mb : ma;
+    js.j[0] = pa ? cb : ca;
+    hipLaunchKernelGGL(s16_absmax_kernel, dim3(kS16ConvParts, 1), dim3(256), 0, cur_stream(), ms, tw_log2_for(ms.j[0].cols >> 2));
+    hipLaunchKernelGGL(split16_convert_kernel, dim3(512, 1), dim3(256), 0, cur_stream(), js, tw_log2_for(js.j[0].pl.ld >> 3));
   }
   return gemm_split16_planes_launch(g, a_kc, b_kc, va, vb, nullptr, nullptr, cfg);
 }
@@ -890,8 +962,9 @@ void aslp_weight_bound(const float *w_parts, int n_w, const float *c_parts, int 
 void aslp_absmax_parts(const float *src, MatrixDim d, float *parts) {
   using namespace aslp;
   if (!src || !parts || (d.cols & 3) || (d.stride & 3) || !aligned16(src)) { set_error("aslp_absmax_parts: unsupported matrix"); return; }
-  MaxJob m = {src, d.rows, d.cols, d.stride, parts};
-  hipLaunchKernelGGL(s16_absmax_kernel, dim3(kS16ConvParts, 1), dim3(256), 0, cur_stream(), m, m, tw_log2_for(d.cols >> 2));
+  MaxJobs ms;
+  ms.j[0] = MaxJob{src, d.rows, d.cols, d.stride, parts};
+  hipLaunchKernelGGL(s16_absmax_kernel, dim3(kS16ConvParts, 1), dim3(256), 0, cur_stream(), ms, tw_log2_for(d.cols >> 2));
   check_launch("aslp_absmax_parts");
 }
 }

@@ -12,6 +12,7 @@
 // index is the row index with the transposing LDS read (ds_read_b64_tr_b16), so ONE pair of planes serves every product that reads
 // the matrix (x: forward and weight gradient; dy: in-diff and weight gradient; W: forward and in-diff).
 #pragma once
+#include "aslp_kernels.h"
 #include "common.h"
 
 namespace aslp {
@@ -100,6 +101,14 @@ class PlaneSet {
   int Cols() const { return cols_; }
   // max pass + conversion of src (two launches on the current stream)
   bool ConvertFrom(const float *src, int rows, int cols, int stride);
+  // several matrices with ONE maximum launch and ONE conversion launch (at most 8)
+  struct ConvertSpec { PlaneSet *planes; const float *src; int rows, cols, stride; };
+  static bool ConvertMany(const ConvertSpec *specs, int n);
+  // a [rows x cols] window of the planes at (row0, col0), for a product that reads that block of the matrix.  As a reduction extent
+  // the window's must be a multiple of 64 (or end at the matrix' edge: behind it the planes hold zeros, inside they hold the neighbours)
+  S16View Window(int row0, int rows, int col0, int cols) const {
+    return S16View{hi_ + (long)row0 * ld_ + col0, lo_ + (long)row0 * ld_ + col0, ld_, rows, cols, slot_};
+  }
   // conversion with the bound already in Parts() (nparts per-workgroup maxima left by the kernel that wrote src)
   bool ConvertWithParts(const float *src, int rows, int cols, int stride, int nparts);
   // the planes were / will be written by a producer under a bound known on the host (e.g. 1 for sigmoid outputs)
@@ -159,6 +168,11 @@ struct S16EpochScope {                       // publishes (fwd, bwd) for the dur
 // kernel knows a bound of |diff| before it runs (Xent on posteriors: |y - t| w <= max w) writes them, tags them and clears this.
 struct S16DiffTarget { PlaneSet *planes = nullptr; long epoch = 0; const void *diff = nullptr; };
 S16DiffTarget &s16_loss_diff_target();
+
+// aslp_sgemm_pair_ex with prepared planes (or windows of planes) of all four operands -- all four or none; K a multiple of 64
+int sgemm_pair_views(int transA, int transB, int M, int N, int K, float alpha, const float *A0, const float *A1, int lda, const float *B0,
+                     const float *B1, int ldb, float beta, float *C0, float *C1, int ldc, const aslp_gemm_epilogue *ep0,
+                     const aslp_gemm_epilogue *ep1, const S16View *va0, const S16View *va1, const S16View *vb0, const S16View *vb1);
 
 // ---- parameters written behind the components' backs (model averaging through the GetGpuParams pointers): whoever writes them calls
 // aslp_params_changed(), which moves this epoch; planes of weights kept from step to step are tagged with it

@@ -10,6 +10,7 @@
 #include <mutex>
 
 #include "common.h"
+#include "split16.h"
 
 namespace aslp {
 
@@ -476,6 +477,11 @@ void CuMatrixBase::AddMatMat(float alpha, const CuMatrixBase &A, MatrixTranspose
 void AddMatMatPair(CuMatrixBase &C0, CuMatrixBase &C1, float alpha, const CuMatrixBase &A0, const CuMatrixBase &A1, MatrixTransposeType tA,
                    const CuMatrixBase &B0, const CuMatrixBase &B1, MatrixTransposeType tB, float beta, const aslp_gemm_epilogue *ep0,
                    const aslp_gemm_epilogue *ep1) {
+  AddMatMatPair(C0, C1, alpha, A0, A1, tA, B0, B1, tB, beta, ep0, ep1, nullptr);
+}
+void AddMatMatPair(CuMatrixBase &C0, CuMatrixBase &C1, float alpha, const CuMatrixBase &A0, const CuMatrixBase &A1, MatrixTransposeType tA,
+                   const CuMatrixBase &B0, const CuMatrixBase &B1, MatrixTransposeType tB, float beta, const aslp_gemm_epilogue *ep0,
+                   const aslp_gemm_epilogue *ep1, const S16View *views) {
   const bool same = SameDim(C0, C1) && SameDim(A0, A1) && SameDim(B0, B1) && C0.Stride() == C1.Stride() && A0.Stride() == A1.Stride() &&
                     B0.Stride() == B1.Stride();
   if (!same || C0.NumCols() == 0) {
@@ -486,8 +492,9 @@ void AddMatMatPair(CuMatrixBase &C0, CuMatrixBase &C1, float alpha, const CuMatr
   const int m = (tB == kTrans ? B0.NumRows() : B0.NumCols()), n = (tA == kTrans ? A0.NumCols() : A0.NumRows());
   const int k = (tB == kTrans ? B0.NumCols() : B0.NumRows()), k1 = (tA == kTrans ? A0.NumRows() : A0.NumCols());
   ASLP_ASSERT(m == C0.NumCols() && n == C0.NumRows() && k == k1);
-  const int rc = aslp_sgemm_pair_ex(tA == kTrans, tB == kTrans, C0.NumRows(), C0.NumCols(), k, alpha, A0.Data(), A1.Data(), A0.Stride(), B0.Data(),
-                                    B1.Data(), B0.Stride(), beta, C0.Data(), C1.Data(), C0.Stride(), ep0, ep1);
+  const int rc = sgemm_pair_views(tA == kTrans, tB == kTrans, C0.NumRows(), C0.NumCols(), k, alpha, A0.Data(), A1.Data(), A0.Stride(), B0.Data(),
+                                  B1.Data(), B0.Stride(), beta, C0.Data(), C1.Data(), C0.Stride(), ep0, ep1, views ? views + 0 : nullptr,
+                                  views ? views + 1 : nullptr, views ? views + 2 : nullptr, views ? views + 3 : nullptr);
   if (rc != 0) ASLP_ERR << "aslp_sgemm_pair argument error " << rc;
   CheckKernels();
 }

@@ -309,6 +309,11 @@ class CuSubMatrix : public CuMatrixBase {
 void AddMatMatPair(CuMatrixBase &C0, CuMatrixBase &C1, float alpha, const CuMatrixBase &A0, const CuMatrixBase &A1, MatrixTransposeType tA,
                    const CuMatrixBase &B0, const CuMatrixBase &B1, MatrixTransposeType tB, float beta, const aslp_gemm_epilogue *ep0 = nullptr,
                    const aslp_gemm_epilogue *ep1 = nullptr);
+// ... with prepared fp16 planes (windows) of the four operands, in the order A0, A1, B0, B1 (csrc/split16.h); NULL: none
+struct S16View;
+void AddMatMatPair(CuMatrixBase &C0, CuMatrixBase &C1, float alpha, const CuMatrixBase &A0, const CuMatrixBase &A1, MatrixTransposeType tA,
+                   const CuMatrixBase &B0, const CuMatrixBase &B1, MatrixTransposeType tB, float beta, const aslp_gemm_epilogue *ep0,
+                   const aslp_gemm_epilogue *ep1, const S16View *views);
 
 inline bool SameDim(const CuMatrixBase &a, const CuMatrixBase &b) { return a.NumRows() == b.NumRows() && a.NumCols() == b.NumCols(); }
 

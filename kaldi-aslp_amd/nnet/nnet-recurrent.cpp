@@ -313,6 +313,13 @@ bool PairsOn() {
   return !off;
 }
 bool SameShape(const LstmDir &f, const LstmDir &b) { return PairsOn() && f.D == b.D && f.C == b.C && f.R == b.R && f.cifg == b.cifg; }
+// Do the layer's batched products run on the fp16 instruction from prepared planes?  Every reduction extent they meet (T S, C, R, 4C)
+// must be a multiple of 64 -- the planes of a buffer's column block or row range are windows, with neighbours instead of zero padding.
+bool PlanesUsable(const LstmDir &f, int T, int S) {
+  static const bool off = getenv("ASLP_LSTM_PLANES") != nullptr && getenv("ASLP_LSTM_PLANES")[0] == '0';  // A/B switch
+  return !off && gemm_split16_enabled() && f.R > 0 && (T * S) % 64 == 0 && f.C % 64 == 0 && f.R % 64 == 0 && T * S >= 128;
+}
+PlaneSet::ConvertSpec Spec(PlaneSet *ps, const CuMatrixBase &m) { return PlaneSet::ConvertSpec{ps, m.Data(), m.NumRows(), m.NumCols(), m.Stride()}; }
 }  // namespace
 
 void LstmDir::RefreshEffPair(const LstmDir &f, const LstmDir &b) {
@@ -326,7 +333,8 @@ void LstmDir::RefreshEffPair(const LstmDir &f, const LstmDir &b) {
 }
 
 void LstmDir::ForwardPreparePair(const LstmDir &f, const LstmDir &b, const CuMatrixBase &in, int T, int S, const CuMatrixBase *init_f,
-                                 CuMatrix *fbuf, CuMatrix *bbuf, bool persistent) {
+                                 CuMatrix *fbuf, CuMatrix *bbuf, bool persistent, LstmPlanes *pl) {
+  if (pl) pl->weights_ok = pl->in_ok = pl->m_ok = pl->od_ok = pl->dg_ok = false;
   if (!SameShape(f, b)) {
     f.ForwardPrepare(in, T, S, false, init_f, fbuf, persistent);
     b.ForwardPrepare(in, T, S, true, nullptr, bbuf, persistent);
@@ -351,10 +359,24 @@ void LstmDir::ForwardPreparePair(const LstmDir &f, const LstmDir &b, const CuMat
   ep_f.bias = f.bias.Data();
   ep_b.bias = b.bias.Data();
   CuSubMatrix gates_f(*fbuf, S, T * S, 0, f.GC()), gates_b(*bbuf, S, T * S, 0, b.GC());
-  AddMatMatPair(gates_f, gates_b, 1.0, in, in, kNoTrans, f.w_x, b.w_x, kTrans, 0.0, &ep_f, &ep_b);
+  if (pl && persistent && PlanesUsable(f, T, S)) {
+    // one maximum + one conversion launch for the layer input and the six weight matrices of this step (the weights' planes also serve
+    // the backward pass: the weights move only in GradsPair, after the last product that reads them)
+    const bool in_ok = f.D % 64 == 0;   // (the first layer's 40-wide input stays below the split kernels' floor)
+    PlaneSet::ConvertSpec sp[7] = {Spec(&pl->wrm[0], f.w_rm), Spec(&pl->wrm[1], b.w_rm), Spec(&pl->wr[0], f.w_r), Spec(&pl->wr[1], b.w_r),
+                                   Spec(&pl->wx[0], f.w_x), Spec(&pl->wx[1], b.w_x), Spec(&pl->in, in)};
+    pl->weights_ok = PlaneSet::ConvertMany(sp, in_ok ? 7 : 4);
+    pl->in_ok = pl->weights_ok && in_ok;
+  }
+  if (pl && pl->in_ok) {
+    const S16View v[4] = {pl->in.View(), pl->in.View(), pl->wx[0].View(), pl->wx[1].View()};
+    AddMatMatPair(gates_f, gates_b, 1.0, in, in, kNoTrans, f.w_x, b.w_x, kTrans, 0.0, &ep_f, &ep_b, v);
+  } else {
+    AddMatMatPair(gates_f, gates_b, 1.0, in, in, kNoTrans, f.w_x, b.w_x, kTrans, 0.0, &ep_f, &ep_b);
+  }
 }
 
-bool LstmDir::ForwardFinishPair(const LstmDir &f, const LstmDir &b, int T, int S, CuMatrix *fbuf, CuMatrix *bbuf, CuMatrixBase *out) {
+bool LstmDir::ForwardFinishPair(const LstmDir &f, const LstmDir &b, int T, int S, CuMatrix *fbuf, CuMatrix *bbuf, CuMatrixBase *out, LstmPlanes *pl) {
   if (f.R <= 0 || !SameShape(f, b)) {
     bool w = f.ForwardFinish(T, S, fbuf, out, 0);
     return b.ForwardFinish(T, S, bbuf, out, f.Rec()) && w;
@@ -366,12 +388,21 @@ bool LstmDir::ForwardFinishPair(const LstmDir &f, const LstmDir &b, int T, int S
     ep_f.act_out = out->Data(); ep_f.ld_act = out->Stride(); ep_f.act = 0;
     ep_b.act_out = out->Data() + f.Rec(); ep_b.ld_act = out->Stride(); ep_b.act = 0;
   }
-  AddMatMatPair(r_f, r_b, 1.0, m_f, m_b, kNoTrans, f.w_rm, b.w_rm, kTrans, 0.0, &ep_f, &ep_b);  // m -> r for every t at once (lc.h:608)
+  if (pl && pl->weights_ok) {   // m of both directions: also the W_rm gradient's operand
+    PlaneSet::ConvertSpec sp[2] = {Spec(&pl->m[0], m_f), Spec(&pl->m[1], m_b)};
+    pl->m_ok = PlaneSet::ConvertMany(sp, 2);
+  }
+  if (pl && pl->m_ok) {
+    const S16View v[4] = {pl->m[0].View(), pl->m[1].View(), pl->wrm[0].View(), pl->wrm[1].View()};
+    AddMatMatPair(r_f, r_b, 1.0, m_f, m_b, kNoTrans, f.w_rm, b.w_rm, kTrans, 0.0, &ep_f, &ep_b, v);
+  } else {
+    AddMatMatPair(r_f, r_b, 1.0, m_f, m_b, kNoTrans, f.w_rm, b.w_rm, kTrans, 0.0, &ep_f, &ep_b);  // m -> r for every t at once (lc.h:608)
+  }
   return out != nullptr;
 }
 
 void LstmDir::BackwardPreparePair(const LstmDir &f, const LstmDir &b, const CuMatrixBase &od_f, const CuMatrixBase &od_b, int T, int S,
-                                  CuMatrix *fdbuf, CuMatrix *bdbuf, bool persistent) {
+                                  CuMatrix *fdbuf, CuMatrix *bdbuf, bool persistent, LstmPlanes *pl) {
   if (f.R <= 0 || !SameShape(f, b)) {
     f.BackwardPrepare(od_f, T, S, fdbuf, persistent);
     b.BackwardPrepare(od_b, T, S, bdbuf, persistent);
@@ -387,11 +418,20 @@ void LstmDir::BackwardPreparePair(const LstmDir &f, const LstmDir &b, const CuMa
     b.BackwardPrepare(od_b, T, S, bdbuf, persistent, false);
   }
   CuSubMatrix dm_f(*fdbuf, S, T * S, f.OffM(), f.C), dm_b(*bdbuf, S, T * S, b.OffM(), b.C);
-  AddMatMatPair(dm_f, dm_b, 1.0, od_f, od_b, kNoTrans, f.w_rm, b.w_rm, kNoTrans, 0.0);  // the loss's share of d_m, all t at once
+  if (pl && pl->weights_ok && persistent) {   // (the weights' planes of this step's forward pass: the weights have not moved)
+    PlaneSet::ConvertSpec sp[2] = {Spec(&pl->od[0], od_f), Spec(&pl->od[1], od_b)};
+    pl->od_ok = PlaneSet::ConvertMany(sp, 2);
+  }
+  if (pl && pl->od_ok) {
+    const S16View v[4] = {pl->od[0].View(), pl->od[1].View(), pl->wrm[0].View(), pl->wrm[1].View()};
+    AddMatMatPair(dm_f, dm_b, 1.0, od_f, od_b, kNoTrans, f.w_rm, b.w_rm, kNoTrans, 0.0, nullptr, nullptr, v);
+  } else {
+    AddMatMatPair(dm_f, dm_b, 1.0, od_f, od_b, kNoTrans, f.w_rm, b.w_rm, kNoTrans, 0.0);  // the loss's share of d_m, all t at once
+  }
 }
 
 void LstmDir::BackwardFinishPair(const LstmDir &f, const LstmDir &b, const CuMatrixBase &od_f, const CuMatrixBase &od_b, int T, int S,
-                                 CuMatrix *fdbuf, CuMatrix *bdbuf, CuMatrixBase *in_diff) {
+                                 CuMatrix *fdbuf, CuMatrix *bdbuf, CuMatrixBase *in_diff, LstmPlanes *pl) {
   if (f.R <= 0 || !SameShape(f, b)) {
     f.BackwardFinish(od_f, T, S, false, fdbuf, in_diff, 0.0, true);
     b.BackwardFinish(od_b, T, S, true, bdbuf, in_diff, 1.0, true);
@@ -404,7 +444,17 @@ void LstmDir::BackwardFinishPair(const LstmDir &f, const LstmDir &b, const CuMat
   aslp_gemm_epilogue ep_f = aslp_gemm_epilogue(), ep_b = aslp_gemm_epilogue();
   ep_f.c_src = od_f.Data(); ep_f.ld_c_src = od_f.Stride();
   ep_b.c_src = od_b.Data(); ep_b.ld_c_src = od_b.Stride();
-  AddMatMatPair(dr_f, dr_b, 1.0, next_f, next_b, kNoTrans, f.w_r, b.w_r, kNoTrans, 1.0, &ep_f, &ep_b);
+  if (pl && pl->od_ok) {   // the dGATES columns of both diff buffers, boundary row blocks included: the products below read shifted row ranges of them
+    CuSubMatrix dga_f(*fdbuf, 0, (T + 2) * S, 0, f.GC()), dga_b(*bdbuf, 0, (T + 2) * S, 0, b.GC());
+    PlaneSet::ConvertSpec sp[2] = {Spec(&pl->dg[0], dga_f), Spec(&pl->dg[1], dga_b)};
+    pl->dg_ok = PlaneSet::ConvertMany(sp, 2);
+  }
+  if (pl && pl->dg_ok) {
+    const S16View v[4] = {pl->dg[0].Window(2 * S, T * S, 0, f.GC()), pl->dg[1].Window(0, T * S, 0, b.GC()), pl->wr[0].View(), pl->wr[1].View()};
+    AddMatMatPair(dr_f, dr_b, 1.0, next_f, next_b, kNoTrans, f.w_r, b.w_r, kNoTrans, 1.0, &ep_f, &ep_b, v);
+  } else {
+    AddMatMatPair(dr_f, dr_b, 1.0, next_f, next_b, kNoTrans, f.w_r, b.w_r, kNoTrans, 1.0, &ep_f, &ep_b);
+  }
   if (!in_diff) return;
   // in_diff = dGATES_f W_x,f + dGATES_b W_x,b.  Two products into one output cannot share a launch; as a pair into (in_diff, scratch)
   // followed by one addition they can, and the [T*S x D] output alone does not fill the chip (240 tiles for D = 512).  The sum is
@@ -418,12 +468,17 @@ void LstmDir::BackwardFinishPair(const LstmDir &f, const LstmDir &b, const CuMat
     b.BackwardFinish(od_b, T, S, true, bdbuf, in_diff, 1.0, false);
     return;
   }
-  AddMatMatPair(*in_diff, scratch, 1.0, dg_f, dg_b, kNoTrans, f.w_x, b.w_x, kNoTrans, 0.0);
+  if (pl && pl->dg_ok && pl->in_ok) {
+    const S16View v[4] = {pl->dg[0].Window(S, T * S, 0, f.GC()), pl->dg[1].Window(S, T * S, 0, b.GC()), pl->wx[0].View(), pl->wx[1].View()};
+    AddMatMatPair(*in_diff, scratch, 1.0, dg_f, dg_b, kNoTrans, f.w_x, b.w_x, kNoTrans, 0.0, nullptr, nullptr, v);
+  } else {
+    AddMatMatPair(*in_diff, scratch, 1.0, dg_f, dg_b, kNoTrans, f.w_x, b.w_x, kNoTrans, 0.0);
+  }
   in_diff->AddMat(1.0, scratch);
 }
 
 void LstmDir::GradsPair(LstmDir &f, LstmDir &b, const CuMatrixBase &in, int T, int S, const CuMatrix &fbuf, const CuMatrix &bbuf,
-                        const CuMatrix &fdbuf, const CuMatrix &bdbuf, float mmt, float clip, float lr_fold, const aslp_lstm_seq *seq) {
+                        const CuMatrix &fdbuf, const CuMatrix &bdbuf, float mmt, float clip, float lr_fold, const aslp_lstm_seq *seq, LstmPlanes *pl) {
   if (!SameShape(f, b)) {
     f.Grads(in, T, S, false, fbuf, fdbuf, mmt, clip, lr_fold, seq, 0);
     b.Grads(in, T, S, true, bbuf, bdbuf, mmt, clip, lr_fold, seq, 1);
@@ -431,22 +486,43 @@ void LstmDir::GradsPair(LstmDir &f, LstmDir &b, const CuMatrixBase &in, int T, i
   }
   // lc.h:976-1058, as in Grads(): corr = grad + mmt * corr, clipped, and (folded) W += -lr * corr
   auto wgrad = [&](CuMatrix &corr_f, CuMatrix &corr_b, CuMatrix &w_f, CuMatrix &w_b, const CuMatrixBase &d_f, const CuMatrixBase &d_b,
-                   const CuMatrixBase &x_f, const CuMatrixBase &x_b) {
+                   const CuMatrixBase &x_f, const CuMatrixBase &x_b, const S16View *views) {
     aslp_gemm_epilogue ep_f = aslp_gemm_epilogue(), ep_b = aslp_gemm_epilogue();
     ep_f.clip = ep_b.clip = clip;
     if (lr_fold != 0.0f) {
       ep_f.W = w_f.Data(); ep_f.ldw = w_f.Stride(); ep_f.w_alpha = -lr_fold;
       ep_b.W = w_b.Data(); ep_b.ldw = w_b.Stride(); ep_b.w_alpha = -lr_fold;
     }
-    AddMatMatPair(corr_f, corr_b, 1.0, d_f, d_b, kTrans, x_f, x_b, kNoTrans, mmt, &ep_f, &ep_b);
+    AddMatMatPair(corr_f, corr_b, 1.0, d_f, d_b, kTrans, x_f, x_b, kNoTrans, mmt, &ep_f, &ep_b, views);
   };
   CuSubMatrix dg_f(fdbuf, S, T * S, 0, f.GC()), dg_b(bdbuf, S, T * S, 0, b.GC());
-  wgrad(f.w_x_corr, b.w_x_corr, f.w_x, b.w_x, dg_f, dg_b, in, in);
-  wgrad(f.w_r_corr, b.w_r_corr, f.w_r, b.w_r, dg_f, dg_b, CuSubMatrix(fbuf, 0, T * S, f.OffRec(), f.Rec()),
-        CuSubMatrix(bbuf, 2 * S, T * S, b.OffRec(), b.Rec()));
-  if (f.R > 0)
-    wgrad(f.w_rm_corr, b.w_rm_corr, f.w_rm, b.w_rm, CuSubMatrix(fdbuf, S, T * S, f.OffRec(), f.R), CuSubMatrix(bdbuf, S, T * S, b.OffRec(), b.R),
-          CuSubMatrix(fbuf, S, T * S, f.OffM(), f.C), CuSubMatrix(bbuf, S, T * S, b.OffM(), b.C));
+  CuSubMatrix dr_f(fdbuf, S, T * S, f.OffRec(), f.R > 0 ? f.R : f.C), dr_b(bdbuf, S, T * S, b.OffRec(), b.R > 0 ? b.R : b.C);
+  // planes: dGATES (made for the in-diff products) and m (made for the projection) are there; r (whole column block: the operand is a
+  // shifted row range of it) and d_r come with one more conversion launch pair
+  bool side_ok = false;
+  if (pl && pl->dg_ok && pl->m_ok && f.R > 0) {
+    CuSubMatrix ra_f(fbuf, 0, (T + 2) * S, f.OffRec(), f.R), ra_b(bbuf, 0, (T + 2) * S, b.OffRec(), b.R);
+    PlaneSet::ConvertSpec sp[4] = {Spec(&pl->r[0], ra_f), Spec(&pl->r[1], ra_b), Spec(&pl->dr[0], dr_f), Spec(&pl->dr[1], dr_b)};
+    side_ok = PlaneSet::ConvertMany(sp, 4);
+  }
+  const S16View dgv[2] = {side_ok ? pl->dg[0].Window(S, T * S, 0, f.GC()) : S16View(), side_ok ? pl->dg[1].Window(S, T * S, 0, b.GC()) : S16View()};
+  if (side_ok && pl->in_ok) {
+    const S16View v[4] = {dgv[0], dgv[1], pl->in.View(), pl->in.View()};
+    wgrad(f.w_x_corr, b.w_x_corr, f.w_x, b.w_x, dg_f, dg_b, in, in, v);
+  } else {
+    wgrad(f.w_x_corr, b.w_x_corr, f.w_x, b.w_x, dg_f, dg_b, in, in, nullptr);
+  }
+  {
+    const S16View v[4] = {dgv[0], dgv[1], side_ok ? pl->r[0].Window(0, T * S, 0, f.R) : S16View(), side_ok ? pl->r[1].Window(2 * S, T * S, 0, b.R) : S16View()};
+    wgrad(f.w_r_corr, b.w_r_corr, f.w_r, b.w_r, dg_f, dg_b, CuSubMatrix(fbuf, 0, T * S, f.OffRec(), f.Rec()),
+          CuSubMatrix(bbuf, 2 * S, T * S, b.OffRec(), b.Rec()), side_ok ? v : nullptr);
+  }
+  if (f.R > 0) {
+    const S16View v[4] = {side_ok ? pl->dr[0].View() : S16View(), side_ok ? pl->dr[1].View() : S16View(), side_ok ? pl->m[0].View() : S16View(),
+                          side_ok ? pl->m[1].View() : S16View()};
+    wgrad(f.w_rm_corr, b.w_rm_corr, f.w_rm, b.w_rm, dr_f, dr_b, CuSubMatrix(fbuf, S, T * S, f.OffM(), f.C), CuSubMatrix(bbuf, S, T * S, b.OffM(), b.C),
+          side_ok ? v : nullptr);
+  }
   if (seq != nullptr && seq->grad_partial != nullptr) {   // the persistent backward launch left the sums: one small finishing launch
     auto vec8 = [](LstmDir &p, float **v) {
       v[0] = p.bias_corr.Data(); v[1] = p.bias.Data();
@@ -590,7 +666,7 @@ void LstmFamily::PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) {
     if (nwin > 1) q.s_count = per_launch;
     const bool persistent = aslp_lstm_seq_supported(&q, 0) != 0;
     last_persistent_ = persistent;
-    if (cfg_.bidir) LstmDir::ForwardPreparePair(f_, b_, in, T, S, carried ? &prev_state_ : nullptr, &f_buf_, &b_buf_, persistent);
+    if (cfg_.bidir) LstmDir::ForwardPreparePair(f_, b_, in, T, S, carried ? &prev_state_ : nullptr, &f_buf_, &b_buf_, persistent, planes_.get());
     else f_.ForwardPrepare(in, T, S, false, carried ? &prev_state_ : nullptr, &f_buf_, persistent);
     // The carried history holds r(0) = m(0) W_rm^T formed with the weights of the PREVIOUS batch (the reference
     // recurs on the stored r, lc.h:575); m(0) W_eff^T would silently re-project it with the updated W_rm.  The persistent
@@ -647,7 +723,7 @@ void LstmFamily::PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) {
     }
     CheckK();
     // with a projection the GEMM that forms r(t) for all t also writes it into this component's output block
-    if (cfg_.bidir) out_written = LstmDir::ForwardFinishPair(f_, b_, T, S, &f_buf_, &b_buf_, out);
+    if (cfg_.bidir) out_written = LstmDir::ForwardFinishPair(f_, b_, T, S, &f_buf_, &b_buf_, out, planes_.get());
     else out_written = f_.ForwardFinish(T, S, &f_buf_, out, 0);
   } else {
     f_.Forward(in, T, S, false, carried ? &prev_state_ : nullptr, nullptr, &f_buf_);
@@ -684,7 +760,7 @@ void LstmFamily::BackpropagateFnc(const CuMatrixBase &in, const CuMatrixBase &, 
     const int per_launch = 64 / q.ndir, nwin = (S + per_launch - 1) / per_launch;   // stream windows as in PropagateFnc
     if (nwin > 1) q.s_count = per_launch;
     const bool persistent = aslp_lstm_seq_supported(&q, 1) != 0;
-    if (cfg_.bidir) LstmDir::BackwardPreparePair(f_, b_, od_f, od_b, T, S, &f_dbuf_, &b_dbuf_, persistent);
+    if (cfg_.bidir) LstmDir::BackwardPreparePair(f_, b_, od_f, od_b, T, S, &f_dbuf_, &b_dbuf_, persistent, planes_.get());
     else f_.BackwardPrepare(od_f, T, S, &f_dbuf_, persistent);
     ASLP_ASSERT(f_dbuf_.Stride() == f_buf_.Stride());
     if (persistent) {
@@ -741,7 +817,7 @@ void LstmFamily::BackpropagateFnc(const CuMatrixBase &in, const CuMatrixBase &, 
     CheckK();
     // (Running the backward direction's batched products beside the forward direction's on the side stream was tried: no gain,
     // 4.289 vs 4.285 ms per LC step -- the small products do not overlap usefully -- so everything stays on one stream.)
-    if (cfg_.bidir) LstmDir::BackwardFinishPair(f_, b_, od_f, od_b, T, S, &f_dbuf_, &b_dbuf_, in_diff);
+    if (cfg_.bidir) LstmDir::BackwardFinishPair(f_, b_, od_f, od_b, T, S, &f_dbuf_, &b_dbuf_, in_diff, planes_.get());
     else f_.BackwardFinish(od_f, T, S, false, &f_dbuf_, in_diff, 0.0, true);
   } else {
     f_.Backward(CuSubMatrix(out_diff, 0, T * S, 0, rec), T, S, false, f_buf_, &f_dbuf_, in_diff, 0.0);
@@ -752,7 +828,7 @@ void LstmFamily::BackpropagateFnc(const CuMatrixBase &in, const CuMatrixBase &, 
   const aslp_lstm_seq *seq = vec_seq_valid_ ? &vec_seq_ : nullptr;
   vec_seq_valid_ = false;
   auto grads = [&]() {
-    if (cfg_.bidir && f_.FusedOk()) LstmDir::GradsPair(f_, b_, in, T, S, f_buf_, b_buf_, f_dbuf_, b_dbuf_, mmt, clip_gradient_, lr_fold, seq);
+    if (cfg_.bidir && f_.FusedOk()) LstmDir::GradsPair(f_, b_, in, T, S, f_buf_, b_buf_, f_dbuf_, b_dbuf_, mmt, clip_gradient_, lr_fold, seq, planes_.get());
     else {
       f_.Grads(in, T, S, false, f_buf_, f_dbuf_, mmt, clip_gradient_, lr_fold, seq, 0);
       if (cfg_.bidir) b_.Grads(in, T, S, true, b_buf_, b_dbuf_, mmt, clip_gradient_, lr_fold, seq, 1);

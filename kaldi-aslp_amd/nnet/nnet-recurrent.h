@@ -12,10 +12,13 @@
 // Per timestep: one skinny GEMM (recurrent), ONE fused gate-block kernel (the reference: ~18-22
 // elementwise launches), one projection GEMM.
 #pragma once
+#include <memory>
+
 #include <string>
 #include <utility>
 #include <vector>
 
+#include "split16.h"
 #include "nnet-component.h"
 
 namespace aslp {
@@ -108,15 +111,18 @@ struct LstmDir {
   // (K or N = R, or a [R x C] output) cannot fill the chip alone -- they go out as pairs, one launch each (AddMatMatPair).
   // `with_gemm = false` on the single-direction methods leaves out the product the *Pair function then issues for both.
   static void RefreshEffPair(const LstmDir &f, const LstmDir &b);
+  // pl (may be NULL): where the layer keeps the fp16 planes of these products' operands (LstmPlanes below)
   static void ForwardPreparePair(const LstmDir &f, const LstmDir &b, const CuMatrixBase &in, int T, int S, const CuMatrixBase *init_f,
-                                 CuMatrix *fbuf, CuMatrix *bbuf, bool persistent);
-  static bool ForwardFinishPair(const LstmDir &f, const LstmDir &b, int T, int S, CuMatrix *fbuf, CuMatrix *bbuf, CuMatrixBase *out);
+                                 CuMatrix *fbuf, CuMatrix *bbuf, bool persistent, struct LstmPlanes *pl = nullptr);
+  static bool ForwardFinishPair(const LstmDir &f, const LstmDir &b, int T, int S, CuMatrix *fbuf, CuMatrix *bbuf, CuMatrixBase *out,
+                                struct LstmPlanes *pl = nullptr);
   static void BackwardPreparePair(const LstmDir &f, const LstmDir &b, const CuMatrixBase &od_f, const CuMatrixBase &od_b, int T, int S,
-                                  CuMatrix *fdbuf, CuMatrix *bdbuf, bool persistent);
+                                  CuMatrix *fdbuf, CuMatrix *bdbuf, bool persistent, struct LstmPlanes *pl = nullptr);
   static void BackwardFinishPair(const LstmDir &f, const LstmDir &b, const CuMatrixBase &od_f, const CuMatrixBase &od_b, int T, int S,
-                                 CuMatrix *fdbuf, CuMatrix *bdbuf, CuMatrixBase *in_diff);
+                                 CuMatrix *fdbuf, CuMatrix *bdbuf, CuMatrixBase *in_diff, struct LstmPlanes *pl = nullptr);
   static void GradsPair(LstmDir &f, LstmDir &b, const CuMatrixBase &in, int T, int S, const CuMatrix &fbuf, const CuMatrix &bbuf,
-                        const CuMatrix &fdbuf, const CuMatrix &bdbuf, float mmt, float clip, float lr_fold, const aslp_lstm_seq *seq = nullptr);
+                        const CuMatrix &fdbuf, const CuMatrix &bdbuf, float mmt, float clip, float lr_fold, const aslp_lstm_seq *seq = nullptr,
+                        struct LstmPlanes *pl = nullptr);
   const CuMatrixBase &Weff() const { return R > 0 ? static_cast<const CuMatrixBase &>(w_eff) : w_r; }
   void ForwardPrepare(const CuMatrixBase &in, int T, int S, bool reverse, const CuMatrixBase *init_state, CuMatrix *buf, bool persistent,
                       bool with_gemm = true) const;
@@ -125,6 +131,21 @@ struct LstmDir {
   void BackwardPrepare(const CuMatrixBase &out_diff, int T, int S, CuMatrix *dbuf, bool persistent, bool with_gemm = true) const;  // dm_ext
   // with_dr: also form d_r (needed by the W_rm gradient); in_diff == NULL: only that
   void BackwardFinish(const CuMatrixBase &out_diff, int T, int S, bool reverse, CuMatrix *dbuf, CuMatrixBase *in_diff, float beta, bool with_dr) const;
+};
+
+// The fp16 planes (csrc/split16.h) of the tensors a bidirectional layer's batched products read, one set per layer: the layer input, the
+// out-diff halves, the weights, and the m / r / dGATES / d_r column blocks of the activation and diff buffers (windows of those planes
+// serve the products that read a shifted row range).  Made by a few multi-matrix conversions per pass; *_ok say what this step has.
+struct LstmPlanes {
+  PlaneSet in, od[2], wx[2], wrm[2], wr[2], m[2], r[2], dg[2], dr[2];
+  bool weights_ok = false, in_ok = false, m_ok = false, od_ok = false, dg_ok = false;
+};
+struct LstmPlanesHolder {   // a copied component starts without planes
+  LstmPlanesHolder() = default;
+  LstmPlanesHolder(const LstmPlanesHolder &) {}
+  LstmPlanesHolder &operator=(const LstmPlanesHolder &) { return *this; }
+  LstmPlanes *get() { if (!p) p.reset(new LstmPlanes()); return p.get(); }
+  std::unique_ptr<LstmPlanes> p;
 };
 
 // Shared implementation; the concrete classes below only fix the configuration.
@@ -174,6 +195,7 @@ class LstmFamily : public RecurrentBase {
   std::vector<int32> sequence_lengths_; // BLstm* masking
   CuArray<int32> seq_len_dev_;
   CuMatrix f_buf_, b_buf_, f_dbuf_, b_dbuf_;
+  LstmPlanesHolder planes_;   // made on first use
   bool last_persistent_ = false;   // the last Propagate ran the recurrence as ONE persistent launch (else: launches per timestep)
   CuMatrix grad_partial_;          // per-chain bias / peephole gradient sums of the persistent backward launch (aslp_lstm_seq.grad_partial)
   aslp_lstm_seq vec_seq_ = aslp_lstm_seq();   // that launch's arguments, for aslp_lstm_seq_vec_grads

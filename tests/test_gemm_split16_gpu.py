@@ -35,7 +35,8 @@ def err_vs_double(C, A, B, tA, tB):
 
 
 @pytest.mark.parametrize("tA,tB,M,N,K", [(0, 1, 1024, 2048, 2048), (0, 0, 1024, 2048, 2048), (1, 0, 2048, 2048, 1024), (1, 1, 512, 640, 768),
-                                         (0, 1, 1000, 3000, 440), (1, 0, 3000, 2048, 1024), (0, 0, 132, 260, 68), (1, 0, 436, 128, 2052)])
+                                         (0, 1, 1000, 3000, 440), (1, 0, 3000, 2048, 1024), (0, 0, 132, 260, 68), (1, 0, 436, 128, 2052),
+                                         (0, 1, 256, 2048, 2048), (0, 0, 256, 2048, 3000), (0, 1, 192, 1920, 1028)])   # (minibatch 256: K split over workgroups)
 def test_as_accurate_as_the_fp32_instruction(aslp, dev, tA, tB, M, N, K):
     g = torch.Generator(device=dev).manual_seed(M + 3 * N + 7 * K)
     A = torch.randn((K, M) if tA else (M, K), device=dev, generator=g)
@@ -107,7 +108,8 @@ def test_zero_and_nonfinite_operands(aslp, dev):
     assert torch.isfinite(c16[ok]).all() and ((c16[ok] - c32[ok]).norm() / c32[ok].norm()).item() < 1e-6
 
 
-@pytest.mark.parametrize("tA,tB,M,N,K,mmt", [(1, 0, 2048, 2048, 1024, 0.9), (1, 0, 3000, 2048, 1024, 0.0), (0, 1, 2048, 2048, 1024, 0.5), (0, 0, 1984, 2176, 640, 0.9)])
+@pytest.mark.parametrize("tA,tB,M,N,K,mmt", [(1, 0, 2048, 2048, 1024, 0.9), (1, 0, 3000, 2048, 1024, 0.0), (0, 1, 2048, 2048, 1024, 0.5), (0, 0, 1984, 2176, 640, 0.9),
+                                             (0, 1, 256, 2048, 2048, 0.9), (1, 0, 2048, 2048, 256, 0.9)])
 def test_full_epilogue(aslp, dev, tA, tB, M, N, K, mmt):
     """momentum on the gradient buffer, clip, W += -lr G, bias gradient + bias step from the column sums (tests/test_fullsize_gpu.py's case)"""
     g = torch.Generator(device=dev).manual_seed(M + N + K)
