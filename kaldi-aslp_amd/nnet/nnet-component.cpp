@@ -105,98 +105,133 @@ Component *Component::NewComponentOfType(ComponentType comp_type, int32 input_di
   return ans;
 }
 
-Component *Component::Init(const std::string &conf_line) {  // nnet-component.cc:211-285
+// ---- the two textual forms of a component ---------------------------------------------------------------------------------------
+// A prototype line:  <Marker> <InputDim> i <OutputDim> o [<Name> n <Input> a[:off],b[:off],...] <component options...>
+// A stored record:   <Marker> o i [<Name> n] id [ inputs ] [ offsets ] <component data...>
+// (the formats are the reference's, nnet-component.cc:211-342; the parsing below is this repo's)
+namespace {
+
+// "a:3,b,c:10" -> names {a, b, c}, offsets {3, 0, 10}: the producers a graph node reads and the column each lands at
+struct LinkList {
+  std::vector<std::string> names;
+  std::vector<int32> offsets;
+  explicit LinkList(const std::string &spec) {
+    size_t pos = 0;
+    while (pos <= spec.size()) {
+      const size_t comma = std::min(spec.find(',', pos), spec.size());
+      const std::string item = spec.substr(pos, comma - pos);
+      pos = comma + 1;
+      if (item.empty()) continue;
+      const size_t colon = item.find(':');
+      ASLP_ASSERT(colon == std::string::npos || item.find(':', colon + 1) == std::string::npos);   // name or name:offset
+      int32 off = 0;
+      if (colon != std::string::npos) ConvertStringToInteger(item.substr(colon + 1), &off);
+      names.push_back(item.substr(0, colon));
+      offsets.push_back(off);
+    }
+  }
+};
+
+// the fixed part of a stored record, in file order
+struct RecordHeader {
+  std::string marker, name;
+  int32 dim_out = 0, dim_in = 0, id = 0;
+  std::vector<int32> input, offset;
+  // false at the end of the net (end of stream or </Nnet>)
+  bool Read(std::istream &is, bool binary) {
+    if (Peek(is, binary) == EOF) return false;
+    ReadToken(is, binary, &marker);
+    if (marker == "<Nnet>") ReadToken(is, binary, &marker);   // the opening tag may sit in front of the first record
+    if (marker == "</Nnet>") return false;
+    ReadBasicType(is, binary, &dim_out);
+    ReadBasicType(is, binary, &dim_in);
+    if (Peek(is, binary) == '<') {   // optional, graph nets only
+      ExpectToken(is, binary, "<Name>");
+      ReadToken(is, binary, &name);
+    }
+    ReadBasicType(is, binary, &id);
+    ReadIntegerVector(is, binary, &input);
+    ReadIntegerVector(is, binary, &offset);
+    ASLP_ASSERT(input.size() == offset.size());
+    return true;
+  }
+  void Write(std::ostream &os, bool binary, bool with_links) const {
+    WriteToken(os, binary, marker);
+    WriteBasicType(os, binary, dim_out);
+    WriteBasicType(os, binary, dim_in);
+    if (with_links) {
+      if (!name.empty()) { WriteToken(os, binary, "<Name>"); WriteToken(os, binary, name); }
+      WriteBasicType(os, binary, id);
+      WriteIntegerVector(os, binary, input);
+      WriteIntegerVector(os, binary, offset);
+    }
+    if (!binary) os << "\n";
+  }
+};
+
+}  // namespace
+
+Component *Component::Init(const std::string &conf_line) {
   std::istringstream is(conf_line);
-  std::string component_type_string;
-  int32 input_dim, output_dim;
-  ReadToken(is, false, &component_type_string);
-  ComponentType component_type = MarkerToType(component_type_string);
-  ExpectToken(is, false, "<InputDim>");
-  ReadBasicType(is, false, &input_dim);
-  ExpectToken(is, false, "<OutputDim>");
-  ReadBasicType(is, false, &output_dim);
-  Component *ans = NewComponentOfType(component_type, input_dim, output_dim);
-  if (conf_line.find("<Name>") != std::string::npos) {
-    std::string name;
+  std::string marker;
+  ReadToken(is, false, &marker);
+  int32 dims[2] = {0, 0};
+  const char *const dim_tokens[2] = {"<InputDim>", "<OutputDim>"};
+  for (int i = 0; i < 2; i++) {
+    ExpectToken(is, false, dim_tokens[i]);
+    ReadBasicType(is, false, &dims[i]);
+  }
+  Component *comp = NewComponentOfType(MarkerToType(marker), dims[0], dims[1]);
+  if (conf_line.find("<Name>") != std::string::npos) {   // a graph node: its own name and the producers it reads
+    std::string name, inputs;
     ExpectToken(is, false, "<Name>");
     ReadToken(is, false, &name);
-    std::string input_string;
     ExpectToken(is, false, "<Input>");
-    ReadToken(is, false, &input_string);
-    std::vector<std::string> sub_input_string;
-    SplitStringToVector(input_string, ",", true, &sub_input_string);
-    int32 num_input = sub_input_string.size();
-    std::vector<std::string> input_name;
-    std::vector<int32> offset(num_input, 0);
-    for (int i = 0; i < num_input; i++) {
-      std::vector<std::string> field;
-      SplitStringToVector(sub_input_string[i], ":", true, &field);
-      ASLP_ASSERT(field.size() >= 1);
-      ASLP_ASSERT(field.size() <= 2);
-      if (field.size() == 2) ConvertStringToInteger(field[1], &offset[i]);
-      input_name.push_back(field[0]);
-    }
-    ans->SetInputName(input_name);
-    ans->SetName(name);
-    ans->SetOffset(offset);
+    ReadToken(is, false, &inputs);
+    const LinkList links(inputs);
+    comp->SetName(name);
+    comp->SetInputName(links.names);
+    comp->SetOffset(links.offsets);
   }
   is >> std::ws;
-  ans->InitData(is);
-  return ans;
+  comp->InitData(is);   // whatever is left belongs to the component
+  return comp;
 }
 
-Component *Component::Read(std::istream &is, bool binary) {  // nnet-component.cc:288-325
-  int32 dim_out, dim_in;
-  std::string token;
-  int first_char = Peek(is, binary);
-  if (first_char == EOF) return NULL;
-  ReadToken(is, binary, &token);
-  if (token == "<Nnet>") ReadToken(is, binary, &token);
-  if (token == "</Nnet>") return NULL;
-  ReadBasicType(is, binary, &dim_out);
-  ReadBasicType(is, binary, &dim_in);
-  std::string name;
-  int32 id;
-  std::vector<int32> input, offset;
-  if (Peek(is, binary) == '<') {
-    ExpectToken(is, binary, "<Name>");
-    ReadToken(is, binary, &name);
-  }
-  ReadBasicType(is, binary, &id);
-  ReadIntegerVector(is, binary, &input);
-  ReadIntegerVector(is, binary, &offset);
-  ASLP_ASSERT(input.size() == offset.size());
-  Component *ans = NewComponentOfType(MarkerToType(token), dim_in, dim_out);
-  ans->ReadData(is, binary);
-  ans->SetName(name);
-  ans->SetId(id);
-  ans->SetInput(input);
-  ans->SetOffset(offset);
-  return ans;
+Component *Component::Read(std::istream &is, bool binary) {
+  RecordHeader h;
+  if (!h.Read(is, binary)) return NULL;
+  Component *comp = NewComponentOfType(MarkerToType(h.marker), h.dim_in, h.dim_out);
+  comp->ReadData(is, binary);
+  comp->SetName(h.name);
+  comp->SetId(h.id);
+  comp->SetInput(h.input);
+  comp->SetOffset(h.offset);
+  return comp;
 }
 
-void Component::Write(std::ostream &os, bool binary) const {  // nnet-component.cc:328-342
-  WriteToken(os, binary, Component::TypeToMarker(GetType()));
-  WriteBasicType(os, binary, OutputDim());
-  WriteBasicType(os, binary, InputDim());
-  if (!name_.empty()) {
-    WriteToken(os, binary, "<Name>");
-    WriteToken(os, binary, name_);
-  }
-  WriteBasicType(os, binary, id_);
-  WriteIntegerVector(os, binary, input_);
-  WriteIntegerVector(os, binary, offset_);
-  if (!binary) os << "\n";
+static RecordHeader HeaderOf(const Component &c, const std::string &name, int32 id, const std::vector<int32> &input, const std::vector<int32> &offset) {
+  RecordHeader h;
+  h.marker = Component::TypeToMarker(c.GetType());
+  h.dim_out = c.OutputDim();
+  h.dim_in = c.InputDim();
+  h.name = name;
+  h.id = id;
+  h.input = input;
+  h.offset = offset;
+  return h;
+}
+
+void Component::Write(std::ostream &os, bool binary) const {
+  HeaderOf(*this, name_, id_, input_, offset_).Write(os, binary, true);
   this->WriteData(os, binary);
 }
 
-void Component::WriteStandard(std::ostream &os, bool binary) const {
-  WriteToken(os, binary, Component::TypeToMarker(GetType()));
-  WriteBasicType(os, binary, OutputDim());
-  WriteBasicType(os, binary, InputDim());
-  if (!binary) os << "\n";
+void Component::WriteStandard(std::ostream &os, bool binary) const {   // the upstream-Kaldi record: no name, id or links
+  HeaderOf(*this, name_, id_, input_, offset_).Write(os, binary, false);
   this->WriteData(os, binary);
 }
+
 
 void Component::Feedforward(const CuMatrixBase &in, CuMatrix *out) {  // nnet-component.h:286-296
   if (input_dim_ != in.NumCols())

@@ -500,23 +500,18 @@ void Nnet::SetChunkSize(int chunk_size) {  // :532-539
     if (BLstmProjectedStreamsLC *l = dynamic_cast<BLstmProjectedStreamsLC *>(components_[c])) l->SetChunkSize(chunk_size);
 }
 
-void Nnet::AutoComplete() {  // :541-568
-  int input_dim = components_[0]->InputDim();
-  Component *in_comp = new InputLayer(input_dim, input_dim);
-  in_comp->SetId(0);
-  in_comp->SetMonoInput(-1);
-  components_.insert(components_.begin(), in_comp);
-  for (size_t i = 1; i < components_.size(); i++) {
-    ASLP_ASSERT(components_[i]->Id() < 0);
-    components_[i]->SetId(i);
-    components_[i]->SetMonoInput(i - 1);
+void Nnet::AutoComplete() {
+  // a plain chain of components (a prototype without <Name> / <Input>) becomes a graph: an InputLayer in front, an OutputLayer behind,
+  // node k reading node k - 1 (what nnet-nnet.cc:541-568 produces)
+  ASLP_ASSERT(!components_.empty());
+  const int32 in_dim = components_.front()->InputDim(), out_dim = components_.back()->OutputDim();
+  for (Component *c : components_) ASLP_ASSERT(c->Id() < 0);   // nobody has numbered them yet
+  components_.insert(components_.begin(), new InputLayer(in_dim, in_dim));
+  components_.push_back(new OutputLayer(out_dim, out_dim));
+  for (size_t k = 0; k < components_.size(); k++) {
+    components_[k]->SetId((int32)k);
+    components_[k]->SetMonoInput((int32)k - 1);   // -1: the network input
   }
-  int num_layers = components_.size();
-  int output_dim = components_[num_layers - 1]->OutputDim();
-  Component *out_comp = new OutputLayer(output_dim, output_dim);
-  out_comp->SetId(num_layers);
-  out_comp->SetMonoInput(num_layers - 1);
-  components_.push_back(out_comp);
 }
 
 void Nnet::InitStream(std::istream &is) {  // :570-612
@@ -750,50 +745,50 @@ void Nnet::GetComponentTime() {  // :872-884
   }
 }
 
-void Nnet::AssignComponentId(std::vector<Component *> &comp) {  // :886-949 (Kahn topological order, LIFO queue)
-  int32 num_comp = comp.size();
-  std::vector<int32> indegree;
-  std::vector<std::string> input_name;
-  for (int i = 0; i < num_comp; i++) {
-    input_name = comp[i]->GetInputName();
-    if (input_name.size() == 1 && input_name[0] == "-1") indegree.push_back(0);
-    else indegree.push_back(input_name.size());
-  }
-  std::vector<std::string> comp_queue;
-  for (int i = 0; i < num_comp; i++)
-    if (indegree[i] == 0) comp_queue.push_back(comp[i]->GetName());
-  int32 id = 0;
-  while (!comp_queue.empty()) {
-    std::string name = comp_queue.back();
-    comp_queue.pop_back();
-    for (int i = 0; i < num_comp; i++) {
-      input_name = comp[i]->GetInputName();
-      if (comp[i]->GetName() == name) {
-        comp[i]->SetId(id);
-        ++id;
-      }
-      for (size_t j = 0; j < input_name.size(); j++) {
-        if (input_name[j] == comp[i]->GetName())
-          ASLP_ERR << "The input of component " << comp[i]->GetName() << "include itself, Please check it!";
-        else if (input_name[j] == name)
-          if (--indegree[i] == 0) comp_queue.push_back(comp[i]->GetName());
-      }
+void Nnet::AssignComponentId(std::vector<Component *> &comp) {
+  // Ids are positions in a topological order of the named graph, found by taking ready nodes from a STACK (the node that became ready
+  // last is numbered next; ready nodes of one step are stacked in prototype order) -- the order nnet-nnet.cc:886-949 assigns, which the
+  // stored <Input> vectors of existing models rely on.  Then every <Input> name is replaced by its producer's id ("-1" = network input).
+  const int32 n = (int32)comp.size();
+  std::map<std::string, int32> index_of;
+  for (int32 i = 0; i < n; i++)
+    if (!index_of.insert(std::make_pair(comp[i]->GetName(), i)).second) ASLP_ERR << "Two components are named " << comp[i]->GetName();
+  std::vector<std::vector<int32>> readers(n);   // producer -> the nodes that read it, one entry per link, in prototype order
+  std::vector<int32> waiting(n, 0);             // links of a node whose producer has no id yet
+  for (int32 i = 0; i < n; i++) {
+    const std::vector<std::string> &in = comp[i]->GetInputName();
+    if (in.size() == 1 && in[0] == "-1") continue;   // reads the network input only
+    for (const std::string &name : in) {
+      if (name == comp[i]->GetName()) ASLP_ERR << "The input of component " << comp[i]->GetName() << "include itself, Please check it!";
+      waiting[i]++;
+      const auto it = index_of.find(name);
+      if (it != index_of.end()) readers[it->second].push_back(i);   // (a link to a name nobody has keeps its node waiting: reported as a cycle below)
     }
   }
-  if (id != num_comp) ASLP_ERR << "The graph has a cycle";
-  std::map<std::string, int32> name_to_id;
-  for (int i = 0; i < num_comp; i++) name_to_id.insert(std::make_pair(comp[i]->GetName(), comp[i]->GetId()));
-  for (int i = 0; i < num_comp; i++) {
-    input_name = comp[i]->GetInputName();
-    std::vector<int32> input(input_name.size(), 0);
-    for (size_t j = 0; j < input_name.size(); j++) {
-      if (input_name[j] == "-1") input[j] = -1;
-      else {
-        auto it = name_to_id.find(input_name[j]);
-        if (it != name_to_id.end()) input[j] = it->second;
-      }
+  std::vector<int32> ready;
+  for (int32 i = 0; i < n; i++)
+    if (waiting[i] == 0) ready.push_back(i);
+  int32 next_id = 0;
+  while (!ready.empty()) {
+    const int32 u = ready.back();
+    ready.pop_back();
+    comp[u]->SetId(next_id++);
+    std::vector<int32> now_ready;
+    for (int32 r : readers[u])
+      if (--waiting[r] == 0) now_ready.push_back(r);
+    std::sort(now_ready.begin(), now_ready.end());   // prototype order
+    ready.insert(ready.end(), now_ready.begin(), now_ready.end());
+  }
+  if (next_id != n) ASLP_ERR << "The graph has a cycle";
+  for (int32 i = 0; i < n; i++) {
+    const std::vector<std::string> &in = comp[i]->GetInputName();
+    std::vector<int32> ids(in.size(), 0);
+    for (size_t j = 0; j < in.size(); j++) {
+      if (in[j] == "-1") { ids[j] = -1; continue; }
+      const auto it = index_of.find(in[j]);
+      if (it != index_of.end()) ids[j] = comp[it->second]->GetId();
     }
-    comp[i]->SetInput(input);
+    comp[i]->SetInput(ids);
   }
 }
 void Nnet::SortComponent(std::vector<Component *> &comp) {  // :951-958

@@ -315,9 +315,14 @@ bool PairsOn() {
 bool SameShape(const LstmDir &f, const LstmDir &b) { return PairsOn() && f.D == b.D && f.C == b.C && f.R == b.R && f.cifg == b.cifg; }
 // Do the layer's batched products run on the fp16 instruction from prepared planes?  Every reduction extent they meet (T S, C, R, 4C)
 // must be a multiple of 64 -- the planes of a buffer's column block or row range are windows, with neighbours instead of zero padding.
+// A/B switch ASLP_LSTM_PLANES: 0 = none of the layer's batched products from planes, 1 = forward only, 2 = forward + the products in front
+// of the backward recurrence, 3 (default) = all of them
+int PlanesLevel() {
+  static const int level = [] { const char *e = getenv("ASLP_LSTM_PLANES"); return e ? atoi(e) : 3; }();
+  return level;
+}
 bool PlanesUsable(const LstmDir &f, int T, int S) {
-  static const bool off = getenv("ASLP_LSTM_PLANES") != nullptr && getenv("ASLP_LSTM_PLANES")[0] == '0';  // A/B switch
-  return !off && gemm_split16_enabled() && f.R > 0 && (T * S) % 64 == 0 && f.C % 64 == 0 && f.R % 64 == 0 && T * S >= 128;
+  return PlanesLevel() > 0 && gemm_split16_enabled() && f.R > 0 && (T * S) % 64 == 0 && f.C % 64 == 0 && f.R % 64 == 0 && T * S >= 128;
 }
 PlaneSet::ConvertSpec Spec(PlaneSet *ps, const CuMatrixBase &m) { return PlaneSet::ConvertSpec{ps, m.Data(), m.NumRows(), m.NumCols(), m.Stride()}; }
 }  // namespace
@@ -418,7 +423,7 @@ void LstmDir::BackwardPreparePair(const LstmDir &f, const LstmDir &b, const CuMa
     b.BackwardPrepare(od_b, T, S, bdbuf, persistent, false);
   }
   CuSubMatrix dm_f(*fdbuf, S, T * S, f.OffM(), f.C), dm_b(*bdbuf, S, T * S, b.OffM(), b.C);
-  if (pl && pl->weights_ok && persistent) {   // (the weights' planes of this step's forward pass: the weights have not moved)
+  if (pl && pl->weights_ok && persistent && PlanesLevel() >= 2) {   // (the weights' planes of this step's forward pass: the weights have not moved)
     PlaneSet::ConvertSpec sp[2] = {Spec(&pl->od[0], od_f), Spec(&pl->od[1], od_b)};
     pl->od_ok = PlaneSet::ConvertMany(sp, 2);
   }
@@ -444,7 +449,7 @@ void LstmDir::BackwardFinishPair(const LstmDir &f, const LstmDir &b, const CuMat
   aslp_gemm_epilogue ep_f = aslp_gemm_epilogue(), ep_b = aslp_gemm_epilogue();
   ep_f.c_src = od_f.Data(); ep_f.ld_c_src = od_f.Stride();
   ep_b.c_src = od_b.Data(); ep_b.ld_c_src = od_b.Stride();
-  if (pl && pl->od_ok) {   // the dGATES columns of both diff buffers, boundary row blocks included: the products below read shifted row ranges of them
+  if (pl && pl->od_ok && PlanesLevel() >= 3) {   // the dGATES columns of both diff buffers, boundary row blocks included: the products below read shifted row ranges of them
     CuSubMatrix dga_f(*fdbuf, 0, (T + 2) * S, 0, f.GC()), dga_b(*bdbuf, 0, (T + 2) * S, 0, b.GC());
     PlaneSet::ConvertSpec sp[2] = {Spec(&pl->dg[0], dga_f), Spec(&pl->dg[1], dga_b)};
     pl->dg_ok = PlaneSet::ConvertMany(sp, 2);

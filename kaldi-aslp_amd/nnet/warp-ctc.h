@@ -5,6 +5,7 @@
 // reference's per-call cudaMalloc x3, row-wise de-stride copy and per-frame copy-back
 // (warp-ctc.cc:85-95, 105-113, 139-147) disappear.
 #pragma once
+#include <cmath>
 #include <string>
 #include <vector>
 
@@ -55,8 +56,34 @@ class WarpCtc {
   int32 report_step_;
   double obj_;
   bool use_gpu_;
-  double loss_sum_, loss_square_sum_, loss_sum_bak_, loss_square_sum_bak_;
-  int32 normal_num_, stat_period_;
+  // Running statistics of the per-frame cost of the utterances accepted so far, over a sliding window of `period` utterances that
+  // restarts from its younger half when full (what the reference keeps in loss_sum_ / loss_sum_bak_ / normal_num_, warp-ctc.cc:288-365)
+  struct CostWindow {
+    explicit CostWindow(int32 period_) : period(period_) {}
+    bool WarmingUp() const { return count < period / 2; }
+    double Mean() const { return sum / count; }
+    double RootMeanSquare() const { return sqrt(sum_sq / count); }   // the reference's "sigma": no mean subtracted
+    void Add(double x) {
+      const bool warm = WarmingUp();
+      count++;
+      sum += x;
+      sum_sq += x * x;
+      if (warm) { young_sum += x; young_sum_sq += x * x; }   // the first half window is what survives the first restart
+      if (count == period) {   // keep the younger half
+        sum -= young_sum;
+        sum_sq -= young_sum_sq;
+        young_sum = sum;
+        young_sum_sq = sum_sq;
+        count = period / 2;
+      }
+    }
+    int32 period, count = 0;
+    double sum = 0.0, sum_sq = 0.0, young_sum = 0.0, young_sum_sq = 0.0;
+  };
+  CostWindow window_;
+  // one utterance into the totals and the progress counters (obj only when it is kept)
+  void Count(int32 frames, bool kept, double obj);
+  void CountBatch(int32 num_sequence);
   std::vector<float> last_costs_;
 };
 
