@@ -797,10 +797,14 @@ def main():
     ap.add_argument("--no-cfg3", action="store_true", help="skip the LC-BLSTM (BASELINE cfg3) block of the JSON line")
     ap.add_argument("--cfg3-bsp-timeout", type=int, default=420, help="N > 1: seconds the extra cfg4_bsp / cfg3_bsp / cfg5_easgd blocks may take before they are dropped")
     ap.add_argument("--launch-timeout", type=int, default=3000, help="N > 1 from a bare shell: seconds the parent waits for rank 0")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the cfg2 step itself (profiler passes: nothing but the timed workload's kernels in the trace); implies the --no-* flags")
     ap.add_argument("--no-e2e-tool", action="store_true", help="skip the end-to-end command-line block of the JSON line (extra key e2e_tool)")
     ap.add_argument("--e2e-frames", type=int, default=1024000)
     ap.add_argument("--dry-run-ranks", action="store_true", help=argparse.SUPPRESS)   # launcher plumbing test (no GPU): tests/test_bench_cpu.py
     args = ap.parse_args()
+    if args.headline_only:
+        args.no_cfg3 = args.no_e2e_tool = args.no_cpu_baseline = True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world == 1 and args.gpus > 1:
@@ -992,7 +996,7 @@ def main():
             out["roofline"] = {"bound": "mfma", "achieved": FLOP_PER_FRAME * args.steps * MB / elapsed / 1e12, "peak": F32_MFMA_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": FLOP_PER_FRAME * args.steps * MB / elapsed / 1e12 / F32_MFMA_PEAK_TFLOPS,
                                "traffic": None, "note": "whole-step algorithmic flops (per-kernel events disabled)"}
-        if world == 1:
+        if world == 1 and not args.headline_only:
             out["ctc_loss_fp32_rel_err"] = ctc_rel_err(aslp, dev)
         if world == 1 and not args.no_cfg3:
             net = None
@@ -1000,7 +1004,7 @@ def main():
             out["cfg3"] = cfg3_block(aslp, dev)
             out["recurrent_layers"] = recurrent_family_block(aslp, dev)
             out["cfg1_gpu"] = cfg1_gpu_block(aslp, dev)
-        if world == 1:
+        if world == 1 and not args.headline_only:
             net = None
             torch.cuda.empty_cache()
             # the same step on the fp32 matrix instruction, the accuracy of every product shape on both instructions, the bandwidth-bound kernels

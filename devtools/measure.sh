@@ -13,13 +13,13 @@ export TMPDIR=/tmp
 cd /tmp
 python3 $R/bench.py --steps 500 --warmup 50 > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 tail -c 3000 $O/${TAG}_bench.json
-rocprofv3 --kernel-trace --stats -d $O/${TAG}_trace -o bench -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-update-overlap --no-cfg3 --no-e2e-tool > $O/${TAG}_trace.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/${TAG}_trace -o bench -- python3 $R/bench.py --steps 20 --warmup 3 --headline-only --no-update-overlap > $O/${TAG}_trace.log 2>&1
 python3 $R/devtools/prof_summary.py $O/${TAG}_trace/bench_results.db > $O/${TAG}_kernel_stats.txt 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/${TAG}_pmc_fetch -o bench -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-gemm-profile --no-update-overlap --no-cfg3 --no-e2e-tool > $O/${TAG}_pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/${TAG}_pmc_fetch -o bench -- python3 $R/bench.py --steps 4 --warmup 2 --headline-only --no-gemm-profile --no-update-overlap > $O/${TAG}_pmc_fetch.log 2>&1
 python3 $R/devtools/prof_summary.py $O/${TAG}_pmc_fetch/bench_results.db > $O/${TAG}_pmc_fetch.txt 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/${TAG}_pmc_write -o bench -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-gemm-profile --no-update-overlap --no-cfg3 --no-e2e-tool > $O/${TAG}_pmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/${TAG}_pmc_write -o bench -- python3 $R/bench.py --steps 4 --warmup 2 --headline-only --no-gemm-profile --no-update-overlap > $O/${TAG}_pmc_write.log 2>&1
 python3 $R/devtools/prof_summary.py $O/${TAG}_pmc_write/bench_results.db > $O/${TAG}_pmc_write.txt 2>&1
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/${TAG}_pmc_mfma -o bench -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-gemm-profile --no-update-overlap --no-cfg3 --no-e2e-tool > $O/${TAG}_pmc_mfma.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/${TAG}_pmc_mfma -o bench -- python3 $R/bench.py --steps 4 --warmup 2 --headline-only --no-gemm-profile --no-update-overlap > $O/${TAG}_pmc_mfma.log 2>&1
 python3 $R/devtools/prof_summary.py $O/${TAG}_pmc_mfma/bench_results.db > $O/${TAG}_pmc_mfma.txt 2>&1
 head -40 $O/${TAG}_kernel_stats.txt
 rm -rf $O/${TAG}_trace $O/${TAG}_pmc_fetch $O/${TAG}_pmc_write $O/${TAG}_pmc_mfma   # keep the text summaries only (dbs are large)

@@ -685,7 +685,8 @@ bool launch_s16_layout(GemmArgs &g, const S16Operands &ops, int cfg) {
     // rounds of 256 workgroups, a 128 x 128 round costing ~1.6 of a 64 x 128 one (measured on 2048 x 2048 x 1024)
     static const int ks128 = [] { const char *e = getenv("ASLP_GEMM_KS128"); return e ? atoi(e) : 1; }();   // A/B switch
     const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * (g.pair ? 2 : 1), t64 = (long)((g.M + 63) / 64) * ((g.N + 127) / 128) * (g.pair ? 2 : 1);
-    const double cost128 = 1.6 * (double)((t128 + 255) / 256), cost64 = (double)((t64 + 255) / 256);
+    static const double round_cost = [] { const char *e = getenv("ASLP_GEMM_KS128_COST"); return e ? atof(e) : 1.6; }();   // (tuning aid)
+    const double cost128 = round_cost * (double)((t128 + 255) / 256), cost64 = (double)((t64 + 255) / 256);
     if (ks128 && (cfg == 0 || cfg == 328) && (cfg == 328 || (t128 >= 200 && cost128 <= cost64)) && (g.N % 8) == 0 && (g.M % 8) == 0) {
       if (extra) launch_s16_ks128<true>(g, ops); else launch_s16_ks128<false>(g, ops);
       t_last_cfg_s16 = 328;

@@ -315,10 +315,14 @@ bool PairsOn() {
 bool SameShape(const LstmDir &f, const LstmDir &b) { return PairsOn() && f.D == b.D && f.C == b.C && f.R == b.R && f.cifg == b.cifg; }
 // Do the layer's batched products run on the fp16 instruction from prepared planes?  Every reduction extent they meet (T S, C, R, 4C)
 // must be a multiple of 64 -- the planes of a buffer's column block or row range are windows, with neighbours instead of zero padding.
-// A/B switch ASLP_LSTM_PLANES: 0 = none of the layer's batched products from planes, 1 = forward only, 2 = forward + the products in front
-// of the backward recurrence, 3 (default) = all of them
+// Switch ASLP_LSTM_PLANES: 0 (default) = the layer's batched products convert their operands call by call or run on the fp32 instruction as
+// aslp_sgemm_pair_ex decides, 1 = the forward products from planes the layer prepares, 2 = + the products in front of the backward
+// recurrence, 3 = all of them.  Measured on the cfg3 step (devtools/bench_lc.py 32 100, one box, two alternations): 2.872 / 2.875 ms
+// with 3 against 2.858 / 2.868 with 0 -- the products get 1.5-2 x faster (gates pair 45 us, in-diff pair 38 us) but the fourteen
+// maximum + conversion launches per layer and step (~70 us) eat it, so it stays off until the recurrence kernels leave the planes
+// of m and dGATES themselves.
 int PlanesLevel() {
-  static const int level = [] { const char *e = getenv("ASLP_LSTM_PLANES"); return e ? atoi(e) : 3; }();
+  static const int level = [] { const char *e = getenv("ASLP_LSTM_PLANES"); return e ? atoi(e) : 0; }();
   return level;
 }
 bool PlanesUsable(const LstmDir &f, int T, int S) {

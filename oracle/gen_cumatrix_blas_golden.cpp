@@ -387,6 +387,107 @@ static void LstmProjected(const char *tag, bool reverse, bool carried, bool cifg
 #undef NAME
 }
 
+// Two TRAINING steps of the projected LSTM with momentum, element-wise gradient clipping and the component's Update, issued as the reference
+// issues them: the corr buffers accumulate with AddMatMat / AddRowSumMat / AddDiagMatMat at beta = momentum (lc.h:976-998 =
+// nnet-lstm-projected-streams.h:560-585), are clipped by ApplyFloor / ApplyCeiling (lc.h:1000-1016), then W.AddMat(-lr, corr)
+// (lc.h:1085-1098).  Sized so that the engine's persistent recurrence serves it (C = 64, S = 8 streams): a golden from the reference's
+// library reaches those kernels.  State zero at the start of every step (the streams are reset).
+static void LstmProjectedTrain(const char *tag, int T, int S, int D, int C, int R, float mmt, float clip, float lr) {
+  const int NG = 4, W = (NG + 3) * C + R;
+  Mat Wx, Wr, Wrm;
+  Vec bias, pi, pf, po;
+  Fill(&Wx, NG * C, D, -0.2f, 0.2f); Fill(&Wr, NG * C, R, -0.2f, 0.2f); Fill(&Wrm, R, C, -0.2f, 0.2f);
+  FillVec(&bias, NG * C, -0.3f, 0.3f); FillVec(&pi, C, -0.3f, 0.3f); FillVec(&pf, C, -0.3f, 0.3f); FillVec(&po, C, -0.3f, 0.3f);
+  Mat cWx(NG * C, D), cWr(NG * C, R), cWrm(R, C);
+  Vec cb(NG * C), cpi(C), cpf(C), cpo(C);
+  char nm[32];
+#define NAME2(x, k) (std::snprintf(nm, 32, "%s_%s%d", tag, x, k), nm)
+  auto put_params = [&](int k) {
+    PutMat(NAME2("Wx", k), Wx); PutMat(NAME2("Wr", k), Wr); PutMat(NAME2("Wrm", k), Wrm); PutVec(NAME2("bias", k), bias);
+    PutVec(NAME2("pi", k), pi); PutVec(NAME2("pf", k), pf); PutVec(NAME2("po", k), po);
+  };
+  put_params(0);
+  const int G = 0, I = 1, F = 2, O = 3, Cc = 4, H = 5, Mm = 6;
+  for (int step = 0; step < 2; step++) {
+    Mat in, od;
+    Fill(&in, T * S, D, -1.5f, 1.5f); Fill(&od, T * S, R, -1.0f, 1.0f);
+    PutMat(NAME2("in", step), in); PutMat(NAME2("od", step), od);
+    Mat Y((T + 2) * S, W), Dd((T + 2) * S, W);
+    struct View {
+      Mat &b; int C, R, S;
+      Sub gate(int k, int t) { return Sub(b, t * S, S, k * C, C); }
+      Sub rec(int t) { return Sub(b, t * S, S, 7 * C, R); }
+      Sub gates(int t0, int n) { return Sub(b, t0 * S, n * S, 0, 4 * C); }
+      Sub cols(int k, int t0, int n) { return Sub(b, t0 * S, n * S, k * C, C); }
+      Sub recs(int t0, int n) { return Sub(b, t0 * S, n * S, 7 * C, R); }
+    } y = {Y, C, R, S}, d = {Dd, C, R, S};
+    y.gates(1, T).AddMatMat(1.0, in, kNoTrans, Wx, kTrans, 0.0);
+    y.gates(1, T).AddVecToRows(1.0, bias);
+    for (int t = 1; t <= T; t++) {
+      const int p = t - 1;
+      y.gates(t, 1).AddMatMat(1.0, y.rec(p), kNoTrans, Wr, kTrans, 1.0);
+      y.gate(I, t).AddMatDiagVec(1.0, y.gate(Cc, p), kNoTrans, pi, 1.0);
+      y.gate(F, t).AddMatDiagVec(1.0, y.gate(Cc, p), kNoTrans, pf, 1.0);
+      y.gate(I, t).Sigmoid(y.gate(I, t));
+      y.gate(F, t).Sigmoid(y.gate(F, t));
+      y.gate(G, t).Tanh(y.gate(G, t));
+      y.gate(Cc, t).AddMatMatElements(1.0, y.gate(G, t), y.gate(I, t), 0.0);
+      y.gate(Cc, t).AddMatMatElements(1.0, y.gate(Cc, p), y.gate(F, t), 1.0);
+      y.gate(Cc, t).ApplyFloor(-50);
+      y.gate(Cc, t).ApplyCeiling(50);
+      y.gate(H, t).Tanh(y.gate(Cc, t));
+      y.gate(O, t).AddMatDiagVec(1.0, y.gate(Cc, t), kNoTrans, po, 1.0);
+      y.gate(O, t).Sigmoid(y.gate(O, t));
+      y.gate(Mm, t).AddMatMatElements(1.0, y.gate(H, t), y.gate(O, t), 0.0);
+      y.rec(t).AddMatMat(1.0, y.gate(Mm, t), kNoTrans, Wrm, kTrans, 0.0);
+    }
+    PutMat(NAME2("out", step), y.recs(1, T));
+    d.recs(1, T).CopyFromMat(od);
+    for (int t = T; t >= 1; t--) {
+      const int p = t - 1, q = t + 1;
+      d.rec(t).AddMatMat(1.0, d.gates(q, 1), kNoTrans, Wr, kNoTrans, 1.0);
+      d.gate(Mm, t).AddMatMat(1.0, d.rec(t), kNoTrans, Wrm, kNoTrans, 0.0);
+      d.gate(H, t).AddMatMatElements(1.0, d.gate(Mm, t), y.gate(O, t), 0.0);
+      d.gate(H, t).DiffTanh(y.gate(H, t), d.gate(H, t));
+      d.gate(O, t).AddMatMatElements(1.0, d.gate(Mm, t), y.gate(H, t), 0.0);
+      d.gate(O, t).DiffSigmoid(y.gate(O, t), d.gate(O, t));
+      d.gate(Cc, t).AddMat(1.0, d.gate(H, t));
+      d.gate(Cc, t).AddMatMatElements(1.0, d.gate(Cc, q), y.gate(F, q), 1.0);
+      d.gate(Cc, t).AddMatDiagVec(1.0, d.gate(I, q), kNoTrans, pi, 1.0);
+      d.gate(Cc, t).AddMatDiagVec(1.0, d.gate(F, q), kNoTrans, pf, 1.0);
+      d.gate(Cc, t).AddMatDiagVec(1.0, d.gate(O, t), kNoTrans, po, 1.0);
+      d.gate(F, t).AddMatMatElements(1.0, d.gate(Cc, t), y.gate(Cc, p), 0.0);
+      d.gate(F, t).DiffSigmoid(y.gate(F, t), d.gate(F, t));
+      d.gate(I, t).AddMatMatElements(1.0, d.gate(Cc, t), y.gate(G, t), 0.0);
+      d.gate(I, t).DiffSigmoid(y.gate(I, t), d.gate(I, t));
+      d.gate(G, t).AddMatMatElements(1.0, d.gate(Cc, t), y.gate(I, t), 0.0);
+      d.gate(G, t).DiffTanh(y.gate(G, t), d.gate(G, t));
+    }
+    Mat id(T * S, D);
+    id.AddMatMat(1.0, d.gates(1, T), kNoTrans, Wx, kNoTrans, 0.0);
+    PutMat(NAME2("in_diff", step), id);
+    // corr = gradient + momentum * corr
+    cWx.AddMatMat(1.0, d.gates(1, T), kTrans, in, kNoTrans, mmt);
+    cWr.AddMatMat(1.0, d.gates(1, T), kTrans, y.recs(0, T), kNoTrans, mmt);
+    cb.AddRowSumMat(1.0, d.gates(1, T), mmt);
+    cpi.AddDiagMatMat(1.0, d.cols(I, 1, T), kTrans, y.cols(Cc, 0, T), kNoTrans, mmt);
+    cpf.AddDiagMatMat(1.0, d.cols(F, 1, T), kTrans, y.cols(Cc, 0, T), kNoTrans, mmt);
+    cpo.AddDiagMatMat(1.0, d.cols(O, 1, T), kTrans, y.cols(Cc, 1, T), kNoTrans, mmt);
+    cWrm.AddMatMat(1.0, d.recs(1, T), kTrans, y.cols(Mm, 1, T), kNoTrans, mmt);
+    // element-wise clipping
+    cWx.ApplyFloor(-clip); cWx.ApplyCeiling(clip); cWr.ApplyFloor(-clip); cWr.ApplyCeiling(clip);
+    cb.ApplyFloor(-clip); cb.ApplyCeiling(clip); cWrm.ApplyFloor(-clip); cWrm.ApplyCeiling(clip);
+    cpi.ApplyFloor(-clip); cpi.ApplyCeiling(clip); cpf.ApplyFloor(-clip); cpf.ApplyCeiling(clip); cpo.ApplyFloor(-clip); cpo.ApplyCeiling(clip);
+    PutMat(NAME2("cWx", step), cWx); PutMat(NAME2("cWrm", step), cWrm);
+    // Update
+    Wx.AddMat(-lr, cWx); Wr.AddMat(-lr, cWr); bias.AddVec(-lr, cb, 1.0);
+    pi.AddVec(-lr, cpi, 1.0); pf.AddVec(-lr, cpf, 1.0); po.AddVec(-lr, cpo, 1.0);
+    Wrm.AddMat(-lr, cWrm);
+    put_params(step + 1);
+  }
+#undef NAME2
+}
+
 // GruStreams: nnet-gru-streams.h:238-450.  Buffer columns z|r|m|g|h; row blocks as above.
 static void Gru() {
   const int T = 5, S = 3, D = 6, H = 7;
@@ -557,6 +658,7 @@ int main(int argc, char **argv) {
   Fsmn();
   XentChain();
   { const int lens[3] = {5, 3, 4}; LstmProjected("bmask", true, false, false, 5, lens); }   // appended last: earlier records unchanged
+  LstmProjectedTrain("lstm2", 6, 8, 48, 64, 32, 0.9f, 0.5f, 0.01f);   // appended behind everything else (round 4)
   std::fclose(g_out);
   return 0;
 }

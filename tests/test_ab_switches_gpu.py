@@ -21,7 +21,7 @@ sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
 import aslp_import
 aslp = aslp_import.load(); aslp.ops.use_torch_stream()
 dev = torch.device("cuda:0")
-S, chunk, T, D, C = 16, 6, 9, 24, 128
+S, chunk, T, D, C = int(os.environ.get("AB_S", "16")), int(os.environ.get("AB_CHUNK", "6")), int(os.environ.get("AB_T", "9")), int(os.environ.get("AB_D", "24")), 128
 proto = ("<NnetProto>\n<BLstmProjectedStreamsLC> <InputDim> %%d <OutputDim> 128 <CellDim> %%d <ParamScale> %%s <ClipGradient> %%s\n</NnetProto>\n" %% (D, C, os.environ.get("AB_PSCALE", "0.05"), os.environ.get("AB_CLIP", "5.0")))
 net = aslp.Nnet.Init(proto, seed=5)
 net.SetTrainOptions(learn_rate=float(os.environ.get("AB_LR", "1e-3")), momentum=0.9)
@@ -139,3 +139,17 @@ def test_xent_wave_per_row_kernel_is_bit_identical(tmp_path):
         return np.load(out)
     a, b = run_x("wave", ASLP_XENT_WAVE="1"), run_x("block")
     assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_lstm_layer_products_from_prepared_planes(tmp_path):
+    """ASLP_LSTM_PLANES=3: the bidirectional layer keeps fp16 planes of its products' operands (layer input, weights, m, dGATES, d_r, r: made by
+    multi-matrix conversion launches, shifted row ranges as windows) and every batched pair product reads them; 1 / 2: only the forward /
+    pre-recurrence ones.  T S, D, C and R are multiples of 64 here so that every product is served.  Same values as the default path to fp32
+    rounding."""
+    shape = {"AB_S": "32", "AB_CHUNK": "5", "AB_T": "8", "AB_D": "64"}
+    base = run(tmp_path, "planes_off", ASLP_LSTM_PLANES="0", **shape)
+    assert np.isfinite(base).all()
+    for level in ("1", "2", "3"):
+        other = run(tmp_path, "planes_" + level, ASLP_LSTM_PLANES=level, **shape)
+        assert np.linalg.norm(other - base) / np.linalg.norm(base) < 1e-5, level
+        assert np.abs(other - base).max() / max(1.0, np.abs(base).max()) < 1e-4, level

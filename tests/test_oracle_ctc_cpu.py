@@ -159,3 +159,33 @@ def test_eesen_restatement_agrees_with_pinned_warpctc(oracle, A, S, T, seed):
         if feas[s]:
             assert np.abs(dg[:in_len[s], s] - wg[:in_len[s], s]).max() < 2e-4
         assert np.all(dg[in_len[s]:, s] == 0)
+
+
+@pytest.mark.parametrize("name", ["small", "grad_a20_t50_l15", "grad_a5_t10_l5_mb65", "ragged", "a128_t200"])
+def test_eesen_restatement_against_reference_output(oracle, name):
+    """The Eesen objective (ctc-loss.cc:115-227, GPU-only in the reference, no output of its own obtainable here) on the softmax of the
+    committed fixtures' activations against what the REFERENCE's Warp-CTC CPU code produced for them (tests/golden/ctc_*.bin: costs and
+    gradients w.r.t. the activations): Eesen's unclipped diff (ctc-loss.cc:180-189, before the +-1 clip) is that gradient and -pzx that
+    cost.  This leans the restatement of row a15 on reference output instead of on another restatement."""
+    g = ctc_golden.load(name)
+    A, S, T = g["A"], g["mb"], g["maxT"]
+    acts = g["acts"].reshape(T * S, A)
+    e = np.exp(acts.astype(np.float64) - acts.max(1, keepdims=True))
+    probs = (e / e.sum(1, keepdims=True)).astype(np.float32)
+    labels, o = [], 0
+    for l in g["label_lengths"]:
+        labels.append([int(v) for v in g["flat_labels"][o:o + l]])
+        o += l
+    diff, pzx = orc_eesen(oracle, probs, labels, g["input_lengths"], T, S, A)
+    # utterances both formulations define: at least one frame, and enough frames for the labels with their repeats (an empty input is
+    # cost 0 for Warp-CTC and "no path" for Eesen's lattice)
+    feas = np.array([t > 0 and len(l) + sum(a == b for a, b in zip(l, l[1:])) <= t for l, t in zip(labels, g["input_lengths"])])
+    fin = np.isfinite(g["costs"]) & (g["costs"] < 1e30) & feas
+    assert fin.any()
+    assert np.allclose(-pzx[fin], g["costs"][fin], rtol=1e-4, atol=1e-4)
+    ref = g["grads"].reshape(T, S, A)
+    dg = diff.reshape(T, S, A)
+    for s_ in range(S):
+        n = int(g["input_lengths"][s_])
+        if fin[s_]:
+            assert np.abs(dg[:n, s_] - ref[:n, s_]).max() < 2e-4, s_

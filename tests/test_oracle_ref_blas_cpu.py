@@ -132,6 +132,35 @@ def test_lstm_family_chains_match_reference_library(oracle, tag, reverse, carrie
         assert close(getattr(gr, n), g["g" + ("b" if k == "bias" else k)], 5e-6), n
 
 
+def test_lstm_two_training_steps_with_momentum_and_clipping_match_reference_library(oracle):
+    """`lstm2` (round 4): two training steps of the projected LSTM at C = 64, R = 32, S = 8 streams, T = 6 with momentum 0.9, element-wise
+    gradient clipping at 0.5 and the component's Update (learn rate 0.01), every operation issued on the reference's library in the order
+    nnet-blstm-projected-streams-lc.h:976-1016, 1085-1098 (= nnet-lstm-projected-streams.h:560-630) issues them.  The oracle's restatement
+    (orc_lstm_grads: corr = grad + mmt corr, clip; W -= lr corr) must land on the same parameters after each step."""
+    g = {k[6:]: v for k, v in cumatrix_golden.load_blas().items() if k.startswith("lstm2_")}
+    Cc, D, R = g["Wx0"].shape[0] // 4, g["Wx0"].shape[1], g["Wr0"].shape[1]
+    S, mmt, clip, lr = 8, 0.9, 0.5, 0.01
+    T = g["in0"].shape[0] // S
+    names = [("w_x", "Wx"), ("w_r", "Wr"), ("bias", "bias"), ("peep_i", "pi"), ("peep_f", "pf"), ("peep_o", "po"), ("w_rm", "Wrm")]
+    d, corr = oracle.LstmDir(D, Cc, R, False, zero=True), oracle.LstmDir(D, Cc, R, False, zero=True)
+    for n, k in names:
+        getattr(d, n)[...] = g[k + "0"]
+    clipped = 0
+    for step in (0, 1):
+        x, od = g["in%d" % step], g["od%d" % step]
+        buf = d.forward(x, T, S)
+        assert close(d.out_of(buf, T, S), g["out%d" % step], 2e-6)
+        dbuf, idf = d.backward(od, T, S, buf)
+        assert close(idf, g["in_diff%d" % step], 5e-6)
+        d.grads(corr, x, T, S, buf, dbuf, mmt, clip)       # corr = grad + mmt * corr, clipped
+        assert close(corr.w_x, g["cWx%d" % step], 5e-6) and close(corr.w_rm, g["cWrm%d" % step], 5e-6)
+        clipped += int((np.abs(g["cWx%d" % step]) == np.float32(clip)).sum())
+        for n, k in names:
+            getattr(d, n)[...] = getattr(d, n) - np.float32(lr) * getattr(corr, n)
+            assert close(getattr(d, n), g["%s%d" % (k, step + 1)], 5e-6), (step, n)
+    assert clipped > 0      # the clip is active in the fixture
+
+
 def test_gru_chain_matches_reference_library(oracle):
     """nnet-gru-streams.h:238-450: forward buffer (z|r|m|g|h), backward buffer, input diff and the four gradients."""
     g = cumatrix_golden.load_blas()

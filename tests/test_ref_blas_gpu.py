@@ -111,6 +111,31 @@ def test_projected_lstm_component_matches_reference_library(aslp, oracle, dev, t
     assert close(net.GetParams(), ref, 5e-6)
 
 
+def test_projected_lstm_two_training_steps_momentum_clip_match_reference_library(aslp, oracle, dev, tmp_path):
+    """`lstm2`: two training steps at C = 64, R = 32, S = 8 streams (sizes the persistent recurrence kernels serve), momentum 0.9, element-wise
+    clipping 0.5, learn rate 0.01, against the parameters the reference's library produces when the update is issued as
+    nnet-blstm-projected-streams-lc.h:976-1016, 1085-1098 issues it (oracle/gen_cumatrix_blas_golden.cpp LstmProjectedTrain)."""
+    g = {k[6:]: v for k, v in cumatrix_golden.load_blas().items() if k.startswith("lstm2_")}
+    Cc, D, R = g["Wx0"].shape[0] // 4, g["Wx0"].shape[1], g["Wr0"].shape[1]
+    S = 8
+    d = oracle.LstmDir(D, Cc, R, False, zero=True)   # container of the fixture's tensors for the model writer (no oracle arithmetic runs)
+    names = (("w_x", "Wx"), ("w_r", "Wr"), ("bias", "bias"), ("peep_i", "pi"), ("peep_f", "pf"), ("peep_o", "po"), ("w_rm", "Wrm"))
+    for n, k in names:
+        getattr(d, n)[...] = g[k + "0"]
+    path = tmp_path / "lstm2.nnet"
+    nnet_io.write_simple_nnet(path, [("<LstmProjectedStreams>", D, R, nnet_io.lstm([d], 0.5, Cc))])
+    net = aslp.Nnet.Read(path)
+    net.SetTrainOptions(learn_rate=0.01, momentum=0.9)
+    for step in (0, 1):
+        net.ResetLstmStreams([1] * S)
+        out = net.Propagate(T(g["in%d" % step], dev)).cpu().numpy()
+        assert close(out, g["out%d" % step], 5e-6), step
+        idf = net.Backpropagate(T(g["od%d" % step], dev), want_in_diff=True).cpu().numpy()
+        assert close(idf, g["in_diff%d" % step], 1e-5), step
+        ref = np.concatenate([g["%s%d" % (k, step + 1)].ravel() for _, k in names])
+        assert close(net.GetParams(), ref, 1e-5), step
+
+
 def test_gru_component_matches_reference_library(aslp, oracle, dev, tmp_path):
     """nnet-gru-streams.h:238-450: output h(1..T), input diff, parameters after one step."""
     g = {k[4:]: v for k, v in cumatrix_golden.load_blas().items() if k.startswith("gru_")}
