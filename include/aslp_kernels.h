@@ -351,6 +351,11 @@ void aslp_softmax_xent_eval(const float *acts, MatrixDim d, const float *tgt, in
  * register-cached row kernel), 0 if only diff was. */
 int aslp_xent_eval_p(const float *net_out, MatrixDim d, const int32_cuda *labels, const float *frame_weights, float *diff, int diff_stride,
                      double *stats_dev, int softmax, const aslp_planes_out *diff_planes);
+/* cudaF_diff_sigmoid which also leaves the planes of its result: |e y (1 - y)| <= max |e| / 4 with max |e| from the n_parts per-workgroup
+ * maxima the producer of e left (aslp_gemm_epilogue.cmax_parts).  The kernel stores the bound to out_planes->slot itself.  Returns 1 if the
+ * planes were written, 0 if only eout was (operands not 16-byte aligned, no maxima). */
+int aslp_diff_sigmoid_p(float *eout, const float *e, const float *y, MatrixDim d, int e_stride, int y_stride, const float *e_max_parts, int n_parts,
+                        const aslp_planes_out *out_planes);
 /* PosteriorToMatrix scatter: mat[row[i]][col[i]] += val[i]  (hmm/posterior.cc, used nnet-loss.cc:168) */
 void aslp_scatter_add(float *mat, MatrixDim d, const int32_cuda *rows, const int32_cuda *cols, const float *vals, int n);
 /* Splice backward (nnet-various.h:143-175): in_diff[t] = sum_k out_diff[clamp(t+off[k])][k-th block] */

@@ -7,6 +7,7 @@
 // grid-strided.  Reference twins are cited by cu-kernels.cu line.
 #include "aslp_kernels.h"
 #include "common.h"
+#include "split16.h"
 
 namespace aslp {
 namespace {
@@ -97,6 +98,37 @@ struct DiffSigmoid { __device__ float operator()(float, float e, float y, int, i
 struct DiffTanh { __device__ float operator()(float, float e, float y, int, int) const { return e * (1.0f - y * y); } };
 struct DiffRelu { __device__ float operator()(float, float in, float od, int, int) const { return in > 0.0f ? od : 0.0f; } };
 struct CopyMat { __device__ float operator()(float, float a, float, int, int) const { return a; } };
+
+// Sigmoid backward which also leaves the fp16 planes of its result (csrc/split16.h): |e y (1 - y)| <= max |e| / 4, and the maxima of |e| come
+// with e from the kernel that wrote it (n_parts per-workgroup values), so the scale is known before the first element is written.  The
+// arithmetic of an element is DiffSigmoid's.  Workgroup 0 stores the bound for the planes' readers.
+__global__ void __launch_bounds__(kBlock) diff_sigmoid_planes_kernel(float *__restrict__ eout, int ldo, const float *__restrict__ e, int lde,
+                                                                     const float *__restrict__ y, int ldy, int rows, int cols4,
+                                                                     const float *__restrict__ e_max_parts, int n_parts, S16Out po) {
+  __shared__ float wm[kBlock / 64];
+  float m = 0.f;
+  for (int i = threadIdx.x; i < n_parts; i += kBlock) m = fmaxf(m, e_max_parts[i]);
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = wm[0];
+  for (int w = 1; w < kBlock / 64; w++) m = fmaxf(m, wm[w]);
+  const float bound = 0.25f * m;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *const_cast<unsigned *>(po.slot) = __float_as_uint(bound);
+  const float s = ldexpf(1.f, s16_exponent(__float_as_uint(bound)));
+  const DiffSigmoid f{};
+  const long n = (long)rows * cols4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cols4), c = (int)(i - (long)r * cols4) * 4;
+    const float4 ev = *reinterpret_cast<const float4 *>(e + (long)r * lde + c), yv = *reinterpret_cast<const float4 *>(y + (long)r * ldy + c);
+    const float4 o = make_float4(f(0.f, ev.x, yv.x, r, c), f(0.f, ev.y, yv.y, r, c + 1), f(0.f, ev.z, yv.z, r, c + 2), f(0.f, ev.w, yv.w, r, c + 3));
+    *reinterpret_cast<float4 *>(eout + (long)r * ldo + c) = o;
+    half4 hi, lo;
+    s16_split4(o, s, &hi, &lo);
+    *reinterpret_cast<half4 *>(po.hi + (long)r * po.ld + c) = hi;
+    *reinterpret_cast<half4 *>(po.lo + (long)r * po.ld + c) = lo;
+  }
+}
 
 // transposed AddMat (rare; cu-kernels.cu:584 A_trans branch)
 __global__ void add_mat_trans_kernel(float alpha, const float *src, float *dst, MatrixDim d, int src_stride) {
@@ -363,6 +395,21 @@ void cudaF_sigmoid(aslp_dim3, aslp_dim3, float *y, const float *x, MatrixDim d, 
 void cudaF_tanh(aslp_dim3, aslp_dim3, float *y, const float *x, MatrixDim d, int src_stride) { launch_map<false>("tanh", y, d, x, src_stride, nullptr, 0, Tanh{}); }
 void cudaF_diff_sigmoid(aslp_dim3, aslp_dim3, float *eout, const float *e, const float *y, MatrixDim d, int e_stride, int y_stride) {
   launch_map<false>("diff_sigmoid", eout, d, e, e_stride, y, y_stride, DiffSigmoid{});
+}
+int aslp_diff_sigmoid_p(float *eout, const float *e, const float *y, MatrixDim d, int e_stride, int y_stride, const float *e_max_parts, int n_parts,
+                        const aslp_planes_out *out_planes) {
+  const bool vec = d.rows > 0 && d.cols > 0 && d.cols % 4 == 0 && d.stride % 4 == 0 && e_stride % 4 == 0 && y_stride % 4 == 0 && aligned16(eout) &&
+                   aligned16(e) && aligned16(y);
+  if (!vec || !e_max_parts || n_parts <= 0 || !out_planes || !out_planes->hi || !out_planes->slot || out_planes->ld < d.cols) {
+    cudaF_diff_sigmoid(aslp_dim3(), aslp_dim3(), eout, e, y, d, e_stride, y_stride);
+    return 0;
+  }
+  S16Out po = {static_cast<h16 *>(out_planes->hi), static_cast<h16 *>(out_planes->lo), out_planes->ld, out_planes->slot, nullptr};
+  const long n = (long)d.rows * (d.cols / 4);
+  hipLaunchKernelGGL(diff_sigmoid_planes_kernel, dim3(grid_for(n)), dim3(kBlock), 0, cur_stream(), eout, d.stride, e, e_stride, y, y_stride, d.rows,
+                     d.cols / 4, e_max_parts, n_parts, po);
+  check_launch("diff_sigmoid_planes");
+  return 1;
 }
 void cudaF_diff_tanh(aslp_dim3, aslp_dim3, float *eout, const float *e, const float *y, MatrixDim d, int e_stride, int y_stride) {
   launch_map<false>("diff_tanh", eout, d, e, e_stride, y, y_stride, DiffTanh{});

@@ -337,7 +337,8 @@ __device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs &g, const f32x
 bool gemm_glds_launch(GemmArgs &g, bool a_kc, bool b_kc, int cfg, int *cfg_used);  // *cfg_used: the tile configuration that ran
 // second half of a split-K product (gemm_glds.hip): C = epilogue(alpha * sum_s part[s] + beta * C), chunks added in order; r: the original
 // product's arguments (pair: the second product's partials follow the first's)
-void gemm_splitk_reduce(const float *part, int split, long stride, const GemmArgs &r);
+// returns the number of workgroups (= per-workgroup maxima left in r.ep.cmax_parts when that is set)
+int gemm_splitk_reduce(const float *part, int split, long stride, const GemmArgs &r);
 // gemm_split16.hip: the same product on the fp16 matrix instruction with two-piece fp32-equivalent operands (A/B: ASLP_GEMM_SPLIT_F16=1).
 // cfg 0 = default tile.  false: not eligible.  Forms ep.colstats itself; ep.colsum stays the caller's.
 bool gemm_split16_enabled();

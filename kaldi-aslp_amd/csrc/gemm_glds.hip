@@ -325,6 +325,10 @@ __global__ void __launch_bounds__(kBlock) splitk_reduce_kernel(const float *__re
     g.C = g.C1; g.ep = g.ep1;
   }
   const long n = (long)g.M * g.N;
+  // what a split-fp16 product leaves for the products that read its output (aslp_gemm_epilogue.planes / cmax_parts): the planes of the
+  // activation output under a bound known before the launch, one maximum of |C| per workgroup
+  const float pscale = (g.ep.planes_of == 2 && g.ep.planes.hi != nullptr && g.ep.act_out != nullptr) ? ldexpf(1.f, s16_exponent(*g.ep.planes.slot)) : 0.f;
+  float cmax = 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int row = (int)(i / g.N), col = (int)(i - (long)row * g.N);
     float acc = part[i];
@@ -336,9 +340,24 @@ __global__ void __launch_bounds__(kBlock) splitk_reduce_kernel(const float *__re
     float v = fmaf(g.alpha, acc, fmaf(g.beta, c_old, bias));  // the epilogue's spelling (gemm_common.h)
     if (g.ep.clip > 0.0f) v = fminf(fmaxf(v, -g.ep.clip), g.ep.clip);
     *cp = v;
+    cmax = fmaxf(cmax, epi_finite_abs(v));
     if (g.ep.W) g.ep.W[(long)row * g.ep.ldw + col] = fmaf(g.ep.w_alpha, v, w_old);
-    if (g.ep.act_out)
-      g.ep.act_out[(long)row * g.ep.ld_act + col] = g.ep.act == 1 ? sigmoid_ref(v) : g.ep.act == 2 ? tanh_ref(v) : g.ep.act == 3 ? fmaxf(v, 0.0f) : v;
+    if (g.ep.act_out) {
+      const float a = g.ep.act == 1 ? sigmoid_ref(v) : g.ep.act == 2 ? tanh_ref(v) : g.ep.act == 3 ? fmaxf(v, 0.0f) : v;
+      g.ep.act_out[(long)row * g.ep.ld_act + col] = a;
+      if (pscale != 0.f) epi_plane_store(g.ep, pscale, a, row, col);
+    }
+  }
+  if (g.ep.cmax_parts != nullptr) {   // (uniform)
+    __shared__ float wmax[kBlock / 64];
+    cmax = wave_max(cmax);
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = cmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float m = wmax[0];
+      for (int w = 1; w < kBlock / 64; w++) m = fmaxf(m, wmax[w]);
+      g.ep.cmax_parts[(long)blockIdx.y * gridDim.x + blockIdx.x] = m;
+    }
   }
 }
 
@@ -381,8 +400,10 @@ bool launch_split(GemmArgs &g, int cfg, int split) {
   return true;
 }
 
-void gemm_splitk_reduce(const float *part, int split, long stride, const GemmArgs &r) {
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for(stride), r.pair ? 2 : 1), dim3(kBlock), 0, cur_stream(), part, split, stride, r);
+int gemm_splitk_reduce(const float *part, int split, long stride, const GemmArgs &r) {
+  const int grid = grid_for(stride);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid, r.pair ? 2 : 1), dim3(kBlock), 0, cur_stream(), part, split, stride, r);
+  return grid * (r.pair ? 2 : 1);   // workgroups = per-workgroup maxima written when r.ep.cmax_parts is set
 }
 
 bool gemm_glds_launch(GemmArgs &g, bool a_kc, bool b_kc, int cfg, int *cfg_used) {

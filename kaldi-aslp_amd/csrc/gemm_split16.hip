@@ -870,8 +870,9 @@ bool gemm_split16_planes_launch(GemmArgs &g, bool a_kc, bool b_kc, const S16View
   const long tiles = (long)((g.M + 63) / 64) * ((g.N + 127) / 128) * (g.pair ? 2 : 1);
   static const int splitk_off = [] { const char *e = getenv("ASLP_GEMM_SPLITK"); return e && atoi(e) == 0; }();
   // (act_out planes asked for by a forward product are given up for the split: the consumer converts the small activation matrix itself)
-  const bool only_act_planes = !g.ep.wmax_parts && !g.ep.cmax_parts && !g.ep.colstats && !g.ep.colsum && g.ep.planes_of == 2 && !g.pair;
-  if (!splitk_off && (!extras || only_act_planes) && (cfg == 0 || cfg == 308) && tiles <= 128 && g.K >= 1024) {
+  // (the second launch writes the planes of an activation output and the maxima of |C| itself: those two requests go with the split)
+  const bool reduce_serves = !g.ep.wmax_parts && !g.ep.colstats && !g.ep.colsum && g.ep.planes_of != 1 && !g.pair;
+  if (!splitk_off && (!extras || reduce_serves) && (cfg == 0 || cfg == 308) && tiles <= 128 && g.K >= 1024) {
     int split = (int)(256 / tiles);
     if (split > g.K / 256) split = g.K / 256;
     if (split > 8) split = 8;
@@ -889,9 +890,8 @@ bool gemm_split16_planes_launch(GemmArgs &g, bool a_kc, bool b_kc, const S16View
         if (launch(pg, 308)) {
           GemmArgs r = g;
           r.split_k = 0;
-          r.ep.planes_of = 0;
-          gemm_splitk_reduce(part, split, stride, r);
-          t_last_parts = 0;
+          const int wgs = gemm_splitk_reduce(part, split, stride, r);
+          t_last_parts = (r.ep.planes_of == 2 || r.ep.cmax_parts) ? wgs : 0;
           return true;
         }
       }

@@ -80,6 +80,7 @@ class AffineTransform : public UpdatableComponent {
     AffineTransform *c = new AffineTransform(*this);
     c->WeightsWritten();   // (planes are not copied)
     c->stats_request_ = nullptr;
+    c->in_diff_maxima_ = nullptr;
     return c;
   }
   ComponentType GetType() const { return kAffineTransform; }
@@ -222,13 +223,25 @@ class AffineTransform : public UpdatableComponent {
     out->AddMatMat(1.0, in, kNoTrans, linearity_, kTrans, 0.0, &ep, pa, pb);
     if (ap && aslp_gemm_last_parts() > 0) ap->Tag(sigmoid_out->Data(), sigmoid_out->Stride(), s16_epochs().fwd);   // (the split-fp16 kernel ran)
   }
+  // Executor peephole (one-shot): a Sigmoid's backward pass reads the next BackpropagateFnc's in-diff and wants the per-workgroup maxima
+  // of it (the scale of ITS result's planes follows from them); they are left in `h`'s maxima array, tagged with the in-diff
+  void LeaveInDiffMaxima(PlaneHolder *h) { in_diff_maxima_ = h; }
   void BackpropagateFnc(const CuMatrixBase &, const CuMatrixBase &, const CuMatrixBase &out_diff, CuMatrixBase *in_diff) {
+    PlaneHolder *mx = in_diff_maxima_;
+    in_diff_maxima_ = nullptr;
     const PlaneSet *pa = nullptr, *pb = nullptr;
     if (gemm_split16_serves(out_diff.NumRows(), input_dim_, output_dim_)) {
       pa = diff_planes_.Of(out_diff, s16_epochs().bwd);
       pb = WeightPlanes();   // (the weights have not moved since the forward pass: Update comes after this)
     }
-    in_diff->AddMatMat(1.0, out_diff, kNoTrans, linearity_, kNoTrans, 0.0, nullptr, pa, pb);  // :193-197
+    aslp_gemm_epilogue ep = aslp_gemm_epilogue();
+    const bool want_max = mx && pa && pb && mx->get().Reserve(in_diff->NumRows(), in_diff->NumCols());
+    if (want_max) ep.cmax_parts = mx->get().Parts();
+    in_diff->AddMatMat(1.0, out_diff, kNoTrans, linearity_, kNoTrans, 0.0, want_max ? &ep : nullptr, pa, pb);  // :193-197
+    if (want_max) {
+      const int n = aslp_gemm_last_parts();
+      if (n > 0) mx->get().TagParts(in_diff->Data(), n, s16_epochs().bwd);
+    }
   }
   void Update(const CuMatrixBase &input, const CuMatrixBase &diff) {  // :200-245
     const BaseFloat lr = opts_.learn_rate * learn_rate_coef_;
@@ -300,6 +313,7 @@ class AffineTransform : public UpdatableComponent {
 
  private:
   CuVectorD *stats_request_ = nullptr;
+  PlaneHolder *in_diff_maxima_ = nullptr;
   PlaneHolder in_planes_, diff_planes_, w_planes_;
   // weights' planes kept from step to step (Update): valid flag, the parameter epoch they belong to, per-workgroup maxima of |W| and
   // |W_corr| in two alternating arrays (one is read by the bound kernel while the epilogue fills the other)
@@ -375,10 +389,33 @@ class BlockSoftmax : public Component {  // :64-143
 class Sigmoid : public Component {
  public:
   Sigmoid(int32 di, int32 dout) : Component(di, dout) {}
-  Component *Copy() const { return new Sigmoid(*this); }
+  Component *Copy() const { Sigmoid *c = new Sigmoid(*this); c->in_diff_planes_ = nullptr; return c; }
   ComponentType GetType() const { return kSigmoid; }
   void PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) { out->Sigmoid(in); }
-  void BackpropagateFnc(const CuMatrixBase &, const CuMatrixBase &out, const CuMatrixBase &od, CuMatrixBase *id) { id->DiffSigmoid(out, od); }
+  // Executor peephole (one-shot): the AffineTransform that reads the next BackpropagateFnc's in-diff as ITS out-diff wants the fp16 planes
+  // of it (csrc/split16.h), and `h` already holds the maxima of this pass' out-diff (AffineTransform::LeaveInDiffMaxima above):
+  // |od y (1 - y)| <= max |od| / 4, so the same launch writes in-diff and planes.
+  void ProduceInDiffPlanes(PlaneHolder *h) { in_diff_planes_ = h; }
+  void BackpropagateFnc(const CuMatrixBase &, const CuMatrixBase &out, const CuMatrixBase &od, CuMatrixBase *id) {
+    PlaneHolder *h = in_diff_planes_;
+    in_diff_planes_ = nullptr;
+    const long epoch = s16_epochs().bwd;
+    const int np = h ? h->get().PartsFor(od.Data(), epoch) : 0;
+    if (np > 0 && h->get().Reserve(id->NumRows(), id->NumCols())) {
+      aslp_planes_out po = aslp_planes_out();
+      aslp_planes_as_output(reinterpret_cast<const aslp_planes *>(&h->get()), &po);
+      h->get().ForgetHostBound();   // (the kernel stores the bound)
+      if (aslp_diff_sigmoid_p(id->Data(), od.Data(), out.Data(), id->Dim(), od.Stride(), out.Stride(), h->get().Parts(), np, &po))
+        h->get().Tag(id->Data(), id->Stride(), epoch);
+      char err[512];
+      if (aslp_get_last_error(err, sizeof(err))) ASLP_ERR << err;
+      return;
+    }
+    id->DiffSigmoid(out, od);
+  }
+
+ private:
+  PlaneHolder *in_diff_planes_ = nullptr;
 };
 class Tanh : public Component {
  public:

@@ -300,6 +300,22 @@ void Nnet::Backpropagate(const std::vector<const CuMatrixBase *> &out_diff, std:
         dynamic_cast<BatchNormalization *>(components_[i])->FoldNextUpdateIntoBackprop();
         dynamic_cast<BatchNormalization *>(components_[i])->BackpropagateWithSigmoid(*in_view_[i], output_buf_[fs], output_diff_buf_[fs], target);
       } else {
+        // AffineTransform <- Sigmoid <- AffineTransform (a sigmoid layer without BatchNormalization): the upper product leaves the maxima
+        // of its in-diff, from which the Sigmoid's backward pass knows the scale of the lower layer's out-diff planes before it writes them
+        if (fuse_layers_ && alias_links_ && !is_input && direct[i]) {
+          const int32 below = components_[i]->GetInput()[0];
+          const int32 sig = components_[i]->GetType() == Component::kAffineTransform ? below : i;
+          if (components_[sig]->GetType() == Component::kSigmoid && !folded[sig] && direct[sig]) {
+            const int32 lower = components_[sig]->GetInput()[0];
+            if (components_[lower]->GetType() == Component::kAffineTransform) {
+              AffineTransform *lo = dynamic_cast<AffineTransform *>(components_[lower]);
+              if (gemm_split16_serves(lo->OutputDim(), lo->InputDim(), num_frame)) {
+                if (sig == i) dynamic_cast<Sigmoid *>(components_[i])->ProduceInDiffPlanes(&lo->DiffPlanes());
+                else dynamic_cast<AffineTransform *>(components_[i])->LeaveInDiffMaxima(&lo->DiffPlanes());
+              }
+            }
+          }
+        }
         if (fuse_layers_) components_[i]->FoldNextUpdateIntoBackprop();
         if (overlap_updates && components_[i]->PersistentRecurrence() && i != lowest_updatable) components_[i]->GradientsBesideLowerLayers();
         if (!want_in_diff && (is_input || feeds_only_input)) components_[i]->InDiffUnusedInNextBackprop();  // here for its gradients only

@@ -38,6 +38,19 @@ std::unique_ptr<aslp::IWorker> MakeWorker(const std::string &type, aslp::Comm *c
 // the worker calls IWorker::Synchronize.  The reference is started by mpirun and syncs through MPI on host copies; this
 // one syncs through RCCL on the device buffers and takes its rank from the launcher's environment (OMPI_COMM_WORLD_*,
 // PMI_*, RANK / WORLD_SIZE) or from --rank / --num-workers, with --comm-file as the rendezvous point.
+// The device of rank `rank` of `num_workers`: --gpu-id if given; one GPU per rank for the RCCL transport; over shared memory (where ranks
+// may share GPUs) rank modulo the number of devices this box has; a single worker lets --use-gpu decide.
+static void SelectWorkerDevice(int gpu_id, int rank, int num_workers, const std::string &comm_transport, const std::string &use_gpu) {
+  using namespace aslp;
+  if (gpu_id >= 0) { CuDevice::Instantiate().SetGpuId(gpu_id); return; }
+  if (num_workers <= 1) { CuDevice::Instantiate().SelectGpuId(use_gpu); return; }
+  std::string t = comm_transport;
+  if (t.empty() && getenv("ASLP_COMM_TRANSPORT") != nullptr) t = getenv("ASLP_COMM_TRANSPORT");
+  int ndev = 1;
+  if (t == "shm" && (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)) ndev = 1;
+  CuDevice::Instantiate().SetGpuId(t == "shm" ? rank % ndev : rank);
+}
+
 int Main_aslp_nnet_train_frame_worker(int argc, char *argv[]) {
   using namespace aslp;
   try {
@@ -91,9 +104,7 @@ int Main_aslp_nnet_train_frame_worker(int argc, char *argv[]) {
                 target_model_filename = po.GetArg(4);
 
     RankFromEnvironment(&rank, &num_workers);
-    if (gpu_id >= 0) CuDevice::Instantiate().SetGpuId(gpu_id);
-    else if (num_workers > 1) CuDevice::Instantiate().SetGpuId(rank);  // one process per GPU of the node
-    else CuDevice::Instantiate().SelectGpuId(use_gpu);
+    SelectWorkerDevice(gpu_id, rank, num_workers, comm_transport, use_gpu);
     // the communicator before the model: RCCL initialised after the first allocations / launches leaves every later step
     // slower on this stack (measured: 1.44 vs 2.39 ms/step on the cfg2 DNN)
     std::unique_ptr<Comm> comm(NewProcessComm(comm_transport, rank, num_workers, comm_file));
@@ -233,9 +244,7 @@ int Main_aslp_nnet_train_lstm_stream_worker(int argc, char *argv[]) {
     std::string target_model_filename;
     if (!crossvalidate) target_model_filename = po.GetArg(4);
     RankFromEnvironment(&rank, &num_workers);
-    if (gpu_id >= 0) CuDevice::Instantiate().SetGpuId(gpu_id);
-    else if (num_workers > 1) CuDevice::Instantiate().SetGpuId(rank);
-    else CuDevice::Instantiate().SelectGpuId(use_gpu);
+    SelectWorkerDevice(gpu_id, rank, num_workers, comm_transport, use_gpu);
     // the communicator before the model (see aslp-nnet-train-frame-worker)
     std::unique_ptr<Comm> comm(NewProcessComm(comm_transport, rank, num_workers, comm_file));
 
@@ -400,9 +409,7 @@ int Main_aslp_nnet_train_lc_blstm_streams_worker(int argc, char *argv[]) {
 
     if (crossvalidate) ASLP_ERR << "the worker tools train only (use aslp-nnet-train-blstm-streams-lc --cross-validate=true)";
     RankFromEnvironment(&rank, &num_workers);
-    if (gpu_id >= 0) CuDevice::Instantiate().SetGpuId(gpu_id);
-    else if (num_workers > 1) CuDevice::Instantiate().SetGpuId(rank);
-    else CuDevice::Instantiate().SelectGpuId(use_gpu);
+    SelectWorkerDevice(gpu_id, rank, num_workers, comm_transport, use_gpu);
     // the communicator before the model: RCCL initialised after the first allocations / launches leaves every later step
     // slower on this stack (measured: 1.44 vs 2.39 ms/step on the cfg2 DNN)
     std::unique_ptr<Comm> comm(NewProcessComm(comm_transport, rank, num_workers, comm_file));
@@ -594,9 +601,7 @@ int Main_aslp_nnet_train_server(int argc, char *argv[]) {
     std::string model_filename = po.GetArg(1), target_model_filename = po.GetArg(2);
     RankFromEnvironment(&rank, &num_workers);
     if (rank != 0) ASLP_ERR << "the parameter server is rank 0 of the group (got rank " << rank << ")";
-    if (gpu_id >= 0) CuDevice::Instantiate().SetGpuId(gpu_id);
-    else if (num_workers > 1) CuDevice::Instantiate().SetGpuId(rank);
-    else CuDevice::Instantiate().SelectGpuId(use_gpu);
+    SelectWorkerDevice(gpu_id, rank, num_workers, comm_transport, use_gpu);
     std::unique_ptr<Comm> comm(NewProcessComm(comm_transport, rank, num_workers, comm_file));
 
     Nnet nnet;
@@ -644,10 +649,7 @@ class PairSimpleSync : public SimpleSync {
     using namespace aslp;
     RankFromEnvironment(&rank_, &num_workers_);
     if (num_workers_ != 2) ASLP_ERR << "num of jobs must be 2";
-    const bool shm = getenv("ASLP_COMM_TRANSPORT") != nullptr && std::string(getenv("ASLP_COMM_TRANSPORT")) == "shm";
-    int ndev = 1;
-    if (shm && (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)) ndev = 1;
-    CuDevice::Instantiate().SetGpuId(shm ? rank_ % ndev : rank_);   // one GPU per rank; over shared memory the two ranks may share one
+    SelectWorkerDevice(-1, rank_, num_workers_, "", "yes");   // one GPU per rank; over shared memory the two ranks may share one
     comm_.reset(NewProcessComm("", rank_, num_workers_, comm_file_));
     pair_.reset(new PairSync(comm_.get()));
   }

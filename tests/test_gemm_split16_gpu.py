@@ -183,11 +183,13 @@ def _bn_dnn_proto(hidden=1024, layers=3, out=3000, bn=True):
                     "<Softmax> <InputDim> %d <OutputDim> %d\n</NnetProto>\n" % (d, out, out, out))
 
 
-@pytest.mark.parametrize("mmt,bn", [(0.0, True), (0.9, True), (0.9, False)])
-def test_weight_planes_kept_from_step_to_step(aslp, dev, mmt, bn):
+@pytest.mark.parametrize("mmt,bn,mb", [(0.0, True, 1024), (0.9, True, 1024), (0.9, False, 1024), (0.0, False, 256), (0.9, False, 256)])
+def test_weight_planes_kept_from_step_to_step(aslp, dev, mmt, bn, mb):
     """The weight-gradient product's epilogue writes the updated weights' planes (under a bound of |W - lr dW| known before the launch) and
     the next step's forward and in-diff products read them: six steps agree with six steps that convert the weights anew every time, and
-    with the fp32 instruction, like two fp32 summation orders do"""
+    with the fp32 instruction, like two fp32 summation orders do.  Without BatchNormalization the sigmoid layers' planes come from the
+    forward epilogue and from the Sigmoid's backward pass (scale from the maxima the in-diff product leaves); at minibatch 256 the layer
+    products split K over workgroups and their second launch writes planes and maxima."""
     runs = {}
     try:
         for name, split, keep in (("fp32", 0, 0), ("convert", 1, 0), ("kept", 1, 1)):
@@ -198,8 +200,8 @@ def test_weight_planes_kept_from_step_to_step(aslp, dev, mmt, bn):
             xe = aslp.Xent()
             g = torch.Generator(device="cpu").manual_seed(5)
             for step in range(6):
-                x = torch.randn(1024, 440, generator=g).to(dev)
-                lab = torch.randint(0, 3000, (1024,), generator=g, dtype=torch.int32).to(dev)
+                x = torch.randn(mb, 440, generator=g).to(dev)
+                lab = torch.randint(0, 3000, (mb,), generator=g, dtype=torch.int32).to(dev)
                 net.TrainStepXent(xe, x, lab)
             st = xe.GetStats()
             runs[name] = ((st["loss"] - st["entropy"]) / st["frames"], np.asarray(net.GetParams(), np.float32))
