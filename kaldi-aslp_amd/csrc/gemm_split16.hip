@@ -238,12 +238,26 @@ __device__ __forceinline__ float s16_frag_sum(float sum, const half8 hi, const h
 
 // ---- the product ---------------------------------------------------------------------------------------------------------------
 struct S16Operands { S16View a, b, a1, b1; int kp; };   // a1 / b1: second product of a pair (blockIdx.z == 1)
+// one of two views, member by member: assigning a whole struct under a condition makes hipcc park both in scratch memory (88 bytes per
+// lane and a private segment on every product kernel)
+__device__ __forceinline__ S16View s16_pick(bool second, const S16View &x, const S16View &y) {
+  S16View v;
+  v.hi = second ? +y.hi : +x.hi;
+  v.lo = second ? +y.lo : +x.lo;
+  v.ld = second ? +y.ld : +x.ld;
+  v.rows = second ? +y.rows : +x.rows;
+  v.cols = second ? +y.cols : +x.cols;
+  v.slot = second ? +y.slot : +x.slot;
+  return v;
+}
 
 // ABL (devtools/micro/s16_ablate.hip only; 0 in the library): 1 = no MFMA, 2 = no DMA, 4 = no LDS reads -- wrong results, for timing
 // EXTRA: the epilogue also leaves planes / maxima of its output (aslp_gemm_epilogue.planes, *_parts); a variant of its own because the
 // extra epilogue state costs the 128 x 128 tile its last registers.
 template <int BM, int BN, int WGM, int WGN, int NS, bool A_KC, bool B_KC, int ABL = 0, bool EXTRA = false>
-__global__ void __launch_bounds__(64 * WGM * WGN) gemm_s16_glds(GemmArgs g, S16Operands ops) {
+__global__ void __launch_bounds__(64 * WGM * WGN)
+    __attribute__((amdgpu_waves_per_eu(1, (NS * 2 * (BM + BN) * 128 > 80 * 1024 && WGM * WGN <= 4) ? 1 : 2)))   // (LDS already limits those to one wave per SIMD: all 512 registers are theirs)
+    gemm_s16_glds(GemmArgs g, S16Operands ops) {
   constexpr int NW = WGM * WGN;
   constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
   // a stage, in bytes (every plane tile is 64 halves x BR rows whichever way it lies): A_hi | A_lo | B_hi | B_lo
@@ -256,7 +270,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_s16_glds(GemmArgs g, S16O
   constexpr int NRH = 2 * (TM * RA + TN * RB);                    // reads per instruction k step
   constexpr int NM = KH * 3 * TM * TN, NRD = KH * NRH, SB = NM / 2 - 1;
   constexpr int UNROLL = (NS % 2 == 0) ? NS : 2 * NS;
-  static_assert(G <= SB + 1, "not enough MFMA slots before the barrier");
+  static_assert(G <= 2 * (SB + 1), "not enough MFMA slots before the barrier");
   static_assert(A_KC || BM == 32 || BM == 64 || BM == 128, "KS image: 32, 64 or 128 columns");
   static_assert(B_KC || BN == 32 || BN == 64 || BN == 128, "KS image: 32, 64 or 128 columns");
   extern __shared__ __attribute__((aligned(1024))) float lds[];
@@ -264,11 +278,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_s16_glds(GemmArgs g, S16O
   lds_char *lds3 = (lds_char *)(__attribute__((address_space(3))) void *)lds;
   const char *ldsb = reinterpret_cast<const char *>(lds);
 
-  S16View va = ops.a, vb = ops.b;
-  if (g.pair && blockIdx.z == 1) {  // second product of a pair (uniform)
-    g.C = g.C1; g.ep = g.ep1;
-    va = ops.a1; vb = ops.b1;
-  }
+  const bool second = g.pair && blockIdx.z == 1;   // second product of a pair (uniform)
+  if (second) { g.C = g.C1; g.ep = g.ep1; }
+  const S16View va = s16_pick(second, ops.a, ops.a1), vb = s16_pick(second, ops.b, ops.b1);
   int tm, tn;
   xcd_tile<BM, BN>(g, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
@@ -290,14 +302,18 @@ __global__ void __launch_bounds__(64 * WGM * WGN) gemm_s16_glds(GemmArgs g, S16O
   static_for<0, G>([&](auto U_) {
     constexpr int u = decltype(U_)::value;
     const int slot = wave + u * NW;  // wave-uniform
-    // plane order inside a stage: A_hi [0, SLOTS_A), A_lo, B_hi [2 SLOTS_A, ...), B_lo
-    const bool is_a = slot < 2 * SLOTS_A;
-    const int s2 = is_a ? slot : slot - 2 * SLOTS_A, per = is_a ? SLOTS_A : SLOTS_B;
-    const bool lo_plane = s2 >= per;
-    const int sr = lo_plane ? s2 - per : s2;   // unit within the plane tile
-    // (field by field: a reference to "va or vb" would put both structs into scratch memory)
-    const h16 *base = is_a ? (lo_plane ? va.lo : va.hi) : (lo_plane ? vb.lo : vb.hi);
-    const int v_ld = is_a ? va.ld : vb.ld, v_rows = is_a ? va.rows : vb.rows;
+    // plane order inside a stage: A_hi [0, SLOTS_A), A_lo, B_hi [2 SLOTS_A, ...), B_lo.  The plane tiles' unit counts are multiples of
+    // the wave count, so WHICH plane unit u of a wave belongs to is a compile-time fact: choosing va / vb members under a run-time
+    // condition makes hipcc select between their ADDRESSES, which parks both views in scratch memory (a private segment per launch)
+    static_assert(SLOTS_A % NW == 0 && SLOTS_B % NW == 0, "a wave's DMA unit must not straddle planes");
+    constexpr bool is_a = u * NW < 2 * SLOTS_A;
+    constexpr int s2c = is_a ? u * NW : u * NW - 2 * SLOTS_A, per = is_a ? SLOTS_A : SLOTS_B;
+    constexpr bool lo_plane = s2c >= per;
+    const int sr = (lo_plane ? s2c - per : s2c) + wave;   // unit within the plane tile
+    const h16 *base;
+    int v_ld, v_rows;
+    if constexpr (is_a) { v_ld = va.ld; v_rows = va.rows; if constexpr (lo_plane) base = va.lo; else base = va.hi; }
+    else { v_ld = vb.ld; v_rows = vb.rows; if constexpr (lo_plane) base = vb.lo; else base = vb.hi; }
     const int rows_p = (v_rows + kS16Pad - 1) / kS16Pad * kS16Pad;
     auto kc_src = [&](int first_row) {
       const int r = lane >> 3;
@@ -505,11 +521,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lds;
   lds_char *lds3 = (lds_char *)(__attribute__((address_space(3))) void *)lds;
 
-  S16View va = ops.a, vb = ops.b;
-  if (g.pair && blockIdx.z == 1) {  // second product of a pair (uniform)
-    g.C = g.C1; g.ep = g.ep1;
-    va = ops.a1; vb = ops.b1;
-  }
+  const bool second = g.pair && blockIdx.z == 1;   // second product of a pair (uniform)
+  if (second) { g.C = g.C1; g.ep = g.ep1; }
+  const S16View va = s16_pick(second, ops.a, ops.a1), vb = s16_pick(second, ops.b, ops.b1);
   int tm, tn;
   xcd_tile<BM, BN>(g, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
@@ -522,11 +536,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
   int adv[G];
   static_for<0, G>([&](auto U_) {
     constexpr int u = decltype(U_)::value;
-    const int unit = wave + u * NW;   // wave-uniform, 0 .. 31
-    const int plane = unit >> 3, sub = unit & 7;
-    const bool is_a = plane < 2, lo_plane = plane & 1;
-    const h16 *base = is_a ? (lo_plane ? va.lo : va.hi) : (lo_plane ? vb.lo : vb.hi);
-    const int v_ld = is_a ? va.ld : vb.ld;
+    // (8 units per plane, 4 waves: the plane of a wave's unit u is a compile-time fact -- see gemm_s16_glds)
+    constexpr int plane = (u * NW) >> 3;
+    const int sub = (wave + u * NW) & 7;
+    constexpr bool is_a = plane < 2, lo_plane = (plane & 1) != 0;
+    const h16 *base;
+    int v_ld;
+    if constexpr (is_a) { v_ld = va.ld; if constexpr (lo_plane) base = va.lo; else base = va.hi; }
+    else { v_ld = vb.ld; if constexpr (lo_plane) base = vb.lo; else base = vb.hi; }
     const int krow = sub * 4 + (lane >> 4);
     const int c = (lane & 15) ^ (4 * (krow & 3));   // the 64-byte column groups of a k row, XOR-swizzled with the row's low bits
     int col = (is_a ? m0 : n0) + 8 * c;
@@ -693,10 +710,19 @@ bool launch_s16_layout(GemmArgs &g, const S16Operands &ops, int cfg) {
       return true;
     }
   }
-  if (cfg == 0 || !(A_KC && B_KC) || extra)
-    cfg = (!extra && A_KC && B_KC && (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * (g.pair ? 2 : 1) >= 224) ? 311 : 308;
+  // (the 128 x 128 tile, cfg 311, only where it is asked for by number: with the operands as prepared planes the 64 x 128 tile is level with
+  // it at 2048^3 ... 8192 x 2048 x 2048 (57.4 / 220.8 against 57.8 / 222.3 us), ahead wherever 128 x 128 leaves a ragged last round
+  // (1920 x 3000 x 1024: 48.5 against 58.1 us) and 1 % behind at 4096^3)
+  if (cfg != 304 && cfg != 305 && (cfg == 0 || !(A_KC && B_KC) || extra)) cfg = 308;
   switch (cfg) {
     case 311: if constexpr (A_KC && B_KC) launch_s16<128, 128, 2, 2, 2, true, true>(g, ops); break;
+    case 304:   // 32 x 64, two waves: 256 workgroups for a 256 x 2048 output with the whole reduction in one launch
+      if (extra) launch_s16<32, 64, 1, 2, 3, A_KC, B_KC, 0, true>(g, ops);
+      else launch_s16<32, 64, 1, 2, 3, A_KC, B_KC>(g, ops);
+      break;
+    case 305:   // (tuning aid: the same with four stages)
+      if constexpr (A_KC) { if (!extra) { launch_s16<32, 64, 1, 2, 4, A_KC, B_KC>(g, ops); break; } }
+      return false;
     case 308:
       if (extra) launch_s16<64, 128, 2, 2, 3, A_KC, B_KC, 0, true>(g, ops);
       else launch_s16<64, 128, 2, 2, 3, A_KC, B_KC>(g, ops);
@@ -872,6 +898,11 @@ bool gemm_split16_planes_launch(GemmArgs &g, bool a_kc, bool b_kc, const S16View
   // (act_out planes asked for by a forward product are given up for the split: the consumer converts the small activation matrix itself)
   // (the second launch writes the planes of an activation output and the maxima of |C| itself: those two requests go with the split)
   const bool reduce_serves = !g.ep.wmax_parts && !g.ep.colstats && !g.ep.colsum && g.ep.planes_of != 1 && !g.pair;
+  // ... unless 32 x 64 tiles fill the chip in ONE round with the whole reduction (256 x 2048 outputs: 15.2 us against 19.4 us for the
+  // two launches of the split; the epilogue, with whatever it was asked to leave, stays in the product's launch)
+  static const int small_off = [] { const char *e = getenv("ASLP_GEMM_S16_SMALL"); return e && atoi(e) == 0; }();   // A/B switch
+  const long t32 = (long)((g.M + 31) / 32) * ((g.N + 63) / 64) * (g.pair ? 2 : 1);
+  if (!small_off && cfg == 0 && tiles <= 64 && t32 <= 256 && g.K >= 1024) return launch(g, 304);
   if (!splitk_off && (!extras || reduce_serves) && (cfg == 0 || cfg == 308) && tiles <= 128 && g.K >= 1024) {
     int split = (int)(256 / tiles);
     if (split > g.K / 256) split = g.K / 256;
@@ -941,7 +972,7 @@ int gemm_split16_last_parts() { return t_last_parts; }
 int gemm_split16_last_tile() { return t_last_cfg_s16; }
 void gemm_split16_reset_last_parts() { t_last_parts = 0; }
 // most per-workgroup maxima a split-fp16 product of this output shape leaves (the caller's arrays must hold them)
-int gemm_split16_max_parts(int M, int N) { return ((M + 63) / 64) * ((N + 127) / 128); }
+int gemm_split16_max_parts(int M, int N) { return std::max(((M + 63) / 64) * ((N + 127) / 128), ((M + 31) / 32) * ((N + 63) / 64) <= 256 ? ((M + 31) / 32) * ((N + 63) / 64) : 0); }
 
 }  // namespace aslp
 

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
-SPLIT_TILES = (308, 311, 328)   # gemm_s16_glds 64x128 / 128x128, gemm_s16_ks128 (csrc/gemm_split16.hip)
+SPLIT_TILES = (304, 308, 311, 328)   # gemm_s16_glds 32x64 / 64x128 / 128x128, gemm_s16_ks128 (csrc/gemm_split16.hip)
 
 
 @pytest.fixture(autouse=True)
@@ -50,6 +50,30 @@ def test_as_accurate_as_the_fp32_instruction(aslp, dev, tA, tB, M, N, K):
     again = torch.zeros_like(c16)
     aslp.ops.sgemm(tA, tB, 1.0, A, B, 0.0, again)
     assert torch.equal(again, c16)
+
+
+@pytest.mark.parametrize("tB", [1, 0])
+def test_minibatch_256_products_run_whole_on_small_tiles(aslp, dev, tB):
+    """256 x 2048 outputs with a long reduction: 256 workgroups of 32 x 64 (tile 304) carry the whole K in one launch instead of K chunks +
+    a second launch.  Same k order and instruction sequence per output element as the 64 x 128 tile: the rows are bit-identical to the
+    same rows inside a 1024-row product"""
+    g = torch.Generator(device=dev).manual_seed(77 + tB)
+    A = torch.randn(1024, 2048, device=dev, generator=g)
+    B = torch.randn(2048, 2048, device=dev, generator=g) * 0.03
+    aslp.lib.aslp_gemm_split16(1)
+    pA, pB = aslp.ops.Planes(A), aslp.ops.Planes(B)
+    big = torch.zeros(1024, 2048, device=dev)
+    aslp.ops.sgemm_planes(0, tB, 1.0, A, pA, B, pB, 0.0, big)
+    assert aslp.lib.aslp_gemm_last_tile() == 308
+    A4 = A[:256].contiguous()
+    pA4 = aslp.ops.Planes(A4)
+    small = torch.zeros(256, 2048, device=dev)
+    aslp.ops.sgemm_planes(0, tB, 1.0, A4, pA4, B, pB, 0.0, small)
+    assert aslp.lib.aslp_gemm_last_tile() == 304
+    assert err_vs_double(small, A4, B, 0, tB) <= 2.5e-7
+    # (the 256 rows' own maximum may give their planes another power-of-two scale than the 1024 rows': exact either way, so the bits agree
+    # whenever no piece leaves fp16's normal range -- N(0, 1) data)
+    assert torch.equal(small, big[:256])
 
 
 @pytest.mark.parametrize("M,N,K", [(1024, 2048, 2048), (1000, 3000, 440), (256, 2048, 2048), (1920, 512, 2048), (132, 260, 68), (1088, 1984, 1028)])
