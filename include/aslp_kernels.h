@@ -222,7 +222,9 @@ int aslp_gemm_last_parts(void);
 void aslp_weight_bound(const float *w_parts, int n_w, const float *c_parts, int n_c, const aslp_planes *a, const aslp_planes *b, int K,
                        float alpha, float beta, float w_alpha, float clip, aslp_planes *w_planes);
 /* Parameters were written through the raw pointers of GetGpuParams (model averaging, a test perturbing weights): planes of weights the
- * components keep from step to step are stale from here on.  The native sync workers call it after every exchange. */
+ * components keep from step to step are stale from here on.  The native sync workers call it before and after every exchange.  It also makes
+ * the calling thread's stream wait for weight updates its latest backward pass left running on the side stream (Nnet::Backpropagate puts
+ * that wait off into the next forward pass): call it on the training thread BEFORE reading or writing parameters through raw pointers. */
 void aslp_params_changed(void);
 /* A/B switch (ASLP_KEEP_WEIGHT_PLANES): 0 = the components convert their weights in every step instead of keeping the planes the
  * weight-gradient epilogue wrote; -1 = back to the environment's choice (default on) */

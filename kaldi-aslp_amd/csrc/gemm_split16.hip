@@ -902,7 +902,10 @@ bool gemm_split16_planes_launch(GemmArgs &g, bool a_kc, bool b_kc, const S16View
   // two launches of the split; the epilogue, with whatever it was asked to leave, stays in the product's launch)
   static const int small_off = [] { const char *e = getenv("ASLP_GEMM_S16_SMALL"); return e && atoi(e) == 0; }();   // A/B switch
   const long t32 = (long)((g.M + 31) / 32) * ((g.N + 63) / 64) * (g.pair ? 2 : 1);
-  if (!small_off && cfg == 0 && tiles <= 64 && t32 <= 256 && g.K >= 1024) return launch(g, 304);
+  // (with planes / maxima to leave, from K = 256: there the 64 x 128 tile's launch, 64 workgroups each with a long epilogue, is the slower
+  // one -- the 440-input layer of the minibatch-256 net 18.6 against 25.7 us; a plain product of that shape is faster on 64 x 128: 9.7 / 12.6)
+  const bool leaves = g.ep.planes_of != 0 || g.ep.wmax_parts || g.ep.cmax_parts;
+  if (!small_off && cfg == 0 && tiles <= 64 && t32 <= 256 && g.K >= (leaves ? 256 : 1024)) return launch(g, 304);
   if (!splitk_off && (!extras || reduce_serves) && (cfg == 0 || cfg == 308) && tiles <= 128 && g.K >= 1024) {
     int split = (int)(256 / tiles);
     if (split > g.K / 256) split = g.K / 256;
@@ -978,7 +981,10 @@ int gemm_split16_max_parts(int M, int N) { return std::max(((M + 63) / 64) * ((N
 
 extern "C" {
 void aslp_keep_weight_planes(int on) { aslp::g_keep_override = on < 0 ? -1 : (on != 0); }
-void aslp_params_changed(void) { aslp::g_param_epoch.fetch_add(1, std::memory_order_relaxed); }
+void aslp_params_changed(void) {
+  aslp::join_side_stream();   // weight updates the calling thread's latest backward pass left running beside it (Nnet::Backpropagate): the caller is about to touch the parameters
+  aslp::g_param_epoch.fetch_add(1, std::memory_order_relaxed);
+}
 void aslp_gemm_split16(int on) { aslp::g_split16_override = on < 0 ? -1 : (on != 0); }
 int aslp_gemm_last_parts(void) { return aslp::gemm_split16_last_parts(); }
 void aslp_weight_bound(const float *w_parts, int n_w, const float *c_parts, int n_c, const aslp_planes *a, const aslp_planes *b, int K, float alpha,

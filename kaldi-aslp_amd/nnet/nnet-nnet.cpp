@@ -92,6 +92,9 @@ void Nnet::Propagate(const std::vector<const CuMatrixBase *> &in, std::vector<Cu
   std::vector<char> done(components_.size(), 0);  // Sigmoids already produced by the BatchNormalization in front of them
   for (int32 i = 0; i < (int32)components_.size(); i++) {
     if (done[i]) continue;
+    // weight updates of the previous backward pass may still be running on the side stream (Backpropagate): the main stream waits for
+    // them in front of the first component that touches what they read or write
+    if (i >= first_after_updates_) JoinUpdates();
     if (components_[i]->GetType() != Component::kInputLayer) {
       const std::vector<int32> &input_idx = components_[i]->GetInput();
       const std::vector<int32> &offset = components_[i]->GetOffset();
@@ -149,6 +152,7 @@ void Nnet::Propagate(const std::vector<const CuMatrixBase *> &in, std::vector<Cu
     propagate_time_[i].first = Component::TypeToMarker(components_[i]->GetType());
     propagate_time_[i].second += tim1.Elapsed();
   }
+  JoinUpdates();
   if (out != NULL)
     for (size_t i = 0; i < output_.size(); i++) *((*out)[i]) = *out_view_[output_[i]];
   // the caller's input may go away: Update() of the consumers reads InputLayer's OUTPUT copy
@@ -223,6 +227,7 @@ void Nnet::BackpropagateFromLossDiff() {
 
 void Nnet::Backpropagate(const std::vector<const CuMatrixBase *> &out_diff, std::vector<CuMatrix *> *in_diff) {  // :108-154
   ASLP_ASSERT(out_diff.size() == output_.size());
+  JoinUpdates();
   int num_frame = out_diff[0]->NumRows();
   const int32 N = NumComponents();
   // the forward buffers as Propagate left them; every diff buffer new (the loss's diff may already carry planes under the epoch
@@ -346,13 +351,42 @@ void Nnet::Backpropagate(const std::vector<const CuMatrixBase *> &out_diff, std:
       }
     }
   }
-  join_side_stream();
+  // The main stream has to wait for the side stream's updates before anything reads the weights -- or overwrites what the updates still
+  // read: the forward buffers and planes that are the weight-gradient products' operands.  Feed-forward nets put that wait off into the
+  // next forward pass: everything in front of the first component that produces an operand of a side-stream update (or is such a
+  // component itself) runs beside the last updates instead of behind them -- the input copy, its conversion and the lowest layer's product,
+  // 34 of the 40 us for which the main stream used to sit idle at the end of a cfg2 step.  Every other way to the parameters (the
+  // accessors below, the C API, aslp_params_changed() of the sync workers) joins first.  A/B: ASLP_LATE_JOIN=0.
+  static const bool late_join_off = getenv("ASLP_LATE_JOIN") != nullptr && getenv("ASLP_LATE_JOIN")[0] == '0';
+  first_after_updates_ = 0;
+  if (overlap_updates && !recurrent_net && !late_join_off && NULL == in_diff) {
+    int32 first = N;
+    for (int32 i = 0; i < N; i++) {
+      if (!(components_[i]->GetType() == Component::kAffineTransform && components_[i]->IsUpdatable() && i != lowest_updatable)) continue;
+      first = std::min(first, i);
+      for (int32 p : components_[i]->GetInput()) first = std::min(first, p);   // its input buffer (and the planes made of it) is an operand
+    }
+    // a component folded into its producer's launch is written by that launch
+    for (int32 i = 0; i < first; i++)
+      if (fused_sigmoid[i] >= first || AffineSigmoidOf(i) >= first) { first = i; i = -1; }
+    first_after_updates_ = first;
+    updates_pending_ = true;
+  } else {
+    join_side_stream();
+  }
   if (NULL == in_diff) return;
   for (size_t i = 0; i < input_.size(); i++)
     if ((*in_diff)[i] != NULL) *((*in_diff)[i]) = input_diff_buf_[input_[i]];
 }
 
+void Nnet::JoinUpdates() const {
+  if (!updates_pending_) return;
+  updates_pending_ = false;
+  join_side_stream();
+}
+
 void Nnet::Feedforward(const std::vector<const CuMatrixBase *> &in, std::vector<CuMatrix *> *out) {  // :156-189
+  JoinUpdates();
   ASLP_ASSERT(NULL != out);
   ASLP_ASSERT(in.size() == input_.size());
   int num_frame = in[0]->NumRows();
@@ -420,10 +454,11 @@ const CuMatrixBase &Nnet::InputDiffBuffer(int32 c) const {
 
 int32 Nnet::OutputDim() const { ASLP_ASSERT(!components_.empty()); return components_.back()->OutputDim(); }
 int32 Nnet::InputDim() const { ASLP_ASSERT(!components_.empty()); return components_.front()->InputDim(); }
-const Component &Nnet::GetComponent(int32 c) const { ASLP_ASSERT(static_cast<size_t>(c) < components_.size()); return *(components_[c]); }
-Component &Nnet::GetComponent(int32 c) { ASLP_ASSERT(static_cast<size_t>(c) < components_.size()); return *(components_[c]); }
+const Component &Nnet::GetComponent(int32 c) const { ASLP_ASSERT(static_cast<size_t>(c) < components_.size()); JoinUpdates(); return *(components_[c]); }
+Component &Nnet::GetComponent(int32 c) { ASLP_ASSERT(static_cast<size_t>(c) < components_.size()); JoinUpdates(); return *(components_[c]); }
 
 void Nnet::SetComponent(int32 c, Component *component) {
+  JoinUpdates();
   ASLP_ASSERT(static_cast<size_t>(c) < components_.size());
   delete components_[c];
   components_[c] = component;
@@ -431,6 +466,7 @@ void Nnet::SetComponent(int32 c, Component *component) {
   Check();
 }
 void Nnet::AppendComponent(Component *comp) {  // :262-272
+  JoinUpdates();
   components_.push_back(comp);
   for (int32 i = 0; i < (int32)components_.size(); i++) {
     components_[i]->SetId(i);
@@ -444,6 +480,7 @@ void Nnet::AppendNnet(const Nnet &other) {
   Check();
 }
 void Nnet::RemoveComponent(int32 c) {
+  JoinUpdates();
   ASLP_ASSERT(c < NumComponents());
   Component *ptr = components_[c];
   components_.erase(components_.begin() + c);
@@ -453,6 +490,7 @@ void Nnet::RemoveComponent(int32 c) {
 }
 
 void Nnet::GetParams(std::vector<BaseFloat> *wei_copy) const {  // :296-311
+  JoinUpdates();
   wei_copy->clear();
   for (size_t i = 0; i < components_.size(); i++)
     if (components_[i]->IsUpdatable()) {
@@ -463,6 +501,7 @@ void Nnet::GetParams(std::vector<BaseFloat> *wei_copy) const {  // :296-311
   ASLP_ASSERT((int32)wei_copy->size() == NumParams());
 }
 void Nnet::GetGpuParams(std::vector<std::pair<BaseFloat *, int>> *params) {  // :314-325
+  JoinUpdates();
   ASLP_ASSERT(params != NULL);
   params->clear();
   for (size_t i = 0; i < components_.size(); i++)
@@ -479,6 +518,7 @@ void Nnet::ParamWritersAnnounce() {
     if (components_[i]->IsUpdatable()) dynamic_cast<UpdatableComponent &>(*components_[i]).ParamsAliased(true);
 }
 void Nnet::GetAccStats(std::vector<double *> *acc_params, std::vector<std::pair<double *, int>> *data_params) {  // :327-342
+  JoinUpdates();
   ASLP_ASSERT(acc_params != NULL && data_params != NULL);
   acc_params->clear();
   data_params->clear();
@@ -593,6 +633,7 @@ void Nnet::Write(const std::string &file, bool binary) const {
   if (!out.Close()) ASLP_ERR << "Error closing output stream " << PrintableWxfilename(file);
 }
 void Nnet::Write(std::ostream &os, bool binary) const {  // :654-663
+  JoinUpdates();
   Check();
   WriteToken(os, binary, "<Nnet>");
   if (binary == false) os << std::endl;
@@ -606,6 +647,7 @@ void Nnet::WriteStandard(const std::string &file, bool binary) const {  // :695-
   if (!out.Close()) ASLP_ERR << "Error closing output stream " << PrintableWxfilename(file);
 }
 void Nnet::WriteStandard(std::ostream &os, bool binary) const {  // :701-712
+  JoinUpdates();
   Check();
   WriteToken(os, binary, "<Nnet>");
   if (binary == false) os << std::endl;
@@ -635,6 +677,7 @@ void Nnet::WriteDotFile(std::ostream &os) const {  // :665-693
 }
 
 std::string Nnet::Info() const {  // :714-737
+  JoinUpdates();
   std::ostringstream ostr;
   ostr << "num-components " << NumComponents() << std::endl;
   ostr << "input-dim " << InputDim() << std::endl;
@@ -651,6 +694,7 @@ std::string Nnet::Info() const {  // :714-737
   return ostr.str();
 }
 std::string Nnet::InfoGradient() const {
+  JoinUpdates();
   std::ostringstream ostr;
   ostr << "### Gradient stats :\n";
   for (int32 i = 0; i < NumComponents(); i++)
@@ -676,6 +720,7 @@ std::string Nnet::InfoBackPropagate() const {
 }
 
 void Nnet::Check() const {  // :776-819
+  JoinUpdates();
   if (input_.size() < 1) ASLP_ERR << "Must have at least one InputLayer";
   if (output_.size() < 1) ASLP_ERR << "Must have at least one OutputLayer";
   for (int i = 0; i < NumComponents(); i++) {
@@ -705,6 +750,7 @@ void Nnet::Check() const {  // :776-819
 }
 
 void Nnet::Destroy() {  // :822-832
+  JoinUpdates();
   for (int32 i = 0; i < NumComponents(); i++) delete components_[i];
   components_.resize(0);
   input_buf_.resize(0);
@@ -719,6 +765,7 @@ void Nnet::Destroy() {  // :822-832
 }
 
 void Nnet::SetTrainOptions(const NnetTrainOptions &opts) {
+  JoinUpdates();
   opts_ = opts;
   for (int32 l = 0; l < NumComponents(); l++)
     if (GetComponent(l).IsUpdatable()) dynamic_cast<UpdatableComponent &>(GetComponent(l)).SetTrainOptions(opts_);

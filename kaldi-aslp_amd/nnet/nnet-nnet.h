@@ -129,6 +129,11 @@ class Nnet {
   bool fuse_layers_ = true;
   bool overlap_updates_ = true;
   bool fold_softmax_request_ = false, softmax_folded_ = false, diff_in_place_ = false;
+  // weight updates issued on the side stream by the latest Backpropagate and not waited for yet (JoinUpdates(): the main stream waits);
+  // the next Propagate joins in front of component first_after_updates_
+  void JoinUpdates() const;
+  mutable bool updates_pending_ = false;
+  int32 first_after_updates_ = 0;
   long next_bwd_epoch_ = 0;  // drawn by LossDiff() for the backward pass that will read the diff the loss is about to write
   long fwd_epoch_ = 0;  // csrc/split16.h: the forward pass whose buffers are still in place (operand planes made from them may be reused)
 };
