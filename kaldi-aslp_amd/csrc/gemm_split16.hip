@@ -710,10 +710,15 @@ bool launch_s16_layout(GemmArgs &g, const S16Operands &ops, int cfg) {
       return true;
     }
   }
-  // (the 128 x 128 tile, cfg 311, only where it is asked for by number: with the operands as prepared planes the 64 x 128 tile is level with
-  // it at 2048^3 ... 8192 x 2048 x 2048 (57.4 / 220.8 against 57.8 / 222.3 us), ahead wherever 128 x 128 leaves a ragged last round
-  // (1920 x 3000 x 1024: 48.5 against 58.1 us) and 1 % behind at 4096^3)
-  if (cfg != 304 && cfg != 305 && (cfg == 0 || !(A_KC && B_KC) || extra)) cfg = 308;
+  // 128 x 128 (cfg 311; both operands reduction-contiguous, nothing extra to leave) where its rounds of 256 workgroups cost no more than the
+  // 64 x 128 tile's, a 128 x 128 round counted as two: level at 2048^3 ... 8192 x 2048 x 2048 (57.8 / 222.3 against 57.4 / 220.8 us from
+  // prepared planes), 1 % ahead at 4096^3, and inside the LC-BLSTM step, whose layer products come as pairs of 1920 x 2048 (480 against 960
+  // workgroups), worth 2.87 against 2.93-3.05 ms; not where it leaves a ragged last round (1920 x 3000 x 1024: 58.1 against 48.5 us)
+  if (cfg != 304 && cfg != 305 && (cfg == 0 || !(A_KC && B_KC) || extra)) {
+    const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * (g.pair ? 2 : 1), t64 = (long)((g.M + 63) / 64) * ((g.N + 127) / 128) * (g.pair ? 2 : 1);
+    static const int any128 = [] { const char *e = getenv("ASLP_GEMM_S16_128_ANY"); return e ? atoi(e) : 0; }();   // (tuning aid: 1 = every grid of >= 224 tiles, 2 = never)
+    cfg = (!extra && A_KC && B_KC && t128 >= 224 && any128 != 2 && (any128 == 1 || 2 * ((t128 + 255) / 256) <= (t64 + 255) / 256)) ? 311 : 308;
+  }
   switch (cfg) {
     case 311: if constexpr (A_KC && B_KC) launch_s16<128, 128, 2, 2, 2, true, true>(g, ops); break;
     case 304:   // 32 x 64, two waves: 256 workgroups for a 256 x 2048 output with the whole reduction in one launch
@@ -905,7 +910,8 @@ bool gemm_split16_planes_launch(GemmArgs &g, bool a_kc, bool b_kc, const S16View
   // (with planes / maxima to leave, from K = 256: there the 64 x 128 tile's launch, 64 workgroups each with a long epilogue, is the slower
   // one -- the 440-input layer of the minibatch-256 net 18.6 against 25.7 us; a plain product of that shape is faster on 64 x 128: 9.7 / 12.6)
   const bool leaves = g.ep.planes_of != 0 || g.ep.wmax_parts || g.ep.cmax_parts;
-  if (!small_off && cfg == 0 && tiles <= 64 && t32 <= 256 && g.K >= (leaves ? 256 : 1024)) return launch(g, 304);
+  static const int leaves_min_k = [] { const char *e = getenv("ASLP_GEMM_S16_SMALL_MINK"); return e ? atoi(e) : 256; }();   // (tuning aid)
+  if (!small_off && cfg == 0 && tiles <= 64 && t32 <= 256 && g.K >= (leaves ? leaves_min_k : 1024)) return launch(g, 304);
   if (!splitk_off && (!extras || reduce_serves) && (cfg == 0 || cfg == 308) && tiles <= 128 && g.K >= 1024) {
     int split = (int)(256 / tiles);
     if (split > g.K / 256) split = g.K / 256;
