@@ -167,7 +167,12 @@ typedef struct aslp_planes_out_ {
   int ld;                 /* halves per plane row */
   const unsigned *slot;   /* device word: bits of the bound (float) the planes are scaled by */
   float *parts;           /* device, 256 floats: per-workgroup maxima, or NULL */
-  int nparts;             /* out: how many the launch wrote (0: none, the kernel that ran does not leave them) */
+  int nparts;             /* out: how many the launch wrote (0: none, the kernel that ran does not leave them; -1: it wrote the PLANES, below) */
+  /* in, optional: two arrays of device maxima from which the kernel can bound its output before it has written it -- it then stores the
+   * bound in `slot` and writes the planes itself (aslp_bn_backward_step_p: a = the forward launch's per-panel max |scale / sigma|,
+   * aslp_bn_forward_stats_p's giv_parts; b = per-workgroup maxima of |out_diff| from the launch that wrote it) */
+  const float *bound_a, *bound_b;
+  int bound_na, bound_nb;
 } aslp_planes_out;
 /* Fused epilogue form.  Applied in this order on the fp32 accumulator `acc`:
  *   v = alpha*acc + beta*C;  if (bias) v += bias[col];  if (clip > 0) v = clamp(v, -clip, clip);
@@ -314,10 +319,11 @@ void aslp_bn_backward_act(const float *in, MatrixDim d, const float *out_diff, i
 int aslp_bn_forward_stats(const float *in, MatrixDim d, float *out, int out_stride, const float *scale, const float *shift, float *mean,
                           float *inv_std, double *acc_means, double *acc_vars, float var_floor, float *act_out, int act_stride,
                           const double *colstats, int groups, int stats_ld);
-/* ... which also leaves the planes of act_out (sigmoid outputs: bound 1; `act_planes->slot` must hold a bound >= 1) */
+/* ... which also leaves the planes of act_out (sigmoid outputs: bound 1; `act_planes->slot` must hold a bound >= 1) and, in giv_parts
+ * [cols / 32] (optional), the per-panel maxima of |scale / sigma| for aslp_bn_backward_step_p's bound */
 int aslp_bn_forward_stats_p(const float *in, MatrixDim d, float *out, int out_stride, const float *scale, const float *shift, float *mean,
                             float *inv_std, double *acc_means, double *acc_vars, float var_floor, float *act_out, int act_stride,
-                            const double *colstats, int groups, int stats_ld, const aslp_planes_out *act_planes);
+                            const double *colstats, int groups, int stats_ld, const aslp_planes_out *act_planes, float *giv_parts);
 
 /* aslp_bn_backward_act + BatchNormalization::Update (nnet-batch-normalization.h:280-284) taken in the statistics
  * finalize: scale -= learn_rate * dscale, shift -= learn_rate * dshift; in_diff is formed with the scale the

@@ -782,10 +782,7 @@ PlaneSet::~PlaneSet() {
   if (hi_) (void)hipFree(hi_);
   if (slot_) (void)hipFree(slot_);
 }
-bool PlaneSet::Reserve(int rows, int cols) {
-  if (rows <= 0 || cols <= 0) return false;
-  const int ld = s16_plane_ld(cols), rows_p = (rows + kS16Pad - 1) / kS16Pad * kS16Pad;
-  const size_t need = (size_t)rows_p * ld;
+bool PlaneSet::ReserveParts() {
   if (!slot_) {
     void *p = nullptr;
     if (hipMalloc(&p, 256 + sizeof(float) * kS16MaxParts) != hipSuccess) { set_error("PlaneSet: hipMalloc failed"); return false; }
@@ -794,6 +791,13 @@ bool PlaneSet::Reserve(int rows, int cols) {
     (void)hipMemsetAsync(p, 0, 256 + sizeof(float) * kS16MaxParts, cur_stream());
     host_bound_ = -1.f;
   }
+  return true;
+}
+bool PlaneSet::Reserve(int rows, int cols) {
+  if (rows <= 0 || cols <= 0) return false;
+  const int ld = s16_plane_ld(cols), rows_p = (rows + kS16Pad - 1) / kS16Pad * kS16Pad;
+  const size_t need = (size_t)rows_p * ld;
+  if (!ReserveParts()) return false;
   const bool reshape = rows != rows_ || cols != cols_;
   if (need > cap_) {
     if (hi_) {

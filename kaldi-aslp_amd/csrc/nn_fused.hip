@@ -523,7 +523,8 @@ __global__ void __launch_bounds__(kPanelThreads) bn_forward_stats_kernel(const f
                                                                         float *__restrict__ mean, float *__restrict__ inv_std,
                                                                         double *__restrict__ acc_means, double *__restrict__ acc_vars, float inv_rows,
                                                                         float floor_, int rows, float *__restrict__ act, int lda, int Q,
-                                                                        const double *__restrict__ part, int groups, int ldp, S16Out po) {
+                                                                        const double *__restrict__ part, int groups, int ldp, S16Out po,
+                                                                        float *__restrict__ giv_parts) {
   constexpr int CG = kCoopCG, L = kCoopLanes, COLS = kCoopCols, SL = kPanelThreads / COLS;  // SL partial-sum slices per column
   __shared__ double red[3][SL][COLS];
   __shared__ float stat[2][COLS];
@@ -569,6 +570,12 @@ __global__ void __launch_bounds__(kPanelThreads) bn_forward_stats_kernel(const f
     stat[1][pc] = is;
   }
   __syncthreads();
+  // the largest |scale / sigma| of this panel: with the largest |out-diff| it bounds the in-diff the backward pass will write (bn_backward_coop)
+  if (giv_parts != nullptr && q == 0 && threadIdx.x < 64) {   // (wave 0, uniform)
+    const float v = threadIdx.x < COLS ? fabsf(scale[p * COLS + threadIdx.x] * stat[1][threadIdx.x]) : 0.f;
+    const float mx = wave_max(v < 3.0e38f ? v : 0.f);
+    if (threadIdx.x == 0) giv_parts[p] = mx;
+  }
   const float4 g = *reinterpret_cast<const float4 *>(scale + c), b = *reinterpret_cast<const float4 *>(shift + c);
   const float4 m = *reinterpret_cast<const float4 *>(&stat[0][cg * 4]), is = *reinterpret_cast<const float4 *>(&stat[1][cg * 4]);
 #pragma unroll
@@ -593,6 +600,8 @@ __global__ void __launch_bounds__(kPanelThreads) bn_forward_stats_kernel(const f
   }
 }
 
+// what bn_backward_coop needs to bound its in-diff before it has written it (see there)
+struct BnDiffBound { const float *giv_parts; int n_giv; const float *od_parts; int n_od; };
 template <int SLOTS, bool HAS_Y, bool RECOMPUTE>
 __global__ void __launch_bounds__(kPanelThreads) bn_backward_coop(const float *__restrict__ dy, int ldd, float *__restrict__ xhat, int ldx,
                                                            float *__restrict__ scale, float *__restrict__ shift,
@@ -600,10 +609,11 @@ __global__ void __launch_bounds__(kPanelThreads) bn_backward_coop(const float *_
                                                            float *__restrict__ dshift, float mmt, float neg_lr, bool step,
                                                            float *__restrict__ in_diff, int ldi, int rows, const float *__restrict__ y, int ldy,
                                                            const float *__restrict__ xin, int ldxin, const float *__restrict__ mean, int Q,
-                                                           unsigned long long *inbox, unsigned *err, float *__restrict__ max_parts) {
+                                                           unsigned long long *inbox, unsigned *err, float *__restrict__ max_parts, S16Out po, BnDiffBound bb) {
   constexpr int CG = kCoopCG, L = kCoopLanes;
   __shared__ float red[kPanelWaves * CG * 8];
   __shared__ float stat[3][4 * CG];  // S1, S2, the scale the forward pass used
+  __shared__ float bred[2 * kPanelWaves];
   const int P = gridDim.x / Q, p = blockIdx.x % P, q = blockIdx.x / P;
   const int rp = (rows + Q - 1) / Q, r0 = q * rp, r1 = min(rows, r0 + rp);
   const int cg = threadIdx.x % CG, lane = threadIdx.x / CG;
@@ -635,6 +645,26 @@ __global__ void __launch_bounds__(kPanelThreads) bn_backward_coop(const float *_
         d[k].z = d[k].z * yy.z * (1.0f - yy.z); d[k].w = d[k].w * yy.w * (1.0f - yy.w);
       }
     }
+  }
+  // (po) the in-diff's fp16 planes from this launch: in_diff = g / sigma (d - x_hat mean(x_hat d) - mean(d)) with |x_hat| <= sqrt(rows) and
+  // mean |x_hat| <= 1, so |in_diff| <= max |g / sigma| max |d| (2 + sqrt(rows)); max |g / sigma| from the forward launch's per-panel maxima
+  // (the scale is only rewritten at the end of THIS launch, by other workgroups), max |d| from the maxima the launch that wrote the
+  // out-diff left (a folded Sigmoid's derivative is at most 1/4).  Every workgroup forms the same bits; workgroup 0 stores them.
+  float pscale = 0.f;
+  if (po.hi != nullptr) {   // uniform
+    float gm = 0.f, em = 0.f;
+    for (int i = threadIdx.x; i < bb.n_giv; i += kPanelThreads) gm = fmaxf(gm, bb.giv_parts[i]);
+    for (int i = threadIdx.x; i < bb.n_od; i += kPanelThreads) em = fmaxf(em, bb.od_parts[i]);
+    gm = wave_max(gm);
+    em = wave_max(em);
+    if ((threadIdx.x & 63) == 0) { bred[2 * (threadIdx.x >> 6)] = gm; bred[2 * (threadIdx.x >> 6) + 1] = em; }
+    __syncthreads();
+    gm = bred[0]; em = bred[1];
+#pragma unroll
+    for (int w = 1; w < kPanelWaves; w++) { gm = fmaxf(gm, bred[2 * w]); em = fmaxf(em, bred[2 * w + 1]); }
+    const float bound = gm * (HAS_Y ? 0.25f * em : em) * (2.0f + sqrtf((float)rows)) * 1.001f;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *const_cast<unsigned *>(po.slot) = __float_as_uint(bound);
+    pscale = ldexpf(1.f, s16_exponent(__float_as_uint(bound)));
   }
   float acc[2][4] = {};
 #pragma unroll
@@ -699,6 +729,12 @@ __global__ void __launch_bounds__(kPanelThreads) bn_backward_coop(const float *_
       }
       if (!RECOMPUTE) *reinterpret_cast<float4 *>(xhat + (long)r * ldx + c) = make_float4(Dv[0], Dv[1], Dv[2], Dv[3]);
       *reinterpret_cast<float4 *>(in_diff + (long)r * ldi + c) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+      if (po.hi != nullptr) {   // uniform
+        half4 hi, lo;
+        s16_split4(make_float4(ov[0], ov[1], ov[2], ov[3]), pscale, &hi, &lo);
+        *reinterpret_cast<half4 *>(po.hi + (long)r * po.ld + c) = hi;
+        *reinterpret_cast<half4 *>(po.lo + (long)r * po.ld + c) = lo;
+      }
       omax = s16_absmax4(omax, make_float4(ov[0], ov[1], ov[2], ov[3]));
     }
     if (max_parts != nullptr) {   // this workgroup's largest |in_diff|: the conversion of in_diff takes its scale from these (split16.h)
@@ -1165,11 +1201,11 @@ int aslp_bn_forward_stats(const float *in, MatrixDim d, float *out, int out_stri
                           float *inv_std, double *acc_means, double *acc_vars, float var_floor, float *act_out, int act_stride,
                           const double *colstats, int groups, int stats_ld) {
   return aslp_bn_forward_stats_p(in, d, out, out_stride, scale, shift, mean, inv_std, acc_means, acc_vars, var_floor, act_out, act_stride, colstats,
-                                 groups, stats_ld, nullptr);
+                                 groups, stats_ld, nullptr, nullptr);
 }
 int aslp_bn_forward_stats_p(const float *in, MatrixDim d, float *out, int out_stride, const float *scale, const float *shift, float *mean,
                             float *inv_std, double *acc_means, double *acc_vars, float var_floor, float *act_out, int act_stride,
-                            const double *colstats, int groups, int stats_ld, const aslp_planes_out *act_planes) {
+                            const double *colstats, int groups, int stats_ld, const aslp_planes_out *act_planes, float *giv_parts) {
   if (d.rows <= 0 || d.cols <= 0 || !colstats) return 0;
   if (!out && !act_out) { set_error("aslp_bn_forward_stats: no output"); return 0; }
   if (groups != (d.rows + 31) / 32 || stats_ld < d.cols) { set_error("aslp_bn_forward_stats: statistics layout does not match the matrix"); return 0; }
@@ -1187,7 +1223,7 @@ int aslp_bn_forward_stats_p(const float *in, MatrixDim d, float *out, int out_st
   if (act_planes && act_planes->hi && act_out && act_planes->slot && act_planes->ld >= d.cols)
     po = S16Out{static_cast<h16 *>(act_planes->hi), static_cast<h16 *>(act_planes->lo), act_planes->ld, act_planes->slot, nullptr};
   hipLaunchKernelGGL(bn_forward_stats_kernel, dim3(P * Q), dim3(kPanelThreads), 0, cur_stream(), in, d.stride, out, out_stride, scale, shift, mean,
-                     inv_std, acc_means, acc_vars, 1.0f / (float)d.rows, var_floor, d.rows, act_out, act_stride, Q, colstats, groups, stats_ld, po);
+                     inv_std, acc_means, acc_vars, 1.0f / (float)d.rows, var_floor, d.rows, act_out, act_stride, Q, colstats, groups, stats_ld, po, giv_parts);
   check_launch("bn_forward_stats");
   return 1;
 }
@@ -1223,10 +1259,21 @@ static void bn_backward_impl(MatrixDim d, const float *out_diff, int od_stride, 
     const dim3 grid((d.cols / kCoopCols) * cs.q), block(kPanelThreads);
     float *max_parts = (diff_out && diff_out->parts && in_diff && (int)grid.x <= kS16MaxParts) ? diff_out->parts : nullptr;
     if (max_parts) diff_out->nparts = (int)grid.x;
+    // the in-diff's planes from this launch, where the caller has the maxima that bound it (aslp_planes_out.bound_*)
+    S16Out po = {nullptr, nullptr, 0, nullptr, nullptr};
+    BnDiffBound bb = {nullptr, 0, nullptr, 0};
+    static const bool planes_off = [] { const char *e = getenv("ASLP_BN_DIFF_PLANES"); return !(e && e[0] == '1'); }();   // A/B switch: default off (measured slower, nnet-nnet.cpp)
+    if (!planes_off && diff_out && in_diff && diff_out->hi && diff_out->lo && diff_out->slot && diff_out->ld >= d.cols && diff_out->bound_a && diff_out->bound_b &&
+        diff_out->bound_na > 0 && diff_out->bound_nb > 0) {
+      po = S16Out{static_cast<h16 *>(diff_out->hi), static_cast<h16 *>(diff_out->lo), diff_out->ld, diff_out->slot, nullptr};
+      bb = BnDiffBound{diff_out->bound_a, diff_out->bound_na, diff_out->bound_b, diff_out->bound_nb};
+      max_parts = nullptr;
+      diff_out->nparts = -1;   // "the planes are written"
+    }
 #define ASLP_BN_BWD_CL(SLOTS, Y, RC)                                                                                                           \
     hipLaunchKernelGGL((bn_backward_coop<SLOTS, Y, RC>), grid, block, 0, cur_stream(), out_diff, od_stride, xhat, xhat_stride, scale, shift, inv_std, \
                        dscale, dshift, momentum, -learn_rate, step, in_diff, id_stride, d.rows, act_y, act_stride, in, d.stride, mean, cs.q, st.inbox, st.err, \
-                       max_parts)
+                       max_parts, po, bb)
 #define ASLP_BN_BWD_COOP(SLOTS)                                                                      \
     case SLOTS:                                                                                      \
       if (act_y) { if (recompute) ASLP_BN_BWD_CL(SLOTS, true, true); else ASLP_BN_BWD_CL(SLOTS, true, false); }     \

@@ -94,6 +94,7 @@ class PlaneSet {
   PlaneSet &operator=(const PlaneSet &) = delete;
   // planes for a [rows x cols] matrix (zeroed when the buffers are new or the shape changed: producers only write the matrix region)
   bool Reserve(int rows, int cols);
+  bool ReserveParts();   // the maxima array and the slot only (a set that only carries a producer's maxima to their reader)
   S16View View() const { return S16View{hi_, lo_, ld_, rows_, cols_, slot_}; }
   float *Parts() const { return parts_; }        // kS16MaxParts per-workgroup maxima (producers) -> Convert / bound kernels
   unsigned *Slot() const { return slot_; }
