@@ -315,14 +315,16 @@ bool PairsOn() {
 bool SameShape(const LstmDir &f, const LstmDir &b) { return PairsOn() && f.D == b.D && f.C == b.C && f.R == b.R && f.cifg == b.cifg; }
 // Do the layer's batched products run on the fp16 instruction from prepared planes?  Every reduction extent they meet (T S, C, R, 4C)
 // must be a multiple of 64 -- the planes of a buffer's column block or row range are windows, with neighbours instead of zero padding.
-// Switch ASLP_LSTM_PLANES: 0 (default) = the layer's batched products convert their operands call by call or run on the fp32 instruction as
-// aslp_sgemm_pair_ex decides, 1 = the forward products from planes the layer prepares, 2 = + the products in front of the backward
-// recurrence, 3 = all of them.  Measured on the cfg3 step (devtools/bench_lc.py 32 100, one box, two alternations): 2.872 / 2.875 ms
-// with 3 against 2.858 / 2.868 with 0 -- the products get 1.5-2 x faster (gates pair 45 us, in-diff pair 38 us) but the fourteen
-// maximum + conversion launches per layer and step (~70 us) eat it, so it stays off until the recurrence kernels leave the planes
-// of m and dGATES themselves.
+// Switch ASLP_LSTM_PLANES: 0 = the layer's batched products convert their operands call by call or run on the fp32 instruction as
+// aslp_sgemm_pair_ex decides (pairs: the fp32 instruction), 1 = the forward products from planes the layer prepares, 2 = + the products in
+// front of the backward recurrence, 3 (default) = all of them, 4 = as 3 but the weight gradients on the fp32 instruction where they are
+// issued beside the recurrence below.  Measured at the end of round 4 (one box each, two alternations): devtools/bench_lc.py 32 30 (output
+// layer 3000 wide) 2.97 / 3.00 ms with 0, 2.98 / 2.99 with 1, 3.13 / 3.08 with 2, 2.86 / 2.85 with 3, 3.07 / 3.07 with 4; bench.py's cfg3
+// block: chunked 2.750 ms with 0 and 2.752-2.759 with 3, whole utterances + Warp-CTC 34.2 ms with 0 and **30.6 with 3** (the products of
+// 25,600 rows are what the long step is made of).  Earlier in the round, before the product kernels lost their private segment, 3 and 0
+// were level on the chunked step (2.872 / 2.858), which is why it shipped off for a while.
 int PlanesLevel() {
-  static const int level = [] { const char *e = getenv("ASLP_LSTM_PLANES"); return e ? atoi(e) : 0; }();
+  static const int level = [] { const char *e = getenv("ASLP_LSTM_PLANES"); return e ? atoi(e) : 3; }();
   return level;
 }
 bool PlanesUsable(const LstmDir &f, int T, int S) {
@@ -508,8 +510,10 @@ void LstmDir::GradsPair(LstmDir &f, LstmDir &b, const CuMatrixBase &in, int T, i
   CuSubMatrix dr_f(fdbuf, S, T * S, f.OffRec(), f.R > 0 ? f.R : f.C), dr_b(bdbuf, S, T * S, b.OffRec(), b.R > 0 ? b.R : b.C);
   // planes: dGATES (made for the in-diff products) and m (made for the projection) are there; r (whole column block: the operand is a
   // shifted row range of it) and d_r come with one more conversion launch pair
+  // (level 4: the weight gradients stay on the fp32-instruction kernels when they are issued beside the recurrence below -- those fit on a CU next
+  // to a persistent workgroup (128 registers per wave, 73 KB of LDS), the split kernels (340 registers, 144 KB) wait until it has left)
   bool side_ok = false;
-  if (pl && pl->dg_ok && pl->m_ok && f.R > 0) {
+  if (pl && pl->dg_ok && pl->m_ok && f.R > 0 && !(PlanesLevel() == 4 && on_side_stream())) {
     CuSubMatrix ra_f(fbuf, 0, (T + 2) * S, f.OffRec(), f.R), ra_b(bbuf, 0, (T + 2) * S, b.OffRec(), b.R);
     PlaneSet::ConvertSpec sp[4] = {Spec(&pl->r[0], ra_f), Spec(&pl->r[1], ra_b), Spec(&pl->dr[0], dr_f), Spec(&pl->dr[1], dr_b)};
     side_ok = PlaneSet::ConvertMany(sp, 4);

@@ -142,14 +142,14 @@ def test_xent_wave_per_row_kernel_is_bit_identical(tmp_path):
 
 
 def test_lstm_layer_products_from_prepared_planes(tmp_path):
-    """ASLP_LSTM_PLANES=3: the bidirectional layer keeps fp16 planes of its products' operands (layer input, weights, m, dGATES, d_r, r: made by
-    multi-matrix conversion launches, shifted row ranges as windows) and every batched pair product reads them; 1 / 2: only the forward /
-    pre-recurrence ones.  T S, D, C and R are multiples of 64 here so that every product is served.  Same values as the default path to fp32
-    rounding."""
+    """ASLP_LSTM_PLANES=3 (the default): the bidirectional layer keeps fp16 planes of its products' operands (layer input, weights, m, dGATES, d_r,
+    r: made by multi-matrix conversion launches, shifted row ranges as windows) and every batched pair product reads them; 1 / 2: only the
+    forward / pre-recurrence ones; 4: all but the weight gradients issued beside a recurrence; 0: the pairs on the fp32 instruction.  T S, D, C
+    and R are multiples of 64 here so that every product is served.  Same values to fp32 rounding."""
     shape = {"AB_S": "32", "AB_CHUNK": "5", "AB_T": "8", "AB_D": "64"}
     base = run(tmp_path, "planes_off", ASLP_LSTM_PLANES="0", **shape)
     assert np.isfinite(base).all()
-    for level in ("1", "2", "3"):
+    for level in ("1", "2", "3", "4"):
         other = run(tmp_path, "planes_" + level, ASLP_LSTM_PLANES=level, **shape)
         assert np.linalg.norm(other - base) / np.linalg.norm(base) < 1e-5, level
         assert np.abs(other - base).max() / max(1.0, np.abs(base).max()) < 1e-4, level
