@@ -455,7 +455,12 @@ typedef struct aslp_lstm_seq_ {
   /* stream window: this launch serves streams [s_begin, s_begin + s_count) of the S streams the buffers hold (s_count == 0: all of them).
    * More streams than one launch has chains for (8 chains of 8 streams: 32 bidirectional, 64 unidirectional) go in several launches. */
   int s_begin, s_count;
+  /* backward, optional: per direction 256 floats -- the kernel leaves the largest finite |d_g, d_i, d_f, d_o| each workgroup wrote (0 for the
+   * other direction's workgroups), i.e. per-workgroup maxima of the direction's dGATES block for aslp_planes conversions without a maximum
+   * pass.  Only with one launch per pass (s_count == 0); aslp_lstm_seq_last_dmax() says whether the kernel that ran wrote them. */
+  float *dmax_parts[2];
 } aslp_lstm_seq;
+int aslp_lstm_seq_last_dmax(void);   /* 256 if the calling thread's latest aslp_lstm_seq_backward left dmax_parts, else 0 */
 int aslp_lstm_seq_supported(const aslp_lstm_seq *a, int backward);
 /* Several processes on ONE GPU (ShmComm ranks, or two jobs given the same device): on != 0 makes every persistent LSTM / GRU launch hold a
  * per-device cross-process lock until its kernel has completed, so that two grids which each need the whole device are never half resident

@@ -850,20 +850,32 @@ bool PlaneSet::ConvertMany(const ConvertSpec *specs, int n) {
   MaxJobs ms;
   ConvJobs js;
   int max_c4 = 0, max_k8 = 0, max_rows = 0;
+  bool need_max = false;
   for (int i = 0; i < n; i++) {
     const ConvertSpec &c = specs[i];
     if (!c.planes || !c.src || (c.cols & 3) || (c.stride & 3) || !aligned16(c.src)) return false;
     if (!c.planes->Reserve(c.rows, c.cols)) return false;
     c.planes->host_bound_ = -1.f;
+    const bool given = c.parts != nullptr && c.nparts > 0 && c.nparts <= kS16MaxParts;
+    need_max = need_max || !given;
     ms.j[i] = MaxJob{c.src, c.rows, c.cols, c.stride, c.planes->parts_};
-    js.j[i] = ConvJob{c.src, c.stride, c.planes->View(), c.planes->parts_, kS16ConvParts};
+    js.j[i] = given ? ConvJob{c.src, c.stride, c.planes->View(), c.parts, c.nparts} : ConvJob{c.src, c.stride, c.planes->View(), c.planes->parts_, kS16ConvParts};
     max_c4 = std::max(max_c4, c.cols >> 2);
     max_k8 = std::max(max_k8, c.planes->ld_ >> 3);
     max_rows = std::max(max_rows, c.planes->rows_p_);
   }
-  hipLaunchKernelGGL(s16_absmax_kernel, dim3(kS16ConvParts, n), dim3(256), 0, cur_stream(), ms, tw_log2_for(max_c4));
+  if (need_max) hipLaunchKernelGGL(s16_absmax_kernel, dim3(kS16ConvParts, n), dim3(256), 0, cur_stream(), ms, tw_log2_for(max_c4));
   hipLaunchKernelGGL(split16_convert_kernel, dim3(std::min(max_rows, 512), n), dim3(256), 0, cur_stream(), js, tw_log2_for(max_k8));
   return true;
+}
+const float *PlaneSet::OneBound() {
+  static float *one = [] {
+    float *p = nullptr;
+    const float v = 1.0f;
+    if (hipMalloc(&p, 256) != hipSuccess || hipMemcpy(p, &v, sizeof(v), hipMemcpyHostToDevice) != hipSuccess) { set_error("PlaneSet::OneBound: allocation failed"); return static_cast<float *>(nullptr); }
+    return p;
+  }();
+  return one;
 }
 
 // C = epilogue(alpha op(A) op(B) + beta C) from planes.  a_kc: A is stored [M x K] (else [K x M]); b_kc: B is stored [N x K]

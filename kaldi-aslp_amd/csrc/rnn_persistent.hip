@@ -1070,7 +1070,13 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd_h(aslp_lstm_seq a, SeqStatus
   timing_begin(st);
   const int SE = a.s_count > 0 ? a.s_begin + a.s_count : a.S;
   const ChainRole R = chain_role(SE - a.s_begin, a.ndir, a.C, st, place, &place_flag);
-  if (!R.active) return;
+  if (!R.active) {
+    if (threadIdx.x == 0) {
+      if (a.dmax_parts[0]) a.dmax_parts[0][blockIdx.x] = 0.f;
+      if (a.dmax_parts[1]) a.dmax_parts[1][blockIdx.x] = 0.f;
+    }
+    return;
+  }
   const aslp_lstm_seq_dir D = a.dir[R.dir];
   const int C = a.C, S = a.S, T = a.T, ld = a.ld;
   const int GC = G * C, oc = GC, oh = GC + C, om = GC + 2 * C;
@@ -1129,6 +1135,7 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd_h(aslp_lstm_seq a, SeqStatus
   // own-cell quantities of the step processed just before (BPTT order): all zero ahead of the first step
   float dn_c = 0.f, dn_f = 0.f, dn_i = 0.f;
   float gsum[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float dmax = 0.f;   // largest finite gate diff of this thread's stream so far (a.dmax_parts)
   unsigned polls = 0u;
   for (int step = 0; step < T; step++) {
     // BPTT runs against the direction's recursion: reverse = 0 (t = T..1), reverse = 1 (t = 1..T)
@@ -1264,6 +1271,7 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd_h(aslp_lstm_seq a, SeqStatus
         int e = 0;
         (void)frexpf(rmax, &e);
         const bool scaled = rmax > 0.f && rmax < 3.0e38f;
+        dmax = fmaxf(dmax, scaled ? rmax : 0.f);
         const int up = scaled ? min(14 - e, 120) : 0;
         const float sc = ldexpf(1.f, up), inv = ldexpf(1.f, -up);
         auto put = [&](int k, float x) {
@@ -1307,6 +1315,18 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd_h(aslp_lstm_seq a, SeqStatus
 #pragma unroll
       for (int q = 1; q < kChainStreams; q++) v += gl[(q * 7 + k) * 16 + c];
       if (c0 + c < C) a.grad_partial[((long)chain * 7 + k) * a.grad_ld + c0 + c] = v;
+    }
+  }
+  if (a.dmax_parts[0] != nullptr || a.dmax_parts[1] != nullptr) {   // uniform.  (a dead lane's gate diffs are zeros: the row maximum is the live cells')
+    __syncthreads();
+    if (threadIdx.x < 128 && cc == 0) shares[sl] = dmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float m = shares[0];
+#pragma unroll
+      for (int q = 1; q < kChainStreams; q++) m = fmaxf(m, shares[q]);
+      if (a.dmax_parts[0]) a.dmax_parts[0][blockIdx.x] = R.dir == 0 ? m : 0.f;
+      if (a.dmax_parts[1]) a.dmax_parts[1][blockIdx.x] = R.dir == 1 ? m : 0.f;
     }
   }
   if (st.timing && blockIdx.x == 0 && threadIdx.x == 0) { timing_flush(st); st.timing[0] += (unsigned long long)T; st.timing[6] += R.local ? 1ull : 0ull; }
@@ -2675,7 +2695,9 @@ void aslp_lstm_seq_fill_pair(float *buf0, float *buf1, int ld, int T, int S, int
   check_launch("aslp_lstm_seq_fill_pair");
 }
 
+thread_local int t_last_dmax = 0;   // aslp_lstm_seq_last_dmax()
 static void launch_seq(const aslp_lstm_seq *a, bool backward, const char *who) {
+  if (backward) t_last_dmax = 0;
   if (!seq_args_ok(a) || !aslp_lstm_seq_supported(a, backward ? 1 : 0)) {
     set_error(std::string(who) + ": arguments outside what the persistent kernel supports (check aslp_lstm_seq_supported first)");
     return;
@@ -2721,7 +2743,11 @@ static void launch_seq(const aslp_lstm_seq *a, bool backward, const char *who) {
     else hipLaunchKernelGGL(pick_bwd4(a->cifg != 0, a->C), dim3(grid), dim3(256), 0, cur_stream(), *a, st, rt.place, rt.inbox);
   } else if (!backward) hipLaunchKernelGGL(dual_on() ? pick_fwd_dual(a->cifg != 0, a->C) : split_f16_on() ? pick_fwd_h(a->cifg != 0, a->C) : pick_fwd(a->cifg != 0, a->C), dim3(kMaxChains * wpc), dim3(512), 0,
                                            cur_stream(), *a, st, rt.place);
-  else hipLaunchKernelGGL(split_f16_on() ? pick_bwd_h(a->cifg != 0, a->C) : pick_bwd(a->cifg != 0, a->C), dim3(kMaxChains * wpc), dim3(512), 0, cur_stream(), *a, st, rt.place, rt.inbox);
+  else {
+    hipLaunchKernelGGL(split_f16_on() ? pick_bwd_h(a->cifg != 0, a->C) : pick_bwd(a->cifg != 0, a->C), dim3(kMaxChains * wpc), dim3(512), 0, cur_stream(), *a, st, rt.place, rt.inbox);
+    // (only lstm_seq_bwd_h forms the per-workgroup maxima of the gate diffs, and only a single launch per pass leaves a complete set)
+    if (split_f16_on() && a->s_count == 0 && (a->dmax_parts[0] || a->dmax_parts[1])) t_last_dmax = kMaxChains * wpc;
+  }
   if (!rt.last_done) (void)hipEventCreateWithFlags(&rt.last_done, hipEventDisableTiming);
   if (rt.last_done) { ASLP_CHECK_HIP(hipEventRecord(rt.last_done, cur_stream())); rt.last_stream = cur_stream(); }
   check_launch(who);
@@ -2856,5 +2882,6 @@ void aslp_lstm_seq_vec_grads2(const aslp_lstm_seq *a, float *const *vec8_dir0, f
 }
 void aslp_lstm_seq_forward(const aslp_lstm_seq *a) { launch_seq(a, false, "aslp_lstm_seq_forward"); }
 void aslp_lstm_seq_backward(const aslp_lstm_seq *a) { launch_seq(a, true, "aslp_lstm_seq_backward"); }
+int aslp_lstm_seq_last_dmax(void) { return t_last_dmax; }
 
 }  // extern "C"

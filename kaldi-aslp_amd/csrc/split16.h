@@ -103,8 +103,11 @@ class PlaneSet {
   // max pass + conversion of src (two launches on the current stream)
   bool ConvertFrom(const float *src, int rows, int cols, int stride);
   // several matrices with ONE maximum launch and ONE conversion launch (at most 8)
-  struct ConvertSpec { PlaneSet *planes; const float *src; int rows, cols, stride; };
+  // (parts / nparts: device maxima that bound |src| -- left by the kernel that wrote src, or OneBound() for values known to lie in
+  // [-1, 1] -- spare that matrix the maximum pass; when every matrix of the call has them there is no maximum launch)
+  struct ConvertSpec { PlaneSet *planes; const float *src; int rows, cols, stride; const float *parts = nullptr; int nparts = 0; };
   static bool ConvertMany(const ConvertSpec *specs, int n);
+  static const float *OneBound();   // a device float holding 1.0
   // a [rows x cols] window of the planes at (row0, col0), for a product that reads that block of the matrix.  As a reduction extent
   // the window's must be a multiple of 64 (or end at the matrix' edge: behind it the planes hold zeros, inside they hold the neighbours)
   S16View Window(int row0, int rows, int col0, int cols) const {

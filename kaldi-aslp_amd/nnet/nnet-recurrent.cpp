@@ -399,8 +399,11 @@ bool LstmDir::ForwardFinishPair(const LstmDir &f, const LstmDir &b, int T, int S
     ep_f.act_out = out->Data(); ep_f.ld_act = out->Stride(); ep_f.act = 0;
     ep_b.act_out = out->Data() + f.Rec(); ep_b.ld_act = out->Stride(); ep_b.act = 0;
   }
-  if (pl && pl->weights_ok) {   // m of both directions: also the W_rm gradient's operand
+  if (pl && pl->weights_ok) {   // m of both directions: also the W_rm gradient's operand.  m = o tanh(c): |m| < 1, no maximum pass
     PlaneSet::ConvertSpec sp[2] = {Spec(&pl->m[0], m_f), Spec(&pl->m[1], m_b)};
+    static const bool known_off = getenv("ASLP_LSTM_KNOWN_BOUNDS") != nullptr && getenv("ASLP_LSTM_KNOWN_BOUNDS")[0] == '0';   // A/B switch
+    if (!known_off && PlaneSet::OneBound() != nullptr)
+      for (auto &c : sp) { c.parts = PlaneSet::OneBound(); c.nparts = 1; }
     pl->m_ok = PlaneSet::ConvertMany(sp, 2);
   }
   if (pl && pl->m_ok) {
@@ -458,6 +461,10 @@ void LstmDir::BackwardFinishPair(const LstmDir &f, const LstmDir &b, const CuMat
   if (pl && pl->od_ok && PlanesLevel() >= 3) {   // the dGATES columns of both diff buffers, boundary row blocks included: the products below read shifted row ranges of them
     CuSubMatrix dga_f(*fdbuf, 0, (T + 2) * S, 0, f.GC()), dga_b(*bdbuf, 0, (T + 2) * S, 0, b.GC());
     PlaneSet::ConvertSpec sp[2] = {Spec(&pl->dg[0], dga_f), Spec(&pl->dg[1], dga_b)};
+    if (pl->dg_parts[0] != nullptr && pl->dg_nparts > 0) {   // the persistent backward launch left the gate diffs' per-workgroup maxima
+      sp[0].parts = pl->dg_parts[0]; sp[1].parts = pl->dg_parts[1];
+      sp[0].nparts = sp[1].nparts = pl->dg_nparts;
+    }
     pl->dg_ok = PlaneSet::ConvertMany(sp, 2);
   }
   if (pl && pl->dg_ok) {
@@ -779,6 +786,13 @@ void LstmFamily::BackpropagateFnc(const CuMatrixBase &in, const CuMatrixBase &, 
     if (persistent) {
       q.ld = f_dbuf_.Stride(); q.ldw = f_.Weff().Stride();
       static const bool vec_fused_off = getenv("ASLP_LSTM_VEC_FUSED") != nullptr && getenv("ASLP_LSTM_VEC_FUSED")[0] == '0';   // A/B switch
+      LstmPlanes *lp = cfg_.bidir ? planes_.get() : nullptr;
+      if (lp) { lp->dg_parts[0] = lp->dg_parts[1] = nullptr; lp->dg_nparts = 0; }
+      static const bool known_off = getenv("ASLP_LSTM_KNOWN_BOUNDS") != nullptr && getenv("ASLP_LSTM_KNOWN_BOUNDS")[0] == '0';   // A/B switch
+      if (lp && !known_off && nwin == 1 && PlanesLevel() >= 3) {   // ... and the per-workgroup maxima of the gate diffs, for their planes
+        if (dmax_parts_.Dim() != 512) dmax_parts_.Resize(512);
+        q.dmax_parts[0] = dmax_parts_.Data(); q.dmax_parts[1] = dmax_parts_.Data() + 256;
+      }
       if (!vec_fused_off && nwin == 1) {   // the kernel also leaves the sums the bias / peephole gradients are made of (8 chains x 7 quantities x C)
         if (grad_partial_.NumRows() != 16 * 7 || grad_partial_.NumCols() != ncell_) grad_partial_.Resize(16 * 7, ncell_, kUndefined);   // <= 16 chains
         q.grad_partial = grad_partial_.Data();
@@ -798,6 +812,10 @@ void LstmFamily::BackpropagateFnc(const CuMatrixBase &in, const CuMatrixBase &, 
       for (int w = 0; w < nwin; w++) {
         if (nwin > 1) { q.s_begin = w * per_launch; q.s_count = std::min(per_launch, S - q.s_begin); }
         aslp_lstm_seq_backward(&q);
+      }
+      if (lp && q.dmax_parts[0] && aslp_lstm_seq_last_dmax() > 0) {
+        lp->dg_parts[0] = q.dmax_parts[0]; lp->dg_parts[1] = q.dmax_parts[1];
+        lp->dg_nparts = aslp_lstm_seq_last_dmax();
       }
       if (q.grad_partial) { vec_seq_ = q; vec_seq_valid_ = true; }
     } else {

@@ -139,6 +139,8 @@ struct LstmDir {
 struct LstmPlanes {
   PlaneSet in, od[2], wx[2], wrm[2], wr[2], m[2], r[2], dg[2], dr[2];
   bool weights_ok = false, in_ok = false, m_ok = false, od_ok = false, dg_ok = false;
+  const float *dg_parts[2] = {nullptr, nullptr};   // per-workgroup maxima of the gate diffs left by this pass' persistent backward launch
+  int dg_nparts = 0;
 };
 struct LstmPlanesHolder {   // a copied component starts without planes
   LstmPlanesHolder() = default;
@@ -198,6 +200,7 @@ class LstmFamily : public RecurrentBase {
   LstmPlanesHolder planes_;   // made on first use
   bool last_persistent_ = false;   // the last Propagate ran the recurrence as ONE persistent launch (else: launches per timestep)
   CuMatrix grad_partial_;          // per-chain bias / peephole gradient sums of the persistent backward launch (aslp_lstm_seq.grad_partial)
+  CuVector dmax_parts_;            // 2 x 256 per-workgroup maxima of the gate diffs from the same launch (aslp_lstm_seq.dmax_parts)
   aslp_lstm_seq vec_seq_ = aslp_lstm_seq();   // that launch's arguments, for aslp_lstm_seq_vec_grads
   bool vec_seq_valid_ = false;
 };

@@ -153,3 +153,9 @@ def test_lstm_layer_products_from_prepared_planes(tmp_path):
         other = run(tmp_path, "planes_" + level, ASLP_LSTM_PLANES=level, **shape)
         assert np.linalg.norm(other - base) / np.linalg.norm(base) < 1e-5, level
         assert np.abs(other - base).max() / max(1.0, np.abs(base).max()) < 1e-4, level
+    # the maxima of the gate diffs from the backward recurrence itself and the known bound of m (|o tanh c| < 1) instead of maximum passes:
+    # at most another power-of-two scale of the same planes
+    passes = run(tmp_path, "max_passes", ASLP_LSTM_KNOWN_BOUNDS="0", **shape)
+    default = run(tmp_path, "default", **shape)
+    assert np.linalg.norm(passes - default) / np.linalg.norm(default) < 1e-6
+    assert np.abs(passes - default).max() / max(1.0, np.abs(default).max()) < 1e-5
