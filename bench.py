@@ -971,8 +971,8 @@ def main():
                 traffic_src = "NOT measured in this run: committed PMC pass profiles/dnn_cfg2_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction)"
             except (OSError, KeyError, ValueError):
                 pass
-            tile_buf = C.create_string_buffer(128)
-            tile_cfg = aslp.lib.aslp_gemm_profile_tile(("NT", "NN", "TN", "TT").index(dom), tile_buf, 128)
+            tile_buf = C.create_string_buffer(256)
+            tile_cfg = aslp.lib.aslp_gemm_profile_tile(("NT", "NN", "TN", "TT").index(dom), tile_buf, 256)
             tile_name = tile_buf.value.decode()
             if traffic is not None and pmc.get("cfg") not in (None, tile_cfg):
                 traffic, traffic_src = None, "committed PMC pass was taken with tile cfg %s, this run used %d: omitted" % (pmc.get("cfg"), tile_cfg)
