@@ -983,6 +983,10 @@ def main():
                                "peak_note": ("dense fp16 MFMA peak %.0f TFLOP/s / 3 instructions per fp32-equivalent product" % F16_MFMA_PEAK_TFLOPS) if split
                                             else "fp32 MFMA peak",
                                "frac_of_fp32_mfma_peak": d["tflops"] / F32_MFMA_PEAK_TFLOPS,
+                               "what_bounds_it": ("measured (DESIGN 7, devtools/micro/lds_feed*.hip): the operand path L2 -> LDS -- one output tile per CU pulls (BM + BN) x K x 4 B "
+                                                  "through it, 402 MB for a 1024 x 2048 x 2048 product on 64 x 128 tiles against the L2's 33-35 TB/s -- and, for the "
+                                                  "weight gradients, an HBM-bound epilogue (W, gradient buffer and the new W's planes: 64-80 MB per launch); the matrix "
+                                                  "pipe is 22-30 % busy") if split else None,
                                "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                                "flop_per_launch": d["flop_per_launch"], "avg_launch_us": d["avg_us"], "launches": d["launches"],
                                "timing": "HIP events on the launch stream, second pass over the same K steps"}
