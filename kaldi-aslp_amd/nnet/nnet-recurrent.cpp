@@ -333,12 +333,12 @@ bool PlanesUsable(const LstmDir &f, int T, int S) {
 PlaneSet::ConvertSpec Spec(PlaneSet *ps, const CuMatrixBase &m) { return PlaneSet::ConvertSpec{ps, m.Data(), m.NumRows(), m.NumCols(), m.Stride()}; }
 }  // namespace
 
-void LstmDir::RefreshEffPair(const LstmDir &f, const LstmDir &b) {
+void LstmDir::RefreshEffPair(const LstmDir &f, const LstmDir &b, const S16View *views) {
   const bool stale_f = f.eff_dirty || f.aliased, stale_b = b.eff_dirty || b.aliased;
   if (!(stale_f && stale_b && f.R > 0 && SameShape(f, b))) { f.RefreshEff(); b.RefreshEff(); return; }
   for (const LstmDir *p : {&f, &b})
     if (p->w_eff.NumRows() != p->GC() || p->w_eff.NumCols() != p->C) p->w_eff.Resize(p->GC(), p->C, kUndefined);
-  AddMatMatPair(f.w_eff, b.w_eff, 1.0, f.w_r, b.w_r, kNoTrans, f.w_rm, b.w_rm, kNoTrans, 0.0);
+  AddMatMatPair(f.w_eff, b.w_eff, 1.0, f.w_r, b.w_r, kNoTrans, f.w_rm, b.w_rm, kNoTrans, 0.0, nullptr, nullptr, views);
   f.eff_dirty = b.eff_dirty = false;
   f.eff_t_dirty = b.eff_t_dirty = true;
 }
@@ -351,7 +351,9 @@ void LstmDir::ForwardPreparePair(const LstmDir &f, const LstmDir &b, const CuMat
     b.ForwardPrepare(in, T, S, true, nullptr, bbuf, persistent);
     return;
   }
-  RefreshEffPair(f, b);
+  // (with prepared planes W_eff = W_r W_rm waits for this step's conversion of the weights below and reads their planes)
+  const bool eff_from_planes = pl && persistent && PlanesUsable(f, T, S) && PlanesLevel() >= 3;
+  if (!eff_from_planes) RefreshEffPair(f, b);
   if (persistent && f.Width() % 4 == 0 && (!init_f || init_f->Stride() % 4 == 0)) {
     // both buffers in one launch: boundary row blocks zero (the forward direction's history block takes the carried state),
     // the m columns of row blocks 1..T "not yet published" (csrc/rnn_persistent.hip)
@@ -378,6 +380,10 @@ void LstmDir::ForwardPreparePair(const LstmDir &f, const LstmDir &b, const CuMat
                                    Spec(&pl->wx[0], f.w_x), Spec(&pl->wx[1], b.w_x), Spec(&pl->in, in)};
     pl->weights_ok = PlaneSet::ConvertMany(sp, in_ok ? 7 : 4);
     pl->in_ok = pl->weights_ok && in_ok;
+  }
+  if (eff_from_planes) {
+    const S16View v[4] = {pl->wr[0].View(), pl->wr[1].View(), pl->wrm[0].View(), pl->wrm[1].View()};
+    RefreshEffPair(f, b, pl->weights_ok ? v : nullptr);
   }
   if (pl && pl->in_ok) {
     const S16View v[4] = {pl->in.View(), pl->in.View(), pl->wx[0].View(), pl->wx[1].View()};

@@ -110,7 +110,7 @@ struct LstmDir {
   // Both directions of a bidirectional layer: every batched product below exists twice with the same shape, and most of them
   // (K or N = R, or a [R x C] output) cannot fill the chip alone -- they go out as pairs, one launch each (AddMatMatPair).
   // `with_gemm = false` on the single-direction methods leaves out the product the *Pair function then issues for both.
-  static void RefreshEffPair(const LstmDir &f, const LstmDir &b);
+  static void RefreshEffPair(const LstmDir &f, const LstmDir &b, const struct S16View *views = nullptr);   // views: planes of w_r (f, b), w_rm (f, b)
   // pl (may be NULL): where the layer keeps the fp16 planes of these products' operands (LstmPlanes below)
   static void ForwardPreparePair(const LstmDir &f, const LstmDir &b, const CuMatrixBase &in, int T, int S, const CuMatrixBase *init_f,
                                  CuMatrix *fbuf, CuMatrix *bbuf, bool persistent, struct LstmPlanes *pl = nullptr);
