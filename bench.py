@@ -28,6 +28,7 @@ FLOP_PER_FRAME = 141131776.0   # 2W fwd + 2(W-W1) bwd-data + 2W 
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
 F16_MFMA_PEAK_TFLOPS = 2516.0  # MI355X_MICROARCH.md: dense fp16 MFMA (v_mfma_f32_32x32x16_f16)
 SPLIT_PEAK_TF_EQUIV = F16_MFMA_PEAK_TFLOPS / 3.0   # three fp16 instructions per fp32-equivalent product: 839 TF-equivalent
+CFG2_LEARN_RATE = 0.008      # run_bn_dnn.sh:81-83 / SURVEY 8d (the kept weight planes' bound depends on it; rounds 1-4 timed at 1e-5)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 ARITHMETIC = "fp32 operands as 2xfp16 pieces behind power-of-two scales, fp32 accumulate"
 
@@ -340,7 +341,7 @@ def fp32_instruction_block(aslp, dev, steps, warmup):
     aslp.lib.aslp_gemm_split16(0)
     try:
         net = aslp.Nnet.Init(proto(), seed=777)
-        net.SetTrainOptions(learn_rate=1e-5, momentum=0.0)
+        net.SetTrainOptions(learn_rate=CFG2_LEARN_RATE, momentum=0.0)
         xent = aslp.Xent()
         g = torch.Generator(device=dev)
         g.manual_seed(1234)
@@ -411,17 +412,21 @@ def hbm_kernels_block(aslp, dev):
     import numpy as np
     import torch
 
-    def timed_us(fn, n=50, warm=5):
-        for _ in range(warm):
+    def timed_us(fn, n=50, warm=5, batches=21):
+        # warm, then the MEDIAN of `batches` back-to-back groups of max(1, n // 5) calls: one slow group (a lazy code-object load, a clock
+        # dip) no longer sets the figure
+        for _ in range(max(warm, 10)):
             fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = max(1, n // 5)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(batches + 1)]
         torch.cuda.synchronize()
-        e0.record()
-        for _ in range(n):
-            fn()
-        e1.record()
+        ev[0].record()
+        for b in range(batches):
+            for _ in range(reps):
+                fn()
+            ev[b + 1].record()
         torch.cuda.synchronize()
-        return e0.elapsed_time(e1) * 1e3 / n
+        return float(np.median([ev[b].elapsed_time(ev[b + 1]) * 1e3 / reps for b in range(batches)]))
 
     out = {}
 
@@ -483,7 +488,7 @@ def hbm_kernels_block(aslp, dev):
         net2.Propagate(x2)
         net2.Backpropagate(od2, want_in_diff=True)
     rec("row_convolution", timed_us(rowconv, 10), 4 * Dm * T * S * 7, "RowConvolution 512, FutureContext 20, T = 800, S = 32: forward + backward + update (7 tensor passes)")
-    return {"peak_gb_per_s": HBM_PEAK_GBS, "timing": "HIP events (torch.cuda.Event on the launch stream), mean over the repetitions", "kernels": out}
+    return {"peak_gb_per_s": HBM_PEAK_GBS, "timing": "HIP events (torch.cuda.Event on the launch stream): >= 10 warm-up calls, then the median over 21 back-to-back groups of calls", "kernels": out}
 
 
 def e2e_tool_block(frames=1024000):
@@ -515,7 +520,7 @@ def e2e_tool_block(frames=1024000):
         subprocess.run([os.path.join(bindir, "aslp-nnet-init"), "--print-args=false", os.path.join(tmp, "nnet.proto"), os.path.join(tmp, "nnet.init")],
                        check=True, capture_output=True, timeout=600)
         t0 = time.time()
-        p = subprocess.run([os.path.join(bindir, "aslp-nnet-train-frame"), "--print-args=false", "--learn-rate=0.00001", "--minibatch-size=%d" % MB,
+        p = subprocess.run([os.path.join(bindir, "aslp-nnet-train-frame"), "--print-args=false", "--learn-rate=%g" % CFG2_LEARN_RATE, "--minibatch-size=%d" % MB,
                             "--randomizer-size=32768", "ark:%s/feats.ark" % tmp, "ark:%s/post.ark" % tmp, os.path.join(tmp, "nnet.init"),
                             os.path.join(tmp, "nnet.out")], capture_output=True, timeout=900)
         wall = time.time() - t0
@@ -851,7 +856,7 @@ def main():
     aslp = aslp_import.load()   # raises if libaslp_hip.so is missing (no fallback)
     aslp.ops.use_torch_stream()
     net = aslp.Nnet.Init(proto(), seed=777)            # same init on every rank (like one aslp-nnet-init model)
-    net.SetTrainOptions(learn_rate=1e-5, momentum=0.0)  # small lr: synthetic labels, keep the run finite
+    net.SetTrainOptions(learn_rate=CFG2_LEARN_RATE, momentum=0.0)   # run_bn_dnn.sh:81-83,99-101
     if args.no_update_overlap:
         net.SetUpdateOverlap(False)
     xent = aslp.Xent()
@@ -915,6 +920,17 @@ def main():
     elapsed = time.perf_counter() - t0
     if comm is not None:
         elapsed = comm.MaxOverRanks(elapsed)
+    # Five more windows of the same K steps (N = 1): `value` above is the driver-comparable one; the spread of short windows on this box
+    # -- minimum, median, maximum -- goes into the line beside it (extra key `windows`)
+    windows = []
+    if comm is None:
+        for _ in range(5):
+            torch.cuda.synchronize()
+            tw = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            windows.append(world * args.steps * MB / (time.perf_counter() - tw))
 
     # Per-kernel durations for the roofline: HIP events around every GEMM launch on the launch stream, over the SAME
     # K steps run once more -- two event records per GEMM inside the timed region cost ~7 % of `value` (measured),
@@ -957,8 +973,12 @@ def main():
                                 if os.environ.get("ASLP_COMM_TRANSPORT") == "shm" else
                                 "native BspWorker on RcclComm (libaslp_parallel.so: ncclAllReduce over the parameter tensors in HBM)") if comm is not None else None,
                        "sync_period_frames": args.sync_period, "comm": _comm_facts(comm) if comm is not None else None,
-                       "learn_rate": 1e-5, "avg_xent_per_frame": (st["loss"] - st["entropy"]) / max(st["frames"], 1.0)},
+                       "learn_rate": CFG2_LEARN_RATE, "avg_xent_per_frame": (st["loss"] - st["entropy"]) / max(st["frames"], 1.0)},
         }
+        if windows:
+            ws = sorted([value] + windows)
+            out["windows"] = {"steps_each": args.steps, "count": len(ws), "min": ws[0], "median": ws[len(ws) // 2], "max": ws[-1],
+                              "note": "`value` and five further windows of the same K steps, back to back on this box"}
         timed = {k: v for k, v in gemm.items() if v["tflops"]}
         if timed:
             dom = max(timed, key=lambda k: timed[k]["avg_us"] * timed[k]["launches"])

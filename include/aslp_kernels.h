@@ -544,6 +544,10 @@ void aslp_fsmn_filter(float *out, int ldo, const float *src, int lds, const floa
                       int reverse);
 void aslp_fsmn_coef_grad(float *coef_corr, int ldc, const float *in, int ldi, const float *out_diff, int ldod, int D, int past, int future,
                          int T, float clip);
+/* The whole backward pass in ONE launch (BackpropagateFnc :204-256 + Update :258-262): in_diff as reverse = 1 above, coef_corr as
+ * coef_grad above, and -- with lr != 0 -- coef += -lr * coef_corr once every read of coef is done.  in_diff must not alias out_diff. */
+void aslp_fsmn_backward(float *in_diff, int ldid, float *coef_corr, int ldcc, float *coef, int ldc, const float *in, int ldi, const float *out_diff,
+                        int ldod, int D, int past, int future, int T, float clip, float lr);
 /* RowConvolution (nnet-row-convolution.cc:105-176): rows t*S + s, w dense [D x (K+1)], seq_len [S] on the device.
  *   forward : out[t] = sum_k w[:,k] .* in[min(t + k, L_s - 1)]   for t < L_s, 0 beyond
  *   backward: in_diff[t] = sum_{k <= t} w[:,k] .* out_diff[t - k] for t < L_s, 0 beyond
@@ -554,6 +558,10 @@ void aslp_rowconv_backward(float *in_diff, int ldid, const float *out_diff, int 
                            const int32_cuda *seq_len);
 void aslp_rowconv_wgrad(float *w_diff, const float *in, int ldi, const float *out_diff, int ldod, int D, int K, int T, int S,
                         const int32_cuda *seq_len);
+/* backward + wgrad in ONE pass over in / out_diff (each read once, in_diff written once) and a small launch that adds the tap partials in a
+ * fixed order; with update != 0 that launch also takes the step of Update (:178-186): w_corr = momentum w_corr + w_diff, w -= learn_rate w_corr */
+void aslp_rowconv_backward_fused(float *in_diff, int ldid, float *w_diff, const float *in, int ldi, const float *out_diff, int ldod, float *w, int D,
+                                 int K, int T, int S, const int32_cuda *seq_len, float *w_corr, float momentum, float learn_rate, int update);
 /* ---- Eesen CTC rows (cu-kernels-ansi.h:366-394; device code cu-kernels.cu:3276-3534) -----------------------
  * One lattice row per launch, log domain with log_zero = -1e30 (ctc-utils.h:28-95); `prob` holds LOG
  * probabilities for alpha/beta and probabilities for error; labels are blank-augmented, -1 padded. */

@@ -160,6 +160,11 @@ _sig("aslp_region_get", C.c_long, C.c_char_p, C.POINTER(C.c_double))
 # fused
 _sig("aslp_bn_forward", None, _vp, _md, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f)
 _sig("aslp_bn_backward", None, _vp, _md, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i)
+# depthwise temporal filters (csrc/temporal.hip)
+_sig("aslp_fsmn_filter", None, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i)
+_sig("aslp_fsmn_backward", None, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _f)
+_sig("aslp_rowconv_forward", None, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp)
+_sig("aslp_rowconv_backward_fused", None, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _f, _f, _i)
 _sig("aslp_bn_apply", None, _vp, _md, _vp, _i, _vp, _vp, _vp, _vp)
 _sig("aslp_xent_eval", None, _vp, _md, _vp, _i, _vp, _vp, _vp, _i, _vp)
 _sig("aslp_bn_forward_act", None, _vp, _md, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i)

@@ -912,9 +912,19 @@ bool gemm_split16_planes_launch(GemmArgs &g, bool a_kc, bool b_kc, const S16View
   // A long reduction on a grid that cannot fill the chip (the minibatch-256 layer products: 64 tiles of 64 x 128 for 256 CUs): K is split
   // over blockIdx.y, the chunks' partial products are added in chunk order by gemm_glds.hip's second launch, which also runs the epilogue
   // (bias, clip, SGD step, activation output -- not planes / maxima / column statistics: such requests keep the single launch).
+  const long tiles = (long)((g.M + 63) / 64) * ((g.N + 127) / 128) * (g.pair ? 2 : 1);
+  // per-workgroup maxima go to arrays of kS16MaxParts floats (PlaneSet::Parts, the components' own): a grid with more workgroups than
+  // that leaves none (the smallest tile of such a grid is 64 x 128), and planes of updated weights, whose bound is formed from maxima, go too
+  if (tiles > kS16MaxParts) {
+    auto drop_maxima = [](aslp_gemm_epilogue &ep) {
+      if (ep.planes_of == 1) { ep.planes_of = 0; ep.bound_w_parts = ep.bound_c_parts = nullptr; }
+      ep.wmax_parts = ep.cmax_parts = nullptr;
+    };
+    drop_maxima(g.ep);
+    if (g.pair) drop_maxima(g.ep1);
+  }
   const bool extras = g.ep.planes_of != 0 || g.ep.wmax_parts || g.ep.cmax_parts || g.ep.colstats || g.ep.colsum ||
                       (g.pair && (g.ep1.planes_of != 0 || g.ep1.wmax_parts || g.ep1.cmax_parts || g.ep1.colstats || g.ep1.colsum));
-  const long tiles = (long)((g.M + 63) / 64) * ((g.N + 127) / 128) * (g.pair ? 2 : 1);
   static const int splitk_off = [] { const char *e = getenv("ASLP_GEMM_SPLITK"); return e && atoi(e) == 0; }();
   // (act_out planes asked for by a forward product are given up for the split: the consumer converts the small activation matrix itself)
   // (the second launch writes the planes of an activation output and the maxima of |C| itself: those two requests go with the split)

@@ -103,6 +103,14 @@ void *scratch(int slot, size_t bytes) {
   return blk;
 }
 
+void *scratch_zeroed(int slot, size_t bytes) {
+  const size_t before = t_arenas.cap[t_bank][slot];
+  void *p = scratch(slot, bytes);
+  if (p && t_arenas.cap[t_bank][slot] != before &&
+      hipMemsetAsync(p, 0, t_arenas.cap[t_bank][slot], cur_stream()) != hipSuccess) { set_error("scratch_zeroed: hipMemsetAsync failed"); return nullptr; }
+  return p;
+}
+
 // ---- side stream: fork / join by events, no host synchronisation --------------------------------------------
 static thread_local hipStream_t t_side = nullptr;
 static thread_local hipEvent_t t_fork_ev = nullptr, t_join_ev = nullptr;
@@ -151,6 +159,23 @@ void join_side_stream() {
   if (hipEventRecord(t_join_ev, t_side) != hipSuccess || hipStreamWaitEvent(t_side_parent, t_join_ev, 0) != hipSuccess)
     set_error("side stream: join failed");
 }
+
+bool side_stream_mark(void **ev) {
+  if (!t_side_dirty || !t_side || !ev) return false;
+  if (!*ev) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { set_error("side stream: cannot create a marker event"); return false; }
+    *ev = e;
+  }
+  if (hipEventRecord(static_cast<hipEvent_t>(*ev), t_side) != hipSuccess) { set_error("side stream: marker record failed"); return false; }
+  return true;
+}
+void side_stream_mark_wait(void *ev, bool host) {
+  if (!ev) return;
+  const hipError_t e = host ? hipEventSynchronize(static_cast<hipEvent_t>(ev)) : hipStreamWaitEvent(cur_stream(), static_cast<hipEvent_t>(ev), 0);
+  if (e != hipSuccess) set_error(std::string("side stream: marker wait failed: ") + hipGetErrorString(e));
+}
+void side_stream_mark_free(void *ev) { if (ev) (void)hipEventDestroy(static_cast<hipEvent_t>(ev)); }
 
 // ---- named region timers (bench.py's cfg3 block): HIP events on the launch stream around a host-side region ------------
 namespace {

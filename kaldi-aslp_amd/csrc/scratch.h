@@ -2,10 +2,13 @@
 #pragma once
 #include <stddef.h>
 namespace aslp {
-enum { kScratchReduce = 0, kScratchReduce2 = 1, kScratchGemm = 2, kScratchCtc = 3, kScratchMisc = 4, kScratchSplitK = 5, kScratchSplit16 = 6, kNumScratch = 7 };
+enum { kScratchReduce = 0, kScratchReduce2 = 1, kScratchGemm = 2, kScratchCtc = 3, kScratchMisc = 4, kScratchSplitK = 5, kScratchSplit16 = 6, kScratchTickets = 7, kNumScratch = 8 };
 // Scratch of the calling thread's current stream: the side stream has its own bank, so ops running there never
 // share a partial-sum buffer with ops on the main stream.
 void *scratch(int slot, size_t bytes);
+// The same, for words that kernels hand from launch to launch (tickets, counters): the block is zero when it is (re)allocated, and every
+// kernel that uses it leaves it zero.  A slot is either used through this call or through scratch(), never both.
+void *scratch_zeroed(int slot, size_t bytes);
 
 // While alive, every launch of this thread goes to the library's side stream, ordered after everything issued on the
 // main stream so far (event wait, no host sync).  join_side_stream() makes the main stream wait for the side work
@@ -33,5 +36,12 @@ class RegionScope {
   void *e0_;
 };
 void join_side_stream();
+// A marker for the side-stream work the calling thread has issued so far, for waiters that may sit on another host thread (whose own
+// join_side_stream() knows nothing of this thread's side stream).  side_stream_mark(ev) records into *ev (created on first use; the
+// caller owns it and gives it back with side_stream_mark_free) and returns false when there is no pending side work.
+// side_stream_mark_wait(ev, host): the calling thread's current stream waits for the marker -- or the host does.
+bool side_stream_mark(void **ev);
+void side_stream_mark_wait(void *ev, bool host);
+void side_stream_mark_free(void *ev);
 bool on_side_stream();  // is the calling thread inside a SideStreamScope?
 }  // namespace aslp

@@ -4,10 +4,24 @@
 // frame and keeps only its diagonal (nnet-row-convolution.cc:128-133, D^2 (K+1) flops for D (K+1)
 // useful ones) plus ~8 elementwise launches per frame in backward; CompactFsmn materialises a
 // T*(P+F+1) x D product matrix and row-sums it (nnet-cfsmn-component.h:191-201).  Both are really
-// per-column FIR filters along time -- HBM/L2-bound, no matrix core involved -- so here each is one
-// direct kernel per pass: lanes run along the feature dimension (coalesced rows), every thread
-// slides a register window over TT consecutive frames, and the tap gradients use a deterministic
-// two-stage reduction (partials per frame chunk, then a fixed-order sum; no float atomics).
+// per-column FIR filters along time -- HBM/L2-bound, no matrix core involved.
+//
+// RowConvolution (tensors of tens of MB): two STREAMING kernels.  A lane owns two adjacent feature columns of one stream and walks
+// down time; every element is loaded once per chunk of 64 frames (+ a halo of K rows) and meets all K + 1 taps in registers
+// (v_pk_fma_f32 on column pairs; at 21 taps x 2 flop per 4 bytes the vector pipe is as close to its limit as the HBM is).
+// Forward keeps a ring of K + 1 running outputs; backward keeps a ring of the last K + 1 out-diff rows, which is all that BOTH the
+// in-diff and the tap gradients need -- one pass over `in` and `out_diff`, one write of `in_diff`.  Workgroup ids are laid out so
+// that the chunks of one strip of columns follow each other on ONE XCD (the halo rows are then L2 hits).  Tap gradients: four
+// streams are summed in LDS, then one partial per (chunk, stream group); a small second launch adds them in a fixed order (no float
+// atomics) and takes the momentum + SGD step.
+//
+// CompactFsmn (one utterance, T x D of a few MB: launch-latency territory): tiles of 64 columns staged in LDS.  Forward: one launch.
+// Backward: ONE launch forms the in-diff (the reversed filter), the tap gradients of its frames, and -- in the workgroup that arrives
+// last at its column tile's ticket -- their fixed-order sum over the chunks, the clip and the SGD step.
+//
+// Shapes outside what these serve (more than 32 taps in RowConvolution, odd widths, filters too long for the LDS tile) run on the
+// simpler kernels kept at the end of each section: lanes along the feature dimension, a register window over TT frames per thread,
+// tap gradients by a two-stage reduction.
 #include "aslp_kernels.h"
 #include "common.h"
 #include "scratch.h"
@@ -194,6 +208,341 @@ __global__ void __launch_bounds__(kBlock) rowconv_wgrad2(float *__restrict__ w_d
   }
 }
 
+// ---- RowConvolution, streaming -----------------------------------------------------------------------------
+typedef float f2 __attribute__((ext_vector_type(2)));
+constexpr int kRcCols = 2 * kWave;   // feature columns per workgroup (two per lane)
+constexpr int kRcStreams = kBlock / kWave;   // streams per workgroup (one per wave)
+
+// workgroup id -> (strip of columns x stream group, chunk of frames): the chunks of a strip are consecutive ids ON ONE XCD
+// (ids go round-robin over the 8 XCDs)
+struct RcPlace { int chunk, dtile, sgroup; bool valid; };
+__device__ __forceinline__ RcPlace rc_place(int nchunks, int dtiles, int nstrips) {
+  const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+  RcPlace p;
+  p.chunk = j % nchunks;
+  const int strip = (j / nchunks) * 8 + xcd;
+  p.valid = strip < nstrips;
+  p.dtile = strip % dtiles;
+  p.sgroup = strip / dtiles;
+  return p;
+}
+
+// out[t] = sum_{k <= K} w[:,k] in[min(t + k, L - 1)] for t < L, 0 beyond.  KP >= K + 1 is the ring length; EXACT: KP == K + 1 (no
+// tap is tested against K).  Row r meets tap k for output t = r - k, which lives in ring slot (t - ta) mod KP: static indices once
+// the row loop is unrolled by KP.  An output is taken out of the ring KP - 1 rows after its own row (taps beyond K are not applied).
+template <int KP, bool EXACT>
+__global__ void __launch_bounds__(kBlock) rowconv_fwd_stream(float *__restrict__ out, int ldo, const float *__restrict__ in, int ldi,
+                                                             const float *__restrict__ w, int D, int K, int T, int S,
+                                                             const int32_t *__restrict__ seq_len, int tc, int nchunks, int dtiles, int nstrips) {
+  const RcPlace pl = rc_place(nchunks, dtiles, nstrips);
+  if (!pl.valid) return;
+  const int d0 = (pl.dtile * kWave + threadIdx.x) * 2, s = pl.sgroup * kRcStreams + threadIdx.y;
+  if (d0 >= D || s >= S) return;
+  const int ta = pl.chunk * tc, tb = min(T, ta + tc);
+  const int L = min(seq_len[s], T), tv = min(tb, L);
+  const long rs_in = (long)S * ldi, rs_out = (long)S * ldo;
+  float *op = out + (long)s * ldo + d0;
+  if (tv > ta) {
+    const float *ip = in + (long)s * ldi + d0;
+    f2 wr[KP], acc[KP];
+#pragma unroll
+    for (int k = 0; k < KP; k++) {
+      wr[k] = (EXACT || k <= K) ? f2{w[(long)d0 * (K + 1) + k], w[(long)(d0 + 1) * (K + 1) + k]} : f2{0.f, 0.f};
+      acc[k] = f2{0.f, 0.f};
+    }
+    const int rend = tv + KP - 1;
+    for (int r0 = ta; r0 < rend; r0 += KP) {
+      f2 x[KP];
+#pragma unroll
+      for (int i = 0; i < KP; i++) x[i] = *reinterpret_cast<const f2 *>(ip + (long)min(r0 + i, L - 1) * rs_in);   // the last frame repeats
+#pragma unroll
+      for (int i = 0; i < KP; i++) {
+#pragma unroll
+        for (int k = 0; k < KP; k++)
+          if (EXACT || k <= K) acc[(i - k + KP) % KP] += wr[k] * x[i];
+        const int t = r0 + i - (KP - 1);
+        if (t >= ta && t < tv) *reinterpret_cast<f2 *>(op + (long)t * rs_out) = acc[(i + 1) % KP];
+        acc[(i + 1) % KP] = f2{0.f, 0.f};
+      }
+    }
+  }
+  for (int t = max(tv, ta); t < tb; t++) *reinterpret_cast<f2 *>(op + (long)t * rs_out) = f2{0.f, 0.f};   // frames past the end stay 0
+}
+
+// One pass over rows r of [0, T + K): with the ring o[k] = out_diff[r - k] (0 outside [0, L))
+//   in_diff[r] = sum_k w[:,k] o[k]                      (r < L; 0 beyond)
+//   g[:,k]    += in[min(r, L - 1)] o[k]                 (every pair (t = r - k < L, k) exactly once over the chunks)
+// then the tap sums of the workgroup's four streams meet in LDS and leave as ONE partial [K + 1][D] per (chunk, stream group).
+template <int KP, bool EXACT>
+__global__ void __launch_bounds__(kBlock) rowconv_bwd_fused(float *__restrict__ in_diff, int ldid, float *__restrict__ partial,
+                                                            const float *__restrict__ in, int ldi, const float *__restrict__ od, int ldod,
+                                                            const float *__restrict__ w, int D, int K, int T, int S,
+                                                            const int32_t *__restrict__ seq_len, int tc, int nchunks, int dtiles, int nstrips,
+                                                            int sgroups) {
+  __shared__ float red[kRcStreams - 1][KP][kRcCols];
+  const RcPlace pl = rc_place(nchunks, dtiles, nstrips);
+  if (!pl.valid) return;   // (the whole workgroup)
+  const int x = threadIdx.x, y = threadIdx.y;
+  const int d0 = (pl.dtile * kWave + x) * 2, s = pl.sgroup * kRcStreams + y;
+  const bool live = d0 < D && s < S;
+  f2 g[KP];
+#pragma unroll
+  for (int k = 0; k < KP; k++) g[k] = f2{0.f, 0.f};
+  if (live) {
+    const int ra = pl.chunk * tc, rb = ra + tc;
+    const int L = min(seq_len[s], T), re = min(rb, L + K);
+    const long rs_in = (long)S * ldi, rs_od = (long)S * ldod, rs_id = (long)S * ldid;
+    float *dp = in_diff + (long)s * ldid + d0;
+    if (re > ra && L > 0) {
+      const float *ip = in + (long)s * ldi + d0, *gp = od + (long)s * ldod + d0;
+      f2 wr[KP], o[KP];
+#pragma unroll
+      for (int k = 0; k < KP; k++) wr[k] = (EXACT || k <= K) ? f2{w[(long)d0 * (K + 1) + k], w[(long)(d0 + 1) * (K + 1) + k]} : f2{0.f, 0.f};
+      // rows ra - (KP - 1) ... ra - 1 in slots 0 ... KP - 2; row r of the loop goes to slot (KP - 1 + i) % KP
+#pragma unroll
+      for (int j = 0; j < KP - 1; j++) {
+        const int r = ra - (KP - 1) + j;
+        o[j] = (r >= 0 && r < L) ? *reinterpret_cast<const f2 *>(gp + (long)r * rs_od) : f2{0.f, 0.f};
+      }
+      o[KP - 1] = f2{0.f, 0.f};
+      for (int r0 = ra; r0 < re; r0 += KP) {
+        f2 xi[KP], oi[KP];
+#pragma unroll
+        for (int i = 0; i < KP; i++) {
+          const int r = min(r0 + i, L - 1);
+          xi[i] = *reinterpret_cast<const f2 *>(ip + (long)r * rs_in);
+          oi[i] = *reinterpret_cast<const f2 *>(gp + (long)r * rs_od);
+        }
+#pragma unroll
+        for (int i = 0; i < KP; i++) {
+          const int r = r0 + i;
+          if (r < re) {   // (uniform over the wave: one stream per wave)
+            o[(KP - 1 + i) % KP] = r < L ? oi[i] : f2{0.f, 0.f};
+            f2 idf = f2{0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < KP; k++)
+              if (EXACT || k <= K) {
+                const f2 ok = o[(KP - 1 + i - k + KP) % KP];
+                g[k] += xi[i] * ok;
+                idf += wr[k] * ok;
+              }
+            if (r < L) *reinterpret_cast<f2 *>(dp + (long)r * rs_id) = idf;
+          }
+        }
+      }
+    }
+    for (int r = max(ra, L); r < min(rb, T); r++) *reinterpret_cast<f2 *>(dp + (long)r * rs_id) = f2{0.f, 0.f};
+  }
+  if (y > 0) {
+#pragma unroll
+    for (int k = 0; k < KP; k++) { red[y - 1][k][2 * x] = g[k].x; red[y - 1][k][2 * x + 1] = g[k].y; }
+  }
+  __syncthreads();
+  if (y == 0 && d0 < D) {
+    float *pp = partial + ((long)pl.chunk * sgroups + pl.sgroup) * (K + 1) * D + d0;
+#pragma unroll
+    for (int k = 0; k < KP; k++)
+      if (EXACT || k <= K) {
+        f2 sum = g[k];
+#pragma unroll
+        for (int j = 0; j < kRcStreams - 1; j++) { sum.x += red[j][k][2 * x]; sum.y += red[j][k][2 * x + 1]; }
+        *reinterpret_cast<f2 *>(pp + (long)k * D) = sum;
+      }
+  }
+}
+// w_diff[d][k] = sum of the partials (a fixed order: wave y adds parts y, y + 16, ..., then the sixteen sums are added in wave order); with
+// `update` the step of nnet-row-convolution.cc:178-186 rides along: w_corr = momentum w_corr + w_diff, w -= lr w_corr.
+// One workgroup per (tap, 64 columns): sixteen waves, so that every thread has a dozen loads in flight instead of two hundred in a row.
+constexpr int kFinishWaves = 16;
+__global__ void __launch_bounds__(kWave * kFinishWaves) rowconv_wgrad_finish(float *__restrict__ w_diff, const float *__restrict__ partial, int D, int K,
+                                                                            int nparts, float *__restrict__ w_corr, float *__restrict__ w, float mmt,
+                                                                            float lr, int update) {
+  __shared__ float red[kFinishWaves][kWave];
+  const int x = threadIdx.x, y = threadIdx.y, d = blockIdx.x * kWave + x, k = blockIdx.y;
+  float s = 0.0f;
+  if (d < D) {
+#pragma unroll 16
+    for (int c = y; c < nparts; c += kFinishWaves) s += partial[((long)c * (K + 1) + k) * D + d];
+  }
+  red[y][x] = s;
+  __syncthreads();
+  if (y != 0 || d >= D) return;
+#pragma unroll
+  for (int j = 1; j < kFinishWaves; j++) s += red[j][x];
+  const long o = (long)d * (K + 1) + k;
+  w_diff[o] = s;
+  if (update) {
+    const float c = mmt * w_corr[o] + s;
+    w_corr[o] = c;
+    w[o] += -lr * c;
+  }
+}
+
+// ---- CompactFsmn, LDS tiles ---------------------------------------------------------------------------------
+// One utterance is a few MB: these kernels are made of latencies, not of bandwidth.  Workgroups of SIXTEEN waves on 64 columns, so that the
+// rows of a tile are a dozen loads per thread, all in flight at once (stage_rows), and the last workgroup of a column tile (backward) has
+// thirty partials per thread to add instead of hundreds.
+constexpr int kFsmnWaves = 16;
+constexpr int kFsmnThreads = kWave * kFsmnWaves;
+
+// rows [r0, r0 + n) of a [T x D] matrix into an LDS tile of 64 columns (zeros outside the matrix; `spare` further rows of zeros), by the
+// whole workgroup; loads go out in batches of twelve per thread (192 rows: every load of the usual tiles in flight at once)
+__device__ __forceinline__ void stage_rows(float *__restrict__ tile, const float *__restrict__ src, int ld, int r0, int n, int spare, int T, bool col_ok,
+                                           int d, int x, int y) {
+  constexpr int U = 12;
+  for (int i0 = y; i0 < n + spare; i0 += kFsmnWaves * U) {
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int i = i0 + u * kFsmnWaves, r = r0 + i;
+      v[u] = (col_ok && i < n && r >= 0 && r < T) ? src[(long)r * ld + d] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int i = i0 + u * kFsmnWaves;
+      if (i < n + spare) tile[i * kWave + x] = v[u];
+    }
+  }
+}
+// out[t] = base[t] + sum_j taps[j] win[t + j] for the wave's blocks of TT frames of a tile: `tile` row i holds source row ta - pad + i
+__device__ __forceinline__ void filter_tile(float *__restrict__ out, int ldo, const float *__restrict__ tile, const float *__restrict__ taps, int C, int pad,
+                                            int ta, int tb, int d, int x, int y) {
+  for (int t0 = y * TT; t0 < tb - ta; t0 += kFsmnWaves * TT) {
+    float acc[TT], win[TT];
+#pragma unroll
+    for (int u = 0; u < TT; u++) { acc[u] = 0.0f; win[u] = tile[(t0 + u) * kWave + x]; }
+#pragma unroll 4
+    for (int j = 0; j < C; j++) {
+      const float c = taps[j * kWave + x];
+#pragma unroll
+      for (int u = 0; u < TT; u++) acc[u] += win[u] * c;
+#pragma unroll
+      for (int u = 0; u < TT - 1; u++) win[u] = win[u + 1];
+      win[TT - 1] = tile[(t0 + TT + j) * kWave + x];   // (at most row tcf + C - 1 + TT - 1: the spare rows)
+    }
+#pragma unroll
+    for (int u = 0; u < TT; u++)
+      if (ta + t0 + u < tb) out[(long)(ta + t0 + u) * ldo + d] = tile[(t0 + u + pad) * kWave + x] + acc[u];
+  }
+}
+
+// out[t] = src[t] + sum_j coef[row(j)] src[t + j - pad] on a tile of 64 columns x tcf frames.
+// sm: [tcf + C - 1 + TT][64] source rows ta - pad ..., then [C][64] taps in application order.
+__global__ void __launch_bounds__(kFsmnThreads) fsmn_filter_lds(float *__restrict__ out, int ldo, const float *__restrict__ src, int lds_,
+                                                                const float *__restrict__ coef, int ldc, int D, int C, int pad, int reverse, int T, int tcf) {
+  extern __shared__ float sm[];
+  const int x = threadIdx.x, y = threadIdx.y, d = blockIdx.x * kWave + x;
+  const int ta = blockIdx.y * tcf, tb = min(T, ta + tcf), rows = tcf + C - 1;
+  float *tile = sm, *taps = sm + (long)(rows + TT) * kWave;
+  stage_rows(tile, src, lds_, ta - pad, rows, TT, T, d < D, d, x, y);
+  for (int j = y; j < C; j += kFsmnWaves) taps[j * kWave + x] = d < D ? coef[(long)(reverse ? C - 1 - j : j) * ldc + d] : 0.0f;
+  __syncthreads();
+  if (d < D) filter_tile(out, ldo, tile, taps, C, pad, ta, tb, d, x, y);
+}
+
+constexpr int kFsmnTapsPerThread = 4;
+// Backward of a tile of 64 columns x tcb frames [ta, tb):
+//   in_diff[t] = od[t] + sum_j coef[C-1-j] od[t + j - F]                  (cfsmn.h:232-249)
+//   partial[chunk][i] = sum_{t in chunk} in[t + i - P] od[t]               (:213-219)
+// and, in the workgroup that is the LAST of its column tile to get here (a ticket per tile): corr[i] = clip(sum over the chunks in
+// chunk order) and, with lr != 0, coef[i] -= lr corr[i] (:258-262) -- every other workgroup of the tile has read its taps by then.
+// sm: [rows + TT][64] od rows ta - F ..., [rows][64] in rows ta - P ... (rows = tcb + C - 1), [C][64] reversed taps.
+__global__ void __launch_bounds__(kFsmnThreads) fsmn_backward_fused(float *__restrict__ in_diff, int ldid, float *__restrict__ partial,
+                                                                    unsigned *__restrict__ tickets, float *__restrict__ corr, int ldcc,
+                                                                    float *__restrict__ coef, int ldc, const float *__restrict__ in, int ldi,
+                                                                    const float *__restrict__ od, int ldod, int D, int C, int P, int F, int T, int tcb,
+                                                                    int nchunks, float clip, float lr) {
+  extern __shared__ float sm[];
+  __shared__ unsigned last_flag;
+  const int x = threadIdx.x, y = threadIdx.y, d = blockIdx.x * kWave + x;
+  const int chunk = blockIdx.y, ta = chunk * tcb, tb = min(T, ta + tcb), rows = tcb + C - 1;
+  float *odt = sm, *int_ = odt + (long)(rows + TT) * kWave, *taps = int_ + (long)rows * kWave;
+  {   // the three tiles in ONE round of loads (as stage_rows, twelve rows of each per thread and round)
+    constexpr int U = 12;
+    const bool col_ok = d < D;
+    for (int i0 = y; i0 < rows + TT || i0 < C; i0 += kFsmnWaves * U) {
+      float vo[U], vi[U], vt[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int i = i0 + u * kFsmnWaves, ro = ta - F + i, ri = ta - P + i;
+        vo[u] = (col_ok && i < rows && ro >= 0 && ro < T) ? od[(long)ro * ldod + d] : 0.0f;
+        vi[u] = (col_ok && i < rows && ri >= 0 && ri < T) ? in[(long)ri * ldi + d] : 0.0f;
+        vt[u] = (col_ok && i < C) ? coef[(long)(C - 1 - i) * ldc + d] : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int i = i0 + u * kFsmnWaves;
+        if (i < rows + TT) odt[i * kWave + x] = vo[u];
+        if (i < rows) int_[i * kWave + x] = vi[u];
+        if (i < C) taps[i * kWave + x] = vt[u];
+      }
+    }
+  }
+  __syncthreads();
+  if (d < D) {
+    filter_tile(in_diff, ldid, odt, taps, C, F, ta, tb, d, x, y);
+    // tap gradients of this chunk: 4 taps per thread, a window of the in tile sliding down the chunk's frames
+    for (int ib = y * kFsmnTapsPerThread; ib < C; ib += kFsmnWaves * kFsmnTapsPerThread) {
+      float acc[kFsmnTapsPerThread], win[kFsmnTapsPerThread];
+#pragma unroll
+      for (int j = 0; j < kFsmnTapsPerThread; j++) { acc[j] = 0.0f; win[j] = ib + j < rows ? int_[(ib + j) * kWave + x] : 0.0f; }
+#pragma unroll 4
+      for (int tt = 0; tt < tb - ta; tt++) {
+        const float gsc = odt[(tt + F) * kWave + x];
+#pragma unroll
+        for (int j = 0; j < kFsmnTapsPerThread; j++) acc[j] += win[j] * gsc;
+#pragma unroll
+        for (int j = 0; j < kFsmnTapsPerThread - 1; j++) win[j] = win[j + 1];
+        const int nx = tt + ib + kFsmnTapsPerThread;
+        win[kFsmnTapsPerThread - 1] = nx < rows ? int_[nx * kWave + x] : 0.0f;
+      }
+#pragma unroll
+      for (int j = 0; j < kFsmnTapsPerThread; j++)
+        if (ib + j < C) partial[((long)chunk * C + ib + j) * D + d] = acc[j];
+    }
+  }
+  // ticket of the column tile
+  __threadfence();
+  __syncthreads();
+  if (x == 0 && y == 0) last_flag = __hip_atomic_fetch_add(tickets + blockIdx.x, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nchunks - 1);
+  __syncthreads();
+  if (!last_flag) return;
+  __threadfence();
+  if (d < D)
+    for (int i0 = y; i0 < C; i0 += kFsmnWaves * 4) {   // four taps per thread and round, eight partials of each in flight
+      float s[4] = {0.0f, 0.0f, 0.0f, 0.0f}, w_old[4];
+#pragma unroll
+      for (int a = 0; a < 4; a++) {
+        const int i = i0 + a * kFsmnWaves;
+        w_old[a] = (lr != 0.0f && i < C) ? coef[(long)i * ldc + d] : 0.0f;
+      }
+      for (int c0 = 0; c0 < nchunks; c0 += 8) {
+        float v[4][8];
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+          for (int c = 0; c < 8; c++) {
+            const int i = i0 + a * kFsmnWaves;
+            v[a][c] = (i < C && c0 + c < nchunks) ? __hip_atomic_load(partial + ((long)(c0 + c) * C + i) * D + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+          }
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+          for (int c = 0; c < 8; c++) s[a] += v[a][c];   // chunk order
+      }
+#pragma unroll
+      for (int a = 0; a < 4; a++) {
+        const int i = i0 + a * kFsmnWaves;
+        if (i >= C) continue;
+        float g = s[a];
+        if (clip > 0.0f) g = fminf(fmaxf(g, -clip), clip);
+        corr[(long)i * ldcc + d] = g;  // beta 0: no momentum in the reference (cfsmn.h:219)
+        if (lr != 0.0f) coef[(long)i * ldc + d] = w_old[a] + -lr * g;
+      }
+    }
+  if (x == 0 && y == 0) __hip_atomic_store(tickets + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+}
+
 // rows per chunk so that (column tiles x chunks) is a few hundred blocks
 int rows_per_chunk(int rows, int ctiles) {
   int want = (512 + ctiles - 1) / ctiles;
@@ -208,13 +557,60 @@ using namespace aslp;
 
 extern "C" {
 
+// LDS budget of the tiled CompactFsmn kernels (of the CU's 160 KB)
+static constexpr int kFsmnLdsRows = 512;   // rows of 64 floats: 128 KB
+
 void aslp_fsmn_filter(float *out, int ldo, const float *src, int lds, const float *coef, int ldc, int D, int past, int future, int T,
                       int reverse) {
   if (T <= 0 || D <= 0) return;
-  const int C = past + future + 1;
-  dim3 block(kWave, kBlock / kWave), grid((D + kWave - 1) / kWave, (T + TT * (kBlock / kWave) - 1) / (TT * (kBlock / kWave)));
-  hipLaunchKernelGGL(fsmn_filter, grid, block, 0, cur_stream(), out, ldo, src, lds, coef, ldc, D, C, reverse ? future : past, reverse, T);
+  const int C = past + future + 1, pad = reverse ? future : past;
+  const int tcf = kFsmnWaves * TT, rows = tcf + C - 1 + TT + C;   // a block of TT frames per wave
+  if (rows <= kFsmnLdsRows) {
+    const size_t lds_bytes = sizeof(float) * (size_t)rows * kWave;
+    static bool attr_set = false;
+    if (!attr_set) {
+      ASLP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fsmn_filter_lds), hipFuncAttributeMaxDynamicSharedMemorySize, kFsmnLdsRows * kWave * sizeof(float)));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(fsmn_filter_lds, dim3((D + kWave - 1) / kWave, (T + tcf - 1) / tcf), dim3(kWave, kFsmnWaves), lds_bytes, cur_stream(), out, ldo,
+                       src, lds, coef, ldc, D, C, pad, reverse, T, tcf);
+  } else {   // a filter too long for the tile
+    dim3 block(kWave, kBlock / kWave), grid((D + kWave - 1) / kWave, (T + TT * (kBlock / kWave) - 1) / (TT * (kBlock / kWave)));
+    hipLaunchKernelGGL(fsmn_filter, grid, block, 0, cur_stream(), out, ldo, src, lds, coef, ldc, D, C, pad, reverse, T);
+  }
   check_launch("aslp_fsmn_filter");
+}
+
+void aslp_fsmn_backward(float *in_diff, int ldid, float *coef_corr, int ldcc, float *coef, int ldc, const float *in, int ldi, const float *out_diff,
+                        int ldod, int D, int past, int future, int T, float clip, float lr) {
+  if (T <= 0 || D <= 0) return;
+  const int C = past + future + 1, ctiles = (D + kWave - 1) / kWave;
+  // frames per chunk: an eighth of the utterance (8 partials for the last workgroup of a tile to add), within the LDS budget
+  const int tcb_max = (kFsmnLdsRows - TT - 2 * (C - 1) - C) / 2;
+  if (tcb_max < 16) {   // a filter too long for the tile: the separate kernels
+    aslp_fsmn_coef_grad(coef_corr, ldcc, in, ldi, out_diff, ldod, D, past, future, T, clip);
+    aslp_fsmn_filter(in_diff, ldid, out_diff, ldod, coef, ldc, D, past, future, T, 1);
+    if (lr != 0.0f) {   // coef += -lr coef_corr, row by row (the two matrices may have different pitches)
+      MatrixDim d = {C, D, ldc};
+      cudaF_add_mat(aslp_dim3{1, 1, 1}, aslp_dim3{1, 1, 1}, -lr, coef_corr, coef, d, ldcc, 0);
+    }
+    return;
+  }
+  int tcb = (T + 7) / 8;
+  tcb = tcb < 32 ? 32 : tcb;
+  tcb = tcb > tcb_max ? tcb_max : tcb;
+  const int nchunks = (T + tcb - 1) / tcb, rows = tcb + C - 1;
+  float *partial = static_cast<float *>(scratch(kScratchMisc, sizeof(float) * (size_t)nchunks * C * D));
+  unsigned *tickets = static_cast<unsigned *>(scratch_zeroed(kScratchTickets, sizeof(unsigned) * (size_t)ctiles));
+  if (!partial || !tickets) return;
+  static bool attr_set = false;
+  if (!attr_set) {
+    ASLP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fsmn_backward_fused), hipFuncAttributeMaxDynamicSharedMemorySize, kFsmnLdsRows * kWave * sizeof(float)));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(fsmn_backward_fused, dim3(ctiles, nchunks), dim3(kWave, kFsmnWaves), sizeof(float) * (size_t)(2 * rows + TT + C) * kWave, cur_stream(),
+                     in_diff, ldid, partial, tickets, coef_corr, ldcc, coef, ldc, in, ldi, out_diff, ldod, D, C, past, future, T, tcb, nchunks, clip, lr);
+  check_launch("aslp_fsmn_backward");
 }
 
 void aslp_fsmn_coef_grad(float *coef_corr, int ldc, const float *in, int ldi, const float *out_diff, int ldod, int D, int past, int future,
@@ -231,12 +627,64 @@ void aslp_fsmn_coef_grad(float *coef_corr, int ldc, const float *in, int ldi, co
   check_launch("aslp_fsmn_coef_grad");
 }
 
+// the streaming RowConvolution kernels serve up to 32 taps on even widths with 8-byte aligned rows
+static bool rowconv_stream_serves(int D, int K, int ld_a, int ld_b, const void *a, const void *b) {
+  return K + 1 <= 32 && !(D & 1) && !(ld_a & 1) && !(ld_b & 1) && !(reinterpret_cast<uintptr_t>(a) & 7u) && !(reinterpret_cast<uintptr_t>(b) & 7u);
+}
+static constexpr int kRcChunk = 64;   // frames per chunk: the K halo rows cost (64 + K) / 64 of the reads
+
 void aslp_rowconv_forward(float *out, int ldo, const float *in, int ldi, const float *w, int D, int K, int T, int S,
                           const int32_cuda *seq_len) {
   if (T <= 0 || D <= 0 || S <= 0) return;
+  if (rowconv_stream_serves(D, K, ldo, ldi, out, in)) {
+    const int dtiles = (D + kRcCols - 1) / kRcCols, sgroups = (S + kRcStreams - 1) / kRcStreams, nstrips = dtiles * sgroups;
+    const int tc = kRcChunk, nchunks = (T + tc - 1) / tc;
+    const dim3 grid(8 * ((nstrips + 7) / 8) * nchunks), block(kWave, kRcStreams);
+#define ASLP_RC_FWD(KP, EXACT) hipLaunchKernelGGL((rowconv_fwd_stream<KP, EXACT>), grid, block, 0, cur_stream(), out, ldo, in, ldi, w, D, K, T, S, seq_len, tc, nchunks, dtiles, nstrips)
+    if (K + 1 == 21) ASLP_RC_FWD(21, true);        // FutureContext 20 (the recipes' value): no tap is tested
+    else if (K + 1 <= 4) ASLP_RC_FWD(4, false);
+    else if (K + 1 <= 8) ASLP_RC_FWD(8, false);
+    else if (K + 1 <= 16) ASLP_RC_FWD(16, false);
+    else ASLP_RC_FWD(32, false);
+#undef ASLP_RC_FWD
+    check_launch("aslp_rowconv_forward");
+    return;
+  }
   dim3 block(kWave, kBlock / kWave), grid((D + kWave - 1) / kWave, (T + TT * (kBlock / kWave) - 1) / (TT * (kBlock / kWave)), S);
   hipLaunchKernelGGL(rowconv_fwd, grid, block, 0, cur_stream(), out, ldo, in, ldi, w, D, K, T, S, seq_len);
   check_launch("aslp_rowconv_forward");
+}
+
+void aslp_rowconv_backward_fused(float *in_diff, int ldid, float *w_diff, const float *in, int ldi, const float *out_diff, int ldod, float *w, int D,
+                                 int K, int T, int S, const int32_cuda *seq_len, float *w_corr, float momentum, float learn_rate, int update) {
+  if (T <= 0 || D <= 0 || S <= 0) return;
+  if (update && !w_corr) { set_error("aslp_rowconv_backward_fused: update without w_corr"); return; }
+  if (!(rowconv_stream_serves(D, K, ldid, ldi, in_diff, in) && !(ldod & 1) && !(reinterpret_cast<uintptr_t>(out_diff) & 7u))) {
+    aslp_rowconv_backward(in_diff, ldid, out_diff, ldod, w, D, K, T, S, seq_len);
+    aslp_rowconv_wgrad(w_diff, in, ldi, out_diff, ldod, D, K, T, S, seq_len);
+    if (update) {   // nnet-row-convolution.cc:178-186
+      const int n = D * (K + 1);
+      cudaF_scale(aslp_dim3{1, 1, 1}, aslp_dim3{1, 1, 1}, w_corr, momentum, MatrixDim{1, n, n});
+      aslp_vec_axpy(1.0f, w_diff, w_corr, n);
+      aslp_vec_axpy(-learn_rate, w_corr, w, n);
+    }
+    return;
+  }
+  const int dtiles = (D + kRcCols - 1) / kRcCols, sgroups = (S + kRcStreams - 1) / kRcStreams, nstrips = dtiles * sgroups;
+  const int tc = kRcChunk, nchunks = (T + K + tc - 1) / tc, nparts = nchunks * sgroups;
+  float *partial = static_cast<float *>(scratch(kScratchMisc, sizeof(float) * (size_t)nparts * (K + 1) * D));
+  if (!partial) return;
+  const dim3 grid(8 * ((nstrips + 7) / 8) * nchunks), block(kWave, kRcStreams);
+#define ASLP_RC_BWD(KP, EXACT) hipLaunchKernelGGL((rowconv_bwd_fused<KP, EXACT>), grid, block, 0, cur_stream(), in_diff, ldid, partial, in, ldi, out_diff, ldod, w, D, K, T, S, seq_len, tc, nchunks, dtiles, nstrips, sgroups)
+  if (K + 1 == 21) ASLP_RC_BWD(21, true);
+  else if (K + 1 <= 4) ASLP_RC_BWD(4, false);
+  else if (K + 1 <= 8) ASLP_RC_BWD(8, false);
+  else if (K + 1 <= 16) ASLP_RC_BWD(16, false);
+  else ASLP_RC_BWD(32, false);
+#undef ASLP_RC_BWD
+  hipLaunchKernelGGL(rowconv_wgrad_finish, dim3((D + kWave - 1) / kWave, K + 1), dim3(kWave, kFinishWaves), 0, cur_stream(), w_diff, partial, D, K, nparts,
+                     w_corr, w, momentum, learn_rate, update);
+  check_launch("aslp_rowconv_backward_fused");
 }
 
 void aslp_rowconv_backward(float *in_diff, int ldid, const float *out_diff, int ldod, const float *w, int D, int K, int T, int S,

@@ -9,10 +9,7 @@
 
 namespace aslp {
 
-Ctc::Ctc()
-    : frames_(0), sequences_num_(0), ref_num_(0), error_num_(0), frames_progress_(0), ref_num_progress_(0), error_num_progress_(0),
-      sequences_progress_(0), obj_progress_(0.0), report_step_(100), obj_(0), loss_sum_(0), loss_square_sum_(0), loss_sum_bak_(0),
-      loss_square_sum_bak_(0), normal_num_(0), stat_period_(100) {}
+Ctc::Ctc() : book_(100) {}
 
 namespace {
 // runs the lattice; diff is zeroed first, costs[s] = -log p(z|x)
@@ -48,13 +45,8 @@ void Ctc::Eval(const CuMatrixBase &net_out, const std::vector<int32> &label, CuM
   double pzx = -last_costs_[0];
   if (pzx < -10000) pzx = -10000;  // :85-86
   if (pzx > 10000) pzx = 10000;
-  obj_ += -pzx;
-  obj_progress_ += -pzx;
-  sequences_progress_ += 1;
-  sequences_num_ += 1;
-  frames_progress_ += net_out.NumRows();
-  frames_ += net_out.NumRows();
-  ProgressReport();
+  book_.CountSingle(net_out.NumRows(), -pzx);
+  book_.ProgressReport();
 }
 
 void Ctc::EvalParallel(const std::vector<std::string> &utt, const std::vector<int32> &frame_num_utt, const CuMatrixBase &net_out,
@@ -69,113 +61,7 @@ void Ctc::EvalParallel(const std::vector<std::string> &utt, const std::vector<in
 #endif
   diff->ApplyFloor(-1.0);  // :210-211
   diff->ApplyCeiling(1.0);
-  ProgressReport();
-}
-
-void Ctc::ProgressReport() {
-  if (sequences_progress_ >= report_step_) {
-    ASLP_LOG << "Progress " << sequences_num_ << " sequences (" << frames_ / (100.0 * 3600) << "Hr):"
-             << " Obj(log[Pzx]) = " << obj_progress_ / sequences_progress_ << " Obj(frame) = " << obj_progress_ / frames_progress_
-             << " TokenAcc = " << 100.0 * (1.0 - error_num_progress_ / ref_num_progress_) << " %";
-    sequences_progress_ = 0;
-    frames_progress_ = 0;
-    obj_progress_ = 0.0;
-    error_num_progress_ = 0;
-    ref_num_progress_ = 0;
-  }
-}
-
-void Ctc::StatAndAverageLossCheck(const std::vector<std::string> &utt, const std::vector<int32> &frame_num_utt,
-                                  const std::vector<float> &pzx_host, CuMatrix *diff) {  // :229-302
-  const int32 num_sequence = frame_num_utt.size();
-  for (int s = 0; s < num_sequence; s++) {
-    if (normal_num_ < stat_period_ / 2) {  // warm-up: only sane costs enter the statistics; nothing is dropped
-      if (std::isfinite(pzx_host[s]) && pzx_host[s] > 0 && pzx_host[s] < 3000) {
-        normal_num_++;
-        const double loss_per_frame = pzx_host[s] / frame_num_utt[s];
-        loss_sum_ += loss_per_frame;
-        loss_sum_bak_ += loss_per_frame;
-        loss_square_sum_ += loss_per_frame * loss_per_frame;
-        loss_square_sum_bak_ += loss_per_frame * loss_per_frame;
-        obj_ += pzx_host[s];
-        obj_progress_ += pzx_host[s];
-      }
-    } else {
-      const double loss_per_frame = pzx_host[s] / frame_num_utt[s];
-      const double mean = loss_sum_ / normal_num_;
-      const double sigma = sqrt(loss_square_sum_ / normal_num_);
-      if (std::isfinite(pzx_host[s]) && (loss_per_frame >= (mean - 6 * sigma) && loss_per_frame <= (mean + 6 * sigma)) &&
-          (pzx_host[s] > 0 && pzx_host[s] < 3000)) {
-        normal_num_++;
-        loss_sum_ += loss_per_frame;
-        loss_square_sum_ += loss_per_frame * loss_per_frame;
-        obj_ += pzx_host[s];
-        obj_progress_ += pzx_host[s];
-        if (normal_num_ == stat_period_) {
-          loss_sum_ -= loss_sum_bak_;
-          loss_square_sum_ -= loss_square_sum_bak_;
-          loss_sum_bak_ = loss_sum_;
-          loss_square_sum_bak_ = loss_square_sum_;
-          normal_num_ = stat_period_ / 2;
-        }
-      } else {
-        ASLP_WARN << "Sequences " << (s < (int)utt.size() ? utt[s] : std::string("?")) << " obj is abnormal(sum " << pzx_host[s]
-                  << " per_frame " << loss_per_frame << " mean " << loss_sum_ / normal_num_ << " sigma " << loss_square_sum_ / normal_num_
-                  << "), drop it's diff and stat";
-        for (int t = 0; t < frame_num_utt[s]; t++) diff->RowRange(t * num_sequence + s, 1).SetZero();
-      }
-    }
-    frames_ += frame_num_utt[s];
-    frames_progress_ += frame_num_utt[s];
-  }
-  double grad_sum = diff->Sum();
-  if (!std::isfinite(grad_sum)) {
-    ASLP_WARN << "DIFF FINITE: nan or inf ocurred in the diff, ignore";
-    diff->SetZero();
-  }
-  sequences_progress_ += num_sequence;
-  sequences_num_ += num_sequence;
-}
-
-void Ctc::StatAndLossCheck(const std::vector<std::string> &utt, const std::vector<int32> &frame_num_utt,
-                           const std::vector<float> &pzx_host, CuMatrix *diff) {  // :304-329
-  const int32 num_sequence = frame_num_utt.size();
-  for (int s = 0; s < num_sequence; s++) {
-    if (pzx_host[s] > 3000 || pzx_host[s] < 0) {
-      ASLP_WARN << "Sequences " << (s < (int)utt.size() ? utt[s] : std::string("?")) << " obj is abnormal(" << pzx_host[s]
-                << "), drop it's diff and stat";
-      for (int t = 0; t < frame_num_utt[s]; t++) diff->RowRange(t * num_sequence + s, 1).SetZero();
-    } else {
-      obj_ += pzx_host[s];
-      obj_progress_ += pzx_host[s];
-    }
-    frames_ += frame_num_utt[s];
-    frames_progress_ += frame_num_utt[s];
-  }
-  sequences_progress_ += num_sequence;
-  sequences_num_ += num_sequence;
-}
-
-void Ctc::StatOnly(const std::vector<std::string> &, const std::vector<int32> &frame_num_utt, const std::vector<float> &pzx_host,
-                   CuMatrix *) {  // :331-344
-  const int32 num_sequence = frame_num_utt.size();
-  for (int s = 0; s < num_sequence; s++) {
-    obj_ += pzx_host[s];
-    obj_progress_ += pzx_host[s];
-    frames_progress_ += frame_num_utt[s];
-    frames_ += frame_num_utt[s];
-  }
-  sequences_progress_ += num_sequence;
-  sequences_num_ += num_sequence;
-}
-
-void Ctc::AccumulateErrors(const std::vector<int32> &ref, const std::vector<int32> &hyp, int32 *err) {
-  int32 ins, del, sub;
-  *err = LevenshteinEditDistance(ref, hyp, &ins, &del, &sub);
-  error_num_ += *err;
-  ref_num_ += ref.size();
-  error_num_progress_ += *err;
-  ref_num_progress_ += ref.size();
+  book_.ProgressReport();
 }
 
 // best path of one sequence: argmax ids with stride `step` starting at `first`, repeats collapsed, blanks dropped
@@ -195,8 +81,9 @@ void Ctc::ErrorRate(const CuMatrixBase &net_out, const std::vector<int32> &label
   std::vector<int32> data;
   maxid.CopyToVec(&data);
   BestPath(data, 0, 1, data.size(), hyp);
-  int32 err;
-  AccumulateErrors(label, *hyp, &err);
+  int32 ins, del, sub;
+  const int32 err = LevenshteinEditDistance(label, *hyp, &ins, &del, &sub);
+  book_.CountTokens(err, label.size());
   *err_rate = (100.0 * err) / label.size();
 }
 
@@ -209,16 +96,9 @@ void Ctc::ErrorRateMSeq(const std::vector<int> &frame_num_utt, const CuMatrixBas
   std::vector<int32> hyp;
   for (int32 s = 0; s < num_seq; s++) {
     BestPath(data, s, num_seq, frame_num_utt[s], &hyp);
-    int32 err;
-    AccumulateErrors(label[s], hyp, &err);
+    int32 ins, del, sub;
+    book_.CountTokens(LevenshteinEditDistance(label[s], hyp, &ins, &del, &sub), label[s].size());
   }
-}
-
-std::string Ctc::Report() {  // :426-432
-  std::ostringstream oss;
-  oss << " Obj(log[Pzx]) = " << obj_ / sequences_num_ << " Obj(frame) = " << obj_ / frames_ << " TOKEN_ACCURACY >> "
-      << 100.0 * (1.0 - error_num_ / ref_num_) << " % <<";
-  return oss.str();
 }
 
 }  // namespace aslp

@@ -236,7 +236,7 @@ class AffineTransform : public UpdatableComponent {
       pb = WeightPlanes();   // (the weights have not moved since the forward pass: Update comes after this)
     }
     aslp_gemm_epilogue ep = aslp_gemm_epilogue();
-    const bool want_max = mx && pa && pb && mx->get().ReserveParts();
+    const bool want_max = mx && pa && pb && gemm_split16_max_parts(out_diff.NumRows(), input_dim_) <= kS16MaxParts && mx->get().ReserveParts();
     if (want_max) ep.cmax_parts = mx->get().Parts();
     in_diff->AddMatMat(1.0, out_diff, kNoTrans, linearity_, kNoTrans, 0.0, want_max ? &ep : nullptr, pa, pb);  // :193-197
     if (want_max) {

@@ -119,7 +119,7 @@ void Xent::Eval(const std::vector<BaseFloat> &frame_weights, const CuMatrixBase 
   EvalLabels(frame_weights_, net_out, labels_, diff);
 }
 
-// Xent on posteriors with one label per frame: |diff| = |y - t| w <= max w, known before the launch when the caller knows its frame
+// Xent with one label per frame.  On posteriors |diff| = |y - t| w <= max w, known before the launch when the caller knows its frame
 // weights' maximum (fw_max > 0).  If the network asked for the diff's planes (Nnet::LossDiff -> s16_loss_diff_target) the kernel
 // writes them beside the diff.
 static void XentLabels(const CuMatrixBase &in, bool softmax, const int32 *labels_dev, const CuVectorBase &fw, float fw_max, CuMatrix *diff,
@@ -127,7 +127,9 @@ static void XentLabels(const CuMatrixBase &in, bool softmax, const int32 *labels
   S16DiffTarget t = s16_loss_diff_target();
   s16_loss_diff_target() = S16DiffTarget();
   aslp_planes_out po = aslp_planes_out();
-  PlaneSet *ps = (t.planes && t.diff == diff->Data() && fw_max > 0.0f && std::isfinite(fw_max)) ? t.planes : nullptr;
+  // (only where the kernel forms the posteriors itself: what a caller hands in as "net_out" need not be posteriors -- a linear output
+  //  layer -- and |y - t| <= 1 is then nobody's promise; the consumer of the diff converts it with a measured maximum instead)
+  PlaneSet *ps = (softmax && t.planes && t.diff == diff->Data() && fw_max > 0.0f && std::isfinite(fw_max)) ? t.planes : nullptr;
   if (ps && ps->Reserve(in.NumRows(), in.NumCols()) && ps->SetBound(fw_max)) aslp_planes_as_output(reinterpret_cast<const aslp_planes *>(ps), &po);
   else ps = nullptr;
   if (aslp_xent_eval_p(in.Data(), in.Dim(), labels_dev, fw.Data(), diff->Data(), diff->Stride(), stats, softmax ? 1 : 0, ps ? &po : nullptr) && ps)

@@ -370,7 +370,13 @@ void Nnet::Backpropagate(const std::vector<const CuMatrixBase *> &out_diff, std:
   // accessors below, the C API, aslp_params_changed() of the sync workers) joins first.  A/B: ASLP_LATE_JOIN=0.
   static const bool late_join_off = getenv("ASLP_LATE_JOIN") != nullptr && getenv("ASLP_LATE_JOIN")[0] == '0';
   first_after_updates_ = 0;
-  if (overlap_updates && !recurrent_net && !late_join_off && NULL == in_diff) {
+  if (params_out_silently_ && !silent_writer_logged_) {
+    silent_writer_logged_ = true;
+    ASLP_LOG << "parameters are aliased through GetGpuParams by a writer that does not announce its writes: every training step ends "
+                "joined with its weight updates and the weights' fp16 planes are made anew in every step "
+                "(ParamWritersAnnounce() + aslp_params_changed() after each write lift both)";
+  }
+  if (overlap_updates && !recurrent_net && !late_join_off && !params_out_silently_ && NULL == in_diff) {
     int32 first = N;
     for (int32 i = 0; i < N; i++) {
       if (!(components_[i]->GetType() == Component::kAffineTransform && components_[i]->IsUpdatable() && i != lowest_updatable)) continue;
@@ -381,7 +387,7 @@ void Nnet::Backpropagate(const std::vector<const CuMatrixBase *> &out_diff, std:
     for (int32 i = 0; i < first; i++)
       if (fused_sigmoid[i] >= first || AffineSigmoidOf(i) >= first) { first = i; i = -1; }
     first_after_updates_ = first;
-    updates_pending_ = true;
+    updates_pending_ = side_stream_mark(&updates_mark_);
   } else {
     join_side_stream();
   }
@@ -390,10 +396,11 @@ void Nnet::Backpropagate(const std::vector<const CuMatrixBase *> &out_diff, std:
     if ((*in_diff)[i] != NULL) *((*in_diff)[i]) = input_diff_buf_[input_[i]];
 }
 
-void Nnet::JoinUpdates() const {
+void Nnet::JoinUpdates(bool host_wait) const {
   if (!updates_pending_) return;
   updates_pending_ = false;
-  join_side_stream();
+  side_stream_mark_wait(updates_mark_, host_wait);   // (whichever host thread this is)
+  join_side_stream();                                // the issuing thread's own bookkeeping; a no-op elsewhere
 }
 
 void Nnet::Feedforward(const std::vector<const CuMatrixBase *> &in, std::vector<CuMatrix *> *out) {  // :156-189
@@ -522,11 +529,13 @@ void Nnet::GetGpuParams(std::vector<std::pair<BaseFloat *, int>> *params) {  // 
       dynamic_cast<UpdatableComponent &>(*components_[i]).ParamsAliased(false);
       params->insert(params->end(), c_params.begin(), c_params.end());
     }
+  params_out_silently_ = true;   // until ParamWritersAnnounce()
   aslp_params_changed();   // (the caller may already hold pointers from an earlier call)
 }
 void Nnet::ParamWritersAnnounce() {
   for (size_t i = 0; i < components_.size(); i++)
     if (components_[i]->IsUpdatable()) dynamic_cast<UpdatableComponent &>(*components_[i]).ParamsAliased(true);
+  params_out_silently_ = false;
 }
 void Nnet::GetAccStats(std::vector<double *> *acc_params, std::vector<std::pair<double *, int>> *data_params) {  // :327-342
   JoinUpdates();
@@ -761,7 +770,10 @@ void Nnet::Check() const {  // :776-819
 }
 
 void Nnet::Destroy() {  // :822-832
-  JoinUpdates();
+  JoinUpdates(true);
+  side_stream_mark_free(updates_mark_);
+  updates_mark_ = nullptr;
+  params_out_silently_ = false;   // (pointers handed out earlier die with the components)
   for (int32 i = 0; i < NumComponents(); i++) delete components_[i];
   components_.resize(0);
   input_buf_.resize(0);

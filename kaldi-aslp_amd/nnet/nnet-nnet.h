@@ -131,9 +131,16 @@ class Nnet {
   bool fold_softmax_request_ = false, softmax_folded_ = false, diff_in_place_ = false;
   // weight updates issued on the side stream by the latest Backpropagate and not waited for yet (JoinUpdates(): the main stream waits);
   // the next Propagate joins in front of component first_after_updates_
-  void JoinUpdates() const;
+  // (host_wait: the HOST waits -- for callers that free what the updates touch.)  The marker is an event on the side stream of the thread that
+  // ran Backpropagate, so a Write / GetParams / Destroy from another host thread waits for the same work.
+  void JoinUpdates(bool host_wait = false) const;
   mutable bool updates_pending_ = false;
+  mutable void *updates_mark_ = nullptr;
   int32 first_after_updates_ = 0;
+  // GetGpuParams handed the parameters' device pointers out and nobody promised aslp_params_changed() for them (the reference's own
+  // workers: itf.h:26-42 has no such call): Backpropagate then returns with the main stream already waiting for the weight updates, so
+  // that whatever the holder of the pointers enqueues behind it -- on that stream or through the null stream -- finds the step complete
+  bool params_out_silently_ = false, silent_writer_logged_ = false;
   long next_bwd_epoch_ = 0;  // drawn by LossDiff() for the backward pass that will read the diff the loss is about to write
   long fwd_epoch_ = 0;  // csrc/split16.h: the forward pass whose buffers are still in place (operand planes made from them may be reused)
 };

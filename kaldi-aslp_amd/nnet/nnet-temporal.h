@@ -19,6 +19,7 @@ class RowConvolution : public UpdatableComponent {
   Component *Copy() const { return new RowConvolution(*this); }
   ComponentType GetType() const { return kRowConvolution; }
   bool GradientInBackprop() const { return true; }
+  void FoldNextUpdateIntoBackprop() { fold_update_ = true; }   // the tap gradients' finishing launch then also takes the SGD step
   void SetSeqLengths(const std::vector<int32> &sequence_lengths) {  // row-convolution.h:39-41
     sequence_lengths_ = sequence_lengths;
     seq_len_dev_.CopyFromVec(sequence_lengths);
@@ -74,12 +75,14 @@ class RowConvolution : public UpdatableComponent {
     const int32 S = sequence_lengths_.size();
     ASLP_ASSERT(S > 0 && in.NumRows() % S == 0);
     const int32 T = in.NumRows() / S;
-    aslp_rowconv_backward(in_diff->Data(), in_diff->Stride(), out_diff.Data(), out_diff.Stride(), w_.Data(), input_dim_, future_ctx_, T, S,
-                          seq_len_dev_.Data());
-    aslp_rowconv_wgrad(w_diff_.Data(), in.Data(), in.Stride(), out_diff.Data(), out_diff.Stride(), input_dim_, future_ctx_, T, S,
-                       seq_len_dev_.Data());
+    const bool fold = fold_update_;
+    fold_update_ = false;
+    update_done_ = fold;
+    aslp_rowconv_backward_fused(in_diff->Data(), in_diff->Stride(), w_diff_.Data(), in.Data(), in.Stride(), out_diff.Data(), out_diff.Stride(), w_.Data(),
+                                input_dim_, future_ctx_, T, S, seq_len_dev_.Data(), w_corr_.Data(), opts_.momentum, opts_.learn_rate, fold ? 1 : 0);
   }
   void Update(const CuMatrixBase &, const CuMatrixBase &) {  // :178-186
+    if (update_done_) { update_done_ = false; return; }   // (rode in BackpropagateFnc's finishing launch)
     w_corr_.AddVec(1.0, w_diff_, opts_.momentum);
     w_.AddVec(-opts_.learn_rate, w_corr_, 1.0);
   }
@@ -94,6 +97,7 @@ class RowConvolution : public UpdatableComponent {
   std::vector<int32> sequence_lengths_;
   CuArray<int32> seq_len_dev_;
   int32 future_ctx_;
+  bool fold_update_ = false, update_done_ = false;
   CuVector w_, w_diff_, w_corr_;  // [D x (K+1)] row-major, unpadded
 };
 
@@ -104,6 +108,7 @@ class CompactFsmn : public UpdatableComponent {
   Component *Copy() const { return new CompactFsmn(*this); }
   ComponentType GetType() const { return kCompactFsmn; }
   bool GradientInBackprop() const { return true; }
+  void FoldNextUpdateIntoBackprop() { fold_update_ = true; }   // the backward launch then also takes the SGD step
   void InitData(std::istream &is) {  // cfsmn.h:53-89
     int past_context = 30, future_context = 30;
     float learn_rate_coef = 1.0, vec_coef_mean = 0.0, vec_coef_range = 1.0;
@@ -167,12 +172,15 @@ class CompactFsmn : public UpdatableComponent {
     const int32 T = in.NumRows();
     ASLP_ASSERT(T <= max_frames_);
     ASLP_ASSERT(in.NumCols() == vec_coef_.NumCols());
-    aslp_fsmn_coef_grad(vec_coef_corr_.Data(), vec_coef_corr_.Stride(), in.Data(), in.Stride(), out_diff.Data(), out_diff.Stride(),
-                        input_dim_, past_context_, future_context_, T, clip_gradient_);
-    aslp_fsmn_filter(in_diff->Data(), in_diff->Stride(), out_diff.Data(), out_diff.Stride(), vec_coef_.Data(), vec_coef_.Stride(),
-                     input_dim_, past_context_, future_context_, T, 1);
+    const bool fold = fold_update_;
+    fold_update_ = false;
+    update_done_ = fold;
+    aslp_fsmn_backward(in_diff->Data(), in_diff->Stride(), vec_coef_corr_.Data(), vec_coef_corr_.Stride(), vec_coef_.Data(), vec_coef_.Stride(), in.Data(),
+                       in.Stride(), out_diff.Data(), out_diff.Stride(), input_dim_, past_context_, future_context_, T, clip_gradient_,
+                       fold ? opts_.learn_rate * learn_rate_coef_ : 0.0f);
   }
   void Update(const CuMatrixBase &, const CuMatrixBase &) {  // :258-262
+    if (update_done_) { update_done_ = false; return; }   // (rode in BackpropagateFnc's launch)
     vec_coef_.AddMat(-opts_.learn_rate * learn_rate_coef_, vec_coef_corr_);
   }
 
@@ -182,6 +190,7 @@ class CompactFsmn : public UpdatableComponent {
   BaseFloat learn_rate_coef_;
   int32 past_context_, future_context_;
   BaseFloat clip_gradient_;
+  bool fold_update_ = false, update_done_ = false;
 };
 
 }  // namespace aslp

@@ -9,9 +9,7 @@
 
 namespace aslp {
 
-WarpCtc::WarpCtc()
-    : frames_(0), sequences_num_(0), ref_num_(0), error_num_(0), frames_progress_(0), ref_num_progress_(0), error_num_progress_(0),
-      sequences_progress_(0), obj_progress_(0.0), report_step_(100), obj_(0), use_gpu_(true), window_(500) {}
+WarpCtc::WarpCtc() : use_gpu_(true), book_(500) {}
 
 void WarpCtc::Eval(const std::vector<std::string> &utt, const std::vector<int32> &frame_num_utt, const CuMatrixBase &net_out,
                    const std::vector<std::vector<int32>> &labels, CuMatrix *diff) {  // warp-ctc.cc:33-46
@@ -65,91 +63,7 @@ void WarpCtc::EvalGpu(const std::vector<std::string> &utt, const std::vector<int
     double grad_sum = diff->Sum();
     ASLP_ASSERT(std::isfinite(grad_sum));
   }
-  ProgressReport();
-}
-
-void WarpCtc::ProgressReport() {   // the reference's line, warp-ctc.cc:188-203
-  if (sequences_progress_ < report_step_) return;
-  ASLP_LOG << "Progress " << sequences_num_ << " sequences (" << frames_ / (100.0 * 3600) << "Hr):"
-           << " Obj(log[Pzx]) = " << obj_progress_ / sequences_progress_ << " Obj(frame) = " << obj_progress_ / frames_progress_
-           << " TokenAcc = " << 100.0 * (1.0 - error_num_progress_ / ref_num_progress_) << " %";
-  sequences_progress_ = frames_progress_ = ref_num_progress_ = 0;
-  obj_progress_ = 0.0;
-  error_num_progress_ = 0;
-}
-
-// ---- what happens to the costs of a batch: three policies over the same bookkeeping ---------------------------------------------------
-// (behaviour of warp-ctc.cc:288-365 / 446-470 / 472-485: which utterances count, which are dropped, what is logged)
-void WarpCtc::Count(int32 frames, bool kept, double obj) {
-  if (kept) { obj_ += obj; obj_progress_ += obj; }
-  frames_ += frames;
-  frames_progress_ += frames;
-}
-void WarpCtc::CountBatch(int32 num_sequence) {
-  sequences_progress_ += num_sequence;
-  sequences_num_ += num_sequence;
-}
-namespace {
-// the rows of utterance s in a (t, stream)-interleaved matrix
-void DropUtterance(CuMatrix *diff, int s, int num_sequence, int frames) {
-  for (int t = 0; t < frames; t++) diff->RowRange(t * num_sequence + s, 1).SetZero();
-}
-const std::string &NameOf(const std::vector<std::string> &utt, int s) {
-  static const std::string unknown("?");
-  return s < (int)utt.size() ? utt[s] : unknown;
-}
-const double kCostCeiling = 3000.0;   // a sequence cost outside (0, 3000) is never trusted
-}  // namespace
-
-// every utterance's cost per frame is held against the window of the accepted ones: outside mean +- 6 "sigma" (or non-finite, or
-// outside (0, 3000)) it neither trains nor counts; the first half window is accepted unseen
-void WarpCtc::StatAndAverageLossCheck(const std::vector<std::string> &utt, const std::vector<int32> &frame_num_utt,
-                                      const std::vector<float> &pzx_host, CuMatrix *diff) {
-  const int32 num_sequence = frame_num_utt.size();
-  for (int s = 0; s < num_sequence; s++) {
-    const double cost = pzx_host[s], per_frame = cost / frame_num_utt[s];
-    bool keep = true;
-    if (!window_.WarmingUp()) {
-      const double mean = window_.Mean(), spread = 6 * window_.RootMeanSquare();
-      keep = std::isfinite(pzx_host[s]) && per_frame >= mean - spread && per_frame <= mean + spread && cost > 0 && cost < kCostCeiling;
-    }
-    if (keep) {
-      window_.Add(per_frame);
-    } else {
-      ASLP_WARN << "Sequences " << NameOf(utt, s) << " obj is abnormal(sum " << pzx_host[s] << " per_frame " << per_frame << " mean "
-                << window_.Mean() << " sigma " << window_.sum_sq / window_.count << "), drop it's diff and stat";
-      DropUtterance(diff, s, num_sequence, frame_num_utt[s]);
-    }
-    Count(frame_num_utt[s], keep, cost);
-  }
-  if (!std::isfinite(diff->Sum())) {
-    ASLP_WARN << "DIFF FINITE: nan or inf ocurred in the diff, ignore";
-    diff->SetZero();
-  }
-  CountBatch(num_sequence);
-}
-
-// only the absolute test: a cost outside [0, 3000] is dropped
-void WarpCtc::StatAndLossCheck(const std::vector<std::string> &utt, const std::vector<int32> &frame_num_utt,
-                               const std::vector<float> &pzx_host, CuMatrix *diff) {
-  const int32 num_sequence = frame_num_utt.size();
-  for (int s = 0; s < num_sequence; s++) {
-    const bool keep = !(pzx_host[s] > kCostCeiling || pzx_host[s] < 0);
-    if (!keep) {
-      ASLP_WARN << "Sequences " << NameOf(utt, s) << " obj is abnormal(" << pzx_host[s] << "), drop it's diff and stat";
-      DropUtterance(diff, s, num_sequence, frame_num_utt[s]);
-    }
-    Count(frame_num_utt[s], keep, pzx_host[s]);
-  }
-  CountBatch(num_sequence);
-}
-
-// no test at all
-void WarpCtc::StatOnly(const std::vector<std::string> &, const std::vector<int32> &frame_num_utt, const std::vector<float> &pzx_host,
-                       CuMatrix *) {
-  const int32 num_sequence = frame_num_utt.size();
-  for (int s = 0; s < num_sequence; s++) Count(frame_num_utt[s], true, pzx_host[s]);
-  CountBatch(num_sequence);
+  book_.ProgressReport();
 }
 
 void WarpCtc::ErrorRate(const std::vector<int> &frame_num_utt, const CuMatrixBase &net_out, std::vector<std::vector<int>> &label) {  // :487-529
@@ -171,19 +85,8 @@ void WarpCtc::ErrorRate(const std::vector<int> &frame_num_utt, const CuMatrixBas
       prev = id;
     }
     int32 ins, del, sub;
-    const int32 err = LevenshteinEditDistance(label[s], hyp_seq, &ins, &del, &sub);
-    error_num_ += err;
-    ref_num_ += label[s].size();
-    error_num_progress_ += err;
-    ref_num_progress_ += label[s].size();
+    book_.CountTokens(LevenshteinEditDistance(label[s], hyp_seq, &ins, &del, &sub), label[s].size());
   }
-}
-
-std::string WarpCtc::Report() {  // :531-538
-  std::ostringstream oss;
-  oss << " Obj(log[Pzx]) = " << obj_ / sequences_num_ << " Obj(frame) = " << obj_ / frames_ << " TOKEN_ACCURACY >> "
-      << 100.0 * (1.0 - error_num_ / ref_num_) << " % <<";
-  return oss.str();
 }
 
 int32 LevenshteinEditDistance(const std::vector<int32> &ref, const std::vector<int32> &hyp, int32 *ins, int32 *del, int32 *sub) {

@@ -9,6 +9,7 @@
 #include <string>
 #include <vector>
 
+#include "ctc-cost-book.h"
 #include "cu-matrix.h"
 
 namespace aslp {
@@ -29,61 +30,32 @@ class WarpCtc {
   void EvalCpu(const std::vector<std::string> &utt, const std::vector<int32> &frame_num_utt, const CuMatrixBase &net_out,
                const std::vector<std::vector<int32>> &labels, CuMatrix *diff);
   void ErrorRate(const std::vector<int> &frame_num_utt, const CuMatrixBase &net_out, std::vector<std::vector<int>> &label);
-  void SetReportStep(int32 report_step) { report_step_ = report_step; }
-  std::string Report();
-  float NumErrorTokens() const { return error_num_; }
-  int32 NumRefTokens() const { return ref_num_; }
+  void SetReportStep(int32 report_step) { book_.SetReportStep(report_step); }
+  std::string Report() { return book_.Report(); }
+  float NumErrorTokens() const { return book_.NumErrorTokens(); }
+  int32 NumRefTokens() const { return book_.NumRefTokens(); }
   void SetUseGpu(bool use_gpu) { use_gpu_ = use_gpu; }
-  void StatOnly(const std::vector<std::string> &utt, const std::vector<int32> &frame_num_utt, const std::vector<float> &pzx_host, CuMatrix *diff);
+  // the reference's three bookkeeping variants (warp-ctc.cc:288-365, 446-470, 472-485), over the shared book
+  void StatOnly(const std::vector<std::string> &, const std::vector<int32> &frame_num_utt, const std::vector<float> &pzx_host, CuMatrix *) {
+    book_.AcceptAll(frame_num_utt, pzx_host);
+  }
   void StatAndLossCheck(const std::vector<std::string> &utt, const std::vector<int32> &frame_num_utt, const std::vector<float> &pzx_host,
-                        CuMatrix *diff);
+                        CuMatrix *diff) {
+    book_.DropOutOfRange(utt, frame_num_utt, pzx_host, diff);
+  }
   void StatAndAverageLossCheck(const std::vector<std::string> &utt, const std::vector<int32> &frame_num_utt,
-                               const std::vector<float> &pzx_host, CuMatrix *diff);
+                               const std::vector<float> &pzx_host, CuMatrix *diff) {
+    book_.DropOutliers(utt, frame_num_utt, pzx_host, diff, /*sane_only_during_warmup=*/false);
+  }
   // accessors for tests / the C ABI
   const std::vector<float> &LastCosts() const { return last_costs_; }
-  double Obj() const { return obj_; }
-  int32 Frames() const { return frames_; }
-  int32 Sequences() const { return sequences_num_; }
+  double Obj() const { return book_.Obj(); }
+  int32 Frames() const { return book_.Frames(); }
+  int32 Sequences() const { return book_.Sequences(); }
 
  private:
-  void ProgressReport();
-  int32 frames_, sequences_num_, ref_num_;
-  float error_num_;
-  int32 frames_progress_, ref_num_progress_;
-  float error_num_progress_;
-  int32 sequences_progress_;
-  double obj_progress_;
-  int32 report_step_;
-  double obj_;
   bool use_gpu_;
-  // Running statistics of the per-frame cost of the utterances accepted so far, over a sliding window of `period` utterances that
-  // restarts from its younger half when full (what the reference keeps in loss_sum_ / loss_sum_bak_ / normal_num_, warp-ctc.cc:288-365)
-  struct CostWindow {
-    explicit CostWindow(int32 period_) : period(period_) {}
-    bool WarmingUp() const { return count < period / 2; }
-    double Mean() const { return sum / count; }
-    double RootMeanSquare() const { return sqrt(sum_sq / count); }   // the reference's "sigma": no mean subtracted
-    void Add(double x) {
-      const bool warm = WarmingUp();
-      count++;
-      sum += x;
-      sum_sq += x * x;
-      if (warm) { young_sum += x; young_sum_sq += x * x; }   // the first half window is what survives the first restart
-      if (count == period) {   // keep the younger half
-        sum -= young_sum;
-        sum_sq -= young_sum_sq;
-        young_sum = sum;
-        young_sum_sq = sum_sq;
-        count = period / 2;
-      }
-    }
-    int32 period, count = 0;
-    double sum = 0.0, sum_sq = 0.0, young_sum = 0.0, young_sum_sq = 0.0;
-  };
-  CostWindow window_;
-  // one utterance into the totals and the progress counters (obj only when it is kept)
-  void Count(int32 frames, bool kept, double obj);
-  void CountBatch(int32 num_sequence);
+  CtcCostBook book_;   // window of 500 utterances (warp-ctc.cc: stat_period_)
   std::vector<float> last_costs_;
 };
 

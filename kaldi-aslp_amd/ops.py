@@ -193,3 +193,35 @@ def ctc_loss(acts, labels, input_lengths, want_grad=True):
         raise RuntimeError("compute_ctc_loss: " + lib.ctcGetStatusString(st).decode())
     check_error()
     return np.array(list(costs), np.float32), grads
+
+
+# ---- depthwise temporal filters (csrc/temporal.hip; nnet-cfsmn-component.h:170-262, nnet-row-convolution.cc:105-186) ----
+def fsmn_forward(out, x, coef, past, future):
+    """out[t] = x[t] + sum_j coef[j] .* x[t + j - past]; coef [(past + future + 1) x D]"""
+    lib.aslp_fsmn_filter(ptr(_chk(out)), dim(out).stride, ptr(_chk(x)), dim(x).stride, ptr(_chk(coef)), dim(coef).stride, x.shape[1], past, future,
+                         x.shape[0], 0)
+    check_error()
+
+
+def fsmn_backward(in_diff, coef_corr, coef, x, out_diff, past, future, clip=0.0, lr=0.0):
+    """one launch: in_diff (reversed filter over out_diff), coef_corr (tap gradients, clipped), and with lr != 0 coef += -lr coef_corr"""
+    lib.aslp_fsmn_backward(ptr(_chk(in_diff)), dim(in_diff).stride, ptr(_chk(coef_corr)), dim(coef_corr).stride, ptr(_chk(coef)), dim(coef).stride,
+                           ptr(_chk(x)), dim(x).stride, ptr(_chk(out_diff)), dim(out_diff).stride, x.shape[1], past, future, x.shape[0], clip, lr)
+    check_error()
+
+
+def rowconv_forward(out, x, w, seq_len, K):
+    """rows t * S + s; w dense [D x (K + 1)]; seq_len int32 [S] on the device"""
+    S = seq_len.numel()
+    lib.aslp_rowconv_forward(ptr(_chk(out)), dim(out).stride, ptr(_chk(x)), dim(x).stride, ptr(w), x.shape[1], K, x.shape[0] // S, S, ptr(seq_len))
+    check_error()
+
+
+def rowconv_backward(in_diff, w_diff, x, out_diff, w, seq_len, K, w_corr=None, momentum=0.0, lr=0.0):
+    """in_diff and the tap gradients from one pass over x / out_diff; with w_corr given also the momentum + SGD step"""
+    S = seq_len.numel()
+    lib.aslp_rowconv_backward_fused(ptr(_chk(in_diff)), dim(in_diff).stride, ptr(w_diff), ptr(_chk(x)), dim(x).stride, ptr(_chk(out_diff)),
+                                    dim(out_diff).stride, ptr(w), x.shape[1], K, x.shape[0] // S, S, ptr(seq_len), ptr(w_corr), momentum, lr,
+                                    1 if w_corr is not None else 0)
+    check_error()
+

@@ -305,9 +305,12 @@ class ShmComm : public FileRendezvousComm {
     if (n > kMaxRanks) ASLP_ERR << "ShmComm: at most " << kMaxRanks << " ranks";
     // ranks of this transport may share a GPU: the persistent LSTM / GRU launches of libaslp_hip then take a cross-process device lock
     // (include/aslp_kernels.h aslp_device_shared; read from the environment at the first such launch).  An explicit setting wins.
+    // The switch is process-wide and stays on after this communicator is gone: another one may live in the process, and a lock around a launch
+    // that no longer needs it costs microseconds.
     if (n > 1) {
-      (void)setenv("ASLP_DEVICE_SHARED", "1", 0);
-      if (getenv("ASLP_DEVICE_SHARED")[0] == '1') aslp_device_shared(1);   // also when libaslp_hip has already read the environment
+      const char *given = getenv("ASLP_DEVICE_SHARED");
+      if (given == nullptr) (void)setenv("ASLP_DEVICE_SHARED", "1", 0);   // (for child processes; a failed setenv only loses that)
+      if (given == nullptr || given[0] == '1') aslp_device_shared(1);       // also when libaslp_hip has already read the environment
     }
     static_assert(std::atomic<int>::is_always_lock_free && std::atomic<long>::is_always_lock_free, "address-free atomics needed in shared memory");
     const size_t slot_mb = getenv("ASLP_SHM_SLOT_MB") ? (size_t)atol(getenv("ASLP_SHM_SLOT_MB")) : 16;

@@ -53,10 +53,23 @@ def oracle_params(oracle, d, bn):
 @pytest.mark.parametrize("dims", [(24, 32, 2, 10, 16), (44, 64, 3, 50, 128), (40, 96, 5, 300, 256), (440, 2048, 5, 3000, 256)])
 @pytest.mark.parametrize("momentum", [0.0, 0.9])
 def test_dnn_train_steps_match_oracle(aslp, oracle, dev, tmp_path, dims, bn, momentum):
+    _train_steps_vs_oracle(aslp, oracle, dev, tmp_path, dims, bn, momentum, lr=0.002)
+
+
+@pytest.mark.parametrize("momentum", [0.0, 0.9])
+def test_cfg2_full_size_matches_oracle(aslp, oracle, dev, tmp_path, momentum):
+    """BASELINE cfg2 itself -- 440 -> 5 x 2048 + BatchNormalization + Sigmoid -> 3000, minibatch 1024, learn rate 0.008 (run_bn_dnn.sh:64-101)
+    -- on the default path (split-fp16 products from producer-made planes, weights' planes kept from step to step, updates on the side
+    stream) against the oracle chain (nnet-batch-normalization.h:177-284, nnet-affine-transform.h:186-245): outputs, every parameter, the
+    gradient each tensor was moved by, largest element.  ~0.4 s per oracle step."""
+    _train_steps_vs_oracle(aslp, oracle, dev, tmp_path, (440, 2048, 5, 3000, 1024), 1, momentum, lr=0.008, steps=3)
+    assert aslp.lib.aslp_gemm_last_tile() in (304, 308, 311, 328)     # the products ran on the split-fp16 kernels
+
+
+def _train_steps_vs_oracle(aslp, oracle, dev, tmp_path, dims, bn, momentum, lr, steps=2):
     in_dim, hid, nh, out_dim, mb = dims
     d, path = make_dnn(oracle, tmp_path, in_dim, hid, nh, out_dim, bn, mb, seed=5)
     net = aslp.Nnet.Read(path)
-    lr = 0.002
     net.SetTrainOptions(learn_rate=lr, momentum=momentum)
     assert net.NumParams() == oracle_params(oracle, d, bn).size
     assert oracle.rel_err(net.GetParams(), oracle_params(oracle, d, bn)) == 0.0  # file round trip is exact
@@ -64,7 +77,7 @@ def test_dnn_train_steps_match_oracle(aslp, oracle, dev, tmp_path, dims, bn, mom
     xent = aslp.Xent()
     tot_loss = 0.0
     prev_e, prev_o = net.GetParams(), oracle_params(oracle, d, bn)
-    for step in range(2):
+    for step in range(steps):
         x = rng.standard_normal((mb, in_dim)).astype(np.float32)
         lab = rng.integers(0, out_dim, mb).astype(np.int32)
         ref_loss = oracle.lib.orc_dnn_train_step(d, x, lab, lr, momentum)
@@ -89,7 +102,7 @@ def test_dnn_train_steps_match_oracle(aslp, oracle, dev, tmp_path, dims, bn, mom
         assert np.max(np.abs(g_e - g_o)) / max(1.0, np.max(np.abs(g_o))) < 10 * TOL + 2 * floor, ("applied gradient, max element", step)
         prev_e, prev_o = got, want
     st = xent.GetStats()
-    assert st["frames"] == 2 * mb
+    assert st["frames"] == steps * mb
     assert abs(st["loss"] - tot_loss) / tot_loss < 1e-5
     assert "AvgLoss:" in xent.Report() and "FRAME_ACCURACY >>" in xent.Report()
     oracle.lib.orc_dnn_destroy(d)
