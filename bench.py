@@ -464,30 +464,48 @@ def hbm_kernels_block(aslp, dev):
     sg, sy = torch.empty_like(x), torch.empty_like(x)
     rec("sigmoid", timed_us(lambda: aslp.ops.sigmoid(sy, x)), 8 * R * D, "Sigmoid forward 1024 x 2048")
     rec("diff_sigmoid", timed_us(lambda: aslp.ops.diff_sigmoid(sg, sy, dy)), 12 * R * D, "Sigmoid backward 1024 x 2048")
-    # cfg5 swaps through the engine (Propagate + Backpropagate + Update of one component)
-    T, Dm = 800, 512
-    net = aslp.Nnet.Init("<NnetProto>\n<CompactFsmn> <InputDim> 512 <OutputDim> 512 <PastContext> 30 <FutureContext> 30 <LearnRateCoef> 1.0\n</NnetProto>\n")
-    net.SetTrainOptions(learn_rate=1e-5)
+    # cfg5 swaps: the component's passes at the kernel level (the launches a training step makes for it), and the same step through the
+    # engine's Python entry points (which add an input copy, an output copy and two diff copies around a one-component net)
+    T, Dm, P, F = 800, 512, 30, 30
     xf = torch.randn(T, Dm, device=dev, generator=g)
     odf = torch.randn(T, Dm, device=dev, generator=g) * 0.01
+    coef = torch.randn(P + F + 1, Dm, device=dev, generator=g) * 0.05
+    corr, of, idff = torch.zeros_like(coef), torch.empty_like(xf), torch.empty_like(xf)
 
     def fsmn():
+        aslp.ops.fsmn_forward(of, xf, coef, P, F)
+        aslp.ops.fsmn_backward(idff, corr, coef, xf, odf, P, F, 0.0, 1e-5)
+    rec("compact_fsmn", timed_us(fsmn, 30), 4 * Dm * T * 7,
+        "CompactFsmn 512, 30 + 30 taps, T = 800: forward; in-diff + tap gradients; their sum + update (3 launches; 2 + 5 tensor passes)")
+    net = aslp.Nnet.Init("<NnetProto>\n<CompactFsmn> <InputDim> 512 <OutputDim> 512 <PastContext> 30 <FutureContext> 30 <LearnRateCoef> 1.0\n</NnetProto>\n")
+    net.SetTrainOptions(learn_rate=1e-5)
+
+    def fsmn_engine():
         net.Propagate(xf)
         net.Backpropagate(odf, want_in_diff=True)
-    rec("compact_fsmn", timed_us(fsmn, 30), 4 * Dm * T * 7, "CompactFsmn 512, 30 + 30 taps, T = 800: forward + backward + update (2 + 5 tensor passes)")
-    S = 32
-    net2 = aslp.Nnet.Init("<NnetProto>\n<RowConvolution> <InputDim> 512 <OutputDim> 512 <FutureContext> 20\n</NnetProto>\n")
-    net2.SetTrainOptions(learn_rate=1e-5, momentum=0.9)
+    out["compact_fsmn"]["through_engine_us"] = timed_us(fsmn_engine, 30)
+    S, K = 32, 20
     lens = np.random.default_rng(0).integers(T // 2, T + 1, S)
     lens[0] = T
-    net2.SetSeqLengths(lens)
     x2 = torch.randn(T * S, Dm, device=dev, generator=g)
     od2 = torch.randn(T * S, Dm, device=dev, generator=g) * 0.01
+    w = torch.randn(Dm * (K + 1), device=dev, generator=g) * 0.1
+    wd, wc, o2, idf2 = torch.zeros_like(w), torch.zeros_like(w), torch.empty_like(x2), torch.empty_like(x2)
+    sl = torch.from_numpy(lens.astype(np.int32)).to(dev)
 
     def rowconv():
+        aslp.ops.rowconv_forward(o2, x2, w, sl, K)
+        aslp.ops.rowconv_backward(idf2, wd, x2, od2, w, sl, K, wc, 0.9, 1e-5)
+    rec("row_convolution", timed_us(rowconv, 10), 4 * Dm * T * S * 7,
+        "RowConvolution 512, FutureContext 20, T = 800, S = 32: forward; in-diff + tap partials in one pass; their sum + momentum + update (3 launches; 7 tensor passes)")
+    net2 = aslp.Nnet.Init("<NnetProto>\n<RowConvolution> <InputDim> 512 <OutputDim> 512 <FutureContext> 20\n</NnetProto>\n")
+    net2.SetTrainOptions(learn_rate=1e-5, momentum=0.9)
+    net2.SetSeqLengths(lens)
+
+    def rowconv_engine():
         net2.Propagate(x2)
         net2.Backpropagate(od2, want_in_diff=True)
-    rec("row_convolution", timed_us(rowconv, 10), 4 * Dm * T * S * 7, "RowConvolution 512, FutureContext 20, T = 800, S = 32: forward + backward + update (7 tensor passes)")
+    out["row_convolution"]["through_engine_us"] = timed_us(rowconv_engine, 10)
     return {"peak_gb_per_s": HBM_PEAK_GBS, "timing": "HIP events (torch.cuda.Event on the launch stream): >= 10 warm-up calls, then the median over 21 back-to-back groups of calls", "kernels": out}
 
 

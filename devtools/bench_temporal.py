@@ -36,3 +36,32 @@ def rc_step():
 s2 = timeit(rc_step, 20)
 print("RowConvolution T=%d S=%d D=%d K=%d: %.1f us/step, %.0f k rows/s, algorithmic (7 tensor passes) %.1f GB/s, %.1f GFLOP/s" % (
     T, S, D, K, s2 * 1e6, T * S / s2 / 1e3, 4 * D * T * S * 7 / s2 / 1e9, 3 * 2 * D * (K + 1) * T * S / s2 / 1e9))
+
+# ---- the same passes at the kernel level (ops bindings): no engine copies of the input / output / diffs around them
+def timeit_ev(fn, reps=10, batches=21):
+    for _ in range(10): fn()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(batches + 1)]
+    torch.cuda.synchronize(); ev[0].record()
+    for b in range(batches):
+        for _ in range(reps): fn()
+        ev[b + 1].record()
+    torch.cuda.synchronize()
+    return float(np.median([ev[b].elapsed_time(ev[b + 1]) / reps for b in range(batches)])) * 1e-3
+
+P = F = 30
+coef = (torch.randn(P + F + 1, D, device=dev) * 0.05); corr = torch.zeros_like(coef)
+o, idf = torch.empty_like(x), torch.empty_like(x)
+def fsmn_ops():
+    aslp.ops.fsmn_forward(o, x, coef, P, F)
+    aslp.ops.fsmn_backward(idf, corr, coef, x, od, P, F, 0.0, 1e-5)
+s = timeit_ev(fsmn_ops)
+print("CompactFsmn  ops level (2 launches: forward; in-diff + tap gradients + update): %.1f us, algorithmic %.1f GB/s" % (s * 1e6, bytes_alg / s / 1e9))
+w = torch.randn(D * (K + 1), device=dev) * 0.1; wd = torch.zeros_like(w); wc = torch.zeros_like(w)
+sl = torch.from_numpy(lens.astype(np.int32)).to(dev)
+o2, idf2 = torch.empty_like(x2), torch.empty_like(x2)
+def rc_ops():
+    aslp.ops.rowconv_forward(o2, x2, w, sl, K)
+    aslp.ops.rowconv_backward(idf2, wd, x2, od2, w, sl, K, wc, 0.9, 1e-5)
+s2 = timeit_ev(rc_ops, reps=5)
+print("RowConvolution ops level (3 launches: forward; in-diff + tap partials; finish + update): %.1f us, algorithmic (7 tensor passes) %.1f GB/s = %.2f of 8 TB/s" % (
+    s2 * 1e6, 4 * D * T * S * 7 / s2 / 1e9, 4 * D * T * S * 7 / s2 / 8e12))

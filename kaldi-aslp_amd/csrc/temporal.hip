@@ -379,46 +379,103 @@ __global__ void __launch_bounds__(kWave * kFinishWaves) rowconv_wgrad_finish(flo
 }
 
 // ---- CompactFsmn, LDS tiles ---------------------------------------------------------------------------------
-// One utterance is a few MB: these kernels are made of latencies, not of bandwidth.  Workgroups of SIXTEEN waves on 64 columns, so that the
-// rows of a tile are a dozen loads per thread, all in flight at once (stage_rows), and the last workgroup of a column tile (backward) has
-// thirty partials per thread to add instead of hundreds.
-constexpr int kFsmnWaves = 16;
-constexpr int kFsmnThreads = kWave * kFsmnWaves;
+// One utterance is a few MB, so the passes are made of latencies and of vector instructions, not of bandwidth: 800 x 512 x 61 multiply-adds
+// are 0.6 us of the chip's vector pipes but 6 us of 56 CUs'.  Hence tiles of 64 columns x 32 frames -- 200 workgroups of four waves for one
+// utterance -- whose rows reach LDS in ONE round trip to memory (every load of a thread is issued before its first LDS write), windows kept as
+// rings in registers (no moves), and tap gradients left as one partial per chunk of frames.
+constexpr int kFsmnWaves = kBlock / kWave;   // 4
+constexpr int kFsmnFrames = kFsmnWaves * TT; // frames per tile: one block of TT per wave
+constexpr int kFsmnSpare = 3 * TT;           // rows behind every LDS region that read-ahead may touch (zeros or stale: never used)
 
-// rows [r0, r0 + n) of a [T x D] matrix into an LDS tile of 64 columns (zeros outside the matrix; `spare` further rows of zeros), by the
-// whole workgroup; loads go out in batches of twelve per thread (192 rows: every load of the usual tiles in flight at once)
-__device__ __forceinline__ void stage_rows(float *__restrict__ tile, const float *__restrict__ src, int ld, int r0, int n, int spare, int T, bool col_ok,
-                                           int d, int x, int y) {
-  constexpr int U = 12;
-  for (int i0 = y; i0 < n + spare; i0 += kFsmnWaves * U) {
-    float v[U];
+// One tap against a ring window of N registers, with the ring position a COMPILE-TIME constant (a loop index inside `win[(u + jj) % N]` is
+// turned into selects by the compiler unless every level of the nest is unrolled; spelled out, it cannot be):
+//   acc[u] += win[(u + JJ) % N] * c for all u, then the slot of the oldest element takes the incoming one
+template <int JJ, int N>
+__device__ __forceinline__ void ring_tap(float (&acc)[N], float (&win)[N], float c, float e) {
 #pragma unroll
-    for (int u = 0; u < U; u++) {
+  for (int u = 0; u < N; u++) acc[u] += win[(u + JJ) % N] * c;
+  win[JJ] = e;
+}
+// taps j0 ... j0 + 7 of a block, operands from registers: a full block straight through, the last block of a count that is not a multiple
+// of 8 tap by tap (those below `limit`)
+__device__ __forceinline__ void ring_block8(float (&acc)[8], float (&win)[8], const float (&c)[8], const float (&e)[8], int j0, int limit) {
+  if (j0 + 8 <= limit) {
+    ring_tap<0, 8>(acc, win, c[0], e[0]); ring_tap<1, 8>(acc, win, c[1], e[1]); ring_tap<2, 8>(acc, win, c[2], e[2]); ring_tap<3, 8>(acc, win, c[3], e[3]);
+    ring_tap<4, 8>(acc, win, c[4], e[4]); ring_tap<5, 8>(acc, win, c[5], e[5]); ring_tap<6, 8>(acc, win, c[6], e[6]); ring_tap<7, 8>(acc, win, c[7], e[7]);
+    return;
+  }
+  if (j0 + 0 < limit) ring_tap<0, 8>(acc, win, c[0], e[0]);
+  if (j0 + 1 < limit) ring_tap<1, 8>(acc, win, c[1], e[1]);
+  if (j0 + 2 < limit) ring_tap<2, 8>(acc, win, c[2], e[2]);
+  if (j0 + 3 < limit) ring_tap<3, 8>(acc, win, c[3], e[3]);
+  if (j0 + 4 < limit) ring_tap<4, 8>(acc, win, c[4], e[4]);
+  if (j0 + 5 < limit) ring_tap<5, 8>(acc, win, c[5], e[5]);
+  if (j0 + 6 < limit) ring_tap<6, 8>(acc, win, c[6], e[6]);
+  if (j0 + 7 < limit) ring_tap<7, 8>(acc, win, c[7], e[7]);
+}
+static_assert(TT == 8, "ring_block8 is written for windows of 8");
+
+// rows [r0, r0 + n) of a [T x D] matrix into an LDS tile of 64 columns (zeros outside the matrix; `spare` further rows of zeros), and -- with
+// taps != nullptr -- the C taps (reversed: tap j is coef row C - 1 - j) into theirs, by the whole workgroup.  Up to 24 rows and 16 taps per
+// thread and round (96 rows, 64 taps: the usual tile in one round); 32-bit element offsets from the scalar bases, one address register per
+// load -- the launchers check that they fit.
+constexpr int kStageU = 24, kStageTapsU = 16;
+__device__ __forceinline__ void stage_rows_and_taps(float *__restrict__ tile, const float *__restrict__ src, int ld, int r0, int n, int spare, int T,
+                                                    float *__restrict__ taps, const float *__restrict__ coef, int ldc, int C, bool reversed, bool col_ok, int d,
+                                                    int x, int y) {
+  for (int i0 = y, j0 = y; i0 < n + spare || (taps != nullptr && j0 < C); i0 += kFsmnWaves * kStageU, j0 += kFsmnWaves * kStageTapsU) {
+    float v[kStageU], c[kStageTapsU];
+#pragma unroll
+    for (int u = 0; u < kStageU; u++) {
       const int i = i0 + u * kFsmnWaves, r = r0 + i;
-      v[u] = (col_ok && i < n && r >= 0 && r < T) ? src[(long)r * ld + d] : 0.0f;
+      v[u] = (col_ok && i < n && r >= 0 && r < T) ? src[(unsigned)(r * ld + d)] : 0.0f;
+    }
+    if (taps != nullptr) {
+#pragma unroll
+      for (int u = 0; u < kStageTapsU; u++) {
+        const int j = j0 + u * kFsmnWaves;
+        c[u] = (col_ok && j < C) ? coef[(unsigned)((reversed ? C - 1 - j : j) * ldc + d)] : 0.0f;
+      }
     }
 #pragma unroll
-    for (int u = 0; u < U; u++) {
+    for (int u = 0; u < kStageU; u++) {
       const int i = i0 + u * kFsmnWaves;
       if (i < n + spare) tile[i * kWave + x] = v[u];
     }
+    if (taps != nullptr) {
+#pragma unroll
+      for (int u = 0; u < kStageTapsU; u++) {
+        const int j = j0 + u * kFsmnWaves;
+        if (j < C) taps[j * kWave + x] = c[u];
+      }
+    }
   }
 }
-// out[t] = base[t] + sum_j taps[j] win[t + j] for the wave's blocks of TT frames of a tile: `tile` row i holds source row ta - pad + i
+// out[t] = tile[t + pad] + sum_j taps[j] tile[t + j] for the wave's blocks of TT frames; `tile` row i holds source row ta - pad + i.  The
+// window is a ring: tap j = j0 + jj reads elements j ... j + TT - 1, element e sits in slot e % TT, and the slot of element j takes j + TT.
 __device__ __forceinline__ void filter_tile(float *__restrict__ out, int ldo, const float *__restrict__ tile, const float *__restrict__ taps, int C, int pad,
                                             int ta, int tb, int d, int x, int y) {
   for (int t0 = y * TT; t0 < tb - ta; t0 += kFsmnWaves * TT) {
     float acc[TT], win[TT];
 #pragma unroll
     for (int u = 0; u < TT; u++) { acc[u] = 0.0f; win[u] = tile[(t0 + u) * kWave + x]; }
-#pragma unroll 4
-    for (int j = 0; j < C; j++) {
-      const float c = taps[j * kWave + x];
+    // taps and incoming elements of a block of TT taps are read one block AHEAD (16 LDS reads in flight under 64 multiply-adds): with one
+    // wave per SIMD nothing else hides an LDS read that is used the moment it is issued
+    float cn[TT], en[TT];
 #pragma unroll
-      for (int u = 0; u < TT; u++) acc[u] += win[u] * c;
+    for (int jj = 0; jj < TT; jj++) { cn[jj] = taps[jj * kWave + x]; en[jj] = tile[(t0 + TT + jj) * kWave + x]; }
+    for (int j0 = 0; j0 < C; j0 += TT) {
+      float c[TT], e[TT];
 #pragma unroll
-      for (int u = 0; u < TT - 1; u++) win[u] = win[u + 1];
-      win[TT - 1] = tile[(t0 + TT + j) * kWave + x];   // (at most row tcf + C - 1 + TT - 1: the spare rows)
+      for (int jj = 0; jj < TT; jj++) { c[jj] = cn[jj]; e[jj] = en[jj]; }
+      // (reads past tap C - 1 land in the regions' spare rows -- kFsmnSpare of them behind each -- and are never used)
+#pragma unroll
+      for (int jj = 0; jj < TT; jj++) {
+        const int j = j0 + TT + jj;
+        cn[jj] = taps[j * kWave + x];
+        en[jj] = tile[(t0 + TT + j) * kWave + x];
+      }
+      ring_block8(acc, win, c, e, j0, C);
     }
 #pragma unroll
     for (int u = 0; u < TT; u++)
@@ -426,89 +483,99 @@ __device__ __forceinline__ void filter_tile(float *__restrict__ out, int ldo, co
   }
 }
 
-// out[t] = src[t] + sum_j coef[row(j)] src[t + j - pad] on a tile of 64 columns x tcf frames.
-// sm: [tcf + C - 1 + TT][64] source rows ta - pad ..., then [C][64] taps in application order.
-__global__ void __launch_bounds__(kFsmnThreads) fsmn_filter_lds(float *__restrict__ out, int ldo, const float *__restrict__ src, int lds_,
-                                                                const float *__restrict__ coef, int ldc, int D, int C, int pad, int reverse, int T, int tcf) {
+// out[t] = src[t] + sum_j coef[row(j)] src[t + j - pad] on a tile of 64 columns x kFsmnFrames frames.
+// sm: [kFsmnFrames + C - 1 + kFsmnSpare][64] source rows ta - pad ..., then [C + kFsmnSpare][64] taps in application order.
+__global__ void __launch_bounds__(kBlock) fsmn_filter_lds(float *__restrict__ out, int ldo, const float *__restrict__ src, int lds_,
+                                                          const float *__restrict__ coef, int ldc, int D, int C, int pad, int reverse, int T) {
   extern __shared__ float sm[];
   const int x = threadIdx.x, y = threadIdx.y, d = blockIdx.x * kWave + x;
-  const int ta = blockIdx.y * tcf, tb = min(T, ta + tcf), rows = tcf + C - 1;
-  float *tile = sm, *taps = sm + (long)(rows + TT) * kWave;
-  stage_rows(tile, src, lds_, ta - pad, rows, TT, T, d < D, d, x, y);
-  for (int j = y; j < C; j += kFsmnWaves) taps[j * kWave + x] = d < D ? coef[(long)(reverse ? C - 1 - j : j) * ldc + d] : 0.0f;
+  const int ta = blockIdx.y * kFsmnFrames, tb = min(T, ta + kFsmnFrames), rows = kFsmnFrames + C - 1;
+  float *tile = sm, *taps = sm + (long)(rows + kFsmnSpare) * kWave;   // (taps: C + kFsmnSpare rows)
+  stage_rows_and_taps(tile, src, lds_, ta - pad, rows, TT, T, taps, coef, ldc, C, reverse != 0, d < D, d, x, y);
   __syncthreads();
   if (d < D) filter_tile(out, ldo, tile, taps, C, pad, ta, tb, d, x, y);
 }
 
-constexpr int kFsmnTapsPerThread = 4;
-// Backward of a tile of 64 columns x tcb frames [ta, tb):
+constexpr int kFsmnTapsPerThread = 8;   // (= the ring length of ring_block8)
+// Backward of a tile of 64 columns x kFsmnFrames frames [ta, tb):
 //   in_diff[t] = od[t] + sum_j coef[C-1-j] od[t + j - F]                  (cfsmn.h:232-249)
 //   partial[chunk][i] = sum_{t in chunk} in[t + i - P] od[t]               (:213-219)
-// and, in the workgroup that is the LAST of its column tile to get here (a ticket per tile): corr[i] = clip(sum over the chunks in
-// chunk order) and, with lr != 0, coef[i] -= lr corr[i] (:258-262) -- every other workgroup of the tile has read its taps by then.
-// sm: [rows + TT][64] od rows ta - F ..., [rows][64] in rows ta - P ... (rows = tcb + C - 1), [C][64] reversed taps.
-__global__ void __launch_bounds__(kFsmnThreads) fsmn_backward_fused(float *__restrict__ in_diff, int ldid, float *__restrict__ partial,
-                                                                    unsigned *__restrict__ tickets, float *__restrict__ corr, int ldcc,
-                                                                    float *__restrict__ coef, int ldc, const float *__restrict__ in, int ldi,
-                                                                    const float *__restrict__ od, int ldod, int D, int C, int P, int F, int T, int tcb,
-                                                                    int nchunks, float clip, float lr) {
+// With finish_here (few chunks: short utterances) the workgroup that is the LAST of its column tile to get here (a ticket per tile) also
+// forms corr[i] = clip(sum over the chunks in chunk order) and, with lr != 0, coef[i] -= lr corr[i] (:258-262) -- every other workgroup of
+// the tile has read its taps by then; otherwise fsmn_grad_finish does that in a launch of its own, spread over the chip.
+// sm: [rows + kFsmnSpare][64] od rows ta - F ..., [rows + kFsmnSpare][64] in rows ta - P ... (rows = kFsmnFrames + C - 1), [C + kFsmnSpare][64] reversed taps.
+__global__ void __launch_bounds__(kBlock) fsmn_backward_fused(float *__restrict__ in_diff, int ldid, float *__restrict__ partial,
+                                                              unsigned *__restrict__ tickets, float *__restrict__ corr, int ldcc,
+                                                              float *__restrict__ coef, int ldc, const float *__restrict__ in, int ldi,
+                                                              const float *__restrict__ od, int ldod, int D, int C, int P, int F, int T, int nchunks,
+                                                              float clip, float lr, int finish_here) {
   extern __shared__ float sm[];
   __shared__ unsigned last_flag;
   const int x = threadIdx.x, y = threadIdx.y, d = blockIdx.x * kWave + x;
-  const int chunk = blockIdx.y, ta = chunk * tcb, tb = min(T, ta + tcb), rows = tcb + C - 1;
-  float *odt = sm, *int_ = odt + (long)(rows + TT) * kWave, *taps = int_ + (long)rows * kWave;
-  {   // the three tiles in ONE round of loads (as stage_rows, twelve rows of each per thread and round)
-    constexpr int U = 12;
-    const bool col_ok = d < D;
-    for (int i0 = y; i0 < rows + TT || i0 < C; i0 += kFsmnWaves * U) {
-      float vo[U], vi[U], vt[U];
+  const int chunk = blockIdx.y, ta = chunk * kFsmnFrames, tb = min(T, ta + kFsmnFrames), rows = kFsmnFrames + C - 1;
+  float *odt = sm, *int_ = odt + (long)(rows + kFsmnSpare) * kWave, *taps = int_ + (long)(rows + kFsmnSpare) * kWave;   // (taps: C + kFsmnSpare rows)
+  const bool col_ok = d < D;
+  // the in rows are needed behind the in-diff only: their loads (up to 24 per thread; more go the plain way below) leave with the od tile's
+  // and reach LDS when the in-diff is done
+  float vin[kStageU];
 #pragma unroll
-      for (int u = 0; u < U; u++) {
-        const int i = i0 + u * kFsmnWaves, ro = ta - F + i, ri = ta - P + i;
-        vo[u] = (col_ok && i < rows && ro >= 0 && ro < T) ? od[(long)ro * ldod + d] : 0.0f;
-        vi[u] = (col_ok && i < rows && ri >= 0 && ri < T) ? in[(long)ri * ldi + d] : 0.0f;
-        vt[u] = (col_ok && i < C) ? coef[(long)(C - 1 - i) * ldc + d] : 0.0f;
-      }
+  for (int u = 0; u < kStageU; u++) {
+    const int i = y + u * kFsmnWaves, r = ta - P + i;
+    vin[u] = (col_ok && i < rows && r >= 0 && r < T) ? in[(unsigned)(r * ldi + d)] : 0.0f;
+  }
+  stage_rows_and_taps(odt, od, ldod, ta - F, rows, TT, T, taps, coef, ldc, C, true, col_ok, d, x, y);
+  __syncthreads();
+  if (col_ok) filter_tile(in_diff, ldid, odt, taps, C, F, ta, tb, d, x, y);
 #pragma unroll
-      for (int u = 0; u < U; u++) {
-        const int i = i0 + u * kFsmnWaves;
-        if (i < rows + TT) odt[i * kWave + x] = vo[u];
-        if (i < rows) int_[i * kWave + x] = vi[u];
-        if (i < C) taps[i * kWave + x] = vt[u];
-      }
-    }
+  for (int u = 0; u < kStageU; u++) {
+    const int i = y + u * kFsmnWaves;
+    if (i < rows) int_[i * kWave + x] = vin[u];
+  }
+  for (int i = y + kStageU * kFsmnWaves; i < rows; i += kFsmnWaves) {
+    const int r = ta - P + i;
+    int_[i * kWave + x] = (col_ok && r >= 0 && r < T) ? in[(unsigned)(r * ldi + d)] : 0.0f;
   }
   __syncthreads();
-  if (d < D) {
-    filter_tile(in_diff, ldid, odt, taps, C, F, ta, tb, d, x, y);
-    // tap gradients of this chunk: 4 taps per thread, a window of the in tile sliding down the chunk's frames
-    for (int ib = y * kFsmnTapsPerThread; ib < C; ib += kFsmnWaves * kFsmnTapsPerThread) {
-      float acc[kFsmnTapsPerThread], win[kFsmnTapsPerThread];
+  if (col_ok) {
+    // tap gradients of this chunk: 8 taps per thread, a ring of the in tile sliding down the chunk's frames (frame tt meets in rows
+    // tt + ib ... tt + ib + 7: element e in slot e % 8)
+    constexpr int G = kFsmnTapsPerThread;
+    for (int ib = y * G; ib < C; ib += kFsmnWaves * G) {
+      float acc[G], win[G];
 #pragma unroll
-      for (int j = 0; j < kFsmnTapsPerThread; j++) { acc[j] = 0.0f; win[j] = ib + j < rows ? int_[(ib + j) * kWave + x] : 0.0f; }
-#pragma unroll 4
-      for (int tt = 0; tt < tb - ta; tt++) {
-        const float gsc = odt[(tt + F) * kWave + x];
+      for (int j = 0; j < G; j++) { acc[j] = 0.0f; win[j] = int_[(ib + j) * kWave + x]; }
+      const int nt = tb - ta;
+      float gn[G], wn[G];   // read one block of frames ahead, as in filter_tile
 #pragma unroll
-        for (int j = 0; j < kFsmnTapsPerThread; j++) acc[j] += win[j] * gsc;
+      for (int tj = 0; tj < G; tj++) { gn[tj] = odt[(tj + F) * kWave + x]; wn[tj] = int_[(tj + ib + G) * kWave + x]; }
+      for (int t0 = 0; t0 < nt; t0 += G) {
+        float gs[G], wi[G];
 #pragma unroll
-        for (int j = 0; j < kFsmnTapsPerThread - 1; j++) win[j] = win[j + 1];
-        const int nx = tt + ib + kFsmnTapsPerThread;
-        win[kFsmnTapsPerThread - 1] = nx < rows ? int_[nx * kWave + x] : 0.0f;
+        for (int tj = 0; tj < G; tj++) { gs[tj] = gn[tj]; wi[tj] = wn[tj]; }
+#pragma unroll
+        for (int tj = 0; tj < G; tj++) {   // (past the chunk: spare rows, never used)
+          const int tt = t0 + G + tj;
+          gn[tj] = odt[(tt + F) * kWave + x];
+          wn[tj] = int_[(tt + ib + G) * kWave + x];
+        }
+        ring_block8(acc, win, gs, wi, t0, nt);
       }
 #pragma unroll
-      for (int j = 0; j < kFsmnTapsPerThread; j++)
+      for (int j = 0; j < G; j++)
         if (ib + j < C) partial[((long)chunk * C + ib + j) * D + d] = acc[j];
     }
   }
-  // ticket of the column tile
-  __threadfence();
+  if (!finish_here) return;
+  // ticket of the column tile.  ONE thread publishes the workgroup's partials (the barrier orders every wave's stores in front of its
+  // device-scope release: every wave writing the L2 back cost this kernel 30 us); the partials are read back with device-scope loads
   __syncthreads();
-  if (x == 0 && y == 0) last_flag = __hip_atomic_fetch_add(tickets + blockIdx.x, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nchunks - 1);
+  if (x == 0 && y == 0) {
+    __threadfence();
+    last_flag = __hip_atomic_fetch_add(tickets + blockIdx.x, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nchunks - 1);
+  }
   __syncthreads();
   if (!last_flag) return;
-  __threadfence();
-  if (d < D)
+  if (col_ok)
     for (int i0 = y; i0 < C; i0 += kFsmnWaves * 4) {   // four taps per thread and round, eight partials of each in flight
       float s[4] = {0.0f, 0.0f, 0.0f, 0.0f}, w_old[4];
 #pragma unroll
@@ -523,7 +590,7 @@ __global__ void __launch_bounds__(kFsmnThreads) fsmn_backward_fused(float *__res
 #pragma unroll
           for (int c = 0; c < 8; c++) {
             const int i = i0 + a * kFsmnWaves;
-            v[a][c] = (i < C && c0 + c < nchunks) ? __hip_atomic_load(partial + ((long)(c0 + c) * C + i) * D + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+            v[a][c] = (i < C && c0 + c < nchunks) ? __hip_atomic_load(partial + (unsigned)(((c0 + c) * C + i) * D + d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
           }
 #pragma unroll
         for (int a = 0; a < 4; a++)
@@ -542,6 +609,26 @@ __global__ void __launch_bounds__(kFsmnThreads) fsmn_backward_fused(float *__res
     }
   if (x == 0 && y == 0) __hip_atomic_store(tickets + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
 }
+// corr[i] = clip(sum of the chunks' partials, in chunk order) and, with lr != 0, coef[i] -= lr corr[i].  A workgroup of sixteen waves per
+// 64 columns x 16 taps: up to 32 partials per thread go out at once.
+constexpr int kFsmnFinishTaps = 16;
+__global__ void __launch_bounds__(kWave * kFsmnFinishTaps) fsmn_grad_finish(float *__restrict__ corr, int ldcc, float *__restrict__ coef, int ldc,
+                                                                          const float *__restrict__ partial, int D, int C, int nchunks, float clip, float lr) {
+  const int d = blockIdx.x * kWave + threadIdx.x, i = blockIdx.y * kFsmnFinishTaps + threadIdx.y;
+  if (d >= D || i >= C) return;
+  const float w_old = lr != 0.0f ? coef[(long)i * ldc + d] : 0.0f;
+  float s = 0.0f;
+  for (int c0 = 0; c0 < nchunks; c0 += 32) {
+    float v[32];
+#pragma unroll
+    for (int c = 0; c < 32; c++) v[c] = c0 + c < nchunks ? partial[(unsigned)(((c0 + c) * C + i) * D + d)] : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 32; c++) s += v[c];
+  }
+  if (clip > 0.0f) s = fminf(fmaxf(s, -clip), clip);
+  corr[(long)i * ldcc + d] = s;
+  if (lr != 0.0f) coef[(long)i * ldc + d] = w_old + -lr * s;
+}
 
 // rows per chunk so that (column tiles x chunks) is a few hundred blocks
 int rows_per_chunk(int rows, int ctiles) {
@@ -557,23 +644,24 @@ using namespace aslp;
 
 extern "C" {
 
-// LDS budget of the tiled CompactFsmn kernels (of the CU's 160 KB)
-static constexpr int kFsmnLdsRows = 512;   // rows of 64 floats: 128 KB
+// LDS budget of the tiled CompactFsmn kernels (of the CU's 160 KB): rows of 64 floats
+static constexpr int kFsmnLdsRows = 512;   // 128 KB
+static bool fsmn_fits32(long rows, long ld) { return rows * ld < (1L << 30); }   // element offsets of the tiled kernels are 32-bit
 
 void aslp_fsmn_filter(float *out, int ldo, const float *src, int lds, const float *coef, int ldc, int D, int past, int future, int T,
                       int reverse) {
   if (T <= 0 || D <= 0) return;
   const int C = past + future + 1, pad = reverse ? future : past;
-  const int tcf = kFsmnWaves * TT, rows = tcf + C - 1 + TT + C;   // a block of TT frames per wave
-  if (rows <= kFsmnLdsRows) {
+  const int rows = kFsmnFrames + C - 1 + kFsmnSpare + C + kFsmnSpare;
+  if (rows <= kFsmnLdsRows && fsmn_fits32(T, lds) && fsmn_fits32(T, ldo) && fsmn_fits32(C, ldc)) {
     const size_t lds_bytes = sizeof(float) * (size_t)rows * kWave;
     static bool attr_set = false;
     if (!attr_set) {
       ASLP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fsmn_filter_lds), hipFuncAttributeMaxDynamicSharedMemorySize, kFsmnLdsRows * kWave * sizeof(float)));
       attr_set = true;
     }
-    hipLaunchKernelGGL(fsmn_filter_lds, dim3((D + kWave - 1) / kWave, (T + tcf - 1) / tcf), dim3(kWave, kFsmnWaves), lds_bytes, cur_stream(), out, ldo,
-                       src, lds, coef, ldc, D, C, pad, reverse, T, tcf);
+    hipLaunchKernelGGL(fsmn_filter_lds, dim3((D + kWave - 1) / kWave, (T + kFsmnFrames - 1) / kFsmnFrames), dim3(kWave, kFsmnWaves), lds_bytes, cur_stream(), out, ldo,
+                       src, lds, coef, ldc, D, C, pad, reverse, T);
   } else {   // a filter too long for the tile
     dim3 block(kWave, kBlock / kWave), grid((D + kWave - 1) / kWave, (T + TT * (kBlock / kWave) - 1) / (TT * (kBlock / kWave)));
     hipLaunchKernelGGL(fsmn_filter, grid, block, 0, cur_stream(), out, ldo, src, lds, coef, ldc, D, C, pad, reverse, T);
@@ -584,22 +672,19 @@ void aslp_fsmn_filter(float *out, int ldo, const float *src, int lds, const floa
 void aslp_fsmn_backward(float *in_diff, int ldid, float *coef_corr, int ldcc, float *coef, int ldc, const float *in, int ldi, const float *out_diff,
                         int ldod, int D, int past, int future, int T, float clip, float lr) {
   if (T <= 0 || D <= 0) return;
-  const int C = past + future + 1, ctiles = (D + kWave - 1) / kWave;
-  // frames per chunk: an eighth of the utterance (8 partials for the last workgroup of a tile to add), within the LDS budget
-  const int tcb_max = (kFsmnLdsRows - TT - 2 * (C - 1) - C) / 2;
-  if (tcb_max < 16) {   // a filter too long for the tile: the separate kernels
+  const int C = past + future + 1, ctiles = (D + kWave - 1) / kWave, rows = kFsmnFrames + C - 1;
+  const int nchunks = (T + kFsmnFrames - 1) / kFsmnFrames;
+  const int lds_rows = 2 * (rows + kFsmnSpare) + C + kFsmnSpare;
+  if (lds_rows > kFsmnLdsRows || !fsmn_fits32(T, ldi) || !fsmn_fits32(T, ldod) || !fsmn_fits32(T, ldid) || !fsmn_fits32(C, ldc) ||
+      !fsmn_fits32((long)nchunks * C, D)) {   // a filter too long for the tile (or offsets beyond 32 bits): the separate kernels
     aslp_fsmn_coef_grad(coef_corr, ldcc, in, ldi, out_diff, ldod, D, past, future, T, clip);
     aslp_fsmn_filter(in_diff, ldid, out_diff, ldod, coef, ldc, D, past, future, T, 1);
-    if (lr != 0.0f) {   // coef += -lr coef_corr, row by row (the two matrices may have different pitches)
+    if (lr != 0.0f) {   // coef += -lr coef_corr
       MatrixDim d = {C, D, ldc};
       cudaF_add_mat(aslp_dim3{1, 1, 1}, aslp_dim3{1, 1, 1}, -lr, coef_corr, coef, d, ldcc, 0);
     }
     return;
   }
-  int tcb = (T + 7) / 8;
-  tcb = tcb < 32 ? 32 : tcb;
-  tcb = tcb > tcb_max ? tcb_max : tcb;
-  const int nchunks = (T + tcb - 1) / tcb, rows = tcb + C - 1;
   float *partial = static_cast<float *>(scratch(kScratchMisc, sizeof(float) * (size_t)nchunks * C * D));
   unsigned *tickets = static_cast<unsigned *>(scratch_zeroed(kScratchTickets, sizeof(unsigned) * (size_t)ctiles));
   if (!partial || !tickets) return;
@@ -608,8 +693,13 @@ void aslp_fsmn_backward(float *in_diff, int ldid, float *coef_corr, int ldcc, fl
     ASLP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fsmn_backward_fused), hipFuncAttributeMaxDynamicSharedMemorySize, kFsmnLdsRows * kWave * sizeof(float)));
     attr_set = true;
   }
-  hipLaunchKernelGGL(fsmn_backward_fused, dim3(ctiles, nchunks), dim3(kWave, kFsmnWaves), sizeof(float) * (size_t)(2 * rows + TT + C) * kWave, cur_stream(),
-                     in_diff, ldid, partial, tickets, coef_corr, ldcc, coef, ldc, in, ldi, out_diff, ldod, D, C, past, future, T, tcb, nchunks, clip, lr);
+  // few chunks: the last workgroup of a column tile adds them itself; many (a long utterance): a second launch spread over the chip does
+  const int finish_here = nchunks <= 8;
+  hipLaunchKernelGGL(fsmn_backward_fused, dim3(ctiles, nchunks), dim3(kWave, kFsmnWaves), sizeof(float) * (size_t)lds_rows * kWave, cur_stream(),
+                     in_diff, ldid, partial, tickets, coef_corr, ldcc, coef, ldc, in, ldi, out_diff, ldod, D, C, past, future, T, nchunks, clip, lr, finish_here);
+  if (!finish_here)
+    hipLaunchKernelGGL(fsmn_grad_finish, dim3(ctiles, (C + kFsmnFinishTaps - 1) / kFsmnFinishTaps), dim3(kWave, kFsmnFinishTaps), 0, cur_stream(), coef_corr, ldcc,
+                       coef, ldc, partial, D, C, nchunks, clip, lr);
   check_launch("aslp_fsmn_backward");
 }
 
