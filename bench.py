@@ -676,9 +676,10 @@ def cfg4_bsp_block(aslp, dev, native_parallel, comm, rank, world, sync_period):
     el = comm.MaxOverRanks(time.perf_counter() - t0)
     sync_ms = comm.MaxOverRanks(sync_s * 1e3 / max(syncs, 1))
     worker.close()
+    st = xent.GetStats()   # (rank 0's shard: also proves the loss stayed finite through the exchanges)
     out = {"workload": "cfg4: 5x2048 sigmoid DNN (no BatchNorm), minibatch 256/GPU, lr 0.008, BSP every %d frames, distinct shards" % sync_period,
            "n_gpus": world, "steps": steps, "ms_per_step": el * 1e3 / steps, "frames_per_sec": world * steps * mb / el, "syncs_timed": syncs,
-           "sync_ms": sync_ms, "scaling": "weak"}
+           "sync_ms": sync_ms, "scaling": "weak", "avg_xent_per_frame_rank0": (st["loss"] - st["entropy"]) / max(st["frames"], 1.0)}
     out.update(_comm_facts(comm))
     return out
 
@@ -745,14 +746,17 @@ def cfg5_easgd_block(aslp, dev, native_parallel, comm, rank, world, sync_period)
         worker.Stop()
         worker.close()
         frames_local, sync_ms_local = float(steps * int(lens.sum())), sync_s * 1e3 / max(syncs, 1)
+        cst = ctc.GetStats()
+        obj_local = cst["obj"] / max(cst["sequences"], 1.0)
     comm.Barrier()
     el = comm.MaxOverRanks(el_local if rank != 0 else 0.0)
     frames = sum(comm.AllReduceHostDouble([frames_local]))
     sync_ms = comm.MaxOverRanks(sync_ms_local)
+    obj = sum(comm.AllReduceHostDouble([obj_local if rank != 0 else 0.0])) / max(world - 1, 1)   # (a non-finite worker objective makes this non-finite)
     out = {"workload": "cfg5: 4 x BLstmProjectedStreamsLC (C 512) + Warp-CTC on whole utterances (S = 32, T <= 800), EASGD alpha 0.5, server on rank 0, "
                        "%d worker(s), exchange every %d valid frames" % (world - 1, sync_period),
            "n_gpus": world, "workers": world - 1, "steps_per_worker": steps, "valid_frames_per_sec": frames / el if el > 0 else 0.0,
-           "ms_per_step": el * 1e3 / steps, "sync_ms": sync_ms, "scaling": "weak"}
+           "ms_per_step": el * 1e3 / steps, "sync_ms": sync_ms, "scaling": "weak", "avg_ctc_obj_per_sequence": obj}
     out.update(_comm_facts(comm))
     return out
 

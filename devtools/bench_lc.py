@@ -63,9 +63,6 @@ if os.environ.get("SEQ_TIMING") == "1":
         buf = (C.c_ulonglong * 8)()
         aslp.lib.aslp_lstm_seq_timing(0, buf)
         n = max(1, buf[0])
-        if mode == 1 and os.environ.get("ASLP_LSTM_DUAL", "0") == "1":
-            print("(wave-specialised forward: per timestep = two half-steps; 'barrier' (2nd) = product waves waiting for the gate waves; the 1st 'barrier' column = "
-                  "gate role: reduce + gate block up to the publication; 'epilogue' = gate role: stores behind the publication)")
         names = ("collect m(t-1)", "barrier", "product", "barrier", "epilogue") if mode == 1 else ("product+publish", "sum shares", "collect shares", "barrier", "gate diffs")
         vals = [buf[k] * 0.01 / n for k in (1, 3, 2, 4, 5)]
         print("%s kernel, workgroup 0 wave 0, us per timestep: %s   (L2-local launches %d of %d; workgroup 0 resident %.1f us per launch)"
@@ -87,35 +84,6 @@ if os.environ.get("SEQ_RESIDENCY") == "1":   # when do the workgroups of a persi
             print("%s layer %d: last entry %.2f us; exit first %.1f / median %.1f / last %.1f us; last exit per chain: %s"
                   % (name, layer, (max(ent) - e0) * 0.01, (min(ext) - e0) * 0.01, (sorted(ext)[128] - e0) * 0.01, (max(ext) - e0) * 0.01,
                      " ".join("%.1f" % ((max(ext[c::8]) - e0) * 0.01) for c in range(8))))
-if os.environ.get("SEQ_CENSUS") == "1":   # half chains: which workgroups share a CU?
-    import ctypes as C
-    import collections
-    aslp.lib.aslp_lstm_seq_census.argtypes = [C.c_void_p, C.c_int]
-    aslp.lib.aslp_lstm_seq_timing(3, None)
-    step(400)
-    aslp.lib.aslp_lstm_seq_timing(0, None)
-    buf = (C.c_ulonglong * 512)()
-    aslp.lib.aslp_lstm_seq_census(buf, 512)
-    cus = collections.defaultdict(list)
-    for b in range(512):
-        v = buf[b]
-        xcc, hw, chain, cb = v >> 48, (v >> 32) & 0xFFFF, (v >> 8) & 0xFF, v & 0xFF
-        cus[(xcc, (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 15)].append((b, chain, cb))
-    sizes = collections.Counter(len(v) for v in cus.values())
-    mixed = sum(1 for v in cus.values() if len(set(c for _, c, _ in v)) > 1)
-    xcc_ok = sum(1 for k, v in cus.items() for (b, _, _) in v if (b & 7) == k[0])
-    print("census: %d distinct (xcc, se, sh, cu); workgroups per CU %s; CUs hosting two different chains %d; workgroups with xcc == b %% 8: %d of 512"
-          % (len(cus), dict(sizes), mixed, xcc_ok))
-    print("census sample:", sorted(cus.items())[:6])
-    plog = (C.c_ulonglong * 512)()
-    aslp.lib.aslp_lstm_seq_phase_log.argtypes = [C.c_void_p]
-    aslp.lib.aslp_lstm_seq_phase_log(plog)
-    t00 = min(plog[0], plog[256])
-    print("phase log (last traced forward launch = layer 3), us since the first stamp: [collected, multiplied, barrier, gates done] for workgroup 0 | its CU partner")
-    for stp in list(range(0, 6)) + list(range(28, 32)) + list(range(56, 60)):
-        a4 = [(plog[4 * stp + k] - t00) * 0.01 for k in range(4)]
-        b4 = [(plog[256 + 4 * stp + k] - t00) * 0.01 for k in range(4)]
-        print("  step %2d: %s | %s" % (stp, " ".join("%7.2f" % v for v in a4), " ".join("%7.2f" % v for v in b4)))
 print("hand-off re-polls per step (all waves): %.0f" % (aslp.lib.aslp_lstm_seq_polls(1) / STEPS))
 if os.environ.get("GEMM_PROFILE") == "1":
     import ctypes as C

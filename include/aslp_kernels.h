@@ -167,12 +167,7 @@ typedef struct aslp_planes_out_ {
   int ld;                 /* halves per plane row */
   const unsigned *slot;   /* device word: bits of the bound (float) the planes are scaled by */
   float *parts;           /* device, 256 floats: per-workgroup maxima, or NULL */
-  int nparts;             /* out: how many the launch wrote (0: none, the kernel that ran does not leave them; -1: it wrote the PLANES, below) */
-  /* in, optional: two arrays of device maxima from which the kernel can bound its output before it has written it -- it then stores the
-   * bound in `slot` and writes the planes itself (aslp_bn_backward_step_p: a = the forward launch's per-panel max |scale / sigma|,
-   * aslp_bn_forward_stats_p's giv_parts; b = per-workgroup maxima of |out_diff| from the launch that wrote it) */
-  const float *bound_a, *bound_b;
-  int bound_na, bound_nb;
+  int nparts;             /* out: how many the launch wrote (0: none, the kernel that ran does not leave them) */
 } aslp_planes_out;
 /* Fused epilogue form.  Applied in this order on the fp32 accumulator `acc`:
  *   v = alpha*acc + beta*C;  if (bias) v += bias[col];  if (clip > 0) v = clamp(v, -clip, clip);
@@ -319,11 +314,10 @@ void aslp_bn_backward_act(const float *in, MatrixDim d, const float *out_diff, i
 int aslp_bn_forward_stats(const float *in, MatrixDim d, float *out, int out_stride, const float *scale, const float *shift, float *mean,
                           float *inv_std, double *acc_means, double *acc_vars, float var_floor, float *act_out, int act_stride,
                           const double *colstats, int groups, int stats_ld);
-/* ... which also leaves the planes of act_out (sigmoid outputs: bound 1; `act_planes->slot` must hold a bound >= 1) and, in giv_parts
- * [cols / 32] (optional), the per-panel maxima of |scale / sigma| for aslp_bn_backward_step_p's bound */
+/* ... which also leaves the planes of act_out (sigmoid outputs: bound 1; `act_planes->slot` must hold a bound >= 1) */
 int aslp_bn_forward_stats_p(const float *in, MatrixDim d, float *out, int out_stride, const float *scale, const float *shift, float *mean,
                             float *inv_std, double *acc_means, double *acc_vars, float var_floor, float *act_out, int act_stride,
-                            const double *colstats, int groups, int stats_ld, const aslp_planes_out *act_planes, float *giv_parts);
+                            const double *colstats, int groups, int stats_ld, const aslp_planes_out *act_planes);
 
 /* aslp_bn_backward_act + BatchNormalization::Update (nnet-batch-normalization.h:280-284) taken in the statistics
  * finalize: scale -= learn_rate * dscale, shift -= learn_rate * dshift; in_diff is formed with the scale the
@@ -473,9 +467,8 @@ void aslp_device_shared(int on);
 void aslp_lstm_split16(int on);
 int aslp_lstm_seq_first_product_supported(int k_first);
 int aslp_lstm_seq_first_product_supported_for(int k_first, int C);   /* ... in a layer of C cells (the staging row is 128 floats for C <= 128) */
-/* Streams per chain the launch for these arguments uses: 8 (one 512-thread workgroup per CU) or 4 (half chains: two 256-thread workgroups
- * of two independent chains per CU, so that one chain's product runs under the other's hand-off and gate block; ASLP_LSTM_HALF_CHAINS=0
- * keeps 8).  grad_partial then has ndir * ceil(streams / that) chains of 7 rows. */
+/* Streams per chain the launch for these arguments uses: 8 (one 512-thread workgroup per CU).  grad_partial then has
+ * ndir * ceil(streams / that) chains of 7 rows. */
 int aslp_lstm_seq_chain_streams(const aslp_lstm_seq *a, int backward);
 /* row blocks 0 and T+1 := 0 (all ld columns); columns [col0, col0 + ncols) of row blocks 1..T := 0xFFFFFFFF words.
  * For the forward kernel: col0 = the m column block (G + 2) * C, ncols = C. */
@@ -490,10 +483,6 @@ void aslp_lstm_seq_forward(const aslp_lstm_seq *a);
  * workgroups 0 .. n-1 of the launch `launches_back` (0 = latest .. 7) persistent launches ago.  Synchronises. */
 void aslp_lstm_seq_residency(unsigned long long *out, int n, int launches_back);
 unsigned aslp_lstm_seq_polls(int reset);
-/* devtools: placement census of the latest traced half-chain forward launch: out[b] = XCC id << 48 | HW_ID[15:0] << 32 | chain << 8 | block */
-void aslp_lstm_seq_census(unsigned long long *out, int n);
-/* devtools: phase log of the latest traced half-chain forward launch: out[slot * 256 + 4 * step + k] (512 words), see csrc/rnn_persistent.hip */
-void aslp_lstm_seq_phase_log(unsigned long long *out);
 /* diagnostics (devtools/bench_lc.py): phase timing of the forward kernel, see csrc/rnn_persistent.hip */
 void aslp_lstm_seq_timing(int enable, unsigned long long *out);
 void aslp_lstm_seq_backward(const aslp_lstm_seq *a);
@@ -544,8 +533,9 @@ void aslp_fsmn_filter(float *out, int ldo, const float *src, int lds, const floa
                       int reverse);
 void aslp_fsmn_coef_grad(float *coef_corr, int ldc, const float *in, int ldi, const float *out_diff, int ldod, int D, int past, int future,
                          int T, float clip);
-/* The whole backward pass in ONE launch (BackpropagateFnc :204-256 + Update :258-262): in_diff as reverse = 1 above, coef_corr as
- * coef_grad above, and -- with lr != 0 -- coef += -lr * coef_corr once every read of coef is done.  in_diff must not alias out_diff. */
+/* The whole backward pass (BackpropagateFnc :204-256 + Update :258-262) in two launches: in_diff as reverse = 1 above and the tap
+ * gradients of every chunk of frames from ONE staging of in / out_diff; then coef_corr as coef_grad above and -- with lr != 0 --
+ * coef += -lr * coef_corr.  in_diff must not alias out_diff. */
 void aslp_fsmn_backward(float *in_diff, int ldid, float *coef_corr, int ldcc, float *coef, int ldc, const float *in, int ldi, const float *out_diff,
                         int ldod, int D, int past, int future, int T, float clip, float lr);
 /* RowConvolution (nnet-row-convolution.cc:105-176): rows t*S + s, w dense [D x (K+1)], seq_len [S] on the device.

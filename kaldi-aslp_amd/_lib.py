@@ -21,8 +21,7 @@ class Dim3(C.Structure):
 
 class PlanesOut(C.Structure):
     """aslp_planes_out (include/aslp_kernels.h)"""
-    _fields_ = [("hi", C.c_void_p), ("lo", C.c_void_p), ("ld", C.c_int), ("slot", C.c_void_p), ("parts", C.c_void_p), ("nparts", C.c_int),
-                ("bound_a", C.c_void_p), ("bound_b", C.c_void_p), ("bound_na", C.c_int), ("bound_nb", C.c_int)]
+    _fields_ = [("hi", C.c_void_p), ("lo", C.c_void_p), ("ld", C.c_int), ("slot", C.c_void_p), ("parts", C.c_void_p), ("nparts", C.c_int)]
 
 
 class GemmEpilogue(C.Structure):

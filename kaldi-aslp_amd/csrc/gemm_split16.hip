@@ -164,24 +164,21 @@ __device__ __forceinline__ float s16_weight_bound(const GemmArgs &g, const S16Vi
 
 // Everything behind the K loop: join the two accumulators and undo the operand scales, the column sums of a reduction-major A
 // (COLSUM), the column statistics, the epilogue (with the planes / maxima of its output when EXTRA).  (row0, col0): this wave's patch.
-// the two accumulators of a patch joined and the operand scales undone: 2^-(up_a + up_b) in two exact factors (either alone may leave
-// fp32's range where their product with the accumulator does not)
-template <int TM, int TN>
-__device__ __forceinline__ void s16_join(const S16View &va, const S16View &vb, f32x16 (&acc)[TM][TN], const f32x16 (&accx)[TM][TN]) {
-  const int e = -(s16_exponent(*va.slot) + s16_exponent(*vb.slot));
-  const float s1 = ldexpf(1.f, e / 2), s2 = ldexpf(1.f, e - e / 2);
-#pragma unroll
-  for (int i = 0; i < TM; i++)
-#pragma unroll
-    for (int j = 0; j < TN; j++)
-#pragma unroll
-      for (int q = 0; q < 16; q++) acc[i][j][q] = (fmaf(accx[i][j][q], 0x1p-11f, acc[i][j][q]) * s1) * s2;
-}
-template <int TM, int TN, int NW, bool EXTRA, bool COLSUM, bool JOINED = false>
+template <int TM, int TN, int NW, bool EXTRA, bool COLSUM>
 __device__ __forceinline__ void s16_finish(const GemmArgs &g, const S16View &va, const S16View &vb, f32x16 (&acc)[TM][TN], const f32x16 (&accx)[TM][TN],
                                            const float (&asum)[TM], bool do_colsum, float w_bound, int row0, int col0, int lane, int wave, float *lds) {
   const int l31 = lane & 31, lh = lane >> 5;
-  if constexpr (!JOINED) s16_join<TM, TN>(va, vb, acc, accx);
+  // 2^-(up_a + up_b) in two exact factors (either alone may leave fp32's range where their product with the accumulator does not)
+  {
+    const int e = -(s16_exponent(*va.slot) + s16_exponent(*vb.slot));
+    const float s1 = ldexpf(1.f, e / 2), s2 = ldexpf(1.f, e - e / 2);
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+      for (int j = 0; j < TN; j++)
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc[i][j][q] = (fmaf(accx[i][j][q], 0x1p-11f, acc[i][j][q]) * s1) * s2;
+  }
   if constexpr (COLSUM) {
     if (do_colsum) {
       const float inv_a = ldexpf(1.f, -s16_exponent(*va.slot));
@@ -257,20 +254,12 @@ __device__ __forceinline__ S16View s16_pick(bool second, const S16View &x, const
 // ABL (devtools/micro/s16_ablate.hip only; 0 in the library): 1 = no MFMA, 2 = no DMA, 4 = no LDS reads -- wrong results, for timing
 // EXTRA: the epilogue also leaves planes / maxima of its output (aslp_gemm_epilogue.planes, *_parts); a variant of its own because the
 // extra epilogue state costs the 128 x 128 tile its last registers.
-// KSPL ("the waves split K"): every wave owns the WHOLE BM x BN output and multiplies only its own instruction k steps of each K tile (wave w:
-// steps w KH / NW ...), so that every staged row is read from LDS exactly ONCE per tile -- the 2 x 2 wave layout reads each row twice (A by
-// the two waves of a tile row, B by the two of a tile column), and at 64 x 128 those reads alone are the LDS' whole bandwidth under a busy
-// matrix pipe.  The price: 2 x BM x BN / 64 accumulator registers per lane (256 for 64 x 128) and one exchange at the end -- every wave
-// leaves its partial patch in the operand LDS (lane-major, in accumulator layout), wave (wm, wn) adds the four partials of its 2 x 2 patch in
-// wave order and runs the usual epilogue on it.  A must be reduction-contiguous (no column sums of A here).
-template <int BM, int BN, int WGM, int WGN, int NS, bool A_KC, bool B_KC, int ABL = 0, bool EXTRA = false, bool KSPL = false>
+template <int BM, int BN, int WGM, int WGN, int NS, bool A_KC, bool B_KC, int ABL = 0, bool EXTRA = false>
 __global__ void __launch_bounds__(64 * WGM * WGN)
     __attribute__((amdgpu_waves_per_eu(1, (NS * 2 * (BM + BN) * 128 > 80 * 1024 && WGM * WGN <= 4) ? 1 : 2)))   // (LDS already limits those to one wave per SIMD: all 512 registers are theirs)
     gemm_s16_glds(GemmArgs g, S16Operands ops) {
   constexpr int NW = WGM * WGN;
-  constexpr int WM = KSPL ? BM : BM / WGM, WN = KSPL ? BN : BN / WGN, TM = WM / 32, TN = WN / 32;
-  constexpr int KHW = KSPL ? KH / NW : KH;   // instruction k steps of a K tile that one wave multiplies
-  static_assert(!KSPL || (KH % NW == 0 && A_KC), "k split: the waves share the tile's k steps evenly; A reduction-contiguous");
+  constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
   // a stage, in bytes (every plane tile is 64 halves x BR rows whichever way it lies): A_hi | A_lo | B_hi | B_lo
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = 2 * (A_BYTES + B_BYTES);
   constexpr int SLOTS_A = BM / 8, SLOTS_B = BN / 8, SLOTS = 2 * (SLOTS_A + SLOTS_B);   // 1-KiB DMA units per tile
@@ -279,7 +268,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN)
   constexpr int D = NS - 1;
   constexpr int RA = A_KC ? 1 : 2, RB = B_KC ? 1 : 2;            // LDS reads per fragment and plane
   constexpr int NRH = 2 * (TM * RA + TN * RB);                    // reads per instruction k step
-  constexpr int NM = KHW * 3 * TM * TN, NRD = KHW * NRH, SB = NM / 2 - 1;
+  constexpr int NM = KH * 3 * TM * TN, NRD = KH * NRH, SB = NM / 2 - 1;
   constexpr int UNROLL = (NS % 2 == 0) ? NS : 2 * NS;
   static_assert(G <= 2 * (SB + 1), "not enough MFMA slots before the barrier");
   static_assert(A_KC || BM == 32 || BM == 64 || BM == 128, "KS image: 32, 64 or 128 columns");
@@ -296,8 +285,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN)
   xcd_tile<BM, BN>(g, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = KSPL ? 0 : wave / WGN, wn = KSPL ? 0 : wave % WGN, l31 = lane & 31, lh = lane >> 5;
-  const int kstep0 = KSPL ? wave * KHW : 0;   // this wave's first instruction k step inside a K tile
+  const int wm = wave / WGN, wn = wave % WGN, l31 = lane & 31, lh = lane >> 5;
   // split-K (as gemm_glds.hip): this workgroup reduces over K chunk blockIdx.y only and leaves a plain, unscaled-back partial product
   // in C + chunk * split_stride (the host has emptied the epilogue; splitk_reduce_kernel adds the chunks in order and applies it)
   int k_first = 0, ktiles = ops.kp / BKH;
@@ -361,7 +349,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN)
   //  KC: row * 128 + swizzled 16-byte chunk (2 h + lh);  KS: lane (p = lane & 15, column half g = (lane >> 4) & 1) of a 16-lane group
   //  addresses k row 8 lh + p / 4, columns 16 g + 4 (p & 3) .. + 3 of its 32-column fragment and receives column 16 g + p, k .. k + 3
   //  (KC keeps one offset per k step: the swizzle is an XOR; KS steps are plain additions that fold into the instruction's offset field)
-  constexpr int AH = A_KC ? KHW : 1, BH = B_KC ? KHW : 1;
+  constexpr int AH = A_KC ? KH : 1, BH = B_KC ? KH : 1;
   int a_off[TM][AH], b_off[TN][BH];
   const int p16 = lane & 15, g16 = (lane >> 4) & 1;
 #pragma unroll
@@ -369,7 +357,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN)
     if constexpr (A_KC) {
       const int row = wm * WM + t * 32 + l31;
 #pragma unroll
-      for (int h = 0; h < KHW; h++) a_off[t][h] = row * 128 + (((2 * (kstep0 + h) + lh) ^ kc_swizzle(row)) << 4);
+      for (int h = 0; h < KH; h++) a_off[t][h] = row * 128 + (((2 * h + lh) ^ kc_swizzle(row)) << 4);
     } else {
       const int T = wm * TM + t, krow = 8 * lh + (p16 >> 2);
       a_off[t][0] = krow * (2 * BM) + 64 * (T ^ ks_swizzle<BM>(krow)) + 32 * g16 + 8 * (p16 & 3);
@@ -380,15 +368,14 @@ __global__ void __launch_bounds__(64 * WGM * WGN)
     if constexpr (B_KC) {
       const int col = wn * WN + t * 32 + l31;
 #pragma unroll
-      for (int h = 0; h < KHW; h++) b_off[t][h] = 2 * A_BYTES + col * 128 + (((2 * (kstep0 + h) + lh) ^ kc_swizzle(col)) << 4);
+      for (int h = 0; h < KH; h++) b_off[t][h] = 2 * A_BYTES + col * 128 + (((2 * h + lh) ^ kc_swizzle(col)) << 4);
     } else {
       const int T = wn * TN + t, krow = 8 * lh + (p16 >> 2);
-      // (k split: the wave's first k step is 16 kstep0 rows down the [k][columns] image; the row swizzle depends on krow & 3 only, and 16 | 4)
-      b_off[t][0] = 2 * A_BYTES + (krow + 16 * kstep0) * (2 * BN) + 64 * (T ^ ks_swizzle<BN>(krow)) + 32 * g16 + 8 * (p16 & 3);
+      b_off[t][0] = 2 * A_BYTES + krow * (2 * BN) + 64 * (T ^ ks_swizzle<BN>(krow)) + 32 * g16 + 8 * (p16 & 3);
     }
   }
   struct Frag {
-    half8 ah[KHW][TM], al[KHW][TM], bh[KHW][TN], bl[KHW][TN];
+    half8 ah[KH][TM], al[KH][TM], bh[KH][TN], bl[KH][TN];
   };
   // one LDS read: flat index r -> (k step h, operand, fragment t, plane, half of the fragment)
   auto read_unit = [&](auto ST_, Frag &f, auto R_) {
@@ -432,7 +419,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN)
     typedef _Float16 half2v __attribute__((ext_vector_type(2)));
     const half2v one = {(h16)1.0f, (h16)1.0f}, eps = {(h16)0x1p-11f, (h16)0x1p-11f};
 #pragma unroll
-    for (int h = 0; h < KHW; h++)
+    for (int h = 0; h < KH; h++)
 #pragma unroll
       for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -482,7 +469,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN)
     half8 z;
 #pragma unroll
     for (int e = 0; e < 8; e++) z[e] = (h16)(float)(lane + e);
-    static_for<0, KHW>([&](auto H_) {
+    static_for<0, KH>([&](auto H_) {
       constexpr int h = decltype(H_)::value;
 #pragma unroll
       for (int t = 0; t < TM; t++) { f0.ah[h][t] = z; f0.al[h][t] = z; f1.ah[h][t] = z; f1.al[h][t] = z; }
@@ -513,48 +500,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN)
   wait_vmcnt<0>();
 
   static_assert(NW * 32 * kEpiPitch * (int)sizeof(float) <= NS * STAGE, "the waves' epilogue slices must fit into the operand LDS");
-  if constexpr (!KSPL) {
-    s16_finish<TM, TN, NW, EXTRA, !A_KC>(g, va, vb, acc, accx, asum, do_colsum, w_bound, m0 + wm * WM, n0 + wn * WN, lane, wave, lds);
-  } else {
-    // the waves' partial products meet: [wave][32 x 32 block][4 accumulator quads][lane] float4 in the operand LDS (every stage has been read),
-    // then wave (rm, rn) of the WGM x WGN layout adds the partials of its patch in wave order and finishes it like a 2 x 2 kernel's wave would
-    constexpr int RM = TM / WGM, RN = TN / WGN;
-    static_assert(TM % WGM == 0 && TN % WGN == 0, "k split: the patch layout of the exchange");
-    static_assert(NW * TM * TN * 4 * 64 * 16 <= NS * STAGE, "k split: the waves' partial patches must fit into the operand LDS");
-    s16_join<TM, TN>(va, vb, acc, accx);
-    float4 *red = reinterpret_cast<float4 *>(lds);
-    __builtin_amdgcn_s_barrier();   // every wave is done with the last stage
-#pragma unroll
-    for (int i = 0; i < TM; i++)
-#pragma unroll
-      for (int j = 0; j < TN; j++)
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-          red[((wave * TM * TN + i * TN + j) * 4 + q) * 64 + lane] = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-    __syncthreads();
-    const int rm = wave / WGN, rn = wave % WGN;
-    f32x16 out[RM][RN], none[RM][RN];
-#pragma unroll
-    for (int i = 0; i < RM; i++)
-#pragma unroll
-      for (int j = 0; j < RN; j++)
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const int blk = (rm * RM + i) * TN + rn * RN + j;
-          float4 v = red[((0 * TM * TN + blk) * 4 + q) * 64 + lane];
-#pragma unroll
-          for (int w = 1; w < NW; w++) {
-            const float4 u = red[((w * TM * TN + blk) * 4 + q) * 64 + lane];
-            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
-          }
-          out[i][j][4 * q] = v.x; out[i][j][4 * q + 1] = v.y; out[i][j][4 * q + 2] = v.z; out[i][j][4 * q + 3] = v.w;
-        }
-    float no_sum[RM];
-#pragma unroll
-    for (int i = 0; i < RM; i++) no_sum[i] = 0.f;
-    __builtin_amdgcn_s_barrier();   // (the epilogue's LDS slices overlap the partials other waves may still be reading)
-    s16_finish<RM, RN, NW, EXTRA, false, true>(g, va, vb, out, none, no_sum, false, w_bound, m0 + rm * RM * 32, n0 + rn * RN * 32, lane, wave, lds);
-  }
+  s16_finish<TM, TN, NW, EXTRA, !A_KC>(g, va, vb, acc, accx, asum, do_colsum, w_bound, m0 + wm * WM, n0 + wn * WN, lane, wave, lds);
 }
 
 // ---- both operands reduction-major (the weight gradient dW = dy^T x), 128 x 128 tile ---------------------------------------------
@@ -730,12 +676,12 @@ void launch_s16_ks128(GemmArgs &g, const S16Operands &ops) {
   t_last_parts = EXTRA ? g.tiles_m * g.tiles_n * (g.pair ? 2 : 1) : 0;
 }
 
-template <int BM, int BN, int WGM, int WGN, int NS, bool A_KC, bool B_KC, int ABL = 0, bool EXTRA = false, bool KSPL = false>
+template <int BM, int BN, int WGM, int WGN, int NS, bool A_KC, bool B_KC, int ABL = 0, bool EXTRA = false>
 void launch_s16(GemmArgs &g, const S16Operands &ops) {
   g.tiles_m = (g.M + BM - 1) / BM;
   g.tiles_n = (g.N + BN - 1) / BN;
   constexpr int lds_bytes = NS * 2 * (BM + BN) * 128;
-  auto kern = gemm_s16_glds<BM, BN, WGM, WGN, NS, A_KC, B_KC, ABL, EXTRA, KSPL>;
+  auto kern = gemm_s16_glds<BM, BN, WGM, WGN, NS, A_KC, B_KC, ABL, EXTRA>;
   static bool attr_set = false;
   if (!attr_set) {
     if (lds_bytes > 48 * 1024)
@@ -786,13 +732,6 @@ bool launch_s16_layout(GemmArgs &g, const S16Operands &ops, int cfg) {
       if (extra) launch_s16<64, 128, 2, 2, 3, A_KC, B_KC, 0, true>(g, ops);
       else launch_s16<64, 128, 2, 2, 3, A_KC, B_KC>(g, ops);
       break;
-    case 318:   // 64 x 128 with the waves splitting K (A reduction-contiguous: forward and in-diff products)
-      if constexpr (A_KC) {
-        if (extra) launch_s16<64, 128, 2, 2, 3, A_KC, B_KC, 0, true, true>(g, ops);
-        else launch_s16<64, 128, 2, 2, 3, A_KC, B_KC, 0, false, true>(g, ops);
-        break;
-      }
-      return false;
     default: return false;
   }
   t_last_cfg_s16 = cfg;
@@ -809,10 +748,9 @@ bool gemm_split16_enabled() {
 }
 
 int s16_plane_ld(int cols) {
-  // (measured: no effect on the layer products -- 31.5 / 31.6 / 31.8 us with 64 / 0 / 128 halves -- so off; ASLP_S16_LD_PAD=<halves> switches it on)
-  static const int pad = [] { const char *e = getenv("ASLP_S16_LD_PAD"); return e ? atoi(e) : 0; }();
-  const int ld = (cols + kS16Pad - 1) / kS16Pad * kS16Pad;
-  return (pad > 0 && (ld * 2) % 2048 == 0) ? ld + pad : ld;
+  // (an extra pitch of 64 or 128 halves on rows whose pitch is a multiple of 2 KB was measured: no effect on the layer products, 31.5 /
+  //  31.6 / 31.8 us)
+  return (cols + kS16Pad - 1) / kS16Pad * kS16Pad;
 }
 bool gemm_split16_serves(int M, int N, int K) {
   return gemm_split16_enabled() && M >= 128 && N >= 128 && K >= 64 && !((M | N | K) & 3);

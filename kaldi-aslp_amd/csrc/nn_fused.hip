@@ -523,8 +523,7 @@ __global__ void __launch_bounds__(kPanelThreads) bn_forward_stats_kernel(const f
                                                                         float *__restrict__ mean, float *__restrict__ inv_std,
                                                                         double *__restrict__ acc_means, double *__restrict__ acc_vars, float inv_rows,
                                                                         float floor_, int rows, float *__restrict__ act, int lda, int Q,
-                                                                        const double *__restrict__ part, int groups, int ldp, S16Out po,
-                                                                        float *__restrict__ giv_parts) {
+                                                                        const double *__restrict__ part, int groups, int ldp, S16Out po) {
   constexpr int CG = kCoopCG, L = kCoopLanes, COLS = kCoopCols, SL = kPanelThreads / COLS;  // SL partial-sum slices per column
   __shared__ double red[3][SL][COLS];
   __shared__ float stat[2][COLS];
@@ -570,12 +569,6 @@ __global__ void __launch_bounds__(kPanelThreads) bn_forward_stats_kernel(const f
     stat[1][pc] = is;
   }
   __syncthreads();
-  // the largest |scale / sigma| of this panel: with the largest |out-diff| it bounds the in-diff the backward pass will write (bn_backward_coop)
-  if (giv_parts != nullptr && q == 0 && threadIdx.x < 64) {   // (wave 0, uniform)
-    const float v = threadIdx.x < COLS ? fabsf(scale[p * COLS + threadIdx.x] * stat[1][threadIdx.x]) : 0.f;
-    const float mx = wave_max(v < 3.0e38f ? v : 0.f);
-    if (threadIdx.x == 0) giv_parts[p] = mx;
-  }
   const float4 g = *reinterpret_cast<const float4 *>(scale + c), b = *reinterpret_cast<const float4 *>(shift + c);
   const float4 m = *reinterpret_cast<const float4 *>(&stat[0][cg * 4]), is = *reinterpret_cast<const float4 *>(&stat[1][cg * 4]);
 #pragma unroll
@@ -601,7 +594,6 @@ __global__ void __launch_bounds__(kPanelThreads) bn_forward_stats_kernel(const f
 }
 
 // what bn_backward_coop needs to bound its in-diff before it has written it (see there)
-struct BnDiffBound { const float *giv_parts; int n_giv; const float *od_parts; int n_od; };
 template <int SLOTS, bool HAS_Y, bool RECOMPUTE>
 __global__ void __launch_bounds__(kPanelThreads) bn_backward_coop(const float *__restrict__ dy, int ldd, float *__restrict__ xhat, int ldx,
                                                            float *__restrict__ scale, float *__restrict__ shift,
@@ -609,11 +601,10 @@ __global__ void __launch_bounds__(kPanelThreads) bn_backward_coop(const float *_
                                                            float *__restrict__ dshift, float mmt, float neg_lr, bool step,
                                                            float *__restrict__ in_diff, int ldi, int rows, const float *__restrict__ y, int ldy,
                                                            const float *__restrict__ xin, int ldxin, const float *__restrict__ mean, int Q,
-                                                           unsigned long long *inbox, unsigned *err, float *__restrict__ max_parts, S16Out po, BnDiffBound bb) {
+                                                           unsigned long long *inbox, unsigned *err, float *__restrict__ max_parts) {
   constexpr int CG = kCoopCG, L = kCoopLanes;
   __shared__ float red[kPanelWaves * CG * 8];
   __shared__ float stat[3][4 * CG];  // S1, S2, the scale the forward pass used
-  __shared__ float bred[2 * kPanelWaves];
   const int P = gridDim.x / Q, p = blockIdx.x % P, q = blockIdx.x / P;
   const int rp = (rows + Q - 1) / Q, r0 = q * rp, r1 = min(rows, r0 + rp);
   const int cg = threadIdx.x % CG, lane = threadIdx.x / CG;
@@ -645,26 +636,6 @@ __global__ void __launch_bounds__(kPanelThreads) bn_backward_coop(const float *_
         d[k].z = d[k].z * yy.z * (1.0f - yy.z); d[k].w = d[k].w * yy.w * (1.0f - yy.w);
       }
     }
-  }
-  // (po) the in-diff's fp16 planes from this launch: in_diff = g / sigma (d - x_hat mean(x_hat d) - mean(d)) with |x_hat| <= sqrt(rows) and
-  // mean |x_hat| <= 1, so |in_diff| <= max |g / sigma| max |d| (2 + sqrt(rows)); max |g / sigma| from the forward launch's per-panel maxima
-  // (the scale is only rewritten at the end of THIS launch, by other workgroups), max |d| from the maxima the launch that wrote the
-  // out-diff left (a folded Sigmoid's derivative is at most 1/4).  Every workgroup forms the same bits; workgroup 0 stores them.
-  float pscale = 0.f;
-  if (po.hi != nullptr) {   // uniform
-    float gm = 0.f, em = 0.f;
-    for (int i = threadIdx.x; i < bb.n_giv; i += kPanelThreads) gm = fmaxf(gm, bb.giv_parts[i]);
-    for (int i = threadIdx.x; i < bb.n_od; i += kPanelThreads) em = fmaxf(em, bb.od_parts[i]);
-    gm = wave_max(gm);
-    em = wave_max(em);
-    if ((threadIdx.x & 63) == 0) { bred[2 * (threadIdx.x >> 6)] = gm; bred[2 * (threadIdx.x >> 6) + 1] = em; }
-    __syncthreads();
-    gm = bred[0]; em = bred[1];
-#pragma unroll
-    for (int w = 1; w < kPanelWaves; w++) { gm = fmaxf(gm, bred[2 * w]); em = fmaxf(em, bred[2 * w + 1]); }
-    const float bound = gm * (HAS_Y ? 0.25f * em : em) * (2.0f + sqrtf((float)rows)) * 1.001f;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *const_cast<unsigned *>(po.slot) = __float_as_uint(bound);
-    pscale = ldexpf(1.f, s16_exponent(__float_as_uint(bound)));
   }
   float acc[2][4] = {};
 #pragma unroll
@@ -729,12 +700,6 @@ __global__ void __launch_bounds__(kPanelThreads) bn_backward_coop(const float *_
       }
       if (!RECOMPUTE) *reinterpret_cast<float4 *>(xhat + (long)r * ldx + c) = make_float4(Dv[0], Dv[1], Dv[2], Dv[3]);
       *reinterpret_cast<float4 *>(in_diff + (long)r * ldi + c) = make_float4(ov[0], ov[1], ov[2], ov[3]);
-      if (po.hi != nullptr) {   // uniform
-        half4 hi, lo;
-        s16_split4(make_float4(ov[0], ov[1], ov[2], ov[3]), pscale, &hi, &lo);
-        *reinterpret_cast<half4 *>(po.hi + (long)r * po.ld + c) = hi;
-        *reinterpret_cast<half4 *>(po.lo + (long)r * po.ld + c) = lo;
-      }
       omax = s16_absmax4(omax, make_float4(ov[0], ov[1], ov[2], ov[3]));
     }
     if (max_parts != nullptr) {   // this workgroup's largest |in_diff|: the conversion of in_diff takes its scale from these (split16.h)
@@ -802,6 +767,47 @@ inline PanelShape bn_panel_shape(int rows, int cols) {
 
 // ---- Xent ------------------------------------------------------------------------------
 constexpr int kXentPerThread = 32;  // cols <= 8192 cached in registers
+
+// stats[0..4] += {frames, correct, -xent, -entropy, likelihood} summed over the rows in a fixed order (thread t: rows t, t + 256, ...; the
+// 64 lanes of a wave; the four waves), by one workgroup of 256 threads.  coherent: the rows were written by other workgroups of the SAME launch
+// (device-scope loads; unused by the shipped callers).  Four rows' loads are in flight at a time.
+__device__ __forceinline__ void xent_sum_rows(const double *rowstats, int rows, double *stats, bool coherent) {
+  __shared__ double sh_sum[4][5];
+  double a[5] = {0, 0, 0, 0, 0};
+  for (int r0 = threadIdx.x; r0 < rows; r0 += 4 * 256) {
+    double v[4][5];
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+      for (int k = 0; k < 5; k++) {
+        const int r = r0 + u * 256;
+        const double *p = rowstats + (long)(r < rows ? r : r0) * 5 + k;
+        const double x = coherent ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+        v[u][k] = r < rows ? x : 0.0;
+      }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (r0 + u * 256 < rows) {   // (adding the 0.0 of a missing row would turn a -0.0 sum into +0.0)
+#pragma unroll
+        for (int k = 0; k < 5; k++) a[k] += v[u][k];
+      }
+  }
+#pragma unroll
+  for (int k = 0; k < 5; k++) a[k] = wave_sum_d(a[k]);
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int k = 0; k < 5; k++) sh_sum[threadIdx.x >> 6][k] = a[k];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s[5];
+    for (int k = 0; k < 5; k++) s[k] = sh_sum[0][k] + sh_sum[1][k] + sh_sum[2][k] + sh_sum[3][k];
+    stats[0] += s[0];
+    stats[1] += s[1];
+    stats[2] += -s[2];
+    stats[3] += -s[3];
+    stats[4] += s[4];
+  }
+}
 
 // One block (256 threads) per row.  rowstats[r][0..4] = {w, correct*w, w*sum t log(y+1e-20),
 // w*sum t log(t+1e-20), w*sum t y} as double; summed in fixed order by xent_finalize.
@@ -932,128 +938,6 @@ __global__ void __launch_bounds__(256) xent_rows_kernel(const float *y, int ldy,
   }
 }
 
-// The same arithmetic with ONE WAVE per row and no workgroup barrier: lane l plays the four threads l, l + 64, l + 128, l + 192 of the
-// kernel above (the same columns tid + 256 k each, the same per-thread partial results), reduces each of the four "waves" with the same
-// butterfly and combines the four results in the same order -- bit for bit the kernel above, but a row no longer pays six barriers and
-// four waves' worth of latency for 12 KB of data.  Four rows per workgroup.  (Measured: not faster, see the launch code; ASLP_XENT_WAVE=1.)
-template <bool DENSE, bool SOFTMAX, int PER>
-__global__ void __launch_bounds__(256) xent_rows_wave_kernel(const float *y, int ldy, const float *t, int ldt, const int32_t *labels, const float *fw,
-                                                             float *diff, int ldd, int rows, int cols, double *rowstats, float *y_out, int ldyo) {
-  const int lane = threadIdx.x & 63;
-  for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += gridDim.x * 4) {
-    const float *yr = y + (long)r * ldy;
-    const float *tr = DENSE ? t + (long)r * ldt : nullptr;
-    const int label = DENSE ? -1 : labels[r];
-    float yv[4][PER];
-#pragma unroll
-    for (int w = 0; w < 4; w++)
-#pragma unroll
-      for (int k = 0; k < PER; k++) {
-        const int c = 64 * w + lane + k * 256;
-        yv[w][k] = c < cols ? yr[c] : 0.0f;
-      }
-    if (SOFTMAX) {
-      float m = -INFINITY;
-#pragma unroll
-      for (int w = 0; w < 4; w++)
-#pragma unroll
-        for (int k = 0; k < PER; k++)
-          if (64 * w + lane + k * 256 < cols) m = fmaxf(m, yv[w][k]);
-      m = wave_max(m);   // (a maximum does not depend on the order)
-      float sw[4];
-#pragma unroll
-      for (int w = 0; w < 4; w++) {
-        float sum = 0.0f;
-#pragma unroll
-        for (int k = 0; k < PER; k++)
-          if (64 * w + lane + k * 256 < cols) {
-            yv[w][k] = expf(yv[w][k] - m);
-            sum += yv[w][k];
-          }
-        sw[w] = wave_sum(sum);
-      }
-      float sum = sw[0];
-      sum += sw[1]; sum += sw[2]; sum += sw[3];
-      const float inv = 1.0f / sum;
-#pragma unroll
-      for (int w = 0; w < 4; w++)
-#pragma unroll
-        for (int k = 0; k < PER; k++) {
-          const int c = 64 * w + lane + k * 256;
-          if (c < cols) {
-            yv[w][k] *= inv;
-            if (y_out) y_out[(long)r * ldyo + c] = yv[w][k];
-          }
-        }
-    }
-    float tsw[4], ybw[4], tbw[4];
-    int yiw[4], tiw[4];
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-      float tsum = 0.0f, ybest = -1e21f, tbest = -1e21f;
-      int yi = -1, ti = -1;
-#pragma unroll
-      for (int k = 0; k < PER; k++) {
-        const int c = 64 * w + lane + k * 256;
-        if (c < cols) {
-          const float tt = DENSE ? tr[c] : (c == label ? 1.0f : 0.0f);
-          tsum += tt;
-          if (ybest < yv[w][k]) { ybest = yv[w][k]; yi = c; }
-          if (tbest < tt) { tbest = tt; ti = c; }
-        }
-      }
-      tsum = wave_sum(tsum);
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        float ov = __shfl_xor(ybest, o, 64); int oi = __shfl_xor(yi, o, 64);
-        if (ov > ybest || (ov == ybest && oi >= 0 && (yi < 0 || oi < yi))) { ybest = ov; yi = oi; }
-        ov = __shfl_xor(tbest, o, 64); oi = __shfl_xor(ti, o, 64);
-        if (ov > tbest || (ov == tbest && oi >= 0 && (ti < 0 || oi < ti))) { tbest = ov; ti = oi; }
-      }
-      // (what lane 0 of that wave held: the butterfly leaves the same value in every lane for the sum; for the arg-max the workgroup kernel
-      //  takes lane 0's)
-      tsw[w] = tsum;
-      ybw[w] = __shfl(ybest, 0, 64); yiw[w] = __shfl(yi, 0, 64); tbw[w] = __shfl(tbest, 0, 64); tiw[w] = __shfl(ti, 0, 64);
-    }
-    const float tsum = tsw[0] + tsw[1] + tsw[2] + tsw[3];
-    float ybest = ybw[0], tbest = tbw[0];
-    int yi = yiw[0], ti = tiw[0];
-#pragma unroll
-    for (int j = 1; j < 4; j++) {
-      if (ybw[j] > ybest || (ybw[j] == ybest && yiw[j] >= 0 && (yi < 0 || yiw[j] < yi))) { ybest = ybw[j]; yi = yiw[j]; }
-      if (tbw[j] > tbest || (tbw[j] == tbest && tiw[j] >= 0 && (ti < 0 || tiw[j] < ti))) { tbest = tbw[j]; ti = tiw[j]; }
-    }
-    const float wr = fw[r] * tsum;
-    double xw[4], ew[4], lw[4];
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-      double xe = 0.0, en = 0.0, lk = 0.0;
-#pragma unroll
-      for (int k = 0; k < PER; k++) {
-        const int c = 64 * w + lane + k * 256;
-        if (c < cols) {
-          const float yy = yv[w][k], tt = DENSE ? tr[c] : (c == label ? 1.0f : 0.0f);
-          diff[(long)r * ldd + c] = (yy - tt) * wr;
-          if (tt != 0.0f) {
-            xe += (double)(logf(yy + 1e-20f) * tt * wr);
-            en += (double)(logf(tt + 1e-20f) * tt * wr);
-            lk += (double)(yy * tt * wr);
-          }
-        }
-      }
-      xw[w] = wave_sum_d(xe); ew[w] = wave_sum_d(en); lw[w] = wave_sum_d(lk);
-    }
-    if (lane == 0) {
-      double *rs = rowstats + (long)r * 5;
-      rs[0] = (double)wr;
-      rs[1] = (double)wr * (yi == ti ? 1.0 : 0.0);
-      rs[2] = xw[0] + xw[1] + xw[2] + xw[3];
-      rs[3] = ew[0] + ew[1] + ew[2] + ew[3];
-      rs[4] = lw[0] + lw[1] + lw[2] + lw[3];
-    }
-  }
-}
-
 // The same for rows of any width (more than 256 * kXentPerThread classes): nothing is cached in registers, the row is streamed twice
 // (targets: sum and both arg-maxes; then diff and the three sums).  Every thread visits the columns tid, tid + 256, ... in the same
 // order and the reductions are those of the kernel above, so the result does not depend on which of the two kernels served a row.
@@ -1121,28 +1005,7 @@ __global__ void __launch_bounds__(256) xent_rows_wide_kernel(const float *y, int
 }
 
 // stats[0..4] += {frames, correct, xent, entropy, likelihood}; fixed-order sum over rows
-__global__ void __launch_bounds__(256) xent_finalize_kernel(const double *rowstats, int rows, double *stats) {
-  __shared__ double sh[4][5];
-  double a[5] = {0, 0, 0, 0, 0};
-  for (int r = threadIdx.x; r < rows; r += 256)
-#pragma unroll
-    for (int k = 0; k < 5; k++) a[k] += rowstats[(long)r * 5 + k];
-#pragma unroll
-  for (int k = 0; k < 5; k++) a[k] = wave_sum_d(a[k]);
-  if ((threadIdx.x & 63) == 0)
-#pragma unroll
-    for (int k = 0; k < 5; k++) sh[threadIdx.x >> 6][k] = a[k];
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double s[5];
-    for (int k = 0; k < 5; k++) s[k] = sh[0][k] + sh[1][k] + sh[2][k] + sh[3][k];
-    stats[0] += s[0];
-    stats[1] += s[1];
-    stats[2] += -s[2];
-    stats[3] += -s[3];
-    stats[4] += s[4];
-  }
-}
+__global__ void __launch_bounds__(256) xent_finalize_kernel(const double *rowstats, int rows, double *stats) { xent_sum_rows(rowstats, rows, stats, false); }
 
 }  // namespace
 }  // namespace aslp
@@ -1201,11 +1064,11 @@ int aslp_bn_forward_stats(const float *in, MatrixDim d, float *out, int out_stri
                           float *inv_std, double *acc_means, double *acc_vars, float var_floor, float *act_out, int act_stride,
                           const double *colstats, int groups, int stats_ld) {
   return aslp_bn_forward_stats_p(in, d, out, out_stride, scale, shift, mean, inv_std, acc_means, acc_vars, var_floor, act_out, act_stride, colstats,
-                                 groups, stats_ld, nullptr, nullptr);
+                                 groups, stats_ld, nullptr);
 }
 int aslp_bn_forward_stats_p(const float *in, MatrixDim d, float *out, int out_stride, const float *scale, const float *shift, float *mean,
                             float *inv_std, double *acc_means, double *acc_vars, float var_floor, float *act_out, int act_stride,
-                            const double *colstats, int groups, int stats_ld, const aslp_planes_out *act_planes, float *giv_parts) {
+                            const double *colstats, int groups, int stats_ld, const aslp_planes_out *act_planes) {
   if (d.rows <= 0 || d.cols <= 0 || !colstats) return 0;
   if (!out && !act_out) { set_error("aslp_bn_forward_stats: no output"); return 0; }
   if (groups != (d.rows + 31) / 32 || stats_ld < d.cols) { set_error("aslp_bn_forward_stats: statistics layout does not match the matrix"); return 0; }
@@ -1223,7 +1086,7 @@ int aslp_bn_forward_stats_p(const float *in, MatrixDim d, float *out, int out_st
   if (act_planes && act_planes->hi && act_out && act_planes->slot && act_planes->ld >= d.cols)
     po = S16Out{static_cast<h16 *>(act_planes->hi), static_cast<h16 *>(act_planes->lo), act_planes->ld, act_planes->slot, nullptr};
   hipLaunchKernelGGL(bn_forward_stats_kernel, dim3(P * Q), dim3(kPanelThreads), 0, cur_stream(), in, d.stride, out, out_stride, scale, shift, mean,
-                     inv_std, acc_means, acc_vars, 1.0f / (float)d.rows, var_floor, d.rows, act_out, act_stride, Q, colstats, groups, stats_ld, po, giv_parts);
+                     inv_std, acc_means, acc_vars, 1.0f / (float)d.rows, var_floor, d.rows, act_out, act_stride, Q, colstats, groups, stats_ld, po);
   check_launch("bn_forward_stats");
   return 1;
 }
@@ -1259,21 +1122,10 @@ static void bn_backward_impl(MatrixDim d, const float *out_diff, int od_stride, 
     const dim3 grid((d.cols / kCoopCols) * cs.q), block(kPanelThreads);
     float *max_parts = (diff_out && diff_out->parts && in_diff && (int)grid.x <= kS16MaxParts) ? diff_out->parts : nullptr;
     if (max_parts) diff_out->nparts = (int)grid.x;
-    // the in-diff's planes from this launch, where the caller has the maxima that bound it (aslp_planes_out.bound_*)
-    S16Out po = {nullptr, nullptr, 0, nullptr, nullptr};
-    BnDiffBound bb = {nullptr, 0, nullptr, 0};
-    static const bool planes_off = [] { const char *e = getenv("ASLP_BN_DIFF_PLANES"); return !(e && e[0] == '1'); }();   // A/B switch: default off (measured slower, nnet-nnet.cpp)
-    if (!planes_off && diff_out && in_diff && diff_out->hi && diff_out->lo && diff_out->slot && diff_out->ld >= d.cols && diff_out->bound_a && diff_out->bound_b &&
-        diff_out->bound_na > 0 && diff_out->bound_nb > 0) {
-      po = S16Out{static_cast<h16 *>(diff_out->hi), static_cast<h16 *>(diff_out->lo), diff_out->ld, diff_out->slot, nullptr};
-      bb = BnDiffBound{diff_out->bound_a, diff_out->bound_na, diff_out->bound_b, diff_out->bound_nb};
-      max_parts = nullptr;
-      diff_out->nparts = -1;   // "the planes are written"
-    }
 #define ASLP_BN_BWD_CL(SLOTS, Y, RC)                                                                                                           \
     hipLaunchKernelGGL((bn_backward_coop<SLOTS, Y, RC>), grid, block, 0, cur_stream(), out_diff, od_stride, xhat, xhat_stride, scale, shift, inv_std, \
                        dscale, dshift, momentum, -learn_rate, step, in_diff, id_stride, d.rows, act_y, act_stride, in, d.stride, mean, cs.q, st.inbox, st.err, \
-                       max_parts, po, bb)
+                       max_parts)
 #define ASLP_BN_BWD_COOP(SLOTS)                                                                      \
     case SLOTS:                                                                                      \
       if (act_y) { if (recompute) ASLP_BN_BWD_CL(SLOTS, true, true); else ASLP_BN_BWD_CL(SLOTS, true, false); }     \
@@ -1369,28 +1221,16 @@ static bool xent_eval_impl(const float *net_out, MatrixDim d, const float *tgt, 
   // elements cached per thread: the smallest of 4 / 8 / 16 / 32 that covers the row (the loops are fully unrolled: a row of
   // 3000 classes runs 16 slots per thread instead of 32 predicated ones)
   const int per = (d.cols + 255) / 256;
-  // enough rows for a wave each to fill the chip: the barrier-free kernel (4 rows per workgroup; same bits, see above)
-  // A/B switch, default off: measured on cfg2 (1024 x 3000, Softmax folded in) the barrier-free kernel is 1 % SLOWER on the step (776 / 777 k
-  // against 782 / 785 k frames/s, two alternations): a lane now walks 47 exponentials in a row where the workgroup kernel's thread walks 12
-  static const bool wave_on = getenv("ASLP_XENT_WAVE") != nullptr && getenv("ASLP_XENT_WAVE")[0] == '1';
-  const bool wave_rows = wave_on && d.rows >= 512 && per <= 16;
-  if (diff_planes && diff_planes->hi && diff_planes->slot && !tgt && !wave_rows && diff_planes->ld >= d.cols) {   // the row kernel, label targets
+  if (diff_planes && diff_planes->hi && diff_planes->slot && !tgt && diff_planes->ld >= d.cols) {   // the row kernel, label targets
     po = S16Out{static_cast<h16 *>(diff_planes->hi), static_cast<h16 *>(diff_planes->lo), diff_planes->ld, diff_planes->slot, nullptr};
     planes_written = true;
   }
-  const int gw = (d.rows + 3) / 4;
-#define XENT_LAUNCH_W(DENSE, SM, P)                                                                                                         \
-  hipLaunchKernelGGL((xent_rows_wave_kernel<DENSE, SM, P>), dim3(gw), dim3(256), 0, cur_stream(), net_out, d.stride, tgt, tgt_stride, labels, \
-                     frame_weights, diff, diff_stride, d.rows, d.cols, rowstats, y_out, y_stride)
 #define XENT_LAUNCH_P(DENSE, SM, P)                                                                                                       \
   hipLaunchKernelGGL((xent_rows_kernel<DENSE, SM, P>), dim3(g), dim3(256), 0, cur_stream(), net_out, d.stride, tgt, tgt_stride, labels, \
                      frame_weights, diff, diff_stride, d.rows, d.cols, rowstats, y_out, y_stride, po)
 #define XENT_LAUNCH(DENSE, SM)                                        \
   do {                                                                \
-    if (wave_rows && per <= 4) XENT_LAUNCH_W(DENSE, SM, 4);           \
-    else if (wave_rows && per <= 8) XENT_LAUNCH_W(DENSE, SM, 8);      \
-    else if (wave_rows) XENT_LAUNCH_W(DENSE, SM, 16);                 \
-    else if (per <= 4) XENT_LAUNCH_P(DENSE, SM, 4);                   \
+    if (per <= 4) XENT_LAUNCH_P(DENSE, SM, 4);                        \
     else if (per <= 8) XENT_LAUNCH_P(DENSE, SM, 8);                   \
     else if (per <= 16) XENT_LAUNCH_P(DENSE, SM, 16);                 \
     else XENT_LAUNCH_P(DENSE, SM, 32);                                \
@@ -1399,7 +1239,8 @@ static bool xent_eval_impl(const float *net_out, MatrixDim d, const float *tgt, 
   else { if (softmax) XENT_LAUNCH(false, true); else XENT_LAUNCH(false, false); }
 #undef XENT_LAUNCH
 #undef XENT_LAUNCH_P
-#undef XENT_LAUNCH_W
+  // (folding this sum into the rows' launch behind a ticket was measured: 54 us instead of 14 -- the device-scope release in front of the
+  //  ticket makes every one of the 1024 workgroups write the L2 back, 12 MB of diff included)
   hipLaunchKernelGGL(xent_finalize_kernel, dim3(1), dim3(256), 0, cur_stream(), rowstats, d.rows, stats_dev);
   check_launch("xent_eval");
   return planes_written;

@@ -100,8 +100,6 @@ struct SeqStatus {
   unsigned epoch;              // launch counter (28 bits, never 0): tags the placement table entries of this launch
   unsigned wave_collect;       // LSTM forward.  bit 0: every wave collects the K slice of m(t-1) it multiplies itself (no workgroup barrier behind the
                                // collection); bit 1: operand reads pinned four fragments ahead of the products
-  unsigned half_map;           // half-chain kernels: which workgroup indices are taken to share a CU (see chain_role4)
-  unsigned half_delay;         // half-chain kernels: the second chain of a CU starts this many 10 ns ticks late (see chain_role4)
 };
 __device__ __forceinline__ long tick(const SeqStatus &st) { return st.timing ? (long)wall_clock64() : 0; }
 // The phase accumulators live in LDS while the kernel runs (a fire-and-forget ds_add per mark): accumulating in global memory put an L2
@@ -1337,749 +1335,6 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd_h(aslp_lstm_seq a, SeqStatus
   if (polls && lane == 0) __hip_atomic_fetch_add(st.abort_flag + 2, polls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// ---- half chains: 4 streams per chain, 256-thread workgroups, TWO per CU --------------------------------------------------------
-// A timestep of the kernels above is a serial chain on every CU: collect (L2 round trip) -> product -> barrier -> gate block -> publish;
-// the MFMA pipe works for a third of it.  Here a chain has 4 streams instead of 8 and a workgroup 4 waves instead of 8, so TWO
-// workgroups -- of two different, independent chains -- live on every CU (one wave of each per SIMD, 2 x ~200 VGPRs): while one
-// chain's workgroup waits for its hand-off or finishes its gate block, the other one's product has the matrix pipe.  The hardware's
-// own wave scheduling does the overlap; there is no new synchronisation.  A wave's K slice doubles (4 waves split K), the weights
-// are again resident in registers (the two workgroups of a CU hold the same 64 gate columns, of the same direction, twice).
-//   v_mfma_f32_4x4x1_16b_f32: all 16 blocks share the A operand (lane l & 3 = stream), block l >> 2 = 4 gate columns -> one
-//   instruction = the chain's 4 streams x all 64 gate columns of the workgroup (column = lane).
-// Workgroup b: XCD x = b & 7 (observed dispatch: round-robin), index i = b >> 3 in [0, 2 wpc): chains x and x + 8 share the XCD.
-// Which i land on the same CU is the dispatcher's business: st.half_map = 0 pairs (chain x, block i >> 1) with (chain x + 8, block
-// i >> 1) as neighbours i, i ^ 1; half_map = 1 as i, i + wpc.  Either way the results are the same; only the overlap differs.
-constexpr int kHalfStreams = 4;
-constexpr int kMaxChains4 = 16;
-
-__device__ __forceinline__ ChainRole chain_role4(int S, int ndir, int C, const SeqStatus &st, unsigned *place, int *lds_flag, int *chain_out, int *cb_out) {
-  ChainRole r;
-  const int wpc = (C + kCellsPerWg - 1) / kCellsPerWg;
-  const int x = blockIdx.x & 7, i = blockIdx.x >> 3;
-  const bool two = (int)gridDim.x > 8 * wpc;   // 16 chains' worth of workgroups launched
-  const int hi = !two ? 0 : (st.half_map ? i / wpc : (i & 1)), cb = !two ? i : (st.half_map ? i % wpc : (i >> 1));
-  const int chain = x + 8 * hi;
-  const int nsg = (S + kHalfStreams - 1) / kHalfStreams, nchains = ndir * nsg;
-  *chain_out = chain; *cb_out = cb;
-  r.active = chain < nchains;
-  r.dir = r.active ? chain % ndir : 0;
-  r.s0 = (r.active ? chain / ndir : 0) * kHalfStreams;
-  r.c0 = cb * kCellsPerWg;
-  r.local = false;
-  if (!r.active) return r;
-  if (threadIdx.x < 64) {  // wave 0
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    xcc = (xcc & 15u) | (st.epoch << 4);
-    unsigned *row = place + chain * kMaxWgPerChain;
-    if (threadIdx.x == 0) __hip_atomic_store(row + cb, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int l = threadIdx.x;
-    unsigned v = xcc;
-    long t0 = 0;
-    bool ok = true;
-    for (unsigned spins = 0;; spins++) {
-      if (l < wpc) v = __hip_atomic_load(row + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (!__any(l < wpc && (v >> 4) != st.epoch)) break;
-      if (!spin_ok(spins, t0, st)) { ok = false; break; }
-      __builtin_amdgcn_s_sleep(4);
-    }
-    const bool same = __all(l >= wpc || v == xcc);
-    if (threadIdx.x == 0) *lds_flag = !ok ? -1 : (same ? 1 : 0);
-  }
-  __syncthreads();
-  const int f = *lds_flag;
-  if (f < 0) r.active = false;
-  r.local = f == 1;
-  // Two chains that start together stay in lock-step: both collect, both multiply (sharing the matrix pipe), both finish their gate
-  // blocks at the same time, and nothing overlaps.  The second chain of every CU therefore starts a fraction of a timestep late;
-  // the two chains have the same period, so the offset persists and one's product falls into the other's hand-off / gate block.
-  if (two && hi == 1 && st.half_delay != 0u && r.active) {
-    const long t0 = (long)wall_clock64();
-    while ((long)wall_clock64() - t0 < (long)st.half_delay) __builtin_amdgcn_s_sleep(2);
-  }
-  return r;
-}
-
-// forward.  grid (8 or 16) * ceil(C / 16) workgroups of 256 threads.  KW: K values per wave (C <= 4 * KW).
-template <bool CIFG, int KW, bool FAST>
-__global__ void __launch_bounds__(256, 2) lstm_seq_fwd4(aslp_lstm_seq a, SeqStatus st, unsigned *place) {
-  constexpr int G = CIFG ? 3 : 4, NS = kHalfStreams, KMAX = 4 * KW, MP = KMAX + 4, RP = 80;
-  __shared__ __attribute__((aligned(16))) float m_lds[NS][MP];
-  __shared__ float red[2][4][NS][RP];
-  __shared__ int fail[2][4];
-  __shared__ int place_flag;
-  const long t_entry = (st.timing || st.trace) ? (long)wall_clock64() : 0;
-  timing_begin(st);
-  const int SE = a.s_count > 0 ? a.s_begin + a.s_count : a.S;
-  // m_lds starts as zeros and is only ever written where k < C (or k < k_first): the product reads whole rows with immediate offsets,
-  // positions past C (whose B fragments are zero) included          (chain_role4's barrier publishes the zeros)
-  for (int i = threadIdx.x; i < NS * MP; i += 256) (&m_lds[0][0])[i] = 0.f;
-  int chain, me;
-  const ChainRole R = chain_role4(SE - a.s_begin, a.ndir, a.C, st, place, &place_flag, &chain, &me);
-  if (st.trace && threadIdx.x == 0) {   // diagnostics: where this workgroup runs (XCC id, HW_ID) and whom it serves
-    unsigned xcc, hw;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    st.trace[8 * 2048u + blockIdx.x] = ((unsigned long long)(xcc & 15u) << 48) | ((unsigned long long)(hw & 0xFFFFu) << 32) | ((unsigned)chain << 8) | (unsigned)me;
-  }
-  if (!R.active) return;
-  const aslp_lstm_seq_dir D = a.dir[R.dir];
-  const int C = a.C, S = a.S, T = a.T, ld = a.ld;
-  const int GC = G * C, oc = GC, oh = GC + C, om = GC + 2 * C;
-  const int c0 = R.c0, s0 = a.s_begin + R.s0;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int jl = lane & 3;
-  const int kw = ((C + 15) / 16) * 4, kb = wave * kw;   // this wave's K range [kb, kb + kw), a multiple of 4 long
-  // B fragments, resident for the launch: this lane's tile column n = lane: gate n >> 4, cell c0 + (n & 15)
-  const int gate_n = lane >> 4, cell_n = c0 + (lane & 15);
-  const bool nvalid = gate_n < G && cell_n < C;
-  f32x4 bw[KW / 4];
-  {
-    const float *brow = D.w + (long)(nvalid ? gate_n * C + cell_n : 0) * a.ldw;
-#pragma unroll
-    for (int i = 0; i < KW / 4; i++) {
-      const int k0 = kb + 4 * i;
-      bw[i] = (nvalid && 4 * i < kw && k0 < C) ? *reinterpret_cast<const f32x4 *>(brow + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-  }
-  const bool first_in_kernel = D.w_first != nullptr && D.k_first > 0 && D.k_first <= kFirstK && D.k_first <= KMAX;
-  // collection role (wave-local): the 4 streams' pieces of this wave's own K slice, lanes take pieces lane and lane + 64 of [stream][kw / 4]
-  const int c4 = C >> 2, kq_w = kw >> 2, npw = NS * kq_w;
-  const int p0 = lane, p1 = lane + 64;
-  int st0 = p0 / kq_w, kq0 = (kb >> 2) + p0 % kq_w, st1 = p1 / kq_w, kq1 = (kb >> 2) + p1 % kq_w;
-  const bool h0 = p0 < npw && kq0 < c4, h1 = p1 < npw && kq1 < c4;
-  if (!h0) { st0 = 0; kq0 = 0; }
-  if (!h1) { st1 = 0; kq1 = 0; }
-  const int off0 = (min(s0 + st0, SE - 1) * ld + om + 4 * kq0) * 4, off1 = (min(s0 + st1, SE - 1) * ld + om + 4 * kq1) * 4;
-  // gate-block role: a quad of lanes owns one (stream, cell) pair, lane r of the quad its gate r (as lstm_seq_fwd)
-  const int pair = threadIdx.x >> 2, role = threadIdx.x & 3;
-  const int sl = pair >> 4, cc = pair & 15, s = s0 + sl, cell = c0 + cc;
-  const bool live = s < SE && cell < C;
-  const int cq = live ? cell : 0, sq = live ? s : 0;
-  float pw = 0.f;
-  if (!CIFG) pw = role == 1 ? D.peep_i[cq] : role == 2 ? D.peep_f[cq] : role == 3 ? D.peep_o[cq] : 0.f;
-  else pw = role == 1 ? D.peep_f[cq] : role == 2 ? D.peep_o[cq] : 0.f;
-  const int slen = (D.seq_lengths && live) ? D.seq_lengths[sq] : 0x7fffffff;
-  float cprev = 0.f;
-  {
-    const int tp0 = D.reverse ? T + 1 : 0;
-    if (live) cprev = D.y[((long)tp0 * S + sq) * ld + oc + cq];
-  }
-  unsigned polls = 0u;
-  // diagnostics (timing mode 3): workgroup 0 and the workgroup taken to share its CU log four absolute clocks per timestep
-  const int wpc_ = (C + kCellsPerWg - 1) / kCellsPerWg;
-  const int log_slot = !st.trace ? -1 : (blockIdx.x == 0 ? 0 : ((int)blockIdx.x == (st.half_map ? 8 * wpc_ : 8) ? 1 : -1));
-  unsigned long long *plog = log_slot >= 0 ? st.trace + 8 * 2048u + 1024u + log_slot * 256 : nullptr;
-  for (int step = 0; step < T; step++) {
-    const int t = D.reverse ? T - step : 1 + step, tp = D.reverse ? t + 1 : t - 1;
-    const int par = step & 1;
-    float *ys = D.y + ((long)t * S + sq) * ld;
-    long tm = tick(st);
-    const float xr = (live && role < G) ? ys[role * C + cq] : 0.f;
-    // EIGHT independent accumulators: one wave per SIMD multiplies at a time (the other workgroup's wave is in another phase), and a
-    // 4x4x1 product returns its accumulator after ~64 cycles -- four chains ran at 18 cycles per instruction, half the pipe's rate
-    f32x4 acc[8];
-#pragma unroll
-    for (int q = 0; q < 8; q++) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bool ok = true;
-    const bool first_special = step == 0 && first_in_kernel;
-    const bool product = !first_special && !(step == 0 && D.skip_first_product);
-    if (first_special) {   // r(0) of the chain's streams -> LDS (the history row block: stored before the launch, no hand-off)
-      const int kq = D.k_first >> 2;
-      for (int p = threadIdx.x; p < NS * kq; p += 256) {
-        const int sp = p / kq, k0 = 4 * (p % kq);
-        *reinterpret_cast<f32x4 *>(&m_lds[sp][k0]) =
-            *reinterpret_cast<const f32x4 *>(D.y + ((long)tp * S + min(s0 + sp, SE - 1)) * ld + D.col_first + k0);
-      }
-    }
-    if (product) {
-      const __amdgpu_buffer_rsrc_t rs = make_rsrc(D.y + (long)tp * S * ld);
-      u32x4 v0 = {0u, 0u, 0u, 0u}, v1 = {0u, 0u, 0u, 0u};
-      long t0 = 0;
-      for (unsigned spins = 0;; spins++) {
-        if (h0) v0 = __builtin_amdgcn_raw_buffer_load_b128(rs, off0, 0, kAuxSc1);
-        if (h1) v1 = __builtin_amdgcn_raw_buffer_load_b128(rs, off1, 0, kAuxSc1);
-        if (!__any((h0 && has_sentinel(v0)) || (h1 && has_sentinel(v1)))) break;
-        asm volatile("" ::: "memory");
-        polls++;
-        if (!spin_ok(spins, t0, st)) { ok = false; break; }
-        __builtin_amdgcn_s_sleep(1);
-      }
-      if (h0) *reinterpret_cast<u32x4 *>(&m_lds[st0][4 * kq0]) = v0;
-      if (h1) *reinterpret_cast<u32x4 *>(&m_lds[st1][4 * kq1]) = v1;
-    }
-    tock(st, 1, tm);  // collection
-    if (plog && threadIdx.x == 0 && step < 64) plog[4 * step + 0] = wall_clock64();
-    if (lane == 0) fail[par][wave] = ok ? 0 : 1;
-    if (first_special) __syncthreads();   // (uniform) every wave reads what all waves staged
-    else __builtin_amdgcn_wave_barrier();  // a wave reads back only what it stored itself
-    tock(st, 3, tm);
-    if (product) {
-      const float *arow = &m_lds[jl][kb];   // fragment i at a compile-time offset from here (past the wave's slice / past C: zeros or finite values x a zero B fragment)
-      constexpr int NF = KW / 4, PD = NF < 4 ? NF : 4;
-      f32x4 av[NF];
-#pragma unroll
-      for (int i = 0; i < PD; i++) av[i] = *reinterpret_cast<const f32x4 *>(arow + 4 * i);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < NF; i++) {
-        if (i + PD < NF) av[i + PD] = *reinterpret_cast<const f32x4 *>(arow + 4 * (i + PD));
-        __builtin_amdgcn_sched_barrier(0);
-        constexpr int b = 0;
-        acc[4 * (i & 1) + 0 + b] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i].x, bw[i].x, acc[4 * (i & 1) + 0 + b], 0, 0, 0);
-        acc[4 * (i & 1) + 1 + b] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i].y, bw[i].y, acc[4 * (i & 1) + 1 + b], 0, 0, 0);
-        acc[4 * (i & 1) + 2 + b] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i].z, bw[i].z, acc[4 * (i & 1) + 2 + b], 0, 0, 0);
-        acc[4 * (i & 1) + 3 + b] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i].w, bw[i].w, acc[4 * (i & 1) + 3 + b], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    if (first_special) {   // r(0) W_first^T: left operand from LDS, this lane's row of W_first straight from memory (one step per launch)
-      const int kwf = ((D.k_first + 15) / 16) * 4, kbf = wave * kwf;
-      const float *arow = &m_lds[jl][0];
-      const float *brow = D.w_first + (long)(nvalid ? gate_n * C + cell_n : 0) * D.ldw_first;
-      for (int k0 = kbf; k0 < min(kbf + kwf, D.k_first); k0 += 4) {
-        const f32x4 av = *reinterpret_cast<const f32x4 *>(arow + k0);
-        const f32x4 b = nvalid ? *reinterpret_cast<const f32x4 *>(brow + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
-        acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.x, b.x, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.y, b.y, acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.z, b.z, acc[2], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.w, b.w, acc[3], 0, 0, 0);
-      }
-    }
-    {   // result register r of a lane = stream r of tile column `lane`
-      const f32x4 sum = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
-      float *rp = &red[par][wave][0][lane];
-      rp[0 * RP] = sum.x; rp[1 * RP] = sum.y; rp[2 * RP] = sum.z; rp[3 * RP] = sum.w;
-    }
-    tock(st, 2, tm);  // product
-    if (plog && threadIdx.x == 0 && step < 64) plog[4 * step + 1] = wall_clock64();
-    __syncthreads();
-    tock(st, 4, tm);
-    if (plog && threadIdx.x == 0 && step < 64) plog[4 * step + 2] = wall_clock64();
-    if (fail[par][0] | fail[par][1] | fail[par][2] | fail[par][3]) return;  // uniform
-    float pre = 0.f;
-    if (role < G) {
-      pre = red[par][0][sl][role * 16 + cc];
-#pragma unroll
-      for (int w = 1; w < 4; w++) pre += red[par][w][sl][role * 16 + cc];
-    }
-    const bool masked = t > slen;
-    float gate = 0.f;
-    if (role == 0) gate = act_tanh<FAST>(xr + pre);
-    else if (role < G - 1) gate = act_sigmoid<FAST>(xr + pre + cprev * pw);
-    const float gg = quad_bcast<0>(gate), g1 = quad_bcast<1>(gate), g2 = quad_bcast<2>(gate);
-    float cellv;
-    if (!CIFG) cellv = gg * g1 + cprev * g2;
-    else cellv = -gg * g1 + gg + cprev * g1;
-    cellv = fminf(fmaxf(cellv, -50.0f), 50.0f);
-    float hh = 0.f;
-    if (role == 0) hh = act_tanh<FAST>(cellv);
-    if (role == G - 1) gate = act_sigmoid<FAST>(xr + pre + cellv * pw);
-    const float oo = quad_bcast<G - 1>(gate);
-    float mm = hh * oo;
-    if (masked) { gate = 0.f; cellv = 0.f; hh = 0.f; mm = 0.f; }
-    {
-      const float m1 = row_up<4>(mm), m2 = row_up<8>(mm), m3 = row_up<12>(mm);
-      if (live && role == 0 && (cc & 3) == 0) {
-        u32x4 pk = {__float_as_uint(mm), __float_as_uint(m1), __float_as_uint(m2), __float_as_uint(m3)};
-        const __amdgpu_buffer_rsrc_t rs = make_rsrc(D.y + (long)t * S * ld);
-        const int off = (s * ld + om + cell) * 4;
-        if (R.local) __builtin_amdgcn_raw_buffer_store_b128(pk, rs, off, 0, 0);
-        else __builtin_amdgcn_raw_buffer_store_b128(pk, rs, off, 0, kAuxSc1);
-      }
-    }
-    if (live) {
-      if (role < G) ys[role * C + cell] = gate;
-      if (role == 0) ys[oh + cell] = hh;
-      if (role == 1) ys[oc + cell] = cellv;
-    }
-    cprev = cellv;
-    tock(st, 5, tm);  // epilogue
-    if (plog && threadIdx.x == 0 && step < 64) plog[4 * step + 3] = wall_clock64();
-  }
-  if (st.timing && blockIdx.x == 0 && threadIdx.x == 0) {
-    timing_flush(st); st.timing[0] += (unsigned long long)T; st.timing[6] += R.local ? 1ull : 0ull;
-    st.timing[7] += (unsigned long long)((long)wall_clock64() - t_entry);
-  }
-  if (st.trace && threadIdx.x == 0) {
-    unsigned long long *tr = st.trace + (st.epoch & 7u) * 2048u;
-    tr[2 * blockIdx.x] = (unsigned long long)t_entry; tr[2 * blockIdx.x + 1] = wall_clock64();
-  }
-  if (polls && lane == 0) __hip_atomic_fetch_add(st.abort_flag + 2, polls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// ---- wave-specialised forward: two half-chains alternating inside ONE workgroup -----------------------------------------------
-// The timestep of lstm_seq_fwd is a serial path -- hand-off (L2 round trip) -> product -> barrier -> gate block -> publish -- of which the
-// matrix pipe works a third.  Here the chain's 8 streams are two halves A and B of 4 streams, and the workgroup's 8 waves have two ROLES:
-//   waves 0-3 ("product"): own the weights (the workgroup's 64 gate columns x K / 4 each, resident in registers as in lstm_seq_fwd4),
-//                          collect m(t-1) of the half whose turn it is and multiply -- A, B, A, B, ... one half per half-step;
-//   waves 4-7 ("gates"):   own c(t-1) of both halves; finish the gate block of the half multiplied in the PREVIOUS half-step and publish
-//                          its m(t) while the product waves are busy with the other half.
-// One workgroup barrier per half-step hands the partial sums (LDS) from the product waves to the gate waves.  For one half the path
-// product -> gates -> publish -> (L2) -> collect closes after two half-steps, during which the matrix pipe serves both halves and the
-// gate waves both gate blocks: a half-step is (path length) / 2 instead of the whole path per 8 streams.
-//   half-step h:   product waves  P_X(h >> 1), X = h & 1        gate waves  G_X'((h - 1) >> 1), X' = (h - 1) & 1        [2 T + 1 half-steps]
-// Chains, placement, hand-off through the buffers ("the data is its own flag") and the bounded spins are lstm_seq_fwd's.
-template <bool CIFG, int KW, bool FAST>
-__global__ void __launch_bounds__(512) lstm_seq_fwd_dual(aslp_lstm_seq a, SeqStatus st, unsigned *place) {
-  constexpr int G = CIFG ? 3 : 4, NS = 4, KMAX = 4 * KW, MP = KMAX + 4, RP = 80;
-  __shared__ __attribute__((aligned(16))) float m_lds[2][NS][MP];   // [half][stream][k]: the left operand of that half's product
-  __shared__ float red[2][4][NS][RP];                                // [half][product wave][stream][tile column]
-  __shared__ int fail[2][8];
-  __shared__ int place_flag;
-  const long t_entry = (st.timing || st.trace) ? (long)wall_clock64() : 0;
-  timing_begin(st);
-  const int SE = a.s_count > 0 ? a.s_begin + a.s_count : a.S;
-  for (int i = threadIdx.x; i < 2 * NS * MP; i += 512) (&m_lds[0][0][0])[i] = 0.f;   // read past C with zero B fragments: must be finite
-  const ChainRole R = chain_role(SE - a.s_begin, a.ndir, a.C, st, place, &place_flag);   // (its barrier publishes the zeros)
-  if (!R.active) return;
-  const aslp_lstm_seq_dir D = a.dir[R.dir];
-  const int C = a.C, S = a.S, T = a.T, ld = a.ld;
-  const int GC = G * C, oc = GC, oh = GC + C, om = GC + 2 * C;
-  const int c0 = R.c0, s0 = a.s_begin + R.s0;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const bool product_role = wave < 4;
-  const int pw_ = wave & 3;   // index within the role
-  const int jl = lane & 3;
-  // ---- product role state
-  const int kw = ((C + 15) / 16) * 4, kb = pw_ * kw;
-  const int gate_n = lane >> 4, cell_n = c0 + (lane & 15);
-  const bool nvalid = gate_n < G && cell_n < C;
-  f32x4 bw[KW / 4];
-  if (product_role) {
-    const float *brow = D.w + (long)(nvalid ? gate_n * C + cell_n : 0) * a.ldw;
-#pragma unroll
-    for (int i = 0; i < KW / 4; i++) {
-      const int k0 = kb + 4 * i;
-      bw[i] = (nvalid && 4 * i < kw && k0 < C) ? *reinterpret_cast<const f32x4 *>(brow + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < KW / 4; i++) bw[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  const bool first_in_kernel = D.w_first != nullptr && D.k_first > 0 && D.k_first <= kFirstK && D.k_first <= KMAX;
-  // collection (gate role): the 4 streams' rows of a half, [stream][C / 4] pieces of 16 bytes, threads take pieces g, g + 256, ...
-  const int c4 = C >> 2, npiece = NS * c4;
-  // ---- gate role state: thread g = threadIdx.x - 256; a quad of lanes owns one (stream, cell) pair of EACH half, lane r of the quad its gate r
-  const int g_ = threadIdx.x & 255;
-  const int pair = g_ >> 2, role = g_ & 3;
-  const int sl = pair >> 4, cc = pair & 15, cell = c0 + cc;
-  float pw = 0.f, cprev[2] = {0.f, 0.f};
-  int slen[2] = {0x7fffffff, 0x7fffffff};
-  bool live[2] = {false, false};
-  if (!product_role) {
-    const int cq = cell < C ? cell : 0;
-    if (!CIFG) pw = role == 1 ? D.peep_i[cq] : role == 2 ? D.peep_f[cq] : role == 3 ? D.peep_o[cq] : 0.f;
-    else pw = role == 1 ? D.peep_f[cq] : role == 2 ? D.peep_o[cq] : 0.f;
-    const int tp0 = D.reverse ? T + 1 : 0;
-#pragma unroll
-    for (int X = 0; X < 2; X++) {
-      const int s = s0 + 4 * X + sl;
-      live[X] = s < SE && cell < C;
-      if (live[X]) {
-        cprev[X] = D.y[((long)tp0 * S + s) * ld + oc + cell];
-        if (D.seq_lengths) slen[X] = D.seq_lengths[s];
-      }
-    }
-  }
-  unsigned polls = 0u;
-  if (!first_in_kernel && !D.skip_first_product) {   // the first product multiplies the history row block: stored before the launch, no hand-off
-    const int tp0 = D.reverse ? T + 1 : 0;
-    for (int p = threadIdx.x; p < 2 * npiece; p += 512) {
-      const int X = p / npiece, q = p - X * npiece, sp = q / c4, kq = q - sp * c4;
-      *reinterpret_cast<f32x4 *>(&m_lds[X][sp][4 * kq]) =
-          *reinterpret_cast<const f32x4 *>(D.y + ((long)tp0 * S + min(s0 + 4 * X + sp, SE - 1)) * ld + om + 4 * kq);
-    }
-  }
-  __syncthreads();
-  for (int h = 0; h <= 2 * T; h++) {
-    const int par = h & 1;
-    bool ok = true;
-    long tm = tick(st);
-    if (product_role) {
-      const int X = h & 1, step = h >> 1;
-      if (step < T) {
-        const int t = D.reverse ? T - step : 1 + step, tp = D.reverse ? t + 1 : t - 1;
-        const int sh = s0 + 4 * X;   // first stream of this half
-        f32x4 acc[8];
-#pragma unroll
-        for (int q = 0; q < 8; q++) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const bool first_special = step == 0 && first_in_kernel;
-        const bool product = !first_special && !(step == 0 && D.skip_first_product);
-        if (first_special) {   // r(0) W_first^T: this wave's K slice of r(0) -> its rows of m_lds (nobody else reads them), B straight from memory
-          const int kwf = ((D.k_first + 15) / 16) * 4, kbf = pw_ * kwf, kqf = kwf >> 2;
-          for (int p = lane; p < NS * kqf; p += 64) {
-            const int sp = p / kqf, k0 = kbf + 4 * (p % kqf);
-            if (k0 < D.k_first)
-              *reinterpret_cast<f32x4 *>(&m_lds[X][sp][k0]) =
-                  *reinterpret_cast<const f32x4 *>(D.y + ((long)tp * S + min(sh + sp, SE - 1)) * ld + D.col_first + k0);
-          }
-          __builtin_amdgcn_wave_barrier();
-          const float *arow = &m_lds[X][jl][0];
-          const float *brow = D.w_first + (long)(nvalid ? gate_n * C + cell_n : 0) * D.ldw_first;
-          // the B fragments of this wave's slice come in groups of four requested together (one round trip per group, not one per fragment;
-          // all sixteen at once would not fit beside the resident weights)
-          constexpr int NFF = kFirstK / 16;
-          for (int i0 = 0; i0 < NFF; i0 += 4) {   // (not unrolled: one step per launch)
-            f32x4 bf[4], af[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-              const int k0 = kbf + 4 * (i0 + j);
-              const bool in = 4 * (i0 + j) < kwf && k0 < D.k_first;
-              bf[j] = (nvalid && in) ? *reinterpret_cast<const f32x4 *>(brow + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
-              af[j] = in ? *reinterpret_cast<const f32x4 *>(arow + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-              acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(af[j].x, bf[j].x, acc[0], 0, 0, 0);
-              acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(af[j].y, bf[j].y, acc[1], 0, 0, 0);
-              acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(af[j].z, bf[j].z, acc[2], 0, 0, 0);
-              acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(af[j].w, bf[j].w, acc[3], 0, 0, 0);
-            }
-          }
-          // r(0) sits where m(t) of the later steps goes: positions of this wave's rows past C (k_first > C) would otherwise keep it
-          __builtin_amdgcn_wave_barrier();
-          for (int p = lane; p < NS * kqf; p += 64) {
-            const int sp = p / kqf, k0 = kbf + 4 * (p % kqf);
-            if (k0 < D.k_first) *reinterpret_cast<f32x4 *>(&m_lds[X][sp][k0]) = f32x4{0.f, 0.f, 0.f, 0.f};
-          }
-        }
-        if (product) {   // m(t-1) of this half is in LDS: the gate waves collected it behind their previous publication (or the prologue did)
-          const float *arow = &m_lds[X][jl][kb];
-          __builtin_amdgcn_s_setprio(2);   // the gate wave on this SIMD yields issue slots to the product
-          constexpr int NF = KW / 4, PD = NF < 4 ? NF : 4;
-          f32x4 av[NF];
-#pragma unroll
-          for (int i = 0; i < PD; i++) av[i] = *reinterpret_cast<const f32x4 *>(arow + 4 * i);
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int i = 0; i < NF; i++) {
-            if (i + PD < NF) av[i + PD] = *reinterpret_cast<const f32x4 *>(arow + 4 * (i + PD));
-            __builtin_amdgcn_sched_barrier(0);
-            acc[4 * (i & 1) + 0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i].x, bw[i].x, acc[4 * (i & 1) + 0], 0, 0, 0);
-            acc[4 * (i & 1) + 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i].y, bw[i].y, acc[4 * (i & 1) + 1], 0, 0, 0);
-            acc[4 * (i & 1) + 2] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i].z, bw[i].z, acc[4 * (i & 1) + 2], 0, 0, 0);
-            acc[4 * (i & 1) + 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[i].w, bw[i].w, acc[4 * (i & 1) + 3], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-          __builtin_amdgcn_s_setprio(0);
-        }
-        {   // result register r of a lane = stream r of tile column `lane`
-          const f32x4 sum = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
-          float *rp = &red[X][pw_][0][lane];
-          rp[0 * RP] = sum.x; rp[1 * RP] = sum.y; rp[2 * RP] = sum.z; rp[3 * RP] = sum.w;
-        }
-        tock(st, 2, tm);  // product
-      }
-    } else if (h >= 1) {
-      const int X = (h - 1) & 1, step = (h - 1) >> 1;   // the half multiplied in the previous half-step (step < T always: h - 1 <= 2 T - 1)
-      const int t = D.reverse ? T - step : 1 + step;
-      const int s = s0 + 4 * X + sl;
-      const bool lv = live[X];
-      const int cq = lv ? cell : 0, sq = lv ? s : 0;
-      float *ys = D.y + ((long)t * S + sq) * ld;
-      const float xr = (lv && role < G) ? ys[role * C + cq] : 0.f;
-      float pre = 0.f;
-      if (role < G) {
-        pre = red[X][0][sl][role * 16 + cc];
-#pragma unroll
-        for (int w = 1; w < 4; w++) pre += red[X][w][sl][role * 16 + cc];
-      }
-      const float cp = cprev[X];
-      const bool masked = t > slen[X];
-      float gate = 0.f;
-      if (role == 0) gate = act_tanh<FAST>(xr + pre);
-      else if (role < G - 1) gate = act_sigmoid<FAST>(xr + pre + cp * pw);
-      const float gg = quad_bcast<0>(gate), g1 = quad_bcast<1>(gate), g2 = quad_bcast<2>(gate);
-      float cellv;
-      if (!CIFG) cellv = gg * g1 + cp * g2;
-      else cellv = -gg * g1 + gg + cp * g1;
-      cellv = fminf(fmaxf(cellv, -50.0f), 50.0f);
-      float hh = 0.f;
-      if (role == 0) hh = act_tanh<FAST>(cellv);
-      if (role == G - 1) gate = act_sigmoid<FAST>(xr + pre + cellv * pw);
-      const float oo = quad_bcast<G - 1>(gate);
-      float mm = hh * oo;
-      if (masked) { gate = 0.f; cellv = 0.f; hh = 0.f; mm = 0.f; }
-      {
-        const float m1 = row_up<4>(mm), m2 = row_up<8>(mm), m3 = row_up<12>(mm);
-        if (lv && role == 0 && (cc & 3) == 0) {
-          u32x4 pk = {__float_as_uint(mm), __float_as_uint(m1), __float_as_uint(m2), __float_as_uint(m3)};
-          const __amdgpu_buffer_rsrc_t rs = make_rsrc(D.y + (long)t * S * ld);
-          const int off = (s * ld + om + cell) * 4;
-          if (R.local) __builtin_amdgcn_raw_buffer_store_b128(pk, rs, off, 0, 0);
-          else __builtin_amdgcn_raw_buffer_store_b128(pk, rs, off, 0, kAuxSc1);
-        }
-      }
-      tock_gate(st, 3, tm);   // gate role: reduce + gate block up to the publication of m(t)
-      if (lv) {
-        if (role < G) ys[role * C + cell] = gate;
-        if (role == 0) ys[oh + cell] = hh;
-        if (role == 1) ys[oc + cell] = cellv;
-      }
-      cprev[X] = cellv;
-      tock_gate(st, 5, tm);   // gate role: the stores behind the publication
-      // m(t) of this half from the chain's other workgroups -> LDS, for the product waves' next turn at this half (half-step h + 1).  They
-      // published it about when this workgroup did; the product waves are busy with the other half meanwhile.
-      if (step + 1 < T) {
-        const __amdgpu_buffer_rsrc_t rs = make_rsrc(D.y + (long)t * S * ld);
-        const int sh = s0 + 4 * X;
-        constexpr int NP = (NS * KMAX / 4 + 255) / 256;   // pieces per thread
-        int off[NP], dst[NP];
-        bool have[NP];
-#pragma unroll
-        for (int j = 0; j < NP; j++) {
-          const int p = g_ + 256 * j;
-          have[j] = p < npiece;
-          const int sp = have[j] ? p / c4 : 0, kq = have[j] ? p % c4 : 0;
-          off[j] = (min(sh + sp, SE - 1) * ld + om + 4 * kq) * 4;
-          dst[j] = sp * MP + 4 * kq;
-        }
-        u32x4 v[NP];
-#pragma unroll
-        for (int j = 0; j < NP; j++) v[j] = u32x4{0u, 0u, 0u, 0u};
-        long t0 = 0;
-        for (unsigned spins = 0;; spins++) {
-          bool missing = false;
-#pragma unroll
-          for (int j = 0; j < NP; j++)
-            if (have[j]) v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[j], 0, kAuxSc1);
-#pragma unroll
-          for (int j = 0; j < NP; j++) missing = missing || (have[j] && has_sentinel(v[j]));
-          if (!__any(missing)) break;
-          asm volatile("" ::: "memory");
-          polls++;
-          if (!spin_ok(spins, t0, st)) { ok = false; break; }
-          __builtin_amdgcn_s_sleep(1);
-        }
-#pragma unroll
-        for (int j = 0; j < NP; j++)
-          if (have[j]) *reinterpret_cast<u32x4 *>(&m_lds[X][0][0] + dst[j]) = v[j];
-        tock_gate(st, 1, tm);   // gate role: collection of the next left operand
-      }
-    }
-    if (lane == 0) fail[par][wave] = ok ? 0 : 1;
-    __syncthreads();
-    if (product_role) tock(st, 4, tm);   // product waves: what is left of the half-step after their product (waiting for the gate waves, or nothing)
-    {
-      int f = 0;
-#pragma unroll
-      for (int w = 0; w < 8; w++) f |= fail[par][w];
-      if (f) return;  // uniform
-    }
-  }
-  if (st.timing && blockIdx.x == 0 && threadIdx.x == 0) {
-    timing_flush(st); st.timing[0] += (unsigned long long)T; st.timing[6] += R.local ? 1ull : 0ull;
-    st.timing[7] += (unsigned long long)((long)wall_clock64() - t_entry);
-  }
-  if (st.trace && threadIdx.x == 0) {
-    unsigned long long *tr = st.trace + (st.epoch & 7u) * 2048u;
-    tr[2 * blockIdx.x] = (unsigned long long)t_entry; tr[2 * blockIdx.x + 1] = wall_clock64();
-  }
-  if (polls && lane == 0) __hip_atomic_fetch_add(st.abort_flag + 2, polls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// backward, partitioned by input like lstm_seq_bwd.  One instruction = the chain's 4 streams x 64 cells (column = lane); wave w covers
-// the cell spans w * NH + h, h < NH (C <= 256 * NH).
-//   inbox[ring slot][chain 16][consumer block][producer block][column 0..15] of f32x4 (the 4 streams)
-template <bool CIFG, int NH>
-__global__ void __launch_bounds__(256, 2) lstm_seq_bwd4(aslp_lstm_seq a, SeqStatus st, unsigned *place, float *inbox) {
-  constexpr int G = CIFG ? 3 : 4, KS = 4 * G, NS = kHalfStreams;
-  __shared__ __attribute__((aligned(16))) float own_dg[2][NS][16 * G + 4];
-  __shared__ __attribute__((aligned(16))) float shares[kMaxWgPerChain * 16 * 4];   // [producer][column][stream]
-  __shared__ int fail[2][4];
-  __shared__ int place_flag;
-  const long t_entry = st.trace ? (long)wall_clock64() : 0;
-  timing_begin(st);
-  const int SE = a.s_count > 0 ? a.s_begin + a.s_count : a.S;
-  int chain, me;
-  const ChainRole R = chain_role4(SE - a.s_begin, a.ndir, a.C, st, place, &place_flag, &chain, &me);
-  if (!R.active) return;
-  const aslp_lstm_seq_dir D = a.dir[R.dir];
-  const int C = a.C, S = a.S, T = a.T, ld = a.ld;
-  const int GC = G * C, oc = GC, oh = GC + C, om = GC + 2 * C;
-  const int og = 0, oi = C, of = CIFG ? C : 2 * C, oo = CIFG ? 2 * C : 3 * C;
-  const int c0 = R.c0, s0 = a.s_begin + R.s0;
-  const int wpc = (C + kCellsPerWg - 1) / kCellsPerWg;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int jl = lane & 3;
-  float bw[NH][KS * 4];
-#pragma unroll
-  for (int h = 0; h < NH; h++) {
-    const int col = 64 * (wave * NH + h) + lane;
-    const bool colok = col < C;
-#pragma unroll
-    for (int kk = 0; kk < KS * 4; kk++) {
-      const int cellk = c0 + (kk & 15);
-      bw[h][kk] = (colok && cellk < C) ? D.w[(long)((kk >> 4) * C + cellk) * a.ldw + col] : 0.f;
-    }
-  }
-  const size_t slot_words = (size_t)kMaxChains4 * kMaxWgPerChain * kMaxWgPerChain * 64;  // floats per ring slot
-  float *chain_box = inbox + (size_t)chain * kMaxWgPerChain * kMaxWgPerChain * 64;
-  const int npiece = wpc * 16;  // 16-byte pieces addressed to this workgroup per timestep: [producer][column]
-  const int sl = threadIdx.x >> 4, cc = threadIdx.x & 15, s = s0 + sl, cell = c0 + cc;
-  const bool live = threadIdx.x < 64 && s < SE && cell < C;
-  const int cq = live ? cell : 0, sq = live ? s : 0;
-  const float pf = D.peep_f[cq], po = D.peep_o[cq], pi = CIFG ? 0.f : D.peep_i[cq];
-  float dn_c = 0.f, dn_f = 0.f, dn_i = 0.f;
-  float gsum[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  unsigned polls = 0u;
-  for (int step = 0; step < T; step++) {
-    const int t = D.reverse ? 1 + step : T - step;
-    const int tn = D.reverse ? t - 1 : t + 1, tp = D.reverse ? t + 1 : t - 1;
-    const int par = step & 1;
-    const long o_ = ((long)t * S + sq) * ld;
-    long tm = tick(st);
-    float dm = 0.f, yo = 0.f, yh = 0.f, yg = 0.f, yf = 0.f, yi = 0.f, yn_f = 0.f, cprev = 0.f, ccur = 0.f;
-    if (live) {
-      dm = D.d[o_ + om + cq];
-      yo = D.y[o_ + oo + cq]; yh = D.y[o_ + oh + cq]; yg = D.y[o_ + og + cq]; yf = D.y[o_ + of + cq];
-      if (!CIFG) yi = D.y[o_ + oi + cq];
-      yn_f = D.y[((long)tn * S + sq) * ld + of + cq];
-      cprev = D.y[((long)tp * S + sq) * ld + oc + cq];
-      if (a.grad_partial) ccur = D.y[o_ + oc + cq];
-    }
-    bool ok = true;
-    if (step > 0) {
-      float *box = chain_box + (size_t)(step % kRing) * slot_words;
-      {
-        f32x4 av[KS];
-        const float *arow = &own_dg[par ^ 1][jl][0];
-        constexpr int PD = KS < 4 ? KS : 4;
-#pragma unroll
-        for (int q = 0; q < PD; q++) av[q] = *reinterpret_cast<const f32x4 *>(arow + 4 * q);
-        f32x4 acc[NH][4];   // 4 NH independent chains per wave (one wave per SIMD multiplies at a time: see lstm_seq_fwd4)
-#pragma unroll
-        for (int h = 0; h < NH; h++)
-#pragma unroll
-          for (int c = 0; c < 4; c++) acc[h][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < KS; q++) {
-          if (q + PD < KS) av[q + PD] = *reinterpret_cast<const f32x4 *>(arow + 4 * (q + PD));
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int h = 0; h < NH; h++) acc[h][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[q].x, bw[h][4 * q + 0], acc[h][0], 0, 0, 0);
-#pragma unroll
-          for (int h = 0; h < NH; h++) acc[h][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[q].y, bw[h][4 * q + 1], acc[h][1], 0, 0, 0);
-#pragma unroll
-          for (int h = 0; h < NH; h++) acc[h][2] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[q].z, bw[h][4 * q + 2], acc[h][2], 0, 0, 0);
-#pragma unroll
-          for (int h = 0; h < NH; h++) acc[h][3] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[q].w, bw[h][4 * q + 3], acc[h][3], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        const __amdgpu_buffer_rsrc_t rs = make_rsrc(box);
-#pragma unroll
-        for (int h = 0; h < NH; h++) {
-          const int col = 64 * (wave * NH + h) + lane, cb = col >> 4;
-          if (cb < wpc) {
-            const f32x4 sum = (acc[h][0] + acc[h][1]) + (acc[h][2] + acc[h][3]);
-            const int off = ((cb * kMaxWgPerChain + me) * 16 + (lane & 15)) * 16;
-            const u32x4 pk = {__float_as_uint(sum.x), __float_as_uint(sum.y), __float_as_uint(sum.z), __float_as_uint(sum.w)};
-            if (R.local) __builtin_amdgcn_raw_buffer_store_b128(pk, rs, off, 0, 0);
-            else __builtin_amdgcn_raw_buffer_store_b128(pk, rs, off, 0, kAuxSc1);
-          }
-        }
-      }
-      tock(st, 1, tm);
-      {
-        const __amdgpu_buffer_rsrc_t rs = make_rsrc(box + (size_t)me * kMaxWgPerChain * 64);
-        const int i0 = threadIdx.x, i1 = threadIdx.x + 256;
-        const bool h0 = i0 < npiece, h1 = i1 < npiece;
-        u32x4 v0 = {0u, 0u, 0u, 0u}, v1 = {0u, 0u, 0u, 0u};
-        long t0 = 0;
-        for (unsigned spins = 0;; spins++) {
-          if (h0) v0 = __builtin_amdgcn_raw_buffer_load_b128(rs, i0 * 16, 0, kAuxSc1);
-          if (h1) v1 = __builtin_amdgcn_raw_buffer_load_b128(rs, i1 * 16, 0, kAuxSc1);
-          if (!__any((h0 && has_sentinel(v0)) || (h1 && has_sentinel(v1)))) break;
-          asm volatile("" ::: "memory");
-          polls++;
-          if (!spin_ok(spins, t0, st)) { ok = false; break; }
-          __builtin_amdgcn_s_sleep(1);
-        }
-        const u32x4 sent = {kSentinel, kSentinel, kSentinel, kSentinel};
-        if (R.local) {
-          if (h0) __builtin_amdgcn_raw_buffer_store_b128(sent, rs, i0 * 16, 0, 0);
-          if (h1) __builtin_amdgcn_raw_buffer_store_b128(sent, rs, i1 * 16, 0, 0);
-        } else {
-          if (h0) __builtin_amdgcn_raw_buffer_store_b128(sent, rs, i0 * 16, 0, kAuxSc1);
-          if (h1) __builtin_amdgcn_raw_buffer_store_b128(sent, rs, i1 * 16, 0, kAuxSc1);
-        }
-        if (h0) *reinterpret_cast<u32x4 *>(&shares[i0 * 4]) = v0;
-        if (h1) *reinterpret_cast<u32x4 *>(&shares[i1 * 4]) = v1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      tock(st, 2, tm);
-    }
-    if (lane == 0) fail[par][wave] = ok ? 0 : 1;
-    __syncthreads();
-    tock(st, 4, tm);
-    if (fail[par][0] | fail[par][1] | fail[par][2] | fail[par][3]) return;
-    if (threadIdx.x < 64) {
-      if (step > 0) {  // shares of my 16 cells, added in workgroup order
-        float psum = 0.f;
-        const int base = cc * 4 + sl;
-        for (int p = 0; p < wpc; p++) psum += shares[p * 64 + base];
-        dm += psum;
-      }
-      const float dh = dtanh(yh, dm * yo);
-      const float dov = dsigm(yo, dm * yh);
-      float dc = dh + dn_c * yn_f;
-      if (!CIFG) dc += dn_i * pi;
-      dc += dn_f * pf;
-      dc += dov * po;
-      float dg, df, di = 0.f;
-      if (!CIFG) {
-        df = dsigm(yf, dc * cprev);
-        di = dsigm(yi, dc * yg);
-        dg = dtanh(yg, dc * yi);
-      } else {
-        df = dsigm(yf, dc * cprev - dc * yg);
-        dg = dtanh(yg, dc - dc * yf);
-      }
-      float *mine = &own_dg[par][sl][cc];
-      mine[0] = dg;
-      if (!CIFG) { mine[16] = di; mine[32] = df; mine[48] = dov; }
-      else { mine[16] = df; mine[32] = dov; }
-      if (live) {
-        D.d[o_ + og + cell] = dg; D.d[o_ + of + cell] = df; D.d[o_ + oo + cell] = dov;
-        if (!CIFG) D.d[o_ + oi + cell] = di;
-        D.d[o_ + om + cell] = dm;
-        D.d[o_ + oh + cell] = dh;
-        D.d[o_ + oc + cell] = dc;
-      }
-      dn_c = dc; dn_f = df; dn_i = di;
-      if (a.grad_partial && live) {
-        gsum[0] += dg; gsum[2] += df; gsum[3] += dov;
-        gsum[5] += df * cprev; gsum[6] += dov * ccur;
-        if (!CIFG) { gsum[1] += di; gsum[4] += di * cprev; }
-      }
-    }
-    tock(st, 5, tm);
-    __syncthreads();
-  }
-  if (a.grad_partial) {   // the chain's 4 streams meet in LDS (stream order), one row of 16 cells per quantity goes out per workgroup
-    float *gl = shares;   // [stream 4][quantity 7][cell 16]
-    if (threadIdx.x < 64) {
-#pragma unroll
-      for (int k = 0; k < 7; k++) gl[(sl * 7 + k) * 16 + cc] = gsum[k];
-    }
-    __syncthreads();
-    if (threadIdx.x < 7 * 16) {
-      const int k = threadIdx.x >> 4, c = threadIdx.x & 15;
-      float v = gl[k * 16 + c];
-#pragma unroll
-      for (int q = 1; q < NS; q++) v += gl[(q * 7 + k) * 16 + c];
-      if (c0 + c < C) a.grad_partial[((long)chain * 7 + k) * a.grad_ld + c0 + c] = v;
-    }
-  }
-  if (st.timing && blockIdx.x == 0 && threadIdx.x == 0) { timing_flush(st); st.timing[0] += (unsigned long long)T; st.timing[6] += R.local ? 1ull : 0ull; }
-  if (st.trace && threadIdx.x == 0) {
-    unsigned long long *tr = st.trace + (st.epoch & 7u) * 2048u;
-    tr[2 * blockIdx.x] = (unsigned long long)t_entry; tr[2 * blockIdx.x + 1] = wall_clock64();
-  }
-  if (polls && lane == 0) __hip_atomic_fetch_add(st.abort_flag + 2, polls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 // ---- GruStreams (nnet-gru-streams.h:238-430): the same persistent scheme, two hand-offs per timestep ------------------------------
 // Buffer columns [z | r | m | g | h], H each.  In each direction of time a GRU step is two products that depend on each other:
@@ -2497,10 +1752,10 @@ SeqRuntime &seq_runtime() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return;
     rt.num_cu = prop.multiProcessorCount;
-    const size_t bytes = 64 + sizeof(unsigned) * kMaxChains4 * kMaxWgPerChain;
+    const size_t bytes = 64 + sizeof(unsigned) * 2 * kMaxChains * kMaxWgPerChain;
     if (hipMalloc(&rt.abort_flag, bytes) != hipSuccess || hipMemset(rt.abort_flag, 0, bytes) != hipSuccess) return;
     rt.place = rt.abort_flag + 16;
-    // 8 timing words, a ring of 8 launches x 2048 residency words, 1024 placement-census words (lstm_seq_fwd4)
+    // 8 timing words, a ring of 8 launches x 2048 residency words, 1024 placement-census words
     if (hipMalloc(&rt.timing, 64 + 8 * 18 * 1024) != hipSuccess || hipMemset(rt.timing, 0, 64 + 8 * 18 * 1024) != hipSuccess) return;   // + 1024 phase-log words
     if (hipMalloc(&rt.inbox, sizeof(float) * (size_t)kRing * kMaxChains * kMaxWgPerChain * kMaxWgPerChain * 128) != hipSuccess) return;
     if (hipHostMalloc(&rt.host_err, 64, hipHostMallocMapped) != hipSuccess) return;
@@ -2556,40 +1811,6 @@ SeqKernelB pick_bwd(bool cifg, int C) {
   return nullptr;
 }
 
-// wave-specialised forward (two half-chains alternating inside the workgroup): ASLP_LSTM_DUAL=1 (A/B switch, default off).  Measured on
-// cfg3 it is SLOWER than lstm_seq_fwd (3.21 / 3.40 ms per step against 3.10): a v_mfma_f32_4x4x1 is two passes, so a product wave takes
-// the SIMD's vector issue port every other slot and the gate wave beside it runs at half speed and vice versa -- product 0.8 us instead
-// of 0.5, gate block 0.97 instead of 0.5 -- and a half's path product -> gates -> publish -> L2 -> collect stays as long as before.
-bool dual_on() {
-  static const bool on = getenv("ASLP_LSTM_DUAL") != nullptr && getenv("ASLP_LSTM_DUAL")[0] == '1';
-  return on;
-}
-SeqKernel pick_fwd_dual(bool cifg, int C) {
-  if (fast_act()) {
-    if (C <= 128) return cifg ? lstm_seq_fwd_dual<true, 32, true> : lstm_seq_fwd_dual<false, 32, true>;
-    if (C <= 512) return cifg ? lstm_seq_fwd_dual<true, 128, true> : lstm_seq_fwd_dual<false, 128, true>;
-    return nullptr;
-  }
-  if (C <= 128) return cifg ? lstm_seq_fwd_dual<true, 32, false> : lstm_seq_fwd_dual<false, 32, false>;
-  if (C <= 512) return cifg ? lstm_seq_fwd_dual<true, 128, false> : lstm_seq_fwd_dual<false, 128, false>;
-  return nullptr;
-}
-SeqKernel pick_fwd4(bool cifg, int C) {
-  if (fast_act()) {
-    if (C <= 128) return cifg ? lstm_seq_fwd4<true, 32, true> : lstm_seq_fwd4<false, 32, true>;
-    if (C <= 512) return cifg ? lstm_seq_fwd4<true, 128, true> : lstm_seq_fwd4<false, 128, true>;
-    return nullptr;
-  }
-  if (C <= 128) return cifg ? lstm_seq_fwd4<true, 32, false> : lstm_seq_fwd4<false, 32, false>;
-  if (C <= 512) return cifg ? lstm_seq_fwd4<true, 128, false> : lstm_seq_fwd4<false, 128, false>;
-  return nullptr;
-}
-SeqKernelB pick_bwd4(bool cifg, int C) {
-  if (C <= 256) return cifg ? lstm_seq_bwd4<true, 1> : lstm_seq_bwd4<false, 1>;
-  if (C <= 512) return cifg ? lstm_seq_bwd4<true, 2> : lstm_seq_bwd4<false, 2>;
-  return nullptr;
-}
-
 typedef void (*GruKernel)(aslp_gru_seq, SeqStatus, unsigned *);
 GruKernel pick_gru(bool backward, int H) {
   if (H <= 128) return backward ? gru_seq_bwd<32, 16> : gru_seq_fwd<16>;
@@ -2627,25 +1848,9 @@ bool grid_fits(const void *k, int threads, long blocks) {
   if (occ < 1) return false;
   return blocks <= (long)rt.num_cu * (occ >= 2 ? occ - 1 : 1);
 }
-// The half-chain kernels want exactly two 256-thread workgroups per CU; at ~200 VGPRs the register file admits two and no third, which
-// is a limit the occupancy API reports exactly (its known over-report comes from the SGPR budget at many blocks per CU).
-bool grid_fits_half(const void *k, long blocks) {
-  SeqRuntime &rt = seq_runtime();
-  if (!rt.ok || !k) return false;
-  return cached_occupancy(k, 256) >= 2 && blocks <= (long)rt.num_cu * 2;
-}
-// Streams per chain a launch with these arguments uses: 4 (half chains, two workgroups per CU) where that scheme applies, else 8.
-int chain_streams_for(const aslp_lstm_seq *a, bool backward) {
-  // A/B switch, default off: measured on cfg3 the half chains are level with the chains of 8 (3.19 vs 3.16 ms per step) -- each chain's
-  // timestep is the same serial hand-off -> product -> gate-block path, and two of them on a CU take each other's LDS / VALU slots
-  static const bool half_on = getenv("ASLP_LSTM_HALF_CHAINS") != nullptr && getenv("ASLP_LSTM_HALF_CHAINS")[0] == '1';
-  if (!half_on || !a) return kChainStreams;
-  const int ns = a->s_count > 0 ? a->s_count : a->S;
-  const int nsg = (ns + kHalfStreams - 1) / kHalfStreams, wpc = (a->C + kCellsPerWg - 1) / kCellsPerWg, nchains = a->ndir * nsg;
-  if (nchains > kMaxChains4 || wpc > kMaxWgPerChain) return kChainStreams;
-  const void *k = backward ? reinterpret_cast<const void *>(pick_bwd4(a->cifg != 0, a->C)) : reinterpret_cast<const void *>(pick_fwd4(a->cifg != 0, a->C));
-  return grid_fits_half(k, (long)(nchains > 8 ? 16 : 8) * wpc) ? kHalfStreams : kChainStreams;
-}
+// Streams per chain a launch with these arguments uses (half chains of 4 streams, two workgroups per CU, were measured level with the chains
+// of 8 and are gone: DESIGN 4a)
+int chain_streams_for(const aslp_lstm_seq *, bool) { return kChainStreams; }
 
 }  // namespace
 }  // namespace aslp
@@ -2658,12 +1863,11 @@ int aslp_lstm_seq_supported(const aslp_lstm_seq *a, int backward) {
   static const bool disabled = getenv("ASLP_LSTM_PERSISTENT") != nullptr && getenv("ASLP_LSTM_PERSISTENT")[0] == '0';
   if (disabled || !seq_args_ok(a)) return 0;
   if (a->s_begin < 0 || a->s_count < 0 || a->s_begin + a->s_count > a->S) return 0;
-  if (chain_streams_for(a, backward != 0) == kHalfStreams) return 1;
   const int ns = a->s_count > 0 ? a->s_count : a->S;   // streams of this launch
   const int nsg = (ns + kChainStreams - 1) / kChainStreams, wpc = (a->C + kCellsPerWg - 1) / kCellsPerWg;
   if (a->ndir * nsg > kMaxChains || wpc > kMaxWgPerChain) return 0;   // <= 32 streams per launch (bidirectional) / 64, C <= 512
   const void *k = backward ? reinterpret_cast<const void *>(split_f16_on() ? pick_bwd_h(a->cifg != 0, a->C) : pick_bwd(a->cifg != 0, a->C))
-                           : reinterpret_cast<const void *>(dual_on() ? pick_fwd_dual(a->cifg != 0, a->C) : split_f16_on() ? pick_fwd_h(a->cifg != 0, a->C) : pick_fwd(a->cifg != 0, a->C));
+                           : reinterpret_cast<const void *>(split_f16_on() ? pick_fwd_h(a->cifg != 0, a->C) : pick_fwd(a->cifg != 0, a->C));
   return grid_fits(k, 512, (long)kMaxChains * wpc) ? 1 : 0;
 }
 
@@ -2720,7 +1924,7 @@ static void launch_seq(const aslp_lstm_seq *a, bool backward, const char *who) {
   // Device-side state is self-cleaning: the placement table is epoch-tagged and every share a backward launch publishes is
   // consumed and reset inside that launch.  Only after a launch that gave up (the mapped error word moved) are the abort
   // word and the share ring put back by hand.
-  const size_t slot_bytes = sizeof(float) * (size_t)kMaxChains * kMaxWgPerChain * kMaxWgPerChain * 128;   // = 16 chains x 64 floats (half chains)
+  const size_t slot_bytes = sizeof(float) * (size_t)kMaxChains * kMaxWgPerChain * kMaxWgPerChain * 128;
   if (*rt.host_err != rt.err_seen || !rt.ring_ready) {
     rt.err_seen = *rt.host_err;
     ASLP_CHECK_HIP(hipMemsetAsync(rt.abort_flag, 0, 4, cur_stream()));
@@ -2731,18 +1935,10 @@ static void launch_seq(const aslp_lstm_seq *a, bool backward, const char *who) {
   if (rt.epoch == 0u) rt.epoch = 1u;
   static const unsigned wave_collect = ((getenv("ASLP_LSTM_WAVE_COLLECT") != nullptr && getenv("ASLP_LSTM_WAVE_COLLECT")[0] == '0') ? 0u : 1u) |   // A/B switches
                                        ((getenv("ASLP_LSTM_READ_AHEAD") != nullptr && getenv("ASLP_LSTM_READ_AHEAD")[0] == '0') ? 0u : 2u);
-  static const unsigned half_map = (getenv("ASLP_LSTM_HALF_MAP") != nullptr && getenv("ASLP_LSTM_HALF_MAP")[0] == '0') ? 0u : 1u;
-  static const unsigned half_delay_ns = getenv("ASLP_LSTM_HALF_DELAY_NS") != nullptr ? (unsigned)atoi(getenv("ASLP_LSTM_HALF_DELAY_NS")) : 1200u;
   SeqStatus st = {rt.abort_flag, rt.host_err_dev, ((rt.timing_mode == 1 && !backward) || (rt.timing_mode == 2 && backward)) ? rt.timing : nullptr,
-                  ((rt.timing_mode == 3 && !backward) || (rt.timing_mode == 4 && backward)) ? rt.timing + 8 : nullptr, rt.epoch, wave_collect, half_map, half_delay_ns / 10u};
+                  ((rt.timing_mode == 3 && !backward) || (rt.timing_mode == 4 && backward)) ? rt.timing + 8 : nullptr, rt.epoch, wave_collect};
   const int wpc = (a->C + kCellsPerWg - 1) / kCellsPerWg;
-  if (chain_streams_for(a, backward) == kHalfStreams) {
-    const int ns = a->s_count > 0 ? a->s_count : a->S, nchains = a->ndir * ((ns + kHalfStreams - 1) / kHalfStreams);
-    const int grid = (nchains > 8 ? 16 : 8) * wpc;
-    if (!backward) hipLaunchKernelGGL(pick_fwd4(a->cifg != 0, a->C), dim3(grid), dim3(256), 0, cur_stream(), *a, st, rt.place);
-    else hipLaunchKernelGGL(pick_bwd4(a->cifg != 0, a->C), dim3(grid), dim3(256), 0, cur_stream(), *a, st, rt.place, rt.inbox);
-  } else if (!backward) hipLaunchKernelGGL(dual_on() ? pick_fwd_dual(a->cifg != 0, a->C) : split_f16_on() ? pick_fwd_h(a->cifg != 0, a->C) : pick_fwd(a->cifg != 0, a->C), dim3(kMaxChains * wpc), dim3(512), 0,
-                                           cur_stream(), *a, st, rt.place);
+  if (!backward) hipLaunchKernelGGL(split_f16_on() ? pick_fwd_h(a->cifg != 0, a->C) : pick_fwd(a->cifg != 0, a->C), dim3(kMaxChains * wpc), dim3(512), 0, cur_stream(), *a, st, rt.place);
   else {
     hipLaunchKernelGGL(split_f16_on() ? pick_bwd_h(a->cifg != 0, a->C) : pick_bwd(a->cifg != 0, a->C), dim3(kMaxChains * wpc), dim3(512), 0, cur_stream(), *a, st, rt.place, rt.inbox);
     // (only lstm_seq_bwd_h forms the per-workgroup maxima of the gate diffs, and only a single launch per pass leaves a complete set)
@@ -2781,7 +1977,7 @@ static void launch_gru(const aslp_gru_seq *a, bool backward, const char *who) {
   rt.epoch = (rt.epoch + 1u) & 0x0FFFFFFFu;
   if (rt.epoch == 0u) rt.epoch = 1u;
   SeqStatus st = {rt.abort_flag, rt.host_err_dev, nullptr, ((rt.timing_mode == 3 && !backward) || (rt.timing_mode == 4 && backward)) ? rt.timing + 8 : nullptr,
-                  rt.epoch, 0u, 0u, 0u};
+                  rt.epoch, 0u};
   const int wpc = (a->H + kCellsPerWg - 1) / kCellsPerWg;
   hipLaunchKernelGGL(pick_gru(backward, a->H), dim3(kMaxChains * wpc), dim3(512), 0, cur_stream(), *a, st, rt.place);
   if (!rt.last_done) (void)hipEventCreateWithFlags(&rt.last_done, hipEventDisableTiming);
@@ -2811,22 +2007,6 @@ void aslp_lstm_seq_residency(unsigned long long *out, int n, int launches_back) 
   if (!rt.ok || !out || n <= 0 || n > 1024 || launches_back < 0 || launches_back > 7) return;
   (void)hipStreamSynchronize(cur_stream());
   (void)hipMemcpy(out, rt.timing + 8 + ((rt.epoch - (unsigned)launches_back) & 7u) * 2048u, sizeof(unsigned long long) * 2 * n, hipMemcpyDeviceToHost);
-}
-// devtools: with aslp_lstm_seq_timing(3, NULL) in effect the half-chain forward kernel (lstm_seq_fwd4) also records where every workgroup
-// ran and whom it served: out[b] = XCC id << 48 | HW_ID[15:0] << 32 | chain << 8 | block within the chain, b < n <= 1024.  Synchronises.
-void aslp_lstm_seq_census(unsigned long long *out, int n) {
-  SeqRuntime &rt = seq_runtime();
-  if (!rt.ok || !out || n <= 0 || n > 1024) return;
-  (void)hipStreamSynchronize(cur_stream());
-  (void)hipMemcpy(out, rt.timing + 8 + 8 * 2048u, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost);
-}
-// devtools: after a traced half-chain forward launch (timing mode 3): out[slot * 256 + 4 * step + k], slot 0 = workgroup 0, slot 1 = the workgroup
-// taken to share its CU; k = clock (10 ns ticks) after collection / product / barrier / gate block of that timestep (step < 64)
-void aslp_lstm_seq_phase_log(unsigned long long *out) {
-  SeqRuntime &rt = seq_runtime();
-  if (!rt.ok || !out) return;
-  (void)hipStreamSynchronize(cur_stream());
-  (void)hipMemcpy(out, rt.timing + 8 + 8 * 2048u + 1024u, sizeof(unsigned long long) * 512, hipMemcpyDeviceToHost);
 }
 unsigned aslp_lstm_seq_polls(int reset) {
   SeqRuntime &rt = seq_runtime();

@@ -103,14 +103,6 @@ void *scratch(int slot, size_t bytes) {
   return blk;
 }
 
-void *scratch_zeroed(int slot, size_t bytes) {
-  const size_t before = t_arenas.cap[t_bank][slot];
-  void *p = scratch(slot, bytes);
-  if (p && t_arenas.cap[t_bank][slot] != before &&
-      hipMemsetAsync(p, 0, t_arenas.cap[t_bank][slot], cur_stream()) != hipSuccess) { set_error("scratch_zeroed: hipMemsetAsync failed"); return nullptr; }
-  return p;
-}
-
 // ---- side stream: fork / join by events, no host synchronisation --------------------------------------------
 static thread_local hipStream_t t_side = nullptr;
 static thread_local hipEvent_t t_fork_ev = nullptr, t_join_ev = nullptr;

@@ -2,13 +2,10 @@
 #pragma once
 #include <stddef.h>
 namespace aslp {
-enum { kScratchReduce = 0, kScratchReduce2 = 1, kScratchGemm = 2, kScratchCtc = 3, kScratchMisc = 4, kScratchSplitK = 5, kScratchSplit16 = 6, kScratchTickets = 7, kNumScratch = 8 };
+enum { kScratchReduce = 0, kScratchReduce2 = 1, kScratchGemm = 2, kScratchCtc = 3, kScratchMisc = 4, kScratchSplitK = 5, kScratchSplit16 = 6, kNumScratch = 7 };
 // Scratch of the calling thread's current stream: the side stream has its own bank, so ops running there never
 // share a partial-sum buffer with ops on the main stream.
 void *scratch(int slot, size_t bytes);
-// The same, for words that kernels hand from launch to launch (tickets, counters): the block is zero when it is (re)allocated, and every
-// kernel that uses it leaves it zero.  A slot is either used through this call or through scratch(), never both.
-void *scratch_zeroed(int slot, size_t bytes);
 
 // While alive, every launch of this thread goes to the library's side stream, ordered after everything issued on the
 // main stream so far (event wait, no host sync).  join_side_stream() makes the main stream wait for the side work

@@ -25,8 +25,7 @@ constexpr int kS16Pad = 64;         // both extents of the planes are multiples 
 constexpr int kS16MaxParts = 4096;  // maxima (one per workgroup) a producer may leave for one matrix
 constexpr int kS16ConvParts = 256;  // what the library's own maximum pass leaves
 
-// halves per plane row for a matrix of `cols` columns: cols rounded up to 64 (ASLP_S16_LD_PAD=<halves> adds that much where the row pitch
-// would be a multiple of 2 KB: an experiment against L2 channel hot-spotting that measured no difference)
+// halves per plane row for a matrix of `cols` columns: cols rounded up to 64
 int s16_plane_ld(int cols);
 
 // what a kernel needs of a pair of planes (by value in kernel arguments)

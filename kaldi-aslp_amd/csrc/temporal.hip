@@ -15,9 +15,9 @@
 // streams are summed in LDS, then one partial per (chunk, stream group); a small second launch adds them in a fixed order (no float
 // atomics) and takes the momentum + SGD step.
 //
-// CompactFsmn (one utterance, T x D of a few MB: launch-latency territory): tiles of 64 columns staged in LDS.  Forward: one launch.
-// Backward: ONE launch forms the in-diff (the reversed filter), the tap gradients of its frames, and -- in the workgroup that arrives
-// last at its column tile's ticket -- their fixed-order sum over the chunks, the clip and the SGD step.
+// CompactFsmn (one utterance, T x D of a few MB: launch-latency territory): tiles of 64 columns x 32 frames staged in LDS.  Forward: one
+// launch.  Backward: one launch forms the in-diff (the reversed filter) and the tap gradients of its frames, a small second one their
+// fixed-order sum over the chunks, the clip and the SGD step.
 //
 // Shapes outside what these serve (more than 32 taps in RowConvolution, odd widths, filters too long for the LDS tile) run on the
 // simpler kernels kept at the end of each section: lanes along the feature dimension, a register window over TT frames per thread,
@@ -500,17 +500,14 @@ constexpr int kFsmnTapsPerThread = 8;   // (= the ring length of ring_block8)
 // Backward of a tile of 64 columns x kFsmnFrames frames [ta, tb):
 //   in_diff[t] = od[t] + sum_j coef[C-1-j] od[t + j - F]                  (cfsmn.h:232-249)
 //   partial[chunk][i] = sum_{t in chunk} in[t + i - P] od[t]               (:213-219)
-// With finish_here (few chunks: short utterances) the workgroup that is the LAST of its column tile to get here (a ticket per tile) also
-// forms corr[i] = clip(sum over the chunks in chunk order) and, with lr != 0, coef[i] -= lr corr[i] (:258-262) -- every other workgroup of
-// the tile has read its taps by then; otherwise fsmn_grad_finish does that in a launch of its own, spread over the chip.
+// fsmn_grad_finish adds the chunks' partials in a launch of its own, spread over the chip.  (Adding them in the last workgroup of a column
+// tile to arrive, behind a ticket, was measured: the device-scope release in front of the ticket costs every workgroup an L2 write-back --
+// 48 us per launch with every wave fencing, 23 with one thread per workgroup, against 16 + 4.5 for the two launches.)
 // sm: [rows + kFsmnSpare][64] od rows ta - F ..., [rows + kFsmnSpare][64] in rows ta - P ... (rows = kFsmnFrames + C - 1), [C + kFsmnSpare][64] reversed taps.
 __global__ void __launch_bounds__(kBlock) fsmn_backward_fused(float *__restrict__ in_diff, int ldid, float *__restrict__ partial,
-                                                              unsigned *__restrict__ tickets, float *__restrict__ corr, int ldcc,
-                                                              float *__restrict__ coef, int ldc, const float *__restrict__ in, int ldi,
-                                                              const float *__restrict__ od, int ldod, int D, int C, int P, int F, int T, int nchunks,
-                                                              float clip, float lr, int finish_here) {
+                                                              const float *__restrict__ coef, int ldc, const float *__restrict__ in, int ldi,
+                                                              const float *__restrict__ od, int ldod, int D, int C, int P, int F, int T) {
   extern __shared__ float sm[];
-  __shared__ unsigned last_flag;
   const int x = threadIdx.x, y = threadIdx.y, d = blockIdx.x * kWave + x;
   const int chunk = blockIdx.y, ta = chunk * kFsmnFrames, tb = min(T, ta + kFsmnFrames), rows = kFsmnFrames + C - 1;
   float *odt = sm, *int_ = odt + (long)(rows + kFsmnSpare) * kWave, *taps = int_ + (long)(rows + kFsmnSpare) * kWave;   // (taps: C + kFsmnSpare rows)
@@ -565,49 +562,6 @@ __global__ void __launch_bounds__(kBlock) fsmn_backward_fused(float *__restrict_
         if (ib + j < C) partial[((long)chunk * C + ib + j) * D + d] = acc[j];
     }
   }
-  if (!finish_here) return;
-  // ticket of the column tile.  ONE thread publishes the workgroup's partials (the barrier orders every wave's stores in front of its
-  // device-scope release: every wave writing the L2 back cost this kernel 30 us); the partials are read back with device-scope loads
-  __syncthreads();
-  if (x == 0 && y == 0) {
-    __threadfence();
-    last_flag = __hip_atomic_fetch_add(tickets + blockIdx.x, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nchunks - 1);
-  }
-  __syncthreads();
-  if (!last_flag) return;
-  if (col_ok)
-    for (int i0 = y; i0 < C; i0 += kFsmnWaves * 4) {   // four taps per thread and round, eight partials of each in flight
-      float s[4] = {0.0f, 0.0f, 0.0f, 0.0f}, w_old[4];
-#pragma unroll
-      for (int a = 0; a < 4; a++) {
-        const int i = i0 + a * kFsmnWaves;
-        w_old[a] = (lr != 0.0f && i < C) ? coef[(long)i * ldc + d] : 0.0f;
-      }
-      for (int c0 = 0; c0 < nchunks; c0 += 8) {
-        float v[4][8];
-#pragma unroll
-        for (int a = 0; a < 4; a++)
-#pragma unroll
-          for (int c = 0; c < 8; c++) {
-            const int i = i0 + a * kFsmnWaves;
-            v[a][c] = (i < C && c0 + c < nchunks) ? __hip_atomic_load(partial + (unsigned)(((c0 + c) * C + i) * D + d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
-          }
-#pragma unroll
-        for (int a = 0; a < 4; a++)
-#pragma unroll
-          for (int c = 0; c < 8; c++) s[a] += v[a][c];   // chunk order
-      }
-#pragma unroll
-      for (int a = 0; a < 4; a++) {
-        const int i = i0 + a * kFsmnWaves;
-        if (i >= C) continue;
-        float g = s[a];
-        if (clip > 0.0f) g = fminf(fmaxf(g, -clip), clip);
-        corr[(long)i * ldcc + d] = g;  // beta 0: no momentum in the reference (cfsmn.h:219)
-        if (lr != 0.0f) coef[(long)i * ldc + d] = w_old[a] + -lr * g;
-      }
-    }
-  if (x == 0 && y == 0) __hip_atomic_store(tickets + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
 }
 // corr[i] = clip(sum of the chunks' partials, in chunk order) and, with lr != 0, coef[i] -= lr corr[i].  A workgroup of sixteen waves per
 // 64 columns x 16 taps: up to 32 partials per thread go out at once.
@@ -686,20 +640,16 @@ void aslp_fsmn_backward(float *in_diff, int ldid, float *coef_corr, int ldcc, fl
     return;
   }
   float *partial = static_cast<float *>(scratch(kScratchMisc, sizeof(float) * (size_t)nchunks * C * D));
-  unsigned *tickets = static_cast<unsigned *>(scratch_zeroed(kScratchTickets, sizeof(unsigned) * (size_t)ctiles));
-  if (!partial || !tickets) return;
+  if (!partial) return;
   static bool attr_set = false;
   if (!attr_set) {
     ASLP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fsmn_backward_fused), hipFuncAttributeMaxDynamicSharedMemorySize, kFsmnLdsRows * kWave * sizeof(float)));
     attr_set = true;
   }
-  // few chunks: the last workgroup of a column tile adds them itself; many (a long utterance): a second launch spread over the chip does
-  const int finish_here = nchunks <= 8;
-  hipLaunchKernelGGL(fsmn_backward_fused, dim3(ctiles, nchunks), dim3(kWave, kFsmnWaves), sizeof(float) * (size_t)lds_rows * kWave, cur_stream(),
-                     in_diff, ldid, partial, tickets, coef_corr, ldcc, coef, ldc, in, ldi, out_diff, ldod, D, C, past, future, T, nchunks, clip, lr, finish_here);
-  if (!finish_here)
-    hipLaunchKernelGGL(fsmn_grad_finish, dim3(ctiles, (C + kFsmnFinishTaps - 1) / kFsmnFinishTaps), dim3(kWave, kFsmnFinishTaps), 0, cur_stream(), coef_corr, ldcc,
-                       coef, ldc, partial, D, C, nchunks, clip, lr);
+  hipLaunchKernelGGL(fsmn_backward_fused, dim3(ctiles, nchunks), dim3(kWave, kFsmnWaves), sizeof(float) * (size_t)lds_rows * kWave, cur_stream(), in_diff, ldid,
+                     partial, coef, ldc, in, ldi, out_diff, ldod, D, C, past, future, T);
+  hipLaunchKernelGGL(fsmn_grad_finish, dim3(ctiles, (C + kFsmnFinishTaps - 1) / kFsmnFinishTaps), dim3(kWave, kFsmnFinishTaps), 0, cur_stream(), coef_corr, ldcc,
+                     coef, ldc, partial, D, C, nchunks, clip, lr);
   check_launch("aslp_fsmn_backward");
 }
 

@@ -225,7 +225,6 @@ class AffineTransform : public UpdatableComponent {
   }
   // Executor peephole (one-shot): a Sigmoid's backward pass reads the next BackpropagateFnc's in-diff and wants the per-workgroup maxima
   // of it (the scale of ITS result's planes follows from them); they are left in `h`'s maxima array, tagged with the in-diff
-  // (a BatchNormalization whose backward pass reads that in-diff bounds ITS in-diff with them: BatchNormalization::OutDiffMaxima)
   void LeaveInDiffMaxima(PlaneHolder *h) { in_diff_maxima_ = h; }
   void BackpropagateFnc(const CuMatrixBase &, const CuMatrixBase &, const CuMatrixBase &out_diff, CuMatrixBase *in_diff) {
     PlaneHolder *mx = in_diff_maxima_;
@@ -786,9 +785,6 @@ class BatchNormalization : public UpdatableComponent {
   // BackpropagateWithSigmoid writes wants the maxima its conversion needs.
   void ProduceOutputPlanes(PlaneHolder *h) { out_planes_ = h; }
   void LeaveDiffMaxima(PlaneHolder *h) { diff_maxima_ = h; }
-  // where the component above leaves the maxima of the out-diff it writes (AffineTransform::LeaveInDiffMaxima): with them and the
-  // forward pass' largest |scale / sigma| the backward launch bounds its in-diff before writing it, i.e. writes the planes itself
-  PlaneHolder &OutDiffMaxima() { return od_maxima_; }
   void PropagateWithSigmoid(const CuMatrixBase &in, CuMatrix *sigmoid_out) {
     ASLP_ASSERT(in.NumCols() == input_dim_);
     if (!acc_cleaned_) { acc_cleaned_ = true; CleanAccs(); }
@@ -819,9 +815,6 @@ class BatchNormalization : public UpdatableComponent {
  private:
   const CuVectorD *input_stats_ = nullptr;
   PlaneHolder *out_planes_ = nullptr, *diff_maxima_ = nullptr;
-  PlaneHolder od_maxima_;
-  CuVector giv_parts_;    // per 32-column panel: max |scale / sigma| of the latest forward pass (bn_forward_stats_kernel)
-  long giv_epoch_ = 0;    // ... the forward epoch it belongs to
   void Backward(const CuMatrixBase &in, const CuMatrixBase &out_diff, BaseFloat *in_diff, int32 id_stride, const BaseFloat *act_y, int32 act_stride) {
     PlaneHolder *dm = diff_maxima_;
     diff_maxima_ = nullptr;
@@ -831,18 +824,11 @@ class BatchNormalization : public UpdatableComponent {
       aslp_planes_out po = aslp_planes_out();
       if (dm && in_diff && dm->get().Reserve(in.NumRows(), input_dim_)) {
         aslp_planes_as_output(reinterpret_cast<const aslp_planes *>(&dm->get()), &po);
-        const S16Epochs ep = s16_epochs();
-        const int nod = (ep.fwd != 0 && giv_epoch_ == ep.fwd && od_maxima_.p) ? od_maxima_.get().PartsFor(out_diff.Data(), ep.bwd) : 0;
-        if (nod > 0) { po.bound_a = giv_parts_.Data(); po.bound_na = giv_parts_.Dim(); po.bound_b = od_maxima_.get().Parts(); po.bound_nb = nod; }
       }
       aslp_bn_backward_step_p(in.Dim(), out_diff.Data(), out_diff.Stride(), xhat_kept_ ? XsharpO_.Data() : nullptr, XsharpO_.Stride(), scale_.Data(),
                               shift_.Data(), var_vec_.Data(), dscale_.Data(), dshift_.Data(), opts_.momentum, opts_.learn_rate, in_diff, id_stride, act_y,
                               act_stride, in.Data(), mean_vec_.Data(), &po);
       if (po.nparts > 0) dm->get().TagParts(in_diff, po.nparts, s16_epochs().bwd);
-      else if (po.nparts == -1) {   // the launch wrote the planes (and their bound)
-        dm->get().ForgetHostBound();
-        dm->get().Tag(in_diff, id_stride, s16_epochs().bwd);
-      }
     } else {
       aslp_bn_backward_act(in.Data(), in.Dim(), out_diff.Data(), out_diff.Stride(), xhat_kept_ ? XsharpO_.Data() : nullptr, XsharpO_.Stride(), scale_.Data(),
                            mean_vec_.Data(), var_vec_.Data(), dscale_.Data(), dshift_.Data(), opts_.momentum, in_diff, id_stride, act_y, act_stride);
@@ -861,12 +847,9 @@ class BatchNormalization : public UpdatableComponent {
     PlaneSet *ps = (oh && act) ? &oh->get() : nullptr;
     if (ps && ps->Reserve(in.NumRows(), output_dim_) && ps->SetBound(1.0f)) aslp_planes_as_output(reinterpret_cast<const aslp_planes *>(ps), &po);
     else ps = nullptr;
-    if (giv_parts_.Dim() != (input_dim_ + 31) / 32) giv_parts_.Resize((input_dim_ + 31) / 32);
-    giv_epoch_ = 0;
     if (!aslp_bn_forward_stats_p(in.Data(), in.Dim(), out, out_stride, scale_.Data(), shift_.Data(), mean_vec_.Data(), var_vec_.Data(), acc_means_.Data(),
-                                 acc_vars_.Data(), var_floor_, act, act_stride, st->Data(), groups, ld, ps ? &po : nullptr, giv_parts_.Data()))
+                                 acc_vars_.Data(), var_floor_, act, act_stride, st->Data(), groups, ld, ps ? &po : nullptr))
       return false;
-    giv_epoch_ = s16_epochs().fwd;
     if (ps) ps->Tag(act, act_stride, s16_epochs().fwd);
     num_acc_frames_ += in.NumRows();
     return true;

@@ -307,17 +307,6 @@ void Nnet::Backpropagate(const std::vector<const CuMatrixBase *> &out_diff, std:
       } else {
         // AffineTransform <- Sigmoid <- AffineTransform (a sigmoid layer without BatchNormalization): the upper product leaves the maxima
         // of its in-diff, from which the Sigmoid's backward pass knows the scale of the lower layer's out-diff planes before it writes them
-        // (measured on the cfg2 step: 0.837-0.841 ms with it against 0.825-0.826 without on one box -- the five conversion passes it saves cost less
-        // than the in-diff products' maxima epilogue and the longer backward launch: off unless ASLP_BN_DIFF_PLANES=1)
-        static const bool bn_planes_off = !(getenv("ASLP_BN_DIFF_PLANES") != nullptr && getenv("ASLP_BN_DIFF_PLANES")[0] == '1');   // A/B switch (also read by the kernel's launcher)
-        if (!bn_planes_off && fuse_layers_ && alias_links_ && !is_input && direct[i] && components_[i]->GetType() == Component::kAffineTransform &&
-            folded[components_[i]->GetInput()[0]]) {
-          // AffineTransform <- (Sigmoid folded into) BatchNormalization: this product's in-diff is what that component's backward launch
-          // reads; with its maxima the launch can bound -- and so write the planes of -- its own in-diff
-          const int32 sg = components_[i]->GetInput()[0];
-          for (int32 b = 0; b < N; b++)
-            if (fused_sigmoid[b] == sg) dynamic_cast<AffineTransform *>(components_[i])->LeaveInDiffMaxima(&dynamic_cast<BatchNormalization *>(components_[b])->OutDiffMaxima());
-        }
         if (fuse_layers_ && alias_links_ && !is_input && direct[i]) {
           const int32 below = components_[i]->GetInput()[0];
           const int32 sig = components_[i]->GetType() == Component::kAffineTransform ? below : i;

@@ -67,12 +67,6 @@ def test_recurrent_ab_switches_agree(tmp_path):
         assert np.array_equal(f32, run(tmp_path, name, ASLP_LSTM_SPLIT_F16="0", **env)), name
     exact = run(tmp_path, "exact_act", ASLP_LSTM_FAST_ACT="0")      # correctly rounded expf / division (the reference's CPU bits)
     assert close(exact, base)
-    half = run(tmp_path, "half_chains", ASLP_LSTM_HALF_CHAINS="1")  # 4 streams per chain, two workgroups per CU: K split over 4 waves
-    assert close(half, base)
-    assert np.array_equal(half, run(tmp_path, "half_map0", ASLP_LSTM_HALF_CHAINS="1", ASLP_LSTM_HALF_MAP="0"))   # who shares a CU changes nothing
-    assert np.array_equal(half, run(tmp_path, "half_delay0", ASLP_LSTM_HALF_CHAINS="1", ASLP_LSTM_HALF_DELAY_NS="0"))
-    dual = run(tmp_path, "dual", ASLP_LSTM_DUAL="1")               # wave-specialised forward: product waves / gate waves, two half-chains
-    assert close(dual, base)
     step = run(tmp_path, "per_timestep", ASLP_LSTM_PERSISTENT="0")
     assert close(step, base)
 
@@ -95,50 +89,6 @@ def test_split_f16_products_keep_fp32_accuracy_at_any_magnitude(tmp_path, pscale
         for lo, hi in ((0, 9 * 16 * 128), (9 * 16 * 128, 9 * 16 * (128 + 24))) if name != "params" else ((0, len(a)),):
             x, y = a[lo:hi].astype(np.float64), b[lo:hi].astype(np.float64)
             assert np.linalg.norm(x - y) <= 1e-5 * np.linalg.norm(y) + 1e-30, (name, lo, np.linalg.norm(x - y) / max(np.linalg.norm(y), 1e-300))
-
-
-XENT_CHILD = r'''
-import sys, ctypes as C
-import numpy as np, torch
-sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
-import aslp_import
-aslp = aslp_import.load(); aslp.ops.use_torch_stream()
-dev = torch.device("cuda:0")
-g = torch.Generator(device="cpu"); g.manual_seed(11)
-outs = []
-for rows, cols in ((1024, 3000), (600, 700), (512, 1500)):
-    logits = (torch.randn(rows, cols, generator=g) * 3).to(dev)
-    y = torch.softmax(logits, 1).contiguous()
-    lab = torch.randint(0, cols, (rows,), generator=g, dtype=torch.int32).to(dev)
-    tgt = torch.zeros(rows, cols); tgt[torch.arange(rows), lab.cpu().long()] = 1.0; tgt[3] = 0; tgt[4, :2] = torch.tensor([0.25, 0.75]); tgt[4, 2:] = 0
-    tgt = tgt.to(dev)
-    fw = torch.rand(rows, generator=g).to(dev); fw[0] = 0
-    for kw in (dict(labels=lab), dict(targets=tgt)):
-        diff = torch.empty_like(y); st = torch.zeros(5, dtype=torch.float64, device=dev)
-        aslp.ops.xent_eval(y, fw, diff, st, **kw)
-        outs += [diff.cpu().numpy().ravel(), st.cpu().numpy().astype(np.float64).view(np.float32)]
-    # the Softmax folded into the loss (what TrainStepXent runs for 513..8192 classes)
-    if aslp.lib.aslp_softmax_xent_supported(cols):
-        from kaldi_aslp_amd.ops import ptr, dim
-        diff = torch.empty_like(y); post = torch.empty_like(y); st = torch.zeros(5, dtype=torch.float64, device=dev)
-        aslp.lib.aslp_softmax_xent_eval(ptr(logits), dim(logits), None, 0, ptr(lab), ptr(fw), ptr(diff), dim(diff).stride, ptr(st), ptr(post), dim(post).stride)
-        outs += [diff.cpu().numpy().ravel(), post.cpu().numpy().ravel(), st.cpu().numpy().astype(np.float64).view(np.float32)]
-np.save(sys.argv[1], np.concatenate(outs))
-'''
-
-
-def test_xent_wave_per_row_kernel_is_bit_identical(tmp_path):
-    """ASLP_XENT_WAVE=1: Xent::Eval on >= 512 rows as one wave per row without workgroup barriers (csrc/nn_fused.hip xent_rows_wave_kernel,
-    an A/B variant: measured 1 % slower on the cfg2 step, so not the default); it plays the
-    four waves of the one-workgroup-per-row kernel lane by lane, so diff, posteriors and the five double statistics are the same BITS."""
-    def run_x(name, **env):
-        out = str(tmp_path / (name + ".npy"))
-        p = subprocess.run([sys.executable, "-c", XENT_CHILD % {"root": ROOT}, out], env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                           timeout=600)
-        assert p.returncode == 0, p.stderr.decode()[-2000:]
-        return np.load(out)
-    a, b = run_x("wave", ASLP_XENT_WAVE="1"), run_x("block")
-    assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
 def test_lstm_layer_products_from_prepared_planes(tmp_path):

@@ -27,7 +27,10 @@ def check_line(out, n):
     # BASELINE's own multi-GPU configurations: cfg4 (cfg1 net, minibatch 256/GPU, BSP) and cfg5 (LC-BLSTM + Warp-CTC, EASGD server + workers)
     c4, c5 = d.get("cfg4_bsp"), d.get("cfg5_easgd")
     assert c4 and "error" not in c4 and c4["n_gpus"] == n and c4["frames_per_sec"] > 0 and c4["sync_ms"] > 0, c4
-    assert c5 and "error" not in c5 and c5["workers"] == n - 1 and c5["valid_frames_per_sec"] > 0, c5
+    assert c5 and "error" not in c5 and c5["workers"] == n - 1 and c5["valid_frames_per_sec"] > 0 and c5["sync_ms"] > 0, c5
+    import math
+    assert math.isfinite(c4["avg_xent_per_frame_rank0"]) and 0.0 < c4["avg_xent_per_frame_rank0"] < 20.0, c4     # the loss survived the exchanges
+    assert math.isfinite(c5["avg_ctc_obj_per_sequence"]) and c5["avg_ctc_obj_per_sequence"] > 0.0, c5
     for blk in (bsp, c4, c5, d["config"]["comm"]):
         assert blk["transport"] == "shm" and blk["ranks_seen"] == n and blk["scaling_measured"] is False   # says so when nothing was scaled
     return d
@@ -50,3 +53,17 @@ def test_bench_two_ranks_under_torch_distributed_run():
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert p.returncode == 0, "\n".join(l for l in p.stderr.decode().splitlines() if "ResetLstmStreams" not in l)[-4000:]
     check_line(p.stdout.decode(), 2)
+
+
+def test_bench_three_ranks_server_and_two_workers():
+    """`bench.py --gpus 3` as the driver would start it for N = 3: cfg4's BSP over three ranks, cfg5's EASGD server on rank 0 with TWO
+    workers exchanging with it (the smallest run in which worker-server traffic interleaves), all on one GPU over shared memory --
+    so the first real SCALE record cannot fail on plumbing."""
+    env = {k: v for k, v in os.environ.items() if k not in CLEAN}
+    env["ASLP_COMM_TRANSPORT"] = "shm"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "6", "--warmup", "2"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+    assert p.returncode == 0, "\n".join(l for l in p.stderr.decode().splitlines() if "ResetLstmStreams" not in l)[-4000:]
+    d = check_line(p.stdout.decode(), 3)
+    assert d["cfg5_easgd"]["workers"] == 2 and d["cfg5_easgd"]["ranks_seen"] == 3 and d["cfg4_bsp"]["ranks_seen"] == 3
+
