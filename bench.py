@@ -1025,12 +1025,22 @@ def main():
                                "peak_note": ("dense fp16 MFMA peak %.0f TFLOP/s / 3 instructions per fp32-equivalent product" % F16_MFMA_PEAK_TFLOPS) if split
                                             else "fp32 MFMA peak",
                                "frac_of_fp32_mfma_peak": d["tflops"] / F32_MFMA_PEAK_TFLOPS,
+                               "frac_of_fp32_mfma_peak_note": ("a ratio of rates (this kernel's fp32-equivalent rate over the fp32 instruction's peak), NOT a utilisation: the "
+                                                               "fp32 instruction is not what runs; the matrix pipe's busy fraction is `matrix_pipe_busy`") if split else None,
+                               "matrix_pipe_busy": (pmc.get("mfma_busy") if traffic is not None else None),
+                               "matrix_pipe_busy_source": ("NOT measured in this run: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs) of the committed PMC pass "
+                                                           "(profiles/dnn_cfg2_pmc.json)") if traffic is not None else None,
                                "what_bounds_it": ("measured (DESIGN 7, devtools/micro/lds_feed*.hip): the operand path L2 -> LDS -- one output tile per CU pulls (BM + BN) x K x 4 B "
                                                   "through it, 402 MB for a 1024 x 2048 x 2048 product on 64 x 128 tiles against the L2's 33-35 TB/s -- and, for the "
                                                   "weight gradients, an HBM-bound epilogue (W, gradient buffer and the new W's planes: 64-80 MB per launch); the matrix "
                                                   "pipe is 22-30 % busy") if split else None,
                                "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                                "flop_per_launch": d["flop_per_launch"], "avg_launch_us": d["avg_us"], "launches": d["launches"],
+                               "launch_mix": {"NT": "per step: the 440-input layer, four 2048 x 2048 hidden layers and the 3000-column output layer, all on the named tile",
+                                              "NN": "per step: four hidden layers' in-diff products and the output layer's (K = 3000), all on the named tile",
+                                              "TN": "per step SIX weight-gradient launches on TWO kernel templates: four 2048 x 2048 x 1024 on gemm_s16_ks128<true> (128 x 128; the "
+                                                    "named one) and the 440-input and 3000-output layers' on gemm_s16_glds<64,128,2,2,3,false,false,0,true>; `achieved` and "
+                                                    "`avg_launch_us` average all six (flop_per_launch = their mean)"}.get(dom),
                                "timing": "HIP events on the launch stream, second pass over the same K steps"}
             tot_fl = sum(v["flop_per_launch"] * v["launches"] for v in timed.values())
             tot_ms = sum(v["avg_us"] * v["launches"] for v in timed.values()) / 1e3

@@ -11,9 +11,10 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-# K + 1 taps select the tap-gradient instantiation (temporal.hip rowconv_wgrad1<8|16|32|64>): K = 2..5 -> <8>, 12 -> <16>,
-# 20 (cfg5's FutureContext, at its full size D=512 / T=800 / S=32) and 31 -> <32>, 40 and 63 -> <64>; 64, 100 and 130 taps and more go in groups
-# of 64 taps, one launch each (the reference has no limit on FutureContext)
+# K + 1 taps select the instantiation of the streaming kernels (temporal.hip rowconv_fwd_stream / rowconv_bwd_fused <ring length, exact>):
+# K = 2 -> <4>, 3 and 5 -> <8>, 12 and 15 -> <16>, 20 (cfg5's FutureContext, at its full size D=512 / T=800 / S=32) -> <21, exact>, 31 -> <32>;
+# an odd width (33) and more than 32 taps (40, 63, 64, 100, 130: the reference has no limit on FutureContext) run on the round-1 kernels,
+# whose tap gradients go in groups of 64 taps
 @pytest.mark.parametrize("dims", [(4, 2, 6, 3), (70, 3, 21, 4), (256, 2, 50, 8), (33, 5, 9, 2), (64, 12, 40, 4), (96, 15, 33, 5),
                                   (512, 20, 800, 32), (40, 31, 64, 3), (48, 40, 90, 3), (130, 63, 70, 2), (72, 64, 150, 3), (40, 100, 120, 2),
                                   (36, 130, 90, 2)])
@@ -44,7 +45,9 @@ def test_rowconv_train_steps_match_oracle(aslp, oracle, dev, tmp_path, dims):
         assert np.all(out.reshape(T, S, D)[lens[1]:, 1] == 0)
 
 
-@pytest.mark.parametrize("dims", [(5, 3, 2, 11), (64, 30, 30, 200), (130, 20, 10, 77), (512, 30, 30, 1000), (16, 40, 40, 5)])
+# (40, 120, 120, 50): 241 taps do not fit the LDS tiles of fsmn_filter_lds / fsmn_backward_fused -- the round-1 kernels serve them;
+# (512, 30, 30, 1000): 32 chunks of frames, (64, 30, 30, 200): 7, (16, 40, 40, 5): one partial tile
+@pytest.mark.parametrize("dims", [(5, 3, 2, 11), (64, 30, 30, 200), (130, 20, 10, 77), (512, 30, 30, 1000), (16, 40, 40, 5), (40, 120, 120, 50)])
 def test_fsmn_train_steps_match_oracle(aslp, oracle, dev, tmp_path, dims):
     D, P, F, T = dims
     rng = np.random.default_rng(6)
