@@ -840,3 +840,14 @@ float *orc_dnn_bias(orc_dnn *d, int l) { return d->b[l]; }
 float *orc_dnn_bn_scale(orc_dnn *d, int l) { return d->bns[l].scale; }
 float *orc_dnn_bn_shift(orc_dnn *d, int l) { return d->bns[l].shift; }
 const float *orc_dnn_output(const orc_dnn *d) { return d->softmax_out; }
+
+/* oracle/gen_cumatrix_blas_golden.cpp: Uniform() and Fill() */
+void orc_golden_uniform_fill(unsigned long long *state, float *out, long n, float lo, float hi) {
+  unsigned long long g = *state;
+  for (long i = 0; i < n; i++) {
+    g ^= g << 13; g ^= g >> 7; g ^= g << 17;
+    out[i] = lo + (hi - lo) * (float)((double)(g >> 40) * (1.0 / 16777216.0));
+  }
+  *state = g;
+}
+

@@ -174,6 +174,11 @@ float *orc_dnn_bn_scale(orc_dnn *d, int layer);
 float *orc_dnn_bn_shift(orc_dnn *d, int layer);
 const float *orc_dnn_output(const orc_dnn *d);             /* softmax output [mb x out] */
 
+/* The golden generators' uniform generator (oracle/gen_cumatrix_blas_golden.cpp Uniform(): xorshift64 13 / 7 / 17, the top 24 bits): out[i] =
+ * lo + (hi - lo) * u, advancing *state.  A fixture that records the generator state in front of a tensor instead of the tensor itself
+ * (tests/golden/lstm_fullwidth.bin) is read back with this. */
+void orc_golden_uniform_fill(unsigned long long *state, float *out, long n, float lo, float hi);
+
 /* ---- recurrent components (aslp_oracle_rnn.c) ---------------------------------------------- */
 typedef struct {   /* one direction of an LSTM-family component; all matrices dense row-major */
   int D, C, R;     /* input dim, cells, projection dim (0 = no projection: Lstm / BLstm) */

@@ -42,14 +42,32 @@ static void Put(const char *name, int rows, int cols, int kind, const void *data
   std::fwrite(hdr, sizeof(int32), 3, g_out);
   std::fwrite(data, elem, (size_t)rows * cols, g_out);
 }
+// digest mode (the full-width fixture: tensors of megabytes): a matrix goes out as every g_stride-th element of its row-major image plus a
+// float64 record `name#` = {sum, sum of squares, element count}; inputs are not written at all (g_skip_inputs) -- the reader regenerates
+// them from the generator state recorded in front (`<tag>_rng`), which is the whole reason the fixture stays small
+static int g_stride = 0;
+static bool g_skip = false;   // set around the PutMat calls of tensors the reader regenerates
 static void PutMat(const char *name, const CuMatrixBase<float> &m) {
+  if (g_skip) return;
   Matrix<float> h(m.NumRows(), m.NumCols());
   m.CopyToMat(&h);
   std::vector<float> flat((size_t)h.NumRows() * h.NumCols());
   for (int r = 0; r < h.NumRows(); r++) std::memcpy(&flat[(size_t)r * h.NumCols()], h.RowData(r), sizeof(float) * h.NumCols());
-  Put(name, h.NumRows(), h.NumCols(), 0, flat.data());
+  if (g_stride <= 0) { Put(name, h.NumRows(), h.NumCols(), 0, flat.data()); return; }
+  std::vector<float> pick;
+  double acc[3] = {0.0, 0.0, (double)flat.size()};
+  for (size_t i = 0; i < flat.size(); i++) {
+    acc[0] += flat[i];
+    acc[1] += (double)flat[i] * flat[i];
+    if (i % (size_t)g_stride == 0) pick.push_back(flat[i]);
+  }
+  Put(name, 1, (int)pick.size(), 0, pick.data());
+  char nm[32];
+  std::snprintf(nm, 32, "%s#", name);
+  Put(nm, 1, 3, 2, acc, 8);
 }
 static void PutVec(const char *name, const CuVectorBase<float> &v) {
+  if (g_skip) return;
   Vector<float> h(v.Dim());
   v.CopyToVec(&h);
   Put(name, 1, v.Dim(), 0, h.Data());
@@ -392,11 +410,14 @@ static void LstmProjected(const char *tag, bool reverse, bool carried, bool cifg
 // nnet-lstm-projected-streams.h:560-585), are clipped by ApplyFloor / ApplyCeiling (lc.h:1000-1016), then W.AddMat(-lr, corr)
 // (lc.h:1085-1098).  Sized so that the engine's persistent recurrence serves it (C = 64, S = 8 streams): a golden from the reference's
 // library reaches those kernels.  State zero at the start of every step (the streams are reset).
-static void LstmProjectedTrain(const char *tag, int T, int S, int D, int C, int R, float mmt, float clip, float lr) {
+static void LstmProjectedTrain(const char *tag, int T, int S, int D, int C, int R, float mmt, float clip, float lr, float wr = 0.2f, float odr = 1.0f,
+                               bool inputs_regenerated = false) {
+  // wr: range of the weight matrices (0.02 at full width: cfg3's <ParamScale>; at 0.2 a 512-cell layer saturates and any two fp32 summation
+  // orders part ways); odr: range of the out-diff; inputs_regenerated: initial parameters, inputs and out-diffs are not written (digest mode)
   const int NG = 4, W = (NG + 3) * C + R;
   Mat Wx, Wr, Wrm;
   Vec bias, pi, pf, po;
-  Fill(&Wx, NG * C, D, -0.2f, 0.2f); Fill(&Wr, NG * C, R, -0.2f, 0.2f); Fill(&Wrm, R, C, -0.2f, 0.2f);
+  Fill(&Wx, NG * C, D, -wr, wr); Fill(&Wr, NG * C, R, -wr, wr); Fill(&Wrm, R, C, -wr, wr);
   FillVec(&bias, NG * C, -0.3f, 0.3f); FillVec(&pi, C, -0.3f, 0.3f); FillVec(&pf, C, -0.3f, 0.3f); FillVec(&po, C, -0.3f, 0.3f);
   Mat cWx(NG * C, D), cWr(NG * C, R), cWrm(R, C);
   Vec cb(NG * C), cpi(C), cpf(C), cpo(C);
@@ -406,12 +427,16 @@ static void LstmProjectedTrain(const char *tag, int T, int S, int D, int C, int 
     PutMat(NAME2("Wx", k), Wx); PutMat(NAME2("Wr", k), Wr); PutMat(NAME2("Wrm", k), Wrm); PutVec(NAME2("bias", k), bias);
     PutVec(NAME2("pi", k), pi); PutVec(NAME2("pf", k), pf); PutVec(NAME2("po", k), po);
   };
+  g_skip = inputs_regenerated;
   put_params(0);
+  g_skip = false;
   const int G = 0, I = 1, F = 2, O = 3, Cc = 4, H = 5, Mm = 6;
   for (int step = 0; step < 2; step++) {
     Mat in, od;
-    Fill(&in, T * S, D, -1.5f, 1.5f); Fill(&od, T * S, R, -1.0f, 1.0f);
+    Fill(&in, T * S, D, -1.5f, 1.5f); Fill(&od, T * S, R, -odr, odr);
+    g_skip = inputs_regenerated;
     PutMat(NAME2("in", step), in); PutMat(NAME2("od", step), od);
+    g_skip = false;
     Mat Y((T + 2) * S, W), Dd((T + 2) * S, W);
     struct View {
       Mat &b; int C, R, S;
@@ -641,7 +666,20 @@ static void XentChain() {
 }
 
 int main(int argc, char **argv) {
-  if (argc != 2) { std::fprintf(stderr, "usage: %s <out.bin>\n", argv[0]); return 1; }
+  if (argc == 3 && !std::strcmp(argv[2], "lstm_fullwidth")) {
+    // tests/golden/lstm_fullwidth.bin: two training steps of ONE projected-LSTM layer at BASELINE cfg3's widths (C 512, R 256, input 512, S = 32
+    // streams, T = 60 frames = chunk 40 + right context 20), momentum 0.9, element-wise clipping 5, learn rate 0.002, on the reference's library
+    // -- as a digest (every 61st element + sums): 6.7 MB of parameters would not be a "small fixture"
+    g_out = std::fopen(argv[1], "wb");
+    if (!g_out) return 1;
+    const int32 rng[2] = {(int32)(g_state & 0xFFFFFFFFull), (int32)(g_state >> 32)};
+    Put("lcfull_rng", 1, 2, 1, rng);
+    g_stride = 61;
+    LstmProjectedTrain("lcfull", 60, 32, 512, 512, 256, 0.9f, 5.0f, 0.002f, 0.02f, 1.0f, true);
+    std::fclose(g_out);
+    return 0;
+  }
+  if (argc != 2) { std::fprintf(stderr, "usage: %s <out.bin> [lstm_fullwidth]\n", argv[0]); return 1; }
   g_out = std::fopen(argv[1], "wb");
   if (!g_out) return 1;
   Operations();

@@ -18,6 +18,27 @@ def load_blas():
     return {k: (v[0] if v.ndim == 2 and v.shape[0] == 1 else v) for k, v in load(BLAS_PATH).items()}
 
 
+FULLWIDTH_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lstm_fullwidth.bin")
+DIGEST_STRIDE = 61
+
+
+def load_fullwidth():
+    """tests/golden/lstm_fullwidth.bin (`oracle/_ref/gen_cumatrix_blas_golden <file> lstm_fullwidth`): two training steps of one projected-LSTM layer
+    at BASELINE cfg3's widths on the reference's library, as a DIGEST -- a matrix record `name` holds every 61st element of the row-major
+    image, `name#` (float64) = {sum, sum of squares, element count}; initial parameters, inputs and out-diffs are not stored: `lcfull_rng` is
+    the generator state in front of them (oracle_lib.GoldenRng replays it).  Returns (records, generator state)."""
+    g = {k: (v[0] if v.ndim == 2 and v.shape[0] == 1 else v) for k, v in load(FULLWIDTH_PATH).items()}
+    rng = g["lcfull_rng"].astype(np.int64)
+    state = (int(rng[0]) & 0xFFFFFFFF) | ((int(rng[1]) & 0xFFFFFFFF) << 32)
+    return {k[7:]: v for k, v in g.items() if k.startswith("lcfull_")}, state
+
+
+def digest_of(a):
+    """what the generator's digest mode keeps of a tensor: (every 61st element, [sum, sum of squares, count])"""
+    f = np.asarray(a, np.float32).ravel()
+    return f[::DIGEST_STRIDE], np.array([f.astype(np.float64).sum(), (f.astype(np.float64) ** 2).sum(), f.size])
+
+
 COMPONENT_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "component_ops.bin")
 
 

@@ -101,6 +101,19 @@ _sig("orc_dnn_bias", C.POINTER(_f), C.c_void_p, _i)
 _sig("orc_dnn_bn_scale", C.POINTER(_f), C.c_void_p, _i)
 _sig("orc_dnn_bn_shift", C.POINTER(_f), C.c_void_p, _i)
 _sig("orc_dnn_output", C.POINTER(_f), C.c_void_p)
+_sig("orc_golden_uniform_fill", None, C.POINTER(C.c_ulonglong), f32p, C.c_long, _f, _f)
+
+
+class GoldenRng:
+    """the golden generators' Uniform() / Fill() (oracle/gen_cumatrix_blas_golden.cpp), seeded with a recorded state"""
+
+    def __init__(self, state):
+        self.state = C.c_ulonglong(int(state))
+
+    def fill(self, shape, lo, hi):
+        out = np.empty(shape, np.float32)
+        lib.orc_golden_uniform_fill(C.byref(self.state), out.reshape(-1), out.size, lo, hi)
+        return out
 
 
 # front-end components of the CNN / cFSMN recipes (oracle/aslp_oracle_conv.c)

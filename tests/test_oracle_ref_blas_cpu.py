@@ -161,6 +161,44 @@ def test_lstm_two_training_steps_with_momentum_and_clipping_match_reference_libr
     assert clipped > 0      # the clip is active in the fixture
 
 
+def test_lstm_full_width_two_training_steps_match_reference_library_digest(oracle):
+    """`lcfull` (tests/golden/lstm_fullwidth.bin): the same two training steps at BASELINE cfg3's widths (C 512, R 256, D 512, S 32, T 60), on the
+    reference's library, kept as a digest (every 61st element of a tensor + its sum, sum of squares and size); parameters, inputs and out-diffs
+    are replayed from the recorded generator state.  Pins the oracle's LSTM chain -- the checker of tests/test_cfg3_step_gpu.py -- at FULL width."""
+    g, state = cumatrix_golden.load_fullwidth()
+    T, S, D, Cc, R, mmt, clip, lr = 60, 32, 512, 512, 256, 0.9, 5.0, 0.002
+    rng = oracle.GoldenRng(state)
+    names = [("w_x", "Wx"), ("w_r", "Wr"), ("bias", "bias"), ("peep_i", "pi"), ("peep_f", "pf"), ("peep_o", "po"), ("w_rm", "Wrm")]
+    d, corr = oracle.LstmDir(D, Cc, R, False, zero=True), oracle.LstmDir(D, Cc, R, False, zero=True)
+    d.w_x[...] = rng.fill((4 * Cc, D), -0.02, 0.02); d.w_r[...] = rng.fill((4 * Cc, R), -0.02, 0.02); d.w_rm[...] = rng.fill((R, Cc), -0.02, 0.02)
+    d.bias[...] = rng.fill((4 * Cc,), -0.3, 0.3)
+    d.peep_i[...] = rng.fill((Cc,), -0.3, 0.3); d.peep_f[...] = rng.fill((Cc,), -0.3, 0.3); d.peep_o[...] = rng.fill((Cc,), -0.3, 0.3)
+
+    def digest_close(x, key, tol):
+        pick, sums = cumatrix_golden.digest_of(x)
+        return pick.shape == g[key].shape and sums[2] == g[key + "#"][2] and close(pick, g[key], tol) and \
+            abs(sums[1] - g[key + "#"][1]) <= 4 * tol * g[key + "#"][1]
+
+    clipped = 0
+    for step in (0, 1):
+        x, od = rng.fill((T * S, D), -1.5, 1.5), rng.fill((T * S, R), -1.0, 1.0)
+        buf = d.forward(x, T, S)
+        assert digest_close(d.out_of(buf, T, S), "out%d" % step, 1e-5), step
+        dbuf, idf = d.backward(od, T, S, buf)
+        assert digest_close(idf, "in_diff%d" % step, 1e-5), step
+        d.grads(corr, x, T, S, buf, dbuf, mmt, clip)
+        assert digest_close(corr.w_x, "cWx%d" % step, 5e-5) and digest_close(corr.w_rm, "cWrm%d" % step, 5e-5), step
+        clipped += int((np.abs(g["cWrm%d" % step]) == np.float32(clip)).sum())
+        for n, k in names:
+            getattr(d, n)[...] = getattr(d, n) - np.float32(lr) * getattr(corr, n)
+            key = "%s%d" % (k, step + 1)
+            if key + "#" in g:
+                assert digest_close(getattr(d, n), key, 2e-5), (step, n)
+            else:
+                assert close(getattr(d, n), g[key], 2e-5), (step, n)
+    assert clipped > 0      # the clip is active in the fixture
+
+
 def test_gru_chain_matches_reference_library(oracle):
     """nnet-gru-streams.h:238-450: forward buffer (z|r|m|g|h), backward buffer, input diff and the four gradients."""
     g = cumatrix_golden.load_blas()

@@ -136,6 +136,61 @@ def test_projected_lstm_two_training_steps_momentum_clip_match_reference_library
         assert close(net.GetParams(), ref, 1e-5), step
 
 
+def _fullwidth_case(oracle):
+    """tensors of tests/golden/lstm_fullwidth.bin regenerated in the generator's own order (oracle/gen_cumatrix_blas_golden.cpp LstmProjectedTrain)"""
+    g, state = cumatrix_golden.load_fullwidth()
+    Tn, S, D, Cc, R = 60, 32, 512, 512, 256
+    rng = oracle.GoldenRng(state)
+    p = dict(w_x=rng.fill((4 * Cc, D), -0.02, 0.02), w_r=rng.fill((4 * Cc, R), -0.02, 0.02), w_rm=rng.fill((R, Cc), -0.02, 0.02),
+             bias=rng.fill((4 * Cc,), -0.3, 0.3), peep_i=rng.fill((Cc,), -0.3, 0.3), peep_f=rng.fill((Cc,), -0.3, 0.3), peep_o=rng.fill((Cc,), -0.3, 0.3))
+    steps = [(rng.fill((Tn * S, D), -1.5, 1.5), rng.fill((Tn * S, R), -1.0, 1.0)) for _ in range(2)]
+    return g, p, steps, (Tn, S, D, Cc, R)
+
+
+def _digest_close(x, g, key, tol):
+    """x against the digest records `key` / `key#`: the sampled elements to tol (relative to max(1, |ref|) per element AND in norm), the sums
+    to tol of the sum of magnitudes"""
+    pick, sums = cumatrix_golden.digest_of(x)
+    ref = g[key]
+    assert pick.shape == ref.shape, (key, pick.shape, ref.shape)
+    assert sums[2] == g[key + "#"][2], key
+    ok = close(pick, ref, tol) and rel(pick, ref) <= tol
+    scale = np.sqrt(sums[2] * g[key + "#"][1])     # >= sum |ref| (Cauchy-Schwarz): the size a sum's error is held against
+    return ok and abs(sums[0] - g[key + "#"][0]) <= tol * max(scale, 1.0) and abs(sums[1] - g[key + "#"][1]) <= 2 * tol * g[key + "#"][1]
+
+
+def test_projected_lstm_full_width_two_training_steps_match_reference_library(aslp, oracle, dev, tmp_path):
+    """`lcfull` (tests/golden/lstm_fullwidth.bin): ONE projected-LSTM layer at BASELINE cfg3's widths -- 512 cells, 256-wide projection, 512
+    inputs, S = 32 streams, T = 60 frames (chunk 40 + right context 20) -- through two training steps with momentum 0.9, element-wise
+    clipping 5 (5-13 % of the W_rm gradients clipped) and learn rate 0.002, as nnet-lstm-projected-streams.h:313-617 /
+    nnet-blstm-projected-streams-lc.h:976-1016, 1085-1098 issue them ON THE REFERENCE'S LIBRARY.  Here the full-width persistent recurrences
+    (four chains of 32 workgroups), the 1920-row layer products from prepared planes and the fused update run; outputs, input diffs and every
+    parameter tensor after each step are held against the digest (every 61st element + sums)."""
+    g, p, steps, (Tn, S, D, Cc, R) = _fullwidth_case(oracle)
+    d = oracle.LstmDir(D, Cc, R, False, zero=True)   # container of the tensors for the model writer (no oracle arithmetic runs)
+    for n, v in p.items():
+        getattr(d, n)[...] = v
+    path = tmp_path / "lcfull.nnet"
+    nnet_io.write_simple_nnet(path, [("<LstmProjectedStreams>", D, R, nnet_io.lstm([d], 5.0, Cc))])
+    net = aslp.Nnet.Read(path)
+    net.SetTrainOptions(learn_rate=0.002, momentum=0.9)
+    names = (("w_x", "Wx"), ("w_r", "Wr"), ("bias", "bias"), ("peep_i", "pi"), ("peep_f", "pf"), ("peep_o", "po"), ("w_rm", "Wrm"))
+    sizes = [p[n].size for n, _ in names]
+    for step, (x, od) in enumerate(steps):
+        net.ResetLstmStreams([1] * S)
+        out = net.Propagate(T(x, dev)).cpu().numpy()
+        assert _digest_close(out, g, "out%d" % step, 1e-4), ("out", step)
+        idf = net.Backpropagate(T(od, dev), want_in_diff=True).cpu().numpy()
+        assert _digest_close(idf, g, "in_diff%d" % step, 1e-4), ("in_diff", step)
+        params = np.split(net.GetParams(), np.cumsum(sizes)[:-1])
+        for (n, k), v in zip(names, params):
+            key = "%s%d" % (k, step + 1)
+            if key + "#" in g:
+                assert _digest_close(v, g, key, 1e-4), (key, step)
+            else:   # vectors are stored whole
+                assert close(v, g[key], 1e-4) and rel(v, g[key]) <= 1e-4, (key, step)
+
+
 def test_gru_component_matches_reference_library(aslp, oracle, dev, tmp_path):
     """nnet-gru-streams.h:238-450: output h(1..T), input diff, parameters after one step."""
     g = {k[4:]: v for k, v in cumatrix_golden.load_blas().items() if k.startswith("gru_")}
