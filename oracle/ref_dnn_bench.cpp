@@ -9,9 +9,13 @@
 // is computed like the reference computes it); every operation is the reference's own code.  The same sequences are what
 // tests/golden/cumatrix_blas_ops.bin pins the oracle and the HIP engine against.
 // usage: ref_dnn_bench <seconds> [max_steps]    ->  one JSON line on stdout
+//        ref_dnn_bench golden <out.bin>        ->  tests/golden/dnn_cfg2_fullsize.bin: two training steps of the same net at lr 0.008 on fresh
+//                                                  minibatches, as a digest (every 257th element of a tensor + its sums; weights and data
+//                                                  are replayed by the reader from the recorded generator state, oracle_lib.GoldenRng)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "aslp-cudamatrix/cu-array.h"
@@ -36,6 +40,42 @@ static void Fill(Mat *m, int rows, int cols, float lo, float hi) {
     for (int c = 0; c < cols; c++) h(r, c) = lo + (hi - lo) * Uniform();
   m->Resize(rows, cols);
   m->CopyFromMat(h);
+}
+
+// ---- golden mode: records as in oracle/gen_cumatrix_blas_golden.cpp ({name[32], rows, cols, kind, data}; kind 0 float32, 1 int32, 2 float64)
+static FILE *g_out = nullptr;
+static const int kDigestStride = 257;
+static void Put(const char *name, int rows, int cols, int kind, const void *data, int elem = 4) {
+  char nm[32];
+  std::memset(nm, 0, sizeof(nm));
+  std::strncpy(nm, name, 31);
+  std::fwrite(nm, 1, 32, g_out);
+  int32 hdr[3] = {rows, cols, kind};
+  std::fwrite(hdr, sizeof(int32), 3, g_out);
+  std::fwrite(data, elem, (size_t)rows * cols, g_out);
+}
+static void PutDigest(const char *name, const CuMatrixBase<float> &m) {   // every kDigestStride-th element + `name#` = {sum, sum of squares, count}
+  Matrix<float> h(m.NumRows(), m.NumCols());
+  m.CopyToMat(&h);
+  std::vector<float> pick;
+  double acc[3] = {0.0, 0.0, (double)h.NumRows() * h.NumCols()};
+  size_t i = 0;
+  for (int r = 0; r < h.NumRows(); r++)
+    for (int c = 0; c < h.NumCols(); c++, i++) {
+      const float v = h(r, c);
+      acc[0] += v;
+      acc[1] += (double)v * v;
+      if (i % (size_t)kDigestStride == 0) pick.push_back(v);
+    }
+  Put(name, 1, (int)pick.size(), 0, pick.data());
+  char nm[32];
+  std::snprintf(nm, 32, "%s#", name);
+  Put(nm, 1, 3, 2, acc, 8);
+}
+static void PutVec(const char *name, const CuVectorBase<float> &v) {
+  Vector<float> h(v.Dim());
+  v.CopyToVec(&h);
+  Put(name, 1, v.Dim(), 0, h.Data());
 }
 
 struct Affine {
@@ -129,21 +169,24 @@ struct BatchNorm {
 };
 
 int main(int argc, char **argv) {
-  const double budget = argc > 1 ? atof(argv[1]) : 10.0;
-  const int max_steps = argc > 2 ? atoi(argv[2]) : 20;
+  const bool golden = argc == 3 && !std::strcmp(argv[1], "golden");
+  const double budget = (!golden && argc > 1) ? atof(argv[1]) : 10.0;
+  const int max_steps = (!golden && argc > 2) ? atoi(argv[2]) : 20;
   const int IN = 440, HID = 2048, NH = 5, OUT = 3000, MB = 1024;
-  const float lr = 1e-5f, mmt = 0.0f;
+  const float lr = golden ? 0.008f : 1e-5f, mmt = 0.0f;
+  const unsigned long long state0 = g_state;
   std::vector<Affine> aff(NH + 1);
   std::vector<BatchNorm> bn(NH);
   for (int l = 0; l <= NH; l++) aff[l].Init(l == NH ? OUT : HID, l == 0 ? IN : HID);
   for (int l = 0; l < NH; l++) bn[l].Init(HID);
   Mat x, tgt;
-  Fill(&x, MB, IN, -1.7f, 1.7f);
-  {
+  auto new_batch = [&]() {   // x uniform in [-1.7, 1.7), one label per frame
+    Fill(&x, MB, IN, -1.7f, 1.7f);
     Matrix<float> ht(MB, OUT);
     for (int r = 0; r < MB; r++) ht(r, (int)(Uniform() * OUT) % OUT) = 1.0f;
     tgt.Resize(MB, OUT); tgt.CopyFromMat(ht);
-  }
+  };
+  new_batch();
   Vector<float> fw_host(MB);
   fw_host.Set(1.0);
   std::vector<Mat> a(NH + 1), z(NH), y(NH), da(NH + 1), dz(NH), dy(NH);   // affine out, BN out, sigmoid out and their diffs
@@ -193,6 +236,31 @@ int main(int argc, char **argv) {
       d = &da[l];
     }
   };
+  if (golden) {
+    g_out = std::fopen(argv[2], "wb");
+    if (!g_out) return 1;
+    const int32 rng[2] = {(int32)(state0 & 0xFFFFFFFFull), (int32)(state0 >> 32)};
+    Put("cfg2_rng", 1, 2, 1, rng);
+    const int32 stride = kDigestStride;
+    Put("cfg2_stride", 1, 1, 1, &stride);
+    char nm[32];
+    for (int s = 0; s < 2; s++) {
+      if (s > 0) new_batch();   // (the first batch was drawn behind the weights, above)
+      step();
+      std::snprintf(nm, 32, "cfg2_post%d", s); PutDigest(nm, post);
+      std::snprintf(nm, 32, "cfg2_loss%d", s); Put(nm, 1, 1, 2, &loss, 8);
+      for (int l = 0; l <= NH; l++) {
+        std::snprintf(nm, 32, "cfg2_W%d_%d", l, s + 1); PutDigest(nm, aff[l].W);
+        std::snprintf(nm, 32, "cfg2_b%d_%d", l, s + 1); PutVec(nm, aff[l].b);
+        if (l < NH) {
+          std::snprintf(nm, 32, "cfg2_sc%d_%d", l, s + 1); PutVec(nm, bn[l].scale);
+          std::snprintf(nm, 32, "cfg2_sh%d_%d", l, s + 1); PutVec(nm, bn[l].shift);
+        }
+      }
+    }
+    std::fclose(g_out);
+    return 0;
+  }
   step();  // warm-up (page-in, OpenBLAS thread start)
   const auto t0 = std::chrono::steady_clock::now();
   int steps = 0;

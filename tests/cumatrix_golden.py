@@ -33,10 +33,36 @@ def load_fullwidth():
     return {k[7:]: v for k, v in g.items() if k.startswith("lcfull_")}, state
 
 
-def digest_of(a):
-    """what the generator's digest mode keeps of a tensor: (every 61st element, [sum, sum of squares, count])"""
+def digest_of(a, stride=DIGEST_STRIDE):
+    """what the generators' digest mode keeps of a tensor: (every stride-th element, [sum, sum of squares, count])"""
     f = np.asarray(a, np.float32).ravel()
-    return f[::DIGEST_STRIDE], np.array([f.astype(np.float64).sum(), (f.astype(np.float64) ** 2).sum(), f.size])
+    return f[::stride], np.array([f.astype(np.float64).sum(), (f.astype(np.float64) ** 2).sum(), f.size])
+
+
+CFG2_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dnn_cfg2_fullsize.bin")
+
+
+def load_cfg2_fullsize():
+    """tests/golden/dnn_cfg2_fullsize.bin (`oracle/_ref/ref_dnn_bench golden <file>`): two training steps of BASELINE cfg2 itself -- 440 -> 5 x 2048 +
+    BatchNormalization + Sigmoid -> 3000, minibatch 1024, learn rate 0.008 -- issued on the reference's library in the order of Nnet::Propagate /
+    Backpropagate (oracle/ref_dnn_bench.cpp), as a digest (stride 257).  Returns (records without the prefix, generator state, stride)."""
+    g = {k: (v[0] if v.ndim == 2 and v.shape[0] == 1 else v) for k, v in load(CFG2_PATH).items()}
+    rng = g["cfg2_rng"].astype(np.int64)
+    state = (int(rng[0]) & 0xFFFFFFFF) | ((int(rng[1]) & 0xFFFFFFFF) << 32)
+    return {k[5:]: v for k, v in g.items() if k.startswith("cfg2_")}, state, int(g["cfg2_stride"][0])
+
+
+def replay_cfg2(rng):
+    """the tensors of that fixture in the generator's order: six weight matrices uniform in [-0.07, 0.07), then per step a minibatch uniform in
+    [-1.7, 1.7) and one label per frame ((int)(u * 3000) % 3000 in float32 arithmetic, as ref_dnn_bench.cpp draws it)"""
+    IN, HID, NH, OUT, MB = 440, 2048, 5, 3000, 1024
+    W = [rng.fill((OUT if l == NH else HID, IN if l == 0 else HID), -0.07, 0.07) for l in range(NH + 1)]
+    batches = []
+    for _ in range(2):
+        x = rng.fill((MB, IN), -1.7, 1.7)
+        u = rng.fill((MB,), 0.0, 1.0)
+        batches.append((x, ((u * np.float32(OUT)).astype(np.int32) % OUT).astype(np.int32)))
+    return W, batches
 
 
 COMPONENT_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "component_ops.bin")

@@ -199,6 +199,51 @@ def test_lstm_full_width_two_training_steps_match_reference_library_digest(oracl
     assert clipped > 0      # the clip is active in the fixture
 
 
+def test_dnn_cfg2_full_size_two_training_steps_match_reference_library_digest(oracle):
+    """tests/golden/dnn_cfg2_fullsize.bin: BASELINE cfg2 ITSELF (440 -> 5 x 2048 + BatchNormalization + Sigmoid -> 3000, minibatch 1024, learn rate
+    0.008, momentum 0) through two training steps on fresh minibatches, every operation issued on the reference's library in the order of
+    Nnet::Propagate / Backpropagate with Update behind each component (oracle/ref_dnn_bench.cpp golden mode) -- as a digest.  The oracle's DNN
+    chain, the checker of tests/test_nnet_gpu.py::test_cfg2_full_size_matches_oracle and of bench.py's smoke, lands on the same posteriors,
+    loss and parameters at FULL size."""
+    import ctypes as C
+    g, state, stride = cumatrix_golden.load_cfg2_fullsize()
+    W, batches = cumatrix_golden.replay_cfg2(oracle.GoldenRng(state))
+    d = oracle.lib.orc_dnn_create(440, 2048, 5, 3000, 1, 1024, 1)
+    L = oracle.lib.orc_dnn_num_layers(d)
+    assert L == 6
+
+    def views(l):
+        r, c = C.c_int(), C.c_int()
+        w = np.ctypeslib.as_array(oracle.lib.orc_dnn_weight(d, l, C.byref(r), C.byref(c)), shape=(r.value, c.value))
+        b = np.ctypeslib.as_array(oracle.lib.orc_dnn_bias(d, l), shape=(r.value,))
+        return w, b
+    for l in range(L):
+        w, b = views(l)
+        w[...] = W[l]
+        b[...] = 0.0
+        if l < L - 1:
+            np.ctypeslib.as_array(oracle.lib.orc_dnn_bn_scale(d, l), shape=(2048,))[...] = 1.0
+            np.ctypeslib.as_array(oracle.lib.orc_dnn_bn_shift(d, l), shape=(2048,))[...] = 0.0
+
+    def digest_close(x, key, tol):
+        pick, sums = cumatrix_golden.digest_of(x, stride)
+        return pick.shape == g[key].shape and sums[2] == g[key + "#"][2] and close(pick, g[key], tol) and \
+            abs(sums[1] - g[key + "#"][1]) <= 4 * tol * g[key + "#"][1]
+    for s, (x, lab) in enumerate(batches):
+        loss = oracle.lib.orc_dnn_train_step(d, x, lab, 0.008, 0.0)
+        post = np.ctypeslib.as_array(oracle.lib.orc_dnn_output(d), shape=(1024, 3000))
+        assert digest_close(post, "post%d" % s, 2e-5), s
+        assert abs(loss - g["loss%d" % s]) <= 2e-5 * abs(g["loss%d" % s]), (s, loss, g["loss%d" % s])
+        for l in range(L):
+            w, b = views(l)
+            assert digest_close(w, "W%d_%d" % (l, s + 1), 2e-5), (s, l)
+            assert close(b, g["b%d_%d" % (l, s + 1)], 2e-5), (s, l)
+            if l < L - 1:
+                assert close(np.ctypeslib.as_array(oracle.lib.orc_dnn_bn_scale(d, l), shape=(2048,)), g["sc%d_%d" % (l, s + 1)], 2e-5), (s, l)
+                assert close(np.ctypeslib.as_array(oracle.lib.orc_dnn_bn_shift(d, l), shape=(2048,)), g["sh%d_%d" % (l, s + 1)], 2e-5), (s, l)
+    oracle.lib.orc_dnn_destroy(d)
+
+
 def test_gru_chain_matches_reference_library(oracle):
     """nnet-gru-streams.h:238-450: forward buffer (z|r|m|g|h), backward buffer, input diff and the four gradients."""
     g = cumatrix_golden.load_blas()
