@@ -285,23 +285,25 @@ static void BatchNorm() {
 // BLstmProjectedStreamsLC (nnet-blstm-projected-streams-lc.h:503-1040) = one direction forward in time from the state carried out of the
 // previous chunk + one direction backward in time from zero.  Buffer columns g|i|f|o|c|h|m|r; row block t holds the S streams of
 // frame t; block 0 / T+1 are the boundaries (carried state or zero).  `tag` prefixes the record names.
-static void LstmProjected(const char *tag, bool reverse, bool carried, bool cifg = false, int R = 5, const int *lens = nullptr) {
+static void LstmProjected(const char *tag, bool reverse, bool carried, bool cifg = false, int R = 5, const int *lens = nullptr,
+                          int T = 5, int S = 3, int D = 6, int C = 8, float wr = 0.4f, bool inputs_regenerated = false) {
   // lens (backward-in-time direction of the whole-utterance BLSTMs only): after a frame is computed, the buffer rows of the streams that
   // have already ended are cleared (nnet-blstm-projected-streams.h:654-657, nnet-recurrent-component.cc:1077-1080)
   // cifg: LstmCifgProjectedStreams (nnet-lstm-couple-if-projected-streams.h): no input gate, i = 1 - f, columns g|f|o|c|h|m|r.
   // R = 0: Lstm of nnet-recurrent-component.cc:235-420: no projection, the recurrence runs on m, columns g|i|f|o|c|h|m.
-  const int T = 5, S = 3, D = 6, C = 8;
+  // (T, S, D, C, wr, inputs_regenerated: the full-width digest records of main()'s second mode; the defaults are the small fixture's)
   const int NG = cifg ? 3 : 4, rec_w = R > 0 ? R : C, W = (NG + 3) * C + R;
   Mat Wx, Wr, Wrm, in, od;
   Vec bias, pi, pf, po;
-  Fill(&Wx, NG * C, D, -0.4f, 0.4f); Fill(&Wr, NG * C, rec_w, -0.4f, 0.4f);
-  if (R > 0) Fill(&Wrm, R, C, -0.4f, 0.4f);
+  Fill(&Wx, NG * C, D, -wr, wr); Fill(&Wr, NG * C, rec_w, -wr, wr);
+  if (R > 0) Fill(&Wrm, R, C, -wr, wr);
   FillVec(&bias, NG * C, -0.3f, 0.3f);
   if (!cifg) FillVec(&pi, C, -0.3f, 0.3f);
   FillVec(&pf, C, -0.3f, 0.3f); FillVec(&po, C, -0.3f, 0.3f);
   Fill(&in, T * S, D, -1.5f, 1.5f); Fill(&od, T * S, rec_w, -1.0f, 1.0f);
   char nm[32];
 #define NAME(x) (std::snprintf(nm, 32, "%s_%s", tag, x), nm)
+  g_skip = inputs_regenerated;
   PutMat(NAME("Wx"), Wx); PutMat(NAME("Wr"), Wr);
   if (R > 0) PutMat(NAME("Wrm"), Wrm);
   PutVec(NAME("bias"), bias);
@@ -314,6 +316,7 @@ static void LstmProjected(const char *tag, bool reverse, bool carried, bool cifg
     PutMat(NAME("state"), st);
     Sub(Y, 0, S, 0, W).CopyFromMat(st);
   }
+  g_skip = false;
   const int G = 0, I = cifg ? -1 : 1, F = cifg ? 1 : 2, O = NG - 1, Cc = NG, H = NG + 1, Mm = NG + 2;
   struct View {
     Mat &b; int C, R, S, NG;
@@ -676,6 +679,14 @@ int main(int argc, char **argv) {
     Put("lcfull_rng", 1, 2, 1, rng);
     g_stride = 61;
     LstmProjectedTrain("lcfull", 60, 32, 512, 512, 256, 0.9f, 5.0f, 0.002f, 0.02f, 1.0f, true);
+    // the two directions of BLstmProjectedStreamsLC at the same widths, as the small `lcf` / `lcb` records pin them: forward in time from a
+    // CARRIED state (a whole row block of an earlier chunk), backward in time from zero -- every gate of every frame (forward and backward
+    // buffers), input diff, all gradients; stride 257 (the buffers are 7.6 M floats each).  Appended: the records above stay as they are.
+    g_stride = 257;
+    const int32 rng2[2] = {(int32)(g_state & 0xFFFFFFFFull), (int32)(g_state >> 32)};
+    Put("lcdir_rng", 1, 2, 1, rng2);
+    LstmProjected("lcff", false, true, false, 256, nullptr, 60, 32, 512, 512, 0.02f, true);
+    LstmProjected("lcfb", true, false, false, 256, nullptr, 60, 32, 512, 512, 0.02f, true);
     std::fclose(g_out);
     return 0;
   }

@@ -33,6 +33,19 @@ def load_fullwidth():
     return {k[7:]: v for k, v in g.items() if k.startswith("lcfull_")}, state
 
 
+DIR_STRIDE = 257
+
+
+def load_fullwidth_directions():
+    """the records behind `lcdir_rng` in the same file: the two directions of BLstmProjectedStreamsLC at cfg3's widths -- `lcff` forward in time from a
+    carried state, `lcfb` backward in time from zero (the small `lcf` / `lcb` records of cumatrix_blas_ops.bin at full width), digest stride 257.
+    Returns ({tag: records}, generator state in front of `lcff`)."""
+    g = {k: (v[0] if v.ndim == 2 and v.shape[0] == 1 else v) for k, v in load(FULLWIDTH_PATH).items()}
+    rng = g["lcdir_rng"].astype(np.int64)
+    state = (int(rng[0]) & 0xFFFFFFFF) | ((int(rng[1]) & 0xFFFFFFFF) << 32)
+    return {tag: {k[len(tag) + 1:]: v for k, v in g.items() if k.startswith(tag + "_")} for tag in ("lcff", "lcfb")}, state
+
+
 def digest_of(a, stride=DIGEST_STRIDE):
     """what the generators' digest mode keeps of a tensor: (every stride-th element, [sum, sum of squares, count])"""
     f = np.asarray(a, np.float32).ravel()

@@ -161,6 +161,50 @@ def test_lstm_two_training_steps_with_momentum_and_clipping_match_reference_libr
     assert clipped > 0      # the clip is active in the fixture
 
 
+def test_lc_directions_at_full_width_match_reference_library_digest(oracle):
+    """`lcff` / `lcfb` (tests/golden/lstm_fullwidth.bin): the two directions of BLstmProjectedStreamsLC (nnet-blstm-projected-streams-lc.h:503-1040)
+    at BASELINE cfg3's widths -- C 512, R 256, 512 inputs, S = 32, T = 60 -- as the small `lcf` / `lcb` records pin them: forward in time from a
+    CARRIED state, backward in time from zero; every gate of every frame (forward and backward buffers), input diff and all seven gradients,
+    on the reference's library, as a digest.  With `lcfull` this pins at full width every function the oracle chain of
+    tests/test_cfg3_step_gpu.py is composed of."""
+    recs, state = cumatrix_golden.load_fullwidth_directions()
+    rng = oracle.GoldenRng(state)
+    T, S, D, Cc, R = 60, 32, 512, 512, 256
+    stride = cumatrix_golden.DIR_STRIDE
+    for tag, reverse, carried in (("lcff", False, True), ("lcfb", True, False)):   # (the generator's order: its state runs on from one to the other)
+        g = recs[tag]
+        d = oracle.LstmDir(D, Cc, R, False, zero=True)
+        d.w_x[...] = rng.fill((4 * Cc, D), -0.02, 0.02); d.w_r[...] = rng.fill((4 * Cc, R), -0.02, 0.02); d.w_rm[...] = rng.fill((R, Cc), -0.02, 0.02)
+        d.bias[...] = rng.fill((4 * Cc,), -0.3, 0.3)
+        d.peep_i[...] = rng.fill((Cc,), -0.3, 0.3); d.peep_f[...] = rng.fill((Cc,), -0.3, 0.3); d.peep_o[...] = rng.fill((Cc,), -0.3, 0.3)
+        x, od = rng.fill((T * S, D), -1.5, 1.5), rng.fill((T * S, R), -1.0, 1.0)
+        st = rng.fill((S, d.width), -0.8, 0.8) if carried else None
+
+        def digest_close(a, key, tol):
+            pick, sums = cumatrix_golden.digest_of(a, stride)
+            return pick.shape == g[key].shape and sums[2] == g[key + "#"][2] and close(pick, g[key], tol) and \
+                abs(sums[1] - g[key + "#"][1]) <= 4 * tol * g[key + "#"][1]
+        buf = d.forward(x, T, S, reverse=reverse, init_state=st)
+        # (the boundary row blocks differ by construction where the generator leaves zeros: compare what both define, the frames 1..T -- the
+        #  digest is over the whole buffer, so the oracle's boundary blocks are set to the generator's first)
+        ref_like = np.zeros_like(buf)
+        ref_like[S:(T + 1) * S] = buf[S:(T + 1) * S]
+        if carried:
+            ref_like[:S] = st
+        assert digest_close(ref_like, "fwd_buf", 1e-5), tag
+        dbuf, idf = d.backward(od, T, S, buf, reverse=reverse)
+        dref = np.zeros_like(dbuf)
+        dref[S:(T + 1) * S] = dbuf[S:(T + 1) * S]
+        assert digest_close(dref, "bwd_buf", 2e-5), tag
+        assert digest_close(idf, "in_diff", 2e-5), tag
+        gr = oracle.LstmDir(D, Cc, R, False, zero=True)
+        d.grads(gr, x, T, S, buf, dbuf, 0.0, 0.0, reverse=reverse)
+        for n, k in (("w_x", "gWx"), ("w_r", "gWr"), ("w_rm", "gWrm")):
+            assert digest_close(getattr(gr, n), k, 5e-5), (tag, n)
+        for n, k in (("bias", "gb"), ("peep_i", "gpi"), ("peep_f", "gpf"), ("peep_o", "gpo")):
+            assert close(getattr(gr, n), g[k], 5e-5), (tag, n)
+
+
 def test_lstm_full_width_two_training_steps_match_reference_library_digest(oracle):
     """`lcfull` (tests/golden/lstm_fullwidth.bin): the same two training steps at BASELINE cfg3's widths (C 512, R 256, D 512, S 32, T 60), on the
     reference's library, kept as a digest (every 61st element of a tensor + its sum, sum of squares and size); parameters, inputs and out-diffs
