@@ -570,14 +570,20 @@ static void Gru() {
 }
 
 // RowConvolution: nnet-row-convolution.cc:90-169 (a D x D product per frame whose diagonal is the output), ragged lengths
-static void RowConv() {
-  const int T = 6, S = 2, D = 7, K = 3, Ts = T + K;
-  const int len[2] = {6, 4};
+// (tag, sizes, lengths: the full-size digest records of main()'s third mode; the defaults are the small fixture's)
+static void RowConv(const char *tag = "rc", int T = 6, int S = 2, int D = 7, int K = 3, const int *len_in = nullptr, bool inputs_regenerated = false) {
+  const int Ts = T + K;
+  const int len_small[2] = {6, 4};
+  const int *len = len_in ? len_in : len_small;
+  char nm[32];
+#define NAME(x) (std::snprintf(nm, 32, "%s_%s", tag, x), nm)
   Mat w, in, od, out(T * S, D), in_buf(Ts * S, D), conv(D, D), idb(Ts * S, D), cd(D, K + 1), wdiff(D, K + 1), idf(T * S, D);
   Fill(&w, D, K + 1, -0.8f, 0.8f); Fill(&in, T * S, D, -1.5f, 1.5f); Fill(&od, T * S, D, -1.0f, 1.0f);
-  PutMat("rc_w", w); PutMat("rc_in", in); PutMat("rc_od", od);
-  std::vector<int32> lens(len, len + 2);
-  Put("rc_lens", 1, 2, 1, lens.data());
+  g_skip = inputs_regenerated;
+  PutMat(NAME("w"), w); PutMat(NAME("in"), in); PutMat(NAME("od"), od);
+  g_skip = false;
+  std::vector<int32> lens(len, len + S);
+  Put(NAME("lens"), 1, S, 1, lens.data());
   for (int s = 0; s < S; s++) {
     for (int t = 0; t < len[s] + K; t++) in_buf.Row(s * Ts + t).CopyFromVec(in.Row((t < len[s] ? t : len[s] - 1) * S + s));
     for (int t = 0; t < len[s]; t++) {
@@ -585,7 +591,7 @@ static void RowConv() {
       out.Row(t * S + s).CopyDiagFromMat(conv);
     }
   }
-  PutMat("rc_out", out);
+  PutMat(NAME("out"), out);
   for (int s = 0; s < S; s++)
     for (int t = 0; t < len[s]; t++) {
       Sub yh(in_buf.RowRange(s * Ts + t, K + 1)), yd(idb.RowRange(s * Ts + t, K + 1));
@@ -594,20 +600,25 @@ static void RowConv() {
     }
   for (int s = 0; s < S; s++)
     for (int t = 0; t < len[s]; t++) idf.Row(t * S + s).CopyFromVec(idb.Row(s * Ts + t));
-  PutMat("rc_in_diff", idf); PutMat("rc_w_diff", wdiff);
+  PutMat(NAME("in_diff"), idf); PutMat(NAME("w_diff"), wdiff);
+#undef NAME
 }
 
 // CompactFsmn: nnet-cfsmn-component.h:169-264 (past 3, future 2 taps)
-static void Fsmn() {
-  const int T = 11, D = 9, P = 3, F = 2, C = P + F + 1;
+static void Fsmn(const char *tag = "fsmn", int T = 11, int D = 9, int P = 3, int F = 2, bool inputs_regenerated = false) {
+  const int C = P + F + 1;
+  char nm[32];
+#define NAME(x) (std::snprintf(nm, 32, "%s_%s", tag, x), nm)
   Mat coef, in, od, pad(T + C - 1, D), tmp(T * C, D), out(T, D), corr(C, D), rev(C, D), idf(T, D);
   Fill(&coef, C, D, -0.5f, 0.5f); Fill(&in, T, D, -1.5f, 1.5f); Fill(&od, T, D, -1.0f, 1.0f);
-  PutMat("fsmn_coef", coef); PutMat("fsmn_in", in); PutMat("fsmn_od", od);
+  g_skip = inputs_regenerated;
+  PutMat(NAME("coef"), coef); PutMat(NAME("in"), in); PutMat(NAME("od"), od);
+  g_skip = false;
   pad.RowRange(P, T).CopyFromMat(in);
   tmp.AddConvMatMatElements(1.0, pad, coef, 0.0);
   out.CopyFromMat(in);
   out.AddRowSumMat(1.0, tmp, 1.0);
-  PutMat("fsmn_out", out);
+  PutMat(NAME("out"), out);
   for (int i = 0; i < C; i++) tmp.RowRange(i * T, T).AddMatMatElements(1.0, pad.RowRange(i, T), od, 0.0);
   corr.AddRowSumMat(1.0, tmp, 0.0);
   pad.SetZero();
@@ -616,7 +627,8 @@ static void Fsmn() {
   tmp.AddConvMatMatElements(1.0, pad, rev, 0.0);
   idf.CopyFromMat(od);
   idf.AddRowSumMat(1.0, tmp, 1.0);
-  PutMat("fsmn_in_diff", idf); PutMat("fsmn_corr", corr);
+  PutMat(NAME("in_diff"), idf); PutMat(NAME("corr"), corr);
+#undef NAME
 }
 
 // Xent::Eval: nnet-loss.cc:63-156 -- frames whose target row sums to zero are masked through the frame weights; diff = (y - t) w;
@@ -690,7 +702,23 @@ int main(int argc, char **argv) {
     std::fclose(g_out);
     return 0;
   }
-  if (argc != 2) { std::fprintf(stderr, "usage: %s <out.bin> [lstm_fullwidth]\n", argv[0]); return 1; }
+  if (argc == 3 && !std::strcmp(argv[2], "temporal_fullsize")) {
+    // tests/golden/temporal_fullsize.bin: RowConvolution (512 wide, FutureContext 20, T = 800, S = 32 ragged streams) and CompactFsmn (512 wide,
+    // 30 + 30 taps, T = 800) at the sizes BASELINE cfg5 swaps them in at, on the reference's library (the D x D product per frame of
+    // nnet-row-convolution.cc:128-133 included), as a digest with stride 257; weights, inputs and out-diffs replayed from `tmp_rng`
+    g_out = std::fopen(argv[1], "wb");
+    if (!g_out) return 1;
+    const int32 rng[2] = {(int32)(g_state & 0xFFFFFFFFull), (int32)(g_state >> 32)};
+    Put("tmp_rng", 1, 2, 1, rng);
+    g_stride = 257;
+    std::vector<int> lens(32);
+    for (int i = 0; i < 32; i++) lens[i] = i == 0 ? 800 : 400 + (int)(Uniform() * 401.0f) % 401;   // 400 .. 800 frames, the first one full
+    RowConv("rcfull", 800, 32, 512, 20, lens.data(), true);
+    Fsmn("fsmnfull", 800, 512, 30, 30, true);
+    std::fclose(g_out);
+    return 0;
+  }
+  if (argc != 2) { std::fprintf(stderr, "usage: %s <out.bin> [lstm_fullwidth | temporal_fullsize]\n", argv[0]); return 1; }
   g_out = std::fopen(argv[1], "wb");
   if (!g_out) return 1;
   Operations();

@@ -52,6 +52,26 @@ def digest_of(a, stride=DIGEST_STRIDE):
     return f[::stride], np.array([f.astype(np.float64).sum(), (f.astype(np.float64) ** 2).sum(), f.size])
 
 
+TEMPORAL_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "temporal_fullsize.bin")
+
+
+def load_temporal_fullsize(rng_factory):
+    """tests/golden/temporal_fullsize.bin (`oracle/_ref/gen_cumatrix_blas_golden <file> temporal_fullsize`): RowConvolution (512 wide, FutureContext
+    20, T = 800, S = 32 ragged streams) and CompactFsmn (512 wide, 30 + 30 taps, T = 800) on the reference's library, digest stride 257.
+    rng_factory(state) -> oracle_lib.GoldenRng.  Returns (rc records, fsmn records, replayed tensors) in the generator's order: 31 length
+    draws, then w / in / od of RowConvolution, then coef / in / od of CompactFsmn."""
+    g = {k: (v[0] if v.ndim == 2 and v.shape[0] == 1 else v) for k, v in load(TEMPORAL_PATH).items()}
+    st = g["tmp_rng"].astype(np.int64)
+    rng = rng_factory((int(st[0]) & 0xFFFFFFFF) | ((int(st[1]) & 0xFFFFFFFF) << 32))
+    u = rng.fill((31,), 0.0, 1.0)
+    lens = np.concatenate([[800], 400 + (u * np.float32(401.0)).astype(np.int32) % 401]).astype(np.int32)
+    rc = {k[7:]: v for k, v in g.items() if k.startswith("rcfull_")}
+    assert np.array_equal(rc["lens"], lens)
+    tens = dict(lens=lens, rc_w=rng.fill((512, 21), -0.8, 0.8), rc_in=rng.fill((800 * 32, 512), -1.5, 1.5), rc_od=rng.fill((800 * 32, 512), -1.0, 1.0),
+                fsmn_coef=rng.fill((61, 512), -0.5, 0.5), fsmn_in=rng.fill((800, 512), -1.5, 1.5), fsmn_od=rng.fill((800, 512), -1.0, 1.0))
+    return rc, {k[9:]: v for k, v in g.items() if k.startswith("fsmnfull_")}, tens
+
+
 CFG2_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dnn_cfg2_fullsize.bin")
 
 

@@ -336,6 +336,32 @@ def test_compact_fsmn_chain_matches_reference_library(oracle):
     assert close(idf, g["fsmn_in_diff"], 2e-6) and close(f.corr, g["fsmn_corr"], 5e-6)
 
 
+def test_temporal_components_at_full_size_match_reference_library_digest(oracle):
+    """tests/golden/temporal_fullsize.bin: RowConvolution (512, FutureContext 20, T = 800, S = 32 ragged streams) and CompactFsmn (512, 30 + 30 taps,
+    T = 800) at the sizes BASELINE cfg5 swaps them in at, on the reference's library -- the D x D product per frame of
+    nnet-row-convolution.cc:128-133 and the materialised T x 61 product of nnet-cfsmn-component.h:191-201 included -- as a digest: the oracle's
+    direct filters (oracle/aslp_oracle_temporal.c), the checker of tests/test_temporal_gpu.py, land on the same outputs, input diffs and tap
+    gradients."""
+    rc, fs, t = cumatrix_golden.load_temporal_fullsize(oracle.GoldenRng)
+    stride = cumatrix_golden.DIR_STRIDE
+
+    def digest_close(a, g, key, tol):
+        pick, sums = cumatrix_golden.digest_of(a, stride)
+        return pick.shape == g[key].shape and sums[2] == g[key + "#"][2] and close(pick, g[key], tol) and \
+            abs(sums[1] - g[key + "#"][1]) <= 4 * tol * g[key + "#"][1]
+    m = oracle.RowConv(512, 20, np.random.default_rng(0))
+    m.w[...] = t["rc_w"]
+    assert digest_close(m.propagate(t["rc_in"], 800, 32, t["lens"]), rc, "out", 1e-5)
+    idf = m.backpropagate(t["rc_od"], 800, 32, t["lens"])
+    assert digest_close(idf, rc, "in_diff", 1e-5)
+    assert digest_close(m.w_diff, rc, "w_diff", 1e-4)     # sums over ~19,000 frames of products up to 1.5: a few units in the seventh digit
+    f = oracle.Fsmn(512, 30, 30, np.random.default_rng(0))
+    f.coef[...] = t["fsmn_coef"]
+    assert digest_close(f.propagate(t["fsmn_in"]), fs, "out", 1e-5)
+    assert digest_close(f.backpropagate(t["fsmn_in"], t["fsmn_od"], 0.0), fs, "in_diff", 1e-5)
+    assert digest_close(f.corr, fs, "corr", 5e-5)
+
+
 def test_xent_eval_chain_matches_reference_library(oracle):
     """Xent::Eval, nnet-loss.cc:63-156: a zero-weight frame, a frame without a target (masked), a soft posterior; the diff and the five
     sums {frames, correct, loss, entropy, likelihood}."""

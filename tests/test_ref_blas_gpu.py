@@ -303,6 +303,39 @@ def test_compact_fsmn_component_matches_reference_library(aslp, dev, tmp_path):
     assert close(net.GetParams(), (coef - 0.1 * g["fsmn_corr"]).ravel(), 5e-6)
 
 
+def test_temporal_components_at_full_size_match_reference_library(aslp, oracle, dev, tmp_path):
+    """tests/golden/temporal_fullsize.bin: the streaming RowConvolution kernels and the LDS-tiled CompactFsmn kernels (csrc/temporal.hip, round 5) at
+    the sizes BASELINE cfg5 swaps the components in at, against the reference's library directly: output, input diff, and the taps after one
+    step (learn rate 0.01, momentum 0) = w - 0.01 x the library's gradient."""
+    rc, fs, t = cumatrix_golden.load_temporal_fullsize(oracle.GoldenRng)
+    stride = cumatrix_golden.DIR_STRIDE
+
+    def digest_close(a, g, key, tol):
+        pick, sums = cumatrix_golden.digest_of(a, stride)
+        assert pick.shape == g[key].shape and sums[2] == g[key + "#"][2], key
+        return close(pick, g[key], tol) and rel(pick, g[key]) <= tol and abs(sums[1] - g[key + "#"][1]) <= 4 * tol * g[key + "#"][1]
+    path = tmp_path / "rc.nnet"
+    nnet_io.write_simple_nnet(path, [("<RowConvolution>", 512, 512, nnet_io.rowconv(t["rc_w"]))])
+    net = aslp.Nnet.Read(path)
+    net.SetTrainOptions(learn_rate=0.01, momentum=0.0)
+    net.SetSeqLengths(t["lens"])
+    assert digest_close(net.Propagate(T(t["rc_in"], dev)).cpu().numpy(), rc, "out", 1e-4)
+    assert digest_close(net.Backpropagate(T(t["rc_od"], dev), want_in_diff=True).cpu().numpy(), rc, "in_diff", 1e-4)
+    # the applied update, read back as (w_before - w_after) / lr, against the library's gradient digest
+    applied = (t["rc_w"].ravel().astype(np.float64) - net.GetParams()) / 0.01
+    pick, _ = cumatrix_golden.digest_of(applied.astype(np.float32), stride)
+    assert rel(pick, rc["w_diff"]) <= 1e-4 + 2.0 ** -22 * np.abs(t["rc_w"]).max() / 0.01 / np.abs(rc["w_diff"]).mean(), rel(pick, rc["w_diff"])
+    path = tmp_path / "fsmn.nnet"
+    nnet_io.write_simple_nnet(path, [("<CompactFsmn>", 512, 512, nnet_io.fsmn(t["fsmn_coef"], 30, 30))])
+    net = aslp.Nnet.Read(path)
+    net.SetTrainOptions(learn_rate=0.01, momentum=0.0)
+    assert digest_close(net.Propagate(T(t["fsmn_in"], dev)).cpu().numpy(), fs, "out", 1e-4)
+    assert digest_close(net.Backpropagate(T(t["fsmn_od"], dev), want_in_diff=True).cpu().numpy(), fs, "in_diff", 1e-4)
+    applied = (t["fsmn_coef"].ravel().astype(np.float64) - net.GetParams()) / 0.01
+    pick, _ = cumatrix_golden.digest_of(applied.astype(np.float32), stride)
+    assert rel(pick, fs["corr"]) <= 1e-4 + 2.0 ** -22 * np.abs(t["fsmn_coef"]).max() / 0.01 / np.abs(fs["corr"]).mean(), rel(pick, fs["corr"])
+
+
 @pytest.mark.parametrize("tag,marker,cifg", [("cifg", "<LstmCifgProjectedStreams>", True), ("lstmnp", "<Lstm>", False)])
 def test_other_lstm_components_match_reference_library(aslp, oracle, dev, tmp_path, tag, marker, cifg):
     """LstmCifgProjectedStreams (nnet-lstm-couple-if-projected-streams.h) and Lstm (nnet-recurrent-component.cc:235-420): output,
