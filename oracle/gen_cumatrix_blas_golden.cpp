@@ -517,13 +517,16 @@ static void LstmProjectedTrain(const char *tag, int T, int S, int D, int C, int 
 }
 
 // GruStreams: nnet-gru-streams.h:238-450.  Buffer columns z|r|m|g|h; row blocks as above.
-static void Gru() {
-  const int T = 5, S = 3, D = 6, H = 7;
+static void Gru(const char *tag = "gru", int T = 5, int S = 3, int D = 6, int H = 7, float wr = 0.4f, bool inputs_regenerated = false) {
+  char nm[32];
+#define NAME(x) (std::snprintf(nm, 32, "%s_%s", tag, x), nm)
   Mat Wx, Wh, Wg, in, od;
   Vec bias;
-  Fill(&Wx, 3 * H, D, -0.4f, 0.4f); Fill(&Wh, 2 * H, H, -0.4f, 0.4f); Fill(&Wg, H, H, -0.4f, 0.4f); FillVec(&bias, 3 * H, -0.3f, 0.3f);
+  Fill(&Wx, 3 * H, D, -wr, wr); Fill(&Wh, 2 * H, H, -wr, wr); Fill(&Wg, H, H, -wr, wr); FillVec(&bias, 3 * H, -0.3f, 0.3f);
   Fill(&in, T * S, D, -1.5f, 1.5f); Fill(&od, T * S, H, -1.0f, 1.0f);
-  PutMat("gru_Wx", Wx); PutMat("gru_Wh", Wh); PutMat("gru_Wg", Wg); PutVec("gru_bias", bias); PutMat("gru_in", in); PutMat("gru_od", od);
+  g_skip = inputs_regenerated;
+  PutMat(NAME("Wx"), Wx); PutMat(NAME("Wh"), Wh); PutMat(NAME("Wg"), Wg); PutVec(NAME("bias"), bias); PutMat(NAME("in"), in); PutMat(NAME("od"), od);
+  g_skip = false;
   Mat Y((T + 2) * S, 5 * H), Dd((T + 2) * S, 5 * H);
   enum { Z, Rr, Mm, G, Hh };
   struct View {
@@ -542,7 +545,7 @@ static void Gru() {
     y.col(Hh, t).AddMatMatElements(-1.0, y.col(Hh, t - 1), y.col(Z, t), 1.0);
     y.col(Hh, t).AddMatMatElements(1.0, y.col(Z, t), y.col(Mm, t), 1.0);
   }
-  PutMat("gru_fwd_buf", Y);
+  PutMat(NAME("fwd_buf"), Y);
   d.col(Hh, 1, T).CopyFromMat(od);
   for (int t = T; t >= 1; t--) {
     d.col(Hh, t).AddMatMat(1.0, d.col(Z, t + 1, 1, 2), kNoTrans, Wh, kNoTrans, 1.0);
@@ -558,7 +561,7 @@ static void Gru() {
     d.col(Z, t).AddMatMatElements(-1.0, d.col(Hh, t), y.col(Hh, t - 1), 1.0);
     d.col(Z, t).DiffSigmoid(y.col(Z, t), d.col(Z, t));
   }
-  PutMat("gru_bwd_buf", Dd);
+  PutMat(NAME("bwd_buf"), Dd);
   Mat id(T * S, D), gWx(3 * H, D), gWh(2 * H, H), gWg(H, H);
   Vec gb(3 * H);
   id.AddMatMat(1.0, d.col(Z, 1, T, 3), kNoTrans, Wx, kNoTrans, 0.0);
@@ -566,7 +569,8 @@ static void Gru() {
   gb.AddRowSumMat(1.0, d.col(Z, 1, T, 3), 0.0);
   gWh.AddMatMat(1.0, d.col(Z, 1, T, 2), kTrans, y.col(Hh, 0, T), kNoTrans, 0.0);
   gWg.AddMatMat(1.0, d.col(Mm, 1, T), kTrans, y.col(G, 1, T), kNoTrans, 0.0);
-  PutMat("gru_in_diff", id); PutMat("gru_gWx", gWx); PutMat("gru_gWh", gWh); PutMat("gru_gWg", gWg); PutVec("gru_gb", gb);
+  PutMat(NAME("in_diff"), id); PutMat(NAME("gWx"), gWx); PutMat(NAME("gWh"), gWh); PutMat(NAME("gWg"), gWg); PutVec(NAME("gb"), gb);
+#undef NAME
 }
 
 // RowConvolution: nnet-row-convolution.cc:90-169 (a D x D product per frame whose diagonal is the output), ragged lengths
@@ -715,6 +719,8 @@ int main(int argc, char **argv) {
     for (int i = 0; i < 32; i++) lens[i] = i == 0 ? 800 : 400 + (int)(Uniform() * 401.0f) % 401;   // 400 .. 800 frames, the first one full
     RowConv("rcfull", 800, 32, 512, 20, lens.data(), true);
     Fsmn("fsmnfull", 800, 512, 30, 30, true);
+    // GruStreams 512 -> 512 (cfg5's swap), S = 32 streams, T = 60 frames: every gate of every frame, input diff, the four gradients (appended)
+    Gru("grufull", 60, 32, 512, 512, 0.03f, true);
     std::fclose(g_out);
     return 0;
   }

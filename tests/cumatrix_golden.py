@@ -69,6 +69,10 @@ def load_temporal_fullsize(rng_factory):
     assert np.array_equal(rc["lens"], lens)
     tens = dict(lens=lens, rc_w=rng.fill((512, 21), -0.8, 0.8), rc_in=rng.fill((800 * 32, 512), -1.5, 1.5), rc_od=rng.fill((800 * 32, 512), -1.0, 1.0),
                 fsmn_coef=rng.fill((61, 512), -0.5, 0.5), fsmn_in=rng.fill((800, 512), -1.5, 1.5), fsmn_od=rng.fill((800, 512), -1.0, 1.0))
+    # behind them: GruStreams 512 -> 512, S = 32, T = 60 (`grufull`): W_x [3H x D], W_h [2H x H], W_g [H x H] in [-0.03, 0.03), bias, in, od
+    tens.update(gru_Wx=rng.fill((1536, 512), -0.03, 0.03), gru_Wh=rng.fill((1024, 512), -0.03, 0.03), gru_Wg=rng.fill((512, 512), -0.03, 0.03),
+                gru_bias=rng.fill((1536,), -0.3, 0.3), gru_in=rng.fill((60 * 32, 512), -1.5, 1.5), gru_od=rng.fill((60 * 32, 512), -1.0, 1.0))
+    tens["gru"] = {k[8:]: v for k, v in g.items() if k.startswith("grufull_")}
     return rc, {k[9:]: v for k, v in g.items() if k.startswith("fsmnfull_")}, tens
 
 

@@ -362,6 +362,35 @@ def test_temporal_components_at_full_size_match_reference_library_digest(oracle)
     assert digest_close(f.corr, fs, "corr", 5e-5)
 
 
+def test_gru_at_full_width_matches_reference_library_digest(oracle):
+    """`grufull` (tests/golden/temporal_fullsize.bin): GruStreams 512 -> 512 (BASELINE cfg5's swap), S = 32 streams, T = 60, on the reference's library
+    (nnet-gru-streams.h:238-450): forward buffer (z|r|m|g|h of every frame), backward buffer, input diff and the four gradients, as a digest."""
+    _, _, t = cumatrix_golden.load_temporal_fullsize(oracle.GoldenRng)
+    g, stride = t["gru"], cumatrix_golden.DIR_STRIDE
+    T, S, D, H = 60, 32, 512, 512
+
+    def digest_close(a, key, tol):
+        pick, sums = cumatrix_golden.digest_of(a, stride)
+        return pick.shape == g[key].shape and sums[2] == g[key + "#"][2] and close(pick, g[key], tol) and \
+            abs(sums[1] - g[key + "#"][1]) <= 4 * tol * g[key + "#"][1]
+    u = oracle.Gru(D, H, zero=True)
+    for n, k in (("w_zrm_x", "gru_Wx"), ("w_zr_h", "gru_Wh"), ("w_m_g", "gru_Wg"), ("bias", "gru_bias")):
+        getattr(u, n)[...] = t[k]
+    buf = u.forward(t["gru_in"], T, S)
+    ref_like = np.zeros_like(buf)
+    ref_like[S:(T + 1) * S] = buf[S:(T + 1) * S]       # (the boundary row blocks are zero in the generator's buffer)
+    assert digest_close(ref_like, "fwd_buf", 1e-5)
+    dbuf, idf = u.backward(t["gru_od"], T, S, buf)
+    dref = np.zeros_like(dbuf)
+    dref[S:(T + 1) * S] = dbuf[S:(T + 1) * S]
+    assert digest_close(dref, "bwd_buf", 2e-5) and digest_close(idf, "in_diff", 2e-5)
+    gr = oracle.Gru(D, H, zero=True)
+    u.grads(gr, t["gru_in"], T, S, buf, dbuf, 0.0, 0.0)
+    for n, k in (("w_zrm_x", "gWx"), ("w_zr_h", "gWh"), ("w_m_g", "gWg")):
+        assert digest_close(getattr(gr, n), k, 5e-5), n
+    assert close(gr.bias, g["gb"], 5e-5)
+
+
 def test_xent_eval_chain_matches_reference_library(oracle):
     """Xent::Eval, nnet-loss.cc:63-156: a zero-weight frame, a frame without a target (masked), a soft posterior; the diff and the five
     sums {frames, correct, loss, entropy, likelihood}."""
