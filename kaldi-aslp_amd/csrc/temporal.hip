@@ -416,10 +416,10 @@ __device__ __forceinline__ void ring_block8(float (&acc)[8], float (&win)[8], co
 static_assert(TT == 8, "ring_block8 is written for windows of 8");
 
 // rows [r0, r0 + n) of a [T x D] matrix into an LDS tile of 64 columns (zeros outside the matrix; `spare` further rows of zeros), and -- with
-// taps != nullptr -- the C taps (reversed: tap j is coef row C - 1 - j) into theirs, by the whole workgroup.  Up to 24 rows and 16 taps per
-// thread and round (96 rows, 64 taps: the usual tile in one round); 32-bit element offsets from the scalar bases, one address register per
+// taps != nullptr -- the C taps (reversed: tap j is coef row C - 1 - j) into theirs, by the whole workgroup.  Up to 26 rows and 16 taps per
+// thread and round (104 rows, 64 taps: the 100 rows of a 30 + 30-tap tile in one round); 32-bit element offsets from the scalar bases, one address register per
 // load -- the launchers check that they fit.
-constexpr int kStageU = 24, kStageTapsU = 16;
+constexpr int kStageU = 26, kStageTapsU = 16;
 __device__ __forceinline__ void stage_rows_and_taps(float *__restrict__ tile, const float *__restrict__ src, int ld, int r0, int n, int spare, int T,
                                                     float *__restrict__ taps, const float *__restrict__ coef, int ldc, int C, bool reversed, bool col_ok, int d,
                                                     int x, int y) {
@@ -512,7 +512,7 @@ __global__ void __launch_bounds__(kBlock) fsmn_backward_fused(float *__restrict_
   const int chunk = blockIdx.y, ta = chunk * kFsmnFrames, tb = min(T, ta + kFsmnFrames), rows = kFsmnFrames + C - 1;
   float *odt = sm, *int_ = odt + (long)(rows + kFsmnSpare) * kWave, *taps = int_ + (long)(rows + kFsmnSpare) * kWave;   // (taps: C + kFsmnSpare rows)
   const bool col_ok = d < D;
-  // the in rows are needed behind the in-diff only: their loads (up to 24 per thread; more go the plain way below) leave with the od tile's
+  // the in rows are needed behind the in-diff only: their loads (up to 26 per thread; more go the plain way below) leave with the od tile's
   // and reach LDS when the in-diff is done
   float vin[kStageU];
 #pragma unroll
