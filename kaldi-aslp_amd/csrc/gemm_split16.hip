@@ -108,13 +108,42 @@ struct ConvJob { const float *src; int ld_src; S16View pl; const float *part; in
 struct ConvJobs { ConvJob j[kS16MaxJobs]; };
 __global__ void __launch_bounds__(256) split16_convert_kernel(ConvJobs jobs, int tw_log2) {
   const ConvJob j = jobs.j[blockIdx.y];
-  const unsigned mbits = __float_as_uint(reduce_parts(j.part, j.nparts));
-  if (blockIdx.x == 0 && threadIdx.x == 0) *j.pl.slot = mbits;   // for the products (launched behind this kernel)
-  const float s = ldexpf(1.f, s16_exponent(mbits));
   const int k8 = j.pl.ld >> 3, tw = 1 << tw_log2, rpw = 256 >> tw_log2;   // ld is a multiple of 64
   const int tr = threadIdx.x >> tw_log2, tc = threadIdx.x & (tw - 1);
   const int rows_p = (j.pl.rows + kS16Pad - 1) / kS16Pad * kS16Pad;
   const int per = (rows_p + gridDim.x - 1) / gridDim.x, r0 = blockIdx.x * per, r1 = min(rows_p, r0 + per);
+  // A workgroup's share of a minibatch-sized matrix is a few 8-column pieces per thread: their loads go out before the maximum is read, so
+  // the kernel is one round trip to memory deep instead of one for the partial maxima and one per row pass.
+  constexpr int kPre = 4;
+  const int units = max(r1 - r0, 0) * k8;
+  if (units <= kPre * 256) {
+    float4 a[kPre][2];
+#pragma unroll
+    for (int i = 0; i < kPre; i++) {
+      const int u = (int)threadIdx.x + i * 256, ur = u / k8, r = r0 + ur, c = u - ur * k8;
+      const bool ok = u < units && r < j.pl.rows;
+      const float *row = j.src + (long)r * j.ld_src;
+      a[i][0] = ok && 8 * c < j.pl.cols ? *reinterpret_cast<const float4 *>(row + 8 * c) : float4{0.f, 0.f, 0.f, 0.f};
+      a[i][1] = ok && 8 * c + 4 < j.pl.cols ? *reinterpret_cast<const float4 *>(row + 8 * c + 4) : float4{0.f, 0.f, 0.f, 0.f};
+    }
+    const unsigned mbits = __float_as_uint(reduce_parts(j.part, j.nparts));
+    if (blockIdx.x == 0 && threadIdx.x == 0) *j.pl.slot = mbits;
+    const float s = ldexpf(1.f, s16_exponent(mbits));
+#pragma unroll
+    for (int i = 0; i < kPre; i++) {
+      const int u = (int)threadIdx.x + i * 256, ur = u / k8, r = r0 + ur, c = u - ur * k8;
+      if (u >= units) break;
+      half4 h0, l0, h1, l1;
+      s16_split4(a[i][0], s, &h0, &l0);   // (padding: zeros split into zeros)
+      s16_split4(a[i][1], s, &h1, &l1);
+      *reinterpret_cast<half8 *>(j.pl.hi + (long)r * j.pl.ld + 8 * c) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+      *reinterpret_cast<half8 *>(j.pl.lo + (long)r * j.pl.ld + 8 * c) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+    return;
+  }
+  const unsigned mbits = __float_as_uint(reduce_parts(j.part, j.nparts));
+  if (blockIdx.x == 0 && threadIdx.x == 0) *j.pl.slot = mbits;   // for the products (launched behind this kernel)
+  const float s = ldexpf(1.f, s16_exponent(mbits));
   for (int r = r0 + tr; r < r1; r += rpw) {
     const float *row = j.src + (long)r * j.ld_src;
     const bool row_ok = r < j.pl.rows;

@@ -245,6 +245,7 @@ __global__ void __launch_bounds__(kPanelThreads) bn_forward_panel(const float *_
     const int r = lane + k * L;
     x[k] = load4_rows(in, ldi, r, rows, c);
   }
+  const float4 g = *reinterpret_cast<const float4 *>(scale + c), b = *reinterpret_cast<const float4 *>(shift + c);   // (in the rows' round trip)
   double acc[3][4] = {};
 #pragma unroll
   for (int k = 0; k < SLOTS; k++) {
@@ -273,7 +274,6 @@ __global__ void __launch_bounds__(kPanelThreads) bn_forward_panel(const float *_
     stat[1][pc] = is;
   }
   __syncthreads();
-  const float4 g = *reinterpret_cast<const float4 *>(scale + c), b = *reinterpret_cast<const float4 *>(shift + c);
   const float4 m = *reinterpret_cast<const float4 *>(&stat[0][cg * 4]), is = *reinterpret_cast<const float4 *>(&stat[1][cg * 4]);
 #pragma unroll
   for (int k = 0; k < SLOTS; k++) {
@@ -455,6 +455,7 @@ __global__ void __launch_bounds__(kPanelThreads) bn_forward_coop(const float *__
     const int r = r0 + lane + k * L;
     x[k] = load4_rows(in, ldi, r, r1, c);
   }
+  const float4 g = *reinterpret_cast<const float4 *>(scale + c), b = *reinterpret_cast<const float4 *>(shift + c);   // (in the rows' round trip)
   double acc[3][4] = {};
 #pragma unroll
   for (int k = 0; k < SLOTS; k++) {
@@ -494,7 +495,6 @@ __global__ void __launch_bounds__(kPanelThreads) bn_forward_coop(const float *__
     stat[1][pc] = is;
   }
   __syncthreads();
-  const float4 g = *reinterpret_cast<const float4 *>(scale + c), b = *reinterpret_cast<const float4 *>(shift + c);
   const float4 m = *reinterpret_cast<const float4 *>(&stat[0][cg * 4]), is = *reinterpret_cast<const float4 *>(&stat[1][cg * 4]);
 #pragma unroll
   for (int k = 0; k < SLOTS; k++) {
@@ -538,13 +538,25 @@ __global__ void __launch_bounds__(kPanelThreads) bn_forward_stats_kernel(const f
     const int r = r0 + lane + k * L;
     x[k] = load4_rows(in, ldi, r, r1, c);
   }
+  // everything else this workgroup reads goes out behind them in the same round: scale and shift, the planes' bound, and the statistics'
+  // partial sums four groups at a time (a loop that adds one group per iteration is one round trip to L2 per iteration)
+  const float4 g = *reinterpret_cast<const float4 *>(scale + c), b = *reinterpret_cast<const float4 *>(shift + c);
+  const unsigned bound_bits = po.hi ? *po.slot : 0u;
   {
     const int pc = threadIdx.x % COLS, sl = threadIdx.x / COLS, col = p * COLS + pc;
     const long plane = (long)groups * ldp;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    for (int gi = sl; gi < groups; gi += SL) {
-      const double *pp = part + (long)gi * ldp + col;
-      s0 += pp[0]; s1 += pp[plane]; s2 += pp[2 * plane];
+    for (int g0 = sl; g0 < groups; g0 += 4 * SL) {
+      double v[4][3];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int gi = g0 + u * SL;
+        const double *pp = part + (long)(gi < groups ? gi : g0) * ldp + col;
+        v[u][0] = pp[0]; v[u][1] = pp[plane]; v[u][2] = pp[2 * plane];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (g0 + u * SL < groups) { s0 += v[u][0]; s1 += v[u][1]; s2 += v[u][2]; }   // (group order, as before)
     }
     red[0][sl][pc] = s0; red[1][sl][pc] = s1; red[2][sl][pc] = s2;
   }
@@ -569,8 +581,8 @@ __global__ void __launch_bounds__(kPanelThreads) bn_forward_stats_kernel(const f
     stat[1][pc] = is;
   }
   __syncthreads();
-  const float4 g = *reinterpret_cast<const float4 *>(scale + c), b = *reinterpret_cast<const float4 *>(shift + c);
   const float4 m = *reinterpret_cast<const float4 *>(&stat[0][cg * 4]), is = *reinterpret_cast<const float4 *>(&stat[1][cg * 4]);
+  const float pscale = po.hi ? ldexpf(1.f, s16_exponent(bound_bits)) : 0.f;
 #pragma unroll
   for (int k = 0; k < kStatSlots; k++) {
     const int r = r0 + lane + k * L;
@@ -585,7 +597,7 @@ __global__ void __launch_bounds__(kPanelThreads) bn_forward_stats_kernel(const f
       *reinterpret_cast<float4 *>(act + (long)r * lda + c) = y;
       if (po.hi) {   // the planes of the activations for the products that read them (bound: a sigmoid's 1)
         half4 hi, lo;
-        s16_split4(y, ldexpf(1.f, s16_exponent(*po.slot)), &hi, &lo);
+        s16_split4(y, pscale, &hi, &lo);
         *reinterpret_cast<half4 *>(po.hi + (long)r * po.ld + c) = hi;
         *reinterpret_cast<half4 *>(po.lo + (long)r * po.ld + c) = lo;
       }
@@ -617,8 +629,17 @@ __global__ void __launch_bounds__(kPanelThreads) bn_backward_coop(const float *_
     if (RECOMPUTE) h[k] = load4_rows(xin, ldxin, r, r1, c);
     else h[k] = load4_rows(xhat, ldx, r, r1, c);
   }
+  // the per-column values go out in the rows' round trip (a load issued where its value is first used costs a trip to L2 of its own there).
+  // The scale the forward pass used: workgroup q == 0 rewrites it (the folded SGD step) only after it has seen every partial of the panel,
+  // and a workgroup publishes its partial only after this load has returned (the wait in front of the exchange).
+  const float4 iv4 = *reinterpret_cast<const float4 *>(inv_std + c);
+  const bool col_thread = threadIdx.x < 4 * CG;
+  const int my_col = p * CG * 4 + (int)threadIdx.x;
+  const float g_fwd = col_thread ? scale[my_col] : 0.f;
+  const float dsh_old = col_thread && q == 0 ? dshift[my_col] : 0.f, dsc_old = col_thread && q == 0 ? dscale[my_col] : 0.f;
+  const float sh_old = col_thread && q == 0 && step ? shift[my_col] : 0.f;
   if (RECOMPUTE) {
-    const float4 m = *reinterpret_cast<const float4 *>(mean + c), is = *reinterpret_cast<const float4 *>(inv_std + c);
+    const float4 m = *reinterpret_cast<const float4 *>(mean + c), is = iv4;
 #pragma unroll
     for (int k = 0; k < SLOTS; k++) {
       const int r = r0 + lane + k * L;
@@ -649,10 +670,8 @@ __global__ void __launch_bounds__(kPanelThreads) bn_backward_coop(const float *_
     unsigned long long mine[1], got[8][1];
     const float p1 = panel_total<float, 2, CG>(red, 0, pc), p2 = panel_total<float, 2, CG>(red, 1, pc);
     mine[0] = ((unsigned long long)__float_as_uint(p2) << 32) | (unsigned long long)__float_as_uint(p1);   // one granule: {S2, S1}
-    // The scale the forward pass used is fetched BEFORE this workgroup publishes its partial: workgroup q == 0 rewrites it
-    // (the folded SGD step) only after it has seen every partial of the panel, i.e. after every workgroup holds its copy.
-    const float g = scale[col];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const float g = g_fwd;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (g_fwd has landed before the partial is published; see the top)
     coop_exchange<1>(inbox, P, Q, p, q, pc, mine, got, err);
     float s1 = 0.f, s2 = 0.f;
     for (int qw = 0; qw < Q; qw++) { s1 += __uint_as_float((unsigned)got[qw][0]); s2 += __uint_as_float((unsigned)(got[qw][0] >> 32)); }
@@ -660,19 +679,18 @@ __global__ void __launch_bounds__(kPanelThreads) bn_backward_coop(const float *_
     stat[1][pc] = s2;
     stat[2][pc] = g;
     if (q == 0) {
-      const float dsh = s1 + mmt * dshift[col], dsc = s2 + mmt * dscale[col];
+      const float dsh = s1 + mmt * dsh_old, dsc = s2 + mmt * dsc_old;
       dshift[col] = dsh;
       dscale[col] = dsc;
       if (step) {
         scale[col] = g + neg_lr * dsc;
-        shift[col] += neg_lr * dsh;
+        shift[col] = sh_old + neg_lr * dsh;
       }
     }
   }
   __syncthreads();
   const float invB = 1.0f / (float)rows;
   if (in_diff != nullptr) {
-    const float4 iv4 = *reinterpret_cast<const float4 *>(inv_std + c);
     const float iv[4] = {iv4.x, iv4.y, iv4.z, iv4.w};
     float gv[4], ca[4], cb[4];  // per column: in_diff = D*inv + xm * ca + cb
 #pragma unroll
