@@ -168,6 +168,8 @@ typedef struct aslp_planes_out_ {
   const unsigned *slot;   /* device word: bits of the bound (float) the planes are scaled by */
   float *parts;           /* device, 256 floats: per-workgroup maxima, or NULL */
   int nparts;             /* out: how many the launch wrote (0: none, the kernel that ran does not leave them) */
+  int planes_written;     /* out: 1 = the launch found the matrix' maximum itself, stored its bits to *slot and wrote hi / lo scaled by it
+                           * (a kernel whose output has no bound known before the launch: aslp_bn_backward_step_p); parts are not left then */
 } aslp_planes_out;
 /* Fused epilogue form.  Applied in this order on the fp32 accumulator `acc`:
  *   v = alpha*acc + beta*C;  if (bias) v += bias[col];  if (clip > 0) v = clamp(v, -clip, clip);

@@ -21,7 +21,7 @@ class Dim3(C.Structure):
 
 class PlanesOut(C.Structure):
     """aslp_planes_out (include/aslp_kernels.h)"""
-    _fields_ = [("hi", C.c_void_p), ("lo", C.c_void_p), ("ld", C.c_int), ("slot", C.c_void_p), ("parts", C.c_void_p), ("nparts", C.c_int)]
+    _fields_ = [("hi", C.c_void_p), ("lo", C.c_void_p), ("ld", C.c_int), ("slot", C.c_void_p), ("parts", C.c_void_p), ("nparts", C.c_int), ("planes_written", C.c_int)]
 
 
 class GemmEpilogue(C.Structure):
@@ -137,6 +137,8 @@ _sig("aslp_gemm_split16", None, _i)
 _sig("aslp_planes_new", _vp)
 _sig("aslp_planes_free", None, _vp)
 _sig("aslp_planes_convert", _i, _vp, _vp, _md)
+_sig("aslp_planes_reserve", None, _vp, _i, _i)
+_sig("aslp_planes_as_output", None, _vp, C.POINTER(PlanesOut))
 _sig("aslp_sgemm_planes_ex", _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _vp, _i, _vp, _f, _vp, _i, C.POINTER(GemmEpilogue))
 _sig("aslp_gemm_last_parts", _i)
 _sig("aslp_params_changed", None)
@@ -170,6 +172,7 @@ _sig("aslp_bn_forward_act", None, _vp, _md, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp
 _sig("aslp_bn_forward_stats", _i, _vp, _md, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _i, _i)
 _sig("aslp_bn_backward_act", None, _vp, _md, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _i)
 _sig("aslp_bn_backward_step", None, _md, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _i, _vp, _i, _vp, _vp)
+_sig("aslp_bn_backward_step_p", None, _md, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _i, _vp, _i, _vp, _vp, C.POINTER(PlanesOut))
 _sig("aslp_bn_panel_supported", _i, _i, _i)
 _sig("aslp_softmax_xent_supported", _i, _i)
 _sig("aslp_softmax_xent_eval", None, _vp, _md, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i)

@@ -816,7 +816,7 @@ void aslp_planes_as_output(const aslp_planes *p, aslp_planes_out *out) {
   if (!p) return;
   const PlaneSet *ps = reinterpret_cast<const PlaneSet *>(p);
   const S16View v = ps->View();
-  out->hi = v.hi; out->lo = v.lo; out->ld = v.ld; out->slot = v.slot; out->parts = ps->Parts(); out->nparts = 0;
+  out->hi = v.hi; out->lo = v.lo; out->ld = v.ld; out->slot = v.slot; out->parts = ps->Parts(); out->nparts = 0; out->planes_written = 0;
 }
 int aslp_sgemm_planes_ex(int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda, const aslp_planes *pa, const float *B,
                          int ldb, const aslp_planes *pb, float beta, float *C, int ldc, const aslp_gemm_epilogue *ep) {

@@ -613,7 +613,8 @@ __global__ void __launch_bounds__(kPanelThreads) bn_backward_coop(const float *_
                                                            float *__restrict__ dshift, float mmt, float neg_lr, bool step,
                                                            float *__restrict__ in_diff, int ldi, int rows, const float *__restrict__ y, int ldy,
                                                            const float *__restrict__ xin, int ldxin, const float *__restrict__ mean, int Q,
-                                                           unsigned long long *inbox, unsigned *err, float *__restrict__ max_parts) {
+                                                           unsigned long long *inbox, unsigned *err, float *__restrict__ max_parts, S16Out po,
+                                                           unsigned long long *gmax, unsigned token) {
   constexpr int CG = kCoopCG, L = kCoopLanes;
   __shared__ float red[kPanelWaves * CG * 8];
   __shared__ float stat[3][4 * CG];  // S1, S2, the scale the forward pass used
@@ -719,21 +720,60 @@ __global__ void __launch_bounds__(kPanelThreads) bn_backward_coop(const float *_
       if (!RECOMPUTE) *reinterpret_cast<float4 *>(xhat + (long)r * ldx + c) = make_float4(Dv[0], Dv[1], Dv[2], Dv[3]);
       *reinterpret_cast<float4 *>(in_diff + (long)r * ldi + c) = make_float4(ov[0], ov[1], ov[2], ov[3]);
       omax = s16_absmax4(omax, make_float4(ov[0], ov[1], ov[2], ov[3]));
+      d[k] = make_float4(ov[0], ov[1], ov[2], ov[3]);   // (kept for the planes below)
     }
-    if (max_parts != nullptr) {   // this workgroup's largest |in_diff|: the conversion of in_diff takes its scale from these (split16.h)
+    if (max_parts != nullptr || po.hi != nullptr) {   // this workgroup's largest |in_diff|
       omax = wave_max(omax);
       __syncthreads();            // (red[] is free: every thread is past the statistics)
       if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = omax;
       __syncthreads();
-      if (threadIdx.x == 0) {
-        float m = red[0];
-        for (int w = 1; w < kPanelWaves; w++) m = fmaxf(m, red[w]);
-        max_parts[blockIdx.x] = m;
+      float m = red[0];
+      for (int w = 1; w < kPanelWaves; w++) m = fmaxf(m, red[w]);
+      // ... for the conversion of in_diff, which takes its scale from these (split16.h) ...
+      if (max_parts != nullptr && threadIdx.x == 0) max_parts[blockIdx.x] = m;
+      // ... or, with every workgroup of the launch resident (the host checks), the planes from this launch: the workgroups' maxima meet in
+      // gmax (one 8-byte word each: this launch's token | the maximum's bits -- nothing to reset, an older launch's word never matches),
+      // every workgroup reads all of them and scales its rows by the matrix maximum, exactly as the conversion pass would have.
+      if (po.hi != nullptr) {
+        if (threadIdx.x == 0)
+          __hip_atomic_store(gmax + blockIdx.x, ((unsigned long long)token << 32) | (unsigned long long)__float_as_uint(m), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+        float gm = 0.f;
+        bool ok = true;
+        for (int i = threadIdx.x; i < (int)gridDim.x; i += kPanelThreads) {
+          int spins = 0;
+          for (;;) {
+            const unsigned long long v = __hip_atomic_load(gmax + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(v >> 32) == token) { gm = fmaxf(gm, __uint_as_float((unsigned)v)); break; }
+            if (++spins > kCoopSpinLimit) { ok = false; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+        if (!ok) __hip_atomic_fetch_add(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        gm = wave_max(gm);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = gm;
+        __syncthreads();
+        gm = red[0];
+        for (int w = 1; w < kPanelWaves; w++) gm = fmaxf(gm, red[w]);
+        const unsigned mbits = __float_as_uint(gm);
+        if (blockIdx.x == 0 && threadIdx.x == 0) *const_cast<unsigned *>(po.slot) = mbits;   // for the products (launched behind this kernel)
+        const float ps = ldexpf(1.f, s16_exponent(mbits));
+#pragma unroll
+        for (int k = 0; k < SLOTS; k++) {
+          const int r = r0 + lane + k * L;
+          if (r >= r1) break;
+          half4 hi, lo;
+          s16_split4(d[k], ps, &hi, &lo);
+          *reinterpret_cast<half4 *>(po.hi + (long)r * po.ld + c) = hi;
+          *reinterpret_cast<half4 *>(po.lo + (long)r * po.ld + c) = lo;
+        }
       }
     }
   }
 }
-struct CoopState { unsigned long long *inbox = nullptr; unsigned *err = nullptr; bool tried = false; };
+constexpr int kCoopGmaxWords = 1024;   // workgroups whose maxima may meet in one launch
+struct CoopState { unsigned long long *inbox = nullptr, *gmax = nullptr; unsigned *err = nullptr, token = 0; bool tried = false; };
 CoopState &coop_state() {
   static CoopState st;
   if (!st.tried) {
@@ -744,9 +784,15 @@ CoopState &coop_state() {
       st.err = new_async_error_word("BatchNormalization cooperative kernel: a workgroup timed out waiting for the partial statistics of its panel "
                                     "(results of that call are invalid)");
       if (st.err) st.inbox = p;
+      unsigned long long *gm = nullptr;
+      if (st.inbox && hipMalloc(&gm, kCoopGmaxWords * 8) == hipSuccess && hipMemset(gm, 0, kCoopGmaxWords * 8) == hipSuccess) st.gmax = gm;   // (token 0 is never used)
     }
   }
   return st;
+}
+inline int coop_cu_count() {
+  static int num_cu = [] { hipDeviceProp_t pr; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 0; }();
+  return num_cu;
 }
 // rows x cols served by the cooperative kernels?  returns Q (row parts per panel) and the slots per thread, or Q = 0
 struct CoopShape { int q, slots; };
@@ -754,7 +800,7 @@ inline CoopShape bn_coop_shape(int rows, int cols) {
   static const int forced = [] { const char *e = getenv("ASLP_BN_COOP"); return e ? atoi(e) : -1; }();
   CoopShape none = {0, 0};
   if (forced == 0 || cols % kCoopCols != 0) return none;
-  static int num_cu = [] { hipDeviceProp_t pr; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 0; }();
+  const int num_cu = coop_cu_count();
   const int P = cols / kCoopCols;
   if (P > 256 || num_cu <= 0) return none;
   int Q = num_cu / P;              // every workgroup resident at once, one per CU (they wait for each other)
@@ -1125,7 +1171,7 @@ static void bn_backward_impl(MatrixDim d, const float *out_diff, int od_stride, 
                              const float *inv_std, float *dscale, float *dshift, float momentum, float *in_diff, int id_stride,
                              const float *act_y, int act_stride, bool step, float learn_rate, const float *in, const float *mean,
                              aslp_planes_out *diff_out = nullptr) {
-  if (diff_out) diff_out->nparts = 0;
+  if (diff_out) { diff_out->nparts = 0; diff_out->planes_written = 0; }
   if (d.rows <= 0 || d.cols <= 0) return;
   const bool y_ok = !act_y || (aligned16(act_y) && act_stride % 4 == 0);
   const bool recompute = xhat == nullptr;
@@ -1138,12 +1184,24 @@ static void bn_backward_impl(MatrixDim d, const float *out_diff, int od_stride, 
   if (cs.q && coop_state().inbox) {
     CoopState &st = coop_state();
     const dim3 grid((d.cols / kCoopCols) * cs.q), block(kPanelThreads);
-    float *max_parts = (diff_out && diff_out->parts && in_diff && (int)grid.x <= kS16MaxParts) ? diff_out->parts : nullptr;
+    // in_diff's planes from this launch when all its workgroups are resident at once (they wait for each other's maxima: one per CU is
+    // what the shape was chosen for), else the maxima for the conversion pass
+    S16Out po = {nullptr, nullptr, 0, nullptr, nullptr};
+    unsigned token = 0;
+    static const bool planes_off = [] { const char *e = getenv("ASLP_BN_DIFF_PLANES"); return e != nullptr && e[0] == '0'; }();   // A/B switch
+    if (diff_out && diff_out->hi && diff_out->lo && diff_out->slot && in_diff && st.gmax && !planes_off && (int)grid.x <= kCoopGmaxWords &&
+        (int)grid.x <= coop_cu_count() && diff_out->ld >= d.cols && diff_out->ld % 4 == 0) {
+      po = S16Out{static_cast<h16 *>(diff_out->hi), static_cast<h16 *>(diff_out->lo), diff_out->ld, diff_out->slot, nullptr};
+      if (++st.token == 0) st.token = 1;
+      token = st.token;
+      diff_out->planes_written = 1;
+    }
+    float *max_parts = (!po.hi && diff_out && diff_out->parts && in_diff && (int)grid.x <= kS16MaxParts) ? diff_out->parts : nullptr;
     if (max_parts) diff_out->nparts = (int)grid.x;
 #define ASLP_BN_BWD_CL(SLOTS, Y, RC)                                                                                                           \
     hipLaunchKernelGGL((bn_backward_coop<SLOTS, Y, RC>), grid, block, 0, cur_stream(), out_diff, od_stride, xhat, xhat_stride, scale, shift, inv_std, \
                        dscale, dshift, momentum, -learn_rate, step, in_diff, id_stride, d.rows, act_y, act_stride, in, d.stride, mean, cs.q, st.inbox, st.err, \
-                       max_parts)
+                       max_parts, po, st.gmax, token)
 #define ASLP_BN_BWD_COOP(SLOTS)                                                                      \
     case SLOTS:                                                                                      \
       if (act_y) { if (recompute) ASLP_BN_BWD_CL(SLOTS, true, true); else ASLP_BN_BWD_CL(SLOTS, true, false); }     \

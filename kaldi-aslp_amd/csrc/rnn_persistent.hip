@@ -1124,7 +1124,6 @@ __global__ void __launch_bounds__(512) lstm_seq_bwd_h(aslp_lstm_seq a, SeqStatus
   // inbox geometry
   const size_t slot_words = (size_t)kMaxChains * kMaxWgPerChain * kMaxWgPerChain * 128;  // floats per ring slot
   float *chain_box = inbox + (size_t)chain * kMaxWgPerChain * kMaxWgPerChain * 128;
-  const int npiece = wpc * 32;  // 16-byte pieces addressed to this workgroup per timestep: [producer][row group][column]
   // epilogue role: threads 0..127 own one (stream, cell) pair each
   const int sl = threadIdx.x >> 4, cc = threadIdx.x & 15, s = s0 + sl, cell = c0 + cc;
   const bool live = threadIdx.x < 128 && s < SE && cell < C;

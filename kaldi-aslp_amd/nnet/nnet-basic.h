@@ -828,7 +828,12 @@ class BatchNormalization : public UpdatableComponent {
       aslp_bn_backward_step_p(in.Dim(), out_diff.Data(), out_diff.Stride(), xhat_kept_ ? XsharpO_.Data() : nullptr, XsharpO_.Stride(), scale_.Data(),
                               shift_.Data(), var_vec_.Data(), dscale_.Data(), dshift_.Data(), opts_.momentum, opts_.learn_rate, in_diff, id_stride, act_y,
                               act_stride, in.Data(), mean_vec_.Data(), &po);
-      if (po.nparts > 0) dm->get().TagParts(in_diff, po.nparts, s16_epochs().bwd);
+      if (po.planes_written) {   // in_diff's planes came out of the launch itself (bound: the matrix maximum, found by its workgroups)
+        dm->get().ForgetHostBound();
+        dm->get().Tag(in_diff, id_stride, s16_epochs().bwd);
+      } else if (po.nparts > 0) {
+        dm->get().TagParts(in_diff, po.nparts, s16_epochs().bwd);
+      }
     } else {
       aslp_bn_backward_act(in.Data(), in.Dim(), out_diff.Data(), out_diff.Stride(), xhat_kept_ ? XsharpO_.Data() : nullptr, XsharpO_.Stride(), scale_.Data(),
                            mean_vec_.Data(), var_vec_.Data(), dscale_.Data(), dshift_.Data(), opts_.momentum, in_diff, id_stride, act_y, act_stride);

@@ -423,6 +423,67 @@ def test_bn_backward_with_folded_sigmoid_is_bit_identical(aslp, dev, rows, cols)
         assert np.array_equal(a, b), name
 
 
+def _planes_to_host(aslp, po, rows, cols):
+    """the [rows x cols] region of a PlanesOut's two fp16 planes, and the bound's bits"""
+    memcpy = aslp.lib.hipMemcpy
+    memcpy.restype = C.c_int
+    memcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    out = []
+    for p in (po.hi, po.lo):
+        h = np.empty((rows, po.ld), np.float16)
+        assert memcpy(h.ctypes.data, p, 2 * rows * po.ld, 2) == 0
+        assert not h[:, cols:].any()   # the padding columns stay zero
+        out.append(h[:, :cols].copy())
+    slot = np.empty(1, np.uint32)
+    assert memcpy(slot.ctypes.data, po.slot, 4, 2) == 0
+    return out[0], out[1], int(slot[0])
+
+
+@pytest.mark.parametrize("rows,cols,with_y", [(1024, 2048, True), (1024, 2048, False), (1000, 1024, True), (256, 2048, True)])
+def test_bn_backward_leaves_in_diff_planes(aslp, dev, rows, cols, with_y):
+    """aslp_bn_backward_step_p with planes to fill: the launch's workgroups find the maximum of |in_diff| among themselves and write the
+    two fp16 planes scaled by it -- bit for bit the planes (and the bound) the maximum pass + conversion pass make of the fp32 in_diff the same
+    launch wrote.  Repeated launches (the exchange words carry a per-launch token and are never reset) and a launch without planes in
+    between.  Shapes the cooperative kernel does not serve must say so (planes_written 0) and leave the maxima or nothing."""
+    _lib = aslp._lib
+    ptr, dim, lib = aslp.ops.ptr, aslp.ops.dim, aslp.ops.lib
+    g = torch.Generator(device="cpu").manual_seed(rows + cols)
+    x = torch.randn(rows, cols, generator=g).to(dev)
+    mean, inv = x.mean(0).contiguous(), (1.0 / torch.sqrt(x.var(0, unbiased=False) + 1e-7)).contiguous()
+    y = torch.sigmoid(torch.randn(rows, cols, generator=g)).to(dev) if with_y else None
+    planes = C.c_void_p(lib.aslp_planes_new())
+    lib.aslp_planes_reserve(planes, rows, cols)
+    try:
+        for it in range(4):
+            od = (torch.randn(rows, cols, generator=g) * 10.0 ** (it - 2)).to(dev)
+            scale, shift = (torch.rand(cols, generator=g) + 0.5).to(dev), torch.zeros(cols, device=dev)
+            ds, dsh = torch.zeros(cols, device=dev), torch.zeros(cols, device=dev)
+            ind = torch.empty(rows, cols, device=dev)
+            po = _lib.PlanesOut()
+            if it != 2:
+                lib.aslp_planes_as_output(planes, C.byref(po))
+            lib.aslp_bn_backward_step_p(dim(od), ptr(od), dim(od).stride, None, 0, ptr(scale), ptr(shift), ptr(inv), ptr(ds), ptr(dsh), 0.0, 0.001,
+                                        ptr(ind), dim(ind).stride, ptr(y) if with_y else None, dim(y).stride if with_y else 0, ptr(x), ptr(mean),
+                                        C.byref(po))
+            aslp.ops.check_error()
+            torch.cuda.synchronize()
+            if it == 2:
+                assert po.planes_written == 0
+                continue
+            if not po.planes_written:
+                pytest.skip("this shape is not served by the cooperative kernel")
+            assert po.nparts == 0
+            hi, lo, bits = _planes_to_host(aslp, po, rows, cols)
+            ref = aslp.ops.Planes(ind)   # maximum pass + conversion pass over the fp32 in_diff
+            rpo = _lib.PlanesOut()
+            lib.aslp_planes_as_output(ref.h, C.byref(rpo))
+            rhi, rlo, rbits = _planes_to_host(aslp, rpo, rows, cols)
+            assert bits == rbits and np.float32(ind.abs().max().item()).view(np.uint32) == bits, it
+            assert np.array_equal(hi.view(np.uint16), rhi.view(np.uint16)) and np.array_equal(lo.view(np.uint16), rlo.view(np.uint16)), it
+    finally:
+        lib.aslp_planes_free(planes)
+
+
 @pytest.mark.parametrize("tA,tB,M,N,K,mode", [
     (0, 1, 1920, 2048, 512, "bias"), (0, 1, 1920, 256, 512, "act_out"), (0, 0, 1920, 512, 256, "plain"), (0, 0, 1920, 256, 2048, "beta1"),
     (0, 0, 2048, 512, 256, "plain"), (1, 0, 2048, 512, 1920, "sgd"), (1, 0, 2048, 256, 1920, "sgd"), (1, 0, 256, 512, 1920, "sgd"),
