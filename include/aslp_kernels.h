@@ -355,6 +355,18 @@ void aslp_softmax_xent_eval(const float *acts, MatrixDim d, const float *tgt, in
  * register-cached row kernel), 0 if only diff was. */
 int aslp_xent_eval_p(const float *net_out, MatrixDim d, const int32_cuda *labels, const float *frame_weights, float *diff, int diff_stride,
                      double *stats_dev, int softmax, const aslp_planes_out *diff_planes);
+/* dst [d] <- src (dst may be NULL) and the planes of src in one launch: the launch's workgroups find the matrix maximum among themselves,
+ * store its bits to *out->slot and write out->hi / lo scaled by it -- what aslp_copy_mat + aslp_planes_convert leave, in one launch instead
+ * of three.  Returns 1 (out->planes_written set) or 0 = not served (more rows than the chip holds at once, unaligned operands): nothing
+ * was written, the caller copies and converts. */
+int aslp_copy_mat_planes(float *dst, MatrixDim d, const float *src, int src_stride, aslp_planes_out *out);
+/* aslp_xent_eval_p in two halves, for a caller that evaluates batch after batch and reads its accumulators rarely (Xent: at Report()):
+ * aslp_xent_eval_rows leaves the batch's per-row statistics in rowstats_out [d.rows x 5 doubles] instead of adding them up -- one launch
+ * less in front of the backward pass of every step; aslp_xent_sum_rowstats adds `batches` such blocks of `rows` rows each (consecutive in
+ * memory, in evaluation order) to stats_dev, with the bits of one aslp_xent_eval_p per batch. */
+int aslp_xent_eval_rows(const float *net_out, MatrixDim d, const int32_cuda *labels, const float *frame_weights, float *diff, int diff_stride,
+                        double *rowstats_out, int softmax, const aslp_planes_out *diff_planes);
+void aslp_xent_sum_rowstats(const double *rowstats, int rows, int batches, double *stats_dev);
 /* cudaF_diff_sigmoid which also leaves the planes of its result: |e y (1 - y)| <= max |e| / 4 with max |e| from the n_parts per-workgroup
  * maxima the producer of e left (aslp_gemm_epilogue.cmax_parts).  The kernel stores the bound to out_planes->slot itself.  Returns 1 if the
  * planes were written, 0 if only eout was (operands not 16-byte aligned, no maxima). */

@@ -138,6 +138,7 @@ _sig("aslp_planes_new", _vp)
 _sig("aslp_planes_free", None, _vp)
 _sig("aslp_planes_convert", _i, _vp, _vp, _md)
 _sig("aslp_planes_reserve", None, _vp, _i, _i)
+_sig("aslp_copy_mat_planes", _i, _vp, _md, _vp, _i, C.POINTER(PlanesOut))
 _sig("aslp_planes_as_output", None, _vp, C.POINTER(PlanesOut))
 _sig("aslp_sgemm_planes_ex", _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _vp, _i, _vp, _f, _vp, _i, C.POINTER(GemmEpilogue))
 _sig("aslp_gemm_last_parts", _i)
@@ -175,6 +176,10 @@ _sig("aslp_bn_backward_step", None, _md, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _
 _sig("aslp_bn_backward_step_p", None, _md, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _i, _vp, _i, _vp, _vp, C.POINTER(PlanesOut))
 _sig("aslp_bn_panel_supported", _i, _i, _i)
 _sig("aslp_softmax_xent_supported", _i, _i)
+_sig("aslp_xent_eval_p", _i, _vp, _md, _vp, _vp, _vp, _i, _vp, _i, C.POINTER(PlanesOut))
+_sig("aslp_xent_eval_rows", _i, _vp, _md, _vp, _vp, _vp, _i, _vp, _i, C.POINTER(PlanesOut))
+_sig("aslp_xent_sum_rowstats", None, _vp, _i, _i, _vp)
+_sig("aslp_device_shared", None, _i)
 _sig("aslp_softmax_xent_eval", None, _vp, _md, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i)
 _sig("aslp_dropout_forward", None, _vp, _i, _vp, _md, _vp, _i, _f, C.c_ulonglong)
 _sig("aslp_dropout_backward", None, _vp, _i, _vp, _md, _vp, _i, _f)

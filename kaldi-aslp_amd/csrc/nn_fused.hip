@@ -605,6 +605,75 @@ __global__ void __launch_bounds__(kPanelThreads) bn_forward_stats_kernel(const f
   }
 }
 
+// The largest of one value per workgroup, in every workgroup of a launch whose workgroups are all resident at once (the host checks: they
+// wait for each other).  They meet in gmax, one 8-byte word each: this launch's token | the value's bits -- nothing to reset, an older
+// launch's word never matches.  wg_max: the workgroup's value (in every thread); red: >= kPanelWaves floats of LDS nobody else is using.
+__device__ __forceinline__ float coop_grid_max(float wg_max, unsigned long long *gmax, unsigned token, unsigned *err, float *red) {
+  if (threadIdx.x == 0)
+    __hip_atomic_store(gmax + blockIdx.x, ((unsigned long long)token << 32) | (unsigned long long)__float_as_uint(wg_max), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  float gm = 0.f;
+  bool ok = true;
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += kPanelThreads) {
+    int spins = 0;
+    for (;;) {
+      const unsigned long long v = __hip_atomic_load(gmax + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((unsigned)(v >> 32) == token) { gm = fmaxf(gm, __uint_as_float((unsigned)v)); break; }
+      if (++spins > kCoopSpinLimit) { ok = false; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  if (!ok) __hip_atomic_fetch_add(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  gm = wave_max(gm);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = gm;
+  __syncthreads();
+  gm = red[0];
+  for (int w = 1; w < kPanelWaves; w++) gm = fmaxf(gm, red[w]);
+  return gm;
+}
+
+// A matrix copied and its fp16 planes made in ONE launch (aslp_copy_mat_planes; the network input: copy + maximum pass + conversion pass
+// were three launches in front of the first layer product): a thread holds U 16-byte pieces, the workgroups' maxima meet as above.
+template <int U>
+__global__ void __launch_bounds__(kPanelThreads) copy_planes_coop(const float *__restrict__ src, int lds_, float *__restrict__ dst, int ldd, int rows,
+                                                                   int cols, S16Out po, unsigned long long *gmax, unsigned token, unsigned *err) {
+  __shared__ float red[kPanelWaves];
+  const int c4 = cols >> 2, units = rows * c4;
+  float4 v[U];
+  int rr[U], cc[U];
+  float m = 0.f;
+#pragma unroll
+  for (int k = 0; k < U; k++) {
+    const int u = ((int)blockIdx.x * U + k) * kPanelThreads + (int)threadIdx.x;
+    const int r = u / c4;
+    rr[k] = u < units ? r : -1;
+    cc[k] = 4 * (u - r * c4);
+    v[k] = u < units ? *reinterpret_cast<const float4 *>(src + (long)r * lds_ + cc[k]) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int k = 0; k < U; k++) {
+    if (rr[k] >= 0 && dst != nullptr) *reinterpret_cast<float4 *>(dst + (long)rr[k] * ldd + cc[k]) = v[k];
+    m = s16_absmax4(m, v[k]);
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = red[0];
+  for (int w = 1; w < kPanelWaves; w++) m = fmaxf(m, red[w]);
+  const unsigned mbits = __float_as_uint(coop_grid_max(m, gmax, token, err, red));
+  if (blockIdx.x == 0 && threadIdx.x == 0) *const_cast<unsigned *>(po.slot) = mbits;
+  const float ps = ldexpf(1.f, s16_exponent(mbits));
+#pragma unroll
+  for (int k = 0; k < U; k++) {
+    if (rr[k] < 0) continue;
+    half4 hi, lo;
+    s16_split4(v[k], ps, &hi, &lo);
+    *reinterpret_cast<half4 *>(po.hi + (long)rr[k] * po.ld + cc[k]) = hi;
+    *reinterpret_cast<half4 *>(po.lo + (long)rr[k] * po.ld + cc[k]) = lo;
+  }
+}
+
 // what bn_backward_coop needs to bound its in-diff before it has written it (see there)
 template <int SLOTS, bool HAS_Y, bool RECOMPUTE>
 __global__ void __launch_bounds__(kPanelThreads) bn_backward_coop(const float *__restrict__ dy, int ldd, float *__restrict__ xhat, int ldx,
@@ -731,31 +800,10 @@ __global__ void __launch_bounds__(kPanelThreads) bn_backward_coop(const float *_
       for (int w = 1; w < kPanelWaves; w++) m = fmaxf(m, red[w]);
       // ... for the conversion of in_diff, which takes its scale from these (split16.h) ...
       if (max_parts != nullptr && threadIdx.x == 0) max_parts[blockIdx.x] = m;
-      // ... or, with every workgroup of the launch resident (the host checks), the planes from this launch: the workgroups' maxima meet in
-      // gmax (one 8-byte word each: this launch's token | the maximum's bits -- nothing to reset, an older launch's word never matches),
-      // every workgroup reads all of them and scales its rows by the matrix maximum, exactly as the conversion pass would have.
+      // ... or the planes from this launch: the workgroups' maxima meet (coop_grid_max) and every workgroup scales its rows by the matrix
+      // maximum, exactly as the conversion pass would have.
       if (po.hi != nullptr) {
-        if (threadIdx.x == 0)
-          __hip_atomic_store(gmax + blockIdx.x, ((unsigned long long)token << 32) | (unsigned long long)__float_as_uint(m), __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
-        float gm = 0.f;
-        bool ok = true;
-        for (int i = threadIdx.x; i < (int)gridDim.x; i += kPanelThreads) {
-          int spins = 0;
-          for (;;) {
-            const unsigned long long v = __hip_atomic_load(gmax + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((unsigned)(v >> 32) == token) { gm = fmaxf(gm, __uint_as_float((unsigned)v)); break; }
-            if (++spins > kCoopSpinLimit) { ok = false; break; }
-            __builtin_amdgcn_s_sleep(1);
-          }
-        }
-        if (!ok) __hip_atomic_fetch_add(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        gm = wave_max(gm);
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = gm;
-        __syncthreads();
-        gm = red[0];
-        for (int w = 1; w < kPanelWaves; w++) gm = fmaxf(gm, red[w]);
+        const float gm = coop_grid_max(m, gmax, token, err, red);
         const unsigned mbits = __float_as_uint(gm);
         if (blockIdx.x == 0 && threadIdx.x == 0) *const_cast<unsigned *>(po.slot) = mbits;   // for the products (launched behind this kernel)
         const float ps = ldexpf(1.f, s16_exponent(mbits));
@@ -781,8 +829,8 @@ CoopState &coop_state() {
     const size_t words = (size_t)256 * 8 * 8 * kCoopCols * 3;  // up to 256 panels x Q <= 8 readers x 8 writers
     unsigned long long *p = nullptr;
     if (hipMalloc(&p, words * 8) == hipSuccess && hipMemset(p, 0xFF, words * 8) == hipSuccess) {
-      st.err = new_async_error_word("BatchNormalization cooperative kernel: a workgroup timed out waiting for the partial statistics of its panel "
-                                    "(results of that call are invalid)");
+      st.err = new_async_error_word("cooperative kernel (BatchNormalization / input planes): a workgroup timed out waiting for the other workgroups of its "
+                                    "launch (results of that call are invalid; if several processes share this GPU set ASLP_DEVICE_SHARED=1)");
       if (st.err) st.inbox = p;
       unsigned long long *gm = nullptr;
       if (st.inbox && hipMalloc(&gm, kCoopGmaxWords * 8) == hipSuccess && hipMemset(gm, 0, kCoopGmaxWords * 8) == hipSuccess) st.gmax = gm;   // (token 0 is never used)
@@ -835,6 +883,7 @@ constexpr int kXentPerThread = 32;  // cols <= 8192 cached in registers
 // stats[0..4] += {frames, correct, -xent, -entropy, likelihood} summed over the rows in a fixed order (thread t: rows t, t + 256, ...; the
 // 64 lanes of a wave; the four waves), by one workgroup of 256 threads.  coherent: the rows were written by other workgroups of the SAME launch
 // (device-scope loads; unused by the shipped callers).  Four rows' loads are in flight at a time.
+template <bool RAW = false>   // RAW: the five sums as they are into stats[0..4] (xent_apply_kernel adds them to the accumulators later)
 __device__ __forceinline__ void xent_sum_rows(const double *rowstats, int rows, double *stats, bool coherent) {
   __shared__ double sh_sum[4][5];
   double a[5] = {0, 0, 0, 0, 0};
@@ -865,6 +914,10 @@ __device__ __forceinline__ void xent_sum_rows(const double *rowstats, int rows, 
   if (threadIdx.x == 0) {
     double s[5];
     for (int k = 0; k < 5; k++) s[k] = sh_sum[0][k] + sh_sum[1][k] + sh_sum[2][k] + sh_sum[3][k];
+    if (RAW) {
+      for (int k = 0; k < 5; k++) stats[k] = s[k];
+      return;
+    }
     stats[0] += s[0];
     stats[1] += s[1];
     stats[2] += -s[2];
@@ -891,6 +944,7 @@ __global__ void __launch_bounds__(256) xent_rows_kernel(const float *y, int ldy,
     const float *yr = y + (long)r * ldy;
     const float *tr = DENSE ? t + (long)r * ldt : nullptr;
     const int label = DENSE ? -1 : labels[r];
+    const float fw_r = fw[r];   // (here, in the row's round trip: read where it is used it is a trip of its own behind the last reduction)
     float yv[PER], tv[PER];
     float tsum = 0.0f, ybest = -1e21f, tbest = -1e21f;
     int yi = -1, ti = -1;
@@ -964,7 +1018,7 @@ __global__ void __launch_bounds__(256) xent_rows_kernel(const float *y, int ldy,
       if (shf[j][2] > tbest || (shf[j][2] == tbest && shi[j][1] >= 0 && (ti < 0 || shi[j][1] < ti))) { tbest = shf[j][2]; ti = shi[j][1]; }
     }
     __syncthreads();
-    const float wr = fw[r] * tsum;  // frames with sum(t) == 0 are switched off (nnet-loss.cc:80-85)
+    const float wr = fw_r * tsum;  // frames with sum(t) == 0 are switched off (nnet-loss.cc:80-85)
     double xe = 0.0, en = 0.0, lk = 0.0;
 #pragma unroll
     for (int k = 0; k < PER; k++) {
@@ -1070,6 +1124,20 @@ __global__ void __launch_bounds__(256) xent_rows_wide_kernel(const float *y, int
 
 // stats[0..4] += {frames, correct, xent, entropy, likelihood}; fixed-order sum over rows
 __global__ void __launch_bounds__(256) xent_finalize_kernel(const double *rowstats, int rows, double *stats) { xent_sum_rows(rowstats, rows, stats, false); }
+// The same for the per-row statistics of several batches at once (aslp_xent_sum_rowstats): workgroup b sums batch b exactly as above, then
+// one thread adds the batches' sums to the accumulators in batch order -- the bits of one xent_finalize_kernel launch per batch.
+__global__ void __launch_bounds__(256) xent_batch_sums_kernel(const double *rowstats, int rows, double *sums) {
+  xent_sum_rows<true>(rowstats + (size_t)blockIdx.x * rows * 5, rows, sums + (size_t)blockIdx.x * 5, false);
+}
+__global__ void xent_apply_kernel(const double *sums, int batches, double *stats) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double a[5] = {stats[0], stats[1], stats[2], stats[3], stats[4]};
+  for (int b = 0; b < batches; b++) {
+    const double *s = sums + (size_t)b * 5;
+    a[0] += s[0]; a[1] += s[1]; a[2] += -s[2]; a[3] += -s[3]; a[4] += s[4];
+  }
+  for (int k = 0; k < 5; k++) stats[k] = a[k];
+}
 
 }  // namespace
 }  // namespace aslp
@@ -1189,7 +1257,7 @@ static void bn_backward_impl(MatrixDim d, const float *out_diff, int od_stride, 
     S16Out po = {nullptr, nullptr, 0, nullptr, nullptr};
     unsigned token = 0;
     static const bool planes_off = [] { const char *e = getenv("ASLP_BN_DIFF_PLANES"); return e != nullptr && e[0] == '0'; }();   // A/B switch
-    if (diff_out && diff_out->hi && diff_out->lo && diff_out->slot && in_diff && st.gmax && !planes_off && (int)grid.x <= kCoopGmaxWords &&
+    if (diff_out && diff_out->hi && diff_out->lo && diff_out->slot && in_diff && st.gmax && !planes_off && !device_shared() && (int)grid.x <= kCoopGmaxWords &&
         (int)grid.x <= coop_cu_count() && diff_out->ld >= d.cols && diff_out->ld % 4 == 0) {
       po = S16Out{static_cast<h16 *>(diff_out->hi), static_cast<h16 *>(diff_out->lo), diff_out->ld, diff_out->slot, nullptr};
       if (++st.token == 0) st.token = 1;
@@ -1276,12 +1344,13 @@ void aslp_bn_backward(const float *in, MatrixDim d, const float *out_diff, int o
 
 static bool xent_eval_impl(const float *net_out, MatrixDim d, const float *tgt, int tgt_stride, const int32_cuda *labels,
                            const float *frame_weights, float *diff, int diff_stride, double *stats_dev, bool softmax, float *y_out, int y_stride,
-                           const aslp_planes_out *diff_planes = nullptr) {
+                           const aslp_planes_out *diff_planes = nullptr, double *rowstats_out = nullptr) {
   if (d.rows <= 0 || d.cols <= 0) return false;
   if (!tgt && !labels) { set_error("aslp_xent_eval: need dense targets or labels"); return false; }
   S16Out po = {nullptr, nullptr, 0, nullptr, nullptr};
   bool planes_written = false;
-  double *rowstats = static_cast<double *>(scratch(kScratchReduce, sizeof(double) * 5 * (size_t)d.rows));
+  // rowstats_out: the caller keeps the per-row statistics and adds them to its accumulators later (aslp_xent_sum_rowstats)
+  double *rowstats = rowstats_out ? rowstats_out : static_cast<double *>(scratch(kScratchReduce, sizeof(double) * 5 * (size_t)d.rows));
   if (!rowstats) return false;
   int g = d.rows > kMaxGrid * 2 ? kMaxGrid * 2 : d.rows;
   if (d.cols > 256 * kXentPerThread) {   // wider than the register-cached kernels hold: the streaming kernel (the reference has no limit)
@@ -1290,7 +1359,7 @@ static bool xent_eval_impl(const float *net_out, MatrixDim d, const float *tgt, 
                                 diff, diff_stride, d.rows, d.cols, rowstats);
     else hipLaunchKernelGGL((xent_rows_wide_kernel<false>), dim3(g), dim3(256), 0, cur_stream(), net_out, d.stride, tgt, tgt_stride, labels, frame_weights,
                             diff, diff_stride, d.rows, d.cols, rowstats);
-    hipLaunchKernelGGL(xent_finalize_kernel, dim3(1), dim3(256), 0, cur_stream(), rowstats, d.rows, stats_dev);
+    if (!rowstats_out) hipLaunchKernelGGL(xent_finalize_kernel, dim3(1), dim3(256), 0, cur_stream(), rowstats, d.rows, stats_dev);
     check_launch("xent_eval");
     return false;
   }
@@ -1317,7 +1386,7 @@ static bool xent_eval_impl(const float *net_out, MatrixDim d, const float *tgt, 
 #undef XENT_LAUNCH_P
   // (folding this sum into the rows' launch behind a ticket was measured: 54 us instead of 14 -- the device-scope release in front of the
   //  ticket makes every one of the 1024 workgroups write the L2 back, 12 MB of diff included)
-  hipLaunchKernelGGL(xent_finalize_kernel, dim3(1), dim3(256), 0, cur_stream(), rowstats, d.rows, stats_dev);
+  if (!rowstats_out) hipLaunchKernelGGL(xent_finalize_kernel, dim3(1), dim3(256), 0, cur_stream(), rowstats, d.rows, stats_dev);
   check_launch("xent_eval");
   return planes_written;
 }
@@ -1330,6 +1399,45 @@ int aslp_xent_eval_p(const float *net_out, MatrixDim d, const int32_cuda *labels
                      double *stats_dev, int softmax, const aslp_planes_out *diff_planes) {
   if (softmax && !aslp_softmax_xent_supported(d.cols)) { set_error("aslp_softmax_xent_eval: unsupported number of classes"); return 0; }
   return xent_eval_impl(net_out, d, nullptr, 0, labels, frame_weights, diff, diff_stride, stats_dev, softmax != 0, nullptr, 0, diff_planes) ? 1 : 0;
+}
+// dst (nullable) <- src and src's planes in one launch; 1 = done (planes_written set), 0 = not served: the caller copies and converts
+int aslp_copy_mat_planes(float *dst, MatrixDim d, const float *src, int src_stride, aslp_planes_out *out) {
+  if (out) { out->nparts = 0; out->planes_written = 0; }
+  if (!out || !out->hi || !out->lo || !out->slot || d.rows <= 0 || d.cols <= 0) return 0;
+  static const bool off = [] { const char *e = getenv("ASLP_COPY_PLANES"); return e != nullptr && e[0] == '0'; }();   // A/B switch
+  if (off || device_shared() || (d.cols & 3) || (src_stride & 3) || !aligned16(src) || (dst && ((d.stride & 3) || !aligned16(dst))) || out->ld < d.cols || (out->ld & 3)) return 0;
+  CoopState &st = coop_state();
+  if (!st.gmax) return 0;
+  const long units = (long)d.rows * (d.cols >> 2);
+  const int cus = std::min(coop_cu_count(), kCoopGmaxWords);
+  int U = 0;
+  for (int u : {4, 8, 16})
+    if (U == 0 && (units + (long)u * kPanelThreads - 1) / ((long)u * kPanelThreads) <= cus) U = u;
+  if (U == 0) return 0;   // more than the chip holds at once
+  const int grid = (int)((units + (long)U * kPanelThreads - 1) / ((long)U * kPanelThreads));
+  const S16Out po = {static_cast<h16 *>(out->hi), static_cast<h16 *>(out->lo), out->ld, out->slot, nullptr};
+  if (++st.token == 0) st.token = 1;
+#define ASLP_COPY_PLANES(UU) \
+  hipLaunchKernelGGL((copy_planes_coop<UU>), dim3(grid), dim3(kPanelThreads), 0, cur_stream(), src, src_stride, dst, d.stride, d.rows, d.cols, po, st.gmax, st.token, st.err)
+  if (U == 4) ASLP_COPY_PLANES(4); else if (U == 8) ASLP_COPY_PLANES(8); else ASLP_COPY_PLANES(16);
+#undef ASLP_COPY_PLANES
+  check_launch("copy_mat_planes");
+  out->planes_written = 1;
+  return 1;
+}
+int aslp_xent_eval_rows(const float *net_out, MatrixDim d, const int32_cuda *labels, const float *frame_weights, float *diff, int diff_stride,
+                        double *rowstats_out, int softmax, const aslp_planes_out *diff_planes) {
+  if (!rowstats_out) { set_error("aslp_xent_eval_rows: no room for the per-row statistics"); return 0; }
+  if (softmax && !aslp_softmax_xent_supported(d.cols)) { set_error("aslp_softmax_xent_eval: unsupported number of classes"); return 0; }
+  return xent_eval_impl(net_out, d, nullptr, 0, labels, frame_weights, diff, diff_stride, nullptr, softmax != 0, nullptr, 0, diff_planes, rowstats_out) ? 1 : 0;
+}
+void aslp_xent_sum_rowstats(const double *rowstats, int rows, int batches, double *stats_dev) {
+  if (rows <= 0 || batches <= 0) return;
+  double *sums = static_cast<double *>(scratch(kScratchReduce, sizeof(double) * 5 * (size_t)batches));
+  if (!sums) return;
+  hipLaunchKernelGGL(xent_batch_sums_kernel, dim3(batches), dim3(256), 0, cur_stream(), rowstats, rows, sums);
+  hipLaunchKernelGGL(xent_apply_kernel, dim3(1), dim3(64), 0, cur_stream(), sums, batches, stats_dev);
+  check_launch("xent_sum_rowstats");
 }
 // Softmax + Xent::Eval in one pass over the activations in front of the Softmax; only rows of 513..8192 classes (the
 // range where cudaF_softmax_reduce uses the same 256-lane row layout, so the posteriors are bit-identical)

@@ -1852,6 +1852,7 @@ bool grid_fits(const void *k, int threads, long blocks) {
 int chain_streams_for(const aslp_lstm_seq *, bool) { return kChainStreams; }
 
 }  // namespace
+bool device_shared() { return device_gate().on; }   // (scratch.h)
 }  // namespace aslp
 
 using namespace aslp;

@@ -40,5 +40,9 @@ void join_side_stream();
 bool side_stream_mark(void **ev);
 void side_stream_mark_wait(void *ev, bool host);
 void side_stream_mark_free(void *ev);
+// Several processes share this GPU (ASLP_DEVICE_SHARED=1 / aslp_device_shared(1); rnn_persistent.hip): kernels whose workgroups wait for
+// ALL workgroups of their launch (resident at once on a device of their own) must not be used -- two such launches half resident beside
+// each other never finish.
+bool device_shared();
 bool on_side_stream();  // is the calling thread inside a SideStreamScope?
 }  // namespace aslp

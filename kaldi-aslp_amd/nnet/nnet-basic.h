@@ -42,8 +42,27 @@ class InputLayer : public Component {
   Component *Copy() const { return new InputLayer(*this); }
   ComponentType GetType() const { return kInputLayer; }
   bool BackpropIsCopy() const { return true; }
-  void PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) { out->CopyFromMat(in); }
+  // Executor peephole (one-shot): the AffineTransform that alone reads the next Propagate's output wants its fp16 planes (csrc/split16.h):
+  // the copy then makes them in the same launch (aslp_copy_mat_planes) instead of a maximum pass and a conversion pass behind it
+  void ProduceOutputPlanes(PlaneHolder *h) { out_planes_ = h; }
+  void PropagateFnc(const CuMatrixBase &in, CuMatrixBase *out) {
+    PlaneHolder *oh = out_planes_;
+    out_planes_ = nullptr;
+    if (oh && oh->get().Reserve(in.NumRows(), in.NumCols())) {
+      aslp_planes_out po = aslp_planes_out();
+      aslp_planes_as_output(reinterpret_cast<const aslp_planes *>(&oh->get()), &po);
+      if (aslp_copy_mat_planes(out->Data(), out->Dim(), in.Data(), in.Stride(), &po)) {
+        oh->get().ForgetHostBound();
+        oh->get().Tag(out->Data(), out->Stride(), s16_epochs().fwd);
+        return;
+      }
+    }
+    out->CopyFromMat(in);
+  }
   void BackpropagateFnc(const CuMatrixBase &, const CuMatrixBase &, const CuMatrixBase &od, CuMatrixBase *id) { id->CopyFromMat(od); }
+
+ private:
+  PlaneHolder *out_planes_ = nullptr;
 };
 class OutputLayer : public Component {
  public:

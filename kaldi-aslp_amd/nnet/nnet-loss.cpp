@@ -43,8 +43,26 @@ Xent::Xent()
   stats_.Resize(5, kSetZero);
 }
 
+double *Xent::PendingRowStats(int32 rows) {
+  static const int32 kMaxBatches = 32, kMaxRows = 1 << 16;
+  if (rows != pending_rows_) {
+    FlushPending();
+    pending_rows_ = rows;
+    pending_cap_ = std::min(kMaxBatches, kMaxRows / std::max(rows, 1));
+    if (pending_cap_ >= 2 && pending_.Dim() < pending_cap_ * rows * 5) pending_.Resize(pending_cap_ * rows * 5, kUndefined);
+  }
+  if (pending_cap_ < 2) return nullptr;
+  if (pending_batches_ == pending_cap_) FlushPending();
+  return pending_.Data() + (size_t)(pending_batches_++) * rows * 5;
+}
+void Xent::FlushPending() {
+  if (pending_batches_ > 0) aslp_xent_sum_rowstats(pending_.Data(), pending_rows_, pending_batches_, stats_.Data());
+  pending_batches_ = 0;
+}
+
 void Xent::Fetch() {
   if (!dirty_) return;
+  FlushPending();
   double h[5];
   stats_.CopyToHost(h);
   stats_.SetZero();
@@ -85,6 +103,7 @@ void Xent::Eval(const std::vector<BaseFloat> &frame_weights, const CuMatrixBase 
   hv.data = frame_weights;
   frame_weights_ = hv;
   diff->Resize(net_out.NumRows(), net_out.NumCols(), kUndefined);
+  FlushPending();   // (the accumulators take the batches in evaluation order)
   aslp_xent_eval(net_out.Data(), net_out.Dim(), targets.Data(), targets.Stride(), nullptr, frame_weights_.Data(), diff->Data(),
                  diff->Stride(), stats_.Data());
   CheckK();
@@ -123,7 +142,7 @@ void Xent::Eval(const std::vector<BaseFloat> &frame_weights, const CuMatrixBase 
 // weights' maximum (fw_max > 0).  If the network asked for the diff's planes (Nnet::LossDiff -> s16_loss_diff_target) the kernel
 // writes them beside the diff.
 static void XentLabels(const CuMatrixBase &in, bool softmax, const int32 *labels_dev, const CuVectorBase &fw, float fw_max, CuMatrix *diff,
-                       double *stats) {
+                       double *stats, double *rowstats_room) {
   S16DiffTarget t = s16_loss_diff_target();
   s16_loss_diff_target() = S16DiffTarget();
   aslp_planes_out po = aslp_planes_out();
@@ -132,13 +151,16 @@ static void XentLabels(const CuMatrixBase &in, bool softmax, const int32 *labels
   PlaneSet *ps = (softmax && t.planes && t.diff == diff->Data() && fw_max > 0.0f && std::isfinite(fw_max)) ? t.planes : nullptr;
   if (ps && ps->Reserve(in.NumRows(), in.NumCols()) && ps->SetBound(fw_max)) aslp_planes_as_output(reinterpret_cast<const aslp_planes *>(ps), &po);
   else ps = nullptr;
-  if (aslp_xent_eval_p(in.Data(), in.Dim(), labels_dev, fw.Data(), diff->Data(), diff->Stride(), stats, softmax ? 1 : 0, ps ? &po : nullptr) && ps)
-    ps->Tag(diff->Data(), diff->Stride(), t.epoch);
+  const int planes = rowstats_room
+                         ? aslp_xent_eval_rows(in.Data(), in.Dim(), labels_dev, fw.Data(), diff->Data(), diff->Stride(), rowstats_room, softmax ? 1 : 0, ps ? &po : nullptr)
+                         : aslp_xent_eval_p(in.Data(), in.Dim(), labels_dev, fw.Data(), diff->Data(), diff->Stride(), stats, softmax ? 1 : 0, ps ? &po : nullptr);
+  if (planes && ps) ps->Tag(diff->Data(), diff->Stride(), t.epoch);
 }
 
 void Xent::EvalLabels(const CuVectorBase &fw, const CuMatrixBase &net_out, const CuArray<int32> &labels, CuMatrix *diff) {
   ASLP_ASSERT(fw.Dim() == net_out.NumRows() && labels.Dim() == net_out.NumRows());
   diff->Resize(net_out.NumRows(), net_out.NumCols(), kUndefined);
+  FlushPending();
   aslp_xent_eval(net_out.Data(), net_out.Dim(), nullptr, 0, labels.Data(), fw.Data(), diff->Data(), diff->Stride(), stats_.Data());
   CheckK();
   AfterEval(net_out.NumRows());
@@ -147,7 +169,7 @@ void Xent::EvalLabels(const CuVectorBase &fw, const CuMatrixBase &net_out, const
 void Xent::EvalLabels(const CuVectorBase &fw, const CuMatrixBase &net_out, const int32 *labels_dev, CuMatrix *diff, float fw_max) {
   ASLP_ASSERT(fw.Dim() == net_out.NumRows());
   diff->Resize(net_out.NumRows(), net_out.NumCols(), kUndefined);
-  XentLabels(net_out, false, labels_dev, fw, fw_max, diff, stats_.Data());
+  XentLabels(net_out, false, labels_dev, fw, fw_max, diff, stats_.Data(), PendingRowStats(net_out.NumRows()));
   CheckK();
   AfterEval(net_out.NumRows());
 }
@@ -155,7 +177,7 @@ void Xent::EvalLabelsPreSoftmax(const CuVectorBase &fw, const CuMatrixBase &acts
   ASLP_ASSERT(fw.Dim() == acts.NumRows());
   diff->Resize(acts.NumRows(), acts.NumCols(), kUndefined);
   if (!aslp_softmax_xent_supported(acts.NumCols())) ASLP_ERR << "Softmax + Xent in one pass: unsupported number of classes " << acts.NumCols();
-  XentLabels(acts, true, labels_dev, fw, fw_max, diff, stats_.Data());
+  XentLabels(acts, true, labels_dev, fw, fw_max, diff, stats_.Data(), PendingRowStats(acts.NumRows()));
   CheckK();
   AfterEval(acts.NumRows());
 }
@@ -183,9 +205,10 @@ void Xent::EvalOnLossInput(const std::vector<BaseFloat> &frame_weights, const Cu
     labels_ = labels;
     float fw_max = 0.0f;
     for (BaseFloat w : frame_weights) fw_max = std::max(fw_max, std::fabs(w));
-    XentLabels(in, true, labels_.Data(), frame_weights_, fw_max, diff, stats_.Data());
+    XentLabels(in, true, labels_.Data(), frame_weights_, fw_max, diff, stats_.Data(), PendingRowStats(num_frames));
   } else {
     PosteriorToMatrix(post, num_pdf, &tgt_mat_);
+    FlushPending();
     aslp_softmax_xent_eval(in.Data(), in.Dim(), tgt_mat_.Data(), tgt_mat_.Stride(), nullptr, frame_weights_.Data(), diff->Data(), diff->Stride(),
                            stats_.Data(), nullptr, 0);
   }

@@ -64,6 +64,12 @@ class Xent : public LossItf {
   CuArray<int32> labels_;
   CuVectorD stats_;  // device accumulators
   bool dirty_;
+  // The label-target evaluations (the step path) leave their per-row statistics here, batch after batch, and the sum into stats_ is made
+  // for all of them at once when the room is used up or the accumulators are read (Fetch): same bits, one launch less per step.
+  double *PendingRowStats(int32 rows);   // room for the next batch's [rows x 5], or NULL: too large to defer
+  void FlushPending();
+  CuVectorD pending_;
+  int32 pending_rows_ = 0, pending_batches_ = 0, pending_cap_ = 0;
 };
 
 class Mse : public LossItf {

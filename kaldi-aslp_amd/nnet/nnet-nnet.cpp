@@ -146,6 +146,11 @@ void Nnet::Propagate(const std::vector<const CuMatrixBase *> &in, std::vector<Cu
       out_view_[i] = in_view_[i];  // the loss kernel forms the posteriors itself
       softmax_folded_ = true;
     } else {
+      if (components_[i]->GetType() == Component::kInputLayer) {   // the copy of the input also makes the planes the first layer product reads
+        const int32 ac = AffineConsumerOf(i);
+        if (ac >= 0 && gemm_split16_serves(num_frame, components_[ac]->OutputDim(), components_[ac]->InputDim()))
+          dynamic_cast<InputLayer *>(components_[i])->ProduceOutputPlanes(&dynamic_cast<AffineTransform *>(components_[ac])->InputPlanes());
+      }
       components_[i]->Propagate(*in_view_[i], &output_buf_[i]);
       out_view_[i] = &output_buf_[i];
     }

@@ -423,6 +423,34 @@ def test_bn_backward_with_folded_sigmoid_is_bit_identical(aslp, dev, rows, cols)
         assert np.array_equal(a, b), name
 
 
+@pytest.mark.parametrize("rows,cols,softmax", [(1024, 3000, 1), (1024, 3000, 0), (257, 600, 1), (64, 9000, 0)])
+def test_xent_deferred_row_sums_are_bit_identical(aslp, dev, rows, cols, softmax):
+    """aslp_xent_eval_rows + one aslp_xent_sum_rowstats over several batches = one aslp_xent_eval_p per batch: the same diff and the same
+    bits in the five accumulators (Xent keeps the per-row statistics of up to 32 steps and adds them up when Report() wants them)."""
+    ptr, dim, lib = aslp.ops.ptr, aslp.ops.dim, aslp.ops.lib
+    g = torch.Generator(device=dev).manual_seed(rows * 3 + cols)
+    nb = 7
+    acts = [torch.randn(rows, cols, device=dev, generator=g) * 3 for _ in range(nb)]
+    if not softmax:
+        acts = [torch.softmax(a, 1).contiguous() for a in acts]
+    lab = [torch.randint(0, cols, (rows,), device=dev, generator=g, dtype=torch.int32) for _ in range(nb)]
+    fw = [(torch.rand(rows, device=dev, generator=g) > 0.1).float() * 0.75 for _ in range(nb)]
+    stats_a = torch.full((5,), 0.125, device=dev, dtype=torch.float64)
+    stats_b = stats_a.clone()
+    room = torch.empty(nb, rows, 5, device=dev, dtype=torch.float64)
+    da, db = torch.empty(rows, cols, device=dev), torch.empty(rows, cols, device=dev)
+    for b in range(nb):
+        lib.aslp_xent_eval_p(ptr(acts[b]), dim(acts[b]), ptr(lab[b]), ptr(fw[b]), ptr(da), dim(da).stride, ptr(stats_a), softmax, None)
+        lib.aslp_xent_eval_rows(ptr(acts[b]), dim(acts[b]), ptr(lab[b]), ptr(fw[b]), ptr(db), dim(db).stride, ptr(room[b]), softmax, None)
+        aslp.ops.check_error()
+        assert torch.equal(da, db), b
+    lib.aslp_xent_sum_rowstats(ptr(room), rows, nb, ptr(stats_b))
+    aslp.ops.check_error()
+    torch.cuda.synchronize()
+    assert torch.equal(stats_a, stats_b), (stats_a, stats_b)
+    assert stats_a[0].item() > 0.125 and torch.isfinite(stats_a).all()
+
+
 def _planes_to_host(aslp, po, rows, cols):
     """the [rows x cols] region of a PlanesOut's two fp16 planes, and the bound's bits"""
     memcpy = aslp.lib.hipMemcpy
@@ -437,6 +465,79 @@ def _planes_to_host(aslp, po, rows, cols):
     slot = np.empty(1, np.uint32)
     assert memcpy(slot.ctypes.data, po.slot, 4, 2) == 0
     return out[0], out[1], int(slot[0])
+
+
+@pytest.mark.parametrize("rows,cols,with_dst", [(1024, 440, True), (1024, 440, False), (256, 40, True), (3000, 2048, True), (8, 4, True), (32768, 440, True)])
+def test_copy_mat_planes(aslp, dev, rows, cols, with_dst):
+    """aslp_copy_mat_planes: the copy and the planes (bound = the matrix maximum, found by the launch's workgroups among themselves) of
+    one launch against aslp_copy_mat + the maximum pass + the conversion pass, bit for bit; inf / NaN elements do not set the scale;
+    repeated launches; a matrix too large for one resident grid is declined (0) and nothing is written."""
+    _lib = aslp._lib
+    ptr, dim, lib = aslp.ops.ptr, aslp.ops.dim, aslp.ops.lib
+    g = torch.Generator(device=dev).manual_seed(rows + cols)
+    planes = C.c_void_p(lib.aslp_planes_new())
+    lib.aslp_planes_reserve(planes, rows, cols)
+    try:
+        for it in range(3):
+            src = torch.randn(rows, cols, device=dev, generator=g) * 10.0 ** (3 * it - 3)
+            if it == 2 and rows > 8:
+                src[3, 1], src[5, 2] = float("inf"), float("nan")
+            dst = torch.full((rows, cols), -7.0, device=dev) if with_dst else None
+            po = _lib.PlanesOut()
+            lib.aslp_planes_as_output(planes, C.byref(po))
+            rc = lib.aslp_copy_mat_planes(ptr(dst) if with_dst else None, dim(dst if with_dst else src), ptr(src), dim(src).stride, C.byref(po))
+            aslp.ops.check_error()
+            torch.cuda.synchronize()
+            if rows * cols // 4 > 256 * 256 * 16:
+                assert rc == 0 and po.planes_written == 0
+                assert dst is None or bool((dst == -7.0).all())
+                return
+            assert rc == 1 and po.planes_written == 1
+            if with_dst:
+                assert torch.equal(dst.view(torch.int32), src.view(torch.int32))
+            hi, lo, bits = _planes_to_host(aslp, po, rows, cols)
+            ref = aslp.ops.Planes(src)
+            rpo = _lib.PlanesOut()
+            lib.aslp_planes_as_output(ref.h, C.byref(rpo))
+            rhi, rlo, rbits = _planes_to_host(aslp, rpo, rows, cols)
+            assert bits == rbits, it
+            assert np.array_equal(hi.view(np.uint16), rhi.view(np.uint16)) and np.array_equal(lo.view(np.uint16), rlo.view(np.uint16)), it
+    finally:
+        lib.aslp_planes_free(planes)
+
+
+def test_grid_wide_kernels_stand_down_on_a_shared_device(aslp, dev):
+    """aslp_device_shared(1) (several processes on this GPU; ShmComm sets it): launches whose workgroups wait for ALL workgroups of the launch
+    are not used -- two of them half resident beside each other would never finish.  aslp_copy_mat_planes declines, the BatchNormalization
+    backward leaves the per-workgroup maxima for a conversion pass instead of the planes."""
+    _lib = aslp._lib
+    ptr, dim, lib = aslp.ops.ptr, aslp.ops.dim, aslp.ops.lib
+    rows, cols = 1024, 2048
+    x = torch.randn(rows, cols, device=dev)
+    planes = C.c_void_p(lib.aslp_planes_new())
+    lib.aslp_planes_reserve(planes, rows, cols)
+    lib.aslp_device_shared(1)
+    try:
+        po = _lib.PlanesOut()
+        lib.aslp_planes_as_output(planes, C.byref(po))
+        dst = torch.empty_like(x)
+        assert lib.aslp_copy_mat_planes(ptr(dst), dim(dst), ptr(x), dim(x).stride, C.byref(po)) == 0 and po.planes_written == 0
+        mean, inv = x.mean(0).contiguous(), (1.0 / torch.sqrt(x.var(0, unbiased=False) + 1e-7)).contiguous()
+        od, scale, shift = torch.randn(rows, cols, device=dev), torch.ones(cols, device=dev), torch.zeros(cols, device=dev)
+        ds, dsh, ind = torch.zeros(cols, device=dev), torch.zeros(cols, device=dev), torch.empty(rows, cols, device=dev)
+        lib.aslp_bn_backward_step_p(dim(od), ptr(od), dim(od).stride, None, 0, ptr(scale), ptr(shift), ptr(inv), ptr(ds), ptr(dsh), 0.0, 0.001,
+                                    ptr(ind), dim(ind).stride, None, 0, ptr(x), ptr(mean), C.byref(po))
+        aslp.ops.check_error()
+        torch.cuda.synchronize()
+        assert po.planes_written == 0 and po.nparts > 0
+        parts = np.empty(po.nparts, np.float32)
+        memcpy = aslp.lib.hipMemcpy
+        memcpy.restype, memcpy.argtypes = C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        assert memcpy(parts.ctypes.data, po.parts, 4 * po.nparts, 2) == 0
+        assert parts.max() == ind.abs().max().item()
+    finally:
+        lib.aslp_device_shared(0)
+        lib.aslp_planes_free(planes)
 
 
 @pytest.mark.parametrize("rows,cols,with_y", [(1024, 2048, True), (1024, 2048, False), (1000, 1024, True), (256, 2048, True)])
