@@ -108,6 +108,9 @@ static thread_local hipStream_t t_side = nullptr;
 static thread_local hipEvent_t t_fork_ev = nullptr, t_join_ev = nullptr;
 static thread_local hipStream_t t_side_parent = nullptr;  // main stream the pending side work has to rejoin
 static thread_local bool t_side_dirty = false;
+static thread_local unsigned long t_side_seq = 0;          // side-stream scopes opened by this thread so far
+static thread_local void *t_mark_ev = nullptr;             // the latest marker this thread recorded and the scope count it covers
+static thread_local unsigned long t_mark_seq = 0;
 
 static bool side_ready() {
   if (t_side) return true;
@@ -137,6 +140,7 @@ SideStreamScope::SideStreamScope() : saved_(nullptr), active_(false) {
   set_cur_stream(t_side);
   t_bank = 1;
   t_side_dirty = true;
+  t_side_seq++;
   active_ = true;
 }
 SideStreamScope::~SideStreamScope() {
@@ -160,12 +164,18 @@ bool side_stream_mark(void **ev) {
     *ev = e;
   }
   if (hipEventRecord(static_cast<hipEvent_t>(*ev), t_side) != hipSuccess) { set_error("side stream: marker record failed"); return false; }
+  t_mark_ev = *ev;
+  t_mark_seq = t_side_seq;
   return true;
 }
 void side_stream_mark_wait(void *ev, bool host) {
   if (!ev) return;
   const hipError_t e = host ? hipEventSynchronize(static_cast<hipEvent_t>(ev)) : hipStreamWaitEvent(cur_stream(), static_cast<hipEvent_t>(ev), 0);
-  if (e != hipSuccess) set_error(std::string("side stream: marker wait failed: ") + hipGetErrorString(e));
+  if (e != hipSuccess) { set_error(std::string("side stream: marker wait failed: ") + hipGetErrorString(e)); return; }
+  // This thread's own latest marker with no side-stream scope opened since: the marker stands behind ALL pending side work, and the wait
+  // just made IS the join with the parent stream -- join_side_stream() need not put a second event wait into that stream (a wait on another
+  // stream's event costs the waiting stream several microseconds of idle time even when the event has long fired).
+  if (ev == t_mark_ev && t_mark_seq == t_side_seq && t_bank == 0 && (host || cur_stream() == t_side_parent)) t_side_dirty = false;
 }
 void side_stream_mark_free(void *ev) { if (ev) (void)hipEventDestroy(static_cast<hipEvent_t>(ev)); }
 
