@@ -360,6 +360,9 @@ int aslp_xent_eval_p(const float *net_out, MatrixDim d, const int32_cuda *labels
  * of three.  Returns 1 (out->planes_written set) or 0 = not served (more rows than the chip holds at once, unaligned operands): nothing
  * was written, the caller copies and converts. */
 int aslp_copy_mat_planes(float *dst, MatrixDim d, const float *src, int src_stride, aslp_planes_out *out);
+/* The same single launch also serves aslp_planes_convert and the components' own conversions where the matrices fit one resident grid;
+ * aslp_coop_convert(0) sends them through the maximum pass + conversion pass again (same planes, bit for bit: tests compare the two). */
+void aslp_coop_convert(int on);
 /* aslp_xent_eval_p in two halves, for a caller that evaluates batch after batch and reads its accumulators rarely (Xent: at Report()):
  * aslp_xent_eval_rows leaves the batch's per-row statistics in rowstats_out [d.rows x 5 doubles] instead of adding them up -- one launch
  * less in front of the backward pass of every step; aslp_xent_sum_rowstats adds `batches` such blocks of `rows` rows each (consecutive in

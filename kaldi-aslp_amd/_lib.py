@@ -180,6 +180,7 @@ _sig("aslp_xent_eval_p", _i, _vp, _md, _vp, _vp, _vp, _i, _vp, _i, C.POINTER(Pla
 _sig("aslp_xent_eval_rows", _i, _vp, _md, _vp, _vp, _vp, _i, _vp, _i, C.POINTER(PlanesOut))
 _sig("aslp_xent_sum_rowstats", None, _vp, _i, _i, _vp)
 _sig("aslp_device_shared", None, _i)
+_sig("aslp_coop_convert", None, _i)
 _sig("aslp_softmax_xent_eval", None, _vp, _md, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i)
 _sig("aslp_dropout_forward", None, _vp, _i, _vp, _md, _vp, _i, _f, C.c_ulonglong)
 _sig("aslp_dropout_backward", None, _vp, _i, _vp, _md, _vp, _i, _f)

@@ -57,7 +57,6 @@ __device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_byte_addr)
 // nothing to zero first; the conversion reduces the partials.  Rows are dealt to the workgroups in contiguous chunks; a row is
 // covered by tw = 2^tw_log2 threads with 16 bytes each per pass (no division anywhere, every load of a thread independent).
 struct MaxJob { const float *p; int rows, cols, ld; float *part; };
-constexpr int kS16MaxJobs = 8;     // matrices per maximum / conversion launch (blockIdx.y)
 struct MaxJobs { MaxJob j[kS16MaxJobs]; };
 __global__ void __launch_bounds__(256) s16_absmax_kernel(MaxJobs jobs, int tw_log2) {
   const MaxJob j = jobs.j[blockIdx.y];
@@ -867,6 +866,10 @@ bool PlaneSet::ConvertWithParts(const float *src, int rows, int cols, int stride
 bool PlaneSet::ConvertFrom(const float *src, int rows, int cols, int stride) {
   if ((cols & 3) || (stride & 3) || !aligned16(src)) return false;
   if (!Reserve(rows, cols)) return false;
+  {
+    const CoopConvJob job = {src, stride, nullptr, 0, View(), nullptr, 0};
+    if (coop_convert_launch(&job, 1)) { host_bound_ = -1.f; return true; }   // one launch instead of two
+  }
   MaxJobs ms;
   ms.j[0] = MaxJob{src, rows, cols, stride, parts_};
   hipLaunchKernelGGL(s16_absmax_kernel, dim3(kS16ConvParts, 1), dim3(256), 0, cur_stream(), ms, tw_log2_for(cols >> 2));
@@ -891,6 +894,15 @@ bool PlaneSet::ConvertMany(const ConvertSpec *specs, int n) {
     max_c4 = std::max(max_c4, c.cols >> 2);
     max_k8 = std::max(max_k8, c.planes->ld_ >> 3);
     max_rows = std::max(max_rows, c.planes->rows_p_);
+  }
+  if (need_max) {   // one launch for the maxima and the planes where the matrices fit one resident grid
+    CoopConvJob cj[kS16MaxJobs];
+    for (int i = 0; i < n; i++) {
+      const ConvertSpec &c = specs[i];
+      const bool given = c.parts != nullptr && c.nparts > 0 && c.nparts <= kS16MaxParts;
+      cj[i] = CoopConvJob{c.src, c.stride, nullptr, 0, c.planes->View(), given ? c.parts : nullptr, given ? c.nparts : 0};
+    }
+    if (coop_convert_launch(cj, n)) return true;
   }
   if (need_max) hipLaunchKernelGGL(s16_absmax_kernel, dim3(kS16ConvParts, n), dim3(256), 0, cur_stream(), ms, tw_log2_for(max_c4));
   hipLaunchKernelGGL(split16_convert_kernel, dim3(std::min(max_rows, 512), n), dim3(256), 0, cur_stream(), js, tw_log2_for(max_k8));

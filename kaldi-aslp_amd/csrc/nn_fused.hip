@@ -633,13 +633,16 @@ __device__ __forceinline__ float coop_grid_max(float wg_max, unsigned long long 
   return gm;
 }
 
-// A matrix copied and its fp16 planes made in ONE launch (aslp_copy_mat_planes; the network input: copy + maximum pass + conversion pass
-// were three launches in front of the first layer product): a thread holds U 16-byte pieces, the workgroups' maxima meet as above.
+// Matrices (up to kS16MaxJobs, blockIdx.y) copied (optional) and their fp16 planes made in ONE launch (coop_convert_launch: the network
+// input -- copy + maximum pass + conversion pass were three launches in front of the first layer product -- and PlaneSet::ConvertFrom /
+// ConvertMany): a thread holds U 16-byte pieces of its matrix, the workgroups of a matrix find its maximum among themselves as above.  A
+// matrix whose bound is given (parts) takes it from there.
+struct CoopConvJobs { CoopConvJob j[kS16MaxJobs]; };
 template <int U>
-__global__ void __launch_bounds__(kPanelThreads) copy_planes_coop(const float *__restrict__ src, int lds_, float *__restrict__ dst, int ldd, int rows,
-                                                                   int cols, S16Out po, unsigned long long *gmax, unsigned token, unsigned *err) {
+__global__ void __launch_bounds__(kPanelThreads) copy_planes_coop(CoopConvJobs jobs, unsigned long long *gmax, unsigned token, unsigned *err) {
   __shared__ float red[kPanelWaves];
-  const int c4 = cols >> 2, units = rows * c4;
+  const CoopConvJob job = jobs.j[blockIdx.y];
+  const int rows = job.pl.rows, cols = job.pl.cols, c4 = cols >> 2, units = rows * c4;
   float4 v[U];
   int rr[U], cc[U];
   float m = 0.f;
@@ -649,28 +652,37 @@ __global__ void __launch_bounds__(kPanelThreads) copy_planes_coop(const float *_
     const int r = u / c4;
     rr[k] = u < units ? r : -1;
     cc[k] = 4 * (u - r * c4);
-    v[k] = u < units ? *reinterpret_cast<const float4 *>(src + (long)r * lds_ + cc[k]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    v[k] = u < units ? *reinterpret_cast<const float4 *>(job.src + (long)r * job.ld_src + cc[k]) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (job.parts != nullptr) {   // (uniform) the bound is known: every workgroup reads it
+    for (int i0 = threadIdx.x; i0 < job.nparts; i0 += 4 * kPanelThreads) {
+      float p[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) { const int i = i0 + q * kPanelThreads; p[q] = i < job.nparts ? job.parts[i] : 0.f; }
+      m = fmaxf(fmaxf(m, fmaxf(p[0], p[1])), fmaxf(p[2], p[3]));
+    }
   }
 #pragma unroll
   for (int k = 0; k < U; k++) {
-    if (rr[k] >= 0 && dst != nullptr) *reinterpret_cast<float4 *>(dst + (long)rr[k] * ldd + cc[k]) = v[k];
-    m = s16_absmax4(m, v[k]);
+    if (rr[k] >= 0 && job.dst != nullptr) *reinterpret_cast<float4 *>(job.dst + (long)rr[k] * job.ld_dst + cc[k]) = v[k];
+    if (job.parts == nullptr) m = s16_absmax4(m, v[k]);
   }
   m = wave_max(m);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
   m = red[0];
   for (int w = 1; w < kPanelWaves; w++) m = fmaxf(m, red[w]);
-  const unsigned mbits = __float_as_uint(coop_grid_max(m, gmax, token, err, red));
-  if (blockIdx.x == 0 && threadIdx.x == 0) *const_cast<unsigned *>(po.slot) = mbits;
+  unsigned mbits = __float_as_uint(m);
+  if (job.parts == nullptr) mbits = __float_as_uint(coop_grid_max(m, gmax + (size_t)blockIdx.y * gridDim.x, token, err, red));
+  if (blockIdx.x == 0 && threadIdx.x == 0) *job.pl.slot = mbits;
   const float ps = ldexpf(1.f, s16_exponent(mbits));
 #pragma unroll
   for (int k = 0; k < U; k++) {
     if (rr[k] < 0) continue;
     half4 hi, lo;
     s16_split4(v[k], ps, &hi, &lo);
-    *reinterpret_cast<half4 *>(po.hi + (long)rr[k] * po.ld + cc[k]) = hi;
-    *reinterpret_cast<half4 *>(po.lo + (long)rr[k] * po.ld + cc[k]) = lo;
+    *reinterpret_cast<half4 *>(job.pl.hi + (long)rr[k] * job.pl.ld + cc[k]) = hi;
+    *reinterpret_cast<half4 *>(job.pl.lo + (long)rr[k] * job.pl.ld + cc[k]) = lo;
   }
 }
 
@@ -822,8 +834,9 @@ __global__ void __launch_bounds__(kPanelThreads) bn_backward_coop(const float *_
 }
 constexpr int kCoopGmaxWords = 1024;   // workgroups whose maxima may meet in one launch
 struct CoopState { unsigned long long *inbox = nullptr, *gmax = nullptr; unsigned *err = nullptr, token = 0; bool tried = false; };
+// (per host thread: launches of different threads run side by side on their own streams and must not meet in one exchange area)
 CoopState &coop_state() {
-  static CoopState st;
+  static thread_local CoopState st;
   if (!st.tried) {
     st.tried = true;
     const size_t words = (size_t)256 * 8 * 8 * kCoopCols * 3;  // up to 256 panels x Q <= 8 readers x 8 writers
@@ -1140,6 +1153,41 @@ __global__ void xent_apply_kernel(const double *sums, int batches, double *stats
 }
 
 }  // namespace
+
+static bool g_coop_convert_on = true;   // aslp_coop_convert (tests: the two-launch conversion as the reference)
+// split16.h: (optional copy and) planes of n matrices in one launch; false = not served, nothing was launched
+bool coop_convert_launch(const CoopConvJob *jobs, int n) {
+  static const bool off = [] { const char *e = getenv("ASLP_COPY_PLANES"); return e != nullptr && e[0] == '0'; }();   // A/B switch
+  // Not beside the main stream: a launch there may share the chip with a persistent recurrence whose workgroups need every CU (each
+  // would wait for workgroups the other keeps from being placed), and two launches of this thread would meet in one exchange area.
+  if (off || !g_coop_convert_on || device_shared() || on_side_stream() || n <= 0 || n > kS16MaxJobs) return false;
+  long max_units = 0;
+  CoopConvJobs js;
+  for (int i = 0; i < n; i++) {
+    const CoopConvJob &c = jobs[i];
+    if (!c.src || !c.pl.hi || !c.pl.lo || !c.pl.slot || c.pl.rows <= 0 || c.pl.cols <= 0 || (c.pl.cols & 3) || (c.ld_src & 3) || !aligned16(c.src) ||
+        (c.dst && ((c.ld_dst & 3) || !aligned16(c.dst))) || c.pl.ld < c.pl.cols || (c.pl.ld & 3) || (c.parts && c.nparts <= 0))
+      return false;
+    max_units = std::max(max_units, (long)c.pl.rows * (c.pl.cols >> 2));
+    js.j[i] = c;
+  }
+  CoopState &st = coop_state();
+  if (!st.gmax) return false;
+  // every workgroup of the launch resident at once (those of a matrix wait for each other): at most one per CU
+  const int cus = std::min(coop_cu_count(), kCoopGmaxWords);
+  int U = 0, gx = 0;
+  for (int u : {4, 8, 16}) {
+    const long g = (max_units + (long)u * kPanelThreads - 1) / ((long)u * kPanelThreads);
+    if (U == 0 && g * n <= cus) { U = u; gx = (int)g; }
+  }
+  if (U == 0) return false;
+  if (++st.token == 0) st.token = 1;
+#define ASLP_COPY_PLANES(UU) hipLaunchKernelGGL((copy_planes_coop<UU>), dim3(gx, n), dim3(kPanelThreads), 0, cur_stream(), js, st.gmax, st.token, st.err)
+  if (U == 4) ASLP_COPY_PLANES(4); else if (U == 8) ASLP_COPY_PLANES(8); else ASLP_COPY_PLANES(16);
+#undef ASLP_COPY_PLANES
+  check_launch("coop_convert");
+  return true;
+}
 }  // namespace aslp
 
 using namespace aslp;
@@ -1257,7 +1305,7 @@ static void bn_backward_impl(MatrixDim d, const float *out_diff, int od_stride, 
     S16Out po = {nullptr, nullptr, 0, nullptr, nullptr};
     unsigned token = 0;
     static const bool planes_off = [] { const char *e = getenv("ASLP_BN_DIFF_PLANES"); return e != nullptr && e[0] == '0'; }();   // A/B switch
-    if (diff_out && diff_out->hi && diff_out->lo && diff_out->slot && in_diff && st.gmax && !planes_off && !device_shared() && (int)grid.x <= kCoopGmaxWords &&
+    if (diff_out && diff_out->hi && diff_out->lo && diff_out->slot && in_diff && st.gmax && !planes_off && !device_shared() && !on_side_stream() && (int)grid.x <= kCoopGmaxWords &&
         (int)grid.x <= coop_cu_count() && diff_out->ld >= d.cols && diff_out->ld % 4 == 0) {
       po = S16Out{static_cast<h16 *>(diff_out->hi), static_cast<h16 *>(diff_out->lo), diff_out->ld, diff_out->slot, nullptr};
       if (++st.token == 0) st.token = 1;
@@ -1403,28 +1451,14 @@ int aslp_xent_eval_p(const float *net_out, MatrixDim d, const int32_cuda *labels
 // dst (nullable) <- src and src's planes in one launch; 1 = done (planes_written set), 0 = not served: the caller copies and converts
 int aslp_copy_mat_planes(float *dst, MatrixDim d, const float *src, int src_stride, aslp_planes_out *out) {
   if (out) { out->nparts = 0; out->planes_written = 0; }
-  if (!out || !out->hi || !out->lo || !out->slot || d.rows <= 0 || d.cols <= 0) return 0;
-  static const bool off = [] { const char *e = getenv("ASLP_COPY_PLANES"); return e != nullptr && e[0] == '0'; }();   // A/B switch
-  if (off || device_shared() || (d.cols & 3) || (src_stride & 3) || !aligned16(src) || (dst && ((d.stride & 3) || !aligned16(dst))) || out->ld < d.cols || (out->ld & 3)) return 0;
-  CoopState &st = coop_state();
-  if (!st.gmax) return 0;
-  const long units = (long)d.rows * (d.cols >> 2);
-  const int cus = std::min(coop_cu_count(), kCoopGmaxWords);
-  int U = 0;
-  for (int u : {4, 8, 16})
-    if (U == 0 && (units + (long)u * kPanelThreads - 1) / ((long)u * kPanelThreads) <= cus) U = u;
-  if (U == 0) return 0;   // more than the chip holds at once
-  const int grid = (int)((units + (long)U * kPanelThreads - 1) / ((long)U * kPanelThreads));
-  const S16Out po = {static_cast<h16 *>(out->hi), static_cast<h16 *>(out->lo), out->ld, out->slot, nullptr};
-  if (++st.token == 0) st.token = 1;
-#define ASLP_COPY_PLANES(UU) \
-  hipLaunchKernelGGL((copy_planes_coop<UU>), dim3(grid), dim3(kPanelThreads), 0, cur_stream(), src, src_stride, dst, d.stride, d.rows, d.cols, po, st.gmax, st.token, st.err)
-  if (U == 4) ASLP_COPY_PLANES(4); else if (U == 8) ASLP_COPY_PLANES(8); else ASLP_COPY_PLANES(16);
-#undef ASLP_COPY_PLANES
-  check_launch("copy_mat_planes");
+  if (!out || !out->hi || !out->lo || !out->slot || d.rows <= 0 || d.cols <= 0 || out->ld < d.cols) return 0;
+  CoopConvJob job = {src, src_stride, dst, d.stride, S16View{static_cast<h16 *>(out->hi), static_cast<h16 *>(out->lo), out->ld, d.rows, d.cols,
+                                                              const_cast<unsigned *>(out->slot)}, nullptr, 0};
+  if (!coop_convert_launch(&job, 1)) return 0;
   out->planes_written = 1;
   return 1;
 }
+void aslp_coop_convert(int on) { g_coop_convert_on = on != 0; }
 int aslp_xent_eval_rows(const float *net_out, MatrixDim d, const int32_cuda *labels, const float *frame_weights, float *diff, int diff_stride,
                         double *rowstats_out, int softmax, const aslp_planes_out *diff_planes) {
   if (!rowstats_out) { set_error("aslp_xent_eval_rows: no room for the per-row statistics"); return 0; }

@@ -83,6 +83,14 @@ __device__ __forceinline__ float s16_absmax4(float m, const float4 v) {
 }
 #endif
 
+// (Optional copy and) planes of up to kS16MaxJobs matrices in ONE launch, each scaled by its own maximum, which the launch's workgroups find
+// among themselves (nn_fused.hip copy_planes_coop): instead of a maximum launch and a conversion launch.  parts / nparts: a bound of the
+// matrix known on the device (as ConvertSpec).  false = not served (too large for one resident grid, unaligned, a shared device): nothing
+// was launched.
+struct CoopConvJob { const float *src; int ld_src; float *dst; int ld_dst; S16View pl; const float *parts; int nparts; };
+constexpr int kS16MaxJobs = 8;     // matrices per maximum / conversion launch (blockIdx.y)
+bool coop_convert_launch(const CoopConvJob *jobs, int n);
+
 // ---- host side: device planes of one fp32 matrix, reused from step to step --------------------------------------------------------
 // valid_for(...): the planes hold the values of that matrix as of the tag's epoch (the executor bumps the epochs: nnet-nnet.cpp).
 class PlaneSet {

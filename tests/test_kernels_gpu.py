@@ -496,7 +496,16 @@ def test_copy_mat_planes(aslp, dev, rows, cols, with_dst):
             if with_dst:
                 assert torch.equal(dst.view(torch.int32), src.view(torch.int32))
             hi, lo, bits = _planes_to_host(aslp, po, rows, cols)
-            ref = aslp.ops.Planes(src)
+            lib.aslp_coop_convert(0)
+            try:
+                ref = aslp.ops.Planes(src)   # maximum pass + conversion pass
+            finally:
+                lib.aslp_coop_convert(1)
+            one = aslp.ops.Planes(src)       # aslp_planes_convert on the single launch
+            opo = _lib.PlanesOut()
+            lib.aslp_planes_as_output(one.h, C.byref(opo))
+            ohi, olo, obits = _planes_to_host(aslp, opo, rows, cols)
+            assert obits == bits and np.array_equal(ohi.view(np.uint16), hi.view(np.uint16)) and np.array_equal(olo.view(np.uint16), lo.view(np.uint16)), it
             rpo = _lib.PlanesOut()
             lib.aslp_planes_as_output(ref.h, C.byref(rpo))
             rhi, rlo, rbits = _planes_to_host(aslp, rpo, rows, cols)
@@ -575,7 +584,11 @@ def test_bn_backward_leaves_in_diff_planes(aslp, dev, rows, cols, with_y):
                 pytest.skip("this shape is not served by the cooperative kernel")
             assert po.nparts == 0
             hi, lo, bits = _planes_to_host(aslp, po, rows, cols)
-            ref = aslp.ops.Planes(ind)   # maximum pass + conversion pass over the fp32 in_diff
+            lib.aslp_coop_convert(0)
+            try:
+                ref = aslp.ops.Planes(ind)   # maximum pass + conversion pass over the fp32 in_diff
+            finally:
+                lib.aslp_coop_convert(1)
             rpo = _lib.PlanesOut()
             lib.aslp_planes_as_output(ref.h, C.byref(rpo))
             rhi, rlo, rbits = _planes_to_host(aslp, rpo, rows, cols)
