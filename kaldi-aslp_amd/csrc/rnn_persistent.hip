@@ -1691,8 +1691,9 @@ struct SeqRuntime {
   int timing_mode = 0;  // 0 off, 1 forward kernel, 2 backward kernel
   unsigned epoch = 0, err_seen = 0;
   bool ring_ready = false;
-  hipEvent_t last_done = nullptr;   // completion of the latest persistent launch, and the stream it went to
-  hipStream_t last_stream = nullptr;
+  hipEvent_t last_done = nullptr;   // (made when a launch first comes from another stream than its predecessor)
+  hipStream_t last_stream = nullptr;   // the stream the latest persistent launch went to
+  bool launched = false;
   unsigned *host_err = nullptr;    // mapped host memory (device-visible)
   unsigned *host_err_dev = nullptr;
   int num_cu = 0;
@@ -1765,6 +1766,17 @@ SeqRuntime &seq_runtime() {
     rt.ok = true;
   });
   return rt;
+}
+
+// One persistent launch at a time: a launch that goes to another stream than its predecessor waits for it.  The event is recorded only then,
+// on the predecessor's stream (it then stands behind that launch and whatever followed it there) -- an event record behind EVERY persistent
+// launch cost the common single-stream case ~6 us of idle stream per launch (8 launches per cfg3 step).  Caller holds rt.launch_mu.
+static void chain_behind_last_launch(SeqRuntime &rt) {
+  if (!rt.launched || rt.last_stream == cur_stream()) return;
+  if (!rt.last_done && hipEventCreateWithFlags(&rt.last_done, hipEventDisableTiming) != hipSuccess) rt.last_done = nullptr;
+  if (rt.last_done && hipEventRecord(rt.last_done, rt.last_stream) == hipSuccess && hipStreamWaitEvent(cur_stream(), rt.last_done, 0) == hipSuccess) return;
+  (void)hipGetLastError();        // (the predecessor's stream is gone, or no event: wait for the device instead)
+  (void)hipDeviceSynchronize();
 }
 
 typedef void (*SeqKernel)(aslp_lstm_seq, SeqStatus, unsigned *);
@@ -1920,7 +1932,7 @@ static void launch_seq(const aslp_lstm_seq *a, bool backward, const char *who) {
   // are therefore chained by an event (no host wait); the common single-stream case costs one event record per launch.
   std::lock_guard<std::mutex> launch_lock(rt.launch_mu);
   SharedDeviceLaunch shared_device;   // ASLP_DEVICE_SHARED=1 only: cross-process lock held until this kernel has completed
-  if (rt.last_done && rt.last_stream != cur_stream()) ASLP_CHECK_HIP(hipStreamWaitEvent(cur_stream(), rt.last_done, 0));
+  chain_behind_last_launch(rt);
   // Device-side state is self-cleaning: the placement table is epoch-tagged and every share a backward launch publishes is
   // consumed and reset inside that launch.  Only after a launch that gave up (the mapped error word moved) are the abort
   // word and the share ring put back by hand.
@@ -1944,8 +1956,8 @@ static void launch_seq(const aslp_lstm_seq *a, bool backward, const char *who) {
     // (only lstm_seq_bwd_h forms the per-workgroup maxima of the gate diffs, and only a single launch per pass leaves a complete set)
     if (split_f16_on() && a->s_count == 0 && (a->dmax_parts[0] || a->dmax_parts[1])) t_last_dmax = kMaxChains * wpc;
   }
-  if (!rt.last_done) (void)hipEventCreateWithFlags(&rt.last_done, hipEventDisableTiming);
-  if (rt.last_done) { ASLP_CHECK_HIP(hipEventRecord(rt.last_done, cur_stream())); rt.last_stream = cur_stream(); }
+  rt.last_stream = cur_stream();
+  rt.launched = true;
   check_launch(who);
 }
 
@@ -1968,7 +1980,7 @@ static void launch_gru(const aslp_gru_seq *a, bool backward, const char *who) {
   SeqRuntime &rt = seq_runtime();
   std::lock_guard<std::mutex> launch_lock(rt.launch_mu);   // as launch_seq (the same lock: LSTM and GRU launches share the runtime state)
   SharedDeviceLaunch shared_device;
-  if (rt.last_done && rt.last_stream != cur_stream()) ASLP_CHECK_HIP(hipStreamWaitEvent(cur_stream(), rt.last_done, 0));
+  chain_behind_last_launch(rt);
   if (*rt.host_err != rt.err_seen) {
     rt.err_seen = *rt.host_err;
     rt.ring_ready = false;   // the LSTM backward's share ring may be half consumed: launch_seq puts it back
@@ -1980,8 +1992,8 @@ static void launch_gru(const aslp_gru_seq *a, bool backward, const char *who) {
                   rt.epoch, 0u};
   const int wpc = (a->H + kCellsPerWg - 1) / kCellsPerWg;
   hipLaunchKernelGGL(pick_gru(backward, a->H), dim3(kMaxChains * wpc), dim3(512), 0, cur_stream(), *a, st, rt.place);
-  if (!rt.last_done) (void)hipEventCreateWithFlags(&rt.last_done, hipEventDisableTiming);
-  if (rt.last_done) { ASLP_CHECK_HIP(hipEventRecord(rt.last_done, cur_stream())); rt.last_stream = cur_stream(); }
+  rt.last_stream = cur_stream();
+  rt.launched = true;
   check_launch(who);
 }
 void aslp_gru_seq_forward(const aslp_gru_seq *a) { launch_gru(a, false, "aslp_gru_seq_forward"); }
