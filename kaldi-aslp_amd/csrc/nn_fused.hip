@@ -1173,8 +1173,9 @@ bool coop_convert_launch(const CoopConvJob *jobs, int n) {
   }
   CoopState &st = coop_state();
   if (!st.gmax) return false;
-  // every workgroup of the launch resident at once (those of a matrix wait for each other): at most one per CU
-  const int cus = std::min(coop_cu_count(), kCoopGmaxWords);
+  // every workgroup of the launch resident at once (those of a matrix wait for each other): at most two per CU (four fit by registers and
+  // wave slots; beside a layer product's workgroup, one -- the second then waits for that workgroup to end, which it does)
+  const int cus = std::min(2 * coop_cu_count(), kCoopGmaxWords);
   int U = 0, gx = 0;
   for (int u : {4, 8, 16}) {
     const long g = (max_units + (long)u * kPanelThreads - 1) / ((long)u * kPanelThreads);
