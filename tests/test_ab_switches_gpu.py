@@ -71,6 +71,19 @@ def test_recurrent_ab_switches_agree(tmp_path):
     assert close(step, base)
 
 
+def test_one_launch_conversion_changes_no_bit(tmp_path):
+    """ASLP_COPY_PLANES=0 sends every fp32 -> fp16-planes conversion through a maximum launch and a conversion launch again; the default
+    makes maxima and planes of up to eight matrices in ONE launch whose workgroups find each matrix' maximum among themselves
+    (nn_fused.hip copy_planes_coop: the layer's six weight matrices and its input, the gate diffs, ...).  Same maxima, same planes, so the
+    same products: a layer wide enough for the planes path (T S = 128 rows, 64-wide input, C 128, R 64) must come out bit for bit."""
+    sizes = {"AB_S": "16", "AB_T": "8", "AB_CHUNK": "6", "AB_D": "64"}
+    one = run(tmp_path, "one_launch", **sizes)
+    assert np.isfinite(one).all()
+    assert np.array_equal(one, run(tmp_path, "two_launches", ASLP_COPY_PLANES="0", **sizes))
+    # ... and the planes path is what ran: products on the fp32 instruction give other bits
+    assert not np.array_equal(one, run(tmp_path, "no_planes", ASLP_LSTM_PLANES="0", **sizes))
+
+
 @pytest.mark.parametrize("pscale,odscale,lr", [("0.3", "1e-9", "1e-3"), ("0.001", "1e5", "1e-12"), ("0.05", "1e-20", "1e-3"), ("0.2", "30.0", "1e-6")])
 def test_split_f16_products_keep_fp32_accuracy_at_any_magnitude(tmp_path, pscale, odscale, lr):
     """The recurrent products carry each fp32 operand as two fp16 pieces behind power-of-two scales (weights per column, gate diffs per
