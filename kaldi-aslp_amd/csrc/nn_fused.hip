@@ -4,6 +4,8 @@
 // gemv launches per BatchNormalization step and ~15 + 5 blocking reductions per Xent::Eval;
 // here BN forward is ONE column-statistics pass + 1 write pass (optionally producing the following Sigmoid's
 // output as well), BN backward 1 statistics pass + 1 write pass (optionally absorbing that Sigmoid's backward), and Xent one pass with the row held in registers.
+#include <atomic>
+
 #include "aslp_kernels.h"
 #include "colreduce.h"
 #include "common.h"
@@ -833,12 +835,22 @@ __global__ void __launch_bounds__(kPanelThreads) bn_backward_coop(const float *_
   }
 }
 constexpr int kCoopGmaxWords = 1024;   // workgroups whose maxima may meet in one launch
-struct CoopState { unsigned long long *inbox = nullptr, *gmax = nullptr; unsigned *err = nullptr, token = 0; bool tried = false; };
+// Host threads of this process that launch cooperative kernels.  With more than one, the launches that wait for ALL their workgroups are not
+// used: two of them (or one beside another thread's persistent recurrence) half resident on one chip would wait for each other's
+// unplaced workgroups -- the same reason as device_shared() (scratch.h), between threads instead of processes.
+static std::atomic<int> g_coop_threads{0};
+struct CoopState {
+  unsigned long long *inbox = nullptr, *gmax = nullptr;
+  unsigned *err = nullptr, token = 0;
+  bool tried = false;
+  ~CoopState() { if (tried) g_coop_threads.fetch_sub(1); }   // (the device buffers stay: the runtime may already be going down)
+};
 // (per host thread: launches of different threads run side by side on their own streams and must not meet in one exchange area)
 CoopState &coop_state() {
   static thread_local CoopState st;
   if (!st.tried) {
     st.tried = true;
+    g_coop_threads.fetch_add(1);
     const size_t words = (size_t)256 * 8 * 8 * kCoopCols * 3;  // up to 256 panels x Q <= 8 readers x 8 writers
     unsigned long long *p = nullptr;
     if (hipMalloc(&p, words * 8) == hipSuccess && hipMemset(p, 0xFF, words * 8) == hipSuccess) {
@@ -851,6 +863,8 @@ CoopState &coop_state() {
   }
   return st;
 }
+// may a launch wait for every one of its workgroups?  (a device of this process' own, one launching host thread, the main stream)
+inline bool coop_grid_wide_ok() { return !device_shared() && !on_side_stream() && g_coop_threads.load() <= 1; }
 inline int coop_cu_count() {
   static int num_cu = [] { hipDeviceProp_t pr; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 0; }();
   return num_cu;
@@ -1160,7 +1174,7 @@ bool coop_convert_launch(const CoopConvJob *jobs, int n) {
   static const bool off = [] { const char *e = getenv("ASLP_COPY_PLANES"); return e != nullptr && e[0] == '0'; }();   // A/B switch
   // Not beside the main stream: a launch there may share the chip with a persistent recurrence whose workgroups need every CU (each
   // would wait for workgroups the other keeps from being placed), and two launches of this thread would meet in one exchange area.
-  if (off || !g_coop_convert_on || device_shared() || on_side_stream() || n <= 0 || n > kS16MaxJobs) return false;
+  if (off || !g_coop_convert_on || n <= 0 || n > kS16MaxJobs) return false;
   long max_units = 0;
   CoopConvJobs js;
   for (int i = 0; i < n; i++) {
@@ -1172,7 +1186,7 @@ bool coop_convert_launch(const CoopConvJob *jobs, int n) {
     js.j[i] = c;
   }
   CoopState &st = coop_state();
-  if (!st.gmax) return false;
+  if (!st.gmax || !coop_grid_wide_ok()) return false;
   // every workgroup of the launch resident at once (those of a matrix wait for each other): at most two per CU (four fit by registers and
   // wave slots; beside a layer product's workgroup, one -- the second then waits for that workgroup to end, which it does)
   const int cus = std::min(2 * coop_cu_count(), kCoopGmaxWords);
@@ -1306,7 +1320,7 @@ static void bn_backward_impl(MatrixDim d, const float *out_diff, int od_stride, 
     S16Out po = {nullptr, nullptr, 0, nullptr, nullptr};
     unsigned token = 0;
     static const bool planes_off = [] { const char *e = getenv("ASLP_BN_DIFF_PLANES"); return e != nullptr && e[0] == '0'; }();   // A/B switch
-    if (diff_out && diff_out->hi && diff_out->lo && diff_out->slot && in_diff && st.gmax && !planes_off && !device_shared() && !on_side_stream() && (int)grid.x <= kCoopGmaxWords &&
+    if (diff_out && diff_out->hi && diff_out->lo && diff_out->slot && in_diff && st.gmax && !planes_off && coop_grid_wide_ok() && (int)grid.x <= kCoopGmaxWords &&
         (int)grid.x <= coop_cu_count() && diff_out->ld >= d.cols && diff_out->ld % 4 == 0) {
       po = S16Out{static_cast<h16 *>(diff_out->hi), static_cast<h16 *>(diff_out->lo), diff_out->ld, diff_out->slot, nullptr};
       if (++st.token == 0) st.token = 1;

@@ -549,6 +549,46 @@ def test_grid_wide_kernels_stand_down_on_a_shared_device(aslp, dev):
         lib.aslp_planes_free(planes)
 
 
+def test_grid_wide_kernels_stand_down_with_two_launching_threads(aslp, dev):
+    """Two host threads of one process that both launch cooperative kernels (the sync workers' thread mode): the launches that wait for
+    all their workgroups are not used while both are alive -- the same hazard as two processes on one GPU -- and come back when the
+    second thread has ended."""
+    import threading
+    _lib = aslp._lib
+    ptr, dim, lib = aslp.ops.ptr, aslp.ops.dim, aslp.ops.lib
+    x = torch.randn(512, 256, device=dev)
+    torch.cuda.synchronize()
+
+    def convert():
+        planes = C.c_void_p(lib.aslp_planes_new())
+        lib.aslp_planes_reserve(planes, 512, 256)
+        po = _lib.PlanesOut()
+        lib.aslp_planes_as_output(planes, C.byref(po))
+        rc = lib.aslp_copy_mat_planes(None, dim(x), ptr(x), dim(x).stride, C.byref(po))
+        aslp.ops.check_error()
+        torch.cuda.synchronize()
+        lib.aslp_planes_free(planes)
+        return rc
+
+    assert convert() == 1
+    seen, go, done = [], threading.Event(), threading.Event()
+
+    def other():
+        seen.append(convert())      # this thread's first cooperative launch: two launching threads from here on
+        go.set()
+        done.wait(60)
+
+    t = threading.Thread(target=other)
+    t.start()
+    assert go.wait(60)
+    try:
+        assert seen == [0] and convert() == 0
+    finally:
+        done.set()
+        t.join()
+    assert convert() == 1
+
+
 @pytest.mark.parametrize("rows,cols,with_y", [(1024, 2048, True), (1024, 2048, False), (1000, 1024, True), (256, 2048, True)])
 def test_bn_backward_leaves_in_diff_planes(aslp, dev, rows, cols, with_y):
     """aslp_bn_backward_step_p with planes to fill: the launch's workgroups find the maximum of |in_diff| among themselves and write the
