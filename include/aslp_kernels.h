@@ -214,30 +214,7 @@ typedef struct aslp_gemm_epilogue_ {
    * NULL when beta == 0) the previous step left, the bounds of its two operands' planes and K. */
   const float *bound_w_parts, *bound_c_parts;
   int bound_n;
-  /* The in-diff product of an AffineTransform whose input came through Sigmoid <- BatchNormalization may take that BatchNormalization's
-   * backward pass into its own launch (honoured by the split-fp16 kernel for NN products of 64 Q rows, Q in 1 2 4 8 16, and a multiple of
-   * 128 columns that fill at most one round of workgroups): see aslp_bn_bwd_fused.  NULL: the classic product. */
-  struct aslp_bn_bwd_fused_ *bn_bwd;
 } aslp_gemm_epilogue;
-/* aslp_gemm_epilogue.bn_bwd.  C = alpha op(A) op(B) is the out-diff dy of the Sigmoid's output y; the launch forms d = dy y (1 - y), the
- * column sums S1 = sum d and S2 = sum d xhat with xhat = (x - mean) inv_std (its workgroups exchange their partial sums), takes the
- * gradient step of scale / shift (dscale = S2 + momentum dscale, dshift = S1 + momentum dshift; scale -= learn_rate dscale, ...: what
- * aslp_bn_backward_step_p does), writes the BatchNormalization's in-diff and its fp16 planes (bound: the matrix maximum, found by the
- * workgroups among themselves: planes.planes_written = 1) -- and does NOT write C.  done (out): 1 = all of that happened in the product's
- * launch; 0 = the product ran as a classic one (C written), the caller runs aslp_bn_backward_step_p itself. */
-typedef struct aslp_bn_bwd_fused_ {
-  const float *y;          /* [M x N] the Sigmoid's output */
-  int ldy;
-  const float *x;          /* [M x N] the BatchNormalization's input */
-  int ldx;
-  const float *mean, *inv_std;              /* [N] of the forward pass */
-  float *scale, *shift, *dscale, *dshift;   /* [N] */
-  float momentum, learn_rate;
-  float *in_diff;          /* [M x N] out */
-  int ldid;
-  aslp_planes_out planes;  /* of in_diff: hi / lo / ld / slot */
-  int done;
-} aslp_bn_bwd_fused;
 /* number of per-workgroup maxima (and proof that the planes were written) of the calling thread's latest aslp_sgemm* call; 0 = the kernel that
  * ran does not leave them */
 int aslp_gemm_last_parts(void);

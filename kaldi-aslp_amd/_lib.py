@@ -30,14 +30,7 @@ class GemmEpilogue(C.Structure):
                 ("colsum", C.c_void_p), ("colsum_beta", C.c_float), ("colsum_w", C.c_void_p), ("colsum_w_alpha", C.c_float),
                 ("colstats", C.c_void_p), ("colstats_ld", C.c_int), ("c_src", C.c_void_p), ("ld_c_src", C.c_int),
                 ("planes", PlanesOut), ("planes_of", C.c_int), ("wmax_parts", C.c_void_p), ("cmax_parts", C.c_void_p),
-                ("bound_w_parts", C.c_void_p), ("bound_c_parts", C.c_void_p), ("bound_n", C.c_int), ("bn_bwd", C.c_void_p)]
-
-
-class BnBwdFused(C.Structure):
-    """aslp_bn_bwd_fused (include/aslp_kernels.h)"""
-    _fields_ = [("y", C.c_void_p), ("ldy", C.c_int), ("x", C.c_void_p), ("ldx", C.c_int), ("mean", C.c_void_p), ("inv_std", C.c_void_p),
-                ("scale", C.c_void_p), ("shift", C.c_void_p), ("dscale", C.c_void_p), ("dshift", C.c_void_p), ("momentum", C.c_float),
-                ("learn_rate", C.c_float), ("in_diff", C.c_void_p), ("ldid", C.c_int), ("planes", PlanesOut), ("done", C.c_int)]
+                ("bound_w_parts", C.c_void_p), ("bound_c_parts", C.c_void_p), ("bound_n", C.c_int)]
 
 
 class GruSeq(C.Structure):

@@ -739,8 +739,6 @@ static int sgemm_impl(int transA, int transB, int M, int N, int K, float alpha, 
   if (K > 0 && (!A || !B)) return -3;
   if (K > 0 && (lda < (transA ? M : K) || ldb < (transB ? K : N))) return -4;
   GemmArgs g;
-  g.bnb = BnBwdArgs();
-  if (ep && ep->bn_bwd) ep->bn_bwd->done = 0;
   g.split_k = 0; g.k_chunk = 0; g.split_stride = 0;
   g.pair = 0; g.A1 = g.B1 = nullptr; g.C1 = nullptr; g.ep1 = aslp_gemm_epilogue();
   static const int wide = [] { const char *e = getenv("ASLP_GEMM_WIDE_EPI"); return e ? atoi(e) : 1; }();
@@ -852,7 +850,6 @@ int aslp::sgemm_pair_views(int transA, int transB, int M, int N, int K, float al
   const bool colsum = (ep0 && (ep0->colsum || ep0->colstats)) || (ep1 && (ep1->colsum || ep1->colstats));
   if (!enabled || g_prof_on || colsum) return two();   // per-launch event timing and the column-sum fallback work on single products
   GemmArgs g;
-  g.bnb = BnBwdArgs();
   g.split_k = 0; g.k_chunk = 0; g.split_stride = 0;
   static const int wide = [] { const char *e = getenv("ASLP_GEMM_WIDE_EPI"); return e ? atoi(e) : 1; }();
   g.wide_epilogue = wide;

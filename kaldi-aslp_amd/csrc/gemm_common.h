@@ -20,24 +20,6 @@ __device__ __forceinline__ void static_for(F &&f) {
   }
 }
 
-// The in-diff product that also takes the backward pass of the BatchNormalization (+ folded Sigmoid) below it (gemm_split16.hip
-// s16_finish_bn_bwd; include/aslp_kernels.h aslp_bn_bwd_fused): device-side arguments, x == NULL = off
-struct BnBwdArgs {
-  const float *y, *x, *mean, *inv_std;
-  int ldy, ldx;
-  float *scale, *shift, *dscale, *dshift;
-  float mmt, neg_lr;
-  int step;
-  float *in_diff;
-  int ldid;
-  void *phi, *plo;       // in_diff's planes
-  int pld;
-  unsigned *pslot;
-  unsigned long long *inbox1, *inbox2, *gmax;   // coop.h
-  unsigned *err;
-  unsigned token;
-};
-
 struct GemmArgs {
   const float *A, *B;
   float *C;
@@ -58,7 +40,6 @@ struct GemmArgs {
   const float *A1, *B1;
   float *C1;
   aslp_gemm_epilogue ep1;
-  BnBwdArgs bnb;
 };
 
 // workgroup id -> (tile row, tile column): each XCD (id % 8, private 4 MB L2) gets a compact 2-D sub-grid of

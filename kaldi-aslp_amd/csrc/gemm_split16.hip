@@ -26,7 +26,6 @@
 
 #include "gemm_common.h"
 #include "scratch.h"
-#include "coop.h"
 #include "split16.h"
 
 #pragma clang diagnostic ignored "-Winline-asm"  // the DMA asm clobbers m0 on purpose
@@ -252,196 +251,6 @@ __device__ __forceinline__ void s16_finish(const GemmArgs &g, const S16View &va,
     }
   }
 }
-// ---- the in-diff product that also takes the BatchNormalization's backward pass (GemmArgs::bnb; include/aslp_kernels.h aslp_bn_bwd_fused) ----------
-// 64 x 128 tile, 2 x 2 waves, NN.  The accumulators hold dy of the Sigmoid's output for the tile; what bn_backward_coop would read back from
-// memory is here already.  A column panel of 128 columns belongs to the Q = M / 64 workgroups (tm = 0 .. Q-1) of one tile column; workgroup
-// q OWNS the panel's columns [q cpo, (q + 1) cpo), cpo = 128 / Q.
-//   A. every wave passes its two 32 x 32 patches through its LDS slice (as the wide epilogue does) and holds, per lane, 4 rows x 4 columns
-//      of each: d = dy y (1 - y), xh = (x - mean) inv_std; the tile's column sums of d and d xh meet in LDS.
-//   1. every workgroup sends each column's pair of sums to the column's owner (one 8-byte word; inbox1), the owner adds the Q pairs in
-//      workgroup order, steps dscale / dshift / scale / shift of its columns, and
-//   2. sends the totals to all Q workgroups of the panel (inbox2).
-//   B. in-diff from the registers; the launch's workgroups find max |in-diff| among themselves (coop_grid_max) and write the planes.
-// Inbox words are taken by their reader ("nothing here" put back), launches are stream-ordered: no other reset.  Arithmetic per element
-// as bn_backward_coop's (nn_fused.hip); the sums are formed in another order (tile rows, then workgroups).
-template <int TM, int TN, int NW>
-__device__ __forceinline__ void s16_finish_bn_bwd(const GemmArgs &g, const S16View &va, const S16View &vb, f32x16 (&acc)[TM][TN], const f32x16 (&accx)[TM][TN],
-                                                  int tm, int tn, int wm, int wn, int lane, int wave, float *lds) {
-  static_assert(TM == 1 && TN == 2 && NW == 4, "64 x 128 tile, 2 x 2 waves");
-  const BnBwdArgs &b = g.bnb;
-  const int l31 = lane & 31, lh = lane >> 5, c4 = lane & 7, rr = lane >> 3;
-  const int Q = g.tiles_m, cpo = 128 / Q, q = tm, p = tn;
-  const int row0 = tm * 64 + wm * 32, colw = wn * 64;     // this wave's rows; its first column inside the panel
-  const int gcol0 = tn * 128 + colw;
-  // everything the tail reads that does not depend on the product goes out first
-  float4 y4[TN][4], x4[TN][4], mean4[TN], inv4[TN], g4[TN];
-#pragma unroll
-  for (int n = 0; n < TN; n++) {
-    const int col = gcol0 + n * 32 + 4 * c4;
-    mean4[n] = *reinterpret_cast<const float4 *>(b.mean + col);
-    inv4[n] = *reinterpret_cast<const float4 *>(b.inv_std + col);
-    g4[n] = *reinterpret_cast<const float4 *>(b.scale + col);
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const long row = row0 + rr + 8 * j;
-      y4[n][j] = *reinterpret_cast<const float4 *>(b.y + row * b.ldy + col);
-      x4[n][j] = *reinterpret_cast<const float4 *>(b.x + row * b.ldx + col);
-    }
-  }
-  const int t = threadIdx.x;
-  const int own_col = tn * 128 + q * cpo + (t < cpo ? t : 0);
-  float g_own = 0.f, dsh_old = 0.f, dsc_old = 0.f, sh_old = 0.f;
-  if (t < cpo) { g_own = b.scale[own_col]; dsh_old = b.dshift[own_col]; dsc_old = b.dscale[own_col]; sh_old = b.shift[own_col]; }
-  // 2^-(up_a + up_b) in two exact factors, as s16_finish
-  {
-    const int e = -(s16_exponent(*va.slot) + s16_exponent(*vb.slot));
-    const float s1 = ldexpf(1.f, e / 2), s2 = ldexpf(1.f, e - e / 2);
-#pragma unroll
-    for (int n = 0; n < TN; n++)
-#pragma unroll
-      for (int k = 0; k < 16; k++) acc[0][n][k] = (fmaf(accx[0][n][k], 0x1p-11f, acc[0][n][k]) * s1) * s2;
-  }
-  // LDS behind the waves' transpose slices
-  float *tile = lds + wave * 32 * kEpiPitch;
-  float *red = lds + NW * 32 * kEpiPitch;        // [2 wave rows][128 columns][2]
-  float *gath = red + 2 * 128 * 2;               // [Q writers][cpo][2]
-  float *tot = gath + 128 * 2;                   // [cpo][2]
-  float *stat = tot + 128 * 2;                   // [128][2]
-  float *red4 = stat + 128 * 2;                  // [4]
-  __builtin_amdgcn_s_barrier();                  // every wave is done with the operand LDS
-  // ---- A
-  float4 d4[TN][4], xh4[TN][4];
-#pragma unroll
-  for (int n = 0; n < TN; n++) {
-#pragma unroll
-    for (int e = 0; e < 16; e++) tile[((e & 3) + 8 * (e >> 2) + 4 * lh) * kEpiPitch + l31] = acc[0][n][e];
-    float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
-    const float m[4] = {mean4[n].x, mean4[n].y, mean4[n].z, mean4[n].w}, is[4] = {inv4[n].x, inv4[n].y, inv4[n].z, inv4[n].w};
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const float4 v = *reinterpret_cast<const float4 *>(tile + (rr + 8 * j) * kEpiPitch + 4 * c4);
-      const float dy[4] = {g.alpha * v.x, g.alpha * v.y, g.alpha * v.z, g.alpha * v.w};
-      const float yy[4] = {y4[n][j].x, y4[n][j].y, y4[n][j].z, y4[n][j].w}, xx[4] = {x4[n][j].x, x4[n][j].y, x4[n][j].z, x4[n][j].w};
-      float dd[4], hh[4];
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        {
-#pragma clang fp contract(off)
-          dd[k] = dy[k] * yy[k] * (1.0f - yy[k]);
-        }
-        hh[k] = (xx[k] - m[k]) * is[k];
-        a1[k] += dd[k];
-        a2[k] += hh[k] * dd[k];
-      }
-      d4[n][j] = make_float4(dd[0], dd[1], dd[2], dd[3]);
-      xh4[n][j] = make_float4(hh[0], hh[1], hh[2], hh[3]);
-    }
-#pragma unroll
-    for (int off = 8; off < 64; off <<= 1)
-#pragma unroll
-      for (int k = 0; k < 4; k++) { a1[k] += __shfl_xor(a1[k], off, 64); a2[k] += __shfl_xor(a2[k], off, 64); }
-    if (rr == 0) {
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        float *r = red + ((wm * 128) + colw + n * 32 + 4 * c4 + k) * 2;
-        r[0] = a1[k];
-        r[1] = a2[k];
-      }
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the old scale of every column has landed before this workgroup's sums go out: see 1.)
-  __syncthreads();
-  bool ok = true;
-  // ---- 1
-  if (t < 128) {
-    const float p1 = red[t * 2] + red[(128 + t) * 2], p2 = red[t * 2 + 1] + red[(128 + t) * 2 + 1];
-    const int o = t / cpo, c = t - o * cpo;
-    coop_put(b.inbox1 + ((((size_t)p * Q + o) * Q + q) * cpo + c), ((unsigned long long)__float_as_uint(p2) << 32) | (unsigned long long)__float_as_uint(p1));
-    const int w = t / cpo;   // as owner: writer w's pair for my column c
-    const unsigned long long v = coop_take(b.inbox1 + ((((size_t)p * Q + q) * Q + w) * cpo + c), &ok);
-    gath[(w * cpo + c) * 2] = __uint_as_float((unsigned)v);
-    gath[(w * cpo + c) * 2 + 1] = __uint_as_float((unsigned)(v >> 32));
-  }
-  __syncthreads();
-  if (t < cpo) {
-    float s1 = 0.f, s2 = 0.f;
-    for (int w = 0; w < Q; w++) { s1 += gath[(w * cpo + t) * 2]; s2 += gath[(w * cpo + t) * 2 + 1]; }   // workgroup order
-    tot[t * 2] = s1;
-    tot[t * 2 + 1] = s2;
-    // the owner's step of its columns (every other workgroup read the old scale before it published: it cannot see this)
-    const float dsh = s1 + b.mmt * dsh_old, dsc = s2 + b.mmt * dsc_old;
-    b.dshift[own_col] = dsh;
-    b.dscale[own_col] = dsc;
-    if (b.step) {
-      b.scale[own_col] = g_own + b.neg_lr * dsc;
-      b.shift[own_col] = sh_old + b.neg_lr * dsh;
-    }
-  }
-  __syncthreads();
-  // ---- 2
-  if (t < 128) {
-    const int r = t / cpo, c = t - r * cpo;
-    coop_put(b.inbox2 + ((((size_t)p * Q + r) * Q + q) * cpo + c),
-             ((unsigned long long)__float_as_uint(tot[c * 2 + 1]) << 32) | (unsigned long long)__float_as_uint(tot[c * 2]));
-    const unsigned long long v = coop_take(b.inbox2 + ((((size_t)p * Q + q) * Q + r) * cpo + c), &ok);   // owner r's column c = panel column t
-    stat[t * 2] = __uint_as_float((unsigned)v);
-    stat[t * 2 + 1] = __uint_as_float((unsigned)(v >> 32));
-  }
-  if (!ok) __hip_atomic_fetch_add(b.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  __syncthreads();
-  // ---- B
-  const float invB = 1.0f / (float)g.M;
-  float omax = 0.f;
-#pragma unroll
-  for (int n = 0; n < TN; n++) {
-    const int pc = colw + n * 32 + 4 * c4, col = tn * 128 + pc;
-    const float gs[4] = {g4[n].x, g4[n].y, g4[n].z, g4[n].w}, iv[4] = {inv4[n].x, inv4[n].y, inv4[n].z, inv4[n].w};
-    float ca[4], cb[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const float S1 = stat[(pc + k) * 2], S2 = stat[(pc + k) * 2 + 1];
-      const float dvar = -0.5f * iv[k] * iv[k] * gs[k] * S2;
-      const float dmean = -iv[k] * gs[k] * S1;
-      ca[k] = (2.0f * invB) * dvar;
-      cb[k] = invB * dmean;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const float dv[4] = {d4[n][j].x, d4[n][j].y, d4[n][j].z, d4[n][j].w}, hv[4] = {xh4[n][j].x, xh4[n][j].y, xh4[n][j].z, xh4[n][j].w};
-      float ov[4];
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const float D = dv[k] * gs[k];
-        const float xm = hv[k] / iv[k];
-        ov[k] = D * iv[k] + xm * ca[k] + cb[k];
-      }
-      const float4 o4 = make_float4(ov[0], ov[1], ov[2], ov[3]);
-      const long row = row0 + rr + 8 * j;
-      *reinterpret_cast<float4 *>(b.in_diff + row * b.ldid + col) = o4;
-      omax = s16_absmax4(omax, o4);
-      d4[n][j] = o4;   // (kept for the planes)
-    }
-  }
-  omax = wave_max(omax);
-  if (lane == 0) red4[wave] = omax;
-  __syncthreads();
-  omax = fmaxf(fmaxf(red4[0], red4[1]), fmaxf(red4[2], red4[3]));
-  const unsigned mbits = __float_as_uint(coop_grid_max(omax, b.gmax, (int)blockIdx.x, (int)gridDim.x, b.token, b.err, red4));
-  if (blockIdx.x == 0 && t == 0) *b.pslot = mbits;
-  const float ps = ldexpf(1.f, s16_exponent(mbits));
-  h16 *phi = static_cast<h16 *>(b.phi), *plo = static_cast<h16 *>(b.plo);
-#pragma unroll
-  for (int n = 0; n < TN; n++)
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const long row = row0 + rr + 8 * j, col = tn * 128 + colw + n * 32 + 4 * c4;
-      half4 hi, lo;
-      s16_split4(d4[n][j], ps, &hi, &lo);
-      *reinterpret_cast<half4 *>(phi + row * b.pld + col) = hi;
-      *reinterpret_cast<half4 *>(plo + row * b.pld + col) = lo;
-    }
-}
-
 // column sums of a reduction-major A from the fragments a wave multiplies anyway: sum over the 8 k of a fragment of hi + 2^-11 lo'
 __device__ __forceinline__ float s16_frag_sum(float sum, const half8 hi, const half8 lo) {
   typedef _Float16 half2v __attribute__((ext_vector_type(2)));
@@ -719,10 +528,6 @@ __global__ void __launch_bounds__(64 * WGM * WGN)
   wait_vmcnt<0>();
 
   static_assert(NW * 32 * kEpiPitch * (int)sizeof(float) <= NS * STAGE, "the waves' epilogue slices must fit into the operand LDS");
-  if constexpr ((ABL & 64) != 0) {   // the in-diff product that also takes the BatchNormalization's backward pass
-    s16_finish_bn_bwd<TM, TN, NW>(g, va, vb, acc, accx, tm, tn, wm, wn, lane, wave, lds);
-    return;
-  }
   s16_finish<TM, TN, NW, EXTRA, !A_KC>(g, va, vb, acc, accx, asum, do_colsum, w_bound, m0 + wm * WM, n0 + wn * WN, lane, wave, lds);
 }
 
@@ -1129,36 +934,6 @@ bool gemm_split16_planes_launch(GemmArgs &g, bool a_kc, bool b_kc, const S16View
   auto fits = [&](const S16View &v, bool kc, int outer) { return v.hi && (kc ? (v.rows == outer && v.cols == g.K) : (v.rows == g.K && v.cols == outer)); };
   if (!fits(ops.a, a_kc, g.M) || !fits(ops.b, b_kc, g.N) || !fits(ops.a1, a_kc, g.M) || !fits(ops.b1, b_kc, g.N)) return false;
   t_last_parts = 0;
-  if (g.ep.bn_bwd != nullptr) {   // the BatchNormalization's backward pass in this product's launch, where that is served (else: a classic product)
-    aslp_bn_bwd_fused *f = g.ep.bn_bwd;
-    g.ep.bn_bwd = nullptr;
-    f->done = 0;
-    f->planes.planes_written = 0;
-    f->planes.nparts = 0;
-    static const bool off = [] { const char *e = getenv("ASLP_GEMM_BN_BWD"); return e != nullptr && e[0] == '0'; }();   // A/B switch
-    const int Q = g.M / 64, P = g.N / 128;
-    const aslp_gemm_epilogue &ep = g.ep;
-    auto al4 = [](const void *p, int ld) { return p != nullptr && (reinterpret_cast<uintptr_t>(p) & 15u) == 0 && (ld & 3) == 0; };
-    const bool shape_ok = a_kc && !b_kc && !g.pair && g.M % 64 == 0 && g.N % 128 == 0 && (Q == 1 || Q == 2 || Q == 4 || Q == 8 || Q == 16) && P >= 1 &&
-                          (long)P * Q <= std::min(coop_num_cus(), std::min(kCoopPanelWords / 128, kCoopGmaxWords)) && g.K >= 64 && (cfg == 0 || cfg == 308);
-    const bool plain = g.beta == 0.0f && !ep.bias && ep.clip <= 0.0f && !ep.W && !ep.act_out && !ep.colstats && !ep.colsum && !ep.c_src && ep.planes_of == 0 &&
-                       !ep.wmax_parts && !ep.cmax_parts;
-    const bool ptrs_ok = al4(f->y, f->ldy) && al4(f->x, f->ldx) && al4(f->in_diff, f->ldid) && al4(f->mean, 0) && al4(f->inv_std, 0) && al4(f->scale, 0) &&
-                         f->shift && f->dscale && f->dshift && f->planes.hi && f->planes.lo && f->planes.slot && f->planes.ld >= g.N && (f->planes.ld & 3) == 0;
-    CoopFusedState cs;
-    if (!off && shape_ok && plain && ptrs_ok && coop_fused_state(&cs)) {
-      g.bnb = BnBwdArgs{f->y, f->x, f->mean, f->inv_std, f->ldy, f->ldx, f->scale, f->shift, f->dscale, f->dshift, f->momentum, -f->learn_rate, 1,
-                        f->in_diff, f->ldid, f->planes.hi, f->planes.lo, f->planes.ld, const_cast<unsigned *>(f->planes.slot), cs.inbox1, cs.inbox2, cs.gmax,
-                        cs.err, cs.token};
-      launch_s16<64, 128, 2, 2, 3, true, false, 64, true>(g, ops);
-      g.bnb = BnBwdArgs();
-      t_last_parts = 0;
-      t_last_cfg_s16 = 308;
-      f->done = 1;
-      f->planes.planes_written = 1;
-      return true;
-    }
-  }
   // planes / maxima of the output are written by the 16-byte epilogue only: where that does not apply the request is dropped (the
   // caller sees aslp_gemm_last_parts() == 0 and converts for itself)
   auto drop_extras = [](aslp_gemm_epilogue &ep) { ep.planes_of = 0; ep.wmax_parts = ep.cmax_parts = nullptr; ep.bound_w_parts = ep.bound_c_parts = nullptr; };

@@ -9,7 +9,6 @@
 #include "aslp_kernels.h"
 #include "colreduce.h"
 #include "common.h"
-#include "coop.h"
 #include "split16.h"
 
 namespace aslp {
@@ -405,7 +404,8 @@ __global__ void __launch_bounds__(kPanelThreads) bn_backward_panel(const float *
 // The launch is ordered behind the previous one on its stream, so a reader-owned reset needs no further protocol.
 // Workgroups p, p + P, p + 2P, ... share a panel: with P a multiple of 8 they sit on one XCD (speed only).
 constexpr int kCoopCG = 8, kCoopCols = 32, kCoopLanes = kPanelThreads / kCoopCG;
-constexpr unsigned long long kNothing = kCoopNothing;
+constexpr unsigned long long kNothing = 0xFFFFFFFFFFFFFFFFull;
+constexpr int kCoopSpinLimit = 1 << 22;  // polls before a reader gives up (seconds): the error word is raised, the output is garbage
 
 template <int NW>  // 8-byte words per column
 __device__ __forceinline__ bool coop_exchange(unsigned long long *inbox, int P, int Q, int p, int q, int pc, const unsigned long long (&mine)[NW],
@@ -607,6 +607,34 @@ __global__ void __launch_bounds__(kPanelThreads) bn_forward_stats_kernel(const f
   }
 }
 
+// The largest of one value per workgroup, in every workgroup of a launch whose workgroups are all resident at once (the host checks: they
+// wait for each other).  They meet in gmax, one 8-byte word each: this launch's token | the value's bits -- nothing to reset, an older
+// launch's word never matches.  wg_max: the workgroup's value (in every thread); red: >= kPanelWaves floats of LDS nobody else is using.
+__device__ __forceinline__ float coop_grid_max(float wg_max, unsigned long long *gmax, unsigned token, unsigned *err, float *red) {
+  if (threadIdx.x == 0)
+    __hip_atomic_store(gmax + blockIdx.x, ((unsigned long long)token << 32) | (unsigned long long)__float_as_uint(wg_max), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  float gm = 0.f;
+  bool ok = true;
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += kPanelThreads) {
+    int spins = 0;
+    for (;;) {
+      const unsigned long long v = __hip_atomic_load(gmax + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((unsigned)(v >> 32) == token) { gm = fmaxf(gm, __uint_as_float((unsigned)v)); break; }
+      if (++spins > kCoopSpinLimit) { ok = false; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  if (!ok) __hip_atomic_fetch_add(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  gm = wave_max(gm);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = gm;
+  __syncthreads();
+  gm = red[0];
+  for (int w = 1; w < kPanelWaves; w++) gm = fmaxf(gm, red[w]);
+  return gm;
+}
+
 // Matrices (up to kS16MaxJobs, blockIdx.y) copied (optional) and their fp16 planes made in ONE launch (coop_convert_launch: the network
 // input -- copy + maximum pass + conversion pass were three launches in front of the first layer product -- and PlaneSet::ConvertFrom /
 // ConvertMany): a thread holds U 16-byte pieces of its matrix, the workgroups of a matrix find its maximum among themselves as above.  A
@@ -647,7 +675,7 @@ __global__ void __launch_bounds__(kPanelThreads) copy_planes_coop(CoopConvJobs j
   m = red[0];
   for (int w = 1; w < kPanelWaves; w++) m = fmaxf(m, red[w]);
   unsigned mbits = __float_as_uint(m);
-  if (job.parts == nullptr) mbits = __float_as_uint(coop_grid_max(m, gmax + (size_t)blockIdx.y * gridDim.x, (int)blockIdx.x, (int)gridDim.x, token, err, red));
+  if (job.parts == nullptr) mbits = __float_as_uint(coop_grid_max(m, gmax + (size_t)blockIdx.y * gridDim.x, token, err, red));
   if (blockIdx.x == 0 && threadIdx.x == 0) *job.pl.slot = mbits;
   const float ps = ldexpf(1.f, s16_exponent(mbits));
 #pragma unroll
@@ -789,7 +817,7 @@ __global__ void __launch_bounds__(kPanelThreads) bn_backward_coop(const float *_
       // ... or the planes from this launch: the workgroups' maxima meet (coop_grid_max) and every workgroup scales its rows by the matrix
       // maximum, exactly as the conversion pass would have.
       if (po.hi != nullptr) {
-        const float gm = coop_grid_max(m, gmax, (int)blockIdx.x, (int)gridDim.x, token, err, red);
+        const float gm = coop_grid_max(m, gmax, token, err, red);
         const unsigned mbits = __float_as_uint(gm);
         if (blockIdx.x == 0 && threadIdx.x == 0) *const_cast<unsigned *>(po.slot) = mbits;   // for the products (launched behind this kernel)
         const float ps = ldexpf(1.f, s16_exponent(mbits));
@@ -806,12 +834,13 @@ __global__ void __launch_bounds__(kPanelThreads) bn_backward_coop(const float *_
     }
   }
 }
+constexpr int kCoopGmaxWords = 1024;   // workgroups whose maxima may meet in one launch
 // Host threads of this process that launch cooperative kernels.  With more than one, the launches that wait for ALL their workgroups are not
 // used: two of them (or one beside another thread's persistent recurrence) half resident on one chip would wait for each other's
 // unplaced workgroups -- the same reason as device_shared() (scratch.h), between threads instead of processes.
 static std::atomic<int> g_coop_threads{0};
 struct CoopState {
-  unsigned long long *inbox = nullptr, *gmax = nullptr, *fused1 = nullptr, *fused2 = nullptr;
+  unsigned long long *inbox = nullptr, *gmax = nullptr;
   unsigned *err = nullptr, token = 0;
   bool tried = false;
   ~CoopState() { if (tried) g_coop_threads.fetch_sub(1); }   // (the device buffers stay: the runtime may already be going down)
@@ -830,11 +859,6 @@ CoopState &coop_state() {
       if (st.err) st.inbox = p;
       unsigned long long *gm = nullptr;
       if (st.inbox && hipMalloc(&gm, kCoopGmaxWords * 8) == hipSuccess && hipMemset(gm, 0, kCoopGmaxWords * 8) == hipSuccess) st.gmax = gm;   // (token 0 is never used)
-      unsigned long long *f = nullptr;   // the two panel inboxes of the fused products (coop.h)
-      if (st.gmax && hipMalloc(&f, 2 * (size_t)kCoopPanelWords * 8) == hipSuccess && hipMemset(f, 0xFF, 2 * (size_t)kCoopPanelWords * 8) == hipSuccess) {
-        st.fused1 = f;
-        st.fused2 = f + kCoopPanelWords;
-      }
     }
   }
   return st;
@@ -1143,16 +1167,6 @@ __global__ void xent_apply_kernel(const double *sums, int batches, double *stats
 }
 
 }  // namespace
-
-// coop.h
-int coop_num_cus() { return coop_cu_count(); }
-bool coop_fused_state(CoopFusedState *out) {
-  CoopState &st = coop_state();
-  if (!st.fused1 || !coop_grid_wide_ok()) return false;
-  if (++st.token == 0) st.token = 1;
-  *out = CoopFusedState{st.fused1, st.fused2, st.gmax, st.err, st.token};
-  return true;
-}
 
 static bool g_coop_convert_on = true;   // aslp_coop_convert (tests: the two-launch conversion as the reference)
 // split16.h: (optional copy and) planes of n matrices in one launch; false = not served, nothing was launched

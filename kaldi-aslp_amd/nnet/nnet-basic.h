@@ -89,7 +89,6 @@ class ScaleLayer : public Component {
   BaseFloat scale_;
 };
 
-class BatchNormalization;
 // ---- AffineTransform (nnet-affine-transform.h:34-286) --------------------------------------------
 class AffineTransform : public UpdatableComponent {
  public:
@@ -263,13 +262,6 @@ class AffineTransform : public UpdatableComponent {
       if (n > 0) mx->get().TagParts(in_diff->Data(), n, s16_epochs().bwd);
     }
   }
-  // Executor peephole: this component's input came through Sigmoid <- BatchNormalization (`bn`, the Sigmoid folded into it).  The in-diff
-  // product then also takes that BatchNormalization's backward pass -- d = dy y (1 - y), the column sums, the step of scale / shift, bn's
-  // in-diff `bn_in_diff` and its planes in `dm` -- in its own launch where the kernel serves the shape (aslp_gemm_epilogue.bn_bwd); the
-  // Sigmoid's out-diff `in_diff` is then never written.  Returns true if so; false: the product ran as BackpropagateFnc would have run it
-  // and bn's backward pass is still to be made.  (defined behind BatchNormalization)
-  bool BackpropagateThroughBatchNorm(const CuMatrixBase &out_diff, CuMatrix *in_diff, BatchNormalization *bn, const CuMatrixBase &bn_in,
-                                     const CuMatrixBase &sigmoid_out, CuMatrix *bn_in_diff, PlaneHolder *dm);
   void Update(const CuMatrixBase &input, const CuMatrixBase &diff) {  // :200-245
     const BaseFloat lr = opts_.learn_rate * learn_rate_coef_;
     const BaseFloat lr_bias = opts_.learn_rate * bias_learn_rate_coef_;
@@ -833,19 +825,6 @@ class BatchNormalization : public UpdatableComponent {
     const BaseFloat lr = opts_.learn_rate;
     aslp_vec_axpy2(-lr, dscale_.Data(), scale_.Data(), dshift_.Data(), shift_.Data(), scale_.Dim());
   }
-  // what a producer needs to take this component's backward pass (+ gradient step) into its own launch: fills everything of `f` but
-  // in_diff / planes; false: the forward pass kept a normalised copy (its backward then goes the component's own way).
-  // BackwardTakenByProducer(): that launch ran -- Update() has nothing left to do.
-  bool FillFusedBackward(const CuMatrixBase &in, const CuMatrixBase &sigmoid_out, aslp_bn_bwd_fused *f) {
-    if (xhat_kept_ || in.NumCols() != input_dim_ || !SameDim(in, sigmoid_out)) return false;
-    f->y = sigmoid_out.Data(); f->ldy = sigmoid_out.Stride();
-    f->x = in.Data(); f->ldx = in.Stride();
-    f->mean = mean_vec_.Data(); f->inv_std = var_vec_.Data();
-    f->scale = scale_.Data(); f->shift = shift_.Data(); f->dscale = dscale_.Data(); f->dshift = dshift_.Data();
-    f->momentum = opts_.momentum; f->learn_rate = opts_.learn_rate;
-    return true;
-  }
-  void BackwardTakenByProducer() { fold_update_ = false; update_done_ = true; diff_maxima_ = nullptr; }
   CuVector &Scale() { return scale_; }
   CuVector &Shift() { return shift_; }
   double NumAccFrames() const { return num_acc_frames_; }
@@ -919,34 +898,5 @@ class BatchNormalization : public UpdatableComponent {
   bool acc_cleaned_;
   bool fold_update_ = false, update_done_ = false, xhat_kept_ = true;
 };
-
-inline bool AffineTransform::BackpropagateThroughBatchNorm(const CuMatrixBase &out_diff, CuMatrix *in_diff, BatchNormalization *bn, const CuMatrixBase &bn_in,
-                                                           const CuMatrixBase &sigmoid_out, CuMatrix *bn_in_diff, PlaneHolder *dm) {
-  ASLP_ASSERT(out_diff.NumCols() == output_dim_ && in_diff != NULL && bn_in_diff != NULL && dm != NULL);
-  in_diff_maxima_ = nullptr;
-  in_diff->Resize(out_diff.NumRows(), input_dim_, kUndefined);
-  const PlaneSet *pa = nullptr, *pb = nullptr;
-  if (gemm_split16_serves(out_diff.NumRows(), input_dim_, output_dim_)) {
-    pa = diff_planes_.Of(out_diff, s16_epochs().bwd);
-    pb = WeightPlanes();
-  }
-  aslp_bn_bwd_fused f = aslp_bn_bwd_fused();
-  aslp_gemm_epilogue ep = aslp_gemm_epilogue();
-  bool asked = false;
-  if (pa && pb && bn->FillFusedBackward(bn_in, sigmoid_out, &f) && sigmoid_out.NumCols() == input_dim_ && dm->get().Reserve(out_diff.NumRows(), input_dim_)) {
-    bn_in_diff->Resize(out_diff.NumRows(), input_dim_, kUndefined);
-    f.in_diff = bn_in_diff->Data();
-    f.ldid = bn_in_diff->Stride();
-    aslp_planes_as_output(reinterpret_cast<const aslp_planes *>(&dm->get()), &f.planes);
-    ep.bn_bwd = &f;
-    asked = true;
-  }
-  in_diff->AddMatMat(1.0, out_diff, kNoTrans, linearity_, kNoTrans, 0.0, asked ? &ep : nullptr, pa, pb);
-  if (!asked || !f.done) return false;
-  dm->get().ForgetHostBound();
-  dm->get().Tag(bn_in_diff->Data(), bn_in_diff->Stride(), s16_epochs().bwd);
-  bn->BackwardTakenByProducer();
-  return true;
-}
 
 }  // namespace aslp

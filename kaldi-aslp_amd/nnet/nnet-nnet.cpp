@@ -77,8 +77,6 @@ const CuMatrixBase &Nnet::OutputBuffer(int32 c) const {
 }
 const CuMatrixBase &Nnet::OutputDiffBuffer(int32 c) const {
   if (FusedSigmoidOf(c) >= 0) ASLP_ERR << "out-diff of component " << c << " is not materialised (fused into the Sigmoid behind it); SetLayerFusion(false)";
-  if ((size_t)c < out_diff_unwritten_.size() && out_diff_unwritten_[c])
-    ASLP_ERR << "out-diff of component " << c << " is not materialised (the in-diff product above took the BatchNormalization's backward pass into its launch); SetLayerFusion(false)";
   return *out_diff_view_[c];
 }
 
@@ -274,8 +272,6 @@ void Nnet::Backpropagate(const std::vector<const CuMatrixBase *> &out_diff, std:
   if (recurrent_net && lstm_side_off) overlap_updates = false;
   std::vector<int32> fused_sigmoid(N, -1);   // BN index -> its folded Sigmoid
   std::vector<char> folded(N, 0);            // Sigmoids handled by their BatchNormalization
-  std::vector<char> bn_taken(N, 0);          // BatchNormalizations whose backward pass the in-diff product above them has taken into its launch
-  out_diff_unwritten_.assign(N, 0);
   for (int32 i = 0; i < N; i++) {
     fused_sigmoid[i] = FusedSigmoidOf(i);
     if (fused_sigmoid[i] >= 0) folded[fused_sigmoid[i]] = 1;
@@ -303,8 +299,6 @@ void Nnet::Backpropagate(const std::vector<const CuMatrixBase *> &out_diff, std:
         // identity backward into the only consumer slot: hand the buffer over instead of copying
         target->Swap(&output_diff_buf_[i]);
         out_diff_view_[i] = target;
-      } else if (bn_taken[i]) {
-        // (in-diff, its planes and the step of scale / shift came out of the AffineTransform's launch above)
       } else if (fused_sigmoid[i] >= 0) {
         const int32 fs = fused_sigmoid[i];
         if (direct[i] && components_[components_[i]->GetInput()[0]]->GetType() == Component::kAffineTransform) {
@@ -335,24 +329,7 @@ void Nnet::Backpropagate(const std::vector<const CuMatrixBase *> &out_diff, std:
         if (fuse_layers_) components_[i]->FoldNextUpdateIntoBackprop();
         if (overlap_updates && components_[i]->PersistentRecurrence() && i != lowest_updatable) components_[i]->GradientsBesideLowerLayers();
         if (!want_in_diff && (is_input || feeds_only_input)) components_[i]->InDiffUnusedInNextBackprop();  // here for its gradients only
-        // AffineTransform <- Sigmoid <- BatchNormalization <- AffineTransform: the in-diff product takes the BatchNormalization's backward
-        // pass into its launch (nnet-basic.h BackpropagateThroughBatchNorm) where the kernel serves the shape
-        bool taken = false;
-        if (fuse_layers_ && alias_links_ && !is_input && direct[i] && components_[i]->GetType() == Component::kAffineTransform) {
-          const int32 fs = components_[i]->GetInput()[0];
-          const int32 bn = (folded[fs] && components_[fs]->GetInput().size() == 1) ? components_[fs]->GetInput()[0] : -1;
-          if (bn >= 0 && fused_sigmoid[bn] == fs && direct[bn] && components_[components_[bn]->GetInput()[0]]->GetType() == Component::kAffineTransform) {
-            AffineTransform *lower = dynamic_cast<AffineTransform *>(components_[components_[bn]->GetInput()[0]]);
-            if (gemm_split16_serves(lower->OutputDim(), lower->InputDim(), num_frame)) {
-              CuMatrix *bn_target = &output_diff_buf_[components_[bn]->GetInput()[0]];
-              taken = dynamic_cast<AffineTransform *>(components_[i])->BackpropagateThroughBatchNorm(
-                  output_diff_buf_[i], target, dynamic_cast<BatchNormalization *>(components_[bn]), *in_view_[bn], output_buf_[fs], bn_target, &lower->DiffPlanes());
-              if (taken) { bn_taken[bn] = 1; out_diff_unwritten_[fs] = 1; }
-              else taken = true;   // (the product ran as a classic one: nothing left to do for THIS component)
-            }
-          }
-        }
-        if (!taken) components_[i]->Backpropagate(*in_view_[i], *out_view_[i], output_diff_buf_[i], target);
+        components_[i]->Backpropagate(*in_view_[i], *out_view_[i], output_diff_buf_[i], target);
       }
       in_diff_view_[i] = target;
     }
@@ -752,10 +729,7 @@ std::string Nnet::InfoBackPropagate() const {
   ostr << "### Backward propagation buffer content :\n";
   ostr << "[0] diff of <Input> " << MomentStatistics(output_diff_buf_[0]) << std::endl;
   for (int32 i = 0; i < NumComponents(); i++)
-    if ((size_t)i < out_diff_unwritten_.size() && out_diff_unwritten_[i])
-      ostr << "[" << 1 + i << "] diff-output of " << Component::TypeToMarker(components_[i]->GetType()) << " ( not materialised: taken into the in-diff product's launch )" << std::endl;
-    else
-      ostr << "[" << 1 + i << "] diff-output of " << Component::TypeToMarker(components_[i]->GetType()) << MomentStatistics(*out_diff_view_[i]) << std::endl;
+    ostr << "[" << 1 + i << "] diff-output of " << Component::TypeToMarker(components_[i]->GetType()) << MomentStatistics(*out_diff_view_[i]) << std::endl;
   return ostr.str();
 }
 

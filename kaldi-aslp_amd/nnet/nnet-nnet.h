@@ -129,7 +129,6 @@ class Nnet {
   bool fuse_layers_ = true;
   bool overlap_updates_ = true;
   bool fold_softmax_request_ = false, softmax_folded_ = false, diff_in_place_ = false;
-  std::vector<char> out_diff_unwritten_;   // per component: the last backward pass never wrote its out-diff (taken into a product's launch)
   // weight updates issued on the side stream by the latest Backpropagate and not waited for yet (JoinUpdates(): the main stream waits);
   // the next Propagate joins in front of component first_after_updates_
   // (host_wait: the HOST waits -- for callers that free what the updates touch.)  The marker is an event on the side stream of the thread that

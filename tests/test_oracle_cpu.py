@@ -35,15 +35,13 @@ def test_ctypes_mirrors_have_the_headers_layout(aslp, tmp_path):
     import ctypes as C
     import subprocess
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "aslp_kernels.h"\nint main() { printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(aslp_planes_out), '
-                   'sizeof(aslp_gemm_epilogue), offsetof(aslp_gemm_epilogue, planes), offsetof(aslp_gemm_epilogue, bound_n), sizeof(aslp_bn_bwd_fused), '
-                   'offsetof(aslp_bn_bwd_fused, planes), offsetof(aslp_bn_bwd_fused, done)); return 0; }\n')
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "aslp_kernels.h"\nint main() { printf("%zu %zu %zu %zu\\n", sizeof(aslp_planes_out), '
+                   'sizeof(aslp_gemm_epilogue), offsetof(aslp_gemm_epilogue, planes), offsetof(aslp_gemm_epilogue, bound_n)); return 0; }\n')
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     sizes = [int(x) for x in subprocess.run([str(exe)], check=True, stdout=subprocess.PIPE).stdout.split()]
     from kaldi_aslp_amd import _lib
-    assert sizes == [C.sizeof(_lib.PlanesOut), C.sizeof(_lib.GemmEpilogue), _lib.GemmEpilogue.planes.offset, _lib.GemmEpilogue.bound_n.offset,
-                     C.sizeof(_lib.BnBwdFused), _lib.BnBwdFused.planes.offset, _lib.BnBwdFused.done.offset]
+    assert sizes == [C.sizeof(_lib.PlanesOut), C.sizeof(_lib.GemmEpilogue), _lib.GemmEpilogue.planes.offset, _lib.GemmEpilogue.bound_n.offset]
 
 
 def test_product_does_not_touch_oracle():
