@@ -450,6 +450,14 @@ def hbm_kernels_block(aslp, dev):
     lab = torch.randint(0, OUT_DIM, (R,), device=dev, generator=g, dtype=torch.int32)
     diff, fw, stats = torch.empty_like(acts), torch.ones(R, device=dev), torch.zeros(5, device=dev, dtype=torch.float64)
     rec("xent", timed_us(lambda: aslp.ops.xent_eval(post, fw, diff, stats, labels=lab)), 8 * R * OUT_DIM, "Xent::Eval 1024 x 3000 (read posteriors, write diff)")
+    # ... and as the engine issues it since round 5: the rows' launch per evaluation, the sum into the accumulators once per 32 evaluations
+    room = torch.empty(32, R, 5, device=dev, dtype=torch.float64)
+    rows_us = timed_us(lambda: aslp.ops.xent_eval_rows(post, fw, diff, room[0], lab))
+    sum_us = timed_us(lambda: aslp.ops.xent_sum_rowstats(room, R, 32, stats), 20)
+    rec("xent_per_step", rows_us + sum_us / 32, 8 * R * OUT_DIM,
+        "Xent::Eval 1024 x 3000 as the training step pays for it: aslp_xent_eval_rows per evaluation + 1/32 of aslp_xent_sum_rowstats over 32 evaluations")
+    out["xent_per_step"]["rows_launch_us"] = rows_us
+    out["xent_per_step"]["sum_of_32_us"] = sum_us
     sm = torch.empty_like(acts)
     rec("softmax", timed_us(lambda: aslp.ops.softmax(sm, acts)), 8 * R * OUT_DIM, "Softmax 1024 x 3000")
     rows = 32768

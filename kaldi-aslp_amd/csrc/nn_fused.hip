@@ -958,15 +958,19 @@ __device__ __forceinline__ void xent_sum_rows(const double *rowstats, int rows, 
 // SOFTMAX: `y` holds the activations in front of the network's final Softmax and the row softmax is formed here,
 // with exactly the arithmetic of softmax_rows_kernel<256> (same lane -> column mapping, same reduction order), so
 // folding the Softmax component into the loss changes no bit; `y_out` (nullable) receives the posteriors.
-template <bool DENSE, bool SOFTMAX, int PER>
+template <bool DENSE, bool SOFTMAX, int PER, bool VEC = false>
 __global__ void __launch_bounds__(256) xent_rows_kernel(const float *y, int ldy, const float *t, int ldt, const int32_t *labels,
                                                         const float *fw, float *diff, int ldd, int rows, int cols, double *rowstats,
                                                         float *y_out, int ldyo, S16Out po) {
+  // VEC: slot k of a thread is column 4 (tid + 256 (k / 4)) + k % 4, every array touched 16 bytes at a time (softmax_rows_kernel's second
+  // map, chosen by the same rule: cols % 4 == 0 and 16-byte aligned rows); else column tid + 256 k
+  static_assert(!VEC || PER % 4 == 0, "whole groups of four slots");
   __shared__ float shf[4][4];
   __shared__ int shi[4][2];
   __shared__ float shs[4];
   const float pscale = po.hi ? ldexpf(1.f, s16_exponent(*po.slot)) : 0.f;   // planes of diff for the product that reads it (split16.h)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  auto col_of = [tid](int k) { return VEC ? 4 * (tid + (k >> 2) * 256) + (k & 3) : tid + k * 256; };
   for (int r = blockIdx.x; r < rows; r += gridDim.x) {
     const float *yr = y + (long)r * ldy;
     const float *tr = DENSE ? t + (long)r * ldt : nullptr;
@@ -975,16 +979,35 @@ __global__ void __launch_bounds__(256) xent_rows_kernel(const float *y, int ldy,
     float yv[PER], tv[PER];
     float tsum = 0.0f, ybest = -1e21f, tbest = -1e21f;
     int yi = -1, ti = -1;
+    // the row (activations or posteriors), as many loads in flight as the thread has slots
+    if (VEC) {
+#pragma unroll
+      for (int k4 = 0; k4 < PER / 4; k4++) {
+        const int c = 4 * (tid + k4 * 256);
+        if (c < cols) {
+          const float4 v4 = *reinterpret_cast<const float4 *>(yr + c);
+          yv[4 * k4] = v4.x; yv[4 * k4 + 1] = v4.y; yv[4 * k4 + 2] = v4.z; yv[4 * k4 + 3] = v4.w;
+          if (DENSE) {
+            const float4 t4 = *reinterpret_cast<const float4 *>(tr + c);
+            tv[4 * k4] = t4.x; tv[4 * k4 + 1] = t4.y; tv[4 * k4 + 2] = t4.z; tv[4 * k4 + 3] = t4.w;
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < PER; k++) {
+        const int c = tid + k * 256;
+        if (c < cols) {
+          yv[k] = yr[c];
+          if (DENSE) tv[k] = tr[c];
+        }
+      }
+    }
     if (SOFTMAX) {
       float m = -INFINITY;
 #pragma unroll
-      for (int k = 0; k < PER; k++) {
-        int c = tid + k * 256;
-        if (c < cols) {
-          yv[k] = yr[c];
-          m = fmaxf(m, yv[k]);
-        }
-      }
+      for (int k = 0; k < PER; k++)
+        if (col_of(k) < cols) m = fmaxf(m, yv[k]);
       m = wave_max(m);
       if (lane == 0) shs[w] = m;
       __syncthreads();
@@ -993,8 +1016,7 @@ __global__ void __launch_bounds__(256) xent_rows_kernel(const float *y, int ldy,
       float sum = 0.0f;
 #pragma unroll
       for (int k = 0; k < PER; k++) {
-        int c = tid + k * 256;
-        if (c < cols) {
+        if (col_of(k) < cols) {
           yv[k] = expf(yv[k] - m);
           sum += yv[k];
         }
@@ -1007,25 +1029,84 @@ __global__ void __launch_bounds__(256) xent_rows_kernel(const float *y, int ldy,
       __syncthreads();
       const float inv = 1.0f / sum;
 #pragma unroll
-      for (int k = 0; k < PER; k++) {
-        int c = tid + k * 256;
-        if (c < cols) {
-          yv[k] *= inv;
-          if (y_out) y_out[(long)r * ldyo + c] = yv[k];
+      for (int k = 0; k < PER; k++)
+        if (col_of(k) < cols) yv[k] *= inv;
+      if (y_out) {
+        if (VEC) {
+#pragma unroll
+          for (int k4 = 0; k4 < PER / 4; k4++) {
+            const int c = 4 * (tid + k4 * 256);
+            if (c < cols) *reinterpret_cast<float4 *>(y_out + (long)r * ldyo + c) = make_float4(yv[4 * k4], yv[4 * k4 + 1], yv[4 * k4 + 2], yv[4 * k4 + 3]);
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < PER; k++) {
+            const int c = tid + k * 256;
+            if (c < cols) y_out[(long)r * ldyo + c] = yv[k];
+          }
         }
       }
     }
 #pragma unroll
     for (int k = 0; k < PER; k++) {
-      int c = tid + k * 256;
+      const int c = col_of(k);
       if (c < cols) {
-        if (!SOFTMAX) yv[k] = yr[c];
-        tv[k] = DENSE ? tr[c] : (c == label ? 1.0f : 0.0f);
+        if (!DENSE) tv[k] = (c == label ? 1.0f : 0.0f);
         tsum += tv[k];
         if (ybest < yv[k]) { ybest = yv[k]; yi = c; }
         if (tbest < tv[k]) { tbest = tv[k]; ti = c; }
       }
     }
+    // diff (and the three sums' terms) from the posteriors in the registers.  wr = frame weight x sum(t): frames with sum(t) == 0 are switched
+    // off (nnet-loss.cc:80-85).  With a label target sum(t) is 1 or 0 by the label alone -- known here, so the diff leaves BEFORE the block
+    // reductions below (which then only feed the row's statistics) instead of behind them.
+    double xe = 0.0, en = 0.0, lk = 0.0;
+    auto emit = [&](const float wr) {
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+      if (col_of(k) < cols) {
+        const float yy = yv[k], tt = tv[k];
+        yv[k] = (yy - tt) * wr;   // the diff, kept for the stores below
+        if (tt != 0.0f) {  // t == 0 terms are exactly 0 (t*log(...) with finite log)
+          xe += (double)(logf(yy + 1e-20f) * tt * wr);
+          en += (double)(logf(tt + 1e-20f) * tt * wr);
+          lk += (double)(yy * tt * wr);
+        }
+      }
+    }
+    if (VEC) {
+#pragma unroll
+      for (int k4 = 0; k4 < PER / 4; k4++) {
+        const int c = 4 * (tid + k4 * 256);
+        if (c < cols) {
+          const float4 d4 = make_float4(yv[4 * k4], yv[4 * k4 + 1], yv[4 * k4 + 2], yv[4 * k4 + 3]);
+          *reinterpret_cast<float4 *>(diff + (long)r * ldd + c) = d4;
+          if (po.hi) {
+            half4 hi, lo;
+            s16_split4(d4, pscale, &hi, &lo);
+            *reinterpret_cast<half4 *>(po.hi + (long)r * po.ld + c) = hi;
+            *reinterpret_cast<half4 *>(po.lo + (long)r * po.ld + c) = lo;
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < PER; k++) {
+        const int c = tid + k * 256;
+        if (c < cols) {
+          diff[(long)r * ldd + c] = yv[k];
+          if (po.hi) {
+            h16 h, l;
+            s16_split(yv[k], pscale, &h, &l);
+            po.hi[(long)r * po.ld + c] = h;
+            po.lo[(long)r * po.ld + c] = l;
+          }
+        }
+      }
+    }
+    };
+    const float tsum_by_label = (label >= 0 && label < cols) ? 1.0f : 0.0f;
+    if (!DENSE) emit(fw_r * tsum_by_label);
     // block reductions: tsum, argmax(y), argmax(t)
     tsum = wave_sum(tsum);
 #pragma unroll
@@ -1045,28 +1126,8 @@ __global__ void __launch_bounds__(256) xent_rows_kernel(const float *y, int ldy,
       if (shf[j][2] > tbest || (shf[j][2] == tbest && shi[j][1] >= 0 && (ti < 0 || shi[j][1] < ti))) { tbest = shf[j][2]; ti = shi[j][1]; }
     }
     __syncthreads();
-    const float wr = fw_r * tsum;  // frames with sum(t) == 0 are switched off (nnet-loss.cc:80-85)
-    double xe = 0.0, en = 0.0, lk = 0.0;
-#pragma unroll
-    for (int k = 0; k < PER; k++) {
-      int c = tid + k * 256;
-      if (c < cols) {
-        float yy = yv[k], tt = tv[k];
-        const float dv = (yy - tt) * wr;
-        diff[(long)r * ldd + c] = dv;
-        if (po.hi) {
-          h16 h, l;
-          s16_split(dv, pscale, &h, &l);
-          po.hi[(long)r * po.ld + c] = h;
-          po.lo[(long)r * po.ld + c] = l;
-        }
-        if (tt != 0.0f) {  // t == 0 terms are exactly 0 (t*log(...) with finite log)
-          xe += (double)(logf(yy + 1e-20f) * tt * wr);
-          en += (double)(logf(tt + 1e-20f) * tt * wr);
-          lk += (double)(yy * tt * wr);
-        }
-      }
-    }
+    const float wr = fw_r * tsum;
+    if (DENSE) emit(wr);
     xe = wave_sum_d(xe); en = wave_sum_d(en); lk = wave_sum_d(lk);
     __shared__ double shd[4][3];
     if (lane == 0) { shd[w][0] = xe; shd[w][1] = en; shd[w][2] = lk; }
@@ -1433,9 +1494,17 @@ static bool xent_eval_impl(const float *net_out, MatrixDim d, const float *tgt, 
     po = S16Out{static_cast<h16 *>(diff_planes->hi), static_cast<h16 *>(diff_planes->lo), diff_planes->ld, diff_planes->slot, nullptr};
     planes_written = true;
   }
+  // 16-byte accesses under softmax_rows_kernel's rule (same map: folding the Softmax into the loss changes no bit), every array's rows aligned
+  const bool vec = softmax_rows_vec_ok(d.cols) && (d.stride & 3) == 0 && aligned16(net_out) && (diff_stride & 3) == 0 && aligned16(diff) &&
+                   (!tgt || ((tgt_stride & 3) == 0 && aligned16(tgt))) && (!y_out || ((y_stride & 3) == 0 && aligned16(y_out))) &&
+                   (!po.hi || ((po.ld & 3) == 0 && aligned16(po.hi) && aligned16(po.lo)));
 #define XENT_LAUNCH_P(DENSE, SM, P)                                                                                                       \
-  hipLaunchKernelGGL((xent_rows_kernel<DENSE, SM, P>), dim3(g), dim3(256), 0, cur_stream(), net_out, d.stride, tgt, tgt_stride, labels, \
-                     frame_weights, diff, diff_stride, d.rows, d.cols, rowstats, y_out, y_stride, po)
+  do {                                                                                                                                    \
+    if (vec) hipLaunchKernelGGL((xent_rows_kernel<DENSE, SM, P, true>), dim3(g), dim3(256), 0, cur_stream(), net_out, d.stride, tgt, tgt_stride, labels, \
+                                frame_weights, diff, diff_stride, d.rows, d.cols, rowstats, y_out, y_stride, po);                       \
+    else hipLaunchKernelGGL((xent_rows_kernel<DENSE, SM, P>), dim3(g), dim3(256), 0, cur_stream(), net_out, d.stride, tgt, tgt_stride, labels, \
+                            frame_weights, diff, diff_stride, d.rows, d.cols, rowstats, y_out, y_stride, po);                           \
+  } while (0)
 #define XENT_LAUNCH(DENSE, SM)                                        \
   do {                                                                \
     if (per <= 4) XENT_LAUNCH_P(DENSE, SM, 4);                        \

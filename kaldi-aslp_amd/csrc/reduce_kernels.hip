@@ -41,28 +41,45 @@ __device__ __forceinline__ float block_reduce_sum(float v, float *sh) {
 }
 
 // T threads cooperate on one row; blockDim = (T, 256/T) so small rows still fill 4 waves.
-template <int T, bool LOG, int PER = kMaxPerThread>
+// VEC (T = 256, cols % 4 == 0, 16-byte aligned rows): slot k of a thread is column 4 (tid + 256 (k / 4)) + k % 4 -- four consecutive columns per
+// 16-byte access instead of one column per 4-byte access; the thread's sum runs over its slots in slot order either way.  xent_rows_kernel
+// (nn_fused.hip) uses the same two maps under the same rule, so folding the Softmax into the loss changes no bit.
+template <int T, bool LOG, int PER = kMaxPerThread, bool VEC = false>
 __global__ void __launch_bounds__(256) softmax_rows_kernel(float *y, const float *x, int rows, int cols, int ldy, int ldx) {
+  static_assert(!VEC || (T == 256 && PER % 4 == 0), "the 16-byte map is for whole-workgroup rows");
   __shared__ float sh_all[4][4];
   float *sh = sh_all[threadIdx.y];
+  auto col_of = [](int k) { return VEC ? 4 * ((int)threadIdx.x + (k >> 2) * T) + (k & 3) : (int)threadIdx.x + k * T; };
   for (int r = blockIdx.x * blockDim.y + threadIdx.y; r < rows; r += gridDim.x * blockDim.y) {
     const float *xr = x + (long)r * ldx;
     float *yr = y + (long)r * ldy;
     float v[PER];
     float m = -INFINITY;
+    if (VEC) {
 #pragma unroll
-    for (int k = 0; k < PER; k++) {
-      int c = threadIdx.x + k * T;
-      if (c < cols) {
-        v[k] = xr[c];
-        m = fmaxf(m, v[k]);
+      for (int k4 = 0; k4 < PER / 4; k4++) {
+        const int c = 4 * ((int)threadIdx.x + k4 * T);
+        if (c < cols) {
+          const float4 t4 = *reinterpret_cast<const float4 *>(xr + c);
+          v[4 * k4] = t4.x; v[4 * k4 + 1] = t4.y; v[4 * k4 + 2] = t4.z; v[4 * k4 + 3] = t4.w;
+          m = fmaxf(fmaxf(m, fmaxf(t4.x, t4.y)), fmaxf(t4.z, t4.w));
+        }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < PER; k++) {
+        int c = threadIdx.x + k * T;
+        if (c < cols) {
+          v[k] = xr[c];
+          m = fmaxf(m, v[k]);
+        }
       }
     }
     m = block_reduce_max<T>(m, sh);
     float s = 0.0f;
 #pragma unroll
     for (int k = 0; k < PER; k++) {
-      int c = threadIdx.x + k * T;
+      int c = col_of(k);
       if (c < cols) {
         if (LOG) {
           v[k] -= m;
@@ -75,10 +92,23 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(float *y, const float
     }
     s = block_reduce_sum<T>(s, sh);
     float k2 = LOG ? logf(s) : 1.0f / s;
+    if (VEC) {
 #pragma unroll
-    for (int k = 0; k < PER; k++) {
-      int c = threadIdx.x + k * T;
-      if (c < cols) yr[c] = LOG ? v[k] - k2 : v[k] * k2;
+      for (int k4 = 0; k4 < PER / 4; k4++) {
+        const int c = 4 * ((int)threadIdx.x + k4 * T);
+        if (c < cols) {
+          float o[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) o[q] = LOG ? v[4 * k4 + q] - k2 : v[4 * k4 + q] * k2;
+          *reinterpret_cast<float4 *>(yr + c) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < PER; k++) {
+        int c = threadIdx.x + k * T;
+        if (c < cols) yr[c] = LOG ? v[k] - k2 : v[k] * k2;
+      }
     }
   }
 }
@@ -113,10 +143,19 @@ void launch_softmax(float *y, const float *x, MatrixDim d, int src_stride) {
     // per-thread slots: the smallest of 4 / 8 / 16 / 32 that covers the row (fully unrolled loops; same lane -> column map and
     // summation order for every choice, so the result does not depend on it)
     const int per = (d.cols + 255) / 256;
-    if (per <= 4) hipLaunchKernelGGL((softmax_rows_kernel<256, LOG, 4>), dim3(g), dim3(256, 1), 0, cur_stream(), y, x, d.rows, d.cols, d.stride, src_stride);
-    else if (per <= 8) hipLaunchKernelGGL((softmax_rows_kernel<256, LOG, 8>), dim3(g), dim3(256, 1), 0, cur_stream(), y, x, d.rows, d.cols, d.stride, src_stride);
-    else if (per <= 16) hipLaunchKernelGGL((softmax_rows_kernel<256, LOG, 16>), dim3(g), dim3(256, 1), 0, cur_stream(), y, x, d.rows, d.cols, d.stride, src_stride);
-    else hipLaunchKernelGGL((softmax_rows_kernel<256, LOG, 32>), dim3(g), dim3(256, 1), 0, cur_stream(), y, x, d.rows, d.cols, d.stride, src_stride);
+    // 16-byte accesses where every row starts on a 16-byte boundary (softmax_rows_vec_ok: the rule xent_rows_kernel follows too)
+    const bool vec = softmax_rows_vec_ok(d.cols) && (d.stride & 3) == 0 && (src_stride & 3) == 0 && aligned16(y) && aligned16(x);
+#define ASLP_SOFTMAX_ROWS(P)                                                                                                                        \
+    do {                                                                                                                                            \
+      if (vec) hipLaunchKernelGGL((softmax_rows_kernel<256, LOG, P, true>), dim3(g), dim3(256, 1), 0, cur_stream(), y, x, d.rows, d.cols, d.stride, src_stride); \
+      else hipLaunchKernelGGL((softmax_rows_kernel<256, LOG, P>), dim3(g), dim3(256, 1), 0, cur_stream(), y, x, d.rows, d.cols, d.stride, src_stride);           \
+    } while (0)
+    // (the slots per thread are chosen from the scalar map's count for both maps: cols / 1024 <= cols / 256)
+    if (per <= 4) ASLP_SOFTMAX_ROWS(4);
+    else if (per <= 8) ASLP_SOFTMAX_ROWS(8);
+    else if (per <= 16) ASLP_SOFTMAX_ROWS(16);
+    else ASLP_SOFTMAX_ROWS(32);
+#undef ASLP_SOFTMAX_ROWS
   } else {
     int g = d.rows > kMaxGrid ? kMaxGrid : d.rows;
     hipLaunchKernelGGL((softmax_rows_wide<LOG>), dim3(g), dim3(256), 0, cur_stream(), y, x, d.rows, d.cols, d.stride, src_stride);

@@ -169,6 +169,19 @@ def xent_eval(net_out, frame_weights, diff, stats, targets=None, labels=None):
     check_error()
 
 
+def xent_eval_rows(net_out, frame_weights, diff, rowstats, labels, softmax=False):
+    """aslp_xent_eval_rows: the loss diff and the batch's per-row statistics (rowstats [rows x 5] float64); the sums are taken later"""
+    lib.aslp_xent_eval_rows(ptr(_chk(net_out)), dim(net_out), ptr(labels), ptr(_chk(frame_weights)), ptr(_chk(diff)), dim(diff).stride,
+                            ptr(_chk(rowstats, torch.float64)), int(bool(softmax)), None)
+    check_error()
+
+
+def xent_sum_rowstats(rowstats, rows, batches, stats):
+    """aslp_xent_sum_rowstats: `batches` blocks of `rows` per-row statistics added to the five accumulators, in order"""
+    lib.aslp_xent_sum_rowstats(ptr(_chk(rowstats, torch.float64)), rows, batches, ptr(_chk(stats, torch.float64)))
+    check_error()
+
+
 def ctc_loss(acts, labels, input_lengths, want_grad=True):
     """compute_ctc_loss (warp-ctc/include/ctc.h:88-97) on device activations [(maxT*mb) x A] laid out (t, n, p).
     labels: list of int lists; returns (costs numpy[mb], grads tensor or None)."""
