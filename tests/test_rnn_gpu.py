@@ -396,3 +396,56 @@ def test_recurrent_products_against_float64(aslp, oracle, dev, tmp_path):
     print("relative error against float64:", errs)
     assert max(errs.values()) < 5e-6, errs
     assert errs["two_piece_fp16"] <= 1.5 * errs["fp32_instruction"] + 2e-7, errs
+
+
+def test_persistent_recurrences_from_two_threads_and_streams(aslp, dev):
+    """Two host threads, each with its own stream and its own LC-BLSTM net, train at the same time.  A persistent recurrence needs every CU, so
+    the launches of a process are chained: a launch that goes to another stream than its predecessor waits for it, through an event recorded
+    on the predecessor's stream at that moment (rnn_persistent.hip chain_behind_last_launch; no event behind every launch).  Each thread
+    must get, bit for bit, what the same net gives when it trains alone."""
+    import threading
+    S, T, D, steps = 16, 8, 64, 6
+    proto = "<NnetProto>\n<BLstmProjectedStreamsLC> <InputDim> %d <OutputDim> 128 <CellDim> 128 <ParamScale> 0.05 <ClipGradient> 5.0\n</NnetProto>\n" % D
+
+    def make(seed):   # (nets are initialised from a process-wide generator: one at a time, on the calling thread)
+        net = aslp.Nnet.Init(proto, seed=seed)
+        net.SetTrainOptions(learn_rate=1e-3, momentum=0.9)
+        net.SetChunkSize(6)
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        data = [(torch.randn(T * S, D, generator=g).to(dev), (torch.randn(T * S, 128, generator=g) * 0.1).to(dev)) for _ in range(steps)]
+        torch.cuda.synchronize()
+        return net, data
+
+    def train(net, data, stream):
+        with torch.cuda.stream(stream):
+            aslp.ops.use_torch_stream()
+            outs = []
+            for step, (x, od) in enumerate(data):
+                net.ResetLstmStreams([1] * S if step == 0 else [0] * S)
+                outs.append(net.Propagate(x).cpu().numpy())
+                outs.append(net.Backpropagate(od, want_in_diff=True).cpu().numpy())
+            outs.append(np.asarray(net.GetParams(), np.float32))
+            stream.synchronize()
+        return np.concatenate([o.ravel() for o in outs])
+
+    try:
+        alone = [train(*make(11 + i), torch.cuda.Stream()) for i in range(2)]
+        jobs = [make(11 + i) for i in range(2)]
+        got, errs = [None, None], []
+
+        def worker(i):
+            try:
+                got[i] = train(jobs[i][0], jobs[i][1], torch.cuda.Stream())
+            except Exception as e:   # noqa: BLE001
+                errs.append(e)
+
+        ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not errs, errs
+        for i in range(2):
+            assert np.isfinite(got[i]).all() and np.array_equal(got[i], alone[i]), i
+    finally:
+        aslp.ops.use_torch_stream()
