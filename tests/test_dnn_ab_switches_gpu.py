@@ -57,6 +57,15 @@ def test_batchnorm_net_switches(tmp_path):
     assert np.isfinite(base).all()
     # the wait for the side-stream weight updates at the end of the backward pass instead of inside the next forward pass: same work, same bits
     assert np.array_equal(base, run(tmp_path, "join_at_end", AB_BN="1", AB_MB="1024", ASLP_LATE_JOIN="0"))
+    # round 5's launch-count work changes who makes an operand's planes and when a sum is taken, never a value: in-diff's planes by a
+    # conversion launch behind bn_backward_coop instead of by its own workgroups; copy, maximum pass and conversion pass of the network input
+    # as three launches; a device declared shared (both of those stand down); every switch together
+    for name, env in (("bn_diff_convert", {"ASLP_BN_DIFF_PLANES": "0"}), ("three_launch_input", {"ASLP_COPY_PLANES": "0"}),
+                      ("shared_device", {"ASLP_DEVICE_SHARED": "1"}),
+                      ("all_off", {"ASLP_BN_DIFF_PLANES": "0", "ASLP_COPY_PLANES": "0", "ASLP_LATE_JOIN": "0"})):
+        assert np.array_equal(base, run(tmp_path, name, AB_BN="1", AB_MB="1024", **env)), name
+    # Softmax / Xent rows one column per access: the rows' sums are formed in another order
+    assert close(run(tmp_path, "scalar_rows", AB_BN="1", AB_MB="1024", ASLP_SOFTMAX_VEC="0"), base, 2e-5)
     # the weights' planes converted in every step / no weight updates beside the backward pass / the fp32 instruction
     assert close(run(tmp_path, "w_convert", AB_BN="1", AB_MB="1024", ASLP_KEEP_WEIGHT_PLANES="0"), base)
     assert close(run(tmp_path, "fp32", AB_BN="1", AB_MB="1024", ASLP_GEMM_SPLIT_F16="0"), base)
