@@ -450,20 +450,30 @@ void LstmDir::BackwardPreparePair(const LstmDir &f, const LstmDir &b, const CuMa
   }
 }
 
-void LstmDir::BackwardFinishPair(const LstmDir &f, const LstmDir &b, const CuMatrixBase &od_f, const CuMatrixBase &od_b, int T, int S,
-                                 CuMatrix *fdbuf, CuMatrix *bdbuf, CuMatrixBase *in_diff, LstmPlanes *pl) {
-  if (f.R <= 0 || !SameShape(f, b)) {
-    f.BackwardFinish(od_f, T, S, false, fdbuf, in_diff, 0.0, true);
-    b.BackwardFinish(od_b, T, S, true, bdbuf, in_diff, 1.0, true);
-    return;
-  }
-  // d_r(t) = out_diff(t) + dGATES(next) W_r (lc.h:791), needed by the W_rm gradient
-  // (out_diff enters as the epilogue's beta term read from its own matrix: no copy into d_r first)
+// d_r(t) = out_diff(t) + dGATES(next) W_r (lc.h:791), needed by the W_rm gradient only
+// (out_diff enters as the epilogue's beta term read from its own matrix: no copy into d_r first)
+void LstmDir::BackwardDrPair(const LstmDir &f, const LstmDir &b, const CuMatrixBase &od_f, const CuMatrixBase &od_b, int T, int S, CuMatrix *fdbuf,
+                             CuMatrix *bdbuf, LstmPlanes *pl) {
   CuSubMatrix dr_f(*fdbuf, S, T * S, f.OffRec(), f.R), dr_b(*bdbuf, S, T * S, b.OffRec(), b.R);
   CuSubMatrix next_f(*fdbuf, 2 * S, T * S, 0, f.GC()), next_b(*bdbuf, 0, T * S, 0, b.GC());  // row blocks of each step's recursion-next
   aslp_gemm_epilogue ep_f = aslp_gemm_epilogue(), ep_b = aslp_gemm_epilogue();
   ep_f.c_src = od_f.Data(); ep_f.ld_c_src = od_f.Stride();
   ep_b.c_src = od_b.Data(); ep_b.ld_c_src = od_b.Stride();
+  if (pl && pl->dg_ok) {
+    const S16View v[4] = {pl->dg[0].Window(2 * S, T * S, 0, f.GC()), pl->dg[1].Window(0, T * S, 0, b.GC()), pl->wr[0].View(), pl->wr[1].View()};
+    AddMatMatPair(dr_f, dr_b, 1.0, next_f, next_b, kNoTrans, f.w_r, b.w_r, kNoTrans, 1.0, &ep_f, &ep_b, v);
+  } else {
+    AddMatMatPair(dr_f, dr_b, 1.0, next_f, next_b, kNoTrans, f.w_r, b.w_r, kNoTrans, 1.0, &ep_f, &ep_b);
+  }
+}
+
+bool LstmDir::BackwardFinishPair(const LstmDir &f, const LstmDir &b, const CuMatrixBase &od_f, const CuMatrixBase &od_b, int T, int S,
+                                 CuMatrix *fdbuf, CuMatrix *bdbuf, CuMatrixBase *in_diff, LstmPlanes *pl, bool with_dr) {
+  if (f.R <= 0 || !SameShape(f, b)) {
+    f.BackwardFinish(od_f, T, S, false, fdbuf, in_diff, 0.0, true);
+    b.BackwardFinish(od_b, T, S, true, bdbuf, in_diff, 1.0, true);
+    return false;
+  }
   if (pl && pl->od_ok && PlanesLevel() >= 3) {   // the dGATES columns of both diff buffers, boundary row blocks included: the products below read shifted row ranges of them
     CuSubMatrix dga_f(*fdbuf, 0, (T + 2) * S, 0, f.GC()), dga_b(*bdbuf, 0, (T + 2) * S, 0, b.GC());
     PlaneSet::ConvertSpec sp[2] = {Spec(&pl->dg[0], dga_f), Spec(&pl->dg[1], dga_b)};
@@ -473,13 +483,8 @@ void LstmDir::BackwardFinishPair(const LstmDir &f, const LstmDir &b, const CuMat
     }
     pl->dg_ok = PlaneSet::ConvertMany(sp, 2);
   }
-  if (pl && pl->dg_ok) {
-    const S16View v[4] = {pl->dg[0].Window(2 * S, T * S, 0, f.GC()), pl->dg[1].Window(0, T * S, 0, b.GC()), pl->wr[0].View(), pl->wr[1].View()};
-    AddMatMatPair(dr_f, dr_b, 1.0, next_f, next_b, kNoTrans, f.w_r, b.w_r, kNoTrans, 1.0, &ep_f, &ep_b, v);
-  } else {
-    AddMatMatPair(dr_f, dr_b, 1.0, next_f, next_b, kNoTrans, f.w_r, b.w_r, kNoTrans, 1.0, &ep_f, &ep_b);
-  }
-  if (!in_diff) return;
+  if (with_dr) BackwardDrPair(f, b, od_f, od_b, T, S, fdbuf, bdbuf, pl);
+  if (!in_diff) return !with_dr;
   // in_diff = dGATES_f W_x,f + dGATES_b W_x,b.  Two products into one output cannot share a launch; as a pair into (in_diff, scratch)
   // followed by one addition they can, and the [T*S x D] output alone does not fill the chip (240 tiles for D = 512).  The sum is
   // rounded once either way (the accumulating epilogue computes acc + C as one rounded addition, gemm_common.h).
@@ -490,7 +495,7 @@ void LstmDir::BackwardFinishPair(const LstmDir &f, const LstmDir &b, const CuMat
   if (scratch.Stride() != in_diff->Stride()) {   // (a view with a foreign stride: keep the two accumulating launches)
     f.BackwardFinish(od_f, T, S, false, fdbuf, in_diff, 0.0, false);
     b.BackwardFinish(od_b, T, S, true, bdbuf, in_diff, 1.0, false);
-    return;
+    return !with_dr;
   }
   if (pl && pl->dg_ok && pl->in_ok) {
     const S16View v[4] = {pl->dg[0].Window(S, T * S, 0, f.GC()), pl->dg[1].Window(S, T * S, 0, b.GC()), pl->wx[0].View(), pl->wx[1].View()};
@@ -499,6 +504,7 @@ void LstmDir::BackwardFinishPair(const LstmDir &f, const LstmDir &b, const CuMat
     AddMatMatPair(*in_diff, scratch, 1.0, dg_f, dg_b, kNoTrans, f.w_x, b.w_x, kNoTrans, 0.0);
   }
   in_diff->AddMat(1.0, scratch);
+  return !with_dr;
 }
 
 void LstmDir::GradsPair(LstmDir &f, LstmDir &b, const CuMatrixBase &in, int T, int S, const CuMatrix &fbuf, const CuMatrix &bbuf,
@@ -779,6 +785,9 @@ void LstmFamily::BackpropagateFnc(const CuMatrixBase &in, const CuMatrixBase &, 
   const int32 T = in.NumRows() / S;
   const int rec = f_.Rec();
   const BaseFloat mmt = opts_.momentum;
+  const bool folded = TakeFoldHint();
+  const bool aside = TakeGradsAside() && folded;   // the gradients (and d_r with them) go beside the recurrence of the layer below
+  bool dr_deferred = false;
   if (f_.FusedOk()) {
     CuSubMatrix od_f(out_diff, 0, T * S, 0, rec), od_b(out_diff, 0, T * S, cfg_.bidir ? rec : 0, rec);
     aslp_lstm_seq q = aslp_lstm_seq();
@@ -854,17 +863,23 @@ void LstmFamily::BackpropagateFnc(const CuMatrixBase &in, const CuMatrixBase &, 
     CheckK();
     // (Running the backward direction's batched products beside the forward direction's on the side stream was tried: no gain,
     // 4.289 vs 4.285 ms per LC step -- the small products do not overlap usefully -- so everything stays on one stream.)
-    if (cfg_.bidir) LstmDir::BackwardFinishPair(f_, b_, od_f, od_b, T, S, &f_dbuf_, &b_dbuf_, in_diff, planes_.get());
+    // d_r feeds the W_rm gradient only: where the gradients go beside the recurrence of the layer below, it goes with them instead of
+    // standing in front of this layer's in-diff (37 us per layer of the LC-BLSTM step's main stream).  A/B: ASLP_LSTM_DR_ASIDE=0.
+    static const bool dr_aside_off = getenv("ASLP_LSTM_DR_ASIDE") != nullptr && getenv("ASLP_LSTM_DR_ASIDE")[0] == '0';
+    if (cfg_.bidir) dr_deferred = LstmDir::BackwardFinishPair(f_, b_, od_f, od_b, T, S, &f_dbuf_, &b_dbuf_, in_diff, planes_.get(), !(aside && !dr_aside_off));
     else f_.BackwardFinish(od_f, T, S, false, &f_dbuf_, in_diff, 0.0, true);
   } else {
     f_.Backward(CuSubMatrix(out_diff, 0, T * S, 0, rec), T, S, false, f_buf_, &f_dbuf_, in_diff, 0.0);
     if (cfg_.bidir) b_.Backward(CuSubMatrix(out_diff, 0, T * S, rec, rec), T, S, true, b_buf_, &b_dbuf_, in_diff, 1.0);
   }
-  const bool folded = TakeFoldHint();
   const BaseFloat lr_fold = folded ? opts_.learn_rate : 0.0f;
   const aslp_lstm_seq *seq = vec_seq_valid_ ? &vec_seq_ : nullptr;
   vec_seq_valid_ = false;
   auto grads = [&]() {
+    if (dr_deferred) {
+      CuSubMatrix od_f2(out_diff, 0, T * S, 0, rec), od_b2(out_diff, 0, T * S, rec, rec);
+      LstmDir::BackwardDrPair(f_, b_, od_f2, od_b2, T, S, &f_dbuf_, &b_dbuf_, planes_.get());
+    }
     if (cfg_.bidir && f_.FusedOk()) LstmDir::GradsPair(f_, b_, in, T, S, f_buf_, b_buf_, f_dbuf_, b_dbuf_, mmt, clip_gradient_, lr_fold, seq, planes_.get());
     else {
       f_.Grads(in, T, S, false, f_buf_, f_dbuf_, mmt, clip_gradient_, lr_fold, seq, 0);
@@ -875,8 +890,8 @@ void LstmFamily::BackpropagateFnc(const CuMatrixBase &in, const CuMatrixBase &, 
   // run on the side stream, where their workgroups share the CUs with the NEXT layer's persistent recurrence -- a latency chain that leaves
   // the CU's issue slots, LDS and registers mostly idle.  Everything they write (corr, W) is next read after the executor's join.
   // (Only with the SGD step folded into them: a separate Update() would follow on the main stream and read corr too early.)
-  if (TakeGradsAside() && folded) {
-    SideStreamScope aside;
+  if (aside) {
+    SideStreamScope aside_scope;
     grads();
   } else {
     grads();

@@ -118,8 +118,12 @@ struct LstmDir {
                                 struct LstmPlanes *pl = nullptr);
   static void BackwardPreparePair(const LstmDir &f, const LstmDir &b, const CuMatrixBase &od_f, const CuMatrixBase &od_b, int T, int S,
                                   CuMatrix *fdbuf, CuMatrix *bdbuf, bool persistent, struct LstmPlanes *pl = nullptr);
-  static void BackwardFinishPair(const LstmDir &f, const LstmDir &b, const CuMatrixBase &od_f, const CuMatrixBase &od_b, int T, int S,
-                                 CuMatrix *fdbuf, CuMatrix *bdbuf, CuMatrixBase *in_diff, struct LstmPlanes *pl = nullptr);
+  // with_dr = false: d_r (which only the W_rm gradient reads) is left to BackwardDrPair -- the caller issues that with the gradients, beside
+  // the recurrence of the layer below, instead of in front of this layer's in-diff on the main stream.  Returns true if d_r was left out.
+  static bool BackwardFinishPair(const LstmDir &f, const LstmDir &b, const CuMatrixBase &od_f, const CuMatrixBase &od_b, int T, int S,
+                                 CuMatrix *fdbuf, CuMatrix *bdbuf, CuMatrixBase *in_diff, struct LstmPlanes *pl = nullptr, bool with_dr = true);
+  static void BackwardDrPair(const LstmDir &f, const LstmDir &b, const CuMatrixBase &od_f, const CuMatrixBase &od_b, int T, int S,
+                             CuMatrix *fdbuf, CuMatrix *bdbuf, struct LstmPlanes *pl);
   static void GradsPair(LstmDir &f, LstmDir &b, const CuMatrixBase &in, int T, int S, const CuMatrix &fbuf, const CuMatrix &bbuf,
                         const CuMatrix &fdbuf, const CuMatrix &bdbuf, float mmt, float clip, float lr_fold, const aslp_lstm_seq *seq = nullptr,
                         struct LstmPlanes *pl = nullptr);

@@ -22,7 +22,9 @@ import aslp_import
 aslp = aslp_import.load(); aslp.ops.use_torch_stream()
 dev = torch.device("cuda:0")
 S, chunk, T, D, C = int(os.environ.get("AB_S", "16")), int(os.environ.get("AB_CHUNK", "6")), int(os.environ.get("AB_T", "9")), int(os.environ.get("AB_D", "24")), 128
-proto = ("<NnetProto>\n<BLstmProjectedStreamsLC> <InputDim> %%d <OutputDim> 128 <CellDim> %%d <ParamScale> %%s <ClipGradient> %%s\n</NnetProto>\n" %% (D, C, os.environ.get("AB_PSCALE", "0.05"), os.environ.get("AB_CLIP", "5.0")))
+layer = "<BLstmProjectedStreamsLC> <InputDim> %%d <OutputDim> 128 <CellDim> %%d <ParamScale> %%s <ClipGradient> %%s\n"
+proto = "<NnetProto>\n" + "".join(layer %% (D if l == 0 else 128, C, os.environ.get("AB_PSCALE", "0.05"), os.environ.get("AB_CLIP", "5.0"))
+                                  for l in range(int(os.environ.get("AB_LAYERS", "1")))) + "</NnetProto>\n"
 net = aslp.Nnet.Init(proto, seed=5)
 net.SetTrainOptions(learn_rate=float(os.environ.get("AB_LR", "1e-3")), momentum=0.9)
 net.SetChunkSize(chunk)
@@ -82,6 +84,19 @@ def test_one_launch_conversion_changes_no_bit(tmp_path):
     assert np.array_equal(one, run(tmp_path, "two_launches", ASLP_COPY_PLANES="0", **sizes))
     # ... and the planes path is what ran: products on the fp32 instruction give other bits
     assert not np.array_equal(one, run(tmp_path, "no_planes", ASLP_LSTM_PLANES="0", **sizes))
+
+
+def test_d_r_beside_the_lower_recurrence_changes_no_bit(tmp_path):
+    """In a stack of LC-BLSTM layers the upper layer's d_r product (which only its W_rm gradient reads) is issued with the gradients, beside the
+    recurrence of the layer below, instead of in front of the layer's in-diff on the main stream (ASLP_LSTM_DR_ASIDE=0: as before).  Same
+    products on another stream: output, input diff and parameters of two training steps must not change by a bit -- which also says that
+    nothing the main stream does meanwhile touches what that product reads or writes."""
+    sizes = {"AB_S": "16", "AB_T": "8", "AB_CHUNK": "6", "AB_D": "64", "AB_LAYERS": "3"}
+    aside = run(tmp_path, "aside", **sizes)
+    assert np.isfinite(aside).all()
+    for k in range(3):
+        assert np.array_equal(aside, run(tmp_path, "main_%d" % k, ASLP_LSTM_DR_ASIDE="0", **sizes)), k
+    assert np.array_equal(aside, run(tmp_path, "aside_again", **sizes))
 
 
 @pytest.mark.parametrize("pscale,odscale,lr", [("0.3", "1e-9", "1e-3"), ("0.001", "1e5", "1e-12"), ("0.05", "1e-20", "1e-3"), ("0.2", "30.0", "1e-6")])
