@@ -281,6 +281,26 @@ void Nnet::Backpropagate(const std::vector<const CuMatrixBase *> &out_diff, std:
     if (components_[i]->IsUpdatable()) lowest_updatable = i;
   static const bool lowest_on_side = getenv("ASLP_LOWEST_UPDATE_ON_SIDE") != nullptr && getenv("ASLP_LOWEST_UPDATE_ON_SIDE")[0] == '1';  // A/B switch
   if (lowest_on_side) lowest_updatable = -1;
+  // How many of the LOWEST updatable components keep their update on the main stream.  The side stream starts late (behind the output layer's
+  // in-diff product) with the largest update and every update carries an HBM-bound epilogue that does not shrink with the minibatch, so it
+  // ends behind the main stream and the next forward pass waits for it: at minibatch 256 the five-hidden-layer net's main stream stood idle
+  // for ~55 of 408 us.  With the lowest TWO AffineTransforms' updates on the main stream the two streams end together there: 0.410 -> 0.394 ms
+  // per step at minibatch 256; at minibatch 512 and 1024 one is the better choice (0.547 against 0.552, 0.742 against 0.745 ms; with
+  // BatchNormalization at 1024: 0.746 against 0.777), and so it is for nets with fewer than four AffineTransforms and for recurrent nets.
+  // A/B: ASLP_UPDATES_ON_MAIN=n.
+  static const int on_main_env = [] { const char *e = getenv("ASLP_UPDATES_ON_MAIN"); return e ? atoi(e) : -1; }();
+  int32 main_below = lowest_updatable;   // updates of updatable components with index <= main_below stay on the main stream
+  {
+    auto is_affine = [&](int32 i) { return components_[i]->GetType() == Component::kAffineTransform && components_[i]->IsUpdatable(); };
+    int affines = 0;
+    for (int32 i = 0; i < N; i++) affines += is_affine(i) ? 1 : 0;
+    const int on_main_n = on_main_env >= 0 ? on_main_env : ((affines >= 4 && !recurrent_net && num_frame <= 384) ? 2 : 1);
+    int seen = 0;
+    for (int32 i = 0; i < N && seen < on_main_n; i++)
+      if (is_affine(i)) { main_below = i; seen++; }
+    if (lowest_updatable < 0 || on_main_n == 0) main_below = -1;
+    else if (main_below < lowest_updatable) main_below = lowest_updatable;
+  }
   for (int32 i = N - 1; i >= 0; i--) {
     if (folded[i]) { in_diff_view_[i] = NULL; continue; }
     Timer tim2;
@@ -337,7 +357,7 @@ void Nnet::Backpropagate(const std::vector<const CuMatrixBase *> &out_diff, std:
       UpdatableComponent *uc = dynamic_cast<UpdatableComponent *>(components_[i]);
       // (the lowest updatable component has nothing below it to run beside: on the main stream it spares the step boundary a
       //  cross-stream event wait, ~10 us before the next forward pass can start)
-      if (overlap_updates && components_[i]->GetType() == Component::kAffineTransform && i != lowest_updatable) {
+      if (overlap_updates && components_[i]->GetType() == Component::kAffineTransform && i > main_below) {
         SideStreamScope side;  // after this component's Backpropagate (which reads the weights), beside everything below it
         uc->Update(*in_view_[i], output_diff_buf_[i]);
       } else {
@@ -373,7 +393,7 @@ void Nnet::Backpropagate(const std::vector<const CuMatrixBase *> &out_diff, std:
   if (overlap_updates && !recurrent_net && !late_join_off && !params_out_silently_ && NULL == in_diff) {
     int32 first = N;
     for (int32 i = 0; i < N; i++) {
-      if (!(components_[i]->GetType() == Component::kAffineTransform && components_[i]->IsUpdatable() && i != lowest_updatable)) continue;
+      if (!(components_[i]->GetType() == Component::kAffineTransform && components_[i]->IsUpdatable() && i > main_below)) continue;
       first = std::min(first, i);
       for (int32 p : components_[i]->GetInput()) first = std::min(first, p);   // its input buffer (and the planes made of it) is an operand
     }
