@@ -867,7 +867,10 @@ void LstmFamily::BackpropagateFnc(const CuMatrixBase &in, const CuMatrixBase &, 
     // standing in front of this layer's in-diff (37 us per layer of the LC-BLSTM step's main stream).  A/B: ASLP_LSTM_DR_ASIDE=0.
     static const bool dr_aside_off = getenv("ASLP_LSTM_DR_ASIDE") != nullptr && getenv("ASLP_LSTM_DR_ASIDE")[0] == '0';
     if (cfg_.bidir) dr_deferred = LstmDir::BackwardFinishPair(f_, b_, od_f, od_b, T, S, &f_dbuf_, &b_dbuf_, in_diff, planes_.get(), !(aside && !dr_aside_off));
-    else f_.BackwardFinish(od_f, T, S, false, &f_dbuf_, in_diff, 0.0, true);
+    else {
+      dr_deferred = aside && !dr_aside_off && f_.R > 0;
+      f_.BackwardFinish(od_f, T, S, false, &f_dbuf_, in_diff, 0.0, !dr_deferred);
+    }
   } else {
     f_.Backward(CuSubMatrix(out_diff, 0, T * S, 0, rec), T, S, false, f_buf_, &f_dbuf_, in_diff, 0.0);
     if (cfg_.bidir) b_.Backward(CuSubMatrix(out_diff, 0, T * S, rec, rec), T, S, true, b_buf_, &b_dbuf_, in_diff, 1.0);
@@ -876,9 +879,11 @@ void LstmFamily::BackpropagateFnc(const CuMatrixBase &in, const CuMatrixBase &, 
   const aslp_lstm_seq *seq = vec_seq_valid_ ? &vec_seq_ : nullptr;
   vec_seq_valid_ = false;
   auto grads = [&]() {
-    if (dr_deferred) {
+    if (dr_deferred && cfg_.bidir) {
       CuSubMatrix od_f2(out_diff, 0, T * S, 0, rec), od_b2(out_diff, 0, T * S, rec, rec);
       LstmDir::BackwardDrPair(f_, b_, od_f2, od_b2, T, S, &f_dbuf_, &b_dbuf_, planes_.get());
+    } else if (dr_deferred) {
+      f_.BackwardFinish(CuSubMatrix(out_diff, 0, T * S, 0, rec), T, S, false, &f_dbuf_, nullptr, 0.0, true);   // (d_r alone)
     }
     if (cfg_.bidir && f_.FusedOk()) LstmDir::GradsPair(f_, b_, in, T, S, f_buf_, b_buf_, f_dbuf_, b_dbuf_, mmt, clip_gradient_, lr_fold, seq, planes_.get());
     else {

@@ -22,7 +22,7 @@ import aslp_import
 aslp = aslp_import.load(); aslp.ops.use_torch_stream()
 dev = torch.device("cuda:0")
 S, chunk, T, D, C = int(os.environ.get("AB_S", "16")), int(os.environ.get("AB_CHUNK", "6")), int(os.environ.get("AB_T", "9")), int(os.environ.get("AB_D", "24")), 128
-layer = "<BLstmProjectedStreamsLC> <InputDim> %%d <OutputDim> 128 <CellDim> %%d <ParamScale> %%s <ClipGradient> %%s\n"
+layer = os.environ.get("AB_MARKER", "<BLstmProjectedStreamsLC>") + " <InputDim> %%d <OutputDim> 128 <CellDim> %%d <ParamScale> %%s <ClipGradient> %%s\n"
 proto = "<NnetProto>\n" + "".join(layer %% (D if l == 0 else 128, C, os.environ.get("AB_PSCALE", "0.05"), os.environ.get("AB_CLIP", "5.0"))
                                   for l in range(int(os.environ.get("AB_LAYERS", "1")))) + "</NnetProto>\n"
 net = aslp.Nnet.Init(proto, seed=5)
@@ -97,6 +97,10 @@ def test_d_r_beside_the_lower_recurrence_changes_no_bit(tmp_path):
     for k in range(3):
         assert np.array_equal(aside, run(tmp_path, "main_%d" % k, ASLP_LSTM_DR_ASIDE="0", **sizes)), k
     assert np.array_equal(aside, run(tmp_path, "aside_again", **sizes))
+    # ... and in a stack of unidirectional projected layers (d_r = out_diff + dGATES(next) W_r by the single-direction product)
+    uni = dict(sizes, AB_MARKER="<LstmProjectedStreams>")
+    a = run(tmp_path, "uni_aside", **uni)
+    assert np.isfinite(a).all() and np.array_equal(a, run(tmp_path, "uni_main", ASLP_LSTM_DR_ASIDE="0", **uni))
 
 
 @pytest.mark.parametrize("pscale,odscale,lr", [("0.3", "1e-9", "1e-3"), ("0.001", "1e5", "1e-12"), ("0.05", "1e-20", "1e-3"), ("0.2", "30.0", "1e-6")])
