@@ -1027,6 +1027,17 @@ bool gemm_split16_launch(GemmArgs &g, bool a_kc, bool b_kc, int cfg, const S16Vi
   const S16View vb = pb ? *pb : S16View{bh, bl, s16_plane_ld(b_cols), b_rows, b_cols, slots + 1};
   const MaxJob ma = {g.A, a_rows, a_cols, g.lda, part}, mb = {g.B, b_rows, b_cols, g.ldb, part + kS16ConvParts};
   const ConvJob ca = {g.A, g.lda, va, part, kS16ConvParts}, cb = {g.B, g.ldb, vb, part + kS16ConvParts, kS16ConvParts};
+  // One launch for maxima and planes where the matrices fit one resident grid (nn_fused.hip copy_planes_coop) -- which writes the matrix
+  // region only: scratch planes are not zeroed, so only for operands without padding rows / columns.
+  {
+    auto unpadded = [&](const S16View &v) { return pad(v.rows) == v.rows && v.ld == v.cols; };
+    CoopConvJob cj[2];
+    int n = 0;
+    bool ok = true;
+    if (!pa) { cj[n++] = CoopConvJob{g.A, g.lda, nullptr, 0, va, nullptr, 0}; ok = ok && unpadded(va); }
+    if (!pb) { cj[n++] = CoopConvJob{g.B, g.ldb, nullptr, 0, vb, nullptr, 0}; ok = ok && unpadded(vb); }
+    if (ok && n > 0 && coop_convert_launch(cj, n)) return gemm_split16_planes_launch(g, a_kc, b_kc, va, vb, nullptr, nullptr, cfg);
+  }
   // (matrices in one launch share the threads-per-row choice: the widest one's)
   MaxJobs ms;
   ConvJobs js;
