@@ -1128,17 +1128,30 @@ __global__ void __launch_bounds__(256) xent_rows_kernel(const float *y, int ldy,
     __syncthreads();
     const float wr = fw_r * tsum;
     if (DENSE) emit(wr);
-    xe = wave_sum_d(xe); en = wave_sum_d(en); lk = wave_sum_d(lk);
-    __shared__ double shd[4][3];
-    if (lane == 0) { shd[w][0] = xe; shd[w][1] = en; shd[w][2] = lk; }
-    __syncthreads();
-    if (tid == 0) {
-      double *rs = rowstats + (long)r * 5;
-      rs[0] = (double)wr;
-      rs[1] = (double)wr * (yi == ti ? 1.0 : 0.0);
-      rs[2] = shd[0][0] + shd[1][0] + shd[2][0] + shd[3][0];
-      rs[3] = shd[0][1] + shd[1][1] + shd[2][1] + shd[3][1];
-      rs[4] = shd[0][2] + shd[1][2] + shd[2][2] + shd[3][2];
+    double *rs = rowstats + (long)r * 5;
+    if (DENSE) {
+      xe = wave_sum_d(xe); en = wave_sum_d(en); lk = wave_sum_d(lk);
+      __shared__ double shd[4][3];
+      if (lane == 0) { shd[w][0] = xe; shd[w][1] = en; shd[w][2] = lk; }
+      __syncthreads();
+      if (tid == 0) {
+        rs[0] = (double)wr;
+        rs[1] = (double)wr * (yi == ti ? 1.0 : 0.0);
+        rs[2] = shd[0][0] + shd[1][0] + shd[2][0] + shd[3][0];
+        rs[3] = shd[0][1] + shd[1][1] + shd[2][1] + shd[3][1];
+        rs[4] = shd[0][2] + shd[1][2] + shd[2][2] + shd[3][2];
+      }
+    } else {
+      // a label target has ONE non-zero term, in the thread that holds the label's column: that thread's three sums ARE the row's (every
+      // other thread's are +0.0, and x + 0.0 = x), so they go out as they are -- no reduction over the workgroup
+      const bool has_label = label >= 0 && label < cols;
+      const bool mine = has_label && (VEC ? ((label >> 2) & 255) == tid : (label & 255) == tid);
+      if (mine) { rs[2] = xe; rs[3] = en; rs[4] = lk; }
+      if (tid == 0) {
+        rs[0] = (double)wr;
+        rs[1] = (double)wr * (yi == ti ? 1.0 : 0.0);
+        if (!has_label) { rs[2] = 0.0; rs[3] = 0.0; rs[4] = 0.0; }
+      }
     }
     __syncthreads();
   }
