@@ -1107,14 +1107,17 @@ __global__ void __launch_bounds__(256) xent_rows_kernel(const float *y, int ldy,
     };
     const float tsum_by_label = (label >= 0 && label < cols) ? 1.0f : 0.0f;
     if (!DENSE) emit(fw_r * tsum_by_label);
-    // block reductions: tsum, argmax(y), argmax(t)
-    tsum = wave_sum(tsum);
+    // block reductions: argmax(y); with dense targets also tsum and argmax(t) -- a label target's are known: sum 1 or 0, arg-max the label
+    // (column 0 for a row of zeros: the lowest index among equals)
+    if (DENSE) tsum = wave_sum(tsum);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       float ov = __shfl_xor(ybest, o, 64); int oi = __shfl_xor(yi, o, 64);
       if (ov > ybest || (ov == ybest && oi >= 0 && (yi < 0 || oi < yi))) { ybest = ov; yi = oi; }
-      ov = __shfl_xor(tbest, o, 64); oi = __shfl_xor(ti, o, 64);
-      if (ov > tbest || (ov == tbest && oi >= 0 && (ti < 0 || oi < ti))) { tbest = ov; ti = oi; }
+      if (DENSE) {
+        ov = __shfl_xor(tbest, o, 64); oi = __shfl_xor(ti, o, 64);
+        if (ov > tbest || (ov == tbest && oi >= 0 && (ti < 0 || oi < ti))) { tbest = ov; ti = oi; }
+      }
     }
     if (lane == 0) { shf[w][0] = tsum; shf[w][1] = ybest; shf[w][2] = tbest; shi[w][0] = yi; shi[w][1] = ti; }
     __syncthreads();
@@ -1123,8 +1126,9 @@ __global__ void __launch_bounds__(256) xent_rows_kernel(const float *y, int ldy,
 #pragma unroll
     for (int j = 1; j < 4; j++) {
       if (shf[j][1] > ybest || (shf[j][1] == ybest && shi[j][0] >= 0 && (yi < 0 || shi[j][0] < yi))) { ybest = shf[j][1]; yi = shi[j][0]; }
-      if (shf[j][2] > tbest || (shf[j][2] == tbest && shi[j][1] >= 0 && (ti < 0 || shi[j][1] < ti))) { tbest = shf[j][2]; ti = shi[j][1]; }
+      if (DENSE && (shf[j][2] > tbest || (shf[j][2] == tbest && shi[j][1] >= 0 && (ti < 0 || shi[j][1] < ti)))) { tbest = shf[j][2]; ti = shi[j][1]; }
     }
+    if (!DENSE) { tsum = tsum_by_label; ti = (label >= 0 && label < cols) ? label : 0; }
     __syncthreads();
     const float wr = fw_r * tsum;
     if (DENSE) emit(wr);
