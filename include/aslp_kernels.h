@@ -130,6 +130,8 @@ void aslp_find_row_max_id(const float *M, MatrixDim d, int32_cuda *id);
 /* sum of all elements -> *out_dev (double, one value)  (CuMatrixBase::Sum) */
 void aslp_matrix_sum(const float *M, MatrixDim d, double *out_dev);
 void aslp_copy_mat(float *dst, MatrixDim d, const float *src, int src_stride);
+/* dst [d] = src^T, src [d.cols x d.rows] (CuMatrixBase::CopyFromMat(M, kTrans), cu-matrix.cc:297-316) */
+void aslp_copy_mat_trans(float *dst, MatrixDim d, const float *src, int src_stride);
 void aslp_vec_axpy(float alpha, const float *x, float *y, int dim);           /* y += alpha x */
 void aslp_vec_axpy2(float alpha, const float *x1, float *y1, const float *x2, float *y2, int dim); /* two at once */
 void aslp_vec_diff(float *out, const float *a, const float *b, int n);        /* out = a - b */

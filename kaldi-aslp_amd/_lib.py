@@ -126,6 +126,7 @@ _sig("aslp_vec_axpy2", None, _f, _vp, _vp, _vp, _vp, _i)
 _sig("aslp_find_row_max_id", None, _vp, _md, _vp)
 _sig("aslp_matrix_sum", None, _vp, _md, _vp)
 _sig("aslp_copy_mat", None, _vp, _md, _vp, _i)
+_sig("aslp_copy_mat_trans", None, _vp, _md, _vp, _i)
 _sig("aslp_vec_axpy", None, _f, _vp, _vp, _i)
 _sig("aslp_f2d", None, _vp, _vp, _i)
 _sig("aslp_d2f", None, _vp, _vp, _i)

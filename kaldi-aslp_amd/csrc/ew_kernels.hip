@@ -139,6 +139,15 @@ __global__ void add_mat_trans_kernel(float alpha, const float *src, float *dst, 
   }
 }
 
+// dst = src^T (no zeroing launch in front of an add: the recurrent layers refresh K-contiguous copies of their weights once per backward pass)
+__global__ void copy_mat_trans_kernel(const float *src, float *dst, MatrixDim d, int src_stride) {
+  long n = (long)d.rows * d.cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int r = (int)(i / d.cols), c = (int)(i % d.cols);
+    dst[(long)r * d.stride + c] = src[(long)c * src_stride + r];
+  }
+}
+
 // _add_mat_diag_vec with a transposed mat2 (generic strides)
 __global__ void add_mat_diag_vec_strided(float alpha, float *mat, MatrixDim d, const float *mat2, int rs, int cs,
                                          const float *vec, float beta) {
@@ -418,6 +427,11 @@ void aslp_diff_relu(float *in_diff, const float *in, const float *out_diff, Matr
   launch_map<false>("diff_relu", in_diff, d, in, in_stride, out_diff, od_stride, DiffRelu{});
 }
 void aslp_copy_mat(float *dst, MatrixDim d, const float *src, int src_stride) { launch_map<false>("copy_mat", dst, d, src, src_stride, nullptr, 0, CopyMat{}); }
+void aslp_copy_mat_trans(float *dst, MatrixDim d, const float *src, int src_stride) {
+  if (d.rows <= 0 || d.cols <= 0) return;
+  hipLaunchKernelGGL(copy_mat_trans_kernel, dim3(grid_for((long)d.rows * d.cols)), dim3(kBlock), 0, cur_stream(), src, dst, d, src_stride);
+  check_launch("copy_mat_trans");
+}
 
 void cudaF_regularize_l1(aslp_dim3, aslp_dim3, float *wei, float *grad, float l1, float lr, MatrixDim d, int stride_grad) {
   if (d.rows <= 0 || d.cols <= 0) return;

@@ -449,6 +449,11 @@ void CuMatrixBase::CopyToMat(HostMatrix *m) const {
   m->Resize(rows_, cols_);
   CopyToHost(m->data.data(), cols_);
 }
+void CuMatrixBase::CopyFromMatTrans(const CuMatrixBase &src) {
+  ASLP_ASSERT(src.NumRows() == cols_ && src.NumCols() == rows_);
+  aslp_copy_mat_trans(data_, Dim(), src.Data(), src.Stride());
+  CheckKernels();
+}
 void CuMatrixBase::AddMat(float alpha, const CuMatrixBase &A, MatrixTransposeType tA) {
   if (tA == kNoTrans) ASLP_ASSERT(SameDim(*this, A));
   else ASLP_ASSERT(A.NumRows() == cols_ && A.NumCols() == rows_);

@@ -225,6 +225,7 @@ class CuMatrixBase {
   void ApplyHeaviside();
   void InvertElements();
   void CopyFromMat(const CuMatrixBase &src);
+  void CopyFromMatTrans(const CuMatrixBase &src);   // *this = src^T (CopyFromMat(src, kTrans))
   void CopyFromHost(const float *src, int ld);
   void CopyFromPinnedHost(const float *src, int ld);  // async, no staging copy: `src` must stay valid until the stream passes
   void CopyToHost(float *dst, int ld) const;

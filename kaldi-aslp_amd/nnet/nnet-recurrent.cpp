@@ -243,8 +243,7 @@ void LstmDir::RefreshEffT() const {
   if (R > 0) {
     w_eff_t.AddMatMat(1.0, w_rm, kTrans, w_r, kTrans, 0.0);
   } else {
-    w_eff_t.SetZero();
-    w_eff_t.AddMat(1.0, w_r, kTrans);
+    w_eff_t.CopyFromMatTrans(w_r);
   }
   eff_t_dirty = false;
 }
@@ -1085,10 +1084,8 @@ void GruStreams::BackpropagateFnc(const CuMatrixBase &in, const CuMatrixBase &, 
   const bool fused = !persistent && !unfused && aslp_gru_step_supported(H);
   if (fused || persistent) {  // the backward products read W (not W^T): keep K-contiguous transposed copies, refreshed here once per call
     if (w_zr_h_t_.NumRows() != H) { w_zr_h_t_.Resize(H, 2 * H, kUndefined); w_m_g_t_.Resize(H, H, kUndefined); }
-    w_zr_h_t_.SetZero();
-    w_zr_h_t_.AddMat(1.0, w_zr_h_, kTrans);
-    w_m_g_t_.SetZero();
-    w_m_g_t_.AddMat(1.0, w_m_g_, kTrans);
+    w_zr_h_t_.CopyFromMatTrans(w_zr_h_);
+    w_m_g_t_.CopyFromMatTrans(w_m_g_);
   }
   if (persistent) {
     q.y = buf_.Data(); q.d = dbuf_.Data();

@@ -451,6 +451,20 @@ def test_xent_deferred_row_sums_are_bit_identical(aslp, dev, rows, cols, softmax
     assert stats_a[0].item() > 0.125 and torch.isfinite(stats_a).all()
 
 
+def test_copy_mat_trans(aslp, dev):
+    """aslp_copy_mat_trans: dst = src^T, strided operands (what the recurrent layers use to refresh their K-contiguous weight copies)"""
+    ptr, dim, lib = aslp.ops.ptr, aslp.ops.dim, aslp.ops.lib
+    for rows, cols in ((512, 1024), (37, 5), (1, 9)):
+        src = torch.randn(cols, rows + 3, device=dev)[:, :rows]      # [cols x rows], stride rows + 3
+        dst = torch.full((rows, cols + 2), 9.0, device=dev)
+        view = dst[:, :cols]
+        MD = aslp._lib.MatrixDim(rows, cols, cols + 2)
+        lib.aslp_copy_mat_trans(ptr(dst), MD, ptr(src), rows + 3)
+        aslp.ops.check_error()
+        torch.cuda.synchronize()
+        assert torch.equal(view, src.t()) and bool((dst[:, cols:] == 9.0).all())
+
+
 def _planes_to_host(aslp, po, rows, cols):
     """the [rows x cols] region of a PlanesOut's two fp16 planes, and the bound's bits"""
     memcpy = aslp.lib.hipMemcpy
