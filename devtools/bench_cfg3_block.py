@@ -9,4 +9,4 @@ aslp = aslp_import.load()
 aslp.ops.use_torch_stream()
 b = bench.cfg3_block(aslp, torch.device("cuda:0"))
 print("chunked %.4f ms  whole %.3f ms  frac %.3f / %.3f" % (b["chunked_xent"]["ms_per_step"], b["whole_utterance_warpctc"]["ms_per_step"],
-      b["chunked_xent"]["frac_of_mfma_peak"], b["whole_utterance_warpctc"]["frac_of_mfma_peak"]))
+      b["chunked_xent"]["frac"], b["whole_utterance_warpctc"]["frac"]))

@@ -1,0 +1,119 @@
+/* aslp_compat_kaldi.h -- source-level drop-in for the Component / Nnet C++ API (SURVEY 8b seam B4).
+ *
+ * A caller written against the reference -- `using namespace kaldi; using namespace kaldi::aslp_nnet;`, `CuMatrix<BaseFloat>`,
+ * `KALDI_LOG`, `trn_opts.Register(&po)`, `#include "aslp-nnet/nnet-nnet.h"` -- compiles against THIS engine unchanged:
+ *
+ *   hipcc -x hip --offload-arch=gfx950 -std=c++17 -I include/kaldi_compat -I include \
+ *         -I kaldi-aslp_amd/nnet -I kaldi-aslp_amd/util -I kaldi-aslp_amd/csrc \
+ *         <reference>/src/aslp-nnetbin/aslp-nnet-train-frame.cc -L kaldi-aslp_amd -laslp_hip
+ *
+ * include/kaldi_compat/ holds one forwarding header per reference header path such a caller includes (base/kaldi-common.h,
+ * util/common-utils.h, base/timer.h, aslp-cudamatrix/cu-device.h, aslp-nnet/{nnet-trnopts,nnet-nnet,nnet-loss,data-reader,...}.h); each
+ * of them includes this file.  What replaces what (reference file:line):
+ *   kaldi::aslp_nnet::Nnet / Component / UpdatableComponent      aslp-nnet/nnet-nnet.h:38-193, nnet-component.h:45-347
+ *   kaldi::aslp_nnet::NnetTrainOptions (+ Register)              aslp-nnet/nnet-trnopts.h:29-63
+ *   kaldi::aslp_nnet::LossItf / Xent / Mse / MultiTaskLoss       aslp-nnet/nnet-loss.h:35-218
+ *   kaldi::aslp_nnet::FrameDataReader, NnetDataRandomizerOptions aslp-nnet/data-reader.h:25-63, nnet-randomizer.h:34-50
+ *   kaldi::CuMatrix<Real> / CuMatrixBase<Real> / CuVector<Real>  aslp-cudamatrix/cu-matrix.h, cu-vector.h (Real = float: the engine is fp32)
+ *   kaldi::CuDevice                                              aslp-cudamatrix/cu-device.h:43-151
+ *   kaldi::ParseOptions, Timer, Posterior, the table typedefs    util/parse-options.h, base/timer.h, hmm/posterior.h, util/table-types.h
+ *   KALDI_LOG / KALDI_WARN / KALDI_ERR / KALDI_VLOG / KALDI_ASSERT   base/kaldi-error.h (errors are std::runtime_error, as in the reference)
+ * HAVE_CUDA is defined to 1: the `#if HAVE_CUDA==1` device-selection blocks of the reference's tools are the ones that apply.
+ * Proof: tests/test_compat_kaldi_cpu.py compiles the reference's own aslp-nnet-train-frame.cc against this header (development container:
+ * the reference tree does not travel); `make -C kaldi-aslp_amd refmains` links it into bin_ref/, which tests/test_tools_gpu.py runs on the GPU. */
+#ifndef ASLP_COMPAT_KALDI_H_
+#define ASLP_COMPAT_KALDI_H_
+
+#ifndef HAVE_CUDA
+#define HAVE_CUDA 1
+#endif
+
+#include <cstdint>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "cu-device.h"
+#include "cu-matrix.h"
+#include "data-reader.h"
+#include "nnet-loss.h"
+#include "nnet-nnet.h"
+#include "nnet-pdf-prior.h"
+#include "nnet-randomizer.h"
+#include "parse-options.h"
+#include "posterior.h"
+
+namespace kaldi {
+
+typedef float BaseFloat;
+typedef int16_t int16;
+typedef int32_t int32;
+typedef int64_t int64;
+typedef uint16_t uint16;
+typedef uint32_t uint32;
+typedef uint64_t uint64;
+typedef float float32;
+typedef double double64;
+
+using ::aslp::OptionsItf;
+using ::aslp::ParseOptions;
+using ::aslp::Input;    /* util/kaldi-io.h: extended filenames (files, pipes, offsets) */
+using ::aslp::Output;
+inline void SetVerboseLevel(int32 level) { ::aslp::g_verbose_level = level; }   /* base/kaldi-error.h */
+inline int32 GetVerboseLevel() { return ::aslp::g_verbose_level; }
+using ::aslp::Posterior;
+using ::aslp::Timer;
+using ::aslp::CuDevice;
+using ::aslp::kSetZero;
+using ::aslp::kUndefined;
+using ::aslp::kCopyData;
+using ::aslp::SequentialBaseFloatMatrixReader;
+using ::aslp::RandomAccessBaseFloatMatrixReader;
+using ::aslp::BaseFloatMatrixWriter;
+using ::aslp::SequentialBaseFloatVectorReader;
+using ::aslp::RandomAccessBaseFloatVectorReader;
+using ::aslp::BaseFloatVectorWriter;
+using ::aslp::RandomAccessBaseFloatReader;
+using ::aslp::SequentialInt32VectorReader;
+using ::aslp::RandomAccessInt32VectorReader;
+using ::aslp::Int32VectorWriter;
+using ::aslp::RandomAccessPosteriorReader;
+
+/* the reference's matrix classes are templates over the element type; the engine computes in fp32 only */
+template <typename Real> using CuMatrixBase = ::aslp::CuMatrixBase;
+template <typename Real> using CuMatrix = ::aslp::CuMatrix;
+template <typename Real> using CuSubMatrix = ::aslp::CuSubMatrix;
+template <typename Real> using CuVectorBase = ::aslp::CuVectorBase;
+template <typename Real> using CuVector = ::aslp::CuVector;
+template <typename T> using CuArray = ::aslp::CuArray<T>;
+
+namespace aslp_nnet {
+using ::aslp::Component;
+using ::aslp::UpdatableComponent;
+using ::aslp::Nnet;
+using ::aslp::NnetTrainOptions;
+using ::aslp::NnetDataRandomizerOptions;
+using ::aslp::RandomizerMask;
+using ::aslp::MatrixRandomizer;
+using ::aslp::VectorRandomizer;
+using ::aslp::PosteriorRandomizer;
+using ::aslp::LossItf;
+using ::aslp::Xent;
+using ::aslp::Mse;
+using ::aslp::MultiTaskLoss;
+using ::aslp::FrameDataReader;
+using ::aslp::SequenceDataReaderOptions;
+using ::aslp::SequenceDataReader;
+using ::aslp::PdfPriorOptions;
+using ::aslp::PdfPrior;
+}  // namespace aslp_nnet
+
+}  // namespace kaldi
+
+#define KALDI_LOG ASLP_LOG
+#define KALDI_WARN ASLP_WARN
+#define KALDI_ERR ASLP_ERR
+#define KALDI_VLOG(v) ASLP_VLOG(v)
+#define KALDI_ASSERT(cond) ASLP_ASSERT(cond)
+
+#endif  /* ASLP_COMPAT_KALDI_H_ */

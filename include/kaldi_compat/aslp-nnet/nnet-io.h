@@ -1,0 +1,2 @@
+/* forwarding header: the reference path "aslp-nnet/nnet-io.h" resolves to the engine through include/aslp_compat_kaldi.h (B4 source-level drop-in) */
+#include "aslp_compat_kaldi.h"

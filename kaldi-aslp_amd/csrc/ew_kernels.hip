@@ -139,12 +139,23 @@ __global__ void add_mat_trans_kernel(float alpha, const float *src, float *dst, 
   }
 }
 
-// dst = src^T (no zeroing launch in front of an add: the recurrent layers refresh K-contiguous copies of their weights once per backward pass)
-__global__ void copy_mat_trans_kernel(const float *src, float *dst, MatrixDim d, int src_stride) {
-  long n = (long)d.rows * d.cols;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    int r = (int)(i / d.cols), c = (int)(i % d.cols);
-    dst[(long)r * d.stride + c] = src[(long)c * src_stride + r];
+// dst = src^T (no zeroing launch in front of an add: the recurrent layers refresh K-contiguous copies of their weights once per backward pass).
+// 32 x 32 tiles through LDS (pitch 33: the column reads fall on 32 different banks): both the reads of src and the writes of dst are
+// 128-byte rows -- a thread-per-element version read src with a stride of a whole row per lane.  dst is [d.rows x d.cols], src [d.cols x d.rows].
+__global__ void __launch_bounds__(256) copy_mat_trans_kernel(const float *src, float *dst, MatrixDim d, int src_stride) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;     // tile of dst: rows r0 .., columns c0 ..
+#pragma unroll
+  for (int j = 0; j < 4; j++) {   // src rows = dst columns c0 + ty + 8 j, src columns = dst rows r0 + tx
+    const int sc = r0 + tx, sr = c0 + ty + 8 * j;
+    if (sr < d.cols && sc < d.rows) tile[ty + 8 * j][tx] = src[(long)sr * src_stride + sc];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int r = r0 + ty + 8 * j, c = c0 + tx;
+    if (r < d.rows && c < d.cols) dst[(long)r * d.stride + c] = tile[tx][ty + 8 * j];
   }
 }
 
@@ -429,7 +440,7 @@ void aslp_diff_relu(float *in_diff, const float *in, const float *out_diff, Matr
 void aslp_copy_mat(float *dst, MatrixDim d, const float *src, int src_stride) { launch_map<false>("copy_mat", dst, d, src, src_stride, nullptr, 0, CopyMat{}); }
 void aslp_copy_mat_trans(float *dst, MatrixDim d, const float *src, int src_stride) {
   if (d.rows <= 0 || d.cols <= 0) return;
-  hipLaunchKernelGGL(copy_mat_trans_kernel, dim3(grid_for((long)d.rows * d.cols)), dim3(kBlock), 0, cur_stream(), src, dst, d, src_stride);
+  hipLaunchKernelGGL(copy_mat_trans_kernel, dim3((d.cols + 31) / 32, (d.rows + 31) / 32), dim3(256), 0, cur_stream(), src, dst, d, src_stride);
   check_launch("copy_mat_trans");
 }
 

@@ -689,6 +689,325 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
   s16_finish<TM, TN, NW, EXTRA, true>(g, va, vb, acc, accx, asum, do_colsum, w_bound, m0 + wm * 64, n0 + wn * 64, lane, wave, lds);
 }
 
+// ---- producer / consumer waves (round 6) -------------------------------------------------------------------------------------------
+// The kernels above run one wave per SIMD that does everything: it issues the K tile's LDS-DMA requests, the fragment reads and the
+// matrix instructions from ONE in-order instruction stream.  The counters (profiles/r06_gemm_split16_pmc_*.txt) say what that costs:
+// 40 % of the wave cycles are instruction-issue stalls (SQ_WAIT_INST_ANY) while the LDS is ~25 % busy with no bank conflicts and the
+// matrix pipe ~45 % busy -- a global_load_lds that waits for the texture path to take it (one 1-KiB request per ~70 cycles and wave at the
+// path's ~56 B/clk/CU) holds up the matrix instructions and reads behind it, and nothing else can issue on that SIMD.  Here a workgroup
+// is EIGHT waves, two per SIMD: waves 0-3 (consumers) only read fragments and multiply, waves 4-7 (producers) only issue the LDS-DMA
+// requests and wait for them; a producer parked on the texture path costs its SIMD nothing, the consumer beside it keeps issuing.  One
+// workgroup barrier per K tile connects the two roles exactly as before (counted vmcnt on the producer side, then the barrier publishes
+// the tile and frees the stage the consumers have just left).  Producers end behind the K loop; the epilogue's barriers then count the
+// surviving consumer waves only.  Same instruction order per accumulator as the kernels above: results are bit-identical to theirs.
+//   KT = 64 halves per K tile (KC operands need 128-byte rows for their LDS image) or 32 when both operands are reduction-major
+//   fragments double-buffered per INSTRUCTION step (registers: at most 256 per wave with two waves per SIMD)
+// ABL (devtools only): 1 = no MFMA, 2 = no DMA, 4 = no LDS reads -- wrong results, for timing
+template <int BM, int BN, int KT, int NS, bool A_KC, bool B_KC, bool EXTRA, int ABL = 0, int OPT = 0>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) gemm_s16_pc(GemmArgs g, S16Operands ops) {
+  constexpr int NC = 4, NP = 4;   // consumer waves (2 x 2 wave tiles), producer waves
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+  constexpr int KHS = KT / 16;    // instruction k steps per K tile
+  static_assert(KT == 64 || (KT == 32 && !A_KC && !B_KC), "an operand whose reduction index is contiguous needs 128-byte rows in its LDS image");
+  static_assert(KHS % 2 == 0, "the two fragment sets alternate per step and every tile starts on the first");
+  constexpr int A_BYTES = BM * KT * 2, B_BYTES = BN * KT * 2, STAGE = 2 * (A_BYTES + B_BYTES);   // A_hi | A_lo | B_hi | B_lo
+  constexpr int SLOTS_A = A_BYTES / 1024, SLOTS_B = B_BYTES / 1024, SLOTS = 2 * (SLOTS_A + SLOTS_B);   // 1-KiB DMA units per plane tile
+  static_assert(SLOTS_A % NP == 0 && SLOTS_B % NP == 0, "a producer's DMA unit must not straddle planes");
+  constexpr int G = SLOTS / NP;
+  constexpr int RA = A_KC ? 1 : 2, RB = B_KC ? 1 : 2;   // LDS reads per fragment and plane
+  constexpr int NRH = 2 * (TM * RA + TN * RB);            // reads per instruction step
+  constexpr int NMS = 3 * TM * TN;                        // matrix instructions per instruction step
+  constexpr int BAR_AT = NMS >= 12 ? 3 : 0;               // behind which instruction of a tile's last step the barrier sits
+  static_assert(!A_KC || true, "");
+  static_assert(A_KC || BM == 64 || BM == 128, "KS image: 64 or 128 columns");
+  static_assert(B_KC || BN == 64 || BN == 128, "KS image: 64 or 128 columns");
+  extern __shared__ __attribute__((aligned(1024))) float lds[];
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lds;
+  lds_char *lds3 = (lds_char *)(__attribute__((address_space(3))) void *)lds;
+  const char *ldsb = reinterpret_cast<const char *>(lds);
+
+  const bool second = g.pair && blockIdx.z == 1;   // second product of a pair (uniform)
+  if (second) { g.C = g.C1; g.ep = g.ep1; }
+  const S16View va = s16_pick(second, ops.a, ops.a1), vb = s16_pick(second, ops.b, ops.b1);
+  int tm, tn;
+  xcd_tile<BM, BN>(g, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int k_first = 0, ktiles = ops.kp / KT;
+  if (g.split_k > 1) {   // (as gemm_s16_glds: this workgroup reduces over K chunk blockIdx.y and leaves a plain partial product)
+    k_first = (int)blockIdx.y * g.k_chunk;
+    ktiles = min(g.k_chunk, ops.kp - k_first) / KT;
+    g.C += (long)blockIdx.y * g.split_stride;
+  }
+
+  if (wave >= NC) {
+    // ================================================= producer =================================================
+    const int pw = wave - NC;
+    if constexpr (OPT & 2) __builtin_amdgcn_s_setprio(1);
+    const h16 *src[G];
+    int adv[G];
+    static_for<0, G>([&](auto U_) {
+      constexpr int u = decltype(U_)::value;
+      constexpr bool is_a = u * NP < 2 * SLOTS_A;
+      constexpr int s2c = is_a ? u * NP : u * NP - 2 * SLOTS_A, per = is_a ? SLOTS_A : SLOTS_B;
+      constexpr bool lo_plane = s2c >= per;
+      const int sr = (lo_plane ? s2c - per : s2c) + pw;   // unit within the plane tile
+      const h16 *base;
+      int v_ld, v_rows;
+      if constexpr (is_a) { v_ld = va.ld; v_rows = va.rows; if constexpr (lo_plane) base = va.lo; else base = va.hi; }
+      else { v_ld = vb.ld; v_rows = vb.rows; if constexpr (lo_plane) base = vb.lo; else base = vb.hi; }
+      constexpr bool kc = is_a ? A_KC : B_KC;
+      constexpr int BR = is_a ? BM : BN;
+      const int first = is_a ? m0 : n0;
+      if constexpr (kc) {   // 8 rows x 128 B per unit, 16-byte chunks XOR-swizzled on the source side
+        const int rows_p = (v_rows + kS16Pad - 1) / kS16Pad * kS16Pad;
+        const int r = lane >> 3, c = (lane & 7) ^ kc_swizzle(sr * 8 + r);
+        int row = first + sr * 8 + r;
+        row = row < rows_p ? row : rows_p - 1;   // (a row of the padding or of another tile: feeds outputs that are not stored)
+        adv[u] = KT;
+        src[u] = base + (long)row * v_ld + 8 * c + k_first;
+      } else {              // 1024 / (2 BR) k rows x 2 BR bytes per unit
+        constexpr int CPR = BR / 8;
+        const int krow = sr * (64 / CPR) + lane / CPR;
+        const int c = (lane % CPR) ^ (4 * ks_swizzle<BR>(krow));
+        int col = first + 8 * c;
+        col = col + 8 <= v_ld ? col : v_ld - 8;   // (columns past the planes: outputs that are not stored)
+        adv[u] = KT * v_ld;
+        src[u] = base + (long)(k_first + krow) * v_ld + col;
+      }
+    });
+    // (OPT & 8 / 16, experiment) scalar loads that pull the 128-byte lines of a LATER K tile into this XCD's L2 -- over the scalar cache's
+    // path, not the texture path the LDS-DMA requests are bound by; their results are never read
+    constexpr int PD = 2;   // tiles ahead of the tile being requested
+    unsigned pf_sink = 0;
+    auto pf_tile = [&](int r) {
+      if constexpr (!(OPT & 24)) return;
+      if (r >= ktiles) return;
+      static_for<0, G>([&](auto U_) {
+        constexpr int u = decltype(U_)::value;
+        constexpr bool is_a = u * NP < 2 * SLOTS_A;
+        constexpr int s2c = is_a ? u * NP : u * NP - 2 * SLOTS_A, per = is_a ? SLOTS_A : SLOTS_B;
+        constexpr bool lo_plane = s2c >= per;
+        const int sr = (lo_plane ? s2c - per : s2c) + pw;
+        const h16 *base;
+        int v_ld, v_rows;
+        if constexpr (is_a) { v_ld = va.ld; v_rows = va.rows; if constexpr (lo_plane) base = va.lo; else base = va.hi; }
+        else { v_ld = vb.ld; v_rows = vb.rows; if constexpr (lo_plane) base = vb.lo; else base = vb.hi; }
+        constexpr bool kc = is_a ? A_KC : B_KC;
+        constexpr int BR = is_a ? BM : BN;
+        const int first = is_a ? m0 : n0;
+        const int share = is_a ? (tn & 3) : (tm & 7);   // (OPT & 16) which of the lines the tiles of this XCD's block share is this workgroup's to fetch
+        static_for<0, 8>([&](auto L_) {
+          constexpr int l = decltype(L_)::value;
+          if constexpr ((OPT & 16) != 0) { if ((l & (is_a ? 3 : 7)) != share) return; }
+          const h16 *p;
+          if constexpr (kc) {
+            const int rows_p = (v_rows + kS16Pad - 1) / kS16Pad * kS16Pad;
+            int row = first + sr * 8 + l;
+            row = row < rows_p ? row : rows_p - 1;
+            p = base + (long)row * v_ld + k_first + (long)r * KT;
+          } else {
+            constexpr int LPR = BR / 64;   // lines per k row
+            const int krow = sr * (8 / LPR) + l / LPR;
+            int col = first + 64 * (l % LPR);
+            col = col + 64 <= v_ld ? col : v_ld - 64;
+            p = base + ((long)k_first + (long)r * KT + krow) * v_ld + col;
+          }
+          const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+          const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)a), hi32 = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+          const unsigned long long au = ((unsigned long long)hi32 << 32) | lo32;
+          // (the load's result lands in its register whenever the line arrives: the register is one the compiler holds for `pf_sink` from
+          //  before the K loop until behind the final lgkmcnt(0), so nothing else lives there when it does)
+          asm volatile("s_load_dword %0, %1, 0x0" : "+s"(pf_sink) : "s"(au));
+        });
+      });
+    };
+    auto dma_tile = [&](auto ST_, int r) {   // K tile r into stage ST
+      constexpr int st = decltype(ST_)::value;
+      static_for<0, G>([&](auto U_) {
+        constexpr int u = decltype(U_)::value;
+        if constexpr (!(ABL & 2)) glds16(src[u], __builtin_amdgcn_readfirstlane(lds_base + st * STAGE + (pw + u * NP) * 1024));
+        if constexpr ((OPT & 4) != 0) src[u] += (r + 1 < ktiles) ? (((r + 1) & 3) == 0 ? -3 * adv[u] : adv[u]) : 0;   // (experiment: every request an L2 hit; wrong results)
+        else src[u] += (r + 1 < ktiles) ? adv[u] : 0;   // requests past the last tile fetch it again into a stage nobody reads any more
+      });
+      pf_tile(r + PD);
+    };
+    static_for<0, NS - 1 + PD>([&](auto T_) { if constexpr (decltype(T_)::value >= 1) pf_tile(decltype(T_)::value); });
+    static_for<0, NS - 1>([&](auto T_) { dma_tile(T_, decltype(T_)::value); });
+    wait_vmcnt<G *(NS - 2)>();   // tile 0 has landed
+    __builtin_amdgcn_s_barrier();
+    for (int t0 = 0; t0 < ktiles; t0 += NS) {
+      static_for<0, NS>([&](auto I_) {
+        constexpr int I = decltype(I_)::value;
+        if (t0 + I < ktiles) {   // uniform
+          // the stage of tile t - 1: every consumer passed the barrier of tile t - 1 behind its last read of it
+          dma_tile(std::integral_constant<int, (I + NS - 1) % NS>(), t0 + I + NS - 1);
+          wait_vmcnt<G *(NS - 2)>();   // this wave's share of tile t + 1 has landed
+          __builtin_amdgcn_s_barrier();
+        }
+      });
+    }
+    wait_vmcnt<0>();                 // (the surplus requests write into the LDS the epilogue is about to use)
+    if constexpr ((OPT & 24) != 0) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      asm volatile("" ::"s"(pf_sink));
+    }
+    __builtin_amdgcn_s_barrier();
+    return;
+  }
+
+  // =================================================== consumer ===================================================
+  if constexpr (OPT & 1) __builtin_amdgcn_s_setprio(1);
+  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lh = lane >> 5;
+  constexpr int AH = A_KC ? KHS : 1, BH = B_KC ? KHS : 1;
+  int a_off[TM][AH], b_off[TN][BH];
+  const int p16 = lane & 15, g16 = (lane >> 4) & 1;
+#pragma unroll
+  for (int t = 0; t < TM; t++) {
+    if constexpr (A_KC) {
+      const int row = wm * WM + t * 32 + l31;
+#pragma unroll
+      for (int h = 0; h < KHS; h++) a_off[t][h] = row * 128 + (((2 * h + lh) ^ kc_swizzle(row)) << 4);
+    } else {
+      const int T = wm * TM + t, krow = 8 * lh + (p16 >> 2);
+      a_off[t][0] = krow * (2 * BM) + 64 * (T ^ ks_swizzle<BM>(krow)) + 32 * g16 + 8 * (p16 & 3);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < TN; t++) {
+    if constexpr (B_KC) {
+      const int col = wn * WN + t * 32 + l31;
+#pragma unroll
+      for (int h = 0; h < KHS; h++) b_off[t][h] = 2 * A_BYTES + col * 128 + (((2 * h + lh) ^ kc_swizzle(col)) << 4);
+    } else {
+      const int T = wn * TN + t, krow = 8 * lh + (p16 >> 2);
+      b_off[t][0] = 2 * A_BYTES + krow * (2 * BN) + 64 * (T ^ ks_swizzle<BN>(krow)) + 32 * g16 + 8 * (p16 & 3);
+    }
+  }
+  struct Frag { half8 ah[TM], al[TM], bh[TN], bl[TN]; };   // one instruction step
+  // LDS read r of instruction step h of the tile in stage st: operand, fragment t, plane, half of the fragment
+  auto read_unit = [&](auto ST_, auto H_, Frag &f, auto R_) {
+    constexpr int r = decltype(R_)::value, st = decltype(ST_)::value, h = decltype(H_)::value;
+    if constexpr (ABL & 4) return;
+    constexpr bool is_a = r < 2 * TM * RA;
+    constexpr int q2 = is_a ? r : r - 2 * TM * RA, RR = is_a ? RA : RB;
+    constexpr int t = q2 / (2 * RR), w = q2 % (2 * RR), lo = w / RR, half = w % RR;
+    constexpr bool kc = is_a ? A_KC : B_KC;
+    constexpr int plane_bytes = is_a ? A_BYTES : B_BYTES, BR = is_a ? BM : BN;
+    int base = st * STAGE + (lo ? plane_bytes : 0);
+    if constexpr (is_a) base += a_off[t][kc ? h : 0]; else base += b_off[t][kc ? h : 0];
+    if constexpr (kc) {
+      const half8 v = *reinterpret_cast<const half8 *>(ldsb + base);
+      if constexpr (is_a) { if constexpr (lo) f.al[t] = v; else f.ah[t] = v; }
+      else { if constexpr (lo) f.bl[t] = v; else f.bh[t] = v; }
+    } else {
+      const half4 v = __builtin_bit_cast(half4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4 *)(lds3 + base + (16 * h + 4 * half) * (2 * BR))));
+      half8 *dst = is_a ? (lo ? &f.al[t] : &f.ah[t]) : (lo ? &f.bl[t] : &f.bh[t]);
+      if constexpr (half == 0) dst->lo = v; else dst->hi = v;
+    }
+  };
+
+  f32x16 acc[TM][TN], accx[TM][TN];   // hi hi; hi lo' + lo' hi
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) { acc[i][j][e] = 0.0f; accx[i][j][e] = 0.0f; }
+  const bool do_colsum = !A_KC && g.ep.colsum != nullptr && tn == 0 && wn == 0;  // wave-uniform
+  float asum[TM];
+#pragma unroll
+  for (int i = 0; i < TM; i++) asum[i] = 0.0f;
+  // matrix instruction m of a step: all main products, then all hi lo', then all lo' hi (an accumulator is met again TM TN instructions later)
+  auto mma_unit = [&](const Frag &f, auto M_) {
+    constexpr int m = decltype(M_)::value;
+    constexpr int n = m % TN, i = (m / TN) % TM, j = m / (TN * TM);
+    if constexpr (ABL & 1) {   // the instruction's operands are waited for where it would issue, nothing more
+      if constexpr (j == 0) asm volatile("" ::"v"(f.ah[i]), "v"(f.bh[n]));
+      else if constexpr (j == 1) asm volatile("" ::"v"(f.bl[n]));
+      else asm volatile("" ::"v"(f.al[i]));
+      return;
+    }
+    if constexpr (j == 0) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[n], acc[i][n], 0, 0, 0);
+    else if constexpr (j == 1) accx[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[n], accx[i][n], 0, 0, 0);
+    else accx[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[n], accx[i][n], 0, 0, 0);
+  };
+  // instruction step h of the tile in stage st from fc; the next step's fragments go into fn -- behind the tile's barrier when they
+  // belong to the next tile
+  auto cstep = [&](auto ST_, auto H_, const Frag &fc, Frag &fn) {
+    constexpr int st = decltype(ST_)::value, h = decltype(H_)::value;
+    constexpr bool last = h == KHS - 1;
+    using StN = std::integral_constant<int, last ? (st + 1) % NS : st>;
+    using HN = std::integral_constant<int, last ? 0 : h + 1>;
+    constexpr int first = last ? BAR_AT : 0, nslots = NMS - first;
+    static_for<0, NMS>([&](auto S_) {
+      constexpr int s = decltype(S_)::value;
+      mma_unit(fc, S_);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!A_KC && s == 0) {
+        if (do_colsum) {
+#pragma unroll
+          for (int i = 0; i < TM; i++) asum[i] = s16_frag_sum(asum[i], fc.ah[i], fc.al[i]);
+        }
+      }
+      if constexpr (last && s == BAR_AT) {
+        __builtin_amdgcn_s_barrier();   // the next tile has landed; the producers may refill this one's stage
+        asm volatile("" ::: "memory");
+      }
+      if constexpr (s >= first) {
+        static_for<(s - first) * NRH / nslots, (s - first + 1) * NRH / nslots>([&](auto R_) { read_unit(StN(), HN(), fn, R_); });
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+
+  Frag f0, f1;
+  if constexpr (ABL & 4) {   // fragments never read: give them defined (non-constant) contents
+    half8 z;
+#pragma unroll
+    for (int e = 0; e < 8; e++) z[e] = (h16)(float)(lane + e);
+#pragma unroll
+    for (int t = 0; t < TM; t++) { f0.ah[t] = z; f0.al[t] = z; f1.ah[t] = z; f1.al[t] = z; }
+#pragma unroll
+    for (int t = 0; t < TN; t++) { f0.bh[t] = z; f0.bl[t] = z; f1.bh[t] = z; f1.bl[t] = z; }
+  }
+  float w_bound = 0.f;
+  if constexpr (EXTRA) w_bound = s16_weight_bound(g, va, vb, lane);   // while the first tiles are on their way
+  __builtin_amdgcn_s_barrier();   // tile 0 has landed
+  asm volatile("" ::: "memory");
+  static_for<0, NRH>([&](auto R_) { read_unit(std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), f0, R_); });
+  for (int t0 = 0; t0 < ktiles; t0 += NS) {
+    static_for<0, NS>([&](auto I_) {
+      constexpr int I = decltype(I_)::value;
+      if (t0 + I < ktiles) {  // wave-uniform
+        static_for<0, KHS>([&](auto H_) {
+          if constexpr (decltype(H_)::value % 2 == 0) cstep(I_, H_, f0, f1);
+          else cstep(I_, H_, f1, f0);
+        });
+      }
+    });
+  }
+  __builtin_amdgcn_s_barrier();   // the producers' last requests have landed: the operand LDS is the epilogue's now
+  asm volatile("" ::: "memory");
+  static_assert(NC * 32 * kEpiPitch * (int)sizeof(float) <= NS * STAGE, "the waves' epilogue slices must fit into the operand LDS");
+  s16_finish<TM, TN, NC, EXTRA, !A_KC>(g, va, vb, acc, accx, asum, do_colsum, w_bound, m0 + wm * WM, n0 + wn * WN, lane, wave, lds);
+}
+
+template <int BM, int BN, int KT, int NS, bool A_KC, bool B_KC, bool EXTRA, int ABL = 0, int OPT = 0>
+void launch_s16_pc(GemmArgs &g, const S16Operands &ops) {
+  g.tiles_m = (g.M + BM - 1) / BM;
+  g.tiles_n = (g.N + BN - 1) / BN;
+  constexpr int lds_bytes = NS * 4 * (BM + BN) * KT;
+  auto kern = gemm_s16_pc<BM, BN, KT, NS, A_KC, B_KC, EXTRA, ABL, OPT>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    ASLP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(g.tiles_m * g.tiles_n, g.split_k > 1 ? g.split_k : 1, g.pair ? 2 : 1), dim3(512), lds_bytes, cur_stream(), g, ops);
+  t_last_parts = EXTRA ? g.tiles_m * g.tiles_n * (g.pair ? 2 : 1) : 0;
+}
+
 template <bool EXTRA>
 void launch_s16_ks128(GemmArgs &g, const S16Operands &ops) {
   g.tiles_m = (g.M + 127) / 128;

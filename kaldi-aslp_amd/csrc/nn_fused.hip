@@ -838,19 +838,19 @@ constexpr int kCoopGmaxWords = 1024;   // workgroups whose maxima may meet in on
 // Host threads of this process that launch cooperative kernels.  With more than one, the launches that wait for ALL their workgroups are not
 // used: two of them (or one beside another thread's persistent recurrence) half resident on one chip would wait for each other's
 // unplaced workgroups -- the same reason as device_shared() (scratch.h), between threads instead of processes.
-static std::atomic<int> g_coop_threads{0};
+// (the count lives in runtime.cpp -- register_grid_wide_thread -- because the persistent recurrences' launchers register in it too: a thread
+//  that only ever runs recurrences never comes through coop_state())
 struct CoopState {
   unsigned long long *inbox = nullptr, *gmax = nullptr;
   unsigned *err = nullptr, token = 0;
   bool tried = false;
-  ~CoopState() { if (tried) g_coop_threads.fetch_sub(1); }   // (the device buffers stay: the runtime may already be going down)
 };
 // (per host thread: launches of different threads run side by side on their own streams and must not meet in one exchange area)
 CoopState &coop_state() {
   static thread_local CoopState st;
   if (!st.tried) {
     st.tried = true;
-    g_coop_threads.fetch_add(1);
+    register_grid_wide_thread();
     const size_t words = (size_t)256 * 8 * 8 * kCoopCols * 3;  // up to 256 panels x Q <= 8 readers x 8 writers
     unsigned long long *p = nullptr;
     if (hipMalloc(&p, words * 8) == hipSuccess && hipMemset(p, 0xFF, words * 8) == hipSuccess) {
@@ -864,7 +864,7 @@ CoopState &coop_state() {
   return st;
 }
 // may a launch wait for every one of its workgroups?  (a device of this process' own, one launching host thread, the main stream)
-inline bool coop_grid_wide_ok() { return !device_shared() && !on_side_stream() && g_coop_threads.load() <= 1; }
+inline bool coop_grid_wide_ok() { return !device_shared() && !on_side_stream() && grid_wide_threads() <= 1; }
 inline int coop_cu_count() {
   static int num_cu = [] { hipDeviceProp_t pr; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 0; }();
   return num_cu;

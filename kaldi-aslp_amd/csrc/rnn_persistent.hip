@@ -38,6 +38,7 @@
 
 #include <cerrno>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <utility>
 #include <vector>
@@ -1693,6 +1694,8 @@ struct SeqRuntime {
   bool ring_ready = false;
   hipEvent_t last_done = nullptr;   // (made when a launch first comes from another stream than its predecessor)
   hipStream_t last_stream = nullptr;   // the stream the latest persistent launch went to
+  std::thread::id last_thread;         // ... and the host thread that issued it (its stream is only touched again by that thread)
+  bool last_done_recorded = false;     // last_done already stands behind the latest launch (recorded by its own launcher)
   bool launched = false;
   unsigned *host_err = nullptr;    // mapped host memory (device-visible)
   unsigned *host_err_dev = nullptr;
@@ -1773,10 +1776,29 @@ SeqRuntime &seq_runtime() {
 // launch cost the common single-stream case ~6 us of idle stream per launch (8 launches per cfg3 step).  Caller holds rt.launch_mu.
 static void chain_behind_last_launch(SeqRuntime &rt) {
   if (!rt.launched || rt.last_stream == cur_stream()) return;
-  if (!rt.last_done && hipEventCreateWithFlags(&rt.last_done, hipEventDisableTiming) != hipSuccess) rt.last_done = nullptr;
-  if (rt.last_done && hipEventRecord(rt.last_done, rt.last_stream) == hipSuccess && hipStreamWaitEvent(cur_stream(), rt.last_done, 0) == hipSuccess) return;
-  (void)hipGetLastError();        // (the predecessor's stream is gone, or no event: wait for the device instead)
+  if (rt.last_done_recorded && rt.last_done) {   // several launching threads: the predecessor left its own marker (note_launch)
+    if (hipStreamWaitEvent(cur_stream(), rt.last_done, 0) == hipSuccess) return;
+  } else if (rt.last_thread == std::this_thread::get_id()) {   // another stream of THIS thread (main / side): alive by construction
+    if (!rt.last_done && hipEventCreateWithFlags(&rt.last_done, hipEventDisableTiming) != hipSuccess) rt.last_done = nullptr;
+    if (rt.last_done && hipEventRecord(rt.last_done, rt.last_stream) == hipSuccess && hipStreamWaitEvent(cur_stream(), rt.last_done, 0) == hipSuccess) return;
+  }
+  // the predecessor came from another host thread without a marker (that thread, and a stream it owned, may be gone), or an event call
+  // failed: wait for the device instead of touching a stream that is not ours
+  (void)hipGetLastError();
   (void)hipDeviceSynchronize();
+}
+// behind a persistent launch (caller holds rt.launch_mu).  With one launching thread nothing is recorded (the ~6 us above); as soon as a
+// second thread launches grid-wide kernels every launch leaves its marker on its OWN stream, so that a successor never has to record
+// into a stream of another thread.
+static void note_launch(SeqRuntime &rt) {
+  rt.last_stream = cur_stream();
+  rt.last_thread = std::this_thread::get_id();
+  rt.launched = true;
+  rt.last_done_recorded = false;
+  if (grid_wide_threads() > 1) {
+    if (!rt.last_done && hipEventCreateWithFlags(&rt.last_done, hipEventDisableTiming) != hipSuccess) rt.last_done = nullptr;
+    if (rt.last_done && hipEventRecord(rt.last_done, cur_stream()) == hipSuccess) rt.last_done_recorded = true;
+  }
 }
 
 typedef void (*SeqKernel)(aslp_lstm_seq, SeqStatus, unsigned *);
@@ -1930,6 +1952,7 @@ static void launch_seq(const aslp_lstm_seq *a, bool backward, const char *who) {
   // One persistent launch at a time per process: the kernels share the placement table, the abort word and the share ring, and two
   // grids that both need every CU must not be half resident beside each other.  Launches from different host threads / streams
   // are therefore chained by an event (no host wait); the common single-stream case costs one event record per launch.
+  register_grid_wide_thread();   // (scratch.h: another thread's grid-wide BatchNormalization / planes launches now stand down)
   std::lock_guard<std::mutex> launch_lock(rt.launch_mu);
   SharedDeviceLaunch shared_device;   // ASLP_DEVICE_SHARED=1 only: cross-process lock held until this kernel has completed
   chain_behind_last_launch(rt);
@@ -1956,8 +1979,7 @@ static void launch_seq(const aslp_lstm_seq *a, bool backward, const char *who) {
     // (only lstm_seq_bwd_h forms the per-workgroup maxima of the gate diffs, and only a single launch per pass leaves a complete set)
     if (split_f16_on() && a->s_count == 0 && (a->dmax_parts[0] || a->dmax_parts[1])) t_last_dmax = kMaxChains * wpc;
   }
-  rt.last_stream = cur_stream();
-  rt.launched = true;
+  note_launch(rt);
   check_launch(who);
 }
 
@@ -1978,6 +2000,7 @@ static void launch_gru(const aslp_gru_seq *a, bool backward, const char *who) {
     return;
   }
   SeqRuntime &rt = seq_runtime();
+  register_grid_wide_thread();
   std::lock_guard<std::mutex> launch_lock(rt.launch_mu);   // as launch_seq (the same lock: LSTM and GRU launches share the runtime state)
   SharedDeviceLaunch shared_device;
   chain_behind_last_launch(rt);
@@ -1992,8 +2015,7 @@ static void launch_gru(const aslp_gru_seq *a, bool backward, const char *who) {
                   rt.epoch, 0u};
   const int wpc = (a->H + kCellsPerWg - 1) / kCellsPerWg;
   hipLaunchKernelGGL(pick_gru(backward, a->H), dim3(kMaxChains * wpc), dim3(512), 0, cur_stream(), *a, st, rt.place);
-  rt.last_stream = cur_stream();
-  rt.launched = true;
+  note_launch(rt);
   check_launch(who);
 }
 void aslp_gru_seq_forward(const aslp_gru_seq *a) { launch_gru(a, false, "aslp_gru_seq_forward"); }

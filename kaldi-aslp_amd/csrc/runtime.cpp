@@ -1,5 +1,6 @@
 // runtime.cpp -- per-thread stream, sticky error slot and device scratch for libaslp_hip.so.
 // Replaces the slice of CuDevice (src/aslp-cudamatrix/cu-device.h:43-151) the hot path needs.
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -109,7 +110,7 @@ static thread_local hipEvent_t t_fork_ev = nullptr, t_join_ev = nullptr;
 static thread_local hipStream_t t_side_parent = nullptr;  // main stream the pending side work has to rejoin
 static thread_local bool t_side_dirty = false;
 static thread_local unsigned long t_side_seq = 0;          // side-stream scopes opened by this thread so far
-static thread_local void *t_mark_ev = nullptr;             // the latest marker this thread recorded and the scope count it covers
+static thread_local unsigned long long t_mark_gen = 0;     // generation of the latest marker this thread recorded, and the scope count it covers
 static thread_local unsigned long t_mark_seq = 0;
 
 static bool side_ready() {
@@ -156,28 +157,57 @@ void join_side_stream() {
     set_error("side stream: join failed");
 }
 
-bool side_stream_mark(void **ev) {
-  if (!t_side_dirty || !t_side || !ev) return false;
-  if (!*ev) {
-    hipEvent_t e = nullptr;
-    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { set_error("side stream: cannot create a marker event"); return false; }
-    *ev = e;
+// A marker is an event plus a generation number drawn from a process-wide counter at every record: "is this my own latest marker" is
+// decided by the number, never by the address (an address can come back from the allocator after a net has been destroyed, and another
+// thread may have recorded into it since).
+namespace {
+struct SideMark { hipEvent_t ev = nullptr; unsigned long long gen = 0; };
+std::atomic<unsigned long long> g_mark_gen{0};
+}  // namespace
+int side_stream_mark(void **ev) {
+  if (!t_side_dirty || !t_side || !ev) return 0;
+  SideMark *m = static_cast<SideMark *>(*ev);
+  if (!m) {
+    m = new SideMark();
+    if (hipEventCreateWithFlags(&m->ev, hipEventDisableTiming) != hipSuccess) { delete m; set_error("side stream: cannot create a marker event"); return -1; }
+    *ev = m;
   }
-  if (hipEventRecord(static_cast<hipEvent_t>(*ev), t_side) != hipSuccess) { set_error("side stream: marker record failed"); return false; }
-  t_mark_ev = *ev;
+  if (hipEventRecord(m->ev, t_side) != hipSuccess) { set_error("side stream: marker record failed"); return -1; }
+  m->gen = ++g_mark_gen;
+  t_mark_gen = m->gen;
   t_mark_seq = t_side_seq;
-  return true;
+  return 1;
 }
 void side_stream_mark_wait(void *ev, bool host) {
-  if (!ev) return;
-  const hipError_t e = host ? hipEventSynchronize(static_cast<hipEvent_t>(ev)) : hipStreamWaitEvent(cur_stream(), static_cast<hipEvent_t>(ev), 0);
+  SideMark *m = static_cast<SideMark *>(ev);
+  if (!m || !m->ev) return;
+  const hipError_t e = host ? hipEventSynchronize(m->ev) : hipStreamWaitEvent(cur_stream(), m->ev, 0);
   if (e != hipSuccess) { set_error(std::string("side stream: marker wait failed: ") + hipGetErrorString(e)); return; }
   // This thread's own latest marker with no side-stream scope opened since: the marker stands behind ALL pending side work, and the wait
   // just made IS the join with the parent stream -- join_side_stream() need not put a second event wait into that stream (a wait on another
   // stream's event costs the waiting stream several microseconds of idle time even when the event has long fired).
-  if (ev == t_mark_ev && t_mark_seq == t_side_seq && t_bank == 0 && (host || cur_stream() == t_side_parent)) t_side_dirty = false;
+  if (m->gen != 0 && m->gen == t_mark_gen && t_mark_seq == t_side_seq && t_bank == 0 && (host || cur_stream() == t_side_parent)) t_side_dirty = false;
 }
-void side_stream_mark_free(void *ev) { if (ev) (void)hipEventDestroy(static_cast<hipEvent_t>(ev)); }
+void side_stream_mark_free(void *ev) {
+  SideMark *m = static_cast<SideMark *>(ev);
+  if (!m) return;
+  if (m->ev) (void)hipEventDestroy(m->ev);
+  delete m;
+}
+
+// ---- host threads that launch kernels whose workgroups wait for ALL workgroups of their launch (scratch.h) --------------------------
+namespace {
+std::atomic<int> g_grid_wide_threads{0};
+struct GridWideRegistrar {
+  bool on = false;
+  ~GridWideRegistrar() { if (on) g_grid_wide_threads.fetch_sub(1); }
+};
+}  // namespace
+void register_grid_wide_thread() {
+  static thread_local GridWideRegistrar r;
+  if (!r.on) { r.on = true; g_grid_wide_threads.fetch_add(1); }
+}
+int grid_wide_threads() { return g_grid_wide_threads.load(); }
 
 // ---- named region timers (bench.py's cfg3 block): HIP events on the launch stream around a host-side region ------------
 namespace {

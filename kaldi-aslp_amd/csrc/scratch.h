@@ -35,9 +35,10 @@ class RegionScope {
 void join_side_stream();
 // A marker for the side-stream work the calling thread has issued so far, for waiters that may sit on another host thread (whose own
 // join_side_stream() knows nothing of this thread's side stream).  side_stream_mark(ev) records into *ev (created on first use; the
-// caller owns it and gives it back with side_stream_mark_free) and returns false when there is no pending side work.
+// caller owns it and gives it back with side_stream_mark_free).  Returns 1 = recorded, 0 = there is no pending side work, -1 = the marker
+// could not be created or recorded (error set): the caller must then join_side_stream() itself -- "failed" is not "nothing pending".
 // side_stream_mark_wait(ev, host): the calling thread's current stream waits for the marker -- or the host does.
-bool side_stream_mark(void **ev);
+int side_stream_mark(void **ev);
 void side_stream_mark_wait(void *ev, bool host);
 void side_stream_mark_free(void *ev);
 // Several processes share this GPU (ASLP_DEVICE_SHARED=1 / aslp_device_shared(1); rnn_persistent.hip): kernels whose workgroups wait for
@@ -45,4 +46,10 @@ void side_stream_mark_free(void *ev);
 // each other never finish.
 bool device_shared();
 bool on_side_stream();  // is the calling thread inside a SideStreamScope?
+// The same hazard between host threads of ONE process: every thread that launches such kernels -- the cooperative BatchNormalization /
+// planes launches of nn_fused.hip AND the persistent LSTM / GRU recurrences of rnn_persistent.hip -- registers itself once; with more than
+// one registered thread the launches that could stand down to a multi-launch path do (coop_grid_wide_ok), the persistent recurrences
+// are serialised against each other by their launch chain.
+void register_grid_wide_thread();
+int grid_wide_threads();
 }  // namespace aslp

@@ -640,7 +640,7 @@ void aslp_fsmn_backward(float *in_diff, int ldid, float *coef_corr, int ldcc, fl
     return;
   }
   float *partial = static_cast<float *>(scratch(kScratchMisc, sizeof(float) * (size_t)nchunks * C * D));
-  if (!partial) return;
+  if (!partial) { set_error("aslp_fsmn_backward: no scratch for the tap-gradient partials -- nothing was launched (no in_diff, no gradient, no step)"); return; }
   static bool attr_set = false;
   if (!attr_set) {
     ASLP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fsmn_backward_fused), hipFuncAttributeMaxDynamicSharedMemorySize, kFsmnLdsRows * kWave * sizeof(float)));
@@ -713,7 +713,7 @@ void aslp_rowconv_backward_fused(float *in_diff, int ldid, float *w_diff, const 
   const int dtiles = (D + kRcCols - 1) / kRcCols, sgroups = (S + kRcStreams - 1) / kRcStreams, nstrips = dtiles * sgroups;
   const int tc = kRcChunk, nchunks = (T + K + tc - 1) / tc, nparts = nchunks * sgroups;
   float *partial = static_cast<float *>(scratch(kScratchMisc, sizeof(float) * (size_t)nparts * (K + 1) * D));
-  if (!partial) return;
+  if (!partial) { set_error("aslp_rowconv_backward_fused: no scratch for the tap-gradient partials -- nothing was launched (no in_diff, no gradient, no step)"); return; }
   const dim3 grid(8 * ((nstrips + 7) / 8) * nchunks), block(kWave, kRcStreams);
 #define ASLP_RC_BWD(KP, EXACT) hipLaunchKernelGGL((rowconv_bwd_fused<KP, EXACT>), grid, block, 0, cur_stream(), in_diff, ldid, partial, in, ldi, out_diff, ldod, w, D, K, T, S, seq_len, tc, nchunks, dtiles, nstrips, sgroups)
   if (K + 1 == 21) ASLP_RC_BWD(21, true);

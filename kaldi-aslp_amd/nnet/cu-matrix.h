@@ -111,6 +111,13 @@ class CuMatrixBase;
 class CuSubVector;
 class PlaneSet;
 
+// a kernel-level error recorded since the last check (aslp_get_last_error: launch failures, unsupported arguments, a scratch block that
+// could not be had) becomes the engine's exception here
+inline void CheckKernelError() {
+  char buf[512];
+  if (aslp_get_last_error(buf, sizeof(buf))) ASLP_ERR << buf;
+}
+
 class CuVectorBase {
  public:
   int Dim() const { return dim_; }

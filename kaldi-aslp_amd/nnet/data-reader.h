@@ -33,6 +33,9 @@ inline void RegisterTrainOptions(NnetTrainOptions *o, OptionsItf *opts) {  // nn
   opts->Register("l1-penalty", &o->l1_penalty, "L1 penalty (promote sparsity)");
 }
 
+inline void NnetTrainOptions::Register(OptionsItf *opts) { RegisterTrainOptions(this, opts); }              // the reference's spelling
+inline void NnetDataRandomizerOptions::Register(OptionsItf *opts) { RegisterRandomizerOptions(this, opts); }
+
 typedef StdVectorRandomizer<std::vector<std::pair<int32, BaseFloat>>> PosteriorRandomizer;
 
 // A background thread parses the two tables (file / pipe reads, Posterior parsing, the copy of each feature matrix into

@@ -14,9 +14,11 @@
 
 namespace aslp {
 
+class OptionsItf;
 struct NnetTrainOptions {  // nnet-trnopts.h:29-47
   BaseFloat learn_rate, momentum, l2_penalty, l1_penalty;
   NnetTrainOptions() : learn_rate(0.008), momentum(0.0), l2_penalty(0.0), l1_penalty(0.0) {}
+  void Register(OptionsItf *opts);   // nnet-trnopts.h:42-47 (defined in data-reader.h, beside the option strings)
 };
 
 class Component {

@@ -316,11 +316,12 @@ std::string MultiTaskLoss::Report() {  // nnet-loss.cc:370-393
   std::ostringstream oss;
   oss << "MultiTaskLoss, with " << loss_vec_.size() << " parallel loss functions." << std::endl;
   for (size_t i = 0; i < loss_vec_.size(); i++) oss << "Loss " << i + 1 << ", " << loss_vec_[i]->Report() << std::endl;
-  oss << "Loss (OVERALL), " << "AvgLoss: " << overall_loss << " (MultiTaskLoss), " << "weights [ ";
+  // (the reference streams both vectors through nnet-utils.h:42-45: every element followed by one blank, no brackets)
+  oss << "Loss (OVERALL), " << "AvgLoss: " << overall_loss << " (MultiTaskLoss), " << "weights ";
   for (BaseFloat w : loss_weights_) oss << w << " ";
-  oss << "], values [ ";
+  oss << ", values ";
   for (LossItf *l : loss_vec_) oss << l->AvgLoss() << " ";
-  oss << "]" << std::endl;
+  oss << std::endl;
   return oss.str();
 }
 BaseFloat MultiTaskLoss::AvgLoss() {  // nnet-loss.cc:395-406

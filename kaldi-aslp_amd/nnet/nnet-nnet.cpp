@@ -401,7 +401,9 @@ void Nnet::Backpropagate(const std::vector<const CuMatrixBase *> &out_diff, std:
     for (int32 i = 0; i < first; i++)
       if (fused_sigmoid[i] >= first || AffineSigmoidOf(i) >= first) { first = i; i = -1; }
     first_after_updates_ = first;
-    updates_pending_ = side_stream_mark(&updates_mark_);
+    const int marked = side_stream_mark(&updates_mark_);
+    updates_pending_ = marked > 0;
+    if (marked < 0) join_side_stream();   // no marker to wait for later: the join is made here (the error is set)
   } else {
     join_side_stream();
   }

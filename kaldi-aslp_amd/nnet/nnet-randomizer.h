@@ -21,9 +21,11 @@
 
 namespace aslp {
 
+class OptionsItf;
 struct NnetDataRandomizerOptions {  // nnet-randomizer.h:34-50
   int32 randomizer_size, randomizer_seed, minibatch_size;
   NnetDataRandomizerOptions() : randomizer_size(32768), randomizer_seed(777), minibatch_size(256) {}
+  void Register(OptionsItf *opts);   // nnet-randomizer.h:43-47 (defined in data-reader.h)
 };
 
 class RandomizerMask {  // :53-64

@@ -80,6 +80,9 @@ class RowConvolution : public UpdatableComponent {
     update_done_ = fold;
     aslp_rowconv_backward_fused(in_diff->Data(), in_diff->Stride(), w_diff_.Data(), in.Data(), in.Stride(), out_diff.Data(), out_diff.Stride(), w_.Data(),
                                 input_dim_, future_ctx_, T, S, seq_len_dev_.Data(), w_corr_.Data(), opts_.momentum, opts_.learn_rate, fold ? 1 : 0);
+    // a launch that did not happen (its scratch could not be had) has applied no step and written no in_diff: the step must not count as
+    // done, and the caller hears about it here rather than at some later kernel's check
+    try { CheckKernelError(); } catch (...) { update_done_ = false; throw; }
   }
   void Update(const CuMatrixBase &, const CuMatrixBase &) {  // :178-186
     if (update_done_) { update_done_ = false; return; }   // (rode in BackpropagateFnc's finishing launch)
@@ -178,6 +181,7 @@ class CompactFsmn : public UpdatableComponent {
     aslp_fsmn_backward(in_diff->Data(), in_diff->Stride(), vec_coef_corr_.Data(), vec_coef_corr_.Stride(), vec_coef_.Data(), vec_coef_.Stride(), in.Data(),
                        in.Stride(), out_diff.Data(), out_diff.Stride(), input_dim_, past_context_, future_context_, T, clip_gradient_,
                        fold ? opts_.learn_rate * learn_rate_coef_ : 0.0f);
+    try { CheckKernelError(); } catch (...) { update_done_ = false; throw; }   // (as RowConvolution: a failed launch has applied no step)
   }
   void Update(const CuMatrixBase &, const CuMatrixBase &) {  // :258-262
     if (update_done_) { update_done_ = false; return; }   // (rode in BackpropagateFnc's launch)

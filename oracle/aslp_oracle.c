@@ -680,6 +680,26 @@ void orc_mse_eval(const float *fw, const float *net_out, int ldn, const float *t
   *frames = num_frames;
 }
 
+void orc_multitask_eval(int n_tasks, const int *kinds, const int *dims, const float *weights, const float *fw, const float *net_out,
+                        int ldn, const float *tgt, int ldt, int rows, float *diff, int ldd, orc_xent_stats *xent_st, double *mse_loss,
+                        double *mse_frames) {
+  /* nnet-loss.cc:341-368: every task evaluates its own column block of the network output against the same block of the dense
+   * target matrix (PosteriorToMatrix over ALL columns, :350), its diff is scaled by the task weight (:362) and copied into the
+   * block (:364).  The column offsets are the running sums of the dims (:330-333). */
+  int off = 0;
+  for (int i = 0; i < n_tasks; i++) {
+    float *d = diff + off;
+    if (kinds[i] == 0) {
+      orc_xent_eval(fw, net_out + off, ldn, tgt + off, ldt, rows, dims[i], d, ldd, &xent_st[i]);
+    } else {
+      orc_mse_eval(fw, net_out + off, ldn, tgt + off, ldt, rows, dims[i], d, ldd, &mse_loss[i], &mse_frames[i]);
+    }
+    for (int r = 0; r < rows; r++)
+      for (int c = 0; c < dims[i]; c++) d[(size_t)r * ldd + c] *= weights[i]; /* diff_aux.Scale(loss_weights_[i]) */
+    off += dims[i];
+  }
+}
+
 /* ------------------------------------------------------------------------------- */
 /* Whole DNN train step (cpu_baseline "port"): the chain Nnet::Propagate ->
  * Xent::Eval -> Nnet::Backpropagate of nnet-nnet.cc:70-154 for a "simple" net

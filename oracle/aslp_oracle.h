@@ -125,6 +125,12 @@ void orc_xent_eval(const float *frame_weights, const float *net_out, int ldn, co
 /* Mse::Eval, nnet-loss.cc:205-258 */
 void orc_mse_eval(const float *frame_weights, const float *net_out, int ldn, const float *targets,
                   int ldt, int rows, int cols, float *diff, int ldd, double *loss, double *frames);
+/* MultiTaskLoss::Eval, nnet-loss.cc:341-368 ('multitask,<type>,<dim>,<weight>,...', :296-339).  kinds[i]: 0 = xent, 1 = mse; task i owns
+ * columns [sum dims[<i], + dims[i]) of net_out / targets / diff; per-call increments of task i go to xent_st[i] or mse_loss[i] /
+ * mse_frames[i] (the other kind's slot is left alone); diff blocks are scaled by weights[i]. */
+void orc_multitask_eval(int n_tasks, const int *kinds, const int *dims, const float *weights, const float *frame_weights,
+                        const float *net_out, int ldn, const float *targets, int ldt, int rows, float *diff, int ldd,
+                        orc_xent_stats *xent_st, double *mse_loss, double *mse_frames);
 
 /* ---- front-end components of the CNN / cFSMN recipes (aslp_oracle_conv.c) ------------------------------------------- */
 /* LinearTransform, nnet-linear-transform.h:127-160 (orc_affine_opts: learn_rate, momentum, l2, l1, learn_rate_coef are used) */

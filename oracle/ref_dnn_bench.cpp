@@ -8,7 +8,7 @@
 // Backpropagate (nnet-nnet.cc:70-154: Update right after each component's Backpropagate; the unused in-diff of the first layer
 // is computed like the reference computes it); every operation is the reference's own code.  The same sequences are what
 // tests/golden/cumatrix_blas_ops.bin pins the oracle and the HIP engine against.
-// usage: ref_dnn_bench <seconds> [max_steps]    ->  one JSON line on stdout
+// usage: ref_dnn_bench <seconds> [max_steps [cfg1]]  ->  one JSON line on stdout ("cfg1": the net without BatchNormalization at minibatch 256)
 //        ref_dnn_bench golden <out.bin>        ->  tests/golden/dnn_cfg2_fullsize.bin: two training steps of the same net at lr 0.008 on fresh
 //                                                  minibatches, as a digest (every 257th element of a tensor + its sums; weights and data
 //                                                  are replayed by the reader from the recorded generator state, oracle_lib.GoldenRng)
@@ -172,8 +172,12 @@ int main(int argc, char **argv) {
   const bool golden = argc == 3 && !std::strcmp(argv[1], "golden");
   const double budget = (!golden && argc > 1) ? atof(argv[1]) : 10.0;
   const int max_steps = (!golden && argc > 2) ? atoi(argv[2]) : 20;
-  const int IN = 440, HID = 2048, NH = 5, OUT = 3000, MB = 1024;
-  const float lr = golden ? 0.008f : 1e-5f, mmt = 0.0f;
+  // "cfg1" as a third argument: BASELINE cfg1 / cfg4's per-GPU leg -- the same net WITHOUT BatchNormalization at minibatch 256, learn rate
+  // 0.008 (run_dnn.sh:81-83), the configuration the >= 30x target is stated on (aslp-nnetbin/aslp-nnet-train-frame.cc:109-131)
+  const bool cfg1 = !golden && argc > 3 && !std::strcmp(argv[3], "cfg1");
+  const bool with_bn = !cfg1;
+  const int IN = 440, HID = 2048, NH = 5, OUT = 3000, MB = cfg1 ? 256 : 1024;
+  const float lr = (golden || cfg1) ? 0.008f : 1e-5f, mmt = 0.0f;
   const unsigned long long state0 = g_state;
   std::vector<Affine> aff(NH + 1);
   std::vector<BatchNorm> bn(NH);
@@ -198,9 +202,9 @@ int main(int argc, char **argv) {
     const Mat *cur = &x;
     for (int l = 0; l < NH; l++) {
       aff[l].Propagate(*cur, &a[l]);
-      bn[l].Propagate(a[l], &z[l]);
+      if (with_bn) bn[l].Propagate(a[l], &z[l]);
       y[l].Resize(MB, HID, kUndefined);
-      y[l].Sigmoid(z[l]);
+      y[l].Sigmoid(with_bn ? z[l] : a[l]);
       cur = &y[l];
     }
     aff[NH].Propagate(*cur, &a[NH]);
@@ -229,10 +233,13 @@ int main(int argc, char **argv) {
     for (int l = NH - 1; l >= 0; l--) {
       dy[l].Resize(MB, HID, kUndefined);
       dy[l].DiffSigmoid(y[l], *d);
-      bn[l].Backpropagate(a[l], dy[l], &dz[l], mmt);
-      bn[l].Update(lr);
-      aff[l].Backpropagate(dz[l], &da[l]);
-      aff[l].Update(l == 0 ? x : y[l - 1], dz[l], lr, mmt);
+      if (with_bn) {
+        bn[l].Backpropagate(a[l], dy[l], &dz[l], mmt);
+        bn[l].Update(lr);
+      }
+      const Mat &dpre = with_bn ? dz[l] : dy[l];
+      aff[l].Backpropagate(dpre, &da[l]);
+      aff[l].Update(l == 0 ? x : y[l - 1], dpre, lr, mmt);
       d = &da[l];
     }
   };
@@ -270,7 +277,7 @@ int main(int argc, char **argv) {
     steps++;
     el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   } while (el < budget && steps < max_steps);
-  std::printf("{\"frames_per_sec\": %.3f, \"steps\": %d, \"seconds\": %.3f, \"minibatch\": %d, \"threads\": %d, \"xent_per_frame\": %.5f}\n",
-              steps * MB / el, steps, el, MB, scipy_openblas_get_num_threads(), loss / MB);
+  std::printf("{\"frames_per_sec\": %.3f, \"steps\": %d, \"seconds\": %.3f, \"minibatch\": %d, \"threads\": %d, \"xent_per_frame\": %.5f, \"batch_norm\": %d}\n",
+              steps * MB / el, steps, el, MB, scipy_openblas_get_num_threads(), loss / MB, with_bn ? 1 : 0);
   return 0;
 }

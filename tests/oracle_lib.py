@@ -92,6 +92,7 @@ class XentStats(C.Structure):
 
 _sig("orc_xent_eval", None, f32p, f32p, _i, f32p, _i, _i, _i, f32p, _i, C.POINTER(XentStats))
 _sig("orc_mse_eval", None, f32p, f32p, _i, f32p, _i, _i, _i, f32p, _i, C.POINTER(C.c_double), C.POINTER(C.c_double))
+_sig("orc_multitask_eval", None, _i, i32p, i32p, f32p, f32p, f32p, _i, f32p, _i, _i, f32p, _i, C.POINTER(XentStats), C.POINTER(C.c_double), C.POINTER(C.c_double))
 _sig("orc_dnn_create", C.c_void_p, _i, _i, _i, _i, _i, _i, C.c_uint)
 _sig("orc_dnn_destroy", None, C.c_void_p)
 _sig("orc_dnn_train_step", C.c_double, C.c_void_p, f32p, i32p, _f, _f)
@@ -213,6 +214,26 @@ def xent_eval(fw, net_out, tgt):
     fw = c32(fw); y = c32(net_out); t = c32(tgt); diff = np.empty_like(y); st = XentStats()
     lib.orc_xent_eval(fw, y, y.shape[1], t, t.shape[1], y.shape[0], y.shape[1], diff, y.shape[1], C.byref(st))
     return diff, dict(frames=st.frames, correct=st.correct, loss=st.loss, entropy=st.entropy, likelyhood=st.likelyhood)
+
+
+def multitask_eval(spec, fw, net_out, tgt):
+    """MultiTaskLoss::Eval (nnet-loss.cc:341-368) for spec = [(kind, dim, weight), ...], kind 'xent' | 'mse'.  Returns the diff and, per
+    task, the call's increments: xent -> dict(frames, correct, loss, entropy, likelyhood); mse -> dict(loss, frames)."""
+    n = len(spec)
+    kinds = np.array([0 if k == "xent" else 1 for k, _, _ in spec], np.int32)
+    dims = np.array([d for _, d, _ in spec], np.int32)
+    wts = np.array([w for _, _, w in spec], np.float32)
+    fw = c32(fw); y = c32(net_out); t = c32(tgt); diff = np.zeros_like(y)
+    xs = (XentStats * n)()
+    ml = (C.c_double * n)(); mf = (C.c_double * n)()
+    lib.orc_multitask_eval(n, kinds, dims, wts, fw, y, y.shape[1], t, t.shape[1], y.shape[0], diff, y.shape[1], xs, ml, mf)
+    out = []
+    for i, (k, _, _) in enumerate(spec):
+        if k == "xent":
+            out.append(dict(frames=xs[i].frames, correct=xs[i].correct, loss=xs[i].loss, entropy=xs[i].entropy, likelyhood=xs[i].likelyhood))
+        else:
+            out.append(dict(loss=ml[i], frames=mf[i]))
+    return diff, out
 
 
 def rel_err(a, b):
@@ -459,6 +480,29 @@ class Linear:
         o = AffineOpts(lr, mmt, l2, l1, coef, 1.0, 0.0)
         lib.orc_linear_update(self.W, self.W.shape[1], self.corr, self.corr.shape[1], x, x.shape[1], od, od.shape[1], x.shape[0], self.W.shape[1],
                               self.W.shape[0], C.byref(o))
+
+
+class Affine:
+    """AffineTransform (nnet-affine-transform.h:186-245): W [out x in], bias, their momentum buffers"""
+    def __init__(self, W, b):
+        self.W = c32(W).copy(); self.b = c32(b).copy()
+        self.Wc = np.zeros_like(self.W); self.bc = np.zeros_like(self.b)
+
+    def propagate(self, x):
+        x = c32(x); out = np.empty((x.shape[0], self.W.shape[0]), np.float32)
+        lib.orc_affine_propagate(out, out.shape[1], x, x.shape[1], x.shape[0], self.W, self.W.shape[1], self.b, self.W.shape[1], self.W.shape[0])
+        return out
+
+    def backpropagate(self, od):
+        od = c32(od); idf = np.empty((od.shape[0], self.W.shape[1]), np.float32)
+        lib.orc_affine_backpropagate(idf, idf.shape[1], od, od.shape[1], od.shape[0], self.W, self.W.shape[1], self.W.shape[1], self.W.shape[0])
+        return idf
+
+    def update(self, x, od, lr, mmt=0.0, l2=0.0, l1=0.0):
+        x, od = c32(x), c32(od)
+        o = AffineOpts(lr, mmt, l2, l1, 1.0, 1.0, 0.0)
+        lib.orc_affine_update(self.W, self.W.shape[1], self.b, self.Wc, self.Wc.shape[1], self.bc, x, x.shape[1], od, od.shape[1], x.shape[0],
+                              self.W.shape[1], self.W.shape[0], C.byref(o))
 
 
 class Conv:

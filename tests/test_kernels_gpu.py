@@ -454,7 +454,7 @@ def test_xent_deferred_row_sums_are_bit_identical(aslp, dev, rows, cols, softmax
 def test_copy_mat_trans(aslp, dev):
     """aslp_copy_mat_trans: dst = src^T, strided operands (what the recurrent layers use to refresh their K-contiguous weight copies)"""
     ptr, dim, lib = aslp.ops.ptr, aslp.ops.dim, aslp.ops.lib
-    for rows, cols in ((512, 1024), (37, 5), (1, 9)):
+    for rows, cols in ((512, 1024), (37, 5), (1, 9), (2048, 256), (33, 65), (64, 31)):   # (32 x 32 LDS tiles: whole, ragged and single-row grids)
         src = torch.randn(cols, rows + 3, device=dev)[:, :rows]      # [cols x rows], stride rows + 3
         dst = torch.full((rows, cols + 2), 9.0, device=dev)
         view = dst[:, :cols]

@@ -13,6 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_cabi_exports_every_declared_symbol(aslp):
     names, par_names = set(), set()
     for h in os.listdir(os.path.join(ROOT, "include")):
+        if not h.endswith(".h") or h == "aslp_compat_kaldi.h":   # (the C++ compat header and its forwarding headers declare no C ABI)
+            continue
         txt = open(os.path.join(ROOT, "include", h)).read()
         txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
         found = set(re.findall(r"\b((?:cudaF_|cudaI32_|aslp_|compute_ctc_loss|get_workspace_size|ctcGetStatusString|get_warpctc_version)\w*)\s*\(", txt))

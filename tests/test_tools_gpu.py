@@ -1017,3 +1017,55 @@ def test_forward_mimo_tool(aslp, dev, tmp_path):
     assert p.returncode != 0 and b"Different key from the features" in p.stderr
     p = tool("aslp-nnet-forward-mimo", str(tmp_path / "mimo.nnet"), "ark:%s" % (tmp_path / "f0.ark"), "ark:%s" % (tmp_path / "x.ark"), ok=False)
     assert p.returncode == 1
+
+
+def test_reference_mains_compiled_unchanged_run_on_this_engine(aslp, oracle, dev, tmp_path):
+    """Seam B4 as a source-level drop-in: kaldi-aslp_amd/bin_ref/* are the REFERENCE's own aslp-nnetbin/*.cc, compiled unchanged against
+    include/aslp_compat_kaldi.h and linked with this engine (`make -C kaldi-aslp_amd refmains`, development container; the binaries
+    travel, the sources do not).  They must do what the engine's own tools do: same model files, same log vocabulary -- and, for the
+    training tool, the reference's arithmetic (CPU oracle over the same minibatches)."""
+    ref_bin = os.path.join(ROOT, "kaldi-aslp_amd", "bin_ref")
+    if not os.path.exists(os.path.join(ref_bin, "aslp-nnet-train-frame")):
+        pytest.skip("bin_ref/ not built (needs the reference tree: make -C kaldi-aslp_amd refmains)")
+
+    def ref_tool(name, *args):
+        p = subprocess.run([os.path.join(ref_bin, name)] + list(args), capture_output=True, timeout=1800)
+        assert p.returncode == 0, p.stderr.decode()[-3000:]
+        return p
+
+    # init / copy / info: byte-identical files and text
+    (tmp_path / "nnet.proto").write_text(PROTO)
+    ref_tool("aslp-nnet-init", "--seed=123", str(tmp_path / "nnet.proto"), str(tmp_path / "r.bin"))
+    tool("aslp-nnet-init", "--seed=123", str(tmp_path / "nnet.proto"), str(tmp_path / "o.bin"))
+    assert (tmp_path / "r.bin").read_bytes() == (tmp_path / "o.bin").read_bytes()
+    ref_tool("aslp-nnet-copy", "--binary=false", str(tmp_path / "r.bin"), str(tmp_path / "r.txt"))
+    tool("aslp-nnet-copy", "--binary=false", str(tmp_path / "o.bin"), str(tmp_path / "o.txt"))
+    assert (tmp_path / "r.txt").read_bytes() == (tmp_path / "o.txt").read_bytes()
+    assert ref_tool("aslp-nnet-info", str(tmp_path / "r.bin")).stdout == tool("aslp-nnet-info", str(tmp_path / "o.bin")).stdout
+
+    # train-frame: the reference's loop body (Propagate, LossItf::Eval, Backpropagate: aslp-nnet-train-frame.cc:109-131) against the engine's
+    # tool (same steps in the executor's own buffers) and against the oracle
+    in_dim, hid, nh, out_dim, mb = 24, 64, 2, 40, 32
+    d, path = make_dnn(oracle, tmp_path, in_dim, hid, nh, out_dim, 1, mb, seed=33)
+    rng = np.random.default_rng(17)
+    keys, feats, posts = write_corpus(tmp_path, rng, 10, in_dim, out_dim)
+    lr, seed, rsize = 0.004, 41, 150
+    args = ["--learn-rate=%g" % lr, "--momentum=0.5", "--minibatch-size=%d" % mb, "--randomizer-size=%d" % rsize, "--randomizer-seed=%d" % seed,
+            "ark:%s" % (tmp_path / "feats.ark"), "ark:%s" % (tmp_path / "post.ark"), str(path)]
+    pr = ref_tool("aslp-nnet-train-frame", *args, str(tmp_path / "ref.nnet"))
+    po = tool("aslp-nnet-train-frame", *args, str(tmp_path / "own.nnet"))
+    got_ref = aslp.Nnet.Read(tmp_path / "ref.nnet").GetParams()
+    got_own = aslp.Nnet.Read(tmp_path / "own.nnet").GetParams()
+    assert oracle.rel_err(got_ref, got_own) < 1e-6      # (the tool leaves the final Softmax to the loss kernel; same bits or a rounding apart)
+    for x, t, _ in minibatches(aslp, feats, posts, mb, seed, rsize):
+        oracle.lib.orc_dnn_train_step(d, np.ascontiguousarray(x), np.array([fr[0][0] for fr in t], np.int32), lr, 0.5)
+    assert oracle.rel_err(got_ref, oracle_params(oracle, d, 1)) < TOL
+    oracle.lib.orc_dnn_destroy(d)
+    er, eo = pr.stderr.decode(), po.stderr.decode()
+    for word in ("TRAINING STARTED", "[TRAINING, RANDOMIZED,", "AvgLoss:", "FRAME_ACCURACY >>"):
+        assert word in er and word in eo
+    assert abs(float(scheduler_reads(er, SCHED_LOSS)) - float(scheduler_reads(eo, SCHED_LOSS))) < 1e-4
+    # cross-validation through the reference's main
+    pc = ref_tool("aslp-nnet-train-frame", "--cross-validate=true", "--minibatch-size=%d" % mb, "ark:%s" % (tmp_path / "feats.ark"),
+                  "ark:%s" % (tmp_path / "post.ark"), str(tmp_path / "ref.nnet"))
+    assert b"CROSS-VALIDATION STARTED" in pc.stderr and b"AvgLoss:" in pc.stderr
