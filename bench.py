@@ -413,7 +413,7 @@ def product_accuracy_block(aslp, dev):
                 C_ = torch.zeros(M, N, device=dev)
                 aslp.ops.sgemm(tA, tB, 1.0, A, B, 0.0, C_)
                 if on:
-                    served = aslp.lib.aslp_gemm_last_tile() in (304, 308, 311, 328)
+                    served = aslp.lib.aslp_gemm_last_tile() in (304, 308, 311, 328, 351)
                 err[key] = ((C_.double() - ref).abs() / mag).max().item()
             le = err["split"] <= err["fp32"] * 1.0000001
             all_le = all_le and le
@@ -1047,7 +1047,7 @@ def main():
             tile_name = tile_buf.value.decode()
             if traffic is not None and pmc.get("cfg") not in (None, tile_cfg):
                 traffic, traffic_src = None, "committed PMC pass was taken with tile cfg %s, this run used %d: omitted" % (pmc.get("cfg"), tile_cfg)
-            split = tile_cfg in (304, 308, 311, 328)   # the product ran on the fp16 instruction (three per fp32-equivalent multiply)
+            split = tile_cfg in (304, 308, 311, 328, 351)   # the product ran on the fp16 instruction (three per fp32-equivalent multiply)
             peak = SPLIT_PEAK_TF_EQUIV if split else F32_MFMA_PEAK_TFLOPS
             out["roofline"] = {"bound": "mfma", "kernel": "aslp_sgemm<%s> (%s; cfg %d)" % (dom, tile_name, tile_cfg), "achieved": d["tflops"], "peak": peak,
                                "unit": "TFLOP/s (fp32-equivalent)" if split else "TFLOP/s", "frac": d["tflops"] / peak,

@@ -94,22 +94,18 @@ int main(int argc, char **argv) {
     run("NT (cfg2 forward)", true, true, 1024, 2048, 2048,
         {V("glds 64x128 4w NS3 (308)", launch_s16<64, 128, 2, 2, 3, true, true>),
          V("pc 64x128 KT64 NS3", launch_s16_pc<64, 128, 64, 3, true, true, false>),
-         V("pc 64x128 + scalar prefetch (all)", launch_s16_pc<64, 128, 64, 3, true, true, false, 0, 8>),
-         V("pc 64x128 + scalar prefetch (dedup)", launch_s16_pc<64, 128, 64, 3, true, true, false, 0, 16>),
          VA("pc 64x128 HOT (every request an L2 hit)", launch_s16_pc<64, 128, 64, 3, true, true, false, 0, 4>),
          VA("pc 64x128 HOT DMA only", launch_s16_pc<64, 128, 64, 3, true, true, false, 5, 4>),
          VA("pc 64x128 no MFMA", launch_s16_pc<64, 128, 64, 3, true, true, false, 1>),
+         VA("pc 64x128 no LDS reads (DMA + MFMA)", launch_s16_pc<64, 128, 64, 3, true, true, false, 4>),
          VA("pc 64x128 no DMA", launch_s16_pc<64, 128, 64, 3, true, true, false, 2>),
          VA("pc 64x128 MFMA only", launch_s16_pc<64, 128, 64, 3, true, true, false, 6>),
          VA("pc 64x128 DMA only", launch_s16_pc<64, 128, 64, 3, true, true, false, 5>),
-         VA("pc 64x128 DMA only + prefetch (all)", launch_s16_pc<64, 128, 64, 3, true, true, false, 5, 8>),
          VA("pc 64x128 reads only", launch_s16_pc<64, 128, 64, 3, true, true, false, 3>)});
   if (sel == 0 || sel == 3)
     run("TN (cfg2 weight gradient)", false, false, 2048, 2048, 1024,
         {V("ks128 128x128 ring4 (328)", launch_s16_ks128<false>),
          V("pc 128x128 KT32 NS4", launch_s16_pc<128, 128, 32, 4, false, false, false>),
-         V("pc 128x128 NS4 + prefetch (all)", launch_s16_pc<128, 128, 32, 4, false, false, false, 0, 8>),
-         V("pc 128x128 NS4 + prefetch (dedup)", launch_s16_pc<128, 128, 32, 4, false, false, false, 0, 16>),
          VA("pc 128x128 NS4 HOT", launch_s16_pc<128, 128, 32, 4, false, false, false, 0, 4>),
          VA("pc 128x128 NS4 no MFMA", launch_s16_pc<128, 128, 32, 4, false, false, false, 1>),
          VA("pc 128x128 NS4 no DMA", launch_s16_pc<128, 128, 32, 4, false, false, false, 2>),
@@ -118,8 +114,6 @@ int main(int argc, char **argv) {
     run("NT 4096^3", true, true, 4096, 4096, 4096,
         {V("glds 128x128 4w NS2 (311)", launch_s16<128, 128, 2, 2, 2, true, true>),
          V("pc 128x128 KT64 NS2", launch_s16_pc<128, 128, 64, 2, true, true, false>),
-         V("pc 128x128 NS2 + prefetch (all)", launch_s16_pc<128, 128, 64, 2, true, true, false, 0, 8>),
-         V("pc 64x128 NS3 + prefetch (all)", launch_s16_pc<64, 128, 64, 3, true, true, false, 0, 8>),
          VA("pc 128x128 NS2 HOT", launch_s16_pc<128, 128, 64, 2, true, true, false, 0, 4>),
          VA("pc 128x128 no MFMA", launch_s16_pc<128, 128, 64, 2, true, true, false, 1>),
          VA("pc 128x128 no DMA", launch_s16_pc<128, 128, 64, 2, true, true, false, 2>)});

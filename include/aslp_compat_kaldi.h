@@ -110,6 +110,17 @@ using ::aslp::PdfPrior;
 
 }  // namespace kaldi
 
+/* The reference's tools seed the C library generator (`std::srand(seed)`, aslp-nnetbin/aslp-nnet-init.cc:56) and its components draw from
+ * rand().  The engine draws from a private copy of that generator (nnet/base.h: inside a HIP process the global rand() state is not the
+ * caller's alone), so a caller's srand must seed both.  `srand` becomes a name that exists in the global namespace AND in std. */
+#include <cstdlib>
+inline void aslp_compat_srand(unsigned seed) {
+  (::srand)(seed);
+  ::aslp::SRand(seed);
+}
+namespace std { using ::aslp_compat_srand; }
+#define srand aslp_compat_srand
+
 #define KALDI_LOG ASLP_LOG
 #define KALDI_WARN ASLP_WARN
 #define KALDI_ERR ASLP_ERR

@@ -240,6 +240,11 @@ void aslp_absmax_parts(const float *src, MatrixDim d, float *parts);
  * rounding).  on = 1 / 0 switches it for this process, -1 hands the choice back to ASLP_GEMM_SPLIT_F16 (default on).  No reference
  * counterpart (cuBLAS sgemm on fp32 CUDA cores). */
 void aslp_gemm_split16(int on);
+/* Tile configuration of those products, by number (csrc/gemm_split16.hip: 304 / 308 / 311 one-role kernels, 351 = 128 x 128 with producer and
+ * consumer waves, 312 = 311 whatever ASLP_GEMM_S16_PC says, 328 = 128 x 128 with both operands reduction-major); 0 = the heuristic, -1 hands
+ * the choice back to ASLP_GEMM_SPLIT_F16_TILE.  A number the product's layout or epilogue does not admit falls back to the heuristic's
+ * choice.  Tests and devtools only: every configuration forms the same bits. */
+void aslp_gemm_split16_tile(int cfg);
 /* Prepared operands of such products: the two fp16 planes of an fp32 matrix, in the matrix' own layout (csrc/split16.h), made once and
  * read by every product the matrix takes part in (as op(A) or op(B), transposed or not).  aslp_planes_convert: one maximum pass and one
  * conversion pass over src [d.rows x d.cols] (cols and stride multiples of 4, 16-byte aligned).  The engine's components keep such

@@ -135,6 +135,7 @@ _sig("aslp_sgemm", _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _f, _vp, _i)
 _sig("aslp_sgemm_ex", _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _f, _vp, _i, C.POINTER(GemmEpilogue))
 _sig("aslp_sgemm_pair_ex", _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _i, C.POINTER(GemmEpilogue), C.POINTER(GemmEpilogue))
 _sig("aslp_gemm_split16", None, _i)
+_sig("aslp_gemm_split16_tile", None, _i)
 _sig("aslp_planes_new", _vp)
 _sig("aslp_planes_free", None, _vp)
 _sig("aslp_planes_convert", _i, _vp, _vp, _md)

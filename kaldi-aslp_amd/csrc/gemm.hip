@@ -961,6 +961,7 @@ int aslp_gemm_profile_tile(int variant, char *buf, int buflen) {
     case 304: d = "gemm_s16_glds 32x64x64 halves, 2 waves, v_mfma_f32_32x32x16_f16 x3 on two-piece fp32 operands, LDS-DMA, 3 stages"; break;
     case 308: d = "gemm_s16_glds 64x128x64 halves, 4 waves, v_mfma_f32_32x32x16_f16 x3 on two-piece fp32 operands, LDS-DMA, 3 stages"; break;
     case 311: d = "gemm_s16_glds 128x128x64 halves, 4 waves, v_mfma_f32_32x32x16_f16 x3 on two-piece fp32 operands, LDS-DMA, 2 stages"; break;
+    case 351: d = "gemm_s16_pc 128x128x64 halves, 4 consumer + 4 producer waves, v_mfma_f32_32x32x16_f16 x3 on two-piece fp32 operands, LDS-DMA, 2 stages"; break;
     case 328: d = "gemm_s16_ks128 128x128x32 halves, 4 waves, v_mfma_f32_32x32x16_f16 x3 on two-piece fp32 operands, transposing LDS reads, ring of 4"; break;
     default: d = "gemm_f32_mfma (devtools tile)"; break;
   }

@@ -33,7 +33,7 @@
 namespace aslp {
 namespace {
 
-thread_local int t_last_cfg_s16 = 0;   // tile the calling thread's latest split-fp16 product ran on: 311 = 128x128, 308 = 64x128, 328 = 128x128 both operands reduction-major
+thread_local int t_last_cfg_s16 = 0;   // tile the calling thread's latest split-fp16 product ran on: 311 = 128x128, 351 = the same with producer / consumer waves, 308 = 64x128, 328 = 128x128 both operands reduction-major
 thread_local int t_last_parts = 0;   // per-wave maxima the calling thread's latest product left (aslp_gemm_last_parts)
 constexpr int BKH = 64;       // halves per K tile
 constexpr int KH = BKH / 16;  // instruction k steps per tile
@@ -689,6 +689,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
   s16_finish<TM, TN, NW, EXTRA, true>(g, va, vb, acc, accx, asum, do_colsum, w_bound, m0 + wm * 64, n0 + wn * 64, lane, wave, lds);
 }
 
+// One scalar load whose result is never read (it pulls a line into the L2 over the scalar cache's path).  The result lands in s100 whenever
+// the line arrives; the kernels that use this are checked to need far fewer scalar registers than that (kernel-resource-usage), so nothing
+// of the compiler's ever lives there.  (An output operand would be a register the compiler re-uses right behind the statement.)
+__device__ __forceinline__ void s16_scalar_touch(unsigned long long addr) {
+  asm volatile("s_load_dword s100, %0, 0x0" ::"s"(addr) : "s100");
+}
+
 // ---- producer / consumer waves (round 6) -------------------------------------------------------------------------------------------
 // The kernels above run one wave per SIMD that does everything: it issues the K tile's LDS-DMA requests, the fragment reads and the
 // matrix instructions from ONE in-order instruction stream.  The counters (profiles/r06_gemm_split16_pmc_*.txt) say what that costs:
@@ -779,7 +786,6 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     // (OPT & 8 / 16, experiment) scalar loads that pull the 128-byte lines of a LATER K tile into this XCD's L2 -- over the scalar cache's
     // path, not the texture path the LDS-DMA requests are bound by; their results are never read
     constexpr int PD = 2;   // tiles ahead of the tile being requested
-    unsigned pf_sink = 0;
     auto pf_tile = [&](int r) {
       if constexpr (!(OPT & 24)) return;
       if (r >= ktiles) return;
@@ -816,9 +822,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
           const unsigned long long a = reinterpret_cast<unsigned long long>(p);
           const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)a), hi32 = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
           const unsigned long long au = ((unsigned long long)hi32 << 32) | lo32;
-          // (the load's result lands in its register whenever the line arrives: the register is one the compiler holds for `pf_sink` from
-          //  before the K loop until behind the final lgkmcnt(0), so nothing else lives there when it does)
-          asm volatile("s_load_dword %0, %1, 0x0" : "+s"(pf_sink) : "s"(au));
+          s16_scalar_touch(au);
         });
       });
     };
@@ -850,7 +854,6 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     wait_vmcnt<0>();                 // (the surplus requests write into the LDS the epilogue is about to use)
     if constexpr ((OPT & 24) != 0) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      asm volatile("" ::"s"(pf_sink));
     }
     __builtin_amdgcn_s_barrier();
     return;
@@ -1061,13 +1064,19 @@ bool launch_s16_layout(GemmArgs &g, const S16Operands &ops, int cfg) {
   // 64 x 128 tile's, a 128 x 128 round counted as two: level at 2048^3 ... 8192 x 2048 x 2048 (57.8 / 222.3 against 57.4 / 220.8 us from
   // prepared planes), 1 % ahead at 4096^3, and inside the LC-BLSTM step, whose layer products come as pairs of 1920 x 2048 (480 against 960
   // workgroups), worth 2.87 against 2.93-3.05 ms; not where it leaves a ragged last round (1920 x 3000 x 1024: 58.1 against 48.5 us)
-  if (cfg != 304 && cfg != 305 && (cfg == 0 || !(A_KC && B_KC) || extra)) {
+  if (cfg != 304 && cfg != 305 && (cfg == 0 || !(A_KC && B_KC) || extra)) {   // (311 / 312 / 351 asked for by number stand when the product is KC / KC without extras)
     const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * (g.pair ? 2 : 1), t64 = (long)((g.M + 63) / 64) * ((g.N + 127) / 128) * (g.pair ? 2 : 1);
     static const int any128 = [] { const char *e = getenv("ASLP_GEMM_S16_128_ANY"); return e ? atoi(e) : 0; }();   // (tuning aid: 1 = every grid of >= 224 tiles, 2 = never)
     cfg = (!extra && A_KC && B_KC && t128 >= 224 && any128 != 2 && (any128 == 1 || 2 * ((t128 + 255) / 256) <= (t64 + 255) / 256)) ? 311 : 308;
   }
+  // the producer / consumer kernel (gemm_s16_pc) where the 128 x 128 tile was chosen: 4096^3 383 against 422 us, same bits (devtools/micro/s16_pc.hip,
+  // profiles/r06_gemm_s16_pc_micro.txt); ASLP_GEMM_S16_PC=0 keeps the one-role kernel (A/B switch)
+  static const int pc_on = [] { const char *e = getenv("ASLP_GEMM_S16_PC"); return e ? atoi(e) : 1; }();
+  if (cfg == 311 && pc_on && A_KC && B_KC && g.split_k <= 1) cfg = 351;
   switch (cfg) {
     case 311: if constexpr (A_KC && B_KC) launch_s16<128, 128, 2, 2, 2, true, true>(g, ops); break;
+    case 312: if constexpr (A_KC && B_KC) launch_s16<128, 128, 2, 2, 2, true, true>(g, ops); cfg = 311; break;   // (forced: the one-role kernel whatever the switch says)
+    case 351: if constexpr (A_KC && B_KC) launch_s16_pc<128, 128, 64, 2, true, true, false>(g, ops); break;
     case 304:   // 32 x 64, two waves: 256 workgroups for a 256 x 2048 output with the whole reduction in one launch
       if (extra) launch_s16<32, 64, 1, 2, 3, A_KC, B_KC, 0, true>(g, ops);
       else launch_s16<32, 64, 1, 2, 3, A_KC, B_KC>(g, ops);
@@ -1086,6 +1095,7 @@ bool launch_s16_layout(GemmArgs &g, const S16Operands &ops, int cfg) {
 }
 
 int g_split16_override = -1;   // aslp_gemm_split16(): -1 = the environment decides
+int g_split16_tile_override = -1;   // aslp_gemm_split16_tile(): -1 = ASLP_GEMM_SPLIT_F16_TILE / the heuristic
 
 }  // namespace
 
@@ -1329,6 +1339,7 @@ bool gemm_split16_planes_launch(GemmArgs &g, bool a_kc, bool b_kc, const S16View
 // conversion in front of the product.
 bool gemm_split16_launch(GemmArgs &g, bool a_kc, bool b_kc, int cfg, const S16View *pa, const S16View *pb) {
   if (g.pair || g.split_k > 1) return false;
+  if (g_split16_tile_override >= 0) cfg = g_split16_tile_override;
   if (!gemm_split16_serves(g.M, g.N, g.K)) return false;
   if ((!pa && !(g.A && g.a_vec)) || (!pb && !(g.B && g.b_vec))) return false;
   if (pa && pb) return gemm_split16_planes_launch(g, a_kc, b_kc, *pa, *pb, nullptr, nullptr, cfg);
@@ -1388,6 +1399,7 @@ void aslp_params_changed(void) {
   aslp::g_param_epoch.fetch_add(1, std::memory_order_relaxed);
 }
 void aslp_gemm_split16(int on) { aslp::g_split16_override = on < 0 ? -1 : (on != 0); }
+void aslp_gemm_split16_tile(int cfg) { aslp::g_split16_tile_override = cfg < 0 ? -1 : cfg; }
 int aslp_gemm_last_parts(void) { return aslp::gemm_split16_last_parts(); }
 void aslp_weight_bound(const float *w_parts, int n_w, const float *c_parts, int n_c, const aslp_planes *a, const aslp_planes *b, int K, float alpha,
                        float beta, float w_alpha, float clip, aslp_planes *w_planes) {

@@ -7,13 +7,14 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
-SPLIT_TILES = (304, 308, 311, 328)   # gemm_s16_glds 32x64 / 64x128 / 128x128, gemm_s16_ks128 (csrc/gemm_split16.hip)
+SPLIT_TILES = (304, 308, 311, 328, 351)   # gemm_s16_glds 32x64 / 64x128 / 128x128, gemm_s16_ks128, gemm_s16_pc 128x128 (csrc/gemm_split16.hip)
 
 
 @pytest.fixture(autouse=True)
 def split_off_afterwards(aslp):
     yield
     aslp.lib.aslp_gemm_split16(-1)
+    aslp.lib.aslp_gemm_split16_tile(-1)
 
 
 def products(aslp, tA, tB, A, B, alpha=1.0, beta=0.0, C0=None, ep=None):
@@ -268,3 +269,45 @@ def test_weights_written_through_the_raw_pointers(aslp, dev, announce):
     finally:
         aslp.lib.aslp_gemm_split16(-1)
         aslp.lib.aslp_keep_weight_planes(-1)
+
+
+@pytest.mark.parametrize("M,N,K", [(2048, 2048, 2048), (1920, 2048, 512), (4096, 4096, 1024), (2000, 2176, 1000)])
+def test_producer_consumer_kernel_forms_the_same_bits(aslp, dev, M, N, K):
+    """gemm_s16_pc (tile 351: four consumer waves multiply, four producer waves issue the LDS-DMA requests; the default wherever the
+    128 x 128 tile is chosen) against the one-role kernels: same instruction order per accumulator, so the results are bit-identical --
+    to the 128 x 128 one-role kernel (312) and to the 64 x 128 one (308) -- whole tiles, a ragged last tile row / column, K not a multiple
+    of the K tile; repeated launches agree bit for bit (the producers' surplus requests never reach the epilogue's LDS)."""
+    g = torch.Generator(device=dev).manual_seed(M + N + K)
+    A = torch.randn(M, K, device=dev, generator=g)
+    B = torch.randn(N, K, device=dev, generator=g)
+    A[5] *= 1e-5
+    outs = {}
+    aslp.lib.aslp_gemm_split16(1)
+    for tile in (351, 312, 308):
+        aslp.lib.aslp_gemm_split16_tile(tile)
+        C = torch.full((M, N), 7.0, device=dev)
+        aslp.ops.sgemm(0, 1, 1.0, A, B, 0.0, C)
+        assert aslp.lib.aslp_gemm_last_tile() == (311 if tile == 312 else tile)
+        outs[tile] = C
+    assert torch.equal(outs[351], outs[312]) and torch.equal(outs[351], outs[308])
+    assert err_vs_double(outs[351], A, B, 0, 1) < 2.5e-7
+    aslp.lib.aslp_gemm_split16_tile(351)
+    for _ in range(5):
+        C = torch.empty(M, N, device=dev)
+        aslp.ops.sgemm(0, 1, 1.0, A, B, 0.0, C)
+        assert torch.equal(C, outs[351])
+    # with beta and a bias (the plain epilogue's other inputs)
+    bias = torch.randn(N, device=dev, generator=g)
+    res = []
+    for tile in (351, 312):
+        aslp.lib.aslp_gemm_split16_tile(tile)
+        C = outs[308].clone()
+        aslp.ops.sgemm(0, 1, 0.5, A, B, 0.25, C, aslp._lib.GemmEpilogue(bias.data_ptr()))
+        res.append(C)
+    assert torch.equal(res[0], res[1])
+    # the heuristic picks it by itself on a grid of >= 224 tiles of 128 x 128
+    aslp.lib.aslp_gemm_split16_tile(-1)
+    if M * N >= 224 * 128 * 128 and M % 128 == 0 and N % 128 == 0:
+        C = torch.empty(M, N, device=dev)
+        aslp.ops.sgemm(0, 1, 1.0, A, B, 0.0, C)
+        assert aslp.lib.aslp_gemm_last_tile() in (351, 308)

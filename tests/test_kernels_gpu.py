@@ -787,3 +787,99 @@ def test_sgemm_beta_term_from_another_matrix(aslp, dev, tA, tB, M, N, K, force):
     assert torch.equal(got, want)
     ref = 0.5 * ((A.t() if tA else A).double() @ (B.t() if tB else B).double()) + 0.75 * src.double()
     assert ((got.double() - ref).norm() / ref.norm()).item() < 2e-6
+
+
+def test_grid_wide_kernels_stand_down_beside_a_thread_of_persistent_recurrences(aslp, dev):
+    """a host thread that only ever launches persistent recurrences (GruStreams here) never came through the cooperative
+    kernels' own registration, so another thread's grid-wide launch could sit half placed beside its persistent grid.  The launchers of
+    the recurrences now register in the same count: while that thread lives the grid-wide launches of THIS thread are not used; DNN +
+    BatchNormalization steps on this thread and GRU steps on the other, side by side, finish without a hand-off time-out and give the bits
+    of the same steps run alone."""
+    import threading
+    _lib = aslp._lib
+    ptr, dim, lib = aslp.ops.ptr, aslp.ops.dim, aslp.ops.lib
+    x = torch.randn(512, 256, device=dev)
+    S, T, H, A = 8, 12, 128, 16
+    gru_proto = ("<NnetProto>\n<GruStreams> <InputDim> %d <OutputDim> %d <ParamScale> 0.1 <ClipGradient> 5.0\n"
+                 "<AffineTransform> <InputDim> %d <OutputDim> %d <BiasMean> 0.0 <BiasRange> 0.0 <ParamStddev> 0.1\n<Softmax> <InputDim> %d <OutputDim> %d\n</NnetProto>\n"
+                 % (H, H, H, A, A, A))
+    dnn_proto = ("<NnetProto>\n<AffineTransform> <InputDim> 256 <OutputDim> 512 <BiasMean> -2.0 <BiasRange> 4.0 <ParamStddev> 0.1\n"
+                 "<BatchNormalization> <InputDim> 512 <OutputDim> 512\n<Sigmoid> <InputDim> 512 <OutputDim> 512\n"
+                 "<AffineTransform> <InputDim> 512 <OutputDim> 64 <BiasMean> 0.0 <BiasRange> 0.0 <ParamStddev> 0.1\n<Softmax> <InputDim> 64 <OutputDim> 64\n</NnetProto>\n")
+    g = torch.Generator(device=dev).manual_seed(9)
+    xg = torch.randn(T * S, H, device=dev, generator=g)
+    lg = torch.randint(0, A, (T * S,), device=dev, generator=g, dtype=torch.int32)
+    ld = torch.randint(0, 64, (512,), device=dev, generator=g, dtype=torch.int32)
+    torch.cuda.synchronize()
+
+    def convert():
+        planes = C.c_void_p(lib.aslp_planes_new())
+        lib.aslp_planes_reserve(planes, 512, 256)
+        po = _lib.PlanesOut()
+        lib.aslp_planes_as_output(planes, C.byref(po))
+        rc = lib.aslp_copy_mat_planes(None, dim(x), ptr(x), dim(x).stride, C.byref(po))
+        aslp.ops.check_error()
+        torch.cuda.synchronize()
+        lib.aslp_planes_free(planes)
+        return rc
+
+    # (nets are made one after the other on this thread: Nnet::Init draws from the process-wide generator, as the reference's does from rand())
+    def gru_net():
+        net = aslp.Nnet.Init(gru_proto, seed=3)
+        net.SetTrainOptions(learn_rate=1e-3, momentum=0.0)
+        net.SetSeqLengths([T] * S)
+        return net
+
+    def dnn_net():
+        net = aslp.Nnet.Init(dnn_proto, seed=4)
+        net.SetTrainOptions(learn_rate=1e-3, momentum=0.0)
+        return net
+
+    def gru_steps(net, n):
+        xe = aslp.Xent()
+        for i in range(n):
+            net.ResetLstmStreams([1] * S)
+            net.TrainStepXent(xe, xg, lg)
+        torch.cuda.synchronize()
+        return net.GetParams()
+
+    def dnn_steps(net, n):
+        xe = aslp.Xent()
+        for i in range(n):
+            net.TrainStepXent(xe, x, ld)
+        torch.cuda.synchronize()
+        return net.GetParams()
+
+    n = 40
+    ref_dnn = dnn_steps(dnn_net(), n)          # alone (this thread may use the grid-wide launches)
+    ref_gru = gru_steps(gru_net(), n)
+    assert convert() == 1
+    nets = {"g1": gru_net(), "g": gru_net(), "d": dnn_net()}
+    out, go, done, errs = {}, threading.Event(), threading.Event(), []
+
+    def other():
+        try:
+            aslp.ops.use_torch_stream()
+            gru_steps(nets["g1"], 1)            # this thread's first persistent launch: two grid-wide launchers from here on
+            go.set()
+            done.wait(120)
+            out["gru"] = gru_steps(nets["g"], n)
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+            go.set()
+
+    t = threading.Thread(target=other)
+    t.start()
+    assert go.wait(120) and not errs, errs
+    try:
+        assert convert() == 0                       # stands down although the other thread never launched a cooperative kernel
+    finally:
+        done.set()
+    beside = dnn_steps(nets["d"], n)                # ... while the other thread runs its recurrences
+    t.join()
+    assert not errs, errs
+    aslp.ops.check_error()                          # no hand-off time-out anywhere
+    # beside the other thread the multi-launch paths run: they form the same values from the same maxima -- the same bits
+    assert np.array_equal(beside, ref_dnn)
+    assert np.array_equal(out["gru"], ref_gru)
+    assert convert() == 1                           # the thread has ended: grid-wide launches are back

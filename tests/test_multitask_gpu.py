@@ -120,8 +120,8 @@ def test_train_simple_multitask_matches_oracle(aslp, oracle, dev, tmp_path):
     # a malformed description: the reference asserts on triplets (nnet-loss.cc:300)
     p = tool("aslp-nnet-train-simple", "--objective-function=multitask,xent,%d" % D1, "ark:%s" % (tmp_path / "f.ark"), "ark:%s" % (tmp_path / "p.ark"),
              str(tmp_path / "m.nnet"), str(tmp_path / "x.out"), ok=False)
-    assert p.returncode != 0
+    assert p.returncode != 0 and b"Assertion failed" in p.stderr
     # a sum of task widths that is not the network's output width (nnet-loss.cc:348)
-    p = tool("aslp-nnet-train-simple", "--objective-function=multitask,xent,%d,1.0,mse,%d,1.0" % (D1, D2 + 1), "ark:%s" % (tmp_path / "f.ark"),
+    p = tool("aslp-nnet-train-simple", "--objective-function=multitask,xent,%d,1.0,mse,%d,1.0" % (D1, D2 + 1), "--minibatch-size=%d" % mb, "ark:%s" % (tmp_path / "f.ark"),
              "ark:%s" % (tmp_path / "p.ark"), str(tmp_path / "m.nnet"), str(tmp_path / "x.out"), ok=False)
-    assert p.returncode != 0
+    assert p.returncode != 0 and b"Assertion failed" in p.stderr
