@@ -808,19 +808,24 @@ def launch_ranks(args):
         procs.append(subprocess.Popen(argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     out0 = b""
     rc = 0
+    import threading
+    got = {}
+    reader = threading.Thread(target=lambda: got.setdefault("out", procs[0].stdout.read()), daemon=True)   # rank 0 prints the line; it ends after the last collective
+    reader.start()
+    t_end = time.time() + args.launch_timeout
     try:
-        try:
-            out0 = procs[0].communicate(timeout=args.launch_timeout)[0]      # rank 0 prints the line; it ends after the last collective
-        except subprocess.TimeoutExpired:
-            procs[0].kill()
-            out0 = procs[0].communicate()[0]
-            rc = 124
-        deadline = time.time() + 120.0
-        for p in procs:
-            try:
-                p.wait(timeout=max(1.0, deadline - time.time()))
-            except subprocess.TimeoutExpired:
-                pass
+        while True:
+            codes = [p.poll() for p in procs]
+            if all(c is not None for c in codes):
+                break
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad:                              # a rank has failed (e.g. its communicator did not come up): the others would wait for it in a
+                rc = bad[0]                      # collective until their own time-outs -- end them now, with the failing rank's status
+                break
+            if time.time() > t_end:
+                rc = 124
+                break
+            time.sleep(0.1)
     finally:
         for p in procs:                        # exactly the processes started here, never a pattern
             if p.poll() is None:
@@ -829,6 +834,8 @@ def launch_ranks(args):
                 rc = rc or 124
         for p in procs:
             rc = rc or (p.returncode or 0)
+        reader.join(timeout=10.0)
+        out0 = got.get("out", b"") or b""
         for f in (comm_file, comm_file + ".ctl"):
             try:
                 os.unlink(f)
@@ -837,6 +844,15 @@ def launch_ranks(args):
     sys.stdout.write(out0.decode(errors="replace"))
     sys.stdout.flush()
     return rc
+
+
+def comm_failed(rank, world, err):
+    """A rank whose communicator does not come up ends the run: one line on stderr with the transport's own error string, exit status 4.
+    Nothing is retried and nothing is re-executed -- the launcher (bench.py's own, or torch.distributed.run) sees the status, ends the other
+    ranks and returns non-zero; a bench line is never printed for a job that did not have all its ranks."""
+    sys.stderr.write("bench.py: rank %d of %d: communicator did not come up: %s\n" % (rank, world, err))
+    sys.stderr.flush()
+    os._exit(4)
 
 
 def main():
@@ -872,6 +888,9 @@ def main():
     if args.dry_run_ranks:
         if os.environ.get("ASLP_BENCH_DRYRUN_FAIL_RANK") == str(rank):
             raise SystemExit(3)
+        if os.environ.get("ASLP_BENCH_DRYRUN_COMM_ERROR") and os.environ.get("ASLP_BENCH_DRYRUN_COMM_ERROR_RANK", "0") == str(rank):
+            # (launcher test: the path a failed ncclCommInitRank takes, without a GPU)
+            comm_failed(rank, world, RuntimeError(os.environ["ASLP_BENCH_DRYRUN_COMM_ERROR"]))
         if rank == 0:
             print(json.dumps({"n_gpus": world, "dry_run": True, "comm_file": os.environ.get("ASLP_COMM_FILE"), "token": os.environ.get("ASLP_COMM_TOKEN")}))
         return
@@ -901,7 +920,13 @@ def main():
             import tempfile
             token = "%s-%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid())
             comm_file = os.path.join(tempfile.gettempdir(), "aslp_bench_comm_" + token)
-        comm = native_parallel.ProcessComm(comm_file, rank=rank, num_nodes=world, token=token, timeout_s=900)   # RcclComm unless ASLP_COMM_TRANSPORT=shm
+        try:
+            comm = native_parallel.ProcessComm(comm_file, rank=rank, num_nodes=world, token=token, timeout_s=900)   # RcclComm unless ASLP_COMM_TRANSPORT=shm
+        except Exception as e:   # noqa: BLE001 -- ncclGetUniqueId / ncclCommInitRank failed or timed out (the native message carries RCCL's own error string)
+            comm_failed(rank, world, e)
+        seen = comm.RanksSeen()
+        if seen != world:
+            comm_failed(rank, world, RuntimeError("the communicator counts %d ranks (ncclCommCount / joined segment), the launcher started %d" % (seen, world)))
 
     import aslp_import
     aslp = aslp_import.load()   # raises if libaslp_hip.so is missing (no fallback)
@@ -1026,6 +1051,8 @@ def main():
                        "sync_period_frames": args.sync_period, "comm": _comm_facts(comm) if comm is not None else None,
                        "learn_rate": CFG2_LEARN_RATE, "avg_xent_per_frame": (st["loss"] - st["entropy"]) / max(st["frames"], 1.0)},
         }
+        if comm is not None:
+            out["comm"] = _comm_facts(comm)   # (also under config.comm): transport and the number of ranks the transport itself counts
         if windows:
             ws = sorted([value] + windows)
             out["windows"] = {"steps_each": args.steps, "count": len(ws), "min": ws[0], "median": ws[len(ws) // 2], "max": ws[-1],

@@ -36,3 +36,23 @@ def test_launcher_environment_is_respected():
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-ranks"], env=env, stdout=subprocess.PIPE, timeout=60)
     assert p.returncode == 0 and json.loads(p.stdout.decode())["n_gpus"] == 2
+
+
+def test_eight_ranks_the_drivers_scale_run():
+    """N = 8 (the SCALE run's largest): eight children, one line, every child's status collected"""
+    p = run(8)
+    assert p.returncode == 0, p.stderr.decode()
+    d = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    assert d["n_gpus"] == 8 and d["dry_run"]
+
+
+def test_a_communicator_that_does_not_come_up_ends_the_run_with_its_error_string():
+    """what a failed ncclCommInitRank does to `bench.py --gpus 8`: the rank says so on stderr with the transport's error string and exits 4,
+    the launcher returns non-zero and prints no bench line -- no retry, no re-exec"""
+    msg = "ncclCommInitRank: unhandled system error (simulated)"
+    p = run(8, {"ASLP_BENCH_DRYRUN_COMM_ERROR": msg, "ASLP_BENCH_DRYRUN_COMM_ERROR_RANK": "5"})
+    assert p.returncode == 4
+    assert ("rank 5 of 8: communicator did not come up: " + msg) in p.stderr.decode()
+    # rank 0 failing: no line on stdout at all
+    p = run(8, {"ASLP_BENCH_DRYRUN_COMM_ERROR": msg, "ASLP_BENCH_DRYRUN_COMM_ERROR_RANK": "0"})
+    assert p.returncode == 4 and p.stdout.decode().strip() == ""

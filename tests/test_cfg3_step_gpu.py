@@ -24,9 +24,21 @@ TOL = 1e-4
 
 
 def test_cfg3_lcblstm_warpctc_two_steps_match_oracle_chain(aslp, oracle, dev, tmp_path):
-    D, Cc, R, A, T, S, NL = 40, 512, 256, 128, 60, 32, 4
+    lcblstm_warpctc_steps_against_oracle(aslp, oracle, dev, tmp_path, T=60, NL=4, steps=2, seed=33)
+
+
+def test_cfg3_whole_utterances_of_400_frames_match_oracle_chain(aslp, oracle, dev, tmp_path):
+    """the whole-utterance Warp-CTC step (bench.py `whole_utterance_warpctc`, T <= 800) was checked against the oracle
+    at T = 60 only.  Here T = 400 (ragged 200 ... 400, L = T / 4 labels), S = 32 streams at the BASELINE widths, on ONE
+    BLstmProjectedStreamsLC layer + AffineTransform + WarpCtc so that the CPU chain stays at seconds: 400 dependent timesteps in either
+    direction of time through the persistent recurrences, the 12800-row layer products from planes, the lattice kernels at T = 400."""
+    lcblstm_warpctc_steps_against_oracle(aslp, oracle, dev, tmp_path, T=400, NL=1, steps=1, seed=47)
+
+
+def lcblstm_warpctc_steps_against_oracle(aslp, oracle, dev, tmp_path, T, NL, steps, seed):
+    D, Cc, R, A, S = 40, 512, 256, 128, 32
     clip, lr, mmt = 5.0, 1e-3, 0.9   # (at 1e-4 the applied gradient, read back as (W_before - W_after) / lr, drowns in the weights' fp32 rounding)
-    rng = np.random.default_rng(33)
+    rng = np.random.default_rng(seed)
     layers, params, grads = [], [], []
     d = D
     for l in range(NL):
@@ -51,7 +63,7 @@ def test_cfg3_lcblstm_warpctc_two_steps_match_oracle_chain(aslp, oracle, dev, tm
         return np.concatenate([p.flat() for dirs in params for p in dirs] + [W.ravel(), b])
 
     assert oracle.rel_err(net.GetParams(), flat()) == 0.0
-    for step in range(2):
+    for step in range(steps):
         in_len = rng.integers(T // 2, T + 1, S).astype(np.int32)
         in_len[0] = T
         labels = [[int(v) for v in rng.integers(1, A, max(1, int(t) // 4))] for t in in_len]
@@ -103,7 +115,7 @@ def test_cfg3_lcblstm_warpctc_two_steps_match_oracle_chain(aslp, oracle, dev, tm
                 off += n
         stt = ctc.GetStats()
         assert abs(stt["obj"] - st.obj) <= 1e-4 * abs(st.obj), step
-    assert ctc.GetStats()["sequences"] == 2 * S
+    assert ctc.GetStats()["sequences"] == steps * S
 
 
 def test_cfg3_chunked_three_chunks_with_mixed_stream_resets(aslp, oracle, dev, tmp_path):

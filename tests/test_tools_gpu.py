@@ -3,6 +3,7 @@ in Kaldi formats in, model / posterior tables out.  Every result is compared wit
 through the engine's API on the same data order (bit-identical: the tools add I/O, not arithmetic) and (b) the CPU oracle
 stepping through the same minibatches (1e-4)."""
 import os
+import re
 import subprocess
 
 import numpy as np
@@ -1069,3 +1070,97 @@ def test_reference_mains_compiled_unchanged_run_on_this_engine(aslp, oracle, dev
     pc = ref_tool("aslp-nnet-train-frame", "--cross-validate=true", "--minibatch-size=%d" % mb, "ark:%s" % (tmp_path / "feats.ark"),
                   "ark:%s" % (tmp_path / "post.ark"), str(tmp_path / "ref.nnet"))
     assert b"CROSS-VALIDATION STARTED" in pc.stderr and b"AvgLoss:" in pc.stderr
+
+
+def test_train_frame_mimo_shared_trunk_matches_oracle(aslp, oracle, dev, tmp_path):
+    """aslp-nnet-train-frame-mimo (aslp-nnetbin/aslp-nnet-train-frame-mimo.cc) on a graph whose two inputs meet in a SHARED trunk and part
+    again into two heads: in0 -> Affine -> Sigmoid \\
+                                                      (concatenated by column offsets) -> Affine -> Sigmoid -> {Affine -> Softmax -> out0,
+                          in1 -> Affine -> Sigmoid /                                                            Affine -> Softmax -> out1}
+    The trunk's out-diff is the SUM of the two heads' in-diffs (nnet-nnet.cc:133-144), its in-diff is cut at the column offsets back to the
+    two branches (:86-95).  Against the oracle's AffineTransform / Sigmoid / Softmax / Xent chain over the same shuffled minibatches: the
+    trained parameters, the gradient applied to every tensor, both losses' reports."""
+    rng = np.random.default_rng(23)
+    d0, d1, h0, h1, ht, a0, a1, mb = 10, 14, 24, 16, 32, 7, 5, 16
+    mk = lambda o, i, s=0.3: (rng.standard_normal((o, i)).astype(np.float32) * s, rng.standard_normal(o).astype(np.float32) * 0.1)
+    P = {"b0": mk(h0, d0), "b1": mk(h1, d1), "t": mk(ht, h0 + h1), "o0": mk(a0, ht), "o1": mk(a1, ht)}
+    comps = [
+        dict(marker="<InputLayer>", dim_in=d0, dim_out=d0, id=0, inputs=[-1], offsets=[0]),
+        dict(marker="<InputLayer>", dim_in=d1, dim_out=d1, id=1, inputs=[-1], offsets=[0]),
+        dict(marker="<AffineTransform>", dim_in=d0, dim_out=h0, id=2, inputs=[0], offsets=[0], data=nnet_io.affine(*P["b0"])),
+        dict(marker="<Sigmoid>", dim_in=h0, dim_out=h0, id=3, inputs=[2], offsets=[0]),
+        dict(marker="<AffineTransform>", dim_in=d1, dim_out=h1, id=4, inputs=[1], offsets=[0], data=nnet_io.affine(*P["b1"])),
+        dict(marker="<Sigmoid>", dim_in=h1, dim_out=h1, id=5, inputs=[4], offsets=[0]),
+        dict(marker="<AffineTransform>", dim_in=h0 + h1, dim_out=ht, id=6, inputs=[3, 5], offsets=[0, h0], data=nnet_io.affine(*P["t"])),   # the shared trunk
+        dict(marker="<Sigmoid>", dim_in=ht, dim_out=ht, id=7, inputs=[6], offsets=[0]),
+        dict(marker="<AffineTransform>", dim_in=ht, dim_out=a0, id=8, inputs=[7], offsets=[0], data=nnet_io.affine(*P["o0"])),
+        dict(marker="<Softmax>", dim_in=a0, dim_out=a0, id=9, inputs=[8], offsets=[0]),
+        dict(marker="<OutputLayer>", dim_in=a0, dim_out=a0, id=10, inputs=[9], offsets=[0]),
+        dict(marker="<AffineTransform>", dim_in=ht, dim_out=a1, id=11, inputs=[7], offsets=[0], data=nnet_io.affine(*P["o1"])),
+        dict(marker="<Softmax>", dim_in=a1, dim_out=a1, id=12, inputs=[11], offsets=[0]),
+        dict(marker="<OutputLayer>", dim_in=a1, dim_out=a1, id=13, inputs=[12], offsets=[0]),
+    ]
+    nnet_io.write_graph_nnet(tmp_path / "trunk.nnet", comps)
+    keys = ["t%02d" % i for i in range(10)]
+    lens = [int(x) for x in rng.integers(15, 50, len(keys))]
+    feats = [[rng.standard_normal((n, d)).astype(np.float32) for n in lens] for d in (d0, d1)]
+    posts = [[[[(int(rng.integers(0, a)), 1.0)] for _ in range(n)] for n in lens] for a in (a0, a1)]
+    for b in range(2):
+        (tmp_path / ("f%d.ark" % b)).write_bytes(kf.archive([(k, kf.matrix_bin(f)) for k, f in zip(keys, feats[b])]))
+        (tmp_path / ("p%d.ark" % b)).write_bytes(kf.archive([(k, kf.posterior_bin(p)) for k, p in zip(keys, posts[b])]))
+    lr, mom, seed, rsize = 0.02, 0.5, 5, 120
+    p = tool("aslp-nnet-train-frame-mimo", "--learn-rate=%g" % lr, "--momentum=%g" % mom, "--minibatch-size=%d" % mb, "--randomizer-size=%d" % rsize,
+             "--randomizer-seed=%d" % seed, "--objective-function=xent:xent", "ark:%s" % (tmp_path / "f0.ark"), "ark:%s" % (tmp_path / "f1.ark"),
+             "ark:%s" % (tmp_path / "p0.ark"), "ark:%s" % (tmp_path / "p1.ark"), str(tmp_path / "trunk.nnet"), str(tmp_path / "trunk.out"))
+    err = p.stderr.decode()
+    assert "Nnet num_input 2 num_output 2" in err and err.count("FRAME_ACCURACY") == 2
+
+    # the oracle chain; one shuffle mask per cache fill serves all four streams, so the two inputs' minibatches are drawn by the same mask
+    A = {k: oracle.Affine(*v) for k, v in P.items()}
+    order = ["b0", "b1", "t", "o0", "o1"]   # GetGpuParams / file order (component ids 2, 4, 6, 8, 11)
+    st = [dict(frames=0.0, correct=0.0, loss=0.0, entropy=0.0), dict(frames=0.0, correct=0.0, loss=0.0, entropy=0.0)]
+    # (one generator over the column-wise concatenation of the two inputs with paired targets: the mask sequence is drawn once per fill)
+    cat_feats = [np.concatenate([f0, f1], axis=1) for f0, f1 in zip(feats[0], feats[1])]
+    cat_posts = [list(zip(q0, q1)) for q0, q1 in zip(posts[0], posts[1])]
+    both = (((np.ascontiguousarray(x[:, :d0]), [q[0] for q in t], None), (np.ascontiguousarray(x[:, d0:]), [q[1] for q in t], None))
+            for x, t, _ in minibatches(aslp, cat_feats, cat_posts, mb, seed, rsize))
+    sig = lambda v: oracle.unary("orc_sigmoid", v)
+    dsig = lambda y, e: oracle.binary("orc_diff_sigmoid", y, e)
+    n_mb = 0
+    for (x0, t0, _), (x1, t1, _) in both:
+        s0, s1 = sig(A["b0"].propagate(x0)), sig(A["b1"].propagate(x1))
+        cat = np.concatenate([s0, s1], axis=1)
+        tr = sig(A["t"].propagate(cat))
+        diffs = []
+        for k, (head, t, a) in enumerate((("o0", t0, a0), ("o1", t1, a1))):
+            y = oracle.unary("orc_softmax_rows", A[head].propagate(tr))
+            tgt = np.zeros((mb, a), np.float32)
+            tgt[np.arange(mb), [fr[0][0] for fr in t]] = 1.0
+            diff, s = oracle.xent_eval(np.ones(mb, np.float32), y, tgt)
+            for key in st[k]:
+                st[k][key] += s[key]
+            diffs.append(diff)
+        d_tr = A["o0"].backpropagate(diffs[0]) + A["o1"].backpropagate(diffs[1])   # link by add
+        A["o0"].update(tr, diffs[0], lr, mom)
+        A["o1"].update(tr, diffs[1], lr, mom)
+        d_t = dsig(tr, d_tr)
+        d_cat = A["t"].backpropagate(d_t)
+        A["t"].update(cat, d_t, lr, mom)
+        e0, e1 = dsig(s0, np.ascontiguousarray(d_cat[:, :h0])), dsig(s1, np.ascontiguousarray(d_cat[:, h0:]))
+        A["b0"].update(x0, e0, lr, mom)
+        A["b1"].update(x1, e1, lr, mom)
+        n_mb += 1
+    assert n_mb >= 10
+    got = aslp.Nnet.Read(tmp_path / "trunk.out").GetParams()
+    want = np.concatenate([np.concatenate([A[k].W.ravel(), A[k].b]) for k in order])
+    init = np.concatenate([np.concatenate([P[k][0].ravel(), P[k][1]]) for k in order])
+    assert got.shape == want.shape and oracle.rel_err(got, want) < TOL
+    off = 0
+    for k in order:   # what the run moved each tensor by (a shared-trunk error would sit in "t", "b0", "b1" only)
+        n = P[k][0].size + P[k][1].size
+        assert oracle.rel_err(got[off:off + n] - init[off:off + n], want[off:off + n] - init[off:off + n]) < 3e-4, k
+        off += n
+    # both reports: "AvgLoss: <xent> (Xent), ... Frame: <n>" in output order
+    losses = [float(x) for x in re.findall(r"AvgLoss: (\S+) \(Xent\)", err)][-2:]
+    for k in range(2):
+        assert abs(losses[k] - (st[k]["loss"] - st[k]["entropy"]) / st[k]["frames"]) <= 2e-4 * abs(losses[k])
