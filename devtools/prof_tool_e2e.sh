@@ -11,5 +11,7 @@ rocprofv3 --kernel-trace --memory-copy-trace -d /tmp/prof_tool -o tool -- "$ROOT
   --learn-rate=0.00001 --minibatch-size=1024 --randomizer-size=32768 ark:/tmp/e2e/feats.ark ark:/tmp/e2e/post.ark /tmp/e2e/nnet.init /tmp/e2e/nnet.out 2>&1 | grep -E "fps|AvgLoss" || true
 DB=$(find /tmp/prof_tool -name "*.db" | head -1)
 python "$ROOT/devtools/prof_tool_gaps.py" "$DB" 150
+python "$ROOT/devtools/prof_tool_refill.py" "$DB" 10 > "$ROOT/gpurun_out/tool_refill.txt" 2>&1 || true
+python "$ROOT/devtools/prof_tool_head.py" "$DB" 120 80 > "$ROOT/gpurun_out/tool_head_tail.txt" 2>&1 || true
 python "$ROOT/devtools/prof_timeline.py" "$DB" xent_rows_kernel 200 > "$ROOT/gpurun_out/tool_step_timeline.txt" 2>&1 || true
 tail -1 "$ROOT/gpurun_out/tool_step_timeline.txt"

@@ -32,6 +32,34 @@ void CheckKernels() {
 }
 }  // namespace
 
+// New blocks of up to 32 MB are carved out of 256 MB slabs instead of being hipMalloc'ed one by one: the first training step of a net asks
+// for a hundred buffers, and a hundred hipMalloc calls stood as ~15 ms of idle GPU at the head of every tool run (on a 288 GB device
+// the slack of a slab is nothing).  Freed pieces go to the size-keyed cache like every other block.  ASLP_ALLOC_SLAB=0: one hipMalloc
+// per new block, as before.
+namespace {
+constexpr size_t kSlabBytes = 256u << 20, kSlabMaxRequest = 32u << 20;
+struct Slab { char *base; size_t used; };
+std::vector<Slab> g_slabs;
+bool InSlab(const void *p) {
+  for (const Slab &s : g_slabs)
+    if (static_cast<const char *>(p) >= s.base && static_cast<const char *>(p) < s.base + kSlabBytes) return true;
+  return false;
+}
+void *SlabCarve(size_t sz) {   // caller holds g_alloc_mu; NULL: not served (too large, switched off, no memory for a slab)
+  static const bool on = !(getenv("ASLP_ALLOC_SLAB") != nullptr && getenv("ASLP_ALLOC_SLAB")[0] == '0');
+  if (!on || sz > kSlabMaxRequest) return nullptr;
+  if (g_slabs.empty() || g_slabs.back().used + sz > kSlabBytes) {
+    void *base = nullptr;
+    if (hipMalloc(&base, kSlabBytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    g_slabs.push_back(Slab{static_cast<char *>(base), 0});
+  }
+  Slab &s = g_slabs.back();
+  void *p = s.base + s.used;
+  s.used += sz;
+  return p;
+}
+}  // namespace
+
 void *DeviceAlloc(size_t bytes) {
   if (bytes == 0) return nullptr;
   size_t sz = RoundSize(bytes);
@@ -42,12 +70,18 @@ void *DeviceAlloc(size_t bytes) {
     p = it->second;
     g_free.erase(it);
   } else {
-    hipError_t e = hipMalloc(&p, sz);
-    if (e != hipSuccess) {
-      // release the cache and retry once
-      for (auto &kv : g_free) (void)hipFree(kv.second);
-      g_free.clear();
-      CheckHip(hipMalloc(&p, sz), "hipMalloc");
+    p = SlabCarve(sz);
+    if (!p) {
+      hipError_t e = hipMalloc(&p, sz);
+      if (e != hipSuccess) {
+        // release the cache (the blocks that are allocations of their own: a piece of a slab cannot go back alone) and retry once
+        for (auto it2 = g_free.begin(); it2 != g_free.end();) {
+          if (InSlab(it2->second)) { ++it2; continue; }
+          (void)hipFree(it2->second);
+          it2 = g_free.erase(it2);
+        }
+        CheckHip(hipMalloc(&p, sz), "hipMalloc");
+      }
     }
   }
   g_live[p] = sz;
@@ -76,20 +110,31 @@ void DeviceToHost(void *dst, const void *src, size_t bytes) {
 // ago (long finished).  A stream synchronise per upload -- labels, frame weights, every utterance of a cache fill -- would
 // empty the launch queue each time and leave the GPU idle while the host refills it (measured on the tool path: 546 k
 // -> see DESIGN.md frames/s end to end).
+// Two rings: a minibatch's labels and frame weights are a few KB each and go out every step, so a ring of eight slots let the host run at most
+// FOUR steps (3 ms) ahead of the GPU -- every longer piece of host work (a randomizer refill: 3.6 ms; the reader's hand-over) then reached the
+// device as idle time, 140 ms per million frames of the cfg2 tool run.  Uploads of up to 64 KB have 512 slots of their own (the host may
+// now lead by a quarter of a thousand steps; the launch queue is what bounds it), the large ones keep the 4 MB slots.
 namespace {
-constexpr size_t kStageBytes = 4u << 20;
-constexpr int kStageSlots = 8;
+constexpr size_t kStageBytes = 4u << 20, kSmallBytes = 64u << 10;
+constexpr int kStageSlots = 8, kSmallSlots = 512;
 struct StageSlot { void *pinned = nullptr; hipEvent_t ev = nullptr; bool pending = false; };
-StageSlot g_stage[kStageSlots];
-int g_stage_next = 0;
+StageSlot g_stage[kStageSlots], g_small[kSmallSlots];
+int g_stage_next = 0, g_small_next = 0;
+char *g_small_block = nullptr;   // one page-locked block carved into the small slots
 std::mutex g_stage_mu;
 }  // namespace
 // next free staging slot (caller holds g_stage_mu)
-static StageSlot &TakeStageSlot() {
-  StageSlot &slot = g_stage[g_stage_next];
-  g_stage_next = (g_stage_next + 1) % kStageSlots;
+static StageSlot &TakeStageSlot(bool small = false) {
+  StageSlot &slot = small ? g_small[g_small_next] : g_stage[g_stage_next];
+  if (small) g_small_next = (g_small_next + 1) % kSmallSlots;
+  else g_stage_next = (g_stage_next + 1) % kStageSlots;
   if (!slot.pinned) {
-    CheckHip(hipHostMalloc(&slot.pinned, kStageBytes, hipHostMallocDefault), "hipHostMalloc(staging)");
+    if (small) {
+      if (!g_small_block) CheckHip(hipHostMalloc(reinterpret_cast<void **>(&g_small_block), kSmallBytes * kSmallSlots, hipHostMallocDefault), "hipHostMalloc(staging)");
+      slot.pinned = g_small_block + kSmallBytes * (size_t)(&slot - g_small);
+    } else {
+      CheckHip(hipHostMalloc(&slot.pinned, kStageBytes, hipHostMallocDefault), "hipHostMalloc(staging)");
+    }
     CheckHip(hipEventCreateWithFlags(&slot.ev, hipEventDisableTiming), "hipEventCreate(staging)");
   }
   if (slot.pending) { CheckHip(hipEventSynchronize(slot.ev), "hipEventSynchronize(staging)"); slot.pending = false; }
@@ -101,7 +146,7 @@ void HostToDevice(void *dst, const void *src, size_t bytes) {
   const char *s = static_cast<const char *>(src);
   char *d = static_cast<char *>(dst);
   while (bytes > 0) {
-    StageSlot &slot = TakeStageSlot();
+    StageSlot &slot = TakeStageSlot(bytes <= kSmallBytes);
     const size_t n = bytes < kStageBytes ? bytes : kStageBytes;
     std::memcpy(slot.pinned, s, n);
     CheckHip(hipMemcpyAsync(d, slot.pinned, n, hipMemcpyHostToDevice, cur_stream()), "hipMemcpy H2D");

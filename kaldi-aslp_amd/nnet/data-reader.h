@@ -115,10 +115,29 @@ class FrameDataReader {
     lk.unlock();
     cv_.notify_all();
   }
+  // the feature table's binary float matrices are read straight into page-locked blocks (host-matrix.h HostMatrixSink)
+  static float *SinkTake(void *ctx, int rows, int cols) {
+    FrameDataReader *self = static_cast<FrameDataReader *>(ctx);
+    self->sunk_ = self->TakeBlock((size_t)rows * cols);
+    self->sunk_valid_ = true;
+    return self->sunk_.ptr;
+  }
   void Produce() {
+    struct SinkScope {   // (this thread reads nothing but the feature table's matrices)
+      explicit SinkScope(FrameDataReader *r) { host_matrix_sink().take = &FrameDataReader::SinkTake; host_matrix_sink().ctx = r; }
+      ~SinkScope() { host_matrix_sink() = HostMatrixSink(); }
+    } sink_scope(this);
+    // ASLP_READER_PROFILE=1: where this thread's time goes (seconds in the table reader's Next(), the targets' look-up + copy, Push)
+    static const bool prof = getenv("ASLP_READER_PROFILE") != nullptr && getenv("ASLP_READER_PROFILE")[0] == '1';
+    double t_next = 0.0, t_tgt = 0.0, t_push = 0.0;
+    Timer tp;
+    struct Report {
+      const bool &on; const double &a, &b, &c;
+      ~Report() { if (on) ASLP_LOG << "FrameDataReader thread: feature table " << a << " s, targets " << b << " s, hand-over " << c << " s"; }
+    } report{prof, t_next, t_tgt, t_push};
     try {
       CuDevice::Instantiate().BindThread();
-      for (; !feature_reader_->Done(); feature_reader_->Next()) {
+      for (; !feature_reader_->Done(); tp.Reset(), feature_reader_->Next(), t_next += tp.Elapsed()) {
         {
           std::lock_guard<std::mutex> lk(mu_);
           if (stop_) return;
@@ -126,16 +145,29 @@ class FrameDataReader {
         Item item;
         item.key = feature_reader_->Key();
         ASLP_VLOG(3) << "Reading " << item.key;
-        const HostMatrix &mat = feature_reader_->Value();
+        const HostMatrix &mat = feature_reader_->Value();   // (loaded by the table reader's Next(): on this thread from the second object on)
         item.rows = mat.rows;
         item.cols = mat.cols;
+        tp.Reset();
         item.has_targets = targets_reader_->HasKey(item.key);
+        const bool sunk = sunk_valid_ && mat.data.empty();   // (else: another encoding, or the table reader had the object before the sink was there)
         if (item.has_targets) {
           item.targets = targets_reader_->Value(item.key);
-          item.block = TakeBlock(mat.data.size());
-          std::memcpy(item.block.ptr, mat.data.data(), sizeof(float) * mat.data.size());
+          t_tgt += tp.Elapsed();
+          if (sunk) {
+            item.block = sunk_;
+          } else {
+            item.block = TakeBlock(mat.data.size());
+            std::memcpy(item.block.ptr, mat.data.data(), sizeof(float) * mat.data.size());
+          }
+        } else if (sunk) {
+          std::lock_guard<std::mutex> lk(mu_);
+          free_blocks_.push_back(sunk_);
         }
+        sunk_valid_ = false;
+        tp.Reset();
         Push(std::move(item));
+        t_push += tp.Elapsed();
       }
     } catch (const std::exception &e) {
       Item item;
@@ -205,11 +237,17 @@ class FrameDataReader {
   }
   void FillRandomizer() {  // data-reader.cc:66-128
     Timer fill_timer;
+    static const bool prof = getenv("ASLP_READER_PROFILE") != nullptr && getenv("ASLP_READER_PROFILE")[0] == '1';
+    Timer tp;
     t_wait_ = 0.0;
     Prefetch(true);
+    const double t_prefetch = tp.Elapsed();
+    tp.Reset();
     feature_randomizer_.StageCommit();
-    for (auto &t : stage_targets_) targets_randomizer_.AddData(t);
+    for (auto &t : stage_targets_) targets_randomizer_.AddData(std::move(t));
     stage_targets_.clear();
+    const double t_commit = tp.Elapsed();
+    tp.Reset();
     const int32 added = stage_added_;
     read_done_ = stage_end_seen_;
     stage_closed_ = false;
@@ -221,13 +259,22 @@ class FrameDataReader {
     // than a minibatch and is dropped.  The reference shuffles here regardless and dies on its own data_begin_ == 0 check.
     if (n == 0 || added == 0) return;
     ASLP_ASSERT(n == targets_randomizer_.NumFrames());
+    double t_mask = 0.0, t_feat = 0.0;
     if (randomize_) {
+      Timer ts;
       const std::vector<int32> &mask = randomizer_mask_.Generate(n);
+      t_mask = ts.Elapsed();
+      ts.Reset();
       feature_randomizer_.Randomize(mask);
+      t_feat = ts.Elapsed();
       targets_randomizer_.Randomize(mask);
     }
     CuDevice::Instantiate().AccuProfile("FrameDataReader::FillRandomizer (host, total)", fill_timer.Elapsed());
+    const double t_shuffle = tp.Elapsed();
+    tp.Reset();
     if (!read_done_) Prefetch(false);  // opens the next stage: whatever the reader thread already has goes up behind the shuffle
+    if (prof) ASLP_LOG << "FillRandomizer: finish the stage " << t_prefetch * 1e3 << " ms (waited " << t_wait_ * 1e3 << "), commit + targets " << t_commit * 1e3
+                       << ", shuffle " << t_shuffle * 1e3 << " (mask " << t_mask * 1e3 << ", features " << t_feat * 1e3 << "), open the next stage " << tp.Elapsed() * 1e3 << " ms; frames " << n;
   }
 
   std::string feature_rspecifier_, targets_rspecifier_;
@@ -239,6 +286,8 @@ class FrameDataReader {
   NnetDataRandomizerOptions rand_opts_;
   bool randomize_, read_done_;
   int32 num_no_tgt_, num_done_;
+  Block sunk_;                 // the block the sink handed out for the object the table reader holds now (producer thread only)
+  bool sunk_valid_ = false;
   std::thread producer_;
   std::mutex mu_;
   std::condition_variable cv_;

@@ -92,6 +92,11 @@ static void ReadCompressedMatrix(std::istream &is, const std::string &token, Hos
   }
 }
 
+HostMatrixSink &host_matrix_sink() {
+  static thread_local HostMatrixSink s;
+  return s;
+}
+
 void HostMatrix::Read(std::istream &is, bool binary) {
   if (binary) {
     int peekval = Peek(is, binary);
@@ -112,8 +117,15 @@ void HostMatrix::Read(std::istream &is, bool binary) {
       int32 r, c;
       ReadBasicType(is, binary, &r);
       ReadBasicType(is, binary, &c);
-      Resize(r, c);
-      is.read(reinterpret_cast<char *>(data.data()), sizeof(float) * data.size());
+      HostMatrixSink &sink = host_matrix_sink();
+      if (sink.take != nullptr && r > 0 && c > 0) {
+        rows = r; cols = c;
+        data.clear();
+        is.read(reinterpret_cast<char *>(sink.take(sink.ctx, r, c)), sizeof(float) * (size_t)r * c);
+      } else {
+        Resize(r, c);
+        is.read(reinterpret_cast<char *>(data.data()), sizeof(float) * data.size());
+      }
     }
     if (is.fail()) ASLP_ERR << "Failed to read matrix from stream (binary, truncated?)";
     return;
@@ -357,14 +369,25 @@ void ReadPosterior(std::istream &is, bool binary, Posterior *post) {
     ReadBasicType(is, true, &sz);
     if (sz < 0 || sz > 10000000) ASLP_ERR << "Reading posterior: got negative or improbably large size" << sz;
     post->resize(sz);
+    // (hmm/posterior.cc:56-72 reads every number with its own ReadBasicType; a million frames per second of training want fewer trips
+    //  through the stream: the 5-byte frame header and the frame's 10-byte pairs are taken from the stream buffer in one piece each)
+    std::streambuf *sb = is.rdbuf();
+    char buf[10 * 64];
     for (auto &frame : *post) {
+      if (sb->sgetn(buf, 5) != 5 || buf[0] != 4) { is.setstate(std::ios::failbit); ASLP_ERR << "ReadBasicType: failed reading a frame's size of a Posterior"; }
       int32 sz2;
-      ReadBasicType(is, true, &sz2);
+      std::memcpy(&sz2, buf + 1, 4);
       if (sz2 < 0) ASLP_ERR << "Reading posteriors: got negative size";
       frame.resize(sz2);
-      for (auto &pr : frame) {
-        ReadBasicType(is, true, &pr.first);
-        ReadBasicType(is, true, &pr.second);
+      for (int32 at = 0; at < sz2; at += 64) {
+        const int32 n = std::min<int32>(64, sz2 - at);
+        if (sb->sgetn(buf, 10 * n) != 10 * n) { is.setstate(std::ios::failbit); ASLP_ERR << "ReadBasicType: failed reading the pairs of a Posterior frame"; }
+        for (int32 i = 0; i < n; i++) {
+          const char *q = buf + 10 * i;
+          if (q[0] != 4 || q[5] != 4) ASLP_ERR << "ReadBasicType: did not get expected integer type, " << (int)q[0] << " vs. 4.  You can change this code to successfully read it later, if needed.";
+          std::memcpy(&frame[at + i].first, q + 1, 4);
+          std::memcpy(&frame[at + i].second, q + 6, 4);
+        }
       }
     }
     return;

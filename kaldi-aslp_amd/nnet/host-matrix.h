@@ -18,6 +18,16 @@ struct HostMatrix {
   void Read(std::istream &is, bool binary);
   void Write(std::ostream &os, bool binary) const;
 };
+// A reader whose matrices go straight on to the device (FrameDataReader's parsing thread) wants the payload of a binary float matrix in
+// page-locked memory, not in `data`: with a sink installed for the calling thread, HostMatrix::Read hands (rows, cols) to the sink, reads the
+// payload into the pointer it returns and leaves `data` EMPTY (rows / cols are set).  Other encodings (double, compressed, text) ignore the
+// sink and fill `data` as always.  One pass over the bytes instead of three (zero-fill, read, copy).
+struct HostMatrixSink {
+  float *(*take)(void *ctx, int rows, int cols) = nullptr;
+  void *ctx = nullptr;
+};
+HostMatrixSink &host_matrix_sink();   // the calling thread's
+
 struct HostVector {
   std::vector<float> data;
   HostVector() {}

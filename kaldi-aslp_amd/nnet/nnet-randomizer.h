@@ -99,7 +99,7 @@ class MatrixRandomizer : public RandomizerBase {  // :67-102
 
  private:
   CuSubMatrix Append(int32 m_rows, int32 m_cols) {
-    if (data_.NumCols() == 0) data_.Resize(conf_.randomizer_size, m_cols);
+    if (data_.NumCols() == 0) data_.Resize(GrownRows(conf_.randomizer_size), m_cols);   // (a cache is "full" one utterance PAST randomizer_size: room for it from the start)
     if (data_begin_ > 0) {
       const int32 leftover = BeginRefill();
       if (leftover > 0) data_.RowRange(0, leftover).CopyFromMat(data_.RowRange(data_begin_, leftover));
@@ -109,7 +109,7 @@ class MatrixRandomizer : public RandomizerBase {  // :67-102
     }
     if (data_.NumRows() < data_end_ + m_rows) {
       CuMatrix data_aux(data_);
-      data_.Resize(data_end_ + m_rows + 1000, data_.NumCols());
+      data_.Resize(GrownRows(data_end_ + m_rows), data_.NumCols());
       data_.RowRange(0, data_aux.NumRows()).CopyFromMat(data_aux);
     }
     ASLP_ASSERT(m_cols == data_.NumCols());
@@ -119,10 +119,15 @@ class MatrixRandomizer : public RandomizerBase {  // :67-102
   }
 
  public:
+  // rows a cache buffer grows to when `need` rows no longer fit: the reference's "+ 1000" (:60-64) rounded up to a multiple of 8192.  The two
+  // buffers of a randomizer grow at different moments; with exact sizes nearly every refill met a row count the allocator had not seen
+  // and paid a 58 MB hipMalloc for it -- 12-16 ms of idle GPU on every other refill of the cfg2 tool run.
+  static int32 GrownRows(int32 need) { return (need + 1000 + 8191) / 8192 * 8192; }
   void Randomize(const std::vector<int32> &mask) {  // :73-88
     CheckRandomize(mask.size());
     mask_dev_.CopyFromVec(mask);
-    if (data_aux_.NumRows() != data_.NumRows() || data_aux_.NumCols() != data_.NumCols())
+    // (the gather target only has to hold the cache's frames; it need not be as tall as data_)
+    if (data_aux_.NumRows() < (int32)mask.size() || data_aux_.NumCols() != data_.NumCols())
       data_aux_.Resize(data_.NumRows(), data_.NumCols(), kUndefined);
     cu::Randomize(data_, mask_dev_, &data_aux_);  // rows [0, mask.size()); rows beyond hold no frames
     data_.Swap(&data_aux_);
@@ -154,13 +159,13 @@ class MatrixRandomizer : public RandomizerBase {  // :67-102
   void StageAddPinned(const float *src, int32 rows, int32 cols, StreamMarker *done) {
     ASLP_ASSERT(staging_);
     if (data_aux_.NumCols() == 0) {
-      data_aux_.Resize(std::max(conf_.randomizer_size, data_.NumRows()), cols, kUndefined);
+      data_aux_.Resize(std::max(GrownRows(conf_.randomizer_size), data_.NumRows()), cols, kUndefined);
       lane_->LaneWaitsForStream();  // the allocator may hand out a block the training stream has not finished with
     }
     ASLP_ASSERT(cols == data_aux_.NumCols());
     if (data_aux_.NumRows() < stage_end_ + rows) {  // the +1000-row growth of :60-64, on the stage
       lane_->Sync();
-      CuMatrix grown(stage_end_ + rows + 1000, cols, kUndefined);
+      CuMatrix grown(GrownRows(stage_end_ + rows), cols, kUndefined);
       if (stage_end_ > stage_leftover_)
         grown.RowRange(stage_leftover_, stage_end_ - stage_leftover_).CopyFromMat(data_aux_.RowRange(stage_leftover_, stage_end_ - stage_leftover_));
       data_aux_.Swap(&grown);
@@ -219,10 +224,41 @@ class StdVectorRandomizer : public RandomizerBase {
     std::copy(v.begin(), v.end(), data_.begin() + data_end_);
     data_end_ += v.size();
   }
+  // the same bookkeeping for a caller that is done with `v`: the elements MOVE into the cache (a Posterior frame is a heap vector: a cache
+  // fill of 32768 frames copied them one malloc at a time, twice, and a third time in Randomize -- 7.6 ms of host time per refill of the
+  // cfg2 tool run, more than the lead the host has over the GPU there)
+  void AddData(std::vector<T> &&v) {
+    if (data_.size() == 0) data_.resize(conf_.randomizer_size);
+    if (data_begin_ > 0) {
+      const int32 leftover = BeginRefill();
+      if (leftover > 0) std::move(data_.begin() + data_begin_, data_.begin() + data_begin_ + leftover, data_.begin());
+      data_begin_ = 0;
+      data_end_ = leftover;
+    }
+    if (data_.size() < data_end_ + v.size()) data_.resize(data_end_ + v.size() + 1000);
+    std::move(v.begin(), v.end(), data_.begin() + data_end_);
+    data_end_ += v.size();
+    v.clear();
+  }
   void Randomize(const std::vector<int32> &mask) {  // :175-187
     CheckRandomize(mask.size());
-    std::vector<T> data_aux(data_);
-    for (size_t i = 0; i < mask.size(); i++) data_.at(i) = data_aux.at(mask.at(i));
+    // data_[i] = old data_[mask[i]]: the mask is a permutation of [0, mask.size()) (RandomizerMask::Generate), so every old element is
+    // taken exactly once and may be moved instead of copied; an arbitrary index list (a caller's own) falls back to copies
+    std::vector<char> seen(mask.size(), 0);
+    bool permutation = true;
+    for (size_t i = 0; i < mask.size() && permutation; i++) {
+      const int32 m = mask[i];
+      if (m < 0 || (size_t)m >= mask.size() || seen[m]) permutation = false;
+      else seen[m] = 1;
+    }
+    if (!permutation) {
+      std::vector<T> data_aux(data_);
+      for (size_t i = 0; i < mask.size(); i++) data_.at(i) = data_aux.at(mask.at(i));
+      return;
+    }
+    std::vector<T> data_aux(mask.size());
+    for (size_t i = 0; i < mask.size(); i++) data_aux[i] = std::move(data_[mask[i]]);
+    std::move(data_aux.begin(), data_aux.end(), data_.begin());
   }
   const std::vector<T> &Value() {  // :194-201
     CheckValue();
