@@ -28,7 +28,7 @@ PASSES = [
     ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F16", "SQ_INSTS_MFMA", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_INST_CYCLES_VMEM", "SQ_ACTIVE_INST_VMEM", "GRBM_GUI_ACTIVE"],
     ["SQ_INSTS_VMEM", "SQ_INSTS_VMEM_RD", "SQ_INSTS_FLAT", "SQ_ACTIVE_INST_FLAT", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_SCA", "SQ_INST_CYCLES_SALU", "SQ_WAIT_INST_VMEM"],
     ["SQ_INSTS_LDS_DMA", "SQ_INSTS_VMEM_LDS", "SQ_IFETCH", "SQ_INSTS_SMEM", "SQ_ACTIVE_INST_MISC", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_BRANCH", "SQ_WAVE_DEP_WAIT"],
-    ["TA_TA_BUSY_sum", "TA_BUSY_avr", "TA_BUSY_max", "TA_FLAT_READ_WAVEFRONTS_sum", "TA_BUFFER_WAVEFRONTS_sum", "TA_ADDR_STALLED_BY_TC_CYCLES_sum", "TA_DATA_STALLED_BY_TC_CYCLES_sum", "GRBM_GUI_ACTIVE"],
+    # (a pass with the TA_* counters never returned on this stack -- ten minutes of the first run -- and is left out)
     ["TCP_TCC_READ_REQ_sum", "TCP_PENDING_STALL_CYCLES_sum", "TCP_TCP_TA_DATA_STALL_CYCLES_sum", "TCP_GATE_EN1_sum", "TCP_GATE_EN2_sum", "TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_LATENCY_sum", "TCP_TA_TCP_STATE_READ_sum"],
     ["TCP_READ_TAGCONFLICT_STALL_CYCLES_sum", "TCP_TCR_TCP_STALL_CYCLES_sum", "TCP_TOTAL_READ_sum", "TCP_UTCL1_REQUEST_sum", "TD_TD_BUSY_sum", "TD_TC_STALL_sum", "TD_LOAD_WAVEFRONT_sum", "TCP_TOTAL_ACCESSES_sum"],
     ["TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum", "TCC_READ_sum"],
@@ -69,7 +69,11 @@ for shape in SHAPES:
             subprocess.run(["rm", "-rf", d])
             e = dict(env, SHAPE=shape, TILE=os.environ.get("TILE", "0"), REPS="10")
             cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + names + ["-d", d, "-o", "og", "--", "python3", os.path.join(ROOT, "devtools", "one_gemm.py")]
-            p = subprocess.run(cmd, capture_output=True, text=True, env=e, cwd=ROOT, timeout=600)
+            try:
+                p = subprocess.run(cmd, capture_output=True, text=True, env=e, cwd=ROOT, timeout=150)
+            except subprocess.TimeoutExpired:
+                f.write("## pass: %s\n# TIMED OUT after 150 s\n" % " ".join(names))
+                continue
             dbs = subprocess.run(["find", d, "-name", "*.db"], capture_output=True, text=True).stdout.split()
             f.write("## pass: %s%s\n" % (" ".join(names), ("   (not on this stack: %s)" % " ".join(missing)) if missing else ""))
             if p.returncode != 0 or not dbs:

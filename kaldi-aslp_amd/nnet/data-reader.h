@@ -75,9 +75,21 @@ class FrameDataReader {
     if (Done()) return false;
     *feat = &feature_randomizer_.Value();
     feature_randomizer_.Next();
+    cur_begin_ = targets_randomizer_.Begin();
     *targets = &targets_randomizer_.Value();
     targets_randomizer_.Next();
     if (!read_done_) Prefetch(false);
+    return true;
+  }
+  // The minibatch ReadData() handed out last, as device-resident labels: when every target frame of the current cache is ONE pdf of weight 1
+  // (alignments through ali-to-post: the normal case) the labels of the whole cache were uploaded once at the refill, and a training loop
+  // can hand `*labels_dev` (one int32 per frame of the minibatch) to Xent::EvalLabelsPreSoftmax with unit frame weights instead of sending
+  // labels and weights to the device in every step -- the same kernel on the same numbers.  *max_label: the largest label in the cache
+  // (the caller checks it against the net's output width).  false: soft or weighted targets in this cache; use the Posterior.
+  bool MinibatchLabels(const int32 **labels_dev, int32 *max_label) const {
+    if (!cache_labels_ok_) return false;
+    *labels_dev = cache_labels_.Data() + cur_begin_;
+    *max_label = cache_label_max_;
     return true;
   }
   int32 NumUtterances() const { return num_done_; }
@@ -257,6 +269,7 @@ class FrameDataReader {
     const int32 n = feature_randomizer_.NumFrames();
     // Nothing new arrived (the previous fill stopped on "cache full" exactly at the last utterance): what is left is less
     // than a minibatch and is dropped.  The reference shuffles here regardless and dies on its own data_begin_ == 0 check.
+    cache_labels_ok_ = false;
     if (n == 0 || added == 0) return;
     ASLP_ASSERT(n == targets_randomizer_.NumFrames());
     double t_mask = 0.0, t_feat = 0.0;
@@ -268,6 +281,22 @@ class FrameDataReader {
       feature_randomizer_.Randomize(mask);
       t_feat = ts.Elapsed();
       targets_randomizer_.Randomize(mask);
+    }
+    {   // one label per frame and unit weights throughout the (shuffled) cache?  then the labels go up once
+      const auto &frames = targets_randomizer_.Cache();
+      host_labels_.resize(n);
+      int32 mx = -1;
+      bool one_hot = true;
+      for (int32 i = 0; i < n && one_hot; i++) {
+        const auto &fr = frames[i];
+        if (fr.size() != 1 || fr[0].second != 1.0f || fr[0].first < 0) one_hot = false;
+        else { host_labels_[i] = fr[0].first; mx = std::max(mx, fr[0].first); }
+      }
+      if (one_hot) {
+        cache_labels_ = host_labels_;
+        cache_label_max_ = mx;
+        cache_labels_ok_ = true;
+      }
     }
     CuDevice::Instantiate().AccuProfile("FrameDataReader::FillRandomizer (host, total)", fill_timer.Elapsed());
     const double t_shuffle = tp.Elapsed();
@@ -286,6 +315,10 @@ class FrameDataReader {
   NnetDataRandomizerOptions rand_opts_;
   bool randomize_, read_done_;
   int32 num_no_tgt_, num_done_;
+  CuArray<int32> cache_labels_;       // labels of the whole current cache (MinibatchLabels)
+  std::vector<int32> host_labels_;
+  bool cache_labels_ok_ = false;
+  int32 cache_label_max_ = -1, cur_begin_ = 0;
   Block sunk_;                 // the block the sink handed out for the object the table reader holds now (producer thread only)
   bool sunk_valid_ = false;
   std::thread producer_;

@@ -260,6 +260,9 @@ class StdVectorRandomizer : public RandomizerBase {
     for (size_t i = 0; i < mask.size(); i++) data_aux[i] = std::move(data_[mask[i]]);
     std::move(data_aux.begin(), data_aux.end(), data_.begin());
   }
+  // the cache itself (frames [Begin(), NumFrames()) have not been handed out yet): for a reader that wants to look at a whole refill at once
+  const std::vector<T> &Cache() const { return data_; }
+  int32 Begin() const { return data_begin_; }
   const std::vector<T> &Value() {  // :194-201
     CheckValue();
     minibatch_.resize(conf_.minibatch_size);

@@ -62,6 +62,7 @@ int Main_aslp_nnet_train_frame(int argc, char *argv[]) {
     else ASLP_ERR << "Unsupported objective function: " << objective_function;
     Xent *xent = dynamic_cast<Xent *>(loss);
     std::vector<BaseFloat> ones;
+    CuVector ones_dev;
 
     Timer time;
     int64_t total_frames = 0, report_frames = 0;
@@ -83,8 +84,17 @@ int Main_aslp_nnet_train_frame(int argc, char *argv[]) {
           nnet.PropagateForLoss(*nnet_in, true);
           CuDevice::Instantiate().AccuProfile("host: Propagate (launches)", t1.Elapsed());
           t1.Reset();
-          ones.assign(nnet_in->NumRows(), 1.0f);
-          xent->EvalOnLossInput(ones, nnet.LossInput(), nnet.LossInputIsPreSoftmax(), *nnet_tgt, nnet.LossDiff(nnet_in->NumRows()));
+          const int32 *labels_dev = nullptr;
+          int32 max_label = -1;
+          if (nnet.LossInputIsPreSoftmax() && reader.MinibatchLabels(&labels_dev, &max_label) && max_label < nnet.LossInput().NumCols()) {
+            // alignment targets: the cache's labels are on the device since the refill, the frame weights are all 1 -- the loss kernel of
+            // the branch below on the same numbers, without two uploads and a pass over the Posterior in every step
+            if (ones_dev.Dim() != nnet_in->NumRows()) { ones_dev.Resize(nnet_in->NumRows(), kUndefined); ones_dev.Set(1.0); }
+            xent->EvalLabelsPreSoftmax(ones_dev, nnet.LossInput(), labels_dev, nnet.LossDiff(nnet_in->NumRows()), 1.0f);
+          } else {
+            ones.assign(nnet_in->NumRows(), 1.0f);
+            xent->EvalOnLossInput(ones, nnet.LossInput(), nnet.LossInputIsPreSoftmax(), *nnet_tgt, nnet.LossDiff(nnet_in->NumRows()));
+          }
           CuDevice::Instantiate().AccuProfile("host: Xent::Eval (launches + label upload)", t1.Elapsed());
           t1.Reset();
           nnet.BackpropagateFromLossDiff();
