@@ -28,6 +28,7 @@ FLOP_PER_FRAME = 141131776.0   # 2W fwd + 2(W-W1) bwd-data + 2W 
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
 F16_MFMA_PEAK_TFLOPS = 2516.0  # MI355X_MICROARCH.md: dense fp16 MFMA (v_mfma_f32_32x32x16_f16)
 SPLIT_PEAK_TF_EQUIV = F16_MFMA_PEAK_TFLOPS / 3.0   # three fp16 instructions per fp32-equivalent product: 839 TF-equivalent
+L2_PEAK_TBS = 34.5   # MI355X_MICROARCH.md: L2 aggregate bandwidth (8 XCDs x 16 channels x 128 B/clk at 2.1 GHz fabric-side)
 CFG2_LEARN_RATE = 0.008      # run_bn_dnn.sh:81-83 / SURVEY 8d (the kept weight planes' bound depends on it; rounds 1-4 timed at 1e-5)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 ARITHMETIC = "fp32 operands as 2xfp16 pieces behind power-of-two scales, fp32 accumulate"
@@ -1080,16 +1081,20 @@ def main():
                                "unit": "TFLOP/s (fp32-equivalent)" if split else "TFLOP/s", "frac": d["tflops"] / peak,
                                "peak_note": ("dense fp16 MFMA peak %.0f TFLOP/s / 3 instructions per fp32-equivalent product" % F16_MFMA_PEAK_TFLOPS) if split
                                             else "fp32 MFMA peak",
-                               "frac_of_fp32_mfma_peak": d["tflops"] / F32_MFMA_PEAK_TFLOPS,
-                               "frac_of_fp32_mfma_peak_note": ("a ratio of rates (this kernel's fp32-equivalent rate over the fp32 instruction's peak), NOT a utilisation: the "
+                               "ratio_to_fp32_mfma_peak": d["tflops"] / F32_MFMA_PEAK_TFLOPS,
+                               "ratio_to_fp32_mfma_peak_note": ("a ratio of rates (this kernel's fp32-equivalent rate over the fp32 instruction's peak), NOT a utilisation: the "
                                                                "fp32 instruction is not what runs; the matrix pipe's busy fraction is `matrix_pipe_busy`") if split else None,
                                "matrix_pipe_busy": (pmc.get("mfma_busy") if traffic is not None else None),
                                "matrix_pipe_busy_source": ("NOT measured in this run: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs) of the committed PMC pass "
                                                            "(profiles/dnn_cfg2_pmc.json)") if traffic is not None else None,
-                               "what_bounds_it": ("measured (DESIGN 7, devtools/micro/lds_feed*.hip): the operand path L2 -> LDS -- one output tile per CU pulls (BM + BN) x K x 4 B "
-                                                  "through it, 402 MB for a 1024 x 2048 x 2048 product on 64 x 128 tiles against the L2's 33-35 TB/s -- and, for the "
-                                                  "weight gradients, an HBM-bound epilogue (W, gradient buffer and the new W's planes: 64-80 MB per launch); the matrix "
-                                                  "pipe is 22-30 % busy") if split else None,
+                               "what_bounds_it": ("round-6 counters and ablations (profiles/r06_gemm_*; DESIGN 7 'Round 6'): INSIDE the K loop the L2 is ~80 % busy "
+                                                  "(TCC_BUSY) feeding LDS-DMA -- a 64 x 128 tile per CU pulls (BM + BN) x K x 4 B through L2 -> LDS, 402 MB per "
+                                                  "1024 x 2048 x 2048 product -- while the matrix pipe is 45-50 % busy and the LDS 25 %; with the matrix "
+                                                  "instructions running the shader clock sits ~20-25 % below the clock of the same kernel without them, and the "
+                                                  "launch takes what its LDS-DMA traffic alone takes at that clock (ablations: DMA + MFMA without LDS reads = the full "
+                                                  "kernel; every request an L2 hit = the full kernel).  Around the loop ~8 us per launch are fixed (dispatch, first "
+                                                  "tile, C stores, kernel end) and the weight gradients add an HBM-bound epilogue (W, gradient and the new W's planes: "
+                                                  "64-80 MB); `feed` below quotes the operand traffic against the L2's peak") if split else None,
                                "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                                "flop_per_launch": d["flop_per_launch"], "avg_launch_us": d["avg_us"], "launches": d["launches"],
                                "launch_mix": {"NT": "per step: the 440-input layer, four 2048 x 2048 hidden layers and the 3000-column output layer, all on the named tile",
@@ -1098,12 +1103,31 @@ def main():
                                                     "named one) and the 440-input and 3000-output layers' on gemm_s16_glds<64,128,2,2,3,false,false,0,true>; `achieved` and "
                                                     "`avg_launch_us` average all six (flop_per_launch = their mean)"}.get(dom),
                                "timing": "HIP events on the launch stream, second pass over the same K steps"}
+            if split:
+                # operand bytes every launch pulls through L2 -> LDS, from the tile geometry the library uses for cfg2's shapes (64 x 128 tiles;
+                # 128 x 128 for the 2048 x 2048 weight gradients): ceil(M / BM) ceil(N / BN) (BM + BN) pad64(K) 4 B
+                def feed(M, N, K, bm, bn):
+                    return -(-M // bm) * -(-N // bn) * (bm + bn) * (-(-K // 64) * 64) * 4.0
+                per_step = {"NT": [feed(MB, HID, IN_DIM, 64, 128)] + [feed(MB, HID, HID, 64, 128)] * (NH - 1) + [feed(MB, OUT_DIM, HID, 64, 128)],
+                            "NN": [feed(MB, HID, HID, 64, 128)] * (NH - 1) + [feed(MB, HID, OUT_DIM, 64, 128)],
+                            "TN": [feed(HID, IN_DIM, MB, 64, 128)] + [feed(HID, HID, MB, 128, 128)] * (NH - 1) + [feed(OUT_DIM, HID, MB, 64, 128)]}.get(dom)
+                if per_step and abs(len(per_step) * args.steps - d["launches"]) <= len(per_step):
+                    bpl = sum(per_step) / len(per_step)
+                    tbs = bpl / (d["avg_us"] * 1e-6) / 1e12
+                    out["roofline"]["feed"] = {
+                        "path": "L2 -> LDS by LDS-DMA (global_load_lds_dwordx4), the operand tiles of the K loop", "bytes_per_launch": bpl,
+                        "achieved": tbs, "peak": L2_PEAK_TBS, "unit": "TB/s", "frac": tbs / L2_PEAK_TBS,
+                        "peak_note": "L2 aggregate ~34.5 TB/s (MI355X_MICROARCH.md; devtools/micro/lds_feed.hip reaches 33-35 TB/s with every request a hit)",
+                        "in_loop_l2_busy": 0.80, "in_loop_matrix_pipe_busy": 0.49,
+                        "in_loop_source": "NOT measured in this run: TCC_BUSY_sum / (128 L2 channel instances x cycles) and SQ_VALU_MFMA_BUSY_CYCLES of the committed "
+                                          "passes profiles/r06_gemm_split16_pmc_*.txt, the launch's fixed ~8 us taken out",
+                        "note": "`achieved` is over the WHOLE launch (fixed part and, for the weight gradients, the HBM-bound update epilogue included), like roofline.achieved"}
             tot_fl = sum(v["flop_per_launch"] * v["launches"] for v in timed.values())
             tot_ms = sum(v["avg_us"] * v["launches"] for v in timed.values()) / 1e3
             step_tf = FLOP_PER_FRAME * args.steps * MB / elapsed / 1e12
             out["gemm_all"] = {"variants": gemm, "tflops": tot_fl / tot_ms / 1e9, "frac_of_step_time": tot_ms / (elapsed * 1e3),
                                "algorithmic_tflops_whole_step": step_tf, "whole_step_frac_of_split_peak": step_tf / SPLIT_PEAK_TF_EQUIV,
-                               "whole_step_frac_of_fp32_mfma_peak": step_tf / F32_MFMA_PEAK_TFLOPS}
+                               "whole_step_ratio_to_fp32_mfma_peak": step_tf / F32_MFMA_PEAK_TFLOPS}
         else:
             out["roofline"] = {"bound": "mfma", "achieved": FLOP_PER_FRAME * args.steps * MB / elapsed / 1e12, "peak": F32_MFMA_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": FLOP_PER_FRAME * args.steps * MB / elapsed / 1e12 / F32_MFMA_PEAK_TFLOPS,

@@ -31,6 +31,7 @@ def check_line(out, n):
     import math
     assert math.isfinite(c4["avg_xent_per_frame_rank0"]) and 0.0 < c4["avg_xent_per_frame_rank0"] < 20.0, c4     # the loss survived the exchanges
     assert math.isfinite(c5["avg_ctc_obj_per_sequence"]) and c5["avg_ctc_obj_per_sequence"] > 0.0, c5
+    assert d["comm"]["ranks_seen"] == n and d["comm"]["transport"] == "shm"     # the top-level copy of the transport's own count
     for blk in (bsp, c4, c5, d["config"]["comm"]):
         assert blk["transport"] == "shm" and blk["ranks_seen"] == n and blk["scaling_measured"] is False   # says so when nothing was scaled
     return d
@@ -67,3 +68,43 @@ def test_bench_three_ranks_server_and_two_workers():
     d = check_line(p.stdout.decode(), 3)
     assert d["cfg5_easgd"]["workers"] == 2 and d["cfg5_easgd"]["ranks_seen"] == 3 and d["cfg4_bsp"]["ranks_seen"] == 3
 
+
+
+def test_single_gpu_line_quotes_every_fraction_against_the_instruction_it_issued():
+    """`python bench.py` (N = 1, short): every `frac` in the line is algorithmic TFLOP/s over the peak of the instruction the
+    kernels ISSUE (split-fp16 products: 2516 / 3 TF-equivalent), the ratio to the fp32 instruction's peak lives under `ratio_to_fp32_mfma_peak`;
+    the headline carries `roofline` (+ the operand-feed block), `cpu_baseline` (thread probe named) and `cfg1_cpu_baseline` with the
+    GPU / CPU ratio on the configuration the >= 30x target is stated on."""
+    env = {k: v for k, v in os.environ.items() if k not in CLEAN}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "30", "--warmup", "5", "--prewarm-steps", "50", "--no-e2e-tool"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    d = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][-1])
+    peak16 = 2516.0 / 3.0
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["peak"] == pytest.approx(peak16) and r["frac"] == pytest.approx(r["achieved"] / peak16, rel=1e-6)
+    assert "ratio_to_fp32_mfma_peak" in r and "frac_of_fp32_mfma_peak" not in r
+    f = r["feed"]
+    assert f["unit"] == "TB/s" and f["frac"] == pytest.approx(f["achieved"] / f["peak"], rel=1e-6) and 0.0 < f["frac"] < 1.0
+    assert f["achieved"] == pytest.approx(f["bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e12, rel=1e-6)
+
+    def walk(x, path=""):
+        if isinstance(x, dict):
+            if "frac" in x and "tflops" in x and "product_accuracy" not in path:
+                assert x["frac"] <= x["tflops"] / peak16 * (1 + 1e-6) or x.get("peak_tflops") == 157.3, (path, x["frac"], x["tflops"])
+            assert "frac_of_mfma_peak" not in x, path
+            for k, v in x.items():
+                walk(v, path + "/" + k)
+    walk(d)
+    for key in ("chunked_xent", "whole_utterance_warpctc"):
+        blk = d["cfg3"][key]
+        assert blk["frac"] == pytest.approx(blk["tflops"] / peak16, rel=1e-6) and blk["ratio_to_fp32_mfma_peak"] == pytest.approx(blk["tflops"] / 157.3, rel=1e-6)
+    c1 = d["cfg1_gpu"]
+    assert c1["frac"] == pytest.approx(c1["tflops"] / peak16, rel=1e-6)
+    assert d["fp32_instruction"]["peak"] == 157.3          # (that block runs the fp32 instruction: its fraction is against 157.3)
+    cb, cb1 = d["cpu_baseline"], d["cfg1_cpu_baseline"]
+    assert cb["kind"] in ("reference", "port") and cb["value"] > 0 and cb["cores"] >= 1
+    if cb["kind"] == "reference":
+        assert str(cb["cores"]) in cb["thread_probe_frames_per_sec"] and "thread_choice" in cb
+    assert cb1["value"] > 0 and "WITHOUT BatchNormalization" in cb1["sample"]
+    assert c1["vs_cfg1_cpu_baseline"] == pytest.approx(c1["frames_per_sec"] / cb1["value"], rel=1e-6) and c1["vs_cfg1_cpu_baseline"] > 30.0
