@@ -1069,6 +1069,10 @@ bool launch_s16_layout(GemmArgs &g, const S16Operands &ops, int cfg) {
     static const int any128 = [] { const char *e = getenv("ASLP_GEMM_S16_128_ANY"); return e ? atoi(e) : 0; }();   // (tuning aid: 1 = every grid of >= 224 tiles, 2 = never)
     cfg = (!extra && A_KC && B_KC && t128 >= 224 && any128 != 2 && (any128 == 1 || 2 * ((t128 + 255) / 256) <= (t64 + 255) / 256)) ? 311 : 308;
   }
+  // (Below 224 tiles -- cfg2's output layer, 1024 x 3000 x 2048: 192 workgroups of 128 x 128 in one round against 384 of 64 x 128 in two -- the
+  // producer / consumer kernel wins only from operands that are hot in the L2: 66.5 against 74.2 us per call in a loop over one product,
+  // 59.6 against 57.8 us inside the training step, where the weights' planes come from HBM and two stages hide less of that than three;
+  // cfg2 0.756 against 0.754 ms per step, three alternations.  The floor stays.)
   // the producer / consumer kernel (gemm_s16_pc) where the 128 x 128 tile was chosen: 4096^3 383 against 422 us, same bits (devtools/micro/s16_pc.hip,
   // profiles/r06_gemm_s16_pc_micro.txt); ASLP_GEMM_S16_PC=0 keeps the one-role kernel (A/B switch)
   static const int pc_on = [] { const char *e = getenv("ASLP_GEMM_S16_PC"); return e ? atoi(e) : 1; }();
