@@ -19,8 +19,14 @@
  *   kaldi::ParseOptions, Timer, Posterior, the table typedefs    util/parse-options.h, base/timer.h, hmm/posterior.h, util/table-types.h
  *   KALDI_LOG / KALDI_WARN / KALDI_ERR / KALDI_VLOG / KALDI_ASSERT   base/kaldi-error.h (errors are std::runtime_error, as in the reference)
  * HAVE_CUDA is defined to 1: the `#if HAVE_CUDA==1` device-selection blocks of the reference's tools are the ones that apply.
- * Proof: tests/test_compat_kaldi_cpu.py compiles the reference's own aslp-nnet-train-frame.cc against this header (development container:
- * the reference tree does not travel); `make -C kaldi-aslp_amd refmains` links it into bin_ref/, which tests/test_tools_gpu.py runs on the GPU. */
+ *   kaldi::Matrix<Real> / Vector<Real> / SubVector / SubMatrix   matrix/kaldi-matrix.h, kaldi-vector.h (aslp_compat_kaldi_matrix.h: over HostMatrix / std::vector<float>)
+ *   kaldi::aslp_nnet::FrameDataReader (both constructors)        aslp-nnet/data-reader.h:23-47
+ *   kaldi::aslp_nnet::Ctc, WarpCtc, AffineTransform              aslp-nnet/ctc-loss.h, warp-ctc.h, nnet-affine-transform.h
+ *   fst::SymbolTable (ReadText, Find)                            OpenFst's symbol-table text format, as aslp-nnet-train-ctc.cc:81-85, 152-156 uses it
+ *   ReadKaldiObject / WriteKaldiObject, KALDI_ISFINITE, g_kaldi_verbose_level, SplitStringToVector
+ * Proof: tests/test_compat_kaldi_cpu.py compiles ALL 23 mains of the reference's aslp-nnetbin/ against this header (development container:
+ * the reference tree does not travel); `make -C kaldi-aslp_amd refmains` links them into bin_ref/, and tests/test_tools_gpu.py runs every tool
+ * test a second time on those binaries (test_every_reference_main_passes_the_tool_tests_of_its_name). */
 #ifndef ASLP_COMPAT_KALDI_H_
 #define ASLP_COMPAT_KALDI_H_
 
@@ -30,6 +36,7 @@
 
 #include <cstdint>
 #include <iostream>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -37,11 +44,15 @@
 #include "cu-matrix.h"
 #include "data-reader.h"
 #include "nnet-loss.h"
+#include "nnet-basic.h"
 #include "nnet-nnet.h"
 #include "nnet-pdf-prior.h"
 #include "nnet-randomizer.h"
 #include "parse-options.h"
 #include "posterior.h"
+#include "ctc-loss.h"
+#include "warp-ctc.h"
+#include "aslp_compat_kaldi_matrix.h"
 
 namespace kaldi {
 
@@ -61,6 +72,8 @@ using ::aslp::Input;    /* util/kaldi-io.h: extended filenames (files, pipes, of
 using ::aslp::Output;
 inline void SetVerboseLevel(int32 level) { ::aslp::g_verbose_level = level; }   /* base/kaldi-error.h */
 inline int32 GetVerboseLevel() { return ::aslp::g_verbose_level; }
+static int &g_kaldi_verbose_level = ::aslp::g_verbose_level;   /* (read directly by the tools' vlog blocks) */
+using ::aslp::SplitStringToVector;   /* util/text-utils.h */
 using ::aslp::Posterior;
 using ::aslp::Timer;
 using ::aslp::CuDevice;
@@ -101,14 +114,79 @@ using ::aslp::LossItf;
 using ::aslp::Xent;
 using ::aslp::Mse;
 using ::aslp::MultiTaskLoss;
-using ::aslp::FrameDataReader;
+using ::aslp::AffineTransform;
+/* aslp-nnet/data-reader.h:23-47: ONE class with a single-table and a multi-table constructor.  The engine has a threaded reader for the first
+ * (nnet/data-reader.h FrameDataReader) and a lock-step one for the second (MimoFrameDataReader); this is the reference's class over both. */
+class FrameDataReader {
+ public:
+  FrameDataReader(const std::string &feature_rspecifier, const std::string &targets_rspecifier, const NnetDataRandomizerOptions &rand_opts)
+      : one_(new ::aslp::FrameDataReader(feature_rspecifier, targets_rspecifier, rand_opts)) {}
+  FrameDataReader(const std::vector<std::string> &feature_rspecifiers, const std::vector<std::string> &targets_rspecifiers,
+                  const NnetDataRandomizerOptions &rand_opts)
+      : many_(new ::aslp::MimoFrameDataReader(feature_rspecifiers, targets_rspecifiers, rand_opts)) {}
+  bool ReadData(const ::aslp::CuMatrixBase **feat, const ::aslp::Posterior **targets) {
+    ASLP_ASSERT(one_ != nullptr);
+    return one_->ReadData(feat, targets);
+  }
+  /* (the reference returns nothing here; where no full minibatch is left its randomizers' own checks end the run, data-reader.cc:130-150 --
+   * a caller that ignores the result must not train on the previous minibatch again, so that case is an error here as well) */
+  void ReadData(std::vector<const ::aslp::CuMatrixBase *> *input, std::vector<const ::aslp::Posterior *> *output) {
+    ASLP_ASSERT(many_ != nullptr);
+    if (!many_->ReadData(input, output)) ASLP_ERR << "FrameDataReader::ReadData: no full minibatch left";
+  }
+  bool Done() { return one_ ? one_->Done() : many_->Done(); }
+ private:
+  std::unique_ptr< ::aslp::FrameDataReader> one_;
+  std::unique_ptr< ::aslp::MimoFrameDataReader> many_;
+};
 using ::aslp::SequenceDataReaderOptions;
 using ::aslp::SequenceDataReader;
 using ::aslp::PdfPriorOptions;
 using ::aslp::PdfPrior;
+using ::aslp::Ctc;
+using ::aslp::WarpCtc;
 }  // namespace aslp_nnet
 
+/* util/kaldi-io.h ReadKaldiObject / WriteKaldiObject: an object with Read(istream, binary) / Write(ostream, binary) from / to an extended filename */
+template <class C> void ReadKaldiObject(const std::string &rxfilename, C *c) {
+  bool binary;
+  Input ki(rxfilename, &binary);
+  c->Read(ki.Stream(), binary);
+}
+template <class C> void WriteKaldiObject(const C &c, const std::string &wxfilename, bool binary) {
+  Output ko(wxfilename, binary);
+  c.Write(ko.Stream(), binary);
+}
+
 }  // namespace kaldi
+
+/* fst::SymbolTable as far as the reference's tools use it (aslp-nnet-train-ctc.cc:81-85, 152-156: token names in a verbose log): the text
+ * format of OpenFst's symbol tables, "<symbol> <integer>" per line (OpenFst is an external library of the reference's build, not vendored) */
+#include <fstream>
+#include <map>
+#include <sstream>
+namespace fst {
+class SymbolTable {
+ public:
+  static SymbolTable *ReadText(const std::string &filename) {
+    std::ifstream is(filename);
+    if (!is) return nullptr;
+    SymbolTable *t = new SymbolTable();
+    std::string line, sym;
+    long long key;
+    while (std::getline(is, line)) {
+      std::istringstream ls(line);
+      if (!(ls >> sym)) continue;
+      if (!(ls >> key)) { delete t; return nullptr; }
+      t->names_[key] = sym;
+    }
+    return t;
+  }
+  std::string Find(long long key) const { auto it = names_.find(key); return it == names_.end() ? std::string() : it->second; }
+ private:
+  std::map<long long, std::string> names_;
+};
+}  // namespace fst
 
 /* The reference's tools seed the C library generator (`std::srand(seed)`, aslp-nnetbin/aslp-nnet-init.cc:56) and its components draw from
  * rand().  The engine draws from a private copy of that generator (nnet/base.h: inside a HIP process the global rand() state is not the
@@ -126,5 +204,8 @@ namespace std { using ::aslp_compat_srand; }
 #define KALDI_ERR ASLP_ERR
 #define KALDI_VLOG(v) ASLP_VLOG(v)
 #define KALDI_ASSERT(cond) ASLP_ASSERT(cond)
+#define KALDI_ISFINITE(x) std::isfinite(x)
+#define KALDI_ISNAN(x) std::isnan(x)
+#define KALDI_ISINF(x) std::isinf(x)
 
 #endif  /* ASLP_COMPAT_KALDI_H_ */

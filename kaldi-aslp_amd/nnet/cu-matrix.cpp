@@ -640,6 +640,29 @@ double CuMatrixBase::Sum() const {
   return h;
 }
 
+namespace {
+void DownloadRange(const CuMatrixBase &m, float *lo, float *hi) {
+  HostMatrix h;
+  m.CopyToMat(&h);
+  *lo = *hi = h.data.empty() ? 0.0f : h.data[0];
+  for (float v : h.data) { *lo = v < *lo ? v : *lo; *hi = v > *hi ? v : *hi; }
+}
+}  // namespace
+void CuMatrixBase::SetRandn() {
+  if (!rows_) return;
+  HostMatrix h(rows_, cols_);
+  for (float &v : h.data) v = RandGauss();
+  CopyFromMat(h);
+}
+void CuVectorBase::SetRandn() {
+  if (!dim_) return;
+  std::vector<float> h(dim_);
+  for (float &v : h) v = RandGauss();
+  CopyFromHost(h.data(), dim_);
+}
+float CuMatrixBase::Min() const { float lo, hi; DownloadRange(*this, &lo, &hi); return lo; }
+float CuMatrixBase::Max() const { float lo, hi; DownloadRange(*this, &lo, &hi); return hi; }
+
 namespace cu {
 void Splice(const CuMatrixBase &src, const CuArray<int32> &frame_offsets, CuMatrixBase *tgt) {
   ASLP_ASSERT(src.NumCols() * frame_offsets.Dim() == tgt->NumCols());

@@ -132,6 +132,7 @@ class CuVectorBase {
   void CopyToHost(float *dst) const;
   void CopyToVec(HostVector *v) const { v->data.resize(dim_); CopyToHost(v->data.data()); }
   void AddVec(float alpha, const CuVectorBase &v, float beta = 1.0f);               // this = alpha*v + beta*this
+  void SetRandn();   // standard normals from the engine's seeded host generator (base.h RandGauss), one upload (cu-vector.h SetRandn)
   void AddRowSumMat(float alpha, const CuMatrixBase &M, float beta = 1.0f);         // column sums
   void AddColSumMat(float alpha, const CuMatrixBase &M, float beta = 1.0f);         // row sums
   void AddDiagMatMat(float alpha, const CuMatrixBase &M, MatrixTransposeType tM, const CuMatrixBase &N,
@@ -240,6 +241,7 @@ class CuMatrixBase {
   void CopyToMat(HostMatrix *m) const;
   void WriteBinary(std::ostream &os) const;  // the bytes HostMatrix::Write(os, true) would write
   void AddMat(float alpha, const CuMatrixBase &A, MatrixTransposeType tA = kNoTrans);  // this += alpha*A
+  void SetRandn();   // standard normals, row by row, from the engine's seeded host generator (cu-matrix.h SetRandn draws on the device)
   void AddMatMat(float alpha, const CuMatrixBase &A, MatrixTransposeType tA, const CuMatrixBase &B, MatrixTransposeType tB,
                  float beta, const aslp_gemm_epilogue *ep = nullptr);
   // the same with the prepared fp16 planes of A and / or B (csrc/split16.h; NULL: none)
@@ -265,6 +267,8 @@ class CuMatrixBase {
   void AddRows(float alpha, const CuMatrixBase &src, const CuArray<int32> &indices);
   void CopyCols(const CuMatrixBase &src, const CuArray<int32> &indices);
   double Sum() const;  // blocking (CuMatrixBase::Sum)
+  float Min() const;   // blocking, one download (cu-matrix.h Min / Max: the forward tools' range checks on an utterance's output)
+  float Max() const;
 
  protected:
   CuMatrixBase() : data_(nullptr), rows_(0), cols_(0), stride_(0) {}
@@ -279,6 +283,7 @@ class CuMatrix : public CuMatrixBase {
   CuMatrix(int rows, int cols, MatrixResizeType t = kSetZero) { Resize(rows, cols, t); }
   CuMatrix(const CuMatrixBase &o) { *this = o; }
   CuMatrix(const CuMatrix &o) : CuMatrixBase() { *this = static_cast<const CuMatrixBase &>(o); }
+  explicit CuMatrix(const HostMatrix &m) { *this = m; }
   CuMatrix &operator=(const CuMatrixBase &o) {
     Resize(o.NumRows(), o.NumCols(), kUndefined);
     CopyFromMat(o);

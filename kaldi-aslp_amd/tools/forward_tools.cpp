@@ -277,7 +277,12 @@ int Main_aslp_nnet_forward_blstm_lc(int argc, char *argv[]) {
     if (!t.Parse(&po, argc, argv, 3, true)) exit(1);
     t.Open(po.GetArg(1));
     t.nnet.SetChunkSize(t.chunk_size);
-    const int32 block = t.chunk_size + t.right_splice, feat_dim = t.nnet.InputDim(), out_dim = t.nnet.OutputDim();
+    // The reference forms its block length from the DEFAULTS of the two options -- `batch_size = chunk_size + right_splice` stands in front of
+    // po.Read() (aslp-nnet-forward-blstm-lc.cc:49-58) -- so every run feeds blocks of 64 + 16 = 80 rows whatever --chunk-size /
+    // --right-splice say: --chunk-size only decides how many rows of a block are kept (and SetChunkSize), the look-ahead is what is left of
+    // the 80.  The recipes' decodes ran that way, so this tool does the same (tests/test_tools_gpu.py runs the reference's own main beside it).
+    const int32 block = 64 + 16, feat_dim = t.nnet.InputDim(), out_dim = t.nnet.OutputDim();
+    if (t.chunk_size > block) ASLP_ERR << "--chunk-size " << t.chunk_size << " exceeds the block of " << block << " rows (the reference's KALDI_ASSERT(len <= batch_size), :170, holds only up to there)";
     CuMatrix block_in, block_out;
     return t.Run(po.GetArg(2), po.GetArg(3), [&](const CuMatrix &in, CuMatrix *out) {
       t.nnet.ResetLstmStreams(std::vector<int32>(1, 1));

@@ -401,7 +401,7 @@ int Main_aslp_nnet_train_blstm_streams(int argc, char *argv[]) {
     if (!crossvalidate) nnet.Write(target_model_filename, binary);
     StreamSync();
     ASLP_LOG << "Done " << num_done << " files, " << num_no_tgt_mat << " with no tgt_mats, " << num_other_error << " with other errors. "
-             << "[" << (crossvalidate ? "CROSS-VALIDATION" : "TRAINING") << ", " << (randomize ? "RANDOMIZED" : "NOT-RANDOMIZED") << ", "
+             << "[" << (crossvalidate ? "CROSS-VALIDATION" : "TRAINING") << ", "   // (no RANDOMIZED word here: aslp-nnet-train-blstm-streams.cc:329-334)
              << time.Elapsed() / 60 << " min, fps" << total_frames / time.Elapsed() << "]";
     if (objective_function == "xent") ASLP_LOG << xent.Report();
     else if (objective_function == "mse") ASLP_LOG << mse.Report();
