@@ -1,0 +1,351 @@
+"""Differential test of the engine's command-line tools against the REFERENCE's own main() functions (seam B7 / B4).
+
+kaldi-aslp_amd/bin_ref/<tool> is src/aslp-nnetbin/<tool>.cc of the reference, compiled unchanged against include/aslp_compat_kaldi.h and
+linked with this engine (`make -C kaldi-aslp_amd refmains`, development container; the binaries travel, the sources do not);
+kaldi-aslp_amd/bin/<tool> is the engine's own tool of that name.  Both sit on the same library, so whatever differs between their outputs
+is a difference in the TOOL's logic -- option handling, utterance bookkeeping, padding, learning-rate arithmetic, what is logged.  Every
+case below runs both on the same inputs with the same flags (option combinations the per-tool tests do not reach: cross-validation,
+frame / utterance weights, --drop-len, --skip-width, --frame-limit, --length-tolerance, text models, feature transforms, priors ...)
+and wants the written models / archives byte for byte and the log lines the schedulers read (AvgLoss, FRAME_ACCURACY, TOKEN_ACCURACY,
+Done ...) word for word, times aside."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import kaldi_formats as kf
+from test_tools_gpu import BLSTM_PROTO, CTC_PROTO, FSMN_PROTO, LC_PROTO, LSTM_PROTO, PROTO
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OWN = os.path.join(ROOT, "kaldi-aslp_amd", "bin")
+REF = os.path.join(ROOT, "kaldi-aslp_amd", "bin_ref")
+
+
+def run(bindir, name, args, ok=True):
+    p = subprocess.run([os.path.join(bindir, name)] + list(args), capture_output=True, timeout=1800)
+    if ok:
+        assert p.returncode == 0, "%s/%s %s\n%s" % (os.path.basename(bindir), name, " ".join(args), p.stderr.decode()[-3000:])
+    return p
+
+
+READ_BY_SCHEDULERS = re.compile(r"AvgLoss|FRAME_ACCURACY|TOKEN_ACCURACY|Done |Obj\(log\[Pzx\]\)|progress: \[")
+
+
+def log_lines(stderr):
+    """the lines a scheduler (or a person) reads, without the `LOG (tool:function():file:line)` tag, with times and rates masked"""
+    out = []
+    for ln in stderr.decode(errors="replace").splitlines():
+        ln = re.sub(r"^(LOG|WARNING|VLOG\[\d+\]) \(\S+\)\s*", "", ln)
+        if not READ_BY_SCHEDULERS.search(ln):
+            continue
+        ln = re.sub(r"[-+0-9.e]+ ?min", "<t> min", ln)
+        ln = re.sub(r"fps ?[-+0-9.einfa]+", "fps<r>", ln)
+        ln = re.sub(r"in [-+0-9.e]+min", "in <t>min", ln)
+        ln = re.sub(r"Time\[[^\]]*\]|\[[-+0-9.e]+ ?s\]", "<t>", ln)
+        out.append(ln.rstrip())
+    return out
+
+
+@pytest.fixture(scope="module")
+def corpus(tmp_path_factory):
+    """one set of small tables for every case: 12-dim features of 9 utterances (one without targets, one far too long), posteriors over 10
+    classes, frame weights, utterance weights, CTC label sequences over 8 tokens + blank; 20-dim features / 30 classes for the DNN"""
+    if not (os.path.isdir(REF) and len(os.listdir(REF)) >= 23):
+        pytest.skip("bin_ref/ not built (needs the reference tree: make -C kaldi-aslp_amd refmains)")
+    d = tmp_path_factory.mktemp("refdiff")
+    rng = np.random.default_rng(2026)
+    keys = ["u%02d" % i for i in range(9)]
+    lens = [23, 7, 41, 12, 30, 5, 18, 64, 27]
+    c = {"dir": d, "keys": keys, "lens": lens}
+    for tag, dim, ncls in (("s", 12, 10), ("d", 20, 30)):
+        feats = [rng.standard_normal((n, dim)).astype(np.float32) for n in lens]
+        posts = [[[(int(rng.integers(0, ncls)), 1.0)] for _ in range(n)] for n in lens]
+        (d / (tag + "_feats.ark")).write_bytes(kf.archive([(k, kf.matrix_bin(f)) for k, f in zip(keys, feats)]))
+        (d / (tag + "_post.ark")).write_bytes(kf.archive([(k, kf.posterior_bin(p)) for k, p in zip(keys, posts) if k != "u05"]))   # u05: no targets
+        posts[2], posts[6] = posts[2][:-2], posts[6][:-9]   # two frames short: inside the default --length-tolerance of 5; nine: outside
+        (d / (tag + "_postshort.ark")).write_bytes(kf.archive([(k, kf.posterior_bin(p)) for k, p in zip(keys, posts) if k != "u05"]))
+        tgts = [rng.uniform(0.05, 0.95, (n, ncls)).astype(np.float32) for n in lens]   # aslp-nnet-train-mse reads its targets as matrices
+        (d / (tag + "_tgt.ark")).write_bytes(kf.archive([(k, kf.matrix_bin(t)) for k, t in zip(keys, tgts)]))   # (read in lock step with the features: same keys)
+        tgts[2], tgts[6] = tgts[2][:-2], tgts[6][:-9]
+        (d / (tag + "_tgtshort.ark")).write_bytes(kf.archive([(k, kf.matrix_bin(t)) for k, t in zip(keys, tgts)]))
+        wts = [rng.choice(np.array([0.0, 1.0, 1.0, 0.5], np.float32), n) for n in lens]
+        (d / (tag + "_fw.ark")).write_bytes(kf.archive([(k, kf.vector_bin(w)) for k, w in zip(keys, wts)]))
+    (d / "uw.ark").write_bytes(kf.archive([(k, b"\0B" + b"\x04" + np.float32(0.5 + 0.25 * (i % 3)).tobytes()) for i, k in enumerate(keys)]))
+    labels = [[int(x) for x in rng.integers(1, 9, max(1, n // 5))] for n in lens]
+    (d / "lab.ark").write_bytes(kf.archive([(k, kf.int32vec_bin(l)) for k, l in zip(keys, labels) if k != "u05"]))
+    (d / "tokens.txt").write_text("".join("tok%d %d\n" % (i, i) for i in range(9)))
+    (d / "counts").write_text("[ " + " ".join(str(int(x)) for x in rng.integers(1, 500, 30)) + " ]\n")
+    (d / "counts10").write_text("[ " + " ".join(str(int(x)) for x in rng.integers(1, 500, 10)) + " ]\n")
+    protos = {"dnn": PROTO, "lstm": LSTM_PROTO, "blstm": BLSTM_PROTO, "lc": LC_PROTO, "ctc": CTC_PROTO, "fsmn": FSMN_PROTO,
+              "uctc": LSTM_PROTO.replace("<OutputDim> 10", "<OutputDim> 9").replace("<InputDim> 10", "<InputDim> 9"),   # one utterance at a time
+              "tr": "<NnetProto>\n<AffineTransform> <InputDim> 12 <OutputDim> 12 <BiasMean> 0.0 <BiasRange> 0.1 <ParamStddev> 0.5\n</NnetProto>\n",
+              "mse": "<NnetProto>\n<AffineTransform> <InputDim> 12 <OutputDim> 10 <BiasMean> 0.0 <BiasRange> 0.0 <ParamStddev> 0.2\n"
+                     "<Sigmoid> <InputDim> 10 <OutputDim> 10\n</NnetProto>\n"}
+    for i, (name, text) in enumerate(sorted(protos.items())):
+        (d / (name + ".proto")).write_text(text)
+        run(OWN, "aslp-nnet-init", ["--seed=%d" % (100 + i), str(d / (name + ".proto")), str(d / (name + ".nnet"))])
+    return c
+
+
+def both(corpus, name, flags, inputs, outputs=("model",), tag=""):
+    """runs bin/<name> and bin_ref/<name>; `outputs`: "model" (a file path appended last) or "ark" (an ark: wspecifier appended last)"""
+    d = corpus["dir"]
+    res = {}
+    for side, bindir in (("own", OWN), ("ref", REF)):
+        outs = []
+        for kind in outputs:
+            path = str(d / ("%s%s.%s.%s" % (name, tag, side, kind)))
+            if os.path.exists(path):
+                os.remove(path)
+            outs.append("ark:" + path if kind == "ark" else path)
+        extra = ["--use-gpu=yes"] if name.startswith("aslp-nnet-forward") else []   # (the reference's forward tools default to "no")
+        p = run(bindir, name, extra + list(flags) + list(inputs) + outs)
+        res[side] = (p, [o[4:] if o.startswith("ark:") else o for o in outs])
+    (po, fo), (pr, fr) = res["own"], res["ref"]
+    for a, b in zip(fo, fr):
+        assert os.path.exists(a) == os.path.exists(b), (a, b)
+        if os.path.exists(a):
+            assert open(a, "rb").read() == open(b, "rb").read(), "%s %s: %s differs from the reference main's" % (name, " ".join(flags), os.path.basename(a))
+    return log_lines(po.stderr), log_lines(pr.stderr), po, pr
+
+
+def tables(corpus, tag, *names):
+    d = corpus["dir"]
+    return ["ark:%s" % (d / ("%s_%s.ark" % (tag, n))) for n in names]
+
+
+FRAME_FLAGS = [
+    [],
+    ["--cross-validate=true"],
+    ["--randomize=false", "--minibatch-size=16"],
+    ["--momentum=0.9", "--l2-penalty=1e-4", "--l1-penalty=1e-6", "--randomizer-seed=5", "--randomizer-size=64", "--minibatch-size=8"],
+    ["--binary=false", "--dropout-retention=1.0", "--report-period=40"],
+]
+
+
+@pytest.mark.parametrize("flags", FRAME_FLAGS, ids=lambda f: " ".join(f) or "defaults")
+def test_train_frame(corpus, flags):
+    d = corpus["dir"]
+    flags = ["--learn-rate=0.01", "--minibatch-size=32"] + flags if not any("minibatch" in f for f in flags) else ["--learn-rate=0.01"] + flags
+    cv = "--cross-validate=true" in flags
+    lo, lr, _, _ = both(corpus, "aslp-nnet-train-frame", flags, tables(corpus, "d", "feats", "post") + [str(d / "dnn.nnet")], () if cv else ("model",),
+                        tag=str(abs(hash(tuple(flags))) % 997))
+    assert lo == lr and any("AvgLoss" in x for x in lo)
+
+
+SIMPLE_FLAGS = [
+    [],
+    ["--cross-validate=true"],
+    ["--frame-weights=ark:{d}/d_fw.ark"],
+    ["--utt-weights=ark:{d}/uw.ark", "--randomize=false"],
+    ["--frame-weights=ark:{d}/d_fw.ark", "--utt-weights=ark:{d}/uw.ark", "--length-tolerance=1"],
+    ["--objective-function=mse", "--learn-rate=0.001"],
+    ["--objective-function=multitask,xent,20,1.0,mse,10,0.1", "--learn-rate=0.001"],
+]
+
+
+@pytest.mark.parametrize("tool_name", ["aslp-nnet-train-simple", "aslp-nnet-train-mse"])
+@pytest.mark.parametrize("flags", SIMPLE_FLAGS, ids=lambda f: " ".join(x.replace("{d}/", "") for x in f) or "defaults")
+def test_train_simple_and_mse(corpus, tool_name, flags):
+    d = corpus["dir"]
+    if tool_name.endswith("mse") and any("multitask" in f for f in flags):
+        pytest.skip("aslp-nnet-train-mse has no multitask objective")
+    flags = ["--learn-rate=0.01", "--minibatch-size=16", "--randomizer-size=100"] + [f.format(d=d) for f in flags]
+    cv = "--cross-validate=true" in flags
+    post = "postshort" if any("utt-weights" in f for f in flags) else "post"   # (some cases on targets that are a few frames short or far too short)
+    if tool_name.endswith("mse"):
+        post = post.replace("post", "tgt")
+    lo, lr, _, _ = both(corpus, tool_name, flags, tables(corpus, "d", "feats", post) + [str(d / "dnn.nnet")], () if cv else ("model",),
+                        tag=str(abs(hash(tuple(flags))) % 997))
+    assert lo == lr and any("AvgLoss" in x for x in lo)
+
+
+def test_train_simple_with_a_feature_transform(corpus):
+    d = corpus["dir"]
+    for flags in (["--feature-transform=%s" % (d / "tr.nnet")], ["--feature-transform=%s" % (d / "tr.nnet"), "--objective-function=mse"]):
+        lo, lr, _, _ = both(corpus, "aslp-nnet-train-simple", ["--learn-rate=0.005", "--minibatch-size=16"] + flags,
+                            tables(corpus, "s", "feats", "post") + [str(d / "mse.nnet")], tag="tr%d" % len(flags))
+        assert lo == lr
+
+
+def test_train_perutt(corpus):
+    d = corpus["dir"]
+    for i, flags in enumerate(([], ["--cross-validate=true"], ["--frame-weights=ark:%s" % (d / "s_fw.ark")], ["--drop-len=40"], ["--randomize=false", "--length-tolerance=1"])):
+        cv = "--cross-validate=true" in flags
+        lo, lr, _, _ = both(corpus, "aslp-nnet-train-perutt", ["--learn-rate=0.5", "--momentum=0.9"] + flags,
+                            tables(corpus, "s", "feats", "postshort" if i >= 2 else "post") + [str(d / "fsmn.nnet")], () if cv else ("model",), tag="p%d" % i)
+        assert lo == lr and any("AvgLoss" in x for x in lo)
+
+
+STREAM_FLAGS = [
+    ["--num-stream=3", "--batch-size=5", "--targets-delay=2"],
+    ["--num-stream=2", "--batch-size=7", "--targets-delay=0", "--cross-validate=true"],
+    ["--num-stream=4", "--batch-size=4", "--targets-delay=3", "--report-period=3", "--momentum=0.9"],
+    ["--num-stream=3", "--batch-size=6", "--drop-len=40"],
+]
+
+
+@pytest.mark.parametrize("flags", STREAM_FLAGS, ids=lambda f: " ".join(f))
+def test_train_lstm_streams(corpus, flags):
+    d = corpus["dir"]
+    cv = "--cross-validate=true" in flags
+    lo, lr, _, _ = both(corpus, "aslp-nnet-train-lstm-streams", ["--learn-rate=0.02"] + flags, tables(corpus, "s", "feats", "post") + [str(d / "lstm.nnet")],
+                        () if cv else ("model",), tag=str(abs(hash(tuple(flags))) % 997))
+    # (the reference's main forms its final report and drops it, aslp-nnet-train-lstm-streams.cc:221; the engine's tool logs it: one line more)
+    final = [x for x in lo if x not in lr]
+    assert [x for x in lo if x not in final] == lr and len(final) <= 2
+
+
+@pytest.mark.parametrize("flags", [f + ["--skip-width=%d" % w] for f in STREAM_FLAGS[:3] for w in (1, 3)], ids=lambda f: " ".join(f))
+def test_train_lstm_streams_skip(corpus, flags):
+    d = corpus["dir"]
+    cv = "--cross-validate=true" in flags
+    lo, lr, _, _ = both(corpus, "aslp-nnet-train-lstm-streams-skip", ["--learn-rate=0.02"] + flags, tables(corpus, "s", "feats", "post") + [str(d / "lstm.nnet")],
+                        () if cv else ("model",), tag=str(abs(hash(tuple(flags))) % 997))
+    assert lo == lr
+
+
+BLSTM_FLAGS = [
+    ["--num-stream=3"],
+    ["--num-stream=2", "--cross-validate=true"],
+    ["--num-stream=4", "--frame-limit=100"],
+    ["--num-stream=3", "--frame-weights=ark:{d}/s_fw.ark", "--momentum=0.9"],
+    ["--num-stream=3", "--length-tolerance=1"],
+    ["--num-stream=2", "--report-period=2", "--objective-function=xent"],
+]
+
+
+@pytest.mark.parametrize("tool_name", ["aslp-nnet-train-blstm-streams", "aslp-nnet-train-blstm-parallel"])
+@pytest.mark.parametrize("flags", BLSTM_FLAGS, ids=lambda f: " ".join(x.replace("{d}/", "") for x in f))
+def test_train_blstm_whole_utterances(corpus, tool_name, flags):
+    d = corpus["dir"]
+    flags = [f.format(d=d) for f in flags]
+    cv = "--cross-validate=true" in flags
+    post = "postshort" if any("length-tolerance" in f or "frame-weights" in f for f in flags) else "post"
+    lo, lr, _, _ = both(corpus, tool_name, ["--learn-rate=0.2" if tool_name.endswith("streams") else "--learn-rate=0.002"] + flags,
+                        tables(corpus, "s", "feats", post) + [str(d / "blstm.nnet")], () if cv else ("model",), tag=str(abs(hash(tuple(flags))) % 997))
+    assert lo == lr and any("AvgLoss" in x for x in lo)
+
+
+@pytest.mark.parametrize("flags", [["--skip-width=2", "--num-stream=3"], ["--drop-len=40", "--num-stream=3"], ["--drop-len=25", "--num-stream=2", "--skip-width=3"]],
+                         ids=lambda f: " ".join(f))
+def test_train_blstm_streams_skip_and_drop(corpus, flags):
+    """--drop-len in this tool steps over the utterance AFTER a dropped one as well (feature_reader.Next() in front of `continue`,
+    aslp-nnet-train-blstm-streams.cc:165-169): whatever the reference's loop does with that, the engine's does"""
+    d = corpus["dir"]
+    lo, lr, _, _ = both(corpus, "aslp-nnet-train-blstm-streams", ["--learn-rate=0.2"] + flags, tables(corpus, "s", "feats", "post") + [str(d / "blstm.nnet")],
+                        tag=str(abs(hash(tuple(flags))) % 997))
+    assert lo == lr
+
+
+LC_FLAGS = [
+    ["--num-stream=3", "--chunk-size=6", "--right-splice=3"],
+    ["--num-stream=2", "--chunk-size=8", "--right-splice=4", "--cross-validate=true"],
+    ["--num-stream=3", "--chunk-size=6", "--right-splice=3", "--drop-len=40", "--momentum=0.9"],
+    ["--num-stream=4", "--chunk-size=5", "--right-splice=2", "--report-period=3"],
+]
+
+
+@pytest.mark.parametrize("flags", LC_FLAGS, ids=lambda f: " ".join(f))
+def test_train_blstm_streams_lc(corpus, flags):
+    d = corpus["dir"]
+    cv = "--cross-validate=true" in flags
+    lo, lr, _, _ = both(corpus, "aslp-nnet-train-blstm-streams-lc", ["--learn-rate=0.02"] + flags, tables(corpus, "s", "feats", "post") + [str(d / "lc.nnet")],
+                        () if cv else ("model",), tag=str(abs(hash(tuple(flags))) % 997))
+    assert lo == lr and any("AvgLoss" in x for x in lo)
+
+
+CTC_FLAGS = [
+    ["--num-stream=3"],
+    ["--num-stream=2", "--cross-validate=true"],
+    ["--num-stream=4", "--frame-limit=100", "--momentum=0.9"],
+    ["--num-stream=3", "--drop-len=40", "--report-step=2"],
+    ["--num-stream=3", "--skip-width=2"],
+]
+
+
+@pytest.mark.parametrize("tool_name", ["aslp-nnet-train-ctc-streams", "aslp-nnet-train-warp-ctc-streams"])
+@pytest.mark.parametrize("flags", CTC_FLAGS, ids=lambda f: " ".join(f))
+def test_train_ctc_streams(corpus, tool_name, flags):
+    d = corpus["dir"]
+    cv = "--cross-validate=true" in flags
+    lo, lr, _, _ = both(corpus, tool_name, ["--learn-rate=0.05"] + flags, ["ark:%s" % (d / "s_feats.ark"), "ark:%s" % (d / "lab.ark"), str(d / "ctc.nnet")],
+                        () if cv else ("model",), tag=str(abs(hash(tuple(flags))) % 997))
+    assert lo == lr and any("TOKEN_ACCURACY" in x or "Obj" in x for x in lo)
+
+
+def test_train_ctc_one_utterance_at_a_time(corpus):
+    d = corpus["dir"]
+    for i, flags in enumerate(([], ["--cross-validate=true"], ["--drop-len=40", "--report-step=2", "--token-symbol-table=%s" % (d / "tokens.txt")])):
+        cv = "--cross-validate=true" in flags
+        lo, lr, po, pr = both(corpus, "aslp-nnet-train-ctc", ["--learn-rate=0.001", "--momentum=0.9"] + flags,
+                              ["ark:%s" % (d / "s_feats.ark"), "ark:%s" % (d / "lab.ark"), str(d / "uctc.nnet")], () if cv else ("model",), tag="c%d" % i)
+        assert lo == lr
+        if i == 2:   # the hypotheses' token names, one line per utterance
+            hyp = lambda p: [ln for ln in p.stderr.decode().splitlines() if re.match(r"u\d\d( tok\d)*\s*$", ln)]
+            assert hyp(po) == hyp(pr) and len(hyp(po)) >= 6
+
+
+FORWARD_FLAGS = [
+    ["--apply-log=false"],
+    [],
+    ["--no-softmax=true", "--apply-log=false"],
+    ["--class-frame-counts={d}/counts", "--prior-scale=0.8"],
+    ["--no-softmax=true", "--apply-log=false", "--class-frame-counts={d}/counts", "--prior-floor=1e-3"],
+    ["--time-shift=2", "--apply-log=false"],
+    ["--skip-width=3", "--apply-log=false"],
+]
+
+
+@pytest.mark.parametrize("flags", FORWARD_FLAGS, ids=lambda f: " ".join(x.replace("{d}/", "") for x in f) or "defaults")
+def test_forward(corpus, flags):
+    d = corpus["dir"]
+    flags = [f.format(d=d) for f in flags]
+    lo, lr, _, _ = both(corpus, "aslp-nnet-forward", flags, [str(d / "dnn.nnet"), "ark:%s" % (d / "d_feats.ark")], ("ark",), tag=str(abs(hash(tuple(flags))) % 997))
+    assert lo == lr
+
+
+def test_forward_recurrent_and_ctc_options(corpus):
+    d = corpus["dir"]
+    cases = [("aslp-nnet-forward", ["--apply-log=false"], "lstm"), ("aslp-nnet-forward", ["--apply-log=false", "--feature-transform=%s" % (d / "tr.nnet")], "blstm"),
+             ("aslp-nnet-forward", ["--add-softmax=true", "--apply-log=true", "--scale-blank=0.5"], "ctc"),
+             ("aslp-nnet-forward-skip", ["--skip-width=2", "--apply-log=false"], "lstm"), ("aslp-nnet-forward-skip", ["--skip-width=3", "--add-softmax=true", "--scale-blank=1.5"], "ctc"),
+             ("aslp-nnet-forward-skip", ["--skip-width=1", "--class-frame-counts=%s" % (d / "counts10")], "blstm"),
+             ("aslp-nnet-forward-blstm-lc", ["--apply-log=false"], "lc"), ("aslp-nnet-forward-blstm-lc", ["--chunk-size=16", "--right-splice=8"], "lc"),
+             ("aslp-nnet-forward-blstm-lc", ["--chunk-size=6", "--right-splice=3", "--class-frame-counts=%s" % (d / "counts10")], "lc")]
+    for i, (name, flags, net) in enumerate(cases):
+        lo, lr, _, _ = both(corpus, name, flags, [str(d / (net + ".nnet")), "ark:%s" % (d / "s_feats.ark")], ("ark",), tag="f%d" % i)
+        assert lo == lr, (name, flags)
+
+
+def test_model_tools(corpus):
+    d = corpus["dir"]
+    for i, (name, flags, inputs) in enumerate([
+            ("aslp-nnet-copy", ["--binary=false"], [str(d / "dnn.nnet")]),
+            ("aslp-nnet-copy", [], [str(d / "lc.nnet")]),
+            ("aslp-nnet-convert-to-standard", [], [str(d / "dnn.nnet")]),
+            ("aslp-nnet-convert-to-standard", ["--binary=false"], [str(d / "fsmn.nnet")]),
+            ("aslp-nnet-init", ["--seed=9"], [str(d / "blstm.proto")]),
+            ("aslp-nnet-init", ["--seed=9", "--binary=false"], [str(d / "fsmn.proto")]),
+            ("aslp-nnet-dot", [], [str(d / "dnn.nnet")])]):
+        both(corpus, name, flags, inputs, tag="m%d" % i)
+    # aslp-nnet-insert: the hidden layer of a second net in front of the last updatable component, which is drawn afresh unless told not to
+    (d / "base.proto").write_text("<NnetProto>\n<AffineTransform> <InputDim> 10 <OutputDim> 64 <BiasMean> -2.0 <BiasRange> 4.0 <ParamStddev> 0.1\n"
+                                  "<Sigmoid> <InputDim> 64 <OutputDim> 64\n<AffineTransform> <InputDim> 64 <OutputDim> 5 <BiasMean> 0.0 <BiasRange> 0.0 <ParamStddev> 0.1\n"
+                                  "<Softmax> <InputDim> 5 <OutputDim> 5\n</NnetProto>\n")
+    (d / "hid.proto").write_text("<NnetProto>\n<AffineTransform> <InputDim> 64 <OutputDim> 64 <BiasMean> -2.0 <BiasRange> 4.0 <ParamStddev> 0.1\n"
+                                 "<Sigmoid> <InputDim> 64 <OutputDim> 64\n</NnetProto>\n")
+    run(OWN, "aslp-nnet-init", ["--seed=1", str(d / "base.proto"), str(d / "base.nnet")])
+    run(OWN, "aslp-nnet-init", ["--seed=2", str(d / "hid.proto"), str(d / "hid.nnet")])
+    both(corpus, "aslp-nnet-insert", ["--randomize-next-component=false"], [str(d / "base.nnet"), str(d / "hid.nnet")], tag="i0")
+    # (with the component drawn afresh the two are not comparable byte for byte: the reference's main registers --srand and never uses it -- its
+    # normals come from the device generator -- while the engine's tool seeds its host generator with it; what both must say is what they did)
+    for bindir in (OWN, REF):
+        p = run(bindir, "aslp-nnet-insert", ["--stddev-factor=0.2", "--srand=5", str(d / "base.nnet"), str(d / "hid.nnet"), str(d / "ins.rand.nnet")])
+        assert b"Inserted 2 components at position 3" in p.stderr and b"Randomized component index 5 with stddev 0.025" in p.stderr
+    both(corpus, "aslp-nnet-insert", ["--insert-at=3", "--randomize-next-component=false", "--binary=false"], [str(d / "base.nnet"), "cat %s |" % (d / "hid.nnet")], tag="i2")
+    for net in ("dnn", "lstm", "blstm", "lc", "ctc", "fsmn"):
+        assert run(OWN, "aslp-nnet-info", [str(d / (net + ".nnet"))]).stdout == run(REF, "aslp-nnet-info", [str(d / (net + ".nnet"))]).stdout
