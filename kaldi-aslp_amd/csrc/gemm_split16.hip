@@ -1209,7 +1209,8 @@ bool PlaneSet::ConvertFrom(const float *src, int rows, int cols, int stride) {
   return ConvertWithParts(src, rows, cols, stride, kS16ConvParts);
 }
 // several matrices in one maximum launch and one conversion launch (the recurrent layers convert up to seven small tensors at a time)
-bool PlaneSet::ConvertMany(const ConvertSpec *specs, int n) {
+bool PlaneSet::ConvertMany(const ConvertSpec *specs, int n, const SeqFillJob *fill, bool *fill_done) {
+  if (fill_done) *fill_done = false;
   if (n <= 0 || n > kS16MaxJobs) return false;
   MaxJobs ms;
   ConvJobs js;
@@ -1235,7 +1236,10 @@ bool PlaneSet::ConvertMany(const ConvertSpec *specs, int n) {
       const bool given = c.parts != nullptr && c.nparts > 0 && c.nparts <= kS16MaxParts;
       cj[i] = CoopConvJob{c.src, c.stride, nullptr, 0, c.planes->View(), given ? c.parts : nullptr, given ? c.nparts : 0};
     }
-    if (coop_convert_launch(cj, n)) return true;
+    if (coop_convert_launch(cj, n, fill)) {
+      if (fill_done) *fill_done = fill != nullptr;
+      return true;
+    }
   }
   if (need_max) hipLaunchKernelGGL(s16_absmax_kernel, dim3(kS16ConvParts, n), dim3(256), 0, cur_stream(), ms, tw_log2_for(max_c4));
   hipLaunchKernelGGL(split16_convert_kernel, dim3(std::min(max_rows, 512), n), dim3(256), 0, cur_stream(), js, tw_log2_for(max_k8));

@@ -641,8 +641,12 @@ __device__ __forceinline__ float coop_grid_max(float wg_max, unsigned long long 
 // matrix whose bound is given (parts) takes it from there.
 struct CoopConvJobs { CoopConvJob j[kS16MaxJobs]; };
 template <int U>
-__global__ void __launch_bounds__(kPanelThreads) copy_planes_coop(CoopConvJobs jobs, unsigned long long *gmax, unsigned token, unsigned *err) {
+__global__ void __launch_bounds__(kPanelThreads) copy_planes_coop(CoopConvJobs jobs, unsigned long long *gmax, unsigned token, unsigned *err, SeqFillJob fill) {
   __shared__ float red[kPanelWaves];
+  if (fill.buf0 != nullptr) {   // (uniform) a recurrent layer's buffer preparation rides along: stores only, spread over the launch's workgroups
+    const int per = (fill.T + 2) * fill.S, nb = (int)(gridDim.x * gridDim.y);
+    for (int r = (int)(blockIdx.y * gridDim.x + blockIdx.x); r < 2 * per; r += nb) seq_fill_row(fill, r % per, r / per);
+  }
   const CoopConvJob job = jobs.j[blockIdx.y];
   const int rows = job.pl.rows, cols = job.pl.cols, c4 = cols >> 2, units = rows * c4;
   float4 v[U];
@@ -1248,7 +1252,7 @@ __global__ void xent_apply_kernel(const double *sums, int batches, double *stats
 
 static bool g_coop_convert_on = true;   // aslp_coop_convert (tests: the two-launch conversion as the reference)
 // split16.h: (optional copy and) planes of n matrices in one launch; false = not served, nothing was launched
-bool coop_convert_launch(const CoopConvJob *jobs, int n) {
+bool coop_convert_launch(const CoopConvJob *jobs, int n, const SeqFillJob *fill) {
   static const bool off = [] { const char *e = getenv("ASLP_COPY_PLANES"); return e != nullptr && e[0] == '0'; }();   // A/B switch
   // Not beside the main stream: a launch there may share the chip with a persistent recurrence whose workgroups need every CU (each
   // would wait for workgroups the other keeps from being placed), and two launches of this thread would meet in one exchange area.
@@ -1275,7 +1279,9 @@ bool coop_convert_launch(const CoopConvJob *jobs, int n) {
   }
   if (U == 0) return false;
   if (++st.token == 0) st.token = 1;
-#define ASLP_COPY_PLANES(UU) hipLaunchKernelGGL((copy_planes_coop<UU>), dim3(gx, n), dim3(kPanelThreads), 0, cur_stream(), js, st.gmax, st.token, st.err)
+  SeqFillJob fj = {nullptr, nullptr, 0, 0, 0, 0, 0, nullptr, 0, 0};
+  if (fill) fj = *fill;
+#define ASLP_COPY_PLANES(UU) hipLaunchKernelGGL((copy_planes_coop<UU>), dim3(gx, n), dim3(kPanelThreads), 0, cur_stream(), js, st.gmax, st.token, st.err, fj)
   if (U == 4) ASLP_COPY_PLANES(4); else if (U == 8) ASLP_COPY_PLANES(8); else ASLP_COPY_PLANES(16);
 #undef ASLP_COPY_PLANES
   check_launch("coop_convert");

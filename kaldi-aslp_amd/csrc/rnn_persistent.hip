@@ -46,6 +46,7 @@
 #include "aslp_kernels.h"
 #include "common.h"
 #include "scratch.h"
+#include "split16.h"   // SeqFillJob / seq_fill_row: the buffer preparation a conversion launch can take along
 
 namespace aslp {
 void register_async_error_word(const volatile unsigned *host_word, const char *what);  // runtime.cpp
@@ -1667,20 +1668,8 @@ __global__ void __launch_bounds__(256) lstm_seq_vec_grads_kernel(SeqVecGradPair 
 // copied into row block 0 of buffer 0 instead of zeros -- the history the forward direction of a stream-carrying layer starts from.
 __global__ void __launch_bounds__(256) lstm_seq_fill_kernel(float *buf0, float *buf1, int ld, int T, int S, int col0, int ncols,
                                                             const float *init, int ld_init, int init_cols) {
-  const int row = blockIdx.x;  // 0 .. (T + 2) * S - 1
-  float *buf = blockIdx.y == 0 ? buf0 : buf1;
-  const bool boundary = row < S || row >= (T + 1) * S;
-  u32x4 *p = reinterpret_cast<u32x4 *>(buf + (long)row * ld + (boundary ? 0 : col0));
-  if (init != nullptr && blockIdx.y == 0 && row < S) {
-    const u32x4 *q = reinterpret_cast<const u32x4 *>(init + (long)row * ld_init);
-    const u32x4 z = {0u, 0u, 0u, 0u};
-    for (int i = threadIdx.x; i < (ld >> 2); i += 256) p[i] = i < (init_cols >> 2) ? q[i] : z;
-    return;
-  }
-  const int n4 = (boundary ? ld : ncols) >> 2;
-  const unsigned w = boundary ? 0u : kSentinel;
-  const u32x4 v = {w, w, w, w};
-  for (int i = threadIdx.x; i < n4; i += 256) p[i] = v;
+  const SeqFillJob f = {buf0, buf1, ld, T, S, col0, ncols, init, ld_init, init_cols};
+  seq_fill_row(f, (int)blockIdx.x, (int)blockIdx.y);   // (split16.h: the same rows a conversion launch fills when it takes the job along)
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------

@@ -89,7 +89,32 @@ __device__ __forceinline__ float s16_absmax4(float m, const float4 v) {
 // was launched.
 struct CoopConvJob { const float *src; int ld_src; float *dst; int ld_dst; S16View pl; const float *parts; int nparts; };
 constexpr int kS16MaxJobs = 8;     // matrices per maximum / conversion launch (blockIdx.y)
-bool coop_convert_launch(const CoopConvJob *jobs, int n);
+// A recurrent layer prepares its two activation buffers for the persistent kernel (rnn_persistent.hip: boundary row blocks 0 and T + 1 := 0, or
+// the carried history in block 0 of buffer 0; columns [col0, col0 + ncols) of row blocks 1..T := "not yet published", every float the pattern
+// 0xFFFFFFFF) right in front of a conversion launch of the same step: the launch takes the fill along (one launch less per layer and pass).
+// buf0 == NULL: nothing to fill.  The conversions never read or write these buffers.
+struct SeqFillJob { float *buf0, *buf1; int ld, T, S, col0, ncols; const float *init; int ld_init, init_cols; };
+bool coop_convert_launch(const CoopConvJob *jobs, int n, const SeqFillJob *fill = nullptr);
+#ifdef __HIPCC__
+// one row (0 .. (T + 2) S - 1) of buffer `which`, by all threads of the calling workgroup
+__device__ __forceinline__ void seq_fill_row(const SeqFillJob &f, int row, int which) {
+  typedef unsigned fill_u32x4 __attribute__((ext_vector_type(4)));
+  float *buf = which == 0 ? f.buf0 : f.buf1;
+  const bool boundary = row < f.S || row >= (f.T + 1) * f.S;
+  fill_u32x4 *p = reinterpret_cast<fill_u32x4 *>(buf + (long)row * f.ld + (boundary ? 0 : f.col0));
+  const int nt = (int)blockDim.x;
+  if (f.init != nullptr && which == 0 && row < f.S) {
+    const fill_u32x4 *q = reinterpret_cast<const fill_u32x4 *>(f.init + (long)row * f.ld_init);
+    const fill_u32x4 z = {0u, 0u, 0u, 0u};
+    for (int i = threadIdx.x; i < (f.ld >> 2); i += nt) p[i] = i < (f.init_cols >> 2) ? q[i] : z;
+    return;
+  }
+  const int n4 = (boundary ? f.ld : f.ncols) >> 2;
+  const unsigned w = boundary ? 0u : 0xFFFFFFFFu;
+  const fill_u32x4 v = {w, w, w, w};
+  for (int i = threadIdx.x; i < n4; i += nt) p[i] = v;
+}
+#endif
 
 // ---- host side: device planes of one fp32 matrix, reused from step to step --------------------------------------------------------
 // valid_for(...): the planes hold the values of that matrix as of the tag's epoch (the executor bumps the epochs: nnet-nnet.cpp).
@@ -113,7 +138,8 @@ class PlaneSet {
   // (parts / nparts: device maxima that bound |src| -- left by the kernel that wrote src, or OneBound() for values known to lie in
   // [-1, 1] -- spare that matrix the maximum pass; when every matrix of the call has them there is no maximum launch)
   struct ConvertSpec { PlaneSet *planes; const float *src; int rows, cols, stride; const float *parts = nullptr; int nparts = 0; };
-  static bool ConvertMany(const ConvertSpec *specs, int n);
+  // fill / fill_done: a recurrent layer's buffer preparation to take along (SeqFillJob above); *fill_done says whether this call did it
+  static bool ConvertMany(const ConvertSpec *specs, int n, const SeqFillJob *fill = nullptr, bool *fill_done = nullptr);
   static const float *OneBound();   // a device float holding 1.0
   // a [rows x cols] window of the planes at (row0, col0), for a product that reads that block of the matrix.  As a reduction extent
   // the window's must be a multiple of 64 (or end at the matrix' edge: behind it the planes hold zeros, inside they hold the neighbours)

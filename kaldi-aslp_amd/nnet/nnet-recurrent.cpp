@@ -329,6 +329,17 @@ int PlanesLevel() {
 bool PlanesUsable(const LstmDir &f, int T, int S) {
   return PlanesLevel() > 0 && gemm_split16_enabled() && f.R > 0 && (T * S) % 64 == 0 && f.C % 64 == 0 && f.R % 64 == 0 && T * S >= 128;
 }
+// The buffer preparation of the persistent kernels (aslp_lstm_seq_fill_pair) as a job for the conversion launch that follows it (split16.h
+// SeqFillJob): one launch less per layer and pass (LC-BLSTM step: 8 of ~100).  The checks are aslp_lstm_seq_fill_pair's own; a job that
+// fails them goes to that function, which names the problem.  A/B: ASLP_LSTM_FILL_ALONG=0.
+bool FillRidesAlong(const SeqFillJob &j) {
+  static const bool off = [] { const char *e = getenv("ASLP_LSTM_FILL_ALONG"); return e != nullptr && e[0] == '0'; }();
+  auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+  if (off || !j.buf0 || !j.buf1 || j.T <= 0 || j.S <= 0 || j.ld <= 0) return false;
+  if ((j.ld & 3) || (j.col0 & 3) || (j.ncols & 3) || j.col0 < 0 || j.col0 + j.ncols > j.ld || !al(j.buf0) || !al(j.buf1)) return false;
+  if (j.init && ((j.ld_init & 3) || (j.init_cols & 3) || j.init_cols > j.ld || j.init_cols > j.ld_init || !al(j.init))) return false;
+  return true;
+}
 PlaneSet::ConvertSpec Spec(PlaneSet *ps, const CuMatrixBase &m) { return PlaneSet::ConvertSpec{ps, m.Data(), m.NumRows(), m.NumCols(), m.Stride()}; }
 }  // namespace
 
@@ -353,6 +364,8 @@ void LstmDir::ForwardPreparePair(const LstmDir &f, const LstmDir &b, const CuMat
   // (with prepared planes W_eff = W_r W_rm waits for this step's conversion of the weights below and reads their planes)
   const bool eff_from_planes = pl && persistent && PlanesUsable(f, T, S) && PlanesLevel() >= 3;
   if (!eff_from_planes) RefreshEffPair(f, b);
+  SeqFillJob fill = {};
+  bool fill_pending = false;
   if (persistent && f.Width() % 4 == 0 && (!init_f || init_f->Stride() % 4 == 0)) {
     // both buffers in one launch: boundary row blocks zero (the forward direction's history block takes the carried state),
     // the m columns of row blocks 1..T "not yet published" (csrc/rnn_persistent.hip)
@@ -361,8 +374,10 @@ void LstmDir::ForwardPreparePair(const LstmDir &f, const LstmDir &b, const CuMat
     bbuf->Resize((T + 2) * S, b.Width(), kUndefined);
     ASLP_ASSERT(fbuf->Stride() == bbuf->Stride());
     if (init_f) ASLP_ASSERT(init_f->NumRows() == S && init_f->NumCols() == f.Width());
-    aslp_lstm_seq_fill_pair(fbuf->Data(), bbuf->Data(), fbuf->Stride(), T, S, f.OffM(), f.C, init_f ? init_f->Data() : nullptr,
-                            init_f ? init_f->Stride() : 0, f.Width());
+    // (issued below: the conversion launch of this step takes it along where there is one)
+    fill = SeqFillJob{fbuf->Data(), bbuf->Data(), fbuf->Stride(), T, S, f.OffM(), f.C, init_f ? init_f->Data() : nullptr,
+                      init_f ? init_f->Stride() : 0, f.Width()};
+    fill_pending = true;
   } else {
     f.ForwardPrepare(in, T, S, false, init_f, fbuf, persistent, false);
     b.ForwardPrepare(in, T, S, true, nullptr, bbuf, persistent, false);
@@ -377,9 +392,13 @@ void LstmDir::ForwardPreparePair(const LstmDir &f, const LstmDir &b, const CuMat
     const bool in_ok = f.D % 64 == 0;   // (the first layer's 40-wide input stays below the split kernels' floor)
     PlaneSet::ConvertSpec sp[7] = {Spec(&pl->wrm[0], f.w_rm), Spec(&pl->wrm[1], b.w_rm), Spec(&pl->wr[0], f.w_r), Spec(&pl->wr[1], b.w_r),
                                    Spec(&pl->wx[0], f.w_x), Spec(&pl->wx[1], b.w_x), Spec(&pl->in, in)};
-    pl->weights_ok = PlaneSet::ConvertMany(sp, in_ok ? 7 : 4);
+    bool filled = false;
+    pl->weights_ok = PlaneSet::ConvertMany(sp, in_ok ? 7 : 4, fill_pending && FillRidesAlong(fill) ? &fill : nullptr, &filled);
     pl->in_ok = pl->weights_ok && in_ok;
+    if (filled) fill_pending = false;
   }
+  if (fill_pending)
+    aslp_lstm_seq_fill_pair(fill.buf0, fill.buf1, fill.ld, fill.T, fill.S, fill.col0, fill.ncols, fill.init, fill.ld_init, fill.init_cols);
   if (eff_from_planes) {
     const S16View v[4] = {pl->wr[0].View(), pl->wr[1].View(), pl->wrm[0].View(), pl->wrm[1].View()};
     RefreshEffPair(f, b, pl->weights_ok ? v : nullptr);
@@ -427,11 +446,14 @@ void LstmDir::BackwardPreparePair(const LstmDir &f, const LstmDir &b, const CuMa
     b.BackwardPrepare(od_b, T, S, bdbuf, persistent);
     return;
   }
+  SeqFillJob fill = {};
+  bool fill_pending = false;
   if (persistent) {   // only the two boundary row blocks of each buffer have to be zero (BackwardPrepare)
     fdbuf->Resize((T + 2) * S, f.Width(), kUndefined);
     bdbuf->Resize((T + 2) * S, b.Width(), kUndefined);
     ASLP_ASSERT(fdbuf->Stride() == bdbuf->Stride());
-    aslp_lstm_seq_fill_pair(fdbuf->Data(), bdbuf->Data(), fdbuf->Stride(), T, S, 0, 0, nullptr, 0, 0);
+    fill = SeqFillJob{fdbuf->Data(), bdbuf->Data(), fdbuf->Stride(), T, S, 0, 0, nullptr, 0, 0};
+    fill_pending = true;
   } else {
     f.BackwardPrepare(od_f, T, S, fdbuf, persistent, false);
     b.BackwardPrepare(od_b, T, S, bdbuf, persistent, false);
@@ -439,8 +461,12 @@ void LstmDir::BackwardPreparePair(const LstmDir &f, const LstmDir &b, const CuMa
   CuSubMatrix dm_f(*fdbuf, S, T * S, f.OffM(), f.C), dm_b(*bdbuf, S, T * S, b.OffM(), b.C);
   if (pl && pl->weights_ok && persistent && PlanesLevel() >= 2) {   // (the weights' planes of this step's forward pass: the weights have not moved)
     PlaneSet::ConvertSpec sp[2] = {Spec(&pl->od[0], od_f), Spec(&pl->od[1], od_b)};
-    pl->od_ok = PlaneSet::ConvertMany(sp, 2);
+    bool filled = false;
+    pl->od_ok = PlaneSet::ConvertMany(sp, 2, fill_pending && FillRidesAlong(fill) ? &fill : nullptr, &filled);
+    if (filled) fill_pending = false;
   }
+  if (fill_pending)
+    aslp_lstm_seq_fill_pair(fill.buf0, fill.buf1, fill.ld, fill.T, fill.S, fill.col0, fill.ncols, fill.init, fill.ld_init, fill.init_cols);
   if (pl && pl->od_ok) {
     const S16View v[4] = {pl->od[0].View(), pl->od[1].View(), pl->wrm[0].View(), pl->wrm[1].View()};
     AddMatMatPair(dm_f, dm_b, 1.0, od_f, od_b, kNoTrans, f.w_rm, b.w_rm, kNoTrans, 0.0, nullptr, nullptr, v);

@@ -141,3 +141,6 @@ def test_lstm_layer_products_from_prepared_planes(tmp_path):
     default = run(tmp_path, "default", **shape)
     assert np.linalg.norm(passes - default) / np.linalg.norm(default) < 1e-6
     assert np.abs(passes - default).max() / max(1.0, np.abs(default).max()) < 1e-5
+    # the buffers' preparation for the persistent kernels as a launch of its own instead of riding along with the conversion launch behind it
+    # (split16.h SeqFillJob): the same stores, the same bits
+    assert np.array_equal(run(tmp_path, "fill_alone", ASLP_LSTM_FILL_ALONG="0", **shape), default)
