@@ -74,6 +74,8 @@ inline void SetVerboseLevel(int32 level) { ::aslp::g_verbose_level = level; }   
 inline int32 GetVerboseLevel() { return ::aslp::g_verbose_level; }
 static int &g_kaldi_verbose_level = ::aslp::g_verbose_level;   /* (read directly by the tools' vlog blocks) */
 using ::aslp::SplitStringToVector;   /* util/text-utils.h */
+using ::aslp::RandGauss;             /* base/kaldi-math.h */
+using ::aslp::RandUniform;
 using ::aslp::Posterior;
 using ::aslp::Timer;
 using ::aslp::CuDevice;
@@ -108,7 +110,16 @@ using ::aslp::NnetTrainOptions;
 using ::aslp::NnetDataRandomizerOptions;
 using ::aslp::RandomizerMask;
 using ::aslp::MatrixRandomizer;
-using ::aslp::VectorRandomizer;
+using ::aslp::Int32VectorRandomizer;
+/* nnet-randomizer.h:120-141: Value() is a VectorBase in the reference (the engine hands out its std::vector<float>; this copies the minibatch's weights) */
+class VectorRandomizer : public ::aslp::VectorRandomizer {
+ public:
+  VectorRandomizer() {}
+  explicit VectorRandomizer(const NnetDataRandomizerOptions &conf) : ::aslp::VectorRandomizer(conf) {}
+  const Vector<BaseFloat> &Value() { value_ = ::aslp::VectorRandomizer::Value(); return value_; }
+ private:
+  Vector<BaseFloat> value_;
+};
 using ::aslp::PosteriorRandomizer;
 using ::aslp::LossItf;
 using ::aslp::Xent;

@@ -109,3 +109,17 @@ def test_staged_refill_equals_add_data_refill(aslp, dev, cap, mb, cols):
             nxt += 1
         fills += 1
     assert fills >= 3 and batches > 10
+
+
+def test_the_references_own_unit_test_binary_passes_on_this_engine():
+    """kaldi-aslp_amd/bin_ref/nnet-randomizer-test IS src/aslp-nnet/nnet-randomizer-test.cc of the reference -- RandomizerMask, MatrixRandomizer,
+    VectorRandomizer, Int32VectorRandomizer: no-shuffle round trips of 1111 rows through capacity 1000 / minibatch 100, the second fill that
+    moves the last 11 rows to the front, 22 minibatches in all -- compiled unchanged against include/aslp_compat_kaldi.h and linked with this
+    engine (`make -C kaldi-aslp_amd refmains`, development container; the binary travels, the source does not).  Not a mirror: the test itself."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kaldi-aslp_amd", "bin_ref", "nnet-randomizer-test")
+    if not os.path.exists(exe):
+        pytest.skip("bin_ref/nnet-randomizer-test not built (needs the reference tree: make -C kaldi-aslp_amd refmains)")
+    p = subprocess.run([exe], capture_output=True, timeout=600)
+    assert p.returncode == 0 and b"Tests succeeded." in p.stdout, (p.stdout + p.stderr).decode()[-2000:]
