@@ -210,6 +210,9 @@ inline void aslp_compat_srand(unsigned seed) {
 namespace std { using ::aslp_compat_srand; }
 #define srand aslp_compat_srand
 
+/* (the reference's aslp-nnet-train-simple-mpi.cc:37 spells `string::npos` at global scope: some header of its Kaldi put the name there) */
+using std::string;
+
 #define KALDI_LOG ASLP_LOG
 #define KALDI_WARN ASLP_WARN
 #define KALDI_ERR ASLP_ERR

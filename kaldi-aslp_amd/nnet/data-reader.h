@@ -72,12 +72,21 @@ class FrameDataReader {
     ASLP_ASSERT(feat != NULL && targets != NULL);
     if (Done()) ASLP_ERR << "Already read done";
     if (feature_randomizer_.Done()) FillRandomizer();
-    if (Done()) return false;
+    if (Done()) {
+      // The reference leaves *feat / *targets alone here, and they point at its randomizers' own minibatch copies (nnet-randomizer.cc:93-98):
+      // a caller that does not look at the result -- the reference's worker mains, aslp-nnet-train-frame-worker.cc:147 -- runs one more step
+      // on the LAST minibatch.  The engine's Value() is a view into the cache, which the fill above may have rearranged, so the last minibatch
+      // was set aside when the fill began and the pointers are moved onto that copy: the same values the reference's caller sees.
+      if (have_last_) { *feat = &last_feat_copy_; *targets = &last_tgt_copy_; }
+      return false;
+    }
     *feat = &feature_randomizer_.Value();
     feature_randomizer_.Next();
     cur_begin_ = targets_randomizer_.Begin();
     *targets = &targets_randomizer_.Value();
     targets_randomizer_.Next();
+    last_feat_ = *feat;
+    last_tgt_ = *targets;
     if (!read_done_) Prefetch(false);
     return true;
   }
@@ -252,6 +261,11 @@ class FrameDataReader {
     static const bool prof = getenv("ASLP_READER_PROFILE") != nullptr && getenv("ASLP_READER_PROFILE")[0] == '1';
     Timer tp;
     t_wait_ = 0.0;
+    if (last_feat_ != nullptr) {   // (once per cache, not per step: one minibatch of rows device to device and its targets; see ReadData)
+      last_feat_copy_ = *last_feat_;
+      last_tgt_copy_ = *last_tgt_;
+      have_last_ = true;
+    }
     Prefetch(true);
     const double t_prefetch = tp.Elapsed();
     tp.Reset();
@@ -319,6 +333,11 @@ class FrameDataReader {
   std::vector<int32> host_labels_;
   bool cache_labels_ok_ = false;
   int32 cache_label_max_ = -1, cur_begin_ = 0;
+  const CuMatrixBase *last_feat_ = nullptr;   // what ReadData handed out last, and the copy of it made when the next fill begins
+  const Posterior *last_tgt_ = nullptr;
+  CuMatrix last_feat_copy_;
+  Posterior last_tgt_copy_;
+  bool have_last_ = false;
   Block sunk_;                 // the block the sink handed out for the object the table reader holds now (producer thread only)
   bool sunk_valid_ = false;
   std::thread producer_;

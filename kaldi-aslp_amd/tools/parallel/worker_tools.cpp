@@ -132,12 +132,16 @@ int Main_aslp_nnet_train_frame_worker(int argc, char *argv[]) {
     ASLP_LOG << "TRAINING STARTED";
     {
       FrameDataReader reader(feature_rspecifier, targets_rspecifier, rnd_opts);
-      const CuMatrixBase *nnet_in;
+      const CuMatrixBase *nnet_in = nullptr;
       CuMatrix nnet_out, obj_diff;
-      const Posterior *nnet_tgt;
+      const Posterior *nnet_tgt = nullptr;
       std::vector<BaseFloat> ones;
       while (!reader.Done()) {
-        if (!reader.ReadData(&nnet_in, &nnet_tgt)) continue;
+        // The reference's worker does not look at what ReadData returns (aslp-nnet-train-frame-worker.cc:147; aslp-nnet-train-frame.cc:110-111
+        // does): when the frames that are left do not fill a minibatch, the loop body runs once more on the minibatch of the step before --
+        // one more update, counted into the frames and the sync schedule.  Same here (the reader keeps that minibatch for the purpose).
+        reader.ReadData(&nnet_in, &nnet_tgt);
+        if (nnet_in == nullptr) continue;   // (no full minibatch in the whole input)
         if (xent != NULL) {
           nnet.PropagateForLoss(*nnet_in, true);
           ones.assign(nnet_in->NumRows(), 1.0f);

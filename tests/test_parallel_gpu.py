@@ -9,11 +9,18 @@ import numpy as np
 import pytest
 
 import kaldi_formats as kf
-from test_tools_gpu import tool, write_corpus
-from test_nnet_gpu import make_dnn
+from test_tools_gpu import minibatches, tool, write_corpus
+from test_nnet_gpu import make_dnn, oracle_params
 
 pytestmark = pytest.mark.gpu
 f32 = np.float32
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def xent_frames(err):
+    """the frame count of the LAST Xent report in a tool's log"""
+    import re
+    return int(float(re.findall(r"AvgLoss: \S+ \(Xent\), Likelyhood: \S+ Frame: (\S+)", err)[-1]))
 
 
 def run_selftest(kind, n, dim, steps, *extra):
@@ -206,8 +213,7 @@ def test_frame_worker_tool_group_of_one(aslp, oracle, dev, tmp_path, worker):
     themselves are checked in test_sod_worker_threads)."""
     in_dim, hid, nh, out_dim, mb = 24, 64, 2, 40, 32
     d, path = make_dnn(oracle, tmp_path, in_dim, hid, nh, out_dim, 1, mb, seed=21)
-    oracle.lib.orc_dnn_destroy(d)
-    write_corpus(tmp_path, np.random.default_rng(7), 12, in_dim, out_dim)
+    _, feats, posts = write_corpus(tmp_path, np.random.default_rng(7), 12, in_dim, out_dim)
     common = ["--learn-rate=0.004", "--momentum=0.5", "--minibatch-size=%d" % mb, "--randomizer-size=150", "--randomizer-seed=9",
               "ark:%s" % (tmp_path / "feats.ark"), "ark:%s" % (tmp_path / "post.ark"), str(path)]
     tool("aslp-nnet-train-frame", *common, str(tmp_path / "ref.nnet"))
@@ -220,10 +226,17 @@ def test_frame_worker_tool_group_of_one(aslp, oracle, dev, tmp_path, worker):
     err = p.stderr.decode()
     assert "Mpi cluster info total 1 worker rank 0" in err and "All worker finished their data" in err and "AvgLoss:" in err
     a, b = aslp.Nnet.Read(tmp_path / "ref.nnet").GetParams(), aslp.Nnet.Read(tmp_path / "w.nnet").GetParams()
-    if worker in ("bsp", "sod"):
-        assert np.array_equal(a, b)
-    else:
-        np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-7)
+    # The worker is NOT aslp-nnet-train-frame with a sync in it: the reference's worker does not look at what ReadData returns
+    # (aslp-nnet-train-frame-worker.cc:147 against aslp-nnet-train-frame.cc:110-111), so when the frames left over do not fill a minibatch its
+    # loop runs once more on the minibatch of the step before.  Oracle chain over the same minibatches with the last one taken twice:
+    steps = list(minibatches(aslp, feats, posts, mb, 9, 150))
+    for x, t, _ in steps + steps[-1:]:
+        oracle.lib.orc_dnn_train_step(d, np.ascontiguousarray(x), np.array([fr[0][0] for fr in t], np.int32), 0.004, 0.5)
+    want = oracle_params(oracle, d, 1)
+    oracle.lib.orc_dnn_destroy(d)
+    assert oracle.rel_err(b, want) < 1e-4
+    assert oracle.rel_err(a, want) > 1e-3       # (the step more is visible: train-frame's model is not the worker's)
+    assert xent_frames(err) == (len(steps) + 1) * mb
 
 
 def test_train_server_tool_and_served_worker_flags(aslp, oracle, dev, tmp_path):
@@ -297,12 +310,20 @@ def run_tools_together(cmds, env_extra, timeout=900):
     """start every command (name, args) as its own OS process -- the ranks of one launch, all on GPU 0 -- and wait for all of them"""
     import secrets
     from test_tools_gpu import BIN
+    from test_tools_gpu import REF_MAINS
     token = secrets.token_hex(6)
     procs = []
     for r, (name, args) in enumerate(cmds):
         env = dict(os.environ, ASLP_COMM_TOKEN=token, ASLP_COMM_TRANSPORT="shm", **env_extra)
-        procs.append(subprocess.Popen([os.path.join(BIN, name), "--rank=%d" % r, "--num-workers=%d" % len(cmds)] + list(args), env=env,
-                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+        argv = [os.path.join(BIN, name), "--rank=%d" % r, "--num-workers=%d" % len(cmds)] + list(args)
+        ref_exe = os.path.join(ROOT, "kaldi-aslp_amd", "bin_ref", name)
+        if REF_MAINS and os.path.exists(ref_exe):
+            # the REFERENCE's own main of that name on the engine's sync layer (include/aslp_compat_kaldi_parallel.h): no --rank / --num-workers /
+            # --comm-file there -- rank and size come from the launcher's environment like under mpirun, the rendezvous file from ASLP_COMM_FILE
+            comm_file = [a.split("=", 1)[1] for a in args if a.startswith("--comm-file=")]
+            argv = [ref_exe] + [a for a in args if not a.startswith("--comm-file=")]
+            env.update(RANK=str(r), WORLD_SIZE=str(len(cmds)), ASLP_COMM_FILE=comm_file[0] if comm_file else "")
+        procs.append(subprocess.Popen(argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
     out = []
     try:
         for p in procs:
@@ -321,14 +342,16 @@ def test_bsp_frame_workers_as_two_processes_on_one_gpu(aslp, oracle, dev, tmp_pa
     """aslp-nnet-train-frame-worker x 2 as separate OS processes on ONE device (--comm-transport / ASLP_COMM_TRANSPORT=shm: rendezvous record,
     sample-count all-reduce, parameter all-reduce from two address spaces).  Both ranks read the SAME shard: their models stay equal,
     the BSP average n_k / N * w_k summed over the two is then w itself in fp32 (0.5 w + 0.5 w), so rank 0's model must equal the
-    single-process aslp-nnet-train-frame run bit for bit -- any lost, doubled or mis-ordered contribution shows."""
+    one-rank aslp-nnet-train-frame-worker run bit for bit -- any lost, doubled or mis-ordered contribution shows."""
     in_dim, hid, nh, out_dim, mb = 24, 64, 2, 40, 32
     d, path = make_dnn(oracle, tmp_path, in_dim, hid, nh, out_dim, 1, mb, seed=21)
     oracle.lib.orc_dnn_destroy(d)
     write_corpus(tmp_path, np.random.default_rng(7), 12, in_dim, out_dim)
     common = ["--learn-rate=0.004", "--momentum=0.5", "--minibatch-size=%d" % mb, "--randomizer-size=150", "--randomizer-seed=9",
               "ark:%s" % (tmp_path / "feats.ark"), "ark:%s" % (tmp_path / "post.ark"), str(path)]
-    tool("aslp-nnet-train-frame", *common, str(tmp_path / "ref.nnet"))
+    # (one rank alone is the yardstick -- not aslp-nnet-train-frame: the worker runs one step more at the end of its data, see
+    # test_frame_worker_tool_group_of_one)
+    tool("aslp-nnet-train-frame-worker", "--worker-type=bsp", "--sync-period=64", *common, str(tmp_path / "ref.nnet"))
     comm = "--comm-file=%s" % (tmp_path / "comm")
     errs = run_tools_together([("aslp-nnet-train-frame-worker", ["--worker-type=bsp", "--sync-period=64", "--gpu-id=0", comm] + common + [str(tmp_path / ("w%d.nnet" % r))])
                                for r in range(2)], {})

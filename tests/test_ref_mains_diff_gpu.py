@@ -349,3 +349,112 @@ def test_model_tools(corpus):
     both(corpus, "aslp-nnet-insert", ["--insert-at=3", "--randomize-next-component=false", "--binary=false"], [str(d / "base.nnet"), "cat %s |" % (d / "hid.nnet")], tag="i2")
     for net in ("dnn", "lstm", "blstm", "lc", "ctc", "fsmn"):
         assert run(OWN, "aslp-nnet-info", [str(d / (net + ".nnet"))]).stdout == run(REF, "aslp-nnet-info", [str(d / (net + ".nnet"))]).stdout
+
+
+# ---- src/aslp-parallelbin/: the workers and the parameter server on the engine's sync layer -------------------------------------------
+WORKER_FLAGS = [
+    ["--worker-type=bsp", "--sync-period=64"],
+    ["--worker-type=bmuf", "--sync-period=100", "--bmuf-learn-rate=0.9", "--bmuf-momentum=0.5"],
+    ["--worker-type=sod", "--sync-period=64", "--solver=adam", "--adam-lr=0.0005"],
+    ["--worker-type=sod", "--sync-period=50", "--solver=momentum", "--lr=0.5", "--sgd-momentum=0.8"],
+]
+
+
+@pytest.mark.parametrize("flags", WORKER_FLAGS, ids=lambda f: " ".join(f))
+def test_workers_alone_in_their_group(corpus, flags):
+    """one rank: every protocol's arithmetic on this rank's own model (BSP: the identity; BMUF: block momentum on w - w_g; SOD: a solver
+    stepping the model by its own delta), the sync schedule, and the loop around them -- including the step more the reference's frame
+    worker takes at the end of its data (tests/test_parallel_gpu.py)"""
+    d = corpus["dir"]
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1")
+    for name, net, extra in (("aslp-nnet-train-frame-worker", "dnn", ["--minibatch-size=16", "--randomizer-size=100", "--learn-rate=0.01"]),
+                             ("aslp-nnet-train-lstm-stream-worker", "lstm", ["--num-stream=3", "--batch-size=5", "--targets-delay=2", "--learn-rate=0.02"]),
+                             ("aslp-nnet-train-lc-blstm-streams-worker", "lc", ["--num-stream=3", "--chunk-size=6", "--right-splice=3", "--learn-rate=0.02"])):
+        if name.startswith("aslp-nnet-train-lc") and "--worker-type=sod" in flags:
+            continue   # (no SOD worker in that tool: aslp-nnet-train-lc-blstm-streams-worker.cc:17-21)
+        outs = {}
+        for side, bindir in (("own", OWN), ("ref", REF)):
+            out = str(d / ("%s.%s.%s.model" % (name, abs(hash(tuple(flags))) % 997, side)))
+            p = subprocess.run([os.path.join(bindir, name)] + flags + extra + tables(corpus, "d" if net == "dnn" else "s", "feats", "post") + [str(d / (net + ".nnet")), out],
+                               capture_output=True, timeout=1800, env=env)
+            assert p.returncode == 0, (side, name, p.stderr.decode()[-2000:])
+            outs[side] = (open(out, "rb").read(), log_lines(p.stderr))
+        assert outs["own"][0] == outs["ref"][0], (name, flags)
+        lo, lr = outs["own"][1], outs["ref"][1]
+        if name != "aslp-nnet-train-frame-worker":   # (the stream workers' final report: formed and dropped by the reference's mains, :265 / :428, logged by the engine's tools -- as aslp-nnet-train-lstm-streams)
+            final = [x for x in lo if x not in lr]
+            lo = [x for x in lo if x not in final]
+            assert len(final) <= 2
+        assert lo == lr, (name, flags)
+
+
+def test_two_bsp_ranks_and_a_server_alone(corpus):
+    """two OS processes on one device (shared-memory transport): the reference's worker main finds its rank, the world size and the rendezvous
+    file in the environment, as it would under mpirun; the engine's tool takes them as flags.  Rank 0's model byte for byte.  And the
+    parameter server with nobody to serve."""
+    import secrets
+    d = corpus["dir"]
+    common = ["--worker-type=bsp", "--sync-period=64", "--minibatch-size=16", "--randomizer-size=100", "--learn-rate=0.01"] + tables(corpus, "d", "feats", "post") + [str(d / "dnn.nnet")]
+    models = {}
+    for side, bindir in (("own", OWN), ("ref", REF)):
+        comm = str(d / ("comm." + side))
+        token = secrets.token_hex(6)
+        procs = []
+        for r in range(2):
+            env = dict(os.environ, ASLP_COMM_TOKEN=token, ASLP_COMM_TRANSPORT="shm")
+            out = str(d / ("bsp2.%s.%d.model" % (side, r)))
+            if side == "own":
+                argv = [os.path.join(bindir, "aslp-nnet-train-frame-worker"), "--rank=%d" % r, "--num-workers=2", "--comm-file=" + comm, "--gpu-id=0"] + common + [out]
+            else:
+                argv = [os.path.join(bindir, "aslp-nnet-train-frame-worker"), "--gpu-id=0"] + common + [out]
+                env.update(RANK=str(r), WORLD_SIZE="2", ASLP_COMM_FILE=comm)
+            procs.append(subprocess.Popen(argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+        try:
+            for r, p in enumerate(procs):
+                _, e = p.communicate(timeout=900)
+                assert p.returncode == 0, (side, r, e.decode()[-2000:])
+                assert ("Mpi cluster info total 2 worker rank %d" % r).encode() in e
+        finally:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        models[side] = open(str(d / ("bsp2.%s.0.model" % side)), "rb").read()
+    assert models["own"] == models["ref"]
+    # aslp-nnet-train-simple-mpi: exactly two ranks swap and average whole models (NnetMpiSync), each on the shard "JOB" names
+    import shutil
+    for r in range(2):
+        shutil.copy(str(d / "d_feats.ark"), str(d / ("mpi_feats.%d.ark" % r)))
+    for side, bindir in (("own", OWN), ("ref", REF)):
+        comm = str(d / ("comm.mpi." + side))
+        token = secrets.token_hex(6)
+        procs = []
+        for r in range(2):
+            env = dict(os.environ, ASLP_COMM_TOKEN=token, ASLP_COMM_TRANSPORT="shm")
+            args = ["--learn-rate=0.01", "--minibatch-size=16", "--randomizer-size=100", "--sync-period=64", "ark:%s" % (d / "mpi_feats.JOB.ark"),
+                    "ark:%s" % (d / "d_post.ark"), str(d / "dnn.nnet"), str(d / ("mpi.%s.%d.model" % (side, r)))]
+            if side == "own":
+                argv = [os.path.join(bindir, "aslp-nnet-train-simple-mpi"), "--rank=%d" % r, "--num-workers=2", "--comm-file=" + comm] + args
+            else:
+                argv = [os.path.join(bindir, "aslp-nnet-train-simple-mpi")] + args
+                env.update(RANK=str(r), WORLD_SIZE="2", ASLP_COMM_FILE=comm)
+            procs.append(subprocess.Popen(argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+        try:
+            for r, p in enumerate(procs):
+                _, e = p.communicate(timeout=900)
+                assert p.returncode == 0, (side, r, e.decode()[-2000:])
+        finally:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        models["mpi." + side] = open(str(d / ("mpi.%s.0.model" % side)), "rb").read()
+    assert models["mpi.own"] == models["mpi.ref"]
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1")
+    for st in ("easgd", "asgd", "masgd"):
+        outs = {}
+        for side, bindir in (("own", OWN), ("ref", REF)):
+            out = str(d / ("server.%s.%s.model" % (st, side)))
+            p = subprocess.run([os.path.join(bindir, "aslp-nnet-train-server"), "--server-type=" + st, "--alpha=0.5", "--sync-period=10", str(d / "dnn.nnet"), out],
+                               capture_output=True, timeout=900, env=env)
+            assert p.returncode == 0 and b"Mpi cluster info total 1 server rank 0" in p.stderr and b"All worker finished" in p.stderr, p.stderr.decode()[-2000:]
+            outs[side] = open(out, "rb").read()
+        assert outs["own"] == outs["ref"]
