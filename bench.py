@@ -539,7 +539,7 @@ def hbm_kernels_block(aslp, dev):
     return {"peak_gb_per_s": HBM_PEAK_GBS, "timing": "HIP events (torch.cuda.Event on the launch stream): >= 10 warm-up calls, then the median over 21 back-to-back groups of calls", "kernels": out}
 
 
-def e2e_tool_block(frames=1024000):
+def e2e_tool_block(frames=1024000, bindir="bin"):
     """SURVEY 8(d) asks for the end-to-end figure beside the compute-only one (extra key `e2e_tool`, N = 1): the cfg2 net trained by the
     command-line tool itself -- aslp-nnet-init, then aslp-nnet-train-frame reading a feature archive and a posterior archive (page
     cache), randomizer 32768, minibatch 1024 -- and the tool's OWN `fps` figure, whose timer spans archive parsing, the randomizer,
@@ -552,6 +552,7 @@ def e2e_tool_block(frames=1024000):
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import kaldi_formats as kf
+    train_bindir = os.path.join(ROOT, "kaldi-aslp_amd", bindir)   # "bin_ref": the REFERENCE's own main() built on the engine
     bindir = os.path.join(ROOT, "kaldi-aslp_amd", "bin")
     base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 6 * frames * IN_DIM else None
     tmp = tempfile.mkdtemp(prefix="aslp_e2e_", dir=base)
@@ -568,7 +569,7 @@ def e2e_tool_block(frames=1024000):
         subprocess.run([os.path.join(bindir, "aslp-nnet-init"), "--print-args=false", os.path.join(tmp, "nnet.proto"), os.path.join(tmp, "nnet.init")],
                        check=True, capture_output=True, timeout=600)
         t0 = time.time()
-        p = subprocess.run([os.path.join(bindir, "aslp-nnet-train-frame"), "--print-args=false", "--learn-rate=%g" % CFG2_LEARN_RATE, "--minibatch-size=%d" % MB,
+        p = subprocess.run([os.path.join(train_bindir, "aslp-nnet-train-frame"), "--print-args=false", "--learn-rate=%g" % CFG2_LEARN_RATE, "--minibatch-size=%d" % MB,
                             "--randomizer-size=32768", "ark:%s/feats.ark" % tmp, "ark:%s/post.ark" % tmp, os.path.join(tmp, "nnet.init"),
                             os.path.join(tmp, "nnet.out")], capture_output=True, timeout=900)
         wall = time.time() - t0
@@ -1163,6 +1164,15 @@ def main():
                     out["e2e_tool"]["steady_state"] = {"frames_per_sec": marg, "of_compute_only": marg / value, "fixed_cost_s": t1 - f1 / marg,
                                                        "how": "(frames_3x - frames_1x) / (seconds_3x - seconds_1x) of the tool's own fps timer; fixed_cost_s = "
                                                               "what the 1x run takes beyond frames_1x at that rate"}
+                # the REFERENCE's own aslp-nnet-train-frame.cc, compiled unchanged against the engine (kaldi-aslp_amd/bin_ref/, built where the
+                # reference tree is; the binary travels): what a caller written against the reference gets without touching its source
+                if os.path.exists(os.path.join(ROOT, "kaldi-aslp_amd", "bin_ref", "aslp-nnet-train-frame")):
+                    refmain = e2e_tool_block(args.e2e_frames, bindir="bin_ref")
+                    if "frames_per_sec" in refmain:
+                        out["e2e_tool"]["reference_main_unchanged"] = {
+                            "frames_per_sec": refmain["frames_per_sec"], "of_the_engines_tool": refmain["frames_per_sec"] / out["e2e_tool"]["frames_per_sec"],
+                            "what": "src/aslp-nnetbin/aslp-nnet-train-frame.cc of the reference built against include/aslp_compat_kaldi.h and linked with "
+                                    "libaslp_hip.so, same archives and flags, its own fps line"}
         if world == 1 and not args.no_cpu_baseline:
             port = cpu_baseline()
             ref = cpu_baseline_reference()
