@@ -655,6 +655,7 @@ int Main_aslp_nnet_train_perutt(int argc, char *argv[]) {
     Mse mse;
     CuMatrix feats, feats_transf, nnet_out, obj_diff;
     Timer time;
+    RandomizerMask randomizer_mask(rnd_opts);   // unused by this tool, as in the reference (aslp-nnet-train-perutt.cc:127), but its construction seeds the generator and says so in the log
     ASLP_LOG << (crossvalidate ? "CROSS-VALIDATION" : "TRAINING") << " STARTED";
     int32 num_done = 0, num_no_tgt_mat = 0, num_other_error = 0;
     for (; !feature_reader.Done(); feature_reader.Next()) {

@@ -261,6 +261,7 @@ int Main_aslp_nnet_train_lstm_stream_worker(int argc, char *argv[]) {
     if (objective_function == "xent") loss = new Xent;
     else if (objective_function == "mse") loss = new Mse;
     else ASLP_ERR << "Unsupported objective function: " << objective_function;
+    RandomizerMask randomizer_mask(rnd_opts);   // unused by this tool, as in the reference (aslp-nnet-train-lstm-stream-worker.cc:111), but its construction seeds the generator and says so in the log
     std::unique_ptr<IWorker> worker = MakeWorker(worker_type, comm.get(), alpha, bmuf_learn_rate, bmuf_momentum, &optimizer_opts);
     std::vector<std::pair<BaseFloat *, int>> params;
     nnet.GetGpuParams(&params);
@@ -293,7 +294,7 @@ int Main_aslp_nnet_train_lstm_stream_worker(int argc, char *argv[]) {
       total_frames += frame_progress;
       num_frames_since_last_sync += frame_progress;
       if (num_frames_since_last_sync > sync_period) {
-        ASLP_VLOG(2) << "Worker " << worker->Rank() << " synchronize once";
+        ASLP_LOG << "Worker " << worker->Rank() << " synchronize once";
         worker->Synchronize(num_frames_since_last_sync);
         num_frames_since_last_sync = 0;
       }
@@ -429,6 +430,7 @@ int Main_aslp_nnet_train_lc_blstm_streams_worker(int argc, char *argv[]) {
     RandomAccessPosteriorReader target_reader(targets_rspecifier);
     Xent xent;
     Mse mse;
+    RandomizerMask randomizer_mask(rnd_opts);   // unused by this tool, as in the reference (aslp-nnet-train-lc-blstm-streams-worker.cc:171), but its construction seeds the generator and says so in the log
     std::unique_ptr<IWorker> worker = MakeWorker(worker_type, comm.get(), alpha, bmuf_learn_rate, bmuf_momentum, nullptr);
     std::vector<std::pair<BaseFloat *, int>> params;
     nnet.GetGpuParams(&params);

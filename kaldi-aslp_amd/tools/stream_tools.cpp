@@ -66,6 +66,7 @@ int Main_aslp_nnet_train_lstm_streams(int argc, char *argv[]) {
     else if (objective_function == "mse") loss = new Mse;
     else ASLP_ERR << "Unsupported objective function: " << objective_function;
     Timer time;
+    RandomizerMask randomizer_mask(rnd_opts);   // unused by this tool, as in the reference (aslp-nnet-train-lstm-streams.cc:94), but its construction seeds the generator and says so in the log
     ASLP_LOG << (crossvalidate ? "CROSS-VALIDATION" : "TRAINING") << " STARTED";
     SequenceDataReader reader(feature_rspecifier, targets_rspecifier, read_opts);
     CuMatrix nnet_out, obj_diff, nnet_in;
@@ -605,6 +606,7 @@ int Main_aslp_nnet_train_blstm_streams_lc(int argc, char *argv[]) {
     Xent xent;
     Mse mse;
     Timer time;
+    RandomizerMask randomizer_mask(rnd_opts);   // unused by this tool, as in the reference (aslp-nnet-train-blstm-streams-lc.cc:151), but its construction seeds the generator and says so in the log
     ASLP_LOG << (crossvalidate ? "CROSS-VALIDATION" : "TRAINING") << " STARTED";
     int32 num_done = 0, num_no_tgt_mat = 0, num_other_error = 0, num_sentence = 0;
     std::vector<std::string> keys(num_stream);
