@@ -384,6 +384,11 @@ int Main_aslp_nnet_train_blstm_streams(int argc, char *argv[]) {
       else if (objective_function == "mse") mse.Eval(weight_host, nnet_out, target_host, &obj_diff);
       else ASLP_ERR << "Unknown objective function code : " << objective_function;
       if (!crossvalidate) nnet.Backpropagate(obj_diff, NULL);
+      if (g_verbose_level >= 2 && total_frames == 0) {   // 1st minibatch: from verbose level 2 here (aslp-nnet-train-blstm-streams.cc:289-296), though the lines are VLOG(1)
+        ASLP_VLOG(1) << "### After " << total_frames << " frames,";
+        ASLP_VLOG(1) << nnet.InfoPropagate();
+        if (!crossvalidate) { ASLP_VLOG(1) << nnet.InfoBackPropagate(); ASLP_VLOG(1) << nnet.InfoGradient(); }
+      }
       num_done += S;
       total_frames += feats_transf.NumRows();
       num_sentence += S;
