@@ -138,7 +138,7 @@ int Main_aslp_nnet_train_frame_worker(int argc, char *argv[]) {
       std::vector<BaseFloat> ones;
       while (!reader.Done()) {
         // The reference's worker does not look at what ReadData returns (aslp-nnet-train-frame-worker.cc:147; aslp-nnet-train-frame.cc:110-111
-        // does): when the frames that are left do not fill a minibatch, the loop body runs once more on the minibatch of the step before --
+        // does): when the last cache fill of the data holds less than one minibatch, the loop body runs once more on the minibatch of the step before --
         // one more update, counted into the frames and the sync schedule.  Same here (the reader keeps that minibatch for the purpose).
         reader.ReadData(&nnet_in, &nnet_tgt);
         if (nnet_in == nullptr) continue;   // (no full minibatch in the whole input)

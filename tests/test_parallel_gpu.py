@@ -227,7 +227,7 @@ def test_frame_worker_tool_group_of_one(aslp, oracle, dev, tmp_path, worker):
     assert "Mpi cluster info total 1 worker rank 0" in err and "All worker finished their data" in err and "AvgLoss:" in err
     a, b = aslp.Nnet.Read(tmp_path / "ref.nnet").GetParams(), aslp.Nnet.Read(tmp_path / "w.nnet").GetParams()
     # The worker is NOT aslp-nnet-train-frame with a sync in it: the reference's worker does not look at what ReadData returns
-    # (aslp-nnet-train-frame-worker.cc:147 against aslp-nnet-train-frame.cc:110-111), so when the frames left over do not fill a minibatch its
+    # (aslp-nnet-train-frame-worker.cc:147 against aslp-nnet-train-frame.cc:110-111), so when the LAST cache fill holds less than one minibatch (as with this corpus) its
     # loop runs once more on the minibatch of the step before.  Oracle chain over the same minibatches with the last one taken twice:
     steps = list(minibatches(aslp, feats, posts, mb, 9, 150))
     for x, t, _ in steps + steps[-1:]:
