@@ -333,6 +333,11 @@ def test_model_tools(corpus):
     for i, (name, flags, inputs) in enumerate([
             ("aslp-nnet-copy", ["--binary=false"], [str(d / "dnn.nnet")]),
             ("aslp-nnet-copy", [], [str(d / "lc.nnet")]),
+            ("aslp-nnet-copy", ["--binary=false"], [str(d / "lstm.nnet")]),
+            ("aslp-nnet-copy", ["--binary=false"], [str(d / "blstm.nnet")]),
+            ("aslp-nnet-copy", ["--binary=false"], [str(d / "lc.nnet")]),
+            ("aslp-nnet-copy", ["--binary=false"], [str(d / "fsmn.nnet")]),
+            ("aslp-nnet-dot", [], [str(d / "lc.nnet")]),
             ("aslp-nnet-convert-to-standard", [], [str(d / "dnn.nnet")]),
             ("aslp-nnet-convert-to-standard", ["--binary=false"], [str(d / "fsmn.nnet")]),
             ("aslp-nnet-init", ["--seed=9"], [str(d / "blstm.proto")]),
