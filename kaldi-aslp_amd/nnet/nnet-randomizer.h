@@ -76,7 +76,21 @@ class RandomizerBase {
     ASLP_ASSERT(data_begin_ == 0);
     ASLP_ASSERT(data_end_ > 0);
     ASLP_ASSERT(data_end_ == (int32)mask_size);
+    CheckCanProgress();
   }
+
+ public:
+  // A cache that counts as full (more than randomizer-size frames) and still holds less than one minibatch can never be consumed: the fill
+  // loops of the frame tools -- the reference's included, aslp-nnet-train-simple.cc:185-263 -- then come back, find it full, read nothing and
+  // spin forever (--randomizer-size smaller than --minibatch-size, found by devtools/r6_fuzz_refmains.py).  Said instead, here where every
+  // such loop passes after a fill (Randomize) and by the tools themselves where --randomize=false skips it.
+  void CheckCanProgress() const {
+    if (data_begin_ == 0 && data_end_ > conf_.randomizer_size && data_end_ < conf_.minibatch_size)
+      ASLP_ERR << "the cache is full at " << data_end_ << " frames (--randomizer-size=" << conf_.randomizer_size << ") and holds less than one minibatch (--minibatch-size="
+               << conf_.minibatch_size << "): no step can be taken; make --randomizer-size at least --minibatch-size";
+  }
+
+ protected:
   void CheckValue() const { ASLP_ASSERT(data_end_ - data_begin_ >= conf_.minibatch_size); }
   NnetDataRandomizerOptions conf_;
   int32 data_begin_, data_end_;

@@ -262,6 +262,7 @@ int TrainSimpleWithSync(int argc, char *argv[], SimpleSync *sync) {
                        << total_frames / time_now << " frames per second.";
         }
       }
+      feature_randomizer.CheckCanProgress();   // (a full cache below one minibatch would be found full again and never read on: nnet-randomizer.h)
       if (!crossvalidate && randomize) {
         const std::vector<int32> &mask = randomizer_mask.Generate(feature_randomizer.NumFrames());
         feature_randomizer.Randomize(mask);
@@ -431,6 +432,7 @@ int Main_aslp_nnet_train_mse(int argc, char *argv[]) {
                        << total_frames / time_now << " frames per second.";
         }
       }
+      feature_randomizer.CheckCanProgress();   // (a full cache below one minibatch would be found full again and never read on: nnet-randomizer.h)
       if (!crossvalidate && randomize) {
         const std::vector<int32> &mask = randomizer_mask.Generate(feature_randomizer.NumFrames());
         feature_randomizer.Randomize(mask);

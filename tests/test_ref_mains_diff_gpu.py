@@ -32,7 +32,7 @@ def run(bindir, name, args, ok=True):
 
 
 # what differs from run to run or from box to box, not from tool to tool: device selection and memory figures, the profile table, timings
-VOLATILE = re.compile(r"free:|Memory used|hipSetDevice|Selected device|active GPU|^-+\[|^-+$|^\S+\s+[0-9.e+-]+s$|Time\[|time elapsed|\t|^\s*$|Total GPU time|profil"
+VOLATILE = re.compile(r"free:|Memory used|hipSetDevice|Selected device|active GPU|^-+\[|^-+$|^\S+\s+[0-9.e+-]+s$|Time\[|time elapsed|\t|^\s*$|Total GPU time|profil|Propagate time \S+s"
                       # the engine's warning to a caller that writes through GetGpuParams() pointers without saying so (the reference's workers do;
                       # the engine's own tools announce their writes): expected on one side only
                       r"|parameters are aliased through GetGpuParams by a writer that does not announce")
@@ -58,11 +58,14 @@ def log_lines(stderr):
 
 @pytest.fixture(scope="module")
 def corpus(tmp_path_factory):
-    """one set of small tables for every case: 12-dim features of 9 utterances (one without targets, one far too long), posteriors over 10
-    classes, frame weights, utterance weights, CTC label sequences over 8 tokens + blank; 20-dim features / 30 classes for the DNN"""
     if not (os.path.isdir(REF) and len(os.listdir(REF)) >= 23):
         pytest.skip("bin_ref/ not built (needs the reference tree: make -C kaldi-aslp_amd refmains)")
-    d = tmp_path_factory.mktemp("refdiff")
+    return build_corpus(tmp_path_factory.mktemp("refdiff"))
+
+
+def build_corpus(d):
+    """one set of small tables for every case: 12-dim features of 9 utterances (one without targets, one far too long), posteriors over 10
+    classes, frame weights, utterance weights, CTC label sequences over 8 tokens + blank; 20-dim features / 30 classes for the DNN"""
     rng = np.random.default_rng(2026)
     keys = ["u%02d" % i for i in range(9)]
     lens = [23, 7, 41, 12, 30, 5, 18, 64, 27]
