@@ -61,6 +61,14 @@ TOOLS = {
                                                                            ("skip-width", ["0", "1", "2"]), ("cross-validate", ["false", "true"]), ("report-step", ["1", "2", "100"])]),
     "aslp-nnet-train-ctc": ("uctc", "s", "lab", TRN + COMMON + [("drop-len", ["0", "25", "40"]), ("cross-validate", ["false", "true"]), ("report-step", ["1", "2", "100"]),
                                                                ("token-symbol-table", [str(d / "tokens.txt")])]),
+    "aslp-nnet-train-frame-worker": ("dnn", "d", "post", TRN + RND + COMMON + [("worker-type", ["bsp", "bmuf", "sod"]), ("sync-period", ["30", "64", "200", "25600"]),
+                                                                             ("bmuf-learn-rate", ["1.0", "0.8"]), ("bmuf-momentum", ["0.0", "0.9"]), ("solver", ["sgd", "momentum", "adagrad", "rmsprop", "adadelta", "adam"]),
+                                                                             ("lr", ["0.01", "0.5"]), ("dropout-retention", ["0", "1.0"])]),
+    "aslp-nnet-train-lstm-stream-worker": ("lstm", "s", "post", TRN + COMMON + SEQ + [("worker-type", ["bsp", "bmuf", "sod"]), ("sync-period", ["30", "64", "25600"]), ("dump-interval", ["0", "2"]),
+                                                                                     ("solver", ["sgd", "adam"]), ("objective-function", ["xent", "mse"])]),
+    "aslp-nnet-train-lc-blstm-streams-worker": ("lc", "s", "post", TRN + COMMON + [("num-stream", ["1", "2", "3"]), ("chunk-size", ["4", "6", "10"]), ("right-splice", ["0", "2", "5"]),
+                                                                                  ("drop-len", ["0", "25", "40"]), ("worker-type", ["bsp", "bmuf"]), ("sync-period", ["30", "64", "25600"]),
+                                                                                  ("dump-interval", ["0", "3"]), ("feature-transform", [str(d / "tr.nnet")])]),
     "aslp-nnet-forward": ("dnn", "d", None, [("apply-log", ["true", "false"]), ("no-softmax", ["true", "false"]), ("class-frame-counts", [str(d / "counts")]), ("prior-scale", ["1.0", "0.5"]),
                                              ("prior-floor", ["1e-10", "1e-3"]), ("time-shift", ["0", "1", "3"]), ("skip-width", ["0", "1", "2", "4"]), ("verbose", ["0", "2"]),
                                              ("add-softmax", ["false", "true"]), ("scale-blank", ["1.0", "0.5"])]),
@@ -89,7 +97,7 @@ for name, (net, tab, tgt, opts) in TOOLS.items():
                 os.remove(out)
             outs = [] if cv else (["ark:" + out] if fwd else [out])
             try:
-                p = subprocess.run([os.path.join(bindir, name)] + flags + inputs + outs, capture_output=True, timeout=90)
+                p = subprocess.run([os.path.join(bindir, name)] + flags + inputs + outs, capture_output=True, timeout=90, env=dict(os.environ, RANK="0", WORLD_SIZE="1"))
             except subprocess.TimeoutExpired:
                 print("HANG (90 s) %s/%s %s" % (os.path.basename(bindir), name, " ".join(flags)), flush=True)
                 res[side] = (-999, None, [])
@@ -99,7 +107,7 @@ for name, (net, tab, tgt, opts) in TOOLS.items():
         total += 1
         (ro, do, lo), (rr, dr, lr) = res["own"], res["ref"]
         same_rc = (ro == 0) == (rr == 0)
-        if name in ("aslp-nnet-train-lstm-streams",) and ro == 0:   # (its final report: logged by the engine's tool, formed and dropped by the reference's main)
+        if name in ("aslp-nnet-train-lstm-streams", "aslp-nnet-train-lstm-stream-worker", "aslp-nnet-train-lc-blstm-streams-worker") and ro == 0:   # (its final report: logged by the engine's tool, formed and dropped by the reference's main)
             extra = [x for x in lo if x not in lr]
             if len(extra) <= 2 and all("AvgLoss" in x or "FRAME_ACCURACY" in x or x == "" for x in extra):
                 lo = [x for x in lo if x not in extra]
