@@ -385,6 +385,8 @@ def test_workers_alone_in_their_group(corpus, flags):
     for name, net, extra in (("aslp-nnet-train-frame-worker", "dnn", ["--minibatch-size=16", "--randomizer-size=100", "--learn-rate=0.01"]),
                              ("aslp-nnet-train-lstm-stream-worker", "lstm", ["--num-stream=3", "--batch-size=5", "--targets-delay=2", "--learn-rate=0.02"]),
                              ("aslp-nnet-train-lc-blstm-streams-worker", "lc", ["--num-stream=3", "--chunk-size=6", "--right-splice=3", "--learn-rate=0.02"])):
+        if name != "aslp-nnet-train-frame-worker" and "--solver=momentum" in flags:
+            continue   # (every protocol on the frame worker; BSP, BMUF and one SOD solver on the stream workers: the suite's time)
         if name.startswith("aslp-nnet-train-lc") and "--worker-type=sod" in flags:
             continue   # (no SOD worker in that tool: aslp-nnet-train-lc-blstm-streams-worker.cc:17-21)
         outs = {}
